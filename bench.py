@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""bench.py -- QGDFoam explicit step throughput (Mcell-steps/s) on N MI355X GPUs of one node.
+
+Workload: BASELINE.json config "QGDFoam 64M-cell hex box" family: box [0,1]^3 of n^3
+uniform hex cells in blockMesh numbering, all six patches zeroGradient, fvsc GaussVolPoint, constScPrModel1
+(Sc=Pr=1, alphaQGD=0.5), explicit diffusion, fixed deltaT, seeded noise.  The mesh shards by cell range
+(k-slabs) over the ranks: strong scaling, total work fixed; one RCCL halo exchange of ghost-cell records per
+step (one cell plane + its patch faces per neighbour).
+
+A step = one pass of the QGDFoam loop body (flux assembly + cell update + BC refresh), inputs resident in HBM.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+# ALGORITHMIC bytes of the fused face kernel: per internal face 144 B streamed in (owner+neighbour 8,
+# Sf 24, weight 8, hQGDf 8, 9 Gauss coefficients + 1/V 80, 4 vertex labels 16) + 40 B net fluxes out; every cell and
+# every vertex record (rho,U,p,e = 48 B) gathered once.
+FACE_BYTES_PER_FACE = 184
+FACE_BYTES_PER_CELL = 48
+FACE_BYTES_PER_POINT = 48
+# whole explicit step, per cell-step on a hex box: vertex interp 196 + face kernel 648 + cell update 240
+STEP_BYTES_PER_CELL = 1084
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--n", type=int, default=int(os.environ.get("QGD_BENCH_N", "400")), help="box edge in cells (n^3 cells in total)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-n", type=int, default=64, help="edge of the CPU-baseline sample box")
+    ap.add_argument("--cpu-steps", type=int, default=5)
+    return ap.parse_args()
+
+
+def slab_range(n, rank, world):
+    lo = (n * rank) // world
+    hi = (n * (rank + 1)) // world
+    k_lo = lo - 1 if rank > 0 else lo
+    k_hi = hi + 1 if rank < world - 1 else hi
+    return lo, hi, k_lo, k_hi
+
+
+def cpu_baseline(n, steps):
+    """The CPU oracle (a restatement of the reference listings: the reference itself cannot be built here) timed on
+    one host core on a bounded sample of the same workload."""
+    import qgdsolver_amd as q
+    import cases
+    from oracle import OracleCase, OracleMesh
+
+    mesh = q.PolyMesh.box(n, n, n)
+    om = OracleMesh(mesh.primitives())
+    h = 1.0 / n
+    opt = q.default_options(stencil="GaussVolPoint", deltaT=0.1 * h / 1.3)
+    oc = OracleCase(om, opt)
+    U, T, p = cases.box_initial_fields(mesh.array("C").reshape(-1, 3))
+    oc.set_fields(U, T, p)
+    oc.step(1)
+    t0 = time.perf_counter()
+    oc.step(steps)
+    dt = time.perf_counter() - t0
+    return {"value": n ** 3 * steps / dt / 1e6, "unit": "Mcell-steps/s", "cores": 1, "kind": "port",
+            "sample": f"{n}^3-cell box, {steps} steps, single-threaded oracle (field-at-a-time restatement)"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+
+    import torch
+    import torch.distributed as dist
+
+    import qgdsolver_amd as q
+    from qgdsolver_amd import _lib as L
+    import cases
+
+    if not torch.cuda.is_available() or q.device_count() < 1:
+        raise RuntimeError("bench.py needs a HIP device: qgdsolver_amd has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    n = args.n
+    lo, hi, k_lo, k_hi = slab_range(n, rank, world)
+    t_setup = time.perf_counter()
+    mesh = q.PolyMesh.box(n, n, n, k_range=(k_lo, k_hi))
+    owned_cells = n * n * (hi - lo)
+    dev = q.Device(mesh, device_id=local_rank)
+    h = 1.0 / n
+    opt = q.default_options(stencil="GaussVolPoint", deltaT=0.1 * h / 1.3)  # fixed deltaT = 0.1 h / (c+|U|)_max
+    case = q.QGDFoamCase(dev, opt)
+    C = mesh.array("C").reshape(-1, 3)
+    U, T, p = cases.box_initial_fields(C)
+    # the noise must be a function of the GLOBAL cell label so that shards agree with the unsharded run
+    rng = np.random.Generator(np.random.MT19937(12345))
+    noise = rng.uniform(-1e-3, 1e-3, size=n * n * n)
+    T = 1.0 + noise[n * n * k_lo: n * n * k_hi]
+    del noise
+    case.set_fields(U, T, p)
+    del U, T, p, C
+    n_if, n_c, n_p = mesh.nInternalFaces, mesh.nCells, mesh.nPoints
+    mesh.close()
+    stream = torch.cuda.current_stream()
+    case.set_stream(stream.cuda_stream)
+    t_setup = time.perf_counter() - t_setup
+
+    # halo buffers (device) and peers: side 0 = lower k neighbour, side 1 = upper
+    sides = [s for s, peer in ((0, rank - 1), (1, rank + 1)) if 0 <= peer < world]
+    peers = {0: rank - 1, 1: rank + 1}
+    send = {s: torch.empty(case.halo_count(s), dtype=torch.float64, device="cuda") for s in sides}
+    recv = {s: torch.empty(case.halo_count(s), dtype=torch.float64, device="cuda") for s in sides}
+
+    def exchange():
+        if not sides:
+            return
+        for s in sides:
+            case.halo_pack(s, send[s].data_ptr())
+        ops = []
+        for s in sides:
+            ops.append(dist.P2POp(dist.isend, send[s], peers[s]))
+            ops.append(dist.P2POp(dist.irecv, recv[s], peers[s]))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        for s in sides:
+            case.halo_unpack(s, recv[s].data_ptr())
+
+    def step():
+        case.step_phase(0)
+        exchange()
+
+    exchange()  # ghost cells start from their owners' records
+    for _ in range(args.warmup):
+        step()
+    case.timing(True)
+    case.timing_reset()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    kt = {}
+    for name, k in (("point", L.K_POINT), ("face", L.K_FACE), ("bface", L.K_BFACE), ("cell", L.K_CELL), ("bc", L.K_BC)):
+        ms, cnt = case.kernel_time(k)
+        kt[name] = {"ms_total": ms, "launches": cnt, "ms_avg": (ms / cnt if cnt else None)}
+    info = case.info()
+    face_bytes = FACE_BYTES_PER_FACE * n_if + FACE_BYTES_PER_CELL * n_c + FACE_BYTES_PER_POINT * n_p
+    face_ms = kt["face"]["ms_avg"]
+    achieved = face_bytes / (face_ms * 1e-3) / 1e9 if face_ms else None
+
+    if rank == 0:
+        total_cells = n ** 3
+        value = total_cells * args.steps / elapsed / 1e6
+        out = {
+            "metric": "Mcell-steps/s (QGDFoam explicit step)",
+            "value": value,
+            "unit": "Mcell-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"QGDFoam {n}^3 = {total_cells / 1e6:.1f}M-cell uniform hex box (blockMesh numbering), "
+                            "GaussVolPoint, constScPrModel1, explicit diffusion, zeroGradient patches, fixed deltaT",
+                "cells": total_cells,
+                "cells_per_gpu": owned_cells,
+                "partition": f"{world} k-slab(s), 1 ghost plane per cut, RCCL send/recv per step" if world > 1 else "single shard",
+                "stencil": "GaussVolPoint",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "faceFluxKernel<GaussVolPoint3D> (rank 0 shard)",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": face_bytes,
+                "avg_launch_ms": face_ms,
+            },
+            "step_roofline_frac": STEP_BYTES_PER_CELL * owned_cells * args.steps / elapsed / (HBM_PEAK_GBS * 1e9),
+            "kernels_ms_avg": {k: v["ms_avg"] for k, v in kt.items()},
+            "device_bytes": case.device_bytes(),
+            "setup_s": t_setup,
+            "min_rho": info["minRho"],
+        }
+        traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(traffic_file):
+            try:
+                tr = json.load(open(traffic_file))
+                key = f"n{n}_gpus{world}"
+                if key in tr:
+                    out["roofline"]["traffic"] = tr[key]["bytes_per_launch"]
+                    out["roofline"]["traffic_source"] = tr[key].get("source")
+            except Exception:
+                pass
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_n, args.cpu_steps)
+        print(json.dumps(out), flush=True)
+    case.close()
+    dev.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

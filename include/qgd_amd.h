@@ -1,0 +1,290 @@
+/*
+ * qgd_amd.h -- C-ABI of the MI355X-native QGD face-flux path.
+ *
+ * This is the drop-in boundary for the per-timestep face-flux assembly of
+ * QGDFoam (unicfdlab/QGDsolver).  Plain pointers and sizes only; no C++ or
+ * torch types cross this boundary.  Every entry returns an int status
+ * (QGD_OK == 0, negative == error) and never throws.
+ *
+ * Citations are to the Doxygen listings of the reference:
+ *   /root/reference/docs/html/<name>_source.html, listing lines L..
+ * (physical HTML line = listing line + 101).
+ *
+ * Reference interface each group replaces:
+ *   qgd_fvsc_*            fvsc::grad / fvsc::div free functions
+ *                         [fvsc_8H_source.html L46-68, fvsc_8C_source.html L87-167]
+ *                         and the four fvscStencil virtuals Grad/Grad/Div/Div
+ *                         [fvscStencil_8H_source.html L105-130]
+ *   qgd_stencil_lookup    fvscStencil::New / lookupOrNew run-time selection by word
+ *                         [fvscStencil_8C_source.html L59-118], with the scheme
+ *                         checks of fvscOpName [fvsc_8C_source.html L47-85]
+ *   qgd_case_update_fluxes  QGDFoam/updateFields.H + QGDFoam/updateFluxes.H
+ *                         [QGDFoam_2updateFields_8H_source.html L45-80,
+ *                          QGDFoam_2updateFluxes_8H_source.html L41-139]
+ *   qgd_case_step         one pass of the QGDFoam while-loop body
+ *                         [QGDFoam_8C_source.html L90-163]
+ *   qgd_case_get_field    QGDThermo accessors tauQGDf/hQGDf/tauQGD/hQGD/muQGD/
+ *                         alphauQGD/c/p/rho/mu [QGDThermo_8H_source.html L99-135]
+ *                         and the registered face fields the qgdFlux BC reads by
+ *                         name ("phiwStar", "tauQGDf")
+ *                         [qgdFluxFvPatchScalarField_8C_source.html L166-192]
+ *
+ * Layout conventions (same as OpenFOAM's):
+ *   - labels are int32, scalars are fp64
+ *   - vectors are 3 contiguous doubles, tensors 9 row-major doubles,
+ *     T[3*i+j]; a face gradient of a vector is out[3*i+j] = d_i U_j
+ *     [leastSquaresStencil_8C_source.html L155-165]
+ *   - a surface field is nFaces records: internal faces 0..nInternalFaces-1
+ *     followed by the boundary faces patch by patch in mesh order.  Faces of
+ *     `empty` patches keep a (zero) slot so that a record is addressed by its
+ *     global face label (OpenFOAM gives those patches size 0).
+ *   - a boundary ("patch") field is nFaces-nInternalFaces records addressed by
+ *     (global face label - nInternalFaces).
+ */
+#ifndef QGD_AMD_H
+#define QGD_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes --------------------------------------------------------- */
+enum {
+    QGD_OK = 0,
+    QGD_ERR_INVALID = -1,     /* bad argument / inconsistent sizes               */
+    QGD_ERR_NO_DEVICE = -2,   /* no HIP device: the product path has NO CPU fallback */
+    QGD_ERR_HIP = -3,         /* a HIP runtime call failed (see qgd_last_error)  */
+    QGD_ERR_SCHEME = -4,      /* scheme rejected, e.g. leastSquares on a 3-D mesh
+                                 [fvsc_8C_source.html L60-63]                     */
+    QGD_ERR_UNKNOWN_NAME = -5,/* unknown stencil / field / model word            */
+    QGD_ERR_NOT_IMPLEMENTED = -6 /* mirrors notImplemented(...) of the base class
+                                 [fvscStencil_8H_source.html L105-130]           */
+};
+
+/* ---- patch (mesh boundary) types: the fvPatch classes the path tests for -- */
+enum {
+    QGD_PATCH_GENERIC = 0,        /* patch / wall: ordinary                      */
+    QGD_PATCH_EMPTY = 1,          /* emptyFvPatch (2-D / 1-D cases)              */
+    QGD_PATCH_SYMMETRYPLANE = 2,  /* symmetryPlaneFvPatch                        */
+    QGD_PATCH_SYMMETRY = 3,       /* symmetryFvPatch                             */
+    QGD_PATCH_WEDGE = 4,          /* wedgeFvPatch                                */
+    QGD_PATCH_CYCLIC = 5,         /* coupled, not processor                      */
+    QGD_PATCH_HALO = 6            /* cut plane of a cell-range shard (plays the
+                                     role of processorFvPatch): its faces are
+                                     never integrated, ghost cells behind it are
+                                     refreshed by the halo exchange              */
+};
+
+/* ---- boundary-condition kinds of the QGDFoam case ------------------------- */
+enum {
+    QGD_BC_ZEROGRADIENT = 0,
+    QGD_BC_FIXEDVALUE = 1,
+    QGD_BC_SLIP = 2,       /* basicSymmetry: U only (also used on symmetryPlane)  */
+    QGD_BC_QGDFLUX = 3,    /* p only: qgdFluxFvPatchScalarField
+                              [qgdFluxFvPatchScalarField_8C_source.html L159-197] */
+    QGD_BC_NONE = 4        /* empty / halo patches                                */
+};
+
+/* ---- fvsc stencil words [fvsc_8C_source.html L60-65] ---------------------- */
+enum {
+    QGD_FVSC_REDUCED = 0,
+    QGD_FVSC_LEASTSQUARES = 1,
+    QGD_FVSC_GAUSSVOLPOINT = 2
+};
+
+/* ---- opaque handles -------------------------------------------------------- */
+typedef struct qgd_mesh_s* qgd_mesh_t;     /* host polyMesh + derived geometry  */
+typedef struct qgd_device_s* qgd_device_t; /* device-resident mesh + stencils   */
+typedef struct qgd_case_s* qgd_case_t;     /* a QGDFoam case on one device      */
+
+/* ---- library ---------------------------------------------------------------- */
+const char* qgd_version(void);
+/* Last error text of the calling thread (never NULL). */
+const char* qgd_last_error(void);
+/* Number of visible HIP devices (0 when there is none; never fails). */
+int qgd_device_count(void);
+
+/* ---- mesh (host side, plain C++; no device needed) ------------------------ */
+
+/* polyMesh arrays exactly as constant/polyMesh/{points,faces,owner,neighbour,
+ * boundary}: faces in upper-triangular order, boundary faces grouped per patch.
+ * Arrays are copied.  Geometry (Sf, Cf, C, V) is computed with OpenFOAM's
+ * face/cell decomposition rules unless supplied via qgd_mesh_set_geometry. */
+int qgd_mesh_create(int32_t nPoints, const double* points,
+                    int32_t nFaces, const int32_t* faceOffsets /*nFaces+1*/,
+                    const int32_t* facePoints,
+                    int32_t nInternalFaces, const int32_t* owner /*nFaces*/,
+                    const int32_t* neighbour /*nInternalFaces*/,
+                    int32_t nCells,
+                    int32_t nPatches, const int32_t* patchStart,
+                    const int32_t* patchSize, const int32_t* patchType,
+                    qgd_mesh_t* out);
+
+/* Structured box in blockMesh numbering: cell i + nx*(j + ny*k), internal faces
+ * sorted by (owner, neighbour), six patches xMin,xMax,yMin,yMax,zMin,zMax.
+ * patchTypes[6] gives the QGD_PATCH_* of each.  kLo/kHi select a k-slab
+ * [kLo,kHi) of a taller box of nzGlobal cells (kLo=0,kHi=nz for the whole box);
+ * z-coordinates stay those of the global box so a shard is bit-identical to the
+ * same cells of the global mesh. */
+int qgd_mesh_box(int32_t nx, int32_t ny, int32_t nzGlobal,
+                 int32_t kLo, int32_t kHi,
+                 const double lo[3], const double hi[3],
+                 const int32_t patchTypes[6],
+                 qgd_mesh_t* out);
+
+/* Forward-facing-step planform (one cell thick in z): nx*ny cells with the
+ * block [ixStep,nx) x [0,iyStep) removed.  Patches: inlet, outlet, bottom,
+ * top, step (walls of the obstacle), frontAndBack (empty). */
+int qgd_mesh_forward_step(int32_t nx, int32_t ny, int32_t ixStep, int32_t iyStep,
+                          double lx, double ly, double lz, qgd_mesh_t* out);
+
+/* Move every point by jitter*h*uniform(-1,1) per coordinate (boundary points
+ * slide in their plane only), then recompute geometry.  Test helper for
+ * non-orthogonal hexahedra. */
+int qgd_mesh_jitter(qgd_mesh_t m, double amplitude, uint64_t seed);
+/* Split every `stride`-th internal and boundary quad into two triangles
+ * (cells stay closed polyhedra): exercises the triangle branch
+ * [GaussVolPointBase3D_8C_source.html L161-318]. */
+int qgd_mesh_split_quads(qgd_mesh_t m, int32_t stride);
+
+int qgd_mesh_set_geometry(qgd_mesh_t m, const double* Sf, const double* Cf,
+                          const double* C, const double* V);
+int qgd_mesh_free(qgd_mesh_t m);
+
+/* sizes[0..6] = nPoints, nFaces, nInternalFaces, nCells, nPatches,
+ *               nFacePoints (sum of face sizes), nGeometricD */
+int qgd_mesh_sizes(qgd_mesh_t m, int64_t sizes[7]);
+/* Copy out a named array: "points","faceOffsets","facePoints","owner",
+ * "neighbour","patchStart","patchSize","patchType" (int32 / double as natural),
+ * "Sf","magSf","Cf","C","V","weights","deltaCoeffs","nonOrthDeltaCoeffs". */
+int qgd_mesh_get(qgd_mesh_t m, const char* name, void* out, int64_t outBytes);
+
+/* ---- device mesh + fvsc operators ----------------------------------------- */
+
+/* Upload the mesh to HIP device `deviceId` and build the static stencil data.
+ * Fails with QGD_ERR_NO_DEVICE when no GPU is present. */
+int qgd_device_create(qgd_mesh_t m, int deviceId, qgd_device_t* out);
+int qgd_device_free(qgd_device_t d);
+
+/* Run-time selection by word, like fvscStencil::New: "reduced",
+ * "leastSquares", "leastSquaresOpt" (alias of leastSquares' serial formula),
+ * "GaussVolPoint".  Applies the checks of fvscOpName: leastSquares* is refused
+ * on 3-D meshes (QGD_ERR_SCHEME); unknown word -> QGD_ERR_UNKNOWN_NAME. */
+int qgd_stencil_lookup(qgd_device_t d, const char* word, int* stencilId);
+
+/* The four fvscStencil operators.  cell = nCells*ncomp, bnd = boundary (patch)
+ * values nBoundaryFaces*ncomp, out = nFaces*ncompOut, all HOST pointers (the
+ * OpenFOAM adapter hands over Field<Type>::cdata()).
+ *   grad_s : ncomp 1 -> 3      grad_v : ncomp 3 -> 9
+ *   div_v  : ncomp 3 -> 1      div_t  : ncomp 9 -> 3
+ * bndGrad (nullable) = patch snGrad for fixedGradient-type patches; when NULL
+ * snGrad = deltaCoeffs*(bnd - internal). */
+int qgd_fvsc_grad_s(qgd_device_t d, int stencilId, const double* cell,
+                    const double* bnd, double* out);
+int qgd_fvsc_grad_v(qgd_device_t d, int stencilId, const double* cell,
+                    const double* bnd, double* out);
+int qgd_fvsc_div_v(qgd_device_t d, int stencilId, const double* cell,
+                   const double* bnd, double* out);
+int qgd_fvsc_div_t(qgd_device_t d, int stencilId, const double* cell,
+                   const double* bnd, double* out);
+
+/* ---- QGDFoam case ----------------------------------------------------------- */
+
+typedef struct qgd_case_options {
+    int32_t stencil;          /* QGD_FVSC_* : fvSchemes fvsc{default ...;}        */
+    int32_t implicitDiffusion;/* must be 0: the explicit branch
+                                 [QGDFoam_2updateFluxes_8H_source.html L95-106]   */
+    int32_t adjustTimeStep;   /* 1: Courant/deltaT control
+                                 [QGDCourantNo_8H_source.html L36-53,
+                                  setDeltaT-QGDQHD_8H_source.html L41-61]         */
+    int32_t reserved;
+    double R;                 /* perfectGas: specific gas constant                */
+    double Cv;                /* eConst (Tref = 0, Esref = 0)                     */
+    double mu;                /* constTransport: mu                               */
+    double Pr;                /* constTransport: Pr                               */
+    double ScQGD;             /* constScPrModel1 [constScPrModel1_8C_source.html L58-89] */
+    double PrQGD;
+    double alphaQGD;          /* uniform alphaQGD (0.5 when the file is absent
+                                 [QGDCoeffs_8C_source.html L145-159])             */
+    double deltaT;            /* (initial) time step                              */
+    double maxCo, maxDeltaT, cTau; /* used when adjustTimeStep                    */
+} qgd_case_options;
+
+int qgd_case_options_default(qgd_case_options* opt);
+
+int qgd_case_create(qgd_device_t d, const qgd_case_options* opt, qgd_case_t* out);
+int qgd_case_free(qgd_case_t c);
+
+/* Boundary conditions, per patch.  value: 3 doubles for U, 1 for T and p
+ * (uniform fixedValue); ignored for the other kinds. */
+int qgd_case_set_bc(qgd_case_t c, int32_t patch, int32_t bcU, const double* valueU,
+                    int32_t bcT, double valueT, int32_t bcP, double valueP);
+
+/* Initial cell fields U (nCells*3), T, p (HOST pointers); evaluates the BCs,
+ * thermo.correct() and the derived conserved fields like createFields.H
+ * [QGDFoam_2createFields_8H_source.html L3-109]. */
+int qgd_case_set_fields(qgd_case_t c, const double* U, const double* T,
+                        const double* p);
+
+/* updateFields.H + updateFluxes.H on the current state.  Afterwards the face
+ * fields "phiJm","phiJmU","phiP","phiPi","phiJmH","phiQ","phiPiU","phiwStar",
+ * "phi","tauQGDf" are readable with qgd_case_get_field (debug / BC coupling
+ * path: it materialises them; qgd_case_step does not). */
+int qgd_case_update_fluxes(qgd_case_t c);
+
+/* nSteps passes of the QGDFoam loop body, fully device resident. */
+int qgd_case_step(qgd_case_t c, int32_t nSteps);
+
+/* Named field copy-out to HOST.  Cell fields: "rho","U","p","e","T","rhoU",
+ * "rhoE","c","psi","mu","alphau","tauQGD","muQGD","alphauQGD","hQGD","H".
+ * Face fields: see qgd_case_update_fluxes plus "hQGDf".
+ * Boundary fields: "<cellfield>.boundary".  outDoubles = capacity of out. */
+int qgd_case_get_field(qgd_case_t c, const char* name, double* out,
+                       int64_t outDoubles);
+
+/* info[0]=time, [1]=deltaT, [2]=CoNum, [3]=min(rho), [4]=min(e), [5]=step count */
+int qgd_case_info(qgd_case_t c, double info[6]);
+
+/* ---- halo exchange of ghost-cell primitives (multi-GPU) ------------------- */
+/* A shard built with qgd_mesh_box(kLo>0 or kHi<nzGlobal) has up to two
+ * neighbours: side 0 = lower k, side 1 = upper k.  count = number of doubles
+ * in one message.  pack gathers the owned boundary-layer cells' records into
+ * the DEVICE buffer sendBuf; unpack scatters recvBuf into the ghost cells.
+ * Both are asynchronous on the case's stream; qgd_case_stream_sync waits. */
+int qgd_case_halo_count(qgd_case_t c, int side, int64_t* count);
+int qgd_case_halo_pack(qgd_case_t c, int side, double* sendBufDevice);
+int qgd_case_halo_unpack(qgd_case_t c, int side, const double* recvBufDevice);
+int qgd_case_stream_sync(qgd_case_t c);
+/* Run the case's kernels on a caller-owned HIP stream (hipStream_t passed as
+ * void*), e.g. the stream the RCCL halo transfers are ordered on, so that
+ * compute and exchange need no host synchronisation between them. */
+int qgd_case_set_stream(qgd_case_t c, void* hipStream);
+/* Run one step split in two so the transport between them is the caller's:
+ * phase 0 = everything up to and including the cell update + pack-ready,
+ * phase 1 = after ghost cells were unpacked (boundary refresh). */
+int qgd_case_step_phase(qgd_case_t c, int phase);
+
+/* ---- measurement ------------------------------------------------------------ */
+/* Kernel ids for qgd_case_kernel_time. */
+enum {
+    QGD_K_POINT = 0,   /* cell -> vertex interpolation                          */
+    QGD_K_FACE = 1,    /* fused internal-face gradient + flux kernel            */
+    QGD_K_BFACE = 2,   /* boundary-face flux kernel                             */
+    QGD_K_CELL = 3,    /* flux gather + Euler update + thermo + QGD coefficients */
+    QGD_K_BC = 4,      /* boundary-condition refresh                            */
+    QGD_K_COUNT = 5
+};
+/* Enable HIP-event timing of every launch of kernel `k` on the case's own
+ * stream; totals since the last reset. */
+int qgd_case_timing(qgd_case_t c, int enable);
+int qgd_case_kernel_time(qgd_case_t c, int k, double* totalMs, int64_t* launches);
+int qgd_case_timing_reset(qgd_case_t c);
+/* Bytes resident on the device for this case + its mesh. */
+int qgd_case_device_bytes(qgd_case_t c, int64_t* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QGD_AMD_H */

@@ -1,0 +1,1604 @@
+// qgd_oracle.cpp -- CPU restatement of the QGDsolver face-flux hot path.
+//
+// TEST INFRASTRUCTURE ONLY (see qgd_oracle.h).  PARITY UNPINNED: the reference
+// cannot be built or run here and ships no tests or golden vectors; this file
+// follows the Doxygen source listings under /root/reference/docs/html/
+// operation by operation, in the reference's own evaluation order, as
+// single-threaded field-at-a-time passes (the structure of the OpenFOAM
+// expressions it restates).  Citations: [file:lines] = listing lines of
+// /root/reference/docs/html/<file with . -> _8, / -> _2>_source.html
+// (physical HTML line = listing line + 101).
+//
+// Everything tagged "L0" restates OpenFOAM v2312 behaviour (the release pinned
+// by /root/reference/README.md:32-37) that the listings call into but that is
+// not itself part of the reference tree.
+#include "qgd_oracle.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+// codes shared with include/qgd_amd.h
+enum { PATCH_GENERIC = 0, PATCH_EMPTY = 1, PATCH_SYMMETRYPLANE = 2, PATCH_SYMMETRY = 3,
+       PATCH_WEDGE = 4, PATCH_CYCLIC = 5, PATCH_HALO = 6 };
+enum { BC_ZEROGRADIENT = 0, BC_FIXEDVALUE = 1, BC_SLIP = 2, BC_QGDFLUX = 3, BC_NONE = 4 };
+enum { FVSC_REDUCED = 0, FVSC_LEASTSQUARES = 1, FVSC_GAUSSVOLPOINT = 2 };
+
+const double SMALL = 1e-15;   // OpenFOAM doubleScalarSMALL (L0)
+const double GREAT = 1e15;
+const double VSMALL = 1e-300;
+
+typedef std::vector<double> dvec;
+typedef std::vector<int> ivec;
+
+inline double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+inline double mag3(const double* a) { return std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); }
+inline void cross3(const double* a, const double* b, double* c) {
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+struct PatchInfo { int type, start, size; };
+
+// ---------------------------------------------------------------------------
+// Mesh + L0 geometry
+// ---------------------------------------------------------------------------
+struct Mesh {
+    int nP = 0, nF = 0, nIF = 0, nC = 0;
+    dvec pts;
+    ivec fOff, fPts, own, nei;
+    std::vector<PatchInfo> patches;
+    // geometry (L0)
+    dvec Sf, Cf, magSf, C, V, w, delta, nonOrthDelta;
+    int geomD[3] = {1, 1, 1};
+    int nGeomD = 3;
+    // adjacency (L0 orders)
+    std::vector<ivec> pointCells;     // ascending cell label
+    std::vector<ivec> cells;          // owned faces ascending, then neighbour faces ascending
+    // volPointInterpolation addressing (L0)
+    std::vector<char> isPatchFace;    // per boundary face
+    std::vector<char> isPatchPoint;   // per point
+    ivec bndMeshPoints;               // boundary.meshPoints()
+    std::vector<ivec> bndPointFaces;  // per boundary point: boundary-face indices (ascending)
+    std::vector<dvec> pointWeights;   // per point (non patch points)
+    std::vector<dvec> bndPointWeights;// per boundary point
+    // halo
+    ivec haloGhost[2], haloSend[2];
+    ivec haloGhostBF[2], haloSendBF[2];  // boundary-face indices (global label - nIF)
+
+    int nBF() const { return nF - nIF; }
+    int fsize(int f) const { return fOff[f + 1] - fOff[f]; }
+    const int* fp(int f) const { return &fPts[fOff[f]]; }
+    bool patchHasFields(int p) const { return patches[p].type != PATCH_EMPTY; }  // emptyFvPatch::size()==0
+    bool coupled(int p) const { return patches[p].type == PATCH_CYCLIC || patches[p].type == PATCH_HALO; }
+
+    void geometry();
+    void addressing();
+    void pointInterpolationWeights();
+    void haloFaces();
+};
+
+// L0: primitiveMeshTools::faceCentresAndAreas, cellCentresAndVols
+void Mesh::geometry() {
+    Sf.assign(3 * (size_t)nF, 0); Cf.assign(3 * (size_t)nF, 0); magSf.assign(nF, 0);
+    C.assign(3 * (size_t)nC, 0); V.assign(nC, 0);
+    for (int f = 0; f < nF; ++f) {
+        const int* q = fp(f);
+        const int n = fsize(f);
+        double* S = &Sf[3 * (size_t)f];
+        double* c = &Cf[3 * (size_t)f];
+        if (n == 3) {
+            const double *a = &pts[3 * (size_t)q[0]], *b = &pts[3 * (size_t)q[1]], *d = &pts[3 * (size_t)q[2]];
+            for (int k = 0; k < 3; ++k) c[k] = (1.0 / 3.0) * (a[k] + b[k] + d[k]);
+            double u[3], v[3], x[3];
+            for (int k = 0; k < 3; ++k) { u[k] = b[k] - a[k]; v[k] = d[k] - a[k]; }
+            cross3(u, v, x);
+            for (int k = 0; k < 3; ++k) S[k] = 0.5 * x[k];
+        } else {
+            double fc[3] = {pts[3 * (size_t)q[0]], pts[3 * (size_t)q[0] + 1], pts[3 * (size_t)q[0] + 2]};
+            for (int i = 1; i < n; ++i) for (int k = 0; k < 3; ++k) fc[k] += pts[3 * (size_t)q[i] + k];
+            for (int k = 0; k < 3; ++k) fc[k] /= n;
+            double sumN[3] = {0, 0, 0}, sumA = 0, sumAc[3] = {0, 0, 0};
+            for (int i = 0; i < n; ++i) {
+                const double* a = &pts[3 * (size_t)q[i]];
+                const double* b = &pts[3 * (size_t)q[(i + 1) % n]];
+                double cc[3], u[3], v[3], nn[3];
+                for (int k = 0; k < 3; ++k) { cc[k] = a[k] + b[k] + fc[k]; u[k] = b[k] - a[k]; v[k] = fc[k] - a[k]; }
+                cross3(u, v, nn);
+                const double an = mag3(nn);
+                for (int k = 0; k < 3; ++k) { sumN[k] += nn[k]; sumAc[k] += an * cc[k]; }
+                sumA += an;
+            }
+            if (sumA < 1e-150) { for (int k = 0; k < 3; ++k) { c[k] = fc[k]; S[k] = 0; } }
+            else { for (int k = 0; k < 3; ++k) { c[k] = (1.0 / 3.0) * sumAc[k] / sumA; S[k] = 0.5 * sumN[k]; } }
+        }
+        magSf[f] = mag3(S);
+    }
+    dvec cEst(3 * (size_t)nC, 0);
+    ivec nFc(nC, 0);
+    for (int f = 0; f < nF; ++f) { for (int k = 0; k < 3; ++k) cEst[3 * (size_t)own[f] + k] += Cf[3 * (size_t)f + k]; nFc[own[f]]++; }
+    for (int f = 0; f < nIF; ++f) { for (int k = 0; k < 3; ++k) cEst[3 * (size_t)nei[f] + k] += Cf[3 * (size_t)f + k]; nFc[nei[f]]++; }
+    for (int c = 0; c < nC; ++c) for (int k = 0; k < 3; ++k) cEst[3 * (size_t)c + k] /= nFc[c];
+    for (int f = 0; f < nF; ++f) {
+        const int o = own[f];
+        double d[3];
+        for (int k = 0; k < 3; ++k) d[k] = Cf[3 * (size_t)f + k] - cEst[3 * (size_t)o + k];
+        const double pyr3 = dot3(&Sf[3 * (size_t)f], d);
+        for (int k = 0; k < 3; ++k) C[3 * (size_t)o + k] += pyr3 * (0.75 * Cf[3 * (size_t)f + k] + 0.25 * cEst[3 * (size_t)o + k]);
+        V[o] += pyr3;
+    }
+    for (int f = 0; f < nIF; ++f) {
+        const int n = nei[f];
+        double d[3];
+        for (int k = 0; k < 3; ++k) d[k] = cEst[3 * (size_t)n + k] - Cf[3 * (size_t)f + k];
+        const double pyr3 = dot3(&Sf[3 * (size_t)f], d);
+        for (int k = 0; k < 3; ++k) C[3 * (size_t)n + k] += pyr3 * (0.75 * Cf[3 * (size_t)f + k] + 0.25 * cEst[3 * (size_t)n + k]);
+        V[n] += pyr3;
+    }
+    for (int c = 0; c < nC; ++c) {
+        if (std::fabs(V[c]) > VSMALL) for (int k = 0; k < 3; ++k) C[3 * (size_t)c + k] /= V[c];
+        else for (int k = 0; k < 3; ++k) C[3 * (size_t)c + k] = cEst[3 * (size_t)c + k];
+        V[c] *= (1.0 / 3.0);
+    }
+    // L0: surfaceInterpolation weights / deltaCoeffs / nonOrthDeltaCoeffs,
+    // fvPatch::delta() patch-normal on non-coupled patches
+    w.assign(nF, 1.0); delta.assign(nF, 0.0); nonOrthDelta.assign(nF, 0.0);
+    for (int f = 0; f < nF; ++f) {
+        const double* S = &Sf[3 * (size_t)f];
+        const double* cf = &Cf[3 * (size_t)f];
+        const double* co = &C[3 * (size_t)own[f]];
+        if (f < nIF) {
+            const double* cn = &C[3 * (size_t)nei[f]];
+            double a[3], b[3], d[3];
+            for (int k = 0; k < 3; ++k) { a[k] = cf[k] - co[k]; b[k] = cn[k] - cf[k]; d[k] = cn[k] - co[k]; }
+            const double sfdOwn = std::fabs(dot3(S, a)), sfdNei = std::fabs(dot3(S, b));
+            w[f] = (std::fabs(sfdOwn + sfdNei) > VSMALL) ? sfdNei / (sfdOwn + sfdNei) : 0.5;
+            const double magd = mag3(d);
+            delta[f] = 1.0 / magd;
+            nonOrthDelta[f] = 1.0 / std::max(dot3(S, d) / magSf[f], 0.05 * magd);
+        } else if (magSf[f] > 0) {
+            double n[3], a[3], dv[3];
+            for (int k = 0; k < 3; ++k) { n[k] = S[k] / magSf[f]; a[k] = cf[k] - co[k]; }
+            const double nd = dot3(n, a);
+            for (int k = 0; k < 3; ++k) dv[k] = n[k] * nd;
+            const double magd = mag3(dv);
+            delta[f] = 1.0 / magd;
+            nonOrthDelta[f] = 1.0 / std::max(dot3(n, dv), 0.05 * magd);
+        }
+    }
+    // L0: polyMesh::calcDirections
+    double dir[3] = {0, 0, 0};
+    bool hasEmpty = false;
+    for (const PatchInfo& p : patches) if (p.type == PATCH_EMPTY) {
+        hasEmpty = hasEmpty || p.size > 0;
+        for (int f = p.start; f < p.start + p.size; ++f)
+            for (int k = 0; k < 3; ++k) dir[k] += std::fabs(Sf[3 * (size_t)f + k] / magSf[f]);
+    }
+    const double md = mag3(dir);
+    nGeomD = 0;
+    for (int k = 0; k < 3; ++k) {
+        geomD[k] = (hasEmpty && md > 0 && dir[k] / md > 1e-6) ? -1 : 1;
+        if (geomD[k] == 1) nGeomD++;
+    }
+}
+
+// L0: primitiveMesh::calcCells / calcPointCells orders
+void Mesh::addressing() {
+    cells.assign(nC, ivec());
+    for (int f = 0; f < nF; ++f) cells[own[f]].push_back(f);
+    for (int f = 0; f < nIF; ++f) cells[nei[f]].push_back(f);
+    pointCells.assign(nP, ivec());
+    for (int c = 0; c < nC; ++c)
+        for (int f : cells[c])
+            for (int q = fOff[f]; q < fOff[f + 1]; ++q) {
+                ivec& pc = pointCells[fPts[q]];
+                if (pc.empty() || pc.back() != c) {
+                    if (std::find(pc.begin(), pc.end(), c) == pc.end()) pc.push_back(c);
+                }
+            }
+}
+
+// L0: volPointInterpolation::calcBoundaryAddressing / makeInternalWeights /
+// makeBoundaryWeights
+void Mesh::pointInterpolationWeights() {
+    const int nb = nBF();
+    isPatchFace.assign(nb, 0);
+    isPatchPoint.assign(nP, 0);
+    for (const PatchInfo& p : patches) {
+        if (p.type == PATCH_EMPTY || p.type == PATCH_CYCLIC || p.type == PATCH_HALO) continue;
+        for (int f = p.start; f < p.start + p.size; ++f) {
+            isPatchFace[f - nIF] = 1;
+            for (int q = fOff[f]; q < fOff[f + 1]; ++q) isPatchPoint[fPts[q]] = 1;
+        }
+    }
+    // boundary primitivePatch addressing: meshPoints in order of first
+    // appearance, pointFaces ascending
+    ivec bIndex(nP, -1);
+    bndMeshPoints.clear(); bndPointFaces.clear();
+    for (int f = nIF; f < nF; ++f)
+        for (int q = fOff[f]; q < fOff[f + 1]; ++q) {
+            const int pt = fPts[q];
+            if (bIndex[pt] < 0) { bIndex[pt] = (int)bndMeshPoints.size(); bndMeshPoints.push_back(pt); bndPointFaces.push_back(ivec()); }
+            bndPointFaces[bIndex[pt]].push_back(f - nIF);
+        }
+    pointWeights.assign(nP, dvec());
+    for (int pt = 0; pt < nP; ++pt) {
+        if (isPatchPoint[pt]) continue;
+        const ivec& pc = pointCells[pt];
+        dvec& pw = pointWeights[pt];
+        pw.resize(pc.size());
+        double sum = 0;
+        for (size_t i = 0; i < pc.size(); ++i) {
+            double d[3];
+            for (int k = 0; k < 3; ++k) d[k] = pts[3 * (size_t)pt + k] - C[3 * (size_t)pc[i] + k];
+            pw[i] = 1.0 / mag3(d);
+            sum += pw[i];
+        }
+        for (size_t i = 0; i < pw.size(); ++i) pw[i] /= sum;
+    }
+    bndPointWeights.assign(bndMeshPoints.size(), dvec());
+    for (size_t i = 0; i < bndMeshPoints.size(); ++i) {
+        const int pt = bndMeshPoints[i];
+        if (!isPatchPoint[pt]) continue;
+        const ivec& pf = bndPointFaces[i];
+        dvec& pw = bndPointWeights[i];
+        pw.resize(pf.size());
+        double sum = 0;
+        for (size_t j = 0; j < pf.size(); ++j) {
+            if (isPatchFace[pf[j]]) {
+                const int f = nIF + pf[j];
+                double d[3];
+                for (int k = 0; k < 3; ++k) d[k] = pts[3 * (size_t)pt + k] - Cf[3 * (size_t)f + k];
+                pw[j] = 1.0 / mag3(d);
+                sum += pw[j];
+            } else pw[j] = 0.0;
+        }
+        for (size_t j = 0; j < pw.size(); ++j) pw[j] /= sum;
+    }
+}
+
+void Mesh::haloFaces() {
+    for (int side = 0; side < 2; ++side) {
+        std::vector<char> isG(nC, 0), isS(nC, 0);
+        for (int c : haloGhost[side]) isG[c] = 1;
+        for (int c : haloSend[side]) isS[c] = 1;
+        haloGhostBF[side].clear(); haloSendBF[side].clear();
+        for (size_t p = 0; p < patches.size(); ++p) {
+            if (patches[p].type == PATCH_HALO) continue;
+            for (int f = patches[p].start; f < patches[p].start + patches[p].size; ++f) {
+                if (isG[own[f]]) haloGhostBF[side].push_back(f - nIF);
+                if (isS[own[f]]) haloSendBF[side].push_back(f - nIF);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// fields
+// ---------------------------------------------------------------------------
+enum SnKind { SN_GENERIC = 0, SN_ZERO = 1, SN_GRADIENT = 2, SN_SYMM = 3 };
+
+struct VolField {
+    int nc = 1;
+    dvec in, bf;    // nC*nc, nBF*nc
+    ivec snKind;    // per patch (empty => generic)
+    dvec grad;      // nBF*nc, gradient() of fixedGradient patches
+    VolField() {}
+    VolField(const Mesh& m, int ncomp) : nc(ncomp), in((size_t)m.nC * ncomp, 0.0), bf((size_t)m.nBF() * ncomp, 0.0) {}
+};
+struct SurfField {
+    int nc = 1;
+    dvec v;  // nF*nc
+    SurfField() {}
+    SurfField(const Mesh& m, int ncomp) : nc(ncomp), v((size_t)m.nF * ncomp, 0.0) {}
+};
+
+// L0: fvPatchField::snGrad() = deltaCoeffs*(*this - patchInternalField()),
+// zeroGradient -> 0, fixedGradient -> gradient(), basicSymmetry ->
+// (transform(I - 2 nn, pif) - pif)*(deltaCoeffs/2)
+void patchSnGrad(const Mesh& m, const VolField& f, int patch, dvec& sn /*nBF*nc*/) {
+    const PatchInfo& p = m.patches[patch];
+    if (!m.patchHasFields(patch)) return;
+    const int kind = f.snKind.empty() ? SN_GENERIC : f.snKind[patch];
+    for (int gf = p.start; gf < p.start + p.size; ++gf) {
+        const int b = gf - m.nIF, o = m.own[gf];
+        if (kind == SN_ZERO) {
+            for (int k = 0; k < f.nc; ++k) sn[(size_t)b * f.nc + k] = 0.0;
+        } else if (kind == SN_GRADIENT) {
+            for (int k = 0; k < f.nc; ++k) sn[(size_t)b * f.nc + k] = f.grad[(size_t)b * f.nc + k];
+        } else if (kind == SN_SYMM && f.nc == 3) {
+            double n[3];
+            for (int k = 0; k < 3; ++k) n[k] = m.Sf[3 * (size_t)gf + k] / m.magSf[gf];
+            // symmTensor T = I - 2.0*sqr(nHat); transform(T, v) = T & v
+            double T[9];
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) T[3 * i + j] = (i == j ? 1.0 : 0.0) - 2.0 * (n[i] * n[j]);
+            const double* v = &f.in[3 * (size_t)o];
+            for (int i = 0; i < 3; ++i) {
+                const double tv = T[3 * i] * v[0] + T[3 * i + 1] * v[1] + T[3 * i + 2] * v[2];
+                sn[(size_t)b * 3 + i] = (tv - v[i]) * (m.delta[gf] / 2.0);
+            }
+        } else {
+            for (int k = 0; k < f.nc; ++k)
+                sn[(size_t)b * f.nc + k] = m.delta[gf] * (f.bf[(size_t)b * f.nc + k] - f.in[(size_t)o * f.nc + k]);
+        }
+    }
+}
+
+dvec allPatchSnGrad(const Mesh& m, const VolField& f) {
+    dvec sn((size_t)m.nBF() * f.nc, 0.0);
+    for (size_t p = 0; p < m.patches.size(); ++p) patchSnGrad(m, f, (int)p, sn);
+    return sn;
+}
+
+// L0: linearInterpolate = surfaceInterpolationScheme::interpolate(vf, weights):
+// sf = lambda*(vf[P] - vf[N]) + vf[N]; boundary = patch value
+SurfField linearInterpolate(const Mesh& m, const VolField& f) {
+    SurfField s(m, f.nc);
+    for (int fc = 0; fc < m.nIF; ++fc)
+        for (int k = 0; k < f.nc; ++k) {
+            const double a = f.in[(size_t)m.own[fc] * f.nc + k], b = f.in[(size_t)m.nei[fc] * f.nc + k];
+            s.v[(size_t)fc * f.nc + k] = m.w[fc] * (a - b) + b;
+        }
+    for (size_t p = 0; p < m.patches.size(); ++p) {
+        if (!m.patchHasFields((int)p)) continue;
+        for (int fc = m.patches[p].start; fc < m.patches[p].start + m.patches[p].size; ++fc)
+            for (int k = 0; k < f.nc; ++k) s.v[(size_t)fc * f.nc + k] = f.bf[(size_t)(fc - m.nIF) * f.nc + k];
+    }
+    return s;
+}
+
+// L0: fvc::snGrad (uncorrected): nonOrthDeltaCoeffs*(vf[N]-vf[P]); boundary = patch snGrad
+SurfField fvcSnGrad(const Mesh& m, const VolField& f) {
+    SurfField s(m, f.nc);
+    for (int fc = 0; fc < m.nIF; ++fc)
+        for (int k = 0; k < f.nc; ++k)
+            s.v[(size_t)fc * f.nc + k] = m.nonOrthDelta[fc] * (f.in[(size_t)m.nei[fc] * f.nc + k] - f.in[(size_t)m.own[fc] * f.nc + k]);
+    dvec sn = allPatchSnGrad(m, f);
+    for (int fc = m.nIF; fc < m.nF; ++fc)
+        for (int k = 0; k < f.nc; ++k) s.v[(size_t)fc * f.nc + k] = sn[(size_t)(fc - m.nIF) * f.nc + k];
+    return s;
+}
+
+VolField component(const Mesh& m, const VolField& f, int d) {
+    VolField c(m, 1);
+    for (int i = 0; i < m.nC; ++i) c.in[i] = f.in[(size_t)i * f.nc + d];
+    for (int i = 0; i < m.nBF(); ++i) c.bf[i] = f.bf[(size_t)i * f.nc + d];
+    return c;  // calculated patches: generic snGrad
+}
+
+// L0: volPointInterpolation::interpolate (internal + boundary override; point
+// constraints are no-ops for the calculated point patches used here)
+dvec volPointInterpolate(const Mesh& m, const VolField& f) {
+    const int nc = f.nc;
+    dvec pf((size_t)m.nP * nc, 0.0);
+    for (int pt = 0; pt < m.nP; ++pt) {
+        if (m.isPatchPoint[pt]) continue;
+        const ivec& pc = m.pointCells[pt];
+        const dvec& pw = m.pointWeights[pt];
+        for (size_t i = 0; i < pc.size(); ++i)
+            for (int k = 0; k < nc; ++k) pf[(size_t)pt * nc + k] += pw[i] * f.in[(size_t)pc[i] * nc + k];
+    }
+    // flatBoundaryField: zero on empty and coupled patches
+    dvec bv((size_t)m.nBF() * nc, 0.0);
+    for (size_t p = 0; p < m.patches.size(); ++p) {
+        if (m.patches[p].type == PATCH_EMPTY || m.coupled((int)p)) continue;
+        for (int fc = m.patches[p].start; fc < m.patches[p].start + m.patches[p].size; ++fc)
+            for (int k = 0; k < nc; ++k) bv[(size_t)(fc - m.nIF) * nc + k] = f.bf[(size_t)(fc - m.nIF) * nc + k];
+    }
+    for (size_t i = 0; i < m.bndMeshPoints.size(); ++i) {
+        const int pt = m.bndMeshPoints[i];
+        if (!m.isPatchPoint[pt]) continue;
+        const ivec& pfc = m.bndPointFaces[i];
+        const dvec& pw = m.bndPointWeights[i];
+        for (int k = 0; k < nc; ++k) pf[(size_t)pt * nc + k] = 0.0;
+        for (size_t j = 0; j < pfc.size(); ++j) {
+            if (!m.isPatchFace[pfc[j]]) continue;
+            for (int k = 0; k < nc; ++k) pf[(size_t)pt * nc + k] += pw[j] * bv[(size_t)pfc[j] * nc + k];
+        }
+    }
+    return pf;
+}
+
+// ---------------------------------------------------------------------------
+// fvsc stencils
+// ---------------------------------------------------------------------------
+struct Stencil {
+    const Mesh& m;
+    dvec nf;  // fvscStencil::nf_ = Sf/magSf [fvscStencil.C:126-129]
+    explicit Stencil(const Mesh& mesh) : m(mesh), nf(3 * (size_t)mesh.nF, 0.0) {
+        for (int f = 0; f < m.nF; ++f)
+            if (m.magSf[f] > 0) for (int k = 0; k < 3; ++k) nf[3 * (size_t)f + k] = m.Sf[3 * (size_t)f + k] / m.magSf[f];
+    }
+    virtual ~Stencil() {}
+    virtual SurfField gradS(const VolField& f) = 0;
+    virtual SurfField gradV(const VolField& f) = 0;
+    virtual SurfField divV(const VolField& f) = 0;
+    virtual SurfField divT(const VolField& f) = 0;
+
+    // nf * snGrad (outer product) and nf & snGrad
+    SurfField nfOuterSnGrad(const VolField& f) const {
+        SurfField sn = fvcSnGrad(m, f);
+        SurfField r(m, 3 * f.nc);
+        for (int fc = 0; fc < m.nF; ++fc)
+            for (int i = 0; i < 3; ++i)
+                for (int k = 0; k < f.nc; ++k)
+                    r.v[(size_t)fc * 3 * f.nc + i * f.nc + k] = nf[3 * (size_t)fc + i] * sn.v[(size_t)fc * f.nc + k];
+        return r;
+    }
+    SurfField nfDotSnGrad(const VolField& f) const {
+        SurfField sn = fvcSnGrad(m, f);
+        const int no = f.nc / 3;  // vector -> scalar, tensor -> vector
+        SurfField r(m, no);
+        for (int fc = 0; fc < m.nF; ++fc)
+            for (int j = 0; j < no; ++j)
+                r.v[(size_t)fc * no + j] = nf[3 * (size_t)fc] * sn.v[(size_t)fc * f.nc + j]
+                                         + nf[3 * (size_t)fc + 1] * sn.v[(size_t)fc * f.nc + no + j]
+                                         + nf[3 * (size_t)fc + 2] * sn.v[(size_t)fc * f.nc + 2 * no + j];
+        return r;
+    }
+};
+
+// [reducedFaceNormalStencil.C:69-108]
+struct Reduced : Stencil {
+    explicit Reduced(const Mesh& mesh) : Stencil(mesh) {}
+    SurfField gradS(const VolField& f) override { return nfOuterSnGrad(f); }
+    SurfField gradV(const VolField& f) override { return nfOuterSnGrad(f); }
+    SurfField divV(const VolField& f) override { return nfDotSnGrad(f); }
+    SurfField divT(const VolField& f) override { return nfDotSnGrad(f); }
+};
+
+// leastSquares, serial branch
+struct LeastSquares : Stencil {
+    std::vector<ivec> neighbourCells;   // [FindNb.C:48-86]
+    std::vector<std::vector<double> > GdfAll, wf2All;  // [CalcW.C:152-153]
+    ivec internalDegFaces;
+    explicit LeastSquares(const Mesh& mesh) : Stencil(mesh) { findNeighbours(); calculateWeights(); }
+
+    void findNeighbours() {  // [extendedFaceStencilFindNeighbours.C:41-86]
+        neighbourCells.assign(m.nIF, ivec());
+        for (int facei = 0; facei < m.nIF; ++facei) {
+            ivec nb;
+            for (int q = m.fOff[facei]; q < m.fOff[facei + 1]; ++q) {
+                const ivec& pc = m.pointCells[m.fPts[q]];
+                for (int celli : pc) {
+                    bool contained = false;
+                    for (int x : nb) if (x == celli) contained = true;
+                    if (!contained) nb.push_back(celli);
+                }
+            }
+            neighbourCells[facei] = nb;
+        }
+    }
+    void calculateWeights() {  // [extendedFaceStencilCalculateWeights.C:43-155]
+        GdfAll.assign(m.nIF, dvec()); wf2All.assign(m.nIF, dvec());
+        for (int facei = 0; facei < m.nIF; ++facei) {
+            const ivec& nb = neighbourCells[facei];
+            dvec df(3 * nb.size()), wf2(nb.size());
+            double G[6] = {0, 0, 0, 0, 0, 0};  // symmTensor xx xy xz yy yz zz
+            const double* Cf = &m.Cf[3 * (size_t)facei];
+            for (size_t i = 0; i < nb.size(); ++i) {
+                double* d = &df[3 * i];
+                for (int k = 0; k < 3; ++k) d[k] = m.C[3 * (size_t)nb[i] + k] - Cf[k];
+                wf2[i] = 1 / (d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+                const double a[6] = {d[0] * d[0], d[0] * d[1], d[0] * d[2], d[1] * d[1], d[1] * d[2], d[2] * d[2]};
+                for (int k = 0; k < 6; ++k) G[k] += a[k] * wf2[i];
+            }
+            double G0[6] = {0, 0, 0, 0, 0, 0};
+            if (std::fabs(G[0]) < SMALL) G0[0] = 1;
+            if (std::fabs(G[3]) < SMALL) G0[3] = 1;
+            if (std::fabs(G[5]) < SMALL) G0[5] = 1;
+            for (int k = 0; k < 6; ++k) G[k] = G[k] + G0[k];
+            // det(symmTensor) (L0 formula)
+            const double detG = G[0] * G[3] * G[5] + G[1] * G[4] * G[2] + G[2] * G[1] * G[4]
+                              - G[0] * G[4] * G[4] - G[1] * G[1] * G[5] - G[2] * G[3] * G[2];
+            if (detG < 1) {
+                internalDegFaces.push_back(facei);
+            } else {
+                // inv(symmTensor) = cofactors/det (L0)
+                const double I[6] = {
+                    (G[3] * G[5] - G[4] * G[4]) / detG, (G[2] * G[4] - G[1] * G[5]) / detG,
+                    (G[1] * G[4] - G[2] * G[3]) / detG, (G[0] * G[5] - G[2] * G[2]) / detG,
+                    (G[1] * G[2] - G[0] * G[4]) / detG, (G[0] * G[3] - G[1] * G[1]) / detG};
+                for (int k = 0; k < 6; ++k) G[k] = I[k] - G0[k];
+            }
+            for (size_t i = 0; i < nb.size(); ++i) {  // df = G & df
+                const double d[3] = {df[3 * i], df[3 * i + 1], df[3 * i + 2]};
+                df[3 * i] = G[0] * d[0] + G[1] * d[1] + G[2] * d[2];
+                df[3 * i + 1] = G[1] * d[0] + G[3] * d[1] + G[4] * d[2];
+                df[3 * i + 2] = G[2] * d[0] + G[4] * d[1] + G[5] * d[2];
+            }
+            GdfAll[facei] = df; wf2All[facei] = wf2;
+        }
+    }
+    SurfField gradS(const VolField& iF) override {  // [extendedFaceStencilScalarGrad.C:50-114]
+        SurfField sF = linearInterpolate(m, iF);
+        SurfField sngF = fvcSnGrad(m, iF);
+        SurfField g(m, 3);  // 0.0*nf*sngF
+        for (int facei = 0; facei < m.nIF; ++facei) {
+            double gf[3] = {0, 0, 0};
+            const ivec& nb = neighbourCells[facei];
+            for (size_t i = 0; i < nb.size(); ++i) {
+                const double dphi = iF.in[nb[i]] - sF.v[facei];
+                for (int k = 0; k < 3; ++k) gf[k] = gf[k] + (wf2All[facei][i] * GdfAll[facei][3 * i + k]) * dphi;
+            }
+            for (int k = 0; k < 3; ++k) g.v[3 * (size_t)facei + k] = gf[k];
+        }
+        for (int d : internalDegFaces)
+            for (int k = 0; k < 3; ++k) g.v[3 * (size_t)d + k] = sngF.v[d] * nf[3 * (size_t)d + k];
+        for (size_t p = 0; p < m.patches.size(); ++p) {
+            const int t = m.patches[p].type;
+            const bool constraint = t == PATCH_EMPTY || t == PATCH_WEDGE || t == PATCH_CYCLIC || t == PATCH_HALO ||
+                                    t == PATCH_SYMMETRY || t == PATCH_SYMMETRYPLANE;
+            if (constraint) continue;
+            dvec sn((size_t)m.nBF(), 0.0);
+            patchSnGrad(m, iF, (int)p, sn);
+            for (int fc = m.patches[p].start; fc < m.patches[p].start + m.patches[p].size; ++fc)
+                for (int k = 0; k < 3; ++k) g.v[3 * (size_t)fc + k] = nf[3 * (size_t)fc + k] * sn[fc - m.nIF];
+        }
+        return g;
+    }
+    SurfField gradV(const VolField& f) override {  // [leastSquaresStencil.C:145-196]
+        SurfField c0 = gradS(component(m, f, 0)), c1 = gradS(component(m, f, 1)), c2 = gradS(component(m, f, 2));
+        SurfField g(m, 9);
+        for (int fc = 0; fc < m.nF; ++fc)
+            for (int i = 0; i < 3; ++i) {
+                g.v[9 * (size_t)fc + 3 * i + 0] = c0.v[3 * (size_t)fc + i];
+                g.v[9 * (size_t)fc + 3 * i + 1] = c1.v[3 * (size_t)fc + i];
+                g.v[9 * (size_t)fc + 3 * i + 2] = c2.v[3 * (size_t)fc + i];
+            }
+        return g;
+    }
+    SurfField divV(const VolField& f) override {  // [leastSquaresStencil.C:204-228]
+        SurfField c0 = gradS(component(m, f, 0)), c1 = gradS(component(m, f, 1)), c2 = gradS(component(m, f, 2));
+        SurfField d(m, 1);
+        for (int fc = 0; fc < m.nF; ++fc) d.v[fc] = c0.v[3 * (size_t)fc] + c1.v[3 * (size_t)fc + 1] + c2.v[3 * (size_t)fc + 2];
+        return d;
+    }
+    SurfField divT(const VolField& f) override {  // [leastSquaresStencil.C:236-275]
+        SurfField g[9];
+        for (int k = 0; k < 9; ++k) g[k] = gradS(component(m, f, k));
+        SurfField d(m, 3);
+        for (int fc = 0; fc < m.nF; ++fc)
+            for (int j = 0; j < 3; ++j)
+                d.v[3 * (size_t)fc + j] = g[j].v[3 * (size_t)fc] + g[3 + j].v[3 * (size_t)fc + 1] + g[6 + j].v[3 * (size_t)fc + 2];
+        return d;
+    }
+};
+
+// GaussVolPoint: 1-D / 2-D / 3-D bases + dispatcher
+struct GaussVolPoint : Stencil {
+    // ---- 3-D [GaussVolPointBase3D.C:41-159] --------------------------------
+    ivec qf, tf, of;                        // internal quad / tri / other faces
+    std::vector<ivec> bqf, btf, bof;        // per patch (patch-local indices)
+    std::vector<dvec> aq[3], at[3];         // per face: 6 / 5 coefficients
+    dvec vq, vt;
+    std::vector<std::vector<dvec> > baq[3], bat[3];
+    std::vector<dvec> bvq, bvt, bmvON;
+    // ---- 2-D [GaussVolPointBase2D.C:44-293] --------------------------------
+    dvec c1, c2, c3, c4, mv42, mv13;
+    ivec ip3, ip1, ic4, ic2;
+    int ie1 = -1, ie2 = -1, ie3 = -1;
+    double e1[3] = {1, 0, 0}, e2[3] = {0, 1, 0};
+    ivec ordinaryPatches;
+    std::vector<ivec> ip3e, ip1e, ic4e;
+    std::vector<dvec> c1e, c2e, c3e, c4e, mv42e, mv13e;
+
+    explicit GaussVolPoint(const Mesh& mesh) : Stencil(mesh) { init2D(); init3D(); }
+
+    void init3D() {
+        const int np = (int)m.patches.size();
+        bqf.assign(np, ivec()); btf.assign(np, ivec()); bof.assign(np, ivec());
+        for (int i = 0; i < m.nIF; ++i) {
+            if (m.fsize(i) == 3) tf.push_back(i);
+            else if (m.fsize(i) == 4) qf.push_back(i);
+            else of.push_back(i);
+        }
+        bmvON.assign(np, dvec());
+        std::vector<dvec> vO(np), vN(np);
+        for (int ip = 0; ip < np; ++ip) {
+            if (!m.patchHasFields(ip)) continue;
+            const PatchInfo& p = m.patches[ip];
+            for (int i = 0; i < p.size; ++i) {
+                const int n = m.fsize(p.start + i);
+                if (n == 3) btf[ip].push_back(i); else if (n == 4) bqf[ip].push_back(i); else bof[ip].push_back(i);
+            }
+            vO[ip].resize(3 * (size_t)p.size); vN[ip].resize(3 * (size_t)p.size); bmvON[ip].resize(p.size);
+            for (int i = 0; i < p.size; ++i) {
+                const int gf = p.start + i;
+                double d[3];
+                for (int k = 0; k < 3; ++k) {
+                    vO[ip][3 * i + k] = m.C[3 * (size_t)m.own[gf] + k];
+                    // vN = vO + 2.0*(Cf - vO)  [3D.C:142-147]
+                    vN[ip][3 * i + k] = vO[ip][3 * i + k] + 2.0 * (m.Cf[3 * (size_t)gf + k] - vO[ip][3 * i + k]);
+                    d[k] = vO[ip][3 * i + k] - vN[ip][3 * i + k];
+                }
+                bmvON[ip][i] = mag3(d);
+            }
+        }
+        const double OneBySix = (1.0 / 6.0);
+        // ---- triangles [3D.C:161-318]
+        for (int d = 0; d < 3; ++d) { at[d].assign(tf.size(), dvec()); bat[d].assign(np, std::vector<dvec>()); }
+        vt.resize(tf.size()); bvt.assign(np, dvec());
+        auto triCoeffs = [&](const double* p1, const double* p2, const double* p3, const double* own, const double* nei,
+                             dvec& ax, dvec& ay, dvec& az, double& vol) {
+            double a[3], b[3], cr[3], on[3];
+            for (int k = 0; k < 3; ++k) { a[k] = p2[k] - p1[k]; b[k] = p3[k] - p1[k]; on[k] = own[k] - nei[k]; }
+            cross3(a, b, cr);
+            vol = dot3(cr, on);
+            vol *= OneBySix;
+            ax.resize(5); ay.resize(5); az.resize(5);
+            // x: (y,z) ; y: (z,x) ; z: (x,y)  -- cyclic permutation of [3D.C:193-229]
+            dvec* A[3] = {&ax, &ay, &az};
+            for (int d = 0; d < 3; ++d) {
+                const int u = (d + 1) % 3, v = (d + 2) % 3;  // x->(y,z), y->(z,x), z->(x,y)
+                dvec& c = *A[d];
+                c[0] = OneBySix * ((own[v] - nei[v]) * (p2[u] - p3[u]) + (nei[u] - own[u]) * (p2[v] - p3[v]));
+                c[1] = OneBySix * ((nei[u] - own[u]) * (p3[v] - p1[v]) + (own[v] - nei[v]) * (p3[u] - p1[u]));
+                c[2] = OneBySix * ((nei[u] - own[u]) * (p1[v] - p2[v]) + (own[v] - nei[v]) * (p1[u] - p2[u]));
+                c[3] = OneBySix * (p1[v] * (p2[u] - p3[u]) + p2[v] * (p3[u] - p1[u]) + p3[v] * (p1[u] - p2[u]));
+                c[4] = -c[3];
+            }
+        };
+        for (size_t i = 0; i < tf.size(); ++i) {
+            const int f = tf[i];
+            const int* q = m.fp(f);
+            triCoeffs(&m.pts[3 * (size_t)q[0]], &m.pts[3 * (size_t)q[1]], &m.pts[3 * (size_t)q[2]],
+                      &m.C[3 * (size_t)m.own[f]], &m.C[3 * (size_t)m.nei[f]], at[0][i], at[1][i], at[2][i], vt[i]);
+        }
+        // ---- quads [3D.C:320-476]
+        for (int d = 0; d < 3; ++d) { aq[d].assign(qf.size(), dvec()); baq[d].assign(np, std::vector<dvec>()); }
+        vq.resize(qf.size()); bvq.assign(np, dvec());
+        auto quadCoeffs = [&](const double* p1, const double* p2, const double* p3, const double* p4, const double* own,
+                              const double* nei, dvec& ax, dvec& ay, dvec& az, double& vol) {
+            double a[3], b[3], on[3], cr[3];
+            for (int k = 0; k < 3; ++k) { a[k] = p3[k] - p1[k]; b[k] = p4[k] - p2[k]; on[k] = own[k] - nei[k]; }
+            cross3(b, on, cr);
+            vol = dot3(a, cr);
+            vol *= OneBySix;
+            ax.resize(6); ay.resize(6); az.resize(6);
+            dvec* A[3] = {&ax, &ay, &az};
+            for (int d = 0; d < 3; ++d) {
+                const int u = (d + 1) % 3, v = (d + 2) % 3;
+                dvec& c = *A[d];
+                c[0] = OneBySix * ((nei[u] - own[u]) * (p2[v] - p4[v]) - (nei[v] - own[v]) * (p2[u] - p4[u]));
+                c[1] = OneBySix * ((nei[u] - own[u]) * (p3[v] - p1[v]) - (nei[v] - own[v]) * (p3[u] - p1[u]));
+                c[5] = OneBySix * ((p1[u] - p3[u]) * (p2[v] - p4[v]) - (p1[v] - p3[v]) * (p2[u] - p4[u]));
+                c[2] = -c[0]; c[3] = -c[1]; c[4] = -c[5];
+            }
+        };
+        for (size_t i = 0; i < qf.size(); ++i) {
+            const int f = qf[i];
+            const int* q = m.fp(f);
+            quadCoeffs(&m.pts[3 * (size_t)q[0]], &m.pts[3 * (size_t)q[1]], &m.pts[3 * (size_t)q[2]], &m.pts[3 * (size_t)q[3]],
+                       &m.C[3 * (size_t)m.own[f]], &m.C[3 * (size_t)m.nei[f]], aq[0][i], aq[1][i], aq[2][i], vq[i]);
+        }
+        for (int ip = 0; ip < np; ++ip) {
+            for (int d = 0; d < 3; ++d) { bat[d][ip].assign(btf[ip].size(), dvec()); baq[d][ip].assign(bqf[ip].size(), dvec()); }
+            bvt[ip].resize(btf[ip].size()); bvq[ip].resize(bqf[ip].size());
+            for (size_t k = 0; k < btf[ip].size(); ++k) {
+                const int li = btf[ip][k], gf = m.patches[ip].start + li;
+                const int* q = m.fp(gf);
+                triCoeffs(&m.pts[3 * (size_t)q[0]], &m.pts[3 * (size_t)q[1]], &m.pts[3 * (size_t)q[2]],
+                          &vO[ip][3 * li], &vN[ip][3 * li], bat[0][ip][k], bat[1][ip][k], bat[2][ip][k], bvt[ip][k]);
+            }
+            for (size_t k = 0; k < bqf[ip].size(); ++k) {
+                const int li = bqf[ip][k], gf = m.patches[ip].start + li;
+                const int* q = m.fp(gf);
+                quadCoeffs(&m.pts[3 * (size_t)q[0]], &m.pts[3 * (size_t)q[1]], &m.pts[3 * (size_t)q[2]], &m.pts[3 * (size_t)q[3]],
+                           &vO[ip][3 * li], &vN[ip][3 * li], baq[0][ip][k], baq[1][ip][k], baq[2][ip][k], bvq[ip][k]);
+            }
+        }
+    }
+
+    // macro dfdxif [3D.C:488-513]: out[face][ocmpt] += (sum_k a_k phi_k)/V
+    void dfdxif(const VolField& vf, const dvec& pf, SurfField& out, const ivec& fi, const dvec& vi,
+                const std::vector<dvec>& ai, int icmpt, int ocmpt) const {
+        if (fi.empty()) return;
+        const int iown = (int)ai[0].size() - 1, inei = iown - 1;
+        const int nc = vf.nc, no = out.nc;
+        for (size_t i = 0; i < fi.size(); ++i) {
+            const int facei = fi[i];
+            double d = vf.in[(size_t)m.nei[facei] * nc + icmpt] * ai[i][inei];
+            d += vf.in[(size_t)m.own[facei] * nc + icmpt] * ai[i][iown];
+            const int* q = m.fp(facei);
+            for (int k = 0; k < m.fsize(facei); ++k) d += pf[(size_t)q[k] * nc + icmpt] * ai[i][k];
+            out.v[(size_t)facei * no + ocmpt] += (d / vi[i]);
+        }
+    }
+    // macro dfdxbf [3D.C:515-539]
+    void dfdxbf(const VolField& vf, const dvec& pf, int patchi, SurfField& out, const ivec& bfi, const dvec& bvfi,
+                const std::vector<dvec>& bai, const dvec& psin, int icmpt, int ocmpt) const {
+        if (bfi.empty()) return;
+        const int iown = (int)bai[0].size() - 1, inei = iown - 1;
+        const int nc = vf.nc, no = out.nc;
+        for (size_t i = 0; i < bfi.size(); ++i) {
+            const int gf = m.patches[patchi].start + bfi[i];
+            const int b = gf - m.nIF;
+            double d = psin[(size_t)b * nc + icmpt] * bai[i][inei];
+            d += vf.in[(size_t)m.own[gf] * nc + icmpt] * bai[i][iown];  // psio = patchInternalField
+            const int* q = m.fp(gf);
+            for (int k = 0; k < m.fsize(gf); ++k) d += pf[(size_t)q[k] * nc + icmpt] * bai[i][k];
+            out.v[(size_t)gf * no + ocmpt] += d / bvfi[i];
+        }
+    }
+    // psin = boundaryField + snGrad*bmvON*0.5 [3D.C:790-793]
+    dvec psiN(const VolField& vf) const {
+        dvec sn = allPatchSnGrad(m, vf);
+        dvec r((size_t)m.nBF() * vf.nc, 0.0);
+        for (size_t ip = 0; ip < m.patches.size(); ++ip) {
+            if (!m.patchHasFields((int)ip)) continue;
+            for (int i = 0; i < m.patches[ip].size; ++i) {
+                const int b = m.patches[ip].start + i - m.nIF;
+                for (int k = 0; k < vf.nc; ++k)
+                    r[(size_t)b * vf.nc + k] = vf.bf[(size_t)b * vf.nc + k] + sn[(size_t)b * vf.nc + k] * bmvON[ip][i] * 0.5;
+            }
+        }
+        return r;
+    }
+    // apply a table of (direction, icmpt, ocmpt) on quads then on triangles,
+    // copy dfdn on other faces; same for every patch
+    struct Term { int dir, ic, oc; };
+    void apply3D(const VolField& vf, SurfField& out, const SurfField& dfdn, const std::vector<Term>& quadTerms,
+                 const std::vector<Term>& triTermsInternal, const std::vector<Term>& triTermsBoundary) const {
+        dvec pf = volPointInterpolate(m, vf);
+        for (const Term& t : quadTerms) dfdxif(vf, pf, out, qf, vq, aq[t.dir], t.ic, t.oc);
+        for (const Term& t : triTermsInternal) dfdxif(vf, pf, out, tf, vt, at[t.dir], t.ic, t.oc);
+        for (int f : of) for (int k = 0; k < out.nc; ++k) out.v[(size_t)f * out.nc + k] = dfdn.v[(size_t)f * out.nc + k];
+        dvec psin = psiN(vf);
+        for (size_t ip = 0; ip < m.patches.size(); ++ip) {
+            if (!m.patchHasFields((int)ip)) continue;
+            for (const Term& t : quadTerms) dfdxbf(vf, pf, (int)ip, out, bqf[ip], bvq[ip], baq[t.dir][ip], psin, t.ic, t.oc);
+            for (const Term& t : triTermsBoundary) dfdxbf(vf, pf, (int)ip, out, btf[ip], bvt[ip], bat[t.dir][ip], psin, t.ic, t.oc);
+            for (int li : bof[ip]) {
+                const int gf = m.patches[ip].start + li;
+                for (int k = 0; k < out.nc; ++k) out.v[(size_t)gf * out.nc + k] = dfdn.v[(size_t)gf * out.nc + k];
+            }
+        }
+    }
+
+    void init2D() {
+        if (m.nGeomD != 2) return;
+        const int nIF = m.nIF, np = (int)m.patches.size();
+        c1.assign(nIF, 0); c2.assign(nIF, 0); c3.assign(nIF, 0); c4.assign(nIF, 0);
+        mv42.assign(nIF, 1); mv13.assign(nIF, 1);
+        ip3.assign(nIF, -1); ip1.assign(nIF, -1); ic4.assign(nIF, -1); ic2.assign(nIF, -1);
+        for (int d = 0; d < 3; ++d) if (m.geomD[d] < 1) ie3 = d;
+        if (ie3 == 0) { e1[0] = 0; e1[1] = 1; e1[2] = 0; e2[0] = 0; e2[1] = 0; e2[2] = 1; ie1 = 1; ie2 = 2; }
+        if (ie3 == 1) { e1[0] = 1; e1[1] = 0; e1[2] = 0; e2[0] = 0; e2[1] = 0; e2[2] = 1; ie1 = 0; ie2 = 2; }
+        if (ie3 == 2) { e1[0] = 1; e1[1] = 0; e1[2] = 0; e2[0] = 0; e2[1] = 1; e2[2] = 0; ie1 = 0; ie2 = 1; }
+        int p1 = -1, p3 = -1;
+        auto coeffs = [&](const double* v42, const double* v13, double& m42, double& m13, double& C1, double& C2, double& C3, double& C4) {
+            m42 = mag3(v42); m13 = mag3(v13);
+            double a[3], b[3];
+            for (int k = 0; k < 3; ++k) { a[k] = v42[k] / m42; b[k] = v13[k] / m13; }
+            const double cosa1 = dot3(a, e1), cosa2 = dot3(b, e1), sina1 = dot3(a, e2), sina2 = dot3(b, e2);
+            const double den = sina2 * cosa1 - sina1 * cosa2;
+            C1 = sina2 / den; C2 = sina1 / den; C3 = cosa1 / den; C4 = cosa2 / den;
+        };
+        for (int f = 0; f < nIF; ++f) {  // [2D.C:122-169]
+            const int c2i = m.nei[f], c4i = m.own[f];
+            const int* q = m.fp(f);
+            const int n = m.fsize(f);
+            for (int k = 0; k < n; ++k) if (m.pts[3 * (size_t)q[k] + ie3] >= m.C[3 * (size_t)c2i + ie3]) { p1 = q[k]; break; }
+            for (int k = 0; k < n; ++k) if (m.pts[3 * (size_t)q[k] + ie3] >= m.C[3 * (size_t)c2i + ie3]) { if (p1 != q[k]) { p3 = q[k]; break; } }
+            ic2[f] = c2i; ic4[f] = c4i; ip3[f] = p3; ip1[f] = p1;
+            double v42[3], v13[3];
+            for (int k = 0; k < 3; ++k) { v42[k] = m.C[3 * (size_t)c2i + k] - m.C[3 * (size_t)c4i + k]; v13[k] = m.pts[3 * (size_t)p3 + k] - m.pts[3 * (size_t)p1 + k]; }
+            coeffs(v42, v13, mv42[f], mv13[f], c1[f], c2[f], c3[f], c4[f]);
+        }
+        ip3e.assign(np, ivec()); ip1e.assign(np, ivec()); ic4e.assign(np, ivec());
+        c1e.assign(np, dvec()); c2e.assign(np, dvec()); c3e.assign(np, dvec()); c4e.assign(np, dvec());
+        mv42e.assign(np, dvec()); mv13e.assign(np, dvec());
+        for (int ip = 0; ip < np; ++ip) {  // [2D.C:172-291]
+            const int t = m.patches[ip].type;
+            if (t == PATCH_EMPTY || t == PATCH_WEDGE) continue;
+            if (t == PATCH_CYCLIC) continue;  // coupled and not processor
+            ordinaryPatches.push_back(ip);
+            const int n = m.patches[ip].size;
+            ic4e[ip].resize(n); ip3e[ip].resize(n); ip1e[ip].resize(n);
+            c1e[ip].resize(n); c2e[ip].resize(n); c3e[ip].resize(n); c4e[ip].resize(n); mv42e[ip].resize(n); mv13e[ip].resize(n);
+            for (int i = 0; i < n; ++i) {
+                const int gf = m.patches[ip].start + i, c4i = m.own[gf];
+                ic4e[ip][i] = c4i;
+                double v42[3], v13[3];
+                for (int k = 0; k < 3; ++k) v42[k] = 2.0 * (m.Cf[3 * (size_t)gf + k] - m.C[3 * (size_t)c4i + k]);
+                int q1 = -1, q3 = -1;
+                const int* q = m.fp(gf);
+                const int nn = m.fsize(gf);
+                for (int k = 0; k < nn; ++k) if (m.pts[3 * (size_t)q[k] + ie3] >= m.C[3 * (size_t)c4i + ie3]) { q1 = q[k]; break; }
+                for (int k = 0; k < nn; ++k) if (m.pts[3 * (size_t)q[k] + ie3] >= m.C[3 * (size_t)c4i + ie3]) { if (q1 != q[k]) { q3 = q[k]; break; } }
+                ip3e[ip][i] = q3; ip1e[ip][i] = q1;
+                for (int k = 0; k < 3; ++k) v13[k] = m.pts[3 * (size_t)q3 + k] - m.pts[3 * (size_t)q1 + k];
+                coeffs(v42, v13, mv42e[ip][i], mv13e[ip][i], c1e[ip][i], c2e[ip][i], c3e[ip][i], c4e[ip][i]);
+            }
+        }
+    }
+    // psi2 = boundaryField + snGrad*mv42e*0.5 [2D.C:343-346]
+    dvec psi2(const VolField& f) const {
+        dvec sn = allPatchSnGrad(m, f);
+        dvec r((size_t)m.nBF() * f.nc, 0.0);
+        for (int ip : ordinaryPatches)
+            for (int i = 0; i < m.patches[ip].size; ++i) {
+                const int b = m.patches[ip].start + i - m.nIF;
+                for (int k = 0; k < f.nc; ++k) r[(size_t)b * f.nc + k] = f.bf[(size_t)b * f.nc + k] + sn[(size_t)b * f.nc + k] * mv42e[ip][i] * 0.5;
+            }
+        return r;
+    }
+    void faceGrad2D(const VolField& f, SurfField& g) const {  // [2D.C:301-367]
+        dvec pF = volPointInterpolate(m, f);
+        for (int fc = 0; fc < m.nIF; ++fc) {
+            const double dfdn = (f.in[ic2[fc]] - f.in[ic4[fc]]) / mv42[fc];
+            const double dfdt = (pF[ip3[fc]] - pF[ip1[fc]]) / mv13[fc];
+            g.v[3 * (size_t)fc + ie1] = (dfdn * c1[fc] - dfdt * c2[fc]);
+            g.v[3 * (size_t)fc + ie2] = (dfdt * c3[fc] - dfdn * c4[fc]);
+            g.v[3 * (size_t)fc + ie3] = 0.0;
+        }
+        dvec p2 = psi2(f);
+        for (int ip : ordinaryPatches)
+            for (int i = 0; i < m.patches[ip].size; ++i) {
+                const int gf = m.patches[ip].start + i, b = gf - m.nIF;
+                const double dfdn = (p2[b] - f.in[ic4e[ip][i]]) / mv42e[ip][i];
+                const double dfdt = (pF[ip3e[ip][i]] - pF[ip1e[ip][i]]) / mv13e[ip][i];
+                g.v[3 * (size_t)gf + ie1] = (dfdn * c1e[ip][i] - dfdt * c2e[ip][i]);
+                g.v[3 * (size_t)gf + ie2] = (dfdt * c3e[ip][i] - dfdn * c4e[ip][i]);
+                g.v[3 * (size_t)gf + ie3] = 0.0;
+            }
+    }
+    void faceDiv2D_V(const VolField& f, SurfField& d) const {  // [2D.C:369-438]
+        dvec pF = volPointInterpolate(m, f);
+        for (int fc = 0; fc < m.nIF; ++fc) {
+            const double df1dn = (f.in[3 * (size_t)ic2[fc] + ie1] - f.in[3 * (size_t)ic4[fc] + ie1]) / mv42[fc];
+            const double df2dn = (f.in[3 * (size_t)ic2[fc] + ie2] - f.in[3 * (size_t)ic4[fc] + ie2]) / mv42[fc];
+            const double df1dt = (pF[3 * (size_t)ip3[fc] + ie1] - pF[3 * (size_t)ip1[fc] + ie1]) / mv13[fc];
+            const double df2dt = (pF[3 * (size_t)ip3[fc] + ie2] - pF[3 * (size_t)ip1[fc] + ie2]) / mv13[fc];
+            d.v[fc] = (df1dn * c1[fc] - df1dt * c2[fc]) + (df2dt * c3[fc] - df2dn * c4[fc]);
+        }
+        dvec p2 = psi2(f);
+        for (int ip : ordinaryPatches)
+            for (int i = 0; i < m.patches[ip].size; ++i) {
+                const int gf = m.patches[ip].start + i, b = gf - m.nIF, o = ic4e[ip][i];
+                const double df1dn = (p2[3 * (size_t)b + ie1] - f.in[3 * (size_t)o + ie1]) / mv42e[ip][i];
+                const double df2dn = (p2[3 * (size_t)b + ie2] - f.in[3 * (size_t)o + ie2]) / mv42e[ip][i];
+                const double df1dt = (pF[3 * (size_t)ip3e[ip][i] + ie1] - pF[3 * (size_t)ip1e[ip][i] + ie1]) / mv13e[ip][i];
+                const double df2dt = (pF[3 * (size_t)ip3e[ip][i] + ie2] - pF[3 * (size_t)ip1e[ip][i] + ie2]) / mv13e[ip][i];
+                d.v[gf] = (df1dn * c1e[ip][i] - df1dt * c2e[ip][i]) + (df2dt * c3e[ip][i] - df2dn * c4e[ip][i]);
+            }
+    }
+    void faceDiv2D_T(const VolField& f, SurfField& d) const {  // [2D.C:440-539]
+        const int i11 = ie1 * 3 + ie1, i21 = ie2 * 3 + ie1, i22 = ie2 * 3 + ie2, i12 = ie1 * 3 + ie2;
+        dvec pF = volPointInterpolate(m, f);
+        auto dn = [&](int fc, int c) { return (f.in[9 * (size_t)ic2[fc] + c] - f.in[9 * (size_t)ic4[fc] + c]) / mv42[fc]; };
+        auto dt = [&](int fc, int c) { return (pF[9 * (size_t)ip3[fc] + c] - pF[9 * (size_t)ip1[fc] + c]) / mv13[fc]; };
+        for (int fc = 0; fc < m.nIF; ++fc) {
+            d.v[3 * (size_t)fc + ie1] = (dn(fc, i11) * c1[fc] - dt(fc, i11) * c2[fc]) + (dt(fc, i21) * c3[fc] - dn(fc, i21) * c4[fc]);
+            d.v[3 * (size_t)fc + ie2] = (dn(fc, i12) * c1[fc] - dt(fc, i12) * c2[fc]) + (dt(fc, i22) * c3[fc] - dn(fc, i22) * c4[fc]);
+        }
+        dvec p2 = psi2(f);
+        for (int ip : ordinaryPatches)
+            for (int i = 0; i < m.patches[ip].size; ++i) {
+                const int gf = m.patches[ip].start + i, b = gf - m.nIF, o = ic4e[ip][i];
+                auto bn = [&](int c) { return (p2[9 * (size_t)b + c] - f.in[9 * (size_t)o + c]) / mv42e[ip][i]; };
+                auto bt = [&](int c) { return (pF[9 * (size_t)ip3e[ip][i] + c] - pF[9 * (size_t)ip1e[ip][i] + c]) / mv13e[ip][i]; };
+                d.v[3 * (size_t)gf + ie1] = (bn(i11) * c1e[ip][i] - bt(i11) * c2e[ip][i]) + (bt(i21) * c3e[ip][i] - bn(i21) * c4e[ip][i]);
+                d.v[3 * (size_t)gf + ie2] = (bn(i12) * c1e[ip][i] - bt(i12) * c2e[ip][i]) + (bt(i22) * c3e[ip][i] - bn(i22) * c4e[ip][i]);
+            }
+    }
+
+    // dispatcher [GaussVolPointBase.C:54-158] + [GaussVolPointStencil.C:71-129]
+    // (the correctBoundaryConditions() of the input is the caller's business here)
+    SurfField gradS(const VolField& f) override {
+        if (m.nGeomD == 1) return nfOuterSnGrad(f);  // [GaussVolPointBase1D.C:49-55]
+        SurfField g(m, 3);
+        if (m.nGeomD == 2) { faceGrad2D(f, g); return g; }
+        SurfField dfdn = nfOuterSnGrad(f);
+        std::vector<Term> t = {{0, 0, 0}, {1, 0, 1}, {2, 0, 2}};  // [3D.C:750-757]
+        apply3D(f, g, dfdn, t, t, t);
+        return g;
+    }
+    SurfField gradV(const VolField& f) override {
+        if (m.nGeomD == 1) return nfOuterSnGrad(f);
+        SurfField g(m, 9);
+        if (m.nGeomD == 2) {  // [GaussVolPointBase.C:79-116]
+            SurfField gc[3] = {SurfField(m, 3), SurfField(m, 3), SurfField(m, 3)};
+            for (int c = 0; c < 3; ++c) faceGrad2D(component(m, f, c), gc[c]);
+            for (int fc = 0; fc < m.nF; ++fc)
+                for (int i = 0; i < 3; ++i)
+                    for (int c = 0; c < 3; ++c) g.v[9 * (size_t)fc + 3 * i + c] = gc[c].v[3 * (size_t)fc + i];
+            return g;
+        }
+        SurfField dfdn = nfOuterSnGrad(f);
+        std::vector<Term> q = {{0, 0, 0}, {0, 1, 1}, {0, 2, 2}, {1, 0, 3}, {1, 1, 4}, {1, 2, 5}, {2, 0, 6}, {2, 1, 7}, {2, 2, 8}};  // [3D.C:831-841]
+        // interior triangles: the listing pairs (atx,0),(aty,1),(atz,2) three times [3D.C:844-854] (quirk B2)
+        std::vector<Term> ti = {{0, 0, 0}, {1, 1, 1}, {2, 2, 2}, {0, 0, 3}, {1, 1, 4}, {2, 2, 5}, {0, 0, 6}, {1, 1, 7}, {2, 2, 8}};
+        apply3D(f, g, dfdn, q, ti, q);  // boundary triangles use the quad pattern [3D.C:909-919]
+        return g;
+    }
+    SurfField divV(const VolField& f) override {
+        if (m.nGeomD == 1) return nfDotSnGrad(f);
+        SurfField d(m, 1);
+        if (m.nGeomD == 2) { faceDiv2D_V(f, d); return d; }
+        SurfField dfdn = nfDotSnGrad(f);
+        std::vector<Term> t = {{0, 0, 0}, {1, 1, 0}, {2, 2, 0}};  // [3D.C:553-560]
+        apply3D(f, d, dfdn, t, t, t);
+        return d;
+    }
+    SurfField divT(const VolField& f) override {
+        if (m.nGeomD == 1) return nfDotSnGrad(f);
+        SurfField d(m, 3);
+        if (m.nGeomD == 2) { faceDiv2D_T(f, d); return d; }
+        SurfField dfdn = nfDotSnGrad(f);
+        std::vector<Term> t = {{0, 0, 0}, {1, 3, 0}, {2, 6, 0}, {0, 1, 1}, {1, 4, 1}, {2, 7, 1}, {0, 2, 2}, {1, 5, 2}, {2, 8, 2}};  // [3D.C:635-659]
+        apply3D(f, d, dfdn, t, t, t);
+        return d;
+    }
+};
+
+// fvscOpName checks + fvscStencil::lookupOrNew cache [fvsc.C:47-85] [fvscStencil.C:98-118]
+struct StencilCache {
+    std::map<std::string, Stencil*> byName;
+    ~StencilCache() { for (auto& kv : byName) delete kv.second; }
+    int lookup(const Mesh& m, const std::string& word, Stencil** out) {
+        if ((word == "leastSquares" || word == "leastSquaresOpt") && m.nGeomD == 3) return -4;
+        auto it = byName.find(word);
+        if (it == byName.end()) {
+            Stencil* s = nullptr;
+            if (word == "reduced") s = new Reduced(m);
+            else if (word == "leastSquares" || word == "leastSquaresOpt") s = new LeastSquares(m);
+            else if (word == "GaussVolPoint") s = new GaussVolPoint(m);
+            else return -5;
+            it = byName.insert(std::make_pair(word, s)).first;
+        }
+        *out = it->second;
+        return 0;
+    }
+};
+
+struct MeshHandle {
+    Mesh m;
+    StencilCache cache;
+};
+
+// ---------------------------------------------------------------------------
+// small tensor algebra in OpenFOAM's component order (L0 operator definitions)
+// ---------------------------------------------------------------------------
+inline void outer(const double* a, const double* b, double* T) { for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) T[3 * i + j] = a[i] * b[j]; }
+inline void TdotV(const double* T, const double* v, double* r) { for (int i = 0; i < 3; ++i) r[i] = T[3 * i] * v[0] + T[3 * i + 1] * v[1] + T[3 * i + 2] * v[2]; }
+inline void VdotT(const double* v, const double* T, double* r) { for (int j = 0; j < 3; ++j) r[j] = v[0] * T[j] + v[1] * T[3 + j] + v[2] * T[6 + j]; }
+inline void TdotT(const double* A, const double* B, double* R) {
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+
+// ---------------------------------------------------------------------------
+// QGDFoam case
+// ---------------------------------------------------------------------------
+struct PatchBC { int bcU = BC_ZEROGRADIENT, bcT = BC_ZEROGRADIENT, bcP = BC_ZEROGRADIENT; double vU[3] = {0, 0, 0}, vT = 0, vP = 0; };
+
+struct Case {
+    MeshHandle* mh;
+    const Mesh& m;
+    orc_case_options opt;
+    std::vector<PatchBC> bc;
+    Stencil* stencil = nullptr;
+    std::string stencilWord;
+    // thermo + state (cells + boundary)
+    VolField p, T, e, U, rho, rhoU, rhoE, psi, mu, alpha, gamma, c, H;
+    // QGDCoeffs
+    VolField hQGD, aQGD, tauQGD, muQGD, alphauQGD, PrQGD, ScQGD;
+    SurfField hQGDf, tauQGDf;
+    // face fields
+    SurfField rhof, Uf, rhoUf, UrhoUf, pf, cf, gammaf, Hf, alphauf, muf;
+    SurfField gradUf, divUf, gradef, gradRhof, gradPf, rhoW, phiw, jm, phiJm, phi, phiJmU, phiP, Pif, phiPi, phiJmH, qf, phiQ, phiPiU;
+    bool phiwRegistered = false;  // "phiwStar" exists in the registry after createFaceFluxes.H
+    double time = 0, deltaT = 0, CoNum = 0;
+    long stepCount = 0;
+
+    Case(MeshHandle* h, const orc_case_options& o) : mh(h), m(h->m), opt(o), bc(h->m.patches.size()) {
+        deltaT = o.deltaT;
+        for (size_t ip = 0; ip < bc.size(); ++ip) {
+            const int t = m.patches[ip].type;
+            if (t == PATCH_EMPTY || t == PATCH_HALO) bc[ip].bcU = bc[ip].bcT = bc[ip].bcP = BC_NONE;
+        }
+    }
+
+    // ---- thermo closures (L0: perfectGas + eConst(Tref=0,Esref=0) + constTransport)
+    double Cp() const { return opt.Cv + opt.R; }
+    double HE(double /*p*/, double T) const { return opt.Cv * T; }
+    double THE(double he, double /*p*/, double T0) const {  // L0: thermo::T Newton, tol 1e-4
+        double Test = T0, Tnew = T0;
+        const double Ttol = T0 * 1e-4;
+        int iter = 0;
+        do {
+            Test = Tnew;
+            Tnew = Test - (opt.Cv * Test - he) / opt.Cv;
+            if (iter++ > 100) break;
+        } while (std::fabs(Tnew - Test) > Ttol);
+        return Tnew;
+    }
+    double psiOf(double /*p*/, double T) const { return 1.0 / (opt.R * T); }
+    double alphahOf() const { const double rPr = 1.0 / opt.Pr; return (Cp() * opt.mu * rPr) / Cp(); }
+
+    template <class Fn> void forPatchFaces(int ip, Fn fn) const {
+        if (!m.patchHasFields(ip)) return;
+        for (int gf = m.patches[ip].start; gf < m.patches[ip].start + m.patches[ip].size; ++gf) fn(gf, gf - m.nIF, m.own[gf]);
+    }
+
+    // ---- boundary-condition evaluation -----------------------------------
+    void correctBC_U() {
+        for (size_t ip = 0; ip < bc.size(); ++ip) forPatchFaces((int)ip, [&](int gf, int b, int o) {
+            const PatchBC& B = bc[ip];
+            if (B.bcU == BC_FIXEDVALUE) { for (int k = 0; k < 3; ++k) U.bf[3 * (size_t)b + k] = B.vU[k]; }
+            else if (B.bcU == BC_SLIP) {  // L0 basicSymmetry::evaluate: (pif + transform(I - 2 nn, pif))/2
+                double n[3], T[9];
+                for (int k = 0; k < 3; ++k) n[k] = m.Sf[3 * (size_t)gf + k] / m.magSf[gf];
+                for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) T[3 * i + j] = (i == j ? 1.0 : 0.0) - 2.0 * (n[i] * n[j]);
+                double tv[3];
+                TdotV(T, &U.in[3 * (size_t)o], tv);
+                for (int k = 0; k < 3; ++k) U.bf[3 * (size_t)b + k] = (U.in[3 * (size_t)o + k] + tv[k]) / 2.0;
+            } else { for (int k = 0; k < 3; ++k) U.bf[3 * (size_t)b + k] = U.in[3 * (size_t)o + k]; }
+        });
+    }
+    // L0 fixedEnergy / gradientEnergy for he [heThermo BCs]
+    void correctBC_e() {
+        for (size_t ip = 0; ip < bc.size(); ++ip) forPatchFaces((int)ip, [&](int gf, int b, int o) {
+            if (bc[ip].bcT == BC_FIXEDVALUE) e.bf[b] = HE(p.bf[b], T.bf[b]);
+            else {
+                // gradient = Cv*Tw.snGrad() + deltaCoeffs*(he(pw,Tw) - he(pw,Tw)[faceCells]) = 0 for a
+                // zeroGradient T; value = pif + gradient/deltaCoeffs
+                const double g = opt.Cv * 0.0 + m.delta[gf] * (HE(p.bf[b], T.bf[b]) - HE(p.bf[b], T.bf[b]));
+                e.bf[b] = e.in[o] + g / m.delta[gf];
+            }
+        });
+    }
+    // qgdFlux [qgdFluxFvPatchScalarField.C:159-197]
+    void correctBC_p() {
+        for (size_t ip = 0; ip < bc.size(); ++ip) forPatchFaces((int)ip, [&](int gf, int b, int o) {
+            const PatchBC& B = bc[ip];
+            if (B.bcP == BC_FIXEDVALUE) p.bf[b] = B.vP;
+            else if (B.bcP == BC_QGDFLUX) {
+                if (phiwRegistered) {
+                    const double fluxSnGrad = phiw.v[gf] / tauQGDf.v[gf] / m.magSf[gf];
+                    p.grad[b] = -fluxSnGrad;
+                }
+                p.bf[b] = p.in[o] + p.grad[b] / m.delta[gf];  // fixedGradient::evaluate
+            } else p.bf[b] = p.in[o];
+        });
+    }
+
+    // ---- hePsiQGDThermo::calculate [hePsiQGDThermo.C:38-126] ------------
+    void thermoCalculate() {
+        for (int ci = 0; ci < m.nC; ++ci) {
+            T.in[ci] = THE(e.in[ci], p.in[ci], T.in[ci]);
+            psi.in[ci] = psiOf(p.in[ci], T.in[ci]);
+            mu.in[ci] = opt.mu;
+            alpha.in[ci] = alphahOf();
+        }
+        for (size_t ip = 0; ip < bc.size(); ++ip) forPatchFaces((int)ip, [&](int, int b, int) {
+            if (bc[ip].bcT == BC_FIXEDVALUE) e.bf[b] = HE(p.bf[b], T.bf[b]);
+            else T.bf[b] = THE(e.bf[b], p.bf[b], T.bf[b]);
+            psi.bf[b] = psiOf(p.bf[b], T.bf[b]);
+            mu.bf[b] = opt.mu;
+            alpha.bf[b] = alphahOf();
+        });
+        const double g = Cp() / opt.Cv;  // gamma_ == Cp()/Cv()
+        for (double& x : gamma.in) x = g;
+        for (double& x : gamma.bf) x = g;
+        for (int ci = 0; ci < m.nC; ++ci) c.in[ci] = std::sqrt(gamma.in[ci] / psi.in[ci]);
+        for (size_t ip = 0; ip < bc.size(); ++ip) forPatchFaces((int)ip, [&](int, int b, int) { c.bf[b] = std::sqrt(gamma.bf[b] / psi.bf[b]); });
+        correctQGD();
+    }
+    // constScPrModel1::correct [constScPrModel1.C:97-131] + QGDThermo::correctQGD [QGDThermo.C:84-111]
+    void computeTauQGDf() {
+        VolField aOc(m, 1);
+        for (int ci = 0; ci < m.nC; ++ci) aOc.in[ci] = aQGD.in[ci] / c.in[ci];
+        for (size_t ip = 0; ip < bc.size(); ++ip) forPatchFaces((int)ip, [&](int, int b, int) { aOc.bf[b] = aQGD.bf[b] / c.bf[b]; });
+        SurfField lin = linearInterpolate(m, aOc);
+        for (int f = 0; f < m.nF; ++f) tauQGDf.v[f] = lin.v[f] * hQGDf.v[f];
+    }
+    void correctQGD() {
+        computeTauQGDf();
+        for (int ci = 0; ci < m.nC; ++ci) {
+            tauQGD.in[ci] = aQGD.in[ci] * hQGD.in[ci] / c.in[ci];
+            muQGD.in[ci] = p.in[ci] * ScQGD.in[ci] * tauQGD.in[ci];
+            alphauQGD.in[ci] = muQGD.in[ci] / PrQGD.in[ci];
+        }
+        for (size_t ip = 0; ip < bc.size(); ++ip) forPatchFaces((int)ip, [&](int, int b, int) {
+            tauQGD.bf[b] = aQGD.bf[b] * hQGD.bf[b] / c.bf[b];
+            muQGD.bf[b] = p.bf[b] * ScQGD.bf[b] * tauQGD.bf[b];
+            alphauQGD.bf[b] = muQGD.bf[b] / PrQGD.bf[b];
+        });
+        for (int ci = 0; ci < m.nC; ++ci) { mu.in[ci] += muQGD.in[ci]; alpha.in[ci] += alphauQGD.in[ci]; }
+        for (size_t ip = 0; ip < bc.size(); ++ip) forPatchFaces((int)ip, [&](int, int b, int) { mu.bf[b] += muQGD.bf[b]; alpha.bf[b] += alphauQGD.bf[b]; });
+    }
+    // QGDCoeffs ctor + updateQGDLength [QGDCoeffs.C:195-199, 298-376]
+    void initQGDCoeffs() {
+        hQGDf = SurfField(m, 1); tauQGDf = SurfField(m, 1);
+        hQGD = VolField(m, 1); aQGD = VolField(m, 1); tauQGD = VolField(m, 1); muQGD = VolField(m, 1);
+        alphauQGD = VolField(m, 1); PrQGD = VolField(m, 1); ScQGD = VolField(m, 1);
+        for (int f = 0; f < m.nF; ++f) hQGDf.v[f] = (m.delta[f] != 0.0) ? 1.0 / std::fabs(m.delta[f]) : 0.0;
+        for (int f = 0; f < m.nIF; ++f) {
+            double a[3], b[3];
+            for (int k = 0; k < 3; ++k) { a[k] = m.C[3 * (size_t)m.own[f] + k] - m.Cf[3 * (size_t)f + k]; b[k] = m.C[3 * (size_t)m.nei[f] + k] - m.Cf[3 * (size_t)f + k]; }
+            hQGDf.v[f] = 2.0 * std::min(mag3(a), mag3(b));
+        }
+        for (size_t ip = 0; ip < m.patches.size(); ++ip)
+            if (!m.coupled((int)ip)) forPatchFaces((int)ip, [&](int gf, int, int) { hQGDf.v[gf] *= 2.0; });
+        for (int ci = 0; ci < m.nC; ++ci) {
+            double hint = 0, surf = 0;
+            for (int fid : m.cells[ci]) {
+                if (fid < m.nIF) { hint += hQGDf.v[fid] * m.magSf[fid]; surf += m.magSf[fid]; }
+                else {
+                    int pid = -1;
+                    for (size_t ip = 0; ip < m.patches.size(); ++ip)
+                        if (fid >= m.patches[ip].start && fid < m.patches[ip].start + m.patches[ip].size) pid = (int)ip;
+                    if (pid >= 0 && m.patches[pid].type != PATCH_EMPTY && m.patches[pid].type != PATCH_WEDGE) {
+                        hint += hQGDf.v[fid] * m.magSf[fid];
+                        surf += m.magSf[fid];
+                    }
+                }
+            }
+            hQGD.in[ci] = hint / surf;
+        }
+        for (size_t ip = 0; ip < m.patches.size(); ++ip) forPatchFaces((int)ip, [&](int gf, int b, int) { hQGD.bf[b] = hQGDf.v[gf] * 1.0; });
+        for (double& x : aQGD.in) x = opt.alphaQGD;   // readOrCreateAlphaQGD: uniform, zeroGradient
+        for (double& x : aQGD.bf) x = opt.alphaQGD;
+        for (double& x : PrQGD.in) x = opt.PrQGD;
+        for (double& x : PrQGD.bf) x = opt.PrQGD;
+        for (double& x : ScQGD.in) x = opt.ScQGD;
+        for (double& x : ScQGD.bf) x = opt.ScQGD;
+    }
+
+    // createFields.H [QGDFoam/createFields.H:3-109] + createFaceFluxes.H
+    int setFields(const double* U0, const double* T0, const double* p0) {
+        int rc = mh->cache.lookup(m, stencilWord, &stencil);
+        if (rc) return rc;
+        p = VolField(m, 1); T = VolField(m, 1); e = VolField(m, 1); U = VolField(m, 3); rho = VolField(m, 1);
+        rhoU = VolField(m, 3); rhoE = VolField(m, 1); psi = VolField(m, 1); mu = VolField(m, 1); alpha = VolField(m, 1);
+        gamma = VolField(m, 1); c = VolField(m, 1); H = VolField(m, 1);
+        p.grad.assign(m.nBF(), 0.0);
+        p.snKind.assign(bc.size(), SN_GENERIC); T.snKind = p.snKind; e.snKind = p.snKind; U.snKind = p.snKind;
+        for (size_t ip = 0; ip < bc.size(); ++ip) {
+            p.snKind[ip] = bc[ip].bcP == BC_ZEROGRADIENT ? SN_ZERO : (bc[ip].bcP == BC_QGDFLUX ? SN_GRADIENT : SN_GENERIC);
+            T.snKind[ip] = bc[ip].bcT == BC_ZEROGRADIENT ? SN_ZERO : SN_GENERIC;
+            // he: fixedEnergy (fixedValue) or gradientEnergy (fixedGradient, gradient()==0 here)
+            e.snKind[ip] = bc[ip].bcT == BC_FIXEDVALUE ? SN_GENERIC : SN_ZERO;
+            U.snKind[ip] = bc[ip].bcU == BC_ZEROGRADIENT ? SN_ZERO : (bc[ip].bcU == BC_SLIP ? SN_SYMM : SN_GENERIC);
+            if (m.patches[ip].type == PATCH_HALO) p.snKind[ip] = T.snKind[ip] = e.snKind[ip] = U.snKind[ip] = SN_ZERO;
+        }
+        std::copy(U0, U0 + 3 * (size_t)m.nC, U.in.begin());
+        std::copy(T0, T0 + m.nC, T.in.begin());
+        std::copy(p0, p0 + m.nC, p.in.begin());
+        // field construction evaluates the patches
+        for (size_t ip = 0; ip < bc.size(); ++ip) forPatchFaces((int)ip, [&](int, int b, int o) {
+            T.bf[b] = bc[ip].bcT == BC_FIXEDVALUE ? bc[ip].vT : T.in[o];
+            p.bf[b] = bc[ip].bcP == BC_FIXEDVALUE ? bc[ip].vP : p.in[o];  // qgdFlux: patchInternalField, gradient 0
+        });
+        correctBC_U();
+        initQGDCoeffs();
+        // heThermo::init: he = he(p,T) on cells and patches
+        for (int ci = 0; ci < m.nC; ++ci) e.in[ci] = HE(p.in[ci], T.in[ci]);
+        for (int b = 0; b < m.nBF(); ++b) e.bf[b] = HE(p.bf[b], T.bf[b]);
+        thermoCalculate();  // hePsiQGDThermo ctor
+        thermoCalculate();  // thermo.correct() [createFields.H:8]
+        for (int ci = 0; ci < m.nC; ++ci) rho.in[ci] = p.in[ci] * psi.in[ci];  // psiThermo::rho()
+        for (int b = 0; b < m.nBF(); ++b) rho.bf[b] = p.bf[b] * psi.bf[b];
+        auto cons = [&](const double* r, const double* u, const double* ee, double* ru, double* rE) {
+            for (int k = 0; k < 3; ++k) ru[k] = r[0] * u[k];
+            rE[0] = r[0] * ee[0] + r[0] * 0.5 * (u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+        };
+        for (int ci = 0; ci < m.nC; ++ci) cons(&rho.in[ci], &U.in[3 * (size_t)ci], &e.in[ci], &rhoU.in[3 * (size_t)ci], &rhoE.in[ci]);
+        for (int b = 0; b < m.nBF(); ++b) cons(&rho.bf[b], &U.bf[3 * (size_t)b], &e.bf[b], &rhoU.bf[3 * (size_t)b], &rhoE.bf[b]);
+        for (int ci = 0; ci < m.nC; ++ci) H.in[ci] = (rhoE.in[ci] + p.in[ci]) / rho.in[ci];
+        for (int b = 0; b < m.nBF(); ++b) H.bf[b] = (rhoE.bf[b] + p.bf[b]) / rho.bf[b];
+        // createFaceFluxes.H registers "phiwStar" = Sf & (tauQGDf*gradPf); with
+        // GaussVolPoint that first grad(p) runs the qgdFlux BC before the name exists
+        phiwRegistered = false;
+        gradPf = fvscGrad(p, true);
+        phiw = SurfField(m, 1);
+        for (int f = 0; f < m.nF; ++f) {
+            double rw[3];
+            for (int k = 0; k < 3; ++k) rw[k] = tauQGDf.v[f] * gradPf.v[3 * (size_t)f + k];
+            phiw.v[f] = dot3(&m.Sf[3 * (size_t)f], rw);
+        }
+        phiwRegistered = true;
+        time = 0; stepCount = 0;
+        return 0;
+    }
+
+    // fvsc::grad: GaussVolPoint re-evaluates the BCs of its input first
+    // [GaussVolPointStencil.C:73,91]; of the case's fields only p's qgdFlux BC changes by that (B6)
+    SurfField fvscGrad(VolField& f, bool isP) {
+        if (isP && stencilWord == "GaussVolPoint") correctBC_p();
+        return f.nc == 1 ? stencil->gradS(f) : stencil->gradV(f);
+    }
+
+    // updateFields.H [QGDFoam/updateFields.H:45-80]
+    void updateFields() {
+        rhof = linearInterpolate(m, rho);
+        Uf = linearInterpolate(m, U);
+        rhoUf = linearInterpolate(m, rhoU);
+        VolField UrhoU(m, 9);
+        for (int ci = 0; ci < m.nC; ++ci) outer(&U.in[3 * (size_t)ci], &rhoU.in[3 * (size_t)ci], &UrhoU.in[9 * (size_t)ci]);
+        for (int b = 0; b < m.nBF(); ++b) outer(&U.bf[3 * (size_t)b], &rhoU.bf[3 * (size_t)b], &UrhoU.bf[9 * (size_t)b]);
+        UrhoUf = linearInterpolate(m, UrhoU);
+        pf = linearInterpolate(m, p);
+        cf = linearInterpolate(m, c);
+        gammaf = linearInterpolate(m, gamma);
+        for (int ci = 0; ci < m.nC; ++ci) H.in[ci] = (rhoE.in[ci] + p.in[ci]) / rho.in[ci];
+        for (int b = 0; b < m.nBF(); ++b) H.bf[b] = (rhoE.bf[b] + p.bf[b]) / rho.bf[b];
+        Hf = linearInterpolate(m, H);
+        // L0: laminar alphaEff() = thermo.alphaEff(alphat=0) = gamma*(alpha + 0) for an
+        // internal-energy thermo; muEff() = mut(=0) + mu
+        VolField aEff(m, 1), mEff(m, 1);
+        for (int ci = 0; ci < m.nC; ++ci) { aEff.in[ci] = gamma.in[ci] * (alpha.in[ci] + 0.0); mEff.in[ci] = 0.0 + mu.in[ci]; }
+        for (int b = 0; b < m.nBF(); ++b) { aEff.bf[b] = gamma.bf[b] * (alpha.bf[b] + 0.0); mEff.bf[b] = 0.0 + mu.bf[b]; }
+        alphauf = linearInterpolate(m, aEff);
+        muf = linearInterpolate(m, mEff);
+    }
+
+    // updateFluxes.H [QGDFoam/updateFluxes.H:41-139], explicit branch
+    void updateFluxes() {
+        const int nF = m.nF;
+        gradUf = fvscGrad(U, false);
+        divUf = SurfField(m, 1);
+        for (int f = 0; f < nF; ++f) divUf.v[f] = gradUf.v[9 * (size_t)f] + gradUf.v[9 * (size_t)f + 4] + gradUf.v[9 * (size_t)f + 8];
+        gradef = fvscGrad(e, false);
+        gradRhof = fvscGrad(rho, false);
+        rhoW = SurfField(m, 3); phiw = SurfField(m, 1);
+        for (int f = 0; f < nF; ++f) {
+            const double* uf = &Uf.v[3 * (size_t)f];
+            const double* ruf = &rhoUf.v[3 * (size_t)f];
+            double A[9], t1[3], t3[3];
+            outer(uf, &gradRhof.v[3 * (size_t)f], A);   // Uf * gradRhof
+            TdotV(A, uf, t1);                           // & Uf
+            VdotT(ruf, &gradUf.v[9 * (size_t)f], t3);   // rhoUf & gradUf
+            for (int k = 0; k < 3; ++k) rhoW.v[3 * (size_t)f + k] = tauQGDf.v[f] * ((t1[k] + (ruf[k] * divUf.v[f])) + t3[k]);
+            phiw.v[f] = dot3(&m.Sf[3 * (size_t)f], &rhoW.v[3 * (size_t)f]);
+        }
+        gradPf = fvscGrad(p, true);
+        jm = SurfField(m, 3); phiJm = SurfField(m, 1); phi = SurfField(m, 1);
+        for (int f = 0; f < nF; ++f) {
+            for (int k = 0; k < 3; ++k) {
+                rhoW.v[3 * (size_t)f + k] += tauQGDf.v[f] * gradPf.v[3 * (size_t)f + k];
+                jm.v[3 * (size_t)f + k] = rhoUf.v[3 * (size_t)f + k] - rhoW.v[3 * (size_t)f + k];
+            }
+            phiJm.v[f] = dot3(&m.Sf[3 * (size_t)f], &jm.v[3 * (size_t)f]);
+            phi.v[f] = dot3(&m.Sf[3 * (size_t)f], &rhoUf.v[3 * (size_t)f]);
+        }
+        phiJmU = SurfField(m, 3); phiP = SurfField(m, 3); Pif = SurfField(m, 9); phiPi = SurfField(m, 3);
+        phiJmH = SurfField(m, 1); qf = SurfField(m, 3); phiQ = SurfField(m, 1); phiPiU = SurfField(m, 1);
+        for (int f = 0; f < nF; ++f) {
+            const double* uf = &Uf.v[3 * (size_t)f];
+            const double* gU = &gradUf.v[9 * (size_t)f];
+            const double* gP = &gradPf.v[3 * (size_t)f];
+            const double tau = tauQGDf.v[f];
+            for (int k = 0; k < 3; ++k) {
+                phiJmU.v[3 * (size_t)f + k] = phiJm.v[f] * uf[k];                 // qgdFlux -> flux*psif [QGDInterpolate.H:104]
+                phiP.v[3 * (size_t)f + k] = m.Sf[3 * (size_t)f + k] * pf.v[f];
+            }
+            double A[9], B[9];
+            TdotT(&UrhoUf.v[9 * (size_t)f], gU, A);   // UrhoUf & gradUf
+            outer(uf, gP, B);                         // Uf*gradPf
+            const double sph = tau * (1.0 * (dot3(uf, gP) + (gammaf.v[f] * pf.v[f] * divUf.v[f])));
+            double* Pi = &Pif.v[9 * (size_t)f];
+            for (int k = 0; k < 9; ++k) Pi[k] = tau * (A[k] + B[k]);
+            Pi[0] += sph; Pi[4] += sph; Pi[8] += sph;
+            // explicit branch [updateFluxes.H:95-106]
+            const double s23 = (2.0 / 3.0) * 1.0 * divUf.v[f];
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+                double t = gU[3 * i + j] + gU[3 * j + i];
+                if (i == j) t = t - s23;
+                Pi[3 * i + j] += muf.v[f] * t;
+            }
+            VdotT(&m.Sf[3 * (size_t)f], Pi, &phiPi.v[3 * (size_t)f]);
+            phiJmH.v[f] = phiJm.v[f] * Hf.v[f];
+            double g2[3], q[3];
+            const double pr2 = pf.v[f] / rhof.v[f] / rhof.v[f];
+            for (int k = 0; k < 3; ++k) g2[k] = gradef.v[3 * (size_t)f + k] - pr2 * gradRhof.v[3 * (size_t)f + k];
+            TdotV(&UrhoUf.v[9 * (size_t)f], g2, q);
+            for (int k = 0; k < 3; ++k) {
+                qf.v[3 * (size_t)f + k] = (-tau) * q[k];
+                qf.v[3 * (size_t)f + k] -= alphauf.v[f] * gradef.v[3 * (size_t)f + k];
+            }
+            phiQ.v[f] = dot3(&m.Sf[3 * (size_t)f], &qf.v[3 * (size_t)f]);
+            double piU[3];
+            TdotV(Pi, uf, piU);
+            phiPiU.v[f] = dot3(&m.Sf[3 * (size_t)f], piU);
+        }
+    }
+
+    // L0 fvc::div(ssf) = surfaceIntegrate: owner += , neighbour -= , patches += , /V
+    dvec fvcDiv(const SurfField& s) const {
+        const int nc = s.nc;
+        dvec d((size_t)m.nC * nc, 0.0);
+        for (int f = 0; f < m.nIF; ++f)
+            for (int k = 0; k < nc; ++k) { d[(size_t)m.own[f] * nc + k] += s.v[(size_t)f * nc + k]; d[(size_t)m.nei[f] * nc + k] -= s.v[(size_t)f * nc + k]; }
+        for (size_t ip = 0; ip < m.patches.size(); ++ip) {
+            if (!m.patchHasFields((int)ip)) continue;
+            for (int f = m.patches[ip].start; f < m.patches[ip].start + m.patches[ip].size; ++f)
+                for (int k = 0; k < nc; ++k) d[(size_t)m.own[f] * nc + k] += s.v[(size_t)f * nc + k];
+        }
+        for (int ci = 0; ci < m.nC; ++ci) for (int k = 0; k < nc; ++k) d[(size_t)ci * nc + k] /= m.V[ci];
+        return d;
+    }
+
+    // [QGDCourantNo.H:36-53] [setDeltaT-QGDQHD.H:41-61]
+    void courantAndDeltaT() {
+        if (!opt.adjustTimeStep) return;
+        double co = -GREAT, mintau = GREAT;
+        for (size_t pass = 0; pass < 1; ++pass) {
+            for (int f = 0; f < m.nF; ++f) {
+                if (f >= m.nIF) { int ip = patchOf(f); if (ip < 0 || !m.patchHasFields(ip) || m.patches[ip].type == PATCH_HALO) continue; }
+                else if (!faceTouchesOwned(f)) continue;
+                double nrm[3];
+                for (int k = 0; k < 3; ++k) nrm[k] = m.Sf[3 * (size_t)f + k] / m.magSf[f];
+                const double Unf = dot3(&Uf.v[3 * (size_t)f], nrm);
+                const double cof = std::max(std::fabs(Unf + cf.v[f]), std::fabs(Unf - cf.v[f])) * deltaT / hQGDf.v[f];
+                co = std::max(co, cof);
+                mintau = std::min(mintau, tauQGDf.v[f]);
+            }
+        }
+        CoNum = co;
+        const double maxDeltaTFact = opt.maxCo / (CoNum + SMALL);
+        const double deltaTFact = std::min(std::min(maxDeltaTFact, 1.0 + 0.1 * maxDeltaTFact), 1.2);
+        double maxDeltaT1 = opt.cTau * mintau;
+        maxDeltaT1 = std::min(opt.maxDeltaT, maxDeltaT1);
+        deltaT = std::min(deltaTFact * deltaT, maxDeltaT1);
+    }
+    int patchOf(int f) const {
+        for (size_t ip = 0; ip < m.patches.size(); ++ip) if (f >= m.patches[ip].start && f < m.patches[ip].start + m.patches[ip].size) return (int)ip;
+        return -1;
+    }
+    std::vector<char> ghostFlag;
+    bool faceTouchesOwned(int f) const {
+        if (ghostFlag.empty()) return true;
+        return !ghostFlag[m.own[f]] || !ghostFlag[m.nei[f]];
+    }
+
+    // loop body [QGDFoam.C:90-163]; phase 0 = through the pressure correction
+    void stepPhase0() {
+        updateFields();
+        updateFluxes();
+        courantAndDeltaT();
+        time += deltaT; stepCount++;
+        const double rDeltaT = 1.0 / deltaT;
+        const dvec rhoOld = rho.in, rhoUOld = rhoU.in, UOld = U.in, rhoEOld = rhoE.in, eOld = e.in;
+        // QGDRhoEqn.H [:40-47]: diag = rDeltaT*V, source = rDeltaT*rho.old*V - V*div(phiJm)
+        {
+            dvec d = fvcDiv(phiJm);
+            for (int ci = 0; ci < m.nC; ++ci) {
+                const double diag = rDeltaT * m.V[ci];
+                double src = rDeltaT * rhoOld[ci] * m.V[ci];
+                src -= m.V[ci] * d[ci];
+                rho.in[ci] = src / diag;
+            }
+        }
+        // QGDUEqn.H [:36-89]
+        {
+            dvec d1 = fvcDiv(phiJmU), d2 = fvcDiv(phiP), d3 = fvcDiv(phiPi);
+            for (int ci = 0; ci < m.nC; ++ci)
+                for (int k = 0; k < 3; ++k) {
+                    const double diag = rDeltaT * m.V[ci];
+                    double src = rDeltaT * rhoUOld[3 * (size_t)ci + k] * m.V[ci];
+                    src -= m.V[ci] * d1[3 * (size_t)ci + k];
+                    src -= m.V[ci] * d2[3 * (size_t)ci + k];
+                    src += m.V[ci] * d3[3 * (size_t)ci + k];
+                    rhoU.in[3 * (size_t)ci + k] = src / diag;
+                }
+            for (int ci = 0; ci < m.nC; ++ci) for (int k = 0; k < 3; ++k) U.in[3 * (size_t)ci + k] = rhoU.in[3 * (size_t)ci + k] / rho.in[ci];
+            correctBC_U();
+            // solve(fvm::ddt(rho,U) - fvc::ddt(rhoU) == rhoUSu) [:79-86]
+            for (int ci = 0; ci < m.nC; ++ci)
+                for (int k = 0; k < 3; ++k) {
+                    const double diag = rDeltaT * rho.in[ci] * m.V[ci];
+                    double src = rDeltaT * rhoOld[ci] * UOld[3 * (size_t)ci + k] * m.V[ci];
+                    src += m.V[ci] * (rDeltaT * (rhoU.in[3 * (size_t)ci + k] - rhoUOld[3 * (size_t)ci + k]));
+                    U.in[3 * (size_t)ci + k] = src / diag;
+                }
+            correctBC_U();  // fvMatrix::solve ends with psi.correctBoundaryConditions() (L0)
+            for (int b = 0; b < m.nBF(); ++b) for (int k = 0; k < 3; ++k) rhoU.bf[3 * (size_t)b + k] = rho.bf[b] * U.bf[3 * (size_t)b + k];
+        }
+        // QGDEEqn.H [:37-76] (phiSigmaDotU == 0 in the explicit branch)
+        {
+            dvec d1 = fvcDiv(phiJmH), d2 = fvcDiv(phiQ), d3 = fvcDiv(phiPiU);
+            for (int ci = 0; ci < m.nC; ++ci) {
+                const double diag = rDeltaT * m.V[ci];
+                double src = rDeltaT * rhoEOld[ci] * m.V[ci];
+                src -= m.V[ci] * d1[ci];
+                src -= m.V[ci] * d2[ci];
+                src += m.V[ci] * d3[ci];
+                src += m.V[ci] * 0.0;  // - fvc::div(phiSigmaDotU), a zero field
+                rhoE.in[ci] = src / diag;
+            }
+            for (int ci = 0; ci < m.nC; ++ci) {
+                const double* u = &U.in[3 * (size_t)ci];
+                e.in[ci] = rhoE.in[ci] / rho.in[ci] - 0.5 * (u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+            }
+            correctBC_e();
+            // solve(fvm::ddt(rho,e) - fvc::ddt(rhoE) == rhoESu) [:67-72] -- as written in the listing
+            for (int ci = 0; ci < m.nC; ++ci) {
+                const double diag = rDeltaT * rho.in[ci] * m.V[ci];
+                double src = rDeltaT * rhoOld[ci] * eOld[ci] * m.V[ci];
+                src += m.V[ci] * (rDeltaT * (rhoE.in[ci] - rhoEOld[ci]));
+                e.in[ci] = src / diag;
+            }
+            correctBC_e();
+            for (int b = 0; b < m.nBF(); ++b) {
+                const double* u = &U.bf[3 * (size_t)b];
+                rhoE.bf[b] = rho.bf[b] * (e.bf[b] + 0.5 * (u[0] * u[0] + u[1] * u[1] + u[2] * u[2]));
+            }
+        }
+        thermoCalculate();  // thermo.correct() [QGDFoam.C:149]
+        for (int ci = 0; ci < m.nC; ++ci) p.in[ci] = rho.in[ci] / psi.in[ci];  // [:152-154]
+        correctBC_p();                                                          // [:155]
+        for (int b = 0; b < m.nBF(); ++b) rho.bf[b] = psi.bf[b] * p.bf[b];      // [:156]
+    }
+    void stepPhase1() {
+        // after a halo unpack: tauQGDf is a pure function of the cell fields
+        if (!m.haloGhost[0].empty() || !m.haloGhost[1].empty()) computeTauQGDf();
+    }
+
+    static const int kCellMsg = 15, kFaceMsg = 16;
+    void haloCount(int side, int64_t* n) const { *n = (int64_t)m.haloSend[side].size() * kCellMsg + (int64_t)m.haloSendBF[side].size() * kFaceMsg; }
+    void packOrUnpack(int side, double* buf, bool pack) {
+        const ivec& cellsL = pack ? m.haloSend[side] : m.haloGhost[side];
+        const ivec& facesL = pack ? m.haloSendBF[side] : m.haloGhostBF[side];
+        size_t q = 0;
+        auto io = [&](double& x) { if (pack) buf[q++] = x; else x = buf[q++]; };
+        for (int ci : cellsL) {
+            io(rho.in[ci]); for (int k = 0; k < 3; ++k) io(U.in[3 * (size_t)ci + k]); for (int k = 0; k < 3; ++k) io(rhoU.in[3 * (size_t)ci + k]);
+            io(rhoE.in[ci]); io(e.in[ci]); io(T.in[ci]); io(p.in[ci]); io(psi.in[ci]); io(mu.in[ci]); io(alpha.in[ci]); io(c.in[ci]);
+        }
+        for (int b : facesL) {
+            io(rho.bf[b]); for (int k = 0; k < 3; ++k) io(U.bf[3 * (size_t)b + k]); for (int k = 0; k < 3; ++k) io(rhoU.bf[3 * (size_t)b + k]);
+            io(rhoE.bf[b]); io(e.bf[b]); io(T.bf[b]); io(p.bf[b]); io(psi.bf[b]); io(mu.bf[b]); io(alpha.bf[b]); io(c.bf[b]); io(p.grad[b]);
+        }
+    }
+};
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// C interface
+// ---------------------------------------------------------------------------
+extern "C" {
+
+void* orc_mesh_create(int32_t nPoints, const double* points, int32_t nFaces, const int32_t* faceOffsets,
+                      const int32_t* facePoints, int32_t nInternalFaces, const int32_t* owner, const int32_t* neighbour,
+                      int32_t nCells, int32_t nPatches, const int32_t* patchStart, const int32_t* patchSize,
+                      const int32_t* patchType) {
+    MeshHandle* h = new MeshHandle();
+    Mesh& m = h->m;
+    m.nP = nPoints; m.nF = nFaces; m.nIF = nInternalFaces; m.nC = nCells;
+    m.pts.assign(points, points + 3 * (size_t)nPoints);
+    m.fOff.assign(faceOffsets, faceOffsets + nFaces + 1);
+    m.fPts.assign(facePoints, facePoints + faceOffsets[nFaces]);
+    m.own.assign(owner, owner + nFaces);
+    m.nei.assign(neighbour, neighbour + nInternalFaces);
+    for (int i = 0; i < nPatches; ++i) m.patches.push_back(PatchInfo{patchType[i], patchStart[i], patchSize[i]});
+    m.geometry();
+    m.addressing();
+    m.pointInterpolationWeights();
+    return h;
+}
+void orc_mesh_free(void* m) { delete (MeshHandle*)m; }
+
+int orc_mesh_get(void* mp, const char* name, double* out, int64_t n) {
+    const Mesh& m = ((MeshHandle*)mp)->m;
+    const dvec* src = nullptr;
+    std::string s(name);
+    if (s == "Sf") src = &m.Sf; else if (s == "magSf") src = &m.magSf; else if (s == "Cf") src = &m.Cf;
+    else if (s == "C") src = &m.C; else if (s == "V") src = &m.V; else if (s == "weights") src = &m.w;
+    else if (s == "deltaCoeffs") src = &m.delta; else if (s == "nonOrthDeltaCoeffs") src = &m.nonOrthDelta;
+    if (!src) return -5;
+    if ((int64_t)src->size() > n) return -1;
+    std::copy(src->begin(), src->end(), out);
+    return 0;
+}
+int orc_mesh_info(void* mp, int64_t info[4]) {
+    const Mesh& m = ((MeshHandle*)mp)->m;
+    info[0] = m.nGeomD; info[1] = m.geomD[0]; info[2] = m.geomD[1]; info[3] = m.geomD[2];
+    return 0;
+}
+int orc_mesh_set_halo(void* mp, int side, int32_t nGhost, const int32_t* ghost, int32_t nSend, const int32_t* send) {
+    Mesh& m = ((MeshHandle*)mp)->m;
+    if (side < 0 || side > 1) return -1;
+    m.haloGhost[side].assign(ghost, ghost + nGhost);
+    m.haloSend[side].assign(send, send + nSend);
+    m.haloFaces();
+    return 0;
+}
+
+int orc_fvsc(void* mp, const char* scheme, const char* op, const double* cell, const double* bnd, double* out) {
+    MeshHandle* h = (MeshHandle*)mp;
+    const Mesh& m = h->m;
+    Stencil* s = nullptr;
+    int rc = h->cache.lookup(m, scheme, &s);
+    if (rc) return rc;
+    std::string o(op);
+    const int nc = (o == "grad_s") ? 1 : (o == "div_t" ? 9 : 3);
+    VolField f(m, nc);
+    std::copy(cell, cell + (size_t)m.nC * nc, f.in.begin());
+    std::copy(bnd, bnd + (size_t)m.nBF() * nc, f.bf.begin());
+    SurfField r;
+    if (o == "grad_s") r = s->gradS(f); else if (o == "grad_v") r = s->gradV(f);
+    else if (o == "div_v") r = s->divV(f); else if (o == "div_t") r = s->divT(f);
+    else return -5;
+    std::copy(r.v.begin(), r.v.end(), out);
+    return 0;
+}
+
+void* orc_case_create(void* mesh, const orc_case_options* opt) {
+    Case* c = new Case((MeshHandle*)mesh, *opt);
+    c->stencilWord = opt->stencil == FVSC_REDUCED ? "reduced" : (opt->stencil == FVSC_LEASTSQUARES ? "leastSquares" : "GaussVolPoint");
+    const Mesh& m = c->m;
+    if (!m.haloGhost[0].empty() || !m.haloGhost[1].empty()) {
+        c->ghostFlag.assign(m.nC, 0);
+        for (int s = 0; s < 2; ++s) for (int g : m.haloGhost[s]) c->ghostFlag[g] = 1;
+    }
+    return c;
+}
+void orc_case_free(void* c) { delete (Case*)c; }
+int orc_case_set_bc(void* cp, int32_t patch, int32_t bcU, const double* valueU, int32_t bcT, double valueT, int32_t bcP, double valueP) {
+    Case* c = (Case*)cp;
+    if (patch < 0 || patch >= (int)c->bc.size()) return -1;
+    PatchBC& b = c->bc[patch];
+    b.bcU = bcU; b.bcT = bcT; b.bcP = bcP; b.vT = valueT; b.vP = valueP;
+    if (valueU) for (int k = 0; k < 3; ++k) b.vU[k] = valueU[k];
+    return 0;
+}
+int orc_case_set_fields(void* cp, const double* U, const double* T, const double* p) { return ((Case*)cp)->setFields(U, T, p); }
+int orc_case_update_fluxes(void* cp) { Case* c = (Case*)cp; c->updateFields(); c->updateFluxes(); return 0; }
+int orc_case_step(void* cp, int32_t n) {
+    Case* c = (Case*)cp;
+    for (int i = 0; i < n; ++i) { c->stepPhase0(); c->stepPhase1(); }
+    return 0;
+}
+int orc_case_step_phase(void* cp, int phase) { Case* c = (Case*)cp; if (phase == 0) c->stepPhase0(); else c->stepPhase1(); return 0; }
+
+int orc_case_get_field(void* cp, const char* name, double* out, int64_t n) {
+    Case* c = (Case*)cp;
+    std::string s(name);
+    bool bnd = false;
+    const std::string suffix = ".boundary";
+    if (s.size() > suffix.size() && s.compare(s.size() - suffix.size(), suffix.size(), suffix) == 0) { bnd = true; s = s.substr(0, s.size() - suffix.size()); }
+    std::map<std::string, const VolField*> vf = {
+        {"rho", &c->rho}, {"U", &c->U}, {"p", &c->p}, {"e", &c->e}, {"T", &c->T}, {"rhoU", &c->rhoU}, {"rhoE", &c->rhoE},
+        {"c", &c->c}, {"psi", &c->psi}, {"mu", &c->mu}, {"alphau", &c->alpha}, {"tauQGD", &c->tauQGD}, {"muQGD", &c->muQGD},
+        {"alphauQGD", &c->alphauQGD}, {"hQGD", &c->hQGD}, {"H", &c->H}, {"gamma", &c->gamma}};
+    std::map<std::string, const SurfField*> sf = {
+        {"phiJm", &c->phiJm}, {"phiJmU", &c->phiJmU}, {"phiP", &c->phiP}, {"phiPi", &c->phiPi}, {"phiJmH", &c->phiJmH},
+        {"phiQ", &c->phiQ}, {"phiPiU", &c->phiPiU}, {"phiwStar", &c->phiw}, {"phi", &c->phi}, {"tauQGDf", &c->tauQGDf},
+        {"hQGDf", &c->hQGDf}, {"gradUf", &c->gradUf}, {"gradef", &c->gradef}, {"gradRhof", &c->gradRhof}, {"gradPf", &c->gradPf},
+        {"rhof", &c->rhof}, {"Uf", &c->Uf}, {"pf", &c->pf}, {"Hf", &c->Hf}, {"muf", &c->muf}, {"alphauf", &c->alphauf}, {"cf", &c->cf},
+        {"Pif", &c->Pif}, {"qf", &c->qf}, {"jm", &c->jm}};
+    const dvec* src = nullptr;
+    auto iv = vf.find(s);
+    if (iv != vf.end()) src = bnd ? &iv->second->bf : &iv->second->in;
+    else { auto is = sf.find(s); if (is != sf.end() && !bnd) src = &is->second->v; }
+    if (!src) return -5;
+    if ((int64_t)src->size() > n) return -1;
+    std::copy(src->begin(), src->end(), out);
+    return 0;
+}
+int orc_case_info(void* cp, double info[6]) {
+    Case* c = (Case*)cp;
+    double mr = GREAT, me = GREAT;
+    for (int ci = 0; ci < c->m.nC; ++ci) {
+        if (!c->ghostFlag.empty() && c->ghostFlag[ci]) continue;
+        mr = std::min(mr, c->rho.in[ci]); me = std::min(me, c->e.in[ci]);
+    }
+    info[0] = c->time; info[1] = c->deltaT; info[2] = c->CoNum; info[3] = mr; info[4] = me; info[5] = (double)c->stepCount;
+    return 0;
+}
+int orc_case_halo_count(void* cp, int side, int64_t* count) { ((Case*)cp)->haloCount(side, count); return 0; }
+int orc_case_halo_pack(void* cp, int side, double* sendBuf) { ((Case*)cp)->packOrUnpack(side, sendBuf, true); return 0; }
+int orc_case_halo_unpack(void* cp, int side, const double* recvBuf) { ((Case*)cp)->packOrUnpack(side, const_cast<double*>(recvBuf), false); return 0; }
+
+}  // extern "C"

@@ -1,0 +1,70 @@
+/*
+ * qgd_oracle.h -- C interface of the CPU ORACLE.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load it, and only as the checker.  The product library (libqgd_amd.so) does
+ * not link, include or call anything in this directory.
+ *
+ * PARITY UNPINNED: the reference snapshot (/root/reference) holds no source
+ * files, tests, tutorials or golden vectors -- only Doxygen listings -- and its
+ * dependency OpenFOAM v2312 is absent, so the reference cannot be built or run
+ * here.  This oracle is a restatement of those listings,
+ * operation by operation in the reference's evaluation order, pinned only by
+ * the analytic known-answer properties in tests/test_oracle_properties.py.
+ */
+#ifndef QGD_ORACLE_H
+#define QGD_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* numeric codes are the same as include/qgd_amd.h (QGD_PATCH_*, QGD_BC_*,
+ * QGD_FVSC_*) so the Python tests can share them */
+
+typedef struct orc_case_options {
+    int32_t stencil, implicitDiffusion, adjustTimeStep, reserved;
+    double R, Cv, mu, Pr, ScQGD, PrQGD, alphaQGD, deltaT, maxCo, maxDeltaT, cTau;
+} orc_case_options;
+
+void* orc_mesh_create(int32_t nPoints, const double* points, int32_t nFaces,
+                      const int32_t* faceOffsets, const int32_t* facePoints,
+                      int32_t nInternalFaces, const int32_t* owner,
+                      const int32_t* neighbour, int32_t nCells, int32_t nPatches,
+                      const int32_t* patchStart, const int32_t* patchSize,
+                      const int32_t* patchType);
+void orc_mesh_free(void* m);
+/* "Sf","magSf","Cf","C","V","weights","deltaCoeffs","nonOrthDeltaCoeffs" */
+int orc_mesh_get(void* m, const char* name, double* out, int64_t n);
+/* info[0]=nGeometricD, info[1..3]=geometricD */
+int orc_mesh_info(void* m, int64_t info[4]);
+/* halo lists for a cell-range shard (side 0 lower, 1 upper) */
+int orc_mesh_set_halo(void* m, int side, int32_t nGhost, const int32_t* ghost,
+                      int32_t nSend, const int32_t* send);
+
+/* fvsc operators: scheme word as in fvSchemes ("reduced","leastSquares",
+ * "leastSquaresOpt","GaussVolPoint"); op = "grad_s","grad_v","div_v","div_t".
+ * Returns 0, or -4 when the scheme is refused (leastSquares in 3-D),
+ * -5 unknown word. */
+int orc_fvsc(void* m, const char* scheme, const char* op, const double* cell,
+             const double* bnd, double* out);
+
+void* orc_case_create(void* mesh, const orc_case_options* opt);
+void orc_case_free(void* c);
+int orc_case_set_bc(void* c, int32_t patch, int32_t bcU, const double* valueU,
+                    int32_t bcT, double valueT, int32_t bcP, double valueP);
+int orc_case_set_fields(void* c, const double* U, const double* T, const double* p);
+int orc_case_update_fluxes(void* c);
+int orc_case_step(void* c, int32_t nSteps);
+int orc_case_get_field(void* c, const char* name, double* out, int64_t n);
+int orc_case_info(void* c, double info[6]);
+int orc_case_halo_count(void* c, int side, int64_t* count);
+int orc_case_halo_pack(void* c, int side, double* sendBuf);
+int orc_case_halo_unpack(void* c, int side, const double* recvBuf);
+int orc_case_step_phase(void* c, int phase);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,108 @@
+"""ctypes binding of libqgd_amd.so (the C-ABI declared in include/qgd_amd.h).
+
+The shared library is built in-tree by ``qgdsolver_amd/csrc/Makefile`` (or
+``__graft_entry__.build()``).  There is no Python or CPU fallback: if the
+library is missing, importing this module raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libqgd_amd.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build the HIP extension first "
+        "(python -c 'import __graft_entry__ as g; g.build()' or make -C qgdsolver_amd/csrc). "
+        "qgdsolver_amd has no CPU fallback."
+    )
+
+lib = C.CDLL(LIB_PATH)
+
+c_int32_p = C.POINTER(C.c_int32)
+c_int64_p = C.POINTER(C.c_int64)
+c_double_p = C.POINTER(C.c_double)
+handle = C.c_void_p
+handle_p = C.POINTER(C.c_void_p)
+
+
+class CaseOptions(C.Structure):
+    """qgd_case_options (same layout as the oracle's orc_case_options)."""
+
+    _fields_ = [
+        ("stencil", C.c_int32), ("implicitDiffusion", C.c_int32), ("adjustTimeStep", C.c_int32), ("reserved", C.c_int32),
+        ("R", C.c_double), ("Cv", C.c_double), ("mu", C.c_double), ("Pr", C.c_double), ("ScQGD", C.c_double),
+        ("PrQGD", C.c_double), ("alphaQGD", C.c_double), ("deltaT", C.c_double), ("maxCo", C.c_double),
+        ("maxDeltaT", C.c_double), ("cTau", C.c_double),
+    ]
+
+
+# every symbol include/qgd_amd.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "qgd_version": (C.c_char_p, []),
+    "qgd_last_error": (C.c_char_p, []),
+    "qgd_device_count": (C.c_int, []),
+    "qgd_mesh_create": (C.c_int, [C.c_int32, c_double_p, C.c_int32, c_int32_p, c_int32_p, C.c_int32, c_int32_p, c_int32_p,
+                                  C.c_int32, C.c_int32, c_int32_p, c_int32_p, c_int32_p, handle_p]),
+    "qgd_mesh_box": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_double_p, c_double_p, c_int32_p, handle_p]),
+    "qgd_mesh_forward_step": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, handle_p]),
+    "qgd_mesh_jitter": (C.c_int, [handle, C.c_double, C.c_uint64]),
+    "qgd_mesh_split_quads": (C.c_int, [handle, C.c_int32]),
+    "qgd_mesh_set_geometry": (C.c_int, [handle, c_double_p, c_double_p, c_double_p, c_double_p]),
+    "qgd_mesh_free": (C.c_int, [handle]),
+    "qgd_mesh_sizes": (C.c_int, [handle, c_int64_p]),
+    "qgd_mesh_get": (C.c_int, [handle, C.c_char_p, C.c_void_p, C.c_int64]),
+    "qgd_device_create": (C.c_int, [handle, C.c_int, handle_p]),
+    "qgd_device_free": (C.c_int, [handle]),
+    "qgd_stencil_lookup": (C.c_int, [handle, C.c_char_p, C.POINTER(C.c_int)]),
+    "qgd_fvsc_grad_s": (C.c_int, [handle, C.c_int, c_double_p, c_double_p, c_double_p]),
+    "qgd_fvsc_grad_v": (C.c_int, [handle, C.c_int, c_double_p, c_double_p, c_double_p]),
+    "qgd_fvsc_div_v": (C.c_int, [handle, C.c_int, c_double_p, c_double_p, c_double_p]),
+    "qgd_fvsc_div_t": (C.c_int, [handle, C.c_int, c_double_p, c_double_p, c_double_p]),
+    "qgd_case_options_default": (C.c_int, [C.POINTER(CaseOptions)]),
+    "qgd_case_create": (C.c_int, [handle, C.POINTER(CaseOptions), handle_p]),
+    "qgd_case_free": (C.c_int, [handle]),
+    "qgd_case_set_bc": (C.c_int, [handle, C.c_int32, C.c_int32, c_double_p, C.c_int32, C.c_double, C.c_int32, C.c_double]),
+    "qgd_case_set_fields": (C.c_int, [handle, c_double_p, c_double_p, c_double_p]),
+    "qgd_case_update_fluxes": (C.c_int, [handle]),
+    "qgd_case_step": (C.c_int, [handle, C.c_int32]),
+    "qgd_case_get_field": (C.c_int, [handle, C.c_char_p, c_double_p, C.c_int64]),
+    "qgd_case_info": (C.c_int, [handle, c_double_p]),
+    "qgd_case_halo_count": (C.c_int, [handle, C.c_int, c_int64_p]),
+    "qgd_case_halo_pack": (C.c_int, [handle, C.c_int, C.c_void_p]),
+    "qgd_case_halo_unpack": (C.c_int, [handle, C.c_int, C.c_void_p]),
+    "qgd_case_stream_sync": (C.c_int, [handle]),
+    "qgd_case_set_stream": (C.c_int, [handle, C.c_void_p]),
+    "qgd_case_step_phase": (C.c_int, [handle, C.c_int]),
+    "qgd_case_timing": (C.c_int, [handle, C.c_int]),
+    "qgd_case_kernel_time": (C.c_int, [handle, C.c_int, c_double_p, c_int64_p]),
+    "qgd_case_timing_reset": (C.c_int, [handle]),
+    "qgd_case_device_bytes": (C.c_int, [handle, c_int64_p]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)  # AttributeError here == the library does not export a declared symbol
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+# enums of include/qgd_amd.h
+QGD_OK = 0
+ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_SCHEME, ERR_UNKNOWN_NAME, ERR_NOT_IMPLEMENTED = -1, -2, -3, -4, -5, -6
+PATCH_GENERIC, PATCH_EMPTY, PATCH_SYMMETRYPLANE, PATCH_SYMMETRY, PATCH_WEDGE, PATCH_CYCLIC, PATCH_HALO = range(7)
+BC_ZEROGRADIENT, BC_FIXEDVALUE, BC_SLIP, BC_QGDFLUX, BC_NONE = range(5)
+FVSC_REDUCED, FVSC_LEASTSQUARES, FVSC_GAUSSVOLPOINT = range(3)
+K_POINT, K_FACE, K_BFACE, K_CELL, K_BC = range(5)
+
+
+class QgdError(RuntimeError):
+    """A non-zero status from the C-ABI (the adapter turns these into FatalError)."""
+
+    def __init__(self, code, where):
+        self.code = code
+        msg = lib.qgd_last_error().decode()
+        super().__init__(f"{where}: status {code}: {msg}")
+
+
+def check(code, where):
+    if code != QGD_OK:
+        raise QgdError(code, where)

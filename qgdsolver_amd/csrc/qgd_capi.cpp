@@ -1,0 +1,853 @@
+// qgd_capi.cpp -- the C-ABI of include/qgd_amd.h (compiled with hipcc).
+//
+// One handle == one HIP device == one calling host thread.  Entries are
+// synchronous at return unless documented otherwise.  No exceptions cross the
+// boundary: every entry catches and converts to a status code, mirroring how the
+// reference turns failures into FatalError exits [fvsc_8C_source.html L62,75-78].
+// There is NO CPU fallback: without a HIP device the device/case entries fail
+// with QGD_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/qgd_amd.h"
+#include "qgd_device.hpp"
+#include "qgd_mesh.hpp"
+#include "qgd_setup.hpp"
+
+using namespace qgd;
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+static thread_local std::string g_lastError;
+static int fail(int code, const std::string& msg) {
+    g_lastError = msg;
+    return code;
+}
+struct HipError : std::runtime_error {
+    explicit HipError(const std::string& s) : std::runtime_error(s) {}
+};
+#define HIP_CHECK(expr)                                                                                     \
+    do {                                                                                                    \
+        hipError_t _e = (expr);                                                                             \
+        if (_e != hipSuccess)                                                                               \
+            throw HipError(std::string(#expr) + ": " + hipGetErrorString(_e) + " at " + __FILE__ + ":" +   \
+                           std::to_string(__LINE__));                                                       \
+    } while (0)
+#define QGD_TRY try {
+#define QGD_CATCH                                                                 \
+    }                                                                             \
+    catch (const HipError& e) { return fail(QGD_ERR_HIP, e.what()); }             \
+    catch (const std::invalid_argument& e) { return fail(QGD_ERR_INVALID, e.what()); } \
+    catch (const std::exception& e) { return fail(QGD_ERR_INVALID, e.what()); }   \
+    catch (...) { return fail(QGD_ERR_INVALID, "unknown exception"); }
+
+// ---------------------------------------------------------------------------
+// handle types
+// ---------------------------------------------------------------------------
+struct qgd_mesh_s {
+    HostMesh m;
+};
+
+struct DeviceArena {
+    std::vector<void*> ptrs;
+    int64_t bytes = 0;
+    template <class T>
+    T* upload(const std::vector<T>& v) {
+        if (v.empty()) return nullptr;
+        void* d = nullptr;
+        HIP_CHECK(hipMalloc(&d, v.size() * sizeof(T)));
+        ptrs.push_back(d);
+        bytes += (int64_t)(v.size() * sizeof(T));
+        HIP_CHECK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+        return (T*)d;
+    }
+    template <class T>
+    T* alloc(size_t n, bool zero = true) {
+        if (n == 0) return nullptr;
+        void* d = nullptr;
+        HIP_CHECK(hipMalloc(&d, n * sizeof(T)));
+        ptrs.push_back(d);
+        bytes += (int64_t)(n * sizeof(T));
+        if (zero) HIP_CHECK(hipMemset(d, 0, n * sizeof(T)));
+        return (T*)d;
+    }
+    void release() {
+        for (void* p : ptrs) (void)hipFree(p);
+        ptrs.clear();
+        bytes = 0;
+    }
+};
+
+struct qgd_device_s {
+    int deviceId = 0;
+    DeviceArena arena;
+    MeshView view{};
+    int32_t nGeomD = 3;
+    bool hasTri = false;
+    std::vector<Patch> patches;
+    std::vector<double> hf;  // host copy of hQGDf for the accessor
+    // halo lists (device) and sizes
+    int32_t* haloGhost[2] = {nullptr, nullptr};
+    int32_t* haloSend[2] = {nullptr, nullptr};
+    int32_t* haloGhostBF[2] = {nullptr, nullptr};
+    int32_t* haloSendBF[2] = {nullptr, nullptr};
+    int32_t nHaloCells[2] = {0, 0}, nHaloSendCells[2] = {0, 0}, nHaloGhostBF[2] = {0, 0}, nHaloSendBF[2] = {0, 0};
+    hipStream_t stream = nullptr;
+};
+
+struct TimedLaunch {
+    int k;
+    hipEvent_t a, b;
+};
+
+struct qgd_case_s {
+    qgd_device_s* dev = nullptr;
+    qgd_case_options opt{};
+    GasModel gas{};
+    int stencil = ST_GVP3;      // device stencil kind
+    bool usesPoints = true;
+    bool hasQgdFlux = false;
+    bool phiwRegistered = false;
+    bool fieldsSet = false;
+    std::vector<PatchBCDev> bc;
+    PatchBCDev* bcDev = nullptr;
+    DeviceArena arena;
+    CaseView view{};
+    double* dbgBuf = nullptr;
+    double time = 0;
+    int64_t steps = 0;
+    // timing
+    bool timing = false;
+    std::vector<TimedLaunch> pending;
+    std::vector<hipEvent_t> freeEvents;
+    double totalMs[QGD_K_COUNT] = {0, 0, 0, 0, 0};
+    int64_t launches[QGD_K_COUNT] = {0, 0, 0, 0, 0};
+    hipEvent_t curStart = nullptr;
+    // optional caller-owned stream (e.g. the one RCCL transfers are ordered on)
+    hipStream_t userStream = nullptr;
+    bool useUserStream = false;
+    hipStream_t stream() const { return useUserStream ? userStream : dev->stream; }
+};
+
+static hipEvent_t getEvent(qgd_case_s* c) {
+    if (!c->freeEvents.empty()) {
+        hipEvent_t e = c->freeEvents.back();
+        c->freeEvents.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+static void timingPre(void* ctx, int) {
+    qgd_case_s* c = (qgd_case_s*)ctx;
+    if (!c->timing) return;
+    c->curStart = getEvent(c);
+    if (c->curStart) (void)hipEventRecord(c->curStart, c->stream());
+}
+static void timingPost(void* ctx, int k) {
+    qgd_case_s* c = (qgd_case_s*)ctx;
+    if (!c->timing || !c->curStart) return;
+    hipEvent_t e = getEvent(c);
+    if (!e) return;
+    (void)hipEventRecord(e, c->stream());
+    c->pending.push_back(TimedLaunch{k, c->curStart, e});
+    c->curStart = nullptr;
+}
+static void harvestTiming(qgd_case_s* c) {
+    if (c->pending.empty()) return;
+    (void)hipStreamSynchronize(c->stream());
+    for (TimedLaunch& t : c->pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
+            c->totalMs[t.k] += ms;
+            c->launches[t.k]++;
+        }
+        c->freeEvents.push_back(t.a);
+        c->freeEvents.push_back(t.b);
+    }
+    c->pending.clear();
+}
+static Launcher launcherOf(qgd_case_s* c) {
+    Launcher L;
+    L.stream = c->stream();
+    L.pre = timingPre;
+    L.post = timingPost;
+    L.ctx = c;
+    return L;
+}
+
+// The OpenMP runtime hipcc links spin-waits between parallel regions by default;
+// on oversubscribed hosts that makes the (short) setup loops slower than serial.
+__attribute__((constructor)) static void qgdInitOpenMP() { setenv("KMP_BLOCKTIME", "0", 0); }
+
+// ---------------------------------------------------------------------------
+extern "C" {
+
+const char* qgd_version(void) { return "qgdsolver_amd 0.1 (gfx950)"; }
+const char* qgd_last_error(void) { return g_lastError.c_str(); }
+int qgd_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ---- mesh -----------------------------------------------------------------------
+int qgd_mesh_create(int32_t nPoints, const double* points, int32_t nFaces, const int32_t* faceOffsets, const int32_t* facePoints,
+                    int32_t nInternalFaces, const int32_t* owner, const int32_t* neighbour, int32_t nCells, int32_t nPatches,
+                    const int32_t* patchStart, const int32_t* patchSize, const int32_t* patchType, qgd_mesh_t* out) {
+    QGD_TRY
+    if (!points || !faceOffsets || !facePoints || !owner || (!neighbour && nInternalFaces > 0) || !out)
+        return fail(QGD_ERR_INVALID, "qgd_mesh_create: null argument");
+    if (nPoints <= 0 || nFaces <= 0 || nCells <= 0 || nInternalFaces < 0 || nInternalFaces > nFaces || nPatches < 0)
+        return fail(QGD_ERR_INVALID, "qgd_mesh_create: bad sizes");
+    qgd_mesh_s* h = new qgd_mesh_s();
+    HostMesh& m = h->m;
+    m.nPoints = nPoints; m.nFaces = nFaces; m.nInternalFaces = nInternalFaces; m.nCells = nCells;
+    m.points.assign(points, points + 3 * (size_t)nPoints);
+    m.faceOffsets.assign(faceOffsets, faceOffsets + nFaces + 1);
+    m.facePoints.assign(facePoints, facePoints + faceOffsets[nFaces]);
+    m.owner.assign(owner, owner + nFaces);
+    if (nInternalFaces) m.neighbour.assign(neighbour, neighbour + nInternalFaces);
+    for (int i = 0; i < nPatches; ++i) {
+        Patch p;
+        p.name = "patch" + std::to_string(i);
+        p.type = patchType[i]; p.start = patchStart[i]; p.size = patchSize[i];
+        m.patches.push_back(p);
+    }
+    std::string err = m.check();
+    if (!err.empty()) { delete h; return fail(QGD_ERR_INVALID, "qgd_mesh_create: " + err); }
+    m.computeGeometry();
+    *out = h;
+    return QGD_OK;
+    QGD_CATCH
+}
+
+int qgd_mesh_box(int32_t nx, int32_t ny, int32_t nzGlobal, int32_t kLo, int32_t kHi, const double lo[3], const double hi[3],
+                 const int32_t patchTypes[6], qgd_mesh_t* out) {
+    QGD_TRY
+    if (!lo || !hi || !out) return fail(QGD_ERR_INVALID, "qgd_mesh_box: null argument");
+    qgd_mesh_s* h = new qgd_mesh_s();
+    try { h->m = makeBox(nx, ny, nzGlobal, kLo, kHi, lo, hi, patchTypes); }
+    catch (...) { delete h; throw; }
+    *out = h;
+    return QGD_OK;
+    QGD_CATCH
+}
+
+int qgd_mesh_forward_step(int32_t nx, int32_t ny, int32_t ixStep, int32_t iyStep, double lx, double ly, double lz, qgd_mesh_t* out) {
+    QGD_TRY
+    if (!out) return fail(QGD_ERR_INVALID, "qgd_mesh_forward_step: null argument");
+    qgd_mesh_s* h = new qgd_mesh_s();
+    try { h->m = makeForwardStep(nx, ny, ixStep, iyStep, lx, ly, lz); }
+    catch (...) { delete h; throw; }
+    *out = h;
+    return QGD_OK;
+    QGD_CATCH
+}
+int qgd_mesh_jitter(qgd_mesh_t m, double amplitude, uint64_t seed) {
+    QGD_TRY
+    if (!m) return fail(QGD_ERR_INVALID, "null mesh");
+    jitterPoints(m->m, amplitude, seed);
+    return QGD_OK;
+    QGD_CATCH
+}
+int qgd_mesh_split_quads(qgd_mesh_t m, int32_t stride) {
+    QGD_TRY
+    if (!m) return fail(QGD_ERR_INVALID, "null mesh");
+    splitQuads(m->m, stride);
+    return QGD_OK;
+    QGD_CATCH
+}
+int qgd_mesh_set_geometry(qgd_mesh_t mh, const double* Sf, const double* Cf, const double* C, const double* V) {
+    QGD_TRY
+    if (!mh || !Sf || !Cf || !C || !V) return fail(QGD_ERR_INVALID, "qgd_mesh_set_geometry: null argument");
+    HostMesh& m = mh->m;
+    m.Sf.assign(Sf, Sf + 3 * (size_t)m.nFaces);
+    m.Cf.assign(Cf, Cf + 3 * (size_t)m.nFaces);
+    m.C.assign(C, C + 3 * (size_t)m.nCells);
+    m.V.assign(V, V + (size_t)m.nCells);
+    for (int32_t f = 0; f < m.nFaces; ++f) {
+        const double* S = &m.Sf[3 * (size_t)f];
+        m.magSf[f] = std::sqrt(S[0] * S[0] + S[1] * S[1] + S[2] * S[2]);
+    }
+    m.computeDerived();
+    return QGD_OK;
+    QGD_CATCH
+}
+int qgd_mesh_free(qgd_mesh_t m) {
+    delete m;
+    return QGD_OK;
+}
+int qgd_mesh_sizes(qgd_mesh_t mh, int64_t sizes[7]) {
+    if (!mh || !sizes) return fail(QGD_ERR_INVALID, "null argument");
+    const HostMesh& m = mh->m;
+    sizes[0] = m.nPoints; sizes[1] = m.nFaces; sizes[2] = m.nInternalFaces; sizes[3] = m.nCells;
+    sizes[4] = (int64_t)m.patches.size(); sizes[5] = (int64_t)m.facePoints.size(); sizes[6] = m.nGeometricD;
+    return QGD_OK;
+}
+int qgd_mesh_get(qgd_mesh_t mh, const char* name, void* out, int64_t outBytes) {
+    QGD_TRY
+    if (!mh || !name || !out) return fail(QGD_ERR_INVALID, "null argument");
+    const HostMesh& m = mh->m;
+    const std::string s(name);
+    const void* src = nullptr;
+    size_t bytes = 0;
+    std::vector<int32_t> tmp;
+    auto D = [&](const std::vector<double>& v) { src = v.data(); bytes = v.size() * sizeof(double); };
+    auto I = [&](const std::vector<int32_t>& v) { src = v.data(); bytes = v.size() * sizeof(int32_t); };
+    if (s == "points") D(m.points);
+    else if (s == "faceOffsets") I(m.faceOffsets);
+    else if (s == "facePoints") I(m.facePoints);
+    else if (s == "owner") I(m.owner);
+    else if (s == "neighbour") I(m.neighbour);
+    else if (s == "patchStart" || s == "patchSize" || s == "patchType") {
+        for (const Patch& p : m.patches) tmp.push_back(s == "patchStart" ? p.start : (s == "patchSize" ? p.size : p.type));
+        I(tmp);
+    } else if (s == "haloGhost0") I(m.haloGhost[0]);
+    else if (s == "haloGhost1") I(m.haloGhost[1]);
+    else if (s == "haloSend0") I(m.haloSend[0]);
+    else if (s == "haloSend1") I(m.haloSend[1]);
+    else if (s == "Sf") D(m.Sf);
+    else if (s == "magSf") D(m.magSf);
+    else if (s == "Cf") D(m.Cf);
+    else if (s == "C") D(m.C);
+    else if (s == "V") D(m.V);
+    else if (s == "weights") D(m.weights);
+    else if (s == "deltaCoeffs") D(m.deltaCoeffs);
+    else if (s == "nonOrthDeltaCoeffs") D(m.nonOrthDeltaCoeffs);
+    else return fail(QGD_ERR_UNKNOWN_NAME, "qgd_mesh_get: unknown array " + s);
+    if ((int64_t)bytes > outBytes) return fail(QGD_ERR_INVALID, "qgd_mesh_get: output too small for " + s);
+    if (bytes) std::memcpy(out, src, bytes);
+    return QGD_OK;
+    QGD_CATCH
+}
+
+// ---- device ----------------------------------------------------------------------
+int qgd_device_create(qgd_mesh_t mh, int deviceId, qgd_device_t* out) {
+    QGD_TRY
+    if (!mh || !out) return fail(QGD_ERR_INVALID, "qgd_device_create: null argument");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(QGD_ERR_NO_DEVICE, "qgd_device_create: no HIP device (this library has no CPU fallback)");
+    if (deviceId < 0 || deviceId >= n) return fail(QGD_ERR_INVALID, "qgd_device_create: bad device id");
+    HIP_CHECK(hipSetDevice(deviceId));
+    const HostMesh& m = mh->m;
+    if (m.patches.size() > QGD_MAX_PATCHES) return fail(QGD_ERR_INVALID, "too many patches");
+    StaticData s = buildStaticData(m);
+    qgd_device_s* d = new qgd_device_s();
+    try {
+        d->deviceId = deviceId;
+        d->nGeomD = m.nGeometricD;
+        d->hasTri = s.hasTri;
+        d->patches = m.patches;
+        d->hf = s.hf;
+        HIP_CHECK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+        DeviceArena& a = d->arena;
+        MeshView& v = d->view;
+        v.nP = s.nP; v.nF = s.nF; v.nIF = s.nIF; v.nC = s.nC; v.nBF = s.nBF;
+        v.ie1 = s.ie1; v.ie2 = s.ie2; v.ie3 = s.ie3; v.ncoef = s.ncoef;
+        // upload + free each table in turn so the host peak stays at one table
+        auto up = [&](auto& vec) { auto* p = a.upload(vec); std::decay_t<decltype(vec)>().swap(vec); return p; };
+        v.own = up(s.own); v.nei = up(s.nei);
+        v.verts = reinterpret_cast<const int4*>(up(s.verts));
+        v.fkind = up(s.fkind);
+        v.Sx = up(s.Sf[0]); v.Sy = up(s.Sf[1]); v.Sz = up(s.Sf[2]);
+        v.magSf = up(s.magSf); v.w = up(s.w); v.hf = up(s.hf); v.dn = up(s.dn);
+        v.coef = up(s.coef); v.rV = up(s.rV); v.bmvON = up(s.bmvON);
+        v.ip13 = reinterpret_cast<const int2*>(up(s.ip13)); v.c2d = up(s.c2d);
+        v.lsqOff = up(s.lsqOff); v.lsqCell = up(s.lsqCell); v.lsqGw = up(s.lsqGw); v.lsqDeg = up(s.lsqDeg);
+        v.lsqBndZero = up(s.lsqBndZero);
+        v.pcOff = up(s.pcOff); v.pcCell = up(s.pcCell); v.pcW = up(s.pcW);
+        v.nBP = (int32_t)s.bpPoint.size();
+        v.bpPoint = up(s.bpPoint); v.bpOff = up(s.bpOff); v.bpFace = up(s.bpFace); v.bpW = up(s.bpW);
+        v.cfOff = up(s.cfOff); v.cfItem = up(s.cfItem);
+        v.V = up(s.V); v.hQGD = up(s.hQGD); v.ghost = up(s.ghost);
+        v.bPatch = up(s.bPatch); v.hQGDb = up(s.hQGDb);
+        for (int side = 0; side < 2; ++side) {
+            d->nHaloCells[side] = (int32_t)s.haloGhost[side].size();
+            d->nHaloSendCells[side] = (int32_t)s.haloSend[side].size();
+            d->nHaloGhostBF[side] = (int32_t)s.haloGhostBF[side].size();
+            d->nHaloSendBF[side] = (int32_t)s.haloSendBF[side].size();
+            d->haloGhost[side] = a.upload(s.haloGhost[side]);
+            d->haloSend[side] = a.upload(s.haloSend[side]);
+            d->haloGhostBF[side] = a.upload(s.haloGhostBF[side]);
+            d->haloSendBF[side] = a.upload(s.haloSendBF[side]);
+        }
+    } catch (...) {
+        d->arena.release();
+        if (d->stream) (void)hipStreamDestroy(d->stream);
+        delete d;
+        throw;
+    }
+    *out = d;
+    return QGD_OK;
+    QGD_CATCH
+}
+int qgd_device_free(qgd_device_t d) {
+    if (!d) return QGD_OK;
+    (void)hipSetDevice(d->deviceId);
+    d->arena.release();
+    if (d->stream) (void)hipStreamDestroy(d->stream);
+    delete d;
+    return QGD_OK;
+}
+
+// fvscOpName + fvscStencil::New [fvsc_8C L47-85, fvscStencil_8C L59-95]
+static int stencilWordToId(int nGeomD, const std::string& w, int* id) {
+    if ((w == "leastSquares" || w == "leastSquaresOpt") && nGeomD == 3)
+        return fail(QGD_ERR_SCHEME, "Can't use leastSquares or leastSquaresOpt in 3D case.");
+    if (w == "reduced") *id = QGD_FVSC_REDUCED;
+    else if (w == "leastSquares" || w == "leastSquaresOpt") *id = QGD_FVSC_LEASTSQUARES;
+    else if (w == "GaussVolPoint") *id = QGD_FVSC_GAUSSVOLPOINT;
+    else return fail(QGD_ERR_UNKNOWN_NAME, "Unknown Model type " + w + "; valid: GaussVolPoint leastSquares leastSquaresOpt reduced");
+    return QGD_OK;
+}
+static int deviceStencil(int nGeomD, int id, int* st) {
+    if (id == QGD_FVSC_REDUCED) *st = ST_REDUCED;
+    else if (id == QGD_FVSC_LEASTSQUARES) {
+        if (nGeomD == 3) return fail(QGD_ERR_SCHEME, "Can't use leastSquares or leastSquaresOpt in 3D case.");
+        *st = ST_LSQ;
+    } else if (id == QGD_FVSC_GAUSSVOLPOINT) *st = (nGeomD == 3) ? ST_GVP3 : (nGeomD == 2 ? ST_GVP2 : ST_REDUCED);
+    else return fail(QGD_ERR_UNKNOWN_NAME, "bad stencil id");
+    return QGD_OK;
+}
+int qgd_stencil_lookup(qgd_device_t d, const char* word, int* stencilId) {
+    if (!d || !word || !stencilId) return fail(QGD_ERR_INVALID, "null argument");
+    return stencilWordToId(d->nGeomD, word, stencilId);
+}
+
+static int fvscOp(qgd_device_t d, int stencilId, int op, int NC, const double* cell, const double* bnd, double* out) {
+    QGD_TRY
+    if (!d || !cell || !out || (!bnd && d->view.nBF > 0)) return fail(QGD_ERR_INVALID, "fvsc operator: null argument");
+    int st = 0;
+    int rc = deviceStencil(d->nGeomD, stencilId, &st);
+    if (rc) return rc;
+    HIP_CHECK(hipSetDevice(d->deviceId));
+    const MeshView& v = d->view;
+    const int NO = (op == 0) ? 3 * NC : NC / 3;
+    double *dc = nullptr, *db = nullptr, *dp = nullptr, *dout = nullptr;
+    auto cleanup = [&]() { (void)hipFree(dc); (void)hipFree(db); (void)hipFree(dp); (void)hipFree(dout); };
+    try {
+        HIP_CHECK(hipMalloc((void**)&dc, sizeof(double) * (size_t)v.nC * NC));
+        HIP_CHECK(hipMalloc((void**)&db, sizeof(double) * std::max<size_t>(1, (size_t)v.nBF * NC)));
+        HIP_CHECK(hipMalloc((void**)&dp, sizeof(double) * (size_t)v.nP * NC));
+        HIP_CHECK(hipMalloc((void**)&dout, sizeof(double) * (size_t)v.nF * NO));
+        HIP_CHECK(hipMemcpyAsync(dc, cell, sizeof(double) * (size_t)v.nC * NC, hipMemcpyHostToDevice, d->stream));
+        if (v.nBF) HIP_CHECK(hipMemcpyAsync(db, bnd, sizeof(double) * (size_t)v.nBF * NC, hipMemcpyHostToDevice, d->stream));
+        HIP_CHECK(hipMemsetAsync(dp, 0, sizeof(double) * (size_t)v.nP * NC, d->stream));
+        launchFvscOp(d->stream, st, op, NC, v, dc, db, dp, dout);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(out, dout, sizeof(double) * (size_t)v.nF * NO, hipMemcpyDeviceToHost, d->stream));
+        HIP_CHECK(hipStreamSynchronize(d->stream));
+    } catch (...) { cleanup(); throw; }
+    cleanup();
+    return QGD_OK;
+    QGD_CATCH
+}
+int qgd_fvsc_grad_s(qgd_device_t d, int id, const double* cell, const double* bnd, double* out) { return fvscOp(d, id, 0, 1, cell, bnd, out); }
+int qgd_fvsc_grad_v(qgd_device_t d, int id, const double* cell, const double* bnd, double* out) { return fvscOp(d, id, 0, 3, cell, bnd, out); }
+int qgd_fvsc_div_v(qgd_device_t d, int id, const double* cell, const double* bnd, double* out) { return fvscOp(d, id, 1, 3, cell, bnd, out); }
+int qgd_fvsc_div_t(qgd_device_t d, int id, const double* cell, const double* bnd, double* out) { return fvscOp(d, id, 1, 9, cell, bnd, out); }
+
+// ---- case ------------------------------------------------------------------------
+int qgd_case_options_default(qgd_case_options* o) {
+    if (!o) return fail(QGD_ERR_INVALID, "null argument");
+    std::memset(o, 0, sizeof(*o));
+    o->stencil = QGD_FVSC_GAUSSVOLPOINT;
+    o->implicitDiffusion = 0;
+    o->adjustTimeStep = 0;
+    o->R = 1.0 / 1.4; o->Cv = (1.0 / 1.4) / 0.4;  // gamma = 1.4, c = 1 at T = 1
+    o->mu = 0.0; o->Pr = 1.0;
+    o->ScQGD = 1.0; o->PrQGD = 1.0; o->alphaQGD = 0.5;
+    o->deltaT = 1e-4; o->maxCo = 0.5; o->maxDeltaT = 1.0; o->cTau = 0.75;
+    return QGD_OK;
+}
+
+int qgd_case_create(qgd_device_t d, const qgd_case_options* opt, qgd_case_t* out) {
+    QGD_TRY
+    if (!d || !opt || !out) return fail(QGD_ERR_INVALID, "qgd_case_create: null argument");
+    if (opt->implicitDiffusion) return fail(QGD_ERR_NOT_IMPLEMENTED, "implicitDiffusion true: only the explicit branch is on this path");
+    if (!(opt->R > 0) || !(opt->Cv > 0) || !(opt->Pr > 0) || !(opt->PrQGD > 0) || !(opt->deltaT > 0))
+        return fail(QGD_ERR_INVALID, "qgd_case_create: R, Cv, Pr, PrQGD, deltaT must be positive");
+    int st = 0;
+    int rc = deviceStencil(d->nGeomD, opt->stencil, &st);
+    if (rc) return rc;
+    HIP_CHECK(hipSetDevice(d->deviceId));
+    qgd_case_s* c = new qgd_case_s();
+    try {
+        c->dev = d; c->opt = *opt; c->stencil = st;
+        c->usesPoints = (st == ST_GVP3 || st == ST_GVP2);
+        GasModel& g = c->gas;
+        g.R = opt->R; g.Cv = opt->Cv; g.mu0 = opt->mu; g.Pr = opt->Pr; g.ScQGD = opt->ScQGD; g.PrQGD = opt->PrQGD;
+        g.alphaQGD = opt->alphaQGD;
+        const double Cp = opt->Cv + opt->R;
+        g.gamma = Cp / opt->Cv;
+        const double rPr = 1.0 / opt->Pr;
+        g.alphah0 = (Cp * opt->mu * rPr) / Cp;
+        const MeshView& v = d->view;
+        DeviceArena& a = c->arena;
+        CaseView& cv = c->view;
+        cv.A = a.alloc<RecA>(v.nC); cv.B = a.alloc<RecB>(v.nC); cv.K = a.alloc<Cons>(v.nC);
+        cv.P = a.alloc<RecA>(v.nP);
+        cv.bA = a.alloc<RecA>(v.nBF); cv.bB = a.alloc<RecB>(v.nBF);
+        cv.bG = a.alloc<double>(v.nBF); cv.bPhiw = a.alloc<double>(v.nBF); cv.bPmid = a.alloc<double>(v.nBF);
+        cv.flux = a.alloc<double>(5 * (size_t)v.nF);
+        cv.red = a.alloc<double>(8);
+        cv.dt = a.alloc<double>(8);
+        cv.dbg = nullptr;
+        c->bc.resize(d->patches.size());
+        for (size_t i = 0; i < d->patches.size(); ++i) {
+            PatchBCDev& b = c->bc[i];
+            std::memset(&b, 0, sizeof(b));
+            b.ptype = d->patches[i].type;
+            const bool none = b.ptype == QGD_PATCH_EMPTY || b.ptype == QGD_PATCH_HALO;
+            b.bcU = b.bcT = b.bcP = none ? QGD_BC_NONE : QGD_BC_ZEROGRADIENT;
+        }
+        c->bcDev = a.alloc<PatchBCDev>(std::max<size_t>(1, c->bc.size()));
+        const double dt0[8] = {opt->deltaT, 0, 0, 0, 0, 0, 0, 0};
+        HIP_CHECK(hipMemcpy(cv.dt, dt0, sizeof(dt0), hipMemcpyHostToDevice));
+    } catch (...) { c->arena.release(); delete c; throw; }
+    *out = c;
+    return QGD_OK;
+    QGD_CATCH
+}
+int qgd_case_free(qgd_case_t c) {
+    if (!c) return QGD_OK;
+    (void)hipSetDevice(c->dev->deviceId);
+    harvestTiming(c);
+    for (hipEvent_t e : c->freeEvents) (void)hipEventDestroy(e);
+    c->arena.release();
+    delete c;
+    return QGD_OK;
+}
+
+int qgd_case_set_bc(qgd_case_t c, int32_t patch, int32_t bcU, const double* valueU, int32_t bcT, double valueT, int32_t bcP, double valueP) {
+    QGD_TRY
+    if (!c) return fail(QGD_ERR_INVALID, "null case");
+    if (patch < 0 || patch >= (int32_t)c->bc.size()) return fail(QGD_ERR_INVALID, "qgd_case_set_bc: patch out of range");
+    auto okU = [](int k) { return k == QGD_BC_ZEROGRADIENT || k == QGD_BC_FIXEDVALUE || k == QGD_BC_SLIP || k == QGD_BC_NONE; };
+    auto okT = [](int k) { return k == QGD_BC_ZEROGRADIENT || k == QGD_BC_FIXEDVALUE || k == QGD_BC_NONE; };
+    auto okP = [](int k) { return k == QGD_BC_ZEROGRADIENT || k == QGD_BC_FIXEDVALUE || k == QGD_BC_QGDFLUX || k == QGD_BC_NONE; };
+    if (!okU(bcU) || !okT(bcT) || !okP(bcP)) return fail(QGD_ERR_INVALID, "qgd_case_set_bc: unsupported boundary-condition kind");
+    PatchBCDev& b = c->bc[patch];
+    if (b.ptype == QGD_PATCH_EMPTY || b.ptype == QGD_PATCH_HALO) { bcU = bcT = bcP = QGD_BC_NONE; }
+    b.bcU = bcU; b.bcT = bcT; b.bcP = bcP; b.vT = valueT; b.vP = valueP;
+    if (valueU) for (int k = 0; k < 3; ++k) b.vU[k] = valueU[k];
+    c->fieldsSet = false;
+    return QGD_OK;
+    QGD_CATCH
+}
+
+// one flux-assembly pass (updateFields.H + updateFluxes.H) on the current state
+static void assembleFluxes(qgd_case_s* c, bool adjust) {
+    const Launcher L = launcherOf(c);
+    const MeshView& m = c->dev->view;
+    const CaseView& v = c->view;
+    if (c->usesPoints) {
+        launchPointInterp(L, m, v);
+        launchBoundaryPoints(L, m, v, false);
+        if (c->hasQgdFlux) {
+            // fvsc::grad(p) under GaussVolPoint re-runs p's BCs after phiwStar was refreshed
+            // [QGDFoam/updateFluxes.H L63-65, GaussVolPointStencil_8C L73]
+            launchBoundaryFaceFlux(L, c->stencil, m, v, c->gas, c->bcDev, true, false);
+            launchPressureMidStep(L, m, v, c->bcDev);
+            launchBoundaryPoints(L, m, v, true);
+        }
+    }
+    launchFaceFlux(L, c->stencil, m, v, c->gas, adjust);
+    launchBoundaryFaceFlux(L, c->stencil, m, v, c->gas, c->bcDev, false, adjust);
+}
+
+int qgd_case_set_fields(qgd_case_t c, const double* U, const double* T, const double* p) {
+    QGD_TRY
+    if (!c || !U || !T || !p) return fail(QGD_ERR_INVALID, "qgd_case_set_fields: null argument");
+    HIP_CHECK(hipSetDevice(c->dev->deviceId));
+    const MeshView& m = c->dev->view;
+    c->hasQgdFlux = false;
+    for (const PatchBCDev& b : c->bc) if (b.bcP == QGD_BC_QGDFLUX) c->hasQgdFlux = true;
+    if (!c->bc.empty()) HIP_CHECK(hipMemcpy(c->bcDev, c->bc.data(), sizeof(PatchBCDev) * c->bc.size(), hipMemcpyHostToDevice));
+    double *dU = nullptr, *dT = nullptr, *dp = nullptr;
+    auto cleanup = [&]() { (void)hipFree(dU); (void)hipFree(dT); (void)hipFree(dp); };
+    try {
+        HIP_CHECK(hipMalloc((void**)&dU, sizeof(double) * 3 * (size_t)m.nC));
+        HIP_CHECK(hipMalloc((void**)&dT, sizeof(double) * (size_t)m.nC));
+        HIP_CHECK(hipMalloc((void**)&dp, sizeof(double) * (size_t)m.nC));
+        HIP_CHECK(hipMemcpy(dU, U, sizeof(double) * 3 * (size_t)m.nC, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(dT, T, sizeof(double) * (size_t)m.nC, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(dp, p, sizeof(double) * (size_t)m.nC, hipMemcpyHostToDevice));
+        Launcher L = launcherOf(c);
+        L.pre = nullptr; L.post = nullptr;
+        launchCellInit(L, m, c->view, c->gas, dU, dT, dp);
+        launchBoundaryUpdate(L, m, c->view, c->gas, c->bcDev, true, false);
+        launchResetReductions(L, c->view);
+        const double dt0[3] = {c->opt.deltaT, 0.0, 0.0};
+        HIP_CHECK(hipMemcpyAsync(c->view.dt, dt0, sizeof(dt0), hipMemcpyHostToDevice, c->stream()));
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(c->stream()));
+    } catch (...) { cleanup(); throw; }
+    cleanup();
+    c->phiwRegistered = true;  // createFaceFluxes.H registers "phiwStar" before the loop starts
+    c->fieldsSet = true;
+    c->time = 0; c->steps = 0;
+    return QGD_OK;
+    QGD_CATCH
+}
+
+int qgd_case_update_fluxes(qgd_case_t c) {
+    QGD_TRY
+    if (!c) return fail(QGD_ERR_INVALID, "null case");
+    if (!c->fieldsSet) return fail(QGD_ERR_INVALID, "qgd_case_update_fluxes: call qgd_case_set_fields first");
+    HIP_CHECK(hipSetDevice(c->dev->deviceId));
+    const MeshView& m = c->dev->view;
+    if (!c->dbgBuf) c->dbgBuf = c->arena.alloc<double>((size_t)DBG_COUNT * m.nF);
+    HIP_CHECK(hipMemsetAsync(c->dbgBuf, 0, sizeof(double) * (size_t)DBG_COUNT * m.nF, c->stream()));
+    c->view.dbg = c->dbgBuf;
+    assembleFluxes(c, false);
+    c->view.dbg = nullptr;
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(c->stream()));
+    return QGD_OK;
+    QGD_CATCH
+}
+
+static void stepOnce(qgd_case_s* c) {
+    const Launcher L = launcherOf(c);
+    const MeshView& m = c->dev->view;
+    const bool adjust = c->opt.adjustTimeStep != 0;
+    assembleFluxes(c, adjust);
+    if (adjust) launchDeltaT(L, c->view, c->opt.maxCo, c->opt.maxDeltaT, c->opt.cTau, nullptr);
+    launchCellUpdate(L, m, c->view, c->gas);
+    launchBoundaryUpdate(L, m, c->view, c->gas, c->bcDev, false, c->phiwRegistered);
+    c->steps++;
+    if (!adjust) c->time += c->opt.deltaT;
+}
+
+int qgd_case_step(qgd_case_t c, int32_t nSteps) {
+    QGD_TRY
+    if (!c) return fail(QGD_ERR_INVALID, "null case");
+    if (!c->fieldsSet) return fail(QGD_ERR_INVALID, "qgd_case_step: call qgd_case_set_fields first");
+    if (c->dev->nHaloCells[0] || c->dev->nHaloCells[1])
+        return fail(QGD_ERR_INVALID, "qgd_case_step: sharded mesh, drive it with qgd_case_step_phase + halo exchange");
+    HIP_CHECK(hipSetDevice(c->dev->deviceId));
+    for (int i = 0; i < nSteps; ++i) stepOnce(c);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(c->stream()));
+    return QGD_OK;
+    QGD_CATCH
+}
+
+int qgd_case_step_phase(qgd_case_t c, int phase) {
+    QGD_TRY
+    if (!c) return fail(QGD_ERR_INVALID, "null case");
+    if (!c->fieldsSet) return fail(QGD_ERR_INVALID, "qgd_case_step_phase: call qgd_case_set_fields first");
+    HIP_CHECK(hipSetDevice(c->dev->deviceId));
+    if (phase == 0) stepOnce(c);
+    HIP_CHECK(hipGetLastError());
+    return QGD_OK;  // asynchronous: qgd_case_stream_sync waits
+    QGD_CATCH
+}
+int qgd_case_set_stream(qgd_case_t c, void* hipStream) {
+    if (!c) return fail(QGD_ERR_INVALID, "null case");
+    (void)hipSetDevice(c->dev->deviceId);
+    harvestTiming(c);
+    (void)hipStreamSynchronize(c->stream());
+    c->userStream = (hipStream_t)hipStream;
+    c->useUserStream = true;
+    return QGD_OK;
+}
+int qgd_case_stream_sync(qgd_case_t c) {
+    QGD_TRY
+    if (!c) return fail(QGD_ERR_INVALID, "null case");
+    HIP_CHECK(hipSetDevice(c->dev->deviceId));
+    HIP_CHECK(hipStreamSynchronize(c->stream()));
+    return QGD_OK;
+    QGD_CATCH
+}
+
+// halo message layout: 14 doubles per cell (RecA, RecB, Cons), 11 per boundary face (RecA, RecB, p gradient)
+int qgd_case_halo_count(qgd_case_t c, int side, int64_t* count) {
+    if (!c || !count || side < 0 || side > 1) return fail(QGD_ERR_INVALID, "bad argument");
+    *count = 14 * (int64_t)c->dev->nHaloSendCells[side] + 11 * (int64_t)c->dev->nHaloSendBF[side];
+    return QGD_OK;
+}
+int qgd_case_halo_pack(qgd_case_t c, int side, double* sendBufDevice) {
+    QGD_TRY
+    if (!c || side < 0 || side > 1) return fail(QGD_ERR_INVALID, "bad argument");
+    qgd_device_s* d = c->dev;
+    if (!d->nHaloSendCells[side]) return QGD_OK;
+    if (!sendBufDevice) return fail(QGD_ERR_INVALID, "null buffer");
+    HIP_CHECK(hipSetDevice(d->deviceId));
+    Launcher L = launcherOf(c);
+    launchHaloPack(L, c->view, d->haloSend[side], d->nHaloSendCells[side], d->haloSendBF[side], d->nHaloSendBF[side], sendBufDevice, true);
+    HIP_CHECK(hipGetLastError());
+    return QGD_OK;
+    QGD_CATCH
+}
+int qgd_case_halo_unpack(qgd_case_t c, int side, const double* recvBufDevice) {
+    QGD_TRY
+    if (!c || side < 0 || side > 1) return fail(QGD_ERR_INVALID, "bad argument");
+    qgd_device_s* d = c->dev;
+    if (!d->nHaloCells[side]) return QGD_OK;
+    if (!recvBufDevice) return fail(QGD_ERR_INVALID, "null buffer");
+    HIP_CHECK(hipSetDevice(d->deviceId));
+    Launcher L = launcherOf(c);
+    launchHaloPack(L, c->view, d->haloGhost[side], d->nHaloCells[side], d->haloGhostBF[side], d->nHaloGhostBF[side],
+                   const_cast<double*>(recvBufDevice), false);
+    HIP_CHECK(hipGetLastError());
+    return QGD_OK;
+    QGD_CATCH
+}
+
+// ---- accessors --------------------------------------------------------------------
+int qgd_case_get_field(qgd_case_t c, const char* name, double* out, int64_t outDoubles) {
+    QGD_TRY
+    if (!c || !name || !out) return fail(QGD_ERR_INVALID, "qgd_case_get_field: null argument");
+    HIP_CHECK(hipSetDevice(c->dev->deviceId));
+    HIP_CHECK(hipStreamSynchronize(c->stream()));
+    const MeshView& m = c->dev->view;
+    const GasModel& g = c->gas;
+    std::string s(name);
+    bool bnd = false;
+    const std::string suffix = ".boundary";
+    if (s.size() > suffix.size() && s.compare(s.size() - suffix.size(), suffix.size(), suffix) == 0) {
+        bnd = true;
+        s = s.substr(0, s.size() - suffix.size());
+    }
+    // face fields from the debug buffer
+    static const std::map<std::string, std::pair<int, int>> faceSlots = {
+        {"phiJm", {DBG_PHIJM, 1}}, {"phiJmU", {DBG_PHIJMU, 3}}, {"phiP", {DBG_PHIP, 3}}, {"phiPi", {DBG_PHIPI, 3}},
+        {"phiJmH", {DBG_PHIJMH, 1}}, {"phiQ", {DBG_PHIQ, 1}}, {"phiPiU", {DBG_PHIPIU, 1}}, {"phiwStar", {DBG_PHIW, 1}},
+        {"phi", {DBG_PHI, 1}}, {"tauQGDf", {DBG_TAU, 1}}, {"gradUf", {DBG_GRADU, 9}}, {"gradef", {DBG_GRADE, 3}},
+        {"gradRhof", {DBG_GRADRHO, 3}}, {"gradPf", {DBG_GRADP, 3}}};
+    if (!bnd && s == "hQGDf") {
+        if ((int64_t)c->dev->hf.size() > outDoubles) return fail(QGD_ERR_INVALID, "output too small");
+        std::copy(c->dev->hf.begin(), c->dev->hf.end(), out);
+        return QGD_OK;
+    }
+    auto fs = faceSlots.find(s);
+    if (!bnd && fs != faceSlots.end()) {
+        if (!c->dbgBuf) return fail(QGD_ERR_INVALID, "face fields are materialised by qgd_case_update_fluxes; call it first");
+        const int slot = fs->second.first, nc = fs->second.second;
+        if ((int64_t)m.nF * nc > outDoubles) return fail(QGD_ERR_INVALID, "output too small");
+        std::vector<double> tmp((size_t)m.nF);
+        for (int k = 0; k < nc; ++k) {
+            HIP_CHECK(hipMemcpy(tmp.data(), c->dbgBuf + (size_t)(slot + k) * m.nF, sizeof(double) * (size_t)m.nF, hipMemcpyDeviceToHost));
+            for (int64_t f = 0; f < m.nF; ++f) out[f * nc + k] = tmp[f];
+        }
+        return QGD_OK;
+    }
+    // cell / boundary fields assembled from the records
+    const int64_t n = bnd ? m.nBF : m.nC;
+    std::vector<RecA> A((size_t)n);
+    std::vector<RecB> B((size_t)n);
+    std::vector<Cons> K;
+    if (n) {
+        HIP_CHECK(hipMemcpy(A.data(), bnd ? c->view.bA : c->view.A, sizeof(RecA) * (size_t)n, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(B.data(), bnd ? c->view.bB : c->view.B, sizeof(RecB) * (size_t)n, hipMemcpyDeviceToHost));
+    }
+    std::vector<double> hq((size_t)n);
+    if (n) HIP_CHECK(hipMemcpy(hq.data(), bnd ? m.hQGDb : m.hQGD, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+    if (!bnd) {
+        K.resize((size_t)n);
+        if (n) HIP_CHECK(hipMemcpy(K.data(), c->view.K, sizeof(Cons) * (size_t)n, hipMemcpyDeviceToHost));
+    }
+    int nc = 1;
+    if (s == "U" || s == "rhoU") nc = 3;
+    if (n * nc > outDoubles) return fail(QGD_ERR_INVALID, "output too small");
+    for (int64_t i = 0; i < n; ++i) {
+        const RecA& a = A[i];
+        const RecB& b = B[i];
+        double* o = out + i * nc;
+        if (s == "rho") o[0] = a.rho;
+        else if (s == "U") { o[0] = a.ux; o[1] = a.uy; o[2] = a.uz; }
+        else if (s == "p") o[0] = a.p;
+        else if (s == "e") o[0] = a.e;
+        else if (s == "T") o[0] = a.e / g.Cv;
+        else if (s == "rhoU") {
+            if (bnd) { o[0] = a.rho * a.ux; o[1] = a.rho * a.uy; o[2] = a.rho * a.uz; }
+            else { o[0] = K[i].rux; o[1] = K[i].ruy; o[2] = K[i].ruz; }
+        } else if (s == "rhoE") o[0] = bnd ? a.rho * (a.e + 0.5 * (a.ux * a.ux + a.uy * a.uy + a.uz * a.uz)) : K[i].rE;
+        else if (s == "c") o[0] = b.c;
+        else if (s == "psi") o[0] = 1.0 / (g.R * (a.e / g.Cv));
+        else if (s == "mu") o[0] = g.mu0 + b.muQGD;
+        else if (s == "alphau") o[0] = g.alphah0 + b.muQGD / g.PrQGD;
+        else if (s == "tauQGD") o[0] = g.alphaQGD * hq[i] / b.c;
+        else if (s == "muQGD") o[0] = b.muQGD;
+        else if (s == "alphauQGD") o[0] = b.muQGD / g.PrQGD;
+        else if (s == "hQGD") o[0] = hq[i];
+        else if (s == "H") o[0] = b.H;
+        else if (s == "gamma") o[0] = g.gamma;
+        else return fail(QGD_ERR_UNKNOWN_NAME, "qgd_case_get_field: unknown field " + s);
+    }
+    return QGD_OK;
+    QGD_CATCH
+}
+
+static double undkeyHost(long long k) {
+    long long b = k >= 0 ? k : (k ^ 0x7fffffffffffffffLL);
+    double x;
+    std::memcpy(&x, &b, sizeof(x));
+    return x;
+}
+int qgd_case_info(qgd_case_t c, double info[6]) {
+    QGD_TRY
+    if (!c || !info) return fail(QGD_ERR_INVALID, "null argument");
+    HIP_CHECK(hipSetDevice(c->dev->deviceId));
+    HIP_CHECK(hipStreamSynchronize(c->stream()));
+    long long red[4];
+    double dt[3];
+    HIP_CHECK(hipMemcpy(red, c->view.red, sizeof(red), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(dt, c->view.dt, sizeof(dt), hipMemcpyDeviceToHost));
+    info[0] = c->opt.adjustTimeStep ? dt[1] : c->time;
+    info[1] = dt[0];
+    info[2] = dt[2];
+    info[3] = undkeyHost(red[2]);
+    info[4] = undkeyHost(red[3]);
+    info[5] = (double)c->steps;
+    // min(rho), min(e) restart from here [QGDFoam_8C L142]
+    const double reset[2] = {1e300, 1e300};  // positive doubles are their own ordered keys
+    HIP_CHECK(hipMemcpy(c->view.red + 2, reset, sizeof(reset), hipMemcpyHostToDevice));
+    return QGD_OK;
+    QGD_CATCH
+}
+
+// ---- measurement -------------------------------------------------------------------
+int qgd_case_timing(qgd_case_t c, int enable) {
+    if (!c) return fail(QGD_ERR_INVALID, "null case");
+    if (!enable) harvestTiming(c);
+    c->timing = enable != 0;
+    return QGD_OK;
+}
+int qgd_case_kernel_time(qgd_case_t c, int k, double* totalMs, int64_t* launches) {
+    if (!c || k < 0 || k >= QGD_K_COUNT || !totalMs || !launches) return fail(QGD_ERR_INVALID, "bad argument");
+    (void)hipSetDevice(c->dev->deviceId);
+    harvestTiming(c);
+    *totalMs = c->totalMs[k];
+    *launches = c->launches[k];
+    return QGD_OK;
+}
+int qgd_case_timing_reset(qgd_case_t c) {
+    if (!c) return fail(QGD_ERR_INVALID, "null case");
+    (void)hipSetDevice(c->dev->deviceId);
+    harvestTiming(c);
+    for (int k = 0; k < QGD_K_COUNT; ++k) { c->totalMs[k] = 0; c->launches[k] = 0; }
+    return QGD_OK;
+}
+int qgd_case_device_bytes(qgd_case_t c, int64_t* bytes) {
+    if (!c || !bytes) return fail(QGD_ERR_INVALID, "null argument");
+    *bytes = c->arena.bytes + c->dev->arena.bytes;
+    return QGD_OK;
+}
+
+}  // extern "C"

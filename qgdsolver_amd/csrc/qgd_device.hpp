@@ -1,0 +1,103 @@
+// qgd_device.hpp -- device-side views and launch entry points (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace qgd {
+
+// ---- gathered records (AoS, 16-B aligned so they move as dwordx4) ----------
+struct alignas(16) RecA { double rho, ux, uy, uz, p, e; };   // 48 B: fields whose face gradients are needed
+struct alignas(16) RecB { double H, c, muQGD, aOc; };        // 32 B: derived per-cell quantities the face kernel interpolates
+struct alignas(16) Cons { double rux, ruy, ruz, rE; };       // 32 B: conserved momentum + total energy
+
+enum StencilKind : int { ST_REDUCED = 0, ST_LSQ = 1, ST_GVP3 = 2, ST_GVP2 = 3 };
+
+// Static mesh data on the device; every face array is indexed by global face label.
+struct MeshView {
+    int32_t nP, nF, nIF, nC, nBF;
+    int32_t ie1, ie2, ie3;
+    int32_t ncoef;           // 9 or 12
+    const int32_t* own;      // nF
+    const int32_t* nei;      // nIF
+    const int4* verts;       // nF
+    const uint8_t* fkind;    // nF
+    const double* Sx; const double* Sy; const double* Sz;  // nF
+    const double* magSf;     // nF
+    const double* w;         // nF
+    const double* hf;        // nF
+    const double* dn;        // nF
+    const double* coef;      // ncoef*nF
+    const double* rV;        // nF
+    const double* bmvON;     // nBF
+    const int2* ip13;        // nF
+    const double* c2d;       // 6*nF
+    const int32_t* lsqOff; const int32_t* lsqCell; const double* lsqGw; const uint8_t* lsqDeg; const uint8_t* lsqBndZero;
+    const int32_t* pcOff; const int32_t* pcCell; const double* pcW;
+    int32_t nBP; const int32_t* bpPoint; const int32_t* bpOff; const int32_t* bpFace; const double* bpW;
+    const int32_t* cfOff; const int32_t* cfItem;
+    const double* V; const double* hQGD; const uint8_t* ghost;
+    const int32_t* bPatch; const double* hQGDb;
+};
+
+// Per-patch boundary-condition table (device copy, <= 64 patches)
+struct PatchBCDev { int32_t bcU, bcT, bcP, ptype; double vU[3]; double vT, vP; };
+#define QGD_MAX_PATCHES 64
+
+struct GasModel {
+    double R, Cv, mu0, Pr, ScQGD, PrQGD, alphaQGD;
+    double gamma;     // Cp/Cv
+    double alphah0;   // (Cp*mu*rPr)/Cp
+};
+
+// Mutable case state on the device
+struct CaseView {
+    RecA* A; RecB* B; Cons* K;      // nC
+    RecA* P;                        // nP vertex records
+    RecA* bA; RecB* bB;             // nBF boundary records
+    double* bG;                     // nBF p gradient (qgdFlux)
+    double* bPhiw;                  // nBF phiwStar on boundary faces
+    double* bPmid;                  // nBF patch pressure after GaussVolPoint's mid-step BC evaluation
+    double* flux;                   // 5*nF net face fluxes
+    double* red;                    // [0]=max Co, [1]=min tauQGDf, [2]=min rho, [3]=min e (as ordered bit patterns)
+    double* dt;                     // [0]=deltaT (device resident so adjustTimeStep needs no host round trip)
+    double* dbg;                    // optional debug face fields (nullptr in the product path)
+};
+
+enum DebugSlot : int {
+    DBG_PHIJM = 0, DBG_PHIJMU = 1, DBG_PHIP = 4, DBG_PHIPI = 7, DBG_PHIJMH = 10, DBG_PHIQ = 11, DBG_PHIPIU = 12,
+    DBG_PHIW = 13, DBG_PHI = 14, DBG_TAU = 15, DBG_GRADU = 16, DBG_GRADE = 25, DBG_GRADRHO = 28, DBG_GRADP = 31,
+    DBG_COUNT = 34
+};
+
+struct Launcher {
+    hipStream_t stream;
+    // timing hooks (set by the C-ABI layer)
+    void (*pre)(void* ctx, int k);
+    void (*post)(void* ctx, int k);
+    void* ctx;
+};
+
+// ---- case kernels -------------------------------------------------------------
+void launchPointInterp(const Launcher& L, const MeshView& m, const CaseView& c);
+void launchBoundaryPoints(const Launcher& L, const MeshView& m, const CaseView& c, bool pOnly);
+void launchPressureMidStep(const Launcher& L, const MeshView& m, const CaseView& c, const PatchBCDev* bc);
+void launchFaceFlux(const Launcher& L, int stencil, const MeshView& m, const CaseView& c, const GasModel& g, bool adjustDt);
+void launchBoundaryFaceFlux(const Launcher& L, int stencil, const MeshView& m, const CaseView& c, const GasModel& g,
+                            const PatchBCDev* bc, bool phiwOnly, bool adjustDt);
+void launchCellUpdate(const Launcher& L, const MeshView& m, const CaseView& c, const GasModel& g);
+void launchBoundaryUpdate(const Launcher& L, const MeshView& m, const CaseView& c, const GasModel& g, const PatchBCDev* bc,
+                          bool init, bool phiwRegistered);
+void launchCellInit(const Launcher& L, const MeshView& m, const CaseView& c, const GasModel& g, const double* U,
+                    const double* T, const double* p);
+void launchDeltaT(const Launcher& L, const CaseView& c, double maxCo, double maxDeltaT, double cTau, double* info);
+void launchResetReductions(const Launcher& L, const CaseView& c);
+void launchHaloPack(const Launcher& L, const CaseView& c, const int32_t* cells, int32_t nCells, const int32_t* bfaces,
+                    int32_t nFaces, double* buf, bool pack);
+
+// ---- fvsc operators on plain fields ----------------------------------------------
+// op: 0 grad (out 3*NC per face), 1 div (out NC/3 per face); NC in {1,3,9}
+void launchFvscOp(hipStream_t s, int stencil, int op, int NC, const MeshView& m, const double* cell, const double* bnd,
+                  double* pt, double* out);
+
+}  // namespace qgd

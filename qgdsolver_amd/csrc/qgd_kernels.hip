@@ -1,0 +1,899 @@
+// qgd_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4, wave64) of the
+// QGDFoam face-flux path.  No MFMA: the path has no dense contraction; every
+// kernel is an HBM/L2-bound indirect-addressing loop (DESIGN.md "Kernels").
+//
+//   P   pointInterpKernel      cell -> vertex inverse-distance interpolation
+//   PB  boundaryPointKernel    patch points: average of boundary-face values
+//   F   faceFluxKernel         fused: 13 face interpolations + 4 fvsc gradients
+//                              + all QGD fluxes, one thread per internal face
+//   FB  boundaryFaceFluxKernel same on boundary faces (mirror-point stencil)
+//   C   cellUpdateKernel       deterministic gather of face fluxes + explicit
+//                              Euler update + thermo + QGD coefficients
+//   B   boundaryUpdateKernel   boundary-condition refresh
+//
+// Reference restated (listing lines under /root/reference/docs/html/):
+//   interpolations   QGDFoam_2updateFields_8H_source.html L45-80
+//   flux algebra     QGDFoam_2updateFluxes_8H_source.html L41-139 (explicit branch)
+//   GaussVolPoint    GaussVolPointBase3D_8C_source.html L488-539 (dfdxif/dfdxbf),
+//                    GaussVolPointBase2D_8C_source.html L315-360
+//   leastSquares     extendedFaceStencilScalarGrad_8C_source.html L62-109
+//   reduced          reducedFaceNormalStencil_8C_source.html L69-108
+//   cell update      QGDRhoEqn_8H L40-47, QGDUEqn_8H L36-89, QGDEEqn_8H L37-76,
+//                    QGDFoam_8C L149-156, hePsiQGDThermo_8C L38-126,
+//                    constScPrModel1_8C L97-131, QGDThermo_8C L84-111
+#include "qgd_device.hpp"
+
+#include "../../include/qgd_amd.h"
+
+namespace qgd {
+
+#define QGD_BLOCK 256
+
+__device__ __forceinline__ double lerpf(double w, double a, double b) { return w * (a - b) + b; }
+
+// order-preserving map double -> int64 so min/max can use integer atomics
+__device__ __forceinline__ long long dkey(double x) {
+    long long k = __double_as_longlong(x);
+    return k >= 0 ? k : (k ^ 0x7fffffffffffffffLL);
+}
+
+template <int NC>
+struct FaceVals {
+    double o[NC];   // owner cell values
+    double n[NC];   // neighbour cell (internal face) or patch value (boundary face)
+    double sn[NC];  // boundary face: patch snGrad
+};
+
+// ---------------------------------------------------------------------------
+// fvsc face gradient of an NC-component field: g[i*NC + k] = d_i phi_k.
+// cellF / ptF are AoS with stride NC (cell and vertex values).
+// UOFF >= 0 marks three consecutive components as a vector so that the
+// interior-triangle pattern of the reference's vector gradient
+// [GaussVolPointBase3D_8C L844-854] is reproduced.
+// ---------------------------------------------------------------------------
+template <int ST, int NC, int UOFF>
+__device__ __forceinline__ void faceGradient(const MeshView& m, const int f, const FaceVals<NC>& v,
+                                             const double* __restrict__ cellF, const double* __restrict__ ptF,
+                                             double* __restrict__ g) {
+    const bool internal = f < m.nIF;
+    const int b = f - m.nIF;
+    const int kind = m.fkind[f];
+#pragma unroll
+    for (int i = 0; i < 3 * NC; ++i) g[i] = 0.0;
+    if (kind == 3) return;  // FK_SKIP: empty patches carry no field
+
+    auto reducedForm = [&]() {
+        const double ms = m.magSf[f];
+        const double nx = m.Sx[f] / ms, ny = m.Sy[f] / ms, nz = m.Sz[f] / ms;
+        const double dn = m.dn[f];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            const double s = internal ? dn * (v.n[k] - v.o[k]) : v.sn[k];
+            g[0 * NC + k] = nx * s;
+            g[1 * NC + k] = ny * s;
+            g[2 * NC + k] = nz * s;
+        }
+    };
+
+    if constexpr (ST == ST_REDUCED) {
+        reducedForm();
+        return;
+    }
+    if constexpr (ST == ST_GVP3) {
+        if (kind == 2) { reducedForm(); return; }  // faces with > 4 vertices [3D.C L759-768]
+        const int4 vt = m.verts[f];
+        const double rV = m.rV[f];
+        double psiN[NC];
+        if (internal) {
+#pragma unroll
+            for (int k = 0; k < NC; ++k) psiN[k] = v.n[k];
+        } else {
+            const double hd = m.bmvON[b];
+#pragma unroll
+            for (int k = 0; k < NC; ++k) psiN[k] = v.n[k] + v.sn[k] * hd * 0.5;  // [3D.C L790-793]
+        }
+        const size_t nF = (size_t)m.nF;
+        if (kind == 0) {  // quad: a2=-a0, a3=-a1, a4(nei)=-a5(own) [3D.C L361-363]
+            const int stride = (m.ncoef == 12) ? 4 : 3;
+            const double* p0 = ptF + (size_t)vt.x * NC;
+            const double* p1 = ptF + (size_t)vt.y * NC;
+            const double* p2 = ptF + (size_t)vt.z * NC;
+            const double* p3 = ptF + (size_t)vt.w * NC;
+            double q0[NC], q1[NC], q2[NC], q3[NC];
+#pragma unroll
+            for (int k = 0; k < NC; ++k) { q0[k] = p0[k]; q1[k] = p1[k]; q2[k] = p2[k]; q3[k] = p3[k]; }
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const double a0 = m.coef[(size_t)(d * stride + 0) * nF + f];
+                const double a1 = m.coef[(size_t)(d * stride + 1) * nF + f];
+                const double a5 = m.coef[(size_t)(d * stride + 2) * nF + f];
+#pragma unroll
+                for (int k = 0; k < NC; ++k) {
+                    double s = psiN[k] * (-a5);
+                    s += v.o[k] * a5;
+                    s += q0[k] * a0;
+                    s += q1[k] * a1;
+                    s += q2[k] * (-a0);
+                    s += q3[k] * (-a1);
+                    g[d * NC + k] = s * rV;
+                }
+            }
+        } else {  // triangle: slots a0,a1,a2 vertices, a3 neighbour, owner = -a3 [3D.C L193-229]
+            const double* p0 = ptF + (size_t)vt.x * NC;
+            const double* p1 = ptF + (size_t)vt.y * NC;
+            const double* p2 = ptF + (size_t)vt.z * NC;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const double a0 = m.coef[(size_t)(d * 4 + 0) * nF + f];
+                const double a1 = m.coef[(size_t)(d * 4 + 1) * nF + f];
+                const double a2 = m.coef[(size_t)(d * 4 + 2) * nF + f];
+                const double a3 = m.coef[(size_t)(d * 4 + 3) * nF + f];
+#pragma unroll
+                for (int k = 0; k < NC; ++k) {
+                    double s = psiN[k] * a3;
+                    s += v.o[k] * (-a3);
+                    s += p0[k] * a0;
+                    s += p1[k] * a1;
+                    s += p2[k] * a2;
+                    g[d * NC + k] = s * rV;
+                }
+            }
+            if (UOFF >= 0 && internal) {
+                // interior triangles, vector field: every row i holds d_j U_j [3D.C L844-854]
+                double dg[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) dg[j] = g[j * NC + UOFF + j];
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) g[i * NC + UOFF + j] = dg[j];
+            }
+        }
+        return;
+    }
+    if constexpr (ST == ST_GVP2) {
+        const int2 ip = m.ip13[f];
+        const size_t nF = (size_t)m.nF;
+        const double c1 = m.c2d[0 * nF + f], c2 = m.c2d[1 * nF + f], c3 = m.c2d[2 * nF + f], c4 = m.c2d[3 * nF + f];
+        const double mv42 = m.c2d[4 * nF + f], mv13 = m.c2d[5 * nF + f];
+        const double* pa = ptF + (size_t)ip.x * NC;
+        const double* pb = ptF + (size_t)ip.y * NC;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            const double hi = internal ? v.n[k] : (v.n[k] + v.sn[k] * mv42 * 0.5);  // [2D.C L343-346]
+            const double dfdn = (hi - v.o[k]) / mv42;
+            const double dfdt = (pb[k] - pa[k]) / mv13;
+            g[m.ie1 * NC + k] = (dfdn * c1 - dfdt * c2);
+            g[m.ie2 * NC + k] = (dfdt * c3 - dfdn * c4);
+        }
+        return;
+    }
+    if constexpr (ST == ST_LSQ) {
+        if (!internal) {
+            if (m.lsqBndZero[b]) return;  // constraint patches stay zero [ScalarGrad.C L90-101]
+            const double ms = m.magSf[f];
+            const double nx = m.Sx[f] / ms, ny = m.Sy[f] / ms, nz = m.Sz[f] / ms;
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                g[0 * NC + k] = nx * v.sn[k];
+                g[1 * NC + k] = ny * v.sn[k];
+                g[2 * NC + k] = nz * v.sn[k];
+            }
+            return;
+        }
+        if (m.lsqDeg[f]) { reducedForm(); return; }  // [ScalarGrad.C L76-83]
+        const double w = m.w[f];
+        double pf[NC];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) pf[k] = lerpf(w, v.o[k], v.n[k]);
+        const int e0 = m.lsqOff[f], e1 = m.lsqOff[f + 1];
+        for (int e = e0; e < e1; ++e) {
+            const double* cv = cellF + (size_t)m.lsqCell[e] * NC;
+            const double gx = m.lsqGw[3 * (size_t)e], gy = m.lsqGw[3 * (size_t)e + 1], gz = m.lsqGw[3 * (size_t)e + 2];
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                const double dphi = cv[k] - pf[k];
+                g[0 * NC + k] = g[0 * NC + k] + gx * dphi;
+                g[1 * NC + k] = g[1 * NC + k] + gy * dphi;
+                g[2 * NC + k] = g[2 * NC + k] + gz * dphi;
+            }
+        }
+        return;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// QGD flux algebra on one face [QGDFoam/updateFluxes.H L41-139, explicit branch]
+// g: gradients of (rho, Ux, Uy, Uz, p, e) with stride 6.
+// ---------------------------------------------------------------------------
+struct FaceState {
+    double rhof, Uf[3], rhoUf[3], UrhoUf[9], pf, cf, Hf, gammaf, alphauf, muf, tauf;
+};
+
+template <bool DBG>
+__device__ __forceinline__ void qgdFluxes(const FaceState& s, const double* __restrict__ g, const double S[3],
+                                          double out[5], double& phiwStar, double* __restrict__ dbg, size_t dbgStride) {
+    double gR[3], gP[3], gE[3], gU[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        gR[i] = g[i * 6 + 0];
+        gU[3 * i + 0] = g[i * 6 + 1];
+        gU[3 * i + 1] = g[i * 6 + 2];
+        gU[3 * i + 2] = g[i * 6 + 3];
+        gP[i] = g[i * 6 + 4];
+        gE[i] = g[i * 6 + 5];
+    }
+    const double tau = s.tauf;
+    const double divU = gU[0] + gU[4] + gU[8];
+    // continuity [L54-72]
+    double rhoW[3], jm[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double t1 = (s.Uf[k] * gR[0]) * s.Uf[0] + (s.Uf[k] * gR[1]) * s.Uf[1] + (s.Uf[k] * gR[2]) * s.Uf[2];
+        const double t3 = s.rhoUf[0] * gU[0 + k] + s.rhoUf[1] * gU[3 + k] + s.rhoUf[2] * gU[6 + k];
+        rhoW[k] = tau * ((t1 + (s.rhoUf[k] * divU)) + t3);
+    }
+    phiwStar = S[0] * rhoW[0] + S[1] * rhoW[1] + S[2] * rhoW[2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        rhoW[k] += tau * gP[k];
+        jm[k] = s.rhoUf[k] - rhoW[k];
+    }
+    const double phiJm = S[0] * jm[0] + S[1] * jm[1] + S[2] * jm[2];
+    // momentum [L78-113]
+    double Pi[9];
+    const double sph = tau * ((s.Uf[0] * gP[0] + s.Uf[1] * gP[1] + s.Uf[2] * gP[2]) + (s.gammaf * s.pf * divU));
+    const double s23 = (2.0 / 3.0) * divU;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const double a = s.UrhoUf[3 * i] * gU[j] + s.UrhoUf[3 * i + 1] * gU[3 + j] + s.UrhoUf[3 * i + 2] * gU[6 + j];
+            double pij = tau * (a + s.Uf[i] * gP[j]);
+            double t = gU[3 * i + j] + gU[3 * j + i];
+            if (i == j) { pij += sph; t = t - s23; }
+            Pi[3 * i + j] = pij + s.muf * t;
+        }
+    double phiPi[3], phiJmU[3], phiP[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        phiPi[j] = S[0] * Pi[j] + S[1] * Pi[3 + j] + S[2] * Pi[6 + j];
+        phiJmU[j] = phiJm * s.Uf[j];
+        phiP[j] = S[j] * s.pf;
+    }
+    // energy [L119-139]
+    const double phiJmH = phiJm * s.Hf;
+    const double pr2 = s.pf / s.rhof / s.rhof;
+    double g2[3], qf[3], piU[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) g2[k] = gE[k] - pr2 * gR[k];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double q = s.UrhoUf[3 * i] * g2[0] + s.UrhoUf[3 * i + 1] * g2[1] + s.UrhoUf[3 * i + 2] * g2[2];
+        qf[i] = (-tau) * q - s.alphauf * gE[i];
+        piU[i] = Pi[3 * i] * s.Uf[0] + Pi[3 * i + 1] * s.Uf[1] + Pi[3 * i + 2] * s.Uf[2];
+    }
+    const double phiQ = S[0] * qf[0] + S[1] * qf[1] + S[2] * qf[2];
+    const double phiPiU = S[0] * piU[0] + S[1] * piU[1] + S[2] * piU[2];
+    // net fluxes consumed by the three equations [QGDRhoEqn/QGDUEqn/QGDEEqn]
+    out[0] = phiJm;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) out[1 + j] = phiJmU[j] + phiP[j] - phiPi[j];
+    out[4] = phiJmH + phiQ - phiPiU;
+    if (DBG) {
+        auto put = [&](int slot, double x) { dbg[(size_t)slot * dbgStride] = x; };
+        put(DBG_PHIJM, phiJm);
+        for (int j = 0; j < 3; ++j) { put(DBG_PHIJMU + j, phiJmU[j]); put(DBG_PHIP + j, phiP[j]); put(DBG_PHIPI + j, phiPi[j]); }
+        put(DBG_PHIJMH, phiJmH); put(DBG_PHIQ, phiQ); put(DBG_PHIPIU, phiPiU); put(DBG_PHIW, phiwStar);
+        put(DBG_PHI, S[0] * s.rhoUf[0] + S[1] * s.rhoUf[1] + S[2] * s.rhoUf[2]);
+        put(DBG_TAU, tau);
+        for (int k = 0; k < 9; ++k) put(DBG_GRADU + k, gU[k]);
+        for (int k = 0; k < 3; ++k) { put(DBG_GRADE + k, gE[k]); put(DBG_GRADRHO + k, gR[k]); put(DBG_GRADP + k, gP[k]); }
+    }
+}
+
+__device__ __forceinline__ void loadVals(const RecA& a, double* o) {
+    o[0] = a.rho; o[1] = a.ux; o[2] = a.uy; o[3] = a.uz; o[4] = a.p; o[5] = a.e;
+}
+
+// effective transport coefficients of a cell/patch value.  L0 assumption:
+// laminar muEff = mut(0) + mu, alphaEff = gamma*(alpha + alphat(0)) for an
+// internal-energy thermo; mu = mu0 + muQGD, alpha = alphah0 + muQGD/PrQGD
+// [QGDThermo_8C L91-98, constScPrModel1_8C L106-115].
+__device__ __forceinline__ double muEffOf(const GasModel& gm, double muQGD) { return 0.0 + (gm.mu0 + muQGD); }
+__device__ __forceinline__ double alphaEffOf(const GasModel& gm, double muQGD) {
+    return gm.gamma * ((gm.alphah0 + muQGD / gm.PrQGD) + 0.0);
+}
+
+// XCD-aware tile order: consecutive workgroups are dealt round-robin to the 8
+// XCDs (block b -> XCD b%8), each with a private L2.  Remap so that every XCD
+// walks one contiguous eighth of the face range and neighbouring tiles (which
+// share cell and vertex records) meet in the same L2.
+__device__ __forceinline__ int xcdTile(int nTiles) {
+    const int b = blockIdx.x;
+    const int per = nTiles >> 3;        // tiles per XCD (the tail past 8*per keeps identity order)
+    if (b >= (per << 3)) return b;
+    return (b & 7) * per + (b >> 3);
+}
+
+template <int ST, bool DBG>
+__global__ __launch_bounds__(QGD_BLOCK) void faceFluxKernel(const MeshView m, const CaseView c, const GasModel gm,
+                                                           const int adjustDt) {
+    const int tile = xcdTile((int)gridDim.x);
+    const int f = tile * QGD_BLOCK + (int)threadIdx.x;
+    double cof = -1e300, tauMin = 1e300;
+    if (f < m.nIF) {
+        const int o = m.own[f], n = m.nei[f];
+        const RecA Ao = c.A[o], An = c.A[n];
+        const RecB Bo = c.B[o], Bn = c.B[n];
+        FaceVals<6> v;
+        loadVals(Ao, v.o);
+        loadVals(An, v.n);
+        double g[18];
+        faceGradient<ST, 6, 1>(m, f, v, reinterpret_cast<const double*>(c.A), reinterpret_cast<const double*>(c.P), g);
+        const double w = m.w[f];
+        FaceState s;
+        s.rhof = lerpf(w, Ao.rho, An.rho);
+        const double Uo[3] = {Ao.ux, Ao.uy, Ao.uz}, Un[3] = {An.ux, An.uy, An.uz};
+        double rUo[3], rUn[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            s.Uf[k] = lerpf(w, Uo[k], Un[k]);
+            rUo[k] = Ao.rho * Uo[k];
+            rUn[k] = An.rho * Un[k];
+            s.rhoUf[k] = lerpf(w, rUo[k], rUn[k]);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) s.UrhoUf[3 * i + j] = lerpf(w, Uo[i] * rUo[j], Un[i] * rUn[j]);
+        s.pf = lerpf(w, Ao.p, An.p);
+        s.cf = lerpf(w, Bo.c, Bn.c);
+        s.Hf = lerpf(w, Bo.H, Bn.H);
+        s.gammaf = lerpf(w, gm.gamma, gm.gamma);
+        s.alphauf = lerpf(w, alphaEffOf(gm, Bo.muQGD), alphaEffOf(gm, Bn.muQGD));
+        s.muf = lerpf(w, muEffOf(gm, Bo.muQGD), muEffOf(gm, Bn.muQGD));
+        const double hf = m.hf[f];
+        s.tauf = lerpf(w, Bo.aOc, Bn.aOc) * hf;  // tauQGDf = lin(aQGD/c)*hQGDf [constScPrModel1_8C L103]
+        const double S[3] = {m.Sx[f], m.Sy[f], m.Sz[f]};
+        double out[5], phiw;
+        qgdFluxes<DBG>(s, g, S, out, phiw, DBG ? c.dbg + f : nullptr, (size_t)m.nF);
+        double* fo = c.flux + 5 * (size_t)f;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) fo[k] = out[k];
+        if (adjustDt) {
+            const bool counted = (m.ghost == nullptr) || !(m.ghost[o] && m.ghost[n]);
+            if (counted) {
+                const double ms = sqrt(S[0] * S[0] + S[1] * S[1] + S[2] * S[2]);
+                const double Unf = s.Uf[0] * (S[0] / ms) + s.Uf[1] * (S[1] / ms) + s.Uf[2] * (S[2] / ms);
+                cof = fmax(fabs(Unf + s.cf), fabs(Unf - s.cf)) * c.dt[0] / hf;  // [QGDCourantNo_8H L44-48]
+                tauMin = s.tauf;
+            }
+        }
+    }
+    if (adjustDt) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            cof = fmax(cof, __shfl_down(cof, off, 64));
+            tauMin = fmin(tauMin, __shfl_down(tauMin, off, 64));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicMax(reinterpret_cast<long long*>(c.red) + 0, dkey(cof));
+            atomicMin(reinterpret_cast<long long*>(c.red) + 1, dkey(tauMin));
+        }
+    }
+}
+
+// patch snGrad of the six case fields on boundary face (global label f)
+__device__ __forceinline__ void boundaryVals(const MeshView& m, const CaseView& c, const PatchBCDev& bc, const int f,
+                                             const RecA& Ao, const RecA& Ab, FaceVals<6>& v) {
+    const int b = f - m.nIF;
+    loadVals(Ao, v.o);
+    loadVals(Ab, v.n);
+    v.n[4] = c.bPmid[b];        // patch pressure after the mid-step BC evaluation
+    const double dc = m.dn[f];  // deltaCoeffs on boundary faces
+#pragma unroll
+    for (int k = 0; k < 6; ++k) v.sn[k] = dc * (v.n[k] - v.o[k]);  // fvPatchField::snGrad (L0)
+    if (bc.bcU == QGD_BC_SLIP) {
+        // basicSymmetry::snGrad (L0): (transform(I - 2 nn, pif) - pif)*(deltaCoeffs/2)
+        const double ms = m.magSf[f];
+        const double n[3] = {m.Sx[f] / ms, m.Sy[f] / ms, m.Sz[f] / ms};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double tv = ((i == 0 ? 1.0 : 0.0) - 2.0 * (n[i] * n[0])) * v.o[1] + ((i == 1 ? 1.0 : 0.0) - 2.0 * (n[i] * n[1])) * v.o[2] +
+                              ((i == 2 ? 1.0 : 0.0) - 2.0 * (n[i] * n[2])) * v.o[3];
+            v.sn[1 + i] = (tv - v.o[1 + i]) * (dc / 2.0);
+        }
+    } else if (bc.bcU == QGD_BC_ZEROGRADIENT || bc.bcU == QGD_BC_NONE) {
+        v.sn[1] = v.sn[2] = v.sn[3] = 0.0;
+    }
+    if (bc.bcP == QGD_BC_QGDFLUX) v.sn[4] = c.bG[b];             // fixedGradient::snGrad = gradient()
+    else if (bc.bcP != QGD_BC_FIXEDVALUE) v.sn[4] = 0.0;          // zeroGradient
+    if (bc.bcT != QGD_BC_FIXEDVALUE) v.sn[5] = 0.0;               // gradientEnergy with zero gradient
+}
+
+template <int ST, bool DBG>
+__global__ __launch_bounds__(QGD_BLOCK) void boundaryFaceFluxKernel(const MeshView m, const CaseView c, const GasModel gm,
+                                                                   const PatchBCDev* __restrict__ bcs, const int phiwOnly,
+                                                                   const int adjustDt) {
+    const int b = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    double cof = -1e300, tauMin = 1e300;
+    if (b < m.nBF) {
+        const int f = m.nIF + b;
+        const PatchBCDev bc = bcs[m.bPatch[b]];
+        const bool live = m.fkind[f] != 3 && bc.ptype != QGD_PATCH_HALO && !(phiwOnly && bc.bcP != QGD_BC_QGDFLUX);
+        if (live) {
+            const int o = m.own[f];
+            const RecA Ao = c.A[o], Ab = c.bA[b];
+            const RecB Bb = c.bB[b];
+            FaceVals<6> v;
+            boundaryVals(m, c, bc, f, Ao, Ab, v);
+            double g[18];
+            faceGradient<ST, 6, 1>(m, f, v, reinterpret_cast<const double*>(c.A), reinterpret_cast<const double*>(c.P), g);
+            FaceState s;
+            s.rhof = Ab.rho;
+            const double Ub[3] = {Ab.ux, Ab.uy, Ab.uz};
+            double rUb[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { s.Uf[k] = Ub[k]; rUb[k] = Ab.rho * Ub[k]; s.rhoUf[k] = rUb[k]; }
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) s.UrhoUf[3 * i + j] = Ub[i] * rUb[j];
+            s.pf = Ab.p; s.cf = Bb.c; s.Hf = Bb.H; s.gammaf = gm.gamma;
+            s.alphauf = alphaEffOf(gm, Bb.muQGD);
+            s.muf = muEffOf(gm, Bb.muQGD);
+            const double hf = m.hf[f];
+            s.tauf = Bb.aOc * hf;
+            const double S[3] = {m.Sx[f], m.Sy[f], m.Sz[f]};
+            double out[5], phiw;
+            qgdFluxes<DBG>(s, g, S, out, phiw, DBG ? c.dbg + f : nullptr, (size_t)m.nF);
+            c.bPhiw[b] = phiw;
+            if (!phiwOnly) {
+                double* fo = c.flux + 5 * (size_t)f;
+#pragma unroll
+                for (int k = 0; k < 5; ++k) fo[k] = out[k];
+                if (adjustDt && !(m.ghost && m.ghost[o])) {
+                    const double ms = m.magSf[f];
+                    const double Unf = s.Uf[0] * (S[0] / ms) + s.Uf[1] * (S[1] / ms) + s.Uf[2] * (S[2] / ms);
+                    cof = fmax(fabs(Unf + s.cf), fabs(Unf - s.cf)) * c.dt[0] / hf;
+                    tauMin = s.tauf;
+                }
+            }
+        }
+    }
+    if (adjustDt && !phiwOnly) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            cof = fmax(cof, __shfl_down(cof, off, 64));
+            tauMin = fmin(tauMin, __shfl_down(tauMin, off, 64));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicMax(reinterpret_cast<long long*>(c.red) + 0, dkey(cof));
+            atomicMin(reinterpret_cast<long long*>(c.red) + 1, dkey(tauMin));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// vertex interpolation (L0: volPointInterpolation)
+// ---------------------------------------------------------------------------
+template <int NC>
+__global__ __launch_bounds__(QGD_BLOCK) void pointInterpKernel(const MeshView m, const double* __restrict__ cellF,
+                                                              const int cellStride, double* __restrict__ ptF) {
+    const int p = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    if (p >= m.nP) return;
+    const int e0 = m.pcOff[p], e1 = m.pcOff[p + 1];
+    if (e0 == e1) return;  // patch point: written by boundaryPointKernel
+    double acc[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) acc[k] = 0.0;
+    for (int e = e0; e < e1; ++e) {
+        const double w = m.pcW[e];
+        const double* cv = cellF + (size_t)m.pcCell[e] * cellStride;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) acc[k] += w * cv[k];
+    }
+    double* o = ptF + (size_t)p * NC;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) o[k] = acc[k];
+}
+
+// patch points: weighted mean of the surrounding boundary-face values.  Source
+// and destination strides/offset are free so the qgdFlux pass can refresh the
+// pressure component alone from the mid-step patch pressures.
+template <int NC>
+__global__ __launch_bounds__(QGD_BLOCK) void boundaryPointKernel(const MeshView m, const double* __restrict__ bndF,
+                                                                const int bndStride, double* __restrict__ ptF,
+                                                                const int ptStride, const int ptOffset) {
+    const int i = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    if (i >= m.nBP) return;
+    const int p = m.bpPoint[i];
+    double acc[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) acc[k] = 0.0;
+    for (int e = m.bpOff[i]; e < m.bpOff[i + 1]; ++e) {
+        const double w = m.bpW[e];
+        const double* bv = bndF + (size_t)m.bpFace[e] * bndStride;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) acc[k] += w * bv[k];
+    }
+    double* o = ptF + (size_t)p * ptStride + ptOffset;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) o[k] = acc[k];
+}
+
+// GaussVolPoint re-evaluates p's boundary conditions inside fvsc::grad(p)
+// [GaussVolPointStencil_8C L73]: with a qgdFlux patch that picks up the fresh
+// phiwStar [qgdFluxFvPatchScalarField_8C L166-192] while the face value pf of
+// this step was already taken [QGDFoam/updateFields.H L58].  bPmid holds the
+// patch pressure after that mid-step evaluation.
+__global__ __launch_bounds__(QGD_BLOCK) void pressureMidStepKernel(const MeshView m, const CaseView c,
+                                                                  const PatchBCDev* __restrict__ bcs) {
+    const int b = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    if (b >= m.nBF) return;
+    const int f = m.nIF + b;
+    if (m.fkind[f] == 3) return;
+    const PatchBCDev bc = bcs[m.bPatch[b]];
+    if (bc.bcP != QGD_BC_QGDFLUX) return;
+    const double tauf = c.bB[b].aOc * m.hf[f];
+    const double grad = -(c.bPhiw[b] / tauf / m.magSf[f]);
+    c.bG[b] = grad;
+    c.bPmid[b] = c.A[m.own[f]].p + grad / m.dn[f];
+}
+
+// ---------------------------------------------------------------------------
+// cell update: gather of the net face fluxes in ascending face order (the
+// summation order of fvc::surfaceIntegrate), explicit Euler, thermo, QGD coeffs
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(QGD_BLOCK) void cellUpdateKernel(const MeshView m, const CaseView c, const GasModel gm) {
+    const int ci = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    double rmin = 1e300, emin = 1e300;
+    if (ci < m.nC) {
+        double sum[5] = {0, 0, 0, 0, 0};
+        const int e0 = m.cfOff[ci], e1 = m.cfOff[ci + 1];
+        for (int e = e0; e < e1; ++e) {
+            const int it = m.cfItem[e];
+            const bool isOwner = it >= 0;
+            const double* fl = c.flux + 5 * (size_t)(isOwner ? it : ~it);
+#pragma unroll
+            for (int k = 0; k < 5; ++k) sum[k] = isOwner ? sum[k] + fl[k] : sum[k] - fl[k];
+        }
+        const RecA A = c.A[ci];
+        const Cons K = c.K[ci];
+        const double dtV = c.dt[0] / m.V[ci];
+        // QGDRhoEqn / QGDUEqn / QGDEEqn: explicit Euler on rho, rhoU, rhoE
+        const double rho = A.rho - dtV * sum[0];
+        Cons Kn;
+        Kn.rux = K.rux - dtV * sum[1];
+        Kn.ruy = K.ruy - dtV * sum[2];
+        Kn.ruz = K.ruz - dtV * sum[3];
+        Kn.rE = K.rE - dtV * sum[4];
+        // solve(fvm::ddt(rho,U) - fvc::ddt(rhoU)) [QGDUEqn_8H L79-86]
+        RecA An;
+        An.rho = rho;
+        An.ux = (A.rho * A.ux + (Kn.rux - K.rux)) / rho;
+        An.uy = (A.rho * A.uy + (Kn.ruy - K.ruy)) / rho;
+        An.uz = (A.rho * A.uz + (Kn.ruz - K.ruz)) / rho;
+        // solve(fvm::ddt(rho,e) - fvc::ddt(rhoE)) [QGDEEqn_8H L67-72], as written in the listing
+        An.e = (A.rho * A.e + (Kn.rE - K.rE)) / rho;
+        // thermo.correct(): eConst + perfectGas [hePsiQGDThermo_8C L48-64, L123-124]
+        const double T = An.e / gm.Cv;
+        const double psi = 1.0 / (gm.R * T);
+        const double cs = sqrt(gm.gamma / psi);
+        // constScPrModel1 [L103-115]: the pressure seen here is still the old one [QGDFoam_8C L149-154]
+        const double tauQGD = gm.alphaQGD * m.hQGD[ci] / cs;
+        RecB Bn;
+        Bn.muQGD = A.p * gm.ScQGD * tauQGD;
+        Bn.c = cs;
+        Bn.aOc = gm.alphaQGD / cs;
+        An.p = rho / psi;                  // [QGDFoam_8C L152-154]
+        Bn.H = (Kn.rE + An.p) / rho;       // H = (rhoE + p)/rho [QGDFoam/updateFields.H L71]
+        c.A[ci] = An;
+        c.B[ci] = Bn;
+        c.K[ci] = Kn;
+        if (!(m.ghost && m.ghost[ci])) { rmin = rho; emin = An.e; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        rmin = fmin(rmin, __shfl_down(rmin, off, 64));
+        emin = fmin(emin, __shfl_down(emin, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(reinterpret_cast<long long*>(c.red) + 2, dkey(rmin));
+        atomicMin(reinterpret_cast<long long*>(c.red) + 3, dkey(emin));
+    }
+}
+
+// createFields.H for the cells [QGDFoam_2createFields_8H L3-109]
+__global__ __launch_bounds__(QGD_BLOCK) void cellInitKernel(const MeshView m, const CaseView c, const GasModel gm,
+                                                           const double* __restrict__ U, const double* __restrict__ T,
+                                                           const double* __restrict__ p) {
+    const int ci = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    if (ci >= m.nC) return;
+    const double Tc = T[ci], pc = p[ci];
+    const double e = gm.Cv * Tc;
+    const double psi = 1.0 / (gm.R * Tc);
+    const double cs = sqrt(gm.gamma / psi);
+    const double rho = pc * psi;
+    RecA A;
+    A.rho = rho; A.ux = U[3 * (size_t)ci]; A.uy = U[3 * (size_t)ci + 1]; A.uz = U[3 * (size_t)ci + 2]; A.p = pc; A.e = e;
+    Cons K;
+    K.rux = rho * A.ux; K.ruy = rho * A.uy; K.ruz = rho * A.uz;
+    K.rE = rho * e + rho * 0.5 * (A.ux * A.ux + A.uy * A.uy + A.uz * A.uz);
+    RecB B;
+    const double tauQGD = gm.alphaQGD * m.hQGD[ci] / cs;
+    B.muQGD = pc * gm.ScQGD * tauQGD;
+    B.c = cs;
+    B.aOc = gm.alphaQGD / cs;
+    B.H = (K.rE + pc) / rho;
+    c.A[ci] = A; c.B[ci] = B; c.K[ci] = K;
+}
+
+// Boundary-condition refresh of every patch face, in the order the loop body
+// applies them: U, e, thermo patch values, QGD coefficients, p (qgdFlux), rho
+// [QGDUEqn_8H L51, QGDEEqn_8H L50, hePsiQGDThermo_8C L84-121, QGDFoam_8C L155-156]
+__global__ __launch_bounds__(QGD_BLOCK) void boundaryUpdateKernel(const MeshView m, const CaseView c, const GasModel gm,
+                                                                 const PatchBCDev* __restrict__ bcs, const int init,
+                                                                 const int phiwRegistered) {
+    const int b = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    if (b >= m.nBF) return;
+    const int f = m.nIF + b;
+    if (m.fkind[f] == 3) return;
+    const PatchBCDev bc = bcs[m.bPatch[b]];
+    const int o = m.own[f];
+    const RecA Ao = c.A[o];
+    RecA Ab;
+    // U
+    if (bc.bcU == QGD_BC_FIXEDVALUE) { Ab.ux = bc.vU[0]; Ab.uy = bc.vU[1]; Ab.uz = bc.vU[2]; }
+    else if (bc.bcU == QGD_BC_SLIP) {
+        const double ms = m.magSf[f];
+        const double n[3] = {m.Sx[f] / ms, m.Sy[f] / ms, m.Sz[f] / ms};
+        const double u[3] = {Ao.ux, Ao.uy, Ao.uz};
+        double r[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double tv = ((i == 0 ? 1.0 : 0.0) - 2.0 * (n[i] * n[0])) * u[0] + ((i == 1 ? 1.0 : 0.0) - 2.0 * (n[i] * n[1])) * u[1] +
+                              ((i == 2 ? 1.0 : 0.0) - 2.0 * (n[i] * n[2])) * u[2];
+            r[i] = (u[i] + tv) / 2.0;
+        }
+        Ab.ux = r[0]; Ab.uy = r[1]; Ab.uz = r[2];
+    } else { Ab.ux = Ao.ux; Ab.uy = Ao.uy; Ab.uz = Ao.uz; }
+    // e / T
+    double Tb;
+    if (bc.bcT == QGD_BC_FIXEDVALUE) { Tb = bc.vT; Ab.e = gm.Cv * Tb; }
+    else { Ab.e = Ao.e; Tb = Ab.e / gm.Cv; }
+    const double psi = 1.0 / (gm.R * Tb);
+    const double cs = sqrt(gm.gamma / psi);
+    RecB Bb;
+    Bb.c = cs;
+    Bb.aOc = gm.alphaQGD / cs;
+    // pressure seen by constScPrModel1 at thermo.correct(): the patch value before p's BC update
+    const double pOld = init ? ((bc.bcP == QGD_BC_FIXEDVALUE) ? bc.vP : Ao.p) : c.bPmid[b];
+    const double tauQGD = gm.alphaQGD * m.hQGDb[b] / cs;
+    Bb.muQGD = pOld * gm.ScQGD * tauQGD;
+    // p
+    if (bc.bcP == QGD_BC_FIXEDVALUE) Ab.p = bc.vP;
+    else if (bc.bcP == QGD_BC_QGDFLUX) {
+        double grad = init ? 0.0 : c.bG[b];
+        if (phiwRegistered) {
+            const double tauf = Bb.aOc * m.hf[f];
+            grad = -(c.bPhiw[b] / tauf / m.magSf[f]);  // [qgdFluxFvPatchScalarField_8C L184-192]
+        }
+        c.bG[b] = grad;
+        Ab.p = Ao.p + grad / m.dn[f];
+    } else Ab.p = Ao.p;
+    Ab.rho = init ? Ab.p * psi : psi * Ab.p;  // thermo.rho() at start-up, psi_b*p_b afterwards [QGDFoam_8C L156]
+    const double rE = init ? (Ab.rho * Ab.e + Ab.rho * 0.5 * (Ab.ux * Ab.ux + Ab.uy * Ab.uy + Ab.uz * Ab.uz))
+                           : (Ab.rho * (Ab.e + 0.5 * (Ab.ux * Ab.ux + Ab.uy * Ab.uy + Ab.uz * Ab.uz)));
+    Bb.H = (rE + Ab.p) / Ab.rho;
+    c.bA[b] = Ab;
+    c.bB[b] = Bb;
+    c.bPmid[b] = Ab.p;
+}
+
+// adjustTimeStep [setDeltaT-QGDQHD_8H L41-61]; one thread
+__device__ __forceinline__ double undkey(long long k) { return __longlong_as_double(k >= 0 ? k : (k ^ 0x7fffffffffffffffLL)); }
+__global__ void deltaTKernel(const CaseView c, const double maxCo, const double maxDeltaT, const double cTau, double* info) {
+    long long* r = reinterpret_cast<long long*>(c.red);
+    const double CoNum = undkey(r[0]);
+    const double minTau = undkey(r[1]);
+    const double maxDeltaTFact = maxCo / (CoNum + 1e-15);
+    const double deltaTFact = fmin(fmin(maxDeltaTFact, 1.0 + 0.1 * maxDeltaTFact), 1.2);
+    double maxDeltaT1 = cTau * minTau;
+    maxDeltaT1 = fmin(maxDeltaT, maxDeltaT1);
+    const double dt = fmin(deltaTFact * c.dt[0], maxDeltaT1);
+    c.dt[0] = dt;
+    c.dt[1] += dt;    // time
+    c.dt[2] = CoNum;
+    r[0] = dkey(-1e300);
+    r[1] = dkey(1e300);
+    if (info) { info[0] = dt; info[1] = CoNum; }
+}
+__global__ void resetReductionsKernel(const CaseView c) {
+    long long* r = reinterpret_cast<long long*>(c.red);
+    r[0] = dkey(-1e300); r[1] = dkey(1e300); r[2] = dkey(1e300); r[3] = dkey(1e300);
+}
+
+// halo message = 14 doubles per listed cell (RecA, RecB, Cons), then 11 per listed
+// boundary face (RecA, RecB, p gradient)
+__global__ __launch_bounds__(QGD_BLOCK) void haloKernel(const CaseView c, const int32_t* __restrict__ cells, const int nCells,
+                                                       const int32_t* __restrict__ bfaces, const int nFaces,
+                                                       double* __restrict__ buf, const int pack) {
+    const int i = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    if (i < nCells) {
+        const int ci = cells[i];
+        double* q = buf + 14 * (size_t)i;
+        if (pack) {
+            const RecA a = c.A[ci]; const RecB b = c.B[ci]; const Cons k = c.K[ci];
+            q[0] = a.rho; q[1] = a.ux; q[2] = a.uy; q[3] = a.uz; q[4] = a.p; q[5] = a.e; q[6] = b.H; q[7] = b.c; q[8] = b.muQGD; q[9] = b.aOc;
+            q[10] = k.rux; q[11] = k.ruy; q[12] = k.ruz; q[13] = k.rE;
+        } else {
+            RecA a; RecB b; Cons k;
+            a.rho = q[0]; a.ux = q[1]; a.uy = q[2]; a.uz = q[3]; a.p = q[4]; a.e = q[5]; b.H = q[6]; b.c = q[7]; b.muQGD = q[8]; b.aOc = q[9];
+            k.rux = q[10]; k.ruy = q[11]; k.ruz = q[12]; k.rE = q[13];
+            c.A[ci] = a; c.B[ci] = b; c.K[ci] = k;
+        }
+    } else if (i < nCells + nFaces) {
+        const int j = i - nCells;
+        const int bi = bfaces[j];
+        double* q = buf + 14 * (size_t)nCells + 11 * (size_t)j;
+        if (pack) {
+            const RecA a = c.bA[bi]; const RecB b = c.bB[bi];
+            q[0] = a.rho; q[1] = a.ux; q[2] = a.uy; q[3] = a.uz; q[4] = a.p; q[5] = a.e; q[6] = b.H; q[7] = b.c; q[8] = b.muQGD; q[9] = b.aOc;
+            q[10] = c.bG[bi];
+        } else {
+            RecA a; RecB b;
+            a.rho = q[0]; a.ux = q[1]; a.uy = q[2]; a.uz = q[3]; a.p = q[4]; a.e = q[5]; b.H = q[6]; b.c = q[7]; b.muQGD = q[8]; b.aOc = q[9];
+            c.bA[bi] = a; c.bB[bi] = b; c.bG[bi] = q[10]; c.bPmid[bi] = a.p;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// fvsc operators on plain NC-component fields (the four fvscStencil virtuals)
+// ---------------------------------------------------------------------------
+template <int ST, int NC, int OP>
+__global__ __launch_bounds__(QGD_BLOCK) void fvscOpKernel(const MeshView m, const double* __restrict__ cellF,
+                                                         const double* __restrict__ bndF, const double* __restrict__ ptF,
+                                                         double* __restrict__ out) {
+    const int f = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    if (f >= m.nF) return;
+    FaceVals<NC> v;
+    const int o = m.own[f];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) v.o[k] = cellF[(size_t)o * NC + k];
+    if (f < m.nIF) {
+        const int n = m.nei[f];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) { v.n[k] = cellF[(size_t)n * NC + k]; v.sn[k] = 0.0; }
+    } else {
+        const int b = f - m.nIF;
+        const double dc = m.dn[f];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) { v.n[k] = bndF[(size_t)b * NC + k]; v.sn[k] = dc * (v.n[k] - v.o[k]); }
+    }
+    double g[3 * NC];
+    // the vector-gradient operator (NC==3, OP==0) carries the interior-triangle pattern
+    faceGradient<ST, NC, (NC == 3 && OP == 0) ? 0 : -1>(m, f, v, cellF, ptF, g);
+    if (OP == 0) {
+#pragma unroll
+        for (int k = 0; k < 3 * NC; ++k) out[(size_t)f * 3 * NC + k] = g[k];
+    } else {
+        constexpr int NO = NC / 3;  // vector -> scalar, tensor -> vector: div_j = sum_i d_i T_ij
+#pragma unroll
+        for (int j = 0; j < NO; ++j) out[(size_t)f * NO + j] = g[0 * NC + 0 * NO + j] + g[1 * NC + 1 * NO + j] + g[2 * NC + 2 * NO + j];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+static inline int gridFor(int64_t n) { return (int)((n + QGD_BLOCK - 1) / QGD_BLOCK); }
+#define QGD_TIMED(L, k, stmt)            \
+    do {                                 \
+        if ((L).pre) (L).pre((L).ctx, k); \
+        stmt;                            \
+        if ((L).post) (L).post((L).ctx, k); \
+    } while (0)
+
+void launchPointInterp(const Launcher& L, const MeshView& m, const CaseView& c) {
+    if (m.nP == 0) return;
+    QGD_TIMED(L, QGD_K_POINT, (pointInterpKernel<6><<<gridFor(m.nP), QGD_BLOCK, 0, L.stream>>>(
+        m, reinterpret_cast<const double*>(c.A), 6, reinterpret_cast<double*>(c.P))));
+}
+void launchBoundaryPoints(const Launcher& L, const MeshView& m, const CaseView& c, bool pOnly) {
+    if (m.nBP == 0) return;
+    if (pOnly)
+        QGD_TIMED(L, QGD_K_POINT, (boundaryPointKernel<1><<<gridFor(m.nBP), QGD_BLOCK, 0, L.stream>>>(
+            m, c.bPmid, 1, reinterpret_cast<double*>(c.P), 6, 4)));
+    else
+        QGD_TIMED(L, QGD_K_POINT, (boundaryPointKernel<6><<<gridFor(m.nBP), QGD_BLOCK, 0, L.stream>>>(
+            m, reinterpret_cast<const double*>(c.bA), 6, reinterpret_cast<double*>(c.P), 6, 0)));
+}
+void launchPressureMidStep(const Launcher& L, const MeshView& m, const CaseView& c, const PatchBCDev* bc) {
+    if (m.nBF == 0) return;
+    QGD_TIMED(L, QGD_K_BC, (pressureMidStepKernel<<<gridFor(m.nBF), QGD_BLOCK, 0, L.stream>>>(m, c, bc)));
+}
+
+template <bool DBG>
+static void launchFaceFluxT(const Launcher& L, int stencil, const MeshView& m, const CaseView& c, const GasModel& g, bool adj) {
+    const int grid = gridFor(m.nIF);
+    if (grid == 0) return;
+    switch (stencil) {
+        case ST_REDUCED: faceFluxKernel<ST_REDUCED, DBG><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, adj); break;
+        case ST_LSQ: faceFluxKernel<ST_LSQ, DBG><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, adj); break;
+        case ST_GVP3: faceFluxKernel<ST_GVP3, DBG><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, adj); break;
+        default: faceFluxKernel<ST_GVP2, DBG><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, adj); break;
+    }
+}
+void launchFaceFlux(const Launcher& L, int stencil, const MeshView& m, const CaseView& c, const GasModel& g, bool adjustDt) {
+    QGD_TIMED(L, QGD_K_FACE, (c.dbg ? launchFaceFluxT<true>(L, stencil, m, c, g, adjustDt)
+                                    : launchFaceFluxT<false>(L, stencil, m, c, g, adjustDt)));
+}
+template <bool DBG>
+static void launchBFaceFluxT(const Launcher& L, int stencil, const MeshView& m, const CaseView& c, const GasModel& g,
+                             const PatchBCDev* bc, bool phiwOnly, bool adj) {
+    const int grid = gridFor(m.nBF);
+    if (grid == 0) return;
+    switch (stencil) {
+        case ST_REDUCED: boundaryFaceFluxKernel<ST_REDUCED, DBG><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, bc, phiwOnly, adj); break;
+        case ST_LSQ: boundaryFaceFluxKernel<ST_LSQ, DBG><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, bc, phiwOnly, adj); break;
+        case ST_GVP3: boundaryFaceFluxKernel<ST_GVP3, DBG><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, bc, phiwOnly, adj); break;
+        default: boundaryFaceFluxKernel<ST_GVP2, DBG><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, bc, phiwOnly, adj); break;
+    }
+}
+void launchBoundaryFaceFlux(const Launcher& L, int stencil, const MeshView& m, const CaseView& c, const GasModel& g,
+                            const PatchBCDev* bc, bool phiwOnly, bool adjustDt) {
+    QGD_TIMED(L, QGD_K_BFACE, (c.dbg && !phiwOnly ? launchBFaceFluxT<true>(L, stencil, m, c, g, bc, phiwOnly, adjustDt)
+                                                   : launchBFaceFluxT<false>(L, stencil, m, c, g, bc, phiwOnly, adjustDt)));
+}
+void launchCellUpdate(const Launcher& L, const MeshView& m, const CaseView& c, const GasModel& g) {
+    QGD_TIMED(L, QGD_K_CELL, (cellUpdateKernel<<<gridFor(m.nC), QGD_BLOCK, 0, L.stream>>>(m, c, g)));
+}
+void launchBoundaryUpdate(const Launcher& L, const MeshView& m, const CaseView& c, const GasModel& g, const PatchBCDev* bc,
+                          bool init, bool phiwRegistered) {
+    if (m.nBF == 0) return;
+    QGD_TIMED(L, QGD_K_BC, (boundaryUpdateKernel<<<gridFor(m.nBF), QGD_BLOCK, 0, L.stream>>>(m, c, g, bc, init, phiwRegistered)));
+}
+void launchCellInit(const Launcher& L, const MeshView& m, const CaseView& c, const GasModel& g, const double* U, const double* T,
+                    const double* p) {
+    cellInitKernel<<<gridFor(m.nC), QGD_BLOCK, 0, L.stream>>>(m, c, g, U, T, p);
+}
+void launchDeltaT(const Launcher& L, const CaseView& c, double maxCo, double maxDeltaT, double cTau, double* info) {
+    deltaTKernel<<<1, 1, 0, L.stream>>>(c, maxCo, maxDeltaT, cTau, info);
+}
+void launchResetReductions(const Launcher& L, const CaseView& c) { resetReductionsKernel<<<1, 1, 0, L.stream>>>(c); }
+void launchHaloPack(const Launcher& L, const CaseView& c, const int32_t* cells, int32_t nCells, const int32_t* bfaces,
+                    int32_t nFaces, double* buf, bool pack) {
+    const int n = nCells + nFaces;
+    if (n == 0) return;
+    haloKernel<<<gridFor(n), QGD_BLOCK, 0, L.stream>>>(c, cells, nCells, bfaces, nFaces, buf, pack ? 1 : 0);
+}
+
+template <int ST, int NC>
+static void launchFvscOpT(hipStream_t s, int op, const MeshView& m, const double* cell, const double* bnd, double* pt, double* out) {
+    if (ST == ST_GVP3 || ST == ST_GVP2) {
+        pointInterpKernel<NC><<<gridFor(m.nP), QGD_BLOCK, 0, s>>>(m, cell, NC, pt);
+        if (m.nBP) boundaryPointKernel<NC><<<gridFor(m.nBP), QGD_BLOCK, 0, s>>>(m, bnd, NC, pt, NC, 0);
+    }
+    if (op == 0) fvscOpKernel<ST, NC, 0><<<gridFor(m.nF), QGD_BLOCK, 0, s>>>(m, cell, bnd, pt, out);
+    else fvscOpKernel<ST, NC, (NC >= 3 ? 1 : 0)><<<gridFor(m.nF), QGD_BLOCK, 0, s>>>(m, cell, bnd, pt, out);
+}
+template <int ST>
+static void launchFvscOpS(hipStream_t s, int op, int NC, const MeshView& m, const double* cell, const double* bnd, double* pt, double* out) {
+    if (NC == 1) launchFvscOpT<ST, 1>(s, op, m, cell, bnd, pt, out);
+    else if (NC == 3) launchFvscOpT<ST, 3>(s, op, m, cell, bnd, pt, out);
+    else launchFvscOpT<ST, 9>(s, op, m, cell, bnd, pt, out);
+}
+void launchFvscOp(hipStream_t s, int stencil, int op, int NC, const MeshView& m, const double* cell, const double* bnd, double* pt,
+                  double* out) {
+    switch (stencil) {
+        case ST_REDUCED: launchFvscOpS<ST_REDUCED>(s, op, NC, m, cell, bnd, pt, out); break;
+        case ST_LSQ: launchFvscOpS<ST_LSQ>(s, op, NC, m, cell, bnd, pt, out); break;
+        case ST_GVP3: launchFvscOpS<ST_GVP3>(s, op, NC, m, cell, bnd, pt, out); break;
+        default: launchFvscOpS<ST_GVP2>(s, op, NC, m, cell, bnd, pt, out); break;
+    }
+}
+
+}  // namespace qgd

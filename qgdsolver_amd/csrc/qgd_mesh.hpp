@@ -1,0 +1,88 @@
+// qgd_mesh.hpp -- host-side polyMesh container of the MI355X QGD face-flux path.
+//
+// Flat arrays in OpenFOAM's own conventions (upper-triangular face order,
+// boundary faces grouped per patch, int32 labels, fp64 scalars), plus the
+// derived geometry the path needs: face area vectors/centres, cell
+// centres/volumes, linear interpolation weights, delta coefficients and the
+// CSR adjacency used by the kernels.  Nothing here touches the GPU.
+//
+// The geometry rules restate OpenFOAM v2312 (the release the reference pins in
+// /root/reference/README.md:32-37); OpenFOAM itself is not part of the
+// reference tree, so these are marked "L0 assumption" where they matter.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace qgd {
+
+struct Patch {
+    std::string name;
+    int32_t type = 0;   // QGD_PATCH_*
+    int32_t start = 0;  // global label of first face
+    int32_t size = 0;
+};
+
+struct HostMesh {
+    // ---- primitives (constant/polyMesh) -------------------------------------
+    int32_t nPoints = 0, nFaces = 0, nInternalFaces = 0, nCells = 0;
+    std::vector<double> points;        // 3*nPoints
+    std::vector<int32_t> faceOffsets;  // nFaces+1
+    std::vector<int32_t> facePoints;   // sum of face sizes
+    std::vector<int32_t> owner;        // nFaces
+    std::vector<int32_t> neighbour;    // nInternalFaces
+    std::vector<Patch> patches;
+
+    // ---- geometry -----------------------------------------------------------
+    std::vector<double> Sf, Cf;        // 3*nFaces
+    std::vector<double> magSf;         // nFaces
+    std::vector<double> C;             // 3*nCells
+    std::vector<double> V;             // nCells
+    std::vector<double> weights;       // nFaces  (boundary = 1)
+    std::vector<double> deltaCoeffs;   // nFaces  1/|d|   (patch-normal delta on boundary)
+    std::vector<double> nonOrthDeltaCoeffs;  // nFaces  1/max(n.d, 0.05|d|)
+    int32_t geometricD[3] = {1, 1, 1}; // -1 for the direction of empty patches
+    int32_t nGeometricD = 3;
+
+    // ---- cell-range sharding (slab halo) ------------------------------------
+    // side 0 = lower neighbour, side 1 = upper neighbour
+    std::vector<int32_t> haloGhost[2]; // local ghost cells refreshed from the neighbour
+    std::vector<int32_t> haloSend[2];  // local owned cells the neighbour needs
+    std::vector<uint8_t> cellIsGhost;  // nCells (empty when unsharded)
+
+    int32_t nBoundaryFaces() const { return nFaces - nInternalFaces; }
+    int32_t faceSize(int32_t f) const { return faceOffsets[f + 1] - faceOffsets[f]; }
+    int32_t patchOfFace(int32_t f) const;  // -1 for internal faces
+
+    // (re)compute Sf, Cf, C, V from points, then the derived coefficients
+    void computeGeometry();
+    // weights / deltaCoeffs / geometric directions from Sf, Cf, C
+    void computeDerived();
+    // sanity checks; returns empty string when consistent
+    std::string check() const;
+};
+
+// CSR adjacency derived from the primitives
+struct Csr {
+    std::vector<int32_t> offsets;
+    std::vector<int32_t> items;
+    int32_t rowSize(int32_t r) const { return offsets[r + 1] - offsets[r]; }
+};
+
+// point -> cells, each row in ascending cell label (OpenFOAM pointCells order)
+Csr buildPointCells(const HostMesh& m);
+// cell -> faces, ascending face label; used both for h_QGD and for the
+// deterministic flux gather (== summation order of fvc::surfaceIntegrate)
+Csr buildCellFaces(const HostMesh& m);
+// cell -> faces in OpenFOAM cells() order: owned faces ascending, then
+// neighbour faces ascending
+Csr buildCellFacesFoamOrder(const HostMesh& m);
+
+HostMesh makeBox(int32_t nx, int32_t ny, int32_t nzGlobal, int32_t kLo, int32_t kHi,
+                 const double lo[3], const double hi[3], const int32_t patchTypes[6]);
+HostMesh makeForwardStep(int32_t nx, int32_t ny, int32_t ixStep, int32_t iyStep,
+                         double lx, double ly, double lz);
+void jitterPoints(HostMesh& m, double amplitude, uint64_t seed);
+void splitQuads(HostMesh& m, int32_t stride);
+
+}  // namespace qgd

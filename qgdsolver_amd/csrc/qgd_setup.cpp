@@ -1,0 +1,405 @@
+// qgd_setup.cpp -- per-mesh static stencil tables (host side, built once).
+//
+// What each table restates (listing lines under /root/reference/docs/html/):
+//   GaussVolPoint 3-D coefficients   GaussVolPointBase3D_8C_source.html L161-476
+//   GaussVolPoint 2-D coefficients   GaussVolPointBase2D_8C_source.html L122-291
+//   leastSquares stencil + weights   extendedFaceStencilFindNeighbours_8C_source.html L41-86,
+//                                    extendedFaceStencilCalculateWeights_8C_source.html L43-155
+//   hQGDf / hQGD                     QGDCoeffs_8C_source.html L195-199, L298-376
+//   vertex interpolation weights     OpenFOAM volPointInterpolation (L0 assumption)
+#include "qgd_setup.hpp"
+
+#include <algorithm>
+#include <cmath>
+
+#include "../../include/qgd_amd.h"
+
+namespace qgd {
+
+namespace {
+inline double dot(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+inline double norm(const double* a) { return std::sqrt(dot(a, a)); }
+inline void cross(const double* a, const double* b, double* c) {
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+}  // namespace
+
+int64_t StaticData::bytes() const {
+    auto sz = [](auto& v) { return (int64_t)(v.size() * sizeof(v[0])); };
+    int64_t b = sz(own) + sz(nei) + sz(verts) + sz(fkind) + sz(magSf) + sz(w) + sz(hf) + sz(dn) + sz(coef) + sz(rV) +
+                sz(bmvON) + sz(ip13) + sz(c2d) + sz(lsqOff) + sz(lsqCell) + sz(lsqGw) + sz(lsqDeg) + sz(lsqBndZero) +
+                sz(pcOff) + sz(pcCell) + sz(pcW) + sz(bpPoint) + sz(bpOff) + sz(bpFace) + sz(bpW) + sz(cfOff) + sz(cfItem) +
+                sz(V) + sz(hQGD) + sz(ghost) + sz(bPatch) + sz(hQGDb);
+    for (int k = 0; k < 3; ++k) b += sz(Sf[k]);
+    return b;
+}
+
+StaticData buildStaticData(const HostMesh& m) {
+    StaticData s;
+    s.nP = m.nPoints; s.nF = m.nFaces; s.nIF = m.nInternalFaces; s.nC = m.nCells; s.nBF = m.nBoundaryFaces();
+    s.nGeomD = m.nGeometricD;
+    const int64_t nF = s.nF, nIF = s.nIF, nC = s.nC, nBF = s.nBF;
+
+    std::vector<int32_t> patchOf((size_t)nBF, -1);
+    std::vector<uint8_t> patchType((size_t)nBF, 0);
+    for (size_t p = 0; p < m.patches.size(); ++p)
+        for (int32_t f = m.patches[p].start; f < m.patches[p].start + m.patches[p].size; ++f) {
+            patchOf[f - nIF] = (int32_t)p;
+            patchType[f - nIF] = (uint8_t)m.patches[p].type;
+        }
+    s.bPatch = patchOf;
+    auto isRealPatchFace = [&](int64_t b) {
+        const int t = patchType[b];
+        return t != QGD_PATCH_EMPTY && t != QGD_PATCH_CYCLIC && t != QGD_PATCH_HALO;
+    };
+    auto hasFields = [&](int64_t b) { return patchType[b] != QGD_PATCH_EMPTY; };
+
+    // ---- faces: topology + streamed geometry --------------------------------
+    s.own = m.owner;
+    s.nei = m.neighbour;
+    s.verts.assign(4 * (size_t)nF, -1);
+    s.fkind.assign((size_t)nF, FK_QUAD);
+    for (int k = 0; k < 3; ++k) s.Sf[k].resize((size_t)nF);
+    s.magSf = m.magSf;
+    s.w = m.weights;
+    s.hf.assign((size_t)nF, 0.0);
+    s.dn.assign((size_t)nF, 0.0);
+    bool hasTri = false;
+    for (int64_t f = 0; f < nF; ++f) {
+        const int n = m.faceSize((int32_t)f);
+        if (n == 3) hasTri = true;
+    }
+    s.hasTri = hasTri;
+    s.ncoef = hasTri ? 12 : 9;
+    const int ncoef = s.ncoef;
+    const bool want3D = (m.nGeometricD == 3);
+    if (want3D) {
+        s.coef.assign((size_t)ncoef * nF, 0.0);
+        s.rV.assign((size_t)nF, 0.0);
+        s.bmvON.assign((size_t)nBF, 0.0);
+    }
+    const double sixth = (1.0 / 6.0);
+
+#pragma omp parallel for schedule(static)
+    for (int64_t f = 0; f < nF; ++f) {
+        const int32_t* fp = &m.facePoints[m.faceOffsets[f]];
+        const int n = m.faceSize((int32_t)f);
+        for (int k = 0; k < 3; ++k) s.Sf[k][f] = m.Sf[3 * f + k];
+        const int32_t o = m.owner[f];
+        const double* O = &m.C[3 * (size_t)o];
+        const double* cf = &m.Cf[3 * f];
+        double Nbuf[3];
+        const double* N;
+        bool skip = false;
+        if (f < nIF) {
+            N = &m.C[3 * (size_t)m.neighbour[f]];
+            double a[3], b[3];
+            for (int k = 0; k < 3; ++k) { a[k] = O[k] - cf[k]; b[k] = N[k] - cf[k]; }
+            s.hf[f] = 2.0 * std::min(norm(a), norm(b));
+            s.dn[f] = m.nonOrthDeltaCoeffs[f];
+        } else {
+            const int64_t b = f - nIF;
+            // mirror point C_O + 2 (C_f - C_O)   [GaussVolPointBase3D.C L142-147]
+            for (int k = 0; k < 3; ++k) Nbuf[k] = O[k] + 2.0 * (cf[k] - O[k]);
+            N = Nbuf;
+            skip = !hasFields(b);
+            const double hb = (m.deltaCoeffs[f] != 0.0) ? 1.0 / std::fabs(m.deltaCoeffs[f]) : 0.0;
+            const bool coupled = patchType[b] == QGD_PATCH_CYCLIC || patchType[b] == QGD_PATCH_HALO;
+            s.hf[f] = coupled ? hb : hb * 2.0;
+            s.dn[f] = m.deltaCoeffs[f];
+            if (want3D) {
+                double d[3];
+                for (int k = 0; k < 3; ++k) d[k] = O[k] - N[k];
+                s.bmvON[b] = norm(d);
+            }
+        }
+        uint8_t kind = (n == 4) ? FK_QUAD : (n == 3 ? FK_TRI : FK_OTHER);
+        if (skip) kind = FK_SKIP;
+        s.fkind[f] = kind;
+        for (int q = 0; q < std::min(n, 4); ++q) s.verts[4 * f + q] = fp[q];
+        if (!want3D || kind == FK_SKIP || kind == FK_OTHER) continue;
+        const double* p1 = &m.points[3 * (size_t)fp[0]];
+        const double* p2 = &m.points[3 * (size_t)fp[1]];
+        const double* p3 = &m.points[3 * (size_t)fp[2]];
+        if (kind == FK_QUAD) {
+            const double* p4 = &m.points[3 * (size_t)fp[3]];
+            double d31[3], d42[3], on[3], cr[3];
+            for (int k = 0; k < 3; ++k) { d31[k] = p3[k] - p1[k]; d42[k] = p4[k] - p2[k]; on[k] = O[k] - N[k]; }
+            cross(d42, on, cr);
+            double vol = dot(d31, cr);
+            vol *= sixth;
+            s.rV[f] = 1.0 / vol;
+            const int stride = hasTri ? 4 : 3;
+            for (int d = 0; d < 3; ++d) {
+                const int u = (d + 1) % 3, v = (d + 2) % 3;
+                const double a0 = sixth * ((N[u] - O[u]) * (p2[v] - p4[v]) - (N[v] - O[v]) * (p2[u] - p4[u]));
+                const double a1 = sixth * ((N[u] - O[u]) * (p3[v] - p1[v]) - (N[v] - O[v]) * (p3[u] - p1[u]));
+                const double a5 = sixth * ((p1[u] - p3[u]) * (p2[v] - p4[v]) - (p1[v] - p3[v]) * (p2[u] - p4[u]));
+                s.coef[(size_t)(d * stride + 0) * nF + f] = a0;
+                s.coef[(size_t)(d * stride + 1) * nF + f] = a1;
+                s.coef[(size_t)(d * stride + 2) * nF + f] = a5;
+            }
+        } else {  // FK_TRI: slots a0,a1,a2 (vertices), a3 (neighbour); owner = -a3
+            double e21[3], e31[3], on[3], cr[3];
+            for (int k = 0; k < 3; ++k) { e21[k] = p2[k] - p1[k]; e31[k] = p3[k] - p1[k]; on[k] = O[k] - N[k]; }
+            cross(e21, e31, cr);
+            double vol = dot(cr, on);
+            vol *= sixth;
+            s.rV[f] = 1.0 / vol;
+            for (int d = 0; d < 3; ++d) {
+                const int u = (d + 1) % 3, v = (d + 2) % 3;
+                const double a0 = sixth * ((O[v] - N[v]) * (p2[u] - p3[u]) + (N[u] - O[u]) * (p2[v] - p3[v]));
+                const double a1 = sixth * ((N[u] - O[u]) * (p3[v] - p1[v]) + (O[v] - N[v]) * (p3[u] - p1[u]));
+                const double a2 = sixth * ((N[u] - O[u]) * (p1[v] - p2[v]) + (O[v] - N[v]) * (p1[u] - p2[u]));
+                const double a3 = sixth * (p1[v] * (p2[u] - p3[u]) + p2[v] * (p3[u] - p1[u]) + p3[v] * (p1[u] - p2[u]));
+                s.coef[(size_t)(d * 4 + 0) * nF + f] = a0;
+                s.coef[(size_t)(d * 4 + 1) * nF + f] = a1;
+                s.coef[(size_t)(d * 4 + 2) * nF + f] = a2;
+                s.coef[(size_t)(d * 4 + 3) * nF + f] = a3;
+            }
+        }
+    }
+
+    // ---- GaussVolPoint 2-D -----------------------------------------------------
+    if (m.nGeometricD == 2) {
+        int ie3 = 2;
+        for (int d = 0; d < 3; ++d) if (m.geometricD[d] < 1) ie3 = d;
+        const int ie1 = (ie3 == 0) ? 1 : 0;
+        const int ie2 = (ie3 == 2) ? 1 : 2;
+        s.ie1 = ie1; s.ie2 = ie2; s.ie3 = ie3;
+        s.ip13.assign(2 * (size_t)nF, -1);
+        s.c2d.assign(6 * (size_t)nF, 0.0);
+        for (int64_t f = 0; f < nF; ++f) {
+            const int32_t o = m.owner[f];
+            const int32_t* fp = &m.facePoints[m.faceOffsets[f]];
+            const int n = m.faceSize((int32_t)f);
+            double v42[3];
+            int32_t refCell;
+            if (f < nIF) {
+                const int32_t nb = m.neighbour[f];
+                for (int k = 0; k < 3; ++k) v42[k] = m.C[3 * (size_t)nb + k] - m.C[3 * (size_t)o + k];
+                refCell = nb;  // vertices are picked against the NEIGHBOUR centre [2D.C L129-147]
+            } else {
+                const int t = patchType[f - nIF];
+                if (t == QGD_PATCH_EMPTY || t == QGD_PATCH_WEDGE || t == QGD_PATCH_CYCLIC) { s.fkind[f] = FK_SKIP; continue; }
+                for (int k = 0; k < 3; ++k) v42[k] = 2.0 * (m.Cf[3 * f + k] - m.C[3 * (size_t)o + k]);
+                refCell = o;
+            }
+            int32_t q1 = -1, q3 = -1;
+            const double zref = m.C[3 * (size_t)refCell + ie3];
+            for (int k = 0; k < n; ++k) if (m.points[3 * (size_t)fp[k] + ie3] >= zref) { q1 = fp[k]; break; }
+            for (int k = 0; k < n; ++k) if (m.points[3 * (size_t)fp[k] + ie3] >= zref && fp[k] != q1) { q3 = fp[k]; break; }
+            if (q1 < 0 || q3 < 0) { s.fkind[f] = FK_SKIP; continue; }
+            s.ip13[2 * f] = q1; s.ip13[2 * f + 1] = q3;
+            double v13[3];
+            for (int k = 0; k < 3; ++k) v13[k] = m.points[3 * (size_t)q3 + k] - m.points[3 * (size_t)q1 + k];
+            const double m42 = norm(v42), m13 = norm(v13);
+            // e1/e2 are coordinate axes, so the dot products are single components
+            const double cosa1 = v42[ie1] / m42, cosa2 = v13[ie1] / m13;
+            const double sina1 = v42[ie2] / m42, sina2 = v13[ie2] / m13;
+            const double den = sina2 * cosa1 - sina1 * cosa2;
+            s.c2d[0 * nF + f] = sina2 / den;
+            s.c2d[1 * nF + f] = sina1 / den;
+            s.c2d[2 * nF + f] = cosa1 / den;
+            s.c2d[3 * nF + f] = cosa2 / den;
+            s.c2d[4 * nF + f] = m42;
+            s.c2d[5 * nF + f] = m13;
+        }
+    }
+
+    // ---- adjacency ---------------------------------------------------------------
+    Csr pc = buildPointCells(m);
+
+    // ---- leastSquares (allowed on 1-D/2-D meshes only [fvsc.C L60-63]) -------
+    s.lsqBndZero.assign((size_t)nBF, 0);
+    for (int64_t b = 0; b < nBF; ++b) {
+        const int t = patchType[b];
+        s.lsqBndZero[b] = (t == QGD_PATCH_EMPTY || t == QGD_PATCH_WEDGE || t == QGD_PATCH_CYCLIC || t == QGD_PATCH_HALO ||
+                           t == QGD_PATCH_SYMMETRY || t == QGD_PATCH_SYMMETRYPLANE) ? 1 : 0;
+    }
+    if (m.nGeometricD < 3) {
+        s.lsqOff.assign((size_t)nIF + 1, 0);
+        s.lsqDeg.assign((size_t)nIF, 0);
+        std::vector<int32_t> nb;
+        for (int64_t f = 0; f < nIF; ++f) {
+            nb.clear();
+            for (int32_t q = m.faceOffsets[f]; q < m.faceOffsets[f + 1]; ++q) {
+                const int32_t pt = m.facePoints[q];
+                for (int32_t k = pc.offsets[pt]; k < pc.offsets[pt + 1]; ++k) {
+                    const int32_t c = pc.items[k];
+                    if (std::find(nb.begin(), nb.end(), c) == nb.end()) nb.push_back(c);
+                }
+            }
+            // weights
+            double G[6] = {0, 0, 0, 0, 0, 0};
+            std::vector<double> d(3 * nb.size()), w2(nb.size());
+            for (size_t i = 0; i < nb.size(); ++i) {
+                for (int k = 0; k < 3; ++k) d[3 * i + k] = m.C[3 * (size_t)nb[i] + k] - m.Cf[3 * f + k];
+                const double* x = &d[3 * i];
+                w2[i] = 1 / (x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+                G[0] += (x[0] * x[0]) * w2[i]; G[1] += (x[0] * x[1]) * w2[i]; G[2] += (x[0] * x[2]) * w2[i];
+                G[3] += (x[1] * x[1]) * w2[i]; G[4] += (x[1] * x[2]) * w2[i]; G[5] += (x[2] * x[2]) * w2[i];
+            }
+            double G0[6] = {0, 0, 0, 0, 0, 0};
+            if (std::fabs(G[0]) < 1e-15) G0[0] = 1;
+            if (std::fabs(G[3]) < 1e-15) G0[3] = 1;
+            if (std::fabs(G[5]) < 1e-15) G0[5] = 1;
+            for (int k = 0; k < 6; ++k) G[k] = G[k] + G0[k];
+            const double det = G[0] * G[3] * G[5] + G[1] * G[4] * G[2] + G[2] * G[1] * G[4] - G[0] * G[4] * G[4] -
+                               G[1] * G[1] * G[5] - G[2] * G[3] * G[2];
+            if (det < 1) {
+                s.lsqDeg[f] = 1;  // G stays un-inverted; the face falls back to nf*snGrad [ScalarGrad.C L76-83]
+            } else {
+                const double I[6] = {(G[3] * G[5] - G[4] * G[4]) / det, (G[2] * G[4] - G[1] * G[5]) / det,
+                                     (G[1] * G[4] - G[2] * G[3]) / det, (G[0] * G[5] - G[2] * G[2]) / det,
+                                     (G[1] * G[2] - G[0] * G[4]) / det, (G[0] * G[3] - G[1] * G[1]) / det};
+                for (int k = 0; k < 6; ++k) G[k] = I[k] - G0[k];
+            }
+            for (size_t i = 0; i < nb.size(); ++i) {
+                const double* x = &d[3 * i];
+                const double g[3] = {G[0] * x[0] + G[1] * x[1] + G[2] * x[2], G[1] * x[0] + G[3] * x[1] + G[4] * x[2],
+                                     G[2] * x[0] + G[4] * x[1] + G[5] * x[2]};
+                s.lsqCell.push_back(nb[i]);
+                for (int k = 0; k < 3; ++k) s.lsqGw.push_back(w2[i] * g[k]);
+            }
+            s.lsqOff[f + 1] = (int32_t)s.lsqCell.size();
+        }
+    }
+
+    // ---- vertex interpolation ------------------------------------------------------
+    std::vector<uint8_t> isPatchPoint((size_t)m.nPoints, 0);
+    for (int64_t b = 0; b < nBF; ++b) {
+        if (!isRealPatchFace(b)) continue;
+        const int64_t f = nIF + b;
+        for (int32_t q = m.faceOffsets[f]; q < m.faceOffsets[f + 1]; ++q) isPatchPoint[m.facePoints[q]] = 1;
+    }
+    s.pcOff.assign((size_t)m.nPoints + 1, 0);
+    for (int32_t p = 0; p < m.nPoints; ++p)
+        s.pcOff[p + 1] = s.pcOff[p] + (isPatchPoint[p] ? 0 : pc.rowSize(p));
+    s.pcCell.resize((size_t)s.pcOff[m.nPoints]);
+    s.pcW.resize((size_t)s.pcOff[m.nPoints]);
+#pragma omp parallel for schedule(static)
+    for (int32_t p = 0; p < m.nPoints; ++p) {
+        if (isPatchPoint[p]) continue;
+        const int32_t n = pc.rowSize(p);
+        int32_t* cells = &s.pcCell[s.pcOff[p]];
+        double* w = &s.pcW[s.pcOff[p]];
+        double sum = 0;
+        for (int32_t i = 0; i < n; ++i) {
+            const int32_t c = pc.items[pc.offsets[p] + i];
+            double d[3];
+            for (int k = 0; k < 3; ++k) d[k] = m.points[3 * (size_t)p + k] - m.C[3 * (size_t)c + k];
+            cells[i] = c;
+            w[i] = 1.0 / norm(d);
+            sum += w[i];
+        }
+        for (int32_t i = 0; i < n; ++i) w[i] /= sum;
+    }
+    {
+        // patch points: boundary faces around each, ascending boundary-face label
+        std::vector<int32_t> cnt((size_t)m.nPoints, 0);
+        for (int64_t b = 0; b < nBF; ++b) {
+            if (!isRealPatchFace(b)) continue;
+            const int64_t f = nIF + b;
+            for (int32_t q = m.faceOffsets[f]; q < m.faceOffsets[f + 1]; ++q) cnt[m.facePoints[q]]++;
+        }
+        std::vector<int32_t> slot((size_t)m.nPoints, -1);
+        s.bpOff.push_back(0);
+        for (int32_t p = 0; p < m.nPoints; ++p)
+            if (isPatchPoint[p]) {
+                slot[p] = (int32_t)s.bpPoint.size();
+                s.bpPoint.push_back(p);
+                s.bpOff.push_back(s.bpOff.back() + cnt[p]);
+            }
+        s.bpFace.resize((size_t)s.bpOff.back());
+        s.bpW.resize((size_t)s.bpOff.back());
+        std::vector<int32_t> fill(s.bpOff.begin(), s.bpOff.end() - 1);
+        for (int64_t b = 0; b < nBF; ++b) {
+            if (!isRealPatchFace(b)) continue;
+            const int64_t f = nIF + b;
+            for (int32_t q = m.faceOffsets[f]; q < m.faceOffsets[f + 1]; ++q) {
+                const int32_t p = m.facePoints[q];
+                const int32_t k = fill[slot[p]]++;
+                s.bpFace[k] = (int32_t)b;
+                double d[3];
+                for (int j = 0; j < 3; ++j) d[j] = m.points[3 * (size_t)p + j] - m.Cf[3 * f + j];
+                s.bpW[k] = 1.0 / norm(d);
+            }
+        }
+        for (size_t i = 0; i < s.bpPoint.size(); ++i) {
+            double sum = 0;
+            for (int32_t k = s.bpOff[i]; k < s.bpOff[i + 1]; ++k) sum += s.bpW[k];
+            for (int32_t k = s.bpOff[i]; k < s.bpOff[i + 1]; ++k) s.bpW[k] /= sum;
+        }
+    }
+
+    // ---- cells ---------------------------------------------------------------------
+    s.V = m.V;
+    {
+        // flux gather list: ascending face label == summation order of
+        // fvc::surfaceIntegrate for that cell (upper-triangular face order)
+        Csr cf = buildCellFaces(m);
+        s.cfOff.assign((size_t)nC + 1, 0);
+        auto keep = [&](int32_t f) {
+            if (f < nIF) return true;
+            const int t = patchType[f - nIF];
+            return t != QGD_PATCH_EMPTY && t != QGD_PATCH_HALO;
+        };
+        for (int64_t c = 0; c < nC; ++c) {
+            int32_t n = 0;
+            for (int32_t k = cf.offsets[c]; k < cf.offsets[c + 1]; ++k) if (keep(cf.items[k])) ++n;
+            s.cfOff[c + 1] = s.cfOff[c] + n;
+        }
+        s.cfItem.resize((size_t)s.cfOff[nC]);
+#pragma omp parallel for schedule(static)
+        for (int64_t c = 0; c < nC; ++c) {
+            int32_t o = s.cfOff[c];
+            for (int32_t k = cf.offsets[c]; k < cf.offsets[c + 1]; ++k) {
+                const int32_t f = cf.items[k];
+                if (!keep(f)) continue;
+                s.cfItem[o++] = (m.owner[f] == c) ? f : ~f;
+            }
+        }
+        // hQGD: area-weighted mean of hQGDf over the cell's faces, OpenFOAM
+        // cells() order, skipping empty/wedge patches [QGDCoeffs.C L323-362]
+        Csr cfo = buildCellFacesFoamOrder(m);
+        s.hQGD.assign((size_t)nC, 0.0);
+#pragma omp parallel for schedule(static)
+        for (int64_t c = 0; c < nC; ++c) {
+            double hint = 0, surf = 0;
+            for (int32_t k = cfo.offsets[c]; k < cfo.offsets[c + 1]; ++k) {
+                const int32_t f = cfo.items[k];
+                if (f >= nIF) {
+                    const int t = patchType[f - nIF];
+                    if (t == QGD_PATCH_EMPTY || t == QGD_PATCH_WEDGE) continue;
+                }
+                hint += s.hf[f] * m.magSf[f];
+                surf += m.magSf[f];
+            }
+            s.hQGD[c] = hint / surf;
+        }
+    }
+    s.hQGDb.assign((size_t)nBF, 0.0);
+    for (int64_t b = 0; b < nBF; ++b) s.hQGDb[b] = s.hf[nIF + b] * 1.0;
+    s.ghost = m.cellIsGhost;
+
+    // ---- halo lists (cells + their real-patch boundary faces, ascending) -----
+    for (int side = 0; side < 2; ++side) {
+        s.haloGhost[side] = m.haloGhost[side];
+        s.haloSend[side] = m.haloSend[side];
+        std::vector<uint8_t> isG((size_t)nC, 0), isS((size_t)nC, 0);
+        for (int32_t c : m.haloGhost[side]) isG[c] = 1;
+        for (int32_t c : m.haloSend[side]) isS[c] = 1;
+        for (int64_t b = 0; b < nBF; ++b) {
+            if (patchType[b] == QGD_PATCH_HALO) continue;
+            const int32_t o = m.owner[nIF + b];
+            if (isG[o]) s.haloGhostBF[side].push_back((int32_t)b);
+            if (isS[o]) s.haloSendBF[side].push_back((int32_t)b);
+        }
+    }
+    return s;
+}
+
+}  // namespace qgd

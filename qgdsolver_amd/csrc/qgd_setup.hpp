@@ -1,0 +1,80 @@
+// qgd_setup.hpp -- static, per-mesh stencil data in the flat layouts the HIP
+// kernels stream (built once on the host, uploaded by qgd_device_create).
+//
+// Layout rules (DESIGN.md "Data layout in HBM"):
+//  * every per-face array is indexed by the GLOBAL face label (internal faces
+//    first, then boundary faces) so internal- and boundary-face kernels share it
+//  * streamed per-face data is SoA (one array per scalar) for coalesced loads
+//  * gathered per-cell / per-vertex data is AoS records (one record = one
+//    contiguous 16-B aligned chunk)
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "qgd_mesh.hpp"
+
+namespace qgd {
+
+enum FaceKind : uint8_t { FK_QUAD = 0, FK_TRI = 1, FK_OTHER = 2, FK_SKIP = 3 };
+
+struct StaticData {
+    int32_t nP = 0, nF = 0, nIF = 0, nC = 0, nBF = 0;
+    int32_t nGeomD = 3, ie1 = 0, ie2 = 1, ie3 = 2;
+    bool hasTri = false;
+
+    // ---- faces --------------------------------------------------------------
+    std::vector<int32_t> own;     // nF
+    std::vector<int32_t> nei;     // nIF
+    std::vector<int32_t> verts;   // 4*nF (tri: [3] = -1)
+    std::vector<uint8_t> fkind;   // nF
+    std::vector<double> Sf[3];    // nF each
+    std::vector<double> magSf;    // nF
+    std::vector<double> w;        // nF linear weights
+    std::vector<double> hf;       // nF hQGDf
+    std::vector<double> dn;       // nF: nonOrthDeltaCoeffs (internal), deltaCoeffs (boundary)
+    // GaussVolPoint 3-D: ncoef = 9 (all quads: a0,a1,a5 per direction) or 12
+    // (with triangles: a0,a1,a2,a3 per direction; quads use slots 0,1,2 = a0,a1,a5)
+    int32_t ncoef = 9;
+    std::vector<double> coef;     // ncoef*nF, coef[k*nF + f]
+    std::vector<double> rV;       // nF: 1/V_f
+    std::vector<double> bmvON;    // nBF
+    // GaussVolPoint 2-D
+    std::vector<int32_t> ip13;    // 2*nF (ip1, ip3)
+    std::vector<double> c2d;      // 6*nF: c1,c2,c3,c4,mv42,mv13 (SoA: [k*nF+f])
+    // leastSquares (internal faces)
+    std::vector<int32_t> lsqOff;  // nIF+1
+    std::vector<int32_t> lsqCell;
+    std::vector<double> lsqGw;    // 3 per entry: wf2*Gdf
+    std::vector<uint8_t> lsqDeg;  // nIF
+    std::vector<uint8_t> lsqBndZero;  // nBF: 1 on constraint patches (gradient left zero)
+
+    // ---- points -------------------------------------------------------------
+    std::vector<int32_t> pcOff;   // nP+1 (patch points have empty rows)
+    std::vector<int32_t> pcCell;
+    std::vector<double> pcW;
+    std::vector<int32_t> bpPoint; // patch points
+    std::vector<int32_t> bpOff;   // bpPoint.size()+1
+    std::vector<int32_t> bpFace;  // boundary-face index (global label - nIF)
+    std::vector<double> bpW;
+
+    // ---- cells --------------------------------------------------------------
+    std::vector<int32_t> cfOff;   // nC+1: flux gather list, ascending face label
+    std::vector<int32_t> cfItem;  // f (owner, +) or ~f (neighbour, -); empty/halo faces left out
+    std::vector<double> V;        // nC
+    std::vector<double> hQGD;     // nC
+    std::vector<uint8_t> ghost;   // nC (may be empty)
+
+    // ---- boundary faces -----------------------------------------------------
+    std::vector<int32_t> bPatch;  // nBF patch index
+    std::vector<double> hQGDb;    // nBF: hQGD boundary (= hQGDf boundary)
+
+    // ---- halo -----------------------------------------------------------------
+    std::vector<int32_t> haloGhost[2], haloSend[2], haloGhostBF[2], haloSendBF[2];
+
+    int64_t bytes() const;
+};
+
+// build every table above; `needLsq` / `needGvp2` are derived from nGeometricD
+StaticData buildStaticData(const HostMesh& m);
+
+}  // namespace qgd

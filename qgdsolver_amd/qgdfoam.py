@@ -1,0 +1,172 @@
+"""Host-side mirror of the QGDFoam loop pieces over the C-ABI.
+
+``QGDFoamCase`` holds what createFields.H / createFaceFields.H / createFaceFluxes.H
+create; ``updateFluxes()`` is updateFields.H + updateFluxes.H; ``step()`` is the
+``while (runTime.run())`` body (QGDFoam.C L90-163).  ``thermo`` exposes the
+QGDThermo accessor names (QGDThermo.H L99-135).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+_VECTOR_FIELDS = {"U": 3, "rhoU": 3, "phiJmU": 3, "phiP": 3, "phiPi": 3, "gradUf": 9, "gradef": 3, "gradRhof": 3, "gradPf": 3}
+_FACE_FIELDS = {"phiJm", "phiJmU", "phiP", "phiPi", "phiJmH", "phiQ", "phiPiU", "phiwStar", "phi", "tauQGDf", "hQGDf",
+                "gradUf", "gradef", "gradRhof", "gradPf"}
+
+STENCIL_IDS = {"reduced": L.FVSC_REDUCED, "leastSquares": L.FVSC_LEASTSQUARES, "leastSquaresOpt": L.FVSC_LEASTSQUARES,
+               "GaussVolPoint": L.FVSC_GAUSSVOLPOINT}
+
+
+def default_options(**kw):
+    o = L.CaseOptions()
+    L.check(L.lib.qgd_case_options_default(C.byref(o)), "qgd_case_options_default")
+    for k, v in kw.items():
+        if k == "stencil" and isinstance(v, str):
+            v = STENCIL_IDS[v]
+        setattr(o, k, v)
+    return o
+
+
+class QGDThermo:
+    """Accessor surface of QGDThermo (QGDThermo.H L99-135)."""
+
+    def __init__(self, case):
+        self._c = case
+
+    def tauQGDf(self):
+        return self._c.field("tauQGDf")
+
+    def hQGDf(self):
+        return self._c.field("hQGDf")
+
+    def tauQGD(self):
+        return self._c.field("tauQGD")
+
+    def hQGD(self):
+        return self._c.field("hQGD")
+
+    def muQGD(self):
+        return self._c.field("muQGD")
+
+    def alphauQGD(self):
+        return self._c.field("alphauQGD")
+
+    def c(self):
+        return self._c.field("c")
+
+    def p(self):
+        return self._c.field("p")
+
+    def rho(self):
+        return self._c.field("rho")
+
+    def mu(self):
+        return self._c.field("mu")
+
+    def implicitDiffusion(self):
+        return bool(self._c.options.implicitDiffusion)
+
+
+class QGDFoamCase:
+    def __init__(self, dev, options=None):
+        self.dev = dev
+        self.mesh = dev.mesh
+        self.options = options if options is not None else default_options()
+        h = C.c_void_p()
+        L.check(L.lib.qgd_case_create(dev._h, C.byref(self.options), C.byref(h)), "qgd_case_create")
+        self._h = h
+        self.thermo = QGDThermo(self)
+
+    def set_bc(self, patch, U=("zeroGradient", None), T=("zeroGradient", None), p=("zeroGradient", None)):
+        kinds = {"zeroGradient": L.BC_ZEROGRADIENT, "fixedValue": L.BC_FIXEDVALUE, "slip": L.BC_SLIP, "qgdFlux": L.BC_QGDFLUX,
+                 "none": L.BC_NONE}
+        vu = np.asarray(U[1] if U[1] is not None else (0.0, 0.0, 0.0), dtype=np.float64)
+        L.check(L.lib.qgd_case_set_bc(self._h, patch, kinds[U[0]], vu.ctypes.data_as(L.c_double_p), kinds[T[0]],
+                                      float(T[1] or 0.0), kinds[p[0]], float(p[1] or 0.0)), "qgd_case_set_bc")
+
+    def set_fields(self, U, T, p):
+        U = np.ascontiguousarray(U, dtype=np.float64)
+        T = np.ascontiguousarray(T, dtype=np.float64)
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        assert U.size == 3 * self.mesh.nCells and T.size == self.mesh.nCells and p.size == self.mesh.nCells
+        L.check(L.lib.qgd_case_set_fields(self._h, U.ctypes.data_as(L.c_double_p), T.ctypes.data_as(L.c_double_p),
+                                          p.ctypes.data_as(L.c_double_p)), "qgd_case_set_fields")
+
+    def updateFluxes(self):
+        L.check(L.lib.qgd_case_update_fluxes(self._h), "qgd_case_update_fluxes")
+
+    def step(self, n=1):
+        L.check(L.lib.qgd_case_step(self._h, int(n)), "qgd_case_step")
+
+    def step_phase(self, phase):
+        L.check(L.lib.qgd_case_step_phase(self._h, int(phase)), "qgd_case_step_phase")
+
+    def set_stream(self, raw_stream):
+        """Run on a caller-owned hipStream_t (e.g. ``torch.cuda.current_stream().cuda_stream``)."""
+        L.check(L.lib.qgd_case_set_stream(self._h, C.c_void_p(raw_stream)), "qgd_case_set_stream")
+
+    def sync(self):
+        L.check(L.lib.qgd_case_stream_sync(self._h), "qgd_case_stream_sync")
+
+    def field(self, name):
+        base = name[:-len(".boundary")] if name.endswith(".boundary") else name
+        nc = _VECTOR_FIELDS.get(base, 1)
+        if name.endswith(".boundary"):
+            n = self.mesh.nBoundaryFaces
+        elif base in _FACE_FIELDS:
+            n = self.mesh.nFaces
+        else:
+            n = self.mesh.nCells
+        out = np.zeros((n, nc) if nc > 1 else (n,), dtype=np.float64)
+        if n:
+            L.check(L.lib.qgd_case_get_field(self._h, name.encode(), out.ctypes.data_as(L.c_double_p), out.size),
+                    f"qgd_case_get_field({name})")
+        return out
+
+    def info(self):
+        a = (C.c_double * 6)()
+        L.check(L.lib.qgd_case_info(self._h, a), "qgd_case_info")
+        return dict(time=a[0], deltaT=a[1], CoNum=a[2], minRho=a[3], minE=a[4], steps=int(a[5]))
+
+    # ---- halo ------------------------------------------------------------------
+    def halo_count(self, side):
+        n = C.c_int64()
+        L.check(L.lib.qgd_case_halo_count(self._h, side, C.byref(n)), "qgd_case_halo_count")
+        return n.value
+
+    def halo_pack(self, side, dev_ptr):
+        L.check(L.lib.qgd_case_halo_pack(self._h, side, C.c_void_p(dev_ptr)), "qgd_case_halo_pack")
+
+    def halo_unpack(self, side, dev_ptr):
+        L.check(L.lib.qgd_case_halo_unpack(self._h, side, C.c_void_p(dev_ptr)), "qgd_case_halo_unpack")
+
+    # ---- measurement --------------------------------------------------------------
+    def timing(self, enable=True):
+        L.check(L.lib.qgd_case_timing(self._h, 1 if enable else 0), "qgd_case_timing")
+
+    def timing_reset(self):
+        L.check(L.lib.qgd_case_timing_reset(self._h), "qgd_case_timing_reset")
+
+    def kernel_time(self, k):
+        ms = C.c_double()
+        n = C.c_int64()
+        L.check(L.lib.qgd_case_kernel_time(self._h, k, C.byref(ms), C.byref(n)), "qgd_case_kernel_time")
+        return ms.value, n.value
+
+    def device_bytes(self):
+        n = C.c_int64()
+        L.check(L.lib.qgd_case_device_bytes(self._h, C.byref(n)), "qgd_case_device_bytes")
+        return n.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            L.lib.qgd_case_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,187 @@
+"""ctypes wrapper of the CPU oracle (oracle/libqgd_oracle.so).  Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB = os.path.join(ORACLE_DIR, "libqgd_oracle.so")
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+
+
+if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(os.path.join(ORACLE_DIR, "qgd_oracle.cpp")):
+    build()
+
+lib = C.CDLL(LIB)
+dp = C.POINTER(C.c_double)
+ip = C.POINTER(C.c_int32)
+
+
+class Options(C.Structure):
+    _fields_ = [
+        ("stencil", C.c_int32), ("implicitDiffusion", C.c_int32), ("adjustTimeStep", C.c_int32), ("reserved", C.c_int32),
+        ("R", C.c_double), ("Cv", C.c_double), ("mu", C.c_double), ("Pr", C.c_double), ("ScQGD", C.c_double),
+        ("PrQGD", C.c_double), ("alphaQGD", C.c_double), ("deltaT", C.c_double), ("maxCo", C.c_double),
+        ("maxDeltaT", C.c_double), ("cTau", C.c_double),
+    ]
+
+
+lib.orc_mesh_create.restype = C.c_void_p
+lib.orc_mesh_create.argtypes = [C.c_int32, dp, C.c_int32, ip, ip, C.c_int32, ip, ip, C.c_int32, C.c_int32, ip, ip, ip]
+lib.orc_mesh_free.argtypes = [C.c_void_p]
+lib.orc_mesh_get.argtypes = [C.c_void_p, C.c_char_p, dp, C.c_int64]
+lib.orc_mesh_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+lib.orc_mesh_set_halo.argtypes = [C.c_void_p, C.c_int, C.c_int32, ip, C.c_int32, ip]
+lib.orc_fvsc.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, dp, dp, dp]
+lib.orc_case_create.restype = C.c_void_p
+lib.orc_case_create.argtypes = [C.c_void_p, C.POINTER(Options)]
+lib.orc_case_free.argtypes = [C.c_void_p]
+lib.orc_case_set_bc.argtypes = [C.c_void_p, C.c_int32, C.c_int32, dp, C.c_int32, C.c_double, C.c_int32, C.c_double]
+lib.orc_case_set_fields.argtypes = [C.c_void_p, dp, dp, dp]
+lib.orc_case_update_fluxes.argtypes = [C.c_void_p]
+lib.orc_case_step.argtypes = [C.c_void_p, C.c_int32]
+lib.orc_case_get_field.argtypes = [C.c_void_p, C.c_char_p, dp, C.c_int64]
+lib.orc_case_info.argtypes = [C.c_void_p, dp]
+lib.orc_case_halo_count.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]
+lib.orc_case_halo_pack.argtypes = [C.c_void_p, C.c_int, dp]
+lib.orc_case_halo_unpack.argtypes = [C.c_void_p, C.c_int, dp]
+lib.orc_case_step_phase.argtypes = [C.c_void_p, C.c_int]
+
+_NCOMP = {"U": 3, "rhoU": 3, "phiJmU": 3, "phiP": 3, "phiPi": 3, "gradUf": 9, "gradef": 3, "gradRhof": 3, "gradPf": 3,
+          "Uf": 3, "Pif": 9, "qf": 3, "jm": 3}
+_FACE = {"phiJm", "phiJmU", "phiP", "phiPi", "phiJmH", "phiQ", "phiPiU", "phiwStar", "phi", "tauQGDf", "hQGDf", "gradUf",
+         "gradef", "gradRhof", "gradPf", "rhof", "Uf", "pf", "Hf", "muf", "alphauf", "cf", "Pif", "qf", "jm"}
+
+
+def _d(a):
+    return a.ctypes.data_as(dp)
+
+
+def _i(a):
+    return a.ctypes.data_as(ip)
+
+
+class OracleMesh:
+    """Built from the same primitive arrays the product mesh was built from."""
+
+    def __init__(self, prim):
+        self.prim = prim
+        p = prim
+        self.nPoints = p["points"].size // 3
+        self.nFaces = p["owner"].size
+        self.nInternalFaces = p["neighbour"].size
+        self.nCells = int(p["nCells"])
+        self.nBoundaryFaces = self.nFaces - self.nInternalFaces
+        self._keep = [np.ascontiguousarray(p[k]) for k in ("points", "faceOffsets", "facePoints", "owner", "neighbour",
+                                                           "patchStart", "patchSize", "patchType")]
+        pts, fo, fp, ow, ne, ps, pz, pt = self._keep
+        ne_arg = ne if ne.size else np.zeros(1, dtype=np.int32)
+        self._h = lib.orc_mesh_create(self.nPoints, _d(pts), self.nFaces, _i(fo), _i(fp), self.nInternalFaces, _i(ow),
+                                      _i(ne_arg), self.nCells, ps.size, _i(ps), _i(pz), _i(pt))
+
+    def array(self, name):
+        n = {"Sf": 3 * self.nFaces, "magSf": self.nFaces, "Cf": 3 * self.nFaces, "C": 3 * self.nCells, "V": self.nCells,
+             "weights": self.nFaces, "deltaCoeffs": self.nFaces, "nonOrthDeltaCoeffs": self.nFaces}[name]
+        out = np.zeros(n)
+        assert lib.orc_mesh_get(self._h, name.encode(), _d(out), n) == 0
+        return out
+
+    def info(self):
+        a = (C.c_int64 * 4)()
+        lib.orc_mesh_info(self._h, a)
+        return dict(nGeometricD=int(a[0]), geometricD=[int(a[1]), int(a[2]), int(a[3])])
+
+    def set_halo(self, side, ghost, send):
+        g = np.ascontiguousarray(ghost, dtype=np.int32)
+        s = np.ascontiguousarray(send, dtype=np.int32)
+        assert lib.orc_mesh_set_halo(self._h, side, g.size, _i(g), s.size, _i(s)) == 0
+
+    def fvsc(self, scheme, op, cell, bnd):
+        """op in grad_s, grad_v, div_v, div_t; returns (status, out)."""
+        nci, nco = {"grad_s": (1, 3), "grad_v": (3, 9), "div_v": (3, 1), "div_t": (9, 3)}[op]
+        cell = np.ascontiguousarray(cell, dtype=np.float64)
+        bnd = np.ascontiguousarray(bnd, dtype=np.float64)
+        if bnd.size == 0:
+            bnd = np.zeros(1)
+        assert cell.size == self.nCells * nci
+        out = np.zeros((self.nFaces, nco) if nco > 1 else (self.nFaces,))
+        rc = lib.orc_fvsc(self._h, scheme.encode(), op.encode(), _d(cell), _d(bnd), _d(out))
+        return rc, out
+
+    def close(self):
+        if self._h:
+            lib.orc_mesh_free(self._h)
+            self._h = None
+
+
+class OracleCase:
+    def __init__(self, omesh, options):
+        self.mesh = omesh
+        o = Options()
+        for f, _ in Options._fields_:
+            setattr(o, f, getattr(options, f))
+        self.options = o
+        self._h = lib.orc_case_create(omesh._h, C.byref(o))
+
+    def set_bc(self, patch, U=("zeroGradient", None), T=("zeroGradient", None), p=("zeroGradient", None)):
+        kinds = {"zeroGradient": 0, "fixedValue": 1, "slip": 2, "qgdFlux": 3, "none": 4}
+        vu = np.asarray(U[1] if U[1] is not None else (0.0, 0.0, 0.0), dtype=np.float64)
+        assert lib.orc_case_set_bc(self._h, patch, kinds[U[0]], _d(vu), kinds[T[0]], float(T[1] or 0.0), kinds[p[0]],
+                                   float(p[1] or 0.0)) == 0
+
+    def set_fields(self, U, T, p):
+        U = np.ascontiguousarray(U, dtype=np.float64)
+        T = np.ascontiguousarray(T, dtype=np.float64)
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        rc = lib.orc_case_set_fields(self._h, _d(U), _d(T), _d(p))
+        assert rc == 0, rc
+
+    def updateFluxes(self):
+        assert lib.orc_case_update_fluxes(self._h) == 0
+
+    def step(self, n=1):
+        assert lib.orc_case_step(self._h, int(n)) == 0
+
+    def step_phase(self, phase):
+        assert lib.orc_case_step_phase(self._h, phase) == 0
+
+    def field(self, name):
+        base = name[:-len(".boundary")] if name.endswith(".boundary") else name
+        nc = _NCOMP.get(base, 1)
+        if name.endswith(".boundary"):
+            n = self.mesh.nBoundaryFaces
+        elif base in _FACE:
+            n = self.mesh.nFaces
+        else:
+            n = self.mesh.nCells
+        out = np.zeros((n, nc) if nc > 1 else (n,))
+        if n:
+            rc = lib.orc_case_get_field(self._h, name.encode(), _d(out), out.size)
+            assert rc == 0, (name, rc)
+        return out
+
+    def info(self):
+        a = (C.c_double * 6)()
+        lib.orc_case_info(self._h, a)
+        return dict(time=a[0], deltaT=a[1], CoNum=a[2], minRho=a[3], minE=a[4], steps=int(a[5]))
+
+    def halo_count(self, side):
+        n = C.c_int64()
+        lib.orc_case_halo_count(self._h, side, C.byref(n))
+        return n.value
+
+    def halo_pack(self, side, buf):
+        lib.orc_case_halo_pack(self._h, side, _d(buf))
+
+    def halo_unpack(self, side, buf):
+        lib.orc_case_halo_unpack(self._h, side, _d(buf))
+
+    def close(self):
+        if self._h:
+            lib.orc_case_free(self._h)
+            self._h = None

@@ -1,0 +1,160 @@
+"""GPU parity of the QGDFoam flux assembly and explicit step against the CPU oracle.
+
+Bar (north_star): <= 1e-10 relative on rho, U, p after N steps.  Face fluxes straight after
+updateFluxes are held to 1e-11 relative to each field's max magnitude.
+"""
+import numpy as np
+import pytest
+
+import qgdsolver_amd as q
+
+import cases
+from oracle import OracleCase
+from util import make_mesh, oracle_mesh_of, rel_err
+
+pytestmark = pytest.mark.gpu
+
+STATE_TOL = 1e-10
+FLUX_TOL = 1e-11
+FACE_FIELDS = ["phiJm", "phiJmU", "phiP", "phiPi", "phiJmH", "phiQ", "phiPiU", "phiwStar", "phi", "tauQGDf", "hQGDf",
+               "gradUf", "gradef", "gradRhof", "gradPf"]
+CELL_FIELDS = ["rho", "U", "p", "e", "T", "rhoU", "rhoE", "c", "psi", "mu", "alphau", "tauQGD", "muQGD", "alphauQGD", "hQGD", "H"]
+
+
+def build_pair(mesh_kind, scheme, bc_fn=None, init_fn=None, **opt):
+    mesh = make_mesh(mesh_kind)
+    om = oracle_mesh_of(mesh)
+    options = q.default_options(stencil=scheme, **opt)
+    dev = q.Device(mesh)
+    gc = q.QGDFoamCase(dev, options)
+    oc = OracleCase(om, options)
+    if bc_fn:
+        bc_fn(gc)
+        bc_fn(oc)
+    C = mesh.array("C").reshape(-1, 3)
+    U, T, p = (init_fn or cases.box_initial_fields)(C)
+    gc.set_fields(U, T, p)
+    oc.set_fields(U, T, p)
+    return mesh, dev, gc, oc
+
+
+def compare_fields(gc, oc, names, tol, tag):
+    worst = {}
+    for n in names:
+        e = rel_err(gc.field(n), oc.field(n))
+        worst[n] = e
+        assert e <= tol, (tag, n, e)
+    return worst
+
+
+def step_init(C):
+    n = C.shape[0]
+    U = np.zeros((n, 3))
+    U[:, 0] = 3.0
+    # a smooth perturbation so that every term of the flux algebra is exercised
+    T = 1.0 + 0.05 * np.sin(2.0 * C[:, 0]) * np.cos(3.0 * C[:, 1])
+    p = 1.0 + 0.05 * np.cos(1.5 * C[:, 0] + C[:, 1])
+    return U, T, p
+
+
+def plane_init(C):
+    U, T, p = cases.box_initial_fields(C)
+    return U, T, p
+
+
+def empty_z_bcs(case):
+    for patch in (4, 5):
+        case.set_bc(patch, U=("none", None), T=("none", None), p=("none", None))
+
+
+def mixed_box_bcs(case):
+    """inlet fixedValue / outlet zeroGradient / slip walls with qgdFlux / fixed-T wall"""
+    case.set_bc(0, U=("fixedValue", (0.3, 0.0, 0.0)), T=("fixedValue", 1.0), p=("zeroGradient", None))
+    case.set_bc(1, U=("zeroGradient", None), T=("zeroGradient", None), p=("fixedValue", 1.0))
+    case.set_bc(2, U=("slip", None), T=("zeroGradient", None), p=("qgdFlux", None))
+    case.set_bc(3, U=("slip", None), T=("fixedValue", 1.05), p=("qgdFlux", None))
+    case.set_bc(4, U=("fixedValue", (0.0, 0.0, 0.0)), T=("zeroGradient", None), p=("zeroGradient", None))
+    case.set_bc(5, U=("slip", None), T=("zeroGradient", None), p=("zeroGradient", None))
+
+
+CASES = [
+    ("box654", "GaussVolPoint", None, None, dict(deltaT=2e-3, mu=1e-3)),
+    ("box654", "reduced", None, None, dict(deltaT=2e-3, mu=1e-3)),
+    ("box654_jitter", "GaussVolPoint", None, None, dict(deltaT=1e-3, mu=1e-3)),
+    ("box654_tri", "GaussVolPoint", None, None, dict(deltaT=1e-3)),
+    ("box654", "GaussVolPoint", mixed_box_bcs, None, dict(deltaT=1e-3, mu=2e-3, Pr=0.7, ScQGD=0.8, PrQGD=0.9, alphaQGD=0.4)),
+    ("box654_jitter", "GaussVolPoint", mixed_box_bcs, None, dict(deltaT=5e-4, mu=2e-3)),
+    ("plane2d", "GaussVolPoint", empty_z_bcs, plane_init, dict(deltaT=1e-3)),
+    ("plane2d", "leastSquares", empty_z_bcs, plane_init, dict(deltaT=1e-3)),
+    ("plane2d_jitter", "leastSquares", empty_z_bcs, plane_init, dict(deltaT=5e-4, mu=1e-3)),
+    ("step2d", "leastSquares", cases.forward_step_bcs, step_init, dict(deltaT=5e-4)),
+    ("step2d", "GaussVolPoint", cases.forward_step_bcs, step_init, dict(deltaT=5e-4)),
+    ("step2d", "reduced", cases.forward_step_bcs, step_init, dict(deltaT=5e-4)),
+]
+
+
+@pytest.mark.parametrize("mesh_kind,scheme,bc_fn,init_fn,opt", CASES)
+def test_update_fluxes_and_steps(mesh_kind, scheme, bc_fn, init_fn, opt):
+    mesh, dev, gc, oc = build_pair(mesh_kind, scheme, bc_fn, init_fn, **opt)
+    tag = (mesh_kind, scheme)
+    # state straight after createFields.H
+    compare_fields(gc, oc, CELL_FIELDS, 1e-13, tag + ("init",))
+    compare_fields(gc, oc, [n + ".boundary" for n in ("rho", "U", "p", "e", "c", "H", "muQGD")], 1e-13, tag + ("init.bnd",))
+    # updateFields.H + updateFluxes.H
+    gc.updateFluxes()
+    oc.updateFluxes()
+    compare_fields(gc, oc, FACE_FIELDS, FLUX_TOL, tag + ("fluxes",))
+    # explicit steps
+    for chunk in (1, 4, 20):
+        gc.step(chunk)
+        oc.step(chunk)
+        compare_fields(gc, oc, ["rho", "U", "p", "e", "rhoU", "rhoE"], STATE_TOL, tag + (f"step+{chunk}",))
+    compare_fields(gc, oc, CELL_FIELDS, STATE_TOL, tag + ("final",))
+    ig, io = gc.info(), oc.info()
+    assert ig["steps"] == io["steps"] == 25
+    assert abs(ig["time"] - io["time"]) <= 1e-12 * max(1.0, abs(io["time"]))
+    assert abs(ig["minRho"] - io["minRho"]) <= 1e-9 and ig["minRho"] > 0 and ig["minE"] > 0
+    gc.close(); dev.close()
+
+
+@pytest.mark.parametrize("mesh_kind,scheme,bc_fn,init_fn", [
+    ("box654", "GaussVolPoint", None, None),
+    ("step2d", "leastSquares", cases.forward_step_bcs, step_init),
+])
+def test_adjust_time_step(mesh_kind, scheme, bc_fn, init_fn):
+    """QGDCourantNo.H + setDeltaT-QGDQHD.H: Courant number and deltaT follow the oracle."""
+    mesh, dev, gc, oc = build_pair(mesh_kind, scheme, bc_fn, init_fn, deltaT=1e-4, adjustTimeStep=1, maxCo=0.3,
+                                   maxDeltaT=1.0, cTau=0.75)
+    for _ in range(10):
+        gc.step(1)
+        oc.step(1)
+        ig, io = gc.info(), oc.info()
+        assert abs(ig["deltaT"] - io["deltaT"]) <= 1e-11 * io["deltaT"], (ig, io)
+        assert abs(ig["CoNum"] - io["CoNum"]) <= 1e-11 * max(io["CoNum"], 1e-30), (ig, io)
+        assert abs(ig["time"] - io["time"]) <= 1e-11 * io["time"]
+    compare_fields(gc, oc, ["rho", "U", "p", "e"], STATE_TOL, (mesh_kind, scheme, "adjust"))
+    gc.close(); dev.close()
+
+
+def test_thermo_accessors():
+    """QGDThermo accessor surface (QGDThermo.H L99-135) returns the oracle's fields."""
+    mesh, dev, gc, oc = build_pair("box654", "GaussVolPoint", None, None, deltaT=1e-3, mu=1e-3)
+    gc.step(2); oc.step(2)
+    gc.updateFluxes(); oc.updateFluxes()
+    th = gc.thermo
+    pairs = [(th.tauQGDf(), "tauQGDf"), (th.hQGDf(), "hQGDf"), (th.tauQGD(), "tauQGD"), (th.hQGD(), "hQGD"),
+             (th.muQGD(), "muQGD"), (th.alphauQGD(), "alphauQGD"), (th.c(), "c"), (th.p(), "p"), (th.rho(), "rho"),
+             (th.mu(), "mu")]
+    for got, name in pairs:
+        assert rel_err(got, oc.field(name)) <= STATE_TOL, name
+    assert th.implicitDiffusion() is False
+    gc.close(); dev.close()
+
+
+def test_implicit_diffusion_not_on_this_path():
+    mesh = make_mesh("box654")
+    dev = q.Device(mesh)
+    with pytest.raises(q.QgdError) as ei:
+        q.QGDFoamCase(dev, q.default_options(implicitDiffusion=1))
+    assert ei.value.code == q._lib.ERR_NOT_IMPLEMENTED
+    dev.close()
