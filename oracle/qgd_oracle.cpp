@@ -1001,6 +1001,10 @@ struct Case {
 
     Case(MeshHandle* h, const orc_case_options& o) : mh(h), m(h->m), opt(o), bc(h->m.patches.size()) {
         deltaT = o.deltaT;
+        liveFace.assign(h->m.nF, 1);
+        for (size_t ip = 0; ip < h->m.patches.size(); ++ip)
+            if (!h->m.patchHasFields((int)ip))
+                for (int f = h->m.patches[ip].start; f < h->m.patches[ip].start + h->m.patches[ip].size; ++f) liveFace[f] = 0;
         for (size_t ip = 0; ip < bc.size(); ++ip) {
             const int t = m.patches[ip].type;
             if (t == PATCH_EMPTY || t == PATCH_HALO) bc[ip].bcU = bc[ip].bcT = bc[ip].bcP = BC_NONE;
@@ -1028,6 +1032,8 @@ struct Case {
         if (!m.patchHasFields(ip)) return;
         for (int gf = m.patches[ip].start; gf < m.patches[ip].start + m.patches[ip].size; ++gf) fn(gf, gf - m.nIF, m.own[gf]);
     }
+
+    template <class Fn> void forAllPatchFaces(Fn fn) const { for (size_t ip = 0; ip < m.patches.size(); ++ip) forPatchFaces((int)ip, fn); }
 
     // ---- boundary-condition evaluation -----------------------------------
     void correctBC_U() {
@@ -1129,6 +1135,7 @@ struct Case {
         }
         for (size_t ip = 0; ip < m.patches.size(); ++ip)
             if (!m.coupled((int)ip)) forPatchFaces((int)ip, [&](int gf, int, int) { hQGDf.v[gf] *= 2.0; });
+        for (int f = 0; f < m.nF; ++f) if (!liveFace[f]) hQGDf.v[f] = 0.0;  // no field entries on empty patches
         for (int ci = 0; ci < m.nC; ++ci) {
             double hint = 0, surf = 0;
             for (int fid : m.cells[ci]) {
@@ -1195,7 +1202,7 @@ struct Case {
         for (int ci = 0; ci < m.nC; ++ci) cons(&rho.in[ci], &U.in[3 * (size_t)ci], &e.in[ci], &rhoU.in[3 * (size_t)ci], &rhoE.in[ci]);
         for (int b = 0; b < m.nBF(); ++b) cons(&rho.bf[b], &U.bf[3 * (size_t)b], &e.bf[b], &rhoU.bf[3 * (size_t)b], &rhoE.bf[b]);
         for (int ci = 0; ci < m.nC; ++ci) H.in[ci] = (rhoE.in[ci] + p.in[ci]) / rho.in[ci];
-        for (int b = 0; b < m.nBF(); ++b) H.bf[b] = (rhoE.bf[b] + p.bf[b]) / rho.bf[b];
+        forAllPatchFaces([&](int, int b, int) { H.bf[b] = (rhoE.bf[b] + p.bf[b]) / rho.bf[b]; });
         // createFaceFluxes.H registers "phiwStar" = Sf & (tauQGDf*gradPf); with
         // GaussVolPoint that first grad(p) runs the qgdFlux BC before the name exists
         phiwRegistered = false;
@@ -1231,7 +1238,7 @@ struct Case {
         cf = linearInterpolate(m, c);
         gammaf = linearInterpolate(m, gamma);
         for (int ci = 0; ci < m.nC; ++ci) H.in[ci] = (rhoE.in[ci] + p.in[ci]) / rho.in[ci];
-        for (int b = 0; b < m.nBF(); ++b) H.bf[b] = (rhoE.bf[b] + p.bf[b]) / rho.bf[b];
+        forAllPatchFaces([&](int, int b, int) { H.bf[b] = (rhoE.bf[b] + p.bf[b]) / rho.bf[b]; });
         Hf = linearInterpolate(m, H);
         // L0: laminar alphaEff() = thermo.alphaEff(alphat=0) = gamma*(alpha + 0) for an
         // internal-energy thermo; muEff() = mut(=0) + mu
@@ -1252,6 +1259,7 @@ struct Case {
         gradRhof = fvscGrad(rho, false);
         rhoW = SurfField(m, 3); phiw = SurfField(m, 1);
         for (int f = 0; f < nF; ++f) {
+            if (!liveFace[f]) continue;
             const double* uf = &Uf.v[3 * (size_t)f];
             const double* ruf = &rhoUf.v[3 * (size_t)f];
             double A[9], t1[3], t3[3];
@@ -1264,6 +1272,7 @@ struct Case {
         gradPf = fvscGrad(p, true);
         jm = SurfField(m, 3); phiJm = SurfField(m, 1); phi = SurfField(m, 1);
         for (int f = 0; f < nF; ++f) {
+            if (!liveFace[f]) continue;
             for (int k = 0; k < 3; ++k) {
                 rhoW.v[3 * (size_t)f + k] += tauQGDf.v[f] * gradPf.v[3 * (size_t)f + k];
                 jm.v[3 * (size_t)f + k] = rhoUf.v[3 * (size_t)f + k] - rhoW.v[3 * (size_t)f + k];
@@ -1274,6 +1283,7 @@ struct Case {
         phiJmU = SurfField(m, 3); phiP = SurfField(m, 3); Pif = SurfField(m, 9); phiPi = SurfField(m, 3);
         phiJmH = SurfField(m, 1); qf = SurfField(m, 3); phiQ = SurfField(m, 1); phiPiU = SurfField(m, 1);
         for (int f = 0; f < nF; ++f) {
+            if (!liveFace[f]) continue;
             const double* uf = &Uf.v[3 * (size_t)f];
             const double* gU = &gradUf.v[9 * (size_t)f];
             const double* gP = &gradPf.v[3 * (size_t)f];
@@ -1356,6 +1366,7 @@ struct Case {
         return -1;
     }
     std::vector<char> ghostFlag;
+    std::vector<char> liveFace;  // 0 on faces of empty patches (emptyFvPatch has size 0: no field entries there)
     bool faceTouchesOwned(int f) const {
         if (ghostFlag.empty()) return true;
         return !ghostFlag[m.own[f]] || !ghostFlag[m.nei[f]];

@@ -446,6 +446,7 @@ static int fvscOp(qgd_device_t d, int stencilId, int op, int NC, const double* c
         HIP_CHECK(hipMemcpyAsync(dc, cell, sizeof(double) * (size_t)v.nC * NC, hipMemcpyHostToDevice, d->stream));
         if (v.nBF) HIP_CHECK(hipMemcpyAsync(db, bnd, sizeof(double) * (size_t)v.nBF * NC, hipMemcpyHostToDevice, d->stream));
         HIP_CHECK(hipMemsetAsync(dp, 0, sizeof(double) * (size_t)v.nP * NC, d->stream));
+        (void)hipGetLastError();  // drop any stale sticky error so the check below is about our launches
         launchFvscOp(d->stream, st, op, NC, v, dc, db, dp, dout);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipMemcpyAsync(out, dout, sizeof(double) * (size_t)v.nF * NO, hipMemcpyDeviceToHost, d->stream));
@@ -502,6 +503,11 @@ int qgd_case_create(qgd_device_t d, const qgd_case_options* opt, qgd_case_t* out
         cv.P = a.alloc<RecA>(v.nP);
         cv.bA = a.alloc<RecA>(v.nBF); cv.bB = a.alloc<RecB>(v.nBF);
         cv.bG = a.alloc<double>(v.nBF); cv.bPhiw = a.alloc<double>(v.nBF); cv.bPmid = a.alloc<double>(v.nBF);
+        cv.bRhoLag = a.alloc<double>(v.nBF);
+        cv.nBlkFace = faceBlocks(v) + bfaceBlocks(v);
+        cv.nBlkCell = cellBlocks(v);
+        cv.blkFace = a.alloc<double>(2 * (size_t)std::max(1, cv.nBlkFace));
+        cv.blkCell = a.alloc<double>(2 * (size_t)std::max(1, cv.nBlkCell));
         cv.flux = a.alloc<double>(5 * (size_t)v.nF);
         cv.red = a.alloc<double>(8);
         cv.dt = a.alloc<double>(8);
@@ -551,6 +557,7 @@ int qgd_case_set_bc(qgd_case_t c, int32_t patch, int32_t bcU, const double* valu
 
 // one flux-assembly pass (updateFields.H + updateFluxes.H) on the current state
 static void assembleFluxes(qgd_case_s* c, bool adjust) {
+    (void)hipGetLastError();  // drop any stale sticky error: the callers check after their launches
     const Launcher L = launcherOf(c);
     const MeshView& m = c->dev->view;
     const CaseView& v = c->view;
@@ -567,6 +574,7 @@ static void assembleFluxes(qgd_case_s* c, bool adjust) {
     }
     launchFaceFlux(L, c->stencil, m, v, c->gas, adjust);
     launchBoundaryFaceFlux(L, c->stencil, m, v, c->gas, c->bcDev, false, adjust);
+    if (c->usesPoints && c->hasQgdFlux) launchCommitMidStepPressure(L, m, v);
 }
 
 int qgd_case_set_fields(qgd_case_t c, const double* U, const double* T, const double* p) {
@@ -588,6 +596,7 @@ int qgd_case_set_fields(qgd_case_t c, const double* U, const double* T, const do
         HIP_CHECK(hipMemcpy(dp, p, sizeof(double) * (size_t)m.nC, hipMemcpyHostToDevice));
         Launcher L = launcherOf(c);
         L.pre = nullptr; L.post = nullptr;
+        (void)hipGetLastError();
         launchCellInit(L, m, c->view, c->gas, dU, dT, dp);
         launchBoundaryUpdate(L, m, c->view, c->gas, c->bcDev, true, false);
         launchResetReductions(L, c->view);
@@ -626,7 +635,7 @@ static void stepOnce(qgd_case_s* c) {
     const MeshView& m = c->dev->view;
     const bool adjust = c->opt.adjustTimeStep != 0;
     assembleFluxes(c, adjust);
-    if (adjust) launchDeltaT(L, c->view, c->opt.maxCo, c->opt.maxDeltaT, c->opt.cTau, nullptr);
+    if (adjust) launchDeltaT(L, c->view, c->opt.maxCo, c->opt.maxDeltaT, c->opt.cTau);
     launchCellUpdate(L, m, c->view, c->gas);
     launchBoundaryUpdate(L, m, c->view, c->gas, c->bcDev, false, c->phiwRegistered);
     c->steps++;
@@ -675,10 +684,10 @@ int qgd_case_stream_sync(qgd_case_t c) {
     QGD_CATCH
 }
 
-// halo message layout: 14 doubles per cell (RecA, RecB, Cons), 11 per boundary face (RecA, RecB, p gradient)
+// halo message layout: 14 doubles per cell (RecA, RecB, Cons), 12 per boundary face (RecA, RecB, p gradient, lagged rho)
 int qgd_case_halo_count(qgd_case_t c, int side, int64_t* count) {
     if (!c || !count || side < 0 || side > 1) return fail(QGD_ERR_INVALID, "bad argument");
-    *count = 14 * (int64_t)c->dev->nHaloSendCells[side] + 11 * (int64_t)c->dev->nHaloSendBF[side];
+    *count = 14 * (int64_t)c->dev->nHaloSendCells[side] + 12 * (int64_t)c->dev->nHaloSendBF[side];
     return QGD_OK;
 }
 int qgd_case_halo_pack(qgd_case_t c, int side, double* sendBufDevice) {
@@ -794,30 +803,24 @@ int qgd_case_get_field(qgd_case_t c, const char* name, double* out, int64_t outD
     QGD_CATCH
 }
 
-static double undkeyHost(long long k) {
-    long long b = k >= 0 ? k : (k ^ 0x7fffffffffffffffLL);
-    double x;
-    std::memcpy(&x, &b, sizeof(x));
-    return x;
-}
 int qgd_case_info(qgd_case_t c, double info[6]) {
     QGD_TRY
     if (!c || !info) return fail(QGD_ERR_INVALID, "null argument");
     HIP_CHECK(hipSetDevice(c->dev->deviceId));
+    Launcher L = launcherOf(c);
+    L.pre = nullptr; L.post = nullptr;
+    launchCellMinReduce(L, c->view);  // min(rho), min(e) since the previous query [QGDFoam_8C L142]
+    HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(c->stream()));
-    long long red[4];
-    double dt[3];
+    double red[4], dt[3];
     HIP_CHECK(hipMemcpy(red, c->view.red, sizeof(red), hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(dt, c->view.dt, sizeof(dt), hipMemcpyDeviceToHost));
     info[0] = c->opt.adjustTimeStep ? dt[1] : c->time;
     info[1] = dt[0];
     info[2] = dt[2];
-    info[3] = undkeyHost(red[2]);
-    info[4] = undkeyHost(red[3]);
+    info[3] = red[2];
+    info[4] = red[3];
     info[5] = (double)c->steps;
-    // min(rho), min(e) restart from here [QGDFoam_8C L142]
-    const double reset[2] = {1e300, 1e300};  // positive doubles are their own ordered keys
-    HIP_CHECK(hipMemcpy(c->view.red + 2, reset, sizeof(reset), hipMemcpyHostToDevice));
     return QGD_OK;
     QGD_CATCH
 }

@@ -58,8 +58,13 @@ struct CaseView {
     double* bG;                     // nBF p gradient (qgdFlux)
     double* bPhiw;                  // nBF phiwStar on boundary faces
     double* bPmid;                  // nBF patch pressure after GaussVolPoint's mid-step BC evaluation
+    double* bRhoLag;                // nBF patch density of the previous step: rhoU_b, rhoE_b are built with it
+                                    //     [QGDUEqn_8H L88-89, QGDEEqn_8H L75-76 run before QGDFoam_8C L156]
     double* flux;                   // 5*nF net face fluxes
-    double* red;                    // [0]=max Co, [1]=min tauQGDf, [2]=min rho, [3]=min e (as ordered bit patterns)
+    double* red;                    // [0]=max Co, [1]=min tauQGDf, [2]=min rho, [3]=min e
+    double* blkFace;                // 2 per face-kernel workgroup (internal then boundary): max Cof, min tauQGDf
+    double* blkCell;                // 2 per cell-kernel workgroup: min rho, min e since the last query
+    int32_t nBlkFace, nBlkCell;
     double* dt;                     // [0]=deltaT (device resident so adjustTimeStep needs no host round trip)
     double* dbg;                    // optional debug face fields (nullptr in the product path)
 };
@@ -81,6 +86,7 @@ struct Launcher {
 // ---- case kernels -------------------------------------------------------------
 void launchPointInterp(const Launcher& L, const MeshView& m, const CaseView& c);
 void launchBoundaryPoints(const Launcher& L, const MeshView& m, const CaseView& c, bool pOnly);
+void launchCommitMidStepPressure(const Launcher& L, const MeshView& m, const CaseView& c);
 void launchPressureMidStep(const Launcher& L, const MeshView& m, const CaseView& c, const PatchBCDev* bc);
 void launchFaceFlux(const Launcher& L, int stencil, const MeshView& m, const CaseView& c, const GasModel& g, bool adjustDt);
 void launchBoundaryFaceFlux(const Launcher& L, int stencil, const MeshView& m, const CaseView& c, const GasModel& g,
@@ -90,8 +96,12 @@ void launchBoundaryUpdate(const Launcher& L, const MeshView& m, const CaseView& 
                           bool init, bool phiwRegistered);
 void launchCellInit(const Launcher& L, const MeshView& m, const CaseView& c, const GasModel& g, const double* U,
                     const double* T, const double* p);
-void launchDeltaT(const Launcher& L, const CaseView& c, double maxCo, double maxDeltaT, double cTau, double* info);
+void launchDeltaT(const Launcher& L, const CaseView& c, double maxCo, double maxDeltaT, double cTau);
 void launchResetReductions(const Launcher& L, const CaseView& c);
+void launchCellMinReduce(const Launcher& L, const CaseView& c);
+int faceBlocks(const MeshView& m);
+int bfaceBlocks(const MeshView& m);
+int cellBlocks(const MeshView& m);
 void launchHaloPack(const Launcher& L, const CaseView& c, const int32_t* cells, int32_t nCells, const int32_t* bfaces,
                     int32_t nFaces, double* buf, bool pack);
 

@@ -31,11 +31,27 @@ namespace qgd {
 
 __device__ __forceinline__ double lerpf(double w, double a, double b) { return w * (a - b) + b; }
 
-// order-preserving map double -> int64 so min/max can use integer atomics
-__device__ __forceinline__ long long dkey(double x) {
-    long long k = __double_as_longlong(x);
-    return k >= 0 ? k : (k ^ 0x7fffffffffffffffLL);
+// Workgroup reduction (wave shuffles + 4-entry LDS): slot[0] = max(a), slot[1] = min(b).
+// With `accumulate` the slot keeps the running extremum since it was last reset.
+__device__ __forceinline__ void blockMaxMin(double a, double b, double* __restrict__ slot, const bool accumulate) {
+    __shared__ double sa[QGD_BLOCK / 64], sb[QGD_BLOCK / 64];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        a = fmax(a, __shfl_down(a, off, 64));
+        b = fmin(b, __shfl_down(b, off, 64));
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sa[wave] = a; sb[wave] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 1; i < QGD_BLOCK / 64; ++i) { a = fmax(a, sa[i]); b = fmin(b, sb[i]); }
+        if (accumulate) { a = fmax(a, slot[0]); b = fmin(b, slot[1]); }
+        slot[0] = a;
+        slot[1] = b;
+    }
 }
+__device__ __forceinline__ int faceBlocksDev(const MeshView& m) { return (m.nIF + QGD_BLOCK - 1) / QGD_BLOCK; }
 
 template <int NC>
 struct FaceVals {
@@ -371,17 +387,7 @@ __global__ __launch_bounds__(QGD_BLOCK) void faceFluxKernel(const MeshView m, co
             }
         }
     }
-    if (adjustDt) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            cof = fmax(cof, __shfl_down(cof, off, 64));
-            tauMin = fmin(tauMin, __shfl_down(tauMin, off, 64));
-        }
-        if ((threadIdx.x & 63) == 0) {
-            atomicMax(reinterpret_cast<long long*>(c.red) + 0, dkey(cof));
-            atomicMin(reinterpret_cast<long long*>(c.red) + 1, dkey(tauMin));
-        }
-    }
+    if (adjustDt) blockMaxMin(cof, tauMin, c.blkFace + 2 * (size_t)tile, false);
 }
 
 // patch snGrad of the six case fields on boundary face (global label f)
@@ -435,7 +441,7 @@ __global__ __launch_bounds__(QGD_BLOCK) void boundaryFaceFluxKernel(const MeshVi
             const double Ub[3] = {Ab.ux, Ab.uy, Ab.uz};
             double rUb[3];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { s.Uf[k] = Ub[k]; rUb[k] = Ab.rho * Ub[k]; s.rhoUf[k] = rUb[k]; }
+            for (int k = 0; k < 3; ++k) { s.Uf[k] = Ub[k]; rUb[k] = c.bRhoLag[b] * Ub[k]; s.rhoUf[k] = rUb[k]; }  // rhoU_b [QGDUEqn_8H L88-89]
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -462,17 +468,7 @@ __global__ __launch_bounds__(QGD_BLOCK) void boundaryFaceFluxKernel(const MeshVi
             }
         }
     }
-    if (adjustDt && !phiwOnly) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            cof = fmax(cof, __shfl_down(cof, off, 64));
-            tauMin = fmin(tauMin, __shfl_down(tauMin, off, 64));
-        }
-        if ((threadIdx.x & 63) == 0) {
-            atomicMax(reinterpret_cast<long long*>(c.red) + 0, dkey(cof));
-            atomicMin(reinterpret_cast<long long*>(c.red) + 1, dkey(tauMin));
-        }
-    }
+    if (adjustDt && !phiwOnly) blockMaxMin(cof, tauMin, c.blkFace + 2 * ((size_t)faceBlocksDev(m) + blockIdx.x), false);
 }
 
 // ---------------------------------------------------------------------------
@@ -497,6 +493,14 @@ __global__ __launch_bounds__(QGD_BLOCK) void pointInterpKernel(const MeshView m,
     double* o = ptF + (size_t)p * NC;
 #pragma unroll
     for (int k = 0; k < NC; ++k) o[k] = acc[k];
+}
+
+// After the boundary-face fluxes took pf from the old patch pressure, the patch field holds the mid-step value
+// (one array in the reference: p.boundaryField()).
+__global__ __launch_bounds__(QGD_BLOCK) void commitMidStepPressureKernel(const MeshView m, const CaseView c) {
+    const int b = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    if (b >= m.nBF) return;
+    c.bA[b].p = c.bPmid[b];
 }
 
 // patch points: weighted mean of the surrounding boundary-face values.  Source
@@ -594,15 +598,8 @@ __global__ __launch_bounds__(QGD_BLOCK) void cellUpdateKernel(const MeshView m, 
         c.K[ci] = Kn;
         if (!(m.ghost && m.ghost[ci])) { rmin = rho; emin = An.e; }
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        rmin = fmin(rmin, __shfl_down(rmin, off, 64));
-        emin = fmin(emin, __shfl_down(emin, off, 64));
-    }
-    if ((threadIdx.x & 63) == 0) {
-        atomicMin(reinterpret_cast<long long*>(c.red) + 2, dkey(rmin));
-        atomicMin(reinterpret_cast<long long*>(c.red) + 3, dkey(emin));
-    }
+    // positivity monitor [QGDFoam_8C L142]: one plain store pair per workgroup, no atomics
+    blockMaxMin(-rmin, emin, c.blkCell + 2 * (size_t)blockIdx.x, true);
 }
 
 // createFields.H for the cells [QGDFoam_2createFields_8H L3-109]
@@ -684,39 +681,67 @@ __global__ __launch_bounds__(QGD_BLOCK) void boundaryUpdateKernel(const MeshView
         Ab.p = Ao.p + grad / m.dn[f];
     } else Ab.p = Ao.p;
     Ab.rho = init ? Ab.p * psi : psi * Ab.p;  // thermo.rho() at start-up, psi_b*p_b afterwards [QGDFoam_8C L156]
+    // rhoU_b and rhoE_b are assigned inside the U and E equations [QGDUEqn_8H L88-89, QGDEEqn_8H L75-76],
+    // i.e. with the patch density of the step before; rho_b itself is refreshed last [QGDFoam_8C L156]
+    const double rhoLag = init ? Ab.rho : c.bA[b].rho;
     const double rE = init ? (Ab.rho * Ab.e + Ab.rho * 0.5 * (Ab.ux * Ab.ux + Ab.uy * Ab.uy + Ab.uz * Ab.uz))
-                           : (Ab.rho * (Ab.e + 0.5 * (Ab.ux * Ab.ux + Ab.uy * Ab.uy + Ab.uz * Ab.uz)));
+                           : (rhoLag * (Ab.e + 0.5 * (Ab.ux * Ab.ux + Ab.uy * Ab.uy + Ab.uz * Ab.uz)));
     Bb.H = (rE + Ab.p) / Ab.rho;
+    c.bRhoLag[b] = rhoLag;
     c.bA[b] = Ab;
     c.bB[b] = Bb;
     c.bPmid[b] = Ab.p;
 }
 
-// adjustTimeStep [setDeltaT-QGDQHD_8H L41-61]; one thread
-__device__ __forceinline__ double undkey(long long k) { return __longlong_as_double(k >= 0 ? k : (k ^ 0x7fffffffffffffffLL)); }
-__global__ void deltaTKernel(const CaseView c, const double maxCo, const double maxDeltaT, const double cTau, double* info) {
-    long long* r = reinterpret_cast<long long*>(c.red);
-    const double CoNum = undkey(r[0]);
-    const double minTau = undkey(r[1]);
-    const double maxDeltaTFact = maxCo / (CoNum + 1e-15);
-    const double deltaTFact = fmin(fmin(maxDeltaTFact, 1.0 + 0.1 * maxDeltaTFact), 1.2);
-    double maxDeltaT1 = cTau * minTau;
-    maxDeltaT1 = fmin(maxDeltaT, maxDeltaT1);
-    const double dt = fmin(deltaTFact * c.dt[0], maxDeltaT1);
-    c.dt[0] = dt;
-    c.dt[1] += dt;    // time
-    c.dt[2] = CoNum;
-    r[0] = dkey(-1e300);
-    r[1] = dkey(1e300);
-    if (info) { info[0] = dt; info[1] = CoNum; }
+// adjustTimeStep [QGDCourantNo_8H L50, setDeltaT-QGDQHD_8H L41-61]: one workgroup folds the per-workgroup
+// partials of the face kernels and advances deltaT on the device
+__global__ __launch_bounds__(QGD_BLOCK) void deltaTKernel(const CaseView c, const double maxCo, const double maxDeltaT,
+                                                         const double cTau) {
+    double co = -1e300, tmin = 1e300;
+    for (int i = threadIdx.x; i < c.nBlkFace; i += QGD_BLOCK) {
+        co = fmax(co, c.blkFace[2 * (size_t)i]);
+        tmin = fmin(tmin, c.blkFace[2 * (size_t)i + 1]);
+    }
+    blockMaxMin(co, tmin, c.red, false);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double CoNum = c.red[0], minTau = c.red[1];
+        const double maxDeltaTFact = maxCo / (CoNum + 1e-15);
+        const double deltaTFact = fmin(fmin(maxDeltaTFact, 1.0 + 0.1 * maxDeltaTFact), 1.2);
+        double maxDeltaT1 = cTau * minTau;
+        maxDeltaT1 = fmin(maxDeltaT, maxDeltaT1);
+        const double dt = fmin(deltaTFact * c.dt[0], maxDeltaT1);
+        c.dt[0] = dt;
+        c.dt[1] += dt;  // time
+        c.dt[2] = CoNum;
+    }
 }
-__global__ void resetReductionsKernel(const CaseView c) {
-    long long* r = reinterpret_cast<long long*>(c.red);
-    r[0] = dkey(-1e300); r[1] = dkey(1e300); r[2] = dkey(1e300); r[3] = dkey(1e300);
+__global__ __launch_bounds__(QGD_BLOCK) void resetReductionsKernel(const CaseView c) {
+    for (int i = blockIdx.x * QGD_BLOCK + threadIdx.x; i < c.nBlkCell; i += gridDim.x * QGD_BLOCK) {
+        c.blkCell[2 * (size_t)i] = -1e300;
+        c.blkCell[2 * (size_t)i + 1] = 1e300;
+    }
+    for (int i = blockIdx.x * QGD_BLOCK + threadIdx.x; i < c.nBlkFace; i += gridDim.x * QGD_BLOCK) {
+        c.blkFace[2 * (size_t)i] = -1e300;
+        c.blkFace[2 * (size_t)i + 1] = 1e300;
+    }
+}
+// min(rho), min(e) over the per-workgroup monitors -> red[2], red[3]; then restart the monitors
+__global__ __launch_bounds__(QGD_BLOCK) void cellMinReduceKernel(const CaseView c) {
+    double a = -1e300, b = 1e300;
+    for (int i = threadIdx.x; i < c.nBlkCell; i += QGD_BLOCK) {
+        a = fmax(a, c.blkCell[2 * (size_t)i]);
+        b = fmin(b, c.blkCell[2 * (size_t)i + 1]);
+        c.blkCell[2 * (size_t)i] = -1e300;
+        c.blkCell[2 * (size_t)i + 1] = 1e300;
+    }
+    blockMaxMin(a, b, c.red + 2, false);
+    __syncthreads();
+    if (threadIdx.x == 0) c.red[2] = -c.red[2];
 }
 
-// halo message = 14 doubles per listed cell (RecA, RecB, Cons), then 11 per listed
-// boundary face (RecA, RecB, p gradient)
+// halo message = 14 doubles per listed cell (RecA, RecB, Cons), then 12 per listed
+// boundary face (RecA, RecB, p gradient, lagged patch density)
 __global__ __launch_bounds__(QGD_BLOCK) void haloKernel(const CaseView c, const int32_t* __restrict__ cells, const int nCells,
                                                        const int32_t* __restrict__ bfaces, const int nFaces,
                                                        double* __restrict__ buf, const int pack) {
@@ -737,15 +762,15 @@ __global__ __launch_bounds__(QGD_BLOCK) void haloKernel(const CaseView c, const 
     } else if (i < nCells + nFaces) {
         const int j = i - nCells;
         const int bi = bfaces[j];
-        double* q = buf + 14 * (size_t)nCells + 11 * (size_t)j;
+        double* q = buf + 14 * (size_t)nCells + 12 * (size_t)j;
         if (pack) {
             const RecA a = c.bA[bi]; const RecB b = c.bB[bi];
             q[0] = a.rho; q[1] = a.ux; q[2] = a.uy; q[3] = a.uz; q[4] = a.p; q[5] = a.e; q[6] = b.H; q[7] = b.c; q[8] = b.muQGD; q[9] = b.aOc;
-            q[10] = c.bG[bi];
+            q[10] = c.bG[bi]; q[11] = c.bRhoLag[bi];
         } else {
             RecA a; RecB b;
             a.rho = q[0]; a.ux = q[1]; a.uy = q[2]; a.uz = q[3]; a.p = q[4]; a.e = q[5]; b.H = q[6]; b.c = q[7]; b.muQGD = q[8]; b.aOc = q[9];
-            c.bA[bi] = a; c.bB[bi] = b; c.bG[bi] = q[10]; c.bPmid[bi] = a.p;
+            c.bA[bi] = a; c.bB[bi] = b; c.bG[bi] = q[10]; c.bPmid[bi] = a.p; c.bRhoLag[bi] = q[11];
         }
     }
 }
@@ -782,7 +807,12 @@ __global__ __launch_bounds__(QGD_BLOCK) void fvscOpKernel(const MeshView m, cons
     } else {
         constexpr int NO = NC / 3;  // vector -> scalar, tensor -> vector: div_j = sum_i d_i T_ij
 #pragma unroll
-        for (int j = 0; j < NO; ++j) out[(size_t)f * NO + j] = g[0 * NC + 0 * NO + j] + g[1 * NC + 1 * NO + j] + g[2 * NC + 2 * NO + j];
+        for (int j = 0; j < NO; ++j) {
+            double d = g[0 * NC + 0 * NO + j] + g[1 * NC + 1 * NO + j] + g[2 * NC + 2 * NO + j];
+            // the 2-D tensor divergence fills the two in-plane components only [GaussVolPointBase2D_8C L471-484]
+            if (ST == ST_GVP2 && NO == 3 && j == m.ie3) d = 0.0;
+            out[(size_t)f * NO + j] = d;
+        }
     }
 }
 
@@ -810,6 +840,10 @@ void launchBoundaryPoints(const Launcher& L, const MeshView& m, const CaseView& 
     else
         QGD_TIMED(L, QGD_K_POINT, (boundaryPointKernel<6><<<gridFor(m.nBP), QGD_BLOCK, 0, L.stream>>>(
             m, reinterpret_cast<const double*>(c.bA), 6, reinterpret_cast<double*>(c.P), 6, 0)));
+}
+void launchCommitMidStepPressure(const Launcher& L, const MeshView& m, const CaseView& c) {
+    if (m.nBF == 0) return;
+    QGD_TIMED(L, QGD_K_BC, (commitMidStepPressureKernel<<<gridFor(m.nBF), QGD_BLOCK, 0, L.stream>>>(m, c)));
 }
 void launchPressureMidStep(const Launcher& L, const MeshView& m, const CaseView& c, const PatchBCDev* bc) {
     if (m.nBF == 0) return;
@@ -860,10 +894,14 @@ void launchCellInit(const Launcher& L, const MeshView& m, const CaseView& c, con
                     const double* p) {
     cellInitKernel<<<gridFor(m.nC), QGD_BLOCK, 0, L.stream>>>(m, c, g, U, T, p);
 }
-void launchDeltaT(const Launcher& L, const CaseView& c, double maxCo, double maxDeltaT, double cTau, double* info) {
-    deltaTKernel<<<1, 1, 0, L.stream>>>(c, maxCo, maxDeltaT, cTau, info);
+void launchDeltaT(const Launcher& L, const CaseView& c, double maxCo, double maxDeltaT, double cTau) {
+    deltaTKernel<<<1, QGD_BLOCK, 0, L.stream>>>(c, maxCo, maxDeltaT, cTau);
 }
-void launchResetReductions(const Launcher& L, const CaseView& c) { resetReductionsKernel<<<1, 1, 0, L.stream>>>(c); }
+void launchResetReductions(const Launcher& L, const CaseView& c) { resetReductionsKernel<<<64, QGD_BLOCK, 0, L.stream>>>(c); }
+void launchCellMinReduce(const Launcher& L, const CaseView& c) { cellMinReduceKernel<<<1, QGD_BLOCK, 0, L.stream>>>(c); }
+int faceBlocks(const MeshView& m) { return gridFor(m.nIF); }
+int bfaceBlocks(const MeshView& m) { return gridFor(m.nBF); }
+int cellBlocks(const MeshView& m) { return gridFor(m.nC); }
 void launchHaloPack(const Launcher& L, const CaseView& c, const int32_t* cells, int32_t nCells, const int32_t* bfaces,
                     int32_t nFaces, double* buf, bool pack) {
     const int n = nCells + nFaces;

@@ -107,7 +107,7 @@ StaticData buildStaticData(const HostMesh& m) {
             skip = !hasFields(b);
             const double hb = (m.deltaCoeffs[f] != 0.0) ? 1.0 / std::fabs(m.deltaCoeffs[f]) : 0.0;
             const bool coupled = patchType[b] == QGD_PATCH_CYCLIC || patchType[b] == QGD_PATCH_HALO;
-            s.hf[f] = coupled ? hb : hb * 2.0;
+            s.hf[f] = skip ? 0.0 : (coupled ? hb : hb * 2.0);  // no field entries on empty patches
             s.dn[f] = m.deltaCoeffs[f];
             if (want3D) {
                 double d[3];

@@ -58,8 +58,10 @@ def step_init(C):
 
 
 def plane_init(C):
-    U, T, p = cases.box_initial_fields(C)
-    return U, T, p
+    """box_initial_fields with the pressure pulse centred in the (one cell thick) plane"""
+    U, T, _ = cases.box_initial_fields(C)
+    r2 = (C[:, 0] - 0.5) ** 2 + (C[:, 1] - 0.4) ** 2
+    return U, T, 1.0 + 0.1 * np.exp(-r2 / 0.01)
 
 
 def empty_z_bcs(case):
@@ -109,11 +111,20 @@ def test_update_fluxes_and_steps(mesh_kind, scheme, bc_fn, init_fn, opt):
         gc.step(chunk)
         oc.step(chunk)
         compare_fields(gc, oc, ["rho", "U", "p", "e", "rhoU", "rhoE"], STATE_TOL, tag + (f"step+{chunk}",))
+    # the reference refreshes H = (rhoE + p)/rho in updateFields.H; the device keeps it current per step
+    gc.updateFluxes()
+    oc.updateFluxes()
     compare_fields(gc, oc, CELL_FIELDS, STATE_TOL, tag + ("final",))
+    compare_fields(gc, oc, FACE_FIELDS, STATE_TOL, tag + ("final fluxes",))
+    # min(rho), min(e) [QGDFoam.C L142]: the device monitor covers the steps since the previous query
+    gc.info()
+    gc.step(1)
+    oc.step(1)
     ig, io = gc.info(), oc.info()
-    assert ig["steps"] == io["steps"] == 25
+    assert ig["steps"] == io["steps"] == 26
     assert abs(ig["time"] - io["time"]) <= 1e-12 * max(1.0, abs(io["time"]))
-    assert abs(ig["minRho"] - io["minRho"]) <= 1e-9 and ig["minRho"] > 0 and ig["minE"] > 0
+    assert abs(ig["minRho"] - io["minRho"]) <= 1e-9 and abs(ig["minE"] - io["minE"]) <= 1e-9
+    assert ig["minRho"] > 0 and ig["minE"] > 0
     gc.close(); dev.close()
 
 
