@@ -45,14 +45,6 @@ def parse():
     return ap.parse_args()
 
 
-def slab_range(n, rank, world):
-    lo = (n * rank) // world
-    hi = (n * (rank + 1)) // world
-    k_lo = lo - 1 if rank > 0 else lo
-    k_hi = hi + 1 if rank < world - 1 else hi
-    return lo, hi, k_lo, k_hi
-
-
 def cpu_baseline(n, steps):
     """The CPU oracle (a restatement of the reference listings: the reference itself cannot be built here) timed on
     one host core on a bounded sample of the same workload."""
@@ -91,6 +83,7 @@ def main():
 
     import qgdsolver_amd as q
     from qgdsolver_amd import _lib as L
+    from qgdsolver_amd.halo import SlabHalo, slab_range
     import cases
 
     if not torch.cuda.is_available() or q.device_count() < 1:
@@ -124,25 +117,10 @@ def main():
     case.set_stream(stream.cuda_stream)
     t_setup = time.perf_counter() - t_setup
 
-    # halo buffers (device) and peers: side 0 = lower k neighbour, side 1 = upper
-    sides = [s for s, peer in ((0, rank - 1), (1, rank + 1)) if 0 <= peer < world]
-    peers = {0: rank - 1, 1: rank + 1}
-    send = {s: torch.empty(case.halo_count(s), dtype=torch.float64, device="cuda") for s in sides}
-    recv = {s: torch.empty(case.halo_count(s), dtype=torch.float64, device="cuda") for s in sides}
-
-    def exchange():
-        if not sides:
-            return
-        for s in sides:
-            case.halo_pack(s, send[s].data_ptr())
-        ops = []
-        for s in sides:
-            ops.append(dist.P2POp(dist.isend, send[s], peers[s]))
-            ops.append(dist.P2POp(dist.irecv, recv[s], peers[s]))
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
-        for s in sides:
-            case.halo_unpack(s, recv[s].data_ptr())
+    # one RCCL send/recv pair per neighbour per step; buffers live in HBM, pack/unpack run on the same stream
+    halo = SlabHalo(case, rank, world, dist, alloc=lambda c: torch.empty(c, dtype=torch.float64, device="cuda"),
+                    arg=lambda t: t.data_ptr())
+    exchange = halo.exchange
 
     def step():
         case.step_phase(0)

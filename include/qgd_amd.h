@@ -253,6 +253,9 @@ int qgd_case_info(qgd_case_t c, double info[6]);
  * in one message.  pack gathers the owned boundary-layer cells' records into
  * the DEVICE buffer sendBuf; unpack scatters recvBuf into the ghost cells.
  * Both are asynchronous on the case's stream; qgd_case_stream_sync waits. */
+/* Plain device buffers for callers that own the transport (GPU-aware MPI, RCCL, ...). */
+int qgd_device_alloc(qgd_device_t d, int64_t bytes, void** devicePtr);
+int qgd_device_release(qgd_device_t d, void* devicePtr);
 int qgd_case_halo_count(qgd_case_t c, int side, int64_t* count);
 int qgd_case_halo_pack(qgd_case_t c, int side, double* sendBufDevice);
 int qgd_case_halo_unpack(qgd_case_t c, int side, const double* recvBufDevice);

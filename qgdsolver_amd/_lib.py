@@ -27,7 +27,7 @@ handle_p = C.POINTER(C.c_void_p)
 
 
 class CaseOptions(C.Structure):
-    """qgd_case_options (same layout as the oracle's orc_case_options)."""
+    """qgd_case_options of include/qgd_amd.h."""
 
     _fields_ = [
         ("stencil", C.c_int32), ("implicitDiffusion", C.c_int32), ("adjustTimeStep", C.c_int32), ("reserved", C.c_int32),
@@ -68,6 +68,8 @@ SIGNATURES = {
     "qgd_case_step": (C.c_int, [handle, C.c_int32]),
     "qgd_case_get_field": (C.c_int, [handle, C.c_char_p, c_double_p, C.c_int64]),
     "qgd_case_info": (C.c_int, [handle, c_double_p]),
+    "qgd_device_alloc": (C.c_int, [handle, C.c_int64, C.POINTER(C.c_void_p)]),
+    "qgd_device_release": (C.c_int, [handle, C.c_void_p]),
     "qgd_case_halo_count": (C.c_int, [handle, C.c_int, c_int64_p]),
     "qgd_case_halo_pack": (C.c_int, [handle, C.c_int, C.c_void_p]),
     "qgd_case_halo_unpack": (C.c_int, [handle, C.c_int, C.c_void_p]),

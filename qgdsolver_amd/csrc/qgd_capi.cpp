@@ -684,6 +684,24 @@ int qgd_case_stream_sync(qgd_case_t c) {
     QGD_CATCH
 }
 
+int qgd_device_alloc(qgd_device_t d, int64_t bytes, void** devicePtr) {
+    QGD_TRY
+    if (!d || !devicePtr || bytes <= 0) return fail(QGD_ERR_INVALID, "qgd_device_alloc: bad argument");
+    HIP_CHECK(hipSetDevice(d->deviceId));
+    HIP_CHECK(hipMalloc(devicePtr, (size_t)bytes));
+    HIP_CHECK(hipMemset(*devicePtr, 0, (size_t)bytes));
+    return QGD_OK;
+    QGD_CATCH
+}
+int qgd_device_release(qgd_device_t d, void* devicePtr) {
+    QGD_TRY
+    if (!d) return fail(QGD_ERR_INVALID, "null device");
+    HIP_CHECK(hipSetDevice(d->deviceId));
+    HIP_CHECK(hipFree(devicePtr));
+    return QGD_OK;
+    QGD_CATCH
+}
+
 // halo message layout: 14 doubles per cell (RecA, RecB, Cons), 12 per boundary face (RecA, RecB, p gradient, lagged rho)
 int qgd_case_halo_count(qgd_case_t c, int side, int64_t* count) {
     if (!c || !count || side < 0 || side > 1) return fail(QGD_ERR_INVALID, "bad argument");

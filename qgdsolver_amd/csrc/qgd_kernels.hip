@@ -477,7 +477,7 @@ __global__ __launch_bounds__(QGD_BLOCK) void boundaryFaceFluxKernel(const MeshVi
 template <int NC>
 __global__ __launch_bounds__(QGD_BLOCK) void pointInterpKernel(const MeshView m, const double* __restrict__ cellF,
                                                               const int cellStride, double* __restrict__ ptF) {
-    const int p = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    const int p = xcdTile((int)gridDim.x) * QGD_BLOCK + threadIdx.x;
     if (p >= m.nP) return;
     const int e0 = m.pcOff[p], e1 = m.pcOff[p + 1];
     if (e0 == e1) return;  // patch point: written by boundaryPointKernel
@@ -551,7 +551,8 @@ __global__ __launch_bounds__(QGD_BLOCK) void pressureMidStepKernel(const MeshVie
 // summation order of fvc::surfaceIntegrate), explicit Euler, thermo, QGD coeffs
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(QGD_BLOCK) void cellUpdateKernel(const MeshView m, const CaseView c, const GasModel gm) {
-    const int ci = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    const int tile = xcdTile((int)gridDim.x);
+    const int ci = tile * QGD_BLOCK + threadIdx.x;
     double rmin = 1e300, emin = 1e300;
     if (ci < m.nC) {
         double sum[5] = {0, 0, 0, 0, 0};
@@ -599,7 +600,7 @@ __global__ __launch_bounds__(QGD_BLOCK) void cellUpdateKernel(const MeshView m, 
         if (!(m.ghost && m.ghost[ci])) { rmin = rho; emin = An.e; }
     }
     // positivity monitor [QGDFoam_8C L142]: one plain store pair per workgroup, no atomics
-    blockMaxMin(-rmin, emin, c.blkCell + 2 * (size_t)blockIdx.x, true);
+    blockMaxMin(-rmin, emin, c.blkCell + 2 * (size_t)tile, true);
 }
 
 // createFields.H for the cells [QGDFoam_2createFields_8H L3-109]

@@ -30,6 +30,15 @@ class Device:
         self.fvSchemes = fv_schemes if fv_schemes is not None else {"fvsc": {"default": "GaussVolPoint"}}
         self._registry = {}  # objectRegistry of stencils by name
 
+    def alloc(self, nbytes):
+        """raw device buffer (zeroed); returns the device pointer as int"""
+        p = C.c_void_p()
+        L.check(L.lib.qgd_device_alloc(self._h, int(nbytes), C.byref(p)), "qgd_device_alloc")
+        return p.value
+
+    def release(self, ptr):
+        L.check(L.lib.qgd_device_release(self._h, C.c_void_p(ptr)), "qgd_device_release")
+
     def close(self):
         if getattr(self, "_h", None):
             L.lib.qgd_device_free(self._h)

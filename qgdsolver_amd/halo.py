@@ -1,0 +1,47 @@
+"""Cell-range (k-slab) sharding of the box and the per-step halo exchange.
+
+One process per GPU; rank r owns the planes [lo, hi) and carries one ghost plane per cut.  Per step each
+rank sends its boundary-layer records (one plane of cells + their patch faces) to each neighbour and
+receives the neighbour's into its ghost plane: ONE message per neighbour per step, point-to-point (a slab has
+at most two neighbours, so each pair talks over its own xGMI link).  ``torch.distributed`` is only the
+transport (backend "nccl" == RCCL on ROCm, "gloo" on CPU); pack/unpack are the library's own kernels.
+"""
+
+
+def slab_range(n, rank, world):
+    """owned planes [lo, hi) and the mesh window [k_lo, k_hi) including ghost planes"""
+    lo = (n * rank) // world
+    hi = (n * (rank + 1)) // world
+    k_lo = lo - 1 if rank > 0 else lo
+    k_hi = hi + 1 if rank < world - 1 else hi
+    return lo, hi, k_lo, k_hi
+
+
+class SlabHalo:
+    """Halo exchange for a case whose mesh came from ``PolyMesh.box(..., k_range=...)``.
+
+    ``alloc(count)`` returns a float64 torch tensor living where the case's data lives;
+    ``arg(tensor)`` turns it into what ``case.halo_pack/unpack`` take (a device pointer for the HIP case).
+    """
+
+    def __init__(self, case, rank, world, dist, alloc, arg):
+        self.case, self.rank, self.world, self.dist = case, rank, world, dist
+        self.arg = arg
+        self.sides = [s for s, peer in ((0, rank - 1), (1, rank + 1)) if 0 <= peer < world]
+        self.peer = {0: rank - 1, 1: rank + 1}
+        self.send = {s: alloc(case.halo_count(s)) for s in self.sides}
+        self.recv = {s: alloc(case.halo_count(s)) for s in self.sides}
+
+    def exchange(self):
+        if not self.sides:
+            return
+        for s in self.sides:
+            self.case.halo_pack(s, self.arg(self.send[s]))
+        ops = []
+        for s in self.sides:
+            ops.append(self.dist.P2POp(self.dist.isend, self.send[s], self.peer[s]))
+            ops.append(self.dist.P2POp(self.dist.irecv, self.recv[s], self.peer[s]))
+        for w in self.dist.batch_isend_irecv(ops):
+            w.wait()
+        for s in self.sides:
+            self.case.halo_unpack(s, self.arg(self.recv[s]))
