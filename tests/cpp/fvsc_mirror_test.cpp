@@ -1,0 +1,53 @@
+// C++ host-side mirror over the C-ABI: reads like a reference call site (fvsc::grad(p), fvsc::div(U)).
+// Linear field on a box: the GaussVolPoint gradient must be exact on interior faces.
+#include <cmath>
+#include <cstdio>
+#include <vector>
+
+#include "qgd_amd_fvsc.hpp"
+
+using namespace qgd_amd;
+
+int main() {
+    if (qgd_device_count() < 1) { std::printf("no device\n"); return 77; }
+    const double lo[3] = {0, 0, 0}, hi[3] = {1, 1, 1};
+    qgd_mesh_t m = nullptr;
+    check(qgd_mesh_box(8, 8, 8, 0, 8, lo, hi, nullptr, &m), "qgd_mesh_box");
+    int64_t sz[7];
+    check(qgd_mesh_sizes(m, sz), "sizes");
+    fvMesh mesh;
+    mesh.nFaces = sz[1]; mesh.nInternalFaces = sz[2]; mesh.nCells = sz[3];
+    check(qgd_device_create(m, 0, &mesh.device), "qgd_device_create");
+    std::vector<double> C(3 * sz[3]), Cf(3 * sz[1]);
+    check(qgd_mesh_get(m, "C", C.data(), (int64_t)C.size() * 8), "C");
+    check(qgd_mesh_get(m, "Cf", Cf.data(), (int64_t)Cf.size() * 8), "Cf");
+    const double g[3] = {1.3, -0.7, 0.4};
+    volField p{"p", 1, {}, {}};
+    for (int64_t c = 0; c < sz[3]; ++c) p.internal.push_back(2.0 + g[0] * C[3 * c] + g[1] * C[3 * c + 1] + g[2] * C[3 * c + 2]);
+    for (int64_t f = sz[2]; f < sz[1]; ++f) p.boundary.push_back(2.0 + g[0] * Cf[3 * f] + g[1] * Cf[3 * f + 1] + g[2] * Cf[3 * f + 2]);
+    surfaceField gp = fvsc::grad(mesh, p);
+    // faces whose centre is at least 2 cells from the boundary
+    double worst = 0;
+    int counted = 0;
+    for (int64_t f = 0; f < sz[2]; ++f) {
+        bool inner = true;
+        for (int k = 0; k < 3; ++k) inner = inner && Cf[3 * f + k] > 0.26 && Cf[3 * f + k] < 0.74;
+        if (!inner) continue;
+        ++counted;
+        for (int k = 0; k < 3; ++k) worst = std::fmax(worst, std::fabs(gp.values[3 * f + k] - g[k]));
+    }
+    std::printf("interior faces %d, max |grad - g| = %.3e\n", counted, worst);
+    if (!(counted > 50) || !(worst < 1e-12)) return 1;
+    // scheme checks behave like fvscOpName: leastSquares is fatal on a 3-D mesh, unknown words are fatal
+    mesh.fvscSchemes["grad(T)"] = "leastSquares";
+    volField T = p; T.name = "T";
+    try { fvsc::grad(mesh, T); return 2; } catch (const FatalError& e) { if (e.status != QGD_ERR_SCHEME) return 3; }
+    mesh.fvscSchemes["grad(T)"] = "noSuchStencil";
+    try { fvsc::grad(mesh, T); return 4; } catch (const FatalError& e) { if (e.status != QGD_ERR_UNKNOWN_NAME) return 5; }
+    if (mesh.registry.size() != 1) return 6;  // lookupOrNew cached exactly the GaussVolPoint stencil
+    mesh.registry.clear();
+    qgd_device_free(mesh.device);
+    qgd_mesh_free(m);
+    std::printf("ok\n");
+    return 0;
+}
