@@ -368,10 +368,10 @@ int qgd_device_create(qgd_mesh_t mh, int deviceId, qgd_device_t* out) {
         v.ip13 = reinterpret_cast<const int2*>(up(s.ip13)); v.c2d = up(s.c2d);
         v.lsqOff = up(s.lsqOff); v.lsqCell = up(s.lsqCell); v.lsqGw = up(s.lsqGw); v.lsqDeg = up(s.lsqDeg);
         v.lsqBndZero = up(s.lsqBndZero);
-        v.pcOff = up(s.pcOff); v.pcCell = up(s.pcCell); v.pcW = up(s.pcW);
+        v.pcSlice = up(s.pcSlice); v.pcCount = up(s.pcCount); v.pcCell = up(s.pcCell); v.pcW = up(s.pcW);
         v.nBP = (int32_t)s.bpPoint.size();
         v.bpPoint = up(s.bpPoint); v.bpOff = up(s.bpOff); v.bpFace = up(s.bpFace); v.bpW = up(s.bpW);
-        v.cfOff = up(s.cfOff); v.cfItem = up(s.cfItem);
+        v.cfSlice = up(s.cfSlice); v.cfCount = up(s.cfCount); v.cfItem = up(s.cfItem);
         v.V = up(s.V); v.hQGD = up(s.hQGD); v.ghost = up(s.ghost);
         v.bPatch = up(s.bPatch); v.hQGDb = up(s.hQGDb);
         for (int side = 0; side < 2; ++side) {

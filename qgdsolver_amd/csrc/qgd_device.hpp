@@ -33,9 +33,9 @@ struct MeshView {
     const int2* ip13;        // nF
     const double* c2d;       // 6*nF
     const int32_t* lsqOff; const int32_t* lsqCell; const double* lsqGw; const uint8_t* lsqDeg; const uint8_t* lsqBndZero;
-    const int32_t* pcOff; const int32_t* pcCell; const double* pcW;
+    const int32_t* pcSlice; const uint8_t* pcCount; const int32_t* pcCell; const double* pcW;  // sliced ELL (64-point slices)
     int32_t nBP; const int32_t* bpPoint; const int32_t* bpOff; const int32_t* bpFace; const double* bpW;
-    const int32_t* cfOff; const int32_t* cfItem;
+    const int32_t* cfSlice; const uint8_t* cfCount; const int32_t* cfItem;                     // sliced ELL (64-cell slices)
     const double* V; const double* hQGD; const uint8_t* ghost;
     const int32_t* bPatch; const double* hQGDb;
 };
@@ -60,7 +60,7 @@ struct CaseView {
     double* bPmid;                  // nBF patch pressure after GaussVolPoint's mid-step BC evaluation
     double* bRhoLag;                // nBF patch density of the previous step: rhoU_b, rhoE_b are built with it
                                     //     [QGDUEqn_8H L88-89, QGDEEqn_8H L75-76 run before QGDFoam_8C L156]
-    double* flux;                   // 5*nF net face fluxes
+    double* flux;                   // 5*nF net face fluxes, SoA: flux[k*nF + f]
     double* red;                    // [0]=max Co, [1]=min tauQGDf, [2]=min rho, [3]=min e
     double* blkFace;                // 2 per face-kernel workgroup (internal then boundary): max Cof, min tauQGDf
     double* blkCell;                // 2 per cell-kernel workgroup: min rho, min e since the last query

@@ -374,9 +374,8 @@ __global__ __launch_bounds__(QGD_BLOCK) void faceFluxKernel(const MeshView m, co
         const double S[3] = {m.Sx[f], m.Sy[f], m.Sz[f]};
         double out[5], phiw;
         qgdFluxes<DBG>(s, g, S, out, phiw, DBG ? c.dbg + f : nullptr, (size_t)m.nF);
-        double* fo = c.flux + 5 * (size_t)f;
 #pragma unroll
-        for (int k = 0; k < 5; ++k) fo[k] = out[k];
+        for (int k = 0; k < 5; ++k) c.flux[(size_t)k * m.nF + f] = out[k];
         if (adjustDt) {
             const bool counted = (m.ghost == nullptr) || !(m.ghost[o] && m.ghost[n]);
             if (counted) {
@@ -456,9 +455,8 @@ __global__ __launch_bounds__(QGD_BLOCK) void boundaryFaceFluxKernel(const MeshVi
             qgdFluxes<DBG>(s, g, S, out, phiw, DBG ? c.dbg + f : nullptr, (size_t)m.nF);
             c.bPhiw[b] = phiw;
             if (!phiwOnly) {
-                double* fo = c.flux + 5 * (size_t)f;
 #pragma unroll
-                for (int k = 0; k < 5; ++k) fo[k] = out[k];
+                for (int k = 0; k < 5; ++k) c.flux[(size_t)k * m.nF + f] = out[k];
                 if (adjustDt && !(m.ghost && m.ghost[o])) {
                     const double ms = m.magSf[f];
                     const double Unf = s.Uf[0] * (S[0] / ms) + s.Uf[1] * (S[1] / ms) + s.Uf[2] * (S[2] / ms);
@@ -479,20 +477,54 @@ __global__ __launch_bounds__(QGD_BLOCK) void pointInterpKernel(const MeshView m,
                                                               const int cellStride, double* __restrict__ ptF) {
     const int p = xcdTile((int)gridDim.x) * QGD_BLOCK + threadIdx.x;
     if (p >= m.nP) return;
-    const int e0 = m.pcOff[p], e1 = m.pcOff[p + 1];
-    if (e0 == e1) return;  // patch point: written by boundaryPointKernel
+    const int n = m.pcCount[p];
+    if (n == 0) return;  // patch point: written by boundaryPointKernel
+    const size_t base = (size_t)m.pcSlice[p >> 6] * 64 + (p & 63);
     double acc[NC];
 #pragma unroll
     for (int k = 0; k < NC; ++k) acc[k] = 0.0;
-    for (int e = e0; e < e1; ++e) {
-        const double w = m.pcW[e];
-        const double* cv = cellF + (size_t)m.pcCell[e] * cellStride;
+    for (int i = 0; i < n; ++i) {
+        const double w = m.pcW[base + (size_t)i * 64];
+        const double* cv = cellF + (size_t)m.pcCell[base + (size_t)i * 64] * cellStride;
 #pragma unroll
         for (int k = 0; k < NC; ++k) acc[k] += w * cv[k];
     }
     double* o = ptF + (size_t)p * NC;
 #pragma unroll
     for (int k = 0; k < NC; ++k) o[k] = acc[k];
+}
+
+// The case's vertex kernel: the gather list of a wave is read as contiguous runs (sliced ELL), the cell records
+// as whole 48-B records (3 x dwordx4), all gathers of a point are issued before the first use.
+__global__ __launch_bounds__(QGD_BLOCK) void pointInterpRecKernel(const MeshView m, const RecA* __restrict__ A,
+                                                                 RecA* __restrict__ P) {
+    const int p = xcdTile((int)gridDim.x) * QGD_BLOCK + threadIdx.x;
+    if (p >= m.nP) return;
+    const int n = m.pcCount[p];
+    if (n == 0) return;
+    const size_t base = (size_t)m.pcSlice[p >> 6] * 64 + (p & 63);
+    RecA acc = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    int i = 0;
+    for (; i + 8 <= n; i += 8) {  // hexahedral interior vertices: exactly one pass
+        int id[8];
+        double w[8];
+        RecA r[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { id[q] = m.pcCell[base + (size_t)(i + q) * 64]; w[q] = m.pcW[base + (size_t)(i + q) * 64]; }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) r[q] = A[id[q]];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            acc.rho += w[q] * r[q].rho; acc.ux += w[q] * r[q].ux; acc.uy += w[q] * r[q].uy;
+            acc.uz += w[q] * r[q].uz; acc.p += w[q] * r[q].p; acc.e += w[q] * r[q].e;
+        }
+    }
+    for (; i < n; ++i) {
+        const double w = m.pcW[base + (size_t)i * 64];
+        const RecA r = A[m.pcCell[base + (size_t)i * 64]];
+        acc.rho += w * r.rho; acc.ux += w * r.ux; acc.uy += w * r.uy; acc.uz += w * r.uz; acc.p += w * r.p; acc.e += w * r.e;
+    }
+    P[p] = acc;
 }
 
 // After the boundary-face fluxes took pf from the old patch pressure, the patch field holds the mid-step value
@@ -556,13 +588,32 @@ __global__ __launch_bounds__(QGD_BLOCK) void cellUpdateKernel(const MeshView m, 
     double rmin = 1e300, emin = 1e300;
     if (ci < m.nC) {
         double sum[5] = {0, 0, 0, 0, 0};
-        const int e0 = m.cfOff[ci], e1 = m.cfOff[ci + 1];
-        for (int e = e0; e < e1; ++e) {
-            const int it = m.cfItem[e];
-            const bool isOwner = it >= 0;
-            const double* fl = c.flux + 5 * (size_t)(isOwner ? it : ~it);
+        const int n = m.cfCount[ci];
+        const size_t base = (size_t)m.cfSlice[ci >> 6] * 64 + (ci & 63);
+        const size_t nF = (size_t)m.nF;
+        int i = 0;
+        for (; i + 6 <= n; i += 6) {  // hexahedra: one pass; all 30 flux loads in flight before the ordered sum
+            int it[6];
+            double fl[6][5];
 #pragma unroll
-            for (int k = 0; k < 5; ++k) sum[k] = isOwner ? sum[k] + fl[k] : sum[k] - fl[k];
+            for (int q = 0; q < 6; ++q) it[q] = m.cfItem[base + (size_t)(i + q) * 64];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                const size_t f = (size_t)(it[q] >= 0 ? it[q] : ~it[q]);
+#pragma unroll
+                for (int k = 0; k < 5; ++k) fl[q][k] = c.flux[k * nF + f];
+            }
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int k = 0; k < 5; ++k) sum[k] = (it[q] >= 0) ? sum[k] + fl[q][k] : sum[k] - fl[q][k];
+        }
+        for (; i < n; ++i) {
+            const int it = m.cfItem[base + (size_t)i * 64];
+            const bool isOwner = it >= 0;
+            const size_t f = (size_t)(isOwner ? it : ~it);
+#pragma unroll
+            for (int k = 0; k < 5; ++k) sum[k] = isOwner ? sum[k] + c.flux[k * nF + f] : sum[k] - c.flux[k * nF + f];
         }
         const RecA A = c.A[ci];
         const Cons K = c.K[ci];
@@ -830,8 +881,7 @@ static inline int gridFor(int64_t n) { return (int)((n + QGD_BLOCK - 1) / QGD_BL
 
 void launchPointInterp(const Launcher& L, const MeshView& m, const CaseView& c) {
     if (m.nP == 0) return;
-    QGD_TIMED(L, QGD_K_POINT, (pointInterpKernel<6><<<gridFor(m.nP), QGD_BLOCK, 0, L.stream>>>(
-        m, reinterpret_cast<const double*>(c.A), 6, reinterpret_cast<double*>(c.P))));
+    QGD_TIMED(L, QGD_K_POINT, (pointInterpRecKernel<<<gridFor(m.nP), QGD_BLOCK, 0, L.stream>>>(m, c.A, c.P)));
 }
 void launchBoundaryPoints(const Launcher& L, const MeshView& m, const CaseView& c, bool pOnly) {
     if (m.nBP == 0) return;

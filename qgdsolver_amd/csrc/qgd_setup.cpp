@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <stdexcept>
 
 #include "../../include/qgd_amd.h"
 
@@ -26,11 +27,41 @@ inline void cross(const double* a, const double* b, double* c) {
 }
 }  // namespace
 
+// CSR (off, items[, weights]) -> sliced ELL with 64-row slices
+static void toSlicedEll(const std::vector<int32_t>& off, int64_t nRows, const std::vector<int32_t>& items,
+                        const std::vector<double>* weights, std::vector<int32_t>& slice, std::vector<uint8_t>& count,
+                        std::vector<int32_t>& ellItems, std::vector<double>* ellW, int32_t padItem) {
+    const int64_t nSlices = (nRows + 63) / 64;
+    slice.assign((size_t)nSlices + 1, 0);
+    count.assign((size_t)nRows, 0);
+    for (int64_t s = 0; s < nSlices; ++s) {
+        int32_t width = 0;
+        for (int64_t r = 64 * s; r < std::min<int64_t>(nRows, 64 * s + 64); ++r) {
+            const int32_t n = off[r + 1] - off[r];
+            if (n > 255) throw std::invalid_argument("gather row longer than 255 entries");
+            count[r] = (uint8_t)n;
+            width = std::max(width, n);
+        }
+        slice[s + 1] = slice[s] + width;
+    }
+    ellItems.assign((size_t)slice[nSlices] * 64, padItem);
+    if (ellW) ellW->assign((size_t)slice[nSlices] * 64, 0.0);
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < nRows; ++r) {
+        const int64_t s = r >> 6, lane = r & 63;
+        for (int32_t i = 0; i < off[r + 1] - off[r]; ++i) {
+            const size_t dst = ((size_t)slice[s] + i) * 64 + lane;
+            ellItems[dst] = items[off[r] + i];
+            if (ellW) (*ellW)[dst] = (*weights)[off[r] + i];
+        }
+    }
+}
+
 int64_t StaticData::bytes() const {
     auto sz = [](auto& v) { return (int64_t)(v.size() * sizeof(v[0])); };
     int64_t b = sz(own) + sz(nei) + sz(verts) + sz(fkind) + sz(magSf) + sz(w) + sz(hf) + sz(dn) + sz(coef) + sz(rV) +
                 sz(bmvON) + sz(ip13) + sz(c2d) + sz(lsqOff) + sz(lsqCell) + sz(lsqGw) + sz(lsqDeg) + sz(lsqBndZero) +
-                sz(pcOff) + sz(pcCell) + sz(pcW) + sz(bpPoint) + sz(bpOff) + sz(bpFace) + sz(bpW) + sz(cfOff) + sz(cfItem) +
+                sz(pcSlice) + sz(pcCount) + sz(pcCell) + sz(pcW) + sz(bpPoint) + sz(bpOff) + sz(bpFace) + sz(bpW) + sz(cfSlice) + sz(cfCount) + sz(cfItem) +
                 sz(V) + sz(hQGD) + sz(ghost) + sz(bPatch) + sz(hQGDb);
     for (int k = 0; k < 3; ++k) b += sz(Sf[k]);
     return b;
@@ -275,17 +306,18 @@ StaticData buildStaticData(const HostMesh& m) {
         const int64_t f = nIF + b;
         for (int32_t q = m.faceOffsets[f]; q < m.faceOffsets[f + 1]; ++q) isPatchPoint[m.facePoints[q]] = 1;
     }
-    s.pcOff.assign((size_t)m.nPoints + 1, 0);
+    std::vector<int32_t> pcOff((size_t)m.nPoints + 1, 0), pcCellCsr;
+    std::vector<double> pcWCsr;
     for (int32_t p = 0; p < m.nPoints; ++p)
-        s.pcOff[p + 1] = s.pcOff[p] + (isPatchPoint[p] ? 0 : pc.rowSize(p));
-    s.pcCell.resize((size_t)s.pcOff[m.nPoints]);
-    s.pcW.resize((size_t)s.pcOff[m.nPoints]);
+        pcOff[p + 1] = pcOff[p] + (isPatchPoint[p] ? 0 : pc.rowSize(p));
+    pcCellCsr.resize((size_t)pcOff[m.nPoints]);
+    pcWCsr.resize((size_t)pcOff[m.nPoints]);
 #pragma omp parallel for schedule(static)
     for (int32_t p = 0; p < m.nPoints; ++p) {
         if (isPatchPoint[p]) continue;
         const int32_t n = pc.rowSize(p);
-        int32_t* cells = &s.pcCell[s.pcOff[p]];
-        double* w = &s.pcW[s.pcOff[p]];
+        int32_t* cells = &pcCellCsr[pcOff[p]];
+        double* w = &pcWCsr[pcOff[p]];
         double sum = 0;
         for (int32_t i = 0; i < n; ++i) {
             const int32_t c = pc.items[pc.offsets[p] + i];
@@ -297,6 +329,8 @@ StaticData buildStaticData(const HostMesh& m) {
         }
         for (int32_t i = 0; i < n; ++i) w[i] /= sum;
     }
+    toSlicedEll(pcOff, m.nPoints, pcCellCsr, &pcWCsr, s.pcSlice, s.pcCount, s.pcCell, &s.pcW, -1);
+    { std::vector<int32_t>().swap(pcCellCsr); std::vector<double>().swap(pcWCsr); std::vector<int32_t>().swap(pcOff); }
     {
         // patch points: boundary faces around each, ascending boundary-face label
         std::vector<int32_t> cnt((size_t)m.nPoints, 0);
@@ -341,7 +375,7 @@ StaticData buildStaticData(const HostMesh& m) {
         // flux gather list: ascending face label == summation order of
         // fvc::surfaceIntegrate for that cell (upper-triangular face order)
         Csr cf = buildCellFaces(m);
-        s.cfOff.assign((size_t)nC + 1, 0);
+        std::vector<int32_t> cfOff((size_t)nC + 1, 0), cfItemCsr;
         auto keep = [&](int32_t f) {
             if (f < nIF) return true;
             const int t = patchType[f - nIF];
@@ -350,18 +384,19 @@ StaticData buildStaticData(const HostMesh& m) {
         for (int64_t c = 0; c < nC; ++c) {
             int32_t n = 0;
             for (int32_t k = cf.offsets[c]; k < cf.offsets[c + 1]; ++k) if (keep(cf.items[k])) ++n;
-            s.cfOff[c + 1] = s.cfOff[c] + n;
+            cfOff[c + 1] = cfOff[c] + n;
         }
-        s.cfItem.resize((size_t)s.cfOff[nC]);
+        cfItemCsr.resize((size_t)cfOff[nC]);
 #pragma omp parallel for schedule(static)
         for (int64_t c = 0; c < nC; ++c) {
-            int32_t o = s.cfOff[c];
+            int32_t o = cfOff[c];
             for (int32_t k = cf.offsets[c]; k < cf.offsets[c + 1]; ++k) {
                 const int32_t f = cf.items[k];
                 if (!keep(f)) continue;
-                s.cfItem[o++] = (m.owner[f] == c) ? f : ~f;
+                cfItemCsr[o++] = (m.owner[f] == c) ? f : ~f;
             }
         }
+        toSlicedEll(cfOff, nC, cfItemCsr, nullptr, s.cfSlice, s.cfCount, s.cfItem, nullptr, 0);
         // hQGD: area-weighted mean of hQGDf over the cell's faces, OpenFOAM
         // cells() order, skipping empty/wedge patches [QGDCoeffs.C L323-362]
         Csr cfo = buildCellFacesFoamOrder(m);

@@ -49,8 +49,13 @@ struct StaticData {
     std::vector<uint8_t> lsqBndZero;  // nBF: 1 on constraint patches (gradient left zero)
 
     // ---- points -------------------------------------------------------------
-    std::vector<int32_t> pcOff;   // nP+1 (patch points have empty rows)
-    std::vector<int32_t> pcCell;
+    // point -> cells in sliced-ELL form: a slice is 64 consecutive points (one wavefront); entry i of the 64
+    // points of slice s sits at (pcSlice[s] + i)*64 + lane, so every gather-list load of a wave is one
+    // contiguous 256/512-B run.  Rows keep OpenFOAM's pointCells order (ascending cell label); patch points
+    // have count 0.
+    std::vector<int32_t> pcSlice; // nSlices+1, in rows of 64 entries
+    std::vector<uint8_t> pcCount; // nP
+    std::vector<int32_t> pcCell;  // padded entries: -1
     std::vector<double> pcW;
     std::vector<int32_t> bpPoint; // patch points
     std::vector<int32_t> bpOff;   // bpPoint.size()+1
@@ -58,8 +63,11 @@ struct StaticData {
     std::vector<double> bpW;
 
     // ---- cells --------------------------------------------------------------
-    std::vector<int32_t> cfOff;   // nC+1: flux gather list, ascending face label
-    std::vector<int32_t> cfItem;  // f (owner, +) or ~f (neighbour, -); empty/halo faces left out
+    // cell -> faces flux gather list, sliced-ELL like pc*; rows in ascending face label (== the summation order of
+    // fvc::surfaceIntegrate); item = f (cell is owner, +) or ~f (cell is neighbour, -); empty/halo faces left out
+    std::vector<int32_t> cfSlice; // nSlices+1
+    std::vector<uint8_t> cfCount; // nC
+    std::vector<int32_t> cfItem;
     std::vector<double> V;        // nC
     std::vector<double> hQGD;     // nC
     std::vector<uint8_t> ghost;   // nC (may be empty)
