@@ -356,7 +356,7 @@ int qgd_device_create(qgd_mesh_t mh, int deviceId, qgd_device_t* out) {
         DeviceArena& a = d->arena;
         MeshView& v = d->view;
         v.nP = s.nP; v.nF = s.nF; v.nIF = s.nIF; v.nC = s.nC; v.nBF = s.nBF;
-        v.ie1 = s.ie1; v.ie2 = s.ie2; v.ie3 = s.ie3; v.ncoef = s.ncoef;
+        v.ie1 = s.ie1; v.ie2 = s.ie2; v.ie3 = s.ie3;
         // upload + free each table in turn so the host peak stays at one table
         auto up = [&](auto& vec) { auto* p = a.upload(vec); std::decay_t<decltype(vec)>().swap(vec); return p; };
         v.own = up(s.own); v.nei = up(s.nei);
@@ -364,7 +364,8 @@ int qgd_device_create(qgd_mesh_t mh, int deviceId, qgd_device_t* out) {
         v.fkind = up(s.fkind);
         v.Sx = up(s.Sf[0]); v.Sy = up(s.Sf[1]); v.Sz = up(s.Sf[2]);
         v.magSf = up(s.magSf); v.w = up(s.w); v.hf = up(s.hf); v.dn = up(s.dn);
-        v.coef = up(s.coef); v.rV = up(s.rV); v.bmvON = up(s.bmvON);
+        v.X = reinterpret_cast<const double4*>(up(s.X)); v.Cc = reinterpret_cast<const double4*>(up(s.Cc));
+        v.bN = reinterpret_cast<const double4*>(up(s.bN)); v.bmvON = up(s.bmvON);
         v.ip13 = reinterpret_cast<const int2*>(up(s.ip13)); v.c2d = up(s.c2d);
         v.lsqOff = up(s.lsqOff); v.lsqCell = up(s.lsqCell); v.lsqGw = up(s.lsqGw); v.lsqDeg = up(s.lsqDeg);
         v.lsqBndZero = up(s.lsqBndZero);

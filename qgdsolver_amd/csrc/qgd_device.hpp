@@ -17,7 +17,6 @@ enum StencilKind : int { ST_REDUCED = 0, ST_LSQ = 1, ST_GVP3 = 2, ST_GVP2 = 3 };
 struct MeshView {
     int32_t nP, nF, nIF, nC, nBF;
     int32_t ie1, ie2, ie3;
-    int32_t ncoef;           // 9 or 12
     const int32_t* own;      // nF
     const int32_t* nei;      // nIF
     const int4* verts;       // nF
@@ -27,8 +26,9 @@ struct MeshView {
     const double* w;         // nF
     const double* hf;        // nF
     const double* dn;        // nF
-    const double* coef;      // ncoef*nF
-    const double* rV;        // nF
+    const double4* X;        // nP  vertex coordinates (x,y,z,0)
+    const double4* Cc;       // nC  cell centres
+    const double4* bN;       // nBF mirror points of boundary faces
     const double* bmvON;     // nBF
     const int2* ip13;        // nF
     const double* c2d;       // 6*nF

@@ -31,6 +31,28 @@ namespace qgd {
 
 __device__ __forceinline__ double lerpf(double w, double a, double b) { return w * (a - b) + b; }
 
+// Streamed-once data (per-face geometry, gather lists) is loaded non-temporally so it does not push the
+// re-used cell/vertex records out of the 4 MiB L2 of the XCD.
+#ifndef QGD_NT
+#define QGD_NT 1
+#endif
+template <class T>
+__device__ __forceinline__ T ldStream(const T* p) {
+#if QGD_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+template <class T>
+__device__ __forceinline__ void stStream(T* p, T v) {
+#if QGD_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 // Workgroup reduction (wave shuffles + 4-entry LDS): slot[0] = max(a), slot[1] = min(b).
 // With `accumulate` the slot keeps the running extremum since it was last reset.
 __device__ __forceinline__ void blockMaxMin(double a, double b, double* __restrict__ slot, const bool accumulate) {
@@ -59,6 +81,54 @@ struct FaceVals {
     double n[NC];   // neighbour cell (internal face) or patch value (boundary face)
     double sn[NC];  // boundary face: patch snGrad
 };
+
+// ---------------------------------------------------------------------------
+// GaussVolPoint 3-D coefficients of one face from its geometry [GaussVolPointBase3D_8C L161-476].
+// O/N: owner / neighbour cell centre (boundary: mirror point), x1..x4: face vertices in face order.
+// quad: a[3d+0]=a0, a[3d+1]=a1, a[3d+2]=a5 (a2=-a0, a3=-a1, a4=-a5) [L353-389];  rV = 1/V [L346-350]
+// tri : t[4d+0..2]=a0..a2 (vertices), t[4d+3]=a3 (neighbour), owner = -a3 [L193-229]; rV = 1/V [L186-190]
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void gvpQuadCoef(const double4 O, const double4 N, const double4 x1, const double4 x2,
+                                            const double4 x3, const double4 x4, double a[9], double& rV) {
+    const double sixth = (1.0 / 6.0);
+    const double o[3] = {O.x, O.y, O.z}, n[3] = {N.x, N.y, N.z};
+    const double p1[3] = {x1.x, x1.y, x1.z}, p2[3] = {x2.x, x2.y, x2.z}, p3[3] = {x3.x, x3.y, x3.z}, p4[3] = {x4.x, x4.y, x4.z};
+    double d31[3], d42[3], on[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { d31[k] = p3[k] - p1[k]; d42[k] = p4[k] - p2[k]; on[k] = o[k] - n[k]; }
+    const double cr[3] = {d42[1] * on[2] - d42[2] * on[1], d42[2] * on[0] - d42[0] * on[2], d42[0] * on[1] - d42[1] * on[0]};
+    double vol = d31[0] * cr[0] + d31[1] * cr[1] + d31[2] * cr[2];
+    vol *= sixth;
+    rV = 1.0 / vol;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int u = (d + 1) % 3, v = (d + 2) % 3;
+        a[3 * d + 0] = sixth * ((n[u] - o[u]) * (p2[v] - p4[v]) - (n[v] - o[v]) * (p2[u] - p4[u]));
+        a[3 * d + 1] = sixth * ((n[u] - o[u]) * (p3[v] - p1[v]) - (n[v] - o[v]) * (p3[u] - p1[u]));
+        a[3 * d + 2] = sixth * ((p1[u] - p3[u]) * (p2[v] - p4[v]) - (p1[v] - p3[v]) * (p2[u] - p4[u]));
+    }
+}
+__device__ __forceinline__ void gvpTriCoef(const double4 O, const double4 N, const double4 x1, const double4 x2,
+                                           const double4 x3, double t[12], double& rV) {
+    const double sixth = (1.0 / 6.0);
+    const double o[3] = {O.x, O.y, O.z}, n[3] = {N.x, N.y, N.z};
+    const double p1[3] = {x1.x, x1.y, x1.z}, p2[3] = {x2.x, x2.y, x2.z}, p3[3] = {x3.x, x3.y, x3.z};
+    double e21[3], e31[3], on[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { e21[k] = p2[k] - p1[k]; e31[k] = p3[k] - p1[k]; on[k] = o[k] - n[k]; }
+    const double cr[3] = {e21[1] * e31[2] - e21[2] * e31[1], e21[2] * e31[0] - e21[0] * e31[2], e21[0] * e31[1] - e21[1] * e31[0]};
+    double vol = cr[0] * on[0] + cr[1] * on[1] + cr[2] * on[2];
+    vol *= sixth;
+    rV = 1.0 / vol;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int u = (d + 1) % 3, v = (d + 2) % 3;
+        t[4 * d + 0] = sixth * ((o[v] - n[v]) * (p2[u] - p3[u]) + (n[u] - o[u]) * (p2[v] - p3[v]));
+        t[4 * d + 1] = sixth * ((n[u] - o[u]) * (p3[v] - p1[v]) + (o[v] - n[v]) * (p3[u] - p1[u]));
+        t[4 * d + 2] = sixth * ((n[u] - o[u]) * (p1[v] - p2[v]) + (o[v] - n[v]) * (p1[u] - p2[u]));
+        t[4 * d + 3] = sixth * (p1[v] * (p2[u] - p3[u]) + p2[v] * (p3[u] - p1[u]) + p3[v] * (p1[u] - p2[u]));
+    }
+}
 
 // ---------------------------------------------------------------------------
 // fvsc face gradient of an NC-component field: g[i*NC + k] = d_i phi_k.
@@ -98,7 +168,6 @@ __device__ __forceinline__ void faceGradient(const MeshView& m, const int f, con
     if constexpr (ST == ST_GVP3) {
         if (kind == 2) { reducedForm(); return; }  // faces with > 4 vertices [3D.C L759-768]
         const int4 vt = m.verts[f];
-        const double rV = m.rV[f];
         double psiN[NC];
         if (internal) {
 #pragma unroll
@@ -108,9 +177,12 @@ __device__ __forceinline__ void faceGradient(const MeshView& m, const int f, con
 #pragma unroll
             for (int k = 0; k < NC; ++k) psiN[k] = v.n[k] + v.sn[k] * hd * 0.5;  // [3D.C L790-793]
         }
-        const size_t nF = (size_t)m.nF;
+        const double4 cO = m.Cc[m.own[f]];
+        const double4 cN = internal ? m.Cc[m.nei[f]] : m.bN[b];
+        double rV;
         if (kind == 0) {  // quad: a2=-a0, a3=-a1, a4(nei)=-a5(own) [3D.C L361-363]
-            const int stride = (m.ncoef == 12) ? 4 : 3;
+            double a[9];
+            gvpQuadCoef(cO, cN, m.X[vt.x], m.X[vt.y], m.X[vt.z], m.X[vt.w], a, rV);
             const double* p0 = ptF + (size_t)vt.x * NC;
             const double* p1 = ptF + (size_t)vt.y * NC;
             const double* p2 = ptF + (size_t)vt.z * NC;
@@ -120,9 +192,7 @@ __device__ __forceinline__ void faceGradient(const MeshView& m, const int f, con
             for (int k = 0; k < NC; ++k) { q0[k] = p0[k]; q1[k] = p1[k]; q2[k] = p2[k]; q3[k] = p3[k]; }
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
-                const double a0 = m.coef[(size_t)(d * stride + 0) * nF + f];
-                const double a1 = m.coef[(size_t)(d * stride + 1) * nF + f];
-                const double a5 = m.coef[(size_t)(d * stride + 2) * nF + f];
+                const double a0 = a[3 * d], a1 = a[3 * d + 1], a5 = a[3 * d + 2];
 #pragma unroll
                 for (int k = 0; k < NC; ++k) {
                     double s = psiN[k] * (-a5);
@@ -135,15 +205,14 @@ __device__ __forceinline__ void faceGradient(const MeshView& m, const int f, con
                 }
             }
         } else {  // triangle: slots a0,a1,a2 vertices, a3 neighbour, owner = -a3 [3D.C L193-229]
+            double t[12];
+            gvpTriCoef(cO, cN, m.X[vt.x], m.X[vt.y], m.X[vt.z], t, rV);
             const double* p0 = ptF + (size_t)vt.x * NC;
             const double* p1 = ptF + (size_t)vt.y * NC;
             const double* p2 = ptF + (size_t)vt.z * NC;
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
-                const double a0 = m.coef[(size_t)(d * 4 + 0) * nF + f];
-                const double a1 = m.coef[(size_t)(d * 4 + 1) * nF + f];
-                const double a2 = m.coef[(size_t)(d * 4 + 2) * nF + f];
-                const double a3 = m.coef[(size_t)(d * 4 + 3) * nF + f];
+                const double a0 = t[4 * d], a1 = t[4 * d + 1], a2 = t[4 * d + 2], a3 = t[4 * d + 3];
 #pragma unroll
                 for (int k = 0; k < NC; ++k) {
                     double s = psiN[k] * a3;
@@ -339,7 +408,7 @@ __global__ __launch_bounds__(QGD_BLOCK) void faceFluxKernel(const MeshView m, co
     const int f = tile * QGD_BLOCK + (int)threadIdx.x;
     double cof = -1e300, tauMin = 1e300;
     if (f < m.nIF) {
-        const int o = m.own[f], n = m.nei[f];
+        const int o = ldStream(m.own + f), n = ldStream(m.nei + f);
         const RecA Ao = c.A[o], An = c.A[n];
         const RecB Bo = c.B[o], Bn = c.B[n];
         FaceVals<6> v;
@@ -347,7 +416,7 @@ __global__ __launch_bounds__(QGD_BLOCK) void faceFluxKernel(const MeshView m, co
         loadVals(An, v.n);
         double g[18];
         faceGradient<ST, 6, 1>(m, f, v, reinterpret_cast<const double*>(c.A), reinterpret_cast<const double*>(c.P), g);
-        const double w = m.w[f];
+        const double w = ldStream(m.w + f);
         FaceState s;
         s.rhof = lerpf(w, Ao.rho, An.rho);
         const double Uo[3] = {Ao.ux, Ao.uy, Ao.uz}, Un[3] = {An.ux, An.uy, An.uz};
@@ -369,9 +438,9 @@ __global__ __launch_bounds__(QGD_BLOCK) void faceFluxKernel(const MeshView m, co
         s.gammaf = lerpf(w, gm.gamma, gm.gamma);
         s.alphauf = lerpf(w, alphaEffOf(gm, Bo.muQGD), alphaEffOf(gm, Bn.muQGD));
         s.muf = lerpf(w, muEffOf(gm, Bo.muQGD), muEffOf(gm, Bn.muQGD));
-        const double hf = m.hf[f];
+        const double hf = ldStream(m.hf + f);
         s.tauf = lerpf(w, Bo.aOc, Bn.aOc) * hf;  // tauQGDf = lin(aQGD/c)*hQGDf [constScPrModel1_8C L103]
-        const double S[3] = {m.Sx[f], m.Sy[f], m.Sz[f]};
+        const double S[3] = {ldStream(m.Sx + f), ldStream(m.Sy + f), ldStream(m.Sz + f)};
         double out[5], phiw;
         qgdFluxes<DBG>(s, g, S, out, phiw, DBG ? c.dbg + f : nullptr, (size_t)m.nF);
 #pragma unroll
@@ -382,6 +451,115 @@ __global__ __launch_bounds__(QGD_BLOCK) void faceFluxKernel(const MeshView m, co
                 const double ms = sqrt(S[0] * S[0] + S[1] * S[1] + S[2] * S[2]);
                 const double Unf = s.Uf[0] * (S[0] / ms) + s.Uf[1] * (S[1] / ms) + s.Uf[2] * (S[2] / ms);
                 cof = fmax(fabs(Unf + s.cf), fabs(Unf - s.cf)) * c.dt[0] / hf;  // [QGDCourantNo_8H L44-48]
+                tauMin = s.tauf;
+            }
+        }
+    }
+    if (adjustDt) blockMaxMin(cof, tauMin, c.blkFace + 2 * (size_t)tile, false);
+}
+
+// ---------------------------------------------------------------------------
+// GaussVolPoint 3-D internal faces: the bench path.  Same arithmetic as faceFluxKernel<ST_GVP3>, written so that
+// every load of a face is in flight before the first use: (0) labels, (1) the 18 streamed doubles of the face,
+// (2) the 2 cell and 4 vertex records; then ~600 fp64 operations out of registers.  One memory round trip per
+// dependency level instead of one per gradient component; the register budget is traded for that on purpose.
+// ---------------------------------------------------------------------------
+#ifndef QGD_F_WAVES_MIN
+#define QGD_F_WAVES_MIN 2
+#endif
+#ifndef QGD_F_WAVES_MAX
+#define QGD_F_WAVES_MAX 3
+#endif
+template <bool DBG>
+__global__ __launch_bounds__(QGD_BLOCK) __attribute__((amdgpu_waves_per_eu(QGD_F_WAVES_MIN, QGD_F_WAVES_MAX)))
+void faceFluxGvp3Kernel(const MeshView m, const CaseView c, const GasModel gm, const int adjustDt) {
+    const int tile = xcdTile((int)gridDim.x);
+    const int f = tile * QGD_BLOCK + (int)threadIdx.x;
+    double cof = -1e300, tauMin = 1e300;
+    if (f < m.nIF) {
+        const size_t nF = (size_t)m.nF;
+        // (0) labels
+        const int o = ldStream(m.own + f), n = ldStream(m.nei + f);
+        const int4 vt = m.verts[f];
+        const int kind = m.fkind[f];
+        // (1) streamed face data
+        const double w = ldStream(m.w + f);
+        const double hf = ldStream(m.hf + f);
+        const double S[3] = {ldStream(m.Sx + f), ldStream(m.Sy + f), ldStream(m.Sz + f)};
+        // (2) gathered records (vertex 3 is clamped for triangles; unused there)
+        const RecA Ao = c.A[o], An = c.A[n];
+        const RecB Bo = c.B[o], Bn = c.B[n];
+        const int v3 = vt.w < 0 ? 0 : vt.w;
+        const RecA q0 = c.P[vt.x], q1 = c.P[vt.y], q2 = c.P[vt.z], q3 = c.P[v3];
+        // geometry the Gauss coefficients are rebuilt from (cached: shared by ~12 faces per vertex, 6 per cell)
+        const double4 cO = m.Cc[o], cN = m.Cc[n];
+        const double4 x0 = m.X[vt.x], x1 = m.X[vt.y], x2 = m.X[vt.z], x3 = m.X[v3];
+        __builtin_amdgcn_sched_barrier(0);
+
+        FaceVals<6> v;
+        loadVals(Ao, v.o);
+        loadVals(An, v.n);
+        double g[18];
+        if (kind == 0) {
+            // Quad [GaussVolPointBase3D_8C L346-389, L488-513] in difference form.  With a2=-a0, a3=-a1, a4=-a5:
+            //   V d_d phi = a5_d (phi_O - phi_N) + a0_d (phi_1 - phi_3) + a1_d (phi_2 - phi_4),
+            //   6 a0 = (N-O) x (p2-p4),  6 a1 = (N-O) x (p3-p1),  6 a5 = (p1-p3) x (p2-p4),  6 V = -(p3-p1).(6 a0)
+            // (the 1/6 cancel).  Same sum as the listing, grouped so the large vertex values cancel first.
+            const double NO[3] = {cN.x - cO.x, cN.y - cO.y, cN.z - cO.z};
+            const double d24[3] = {x1.x - x3.x, x1.y - x3.y, x1.z - x3.z};
+            const double d31[3] = {x2.x - x0.x, x2.y - x0.y, x2.z - x0.z};
+            double A0[3], A1[3], A5[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const int u = (d + 1) % 3, w2 = (d + 2) % 3;
+                A0[d] = NO[u] * d24[w2] - NO[w2] * d24[u];
+                A1[d] = NO[u] * d31[w2] - NO[w2] * d31[u];
+                A5[d] = d24[u] * d31[w2] - d24[w2] * d31[u];
+            }
+            const double rV6 = -1.0 / (d31[0] * A0[0] + d31[1] * A0[1] + d31[2] * A0[2]);
+            double p0[6], p1[6], p2[6], p3[6];
+            loadVals(q0, p0); loadVals(q1, p1); loadVals(q2, p2); loadVals(q3, p3);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const double D5 = (v.o[k] - v.n[k]) * rV6, D0 = (p0[k] - p2[k]) * rV6, D1 = (p1[k] - p3[k]) * rV6;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) g[d * 6 + k] = A5[d] * D5 + A0[d] * D0 + A1[d] * D1;
+            }
+        } else {
+            faceGradient<ST_GVP3, 6, 1>(m, f, v, reinterpret_cast<const double*>(c.A), reinterpret_cast<const double*>(c.P), g);
+        }
+        FaceState s;
+        s.rhof = lerpf(w, Ao.rho, An.rho);
+        const double Uo[3] = {Ao.ux, Ao.uy, Ao.uz}, Un[3] = {An.ux, An.uy, An.uz};
+        double rUo[3], rUn[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            s.Uf[k] = lerpf(w, Uo[k], Un[k]);
+            rUo[k] = Ao.rho * Uo[k];
+            rUn[k] = An.rho * Un[k];
+            s.rhoUf[k] = lerpf(w, rUo[k], rUn[k]);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) s.UrhoUf[3 * i + j] = lerpf(w, Uo[i] * rUo[j], Un[i] * rUn[j]);
+        s.pf = lerpf(w, Ao.p, An.p);
+        s.cf = lerpf(w, Bo.c, Bn.c);
+        s.Hf = lerpf(w, Bo.H, Bn.H);
+        s.gammaf = lerpf(w, gm.gamma, gm.gamma);
+        s.alphauf = lerpf(w, alphaEffOf(gm, Bo.muQGD), alphaEffOf(gm, Bn.muQGD));
+        s.muf = lerpf(w, muEffOf(gm, Bo.muQGD), muEffOf(gm, Bn.muQGD));
+        s.tauf = lerpf(w, Bo.aOc, Bn.aOc) * hf;
+        double out[5], phiw;
+        qgdFluxes<DBG>(s, g, S, out, phiw, DBG ? c.dbg + f : nullptr, nF);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) c.flux[(size_t)k * nF + f] = out[k];
+        if (adjustDt) {
+            const bool counted = (m.ghost == nullptr) || !(m.ghost[o] && m.ghost[n]);
+            if (counted) {
+                const double ms = sqrt(S[0] * S[0] + S[1] * S[1] + S[2] * S[2]);
+                const double Unf = s.Uf[0] * (S[0] / ms) + s.Uf[1] * (S[1] / ms) + s.Uf[2] * (S[2] / ms);
+                cof = fmax(fabs(Unf + s.cf), fabs(Unf - s.cf)) * c.dt[0] / hf;
                 tauMin = s.tauf;
             }
         }
@@ -496,8 +674,14 @@ __global__ __launch_bounds__(QGD_BLOCK) void pointInterpKernel(const MeshView m,
 
 // The case's vertex kernel: the gather list of a wave is read as contiguous runs (sliced ELL), the cell records
 // as whole 48-B records (3 x dwordx4), all gathers of a point are issued before the first use.
-__global__ __launch_bounds__(QGD_BLOCK) void pointInterpRecKernel(const MeshView m, const RecA* __restrict__ A,
-                                                                 RecA* __restrict__ P) {
+#ifndef QGD_P_WAVES_MIN
+#define QGD_P_WAVES_MIN 3
+#endif
+#ifndef QGD_P_WAVES_MAX
+#define QGD_P_WAVES_MAX 4
+#endif
+__global__ __launch_bounds__(QGD_BLOCK) __attribute__((amdgpu_waves_per_eu(QGD_P_WAVES_MIN, QGD_P_WAVES_MAX)))
+void pointInterpRecKernel(const MeshView m, const RecA* __restrict__ A, RecA* __restrict__ P) {
     const int p = xcdTile((int)gridDim.x) * QGD_BLOCK + threadIdx.x;
     if (p >= m.nP) return;
     const int n = m.pcCount[p];
@@ -513,6 +697,7 @@ __global__ __launch_bounds__(QGD_BLOCK) void pointInterpRecKernel(const MeshView
         for (int q = 0; q < 8; ++q) { id[q] = m.pcCell[base + (size_t)(i + q) * 64]; w[q] = m.pcW[base + (size_t)(i + q) * 64]; }
 #pragma unroll
         for (int q = 0; q < 8; ++q) r[q] = A[id[q]];
+        __builtin_amdgcn_sched_barrier(0);  // all eight 48-B gathers in flight before the ordered sum
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             acc.rho += w[q] * r[q].rho; acc.ux += w[q] * r[q].ux; acc.uy += w[q] * r[q].uy;
@@ -582,7 +767,14 @@ __global__ __launch_bounds__(QGD_BLOCK) void pressureMidStepKernel(const MeshVie
 // cell update: gather of the net face fluxes in ascending face order (the
 // summation order of fvc::surfaceIntegrate), explicit Euler, thermo, QGD coeffs
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(QGD_BLOCK) void cellUpdateKernel(const MeshView m, const CaseView c, const GasModel gm) {
+#ifndef QGD_C_WAVES_MIN
+#define QGD_C_WAVES_MIN 3
+#endif
+#ifndef QGD_C_WAVES_MAX
+#define QGD_C_WAVES_MAX 4
+#endif
+__global__ __launch_bounds__(QGD_BLOCK) __attribute__((amdgpu_waves_per_eu(QGD_C_WAVES_MIN, QGD_C_WAVES_MAX)))
+void cellUpdateKernel(const MeshView m, const CaseView c, const GasModel gm) {
     const int tile = xcdTile((int)gridDim.x);
     const int ci = tile * QGD_BLOCK + threadIdx.x;
     double rmin = 1e300, emin = 1e300;
@@ -591,6 +783,10 @@ __global__ __launch_bounds__(QGD_BLOCK) void cellUpdateKernel(const MeshView m, 
         const int n = m.cfCount[ci];
         const size_t base = (size_t)m.cfSlice[ci >> 6] * 64 + (ci & 63);
         const size_t nF = (size_t)m.nF;
+        // the cell's own records stream in while the flux gather is in flight
+        const RecA A = c.A[ci];
+        const Cons K = c.K[ci];
+        const double Vc = m.V[ci], hq = m.hQGD[ci];
         int i = 0;
         for (; i + 6 <= n; i += 6) {  // hexahedra: one pass; all 30 flux loads in flight before the ordered sum
             int it[6];
@@ -603,6 +799,7 @@ __global__ __launch_bounds__(QGD_BLOCK) void cellUpdateKernel(const MeshView m, 
 #pragma unroll
                 for (int k = 0; k < 5; ++k) fl[q][k] = c.flux[k * nF + f];
             }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < 6; ++q)
 #pragma unroll
@@ -615,9 +812,7 @@ __global__ __launch_bounds__(QGD_BLOCK) void cellUpdateKernel(const MeshView m, 
 #pragma unroll
             for (int k = 0; k < 5; ++k) sum[k] = isOwner ? sum[k] + c.flux[k * nF + f] : sum[k] - c.flux[k * nF + f];
         }
-        const RecA A = c.A[ci];
-        const Cons K = c.K[ci];
-        const double dtV = c.dt[0] / m.V[ci];
+        const double dtV = c.dt[0] / Vc;
         // QGDRhoEqn / QGDUEqn / QGDEEqn: explicit Euler on rho, rhoU, rhoE
         const double rho = A.rho - dtV * sum[0];
         Cons Kn;
@@ -638,7 +833,7 @@ __global__ __launch_bounds__(QGD_BLOCK) void cellUpdateKernel(const MeshView m, 
         const double psi = 1.0 / (gm.R * T);
         const double cs = sqrt(gm.gamma / psi);
         // constScPrModel1 [L103-115]: the pressure seen here is still the old one [QGDFoam_8C L149-154]
-        const double tauQGD = gm.alphaQGD * m.hQGD[ci] / cs;
+        const double tauQGD = gm.alphaQGD * hq / cs;
         RecB Bn;
         Bn.muQGD = A.p * gm.ScQGD * tauQGD;
         Bn.c = cs;
@@ -908,7 +1103,7 @@ static void launchFaceFluxT(const Launcher& L, int stencil, const MeshView& m, c
     switch (stencil) {
         case ST_REDUCED: faceFluxKernel<ST_REDUCED, DBG><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, adj); break;
         case ST_LSQ: faceFluxKernel<ST_LSQ, DBG><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, adj); break;
-        case ST_GVP3: faceFluxKernel<ST_GVP3, DBG><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, adj); break;
+        case ST_GVP3: faceFluxGvp3Kernel<DBG><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, adj); break;
         default: faceFluxKernel<ST_GVP2, DBG><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, adj); break;
     }
 }

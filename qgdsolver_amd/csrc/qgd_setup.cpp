@@ -59,7 +59,7 @@ static void toSlicedEll(const std::vector<int32_t>& off, int64_t nRows, const st
 
 int64_t StaticData::bytes() const {
     auto sz = [](auto& v) { return (int64_t)(v.size() * sizeof(v[0])); };
-    int64_t b = sz(own) + sz(nei) + sz(verts) + sz(fkind) + sz(magSf) + sz(w) + sz(hf) + sz(dn) + sz(coef) + sz(rV) +
+    int64_t b = sz(own) + sz(nei) + sz(verts) + sz(fkind) + sz(magSf) + sz(w) + sz(hf) + sz(dn) + sz(X) + sz(Cc) + sz(bN) +
                 sz(bmvON) + sz(ip13) + sz(c2d) + sz(lsqOff) + sz(lsqCell) + sz(lsqGw) + sz(lsqDeg) + sz(lsqBndZero) +
                 sz(pcSlice) + sz(pcCount) + sz(pcCell) + sz(pcW) + sz(bpPoint) + sz(bpOff) + sz(bpFace) + sz(bpW) + sz(cfSlice) + sz(cfCount) + sz(cfItem) +
                 sz(V) + sz(hQGD) + sz(ghost) + sz(bPatch) + sz(hQGDb);
@@ -103,15 +103,15 @@ StaticData buildStaticData(const HostMesh& m) {
         if (n == 3) hasTri = true;
     }
     s.hasTri = hasTri;
-    s.ncoef = hasTri ? 12 : 9;
-    const int ncoef = s.ncoef;
     const bool want3D = (m.nGeometricD == 3);
     if (want3D) {
-        s.coef.assign((size_t)ncoef * nF, 0.0);
-        s.rV.assign((size_t)nF, 0.0);
         s.bmvON.assign((size_t)nBF, 0.0);
+        s.bN.assign(4 * (size_t)nBF, 0.0);
+        s.X.assign(4 * (size_t)m.nPoints, 0.0);
+        s.Cc.assign(4 * (size_t)nC, 0.0);
+        for (int64_t p = 0; p < m.nPoints; ++p) for (int k = 0; k < 3; ++k) s.X[4 * p + k] = m.points[3 * p + k];
+        for (int64_t c = 0; c < nC; ++c) for (int k = 0; k < 3; ++k) s.Cc[4 * c + k] = m.C[3 * c + k];
     }
-    const double sixth = (1.0 / 6.0);
 
 #pragma omp parallel for schedule(static)
     for (int64_t f = 0; f < nF; ++f) {
@@ -142,7 +142,7 @@ StaticData buildStaticData(const HostMesh& m) {
             s.dn[f] = m.deltaCoeffs[f];
             if (want3D) {
                 double d[3];
-                for (int k = 0; k < 3; ++k) d[k] = O[k] - N[k];
+                for (int k = 0; k < 3; ++k) { d[k] = O[k] - N[k]; s.bN[4 * b + k] = N[k]; }
                 s.bmvON[b] = norm(d);
             }
         }
@@ -150,47 +150,6 @@ StaticData buildStaticData(const HostMesh& m) {
         if (skip) kind = FK_SKIP;
         s.fkind[f] = kind;
         for (int q = 0; q < std::min(n, 4); ++q) s.verts[4 * f + q] = fp[q];
-        if (!want3D || kind == FK_SKIP || kind == FK_OTHER) continue;
-        const double* p1 = &m.points[3 * (size_t)fp[0]];
-        const double* p2 = &m.points[3 * (size_t)fp[1]];
-        const double* p3 = &m.points[3 * (size_t)fp[2]];
-        if (kind == FK_QUAD) {
-            const double* p4 = &m.points[3 * (size_t)fp[3]];
-            double d31[3], d42[3], on[3], cr[3];
-            for (int k = 0; k < 3; ++k) { d31[k] = p3[k] - p1[k]; d42[k] = p4[k] - p2[k]; on[k] = O[k] - N[k]; }
-            cross(d42, on, cr);
-            double vol = dot(d31, cr);
-            vol *= sixth;
-            s.rV[f] = 1.0 / vol;
-            const int stride = hasTri ? 4 : 3;
-            for (int d = 0; d < 3; ++d) {
-                const int u = (d + 1) % 3, v = (d + 2) % 3;
-                const double a0 = sixth * ((N[u] - O[u]) * (p2[v] - p4[v]) - (N[v] - O[v]) * (p2[u] - p4[u]));
-                const double a1 = sixth * ((N[u] - O[u]) * (p3[v] - p1[v]) - (N[v] - O[v]) * (p3[u] - p1[u]));
-                const double a5 = sixth * ((p1[u] - p3[u]) * (p2[v] - p4[v]) - (p1[v] - p3[v]) * (p2[u] - p4[u]));
-                s.coef[(size_t)(d * stride + 0) * nF + f] = a0;
-                s.coef[(size_t)(d * stride + 1) * nF + f] = a1;
-                s.coef[(size_t)(d * stride + 2) * nF + f] = a5;
-            }
-        } else {  // FK_TRI: slots a0,a1,a2 (vertices), a3 (neighbour); owner = -a3
-            double e21[3], e31[3], on[3], cr[3];
-            for (int k = 0; k < 3; ++k) { e21[k] = p2[k] - p1[k]; e31[k] = p3[k] - p1[k]; on[k] = O[k] - N[k]; }
-            cross(e21, e31, cr);
-            double vol = dot(cr, on);
-            vol *= sixth;
-            s.rV[f] = 1.0 / vol;
-            for (int d = 0; d < 3; ++d) {
-                const int u = (d + 1) % 3, v = (d + 2) % 3;
-                const double a0 = sixth * ((O[v] - N[v]) * (p2[u] - p3[u]) + (N[u] - O[u]) * (p2[v] - p3[v]));
-                const double a1 = sixth * ((N[u] - O[u]) * (p3[v] - p1[v]) + (O[v] - N[v]) * (p3[u] - p1[u]));
-                const double a2 = sixth * ((N[u] - O[u]) * (p1[v] - p2[v]) + (O[v] - N[v]) * (p1[u] - p2[u]));
-                const double a3 = sixth * (p1[v] * (p2[u] - p3[u]) + p2[v] * (p3[u] - p1[u]) + p3[v] * (p1[u] - p2[u]));
-                s.coef[(size_t)(d * 4 + 0) * nF + f] = a0;
-                s.coef[(size_t)(d * 4 + 1) * nF + f] = a1;
-                s.coef[(size_t)(d * 4 + 2) * nF + f] = a2;
-                s.coef[(size_t)(d * 4 + 3) * nF + f] = a3;
-            }
-        }
     }
 
     // ---- GaussVolPoint 2-D -----------------------------------------------------

@@ -32,11 +32,12 @@ struct StaticData {
     std::vector<double> w;        // nF linear weights
     std::vector<double> hf;       // nF hQGDf
     std::vector<double> dn;       // nF: nonOrthDeltaCoeffs (internal), deltaCoeffs (boundary)
-    // GaussVolPoint 3-D: ncoef = 9 (all quads: a0,a1,a5 per direction) or 12
-    // (with triangles: a0,a1,a2,a3 per direction; quads use slots 0,1,2 = a0,a1,a5)
-    int32_t ncoef = 9;
-    std::vector<double> coef;     // ncoef*nF, coef[k*nF + f]
-    std::vector<double> rV;       // nF: 1/V_f
+    // GaussVolPoint 3-D: the 10 (quad) / 13 (triangle) Gauss coefficients of a face are NOT stored: the face kernel
+    // rebuilds them from the vertex coordinates and the two cell centres, which are gathered (and cached) instead
+    // of streaming 80 B per face.  Boundary faces use the mirror point C_O + 2 (C_f - C_O) as "neighbour centre".
+    std::vector<double> X;        // 4*nP: x,y,z,0 (32-B records)
+    std::vector<double> Cc;       // 4*nC: cell centres (32-B records)
+    std::vector<double> bN;       // 4*nBF: mirror points of the boundary faces
     std::vector<double> bmvON;    // nBF
     // GaussVolPoint 2-D
     std::vector<int32_t> ip13;    // 2*nF (ip1, ip3)
