@@ -38,10 +38,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--n", type=int, default=int(os.environ.get("QGD_BENCH_N", "400")), help="box edge in cells (n^3 cells in total)")
+    ap.add_argument("--edge", dest="n", type=int, default=int(os.environ.get("QGD_BENCH_N", "400")), help="box edge in cells (n^3 cells in total)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-n", type=int, default=64, help="edge of the CPU-baseline sample box")
-    ap.add_argument("--cpu-steps", type=int, default=5)
+    ap.add_argument("--cpu-n", type=int, default=96, help="edge of the CPU-baseline sample box")
+    ap.add_argument("--cpu-steps", type=int, default=12)
     return ap.parse_args()
 
 
