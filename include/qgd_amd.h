@@ -190,6 +190,36 @@ int qgd_fvsc_div_v(qgd_device_t d, int stencilId, const double* cell,
 int qgd_fvsc_div_t(qgd_device_t d, int stencilId, const double* cell,
                    const double* bnd, double* out);
 
+/* ---- QHDFoam flux assembly (stateless, host pointers) -------------------- */
+/* The face-flux parts of the QHDFoam step: QHDFoam/updateFields.H L36-73 (gradients, interpolations, BdFrc),
+ * QHDFoam/updateFluxes.H L33-38 (phiu, phiwo, taubyrhof), QHDUEqn.H L36-43 (gradPf, Wf, phiUf) and QHDTEqn.H
+ * L65-66 (phiTf, phiTauTReg).  The implicit pressure Poisson solve between them (QHDpEqn.H L35-47) stays with the
+ * caller: call once with p = phi = NULL for the first group, again with p and phi for the rest (or once with
+ * everything).  cell arrays: nCells*ncomp, patch arrays: nBoundaryFaces*ncomp, face arrays: nFaces*ncomp. */
+typedef struct qgd_qhd_inputs {
+    const double* U;   const double* Ub;     /* 3 */
+    const double* T;   const double* Tb;     /* 1 */
+    const double* p;   const double* pb;     /* 1, nullable */
+    const double* rho; const double* rhob;   /* 1 */
+    const double* tauQGDf;                   /* nFaces: thermo.tauQGDf() of the chosen QGDCoeffs model */
+    const double* phi;                       /* nFaces, nullable: phiu - phiwo + pEqn.flux() */
+    double beta;                             /* thermal expansion coefficient */
+    double g[3];                             /* gravitational acceleration */
+} qgd_qhd_inputs;
+typedef struct qgd_qhd_outputs {             /* every pointer may be NULL */
+    double* gradUf;      /* 9: fvsc::grad(U) */
+    double* gradTf;      /* 3: fvsc::grad(T) */
+    double* phiu;        /* 1 */
+    double* phiwo;       /* 1 */
+    double* taubyrhof;   /* 1 */
+    double* gradPf;      /* 3: needs p */
+    double* Wf;          /* 3: needs p */
+    double* phiUf;       /* 3: needs p and phi */
+    double* phiTf;       /* 1: needs phi */
+    double* phiTauTReg;  /* 1 */
+} qgd_qhd_outputs;
+int qgd_qhd_fluxes(qgd_device_t d, int stencilId, const qgd_qhd_inputs* in, qgd_qhd_outputs* out);
+
 /* ---- QGDFoam case ----------------------------------------------------------- */
 
 typedef struct qgd_case_options {

@@ -1545,6 +1545,71 @@ int orc_fvsc(void* mp, const char* scheme, const char* op, const double* cell, c
     return 0;
 }
 
+// QHDFoam face-flux parts, field at a time:
+// [QHDFoam/updateFields.H:36-73] [QHDFoam/updateFluxes.H:33-38] [QHDUEqn.H:36-43] [QHDTEqn.H:65-66]
+int orc_qhd_fluxes(void* mp, const char* scheme, const orc_qhd_inputs* in, orc_qhd_outputs* out) {
+    MeshHandle* h = (MeshHandle*)mp;
+    const Mesh& m = h->m;
+    Stencil* st = nullptr;
+    int rc = h->cache.lookup(m, scheme, &st);
+    if (rc) return rc;
+    const int nC = m.nC, nB = m.nBF(), nF = m.nF;
+    VolField U(m, 3), T(m, 1), p(m, 1), rho(m, 1), BdFrc(m, 3);
+    std::copy(in->U, in->U + 3 * (size_t)nC, U.in.begin());
+    std::copy(in->T, in->T + nC, T.in.begin());
+    std::copy(in->rho, in->rho + nC, rho.in.begin());
+    if (nB) { std::copy(in->Ub, in->Ub + 3 * (size_t)nB, U.bf.begin()); std::copy(in->Tb, in->Tb + nB, T.bf.begin()); std::copy(in->rhob, in->rhob + nB, rho.bf.begin()); }
+    if (in->p) { std::copy(in->p, in->p + nC, p.in.begin()); if (nB) std::copy(in->pb, in->pb + nB, p.bf.begin()); }
+    // updateFields.H
+    SurfField gradUf = st->gradV(U);                      // L36
+    SurfField gradTf = st->gradS(T);                      // L40
+    SurfField rhof = linearInterpolate(m, rho);           // L57
+    SurfField Uf = linearInterpolate(m, U);               // L60
+    SurfField Tf = linearInterpolate(m, T);               // L63
+    for (int c = 0; c < nC; ++c) for (int k = 0; k < 3; ++k) BdFrc.in[3 * (size_t)c + k] = (in->beta * T.in[c]) * in->g[k];   // L66
+    for (int b = 0; b < nB; ++b) for (int k = 0; k < 3; ++k) BdFrc.bf[3 * (size_t)b + k] = (in->beta * T.bf[b]) * in->g[k];
+    SurfField BdFrcf = linearInterpolate(m, BdFrc);       // L67
+    std::vector<char> live(nF, 1);
+    for (size_t ip = 0; ip < m.patches.size(); ++ip)
+        if (!m.patchHasFields((int)ip)) for (int f = m.patches[ip].start; f < m.patches[ip].start + m.patches[ip].size; ++f) live[f] = 0;
+    // updateFluxes.H
+    SurfField phiu(m, 1), phiwo(m, 1), taubyrhof(m, 1), UgU(m, 3);
+    for (int f = 0; f < nF; ++f) {
+        if (!live[f]) continue;
+        const double* S = &m.Sf[3 * (size_t)f];
+        phiu.v[f] = dot3(S, &Uf.v[3 * (size_t)f]);                                           // L33
+        VdotT(&Uf.v[3 * (size_t)f], &gradUf.v[9 * (size_t)f], &UgU.v[3 * (size_t)f]);        // Uf & gradUf
+        double wo[3];
+        for (int k = 0; k < 3; ++k) wo[k] = in->tauQGDf[f] * (UgU.v[3 * (size_t)f + k] - BdFrcf.v[3 * (size_t)f + k]);
+        phiwo.v[f] = dot3(S, wo);                                                            // L35
+        taubyrhof.v[f] = in->tauQGDf[f] / rhof.v[f];                                         // L38
+    }
+    auto give = [&](double* dst, const SurfField& s) { if (dst) std::copy(s.v.begin(), s.v.end(), dst); };
+    give(out->gradUf, gradUf); give(out->gradTf, gradTf); give(out->phiu, phiu); give(out->phiwo, phiwo); give(out->taubyrhof, taubyrhof);
+    // QHDTEqn.H L66
+    if (out->phiTauTReg) for (int f = 0; f < nF; ++f)
+        out->phiTauTReg[f] = live[f] ? in->tauQGDf[f] * phiu.v[f] * dot3(&Uf.v[3 * (size_t)f], &gradTf.v[3 * (size_t)f]) : 0.0;
+    if (out->phiTf) for (int f = 0; f < nF; ++f) out->phiTf[f] = live[f] ? in->phi[f] * Tf.v[f] : 0.0;   // L65 qgdFlux -> flux*psif
+    if (in->p) {
+        SurfField gradPf = st->gradS(p);                                                     // QHDUEqn.H L36
+        SurfField Wf(m, 3);
+        for (int f = 0; f < nF; ++f) {
+            if (!live[f]) continue;
+            for (int k = 0; k < 3; ++k)
+                Wf.v[3 * (size_t)f + k] = in->tauQGDf[f] * ((UgU.v[3 * (size_t)f + k] + gradPf.v[3 * (size_t)f + k] / rhof.v[f]) - BdFrcf.v[3 * (size_t)f + k]);  // L37
+        }
+        give(out->gradPf, gradPf); give(out->Wf, Wf);
+        if (out->phiUf) for (int f = 0; f < nF; ++f) {
+            if (!live[f]) { for (int k = 0; k < 3; ++k) out->phiUf[3 * (size_t)f + k] = 0.0; continue; }
+            double UW[9], uw[3];
+            outer(&Uf.v[3 * (size_t)f], &Wf.v[3 * (size_t)f], UW);                           // Uf * Wf
+            VdotT(&m.Sf[3 * (size_t)f], UW, uw);                                             // L39
+            for (int k = 0; k < 3; ++k) out->phiUf[3 * (size_t)f + k] = in->phi[f] * Uf.v[3 * (size_t)f + k] - uw[k];   // L41-43
+        }
+    }
+    return 0;
+}
+
 void* orc_case_create(void* mesh, const orc_case_options* opt) {
     Case* c = new Case((MeshHandle*)mesh, *opt);
     c->stencilWord = opt->stencil == FVSC_REDUCED ? "reduced" : (opt->stencil == FVSC_LEASTSQUARES ? "leastSquares" : "GaussVolPoint");

@@ -50,6 +50,16 @@ int orc_mesh_set_halo(void* m, int side, int32_t nGhost, const int32_t* ghost,
 int orc_fvsc(void* m, const char* scheme, const char* op, const double* cell,
              const double* bnd, double* out);
 
+/* QHDFoam face fluxes; same argument meaning as qgd_qhd_fluxes (pointers may be NULL as there) */
+typedef struct orc_qhd_inputs {
+    const double *U, *Ub, *T, *Tb, *p, *pb, *rho, *rhob, *tauQGDf, *phi;
+    double beta; double g[3];
+} orc_qhd_inputs;
+typedef struct orc_qhd_outputs {
+    double *gradUf, *gradTf, *phiu, *phiwo, *taubyrhof, *gradPf, *Wf, *phiUf, *phiTf, *phiTauTReg;
+} orc_qhd_outputs;
+int orc_qhd_fluxes(void* mesh, const char* scheme, const orc_qhd_inputs* in, orc_qhd_outputs* out);
+
 void* orc_case_create(void* mesh, const orc_case_options* opt);
 void orc_case_free(void* c);
 int orc_case_set_bc(void* c, int32_t patch, int32_t bcU, const double* valueU,

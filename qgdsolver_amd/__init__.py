@@ -12,6 +12,7 @@ from .mesh import PolyMesh  # noqa: F401
 from .fvsc import Device, fvscStencil, volField  # noqa: F401
 from . import fvsc  # noqa: F401
 from .qgdfoam import QGDFoamCase, QGDThermo, default_options  # noqa: F401
+from . import qhdfoam  # noqa: F401
 
 
 def device_count():

@@ -59,6 +59,7 @@ SIGNATURES = {
     "qgd_fvsc_grad_v": (C.c_int, [handle, C.c_int, c_double_p, c_double_p, c_double_p]),
     "qgd_fvsc_div_v": (C.c_int, [handle, C.c_int, c_double_p, c_double_p, c_double_p]),
     "qgd_fvsc_div_t": (C.c_int, [handle, C.c_int, c_double_p, c_double_p, c_double_p]),
+    "qgd_qhd_fluxes": (C.c_int, [handle, C.c_int, C.c_void_p, C.c_void_p]),
     "qgd_case_options_default": (C.c_int, [C.POINTER(CaseOptions)]),
     "qgd_case_create": (C.c_int, [handle, C.POINTER(CaseOptions), handle_p]),
     "qgd_case_free": (C.c_int, [handle]),

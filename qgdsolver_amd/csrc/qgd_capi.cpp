@@ -462,6 +462,70 @@ int qgd_fvsc_grad_v(qgd_device_t d, int id, const double* cell, const double* bn
 int qgd_fvsc_div_v(qgd_device_t d, int id, const double* cell, const double* bnd, double* out) { return fvscOp(d, id, 1, 3, cell, bnd, out); }
 int qgd_fvsc_div_t(qgd_device_t d, int id, const double* cell, const double* bnd, double* out) { return fvscOp(d, id, 1, 9, cell, bnd, out); }
 
+// ---- QHDFoam face fluxes -------------------------------------------------------------
+int qgd_qhd_fluxes(qgd_device_t d, int stencilId, const qgd_qhd_inputs* in, qgd_qhd_outputs* out) {
+    QGD_TRY
+    if (!d || !in || !out) return fail(QGD_ERR_INVALID, "qgd_qhd_fluxes: null argument");
+    const MeshView& v = d->view;
+    if (!in->U || !in->T || !in->rho || !in->tauQGDf || (v.nBF > 0 && (!in->Ub || !in->Tb || !in->rhob)))
+        return fail(QGD_ERR_INVALID, "qgd_qhd_fluxes: U, T, rho (cell + patch values) and tauQGDf are required");
+    const bool haveP = in->p != nullptr;
+    if (haveP && v.nBF > 0 && !in->pb) return fail(QGD_ERR_INVALID, "qgd_qhd_fluxes: p given without its patch values");
+    if ((out->gradPf || out->Wf || out->phiUf) && !haveP) return fail(QGD_ERR_INVALID, "qgd_qhd_fluxes: gradPf/Wf/phiUf need p");
+    if ((out->phiUf || out->phiTf) && !in->phi) return fail(QGD_ERR_INVALID, "qgd_qhd_fluxes: phiUf/phiTf need phi");
+    int st = 0;
+    int rc = deviceStencil(d->nGeomD, stencilId, &st);
+    if (rc) return rc;
+    HIP_CHECK(hipSetDevice(d->deviceId));
+    const size_t nC = (size_t)v.nC, nB = (size_t)v.nBF, nF = (size_t)v.nF, nP = (size_t)v.nP;
+    // host-side packing of the 5-component records {Ux,Uy,Uz,T,p}
+    std::vector<double> cell5(5 * nC), bnd5(5 * std::max<size_t>(nB, 1), 0.0);
+    for (size_t c = 0; c < nC; ++c) {
+        for (int k = 0; k < 3; ++k) cell5[5 * c + k] = in->U[3 * c + k];
+        cell5[5 * c + 3] = in->T[c];
+        cell5[5 * c + 4] = haveP ? in->p[c] : 0.0;
+    }
+    for (size_t b = 0; b < nB; ++b) {
+        for (int k = 0; k < 3; ++k) bnd5[5 * b + k] = in->Ub[3 * b + k];
+        bnd5[5 * b + 3] = in->Tb[b];
+        bnd5[5 * b + 4] = haveP ? in->pb[b] : 0.0;
+    }
+    DeviceArena tmp;
+    try {
+        double* dCell = tmp.upload(cell5);
+        double* dBnd = tmp.upload(bnd5);
+        double* dPt = tmp.alloc<double>(5 * nP);
+        double* dRho = tmp.alloc<double>(nC, false);
+        double* dRhob = tmp.alloc<double>(std::max<size_t>(nB, 1));
+        double* dTau = tmp.alloc<double>(nF, false);
+        double* dPhi = in->phi ? tmp.alloc<double>(nF, false) : nullptr;
+        double* dOut = tmp.alloc<double>((size_t)QHD_COUNT * nF);
+        HIP_CHECK(hipMemcpy(dRho, in->rho, sizeof(double) * nC, hipMemcpyHostToDevice));
+        if (nB) HIP_CHECK(hipMemcpy(dRhob, in->rhob, sizeof(double) * nB, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(dTau, in->tauQGDf, sizeof(double) * nF, hipMemcpyHostToDevice));
+        if (dPhi) HIP_CHECK(hipMemcpy(dPhi, in->phi, sizeof(double) * nF, hipMemcpyHostToDevice));
+        (void)hipGetLastError();
+        launchQhdFluxes(d->stream, st, v, dCell, dBnd, dPt, dRho, dRhob, dTau, dPhi, in->beta, in->g[0], in->g[1], in->g[2], dOut);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(d->stream));
+        std::vector<double> slot(nF);
+        auto fetch = [&](double* dst, int first, int nc) {
+            if (!dst) return;
+            for (int k = 0; k < nc; ++k) {
+                HIP_CHECK(hipMemcpy(slot.data(), dOut + (size_t)(first + k) * nF, sizeof(double) * nF, hipMemcpyDeviceToHost));
+                for (size_t f = 0; f < nF; ++f) dst[f * nc + k] = slot[f];
+            }
+        };
+        fetch(out->gradUf, QHD_GRADU, 9); fetch(out->gradTf, QHD_GRADT, 3); fetch(out->phiu, QHD_PHIU, 1);
+        fetch(out->phiwo, QHD_PHIWO, 1); fetch(out->taubyrhof, QHD_TAUBYRHO, 1); fetch(out->gradPf, QHD_GRADP, 3);
+        fetch(out->Wf, QHD_WF, 3); fetch(out->phiUf, QHD_PHIUF, 3); fetch(out->phiTf, QHD_PHITF, 1);
+        fetch(out->phiTauTReg, QHD_PHITAUT, 1);
+    } catch (...) { tmp.release(); throw; }
+    tmp.release();
+    return QGD_OK;
+    QGD_CATCH
+}
+
 // ---- case ------------------------------------------------------------------------
 int qgd_case_options_default(qgd_case_options* o) {
     if (!o) return fail(QGD_ERR_INVALID, "null argument");
@@ -717,6 +781,7 @@ int qgd_case_halo_pack(qgd_case_t c, int side, double* sendBufDevice) {
     if (!sendBufDevice) return fail(QGD_ERR_INVALID, "null buffer");
     HIP_CHECK(hipSetDevice(d->deviceId));
     Launcher L = launcherOf(c);
+    (void)hipGetLastError();
     launchHaloPack(L, c->view, d->haloSend[side], d->nHaloSendCells[side], d->haloSendBF[side], d->nHaloSendBF[side], sendBufDevice, true);
     HIP_CHECK(hipGetLastError());
     return QGD_OK;
@@ -730,6 +795,7 @@ int qgd_case_halo_unpack(qgd_case_t c, int side, const double* recvBufDevice) {
     if (!recvBufDevice) return fail(QGD_ERR_INVALID, "null buffer");
     HIP_CHECK(hipSetDevice(d->deviceId));
     Launcher L = launcherOf(c);
+    (void)hipGetLastError();
     launchHaloPack(L, c->view, d->haloGhost[side], d->nHaloCells[side], d->haloGhostBF[side], d->nHaloGhostBF[side],
                    const_cast<double*>(recvBufDevice), false);
     HIP_CHECK(hipGetLastError());
@@ -828,6 +894,7 @@ int qgd_case_info(qgd_case_t c, double info[6]) {
     HIP_CHECK(hipSetDevice(c->dev->deviceId));
     Launcher L = launcherOf(c);
     L.pre = nullptr; L.post = nullptr;
+    (void)hipGetLastError();
     launchCellMinReduce(L, c->view);  // min(rho), min(e) since the previous query [QGDFoam_8C L142]
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(c->stream()));

@@ -110,4 +110,12 @@ void launchHaloPack(const Launcher& L, const CaseView& c, const int32_t* cells, 
 void launchFvscOp(hipStream_t s, int stencil, int op, int NC, const MeshView& m, const double* cell, const double* bnd,
                   double* pt, double* out);
 
+// ---- QHDFoam face fluxes --------------------------------------------------------
+// rec5 = {Ux,Uy,Uz,T,p} per cell / patch face / vertex; out = 26 SoA slots of nF doubles (see QhdSlot)
+enum QhdSlot : int { QHD_GRADU = 0, QHD_GRADT = 9, QHD_PHIU = 12, QHD_PHIWO = 13, QHD_TAUBYRHO = 14, QHD_GRADP = 15,
+                     QHD_WF = 18, QHD_PHIUF = 21, QHD_PHITF = 24, QHD_PHITAUT = 25, QHD_COUNT = 26 };
+void launchQhdFluxes(hipStream_t s, int stencil, const MeshView& m, const double* cell5, const double* bnd5, double* pt5,
+                     const double* rho, const double* rhob, const double* tau, const double* phi, double beta,
+                     double gx, double gy, double gz, double* out);
+
 }  // namespace qgd

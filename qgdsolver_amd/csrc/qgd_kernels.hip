@@ -1064,6 +1064,91 @@ __global__ __launch_bounds__(QGD_BLOCK) void fvscOpKernel(const MeshView m, cons
 }
 
 // ---------------------------------------------------------------------------
+// QHDFoam face fluxes [QHDFoam/updateFields.H L36-73, updateFluxes.H L33-38, QHDUEqn_8H L36-43, QHDTEqn_8H L65-66]
+// one thread per face (internal and patch faces); fields U,T,p travel as one 5-component record so the three
+// fvsc::grad calls are a single stencil walk.
+// ---------------------------------------------------------------------------
+template <int ST>
+__global__ __launch_bounds__(QGD_BLOCK) void qhdFaceKernel(const MeshView m, const double* __restrict__ cell5,
+                                                          const double* __restrict__ bnd5, const double* __restrict__ pt5,
+                                                          const double* __restrict__ rho, const double* __restrict__ rhob,
+                                                          const double* __restrict__ tauF, const double* __restrict__ phiF,
+                                                          const double beta, const double gx, const double gy, const double gz,
+                                                          double* __restrict__ out) {
+    const int f = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    if (f >= m.nF) return;
+    if (m.fkind[f] == 3) return;  // empty patches carry no field
+    const bool internal = f < m.nIF;
+    const int o = m.own[f];
+    FaceVals<5> v;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) v.o[k] = cell5[(size_t)o * 5 + k];
+    double rhof, w = 1.0;
+    if (internal) {
+        const int n = m.nei[f];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) { v.n[k] = cell5[(size_t)n * 5 + k]; v.sn[k] = 0.0; }
+        w = m.w[f];
+        rhof = lerpf(w, rho[o], rho[n]);
+    } else {
+        const int b = f - m.nIF;
+        const double dc = m.dn[f];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) { v.n[k] = bnd5[(size_t)b * 5 + k]; v.sn[k] = dc * (v.n[k] - v.o[k]); }
+        rhof = rhob[b];
+    }
+    double g[15];
+    faceGradient<ST, 5, 0>(m, f, v, cell5, pt5, g);
+    double gU[9], gT[3], gP[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        gU[3 * i] = g[i * 5]; gU[3 * i + 1] = g[i * 5 + 1]; gU[3 * i + 2] = g[i * 5 + 2];
+        gT[i] = g[i * 5 + 3]; gP[i] = g[i * 5 + 4];
+    }
+    const double gv[3] = {gx, gy, gz};
+    double Uf[3], Bf[3];
+    double Tf;
+    if (internal) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            Uf[k] = lerpf(w, v.o[k], v.n[k]);
+            Bf[k] = lerpf(w, (beta * v.o[3]) * gv[k], (beta * v.n[3]) * gv[k]);  // BdFrc = beta*T*g [updateFields.H L66-67]
+        }
+        Tf = lerpf(w, v.o[3], v.n[3]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { Uf[k] = v.n[k]; Bf[k] = (beta * v.n[3]) * gv[k]; }
+        Tf = v.n[3];
+    }
+    const double S[3] = {m.Sx[f], m.Sy[f], m.Sz[f]};
+    const double tau = tauF[f];
+    const size_t nF = (size_t)m.nF;
+    auto put = [&](int slot, double x) { out[(size_t)slot * nF + f] = x; };
+    const double phiu = S[0] * Uf[0] + S[1] * Uf[1] + S[2] * Uf[2];                       // [updateFluxes.H L33]
+    double UgU[3], wo[3], Wf[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        UgU[j] = Uf[0] * gU[j] + Uf[1] * gU[3 + j] + Uf[2] * gU[6 + j];                  // Uf & gradUf
+        wo[j] = tau * (UgU[j] - Bf[j]);
+        Wf[j] = tau * ((UgU[j] + gP[j] / rhof) - Bf[j]);                                  // [QHDUEqn_8H L37]
+    }
+    const double phiwo = S[0] * wo[0] + S[1] * wo[1] + S[2] * wo[2];                      // [updateFluxes.H L35]
+    for (int k = 0; k < 9; ++k) put(QHD_GRADU + k, gU[k]);
+    for (int k = 0; k < 3; ++k) { put(QHD_GRADT + k, gT[k]); put(QHD_GRADP + k, gP[k]); put(QHD_WF + k, Wf[k]); }
+    put(QHD_PHIU, phiu);
+    put(QHD_PHIWO, phiwo);
+    put(QHD_TAUBYRHO, tau / rhof);                                                        // [updateFluxes.H L38]
+    const double phi = phiF ? phiF[f] : 0.0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const double uw = S[0] * (Uf[0] * Wf[j]) + S[1] * (Uf[1] * Wf[j]) + S[2] * (Uf[2] * Wf[j]);  // Sf & (Uf*Wf)
+        put(QHD_PHIUF + j, phi * Uf[j] - uw);                                             // [QHDUEqn_8H L39-43]
+    }
+    put(QHD_PHITF, phi * Tf);                                                             // [QHDTEqn_8H L65]
+    put(QHD_PHITAUT, tau * phiu * (Uf[0] * gT[0] + Uf[1] * gT[1] + Uf[2] * gT[2]));       // [QHDTEqn_8H L66]
+}
+
+// ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
 static inline int gridFor(int64_t n) { return (int)((n + QGD_BLOCK - 1) / QGD_BLOCK); }
@@ -1177,6 +1262,27 @@ void launchFvscOp(hipStream_t s, int stencil, int op, int NC, const MeshView& m,
         case ST_LSQ: launchFvscOpS<ST_LSQ>(s, op, NC, m, cell, bnd, pt, out); break;
         case ST_GVP3: launchFvscOpS<ST_GVP3>(s, op, NC, m, cell, bnd, pt, out); break;
         default: launchFvscOpS<ST_GVP2>(s, op, NC, m, cell, bnd, pt, out); break;
+    }
+}
+
+template <int ST>
+static void launchQhdT(hipStream_t s, const MeshView& m, const double* cell5, const double* bnd5, double* pt5, const double* rho,
+                       const double* rhob, const double* tau, const double* phi, double beta, double gx, double gy, double gz,
+                       double* out) {
+    if (ST == ST_GVP3 || ST == ST_GVP2) {
+        pointInterpKernel<5><<<gridFor(m.nP), QGD_BLOCK, 0, s>>>(m, cell5, 5, pt5);
+        if (m.nBP) boundaryPointKernel<5><<<gridFor(m.nBP), QGD_BLOCK, 0, s>>>(m, bnd5, 5, pt5, 5, 0);
+    }
+    qhdFaceKernel<ST><<<gridFor(m.nF), QGD_BLOCK, 0, s>>>(m, cell5, bnd5, pt5, rho, rhob, tau, phi, beta, gx, gy, gz, out);
+}
+void launchQhdFluxes(hipStream_t s, int stencil, const MeshView& m, const double* cell5, const double* bnd5, double* pt5,
+                     const double* rho, const double* rhob, const double* tau, const double* phi, double beta, double gx,
+                     double gy, double gz, double* out) {
+    switch (stencil) {
+        case ST_REDUCED: launchQhdT<ST_REDUCED>(s, m, cell5, bnd5, pt5, rho, rhob, tau, phi, beta, gx, gy, gz, out); break;
+        case ST_LSQ: launchQhdT<ST_LSQ>(s, m, cell5, bnd5, pt5, rho, rhob, tau, phi, beta, gx, gy, gz, out); break;
+        case ST_GVP3: launchQhdT<ST_GVP3>(s, m, cell5, bnd5, pt5, rho, rhob, tau, phi, beta, gx, gy, gz, out); break;
+        default: launchQhdT<ST_GVP2>(s, m, cell5, bnd5, pt5, rho, rhob, tau, phi, beta, gx, gy, gz, out); break;
     }
 }
 

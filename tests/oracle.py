@@ -119,6 +119,22 @@ class OracleMesh:
             self._h = None
 
 
+def qhd_fluxes(omesh, scheme, U, T, rho, tauQGDf, beta, g, p=None, phi=None):
+    """oracle counterpart of qgdsolver_amd.qhdfoam.updateFluxes (same struct layouts)"""
+    from qgdsolver_amd import qhdfoam
+
+    class FakeDev:
+        mesh = omesh
+
+    lib.orc_qhd_fluxes.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p]
+
+    def call(sch, i, o):
+        rc = lib.orc_qhd_fluxes(omesh._h, sch.encode(), C.byref(i), C.byref(o))
+        assert rc == 0, rc
+
+    return qhdfoam.updateFluxes(FakeDev, scheme, U, T, rho, tauQGDf, beta, g, p=p, phi=phi, call=call)
+
+
 class OracleCase:
     def __init__(self, omesh, options):
         self.mesh = omesh
