@@ -123,7 +123,8 @@ def main():
     exchange = halo.exchange
 
     def step():
-        case.step_phase(0)
+        case.step_phase(0)   # flux assembly
+        case.step_phase(1)   # cell update + boundary refresh (fixed deltaT: no global reduction needed)
         exchange()
 
     exchange()  # ghost cells start from their owners' records

@@ -294,10 +294,13 @@ int qgd_case_stream_sync(qgd_case_t c);
  * void*), e.g. the stream the RCCL halo transfers are ordered on, so that
  * compute and exchange need no host synchronisation between them. */
 int qgd_case_set_stream(qgd_case_t c, void* hipStream);
-/* Run one step split in two so the transport between them is the caller's:
- * phase 0 = everything up to and including the cell update + pack-ready,
- * phase 1 = after ghost cells were unpacked (boundary refresh). */
+/* One step in two stream-ordered phases so that the exchanges between them are the caller's:
+ *   phase 0 = flux assembly; with adjustTimeStep it leaves {max Cof, -min tauQGDf} of this shard in the
+ *             2-double device buffer of qgd_case_reduction_ptr -- MAX-all-reduce it over the ranks in place
+ *             [QGDCourantNo_8H L50, setDeltaT-QGDQHD_8H L46 are global reductions];
+ *   phase 1 = deltaT, cell update, boundary refresh; then halo_pack / exchange / halo_unpack. */
 int qgd_case_step_phase(qgd_case_t c, int phase);
+int qgd_case_reduction_ptr(qgd_case_t c, void** devicePtr);
 
 /* ---- measurement ------------------------------------------------------------ */
 /* Kernel ids for qgd_case_kernel_time. */

@@ -1339,12 +1339,18 @@ struct Case {
     }
 
     // [QGDCourantNo.H:36-53] [setDeltaT-QGDQHD.H:41-61]
-    void courantAndDeltaT() {
+    // local part of the reductions (a sharded run max/min-reduces redCo / redMinTau over the ranks in between)
+    double redCo = -GREAT, redMinTau = GREAT;
+    void courantLocal() {
         if (!opt.adjustTimeStep) return;
         double co = -GREAT, mintau = GREAT;
-        for (size_t pass = 0; pass < 1; ++pass) {
+        {
             for (int f = 0; f < m.nF; ++f) {
-                if (f >= m.nIF) { int ip = patchOf(f); if (ip < 0 || !m.patchHasFields(ip) || m.patches[ip].type == PATCH_HALO) continue; }
+                if (f >= m.nIF) {
+                    int ip = patchOf(f);
+                    if (ip < 0 || !m.patchHasFields(ip) || m.patches[ip].type == PATCH_HALO) continue;
+                    if (!ghostFlag.empty() && ghostFlag[m.own[f]]) continue;
+                }
                 else if (!faceTouchesOwned(f)) continue;
                 double nrm[3];
                 for (int k = 0; k < 3; ++k) nrm[k] = m.Sf[3 * (size_t)f + k] / m.magSf[f];
@@ -1354,7 +1360,12 @@ struct Case {
                 mintau = std::min(mintau, tauQGDf.v[f]);
             }
         }
-        CoNum = co;
+        redCo = co; redMinTau = mintau;
+    }
+    void setDeltaT() {
+        if (!opt.adjustTimeStep) return;
+        CoNum = redCo;
+        const double mintau = redMinTau;
         const double maxDeltaTFact = opt.maxCo / (CoNum + SMALL);
         const double deltaTFact = std::min(std::min(maxDeltaTFact, 1.0 + 0.1 * maxDeltaTFact), 1.2);
         double maxDeltaT1 = opt.cTau * mintau;
@@ -1372,11 +1383,15 @@ struct Case {
         return !ghostFlag[m.own[f]] || !ghostFlag[m.nei[f]];
     }
 
-    // loop body [QGDFoam.C:90-163]; phase 0 = through the pressure correction
+    // loop body [QGDFoam.C:90-163]: phase 0 = flux assembly + local Courant/tau reductions, phase 1 = deltaT and the
+    // rest of the body, phase 2 = refresh after a halo unpack
     void stepPhase0() {
         updateFields();
         updateFluxes();
-        courantAndDeltaT();
+        courantLocal();
+    }
+    void stepPhase1() {
+        setDeltaT();
         time += deltaT; stepCount++;
         const double rDeltaT = 1.0 / deltaT;
         const dvec rhoOld = rho.in, rhoUOld = rhoU.in, UOld = U.in, rhoEOld = rhoE.in, eOld = e.in;
@@ -1450,7 +1465,7 @@ struct Case {
         correctBC_p();                                                          // [:155]
         for (int b = 0; b < m.nBF(); ++b) rho.bf[b] = psi.bf[b] * p.bf[b];      // [:156]
     }
-    void stepPhase1() {
+    void stepPhase2() {
         // after a halo unpack: tauQGDf is a pure function of the cell fields
         if (!m.haloGhost[0].empty() || !m.haloGhost[1].empty()) computeTauQGDf();
     }
@@ -1633,10 +1648,20 @@ int orc_case_set_fields(void* cp, const double* U, const double* T, const double
 int orc_case_update_fluxes(void* cp) { Case* c = (Case*)cp; c->updateFields(); c->updateFluxes(); return 0; }
 int orc_case_step(void* cp, int32_t n) {
     Case* c = (Case*)cp;
-    for (int i = 0; i < n; ++i) { c->stepPhase0(); c->stepPhase1(); }
+    for (int i = 0; i < n; ++i) { c->stepPhase0(); c->stepPhase1(); c->stepPhase2(); }
     return 0;
 }
-int orc_case_step_phase(void* cp, int phase) { Case* c = (Case*)cp; if (phase == 0) c->stepPhase0(); else c->stepPhase1(); return 0; }
+int orc_case_step_phase(void* cp, int phase) {
+    Case* c = (Case*)cp;
+    if (phase == 0) c->stepPhase0(); else if (phase == 1) c->stepPhase1(); else c->stepPhase2();
+    return 0;
+}
+// [0] = max Cof, [1] = -min tauQGDf of this shard: MAX-reduce over the ranks between phase 0 and phase 1
+int orc_case_reduction(void* cp, double* buf, int set) {
+    Case* c = (Case*)cp;
+    if (set) { c->redCo = buf[0]; c->redMinTau = -buf[1]; } else { buf[0] = c->redCo; buf[1] = -c->redMinTau; }
+    return 0;
+}
 
 int orc_case_get_field(void* cp, const char* name, double* out, int64_t n) {
     Case* c = (Case*)cp;

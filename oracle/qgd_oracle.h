@@ -73,6 +73,7 @@ int orc_case_halo_count(void* c, int side, int64_t* count);
 int orc_case_halo_pack(void* c, int side, double* sendBuf);
 int orc_case_halo_unpack(void* c, int side, const double* recvBuf);
 int orc_case_step_phase(void* c, int phase);
+int orc_case_reduction(void* c, double* buf2, int set);
 
 #ifdef __cplusplus
 }

@@ -695,11 +695,17 @@ int qgd_case_update_fluxes(qgd_case_t c) {
     QGD_CATCH
 }
 
-static void stepOnce(qgd_case_s* c) {
+// phase 0: flux assembly (+ the shard's max Cof / min tauQGDf into red[0], -red[1]);
+// phase 1: deltaT, cell update, boundary refresh
+static void stepAssemble(qgd_case_s* c) {
+    const bool adjust = c->opt.adjustTimeStep != 0;
+    assembleFluxes(c, adjust);
+    if (adjust) launchFaceReduce(launcherOf(c), c->view);
+}
+static void stepAdvance(qgd_case_s* c) {
     const Launcher L = launcherOf(c);
     const MeshView& m = c->dev->view;
     const bool adjust = c->opt.adjustTimeStep != 0;
-    assembleFluxes(c, adjust);
     if (adjust) launchDeltaT(L, c->view, c->opt.maxCo, c->opt.maxDeltaT, c->opt.cTau);
     launchCellUpdate(L, m, c->view, c->gas);
     launchBoundaryUpdate(L, m, c->view, c->gas, c->bcDev, false, c->phiwRegistered);
@@ -714,7 +720,7 @@ int qgd_case_step(qgd_case_t c, int32_t nSteps) {
     if (c->dev->nHaloCells[0] || c->dev->nHaloCells[1])
         return fail(QGD_ERR_INVALID, "qgd_case_step: sharded mesh, drive it with qgd_case_step_phase + halo exchange");
     HIP_CHECK(hipSetDevice(c->dev->deviceId));
-    for (int i = 0; i < nSteps; ++i) stepOnce(c);
+    for (int i = 0; i < nSteps; ++i) { stepAssemble(c); stepAdvance(c); }
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(c->stream()));
     return QGD_OK;
@@ -726,10 +732,16 @@ int qgd_case_step_phase(qgd_case_t c, int phase) {
     if (!c) return fail(QGD_ERR_INVALID, "null case");
     if (!c->fieldsSet) return fail(QGD_ERR_INVALID, "qgd_case_step_phase: call qgd_case_set_fields first");
     HIP_CHECK(hipSetDevice(c->dev->deviceId));
-    if (phase == 0) stepOnce(c);
+    if (phase == 0) stepAssemble(c);
+    else if (phase == 1) stepAdvance(c);
     HIP_CHECK(hipGetLastError());
     return QGD_OK;  // asynchronous: qgd_case_stream_sync waits
     QGD_CATCH
+}
+int qgd_case_reduction_ptr(qgd_case_t c, void** devicePtr) {
+    if (!c || !devicePtr) return fail(QGD_ERR_INVALID, "null argument");
+    *devicePtr = c->view.red;
+    return QGD_OK;
 }
 int qgd_case_set_stream(qgd_case_t c, void* hipStream) {
     if (!c) return fail(QGD_ERR_INVALID, "null case");

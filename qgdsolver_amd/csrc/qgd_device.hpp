@@ -97,6 +97,7 @@ void launchBoundaryUpdate(const Launcher& L, const MeshView& m, const CaseView& 
 void launchCellInit(const Launcher& L, const MeshView& m, const CaseView& c, const GasModel& g, const double* U,
                     const double* T, const double* p);
 void launchDeltaT(const Launcher& L, const CaseView& c, double maxCo, double maxDeltaT, double cTau);
+void launchFaceReduce(const Launcher& L, const CaseView& c);
 void launchResetReductions(const Launcher& L, const CaseView& c);
 void launchCellMinReduce(const Launcher& L, const CaseView& c);
 int faceBlocks(const MeshView& m);

@@ -940,10 +940,9 @@ __global__ __launch_bounds__(QGD_BLOCK) void boundaryUpdateKernel(const MeshView
     c.bPmid[b] = Ab.p;
 }
 
-// adjustTimeStep [QGDCourantNo_8H L50, setDeltaT-QGDQHD_8H L41-61]: one workgroup folds the per-workgroup
-// partials of the face kernels and advances deltaT on the device
-__global__ __launch_bounds__(QGD_BLOCK) void deltaTKernel(const CaseView c, const double maxCo, const double maxDeltaT,
-                                                         const double cTau) {
+// adjustTimeStep: one workgroup folds the per-workgroup partials of the face kernels into red[0] = max Cof and
+// red[1] = -min tauQGDf (one MAX all-reduce serves both in a sharded run) [QGDCourantNo_8H L50, setDeltaT-QGDQHD_8H L46]
+__global__ __launch_bounds__(QGD_BLOCK) void faceReduceKernel(const CaseView c) {
     double co = -1e300, tmin = 1e300;
     for (int i = threadIdx.x; i < c.nBlkFace; i += QGD_BLOCK) {
         co = fmax(co, c.blkFace[2 * (size_t)i]);
@@ -951,17 +950,19 @@ __global__ __launch_bounds__(QGD_BLOCK) void deltaTKernel(const CaseView c, cons
     }
     blockMaxMin(co, tmin, c.red, false);
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const double CoNum = c.red[0], minTau = c.red[1];
-        const double maxDeltaTFact = maxCo / (CoNum + 1e-15);
-        const double deltaTFact = fmin(fmin(maxDeltaTFact, 1.0 + 0.1 * maxDeltaTFact), 1.2);
-        double maxDeltaT1 = cTau * minTau;
-        maxDeltaT1 = fmin(maxDeltaT, maxDeltaT1);
-        const double dt = fmin(deltaTFact * c.dt[0], maxDeltaT1);
-        c.dt[0] = dt;
-        c.dt[1] += dt;  // time
-        c.dt[2] = CoNum;
-    }
+    if (threadIdx.x == 0) c.red[1] = -c.red[1];
+}
+// deltaT on the device [setDeltaT-QGDQHD_8H L41-61]
+__global__ void deltaTKernel(const CaseView c, const double maxCo, const double maxDeltaT, const double cTau) {
+    const double CoNum = c.red[0], minTau = -c.red[1];
+    const double maxDeltaTFact = maxCo / (CoNum + 1e-15);
+    const double deltaTFact = fmin(fmin(maxDeltaTFact, 1.0 + 0.1 * maxDeltaTFact), 1.2);
+    double maxDeltaT1 = cTau * minTau;
+    maxDeltaT1 = fmin(maxDeltaT, maxDeltaT1);
+    const double dt = fmin(deltaTFact * c.dt[0], maxDeltaT1);
+    c.dt[0] = dt;
+    c.dt[1] += dt;  // time
+    c.dt[2] = CoNum;
 }
 __global__ __launch_bounds__(QGD_BLOCK) void resetReductionsKernel(const CaseView c) {
     for (int i = blockIdx.x * QGD_BLOCK + threadIdx.x; i < c.nBlkCell; i += gridDim.x * QGD_BLOCK) {
@@ -1226,8 +1227,9 @@ void launchCellInit(const Launcher& L, const MeshView& m, const CaseView& c, con
     cellInitKernel<<<gridFor(m.nC), QGD_BLOCK, 0, L.stream>>>(m, c, g, U, T, p);
 }
 void launchDeltaT(const Launcher& L, const CaseView& c, double maxCo, double maxDeltaT, double cTau) {
-    deltaTKernel<<<1, QGD_BLOCK, 0, L.stream>>>(c, maxCo, maxDeltaT, cTau);
+    deltaTKernel<<<1, 1, 0, L.stream>>>(c, maxCo, maxDeltaT, cTau);
 }
+void launchFaceReduce(const Launcher& L, const CaseView& c) { faceReduceKernel<<<1, QGD_BLOCK, 0, L.stream>>>(c); }
 void launchResetReductions(const Launcher& L, const CaseView& c) { resetReductionsKernel<<<64, QGD_BLOCK, 0, L.stream>>>(c); }
 void launchCellMinReduce(const Launcher& L, const CaseView& c) { cellMinReduceKernel<<<1, QGD_BLOCK, 0, L.stream>>>(c); }
 int faceBlocks(const MeshView& m) { return gridFor(m.nIF); }

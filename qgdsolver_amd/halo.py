@@ -45,3 +45,14 @@ class SlabHalo:
             w.wait()
         for s in self.sides:
             self.case.halo_unpack(s, self.arg(self.recv[s]))
+
+
+    def step(self, allreduce_max=None):
+        """One sharded step: assemble, (adjustTimeStep: MAX all-reduce of the 2-double reduction buffer through
+        ``allreduce_max(case)``), advance, halo exchange, post-exchange refresh."""
+        self.case.step_phase(0)
+        if allreduce_max is not None:
+            allreduce_max(self.case)
+        self.case.step_phase(1)
+        self.exchange()
+        self.case.step_phase(2)

@@ -103,6 +103,12 @@ class QGDFoamCase:
     def step_phase(self, phase):
         L.check(L.lib.qgd_case_step_phase(self._h, int(phase)), "qgd_case_step_phase")
 
+    def reduction_ptr(self):
+        """device pointer of the 2-double {max Cof, -min tauQGDf} buffer (valid between phase 0 and phase 1)"""
+        p = C.c_void_p()
+        L.check(L.lib.qgd_case_reduction_ptr(self._h, C.byref(p)), "qgd_case_reduction_ptr")
+        return p.value
+
     def set_stream(self, raw_stream):
         """Run on a caller-owned hipStream_t (e.g. ``torch.cuda.current_stream().cuda_stream``)."""
         L.check(L.lib.qgd_case_set_stream(self._h, C.c_void_p(raw_stream)), "qgd_case_set_stream")

@@ -12,6 +12,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def main():
     outdir, n, steps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    adjust = int(sys.argv[4]) if len(sys.argv) > 4 else 0
     import torch
     import torch.distributed as dist
 
@@ -28,7 +29,7 @@ def main():
     om = OracleMesh(mesh.primitives())
     for side in (0, 1):
         om.set_halo(side, mesh.array(f"haloGhost{side}"), mesh.array(f"haloSend{side}"))
-    opt = q.default_options(stencil="GaussVolPoint", deltaT=2e-3, mu=1e-3)
+    opt = q.default_options(stencil="GaussVolPoint", deltaT=2e-3, mu=1e-3, adjustTimeStep=adjust, maxCo=0.3, maxDeltaT=1.0, cTau=0.75)
     case = OracleCase(om, opt)
     # initial fields are functions of the GLOBAL mesh: build them there and cut the window
     gmesh = q.PolyMesh.box(nx, ny, n)
@@ -39,13 +40,19 @@ def main():
     halo = SlabHalo(case, rank, world, dist, alloc=lambda c: torch.zeros(c, dtype=torch.float64),
                     arg=lambda t: t.numpy())
     halo.exchange()
-    case.step_phase(1)
+    case.step_phase(2)
+
+    def allreduce_max(c):
+        t = torch.from_numpy(c.reduction())
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        c.reduction(t.numpy())
+
     for _ in range(steps):
-        case.step_phase(0)
-        halo.exchange()
-        case.step_phase(1)
+        halo.step(allreduce_max if adjust else None)
     own = slice(plane * (lo - k_lo), plane * (hi - k_lo))
-    np.savez(os.path.join(outdir, f"rank{rank}.npz"), lo=lo, hi=hi, **{f: case.field(f)[own] for f in ("rho", "U", "p", "e")})
+    info = case.info()
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), lo=lo, hi=hi, time=info["time"], deltaT=info["deltaT"],
+             **{f: case.field(f)[own] for f in ("rho", "U", "p", "e")})
     dist.barrier()
     dist.destroy_process_group()
 

@@ -51,6 +51,7 @@ lib.orc_case_halo_count.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]
 lib.orc_case_halo_pack.argtypes = [C.c_void_p, C.c_int, dp]
 lib.orc_case_halo_unpack.argtypes = [C.c_void_p, C.c_int, dp]
 lib.orc_case_step_phase.argtypes = [C.c_void_p, C.c_int]
+lib.orc_case_reduction.argtypes = [C.c_void_p, dp, C.c_int]
 
 _NCOMP = {"U": 3, "rhoU": 3, "phiJmU": 3, "phiP": 3, "phiPi": 3, "gradUf": 9, "gradef": 3, "gradRhof": 3, "gradPf": 3,
           "Uf": 3, "Pif": 9, "qf": 3, "jm": 3}
@@ -185,6 +186,15 @@ class OracleCase:
         a = (C.c_double * 6)()
         lib.orc_case_info(self._h, a)
         return dict(time=a[0], deltaT=a[1], CoNum=a[2], minRho=a[3], minE=a[4], steps=int(a[5]))
+
+    def reduction(self, buf=None):
+        """get (buf None) or set the 2-double {max Cof, -min tauQGDf} of this shard"""
+        if buf is None:
+            out = np.zeros(2)
+            lib.orc_case_reduction(self._h, _d(out), 0)
+            return out
+        b = np.ascontiguousarray(buf, dtype=np.float64)
+        lib.orc_case_reduction(self._h, _d(b), 1)
 
     def halo_count(self, side):
         n = C.c_int64()

@@ -17,16 +17,17 @@ from util import oracle_mesh_of
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_oracle_matches_unsharded(tmp_path, world):
+@pytest.mark.parametrize("world,adjust", [(2, 0), (3, 0), (2, 1)])
+def test_sharded_oracle_matches_unsharded(tmp_path, world, adjust):
     n, steps = 9, 6
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(29500 + world), os.path.join(ROOT, "tests", "halo_worker.py"), str(tmp_path), str(n), str(steps)]
+           "--master-port", str(29500 + world), os.path.join(ROOT, "tests", "halo_worker.py"), str(tmp_path), str(n), str(steps), str(adjust)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     mesh = q.PolyMesh.box(n, n - 1, n)
-    oc = OracleCase(oracle_mesh_of(mesh), q.default_options(stencil="GaussVolPoint", deltaT=2e-3, mu=1e-3))
+    oc = OracleCase(oracle_mesh_of(mesh), q.default_options(stencil="GaussVolPoint", deltaT=2e-3, mu=1e-3, adjustTimeStep=adjust,
+                                                             maxCo=0.3, maxDeltaT=1.0, cTau=0.75))
     U, T, p = cases.box_initial_fields(mesh.array("C").reshape(-1, 3))
     oc.set_fields(U, T, p)
     oc.step(steps)
@@ -35,6 +36,9 @@ def test_sharded_oracle_matches_unsharded(tmp_path, world):
     for rank in range(world):
         d = np.load(os.path.join(tmp_path, f"rank{rank}.npz"))
         lo, hi = int(d["lo"]), int(d["hi"])
+        # with adjustTimeStep the Courant number / min tau are global reductions: every rank walks the same time axis
+        assert abs(float(d["time"]) - oc.info()["time"]) <= 1e-12 * oc.info()["time"]
+        assert abs(float(d["deltaT"]) - oc.info()["deltaT"]) <= 1e-12 * oc.info()["deltaT"]
         covered += hi - lo
         for f in ("rho", "U", "p", "e"):
             ref = oc.field(f)[plane * lo: plane * hi]

@@ -54,6 +54,7 @@ def test_two_shards_on_one_device_match_unsharded():
     exchange()
     for _ in range(steps):
         c0.step_phase(0); c1.step_phase(0)
+        c0.step_phase(1); c1.step_phase(1)
         exchange()
     for lo, hi, k_lo, k_hi, mesh, dev, case in shards:
         own = slice(plane * (lo - k_lo), plane * (hi - k_lo))
