@@ -779,10 +779,10 @@ int qgd_device_release(qgd_device_t d, void* devicePtr) {
     QGD_CATCH
 }
 
-// halo message layout: 14 doubles per cell (RecA, RecB, Cons), 12 per boundary face (RecA, RecB, p gradient, lagged rho)
+// halo message layout: 10 doubles per cell (RecA, RecB), 12 per boundary face (RecA, RecB, p gradient, lagged rho)
 int qgd_case_halo_count(qgd_case_t c, int side, int64_t* count) {
     if (!c || !count || side < 0 || side > 1) return fail(QGD_ERR_INVALID, "bad argument");
-    *count = 14 * (int64_t)c->dev->nHaloSendCells[side] + 12 * (int64_t)c->dev->nHaloSendBF[side];
+    *count = 10 * (int64_t)c->dev->nHaloSendCells[side] + 12 * (int64_t)c->dev->nHaloSendBF[side];
     return QGD_OK;
 }
 int qgd_case_halo_pack(qgd_case_t c, int side, double* sendBufDevice) {

@@ -988,29 +988,29 @@ __global__ __launch_bounds__(QGD_BLOCK) void cellMinReduceKernel(const CaseView 
     if (threadIdx.x == 0) c.red[2] = -c.red[2];
 }
 
-// halo message = 14 doubles per listed cell (RecA, RecB, Cons), then 12 per listed
-// boundary face (RecA, RecB, p gradient, lagged patch density)
+// halo message = 10 doubles per listed cell (RecA, RecB), then 12 per listed boundary face (RecA, RecB, p gradient,
+// lagged patch density).  A ghost cell's conserved record is rebuilt from what arrives (it only feeds the ghost's
+// own, discarded, update).
 __global__ __launch_bounds__(QGD_BLOCK) void haloKernel(const CaseView c, const int32_t* __restrict__ cells, const int nCells,
                                                        const int32_t* __restrict__ bfaces, const int nFaces,
                                                        double* __restrict__ buf, const int pack) {
     const int i = blockIdx.x * QGD_BLOCK + threadIdx.x;
     if (i < nCells) {
         const int ci = cells[i];
-        double* q = buf + 14 * (size_t)i;
+        double* q = buf + 10 * (size_t)i;
         if (pack) {
-            const RecA a = c.A[ci]; const RecB b = c.B[ci]; const Cons k = c.K[ci];
+            const RecA a = c.A[ci]; const RecB b = c.B[ci];
             q[0] = a.rho; q[1] = a.ux; q[2] = a.uy; q[3] = a.uz; q[4] = a.p; q[5] = a.e; q[6] = b.H; q[7] = b.c; q[8] = b.muQGD; q[9] = b.aOc;
-            q[10] = k.rux; q[11] = k.ruy; q[12] = k.ruz; q[13] = k.rE;
         } else {
             RecA a; RecB b; Cons k;
             a.rho = q[0]; a.ux = q[1]; a.uy = q[2]; a.uz = q[3]; a.p = q[4]; a.e = q[5]; b.H = q[6]; b.c = q[7]; b.muQGD = q[8]; b.aOc = q[9];
-            k.rux = q[10]; k.ruy = q[11]; k.ruz = q[12]; k.rE = q[13];
+            k.rux = a.rho * a.ux; k.ruy = a.rho * a.uy; k.ruz = a.rho * a.uz; k.rE = b.H * a.rho - a.p;
             c.A[ci] = a; c.B[ci] = b; c.K[ci] = k;
         }
     } else if (i < nCells + nFaces) {
         const int j = i - nCells;
         const int bi = bfaces[j];
-        double* q = buf + 14 * (size_t)nCells + 12 * (size_t)j;
+        double* q = buf + 10 * (size_t)nCells + 12 * (size_t)j;
         if (pack) {
             const RecA a = c.bA[bi]; const RecB b = c.bB[bi];
             q[0] = a.rho; q[1] = a.ux; q[2] = a.uy; q[3] = a.uz; q[4] = a.p; q[5] = a.e; q[6] = b.H; q[7] = b.c; q[8] = b.muQGD; q[9] = b.aOc;
