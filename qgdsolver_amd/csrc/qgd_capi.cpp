@@ -61,23 +61,24 @@ struct qgd_mesh_s {
 struct DeviceArena {
     std::vector<void*> ptrs;
     int64_t bytes = 0;
+    void* raw(size_t nbytes) {
+        void* d = nullptr;
+        HIP_CHECK(hipMalloc(&d, nbytes));
+        ptrs.push_back(d);
+        bytes += (int64_t)nbytes;
+        return d;
+    }
     template <class T>
     T* upload(const std::vector<T>& v) {
         if (v.empty()) return nullptr;
-        void* d = nullptr;
-        HIP_CHECK(hipMalloc(&d, v.size() * sizeof(T)));
-        ptrs.push_back(d);
-        bytes += (int64_t)(v.size() * sizeof(T));
+        void* d = raw(v.size() * sizeof(T));
         HIP_CHECK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
         return (T*)d;
     }
     template <class T>
     T* alloc(size_t n, bool zero = true) {
         if (n == 0) return nullptr;
-        void* d = nullptr;
-        HIP_CHECK(hipMalloc(&d, n * sizeof(T)));
-        ptrs.push_back(d);
-        bytes += (int64_t)(n * sizeof(T));
+        void* d = raw(n * sizeof(T));
         if (zero) HIP_CHECK(hipMemset(d, 0, n * sizeof(T)));
         return (T*)d;
     }
