@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--edge", dest="n", type=int, default=int(os.environ.get("QGD_BENCH_N", "400")), help="box edge in cells (n^3 cells in total)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = debugging aid: all ranks share GPU 0 and halo messages are staged through host memory")
+    ap.add_argument("--check", action="store_true", help="print a checksum of the owned cells (to compare runs at different N)")
     ap.add_argument("--cpu-n", type=int, default=96, help="edge of the CPU-baseline sample box")
     ap.add_argument("--cpu-steps", type=int, default=12)
     return ap.parse_args()
@@ -88,10 +91,16 @@ def main():
 
     if not torch.cuda.is_available() or q.device_count() < 1:
         raise RuntimeError("bench.py needs a HIP device: qgdsolver_amd has no CPU fallback")
+    staged = args.backend == "gloo"
+    if staged:
+        local_rank = 0  # every rank on GPU 0; exercises the multi-rank logic on a 1-GPU box
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if staged:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     n = args.n
     lo, hi, k_lo, k_hi = slab_range(n, rank, world)
@@ -118,9 +127,36 @@ def main():
     t_setup = time.perf_counter() - t_setup
 
     # one RCCL send/recv pair per neighbour per step; buffers live in HBM, pack/unpack run on the same stream
-    halo = SlabHalo(case, rank, world, dist, alloc=lambda c: torch.empty(c, dtype=torch.float64, device="cuda"),
-                    arg=lambda t: t.data_ptr())
-    exchange = halo.exchange
+    if not staged:
+        halo = SlabHalo(case, rank, world, dist, alloc=lambda c: torch.empty(c, dtype=torch.float64, device="cuda"),
+                        arg=lambda t: t.data_ptr())
+        exchange = halo.exchange
+    else:
+        class Staged(SlabHalo):
+            """host-staged variant for the gloo debugging mode"""
+
+            def exchange(self):
+                if not self.sides:
+                    return
+                dev_s = {s: torch.empty_like(self.send[s], device="cuda") for s in self.sides}
+                for s in self.sides:
+                    self.case.halo_pack(s, dev_s[s].data_ptr())
+                torch.cuda.synchronize()
+                for s in self.sides:
+                    self.send[s].copy_(dev_s[s])
+                ops = []
+                for s in self.sides:
+                    ops.append(self.dist.P2POp(self.dist.isend, self.send[s], self.peer[s]))
+                    ops.append(self.dist.P2POp(self.dist.irecv, self.recv[s], self.peer[s]))
+                for w in self.dist.batch_isend_irecv(ops):
+                    w.wait()
+                for s in self.sides:
+                    dev_s[s].copy_(self.recv[s])
+                    self.case.halo_unpack(s, dev_s[s].data_ptr())
+                torch.cuda.synchronize()
+
+        halo = Staged(case, rank, world, dist, alloc=lambda c: torch.empty(c, dtype=torch.float64), arg=None)
+        exchange = halo.exchange
 
     def step():
         case.step_phase(0)   # flux assembly
@@ -142,10 +178,19 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if staged else "cuda")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    checksum = None
+    if args.check:
+        plane = n * n
+        rho_owned = case.field("rho")[plane * (lo - k_lo): plane * (hi - k_lo)]
+        cs = torch.tensor([float(rho_owned.sum()), float((rho_owned ** 2).sum())], dtype=torch.float64,
+                          device="cpu" if staged else "cuda")
+        if world > 1:
+            dist.all_reduce(cs, op=dist.ReduceOp.SUM)
+        checksum = [float(x) for x in cs]
 
     kt = {}
     for name, k in (("point", L.K_POINT), ("face", L.K_FACE), ("bface", L.K_BFACE), ("cell", L.K_CELL), ("bc", L.K_BC)):
@@ -197,6 +242,8 @@ def main():
             "setup_s": t_setup,
             "min_rho": info["minRho"],
         }
+        if checksum is not None:
+            out["checksum_rho"] = checksum
         traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(traffic_file):
             try:
