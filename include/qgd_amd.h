@@ -190,6 +190,17 @@ int qgd_fvsc_div_v(qgd_device_t d, int stencilId, const double* cell,
 int qgd_fvsc_div_t(qgd_device_t d, int stencilId, const double* cell,
                    const double* bnd, double* out);
 
+/* qgdInterpolate / linearInterpolate [QGDInterpolate_8H_source.html L38-67]: face = w*(phi_O - phi_N) + phi_N, patch faces
+ * take the patch value.  cell nCells*ncomp, bnd nBoundaryFaces*ncomp, out nFaces*ncomp (HOST pointers), ncomp in 1..9. */
+int qgd_interpolate(qgd_device_t d, int32_t ncomp, const double* cell, const double* bnd, double* out);
+/* qgdFlux [QGDInterpolate_8H_source.html L76-118] without a divSchemes entry: out = flux*psif (flux nFaces, psif and out
+ * nFaces*ncomp).  Pure host arithmetic (one multiply per value): kept so call sites read like the reference. */
+int qgd_flux(qgd_device_t d, int32_t ncomp, const double* flux, const double* psif, double* out);
+/* Static QGD length scales of the mesh [QGDCoeffs_8C_source.html L298-376]: name = "hQGD" (nCells), "hQGDf" (nFaces),
+ * "hQGD.boundary" (nBoundaryFaces).  The QHD tau closures (constTau, HbyUQHD, T0byGr, H2bynuQHD) are one line each on
+ * top of these and qgd_interpolate; see qgdsolver_amd/qhdfoam.py. */
+int qgd_device_get(qgd_device_t d, const char* name, double* out, int64_t outDoubles);
+
 /* ---- QHDFoam flux assembly (stateless, host pointers) -------------------- */
 /* The face-flux parts of the QHDFoam step: QHDFoam/updateFields.H L36-73 (gradients, interpolations, BdFrc),
  * QHDFoam/updateFluxes.H L33-38 (phiu, phiwo, taubyrhof), QHDUEqn.H L36-43 (gradPf, Wf, phiUf) and QHDTEqn.H

@@ -59,6 +59,9 @@ SIGNATURES = {
     "qgd_fvsc_grad_v": (C.c_int, [handle, C.c_int, c_double_p, c_double_p, c_double_p]),
     "qgd_fvsc_div_v": (C.c_int, [handle, C.c_int, c_double_p, c_double_p, c_double_p]),
     "qgd_fvsc_div_t": (C.c_int, [handle, C.c_int, c_double_p, c_double_p, c_double_p]),
+    "qgd_interpolate": (C.c_int, [handle, C.c_int32, c_double_p, c_double_p, c_double_p]),
+    "qgd_flux": (C.c_int, [handle, C.c_int32, c_double_p, c_double_p, c_double_p]),
+    "qgd_device_get": (C.c_int, [handle, C.c_char_p, c_double_p, C.c_int64]),
     "qgd_qhd_fluxes": (C.c_int, [handle, C.c_int, C.c_void_p, C.c_void_p]),
     "qgd_case_options_default": (C.c_int, [C.POINTER(CaseOptions)]),
     "qgd_case_create": (C.c_int, [handle, C.POINTER(CaseOptions), handle_p]),

@@ -463,6 +463,55 @@ int qgd_fvsc_grad_v(qgd_device_t d, int id, const double* cell, const double* bn
 int qgd_fvsc_div_v(qgd_device_t d, int id, const double* cell, const double* bnd, double* out) { return fvscOp(d, id, 1, 3, cell, bnd, out); }
 int qgd_fvsc_div_t(qgd_device_t d, int id, const double* cell, const double* bnd, double* out) { return fvscOp(d, id, 1, 9, cell, bnd, out); }
 
+int qgd_interpolate(qgd_device_t d, int32_t ncomp, const double* cell, const double* bnd, double* out) {
+    QGD_TRY
+    if (!d || !cell || !out || ncomp < 1 || ncomp > 9 || (!bnd && d->view.nBF > 0)) return fail(QGD_ERR_INVALID, "qgd_interpolate: bad argument");
+    HIP_CHECK(hipSetDevice(d->deviceId));
+    const MeshView& v = d->view;
+    DeviceArena tmp;
+    try {
+        double* dc = tmp.alloc<double>((size_t)v.nC * ncomp, false);
+        double* db = tmp.alloc<double>(std::max<size_t>(1, (size_t)v.nBF * ncomp));
+        double* dout = tmp.alloc<double>((size_t)v.nF * ncomp, false);
+        HIP_CHECK(hipMemcpy(dc, cell, sizeof(double) * (size_t)v.nC * ncomp, hipMemcpyHostToDevice));
+        if (v.nBF) HIP_CHECK(hipMemcpy(db, bnd, sizeof(double) * (size_t)v.nBF * ncomp, hipMemcpyHostToDevice));
+        (void)hipGetLastError();
+        launchInterpolate(d->stream, ncomp, v, dc, db, dout);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(d->stream));
+        HIP_CHECK(hipMemcpy(out, dout, sizeof(double) * (size_t)v.nF * ncomp, hipMemcpyDeviceToHost));
+    } catch (...) { tmp.release(); throw; }
+    tmp.release();
+    return QGD_OK;
+    QGD_CATCH
+}
+int qgd_flux(qgd_device_t d, int32_t ncomp, const double* flux, const double* psif, double* out) {
+    if (!d || !flux || !psif || !out || ncomp < 1) return fail(QGD_ERR_INVALID, "qgd_flux: bad argument");
+    const int64_t nF = d->view.nF;
+    for (int64_t f = 0; f < nF; ++f)
+        for (int k = 0; k < ncomp; ++k) out[f * ncomp + k] = flux[f] * psif[f * ncomp + k];  // flux*psif [QGDInterpolate_8H L104]
+    return QGD_OK;
+}
+int qgd_device_get(qgd_device_t d, const char* name, double* out, int64_t outDoubles) {
+    QGD_TRY
+    if (!d || !name || !out) return fail(QGD_ERR_INVALID, "qgd_device_get: null argument");
+    HIP_CHECK(hipSetDevice(d->deviceId));
+    const MeshView& v = d->view;
+    const std::string s(name);
+    if (s == "hQGDf") {
+        if ((int64_t)d->hf.size() > outDoubles) return fail(QGD_ERR_INVALID, "output too small");
+        std::copy(d->hf.begin(), d->hf.end(), out);
+    } else if (s == "hQGD") {
+        if (v.nC > outDoubles) return fail(QGD_ERR_INVALID, "output too small");
+        HIP_CHECK(hipMemcpy(out, v.hQGD, sizeof(double) * (size_t)v.nC, hipMemcpyDeviceToHost));
+    } else if (s == "hQGD.boundary") {
+        if (v.nBF > outDoubles) return fail(QGD_ERR_INVALID, "output too small");
+        if (v.nBF) HIP_CHECK(hipMemcpy(out, v.hQGDb, sizeof(double) * (size_t)v.nBF, hipMemcpyDeviceToHost));
+    } else return fail(QGD_ERR_UNKNOWN_NAME, "qgd_device_get: unknown name " + s);
+    return QGD_OK;
+    QGD_CATCH
+}
+
 // ---- QHDFoam face fluxes -------------------------------------------------------------
 int qgd_qhd_fluxes(qgd_device_t d, int stencilId, const qgd_qhd_inputs* in, qgd_qhd_outputs* out) {
     QGD_TRY

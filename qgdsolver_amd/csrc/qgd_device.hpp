@@ -111,6 +111,8 @@ void launchHaloPack(const Launcher& L, const CaseView& c, const int32_t* cells, 
 void launchFvscOp(hipStream_t s, int stencil, int op, int NC, const MeshView& m, const double* cell, const double* bnd,
                   double* pt, double* out);
 
+void launchInterpolate(hipStream_t s, int NC, const MeshView& m, const double* cell, const double* bnd, double* out);
+
 // ---- QHDFoam face fluxes --------------------------------------------------------
 // rec5 = {Ux,Uy,Uz,T,p} per cell / patch face / vertex; out = 26 SoA slots of nF doubles (see QhdSlot)
 enum QhdSlot : int { QHD_GRADU = 0, QHD_GRADT = 9, QHD_PHIU = 12, QHD_PHIWO = 13, QHD_TAUBYRHO = 14, QHD_GRADP = 15,

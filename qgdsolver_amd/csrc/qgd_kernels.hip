@@ -1267,6 +1267,24 @@ void launchFvscOp(hipStream_t s, int stencil, int op, int NC, const MeshView& m,
     }
 }
 
+// qgdInterpolate with the default (linear) scheme [QGDInterpolate_8H L38-67]
+__global__ __launch_bounds__(QGD_BLOCK) void interpolateKernel(const MeshView m, const int NC, const double* __restrict__ cell,
+                                                              const double* __restrict__ bnd, double* __restrict__ out) {
+    const int f = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    if (f >= m.nF) return;
+    if (f < m.nIF) {
+        const int o = m.own[f], n = m.nei[f];
+        const double w = m.w[f];
+        for (int k = 0; k < NC; ++k) out[(size_t)f * NC + k] = lerpf(w, cell[(size_t)o * NC + k], cell[(size_t)n * NC + k]);
+    } else {
+        const bool live = m.fkind[f] != 3;
+        for (int k = 0; k < NC; ++k) out[(size_t)f * NC + k] = live ? bnd[(size_t)(f - m.nIF) * NC + k] : 0.0;
+    }
+}
+void launchInterpolate(hipStream_t s, int NC, const MeshView& m, const double* cell, const double* bnd, double* out) {
+    interpolateKernel<<<gridFor(m.nF), QGD_BLOCK, 0, s>>>(m, NC, cell, bnd, out);
+}
+
 template <int ST>
 static void launchQhdT(hipStream_t s, const MeshView& m, const double* cell5, const double* bnd5, double* pt5, const double* rho,
                        const double* rhob, const double* tau, const double* phi, double beta, double gx, double gy, double gz,

@@ -132,3 +132,33 @@ def grad(dev, vf):
 
 def div(dev, vf):
     return fvscStencil.lookupOrNew(fvscOpName(dev, f"div({vf.name})"), dev).Div(vf)
+
+
+def qgdInterpolate(dev, vf):
+    """QGDInterpolate.H L38-67 with no interpolationSchemes entry: linearInterpolate."""
+    m = dev.mesh
+    nc = vf.ncomp
+    out = np.zeros((m.nFaces, nc) if nc > 1 else (m.nFaces,))
+    bnd = vf.boundary if vf.boundary.size else np.zeros(1)
+    L.check(L.lib.qgd_interpolate(dev._h, nc, vf.internal.ctypes.data_as(L.c_double_p), bnd.ctypes.data_as(L.c_double_p),
+                                  out.ctypes.data_as(L.c_double_p)), "qgd_interpolate")
+    return out
+
+
+def qgdFlux(dev, flux, psif):
+    """QGDInterpolate.H L76-118 with no divSchemes entry: flux*psif."""
+    flux = np.ascontiguousarray(flux, dtype=np.float64)
+    psif = np.ascontiguousarray(psif, dtype=np.float64)
+    nc = 1 if psif.ndim == 1 else psif.shape[1]
+    out = np.zeros_like(psif)
+    L.check(L.lib.qgd_flux(dev._h, nc, flux.ctypes.data_as(L.c_double_p), psif.ctypes.data_as(L.c_double_p),
+                           out.ctypes.data_as(L.c_double_p)), "qgd_flux")
+    return out
+
+
+def device_field(dev, name):
+    m = dev.mesh
+    n = {"hQGD": m.nCells, "hQGDf": m.nFaces, "hQGD.boundary": m.nBoundaryFaces}[name]
+    out = np.zeros(max(n, 1))
+    L.check(L.lib.qgd_device_get(dev._h, name.encode(), out.ctypes.data_as(L.c_double_p), out.size), "qgd_device_get")
+    return out[:n]

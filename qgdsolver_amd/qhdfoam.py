@@ -67,3 +67,30 @@ def updateFluxes(dev, scheme, U, T, rho, tauQGDf, beta, g, p=None, phi=None, str
     else:
         call(scheme, i, o)
     return res
+
+
+# ---- QGDCoeffs closures used by the QHD solvers (one line each on top of hQGD and qgdInterpolate) ---------------------
+def tauQGDf(dev, model, aQGD=0.5, **par):
+    """thermo.tauQGDf() for the QHD closures:
+    constTau  tau = Tau                         constTau.C L71-74
+    HbyUQHD   tau = aQGD*hQGD/UQHD              HbyUQHD.C L80-83
+    T0byGr    tau = T0/Gr                       T0byGr.C L84-87
+    H2bynuQHD tau = aQGD*hQGD^2/nu, nu = mu/rho H2bynuQHD.C L78-82   (pass nu=(cells, patch values))
+    followed by tauQGDf = linearInterpolate(tauQGD)."""
+    from . import fvsc
+
+    m = dev.mesh
+    h = fvsc.device_field(dev, "hQGD")
+    hb = fvsc.device_field(dev, "hQGD.boundary")
+    if model == "constTau":
+        tau, taub = np.full(m.nCells, float(par["Tau"])), np.full(m.nBoundaryFaces, float(par["Tau"]))
+    elif model == "HbyUQHD":
+        tau, taub = aQGD * h / float(par["UQHD"]), aQGD * hb / float(par["UQHD"])
+    elif model == "T0byGr":
+        tau, taub = np.full(m.nCells, par["T0"] / par["Gr"]), np.full(m.nBoundaryFaces, par["T0"] / par["Gr"])
+    elif model == "H2bynuQHD":
+        nu, nub = par["nu"]
+        tau, taub = aQGD * h * h / nu, aQGD * hb * hb / nub
+    else:
+        raise KeyError(model)
+    return fvsc.qgdInterpolate(dev, fvsc.volField("tauQGD", tau, taub))

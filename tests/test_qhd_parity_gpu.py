@@ -62,3 +62,54 @@ def test_qhd_argument_checks():
     with pytest.raises(q.QgdError):
         qhdfoam.updateFluxes(dev, "leastSquares", U, T, rho, tau, 1e-3, (0, 0, -9.81))   # 3-D: refused like fvscOpName
     dev.close()
+
+
+@pytest.mark.parametrize("kind", ["box654_jitter", "plane2d_jitter"])
+def test_qgdInterpolate_qgdFlux_and_tau_closures(kind):
+    """QGDInterpolate.H L38-118 helpers and the QHD tau closures (constTau / HbyUQHD / T0byGr / H2bynuQHD)."""
+    from qgdsolver_amd import fvsc
+    from oracle import OracleCase
+
+    mesh = make_mesh(kind)
+    om = oracle_mesh_of(mesh)
+    dev = q.Device(mesh)
+    own, nei, w = mesh.array("owner"), mesh.array("neighbour"), mesh.array("weights")
+    nif = mesh.nInternalFaces
+    live = np.ones(mesh.nBoundaryFaces, bool)
+    for t, s, z in zip(mesh.array("patchType"), mesh.array("patchStart"), mesh.array("patchSize")):
+        if t == q._lib.PATCH_EMPTY:
+            live[s - nif: s - nif + z] = False
+    for nc in (1, 3, 9):
+        cell, bnd = cases.random_fields(mesh.nCells, mesh.nBoundaryFaces, nc, 7)
+        got = fvsc.qgdInterpolate(dev, q.volField("f", cell, bnd))
+        c2 = cell.reshape(mesh.nCells, -1)
+        ref_i = w[:nif, None] * (c2[own[:nif]] - c2[nei]) + c2[nei]
+        assert rel_err(got.reshape(mesh.nFaces, -1)[:nif], ref_i) <= 4e-16    # one fma vs mul+add
+        assert np.array_equal(got.reshape(mesh.nFaces, -1)[nif:][live], bnd.reshape(mesh.nBoundaryFaces, -1)[live])
+    flux = np.random.default_rng(1).standard_normal(mesh.nFaces)
+    psif = np.random.default_rng(2).standard_normal((mesh.nFaces, 3))
+    assert np.array_equal(fvsc.qgdFlux(dev, flux, psif), flux[:, None] * psif)
+    # length scales equal the oracle's QGDCoeffs::updateQGDLength
+    oc = OracleCase(om, q.default_options(stencil="reduced"))
+    if kind.startswith("plane2d"):
+        for patch in (4, 5):
+            oc.set_bc(patch, U=("none", None), T=("none", None), p=("none", None))
+    U, T, p = cases.box_initial_fields(mesh.array("C").reshape(-1, 3))
+    oc.set_fields(U, T, p)
+    oc.updateFluxes()
+    h, hf, hb = fvsc.device_field(dev, "hQGD"), fvsc.device_field(dev, "hQGDf"), fvsc.device_field(dev, "hQGD.boundary")
+    assert rel_err(h, oc.field("hQGD")) <= 1e-15 and rel_err(hf, oc.field("hQGDf")) <= 1e-15
+    assert rel_err(hb, oc.field("hQGD.boundary")) <= 1e-15
+    # closures
+    t_const = qhdfoam.tauQGDf(dev, "constTau", Tau=2e-3)
+    assert np.array_equal(t_const[:nif], np.full(nif, 2e-3))
+    t_hu = qhdfoam.tauQGDf(dev, "HbyUQHD", aQGD=0.4, UQHD=2.0)
+    th = 0.4 * h / 2.0
+    assert rel_err(t_hu[:nif], w[:nif] * (th[own[:nif]] - th[nei]) + th[nei]) <= 4e-16
+    t_gr = qhdfoam.tauQGDf(dev, "T0byGr", T0=3.0, Gr=1.5e3)
+    assert np.array_equal(t_gr[:nif], np.full(nif, 3.0 / 1.5e3))
+    nu = (1e-3 * (1 + np.random.default_rng(3).random(mesh.nCells)), np.full(mesh.nBoundaryFaces, 1e-3))
+    t_h2 = qhdfoam.tauQGDf(dev, "H2bynuQHD", aQGD=0.5, nu=nu)
+    th2 = 0.5 * h * h / nu[0]
+    assert rel_err(t_h2[:nif], w[:nif] * (th2[own[:nif]] - th2[nei]) + th2[nei]) <= 4e-16
+    dev.close()
