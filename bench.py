@@ -158,10 +158,19 @@ def main():
         halo = Staged(case, rank, world, dist, alloc=lambda c: torch.empty(c, dtype=torch.float64), arg=None)
         exchange = halo.exchange
 
-    def step():
-        case.step_phase(0)   # flux assembly
-        case.step_phase(1)   # cell update + boundary refresh (fixed deltaT: no global reduction needed)
-        exchange()
+    overlap = (world > 1) and (not staged) and os.environ.get("QGD_BENCH_OVERLAP", "1") != "0"
+    if overlap:
+        halo_stream = torch.cuda.Stream()
+        case.set_halo_stream(halo_stream.cuda_stream)
+
+        def step():
+            # exchange hidden behind the bulk of the cell update (boundary layer of the shard is updated first)
+            halo.step_overlapped(torch, stream, halo_stream)
+    else:
+        def step():
+            case.step_phase(0)   # flux assembly
+            case.step_phase(1)   # cell update + boundary refresh (fixed deltaT: no global reduction needed)
+            exchange()
 
     exchange()  # ghost cells start from their owners' records
     for _ in range(args.warmup):
@@ -222,7 +231,8 @@ def main():
                             "GaussVolPoint, constScPrModel1, explicit diffusion, zeroGradient patches, fixed deltaT",
                 "cells": total_cells,
                 "cells_per_gpu": owned_cells,
-                "partition": f"{world} k-slab(s), 1 ghost plane per cut, RCCL send/recv per step" if world > 1 else "single shard",
+                "partition": (f"{world} k-slab(s), 1 ghost plane per cut, RCCL send/recv per step"
+                              + (", exchange overlapped with the cell update" if overlap else "")) if world > 1 else "single shard",
                 "stencil": "GaussVolPoint",
             },
             "roofline": {

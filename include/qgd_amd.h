@@ -309,9 +309,17 @@ int qgd_case_set_stream(qgd_case_t c, void* hipStream);
  *   phase 0 = flux assembly; with adjustTimeStep it leaves {max Cof, -min tauQGDf} of this shard in the
  *             2-double device buffer of qgd_case_reduction_ptr -- MAX-all-reduce it over the ranks in place
  *             [QGDCourantNo_8H L50, setDeltaT-QGDQHD_8H L46 are global reductions];
- *   phase 1 = deltaT, cell update, boundary refresh; then halo_pack / exchange / halo_unpack. */
+ *   phase 1 = deltaT, cell update, boundary refresh; then halo_pack / exchange / halo_unpack.
+ * To overlap the exchange with the bulk of the cell update, phase 1 splits further:
+ *   phase 10 = deltaT + update of the shard's boundary layer only (the cells a neighbour needs and their patch faces),
+ *   phase 11 = update of all remaining owned cells and patch faces;
+ * halo_pack may start as soon as phase 10 is done (on the halo stream of qgd_case_set_halo_stream, ordered after the
+ * compute stream by the caller), phase 11 runs meanwhile, and the next phase 0 waits for halo_unpack.
+ * Ghost cells and their patch faces are written by halo_unpack only.  phase 2 is a no-op hook. */
 int qgd_case_step_phase(qgd_case_t c, int phase);
 int qgd_case_reduction_ptr(qgd_case_t c, void** devicePtr);
+/* Stream (hipStream_t as void*) the halo pack/unpack kernels run on; default: the case's compute stream. */
+int qgd_case_set_halo_stream(qgd_case_t c, void* hipStream);
 
 /* ---- measurement ------------------------------------------------------------ */
 /* Kernel ids for qgd_case_kernel_time. */

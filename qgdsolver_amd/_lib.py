@@ -80,6 +80,7 @@ SIGNATURES = {
     "qgd_case_stream_sync": (C.c_int, [handle]),
     "qgd_case_set_stream": (C.c_int, [handle, C.c_void_p]),
     "qgd_case_step_phase": (C.c_int, [handle, C.c_int]),
+    "qgd_case_set_halo_stream": (C.c_int, [handle, C.c_void_p]),
     "qgd_case_reduction_ptr": (C.c_int, [handle, C.POINTER(C.c_void_p)]),
     "qgd_case_timing": (C.c_int, [handle, C.c_int]),
     "qgd_case_kernel_time": (C.c_int, [handle, C.c_int, c_double_p, c_int64_p]),

@@ -103,6 +103,9 @@ struct qgd_device_s {
     int32_t* haloGhostBF[2] = {nullptr, nullptr};
     int32_t* haloSendBF[2] = {nullptr, nullptr};
     int32_t nHaloCells[2] = {0, 0}, nHaloSendCells[2] = {0, 0}, nHaloGhostBF[2] = {0, 0}, nHaloSendBF[2] = {0, 0};
+    int32_t* sendAll = nullptr;     // send cells of both sides
+    int32_t* sendBFAll = nullptr;   // their real-patch boundary faces
+    int32_t nSendAll = 0, nSendBFAll = 0;
     hipStream_t stream = nullptr;
 };
 
@@ -138,6 +141,8 @@ struct qgd_case_s {
     hipStream_t userStream = nullptr;
     bool useUserStream = false;
     hipStream_t stream() const { return useUserStream ? userStream : dev->stream; }
+    hipStream_t haloStream = nullptr;  // pack/unpack stream (defaults to stream())
+    bool useHaloStream = false;
 };
 
 static hipEvent_t getEvent(qgd_case_s* c) {
@@ -376,6 +381,15 @@ int qgd_device_create(qgd_mesh_t mh, int deviceId, qgd_device_t* out) {
         v.cfSlice = up(s.cfSlice); v.cfCount = up(s.cfCount); v.cfItem = up(s.cfItem);
         v.V = up(s.V); v.hQGD = up(s.hQGD); v.ghost = up(s.ghost);
         v.bPatch = up(s.bPatch); v.hQGDb = up(s.hQGDb);
+        {
+            std::vector<int32_t> sc, sf;
+            for (int side = 0; side < 2; ++side) {
+                sc.insert(sc.end(), s.haloSend[side].begin(), s.haloSend[side].end());
+                sf.insert(sf.end(), s.haloSendBF[side].begin(), s.haloSendBF[side].end());
+            }
+            d->nSendAll = (int32_t)sc.size(); d->nSendBFAll = (int32_t)sf.size();
+            d->sendAll = a.upload(sc); d->sendBFAll = a.upload(sf);
+        }
         for (int side = 0; side < 2; ++side) {
             d->nHaloCells[side] = (int32_t)s.haloGhost[side].size();
             d->nHaloSendCells[side] = (int32_t)s.haloSend[side].size();
@@ -620,7 +634,7 @@ int qgd_case_create(qgd_device_t d, const qgd_case_options* opt, qgd_case_t* out
         cv.bG = a.alloc<double>(v.nBF); cv.bPhiw = a.alloc<double>(v.nBF); cv.bPmid = a.alloc<double>(v.nBF);
         cv.bRhoLag = a.alloc<double>(v.nBF);
         cv.nBlkFace = faceBlocks(v) + bfaceBlocks(v);
-        cv.nBlkCell = cellBlocks(v);
+        cv.nBlkCell = cellBlocks(v) + (d->nSendAll + 255) / 256;
         cv.blkFace = a.alloc<double>(2 * (size_t)std::max(1, cv.nBlkFace));
         cv.blkCell = a.alloc<double>(2 * (size_t)std::max(1, cv.nBlkCell));
         cv.flux = a.alloc<double>(5 * (size_t)v.nF);
@@ -713,7 +727,7 @@ int qgd_case_set_fields(qgd_case_t c, const double* U, const double* T, const do
         L.pre = nullptr; L.post = nullptr;
         (void)hipGetLastError();
         launchCellInit(L, m, c->view, c->gas, dU, dT, dp);
-        launchBoundaryUpdate(L, m, c->view, c->gas, c->bcDev, true, false);
+        launchBoundaryUpdate(L, m, c->view, c->gas, c->bcDev, true, false, 0, nullptr, 0);
         launchResetReductions(L, c->view);
         const double dt0[3] = {c->opt.deltaT, 0.0, 0.0};
         HIP_CHECK(hipMemcpyAsync(c->view.dt, dt0, sizeof(dt0), hipMemcpyHostToDevice, c->stream()));
@@ -752,15 +766,28 @@ static void stepAssemble(qgd_case_s* c) {
     assembleFluxes(c, adjust);
     if (adjust) launchFaceReduce(launcherOf(c), c->view);
 }
-static void stepAdvance(qgd_case_s* c) {
+// part 0 = everything; part 1 = deltaT + the shard's boundary layer (cells a neighbour needs, and their patch faces);
+// part 2 = the remaining owned cells/faces.  Ghost cells and their patch faces are only ever written by halo_unpack.
+static void stepAdvance(qgd_case_s* c, int part) {
     const Launcher L = launcherOf(c);
-    const MeshView& m = c->dev->view;
+    const qgd_device_s* d = c->dev;
+    const MeshView& m = d->view;
     const bool adjust = c->opt.adjustTimeStep != 0;
-    if (adjust) launchDeltaT(L, c->view, c->opt.maxCo, c->opt.maxDeltaT, c->opt.cTau);
-    launchCellUpdate(L, m, c->view, c->gas);
-    launchBoundaryUpdate(L, m, c->view, c->gas, c->bcDev, false, c->phiwRegistered);
-    c->steps++;
-    if (!adjust) c->time += c->opt.deltaT;
+    if (part != 2) {
+        if (adjust) launchDeltaT(L, c->view, c->opt.maxCo, c->opt.maxDeltaT, c->opt.cTau);
+        c->steps++;
+        if (!adjust) c->time += c->opt.deltaT;
+    }
+    if (part == 0) {
+        launchCellUpdate(L, m, c->view, c->gas, 0, nullptr, 0);
+        launchBoundaryUpdate(L, m, c->view, c->gas, c->bcDev, false, c->phiwRegistered, 0, nullptr, 0);
+    } else if (part == 1) {
+        launchCellUpdate(L, m, c->view, c->gas, 1, d->sendAll, d->nSendAll);
+        launchBoundaryUpdate(L, m, c->view, c->gas, c->bcDev, false, c->phiwRegistered, 1, d->sendBFAll, d->nSendBFAll);
+    } else {
+        launchCellUpdate(L, m, c->view, c->gas, 2, nullptr, 0);
+        launchBoundaryUpdate(L, m, c->view, c->gas, c->bcDev, false, c->phiwRegistered, 2, nullptr, 0);
+    }
 }
 
 int qgd_case_step(qgd_case_t c, int32_t nSteps) {
@@ -770,7 +797,7 @@ int qgd_case_step(qgd_case_t c, int32_t nSteps) {
     if (c->dev->nHaloCells[0] || c->dev->nHaloCells[1])
         return fail(QGD_ERR_INVALID, "qgd_case_step: sharded mesh, drive it with qgd_case_step_phase + halo exchange");
     HIP_CHECK(hipSetDevice(c->dev->deviceId));
-    for (int i = 0; i < nSteps; ++i) { stepAssemble(c); stepAdvance(c); }
+    for (int i = 0; i < nSteps; ++i) { stepAssemble(c); stepAdvance(c, 0); }
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(c->stream()));
     return QGD_OK;
@@ -783,10 +810,19 @@ int qgd_case_step_phase(qgd_case_t c, int phase) {
     if (!c->fieldsSet) return fail(QGD_ERR_INVALID, "qgd_case_step_phase: call qgd_case_set_fields first");
     HIP_CHECK(hipSetDevice(c->dev->deviceId));
     if (phase == 0) stepAssemble(c);
-    else if (phase == 1) stepAdvance(c);
+    else if (phase == 1) stepAdvance(c, 0);
+    else if (phase == 10) stepAdvance(c, 1);
+    else if (phase == 11) stepAdvance(c, 2);
+    else if (phase != 2) return fail(QGD_ERR_INVALID, "qgd_case_step_phase: phase must be 0, 1, 2, 10 or 11");
     HIP_CHECK(hipGetLastError());
     return QGD_OK;  // asynchronous: qgd_case_stream_sync waits
     QGD_CATCH
+}
+int qgd_case_set_halo_stream(qgd_case_t c, void* hipStream) {
+    if (!c) return fail(QGD_ERR_INVALID, "null case");
+    c->haloStream = (hipStream_t)hipStream;
+    c->useHaloStream = true;
+    return QGD_OK;
 }
 int qgd_case_reduction_ptr(qgd_case_t c, void** devicePtr) {
     if (!c || !devicePtr) return fail(QGD_ERR_INVALID, "null argument");
@@ -843,6 +879,8 @@ int qgd_case_halo_pack(qgd_case_t c, int side, double* sendBufDevice) {
     if (!sendBufDevice) return fail(QGD_ERR_INVALID, "null buffer");
     HIP_CHECK(hipSetDevice(d->deviceId));
     Launcher L = launcherOf(c);
+    L.pre = nullptr; L.post = nullptr;
+    if (c->useHaloStream) L.stream = c->haloStream;
     (void)hipGetLastError();
     launchHaloPack(L, c->view, d->haloSend[side], d->nHaloSendCells[side], d->haloSendBF[side], d->nHaloSendBF[side], sendBufDevice, true);
     HIP_CHECK(hipGetLastError());
@@ -857,6 +895,8 @@ int qgd_case_halo_unpack(qgd_case_t c, int side, const double* recvBufDevice) {
     if (!recvBufDevice) return fail(QGD_ERR_INVALID, "null buffer");
     HIP_CHECK(hipSetDevice(d->deviceId));
     Launcher L = launcherOf(c);
+    L.pre = nullptr; L.post = nullptr;
+    if (c->useHaloStream) L.stream = c->haloStream;
     (void)hipGetLastError();
     launchHaloPack(L, c->view, d->haloGhost[side], d->nHaloCells[side], d->haloGhostBF[side], d->nHaloGhostBF[side],
                    const_cast<double*>(recvBufDevice), false);

@@ -91,9 +91,10 @@ void launchPressureMidStep(const Launcher& L, const MeshView& m, const CaseView&
 void launchFaceFlux(const Launcher& L, int stencil, const MeshView& m, const CaseView& c, const GasModel& g, bool adjustDt);
 void launchBoundaryFaceFlux(const Launcher& L, int stencil, const MeshView& m, const CaseView& c, const GasModel& g,
                             const PatchBCDev* bc, bool phiwOnly, bool adjustDt);
-void launchCellUpdate(const Launcher& L, const MeshView& m, const CaseView& c, const GasModel& g);
+void launchCellUpdate(const Launcher& L, const MeshView& m, const CaseView& c, const GasModel& g, int mode,
+                      const int32_t* list, int nList);
 void launchBoundaryUpdate(const Launcher& L, const MeshView& m, const CaseView& c, const GasModel& g, const PatchBCDev* bc,
-                          bool init, bool phiwRegistered);
+                          bool init, bool phiwRegistered, int mode, const int32_t* list, int nList);
 void launchCellInit(const Launcher& L, const MeshView& m, const CaseView& c, const GasModel& g, const double* U,
                     const double* T, const double* p);
 void launchDeltaT(const Launcher& L, const CaseView& c, double maxCo, double maxDeltaT, double cTau);

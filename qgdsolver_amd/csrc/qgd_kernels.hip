@@ -446,7 +446,7 @@ __global__ __launch_bounds__(QGD_BLOCK) void faceFluxKernel(const MeshView m, co
 #pragma unroll
         for (int k = 0; k < 5; ++k) c.flux[(size_t)k * m.nF + f] = out[k];
         if (adjustDt) {
-            const bool counted = (m.ghost == nullptr) || !(m.ghost[o] && m.ghost[n]);
+            const bool counted = (m.ghost == nullptr) || !(m.ghost[o] == 1 && m.ghost[n] == 1);
             if (counted) {
                 const double ms = sqrt(S[0] * S[0] + S[1] * S[1] + S[2] * S[2]);
                 const double Unf = s.Uf[0] * (S[0] / ms) + s.Uf[1] * (S[1] / ms) + s.Uf[2] * (S[2] / ms);
@@ -555,7 +555,7 @@ void faceFluxGvp3Kernel(const MeshView m, const CaseView c, const GasModel gm, c
 #pragma unroll
         for (int k = 0; k < 5; ++k) c.flux[(size_t)k * nF + f] = out[k];
         if (adjustDt) {
-            const bool counted = (m.ghost == nullptr) || !(m.ghost[o] && m.ghost[n]);
+            const bool counted = (m.ghost == nullptr) || !(m.ghost[o] == 1 && m.ghost[n] == 1);
             if (counted) {
                 const double ms = sqrt(S[0] * S[0] + S[1] * S[1] + S[2] * S[2]);
                 const double Unf = s.Uf[0] * (S[0] / ms) + s.Uf[1] * (S[1] / ms) + s.Uf[2] * (S[2] / ms);
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(QGD_BLOCK) void boundaryFaceFluxKernel(const MeshVi
             if (!phiwOnly) {
 #pragma unroll
                 for (int k = 0; k < 5; ++k) c.flux[(size_t)k * m.nF + f] = out[k];
-                if (adjustDt && !(m.ghost && m.ghost[o])) {
+                if (adjustDt && !(m.ghost && m.ghost[o] == 1)) {
                     const double ms = m.magSf[f];
                     const double Unf = s.Uf[0] * (S[0] / ms) + s.Uf[1] * (S[1] / ms) + s.Uf[2] * (S[2] / ms);
                     cof = fmax(fabs(Unf + s.cf), fabs(Unf - s.cf)) * c.dt[0] / hf;
@@ -774,11 +774,20 @@ __global__ __launch_bounds__(QGD_BLOCK) void pressureMidStepKernel(const MeshVie
 #define QGD_C_WAVES_MAX 4
 #endif
 __global__ __launch_bounds__(QGD_BLOCK) __attribute__((amdgpu_waves_per_eu(QGD_C_WAVES_MIN, QGD_C_WAVES_MAX)))
-void cellUpdateKernel(const MeshView m, const CaseView c, const GasModel gm) {
-    const int tile = xcdTile((int)gridDim.x);
-    const int ci = tile * QGD_BLOCK + threadIdx.x;
+void cellUpdateKernel(const MeshView m, const CaseView c, const GasModel gm, const int mode,
+                      const int32_t* __restrict__ list, const int nList, const int slotBase) {
+    // mode 0: every cell but the ghosts; mode 1: the cells of `list` (boundary layer of a shard: its records are what the
+    // neighbours wait for); mode 2: ordinary owned cells only (the rest, while the exchange is in flight)
+    const int tile = (mode == 1) ? (int)blockIdx.x : xcdTile((int)gridDim.x);
+    const int idx = tile * QGD_BLOCK + threadIdx.x;
+    int ci = -1;
+    if (mode == 1) { if (idx < nList) ci = list[idx]; }
+    else if (idx < m.nC) {
+        const int role = m.ghost ? m.ghost[idx] : 0;
+        if (role != 1 && !(mode == 2 && role == 2)) ci = idx;
+    }
     double rmin = 1e300, emin = 1e300;
-    if (ci < m.nC) {
+    if (ci >= 0) {
         double sum[5] = {0, 0, 0, 0, 0};
         const int n = m.cfCount[ci];
         const size_t base = (size_t)m.cfSlice[ci >> 6] * 64 + (ci & 63);
@@ -843,10 +852,10 @@ void cellUpdateKernel(const MeshView m, const CaseView c, const GasModel gm) {
         c.A[ci] = An;
         c.B[ci] = Bn;
         c.K[ci] = Kn;
-        if (!(m.ghost && m.ghost[ci])) { rmin = rho; emin = An.e; }
+        rmin = rho; emin = An.e;
     }
     // positivity monitor [QGDFoam_8C L142]: one plain store pair per workgroup, no atomics
-    blockMaxMin(-rmin, emin, c.blkCell + 2 * (size_t)tile, true);
+    blockMaxMin(-rmin, emin, c.blkCell + 2 * (size_t)(slotBase + tile), true);
 }
 
 // createFields.H for the cells [QGDFoam_2createFields_8H L3-109]
@@ -879,13 +888,21 @@ __global__ __launch_bounds__(QGD_BLOCK) void cellInitKernel(const MeshView m, co
 // [QGDUEqn_8H L51, QGDEEqn_8H L50, hePsiQGDThermo_8C L84-121, QGDFoam_8C L155-156]
 __global__ __launch_bounds__(QGD_BLOCK) void boundaryUpdateKernel(const MeshView m, const CaseView c, const GasModel gm,
                                                                  const PatchBCDev* __restrict__ bcs, const int init,
-                                                                 const int phiwRegistered) {
-    const int b = blockIdx.x * QGD_BLOCK + threadIdx.x;
-    if (b >= m.nBF) return;
+                                                                 const int phiwRegistered, const int mode,
+                                                                 const int32_t* __restrict__ list, const int nList) {
+    // modes as in cellUpdateKernel, by the role of the face's owner cell; init evaluates every face
+    const int idx = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    int b;
+    if (mode == 1) { if (idx >= nList) return; b = list[idx]; }
+    else { if (idx >= m.nBF) return; b = idx; }
     const int f = m.nIF + b;
     if (m.fkind[f] == 3) return;
     const PatchBCDev bc = bcs[m.bPatch[b]];
     const int o = m.own[f];
+    if (!init && mode != 1 && m.ghost) {
+        const int role = m.ghost[o];
+        if (role == 1 || (mode == 2 && role == 2)) return;
+    }
     const RecA Ao = c.A[o];
     RecA Ab;
     // U
@@ -1214,13 +1231,19 @@ void launchBoundaryFaceFlux(const Launcher& L, int stencil, const MeshView& m, c
     QGD_TIMED(L, QGD_K_BFACE, (c.dbg && !phiwOnly ? launchBFaceFluxT<true>(L, stencil, m, c, g, bc, phiwOnly, adjustDt)
                                                    : launchBFaceFluxT<false>(L, stencil, m, c, g, bc, phiwOnly, adjustDt)));
 }
-void launchCellUpdate(const Launcher& L, const MeshView& m, const CaseView& c, const GasModel& g) {
-    QGD_TIMED(L, QGD_K_CELL, (cellUpdateKernel<<<gridFor(m.nC), QGD_BLOCK, 0, L.stream>>>(m, c, g)));
+void launchCellUpdate(const Launcher& L, const MeshView& m, const CaseView& c, const GasModel& g, int mode,
+                      const int32_t* list, int nList) {
+    const int n = (mode == 1) ? nList : m.nC;
+    if (n == 0) return;
+    const int slotBase = (mode == 1) ? gridFor(m.nC) : 0;  // the list launch monitors min(rho), min(e) in its own slots
+    QGD_TIMED(L, QGD_K_CELL, (cellUpdateKernel<<<gridFor(n), QGD_BLOCK, 0, L.stream>>>(m, c, g, mode, list, nList, slotBase)));
 }
 void launchBoundaryUpdate(const Launcher& L, const MeshView& m, const CaseView& c, const GasModel& g, const PatchBCDev* bc,
-                          bool init, bool phiwRegistered) {
-    if (m.nBF == 0) return;
-    QGD_TIMED(L, QGD_K_BC, (boundaryUpdateKernel<<<gridFor(m.nBF), QGD_BLOCK, 0, L.stream>>>(m, c, g, bc, init, phiwRegistered)));
+                          bool init, bool phiwRegistered, int mode, const int32_t* list, int nList) {
+    const int n = (mode == 1) ? nList : m.nBF;
+    if (n == 0) return;
+    QGD_TIMED(L, QGD_K_BC, (boundaryUpdateKernel<<<gridFor(n), QGD_BLOCK, 0, L.stream>>>(m, c, g, bc, init, phiwRegistered, mode,
+                                                                                          list, nList)));
 }
 void launchCellInit(const Launcher& L, const MeshView& m, const CaseView& c, const GasModel& g, const double* U, const double* T,
                     const double* p) {

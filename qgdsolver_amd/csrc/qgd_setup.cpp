@@ -377,7 +377,12 @@ StaticData buildStaticData(const HostMesh& m) {
     }
     s.hQGDb.assign((size_t)nBF, 0.0);
     for (int64_t b = 0; b < nBF; ++b) s.hQGDb[b] = s.hf[nIF + b] * 1.0;
+    // cell roles of a shard: 0 = ordinary owned cell, 1 = ghost (refreshed by the halo exchange, never updated here),
+    // 2 = owned cell whose records a neighbour needs (updated first so the exchange can overlap the rest)
     s.ghost = m.cellIsGhost;
+    if (!s.ghost.empty())
+        for (int side = 0; side < 2; ++side)
+            for (int32_t c : m.haloSend[side]) s.ghost[c] = 2;
 
     // ---- halo lists (cells + their real-patch boundary faces, ascending) -----
     for (int side = 0; side < 2; ++side) {

@@ -71,7 +71,7 @@ struct StaticData {
     std::vector<int32_t> cfItem;
     std::vector<double> V;        // nC
     std::vector<double> hQGD;     // nC
-    std::vector<uint8_t> ghost;   // nC (may be empty)
+    std::vector<uint8_t> ghost;   // nC cell role (empty when unsharded): 0 owned, 1 ghost, 2 owned + sent to a neighbour
 
     // ---- boundary faces -----------------------------------------------------
     std::vector<int32_t> bPatch;  // nBF patch index

@@ -56,3 +56,17 @@ class SlabHalo:
         self.case.step_phase(1)
         self.exchange()
         self.case.step_phase(2)
+
+    def step_overlapped(self, torch, compute_stream, halo_stream):
+        """One sharded step with the exchange hidden behind the bulk of the cell update (fixed deltaT):
+        compute stream: assemble, boundary-layer update | remaining cells ............ | next step waits
+        halo stream   :                                 | pack, send/recv, unpack ...  |
+        The case's kernels run on ``compute_stream`` (``case.set_stream``), pack/unpack on ``halo_stream``
+        (``case.set_halo_stream``); torch.distributed orders the RCCL transfer after the halo stream's pack."""
+        self.case.step_phase(0)
+        self.case.step_phase(10)
+        halo_stream.wait_stream(compute_stream)
+        with torch.cuda.stream(halo_stream):
+            self.exchange()
+        self.case.step_phase(11)
+        compute_stream.wait_stream(halo_stream)

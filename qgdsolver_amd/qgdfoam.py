@@ -113,6 +113,9 @@ class QGDFoamCase:
         """Run on a caller-owned hipStream_t (e.g. ``torch.cuda.current_stream().cuda_stream``)."""
         L.check(L.lib.qgd_case_set_stream(self._h, C.c_void_p(raw_stream)), "qgd_case_set_stream")
 
+    def set_halo_stream(self, raw_stream):
+        L.check(L.lib.qgd_case_set_halo_stream(self._h, C.c_void_p(raw_stream)), "qgd_case_set_halo_stream")
+
     def sync(self):
         L.check(L.lib.qgd_case_stream_sync(self._h), "qgd_case_stream_sync")
 

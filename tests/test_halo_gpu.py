@@ -13,7 +13,8 @@ from util import oracle_mesh_of, rel_err
 pytestmark = pytest.mark.gpu
 
 
-def test_two_shards_on_one_device_match_unsharded():
+@pytest.mark.parametrize("split", [False, True])
+def test_two_shards_on_one_device_match_unsharded(split):
     nx, ny, n, steps = 10, 9, 12, 8
     opt = q.default_options(stencil="GaussVolPoint", deltaT=2e-3, mu=1e-3)
     gmesh = q.PolyMesh.box(nx, ny, n)
@@ -54,8 +55,17 @@ def test_two_shards_on_one_device_match_unsharded():
     exchange()
     for _ in range(steps):
         c0.step_phase(0); c1.step_phase(0)
-        c0.step_phase(1); c1.step_phase(1)
-        exchange()
+        if not split:
+            c0.step_phase(1); c1.step_phase(1)
+            exchange()
+        else:
+            # boundary layer first, pack, then the rest of the cells, then unpack: the order the overlapped exchange uses
+            c0.step_phase(10); c1.step_phase(10)
+            c0.halo_pack(1, b01); c1.halo_pack(0, b10)
+            c0.step_phase(11); c1.step_phase(11)
+            c0.sync(); c1.sync()
+            c1.halo_unpack(0, b01); c0.halo_unpack(1, b10)
+            c0.sync(); c1.sync()
     for lo, hi, k_lo, k_hi, mesh, dev, case in shards:
         own = slice(plane * (lo - k_lo), plane * (hi - k_lo))
         for f in ("rho", "U", "p", "e"):
@@ -66,3 +76,17 @@ def test_two_shards_on_one_device_match_unsharded():
         assert info["minRho"] > 0
     shards[0][5].release(b01)
     shards[1][5].release(b10)
+
+
+def test_overlapped_choreography():
+    """compute stream + halo stream with events, as bench.py drives the multi-GPU step (run in a subprocess so that torch
+    initialises the HIP runtime first)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "overlap_worker.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    worst = float([ln for ln in r.stdout.splitlines() if ln.startswith("OVERLAP_WORST")][-1].split()[1])
+    assert worst <= 1e-13
