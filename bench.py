@@ -119,6 +119,7 @@ def main():
     T = 1.0 + noise[n * n * k_lo: n * n * k_hi]
     del noise
     case.set_fields(U, T, p)
+    init_fields = (U, T, p) if world > 1 else None
     del U, T, p, C
     n_if, n_c, n_p = mesh.nInternalFaces, mesh.nCells, mesh.nPoints
     mesh.close()
@@ -158,21 +159,63 @@ def main():
         halo = Staged(case, rank, world, dist, alloc=lambda c: torch.empty(c, dtype=torch.float64), arg=None)
         exchange = halo.exchange
 
-    overlap = (world > 1) and (not staged) and os.environ.get("QGD_BENCH_OVERLAP", "1") != "0"
+    ov = os.environ.get("QGD_BENCH_OVERLAP", "1")
+    overlap = (world > 1) and ov != "0" and (not staged or ov == "force")
+    def plain_step():
+        case.step_phase(0)   # flux assembly
+        case.step_phase(1)   # cell update + boundary refresh (fixed deltaT: no global reduction needed)
+        exchange()           # pack/unpack on the compute stream: strictly after the update, before the next assembly
+
     if overlap:
         halo_stream = torch.cuda.Stream()
-        case.set_halo_stream(halo_stream.cuda_stream)
 
         def step():
             # exchange hidden behind the bulk of the cell update (boundary layer of the shard is updated first)
             halo.step_overlapped(torch, stream, halo_stream)
     else:
-        def step():
-            case.step_phase(0)   # flux assembly
-            case.step_phase(1)   # cell update + boundary refresh (fixed deltaT: no global reduction needed)
-            exchange()
+        step = plain_step
+
+    def owned_checksum():
+        plane = n * n
+        r = case.field("rho")[plane * (lo - k_lo): plane * (hi - k_lo)]
+        t = torch.tensor([float(r.sum()), float((r * r).sum())], dtype=torch.float64, device="cpu" if staged else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return [float(x) for x in t]
 
     exchange()  # ghost cells start from their owners' records
+    selfcheck = None
+    if overlap:
+        # insurance for the overlapped exchange: 3 steps in the plain order and 3 in the overlapped order from the same
+        # state must give the same owned-cell checksums; otherwise fall back to the plain order and say so
+        case.set_halo_stream(stream.cuda_stream)
+        for _ in range(3):
+            plain_step()
+        torch.cuda.synchronize()
+        ref = owned_checksum()
+        case.set_fields(*init_fields)
+        exchange()
+        torch.cuda.synchronize()
+        case.set_halo_stream(halo_stream.cuda_stream)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        got = owned_checksum()
+        selfcheck = max(abs(a - b) / abs(b) for a, b in zip(got, ref))
+        if not selfcheck <= 1e-12:
+            overlap = False
+            step = plain_step
+            case.set_halo_stream(stream.cuda_stream)
+        # restart from the initial state so that runs at every N cover the same steps
+        case.set_fields(*init_fields)
+        torch.cuda.synchronize()
+        if overlap:
+            halo_stream.wait_stream(stream)
+            with torch.cuda.stream(halo_stream):
+                exchange()
+            stream.wait_stream(halo_stream)
+        else:
+            exchange()
+    init_fields = None
     for _ in range(args.warmup):
         step()
     case.timing(True)
@@ -254,6 +297,8 @@ def main():
         }
         if checksum is not None:
             out["checksum_rho"] = checksum
+        if selfcheck is not None:
+            out["overlap_selfcheck_rel"] = selfcheck
         traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(traffic_file):
             try:
