@@ -148,6 +148,10 @@ int qgd_mesh_jitter(qgd_mesh_t m, double amplitude, uint64_t seed);
  * (cells stay closed polyhedra): exercises the triangle branch
  * [GaussVolPointBase3D_8C_source.html L161-318]. */
 int qgd_mesh_split_quads(qgd_mesh_t m, int32_t stride);
+/* Insert a mid-edge vertex on edge 0 of every `stride`-th internal quad; every face sharing that edge gains the vertex
+ * (pentagons, hexagons): exercises the "other faces" fallback to nf*snGrad
+ * [GaussVolPointBase3D_8C_source.html L759-768].  Test helper. */
+int qgd_mesh_split_edges(qgd_mesh_t m, int32_t stride);
 
 int qgd_mesh_set_geometry(qgd_mesh_t m, const double* Sf, const double* Cf,
                           const double* C, const double* V);

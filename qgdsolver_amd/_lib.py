@@ -48,6 +48,7 @@ SIGNATURES = {
     "qgd_mesh_forward_step": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, handle_p]),
     "qgd_mesh_jitter": (C.c_int, [handle, C.c_double, C.c_uint64]),
     "qgd_mesh_split_quads": (C.c_int, [handle, C.c_int32]),
+    "qgd_mesh_split_edges": (C.c_int, [handle, C.c_int32]),
     "qgd_mesh_set_geometry": (C.c_int, [handle, c_double_p, c_double_p, c_double_p, c_double_p]),
     "qgd_mesh_free": (C.c_int, [handle]),
     "qgd_mesh_sizes": (C.c_int, [handle, c_int64_p]),

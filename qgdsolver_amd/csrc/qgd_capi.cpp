@@ -275,6 +275,13 @@ int qgd_mesh_split_quads(qgd_mesh_t m, int32_t stride) {
     return QGD_OK;
     QGD_CATCH
 }
+int qgd_mesh_split_edges(qgd_mesh_t m, int32_t stride) {
+    QGD_TRY
+    if (!m) return fail(QGD_ERR_INVALID, "null mesh");
+    splitEdges(m->m, stride);
+    return QGD_OK;
+    QGD_CATCH
+}
 int qgd_mesh_set_geometry(qgd_mesh_t mh, const double* Sf, const double* Cf, const double* C, const double* V) {
     QGD_TRY
     if (!mh || !Sf || !Cf || !C || !V) return fail(QGD_ERR_INVALID, "qgd_mesh_set_geometry: null argument");

@@ -717,7 +717,14 @@ void pointInterpRecKernel(const MeshView m, const RecA* __restrict__ A, RecA* __
 __global__ __launch_bounds__(QGD_BLOCK) void commitMidStepPressureKernel(const MeshView m, const CaseView c) {
     const int b = blockIdx.x * QGD_BLOCK + threadIdx.x;
     if (b >= m.nBF) return;
-    c.bA[b].p = c.bPmid[b];
+    if (m.fkind[m.nIF + b] == 3) return;
+    RecA a = c.bA[b];
+    if (a.p == c.bPmid[b]) return;
+    a.p = c.bPmid[b];
+    c.bA[b] = a;
+    // H = (rhoE + p)/rho is re-formed by the next updateFields.H from this patch pressure [QGDFoam/updateFields.H L71]
+    const double rE = c.bRhoLag[b] * (a.e + 0.5 * (a.ux * a.ux + a.uy * a.uy + a.uz * a.uz));
+    c.bB[b].H = (rE + a.p) / a.rho;
 }
 
 // patch points: weighted mean of the surrounding boundary-face values.  Source

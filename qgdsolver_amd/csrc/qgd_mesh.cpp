@@ -543,4 +543,49 @@ void splitQuads(HostMesh& m, int32_t stride) {
     m.computeGeometry();
 }
 
+void splitEdges(HostMesh& m, int32_t stride) {
+    if (stride < 1) return;
+    // pick edges: edge (v0,v1) of every stride-th internal quad, unless one of its vertices already lies on a picked edge
+    std::vector<std::pair<int32_t, int32_t>> edges;
+    std::vector<uint8_t> used((size_t)m.nPoints, 0);
+    int32_t count = 0;
+    for (int32_t f = 0; f < m.nInternalFaces; ++f) {
+        if (m.faceSize(f) != 4) continue;
+        if ((count++ % stride) != 0) continue;
+        const int32_t a = m.facePoints[m.faceOffsets[f]], b = m.facePoints[m.faceOffsets[f] + 1];
+        if (used[a] || used[b]) continue;
+        used[a] = used[b] = 1;
+        edges.push_back({std::min(a, b), std::max(a, b)});
+    }
+    std::sort(edges.begin(), edges.end());
+    std::vector<int32_t> mid(edges.size());
+    for (size_t e = 0; e < edges.size(); ++e) {
+        mid[e] = m.nPoints++;
+        for (int k = 0; k < 3; ++k)
+            m.points.push_back(0.5 * (m.points[3 * (size_t)edges[e].first + k] + m.points[3 * (size_t)edges[e].second + k]));
+    }
+    auto midOf = [&](int32_t a, int32_t b) -> int32_t {
+        const std::pair<int32_t, int32_t> key{std::min(a, b), std::max(a, b)};
+        auto it = std::lower_bound(edges.begin(), edges.end(), key);
+        return (it != edges.end() && *it == key) ? mid[it - edges.begin()] : -1;
+    };
+    std::vector<int32_t> newOff(1, 0), newPts;
+    for (int32_t f = 0; f < m.nFaces; ++f) {
+        const int n = m.faceSize(f);
+        const int32_t* fp = &m.facePoints[m.faceOffsets[f]];
+        // faces of empty patches stay quads (the 2-D stencils assume them)
+        const int32_t pi = m.patchOfFace(f);
+        const bool frozen = pi >= 0 && m.patches[pi].type == QGD_PATCH_EMPTY;
+        for (int q = 0; q < n; ++q) {
+            newPts.push_back(fp[q]);
+            const int32_t mm = frozen ? -1 : midOf(fp[q], fp[(q + 1) % n]);
+            if (mm >= 0) newPts.push_back(mm);
+        }
+        newOff.push_back((int32_t)newPts.size());
+    }
+    m.faceOffsets.swap(newOff);
+    m.facePoints.swap(newPts);
+    m.computeGeometry();
+}
+
 }  // namespace qgd

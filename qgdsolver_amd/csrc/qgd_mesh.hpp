@@ -84,5 +84,6 @@ HostMesh makeForwardStep(int32_t nx, int32_t ny, int32_t ixStep, int32_t iyStep,
                          double lx, double ly, double lz);
 void jitterPoints(HostMesh& m, double amplitude, uint64_t seed);
 void splitQuads(HostMesh& m, int32_t stride);
+void splitEdges(HostMesh& m, int32_t stride);
 
 }  // namespace qgd

@@ -91,6 +91,11 @@ class PolyMesh:
         self.__init__(self._h)
         return self
 
+    def split_edges(self, stride):
+        L.check(L.lib.qgd_mesh_split_edges(self._h, int(stride)), "qgd_mesh_split_edges")
+        self.__init__(self._h)
+        return self
+
     def close(self):
         if self._h:
             L.lib.qgd_mesh_free(self._h)

@@ -26,6 +26,7 @@ GOLDEN = {
     "box654_tri_gvp": ("box654_tri", "GaussVolPoint", None, "box", dict(deltaT=1e-3), 10),
     "step2d_lsq_qgdflux": ("step2d", "leastSquares", "forward_step", "step", dict(deltaT=5e-4), 10),
     "step2d_gvp_qgdflux": ("step2d", "GaussVolPoint", "forward_step", "step", dict(deltaT=5e-4), 10),
+    "box654_poly_gvp_mixed": ("box654_poly", "GaussVolPoint", "mixed_box", "box", dict(deltaT=5e-4, mu=1e-3), 10),
     "plane2d_reduced": ("plane2d", "reduced", "empty_z", "plane", dict(deltaT=1e-3, mu=1e-3), 10),
 }
 FLUX_FIELDS = ["phiJm", "phiJmU", "phiP", "phiPi", "phiJmH", "phiQ", "phiPiU", "phiwStar", "tauQGDf"]
@@ -47,6 +48,13 @@ def init_fields(name, C):
 def apply_bcs(name, case):
     if name == "forward_step":
         cases.forward_step_bcs(case)
+    elif name == "mixed_box":
+        case.set_bc(0, U=("fixedValue", (0.3, 0.0, 0.0)), T=("fixedValue", 1.0), p=("zeroGradient", None))
+        case.set_bc(1, U=("zeroGradient", None), T=("zeroGradient", None), p=("fixedValue", 1.0))
+        case.set_bc(2, U=("slip", None), T=("zeroGradient", None), p=("qgdFlux", None))
+        case.set_bc(3, U=("slip", None), T=("fixedValue", 1.05), p=("qgdFlux", None))
+        case.set_bc(4, U=("fixedValue", (0.0, 0.0, 0.0)), T=("zeroGradient", None), p=("zeroGradient", None))
+        case.set_bc(5, U=("slip", None), T=("zeroGradient", None), p=("zeroGradient", None))
     elif name == "empty_z":
         for patch in (4, 5):
             case.set_bc(patch, U=("none", None), T=("none", None), p=("none", None))

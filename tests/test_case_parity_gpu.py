@@ -84,6 +84,8 @@ CASES = [
     ("box654", "reduced", None, None, dict(deltaT=2e-3, mu=1e-3)),
     ("box654_jitter", "GaussVolPoint", None, None, dict(deltaT=1e-3, mu=1e-3)),
     ("box654_tri", "GaussVolPoint", None, None, dict(deltaT=1e-3)),
+    ("box654_poly", "GaussVolPoint", None, None, dict(deltaT=1e-3, mu=1e-3)),
+    ("box654_poly", "GaussVolPoint", mixed_box_bcs, None, dict(deltaT=5e-4, mu=1e-3)),
     ("box654", "GaussVolPoint", mixed_box_bcs, None, dict(deltaT=1e-3, mu=2e-3, Pr=0.7, ScQGD=0.8, PrQGD=0.9, alphaQGD=0.4)),
     ("box654_jitter", "GaussVolPoint", mixed_box_bcs, None, dict(deltaT=5e-4, mu=2e-3)),
     ("plane2d", "GaussVolPoint", empty_z_bcs, plane_init, dict(deltaT=1e-3)),

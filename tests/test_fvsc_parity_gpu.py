@@ -21,6 +21,7 @@ MESH_SCHEMES = [
     ("box654", "reduced"), ("box654", "GaussVolPoint"),
     ("box654_jitter", "reduced"), ("box654_jitter", "GaussVolPoint"),
     ("box654_tri", "GaussVolPoint"), ("box654_tri", "reduced"),
+    ("box654_poly", "GaussVolPoint"), ("box654_poly", "reduced"),
     ("plane2d", "GaussVolPoint"), ("plane2d", "leastSquares"), ("plane2d", "leastSquaresOpt"), ("plane2d", "reduced"),
     ("plane2d_jitter", "GaussVolPoint"), ("plane2d_jitter", "leastSquares"),
     ("plane2d_y", "GaussVolPoint"), ("plane2d_y", "leastSquares"),

@@ -68,6 +68,21 @@ def test_gaussvolpoint_1d_equals_reduced():
         assert np.array_equal(a, b), op
 
 
+def test_gaussvolpoint_polygon_faces_fall_back_to_reduced():
+    """Property 2, second half [GaussVolPointBase3D.C:759-768, 808-817]: faces with more than 4 vertices take nf*snGrad"""
+    mesh = make_mesh("box654_poly"); om = oracle_mesh_of(mesh)
+    sizes = np.diff(mesh.array("faceOffsets"))
+    poly = np.where(sizes > 4)[0]
+    assert len(poly) > 50 and (poly >= mesh.nInternalFaces).any() and (poly < mesh.nInternalFaces).any()
+    for op, nc in (("grad_s", 1), ("grad_v", 3), ("div_v", 3), ("div_t", 9)):
+        cell, bnd = cases.random_fields(mesh.nCells, mesh.nBoundaryFaces, nc, 11)
+        a = om.fvsc("GaussVolPoint", op, cell, bnd)[1]
+        b = om.fvsc("reduced", op, cell, bnd)[1]
+        assert np.array_equal(a[poly], b[poly]), op
+        quad = np.where(sizes[:mesh.nInternalFaces] == 4)[0]
+        assert not np.array_equal(a[quad], b[quad])
+
+
 @pytest.mark.parametrize("kind,scheme", [("plane2d", "leastSquares"), ("plane2d", "GaussVolPoint"), ("plane2d_y", "leastSquares"),
                                          ("plane2d_y", "GaussVolPoint")])
 def test_linear_field_exact_2d(kind, scheme):

@@ -11,7 +11,7 @@ from util import make_mesh, oracle_mesh_of, rel_err
 
 pytestmark = pytest.mark.gpu
 
-CASES = [("box654_jitter", "GaussVolPoint"), ("box654_tri", "GaussVolPoint"), ("box654", "reduced"),
+CASES = [("box654_jitter", "GaussVolPoint"), ("box654_tri", "GaussVolPoint"), ("box654_poly", "GaussVolPoint"), ("box654", "reduced"),
          ("plane2d_jitter", "leastSquares"), ("plane2d", "GaussVolPoint"), ("step2d", "leastSquares"), ("line1d", "GaussVolPoint")]
 
 

@@ -24,6 +24,8 @@ def make_mesh(kind):
         return q.PolyMesh.box(6, 5, 4).jitter(0.15, seed=2024)
     if kind == "box654_tri":
         return q.PolyMesh.box(6, 5, 4).jitter(0.1, seed=7).split_quads(3)
+    if kind == "box654_poly":  # pentagon / hexagon faces (mid-edge vertices) + triangles + jitter
+        return q.PolyMesh.box(6, 5, 4).jitter(0.1, seed=3).split_quads(5).split_edges(4)
     if kind == "plane2d":  # 8 x 7 x 1, z empty
         return q.PolyMesh.box(8, 7, 1, hi=(1.0, 0.875, 0.1), patch_types=[G, G, G, G, E, E])
     if kind == "plane2d_jitter":
