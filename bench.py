@@ -43,14 +43,15 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = debugging aid: all ranks share GPU 0 and halo messages are staged through host memory")
     ap.add_argument("--check", action="store_true", help="print a checksum of the owned cells (to compare runs at different N)")
-    ap.add_argument("--cpu-n", type=int, default=96, help="edge of the CPU-baseline sample box")
-    ap.add_argument("--cpu-steps", type=int, default=12)
+    ap.add_argument("--cpu-n", type=int, default=64, help="edge of each CPU-baseline rank's sample box")
+    ap.add_argument("--cpu-steps", type=int, default=24)
+    ap.add_argument("--cpu-ranks", type=int, default=0, help="CPU-baseline ranks (0 = one per physical core, at most 128)")
     return ap.parse_args()
 
 
-def cpu_baseline(n, steps):
-    """The CPU oracle (a restatement of the reference listings: the reference itself cannot be built here) timed on
-    one host core on a bounded sample of the same workload."""
+def _cpu_rank_worker(n, steps, sync_dir, idx):
+    """One single-threaded "rank" of the CPU baseline (child process started by cpu_baseline): the oracle on its own
+    n^3 box.  Ranks start their timed region together through a ready/go file handshake."""
     import qgdsolver_amd as q
     import cases
     from oracle import OracleCase, OracleMesh
@@ -63,11 +64,49 @@ def cpu_baseline(n, steps):
     U, T, p = cases.box_initial_fields(mesh.array("C").reshape(-1, 3))
     oc.set_fields(U, T, p)
     oc.step(1)
+    open(os.path.join(sync_dir, f"ready{idx}"), "w").close()
+    go = os.path.join(sync_dir, "go")
+    t_wait = time.time()
+    while not os.path.exists(go):
+        if time.time() - t_wait > 300:
+            sys.exit(3)
+        time.sleep(0.005)
     t0 = time.perf_counter()
     oc.step(steps)
-    dt = time.perf_counter() - t0
-    return {"value": n ** 3 * steps / dt / 1e6, "unit": "Mcell-steps/s", "cores": 1, "kind": "port",
-            "sample": f"{n}^3-cell box, {steps} steps, single-threaded oracle (field-at-a-time restatement)"}
+    print(f"CPU_RANK_SECONDS {time.perf_counter() - t0:.6f}", flush=True)
+
+
+def cpu_baseline(n, steps, ranks):
+    """The CPU oracle (a restatement of the reference listings: the reference itself cannot be built here) timed on
+    the host cores the way the reference would run: R single-threaded ranks, one per core, each with its own slab of
+    the box (n^3 cells per rank, no halo traffic -- an upper bound for an MPI run), on a bounded sample.  The ranks
+    are child processes (this process has initialised the GPU and must not fork workers)."""
+    import subprocess
+    import tempfile
+
+    env = dict(os.environ, OMP_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    with tempfile.TemporaryDirectory() as sync_dir:
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-rank-worker", str(n), str(steps), sync_dir, str(i)],
+                                  stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env) for i in range(ranks)]
+        t_wait = time.time()
+        while sum(os.path.exists(os.path.join(sync_dir, f"ready{i}")) for i in range(ranks)) < ranks:
+            if any(pr.poll() not in (None, 0) for pr in procs) or time.time() - t_wait > 280:
+                for pr in procs:
+                    pr.kill()
+                return {"value": None, "unit": "Mcell-steps/s", "cores": ranks, "kind": "port", "sample": "CPU baseline ranks failed to start"}
+            time.sleep(0.05)
+        open(os.path.join(sync_dir, "go"), "w").close()
+        times = []
+        for pr in procs:
+            out, _ = pr.communicate(timeout=900)
+            times += [float(line.split()[1]) for line in out.splitlines() if line.startswith("CPU_RANK_SECONDS")]
+    if len(times) != ranks:
+        return {"value": None, "unit": "Mcell-steps/s", "cores": ranks, "kind": "port", "sample": "CPU baseline ranks failed"}
+    dt = max(times)
+    return {"value": ranks * n ** 3 * steps / dt / 1e6, "unit": "Mcell-steps/s", "cores": ranks, "kind": "port",
+            "sample": f"{ranks} single-threaded oracle ranks x {n}^3-cell box x {steps} steps (field-at-a-time restatement "
+                      f"of the reference listings, no halo exchange; slowest rank {dt:.1f} s)",
+            "single_rank_value": n ** 3 * steps / min(times) / 1e6}
 
 
 def main():
@@ -310,7 +349,13 @@ def main():
             except Exception:
                 pass
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_n, args.cpu_steps)
+            ranks = args.cpu_ranks or max(1, min(128, (os.cpu_count() or 2) // 2))
+            try:  # each rank holds about 5.2 kB per cell of oracle fields: stay within half of the free host memory
+                avail = [int(l.split()[1]) * 1024 for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0]
+                ranks = max(1, min(ranks, int(0.5 * avail / (5200.0 * args.cpu_n ** 3))))
+            except (OSError, IndexError, ValueError):
+                pass
+            out["cpu_baseline"] = cpu_baseline(args.cpu_n, args.cpu_steps, ranks)
         print(json.dumps(out), flush=True)
     case.close()
     dev.close()
@@ -319,4 +364,7 @@ def main():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) == 6 and sys.argv[1] == "--cpu-rank-worker":
+        _cpu_rank_worker(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], int(sys.argv[5]))
+        sys.exit(0)
     main()
