@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--check", action="store_true", help="print a checksum of the owned cells (to compare runs at different N)")
     ap.add_argument("--cpu-n", type=int, default=64, help="edge of each CPU-baseline rank's sample box")
     ap.add_argument("--cpu-steps", type=int, default=24)
+    ap.add_argument("--cpu-only", action="store_true", help="only time the CPU baseline (no GPU needed) and print it")
     ap.add_argument("--cpu-ranks", type=int, default=0, help="CPU-baseline ranks (0 = one per physical core, at most 128)")
     return ap.parse_args()
 
@@ -74,6 +75,36 @@ def _cpu_rank_worker(n, steps, sync_dir, idx):
     t0 = time.perf_counter()
     oc.step(steps)
     print(f"CPU_RANK_SECONDS {time.perf_counter() - t0:.6f}", flush=True)
+
+
+def cpu_rank_budget(n):
+    """How many single-threaded ranks the host really gives this process: physical cores, clipped by the scheduler
+    affinity, the cgroup CPU quota (the GPU boxes expose 256 hardware threads but a 16-CPU quota) and half of the free
+    memory (a rank holds about 5.2 kB of oracle fields per cell)."""
+    cores = max(1, (os.cpu_count() or 2) // 2)
+    try:
+        cores = min(cores, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            words = open(path).read().split()
+            quota = float(words[0])
+            period = float(words[1]) if len(words) > 1 else float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                cores = min(cores, max(1, int(quota / period)))
+        except (OSError, ValueError, IndexError):
+            pass
+    try:
+        avail = [int(l.split()[1]) * 1024 for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0]
+        try:
+            avail = min(avail, int(open("/sys/fs/cgroup/memory.max").read()) - int(open("/sys/fs/cgroup/memory.current").read()))
+        except (OSError, ValueError):
+            pass
+        cores = min(cores, int(0.5 * avail / (5200.0 * n ** 3)))
+    except (OSError, IndexError, ValueError):
+        pass
+    return max(1, min(128, cores))
 
 
 def cpu_baseline(n, steps, ranks):
@@ -119,6 +150,10 @@ def main():
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
         if world == 1 and args.gpus > 1:
             sys.exit(2)
+
+    if args.cpu_only:
+        print(json.dumps(cpu_baseline(args.cpu_n, args.cpu_steps, args.cpu_ranks or cpu_rank_budget(args.cpu_n))))
+        return
 
     import torch
     import torch.distributed as dist
@@ -349,12 +384,7 @@ def main():
             except Exception:
                 pass
         if world == 1 and not args.no_cpu_baseline:
-            ranks = args.cpu_ranks or max(1, min(128, (os.cpu_count() or 2) // 2))
-            try:  # each rank holds about 5.2 kB per cell of oracle fields: stay within half of the free host memory
-                avail = [int(l.split()[1]) * 1024 for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0]
-                ranks = max(1, min(ranks, int(0.5 * avail / (5200.0 * args.cpu_n ** 3))))
-            except (OSError, IndexError, ValueError):
-                pass
+            ranks = args.cpu_ranks or cpu_rank_budget(args.cpu_n)
             out["cpu_baseline"] = cpu_baseline(args.cpu_n, args.cpu_steps, ranks)
         print(json.dumps(out), flush=True)
     case.close()
