@@ -13,6 +13,7 @@ from .fvsc import Device, fvscStencil, volField  # noqa: F401
 from . import fvsc  # noqa: F401
 from .qgdfoam import QGDFoamCase, QGDThermo, default_options  # noqa: F401
 from . import qhdfoam  # noqa: F401
+from . import foamfile  # noqa: F401
 
 
 def device_count():

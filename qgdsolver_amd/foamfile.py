@@ -1,0 +1,546 @@
+"""OpenFOAM ASCII case files <-> the flat arrays of the C-ABI.
+
+Readers and writers for ``constant/polyMesh/{points,faces,owner,neighbour,boundary}``,
+``vol{Scalar,Vector}Field`` files of a time directory, and the handful of dictionary
+entries QGDFoam reads (QGDFoam/createFields.H, thermophysicalProperties, fvSchemes
+``fvsc`` [fvsc.C L47-58], controlDict), so that a case prepared for the reference
+solver can be loaded into a ``QGDFoamCase`` and its result written back.
+
+Only the ASCII stream format is handled (``format binary`` is refused loudly).
+The file grammar is OpenFOAM's (L0: OpenFOAM itself is not part of the reference
+tree); nothing in here is on the timed path.
+"""
+import os
+import re
+
+import numpy as np
+
+from . import _lib as L
+from .mesh import PolyMesh
+
+# OpenFOAM v2312 universal gas constant [J/(kmol K)] (L0 assumption: 1000 * physicoChemical::R)
+RR = 8314.46261815324
+
+PATCH_TYPES = {
+    "patch": L.PATCH_GENERIC, "wall": L.PATCH_GENERIC, "empty": L.PATCH_EMPTY, "symmetryPlane": L.PATCH_SYMMETRYPLANE,
+    "symmetry": L.PATCH_SYMMETRY, "wedge": L.PATCH_WEDGE, "cyclic": L.PATCH_CYCLIC,
+}
+PATCH_WORDS = {L.PATCH_GENERIC: "patch", L.PATCH_EMPTY: "empty", L.PATCH_SYMMETRYPLANE: "symmetryPlane",
+               L.PATCH_SYMMETRY: "symmetry", L.PATCH_WEDGE: "wedge", L.PATCH_CYCLIC: "cyclic"}
+_CONSTRAINT_BCS = {"empty", "symmetryPlane", "symmetry", "wedge", "cyclic"}
+
+
+class FoamFileError(ValueError):
+    pass
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# tokenizer / dictionary parser
+# ---------------------------------------------------------------------------------------------------------------------
+_COMMENT = re.compile(r"//[^\n]*|/\*.*?\*/", re.S)
+_TOKEN = re.compile(r'"(?:[^"\\]|\\.)*"|[{}()\[\];]|[^\s{}()\[\];"]+')
+_LIST_HEAD = re.compile(r"(?:List<\s*(\w+)\s*>\s*)?(\d+)\s*\(")
+
+
+def _strip_comments(text):
+    return _COMMENT.sub(" ", text)
+
+
+def _number(tok):
+    try:
+        return int(tok)
+    except ValueError:
+        try:
+            return float(tok)
+        except ValueError:
+            return tok
+
+
+class _Parser:
+    def __init__(self, text, lists):
+        self.toks = _TOKEN.findall(text)
+        self.i = 0
+        self.lists = lists
+
+    def peek(self):
+        return self.toks[self.i] if self.i < len(self.toks) else None
+
+    def next(self):
+        t = self.peek()
+        if t is None:
+            raise FoamFileError("unexpected end of file")
+        self.i += 1
+        return t
+
+    def parse_dict_body(self, top=False):
+        d = {}
+        while True:
+            t = self.peek()
+            if t is None:
+                if top:
+                    return d
+                raise FoamFileError("missing '}'")
+            if t == "}":
+                if top:
+                    raise FoamFileError("unbalanced '}'")
+                self.i += 1
+                return d
+            key = self.next()
+            if key == ";":
+                continue
+            if key.startswith('"'):
+                key = key[1:-1]
+            if self.peek() == "{":
+                self.i += 1
+                d[key] = self.parse_dict_body()
+                continue
+            vals = []
+            while self.peek() != ";":
+                if self.peek() is None or self.peek() == "}":
+                    raise FoamFileError(f"entry '{key}' is not terminated by ';'")
+                vals.append(self.parse_value())
+            self.i += 1
+            d[key] = vals[0] if len(vals) == 1 else vals
+        return d
+
+    def parse_value(self):
+        t = self.next()
+        if t == "(":
+            return self.parse_list()
+        if t == "[":
+            out = []
+            while self.peek() != "]":
+                out.append(_number(self.next()))
+            self.i += 1
+            return ("dimensions", out)
+        if t == "{":
+            return self.parse_dict_body()
+        if t.startswith("@LIST"):
+            return self.lists[int(t[5:])]
+        if t.startswith('"'):
+            return t[1:-1]
+        # "N(" and "List<T> N (" prefixes of short in-line lists
+        if re.fullmatch(r"\d+", t) and self.peek() == "(":
+            self.i += 1
+            return self.parse_list()
+        if re.fullmatch(r"List<\w+>", t):
+            return self.parse_value()
+        return _number(t)
+
+    def parse_list(self):
+        out = []
+        while self.peek() != ")":
+            if self.peek() is None:
+                raise FoamFileError("missing ')'")
+            out.append(self.parse_value())
+        self.i += 1
+        return out
+
+
+def _extract_big_lists(text, min_items=64):
+    """Replace long numeric lists ``N ( ... )`` by @LISTk placeholders, parsed with numpy."""
+    lists = []
+    out = []
+    pos = 0
+    for m in _LIST_HEAD.finditer(text):
+        if m.start() < pos:
+            continue
+        n = int(m.group(2))
+        if n < min_items:
+            continue
+        start = m.end()
+        # depth of the items: scalar list "1 2 3", or nested "(x y z)" / "4(a b c d)"
+        k = start
+        while k < len(text) and text[k].isspace():
+            k += 1
+        nested = k < len(text) and (text[k] == "(" or re.match(r"\d+\s*\(", text[k:k + 24]) is not None)
+        if nested:
+            e = re.compile(r"\)\s*\)").search(text, start)
+            if e is None:
+                raise FoamFileError("unterminated list")
+            end = e.end() - 1
+        else:
+            end = text.find(")", start)
+            if end < 0:
+                raise FoamFileError("unterminated list")
+        body = text[start:end]
+        ragged = nested and text[k] != "("
+        flat = np.array(body.replace("(", " ").replace(")", " ").split(), dtype=np.float64)
+        if ragged:
+            lists.append(("ragged", n, flat))
+        elif nested:
+            if flat.size % n:
+                raise FoamFileError("list length does not match its header")
+            lists.append(flat.reshape(n, flat.size // n))
+        else:
+            if flat.size != n:
+                raise FoamFileError(f"list of {flat.size} items announced as {n}")
+            lists.append(flat)
+        out.append(text[pos:m.start()])
+        out.append(f" @LIST{len(lists) - 1} ")
+        pos = end + 1
+    out.append(text[pos:])
+    return "".join(out), lists
+
+
+def parse_foam_text(text):
+    """Parse an OpenFOAM dictionary-style file into nested dicts (lists -> python lists / numpy arrays)."""
+    text = _strip_comments(text)
+    text, lists = _extract_big_lists(text)
+    p = _Parser(text, lists)
+    d = p.parse_dict_body(top=True)
+    hdr = d.get("FoamFile", {})
+    if isinstance(hdr, dict) and str(hdr.get("format", "ascii")) != "ascii":
+        raise FoamFileError("only 'format ascii' files are supported")
+    return d
+
+
+def read_dict(path):
+    with open(path) as f:
+        return parse_foam_text(f.read())
+
+
+def _split_header(text):
+    """(FoamFile dict, rest of the text) of a list-style file (points, faces, owner, ...)"""
+    text = _strip_comments(text)
+    m = re.search(r"FoamFile\s*\{", text)
+    hdr = {}
+    if m:
+        end = text.index("}", m.end())
+        hdr = _Parser(text[m.end():end], []).parse_dict_body(top=True)
+        text = text[end + 1:]
+    if str(hdr.get("format", "ascii")) != "ascii":
+        raise FoamFileError("only 'format ascii' files are supported")
+    return hdr, text
+
+
+def _read_list_file(path):
+    with open(path) as f:
+        hdr, text = _split_header(f.read())
+    m = _LIST_HEAD.search(text)
+    if m is None:
+        raise FoamFileError(f"{path}: no list found")
+    n = int(m.group(2))
+    body = text[m.end():text.rindex(")")]
+    flat = np.array(body.replace("(", " ").replace(")", " ").split(), dtype=np.float64)
+    return hdr, n, flat
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# polyMesh
+# ---------------------------------------------------------------------------------------------------------------------
+def read_polymesh(poly_dir):
+    """constant/polyMesh -> PolyMesh (with ``patch_names``).  processor patches are refused: a decomposed case is
+    loaded whole and sharded by cell ranges instead (multi-GPU)."""
+    _, npnt, flat = _read_list_file(os.path.join(poly_dir, "points"))
+    if flat.size != 3 * npnt:
+        raise FoamFileError("points: size mismatch")
+    points = flat
+    _, nf, flat = _read_list_file(os.path.join(poly_dir, "faces"))
+    ints = flat.astype(np.int64)
+    if ints.size == 5 * nf and np.all(ints[0::5] == 4):
+        sizes = np.full(nf, 4, dtype=np.int64)
+        fp = ints.reshape(nf, 5)[:, 1:].reshape(-1)
+    else:
+        sizes = np.empty(nf, dtype=np.int64)
+        keep = np.ones(ints.size, dtype=bool)
+        k = 0
+        for f in range(nf):
+            s = ints[k]
+            sizes[f] = s
+            keep[k] = False
+            k += s + 1
+        if k != ints.size:
+            raise FoamFileError("faces: size mismatch")
+        fp = ints[keep]
+    fo = np.zeros(nf + 1, dtype=np.int64)
+    np.cumsum(sizes, out=fo[1:])
+    hdr_o, no, owner = _read_list_file(os.path.join(poly_dir, "owner"))
+    _, nn, neighbour = _read_list_file(os.path.join(poly_dir, "neighbour"))
+    if no != nf or owner.size != nf or neighbour.size != nn:
+        raise FoamFileError("owner/neighbour: size mismatch")
+    owner = owner.astype(np.int32)
+    neighbour = neighbour.astype(np.int32)
+    n_cells = int(owner.max()) + 1 if nf else 0
+    note = str(hdr_o.get("note", ""))
+    m = re.search(r"nCells:\s*(\d+)", note)
+    if m:
+        n_cells = int(m.group(1))
+
+    with open(os.path.join(poly_dir, "boundary")) as f:
+        _, text = _split_header(f.read())
+    m = re.search(r"(\d+)\s*\(", text)
+    if m is None:
+        raise FoamFileError("boundary: no patch list")
+    body = text[m.end():text.rindex(")")]
+    pd = _Parser(body, []).parse_dict_body(top=True)
+    if len(pd) != int(m.group(1)):
+        raise FoamFileError("boundary: patch count mismatch")
+    names, start, size, ptype = [], [], [], []
+    for name, e in pd.items():
+        t = str(e.get("type", "patch"))
+        if t not in PATCH_TYPES:
+            raise FoamFileError(f"boundary: patch '{name}' of type '{t}' is not supported")
+        names.append(name)
+        start.append(int(e["startFace"]))
+        size.append(int(e["nFaces"]))
+        ptype.append(PATCH_TYPES[t])
+    mesh = PolyMesh.from_arrays(points, fo, fp, owner, neighbour, n_cells, start, size, ptype)
+    mesh.patch_names = names
+    return mesh
+
+
+def _header(cls, obj, location, note=None):
+    lines = ["FoamFile", "{", "    version     2.0;", "    format      ascii;", f"    class       {cls};"]
+    if note:
+        lines.append(f'    note        "{note}";')
+    lines += [f'    location    "{location}";', f"    object      {obj};", "}", ""]
+    return "\n".join(lines) + "\n"
+
+
+def _fmt(x):
+    return repr(float(x))
+
+
+def write_polymesh(mesh, poly_dir, patch_names=None):
+    """PolyMesh -> constant/polyMesh (ASCII, full-precision reals so a round trip is bit-exact)."""
+    os.makedirs(poly_dir, exist_ok=True)
+    names = patch_names or getattr(mesh, "patch_names", None) or [f"patch{i}" for i in range(mesh.nPatches)]
+    pts = mesh.array("points").reshape(-1, 3)
+    fo = mesh.array("faceOffsets")
+    fp = mesh.array("facePoints")
+    owner = mesh.array("owner")
+    neighbour = mesh.array("neighbour")
+    note = f"nPoints:{mesh.nPoints}  nCells:{mesh.nCells}  nFaces:{mesh.nFaces}  nInternalFaces:{mesh.nInternalFaces}"
+    with open(os.path.join(poly_dir, "points"), "w") as f:
+        f.write(_header("vectorField", "points", "constant/polyMesh"))
+        f.write(f"{mesh.nPoints}\n(\n")
+        f.write("\n".join(f"({_fmt(p[0])} {_fmt(p[1])} {_fmt(p[2])})" for p in pts))
+        f.write("\n)\n")
+    with open(os.path.join(poly_dir, "faces"), "w") as f:
+        f.write(_header("faceList", "faces", "constant/polyMesh"))
+        f.write(f"{mesh.nFaces}\n(\n")
+        f.write("\n".join(f"{fo[i + 1] - fo[i]}({' '.join(map(str, fp[fo[i]:fo[i + 1]]))})" for i in range(mesh.nFaces)))
+        f.write("\n)\n")
+    for name, arr in (("owner", owner), ("neighbour", neighbour)):
+        with open(os.path.join(poly_dir, name), "w") as f:
+            f.write(_header("labelList", name, "constant/polyMesh", note))
+            f.write(f"{arr.size}\n(\n")
+            f.write("\n".join(map(str, arr)))
+            f.write("\n)\n")
+    ps, pz, pt = mesh.array("patchStart"), mesh.array("patchSize"), mesh.array("patchType")
+    with open(os.path.join(poly_dir, "boundary"), "w") as f:
+        f.write(_header("polyBoundaryMesh", "boundary", "constant/polyMesh"))
+        f.write(f"{mesh.nPatches}\n(\n")
+        for i in range(mesh.nPatches):
+            if int(pt[i]) not in PATCH_WORDS:
+                raise FoamFileError("halo (cell-range shard) patches have no polyMesh spelling")
+            f.write(f"    {names[i]}\n    {{\n        type            {PATCH_WORDS[int(pt[i])]};\n"
+                    f"        nFaces          {int(pz[i])};\n        startFace       {int(ps[i])};\n    }}\n")
+        f.write(")\n")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# fields
+# ---------------------------------------------------------------------------------------------------------------------
+def _field_values(v, n, ncomp, what):
+    """'uniform x' / 'nonuniform List<T> N (...)' entry -> (n, ncomp) array"""
+    if isinstance(v, list) and len(v) == 2 and v[0] == "uniform":
+        val = np.asarray(v[1], dtype=np.float64).reshape(-1)
+        if val.size != ncomp:
+            raise FoamFileError(f"{what}: uniform value has {val.size} components, expected {ncomp}")
+        return np.tile(val, (n, 1))
+    if isinstance(v, list) and len(v) >= 2 and v[0] == "nonuniform":
+        arr = np.asarray(v[-1], dtype=np.float64)
+        if arr.size != n * ncomp:
+            raise FoamFileError(f"{what}: {arr.size} values for {n} x {ncomp}")
+        return arr.reshape(n, ncomp)
+    raise FoamFileError(f"{what}: cannot read value '{v}'")
+
+
+def read_field(path, mesh):
+    """vol<Type>Field file -> (internal (nCells, ncomp) array, {patch name: {'type': word, 'value': array|None, ...}})"""
+    d = read_dict(path)
+    cls = str(d.get("FoamFile", {}).get("class", ""))
+    ncomp = {"volScalarField": 1, "volVectorField": 3}.get(cls)
+    if ncomp is None:
+        raise FoamFileError(f"{path}: class '{cls}' is not a vol scalar/vector field")
+    internal = _field_values(d["internalField"], mesh.nCells, ncomp, f"{path}: internalField")
+    names = getattr(mesh, "patch_names", None) or [f"patch{i}" for i in range(mesh.nPatches)]
+    sizes = mesh.array("patchSize")
+    bf = d.get("boundaryField", {})
+    patches = {}
+    for i, name in enumerate(names):
+        e = bf.get(name)
+        if e is None:  # OpenFOAM also accepts regular-expression keys
+            for k, v in bf.items():
+                try:
+                    if re.fullmatch(k, name):
+                        e = v
+                        break
+                except re.error:
+                    pass
+        if e is None:
+            raise FoamFileError(f"{path}: no boundaryField entry for patch '{name}'")
+        rec = dict(e)
+        rec["type"] = str(e["type"])
+        rec["value"] = _field_values(e["value"], int(sizes[i]), ncomp, f"{path}: {name}.value") if "value" in e else None
+        patches[name] = rec
+    return internal, patches
+
+
+def write_field(path, mesh, name, internal, patches, dimensions="[0 0 0 0 0 0 0]"):
+    """(nCells[, 3]) array + {patch: (type word, value or None)} -> vol<Type>Field file (values at full precision)"""
+    a = np.asarray(internal, dtype=np.float64)
+    vec = a.ndim == 2 and a.shape[1] == 3
+    cls, typ = ("volVectorField", "vector") if vec else ("volScalarField", "scalar")
+
+    def one(x):
+        return f"({_fmt(x[0])} {_fmt(x[1])} {_fmt(x[2])})" if vec else _fmt(x)
+
+    def values(arr):
+        arr = np.asarray(arr, dtype=np.float64)
+        if arr.ndim == (1 if vec else 0):
+            return f"uniform {one(arr)}"
+        return f"nonuniform List<{typ}> {len(arr)}\n(\n" + "\n".join(one(x) for x in arr) + "\n)"
+
+    names = getattr(mesh, "patch_names", None) or [f"patch{i}" for i in range(mesh.nPatches)]
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "w") as f:
+        f.write(_header(cls, name, os.path.basename(os.path.dirname(path))))
+        f.write(f"dimensions      {dimensions};\n\ninternalField   {values(a)};\n\nboundaryField\n{{\n")
+        for pn in names:
+            t, v = patches[pn]
+            f.write(f"    {pn}\n    {{\n        type            {t};\n")
+            if v is not None:
+                f.write(f"        value           {values(v)};\n")
+            f.write("    }\n")
+        f.write("}\n")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# case set-up (what QGDFoam's createFields.H reads)
+# ---------------------------------------------------------------------------------------------------------------------
+def _bc(rec, vector, patch_type_word, what):
+    """boundaryField entry -> the (kind, value) pair QGDFoamCase.set_bc takes"""
+    t = rec["type"]
+    if t in _CONSTRAINT_BCS:
+        return ("none", None)
+    if t in ("zeroGradient", "slip", "qgdFlux"):
+        if t == "slip" and not vector:
+            return ("zeroGradient", None)  # slip on a scalar is zeroGradient (basicSymmetry, L0)
+        return (t, None)
+    if t == "fixedValue":
+        v = rec["value"]
+        if v is None:
+            raise FoamFileError(f"{what}: fixedValue needs a value")
+        if np.any(v != v[0]):
+            raise FoamFileError(f"{what}: only uniform fixedValue patches are supported")
+        return ("fixedValue", v[0] if vector else float(v[0, 0]))
+    raise FoamFileError(f"{what}: boundary condition '{t}' is not supported")
+
+
+def read_case_setup(case_dir, time="0"):
+    """Read an OpenFOAM QGDFoam case directory.
+
+    Returns (mesh, options dict for ``default_options``, {'U','T','p'} internal arrays, per-patch BC triples).
+    Entries read: constant/polyMesh; constant/thermophysicalProperties (mixture.specie.molWeight,
+    thermodynamics.Cv|Cp, transport.mu/Pr; QGD{implicitDiffusion, QGDCoeffs, <model>Dict{ScQGD,PrQGD}} as in
+    QGDThermo.C L48-82, QGDCoeffs.C L57-160, constScPrModel1.C L48-90); system/fvSchemes fvsc.default (fvsc.C L47-58);
+    system/controlDict deltaT/adjustTimeStep/maxCo/maxDeltaT (setDeltaT-QGDQHD.H); <time>/{U,T,p}.
+    """
+    mesh = read_polymesh(os.path.join(case_dir, "constant", "polyMesh"))
+    opt = {}
+    tp = read_dict(os.path.join(case_dir, "constant", "thermophysicalProperties"))
+    tt = tp.get("thermoType", {})
+    for key, want in (("equationOfState", "perfectGas"), ("transport", "const")):
+        if isinstance(tt, dict) and key in tt and str(tt[key]) != want:
+            raise FoamFileError(f"thermoType.{key} '{tt[key]}' is not supported (only {want})")
+    mix = tp["mixture"]
+    R = RR / float(mix["specie"]["molWeight"])
+    th = mix["thermodynamics"]
+    opt["R"] = R
+    opt["Cv"] = float(th["Cv"]) if "Cv" in th else float(th["Cp"]) - R
+    opt["mu"] = float(mix["transport"]["mu"])
+    opt["Pr"] = float(mix["transport"]["Pr"])
+    qgd = tp["QGD"]
+    # QGDThermo::read(): implicitDiffusion defaults to true when absent [QGDThermo.C L70-82]
+    opt["implicitDiffusion"] = 1 if str(qgd.get("implicitDiffusion", "true")) in ("true", "on", "yes", "1") else 0
+    model = str(qgd["QGDCoeffs"])
+    if model != "constScPrModel1":
+        raise FoamFileError(f"QGDCoeffs '{model}' is not supported (only constScPrModel1)")
+    md = qgd.get(model + "Dict", qgd)  # QGDCoeffs::New: <type>Dict when present, else the QGD dict [QGDCoeffs.C L81-116]
+    for k in ("ScQGD", "PrQGD"):       # both default to 1 [constScPrModel1.C L58-89]
+        opt[k] = float(md[k]) if k in md else 1.0
+    tdir = os.path.join(case_dir, str(time))
+    # alphaQGD and ScQGD are READ_IF_PRESENT fields of the time directory [QGDCoeffs.C L119-160, constScPrModel1.C
+    # L66-79]; this path carries them as scalars, so only uniform ones are accepted
+    opt["alphaQGD"] = 0.5
+    for fname in ("alphaQGD", "ScQGD"):
+        fpath = os.path.join(tdir, fname)
+        if os.path.exists(fpath):
+            vals, _ = read_field(fpath, mesh)
+            if np.any(vals != vals[0]):
+                raise FoamFileError(f"{fpath}: only a uniform {fname} field is supported")
+            opt[fname] = float(vals[0, 0])
+    fs = read_dict(os.path.join(case_dir, "system", "fvSchemes"))
+    opt["stencil"] = str(fs.get("fvsc", {}).get("default", "reduced"))
+    cd = read_dict(os.path.join(case_dir, "system", "controlDict"))
+    opt["deltaT"] = float(cd["deltaT"])
+    opt["adjustTimeStep"] = 1 if str(cd.get("adjustTimeStep", "no")) in ("yes", "on", "true", "1") else 0
+    if "maxCo" in cd:
+        opt["maxCo"] = float(cd["maxCo"])
+    if "maxDeltaT" in cd:
+        opt["maxDeltaT"] = float(cd["maxDeltaT"])
+
+    U, bU = read_field(os.path.join(tdir, "U"), mesh)
+    T, bT = read_field(os.path.join(tdir, "T"), mesh)
+    p, bP = read_field(os.path.join(tdir, "p"), mesh)
+    ptw = [PATCH_WORDS.get(int(t), "patch") for t in mesh.array("patchType")]
+    bcs = []
+    for i, name in enumerate(mesh.patch_names):
+        bcs.append({"U": _bc(bU[name], True, ptw[i], f"U.{name}"), "T": _bc(bT[name], False, ptw[i], f"T.{name}"),
+                    "p": _bc(bP[name], False, ptw[i], f"p.{name}")})
+    return mesh, opt, {"U": U, "T": T[:, 0], "p": p[:, 0]}, bcs
+
+
+def load_case(case_dir, time="0", device_id=0):
+    """Case directory -> (Device, QGDFoamCase) ready to ``step()``: the createFields.H sequence of QGDFoam over the
+    C-ABI.  Needs the HIP device (there is no CPU fallback)."""
+    from .fvsc import Device
+    from .qgdfoam import QGDFoamCase, default_options
+
+    mesh, opt, fields, bcs = read_case_setup(case_dir, time)
+    dev = Device(mesh, device_id, fv_schemes={"fvsc": {"default": opt["stencil"]}})
+    case = QGDFoamCase(dev, default_options(**opt))
+    for i, bc in enumerate(bcs):
+        case.set_bc(i, U=bc["U"], T=bc["T"], p=bc["p"])
+    case.set_fields(fields["U"], fields["T"], fields["p"])
+    return dev, case
+
+
+def write_time(case, case_dir, time_name, bcs=None):
+    """Write U, T, p, rho of a QGDFoamCase into <case_dir>/<time_name>/ (what runTime.write() leaves for QGDFoam's
+    AUTO_WRITE fields); patch entries carry the patch values as ``value``."""
+    mesh = case.mesh
+    names = getattr(mesh, "patch_names", None) or [f"patch{i}" for i in range(mesh.nPatches)]
+    ps, pz, pt = mesh.array("patchStart"), mesh.array("patchSize"), mesh.array("patchType")
+    nIF = mesh.nInternalFaces
+    dims = {"U": "[0 1 -1 0 0 0 0]", "T": "[0 0 0 1 0 0 0]", "p": "[1 -1 -2 0 0 0 0]", "rho": "[1 -3 0 0 0 0 0]"}
+    for fname in ("U", "T", "p", "rho"):
+        internal = case.field(fname)
+        bvals = case.field(fname + ".boundary")
+        patches = {}
+        for i, pn in enumerate(names):
+            word = PATCH_WORDS.get(int(pt[i]), "patch")
+            if word in _CONSTRAINT_BCS:
+                patches[pn] = (word, None)
+                continue
+            kind = "calculated"
+            if bcs is not None and fname in bcs[i]:
+                kind = bcs[i][fname][0]
+                if kind == "none":
+                    kind = "calculated"
+            b0 = int(ps[i]) - nIF
+            patches[pn] = (kind, bvals[b0:b0 + int(pz[i])])
+        write_field(os.path.join(case_dir, str(time_name), fname), mesh, fname, internal, patches, dims[fname])
