@@ -164,3 +164,10 @@ def test_unsupported_entries_fail_loudly(tmp_path):
     open(upath, "w").write(utext.replace("type zeroGradient;", "type waveTransmissive;"))
     with pytest.raises(ff.FoamFileError, match="waveTransmissive"):
         ff.read_case_setup(str(tmp_path))
+
+
+def test_time_names_follow_openfoam():
+    from qgdsolver_amd.QGDFoam import time_name
+    assert time_name(0.0) == "0" and time_name(0.005) == "0.005" and time_name(0.0125) == "0.0125"
+    assert time_name(1.0) == "1" and time_name(1e-7) == "1e-07" and time_name(0.1 + 0.2) == "0.3"
+    assert time_name(123456.789, 8) == "123456.79"
