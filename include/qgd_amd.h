@@ -153,6 +153,24 @@ int qgd_mesh_split_quads(qgd_mesh_t m, int32_t stride);
  * [GaussVolPointBase3D_8C_source.html L759-768].  Test helper. */
 int qgd_mesh_split_edges(qgd_mesh_t m, int32_t stride);
 
+/* ---- renumbering and cell-range sharding of any polyMesh ("ranges after a bandwidth-reducing
+ * renumbering"; stands in for OpenFOAM's renumberMesh / decomposePar, which are not part of the reference tree) ---- */
+/* Relabel the cells in place, newOfOld[old cell] = new cell (a permutation).  Internal faces are re-oriented and
+ * re-sorted into upper-triangular order, boundary faces keep their labels.  faceNewOfOld (nFaces, may be NULL)
+ * receives each old face's new label, or -1-label when the face was reversed (fluxes change sign). */
+int qgd_mesh_renumber(qgd_mesh_t m, const int32_t* newOfOld, int32_t* faceNewOfOld);
+/* newOfOld (nCells) of a reverse Cuthill-McKee ordering of the face-neighbour graph. */
+int qgd_mesh_rcm_order(qgd_mesh_t m, int32_t* newOfOld);
+/* The shard of `rank` when the cells of `global` are cut into the contiguous ranges cellStart[r]..cellStart[r+1]
+ * (cellStart[0]=0, cellStart[nRanks]=nCells): owned cells + one vertex-connected ghost layer (what
+ * volPointInterpolation and the leastSquares stencil reach, extendedFaceStencilFindNeighbours_8C_source.html L55-80),
+ * all faces of those cells, the global patches (same indices, possibly empty) followed by one QGD_PATCH_HALO patch,
+ * and one halo slot per neighbouring rank.  qgd_mesh_get names of a shard: "cellGlobal","faceGlobal" (-1-label when
+ * reversed),"pointGlobal","haloPeer","haloGhost<slot>","haloSend<slot>". */
+int qgd_mesh_shard(qgd_mesh_t global, int32_t nRanks, const int32_t* cellStart, int32_t rank, qgd_mesh_t* out);
+/* number of halo slots (neighbouring shards) of a mesh; 0 when unsharded, 2 for a qgd_mesh_box slab */
+int qgd_mesh_halo_slots(qgd_mesh_t m, int32_t* nSlots);
+
 int qgd_mesh_set_geometry(qgd_mesh_t m, const double* Sf, const double* Cf,
                           const double* C, const double* V);
 int qgd_mesh_free(qgd_mesh_t m);
@@ -162,7 +180,8 @@ int qgd_mesh_free(qgd_mesh_t m);
 int qgd_mesh_sizes(qgd_mesh_t m, int64_t sizes[7]);
 /* Copy out a named array: "points","faceOffsets","facePoints","owner",
  * "neighbour","patchStart","patchSize","patchType" (int32 / double as natural),
- * "Sf","magSf","Cf","C","V","weights","deltaCoeffs","nonOrthDeltaCoeffs". */
+ * "Sf","magSf","Cf","C","V","weights","deltaCoeffs","nonOrthDeltaCoeffs".
+ * outBytes < 0 asks for the size: *(int64_t*)out receives the array's length in bytes. */
 int qgd_mesh_get(qgd_mesh_t m, const char* name, void* out, int64_t outBytes);
 
 /* ---- device mesh + fvsc operators ----------------------------------------- */
@@ -293,17 +312,18 @@ int qgd_case_get_field(qgd_case_t c, const char* name, double* out,
 int qgd_case_info(qgd_case_t c, double info[6]);
 
 /* ---- halo exchange of ghost-cell primitives (multi-GPU) ------------------- */
-/* A shard built with qgd_mesh_box(kLo>0 or kHi<nzGlobal) has up to two
- * neighbours: side 0 = lower k, side 1 = upper k.  count = number of doubles
- * in one message.  pack gathers the owned boundary-layer cells' records into
+/* A shard has one halo slot per neighbouring shard: a qgd_mesh_box slab (kLo>0 or kHi<nzGlobal) has slot 0 = lower k
+ * and slot 1 = upper k; a qgd_mesh_shard mesh has one per rank in "haloPeer".  count / recv_count = number of doubles
+ * in the message sent to / received from that neighbour.  pack gathers the owned boundary-layer cells' records into
  * the DEVICE buffer sendBuf; unpack scatters recvBuf into the ghost cells.
  * Both are asynchronous on the case's stream; qgd_case_stream_sync waits. */
 /* Plain device buffers for callers that own the transport (GPU-aware MPI, RCCL, ...). */
 int qgd_device_alloc(qgd_device_t d, int64_t bytes, void** devicePtr);
 int qgd_device_release(qgd_device_t d, void* devicePtr);
-int qgd_case_halo_count(qgd_case_t c, int side, int64_t* count);
-int qgd_case_halo_pack(qgd_case_t c, int side, double* sendBufDevice);
-int qgd_case_halo_unpack(qgd_case_t c, int side, const double* recvBufDevice);
+int qgd_case_halo_count(qgd_case_t c, int slot, int64_t* count);
+int qgd_case_halo_recv_count(qgd_case_t c, int slot, int64_t* count);
+int qgd_case_halo_pack(qgd_case_t c, int slot, double* sendBufDevice);
+int qgd_case_halo_unpack(qgd_case_t c, int slot, const double* recvBufDevice);
 int qgd_case_stream_sync(qgd_case_t c);
 /* Run the case's kernels on a caller-owned HIP stream (hipStream_t passed as
  * void*), e.g. the stream the RCCL halo transfers are ordered on, so that

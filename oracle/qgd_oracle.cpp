@@ -70,8 +70,9 @@ struct Mesh {
     std::vector<dvec> pointWeights;   // per point (non patch points)
     std::vector<dvec> bndPointWeights;// per boundary point
     // halo
-    ivec haloGhost[2], haloSend[2];
-    ivec haloGhostBF[2], haloSendBF[2];  // boundary-face indices (global label - nIF)
+    std::vector<ivec> haloGhost, haloSend;      // one entry per halo slot (neighbouring shard)
+    std::vector<ivec> haloGhostBF, haloSendBF;  // boundary-face indices (global label - nIF)
+    bool sharded() const { for (const ivec& g : haloGhost) if (!g.empty()) return true; return false; }
 
     int nBF() const { return nF - nIF; }
     int fsize(int f) const { return fOff[f + 1] - fOff[f]; }
@@ -265,7 +266,9 @@ void Mesh::pointInterpolationWeights() {
 }
 
 void Mesh::haloFaces() {
-    for (int side = 0; side < 2; ++side) {
+    haloGhostBF.resize(haloGhost.size());
+    haloSendBF.resize(haloGhost.size());
+    for (size_t side = 0; side < haloGhost.size(); ++side) {
         std::vector<char> isG(nC, 0), isS(nC, 0);
         for (int c : haloGhost[side]) isG[c] = 1;
         for (int c : haloSend[side]) isS[c] = 1;
@@ -1467,12 +1470,19 @@ struct Case {
     }
     void stepPhase2() {
         // after a halo unpack: tauQGDf is a pure function of the cell fields
-        if (!m.haloGhost[0].empty() || !m.haloGhost[1].empty()) computeTauQGDf();
+        if (m.sharded()) computeTauQGDf();
     }
 
     static const int kCellMsg = 15, kFaceMsg = 16;
-    void haloCount(int side, int64_t* n) const { *n = (int64_t)m.haloSend[side].size() * kCellMsg + (int64_t)m.haloSendBF[side].size() * kFaceMsg; }
+    void haloCount(int side, int64_t* n, bool recv) const {
+        *n = 0;
+        if (side < 0 || (size_t)side >= m.haloGhost.size()) return;
+        const ivec& cells = recv ? m.haloGhost[side] : m.haloSend[side];
+        const ivec& faces = recv ? m.haloGhostBF[side] : m.haloSendBF[side];
+        *n = (int64_t)cells.size() * kCellMsg + (int64_t)faces.size() * kFaceMsg;
+    }
     void packOrUnpack(int side, double* buf, bool pack) {
+        if (side < 0 || (size_t)side >= m.haloGhost.size()) return;
         const ivec& cellsL = pack ? m.haloSend[side] : m.haloGhost[side];
         const ivec& facesL = pack ? m.haloSendBF[side] : m.haloGhostBF[side];
         size_t q = 0;
@@ -1534,7 +1544,8 @@ int orc_mesh_info(void* mp, int64_t info[4]) {
 }
 int orc_mesh_set_halo(void* mp, int side, int32_t nGhost, const int32_t* ghost, int32_t nSend, const int32_t* send) {
     Mesh& m = ((MeshHandle*)mp)->m;
-    if (side < 0 || side > 1) return -1;
+    if (side < 0) return -1;
+    if ((size_t)side >= m.haloGhost.size()) { m.haloGhost.resize((size_t)side + 1); m.haloSend.resize((size_t)side + 1); }
     m.haloGhost[side].assign(ghost, ghost + nGhost);
     m.haloSend[side].assign(send, send + nSend);
     m.haloFaces();
@@ -1629,9 +1640,9 @@ void* orc_case_create(void* mesh, const orc_case_options* opt) {
     Case* c = new Case((MeshHandle*)mesh, *opt);
     c->stencilWord = opt->stencil == FVSC_REDUCED ? "reduced" : (opt->stencil == FVSC_LEASTSQUARES ? "leastSquares" : "GaussVolPoint");
     const Mesh& m = c->m;
-    if (!m.haloGhost[0].empty() || !m.haloGhost[1].empty()) {
+    if (m.sharded()) {
         c->ghostFlag.assign(m.nC, 0);
-        for (int s = 0; s < 2; ++s) for (int g : m.haloGhost[s]) c->ghostFlag[g] = 1;
+        for (const ivec& gl : m.haloGhost) for (int g : gl) c->ghostFlag[g] = 1;
     }
     return c;
 }
@@ -1698,7 +1709,8 @@ int orc_case_info(void* cp, double info[6]) {
     info[0] = c->time; info[1] = c->deltaT; info[2] = c->CoNum; info[3] = mr; info[4] = me; info[5] = (double)c->stepCount;
     return 0;
 }
-int orc_case_halo_count(void* cp, int side, int64_t* count) { ((Case*)cp)->haloCount(side, count); return 0; }
+int orc_case_halo_count(void* cp, int side, int64_t* count) { ((Case*)cp)->haloCount(side, count, false); return 0; }
+int orc_case_halo_recv_count(void* cp, int side, int64_t* count) { ((Case*)cp)->haloCount(side, count, true); return 0; }
 int orc_case_halo_pack(void* cp, int side, double* sendBuf) { ((Case*)cp)->packOrUnpack(side, sendBuf, true); return 0; }
 int orc_case_halo_unpack(void* cp, int side, const double* recvBuf) { ((Case*)cp)->packOrUnpack(side, const_cast<double*>(recvBuf), false); return 0; }
 

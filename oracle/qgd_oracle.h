@@ -39,7 +39,7 @@ void orc_mesh_free(void* m);
 int orc_mesh_get(void* m, const char* name, double* out, int64_t n);
 /* info[0]=nGeometricD, info[1..3]=geometricD */
 int orc_mesh_info(void* m, int64_t info[4]);
-/* halo lists for a cell-range shard (side 0 lower, 1 upper) */
+/* halo lists of a cell-range shard, one call per halo slot (= neighbouring shard; box slabs: 0 lower, 1 upper) */
 int orc_mesh_set_halo(void* m, int side, int32_t nGhost, const int32_t* ghost,
                       int32_t nSend, const int32_t* send);
 
@@ -70,6 +70,7 @@ int orc_case_step(void* c, int32_t nSteps);
 int orc_case_get_field(void* c, const char* name, double* out, int64_t n);
 int orc_case_info(void* c, double info[6]);
 int orc_case_halo_count(void* c, int side, int64_t* count);
+int orc_case_halo_recv_count(void* c, int side, int64_t* count);
 int orc_case_halo_pack(void* c, int side, double* sendBuf);
 int orc_case_halo_unpack(void* c, int side, const double* recvBuf);
 int orc_case_step_phase(void* c, int phase);

@@ -49,6 +49,10 @@ SIGNATURES = {
     "qgd_mesh_jitter": (C.c_int, [handle, C.c_double, C.c_uint64]),
     "qgd_mesh_split_quads": (C.c_int, [handle, C.c_int32]),
     "qgd_mesh_split_edges": (C.c_int, [handle, C.c_int32]),
+    "qgd_mesh_renumber": (C.c_int, [handle, c_int32_p, c_int32_p]),
+    "qgd_mesh_rcm_order": (C.c_int, [handle, c_int32_p]),
+    "qgd_mesh_shard": (C.c_int, [handle, C.c_int32, c_int32_p, C.c_int32, handle_p]),
+    "qgd_mesh_halo_slots": (C.c_int, [handle, c_int32_p]),
     "qgd_mesh_set_geometry": (C.c_int, [handle, c_double_p, c_double_p, c_double_p, c_double_p]),
     "qgd_mesh_free": (C.c_int, [handle]),
     "qgd_mesh_sizes": (C.c_int, [handle, c_int64_p]),
@@ -76,6 +80,7 @@ SIGNATURES = {
     "qgd_device_alloc": (C.c_int, [handle, C.c_int64, C.POINTER(C.c_void_p)]),
     "qgd_device_release": (C.c_int, [handle, C.c_void_p]),
     "qgd_case_halo_count": (C.c_int, [handle, C.c_int, c_int64_p]),
+    "qgd_case_halo_recv_count": (C.c_int, [handle, C.c_int, c_int64_p]),
     "qgd_case_halo_pack": (C.c_int, [handle, C.c_int, C.c_void_p]),
     "qgd_case_halo_unpack": (C.c_int, [handle, C.c_int, C.c_void_p]),
     "qgd_case_stream_sync": (C.c_int, [handle]),

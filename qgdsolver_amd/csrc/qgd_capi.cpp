@@ -97,13 +97,14 @@ struct qgd_device_s {
     bool hasTri = false;
     std::vector<Patch> patches;
     std::vector<double> hf;  // host copy of hQGDf for the accessor
-    // halo lists (device) and sizes
-    int32_t* haloGhost[2] = {nullptr, nullptr};
-    int32_t* haloSend[2] = {nullptr, nullptr};
-    int32_t* haloGhostBF[2] = {nullptr, nullptr};
-    int32_t* haloSendBF[2] = {nullptr, nullptr};
-    int32_t nHaloCells[2] = {0, 0}, nHaloSendCells[2] = {0, 0}, nHaloGhostBF[2] = {0, 0}, nHaloSendBF[2] = {0, 0};
-    int32_t* sendAll = nullptr;     // send cells of both sides
+    // halo lists (device) and sizes, one entry per halo slot (neighbouring shard)
+    struct HaloSlot {
+        int32_t *ghost = nullptr, *send = nullptr, *ghostBF = nullptr, *sendBF = nullptr;
+        int32_t nGhost = 0, nSend = 0, nGhostBF = 0, nSendBF = 0;
+    };
+    std::vector<HaloSlot> halo;
+    bool sharded() const { for (const HaloSlot& h : halo) if (h.nGhost || h.nSend) return true; return false; }
+    int32_t* sendAll = nullptr;     // send cells of every slot (each cell once)
     int32_t* sendBFAll = nullptr;   // their real-patch boundary faces
     int32_t nSendAll = 0, nSendBFAll = 0;
     hipStream_t stream = nullptr;
@@ -309,6 +310,7 @@ int qgd_mesh_sizes(qgd_mesh_t mh, int64_t sizes[7]) {
     sizes[4] = (int64_t)m.patches.size(); sizes[5] = (int64_t)m.facePoints.size(); sizes[6] = m.nGeometricD;
     return QGD_OK;
 }
+// outBytes < 0: size query, *(int64_t*)out receives the array's size in bytes
 int qgd_mesh_get(qgd_mesh_t mh, const char* name, void* out, int64_t outBytes) {
     QGD_TRY
     if (!mh || !name || !out) return fail(QGD_ERR_INVALID, "null argument");
@@ -327,10 +329,15 @@ int qgd_mesh_get(qgd_mesh_t mh, const char* name, void* out, int64_t outBytes) {
     else if (s == "patchStart" || s == "patchSize" || s == "patchType") {
         for (const Patch& p : m.patches) tmp.push_back(s == "patchStart" ? p.start : (s == "patchSize" ? p.size : p.type));
         I(tmp);
-    } else if (s == "haloGhost0") I(m.haloGhost[0]);
-    else if (s == "haloGhost1") I(m.haloGhost[1]);
-    else if (s == "haloSend0") I(m.haloSend[0]);
-    else if (s == "haloSend1") I(m.haloSend[1]);
+    } else if (s.rfind("haloGhost", 0) == 0 || s.rfind("haloSend", 0) == 0) {
+        const bool ghost = s[4] == 'G';
+        const int slot = std::atoi(s.c_str() + (ghost ? 9 : 8));
+        const auto& lists = ghost ? m.haloGhost : m.haloSend;
+        if (slot >= 0 && slot < (int)lists.size()) I(lists[slot]); else I(tmp);
+    } else if (s == "haloPeer") I(m.haloPeer);
+    else if (s == "cellGlobal") I(m.cellGlobal);
+    else if (s == "faceGlobal") I(m.faceGlobal);
+    else if (s == "pointGlobal") I(m.pointGlobal);
     else if (s == "Sf") D(m.Sf);
     else if (s == "magSf") D(m.magSf);
     else if (s == "Cf") D(m.Cf);
@@ -340,10 +347,53 @@ int qgd_mesh_get(qgd_mesh_t mh, const char* name, void* out, int64_t outBytes) {
     else if (s == "deltaCoeffs") D(m.deltaCoeffs);
     else if (s == "nonOrthDeltaCoeffs") D(m.nonOrthDeltaCoeffs);
     else return fail(QGD_ERR_UNKNOWN_NAME, "qgd_mesh_get: unknown array " + s);
+    if (outBytes < 0) { *static_cast<int64_t*>(out) = (int64_t)bytes; return QGD_OK; }
     if ((int64_t)bytes > outBytes) return fail(QGD_ERR_INVALID, "qgd_mesh_get: output too small for " + s);
     if (bytes) std::memcpy(out, src, bytes);
     return QGD_OK;
     QGD_CATCH
+}
+
+int qgd_mesh_renumber(qgd_mesh_t mh, const int32_t* newOfOld, int32_t* faceNewOfOld) {
+    QGD_TRY
+    if (!mh || !newOfOld) return fail(QGD_ERR_INVALID, "qgd_mesh_renumber: null argument");
+    if (!mh->m.haloGhost.empty()) return fail(QGD_ERR_INVALID, "qgd_mesh_renumber: renumber before sharding");
+    renumberCells(mh->m, newOfOld, faceNewOfOld);
+    const std::string err = mh->m.check();
+    if (!err.empty()) return fail(QGD_ERR_INVALID, "qgd_mesh_renumber: " + err);
+    return QGD_OK;
+    QGD_CATCH
+}
+int qgd_mesh_rcm_order(qgd_mesh_t mh, int32_t* newOfOld) {
+    QGD_TRY
+    if (!mh || !newOfOld) return fail(QGD_ERR_INVALID, "qgd_mesh_rcm_order: null argument");
+    const std::vector<int32_t> order = cuthillMcKee(mh->m);
+    std::memcpy(newOfOld, order.data(), sizeof(int32_t) * order.size());
+    return QGD_OK;
+    QGD_CATCH
+}
+int qgd_mesh_shard(qgd_mesh_t global, int32_t nRanks, const int32_t* cellStart, int32_t rank, qgd_mesh_t* out) {
+    QGD_TRY
+    if (!global || !cellStart || !out) return fail(QGD_ERR_INVALID, "qgd_mesh_shard: null argument");
+    if (nRanks < 1 || rank < 0 || rank >= nRanks) return fail(QGD_ERR_INVALID, "qgd_mesh_shard: rank out of range");
+    if (!global->m.haloGhost.empty()) return fail(QGD_ERR_INVALID, "qgd_mesh_shard: the mesh is already a shard");
+    if (cellStart[0] != 0 || cellStart[nRanks] != global->m.nCells) return fail(QGD_ERR_INVALID, "qgd_mesh_shard: cellStart must run from 0 to nCells");
+    for (int r = 0; r < nRanks; ++r)
+        if (cellStart[r + 1] <= cellStart[r]) return fail(QGD_ERR_INVALID, "qgd_mesh_shard: every rank needs at least one cell");
+    qgd_mesh_s* h = new qgd_mesh_s();
+    try {
+        h->m = extractShard(global->m, nRanks, cellStart, rank);
+        const std::string err = h->m.check();
+        if (!err.empty()) { delete h; return fail(QGD_ERR_INVALID, "qgd_mesh_shard: " + err); }
+    } catch (...) { delete h; throw; }
+    *out = h;
+    return QGD_OK;
+    QGD_CATCH
+}
+int qgd_mesh_halo_slots(qgd_mesh_t mh, int32_t* nSlots) {
+    if (!mh || !nSlots) return fail(QGD_ERR_INVALID, "null argument");
+    *nSlots = (int32_t)mh->m.haloGhost.size();
+    return QGD_OK;
 }
 
 // ---- device ----------------------------------------------------------------------
@@ -389,23 +439,28 @@ int qgd_device_create(qgd_mesh_t mh, int deviceId, qgd_device_t* out) {
         v.V = up(s.V); v.hQGD = up(s.hQGD); v.ghost = up(s.ghost);
         v.bPatch = up(s.bPatch); v.hQGDb = up(s.hQGDb);
         {
+            // a cell on a shard corner is needed by several neighbours: once in the list the update kernel walks
             std::vector<int32_t> sc, sf;
-            for (int side = 0; side < 2; ++side) {
-                sc.insert(sc.end(), s.haloSend[side].begin(), s.haloSend[side].end());
-                sf.insert(sf.end(), s.haloSendBF[side].begin(), s.haloSendBF[side].end());
+            for (size_t slot = 0; slot < s.haloSend.size(); ++slot) {
+                sc.insert(sc.end(), s.haloSend[slot].begin(), s.haloSend[slot].end());
+                sf.insert(sf.end(), s.haloSendBF[slot].begin(), s.haloSendBF[slot].end());
             }
+            std::sort(sc.begin(), sc.end()); sc.erase(std::unique(sc.begin(), sc.end()), sc.end());
+            std::sort(sf.begin(), sf.end()); sf.erase(std::unique(sf.begin(), sf.end()), sf.end());
             d->nSendAll = (int32_t)sc.size(); d->nSendBFAll = (int32_t)sf.size();
             d->sendAll = a.upload(sc); d->sendBFAll = a.upload(sf);
         }
-        for (int side = 0; side < 2; ++side) {
-            d->nHaloCells[side] = (int32_t)s.haloGhost[side].size();
-            d->nHaloSendCells[side] = (int32_t)s.haloSend[side].size();
-            d->nHaloGhostBF[side] = (int32_t)s.haloGhostBF[side].size();
-            d->nHaloSendBF[side] = (int32_t)s.haloSendBF[side].size();
-            d->haloGhost[side] = a.upload(s.haloGhost[side]);
-            d->haloSend[side] = a.upload(s.haloSend[side]);
-            d->haloGhostBF[side] = a.upload(s.haloGhostBF[side]);
-            d->haloSendBF[side] = a.upload(s.haloSendBF[side]);
+        d->halo.resize(s.haloGhost.size());
+        for (size_t slot = 0; slot < d->halo.size(); ++slot) {
+            qgd_device_s::HaloSlot& h = d->halo[slot];
+            h.nGhost = (int32_t)s.haloGhost[slot].size();
+            h.nSend = (int32_t)s.haloSend[slot].size();
+            h.nGhostBF = (int32_t)s.haloGhostBF[slot].size();
+            h.nSendBF = (int32_t)s.haloSendBF[slot].size();
+            h.ghost = a.upload(s.haloGhost[slot]);
+            h.send = a.upload(s.haloSend[slot]);
+            h.ghostBF = a.upload(s.haloGhostBF[slot]);
+            h.sendBF = a.upload(s.haloSendBF[slot]);
         }
     } catch (...) {
         d->arena.release();
@@ -801,7 +856,7 @@ int qgd_case_step(qgd_case_t c, int32_t nSteps) {
     QGD_TRY
     if (!c) return fail(QGD_ERR_INVALID, "null case");
     if (!c->fieldsSet) return fail(QGD_ERR_INVALID, "qgd_case_step: call qgd_case_set_fields first");
-    if (c->dev->nHaloCells[0] || c->dev->nHaloCells[1])
+    if (c->dev->sharded())
         return fail(QGD_ERR_INVALID, "qgd_case_step: sharded mesh, drive it with qgd_case_step_phase + halo exchange");
     HIP_CHECK(hipSetDevice(c->dev->deviceId));
     for (int i = 0; i < nSteps; ++i) { stepAssemble(c); stepAdvance(c, 0); }
@@ -873,40 +928,50 @@ int qgd_device_release(qgd_device_t d, void* devicePtr) {
 }
 
 // halo message layout: 10 doubles per cell (RecA, RecB), 12 per boundary face (RecA, RecB, p gradient, lagged rho)
-int qgd_case_halo_count(qgd_case_t c, int side, int64_t* count) {
-    if (!c || !count || side < 0 || side > 1) return fail(QGD_ERR_INVALID, "bad argument");
-    *count = 10 * (int64_t)c->dev->nHaloSendCells[side] + 12 * (int64_t)c->dev->nHaloSendBF[side];
+int qgd_case_halo_count(qgd_case_t c, int slot, int64_t* count) {
+    if (!c || !count || slot < 0) return fail(QGD_ERR_INVALID, "bad argument");
+    *count = 0;
+    if (slot >= (int)c->dev->halo.size()) return QGD_OK;  // an unsharded mesh has no slots: nothing to exchange
+    *count = 10 * (int64_t)c->dev->halo[slot].nSend + 12 * (int64_t)c->dev->halo[slot].nSendBF;
     return QGD_OK;
 }
-int qgd_case_halo_pack(qgd_case_t c, int side, double* sendBufDevice) {
+int qgd_case_halo_recv_count(qgd_case_t c, int slot, int64_t* count) {
+    if (!c || !count || slot < 0) return fail(QGD_ERR_INVALID, "bad argument");
+    *count = 0;
+    if (slot >= (int)c->dev->halo.size()) return QGD_OK;
+    *count = 10 * (int64_t)c->dev->halo[slot].nGhost + 12 * (int64_t)c->dev->halo[slot].nGhostBF;
+    return QGD_OK;
+}
+int qgd_case_halo_pack(qgd_case_t c, int slot, double* sendBufDevice) {
     QGD_TRY
-    if (!c || side < 0 || side > 1) return fail(QGD_ERR_INVALID, "bad argument");
+    if (!c || slot < 0) return fail(QGD_ERR_INVALID, "bad argument");
     qgd_device_s* d = c->dev;
-    if (!d->nHaloSendCells[side]) return QGD_OK;
+    if (slot >= (int)d->halo.size() || !d->halo[slot].nSend) return QGD_OK;
     if (!sendBufDevice) return fail(QGD_ERR_INVALID, "null buffer");
+    const qgd_device_s::HaloSlot& h = d->halo[slot];
     HIP_CHECK(hipSetDevice(d->deviceId));
     Launcher L = launcherOf(c);
     L.pre = nullptr; L.post = nullptr;
     if (c->useHaloStream) L.stream = c->haloStream;
     (void)hipGetLastError();
-    launchHaloPack(L, c->view, d->haloSend[side], d->nHaloSendCells[side], d->haloSendBF[side], d->nHaloSendBF[side], sendBufDevice, true);
+    launchHaloPack(L, c->view, h.send, h.nSend, h.sendBF, h.nSendBF, sendBufDevice, true);
     HIP_CHECK(hipGetLastError());
     return QGD_OK;
     QGD_CATCH
 }
-int qgd_case_halo_unpack(qgd_case_t c, int side, const double* recvBufDevice) {
+int qgd_case_halo_unpack(qgd_case_t c, int slot, const double* recvBufDevice) {
     QGD_TRY
-    if (!c || side < 0 || side > 1) return fail(QGD_ERR_INVALID, "bad argument");
+    if (!c || slot < 0) return fail(QGD_ERR_INVALID, "bad argument");
     qgd_device_s* d = c->dev;
-    if (!d->nHaloCells[side]) return QGD_OK;
+    if (slot >= (int)d->halo.size() || !d->halo[slot].nGhost) return QGD_OK;
     if (!recvBufDevice) return fail(QGD_ERR_INVALID, "null buffer");
+    const qgd_device_s::HaloSlot& h = d->halo[slot];
     HIP_CHECK(hipSetDevice(d->deviceId));
     Launcher L = launcherOf(c);
     L.pre = nullptr; L.post = nullptr;
     if (c->useHaloStream) L.stream = c->haloStream;
     (void)hipGetLastError();
-    launchHaloPack(L, c->view, d->haloGhost[side], d->nHaloCells[side], d->haloGhostBF[side], d->nHaloGhostBF[side],
-                   const_cast<double*>(recvBufDevice), false);
+    launchHaloPack(L, c->view, h.ghost, h.nGhost, h.ghostBF, h.nGhostBF, const_cast<double*>(recvBufDevice), false);
     HIP_CHECK(hipGetLastError());
     return QGD_OK;
     QGD_CATCH

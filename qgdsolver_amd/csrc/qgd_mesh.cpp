@@ -380,6 +380,9 @@ HostMesh makeBox(int32_t nx, int32_t ny, int32_t nzGlobal, int32_t kLo, int32_t 
     const bool cutLo = kLo > 0, cutHi = kHi < nzGlobal;
     if (cutLo || cutHi) {
         m.cellIsGhost.assign((size_t)nC, 0);
+        m.haloGhost.assign(2, {});
+        m.haloSend.assign(2, {});
+        m.haloPeer.assign(2, -1);
         const int64_t plane = (int64_t)nx * ny;
         if (cutLo) {
             if (nz < 2) throw std::invalid_argument("makeBox: slab too thin for a ghost layer");

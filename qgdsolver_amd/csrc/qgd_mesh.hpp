@@ -44,11 +44,15 @@ struct HostMesh {
     int32_t geometricD[3] = {1, 1, 1}; // -1 for the direction of empty patches
     int32_t nGeometricD = 3;
 
-    // ---- cell-range sharding (slab halo) ------------------------------------
-    // side 0 = lower neighbour, side 1 = upper neighbour
-    std::vector<int32_t> haloGhost[2]; // local ghost cells refreshed from the neighbour
-    std::vector<int32_t> haloSend[2];  // local owned cells the neighbour needs
+    // ---- cell-range sharding --------------------------------------------------
+    // one slot per neighbouring shard: the local ghost cells refreshed from it and the local owned cells it needs,
+    // both in ascending label order (box slabs: slot 0 = lower, slot 1 = upper neighbour, either may be empty)
+    std::vector<std::vector<int32_t>> haloGhost, haloSend;
+    std::vector<int32_t> haloPeer;     // rank behind each slot (-1 when the builder does not know it)
     std::vector<uint8_t> cellIsGhost;  // nCells (empty when unsharded)
+    // labels in the unsharded mesh (filled by extractShard, empty otherwise); faceGlobal is -1-label for flipped faces
+    std::vector<int32_t> cellGlobal, faceGlobal, pointGlobal;
+    int32_t ownedBegin = 0, ownedEnd = 0;  // local label range of the owned cells of an extracted shard
 
     int32_t nBoundaryFaces() const { return nFaces - nInternalFaces; }
     int32_t faceSize(int32_t f) const { return faceOffsets[f + 1] - faceOffsets[f]; }
@@ -85,5 +89,17 @@ HostMesh makeForwardStep(int32_t nx, int32_t ny, int32_t ixStep, int32_t iyStep,
 void jitterPoints(HostMesh& m, double amplitude, uint64_t seed);
 void splitQuads(HostMesh& m, int32_t stride);
 void splitEdges(HostMesh& m, int32_t stride);
+
+// ---- renumbering and cell-range partitioning (qgd_partition.cpp) ---------------
+// Relabel the cells (newOfOld[old] = new): owner/neighbour are swapped and the face reversed where needed, internal
+// faces are re-sorted into upper-triangular order, boundary faces keep their order.  faceNewOfOld (optional, nFaces)
+// receives new label, or -1-new when the face was reversed.
+void renumberCells(HostMesh& m, const int32_t* newOfOld, int32_t* faceNewOfOld);
+// reverse Cuthill-McKee order over the face-neighbour graph (bandwidth reduction before cell-range sharding)
+std::vector<int32_t> cuthillMcKee(const HostMesh& m);
+// The shard of rank `rank` when the cells are cut into the ranges cellStart[r] .. cellStart[r+1]: its owned cells plus
+// one vertex-connected layer of ghost cells, every face of those cells (faces whose other cell is absent form a trailing
+// QGD_PATCH_HALO patch), halo lists per neighbouring rank.
+HostMesh extractShard(const HostMesh& g, int32_t nRanks, const int32_t* cellStart, int32_t rank);
 
 }  // namespace qgd

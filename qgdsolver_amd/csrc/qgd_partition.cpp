@@ -1,0 +1,227 @@
+// qgd_partition.cpp -- cell renumbering and cell-range sharding of an arbitrary polyMesh.
+//
+// The reference runs in parallel on OpenFOAM's decomposition (processor patches + the "corner" neighbour ranks of
+// extendedFaceStencilFindNeighbours_8C_source.html L88-268); decomposePar and renumberMesh are OpenFOAM tools (L0) and
+// are not available, so this file provides what SURVEY.md 8(e) asks for instead: a bandwidth-reducing order
+// (reverse Cuthill-McKee), the relabelling itself, and the extraction of one rank's shard -- owned cells plus one
+// vertex-connected ghost layer, which is exactly the neighbourhood volPointInterpolation and the leastSquares stencil
+// reach [FindNb.C:55-80] -- with the halo lists per neighbouring rank.  Host-side set-up code, nothing on the GPU.
+#include <algorithm>
+#include <numeric>
+#include <queue>
+#include <stdexcept>
+
+#include "../../include/qgd_amd.h"
+#include "qgd_mesh.hpp"
+
+namespace qgd {
+
+void renumberCells(HostMesh& m, const int32_t* newOfOld, int32_t* faceNewOfOld) {
+    const int32_t nC = m.nCells, nIF = m.nInternalFaces, nF = m.nFaces;
+    {   // a permutation?
+        std::vector<uint8_t> seen((size_t)nC, 0);
+        for (int32_t c = 0; c < nC; ++c) {
+            const int32_t n = newOfOld[c];
+            if (n < 0 || n >= nC || seen[n]) throw std::invalid_argument("renumberCells: newOfOld is not a permutation");
+            seen[n] = 1;
+        }
+    }
+    struct Key { int32_t o, n, old; bool flip; };
+    std::vector<Key> keys((size_t)nIF);
+    for (int32_t f = 0; f < nIF; ++f) {
+        int32_t o = newOfOld[m.owner[f]], n = newOfOld[m.neighbour[f]];
+        const bool flip = o > n;
+        if (flip) std::swap(o, n);
+        keys[f] = Key{o, n, f, flip};
+    }
+    // upper-triangular order: by owner, then by neighbour (ties: old label)
+    std::stable_sort(keys.begin(), keys.end(), [](const Key& a, const Key& b) { return a.o != b.o ? a.o < b.o : a.n < b.n; });
+    std::vector<int32_t> fo((size_t)nF + 1, 0), fp;
+    fp.reserve(m.facePoints.size());
+    std::vector<int32_t> own((size_t)nF), nei((size_t)nIF);
+    for (int32_t k = 0; k < nIF; ++k) {
+        const Key& q = keys[k];
+        const int32_t b = m.faceOffsets[q.old], e = m.faceOffsets[q.old + 1];
+        if (!q.flip) fp.insert(fp.end(), m.facePoints.begin() + b, m.facePoints.begin() + e);
+        else {  // face::reverseFace (L0): the first point stays, the others run backwards
+            fp.push_back(m.facePoints[b]);
+            for (int32_t i = e - 1; i > b; --i) fp.push_back(m.facePoints[i]);
+        }
+        fo[k + 1] = (int32_t)fp.size();
+        own[k] = q.o;
+        nei[k] = q.n;
+        if (faceNewOfOld) faceNewOfOld[q.old] = q.flip ? -1 - k : k;
+    }
+    for (int32_t f = nIF; f < nF; ++f) {
+        fp.insert(fp.end(), m.facePoints.begin() + m.faceOffsets[f], m.facePoints.begin() + m.faceOffsets[f + 1]);
+        fo[f + 1] = (int32_t)fp.size();
+        own[f] = newOfOld[m.owner[f]];
+        if (faceNewOfOld) faceNewOfOld[f] = f;
+    }
+    m.faceOffsets.swap(fo);
+    m.facePoints.swap(fp);
+    m.owner.swap(own);
+    m.neighbour.swap(nei);
+    m.computeGeometry();
+}
+
+std::vector<int32_t> cuthillMcKee(const HostMesh& m) {
+    const int32_t nC = m.nCells;
+    // face-neighbour graph in CSR
+    std::vector<int32_t> off((size_t)nC + 1, 0);
+    for (int32_t f = 0; f < m.nInternalFaces; ++f) { off[m.owner[f] + 1]++; off[m.neighbour[f] + 1]++; }
+    for (int32_t c = 0; c < nC; ++c) off[c + 1] += off[c];
+    std::vector<int32_t> adj((size_t)off[nC]), fill(off.begin(), off.end() - 1);
+    for (int32_t f = 0; f < m.nInternalFaces; ++f) {
+        adj[fill[m.owner[f]]++] = m.neighbour[f];
+        adj[fill[m.neighbour[f]]++] = m.owner[f];
+    }
+    auto degree = [&](int32_t c) { return off[c + 1] - off[c]; };
+    std::vector<int32_t> order;  // visit order
+    order.reserve((size_t)nC);
+    std::vector<uint8_t> seen((size_t)nC, 0);
+    // component seeds in ascending (degree, label): a low-degree cell is a good peripheral start
+    std::vector<int32_t> seeds((size_t)nC);
+    std::iota(seeds.begin(), seeds.end(), 0);
+    std::stable_sort(seeds.begin(), seeds.end(), [&](int32_t a, int32_t b) { return degree(a) < degree(b); });
+    std::vector<int32_t> nb;
+    for (int32_t seed : seeds) {
+        if (seen[seed]) continue;
+        size_t head = order.size();
+        order.push_back(seed);
+        seen[seed] = 1;
+        while (head < order.size()) {
+            const int32_t c = order[head++];
+            nb.clear();
+            for (int32_t k = off[c]; k < off[c + 1]; ++k)
+                if (!seen[adj[k]]) { seen[adj[k]] = 1; nb.push_back(adj[k]); }
+            std::sort(nb.begin(), nb.end(), [&](int32_t a, int32_t b) { return degree(a) != degree(b) ? degree(a) < degree(b) : a < b; });
+            order.insert(order.end(), nb.begin(), nb.end());
+        }
+    }
+    std::vector<int32_t> newOfOld((size_t)nC);
+    for (int32_t k = 0; k < nC; ++k) newOfOld[order[k]] = nC - 1 - k;  // reversed
+    return newOfOld;
+}
+
+HostMesh extractShard(const HostMesh& g, int32_t nRanks, const int32_t* cellStart, int32_t rank) {
+    const int32_t lo = cellStart[rank], hi = cellStart[rank + 1];
+    auto rankOf = [&](int32_t c) { return (int32_t)(std::upper_bound(cellStart, cellStart + nRanks + 1, c) - cellStart) - 1; };
+    auto owned = [&](int32_t c) { return c >= lo && c < hi; };
+    const Csr pc = buildPointCells(g);
+
+    // points touched by the owned cells; every cell around such a point is local (owned or ghost)
+    std::vector<uint8_t> pointOwned((size_t)g.nPoints, 0);
+    for (int32_t f = 0; f < g.nFaces; ++f) {
+        const bool mine = owned(g.owner[f]) || (f < g.nInternalFaces && owned(g.neighbour[f]));
+        if (!mine) continue;
+        for (int32_t k = g.faceOffsets[f]; k < g.faceOffsets[f + 1]; ++k) pointOwned[g.facePoints[k]] = 1;
+    }
+    std::vector<int32_t> localOf((size_t)g.nCells, -1);
+    std::vector<uint8_t> isLocal((size_t)g.nCells, 0);
+    for (int32_t c = lo; c < hi; ++c) isLocal[c] = 1;
+    // send sets: owned cells around a point that a cell of another rank also touches
+    std::vector<std::vector<int32_t>> sendTo((size_t)nRanks);
+    std::vector<int32_t> ranksHere;
+    for (int32_t p = 0; p < g.nPoints; ++p) {
+        if (!pointOwned[p]) continue;
+        ranksHere.clear();
+        for (int32_t k = pc.offsets[p]; k < pc.offsets[p + 1]; ++k) {
+            const int32_t c = pc.items[k];
+            isLocal[c] = 1;
+            if (!owned(c)) ranksHere.push_back(rankOf(c));
+        }
+        if (ranksHere.empty()) continue;
+        std::sort(ranksHere.begin(), ranksHere.end());
+        ranksHere.erase(std::unique(ranksHere.begin(), ranksHere.end()), ranksHere.end());
+        for (int32_t k = pc.offsets[p]; k < pc.offsets[p + 1]; ++k) {
+            const int32_t c = pc.items[k];
+            if (owned(c)) for (int32_t r : ranksHere) sendTo[r].push_back(c);
+        }
+    }
+    HostMesh m;
+    for (int32_t c = 0; c < g.nCells; ++c)
+        if (isLocal[c]) { localOf[c] = m.nCells++; m.cellGlobal.push_back(c); }
+    m.ownedBegin = localOf[lo];
+    m.ownedEnd = m.ownedBegin + (hi - lo);
+
+    // faces: internal (both cells local), real patches, then the halo patch (other cell absent)
+    std::vector<int32_t> pointLocal((size_t)g.nPoints, -1);
+    auto addFace = [&](int32_t f, bool flip) {
+        const int32_t b = g.faceOffsets[f], e = g.faceOffsets[f + 1];
+        if (!flip) for (int32_t k = b; k < e; ++k) m.facePoints.push_back(g.facePoints[k]);
+        else { m.facePoints.push_back(g.facePoints[b]); for (int32_t k = e - 1; k > b; --k) m.facePoints.push_back(g.facePoints[k]); }
+        m.faceOffsets.push_back((int32_t)m.facePoints.size());
+        m.faceGlobal.push_back(flip ? -1 - f : f);
+    };
+    m.faceOffsets.push_back(0);
+    for (int32_t f = 0; f < g.nInternalFaces; ++f) {
+        const int32_t a = localOf[g.owner[f]], b = localOf[g.neighbour[f]];
+        if (a < 0 || b < 0) continue;
+        addFace(f, false);
+        m.owner.push_back(a);
+        m.neighbour.push_back(b);
+    }
+    m.nInternalFaces = (int32_t)m.owner.size();
+    for (const Patch& gp : g.patches) {
+        Patch p = gp;
+        p.start = (int32_t)m.owner.size();
+        for (int32_t f = gp.start; f < gp.start + gp.size; ++f) {
+            const int32_t a = localOf[g.owner[f]];
+            if (a < 0) continue;
+            addFace(f, false);
+            m.owner.push_back(a);
+        }
+        p.size = (int32_t)m.owner.size() - p.start;
+        m.patches.push_back(p);
+    }
+    if (nRanks > 1) {
+        Patch p;
+        p.name = "halo";
+        p.type = QGD_PATCH_HALO;
+        p.start = (int32_t)m.owner.size();
+        for (int32_t f = 0; f < g.nInternalFaces; ++f) {
+            const int32_t a = localOf[g.owner[f]], b = localOf[g.neighbour[f]];
+            if ((a < 0) == (b < 0)) continue;
+            addFace(f, a < 0);  // the local cell becomes the owner; reversed when it was the neighbour
+            m.owner.push_back(a < 0 ? b : a);
+        }
+        p.size = (int32_t)m.owner.size() - p.start;
+        m.patches.push_back(p);
+    }
+    m.nFaces = (int32_t)m.owner.size();
+    // points in ascending global label
+    for (int32_t v : m.facePoints) pointLocal[v] = 0;
+    for (int32_t p = 0; p < g.nPoints; ++p)
+        if (pointLocal[p] == 0) {
+            pointLocal[p] = m.nPoints++;
+            m.pointGlobal.push_back(p);
+            for (int d = 0; d < 3; ++d) m.points.push_back(g.points[3 * (size_t)p + d]);
+        }
+    for (int32_t& v : m.facePoints) v = pointLocal[v];
+
+    // halo slots, one per neighbouring rank in ascending rank order
+    m.cellIsGhost.assign((size_t)m.nCells, 0);
+    std::vector<std::vector<int32_t>> ghostOf((size_t)nRanks);
+    for (int32_t c = 0; c < m.nCells; ++c) {
+        const int32_t gc = m.cellGlobal[c];
+        if (owned(gc)) continue;
+        m.cellIsGhost[c] = 1;
+        ghostOf[rankOf(gc)].push_back(c);
+    }
+    for (int32_t r = 0; r < nRanks; ++r) {
+        std::vector<int32_t>& s = sendTo[r];
+        std::sort(s.begin(), s.end());
+        s.erase(std::unique(s.begin(), s.end()), s.end());
+        if (s.empty() && ghostOf[r].empty()) continue;
+        // sharing a point is symmetric, so rank r's ghost list from this rank is exactly s (same ascending order)
+        for (int32_t& c : s) c = localOf[c];
+        m.haloPeer.push_back(r);
+        m.haloGhost.push_back(ghostOf[r]);
+        m.haloSend.push_back(s);
+    }
+    m.computeGeometry();
+    return m;
+}
+
+}  // namespace qgd

@@ -380,22 +380,25 @@ StaticData buildStaticData(const HostMesh& m) {
     // cell roles of a shard: 0 = ordinary owned cell, 1 = ghost (refreshed by the halo exchange, never updated here),
     // 2 = owned cell whose records a neighbour needs (updated first so the exchange can overlap the rest)
     s.ghost = m.cellIsGhost;
+    const size_t nSlots = m.haloGhost.size();
     if (!s.ghost.empty())
-        for (int side = 0; side < 2; ++side)
-            for (int32_t c : m.haloSend[side]) s.ghost[c] = 2;
+        for (size_t slot = 0; slot < nSlots; ++slot)
+            for (int32_t c : m.haloSend[slot]) s.ghost[c] = 2;
 
     // ---- halo lists (cells + their real-patch boundary faces, ascending) -----
-    for (int side = 0; side < 2; ++side) {
-        s.haloGhost[side] = m.haloGhost[side];
-        s.haloSend[side] = m.haloSend[side];
+    s.haloGhost = m.haloGhost;
+    s.haloSend = m.haloSend;
+    s.haloGhostBF.assign(nSlots, {});
+    s.haloSendBF.assign(nSlots, {});
+    for (size_t slot = 0; slot < nSlots; ++slot) {
         std::vector<uint8_t> isG((size_t)nC, 0), isS((size_t)nC, 0);
-        for (int32_t c : m.haloGhost[side]) isG[c] = 1;
-        for (int32_t c : m.haloSend[side]) isS[c] = 1;
+        for (int32_t c : m.haloGhost[slot]) isG[c] = 1;
+        for (int32_t c : m.haloSend[slot]) isS[c] = 1;
         for (int64_t b = 0; b < nBF; ++b) {
             if (patchType[b] == QGD_PATCH_HALO) continue;
             const int32_t o = m.owner[nIF + b];
-            if (isG[o]) s.haloGhostBF[side].push_back((int32_t)b);
-            if (isS[o]) s.haloSendBF[side].push_back((int32_t)b);
+            if (isG[o]) s.haloGhostBF[slot].push_back((int32_t)b);
+            if (isS[o]) s.haloSendBF[slot].push_back((int32_t)b);
         }
     }
     return s;

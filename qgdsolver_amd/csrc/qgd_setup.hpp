@@ -78,7 +78,7 @@ struct StaticData {
     std::vector<double> hQGDb;    // nBF: hQGD boundary (= hQGDf boundary)
 
     // ---- halo -----------------------------------------------------------------
-    std::vector<int32_t> haloGhost[2], haloSend[2], haloGhostBF[2], haloSendBF[2];
+    std::vector<std::vector<int32_t>> haloGhost, haloSend, haloGhostBF, haloSendBF;  // one entry per halo slot
 
     int64_t bytes() const;
 };

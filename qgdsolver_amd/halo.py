@@ -24,13 +24,15 @@ class SlabHalo:
     ``arg(tensor)`` turns it into what ``case.halo_pack/unpack`` take (a device pointer for the HIP case).
     """
 
-    def __init__(self, case, rank, world, dist, alloc, arg):
+    def __init__(self, case, rank, world, dist, alloc, arg, peers=None):
         self.case, self.rank, self.world, self.dist = case, rank, world, dist
         self.arg = arg
-        self.sides = [s for s, peer in ((0, rank - 1), (1, rank + 1)) if 0 <= peer < world]
-        self.peer = {0: rank - 1, 1: rank + 1}
+        if peers is None:  # box slab: slot 0 = lower, slot 1 = upper neighbour
+            peers = {0: rank - 1, 1: rank + 1}
+        self.peer = dict(peers)
+        self.sides = [s for s, peer in sorted(self.peer.items()) if 0 <= peer < world]
         self.send = {s: alloc(case.halo_count(s)) for s in self.sides}
-        self.recv = {s: alloc(case.halo_count(s)) for s in self.sides}
+        self.recv = {s: alloc(case.halo_recv_count(s)) for s in self.sides}
 
     def exchange(self):
         if not self.sides:
@@ -70,3 +72,12 @@ class SlabHalo:
             self.exchange()
         self.case.step_phase(11)
         compute_stream.wait_stream(halo_stream)
+
+
+class RangeHalo(SlabHalo):
+    """Halo exchange for a case on a ``PolyMesh.shard`` mesh (any polyMesh cut into contiguous cell ranges): one
+    message per neighbouring rank per step, the neighbours being whoever shares a vertex with the owned range."""
+
+    def __init__(self, case, rank, world, dist, alloc, arg):
+        peers = {slot: int(p) for slot, p in enumerate(case.mesh.array("haloPeer"))}
+        super().__init__(case, rank, world, dist, alloc, arg, peers=peers)

@@ -6,7 +6,7 @@ import numpy as np
 from . import _lib as L
 
 _INT_ARRAYS = {"faceOffsets", "facePoints", "owner", "neighbour", "patchStart", "patchSize", "patchType",
-               "haloGhost0", "haloGhost1", "haloSend0", "haloSend1"}
+               "haloPeer", "cellGlobal", "faceGlobal", "pointGlobal"}
 
 
 def _dp(a):
@@ -61,20 +61,21 @@ class PolyMesh:
 
     # ---- access ---------------------------------------------------------------
     def array(self, name):
-        n = {
-            "points": 3 * self.nPoints, "faceOffsets": self.nFaces + 1, "facePoints": self.nFacePoints,
-            "owner": self.nFaces, "neighbour": self.nInternalFaces, "patchStart": self.nPatches,
-            "patchSize": self.nPatches, "patchType": self.nPatches, "Sf": 3 * self.nFaces, "magSf": self.nFaces,
-            "Cf": 3 * self.nFaces, "C": 3 * self.nCells, "V": self.nCells, "weights": self.nFaces,
-            "deltaCoeffs": self.nFaces, "nonOrthDeltaCoeffs": self.nFaces,
-            "haloGhost0": self.nCells, "haloGhost1": self.nCells, "haloSend0": self.nCells, "haloSend1": self.nCells,
-        }[name]
-        dt = np.int32 if name in _INT_ARRAYS else np.float64
-        out = np.full(max(n, 1), -1 if dt == np.int32 else 0, dtype=dt)
-        L.check(L.lib.qgd_mesh_get(self._h, name.encode(), out.ctypes.data_as(C.c_void_p), out.nbytes), f"qgd_mesh_get({name})")
-        if name.startswith("halo"):
-            return out[out >= 0]
-        return out[:n]
+        """named array of qgd_mesh_get (sizes are asked from the library)"""
+        nbytes = C.c_int64()
+        L.check(L.lib.qgd_mesh_get(self._h, name.encode(), C.byref(nbytes), -1), f"qgd_mesh_get({name})")
+        integer = name in _INT_ARRAYS or name.startswith("haloGhost") or name.startswith("haloSend")
+        dt = np.int32 if integer else np.float64
+        out = np.zeros(nbytes.value // np.dtype(dt).itemsize, dtype=dt)
+        if out.size:
+            L.check(L.lib.qgd_mesh_get(self._h, name.encode(), out.ctypes.data_as(C.c_void_p), out.nbytes), f"qgd_mesh_get({name})")
+        return out
+
+    @property
+    def halo_slots(self):
+        n = C.c_int32()
+        L.check(L.lib.qgd_mesh_halo_slots(self._h, C.byref(n)), "qgd_mesh_halo_slots")
+        return n.value
 
     def primitives(self):
         """Arrays in the order qgd_mesh_create / orc_mesh_create take them."""
@@ -95,6 +96,36 @@ class PolyMesh:
         L.check(L.lib.qgd_mesh_split_edges(self._h, int(stride)), "qgd_mesh_split_edges")
         self.__init__(self._h)
         return self
+
+    # ---- renumbering / cell-range sharding ---------------------------------------
+    def rcm_order(self):
+        """newOfOld of a reverse Cuthill-McKee ordering (bandwidth reduction before cutting cell ranges)"""
+        out = np.zeros(self.nCells, dtype=np.int32)
+        L.check(L.lib.qgd_mesh_rcm_order(self._h, _ip(out)), "qgd_mesh_rcm_order")
+        return out
+
+    def renumber(self, new_of_old):
+        """relabel the cells in place; returns faceNewOfOld (new face label, or -1-label where the face was reversed)"""
+        perm = np.ascontiguousarray(new_of_old, dtype=np.int32)
+        assert perm.size == self.nCells
+        face_map = np.zeros(self.nFaces, dtype=np.int32)
+        L.check(L.lib.qgd_mesh_renumber(self._h, _ip(perm), _ip(face_map)), "qgd_mesh_renumber")
+        self.__init__(self._h)
+        return face_map
+
+    def shard(self, n_ranks, rank, cell_start=None):
+        """the shard of ``rank``: owned cell range + one vertex-connected ghost layer + halo slots per neighbour"""
+        if cell_start is None:
+            cell_start = [(self.nCells * r) // n_ranks for r in range(n_ranks + 1)]
+        cs = np.ascontiguousarray(cell_start, dtype=np.int32)
+        assert cs.size == n_ranks + 1
+        h = C.c_void_p()
+        L.check(L.lib.qgd_mesh_shard(self._h, int(n_ranks), _ip(cs), int(rank), C.byref(h)), "qgd_mesh_shard")
+        out = PolyMesh(h)
+        names = getattr(self, "patch_names", None)
+        if names:
+            out.patch_names = list(names) + (["halo"] if n_ranks > 1 else [])
+        return out
 
     def close(self):
         if self._h:

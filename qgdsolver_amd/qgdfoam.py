@@ -140,9 +140,15 @@ class QGDFoamCase:
         return dict(time=a[0], deltaT=a[1], CoNum=a[2], minRho=a[3], minE=a[4], steps=int(a[5]))
 
     # ---- halo ------------------------------------------------------------------
-    def halo_count(self, side):
+    def halo_count(self, slot):
+        """doubles in the message sent to the neighbour behind halo slot ``slot``"""
         n = C.c_int64()
-        L.check(L.lib.qgd_case_halo_count(self._h, side, C.byref(n)), "qgd_case_halo_count")
+        L.check(L.lib.qgd_case_halo_count(self._h, slot, C.byref(n)), "qgd_case_halo_count")
+        return n.value
+
+    def halo_recv_count(self, slot):
+        n = C.c_int64()
+        L.check(L.lib.qgd_case_halo_recv_count(self._h, slot, C.byref(n)), "qgd_case_halo_recv_count")
         return n.value
 
     def halo_pack(self, side, dev_ptr):

@@ -48,6 +48,7 @@ lib.orc_case_step.argtypes = [C.c_void_p, C.c_int32]
 lib.orc_case_get_field.argtypes = [C.c_void_p, C.c_char_p, dp, C.c_int64]
 lib.orc_case_info.argtypes = [C.c_void_p, dp]
 lib.orc_case_halo_count.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]
+lib.orc_case_halo_recv_count.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]
 lib.orc_case_halo_pack.argtypes = [C.c_void_p, C.c_int, dp]
 lib.orc_case_halo_unpack.argtypes = [C.c_void_p, C.c_int, dp]
 lib.orc_case_step_phase.argtypes = [C.c_void_p, C.c_int]
@@ -199,6 +200,11 @@ class OracleCase:
     def halo_count(self, side):
         n = C.c_int64()
         lib.orc_case_halo_count(self._h, side, C.byref(n))
+        return n.value
+
+    def halo_recv_count(self, side):
+        n = C.c_int64()
+        lib.orc_case_halo_recv_count(self._h, side, C.byref(n))
         return n.value
 
     def halo_pack(self, side, buf):
