@@ -525,6 +525,33 @@ void faceFluxGvp3Kernel(const MeshView m, const CaseView c, const GasModel gm, c
 #pragma unroll
                 for (int d = 0; d < 3; ++d) g[d * 6 + k] = A5[d] * D5 + A0[d] * D0 + A1[d] * D1;
             }
+        } else if (kind == 1) {
+            // Triangle [GaussVolPointBase3D_8C L193-229, L844-854], out of the records already in registers: the same
+            // operations in the same order as faceGradient<ST_GVP3> (no second round of loads in mixed wavefronts)
+            double t[12], rV;
+            gvpTriCoef(cO, cN, x0, x1, x2, t, rV);
+            double p0[6], p1[6], p2[6];
+            loadVals(q0, p0); loadVals(q1, p1); loadVals(q2, p2);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const double a0 = t[4 * d], a1 = t[4 * d + 1], a2 = t[4 * d + 2], a3 = t[4 * d + 3];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    double sg = v.n[k] * a3;
+                    sg += v.o[k] * (-a3);
+                    sg += p0[k] * a0;
+                    sg += p1[k] * a1;
+                    sg += p2[k] * a2;
+                    g[d * 6 + k] = sg * rV;
+                }
+            }
+            double dg[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) dg[j] = g[j * 6 + 1 + j];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) g[i * 6 + 1 + j] = dg[j];
         } else {
             faceGradient<ST_GVP3, 6, 1>(m, f, v, reinterpret_cast<const double*>(c.A), reinterpret_cast<const double*>(c.P), g);
         }

@@ -45,3 +45,29 @@ def test_sharded_oracle_matches_unsharded(tmp_path, world, adjust):
             # ghost-plane geometry differs from the global mesh in the last bit (see tests/test_mesh.py), hence not exact
             assert np.abs(d[f] - ref).max() <= 1e-13 * np.abs(ref).max(), (rank, f, np.abs(d[f] - ref).max())
     assert covered == n
+
+
+@pytest.mark.parametrize("kind,stencil,world", [("box654_poly", "GaussVolPoint", 3), ("step2d", "leastSquares", 4)])
+def test_range_sharded_oracle_matches_unsharded(tmp_path, kind, stencil, world):
+    """any mesh cut into contiguous cell ranges (PolyMesh.shard + RangeHalo): several neighbours per rank"""
+    from test_partition import case_setup, run_oracle
+
+    steps = 6
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(29520 + world), os.path.join(ROOT, "tests", "range_halo_worker.py"), str(tmp_path), kind, stencil, str(steps)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    g, bc_fn, (U, T, p), opt = case_setup(kind)
+    ref = run_oracle(g, stencil, bc_fn, U, T, p, steps, **opt)
+    covered, most_peers = 0, 0
+    for rank in range(world):
+        d = np.load(os.path.join(tmp_path, f"rank{rank}.npz"))
+        covered += d["cells"].size
+        most_peers = max(most_peers, d["peers"].size)
+        for f in ("rho", "U", "p", "e"):
+            want = ref[f][d["cells"]]
+            assert np.abs(d[f] - want).max() <= 1e-12 * np.abs(ref[f]).max(), (rank, f)
+    assert covered == g.nCells
+    if kind == "box654_poly":
+        assert most_peers >= 2  # the renumbered mesh gives every rank more than one neighbour

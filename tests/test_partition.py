@@ -194,6 +194,20 @@ def test_sharded_oracle_on_arbitrary_meshes(kind, stencil, world, bc_fn, opt):
         assert np.abs(got[f] - ref[f]).max() <= 1e-12 * np.abs(ref[f]).max(), (kind, stencil, f)
 
 
+def case_setup(kind):
+    """(global mesh, BC function, initial fields, options) shared with tests/range_halo_worker.py"""
+    g = make_mesh(kind)
+    if kind == "box654_poly":
+        g.renumber(random_perm(g.nCells, 21))
+    C = g.array("C").reshape(-1, 3)
+    if kind == "step2d":
+        U = np.zeros((g.nCells, 3)); U[:, 0] = 3.0
+        T = 1.0 + 0.05 * np.sin(2.0 * C[:, 0]) * np.cos(3.0 * C[:, 1])
+        p = 1.0 + 0.05 * np.cos(1.5 * C[:, 0] + C[:, 1])
+        return g, cases.forward_step_bcs, (U, T, p), dict(deltaT=5e-4)
+    return g, mixed_bcs, cases.box_initial_fields(C), dict(deltaT=1e-3, mu=1e-3)
+
+
 def test_uneven_ranges_and_bad_arguments():
     g = make_mesh("box654")
     U, T, p = cases.box_initial_fields(g.array("C").reshape(-1, 3))
