@@ -156,11 +156,15 @@ int qgd_mesh_split_edges(qgd_mesh_t m, int32_t stride);
 /* ---- renumbering and cell-range sharding of any polyMesh ("ranges after a bandwidth-reducing
  * renumbering"; stands in for OpenFOAM's renumberMesh / decomposePar, which are not part of the reference tree) ---- */
 /* Relabel the cells in place, newOfOld[old cell] = new cell (a permutation).  Internal faces are re-oriented and
- * re-sorted into upper-triangular order, boundary faces keep their labels.  faceNewOfOld (nFaces, may be NULL)
+ * re-sorted into upper-triangular order, boundary faces keep their labels, points are relabelled to follow their
+ * cells (by the lowest new cell label using them).  faceNewOfOld (nFaces, may be NULL)
  * receives each old face's new label, or -1-label when the face was reversed (fluxes change sign). */
 int qgd_mesh_renumber(qgd_mesh_t m, const int32_t* newOfOld, int32_t* faceNewOfOld);
 /* newOfOld (nCells) of a reverse Cuthill-McKee ordering of the face-neighbour graph. */
 int qgd_mesh_rcm_order(qgd_mesh_t m, int32_t* newOfOld);
+/* newOfOld (nCells) of the Morton (Z-curve) order of the cell centres: spatial neighbours stay close in memory at
+ * every scale (cache locality on the device); also a reasonable order to cut cell ranges from. */
+int qgd_mesh_morton_order(qgd_mesh_t m, int32_t* newOfOld);
 /* The shard of `rank` when the cells of `global` are cut into the contiguous ranges cellStart[r]..cellStart[r+1]
  * (cellStart[0]=0, cellStart[nRanks]=nCells): owned cells + one vertex-connected ghost layer (what
  * volPointInterpolation and the leastSquares stencil reach, extendedFaceStencilFindNeighbours_8C_source.html L55-80),

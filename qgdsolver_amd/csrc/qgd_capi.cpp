@@ -372,6 +372,14 @@ int qgd_mesh_rcm_order(qgd_mesh_t mh, int32_t* newOfOld) {
     return QGD_OK;
     QGD_CATCH
 }
+int qgd_mesh_morton_order(qgd_mesh_t mh, int32_t* newOfOld) {
+    QGD_TRY
+    if (!mh || !newOfOld) return fail(QGD_ERR_INVALID, "qgd_mesh_morton_order: null argument");
+    const std::vector<int32_t> order = mortonOrder(mh->m);
+    std::memcpy(newOfOld, order.data(), sizeof(int32_t) * order.size());
+    return QGD_OK;
+    QGD_CATCH
+}
 int qgd_mesh_shard(qgd_mesh_t global, int32_t nRanks, const int32_t* cellStart, int32_t rank, qgd_mesh_t* out) {
     QGD_TRY
     if (!global || !cellStart || !out) return fail(QGD_ERR_INVALID, "qgd_mesh_shard: null argument");

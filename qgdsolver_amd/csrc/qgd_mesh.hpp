@@ -97,6 +97,8 @@ void splitEdges(HostMesh& m, int32_t stride);
 void renumberCells(HostMesh& m, const int32_t* newOfOld, int32_t* faceNewOfOld);
 // reverse Cuthill-McKee order over the face-neighbour graph (bandwidth reduction before cell-range sharding)
 std::vector<int32_t> cuthillMcKee(const HostMesh& m);
+// Morton (Z-curve) order of the cell centres
+std::vector<int32_t> mortonOrder(const HostMesh& m);
 // The shard of rank `rank` when the cells are cut into the ranges cellStart[r] .. cellStart[r+1]: its owned cells plus
 // one vertex-connected layer of ghost cells, every face of those cells (faces whose other cell is absent form a trailing
 // QGD_PATCH_HALO patch), halo lists per neighbouring rank.

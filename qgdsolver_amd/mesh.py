@@ -104,6 +104,12 @@ class PolyMesh:
         L.check(L.lib.qgd_mesh_rcm_order(self._h, _ip(out)), "qgd_mesh_rcm_order")
         return out
 
+    def morton_order(self):
+        """newOfOld of the Morton (Z-curve) order of the cell centres"""
+        out = np.zeros(self.nCells, dtype=np.int32)
+        L.check(L.lib.qgd_mesh_morton_order(self._h, _ip(out)), "qgd_mesh_morton_order")
+        return out
+
     def renumber(self, new_of_old):
         """relabel the cells in place; returns faceNewOfOld (new face label, or -1-label where the face was reversed)"""
         perm = np.ascontiguousarray(new_of_old, dtype=np.int32)

@@ -65,3 +65,9 @@ t1 = time.perf_counter()
 mesh.renumber(order)
 print(f"rcm: order {t1 - t0:.1f} s, renumber {time.perf_counter() - t1:.1f} s", flush=True)
 run(mesh, "rcm", steps)
+t0 = time.perf_counter()
+order = mesh.morton_order()
+t1 = time.perf_counter()
+mesh.renumber(order)
+print(f"morton: order {t1 - t0:.1f} s, renumber {time.perf_counter() - t1:.1f} s", flush=True)
+run(mesh, "morton", steps)

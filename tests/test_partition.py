@@ -84,6 +84,32 @@ def test_rcm_reduces_the_bandwidth_of_a_shuffled_mesh():
     assert bandwidth(mesh) < shuffled / 3 and bandwidth(mesh) <= 2 * natural
 
 
+def test_morton_order_restores_locality():
+    """Z-curve order of the cell centres: a permutation that brings face neighbours (and, through renumber, the
+    vertices of a cell) back together after a random relabelling"""
+    mesh = q.PolyMesh.box(16, 16, 16)
+    mesh.renumber(random_perm(mesh.nCells, 8))
+
+    def mean_gap(m):
+        return float(np.abs(m.array("neighbour").astype(np.int64) - m.array("owner")[:m.nInternalFaces]).mean())
+
+    def vertex_spread(m):
+        fp, fo = m.array("facePoints").astype(np.int64), m.array("faceOffsets")
+        quads = fp.reshape(-1, 4)  # a hex box has quads only
+        assert fo[-1] == quads.size
+        return float((quads.max(axis=1) - quads.min(axis=1)).mean())
+
+    gap0, spread0 = mean_gap(mesh), vertex_spread(mesh)
+    order = mesh.morton_order()
+    assert sorted(order) == list(range(mesh.nCells))
+    mesh.renumber(order)
+    assert mean_gap(mesh) < gap0 / 5 and vertex_spread(mesh) < spread0 / 5
+    # 8 consecutive labels form a 2x2x2 brick
+    Cc = mesh.array("C").reshape(-1, 3)
+    brick = Cc[:8]
+    assert np.allclose(brick.max(axis=0) - brick.min(axis=0), 1.0 / 16, atol=1e-12)
+
+
 def shards_of(gmesh, world, cell_start=None):
     return [gmesh.shard(world, r, cell_start) for r in range(world)]
 
