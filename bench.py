@@ -207,28 +207,11 @@ def main():
                         arg=lambda t: t.data_ptr())
         exchange = halo.exchange
     else:
-        class Staged(SlabHalo):
-            """host-staged variant for the gloo debugging mode"""
+        from qgdsolver_amd.halo import HostStaged
 
-            def exchange(self):
-                if not self.sides:
-                    return
-                dev_s = {s: torch.empty_like(self.send[s], device="cuda") for s in self.sides}
-                for s in self.sides:
-                    self.case.halo_pack(s, dev_s[s].data_ptr())
-                torch.cuda.synchronize()
-                for s in self.sides:
-                    self.send[s].copy_(dev_s[s])
-                ops = []
-                for s in self.sides:
-                    ops.append(self.dist.P2POp(self.dist.isend, self.send[s], self.peer[s]))
-                    ops.append(self.dist.P2POp(self.dist.irecv, self.recv[s], self.peer[s]))
-                for w in self.dist.batch_isend_irecv(ops):
-                    w.wait()
-                for s in self.sides:
-                    dev_s[s].copy_(self.recv[s])
-                    self.case.halo_unpack(s, dev_s[s].data_ptr())
-                torch.cuda.synchronize()
+        class Staged(HostStaged, SlabHalo):
+            """host-staged variant for the gloo debugging mode"""
+            torch = __import__("torch")
 
         halo = Staged(case, rank, world, dist, alloc=lambda c: torch.empty(c, dtype=torch.float64), arg=None)
         exchange = halo.exchange

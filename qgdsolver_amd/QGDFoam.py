@@ -47,14 +47,98 @@ def find_start_time(case_dir, cd):
     raise ff.FoamFileError(f"{case_dir}: no time directory for startTime {want}")
 
 
-def run(case_dir, n_steps=None, device_id=0, write=True, log=print):
+def _distributed():
+    """(rank, world, local_rank) from the torch.distributed.run environment"""
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def run(case_dir, n_steps=None, device_id=0, write=True, log=print, renumber="none", backend="nccl"):
+    """One rank of the run.  With WORLD_SIZE > 1 (``python -m torch.distributed.run ... -m qgdsolver_amd.QGDFoam``) the
+    undecomposed case is read by every rank, relabelled (``renumber``: none | rcm | morton), cut into contiguous cell
+    ranges (``PolyMesh.shard``) and advanced with one halo message per neighbouring rank per step (``halo.RangeHalo``
+    over RCCL; backend "gloo" stages the messages through host memory and lets all ranks share GPU 0: a debugging
+    aid).  Rank 0 gathers the owned cells and writes the time directories in the case's own cell order."""
+    rank, world, local_rank = _distributed()
+    if rank != 0:
+        log = lambda *a, **k: None  # noqa: E731
     cd = ff.read_dict(os.path.join(case_dir, "system", "controlDict"))
     t0, t0_name = find_start_time(case_dir, cd)
-    dev, case = ff.load_case(case_dir, t0_name, device_id)
-    _, _, _, bcs = ff.read_case_setup(case_dir, t0_name)
+    from .fvsc import Device
+    from .qgdfoam import QGDFoamCase, default_options
+
+    gmesh, opt, fields, bcs = ff.read_case_setup(case_dir, t0_name)
+    n_global = gmesh.nCells
+    new_of_old = np.arange(n_global, dtype=np.int32)
+    if renumber != "none":
+        new_of_old = gmesh.rcm_order() if renumber == "rcm" else gmesh.morton_order()
+        gmesh.renumber(new_of_old)
+    old_of_new = np.argsort(new_of_old)
+    dist = halo = torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        from .halo import HostStaged, RangeHalo
+
+        staged = backend == "gloo"
+        device_id = 0 if staged else local_rank
+        torch.cuda.set_device(device_id)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if staged:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_id))
+        mesh = gmesh.shard(world, rank)
+        cells = old_of_new[mesh.array("cellGlobal")]  # labels in the case files of the shard's cells
+        lo, hi = (n_global * rank) // world, (n_global * (rank + 1)) // world
+        owned = (mesh.array("cellGlobal") >= lo) & (mesh.array("cellGlobal") < hi)
+    else:
+        mesh, cells, owned = gmesh, old_of_new, np.ones(n_global, dtype=bool)
+    dev = Device(mesh, device_id, fv_schemes={"fvsc": {"default": opt["stencil"]}})
+    case = QGDFoamCase(dev, default_options(**opt))
+    for i, bc in enumerate(bcs):
+        case.set_bc(i, U=bc["U"], T=bc["T"], p=bc["p"])
+    case.set_fields(fields["U"][cells], fields["T"][cells], fields["p"][cells])
+    adjust = bool(case.options.adjustTimeStep)
+    if world > 1:
+        case.set_stream(torch.cuda.current_stream().cuda_stream)
+        if staged:
+            class Halo(HostStaged, RangeHalo):
+                pass
+            Halo.torch = torch
+            halo = Halo(case, rank, world, dist, alloc=lambda c: torch.empty(c, dtype=torch.float64), arg=None)
+        else:
+            halo = RangeHalo(case, rank, world, dist, alloc=lambda c: torch.empty(c, dtype=torch.float64, device="cuda"),
+                             arg=lambda t: t.data_ptr())
+        halo.exchange()
+        from .halo import allreduce_max_of
+        allreduce_max = allreduce_max_of(torch, dist, case, staged)
+
+    def advance(n):
+        if world == 1:
+            case.step(n)
+            return
+        for _ in range(n):
+            halo.step(allreduce_max if adjust else None)
+        case.sync()
+
+    def gather(name):
+        """owned cells of every rank -> the field in the case's own cell order (rank 0; None elsewhere)"""
+        local = case.field(name)
+        if world == 1:
+            out = np.empty_like(local)
+            out[cells] = local
+            return out
+        parts = [None] * world if rank == 0 else None
+        dist.gather_object((cells[owned], local[owned]), parts, dst=0)
+        if rank != 0:
+            return None
+        out = np.empty((n_global,) + local.shape[1:])
+        for idx, vals in parts:
+            out[idx] = vals
+        return out
+
     dt = float(cd["deltaT"])
     end_time = float(cd["endTime"])
-    adjust = bool(case.options.adjustTimeStep)
     control = str(cd.get("writeControl", "timeStep"))
     interval = float(cd.get("writeInterval", 1))
     precision = int(cd.get("timePrecision", 6))
@@ -65,8 +149,8 @@ def run(case_dir, n_steps=None, device_id=0, write=True, log=print):
     else:
         raise ff.FoamFileError(f"writeControl '{control}' with adjustTimeStep is not supported (use writeControl timeStep)")
     total = n_steps if n_steps is not None else (None if adjust else int(round((end_time - t0) / dt)))
-    log(f"QGDFoam (qgdsolver_amd, explicit branch): {case.mesh.nCells} cells, fvsc {case.dev.fvSchemes['fvsc']['default']}, "
-        f"deltaT {dt:g}, start {t0_name}")
+    log(f"QGDFoam (qgdsolver_amd, explicit branch): {n_global} cells on {world} rank(s), fvsc {opt['stencil']}, "
+        f"deltaT {dt:g}, start {t0_name}, cell order {renumber}")
     done = 0
     wall0 = _time.perf_counter()
     written = []
@@ -74,9 +158,14 @@ def run(case_dir, n_steps=None, device_id=0, write=True, log=print):
         if total is not None and done >= total:
             break
         n = chunk if total is None else min(chunk, total - done)
-        case.step(n)
+        advance(n)
         done += n
         info = case.info()
+        if world > 1:
+            mins = [None] * world
+            dist.all_gather_object(mins, (info["minRho"], info["minE"], info["CoNum"]))
+            info["minRho"], info["minE"] = min(m[0] for m in mins), min(m[1] for m in mins)
+            info["CoNum"] = max(m[2] for m in mins)
         t = t0 + info["time"]
         log(f"Time = {time_name(t, precision)}  steps {done}  deltaT {info['deltaT']:.6g}  Courant max {info['CoNum']:.6g}  "
             f"min rho {info['minRho']:.6g}  min e {info['minE']:.6g}  ClockTime {_time.perf_counter() - wall0:.2f} s")
@@ -84,12 +173,37 @@ def run(case_dir, n_steps=None, device_id=0, write=True, log=print):
             raise FloatingPointError(f"density lost positivity at time {t:g}")
         if write:
             name = time_name(t, precision)
-            ff.write_time(case, case_dir, name, bcs)
+            data = {f: gather(f) for f in ("U", "T", "p", "rho")}
+            if rank == 0:
+                _write_cell_fields(case_dir, name, data, bcs, gmesh)
             written.append(name)
         if total is None and t >= end_time - 1e-12 * max(1.0, abs(end_time)):
             break
     log("End")
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
     return dev, case, written
+
+
+def _write_cell_fields(case_dir, name, data, bcs, file_mesh):
+    """Time directory from gathered cell fields.  Patch entries carry the BC type; values of fixedValue patches are
+    the prescribed ones, the others are written without a value (the solver evaluates them at start-up)."""
+    dims = {"U": "[0 1 -1 0 0 0 0]", "T": "[0 0 0 1 0 0 0]", "p": "[1 -1 -2 0 0 0 0]", "rho": "[1 -3 0 0 0 0 0]"}
+    names = file_mesh.patch_names
+    pt = file_mesh.array("patchType")
+    for fname, values in data.items():
+        patches = {}
+        for i, pn in enumerate(names):
+            word = ff.PATCH_WORDS.get(int(pt[i]), "patch")
+            if word in ff._CONSTRAINT_BCS:
+                patches[pn] = (word, None)
+                continue
+            kind, val = bcs[i].get(fname, ("calculated", None)) if fname != "rho" else ("calculated", None)
+            if kind == "none":
+                kind = "calculated"
+            patches[pn] = (kind, np.asarray(val, dtype=np.float64) if (kind == "fixedValue" and val is not None) else None)
+        ff.write_field(os.path.join(case_dir, str(name), fname), file_mesh, fname, values, patches, dims[fname])
 
 
 def main(argv=None):
@@ -98,8 +212,12 @@ def main(argv=None):
     ap.add_argument("-nSteps", dest="n_steps", type=int, default=None, help="run this many steps instead of up to endTime")
     ap.add_argument("-device", dest="device", type=int, default=0)
     ap.add_argument("-noWrite", dest="no_write", action="store_true")
+    ap.add_argument("-renumber", dest="renumber", default="none", choices=["none", "rcm", "morton"],
+                    help="relabel the cells on the device side (results are written in the case's own order)")
+    ap.add_argument("-backend", dest="backend", default="nccl", choices=["nccl", "gloo"],
+                    help="multi-rank transport; gloo = host-staged messages, all ranks on GPU 0 (debugging)")
     a = ap.parse_args(argv)
-    dev, case, _ = run(a.case, a.n_steps, a.device, not a.no_write)
+    dev, case, _ = run(a.case, a.n_steps, a.device, not a.no_write, renumber=a.renumber, backend=a.backend)
     case.close()
     dev.close()
     return 0

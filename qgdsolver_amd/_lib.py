@@ -6,6 +6,7 @@ library is missing, importing this module raises.
 """
 import ctypes as C
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libqgd_amd.so")
@@ -16,6 +17,14 @@ if not os.path.exists(LIB_PATH):
         "(python -c 'import __graft_entry__ as g; g.build()' or make -C qgdsolver_amd/csrc). "
         "qgdsolver_amd has no CPU fallback."
     )
+
+# torch ships its own copy of the HIP runtime; when both live in one process torch's has to be loaded first (otherwise
+# the second runtime sees no devices).  Multi-rank runs always use torch.distributed, so load it before the library.
+if int(os.environ.get("WORLD_SIZE", "1")) > 1 and "torch" not in sys.modules:
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
 
 lib = C.CDLL(LIB_PATH)
 

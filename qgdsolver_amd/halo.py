@@ -74,6 +74,65 @@ class SlabHalo:
         compute_stream.wait_stream(halo_stream)
 
 
+class _DeviceBuffer:
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+
+def device_tensor(torch, ptr, n):
+    """float64 torch view of ``n`` doubles of library-owned device memory (no copy), e.g. ``case.reduction_ptr()``"""
+    return torch.as_tensor(_DeviceBuffer(ptr, n), device="cuda")
+
+
+def allreduce_max_of(torch, dist, case, staged=False):
+    """The MAX all-reduce of the {max Co, -min tauQGDf} buffer that QGDCourantNo.H / setDeltaT-QGDQHD.H need across
+    shards (their ``reduce(..., maxOp)`` / ``gMin``), applied to the case's device buffer in place.  Returns the
+    callable ``SlabHalo.step`` takes."""
+    view = device_tensor(torch, case.reduction_ptr(), 2)
+
+    def run(_case):
+        if staged:
+            _case.sync()
+            host = view.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.MAX)
+            view.copy_(host)
+            torch.cuda.synchronize()
+        else:
+            dist.all_reduce(view, op=dist.ReduceOp.MAX)
+
+    return run
+
+
+class HostStaged:
+    """Mixin for transports that cannot take device buffers (the gloo debugging mode: every rank may even share one
+    GPU): pack into a device buffer, stage through host tensors, unpack from a device buffer.  ``alloc`` must return
+    host tensors; ``torch`` is passed in by the caller."""
+
+    torch = None
+
+    def exchange(self):
+        if not self.sides:
+            return
+        torch = self.torch
+        dev_s = {s: torch.empty(self.send[s].numel(), dtype=torch.float64, device="cuda") for s in self.sides}
+        dev_r = {s: torch.empty(self.recv[s].numel(), dtype=torch.float64, device="cuda") for s in self.sides}
+        for s in self.sides:
+            self.case.halo_pack(s, dev_s[s].data_ptr())
+        torch.cuda.synchronize()
+        for s in self.sides:
+            self.send[s].copy_(dev_s[s])
+        ops = []
+        for s in self.sides:
+            ops.append(self.dist.P2POp(self.dist.isend, self.send[s], self.peer[s]))
+            ops.append(self.dist.P2POp(self.dist.irecv, self.recv[s], self.peer[s]))
+        for w in self.dist.batch_isend_irecv(ops):
+            w.wait()
+        for s in self.sides:
+            dev_r[s].copy_(self.recv[s])
+            self.case.halo_unpack(s, dev_r[s].data_ptr())
+        torch.cuda.synchronize()
+
+
 class RangeHalo(SlabHalo):
     """Halo exchange for a case on a ``PolyMesh.shard`` mesh (any polyMesh cut into contiguous cell ranges): one
     message per neighbouring rank per step, the neighbours being whoever shares a vertex with the owned range."""

@@ -108,3 +108,37 @@ def test_application_and_reference_run_comparison(tmp_path):
     ff.write_field(os.path.join(ref_dir, "rho"), mesh, "rho", rho, calc)
     r = subprocess.run([sys.executable, script, case_dir, "0", "0.01"], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 1 and "PARITY FAILED" in r.stdout
+
+
+@pytest.mark.parametrize("world,renumber,adjust", [(3, "morton", "no"), (2, "rcm", "yes")])
+def test_application_on_several_ranks(tmp_path, world, renumber, adjust):
+    """torch.distributed.run -m qgdsolver_amd.QGDFoam on W ranks (gloo-staged halo messages, all ranks on this one GPU),
+    cells relabelled on the device side: the written time directory equals the single-rank run's to rounding."""
+    import shutil
+    import subprocess
+    import sys
+
+    one = str(tmp_path / "one")
+    many = str(tmp_path / "many")
+    os.makedirs(one)
+    mesh = write_step_case(one, "GaussVolPoint")
+    cd = os.path.join(one, "system", "controlDict")
+    text = open(cd).read().replace("adjustTimeStep no;", f"adjustTimeStep {adjust};")
+    open(cd, "w").write(text + "writeControl timeStep;\nwriteInterval 12;\ntimePrecision 10;\nmaxDeltaT 1;\n")
+    shutil.copytree(one, many)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "qgdsolver_amd.QGDFoam", "-case", one, "-nSteps", "12"], capture_output=True, text=True,
+                       env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
+                        "127.0.0.1", "--master-port", str(29540 + world), "-m", "qgdsolver_amd.QGDFoam", "-case", many, "-nSteps", "12",
+                        "-renumber", renumber, "-backend", "gloo"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    assert f"on {world} rank(s)" in r.stdout
+    times = sorted(d for d in os.listdir(one) if d not in ("0", "constant", "system"))
+    assert len(times) == 1 and os.path.isdir(os.path.join(many, times[0])), (times, os.listdir(many))
+    for n in ("rho", "U", "p", "T"):
+        a, _ = ff.read_field(os.path.join(one, times[0], n), mesh)
+        b, _ = ff.read_field(os.path.join(many, times[0], n), mesh)
+        assert np.abs(a - b).max() <= 1e-12 * np.abs(a).max(), (n, np.abs(a - b).max())
