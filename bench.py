@@ -75,6 +75,21 @@ def _cpu_rank_worker(n, steps, sync_dir, idx):
     t0 = time.perf_counter()
     oc.step(steps)
     print(f"CPU_RANK_SECONDS {time.perf_counter() - t0:.6f}", flush=True)
+    # host-bandwidth yardstick on the same cores, all ranks at once: STREAM triad over 3 x 256 MB per rank
+    import oracle as orc
+    m = 32 * 1024 * 1024
+    a, b, c = np.zeros(m), np.ones(m), np.full(m, 2.0)
+    orc.lib.orc_stream_triad(orc._d(a), orc._d(b), orc._d(c), 3.0, m, 1)
+    open(os.path.join(sync_dir, f"ready2_{idx}"), "w").close()
+    t_wait = time.time()
+    while not os.path.exists(os.path.join(sync_dir, "go2")):
+        if time.time() - t_wait > 300:
+            sys.exit(3)
+        time.sleep(0.005)
+    reps = 10
+    t0 = time.perf_counter()
+    orc.lib.orc_stream_triad(orc._d(a), orc._d(b), orc._d(c), 3.0, m, reps)
+    print(f"CPU_RANK_TRIAD_GBS {24.0 * m * reps / (time.perf_counter() - t0) / 1e9:.4f}", flush=True)
 
 
 def cpu_rank_budget(n):
@@ -127,17 +142,28 @@ def cpu_baseline(n, steps, ranks):
                 return {"value": None, "unit": "Mcell-steps/s", "cores": ranks, "kind": "port", "sample": "CPU baseline ranks failed to start"}
             time.sleep(0.05)
         open(os.path.join(sync_dir, "go"), "w").close()
-        times = []
+        t_wait = time.time()
+        while sum(os.path.exists(os.path.join(sync_dir, f"ready2_{i}")) for i in range(ranks)) < ranks:
+            if any(pr.poll() not in (None, 0) for pr in procs) or time.time() - t_wait > 900:
+                break
+            time.sleep(0.05)
+        open(os.path.join(sync_dir, "go2"), "w").close()
+        times, triad = [], []
         for pr in procs:
             out, _ = pr.communicate(timeout=900)
             times += [float(line.split()[1]) for line in out.splitlines() if line.startswith("CPU_RANK_SECONDS")]
+            triad += [float(line.split()[1]) for line in out.splitlines() if line.startswith("CPU_RANK_TRIAD_GBS")]
     if len(times) != ranks:
         return {"value": None, "unit": "Mcell-steps/s", "cores": ranks, "kind": "port", "sample": "CPU baseline ranks failed"}
     dt = max(times)
     return {"value": ranks * n ** 3 * steps / dt / 1e6, "unit": "Mcell-steps/s", "cores": ranks, "kind": "port",
             "sample": f"{ranks} single-threaded oracle ranks x {n}^3-cell box x {steps} steps (field-at-a-time restatement "
                       f"of the reference listings, no halo exchange; slowest rank {dt:.1f} s)",
-            "single_rank_value": n ** 3 * steps / min(times) / 1e6}
+            "single_rank_value": n ** 3 * steps / min(times) / 1e6,
+            # what ANY CPU code (a perfectly fused one included) could reach on these cores: the step's algorithmic
+            # bytes per cell-step against the STREAM-triad bandwidth the same ranks sustain together
+            "host_triad_GBs": sum(triad) if len(triad) == ranks else None,
+            "fused_cpu_upper_bound": (sum(triad) * 1e9 / STEP_BYTES_PER_CELL / 1e6) if len(triad) == ranks else None}
 
 
 def main():

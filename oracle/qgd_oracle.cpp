@@ -1709,6 +1709,15 @@ int orc_case_info(void* cp, double info[6]) {
     info[0] = c->time; info[1] = c->deltaT; info[2] = c->CoNum; info[3] = mr; info[4] = me; info[5] = (double)c->stepCount;
     return 0;
 }
+// STREAM triad a = b + s*c (24 bytes per element by the STREAM convention): bench.py times it on the same host cores as
+// the oracle ranks to bound what ANY fused CPU implementation of the step could reach there (bytes per cell-step / bandwidth)
+void orc_stream_triad(double* a, const double* b, const double* c, double s, int64_t n, int32_t reps) {
+    for (int32_t r = 0; r < reps; ++r) {
+        for (int64_t i = 0; i < n; ++i) a[i] = b[i] + s * c[i];
+        s += 1e-9 * a[(size_t)(n / 2)];  // keep the repetitions dependent
+    }
+}
+
 int orc_case_halo_count(void* cp, int side, int64_t* count) { ((Case*)cp)->haloCount(side, count, false); return 0; }
 int orc_case_halo_recv_count(void* cp, int side, int64_t* count) { ((Case*)cp)->haloCount(side, count, true); return 0; }
 int orc_case_halo_pack(void* cp, int side, double* sendBuf) { ((Case*)cp)->packOrUnpack(side, sendBuf, true); return 0; }

@@ -74,6 +74,8 @@ int orc_case_halo_recv_count(void* c, int side, int64_t* count);
 int orc_case_halo_pack(void* c, int side, double* sendBuf);
 int orc_case_halo_unpack(void* c, int side, const double* recvBuf);
 int orc_case_step_phase(void* c, int phase);
+/* STREAM triad on the calling core (host-bandwidth yardstick for bench.py's cpu_baseline) */
+void orc_stream_triad(double* a, const double* b, const double* c, double s, int64_t n, int32_t reps);
 int orc_case_reduction(void* c, double* buf2, int set);
 
 #ifdef __cplusplus

@@ -48,6 +48,8 @@ lib.orc_case_step.argtypes = [C.c_void_p, C.c_int32]
 lib.orc_case_get_field.argtypes = [C.c_void_p, C.c_char_p, dp, C.c_int64]
 lib.orc_case_info.argtypes = [C.c_void_p, dp]
 lib.orc_case_halo_count.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]
+lib.orc_stream_triad.argtypes = [dp, dp, dp, C.c_double, C.c_int64, C.c_int32]
+lib.orc_stream_triad.restype = None
 lib.orc_case_halo_recv_count.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]
 lib.orc_case_halo_pack.argtypes = [C.c_void_p, C.c_int, dp]
 lib.orc_case_halo_unpack.argtypes = [C.c_void_p, C.c_int, dp]
