@@ -258,6 +258,27 @@ typedef struct qgd_qhd_outputs {             /* every pointer may be NULL */
 } qgd_qhd_outputs;
 int qgd_qhd_fluxes(qgd_device_t d, int stencilId, const qgd_qhd_inputs* in, qgd_qhd_outputs* out);
 
+/* QHDFoam's pressure equation -- QHDpEqn_8H_source.html L35-47:
+ *     fvScalarMatrix pEqn(fvc::div(phiu) - fvc::div(phiwo) - fvm::laplacian(taubyrhof, p));
+ *     pEqn.setReference(pRefCell, pRefValue);  pEqn.solve();  phi = phiu - phiwo + pEqn.flux();
+ * assembled and solved on the device: Gauss laplacian with the uncorrected surface-normal gradient (L0), a
+ * Jacobi-preconditioned conjugate gradient with reproducible reductions, converged on OpenFOAM's normalised residual
+ * sum|b-Ax|/normFactor < tolerance (or < relTol x initial), at most maxIter iterations.
+ * phiu, phiwo, taubyrhof: nFaces.  patchKind[nPatches]: QGD_BC_ZEROGRADIENT, QGD_BC_FIXEDVALUE (values pb[nBoundaryFaces])
+ * or QGD_BC_QGDFLUX = fixedGradient with gradb[nBoundaryFaces] (what qhdFluxFvPatchScalarField::updateCoeffs leaves in
+ * gradient(), qhdFluxFvPatchScalarField_8C_source.html L159-208); constraint patches are skipped.
+ * p[nCells]: initial guess in, solution out.  phi[nFaces] out.  info = {iterations, initial residual, final residual}.
+ * The reference level is applied only when no patch is fixedValue (fvMatrix::setReference, L0); pRefCell < 0: never. */
+typedef struct qgd_poisson_control {
+    double tolerance, relTol;
+    int32_t maxIter, pRefCell;
+    double pRefValue;
+} qgd_poisson_control;
+int qgd_poisson_control_default(qgd_poisson_control* c);
+int qgd_qhd_pressure(qgd_device_t d, const double* phiu, const double* phiwo, const double* taubyrhof,
+                     const int32_t* patchKind, const double* pb, const double* gradb, const qgd_poisson_control* ctl,
+                     double* p, double* phi, double info[3]);
+
 /* ---- QGDFoam case ----------------------------------------------------------- */
 
 typedef struct qgd_case_options {

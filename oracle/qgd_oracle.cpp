@@ -1709,6 +1709,95 @@ int orc_case_info(void* cp, double info[6]) {
     info[0] = c->time; info[1] = c->deltaT; info[2] = c->CoNum; info[3] = mr; info[4] = me; info[5] = (double)c->stepCount;
     return 0;
 }
+
+// QHDpEqn.H L35-47: fvc::div(phiu) - fvc::div(phiwo) - fvm::laplacian(taubyrhof, p) == 0 with setReference and
+// phi = phiu - phiwo + pEqn.flux().  L0 assumptions: Gauss laplacian, uncorrected snGrad (nonOrthDeltaCoeffs inside,
+// deltaCoeffs on patches); fixedValue / fixedGradient / zeroGradient patch coefficients; the linear solver is a plain
+// diagonal-preconditioned CG run to `tolerance` on OpenFOAM's normalised residual (sequential sums).
+int orc_qhd_pressure(void* mp, const double* phiu, const double* phiwo, const double* taubyrhof, const int32_t* patchKind,
+                     const double* pb, const double* gradb, double tolerance, double relTol, int32_t maxIter, int32_t pRefCell,
+                     double pRefValue, double* p, double* phi, double info[3]) {
+    MeshHandle* h = (MeshHandle*)mp;
+    const Mesh& m = h->m;
+    const int nC = m.nC, nF = m.nF, nIF = m.nIF;
+    dvec a((size_t)nF), diag((size_t)nC, 0.0), rhs((size_t)nC, 0.0);
+    std::vector<int> kind((size_t)std::max(m.nBF(), 1), 0);
+    bool anyFixed = false;
+    for (size_t ip = 0; ip < m.patches.size(); ++ip) {
+        int k = patchKind[ip];
+        if (m.patches[ip].type != PATCH_GENERIC) k = BC_NONE;
+        const int kk = k == BC_FIXEDVALUE ? 1 : (k == BC_QGDFLUX ? 2 : 0);
+        if (kk == 1 && m.patches[ip].size > 0) anyFixed = true;
+        for (int f = m.patches[ip].start; f < m.patches[ip].start + m.patches[ip].size; ++f) kind[f - nIF] = kk;
+    }
+    for (int f = 0; f < nF; ++f) a[f] = taubyrhof[f] * m.magSf[f] * (f < nIF ? m.nonOrthDelta[f] : m.delta[f]);
+    std::vector<char> liveB((size_t)std::max(m.nBF(), 1), 1);
+    for (size_t ip = 0; ip < m.patches.size(); ++ip)
+        if (!m.patchHasFields((int)ip))
+            for (int f = m.patches[ip].start; f < m.patches[ip].start + m.patches[ip].size; ++f) liveB[f - nIF] = 0;
+    auto live = [&](int f) { return f < nIF || liveB[f - nIF]; };
+    for (int f = 0; f < nF; ++f) {  // ascending face order per cell, as the device gathers
+        if (!live(f)) continue;
+        const double flux = phiu[f] - phiwo[f];
+        rhs[m.own[f]] -= flux;
+        if (f < nIF) { rhs[m.nei[f]] += flux; diag[m.own[f]] += a[f]; diag[m.nei[f]] += a[f]; }
+        else {
+            const int b = f - nIF;
+            if (kind[b] == 1) { diag[m.own[f]] += a[f]; rhs[m.own[f]] += a[f] * pb[b]; }
+            else if (kind[b] == 2) rhs[m.own[f]] += taubyrhof[f] * m.magSf[f] * gradb[b];
+        }
+    }
+    if (!anyFixed && pRefCell >= 0) { rhs[pRefCell] += diag[pRefCell] * pRefValue; diag[pRefCell] += diag[pRefCell]; }
+    auto apply = [&](const double* x, dvec& y) {
+        for (int c = 0; c < nC; ++c) y[c] = diag[c] * x[c];
+        for (int f = 0; f < nIF; ++f) { y[m.own[f]] -= a[f] * x[m.nei[f]]; y[m.nei[f]] -= a[f] * x[m.own[f]]; }
+    };
+    dvec r((size_t)nC), z((size_t)nC), d((size_t)nC), q((size_t)nC), A1((size_t)nC), ones((size_t)nC, 1.0);
+    apply(ones.data(), A1);
+    apply(p, q);
+    double xbar = 0;
+    for (int c = 0; c < nC; ++c) xbar += p[c];
+    xbar /= nC;
+    double normFactor = 1e-20, sumAbs = 0, rz = 0;
+    for (int c = 0; c < nC; ++c) {
+        normFactor += std::fabs(q[c] - xbar * A1[c]) + std::fabs(rhs[c] - xbar * A1[c]);
+        r[c] = rhs[c] - q[c]; z[c] = r[c] / diag[c]; d[c] = z[c];
+        sumAbs += std::fabs(r[c]); rz += r[c] * z[c];
+    }
+    double res = sumAbs / normFactor;
+    const double res0 = res;
+    int it = 0;
+    while (it < maxIter && !(res < tolerance || (relTol > 0 && res < relTol * res0))) {
+        apply(d.data(), q);
+        double dq = 0;
+        for (int c = 0; c < nC; ++c) dq += d[c] * q[c];
+        if (!(dq > 0) || !(rz > 0)) break;
+        const double alpha = rz / dq;
+        double rzNew = 0; sumAbs = 0;
+        for (int c = 0; c < nC; ++c) {
+            p[c] += alpha * d[c]; r[c] -= alpha * q[c]; z[c] = r[c] / diag[c];
+            rzNew += r[c] * z[c]; sumAbs += std::fabs(r[c]);
+        }
+        res = sumAbs / normFactor;
+        const double beta = rzNew / rz;
+        for (int c = 0; c < nC; ++c) d[c] = z[c] + beta * d[c];
+        rz = rzNew;
+        ++it;
+    }
+    for (int f = 0; f < nF; ++f) {
+        double corr = 0;
+        if (f < nIF) corr = -a[f] * (p[m.nei[f]] - p[m.own[f]]);
+        else {
+            const int b = f - nIF;
+            if (kind[b] == 1) corr = -a[f] * (pb[b] - p[m.own[f]]);
+            else if (kind[b] == 2) corr = -taubyrhof[f] * m.magSf[f] * gradb[b];
+        }
+        phi[f] = live(f) ? (phiu[f] - phiwo[f]) + corr : 0.0;
+    }
+    if (info) { info[0] = it; info[1] = res0; info[2] = res; }
+    return 0;
+}
+
 // STREAM triad a = b + s*c (24 bytes per element by the STREAM convention): bench.py times it on the same host cores as
 // the oracle ranks to bound what ANY fused CPU implementation of the step could reach there (bytes per cell-step / bandwidth)
 void orc_stream_triad(double* a, const double* b, const double* c, double s, int64_t n, int32_t reps) {

@@ -60,6 +60,11 @@ typedef struct orc_qhd_outputs {
 } orc_qhd_outputs;
 int orc_qhd_fluxes(void* mesh, const char* scheme, const orc_qhd_inputs* in, orc_qhd_outputs* out);
 
+/* QHDFoam pressure equation; same argument meaning as qgd_qhd_pressure (QHDpEqn.H L35-47) */
+int orc_qhd_pressure(void* mesh, const double* phiu, const double* phiwo, const double* taubyrhof, const int32_t* patchKind,
+                     const double* pb, const double* gradb, double tolerance, double relTol, int32_t maxIter, int32_t pRefCell,
+                     double pRefValue, double* p, double* phi, double info[3]);
+
 void* orc_case_create(void* mesh, const orc_case_options* opt);
 void orc_case_free(void* c);
 int orc_case_set_bc(void* c, int32_t patch, int32_t bcU, const double* valueU,

@@ -660,6 +660,69 @@ int qgd_qhd_fluxes(qgd_device_t d, int stencilId, const qgd_qhd_inputs* in, qgd_
     QGD_CATCH
 }
 
+int qgd_poisson_control_default(qgd_poisson_control* c) {
+    if (!c) return fail(QGD_ERR_INVALID, "null argument");
+    c->tolerance = 1e-6; c->relTol = 0.0; c->maxIter = 1000; c->pRefCell = 0; c->pRefValue = 0.0;
+    return QGD_OK;
+}
+
+int qgd_qhd_pressure(qgd_device_t d, const double* phiu, const double* phiwo, const double* taubyrhof, const int32_t* patchKind,
+                     const double* pb, const double* gradb, const qgd_poisson_control* ctl, double* p, double* phi, double info[3]) {
+    QGD_TRY
+    if (!d || !phiu || !phiwo || !taubyrhof || !patchKind || !ctl || !p || !phi)
+        return fail(QGD_ERR_INVALID, "qgd_qhd_pressure: null argument");
+    const MeshView& v = d->view;
+    const size_t nC = (size_t)v.nC, nB = (size_t)v.nBF, nF = (size_t)v.nF;
+    if (d->sharded()) return fail(QGD_ERR_NOT_IMPLEMENTED, "qgd_qhd_pressure: the pressure equation is not distributed");
+    if (!(ctl->tolerance >= 0) || ctl->maxIter < 0) return fail(QGD_ERR_INVALID, "qgd_qhd_pressure: bad solver controls");
+    // per boundary face: 0 nothing to add (zeroGradient, constraint patches), 1 fixedValue, 2 fixedGradient
+    std::vector<uint8_t> bKind(std::max<size_t>(nB, 1), 0);
+    bool anyFixedValue = false;
+    for (size_t ip = 0; ip < d->patches.size(); ++ip) {
+        const Patch& pt = d->patches[ip];
+        int kind = patchKind[ip];
+        if (pt.type != QGD_PATCH_GENERIC) kind = QGD_BC_NONE;  // constraint patches carry no matrix contribution here
+        uint8_t k = 0;
+        if (kind == QGD_BC_FIXEDVALUE) { k = 1; anyFixedValue = anyFixedValue || pt.size > 0; if (!pb) return fail(QGD_ERR_INVALID, "qgd_qhd_pressure: fixedValue patch without pb"); }
+        else if (kind == QGD_BC_QGDFLUX) { k = 2; if (!gradb) return fail(QGD_ERR_INVALID, "qgd_qhd_pressure: fixedGradient patch without gradb"); }
+        else if (kind != QGD_BC_ZEROGRADIENT && kind != QGD_BC_NONE) return fail(QGD_ERR_INVALID, "qgd_qhd_pressure: unsupported patch kind");
+        for (int32_t f = pt.start; f < pt.start + pt.size; ++f) bKind[(size_t)(f - v.nIF)] = k;
+    }
+    // fvMatrix::setReference acts only when the field needs a reference level (no fixedValue patch), L0
+    int refCell = (!anyFixedValue && ctl->pRefCell >= 0) ? ctl->pRefCell : -1;
+    if (refCell >= (int)nC) return fail(QGD_ERR_INVALID, "qgd_qhd_pressure: pRefCell out of range");
+    HIP_CHECK(hipSetDevice(d->deviceId));
+    DeviceArena tmp;
+    try {
+        auto upD = [&](const double* src, size_t n) {
+            double* dst = tmp.alloc<double>(std::max<size_t>(n, 1), false);
+            if (src && n) HIP_CHECK(hipMemcpy(dst, src, sizeof(double) * n, hipMemcpyHostToDevice));
+            else HIP_CHECK(hipMemset(dst, 0, sizeof(double) * std::max<size_t>(n, 1)));
+            return dst;
+        };
+        double* dGamma = upD(taubyrhof, nF);
+        double* dPhiu = upD(phiu, nF);
+        double* dPhiwo = upD(phiwo, nF);
+        double* dPb = upD(pb, nB);
+        double* dGb = upD(gradb, nB);
+        double* dP = upD(p, nC);
+        double* dPhi = tmp.alloc<double>(nF, false);
+        uint8_t* dKind = tmp.upload(bKind);
+        const size_t nBlocks = (nC + 255) / 256;
+        double* work = tmp.alloc<double>(8 * nC + nF + std::max<size_t>(nB, 1) + 3 * nBlocks + 8, false);
+        double res[2] = {0, 0};
+        (void)hipGetLastError();
+        const int iters = solveQhdPressure(d->stream, v, dGamma, dPhiu, dPhiwo, dKind, dPb, dGb, refCell, ctl->pRefValue, ctl->tolerance,
+                                           ctl->relTol, ctl->maxIter, dP, dPhi, work, res);
+        HIP_CHECK(hipMemcpy(p, dP, sizeof(double) * nC, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(phi, dPhi, sizeof(double) * nF, hipMemcpyDeviceToHost));
+        if (info) { info[0] = iters; info[1] = res[0]; info[2] = res[1]; }
+    } catch (...) { tmp.release(); throw; }
+    tmp.release();
+    return QGD_OK;
+    QGD_CATCH
+}
+
 // ---- case ------------------------------------------------------------------------
 int qgd_case_options_default(qgd_case_options* o) {
     if (!o) return fail(QGD_ERR_INVALID, "null argument");

@@ -122,4 +122,10 @@ void launchQhdFluxes(hipStream_t s, int stencil, const MeshView& m, const double
                      const double* rho, const double* rhob, const double* tau, const double* phi, double beta,
                      double gx, double gy, double gz, double* out);
 
+// ---- QHDFoam pressure equation (qgd_poisson.hip) -------------------------------------
+// all pointers are device memory; work holds 8*nC + nF + max(nBF,1) + 3*ceil(nC/256) + 8 doubles
+int solveQhdPressure(hipStream_t stream, const MeshView& m, const double* gamma, const double* phiu, const double* phiwo,
+                     const uint8_t* bKind, const double* pb, const double* gb, int refCell, double refValue, double tolerance,
+                     double relTol, int maxIter, double* p, double* phi, double* work, double residuals[2]);
+
 }  // namespace qgd

@@ -2,7 +2,7 @@
 
 ``updateFluxes(...)`` covers QHDFoam/updateFields.H L36-73 + updateFluxes.H L33-38 (call it without p/phi before the
 pressure equation) and the flux parts of QHDUEqn.H L36-43 / QHDTEqn.H L65-66 (call it again with p and phi).
-The pressure Poisson solve itself (QHDpEqn.H) is not on this path.
+``pEqn(...)`` is QHDpEqn.H L35-47 (qgd_qhd_pressure): the pressure Poisson equation assembled and solved on the device.
 """
 import ctypes as C
 
@@ -94,3 +94,52 @@ def tauQGDf(dev, model, aQGD=0.5, **par):
     else:
         raise KeyError(model)
     return fvsc.qgdInterpolate(dev, fvsc.volField("tauQGD", tau, taub))
+
+
+class PoissonControl(C.Structure):
+    """qgd_poisson_control: the fvSolution entries of p (tolerance, relTol, maxIter) + the reference level"""
+    _fields_ = [("tolerance", C.c_double), ("relTol", C.c_double), ("maxIter", C.c_int32), ("pRefCell", C.c_int32),
+                ("pRefValue", C.c_double)]
+
+
+_P_KINDS = {"zeroGradient": L.BC_ZEROGRADIENT, "fixedValue": L.BC_FIXEDVALUE, "fixedGradient": L.BC_QGDFLUX, "qhdFlux": L.BC_QGDFLUX,
+            "none": L.BC_NONE}
+
+
+def qhdFluxGradient(phiwStar_b, tauQGDf_b, rhof_b, magSf_b):
+    """gradient() of the qhdFlux patch field: -(phiwStar/tauQGDf*rhof/|Sf|) [qhdFluxFvPatchScalarField.C L193-203].
+    (QHDFoam itself registers that flux as "phiwo", not "phiwStar", so there the lookup at L166-168 fails and the patch
+    keeps the gradient read from its file; solvers that register phiwStar get this value.)"""
+    return -(np.asarray(phiwStar_b) / np.asarray(tauQGDf_b) * np.asarray(rhof_b) / np.asarray(magSf_b))
+
+
+def pEqn(dev, phiu, phiwo, taubyrhof, p, patch_kinds, pb=None, gradb=None, tolerance=1e-6, relTol=0.0, maxIter=1000,
+         pRefCell=0, pRefValue=0.0, call=None):
+    """QHDpEqn.H L35-47.  ``p``: initial guess (nCells); ``patch_kinds``: one word per patch (zeroGradient | fixedValue |
+    fixedGradient/qhdFlux | none); ``pb`` / ``gradb``: patch values / patch-normal gradients (nBoundaryFaces).
+    Returns (p, phi, info) with info = dict(iterations, initialResidual, finalResidual)."""
+    m = dev.mesh
+
+    def arr(a, n):
+        if a is None:
+            return None
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        assert a.size == n
+        return a
+
+    phiu, phiwo, tbr = arr(phiu, m.nFaces), arr(phiwo, m.nFaces), arr(taubyrhof, m.nFaces)
+    pb, gradb = arr(pb, m.nBoundaryFaces), arr(gradb, m.nBoundaryFaces)
+    kinds = np.asarray([_P_KINDS[k] for k in patch_kinds], dtype=np.int32)
+    assert kinds.size == m.nPatches
+    ctl = PoissonControl(float(tolerance), float(relTol), int(maxIter), int(pRefCell), float(pRefValue))
+    p_out = np.array(p, dtype=np.float64, copy=True).reshape(-1)
+    assert p_out.size == m.nCells
+    phi = np.zeros(m.nFaces)
+    info = np.zeros(3)
+    dp = lambda a: a.ctypes.data_as(L.c_double_p) if a is not None and a.size else None  # noqa: E731
+    if call is None:
+        L.check(L.lib.qgd_qhd_pressure(dev._h, dp(phiu), dp(phiwo), dp(tbr), kinds.ctypes.data_as(L.c_int32_p), dp(pb), dp(gradb),
+                                       C.byref(ctl), dp(p_out), dp(phi), dp(info)), "qgd_qhd_pressure")
+    else:
+        call(phiu, phiwo, tbr, kinds, pb, gradb, ctl, p_out, phi, info)
+    return p_out, phi, dict(iterations=int(info[0]), initialResidual=float(info[1]), finalResidual=float(info[2]))

@@ -48,6 +48,7 @@ lib.orc_case_step.argtypes = [C.c_void_p, C.c_int32]
 lib.orc_case_get_field.argtypes = [C.c_void_p, C.c_char_p, dp, C.c_int64]
 lib.orc_case_info.argtypes = [C.c_void_p, dp]
 lib.orc_case_halo_count.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]
+lib.orc_qhd_pressure.argtypes = [C.c_void_p, dp, dp, dp, ip, dp, dp, C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_double, dp, dp, dp]
 lib.orc_stream_triad.argtypes = [dp, dp, dp, C.c_double, C.c_int64, C.c_int32]
 lib.orc_stream_triad.restype = None
 lib.orc_case_halo_recv_count.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]
@@ -219,3 +220,12 @@ class OracleCase:
         if self._h:
             lib.orc_case_free(self._h)
             self._h = None
+
+
+def qhd_pressure(omesh, phiu, phiwo, taubyrhof, kinds, pb, gradb, ctl, p, phi, info):
+    """drop-in for the `call` hook of qgdsolver_amd.qhdfoam.pEqn"""
+    z = np.zeros(1)
+    rc = lib.orc_qhd_pressure(omesh._h, _d(phiu), _d(phiwo), _d(taubyrhof), _i(kinds), _d(pb if pb is not None and pb.size else z),
+                              _d(gradb if gradb is not None and gradb.size else z), ctl.tolerance, ctl.relTol, ctl.maxIter, ctl.pRefCell,
+                              ctl.pRefValue, _d(p), _d(phi), _d(info))
+    assert rc == 0
