@@ -883,7 +883,9 @@ void cellUpdateKernel(const MeshView m, const CaseView c, const GasModel gm, con
         c.A[ci] = An;
         c.B[ci] = Bn;
         c.K[ci] = Kn;
-        rmin = rho; emin = An.e;
+        // a NaN must not hide behind fmin(): it counts as a lost positivity
+        rmin = (rho == rho) ? rho : -1e300;
+        emin = (An.e == An.e) ? An.e : -1e300;
     }
     // positivity monitor [QGDFoam_8C L142]: one plain store pair per workgroup, no atomics
     blockMaxMin(-rmin, emin, c.blkCell + 2 * (size_t)(slotBase + tile), true);
