@@ -258,6 +258,16 @@ typedef struct qgd_qhd_outputs {             /* every pointer may be NULL */
 } qgd_qhd_outputs;
 int qgd_qhd_fluxes(qgd_device_t d, int stencilId, const qgd_qhd_inputs* in, qgd_qhd_outputs* out);
 
+/* Species flux block -- reactingLagrangianQGDFoam_2updateFluxes_8H_source.html L117-132, one species:
+ *     gradYf = fvsc::grad(Y);  phiJmY = qgdFlux(phiJm, Y, Yf);  dydtflux = -phi*tauQGDf*(Uf & gradYf);
+ *     phiJmY += dydtflux;  diffusiveFlux = dydtflux;
+ * Y[nCells], Yb[nBoundaryFaces], U[3 nCells], Ub[3 nBoundaryFaces] (patch values after their BCs), phiJm, phi, tauQGDf [nFaces]
+ * as the QGDFoam block produced them (qgd_case_get_field "phiJm","phi","tauQGDf").  Out: phiJmY, diffusiveFlux [nFaces],
+ * gradYf [3 nFaces] (may be NULL).  What QGDYEqn_8H_source.html L35-93 then does with them stays with the caller. */
+int qgd_species_flux(qgd_device_t d, int stencilId, const double* Y, const double* Yb, const double* U, const double* Ub,
+                     const double* phiJm, const double* phi, const double* tauQGDf, double* phiJmY, double* diffusiveFlux,
+                     double* gradYf);
+
 /* QHDFoam's pressure equation -- QHDpEqn_8H_source.html L35-47:
  *     fvScalarMatrix pEqn(fvc::div(phiu) - fvc::div(phiwo) - fvm::laplacian(taubyrhof, p));
  *     pEqn.setReference(pRefCell, pRefValue);  pEqn.solve();  phi = phiu - phiwo + pEqn.flux();

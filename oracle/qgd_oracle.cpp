@@ -1710,6 +1710,38 @@ int orc_case_info(void* cp, double info[6]) {
     return 0;
 }
 
+// Species block of reactingLagrangianQGDFoam/updateFluxes.H L117-132 for one species:
+//   gradYf = fvsc::grad(Y);  phiJmY = qgdFlux(phiJm, Y, Yf) [= phiJm*Yf, QGDInterpolate.H L104];
+//   dydtflux = -phi*tauQGDf*(Uf & gradYf);  phiJmY += dydtflux;  diffusiveFlux = dydtflux
+int orc_species_flux(void* mp, const char* scheme, const double* Yc, const double* Yb, const double* Uc, const double* Ub,
+                     const double* phiJm, const double* phi, const double* tauQGDf, double* phiJmY, double* diffusiveFlux,
+                     double* gradYfOut) {
+    MeshHandle* h = (MeshHandle*)mp;
+    const Mesh& m = h->m;
+    Stencil* st = nullptr;
+    int rc = h->cache.lookup(m, scheme, &st);
+    if (rc) return rc;
+    const int nC = m.nC, nB = m.nBF(), nF = m.nF;
+    VolField Y(m, 1), U(m, 3);
+    std::copy(Yc, Yc + nC, Y.in.begin());
+    std::copy(Uc, Uc + 3 * (size_t)nC, U.in.begin());
+    if (nB) { std::copy(Yb, Yb + nB, Y.bf.begin()); std::copy(Ub, Ub + 3 * (size_t)nB, U.bf.begin()); }
+    SurfField gradYf = st->gradS(Y);
+    SurfField Yf = linearInterpolate(m, Y);
+    SurfField Uf = linearInterpolate(m, U);
+    std::vector<char> live(nF, 1);
+    for (size_t ip = 0; ip < m.patches.size(); ++ip)
+        if (!m.patchHasFields((int)ip)) for (int f = m.patches[ip].start; f < m.patches[ip].start + m.patches[ip].size; ++f) live[f] = 0;
+    for (int f = 0; f < nF; ++f) {
+        if (!live[f]) { phiJmY[f] = 0.0; diffusiveFlux[f] = 0.0; continue; }
+        const double dydt = (-phi[f]) * tauQGDf[f] * dot3(&Uf.v[3 * (size_t)f], &gradYf.v[3 * (size_t)f]);
+        phiJmY[f] = phiJm[f] * Yf.v[f] + dydt;
+        diffusiveFlux[f] = dydt;
+    }
+    if (gradYfOut) std::copy(gradYf.v.begin(), gradYf.v.end(), gradYfOut);
+    return 0;
+}
+
 // QHDpEqn.H L35-47: fvc::div(phiu) - fvc::div(phiwo) - fvm::laplacian(taubyrhof, p) == 0 with setReference and
 // phi = phiu - phiwo + pEqn.flux().  L0 assumptions: Gauss laplacian, uncorrected snGrad (nonOrthDeltaCoeffs inside,
 // deltaCoeffs on patches); fixedValue / fixedGradient / zeroGradient patch coefficients; the linear solver is a plain

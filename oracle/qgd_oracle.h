@@ -60,6 +60,11 @@ typedef struct orc_qhd_outputs {
 } orc_qhd_outputs;
 int orc_qhd_fluxes(void* mesh, const char* scheme, const orc_qhd_inputs* in, orc_qhd_outputs* out);
 
+/* species flux block of reactingLagrangianQGDFoam/updateFluxes.H L117-132; same argument meaning as qgd_species_flux */
+int orc_species_flux(void* mesh, const char* scheme, const double* Y, const double* Yb, const double* U, const double* Ub,
+                     const double* phiJm, const double* phi, const double* tauQGDf, double* phiJmY, double* diffusiveFlux,
+                     double* gradYf);
+
 /* QHDFoam pressure equation; same argument meaning as qgd_qhd_pressure (QHDpEqn.H L35-47) */
 int orc_qhd_pressure(void* mesh, const double* phiu, const double* phiwo, const double* taubyrhof, const int32_t* patchKind,
                      const double* pb, const double* gradb, double tolerance, double relTol, int32_t maxIter, int32_t pRefCell,

@@ -89,6 +89,7 @@ SIGNATURES = {
     "qgd_case_info": (C.c_int, [handle, c_double_p]),
     "qgd_device_alloc": (C.c_int, [handle, C.c_int64, C.POINTER(C.c_void_p)]),
     "qgd_device_release": (C.c_int, [handle, C.c_void_p]),
+    "qgd_species_flux": (C.c_int, [handle, C.c_int] + [c_double_p] * 10),
     "qgd_poisson_control_default": (C.c_int, [C.c_void_p]),
     "qgd_qhd_pressure": (C.c_int, [handle, c_double_p, c_double_p, c_double_p, c_int32_p, c_double_p, c_double_p, C.c_void_p,
                                    c_double_p, c_double_p, c_double_p]),

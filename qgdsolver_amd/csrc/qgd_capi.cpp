@@ -660,6 +660,49 @@ int qgd_qhd_fluxes(qgd_device_t d, int stencilId, const qgd_qhd_inputs* in, qgd_
     QGD_CATCH
 }
 
+int qgd_species_flux(qgd_device_t d, int stencilId, const double* Y, const double* Yb, const double* U, const double* Ub,
+                     const double* phiJm, const double* phi, const double* tauQGDf, double* phiJmY, double* diffusiveFlux,
+                     double* gradYf) {
+    QGD_TRY
+    if (!d || !Y || !U || !phiJm || !phi || !tauQGDf || !phiJmY || !diffusiveFlux)
+        return fail(QGD_ERR_INVALID, "qgd_species_flux: null argument");
+    const MeshView& v = d->view;
+    if (v.nBF > 0 && (!Yb || !Ub)) return fail(QGD_ERR_INVALID, "qgd_species_flux: patch values of Y and U are required");
+    int st = 0;
+    int rc = deviceStencil(d->nGeomD, stencilId, &st);
+    if (rc) return rc;
+    HIP_CHECK(hipSetDevice(d->deviceId));
+    const size_t nC = (size_t)v.nC, nB = (size_t)v.nBF, nF = (size_t)v.nF, nP = (size_t)v.nP;
+    DeviceArena tmp;
+    try {
+        auto upD = [&](const double* src, size_t n) {
+            double* dst = tmp.alloc<double>(std::max<size_t>(n, 1), false);
+            if (src && n) HIP_CHECK(hipMemcpy(dst, src, sizeof(double) * n, hipMemcpyHostToDevice));
+            return dst;
+        };
+        double *dY = upD(Y, nC), *dYb = upD(Yb, nB), *dU = upD(U, 3 * nC), *dUb = upD(Ub, 3 * nB);
+        double *dJm = upD(phiJm, nF), *dPhi = upD(phi, nF), *dTau = upD(tauQGDf, nF);
+        double* dPt = tmp.alloc<double>(std::max<size_t>(nP, 1));
+        double* dOut = tmp.alloc<double>(5 * nF);
+        (void)hipGetLastError();
+        launchSpeciesFlux(d->stream, st, v, dY, dYb, dPt, dU, dUb, dJm, dPhi, dTau, dOut);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(d->stream));
+        HIP_CHECK(hipMemcpy(phiJmY, dOut, sizeof(double) * nF, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(diffusiveFlux, dOut + nF, sizeof(double) * nF, hipMemcpyDeviceToHost));
+        if (gradYf) {
+            std::vector<double> slot(nF);
+            for (int k = 0; k < 3; ++k) {
+                HIP_CHECK(hipMemcpy(slot.data(), dOut + (size_t)(2 + k) * nF, sizeof(double) * nF, hipMemcpyDeviceToHost));
+                for (size_t f = 0; f < nF; ++f) gradYf[3 * f + k] = slot[f];
+            }
+        }
+    } catch (...) { tmp.release(); throw; }
+    tmp.release();
+    return QGD_OK;
+    QGD_CATCH
+}
+
 int qgd_poisson_control_default(qgd_poisson_control* c) {
     if (!c) return fail(QGD_ERR_INVALID, "null argument");
     c->tolerance = 1e-6; c->relTol = 0.0; c->maxIter = 1000; c->pRefCell = 0; c->pRefValue = 0.0;

@@ -122,6 +122,10 @@ void launchQhdFluxes(hipStream_t s, int stencil, const MeshView& m, const double
                      const double* rho, const double* rhob, const double* tau, const double* phi, double beta,
                      double gx, double gy, double gz, double* out);
 
+// ---- species flux block: out = 5 SoA slots of nF doubles {phiJmY, diffusiveFlux, gradYf(3)} -------------------
+void launchSpeciesFlux(hipStream_t s, int stencil, const MeshView& m, const double* Y, const double* Yb, double* ptY,
+                       const double* U, const double* Ub, const double* phiJm, const double* phi, const double* tau, double* out);
+
 // ---- QHDFoam pressure equation (qgd_poisson.hip) -------------------------------------
 // all pointers are device memory; work holds 8*nC + nF + max(nBF,1) + 3*ceil(nC/256) + 8 doubles
 int solveQhdPressure(hipStream_t stream, const MeshView& m, const double* gamma, const double* phiu, const double* phiwo,

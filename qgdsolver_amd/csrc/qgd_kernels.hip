@@ -1362,4 +1362,70 @@ void launchQhdFluxes(hipStream_t s, int stencil, const MeshView& m, const double
     }
 }
 
+// ---------------------------------------------------------------------------
+// Species block [reactingLagrangianQGDFoam/updateFluxes.H L117-132]: one stencil walk for fvsc::grad(Y), the two
+// interpolations and the regularised species flux.  out: phiJmY, diffusiveFlux, gradYf(3) as SoA slots of nF.
+// ---------------------------------------------------------------------------
+template <int ST>
+__global__ __launch_bounds__(QGD_BLOCK) void speciesFaceKernel(const MeshView m, const double* __restrict__ Yc,
+                                                              const double* __restrict__ Yb, const double* __restrict__ ptY,
+                                                              const double* __restrict__ Uc, const double* __restrict__ Ub,
+                                                              const double* __restrict__ phiJm, const double* __restrict__ phi,
+                                                              const double* __restrict__ tauF, double* __restrict__ out) {
+    const int f = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    if (f >= m.nF) return;
+    const size_t nF = (size_t)m.nF;
+    if (m.fkind[f] == 3) {  // empty patches carry no field
+        for (int k = 0; k < 5; ++k) out[(size_t)k * nF + f] = 0.0;
+        return;
+    }
+    const bool internal = f < m.nIF;
+    const int o = m.own[f];
+    FaceVals<1> v;
+    v.o[0] = Yc[o];
+    double Uf[3], Yf;
+    if (internal) {
+        const int n = m.nei[f];
+        v.n[0] = Yc[n];
+        v.sn[0] = 0.0;
+        const double w = m.w[f];
+        Yf = lerpf(w, v.o[0], v.n[0]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) Uf[k] = lerpf(w, Uc[3 * (size_t)o + k], Uc[3 * (size_t)n + k]);
+    } else {
+        const int b = f - m.nIF;
+        v.n[0] = Yb[b];
+        v.sn[0] = m.dn[f] * (v.n[0] - v.o[0]);  // fvPatchField::snGrad (L0)
+        Yf = v.n[0];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) Uf[k] = Ub[3 * (size_t)b + k];
+    }
+    double g[3];
+    faceGradient<ST, 1, -1>(m, f, v, Yc, ptY, g);
+    const double dydt = (-phi[f]) * tauF[f] * (Uf[0] * g[0] + Uf[1] * g[1] + Uf[2] * g[2]);  // L124-125
+    out[f] = phiJm[f] * Yf + dydt;                                                             // L123, L126
+    out[nF + f] = dydt;                                                                        // L127
+#pragma unroll
+    for (int k = 0; k < 3; ++k) out[(size_t)(2 + k) * nF + f] = g[k];
+}
+
+template <int ST>
+static void launchSpeciesT(hipStream_t s, const MeshView& m, const double* Y, const double* Yb, double* ptY, const double* U,
+                           const double* Ub, const double* phiJm, const double* phi, const double* tau, double* out) {
+    if (ST == ST_GVP3 || ST == ST_GVP2) {
+        pointInterpKernel<1><<<gridFor(m.nP), QGD_BLOCK, 0, s>>>(m, Y, 1, ptY);
+        if (m.nBP) boundaryPointKernel<1><<<gridFor(m.nBP), QGD_BLOCK, 0, s>>>(m, Yb, 1, ptY, 1, 0);
+    }
+    speciesFaceKernel<ST><<<gridFor(m.nF), QGD_BLOCK, 0, s>>>(m, Y, Yb, ptY, U, Ub, phiJm, phi, tau, out);
+}
+void launchSpeciesFlux(hipStream_t s, int stencil, const MeshView& m, const double* Y, const double* Yb, double* ptY,
+                       const double* U, const double* Ub, const double* phiJm, const double* phi, const double* tau, double* out) {
+    switch (stencil) {
+        case ST_REDUCED: launchSpeciesT<ST_REDUCED>(s, m, Y, Yb, ptY, U, Ub, phiJm, phi, tau, out); break;
+        case ST_LSQ: launchSpeciesT<ST_LSQ>(s, m, Y, Yb, ptY, U, Ub, phiJm, phi, tau, out); break;
+        case ST_GVP3: launchSpeciesT<ST_GVP3>(s, m, Y, Yb, ptY, U, Ub, phiJm, phi, tau, out); break;
+        default: launchSpeciesT<ST_GVP2>(s, m, Y, Yb, ptY, U, Ub, phiJm, phi, tau, out); break;
+    }
+}
+
 }  // namespace qgd

@@ -185,3 +185,22 @@ class QGDFoamCase:
             self.close()
         except Exception:
             pass
+
+
+def speciesFlux(dev, scheme, Y, U, phiJm, phi, tauQGDf, call=None):
+    """Species block of reactingLagrangianQGDFoam/updateFluxes.H L117-132 for one species.
+    Y, U: (internal, boundary) pairs; returns dict(phiJmY, diffusiveFlux, gradYf)."""
+    m = dev.mesh
+    a = lambda x, n: np.ascontiguousarray(x, dtype=np.float64).reshape(-1) if n else np.zeros(1)  # noqa: E731
+    Yc, Yb, Uc, Ub = a(Y[0], m.nCells), a(Y[1], m.nBoundaryFaces), a(U[0], m.nCells), a(U[1], m.nBoundaryFaces)
+    jm, ph, tau = a(phiJm, 1), a(phi, 1), a(tauQGDf, 1)
+    assert Yc.size == m.nCells and Uc.size == 3 * m.nCells and jm.size == m.nFaces and ph.size == m.nFaces and tau.size == m.nFaces
+    out = dict(phiJmY=np.zeros(m.nFaces), diffusiveFlux=np.zeros(m.nFaces), gradYf=np.zeros((m.nFaces, 3)))
+    dp = lambda x: x.ctypes.data_as(L.c_double_p)  # noqa: E731
+    if call is None:
+        sid = STENCIL_IDS[scheme] if isinstance(scheme, str) else int(scheme)
+        L.check(L.lib.qgd_species_flux(dev._h, sid, dp(Yc), dp(Yb), dp(Uc), dp(Ub), dp(jm), dp(ph), dp(tau), dp(out["phiJmY"]),
+                                       dp(out["diffusiveFlux"]), dp(out["gradYf"])), "qgd_species_flux")
+    else:
+        call(scheme, Yc, Yb, Uc, Ub, jm, ph, tau, out["phiJmY"], out["diffusiveFlux"], out["gradYf"])
+    return out

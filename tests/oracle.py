@@ -48,6 +48,7 @@ lib.orc_case_step.argtypes = [C.c_void_p, C.c_int32]
 lib.orc_case_get_field.argtypes = [C.c_void_p, C.c_char_p, dp, C.c_int64]
 lib.orc_case_info.argtypes = [C.c_void_p, dp]
 lib.orc_case_halo_count.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]
+lib.orc_species_flux.argtypes = [C.c_void_p, C.c_char_p] + [dp] * 10
 lib.orc_qhd_pressure.argtypes = [C.c_void_p, dp, dp, dp, ip, dp, dp, C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_double, dp, dp, dp]
 lib.orc_stream_triad.argtypes = [dp, dp, dp, C.c_double, C.c_int64, C.c_int32]
 lib.orc_stream_triad.restype = None
@@ -229,3 +230,9 @@ def qhd_pressure(omesh, phiu, phiwo, taubyrhof, kinds, pb, gradb, ctl, p, phi, i
                               _d(gradb if gradb is not None and gradb.size else z), ctl.tolerance, ctl.relTol, ctl.maxIter, ctl.pRefCell,
                               ctl.pRefValue, _d(p), _d(phi), _d(info))
     assert rc == 0
+
+
+def species_flux(omesh, scheme, Yc, Yb, Uc, Ub, jm, ph, tau, phiJmY, diffusiveFlux, gradYf):
+    """drop-in for the `call` hook of qgdsolver_amd.qgdfoam.speciesFlux; returns the status code"""
+    return lib.orc_species_flux(omesh._h, scheme.encode(), _d(Yc), _d(Yb), _d(Uc), _d(Ub), _d(jm), _d(ph), _d(tau), _d(phiJmY),
+                                _d(diffusiveFlux), _d(gradYf))
