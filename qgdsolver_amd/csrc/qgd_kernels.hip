@@ -830,25 +830,43 @@ void cellUpdateKernel(const MeshView m, const CaseView c, const GasModel gm, con
         const RecA A = c.A[ci];
         const Cons K = c.K[ci];
         const double Vc = m.V[ci], hq = m.hQGD[ci];
-        // six faces per pass, every flux load of the pass in flight before the ordered sum (hexahedra: one full pass;
-        // tetrahedra, prisms, split cells: the missing slots are predicated off, the order stays ascending face label)
-        for (int i = 0; i < n; i += 6) {
+        // six faces per pass, every flux load of the pass in flight before the ordered sum, ascending face label.
+        // A wavefront of hexahedra only takes the unpredicated pass; one with other cells (tetrahedra, prisms, split
+        // cells) takes the predicated loop as a whole, so no wavefront ever runs both.
+        if (__ballot(n != 6) == 0) {
             int it[6];
             double fl[6][5];
 #pragma unroll
-            for (int q = 0; q < 6; ++q) it[q] = (i + q < n) ? m.cfItem[base + (size_t)(i + q) * 64] : 0;
+            for (int q = 0; q < 6; ++q) it[q] = m.cfItem[base + (size_t)q * 64];
 #pragma unroll
             for (int q = 0; q < 6; ++q) {
                 const size_t f = (size_t)(it[q] >= 0 ? it[q] : ~it[q]);
 #pragma unroll
-                for (int k = 0; k < 5; ++k) fl[q][k] = (i + q < n) ? c.flux[k * nF + f] : 0.0;
+                for (int k = 0; k < 5; ++k) fl[q][k] = c.flux[k * nF + f];
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int q = 0; q < 6; ++q) {
-                if (i + q < n) {
+            for (int q = 0; q < 6; ++q)
 #pragma unroll
-                    for (int k = 0; k < 5; ++k) sum[k] = (it[q] >= 0) ? sum[k] + fl[q][k] : sum[k] - fl[q][k];
+                for (int k = 0; k < 5; ++k) sum[k] = (it[q] >= 0) ? sum[k] + fl[q][k] : sum[k] - fl[q][k];
+        } else {
+            for (int i = 0; i < n; i += 6) {
+                int it[6];
+                double fl[6][5];
+#pragma unroll
+                for (int q = 0; q < 6; ++q) it[q] = (i + q < n) ? m.cfItem[base + (size_t)(i + q) * 64] : 0;
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    const size_t f = (size_t)(it[q] >= 0 ? it[q] : ~it[q]);
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) fl[q][k] = (i + q < n) ? c.flux[k * nF + f] : 0.0;
+                }
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    if (i + q < n) {
+#pragma unroll
+                        for (int k = 0; k < 5; ++k) sum[k] = (it[q] >= 0) ? sum[k] + fl[q][k] : sum[k] - fl[q][k];
+                    }
                 }
             }
         }
