@@ -438,7 +438,8 @@ int qgd_device_create(qgd_mesh_t mh, int deviceId, qgd_device_t* out) {
         v.X = reinterpret_cast<const double4*>(up(s.X)); v.Cc = reinterpret_cast<const double4*>(up(s.Cc));
         v.bN = reinterpret_cast<const double4*>(up(s.bN)); v.bmvON = up(s.bmvON);
         v.ip13 = reinterpret_cast<const int2*>(up(s.ip13)); v.c2d = up(s.c2d);
-        v.lsqOff = up(s.lsqOff); v.lsqCell = up(s.lsqCell); v.lsqGw = up(s.lsqGw); v.lsqDeg = up(s.lsqDeg);
+        v.lsqSlice = up(s.lsqSlice); v.lsqCnt = up(s.lsqCnt); v.lsqCell = up(s.lsqCell);
+        v.lsqGx = up(s.lsqGx); v.lsqGy = up(s.lsqGy); v.lsqGz = up(s.lsqGz); v.lsqDeg = up(s.lsqDeg);
         v.lsqBndZero = up(s.lsqBndZero);
         v.pcSlice = up(s.pcSlice); v.pcCount = up(s.pcCount); v.pcCell = up(s.pcCell); v.pcW = up(s.pcW);
         v.nBP = (int32_t)s.bpPoint.size();

@@ -32,7 +32,8 @@ struct MeshView {
     const double* bmvON;     // nBF
     const int2* ip13;        // nF
     const double* c2d;       // 6*nF
-    const int32_t* lsqOff; const int32_t* lsqCell; const double* lsqGw; const uint8_t* lsqDeg; const uint8_t* lsqBndZero;
+    const int32_t* lsqSlice; const uint8_t* lsqCnt; const int32_t* lsqCell;               // sliced ELL (64-face slices)
+    const double* lsqGx; const double* lsqGy; const double* lsqGz; const uint8_t* lsqDeg; const uint8_t* lsqBndZero;
     const int32_t* pcSlice; const uint8_t* pcCount; const int32_t* pcCell; const double* pcW;  // sliced ELL (64-point slices)
     int32_t nBP; const int32_t* bpPoint; const int32_t* bpOff; const int32_t* bpFace; const double* bpW;
     const int32_t* cfSlice; const uint8_t* cfCount; const int32_t* cfItem;                     // sliced ELL (64-cell slices)

@@ -271,10 +271,12 @@ __device__ __forceinline__ void faceGradient(const MeshView& m, const int f, con
         double pf[NC];
 #pragma unroll
         for (int k = 0; k < NC; ++k) pf[k] = lerpf(w, v.o[k], v.n[k]);
-        const int e0 = m.lsqOff[f], e1 = m.lsqOff[f + 1];
-        for (int e = e0; e < e1; ++e) {
+        const int cnt = m.lsqCnt[f];
+        const size_t base = (size_t)m.lsqSlice[f >> 6] * 64 + (f & 63);
+        for (int i = 0; i < cnt; ++i) {
+            const size_t e = base + (size_t)i * 64;
             const double* cv = cellF + (size_t)m.lsqCell[e] * NC;
-            const double gx = m.lsqGw[3 * (size_t)e], gy = m.lsqGw[3 * (size_t)e + 1], gz = m.lsqGw[3 * (size_t)e + 2];
+            const double gx = m.lsqGx[e], gy = m.lsqGy[e], gz = m.lsqGz[e];
 #pragma unroll
             for (int k = 0; k < NC; ++k) {
                 const double dphi = cv[k] - pf[k];

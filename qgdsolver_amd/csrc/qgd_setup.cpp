@@ -60,7 +60,7 @@ static void toSlicedEll(const std::vector<int32_t>& off, int64_t nRows, const st
 int64_t StaticData::bytes() const {
     auto sz = [](auto& v) { return (int64_t)(v.size() * sizeof(v[0])); };
     int64_t b = sz(own) + sz(nei) + sz(verts) + sz(fkind) + sz(magSf) + sz(w) + sz(hf) + sz(dn) + sz(X) + sz(Cc) + sz(bN) +
-                sz(bmvON) + sz(ip13) + sz(c2d) + sz(lsqOff) + sz(lsqCell) + sz(lsqGw) + sz(lsqDeg) + sz(lsqBndZero) +
+                sz(bmvON) + sz(ip13) + sz(c2d) + sz(lsqSlice) + sz(lsqCnt) + sz(lsqCell) + sz(lsqGx) + sz(lsqGy) + sz(lsqGz) + sz(lsqDeg) + sz(lsqBndZero) +
                 sz(pcSlice) + sz(pcCount) + sz(pcCell) + sz(pcW) + sz(bpPoint) + sz(bpOff) + sz(bpFace) + sz(bpW) + sz(cfSlice) + sz(cfCount) + sz(cfItem) +
                 sz(V) + sz(hQGD) + sz(ghost) + sz(bPatch) + sz(hQGDb);
     for (int k = 0; k < 3; ++k) b += sz(Sf[k]);
@@ -210,7 +210,8 @@ StaticData buildStaticData(const HostMesh& m) {
                            t == QGD_PATCH_SYMMETRY || t == QGD_PATCH_SYMMETRYPLANE) ? 1 : 0;
     }
     if (m.nGeometricD < 3) {
-        s.lsqOff.assign((size_t)nIF + 1, 0);
+        std::vector<int32_t> lsqOff((size_t)nIF + 1, 0), lsqCellCsr;
+        std::vector<double> gwCsr[3];
         s.lsqDeg.assign((size_t)nIF, 0);
         std::vector<int32_t> nb;
         for (int64_t f = 0; f < nIF; ++f) {
@@ -251,11 +252,15 @@ StaticData buildStaticData(const HostMesh& m) {
                 const double* x = &d[3 * i];
                 const double g[3] = {G[0] * x[0] + G[1] * x[1] + G[2] * x[2], G[1] * x[0] + G[3] * x[1] + G[4] * x[2],
                                      G[2] * x[0] + G[4] * x[1] + G[5] * x[2]};
-                s.lsqCell.push_back(nb[i]);
-                for (int k = 0; k < 3; ++k) s.lsqGw.push_back(w2[i] * g[k]);
+                lsqCellCsr.push_back(nb[i]);
+                for (int k = 0; k < 3; ++k) gwCsr[k].push_back(w2[i] * g[k]);
             }
-            s.lsqOff[f + 1] = (int32_t)s.lsqCell.size();
+            lsqOff[f + 1] = (int32_t)lsqCellCsr.size();
         }
+        std::vector<int32_t> dupCells;
+        toSlicedEll(lsqOff, nIF, lsqCellCsr, &gwCsr[0], s.lsqSlice, s.lsqCnt, s.lsqCell, &s.lsqGx, 0);
+        toSlicedEll(lsqOff, nIF, lsqCellCsr, &gwCsr[1], s.lsqSlice, s.lsqCnt, dupCells, &s.lsqGy, 0);
+        toSlicedEll(lsqOff, nIF, lsqCellCsr, &gwCsr[2], s.lsqSlice, s.lsqCnt, dupCells, &s.lsqGz, 0);
     }
 
     // ---- vertex interpolation ------------------------------------------------------

@@ -43,9 +43,12 @@ struct StaticData {
     std::vector<int32_t> ip13;    // 2*nF (ip1, ip3)
     std::vector<double> c2d;      // 6*nF: c1,c2,c3,c4,mv42,mv13 (SoA: [k*nF+f])
     // leastSquares (internal faces)
-    std::vector<int32_t> lsqOff;  // nIF+1
+    // leastSquares stencil as sliced ELL over the internal faces (64-face slices, entry e of face f at
+    // (lsqSlice[f/64] + e)*64 + f%64): neighbour cell and the three components of wf2*Gdf
+    std::vector<int32_t> lsqSlice;  // nSlices+1
+    std::vector<uint8_t> lsqCnt;    // nIF
     std::vector<int32_t> lsqCell;
-    std::vector<double> lsqGw;    // 3 per entry: wf2*Gdf
+    std::vector<double> lsqGx, lsqGy, lsqGz;
     std::vector<uint8_t> lsqDeg;  // nIF
     std::vector<uint8_t> lsqBndZero;  // nBF: 1 on constraint patches (gradient left zero)
 
