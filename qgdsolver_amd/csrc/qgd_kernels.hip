@@ -461,6 +461,180 @@ __global__ __launch_bounds__(QGD_BLOCK) void faceFluxKernel(const MeshView m, co
 }
 
 // ---------------------------------------------------------------------------
+// What follows the gradient on an internal face: the 13 interpolations of updateFields.H, the flux algebra, the five
+// net fluxes, the face's share of the Courant number.  Shared by the loads-first kernels of the 2-D stencils below.
+// ---------------------------------------------------------------------------
+template <bool DBG>
+__device__ __forceinline__ void finishInternalFace(const MeshView& m, const CaseView& c, const GasModel& gm, const int f, const int o,
+                                                   const int n, const RecA& Ao, const RecA& An, const RecB& Bo, const RecB& Bn,
+                                                   const double w, const double hf, const double S[3], const double* __restrict__ g,
+                                                   const int adjustDt, double& cof, double& tauMin) {
+    const size_t nF = (size_t)m.nF;
+    FaceState s;
+    s.rhof = lerpf(w, Ao.rho, An.rho);
+    const double Uo[3] = {Ao.ux, Ao.uy, Ao.uz}, Un[3] = {An.ux, An.uy, An.uz};
+    double rUo[3], rUn[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        s.Uf[k] = lerpf(w, Uo[k], Un[k]);
+        rUo[k] = Ao.rho * Uo[k];
+        rUn[k] = An.rho * Un[k];
+        s.rhoUf[k] = lerpf(w, rUo[k], rUn[k]);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) s.UrhoUf[3 * i + j] = lerpf(w, Uo[i] * rUo[j], Un[i] * rUn[j]);
+    s.pf = lerpf(w, Ao.p, An.p);
+    s.cf = lerpf(w, Bo.c, Bn.c);
+    s.Hf = lerpf(w, Bo.H, Bn.H);
+    s.gammaf = lerpf(w, gm.gamma, gm.gamma);
+    s.alphauf = lerpf(w, alphaEffOf(gm, Bo.muQGD), alphaEffOf(gm, Bn.muQGD));
+    s.muf = lerpf(w, muEffOf(gm, Bo.muQGD), muEffOf(gm, Bn.muQGD));
+    s.tauf = lerpf(w, Bo.aOc, Bn.aOc) * hf;  // tauQGDf = lin(aQGD/c)*hQGDf [constScPrModel1_8C L103]
+    double out[5], phiw;
+    qgdFluxes<DBG>(s, g, S, out, phiw, DBG ? c.dbg + f : nullptr, nF);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) c.flux[(size_t)k * nF + f] = out[k];
+    if (adjustDt) {
+        const bool counted = (m.ghost == nullptr) || !(m.ghost[o] == 1 && m.ghost[n] == 1);
+        if (counted) {
+            const double ms = sqrt(S[0] * S[0] + S[1] * S[1] + S[2] * S[2]);
+            const double Unf = s.Uf[0] * (S[0] / ms) + s.Uf[1] * (S[1] / ms) + s.Uf[2] * (S[2] / ms);
+            cof = fmax(fabs(Unf + s.cf), fabs(Unf - s.cf)) * c.dt[0] / hf;  // [QGDCourantNo_8H L44-48]
+            tauMin = s.tauf;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// leastSquares internal faces (1-D / 2-D meshes, config 2): same arithmetic as faceFluxKernel<ST_LSQ>
+// [extendedFaceStencilScalarGrad_8C L50-88], written loads-first like the 3-D kernel: labels and counts; the streamed face
+// data and the first QGD_LSQ_SLOTS stencil entries (neighbour label + wf2*Gdf, coalesced out of the sliced ELL); every
+// gathered record; then the ordered accumulation out of registers.  Longer stencils finish in a loop.
+// ---------------------------------------------------------------------------
+#define QGD_LSQ_SLOTS 6
+template <bool DBG>
+__global__ __launch_bounds__(QGD_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 3)))
+void faceFluxLsqKernel(const MeshView m, const CaseView c, const GasModel gm, const int adjustDt) {
+    const int tile = xcdTile((int)gridDim.x);
+    const int f = tile * QGD_BLOCK + (int)threadIdx.x;
+    double cof = -1e300, tauMin = 1e300;
+    if (f < m.nIF) {
+        // (0) labels
+        const int o = ldStream(m.own + f), n = ldStream(m.nei + f);
+        const int cnt = m.lsqCnt[f];
+        const bool degenerate = m.lsqDeg[f] != 0;
+        const size_t base = (size_t)m.lsqSlice[f >> 6] * 64 + (f & 63);
+        // (1) streamed face data and stencil entries
+        const double w = ldStream(m.w + f);
+        const double hf = ldStream(m.hf + f);
+        const double S[3] = {ldStream(m.Sx + f), ldStream(m.Sy + f), ldStream(m.Sz + f)};
+        int sc[QGD_LSQ_SLOTS];
+        double gx[QGD_LSQ_SLOTS], gy[QGD_LSQ_SLOTS], gz[QGD_LSQ_SLOTS];
+#pragma unroll
+        for (int e = 0; e < QGD_LSQ_SLOTS; ++e) {
+            const size_t i = base + (size_t)e * 64;
+            const bool on = e < cnt;
+            sc[e] = on ? ldStream(m.lsqCell + i) : o;
+            gx[e] = on ? ldStream(m.lsqGx + i) : 0.0;
+            gy[e] = on ? ldStream(m.lsqGy + i) : 0.0;
+            gz[e] = on ? ldStream(m.lsqGz + i) : 0.0;
+        }
+        // (2) gathered records
+        const RecA Ao = c.A[o], An = c.A[n];
+        const RecB Bo = c.B[o], Bn = c.B[n];
+        RecA R[QGD_LSQ_SLOTS];
+#pragma unroll
+        for (int e = 0; e < QGD_LSQ_SLOTS; ++e) R[e] = c.A[sc[e]];
+        __builtin_amdgcn_sched_barrier(0);
+
+        FaceVals<6> v;
+        loadVals(Ao, v.o);
+        loadVals(An, v.n);
+        double g[18];
+        if (degenerate) {
+            faceGradient<ST_LSQ, 6, 1>(m, f, v, reinterpret_cast<const double*>(c.A), nullptr, g);  // nf*snGrad [L76-83]
+        } else {
+#pragma unroll
+            for (int i = 0; i < 18; ++i) g[i] = 0.0;
+            double pf[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) pf[k] = lerpf(w, v.o[k], v.n[k]);
+#pragma unroll
+            for (int e = 0; e < QGD_LSQ_SLOTS; ++e) {
+                if (e < cnt) {
+                    double cv[6];
+                    loadVals(R[e], cv);
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        const double dphi = cv[k] - pf[k];
+                        g[0 * 6 + k] = g[0 * 6 + k] + gx[e] * dphi;
+                        g[1 * 6 + k] = g[1 * 6 + k] + gy[e] * dphi;
+                        g[2 * 6 + k] = g[2 * 6 + k] + gz[e] * dphi;
+                    }
+                }
+            }
+            for (int e = QGD_LSQ_SLOTS; e < cnt; ++e) {
+                const size_t i = base + (size_t)e * 64;
+                double cv[6];
+                loadVals(c.A[m.lsqCell[i]], cv);
+                const double ex = m.lsqGx[i], ey = m.lsqGy[i], ez = m.lsqGz[i];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    const double dphi = cv[k] - pf[k];
+                    g[0 * 6 + k] = g[0 * 6 + k] + ex * dphi;
+                    g[1 * 6 + k] = g[1 * 6 + k] + ey * dphi;
+                    g[2 * 6 + k] = g[2 * 6 + k] + ez * dphi;
+                }
+            }
+        }
+        finishInternalFace<DBG>(m, c, gm, f, o, n, Ao, An, Bo, Bn, w, hf, S, g, adjustDt, cof, tauMin);
+    }
+    if (adjustDt) blockMaxMin(cof, tauMin, c.blkFace + 2 * (size_t)tile, false);
+}
+
+// ---------------------------------------------------------------------------
+// GaussVolPoint 2-D internal faces: faceFluxKernel<ST_GVP2> [GaussVolPointBase2D_8C L301-367] loads-first: labels and the
+// two face vertices; the streamed face data incl. the six coefficients; the two cell and two vertex records.
+// ---------------------------------------------------------------------------
+template <bool DBG>
+__global__ __launch_bounds__(QGD_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 4)))
+void faceFluxGvp2Kernel(const MeshView m, const CaseView c, const GasModel gm, const int adjustDt) {
+    const int tile = xcdTile((int)gridDim.x);
+    const int f = tile * QGD_BLOCK + (int)threadIdx.x;
+    double cof = -1e300, tauMin = 1e300;
+    if (f < m.nIF) {
+        const size_t nF = (size_t)m.nF;
+        const int o = ldStream(m.own + f), n = ldStream(m.nei + f);
+        const int2 ip = m.ip13[f];
+        const double w = ldStream(m.w + f);
+        const double hf = ldStream(m.hf + f);
+        const double S[3] = {ldStream(m.Sx + f), ldStream(m.Sy + f), ldStream(m.Sz + f)};
+        const double c1 = ldStream(m.c2d + 0 * nF + f), c2 = ldStream(m.c2d + 1 * nF + f), c3 = ldStream(m.c2d + 2 * nF + f),
+                     c4 = ldStream(m.c2d + 3 * nF + f), mv42 = ldStream(m.c2d + 4 * nF + f), mv13 = ldStream(m.c2d + 5 * nF + f);
+        const RecA Ao = c.A[o], An = c.A[n];
+        const RecB Bo = c.B[o], Bn = c.B[n];
+        const RecA Pa = c.P[ip.x], Pb = c.P[ip.y];
+        __builtin_amdgcn_sched_barrier(0);
+
+        double vo[6], vn[6], pa[6], pb[6], g[18];
+        loadVals(Ao, vo); loadVals(An, vn); loadVals(Pa, pa); loadVals(Pb, pb);
+        const int ie1 = m.ie1, ie2 = m.ie2;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const double dfdn = (vn[k] - vo[k]) / mv42;   // [2D.C L317-321]
+            const double dfdt = (pb[k] - pa[k]) / mv13;   // [2D.C L322-328]
+            const double g1 = (dfdn * c1 - dfdt * c2), g2 = (dfdt * c3 - dfdn * c4);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) g[d * 6 + k] = (d == ie1) ? g1 : ((d == ie2) ? g2 : 0.0);  // no dynamic register index
+        }
+        finishInternalFace<DBG>(m, c, gm, f, o, n, Ao, An, Bo, Bn, w, hf, S, g, adjustDt, cof, tauMin);
+    }
+    if (adjustDt) blockMaxMin(cof, tauMin, c.blkFace + 2 * (size_t)tile, false);
+}
+
+// ---------------------------------------------------------------------------
 // GaussVolPoint 3-D internal faces: the bench path.  Same arithmetic as faceFluxKernel<ST_GVP3>, written so that
 // every load of a face is in flight before the first use: (0) labels, (1) the 18 streamed doubles of the face,
 // (2) the 2 cell and 4 vertex records; then ~600 fp64 operations out of registers.  One memory round trip per
@@ -1258,9 +1432,9 @@ static void launchFaceFluxT(const Launcher& L, int stencil, const MeshView& m, c
     if (grid == 0) return;
     switch (stencil) {
         case ST_REDUCED: faceFluxKernel<ST_REDUCED, DBG><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, adj); break;
-        case ST_LSQ: faceFluxKernel<ST_LSQ, DBG><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, adj); break;
+        case ST_LSQ: faceFluxLsqKernel<DBG><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, adj); break;
         case ST_GVP3: faceFluxGvp3Kernel<DBG><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, adj); break;
-        default: faceFluxKernel<ST_GVP2, DBG><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, adj); break;
+        default: faceFluxGvp2Kernel<DBG><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, adj); break;
     }
 }
 void launchFaceFlux(const Launcher& L, int stencil, const MeshView& m, const CaseView& c, const GasModel& g, bool adjustDt) {
