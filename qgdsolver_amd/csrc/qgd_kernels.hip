@@ -891,26 +891,44 @@ void pointInterpRecKernel(const MeshView m, const RecA* __restrict__ A, RecA* __
     if (n == 0) return;
     const size_t base = (size_t)m.pcSlice[p >> 6] * 64 + (p & 63);
     RecA acc = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    int i = 0;
-    for (; i + 8 <= n; i += 8) {  // hexahedral interior vertices: exactly one pass
+    // eight cells per pass, every 48-B gather of the pass in flight before the ordered sum.  A wavefront of interior
+    // hexahedral vertices (8 cells each) takes the unpredicated pass; any other (2-D meshes: 4 cells; triangles,
+    // polyhedra) the predicated loop as a whole.
+    if (__ballot(n != 8) == 0) {
         int id[8];
         double w[8];
         RecA r[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { id[q] = m.pcCell[base + (size_t)(i + q) * 64]; w[q] = m.pcW[base + (size_t)(i + q) * 64]; }
+        for (int q = 0; q < 8; ++q) { id[q] = m.pcCell[base + (size_t)q * 64]; w[q] = m.pcW[base + (size_t)q * 64]; }
 #pragma unroll
         for (int q = 0; q < 8; ++q) r[q] = A[id[q]];
-        __builtin_amdgcn_sched_barrier(0);  // all eight 48-B gathers in flight before the ordered sum
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             acc.rho += w[q] * r[q].rho; acc.ux += w[q] * r[q].ux; acc.uy += w[q] * r[q].uy;
             acc.uz += w[q] * r[q].uz; acc.p += w[q] * r[q].p; acc.e += w[q] * r[q].e;
         }
-    }
-    for (; i < n; ++i) {
-        const double w = m.pcW[base + (size_t)i * 64];
-        const RecA r = A[m.pcCell[base + (size_t)i * 64]];
-        acc.rho += w * r.rho; acc.ux += w * r.ux; acc.uy += w * r.uy; acc.uz += w * r.uz; acc.p += w * r.p; acc.e += w * r.e;
+    } else {
+        for (int i = 0; i < n; i += 8) {
+            int id[8];
+            double w[8];
+            RecA r[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const bool on = i + q < n;
+                id[q] = on ? m.pcCell[base + (size_t)(i + q) * 64] : 0;
+                w[q] = on ? m.pcW[base + (size_t)(i + q) * 64] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) if (i + q < n) r[q] = A[id[q]];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (i + q < n) {
+                    acc.rho += w[q] * r[q].rho; acc.ux += w[q] * r[q].ux; acc.uy += w[q] * r[q].uy;
+                    acc.uz += w[q] * r[q].uz; acc.p += w[q] * r[q].p; acc.e += w[q] * r[q].e;
+                }
+            }
+        }
     }
     P[p] = acc;
 }

@@ -270,15 +270,22 @@ StaticData buildStaticData(const HostMesh& m) {
         const int64_t f = nIF + b;
         for (int32_t q = m.faceOffsets[f]; q < m.faceOffsets[f + 1]; ++q) isPatchPoint[m.facePoints[q]] = 1;
     }
+    // 2-D: GaussVolPoint only ever reads the two face vertices on the far side of the empty direction [2D.C L129-147];
+    // the other half of the vertices need no value (volPointInterpolation computes them, nothing observes them)
+    std::vector<uint8_t> pointUsed((size_t)m.nPoints, 1);
+    if (m.nGeometricD == 2) {
+        std::fill(pointUsed.begin(), pointUsed.end(), 0);
+        for (int32_t v : s.ip13) if (v >= 0) pointUsed[v] = 1;
+    }
     std::vector<int32_t> pcOff((size_t)m.nPoints + 1, 0), pcCellCsr;
     std::vector<double> pcWCsr;
     for (int32_t p = 0; p < m.nPoints; ++p)
-        pcOff[p + 1] = pcOff[p] + (isPatchPoint[p] ? 0 : pc.rowSize(p));
+        pcOff[p + 1] = pcOff[p] + ((isPatchPoint[p] || !pointUsed[p]) ? 0 : pc.rowSize(p));
     pcCellCsr.resize((size_t)pcOff[m.nPoints]);
     pcWCsr.resize((size_t)pcOff[m.nPoints]);
 #pragma omp parallel for schedule(static)
     for (int32_t p = 0; p < m.nPoints; ++p) {
-        if (isPatchPoint[p]) continue;
+        if (isPatchPoint[p] || !pointUsed[p]) continue;
         const int32_t n = pc.rowSize(p);
         int32_t* cells = &pcCellCsr[pcOff[p]];
         double* w = &pcWCsr[pcOff[p]];
