@@ -873,14 +873,12 @@ static void assembleFluxes(qgd_case_s* c, bool adjust) {
         if (c->hasQgdFlux) {
             // fvsc::grad(p) under GaussVolPoint re-runs p's BCs after phiwStar was refreshed
             // [QGDFoam/updateFluxes.H L63-65, GaussVolPointStencil_8C L73]
-            launchBoundaryFaceFlux(L, c->stencil, m, v, c->gas, c->bcDev, true, false);
-            launchPressureMidStep(L, m, v, c->bcDev);
+            launchBoundaryFaceFlux(L, c->stencil, m, v, c->gas, c->bcDev, 1, false);  // + the mid-step pressure itself
             launchBoundaryPoints(L, m, v, true);
         }
     }
     launchFaceFlux(L, c->stencil, m, v, c->gas, adjust);
-    launchBoundaryFaceFlux(L, c->stencil, m, v, c->gas, c->bcDev, false, adjust);
-    if (c->usesPoints && c->hasQgdFlux) launchCommitMidStepPressure(L, m, v);
+    launchBoundaryFaceFlux(L, c->stencil, m, v, c->gas, c->bcDev, (c->usesPoints && c->hasQgdFlux) ? 2 : 0, adjust);
 }
 
 int qgd_case_set_fields(qgd_case_t c, const double* U, const double* T, const double* p) {

@@ -87,11 +87,9 @@ struct Launcher {
 // ---- case kernels -------------------------------------------------------------
 void launchPointInterp(const Launcher& L, const MeshView& m, const CaseView& c);
 void launchBoundaryPoints(const Launcher& L, const MeshView& m, const CaseView& c, bool pOnly);
-void launchCommitMidStepPressure(const Launcher& L, const MeshView& m, const CaseView& c);
-void launchPressureMidStep(const Launcher& L, const MeshView& m, const CaseView& c, const PatchBCDev* bc);
 void launchFaceFlux(const Launcher& L, int stencil, const MeshView& m, const CaseView& c, const GasModel& g, bool adjustDt);
 void launchBoundaryFaceFlux(const Launcher& L, int stencil, const MeshView& m, const CaseView& c, const GasModel& g,
-                            const PatchBCDev* bc, bool phiwOnly, bool adjustDt);
+                            const PatchBCDev* bc, int phiwOnly, bool adjustDt);
 void launchCellUpdate(const Launcher& L, const MeshView& m, const CaseView& c, const GasModel& g, int mode,
                       const int32_t* list, int nList);
 void launchBoundaryUpdate(const Launcher& L, const MeshView& m, const CaseView& c, const GasModel& g, const PatchBCDev* bc,

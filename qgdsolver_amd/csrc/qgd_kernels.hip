@@ -802,12 +802,14 @@ template <int ST, bool DBG>
 __global__ __launch_bounds__(QGD_BLOCK) void boundaryFaceFluxKernel(const MeshView m, const CaseView c, const GasModel gm,
                                                                    const PatchBCDev* __restrict__ bcs, const int phiwOnly,
                                                                    const int adjustDt) {
+    // phiwOnly: 0 = fluxes; 1 = phiwStar + the mid-step pressure of qgdFlux patches only; 2 = fluxes, then the patch
+    // pressure becomes the mid-step one
     const int b = blockIdx.x * QGD_BLOCK + threadIdx.x;
     double cof = -1e300, tauMin = 1e300;
     if (b < m.nBF) {
         const int f = m.nIF + b;
         const PatchBCDev bc = bcs[m.bPatch[b]];
-        const bool live = m.fkind[f] != 3 && bc.ptype != QGD_PATCH_HALO && !(phiwOnly && bc.bcP != QGD_BC_QGDFLUX);
+        const bool live = m.fkind[f] != 3 && bc.ptype != QGD_PATCH_HALO && !(phiwOnly == 1 && bc.bcP != QGD_BC_QGDFLUX);
         if (live) {
             const int o = m.own[f];
             const RecA Ao = c.A[o], Ab = c.bA[b];
@@ -835,9 +837,27 @@ __global__ __launch_bounds__(QGD_BLOCK) void boundaryFaceFluxKernel(const MeshVi
             double out[5], phiw;
             qgdFluxes<DBG>(s, g, S, out, phiw, DBG ? c.dbg + f : nullptr, (size_t)m.nF);
             c.bPhiw[b] = phiw;
-            if (!phiwOnly) {
+            if (phiwOnly == 1) {
+                // p's boundary conditions re-evaluated in the middle of updateFluxes.H with the fresh phiwStar
+                // [qgdFluxFvPatchScalarField_8C L166-192]; bPmid holds the patch pressure after that evaluation
+                const double grad = -(phiw / s.tauf / m.magSf[f]);
+                c.bG[b] = grad;
+                c.bPmid[b] = Ao.p + grad / m.dn[f];
+            } else {
 #pragma unroll
                 for (int k = 0; k < 5; ++k) c.flux[(size_t)k * m.nF + f] = out[k];
+                if (phiwOnly == 2) {
+                    // the face value pf above came from the old patch pressure; from here on the patch field holds the
+                    // mid-step value (one array in the reference: p.boundaryField())
+                    const double pm = c.bPmid[b];
+                    if (Ab.p != pm) {
+                        RecA a = Ab;
+                        a.p = pm;
+                        c.bA[b] = a;
+                        const double rE = c.bRhoLag[b] * (a.e + 0.5 * (a.ux * a.ux + a.uy * a.uy + a.uz * a.uz));
+                        c.bB[b].H = (rE + a.p) / a.rho;
+                    }
+                }
                 if (adjustDt && !(m.ghost && m.ghost[o] == 1)) {
                     const double ms = m.magSf[f];
                     const double Unf = s.Uf[0] * (S[0] / ms) + s.Uf[1] * (S[1] / ms) + s.Uf[2] * (S[2] / ms);
@@ -847,7 +867,7 @@ __global__ __launch_bounds__(QGD_BLOCK) void boundaryFaceFluxKernel(const MeshVi
             }
         }
     }
-    if (adjustDt && !phiwOnly) blockMaxMin(cof, tauMin, c.blkFace + 2 * ((size_t)faceBlocksDev(m) + blockIdx.x), false);
+    if (adjustDt && phiwOnly != 1) blockMaxMin(cof, tauMin, c.blkFace + 2 * ((size_t)faceBlocksDev(m) + blockIdx.x), false);
 }
 
 // ---------------------------------------------------------------------------
@@ -933,21 +953,6 @@ void pointInterpRecKernel(const MeshView m, const RecA* __restrict__ A, RecA* __
     P[p] = acc;
 }
 
-// After the boundary-face fluxes took pf from the old patch pressure, the patch field holds the mid-step value
-// (one array in the reference: p.boundaryField()).
-__global__ __launch_bounds__(QGD_BLOCK) void commitMidStepPressureKernel(const MeshView m, const CaseView c) {
-    const int b = blockIdx.x * QGD_BLOCK + threadIdx.x;
-    if (b >= m.nBF) return;
-    if (m.fkind[m.nIF + b] == 3) return;
-    RecA a = c.bA[b];
-    if (a.p == c.bPmid[b]) return;
-    a.p = c.bPmid[b];
-    c.bA[b] = a;
-    // H = (rhoE + p)/rho is re-formed by the next updateFields.H from this patch pressure [QGDFoam/updateFields.H L71]
-    const double rE = c.bRhoLag[b] * (a.e + 0.5 * (a.ux * a.ux + a.uy * a.uy + a.uz * a.uz));
-    c.bB[b].H = (rE + a.p) / a.rho;
-}
-
 // patch points: weighted mean of the surrounding boundary-face values.  Source
 // and destination strides/offset are free so the qgdFlux pass can refresh the
 // pressure component alone from the mid-step patch pressures.
@@ -970,25 +975,6 @@ __global__ __launch_bounds__(QGD_BLOCK) void boundaryPointKernel(const MeshView 
     double* o = ptF + (size_t)p * ptStride + ptOffset;
 #pragma unroll
     for (int k = 0; k < NC; ++k) o[k] = acc[k];
-}
-
-// GaussVolPoint re-evaluates p's boundary conditions inside fvsc::grad(p)
-// [GaussVolPointStencil_8C L73]: with a qgdFlux patch that picks up the fresh
-// phiwStar [qgdFluxFvPatchScalarField_8C L166-192] while the face value pf of
-// this step was already taken [QGDFoam/updateFields.H L58].  bPmid holds the
-// patch pressure after that mid-step evaluation.
-__global__ __launch_bounds__(QGD_BLOCK) void pressureMidStepKernel(const MeshView m, const CaseView c,
-                                                                  const PatchBCDev* __restrict__ bcs) {
-    const int b = blockIdx.x * QGD_BLOCK + threadIdx.x;
-    if (b >= m.nBF) return;
-    const int f = m.nIF + b;
-    if (m.fkind[f] == 3) return;
-    const PatchBCDev bc = bcs[m.bPatch[b]];
-    if (bc.bcP != QGD_BC_QGDFLUX) return;
-    const double tauf = c.bB[b].aOc * m.hf[f];
-    const double grad = -(c.bPhiw[b] / tauf / m.magSf[f]);
-    c.bG[b] = grad;
-    c.bPmid[b] = c.A[m.own[f]].p + grad / m.dn[f];
 }
 
 // ---------------------------------------------------------------------------
@@ -1435,15 +1421,6 @@ void launchBoundaryPoints(const Launcher& L, const MeshView& m, const CaseView& 
         QGD_TIMED(L, QGD_K_POINT, (boundaryPointKernel<6><<<gridFor(m.nBP), QGD_BLOCK, 0, L.stream>>>(
             m, reinterpret_cast<const double*>(c.bA), 6, reinterpret_cast<double*>(c.P), 6, 0)));
 }
-void launchCommitMidStepPressure(const Launcher& L, const MeshView& m, const CaseView& c) {
-    if (m.nBF == 0) return;
-    QGD_TIMED(L, QGD_K_BC, (commitMidStepPressureKernel<<<gridFor(m.nBF), QGD_BLOCK, 0, L.stream>>>(m, c)));
-}
-void launchPressureMidStep(const Launcher& L, const MeshView& m, const CaseView& c, const PatchBCDev* bc) {
-    if (m.nBF == 0) return;
-    QGD_TIMED(L, QGD_K_BC, (pressureMidStepKernel<<<gridFor(m.nBF), QGD_BLOCK, 0, L.stream>>>(m, c, bc)));
-}
-
 template <bool DBG>
 static void launchFaceFluxT(const Launcher& L, int stencil, const MeshView& m, const CaseView& c, const GasModel& g, bool adj) {
     const int grid = gridFor(m.nIF);
@@ -1461,7 +1438,7 @@ void launchFaceFlux(const Launcher& L, int stencil, const MeshView& m, const Cas
 }
 template <bool DBG>
 static void launchBFaceFluxT(const Launcher& L, int stencil, const MeshView& m, const CaseView& c, const GasModel& g,
-                             const PatchBCDev* bc, bool phiwOnly, bool adj) {
+                             const PatchBCDev* bc, int phiwOnly, bool adj) {
     const int grid = gridFor(m.nBF);
     if (grid == 0) return;
     switch (stencil) {
@@ -1472,8 +1449,8 @@ static void launchBFaceFluxT(const Launcher& L, int stencil, const MeshView& m, 
     }
 }
 void launchBoundaryFaceFlux(const Launcher& L, int stencil, const MeshView& m, const CaseView& c, const GasModel& g,
-                            const PatchBCDev* bc, bool phiwOnly, bool adjustDt) {
-    QGD_TIMED(L, QGD_K_BFACE, (c.dbg && !phiwOnly ? launchBFaceFluxT<true>(L, stencil, m, c, g, bc, phiwOnly, adjustDt)
+                            const PatchBCDev* bc, int phiwOnly, bool adjustDt) {
+    QGD_TIMED(L, QGD_K_BFACE, (c.dbg && phiwOnly != 1 ? launchBFaceFluxT<true>(L, stencil, m, c, g, bc, phiwOnly, adjustDt)
                                                    : launchBFaceFluxT<false>(L, stencil, m, c, g, bc, phiwOnly, adjustDt)));
 }
 void launchCellUpdate(const Launcher& L, const MeshView& m, const CaseView& c, const GasModel& g, int mode,
