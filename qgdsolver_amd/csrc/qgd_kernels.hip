@@ -4,8 +4,9 @@
 //
 //   P   pointInterpKernel      cell -> vertex inverse-distance interpolation
 //   PB  boundaryPointKernel    patch points: average of boundary-face values
-//   F   faceFluxKernel         fused: 13 face interpolations + 4 fvsc gradients
-//                              + all QGD fluxes, one thread per internal face
+//   F   faceFlux{Gvp3,Gvp2,Lsq,Reduced}Kernel   fused: 13 face interpolations + 4 fvsc
+//                              gradients + all QGD fluxes, one thread per internal face,
+//                              one loads-first kernel per stencil
 //   FB  boundaryFaceFluxKernel same on boundary faces (mirror-point stencil)
 //   C   cellUpdateKernel       deterministic gather of face fluxes + explicit
 //                              Euler update + thermo + QGD coefficients
@@ -403,63 +404,6 @@ __device__ __forceinline__ int xcdTile(int nTiles) {
     return (b & 7) * per + (b >> 3);
 }
 
-template <int ST, bool DBG>
-__global__ __launch_bounds__(QGD_BLOCK) void faceFluxKernel(const MeshView m, const CaseView c, const GasModel gm,
-                                                           const int adjustDt) {
-    const int tile = xcdTile((int)gridDim.x);
-    const int f = tile * QGD_BLOCK + (int)threadIdx.x;
-    double cof = -1e300, tauMin = 1e300;
-    if (f < m.nIF) {
-        const int o = ldStream(m.own + f), n = ldStream(m.nei + f);
-        const RecA Ao = c.A[o], An = c.A[n];
-        const RecB Bo = c.B[o], Bn = c.B[n];
-        FaceVals<6> v;
-        loadVals(Ao, v.o);
-        loadVals(An, v.n);
-        double g[18];
-        faceGradient<ST, 6, 1>(m, f, v, reinterpret_cast<const double*>(c.A), reinterpret_cast<const double*>(c.P), g);
-        const double w = ldStream(m.w + f);
-        FaceState s;
-        s.rhof = lerpf(w, Ao.rho, An.rho);
-        const double Uo[3] = {Ao.ux, Ao.uy, Ao.uz}, Un[3] = {An.ux, An.uy, An.uz};
-        double rUo[3], rUn[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            s.Uf[k] = lerpf(w, Uo[k], Un[k]);
-            rUo[k] = Ao.rho * Uo[k];
-            rUn[k] = An.rho * Un[k];
-            s.rhoUf[k] = lerpf(w, rUo[k], rUn[k]);
-        }
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) s.UrhoUf[3 * i + j] = lerpf(w, Uo[i] * rUo[j], Un[i] * rUn[j]);
-        s.pf = lerpf(w, Ao.p, An.p);
-        s.cf = lerpf(w, Bo.c, Bn.c);
-        s.Hf = lerpf(w, Bo.H, Bn.H);
-        s.gammaf = lerpf(w, gm.gamma, gm.gamma);
-        s.alphauf = lerpf(w, alphaEffOf(gm, Bo.muQGD), alphaEffOf(gm, Bn.muQGD));
-        s.muf = lerpf(w, muEffOf(gm, Bo.muQGD), muEffOf(gm, Bn.muQGD));
-        const double hf = ldStream(m.hf + f);
-        s.tauf = lerpf(w, Bo.aOc, Bn.aOc) * hf;  // tauQGDf = lin(aQGD/c)*hQGDf [constScPrModel1_8C L103]
-        const double S[3] = {ldStream(m.Sx + f), ldStream(m.Sy + f), ldStream(m.Sz + f)};
-        double out[5], phiw;
-        qgdFluxes<DBG>(s, g, S, out, phiw, DBG ? c.dbg + f : nullptr, (size_t)m.nF);
-#pragma unroll
-        for (int k = 0; k < 5; ++k) c.flux[(size_t)k * m.nF + f] = out[k];
-        if (adjustDt) {
-            const bool counted = (m.ghost == nullptr) || !(m.ghost[o] == 1 && m.ghost[n] == 1);
-            if (counted) {
-                const double ms = sqrt(S[0] * S[0] + S[1] * S[1] + S[2] * S[2]);
-                const double Unf = s.Uf[0] * (S[0] / ms) + s.Uf[1] * (S[1] / ms) + s.Uf[2] * (S[2] / ms);
-                cof = fmax(fabs(Unf + s.cf), fabs(Unf - s.cf)) * c.dt[0] / hf;  // [QGDCourantNo_8H L44-48]
-                tauMin = s.tauf;
-            }
-        }
-    }
-    if (adjustDt) blockMaxMin(cof, tauMin, c.blkFace + 2 * (size_t)tile, false);
-}
-
 // ---------------------------------------------------------------------------
 // What follows the gradient on an internal face: the 13 interpolations of updateFields.H, the flux algebra, the five
 // net fluxes, the face's share of the Courant number.  Shared by the loads-first kernels of the 2-D stencils below.
@@ -508,7 +452,7 @@ __device__ __forceinline__ void finishInternalFace(const MeshView& m, const Case
 }
 
 // ---------------------------------------------------------------------------
-// leastSquares internal faces (1-D / 2-D meshes, config 2): same arithmetic as faceFluxKernel<ST_LSQ>
+// leastSquares internal faces (1-D / 2-D meshes, config 2): the arithmetic of faceGradient<ST_LSQ>
 // [extendedFaceStencilScalarGrad_8C L50-88], written loads-first like the 3-D kernel: labels and counts; the streamed face
 // data and the first QGD_LSQ_SLOTS stencil entries (neighbour label + wf2*Gdf, coalesced out of the sliced ELL); every
 // gathered record; then the ordered accumulation out of registers.  Longer stencils finish in a loop.
@@ -595,7 +539,41 @@ void faceFluxLsqKernel(const MeshView m, const CaseView c, const GasModel gm, co
 }
 
 // ---------------------------------------------------------------------------
-// GaussVolPoint 2-D internal faces: faceFluxKernel<ST_GVP2> [GaussVolPointBase2D_8C L301-367] loads-first: labels and the
+// reduced stencil internal faces: nf (x) snGrad [reducedFaceNormalStencil_8C L69-108], loads-first.
+// ---------------------------------------------------------------------------
+template <bool DBG>
+__global__ __launch_bounds__(QGD_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 4)))
+void faceFluxReducedKernel(const MeshView m, const CaseView c, const GasModel gm, const int adjustDt) {
+    const int tile = xcdTile((int)gridDim.x);
+    const int f = tile * QGD_BLOCK + (int)threadIdx.x;
+    double cof = -1e300, tauMin = 1e300;
+    if (f < m.nIF) {
+        const int o = ldStream(m.own + f), n = ldStream(m.nei + f);
+        const double w = ldStream(m.w + f);
+        const double hf = ldStream(m.hf + f);
+        const double S[3] = {ldStream(m.Sx + f), ldStream(m.Sy + f), ldStream(m.Sz + f)};
+        const double ms = ldStream(m.magSf + f), dn = ldStream(m.dn + f);
+        const RecA Ao = c.A[o], An = c.A[n];
+        const RecB Bo = c.B[o], Bn = c.B[n];
+        __builtin_amdgcn_sched_barrier(0);
+
+        double vo[6], vn[6], g[18];
+        loadVals(Ao, vo); loadVals(An, vn);
+        const double nx = S[0] / ms, ny = S[1] / ms, nz = S[2] / ms;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const double sn = dn * (vn[k] - vo[k]);
+            g[0 * 6 + k] = nx * sn;
+            g[1 * 6 + k] = ny * sn;
+            g[2 * 6 + k] = nz * sn;
+        }
+        finishInternalFace<DBG>(m, c, gm, f, o, n, Ao, An, Bo, Bn, w, hf, S, g, adjustDt, cof, tauMin);
+    }
+    if (adjustDt) blockMaxMin(cof, tauMin, c.blkFace + 2 * (size_t)tile, false);
+}
+
+// ---------------------------------------------------------------------------
+// GaussVolPoint 2-D internal faces: the arithmetic of faceGradient<ST_GVP2> [GaussVolPointBase2D_8C L301-367], loads-first: labels and the
 // two face vertices; the streamed face data incl. the six coefficients; the two cell and two vertex records.
 // ---------------------------------------------------------------------------
 template <bool DBG>
@@ -635,7 +613,7 @@ void faceFluxGvp2Kernel(const MeshView m, const CaseView c, const GasModel gm, c
 }
 
 // ---------------------------------------------------------------------------
-// GaussVolPoint 3-D internal faces: the bench path.  Same arithmetic as faceFluxKernel<ST_GVP3>, written so that
+// GaussVolPoint 3-D internal faces: the bench path.  Same arithmetic as faceGradient<ST_GVP3>, written so that
 // every load of a face is in flight before the first use: (0) labels, (1) the 18 streamed doubles of the face,
 // (2) the 2 cell and 4 vertex records; then ~600 fp64 operations out of registers.  One memory round trip per
 // dependency level instead of one per gradient component; the register budget is traded for that on purpose.
@@ -1426,7 +1404,7 @@ static void launchFaceFluxT(const Launcher& L, int stencil, const MeshView& m, c
     const int grid = gridFor(m.nIF);
     if (grid == 0) return;
     switch (stencil) {
-        case ST_REDUCED: faceFluxKernel<ST_REDUCED, DBG><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, adj); break;
+        case ST_REDUCED: faceFluxReducedKernel<DBG><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, adj); break;
         case ST_LSQ: faceFluxLsqKernel<DBG><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, adj); break;
         case ST_GVP3: faceFluxGvp3Kernel<DBG><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, adj); break;
         default: faceFluxGvp2Kernel<DBG><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, adj); break;
