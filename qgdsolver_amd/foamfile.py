@@ -195,9 +195,22 @@ def parse_foam_text(text):
     return d
 
 
-def read_dict(path):
+def _read_text(path):
+    """text of a case file; OpenFOAM's writeCompression leaves <name>.gz instead of <name>"""
+    if not os.path.exists(path) and os.path.exists(path + ".gz"):
+        import gzip
+        with gzip.open(path + ".gz", "rt") as f:
+            return f.read()
     with open(path) as f:
-        return parse_foam_text(f.read())
+        return f.read()
+
+
+def _exists(path):
+    return os.path.exists(path) or os.path.exists(path + ".gz")
+
+
+def read_dict(path):
+    return parse_foam_text(_read_text(path))
 
 
 def _split_header(text):
@@ -215,8 +228,7 @@ def _split_header(text):
 
 
 def _read_list_file(path):
-    with open(path) as f:
-        hdr, text = _split_header(f.read())
+    hdr, text = _split_header(_read_text(path))
     m = _LIST_HEAD.search(text)
     if m is None:
         raise FoamFileError(f"{path}: no list found")
@@ -267,8 +279,7 @@ def read_polymesh(poly_dir):
     if m:
         n_cells = int(m.group(1))
 
-    with open(os.path.join(poly_dir, "boundary")) as f:
-        _, text = _split_header(f.read())
+    _, text = _split_header(_read_text(os.path.join(poly_dir, "boundary")))
     m = re.search(r"(\d+)\s*\(", text)
     if m is None:
         raise FoamFileError("boundary: no patch list")
@@ -478,7 +489,7 @@ def read_case_setup(case_dir, time="0"):
     opt["alphaQGD"] = 0.5
     for fname in ("alphaQGD", "ScQGD"):
         fpath = os.path.join(tdir, fname)
-        if os.path.exists(fpath):
+        if _exists(fpath):
             vals, _ = read_field(fpath, mesh)
             if np.any(vals != vals[0]):
                 raise FoamFileError(f"{fpath}: only a uniform {fname} field is supported")

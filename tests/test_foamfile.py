@@ -171,3 +171,21 @@ def test_time_names_follow_openfoam():
     assert time_name(0.0) == "0" and time_name(0.005) == "0.005" and time_name(0.0125) == "0.0125"
     assert time_name(1.0) == "1" and time_name(1e-7) == "1e-07" and time_name(0.1 + 0.2) == "0.3"
     assert time_name(123456.789, 8) == "123456.79"
+
+
+def test_gzipped_case_files(tmp_path):
+    """writeCompression on: every file of the case may be <name>.gz"""
+    import gzip
+    import shutil
+
+    write_step_case(str(tmp_path))
+    ref = ff.read_case_setup(str(tmp_path))
+    for sub in ("constant/polyMesh/points", "constant/polyMesh/faces", "constant/polyMesh/owner", "constant/polyMesh/neighbour",
+                "constant/polyMesh/boundary", "0/U", "0/T", "0/p"):
+        path = os.path.join(str(tmp_path), sub)
+        with open(path, "rb") as fi, gzip.open(path + ".gz", "wb") as fo:
+            shutil.copyfileobj(fi, fo)
+        os.remove(path)
+    got = ff.read_case_setup(str(tmp_path))
+    assert np.array_equal(got[0].array("points"), ref[0].array("points")) and np.array_equal(got[0].array("facePoints"), ref[0].array("facePoints"))
+    assert got[1] == ref[1] and all(np.array_equal(got[2][k], ref[2][k]) for k in ref[2])
