@@ -298,7 +298,11 @@ typedef struct qgd_case_options {
     int32_t adjustTimeStep;   /* 1: Courant/deltaT control
                                  [QGDCourantNo_8H_source.html L36-53,
                                   setDeltaT-QGDQHD_8H_source.html L41-61]         */
-    int32_t reserved;
+    int32_t consistentEnergy; /* 0: the explicit energy re-solve as the listing has it, fvm::ddt(rho,e) - fvc::ddt(rhoE)
+                                 [QGDEEqn_8H_source.html L67-72]: rho*e advances by the increment of rhoE and never gives
+                                 the kinetic energy back (Sod's plateau comes out at p* = 0.330 instead of 0.303);
+                                 1: keep e = rhoE/rho - |U|^2/2 of L49 (what the implicit branch's fvc::ddt(rho,e) form,
+                                 L57, gives with a zero source): the physically consistent update                  */
     double R;                 /* perfectGas: specific gas constant                */
     double Cv;                /* eConst (Tref = 0, Esref = 0)                     */
     double mu;                /* constTransport: mu                               */

@@ -1450,8 +1450,10 @@ struct Case {
                 e.in[ci] = rhoE.in[ci] / rho.in[ci] - 0.5 * (u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
             }
             correctBC_e();
-            // solve(fvm::ddt(rho,e) - fvc::ddt(rhoE) == rhoESu) [:67-72] -- as written in the listing
-            for (int ci = 0; ci < m.nC; ++ci) {
+            // solve(fvm::ddt(rho,e) - fvc::ddt(rhoE) == rhoESu) [:67-72] -- as written in the listing: rho*e advances by
+            // the increment of rhoE, the kinetic energy is not taken out again.  consistentEnergy keeps the e of [:49]
+            // (what fvc::ddt(rho,e), the form of the implicit branch [:57], would give with rhoESu = 0).
+            if (!opt.consistentEnergy) for (int ci = 0; ci < m.nC; ++ci) {
                 const double diag = rDeltaT * rho.in[ci] * m.V[ci];
                 double src = rDeltaT * rhoOld[ci] * eOld[ci] * m.V[ci];
                 src += m.V[ci] * (rDeltaT * (rhoE.in[ci] - rhoEOld[ci]));

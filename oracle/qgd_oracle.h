@@ -24,7 +24,7 @@ extern "C" {
  * QGD_FVSC_*) so the Python tests can share them */
 
 typedef struct orc_case_options {
-    int32_t stencil, implicitDiffusion, adjustTimeStep, reserved;
+    int32_t stencil, implicitDiffusion, adjustTimeStep, consistentEnergy;
     double R, Cv, mu, Pr, ScQGD, PrQGD, alphaQGD, deltaT, maxCo, maxDeltaT, cTau;
 } orc_case_options;
 

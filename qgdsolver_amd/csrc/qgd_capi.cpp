@@ -798,6 +798,7 @@ int qgd_case_create(qgd_device_t d, const qgd_case_options* opt, qgd_case_t* out
         GasModel& g = c->gas;
         g.R = opt->R; g.Cv = opt->Cv; g.mu0 = opt->mu; g.Pr = opt->Pr; g.ScQGD = opt->ScQGD; g.PrQGD = opt->PrQGD;
         g.alphaQGD = opt->alphaQGD;
+        g.consistentEnergy = opt->consistentEnergy ? 1 : 0;
         const double Cp = opt->Cv + opt->R;
         g.gamma = Cp / opt->Cv;
         const double rPr = 1.0 / opt->Pr;

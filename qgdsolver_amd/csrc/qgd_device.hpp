@@ -49,6 +49,7 @@ struct GasModel {
     double R, Cv, mu0, Pr, ScQGD, PrQGD, alphaQGD;
     double gamma;     // Cp/Cv
     double alphah0;   // (Cp*mu*rPr)/Cp
+    int32_t consistentEnergy;  // qgd_case_options::consistentEnergy
 };
 
 // Mutable case state on the device

@@ -1043,7 +1043,8 @@ void cellUpdateKernel(const MeshView m, const CaseView c, const GasModel gm, con
         An.uy = (A.rho * A.uy + (Kn.ruy - K.ruy)) / rho;
         An.uz = (A.rho * A.uz + (Kn.ruz - K.ruz)) / rho;
         // solve(fvm::ddt(rho,e) - fvc::ddt(rhoE)) [QGDEEqn_8H L67-72], as written in the listing
-        An.e = (A.rho * A.e + (Kn.rE - K.rE)) / rho;
+        An.e = gm.consistentEnergy ? Kn.rE / rho - 0.5 * (An.ux * An.ux + An.uy * An.uy + An.uz * An.uz)   // e of [QGDEEqn_8H L49] kept
+                                   : (A.rho * A.e + (Kn.rE - K.rE)) / rho;
         // thermo.correct(): eConst + perfectGas [hePsiQGDThermo_8C L48-64, L123-124]
         const double T = An.e / gm.Cv;
         const double psi = 1.0 / (gm.R * T);

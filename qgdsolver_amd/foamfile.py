@@ -477,6 +477,9 @@ def read_case_setup(case_dir, time="0"):
     qgd = tp["QGD"]
     # QGDThermo::read(): implicitDiffusion defaults to true when absent [QGDThermo.C L70-82]
     opt["implicitDiffusion"] = 1 if str(qgd.get("implicitDiffusion", "true")) in ("true", "on", "yes", "1") else 0
+    # not a reference entry: selects the physically consistent explicit energy update (qgd_case_options::consistentEnergy)
+    if "consistentEnergy" in qgd:
+        opt["consistentEnergy"] = 1 if str(qgd["consistentEnergy"]) in ("true", "on", "yes", "1") else 0
     model = str(qgd["QGDCoeffs"])
     if model != "constScPrModel1":
         raise FoamFileError(f"QGDCoeffs '{model}' is not supported (only constScPrModel1)")
