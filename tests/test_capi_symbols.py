@@ -61,3 +61,26 @@ def test_bad_arguments_return_status():
     lo = np.zeros(3); hi = np.ones(3)
     rc = L.lib.qgd_mesh_box(0, 3, 3, 0, 3, lo.ctypes.data_as(L.c_double_p), hi.ctypes.data_as(L.c_double_p), None, C.byref(h))
     assert rc == L.ERR_INVALID and b"makeBox" in L.lib.qgd_last_error()
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/qgd_amd.h is a C header (C99, -pedantic -Werror) and a C program links against the library: the boundary a
+    non-C++ host (cgo, JNI, ctypes, Fortran bind(C)) would use"""
+    import subprocess
+
+    src = tmp_path / "t.c"
+    src.write_text('#include <stdio.h>\n#include "qgd_amd.h"\n'
+                   'int main(void) {\n'
+                   '    qgd_case_options o; qgd_poisson_control c; qgd_mesh_t m = 0; int64_t s[7];\n'
+                   '    double lo[3] = {0, 0, 0}, hi[3] = {1, 1, 1}; int32_t pt[6] = {0, 0, 0, 0, 0, 0};\n'
+                   '    if (qgd_case_options_default(&o) || qgd_poisson_control_default(&c)) return 1;\n'
+                   '    if (qgd_mesh_box(3, 2, 2, 0, 2, lo, hi, pt, &m) || qgd_mesh_sizes(m, s)) return 2;\n'
+                   '    printf("%s %lld %d\\n", qgd_version(), (long long)s[3], o.stencil);\n'
+                   '    return qgd_mesh_free(m);\n}\n')
+    exe = tmp_path / "t"
+    libdir = os.path.join(ROOT, "qgdsolver_amd")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), str(src),
+                        "-o", str(exe), "-L", libdir, "-lqgd_amd", f"-Wl,-rpath,{libdir}"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.split()[-2:] == ["12", "2"], (r.returncode, r.stdout, r.stderr)
