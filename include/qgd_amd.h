@@ -392,7 +392,8 @@ enum {
     QGD_K_BFACE = 2,   /* boundary-face flux kernel                             */
     QGD_K_CELL = 3,    /* flux gather + Euler update + thermo + QGD coefficients */
     QGD_K_BC = 4,      /* boundary-condition refresh                            */
-    QGD_K_COUNT = 5
+    QGD_K_BPOINT = 5,  /* patch points: mean of the surrounding patch-face values */
+    QGD_K_COUNT = 6
 };
 /* Enable HIP-event timing of every launch of kernel `k` on the case's own
  * stream; totals since the last reset. */

@@ -81,6 +81,7 @@ struct Mesh {
     bool coupled(int p) const { return patches[p].type == PATCH_CYCLIC || patches[p].type == PATCH_HALO; }
 
     void geometry();
+    void derivedGeometry();
     void addressing();
     void pointInterpolationWeights();
     void haloFaces();
@@ -148,6 +149,10 @@ void Mesh::geometry() {
         else for (int k = 0; k < 3; ++k) C[3 * (size_t)c + k] = cEst[3 * (size_t)c + k];
         V[c] *= (1.0 / 3.0);
     }
+    derivedGeometry();
+}
+
+void Mesh::derivedGeometry() {
     // L0: surfaceInterpolation weights / deltaCoeffs / nonOrthDeltaCoeffs,
     // fvPatch::delta() patch-normal on non-coupled patches
     w.assign(nF, 1.0); delta.assign(nF, 0.0); nonOrthDelta.assign(nF, 0.0);
@@ -1537,6 +1542,20 @@ int orc_mesh_get(void* mp, const char* name, double* out, int64_t n) {
     if (!src) return -5;
     if ((int64_t)src->size() > n) return -1;
     std::copy(src->begin(), src->end(), out);
+    return 0;
+}
+/* geometry handed over by the caller (what an OpenFOAM adapter does with mesh.Sf(), Cf(), C(), V(); counterpart of
+ * qgd_mesh_set_geometry): everything derived from it is rebuilt, stencils built so far are dropped */
+int orc_mesh_set_geometry(void* mp, const double* Sf, const double* Cf, const double* C, const double* V) {
+    MeshHandle* h = (MeshHandle*)mp;
+    Mesh& m = h->m;
+    m.Sf.assign(Sf, Sf + 3 * (size_t)m.nF); m.Cf.assign(Cf, Cf + 3 * (size_t)m.nF);
+    m.C.assign(C, C + 3 * (size_t)m.nC); m.V.assign(V, V + (size_t)m.nC);
+    for (int f = 0; f < m.nF; ++f) m.magSf[f] = mag3(&m.Sf[3 * (size_t)f]);
+    m.derivedGeometry();
+    m.pointInterpolationWeights();
+    for (auto& kv : h->cache.byName) delete kv.second;
+    h->cache.byName.clear();
     return 0;
 }
 int orc_mesh_info(void* mp, int64_t info[4]) {

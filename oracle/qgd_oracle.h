@@ -37,6 +37,8 @@ void* orc_mesh_create(int32_t nPoints, const double* points, int32_t nFaces,
 void orc_mesh_free(void* m);
 /* "Sf","magSf","Cf","C","V","weights","deltaCoeffs","nonOrthDeltaCoeffs" */
 int orc_mesh_get(void* m, const char* name, double* out, int64_t n);
+/* geometry supplied by the caller (counterpart of qgd_mesh_set_geometry); derived coefficients are rebuilt */
+int orc_mesh_set_geometry(void* m, const double* Sf, const double* Cf, const double* C, const double* V);
 /* info[0]=nGeometricD, info[1..3]=geometricD */
 int orc_mesh_info(void* m, int64_t info[4]);
 /* halo lists of a cell-range shard, one call per halo slot (= neighbouring shard; box slabs: 0 lower, 1 upper) */

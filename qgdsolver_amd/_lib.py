@@ -119,7 +119,7 @@ ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_SCHEME, ERR_UNKNOWN_NAME, ERR_NOT_IMPLE
 PATCH_GENERIC, PATCH_EMPTY, PATCH_SYMMETRYPLANE, PATCH_SYMMETRY, PATCH_WEDGE, PATCH_CYCLIC, PATCH_HALO = range(7)
 BC_ZEROGRADIENT, BC_FIXEDVALUE, BC_SLIP, BC_QGDFLUX, BC_NONE = range(5)
 FVSC_REDUCED, FVSC_LEASTSQUARES, FVSC_GAUSSVOLPOINT = range(3)
-K_POINT, K_FACE, K_BFACE, K_CELL, K_BC = range(5)
+K_POINT, K_FACE, K_BFACE, K_CELL, K_BC, K_BPOINT = range(6)
 
 
 class QgdError(RuntimeError):

@@ -135,8 +135,8 @@ struct qgd_case_s {
     bool timing = false;
     std::vector<TimedLaunch> pending;
     std::vector<hipEvent_t> freeEvents;
-    double totalMs[QGD_K_COUNT] = {0, 0, 0, 0, 0};
-    int64_t launches[QGD_K_COUNT] = {0, 0, 0, 0, 0};
+    double totalMs[QGD_K_COUNT] = {};
+    int64_t launches[QGD_K_COUNT] = {};
     hipEvent_t curStart = nullptr;
     // optional caller-owned stream (e.g. the one RCCL transfers are ordered on)
     hipStream_t userStream = nullptr;
@@ -445,6 +445,7 @@ int qgd_device_create(qgd_mesh_t mh, int deviceId, qgd_device_t* out) {
         v.nBP = (int32_t)s.bpPoint.size();
         v.bpPoint = up(s.bpPoint); v.bpOff = up(s.bpOff); v.bpFace = up(s.bpFace); v.bpW = up(s.bpW);
         v.cfSlice = up(s.cfSlice); v.cfCount = up(s.cfCount); v.cfItem = up(s.cfItem);
+        v.fpos = up(s.fpos); v.cfPos = up(s.cfPos);
         v.V = up(s.V); v.hQGD = up(s.hQGD); v.ghost = up(s.ghost);
         v.bPatch = up(s.bPatch); v.hQGDb = up(s.hQGDb);
         {
@@ -1129,49 +1130,28 @@ int qgd_case_get_field(qgd_case_t c, const char* name, double* out, int64_t outD
         }
         return QGD_OK;
     }
-    // cell / boundary fields assembled from the records
+    // cell / boundary fields: extracted from the records on the device, one dense copy back
+    static const std::map<std::string, int> cellFields = {
+        {"rho", XF_RHO}, {"U", XF_U}, {"p", XF_P}, {"e", XF_E}, {"T", XF_T}, {"rhoU", XF_RHOU}, {"rhoE", XF_RHOE}, {"c", XF_C},
+        {"psi", XF_PSI}, {"mu", XF_MU}, {"alphau", XF_ALPHAU}, {"tauQGD", XF_TAUQGD}, {"muQGD", XF_MUQGD},
+        {"alphauQGD", XF_ALPHAUQGD}, {"hQGD", XF_HQGD}, {"H", XF_H}, {"gamma", XF_GAMMA}};
+    auto cf = cellFields.find(s);
+    if (cf == cellFields.end()) return fail(QGD_ERR_UNKNOWN_NAME, "qgd_case_get_field: unknown field " + s);
     const int64_t n = bnd ? m.nBF : m.nC;
-    std::vector<RecA> A((size_t)n);
-    std::vector<RecB> B((size_t)n);
-    std::vector<Cons> K;
-    if (n) {
-        HIP_CHECK(hipMemcpy(A.data(), bnd ? c->view.bA : c->view.A, sizeof(RecA) * (size_t)n, hipMemcpyDeviceToHost));
-        HIP_CHECK(hipMemcpy(B.data(), bnd ? c->view.bB : c->view.B, sizeof(RecB) * (size_t)n, hipMemcpyDeviceToHost));
-    }
-    std::vector<double> hq((size_t)n);
-    if (n) HIP_CHECK(hipMemcpy(hq.data(), bnd ? m.hQGDb : m.hQGD, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
-    if (!bnd) {
-        K.resize((size_t)n);
-        if (n) HIP_CHECK(hipMemcpy(K.data(), c->view.K, sizeof(Cons) * (size_t)n, hipMemcpyDeviceToHost));
-    }
-    int nc = 1;
-    if (s == "U" || s == "rhoU") nc = 3;
+    const int nc = (cf->second == XF_U || cf->second == XF_RHOU) ? 3 : 1;
     if (n * nc > outDoubles) return fail(QGD_ERR_INVALID, "output too small");
-    for (int64_t i = 0; i < n; ++i) {
-        const RecA& a = A[i];
-        const RecB& b = B[i];
-        double* o = out + i * nc;
-        if (s == "rho") o[0] = a.rho;
-        else if (s == "U") { o[0] = a.ux; o[1] = a.uy; o[2] = a.uz; }
-        else if (s == "p") o[0] = a.p;
-        else if (s == "e") o[0] = a.e;
-        else if (s == "T") o[0] = a.e / g.Cv;
-        else if (s == "rhoU") {
-            if (bnd) { o[0] = a.rho * a.ux; o[1] = a.rho * a.uy; o[2] = a.rho * a.uz; }
-            else { o[0] = K[i].rux; o[1] = K[i].ruy; o[2] = K[i].ruz; }
-        } else if (s == "rhoE") o[0] = bnd ? a.rho * (a.e + 0.5 * (a.ux * a.ux + a.uy * a.uy + a.uz * a.uz)) : K[i].rE;
-        else if (s == "c") o[0] = b.c;
-        else if (s == "psi") o[0] = 1.0 / (g.R * (a.e / g.Cv));
-        else if (s == "mu") o[0] = g.mu0 + b.muQGD;
-        else if (s == "alphau") o[0] = g.alphah0 + b.muQGD / g.PrQGD;
-        else if (s == "tauQGD") o[0] = g.alphaQGD * hq[i] / b.c;
-        else if (s == "muQGD") o[0] = b.muQGD;
-        else if (s == "alphauQGD") o[0] = b.muQGD / g.PrQGD;
-        else if (s == "hQGD") o[0] = hq[i];
-        else if (s == "H") o[0] = b.H;
-        else if (s == "gamma") o[0] = g.gamma;
-        else return fail(QGD_ERR_UNKNOWN_NAME, "qgd_case_get_field: unknown field " + s);
-    }
+    if (n == 0) return QGD_OK;
+    double* tmp = nullptr;
+    HIP_CHECK(hipMalloc((void**)&tmp, sizeof(double) * (size_t)(n * nc)));
+    try {
+        (void)hipGetLastError();
+        launchExtractField(c->stream(), bnd ? c->view.bA : c->view.A, bnd ? c->view.bB : c->view.B, bnd ? nullptr : c->view.K,
+                           bnd ? m.hQGDb : m.hQGD, n, g, cf->second, tmp);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(c->stream()));
+        HIP_CHECK(hipMemcpy(out, tmp, sizeof(double) * (size_t)(n * nc), hipMemcpyDeviceToHost));
+    } catch (...) { (void)hipFree(tmp); throw; }
+    (void)hipFree(tmp);
     return QGD_OK;
     QGD_CATCH
 }

@@ -37,6 +37,8 @@ struct MeshView {
     const int32_t* pcSlice; const uint8_t* pcCount; const int32_t* pcCell; const double* pcW;  // sliced ELL (64-point slices)
     int32_t nBP; const int32_t* bpPoint; const int32_t* bpOff; const int32_t* bpFace; const double* bpW;
     const int32_t* cfSlice; const uint8_t* cfCount; const int32_t* cfItem;                     // sliced ELL (64-cell slices)
+    const int32_t* fpos;     // nIF: storage position of an internal face's net fluxes (slot-major, qgd_setup.hpp)
+    const int32_t* cfPos;    // cfItem with positions instead of labels: gather list of the cell kernel
     const double* V; const double* hQGD; const uint8_t* ghost;
     const int32_t* bPatch; const double* hQGDb;
 };
@@ -62,7 +64,7 @@ struct CaseView {
     double* bPmid;                  // nBF patch pressure after GaussVolPoint's mid-step BC evaluation
     double* bRhoLag;                // nBF patch density of the previous step: rhoU_b, rhoE_b are built with it
                                     //     [QGDUEqn_8H L88-89, QGDEEqn_8H L75-76 run before QGDFoam_8C L156]
-    double* flux;                   // 5*nF net face fluxes, SoA: flux[k*nF + f]
+    double* flux;                   // 5*nF net face fluxes, SoA: flux[k*nF + fpos[f]] (boundary faces: their label)
     double* red;                    // [0]=max Co, [1]=min tauQGDf, [2]=min rho, [3]=min e
     double* blkFace;                // 2 per face-kernel workgroup (internal then boundary): max Cof, min tauQGDf
     double* blkCell;                // 2 per cell-kernel workgroup: min rho, min e since the last query
@@ -106,6 +108,12 @@ int bfaceBlocks(const MeshView& m);
 int cellBlocks(const MeshView& m);
 void launchHaloPack(const Launcher& L, const CaseView& c, const int32_t* cells, int32_t nCells, const int32_t* bfaces,
                     int32_t nFaces, double* buf, bool pack);
+
+// ---- accessor: one named cell / patch field out of the records (K == nullptr on patches) ----------------------------
+enum ExtractField : int { XF_RHO = 0, XF_U, XF_P, XF_E, XF_T, XF_RHOU, XF_RHOE, XF_C, XF_PSI, XF_MU, XF_ALPHAU, XF_TAUQGD, XF_MUQGD,
+                          XF_ALPHAUQGD, XF_HQGD, XF_H, XF_GAMMA };
+void launchExtractField(hipStream_t s, const RecA* A, const RecB* B, const Cons* K, const double* hq, int64_t n, const GasModel& g,
+                        int field, double* out);
 
 // ---- fvsc operators on plain fields ----------------------------------------------
 // op: 0 grad (out 3*NC per face), 1 div (out NC/3 per face); NC in {1,3,9}

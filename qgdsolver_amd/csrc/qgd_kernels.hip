@@ -412,7 +412,7 @@ template <bool DBG>
 __device__ __forceinline__ void finishInternalFace(const MeshView& m, const CaseView& c, const GasModel& gm, const int f, const int o,
                                                    const int n, const RecA& Ao, const RecA& An, const RecB& Bo, const RecB& Bn,
                                                    const double w, const double hf, const double S[3], const double* __restrict__ g,
-                                                   const int adjustDt, double& cof, double& tauMin) {
+                                                   const int fp, const int adjustDt, double& cof, double& tauMin) {
     const size_t nF = (size_t)m.nF;
     FaceState s;
     s.rhof = lerpf(w, Ao.rho, An.rho);
@@ -439,7 +439,7 @@ __device__ __forceinline__ void finishInternalFace(const MeshView& m, const Case
     double out[5], phiw;
     qgdFluxes<DBG>(s, g, S, out, phiw, DBG ? c.dbg + f : nullptr, nF);
 #pragma unroll
-    for (int k = 0; k < 5; ++k) c.flux[(size_t)k * nF + f] = out[k];
+    for (int k = 0; k < 5; ++k) c.flux[(size_t)k * nF + fp] = out[k];
     if (adjustDt) {
         const bool counted = (m.ghost == nullptr) || !(m.ghost[o] == 1 && m.ghost[n] == 1);
         if (counted) {
@@ -466,7 +466,7 @@ void faceFluxLsqKernel(const MeshView m, const CaseView c, const GasModel gm, co
     double cof = -1e300, tauMin = 1e300;
     if (f < m.nIF) {
         // (0) labels
-        const int o = ldStream(m.own + f), n = ldStream(m.nei + f);
+        const int o = ldStream(m.own + f), n = ldStream(m.nei + f), fp = ldStream(m.fpos + f);
         const int cnt = m.lsqCnt[f];
         const bool degenerate = m.lsqDeg[f] != 0;
         const size_t base = (size_t)m.lsqSlice[f >> 6] * 64 + (f & 63);
@@ -533,7 +533,7 @@ void faceFluxLsqKernel(const MeshView m, const CaseView c, const GasModel gm, co
                 }
             }
         }
-        finishInternalFace<DBG>(m, c, gm, f, o, n, Ao, An, Bo, Bn, w, hf, S, g, adjustDt, cof, tauMin);
+        finishInternalFace<DBG>(m, c, gm, f, o, n, Ao, An, Bo, Bn, w, hf, S, g, fp, adjustDt, cof, tauMin);
     }
     if (adjustDt) blockMaxMin(cof, tauMin, c.blkFace + 2 * (size_t)tile, false);
 }
@@ -548,7 +548,7 @@ void faceFluxReducedKernel(const MeshView m, const CaseView c, const GasModel gm
     const int f = tile * QGD_BLOCK + (int)threadIdx.x;
     double cof = -1e300, tauMin = 1e300;
     if (f < m.nIF) {
-        const int o = ldStream(m.own + f), n = ldStream(m.nei + f);
+        const int o = ldStream(m.own + f), n = ldStream(m.nei + f), fp = ldStream(m.fpos + f);
         const double w = ldStream(m.w + f);
         const double hf = ldStream(m.hf + f);
         const double S[3] = {ldStream(m.Sx + f), ldStream(m.Sy + f), ldStream(m.Sz + f)};
@@ -567,7 +567,7 @@ void faceFluxReducedKernel(const MeshView m, const CaseView c, const GasModel gm
             g[1 * 6 + k] = ny * sn;
             g[2 * 6 + k] = nz * sn;
         }
-        finishInternalFace<DBG>(m, c, gm, f, o, n, Ao, An, Bo, Bn, w, hf, S, g, adjustDt, cof, tauMin);
+        finishInternalFace<DBG>(m, c, gm, f, o, n, Ao, An, Bo, Bn, w, hf, S, g, fp, adjustDt, cof, tauMin);
     }
     if (adjustDt) blockMaxMin(cof, tauMin, c.blkFace + 2 * (size_t)tile, false);
 }
@@ -584,7 +584,7 @@ void faceFluxGvp2Kernel(const MeshView m, const CaseView c, const GasModel gm, c
     double cof = -1e300, tauMin = 1e300;
     if (f < m.nIF) {
         const size_t nF = (size_t)m.nF;
-        const int o = ldStream(m.own + f), n = ldStream(m.nei + f);
+        const int o = ldStream(m.own + f), n = ldStream(m.nei + f), fp = ldStream(m.fpos + f);
         const int2 ip = m.ip13[f];
         const double w = ldStream(m.w + f);
         const double hf = ldStream(m.hf + f);
@@ -607,7 +607,7 @@ void faceFluxGvp2Kernel(const MeshView m, const CaseView c, const GasModel gm, c
 #pragma unroll
             for (int d = 0; d < 3; ++d) g[d * 6 + k] = (d == ie1) ? g1 : ((d == ie2) ? g2 : 0.0);  // no dynamic register index
         }
-        finishInternalFace<DBG>(m, c, gm, f, o, n, Ao, An, Bo, Bn, w, hf, S, g, adjustDt, cof, tauMin);
+        finishInternalFace<DBG>(m, c, gm, f, o, n, Ao, An, Bo, Bn, w, hf, S, g, fp, adjustDt, cof, tauMin);
     }
     if (adjustDt) blockMaxMin(cof, tauMin, c.blkFace + 2 * (size_t)tile, false);
 }
@@ -633,7 +633,7 @@ void faceFluxGvp3Kernel(const MeshView m, const CaseView c, const GasModel gm, c
     if (f < m.nIF) {
         const size_t nF = (size_t)m.nF;
         // (0) labels
-        const int o = ldStream(m.own + f), n = ldStream(m.nei + f);
+        const int o = ldStream(m.own + f), n = ldStream(m.nei + f), fp = ldStream(m.fpos + f);
         const int4 vt = m.verts[f];
         const int kind = m.fkind[f];
         // (1) streamed face data
@@ -734,7 +734,7 @@ void faceFluxGvp3Kernel(const MeshView m, const CaseView c, const GasModel gm, c
         double out[5], phiw;
         qgdFluxes<DBG>(s, g, S, out, phiw, DBG ? c.dbg + f : nullptr, nF);
 #pragma unroll
-        for (int k = 0; k < 5; ++k) c.flux[(size_t)k * nF + f] = out[k];
+        for (int k = 0; k < 5; ++k) c.flux[(size_t)k * nF + fp] = out[k];
         if (adjustDt) {
             const bool counted = (m.ghost == nullptr) || !(m.ghost[o] == 1 && m.ghost[n] == 1);
             if (counted) {
@@ -995,7 +995,7 @@ void cellUpdateKernel(const MeshView m, const CaseView c, const GasModel gm, con
             int it[6];
             double fl[6][5];
 #pragma unroll
-            for (int q = 0; q < 6; ++q) it[q] = m.cfItem[base + (size_t)q * 64];
+            for (int q = 0; q < 6; ++q) it[q] = m.cfPos[base + (size_t)q * 64];
 #pragma unroll
             for (int q = 0; q < 6; ++q) {
                 const size_t f = (size_t)(it[q] >= 0 ? it[q] : ~it[q]);
@@ -1012,7 +1012,7 @@ void cellUpdateKernel(const MeshView m, const CaseView c, const GasModel gm, con
                 int it[6];
                 double fl[6][5];
 #pragma unroll
-                for (int q = 0; q < 6; ++q) it[q] = (i + q < n) ? m.cfItem[base + (size_t)(i + q) * 64] : 0;
+                for (int q = 0; q < 6; ++q) it[q] = (i + q < n) ? m.cfPos[base + (size_t)(i + q) * 64] : 0;
 #pragma unroll
                 for (int q = 0; q < 6; ++q) {
                     const size_t f = (size_t)(it[q] >= 0 ? it[q] : ~it[q]);
@@ -1376,6 +1376,41 @@ __global__ __launch_bounds__(QGD_BLOCK) void qhdFaceKernel(const MeshView m, con
     put(QHD_PHITAUT, tau * phiu * (Uf[0] * gT[0] + Uf[1] * gT[1] + Uf[2] * gT[2]));       // [QHDTEqn_8H L66]
 }
 
+// Named cell / patch field out of the records into a dense array (the accessor path of qgd_case_get_field: one pass on
+// the device and one copy of what was asked for, instead of shipping every record to the host).
+__global__ __launch_bounds__(QGD_BLOCK) void extractFieldKernel(const RecA* __restrict__ A, const RecB* __restrict__ B,
+                                                               const Cons* __restrict__ K, const double* __restrict__ hq,
+                                                               const int64_t n, const GasModel g, const int field,
+                                                               double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * QGD_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const RecA a = A[i];
+    const RecB b = B[i];
+    const double ke = 0.5 * (a.ux * a.ux + a.uy * a.uy + a.uz * a.uz);
+    switch (field) {
+        case XF_RHO: out[i] = a.rho; break;
+        case XF_U: out[3 * i] = a.ux; out[3 * i + 1] = a.uy; out[3 * i + 2] = a.uz; break;
+        case XF_P: out[i] = a.p; break;
+        case XF_E: out[i] = a.e; break;
+        case XF_T: out[i] = a.e / g.Cv; break;
+        case XF_RHOU:
+            if (K) { out[3 * i] = K[i].rux; out[3 * i + 1] = K[i].ruy; out[3 * i + 2] = K[i].ruz; }
+            else { out[3 * i] = a.rho * a.ux; out[3 * i + 1] = a.rho * a.uy; out[3 * i + 2] = a.rho * a.uz; }
+            break;
+        case XF_RHOE: out[i] = K ? K[i].rE : a.rho * (a.e + ke); break;
+        case XF_C: out[i] = b.c; break;
+        case XF_PSI: out[i] = 1.0 / (g.R * (a.e / g.Cv)); break;
+        case XF_MU: out[i] = g.mu0 + b.muQGD; break;
+        case XF_ALPHAU: out[i] = g.alphah0 + b.muQGD / g.PrQGD; break;
+        case XF_TAUQGD: out[i] = g.alphaQGD * hq[i] / b.c; break;
+        case XF_MUQGD: out[i] = b.muQGD; break;
+        case XF_ALPHAUQGD: out[i] = b.muQGD / g.PrQGD; break;
+        case XF_HQGD: out[i] = hq[i]; break;
+        case XF_H: out[i] = b.H; break;
+        default: out[i] = g.gamma; break;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
@@ -1394,10 +1429,10 @@ void launchPointInterp(const Launcher& L, const MeshView& m, const CaseView& c) 
 void launchBoundaryPoints(const Launcher& L, const MeshView& m, const CaseView& c, bool pOnly) {
     if (m.nBP == 0) return;
     if (pOnly)
-        QGD_TIMED(L, QGD_K_POINT, (boundaryPointKernel<1><<<gridFor(m.nBP), QGD_BLOCK, 0, L.stream>>>(
+        QGD_TIMED(L, QGD_K_BPOINT, (boundaryPointKernel<1><<<gridFor(m.nBP), QGD_BLOCK, 0, L.stream>>>(
             m, c.bPmid, 1, reinterpret_cast<double*>(c.P), 6, 4)));
     else
-        QGD_TIMED(L, QGD_K_POINT, (boundaryPointKernel<6><<<gridFor(m.nBP), QGD_BLOCK, 0, L.stream>>>(
+        QGD_TIMED(L, QGD_K_BPOINT, (boundaryPointKernel<6><<<gridFor(m.nBP), QGD_BLOCK, 0, L.stream>>>(
             m, reinterpret_cast<const double*>(c.bA), 6, reinterpret_cast<double*>(c.P), 6, 0)));
 }
 template <bool DBG>
@@ -1464,6 +1499,12 @@ void launchHaloPack(const Launcher& L, const CaseView& c, const int32_t* cells, 
     const int n = nCells + nFaces;
     if (n == 0) return;
     haloKernel<<<gridFor(n), QGD_BLOCK, 0, L.stream>>>(c, cells, nCells, bfaces, nFaces, buf, pack ? 1 : 0);
+}
+
+void launchExtractField(hipStream_t s, const RecA* A, const RecB* B, const Cons* K, const double* hq, int64_t n, const GasModel& g,
+                        int field, double* out) {
+    if (n == 0) return;
+    extractFieldKernel<<<gridFor(n), QGD_BLOCK, 0, s>>>(A, B, K, hq, n, g, field, out);
 }
 
 template <int ST, int NC>

@@ -61,7 +61,7 @@ int64_t StaticData::bytes() const {
     auto sz = [](auto& v) { return (int64_t)(v.size() * sizeof(v[0])); };
     int64_t b = sz(own) + sz(nei) + sz(verts) + sz(fkind) + sz(magSf) + sz(w) + sz(hf) + sz(dn) + sz(X) + sz(Cc) + sz(bN) +
                 sz(bmvON) + sz(ip13) + sz(c2d) + sz(lsqSlice) + sz(lsqCnt) + sz(lsqCell) + sz(lsqGx) + sz(lsqGy) + sz(lsqGz) + sz(lsqDeg) + sz(lsqBndZero) +
-                sz(pcSlice) + sz(pcCount) + sz(pcCell) + sz(pcW) + sz(bpPoint) + sz(bpOff) + sz(bpFace) + sz(bpW) + sz(cfSlice) + sz(cfCount) + sz(cfItem) +
+                sz(pcSlice) + sz(pcCount) + sz(pcCell) + sz(pcW) + sz(bpPoint) + sz(bpOff) + sz(bpFace) + sz(bpW) + sz(cfSlice) + sz(cfCount) + sz(cfItem) + sz(fpos) + sz(cfPos) +
                 sz(V) + sz(hQGD) + sz(ghost) + sz(bPatch) + sz(hQGDb);
     for (int k = 0; k < 3; ++k) b += sz(Sf[k]);
     return b;
@@ -368,6 +368,29 @@ StaticData buildStaticData(const HostMesh& m) {
             }
         }
         toSlicedEll(cfOff, nC, cfItemCsr, nullptr, s.cfSlice, s.cfCount, s.cfItem, nullptr, 0);
+        // slot-major storage positions of the internal-face fluxes (see qgd_setup.hpp)
+        {
+            s.fpos.assign((size_t)nIF, 0);
+            std::vector<int32_t> rank((size_t)nIF, 0), owned((size_t)nC, 0);
+            std::vector<int64_t> bucket;
+            for (int64_t f = 0; f < nIF; ++f) {
+                const int32_t r = owned[m.owner[f]]++;
+                rank[f] = r;
+                if ((size_t)r >= bucket.size()) bucket.resize((size_t)r + 1, 0);
+                bucket[r]++;
+            }
+            std::vector<int64_t> start(bucket.size() + 1, 0);
+            for (size_t r = 0; r < bucket.size(); ++r) start[r + 1] = start[r] + bucket[r];
+            for (int64_t f = 0; f < nIF; ++f) s.fpos[f] = (int32_t)(start[rank[f]]++);
+            for (int32_t& it : cfItemCsr) {
+                const int32_t f = it >= 0 ? it : ~it;
+                const int32_t pos = f < nIF ? s.fpos[f] : f;
+                it = it >= 0 ? pos : ~pos;
+            }
+            std::vector<int32_t> slice2;
+            std::vector<uint8_t> count2;
+            toSlicedEll(cfOff, nC, cfItemCsr, nullptr, slice2, count2, s.cfPos, nullptr, 0);
+        }
         // hQGD: area-weighted mean of hQGDf over the cell's faces, OpenFOAM
         // cells() order, skipping empty/wedge patches [QGDCoeffs.C L323-362]
         Csr cfo = buildCellFacesFoamOrder(m);

@@ -72,6 +72,14 @@ struct StaticData {
     std::vector<int32_t> cfSlice; // nSlices+1
     std::vector<uint8_t> cfCount; // nC
     std::vector<int32_t> cfItem;
+    // Storage order of the net face fluxes (CaseView::flux).  Internal face f keeps its five fluxes at position
+    // fpos[f] of each SoA plane: faces are bucketed by their rank among the faces their owner owns (bucket 0 = every
+    // cell's first owned face, in cell order, then bucket 1, ...), so that consecutive cells find their own faces AND
+    // the faces they are the neighbour of (on a hexahedral box: the i-1, j-1 and k-1 faces) at consecutive positions.
+    // Boundary faces stay at their label.  cfPos = cfItem with the label replaced by the position (same row order, ~pos
+    // when the cell is the neighbour): the cell kernel's gather list.
+    std::vector<int32_t> fpos;    // nIF
+    std::vector<int32_t> cfPos;   // like cfItem
     std::vector<double> V;        // nC
     std::vector<double> hQGD;     // nC
     std::vector<uint8_t> ghost;   // nC cell role (empty when unsharded): 0 owned, 1 ghost, 2 owned + sent to a neighbour

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Regenerates the judged summaries under profiles/ on an MI355X box (run through gpurun from the repo root):
-#   gpurun --timeout 2400 -- 'bash scripts/collect_profiles.sh r01'
+#   gpurun --timeout 2400 -- 'bash scripts/collect_profiles.sh r02'
 # 1. rocprofv3 --kernel-trace --stats of the default bench workload (400^3) and of one 8-GPU shard's size (200^3)
 # 2. separate --pmc passes (L2<->fabric read requests by size; write requests) for the HBM-side bytes per launch
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG

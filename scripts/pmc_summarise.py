@@ -55,6 +55,11 @@ for n in (400, 200):
                     "source": "rocprofv3 --pmc TCC_EA0_RDREQ_{32B,64B,128B}_sum / TCC_EA0_WRREQ{,_64B}_sum (separate passes, "
                               "scripts/collect_profiles.sh), bytes = sum(size*requests); FETCH_SIZE*1024 reads exactly half of the read "
                               f"side on gfx950 (x2 correction of MI355X_MICROARCH.md), WRITE_SIZE*1024 matches; profiles/{tag}_n{n}_pmc_tcc.json"}
+        for name, c in per_kernel.items():
+            for short, pattern in (("point", "pointInterpRecKernel"), ("cell", "cellUpdateKernel")):
+                if pattern in name and "hbm_read_bytes" in c and "hbm_write_bytes" in c and f"n{n}_gpus1" in traffic:
+                    traffic[f"n{n}_gpus1"][short + "_bytes_per_launch"] = c["hbm_read_bytes"] + c["hbm_write_bytes"]
+                    traffic[f"n{n}_gpus1"][short + "_read_bytes"] = c["hbm_read_bytes"]
 if traffic:
     json.dump(traffic, open(os.path.join(prof, "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
 print("summaries:", sorted(os.listdir(prof)))

@@ -1,0 +1,646 @@
+#!/usr/bin/env python3
+"""Golden vectors evaluated MECHANICALLY from the text of the reference's own source listings.
+
+The reference snapshot (/root/reference) holds only Doxygen listings; nothing of it compiles here (OpenFOAM is absent), so
+the oracle cannot be checked against a reference build.  What CAN be done is to take the scalar/vector/tensor C++
+expressions of the densest arithmetic on the hot path straight out of the listing text, transliterate the C++ statement
+syntax (declarations, forAll, if/else, `::`, `!`) into Python WITHOUT touching the expressions themselves, and evaluate
+them with small Python classes that emulate OpenFOAM's Vector/Tensor algebra (operators `&` inner product, `^` cross
+product, `*` scaling / outer product, `.x()`, `tr`, `T`, `I`, `symmTensor`, `inv`, `det`; C++ and Python give `* / + -
+& ^` the same relative precedence).  Indices, signs, operand order and slot assignments therefore come from the reference
+text and not from anybody's reading of it.  No reference text is stored: only numbers (inputs + results) go to
+tests/golden/ref_expr_*.npz.
+
+Runs only where /root/reference exists (the build container):   python tests/golden/make_ref_expr.py
+
+Snippets evaluated (listing lines of /root/reference/docs/html/<file>_source.html):
+  gvp3d   GaussVolPointBase3D.C   L186-229 (triangle coefficients), L346-389 (quad coefficients),
+                                  L490-512 (macro dfdxif), L750-757 / L831-854 (its invocations for scalar / vector fields)
+  gvp2d   GaussVolPointBase2D.C   L154-168 (c1..c4), L317-328 (apply)
+  lsq     extendedFaceStencilCalculateWeights.C L64-153, extendedFaceStencilScalarGrad.C L66-72
+  case2cell  QGDFoam/updateFields.H L45-80, QGDFoam/updateFluxes.H L41-139 (explicit branch), constScPrModel1.C L103-114,
+             QGDCoeffs.C L305-307, with the four fvsc::grad evaluated by the gvp3d text
+
+Every configuration is ONE internal face between cells whose centres are prescribed (qgd_mesh_set_geometry /
+orc_mesh_set_geometry), so the public operators (fvsc grad, the QGDFoam case) can be run on it as they are; vertex values
+follow the inverse-distance rule of volPointInterpolation (L0) from those cells.
+"""
+import html
+import os
+import re
+import sys
+
+import numpy as np
+
+REF = "/root/reference/docs/html"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# listing text
+# ----------------------------------------------------------------------------------------------------------------------
+def listing(name):
+    out = {}
+    for line in open(os.path.join(REF, name), encoding="utf-8", errors="replace"):
+        m = re.search(r'<a (?:id|name)="l(\d+)"', line)
+        if m:
+            t = html.unescape(re.sub(r"<[^>]+>", "", line))
+            out[int(m.group(1))] = re.sub(r"^\s*\d+", "", t, count=1).rstrip("\n")
+    return out
+
+
+def lines(name, a, b):
+    L = listing(name)
+    return [L.get(i, "") for i in range(a, b + 1)]
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# C++ statement syntax -> Python statement syntax (expressions are left alone)
+# ----------------------------------------------------------------------------------------------------------------------
+TYPES = r"(?:const\s+)?(?:scalar|label|vector|tensor|symmTensor|bool|surfaceScalarField|surfaceVectorField)\b\s*&?"
+
+
+def strip_comments(src):
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    return "\n".join(re.sub(r"//.*$", "", ln) for ln in src.split("\n") if not ln.lstrip().startswith("#"))
+
+
+def split_top(s, sep=","):
+    parts, depth, cur = [], 0, ""
+    for ch in s:
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch == sep and depth == 0:
+            parts.append(cur)
+            cur = ""
+        else:
+            cur += ch
+    parts.append(cur)
+    return parts
+
+
+def expr(e):
+    """the only rewrites inside expressions: scope operator, logical operators, conditional operator, whitespace"""
+    e = " ".join(e.split())
+    q = split_top(e, "?")
+    if len(q) == 2:                                   # cond ? a : b
+        a, b = split_top(q[1], ":")
+        return f"({expr(a)}) if ({expr(q[0])}) else ({expr(b)})"
+    e = e.replace("::", ".").replace("->", ".")
+    e = re.sub(r"!(?!=)", " not ", e)
+    e = e.replace("&&", " and ").replace("||", " or ")
+    return e
+
+
+def statement(st):
+    st = " ".join(st.split())
+    if not st:
+        return []
+    m = re.match(r"^List<\s*vector\s*>\s+(\w+)\((.*)\)$", st) or re.match(r"^scalarList\s+(\w+)\((.*)\)$", st)
+    if m:
+        return [f"{m.group(1)} = RList([None]*({expr(m.group(2))}))"]
+    m = re.match(r"^symmTensor\s+(\w+)\((.*)\)$", st)
+    if m:
+        return [f"{m.group(1)} = symmTensor({expr(m.group(2))})"]
+    m = re.match(rf"^{TYPES}\s*(.*)$", st)
+    if m and re.match(r"^\w+\s*(=|,|$)", m.group(1)):
+        out = []
+        for decl in split_top(m.group(1)):
+            if "=" in decl:
+                out += statement(decl)
+        return out
+    m = re.match(r"^(\w+)(\+\+|--)$", st)
+    if m:
+        return [f"{m.group(1)} {'+' if m.group(2) == '++' else '-'}= 1"]
+    m = re.match(r"^(.*?\))\s*(\+=|-=|\*=|=)(?!=)\s*(.*)$", st)
+    if m and re.match(r"^(\w+)\.(xx|yy|zz)\(\)$", m.group(1)):   # G0.xx() = 1
+        obj, cmpt = re.match(r"^(\w+)\.(xx|yy|zz)\(\)$", m.group(1)).groups()
+        return [f"{obj}.set('{cmpt}', {expr(m.group(3))})"]
+    if m and re.match(r"^oop\((.*)\)$", m.group(1)):                      # oop(field[facei],ocmpt) += value
+        tgt, cm = split_top(re.match(r"^oop\((.*)\)$", m.group(1)).group(1))
+        return [f"oop_add({expr(tgt)}, {expr(cm)}, {expr(m.group(3))})"]
+    if m and re.match(r"^\w+\(\)$", m.group(1)):                         # tauMCPtr() = ...
+        return [f"{m.group(1)}.assign({expr(m.group(3))})"]
+    m = re.match(r"^(.*?)\.resize\((.*)\)$", st)
+    if m:
+        return [f"{expr(m.group(1))}.resize({expr(m.group(2))})"]
+    # plain assignment: the conditional operator, if any, belongs to the right-hand side
+    depth = 0
+    for k, ch in enumerate(st):
+        depth += ch in "([{"
+        depth -= ch in ")]}"
+        if ch == "=" and depth == 0 and st[k + 1:k + 2] != "=" and st[k - 1] not in "=!<>":
+            op = st[k - 1] + "=" if st[k - 1] in "+-*/" else "="
+            lhs = st[:k - (len(op) - 1)]
+            return [f"{expr(lhs)} {op} {expr(st[k + 1:])}"]
+    return [expr(st)]
+
+
+def transpile(src_lines, continuation=False):
+    """statements, forAll, if/else blocks -> indented Python source"""
+    src = "\n".join(ln.rstrip().rstrip("\\") if continuation else ln for ln in src_lines)
+    src = strip_comments(src) + "\n"
+    out, ind, i, n = [], 0, 0, len(src)
+    pending_block = []
+
+    def emit(s):
+        out.append("    " * ind + s)
+
+    buf = ""
+    while i < n:
+        ch = src[i]
+        if ch == "{":
+            head = " ".join(buf.split())
+            buf = ""
+            if head:
+                m = re.match(r"^forAll\s*\((.*)\)$", head)
+                if m:
+                    lst, var = split_top(m.group(1))
+                    emit(f"for {var.strip()} in range(len({expr(lst)})):")
+                elif re.match(r"^if\s*\(", head):
+                    emit(f"if {expr(head[2:].strip())}:")
+                elif head == "else":
+                    emit("else:")
+                else:
+                    raise SyntaxError("block head: " + head)
+                pending_block.append(True)
+            else:
+                emit("if True:")
+                pending_block.append(True)
+            ind += 1
+            emit("pass")
+        elif ch == "}":
+            if buf.strip():
+                raise SyntaxError("unterminated statement: " + buf)
+            ind -= 1
+            pending_block.pop()
+        elif ch == ";":
+            for s in statement(buf):
+                emit(s)
+            buf = ""
+        else:
+            buf += ch
+            # macro invocations written without a semicolon, one per line
+            if ch == "\n" and re.match(r"^\s*dfdxif\(.*\)\s*$", buf):
+                emit(expr(buf))
+                buf = ""
+        i += 1
+    if buf.strip():
+        raise SyntaxError("trailing text: " + buf)
+    return "\n".join(out) + "\n"
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# OpenFOAM algebra (L0 semantics: Vector/Tensor/SymmTensor operators of OpenFOAM's primitives library)
+# ----------------------------------------------------------------------------------------------------------------------
+def _num(x):
+    return isinstance(x, (int, float, np.floating, np.integer))
+
+
+class Vec:
+    def __init__(self, *c):
+        self.c = np.array(c if len(c) == 3 else c[0], dtype=float)
+
+    def x(self): return float(self.c[0])
+    def y(self): return float(self.c[1])
+    def z(self): return float(self.c[2])
+    def component(self, i): return float(self.c[i])
+    def __getitem__(self, i): return float(self.c[i])
+    def __setitem__(self, i, v): self.c[i] = v
+    def __add__(self, o): return Vec(self.c + o.c)
+    def __sub__(self, o): return Vec(self.c - o.c)
+    def __neg__(self): return Vec(-self.c)
+
+    def __mul__(self, o):
+        if _num(o):
+            return Vec(self.c * o)
+        if isinstance(o, Vec):                      # outer product: (a*b)_ij = a_i b_j
+            return Tensor(np.outer(self.c, o.c))
+        return NotImplemented
+
+    def __rmul__(self, o):
+        return Vec(o * self.c) if _num(o) else NotImplemented
+
+    def __truediv__(self, o): return Vec(self.c / o)
+
+    def __and__(self, o):
+        if isinstance(o, Vec):
+            return float(self.c[0] * o.c[0] + self.c[1] * o.c[1] + self.c[2] * o.c[2])
+        if isinstance(o, Tensor):                   # (v & T)_j = v_i T_ij
+            return Vec([sum(self.c[i] * o.m[i, j] for i in range(3)) for j in range(3)])
+        return NotImplemented
+
+    def __xor__(self, o):
+        a, b = self.c, o.c
+        return Vec(a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0])
+
+
+class Sph:
+    """sphericalTensor: I and its scalar multiples"""
+    def __init__(self, s=1.0): self.s = float(s)
+    def __mul__(self, o): return Sph(self.s * o) if _num(o) else NotImplemented
+    def __rmul__(self, o): return Sph(self.s * o) if _num(o) else NotImplemented
+
+
+class Tensor:
+    def __init__(self, m): self.m = np.array(m, dtype=float).reshape(3, 3)
+
+    def __add__(self, o):
+        if isinstance(o, Sph):
+            return Tensor(self.m + o.s * np.eye(3))
+        return Tensor(self.m + o.m)
+
+    def __radd__(self, o): return self.__add__(o)
+
+    def __sub__(self, o):
+        if isinstance(o, Sph):
+            return Tensor(self.m - o.s * np.eye(3))
+        return Tensor(self.m - o.m)
+
+    def __mul__(self, o): return Tensor(self.m * o) if _num(o) else NotImplemented
+    def __rmul__(self, o): return Tensor(self.m * o) if _num(o) else NotImplemented
+
+    def __and__(self, o):
+        if isinstance(o, Vec):                      # (T & v)_i = T_ij v_j
+            return Vec([sum(self.m[i, j] * o.c[j] for j in range(3)) for i in range(3)])
+        if isinstance(o, Tensor):
+            return Tensor([[sum(self.m[i, k] * o.m[k, j] for k in range(3)) for j in range(3)] for i in range(3)])
+        return NotImplemented
+
+    def T(self): return Tensor(self.m.T.copy())
+
+
+class symmTensor:
+    """xx xy xz yy yz zz"""
+    def __init__(self, *c):
+        self.c = np.zeros(6) if (len(c) == 1 and c[0] == 0) else np.array(c, dtype=float)
+
+    def xx(self): return float(self.c[0])
+    def yy(self): return float(self.c[3])
+    def zz(self): return float(self.c[5])
+    def set(self, name, v): self.c[{"xx": 0, "yy": 3, "zz": 5}[name]] = v
+    def __add__(self, o): return symmTensor(*(self.c + o.c))
+    def __sub__(self, o): return symmTensor(*(self.c - o.c))
+    def __iadd__(self, o): return symmTensor(*(self.c + o.c))
+    def __mul__(self, o): return symmTensor(*(self.c * o)) if _num(o) else NotImplemented
+
+    def __and__(self, v):
+        xx, xy, xz, yy, yz, zz = self.c
+        return Vec(xx * v.c[0] + xy * v.c[1] + xz * v.c[2], xy * v.c[0] + yy * v.c[1] + yz * v.c[2], xz * v.c[0] + yz * v.c[1] + zz * v.c[2])
+
+
+def sqr(v): return symmTensor(v.c[0] * v.c[0], v.c[0] * v.c[1], v.c[0] * v.c[2], v.c[1] * v.c[1], v.c[1] * v.c[2], v.c[2] * v.c[2])
+def magSqr(v): return float(v.c[0] * v.c[0] + v.c[1] * v.c[1] + v.c[2] * v.c[2])
+def mag(v): return abs(v) if _num(v) else float(np.sqrt(magSqr(v)))
+
+
+def det(s):  # SymmTensorI.H
+    xx, xy, xz, yy, yz, zz = s.c
+    return float(xx * yy * zz + xy * yz * xz + xz * xy * yz - xx * yz * yz - xy * xy * zz - xz * yy * xz)
+
+
+def inv(s):  # SymmTensorI.H: inv(st, det(st))
+    xx, xy, xz, yy, yz, zz = s.c
+    d = det(s)
+    return symmTensor((yy * zz - yz * yz) / d, (xz * yz - xy * zz) / d, (xy * yz - xz * yy) / d, (xx * zz - xz * xz) / d,
+                      (xy * xz - xx * yz) / d, (xx * yy - xy * xy) / d)
+
+
+def tr(t): return float(t.m[0, 0] + t.m[1, 1] + t.m[2, 2])
+
+
+class RList(list):
+    def resize(self, n):
+        del self[n:]
+        self.extend([0.0] * (n - len(self)))
+
+    def size(self): return len(self)
+
+
+class Obj:
+    def __init__(self, **kw): self.__dict__.update(kw)
+
+
+def call(v):
+    return lambda: v
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# snippets
+# ----------------------------------------------------------------------------------------------------------------------
+def rnd_vec(rng, scale=1.0): return Vec(*(scale * rng.standard_normal(3)))
+
+
+def skew_face(rng, nv):
+    """a skewed, non-planar face near the unit square / triangle in the plane x = 0, with cell centres on either side"""
+    base = [(0, 0, 0), (0, 1, 0), (0, 1, 1), (0, 0, 1)] if nv == 4 else [(0, 0, 0), (0, 1, 0), (0, 0.3, 1)]
+    pts = [Vec(*(np.array(b, float) + 0.15 * rng.standard_normal(3))) for b in base]
+    own = Vec(*(np.array([-0.5, 0.5, 0.5]) + 0.15 * rng.standard_normal(3)))
+    nei = Vec(*(np.array([0.5, 0.5, 0.5]) + 0.15 * rng.standard_normal(3)))
+    return pts, own, nei
+
+
+def inv_dist(x, centres, vals):
+    """L0 volPointInterpolation on a mesh whose every point belongs to the same cells: weights 1/|x - C_c|, normalised"""
+    w = [1.0 / float(np.sqrt(((x.c - c.c) ** 2).sum())) for c in centres]
+    sw = sum(w)
+    w = [wi / sw for wi in w]
+    acc = None
+    for wi, v in zip(w, vals):
+        acc = wi * v if acc is None else acc + wi * v
+    return acc
+
+
+def face_area_centre(pts):
+    """some area vector and centre for the face (inputs of set_geometry, not part of what is checked)"""
+    P = np.array([p.c for p in pts])
+    c = P.mean(axis=0)
+    S = np.zeros(3)
+    for i in range(len(P)):
+        S += 0.5 * np.cross(P[i] - c, P[(i + 1) % len(P)] - c)
+    return S, c
+
+
+class Gvp3dText:
+    """the 3-D GaussVolPoint listing text, ready to be evaluated on one face"""
+    def __init__(self):
+        f3 = "GaussVolPointBase3D_8C_source.html"
+        self.tri_src = transpile(lines(f3, 186, 229))
+        self.qua_src = transpile(lines(f3, 346, 389))
+        self.macro = transpile(lines(f3, 489, 513), continuation=True)
+        self.inv_s = transpile(lines(f3, 749, 757))
+        self.inv_v = transpile(lines(f3, 830, 854))
+
+    def coeffs(self, pts, own, nei):
+        nv = len(pts)
+        mesh = Obj(C=call([own, nei]), owner=call([0]), neighbour=call([1]))
+        env = dict(points=pts, faces=[list(range(nv))], mesh=mesh, OneBySix=(1.0 / 6.0), own=0, nei=1, i=0, facei=0)
+        if nv == 3:
+            env.update(p1=0, p2=1, p3=2, vt_=[0.0], atx_=RList([RList()]), aty_=RList([RList()]), atz_=RList([RList()]))
+            exec(self.tri_src, env)
+            return env["atx_"], env["aty_"], env["atz_"], env["vt_"], mesh
+        env.update(p1=0, p2=1, p3=2, p4=3, vq_=[0.0], aqx_=RList([RList()]), aqy_=RList([RList()]), aqz_=RList([RList()]))
+        exec(self.qua_src, env)
+        return env["aqx_"], env["aqy_"], env["aqz_"], env["vq_"], mesh
+
+    def grad(self, pts, own, nei, cell_vals, pt_vals, vector):
+        """the macro body becomes a function, its invocations [L750-757 / L831-854] are executed as written"""
+        nv = len(pts)
+        ax, ay, az, vol, mesh = self.coeffs(pts, own, nei)
+        faces = [list(range(nv))]
+        grad = [np.zeros(9 if vector else 3)]
+        fld = Obj(mesh=call(mesh), primitiveField=call(cell_vals))
+        out = Obj(primitiveFieldRef=call(grad))
+        macro = self.macro
+
+        def dfdxif(vf, pf, dfdxfield, fi, vi, ai, icmpt, ocmpt, iop, oop):
+            def oop_add(target, cm, value):
+                target[cm] += value
+            exec(macro, dict(vf=vf, pf=pf, dfdxfield=dfdxfield, fi=fi, vi=vi, ai=ai, icmpt=icmpt, ocmpt=ocmpt, iop=iop, oop=oop,
+                             faces=faces, oop_add=oop_add))
+
+        e = dict(dfdxif=dfdxif, sf=fld, vf=fld, pf=pt_vals, gradf=out, SCA_CMPT=lambda V, c: V, VEC_CMPT=lambda V, c: V[c],
+                 qf_=[0] if nv == 4 else [], tf_=[0] if nv == 3 else [], vq_=vol if nv == 4 else [], vt_=vol if nv == 3 else [],
+                 aqx_=ax if nv == 4 else RList(), aqy_=ay if nv == 4 else RList(), aqz_=az if nv == 4 else RList(),
+                 atx_=ax if nv == 3 else RList(), aty_=ay if nv == 3 else RList(), atz_=az if nv == 3 else RList())
+        exec(self.inv_v if vector else self.inv_s, e)
+        return grad[0], (ax, ay, az, vol)
+
+
+def gvp3d(nfaces=48, seed=11):
+    """one internal face between two cells with prescribed centres; vertex values by inverse distance from the two cells"""
+    text = Gvp3dText()
+    rng = np.random.default_rng(seed)
+    rec = {k: [] for k in ("nv", "pts", "Sf", "Cf", "C", "cell_s", "cell_v", "pt_s", "pt_v", "coef_x", "coef_y", "coef_z", "vol",
+                           "grad_s", "grad_v")}
+    for n in range(nfaces):
+        nv = 4 if n % 2 == 0 else 3
+        pts, own, nei = skew_face(rng, nv)
+        cell_s = [float(rng.uniform(0.8, 1.3)), float(rng.uniform(0.8, 1.3))]
+        cell_v = [rnd_vec(rng), rnd_vec(rng)]
+        pt_s = [inv_dist(x, [own, nei], cell_s) for x in pts]
+        pt_v = [inv_dist(x, [own, nei], cell_v) for x in pts]
+        gs, (ax, ay, az, vol) = text.grad(pts, own, nei, cell_s, pt_s, False)
+        gv, _ = text.grad(pts, own, nei, cell_v, pt_v, True)
+        S, cf = face_area_centre(pts)
+        pad3, pad = ([[0, 0, 0]] if nv == 3 else []), ([0.0] if nv == 3 else [])
+        rec["nv"].append(nv); rec["pts"].append(np.array([p.c for p in pts] + pad3)); rec["Sf"].append(S); rec["Cf"].append(cf)
+        rec["C"].append(np.array([own.c, nei.c])); rec["cell_s"].append(cell_s); rec["cell_v"].append(np.array([v.c for v in cell_v]))
+        rec["pt_s"].append(np.array(pt_s + pad)); rec["pt_v"].append(np.array([v.c for v in pt_v] + pad3))
+        rec["coef_x"].append(np.array(list(ax[0]) + pad)); rec["coef_y"].append(np.array(list(ay[0]) + pad))
+        rec["coef_z"].append(np.array(list(az[0]) + pad)); rec["vol"].append(vol[0])
+        rec["grad_s"].append(gs); rec["grad_v"].append(gv)
+    return {k: np.array(v) for k, v in rec.items()}
+
+
+def gvp2d(nfaces=30, seed=12):
+    """one internal quad between two cells of a one-cell-thick mesh (empty direction ie3)"""
+    f2 = "GaussVolPointBase2D_8C_source.html"
+    coef_src = transpile(lines(f2, 154, 168))
+    apply_src = transpile(lines(f2, 317, 328))
+    rng = np.random.default_rng(seed)
+    rec = {k: [] for k in ("ie3", "pts", "Sf", "Cf", "C", "f", "pF", "c", "mv", "grad")}
+    for n in range(nfaces):
+        ie3 = n % 3
+        ie1, ie2 = (1, 2) if ie3 == 0 else ((0, 2) if ie3 == 1 else (0, 1))
+        e1, e2 = Vec(*np.eye(3)[ie1]), Vec(*np.eye(3)[ie2])
+
+        def place(a, b, h):
+            v = np.zeros(3); v[ie1], v[ie2], v[ie3] = a, b, h
+            return Vec(*v)
+        C4 = place(*(0.2 * rng.standard_normal(2)), 0.05)                                      # owner centre
+        C2 = place(1.0 + 0.2 * rng.standard_normal(), 0.2 * rng.standard_normal(), 0.05)       # neighbour centre
+        a0, b0 = 0.5 + 0.2 * rng.standard_normal(), -0.5 + 0.2 * rng.standard_normal()
+        a1, b1 = 0.5 + 0.2 * rng.standard_normal(), 0.5 + 0.2 * rng.standard_normal()
+        # face vertices in face order: lower edge, then the two upper vertices (the ones the listing picks: first and second
+        # vertex with coordinate >= the neighbour centre's along the empty direction [L129-147])
+        order = [(a0, b0, 0.0), (a0, b0, 0.1), (a1, b1, 0.1), (a1, b1, 0.0)]
+        shift = n % 4
+        order = order[shift:] + order[:shift]
+        pts = [place(*o) for o in order]
+        upper = [k for k, o in enumerate(order) if o[2] >= 0.05]
+        ip1, ip3 = upper[0], upper[1]
+        mesh = Obj(C=call([C4, C2]), points=call(pts))
+        one = lambda: [None]  # noqa: E731
+        env = dict(mesh=mesh, iFace=0, ic2=1, ic4=0, ip1=ip1, ip3=ip3, e1_=e1, e2_=e2, mag=mag, v42=one(), v13=one(), mv42_=one(),
+                   mv13_=one(), cosa1=one(), cosa2=one(), sina1=one(), sina2=one(), den=one(), c1_=one(), c2_=one(), c3_=one(), c4_=one())
+        exec(coef_src, env)
+        fvals = [float(rng.standard_normal()), float(rng.standard_normal())]                    # f[ic4], f[ic2]
+        pvals = [inv_dist(x, [C4, C2], fvals) for x in pts]
+        g = [[0.0, 0.0, 0.0]]
+        env.update(f=fvals, pF=pvals, gradf=g, ic2_=[1], ic4_=[0], ip1_=[ip1], ip3_=[ip3], ie1_=ie1, ie2_=ie2, ie3_=ie3, dfdn=0.0, dfdt=0.0)
+        exec(apply_src, env)
+        S, cf = face_area_centre(pts)
+        rec["ie3"].append(ie3); rec["pts"].append(np.array([p.c for p in pts])); rec["Sf"].append(S); rec["Cf"].append(cf)
+        rec["C"].append(np.array([C4.c, C2.c])); rec["f"].append(fvals); rec["pF"].append(pvals)
+        rec["c"].append([env["c1_"][0], env["c2_"][0], env["c3_"][0], env["c4_"][0]])
+        rec["mv"].append([env["mv42_"][0], env["mv13_"][0]]); rec["grad"].append(g[0])
+    return {k: np.array(v) for k, v in rec.items()}
+
+
+def lsq(nfaces=30, seed=13):
+    """one internal face with a stencil of n cells (cells 0 and 1 are its owner and neighbour, placed symmetrically about the
+    face centre so that the linear weight is 1/2 and sF = (iF[0] + iF[1])/2 needs no further L0 rule)"""
+    w_src = transpile(lines("extendedFaceStencilCalculateWeights_8C_source.html", 64, 153))
+    a_src = transpile(lines("extendedFaceStencilScalarGrad_8C_source.html", 66, 72))
+    rng = np.random.default_rng(seed)
+    rec = {k: [] for k in ("n", "Cf", "centres", "deg", "Gdf", "wf2", "iF", "sF", "grad")}
+    nmax = 8
+    for n in range(nfaces):
+        ns = [6, 6, 4, 8, 5, 2][n % 6]
+        scale = [1.0, 0.3, 3.0][n % 3]   # det(G) < 1 marks a face degenerate: it depends on the length unit (quirk B3)
+        Cf = Vec(*(scale * np.array([0.5, 0.5, 0.05])))
+        d0 = scale * np.array([-0.5 + 0.1 * rng.standard_normal(), 0.1 * rng.standard_normal(), 0.0])
+        cents = [Vec(*(Cf.c + d0)), Vec(*(Cf.c - d0))]
+        if ns == 2:                       # a 1-D stencil: the two cells on the x-axis
+            cents = [Vec(*(Cf.c + scale * np.array([-0.5, 0, 0]))), Vec(*(Cf.c + scale * np.array([0.5, 0, 0])))]
+        for _ in range(ns - 2):           # 2-D meshes: every centre in the plane of the face centre (G.zz == 0)
+            cents.append(Vec(*(Cf.c + scale * np.array([rng.uniform(-1.5, 1.5), rng.uniform(-1.0, 1.0), 0.0]))))
+        cMesh = Obj(faceCentres=call([Cf]), cellCentres=call(cents), nGeometricD=call(1 if ns == 2 else 2))
+
+        class Sink:
+            def __lshift__(self, o): return self
+        deg = RList()
+        env = dict(neighbourCells_=[RList(range(len(cents)))], facei=0, cMesh_=cMesh, symmTensor=symmTensor, RList=RList, sqr=sqr,
+                   magSqr=magSqr, mag=mag, det=det, inv=inv, SMALL=1e-15, GREAT=1e15, cellDim=3, minDet=1e15, detG=0.0,
+                   nDegFaces=0, internalDegFaces_=deg, GdfAll_=[None], wf2All_=[None], WarningInFunction=Sink(), Pout=Sink(),
+                   nl="\n", endl="\n")
+        exec(w_src, env)
+        Gdf, wf2 = env["GdfAll_"][0], env["wf2All_"][0]
+        iF = [float(rng.standard_normal()) for _ in cents]
+        sF = [0.5 * (iF[0] - iF[1]) + iF[1]]
+        gradIF = [None]
+        e2 = dict(GdfAll_=[Gdf], wf2All_=[wf2], neighbourCells_=[RList(range(len(cents)))], iF=iF, sF=sF, gradIF=gradIF, facei=0,
+                  vector=Obj(zero=Vec(0, 0, 0)), gf=None)
+        exec(a_src, e2)
+        pad = nmax - len(cents)
+        rec["n"].append(len(cents)); rec["Cf"].append(Cf.c)
+        rec["centres"].append(np.array([c.c for c in cents] + [[0, 0, 0]] * pad))
+        rec["deg"].append(len(deg)); rec["Gdf"].append(np.array([g.c for g in Gdf] + [[0, 0, 0]] * pad))
+        rec["wf2"].append(np.array(list(wf2) + [0.0] * pad)); rec["iF"].append(np.array(iF + [0.0] * pad)); rec["sF"].append(sF[0])
+        rec["grad"].append(gradIF[0].c)
+    return {k: np.array(v) for k, v in rec.items()}
+
+
+class Pair:
+    """a cell field seen from one face: (owner value, neighbour value)"""
+    def __init__(self, o, n): self.o, self.n = o, n
+    def __mul__(self, other): return Pair(self.o * other.o, self.n * other.n)
+    def __add__(self, other): return Pair(self.o + other.o, self.n + other.n)
+    def __truediv__(self, other): return Pair(self.o / other.o, self.n / other.n)
+
+
+def case2cell(nfaces=40, seed=14):
+    """A whole QGDFoam flux assembly on one internal face between two cells (3-D, GaussVolPoint): updateFields.H,
+    the four fvsc::grad (coefficients + dfdxif from the 3-D listing), updateFluxes.H, constScPrModel1, hQGDf -- every line from
+    the listing text.  Inputs the case entries take: mesh arrays + geometry, U, T, p, the gas model."""
+    text = Gvp3dText()
+    fields_src = transpile(lines("QGDFoam_2updateFields_8H_source.html", 45, 80))
+    flux_src = transpile(lines("QGDFoam_2updateFluxes_8H_source.html", 41, 139))
+    cs = listing("constScPrModel1_8C_source.html")
+    tau_src = transpile([cs[103].replace("this->", ""), cs[104].replace("this->", "")])
+    mu_src = transpile([cs[i] for i in range(108, 115)])
+    h_src = transpile(lines("QGDCoeffs_8C_source.html", 305, 307))
+    rng = np.random.default_rng(seed)
+    names = ("nv", "pts", "Sf", "Cf", "C", "V", "U", "T", "p", "R", "Cv", "mu", "Pr", "ScQGD", "PrQGD", "alphaQGD",
+             "w", "hQGDf", "rhof", "Uf", "rhoUf", "UrhoUf", "pf", "cf", "gammaf", "Hf", "alphauf", "muf", "tauQGDf",
+             "gradUf", "gradef", "gradRhof", "gradPf", "phiwStar", "phiJm", "phi", "phiJmU", "phiP", "phiPi", "phiJmH", "phiQ", "phiPiU",
+             "muQGD", "alphauQGD", "tauQGD", "hQGD")
+    rec = {k: [] for k in names}
+    for n in range(nfaces):
+        nv = 4 if n % 3 != 2 else 3
+        pts, own, nei = skew_face(rng, nv)
+        S, cf = face_area_centre(pts)
+        S, Cf = Vec(*S), Vec(*cf)
+        R = 1 / 1.4
+        Cv = R / 0.4
+        gam = (Cv + R) / Cv
+        mu0, Pr = float(rng.uniform(0, 2e-3)), float(rng.uniform(0.6, 1.2))
+        Sc, PrQ, aQ = float(rng.uniform(0.5, 1.5)), float(rng.uniform(0.5, 1.5)), float(rng.uniform(0.3, 0.7))
+        U = [rnd_vec(rng, 0.7), rnd_vec(rng, 0.7)]
+        T = [float(rng.uniform(0.8, 1.3)) for _ in range(2)]
+        p = [float(rng.uniform(0.7, 1.4)) for _ in range(2)]
+        # L0 thermo (perfectGas + eConst + constTransport): what createFields.H / thermo.correct() hand to the face code
+        e = [Cv * t for t in T]
+        psi = [1.0 / (R * t) for t in T]
+        rho = [ps * pp for ps, pp in zip(psi, p)]
+        c = [float(np.sqrt(gam / ps)) for ps in psi]
+        Cp = Cv + R
+        alphah0 = (Cp * mu0 * (1.0 / Pr)) / Cp
+        # linear weight (L0: surfaceInterpolation::makeWeights)
+        sfo, sfn = abs(S & (Cf - own)), abs(S & (nei - Cf))
+        w = sfn / (sfo + sfn)
+        lin = lambda q: w * (q.o - q.n) + q.n  # noqa: E731   surfaceInterpolationScheme::interpolate (L0)
+        # hQGDf [QGDCoeffs.C L305-307]; hQGD of a cell with this one face [L336-361]
+        hq = [0.0]
+        magS = mag(S)
+        ev = dict(mag=mag, min=min, mesh=Obj(C=call([own, nei]), Cf=call([Cf]), owner=call([0]), neighbour=call([1])), iFace=0,
+                  hQGDf_=Obj(primitiveFieldRef=call(hq)), hown=0.0, hnei=0.0)
+        exec(h_src, ev)
+        hf = hq[0]
+        hcell = (hf * magS) / magS
+        muQGD, alphauQGD = [], []
+        for k in range(2):
+            m_, a_ = [0.0], [0.0]
+            ev = dict(p=Obj(primitiveField=call([p[k]])), ScQGD_=Obj(primitiveField=call([Sc])), PrQGD_=Obj(primitiveField=call([PrQ])),
+                      tauQGD_=Obj(primitiveField=call([aQ * hcell / c[k]])), celli=0,
+                      muQGD_=Obj(primitiveFieldRef=call(m_), primitiveField=call(m_)), alphauQGD_=Obj(primitiveFieldRef=call(a_)))
+            exec(mu_src, ev)
+            muQGD.append(m_[0]); alphauQGD.append(a_[0])
+        ev = dict(aQGD_=Pair(aQ, aQ), cSound=Pair(*c), hQGDf_=hf, hQGD_=Pair(hcell, hcell), linearInterpolate=lin)
+        exec(tau_src, ev)
+        tauf, tauc = ev["tauQGDf_"], ev["tauQGD_"]
+        # QGDThermo::correctQGD adds muQGD / alphauQGD into mu / alpha [QGDThermo.C L91-98]; laminar muEff = mu,
+        # alphaEff = gamma*alpha for an internal-energy thermo (L0)
+        muEff = Pair(0.0 + (mu0 + muQGD[0]), 0.0 + (mu0 + muQGD[1]))
+        alphaEff = Pair(gam * ((alphah0 + alphauQGD[0]) + 0.0), gam * ((alphah0 + alphauQGD[1]) + 0.0))
+        rhoU = Pair(rho[0] * U[0], rho[1] * U[1])
+        rhoE = Pair(rho[0] * e[0] + rho[0] * 0.5 * (U[0] & U[0]), rho[1] * e[1] + rho[1] * 0.5 * (U[1] & U[1]))
+        env = dict(qgdInterpolate=lin, rho=Pair(*rho), U=Pair(*U), rhoU=rhoU, p=Pair(*p), gamma=Pair(gam, gam), rhoE=rhoE,
+                   thermo=Obj(c=call(Pair(*c)), Cp=call(Pair(Cp, Cp))), turbulence=Obj(alphaEff=call(alphaEff), muEff=call(muEff)))
+        exec(fields_src, env)
+        # the four fvsc::grad: vertex values by inverse distance, then coefficients + dfdxif as listed
+        cen = [own, nei]
+        gU, _ = text.grad(pts, own, nei, U, [inv_dist(x, cen, U) for x in pts], True)
+        gE, _ = text.grad(pts, own, nei, e, [inv_dist(x, cen, e) for x in pts], False)
+        gR, _ = text.grad(pts, own, nei, rho, [inv_dist(x, cen, rho) for x in pts], False)
+        gP, _ = text.grad(pts, own, nei, p, [inv_dist(x, cen, p) for x in pts], False)
+        grads = dict(U=Tensor(gU), e=Vec(*gE), rho=Vec(*gR), p=Vec(*gP))
+        env2 = {k: env[k] for k in ("rhof", "Uf", "rhoUf", "UrhoUf", "pf", "gammaf", "Hf", "alphauf", "muf")}
+        env2.update(tr=tr, tauQGDf=tauf, mesh=Obj(Sf=call(S)), fvsc=Obj(grad=lambda fld: grads[fld]), U="U", e="e", rho="rho", p="p",
+                    I=Sph(1.0), implicitDiffusion=False, Foam=Obj(T=lambda t: t.T()), qgdFlux=lambda flux, psi, psif: flux * psif, H="H")
+        exec(flux_src, env2)
+        g = env2
+
+        def val(x):
+            return x.c if isinstance(x, Vec) else (x.m.reshape(9) if isinstance(x, Tensor) else x)
+        out = dict(nv=nv, pts=np.array([q.c for q in pts] + ([[0, 0, 0]] if nv == 3 else [])), Sf=S.c, Cf=Cf.c, C=np.array([own.c, nei.c]),
+                   V=[1.0, 1.0], U=np.array([u.c for u in U]), T=T, p=p, R=R, Cv=Cv, mu=mu0, Pr=Pr, ScQGD=Sc, PrQGD=PrQ, alphaQGD=aQ,
+                   w=w, hQGDf=hf, cf=env["cf"], tauQGDf=tauf, phiwStar=g["phiw"], muQGD=muQGD, alphauQGD=alphauQGD,
+                   tauQGD=[tauc.o, tauc.n], hQGD=[hcell, hcell])
+        for k in ("rhof", "Uf", "rhoUf", "UrhoUf", "pf", "gammaf", "Hf", "alphauf", "muf", "gradUf", "gradef", "gradRhof", "gradPf",
+                  "phiJm", "phi", "phiJmU", "phiP", "phiPi", "phiJmH", "phiQ", "phiPiU"):
+            out[k] = val(g[k])
+        for k in names:
+            rec[k].append(np.array(out[k], dtype=float))
+    return {k: np.array(v) for k, v in rec.items()}
+
+
+def main():
+    if not os.path.isdir(REF):
+        sys.exit("make_ref_expr.py needs the reference listings under /root/reference (build container only)")
+    for name, fn in (("gvp3d", gvp3d), ("gvp2d", gvp2d), ("lsq", lsq), ("case2cell", case2cell)):
+        data = fn()
+        path = os.path.join(HERE, f"ref_expr_{name}.npz")
+        np.savez_compressed(path, **data)
+        print(name, {k: v.shape for k, v in data.items()})
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--show":
+        f, a, b = sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+        print(transpile(lines(f, a, b), continuation="--macro" in sys.argv))
+    else:
+        main()

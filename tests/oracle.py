@@ -36,6 +36,7 @@ lib.orc_mesh_create.argtypes = [C.c_int32, dp, C.c_int32, ip, ip, C.c_int32, ip,
 lib.orc_mesh_free.argtypes = [C.c_void_p]
 lib.orc_mesh_get.argtypes = [C.c_void_p, C.c_char_p, dp, C.c_int64]
 lib.orc_mesh_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+lib.orc_mesh_set_geometry.argtypes = [C.c_void_p, dp, dp, dp, dp]
 lib.orc_mesh_set_halo.argtypes = [C.c_void_p, C.c_int, C.c_int32, ip, C.c_int32, ip]
 lib.orc_fvsc.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, dp, dp, dp]
 lib.orc_case_create.restype = C.c_void_p
@@ -96,6 +97,11 @@ class OracleMesh:
         out = np.zeros(n)
         assert lib.orc_mesh_get(self._h, name.encode(), _d(out), n) == 0
         return out
+
+    def set_geometry(self, Sf, Cf, Cc, V):
+        a = [np.ascontiguousarray(x, dtype=np.float64) for x in (Sf, Cf, Cc, V)]
+        assert a[0].size == 3 * self.nFaces and a[2].size == 3 * self.nCells and a[3].size == self.nCells
+        assert lib.orc_mesh_set_geometry(self._h, *[_d(x) for x in a]) == 0
 
     def info(self):
         a = (C.c_int64 * 4)()

@@ -1,0 +1,166 @@
+"""BASELINE config 5 ("QHDFoam buoyant cavity, 16M unstructured polyhedral cells: irregular stencil stress") on the device.
+
+No polyhedral mesher exists here, so the mesh is the stand-in SURVEY 8(d) C5 names: a 252^3 hexahedral box with the
+vertices jittered by 0.2 h (seed 2024), every 7th quad split into two triangles (cells with 6-8 faces), cell labels
+shuffled within chunks of 64^3 and then put into the library's Morton order (qgd_mesh_renumber(qgd_mesh_morton_order())).
+On it the QHDFoam flux assembly (qgd_qhd_fluxes = QHDFoam/updateFields.H L36-73, updateFluxes.H L33-38, QHDUEqn.H L36-43,
+QHDTEqn.H L65-66) runs with the T0byGr / HbyUQHD closures for tauQGDf, and is checked
+
+  * at full size through properties that need no oracle run: phiu = Sf . Uf with the linear weights; a uniform state
+    gives zero gradients and phiwo = -tau beta T0 (Sf . g); the triangle pattern of grad(U) (reference quirk B2);
+  * at full size against the ORACLE ON A CUT OF THE SAME MESH: a range of ~12 000 cells out of the middle of the 16 M,
+    extracted with its vertex-connected ghost layer by qgd_mesh_shard, carries the complete stencil of every face that
+    touches an owned cell, so the oracle run on the cut must reproduce the device's full-size result on those faces;
+  * against the oracle on a whole 13 824-cell mesh of the same recipe (jitter + triangles + polygon faces + shuffled
+    labels + Morton order), all ten outputs, <= 1e-12.
+"""
+import numpy as np
+import pytest
+
+import qgdsolver_amd as q
+from qgdsolver_amd import qhdfoam
+
+import oracle
+from util import oracle_mesh_of, rel_err
+
+pytestmark = pytest.mark.gpu
+
+BETA, G = 3.4e-3, (0.0, -9.81, 0.0)
+
+
+def c5_mesh(n, chunk, poly=False):
+    """the C5 stand-in recipe at edge n"""
+    mesh = q.PolyMesh.box(n, n, n)
+    mesh.jitter(0.2, seed=2024)
+    mesh.split_quads(7)
+    if poly:
+        mesh.split_edges(11)
+    rng = np.random.default_rng(7)
+    perm = np.arange(mesh.nCells, dtype=np.int32)
+    for a in range(0, mesh.nCells, chunk):
+        b = min(a + chunk, mesh.nCells)
+        perm[a:b] = a + rng.permutation(b - a)
+    mesh.renumber(perm)
+    mesh.renumber(mesh.morton_order())
+    return mesh
+
+
+def cavity_fields(mesh, seed=5):
+    """buoyant-cavity-like state: hot xMin wall, cold xMax wall, a smooth velocity + noise so that nothing cancels"""
+    rng = np.random.default_rng(seed)
+    C = mesh.array("C").reshape(-1, 3)
+    Cf = mesh.array("Cf").reshape(-1, 3)[mesh.nInternalFaces:]
+    n, nb = mesh.nCells, mesh.nBoundaryFaces
+
+    def vel(X):
+        x, y, z = X[:, 0], X[:, 1], X[:, 2]
+        return np.stack([np.sin(np.pi * x) * np.cos(np.pi * y), -np.cos(np.pi * x) * np.sin(np.pi * y), 0.1 * np.sin(2 * np.pi * z)], axis=1)
+
+    U = (0.1 * vel(C) + 1e-3 * rng.standard_normal((n, 3)), np.zeros((nb, 3)))           # no-slip walls
+    T = (300.0 + 10.0 * (0.5 - C[:, 0]) + 0.1 * rng.standard_normal(n), 300.0 + 10.0 * (0.5 - Cf[:, 0]))
+    p = (1e-2 * np.cos(np.pi * C[:, 1]) + 1e-4 * rng.standard_normal(n), 1e-2 * np.cos(np.pi * Cf[:, 1]))
+    rho = (np.ones(n), np.ones(nb))
+    return U, T, p, rho
+
+
+def test_c5_recipe_small_mesh_matches_oracle():
+    mesh = c5_mesh(24, 8 ** 3, poly=True)
+    assert mesh.nCells == 13824
+    sizes = np.diff(mesh.array("faceOffsets"))
+    assert (sizes == 3).any() and (sizes == 4).any() and (sizes > 4).any()
+    om = oracle_mesh_of(mesh)
+    dev = q.Device(mesh)
+    U, T, p, rho = cavity_fields(mesh)
+    phi = np.random.default_rng(2).standard_normal(mesh.nFaces) * 1e-4
+    for model, par in (("T0byGr", dict(T0=1.0, Gr=1.0e3)), ("HbyUQHD", dict(aQGD=0.5, UQHD=0.1))):
+        tau = qhdfoam.tauQGDf(dev, model, **par)
+        got = qhdfoam.updateFluxes(dev, "GaussVolPoint", U, T, rho, tau, BETA, G, p=p, phi=phi)
+        ref = oracle.qhd_fluxes(om, "GaussVolPoint", U, T, rho, tau, BETA, G, p=p, phi=phi)
+        assert len(ref) == 10
+        for k in ref:
+            assert rel_err(got[k], ref[k]) <= 1e-12, (model, k, rel_err(got[k], ref[k]))
+    dev.close()
+
+
+def test_c5_full_size_16M_irregular_cells():
+    n = 252
+    mesh = c5_mesh(n, 64 ** 3)
+    assert mesh.nCells == n ** 3
+    nif, nf, nc = mesh.nInternalFaces, mesh.nFaces, mesh.nCells
+    sizes = np.diff(mesh.array("faceOffsets"))
+    tri = sizes == 3
+    assert 0.2 < tri.mean() < 0.3 and (sizes[~tri] == 4).all()   # every 7th quad became two triangles
+    own, nei, w = mesh.array("owner"), mesh.array("neighbour"), mesh.array("weights")
+    Sf = mesh.array("Sf").reshape(-1, 3)
+    dev = q.Device(mesh)
+    tau = qhdfoam.tauQGDf(dev, "T0byGr", T0=1.0, Gr=1.0e3)
+    assert np.array_equal(tau[:nif], np.full(nif, 1e-3))
+
+    # ---- a uniform state: zero gradients, phiwo = -tau beta T0 (Sf . g) --------------------------------------------
+    U0 = (np.tile([0.3, -0.2, 0.1], (nc, 1)), np.tile([0.3, -0.2, 0.1], (nf - nif, 1)))
+    T0 = (np.full(nc, 300.0), np.full(nf - nif, 300.0))
+    one = (np.ones(nc), np.ones(nf - nif))
+    got = qhdfoam.updateFluxes(dev, "GaussVolPoint", U0, T0, one, tau, BETA, G)
+    h = 1.0 / n
+    assert np.abs(got["gradUf"]).max() <= 1e-12 * 0.3 / h
+    assert np.abs(got["gradTf"]).max() <= 1e-12 * 300.0 / h
+    assert np.allclose(got["phiu"], Sf @ np.array([0.3, -0.2, 0.1]), rtol=1e-13, atol=1e-18)
+    expect = -(tau * (BETA * 300.0)) * (Sf @ np.array(G))
+    assert np.abs(got["phiwo"] - expect).max() <= 1e-10 * np.abs(expect).max()
+    del got, U0, T0, expect
+
+    # ---- the cavity state ------------------------------------------------------------------------------------------
+    U, T, p, rho = cavity_fields(mesh)
+    phi = np.random.default_rng(2).standard_normal(nf) * 1e-6
+    tau = qhdfoam.tauQGDf(dev, "HbyUQHD", aQGD=0.5, UQHD=0.1)
+    got = qhdfoam.updateFluxes(dev, "GaussVolPoint", U, T, rho, tau, BETA, G, p=p, phi=phi)
+    # phiu = Sf . Uf, Uf by linear interpolation [QHDFoam/updateFluxes.H L33]
+    Uf = w[:nif, None] * (U[0][own[:nif]] - U[0][nei]) + U[0][nei]
+    ref_phiu = (Sf[:nif] * Uf).sum(1)
+    assert np.abs(got["phiu"][:nif] - ref_phiu).max() <= 1e-13 * np.abs(ref_phiu).max()
+    assert np.array_equal(got["taubyrhof"][:nif], tau[:nif])
+    assert np.abs(got["phiTf"][:nif] - phi[:nif] * (w[:nif] * (T[0][own[:nif]] - T[0][nei]) + T[0][nei])).max() <= 1e-13 * 300e-6
+    del Uf, ref_phiu
+    # interior triangles: every row of grad(U) holds (dxUx, dyUy, dzUz) [GaussVolPointBase3D.C L844-854]
+    gU = got["gradUf"][:nif][tri[:nif]]
+    assert np.array_equal(gU[:, 0:3], gU[:, 3:6]) and np.array_equal(gU[:, 0:3], gU[:, 6:9])
+    quad_rows = got["gradUf"][:nif][~tri[:nif]][:100000]
+    assert not np.array_equal(quad_rows[:, 0:3], quad_rows[:, 3:6])
+    del gU, quad_rows
+
+    # ---- the oracle on a cut of this very mesh ---------------------------------------------------------------------
+    a = nc // 2 + 12345
+    cut = mesh.shard(3, 1, cell_start=[0, a, a + 12000, nc])
+    cg, fg = cut.array("cellGlobal"), cut.array("faceGlobal")
+    assert cut.nCells < 60000
+    flipped = fg < 0
+    gface = np.where(flipped, -1 - fg, fg)
+    cnif = cut.nInternalFaces
+    gb = gface[cnif:] - nif              # boundary index in the full mesh; negative: a cut (halo) face
+    real = gb >= 0
+    assert not flipped[cnif:][real].any()
+
+    def restrict(pair):
+        cell, bnd = pair
+        b = np.zeros((cut.nBoundaryFaces,) + bnd.shape[1:])
+        b[real] = bnd[gb[real]]
+        return cell[cg], b
+
+    om = oracle_mesh_of(cut)
+    ref = oracle.qhd_fluxes(om, "GaussVolPoint", restrict(U), restrict(T), restrict(rho), tau[gface], BETA, G, p=restrict(p),
+                            phi=np.where(flipped, -phi[gface], phi[gface]))
+    cown, cnei = cut.array("owner"), cut.array("neighbour")
+    owned = (cg >= a) & (cg < a + 12000)
+    sel = np.zeros(cut.nFaces, bool)
+    sel[:cnif] = owned[cown[:cnif]] | owned[cnei]           # complete stencil: the face touches an owned cell
+    sel[cnif:] = real & owned[cown[cnif:]]
+    assert sel.sum() > 3 * 12000
+    odd = {"phiu", "phiwo", "phiUf", "phiTf", "phiTauTReg"}   # fluxes change sign with the face orientation
+    for k in ref:
+        g = got[k][gface]
+        if k in odd:
+            g = np.where(flipped.reshape((-1,) + (1,) * (g.ndim - 1)), -g, g)
+        scale = np.abs(ref[k][sel]).max()
+        err = np.abs(g[sel] - ref[k][sel]).max() / scale
+        assert err <= 1e-11, (k, err)
+    dev.close()
