@@ -325,6 +325,13 @@ int qgd_case_free(qgd_case_t c);
 int qgd_case_set_bc(qgd_case_t c, int32_t patch, int32_t bcU, const double* valueU,
                     int32_t bcT, double valueT, int32_t bcP, double valueP);
 
+/* Non-uniform alphaQGD / ScQGD: the READ_IF_PRESENT volScalarFields "alphaQGD" [QGDCoeffs_8C_source.html L119-160] and
+ * "ScQGD" [constScPrModel1_8C_source.html L66-79] of the time directory, cell values (nCells) and patch values
+ * (nBoundaryFaces) as the files' own boundary conditions evaluate them.  NULL keeps the uniform value of the options.
+ * Call before qgd_case_set_fields. */
+int qgd_case_set_qgd_coeffs(qgd_case_t c, const double* alphaQGD, const double* alphaQGDb, const double* ScQGD,
+                            const double* ScQGDb);
+
 /* Initial cell fields U (nCells*3), T, p (HOST pointers); evaluates the BCs,
  * thermo.correct() and the derived conserved fields like createFields.H
  * [QGDFoam_2createFields_8H_source.html L3-109]. */

@@ -999,6 +999,7 @@ struct Case {
     VolField p, T, e, U, rho, rhoU, rhoE, psi, mu, alpha, gamma, c, H;
     // QGDCoeffs
     VolField hQGD, aQGD, tauQGD, muQGD, alphauQGD, PrQGD, ScQGD;
+    dvec aQGDin, aQGDbf, ScQGDin, ScQGDbf;   // non-uniform alphaQGD / ScQGD handed over by the caller (empty: uniform)
     SurfField hQGDf, tauQGDf;
     // face fields
     SurfField rhof, Uf, rhoUf, UrhoUf, pf, cf, gammaf, Hf, alphauf, muf;
@@ -1163,10 +1164,12 @@ struct Case {
         for (size_t ip = 0; ip < m.patches.size(); ++ip) forPatchFaces((int)ip, [&](int gf, int b, int) { hQGD.bf[b] = hQGDf.v[gf] * 1.0; });
         for (double& x : aQGD.in) x = opt.alphaQGD;   // readOrCreateAlphaQGD: uniform, zeroGradient
         for (double& x : aQGD.bf) x = opt.alphaQGD;
+        if (!aQGDin.empty()) { aQGD.in = aQGDin; aQGD.bf = aQGDbf; }   // the alphaQGD file [QGDCoeffs.C:119-143]
         for (double& x : PrQGD.in) x = opt.PrQGD;
         for (double& x : PrQGD.bf) x = opt.PrQGD;
         for (double& x : ScQGD.in) x = opt.ScQGD;
         for (double& x : ScQGD.bf) x = opt.ScQGD;
+        if (!ScQGDin.empty()) { ScQGD.in = ScQGDin; ScQGD.bf = ScQGDbf; }   // the ScQGD file [constScPrModel1.C:66-79]
     }
 
     // createFields.H [QGDFoam/createFields.H:3-109] + createFaceFluxes.H
@@ -1674,6 +1677,14 @@ int orc_case_set_bc(void* cp, int32_t patch, int32_t bcU, const double* valueU, 
     PatchBC& b = c->bc[patch];
     b.bcU = bcU; b.bcT = bcT; b.bcP = bcP; b.vT = valueT; b.vP = valueP;
     if (valueU) for (int k = 0; k < 3; ++k) b.vU[k] = valueU[k];
+    return 0;
+}
+int orc_case_set_qgd_coeffs(void* cp, const double* a, const double* ab, const double* sc, const double* scb) {
+    Case* c = (Case*)cp;
+    const size_t nC = (size_t)c->m.nC, nB = (size_t)c->m.nBF();
+    c->aQGDin.clear(); c->aQGDbf.clear(); c->ScQGDin.clear(); c->ScQGDbf.clear();
+    if (a) { c->aQGDin.assign(a, a + nC); c->aQGDbf.assign(nB, 0.0); if (nB) std::copy(ab, ab + nB, c->aQGDbf.begin()); }
+    if (sc) { c->ScQGDin.assign(sc, sc + nC); c->ScQGDbf.assign(nB, 0.0); if (nB) std::copy(scb, scb + nB, c->ScQGDbf.begin()); }
     return 0;
 }
 int orc_case_set_fields(void* cp, const double* U, const double* T, const double* p) { return ((Case*)cp)->setFields(U, T, p); }

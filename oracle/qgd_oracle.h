@@ -76,6 +76,8 @@ void* orc_case_create(void* mesh, const orc_case_options* opt);
 void orc_case_free(void* c);
 int orc_case_set_bc(void* c, int32_t patch, int32_t bcU, const double* valueU,
                     int32_t bcT, double valueT, int32_t bcP, double valueP);
+/* non-uniform alphaQGD / ScQGD (cell + patch values; NULL = uniform), before orc_case_set_fields */
+int orc_case_set_qgd_coeffs(void* c, const double* alphaQGD, const double* alphaQGDb, const double* ScQGD, const double* ScQGDb);
 int orc_case_set_fields(void* c, const double* U, const double* T, const double* p);
 int orc_case_update_fluxes(void* c);
 int orc_case_step(void* c, int32_t nSteps);

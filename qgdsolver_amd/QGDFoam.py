@@ -97,6 +97,23 @@ def run(case_dir, n_steps=None, device_id=0, write=True, log=print, renumber="no
     case = QGDFoamCase(dev, default_options(**opt))
     for i, bc in enumerate(bcs):
         case.set_bc(i, U=bc["U"], T=bc["T"], p=bc["p"])
+    if "alphaQGD" in fields or "ScQGD" in fields:
+        # non-uniform alphaQGD / ScQGD files: cell values follow the relabelling; boundary faces keep their labels under
+        # renumbering, a shard's real patch faces are found through faceGlobal (cut faces carry no patch value)
+        nif_g = gmesh.nInternalFaces
+        if world > 1:
+            fg = mesh.array("faceGlobal")[mesh.nInternalFaces:]
+            gb = np.where(fg >= nif_g, fg - nif_g, -1)
+        else:
+            gb = np.arange(gmesh.nBoundaryFaces)
+
+        def local(pair):
+            if pair is None:
+                return None
+            cellv, bndv = pair
+            b = np.where(gb >= 0, bndv[np.maximum(gb, 0)], cellv[cells][mesh.array("owner")[mesh.nInternalFaces:]])
+            return cellv[cells], b
+        case.set_qgd_coeffs(alphaQGD=local(fields.get("alphaQGD")), ScQGD=local(fields.get("ScQGD")))
     case.set_fields(fields["U"][cells], fields["T"][cells], fields["p"][cells])
     adjust = bool(case.options.adjustTimeStep)
     if world > 1:
@@ -158,7 +175,17 @@ def run(case_dir, n_steps=None, device_id=0, write=True, log=print, renumber="no
         if total is not None and done >= total:
             break
         n = chunk if total is None else min(chunk, total - done)
-        advance(n)
+        if total is None:
+            # adjustTimeStep: runTime.run() is asked after every step [QGDFoam.C L90]; the write cadence stays `chunk`
+            n_done = 0
+            while n_done < n:
+                advance(1)
+                n_done += 1
+                if t0 + case.info()["time"] >= end_time - 1e-12 * max(1.0, abs(end_time)):
+                    break
+            n = n_done
+        else:
+            advance(n)
         done += n
         info = case.info()
         if world > 1:

@@ -83,6 +83,7 @@ SIGNATURES = {
     "qgd_case_free": (C.c_int, [handle]),
     "qgd_case_set_bc": (C.c_int, [handle, C.c_int32, C.c_int32, c_double_p, C.c_int32, C.c_double, C.c_int32, C.c_double]),
     "qgd_case_set_fields": (C.c_int, [handle, c_double_p, c_double_p, c_double_p]),
+    "qgd_case_set_qgd_coeffs": (C.c_int, [handle, c_double_p, c_double_p, c_double_p, c_double_p]),
     "qgd_case_update_fluxes": (C.c_int, [handle]),
     "qgd_case_step": (C.c_int, [handle, C.c_int32]),
     "qgd_case_get_field": (C.c_int, [handle, C.c_char_p, c_double_p, C.c_int64]),

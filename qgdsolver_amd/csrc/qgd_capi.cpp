@@ -129,6 +129,7 @@ struct qgd_case_s {
     DeviceArena arena;
     CaseView view{};
     double* dbgBuf = nullptr;
+    double* coef[4] = {nullptr, nullptr, nullptr, nullptr};  // device copies of non-uniform alphaQGD / ScQGD (cells, patch faces)
     double time = 0;
     int64_t steps = 0;
     // timing
@@ -428,6 +429,7 @@ int qgd_device_create(qgd_mesh_t mh, int deviceId, qgd_device_t* out) {
         MeshView& v = d->view;
         v.nP = s.nP; v.nF = s.nF; v.nIF = s.nIF; v.nC = s.nC; v.nBF = s.nBF;
         v.ie1 = s.ie1; v.ie2 = s.ie2; v.ie3 = s.ie3;
+        { const char* e = std::getenv("QGD_XCD_RUN"); v.xcdRun = e ? std::atoi(e) : 0; }
         // upload + free each table in turn so the host peak stays at one table
         auto up = [&](auto& vec) { auto* p = a.upload(vec); std::decay_t<decltype(vec)>().swap(vec); return p; };
         v.own = up(s.own); v.nei = up(s.nei);
@@ -863,6 +865,28 @@ int qgd_case_set_bc(qgd_case_t c, int32_t patch, int32_t bcU, const double* valu
     QGD_CATCH
 }
 
+int qgd_case_set_qgd_coeffs(qgd_case_t c, const double* alphaQGD, const double* alphaQGDb, const double* ScQGD, const double* ScQGDb) {
+    QGD_TRY
+    if (!c) return fail(QGD_ERR_INVALID, "null case");
+    if (c->dev->view.nBF > 0 && ((alphaQGD && !alphaQGDb) || (ScQGD && !ScQGDb)))
+        return fail(QGD_ERR_INVALID, "qgd_case_set_qgd_coeffs: a field needs both its cell and its patch values");
+    HIP_CHECK(hipSetDevice(c->dev->deviceId));
+    const MeshView& m = c->dev->view;
+    auto put = [&](const double* src, size_t n, double*& slot) -> const double* {
+        if (!src) return nullptr;
+        if (!slot) slot = c->arena.alloc<double>(std::max<size_t>(n, 1), false);
+        if (n) HIP_CHECK(hipMemcpy(slot, src, sizeof(double) * n, hipMemcpyHostToDevice));
+        return slot;
+    };
+    c->view.aQ = put(alphaQGD, (size_t)m.nC, c->coef[0]);
+    c->view.aQb = put(alphaQGD ? alphaQGDb : nullptr, (size_t)m.nBF, c->coef[1]);
+    c->view.sc = put(ScQGD, (size_t)m.nC, c->coef[2]);
+    c->view.scb = put(ScQGD ? ScQGDb : nullptr, (size_t)m.nBF, c->coef[3]);
+    c->fieldsSet = false;
+    return QGD_OK;
+    QGD_CATCH
+}
+
 // one flux-assembly pass (updateFields.H + updateFluxes.H) on the current state
 static void assembleFluxes(qgd_case_s* c, bool adjust) {
     (void)hipGetLastError();  // drop any stale sticky error: the callers check after their launches
@@ -1146,7 +1170,7 @@ int qgd_case_get_field(qgd_case_t c, const char* name, double* out, int64_t outD
     try {
         (void)hipGetLastError();
         launchExtractField(c->stream(), bnd ? c->view.bA : c->view.A, bnd ? c->view.bB : c->view.B, bnd ? nullptr : c->view.K,
-                           bnd ? m.hQGDb : m.hQGD, n, g, cf->second, tmp);
+                           bnd ? m.hQGDb : m.hQGD, bnd ? c->view.aQb : c->view.aQ, n, g, cf->second, tmp);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipStreamSynchronize(c->stream()));
         HIP_CHECK(hipMemcpy(out, tmp, sizeof(double) * (size_t)(n * nc), hipMemcpyDeviceToHost));

@@ -17,6 +17,7 @@ enum StencilKind : int { ST_REDUCED = 0, ST_LSQ = 1, ST_GVP3 = 2, ST_GVP2 = 3 };
 struct MeshView {
     int32_t nP, nF, nIF, nC, nBF;
     int32_t ie1, ie2, ie3;
+    int32_t xcdRun;          // tiles per XCD run of the workgroup->tile map (0: one contiguous eighth per XCD)
     const int32_t* own;      // nF
     const int32_t* nei;      // nIF
     const int4* verts;       // nF
@@ -71,6 +72,9 @@ struct CaseView {
     int32_t nBlkFace, nBlkCell;
     double* dt;                     // [0]=deltaT (device resident so adjustTimeStep needs no host round trip)
     double* dbg;                    // optional debug face fields (nullptr in the product path)
+    // non-uniform alphaQGD / ScQGD (the READ_IF_PRESENT fields of QGDCoeffs_8C L119-160, constScPrModel1_8C L66-79);
+    // nullptr = the uniform value of GasModel
+    const double* aQ; const double* aQb; const double* sc; const double* scb;
 };
 
 enum DebugSlot : int {
@@ -112,8 +116,8 @@ void launchHaloPack(const Launcher& L, const CaseView& c, const int32_t* cells, 
 // ---- accessor: one named cell / patch field out of the records (K == nullptr on patches) ----------------------------
 enum ExtractField : int { XF_RHO = 0, XF_U, XF_P, XF_E, XF_T, XF_RHOU, XF_RHOE, XF_C, XF_PSI, XF_MU, XF_ALPHAU, XF_TAUQGD, XF_MUQGD,
                           XF_ALPHAUQGD, XF_HQGD, XF_H, XF_GAMMA };
-void launchExtractField(hipStream_t s, const RecA* A, const RecB* B, const Cons* K, const double* hq, int64_t n, const GasModel& g,
-                        int field, double* out);
+void launchExtractField(hipStream_t s, const RecA* A, const RecB* B, const Cons* K, const double* hq, const double* aQ, int64_t n,
+                        const GasModel& g, int field, double* out);
 
 // ---- fvsc operators on plain fields ----------------------------------------------
 // op: 0 grad (out 3*NC per face), 1 div (out NC/3 per face); NC in {1,3,9}

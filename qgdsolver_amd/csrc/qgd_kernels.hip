@@ -397,11 +397,21 @@ __device__ __forceinline__ double alphaEffOf(const GasModel& gm, double muQGD) {
 // XCDs (block b -> XCD b%8), each with a private L2.  Remap so that every XCD
 // walks one contiguous eighth of the face range and neighbouring tiles (which
 // share cell and vertex records) meet in the same L2.
-__device__ __forceinline__ int xcdTile(int nTiles) {
+__device__ __forceinline__ int xcdTile(int nTiles, int run = 0) {
     const int b = blockIdx.x;
-    const int per = nTiles >> 3;        // tiles per XCD (the tail past 8*per keeps identity order)
-    if (b >= (per << 3)) return b;
-    return (b & 7) * per + (b >> 3);
+    if (run <= 0) {
+        const int per = nTiles >> 3;        // tiles per XCD (the tail past 8*per keeps identity order)
+        if (b >= (per << 3)) return b;
+        return (b & 7) * per + (b >> 3);
+    }
+    // runs of `run` consecutive tiles dealt round-robin to the XCDs: consecutive tiles still meet in one L2, and the
+    // eight XCDs stay inside one window of 8*run tiles, so what one of them fetched from HBM is found by the others (one
+    // k-plane later) in the shared Infinity Cache instead of each XCD keeping a plane-sized working set of its own
+    const int span = run << 3;
+    const int full = (nTiles / span) * span;
+    if (b >= full) return b;
+    const int xcd = b & 7, i = b >> 3;
+    return ((i / run) * 8 + xcd) * run + (i % run);
 }
 
 // ---------------------------------------------------------------------------
@@ -461,7 +471,7 @@ __device__ __forceinline__ void finishInternalFace(const MeshView& m, const Case
 template <bool DBG>
 __global__ __launch_bounds__(QGD_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 3)))
 void faceFluxLsqKernel(const MeshView m, const CaseView c, const GasModel gm, const int adjustDt) {
-    const int tile = xcdTile((int)gridDim.x);
+    const int tile = xcdTile((int)gridDim.x, m.xcdRun);
     const int f = tile * QGD_BLOCK + (int)threadIdx.x;
     double cof = -1e300, tauMin = 1e300;
     if (f < m.nIF) {
@@ -544,7 +554,7 @@ void faceFluxLsqKernel(const MeshView m, const CaseView c, const GasModel gm, co
 template <bool DBG>
 __global__ __launch_bounds__(QGD_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 4)))
 void faceFluxReducedKernel(const MeshView m, const CaseView c, const GasModel gm, const int adjustDt) {
-    const int tile = xcdTile((int)gridDim.x);
+    const int tile = xcdTile((int)gridDim.x, m.xcdRun);
     const int f = tile * QGD_BLOCK + (int)threadIdx.x;
     double cof = -1e300, tauMin = 1e300;
     if (f < m.nIF) {
@@ -579,7 +589,7 @@ void faceFluxReducedKernel(const MeshView m, const CaseView c, const GasModel gm
 template <bool DBG>
 __global__ __launch_bounds__(QGD_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 4)))
 void faceFluxGvp2Kernel(const MeshView m, const CaseView c, const GasModel gm, const int adjustDt) {
-    const int tile = xcdTile((int)gridDim.x);
+    const int tile = xcdTile((int)gridDim.x, m.xcdRun);
     const int f = tile * QGD_BLOCK + (int)threadIdx.x;
     double cof = -1e300, tauMin = 1e300;
     if (f < m.nIF) {
@@ -627,7 +637,7 @@ void faceFluxGvp2Kernel(const MeshView m, const CaseView c, const GasModel gm, c
 template <bool DBG>
 __global__ __launch_bounds__(QGD_BLOCK) __attribute__((amdgpu_waves_per_eu(QGD_F_WAVES_MIN, QGD_F_WAVES_MAX)))
 void faceFluxGvp3Kernel(const MeshView m, const CaseView c, const GasModel gm, const int adjustDt) {
-    const int tile = xcdTile((int)gridDim.x);
+    const int tile = xcdTile((int)gridDim.x, m.xcdRun);
     const int f = tile * QGD_BLOCK + (int)threadIdx.x;
     double cof = -1e300, tauMin = 1e300;
     if (f < m.nIF) {
@@ -854,7 +864,7 @@ __global__ __launch_bounds__(QGD_BLOCK) void boundaryFaceFluxKernel(const MeshVi
 template <int NC>
 __global__ __launch_bounds__(QGD_BLOCK) void pointInterpKernel(const MeshView m, const double* __restrict__ cellF,
                                                               const int cellStride, double* __restrict__ ptF) {
-    const int p = xcdTile((int)gridDim.x) * QGD_BLOCK + threadIdx.x;
+    const int p = xcdTile((int)gridDim.x, m.xcdRun) * QGD_BLOCK + threadIdx.x;
     if (p >= m.nP) return;
     const int n = m.pcCount[p];
     if (n == 0) return;  // patch point: written by boundaryPointKernel
@@ -883,7 +893,7 @@ __global__ __launch_bounds__(QGD_BLOCK) void pointInterpKernel(const MeshView m,
 #endif
 __global__ __launch_bounds__(QGD_BLOCK) __attribute__((amdgpu_waves_per_eu(QGD_P_WAVES_MIN, QGD_P_WAVES_MAX)))
 void pointInterpRecKernel(const MeshView m, const RecA* __restrict__ A, RecA* __restrict__ P) {
-    const int p = xcdTile((int)gridDim.x) * QGD_BLOCK + threadIdx.x;
+    const int p = xcdTile((int)gridDim.x, m.xcdRun) * QGD_BLOCK + threadIdx.x;
     if (p >= m.nP) return;
     const int n = m.pcCount[p];
     if (n == 0) return;
@@ -970,7 +980,7 @@ void cellUpdateKernel(const MeshView m, const CaseView c, const GasModel gm, con
                       const int32_t* __restrict__ list, const int nList, const int slotBase) {
     // mode 0: every cell but the ghosts; mode 1: the cells of `list` (boundary layer of a shard: its records are what the
     // neighbours wait for); mode 2: ordinary owned cells only (the rest, while the exchange is in flight)
-    const int tile = (mode == 1) ? (int)blockIdx.x : xcdTile((int)gridDim.x);
+    const int tile = (mode == 1) ? (int)blockIdx.x : xcdTile((int)gridDim.x, m.xcdRun);
     const int idx = tile * QGD_BLOCK + threadIdx.x;
     int ci = -1;
     if (mode == 1) { if (idx < nList) ci = list[idx]; }
@@ -1050,11 +1060,12 @@ void cellUpdateKernel(const MeshView m, const CaseView c, const GasModel gm, con
         const double psi = 1.0 / (gm.R * T);
         const double cs = sqrt(gm.gamma / psi);
         // constScPrModel1 [L103-115]: the pressure seen here is still the old one [QGDFoam_8C L149-154]
-        const double tauQGD = gm.alphaQGD * hq / cs;
+        const double aq = c.aQ ? c.aQ[ci] : gm.alphaQGD, scq = c.sc ? c.sc[ci] : gm.ScQGD;
+        const double tauQGD = aq * hq / cs;
         RecB Bn;
-        Bn.muQGD = A.p * gm.ScQGD * tauQGD;
+        Bn.muQGD = A.p * scq * tauQGD;
         Bn.c = cs;
-        Bn.aOc = gm.alphaQGD / cs;
+        Bn.aOc = aq / cs;
         An.p = rho / psi;                  // [QGDFoam_8C L152-154]
         Bn.H = (Kn.rE + An.p) / rho;       // H = (rhoE + p)/rho [QGDFoam/updateFields.H L71]
         c.A[ci] = An;
@@ -1085,10 +1096,11 @@ __global__ __launch_bounds__(QGD_BLOCK) void cellInitKernel(const MeshView m, co
     K.rux = rho * A.ux; K.ruy = rho * A.uy; K.ruz = rho * A.uz;
     K.rE = rho * e + rho * 0.5 * (A.ux * A.ux + A.uy * A.uy + A.uz * A.uz);
     RecB B;
-    const double tauQGD = gm.alphaQGD * m.hQGD[ci] / cs;
-    B.muQGD = pc * gm.ScQGD * tauQGD;
+    const double aq = c.aQ ? c.aQ[ci] : gm.alphaQGD, scq = c.sc ? c.sc[ci] : gm.ScQGD;
+    const double tauQGD = aq * m.hQGD[ci] / cs;
+    B.muQGD = pc * scq * tauQGD;
     B.c = cs;
-    B.aOc = gm.alphaQGD / cs;
+    B.aOc = aq / cs;
     B.H = (K.rE + pc) / rho;
     c.A[ci] = A; c.B[ci] = B; c.K[ci] = K;
 }
@@ -1137,12 +1149,13 @@ __global__ __launch_bounds__(QGD_BLOCK) void boundaryUpdateKernel(const MeshView
     const double psi = 1.0 / (gm.R * Tb);
     const double cs = sqrt(gm.gamma / psi);
     RecB Bb;
+    const double aq = c.aQb ? c.aQb[b] : gm.alphaQGD, scq = c.scb ? c.scb[b] : gm.ScQGD;
     Bb.c = cs;
-    Bb.aOc = gm.alphaQGD / cs;
+    Bb.aOc = aq / cs;
     // pressure seen by constScPrModel1 at thermo.correct(): the patch value before p's BC update
     const double pOld = init ? ((bc.bcP == QGD_BC_FIXEDVALUE) ? bc.vP : Ao.p) : c.bPmid[b];
-    const double tauQGD = gm.alphaQGD * m.hQGDb[b] / cs;
-    Bb.muQGD = pOld * gm.ScQGD * tauQGD;
+    const double tauQGD = aq * m.hQGDb[b] / cs;
+    Bb.muQGD = pOld * scq * tauQGD;
     // p
     if (bc.bcP == QGD_BC_FIXEDVALUE) Ab.p = bc.vP;
     else if (bc.bcP == QGD_BC_QGDFLUX) {
@@ -1380,6 +1393,7 @@ __global__ __launch_bounds__(QGD_BLOCK) void qhdFaceKernel(const MeshView m, con
 // the device and one copy of what was asked for, instead of shipping every record to the host).
 __global__ __launch_bounds__(QGD_BLOCK) void extractFieldKernel(const RecA* __restrict__ A, const RecB* __restrict__ B,
                                                                const Cons* __restrict__ K, const double* __restrict__ hq,
+                                                               const double* __restrict__ aQ,
                                                                const int64_t n, const GasModel g, const int field,
                                                                double* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * QGD_BLOCK + threadIdx.x;
@@ -1402,7 +1416,7 @@ __global__ __launch_bounds__(QGD_BLOCK) void extractFieldKernel(const RecA* __re
         case XF_PSI: out[i] = 1.0 / (g.R * (a.e / g.Cv)); break;
         case XF_MU: out[i] = g.mu0 + b.muQGD; break;
         case XF_ALPHAU: out[i] = g.alphah0 + b.muQGD / g.PrQGD; break;
-        case XF_TAUQGD: out[i] = g.alphaQGD * hq[i] / b.c; break;
+        case XF_TAUQGD: out[i] = (aQ ? aQ[i] : g.alphaQGD) * hq[i] / b.c; break;
         case XF_MUQGD: out[i] = b.muQGD; break;
         case XF_ALPHAUQGD: out[i] = b.muQGD / g.PrQGD; break;
         case XF_HQGD: out[i] = hq[i]; break;
@@ -1501,10 +1515,10 @@ void launchHaloPack(const Launcher& L, const CaseView& c, const int32_t* cells, 
     haloKernel<<<gridFor(n), QGD_BLOCK, 0, L.stream>>>(c, cells, nCells, bfaces, nFaces, buf, pack ? 1 : 0);
 }
 
-void launchExtractField(hipStream_t s, const RecA* A, const RecB* B, const Cons* K, const double* hq, int64_t n, const GasModel& g,
-                        int field, double* out) {
+void launchExtractField(hipStream_t s, const RecA* A, const RecB* B, const Cons* K, const double* hq, const double* aQ, int64_t n,
+                        const GasModel& g, int field, double* out) {
     if (n == 0) return;
-    extractFieldKernel<<<gridFor(n), QGD_BLOCK, 0, s>>>(A, B, K, hq, n, g, field, out);
+    extractFieldKernel<<<gridFor(n), QGD_BLOCK, 0, s>>>(A, B, K, hq, aQ, n, g, field, out);
 }
 
 template <int ST, int NC>

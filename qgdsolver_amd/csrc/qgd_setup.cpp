@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <stdexcept>
 
 #include "../../include/qgd_amd.h"
@@ -381,7 +382,8 @@ StaticData buildStaticData(const HostMesh& m) {
             }
             std::vector<int64_t> start(bucket.size() + 1, 0);
             for (size_t r = 0; r < bucket.size(); ++r) start[r + 1] = start[r] + bucket[r];
-            for (int64_t f = 0; f < nIF; ++f) s.fpos[f] = (int32_t)(start[rank[f]]++);
+            const bool labelOrder = std::getenv("QGD_FLUX_LABEL_ORDER") != nullptr;  // experiment switch
+            for (int64_t f = 0; f < nIF; ++f) s.fpos[f] = labelOrder ? (int32_t)f : (int32_t)(start[rank[f]]++);
             for (int32_t& it : cfItemCsr) {
                 const int32_t f = it >= 0 ? it : ~it;
                 const int32_t pos = f < nIF ? s.fpos[f] : f;

@@ -39,7 +39,7 @@ class FoamFileError(ValueError):
 # ---------------------------------------------------------------------------------------------------------------------
 _COMMENT = re.compile(r"//[^\n]*|/\*.*?\*/", re.S)
 _TOKEN = re.compile(r'"(?:[^"\\]|\\.)*"|[{}()\[\];]|[^\s{}()\[\];"]+')
-_LIST_HEAD = re.compile(r"(?:List<\s*(\w+)\s*>\s*)?(\d+)\s*\(")
+_LIST_HEAD = re.compile(r"(?:List<\s*(\w+)\s*>\s*)?(?<![\w.+-])(\d+)\s*\(")
 
 
 def _strip_comments(text):
@@ -165,7 +165,10 @@ def _extract_big_lists(text, min_items=64):
                 raise FoamFileError("unterminated list")
         body = text[start:end]
         ragged = nested and text[k] != "("
-        flat = np.array(body.replace("(", " ").replace(")", " ").split(), dtype=np.float64)
+        try:
+            flat = np.array(body.replace("(", " ").replace(")", " ").split(), dtype=np.float64)
+        except ValueError:
+            continue  # not a numeric list (e.g. a boundary file with 64 or more patches): left to the token parser
         if ragged:
             lists.append(("ragged", n, flat))
         elif nested:
@@ -488,24 +491,27 @@ def read_case_setup(case_dir, time="0"):
         opt[k] = float(md[k]) if k in md else 1.0
     tdir = os.path.join(case_dir, str(time))
     # alphaQGD and ScQGD are READ_IF_PRESENT fields of the time directory [QGDCoeffs.C L119-160, constScPrModel1.C
-    # L66-79]; this path carries them as scalars, so only uniform ones are accepted
+    # L66-79]: a uniform one becomes the scalar of the options, a non-uniform one travels as (cell values, patch values)
     opt["alphaQGD"] = 0.5
+    coeff_fields = {}
     for fname in ("alphaQGD", "ScQGD"):
         fpath = os.path.join(tdir, fname)
         if _exists(fpath):
-            vals, _ = read_field(fpath, mesh)
-            if np.any(vals != vals[0]):
-                raise FoamFileError(f"{fpath}: only a uniform {fname} field is supported")
-            opt[fname] = float(vals[0, 0])
+            vals, bvals = read_field(fpath, mesh)
+            patch_vals = _patch_values(mesh, vals[:, 0], bvals, fpath)
+            if np.all(vals == vals[0]) and np.all(patch_vals == vals[0, 0]):
+                opt[fname] = float(vals[0, 0])
+            else:
+                coeff_fields[fname] = (vals[:, 0].copy(), patch_vals)
     fs = read_dict(os.path.join(case_dir, "system", "fvSchemes"))
     opt["stencil"] = str(fs.get("fvsc", {}).get("default", "reduced"))
     cd = read_dict(os.path.join(case_dir, "system", "controlDict"))
     opt["deltaT"] = float(cd["deltaT"])
     opt["adjustTimeStep"] = 1 if str(cd.get("adjustTimeStep", "no")) in ("yes", "on", "true", "1") else 0
-    if "maxCo" in cd:
-        opt["maxCo"] = float(cd["maxCo"])
-    if "maxDeltaT" in cd:
-        opt["maxDeltaT"] = float(cd["maxDeltaT"])
+    # createTimeControls.H (L0): maxCo defaults to 1, maxDeltaT to GREAT; setDeltaT-QGDQHD.H L45: cTau defaults to 0.75
+    opt["maxCo"] = float(cd.get("maxCo", 1.0))
+    opt["maxDeltaT"] = float(cd.get("maxDeltaT", 1e300))
+    opt["cTau"] = float(cd.get("cTau", 0.75))
 
     U, bU = read_field(os.path.join(tdir, "U"), mesh)
     T, bT = read_field(os.path.join(tdir, "T"), mesh)
@@ -515,7 +521,32 @@ def read_case_setup(case_dir, time="0"):
     for i, name in enumerate(mesh.patch_names):
         bcs.append({"U": _bc(bU[name], True, ptw[i], f"U.{name}"), "T": _bc(bT[name], False, ptw[i], f"T.{name}"),
                     "p": _bc(bP[name], False, ptw[i], f"p.{name}")})
-    return mesh, opt, {"U": U, "T": T[:, 0], "p": p[:, 0]}, bcs
+    fields = {"U": U, "T": T[:, 0], "p": p[:, 0]}
+    fields.update(coeff_fields)
+    return mesh, opt, fields, bcs
+
+
+def _patch_values(mesh, internal, patches, what):
+    """patch values (nBoundaryFaces) of a scalar field read by read_field: `value` where the file gives one, otherwise
+    the owner cell's value (zeroGradient / calculated without value; also on constraint patches, which carry no field)"""
+    nif = mesh.nInternalFaces
+    own = mesh.array("owner")
+    out = np.zeros(mesh.nBoundaryFaces)
+    ps, pz, pt = mesh.array("patchStart"), mesh.array("patchSize"), mesh.array("patchType")
+    names = getattr(mesh, "patch_names", None) or [f"patch{i}" for i in range(mesh.nPatches)]
+    for i, name in enumerate(names):
+        sl = slice(int(ps[i]) - nif, int(ps[i]) - nif + int(pz[i]))
+        if PATCH_WORDS.get(int(pt[i]), "patch") in _CONSTRAINT_BCS:
+            out[sl] = internal[own[int(ps[i]): int(ps[i]) + int(pz[i])]]   # carries no field; never read
+            continue
+        rec = patches[name]
+        if rec["value"] is not None:
+            out[sl] = rec["value"][:, 0]
+        elif rec["type"] in ("zeroGradient", "calculated"):
+            out[sl] = internal[own[int(ps[i]): int(ps[i]) + int(pz[i])]]
+        else:
+            raise FoamFileError(f"{what}: patch '{name}' of type '{rec['type']}' needs a value")
+    return out
 
 
 def load_case(case_dir, time="0", device_id=0):
@@ -529,6 +560,8 @@ def load_case(case_dir, time="0", device_id=0):
     case = QGDFoamCase(dev, default_options(**opt))
     for i, bc in enumerate(bcs):
         case.set_bc(i, U=bc["U"], T=bc["T"], p=bc["p"])
+    if "alphaQGD" in fields or "ScQGD" in fields:
+        case.set_qgd_coeffs(alphaQGD=fields.get("alphaQGD"), ScQGD=fields.get("ScQGD"))
     case.set_fields(fields["U"], fields["T"], fields["p"])
     return dev, case
 

@@ -65,6 +65,10 @@ class SlabHalo:
         halo stream   :                                 | pack, send/recv, unpack ...  |
         The case's kernels run on ``compute_stream`` (``case.set_stream``), pack/unpack on ``halo_stream``
         (``case.set_halo_stream``); torch.distributed orders the RCCL transfer after the halo stream's pack."""
+        if getattr(self, "_halo_stream", None) is not halo_stream:
+            # pack/unpack must be enqueued on the stream the RCCL transfer is ordered against
+            self.case.set_halo_stream(halo_stream.cuda_stream)
+            self._halo_stream = halo_stream
         self.case.step_phase(0)
         self.case.step_phase(10)
         halo_stream.wait_stream(compute_stream)

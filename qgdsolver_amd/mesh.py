@@ -83,6 +83,15 @@ class PolyMesh:
                     owner=self.array("owner"), neighbour=self.array("neighbour"), nCells=self.nCells,
                     patchStart=self.array("patchStart"), patchSize=self.array("patchSize"), patchType=self.array("patchType"))
 
+    def set_geometry(self, Sf, Cf, C_, V):
+        """hand over the caller's own face area vectors / centres, cell centres / volumes (qgd_mesh_set_geometry: what the
+        OpenFOAM adapter does with mesh.Sf(), Cf(), C(), V()); derived coefficients are recomputed from them"""
+        a = [np.ascontiguousarray(x, dtype=np.float64).reshape(-1) for x in (Sf, Cf, C_, V)]
+        assert a[0].size == 3 * self.nFaces and a[1].size == 3 * self.nFaces and a[2].size == 3 * self.nCells and a[3].size == self.nCells
+        L.check(L.lib.qgd_mesh_set_geometry(self._h, *[_dp(x) for x in a]), "qgd_mesh_set_geometry")
+        self.__init__(self._h)
+        return self
+
     def jitter(self, amplitude, seed=2024):
         L.check(L.lib.qgd_mesh_jitter(self._h, float(amplitude), int(seed)), "qgd_mesh_jitter")
         return self

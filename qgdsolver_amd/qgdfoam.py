@@ -94,6 +94,26 @@ class QGDFoamCase:
         L.check(L.lib.qgd_case_set_fields(self._h, U.ctypes.data_as(L.c_double_p), T.ctypes.data_as(L.c_double_p),
                                           p.ctypes.data_as(L.c_double_p)), "qgd_case_set_fields")
 
+    def set_qgd_coeffs(self, alphaQGD=None, ScQGD=None):
+        """non-uniform alphaQGD / ScQGD fields (QGDCoeffs.C L119-160, constScPrModel1.C L66-79): each a pair
+        (cell values, patch values) or None for the uniform value of the options; call before set_fields"""
+        keep = []
+
+        def ptrs(pair):
+            if pair is None:
+                return None, None
+            c = np.ascontiguousarray(pair[0], dtype=np.float64)
+            b = np.ascontiguousarray(pair[1], dtype=np.float64)
+            assert c.size == self.mesh.nCells and b.size == self.mesh.nBoundaryFaces
+            if b.size == 0:
+                b = np.zeros(1)
+            keep.extend([c, b])
+            return c.ctypes.data_as(L.c_double_p), b.ctypes.data_as(L.c_double_p)
+
+        a, ab = ptrs(alphaQGD)
+        s, sb = ptrs(ScQGD)
+        L.check(L.lib.qgd_case_set_qgd_coeffs(self._h, a, ab, s, sb), "qgd_case_set_qgd_coeffs")
+
     def updateFluxes(self):
         L.check(L.lib.qgd_case_update_fluxes(self._h), "qgd_case_update_fluxes")
 

@@ -44,6 +44,7 @@ lib.orc_case_create.argtypes = [C.c_void_p, C.POINTER(Options)]
 lib.orc_case_free.argtypes = [C.c_void_p]
 lib.orc_case_set_bc.argtypes = [C.c_void_p, C.c_int32, C.c_int32, dp, C.c_int32, C.c_double, C.c_int32, C.c_double]
 lib.orc_case_set_fields.argtypes = [C.c_void_p, dp, dp, dp]
+lib.orc_case_set_qgd_coeffs.argtypes = [C.c_void_p, dp, dp, dp, dp]
 lib.orc_case_update_fluxes.argtypes = [C.c_void_p]
 lib.orc_case_step.argtypes = [C.c_void_p, C.c_int32]
 lib.orc_case_get_field.argtypes = [C.c_void_p, C.c_char_p, dp, C.c_int64]
@@ -168,6 +169,23 @@ class OracleCase:
         p = np.ascontiguousarray(p, dtype=np.float64)
         rc = lib.orc_case_set_fields(self._h, _d(U), _d(T), _d(p))
         assert rc == 0, rc
+
+    def set_qgd_coeffs(self, alphaQGD=None, ScQGD=None):
+        keep = []
+
+        def ptrs(pair):
+            if pair is None:
+                return None, None
+            c = np.ascontiguousarray(pair[0], dtype=np.float64)
+            b = np.ascontiguousarray(pair[1], dtype=np.float64)
+            if b.size == 0:
+                b = np.zeros(1)
+            keep.extend([c, b])
+            return _d(c), _d(b)
+
+        a, ab = ptrs(alphaQGD)
+        s, sb = ptrs(ScQGD)
+        assert lib.orc_case_set_qgd_coeffs(self._h, a, ab, s, sb) == 0
 
     def updateFluxes(self):
         assert lib.orc_case_update_fluxes(self._h) == 0

@@ -189,3 +189,54 @@ def test_gzipped_case_files(tmp_path):
     got = ff.read_case_setup(str(tmp_path))
     assert np.array_equal(got[0].array("points"), ref[0].array("points")) and np.array_equal(got[0].array("facePoints"), ref[0].array("facePoints"))
     assert got[1] == ref[1] and all(np.array_equal(got[2][k], ref[2][k]) for k in ref[2])
+
+
+def test_time_controls_defaults_and_cTau(tmp_path):
+    """setDeltaT-QGDQHD.H L45: cTau from controlDict (default 0.75); createTimeControls defaults (L0): maxCo 1, maxDeltaT GREAT"""
+    write_step_case(str(tmp_path))
+    cpath = os.path.join(str(tmp_path), "system", "controlDict")
+    text = open(cpath).read()
+    opt = ff.read_case_setup(str(tmp_path))[1]
+    assert opt["maxCo"] == 0.2 and opt["cTau"] == 0.75 and opt["maxDeltaT"] >= 1e299
+    open(cpath, "w").write(text.replace("maxCo 0.2;", "adjustTimeStep yes;\ncTau 0.3;\nmaxDeltaT 2e-3;"))
+    opt = ff.read_case_setup(str(tmp_path))[1]
+    assert opt["maxCo"] == 1.0 and opt["cTau"] == 0.3 and opt["maxDeltaT"] == 2e-3
+    o = q.default_options(**opt)
+    assert (o.maxCo, o.cTau, o.maxDeltaT) == (1.0, 0.3, 2e-3)
+
+
+def test_nonuniform_alphaQGD_and_ScQGD_files(tmp_path):
+    """alphaQGD / ScQGD are volScalarFields read if present [QGDCoeffs.C L119-160, constScPrModel1.C L66-79]"""
+    mesh = write_step_case(str(tmp_path))
+    m2, opt, fields, bcs = ff.read_case_setup(str(tmp_path))
+    assert "alphaQGD" not in fields and "ScQGD" not in fields
+    rng = np.random.default_rng(3)
+    a = 0.3 + 0.4 * rng.random(m2.nCells)
+    by = dict(zip(m2.patch_names, bcs))
+    sizes = dict(zip(m2.patch_names, m2.array("patchSize")))
+    patches = {n: (("empty", None) if by[n]["U"][0] == "none" else
+                   (("calculated", np.full(int(sizes[n]), 0.45)) if n == "inlet" else ("zeroGradient", None))) for n in m2.patch_names}
+    ff.write_field(os.path.join(str(tmp_path), "0", "alphaQGD"), m2, "alphaQGD", a, patches)
+    ff.write_field(os.path.join(str(tmp_path), "0", "ScQGD"), m2, "ScQGD", np.float64(0.8), {n: patches[n] if patches[n][0] == "empty" else ("zeroGradient", None) for n in m2.patch_names})
+    m3, opt3, fields3, _ = ff.read_case_setup(str(tmp_path))
+    assert opt3["ScQGD"] == 0.8 and "ScQGD" not in fields3          # uniform file -> the scalar option
+    cells, bnd = fields3["alphaQGD"]
+    assert np.array_equal(cells, a) and bnd.size == m3.nBoundaryFaces
+    nif, own = m3.nInternalFaces, m3.array("owner")
+    ps, pz = m3.array("patchStart"), m3.array("patchSize")
+    for i, n in enumerate(m3.patch_names):
+        sl = slice(int(ps[i]) - nif, int(ps[i]) - nif + int(pz[i]))
+        if n == "inlet":
+            assert np.all(bnd[sl] == 0.45)
+        elif patches[n][0] == "zeroGradient":
+            assert np.array_equal(bnd[sl], a[own[int(ps[i]): int(ps[i]) + int(pz[i])]])
+
+
+def test_list_head_is_not_found_inside_numbers_or_words():
+    d = ff.parse_foam_text("FoamFile { format ascii; }\nv 0.125 (1 0 0);\nname3 (4 5);\nw 2(7 8);")
+    assert d["w"] == [7, 8]
+    assert d["v"][0] == 0.125
+    # a non-numeric list of 64 or more items goes to the token parser, not to numpy
+    words = " ".join(f"p{i}" for i in range(70))
+    d = ff.parse_foam_text(f"FoamFile {{ format ascii; }}\nnames 70({words});")
+    assert d["names"][0] == "p0" and len(d["names"]) == 70

@@ -1,0 +1,105 @@
+"""The oracle against numbers evaluated mechanically from the reference's own listing text (tests/golden/make_ref_expr.py:
+the C++ expressions of the listings executed with an emulation of OpenFOAM's vector/tensor operators).  Every golden
+configuration is one internal face between cells with prescribed centres, so the oracle's PUBLIC operators are what is
+checked -- stencil coefficients, slot order of the dfdxif macro, the tensor layout, the interior-triangle pattern, the
+leastSquares weights and degeneracy rule, and the whole updateFields.H / updateFluxes.H flux algebra."""
+import numpy as np
+import pytest
+
+from oracle import OracleCase, OracleMesh
+import oracle
+import ref_expr_cases as rc
+
+import qgdsolver_amd as q
+
+TOL = 2e-13
+
+
+def rel(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def oracle_mesh(prim, geom):
+    om = OracleMesh(prim)
+    om.set_geometry(geom["Sf"], geom["Cf"], geom["C"], geom["V"])
+    return om
+
+
+def test_gaussvolpoint_3d_coefficients_and_macro():
+    g = rc.load("gvp3d")
+    assert set(g["nv"]) == {3, 4}
+    for i in range(len(g["nv"])):
+        nv = int(g["nv"][i])
+        prim, geom = rc.two_cell_mesh(g["pts"][i], nv, g["Sf"][i], g["Cf"][i], g["C"][i])
+        om = oracle_mesh(prim, geom)
+        assert om.info()["nGeometricD"] == 3
+        rc_s, gs = om.fvsc("GaussVolPoint", "grad_s", g["cell_s"][i], np.zeros(0))
+        rc_v, gv = om.fvsc("GaussVolPoint", "grad_v", g["cell_v"][i], np.zeros(0))
+        assert rc_s == 0 and rc_v == 0
+        assert rel(gs[0], g["grad_s"][i]) <= TOL, (i, nv, gs[0], g["grad_s"][i])
+        assert rel(gv[0], g["grad_v"][i]) <= TOL, (i, nv)
+        if nv == 3:   # the listing's interior-triangle pattern: every row holds (dxUx, dyUy, dzUz)
+            assert np.array_equal(g["grad_v"][i][0:3], g["grad_v"][i][3:6]) and np.array_equal(g["grad_v"][i][0:3], g["grad_v"][i][6:9])
+        om.close()
+
+
+def test_gaussvolpoint_2d_coefficients_and_apply():
+    g = rc.load("gvp2d")
+    for i in range(len(g["ie3"])):
+        ie3 = int(g["ie3"][i])
+        prim, geom = rc.two_cell_mesh(g["pts"][i], 4, g["Sf"][i], g["Cf"][i], g["C"][i], empty_normals=[rc.unit(ie3)])
+        om = oracle_mesh(prim, geom)
+        info = om.info()
+        assert info["nGeometricD"] == 2 and info["geometricD"][ie3] == -1
+        st, gs = om.fvsc("GaussVolPoint", "grad_s", g["f"][i], np.zeros(1))
+        assert st == 0
+        assert rel(gs[0], g["grad"][i]) <= TOL, (i, ie3, gs[0], g["grad"][i])
+        om.close()
+
+
+def test_leastsquares_weights_degeneracy_and_apply():
+    g = rc.load("lsq")
+    assert 0 < g["deg"].sum() < len(g["deg"])     # both branches of det(G) < 1 occur
+    for i in range(len(g["n"])):
+        n = int(g["n"][i])
+        prim, geom = rc.lsq_mesh(n, g["Cf"][i], g["centres"][i], one_d=(n == 2))
+        om = oracle_mesh(prim, geom)
+        assert om.info()["nGeometricD"] == (1 if n == 2 else 2)
+        nb = prim["owner"].size - 1
+        cell = g["iF"][i][:n]
+        bnd = np.zeros(nb)
+        st, got = om.fvsc("leastSquares", "grad_s", cell, bnd)
+        assert st == 0
+        if g["deg"][i]:
+            st2, red = om.fvsc("reduced", "grad_s", cell, bnd)   # degenerate faces fall back to nf*snGrad [ScalarGrad.C L76-83]
+            assert np.array_equal(got[0], red[0]), i
+        else:
+            assert rel(got[0], g["grad"][i]) <= TOL, (i, n, got[0], g["grad"][i])
+        om.close()
+
+
+FACE_FIELDS = ("rhof", "Uf", "pf", "cf", "Hf", "alphauf", "muf", "tauQGDf", "hQGDf", "gradUf", "gradef", "gradRhof", "gradPf",
+               "phiwStar", "phiJm", "phi", "phiJmU", "phiP", "phiPi", "phiJmH", "phiQ", "phiPiU")
+
+
+def case_options(g, i):
+    return q.default_options(stencil="GaussVolPoint", R=float(g["R"][i]), Cv=float(g["Cv"][i]), mu=float(g["mu"][i]), Pr=float(g["Pr"][i]),
+                             ScQGD=float(g["ScQGD"][i]), PrQGD=float(g["PrQGD"][i]), alphaQGD=float(g["alphaQGD"][i]), deltaT=1e-6)
+
+
+def test_flux_assembly_of_one_face():
+    g = rc.load("case2cell")
+    for i in range(len(g["nv"])):
+        nv = int(g["nv"][i])
+        prim, geom = rc.two_cell_mesh(g["pts"][i], nv, g["Sf"][i], g["Cf"][i], g["C"][i])
+        om = oracle_mesh(prim, geom)
+        assert rel(om.array("weights")[0], g["w"][i]) <= 1e-15
+        oc = OracleCase(om, case_options(g, i))
+        oc.set_fields(g["U"][i], g["T"][i], g["p"][i])
+        oc.updateFluxes()
+        for f in FACE_FIELDS:
+            assert rel(oc.field(f)[0], g[f][i]) <= TOL, (i, nv, f, oc.field(f)[0], g[f][i])
+        for f in ("muQGD", "alphauQGD", "tauQGD", "hQGD"):
+            assert rel(oc.field(f), g[f][i]) <= TOL, (i, f)
+        oc.close(); om.close()

@@ -1,0 +1,82 @@
+"""The HIP path against numbers evaluated mechanically from the reference's own listing text (tests/golden/make_ref_expr.py),
+through the C-ABI: qgd_mesh_create + qgd_mesh_set_geometry, the fvsc operators, and the QGDFoam case (whose internal face
+goes through the fused, loads-first face kernel).  Same golden files and meshes as tests/test_ref_expr.py uses for the oracle."""
+import numpy as np
+import pytest
+
+import qgdsolver_amd as q
+from qgdsolver_amd import fvsc
+
+import ref_expr_cases as rc
+from test_ref_expr import FACE_FIELDS, case_options, rel
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-12
+
+
+def device_mesh(prim, geom):
+    m = q.PolyMesh.from_arrays(prim["points"], prim["faceOffsets"], prim["facePoints"], prim["owner"], prim["neighbour"], prim["nCells"],
+                               prim["patchStart"], prim["patchSize"], prim["patchType"])
+    m.set_geometry(geom["Sf"], geom["Cf"], geom["C"], geom["V"])
+    return m
+
+
+def test_gaussvolpoint_3d_on_the_device():
+    g = rc.load("gvp3d")
+    for i in range(len(g["nv"])):
+        nv = int(g["nv"][i])
+        mesh = device_mesh(*rc.two_cell_mesh(g["pts"][i], nv, g["Sf"][i], g["Cf"][i], g["C"][i]))
+        dev = q.Device(mesh, fv_schemes={"fvsc": {"default": "GaussVolPoint"}})
+        gs = fvsc.grad(dev, q.volField("f", g["cell_s"][i], np.zeros(0)))
+        gv = fvsc.grad(dev, q.volField("U", g["cell_v"][i], np.zeros((0, 3))))
+        assert rel(gs[0], g["grad_s"][i]) <= TOL, (i, nv)
+        assert rel(gv[0], g["grad_v"][i]) <= TOL, (i, nv)
+        dev.close()
+
+
+def test_gaussvolpoint_2d_on_the_device():
+    g = rc.load("gvp2d")
+    for i in range(len(g["ie3"])):
+        ie3 = int(g["ie3"][i])
+        mesh = device_mesh(*rc.two_cell_mesh(g["pts"][i], 4, g["Sf"][i], g["Cf"][i], g["C"][i], empty_normals=[rc.unit(ie3)]))
+        assert mesh.nGeometricD == 2
+        dev = q.Device(mesh, fv_schemes={"fvsc": {"default": "GaussVolPoint"}})
+        gs = fvsc.grad(dev, q.volField("f", g["f"][i], np.zeros(1)))
+        assert rel(gs[0], g["grad"][i]) <= TOL, (i, ie3)
+        dev.close()
+
+
+def test_leastsquares_on_the_device():
+    g = rc.load("lsq")
+    for i in range(len(g["n"])):
+        n = int(g["n"][i])
+        prim, geom = rc.lsq_mesh(n, g["Cf"][i], g["centres"][i], one_d=(n == 2))
+        mesh = device_mesh(prim, geom)
+        dev = q.Device(mesh, fv_schemes={"fvsc": {"default": "leastSquares", "grad(r)": "reduced"}})
+        nb = mesh.nBoundaryFaces
+        got = fvsc.grad(dev, q.volField("f", g["iF"][i][:n], np.zeros(nb)))
+        if g["deg"][i]:
+            red = fvsc.grad(dev, q.volField("r", g["iF"][i][:n], np.zeros(nb)))
+            assert rel(got[0], red[0]) <= 1e-15, i
+        else:
+            assert rel(got[0], g["grad"][i]) <= TOL, (i, n)
+        dev.close()
+
+
+def test_flux_assembly_of_one_face_on_the_device():
+    g = rc.load("case2cell")
+    for i in range(len(g["nv"])):
+        nv = int(g["nv"][i])
+        mesh = device_mesh(*rc.two_cell_mesh(g["pts"][i], nv, g["Sf"][i], g["Cf"][i], g["C"][i]))
+        dev = q.Device(mesh)
+        case = q.QGDFoamCase(dev, case_options(g, i))
+        case.set_fields(g["U"][i], g["T"][i], g["p"][i])
+        case.updateFluxes()
+        for f in FACE_FIELDS:
+            if f in ("rhof", "Uf", "pf", "cf", "Hf", "alphauf", "muf"):
+                continue   # interpolated fields stay in registers on the device; their consumers below are compared
+            assert rel(case.field(f)[0], g[f][i]) <= TOL, (i, nv, f, case.field(f)[0], g[f][i])
+        for f in ("muQGD", "alphauQGD", "tauQGD", "hQGD"):
+            assert rel(case.field(f), g[f][i]) <= TOL, (i, f)
+        case.close(); dev.close()
