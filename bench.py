@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--edge", dest="n", type=int, default=int(os.environ.get("QGD_BENCH_N", "400")), help="box edge in cells (n^3 cells in total)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the second line (fvsc drop-in path with host fields)")
+    ap.add_argument("--dropin-n", type=int, default=200, help="box edge of the fvsc drop-in measurement")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = debugging aid: all ranks share GPU 0 and halo messages are staged through host memory")
     ap.add_argument("--check", action="store_true", help="print a checksum of the owned cells (to compare runs at different N)")
@@ -173,6 +175,59 @@ def cpu_baseline(n, steps, ranks):
             # bytes per cell-step against the STREAM-triad bandwidth the same ranks sustain together
             "host_triad_GBs": sum(triad) if len(triad) == ranks else None,
             "fused_cpu_upper_bound": (sum(triad) * 1e9 / STEP_BYTES_PER_CELL / 1e6) if len(triad) == ranks else None}
+
+
+def dropin_fvsc_line(q, n, reps):
+    """The literal drop-in path of north_star: an unmodified updateFluxes.H calls fvsc::grad(U), grad(e), grad(rho), grad(p)
+    per step [QGDFoam/updateFluxes.H L41-65], each handing HOST fields over and taking a host face field back
+    (qgd_fvsc_grad_v / qgd_fvsc_grad_s).  Times, per step of four calls at edge n: end to end (PCIe both ways included),
+    and the kernels alone against their own compulsory bytes.  Reported beside the headline, never as the headline."""
+    import ctypes as C
+    from qgdsolver_amd import fvsc
+    from qgdsolver_amd import _lib as L
+
+    mesh = q.PolyMesh.box(n, n, n)
+    dev = q.Device(mesh, fv_schemes={"fvsc": {"default": "GaussVolPoint"}})
+    rng = np.random.default_rng(1)
+    nc, nb, nif, npnt = mesh.nCells, mesh.nBoundaryFaces, mesh.nInternalFaces, mesh.nPoints
+    fields = [q.volField("U", rng.standard_normal((nc, 3)), rng.standard_normal((nb, 3)))] + \
+             [q.volField(name, rng.standard_normal(nc), rng.standard_normal(nb)) for name in ("e", "rho", "p")]
+    ms = (C.c_double * 3)()
+    # host face fields are allocated (and touched) once, like the surface fields an OpenFOAM solver keeps alive
+    # [QGDFoam/createFaceFluxes.H L40-218]; every call goes straight to the C entry
+    sid = C.c_int()
+    L.check(L.lib.qgd_stencil_lookup(dev._h, b"GaussVolPoint", C.byref(sid)), "qgd_stencil_lookup")
+    outs = [np.ones((mesh.nFaces, 3 * vf.ncomp)) for vf in fields]
+    dp = lambda a: a.ctypes.data_as(L.c_double_p)  # noqa: E731
+
+    def call(vf, out):
+        fn = L.lib.qgd_fvsc_grad_v if vf.ncomp == 3 else L.lib.qgd_fvsc_grad_s
+        L.check(fn(dev._h, sid.value, dp(vf.internal), dp(vf.boundary), dp(out)), "qgd_fvsc_grad")
+
+    for vf, out in zip(fields, outs):          # first calls size the persistent workspace
+        call(vf, out)
+    wall, parts = [], np.zeros(3)
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        for vf, out in zip(fields, outs):
+            call(vf, out)
+            L.lib.qgd_device_op_times(dev._h, ms)
+            parts += np.array(list(ms))
+        wall.append(time.perf_counter() - t0)
+    parts /= reps
+    # compulsory bytes of the four kernels pairs (vertex interpolation + face gradient), own layout: per internal face labels 25 B
+    # + result 24*ncomp B; per cell value 8*ncomp + centre 32 B; per vertex value written and read 16*ncomp + coordinates 32 B +
+    # its gather list 96 B + 8 cell values 8*ncomp*... counted once per cell above
+    kb = sum(nif * (25 + 24 * k) + nc * (8 * k + 32) + npnt * (16 * k + 32 + 96) for k in (3, 1, 1, 1))
+    pcie = sum(8 * (nc * k + nb * k + mesh.nFaces * 3 * k) for k in (3, 1, 1, 1))
+    out = {"workload": f"fvsc::grad(U)+grad(e)+grad(rho)+grad(p), GaussVolPoint, {n}^3 cells, host fields in / host face fields out",
+           "ms_per_step_end_to_end": 1e3 * min(wall), "ms_host_to_device": parts[0], "ms_kernels": parts[1], "ms_device_to_host": parts[2],
+           "pcie_bytes_per_step": pcie, "pcie_GBs": pcie / min(wall) / 1e9,
+           "kernel_bytes_per_step": kb, "kernel_frac_of_hbm_peak": kb / (parts[1] * 1e-3) / 1e9 / HBM_PEAK_GBS if parts[1] else None,
+           "Mcell_steps_per_s_end_to_end": nc / min(wall) / 1e6}
+    dev.close()
+    mesh.close()
+    return out
 
 
 def main():
@@ -423,12 +478,18 @@ def main():
                                                              ("cell", tr[key].get("cell_bytes_per_launch"), CELL_BYTES_PER_CELL)) if v}}
             except Exception:
                 pass
+    case.close()
+    dev.close()
+    if rank == 0:
+        if world == 1 and not args.no_dropin:
+            try:
+                out["dropin_fvsc"] = dropin_fvsc_line(q, args.dropin_n, 3)
+            except Exception as e:  # the second line must never cost the headline
+                out["dropin_fvsc"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             ranks = args.cpu_ranks or cpu_rank_budget(args.cpu_n)
             out["cpu_baseline"] = cpu_baseline(args.cpu_n, args.cpu_steps, ranks)
         print(json.dumps(out), flush=True)
-    case.close()
-    dev.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -217,6 +217,11 @@ int qgd_fvsc_div_v(qgd_device_t d, int stencilId, const double* cell,
 int qgd_fvsc_div_t(qgd_device_t d, int stencilId, const double* cell,
                    const double* bnd, double* out);
 
+/* Where the time of the last qgd_fvsc_* call on this device went: ms[0] = host -> device copies, ms[1] = kernels (HIP events),
+ * ms[2] = device -> host copy.  Pageable caller memory moves through two pinned staging chunks in a double-buffered
+ * pipeline; buffers of the persistent per-device workspace are reused from call to call (no allocation per call). */
+int qgd_device_op_times(qgd_device_t d, double ms[3]);
+
 /* qgdInterpolate / linearInterpolate [QGDInterpolate_8H_source.html L38-67]: face = w*(phi_O - phi_N) + phi_N, patch faces
  * take the patch value.  cell nCells*ncomp, bnd nBoundaryFaces*ncomp, out nFaces*ncomp (HOST pointers), ncomp in 1..9. */
 int qgd_interpolate(qgd_device_t d, int32_t ncomp, const double* cell, const double* bnd, double* out);
@@ -390,6 +395,30 @@ int qgd_case_step_phase(qgd_case_t c, int phase);
 int qgd_case_reduction_ptr(qgd_case_t c, void** devicePtr);
 /* Stream (hipStream_t as void*) the halo pack/unpack kernels run on; default: the case's compute stream. */
 int qgd_case_set_halo_stream(qgd_case_t c, void* hipStream);
+
+/* ---- native halo transport (RCCL over xGMI, inside the library) ------------------------------------------------------ */
+/* For a C++/MPI host: what replaces the reference's per-gradient-call PstreamBuffers exchange
+ * [extendedFaceStencilScalarGrad_8C_source.html L145-233] and the processor-patch evaluation behind
+ * correctBoundaryConditions() [GaussVolPointStencil_8C_source.html L73] is ONE grouped ncclSend/ncclRecv pair per
+ * neighbouring rank per step.  RCCL is bound at run time (an RCCL already loaded in the process is reused, otherwise
+ * librccl.so of the ROCm installation; QGD_RCCL_LIB overrides); without it these entries return QGD_ERR_NOT_IMPLEMENTED
+ * and the pack/unpack entries above remain for callers with their own transport (GPU-aware MPI, torch.distributed).
+ * Bootstrap like NCCL's: rank 0 asks for the 128-byte unique id, the host broadcasts it (MPI_Bcast / Pstream), every rank
+ * creates its communicator for its HIP device. */
+typedef struct qgd_comm_s* qgd_comm_t;
+int qgd_comm_unique_id(void* id128);
+int qgd_comm_create(int deviceId, int rank, int nRanks, const void* id128, qgd_comm_t* out);
+int qgd_comm_free(qgd_comm_t comm);
+/* pack -> send/recv with peers[slot] (rank behind each halo slot; < 0: skip the slot) -> unpack, stream-ordered on the
+ * case's stream, buffers owned by the library.  No-op for an unsharded case. */
+int qgd_case_halo_exchange(qgd_case_t c, qgd_comm_t comm, const int32_t* peers, int nSlots);
+/* MAX all-reduce of the {max Cof, -min tauQGDf} device buffer between step phases 0 and 1 (adjustTimeStep)
+ * [QGDCourantNo_8H_source.html L50, setDeltaT-QGDQHD_8H_source.html L46]; no-op on one rank */
+int qgd_case_allreduce_max(qgd_case_t c, qgd_comm_t comm);
+/* One step of a sharded case: assemble, (adjustTimeStep: all-reduce), advance, exchange.  overlapped != 0: the shard's
+ * boundary layer is updated first and the exchange runs on the library's halo stream while the compute stream updates the
+ * remaining cells; the next assembly waits for the unpack through an event.  Stream-ordered (qgd_case_stream_sync waits). */
+int qgd_case_step_sharded(qgd_case_t c, qgd_comm_t comm, const int32_t* peers, int nSlots, int overlapped);
 
 /* ---- measurement ------------------------------------------------------------ */
 /* Kernel ids for qgd_case_kernel_time. */

@@ -4,6 +4,7 @@
 //   fvsc::grad(vf) / fvsc::div(vf)                 fvsc.H L46-68, fvsc.C L87-167
 //   fvscStencil::New / lookupOrNew, TypeName words fvscStencil.H L46-137, fvscStencil.C L59-118
 //   scheme word from fvSchemes.fvsc[term] else default, leastSquares refused in 3-D   fvsc.C L47-63
+//   qgdInterpolate(psi), qgdFlux(flux, psi, psif[, fluxName])                          QGDInterpolate.H L38-131
 // Fields are plain std::vector<double> containers (OpenFOAM itself is not required); the OpenFOAM adapter in
 // INTEGRATION.md wraps the same C entries with tmp<surface*Field> results.
 #pragma once
@@ -44,6 +45,9 @@ struct fvMesh {
     qgd_device_t device = nullptr;
     int64_t nCells = 0, nFaces = 0, nInternalFaces = 0;
     std::map<std::string, std::string> fvscSchemes{{"default", "GaussVolPoint"}};
+    // fvSchemes.interpolationSchemes / divSchemes as qgdInterpolate / qgdFlux consult them [QGDInterpolate.H L42-66, L86]
+    std::map<std::string, std::string> interpolationSchemes;
+    std::map<std::string, std::string> divSchemes;
     std::map<std::string, std::shared_ptr<fvscStencil>> registry;
 };
 
@@ -114,6 +118,38 @@ inline surfaceField div(fvMesh& mesh, const volField& vf) {
 }
 
 }  // namespace fvsc
+
+// qgdInterpolate [QGDInterpolate.H L38-67]: linearInterpolate(psi) unless interpolationSchemes names a scheme for
+// "interpolate(<psi>)" or a default other than `none`; those branches hand the field to fvc::interpolate, i.e. to OpenFOAM's
+// own scheme library, which is not behind this boundary: here they are fatal, like a missing run-time table entry.
+inline surfaceField qgdInterpolate(fvMesh& mesh, const volField& psi) {
+    const auto& is = mesh.interpolationSchemes;
+    const bool own = is.count("interpolate(" + psi.name + ")") > 0;
+    const auto def = is.find("default");
+    if (own || (def != is.end() && def->second != "none"))
+        throw FatalError(QGD_ERR_NOT_IMPLEMENTED, "qgdInterpolate(" + psi.name + "): fvc::interpolate with a user scheme stays in OpenFOAM");
+    surfaceField r;
+    r.ncomp = psi.ncomp;
+    r.values.resize((size_t)mesh.nFaces * psi.ncomp);
+    check(qgd_interpolate(mesh.device, psi.ncomp, psi.internal.data(), psi.boundary.data(), r.values.data()), "qgdInterpolate");
+    return r;
+}
+// qgdFlux [QGDInterpolate.H L76-118]: flux*psif unless divSchemes holds an entry for the flux name (then fvc::flux, OpenFOAM's)
+inline surfaceField qgdFlux(fvMesh& mesh, const surfaceField& flux, const volField& psi, const surfaceField& psif,
+                            const std::string& fluxName) {
+    if (mesh.divSchemes.count(fluxName))
+        throw FatalError(QGD_ERR_NOT_IMPLEMENTED, "qgdFlux(" + fluxName + "): fvc::flux with a user scheme stays in OpenFOAM");
+    (void)psi;
+    surfaceField r;
+    r.ncomp = psif.ncomp;
+    r.values.resize(psif.values.size());
+    check(qgd_flux(mesh.device, psif.ncomp, flux.values.data(), psif.values.data(), r.values.data()), "qgdFlux");
+    return r;
+}
+inline surfaceField qgdFlux(fvMesh& mesh, const surfaceField& flux, const std::string& fluxFieldName, const volField& psi,
+                            const surfaceField& psif) {
+    return qgdFlux(mesh, flux, psi, psif, "div(" + fluxFieldName + "," + psi.name + ")");  // [L116]
+}
 
 class fvscStencil : public fvsc::fvscStencil {
     using fvsc::fvscStencil::fvscStencil;

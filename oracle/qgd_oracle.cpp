@@ -27,7 +27,7 @@ namespace {
 // codes shared with include/qgd_amd.h
 enum { PATCH_GENERIC = 0, PATCH_EMPTY = 1, PATCH_SYMMETRYPLANE = 2, PATCH_SYMMETRY = 3,
        PATCH_WEDGE = 4, PATCH_CYCLIC = 5, PATCH_HALO = 6 };
-enum { BC_ZEROGRADIENT = 0, BC_FIXEDVALUE = 1, BC_SLIP = 2, BC_QGDFLUX = 3, BC_NONE = 4 };
+enum { BC_ZEROGRADIENT = 0, BC_FIXEDVALUE = 1, BC_SLIP = 2, BC_QGDFLUX = 3, BC_NONE = 4, BC_QHDFLUX = 5 };
 enum { FVSC_REDUCED = 0, FVSC_LEASTSQUARES = 1, FVSC_GAUSSVOLPOINT = 2 };
 
 const double SMALL = 1e-15;   // OpenFOAM doubleScalarSMALL (L0)
@@ -954,6 +954,16 @@ struct StencilCache {
     ~StencilCache() { for (auto& kv : byName) delete kv.second; }
     int lookup(const Mesh& m, const std::string& word, Stencil** out) {
         if ((word == "leastSquares" || word == "leastSquaresOpt") && m.nGeomD == 3) return -4;
+        if (word == "GaussVolPoint") {  // wedge patches + prism cells are fatal [fvsc.C:65-82]
+            bool wedge = false;
+            for (const PatchInfo& p : m.patches) wedge = wedge || (p.type == PATCH_WEDGE && p.size > 0);
+            if (wedge)
+                for (int c = 0; c < m.nC; ++c) {
+                    int tri = 0, quad = 0, other = 0;
+                    for (int f : m.cells[c]) { const int n = m.fsize(f); if (n == 3) ++tri; else if (n == 4) ++quad; else ++other; }
+                    if (tri == 2 && quad == 3 && other == 0) return -4;  // prismMatcher (L0): 2 triangles + 3 quadrilaterals
+                }
+        }
         auto it = byName.find(word);
         if (it == byName.end()) {
             Stencil* s = nullptr;
@@ -1513,6 +1523,267 @@ struct Case {
 // ---------------------------------------------------------------------------
 // C interface
 // ---------------------------------------------------------------------------
+extern "C" int orc_qhd_pressure(void* mp, const double* phiu, const double* phiwo, const double* taubyrhof, const int32_t* patchKind,
+                                const double* pb, const double* gradb, double tolerance, double relTol, int32_t maxIter, int32_t pRefCell,
+                                double pRefValue, double* p, double* phi, double info[3]);
+
+// ---------------------------------------------------------------------------
+// QHDFoam case: the loop body of QHDFoam.C L83-139, explicit branch (implicitDiffusion false), with rhoConst +
+// constTransport thermo (rho, mu, alpha = mu/Pr uniform; the QHD closures keep muQGD = alphauQGD = 0 [T0byGr.C L62-72])
+// and laminar transport.  thermo.correct() is not called inside the loop [QHDFoam.C L83-139], so rho, mu, alpha and
+// tauQGDf are those of start-up.
+// L0 pieces restated here: fvc::grad (Gauss linear + gaussGrad::correctBoundaryConditions), fvc::laplacian (Gauss,
+// uncorrected snGrad), fvc::div (surfaceIntegrate), Euler ddt, setReference / needReference.
+// ---------------------------------------------------------------------------
+struct QhdCase {
+    MeshHandle* mh;
+    const Mesh& m;
+    orc_qhd_options opt;
+    std::vector<PatchBC> bc;
+    Stencil* stencil = nullptr;
+    std::string word;
+    VolField U, T, p;
+    SurfField tauQGDf, phi, phiu, phiwo;
+    dvec hQGD, hQGDb, hQGDf;
+    std::vector<char> liveFace;
+    double time = 0;
+    int64_t steps = 0;
+    double lastPIter = 0, lastPRes0 = 0, lastPRes = 0;
+
+    QhdCase(MeshHandle* h, const orc_qhd_options& o) : mh(h), m(h->m), opt(o), bc(h->m.patches.size()) {
+        for (size_t ip = 0; ip < bc.size(); ++ip)
+            if (m.patches[ip].type == PATCH_EMPTY || m.patches[ip].type == PATCH_HALO) bc[ip].bcU = bc[ip].bcT = bc[ip].bcP = BC_NONE;
+        liveFace.assign(m.nF, 1);
+        for (size_t ip = 0; ip < m.patches.size(); ++ip)
+            if (!m.patchHasFields((int)ip))
+                for (int f = m.patches[ip].start; f < m.patches[ip].start + m.patches[ip].size; ++f) liveFace[f] = 0;
+    }
+    template <class Fn> void forPatchFaces(int ip, Fn fn) const {
+        if (!m.patchHasFields(ip)) return;
+        const PatchInfo& pi = m.patches[ip];
+        for (int gf = pi.start; gf < pi.start + pi.size; ++gf) fn(gf, gf - m.nIF, m.own[gf]);
+    }
+    void correctU() {
+        for (size_t ip = 0; ip < bc.size(); ++ip) forPatchFaces((int)ip, [&](int gf, int b, int o) {
+            const PatchBC& B = bc[ip];
+            if (B.bcU == BC_FIXEDVALUE) { for (int k = 0; k < 3; ++k) U.bf[3 * (size_t)b + k] = B.vU[k]; }
+            else if (B.bcU == BC_SLIP) {
+                double n[3], Tm[9], tv[3];
+                for (int k = 0; k < 3; ++k) n[k] = m.Sf[3 * (size_t)gf + k] / m.magSf[gf];
+                for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Tm[3 * i + j] = (i == j ? 1.0 : 0.0) - 2.0 * (n[i] * n[j]);
+                TdotV(Tm, &U.in[3 * (size_t)o], tv);
+                for (int k = 0; k < 3; ++k) U.bf[3 * (size_t)b + k] = (U.in[3 * (size_t)o + k] + tv[k]) / 2.0;
+            } else { for (int k = 0; k < 3; ++k) U.bf[3 * (size_t)b + k] = U.in[3 * (size_t)o + k]; }
+        });
+    }
+    void correctT() {
+        for (size_t ip = 0; ip < bc.size(); ++ip) forPatchFaces((int)ip, [&](int, int b, int o) {
+            T.bf[b] = bc[ip].bcT == BC_FIXEDVALUE ? bc[ip].vT : T.in[o];
+        });
+    }
+    void correctP() {  // fixedValue | fixedGradient (qhdFlux keeps the gradient of its file: the registry lookup of
+                       // "phiwStar" finds nothing in QHDFoam [qhdFluxFvPatchScalarField.C L166-168]) | zeroGradient
+        for (size_t ip = 0; ip < bc.size(); ++ip) forPatchFaces((int)ip, [&](int gf, int b, int o) {
+            const PatchBC& B = bc[ip];
+            if (B.bcP == BC_FIXEDVALUE) p.bf[b] = B.vP;
+            else if (B.bcP == BC_QGDFLUX) { p.grad[b] = B.vP; p.bf[b] = p.in[o] + p.grad[b] / m.delta[gf]; }
+            else if (B.bcP == BC_QHDFLUX) {
+                // qhdFlux with its flux registered (as the QHD solvers that register "phiwStar" do, e.g.
+                // mulesQHDFoam/createFields.H): gradient = -(phiw/tauQGDf*rhof/|Sf|) [qhdFluxFvPatchScalarField.C L193-203]
+                p.grad[b] = -(phiwo.v[gf] / tauQGDf.v[gf] * opt.rho0 / m.magSf[gf]);
+                p.bf[b] = p.in[o] + p.grad[b] / m.delta[gf];
+            } else p.bf[b] = p.in[o];
+        });
+    }
+    // QGDCoeffs lengths [QGDCoeffs.C L195-199, L298-376] and the QHD closures [constTau.C L71-74, HbyUQHD.C L80-83,
+    // T0byGr.C L84-87, H2bynuQHD.C L78-82]: tauQGD per cell and patch face, tauQGDf = linearInterpolate(tauQGD)
+    void initTau() {
+        hQGDf.assign(m.nF, 0.0); hQGD.assign(m.nC, 0.0); hQGDb.assign(m.nBF(), 0.0);
+        for (int f = 0; f < m.nF; ++f) hQGDf[f] = (m.delta[f] != 0.0) ? 1.0 / std::fabs(m.delta[f]) : 0.0;
+        for (int f = 0; f < m.nIF; ++f) {
+            double a[3], b[3];
+            for (int k = 0; k < 3; ++k) { a[k] = m.C[3 * (size_t)m.own[f] + k] - m.Cf[3 * (size_t)f + k]; b[k] = m.C[3 * (size_t)m.nei[f] + k] - m.Cf[3 * (size_t)f + k]; }
+            hQGDf[f] = 2.0 * std::min(mag3(a), mag3(b));
+        }
+        for (size_t ip = 0; ip < m.patches.size(); ++ip)
+            if (!m.coupled((int)ip)) forPatchFaces((int)ip, [&](int gf, int, int) { hQGDf[gf] *= 2.0; });
+        for (int f = 0; f < m.nF; ++f) if (!liveFace[f]) hQGDf[f] = 0.0;
+        for (int ci = 0; ci < m.nC; ++ci) {
+            double hint = 0, surf = 0;
+            for (int fid : m.cells[ci]) {
+                if (fid >= m.nIF) {
+                    int pid = -1;
+                    for (size_t ip = 0; ip < m.patches.size(); ++ip)
+                        if (fid >= m.patches[ip].start && fid < m.patches[ip].start + m.patches[ip].size) pid = (int)ip;
+                    if (pid < 0 || m.patches[pid].type == PATCH_EMPTY || m.patches[pid].type == PATCH_WEDGE) continue;
+                }
+                hint += hQGDf[fid] * m.magSf[fid];
+                surf += m.magSf[fid];
+            }
+            hQGD[ci] = hint / surf;
+        }
+        for (size_t ip = 0; ip < m.patches.size(); ++ip) forPatchFaces((int)ip, [&](int gf, int b, int) { hQGDb[b] = hQGDf[gf] * 1.0; });
+        VolField tau(m, 1);
+        const double nu = opt.mu / opt.rho0;
+        auto closure = [&](double h) {
+            switch (opt.tauModel) {
+                case 0: return opt.Tau;
+                case 1: return opt.aQGD * h / opt.UQHD;
+                case 2: return opt.T0 / opt.Gr;
+                default: return opt.aQGD * h * h / nu;
+            }
+        };
+        for (int ci = 0; ci < m.nC; ++ci) tau.in[ci] = closure(hQGD[ci]);
+        for (int b = 0; b < m.nBF(); ++b) tau.bf[b] = closure(hQGDb[b]);
+        tauQGDf = linearInterpolate(m, tau);
+    }
+    int setFields(const double* U0, const double* T0, const double* p0) {
+        int rc = mh->cache.lookup(m, word, &stencil);
+        if (rc) return rc;
+        U = VolField(m, 3); T = VolField(m, 1); p = VolField(m, 1);
+        p.grad.assign(m.nBF(), 0.0);
+        p.snKind.assign(bc.size(), SN_GENERIC); T.snKind = p.snKind; U.snKind = p.snKind;
+        for (size_t ip = 0; ip < bc.size(); ++ip) {
+            p.snKind[ip] = bc[ip].bcP == BC_FIXEDVALUE ? SN_GENERIC : ((bc[ip].bcP == BC_QGDFLUX || bc[ip].bcP == BC_QHDFLUX) ? SN_GRADIENT : SN_ZERO);
+            T.snKind[ip] = bc[ip].bcT == BC_FIXEDVALUE ? SN_GENERIC : SN_ZERO;
+            U.snKind[ip] = bc[ip].bcU == BC_FIXEDVALUE ? SN_GENERIC : (bc[ip].bcU == BC_SLIP ? SN_SYMM : SN_ZERO);
+            if (m.patches[ip].type == PATCH_HALO) p.snKind[ip] = T.snKind[ip] = U.snKind[ip] = SN_ZERO;
+        }
+        std::copy(U0, U0 + 3 * (size_t)m.nC, U.in.begin());
+        std::copy(T0, T0 + m.nC, T.in.begin());
+        std::copy(p0, p0 + m.nC, p.in.begin());
+        phi = SurfField(m, 1); phiu = SurfField(m, 1); phiwo = SurfField(m, 1);
+        initTau();
+        correctU(); correctT(); correctP();
+        time = 0; steps = 0;
+        return 0;
+    }
+    // L0 fvc::grad(U), Gauss linear, with gaussGrad::correctBoundaryConditions on the patch values
+    VolField gaussGradV(const VolField& f) const {
+        SurfField ff = linearInterpolate(m, f);
+        VolField g(m, 9);
+        for (int fc = 0; fc < m.nF; ++fc) {
+            if (!liveFace[fc]) continue;
+            const double* S = &m.Sf[3 * (size_t)fc];
+            double* go = &g.in[9 * (size_t)m.own[fc]];
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) go[3 * i + j] += S[i] * ff.v[3 * (size_t)fc + j];
+            if (fc < m.nIF) {
+                double* gn = &g.in[9 * (size_t)m.nei[fc]];
+                for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) gn[3 * i + j] -= S[i] * ff.v[3 * (size_t)fc + j];
+            }
+        }
+        for (int c = 0; c < m.nC; ++c) for (int k = 0; k < 9; ++k) g.in[9 * (size_t)c + k] /= m.V[c];
+        dvec sn = allPatchSnGrad(m, f);
+        for (size_t ip = 0; ip < m.patches.size(); ++ip) {
+            if (!m.patchHasFields((int)ip)) continue;
+            for (int gf = m.patches[ip].start; gf < m.patches[ip].start + m.patches[ip].size; ++gf) {
+                const int b = gf - m.nIF;
+                double* gb = &g.bf[9 * (size_t)b];
+                for (int k = 0; k < 9; ++k) gb[k] = g.in[9 * (size_t)m.own[gf] + k];   // extrapolatedCalculated
+                if (m.coupled((int)ip)) continue;
+                double n[3], ng[3];
+                for (int k = 0; k < 3; ++k) n[k] = m.Sf[3 * (size_t)gf + k] / m.magSf[gf];
+                VdotT(n, gb, ng);
+                for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) gb[3 * i + j] += n[i] * (sn[3 * (size_t)b + j] - ng[j]);
+            }
+        }
+        return g;
+    }
+    void step() {
+        const int nC = m.nC, nF = m.nF, nB = m.nBF();
+        const double dt = opt.deltaT;
+        // updateFields.H L36-73
+        SurfField gradUf = stencil->gradV(U), gradTf = stencil->gradS(T);
+        SurfField Uf = linearInterpolate(m, U), Tf = linearInterpolate(m, T);
+        VolField BdFrc(m, 3);
+        for (int c = 0; c < nC; ++c) for (int k = 0; k < 3; ++k) BdFrc.in[3 * (size_t)c + k] = (opt.beta * T.in[c]) * opt.g[k];
+        for (int b = 0; b < nB; ++b) for (int k = 0; k < 3; ++k) BdFrc.bf[3 * (size_t)b + k] = (opt.beta * T.bf[b]) * opt.g[k];
+        SurfField BdFrcf = linearInterpolate(m, BdFrc);
+        const double rhof = opt.rho0, muf = opt.mu, alphaf = opt.mu / opt.Pr;   // uniform: interpolation returns the value
+        const double Hif = alphaf / rhof, nuf = muf / rhof;
+        // updateFluxes.H L33-38
+        SurfField UgU(m, 3), taubyrhof(m, 1), phiTauTReg(m, 1);
+        for (int f = 0; f < nF; ++f) {
+            if (!liveFace[f]) continue;
+            const double* S = &m.Sf[3 * (size_t)f];
+            phiu.v[f] = dot3(S, &Uf.v[3 * (size_t)f]);
+            VdotT(&Uf.v[3 * (size_t)f], &gradUf.v[9 * (size_t)f], &UgU.v[3 * (size_t)f]);
+            double wo[3];
+            for (int k = 0; k < 3; ++k) wo[k] = tauQGDf.v[f] * (UgU.v[3 * (size_t)f + k] - BdFrcf.v[3 * (size_t)f + k]);
+            phiwo.v[f] = dot3(S, wo);
+            taubyrhof.v[f] = tauQGDf.v[f] / rhof;
+            phiTauTReg.v[f] = tauQGDf.v[f] * phiu.v[f] * dot3(&Uf.v[3 * (size_t)f], &gradTf.v[3 * (size_t)f]);   // QHDTEqn.H L66
+        }
+        time += dt;
+        // QHDpEqn.H L35-47
+        correctP();
+        std::vector<int32_t> kinds(bc.size());
+        for (size_t ip = 0; ip < bc.size(); ++ip) kinds[ip] = bc[ip].bcP;
+        dvec pb = p.bf, gb = p.grad;
+        if (pb.empty()) { pb.assign(1, 0.0); gb.assign(1, 0.0); }
+        double info[3];
+        orc_qhd_pressure(mh, phiu.v.data(), phiwo.v.data(), taubyrhof.v.data(), kinds.data(), pb.data(), gb.data(), opt.pTol, opt.pRelTol,
+                         opt.pMaxIter, opt.pRefCell, p.in[std::max(opt.pRefCell, 0)], p.in.data(), phi.v.data(), info);
+        lastPIter = info[0]; lastPRes0 = info[1]; lastPRes = info[2];
+        correctP();   // fvMatrix::solve ends in correctBoundaryConditions()
+        // QHDUEqn.H L36-84 (explicit branch)
+        SurfField gradPf = stencil->gradS(p);
+        SurfField pf = linearInterpolate(m, p);
+        VolField gU = gaussGradV(U);
+        VolField gUT(m, 9);
+        for (int c = 0; c < nC; ++c) for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) gUT.in[9 * (size_t)c + 3 * i + j] = gU.in[9 * (size_t)c + 3 * j + i];
+        for (int b = 0; b < nB; ++b) for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) gUT.bf[9 * (size_t)b + 3 * i + j] = gU.bf[9 * (size_t)b + 3 * j + i];
+        SurfField gUTf = linearInterpolate(m, gUT);
+        SurfField snU = fvcSnGrad(m, U), snT = fvcSnGrad(m, T);
+        dvec FU(3 * (size_t)nF, 0.0), FT((size_t)nF, 0.0), Gp(3 * (size_t)nF, 0.0);
+        for (int f = 0; f < nF; ++f) {
+            if (!liveFace[f]) continue;
+            const double* S = &m.Sf[3 * (size_t)f];
+            double Wf[3], UW[9], uw[3], ext[3];
+            for (int k = 0; k < 3; ++k)
+                Wf[k] = tauQGDf.v[f] * ((UgU.v[3 * (size_t)f + k] + gradPf.v[3 * (size_t)f + k] / rhof) - BdFrcf.v[3 * (size_t)f + k]);   // L37
+            outer(&Uf.v[3 * (size_t)f], Wf, UW);
+            VdotT(S, UW, uw);                                                                          // L39
+            VdotT(S, &gUTf.v[9 * (size_t)f], ext);                                                     // Sf & lin(T(grad U)), L76
+            for (int k = 0; k < 3; ++k) {
+                const double phiUf = phi.v[f] * Uf.v[3 * (size_t)f + k] - uw[k];                       // L41-43
+                const double lap = nuf * snU.v[3 * (size_t)f + k] * m.magSf[f];                        // fvc::laplacian(muf/rhof, U), L74
+                FU[3 * (size_t)f + k] = (phiUf - lap) - nuf * ext[k];
+                Gp[3 * (size_t)f + k] = S[k] * pf.v[f];                                                // fvc::grad(p), Gauss linear
+            }
+            FT[f] = (phi.v[f] * Tf.v[f] - Hif * snT.v[f] * m.magSf[f]) - phiTauTReg.v[f];              // QHDTEqn.H L65-66, L85-88
+        }
+        dvec sumU(3 * (size_t)nC, 0.0), sumT((size_t)nC, 0.0), sumG(3 * (size_t)nC, 0.0);
+        for (int f = 0; f < nF; ++f) {   // surfaceIntegrate order
+            if (!liveFace[f]) continue;
+            const int o = m.own[f];
+            for (int k = 0; k < 3; ++k) { sumU[3 * (size_t)o + k] += FU[3 * (size_t)f + k]; sumG[3 * (size_t)o + k] += Gp[3 * (size_t)f + k]; }
+            sumT[o] += FT[f];
+            if (f < m.nIF) {
+                const int n = m.nei[f];
+                for (int k = 0; k < 3; ++k) { sumU[3 * (size_t)n + k] -= FU[3 * (size_t)f + k]; sumG[3 * (size_t)n + k] -= Gp[3 * (size_t)f + k]; }
+                sumT[n] -= FT[f];
+            }
+        }
+        for (int c = 0; c < nC; ++c) {
+            const double rV = 1.0 / m.V[c];
+            for (int k = 0; k < 3; ++k)
+                U.in[3 * (size_t)c + k] += dt * ((-(sumU[3 * (size_t)c + k] * rV) - (sumG[3 * (size_t)c + k] * rV) / opt.rho0) + BdFrc.in[3 * (size_t)c + k]);
+            T.in[c] += dt * (-(sumT[c] * rV));
+        }
+        correctU(); correctT();
+        // QHDFoam.C L123-130
+        bool anyFixed = false;
+        for (size_t ip = 0; ip < bc.size(); ++ip) anyFixed = anyFixed || (bc[ip].bcP == BC_FIXEDVALUE && m.patches[ip].size > 0 && m.patches[ip].type == PATCH_GENERIC);
+        if (!anyFixed && opt.pRefCell >= 0) {
+            const double shift = opt.pRefValue - p.in[opt.pRefCell];
+            for (double& x : p.in) x += shift;
+            for (int b = 0; b < nB; ++b) p.bf[b] += shift;
+        }
+        ++steps;
+    }
+};
+
 extern "C" {
 
 void* orc_mesh_create(int32_t nPoints, const double* points, int32_t nFaces, const int32_t* faceOffsets,
@@ -1790,7 +2061,7 @@ int orc_qhd_pressure(void* mp, const double* phiu, const double* phiwo, const do
     for (size_t ip = 0; ip < m.patches.size(); ++ip) {
         int k = patchKind[ip];
         if (m.patches[ip].type != PATCH_GENERIC) k = BC_NONE;
-        const int kk = k == BC_FIXEDVALUE ? 1 : (k == BC_QGDFLUX ? 2 : 0);
+        const int kk = k == BC_FIXEDVALUE ? 1 : ((k == BC_QGDFLUX || k == BC_QHDFLUX) ? 2 : 0);
         if (kk == 1 && m.patches[ip].size > 0) anyFixed = true;
         for (int f = m.patches[ip].start; f < m.patches[ip].start + m.patches[ip].size; ++f) kind[f - nIF] = kk;
     }
@@ -1864,6 +2135,42 @@ int orc_qhd_pressure(void* mp, const double* phiu, const double* phiwo, const do
 
 // STREAM triad a = b + s*c (24 bytes per element by the STREAM convention): bench.py times it on the same host cores as
 // the oracle ranks to bound what ANY fused CPU implementation of the step could reach there (bytes per cell-step / bandwidth)
+void* orc_qhd_case_create(void* mesh, const orc_qhd_options* opt) {
+    QhdCase* c = new QhdCase((MeshHandle*)mesh, *opt);
+    c->word = opt->stencil == FVSC_REDUCED ? "reduced" : (opt->stencil == FVSC_LEASTSQUARES ? "leastSquares" : "GaussVolPoint");
+    return c;
+}
+void orc_qhd_case_free(void* c) { delete (QhdCase*)c; }
+int orc_qhd_case_set_bc(void* cp, int32_t patch, int32_t bcU, const double* vU, int32_t bcT, double vT, int32_t bcP, double vP) {
+    QhdCase* c = (QhdCase*)cp;
+    if (patch < 0 || patch >= (int32_t)c->bc.size()) return -1;
+    PatchBC& b = c->bc[patch];
+    if (c->m.patches[patch].type == PATCH_EMPTY || c->m.patches[patch].type == PATCH_HALO) { bcU = bcT = bcP = BC_NONE; }
+    b.bcU = bcU; b.bcT = bcT; b.bcP = bcP; b.vT = vT; b.vP = vP;
+    if (vU) for (int k = 0; k < 3; ++k) b.vU[k] = vU[k];
+    return 0;
+}
+int orc_qhd_case_set_fields(void* cp, const double* U, const double* T, const double* p) { return ((QhdCase*)cp)->setFields(U, T, p); }
+int orc_qhd_case_step(void* cp, int32_t n) { for (int i = 0; i < n; ++i) ((QhdCase*)cp)->step(); return 0; }
+int orc_qhd_case_get_field(void* cp, const char* name, double* out, int64_t n) {
+    QhdCase* c = (QhdCase*)cp;
+    const std::string s(name);
+    const dvec* src = nullptr;
+    if (s == "U") src = &c->U.in; else if (s == "T") src = &c->T.in; else if (s == "p") src = &c->p.in;
+    else if (s == "U.boundary") src = &c->U.bf; else if (s == "T.boundary") src = &c->T.bf; else if (s == "p.boundary") src = &c->p.bf;
+    else if (s == "phi") src = &c->phi.v; else if (s == "phiu") src = &c->phiu.v; else if (s == "phiwo") src = &c->phiwo.v;
+    else if (s == "tauQGDf") src = &c->tauQGDf.v;
+    if (!src) return -5;
+    if ((int64_t)src->size() > n) return -1;
+    std::copy(src->begin(), src->end(), out);
+    return 0;
+}
+int orc_qhd_case_info(void* cp, double info[6]) {
+    QhdCase* c = (QhdCase*)cp;
+    info[0] = c->time; info[1] = c->opt.deltaT; info[2] = c->lastPIter; info[3] = c->lastPRes0; info[4] = c->lastPRes; info[5] = (double)c->steps;
+    return 0;
+}
+
 void orc_stream_triad(double* a, const double* b, const double* c, double s, int64_t n, int32_t reps) {
     for (int32_t r = 0; r < reps; ++r) {
         for (int64_t i = 0; i < n; ++i) a[i] = b[i] + s * c[i];

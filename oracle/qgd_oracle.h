@@ -72,6 +72,19 @@ int orc_qhd_pressure(void* mesh, const double* phiu, const double* phiwo, const 
                      const double* pb, const double* gradb, double tolerance, double relTol, int32_t maxIter, int32_t pRefCell,
                      double pRefValue, double* p, double* phi, double info[3]);
 
+/* QHDFoam case (explicit branch of QHDFoam.C L83-139); same layout and meaning as qgd_qhd_options of include/qgd_amd.h */
+typedef struct orc_qhd_options {
+    int32_t stencil, implicitDiffusion, tauModel, pRefCell, pMaxIter, precond;
+    double rho0, mu, Pr, beta, g[3], deltaT, Tau, aQGD, UQHD, T0, Gr, pTol, pRelTol, pRefValue;
+} orc_qhd_options;
+void* orc_qhd_case_create(void* mesh, const orc_qhd_options* opt);
+void orc_qhd_case_free(void* c);
+int orc_qhd_case_set_bc(void* c, int32_t patch, int32_t bcU, const double* valueU, int32_t bcT, double valueT, int32_t bcP, double valueP);
+int orc_qhd_case_set_fields(void* c, const double* U, const double* T, const double* p);
+int orc_qhd_case_step(void* c, int32_t nSteps);
+int orc_qhd_case_get_field(void* c, const char* name, double* out, int64_t n);
+int orc_qhd_case_info(void* c, double info[6]);
+
 void* orc_case_create(void* mesh, const orc_case_options* opt);
 void orc_case_free(void* c);
 int orc_case_set_bc(void* c, int32_t patch, int32_t bcU, const double* valueU,

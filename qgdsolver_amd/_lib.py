@@ -74,6 +74,7 @@ SIGNATURES = {
     "qgd_fvsc_grad_v": (C.c_int, [handle, C.c_int, c_double_p, c_double_p, c_double_p]),
     "qgd_fvsc_div_v": (C.c_int, [handle, C.c_int, c_double_p, c_double_p, c_double_p]),
     "qgd_fvsc_div_t": (C.c_int, [handle, C.c_int, c_double_p, c_double_p, c_double_p]),
+    "qgd_device_op_times": (C.c_int, [handle, c_double_p]),
     "qgd_interpolate": (C.c_int, [handle, C.c_int32, c_double_p, c_double_p, c_double_p]),
     "qgd_flux": (C.c_int, [handle, C.c_int32, c_double_p, c_double_p, c_double_p]),
     "qgd_device_get": (C.c_int, [handle, C.c_char_p, c_double_p, C.c_int64]),
@@ -103,6 +104,12 @@ SIGNATURES = {
     "qgd_case_step_phase": (C.c_int, [handle, C.c_int]),
     "qgd_case_set_halo_stream": (C.c_int, [handle, C.c_void_p]),
     "qgd_case_reduction_ptr": (C.c_int, [handle, C.POINTER(C.c_void_p)]),
+    "qgd_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "qgd_comm_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, handle_p]),
+    "qgd_comm_free": (C.c_int, [handle]),
+    "qgd_case_halo_exchange": (C.c_int, [handle, handle, c_int32_p, C.c_int]),
+    "qgd_case_allreduce_max": (C.c_int, [handle, handle]),
+    "qgd_case_step_sharded": (C.c_int, [handle, handle, c_int32_p, C.c_int, C.c_int]),
     "qgd_case_timing": (C.c_int, [handle, C.c_int]),
     "qgd_case_kernel_time": (C.c_int, [handle, C.c_int, c_double_p, c_int64_p]),
     "qgd_case_timing_reset": (C.c_int, [handle]),

@@ -7,12 +7,15 @@
 // There is NO CPU fallback: without a HIP device the device/case entries fail
 // with QGD_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // declarations only: RCCL is bound at run time (dlopen), the library does not link it
 
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <map>
 #include <stdexcept>
 #include <string>
@@ -89,12 +92,105 @@ struct DeviceArena {
     }
 };
 
+// Persistent per-device workspace of the host-pointer operator entries (qgd_fvsc_*, qgd_interpolate, qgd_qhd_*,
+// qgd_species_flux): grow-only device buffers by slot, and two pinned staging chunks through which pageable caller memory
+// is moved in a double-buffered pipeline (the host copy of chunk k+1 overlaps the DMA of chunk k).  Nothing is allocated
+// or freed per call once the sizes have been seen.
+struct Workspace {
+    struct Buf { void* p = nullptr; size_t cap = 0; };
+    std::vector<Buf> dev;
+    void* pin[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    static constexpr size_t CHUNK = (size_t)32 << 20;
+    int64_t bytes = 0;
+
+    template <class T>
+    T* get(size_t slot, size_t n) {
+        if (dev.size() <= slot) dev.resize(slot + 1);
+        const size_t need = std::max<size_t>(n, 1) * sizeof(T);
+        Buf& b = dev[slot];
+        if (b.cap < need) {
+            if (b.p) { (void)hipFree(b.p); bytes -= (int64_t)b.cap; b.p = nullptr; b.cap = 0; }
+            HIP_CHECK(hipMalloc(&b.p, need));
+            b.cap = need; bytes += (int64_t)need;
+        }
+        return (T*)b.p;
+    }
+    void ensurePinned() {
+        if (pin[0]) return;
+        for (int i = 0; i < 2; ++i) {
+            HIP_CHECK(hipHostMalloc(&pin[i], CHUNK, hipHostMallocDefault));
+            HIP_CHECK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+        }
+    }
+    static bool devAccessible(const void* p) {
+        hipPointerAttribute_t a;
+        if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+        return a.type == hipMemoryTypeHost || a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+    }
+    static void hostCopy(void* dst, const void* src, size_t n) {
+        const int64_t blocks = (int64_t)((n + ((size_t)1 << 20) - 1) >> 20);
+#pragma omp parallel for schedule(static) if (blocks > 4)
+        for (int64_t b = 0; b < blocks; ++b) {
+            const size_t off = (size_t)b << 20;
+            std::memcpy((char*)dst + off, (const char*)src + off, std::min<size_t>((size_t)1 << 20, n - off));
+        }
+    }
+    // host -> device, stream-ordered on s; returns when the source may be reused
+    void h2d(void* dst, const void* src, size_t n, hipStream_t s) {
+        if (!n) return;
+        if (devAccessible(src)) { HIP_CHECK(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, s)); HIP_CHECK(hipStreamSynchronize(s)); return; }
+        ensurePinned();
+        int k = 0;
+        for (size_t off = 0; off < n; off += CHUNK, k ^= 1) {
+            const size_t len = std::min(CHUNK, n - off);
+            HIP_CHECK(hipEventSynchronize(ev[k]));
+            hostCopy(pin[k], (const char*)src + off, len);
+            HIP_CHECK(hipMemcpyAsync((char*)dst + off, pin[k], len, hipMemcpyHostToDevice, s));
+            HIP_CHECK(hipEventRecord(ev[k], s));
+        }
+    }
+    // device -> host, after everything queued on s; returns when dst holds the data
+    void d2h(void* dst, const void* src, size_t n, hipStream_t s) {
+        if (!n) return;
+        if (devAccessible(dst)) { HIP_CHECK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, s)); HIP_CHECK(hipStreamSynchronize(s)); return; }
+        ensurePinned();
+        HIP_CHECK(hipEventSynchronize(ev[0]));
+        HIP_CHECK(hipEventSynchronize(ev[1]));
+        size_t prevOff = 0, prevLen = 0;
+        int k = 0;
+        for (size_t off = 0; off < n; off += CHUNK, k ^= 1) {
+            const size_t len = std::min(CHUNK, n - off);
+            HIP_CHECK(hipMemcpyAsync(pin[k], (const char*)src + off, len, hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipEventRecord(ev[k], s));
+            if (prevLen) { HIP_CHECK(hipEventSynchronize(ev[k ^ 1])); hostCopy((char*)dst + prevOff, pin[k ^ 1], prevLen); }
+            prevOff = off; prevLen = len;
+        }
+        HIP_CHECK(hipEventSynchronize(ev[k ^ 1]));
+        hostCopy((char*)dst + prevOff, pin[k ^ 1], prevLen);
+    }
+    void release() {
+        for (Buf& b : dev) if (b.p) (void)hipFree(b.p);
+        dev.clear();
+        for (int i = 0; i < 2; ++i) {
+            if (pin[i]) (void)hipHostFree(pin[i]);
+            if (ev[i]) (void)hipEventDestroy(ev[i]);
+            pin[i] = nullptr; ev[i] = nullptr;
+        }
+        bytes = 0;
+    }
+};
+
 struct qgd_device_s {
     int deviceId = 0;
+    Workspace ws;
+    double opMs[3] = {0, 0, 0};  // last host-pointer operator call: host->device, kernels, device->host (qgd_device_op_times)
+    hipEvent_t opEv[2] = {nullptr, nullptr};
     DeviceArena arena;
     MeshView view{};
     int32_t nGeomD = 3;
     bool hasTri = false;
+    bool wedgePrism = false;  // wedge patches + prism cells: GaussVolPoint is refused [fvsc_8C L65-82]
     std::vector<Patch> patches;
     std::vector<double> hf;  // host copy of hQGDf for the accessor
     // halo lists (device) and sizes, one entry per halo slot (neighbouring shard)
@@ -145,6 +241,10 @@ struct qgd_case_s {
     hipStream_t stream() const { return useUserStream ? userStream : dev->stream; }
     hipStream_t haloStream = nullptr;  // pack/unpack stream (defaults to stream())
     bool useHaloStream = false;
+    // native halo transport (qgd_case_halo_exchange): message buffers per halo slot, events ordering the two streams
+    std::vector<double*> sendBuf, recvBuf;
+    hipStream_t ownHaloStream = nullptr;
+    hipEvent_t evLayerDone = nullptr, evUnpacked = nullptr;
 };
 
 static hipEvent_t getEvent(qgd_case_s* c) {
@@ -198,6 +298,8 @@ static Launcher launcherOf(qgd_case_s* c) {
 // The OpenMP runtime hipcc links spin-waits between parallel regions by default;
 // on oversubscribed hosts that makes the (short) setup loops slower than serial.
 __attribute__((constructor)) static void qgdInitOpenMP() { setenv("KMP_BLOCKTIME", "0", 0); }
+
+static bool hasWedgeAndPrism(const HostMesh& m);
 
 // ---------------------------------------------------------------------------
 extern "C" {
@@ -422,6 +524,7 @@ int qgd_device_create(qgd_mesh_t mh, int deviceId, qgd_device_t* out) {
         d->deviceId = deviceId;
         d->nGeomD = m.nGeometricD;
         d->hasTri = s.hasTri;
+        d->wedgePrism = hasWedgeAndPrism(m);
         d->patches = m.patches;
         d->hf = s.hf;
         HIP_CHECK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
@@ -429,7 +532,10 @@ int qgd_device_create(qgd_mesh_t mh, int deviceId, qgd_device_t* out) {
         MeshView& v = d->view;
         v.nP = s.nP; v.nF = s.nF; v.nIF = s.nIF; v.nC = s.nC; v.nBF = s.nBF;
         v.ie1 = s.ie1; v.ie2 = s.ie2; v.ie3 = s.ie3;
-        { const char* e = std::getenv("QGD_XCD_RUN"); v.xcdRun = e ? std::atoi(e) : 0; }
+        { const char* e = std::getenv("QGD_XCD_RUN"); v.xcdRun = e ? std::atoi(e) : 16; }
+        { const char* e = std::getenv("QGD_FBLOCK"); v.fblock = e ? std::atoi(e) : 128; }
+        { const char* e = std::getenv("QGD_CBLOCK"); v.cblock = e ? std::atoi(e) : 256; }
+        { const char* e = std::getenv("QGD_PBLOCK"); v.pblock = e ? std::atoi(e) : 256; }
         // upload + free each table in turn so the host peak stays at one table
         auto up = [&](auto& vec) { auto* p = a.upload(vec); std::decay_t<decltype(vec)>().swap(vec); return p; };
         v.own = up(s.own); v.nei = up(s.nei);
@@ -487,11 +593,32 @@ int qgd_device_create(qgd_mesh_t mh, int deviceId, qgd_device_t* out) {
 int qgd_device_free(qgd_device_t d) {
     if (!d) return QGD_OK;
     (void)hipSetDevice(d->deviceId);
+    d->ws.release();
+    for (hipEvent_t e : d->opEv) if (e) (void)hipEventDestroy(e);
     d->arena.release();
     if (d->stream) (void)hipStreamDestroy(d->stream);
     delete d;
     return QGD_OK;
 }
+
+// prismMatcher + findIndices("wedge") of fvscOpName [fvsc_8C L65-82]: a wedge patch and at least one prism cell
+// (five faces: two triangles and three quadrilaterals, six vertices)
+static bool hasWedgeAndPrism(const HostMesh& m) {
+    bool wedge = false;
+    for (const Patch& p : m.patches) wedge = wedge || (p.type == QGD_PATCH_WEDGE && p.size > 0);
+    if (!wedge) return false;
+    std::vector<uint8_t> nTri((size_t)m.nCells, 0), nQuad((size_t)m.nCells, 0), nOther((size_t)m.nCells, 0);
+    auto count = [&](int32_t c, int n) { if (n == 3) nTri[c]++; else if (n == 4) nQuad[c]++; else nOther[c]++; };
+    for (int32_t f = 0; f < m.nFaces; ++f) {
+        count(m.owner[f], m.faceSize(f));
+        if (f < m.nInternalFaces) count(m.neighbour[f], m.faceSize(f));
+    }
+    for (int32_t c = 0; c < m.nCells; ++c)
+        if (nTri[c] == 2 && nQuad[c] == 3 && nOther[c] == 0) return true;
+    return false;
+}
+static const char* kWedgePrismMessage =
+    "GaussVolPoint scheme does not support solving axisymmetric cases with wedge BC and prism cells. Try to set leastSquares scheme.";
 
 // fvscOpName + fvscStencil::New [fvsc_8C L47-85, fvscStencil_8C L59-95]
 static int stencilWordToId(int nGeomD, const std::string& w, int* id) {
@@ -503,7 +630,12 @@ static int stencilWordToId(int nGeomD, const std::string& w, int* id) {
     else return fail(QGD_ERR_UNKNOWN_NAME, "Unknown Model type " + w + "; valid: GaussVolPoint leastSquares leastSquaresOpt reduced");
     return QGD_OK;
 }
-static int deviceStencil(int nGeomD, int id, int* st) {
+static int deviceStencilRaw(int nGeomD, int id, int* st);
+static int deviceStencil(const qgd_device_s* d, int id, int* st) {
+    if (d->wedgePrism && id == QGD_FVSC_GAUSSVOLPOINT) return fail(QGD_ERR_SCHEME, kWedgePrismMessage);
+    return deviceStencilRaw(d->nGeomD, id, st);
+}
+static int deviceStencilRaw(int nGeomD, int id, int* st) {
     if (id == QGD_FVSC_REDUCED) *st = ST_REDUCED;
     else if (id == QGD_FVSC_LEASTSQUARES) {
         if (nGeomD == 3) return fail(QGD_ERR_SCHEME, "Can't use leastSquares or leastSquaresOpt in 3D case.");
@@ -514,37 +646,56 @@ static int deviceStencil(int nGeomD, int id, int* st) {
 }
 int qgd_stencil_lookup(qgd_device_t d, const char* word, int* stencilId) {
     if (!d || !word || !stencilId) return fail(QGD_ERR_INVALID, "null argument");
+    if (d->wedgePrism && std::string(word) == "GaussVolPoint") return fail(QGD_ERR_SCHEME, kWedgePrismMessage);
     return stencilWordToId(d->nGeomD, word, stencilId);
 }
 
+enum WsSlot { WS_CELL = 0, WS_BND, WS_PT, WS_OUT, WS_A, WS_B, WS_C, WS_D, WS_E, WS_F, WS_G, WS_H };
+static double nowMs() {
+    timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return 1e3 * (double)t.tv_sec + 1e-6 * (double)t.tv_nsec;
+}
 static int fvscOp(qgd_device_t d, int stencilId, int op, int NC, const double* cell, const double* bnd, double* out) {
     QGD_TRY
     if (!d || !cell || !out || (!bnd && d->view.nBF > 0)) return fail(QGD_ERR_INVALID, "fvsc operator: null argument");
     int st = 0;
-    int rc = deviceStencil(d->nGeomD, stencilId, &st);
+    int rc = deviceStencil(d, stencilId, &st);
     if (rc) return rc;
     HIP_CHECK(hipSetDevice(d->deviceId));
     const MeshView& v = d->view;
     const int NO = (op == 0) ? 3 * NC : NC / 3;
-    double *dc = nullptr, *db = nullptr, *dp = nullptr, *dout = nullptr;
-    auto cleanup = [&]() { (void)hipFree(dc); (void)hipFree(db); (void)hipFree(dp); (void)hipFree(dout); };
-    try {
-        HIP_CHECK(hipMalloc((void**)&dc, sizeof(double) * (size_t)v.nC * NC));
-        HIP_CHECK(hipMalloc((void**)&db, sizeof(double) * std::max<size_t>(1, (size_t)v.nBF * NC)));
-        HIP_CHECK(hipMalloc((void**)&dp, sizeof(double) * (size_t)v.nP * NC));
-        HIP_CHECK(hipMalloc((void**)&dout, sizeof(double) * (size_t)v.nF * NO));
-        HIP_CHECK(hipMemcpyAsync(dc, cell, sizeof(double) * (size_t)v.nC * NC, hipMemcpyHostToDevice, d->stream));
-        if (v.nBF) HIP_CHECK(hipMemcpyAsync(db, bnd, sizeof(double) * (size_t)v.nBF * NC, hipMemcpyHostToDevice, d->stream));
-        HIP_CHECK(hipMemsetAsync(dp, 0, sizeof(double) * (size_t)v.nP * NC, d->stream));
-        (void)hipGetLastError();  // drop any stale sticky error so the check below is about our launches
-        launchFvscOp(d->stream, st, op, NC, v, dc, db, dp, dout);
-        HIP_CHECK(hipGetLastError());
-        HIP_CHECK(hipMemcpyAsync(out, dout, sizeof(double) * (size_t)v.nF * NO, hipMemcpyDeviceToHost, d->stream));
-        HIP_CHECK(hipStreamSynchronize(d->stream));
-    } catch (...) { cleanup(); throw; }
-    cleanup();
+    Workspace& ws = d->ws;
+    double* dc = ws.get<double>(WS_CELL, (size_t)v.nC * NC);
+    double* db = ws.get<double>(WS_BND, (size_t)v.nBF * NC);
+    double* dp = ws.get<double>(WS_PT, (size_t)v.nP * NC);
+    double* dout = ws.get<double>(WS_OUT, (size_t)v.nF * NO);
+    if (!d->opEv[0]) { HIP_CHECK(hipEventCreate(&d->opEv[0])); HIP_CHECK(hipEventCreate(&d->opEv[1])); }
+    const double t0 = nowMs();
+    ws.h2d(dc, cell, sizeof(double) * (size_t)v.nC * NC, d->stream);
+    if (v.nBF) ws.h2d(db, bnd, sizeof(double) * (size_t)v.nBF * NC, d->stream);
+    HIP_CHECK(hipMemsetAsync(dp, 0, sizeof(double) * (size_t)v.nP * NC, d->stream));
+    HIP_CHECK(hipStreamSynchronize(d->stream));
+    const double t1 = nowMs();
+    (void)hipGetLastError();  // drop any stale sticky error so the check below is about our launches
+    HIP_CHECK(hipEventRecord(d->opEv[0], d->stream));
+    launchFvscOp(d->stream, st, op, NC, v, dc, db, dp, dout);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipEventRecord(d->opEv[1], d->stream));
+    HIP_CHECK(hipEventSynchronize(d->opEv[1]));
+    const double t2 = nowMs();
+    ws.d2h(out, dout, sizeof(double) * (size_t)v.nF * NO, d->stream);
+    HIP_CHECK(hipStreamSynchronize(d->stream));
+    float kms = 0;
+    (void)hipEventElapsedTime(&kms, d->opEv[0], d->opEv[1]);
+    d->opMs[0] = t1 - t0; d->opMs[1] = kms; d->opMs[2] = nowMs() - t2;
     return QGD_OK;
     QGD_CATCH
+}
+int qgd_device_op_times(qgd_device_t d, double ms[3]) {
+    if (!d || !ms) return fail(QGD_ERR_INVALID, "null argument");
+    for (int k = 0; k < 3; ++k) ms[k] = d->opMs[k];
+    return QGD_OK;
 }
 int qgd_fvsc_grad_s(qgd_device_t d, int id, const double* cell, const double* bnd, double* out) { return fvscOp(d, id, 0, 1, cell, bnd, out); }
 int qgd_fvsc_grad_v(qgd_device_t d, int id, const double* cell, const double* bnd, double* out) { return fvscOp(d, id, 0, 3, cell, bnd, out); }
@@ -556,20 +707,17 @@ int qgd_interpolate(qgd_device_t d, int32_t ncomp, const double* cell, const dou
     if (!d || !cell || !out || ncomp < 1 || ncomp > 9 || (!bnd && d->view.nBF > 0)) return fail(QGD_ERR_INVALID, "qgd_interpolate: bad argument");
     HIP_CHECK(hipSetDevice(d->deviceId));
     const MeshView& v = d->view;
-    DeviceArena tmp;
-    try {
-        double* dc = tmp.alloc<double>((size_t)v.nC * ncomp, false);
-        double* db = tmp.alloc<double>(std::max<size_t>(1, (size_t)v.nBF * ncomp));
-        double* dout = tmp.alloc<double>((size_t)v.nF * ncomp, false);
-        HIP_CHECK(hipMemcpy(dc, cell, sizeof(double) * (size_t)v.nC * ncomp, hipMemcpyHostToDevice));
-        if (v.nBF) HIP_CHECK(hipMemcpy(db, bnd, sizeof(double) * (size_t)v.nBF * ncomp, hipMemcpyHostToDevice));
-        (void)hipGetLastError();
-        launchInterpolate(d->stream, ncomp, v, dc, db, dout);
-        HIP_CHECK(hipGetLastError());
-        HIP_CHECK(hipStreamSynchronize(d->stream));
-        HIP_CHECK(hipMemcpy(out, dout, sizeof(double) * (size_t)v.nF * ncomp, hipMemcpyDeviceToHost));
-    } catch (...) { tmp.release(); throw; }
-    tmp.release();
+    Workspace& ws = d->ws;
+    double* dc = ws.get<double>(WS_CELL, (size_t)v.nC * ncomp);
+    double* db = ws.get<double>(WS_BND, (size_t)v.nBF * ncomp);
+    double* dout = ws.get<double>(WS_OUT, (size_t)v.nF * ncomp);
+    ws.h2d(dc, cell, sizeof(double) * (size_t)v.nC * ncomp, d->stream);
+    if (v.nBF) ws.h2d(db, bnd, sizeof(double) * (size_t)v.nBF * ncomp, d->stream);
+    (void)hipGetLastError();
+    launchInterpolate(d->stream, ncomp, v, dc, db, dout);
+    HIP_CHECK(hipGetLastError());
+    ws.d2h(out, dout, sizeof(double) * (size_t)v.nF * ncomp, d->stream);
+    HIP_CHECK(hipStreamSynchronize(d->stream));
     return QGD_OK;
     QGD_CATCH
 }
@@ -612,7 +760,7 @@ int qgd_qhd_fluxes(qgd_device_t d, int stencilId, const qgd_qhd_inputs* in, qgd_
     if ((out->gradPf || out->Wf || out->phiUf) && !haveP) return fail(QGD_ERR_INVALID, "qgd_qhd_fluxes: gradPf/Wf/phiUf need p");
     if ((out->phiUf || out->phiTf) && !in->phi) return fail(QGD_ERR_INVALID, "qgd_qhd_fluxes: phiUf/phiTf need phi");
     int st = 0;
-    int rc = deviceStencil(d->nGeomD, stencilId, &st);
+    int rc = deviceStencil(d, stencilId, &st);
     if (rc) return rc;
     HIP_CHECK(hipSetDevice(d->deviceId));
     const size_t nC = (size_t)v.nC, nB = (size_t)v.nBF, nF = (size_t)v.nF, nP = (size_t)v.nP;
@@ -628,38 +776,41 @@ int qgd_qhd_fluxes(qgd_device_t d, int stencilId, const qgd_qhd_inputs* in, qgd_
         bnd5[5 * b + 3] = in->Tb[b];
         bnd5[5 * b + 4] = haveP ? in->pb[b] : 0.0;
     }
-    DeviceArena tmp;
-    try {
-        double* dCell = tmp.upload(cell5);
-        double* dBnd = tmp.upload(bnd5);
-        double* dPt = tmp.alloc<double>(5 * nP);
-        double* dRho = tmp.alloc<double>(nC, false);
-        double* dRhob = tmp.alloc<double>(std::max<size_t>(nB, 1));
-        double* dTau = tmp.alloc<double>(nF, false);
-        double* dPhi = in->phi ? tmp.alloc<double>(nF, false) : nullptr;
-        double* dOut = tmp.alloc<double>((size_t)QHD_COUNT * nF);
-        HIP_CHECK(hipMemcpy(dRho, in->rho, sizeof(double) * nC, hipMemcpyHostToDevice));
-        if (nB) HIP_CHECK(hipMemcpy(dRhob, in->rhob, sizeof(double) * nB, hipMemcpyHostToDevice));
-        HIP_CHECK(hipMemcpy(dTau, in->tauQGDf, sizeof(double) * nF, hipMemcpyHostToDevice));
-        if (dPhi) HIP_CHECK(hipMemcpy(dPhi, in->phi, sizeof(double) * nF, hipMemcpyHostToDevice));
-        (void)hipGetLastError();
-        launchQhdFluxes(d->stream, st, v, dCell, dBnd, dPt, dRho, dRhob, dTau, dPhi, in->beta, in->g[0], in->g[1], in->g[2], dOut);
-        HIP_CHECK(hipGetLastError());
-        HIP_CHECK(hipStreamSynchronize(d->stream));
-        std::vector<double> slot(nF);
-        auto fetch = [&](double* dst, int first, int nc) {
-            if (!dst) return;
-            for (int k = 0; k < nc; ++k) {
-                HIP_CHECK(hipMemcpy(slot.data(), dOut + (size_t)(first + k) * nF, sizeof(double) * nF, hipMemcpyDeviceToHost));
-                for (size_t f = 0; f < nF; ++f) dst[f * nc + k] = slot[f];
-            }
-        };
-        fetch(out->gradUf, QHD_GRADU, 9); fetch(out->gradTf, QHD_GRADT, 3); fetch(out->phiu, QHD_PHIU, 1);
-        fetch(out->phiwo, QHD_PHIWO, 1); fetch(out->taubyrhof, QHD_TAUBYRHO, 1); fetch(out->gradPf, QHD_GRADP, 3);
-        fetch(out->Wf, QHD_WF, 3); fetch(out->phiUf, QHD_PHIUF, 3); fetch(out->phiTf, QHD_PHITF, 1);
-        fetch(out->phiTauTReg, QHD_PHITAUT, 1);
-    } catch (...) { tmp.release(); throw; }
-    tmp.release();
+    Workspace& ws = d->ws;
+    hipStream_t st_ = d->stream;
+    auto up = [&](int slot, const double* src, size_t n) {
+        double* dst = ws.get<double>((size_t)slot, n);
+        if (src && n) ws.h2d(dst, src, sizeof(double) * n, st_);
+        return dst;
+    };
+    double* dCell = up(WS_CELL, cell5.data(), cell5.size());
+    double* dBnd = up(WS_BND, bnd5.data(), bnd5.size());
+    double* dPt = ws.get<double>(WS_PT, 5 * nP);
+    HIP_CHECK(hipMemsetAsync(dPt, 0, sizeof(double) * std::max<size_t>(5 * nP, 1), st_));
+    double* dRho = up(WS_A, in->rho, nC);
+    double* dRhob = up(WS_B, in->rhob, nB);
+    double* dTau = up(WS_C, in->tauQGDf, nF);
+    double* dPhi = in->phi ? up(WS_D, in->phi, nF) : nullptr;
+    double* dOut = ws.get<double>(WS_OUT, (size_t)QHD_COUNT * nF);
+    HIP_CHECK(hipMemsetAsync(dOut, 0, sizeof(double) * (size_t)QHD_COUNT * nF, st_));
+    (void)hipGetLastError();
+    launchQhdFluxes(st_, st, v, dCell, dBnd, dPt, dRho, dRhob, dTau, dPhi, in->beta, in->g[0], in->g[1], in->g[2], dOut);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(st_));
+    std::vector<double> slot(nF);
+    auto fetch = [&](double* dst, int first, int nc) {
+        if (!dst) return;
+        if (nc == 1) { ws.d2h(dst, dOut + (size_t)first * nF, sizeof(double) * nF, st_); return; }
+        for (int k = 0; k < nc; ++k) {
+            ws.d2h(slot.data(), dOut + (size_t)(first + k) * nF, sizeof(double) * nF, st_);
+#pragma omp parallel for schedule(static)
+            for (int64_t f = 0; f < (int64_t)nF; ++f) dst[(size_t)f * nc + k] = slot[(size_t)f];
+        }
+    };
+    fetch(out->gradUf, QHD_GRADU, 9); fetch(out->gradTf, QHD_GRADT, 3); fetch(out->phiu, QHD_PHIU, 1);
+    fetch(out->phiwo, QHD_PHIWO, 1); fetch(out->taubyrhof, QHD_TAUBYRHO, 1); fetch(out->gradPf, QHD_GRADP, 3);
+    fetch(out->Wf, QHD_WF, 3); fetch(out->phiUf, QHD_PHIUF, 3); fetch(out->phiTf, QHD_PHITF, 1);
+    fetch(out->phiTauTReg, QHD_PHITAUT, 1);
     return QGD_OK;
     QGD_CATCH
 }
@@ -673,36 +824,36 @@ int qgd_species_flux(qgd_device_t d, int stencilId, const double* Y, const doubl
     const MeshView& v = d->view;
     if (v.nBF > 0 && (!Yb || !Ub)) return fail(QGD_ERR_INVALID, "qgd_species_flux: patch values of Y and U are required");
     int st = 0;
-    int rc = deviceStencil(d->nGeomD, stencilId, &st);
+    int rc = deviceStencil(d, stencilId, &st);
     if (rc) return rc;
     HIP_CHECK(hipSetDevice(d->deviceId));
     const size_t nC = (size_t)v.nC, nB = (size_t)v.nBF, nF = (size_t)v.nF, nP = (size_t)v.nP;
-    DeviceArena tmp;
-    try {
-        auto upD = [&](const double* src, size_t n) {
-            double* dst = tmp.alloc<double>(std::max<size_t>(n, 1), false);
-            if (src && n) HIP_CHECK(hipMemcpy(dst, src, sizeof(double) * n, hipMemcpyHostToDevice));
-            return dst;
-        };
-        double *dY = upD(Y, nC), *dYb = upD(Yb, nB), *dU = upD(U, 3 * nC), *dUb = upD(Ub, 3 * nB);
-        double *dJm = upD(phiJm, nF), *dPhi = upD(phi, nF), *dTau = upD(tauQGDf, nF);
-        double* dPt = tmp.alloc<double>(std::max<size_t>(nP, 1));
-        double* dOut = tmp.alloc<double>(5 * nF);
-        (void)hipGetLastError();
-        launchSpeciesFlux(d->stream, st, v, dY, dYb, dPt, dU, dUb, dJm, dPhi, dTau, dOut);
-        HIP_CHECK(hipGetLastError());
-        HIP_CHECK(hipStreamSynchronize(d->stream));
-        HIP_CHECK(hipMemcpy(phiJmY, dOut, sizeof(double) * nF, hipMemcpyDeviceToHost));
-        HIP_CHECK(hipMemcpy(diffusiveFlux, dOut + nF, sizeof(double) * nF, hipMemcpyDeviceToHost));
-        if (gradYf) {
-            std::vector<double> slot(nF);
-            for (int k = 0; k < 3; ++k) {
-                HIP_CHECK(hipMemcpy(slot.data(), dOut + (size_t)(2 + k) * nF, sizeof(double) * nF, hipMemcpyDeviceToHost));
-                for (size_t f = 0; f < nF; ++f) gradYf[3 * f + k] = slot[f];
-            }
+    Workspace& ws = d->ws;
+    hipStream_t st_ = d->stream;
+    int nextSlot = WS_CELL;
+    auto upD = [&](const double* src, size_t n) {
+        double* dst = ws.get<double>((size_t)nextSlot++, n);
+        if (src && n) ws.h2d(dst, src, sizeof(double) * n, st_);
+        return dst;
+    };
+    double *dY = upD(Y, nC), *dYb = upD(Yb, nB), *dU = upD(U, 3 * nC), *dUb = upD(Ub, 3 * nB);
+    double *dJm = upD(phiJm, nF), *dPhi = upD(phi, nF), *dTau = upD(tauQGDf, nF);
+    double* dPt = upD(nullptr, nP);
+    HIP_CHECK(hipMemsetAsync(dPt, 0, sizeof(double) * std::max<size_t>(nP, 1), st_));
+    double* dOut = upD(nullptr, 5 * nF);
+    (void)hipGetLastError();
+    launchSpeciesFlux(st_, st, v, dY, dYb, dPt, dU, dUb, dJm, dPhi, dTau, dOut);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(st_));
+    ws.d2h(phiJmY, dOut, sizeof(double) * nF, st_);
+    ws.d2h(diffusiveFlux, dOut + nF, sizeof(double) * nF, st_);
+    if (gradYf) {
+        std::vector<double> slot(nF);
+        for (int k = 0; k < 3; ++k) {
+            ws.d2h(slot.data(), dOut + (size_t)(2 + k) * nF, sizeof(double) * nF, st_);
+            for (size_t f = 0; f < nF; ++f) gradYf[3 * f + k] = slot[f];
         }
-    } catch (...) { tmp.release(); throw; }
-    tmp.release();
+    }
     return QGD_OK;
     QGD_CATCH
 }
@@ -791,7 +942,7 @@ int qgd_case_create(qgd_device_t d, const qgd_case_options* opt, qgd_case_t* out
     if (!(opt->R > 0) || !(opt->Cv > 0) || !(opt->Pr > 0) || !(opt->PrQGD > 0) || !(opt->deltaT > 0))
         return fail(QGD_ERR_INVALID, "qgd_case_create: R, Cv, Pr, PrQGD, deltaT must be positive");
     int st = 0;
-    int rc = deviceStencil(d->nGeomD, opt->stencil, &st);
+    int rc = deviceStencil(d, opt->stencil, &st);
     if (rc) return rc;
     HIP_CHECK(hipSetDevice(d->deviceId));
     qgd_case_s* c = new qgd_case_s();
@@ -809,13 +960,13 @@ int qgd_case_create(qgd_device_t d, const qgd_case_options* opt, qgd_case_t* out
         const MeshView& v = d->view;
         DeviceArena& a = c->arena;
         CaseView& cv = c->view;
-        cv.A = a.alloc<RecA>(v.nC); cv.B = a.alloc<RecB>(v.nC); cv.K = a.alloc<Cons>(v.nC);
+        cv.A = a.alloc<RecA>(v.nC); cv.B = a.alloc<RecB>(v.nC); cv.rE = a.alloc<double>(v.nC);
         cv.P = a.alloc<RecA>(v.nP);
         cv.bA = a.alloc<RecA>(v.nBF); cv.bB = a.alloc<RecB>(v.nBF);
         cv.bG = a.alloc<double>(v.nBF); cv.bPhiw = a.alloc<double>(v.nBF); cv.bPmid = a.alloc<double>(v.nBF);
         cv.bRhoLag = a.alloc<double>(v.nBF);
         cv.nBlkFace = faceBlocks(v) + bfaceBlocks(v);
-        cv.nBlkCell = cellBlocks(v) + (d->nSendAll + 255) / 256;
+        cv.nBlkCell = cellBlocks(v) + (d->nSendAll + 63) / 64;
         cv.blkFace = a.alloc<double>(2 * (size_t)std::max(1, cv.nBlkFace));
         cv.blkCell = a.alloc<double>(2 * (size_t)std::max(1, cv.nBlkCell));
         cv.flux = a.alloc<double>(5 * (size_t)v.nF);
@@ -843,6 +994,9 @@ int qgd_case_free(qgd_case_t c) {
     (void)hipSetDevice(c->dev->deviceId);
     harvestTiming(c);
     for (hipEvent_t e : c->freeEvents) (void)hipEventDestroy(e);
+    if (c->ownHaloStream) { (void)hipStreamSynchronize(c->ownHaloStream); (void)hipStreamDestroy(c->ownHaloStream); }
+    if (c->evLayerDone) (void)hipEventDestroy(c->evLayerDone);
+    if (c->evUnpacked) (void)hipEventDestroy(c->evUnpacked);
     c->arena.release();
     delete c;
     return QGD_OK;
@@ -1116,6 +1270,198 @@ int qgd_case_halo_unpack(qgd_case_t c, int slot, const double* recvBufDevice) {
     QGD_CATCH
 }
 
+// ---- native halo transport: RCCL send/recv inside the library -----------------------------------------------------------
+// Replaces, for a C++/MPI host, what the reference does per gradient call with PstreamBuffers
+// [extendedFaceStencilScalarGrad_8C L145-233] and with processor-patch evaluation [GaussVolPointStencil_8C L73]:
+// ONE grouped send/recv pair per neighbouring rank per step, device buffers, stream-ordered, no host synchronisation.
+extern "C++" {
+namespace {
+struct Rccl {
+    void* lib = nullptr;
+    decltype(&ncclGetUniqueId) getUniqueId = nullptr;
+    decltype(&ncclCommInitRank) commInitRank = nullptr;
+    decltype(&ncclCommDestroy) commDestroy = nullptr;
+    decltype(&ncclSend) send = nullptr;
+    decltype(&ncclRecv) recv = nullptr;
+    decltype(&ncclAllReduce) allReduce = nullptr;
+    decltype(&ncclGroupStart) groupStart = nullptr;
+    decltype(&ncclGroupEnd) groupEnd = nullptr;
+    decltype(&ncclGetErrorString) errorString = nullptr;
+    std::string why;
+};
+Rccl& rcclRef() {
+    static Rccl r;
+    static bool tried = false;
+    if (tried) return r;
+    tried = true;
+    // an RCCL already in the process (e.g. the one torch.distributed brought) is reused; otherwise the ROCm one is loaded
+    const char* env = std::getenv("QGD_RCCL_LIB");
+    const char* names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char* n : names) {
+        if (!n) continue;
+        r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+        if (r.lib) break;
+    }
+    for (const char* n : names) {
+        if (r.lib) break;
+        if (!n) continue;
+        r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    }
+    if (!r.lib) { r.why = "RCCL not found (librccl.so; set QGD_RCCL_LIB)"; return r; }
+    auto sym = [&](const char* name) { void* p = dlsym(r.lib, name); if (!p && r.why.empty()) r.why = std::string("RCCL symbol missing: ") + name; return p; };
+    r.getUniqueId = (decltype(r.getUniqueId))sym("ncclGetUniqueId");
+    r.commInitRank = (decltype(r.commInitRank))sym("ncclCommInitRank");
+    r.commDestroy = (decltype(r.commDestroy))sym("ncclCommDestroy");
+    r.send = (decltype(r.send))sym("ncclSend");
+    r.recv = (decltype(r.recv))sym("ncclRecv");
+    r.allReduce = (decltype(r.allReduce))sym("ncclAllReduce");
+    r.groupStart = (decltype(r.groupStart))sym("ncclGroupStart");
+    r.groupEnd = (decltype(r.groupEnd))sym("ncclGroupEnd");
+    r.errorString = (decltype(r.errorString))sym("ncclGetErrorString");
+    return r;
+}
+}  // namespace
+}  // extern "C++"
+struct qgd_comm_s {
+    ncclComm_t comm = nullptr;
+    int rank = 0, nRanks = 1, deviceId = 0;
+};
+#define RCCL_CHECK(expr)                                                                                          \
+    do {                                                                                                          \
+        ncclResult_t _r = (expr);                                                                                 \
+        if (_r != ncclSuccess)                                                                                    \
+            throw HipError(std::string(#expr) + ": " + (rcclRef().errorString ? rcclRef().errorString(_r) : "RCCL error")); \
+    } while (0)
+
+int qgd_comm_unique_id(void* id128) {
+    QGD_TRY
+    if (!id128) return fail(QGD_ERR_INVALID, "qgd_comm_unique_id: null argument");
+    if (!rcclRef().why.empty()) return fail(QGD_ERR_NOT_IMPLEMENTED, rcclRef().why);
+    ncclUniqueId id;
+    RCCL_CHECK(rcclRef().getUniqueId(&id));
+    static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+    std::memcpy(id128, &id, sizeof(id));
+    return QGD_OK;
+    QGD_CATCH
+}
+int qgd_comm_create(int deviceId, int rank, int nRanks, const void* id128, qgd_comm_t* out) {
+    QGD_TRY
+    if (!out || !id128 || nRanks < 1 || rank < 0 || rank >= nRanks) return fail(QGD_ERR_INVALID, "qgd_comm_create: bad argument");
+    if (!rcclRef().why.empty()) return fail(QGD_ERR_NOT_IMPLEMENTED, rcclRef().why);
+    HIP_CHECK(hipSetDevice(deviceId));
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof(id));
+    qgd_comm_s* c = new qgd_comm_s();
+    c->rank = rank; c->nRanks = nRanks; c->deviceId = deviceId;
+    try { RCCL_CHECK(rcclRef().commInitRank(&c->comm, nRanks, id, rank)); }
+    catch (...) { delete c; throw; }
+    *out = c;
+    return QGD_OK;
+    QGD_CATCH
+}
+int qgd_comm_free(qgd_comm_t c) {
+    if (!c) return QGD_OK;
+    if (c->comm && rcclRef().commDestroy) (void)rcclRef().commDestroy(c->comm);
+    delete c;
+    return QGD_OK;
+}
+
+static void ensureHaloBuffers(qgd_case_s* c) {
+    qgd_device_s* d = c->dev;
+    if (c->sendBuf.size() == d->halo.size()) return;
+    c->sendBuf.assign(d->halo.size(), nullptr);
+    c->recvBuf.assign(d->halo.size(), nullptr);
+    for (size_t s = 0; s < d->halo.size(); ++s) {
+        const qgd_device_s::HaloSlot& h = d->halo[s];
+        c->sendBuf[s] = c->arena.alloc<double>(10 * (size_t)h.nSend + 12 * (size_t)h.nSendBF);
+        c->recvBuf[s] = c->arena.alloc<double>(10 * (size_t)h.nGhost + 12 * (size_t)h.nGhostBF);
+    }
+}
+// pack -> grouped send/recv -> unpack on `stream`
+static void haloExchangeOn(qgd_case_s* c, qgd_comm_s* comm, const int32_t* peers, int nSlots, hipStream_t stream) {
+    qgd_device_s* d = c->dev;
+    ensureHaloBuffers(c);
+    Launcher L = launcherOf(c);
+    L.pre = nullptr; L.post = nullptr; L.stream = stream;
+    const int n = std::min<int>(nSlots, (int)d->halo.size());
+    (void)hipGetLastError();
+    for (int s = 0; s < n; ++s) {
+        const qgd_device_s::HaloSlot& h = d->halo[s];
+        if (peers[s] < 0 || !h.nSend) continue;
+        launchHaloPack(L, c->view, h.send, h.nSend, h.sendBF, h.nSendBF, c->sendBuf[s], true);
+    }
+    HIP_CHECK(hipGetLastError());
+    RCCL_CHECK(rcclRef().groupStart());
+    for (int s = 0; s < n; ++s) {
+        const qgd_device_s::HaloSlot& h = d->halo[s];
+        if (peers[s] < 0) continue;
+        const size_t ns = 10 * (size_t)h.nSend + 12 * (size_t)h.nSendBF, nr = 10 * (size_t)h.nGhost + 12 * (size_t)h.nGhostBF;
+        if (ns) RCCL_CHECK(rcclRef().send(c->sendBuf[s], ns, ncclFloat64, peers[s], comm->comm, stream));
+        if (nr) RCCL_CHECK(rcclRef().recv(c->recvBuf[s], nr, ncclFloat64, peers[s], comm->comm, stream));
+    }
+    RCCL_CHECK(rcclRef().groupEnd());
+    for (int s = 0; s < n; ++s) {
+        const qgd_device_s::HaloSlot& h = d->halo[s];
+        if (peers[s] < 0 || !h.nGhost) continue;
+        launchHaloPack(L, c->view, h.ghost, h.nGhost, h.ghostBF, h.nGhostBF, c->recvBuf[s], false);
+    }
+    HIP_CHECK(hipGetLastError());
+}
+int qgd_case_halo_exchange(qgd_case_t c, qgd_comm_t comm, const int32_t* peers, int nSlots) {
+    QGD_TRY
+    if (!c) return fail(QGD_ERR_INVALID, "null case");
+    if (c->dev->halo.empty() || nSlots <= 0) return QGD_OK;  // unsharded: nothing to exchange
+    if (!comm || !peers) return fail(QGD_ERR_INVALID, "qgd_case_halo_exchange: null argument");
+    HIP_CHECK(hipSetDevice(c->dev->deviceId));
+    haloExchangeOn(c, comm, peers, nSlots, c->stream());
+    return QGD_OK;  // stream-ordered on the case's stream
+    QGD_CATCH
+}
+int qgd_case_allreduce_max(qgd_case_t c, qgd_comm_t comm) {
+    QGD_TRY
+    if (!c) return fail(QGD_ERR_INVALID, "null case");
+    if (!comm || comm->nRanks == 1) return QGD_OK;
+    HIP_CHECK(hipSetDevice(c->dev->deviceId));
+    RCCL_CHECK(rcclRef().allReduce(c->view.red, c->view.red, 2, ncclFloat64, ncclMax, comm->comm, c->stream()));
+    return QGD_OK;
+    QGD_CATCH
+}
+int qgd_case_step_sharded(qgd_case_t c, qgd_comm_t comm, const int32_t* peers, int nSlots, int overlapped) {
+    QGD_TRY
+    if (!c) return fail(QGD_ERR_INVALID, "null case");
+    if (!c->fieldsSet) return fail(QGD_ERR_INVALID, "qgd_case_step_sharded: call qgd_case_set_fields first");
+    const bool sharded = !c->dev->halo.empty() && nSlots > 0;
+    if (sharded && (!comm || !peers)) return fail(QGD_ERR_INVALID, "qgd_case_step_sharded: null argument");
+    HIP_CHECK(hipSetDevice(c->dev->deviceId));
+    const bool adjust = c->opt.adjustTimeStep != 0;
+    stepAssemble(c);
+    if (adjust && comm && comm->nRanks > 1)
+        RCCL_CHECK(rcclRef().allReduce(c->view.red, c->view.red, 2, ncclFloat64, ncclMax, comm->comm, c->stream()));
+    if (!sharded) { stepAdvance(c, 0); HIP_CHECK(hipGetLastError()); return QGD_OK; }
+    if (!overlapped) {
+        stepAdvance(c, 0);
+        haloExchangeOn(c, comm, peers, nSlots, c->stream());
+    } else {
+        // boundary layer first; pack / send / recv / unpack on the library's halo stream while the compute stream
+        // updates the remaining cells; the next assembly waits for the unpack
+        if (!c->ownHaloStream) {
+            HIP_CHECK(hipStreamCreateWithFlags(&c->ownHaloStream, hipStreamNonBlocking));
+            HIP_CHECK(hipEventCreateWithFlags(&c->evLayerDone, hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&c->evUnpacked, hipEventDisableTiming));
+        }
+        stepAdvance(c, 1);
+        HIP_CHECK(hipEventRecord(c->evLayerDone, c->stream()));
+        HIP_CHECK(hipStreamWaitEvent(c->ownHaloStream, c->evLayerDone, 0));
+        haloExchangeOn(c, comm, peers, nSlots, c->ownHaloStream);
+        HIP_CHECK(hipEventRecord(c->evUnpacked, c->ownHaloStream));
+        stepAdvance(c, 2);
+        HIP_CHECK(hipStreamWaitEvent(c->stream(), c->evUnpacked, 0));
+    }
+    HIP_CHECK(hipGetLastError());
+    return QGD_OK;  // stream-ordered: qgd_case_stream_sync waits
+    QGD_CATCH
+}
+
 // ---- accessors --------------------------------------------------------------------
 int qgd_case_get_field(qgd_case_t c, const char* name, double* out, int64_t outDoubles) {
     QGD_TRY
@@ -1169,7 +1515,7 @@ int qgd_case_get_field(qgd_case_t c, const char* name, double* out, int64_t outD
     HIP_CHECK(hipMalloc((void**)&tmp, sizeof(double) * (size_t)(n * nc)));
     try {
         (void)hipGetLastError();
-        launchExtractField(c->stream(), bnd ? c->view.bA : c->view.A, bnd ? c->view.bB : c->view.B, bnd ? nullptr : c->view.K,
+        launchExtractField(c->stream(), bnd ? c->view.bA : c->view.A, bnd ? c->view.bB : c->view.B, bnd ? nullptr : c->view.rE,
                            bnd ? m.hQGDb : m.hQGD, bnd ? c->view.aQb : c->view.aQ, n, g, cf->second, tmp);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipStreamSynchronize(c->stream()));

@@ -9,7 +9,6 @@ namespace qgd {
 // ---- gathered records (AoS, 16-B aligned so they move as dwordx4) ----------
 struct alignas(16) RecA { double rho, ux, uy, uz, p, e; };   // 48 B: fields whose face gradients are needed
 struct alignas(16) RecB { double H, c, muQGD, aOc; };        // 32 B: derived per-cell quantities the face kernel interpolates
-struct alignas(16) Cons { double rux, ruy, ruz, rE; };       // 32 B: conserved momentum + total energy
 
 enum StencilKind : int { ST_REDUCED = 0, ST_LSQ = 1, ST_GVP3 = 2, ST_GVP2 = 3 };
 
@@ -17,6 +16,8 @@ enum StencilKind : int { ST_REDUCED = 0, ST_LSQ = 1, ST_GVP3 = 2, ST_GVP2 = 3 };
 struct MeshView {
     int32_t nP, nF, nIF, nC, nBF;
     int32_t ie1, ie2, ie3;
+    int32_t cblock, pblock;  // tiles of the cell-update and vertex kernels (64, 128 or 256)
+    int32_t fblock;          // face tile of the 3-D GaussVolPoint kernel: 64, 128 or 256 faces per workgroup
     int32_t xcdRun;          // tiles per XCD run of the workgroup->tile map (0: one contiguous eighth per XCD)
     const int32_t* own;      // nF
     const int32_t* nei;      // nIF
@@ -57,7 +58,8 @@ struct GasModel {
 
 // Mutable case state on the device
 struct CaseView {
-    RecA* A; RecB* B; Cons* K;      // nC
+    RecA* A; RecB* B;               // nC
+    double* rE;                     // nC total energy rho*E (rhoU is rho*U of the record: the explicit re-solve keeps them equal)
     RecA* P;                        // nP vertex records
     RecA* bA; RecB* bB;             // nBF boundary records
     double* bG;                     // nBF p gradient (qgdFlux)
@@ -116,7 +118,7 @@ void launchHaloPack(const Launcher& L, const CaseView& c, const int32_t* cells, 
 // ---- accessor: one named cell / patch field out of the records (K == nullptr on patches) ----------------------------
 enum ExtractField : int { XF_RHO = 0, XF_U, XF_P, XF_E, XF_T, XF_RHOU, XF_RHOE, XF_C, XF_PSI, XF_MU, XF_ALPHAU, XF_TAUQGD, XF_MUQGD,
                           XF_ALPHAUQGD, XF_HQGD, XF_H, XF_GAMMA };
-void launchExtractField(hipStream_t s, const RecA* A, const RecB* B, const Cons* K, const double* hq, const double* aQ, int64_t n,
+void launchExtractField(hipStream_t s, const RecA* A, const RecB* B, const double* rE, const double* hq, const double* aQ, int64_t n,
                         const GasModel& g, int field, double* out);
 
 // ---- fvsc operators on plain fields ----------------------------------------------

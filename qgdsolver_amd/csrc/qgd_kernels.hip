@@ -25,39 +25,15 @@
 #include "qgd_device.hpp"
 
 #include "../../include/qgd_amd.h"
+#include "qgd_stencil_dev.hpp"
 
 namespace qgd {
 
-#define QGD_BLOCK 256
-
-__device__ __forceinline__ double lerpf(double w, double a, double b) { return w * (a - b) + b; }
-
-// Streamed-once data (per-face geometry, gather lists) is loaded non-temporally so it does not push the
-// re-used cell/vertex records out of the 4 MiB L2 of the XCD.
-#ifndef QGD_NT
-#define QGD_NT 1
-#endif
-template <class T>
-__device__ __forceinline__ T ldStream(const T* p) {
-#if QGD_NT
-    return __builtin_nontemporal_load(p);
-#else
-    return *p;
-#endif
-}
-template <class T>
-__device__ __forceinline__ void stStream(T* p, T v) {
-#if QGD_NT
-    __builtin_nontemporal_store(v, p);
-#else
-    *p = v;
-#endif
-}
-
 // Workgroup reduction (wave shuffles + 4-entry LDS): slot[0] = max(a), slot[1] = min(b).
 // With `accumulate` the slot keeps the running extremum since it was last reset.
+template <int BLOCK = QGD_BLOCK>
 __device__ __forceinline__ void blockMaxMin(double a, double b, double* __restrict__ slot, const bool accumulate) {
-    __shared__ double sa[QGD_BLOCK / 64], sb[QGD_BLOCK / 64];
+    __shared__ double sa[BLOCK / 64], sb[BLOCK / 64];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         a = fmax(a, __shfl_down(a, off, 64));
@@ -68,227 +44,14 @@ __device__ __forceinline__ void blockMaxMin(double a, double b, double* __restri
     __syncthreads();
     if (threadIdx.x == 0) {
 #pragma unroll
-        for (int i = 1; i < QGD_BLOCK / 64; ++i) { a = fmax(a, sa[i]); b = fmin(b, sb[i]); }
+        for (int i = 1; i < BLOCK / 64; ++i) { a = fmax(a, sa[i]); b = fmin(b, sb[i]); }
         if (accumulate) { a = fmax(a, slot[0]); b = fmin(b, slot[1]); }
         slot[0] = a;
         slot[1] = b;
     }
 }
-__device__ __forceinline__ int faceBlocksDev(const MeshView& m) { return (m.nIF + QGD_BLOCK - 1) / QGD_BLOCK; }
-
-template <int NC>
-struct FaceVals {
-    double o[NC];   // owner cell values
-    double n[NC];   // neighbour cell (internal face) or patch value (boundary face)
-    double sn[NC];  // boundary face: patch snGrad
-};
-
-// ---------------------------------------------------------------------------
-// GaussVolPoint 3-D coefficients of one face from its geometry [GaussVolPointBase3D_8C L161-476].
-// O/N: owner / neighbour cell centre (boundary: mirror point), x1..x4: face vertices in face order.
-// quad: a[3d+0]=a0, a[3d+1]=a1, a[3d+2]=a5 (a2=-a0, a3=-a1, a4=-a5) [L353-389];  rV = 1/V [L346-350]
-// tri : t[4d+0..2]=a0..a2 (vertices), t[4d+3]=a3 (neighbour), owner = -a3 [L193-229]; rV = 1/V [L186-190]
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ void gvpQuadCoef(const double4 O, const double4 N, const double4 x1, const double4 x2,
-                                            const double4 x3, const double4 x4, double a[9], double& rV) {
-    const double sixth = (1.0 / 6.0);
-    const double o[3] = {O.x, O.y, O.z}, n[3] = {N.x, N.y, N.z};
-    const double p1[3] = {x1.x, x1.y, x1.z}, p2[3] = {x2.x, x2.y, x2.z}, p3[3] = {x3.x, x3.y, x3.z}, p4[3] = {x4.x, x4.y, x4.z};
-    double d31[3], d42[3], on[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { d31[k] = p3[k] - p1[k]; d42[k] = p4[k] - p2[k]; on[k] = o[k] - n[k]; }
-    const double cr[3] = {d42[1] * on[2] - d42[2] * on[1], d42[2] * on[0] - d42[0] * on[2], d42[0] * on[1] - d42[1] * on[0]};
-    double vol = d31[0] * cr[0] + d31[1] * cr[1] + d31[2] * cr[2];
-    vol *= sixth;
-    rV = 1.0 / vol;
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        const int u = (d + 1) % 3, v = (d + 2) % 3;
-        a[3 * d + 0] = sixth * ((n[u] - o[u]) * (p2[v] - p4[v]) - (n[v] - o[v]) * (p2[u] - p4[u]));
-        a[3 * d + 1] = sixth * ((n[u] - o[u]) * (p3[v] - p1[v]) - (n[v] - o[v]) * (p3[u] - p1[u]));
-        a[3 * d + 2] = sixth * ((p1[u] - p3[u]) * (p2[v] - p4[v]) - (p1[v] - p3[v]) * (p2[u] - p4[u]));
-    }
-}
-__device__ __forceinline__ void gvpTriCoef(const double4 O, const double4 N, const double4 x1, const double4 x2,
-                                           const double4 x3, double t[12], double& rV) {
-    const double sixth = (1.0 / 6.0);
-    const double o[3] = {O.x, O.y, O.z}, n[3] = {N.x, N.y, N.z};
-    const double p1[3] = {x1.x, x1.y, x1.z}, p2[3] = {x2.x, x2.y, x2.z}, p3[3] = {x3.x, x3.y, x3.z};
-    double e21[3], e31[3], on[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { e21[k] = p2[k] - p1[k]; e31[k] = p3[k] - p1[k]; on[k] = o[k] - n[k]; }
-    const double cr[3] = {e21[1] * e31[2] - e21[2] * e31[1], e21[2] * e31[0] - e21[0] * e31[2], e21[0] * e31[1] - e21[1] * e31[0]};
-    double vol = cr[0] * on[0] + cr[1] * on[1] + cr[2] * on[2];
-    vol *= sixth;
-    rV = 1.0 / vol;
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        const int u = (d + 1) % 3, v = (d + 2) % 3;
-        t[4 * d + 0] = sixth * ((o[v] - n[v]) * (p2[u] - p3[u]) + (n[u] - o[u]) * (p2[v] - p3[v]));
-        t[4 * d + 1] = sixth * ((n[u] - o[u]) * (p3[v] - p1[v]) + (o[v] - n[v]) * (p3[u] - p1[u]));
-        t[4 * d + 2] = sixth * ((n[u] - o[u]) * (p1[v] - p2[v]) + (o[v] - n[v]) * (p1[u] - p2[u]));
-        t[4 * d + 3] = sixth * (p1[v] * (p2[u] - p3[u]) + p2[v] * (p3[u] - p1[u]) + p3[v] * (p1[u] - p2[u]));
-    }
-}
-
-// ---------------------------------------------------------------------------
-// fvsc face gradient of an NC-component field: g[i*NC + k] = d_i phi_k.
-// cellF / ptF are AoS with stride NC (cell and vertex values).
-// UOFF >= 0 marks three consecutive components as a vector so that the
-// interior-triangle pattern of the reference's vector gradient
-// [GaussVolPointBase3D_8C L844-854] is reproduced.
-// ---------------------------------------------------------------------------
-template <int ST, int NC, int UOFF>
-__device__ __forceinline__ void faceGradient(const MeshView& m, const int f, const FaceVals<NC>& v,
-                                             const double* __restrict__ cellF, const double* __restrict__ ptF,
-                                             double* __restrict__ g) {
-    const bool internal = f < m.nIF;
-    const int b = f - m.nIF;
-    const int kind = m.fkind[f];
-#pragma unroll
-    for (int i = 0; i < 3 * NC; ++i) g[i] = 0.0;
-    if (kind == 3) return;  // FK_SKIP: empty patches carry no field
-
-    auto reducedForm = [&]() {
-        const double ms = m.magSf[f];
-        const double nx = m.Sx[f] / ms, ny = m.Sy[f] / ms, nz = m.Sz[f] / ms;
-        const double dn = m.dn[f];
-#pragma unroll
-        for (int k = 0; k < NC; ++k) {
-            const double s = internal ? dn * (v.n[k] - v.o[k]) : v.sn[k];
-            g[0 * NC + k] = nx * s;
-            g[1 * NC + k] = ny * s;
-            g[2 * NC + k] = nz * s;
-        }
-    };
-
-    if constexpr (ST == ST_REDUCED) {
-        reducedForm();
-        return;
-    }
-    if constexpr (ST == ST_GVP3) {
-        if (kind == 2) { reducedForm(); return; }  // faces with > 4 vertices [3D.C L759-768]
-        const int4 vt = m.verts[f];
-        double psiN[NC];
-        if (internal) {
-#pragma unroll
-            for (int k = 0; k < NC; ++k) psiN[k] = v.n[k];
-        } else {
-            const double hd = m.bmvON[b];
-#pragma unroll
-            for (int k = 0; k < NC; ++k) psiN[k] = v.n[k] + v.sn[k] * hd * 0.5;  // [3D.C L790-793]
-        }
-        const double4 cO = m.Cc[m.own[f]];
-        const double4 cN = internal ? m.Cc[m.nei[f]] : m.bN[b];
-        double rV;
-        if (kind == 0) {  // quad: a2=-a0, a3=-a1, a4(nei)=-a5(own) [3D.C L361-363]
-            double a[9];
-            gvpQuadCoef(cO, cN, m.X[vt.x], m.X[vt.y], m.X[vt.z], m.X[vt.w], a, rV);
-            const double* p0 = ptF + (size_t)vt.x * NC;
-            const double* p1 = ptF + (size_t)vt.y * NC;
-            const double* p2 = ptF + (size_t)vt.z * NC;
-            const double* p3 = ptF + (size_t)vt.w * NC;
-            double q0[NC], q1[NC], q2[NC], q3[NC];
-#pragma unroll
-            for (int k = 0; k < NC; ++k) { q0[k] = p0[k]; q1[k] = p1[k]; q2[k] = p2[k]; q3[k] = p3[k]; }
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                const double a0 = a[3 * d], a1 = a[3 * d + 1], a5 = a[3 * d + 2];
-#pragma unroll
-                for (int k = 0; k < NC; ++k) {
-                    double s = psiN[k] * (-a5);
-                    s += v.o[k] * a5;
-                    s += q0[k] * a0;
-                    s += q1[k] * a1;
-                    s += q2[k] * (-a0);
-                    s += q3[k] * (-a1);
-                    g[d * NC + k] = s * rV;
-                }
-            }
-        } else {  // triangle: slots a0,a1,a2 vertices, a3 neighbour, owner = -a3 [3D.C L193-229]
-            double t[12];
-            gvpTriCoef(cO, cN, m.X[vt.x], m.X[vt.y], m.X[vt.z], t, rV);
-            const double* p0 = ptF + (size_t)vt.x * NC;
-            const double* p1 = ptF + (size_t)vt.y * NC;
-            const double* p2 = ptF + (size_t)vt.z * NC;
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                const double a0 = t[4 * d], a1 = t[4 * d + 1], a2 = t[4 * d + 2], a3 = t[4 * d + 3];
-#pragma unroll
-                for (int k = 0; k < NC; ++k) {
-                    double s = psiN[k] * a3;
-                    s += v.o[k] * (-a3);
-                    s += p0[k] * a0;
-                    s += p1[k] * a1;
-                    s += p2[k] * a2;
-                    g[d * NC + k] = s * rV;
-                }
-            }
-            if (UOFF >= 0 && internal) {
-                // interior triangles, vector field: every row i holds d_j U_j [3D.C L844-854]
-                double dg[3];
-#pragma unroll
-                for (int j = 0; j < 3; ++j) dg[j] = g[j * NC + UOFF + j];
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) g[i * NC + UOFF + j] = dg[j];
-            }
-        }
-        return;
-    }
-    if constexpr (ST == ST_GVP2) {
-        const int2 ip = m.ip13[f];
-        const size_t nF = (size_t)m.nF;
-        const double c1 = m.c2d[0 * nF + f], c2 = m.c2d[1 * nF + f], c3 = m.c2d[2 * nF + f], c4 = m.c2d[3 * nF + f];
-        const double mv42 = m.c2d[4 * nF + f], mv13 = m.c2d[5 * nF + f];
-        const double* pa = ptF + (size_t)ip.x * NC;
-        const double* pb = ptF + (size_t)ip.y * NC;
-#pragma unroll
-        for (int k = 0; k < NC; ++k) {
-            const double hi = internal ? v.n[k] : (v.n[k] + v.sn[k] * mv42 * 0.5);  // [2D.C L343-346]
-            const double dfdn = (hi - v.o[k]) / mv42;
-            const double dfdt = (pb[k] - pa[k]) / mv13;
-            g[m.ie1 * NC + k] = (dfdn * c1 - dfdt * c2);
-            g[m.ie2 * NC + k] = (dfdt * c3 - dfdn * c4);
-        }
-        return;
-    }
-    if constexpr (ST == ST_LSQ) {
-        if (!internal) {
-            if (m.lsqBndZero[b]) return;  // constraint patches stay zero [ScalarGrad.C L90-101]
-            const double ms = m.magSf[f];
-            const double nx = m.Sx[f] / ms, ny = m.Sy[f] / ms, nz = m.Sz[f] / ms;
-#pragma unroll
-            for (int k = 0; k < NC; ++k) {
-                g[0 * NC + k] = nx * v.sn[k];
-                g[1 * NC + k] = ny * v.sn[k];
-                g[2 * NC + k] = nz * v.sn[k];
-            }
-            return;
-        }
-        if (m.lsqDeg[f]) { reducedForm(); return; }  // [ScalarGrad.C L76-83]
-        const double w = m.w[f];
-        double pf[NC];
-#pragma unroll
-        for (int k = 0; k < NC; ++k) pf[k] = lerpf(w, v.o[k], v.n[k]);
-        const int cnt = m.lsqCnt[f];
-        const size_t base = (size_t)m.lsqSlice[f >> 6] * 64 + (f & 63);
-        for (int i = 0; i < cnt; ++i) {
-            const size_t e = base + (size_t)i * 64;
-            const double* cv = cellF + (size_t)m.lsqCell[e] * NC;
-            const double gx = m.lsqGx[e], gy = m.lsqGy[e], gz = m.lsqGz[e];
-#pragma unroll
-            for (int k = 0; k < NC; ++k) {
-                const double dphi = cv[k] - pf[k];
-                g[0 * NC + k] = g[0 * NC + k] + gx * dphi;
-                g[1 * NC + k] = g[1 * NC + k] + gy * dphi;
-                g[2 * NC + k] = g[2 * NC + k] + gz * dphi;
-            }
-        }
-        return;
-    }
-}
+// partial slots of the internal-face kernels are laid out for the smallest face tile (64)
+__device__ __forceinline__ int faceBlocksDev(const MeshView& m) { return (m.nIF + 63) / 64; }
 
 // ---------------------------------------------------------------------------
 // QGD flux algebra on one face [QGDFoam/updateFluxes.H L41-139, explicit branch]
@@ -391,27 +154,6 @@ __device__ __forceinline__ void loadVals(const RecA& a, double* o) {
 __device__ __forceinline__ double muEffOf(const GasModel& gm, double muQGD) { return 0.0 + (gm.mu0 + muQGD); }
 __device__ __forceinline__ double alphaEffOf(const GasModel& gm, double muQGD) {
     return gm.gamma * ((gm.alphah0 + muQGD / gm.PrQGD) + 0.0);
-}
-
-// XCD-aware tile order: consecutive workgroups are dealt round-robin to the 8
-// XCDs (block b -> XCD b%8), each with a private L2.  Remap so that every XCD
-// walks one contiguous eighth of the face range and neighbouring tiles (which
-// share cell and vertex records) meet in the same L2.
-__device__ __forceinline__ int xcdTile(int nTiles, int run = 0) {
-    const int b = blockIdx.x;
-    if (run <= 0) {
-        const int per = nTiles >> 3;        // tiles per XCD (the tail past 8*per keeps identity order)
-        if (b >= (per << 3)) return b;
-        return (b & 7) * per + (b >> 3);
-    }
-    // runs of `run` consecutive tiles dealt round-robin to the XCDs: consecutive tiles still meet in one L2, and the
-    // eight XCDs stay inside one window of 8*run tiles, so what one of them fetched from HBM is found by the others (one
-    // k-plane later) in the shared Infinity Cache instead of each XCD keeping a plane-sized working set of its own
-    const int span = run << 3;
-    const int full = (nTiles / span) * span;
-    if (b >= full) return b;
-    const int xcd = b & 7, i = b >> 3;
-    return ((i / run) * 8 + xcd) * run + (i % run);
 }
 
 // ---------------------------------------------------------------------------
@@ -634,11 +376,11 @@ void faceFluxGvp2Kernel(const MeshView m, const CaseView c, const GasModel gm, c
 #ifndef QGD_F_WAVES_MAX
 #define QGD_F_WAVES_MAX 3
 #endif
-template <bool DBG>
-__global__ __launch_bounds__(QGD_BLOCK) __attribute__((amdgpu_waves_per_eu(QGD_F_WAVES_MIN, QGD_F_WAVES_MAX)))
+template <bool DBG, int FB>
+__global__ __launch_bounds__(FB) __attribute__((amdgpu_waves_per_eu(QGD_F_WAVES_MIN, QGD_F_WAVES_MAX)))
 void faceFluxGvp3Kernel(const MeshView m, const CaseView c, const GasModel gm, const int adjustDt) {
-    const int tile = xcdTile((int)gridDim.x, m.xcdRun);
-    const int f = tile * QGD_BLOCK + (int)threadIdx.x;
+    const int tile = xcdTile((int)gridDim.x, m.xcdRun * (QGD_BLOCK / FB));
+    const int f = tile * FB + (int)threadIdx.x;
     double cof = -1e300, tauMin = 1e300;
     if (f < m.nIF) {
         const size_t nF = (size_t)m.nF;
@@ -755,7 +497,7 @@ void faceFluxGvp3Kernel(const MeshView m, const CaseView c, const GasModel gm, c
             }
         }
     }
-    if (adjustDt) blockMaxMin(cof, tauMin, c.blkFace + 2 * (size_t)tile, false);
+    if (adjustDt) blockMaxMin<FB>(cof, tauMin, c.blkFace + 2 * (size_t)tile, false);
 }
 
 // patch snGrad of the six case fields on boundary face (global label f)
@@ -891,9 +633,10 @@ __global__ __launch_bounds__(QGD_BLOCK) void pointInterpKernel(const MeshView m,
 #ifndef QGD_P_WAVES_MAX
 #define QGD_P_WAVES_MAX 4
 #endif
-__global__ __launch_bounds__(QGD_BLOCK) __attribute__((amdgpu_waves_per_eu(QGD_P_WAVES_MIN, QGD_P_WAVES_MAX)))
+template <int PB>
+__global__ __launch_bounds__(PB) __attribute__((amdgpu_waves_per_eu(QGD_P_WAVES_MIN, QGD_P_WAVES_MAX)))
 void pointInterpRecKernel(const MeshView m, const RecA* __restrict__ A, RecA* __restrict__ P) {
-    const int p = xcdTile((int)gridDim.x, m.xcdRun) * QGD_BLOCK + threadIdx.x;
+    const int p = xcdTile((int)gridDim.x, m.xcdRun * (QGD_BLOCK / PB)) * PB + threadIdx.x;
     if (p >= m.nP) return;
     const int n = m.pcCount[p];
     if (n == 0) return;
@@ -975,13 +718,14 @@ __global__ __launch_bounds__(QGD_BLOCK) void boundaryPointKernel(const MeshView 
 #ifndef QGD_C_WAVES_MAX
 #define QGD_C_WAVES_MAX 4
 #endif
-__global__ __launch_bounds__(QGD_BLOCK) __attribute__((amdgpu_waves_per_eu(QGD_C_WAVES_MIN, QGD_C_WAVES_MAX)))
+template <int CB>
+__global__ __launch_bounds__(CB) __attribute__((amdgpu_waves_per_eu(QGD_C_WAVES_MIN, QGD_C_WAVES_MAX)))
 void cellUpdateKernel(const MeshView m, const CaseView c, const GasModel gm, const int mode,
                       const int32_t* __restrict__ list, const int nList, const int slotBase) {
     // mode 0: every cell but the ghosts; mode 1: the cells of `list` (boundary layer of a shard: its records are what the
     // neighbours wait for); mode 2: ordinary owned cells only (the rest, while the exchange is in flight)
-    const int tile = (mode == 1) ? (int)blockIdx.x : xcdTile((int)gridDim.x, m.xcdRun);
-    const int idx = tile * QGD_BLOCK + threadIdx.x;
+    const int tile = (mode == 1) ? (int)blockIdx.x : xcdTile((int)gridDim.x, m.xcdRun * (QGD_BLOCK / CB));
+    const int idx = tile * CB + threadIdx.x;
     int ci = -1;
     if (mode == 1) { if (idx < nList) ci = list[idx]; }
     else if (idx < m.nC) {
@@ -996,7 +740,7 @@ void cellUpdateKernel(const MeshView m, const CaseView c, const GasModel gm, con
         const size_t nF = (size_t)m.nF;
         // the cell's own records stream in while the flux gather is in flight
         const RecA A = c.A[ci];
-        const Cons K = c.K[ci];
+        const double rEold = c.rE[ci];
         const double Vc = m.V[ci], hq = m.hQGD[ci];
         // six faces per pass, every flux load of the pass in flight before the ordered sum, ascending face label.
         // A wavefront of hexahedra only takes the unpredicated pass; one with other cells (tetrahedra, prisms, split
@@ -1041,20 +785,19 @@ void cellUpdateKernel(const MeshView m, const CaseView c, const GasModel gm, con
         const double dtV = c.dt[0] / Vc;
         // QGDRhoEqn / QGDUEqn / QGDEEqn: explicit Euler on rho, rhoU, rhoE
         const double rho = A.rho - dtV * sum[0];
-        Cons Kn;
-        Kn.rux = K.rux - dtV * sum[1];
-        Kn.ruy = K.ruy - dtV * sum[2];
-        Kn.ruz = K.ruz - dtV * sum[3];
-        Kn.rE = K.rE - dtV * sum[4];
+        // rhoU is not stored: it equals rho*U up to rounding by the re-solve identity below, so its increment is taken
+        // directly (rhoU_new - rhoU_old = -dtV*sum); rhoE is an independent field (the explicit energy re-solve as listed does
+        // not keep rhoE = rho*(e + |U|^2/2)), 8 B per cell
+        const double rEnew = rEold - dtV * sum[4];
         // solve(fvm::ddt(rho,U) - fvc::ddt(rhoU)) [QGDUEqn_8H L79-86]
         RecA An;
         An.rho = rho;
-        An.ux = (A.rho * A.ux + (Kn.rux - K.rux)) / rho;
-        An.uy = (A.rho * A.uy + (Kn.ruy - K.ruy)) / rho;
-        An.uz = (A.rho * A.uz + (Kn.ruz - K.ruz)) / rho;
+        An.ux = (A.rho * A.ux + (-(dtV * sum[1]))) / rho;
+        An.uy = (A.rho * A.uy + (-(dtV * sum[2]))) / rho;
+        An.uz = (A.rho * A.uz + (-(dtV * sum[3]))) / rho;
         // solve(fvm::ddt(rho,e) - fvc::ddt(rhoE)) [QGDEEqn_8H L67-72], as written in the listing
-        An.e = gm.consistentEnergy ? Kn.rE / rho - 0.5 * (An.ux * An.ux + An.uy * An.uy + An.uz * An.uz)   // e of [QGDEEqn_8H L49] kept
-                                   : (A.rho * A.e + (Kn.rE - K.rE)) / rho;
+        An.e = gm.consistentEnergy ? rEnew / rho - 0.5 * (An.ux * An.ux + An.uy * An.uy + An.uz * An.uz)   // e of [QGDEEqn_8H L49] kept
+                                   : (A.rho * A.e + (rEnew - rEold)) / rho;
         // thermo.correct(): eConst + perfectGas [hePsiQGDThermo_8C L48-64, L123-124]
         const double T = An.e / gm.Cv;
         const double psi = 1.0 / (gm.R * T);
@@ -1067,16 +810,16 @@ void cellUpdateKernel(const MeshView m, const CaseView c, const GasModel gm, con
         Bn.c = cs;
         Bn.aOc = aq / cs;
         An.p = rho / psi;                  // [QGDFoam_8C L152-154]
-        Bn.H = (Kn.rE + An.p) / rho;       // H = (rhoE + p)/rho [QGDFoam/updateFields.H L71]
+        Bn.H = (rEnew + An.p) / rho;       // H = (rhoE + p)/rho [QGDFoam/updateFields.H L71]
         c.A[ci] = An;
         c.B[ci] = Bn;
-        c.K[ci] = Kn;
+        c.rE[ci] = rEnew;
         // a NaN must not hide behind fmin(): it counts as a lost positivity
         rmin = (rho == rho) ? rho : -1e300;
         emin = (An.e == An.e) ? An.e : -1e300;
     }
     // positivity monitor [QGDFoam_8C L142]: one plain store pair per workgroup, no atomics
-    blockMaxMin(-rmin, emin, c.blkCell + 2 * (size_t)(slotBase + tile), true);
+    blockMaxMin<CB>(-rmin, emin, c.blkCell + 2 * (size_t)(slotBase + tile), true);
 }
 
 // createFields.H for the cells [QGDFoam_2createFields_8H L3-109]
@@ -1092,17 +835,15 @@ __global__ __launch_bounds__(QGD_BLOCK) void cellInitKernel(const MeshView m, co
     const double rho = pc * psi;
     RecA A;
     A.rho = rho; A.ux = U[3 * (size_t)ci]; A.uy = U[3 * (size_t)ci + 1]; A.uz = U[3 * (size_t)ci + 2]; A.p = pc; A.e = e;
-    Cons K;
-    K.rux = rho * A.ux; K.ruy = rho * A.uy; K.ruz = rho * A.uz;
-    K.rE = rho * e + rho * 0.5 * (A.ux * A.ux + A.uy * A.uy + A.uz * A.uz);
+    const double rE = rho * e + rho * 0.5 * (A.ux * A.ux + A.uy * A.uy + A.uz * A.uz);
     RecB B;
     const double aq = c.aQ ? c.aQ[ci] : gm.alphaQGD, scq = c.sc ? c.sc[ci] : gm.ScQGD;
     const double tauQGD = aq * m.hQGD[ci] / cs;
     B.muQGD = pc * scq * tauQGD;
     B.c = cs;
     B.aOc = aq / cs;
-    B.H = (K.rE + pc) / rho;
-    c.A[ci] = A; c.B[ci] = B; c.K[ci] = K;
+    B.H = (rE + pc) / rho;
+    c.A[ci] = A; c.B[ci] = B; c.rE[ci] = rE;
 }
 
 // Boundary-condition refresh of every patch face, in the order the loop body
@@ -1242,10 +983,9 @@ __global__ __launch_bounds__(QGD_BLOCK) void haloKernel(const CaseView c, const 
             const RecA a = c.A[ci]; const RecB b = c.B[ci];
             q[0] = a.rho; q[1] = a.ux; q[2] = a.uy; q[3] = a.uz; q[4] = a.p; q[5] = a.e; q[6] = b.H; q[7] = b.c; q[8] = b.muQGD; q[9] = b.aOc;
         } else {
-            RecA a; RecB b; Cons k;
+            RecA a; RecB b;
             a.rho = q[0]; a.ux = q[1]; a.uy = q[2]; a.uz = q[3]; a.p = q[4]; a.e = q[5]; b.H = q[6]; b.c = q[7]; b.muQGD = q[8]; b.aOc = q[9];
-            k.rux = a.rho * a.ux; k.ruy = a.rho * a.uy; k.ruz = a.rho * a.uz; k.rE = b.H * a.rho - a.p;
-            c.A[ci] = a; c.B[ci] = b; c.K[ci] = k;
+            c.A[ci] = a; c.B[ci] = b; c.rE[ci] = b.H * a.rho - a.p;
         }
     } else if (i < nCells + nFaces) {
         const int j = i - nCells;
@@ -1269,8 +1009,8 @@ __global__ __launch_bounds__(QGD_BLOCK) void haloKernel(const CaseView c, const 
 template <int ST, int NC, int OP>
 __global__ __launch_bounds__(QGD_BLOCK) void fvscOpKernel(const MeshView m, const double* __restrict__ cellF,
                                                          const double* __restrict__ bndF, const double* __restrict__ ptF,
-                                                         double* __restrict__ out) {
-    const int f = blockIdx.x * QGD_BLOCK + threadIdx.x;
+                                                         double* __restrict__ out, const int f0) {
+    const int f = f0 + blockIdx.x * QGD_BLOCK + threadIdx.x;
     if (f >= m.nF) return;
     FaceVals<NC> v;
     const int o = m.own[f];
@@ -1302,6 +1042,133 @@ __global__ __launch_bounds__(QGD_BLOCK) void fvscOpKernel(const MeshView m, cons
             out[(size_t)f * NO + j] = d;
         }
     }
+}
+
+// ---------------------------------------------------------------------------
+// The drop-in fvsc::grad of the 3-D GaussVolPoint stencil (what an unmodified updateFluxes.H calls four times per step,
+// QGDFoam/updateFluxes.H L41-65): loads-first like the fused flux kernel -- labels; cell + vertex values and the geometry the
+// Gauss coefficients are rebuilt from, all in flight before the first use -- and the 3*NC results of a 256-face tile go out
+// through LDS as one contiguous block (the AoS face field of the reference's surfaceVector/TensorField, 24/72 B per face).
+// Internal faces only; patch faces take fvscOpKernel.
+// ---------------------------------------------------------------------------
+template <int NC>
+__global__ __launch_bounds__(QGD_BLOCK) void fvscGradGvp3Kernel(const MeshView m, const double* __restrict__ cellF,
+                                                               const double* __restrict__ ptF, double* __restrict__ out) {
+    __shared__ double stage[QGD_BLOCK * 3 * NC];
+    const int tile = xcdTile((int)gridDim.x, m.xcdRun);
+    const int f = tile * QGD_BLOCK + (int)threadIdx.x;
+    double g[3 * NC];
+#pragma unroll
+    for (int i = 0; i < 3 * NC; ++i) g[i] = 0.0;
+    if (f < m.nIF) {
+        const int o = ldStream(m.own + f), n = ldStream(m.nei + f);
+        const int4 vt = m.verts[f];
+        const int kind = m.fkind[f];
+        const int v3 = vt.w < 0 ? 0 : vt.w;
+        FaceVals<NC> v;
+        double p0[NC], p1[NC], p2[NC], p3[NC];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            v.o[k] = cellF[(size_t)o * NC + k]; v.n[k] = cellF[(size_t)n * NC + k]; v.sn[k] = 0.0;
+            p0[k] = ptF[(size_t)vt.x * NC + k]; p1[k] = ptF[(size_t)vt.y * NC + k];
+            p2[k] = ptF[(size_t)vt.z * NC + k]; p3[k] = ptF[(size_t)v3 * NC + k];
+        }
+        const double4 cO = m.Cc[o], cN = m.Cc[n];
+        const double4 x0 = m.X[vt.x], x1 = m.X[vt.y], x2 = m.X[vt.z], x3 = m.X[v3];
+        __builtin_amdgcn_sched_barrier(0);
+        if (kind == 0) {
+            // quad, difference form (see faceFluxGvp3Kernel): V d_d phi = a5_d (phi_O - phi_N) + a0_d (phi_1 - phi_3) + a1_d (phi_2 - phi_4)
+            const double NO[3] = {cN.x - cO.x, cN.y - cO.y, cN.z - cO.z};
+            const double d24[3] = {x1.x - x3.x, x1.y - x3.y, x1.z - x3.z};
+            const double d31[3] = {x2.x - x0.x, x2.y - x0.y, x2.z - x0.z};
+            double A0[3], A1[3], A5[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const int u = (d + 1) % 3, w2 = (d + 2) % 3;
+                A0[d] = NO[u] * d24[w2] - NO[w2] * d24[u];
+                A1[d] = NO[u] * d31[w2] - NO[w2] * d31[u];
+                A5[d] = d24[u] * d31[w2] - d24[w2] * d31[u];
+            }
+            const double rV6 = -1.0 / (d31[0] * A0[0] + d31[1] * A0[1] + d31[2] * A0[2]);
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                const double D5 = (v.o[k] - v.n[k]) * rV6, D0 = (p0[k] - p2[k]) * rV6, D1 = (p1[k] - p3[k]) * rV6;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) g[d * NC + k] = A5[d] * D5 + A0[d] * D0 + A1[d] * D1;
+            }
+        } else if (kind == 1) {
+            double t[12], rV;
+            gvpTriCoef(cO, cN, x0, x1, x2, t, rV);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const double a0 = t[4 * d], a1 = t[4 * d + 1], a2 = t[4 * d + 2], a3 = t[4 * d + 3];
+#pragma unroll
+                for (int k = 0; k < NC; ++k) {
+                    double sg = v.n[k] * a3;
+                    sg += v.o[k] * (-a3);
+                    sg += p0[k] * a0;
+                    sg += p1[k] * a1;
+                    sg += p2[k] * a2;
+                    g[d * NC + k] = sg * rV;
+                }
+            }
+            if (NC == 3) {  // interior triangles of a vector field: every row holds (dxUx, dyUy, dzUz) [3D.C L844-854]
+                double dg[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) dg[j] = g[j * NC + (j % NC)];
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) g[i * NC + (j % NC)] = dg[j];
+            }
+        } else {
+            faceGradient<ST_GVP3, NC, (NC == 3) ? 0 : -1>(m, f, v, cellF, ptF, g);  // > 4 vertices: nf*snGrad [3D.C L759-768]
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 3 * NC; ++i) stage[(size_t)threadIdx.x * 3 * NC + i] = g[i];
+    __syncthreads();
+    const int64_t first = (int64_t)tile * QGD_BLOCK;
+    const int64_t cnt = ((m.nIF - first) < QGD_BLOCK ? (m.nIF - first) : QGD_BLOCK) * 3 * NC;
+    double* dst = out + first * 3 * NC;
+    for (int i = threadIdx.x; i < cnt; i += QGD_BLOCK) dst[i] = stage[i];
+}
+
+// cell -> vertex interpolation of a plain NC-component field with the structure of pointInterpRecKernel (sliced-ELL list
+// read as contiguous runs, eight gathers in flight before the ordered sum)
+template <int NC>
+__global__ __launch_bounds__(QGD_BLOCK) void pointInterpFastKernel(const MeshView m, const double* __restrict__ cellF,
+                                                                  double* __restrict__ ptF) {
+    const int p = xcdTile((int)gridDim.x, m.xcdRun) * QGD_BLOCK + threadIdx.x;
+    if (p >= m.nP) return;
+    const int n = m.pcCount[p];
+    if (n == 0) return;
+    const size_t base = (size_t)m.pcSlice[p >> 6] * 64 + (p & 63);
+    double acc[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) acc[k] = 0.0;
+    for (int i = 0; i < n; i += 8) {
+        int id[8];
+        double w[8], r[8][NC];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const bool on = i + q < n;
+            id[q] = on ? m.pcCell[base + (size_t)(i + q) * 64] : 0;
+            w[q] = on ? m.pcW[base + (size_t)(i + q) * 64] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int k = 0; k < NC; ++k) r[q][k] = (i + q < n) ? cellF[(size_t)id[q] * NC + k] : 0.0;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (i + q < n)
+#pragma unroll
+                for (int k = 0; k < NC; ++k) acc[k] += w[q] * r[q][k];
+    }
+#pragma unroll
+    for (int k = 0; k < NC; ++k) ptF[(size_t)p * NC + k] = acc[k];
 }
 
 // ---------------------------------------------------------------------------
@@ -1392,7 +1259,7 @@ __global__ __launch_bounds__(QGD_BLOCK) void qhdFaceKernel(const MeshView m, con
 // Named cell / patch field out of the records into a dense array (the accessor path of qgd_case_get_field: one pass on
 // the device and one copy of what was asked for, instead of shipping every record to the host).
 __global__ __launch_bounds__(QGD_BLOCK) void extractFieldKernel(const RecA* __restrict__ A, const RecB* __restrict__ B,
-                                                               const Cons* __restrict__ K, const double* __restrict__ hq,
+                                                               const double* __restrict__ rE, const double* __restrict__ hq,
                                                                const double* __restrict__ aQ,
                                                                const int64_t n, const GasModel g, const int field,
                                                                double* __restrict__ out) {
@@ -1408,10 +1275,9 @@ __global__ __launch_bounds__(QGD_BLOCK) void extractFieldKernel(const RecA* __re
         case XF_E: out[i] = a.e; break;
         case XF_T: out[i] = a.e / g.Cv; break;
         case XF_RHOU:
-            if (K) { out[3 * i] = K[i].rux; out[3 * i + 1] = K[i].ruy; out[3 * i + 2] = K[i].ruz; }
-            else { out[3 * i] = a.rho * a.ux; out[3 * i + 1] = a.rho * a.uy; out[3 * i + 2] = a.rho * a.uz; }
+            out[3 * i] = a.rho * a.ux; out[3 * i + 1] = a.rho * a.uy; out[3 * i + 2] = a.rho * a.uz;
             break;
-        case XF_RHOE: out[i] = K ? K[i].rE : a.rho * (a.e + ke); break;
+        case XF_RHOE: out[i] = rE ? rE[i] : a.rho * (a.e + ke); break;
         case XF_C: out[i] = b.c; break;
         case XF_PSI: out[i] = 1.0 / (g.R * (a.e / g.Cv)); break;
         case XF_MU: out[i] = g.mu0 + b.muQGD; break;
@@ -1438,7 +1304,9 @@ static inline int gridFor(int64_t n) { return (int)((n + QGD_BLOCK - 1) / QGD_BL
 
 void launchPointInterp(const Launcher& L, const MeshView& m, const CaseView& c) {
     if (m.nP == 0) return;
-    QGD_TIMED(L, QGD_K_POINT, (pointInterpRecKernel<<<gridFor(m.nP), QGD_BLOCK, 0, L.stream>>>(m, c.A, c.P)));
+    if (m.pblock == 64) QGD_TIMED(L, QGD_K_POINT, (pointInterpRecKernel<64><<<(m.nP + 63) / 64, 64, 0, L.stream>>>(m, c.A, c.P)));
+    else if (m.pblock == 128) QGD_TIMED(L, QGD_K_POINT, (pointInterpRecKernel<128><<<(m.nP + 127) / 128, 128, 0, L.stream>>>(m, c.A, c.P)));
+    else QGD_TIMED(L, QGD_K_POINT, (pointInterpRecKernel<256><<<gridFor(m.nP), QGD_BLOCK, 0, L.stream>>>(m, c.A, c.P)));
 }
 void launchBoundaryPoints(const Launcher& L, const MeshView& m, const CaseView& c, bool pOnly) {
     if (m.nBP == 0) return;
@@ -1456,7 +1324,11 @@ static void launchFaceFluxT(const Launcher& L, int stencil, const MeshView& m, c
     switch (stencil) {
         case ST_REDUCED: faceFluxReducedKernel<DBG><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, adj); break;
         case ST_LSQ: faceFluxLsqKernel<DBG><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, adj); break;
-        case ST_GVP3: faceFluxGvp3Kernel<DBG><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, adj); break;
+        case ST_GVP3:
+            if (m.fblock == 64) faceFluxGvp3Kernel<DBG, 64><<<(m.nIF + 63) / 64, 64, 0, L.stream>>>(m, c, g, adj);
+            else if (m.fblock == 128) faceFluxGvp3Kernel<DBG, 128><<<(m.nIF + 127) / 128, 128, 0, L.stream>>>(m, c, g, adj);
+            else faceFluxGvp3Kernel<DBG, 256><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, adj);
+            break;
         default: faceFluxGvp2Kernel<DBG><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, adj); break;
     }
 }
@@ -1485,8 +1357,10 @@ void launchCellUpdate(const Launcher& L, const MeshView& m, const CaseView& c, c
                       const int32_t* list, int nList) {
     const int n = (mode == 1) ? nList : m.nC;
     if (n == 0) return;
-    const int slotBase = (mode == 1) ? gridFor(m.nC) : 0;  // the list launch monitors min(rho), min(e) in its own slots
-    QGD_TIMED(L, QGD_K_CELL, (cellUpdateKernel<<<gridFor(n), QGD_BLOCK, 0, L.stream>>>(m, c, g, mode, list, nList, slotBase)));
+    const int slotBase = (mode == 1) ? cellBlocks(m) : 0;  // the list launch monitors min(rho), min(e) in its own slots
+    if (m.cblock == 64) QGD_TIMED(L, QGD_K_CELL, (cellUpdateKernel<64><<<(n + 63) / 64, 64, 0, L.stream>>>(m, c, g, mode, list, nList, slotBase)));
+    else if (m.cblock == 128) QGD_TIMED(L, QGD_K_CELL, (cellUpdateKernel<128><<<(n + 127) / 128, 128, 0, L.stream>>>(m, c, g, mode, list, nList, slotBase)));
+    else QGD_TIMED(L, QGD_K_CELL, (cellUpdateKernel<256><<<gridFor(n), QGD_BLOCK, 0, L.stream>>>(m, c, g, mode, list, nList, slotBase)));
 }
 void launchBoundaryUpdate(const Launcher& L, const MeshView& m, const CaseView& c, const GasModel& g, const PatchBCDev* bc,
                           bool init, bool phiwRegistered, int mode, const int32_t* list, int nList) {
@@ -1505,9 +1379,9 @@ void launchDeltaT(const Launcher& L, const CaseView& c, double maxCo, double max
 void launchFaceReduce(const Launcher& L, const CaseView& c) { faceReduceKernel<<<1, QGD_BLOCK, 0, L.stream>>>(c); }
 void launchResetReductions(const Launcher& L, const CaseView& c) { resetReductionsKernel<<<64, QGD_BLOCK, 0, L.stream>>>(c); }
 void launchCellMinReduce(const Launcher& L, const CaseView& c) { cellMinReduceKernel<<<1, QGD_BLOCK, 0, L.stream>>>(c); }
-int faceBlocks(const MeshView& m) { return gridFor(m.nIF); }
+int faceBlocks(const MeshView& m) { return (m.nIF + 63) / 64; }
 int bfaceBlocks(const MeshView& m) { return gridFor(m.nBF); }
-int cellBlocks(const MeshView& m) { return gridFor(m.nC); }
+int cellBlocks(const MeshView& m) { return (m.nC + 63) / 64; }  // slots laid out for the smallest cell tile
 void launchHaloPack(const Launcher& L, const CaseView& c, const int32_t* cells, int32_t nCells, const int32_t* bfaces,
                     int32_t nFaces, double* buf, bool pack) {
     const int n = nCells + nFaces;
@@ -1515,7 +1389,7 @@ void launchHaloPack(const Launcher& L, const CaseView& c, const int32_t* cells, 
     haloKernel<<<gridFor(n), QGD_BLOCK, 0, L.stream>>>(c, cells, nCells, bfaces, nFaces, buf, pack ? 1 : 0);
 }
 
-void launchExtractField(hipStream_t s, const RecA* A, const RecB* B, const Cons* K, const double* hq, const double* aQ, int64_t n,
+void launchExtractField(hipStream_t s, const RecA* A, const RecB* B, const double* K, const double* hq, const double* aQ, int64_t n,
                         const GasModel& g, int field, double* out) {
     if (n == 0) return;
     extractFieldKernel<<<gridFor(n), QGD_BLOCK, 0, s>>>(A, B, K, hq, aQ, n, g, field, out);
@@ -1524,11 +1398,17 @@ void launchExtractField(hipStream_t s, const RecA* A, const RecB* B, const Cons*
 template <int ST, int NC>
 static void launchFvscOpT(hipStream_t s, int op, const MeshView& m, const double* cell, const double* bnd, double* pt, double* out) {
     if (ST == ST_GVP3 || ST == ST_GVP2) {
-        pointInterpKernel<NC><<<gridFor(m.nP), QGD_BLOCK, 0, s>>>(m, cell, NC, pt);
+        pointInterpFastKernel<NC><<<gridFor(m.nP), QGD_BLOCK, 0, s>>>(m, cell, pt);
         if (m.nBP) boundaryPointKernel<NC><<<gridFor(m.nBP), QGD_BLOCK, 0, s>>>(m, bnd, NC, pt, NC, 0);
     }
-    if (op == 0) fvscOpKernel<ST, NC, 0><<<gridFor(m.nF), QGD_BLOCK, 0, s>>>(m, cell, bnd, pt, out);
-    else fvscOpKernel<ST, NC, (NC >= 3 ? 1 : 0)><<<gridFor(m.nF), QGD_BLOCK, 0, s>>>(m, cell, bnd, pt, out);
+    if (ST == ST_GVP3 && op == 0 && NC <= 3) {
+        // the drop-in path of updateFluxes.H: internal faces through the loads-first kernel, patch faces through the generic one
+        if (m.nIF) fvscGradGvp3Kernel<(NC <= 3 ? NC : 1)><<<gridFor(m.nIF), QGD_BLOCK, 0, s>>>(m, cell, pt, out);
+        if (m.nBF) fvscOpKernel<ST, NC, 0><<<gridFor(m.nBF), QGD_BLOCK, 0, s>>>(m, cell, bnd, pt, out, m.nIF);
+        return;
+    }
+    if (op == 0) fvscOpKernel<ST, NC, 0><<<gridFor(m.nF), QGD_BLOCK, 0, s>>>(m, cell, bnd, pt, out, 0);
+    else fvscOpKernel<ST, NC, (NC >= 3 ? 1 : 0)><<<gridFor(m.nF), QGD_BLOCK, 0, s>>>(m, cell, bnd, pt, out, 0);
 }
 template <int ST>
 static void launchFvscOpS(hipStream_t s, int op, int NC, const MeshView& m, const double* cell, const double* bnd, double* pt, double* out) {

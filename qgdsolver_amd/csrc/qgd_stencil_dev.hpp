@@ -1,0 +1,272 @@
+// qgd_stencil_dev.hpp -- device functions shared by the kernel files (qgd_kernels.hip: QGDFoam path, qgd_qhd.hip: QHDFoam
+// path): streamed loads, the fvsc face gradient of every stencil (reduced, leastSquares, GaussVolPoint 2-D / 3-D with its
+// coefficients rebuilt from geometry) and the XCD-aware workgroup -> tile map.  Reference listings as cited per function.
+#pragma once
+#include "qgd_device.hpp"
+
+namespace qgd {
+
+#ifndef QGD_BLOCK
+#define QGD_BLOCK 256
+#endif
+
+__device__ __forceinline__ double lerpf(double w, double a, double b) { return w * (a - b) + b; }
+
+// Streamed-once data (per-face geometry, gather lists) is loaded non-temporally so it does not push the
+// re-used cell/vertex records out of the 4 MiB L2 of the XCD.
+#ifndef QGD_NT
+#define QGD_NT 1
+#endif
+template <class T>
+__device__ __forceinline__ T ldStream(const T* p) {
+#if QGD_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+template <class T>
+__device__ __forceinline__ void stStream(T* p, T v) {
+#if QGD_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
+template <int NC>
+struct FaceVals {
+    double o[NC];   // owner cell values
+    double n[NC];   // neighbour cell (internal face) or patch value (boundary face)
+    double sn[NC];  // boundary face: patch snGrad
+};
+
+// ---------------------------------------------------------------------------
+// GaussVolPoint 3-D coefficients of one face from its geometry [GaussVolPointBase3D_8C L161-476].
+// O/N: owner / neighbour cell centre (boundary: mirror point), x1..x4: face vertices in face order.
+// quad: a[3d+0]=a0, a[3d+1]=a1, a[3d+2]=a5 (a2=-a0, a3=-a1, a4=-a5) [L353-389];  rV = 1/V [L346-350]
+// tri : t[4d+0..2]=a0..a2 (vertices), t[4d+3]=a3 (neighbour), owner = -a3 [L193-229]; rV = 1/V [L186-190]
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void gvpQuadCoef(const double4 O, const double4 N, const double4 x1, const double4 x2,
+                                            const double4 x3, const double4 x4, double a[9], double& rV) {
+    const double sixth = (1.0 / 6.0);
+    const double o[3] = {O.x, O.y, O.z}, n[3] = {N.x, N.y, N.z};
+    const double p1[3] = {x1.x, x1.y, x1.z}, p2[3] = {x2.x, x2.y, x2.z}, p3[3] = {x3.x, x3.y, x3.z}, p4[3] = {x4.x, x4.y, x4.z};
+    double d31[3], d42[3], on[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { d31[k] = p3[k] - p1[k]; d42[k] = p4[k] - p2[k]; on[k] = o[k] - n[k]; }
+    const double cr[3] = {d42[1] * on[2] - d42[2] * on[1], d42[2] * on[0] - d42[0] * on[2], d42[0] * on[1] - d42[1] * on[0]};
+    double vol = d31[0] * cr[0] + d31[1] * cr[1] + d31[2] * cr[2];
+    vol *= sixth;
+    rV = 1.0 / vol;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int u = (d + 1) % 3, v = (d + 2) % 3;
+        a[3 * d + 0] = sixth * ((n[u] - o[u]) * (p2[v] - p4[v]) - (n[v] - o[v]) * (p2[u] - p4[u]));
+        a[3 * d + 1] = sixth * ((n[u] - o[u]) * (p3[v] - p1[v]) - (n[v] - o[v]) * (p3[u] - p1[u]));
+        a[3 * d + 2] = sixth * ((p1[u] - p3[u]) * (p2[v] - p4[v]) - (p1[v] - p3[v]) * (p2[u] - p4[u]));
+    }
+}
+__device__ __forceinline__ void gvpTriCoef(const double4 O, const double4 N, const double4 x1, const double4 x2,
+                                           const double4 x3, double t[12], double& rV) {
+    const double sixth = (1.0 / 6.0);
+    const double o[3] = {O.x, O.y, O.z}, n[3] = {N.x, N.y, N.z};
+    const double p1[3] = {x1.x, x1.y, x1.z}, p2[3] = {x2.x, x2.y, x2.z}, p3[3] = {x3.x, x3.y, x3.z};
+    double e21[3], e31[3], on[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { e21[k] = p2[k] - p1[k]; e31[k] = p3[k] - p1[k]; on[k] = o[k] - n[k]; }
+    const double cr[3] = {e21[1] * e31[2] - e21[2] * e31[1], e21[2] * e31[0] - e21[0] * e31[2], e21[0] * e31[1] - e21[1] * e31[0]};
+    double vol = cr[0] * on[0] + cr[1] * on[1] + cr[2] * on[2];
+    vol *= sixth;
+    rV = 1.0 / vol;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int u = (d + 1) % 3, v = (d + 2) % 3;
+        t[4 * d + 0] = sixth * ((o[v] - n[v]) * (p2[u] - p3[u]) + (n[u] - o[u]) * (p2[v] - p3[v]));
+        t[4 * d + 1] = sixth * ((n[u] - o[u]) * (p3[v] - p1[v]) + (o[v] - n[v]) * (p3[u] - p1[u]));
+        t[4 * d + 2] = sixth * ((n[u] - o[u]) * (p1[v] - p2[v]) + (o[v] - n[v]) * (p1[u] - p2[u]));
+        t[4 * d + 3] = sixth * (p1[v] * (p2[u] - p3[u]) + p2[v] * (p3[u] - p1[u]) + p3[v] * (p1[u] - p2[u]));
+    }
+}
+
+// ---------------------------------------------------------------------------
+// fvsc face gradient of an NC-component field: g[i*NC + k] = d_i phi_k.
+// cellF / ptF are AoS with stride NC (cell and vertex values).
+// UOFF >= 0 marks three consecutive components as a vector so that the
+// interior-triangle pattern of the reference's vector gradient
+// [GaussVolPointBase3D_8C L844-854] is reproduced.
+// ---------------------------------------------------------------------------
+template <int ST, int NC, int UOFF>
+__device__ __forceinline__ void faceGradient(const MeshView& m, const int f, const FaceVals<NC>& v,
+                                             const double* __restrict__ cellF, const double* __restrict__ ptF,
+                                             double* __restrict__ g) {
+    const bool internal = f < m.nIF;
+    const int b = f - m.nIF;
+    const int kind = m.fkind[f];
+#pragma unroll
+    for (int i = 0; i < 3 * NC; ++i) g[i] = 0.0;
+    if (kind == 3) return;  // FK_SKIP: empty patches carry no field
+
+    auto reducedForm = [&]() {
+        const double ms = m.magSf[f];
+        const double nx = m.Sx[f] / ms, ny = m.Sy[f] / ms, nz = m.Sz[f] / ms;
+        const double dn = m.dn[f];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            const double s = internal ? dn * (v.n[k] - v.o[k]) : v.sn[k];
+            g[0 * NC + k] = nx * s;
+            g[1 * NC + k] = ny * s;
+            g[2 * NC + k] = nz * s;
+        }
+    };
+
+    if constexpr (ST == ST_REDUCED) {
+        reducedForm();
+        return;
+    }
+    if constexpr (ST == ST_GVP3) {
+        if (kind == 2) { reducedForm(); return; }  // faces with > 4 vertices [3D.C L759-768]
+        const int4 vt = m.verts[f];
+        double psiN[NC];
+        if (internal) {
+#pragma unroll
+            for (int k = 0; k < NC; ++k) psiN[k] = v.n[k];
+        } else {
+            const double hd = m.bmvON[b];
+#pragma unroll
+            for (int k = 0; k < NC; ++k) psiN[k] = v.n[k] + v.sn[k] * hd * 0.5;  // [3D.C L790-793]
+        }
+        const double4 cO = m.Cc[m.own[f]];
+        const double4 cN = internal ? m.Cc[m.nei[f]] : m.bN[b];
+        double rV;
+        if (kind == 0) {  // quad: a2=-a0, a3=-a1, a4(nei)=-a5(own) [3D.C L361-363]
+            double a[9];
+            gvpQuadCoef(cO, cN, m.X[vt.x], m.X[vt.y], m.X[vt.z], m.X[vt.w], a, rV);
+            const double* p0 = ptF + (size_t)vt.x * NC;
+            const double* p1 = ptF + (size_t)vt.y * NC;
+            const double* p2 = ptF + (size_t)vt.z * NC;
+            const double* p3 = ptF + (size_t)vt.w * NC;
+            double q0[NC], q1[NC], q2[NC], q3[NC];
+#pragma unroll
+            for (int k = 0; k < NC; ++k) { q0[k] = p0[k]; q1[k] = p1[k]; q2[k] = p2[k]; q3[k] = p3[k]; }
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const double a0 = a[3 * d], a1 = a[3 * d + 1], a5 = a[3 * d + 2];
+#pragma unroll
+                for (int k = 0; k < NC; ++k) {
+                    double s = psiN[k] * (-a5);
+                    s += v.o[k] * a5;
+                    s += q0[k] * a0;
+                    s += q1[k] * a1;
+                    s += q2[k] * (-a0);
+                    s += q3[k] * (-a1);
+                    g[d * NC + k] = s * rV;
+                }
+            }
+        } else {  // triangle: slots a0,a1,a2 vertices, a3 neighbour, owner = -a3 [3D.C L193-229]
+            double t[12];
+            gvpTriCoef(cO, cN, m.X[vt.x], m.X[vt.y], m.X[vt.z], t, rV);
+            const double* p0 = ptF + (size_t)vt.x * NC;
+            const double* p1 = ptF + (size_t)vt.y * NC;
+            const double* p2 = ptF + (size_t)vt.z * NC;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const double a0 = t[4 * d], a1 = t[4 * d + 1], a2 = t[4 * d + 2], a3 = t[4 * d + 3];
+#pragma unroll
+                for (int k = 0; k < NC; ++k) {
+                    double s = psiN[k] * a3;
+                    s += v.o[k] * (-a3);
+                    s += p0[k] * a0;
+                    s += p1[k] * a1;
+                    s += p2[k] * a2;
+                    g[d * NC + k] = s * rV;
+                }
+            }
+            if (UOFF >= 0 && internal) {
+                // interior triangles, vector field: every row i holds d_j U_j [3D.C L844-854]
+                double dg[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) dg[j] = g[j * NC + UOFF + j];
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) g[i * NC + UOFF + j] = dg[j];
+            }
+        }
+        return;
+    }
+    if constexpr (ST == ST_GVP2) {
+        const int2 ip = m.ip13[f];
+        const size_t nF = (size_t)m.nF;
+        const double c1 = m.c2d[0 * nF + f], c2 = m.c2d[1 * nF + f], c3 = m.c2d[2 * nF + f], c4 = m.c2d[3 * nF + f];
+        const double mv42 = m.c2d[4 * nF + f], mv13 = m.c2d[5 * nF + f];
+        const double* pa = ptF + (size_t)ip.x * NC;
+        const double* pb = ptF + (size_t)ip.y * NC;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            const double hi = internal ? v.n[k] : (v.n[k] + v.sn[k] * mv42 * 0.5);  // [2D.C L343-346]
+            const double dfdn = (hi - v.o[k]) / mv42;
+            const double dfdt = (pb[k] - pa[k]) / mv13;
+            g[m.ie1 * NC + k] = (dfdn * c1 - dfdt * c2);
+            g[m.ie2 * NC + k] = (dfdt * c3 - dfdn * c4);
+        }
+        return;
+    }
+    if constexpr (ST == ST_LSQ) {
+        if (!internal) {
+            if (m.lsqBndZero[b]) return;  // constraint patches stay zero [ScalarGrad.C L90-101]
+            const double ms = m.magSf[f];
+            const double nx = m.Sx[f] / ms, ny = m.Sy[f] / ms, nz = m.Sz[f] / ms;
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                g[0 * NC + k] = nx * v.sn[k];
+                g[1 * NC + k] = ny * v.sn[k];
+                g[2 * NC + k] = nz * v.sn[k];
+            }
+            return;
+        }
+        if (m.lsqDeg[f]) { reducedForm(); return; }  // [ScalarGrad.C L76-83]
+        const double w = m.w[f];
+        double pf[NC];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) pf[k] = lerpf(w, v.o[k], v.n[k]);
+        const int cnt = m.lsqCnt[f];
+        const size_t base = (size_t)m.lsqSlice[f >> 6] * 64 + (f & 63);
+        for (int i = 0; i < cnt; ++i) {
+            const size_t e = base + (size_t)i * 64;
+            const double* cv = cellF + (size_t)m.lsqCell[e] * NC;
+            const double gx = m.lsqGx[e], gy = m.lsqGy[e], gz = m.lsqGz[e];
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                const double dphi = cv[k] - pf[k];
+                g[0 * NC + k] = g[0 * NC + k] + gx * dphi;
+                g[1 * NC + k] = g[1 * NC + k] + gy * dphi;
+                g[2 * NC + k] = g[2 * NC + k] + gz * dphi;
+            }
+        }
+        return;
+    }
+}
+
+// XCD-aware tile order: consecutive workgroups are dealt round-robin to the 8
+// XCDs (block b -> XCD b%8), each with a private L2.  Remap so that every XCD
+// walks one contiguous eighth of the face range and neighbouring tiles (which
+// share cell and vertex records) meet in the same L2.
+__device__ __forceinline__ int xcdTile(int nTiles, int run = 0) {
+    const int b = blockIdx.x;
+    if (run <= 0) {
+        const int per = nTiles >> 3;        // tiles per XCD (the tail past 8*per keeps identity order)
+        if (b >= (per << 3)) return b;
+        return (b & 7) * per + (b >> 3);
+    }
+    // runs of `run` consecutive tiles dealt round-robin to the XCDs: consecutive tiles still meet in one L2, and the
+    // eight XCDs stay inside one window of 8*run tiles, so what one of them fetched from HBM is found by the others (one
+    // k-plane later) in the shared Infinity Cache instead of each XCD keeping a plane-sized working set of its own
+    const int span = run << 3;
+    const int full = (nTiles / span) * span;
+    if (b >= full) return b;
+    const int xcd = b & 7, i = b >> 3;
+    return ((i / run) * 8 + xcd) * run + (i % run);
+}
+
+}  // namespace qgd

@@ -144,3 +144,45 @@ class RangeHalo(SlabHalo):
     def __init__(self, case, rank, world, dist, alloc, arg):
         peers = {slot: int(p) for slot, p in enumerate(case.mesh.array("haloPeer"))}
         super().__init__(case, rank, world, dist, alloc, arg, peers=peers)
+
+
+class NativeComm:
+    """qgd_comm_t: the library's own RCCL communicator (qgd_comm_* / qgd_case_halo_exchange / qgd_case_step_sharded in
+    include/qgd_amd.h) -- what a C++/MPI host uses; this wrapper bootstraps it the way such a host would, with the launcher's
+    broadcast standing in for MPI_Bcast (``bcast(bytes_or_None) -> bytes`` on every rank; identity on one rank)."""
+
+    def __init__(self, device_id, rank=0, world=1, bcast=None):
+        import ctypes as C
+        from . import _lib as L
+        self._L, self._C = L, C
+        uid = (C.c_char * 128)()
+        if rank == 0:
+            L.check(L.lib.qgd_comm_unique_id(uid), "qgd_comm_unique_id")
+        raw = bytes(uid.raw)
+        if world > 1:
+            raw = bcast(raw if rank == 0 else None)
+        buf = (C.c_char * 128).from_buffer_copy(raw)
+        h = C.c_void_p()
+        L.check(L.lib.qgd_comm_create(int(device_id), int(rank), int(world), buf, C.byref(h)), "qgd_comm_create")
+        self._h, self.rank, self.world = h, rank, world
+
+    def _peers(self, peers):
+        import numpy as np
+        a = np.ascontiguousarray(peers, dtype=np.int32)
+        return a, a.ctypes.data_as(self._L.c_int32_p), int(a.size)
+
+    def exchange(self, case, peers):
+        a, p, n = self._peers(peers)
+        self._L.check(self._L.lib.qgd_case_halo_exchange(case._h, self._h, p, n), "qgd_case_halo_exchange")
+
+    def step(self, case, peers, overlapped=False):
+        a, p, n = self._peers(peers)
+        self._L.check(self._L.lib.qgd_case_step_sharded(case._h, self._h, p, n, 1 if overlapped else 0), "qgd_case_step_sharded")
+
+    def allreduce_max(self, case):
+        self._L.check(self._L.lib.qgd_case_allreduce_max(case._h, self._h), "qgd_case_allreduce_max")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.lib.qgd_comm_free(self._h)
+            self._h = None

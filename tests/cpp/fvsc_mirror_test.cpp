@@ -45,6 +45,27 @@ int main() {
     mesh.fvscSchemes["grad(T)"] = "noSuchStencil";
     try { fvsc::grad(mesh, T); return 4; } catch (const FatalError& e) { if (e.status != QGD_ERR_UNKNOWN_NAME) return 5; }
     if (mesh.registry.size() != 1) return 6;  // lookupOrNew cached exactly the GaussVolPoint stencil
+    // qgdInterpolate / qgdFlux read like the reference's call sites [QGDFoam/updateFields.H L45, updateFluxes.H L78]
+    surfaceField pf = qgdInterpolate(mesh, p);
+    std::vector<double> w(sz[1]);
+    std::vector<int32_t> own(sz[1]), nei(sz[2]);
+    check(qgd_mesh_get(m, "weights", w.data(), (int64_t)w.size() * 8), "weights");
+    check(qgd_mesh_get(m, "owner", own.data(), (int64_t)own.size() * 4), "owner");
+    check(qgd_mesh_get(m, "neighbour", nei.data(), (int64_t)nei.size() * 4), "neighbour");
+    for (int64_t f = 0; f < sz[2]; ++f) {
+        const double ref = w[f] * (p.internal[own[f]] - p.internal[nei[f]]) + p.internal[nei[f]];
+        if (std::fabs(pf.values[f] - ref) > 1e-15 * std::fabs(ref)) return 7;
+    }
+    for (int64_t f = sz[2]; f < sz[1]; ++f) if (pf.values[f] != p.boundary[f - sz[2]]) return 8;
+    surfaceField phi{1, std::vector<double>(sz[1], 2.0)};
+    surfaceField phiP = qgdFlux(mesh, phi, "phiJm", p, pf);
+    for (int64_t f = 0; f < sz[1]; ++f) if (phiP.values[f] != 2.0 * pf.values[f]) return 9;
+    mesh.interpolationSchemes["default"] = "none";          // `none` still means linearInterpolate [L56-63]
+    if (qgdInterpolate(mesh, p).values[0] != pf.values[0]) return 10;
+    mesh.interpolationSchemes["interpolate(p)"] = "vanLeer";  // a user scheme is OpenFOAM's business: fatal here
+    try { qgdInterpolate(mesh, p); return 11; } catch (const FatalError& e) { if (e.status != QGD_ERR_NOT_IMPLEMENTED) return 12; }
+    mesh.divSchemes["div(phiJm,p)"] = "Gauss linear";
+    try { qgdFlux(mesh, phi, "phiJm", p, pf); return 13; } catch (const FatalError& e) { if (e.status != QGD_ERR_NOT_IMPLEMENTED) return 14; }
     mesh.registry.clear();
     qgd_device_free(mesh.device);
     qgd_mesh_free(m);

@@ -60,6 +60,24 @@ lib.orc_case_halo_unpack.argtypes = [C.c_void_p, C.c_int, dp]
 lib.orc_case_step_phase.argtypes = [C.c_void_p, C.c_int]
 lib.orc_case_reduction.argtypes = [C.c_void_p, dp, C.c_int]
 
+class QhdOptions(C.Structure):
+    """orc_qhd_options == qgd_qhd_options"""
+    _fields_ = [("stencil", C.c_int32), ("implicitDiffusion", C.c_int32), ("tauModel", C.c_int32), ("pRefCell", C.c_int32),
+                ("pMaxIter", C.c_int32), ("precond", C.c_int32),
+                ("rho0", C.c_double), ("mu", C.c_double), ("Pr", C.c_double), ("beta", C.c_double), ("g", C.c_double * 3),
+                ("deltaT", C.c_double), ("Tau", C.c_double), ("aQGD", C.c_double), ("UQHD", C.c_double), ("T0", C.c_double),
+                ("Gr", C.c_double), ("pTol", C.c_double), ("pRelTol", C.c_double), ("pRefValue", C.c_double)]
+
+
+lib.orc_qhd_case_create.restype = C.c_void_p
+lib.orc_qhd_case_create.argtypes = [C.c_void_p, C.POINTER(QhdOptions)]
+lib.orc_qhd_case_free.argtypes = [C.c_void_p]
+lib.orc_qhd_case_set_bc.argtypes = [C.c_void_p, C.c_int32, C.c_int32, dp, C.c_int32, C.c_double, C.c_int32, C.c_double]
+lib.orc_qhd_case_set_fields.argtypes = [C.c_void_p, dp, dp, dp]
+lib.orc_qhd_case_step.argtypes = [C.c_void_p, C.c_int32]
+lib.orc_qhd_case_get_field.argtypes = [C.c_void_p, C.c_char_p, dp, C.c_int64]
+lib.orc_qhd_case_info.argtypes = [C.c_void_p, dp]
+
 _NCOMP = {"U": 3, "rhoU": 3, "phiJmU": 3, "phiP": 3, "phiPi": 3, "gradUf": 9, "gradef": 3, "gradRhof": 3, "gradPf": 3,
           "Uf": 3, "Pif": 9, "qf": 3, "jm": 3}
 _FACE = {"phiJm", "phiJmU", "phiP", "phiPi", "phiJmH", "phiQ", "phiPiU", "phiwStar", "phi", "tauQGDf", "hQGDf", "gradUf",
@@ -260,3 +278,54 @@ def species_flux(omesh, scheme, Yc, Yb, Uc, Ub, jm, ph, tau, phiJmY, diffusiveFl
     """drop-in for the `call` hook of qgdsolver_amd.qgdfoam.speciesFlux; returns the status code"""
     return lib.orc_species_flux(omesh._h, scheme.encode(), _d(Yc), _d(Yb), _d(Uc), _d(Ub), _d(jm), _d(ph), _d(tau), _d(phiJmY),
                                 _d(diffusiveFlux), _d(gradYf))
+
+
+class OracleQhdCase:
+    """QHDFoam case of the oracle (explicit branch of QHDFoam.C L83-139); mirrors qgdsolver_amd.qhdfoam.QHDFoamCase"""
+    KINDS = {"zeroGradient": 0, "fixedValue": 1, "slip": 2, "fixedGradient": 3, "qhdFlux": 3, "none": 4, "qhdFluxCoupled": 5}
+
+    def __init__(self, omesh, options):
+        self.mesh = omesh
+        o = QhdOptions()
+        for f, _ in QhdOptions._fields_:
+            v = getattr(options, f)
+            if f == "g":
+                for k in range(3):
+                    o.g[k] = v[k]
+            else:
+                setattr(o, f, v)
+        self.options = o
+        self._h = lib.orc_qhd_case_create(omesh._h, C.byref(o))
+
+    def set_bc(self, patch, U=("zeroGradient", None), T=("zeroGradient", None), p=("zeroGradient", None)):
+        vu = np.asarray(U[1] if U[1] is not None else (0.0, 0.0, 0.0), dtype=np.float64)
+        assert lib.orc_qhd_case_set_bc(self._h, patch, self.KINDS[U[0]], _d(vu), self.KINDS[T[0]], float(T[1] or 0.0), self.KINDS[p[0]],
+                                       float(p[1] or 0.0)) == 0
+
+    def set_fields(self, U, T, p):
+        a = [np.ascontiguousarray(x, dtype=np.float64) for x in (U, T, p)]
+        rc = lib.orc_qhd_case_set_fields(self._h, *[_d(x) for x in a])
+        assert rc == 0, rc
+
+    def step(self, n=1):
+        assert lib.orc_qhd_case_step(self._h, int(n)) == 0
+
+    def field(self, name):
+        base = name[:-len(".boundary")] if name.endswith(".boundary") else name
+        nc = 3 if base == "U" else 1
+        n = self.mesh.nBoundaryFaces if name.endswith(".boundary") else (self.mesh.nFaces if base in ("phi", "phiu", "phiwo", "tauQGDf") else self.mesh.nCells)
+        out = np.zeros((n, nc) if nc > 1 else (n,))
+        if n:
+            rc = lib.orc_qhd_case_get_field(self._h, name.encode(), _d(out), out.size)
+            assert rc == 0, (name, rc)
+        return out
+
+    def info(self):
+        a = (C.c_double * 6)()
+        lib.orc_qhd_case_info(self._h, a)
+        return dict(time=a[0], deltaT=a[1], pIterations=int(a[2]), pInitialResidual=a[3], pFinalResidual=a[4], steps=int(a[5]))
+
+    def close(self):
+        if self._h:
+            lib.orc_qhd_case_free(self._h)
+            self._h = None

@@ -82,3 +82,20 @@ def test_per_term_scheme_entry():
     assert rel_err(got_p, om.fvsc("GaussVolPoint", "grad_s", cell, bnd)[1]) <= TOL
     assert set(dev._registry) == {"reduced", "GaussVolPoint"}  # lookupOrNew caches one stencil per word
     dev.close()
+
+
+def test_gaussvolpoint_refused_on_wedge_meshes_with_prisms():
+    """fvsc.C L65-82: fatal for GaussVolPoint when the mesh has wedge patches and prism cells"""
+    from test_oracle_properties import wedge_prism_mesh
+    mesh = wedge_prism_mesh(True)
+    dev = q.Device(mesh, fv_schemes={"fvsc": {"default": "GaussVolPoint", "grad(r)": "reduced"}})
+    with pytest.raises(q.QgdError) as ei:
+        fvsc.grad(dev, q.volField("p", np.ones(1), np.ones(5)))
+    assert ei.value.code == q._lib.ERR_SCHEME and "wedge" in str(ei.value)
+    with pytest.raises(q.QgdError):
+        q.QGDFoamCase(dev, q.default_options(stencil="GaussVolPoint"))
+    fvsc.grad(dev, q.volField("r", np.ones(1), np.ones(5)))   # the other stencils are accepted
+    dev.close()
+    dev2 = q.Device(wedge_prism_mesh(False))
+    fvsc.grad(dev2, q.volField("p", np.ones(1), np.ones(5)))   # no wedge patch: accepted
+    dev2.close()

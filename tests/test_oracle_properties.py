@@ -266,3 +266,24 @@ def test_qgdflux_bc_sets_the_wall_mass_flux():
         b = f - mesh.nInternalFaces
         grad = dc[f] * (pb[b] - p[own[f]])
         assert np.allclose(grad, -phiw[f] / tau[f] / magSf[f], rtol=1e-9, atol=1e-12)
+
+
+def wedge_prism_mesh(wedge=True):
+    """one prism cell: triangles bottom/top on a generic patch, the three quadrilaterals split between a generic and a
+    wedge patch"""
+    import qgdsolver_amd as q
+    from qgdsolver_amd import _lib as L
+    pts = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1], [1, 0, 1], [0, 1, 1]], float)
+    faces = [[0, 2, 1], [3, 4, 5], [0, 1, 4, 3], [1, 2, 5, 4], [2, 0, 3, 5]]
+    return q.PolyMesh.from_arrays(pts, np.cumsum([0] + [len(f) for f in faces]), np.concatenate(faces), np.zeros(5, np.int32),
+                                  np.zeros(0, np.int32), 1, [0, 3], [3, 2], [L.PATCH_GENERIC, L.PATCH_WEDGE if wedge else L.PATCH_GENERIC])
+
+
+def test_gaussvolpoint_refused_on_wedge_meshes_with_prisms():
+    """fvsc.C L65-82: GaussVolPoint on a wedge mesh with prism cells is fatal; other stencils and non-wedge meshes are not"""
+    from oracle import OracleMesh
+    om = OracleMesh(wedge_prism_mesh(True).primitives())
+    assert om.fvsc("GaussVolPoint", "grad_s", np.ones(1), np.ones(5))[0] == -4
+    assert om.fvsc("reduced", "grad_s", np.ones(1), np.ones(5))[0] == 0
+    om2 = OracleMesh(wedge_prism_mesh(False).primitives())
+    assert om2.fvsc("GaussVolPoint", "grad_s", np.ones(1), np.ones(5))[0] == 0
