@@ -84,7 +84,11 @@ enum {
     QGD_BC_SLIP = 2,       /* basicSymmetry: U only (also used on symmetryPlane)  */
     QGD_BC_QGDFLUX = 3,    /* p only: qgdFluxFvPatchScalarField
                               [qgdFluxFvPatchScalarField_8C_source.html L159-197] */
-    QGD_BC_NONE = 4        /* empty / halo patches                                */
+    QGD_BC_NONE = 4,       /* empty / halo patches                                */
+    QGD_BC_QHDFLUX = 5     /* p of the QHD case only: qhdFlux fed by the registered flux, gradient =
+                              -(phiw/tauQGDf*rhof/|Sf|) [qhdFluxFvPatchScalarField_8C_source.html L193-203], as in the
+                              QHD solvers that register "phiwStar" (mulesQHDFoam/createFields.H); QHDFoam itself does not,
+                              there the patch keeps the gradient of its file = QGD_BC_QGDFLUX with that value */
 };
 
 /* ---- fvsc stencil words [fvsc_8C_source.html L60-65] ---------------------- */
@@ -293,6 +297,41 @@ int qgd_poisson_control_default(qgd_poisson_control* c);
 int qgd_qhd_pressure(qgd_device_t d, const double* phiu, const double* phiwo, const double* taubyrhof,
                      const int32_t* patchKind, const double* pb, const double* gradb, const qgd_poisson_control* ctl,
                      double* p, double* phi, double info[3]);
+
+/* ---- QHDFoam case resident on the device --------------------------------------------------------------------------- */
+/* The loop body of QHDFoam [QHDFoam_8C_source.html L83-139], explicit branch (implicitDiffusion false): updateFields.H,
+ * updateFluxes.H, the pressure equation QHDpEqn.H L35-47 (conjugate gradients preconditioned by an aggregation multigrid
+ * built once: the matrix does not change, QHDFoam never re-corrects its thermo inside the loop), QHDUEqn.H L36-84,
+ * QHDTEqn.H L65-91, the reference level of p (L123-130).  Thermo: rhoConst + constTransport (uniform rho0, mu, Pr; the QHD
+ * closures leave muQGD = alphauQGD = 0 [T0byGr_8C_source.html L62-72]), laminar; L0 discretisation assumed: Gauss linear
+ * gradients, Gauss linear uncorrected laplacians, Euler ddt.  Unsharded meshes only. */
+typedef struct qgd_qhd_options {
+    int32_t stencil;          /* QGD_FVSC_*                                                                    */
+    int32_t implicitDiffusion;/* must be 0                                                                     */
+    int32_t tauModel;         /* QGDCoeffs closure: 0 constTau (Tau), 1 HbyUQHD (aQGD, UQHD), 2 T0byGr (T0, Gr),
+                                 3 H2bynuQHD (aQGD; nu = mu/rho0)                                                */
+    int32_t pRefCell;         /* fvSolution pRefCell; < 0: no reference level                                  */
+    int32_t pMaxIter;
+    int32_t precond;          /* 1 aggregation multigrid (default), 0 Jacobi                                    */
+    double rho0, mu, Pr, beta, g[3], deltaT;
+    double Tau, aQGD, UQHD, T0, Gr;
+    double pTol, pRelTol, pRefValue;
+} qgd_qhd_options;
+typedef struct qgd_qhd_case_s* qgd_qhd_case_t;
+int qgd_qhd_options_default(qgd_qhd_options* opt);
+int qgd_qhd_case_create(qgd_device_t d, const qgd_qhd_options* opt, qgd_qhd_case_t* out);
+int qgd_qhd_case_free(qgd_qhd_case_t c);
+/* per patch: U zeroGradient | fixedValue | slip; T zeroGradient | fixedValue; p zeroGradient | fixedValue (valueP) |
+ * QGD_BC_QGDFLUX = fixedGradient with gradient valueP (what qhdFlux is inside QHDFoam) | QGD_BC_QHDFLUX (see the enum) */
+int qgd_qhd_case_set_bc(qgd_qhd_case_t c, int32_t patch, int32_t bcU, const double* valueU, int32_t bcT, double valueT,
+                        int32_t bcP, double valueP);
+int qgd_qhd_case_set_fields(qgd_qhd_case_t c, const double* U, const double* T, const double* p);
+int qgd_qhd_case_step(qgd_qhd_case_t c, int32_t nSteps);
+/* "U","T","p" (+ ".boundary"), face fields "phi","phiu","phiwo","tauQGDf" */
+int qgd_qhd_case_get_field(qgd_qhd_case_t c, const char* name, double* out, int64_t outDoubles);
+/* info[0]=time, [1]=deltaT, [2..4]= iterations / initial / final normalised residual of the last pressure solve,
+ * [5]=steps, [6]=multigrid levels, [7]=milliseconds of the last pressure solve */
+int qgd_qhd_case_info(qgd_qhd_case_t c, double info[8]);
 
 /* ---- QGDFoam case ----------------------------------------------------------- */
 

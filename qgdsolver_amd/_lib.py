@@ -46,6 +46,15 @@ class CaseOptions(C.Structure):
     ]
 
 
+class QhdOptions(C.Structure):
+    """qgd_qhd_options"""
+    _fields_ = [("stencil", C.c_int32), ("implicitDiffusion", C.c_int32), ("tauModel", C.c_int32), ("pRefCell", C.c_int32),
+                ("pMaxIter", C.c_int32), ("precond", C.c_int32),
+                ("rho0", C.c_double), ("mu", C.c_double), ("Pr", C.c_double), ("beta", C.c_double), ("g", C.c_double * 3),
+                ("deltaT", C.c_double), ("Tau", C.c_double), ("aQGD", C.c_double), ("UQHD", C.c_double), ("T0", C.c_double),
+                ("Gr", C.c_double), ("pTol", C.c_double), ("pRelTol", C.c_double), ("pRefValue", C.c_double)]
+
+
 # every symbol include/qgd_amd.h declares: name -> (restype, argtypes)
 SIGNATURES = {
     "qgd_version": (C.c_char_p, []),
@@ -79,6 +88,14 @@ SIGNATURES = {
     "qgd_flux": (C.c_int, [handle, C.c_int32, c_double_p, c_double_p, c_double_p]),
     "qgd_device_get": (C.c_int, [handle, C.c_char_p, c_double_p, C.c_int64]),
     "qgd_qhd_fluxes": (C.c_int, [handle, C.c_int, C.c_void_p, C.c_void_p]),
+    "qgd_qhd_options_default": (C.c_int, [C.POINTER(QhdOptions)]),
+    "qgd_qhd_case_create": (C.c_int, [handle, C.POINTER(QhdOptions), handle_p]),
+    "qgd_qhd_case_free": (C.c_int, [handle]),
+    "qgd_qhd_case_set_bc": (C.c_int, [handle, C.c_int32, C.c_int32, c_double_p, C.c_int32, C.c_double, C.c_int32, C.c_double]),
+    "qgd_qhd_case_set_fields": (C.c_int, [handle, c_double_p, c_double_p, c_double_p]),
+    "qgd_qhd_case_step": (C.c_int, [handle, C.c_int32]),
+    "qgd_qhd_case_get_field": (C.c_int, [handle, C.c_char_p, c_double_p, C.c_int64]),
+    "qgd_qhd_case_info": (C.c_int, [handle, c_double_p]),
     "qgd_case_options_default": (C.c_int, [C.POINTER(CaseOptions)]),
     "qgd_case_create": (C.c_int, [handle, C.POINTER(CaseOptions), handle_p]),
     "qgd_case_free": (C.c_int, [handle]),
@@ -125,7 +142,7 @@ for _name, (_res, _args) in SIGNATURES.items():
 QGD_OK = 0
 ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_SCHEME, ERR_UNKNOWN_NAME, ERR_NOT_IMPLEMENTED = -1, -2, -3, -4, -5, -6
 PATCH_GENERIC, PATCH_EMPTY, PATCH_SYMMETRYPLANE, PATCH_SYMMETRY, PATCH_WEDGE, PATCH_CYCLIC, PATCH_HALO = range(7)
-BC_ZEROGRADIENT, BC_FIXEDVALUE, BC_SLIP, BC_QGDFLUX, BC_NONE = range(5)
+BC_ZEROGRADIENT, BC_FIXEDVALUE, BC_SLIP, BC_QGDFLUX, BC_NONE, BC_QHDFLUX = range(6)
 FVSC_REDUCED, FVSC_LEASTSQUARES, FVSC_GAUSSVOLPOINT = range(3)
 K_POINT, K_FACE, K_BFACE, K_CELL, K_BC, K_BPOINT = range(6)
 

@@ -1270,6 +1270,214 @@ int qgd_case_halo_unpack(qgd_case_t c, int slot, const double* recvBufDevice) {
     QGD_CATCH
 }
 
+// ---- QHDFoam case resident on the device -------------------------------------------------------------------------------
+struct qgd_qhd_case_s {
+    qgd_device_s* dev = nullptr;
+    qgd_qhd_options opt{};
+    int stencil = ST_GVP3;
+    bool usesPoints = true, fieldsSet = false;
+    std::vector<PatchBCDev> bc;
+    PatchBCDev* bcDev = nullptr;
+    DeviceArena arena;
+    QhdView view{};
+    double *tauF = nullptr, *tbr = nullptr, *scratch = nullptr;
+    uint8_t* bKind = nullptr;
+    PressureSolver* solver = nullptr;
+    bool needRef = false;
+    double time = 0, lastIter = 0, lastRes0 = 0, lastRes = 0, lastSolveMs = 0;
+    int64_t steps = 0;
+};
+
+int qgd_qhd_options_default(qgd_qhd_options* o) {
+    if (!o) return fail(QGD_ERR_INVALID, "null argument");
+    std::memset(o, 0, sizeof(*o));
+    o->stencil = QGD_FVSC_GAUSSVOLPOINT;
+    o->tauModel = 2; o->pRefCell = 0; o->pMaxIter = 1000; o->precond = 1;
+    o->rho0 = 1.0; o->mu = 1e-3; o->Pr = 0.71; o->beta = 3e-3; o->g[1] = -9.81; o->deltaT = 1e-3;
+    o->Tau = 1e-3; o->aQGD = 0.5; o->UQHD = 1.0; o->T0 = 1.0; o->Gr = 1e3; o->pTol = 1e-8; o->pRelTol = 0.0; o->pRefValue = 0.0;
+    return QGD_OK;
+}
+int qgd_qhd_case_create(qgd_device_t d, const qgd_qhd_options* opt, qgd_qhd_case_t* out) {
+    QGD_TRY
+    if (!d || !opt || !out) return fail(QGD_ERR_INVALID, "qgd_qhd_case_create: null argument");
+    if (opt->implicitDiffusion) return fail(QGD_ERR_NOT_IMPLEMENTED, "implicitDiffusion true: only the explicit branch is on this path");
+    if (d->sharded()) return fail(QGD_ERR_NOT_IMPLEMENTED, "qgd_qhd_case_create: the QHD case (pressure equation, fvc::grad(U)) is not distributed");
+    if (!(opt->rho0 > 0) || !(opt->Pr > 0) || !(opt->deltaT > 0) || opt->tauModel < 0 || opt->tauModel > 3)
+        return fail(QGD_ERR_INVALID, "qgd_qhd_case_create: rho0, Pr, deltaT must be positive, tauModel in 0..3");
+    int st = 0;
+    int rc = deviceStencil(d, opt->stencil, &st);
+    if (rc) return rc;
+    HIP_CHECK(hipSetDevice(d->deviceId));
+    qgd_qhd_case_s* c = new qgd_qhd_case_s();
+    try {
+        c->dev = d; c->opt = *opt; c->stencil = st;
+        c->usesPoints = (st == ST_GVP3 || st == ST_GVP2);
+        const MeshView& v = d->view;
+        if (opt->pRefCell >= v.nC) { delete c; return fail(QGD_ERR_INVALID, "qgd_qhd_case_create: pRefCell out of range"); }
+        DeviceArena& a = c->arena;
+        QhdView& q = c->view;
+        const size_t nC = (size_t)v.nC, nB = (size_t)std::max(v.nBF, 1), nF = (size_t)v.nF, nP = (size_t)std::max(v.nP, 1);
+        q.c4 = a.alloc<double>(4 * nC); q.b4 = a.alloc<double>(4 * nB); q.pt4 = a.alloc<double>(4 * nP);
+        q.p = a.alloc<double>(nC); q.pb = a.alloc<double>(nB); q.pgb = a.alloc<double>(nB); q.ptp = a.alloc<double>(nP);
+        c->tauF = a.alloc<double>(nF); c->tbr = a.alloc<double>(nF); q.tauF = c->tauF;
+        q.phiu = a.alloc<double>(nF); q.phiwo = a.alloc<double>(nF); q.phi = a.alloc<double>(nF); q.phitr = a.alloc<double>(nF);
+        q.ugu = a.alloc<double>(3 * nF); q.bdf = a.alloc<double>(3 * nF); q.gUc = a.alloc<double>(9 * nC); q.F = a.alloc<double>(4 * nF);
+        c->scratch = a.alloc<double>(8);
+        q.rho0 = opt->rho0; q.nu = opt->mu / opt->rho0; q.Hi = (opt->mu / opt->Pr) / opt->rho0; q.beta = opt->beta;
+        for (int k = 0; k < 3; ++k) q.g[k] = opt->g[k];
+        q.dt = opt->deltaT; q.tauModel = opt->tauModel; q.Tau = opt->Tau; q.aQGD = opt->aQGD; q.UQHD = opt->UQHD; q.T0 = opt->T0; q.Gr = opt->Gr;
+        c->bc.resize(d->patches.size());
+        for (size_t i = 0; i < d->patches.size(); ++i) {
+            PatchBCDev& b = c->bc[i];
+            std::memset(&b, 0, sizeof(b));
+            b.ptype = d->patches[i].type;
+            const bool none = b.ptype == QGD_PATCH_EMPTY || b.ptype == QGD_PATCH_HALO;
+            b.bcU = b.bcT = b.bcP = none ? QGD_BC_NONE : QGD_BC_ZEROGRADIENT;
+        }
+        c->bcDev = a.alloc<PatchBCDev>(std::max<size_t>(1, c->bc.size()));
+        c->bKind = a.alloc<uint8_t>(nB);
+    } catch (...) { c->arena.release(); delete c; throw; }
+    *out = c;
+    return QGD_OK;
+    QGD_CATCH
+}
+int qgd_qhd_case_free(qgd_qhd_case_t c) {
+    if (!c) return QGD_OK;
+    (void)hipSetDevice(c->dev->deviceId);
+    if (c->solver) pressureSolverFree(c->solver);
+    c->arena.release();
+    delete c;
+    return QGD_OK;
+}
+int qgd_qhd_case_set_bc(qgd_qhd_case_t c, int32_t patch, int32_t bcU, const double* valueU, int32_t bcT, double valueT, int32_t bcP,
+                        double valueP) {
+    QGD_TRY
+    if (!c) return fail(QGD_ERR_INVALID, "null case");
+    if (patch < 0 || patch >= (int32_t)c->bc.size()) return fail(QGD_ERR_INVALID, "qgd_qhd_case_set_bc: patch out of range");
+    auto okU = [](int k) { return k == QGD_BC_ZEROGRADIENT || k == QGD_BC_FIXEDVALUE || k == QGD_BC_SLIP || k == QGD_BC_NONE; };
+    auto okT = [](int k) { return k == QGD_BC_ZEROGRADIENT || k == QGD_BC_FIXEDVALUE || k == QGD_BC_NONE; };
+    auto okP = [](int k) { return k == QGD_BC_ZEROGRADIENT || k == QGD_BC_FIXEDVALUE || k == QGD_BC_QGDFLUX || k == QGD_BC_QHDFLUX || k == QGD_BC_NONE; };
+    if (!okU(bcU) || !okT(bcT) || !okP(bcP)) return fail(QGD_ERR_INVALID, "qgd_qhd_case_set_bc: unsupported boundary-condition kind");
+    PatchBCDev& b = c->bc[patch];
+    if (b.ptype == QGD_PATCH_EMPTY || b.ptype == QGD_PATCH_HALO) { bcU = bcT = bcP = QGD_BC_NONE; }
+    b.bcU = bcU; b.bcT = bcT; b.bcP = bcP; b.vT = valueT; b.vP = valueP;
+    if (valueU) for (int k = 0; k < 3; ++k) b.vU[k] = valueU[k];
+    c->fieldsSet = false;
+    return QGD_OK;
+    QGD_CATCH
+}
+int qgd_qhd_case_set_fields(qgd_qhd_case_t c, const double* U, const double* T, const double* p) {
+    QGD_TRY
+    if (!c || !U || !T || !p) return fail(QGD_ERR_INVALID, "qgd_qhd_case_set_fields: null argument");
+    qgd_device_s* d = c->dev;
+    HIP_CHECK(hipSetDevice(d->deviceId));
+    const MeshView& m = d->view;
+    if (!c->bc.empty()) HIP_CHECK(hipMemcpy(c->bcDev, c->bc.data(), sizeof(PatchBCDev) * c->bc.size(), hipMemcpyHostToDevice));
+    // matrix kinds of the pressure equation per boundary face; fvMatrix::setReference acts only without a fixedValue patch
+    std::vector<uint8_t> kind((size_t)std::max(m.nBF, 1), 0);
+    bool anyFixed = false;
+    for (size_t ip = 0; ip < d->patches.size(); ++ip) {
+        const Patch& pt = d->patches[ip];
+        int k = c->bc[ip].bcP;
+        if (pt.type != QGD_PATCH_GENERIC) k = QGD_BC_NONE;
+        const uint8_t kk = k == QGD_BC_FIXEDVALUE ? 1 : ((k == QGD_BC_QGDFLUX || k == QGD_BC_QHDFLUX) ? 2 : 0);
+        if (kk == 1 && pt.size > 0) anyFixed = true;
+        for (int32_t f = pt.start; f < pt.start + pt.size; ++f) kind[(size_t)(f - m.nIF)] = kk;
+    }
+    HIP_CHECK(hipMemcpy(c->bKind, kind.data(), kind.size(), hipMemcpyHostToDevice));
+    c->needRef = !anyFixed && c->opt.pRefCell >= 0;
+    Workspace& ws = d->ws;
+    double* dU = ws.get<double>(WS_CELL, 3 * (size_t)m.nC);
+    double* dT = ws.get<double>(WS_A, (size_t)m.nC);
+    double* dp = ws.get<double>(WS_B, (size_t)m.nC);
+    ws.h2d(dU, U, sizeof(double) * 3 * (size_t)m.nC, d->stream);
+    ws.h2d(dT, T, sizeof(double) * (size_t)m.nC, d->stream);
+    ws.h2d(dp, p, sizeof(double) * (size_t)m.nC, d->stream);
+    (void)hipGetLastError();
+    HIP_CHECK(hipMemsetAsync(c->view.phiwo, 0, sizeof(double) * (size_t)m.nF, d->stream));
+    launchQhdInit(d->stream, m, c->view, c->bcDev, dU, dT, dp, c->tauF, c->tbr);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(d->stream));
+    if (c->solver) { pressureSolverFree(c->solver); c->solver = nullptr; }
+    c->solver = pressureSolverCreate(d->stream, m, c->tbr, c->bKind, c->needRef ? c->opt.pRefCell : -1, c->opt.precond);
+    c->fieldsSet = true;
+    c->time = 0; c->steps = 0;
+    return QGD_OK;
+    QGD_CATCH
+}
+int qgd_qhd_case_step(qgd_qhd_case_t c, int32_t nSteps) {
+    QGD_TRY
+    if (!c) return fail(QGD_ERR_INVALID, "null case");
+    if (!c->fieldsSet) return fail(QGD_ERR_INVALID, "qgd_qhd_case_step: call qgd_qhd_case_set_fields first");
+    qgd_device_s* d = c->dev;
+    HIP_CHECK(hipSetDevice(d->deviceId));
+    const MeshView& m = d->view;
+    for (int i = 0; i < nSteps; ++i) {
+        (void)hipGetLastError();
+        launchQhdAssemble(d->stream, c->stencil, c->usesPoints, m, c->view, c->bcDev);
+        HIP_CHECK(hipGetLastError());
+        double res[2] = {0, 0};
+        const double t0 = nowMs();
+        const int it = pressureSolve(c->solver, c->view.phiu, c->view.phiwo, c->view.pb, c->view.pgb, c->opt.pTol, c->opt.pRelTol, c->opt.pMaxIter,
+                                     c->view.p, c->view.phi, res);
+        HIP_CHECK(hipStreamSynchronize(d->stream));
+        c->lastSolveMs = nowMs() - t0;
+        c->lastIter = it; c->lastRes0 = res[0]; c->lastRes = res[1];
+        launchQhdAdvance(d->stream, c->stencil, c->usesPoints, m, c->view, c->bcDev, c->needRef ? c->opt.pRefCell : -1, c->opt.pRefValue, c->scratch);
+        HIP_CHECK(hipGetLastError());
+        c->time += c->opt.deltaT;
+        c->steps++;
+    }
+    HIP_CHECK(hipStreamSynchronize(d->stream));
+    return QGD_OK;
+    QGD_CATCH
+}
+int qgd_qhd_case_get_field(qgd_qhd_case_t c, const char* name, double* out, int64_t outDoubles) {
+    QGD_TRY
+    if (!c || !name || !out) return fail(QGD_ERR_INVALID, "qgd_qhd_case_get_field: null argument");
+    qgd_device_s* d = c->dev;
+    HIP_CHECK(hipSetDevice(d->deviceId));
+    HIP_CHECK(hipStreamSynchronize(d->stream));
+    const MeshView& m = d->view;
+    std::string s(name);
+    const std::string suffix = ".boundary";
+    bool bnd = false;
+    if (s.size() > suffix.size() && s.compare(s.size() - suffix.size(), suffix.size(), suffix) == 0) { bnd = true; s = s.substr(0, s.size() - suffix.size()); }
+    const int64_t n = bnd ? m.nBF : m.nC;
+    const QhdView& q = c->view;
+    const double* direct = nullptr;
+    int64_t count = 0;
+    if (s == "p") { direct = bnd ? q.pb : q.p; count = n; }
+    else if (!bnd && s == "phi") { direct = q.phi; count = m.nF; }
+    else if (!bnd && s == "phiu") { direct = q.phiu; count = m.nF; }
+    else if (!bnd && s == "phiwo") { direct = q.phiwo; count = m.nF; }
+    else if (!bnd && s == "tauQGDf") { direct = c->tauF; count = m.nF; }
+    if (direct) {
+        if (count > outDoubles) return fail(QGD_ERR_INVALID, "output too small");
+        if (count) d->ws.d2h(out, direct, sizeof(double) * (size_t)count, d->stream);
+        return QGD_OK;
+    }
+    if (s != "U" && s != "T") return fail(QGD_ERR_UNKNOWN_NAME, "qgd_qhd_case_get_field: unknown field " + s);
+    const int nc = s == "U" ? 3 : 1;
+    if (n * nc > outDoubles) return fail(QGD_ERR_INVALID, "output too small");
+    if (n == 0) return QGD_OK;
+    double* tmp = d->ws.get<double>(WS_OUT, (size_t)(n * nc));
+    (void)hipGetLastError();
+    launchQhdExtract(d->stream, n, bnd ? q.b4 : q.c4, s == "U" ? 0 : 1, tmp);
+    HIP_CHECK(hipGetLastError());
+    d->ws.d2h(out, tmp, sizeof(double) * (size_t)(n * nc), d->stream);
+    return QGD_OK;
+    QGD_CATCH
+}
+int qgd_qhd_case_info(qgd_qhd_case_t c, double info[8]) {
+    if (!c || !info) return fail(QGD_ERR_INVALID, "null argument");
+    int sizes[16];
+    info[0] = c->time; info[1] = c->opt.deltaT; info[2] = c->lastIter; info[3] = c->lastRes0; info[4] = c->lastRes; info[5] = (double)c->steps;
+    info[6] = c->solver ? (double)pressureSolverLevels(c->solver, sizes, 16) : 0.0;
+    info[7] = c->lastSolveMs;
+    return QGD_OK;
+}
+
 // ---- native halo transport: RCCL send/recv inside the library -----------------------------------------------------------
 // Replaces, for a C++/MPI host, what the reference does per gradient call with PstreamBuffers
 // [extendedFaceStencilScalarGrad_8C L145-233] and with processor-patch evaluation [GaussVolPointStencil_8C L73]:

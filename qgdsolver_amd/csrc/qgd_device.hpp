@@ -140,6 +140,35 @@ void launchQhdFluxes(hipStream_t s, int stencil, const MeshView& m, const double
 void launchSpeciesFlux(hipStream_t s, int stencil, const MeshView& m, const double* Y, const double* Yb, double* ptY,
                        const double* U, const double* Ub, const double* phiJm, const double* phi, const double* tau, double* out);
 
+// ---- QHDFoam case resident on the device (qgd_qhd.hip) ---------------------------------------------------------------
+struct QhdView {
+    double* c4;  double* b4;  double* pt4;     // {Ux,Uy,Uz,T}: cells (nC*4), patch faces (nBF*4), vertices (nP*4)
+    double* p;   double* pb;  double* pgb;  double* ptp;   // p: cells, patch values, patch gradients, vertices
+    const double* tauF;                        // nF tauQGDf
+    double *phiu, *phiwo, *phi, *phitr;        // nF
+    double *ugu, *bdf;                         // 3*nF SoA: Uf & gradUf, BdFrcf
+    double* gUc;                               // 9*nC fvc::grad(U)
+    double* F;                                 // 4*nF SoA: net face terms of the U (3) and T equations
+    double rho0, nu, Hi, beta, g[3], dt;
+    int32_t tauModel;                          // 0 constTau, 1 HbyUQHD, 2 T0byGr, 3 H2bynuQHD
+    double Tau, aQGD, UQHD, T0, Gr;
+};
+void launchQhdInit(hipStream_t s, const MeshView& m, const QhdView& q, const PatchBCDev* bc, const double* U, const double* T, const double* p,
+                   double* tauF, double* taubyrho);
+void launchQhdAssemble(hipStream_t s, int stencil, bool usesPoints, const MeshView& m, const QhdView& q, const PatchBCDev* bc);
+void launchQhdAdvance(hipStream_t s, int stencil, bool usesPoints, const MeshView& m, const QhdView& q, const PatchBCDev* bc, int refCell,
+                      double refValue, double* scratch);
+void launchQhdExtract(hipStream_t s, int64_t n, const double* rec4, int field, double* out);
+
+// persistent pressure solver: PCG preconditioned by aggregation multigrid (precond 1) or Jacobi (0); qgd_poisson.hip
+struct PressureSolver;
+PressureSolver* pressureSolverCreate(hipStream_t stream, const MeshView& m, const double* taubyrho, const uint8_t* bKind, int refCell, int precond);
+void pressureSolverFree(PressureSolver* S);
+int64_t pressureSolverBytes(const PressureSolver* S);
+int pressureSolverLevels(const PressureSolver* S, int* sizes, int cap);
+int pressureSolve(PressureSolver* S, const double* phiu, const double* phiwo, const double* pb, const double* gb, double tolerance,
+                  double relTol, int maxIter, double* p, double* phi, double residuals[2]);
+
 // ---- QHDFoam pressure equation (qgd_poisson.hip) -------------------------------------
 // all pointers are device memory; work holds 8*nC + nF + max(nBF,1) + 3*ceil(nC/256) + 8 doubles
 int solveQhdPressure(hipStream_t stream, const MeshView& m, const double* gamma, const double* phiu, const double* phiwo,

@@ -684,30 +684,6 @@ void pointInterpRecKernel(const MeshView m, const RecA* __restrict__ A, RecA* __
     P[p] = acc;
 }
 
-// patch points: weighted mean of the surrounding boundary-face values.  Source
-// and destination strides/offset are free so the qgdFlux pass can refresh the
-// pressure component alone from the mid-step patch pressures.
-template <int NC>
-__global__ __launch_bounds__(QGD_BLOCK) void boundaryPointKernel(const MeshView m, const double* __restrict__ bndF,
-                                                                const int bndStride, double* __restrict__ ptF,
-                                                                const int ptStride, const int ptOffset) {
-    const int i = blockIdx.x * QGD_BLOCK + threadIdx.x;
-    if (i >= m.nBP) return;
-    const int p = m.bpPoint[i];
-    double acc[NC];
-#pragma unroll
-    for (int k = 0; k < NC; ++k) acc[k] = 0.0;
-    for (int e = m.bpOff[i]; e < m.bpOff[i + 1]; ++e) {
-        const double w = m.bpW[e];
-        const double* bv = bndF + (size_t)m.bpFace[e] * bndStride;
-#pragma unroll
-        for (int k = 0; k < NC; ++k) acc[k] += w * bv[k];
-    }
-    double* o = ptF + (size_t)p * ptStride + ptOffset;
-#pragma unroll
-    for (int k = 0; k < NC; ++k) o[k] = acc[k];
-}
-
 // ---------------------------------------------------------------------------
 // cell update: gather of the net face fluxes in ascending face order (the
 // summation order of fvc::surfaceIntegrate), explicit Euler, thermo, QGD coeffs
@@ -1132,43 +1108,6 @@ __global__ __launch_bounds__(QGD_BLOCK) void fvscGradGvp3Kernel(const MeshView m
     const int64_t cnt = ((m.nIF - first) < QGD_BLOCK ? (m.nIF - first) : QGD_BLOCK) * 3 * NC;
     double* dst = out + first * 3 * NC;
     for (int i = threadIdx.x; i < cnt; i += QGD_BLOCK) dst[i] = stage[i];
-}
-
-// cell -> vertex interpolation of a plain NC-component field with the structure of pointInterpRecKernel (sliced-ELL list
-// read as contiguous runs, eight gathers in flight before the ordered sum)
-template <int NC>
-__global__ __launch_bounds__(QGD_BLOCK) void pointInterpFastKernel(const MeshView m, const double* __restrict__ cellF,
-                                                                  double* __restrict__ ptF) {
-    const int p = xcdTile((int)gridDim.x, m.xcdRun) * QGD_BLOCK + threadIdx.x;
-    if (p >= m.nP) return;
-    const int n = m.pcCount[p];
-    if (n == 0) return;
-    const size_t base = (size_t)m.pcSlice[p >> 6] * 64 + (p & 63);
-    double acc[NC];
-#pragma unroll
-    for (int k = 0; k < NC; ++k) acc[k] = 0.0;
-    for (int i = 0; i < n; i += 8) {
-        int id[8];
-        double w[8], r[8][NC];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const bool on = i + q < n;
-            id[q] = on ? m.pcCell[base + (size_t)(i + q) * 64] : 0;
-            w[q] = on ? m.pcW[base + (size_t)(i + q) * 64] : 0.0;
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-#pragma unroll
-            for (int k = 0; k < NC; ++k) r[q][k] = (i + q < n) ? cellF[(size_t)id[q] * NC + k] : 0.0;
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-            if (i + q < n)
-#pragma unroll
-                for (int k = 0; k < NC; ++k) acc[k] += w[q] * r[q][k];
-    }
-#pragma unroll
-    for (int k = 0; k < NC; ++k) ptF[(size_t)p * NC + k] = acc[k];
 }
 
 // ---------------------------------------------------------------------------

@@ -1,0 +1,375 @@
+// qgd_qhd.hip -- QHDFoam's loop body resident on the device (explicit branch, QHDFoam_8C_source.html L83-139):
+//
+//   updateFields.H L36-73      gradUf, gradTf, Uf, Tf, BdFrcf                          face pass 1
+//   updateFluxes.H L33-38      phiu, phiwo, taubyrhof                                  face pass 1
+//   QHDpEqn.H L35-47           p BCs, pressure equation, phi                           qgd_poisson.hip
+//   QHDUEqn.H L36-84           gradPf, Wf, phiUf, fvc::laplacian, fvc::div(nu Sf & lin(T(grad U))), -grad(p)/rho + BdFrc
+//   QHDTEqn.H L65-91           phiTf, phiTauTReg, fvc::laplacian(Hif, T)               face pass 2 + cell update
+//   QHDFoam.C L123-130         reference level of p
+//
+// Thermo: rhoConst + constTransport (rho, mu, alpha = mu/Pr uniform; the QHD closures keep muQGD = alphauQGD = 0,
+// T0byGr_8C L62-72), not corrected inside the loop (the listing never calls thermo.correct() there), so tauQGDf and the
+// pressure matrix are those of start-up.  State: cell records {Ux,Uy,Uz,T} (32 B) and p separately (the solver's vector).
+#include "../../include/qgd_amd.h"
+#include "qgd_device.hpp"
+#include "qgd_stencil_dev.hpp"
+
+namespace qgd {
+
+namespace {
+
+// patch snGrad of {U,T} (4 components) on boundary face f: fvPatchField::snGrad = deltaCoeffs*(value - internal) (L0);
+// basicSymmetry::snGrad for slip
+__device__ __forceinline__ void qhdBoundaryVals4(const MeshView& m, const PatchBCDev& bc, const int f, const double* o4, const double* b4,
+                                                 FaceVals<4>& v) {
+    const double dc = m.dn[f];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v.o[k] = o4[k]; v.n[k] = b4[k]; v.sn[k] = dc * (b4[k] - o4[k]); }
+    if (bc.bcU == QGD_BC_SLIP) {
+        const double ms = m.magSf[f];
+        const double n[3] = {m.Sx[f] / ms, m.Sy[f] / ms, m.Sz[f] / ms};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double tv = ((i == 0 ? 1.0 : 0.0) - 2.0 * (n[i] * n[0])) * o4[0] + ((i == 1 ? 1.0 : 0.0) - 2.0 * (n[i] * n[1])) * o4[1] +
+                              ((i == 2 ? 1.0 : 0.0) - 2.0 * (n[i] * n[2])) * o4[2];
+            v.sn[i] = (tv - o4[i]) * (dc / 2.0);
+        }
+    } else if (bc.bcU != QGD_BC_FIXEDVALUE) v.sn[0] = v.sn[1] = v.sn[2] = 0.0;
+    if (bc.bcT != QGD_BC_FIXEDVALUE) v.sn[3] = 0.0;
+}
+
+// face pass 1 [updateFields.H L36-73, updateFluxes.H L33-38, QHDTEqn.H L66]
+template <int ST>
+__global__ __launch_bounds__(QGD_BLOCK) void qhdFace1Kernel(const MeshView m, const QhdView q, const PatchBCDev* __restrict__ bcs) {
+    const int f = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    if (f >= m.nF) return;
+    if (m.fkind[f] == 3) return;
+    const bool internal = f < m.nIF;
+    const int o = m.own[f];
+    FaceVals<4> v;
+    double w = 1.0;
+    if (internal) {
+        const int n = m.nei[f];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v.o[k] = q.c4[(size_t)o * 4 + k]; v.n[k] = q.c4[(size_t)n * 4 + k]; v.sn[k] = 0.0; }
+        w = m.w[f];
+    } else {
+        const int b = f - m.nIF;
+        qhdBoundaryVals4(m, bcs[m.bPatch[b]], f, q.c4 + (size_t)o * 4, q.b4 + (size_t)b * 4, v);
+    }
+    double g[12];
+    faceGradient<ST, 4, 0>(m, f, v, q.c4, q.pt4, g);   // g[i*4 + k] = d_i {Ux,Uy,Uz,T}_k
+    const double gv[3] = {q.g[0], q.g[1], q.g[2]};
+    double Uf[3], Bf[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        Uf[k] = internal ? lerpf(w, v.o[k], v.n[k]) : v.n[k];
+        Bf[k] = internal ? lerpf(w, (q.beta * v.o[3]) * gv[k], (q.beta * v.n[3]) * gv[k]) : (q.beta * v.n[3]) * gv[k];   // L66-67
+    }
+    const double S[3] = {m.Sx[f], m.Sy[f], m.Sz[f]};
+    const double tau = q.tauF[f];
+    const size_t nF = (size_t)m.nF;
+    const double phiu = S[0] * Uf[0] + S[1] * Uf[1] + S[2] * Uf[2];
+    double wo[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const double UgU = Uf[0] * g[0 * 4 + j] + Uf[1] * g[1 * 4 + j] + Uf[2] * g[2 * 4 + j];   // Uf & gradUf
+        q.ugu[(size_t)j * nF + f] = UgU;
+        q.bdf[(size_t)j * nF + f] = Bf[j];
+        wo[j] = tau * (UgU - Bf[j]);
+    }
+    q.phiu[f] = phiu;
+    q.phiwo[f] = S[0] * wo[0] + S[1] * wo[1] + S[2] * wo[2];
+    q.phitr[f] = tau * phiu * (Uf[0] * g[0 * 4 + 3] + Uf[1] * g[1 * 4 + 3] + Uf[2] * g[2 * 4 + 3]);
+}
+
+// p's boundary conditions [QHDpEqn.H L35]: fixedValue | fixedGradient (qhdFlux with the gradient of its file) |
+// qhdFlux fed by the registered flux [qhdFluxFvPatchScalarField_8C L193-203] | zeroGradient
+__global__ __launch_bounds__(QGD_BLOCK) void qhdPressureBcKernel(const MeshView m, const QhdView q, const PatchBCDev* __restrict__ bcs) {
+    const int b = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    if (b >= m.nBF) return;
+    const int f = m.nIF + b;
+    if (m.fkind[f] == 3) return;
+    const PatchBCDev bc = bcs[m.bPatch[b]];
+    const double po = q.p[m.own[f]];
+    double pb = po, gb = 0.0;
+    if (bc.bcP == QGD_BC_FIXEDVALUE) pb = bc.vP;
+    else if (bc.bcP == QGD_BC_QGDFLUX) { gb = bc.vP; pb = po + gb / m.dn[f]; }
+    else if (bc.bcP == QGD_BC_QHDFLUX) { gb = -(q.phiwo[f] / q.tauF[f] * q.rho0 / m.magSf[f]); pb = po + gb / m.dn[f]; }
+    q.pb[b] = pb;
+    q.pgb[b] = gb;
+}
+
+// fvc::grad(U), Gauss linear (L0): cell gather in ascending face order
+__global__ __launch_bounds__(QGD_BLOCK) void qhdCellGradKernel(const MeshView m, const QhdView q) {
+    const int c = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    if (c >= m.nC) return;
+    const int n = m.cfCount[c];
+    const size_t base = (size_t)m.cfSlice[c >> 6] * 64 + (c & 63);
+    double G[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < n; ++i) {
+        const int it = m.cfItem[base + (size_t)i * 64];
+        const int f = it >= 0 ? it : ~it;
+        if (m.fkind[f] == 3) continue;
+        double Uf[3];
+        if (f < m.nIF) {
+            const int o = m.own[f], nb = m.nei[f];
+            const double w = m.w[f];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) Uf[k] = lerpf(w, q.c4[(size_t)o * 4 + k], q.c4[(size_t)nb * 4 + k]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) Uf[k] = q.b4[(size_t)(f - m.nIF) * 4 + k];
+        }
+        const double S[3] = {m.Sx[f], m.Sy[f], m.Sz[f]};
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) G[3 * a + j] = it >= 0 ? G[3 * a + j] + S[a] * Uf[j] : G[3 * a + j] - S[a] * Uf[j];
+    }
+    const double V = m.V[c];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) q.gUc[(size_t)c * 9 + k] = G[k] / V;
+}
+
+// face pass 2 [QHDUEqn.H L36-84, QHDTEqn.H L65-91]: the net face terms of the U and T equations
+template <int ST>
+__global__ __launch_bounds__(QGD_BLOCK) void qhdFace2Kernel(const MeshView m, const QhdView q, const PatchBCDev* __restrict__ bcs) {
+    const int f = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    if (f >= m.nF) return;
+    const size_t nF = (size_t)m.nF;
+    if (m.fkind[f] == 3) { for (int k = 0; k < 4; ++k) q.F[(size_t)k * nF + f] = 0.0; return; }
+    const bool internal = f < m.nIF;
+    const int o = m.own[f];
+    const double S[3] = {m.Sx[f], m.Sy[f], m.Sz[f]};
+    const double magS = m.magSf[f];
+    double Uo[3], Un[3], To, Tn, snU[3], snT, pf, w = 1.0;
+    FaceVals<1> vp;
+    vp.o[0] = q.p[o];
+    double gUT[9];   // T(grad U) at the face: gUT[3i+j] = lin(gradU)[3j+i]
+#pragma unroll
+    for (int k = 0; k < 3; ++k) Uo[k] = q.c4[(size_t)o * 4 + k];
+    To = q.c4[(size_t)o * 4 + 3];
+    if (internal) {
+        const int n = m.nei[f];
+        w = m.w[f];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) Un[k] = q.c4[(size_t)n * 4 + k];
+        Tn = q.c4[(size_t)n * 4 + 3];
+        vp.n[0] = q.p[n]; vp.sn[0] = 0.0;
+        const double dn = m.dn[f];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) snU[k] = dn * (Un[k] - Uo[k]);   // fvc::snGrad, uncorrected (L0)
+        snT = dn * (Tn - To);
+        pf = lerpf(w, vp.o[0], vp.n[0]);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) gUT[3 * i + j] = lerpf(w, q.gUc[(size_t)o * 9 + 3 * j + i], q.gUc[(size_t)n * 9 + 3 * j + i]);
+    } else {
+        const int b = f - m.nIF;
+        const PatchBCDev bc = bcs[m.bPatch[b]];
+        FaceVals<4> v4;
+        qhdBoundaryVals4(m, bc, f, q.c4 + (size_t)o * 4, q.b4 + (size_t)b * 4, v4);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { Un[k] = v4.n[k]; snU[k] = v4.sn[k]; }
+        Tn = v4.n[3]; snT = v4.sn[3];
+        vp.n[0] = q.pb[b];
+        vp.sn[0] = (bc.bcP == QGD_BC_QGDFLUX || bc.bcP == QGD_BC_QHDFLUX) ? q.pgb[b] : (bc.bcP == QGD_BC_FIXEDVALUE ? m.dn[f] * (vp.n[0] - vp.o[0]) : 0.0);
+        pf = vp.n[0];
+        // patch value of fvc::grad(U): the owner's gradient with its normal part replaced by the patch snGrad
+        // (gaussGrad::correctBoundaryConditions, L0); cut (halo) faces keep the extrapolated value
+        double gb[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) gb[k] = q.gUc[(size_t)o * 9 + k];
+        if (bc.ptype != QGD_PATCH_HALO && bc.ptype != QGD_PATCH_CYCLIC) {
+            const double n[3] = {S[0] / magS, S[1] / magS, S[2] / magS};
+            double ng[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) ng[j] = n[0] * gb[j] + n[1] * gb[3 + j] + n[2] * gb[6 + j];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) gb[3 * i + j] += n[i] * (snU[j] - ng[j]);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) gUT[3 * i + j] = gb[3 * j + i];
+    }
+    double gP[3];
+    faceGradient<ST, 1, -1>(m, f, vp, q.p, q.ptp, gP);                                           // QHDUEqn.H L36
+    const double tau = q.tauF[f], phi = q.phi[f];
+    double Uf[3], Wf[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        Uf[k] = internal ? lerpf(w, Uo[k], Un[k]) : Un[k];
+        Wf[k] = tau * ((q.ugu[(size_t)k * nF + f] + gP[k] / q.rho0) - q.bdf[(size_t)k * nF + f]);   // L37
+    }
+    const double Tf = internal ? lerpf(w, To, Tn) : Tn;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const double uw = S[0] * (Uf[0] * Wf[j]) + S[1] * (Uf[1] * Wf[j]) + S[2] * (Uf[2] * Wf[j]);   // Sf & (Uf*Wf), L39
+        const double phiUf = phi * Uf[j] - uw;                                                       // L41-43
+        const double lap = q.nu * snU[j] * magS;                                                     // fvc::laplacian(muf/rhof, U), L74
+        const double ext = S[0] * gUT[0 * 3 + j] + S[1] * gUT[1 * 3 + j] + S[2] * gUT[2 * 3 + j];    // Sf & lin(T(grad U)), L76
+        // the Gauss term of -fvc::grad(p)/rho (uniform rho) rides in the same face flux: S_j p_f / rho
+        q.F[(size_t)j * nF + f] = ((phiUf - lap) - q.nu * ext) + (S[j] * pf) / q.rho0;
+    }
+    q.F[3 * nF + f] = (phi * Tf - q.Hi * snT * magS) - q.phitr[f];                                   // QHDTEqn.H L65-66, L85-88
+}
+
+// explicit Euler of the U and T equations [QHDUEqn.H L68-84, QHDTEqn.H L83-91]
+__global__ __launch_bounds__(QGD_BLOCK) void qhdCellUpdateKernel(const MeshView m, const QhdView q) {
+    const int c = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    if (c >= m.nC) return;
+    if (m.ghost && m.ghost[c] == 1) return;
+    const int n = m.cfCount[c];
+    const size_t base = (size_t)m.cfSlice[c >> 6] * 64 + (c & 63);
+    const size_t nF = (size_t)m.nF;
+    double s[4] = {0, 0, 0, 0};
+    for (int i = 0; i < n; ++i) {
+        const int it = m.cfItem[base + (size_t)i * 64];
+        const size_t f = (size_t)(it >= 0 ? it : ~it);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const double x = q.F[(size_t)k * nF + f]; s[k] = it >= 0 ? s[k] + x : s[k] - x; }
+    }
+    const double rV = 1.0 / m.V[c];
+    double* rec = q.c4 + (size_t)c * 4;
+    const double T = rec[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) rec[k] += q.dt * (-(s[k] * rV) + (q.beta * T) * q.g[k]);   // BdFrc = beta*T*g of updateFields.H L66
+    rec[3] = T + q.dt * (-(s[3] * rV));
+}
+
+// correctBoundaryConditions of U and T after their solves
+__global__ __launch_bounds__(QGD_BLOCK) void qhdBcKernel(const MeshView m, const QhdView q, const PatchBCDev* __restrict__ bcs) {
+    const int b = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    if (b >= m.nBF) return;
+    const int f = m.nIF + b;
+    if (m.fkind[f] == 3) return;
+    const PatchBCDev bc = bcs[m.bPatch[b]];
+    if (bc.ptype == QGD_PATCH_HALO) return;
+    const double* o4 = q.c4 + (size_t)m.own[f] * 4;
+    double* b4 = q.b4 + (size_t)b * 4;
+    if (bc.bcU == QGD_BC_FIXEDVALUE) { b4[0] = bc.vU[0]; b4[1] = bc.vU[1]; b4[2] = bc.vU[2]; }
+    else if (bc.bcU == QGD_BC_SLIP) {
+        const double ms = m.magSf[f];
+        const double n[3] = {m.Sx[f] / ms, m.Sy[f] / ms, m.Sz[f] / ms};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double tv = ((i == 0 ? 1.0 : 0.0) - 2.0 * (n[i] * n[0])) * o4[0] + ((i == 1 ? 1.0 : 0.0) - 2.0 * (n[i] * n[1])) * o4[1] +
+                              ((i == 2 ? 1.0 : 0.0) - 2.0 * (n[i] * n[2])) * o4[2];
+            b4[i] = (o4[i] + tv) / 2.0;
+        }
+    } else { b4[0] = o4[0]; b4[1] = o4[1]; b4[2] = o4[2]; }
+    b4[3] = bc.bcT == QGD_BC_FIXEDVALUE ? bc.vT : o4[3];
+}
+
+// p += pRefValue - p[pRefCell] when the field needs a reference level [QHDFoam.C L123-130]
+__global__ void qhdRefReadKernel(const QhdView q, const int refCell, const double refValue, double* __restrict__ shift) {
+    shift[0] = refValue - q.p[refCell];
+}
+__global__ __launch_bounds__(QGD_BLOCK) void qhdRefShiftKernel(const int nC, const int nBF, const QhdView q, const double* __restrict__ shift) {
+    const int i = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    if (i < nC) q.p[i] += shift[0];
+    else if (i < nC + nBF) q.pb[i - nC] += shift[0];
+}
+
+// createFields: cell records from U, T (host order) and p
+__global__ __launch_bounds__(QGD_BLOCK) void qhdInitKernel(const int nC, const QhdView q, const double* __restrict__ U, const double* __restrict__ T,
+                                                          const double* __restrict__ p) {
+    const int c = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    if (c >= nC) return;
+    q.c4[(size_t)c * 4] = U[3 * (size_t)c]; q.c4[(size_t)c * 4 + 1] = U[3 * (size_t)c + 1]; q.c4[(size_t)c * 4 + 2] = U[3 * (size_t)c + 2];
+    q.c4[(size_t)c * 4 + 3] = T[c];
+    q.p[c] = p[c];
+}
+// tauQGDf = linearInterpolate(tauQGD) of the QHD closures [constTau_8C L71-74, HbyUQHD_8C L80-83, T0byGr_8C L84-87,
+// H2bynuQHD_8C L78-82]; taubyrhof = tauQGDf/rhof [updateFluxes.H L38]
+__device__ __forceinline__ double qhdTauOf(const QhdView& q, const double h) {
+    switch (q.tauModel) {
+        case 0: return q.Tau;
+        case 1: return q.aQGD * h / q.UQHD;
+        case 2: return q.T0 / q.Gr;
+        default: return q.aQGD * h * h / q.nu;
+    }
+}
+__global__ __launch_bounds__(QGD_BLOCK) void qhdTauKernel(const MeshView m, const QhdView q, double* __restrict__ tauF, double* __restrict__ tbr) {
+    const int f = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    if (f >= m.nF) return;
+    double t = 0.0;
+    if (m.fkind[f] != 3) {
+        if (f < m.nIF) t = lerpf(m.w[f], qhdTauOf(q, m.hQGD[m.own[f]]), qhdTauOf(q, m.hQGD[m.nei[f]]));
+        else t = qhdTauOf(q, m.hQGDb[f - m.nIF]);
+    }
+    tauF[f] = t;
+    tbr[f] = t / q.rho0;
+}
+// named field out of the records
+__global__ __launch_bounds__(QGD_BLOCK) void qhdExtractKernel(const int64_t n, const double* __restrict__ rec4, const int field, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * QGD_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    if (field == 0) { out[3 * i] = rec4[4 * i]; out[3 * i + 1] = rec4[4 * i + 1]; out[3 * i + 2] = rec4[4 * i + 2]; }
+    else out[i] = rec4[4 * i + 3];
+}
+
+inline int gridOf(int64_t n) { return (int)((n + QGD_BLOCK - 1) / QGD_BLOCK); }
+
+template <int ST>
+void face1(hipStream_t s, const MeshView& m, const QhdView& q, const PatchBCDev* bc) { qhdFace1Kernel<ST><<<gridOf(m.nF), QGD_BLOCK, 0, s>>>(m, q, bc); }
+template <int ST>
+void face2(hipStream_t s, const MeshView& m, const QhdView& q, const PatchBCDev* bc) { qhdFace2Kernel<ST><<<gridOf(m.nF), QGD_BLOCK, 0, s>>>(m, q, bc); }
+
+}  // namespace
+
+void launchQhdInit(hipStream_t s, const MeshView& m, const QhdView& q, const PatchBCDev* bc, const double* U, const double* T, const double* p,
+                   double* tauF, double* taubyrho) {
+    qhdInitKernel<<<gridOf(m.nC), QGD_BLOCK, 0, s>>>(m.nC, q, U, T, p);
+    qhdTauKernel<<<gridOf(m.nF), QGD_BLOCK, 0, s>>>(m, q, tauF, taubyrho);
+    if (m.nBF) {
+        qhdBcKernel<<<gridOf(m.nBF), QGD_BLOCK, 0, s>>>(m, q, bc);
+        qhdPressureBcKernel<<<gridOf(m.nBF), QGD_BLOCK, 0, s>>>(m, q, bc);
+    }
+}
+// everything of the step before the pressure equation
+void launchQhdAssemble(hipStream_t s, int stencil, bool usesPoints, const MeshView& m, const QhdView& q, const PatchBCDev* bc) {
+    if (usesPoints) {
+        pointInterpFastKernel<4><<<gridOf(m.nP), QGD_BLOCK, 0, s>>>(m, q.c4, q.pt4);
+        if (m.nBP) boundaryPointKernel<4><<<gridOf(m.nBP), QGD_BLOCK, 0, s>>>(m, q.b4, 4, q.pt4, 4, 0);
+    }
+    switch (stencil) {
+        case ST_REDUCED: face1<ST_REDUCED>(s, m, q, bc); break;
+        case ST_LSQ: face1<ST_LSQ>(s, m, q, bc); break;
+        case ST_GVP3: face1<ST_GVP3>(s, m, q, bc); break;
+        default: face1<ST_GVP2>(s, m, q, bc); break;
+    }
+    if (m.nBF) qhdPressureBcKernel<<<gridOf(m.nBF), QGD_BLOCK, 0, s>>>(m, q, bc);   // p.correctBoundaryConditions() [QHDpEqn.H L35]
+}
+// everything after it
+void launchQhdAdvance(hipStream_t s, int stencil, bool usesPoints, const MeshView& m, const QhdView& q, const PatchBCDev* bc, int refCell,
+                      double refValue, double* scratch) {
+    if (m.nBF) qhdPressureBcKernel<<<gridOf(m.nBF), QGD_BLOCK, 0, s>>>(m, q, bc);   // solve() ends in correctBoundaryConditions()
+    if (usesPoints) {
+        pointInterpFastKernel<1><<<gridOf(m.nP), QGD_BLOCK, 0, s>>>(m, q.p, q.ptp);
+        if (m.nBP) boundaryPointKernel<1><<<gridOf(m.nBP), QGD_BLOCK, 0, s>>>(m, q.pb, 1, q.ptp, 1, 0);
+    }
+    qhdCellGradKernel<<<gridOf(m.nC), QGD_BLOCK, 0, s>>>(m, q);
+    switch (stencil) {
+        case ST_REDUCED: face2<ST_REDUCED>(s, m, q, bc); break;
+        case ST_LSQ: face2<ST_LSQ>(s, m, q, bc); break;
+        case ST_GVP3: face2<ST_GVP3>(s, m, q, bc); break;
+        default: face2<ST_GVP2>(s, m, q, bc); break;
+    }
+    qhdCellUpdateKernel<<<gridOf(m.nC), QGD_BLOCK, 0, s>>>(m, q);
+    if (m.nBF) qhdBcKernel<<<gridOf(m.nBF), QGD_BLOCK, 0, s>>>(m, q, bc);
+    if (refCell >= 0) {
+        qhdRefReadKernel<<<1, 1, 0, s>>>(q, refCell, refValue, scratch);
+        qhdRefShiftKernel<<<gridOf((int64_t)m.nC + m.nBF), QGD_BLOCK, 0, s>>>(m.nC, m.nBF, q, scratch);
+    }
+}
+void launchQhdExtract(hipStream_t s, int64_t n, const double* rec4, int field, double* out) {
+    if (n) qhdExtractKernel<<<gridOf(n), QGD_BLOCK, 0, s>>>(n, rec4, field, out);
+}
+
+}  // namespace qgd

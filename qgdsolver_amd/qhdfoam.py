@@ -143,3 +143,77 @@ def pEqn(dev, phiu, phiwo, taubyrhof, p, patch_kinds, pb=None, gradb=None, toler
     else:
         call(phiu, phiwo, tbr, kinds, pb, gradb, ctl, p_out, phi, info)
     return p_out, phi, dict(iterations=int(info[0]), initialResidual=float(info[1]), finalResidual=float(info[2]))
+
+
+# ---- QHDFoam case resident on the device ------------------------------------------------------------------------------
+TAU_MODELS = {"constTau": 0, "HbyUQHD": 1, "T0byGr": 2, "H2bynuQHD": 3}
+_BC = {"zeroGradient": L.BC_ZEROGRADIENT, "fixedValue": L.BC_FIXEDVALUE, "slip": L.BC_SLIP, "fixedGradient": L.BC_QGDFLUX,
+       "qhdFlux": L.BC_QGDFLUX, "qhdFluxCoupled": L.BC_QHDFLUX, "none": L.BC_NONE}
+
+
+def qhd_options(**kw):
+    """qgd_qhd_options with the library defaults; stencil and tauModel may be given as words, g as a 3-tuple"""
+    o = L.QhdOptions()
+    L.check(L.lib.qgd_qhd_options_default(C.byref(o)), "qgd_qhd_options_default")
+    for k, v in kw.items():
+        if k == "stencil" and isinstance(v, str):
+            v = STENCIL_IDS[v]
+        if k == "tauModel" and isinstance(v, str):
+            v = TAU_MODELS[v]
+        if k == "g":
+            for i in range(3):
+                o.g[i] = float(v[i])
+            continue
+        setattr(o, k, v)
+    return o
+
+
+class QHDFoamCase:
+    """createFields.H + the while-loop body of QHDFoam.C L83-139 (explicit branch) over the C-ABI (qgd_qhd_case_*)"""
+
+    def __init__(self, dev, options=None):
+        self.dev, self.mesh = dev, dev.mesh
+        self.options = options if options is not None else qhd_options()
+        h = C.c_void_p()
+        L.check(L.lib.qgd_qhd_case_create(dev._h, C.byref(self.options), C.byref(h)), "qgd_qhd_case_create")
+        self._h = h
+
+    def set_bc(self, patch, U=("zeroGradient", None), T=("zeroGradient", None), p=("zeroGradient", None)):
+        vu = np.asarray(U[1] if U[1] is not None else (0.0, 0.0, 0.0), dtype=np.float64)
+        L.check(L.lib.qgd_qhd_case_set_bc(self._h, int(patch), _BC[U[0]], vu.ctypes.data_as(L.c_double_p), _BC[T[0]], float(T[1] or 0.0),
+                                          _BC[p[0]], float(p[1] or 0.0)), "qgd_qhd_case_set_bc")
+
+    def set_fields(self, U, T, p):
+        a = [np.ascontiguousarray(x, dtype=np.float64) for x in (U, T, p)]
+        assert a[0].size == 3 * self.mesh.nCells and a[1].size == self.mesh.nCells and a[2].size == self.mesh.nCells
+        L.check(L.lib.qgd_qhd_case_set_fields(self._h, *[x.ctypes.data_as(L.c_double_p) for x in a]), "qgd_qhd_case_set_fields")
+
+    def step(self, n=1):
+        L.check(L.lib.qgd_qhd_case_step(self._h, int(n)), "qgd_qhd_case_step")
+
+    def field(self, name):
+        base = name[:-len(".boundary")] if name.endswith(".boundary") else name
+        nc = 3 if base == "U" else 1
+        n = self.mesh.nBoundaryFaces if name.endswith(".boundary") else (self.mesh.nFaces if base in ("phi", "phiu", "phiwo", "tauQGDf")
+                                                                         else self.mesh.nCells)
+        out = np.zeros((n, nc) if nc > 1 else (n,))
+        if n:
+            L.check(L.lib.qgd_qhd_case_get_field(self._h, name.encode(), out.ctypes.data_as(L.c_double_p), out.size), f"qgd_qhd_case_get_field({name})")
+        return out
+
+    def info(self):
+        a = (C.c_double * 8)()
+        L.check(L.lib.qgd_qhd_case_info(self._h, a), "qgd_qhd_case_info")
+        return dict(time=a[0], deltaT=a[1], pIterations=int(a[2]), pInitialResidual=a[3], pFinalResidual=a[4], steps=int(a[5]),
+                    mgLevels=int(a[6]), pSolveMs=a[7])
+
+    def close(self):
+        if getattr(self, "_h", None):
+            L.lib.qgd_qhd_case_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
