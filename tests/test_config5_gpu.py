@@ -163,4 +163,22 @@ def test_c5_full_size_16M_irregular_cells():
         scale = np.abs(ref[k][sel]).max()
         err = np.abs(g[sel] - ref[k][sel]).max() / scale
         assert err <= 1e-11, (k, err)
+    del got, ref
+
+    # ---- config 5 end to end: the resident QHDFoam step on this mesh (buoyant cavity, pressure equation included) ------
+    from test_qhd_case import cavity_bcs, divergence
+    case = qhdfoam.QHDFoamCase(dev, qhdfoam.qhd_options(stencil="GaussVolPoint", tauModel="HbyUQHD", aQGD=0.5, UQHD=0.1, rho0=1.0, mu=1e-3,
+                                                        Pr=0.71, beta=BETA, g=G, deltaT=0.02 * h / 0.1, pTol=1e-8, pMaxIter=300, pRefCell=0))
+    cavity_bcs(case, mesh)
+    case.set_fields(U[0], T[0], p[0])
+    case.step(3)
+    info = case.info()
+    print(f"C5 QHDFoam step, {nc} cells: {info}")
+    assert info["steps"] == 3 and info["pFinalResidual"] < 1e-8 and 0 < info["pIterations"] < 150, info
+    phi3 = case.field("phi")
+    assert np.abs(divergence(mesh, phi3)).max() <= 1e-5 * np.abs(phi3).max()
+    assert np.abs(phi3[nif:]).max() <= 1e-12 * np.abs(phi3).max()          # impermeable walls
+    Un, Tn = case.field("U"), case.field("T")
+    assert np.isfinite(Un).all() and np.isfinite(Tn).all() and np.abs(Un).max() < 1.0 and 289.0 < Tn.min() and Tn.max() < 311.0
+    case.close()
     dev.close()
