@@ -337,8 +337,10 @@ int qgd_qhd_case_info(qgd_qhd_case_t c, double info[8]);
 
 typedef struct qgd_case_options {
     int32_t stencil;          /* QGD_FVSC_* : fvSchemes fvsc{default ...;}        */
-    int32_t implicitDiffusion;/* must be 0: the explicit branch
-                                 [QGDFoam_2updateFluxes_8H_source.html L95-106]   */
+    int32_t implicitDiffusion;/* 0: the explicit branch [QGDFoam_2updateFluxes_8H_source.html L95-106];
+                                 1: the reference's default [QGDThermo_8C_source.html L70-82]: viscous stress and heat
+                                 conduction implicit, tauMC / phiSigmaDotU [updateFluxes.H L107-111, QGDUEqn_8H L54-75,
+                                 QGDEEqn_8H L53-64]; unsharded meshes only                                          */
     int32_t adjustTimeStep;   /* 1: Courant/deltaT control
                                  [QGDCourantNo_8H_source.html L36-53,
                                   setDeltaT-QGDQHD_8H_source.html L41-61]         */
@@ -357,6 +359,10 @@ typedef struct qgd_case_options {
                                  [QGDCoeffs_8C_source.html L145-159])             */
     double deltaT;            /* (initial) time step                              */
     double maxCo, maxDeltaT, cTau; /* used when adjustTimeStep                    */
+    double implicitTol;       /* implicitDiffusion: tolerance (OpenFOAM's normalised residual) of the U and e solves,
+                                 fvSolution's `tolerance` of those fields                                         */
+    int32_t implicitMaxIter;  /* ... and their iteration limit                                                    */
+    int32_t pad_;
 } qgd_case_options;
 
 int qgd_case_options_default(qgd_case_options* opt);

@@ -993,6 +993,82 @@ inline void TdotT(const double* A, const double* B, double* R) {
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
 }
 
+// L0: fvc::grad(U) with the Gauss linear scheme: (1/V) sum_f Sf (x) Uf, tensor component 3*i+j = d_i U_j; patch values =
+// owner cell's gradient (extrapolatedCalculated) with the normal part replaced by the patch snGrad on non-coupled patches
+// (gaussGrad::correctBoundaryConditions)
+VolField gaussGradVector(const Mesh& m, const std::vector<char>& liveFace, const VolField& f) {
+    SurfField ff = linearInterpolate(m, f);
+    VolField g(m, 9);
+    for (int fc = 0; fc < m.nF; ++fc) {
+        if (!liveFace[fc]) continue;
+        const double* S = &m.Sf[3 * (size_t)fc];
+        double* go = &g.in[9 * (size_t)m.own[fc]];
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) go[3 * i + j] += S[i] * ff.v[3 * (size_t)fc + j];
+        if (fc < m.nIF) {
+            double* gn = &g.in[9 * (size_t)m.nei[fc]];
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) gn[3 * i + j] -= S[i] * ff.v[3 * (size_t)fc + j];
+        }
+    }
+    for (int c = 0; c < m.nC; ++c) for (int k = 0; k < 9; ++k) g.in[9 * (size_t)c + k] /= m.V[c];
+    dvec sn = allPatchSnGrad(m, f);
+    for (size_t ip = 0; ip < m.patches.size(); ++ip) {
+        if (!m.patchHasFields((int)ip)) continue;
+        for (int gf = m.patches[ip].start; gf < m.patches[ip].start + m.patches[ip].size; ++gf) {
+            const int b = gf - m.nIF;
+            double* gb = &g.bf[9 * (size_t)b];
+            for (int k = 0; k < 9; ++k) gb[k] = g.in[9 * (size_t)m.own[gf] + k];
+            if (m.coupled((int)ip)) continue;
+            double n[3], ng[3];
+            for (int k = 0; k < 3; ++k) n[k] = m.Sf[3 * (size_t)gf + k] / m.magSf[gf];
+            VdotT(n, gb, ng);
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) gb[3 * i + j] += n[i] * (sn[3 * (size_t)b + j] - ng[j]);
+        }
+    }
+    return g;
+}
+
+// Symmetric positive definite system of a Gauss laplacian plus a diagonal: (diag_c) x_c - sum_f a_f (x_nb - ... ) in the form
+// y_c = diag_c x_c - sum_{faces} a_f x_nb; Jacobi-preconditioned conjugate gradients, OpenFOAM's normalised residual (L0)
+int solveDiagLaplacian(const Mesh& m, const dvec& a, const dvec& diag, const dvec& rhs, double* x, double tol, int maxIter) {
+    const int nC = m.nC;
+    auto apply = [&](const double* v, dvec& y) {
+        for (int c = 0; c < nC; ++c) y[c] = diag[c] * v[c];
+        for (int f = 0; f < m.nIF; ++f) { y[m.own[f]] -= a[f] * v[m.nei[f]]; y[m.nei[f]] -= a[f] * v[m.own[f]]; }
+    };
+    dvec r((size_t)nC), z((size_t)nC), d((size_t)nC), q((size_t)nC), A1((size_t)nC), ones((size_t)nC, 1.0);
+    apply(ones.data(), A1);
+    apply(x, q);
+    double xbar = 0;
+    for (int c = 0; c < nC; ++c) xbar += x[c];
+    xbar /= nC;
+    double normFactor = 1e-20, sumAbs = 0, rz = 0;
+    for (int c = 0; c < nC; ++c) {
+        normFactor += std::fabs(q[c] - xbar * A1[c]) + std::fabs(rhs[c] - xbar * A1[c]);
+        r[c] = rhs[c] - q[c]; z[c] = r[c] / diag[c]; d[c] = z[c];
+        sumAbs += std::fabs(r[c]); rz += r[c] * z[c];
+    }
+    double res = sumAbs / normFactor;
+    int it = 0;
+    while (it < maxIter && !(res < tol)) {
+        apply(d.data(), q);
+        double dq = 0;
+        for (int c = 0; c < nC; ++c) dq += d[c] * q[c];
+        if (!(dq > 0) || !(rz > 0)) break;
+        const double alpha = rz / dq;
+        double rzNew = 0; sumAbs = 0;
+        for (int c = 0; c < nC; ++c) {
+            x[c] += alpha * d[c]; r[c] -= alpha * q[c]; z[c] = r[c] / diag[c];
+            rzNew += r[c] * z[c]; sumAbs += std::fabs(r[c]);
+        }
+        res = sumAbs / normFactor;
+        const double beta = rzNew / rz;
+        for (int c = 0; c < nC; ++c) d[c] = z[c] + beta * d[c];
+        rz = rzNew;
+        ++it;
+    }
+    return it;
+}
+
 // ---------------------------------------------------------------------------
 // QGDFoam case
 // ---------------------------------------------------------------------------
@@ -1014,6 +1090,8 @@ struct Case {
     // face fields
     SurfField rhof, Uf, rhoUf, UrhoUf, pf, cf, gammaf, Hf, alphauf, muf;
     SurfField gradUf, divUf, gradef, gradRhof, gradPf, rhoW, phiw, jm, phiJm, phi, phiJmU, phiP, Pif, phiPi, phiJmH, qf, phiQ, phiPiU;
+    SurfField tauMC, phiTauMC, phiSigmaDotU;   // implicitDiffusion branch [createFaceFluxes.H, updateFluxes.H:107-111, QGDUEqn.H:72-74]
+    int lastIterU[3] = {0, 0, 0}, lastIterE = 0;
     bool phiwRegistered = false;  // "phiwStar" exists in the registry after createFaceFluxes.H
     double time = 0, deltaT = 0, CoNum = 0;
     long stepCount = 0;
@@ -1322,7 +1400,7 @@ struct Case {
             Pi[0] += sph; Pi[4] += sph; Pi[8] += sph;
             // explicit branch [updateFluxes.H:95-106]
             const double s23 = (2.0 / 3.0) * 1.0 * divUf.v[f];
-            for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+            if (!opt.implicitDiffusion) for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
                 double t = gU[3 * i + j] + gU[3 * j + i];
                 if (i == j) t = t - s23;
                 Pi[3 * i + j] += muf.v[f] * t;
@@ -1335,13 +1413,49 @@ struct Case {
             TdotV(&UrhoUf.v[9 * (size_t)f], g2, q);
             for (int k = 0; k < 3; ++k) {
                 qf.v[3 * (size_t)f + k] = (-tau) * q[k];
-                qf.v[3 * (size_t)f + k] -= alphauf.v[f] * gradef.v[3 * (size_t)f + k];
+                if (!opt.implicitDiffusion) qf.v[3 * (size_t)f + k] -= alphauf.v[f] * gradef.v[3 * (size_t)f + k];   // [:131-135]
             }
             phiQ.v[f] = dot3(&m.Sf[3 * (size_t)f], &qf.v[3 * (size_t)f]);
             double piU[3];
             TdotV(Pi, uf, piU);
             phiPiU.v[f] = dot3(&m.Sf[3 * (size_t)f], piU);
         }
+        if (opt.implicitDiffusion) {
+            // tauMC = qgdInterpolate(muEff * dev2(T(fvc::grad(U)))), phiTauMC = Sf & tauMC [updateFluxes.H:107-111]
+            VolField gU = gaussGradVector(m, liveFace, U);
+            VolField prod(m, 9);
+            auto dev2T = [](const double* g, double muEff, double* out) {   // dev2(A) = A - (2/3) tr(A) I, A = T(g)
+                const double tr = g[0] + g[4] + g[8];
+                for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+                    double a = g[3 * j + i];
+                    if (i == j) a = a - (2.0 / 3.0) * tr;
+                    out[3 * i + j] = muEff * a;
+                }
+            };
+            for (int ci = 0; ci < m.nC; ++ci) dev2T(&gU.in[9 * (size_t)ci], 0.0 + mu.in[ci], &prod.in[9 * (size_t)ci]);
+            for (int b = 0; b < m.nBF(); ++b) dev2T(&gU.bf[9 * (size_t)b], 0.0 + mu.bf[b], &prod.bf[9 * (size_t)b]);
+            tauMC = linearInterpolate(m, prod);
+            phiTauMC = SurfField(m, 3);
+            for (int f = 0; f < nF; ++f) if (liveFace[f]) VdotT(&m.Sf[3 * (size_t)f], &tauMC.v[9 * (size_t)f], &phiTauMC.v[3 * (size_t)f]);
+        }
+    }
+
+    // the matrix of fvm::ddt(rho, x) - fvm::laplacian(gamma_f, x) for one scalar (component): face coefficients a_f =
+    // gamma_f |S_f| delta_f (uncorrected, L0), diagonal rDeltaT rho V + sum a_f + the patch internal coefficients
+    // icoef(face) (gamma |S| x -gradientInternalCoeffs), source bsrc(face) (gamma |S| x gradientBoundaryCoeffs)
+    template <class IC, class BS>
+    int implicitDiffusionSolve(const SurfField& gammaf, double rDeltaT, const dvec& rhsCell, IC icoef, BS bsrc, double* x) {
+        dvec a((size_t)m.nF, 0.0), diag((size_t)m.nC), rhs = rhsCell;
+        for (int f = 0; f < m.nIF; ++f) a[f] = gammaf.v[f] * m.magSf[f] * m.nonOrthDelta[f];
+        for (int ci = 0; ci < m.nC; ++ci) diag[ci] = rDeltaT * rho.in[ci] * m.V[ci];
+        for (int f = 0; f < m.nIF; ++f) { diag[m.own[f]] += a[f]; diag[m.nei[f]] += a[f]; }
+        for (size_t ip = 0; ip < bc.size(); ++ip) forPatchFaces((int)ip, [&](int gf, int b, int o) {
+            if (m.coupled((int)ip)) return;
+            const double gs = gammaf.v[gf] * m.magSf[gf];
+            diag[o] += gs * icoef((int)ip, gf, b, o);
+            rhs[o] += gs * bsrc((int)ip, gf, b, o);
+        });
+        return solveDiagLaplacian(m, a, diag, rhs, x, opt.implicitTol, opt.implicitMaxIter);
     }
 
     // L0 fvc::div(ssf) = surfaceIntegrate: owner += , neighbour -= , patches += , /V
@@ -1440,6 +1554,54 @@ struct Case {
                 }
             for (int ci = 0; ci < m.nC; ++ci) for (int k = 0; k < 3; ++k) U.in[3 * (size_t)ci + k] = rhoU.in[3 * (size_t)ci + k] / rho.in[ci];
             correctBC_U();
+            if (opt.implicitDiffusion) {
+                // UEqn: fvm::ddt(rho,U) - fvc::ddt(rho,U) - fvm::laplacian(muf,U) - fvc::div(phiTauMC) == rhoUSu [:56-68],
+                // solved component by component (fvMatrix<vector>::solveSegregated, L0); patch coefficients:
+                // fixedValue: -gradientInternalCoeffs = delta, gradientBoundaryCoeffs = delta*value;
+                // basicSymmetry (slip): -gIC = delta*|n_cmpt|, gBC = snGrad - gIC*patchInternalField (transformFvPatchField);
+                // zeroGradient: none
+                dvec dT = fvcDiv(phiTauMC);
+                dvec sn = allPatchSnGrad(m, U);
+                const dvec Ucur = U.in;
+                for (int k = 0; k < 3; ++k) {
+                    if (m.geomD[k] < 0) continue;   // validComponents: the empty direction is not solved
+                    dvec rhs((size_t)m.nC), x((size_t)m.nC);
+                    for (int ci = 0; ci < m.nC; ++ci) {
+                        // rDeltaT rho.old U.old V  +  V rDeltaT (rho U - rho.old U.old)  +  V div(phiTauMC)
+                        double src = rDeltaT * rhoOld[ci] * UOld[3 * (size_t)ci + k] * m.V[ci];
+                        src += m.V[ci] * (rDeltaT * (rho.in[ci] * Ucur[3 * (size_t)ci + k] - rhoOld[ci] * UOld[3 * (size_t)ci + k]));
+                        src += m.V[ci] * dT[3 * (size_t)ci + k];
+                        rhs[ci] = src;
+                        x[ci] = Ucur[3 * (size_t)ci + k];
+                    }
+                    auto ic = [&](int ip, int gf, int, int) {
+                        if (bc[ip].bcU == BC_FIXEDVALUE) return m.delta[gf];
+                        if (bc[ip].bcU == BC_SLIP) return m.delta[gf] * std::fabs(m.Sf[3 * (size_t)gf + k] / m.magSf[gf]);
+                        return 0.0;
+                    };
+                    auto bs = [&](int ip, int gf, int b, int o) {
+                        if (bc[ip].bcU == BC_FIXEDVALUE) return m.delta[gf] * U.bf[3 * (size_t)b + k];
+                        if (bc[ip].bcU == BC_SLIP)
+                            return sn[3 * (size_t)b + k] + m.delta[gf] * std::fabs(m.Sf[3 * (size_t)gf + k] / m.magSf[gf]) * Ucur[3 * (size_t)o + k];
+                        return 0.0;
+                    };
+                    lastIterU[k] = implicitDiffusionSolve(muf, rDeltaT, rhs, ic, bs, x.data());
+                    for (int ci = 0; ci < m.nC; ++ci) U.in[3 * (size_t)ci + k] = x[ci];
+                }
+                correctBC_U();
+                for (int ci = 0; ci < m.nC; ++ci) for (int k = 0; k < 3; ++k) rhoU.in[3 * (size_t)ci + k] = rho.in[ci] * U.in[3 * (size_t)ci + k];   // [:70]
+                // sigmaDotU = (muf*linearInterpolate(fvc::grad(U)) + tauMC) & Uf;  phiSigmaDotU = Sf & sigmaDotU [:72-74]
+                VolField gUn = gaussGradVector(m, liveFace, U);
+                SurfField gUf = linearInterpolate(m, gUn);
+                phiSigmaDotU = SurfField(m, 1);
+                for (int f = 0; f < m.nF; ++f) {
+                    if (!liveFace[f]) continue;
+                    double A[9], sd[3];
+                    for (int q = 0; q < 9; ++q) A[q] = muf.v[f] * gUf.v[9 * (size_t)f + q] + tauMC.v[9 * (size_t)f + q];
+                    TdotV(A, &Uf.v[3 * (size_t)f], sd);
+                    phiSigmaDotU.v[f] = dot3(&m.Sf[3 * (size_t)f], sd);
+                }
+            } else {
             // solve(fvm::ddt(rho,U) - fvc::ddt(rhoU) == rhoUSu) [:79-86]
             for (int ci = 0; ci < m.nC; ++ci)
                 for (int k = 0; k < 3; ++k) {
@@ -1449,6 +1611,7 @@ struct Case {
                     U.in[3 * (size_t)ci + k] = src / diag;
                 }
             correctBC_U();  // fvMatrix::solve ends with psi.correctBoundaryConditions() (L0)
+            }
             for (int b = 0; b < m.nBF(); ++b) for (int k = 0; k < 3; ++k) rhoU.bf[3 * (size_t)b + k] = rho.bf[b] * U.bf[3 * (size_t)b + k];
         }
         // QGDEEqn.H [:37-76] (phiSigmaDotU == 0 in the explicit branch)
@@ -1460,8 +1623,20 @@ struct Case {
                 src -= m.V[ci] * d1[ci];
                 src -= m.V[ci] * d2[ci];
                 src += m.V[ci] * d3[ci];
-                src += m.V[ci] * 0.0;  // - fvc::div(phiSigmaDotU), a zero field
+                src += m.V[ci] * 0.0;  // - fvc::div(phiSigmaDotU), a zero field in the explicit branch
                 rhoE.in[ci] = src / diag;
+            }
+            if (opt.implicitDiffusion) {   // the real phiSigmaDotU [:43]
+                dvec d4 = fvcDiv(phiSigmaDotU);
+                for (int ci = 0; ci < m.nC; ++ci) {
+                    const double diag = rDeltaT * m.V[ci];
+                    double src = rDeltaT * rhoEOld[ci] * m.V[ci];
+                    src -= m.V[ci] * d1[ci];
+                    src -= m.V[ci] * d2[ci];
+                    src += m.V[ci] * d3[ci];
+                    src += m.V[ci] * d4[ci];
+                    rhoE.in[ci] = src / diag;
+                }
             }
             for (int ci = 0; ci < m.nC; ++ci) {
                 const double* u = &U.in[3 * (size_t)ci];
@@ -1471,7 +1646,25 @@ struct Case {
             // solve(fvm::ddt(rho,e) - fvc::ddt(rhoE) == rhoESu) [:67-72] -- as written in the listing: rho*e advances by
             // the increment of rhoE, the kinetic energy is not taken out again.  consistentEnergy keeps the e of [:49]
             // (what fvc::ddt(rho,e), the form of the implicit branch [:57], would give with rhoESu = 0).
-            if (!opt.consistentEnergy) for (int ci = 0; ci < m.nC; ++ci) {
+            if (opt.implicitDiffusion) {
+                // solve(fvm::ddt(rho,e) - fvc::ddt(rho,e) - fvm::laplacian(alphauf,e) == rhoESu) [:55-61]; e's patches:
+                // fixedEnergy = fixedValue, gradientEnergy = fixedGradient with a zero gradient here
+                dvec rhs((size_t)m.nC), x = e.in;
+                for (int ci = 0; ci < m.nC; ++ci) {
+                    double src = rDeltaT * rhoOld[ci] * eOld[ci] * m.V[ci];
+                    src += m.V[ci] * (rDeltaT * (rho.in[ci] * e.in[ci] - rhoOld[ci] * eOld[ci]));
+                    rhs[ci] = src;
+                }
+                auto ic = [&](int ip, int gf, int, int) { return bc[ip].bcT == BC_FIXEDVALUE ? m.delta[gf] : 0.0; };
+                auto bs = [&](int ip, int gf, int b, int) { return bc[ip].bcT == BC_FIXEDVALUE ? m.delta[gf] * e.bf[b] : 0.0; };
+                lastIterE = implicitDiffusionSolve(alphauf, rDeltaT, rhs, ic, bs, x.data());
+                e.in = x;
+                correctBC_e();
+                for (int ci = 0; ci < m.nC; ++ci) {
+                    const double* u = &U.in[3 * (size_t)ci];
+                    rhoE.in[ci] = rho.in[ci] * (e.in[ci] + 0.5 * (u[0] * u[0] + u[1] * u[1] + u[2] * u[2]));   // [:63]
+                }
+            } else if (!opt.consistentEnergy) for (int ci = 0; ci < m.nC; ++ci) {
                 const double diag = rDeltaT * rho.in[ci] * m.V[ci];
                 double src = rDeltaT * rhoOld[ci] * eOld[ci] * m.V[ci];
                 src += m.V[ci] * (rDeltaT * (rhoE.in[ci] - rhoEOld[ci]));

@@ -26,6 +26,8 @@ extern "C" {
 typedef struct orc_case_options {
     int32_t stencil, implicitDiffusion, adjustTimeStep, consistentEnergy;
     double R, Cv, mu, Pr, ScQGD, PrQGD, alphaQGD, deltaT, maxCo, maxDeltaT, cTau;
+    double implicitTol;        /* fvSolution tolerance of the two implicit-diffusion solves */
+    int32_t implicitMaxIter, pad_;
 } orc_case_options;
 
 void* orc_mesh_create(int32_t nPoints, const double* points, int32_t nFaces,

@@ -225,6 +225,9 @@ struct qgd_case_s {
     DeviceArena arena;
     CaseView view{};
     double* dbgBuf = nullptr;
+    ImplView impl{};            // implicitDiffusion branch: its face / cell work arrays
+    double* implWork = nullptr;
+    int implIters[4] = {0, 0, 0, 0};
     double* coef[4] = {nullptr, nullptr, nullptr, nullptr};  // device copies of non-uniform alphaQGD / ScQGD (cells, patch faces)
     double time = 0;
     int64_t steps = 0;
@@ -532,6 +535,8 @@ int qgd_device_create(qgd_mesh_t mh, int deviceId, qgd_device_t* out) {
         MeshView& v = d->view;
         v.nP = s.nP; v.nF = s.nF; v.nIF = s.nIF; v.nC = s.nC; v.nBF = s.nBF;
         v.ie1 = s.ie1; v.ie2 = s.ie2; v.ie3 = s.ie3;
+        v.nGeomD = m.nGeometricD;
+        for (int k = 0; k < 3; ++k) v.emptyDir[k] = m.geometricD[k] < 0 ? 1 : 0;
         { const char* e = std::getenv("QGD_XCD_RUN"); v.xcdRun = e ? std::atoi(e) : 16; }
         { const char* e = std::getenv("QGD_FBLOCK"); v.fblock = e ? std::atoi(e) : 128; }
         { const char* e = std::getenv("QGD_CBLOCK"); v.cblock = e ? std::atoi(e) : 256; }
@@ -932,13 +937,17 @@ int qgd_case_options_default(qgd_case_options* o) {
     o->mu = 0.0; o->Pr = 1.0;
     o->ScQGD = 1.0; o->PrQGD = 1.0; o->alphaQGD = 0.5;
     o->deltaT = 1e-4; o->maxCo = 0.5; o->maxDeltaT = 1.0; o->cTau = 0.75;
+    o->implicitTol = 1e-10; o->implicitMaxIter = 1000;
     return QGD_OK;
 }
 
 int qgd_case_create(qgd_device_t d, const qgd_case_options* opt, qgd_case_t* out) {
     QGD_TRY
     if (!d || !opt || !out) return fail(QGD_ERR_INVALID, "qgd_case_create: null argument");
-    if (opt->implicitDiffusion) return fail(QGD_ERR_NOT_IMPLEMENTED, "implicitDiffusion true: only the explicit branch is on this path");
+    if (opt->implicitDiffusion && d->sharded())
+        return fail(QGD_ERR_NOT_IMPLEMENTED, "implicitDiffusion true on a sharded mesh: the implicit solves and fvc::grad(U) are not distributed");
+    if (opt->implicitDiffusion && (!(opt->implicitTol >= 0) || opt->implicitMaxIter < 0))
+        return fail(QGD_ERR_INVALID, "qgd_case_create: bad implicitTol / implicitMaxIter");
     if (!(opt->R > 0) || !(opt->Cv > 0) || !(opt->Pr > 0) || !(opt->PrQGD > 0) || !(opt->deltaT > 0))
         return fail(QGD_ERR_INVALID, "qgd_case_create: R, Cv, Pr, PrQGD, deltaT must be positive");
     int st = 0;
@@ -953,6 +962,7 @@ int qgd_case_create(qgd_device_t d, const qgd_case_options* opt, qgd_case_t* out
         g.R = opt->R; g.Cv = opt->Cv; g.mu0 = opt->mu; g.Pr = opt->Pr; g.ScQGD = opt->ScQGD; g.PrQGD = opt->PrQGD;
         g.alphaQGD = opt->alphaQGD;
         g.consistentEnergy = opt->consistentEnergy ? 1 : 0;
+        g.implicitDiffusion = opt->implicitDiffusion ? 1 : 0;
         const double Cp = opt->Cv + opt->R;
         g.gamma = Cp / opt->Cv;
         const double rPr = 1.0 / opt->Pr;
@@ -973,6 +983,18 @@ int qgd_case_create(qgd_device_t d, const qgd_case_options* opt, qgd_case_t* out
         cv.red = a.alloc<double>(8);
         cv.dt = a.alloc<double>(8);
         cv.dbg = nullptr;
+        if (opt->implicitDiffusion) {
+            ImplView& iv = c->impl;
+            const size_t nC = (size_t)v.nC, nF = (size_t)v.nF;
+            iv.gUc = a.alloc<double>(9 * nC);
+            iv.phiTau = a.alloc<double>(3 * nF); iv.UfS = a.alloc<double>(3 * nF);
+            iv.sTau = a.alloc<double>(nF); iv.mufS = a.alloc<double>(nF); iv.aU = a.alloc<double>(nF); iv.aE = a.alloc<double>(nF);
+            iv.phiSig = a.alloc<double>(nF);
+            iv.rhoNew = a.alloc<double>(nC);
+            iv.xU = a.alloc<double>(3 * nC); iv.diagU = a.alloc<double>(3 * nC); iv.rhsU = a.alloc<double>(3 * nC);
+            iv.xE = a.alloc<double>(nC); iv.diagE = a.alloc<double>(nC); iv.rhsE = a.alloc<double>(nC);
+            c->implWork = a.alloc<double>(6 * nC + 3 * ((nC + 255) / 256) + 8);
+        }
         c->bc.resize(d->patches.size());
         for (size_t i = 0; i < d->patches.size(); ++i) {
             PatchBCDev& b = c->bc[i];
@@ -1132,6 +1154,13 @@ static void stepAdvance(qgd_case_s* c, int part) {
         if (adjust) launchDeltaT(L, c->view, c->opt.maxCo, c->opt.maxDeltaT, c->opt.cTau);
         c->steps++;
         if (!adjust) c->time += c->opt.deltaT;
+    }
+    if (c->opt.implicitDiffusion) {
+        // [QGDUEqn.H L54-75, QGDEEqn.H L53-64]: two linear solves inside the step (host-synchronised convergence checks)
+        launchImplicitAdvance(c->stream(), m, c->view, c->impl, c->gas, c->bcDev, c->opt.implicitTol, c->opt.implicitMaxIter, c->implWork,
+                              c->implIters);
+        launchBoundaryUpdate(L, m, c->view, c->gas, c->bcDev, false, c->phiwRegistered, 0, nullptr, 0);
+        return;
     }
     if (part == 0) {
         launchCellUpdate(L, m, c->view, c->gas, 0, nullptr, 0);

@@ -16,6 +16,8 @@ enum StencilKind : int { ST_REDUCED = 0, ST_LSQ = 1, ST_GVP3 = 2, ST_GVP2 = 3 };
 struct MeshView {
     int32_t nP, nF, nIF, nC, nBF;
     int32_t ie1, ie2, ie3;
+    int32_t nGeomD;          // mesh.nGeometricD()
+    int32_t emptyDir[3];     // 1 for the directions of empty patches (vector components the segregated solves skip)
     int32_t cblock, pblock;  // tiles of the cell-update and vertex kernels (64, 128 or 256)
     int32_t fblock;          // face tile of the 3-D GaussVolPoint kernel: 64, 128 or 256 faces per workgroup
     int32_t xcdRun;          // tiles per XCD run of the workgroup->tile map (0: one contiguous eighth per XCD)
@@ -54,6 +56,7 @@ struct GasModel {
     double gamma;     // Cp/Cv
     double alphah0;   // (Cp*mu*rPr)/Cp
     int32_t consistentEnergy;  // qgd_case_options::consistentEnergy
+    int32_t implicitDiffusion; // qgd_case_options::implicitDiffusion
 };
 
 // Mutable case state on the device
@@ -140,6 +143,18 @@ void launchQhdFluxes(hipStream_t s, int stencil, const MeshView& m, const double
 void launchSpeciesFlux(hipStream_t s, int stencil, const MeshView& m, const double* Y, const double* Yb, double* ptY,
                        const double* U, const double* Ub, const double* phiJm, const double* phi, const double* tau, double* out);
 
+// ---- implicitDiffusion branch of QGDFoam (qgd_implicit.hip) -----------------------------------------------------------
+struct ImplView {
+    double* gUc;                         // 9*nC fvc::grad(U)
+    double *phiTau, *UfS;                // 3*nF SoA: Sf & tauMC, Uf
+    double *sTau, *mufS, *aU, *aE, *phiSig;   // nF: Sf.(tauMC & Uf), muf, laplacian coefficients of U and e, phiSigmaDotU
+    double* rhoNew;                      // nC
+    double *xU, *diagU, *rhsU;           // 3*nC SoA: the component systems of UEqn
+    double *xE, *diagE, *rhsE;           // nC
+};
+void launchImplicitAdvance(hipStream_t s, const MeshView& m, const CaseView& c, const ImplView& iv, const GasModel& g, const PatchBCDev* bc,
+                           double tol, int maxIter, double* work, int iters[4]);
+
 // ---- QHDFoam case resident on the device (qgd_qhd.hip) ---------------------------------------------------------------
 struct QhdView {
     double* c4;  double* b4;  double* pt4;     // {Ux,Uy,Uz,T}: cells (nC*4), patch faces (nBF*4), vertices (nP*4)
@@ -168,6 +183,9 @@ int64_t pressureSolverBytes(const PressureSolver* S);
 int pressureSolverLevels(const PressureSolver* S, int* sizes, int cap);
 int pressureSolve(PressureSolver* S, const double* phiu, const double* phiwo, const double* pb, const double* gb, double tolerance,
                   double relTol, int maxIter, double* p, double* phi, double residuals[2]);
+
+int diagLaplacianPcg(hipStream_t stream, const MeshView& m, const double* a, const double* diag, const double* rhs, double* x,
+                     double* work, double tolerance, int maxIter, double residuals[2]);
 
 // ---- QHDFoam pressure equation (qgd_poisson.hip) -------------------------------------
 // all pointers are device memory; work holds 8*nC + nF + max(nBF,1) + 3*ceil(nC/256) + 8 doubles

@@ -29,27 +29,6 @@
 
 namespace qgd {
 
-// Workgroup reduction (wave shuffles + 4-entry LDS): slot[0] = max(a), slot[1] = min(b).
-// With `accumulate` the slot keeps the running extremum since it was last reset.
-template <int BLOCK = QGD_BLOCK>
-__device__ __forceinline__ void blockMaxMin(double a, double b, double* __restrict__ slot, const bool accumulate) {
-    __shared__ double sa[BLOCK / 64], sb[BLOCK / 64];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        a = fmax(a, __shfl_down(a, off, 64));
-        b = fmin(b, __shfl_down(b, off, 64));
-    }
-    const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { sa[wave] = a; sb[wave] = b; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int i = 1; i < BLOCK / 64; ++i) { a = fmax(a, sa[i]); b = fmin(b, sb[i]); }
-        if (accumulate) { a = fmax(a, slot[0]); b = fmin(b, slot[1]); }
-        slot[0] = a;
-        slot[1] = b;
-    }
-}
 // partial slots of the internal-face kernels are laid out for the smallest face tile (64)
 __device__ __forceinline__ int faceBlocksDev(const MeshView& m) { return (m.nIF + 63) / 64; }
 
@@ -59,6 +38,7 @@ __device__ __forceinline__ int faceBlocksDev(const MeshView& m) { return (m.nIF 
 // ---------------------------------------------------------------------------
 struct FaceState {
     double rhof, Uf[3], rhoUf[3], UrhoUf[9], pf, cf, Hf, gammaf, alphauf, muf, tauf;
+    int implicitDiffusion;   // 1: the Navier-Stokes part of Pi and the Fourier part of q are left to the implicit solves
 };
 
 template <bool DBG>
@@ -103,7 +83,7 @@ __device__ __forceinline__ void qgdFluxes(const FaceState& s, const double* __re
             double pij = tau * (a + s.Uf[i] * gP[j]);
             double t = gU[3 * i + j] + gU[3 * j + i];
             if (i == j) { pij += sph; t = t - s23; }
-            Pi[3 * i + j] = pij + s.muf * t;
+            Pi[3 * i + j] = s.implicitDiffusion ? pij : pij + s.muf * t;   // [updateFluxes.H L95-106]
         }
     double phiPi[3], phiJmU[3], phiP[3];
 #pragma unroll
@@ -121,7 +101,7 @@ __device__ __forceinline__ void qgdFluxes(const FaceState& s, const double* __re
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const double q = s.UrhoUf[3 * i] * g2[0] + s.UrhoUf[3 * i + 1] * g2[1] + s.UrhoUf[3 * i + 2] * g2[2];
-        qf[i] = (-tau) * q - s.alphauf * gE[i];
+        qf[i] = s.implicitDiffusion ? (-tau) * q : (-tau) * q - s.alphauf * gE[i];   // [updateFluxes.H L131-135]
         piU[i] = Pi[3 * i] * s.Uf[0] + Pi[3 * i + 1] * s.Uf[1] + Pi[3 * i + 2] * s.Uf[2];
     }
     const double phiQ = S[0] * qf[0] + S[1] * qf[1] + S[2] * qf[2];
@@ -145,15 +125,6 @@ __device__ __forceinline__ void qgdFluxes(const FaceState& s, const double* __re
 
 __device__ __forceinline__ void loadVals(const RecA& a, double* o) {
     o[0] = a.rho; o[1] = a.ux; o[2] = a.uy; o[3] = a.uz; o[4] = a.p; o[5] = a.e;
-}
-
-// effective transport coefficients of a cell/patch value.  L0 assumption:
-// laminar muEff = mut(0) + mu, alphaEff = gamma*(alpha + alphat(0)) for an
-// internal-energy thermo; mu = mu0 + muQGD, alpha = alphah0 + muQGD/PrQGD
-// [QGDThermo_8C L91-98, constScPrModel1_8C L106-115].
-__device__ __forceinline__ double muEffOf(const GasModel& gm, double muQGD) { return 0.0 + (gm.mu0 + muQGD); }
-__device__ __forceinline__ double alphaEffOf(const GasModel& gm, double muQGD) {
-    return gm.gamma * ((gm.alphah0 + muQGD / gm.PrQGD) + 0.0);
 }
 
 // ---------------------------------------------------------------------------
@@ -188,6 +159,7 @@ __device__ __forceinline__ void finishInternalFace(const MeshView& m, const Case
     s.alphauf = lerpf(w, alphaEffOf(gm, Bo.muQGD), alphaEffOf(gm, Bn.muQGD));
     s.muf = lerpf(w, muEffOf(gm, Bo.muQGD), muEffOf(gm, Bn.muQGD));
     s.tauf = lerpf(w, Bo.aOc, Bn.aOc) * hf;  // tauQGDf = lin(aQGD/c)*hQGDf [constScPrModel1_8C L103]
+    s.implicitDiffusion = gm.implicitDiffusion;
     double out[5], phiw;
     qgdFluxes<DBG>(s, g, S, out, phiw, DBG ? c.dbg + f : nullptr, nF);
 #pragma unroll
@@ -483,6 +455,7 @@ void faceFluxGvp3Kernel(const MeshView m, const CaseView c, const GasModel gm, c
         s.alphauf = lerpf(w, alphaEffOf(gm, Bo.muQGD), alphaEffOf(gm, Bn.muQGD));
         s.muf = lerpf(w, muEffOf(gm, Bo.muQGD), muEffOf(gm, Bn.muQGD));
         s.tauf = lerpf(w, Bo.aOc, Bn.aOc) * hf;
+        s.implicitDiffusion = gm.implicitDiffusion;
         double out[5], phiw;
         qgdFluxes<DBG>(s, g, S, out, phiw, DBG ? c.dbg + f : nullptr, nF);
 #pragma unroll
@@ -563,6 +536,7 @@ __global__ __launch_bounds__(QGD_BLOCK) void boundaryFaceFluxKernel(const MeshVi
             s.muf = muEffOf(gm, Bb.muQGD);
             const double hf = m.hf[f];
             s.tauf = Bb.aOc * hf;
+            s.implicitDiffusion = gm.implicitDiffusion;
             const double S[3] = {m.Sx[f], m.Sy[f], m.Sz[f]};
             double out[5], phiw;
             qgdFluxes<DBG>(s, g, S, out, phiw, DBG ? c.dbg + f : nullptr, (size_t)m.nF);

@@ -330,4 +330,34 @@ __global__ __launch_bounds__(QGD_BLOCK) void pointInterpFastKernel(const MeshVie
     for (int k = 0; k < NC; ++k) ptF[(size_t)p * NC + k] = acc[k];
 }
 
+// Workgroup reduction (wave shuffles + 4-entry LDS): slot[0] = max(a), slot[1] = min(b).
+// With `accumulate` the slot keeps the running extremum since it was last reset.
+template <int BLOCK = QGD_BLOCK>
+__device__ __forceinline__ void blockMaxMin(double a, double b, double* __restrict__ slot, const bool accumulate) {
+    __shared__ double sa[BLOCK / 64], sb[BLOCK / 64];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        a = fmax(a, __shfl_down(a, off, 64));
+        b = fmin(b, __shfl_down(b, off, 64));
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sa[wave] = a; sb[wave] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 1; i < BLOCK / 64; ++i) { a = fmax(a, sa[i]); b = fmin(b, sb[i]); }
+        if (accumulate) { a = fmax(a, slot[0]); b = fmin(b, slot[1]); }
+        slot[0] = a;
+        slot[1] = b;
+    }
+}
+// effective transport coefficients of a cell/patch value.  L0 assumption:
+// laminar muEff = mut(0) + mu, alphaEff = gamma*(alpha + alphat(0)) for an
+// internal-energy thermo; mu = mu0 + muQGD, alpha = alphah0 + muQGD/PrQGD
+// [QGDThermo_8C L91-98, constScPrModel1_8C L106-115].
+__device__ __forceinline__ double muEffOf(const GasModel& gm, double muQGD) { return 0.0 + (gm.mu0 + muQGD); }
+__device__ __forceinline__ double alphaEffOf(const GasModel& gm, double muQGD) {
+    return gm.gamma * ((gm.alphah0 + muQGD / gm.PrQGD) + 0.0);
+}
+
 }  // namespace qgd

@@ -58,15 +58,18 @@ def test_case_directory_runs_like_the_hand_built_case(tmp_path, stencil):
     dev.close()
 
 
-def test_implicit_diffusion_default_is_refused(tmp_path):
-    """an absent QGD.implicitDiffusion means true in the reference [QGDThermo.C L70-82]: outside this path, loudly"""
+def test_implicit_diffusion_default_runs(tmp_path):
+    """an absent QGD.implicitDiffusion means true in the reference [QGDThermo.C L70-82]: the case runs the implicit branch"""
     case_dir = str(tmp_path)
     write_step_case(case_dir)
     tp = os.path.join(case_dir, "constant", "thermophysicalProperties")
     text = open(tp).read()
     open(tp, "w").write(text.replace("implicitDiffusion false;", ""))
-    with pytest.raises(q.QgdError):
-        ff.load_case(case_dir)
+    dev, gc = ff.load_case(case_dir)
+    assert gc.options.implicitDiffusion == 1 and gc.thermo.implicitDiffusion() is True
+    gc.step(3)
+    assert gc.info()["minRho"] > 0
+    gc.close(); dev.close()
 
 
 def test_application_and_reference_run_comparison(tmp_path):

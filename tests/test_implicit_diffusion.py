@@ -1,0 +1,119 @@
+"""The implicitDiffusion branch of QGDFoam (the reference's default, QGDThermo.C L70-82): tauMC / phiTauMC
+[updateFluxes.H L107-111], the implicit U solve and phiSigmaDotU [QGDUEqn.H L54-75], the implicit e solve [QGDEEqn.H L53-64].
+
+CPU (oracle): with no viscosity at all (mu = 0, ScQGD = 0) the implicit branch is the explicit one with the consistent
+energy update, to rounding; a shear wave decays at the analytic rate in both branches (the two discretise the same
+operator: laplacian + div(mu dev2(T(grad U))) against the face-gradient form); vector components along empty directions are
+not solved (validComponents).  GPU: device against oracle after N steps, several meshes / stencils / patch kinds."""
+import numpy as np
+import pytest
+
+import qgdsolver_amd as q
+from qgdsolver_amd import _lib as L
+
+import cases
+from oracle import OracleCase
+from test_partition import mixed_bcs
+from util import make_mesh, oracle_mesh_of
+
+G, E = L.PATCH_GENERIC, L.PATCH_EMPTY
+
+
+def run_oracle(mesh, bc_fn, fields, steps, **opt):
+    oc = OracleCase(oracle_mesh_of(mesh), q.default_options(**opt))
+    if bc_fn:
+        bc_fn(oc)
+    oc.set_fields(*fields)
+    oc.step(steps)
+    return {f: oc.field(f) for f in ("rho", "U", "p", "e")}
+
+
+def test_without_viscosity_the_implicit_branch_is_the_consistent_explicit_one():
+    mesh = make_mesh("box654_jitter")
+    fields = cases.box_initial_fields(mesh.array("C").reshape(-1, 3))
+    base = dict(stencil="GaussVolPoint", deltaT=1e-3, mu=0.0, ScQGD=0.0, implicitTol=1e-15)
+    ex = run_oracle(mesh, mixed_bcs, fields, 10, implicitDiffusion=0, consistentEnergy=1, **base)
+    im = run_oracle(mesh, mixed_bcs, fields, 10, implicitDiffusion=1, **base)
+    for f in ex:
+        assert np.abs(ex[f] - im[f]).max() <= 1e-13 * np.abs(ex[f]).max(), f
+
+
+@pytest.mark.parametrize("implicit", [0, 1])
+def test_shear_wave_decays_at_the_analytic_rate(implicit):
+    """U_y = A sin(pi x) between two walls, rho = p = 1, no regularisation: rho dU_y/dt = mu d2U_y/dx2"""
+    rates = []
+    for n in (20, 40):
+        mesh = q.PolyMesh.box(n, 4, 1, hi=(1.0, 0.2, 0.05), patch_types=[G, G, G, G, E, E])
+        x = mesh.array("C").reshape(-1, 3)[:, 0]
+        mu, dt = 0.05, 2e-4 * (20 / n) ** 2
+        oc = OracleCase(oracle_mesh_of(mesh), q.default_options(stencil="reduced", deltaT=dt, mu=mu, alphaQGD=1e-12, ScQGD=0.0,
+                                                                implicitDiffusion=implicit, implicitTol=1e-14, consistentEnergy=1))
+        for patch in (0, 1):
+            oc.set_bc(patch, U=("fixedValue", (0.0, 0.0, 0.0)))
+        for patch in (4, 5):
+            oc.set_bc(patch, U=("none", None), T=("none", None), p=("none", None))
+        U = np.zeros((mesh.nCells, 3))
+        U[:, 1] = 1e-3 * np.sin(np.pi * x)
+        oc.set_fields(U, np.ones(mesh.nCells), np.ones(mesh.nCells))
+        oc.step(int(round(0.2 / dt)))
+        rho = oc.field("rho")[0]
+        i = n // 2
+        rates.append(abs(oc.field("U")[i, 1] / U[i, 1] - np.exp(-mu / rho * np.pi ** 2 * 0.2)))
+    assert rates[0] < 2e-4 and rates[1] < rates[0] / 3      # second order in h
+
+
+def test_components_along_empty_directions_are_not_solved():
+    mesh = q.PolyMesh.box(20, 1, 1, hi=(1.0, 0.05, 0.05), patch_types=[G, G, E, E, E, E])
+    x = mesh.array("C").reshape(-1, 3)[:, 0]
+    oc = OracleCase(oracle_mesh_of(mesh), q.default_options(stencil="reduced", deltaT=2e-4, mu=0.05, alphaQGD=1e-12, ScQGD=0.0,
+                                                            implicitDiffusion=1, implicitTol=1e-14))
+    for patch in (0, 1):
+        oc.set_bc(patch, U=("fixedValue", (0.0, 0.0, 0.0)))
+    for patch in (2, 3, 4, 5):
+        oc.set_bc(patch, U=("none", None), T=("none", None), p=("none", None))
+    U = np.zeros((mesh.nCells, 3))
+    U[:, 1] = 1e-3 * np.sin(np.pi * x)
+    oc.set_fields(U, np.ones(mesh.nCells), np.ones(mesh.nCells))
+    oc.step(200)
+    assert np.abs(oc.field("U")[:, 1] / U[:, 1] - 1.0).max() < 1e-8   # fvMatrix<vector>::solve skips invalid components (L0)
+
+
+GPU_CASES = [("box654_jitter", "GaussVolPoint", mixed_bcs), ("box654_tri", "GaussVolPoint", mixed_bcs), ("box654", "reduced", None),
+             ("step2d", "leastSquares", cases.forward_step_bcs), ("step2d", "GaussVolPoint", cases.forward_step_bcs),
+             ("plane2d_jitter", "leastSquares", None)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,stencil,bc_fn", GPU_CASES)
+def test_device_implicit_branch_matches_oracle(kind, stencil, bc_fn):
+    mesh = make_mesh(kind)
+    C = mesh.array("C").reshape(-1, 3)
+    if kind == "step2d":
+        U = np.zeros((mesh.nCells, 3)); U[:, 0] = 3.0
+        fields = (U, 1.0 + 0.05 * np.sin(2.0 * C[:, 0]) * np.cos(3.0 * C[:, 1]), 1.0 + 0.05 * np.cos(1.5 * C[:, 0] + C[:, 1]))
+    else:
+        fields = cases.box_initial_fields(C)
+        if mesh.nGeometricD == 2:
+            fields[0][:, 2] = 0.0
+    opt = dict(stencil=stencil, deltaT=5e-4, mu=2e-2, implicitDiffusion=1, implicitTol=1e-14, implicitMaxIter=2000)
+
+    def empty_patches(case):
+        for ip, t in enumerate(mesh.array("patchType")):
+            if t == E:
+                case.set_bc(ip, U=("none", None), T=("none", None), p=("none", None))
+
+    setup = bc_fn if bc_fn else empty_patches
+    ref = run_oracle(mesh, setup, fields, 12, **opt)
+    dev = q.Device(mesh)
+    gc = q.QGDFoamCase(dev, q.default_options(**opt))
+    setup(gc)
+    gc.set_fields(*fields)
+    gc.step(12)
+    for f in ref:
+        err = np.abs(gc.field(f) - ref[f]).max() / np.abs(ref[f]).max()
+        assert err <= 1e-10, (kind, stencil, f, err)
+    assert gc.info()["minRho"] > 0
+    # and it is not the explicit branch in disguise
+    ex = run_oracle(mesh, setup, fields, 12, **dict(opt, implicitDiffusion=0))
+    assert np.abs(ex["U"] - ref["U"]).max() > 1e-6 * np.abs(ref["U"]).max()
+    gc.close(); dev.close()
