@@ -548,7 +548,7 @@ int qgd_device_create(qgd_mesh_t mh, int deviceId, qgd_device_t* out) {
         v.fkind = up(s.fkind);
         v.Sx = up(s.Sf[0]); v.Sy = up(s.Sf[1]); v.Sz = up(s.Sf[2]);
         v.magSf = up(s.magSf); v.w = up(s.w); v.hf = up(s.hf); v.dn = up(s.dn);
-        v.X = reinterpret_cast<const double4*>(up(s.X)); v.Cc = reinterpret_cast<const double4*>(up(s.Cc));
+        v.X = up(s.X); v.Cc = up(s.Cc);
         v.bN = reinterpret_cast<const double4*>(up(s.bN)); v.bmvON = up(s.bmvON);
         v.ip13 = reinterpret_cast<const int2*>(up(s.ip13)); v.c2d = up(s.c2d);
         v.lsqSlice = up(s.lsqSlice); v.lsqCnt = up(s.lsqCnt); v.lsqCell = up(s.lsqCell);

@@ -30,8 +30,8 @@ struct MeshView {
     const double* w;         // nF
     const double* hf;        // nF
     const double* dn;        // nF
-    const double4* X;        // nP  vertex coordinates (x,y,z,0)
-    const double4* Cc;       // nC  cell centres
+    const double* X;         // 3*nP vertex coordinates, packed
+    const double* Cc;        // 3*nC cell centres, packed
     const double4* bN;       // nBF mirror points of boundary faces
     const double* bmvON;     // nBF
     const int2* ip13;        // nF

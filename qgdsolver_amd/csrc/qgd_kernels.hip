@@ -370,8 +370,8 @@ void faceFluxGvp3Kernel(const MeshView m, const CaseView c, const GasModel gm, c
         const int v3 = vt.w < 0 ? 0 : vt.w;
         const RecA q0 = c.P[vt.x], q1 = c.P[vt.y], q2 = c.P[vt.z], q3 = c.P[v3];
         // geometry the Gauss coefficients are rebuilt from (cached: shared by ~12 faces per vertex, 6 per cell)
-        const double4 cO = m.Cc[o], cN = m.Cc[n];
-        const double4 x0 = m.X[vt.x], x1 = m.X[vt.y], x2 = m.X[vt.z], x3 = m.X[v3];
+        const double4 cO = ld3(m.Cc, o), cN = ld3(m.Cc, n);
+        const double4 x0 = ld3(m.X, vt.x), x1 = ld3(m.X, vt.y), x2 = ld3(m.X, vt.z), x3 = ld3(m.X, v3);
         __builtin_amdgcn_sched_barrier(0);
 
         FaceVals<6> v;
@@ -1023,8 +1023,8 @@ __global__ __launch_bounds__(QGD_BLOCK) void fvscGradGvp3Kernel(const MeshView m
             p0[k] = ptF[(size_t)vt.x * NC + k]; p1[k] = ptF[(size_t)vt.y * NC + k];
             p2[k] = ptF[(size_t)vt.z * NC + k]; p3[k] = ptF[(size_t)v3 * NC + k];
         }
-        const double4 cO = m.Cc[o], cN = m.Cc[n];
-        const double4 x0 = m.X[vt.x], x1 = m.X[vt.y], x2 = m.X[vt.z], x3 = m.X[v3];
+        const double4 cO = ld3(m.Cc, o), cN = ld3(m.Cc, n);
+        const double4 x0 = ld3(m.X, vt.x), x1 = ld3(m.X, vt.y), x2 = ld3(m.X, vt.z), x3 = ld3(m.X, v3);
         __builtin_amdgcn_sched_barrier(0);
         if (kind == 0) {
             // quad, difference form (see faceFluxGvp3Kernel): V d_d phi = a5_d (phi_O - phi_N) + a0_d (phi_1 - phi_3) + a1_d (phi_2 - phi_4)

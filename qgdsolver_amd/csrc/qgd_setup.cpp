@@ -108,10 +108,8 @@ StaticData buildStaticData(const HostMesh& m) {
     if (want3D) {
         s.bmvON.assign((size_t)nBF, 0.0);
         s.bN.assign(4 * (size_t)nBF, 0.0);
-        s.X.assign(4 * (size_t)m.nPoints, 0.0);
-        s.Cc.assign(4 * (size_t)nC, 0.0);
-        for (int64_t p = 0; p < m.nPoints; ++p) for (int k = 0; k < 3; ++k) s.X[4 * p + k] = m.points[3 * p + k];
-        for (int64_t c = 0; c < nC; ++c) for (int k = 0; k < 3; ++k) s.Cc[4 * c + k] = m.C[3 * c + k];
+        s.X = m.points;
+        s.Cc = m.C;
     }
 
 #pragma omp parallel for schedule(static)

@@ -35,8 +35,8 @@ struct StaticData {
     // GaussVolPoint 3-D: the 10 (quad) / 13 (triangle) Gauss coefficients of a face are NOT stored: the face kernel
     // rebuilds them from the vertex coordinates and the two cell centres, which are gathered (and cached) instead
     // of streaming 80 B per face.  Boundary faces use the mirror point C_O + 2 (C_f - C_O) as "neighbour centre".
-    std::vector<double> X;        // 4*nP: x,y,z,0 (32-B records)
-    std::vector<double> Cc;       // 4*nC: cell centres (32-B records)
+    std::vector<double> X;        // 3*nP: vertex coordinates (packed 24-B records)
+    std::vector<double> Cc;       // 3*nC: cell centres (packed 24-B records)
     std::vector<double> bN;       // 4*nBF: mirror points of the boundary faces
     std::vector<double> bmvON;    // nBF
     // GaussVolPoint 2-D

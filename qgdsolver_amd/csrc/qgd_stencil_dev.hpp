@@ -12,6 +12,14 @@ namespace qgd {
 
 __device__ __forceinline__ double lerpf(double w, double a, double b) { return w * (a - b) + b; }
 
+// geometry records are packed triples (24 B): the face kernels pay for every byte their gathers pull in, padding included
+__device__ __forceinline__ double4 ld3(const double* __restrict__ base, const int i) {
+    const double* p = base + 3 * (size_t)i;
+    double4 r;
+    r.x = p[0]; r.y = p[1]; r.z = p[2]; r.w = 0.0;
+    return r;
+}
+
 // Streamed-once data (per-face geometry, gather lists) is loaded non-temporally so it does not push the
 // re-used cell/vertex records out of the 4 MiB L2 of the XCD.
 #ifndef QGD_NT
@@ -136,12 +144,12 @@ __device__ __forceinline__ void faceGradient(const MeshView& m, const int f, con
 #pragma unroll
             for (int k = 0; k < NC; ++k) psiN[k] = v.n[k] + v.sn[k] * hd * 0.5;  // [3D.C L790-793]
         }
-        const double4 cO = m.Cc[m.own[f]];
-        const double4 cN = internal ? m.Cc[m.nei[f]] : m.bN[b];
+        const double4 cO = ld3(m.Cc, m.own[f]);
+        const double4 cN = internal ? ld3(m.Cc, m.nei[f]) : m.bN[b];
         double rV;
         if (kind == 0) {  // quad: a2=-a0, a3=-a1, a4(nei)=-a5(own) [3D.C L361-363]
             double a[9];
-            gvpQuadCoef(cO, cN, m.X[vt.x], m.X[vt.y], m.X[vt.z], m.X[vt.w], a, rV);
+            gvpQuadCoef(cO, cN, ld3(m.X, vt.x), ld3(m.X, vt.y), ld3(m.X, vt.z), ld3(m.X, vt.w), a, rV);
             const double* p0 = ptF + (size_t)vt.x * NC;
             const double* p1 = ptF + (size_t)vt.y * NC;
             const double* p2 = ptF + (size_t)vt.z * NC;
@@ -165,7 +173,7 @@ __device__ __forceinline__ void faceGradient(const MeshView& m, const int f, con
             }
         } else {  // triangle: slots a0,a1,a2 vertices, a3 neighbour, owner = -a3 [3D.C L193-229]
             double t[12];
-            gvpTriCoef(cO, cN, m.X[vt.x], m.X[vt.y], m.X[vt.z], t, rV);
+            gvpTriCoef(cO, cN, ld3(m.X, vt.x), ld3(m.X, vt.y), ld3(m.X, vt.z), t, rV);
             const double* p0 = ptF + (size_t)vt.x * NC;
             const double* p1 = ptF + (size_t)vt.y * NC;
             const double* p2 = ptF + (size_t)vt.z * NC;
