@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--dropin-n", type=int, default=200, help="box edge of the fvsc drop-in measurement")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = debugging aid: all ranks share GPU 0 and halo messages are staged through host memory")
+    ap.add_argument("--halo", default=os.environ.get("QGD_BENCH_HALO", "torch"), choices=["torch", "native"],
+                    help="halo transport: torch.distributed P2P (default) or the library's own RCCL path (qgd_case_step_sharded)")
     ap.add_argument("--check", action="store_true", help="print a checksum of the owned cells (to compare runs at different N)")
     ap.add_argument("--cpu-n", type=int, default=64, help="edge of each CPU-baseline rank's sample box")
     ap.add_argument("--cpu-steps", type=int, default=24)
@@ -308,7 +310,24 @@ def main():
 
     ov = os.environ.get("QGD_BENCH_OVERLAP", "1")
     overlap = (world > 1) and ov != "0" and (not staged or ov == "force")
+    native = (args.halo == "native") and world > 1 and not staged
+    if native:
+        # the library's own transport: communicator bootstrapped like an MPI host would (id from rank 0, broadcast by the launcher)
+        from qgdsolver_amd.halo import NativeComm
+
+        def bcast(raw):
+            box = [raw]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+
+        comm = NativeComm(local_rank, rank, world, bcast=bcast)
+        peers = [rank - 1 if rank > 0 else -1, rank + 1 if rank < world - 1 else -1]
+        exchange = lambda: comm.exchange(case, peers)  # noqa: E731
+
     def plain_step():
+        if native:
+            comm.step(case, peers, overlapped=False)
+            return
         case.step_phase(0)   # flux assembly
         case.step_phase(1)   # cell update + boundary refresh (fixed deltaT: no global reduction needed)
         exchange()           # pack/unpack on the compute stream: strictly after the update, before the next assembly
@@ -318,7 +337,10 @@ def main():
 
         def step():
             # exchange hidden behind the bulk of the cell update (boundary layer of the shard is updated first)
-            halo.step_overlapped(torch, stream, halo_stream)
+            if native:
+                comm.step(case, peers, overlapped=True)   # the library's own halo stream and events
+            else:
+                halo.step_overlapped(torch, stream, halo_stream)
     else:
         step = plain_step
 
@@ -334,7 +356,8 @@ def main():
     if overlap:
         # insurance for the overlapped exchange: 3 steps in the plain order and 3 in the overlapped order from the same
         # state must give the same owned-cell checksums; otherwise fall back to the plain order and say so
-        case.set_halo_stream(stream.cuda_stream)
+        if not native:
+            case.set_halo_stream(stream.cuda_stream)
         for _ in range(3):
             plain_step()
         torch.cuda.synchronize()
@@ -342,7 +365,8 @@ def main():
         case.set_fields(*init_fields)
         exchange()
         torch.cuda.synchronize()
-        case.set_halo_stream(halo_stream.cuda_stream)
+        if not native:
+            case.set_halo_stream(halo_stream.cuda_stream)
         for _ in range(3):
             step()
         torch.cuda.synchronize()
@@ -351,11 +375,12 @@ def main():
         if not selfcheck <= 1e-12:
             overlap = False
             step = plain_step
-            case.set_halo_stream(stream.cuda_stream)
+            if not native:
+                case.set_halo_stream(stream.cuda_stream)
         # restart from the initial state so that runs at every N cover the same steps
         case.set_fields(*init_fields)
         torch.cuda.synchronize()
-        if overlap:
+        if overlap and not native:
             halo_stream.wait_stream(stream)
             with torch.cuda.stream(halo_stream):
                 exchange()
@@ -428,7 +453,7 @@ def main():
                             "GaussVolPoint, constScPrModel1, explicit diffusion, zeroGradient patches, fixed deltaT",
                 "cells": total_cells,
                 "cells_per_gpu": owned_cells,
-                "partition": (f"{world} k-slab(s), 1 ghost plane per cut, RCCL send/recv per step"
+                "partition": (f"{world} k-slab(s), 1 ghost plane per cut, RCCL send/recv per step ({'library transport' if native else 'torch.distributed'})"
                               + (", exchange overlapped with the cell update" if overlap else "")) if world > 1 else "single shard",
                 "stencil": "GaussVolPoint",
             },

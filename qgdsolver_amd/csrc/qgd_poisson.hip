@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -438,6 +439,10 @@ struct PressureSolver {
            *ones = nullptr, *part = nullptr, *scal = nullptr;
     const uint8_t* bKind = nullptr;
     int64_t bytes = 0;
+    // the V-cycle is a fixed sequence of ~75 small launches on fixed buffers (r -> z): captured once into a hipGraph and
+    // replayed per CG iteration (the coarse levels are launch-latency bound)
+    hipGraphExec_t cycleGraph = nullptr;
+    bool cycleGraphTried = false;
 
     template <class T>
     T* alloc(size_t n, const T* host = nullptr) {
@@ -450,7 +455,10 @@ struct PressureSolver {
         else PCHECK(hipMemset(p, 0, nb));
         return (T*)p;
     }
-    ~PressureSolver() { for (void* p : owned) (void)hipFree(p); }
+    ~PressureSolver() {
+        if (cycleGraph) (void)hipGraphExecDestroy(cycleGraph);
+        for (void* p : owned) (void)hipFree(p);
+    }
 
     // z = M r on level l (b -> x)
     void vcycle(size_t l, const double* b, double* x) {
@@ -648,8 +656,23 @@ int pressureSolve(PressureSolver* S, const double* phiu, const double* phiwo, co
     double res = sumAbsR / normFactor;
     residuals[0] = res;
     auto precondition = [&]() {   // z = M r
-        if (S->precond == 1 && !S->L.empty()) S->vcycle(0, S->r, S->z);
-        else mgSmoothKernel<<<nb, PB, 0, stream>>>(MgLevelDev{nC, 0, S->diag}, 1.0, S->r, nullptr, S->z, nullptr);   // z = r/diag
+        if (S->precond == 1 && !S->L.empty()) {
+            if (!S->cycleGraphTried) {
+                S->cycleGraphTried = true;
+                hipGraph_t g = nullptr;
+                if (!std::getenv("QGD_MG_NOGRAPH") && hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                    bool ok = true;
+                    try { S->vcycle(0, S->r, S->z); } catch (...) { ok = false; }
+                    if (hipStreamEndCapture(stream, &g) != hipSuccess || !ok || !g) { g = nullptr; (void)hipGetLastError(); }
+                    if (g) {
+                        if (hipGraphInstantiate(&S->cycleGraph, g, nullptr, nullptr, 0) != hipSuccess) { S->cycleGraph = nullptr; (void)hipGetLastError(); }
+                        (void)hipGraphDestroy(g);
+                    }
+                }
+            }
+            if (S->cycleGraph) PCHECK(hipGraphLaunch(S->cycleGraph, stream));
+            else S->vcycle(0, S->r, S->z);
+        } else mgSmoothKernel<<<nb, PB, 0, stream>>>(MgLevelDev{nC, 0, S->diag}, 1.0, S->r, nullptr, S->z, nullptr);   // z = r/diag
     };
     auto dot = [&](const double* x, const double* y) {
         dotKernel<<<nb, PB, 0, stream>>>(nC, x, y, S->part);
