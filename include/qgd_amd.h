@@ -226,6 +226,13 @@ int qgd_fvsc_div_t(qgd_device_t d, int stencilId, const double* cell,
  * pipeline; buffers of the persistent per-device workspace are reused from call to call (no allocation per call). */
 int qgd_device_op_times(qgd_device_t d, double ms[3]);
 
+/* How the internal faces of a 3-D mesh go through the GaussVolPoint flux kernel: info[0] = faces per tile (workgroup) of the
+ * LDS-staged kernel, 0 when every face goes through the gather kernel (not a 3-D mesh, QGD_FTILE=0); info[1] = tiles;
+ * info[2] = tiles left to the gather kernel (more distinct cell / vertex records than the staged kernel brings in);
+ * info[3] = LDS bytes per workgroup.  Both kernels do the arithmetic of GaussVolPointBase3D_8C_source.html L346-389,
+ * L488-513 + QGDFoam_2updateFluxes_8H_source.html L41-139 in the same order: results are bit-identical. */
+int qgd_device_face_tiles(qgd_device_t d, int64_t info[4]);
+
 /* qgdInterpolate / linearInterpolate [QGDInterpolate_8H_source.html L38-67]: face = w*(phi_O - phi_N) + phi_N, patch faces
  * take the patch value.  cell nCells*ncomp, bnd nBoundaryFaces*ncomp, out nFaces*ncomp (HOST pointers), ncomp in 1..9. */
 int qgd_interpolate(qgd_device_t d, int32_t ncomp, const double* cell, const double* bnd, double* out);

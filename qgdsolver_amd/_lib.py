@@ -9,7 +9,8 @@ import os
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libqgd_amd.so")
+# QGD_AMD_LIB: another build of the same library (A/B timing of compile-time variants, scripts/ab_variants.sh)
+LIB_PATH = os.environ.get("QGD_AMD_LIB") or os.path.join(_HERE, "libqgd_amd.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -84,6 +85,7 @@ SIGNATURES = {
     "qgd_fvsc_div_v": (C.c_int, [handle, C.c_int, c_double_p, c_double_p, c_double_p]),
     "qgd_fvsc_div_t": (C.c_int, [handle, C.c_int, c_double_p, c_double_p, c_double_p]),
     "qgd_device_op_times": (C.c_int, [handle, c_double_p]),
+    "qgd_device_face_tiles": (C.c_int, [handle, C.POINTER(C.c_int64)]),
     "qgd_interpolate": (C.c_int, [handle, C.c_int32, c_double_p, c_double_p, c_double_p]),
     "qgd_flux": (C.c_int, [handle, C.c_int32, c_double_p, c_double_p, c_double_p]),
     "qgd_device_get": (C.c_int, [handle, C.c_char_p, c_double_p, C.c_int64]),

@@ -539,10 +539,27 @@ int qgd_device_create(qgd_mesh_t mh, int deviceId, qgd_device_t* out) {
         for (int k = 0; k < 3; ++k) v.emptyDir[k] = m.geometricD[k] < 0 ? 1 : 0;
         { const char* e = std::getenv("QGD_XCD_RUN"); v.xcdRun = e ? std::atoi(e) : 16; }
         { const char* e = std::getenv("QGD_FBLOCK"); v.fblock = e ? std::atoi(e) : 128; }
+        v.hasOther = 0;
+        for (int64_t f = 0; f < s.nIF; ++f) if (s.fkind[f] == FK_OTHER) { v.hasOther = 1; break; }
+        { const char* e = std::getenv("QGD_FPERSIST"); v.fpersist = e ? std::atoi(e) : 0; }
         { const char* e = std::getenv("QGD_CBLOCK"); v.cblock = e ? std::atoi(e) : 256; }
         { const char* e = std::getenv("QGD_PBLOCK"); v.pblock = e ? std::atoi(e) : 256; }
         // upload + free each table in turn so the host peak stays at one table
         auto up = [&](auto& vec) { auto* p = a.upload(vec); std::decay_t<decltype(vec)>().swap(vec); return p; };
+        {
+            // face tiles of the LDS-staged 3-D GaussVolPoint kernel (QGD_FTILE=0: the gather kernel)
+            const char* e = std::getenv("QGD_FTILE");
+            FaceTiles t;
+            if (!e || std::atoi(e) != 0) t = buildFaceTiles(s, v.fblock);
+            const int64_t lds = ((int64_t)t.maxCells * 104 + (int64_t)t.maxVerts * 72 + 255) / 256 * 256;
+            if (t.fb != 0 && lds <= 65536) {
+                v.tileLds = (int32_t)lds;
+                { const char* w = std::getenv("QGD_FT_WAVES"); v.tileWaves = w ? std::atoi(w) : 3; }
+                v.nTileSpill = (int32_t)t.spill.size(); v.tileSpill = up(t.spill);
+                v.tileOff = up(t.off); v.tileCells = up(t.cells); v.tileVerts = up(t.verts);
+                v.locC = up(t.locC); v.locV = reinterpret_cast<const uint2*>(up(t.locV));
+            }
+        }
         v.own = up(s.own); v.nei = up(s.nei);
         v.verts = reinterpret_cast<const int4*>(up(s.verts));
         v.fkind = up(s.fkind);
@@ -700,6 +717,16 @@ static int fvscOp(qgd_device_t d, int stencilId, int op, int NC, const double* c
 int qgd_device_op_times(qgd_device_t d, double ms[3]) {
     if (!d || !ms) return fail(QGD_ERR_INVALID, "null argument");
     for (int k = 0; k < 3; ++k) ms[k] = d->opMs[k];
+    return QGD_OK;
+}
+int qgd_device_face_tiles(qgd_device_t d, int64_t info[4]) {
+    if (!d || !info) return fail(QGD_ERR_INVALID, "null argument");
+    const MeshView& v = d->view;
+    const bool on = v.tileOff != nullptr;
+    info[0] = on ? v.fblock : 0;
+    info[1] = on ? (v.nIF + v.fblock - 1) / v.fblock : 0;
+    info[2] = on ? v.nTileSpill : 0;
+    info[3] = on ? v.tileLds : 0;
     return QGD_OK;
 }
 int qgd_fvsc_grad_s(qgd_device_t d, int id, const double* cell, const double* bnd, double* out) { return fvscOp(d, id, 0, 1, cell, bnd, out); }

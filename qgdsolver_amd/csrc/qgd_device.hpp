@@ -20,6 +20,8 @@ struct MeshView {
     int32_t emptyDir[3];     // 1 for the directions of empty patches (vector components the segregated solves skip)
     int32_t cblock, pblock;  // tiles of the cell-update and vertex kernels (64, 128 or 256)
     int32_t fblock;          // face tile of the 3-D GaussVolPoint kernel: 64, 128 or 256 faces per workgroup
+    int32_t hasOther;        // 1: some internal face has more than four vertices (FK_OTHER)
+    int32_t fpersist;        // > 0: workgroups of the persistent face kernel (experiment switch QGD_FPERSIST)
     int32_t xcdRun;          // tiles per XCD run of the workgroup->tile map (0: one contiguous eighth per XCD)
     const int32_t* own;      // nF
     const int32_t* nei;      // nIF
@@ -43,6 +45,12 @@ struct MeshView {
     const int32_t* cfSlice; const uint8_t* cfCount; const int32_t* cfItem;                     // sliced ELL (64-cell slices)
     const int32_t* fpos;     // nIF: storage position of an internal face's net fluxes (slot-major, qgd_setup.hpp)
     const int32_t* cfPos;    // cfItem with positions instead of labels: gather list of the cell kernel
+    // face tiles of the LDS-staged 3-D GaussVolPoint kernel (qgd_setup.hpp FaceTiles); tileOff == nullptr: gather kernel
+    const int32_t* tileOff; const int32_t* tileCells; const int32_t* tileVerts;
+    const uint32_t* locC; const uint2* locV;
+    const int32_t* tileSpill; int32_t nTileSpill;   // tiles left to the gather kernel
+    int32_t tileLds;         // dynamic LDS bytes of the largest tile
+    int32_t tileWaves;       // waves per SIMD the staged kernel is compiled for (2, 3 or 4)
     const double* V; const double* hQGD; const uint8_t* ghost;
     const int32_t* bPatch; const double* hQGDb;
 };

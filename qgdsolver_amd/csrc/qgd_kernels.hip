@@ -348,14 +348,168 @@ void faceFluxGvp2Kernel(const MeshView m, const CaseView c, const GasModel gm, c
 #ifndef QGD_F_WAVES_MAX
 #define QGD_F_WAVES_MAX 3
 #endif
+// Gauss coefficients of one internal face from the geometry records alone (so that a kernel holding its records in LDS can
+// let go of the geometry before it touches the field values).  Quad [GaussVolPointBase3D_8C L346-389, L488-513] in difference
+// form: with a2=-a0, a3=-a1, a4=-a5,
+//   V d_d phi = a5_d (phi_O - phi_N) + a0_d (phi_1 - phi_3) + a1_d (phi_2 - phi_4),
+//   6 a0 = (N-O) x (p2-p4),  6 a1 = (N-O) x (p3-p1),  6 a5 = (p1-p3) x (p2-p4),  6 V = -(p3-p1).(6 a0)
+// (the 1/6 cancel): coef = {a0[3], a1[3], a5[3]}, rV = 1/(6V).  Triangle [L193-229]: coef = t[12] of gvpTriCoef.
+__device__ __forceinline__ void gvp3Coefs(const int kind, const double4& cO, const double4& cN, const double4& x0, const double4& x1,
+                                          const double4& x2, const double4& x3, double (&coef)[12], double& rV) {
+    if (kind == 0) {
+        const double NO[3] = {cN.x - cO.x, cN.y - cO.y, cN.z - cO.z};
+        const double d24[3] = {x1.x - x3.x, x1.y - x3.y, x1.z - x3.z};
+        const double d31[3] = {x2.x - x0.x, x2.y - x0.y, x2.z - x0.z};
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int u = (d + 1) % 3, w2 = (d + 2) % 3;
+            coef[d] = NO[u] * d24[w2] - NO[w2] * d24[u];
+            coef[3 + d] = NO[u] * d31[w2] - NO[w2] * d31[u];
+            coef[6 + d] = d24[u] * d31[w2] - d24[w2] * d31[u];
+        }
+        coef[9] = coef[10] = coef[11] = 0.0;
+        rV = -1.0 / (d31[0] * coef[0] + d31[1] * coef[1] + d31[2] * coef[2]);
+    } else if (kind == 1) {
+        gvpTriCoef(cO, cN, x0, x1, x2, coef, rV);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) coef[i] = 0.0;
+        rV = 0.0;
+    }
+}
+
+// everything after the loads of one internal face: gradient coefficients from the geometry, the 6-component gradient, the 13
+// interpolations, the flux algebra, the five net fluxes (slot-major position fp), the face's share of the Courant number
+template <bool DBG>
+__device__ __forceinline__ void gvp3FaceBody(const MeshView& m, const CaseView& c, const GasModel& gm, const int f, const int fp, const int kind,
+                                             const double w, const double hf, const double (&S)[3], const RecA& Ao, const RecA& An,
+                                             const RecB& Bo, const RecB& Bn, const RecA& q0, const RecA& q1, const RecA& q2, const RecA& q3,
+                                             const double (&coef)[12], const double rVc, const double msO, const double dnO,
+                                             const int adjustDt, double& cof, double& tauMin) {
+    // msO, dnO: |Sf| and deltaCoeffs of the face, read only on meshes that have faces with more than four vertices
+    const size_t nF = (size_t)m.nF;
+#ifdef QGD_F_EXPERIMENT
+    // timing experiments only (wrong results): 1 = every load consumed, no flux algebra; 2 = as 1 and nothing stored but one value per wave
+    {
+        double acc = w + hf + S[0] + S[1] + S[2] + rVc + coef[0] + coef[1] + coef[2] + coef[3] + coef[4] + coef[5] + coef[6] + coef[7] + coef[8] +
+                     coef[9] + coef[10] + coef[11] + Bo.H + Bo.c + Bo.muQGD + Bo.aOc + Bn.H + Bn.c + Bn.muQGD + Bn.aOc;
+        const RecA* r[6] = {&Ao, &An, &q0, &q1, &q2, &q3};
+#pragma unroll
+        for (int i = 0; i < 6; ++i) acc += r[i]->rho + r[i]->ux + r[i]->uy + r[i]->uz + r[i]->p + r[i]->e;
+        acc += (double)kind;
+        if (QGD_F_EXPERIMENT == 1) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) c.flux[(size_t)k * nF + fp] = acc + k;
+        } else if (acc == 1.2345e300) c.flux[fp] = acc;   // experiments 2, 3
+        return;
+    }
+#endif
+    FaceVals<6> v;
+    loadVals(Ao, v.o);
+    loadVals(An, v.n);
+    double g[18];
+    if (kind == 0) {
+        // Quad: coef = {a0, a1, a5}, rVc = 1/(6V) (gvp3Coefs)
+        const double* A0 = coef;
+        const double* A1 = coef + 3;
+        const double* A5 = coef + 6;
+        const double rV6 = rVc;
+        double p0[6], p1[6], p2[6], p3[6];
+        loadVals(q0, p0); loadVals(q1, p1); loadVals(q2, p2); loadVals(q3, p3);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const double D5 = (v.o[k] - v.n[k]) * rV6, D0 = (p0[k] - p2[k]) * rV6, D1 = (p1[k] - p3[k]) * rV6;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) g[d * 6 + k] = A5[d] * D5 + A0[d] * D0 + A1[d] * D1;
+        }
+    } else if (kind == 1) {
+        // Triangle [GaussVolPointBase3D_8C L193-229, L844-854], out of the records already in registers: the same
+        // operations in the same order as faceGradient<ST_GVP3> (no second round of loads in mixed wavefronts)
+        const double* t = coef;
+        const double rV = rVc;
+        double p0[6], p1[6], p2[6];
+        loadVals(q0, p0); loadVals(q1, p1); loadVals(q2, p2);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const double a0 = t[4 * d], a1 = t[4 * d + 1], a2 = t[4 * d + 2], a3 = t[4 * d + 3];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                double sg = v.n[k] * a3;
+                sg += v.o[k] * (-a3);
+                sg += p0[k] * a0;
+                sg += p1[k] * a1;
+                sg += p2[k] * a2;
+                g[d * 6 + k] = sg * rV;
+            }
+        }
+        double dg[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) dg[j] = g[j * 6 + 1 + j];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) g[i * 6 + 1 + j] = dg[j];
+    } else if (kind == 2) {
+        // more than four vertices: nf (x) snGrad [GaussVolPointBase3D_8C L759-768], as faceGradient<ST_GVP3> has it
+        const double nx = S[0] / msO, ny = S[1] / msO, nz = S[2] / msO;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const double sn = dnO * (v.n[k] - v.o[k]);
+            g[0 * 6 + k] = nx * sn;
+            g[1 * 6 + k] = ny * sn;
+            g[2 * 6 + k] = nz * sn;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 18; ++i) g[i] = 0.0;
+    }
+    FaceState s;
+    s.rhof = lerpf(w, Ao.rho, An.rho);
+    const double Uo[3] = {Ao.ux, Ao.uy, Ao.uz}, Un[3] = {An.ux, An.uy, An.uz};
+    double rUo[3], rUn[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        s.Uf[k] = lerpf(w, Uo[k], Un[k]);
+        rUo[k] = Ao.rho * Uo[k];
+        rUn[k] = An.rho * Un[k];
+        s.rhoUf[k] = lerpf(w, rUo[k], rUn[k]);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) s.UrhoUf[3 * i + j] = lerpf(w, Uo[i] * rUo[j], Un[i] * rUn[j]);
+    s.pf = lerpf(w, Ao.p, An.p);
+    s.cf = lerpf(w, Bo.c, Bn.c);
+    s.Hf = lerpf(w, Bo.H, Bn.H);
+    s.gammaf = lerpf(w, gm.gamma, gm.gamma);
+    s.alphauf = lerpf(w, alphaEffOf(gm, Bo.muQGD), alphaEffOf(gm, Bn.muQGD));
+    s.muf = lerpf(w, muEffOf(gm, Bo.muQGD), muEffOf(gm, Bn.muQGD));
+    s.tauf = lerpf(w, Bo.aOc, Bn.aOc) * hf;
+    s.implicitDiffusion = gm.implicitDiffusion;
+    double out[5], phiw;
+    qgdFluxes<DBG>(s, g, S, out, phiw, DBG ? c.dbg + f : nullptr, nF);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) c.flux[(size_t)k * nF + fp] = out[k];
+    if (adjustDt) {
+        bool counted = true;
+        if (m.ghost != nullptr) counted = !(m.ghost[m.own[f]] == 1 && m.ghost[m.nei[f]] == 1);
+        if (counted) {
+            const double ms = sqrt(S[0] * S[0] + S[1] * S[1] + S[2] * S[2]);
+            const double Unf = s.Uf[0] * (S[0] / ms) + s.Uf[1] * (S[1] / ms) + s.Uf[2] * (S[2] / ms);
+            cof = fmax(fabs(Unf + s.cf), fabs(Unf - s.cf)) * c.dt[0] / hf;
+            tauMin = s.tauf;
+        }
+    }
+}
+
 template <bool DBG, int FB>
 __global__ __launch_bounds__(FB) __attribute__((amdgpu_waves_per_eu(QGD_F_WAVES_MIN, QGD_F_WAVES_MAX)))
-void faceFluxGvp3Kernel(const MeshView m, const CaseView c, const GasModel gm, const int adjustDt) {
-    const int tile = xcdTile((int)gridDim.x, m.xcdRun * (QGD_BLOCK / FB));
+void faceFluxGvp3Kernel(const MeshView m, const CaseView c, const GasModel gm, const int adjustDt, const int32_t* __restrict__ tileList) {
+    // tileList: the tiles the staged kernel below leaves to this one (nullptr: every tile)
+    const int tile = tileList ? tileList[blockIdx.x] : xcdTile((int)gridDim.x, m.xcdRun * (QGD_BLOCK / FB));
     const int f = tile * FB + (int)threadIdx.x;
     double cof = -1e300, tauMin = 1e300;
     if (f < m.nIF) {
-        const size_t nF = (size_t)m.nF;
         // (0) labels
         const int o = ldStream(m.own + f), n = ldStream(m.nei + f), fp = ldStream(m.fpos + f);
         const int4 vt = m.verts[f];
@@ -364,7 +518,16 @@ void faceFluxGvp3Kernel(const MeshView m, const CaseView c, const GasModel gm, c
         const double w = ldStream(m.w + f);
         const double hf = ldStream(m.hf + f);
         const double S[3] = {ldStream(m.Sx + f), ldStream(m.Sy + f), ldStream(m.Sz + f)};
+        double msO = 1.0, dnO = 0.0;
+        if (m.hasOther) { msO = m.magSf[f]; dnO = m.dn[f]; }
         // (2) gathered records (vertex 3 is clamped for triangles; unused there)
+#if defined(QGD_F_EXPERIMENT) && QGD_F_EXPERIMENT == 3
+        // timing experiment: the streamed face data only, no gathers
+        const RecA Ao = {(double)o, 0, 0, 0, 0, 0}, An = {(double)n, 0, 0, 0, 0, 0};
+        const RecB Bo = {0, 0, 0, 0}, Bn = {0, 0, 0, 0};
+        const RecA q0 = {(double)vt.x, 0, 0, 0, 0, 0}, q1 = {(double)vt.y, 0, 0, 0, 0, 0}, q2 = {(double)vt.z, 0, 0, 0, 0, 0}, q3 = {(double)vt.w, 0, 0, 0, 0, 0};
+        const double4 cO = make_double4(0, 0, 0, 0), cN = cO, x0 = cO, x1 = cO, x2 = cO, x3 = cO;
+#else
         const RecA Ao = c.A[o], An = c.A[n];
         const RecB Bo = c.B[o], Bn = c.B[n];
         const int v3 = vt.w < 0 ? 0 : vt.w;
@@ -373,102 +536,179 @@ void faceFluxGvp3Kernel(const MeshView m, const CaseView c, const GasModel gm, c
         const double4 cO = ld3(m.Cc, o), cN = ld3(m.Cc, n);
         const double4 x0 = ld3(m.X, vt.x), x1 = ld3(m.X, vt.y), x2 = ld3(m.X, vt.z), x3 = ld3(m.X, v3);
         __builtin_amdgcn_sched_barrier(0);
+#endif
 
-        FaceVals<6> v;
-        loadVals(Ao, v.o);
-        loadVals(An, v.n);
-        double g[18];
-        if (kind == 0) {
-            // Quad [GaussVolPointBase3D_8C L346-389, L488-513] in difference form.  With a2=-a0, a3=-a1, a4=-a5:
-            //   V d_d phi = a5_d (phi_O - phi_N) + a0_d (phi_1 - phi_3) + a1_d (phi_2 - phi_4),
-            //   6 a0 = (N-O) x (p2-p4),  6 a1 = (N-O) x (p3-p1),  6 a5 = (p1-p3) x (p2-p4),  6 V = -(p3-p1).(6 a0)
-            // (the 1/6 cancel).  Same sum as the listing, grouped so the large vertex values cancel first.
-            const double NO[3] = {cN.x - cO.x, cN.y - cO.y, cN.z - cO.z};
-            const double d24[3] = {x1.x - x3.x, x1.y - x3.y, x1.z - x3.z};
-            const double d31[3] = {x2.x - x0.x, x2.y - x0.y, x2.z - x0.z};
-            double A0[3], A1[3], A5[3];
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                const int u = (d + 1) % 3, w2 = (d + 2) % 3;
-                A0[d] = NO[u] * d24[w2] - NO[w2] * d24[u];
-                A1[d] = NO[u] * d31[w2] - NO[w2] * d31[u];
-                A5[d] = d24[u] * d31[w2] - d24[w2] * d31[u];
-            }
-            const double rV6 = -1.0 / (d31[0] * A0[0] + d31[1] * A0[1] + d31[2] * A0[2]);
-            double p0[6], p1[6], p2[6], p3[6];
-            loadVals(q0, p0); loadVals(q1, p1); loadVals(q2, p2); loadVals(q3, p3);
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                const double D5 = (v.o[k] - v.n[k]) * rV6, D0 = (p0[k] - p2[k]) * rV6, D1 = (p1[k] - p3[k]) * rV6;
-#pragma unroll
-                for (int d = 0; d < 3; ++d) g[d * 6 + k] = A5[d] * D5 + A0[d] * D0 + A1[d] * D1;
-            }
-        } else if (kind == 1) {
-            // Triangle [GaussVolPointBase3D_8C L193-229, L844-854], out of the records already in registers: the same
-            // operations in the same order as faceGradient<ST_GVP3> (no second round of loads in mixed wavefronts)
-            double t[12], rV;
-            gvpTriCoef(cO, cN, x0, x1, x2, t, rV);
-            double p0[6], p1[6], p2[6];
-            loadVals(q0, p0); loadVals(q1, p1); loadVals(q2, p2);
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                const double a0 = t[4 * d], a1 = t[4 * d + 1], a2 = t[4 * d + 2], a3 = t[4 * d + 3];
-#pragma unroll
-                for (int k = 0; k < 6; ++k) {
-                    double sg = v.n[k] * a3;
-                    sg += v.o[k] * (-a3);
-                    sg += p0[k] * a0;
-                    sg += p1[k] * a1;
-                    sg += p2[k] * a2;
-                    g[d * 6 + k] = sg * rV;
-                }
-            }
-            double dg[3];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) dg[j] = g[j * 6 + 1 + j];
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int j = 0; j < 3; ++j) g[i * 6 + 1 + j] = dg[j];
-        } else {
-            faceGradient<ST_GVP3, 6, 1>(m, f, v, reinterpret_cast<const double*>(c.A), reinterpret_cast<const double*>(c.P), g);
+        double coef[12], rVc;
+        gvp3Coefs(kind, cO, cN, x0, x1, x2, x3, coef, rVc);
+        gvp3FaceBody<DBG>(m, c, gm, f, fp, kind, w, hf, S, Ao, An, Bo, Bn, q0, q1, q2, q3, coef, rVc, msO, dnO, adjustDt, cof, tauMin);
+    }
+    if (adjustDt) blockMaxMin<FB>(cof, tauMin, c.blkFace + 2 * (size_t)tile, false);
+}
+
+// ---------------------------------------------------------------------------
+// The same faces through LDS (qgd_setup.hpp FaceTiles).  The gather kernel above asks the vector L1 for 2 + 4 records per
+// face as 16-B pieces at a 48-B stride: ~40 cache-line lookups per wave instruction, 44 such instructions per wave, and
+// the counters show the L1 tag pipe busy all of the kernel (TCP_GATE_EN ~ 100 %, TA address stalls 42 %) while neither
+// the time nor the HBM bytes respond to better cell orders.  Here the workgroup loads each DISTINCT record of its tile
+// once, as consecutive 16-B (records) and 8-B (geometry) pieces -- lane q takes piece q, so a wave instruction covers
+// whole cache lines -- parks them in LDS and every face reads its six records from there.  Same arithmetic, same
+// operation order, bit-identical fluxes.
+// ---------------------------------------------------------------------------
+// ---------------------------------------------------------------------------
+// Persistent form of the gather kernel: a workgroup walks tiles b, b + G, b + 2G, ... (G workgroups = what the chip holds at
+// once) and asks for the labels and streamed data of its NEXT tile before it computes the current one.  A wave of the
+// one-tile-per-workgroup kernel lives through four latencies in series -- launch, labels, gathered records, store drain at
+// s_endpgm -- and only two such waves fit a SIMD; here the chain per tile is the gathers alone.
+// ---------------------------------------------------------------------------
+template <int FB>
+__global__ __launch_bounds__(FB) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void faceFluxGvp3PersistKernel(const MeshView m, const CaseView c, const GasModel gm, const int adjustDt) {
+    const int G = (int)gridDim.x, b = (int)blockIdx.x;
+    const int nTiles = (m.nIF + FB - 1) / FB;
+    const int run = max(1, m.xcdRun * (QGD_BLOCK / FB));
+    // within every window of G consecutive tiles: runs of `run` tiles per XCD (block b sits on XCD b % 8)
+    const int j = b >> 3;
+    const int slot = ((G % (8 * run)) == 0) ? ((j / run) * 8 + (b & 7)) * run + (j % run) : b;
+    const int tid = (int)threadIdx.x;
+    const int last = m.nIF - 1;
+    int tile = slot;
+    if (tile >= nTiles) return;
+    // labels + streamed data of the first tile
+    int f = min(tile * FB + tid, last);
+    int o = ldStream(m.own + f), n = ldStream(m.nei + f), fp = ldStream(m.fpos + f);
+    int4 vt = m.verts[f];
+    int kind = m.fkind[f];
+    double w = ldStream(m.w + f), hf = ldStream(m.hf + f);
+    double Sx = ldStream(m.Sx + f), Sy = ldStream(m.Sy + f), Sz = ldStream(m.Sz + f);
+    double msO = 1.0, dnO = 0.0;
+    if (m.hasOther) { msO = m.magSf[f]; dnO = m.dn[f]; }
+    while (true) {
+        const int fReal = tile * FB + tid;
+        // (2) gathered records of this tile
+        const RecA Ao = c.A[o], An = c.A[n];
+        const RecB Bo = c.B[o], Bn = c.B[n];
+        const int v3 = vt.w < 0 ? 0 : vt.w;
+        const RecA q0 = c.P[vt.x], q1 = c.P[vt.y], q2 = c.P[vt.z], q3 = c.P[v3];
+        const double4 cO = ld3(m.Cc, o), cN = ld3(m.Cc, n);
+        const double4 x0 = ld3(m.X, vt.x), x1 = ld3(m.X, vt.y), x2 = ld3(m.X, vt.z), x3 = ld3(m.X, v3);
+        __builtin_amdgcn_sched_barrier(0);
+        // (0', 1') labels and streamed data of the next tile, in flight while this one is computed
+        const int next = tile + G;
+        const bool more = next < nTiles;
+        const int fn = min((more ? next : tile) * FB + tid, last);
+        const int o2 = ldStream(m.own + fn), n2 = ldStream(m.nei + fn), fp2 = ldStream(m.fpos + fn);
+        const int4 vt2 = m.verts[fn];
+        const int kind2 = m.fkind[fn];
+        const double w2 = ldStream(m.w + fn), hf2 = ldStream(m.hf + fn);
+        const double Sx2 = ldStream(m.Sx + fn), Sy2 = ldStream(m.Sy + fn), Sz2 = ldStream(m.Sz + fn);
+        double msO2 = 1.0, dnO2 = 0.0;
+        if (m.hasOther) { msO2 = m.magSf[fn]; dnO2 = m.dn[fn]; }
+        __builtin_amdgcn_sched_barrier(0);
+        double cof = -1e300, tauMin = 1e300;
+        if (fReal < m.nIF) {
+            const double S[3] = {Sx, Sy, Sz};
+            double coef[12], rVc;
+            gvp3Coefs(kind, cO, cN, x0, x1, x2, x3, coef, rVc);
+            gvp3FaceBody<false>(m, c, gm, fReal, fp, kind, w, hf, S, Ao, An, Bo, Bn, q0, q1, q2, q3, coef, rVc, msO, dnO, adjustDt, cof, tauMin);
         }
-        FaceState s;
-        s.rhof = lerpf(w, Ao.rho, An.rho);
-        const double Uo[3] = {Ao.ux, Ao.uy, Ao.uz}, Un[3] = {An.ux, An.uy, An.uz};
-        double rUo[3], rUn[3];
+        if (adjustDt) blockMaxMin<FB>(cof, tauMin, c.blkFace + 2 * (size_t)tile, false);
+        if (!more) break;
+        tile = next;
+        o = o2; n = n2; fp = fp2; vt = vt2; kind = kind2; w = w2; hf = hf2; Sx = Sx2; Sy = Sy2; Sz = Sz2; msO = msO2; dnO = dnO2;
+    }
+}
+
+typedef double v2d __attribute__((ext_vector_type(2)));   // one 16-B piece
+#ifndef QGD_FT_WAVES_MIN
+#define QGD_FT_WAVES_MIN 2
+#endif
+#ifndef QGD_FT_WAVES_MAX
+#define QGD_FT_WAVES_MAX 3
+#endif
+template <int FB, int WAVES>
+__global__ __launch_bounds__(FB) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
+void faceFluxGvp3TileKernel(const MeshView m, const CaseView c, const GasModel gm, const int adjustDt) {
+    extern __shared__ v2d tileLds[];
+    constexpr int KC = 4, KB2 = 3, KV = 5;   // piece loads per thread: ceil(3 capC / FB), ceil(2 capC / FB), ceil(3 capV / FB) (faceTileCap*)
+    static_assert(3 * (FB + FB / 16) <= KC * FB && 2 * (FB + FB / 16) <= KB2 * FB && 3 * (((FB * 23) / 16 + 7) / 8 * 8) <= KV * FB, "caps");
+    const int tile = xcdTile((int)gridDim.x, m.xcdRun * (QGD_BLOCK / FB));
+    const int tid = (int)threadIdx.x;
+    const int f = tile * FB + tid;
+    const bool active = f < m.nIF;
+    const int cOff = m.tileOff[2 * tile], vOff = m.tileOff[2 * tile + 1];
+    const int nUc = m.tileOff[2 * tile + 2] - cOff, nUv = m.tileOff[2 * tile + 3] - vOff;
+    if (nUc == 0) return;   // more distinct records than the piece loads below cover: in m.tileSpill, done by the gather kernel
+    v2d* const sA = tileLds;               // 3 nUc pieces: cell RecA
+    v2d* const sB = sA + 3 * nUc;          // 2 nUc: cell RecB
+    v2d* const sP = sB + 2 * nUc;          // 3 nUv: vertex RecA
+    double* const sC = reinterpret_cast<double*>(sP + 3 * nUv);   // 3 nUc: cell centres
+    double* const sX = sC + 3 * nUc;           // 3 nUv: vertex coordinates
+    // (0) labels of this thread's pieces; the face's own streamed data
+    const int fl = active ? f : m.nIF - 1;
+    const unsigned lc = ldStream(m.locC + fl);
+    const uint2 lv = m.locV[fl];
+    const int fp = ldStream(m.fpos + fl);
+    const int kind = m.fkind[fl];
+    const double w = ldStream(m.w + fl);
+    const double hf = ldStream(m.hf + fl);
+    const double S[3] = {ldStream(m.Sx + fl), ldStream(m.Sy + fl), ldStream(m.Sz + fl)};
+    double msO = 1.0, dnO = 0.0;
+    if (m.hasOther) { msO = m.magSf[fl]; dnO = m.dn[fl]; }
+    int idC[KC], idB[KB2], idV[KV];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            s.Uf[k] = lerpf(w, Uo[k], Un[k]);
-            rUo[k] = Ao.rho * Uo[k];
-            rUn[k] = An.rho * Un[k];
-            s.rhoUf[k] = lerpf(w, rUo[k], rUn[k]);
+    for (int k = 0; k < KC; ++k) {
+        const int q = tid + k * FB, r = (q * 43691) >> 17;   // q / 3 for q < 98304
+        idC[k] = m.tileCells[cOff + min(r, nUc - 1)] * 3 + (q - 3 * r);
+    }
+#pragma unroll
+    for (int k = 0; k < KB2; ++k) {
+        const int q = tid + k * FB, r = q >> 1;
+        idB[k] = m.tileCells[cOff + min(r, nUc - 1)] * 2 + (q & 1);
+    }
+#pragma unroll
+    for (int k = 0; k < KV; ++k) {
+        const int q = tid + k * FB, r = (q * 43691) >> 17;
+        idV[k] = m.tileVerts[vOff + min(r, nUv - 1)] * 3 + (q - 3 * r);
+    }
+    // (1) the distinct records of the tile, piece by piece (pieces past the end repeat the last record and are dropped)
+    const v2d* __restrict__ gA = reinterpret_cast<const v2d*>(c.A);
+    const v2d* __restrict__ gB = reinterpret_cast<const v2d*>(c.B);
+    const v2d* __restrict__ gP = reinterpret_cast<const v2d*>(c.P);
+    v2d dA[KC], dB[KB2], dP[KV];
+    double dC[KC], dX[KV];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) { dA[k] = gA[idC[k]]; dC[k] = m.Cc[idC[k]]; }
+#pragma unroll
+    for (int k = 0; k < KB2; ++k) dB[k] = gB[idB[k]];
+#pragma unroll
+    for (int k = 0; k < KV; ++k) { dP[k] = gP[idV[k]]; dX[k] = m.X[idV[k]]; }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < KC; ++k) { const int q = tid + k * FB; if (q < 3 * nUc) { sA[q] = dA[k]; sC[q] = dC[k]; } }
+#pragma unroll
+    for (int k = 0; k < KB2; ++k) { const int q = tid + k * FB; if (q < 2 * nUc) sB[q] = dB[k]; }
+#pragma unroll
+    for (int k = 0; k < KV; ++k) { const int q = tid + k * FB; if (q < 3 * nUv) { sP[q] = dP[k]; sX[q] = dX[k]; } }
+    __syncthreads();
+    // (2) every face picks its records out of LDS
+    double cof = -1e300, tauMin = 1e300;
+    if (active) {
+        const int lo = (int)(lc & 0xffffu), ln = (int)(lc >> 16);
+        const int v0 = (int)(lv.x & 0xffffu), v1 = (int)(lv.x >> 16), v2 = (int)(lv.y & 0xffffu), v3 = (int)(lv.y >> 16);
+        // geometry first: once the Gauss coefficients are there its 36 registers are free for the field values
+        auto l3 = [](const double* p, int i) { return make_double4(p[3 * i], p[3 * i + 1], p[3 * i + 2], 0.0); };
+        double coef[12], rVc;
+        {
+            const double4 cO = l3(sC, lo), cN = l3(sC, ln);
+            const double4 x0 = l3(sX, v0), x1 = l3(sX, v1), x2 = l3(sX, v2), x3 = l3(sX, v3);
+            gvp3Coefs(kind, cO, cN, x0, x1, x2, x3, coef, rVc);
         }
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) s.UrhoUf[3 * i + j] = lerpf(w, Uo[i] * rUo[j], Un[i] * rUn[j]);
-        s.pf = lerpf(w, Ao.p, An.p);
-        s.cf = lerpf(w, Bo.c, Bn.c);
-        s.Hf = lerpf(w, Bo.H, Bn.H);
-        s.gammaf = lerpf(w, gm.gamma, gm.gamma);
-        s.alphauf = lerpf(w, alphaEffOf(gm, Bo.muQGD), alphaEffOf(gm, Bn.muQGD));
-        s.muf = lerpf(w, muEffOf(gm, Bo.muQGD), muEffOf(gm, Bn.muQGD));
-        s.tauf = lerpf(w, Bo.aOc, Bn.aOc) * hf;
-        s.implicitDiffusion = gm.implicitDiffusion;
-        double out[5], phiw;
-        qgdFluxes<DBG>(s, g, S, out, phiw, DBG ? c.dbg + f : nullptr, nF);
-#pragma unroll
-        for (int k = 0; k < 5; ++k) c.flux[(size_t)k * nF + fp] = out[k];
-        if (adjustDt) {
-            const bool counted = (m.ghost == nullptr) || !(m.ghost[o] == 1 && m.ghost[n] == 1);
-            if (counted) {
-                const double ms = sqrt(S[0] * S[0] + S[1] * S[1] + S[2] * S[2]);
-                const double Unf = s.Uf[0] * (S[0] / ms) + s.Uf[1] * (S[1] / ms) + s.Uf[2] * (S[2] / ms);
-                cof = fmax(fabs(Unf + s.cf), fabs(Unf - s.cf)) * c.dt[0] / hf;
-                tauMin = s.tauf;
-            }
-        }
+        __builtin_amdgcn_sched_barrier(0);
+        const RecA Ao = *reinterpret_cast<const RecA*>(sA + 3 * lo), An = *reinterpret_cast<const RecA*>(sA + 3 * ln);
+        const RecB Bo = *reinterpret_cast<const RecB*>(sB + 2 * lo), Bn = *reinterpret_cast<const RecB*>(sB + 2 * ln);
+        const RecA q0 = *reinterpret_cast<const RecA*>(sP + 3 * v0), q1 = *reinterpret_cast<const RecA*>(sP + 3 * v1),
+                   q2 = *reinterpret_cast<const RecA*>(sP + 3 * v2), q3 = *reinterpret_cast<const RecA*>(sP + 3 * v3);
+        gvp3FaceBody<false>(m, c, gm, f, fp, kind, w, hf, S, Ao, An, Bo, Bn, q0, q1, q2, q3, coef, rVc, msO, dnO, adjustDt, cof, tauMin);
     }
     if (adjustDt) blockMaxMin<FB>(cof, tauMin, c.blkFace + 2 * (size_t)tile, false);
 }
@@ -1238,9 +1478,23 @@ static void launchFaceFluxT(const Launcher& L, int stencil, const MeshView& m, c
         case ST_REDUCED: faceFluxReducedKernel<DBG><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, adj); break;
         case ST_LSQ: faceFluxLsqKernel<DBG><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, adj); break;
         case ST_GVP3:
-            if (m.fblock == 64) faceFluxGvp3Kernel<DBG, 64><<<(m.nIF + 63) / 64, 64, 0, L.stream>>>(m, c, g, adj);
-            else if (m.fblock == 128) faceFluxGvp3Kernel<DBG, 128><<<(m.nIF + 127) / 128, 128, 0, L.stream>>>(m, c, g, adj);
-            else faceFluxGvp3Kernel<DBG, 256><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, adj);
+            if (!DBG && m.fpersist > 0 && m.fblock == 128) {
+                const int nTiles = (m.nIF + 127) / 128;
+                faceFluxGvp3PersistKernel<128><<<nTiles < m.fpersist ? nTiles : m.fpersist, 128, 0, L.stream>>>(m, c, g, adj);
+            } else if (!DBG && m.tileOff != nullptr) {
+                if (m.fblock == 64) faceFluxGvp3TileKernel<64, 3><<<(m.nIF + 63) / 64, 64, m.tileLds, L.stream>>>(m, c, g, adj);
+                else if (m.fblock == 256) faceFluxGvp3TileKernel<256, 3><<<grid, QGD_BLOCK, m.tileLds, L.stream>>>(m, c, g, adj);
+                else if (m.tileWaves == 2) faceFluxGvp3TileKernel<128, 2><<<(m.nIF + 127) / 128, 128, m.tileLds, L.stream>>>(m, c, g, adj);
+                else if (m.tileWaves == 4) faceFluxGvp3TileKernel<128, 4><<<(m.nIF + 127) / 128, 128, m.tileLds, L.stream>>>(m, c, g, adj);
+                else faceFluxGvp3TileKernel<128, 3><<<(m.nIF + 127) / 128, 128, m.tileLds, L.stream>>>(m, c, g, adj);
+                if (m.nTileSpill > 0) {
+                    if (m.fblock == 64) faceFluxGvp3Kernel<false, 64><<<m.nTileSpill, 64, 0, L.stream>>>(m, c, g, adj, m.tileSpill);
+                    else if (m.fblock == 256) faceFluxGvp3Kernel<false, 256><<<m.nTileSpill, 256, 0, L.stream>>>(m, c, g, adj, m.tileSpill);
+                    else faceFluxGvp3Kernel<false, 128><<<m.nTileSpill, 128, 0, L.stream>>>(m, c, g, adj, m.tileSpill);
+                }
+            } else if (m.fblock == 64) faceFluxGvp3Kernel<DBG, 64><<<(m.nIF + 63) / 64, 64, 0, L.stream>>>(m, c, g, adj, nullptr);
+            else if (m.fblock == 128) faceFluxGvp3Kernel<DBG, 128><<<(m.nIF + 127) / 128, 128, 0, L.stream>>>(m, c, g, adj, nullptr);
+            else faceFluxGvp3Kernel<DBG, 256><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, adj, nullptr);
             break;
         default: faceFluxGvp2Kernel<DBG><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, adj); break;
     }

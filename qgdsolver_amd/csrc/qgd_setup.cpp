@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdint>
 #include <cstdlib>
 #include <stdexcept>
 
@@ -437,6 +438,72 @@ StaticData buildStaticData(const HostMesh& m) {
         }
     }
     return s;
+}
+
+FaceTiles buildFaceTiles(const StaticData& s, int32_t fb) {
+    FaceTiles t;
+    const int64_t nIF = s.nIF;
+    if (nIF == 0 || s.nGeomD != 3 || (fb != 64 && fb != 128 && fb != 256)) return t;
+    const int64_t nTiles = (nIF + fb - 1) / fb;
+    const int32_t capC = faceTileCapCells(fb), capV = faceTileCapVerts(fb);
+    std::vector<int32_t> cnt(2 * (size_t)nTiles, 0);
+    auto collect = [&](int64_t tile, std::vector<int32_t>& uc, std::vector<int32_t>& uv) {
+        uc.clear(); uv.clear();
+        const int64_t f0 = tile * fb, f1 = std::min<int64_t>(nIF, f0 + fb);
+        for (int64_t f = f0; f < f1; ++f) {
+            uc.push_back(s.own[f]); uc.push_back(s.nei[f]);
+            for (int q = 0; q < 4; ++q) if (s.verts[4 * f + q] >= 0) uv.push_back(s.verts[4 * f + q]);
+        }
+        std::sort(uc.begin(), uc.end()); uc.erase(std::unique(uc.begin(), uc.end()), uc.end());
+        std::sort(uv.begin(), uv.end()); uv.erase(std::unique(uv.begin(), uv.end()), uv.end());
+    };
+    bool fits = true;
+#pragma omp parallel
+    {
+        std::vector<int32_t> uc, uv;
+#pragma omp for schedule(static)
+        for (int64_t tile = 0; tile < nTiles; ++tile) {
+            collect(tile, uc, uv);
+            const bool over = (int32_t)uc.size() > capC || (int32_t)uv.size() > capV || uv.empty();
+            cnt[2 * tile] = over ? 0 : (int32_t)uc.size();
+            cnt[2 * tile + 1] = over ? 0 : (int32_t)uv.size();
+        }
+    }
+    t.off.assign(2 * (size_t)(nTiles + 1), 0);
+    int64_t totC = 0, totV = 0;
+    for (int64_t tile = 0; tile < nTiles; ++tile) {
+        t.maxCells = std::max(t.maxCells, cnt[2 * tile]);
+        t.maxVerts = std::max(t.maxVerts, cnt[2 * tile + 1]);
+        totC += cnt[2 * tile]; totV += cnt[2 * tile + 1];
+        if (cnt[2 * tile] == 0) t.spill.push_back((int32_t)tile);
+        if (totC > INT32_MAX || totV > INT32_MAX) { fits = false; break; }
+        t.off[2 * (tile + 1)] = (int32_t)totC;
+        t.off[2 * (tile + 1) + 1] = (int32_t)totV;
+    }
+    if (!fits || t.maxVerts == 0) return FaceTiles();
+    t.cells.resize((size_t)totC); t.verts.resize((size_t)totV);
+    t.locC.resize((size_t)nIF); t.locV.resize(2 * (size_t)nIF);
+#pragma omp parallel
+    {
+        std::vector<int32_t> uc, uv;
+#pragma omp for schedule(static)
+        for (int64_t tile = 0; tile < nTiles; ++tile) {
+            if (cnt[2 * tile] == 0) continue;
+            collect(tile, uc, uv);
+            std::copy(uc.begin(), uc.end(), t.cells.begin() + t.off[2 * tile]);
+            std::copy(uv.begin(), uv.end(), t.verts.begin() + t.off[2 * tile + 1]);
+            const int64_t f0 = tile * fb, f1 = std::min<int64_t>(nIF, f0 + fb);
+            auto posC = [&](int32_t id) { return (uint32_t)(std::lower_bound(uc.begin(), uc.end(), id) - uc.begin()); };
+            auto posV = [&](int32_t id) { return id < 0 ? 0u : (uint32_t)(std::lower_bound(uv.begin(), uv.end(), id) - uv.begin()); };
+            for (int64_t f = f0; f < f1; ++f) {
+                t.locC[f] = posC(s.own[f]) | (posC(s.nei[f]) << 16);
+                t.locV[2 * f] = posV(s.verts[4 * f]) | (posV(s.verts[4 * f + 1]) << 16);
+                t.locV[2 * f + 1] = posV(s.verts[4 * f + 2]) | (posV(s.verts[4 * f + 3]) << 16);
+            }
+        }
+    }
+    t.fb = fb;
+    return t;
 }
 
 }  // namespace qgd

@@ -97,4 +97,28 @@ struct StaticData {
 // build every table above; `needLsq` / `needGvp2` are derived from nGeometricD
 StaticData buildStaticData(const HostMesh& m);
 
+// ---- face tiles of the LDS-staged 3-D GaussVolPoint kernel ------------------------------------------------------------
+// A tile is `fb` consecutive internal faces (one workgroup).  Its faces reference far fewer distinct cell and vertex
+// records than 2 + 4 per face (blockMesh numbering, fb = 128: 130 cells and 175 vertices instead of 256 + 512), so the
+// workgroup brings each distinct record in ONCE, as contiguous 16-B pieces, stages it in LDS and lets every face pick
+// its six records from there: cells[]/verts[] list the distinct labels of each tile in ascending order (off[] = the
+// two CSR offsets per tile), locC/locV hold each face's positions in those lists (16 bit each).
+struct FaceTiles {
+    int32_t fb = 0;                  // 0: not built (not a 3-D mesh or switched off)
+    int32_t maxCells = 0, maxVerts = 0;   // over the staged tiles
+    std::vector<int32_t> off;        // 2*(nTiles+1): {cell offset, vertex offset}
+    std::vector<int32_t> spill;      // tiles with more distinct records than the caps below (e.g. the last rows of a box, whose
+                                     // cells own one internal face each): empty lists here, they go through the gather kernel
+    std::vector<int32_t> cells, verts;
+    std::vector<uint32_t> locC;      // nIF: owner position | neighbour position << 16
+    std::vector<uint32_t> locV;      // 2*nIF: v0 | v1 << 16,  v2 | v3 << 16 (absent vertex: 0)
+};
+// distinct records a tile may hold: what the kernel's fixed number of piece loads per thread covers
+// (4, 3 and 5 rounds of 16-B pieces for cell RecA / RecB / vertex RecA).  A box in blockMesh numbering has fb + 3 cells and
+// 11/8 fb vertices in all but the row-end tiles (< 1 %), which the tighter vertex cap leaves to the gather kernel: LDS per
+// workgroup stays at 26.8 KB for fb = 128, six workgroups per CU.
+inline int32_t faceTileCapCells(int32_t fb) { return fb + fb / 16; }
+inline int32_t faceTileCapVerts(int32_t fb) { return ((fb * 23) / 16 + 7) / 8 * 8; }
+FaceTiles buildFaceTiles(const StaticData& s, int32_t fb);
+
 }  // namespace qgd

@@ -39,6 +39,12 @@ class Device:
     def release(self, ptr):
         L.check(L.lib.qgd_device_release(self._h, C.c_void_p(ptr)), "qgd_device_release")
 
+    def face_tiles(self):
+        """how the internal faces go through the 3-D GaussVolPoint flux kernel (qgd_device_face_tiles)"""
+        a = (C.c_int64 * 4)()
+        L.check(L.lib.qgd_device_face_tiles(self._h, a), "qgd_device_face_tiles")
+        return dict(facesPerTile=a[0], tiles=a[1], gatherTiles=a[2], ldsBytes=a[3])
+
     def close(self):
         if getattr(self, "_h", None):
             L.lib.qgd_device_free(self._h)
