@@ -29,13 +29,14 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.
 FACE_BYTES_PER_FACE = 184
 FACE_BYTES_PER_CELL = 48
 FACE_BYTES_PER_POINT = 48
-# What the kernel that is actually launched (faceFluxGvp3Kernel) has to move at least once, in its own layout: it does not
-# stream the 80 B of Gauss coefficients but rebuilds them from gathered geometry.  Per internal face: owner+neighbour 8,
-# 4 vertex labels 16, kind 1, weight 8, hQGDf 8, Sf 24, flux position 4 = 69 B in + 40 B out; per cell RecA 48 + RecB 32 +
-# centre 32 = 112 B; per vertex RecA 48 + coordinates 32 = 80 B.  Reported beside the SURVEY figure, never instead of it.
-OWN_BYTES_PER_FACE = 109
-OWN_BYTES_PER_CELL = 112
-OWN_BYTES_PER_POINT = 80
+# What the kernel that is actually launched (faceFluxGvp3TileKernel) has to move at least once, in its own layout: it does not
+# stream the 80 B of Gauss coefficients but rebuilds them from gathered geometry, and it addresses its records through per-tile
+# lists of distinct labels.  Per internal face: six 16-bit list positions 12, flux position 4, kind 1, weight 8, hQGDf 8, Sf 24
+# = 57 B in, ~10 B of label lists (130 cells + 176 vertices per 128 faces on a box), 40 B out; per cell RecA 48 + RecB 32 +
+# centre 24 = 104 B; per vertex RecA 48 + coordinates 24 = 72 B.  Reported beside the SURVEY figure, never instead of it.
+OWN_BYTES_PER_FACE = 107
+OWN_BYTES_PER_CELL = 104
+OWN_BYTES_PER_POINT = 72
 # whole explicit step, per cell-step on a hex box: vertex interp 196 + face kernel 648 + cell update 240
 STEP_BYTES_PER_CELL = 1084
 POINT_BYTES_PER_CELL = 196
@@ -429,6 +430,9 @@ def main():
     info = case.info()
     face_bytes = FACE_BYTES_PER_FACE * n_if + FACE_BYTES_PER_CELL * n_c + FACE_BYTES_PER_POINT * n_p
     face_ms = kt["face"]["ms_avg"]
+    ft = dev.face_tiles()
+    face_kernel_name = (f"faceFluxGvp3TileKernel<{ft['facesPerTile']}> (+ faceFluxGvp3Kernel on {ft['gatherTiles']} of {ft['tiles']} tiles; "
+                        "avg_launch_ms covers both launches)") if ft["facesPerTile"] else "faceFluxGvp3Kernel"
     achieved = face_bytes / (face_ms * 1e-3) / 1e9 if face_ms else None
     own_bytes = OWN_BYTES_PER_FACE * n_if + OWN_BYTES_PER_CELL * n_c + OWN_BYTES_PER_POINT * n_p
 
@@ -459,7 +463,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "faceFluxGvp3Kernel (rank 0 shard)",
+                "kernel": face_kernel_name + " (rank 0 shard)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

@@ -541,7 +541,6 @@ int qgd_device_create(qgd_mesh_t mh, int deviceId, qgd_device_t* out) {
         { const char* e = std::getenv("QGD_FBLOCK"); v.fblock = e ? std::atoi(e) : 128; }
         v.hasOther = 0;
         for (int64_t f = 0; f < s.nIF; ++f) if (s.fkind[f] == FK_OTHER) { v.hasOther = 1; break; }
-        { const char* e = std::getenv("QGD_FPERSIST"); v.fpersist = e ? std::atoi(e) : 0; }
         { const char* e = std::getenv("QGD_CBLOCK"); v.cblock = e ? std::atoi(e) : 256; }
         { const char* e = std::getenv("QGD_PBLOCK"); v.pblock = e ? std::atoi(e) : 256; }
         // upload + free each table in turn so the host peak stays at one table

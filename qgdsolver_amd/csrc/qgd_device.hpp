@@ -21,7 +21,6 @@ struct MeshView {
     int32_t cblock, pblock;  // tiles of the cell-update and vertex kernels (64, 128 or 256)
     int32_t fblock;          // face tile of the 3-D GaussVolPoint kernel: 64, 128 or 256 faces per workgroup
     int32_t hasOther;        // 1: some internal face has more than four vertices (FK_OTHER)
-    int32_t fpersist;        // > 0: workgroups of the persistent face kernel (experiment switch QGD_FPERSIST)
     int32_t xcdRun;          // tiles per XCD run of the workgroup->tile map (0: one contiguous eighth per XCD)
     const int32_t* own;      // nF
     const int32_t* nei;      // nIF

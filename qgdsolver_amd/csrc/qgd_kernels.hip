@@ -554,70 +554,6 @@ void faceFluxGvp3Kernel(const MeshView m, const CaseView c, const GasModel gm, c
 // whole cache lines -- parks them in LDS and every face reads its six records from there.  Same arithmetic, same
 // operation order, bit-identical fluxes.
 // ---------------------------------------------------------------------------
-// ---------------------------------------------------------------------------
-// Persistent form of the gather kernel: a workgroup walks tiles b, b + G, b + 2G, ... (G workgroups = what the chip holds at
-// once) and asks for the labels and streamed data of its NEXT tile before it computes the current one.  A wave of the
-// one-tile-per-workgroup kernel lives through four latencies in series -- launch, labels, gathered records, store drain at
-// s_endpgm -- and only two such waves fit a SIMD; here the chain per tile is the gathers alone.
-// ---------------------------------------------------------------------------
-template <int FB>
-__global__ __launch_bounds__(FB) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void faceFluxGvp3PersistKernel(const MeshView m, const CaseView c, const GasModel gm, const int adjustDt) {
-    const int G = (int)gridDim.x, b = (int)blockIdx.x;
-    const int nTiles = (m.nIF + FB - 1) / FB;
-    const int run = max(1, m.xcdRun * (QGD_BLOCK / FB));
-    // within every window of G consecutive tiles: runs of `run` tiles per XCD (block b sits on XCD b % 8)
-    const int j = b >> 3;
-    const int slot = ((G % (8 * run)) == 0) ? ((j / run) * 8 + (b & 7)) * run + (j % run) : b;
-    const int tid = (int)threadIdx.x;
-    const int last = m.nIF - 1;
-    int tile = slot;
-    if (tile >= nTiles) return;
-    // labels + streamed data of the first tile
-    int f = min(tile * FB + tid, last);
-    int o = ldStream(m.own + f), n = ldStream(m.nei + f), fp = ldStream(m.fpos + f);
-    int4 vt = m.verts[f];
-    int kind = m.fkind[f];
-    double w = ldStream(m.w + f), hf = ldStream(m.hf + f);
-    double Sx = ldStream(m.Sx + f), Sy = ldStream(m.Sy + f), Sz = ldStream(m.Sz + f);
-    double msO = 1.0, dnO = 0.0;
-    if (m.hasOther) { msO = m.magSf[f]; dnO = m.dn[f]; }
-    while (true) {
-        const int fReal = tile * FB + tid;
-        // (2) gathered records of this tile
-        const RecA Ao = c.A[o], An = c.A[n];
-        const RecB Bo = c.B[o], Bn = c.B[n];
-        const int v3 = vt.w < 0 ? 0 : vt.w;
-        const RecA q0 = c.P[vt.x], q1 = c.P[vt.y], q2 = c.P[vt.z], q3 = c.P[v3];
-        const double4 cO = ld3(m.Cc, o), cN = ld3(m.Cc, n);
-        const double4 x0 = ld3(m.X, vt.x), x1 = ld3(m.X, vt.y), x2 = ld3(m.X, vt.z), x3 = ld3(m.X, v3);
-        __builtin_amdgcn_sched_barrier(0);
-        // (0', 1') labels and streamed data of the next tile, in flight while this one is computed
-        const int next = tile + G;
-        const bool more = next < nTiles;
-        const int fn = min((more ? next : tile) * FB + tid, last);
-        const int o2 = ldStream(m.own + fn), n2 = ldStream(m.nei + fn), fp2 = ldStream(m.fpos + fn);
-        const int4 vt2 = m.verts[fn];
-        const int kind2 = m.fkind[fn];
-        const double w2 = ldStream(m.w + fn), hf2 = ldStream(m.hf + fn);
-        const double Sx2 = ldStream(m.Sx + fn), Sy2 = ldStream(m.Sy + fn), Sz2 = ldStream(m.Sz + fn);
-        double msO2 = 1.0, dnO2 = 0.0;
-        if (m.hasOther) { msO2 = m.magSf[fn]; dnO2 = m.dn[fn]; }
-        __builtin_amdgcn_sched_barrier(0);
-        double cof = -1e300, tauMin = 1e300;
-        if (fReal < m.nIF) {
-            const double S[3] = {Sx, Sy, Sz};
-            double coef[12], rVc;
-            gvp3Coefs(kind, cO, cN, x0, x1, x2, x3, coef, rVc);
-            gvp3FaceBody<false>(m, c, gm, fReal, fp, kind, w, hf, S, Ao, An, Bo, Bn, q0, q1, q2, q3, coef, rVc, msO, dnO, adjustDt, cof, tauMin);
-        }
-        if (adjustDt) blockMaxMin<FB>(cof, tauMin, c.blkFace + 2 * (size_t)tile, false);
-        if (!more) break;
-        tile = next;
-        o = o2; n = n2; fp = fp2; vt = vt2; kind = kind2; w = w2; hf = hf2; Sx = Sx2; Sy = Sy2; Sz = Sz2; msO = msO2; dnO = dnO2;
-    }
-}
-
 typedef double v2d __attribute__((ext_vector_type(2)));   // one 16-B piece
 #ifndef QGD_FT_WAVES_MIN
 #define QGD_FT_WAVES_MIN 2
@@ -1478,10 +1414,7 @@ static void launchFaceFluxT(const Launcher& L, int stencil, const MeshView& m, c
         case ST_REDUCED: faceFluxReducedKernel<DBG><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, adj); break;
         case ST_LSQ: faceFluxLsqKernel<DBG><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, adj); break;
         case ST_GVP3:
-            if (!DBG && m.fpersist > 0 && m.fblock == 128) {
-                const int nTiles = (m.nIF + 127) / 128;
-                faceFluxGvp3PersistKernel<128><<<nTiles < m.fpersist ? nTiles : m.fpersist, 128, 0, L.stream>>>(m, c, g, adj);
-            } else if (!DBG && m.tileOff != nullptr) {
+            if (!DBG && m.tileOff != nullptr) {
                 if (m.fblock == 64) faceFluxGvp3TileKernel<64, 3><<<(m.nIF + 63) / 64, 64, m.tileLds, L.stream>>>(m, c, g, adj);
                 else if (m.fblock == 256) faceFluxGvp3TileKernel<256, 3><<<grid, QGD_BLOCK, m.tileLds, L.stream>>>(m, c, g, adj);
                 else if (m.tileWaves == 2) faceFluxGvp3TileKernel<128, 2><<<(m.nIF + 127) / 128, 128, m.tileLds, L.stream>>>(m, c, g, adj);

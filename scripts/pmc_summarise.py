@@ -47,14 +47,16 @@ for n in (400, 200):
             c["hbm_write_bytes"] = 64 * c.get("TCC_EA0_WRREQ_64B_sum", 0) + 32 * (c["TCC_EA0_WRREQ_sum"] - c.get("TCC_EA0_WRREQ_64B_sum", 0))
     if per_kernel:
         json.dump(per_kernel, open(os.path.join(prof, f"{tag}_n{n}_pmc_tcc.json"), "w"), indent=1, sort_keys=True)
-        for name, c in per_kernel.items():
-            if "faceFluxGvp3Kernel" in name and "hbm_read_bytes" in c and "hbm_write_bytes" in c:
-                traffic[f"n{n}_gpus1"] = {
-                    "kernel": name, "read_bytes": c["hbm_read_bytes"], "write_bytes": c["hbm_write_bytes"],
-                    "bytes_per_launch": c["hbm_read_bytes"] + c["hbm_write_bytes"],
-                    "source": "rocprofv3 --pmc TCC_EA0_RDREQ_{32B,64B,128B}_sum / TCC_EA0_WRREQ{,_64B}_sum (separate passes, "
-                              "scripts/collect_profiles.sh), bytes = sum(size*requests); FETCH_SIZE*1024 reads exactly half of the read "
-                              f"side on gfx950 (x2 correction of MI355X_MICROARCH.md), WRITE_SIZE*1024 matches; profiles/{tag}_n{n}_pmc_tcc.json"}
+        # the face pass is the LDS-staged kernel plus the gather kernel on the tiles the former leaves out: one launch of each per step
+        face = [(name, c) for name, c in per_kernel.items() if "faceFluxGvp3" in name and "hbm_read_bytes" in c and "hbm_write_bytes" in c]
+        if face:
+            rd = sum(c["hbm_read_bytes"] for _, c in face)
+            wr = sum(c["hbm_write_bytes"] for _, c in face)
+            traffic[f"n{n}_gpus1"] = {
+                "kernel": " + ".join(sorted(name for name, _ in face)), "read_bytes": rd, "write_bytes": wr, "bytes_per_launch": rd + wr,
+                "source": "rocprofv3 --pmc TCC_EA0_RDREQ_{32B,64B,128B}_sum / TCC_EA0_WRREQ{,_64B}_sum (separate passes, "
+                          "scripts/collect_profiles.sh), bytes = sum(size*requests); FETCH_SIZE*1024 reads exactly half of the read "
+                          f"side on gfx950 (x2 correction of MI355X_MICROARCH.md), WRITE_SIZE*1024 matches; profiles/{tag}_n{n}_pmc_tcc.json"}
         for name, c in per_kernel.items():
             for short, pattern in (("point", "pointInterpRecKernel"), ("cell", "cellUpdateKernel")):
                 if pattern in name and "hbm_read_bytes" in c and "hbm_write_bytes" in c and f"n{n}_gpus1" in traffic:

@@ -30,9 +30,7 @@ def run(mesh, steps, env, phases=False, **opt):
             else:
                 os.environ[k] = v
     ft = dev.face_tiles()
-    if "QGD_FPERSIST" in env:
-        pass
-    elif env.get("QGD_FTILE") == "0":
+    if env.get("QGD_FTILE") == "0":
         assert ft["facesPerTile"] == 0
     else:   # the staged kernel really is the one that runs, and the gather kernel only mops up
         assert ft["facesPerTile"] == int(env.get("QGD_FBLOCK", 128)) and 0 < ft["ldsBytes"] <= 65536, ft
@@ -84,16 +82,3 @@ def test_staged_kernel_on_a_shard():
     for k in a:
         assert np.array_equal(a[k], b[k]), k
 
-
-@pytest.mark.parametrize("groups", [8, 24, 1024])
-def test_persistent_kernel_is_bit_identical_to_gather_kernel(groups):
-    """faceFluxGvp3PersistKernel (QGD_FPERSIST = number of workgroups): tiles b, b + G, ... per workgroup, labels of the next tile
-    prefetched; few workgroups so that every one of them loops"""
-    for tag, mesh in meshes():
-        h = 1.0 / 20
-        for opt in (dict(deltaT=0.05 * h), dict(deltaT=0.05 * h, adjustTimeStep=1, maxCo=0.2)):
-            a = run(mesh, 4, {"QGD_FTILE": "0"}, **opt)
-            b = run(mesh, 4, {"QGD_FTILE": "0", "QGD_FPERSIST": str(groups)}, **opt)
-            a.pop("tiles"); b.pop("tiles")
-            for k in a:
-                assert np.array_equal(a[k], b[k]), (tag, groups, opt, k, np.abs(a[k] - b[k]).max())
