@@ -32,9 +32,9 @@ def run(mesh, steps, env, phases=False, **opt):
     ft = dev.face_tiles()
     if env.get("QGD_FTILE") == "0":
         assert ft["facesPerTile"] == 0
-    else:   # the staged kernel really is the one that runs, and the gather kernel only mops up
+    elif ft["facesPerTile"]:   # the staged kernel runs, the gather kernel only mops up (at most a quarter of the tiles)
         assert ft["facesPerTile"] == int(env.get("QGD_FBLOCK", 128)) and 0 < ft["ldsBytes"] <= 65536, ft
-        assert ft["gatherTiles"] < ft["tiles"], ft
+        assert 4 * ft["gatherTiles"] <= ft["tiles"], ft
     case = q.QGDFoamCase(dev, q.default_options(stencil="GaussVolPoint", **opt))
     U, T, p = cases.box_initial_fields(mesh.array("C").reshape(-1, 3))
     case.set_fields(U, T, p)
@@ -66,6 +66,8 @@ def test_staged_kernel_is_bit_identical_to_gather_kernel(fb):
             a = run(mesh, 5, {"QGD_FTILE": "0", "QGD_FBLOCK": str(fb)}, **opt)
             b = run(mesh, 5, {"QGD_FTILE": "1", "QGD_FBLOCK": str(fb)}, **opt)
             ft = b.pop("tiles"); a.pop("tiles")
+            if tag.startswith("hex 20") or tag.startswith("jitter"):
+                assert ft["facesPerTile"] == fb, (tag, ft)    # these do go through the staged kernel
             if tag.startswith("hex 150") and fb <= 128:
                 assert ft["gatherTiles"] > 0, ft     # the last row of a box: one internal face per cell, 4 fresh vertices each
             for k in a:
