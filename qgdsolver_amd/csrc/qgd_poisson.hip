@@ -161,9 +161,13 @@ __global__ __launch_bounds__(PB) void fillKernel(const int n, const double v, do
 // second level of the sums: one workgroup folds `count` rows of nBlocks partials in ascending order
 __global__ __launch_bounds__(PB) void foldKernel(const double* __restrict__ part, const int nBlocks, const int count, double* __restrict__ out) {
     for (int k = 0; k < count; ++k) {
-        double v = 0;
-        for (int i = threadIdx.x; i < nBlocks; i += PB) v += part[(size_t)k * nBlocks + i];
-        const double t = blockSum(v);
+        // four independent chains per thread (the partials of 8 M cells are 31 250: 122 dependent adds per thread otherwise)
+        const double* __restrict__ p = part + (size_t)k * nBlocks;
+        double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+        int i = threadIdx.x;
+        for (; i + 3 * PB < nBlocks; i += 4 * PB) { v0 += p[i]; v1 += p[i + PB]; v2 += p[i + 2 * PB]; v3 += p[i + 3 * PB]; }
+        for (; i < nBlocks; i += PB) v0 += p[i];
+        const double t = blockSum((v0 + v1) + (v2 + v3));
         if (threadIdx.x == 0) out[k] = t;
     }
 }
@@ -332,70 +336,114 @@ int diagLaplacianPcg(hipStream_t stream, const MeshView& m, const double* a, con
 // ---------------------------------------------------------------------------------------------------------------------
 namespace {
 
-struct MgLevelDev {
+template <typename T>
+struct MgLevelT {
     int n = 0, width = 0;
-    double* diag = nullptr;     // n
+    T* diag = nullptr;          // n
     int* col = nullptr;         // width*n, column-major ELL, -1 = padding
-    double* val = nullptr;      // width*n: a_ij > 0 (A_ij = -a_ij)
+    T* val = nullptr;           // width*n: a_ij > 0 (A_ij = -a_ij)
     int* agg = nullptr;         // n: aggregate of each node in the next level
     int* aggStart = nullptr;    // nNext+1
     int* aggItems = nullptr;    // n
-    double *x = nullptr, *x2 = nullptr, *b = nullptr, *r = nullptr;
+    T *x = nullptr, *x2 = nullptr, *b = nullptr, *r = nullptr;
 };
+using MgLevelDev = MgLevelT<double>;   // the cycle in double; MgLevelT<float>: the same cycle as a single-precision preconditioner
 
 // xout = xin + omega (b - A xin)/diag   (xin == nullptr: from zero, xout = omega b/diag);  rout (optional) = b - A xin
-__global__ __launch_bounds__(PB) void mgSmoothKernel(const MgLevelDev L, const double omega, const double* __restrict__ b,
-                                                     const double* __restrict__ xin, double* __restrict__ xout, double* __restrict__ rout) {
+template <typename T>
+__global__ __launch_bounds__(PB) void mgSmoothKernel(const MgLevelT<T> L, const T omega, const T* __restrict__ b,
+                                                     const T* __restrict__ xin, T* __restrict__ xout, T* __restrict__ rout) {
     const int i = blockIdx.x * PB + threadIdx.x;
     if (i >= L.n) return;
-    const double d = L.diag[i];
+    const T d = L.diag[i];
     if (!xin) { xout[i] = omega * b[i] / d; return; }
-    const double xi = xin[i];
-    double s = d * xi;
+    const T xi = xin[i];
+    T s = d * xi;
     for (int k = 0; k < L.width; ++k) {
         const int c = L.col[(size_t)k * L.n + i];
         if (c >= 0) s -= L.val[(size_t)k * L.n + i] * xin[c];
     }
-    const double r = b[i] - s;
+    const T r = b[i] - s;
     if (rout) rout[i] = r;
     if (xout) xout[i] = xi + omega * r / d;
 }
+// vectors between the double-precision CG and a single-precision cycle
+template <typename A, typename B>
+__global__ __launch_bounds__(PB) void mgConvertKernel(const int n, const A* __restrict__ in, B* __restrict__ out) {
+    const int i = blockIdx.x * PB + threadIdx.x;
+    if (i < n) out[i] = (B)in[i];
+}
+// y = A x through the ELL rows of level 0 (the same matrix as applyKernel walks face by face: 150 instead of 266 us at 8 M rows),
+// block partial sums of x.y
+__global__ __launch_bounds__(PB) void mgApplyKernel(const MgLevelDev L, const double* __restrict__ x, double* __restrict__ y,
+                                                    double* __restrict__ part) {
+    const int i = blockIdx.x * PB + threadIdx.x;
+    double xy = 0;
+    if (i < L.n) {
+        const double xi = x[i];
+        double s = L.diag[i] * xi;
+        for (int k = 0; k < L.width; ++k) {
+            const int c = L.col[(size_t)k * L.n + i];
+            if (c >= 0) s -= L.val[(size_t)k * L.n + i] * x[c];
+        }
+        y[i] = s;
+        xy = xi * s;
+    }
+    const double t = blockSum(xy);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+template <typename T>
 __global__ __launch_bounds__(PB) void mgRestrictKernel(const int nCoarse, const int* __restrict__ aggStart, const int* __restrict__ aggItems,
-                                                       const double* __restrict__ r, double* __restrict__ rc) {
+                                                       const T* __restrict__ r, T* __restrict__ rc) {
     const int I = blockIdx.x * PB + threadIdx.x;
     if (I >= nCoarse) return;
-    double s = 0;
+    T s = 0;
     for (int k = aggStart[I]; k < aggStart[I + 1]; ++k) s += r[aggItems[k]];
     rc[I] = s;
 }
-__global__ __launch_bounds__(PB) void mgProlongKernel(const int n, const int* __restrict__ agg, const double oc, const double* __restrict__ ec,
-                                                      double* __restrict__ x) {
+template <typename T>
+__global__ __launch_bounds__(PB) void mgProlongKernel(const int n, const int* __restrict__ agg, const T oc, const T* __restrict__ ec,
+                                                      T* __restrict__ x) {
     const int i = blockIdx.x * PB + threadIdx.x;
     if (i < n) x[i] += oc * ec[agg[i]];
 }
 // coarsest level: `sweeps` Jacobi sweeps by one workgroup (n <= MG_COARSE_MAX), the iterate in LDS
 #define MG_COARSE_MAX 1024
-__global__ __launch_bounds__(1024) void mgCoarseKernel(const MgLevelDev L, const double omega, const int sweeps, const double* __restrict__ b,
-                                                        double* __restrict__ x) {
-    __shared__ double xa[MG_COARSE_MAX], xb[MG_COARSE_MAX];
+template <typename T>
+__global__ __launch_bounds__(1024) void mgCoarseKernel(const MgLevelT<T> L, const T omega, const int sweeps, const T* __restrict__ b,
+                                                        T* __restrict__ x) {
+    __shared__ T xa[MG_COARSE_MAX], xb[MG_COARSE_MAX];
     const int i = threadIdx.x;
     const bool on = i < L.n;
-    const double d = on ? L.diag[i] : 1.0, bi = on ? b[i] : 0.0;
-    double* cur = xa;
-    double* nxt = xb;
+    const T d = on ? L.diag[i] : (T)1, bi = on ? b[i] : (T)0;
+    T* cur = xa;
+    T* nxt = xb;
+    // the row of this thread stays in registers across the sweeps (rows wider than MG_COARSE_ROW read the rest from memory)
+    constexpr int MG_COARSE_ROW = 32;
+    int cc[MG_COARSE_ROW];
+    T vv[MG_COARSE_ROW];
+#pragma unroll
+    for (int k = 0; k < MG_COARSE_ROW; ++k) {
+        const bool has = on && k < L.width;
+        cc[k] = has ? L.col[(size_t)k * L.n + i] : -1;
+        vv[k] = (has && cc[k] >= 0) ? L.val[(size_t)k * L.n + i] : (T)0;
+        if (cc[k] < 0) cc[k] = i;   // value 0: reads its own entry
+    }
     if (on) cur[i] = omega * bi / d;
     __syncthreads();
     for (int s = 1; s < sweeps; ++s) {
         if (on) {
-            double t = d * cur[i];
-            for (int k = 0; k < L.width; ++k) {
+            T t = d * cur[i];
+#pragma unroll
+            for (int k = 0; k < MG_COARSE_ROW; ++k) t -= vv[k] * cur[cc[k]];
+            for (int k = MG_COARSE_ROW; k < L.width; ++k) {
                 const int c = L.col[(size_t)k * L.n + i];
                 if (c >= 0) t -= L.val[(size_t)k * L.n + i] * cur[c];
             }
             nxt[i] = cur[i] + omega * (bi - t) / d;
         }
         __syncthreads();
-        double* tmp = cur; cur = nxt; nxt = tmp;
+        T* tmp = cur; cur = nxt; nxt = tmp;
     }
     if (on) x[i] = cur[i];
 }
@@ -434,13 +482,16 @@ struct PressureSolver {
     int nu = 2, coarseSweeps = 40;
     std::vector<void*> owned;
     std::vector<MgLevelDev> L;
+    std::vector<MgLevelT<float>> Lf;   // single-precision copy of the hierarchy (QGD_MG_F32; level 0 of L stays for the CG's own A x)
+    bool f32 = false;
     // finest-level vectors
     double *a = nullptr, *gs = nullptr, *diag = nullptr, *rhs = nullptr, *r = nullptr, *z = nullptr, *d = nullptr, *q = nullptr, *A1 = nullptr,
            *ones = nullptr, *part = nullptr, *scal = nullptr;
     const uint8_t* bKind = nullptr;
     int64_t bytes = 0;
-    // the V-cycle is a fixed sequence of ~75 small launches on fixed buffers (r -> z): captured once into a hipGraph and
-    // replayed per CG iteration (the coarse levels are launch-latency bound)
+    // the V-cycle is a fixed sequence of ~75 small launches on fixed buffers (r -> z); with QGD_MG_GRAPH=1 it is captured once into
+    // a hipGraph and replayed per CG iteration.  Measured: 5.11 -> 5.03 ms per step at 64^3, nothing at 128^3 / 200^3 (the
+    // asynchronous launches were already hidden), and rocprofv3 crashes on the captured graph -- hence opt-in.
     hipGraphExec_t cycleGraph = nullptr;
     bool cycleGraphTried = false;
 
@@ -460,30 +511,43 @@ struct PressureSolver {
         for (void* p : owned) (void)hipFree(p);
     }
 
-    // z = M r on level l (b -> x)
-    void vcycle(size_t l, const double* b, double* x) {
-        MgLevelDev& lv = L[l];
+    // z = M r on level l (b -> x), in the precision of the level arrays
+    template <typename T>
+    void vcycleT(std::vector<MgLevelT<T>>& Lv, size_t l, const T* b, T* x) {
+        MgLevelT<T>& lv = Lv[l];
         const int nb = blocksOf(lv.n);
-        if (l + 1 == L.size()) {
-            if (lv.n <= MG_COARSE_MAX) mgCoarseKernel<<<1, 1024, 0, stream>>>(lv, omega, coarseSweeps, b, x);
+        const T om = (T)omega, over = (T)oc;
+        const T* none = nullptr;
+        T* noOut = nullptr;
+        if (l + 1 == Lv.size()) {
+            if (lv.n <= MG_COARSE_MAX) mgCoarseKernel<T><<<1, 1024, 0, stream>>>(lv, om, coarseSweeps, b, x);
             else {
-                double* cur = x; double* nxt = lv.x2;
-                mgSmoothKernel<<<nb, PB, 0, stream>>>(lv, omega, b, nullptr, cur, nullptr);
-                for (int s = 1; s < coarseSweeps; ++s) { mgSmoothKernel<<<nb, PB, 0, stream>>>(lv, omega, b, cur, nxt, nullptr); std::swap(cur, nxt); }
-                if (cur != x) PCHECK(hipMemcpyAsync(x, cur, sizeof(double) * lv.n, hipMemcpyDeviceToDevice, stream));
+                T* cur = x; T* nxt = lv.x2;
+                mgSmoothKernel<T><<<nb, PB, 0, stream>>>(lv, om, b, none, cur, noOut);
+                for (int s = 1; s < coarseSweeps; ++s) { mgSmoothKernel<T><<<nb, PB, 0, stream>>>(lv, om, b, cur, nxt, noOut); std::swap(cur, nxt); }
+                if (cur != x) PCHECK(hipMemcpyAsync(x, cur, sizeof(T) * lv.n, hipMemcpyDeviceToDevice, stream));
             }
             return;
         }
-        MgLevelDev& nx = L[l + 1];
-        double* cur = x; double* nxt = lv.x2;
-        mgSmoothKernel<<<nb, PB, 0, stream>>>(lv, omega, b, nullptr, cur, nullptr);
-        for (int s = 1; s < nu; ++s) { mgSmoothKernel<<<nb, PB, 0, stream>>>(lv, omega, b, cur, nxt, nullptr); std::swap(cur, nxt); }
-        mgSmoothKernel<<<nb, PB, 0, stream>>>(lv, omega, b, cur, nullptr, lv.r);           // r = b - A x
-        mgRestrictKernel<<<blocksOf(nx.n), PB, 0, stream>>>(nx.n, lv.aggStart, lv.aggItems, lv.r, nx.b);
-        vcycle(l + 1, nx.b, nx.x);
-        mgProlongKernel<<<nb, PB, 0, stream>>>(lv.n, lv.agg, oc, nx.x, cur);
-        for (int s = 0; s < nu; ++s) { mgSmoothKernel<<<nb, PB, 0, stream>>>(lv, omega, b, cur, nxt, nullptr); std::swap(cur, nxt); }
-        if (cur != x) PCHECK(hipMemcpyAsync(x, cur, sizeof(double) * lv.n, hipMemcpyDeviceToDevice, stream));
+        MgLevelT<T>& nx = Lv[l + 1];
+        T* cur = x; T* nxt = lv.x2;
+        mgSmoothKernel<T><<<nb, PB, 0, stream>>>(lv, om, b, none, cur, noOut);
+        for (int s = 1; s < nu; ++s) { mgSmoothKernel<T><<<nb, PB, 0, stream>>>(lv, om, b, cur, nxt, noOut); std::swap(cur, nxt); }
+        mgSmoothKernel<T><<<nb, PB, 0, stream>>>(lv, om, b, cur, noOut, lv.r);           // r = b - A x
+        mgRestrictKernel<T><<<blocksOf(nx.n), PB, 0, stream>>>(nx.n, lv.aggStart, lv.aggItems, lv.r, nx.b);
+        vcycleT<T>(Lv, l + 1, nx.b, nx.x);
+        mgProlongKernel<T><<<nb, PB, 0, stream>>>(lv.n, lv.agg, over, nx.x, cur);
+        for (int s = 0; s < nu; ++s) { mgSmoothKernel<T><<<nb, PB, 0, stream>>>(lv, om, b, cur, nxt, noOut); std::swap(cur, nxt); }
+        if (cur != x) PCHECK(hipMemcpyAsync(x, cur, sizeof(T) * lv.n, hipMemcpyDeviceToDevice, stream));
+    }
+    void vcycle(size_t l, const double* b, double* x) {
+        if (!Lf.empty() && l == 0) {
+            // the cycle as a single-precision operator between double-precision CG vectors: half the bytes of every sweep
+            const int nb = blocksOf(L[0].n);
+            mgConvertKernel<double, float><<<nb, PB, 0, stream>>>(L[0].n, b, Lf[0].b);
+            vcycleT<float>(Lf, 0, Lf[0].b, Lf[0].x);
+            mgConvertKernel<float, double><<<nb, PB, 0, stream>>>(L[0].n, Lf[0].x, x);
+        } else vcycleT<double>(L, l, b, x);
     }
 };
 
@@ -559,7 +623,18 @@ static void mgUploadLevel(PressureSolver* S, int n, const std::vector<int>& I, c
     lv.diag = S->alloc<double>(n, diag.data());
     lv.col = S->alloc<int>(col.size(), col.data());
     lv.val = S->alloc<double>(val.size(), val.data());
-    lv.x = S->alloc<double>(n); lv.x2 = S->alloc<double>(n); lv.b = S->alloc<double>(n); lv.r = S->alloc<double>(n);
+    if (S->f32) {
+        // the double-precision level keeps only what the CG's own matrix product needs (level 0) or nothing
+        std::vector<float> vf(val.begin(), val.end()), df(diag.begin(), diag.end());
+        MgLevelT<float> lf;
+        lf.n = n; lf.width = width; lf.col = lv.col;
+        lf.diag = S->alloc<float>(n, df.data());
+        lf.val = S->alloc<float>(vf.size(), vf.data());
+        lf.x = S->alloc<float>(n); lf.x2 = S->alloc<float>(n); lf.b = S->alloc<float>(n); lf.r = S->alloc<float>(n);
+        S->Lf.push_back(lf);
+    } else {
+        lv.x = S->alloc<double>(n); lv.x2 = S->alloc<double>(n); lv.b = S->alloc<double>(n); lv.r = S->alloc<double>(n);
+    }
     S->L.push_back(lv);
 }
 
@@ -568,6 +643,7 @@ PressureSolver* pressureSolverCreate(hipStream_t stream, const MeshView& m, cons
     PressureSolver* S = new PressureSolver();
     try {
         S->m = m; S->stream = stream; S->refCell = refCell; S->precond = precond; S->bKind = bKind;
+        { const char* e = std::getenv("QGD_MG_F32"); S->f32 = !e || std::atoi(e) != 0; }   // default: single-precision cycle
         const int nC = m.nC, nF = m.nF, nb = blocksOf(nC);
         S->a = S->alloc<double>(nF); S->gs = S->alloc<double>(std::max(m.nBF, 1));
         S->diag = S->alloc<double>(nC); S->rhs = S->alloc<double>(nC); S->r = S->alloc<double>(nC); S->z = S->alloc<double>(nC);
@@ -616,6 +692,7 @@ PressureSolver* pressureSolverCreate(hipStream_t stream, const MeshView& m, cons
                 fine.agg = S->alloc<int>(n, total.data());
                 fine.aggStart = S->alloc<int>((size_t)cur + 1, start.data());
                 fine.aggItems = S->alloc<int>(n, items.data());
+                if (S->f32) { MgLevelT<float>& ff = S->Lf.back(); ff.agg = fine.agg; ff.aggStart = fine.aggStart; ff.aggItems = fine.aggItems; }
                 n = cur;
                 mgUploadLevel(S, n, I, J, w, diag);
             }
@@ -660,7 +737,7 @@ int pressureSolve(PressureSolver* S, const double* phiu, const double* phiwo, co
             if (!S->cycleGraphTried) {
                 S->cycleGraphTried = true;
                 hipGraph_t g = nullptr;
-                if (!std::getenv("QGD_MG_NOGRAPH") && hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                if (std::getenv("QGD_MG_GRAPH") && hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
                     bool ok = true;
                     try { S->vcycle(0, S->r, S->z); } catch (...) { ok = false; }
                     if (hipStreamEndCapture(stream, &g) != hipSuccess || !ok || !g) { g = nullptr; (void)hipGetLastError(); }
@@ -672,7 +749,11 @@ int pressureSolve(PressureSolver* S, const double* phiu, const double* phiwo, co
             }
             if (S->cycleGraph) PCHECK(hipGraphLaunch(S->cycleGraph, stream));
             else S->vcycle(0, S->r, S->z);
-        } else mgSmoothKernel<<<nb, PB, 0, stream>>>(MgLevelDev{nC, 0, S->diag}, 1.0, S->r, nullptr, S->z, nullptr);   // z = r/diag
+        } else {
+            MgLevelDev jl; jl.n = nC; jl.diag = S->diag;
+            const double* none = nullptr; double* noOut = nullptr;
+            mgSmoothKernel<double><<<nb, PB, 0, stream>>>(jl, 1.0, S->r, none, S->z, noOut);   // z = r/diag
+        }
     };
     auto dot = [&](const double* x, const double* y) {
         dotKernel<<<nb, PB, 0, stream>>>(nC, x, y, S->part);
@@ -689,7 +770,8 @@ int pressureSolve(PressureSolver* S, const double* phiu, const double* phiwo, co
         rz = dot(S->r, S->z);
     }
     while (it < maxIter && !(res < tolerance || (relTol > 0 && res < relTol * residuals[0]))) {
-        applyKernel<<<nb, PB, 0, stream>>>(m, S->a, S->diag, S->d, S->q, S->part);
+        if (S->precond == 1 && !S->L.empty()) mgApplyKernel<<<nb, PB, 0, stream>>>(S->L[0], S->d, S->q, S->part);
+        else applyKernel<<<nb, PB, 0, stream>>>(m, S->a, S->diag, S->d, S->q, S->part);
         foldKernel<<<1, PB, 0, stream>>>(S->part, nb, 1, S->scal);
         PCHECK(hipMemcpyAsync(h, S->scal, sizeof(double), hipMemcpyDeviceToHost, stream));
         PCHECK(hipStreamSynchronize(stream));

@@ -1,5 +1,5 @@
 """wall time of the resident QHDFoam step (qgd_qhd_case_step) on an n^3 box: usage  qhd_step_timing.py n [steps]
-QGD_MG_NOGRAPH=1 replays the V-cycle launch by launch instead of as a hipGraph."""
+QGD_MG_GRAPH=1 replays the V-cycle as a captured hipGraph instead of launch by launch."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,4 +16,4 @@ c.set_fields(*initial(mesh))
 c.step(2)
 t0 = time.perf_counter(); c.step(steps); c.field("p")[:1]; dt = (time.perf_counter() - t0) / steps
 info = c.info()
-print(f"QHD {n}^3 graph={'off' if os.environ.get('QGD_MG_NOGRAPH') else 'on'}: {dt * 1e3:.2f} ms/step, {info}", flush=True)
+print(f"QHD {n}^3 graph={'on' if os.environ.get('QGD_MG_GRAPH') else 'off'}: {dt * 1e3:.2f} ms/step, {info}", flush=True)
