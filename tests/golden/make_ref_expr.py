@@ -18,6 +18,8 @@ Snippets evaluated (listing lines of /root/reference/docs/html/<file>_source.htm
                                   L490-512 (macro dfdxif), L750-757 / L831-854 (its invocations for scalar / vector fields)
   gvp2d   GaussVolPointBase2D.C   L154-168 (c1..c4), L317-328 (apply)
   lsq     extendedFaceStencilCalculateWeights.C L64-153, extendedFaceStencilScalarGrad.C L66-72
+  qhdface    QHDFoam/updateFields.H L36-73, QHDFoam/updateFluxes.H L33-38, QHDUEqn.H L36-43, QHDTEqn.H L65-66 (the face
+             expressions qgd_qhd_fluxes returns), with the three fvsc::grad evaluated by the gvp3d text
   case2cell  QGDFoam/updateFields.H L45-80, QGDFoam/updateFluxes.H L41-139 (explicit branch), constScPrModel1.C L103-114,
              QGDCoeffs.C L305-307, with the four fvsc::grad evaluated by the gvp3d text
 
@@ -628,10 +630,77 @@ def case2cell(nfaces=40, seed=14):
     return {k: np.array(v) for k, v in rec.items()}
 
 
+def qhdface(nfaces=36, seed=15):
+    """The QHDFoam face expressions on one internal face between two cells (3-D, GaussVolPoint): updateFields.H (interpolations, body
+    force), updateFluxes.H (phiu, phiwo, taubyrhof), the flux parts of QHDUEqn.H (Wf, phiUfWf, phiUf) and QHDTEqn.H (phiTf,
+    phiTauTReg) -- every line from the listing text, the gradients through the 3-D GaussVolPoint text.  tauQGDf, rho, phi are inputs
+    (what thermo.tauQGDf(), the rhoConst thermo and the pressure equation hand over)."""
+    text = Gvp3dText()
+    fields_src = transpile(lines("QHDFoam_2updateFields_8H_source.html", 36, 73))
+    flux_src = transpile(lines("QHDFoam_2updateFluxes_8H_source.html", 33, 38))
+    ueqn_src = transpile(lines("QHDUEqn_8H_source.html", 36, 43))
+    teqn_src = transpile(lines("QHDTEqn_8H_source.html", 65, 66))
+    rng = np.random.default_rng(seed)
+    names = ("nv", "pts", "Sf", "Cf", "C", "U", "T", "p", "rho", "tauQGDf", "phi", "beta", "g", "w",
+             "gradUf", "gradTf", "gradPf", "phiu", "phiwo", "taubyrhof", "Wf", "phiUf", "phiTf", "phiTauTReg")
+    rec = {k: [] for k in names}
+    for n in range(nfaces):
+        nv = 4 if n % 3 != 2 else 3
+        pts, own, nei = skew_face(rng, nv)
+        S, cf = face_area_centre(pts)
+        S, Cf = Vec(*S), Vec(*cf)
+        U = [rnd_vec(rng, 0.3), rnd_vec(rng, 0.3)]
+        T = [float(rng.uniform(290.0, 310.0)) for _ in range(2)]
+        p = [float(rng.uniform(-0.1, 0.1)) for _ in range(2)]
+        rho = [float(rng.uniform(0.9, 1.2)) for _ in range(2)]
+        tauf = float(rng.uniform(1e-4, 1e-2))
+        phi = float(rng.standard_normal() * 1e-2)
+        beta = float(rng.uniform(1e-3, 5e-3))
+        g = rnd_vec(rng, 9.81)
+        sfo, sfn = abs(S & (Cf - own)), abs(S & (nei - Cf))
+        w = sfn / (sfo + sfn)
+        lin = lambda q: w * (q.o - q.n) + q.n  # noqa: E731   surfaceInterpolationScheme::interpolate (L0)
+        cen = [own, nei]
+        gU, _ = text.grad(pts, own, nei, U, [inv_dist(x, cen, U) for x in pts], True)
+        gT, _ = text.grad(pts, own, nei, T, [inv_dist(x, cen, T) for x in pts], False)
+        gP, _ = text.grad(pts, own, nei, p, [inv_dist(x, cen, p) for x in pts], False)
+        grads = dict(U=Tensor(gU), T=Vec(*gT), p=Vec(*gP), W=Tensor(np.zeros(9)))
+        one = Pair(1.0, 1.0)
+
+        class PS(Pair):   # a pair of scalars that can be scaled and multiplied by a vector (BdFrc = beta*T*g)
+            def __rmul__(self, s): return PS(s * self.o, s * self.n)
+            def __mul__(self, v): return Pair(self.o * v, self.n * v) if isinstance(v, Vec) else Pair.__mul__(self, v)
+        fU, fT, fW = Pair(*U), PS(*T), Pair(Vec(0, 0, 0), Vec(0, 0, 0))
+        # the listing passes fields by name: fvsc.grad looks the gradient up by the field's identity, qgdInterpolate takes its
+        # (owner, neighbour) pair
+        env = dict(qgdInterpolate=lin, fvsc=Obj(grad=lambda fld: grads["U" if fld is fU else ("T" if fld is fT else "W")]),
+                   U=fU, T=fT, W=fW, rho=Pair(*rho), beta=beta, g=g,
+                   turbulence=Obj(muEff=call(one)), thermo=Obj(alpha=call(one), Cp=call(one)))
+        exec(fields_src, env)
+        env2 = dict(mesh=Obj(Sf=call(S)), Uf=env["Uf"], gradUf=env["gradUf"], BdFrcf=env["BdFrcf"], tauQGDf=tauf, rhof=env["rhof"])
+        src2 = "\n".join(l for l in flux_src.split("\n") if "setOriented" not in l)
+        exec(src2, env2)
+        env3 = dict(env2, fvsc=Obj(grad=lambda fld: grads["p"]), p="p", phi=phi, U="U", qgdFlux=lambda flux, psi, psif: flux * psif)
+        src3 = "\n".join(l for l in ueqn_src.split("\n") if "setOriented" not in l)
+        exec(src3, env3)
+        env4 = dict(env3, T="T", Tf=env["Tf"], gradTf=env["gradTf"])
+        exec(teqn_src, env4)
+
+        def val(x):
+            return x.c if isinstance(x, Vec) else (x.m.reshape(9) if isinstance(x, Tensor) else x)
+        out = dict(nv=nv, pts=np.array([q.c for q in pts] + ([[0, 0, 0]] if nv == 3 else [])), Sf=S.c, Cf=Cf.c, C=np.array([own.c, nei.c]),
+                   U=np.array([u.c for u in U]), T=T, p=p, rho=rho, tauQGDf=tauf, phi=phi, beta=beta, g=g.c, w=w,
+                   gradUf=val(env["gradUf"]), gradTf=val(env["gradTf"]), gradPf=val(env3["gradPf"]), phiu=env2["phiu"], phiwo=env2["phiwo"],
+                   taubyrhof=env2["taubyrhof"], Wf=val(env3["Wf"]), phiUf=val(env3["phiUf"]), phiTf=env4["phiTf"], phiTauTReg=env4["phiTauTReg"])
+        for k in names:
+            rec[k].append(np.array(out[k], dtype=float))
+    return {k: np.array(v) for k, v in rec.items()}
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit("make_ref_expr.py needs the reference listings under /root/reference (build container only)")
-    for name, fn in (("gvp3d", gvp3d), ("gvp2d", gvp2d), ("lsq", lsq), ("case2cell", case2cell)):
+    for name, fn in (("gvp3d", gvp3d), ("gvp2d", gvp2d), ("lsq", lsq), ("case2cell", case2cell), ("qhdface", qhdface)):
         data = fn()
         path = os.path.join(HERE, f"ref_expr_{name}.npz")
         np.savez_compressed(path, **data)

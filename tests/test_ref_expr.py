@@ -103,3 +103,31 @@ def test_flux_assembly_of_one_face():
         for f in ("muQGD", "alphauQGD", "tauQGD", "hQGD"):
             assert rel(oc.field(f), g[f][i]) <= TOL, (i, f)
         oc.close(); om.close()
+
+
+QHD_FIELDS = ["gradUf", "gradTf", "gradPf", "phiu", "phiwo", "taubyrhof", "Wf", "phiUf", "phiTf", "phiTauTReg"]
+
+
+def qhd_inputs(g, i):
+    """arguments of updateFluxes for golden configuration i (no boundary faces on the two-cell mesh)"""
+    return dict(U=(g["U"][i], np.zeros((0, 3))), T=(g["T"][i], np.zeros(0)), rho=(g["rho"][i], np.zeros(0)), tauQGDf=np.array([g["tauQGDf"][i]]),
+                beta=float(g["beta"][i]), g=g["g"][i], p=(g["p"][i], np.zeros(0)), phi=np.array([g["phi"][i]]))
+
+
+def test_qhd_face_expressions():
+    """QHDFoam/updateFields.H L36-73, updateFluxes.H L33-38, QHDUEqn.H L36-43, QHDTEqn.H L65-66 evaluated from the listing text
+    against the oracle's qhd_fluxes: gradients, phiu, phiwo (body force included), taubyrhof, Wf, phiUf = phi Uf - Sf.(Uf Wf), phiTf,
+    phiTauTReg"""
+    g = rc.load("qhdface")
+    assert set(g["nv"]) == {3, 4}
+    for i in range(len(g["nv"])):
+        nv = int(g["nv"][i])
+        prim, geom = rc.two_cell_mesh(g["pts"][i], nv, g["Sf"][i], g["Cf"][i], g["C"][i])
+        om = oracle_mesh(prim, geom)
+        assert rel(om.array("weights")[0], g["w"][i]) <= 1e-15
+        a = qhd_inputs(g, i)
+        res = oracle.qhd_fluxes(om, "GaussVolPoint", a["U"], a["T"], a["rho"], a["tauQGDf"], a["beta"], a["g"], p=a["p"], phi=a["phi"])
+        assert sorted(res) == sorted(QHD_FIELDS)
+        for f in QHD_FIELDS:
+            assert rel(res[f][0], g[f][i]) <= TOL, (i, nv, f, res[f][0], g[f][i])
+        om.close()

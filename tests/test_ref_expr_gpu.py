@@ -8,7 +8,7 @@ import qgdsolver_amd as q
 from qgdsolver_amd import fvsc
 
 import ref_expr_cases as rc
-from test_ref_expr import FACE_FIELDS, case_options, rel
+from test_ref_expr import FACE_FIELDS, QHD_FIELDS, case_options, qhd_inputs, rel
 
 pytestmark = pytest.mark.gpu
 
@@ -80,3 +80,18 @@ def test_flux_assembly_of_one_face_on_the_device():
         for f in ("muQGD", "alphauQGD", "tauQGD", "hQGD"):
             assert rel(case.field(f), g[f][i]) <= TOL, (i, f)
         case.close(); dev.close()
+
+
+def test_qhd_face_expressions_on_the_device():
+    """qgd_qhd_fluxes against the QHDFoam face expressions evaluated from the listing text (tests/golden/ref_expr_qhdface.npz)"""
+    from qgdsolver_amd import qhdfoam
+    g = rc.load("qhdface")
+    for i in range(len(g["nv"])):
+        nv = int(g["nv"][i])
+        mesh = device_mesh(*rc.two_cell_mesh(g["pts"][i], nv, g["Sf"][i], g["Cf"][i], g["C"][i]))
+        dev = q.Device(mesh)
+        a = qhd_inputs(g, i)
+        res = qhdfoam.updateFluxes(dev, "GaussVolPoint", a["U"], a["T"], a["rho"], a["tauQGDf"], a["beta"], a["g"], p=a["p"], phi=a["phi"])
+        for f in QHD_FIELDS:
+            assert rel(res[f][0], g[f][i]) <= TOL, (i, nv, f, res[f][0], g[f][i])
+        dev.close()
