@@ -20,6 +20,8 @@ Snippets evaluated (listing lines of /root/reference/docs/html/<file>_source.htm
   lsq     extendedFaceStencilCalculateWeights.C L64-153, extendedFaceStencilScalarGrad.C L66-72
   qhdface    QHDFoam/updateFields.H L36-73, QHDFoam/updateFluxes.H L33-38, QHDUEqn.H L36-43, QHDTEqn.H L65-66 (the face
              expressions qgd_qhd_fluxes returns), with the three fvsc::grad evaluated by the gvp3d text
+  species    reactingLagrangianQGDFoam/updateFields.H L38 (Yf), updateFluxes.H L122-127 (one species of the forAll): what
+             qgd_species_flux returns
   case2cell  QGDFoam/updateFields.H L45-80, QGDFoam/updateFluxes.H L41-139 (explicit branch), constScPrModel1.C L103-114,
              QGDCoeffs.C L305-307, with the four fvsc::grad evaluated by the gvp3d text
 
@@ -697,10 +699,45 @@ def qhdface(nfaces=36, seed=15):
     return {k: np.array(v) for k, v in rec.items()}
 
 
+def species(nfaces=30, seed=16):
+    """One species of reactingLagrangianQGDFoam/updateFluxes.H L117-132 on one internal face: gradYf, phiJmY = qgdFlux(phiJm, Y, Yf) +
+    dydtflux, diffusiveFlux = dydtflux = -phi tauQGDf (Uf & gradYf); Yf from updateFields.H L38; Uf = qgdInterpolate(U)."""
+    text = Gvp3dText()
+    yf_src = transpile(lines("reactingLagrangianQGDFoam_2updateFields_8H_source.html", 38, 38))
+    src = transpile(lines("reactingLagrangianQGDFoam_2updateFluxes_8H_source.html", 122, 127))
+    rng = np.random.default_rng(seed)
+    names = ("nv", "pts", "Sf", "Cf", "C", "U", "Y", "phiJm", "phi", "tauQGDf", "gradYf", "phiJmY", "diffusiveFlux")
+    rec = {k: [] for k in names}
+    for n in range(nfaces):
+        nv = 4 if n % 3 != 2 else 3
+        pts, own, nei = skew_face(rng, nv)
+        S, cf = face_area_centre(pts)
+        S, Cf = Vec(*S), Vec(*cf)
+        U = [rnd_vec(rng, 0.7), rnd_vec(rng, 0.7)]
+        Y = [float(rng.uniform(0.0, 1.0)) for _ in range(2)]
+        phiJm, phi, tauf = float(rng.standard_normal()), float(rng.standard_normal()), float(rng.uniform(1e-4, 1e-2))
+        sfo, sfn = abs(S & (Cf - own)), abs(S & (nei - Cf))
+        w = sfn / (sfo + sfn)
+        lin = lambda q: w * (q.o - q.n) + q.n  # noqa: E731
+        gY, _ = text.grad(pts, own, nei, Y, [inv_dist(x, [own, nei], Y) for x in pts], False)
+        fY = Pair(*Y)
+        env = dict(qgdInterpolate=lin, Y=[fY], Yf=[None], i=0)
+        exec(yf_src, env)
+        env2 = dict(fvsc=Obj(grad=lambda fld: Vec(*gY)), Y=[fY], Yf=env["Yf"], i=0, qgdFlux=lambda flux, psi, psif: flux * psif,
+                    phiJm=phiJm, phi=phi, tauQGDf=tauf, Uf=lin(Pair(*U)), phiJmY=[None], diffusiveFlux=[None])
+        exec(src, env2)
+        out = dict(nv=nv, pts=np.array([q.c for q in pts] + ([[0, 0, 0]] if nv == 3 else [])), Sf=S.c, Cf=Cf.c, C=np.array([own.c, nei.c]),
+                   U=np.array([u.c for u in U]), Y=Y, phiJm=phiJm, phi=phi, tauQGDf=tauf, gradYf=env2["gradYf"].c, phiJmY=env2["phiJmY"][0],
+                   diffusiveFlux=env2["diffusiveFlux"][0])
+        for k in names:
+            rec[k].append(np.array(out[k], dtype=float))
+    return {k: np.array(v) for k, v in rec.items()}
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit("make_ref_expr.py needs the reference listings under /root/reference (build container only)")
-    for name, fn in (("gvp3d", gvp3d), ("gvp2d", gvp2d), ("lsq", lsq), ("case2cell", case2cell), ("qhdface", qhdface)):
+    for name, fn in (("gvp3d", gvp3d), ("gvp2d", gvp2d), ("lsq", lsq), ("case2cell", case2cell), ("qhdface", qhdface), ("species", species)):
         data = fn()
         path = os.path.join(HERE, f"ref_expr_{name}.npz")
         np.savez_compressed(path, **data)

@@ -131,3 +131,21 @@ def test_qhd_face_expressions():
         for f in QHD_FIELDS:
             assert rel(res[f][0], g[f][i]) <= TOL, (i, nv, f, res[f][0], g[f][i])
         om.close()
+
+
+def test_species_flux_expressions():
+    """reactingLagrangianQGDFoam/updateFluxes.H L122-127 (+ updateFields.H L38) from the listing text against the oracle's species block"""
+    from qgdsolver_amd import qgdfoam
+    g = rc.load("species")
+    for i in range(len(g["nv"])):
+        nv = int(g["nv"][i])
+        prim, geom = rc.two_cell_mesh(g["pts"][i], nv, g["Sf"][i], g["Cf"][i], g["C"][i])
+        om = oracle_mesh(prim, geom)
+
+        class FakeDev:
+            mesh = om
+        res = qgdfoam.speciesFlux(FakeDev, "GaussVolPoint", (g["Y"][i], np.zeros(0)), (g["U"][i], np.zeros((0, 3))), [g["phiJm"][i]], [g["phi"][i]],
+                                  [g["tauQGDf"][i]], call=lambda sch, *a: oracle.species_flux(om, sch, *a))
+        for f in ("gradYf", "phiJmY", "diffusiveFlux"):
+            assert rel(res[f][0], g[f][i]) <= TOL, (i, nv, f, res[f][0], g[f][i])
+        om.close()

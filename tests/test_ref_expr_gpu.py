@@ -95,3 +95,18 @@ def test_qhd_face_expressions_on_the_device():
         for f in QHD_FIELDS:
             assert rel(res[f][0], g[f][i]) <= TOL, (i, nv, f, res[f][0], g[f][i])
         dev.close()
+
+
+def test_species_flux_expressions_on_the_device():
+    """qgd_species_flux against reactingLagrangianQGDFoam/updateFluxes.H L122-127 evaluated from the listing text"""
+    from qgdsolver_amd import qgdfoam
+    g = rc.load("species")
+    for i in range(len(g["nv"])):
+        nv = int(g["nv"][i])
+        mesh = device_mesh(*rc.two_cell_mesh(g["pts"][i], nv, g["Sf"][i], g["Cf"][i], g["C"][i]))
+        dev = q.Device(mesh)
+        res = qgdfoam.speciesFlux(dev, "GaussVolPoint", (g["Y"][i], np.zeros(0)), (g["U"][i], np.zeros((0, 3))), [g["phiJm"][i]], [g["phi"][i]],
+                                  [g["tauQGDf"][i]])
+        for f in ("gradYf", "phiJmY", "diffusiveFlux"):
+            assert rel(res[f][0], g[f][i]) <= TOL, (i, nv, f, res[f][0], g[f][i])
+        dev.close()
