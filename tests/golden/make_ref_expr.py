@@ -16,6 +16,9 @@ Runs only where /root/reference exists (the build container):   python tests/gol
 Snippets evaluated (listing lines of /root/reference/docs/html/<file>_source.html):
   gvp3d   GaussVolPointBase3D.C   L186-229 (triangle coefficients), L346-389 (quad coefficients),
                                   L490-512 (macro dfdxif), L750-757 / L831-854 (its invocations for scalar / vector fields)
+  gvp3d_bnd  the same file's boundary-face text: mirror point and |vO - vN| L129-154, boundary triangle / quad coefficients
+             L232-317 / L391-475, macro dfdxbf L515-539, its invocations with psin = patch value + snGrad*bmvON/2 (calcGradfBF
+             L780-806 scalar, L877-919 vector; calcDivfBF L583-609 vector, L683-725 tensor)
   gvp2d   GaussVolPointBase2D.C   L154-168 (c1..c4), L317-328 (apply)
   lsq     extendedFaceStencilCalculateWeights.C L64-153, extendedFaceStencilScalarGrad.C L66-72
   qhdface    QHDFoam/updateFields.H L36-73, QHDFoam/updateFluxes.H L33-38, QHDUEqn.H L36-43, QHDTEqn.H L65-66 (the face
@@ -92,6 +95,7 @@ def expr(e):
     if len(q) == 2:                                   # cond ? a : b
         a, b = split_top(q[1], ":")
         return f"({expr(a)}) if ({expr(q[0])}) else ({expr(b)})"
+    e = re.sub(r"refCast\s*<[^(]*\(", "refCast(", e)   # template arguments of a cast are not part of any arithmetic
     e = e.replace("::", ".").replace("->", ".")
     e = re.sub(r"!(?!=)", " not ", e)
     e = e.replace("&&", " and ").replace("||", " or ")
@@ -108,6 +112,15 @@ def statement(st):
     m = re.match(r"^symmTensor\s+(\w+)\((.*)\)$", st)
     if m:
         return [f"{m.group(1)} = symmTensor({expr(m.group(2))})"]
+    m = re.match(r"^List<\s*List<\s*\w+\s*>\s*>\s*(\w+)\s*\((.*)\)$", st)          # List<List<scalar> > psin (n)
+    if m:
+        return [f"{m.group(1)} = RList([None]*({expr(m.group(2))}))"]
+    m = re.match(r"^(?:scalar|vector|tensor)Field\s+(\w+)\s*\((.*)\)$", st)          # vectorField v(n, vector::zero) | scalarField psio (expr)
+    if m:
+        args = split_top(m.group(2))
+        if len(args) == 2:
+            return [f"{m.group(1)} = Fld([None]*({expr(args[0])}))"]
+        return [f"{m.group(1)} = {expr(m.group(2))}"]
     m = re.match(rf"^{TYPES}\s*(.*)$", st)
     if m and re.match(r"^\w+\s*(=|,|$)", m.group(1)):
         out = []
@@ -187,7 +200,7 @@ def transpile(src_lines, continuation=False):
         else:
             buf += ch
             # macro invocations written without a semicolon, one per line
-            if ch == "\n" and re.match(r"^\s*dfdxif\(.*\)\s*$", buf):
+            if ch == "\n" and re.match(r"^\s*dfdx[ib]f\(.*\)\s*$", buf):
                 emit(expr(buf))
                 buf = ""
         i += 1
@@ -297,7 +310,10 @@ class symmTensor:
 
 def sqr(v): return symmTensor(v.c[0] * v.c[0], v.c[0] * v.c[1], v.c[0] * v.c[2], v.c[1] * v.c[1], v.c[1] * v.c[2], v.c[2] * v.c[2])
 def magSqr(v): return float(v.c[0] * v.c[0] + v.c[1] * v.c[1] + v.c[2] * v.c[2])
-def mag(v): return abs(v) if _num(v) else float(np.sqrt(magSqr(v)))
+def mag(v):
+    if isinstance(v, Fld):
+        return Fld([mag(a) for a in v])
+    return abs(v) if _num(v) else float(np.sqrt(magSqr(v)))
 
 
 def det(s):  # SymmTensorI.H
@@ -321,6 +337,16 @@ class RList(list):
         self.extend([0.0] * (n - len(self)))
 
     def size(self): return len(self)
+
+
+class Fld(list):
+    """a field over the faces of one patch: elementwise arithmetic, scalars broadcast (scalarField / vectorField / tensorField)"""
+    def _zip(self, o, f):
+        return Fld([f(a, b) for a, b in zip(self, o)]) if isinstance(o, list) else Fld([f(a, o) for a in self])
+    def __add__(self, o): return self._zip(o, lambda a, b: a + b)
+    def __sub__(self, o): return self._zip(o, lambda a, b: a - b)
+    def __mul__(self, o): return self._zip(o, lambda a, b: a * b)
+    def __rmul__(self, o): return Fld([o * a for a in self])
 
 
 class Obj:
@@ -367,6 +393,14 @@ def face_area_centre(pts):
     return S, c
 
 
+class Cell0:
+    """a scalar face value that `oop(field[facei], ocmpt) += x` with oop = SCA_CMPT can accumulate into"""
+    def __init__(self): self.v = 0.0
+    def __iadd__(self, x):
+        self.v += x
+        return self
+
+
 class Gvp3dText:
     """the 3-D GaussVolPoint listing text, ready to be evaluated on one face"""
     def __init__(self):
@@ -376,6 +410,17 @@ class Gvp3dText:
         self.macro = transpile(lines(f3, 489, 513), continuation=True)
         self.inv_s = transpile(lines(f3, 749, 757))
         self.inv_v = transpile(lines(f3, 830, 854))
+        self.inv_div_v = transpile(lines(f3, 552, 560))     # calcDivfIF(volVectorField): scalar out
+        self.inv_div_t = transpile(lines(f3, 633, 659))     # calcDivfIF(volTensorField): vector out
+        # boundary faces: mirror point and |vO - vN| [L129-154], triangle / quad coefficients [L232-317 / L391-475], the macro
+        # dfdxbf [L515-539] and its invocations with psin = patch value + snGrad*bmvON/2 [calcGradfBF L780-806 (scalar),
+        # L860-ff (vector), calcDivfBF L583-609 (vector), L683-725 (tensor)]
+        self.bmv_src = transpile(lines(f3, 129, 154))
+        self.btri_src = transpile(lines(f3, 232, 317))
+        self.bqua_src = transpile(lines(f3, 391, 475))
+        self.bmacro = transpile(lines(f3, 516, 539), continuation=True)
+        self.binv = {"grad_s": transpile(lines(f3, 780, 806)), "grad_v": transpile(lines(f3, 877, 919)), "div_v": transpile(lines(f3, 583, 609)),
+                     "div_t": transpile(lines(f3, 683, 725))}
 
     def coeffs(self, pts, own, nei):
         nv = len(pts)
@@ -389,28 +434,85 @@ class Gvp3dText:
         exec(self.qua_src, env)
         return env["aqx_"], env["aqy_"], env["aqz_"], env["vq_"], mesh
 
-    def grad(self, pts, own, nei, cell_vals, pt_vals, vector):
-        """the macro body becomes a function, its invocations [L750-757 / L831-854] are executed as written"""
+    def grad(self, pts, own, nei, cell_vals, pt_vals, vector, op="grad"):
+        """the macro body becomes a function, its invocations [L750-757 / L831-854; div: L552-560 / L633-659] are executed as written"""
         nv = len(pts)
         ax, ay, az, vol, mesh = self.coeffs(pts, own, nei)
         faces = [list(range(nv))]
         grad = [np.zeros(9 if vector else 3)]
+        if op == "div_v":
+            grad = [Cell0()]        # a scalar the SCA_CMPT output operator can add into
+        elif op == "div_t":
+            grad = [np.zeros(3)]
         fld = Obj(mesh=call(mesh), primitiveField=call(cell_vals))
         out = Obj(primitiveFieldRef=call(grad))
         macro = self.macro
 
         def dfdxif(vf, pf, dfdxfield, fi, vi, ai, icmpt, ocmpt, iop, oop):
             def oop_add(target, cm, value):
-                target[cm] += value
+                if isinstance(target, Cell0):   # oop = SCA_CMPT: the scalar itself
+                    target.v += value
+                else:
+                    target[cm] += value
             exec(macro, dict(vf=vf, pf=pf, dfdxfield=dfdxfield, fi=fi, vi=vi, ai=ai, icmpt=icmpt, ocmpt=ocmpt, iop=iop, oop=oop,
                              faces=faces, oop_add=oop_add))
 
-        e = dict(dfdxif=dfdxif, sf=fld, vf=fld, pf=pt_vals, gradf=out, SCA_CMPT=lambda V, c: V, VEC_CMPT=lambda V, c: V[c],
+        e = dict(dfdxif=dfdxif, sf=fld, vf=fld, tf=fld, pf=pt_vals, gradf=out, divf=out, SCA_CMPT=lambda V, c: V, VEC_CMPT=lambda V, c: V[c],
                  qf_=[0] if nv == 4 else [], tf_=[0] if nv == 3 else [], vq_=vol if nv == 4 else [], vt_=vol if nv == 3 else [],
                  aqx_=ax if nv == 4 else RList(), aqy_=ay if nv == 4 else RList(), aqz_=az if nv == 4 else RList(),
                  atx_=ax if nv == 3 else RList(), aty_=ay if nv == 3 else RList(), atz_=az if nv == 3 else RList())
-        exec(self.inv_v if vector else self.inv_s, e)
-        return grad[0], (ax, ay, az, vol)
+        exec({"grad": self.inv_v if vector else self.inv_s, "div_v": self.inv_div_v, "div_t": self.inv_div_t}[op], e)
+        return (grad[0].v if op == "div_v" else grad[0]), (ax, ay, az, vol)
+
+    def boundary(self, pts, own, Cf, cell_val, bnd_val, sn_grad, pt_vals, op):
+        """fvsc gradient / divergence on ONE boundary face (patch 0, face 0) owned by a cell centred at `own`: everything from the
+        text.  cell_val / bnd_val / sn_grad: the owner's value, the patch value and fvPatchField::snGrad() of the face (L0)."""
+        nv = len(pts)
+        patch = Obj(size=lambda: 1, Cn=lambda: Fld([own]), Cf=lambda: Fld([Cf]))
+        mesh = Obj(boundary=call([patch]))
+        base = dict(mesh=mesh, processorPatch_=[False], bgfid_=[RList([0])], Fld=Fld, RList=RList, mag=mag, refCast=None,
+                    vector=Obj(zero=Vec(0, 0, 0)))
+        env = dict(base, bmvON_=[None])
+        exec(self.bmv_src, env)
+        bmvON = env["bmvON_"]
+        co = dict(base, points=pts, faces=[list(range(nv))], OneBySix=(1.0 / 6.0), facei=-1, p1=-1, p2=-1, p3=-1, p4=-1)
+        empty = lambda: [RList()]   # noqa: E731  no faces of the other kind on the patch
+        one = lambda: [RList([RList()])]   # noqa: E731
+        if nv == 3:
+            co.update(btf_=[RList([0])], batx_=one(), baty_=one(), batz_=one(), bvt_=[RList([0.0])])
+            exec(self.btri_src, co)
+            coef = dict(btf_=co["btf_"], batx_=co["batx_"], baty_=co["baty_"], batz_=co["batz_"], bvt_=co["bvt_"],
+                        bqf_=[RList()], baqx_=empty(), baqy_=empty(), baqz_=empty(), bvq_=[RList()])
+            ax, ay, az, vol = co["batx_"][0][0], co["baty_"][0][0], co["batz_"][0][0], co["bvt_"][0][0]
+        else:
+            co.update(bqf_=[RList([0])], baqx_=one(), baqy_=one(), baqz_=one(), bvq_=[RList([0.0])])
+            exec(self.bqua_src, co)
+            coef = dict(bqf_=co["bqf_"], baqx_=co["baqx_"], baqy_=co["baqy_"], baqz_=co["baqz_"], bvq_=co["bvq_"],
+                        btf_=[RList()], batx_=empty(), baty_=empty(), batz_=empty(), bvt_=[RList()])
+            ax, ay, az, vol = co["baqx_"][0][0], co["baqy_"][0][0], co["baqz_"][0][0], co["bvq_"][0][0]
+
+        class PatchField(Fld):
+            def snGrad(self): return Fld([sn_grad])
+            def patchInternalField(self): return Fld([cell_val])
+        fld = Obj(boundaryField=call(RList([PatchField([bnd_val])])))
+        res = [Cell0()] if op == "div_v" else [np.zeros(9 if op == "grad_v" else 3)]
+        out = Obj(boundaryFieldRef=call([res]))
+        faces = [list(range(nv))]
+        macro = self.bmacro
+        e = dict(coef, sf=fld, vf=fld, tf=fld, pf=pt_vals, gradf=out, divf=out, processorPatch_=[False], bmvON_=bmvON, RList=RList, refCast=None,
+                 SCA_CMPT=lambda V, c: V, VEC_CMPT=lambda V, c: V[c], bof_=[RList()], dfdn=None)
+
+        def dfdxbf(vf, pf, patchi, dfdxfield, bfi, bvfi, bai, icmpt, ocmpt, iop, oop):
+            def oop_add(target, cm, value):
+                if isinstance(target, Cell0):
+                    target.v += value
+                else:
+                    target[cm] += value
+            exec(macro, dict(vf=vf, pf=pf, patchi=patchi, dfdxfield=dfdxfield, bfi=bfi, bvfi=bvfi, bai=bai, icmpt=icmpt, ocmpt=ocmpt, iop=iop,
+                             oop=oop, faces=faces, bgfid_=[RList([0])], psin=e["psin"], psio=e["psio"], oop_add=oop_add))
+        e["dfdxbf"] = dfdxbf
+        exec(self.binv[op], e)
+        return (res[0].v if op == "div_v" else res[0]), (ax, ay, az, vol, bmvON[0][0])
 
 
 def gvp3d(nfaces=48, seed=11):
@@ -418,7 +520,7 @@ def gvp3d(nfaces=48, seed=11):
     text = Gvp3dText()
     rng = np.random.default_rng(seed)
     rec = {k: [] for k in ("nv", "pts", "Sf", "Cf", "C", "cell_s", "cell_v", "pt_s", "pt_v", "coef_x", "coef_y", "coef_z", "vol",
-                           "grad_s", "grad_v")}
+                           "grad_s", "grad_v", "cell_t", "div_v", "div_t")}
     for n in range(nfaces):
         nv = 4 if n % 2 == 0 else 3
         pts, own, nei = skew_face(rng, nv)
@@ -428,6 +530,11 @@ def gvp3d(nfaces=48, seed=11):
         pt_v = [inv_dist(x, [own, nei], cell_v) for x in pts]
         gs, (ax, ay, az, vol) = text.grad(pts, own, nei, cell_s, pt_s, False)
         gv, _ = text.grad(pts, own, nei, cell_v, pt_v, True)
+        # the two divergences [calcDivfIF L552-560, L633-659]; the tensor field as 9 components, T[3*i + j] as the listing indexes it
+        cell_t = [rng.standard_normal(9), rng.standard_normal(9)]
+        pt_t = [inv_dist(x, [own, nei], cell_t) for x in pts]
+        dv, _ = text.grad(pts, own, nei, cell_v, pt_v, True, op="div_v")
+        dt, _ = text.grad(pts, own, nei, cell_t, pt_t, True, op="div_t")
         S, cf = face_area_centre(pts)
         pad3, pad = ([[0, 0, 0]] if nv == 3 else []), ([0.0] if nv == 3 else [])
         rec["nv"].append(nv); rec["pts"].append(np.array([p.c for p in pts] + pad3)); rec["Sf"].append(S); rec["Cf"].append(cf)
@@ -436,6 +543,39 @@ def gvp3d(nfaces=48, seed=11):
         rec["coef_x"].append(np.array(list(ax[0]) + pad)); rec["coef_y"].append(np.array(list(ay[0]) + pad))
         rec["coef_z"].append(np.array(list(az[0]) + pad)); rec["vol"].append(vol[0])
         rec["grad_s"].append(gs); rec["grad_v"].append(gv)
+        rec["cell_t"].append(np.array(cell_t)); rec["div_v"].append(dv); rec["div_t"].append(dt)
+    return {k: np.array(v) for k, v in rec.items()}
+
+
+def gvp3d_bnd(nfaces=40, seed=17):
+    """one BOUNDARY face (generic patch) of a cell with prescribed centre; its vertices are boundary points and carry the patch value
+    (L0: inverse-distance mean over the adjacent real-patch faces, here one); fvPatchField::snGrad = deltaCoeffs (patch value - cell
+    value) with the patch-normal delta of OpenFOAM v2312 (L0)"""
+    text = Gvp3dText()
+    rng = np.random.default_rng(seed)
+    names = ("nv", "pts", "Sf", "Cf", "C", "cell_s", "bnd_s", "cell_v", "bnd_v", "cell_t", "bnd_t", "bmvON", "vol", "coef_x", "coef_y", "coef_z",
+             "grad_s", "grad_v", "div_v", "div_t")
+    rec = {k: [] for k in names}
+    for n in range(nfaces):
+        nv = 4 if n % 2 == 0 else 3
+        pts, own, _ = skew_face(rng, nv)
+        S, cf = face_area_centre(pts)
+        Cf = Vec(*cf)
+        nf = S / np.sqrt((S * S).sum())
+        dc = 1.0 / abs(float(nf @ (cf - own.c)))           # fvPatch::deltaCoeffs, delta = nf (nf & (Cf - Cn))  (L0)
+        cs, bs = float(rng.uniform(0.8, 1.3)), float(rng.uniform(0.8, 1.3))
+        cv, bv = rnd_vec(rng), rnd_vec(rng)
+        ct, bt = rng.standard_normal(9), rng.standard_normal(9)
+        gs, (ax, ay, az, vol, bmv) = text.boundary(pts, own, Cf, cs, bs, dc * (bs - cs), [bs] * nv, "grad_s")
+        gv, _ = text.boundary(pts, own, Cf, cv, bv, dc * (bv - cv), [bv] * nv, "grad_v")
+        dv, _ = text.boundary(pts, own, Cf, cv, bv, dc * (bv - cv), [bv] * nv, "div_v")
+        dt, _ = text.boundary(pts, own, Cf, ct, bt, dc * (bt - ct), [bt] * nv, "div_t")
+        pad3, pad = ([[0, 0, 0]] if nv == 3 else []), ([0.0] if nv == 3 else [])
+        out = dict(nv=nv, pts=np.array([p.c for p in pts] + pad3), Sf=S, Cf=cf, C=own.c, cell_s=cs, bnd_s=bs, cell_v=cv.c, bnd_v=bv.c, cell_t=ct,
+                   bnd_t=bt, bmvON=bmv, vol=vol, coef_x=np.array(list(ax) + pad), coef_y=np.array(list(ay) + pad), coef_z=np.array(list(az) + pad),
+                   grad_s=gs, grad_v=gv, div_v=dv, div_t=dt)
+        for k in names:
+            rec[k].append(np.array(out[k], dtype=float))
     return {k: np.array(v) for k, v in rec.items()}
 
 
@@ -737,7 +877,7 @@ def species(nfaces=30, seed=16):
 def main():
     if not os.path.isdir(REF):
         sys.exit("make_ref_expr.py needs the reference listings under /root/reference (build container only)")
-    for name, fn in (("gvp3d", gvp3d), ("gvp2d", gvp2d), ("lsq", lsq), ("case2cell", case2cell), ("qhdface", qhdface), ("species", species)):
+    for name, fn in (("gvp3d", gvp3d), ("gvp3d_bnd", gvp3d_bnd), ("gvp2d", gvp2d), ("lsq", lsq), ("case2cell", case2cell), ("qhdface", qhdface), ("species", species)):
         data = fn()
         path = os.path.join(HERE, f"ref_expr_{name}.npz")
         np.savez_compressed(path, **data)

@@ -33,6 +33,23 @@ def two_cell_mesh(pts, nv, Sf, Cf, C, empty_normals=()):
     return prim, geom
 
 
+def boundary_face_mesh(pts, nv, Sf, Cf, C):
+    """cell 0 (centre C) with ONE boundary face on a generic patch: face 1, vertices 0..nv-1, area vector / centre prescribed; an
+    internal quad (face 0) a unit length behind the cell connects it to cell 1 and shares no vertex with the boundary face, so the
+    boundary face's vertices are boundary points of that face alone"""
+    pts = np.asarray(pts, float)[:nv]
+    C = np.asarray(C, float)
+    back = C + np.array([-1.0, 0.0, 0.0])
+    quad = [back + np.array([0.0, a, b]) for a, b in ((-0.5, -0.5), (-0.5, 0.5), (0.5, 0.5), (0.5, -0.5))]
+    faces = [list(range(nv, nv + 4)), list(range(nv))]
+    prim = dict(points=np.concatenate([pts, np.array(quad)]).reshape(-1), faceOffsets=np.cumsum([0] + [len(f) for f in faces]).astype(np.int32),
+                facePoints=np.concatenate(faces).astype(np.int32), owner=np.array([0, 0], np.int32), neighbour=np.array([1], np.int32),
+                nCells=2, patchStart=np.array([1], np.int32), patchSize=np.array([1], np.int32), patchType=np.array([GENERIC], np.int32))
+    geom = dict(Sf=np.array([[-1.0, 0.0, 0.0], np.asarray(Sf, float)]), Cf=np.array([back, np.asarray(Cf, float)]),
+                C=np.array([C, C + np.array([-2.0, 0.0, 0.0])]), V=np.ones(2))
+    return prim, geom
+
+
 def lsq_mesh(n, Cf, centres, one_d):
     """internal face 0 between cells 0 and 1 (a quad normal to x around Cf); cells 2..n-1 hang on vertex 0 of that face through
     one generic boundary triangle each, so that the face's point-neighbour stencil is cells 0..n-1 in this order

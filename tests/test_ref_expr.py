@@ -41,6 +41,37 @@ def test_gaussvolpoint_3d_coefficients_and_macro():
         assert rel(gv[0], g["grad_v"][i]) <= TOL, (i, nv)
         if nv == 3:   # the listing's interior-triangle pattern: every row holds (dxUx, dyUy, dzUz)
             assert np.array_equal(g["grad_v"][i][0:3], g["grad_v"][i][3:6]) and np.array_equal(g["grad_v"][i][0:3], g["grad_v"][i][6:9])
+        # the divergences [calcDivfIF L552-560 (vector), L633-659 (tensor: d_i T_ij, component 3*i + j)]
+        rc_dv, dv = om.fvsc("GaussVolPoint", "div_v", g["cell_v"][i], np.zeros(0))
+        rc_dt, dt = om.fvsc("GaussVolPoint", "div_t", g["cell_t"][i], np.zeros(0))
+        assert rc_dv == 0 and rc_dt == 0
+        assert rel(dv[0], g["div_v"][i]) <= TOL, (i, nv, dv[0], g["div_v"][i])
+        assert rel(dt[0], g["div_t"][i]) <= TOL, (i, nv, dt[0], g["div_t"][i])
+        om.close()
+
+
+def bnd_ops(g, i):
+    """(op, cell values of the two cells, patch value, expected) of boundary golden configuration i; cell 1 is a bystander"""
+    return (("grad_s", [g["cell_s"][i], 0.3], [g["bnd_s"][i]], g["grad_s"][i]),
+            ("grad_v", [g["cell_v"][i], [0.1, 0.2, 0.3]], [g["bnd_v"][i]], g["grad_v"][i]),
+            ("div_v", [g["cell_v"][i], [0.1, 0.2, 0.3]], [g["bnd_v"][i]], g["div_v"][i]),
+            ("div_t", [g["cell_t"][i], np.arange(9.0)], [g["bnd_t"][i]], g["div_t"][i]))
+
+
+def test_gaussvolpoint_3d_boundary_faces():
+    """the boundary-face text of GaussVolPointBase3D.C: mirror point, coefficients with owner / mirror slots, psin = patch value +
+    snGrad bmvON/2, macro dfdxbf, for scalar and vector gradients and vector and tensor divergences, quads and triangles"""
+    g = rc.load("gvp3d_bnd")
+    assert set(g["nv"]) == {3, 4}
+    for i in range(len(g["nv"])):
+        nv = int(g["nv"][i])
+        prim, geom = rc.boundary_face_mesh(g["pts"][i], nv, g["Sf"][i], g["Cf"][i], g["C"][i])
+        om = oracle_mesh(prim, geom)
+        assert om.info()["nGeometricD"] == 3
+        for op, cell, bnd, want in bnd_ops(g, i):
+            st, got = om.fvsc("GaussVolPoint", op, np.array(cell, float), np.array(bnd, float))
+            assert st == 0
+            assert rel(got[1], want) <= TOL, (i, nv, op, got[1], want)
         om.close()
 
 

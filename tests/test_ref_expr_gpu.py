@@ -8,7 +8,7 @@ import qgdsolver_amd as q
 from qgdsolver_amd import fvsc
 
 import ref_expr_cases as rc
-from test_ref_expr import FACE_FIELDS, QHD_FIELDS, case_options, qhd_inputs, rel
+from test_ref_expr import FACE_FIELDS, QHD_FIELDS, bnd_ops, case_options, qhd_inputs, rel
 
 pytestmark = pytest.mark.gpu
 
@@ -32,6 +32,24 @@ def test_gaussvolpoint_3d_on_the_device():
         gv = fvsc.grad(dev, q.volField("U", g["cell_v"][i], np.zeros((0, 3))))
         assert rel(gs[0], g["grad_s"][i]) <= TOL, (i, nv)
         assert rel(gv[0], g["grad_v"][i]) <= TOL, (i, nv)
+        dv = fvsc.div(dev, q.volField("U", g["cell_v"][i], np.zeros((0, 3))))
+        dt = fvsc.div(dev, q.volField("T", g["cell_t"][i], np.zeros((0, 9))))
+        assert rel(dv[0], g["div_v"][i]) <= TOL, (i, nv)
+        assert rel(dt[0], g["div_t"][i]) <= TOL, (i, nv)
+        dev.close()
+
+
+def test_gaussvolpoint_3d_boundary_faces_on_the_device():
+    """the boundary-face text of GaussVolPointBase3D.C (tests/golden/ref_expr_gvp3d_bnd.npz) through qgd_fvsc_*"""
+    g = rc.load("gvp3d_bnd")
+    for i in range(len(g["nv"])):
+        nv = int(g["nv"][i])
+        mesh = device_mesh(*rc.boundary_face_mesh(g["pts"][i], nv, g["Sf"][i], g["Cf"][i], g["C"][i]))
+        dev = q.Device(mesh, fv_schemes={"fvsc": {"default": "GaussVolPoint"}})
+        for op, cell, bnd, want in bnd_ops(g, i):
+            vf = q.volField("f", np.array(cell, float), np.array(bnd, float))
+            got = fvsc.grad(dev, vf) if op.startswith("grad") else fvsc.div(dev, vf)
+            assert rel(got[1], want) <= TOL, (i, nv, op, got[1], want)
         dev.close()
 
 
