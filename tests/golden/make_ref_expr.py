@@ -20,6 +20,8 @@ Snippets evaluated (listing lines of /root/reference/docs/html/<file>_source.htm
              L232-317 / L391-475, macro dfdxbf L515-539, its invocations with psin = patch value + snGrad*bmvON/2 (calcGradfBF
              L780-806 scalar, L877-919 vector; calcDivfBF L583-609 vector, L683-725 tensor)
   gvp2d   GaussVolPointBase2D.C   L154-168 (c1..c4), L317-328 (apply)
+  gvp2d_bnd  the same file's boundary faces: v42 = 2 (Cf - C) L235-239, vertex choice and coefficients L244-288, psi2 = patch value +
+             snGrad*|v42|/2 L343-346, apply L352-359
   lsq     extendedFaceStencilCalculateWeights.C L64-153, extendedFaceStencilScalarGrad.C L66-72
   qhdface    QHDFoam/updateFields.H L36-73, QHDFoam/updateFluxes.H L33-38, QHDUEqn.H L36-43, QHDTEqn.H L65-66 (the face
              expressions qgd_qhd_fluxes returns), with the three fvsc::grad evaluated by the gvp3d text
@@ -64,7 +66,7 @@ def lines(name, a, b):
 # ----------------------------------------------------------------------------------------------------------------------
 # C++ statement syntax -> Python statement syntax (expressions are left alone)
 # ----------------------------------------------------------------------------------------------------------------------
-TYPES = r"(?:const\s+)?(?:scalar|label|vector|tensor|symmTensor|bool|surfaceScalarField|surfaceVectorField)\b\s*&?"
+TYPES = r"(?:const\s+)?(?:scalar|label|vector|tensor|symmTensor|bool|face|surfaceScalarField|surfaceVectorField)\b\s*&?"
 
 
 def strip_comments(src):
@@ -349,6 +351,14 @@ class Fld(list):
     def __rmul__(self, o): return Fld([o * a for a in self])
 
 
+class FieldWithPatches(list):
+    """a volScalarField as the 2-D listing uses it: f[celli] and f.boundaryField()[patchi]"""
+    def __init__(self, cells, patches):
+        super().__init__(cells)
+        self._patches = patches
+    def boundaryField(self): return self._patches
+
+
 class Obj:
     def __init__(self, **kw): self.__dict__.update(kw)
 
@@ -624,6 +634,64 @@ def gvp2d(nfaces=30, seed=12):
     return {k: np.array(v) for k, v in rec.items()}
 
 
+def gvp2d_bnd(nfaces=24, seed=18):
+    """one BOUNDARY quad (generic patch) of a cell of a one-cell-thick mesh (empty direction ie3); its vertices carry the patch value
+    (L0: boundary points average the adjacent real-patch faces, here one); snGrad = deltaCoeffs (patch value - cell value), patch-normal
+    delta (L0)"""
+    f2 = "GaussVolPointBase2D_8C_source.html"
+    v42_src = transpile(lines(f2, 235, 239))
+    coef_src = transpile(lines(f2, 244, 288))
+    psi_src = transpile(lines(f2, 343, 346))
+    apply_src = transpile(lines(f2, 352, 359))
+    rng = np.random.default_rng(seed)
+    rec = {k: [] for k in ("ie3", "pts", "Sf", "Cf", "C", "f", "fb", "c", "mv", "ip", "grad")}
+    for n in range(nfaces):
+        ie3 = n % 3
+        ie1, ie2 = (1, 2) if ie3 == 0 else ((0, 2) if ie3 == 1 else (0, 1))
+        e1, e2 = Vec(*np.eye(3)[ie1]), Vec(*np.eye(3)[ie2])
+
+        def place(a, b, h):
+            v = np.zeros(3); v[ie1], v[ie2], v[ie3] = a, b, h
+            return Vec(*v)
+        C4 = place(*(0.2 * rng.standard_normal(2)), 0.05)
+        a0, b0 = 0.5 + 0.2 * rng.standard_normal(), -0.5 + 0.2 * rng.standard_normal()
+        a1, b1 = 0.5 + 0.2 * rng.standard_normal(), 0.5 + 0.2 * rng.standard_normal()
+        order = [(a0, b0, 0.0), (a0, b0, 0.1), (a1, b1, 0.1), (a1, b1, 0.0)]
+        shift = n % 4
+        order = order[shift:] + order[:shift]
+        pts = [place(*o) for o in order]
+        S, cf = face_area_centre(pts)
+        if S @ (cf - C4.c) < 0:          # a boundary face points away from its cell
+            pts = pts[::-1]
+            S, cf = face_area_centre(pts)
+        Cf = Vec(*cf)
+        nf = S / np.sqrt((S * S).sum())
+        dc = 1.0 / abs(float(nf @ (cf - C4.c)))
+        fc, fb = float(rng.standard_normal()), float(rng.standard_normal())
+        patch = Obj(Cf=call(Fld([Cf])), start=lambda: 0)
+        mesh = Obj(C=call([C4]), points=call(pts), boundary=call([patch]), faces=call([list(range(4))]))
+        one = lambda: [[None]]  # noqa: E731
+        env = dict(mesh=mesh, patchId=0, iFace=0, ie3_=ie3, e1_=e1, e2_=e2, mag=mag, v42=[None], v13=[None], ic4e_=[[0]], ip3e_=one(),
+                   ip1e_=one(), mv42e_=one(), mv13e_=one(), cosa1e=one(), cosa2e=one(), sina1e=one(), sina2e=one(), dene=one(), c1e_=one(),
+                   c2e_=one(), c3e_=one(), c4e_=one())
+        exec(v42_src, env)
+        exec(coef_src, env)
+
+        class PatchField(Fld):
+            def snGrad(self): return Fld([dc * (fb - fc)])
+        g = [[[0.0, 0.0, 0.0]]]
+        env.update(f=FieldWithPatches([fc], [PatchField([fb])]), pF=[fb] * 4, psi2=[None], gradf=Obj(boundaryFieldRef=call(g)), ie1_=ie1,
+                   ie2_=ie2, dfdn=0.0, dfdt=0.0, mv42e_=[Fld(env["mv42e_"][0])])
+        exec(psi_src, env)
+        exec(apply_src, env)
+        rec["ie3"].append(ie3); rec["pts"].append(np.array([p.c for p in pts])); rec["Sf"].append(S); rec["Cf"].append(cf); rec["C"].append(C4.c)
+        rec["f"].append(fc); rec["fb"].append(fb)
+        rec["c"].append([env["c1e_"][0][0], env["c2e_"][0][0], env["c3e_"][0][0], env["c4e_"][0][0]])
+        rec["mv"].append([env["mv42e_"][0][0], env["mv13e_"][0][0]]); rec["ip"].append([env["ip1e_"][0][0], env["ip3e_"][0][0]])
+        rec["grad"].append(g[0][0])
+    return {k: np.array(v) for k, v in rec.items()}
+
+
 def lsq(nfaces=30, seed=13):
     """one internal face with a stencil of n cells (cells 0 and 1 are its owner and neighbour, placed symmetrically about the
     face centre so that the linear weight is 1/2 and sF = (iF[0] + iF[1])/2 needs no further L0 rule)"""
@@ -877,7 +945,7 @@ def species(nfaces=30, seed=16):
 def main():
     if not os.path.isdir(REF):
         sys.exit("make_ref_expr.py needs the reference listings under /root/reference (build container only)")
-    for name, fn in (("gvp3d", gvp3d), ("gvp3d_bnd", gvp3d_bnd), ("gvp2d", gvp2d), ("lsq", lsq), ("case2cell", case2cell), ("qhdface", qhdface), ("species", species)):
+    for name, fn in (("gvp3d", gvp3d), ("gvp3d_bnd", gvp3d_bnd), ("gvp2d", gvp2d), ("gvp2d_bnd", gvp2d_bnd), ("lsq", lsq), ("case2cell", case2cell), ("qhdface", qhdface), ("species", species)):
         data = fn()
         path = os.path.join(HERE, f"ref_expr_{name}.npz")
         np.savez_compressed(path, **data)

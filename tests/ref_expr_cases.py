@@ -33,20 +33,25 @@ def two_cell_mesh(pts, nv, Sf, Cf, C, empty_normals=()):
     return prim, geom
 
 
-def boundary_face_mesh(pts, nv, Sf, Cf, C):
+def boundary_face_mesh(pts, nv, Sf, Cf, C, back_axis=0, empty_normals=()):
     """cell 0 (centre C) with ONE boundary face on a generic patch: face 1, vertices 0..nv-1, area vector / centre prescribed; an
-    internal quad (face 0) a unit length behind the cell connects it to cell 1 and shares no vertex with the boundary face, so the
-    boundary face's vertices are boundary points of that face alone"""
+    internal quad (face 0) a unit length behind the cell along -e_back_axis connects it to cell 1 and shares no vertex with the
+    boundary face, so the boundary face's vertices are boundary points of that face alone.  One `empty` face per entry of
+    empty_normals (owned by cell 0, on the back quad's vertices; its normal only sets the mesh's empty directions)."""
     pts = np.asarray(pts, float)[:nv]
     C = np.asarray(C, float)
-    back = C + np.array([-1.0, 0.0, 0.0])
-    quad = [back + np.array([0.0, a, b]) for a, b in ((-0.5, -0.5), (-0.5, 0.5), (0.5, 0.5), (0.5, -0.5))]
-    faces = [list(range(nv, nv + 4)), list(range(nv))]
+    back = C - unit(back_axis)
+    u, v = unit((back_axis + 1) % 3), unit((back_axis + 2) % 3)
+    quad = [back + a * u + b * v for a, b in ((-0.5, -0.5), (-0.5, 0.5), (0.5, 0.5), (0.5, -0.5))]
+    faces = [list(range(nv, nv + 4)), list(range(nv))] + [[nv, nv + 1, nv + 2] for _ in empty_normals]
+    n_e = len(empty_normals)
     prim = dict(points=np.concatenate([pts, np.array(quad)]).reshape(-1), faceOffsets=np.cumsum([0] + [len(f) for f in faces]).astype(np.int32),
-                facePoints=np.concatenate(faces).astype(np.int32), owner=np.array([0, 0], np.int32), neighbour=np.array([1], np.int32),
-                nCells=2, patchStart=np.array([1], np.int32), patchSize=np.array([1], np.int32), patchType=np.array([GENERIC], np.int32))
-    geom = dict(Sf=np.array([[-1.0, 0.0, 0.0], np.asarray(Sf, float)]), Cf=np.array([back, np.asarray(Cf, float)]),
-                C=np.array([C, C + np.array([-2.0, 0.0, 0.0])]), V=np.ones(2))
+                facePoints=np.concatenate(faces).astype(np.int32), owner=np.zeros(len(faces), np.int32), neighbour=np.array([1], np.int32),
+                nCells=2, patchStart=np.array([1, 2][:1 + (n_e > 0)], np.int32), patchSize=np.array([1, n_e][:1 + (n_e > 0)], np.int32),
+                patchType=np.array([GENERIC, EMPTY][:1 + (n_e > 0)], np.int32))
+    geom = dict(Sf=np.array([-unit(back_axis), np.asarray(Sf, float)] + [np.asarray(n, float) for n in empty_normals]),
+                Cf=np.array([back, np.asarray(Cf, float)] + [C + 0.1 * np.asarray(n, float) for n in empty_normals]),
+                C=np.array([C, C - 2.0 * unit(back_axis)]), V=np.ones(2))
     return prim, geom
 
 

@@ -75,6 +75,22 @@ def test_gaussvolpoint_3d_boundary_faces():
         om.close()
 
 
+def test_gaussvolpoint_2d_boundary_faces():
+    """GaussVolPointBase2D.C boundary faces: v42 = 2 (Cf - C), the two vertices above the cell centre, c1e..c4e, psi2 = patch value +
+    snGrad |v42|/2, the apply of L352-359"""
+    g = rc.load("gvp2d_bnd")
+    for i in range(len(g["ie3"])):
+        ie3 = int(g["ie3"][i])
+        prim, geom = rc.boundary_face_mesh(g["pts"][i], 4, g["Sf"][i], g["Cf"][i], g["C"][i], back_axis=(ie3 + 1) % 3, empty_normals=[rc.unit(ie3)])
+        om = oracle_mesh(prim, geom)
+        info = om.info()
+        assert info["nGeometricD"] == 2 and info["geometricD"][ie3] == -1
+        st, gs = om.fvsc("GaussVolPoint", "grad_s", np.array([g["f"][i], 0.3]), np.array([g["fb"][i], 0.0]))
+        assert st == 0
+        assert rel(gs[1], g["grad"][i]) <= TOL, (i, ie3, gs[1], g["grad"][i])
+        om.close()
+
+
 def test_gaussvolpoint_2d_coefficients_and_apply():
     g = rc.load("gvp2d")
     for i in range(len(g["ie3"])):

@@ -65,6 +65,19 @@ def test_gaussvolpoint_2d_on_the_device():
         dev.close()
 
 
+def test_gaussvolpoint_2d_boundary_faces_on_the_device():
+    g = rc.load("gvp2d_bnd")
+    for i in range(len(g["ie3"])):
+        ie3 = int(g["ie3"][i])
+        mesh = device_mesh(*rc.boundary_face_mesh(g["pts"][i], 4, g["Sf"][i], g["Cf"][i], g["C"][i], back_axis=(ie3 + 1) % 3,
+                                                  empty_normals=[rc.unit(ie3)]))
+        assert mesh.nGeometricD == 2
+        dev = q.Device(mesh, fv_schemes={"fvsc": {"default": "GaussVolPoint"}})
+        gs = fvsc.grad(dev, q.volField("f", np.array([g["f"][i], 0.3]), np.array([g["fb"][i], 0.0])))
+        assert rel(gs[1], g["grad"][i]) <= TOL, (i, ie3, gs[1], g["grad"][i])
+        dev.close()
+
+
 def test_leastsquares_on_the_device():
     g = rc.load("lsq")
     for i in range(len(g["n"])):
