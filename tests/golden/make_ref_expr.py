@@ -22,6 +22,7 @@ Snippets evaluated (listing lines of /root/reference/docs/html/<file>_source.htm
   gvp2d   GaussVolPointBase2D.C   L154-168 (c1..c4), L317-328 (apply)
   gvp2d_bnd  the same file's boundary faces: v42 = 2 (Cf - C) L235-239, vertex choice and coefficients L244-288, psi2 = patch value +
              snGrad*|v42|/2 L343-346, apply L352-359
+  reduced    reducedFaceNormalStencil.C L71, L85, L92, L105 (nf * snGrad, nf & snGrad: operand order and tensor layout)
   lsq     extendedFaceStencilCalculateWeights.C L64-153, extendedFaceStencilScalarGrad.C L66-72
   qhdface    QHDFoam/updateFields.H L36-73, QHDFoam/updateFluxes.H L33-38, QHDUEqn.H L36-43, QHDTEqn.H L65-66 (the face
              expressions qgd_qhd_fluxes returns), with the three fvsc::grad evaluated by the gvp3d text
@@ -114,6 +115,9 @@ def statement(st):
     m = re.match(r"^symmTensor\s+(\w+)\((.*)\)$", st)
     if m:
         return [f"{m.group(1)} = symmTensor({expr(m.group(2))})"]
+    m = re.match(r"^tmp<\s*\w+\s*>\s+(\w+)\s*\((.*)\)$", st)                          # tmp<surfaceVectorField> t(expr)
+    if m:
+        return [f"{m.group(1)} = {expr(m.group(2))}"]
     m = re.match(r"^List<\s*List<\s*\w+\s*>\s*>\s*(\w+)\s*\((.*)\)$", st)          # List<List<scalar> > psin (n)
     if m:
         return [f"{m.group(1)} = RList([None]*({expr(m.group(2))}))"]
@@ -692,6 +696,40 @@ def gvp2d_bnd(nfaces=24, seed=18):
     return {k: np.array(v) for k, v in rec.items()}
 
 
+def reduced(nfaces=24, seed=19):
+    """the four operators of the reduced stencil on one internal face: nf (x) snGrad and nf . snGrad as the listing writes them;
+    fvc::snGrad is OpenFOAM's uncorrected (psi_N - psi_O) nonOrthDeltaCoeffs (L0), nf = Sf/|Sf| [fvscStencil.C]"""
+    f = "reducedFaceNormalStencil_8C_source.html"
+    src = {"grad_s": (transpile(lines(f, 71, 71)), "vF", "tgradIF"), "grad_v": (transpile(lines(f, 85, 85)), "iVF", "tgradIVF"),
+           "div_v": (transpile(lines(f, 92, 92)), "iVF", "tdivIVF"), "div_t": (transpile(lines(f, 105, 105)), "iTF", "tdivITF")}
+    rng = np.random.default_rng(seed)
+    rec = {k: [] for k in ("nv", "pts", "Sf", "Cf", "C", "cell_s", "cell_v", "cell_t", "grad_s", "grad_v", "div_v", "div_t")}
+    for n in range(nfaces):
+        nv = 4 if n % 2 == 0 else 3
+        pts, own, nei = skew_face(rng, nv)
+        S, cf = face_area_centre(pts)
+        nf = Vec(*(S / np.sqrt((S * S).sum())))
+        d = nei - own
+        dcoef = 1.0 / max(nf & d, 0.05 * mag(d))            # surfaceInterpolation::nonOrthDeltaCoeffs (L0)
+        cs = [float(rng.standard_normal()) for _ in range(2)]
+        cv = [rnd_vec(rng), rnd_vec(rng)]
+        ct = [Tensor(rng.standard_normal(9)), Tensor(rng.standard_normal(9))]
+        vals = {"vF": cs, "iVF": cv, "iTF": ct}
+        out = {}
+        for op, (code, arg, res) in src.items():
+            fld = vals[arg]
+            env = dict(nf_=nf, fvc=Obj(snGrad=lambda x: (x[1] - x[0]) * dcoef), **{arg: fld})
+            exec(code, env)
+            r = env[res]
+            out[op] = r.c if isinstance(r, Vec) else (r.m.reshape(9) if isinstance(r, Tensor) else r)
+        rec["nv"].append(nv); rec["pts"].append(np.array([p.c for p in pts] + ([[0, 0, 0]] if nv == 3 else []))); rec["Sf"].append(S)
+        rec["Cf"].append(cf); rec["C"].append(np.array([own.c, nei.c])); rec["cell_s"].append(cs); rec["cell_v"].append(np.array([v.c for v in cv]))
+        rec["cell_t"].append(np.array([t.m.reshape(9) for t in ct]))
+        for op in src:
+            rec[op].append(np.array(out[op], dtype=float))
+    return {k: np.array(v) for k, v in rec.items()}
+
+
 def lsq(nfaces=30, seed=13):
     """one internal face with a stencil of n cells (cells 0 and 1 are its owner and neighbour, placed symmetrically about the
     face centre so that the linear weight is 1/2 and sF = (iF[0] + iF[1])/2 needs no further L0 rule)"""
@@ -945,7 +983,7 @@ def species(nfaces=30, seed=16):
 def main():
     if not os.path.isdir(REF):
         sys.exit("make_ref_expr.py needs the reference listings under /root/reference (build container only)")
-    for name, fn in (("gvp3d", gvp3d), ("gvp3d_bnd", gvp3d_bnd), ("gvp2d", gvp2d), ("gvp2d_bnd", gvp2d_bnd), ("lsq", lsq), ("case2cell", case2cell), ("qhdface", qhdface), ("species", species)):
+    for name, fn in (("gvp3d", gvp3d), ("gvp3d_bnd", gvp3d_bnd), ("gvp2d", gvp2d), ("gvp2d_bnd", gvp2d_bnd), ("reduced", reduced), ("lsq", lsq), ("case2cell", case2cell), ("qhdface", qhdface), ("species", species)):
         data = fn()
         path = os.path.join(HERE, f"ref_expr_{name}.npz")
         np.savez_compressed(path, **data)

@@ -75,6 +75,20 @@ def test_gaussvolpoint_3d_boundary_faces():
         om.close()
 
 
+def test_reduced_stencil_operators():
+    """reducedFaceNormalStencil.C L71-105: nf * snGrad (outer product, layout d_i psi_j) and nf & snGrad for the four operators"""
+    g = rc.load("reduced")
+    for i in range(len(g["nv"])):
+        nv = int(g["nv"][i])
+        prim, geom = rc.two_cell_mesh(g["pts"][i], nv, g["Sf"][i], g["Cf"][i], g["C"][i])
+        om = oracle_mesh(prim, geom)
+        for op, cell in (("grad_s", g["cell_s"][i]), ("grad_v", g["cell_v"][i]), ("div_v", g["cell_v"][i]), ("div_t", g["cell_t"][i])):
+            st, got = om.fvsc("reduced", op, cell, np.zeros(0))
+            assert st == 0
+            assert rel(got[0], g[op][i]) <= TOL, (i, nv, op, got[0], g[op][i])
+        om.close()
+
+
 def test_gaussvolpoint_2d_boundary_faces():
     """GaussVolPointBase2D.C boundary faces: v42 = 2 (Cf - C), the two vertices above the cell centre, c1e..c4e, psi2 = patch value +
     snGrad |v42|/2, the apply of L352-359"""

@@ -78,6 +78,19 @@ def test_gaussvolpoint_2d_boundary_faces_on_the_device():
         dev.close()
 
 
+def test_reduced_stencil_on_the_device():
+    g = rc.load("reduced")
+    for i in range(len(g["nv"])):
+        nv = int(g["nv"][i])
+        mesh = device_mesh(*rc.two_cell_mesh(g["pts"][i], nv, g["Sf"][i], g["Cf"][i], g["C"][i]))
+        dev = q.Device(mesh, fv_schemes={"fvsc": {"default": "reduced"}})
+        for op, cell, nb in (("grad_s", g["cell_s"][i], ()), ("grad_v", g["cell_v"][i], (3,)), ("div_v", g["cell_v"][i], (3,)), ("div_t", g["cell_t"][i], (9,))):
+            vf = q.volField("f", cell, np.zeros((0,) + nb))
+            got = fvsc.grad(dev, vf) if op.startswith("grad") else fvsc.div(dev, vf)
+            assert rel(got[0], g[op][i]) <= TOL, (i, nv, op)
+        dev.close()
+
+
 def test_leastsquares_on_the_device():
     g = rc.load("lsq")
     for i in range(len(g["n"])):
