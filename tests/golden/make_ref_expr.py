@@ -115,6 +115,12 @@ def statement(st):
     m = re.match(r"^symmTensor\s+(\w+)\((.*)\)$", st)
     if m:
         return [f"{m.group(1)} = symmTensor({expr(m.group(2))})"]
+    m = re.match(r"^fv(?:Scalar|Vector)Matrix\s+(\w+)\s*\((.*)\)$", st)                # fvScalarMatrix EEqn(expr)
+    if m:
+        return [f"{m.group(1)} = {expr(m.group(2))}"]
+    m = re.match(r"^(\w+)\.ref\(\)\s*=(?!=)\s*(.*)$", st)                              # U.ref() = expr: values into the existing field
+    if m:
+        return [f"{m.group(1)}.assign({expr(m.group(2))})"]
     m = re.match(r"^tmp<\s*\w+\s*>\s+(\w+)\s*\((.*)\)$", st)                          # tmp<surfaceVectorField> t(expr)
     if m:
         return [f"{m.group(1)} = {expr(m.group(2))}"]
@@ -315,7 +321,12 @@ class symmTensor:
 
 
 def sqr(v): return symmTensor(v.c[0] * v.c[0], v.c[0] * v.c[1], v.c[0] * v.c[2], v.c[1] * v.c[1], v.c[1] * v.c[2], v.c[2] * v.c[2])
-def magSqr(v): return float(v.c[0] * v.c[0] + v.c[1] * v.c[1] + v.c[2] * v.c[2])
+def magSqr(v):
+    if isinstance(v, Nil):
+        return v
+    if isinstance(v, list):
+        return type(v)([magSqr(a) for a in v])
+    return float(v.c[0] * v.c[0] + v.c[1] * v.c[1] + v.c[2] * v.c[2])
 def mag(v):
     if isinstance(v, Fld):
         return Fld([mag(a) for a in v])
@@ -782,6 +793,58 @@ class Pair:
     def __truediv__(self, other): return Pair(self.o / other.o, self.n / other.n)
 
 
+class CF(list):
+    """a cell field with its old-time values: elementwise arithmetic; assignment keeps the object (OpenFOAM assigns values)"""
+    def __init__(self, vals, old=None):
+        super().__init__(vals)
+        self.old = list(old) if old is not None else list(vals)
+    def _z(self, o, f): return CF([f(a, b) for a, b in zip(self, o)]) if isinstance(o, list) else CF([f(a, o) for a in self])
+    def __add__(self, o): return self._z(o, lambda a, b: a + b)
+    def __sub__(self, o): return self._z(o, lambda a, b: a - b)
+    def __mul__(self, o): return self._z(o, lambda a, b: a * b)
+    def __rmul__(self, o): return CF([o * a for a in self])
+    def __truediv__(self, o): return self._z(o, lambda a, b: a / b)
+    def __call__(self): return self
+    def assign(self, o): self[:] = list(o)
+    def correctBoundaryConditions(self): pass
+    def boundaryFieldRef(self): return Nil()
+    def boundaryField(self): return Nil()
+
+
+class Nil:
+    """the (absent) boundary of the two-cell mesh: absorbs whatever the listing does to patch fields"""
+    def __eq__(self, o): return None
+    def __mul__(self, o): return self
+    __rmul__ = __add__ = __radd__ = __mul__
+    __hash__ = None
+
+
+class Mat:
+    """a diagonal fvMatrix: a psi = b per cell (Euler ddt terms only -- the explicit branch has no other implicit operator)"""
+    def __init__(self, psi, a, b): self.psi, self.a, self.b = psi, list(a), list(b)
+    def __add__(self, f): return Mat(self.psi, self.a, [b - x for b, x in zip(self.b, f)])      # M + F = 0  ->  a psi = b - F
+    def __sub__(self, f): return Mat(self.psi, self.a, [b + x for b, x in zip(self.b, f)])
+    def __eq__(self, s): return Mat(self.psi, self.a, [b + x for b, x in zip(self.b, s)])       # M == S   ->  a psi = b + S
+    __hash__ = None
+    def solve(self): self.psi.assign([b / a for a, b in zip(self.a, self.b)])
+
+
+def fv_emulation(dt, V):
+    """fvm::ddt / fvc::ddt (Euler) and fvc::div (= surfaceIntegrate of a face flux) on the two-cell mesh: face 0 points from cell 0
+    to cell 1 (L0 semantics; the equations themselves come from the listing text)"""
+    fvm = Obj(ddt=lambda *a: (Mat(a[0], [1.0 / dt] * 2, [o / dt for o in a[0].old]) if len(a) == 1 else
+                              Mat(a[1], [r / dt for r in a[0]], [ro * o / dt for ro, o in zip(a[0].old, a[1].old)])))
+    fvc = Obj(ddt=lambda *a: (CF([(x - o) / dt for x, o in zip(a[0], a[0].old)]) if len(a) == 1 else
+                              CF([(r * x - ro * o) / dt for r, x, ro, o in zip(a[0], a[1], a[0].old, a[1].old)])),
+              div=lambda phi: CF([phi / V[0], -phi / V[1]]))
+    return fvm, fvc
+
+
+def field_assignments(src, names):
+    """`e = expr;` on a field assigns values into the existing object (its old-time level stays): rewrite those statements"""
+    return re.sub(r"^(\s*)(%s)\s*=(?!=)\s*(.*)$" % "|".join(names), r"\1\2.assign(\3)", src, flags=re.M)
+
+
 def case2cell(nfaces=40, seed=14):
     """A whole QGDFoam flux assembly on one internal face between two cells (3-D, GaussVolPoint): updateFields.H,
     the four fvsc::grad (coefficients + dfdxif from the 3-D listing), updateFluxes.H, constScPrModel1, hQGDf -- every line from
@@ -793,8 +856,14 @@ def case2cell(nfaces=40, seed=14):
     tau_src = transpile([cs[103].replace("this->", ""), cs[104].replace("this->", "")])
     mu_src = transpile([cs[i] for i in range(108, 115)])
     h_src = transpile(lines("QGDCoeffs_8C_source.html", 305, 307))
+    # the three equations of the explicit step [QGDRhoEqn.H L40-47, QGDUEqn.H L36-89, QGDEEqn.H L37-76]
+    eq_src = [transpile(lines("QGDRhoEqn_8H_source.html", 40, 47)),
+              field_assignments(transpile(lines("QGDUEqn_8H_source.html", 36, 89)), ("rhoU", "U")),
+              field_assignments(transpile(lines("QGDEEqn_8H_source.html", 37, 76)), ("rhoE", "e"))]
+    dt = 1e-3
     rng = np.random.default_rng(seed)
-    names = ("nv", "pts", "Sf", "Cf", "C", "V", "U", "T", "p", "R", "Cv", "mu", "Pr", "ScQGD", "PrQGD", "alphaQGD",
+    names = ("nv", "pts", "Sf", "Cf", "C", "V", "U", "T", "p", "R", "Cv", "mu", "Pr", "ScQGD", "PrQGD", "alphaQGD", "deltaT", "rho1", "U1", "e1",
+             "rhoU1", "rhoE1",
              "w", "hQGDf", "rhof", "Uf", "rhoUf", "UrhoUf", "pf", "cf", "gammaf", "Hf", "alphauf", "muf", "tauQGDf",
              "gradUf", "gradef", "gradRhof", "gradPf", "phiwStar", "phiJm", "phi", "phiJmU", "phiP", "phiPi", "phiJmH", "phiQ", "phiPiU",
              "muQGD", "alphauQGD", "tauQGD", "hQGD")
@@ -864,10 +933,22 @@ def case2cell(nfaces=40, seed=14):
         exec(flux_src, env2)
         g = env2
 
+        # one explicit step of the three equations with those fluxes (zero sources)
+        fvm, fvc = fv_emulation(dt, [1.0, 1.0])
+        zero_s, zero_v = CF([0.0, 0.0]), CF([Vec(0, 0, 0), Vec(0, 0, 0)])
+        eq = dict(fvm=fvm, fvc=fvc, solve=lambda M: M.solve(), implicitDiffusion=False, magSqr=magSqr,
+                  rho=CF(rho), U=CF(U), e=CF(e), rhoU=CF([rhoU.o, rhoU.n]), rhoE=CF([rhoE.o, rhoE.n]),
+                  rhoSu=zero_s, rhoUSu=zero_v, rhoESu=zero_s, phiSigmaDotU=0.0,
+                  **{k: g[k] for k in ("phiJm", "phiJmU", "phiP", "phiPi", "phiJmH", "phiQ", "phiPiU")})
+        for code in eq_src:
+            exec(code, eq)
+
         def val(x):
             return x.c if isinstance(x, Vec) else (x.m.reshape(9) if isinstance(x, Tensor) else x)
         out = dict(nv=nv, pts=np.array([q.c for q in pts] + ([[0, 0, 0]] if nv == 3 else [])), Sf=S.c, Cf=Cf.c, C=np.array([own.c, nei.c]),
-                   V=[1.0, 1.0], U=np.array([u.c for u in U]), T=T, p=p, R=R, Cv=Cv, mu=mu0, Pr=Pr, ScQGD=Sc, PrQGD=PrQ, alphaQGD=aQ,
+                   V=[1.0, 1.0], U=np.array([u.c for u in U]), T=T, p=p, R=R, Cv=Cv, mu=mu0, Pr=Pr, ScQGD=Sc, PrQGD=PrQ, alphaQGD=aQ, deltaT=dt,
+                   rho1=list(eq["rho"]), U1=np.array([u.c for u in eq["U"]]), e1=list(eq["e"]), rhoU1=np.array([u.c for u in eq["rhoU"]]),
+                   rhoE1=list(eq["rhoE"]),
                    w=w, hQGDf=hf, cf=env["cf"], tauQGDf=tauf, phiwStar=g["phiw"], muQGD=muQGD, alphauQGD=alphauQGD,
                    tauQGD=[tauc.o, tauc.n], hQGD=[hcell, hcell])
         for k in ("rhof", "Uf", "rhoUf", "UrhoUf", "pf", "gammaf", "Hf", "alphauf", "muf", "gradUf", "gradef", "gradRhof", "gradPf",

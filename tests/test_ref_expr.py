@@ -144,9 +144,12 @@ FACE_FIELDS = ("rhof", "Uf", "pf", "cf", "Hf", "alphauf", "muf", "tauQGDf", "hQG
                "phiwStar", "phiJm", "phi", "phiJmU", "phiP", "phiPi", "phiJmH", "phiQ", "phiPiU")
 
 
+STEP_FIELDS = ["rho", "U", "e", "rhoU", "rhoE"]
+
+
 def case_options(g, i):
     return q.default_options(stencil="GaussVolPoint", R=float(g["R"][i]), Cv=float(g["Cv"][i]), mu=float(g["mu"][i]), Pr=float(g["Pr"][i]),
-                             ScQGD=float(g["ScQGD"][i]), PrQGD=float(g["PrQGD"][i]), alphaQGD=float(g["alphaQGD"][i]), deltaT=1e-6)
+                             ScQGD=float(g["ScQGD"][i]), PrQGD=float(g["PrQGD"][i]), alphaQGD=float(g["alphaQGD"][i]), deltaT=float(g["deltaT"][i]))
 
 
 def test_flux_assembly_of_one_face():
@@ -163,6 +166,11 @@ def test_flux_assembly_of_one_face():
             assert rel(oc.field(f)[0], g[f][i]) <= TOL, (i, nv, f, oc.field(f)[0], g[f][i])
         for f in ("muQGD", "alphauQGD", "tauQGD", "hQGD"):
             assert rel(oc.field(f), g[f][i]) <= TOL, (i, f)
+        # ... and one explicit step: QGDRhoEqn.H L40-47, QGDUEqn.H L36-89, QGDEEqn.H L37-76 executed from the listing text (Euler ddt and
+        # fvc::div = surfaceIntegrate emulated, L0) with the fluxes above
+        oc.step(1)
+        for f in STEP_FIELDS:
+            assert rel(oc.field(f), g[f + "1"][i]) <= TOL, (i, nv, f, oc.field(f), g[f + "1"][i])
         oc.close(); om.close()
 
 

@@ -8,7 +8,7 @@ import qgdsolver_amd as q
 from qgdsolver_amd import fvsc
 
 import ref_expr_cases as rc
-from test_ref_expr import FACE_FIELDS, QHD_FIELDS, bnd_ops, case_options, qhd_inputs, rel
+from test_ref_expr import FACE_FIELDS, QHD_FIELDS, STEP_FIELDS, bnd_ops, case_options, qhd_inputs, rel
 
 pytestmark = pytest.mark.gpu
 
@@ -123,6 +123,10 @@ def test_flux_assembly_of_one_face_on_the_device():
             assert rel(case.field(f)[0], g[f][i]) <= TOL, (i, nv, f, case.field(f)[0], g[f][i])
         for f in ("muQGD", "alphauQGD", "tauQGD", "hQGD"):
             assert rel(case.field(f), g[f][i]) <= TOL, (i, f)
+        # one explicit step against QGDRhoEqn.H / QGDUEqn.H / QGDEEqn.H executed from the listing text
+        case.step(1)
+        for f in STEP_FIELDS:
+            assert rel(case.field(f), g[f + "1"][i]) <= TOL, (i, nv, f, case.field(f), g[f + "1"][i])
         case.close(); dev.close()
 
 
