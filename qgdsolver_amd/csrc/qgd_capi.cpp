@@ -576,7 +576,7 @@ int qgd_device_create(qgd_mesh_t mh, int deviceId, qgd_device_t* out) {
         v.pcSlice = up(s.pcSlice); v.pcCount = up(s.pcCount); v.pcCell = up(s.pcCell); v.pcW = up(s.pcW);
         v.nBP = (int32_t)s.bpPoint.size();
         v.bpPoint = up(s.bpPoint); v.bpOff = up(s.bpOff); v.bpFace = up(s.bpFace); v.bpW = up(s.bpW);
-        v.cfSlice = up(s.cfSlice); v.cfCount = up(s.cfCount); v.cfItem = up(s.cfItem);
+        v.cfSlice = up(s.cfSlice); v.cfCount = up(s.cfCount); v.cfItem = up(s.cfItem); v.cfNbr = up(s.cfNbr);
         v.fpos = up(s.fpos); v.cfPos = up(s.cfPos);
         v.V = up(s.V); v.hQGD = up(s.hQGD); v.ghost = up(s.ghost);
         v.bPatch = up(s.bPatch); v.hQGDb = up(s.hQGDb);

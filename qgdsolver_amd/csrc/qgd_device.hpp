@@ -44,6 +44,7 @@ struct MeshView {
     const int32_t* cfSlice; const uint8_t* cfCount; const int32_t* cfItem;                     // sliced ELL (64-cell slices)
     const int32_t* fpos;     // nIF: storage position of an internal face's net fluxes (slot-major, qgd_setup.hpp)
     const int32_t* cfPos;    // cfItem with positions instead of labels: gather list of the cell kernel
+    const int32_t* cfNbr;    // cfItem's neighbour cells (-1: boundary face): gather list of the matrix products
     // face tiles of the LDS-staged 3-D GaussVolPoint kernel (qgd_setup.hpp FaceTiles); tileOff == nullptr: gather kernel
     const int32_t* tileOff; const int32_t* tileCells; const int32_t* tileVerts;
     const uint32_t* locC; const uint2* locV;

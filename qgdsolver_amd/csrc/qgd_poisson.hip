@@ -100,12 +100,21 @@ __global__ __launch_bounds__(PB) void applyKernel(const MeshView m, const double
         const size_t base = (size_t)m.cfSlice[c >> 6] * 64 + (c & 63);
         const double xc = x[c];
         double s = diag[c] * xc;
-        for (int i = 0; i < n; ++i) {
-            const int it = m.cfItem[base + (size_t)i * 64];
-            const int f = it >= 0 ? it : ~it;
-            if (f >= m.nIF) continue;
-            const int nb = it >= 0 ? m.nei[f] : m.own[f];
-            s -= a[f] * x[nb];
+        // eight entries per pass, their face labels, neighbour cells, coefficients and x values in flight before the ordered sum
+        for (int i0 = 0; i0 < n; i0 += 8) {
+            int nbv[8];
+            double av[8], xv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const bool on = i0 + q < n;
+                const int it = on ? m.cfItem[base + (size_t)(i0 + q) * 64] : 0;
+                nbv[q] = on ? m.cfNbr[base + (size_t)(i0 + q) * 64] : -1;
+                const int f = it >= 0 ? it : ~it;
+                av[q] = nbv[q] >= 0 ? a[f] : 0.0;
+                xv[q] = nbv[q] >= 0 ? x[nbv[q]] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) if (nbv[q] >= 0) s -= av[q] * xv[q];
         }
         y[c] = s;
         xy = xc * s;

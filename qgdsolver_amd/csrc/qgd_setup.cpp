@@ -63,7 +63,7 @@ int64_t StaticData::bytes() const {
     auto sz = [](auto& v) { return (int64_t)(v.size() * sizeof(v[0])); };
     int64_t b = sz(own) + sz(nei) + sz(verts) + sz(fkind) + sz(magSf) + sz(w) + sz(hf) + sz(dn) + sz(X) + sz(Cc) + sz(bN) +
                 sz(bmvON) + sz(ip13) + sz(c2d) + sz(lsqSlice) + sz(lsqCnt) + sz(lsqCell) + sz(lsqGx) + sz(lsqGy) + sz(lsqGz) + sz(lsqDeg) + sz(lsqBndZero) +
-                sz(pcSlice) + sz(pcCount) + sz(pcCell) + sz(pcW) + sz(bpPoint) + sz(bpOff) + sz(bpFace) + sz(bpW) + sz(cfSlice) + sz(cfCount) + sz(cfItem) + sz(fpos) + sz(cfPos) +
+                sz(pcSlice) + sz(pcCount) + sz(pcCell) + sz(pcW) + sz(bpPoint) + sz(bpOff) + sz(bpFace) + sz(bpW) + sz(cfSlice) + sz(cfCount) + sz(cfItem) + sz(cfNbr) + sz(fpos) + sz(cfPos) +
                 sz(V) + sz(hQGD) + sz(ghost) + sz(bPatch) + sz(hQGDb);
     for (int k = 0; k < 3; ++k) b += sz(Sf[k]);
     return b;
@@ -368,6 +368,19 @@ StaticData buildStaticData(const HostMesh& m) {
             }
         }
         toSlicedEll(cfOff, nC, cfItemCsr, nullptr, s.cfSlice, s.cfCount, s.cfItem, nullptr, 0);
+        {
+            // the cell on the other side of each entry (-1: a boundary face): the matrix products of the implicit solves and of the
+            // pressure equation gather x[cfNbr] and a[face] side by side instead of following face -> owner/neighbour -> x
+            std::vector<int32_t> nbrCsr(cfItemCsr.size());
+#pragma omp parallel for schedule(static)
+            for (int64_t k = 0; k < (int64_t)cfItemCsr.size(); ++k) {
+                const int32_t it = cfItemCsr[k], f = it >= 0 ? it : ~it;
+                nbrCsr[k] = f >= nIF ? -1 : (it >= 0 ? m.neighbour[f] : m.owner[f]);
+            }
+            std::vector<int32_t> slice2;
+            std::vector<uint8_t> count2;
+            toSlicedEll(cfOff, nC, nbrCsr, nullptr, slice2, count2, s.cfNbr, nullptr, -1);
+        }
         // slot-major storage positions of the internal-face fluxes (see qgd_setup.hpp)
         {
             s.fpos.assign((size_t)nIF, 0);

@@ -72,6 +72,7 @@ struct StaticData {
     std::vector<int32_t> cfSlice; // nSlices+1
     std::vector<uint8_t> cfCount; // nC
     std::vector<int32_t> cfItem;
+    std::vector<int32_t> cfNbr;   // like cfItem: the cell across the face, -1 for boundary faces
     // Storage order of the net face fluxes (CaseView::flux).  Internal face f keeps its five fluxes at position
     // fpos[f] of each SoA plane: faces are bucketed by their rank among the faces their owner owns (bucket 0 = every
     // cell's first owned face, in cell order, then bucket 1, ...), so that consecutive cells find their own faces AND
