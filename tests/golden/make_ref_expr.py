@@ -23,6 +23,8 @@ Snippets evaluated (listing lines of /root/reference/docs/html/<file>_source.htm
   gvp2d_bnd  the same file's boundary faces: v42 = 2 (Cf - C) L235-239, vertex choice and coefficients L244-288, psi2 = patch value +
              snGrad*|v42|/2 L343-346, apply L352-359
   reduced    reducedFaceNormalStencil.C L71, L85, L92, L105 (nf * snGrad, nf & snGrad: operand order and tensor layout)
+  lsq_bnd    extendedFaceStencilScalarGrad.C L86-109: boundary faces of the leastSquares gradient (nf * snGrad on ordinary patches,
+             the zero of L55 left on empty / wedge / coupled / symmetry / symmetryPlane patches)
   lsq     extendedFaceStencilCalculateWeights.C L64-153, extendedFaceStencilScalarGrad.C L66-72
   qhdface    QHDFoam/updateFields.H L36-73, QHDFoam/updateFluxes.H L33-38, QHDUEqn.H L36-43, QHDTEqn.H L65-66 (the face
              expressions qgd_qhd_fluxes returns), with the three fvsc::grad evaluated by the gvp3d text
@@ -67,7 +69,7 @@ def lines(name, a, b):
 # ----------------------------------------------------------------------------------------------------------------------
 # C++ statement syntax -> Python statement syntax (expressions are left alone)
 # ----------------------------------------------------------------------------------------------------------------------
-TYPES = r"(?:const\s+)?(?:scalar|label|vector|tensor|symmTensor|bool|face|surfaceScalarField|surfaceVectorField)\b\s*&?"
+TYPES = r"(?:const\s+)?(?:scalar|label|vector|tensor|symmTensor|bool|face|fvPatch|surfaceScalarField|surfaceVectorField)\b\s*&?"
 
 
 def strip_comments(src):
@@ -99,6 +101,7 @@ def expr(e):
         a, b = split_top(q[1], ":")
         return f"({expr(a)}) if ({expr(q[0])}) else ({expr(b)})"
     e = re.sub(r"refCast\s*<[^(]*\(", "refCast(", e)   # template arguments of a cast are not part of any arithmetic
+    e = re.sub(r"isA<\s*(\w+)\s*>\s*\(", r'isA("\1", ', e)   # isA<emptyFvPatch>(fvp) -> isA("emptyFvPatch", fvp)
     e = e.replace("::", ".").replace("->", ".")
     e = re.sub(r"!(?!=)", " not ", e)
     e = e.replace("&&", " and ").replace("||", " or ")
@@ -741,6 +744,45 @@ def reduced(nfaces=24, seed=19):
     return {k: np.array(v) for k, v in rec.items()}
 
 
+def lsq_bnd(nfaces=16, seed=20):
+    """one boundary quad of a cell of a one-cell-thick mesh under the leastSquares gradient: ordinary patch -> nf * snGrad, symmetryPlane
+    patch -> the initial zero [ScalarGrad.C L55, L86-109]"""
+    src = transpile(lines("extendedFaceStencilScalarGrad_8C_source.html", 86, 109))
+    rng = np.random.default_rng(seed)
+    rec = {k: [] for k in ("ie3", "pts", "Sf", "Cf", "C", "f", "fb", "symmetry", "grad")}
+    for n in range(nfaces):
+        ie3 = n % 3
+        ie1, ie2 = (1, 2) if ie3 == 0 else ((0, 2) if ie3 == 1 else (0, 1))
+
+        def place(a, b, h):
+            v = np.zeros(3); v[ie1], v[ie2], v[ie3] = a, b, h
+            return Vec(*v)
+        C4 = place(*(0.2 * rng.standard_normal(2)), 0.05)
+        a0, b0 = 0.5 + 0.2 * rng.standard_normal(), -0.5 + 0.2 * rng.standard_normal()
+        a1, b1 = 0.5 + 0.2 * rng.standard_normal(), 0.5 + 0.2 * rng.standard_normal()
+        pts = [place(a0, b0, 0.0), place(a0, b0, 0.1), place(a1, b1, 0.1), place(a1, b1, 0.0)]
+        S, cf = face_area_centre(pts)
+        if S @ (cf - C4.c) < 0:
+            pts = pts[::-1]
+            S, cf = face_area_centre(pts)
+        nf = S / np.sqrt((S * S).sum())
+        dc = 1.0 / abs(float(nf @ (cf - C4.c)))
+        fc, fb = float(rng.standard_normal()), float(rng.standard_normal())
+        symmetry = n % 4 == 3
+        kinds = {"symmetryPlaneFvPatch"} if symmetry else set()
+
+        class PatchField(Fld):
+            def snGrad(self): return Fld([dc * (fb - fc)])
+        out = [Fld([Vec(0, 0, 0)])]          # gradIF starts from zero [L55]
+        env = dict(mesh_=Obj(boundaryMesh=call([0]), boundary=call([kinds])), isA=lambda name, patch: name in patch, true=True, false=False,
+                   gradIF=Obj(boundaryFieldRef=call(out)), nf_=Obj(boundaryField=call([Fld([Vec(*nf)])])),
+                   iF=Obj(boundaryField=call([PatchField([fb])])))
+        exec(src, env)
+        rec["ie3"].append(ie3); rec["pts"].append(np.array([p.c for p in pts])); rec["Sf"].append(S); rec["Cf"].append(cf); rec["C"].append(C4.c)
+        rec["f"].append(fc); rec["fb"].append(fb); rec["symmetry"].append(int(symmetry)); rec["grad"].append(out[0][0].c)
+    return {k: np.array(v) for k, v in rec.items()}
+
+
 def lsq(nfaces=30, seed=13):
     """one internal face with a stencil of n cells (cells 0 and 1 are its owner and neighbour, placed symmetrically about the
     face centre so that the linear weight is 1/2 and sF = (iF[0] + iF[1])/2 needs no further L0 rule)"""
@@ -1064,7 +1106,7 @@ def species(nfaces=30, seed=16):
 def main():
     if not os.path.isdir(REF):
         sys.exit("make_ref_expr.py needs the reference listings under /root/reference (build container only)")
-    for name, fn in (("gvp3d", gvp3d), ("gvp3d_bnd", gvp3d_bnd), ("gvp2d", gvp2d), ("gvp2d_bnd", gvp2d_bnd), ("reduced", reduced), ("lsq", lsq), ("case2cell", case2cell), ("qhdface", qhdface), ("species", species)):
+    for name, fn in (("gvp3d", gvp3d), ("gvp3d_bnd", gvp3d_bnd), ("gvp2d", gvp2d), ("gvp2d_bnd", gvp2d_bnd), ("reduced", reduced), ("lsq_bnd", lsq_bnd), ("lsq", lsq), ("case2cell", case2cell), ("qhdface", qhdface), ("species", species)):
         data = fn()
         path = os.path.join(HERE, f"ref_expr_{name}.npz")
         np.savez_compressed(path, **data)

@@ -33,7 +33,7 @@ def two_cell_mesh(pts, nv, Sf, Cf, C, empty_normals=()):
     return prim, geom
 
 
-def boundary_face_mesh(pts, nv, Sf, Cf, C, back_axis=0, empty_normals=()):
+def boundary_face_mesh(pts, nv, Sf, Cf, C, back_axis=0, empty_normals=(), patch_type=GENERIC):
     """cell 0 (centre C) with ONE boundary face on a generic patch: face 1, vertices 0..nv-1, area vector / centre prescribed; an
     internal quad (face 0) a unit length behind the cell along -e_back_axis connects it to cell 1 and shares no vertex with the
     boundary face, so the boundary face's vertices are boundary points of that face alone.  One `empty` face per entry of
@@ -48,7 +48,7 @@ def boundary_face_mesh(pts, nv, Sf, Cf, C, back_axis=0, empty_normals=()):
     prim = dict(points=np.concatenate([pts, np.array(quad)]).reshape(-1), faceOffsets=np.cumsum([0] + [len(f) for f in faces]).astype(np.int32),
                 facePoints=np.concatenate(faces).astype(np.int32), owner=np.zeros(len(faces), np.int32), neighbour=np.array([1], np.int32),
                 nCells=2, patchStart=np.array([1, 2][:1 + (n_e > 0)], np.int32), patchSize=np.array([1, n_e][:1 + (n_e > 0)], np.int32),
-                patchType=np.array([GENERIC, EMPTY][:1 + (n_e > 0)], np.int32))
+                patchType=np.array([patch_type, EMPTY][:1 + (n_e > 0)], np.int32))
     geom = dict(Sf=np.array([-unit(back_axis), np.asarray(Sf, float)] + [np.asarray(n, float) for n in empty_normals]),
                 Cf=np.array([back, np.asarray(Cf, float)] + [C + 0.1 * np.asarray(n, float) for n in empty_normals]),
                 C=np.array([C, C - 2.0 * unit(back_axis)]), V=np.ones(2))

@@ -75,6 +75,28 @@ def test_gaussvolpoint_3d_boundary_faces():
         om.close()
 
 
+def lsq_bnd_mesh(g, i):
+    from qgdsolver_amd import _lib as L
+    ie3 = int(g["ie3"][i])
+    return rc.boundary_face_mesh(g["pts"][i], 4, g["Sf"][i], g["Cf"][i], g["C"][i], back_axis=(ie3 + 1) % 3, empty_normals=[rc.unit(ie3)],
+                                 patch_type=L.PATCH_SYMMETRYPLANE if g["symmetry"][i] else L.PATCH_GENERIC)
+
+
+def test_leastsquares_boundary_faces():
+    """extendedFaceStencilScalarGrad.C L86-109: nf * snGrad on ordinary patches, zero on symmetryPlane (constraint) patches"""
+    g = rc.load("lsq_bnd")
+    assert set(g["symmetry"]) == {0, 1}
+    for i in range(len(g["ie3"])):
+        om = oracle_mesh(*lsq_bnd_mesh(g, i))
+        st, gs = om.fvsc("leastSquares", "grad_s", np.array([g["f"][i], 0.3]), np.array([g["fb"][i], 0.0]))
+        assert st == 0
+        if g["symmetry"][i]:
+            assert np.array_equal(gs[1], np.zeros(3)) and np.array_equal(g["grad"][i], np.zeros(3))
+        else:
+            assert rel(gs[1], g["grad"][i]) <= TOL, (i, gs[1], g["grad"][i])
+        om.close()
+
+
 def test_reduced_stencil_operators():
     """reducedFaceNormalStencil.C L71-105: nf * snGrad (outer product, layout d_i psi_j) and nf & snGrad for the four operators"""
     g = rc.load("reduced")

@@ -8,7 +8,7 @@ import qgdsolver_amd as q
 from qgdsolver_amd import fvsc
 
 import ref_expr_cases as rc
-from test_ref_expr import FACE_FIELDS, QHD_FIELDS, STEP_FIELDS, bnd_ops, case_options, qhd_inputs, rel
+from test_ref_expr import FACE_FIELDS, QHD_FIELDS, STEP_FIELDS, bnd_ops, lsq_bnd_mesh, case_options, qhd_inputs, rel
 
 pytestmark = pytest.mark.gpu
 
@@ -88,6 +88,19 @@ def test_reduced_stencil_on_the_device():
             vf = q.volField("f", cell, np.zeros((0,) + nb))
             got = fvsc.grad(dev, vf) if op.startswith("grad") else fvsc.div(dev, vf)
             assert rel(got[0], g[op][i]) <= TOL, (i, nv, op)
+        dev.close()
+
+
+def test_leastsquares_boundary_faces_on_the_device():
+    g = rc.load("lsq_bnd")
+    for i in range(len(g["ie3"])):
+        mesh = device_mesh(*lsq_bnd_mesh(g, i))
+        dev = q.Device(mesh, fv_schemes={"fvsc": {"default": "leastSquares"}})
+        gs = fvsc.grad(dev, q.volField("f", np.array([g["f"][i], 0.3]), np.array([g["fb"][i], 0.0])))
+        if g["symmetry"][i]:
+            assert np.array_equal(gs[1], np.zeros(3))
+        else:
+            assert rel(gs[1], g["grad"][i]) <= TOL, (i, gs[1], g["grad"][i])
         dev.close()
 
 
