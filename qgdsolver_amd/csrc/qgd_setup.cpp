@@ -457,6 +457,7 @@ FaceTiles buildFaceTiles(const StaticData& s, int32_t fb) {
     FaceTiles t;
     const int64_t nIF = s.nIF;
     if (nIF == 0 || s.nGeomD != 3 || (fb != 64 && fb != 128 && fb != 256)) return t;
+    if (3 * (int64_t)s.nC > INT32_MAX || 3 * (int64_t)s.nP > INT32_MAX) return t;   // the kernel indexes 16-B pieces with 32-bit integers
     const int64_t nTiles = (nIF + fb - 1) / fb;
     const int32_t capC = faceTileCapCells(fb), capV = faceTileCapVerts(fb);
     std::vector<int32_t> cnt(2 * (size_t)nTiles, 0);
