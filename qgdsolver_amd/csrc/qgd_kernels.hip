@@ -388,22 +388,6 @@ __device__ __forceinline__ void gvp3FaceBody(const MeshView& m, const CaseView& 
                                              const int adjustDt, double& cof, double& tauMin) {
     // msO, dnO: |Sf| and deltaCoeffs of the face, read only on meshes that have faces with more than four vertices
     const size_t nF = (size_t)m.nF;
-#ifdef QGD_F_EXPERIMENT
-    // timing experiments only (wrong results): 1 = every load consumed, no flux algebra; 2 = as 1 and nothing stored but one value per wave
-    {
-        double acc = w + hf + S[0] + S[1] + S[2] + rVc + coef[0] + coef[1] + coef[2] + coef[3] + coef[4] + coef[5] + coef[6] + coef[7] + coef[8] +
-                     coef[9] + coef[10] + coef[11] + Bo.H + Bo.c + Bo.muQGD + Bo.aOc + Bn.H + Bn.c + Bn.muQGD + Bn.aOc;
-        const RecA* r[6] = {&Ao, &An, &q0, &q1, &q2, &q3};
-#pragma unroll
-        for (int i = 0; i < 6; ++i) acc += r[i]->rho + r[i]->ux + r[i]->uy + r[i]->uz + r[i]->p + r[i]->e;
-        acc += (double)kind;
-        if (QGD_F_EXPERIMENT == 1) {
-#pragma unroll
-            for (int k = 0; k < 5; ++k) c.flux[(size_t)k * nF + fp] = acc + k;
-        } else if (acc == 1.2345e300) c.flux[fp] = acc;   // experiments 2, 3
-        return;
-    }
-#endif
     FaceVals<6> v;
     loadVals(Ao, v.o);
     loadVals(An, v.n);
@@ -521,13 +505,6 @@ void faceFluxGvp3Kernel(const MeshView m, const CaseView c, const GasModel gm, c
         double msO = 1.0, dnO = 0.0;
         if (m.hasOther) { msO = m.magSf[f]; dnO = m.dn[f]; }
         // (2) gathered records (vertex 3 is clamped for triangles; unused there)
-#if defined(QGD_F_EXPERIMENT) && QGD_F_EXPERIMENT == 3
-        // timing experiment: the streamed face data only, no gathers
-        const RecA Ao = {(double)o, 0, 0, 0, 0, 0}, An = {(double)n, 0, 0, 0, 0, 0};
-        const RecB Bo = {0, 0, 0, 0}, Bn = {0, 0, 0, 0};
-        const RecA q0 = {(double)vt.x, 0, 0, 0, 0, 0}, q1 = {(double)vt.y, 0, 0, 0, 0, 0}, q2 = {(double)vt.z, 0, 0, 0, 0, 0}, q3 = {(double)vt.w, 0, 0, 0, 0, 0};
-        const double4 cO = make_double4(0, 0, 0, 0), cN = cO, x0 = cO, x1 = cO, x2 = cO, x3 = cO;
-#else
         const RecA Ao = c.A[o], An = c.A[n];
         const RecB Bo = c.B[o], Bn = c.B[n];
         const int v3 = vt.w < 0 ? 0 : vt.w;
@@ -536,7 +513,6 @@ void faceFluxGvp3Kernel(const MeshView m, const CaseView c, const GasModel gm, c
         const double4 cO = ld3(m.Cc, o), cN = ld3(m.Cc, n);
         const double4 x0 = ld3(m.X, vt.x), x1 = ld3(m.X, vt.y), x2 = ld3(m.X, vt.z), x3 = ld3(m.X, v3);
         __builtin_amdgcn_sched_barrier(0);
-#endif
 
         double coef[12], rVc;
         gvp3Coefs(kind, cO, cN, x0, x1, x2, x3, coef, rVc);
