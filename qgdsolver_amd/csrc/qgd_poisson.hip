@@ -336,8 +336,8 @@ int diagLaplacianPcg(hipStream_t stream, const MeshView& m, const double* a, con
 // The Jacobi-PCG above needs 772 / 1174 iterations at 2 M / 8 M cells; QHDFoam solves this equation every step
 // [QHDpEqn.H L36-47], and in QHDFoam its matrix never changes (taubyrhof is fixed after start-up), so a hierarchy built once
 // pays for itself at the first step.  Built on the host from the face coefficients: pairwise matching along the strongest
-// connection, three passes per level (aggregates of about eight cells, what OpenFOAM's GAMG does with faceAreaPair
-// agglomeration), Galerkin coarse operators with piecewise-constant prolongation (coarse face coefficient = sum of the fine
+// connection, two passes per level (aggregates of about four cells; three passes -- the eight-cell aggregates of OpenFOAM's
+// faceAreaPair agglomeration -- need twice the iterations here), Galerkin coarse operators with piecewise-constant prolongation (coarse face coefficient = sum of the fine
 // ones between two aggregates).  One V-cycle = nu damped-Jacobi sweeps before and after the coarse-grid correction, which is
 // over-weighted (x += oc * P e_c, oc = 1.8: plain aggregation under-estimates smooth corrections); with equal pre- and
 // post-smoothing the cycle is a symmetric positive definite operator, as CG needs.  Every sum is a gather in a fixed order:
@@ -487,7 +487,7 @@ struct PressureSolver {
     MeshView m{};
     hipStream_t stream = nullptr;
     int refCell = -1, precond = 1;
-    double omega = 0.67, oc = 1.8;
+    double omega = 0.8, oc = 1.8;   // measured (8 M cells / 16 M irregular): 0.67 -> 0.8 with 4:1 coarsening 46 -> 24 / 52 -> 25 iterations
     int nu = 2, coarseSweeps = 40;
     std::vector<void*> owned;
     std::vector<MgLevelDev> L;
@@ -653,6 +653,13 @@ PressureSolver* pressureSolverCreate(hipStream_t stream, const MeshView& m, cons
     try {
         S->m = m; S->stream = stream; S->refCell = refCell; S->precond = precond; S->bKind = bKind;
         { const char* e = std::getenv("QGD_MG_F32"); S->f32 = !e || std::atoi(e) != 0; }   // default: single-precision cycle
+        // tuning knobs of the cycle (experiments; the defaults are what the tests and DESIGN.md's numbers use)
+        if (const char* e = std::getenv("QGD_MG_NU")) S->nu = std::max(1, std::atoi(e));
+        if (const char* e = std::getenv("QGD_MG_OC")) S->oc = std::atof(e);
+        if (const char* e = std::getenv("QGD_MG_OMEGA")) S->omega = std::atof(e);
+        if (const char* e = std::getenv("QGD_MG_COARSE_SWEEPS")) S->coarseSweeps = std::max(1, std::atoi(e));
+        int passes = 2;   // pairwise matching passes per level: aggregates of ~4 cells (3 passes = ~8 cells need twice the iterations)
+        if (const char* e = std::getenv("QGD_MG_PASSES")) passes = std::min(4, std::max(1, std::atoi(e)));
         const int nC = m.nC, nF = m.nF, nb = blocksOf(nC);
         S->a = S->alloc<double>(nF); S->gs = S->alloc<double>(std::max(m.nBF, 1));
         S->diag = S->alloc<double>(nC); S->rhs = S->alloc<double>(nC); S->r = S->alloc<double>(nC); S->z = S->alloc<double>(nC);
@@ -683,7 +690,7 @@ PressureSolver* pressureSolverCreate(hipStream_t stream, const MeshView& m, cons
                 std::vector<int> total((size_t)n);
                 for (int i = 0; i < n; ++i) total[i] = i;
                 int cur = n;
-                for (int pass = 0; pass < 3 && cur > 64; ++pass) {
+                for (int pass = 0; pass < passes && cur > 64; ++pass) {
                     std::vector<int> agg;
                     const int na = pairwisePass(cur, I, J, w, agg);
                     coarsenGraph(na, agg, I, J, w, diag);
