@@ -56,6 +56,15 @@ def meshes():
     yield "hex 37x11x5 (ragged last tile)", q.PolyMesh.box(37, 11, 5)
     yield "hex 150x6x6 (long rows)", q.PolyMesh.box(150, 6, 6)
     yield "jitter + triangles + polygons, Morton order", c5_mesh(16, 8 ** 3, poly=True)
+    tri = q.PolyMesh.box(9, 7, 5)
+    tri.jitter(0.15, seed=3); tri.split_quads(3)
+    yield "every third quad split, natural order", tri
+    scr = q.PolyMesh.box(12, 10, 8)
+    scr.renumber(np.random.default_rng(5).permutation(scr.nCells).astype(np.int32))
+    yield "scrambled labels (most tiles beyond the caps)", scr
+    rcm = q.PolyMesh.box(30, 6, 5)
+    rcm.renumber(rcm.rcm_order())
+    yield "reverse Cuthill-McKee order", rcm
 
 
 @pytest.mark.parametrize("fb", [64, 128, 256])
