@@ -93,3 +93,15 @@ def test_staged_kernel_on_a_shard():
     for k in a:
         assert np.array_equal(a[k], b[k]), k
 
+
+
+def test_staged_kernel_stays_bit_identical_over_a_long_run():
+    """300 steps on 48^3 cells (the bench's state and time step): any difference between the two kernels would be amplified"""
+    mesh = q.PolyMesh.box(48, 48, 48)
+    opt = dict(deltaT=0.1 / 48 / 1.3)
+    a = run(mesh, 300, {"QGD_FTILE": "0"}, **opt)
+    b = run(mesh, 300, {"QGD_FTILE": "1"}, **opt)
+    assert b.pop("tiles")["facesPerTile"] == 128
+    a.pop("tiles")
+    for k in a:
+        assert np.isfinite(a[k]).all() and np.array_equal(a[k], b[k]), k
