@@ -2185,7 +2185,8 @@ int orc_case_get_field(void* cp, const char* name, double* out, int64_t n) {
         {"phiQ", &c->phiQ}, {"phiPiU", &c->phiPiU}, {"phiwStar", &c->phiw}, {"phi", &c->phi}, {"tauQGDf", &c->tauQGDf},
         {"hQGDf", &c->hQGDf}, {"gradUf", &c->gradUf}, {"gradef", &c->gradef}, {"gradRhof", &c->gradRhof}, {"gradPf", &c->gradPf},
         {"rhof", &c->rhof}, {"Uf", &c->Uf}, {"pf", &c->pf}, {"Hf", &c->Hf}, {"muf", &c->muf}, {"alphauf", &c->alphauf}, {"cf", &c->cf},
-        {"Pif", &c->Pif}, {"qf", &c->qf}, {"jm", &c->jm}};
+        {"Pif", &c->Pif}, {"qf", &c->qf}, {"jm", &c->jm},
+        {"tauMC", &c->tauMC}, {"phiTauMC", &c->phiTauMC}, {"phiSigmaDotU", &c->phiSigmaDotU}};   // implicitDiffusion branch
     const dvec* src = nullptr;
     auto iv = vf.find(s);
     if (iv != vf.end()) src = bnd ? &iv->second->bf : &iv->second->in;

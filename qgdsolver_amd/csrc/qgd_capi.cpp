@@ -1754,6 +1754,20 @@ int qgd_case_get_field(qgd_case_t c, const char* name, double* out, int64_t outD
         std::copy(c->dev->hf.begin(), c->dev->hf.end(), out);
         return QGD_OK;
     }
+    // face fields of the implicitDiffusion branch, as the last step left them [updateFluxes.H L107-111, QGDUEqn.H L72-74]
+    if (!bnd && (s == "phiTauMC" || s == "phiSigmaDotU")) {
+        if (!c->impl.phiTau) return fail(QGD_ERR_INVALID, "qgd_case_get_field: " + s + " exists with implicitDiffusion true only");
+        const int nc = s == "phiTauMC" ? 3 : 1;
+        if ((int64_t)m.nF * nc > outDoubles) return fail(QGD_ERR_INVALID, "output too small");
+        HIP_CHECK(hipStreamSynchronize(c->stream()));
+        std::vector<double> tmp((size_t)m.nF);
+        for (int k = 0; k < nc; ++k) {
+            const double* src = nc == 3 ? c->impl.phiTau + (size_t)k * m.nF : c->impl.phiSig;
+            HIP_CHECK(hipMemcpy(tmp.data(), src, sizeof(double) * (size_t)m.nF, hipMemcpyDeviceToHost));
+            for (int64_t f = 0; f < m.nF; ++f) out[f * nc + k] = tmp[f];
+        }
+        return QGD_OK;
+    }
     auto fs = faceSlots.find(s);
     if (!bnd && fs != faceSlots.end()) {
         if (!c->dbgBuf) return fail(QGD_ERR_INVALID, "face fields are materialised by qgd_case_update_fluxes; call it first");

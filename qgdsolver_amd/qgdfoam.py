@@ -11,9 +11,9 @@ import numpy as np
 
 from . import _lib as L
 
-_VECTOR_FIELDS = {"U": 3, "rhoU": 3, "phiJmU": 3, "phiP": 3, "phiPi": 3, "gradUf": 9, "gradef": 3, "gradRhof": 3, "gradPf": 3}
+_VECTOR_FIELDS = {"U": 3, "rhoU": 3, "phiJmU": 3, "phiP": 3, "phiPi": 3, "gradUf": 9, "gradef": 3, "gradRhof": 3, "gradPf": 3, "phiTauMC": 3}
 _FACE_FIELDS = {"phiJm", "phiJmU", "phiP", "phiPi", "phiJmH", "phiQ", "phiPiU", "phiwStar", "phi", "tauQGDf", "hQGDf",
-                "gradUf", "gradef", "gradRhof", "gradPf"}
+                "gradUf", "gradef", "gradRhof", "gradPf", "phiTauMC", "phiSigmaDotU"}
 
 STENCIL_IDS = {"reduced": L.FVSC_REDUCED, "leastSquares": L.FVSC_LEASTSQUARES, "leastSquaresOpt": L.FVSC_LEASTSQUARES,
                "GaussVolPoint": L.FVSC_GAUSSVOLPOINT}

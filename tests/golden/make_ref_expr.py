@@ -827,6 +827,17 @@ def lsq(nfaces=30, seed=13):
     return {k: np.array(v) for k, v in rec.items()}
 
 
+def dev2(t):
+    """OpenFOAM's dev2(T) = T - (2/3) tr(T) I (L0)"""
+    return Tensor(t.m - (2.0 / 3.0) * np.trace(t.m) * np.eye(3))
+
+
+class MulPair:
+    """a pair of scalars that scales a pair of tensors from the left: muEff * dev2(...)"""
+    def __init__(self, o, n): self.o, self.n = o, n
+    def __mul__(self, t): return type(t)(self.o * t.o, self.n * t.n)
+
+
 class Pair:
     """a cell field seen from one face: (owner value, neighbour value)"""
     def __init__(self, o, n): self.o, self.n = o, n
@@ -905,7 +916,7 @@ def case2cell(nfaces=40, seed=14):
     dt = 1e-3
     rng = np.random.default_rng(seed)
     names = ("nv", "pts", "Sf", "Cf", "C", "V", "U", "T", "p", "R", "Cv", "mu", "Pr", "ScQGD", "PrQGD", "alphaQGD", "deltaT", "rho1", "U1", "e1",
-             "rhoU1", "rhoE1",
+             "rhoU1", "rhoE1", "phiPi_impl", "phiQ_impl", "phiTauMC", "tauMC",
              "w", "hQGDf", "rhof", "Uf", "rhoUf", "UrhoUf", "pf", "cf", "gammaf", "Hf", "alphauf", "muf", "tauQGDf",
              "gradUf", "gradef", "gradRhof", "gradPf", "phiwStar", "phiJm", "phi", "phiJmU", "phiP", "phiPi", "phiJmH", "phiQ", "phiPiU",
              "muQGD", "alphauQGD", "tauQGD", "hQGD")
@@ -974,6 +985,28 @@ def case2cell(nfaces=40, seed=14):
                     I=Sph(1.0), implicitDiffusion=False, Foam=Obj(T=lambda t: t.T()), qgdFlux=lambda flux, psi, psif: flux * psif, H="H")
         exec(flux_src, env2)
         g = env2
+        # the same listing with implicitDiffusion true: Pif / qf without the Navier-Stokes / Fourier parts and
+        # tauMC = qgdInterpolate(muEff * dev2(T(fvc::grad(U)))), phiTauMC = Sf & tauMC [updateFluxes.H L95-111, L131-135].  fvc::grad(U) of
+        # the two one-face cells is Gauss linear: +Sf (x) Uf / V in the owner, -Sf (x) Uf / V in the neighbour (L0)
+        Uf_lin = lin(Pair(*U))
+        gradUc = Pair(Tensor(np.outer(S.c, Uf_lin.c) / 1.0), Tensor(-np.outer(S.c, Uf_lin.c) / 1.0))
+
+        class Holder:
+            v = None
+            def __call__(self): return self if self.v is None else self.v
+            def assign(self, x): self.v = x
+        tauMC = Holder()
+
+        class PT(Pair):   # pairs of tensors scaled by pairs of scalars
+            def __rmul__(self, sc): return PT(sc.o * self.o, sc.n * self.n) if isinstance(sc, Pair) else PT(sc * self.o, sc * self.n)
+        env3 = {k: env[k] for k in ("rhof", "Uf", "rhoUf", "UrhoUf", "pf", "gammaf", "Hf", "alphauf", "muf")}
+        env3.update(tr=tr, tauQGDf=tauf, mesh=Obj(Sf=call(S)), fvsc=Obj(grad=lambda fld: grads[fld]), U="U", e="e", rho="rho", p="p",
+                    I=Sph(1.0), implicitDiffusion=True, Foam=Obj(T=lambda t: PT(t.o.T(), t.n.T()) if isinstance(t, Pair) else t.T()),
+                    qgdFlux=lambda flux, psi, psif: flux * psif, H="H", tauMCPtr=tauMC, qgdInterpolate=lin,
+                    turbulence=Obj(muEff=call(MulPair(muEff.o, muEff.n))), fvc=Obj(grad=lambda fld: PT(gradUc.o, gradUc.n)),
+                    dev2=lambda t: PT(dev2(t.o), dev2(t.n)))
+        exec(flux_src, env3)
+        gi = env3
 
         # one explicit step of the three equations with those fluxes (zero sources)
         fvm, fvc = fv_emulation(dt, [1.0, 1.0])
@@ -990,7 +1023,8 @@ def case2cell(nfaces=40, seed=14):
         out = dict(nv=nv, pts=np.array([q.c for q in pts] + ([[0, 0, 0]] if nv == 3 else [])), Sf=S.c, Cf=Cf.c, C=np.array([own.c, nei.c]),
                    V=[1.0, 1.0], U=np.array([u.c for u in U]), T=T, p=p, R=R, Cv=Cv, mu=mu0, Pr=Pr, ScQGD=Sc, PrQGD=PrQ, alphaQGD=aQ, deltaT=dt,
                    rho1=list(eq["rho"]), U1=np.array([u.c for u in eq["U"]]), e1=list(eq["e"]), rhoU1=np.array([u.c for u in eq["rhoU"]]),
-                   rhoE1=list(eq["rhoE"]),
+                   rhoE1=list(eq["rhoE"]), phiPi_impl=val(gi["phiPi"]), phiQ_impl=val(gi["phiQ"]), phiTauMC=val(gi["phiTauMC"]),
+                   tauMC=val(tauMC()),
                    w=w, hQGDf=hf, cf=env["cf"], tauQGDf=tauf, phiwStar=g["phiw"], muQGD=muQGD, alphauQGD=alphauQGD,
                    tauQGD=[tauc.o, tauc.n], hQGD=[hcell, hcell])
         for k in ("rhof", "Uf", "rhoUf", "UrhoUf", "pf", "gammaf", "Hf", "alphauf", "muf", "gradUf", "gradef", "gradRhof", "gradPf",

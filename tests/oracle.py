@@ -79,9 +79,10 @@ lib.orc_qhd_case_get_field.argtypes = [C.c_void_p, C.c_char_p, dp, C.c_int64]
 lib.orc_qhd_case_info.argtypes = [C.c_void_p, dp]
 
 _NCOMP = {"U": 3, "rhoU": 3, "phiJmU": 3, "phiP": 3, "phiPi": 3, "gradUf": 9, "gradef": 3, "gradRhof": 3, "gradPf": 3,
-          "Uf": 3, "Pif": 9, "qf": 3, "jm": 3}
+          "Uf": 3, "Pif": 9, "qf": 3, "jm": 3, "tauMC": 9, "phiTauMC": 3}
 _FACE = {"phiJm", "phiJmU", "phiP", "phiPi", "phiJmH", "phiQ", "phiPiU", "phiwStar", "phi", "tauQGDf", "hQGDf", "gradUf",
-         "gradef", "gradRhof", "gradPf", "rhof", "Uf", "pf", "Hf", "muf", "alphauf", "cf", "Pif", "qf", "jm"}
+         "gradef", "gradRhof", "gradPf", "rhof", "Uf", "pf", "Hf", "muf", "alphauf", "cf", "Pif", "qf", "jm", "tauMC", "phiTauMC",
+         "phiSigmaDotU"}
 
 
 def _d(a):

@@ -196,6 +196,25 @@ def test_flux_assembly_of_one_face():
         oc.close(); om.close()
 
 
+def test_implicit_branch_face_expressions():
+    """updateFluxes.H with implicitDiffusion true, from the listing text: Pif / qf without their Navier-Stokes / Fourier parts (L95-106,
+    L131-135) and tauMC = qgdInterpolate(muEff dev2(T(fvc::grad(U)))), phiTauMC = Sf & tauMC (L107-111)"""
+    g = rc.load("case2cell")
+    for i in range(len(g["nv"])):
+        nv = int(g["nv"][i])
+        prim, geom = rc.two_cell_mesh(g["pts"][i], nv, g["Sf"][i], g["Cf"][i], g["C"][i])
+        om = oracle_mesh(prim, geom)
+        opt = case_options(g, i)
+        opt.implicitDiffusion = 1
+        oc = OracleCase(om, opt)
+        oc.set_fields(g["U"][i], g["T"][i], g["p"][i])
+        oc.updateFluxes()
+        for f, want in (("phiPi", "phiPi_impl"), ("phiQ", "phiQ_impl"), ("tauMC", "tauMC"), ("phiTauMC", "phiTauMC")):
+            assert rel(oc.field(f)[0], g[want][i]) <= TOL, (i, nv, f, oc.field(f)[0], g[want][i])
+        assert rel(oc.field("phiJm")[0], g["phiJm"][i]) <= TOL          # the mass flux does not depend on the branch
+        oc.close(); om.close()
+
+
 QHD_FIELDS = ["gradUf", "gradTf", "gradPf", "phiu", "phiwo", "taubyrhof", "Wf", "phiUf", "phiTf", "phiTauTReg"]
 
 

@@ -143,6 +143,26 @@ def test_flux_assembly_of_one_face_on_the_device():
         case.close(); dev.close()
 
 
+def test_implicit_branch_face_expressions_on_the_device():
+    """updateFluxes.H with implicitDiffusion true against the listing text: phiPi, phiQ from the face kernel, phiTauMC as the implicit
+    step forms it from fvc::grad(U) of the state before the step"""
+    g = rc.load("case2cell")
+    for i in range(len(g["nv"])):
+        nv = int(g["nv"][i])
+        mesh = device_mesh(*rc.two_cell_mesh(g["pts"][i], nv, g["Sf"][i], g["Cf"][i], g["C"][i]))
+        dev = q.Device(mesh)
+        opt = case_options(g, i)
+        opt.implicitDiffusion = 1
+        case = q.QGDFoamCase(dev, opt)
+        case.set_fields(g["U"][i], g["T"][i], g["p"][i])
+        case.updateFluxes()
+        for f, want in (("phiPi", "phiPi_impl"), ("phiQ", "phiQ_impl"), ("phiJm", "phiJm")):
+            assert rel(case.field(f)[0], g[want][i]) <= TOL, (i, nv, f, case.field(f)[0], g[want][i])
+        case.step(1)
+        assert rel(case.field("phiTauMC")[0], g["phiTauMC"][i]) <= TOL, (i, nv, case.field("phiTauMC")[0], g["phiTauMC"][i])
+        case.close(); dev.close()
+
+
 def test_qhd_face_expressions_on_the_device():
     """qgd_qhd_fluxes against the QHDFoam face expressions evaluated from the listing text (tests/golden/ref_expr_qhdface.npz)"""
     from qgdsolver_amd import qhdfoam
