@@ -406,7 +406,8 @@ int qgd_case_step(qgd_case_t c, int32_t nSteps);
 
 /* Named field copy-out to HOST.  Cell fields: "rho","U","p","e","T","rhoU",
  * "rhoE","c","psi","mu","alphau","tauQGD","muQGD","alphauQGD","hQGD","H".
- * Face fields: see qgd_case_update_fluxes plus "hQGDf".
+ * Face fields: see qgd_case_update_fluxes plus "hQGDf"; with implicitDiffusion true also "phiTauMC" (3 per face)
+ * and "phiSigmaDotU" as the last step formed them [QGDFoam_2updateFluxes_8H_source.html L107-111, QGDUEqn_8H_source.html L72-74].
  * Boundary fields: "<cellfield>.boundary".  outDoubles = capacity of out. */
 int qgd_case_get_field(qgd_case_t c, const char* name, double* out,
                        int64_t outDoubles);
