@@ -233,16 +233,88 @@ def dropin_fvsc_line(q, n, reps):
     return out
 
 
+def host_cpu_quota():
+    """CPUs this process may really use: hardware threads clipped by the scheduler affinity and the cgroup quota."""
+    cpus = os.cpu_count() or 1
+    try:
+        cpus = min(cpus, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            words = open(path).read().split()
+            quota = float(words[0])
+            period = float(words[1]) if len(words) > 1 else float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                cpus = min(cpus, max(1, int(quota / period)))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, cpus)
+
+
+def self_launch(n_ranks):
+    """`python bench.py --gpus N` without a launcher around it: start N rank processes (one per GPU) as plain children
+    BEFORE this process imports torch or touches HIP, relay rank 0's JSON line and exit with the worst child status.
+    Nothing is re-exec'ed: the parent stays a relay that never initialises the GPU.  Host set-up of the library is OpenMP:
+    every rank gets cpu_quota // N threads so that N ranks do not oversubscribe the cgroup."""
+    import socket
+    import subprocess
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    threads = max(1, host_cpu_quota() // n_ranks)
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.setdefault("OMP_NUM_THREADS", str(threads))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
+    worst = 0
+    line = None
+    try:
+        # rank 0's stdout is the result line; the others only have a status.  A rank that dies takes the job with it
+        # (its peers would wait in the rendezvous or the first exchange for ever).
+        while any(pr.poll() is None for pr in procs):
+            dead = [pr for pr in procs if pr.poll() not in (None, 0)]
+            if dead:
+                for pr in procs:
+                    if pr.poll() is None:
+                        pr.kill()
+                break
+            time.sleep(0.2)
+        out, _ = procs[0].communicate()
+        for pr in procs:
+            rc = pr.wait()
+            worst = max(worst, abs(rc)) if rc else worst
+        for ln in (out or "").splitlines():
+            if ln.startswith("{"):
+                line = ln
+            elif ln.strip():
+                print(ln, file=sys.stderr)
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    if line:
+        print(line, flush=True)
+    elif worst == 0:
+        worst = 1
+    sys.exit(min(worst, 255))
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.cpu_only:
+        self_launch(args.gpus)   # never returns
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag disagree", file=sys.stderr)
+        sys.exit(2)
 
     if args.cpu_only:
         print(json.dumps(cpu_baseline(args.cpu_n, args.cpu_steps, args.cpu_ranks or cpu_rank_budget(args.cpu_n))))
@@ -407,7 +479,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     checksum = None
-    if args.check:
+    if args.check or world > 1:   # N > 1: always, so that every point of a scaling run can be compared with N = 1
         plane = n * n
         rho_owned = case.field("rho")[plane * (lo - k_lo): plane * (hi - k_lo)]
         cs = torch.tensor([float(rho_owned.sum()), float((rho_owned ** 2).sum())], dtype=torch.float64,
@@ -457,8 +529,12 @@ def main():
                             "GaussVolPoint, constScPrModel1, explicit diffusion, zeroGradient patches, fixed deltaT",
                 "cells": total_cells,
                 "cells_per_gpu": owned_cells,
-                "partition": (f"{world} k-slab(s), 1 ghost plane per cut, RCCL send/recv per step ({'library transport' if native else 'torch.distributed'})"
+                "partition": (f"{world} k-slab(s), 1 ghost plane per cut, one send/recv pair per neighbour per step"
                               + (", exchange overlapped with the cell update" if overlap else "")) if world > 1 else "single shard",
+                "transport": (("gloo, host-staged (debugging mode: every rank on GPU 0)" if staged else
+                               ("RCCL inside the library (qgd_case_step_sharded)" if native else "RCCL through torch.distributed P2P"))
+                              if world > 1 else None),
+                "host_threads_per_rank": int(os.environ.get("OMP_NUM_THREADS", "0")) or None,
                 "stencil": "GaussVolPoint",
             },
             "roofline": {
@@ -500,6 +576,9 @@ def main():
                 if key in tr:
                     out["roofline"]["traffic"] = tr[key]["bytes_per_launch"]
                     out["roofline"]["traffic_source"] = tr[key].get("source")
+                    # a constant read from profiles/pmc_traffic.json (counters of the builder's profiling run of this
+                    # workload), not counters of THIS run
+                    out["roofline"]["traffic_is_static"] = True
                     # measured HBM-side bytes / algorithmic bytes, per kernel (1.0 = nothing fetched twice)
                     out["roofline"]["kernel_traffic_ratio"] = {
                         "face": tr[key]["bytes_per_launch"] / face_bytes,

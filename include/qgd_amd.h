@@ -104,7 +104,13 @@ typedef struct qgd_device_s* qgd_device_t; /* device-resident mesh + stencils   
 typedef struct qgd_case_s* qgd_case_t;     /* a QGDFoam case on one device      */
 
 /* ---- library ---------------------------------------------------------------- */
+/* Bumped whenever an options struct grows or an entry changes its meaning (3: round 3). */
+#define QGD_ABI_VERSION 3
 const char* qgd_version(void);
+/* sizes[0..2] = sizeof(qgd_case_options), sizeof(qgd_qhd_options), sizeof(qgd_poisson_control) as THIS library was built,
+ * sizes[3] = its QGD_ABI_VERSION: a host compiled against another header compares before it passes a struct (the structs
+ * carry no size member; the library copies sizeof(its own) bytes). */
+int qgd_struct_sizes(int64_t sizes[4]);
 /* Last error text of the calling thread (never NULL). */
 const char* qgd_last_error(void);
 /* Number of visible HIP devices (0 when there is none; never fails). */
@@ -210,8 +216,8 @@ int qgd_stencil_lookup(qgd_device_t d, const char* word, int* stencilId);
  * OpenFOAM adapter hands over Field<Type>::cdata()).
  *   grad_s : ncomp 1 -> 3      grad_v : ncomp 3 -> 9
  *   div_v  : ncomp 3 -> 1      div_t  : ncomp 9 -> 3
- * bndGrad (nullable) = patch snGrad for fixedGradient-type patches; when NULL
- * snGrad = deltaCoeffs*(bnd - internal). */
+ * The patch surface-normal gradient the boundary-face rules need is
+ * deltaCoeffs*(bnd - internal), fvPatchField::snGrad (L0). */
 int qgd_fvsc_grad_s(qgd_device_t d, int stencilId, const double* cell,
                     const double* bnd, double* out);
 int qgd_fvsc_grad_v(qgd_device_t d, int stencilId, const double* cell,
@@ -414,6 +420,12 @@ int qgd_case_get_field(qgd_case_t c, const char* name, double* out,
 
 /* info[0]=time, [1]=deltaT, [2]=CoNum, [3]=min(rho), [4]=min(e), [5]=step count */
 int qgd_case_info(qgd_case_t c, double info[6]);
+/* The linear solves of the implicitDiffusion branch in the last step (what OpenFOAM prints as "Solving for Ux, Initial
+ * residual = ..., Final residual = ..., No Iterations ...") [QGDUEqn_8H_source.html L54-68, QGDEEqn_8H_source.html L53-61]:
+ * info[0..3] = iterations of Ux, Uy, Uz, e; [4..7] = initial, [8..11] = final normalised residuals; [12] = number of steps
+ * since qgd_case_set_fields in which a solve stopped above implicitTol (iteration limit or breakdown: the step keeps the last
+ * iterate, as OpenFOAM does, and counts here); [13] = 1 when the case runs the implicit branch. */
+int qgd_case_implicit_info(qgd_case_t c, double info[14]);
 
 /* ---- halo exchange of ghost-cell primitives (multi-GPU) ------------------- */
 /* A shard has one halo slot per neighbouring shard: a qgd_mesh_box slab (kLo>0 or kHi<nzGlobal) has slot 0 = lower k

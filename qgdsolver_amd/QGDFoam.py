@@ -166,7 +166,8 @@ def run(case_dir, n_steps=None, device_id=0, write=True, log=print, renumber="no
     else:
         raise ff.FoamFileError(f"writeControl '{control}' with adjustTimeStep is not supported (use writeControl timeStep)")
     total = n_steps if n_steps is not None else (None if adjust else int(round((end_time - t0) / dt)))
-    log(f"QGDFoam (qgdsolver_amd, explicit branch): {n_global} cells on {world} rank(s), fvsc {opt['stencil']}, "
+    branch = "implicitDiffusion true" if opt.get("implicitDiffusion") else "explicit branch"
+    log(f"QGDFoam (qgdsolver_amd, {branch}): {n_global} cells on {world} rank(s), fvsc {opt['stencil']}, "
         f"deltaT {dt:g}, start {t0_name}, cell order {renumber}")
     done = 0
     wall0 = _time.perf_counter()
@@ -196,6 +197,12 @@ def run(case_dir, n_steps=None, device_id=0, write=True, log=print, renumber="no
         t = t0 + info["time"]
         log(f"Time = {time_name(t, precision)}  steps {done}  deltaT {info['deltaT']:.6g}  Courant max {info['CoNum']:.6g}  "
             f"min rho {info['minRho']:.6g}  min e {info['minE']:.6g}  ClockTime {_time.perf_counter() - wall0:.2f} s")
+        if opt.get("implicitDiffusion"):
+            ii = case.implicit_info()
+            log("  " + "  ".join(f"{k}: {v['initial']:.3g} -> {v['final']:.3g} in {v['iterations']}" for k, v in ii["solves"].items()))
+            if ii["unconverged_steps"]:
+                log(f"  WARNING: {ii['unconverged_steps']} step(s) so far in which an implicit solve stopped above its tolerance "
+                    f"(implicitTol {case.options.implicitTol:g}, maxIter {case.options.implicitMaxIter})")
         if not np.isfinite(info["minRho"]) or info["minRho"] <= 0:
             raise FloatingPointError(f"density lost positivity at time {t:g}")
         if write:

@@ -108,6 +108,8 @@ SIGNATURES = {
     "qgd_case_step": (C.c_int, [handle, C.c_int32]),
     "qgd_case_get_field": (C.c_int, [handle, C.c_char_p, c_double_p, C.c_int64]),
     "qgd_case_info": (C.c_int, [handle, c_double_p]),
+    "qgd_case_implicit_info": (C.c_int, [handle, c_double_p]),
+    "qgd_struct_sizes": (C.c_int, [c_int64_p]),
     "qgd_device_alloc": (C.c_int, [handle, C.c_int64, C.POINTER(C.c_void_p)]),
     "qgd_device_release": (C.c_int, [handle, C.c_void_p]),
     "qgd_species_flux": (C.c_int, [handle, C.c_int] + [c_double_p] * 10),
@@ -139,6 +141,14 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(lib, _name)  # AttributeError here == the library does not export a declared symbol
     _fn.restype = _res
     _fn.argtypes = _args
+
+# the structs above must be the library's own (they carry no size member)
+_sizes = (C.c_int64 * 4)()
+lib.qgd_struct_sizes(_sizes)
+if (_sizes[0], _sizes[1]) != (C.sizeof(CaseOptions), C.sizeof(QhdOptions)):
+    raise ImportError(f"{LIB_PATH}: options structs of the library ({_sizes[0]}, {_sizes[1]} bytes) differ from this binding "
+                      f"({C.sizeof(CaseOptions)}, {C.sizeof(QhdOptions)}): rebuild qgdsolver_amd/csrc")
+ABI_VERSION = int(_sizes[3])
 
 # enums of include/qgd_amd.h
 QGD_OK = 0

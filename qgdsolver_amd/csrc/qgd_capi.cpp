@@ -139,7 +139,7 @@ struct Workspace {
     // host -> device, stream-ordered on s; returns when the source may be reused
     void h2d(void* dst, const void* src, size_t n, hipStream_t s) {
         if (!n) return;
-        if (devAccessible(src)) { HIP_CHECK(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, s)); HIP_CHECK(hipStreamSynchronize(s)); return; }
+        if (devAccessible(src)) { HIP_CHECK(hipMemcpyAsync(dst, src, n, hipMemcpyDefault, s)); HIP_CHECK(hipStreamSynchronize(s)); return; }
         ensurePinned();
         int k = 0;
         for (size_t off = 0; off < n; off += CHUNK, k ^= 1) {
@@ -153,7 +153,7 @@ struct Workspace {
     // device -> host, after everything queued on s; returns when dst holds the data
     void d2h(void* dst, const void* src, size_t n, hipStream_t s) {
         if (!n) return;
-        if (devAccessible(dst)) { HIP_CHECK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, s)); HIP_CHECK(hipStreamSynchronize(s)); return; }
+        if (devAccessible(dst)) { HIP_CHECK(hipMemcpyAsync(dst, src, n, hipMemcpyDefault, s)); HIP_CHECK(hipStreamSynchronize(s)); return; }
         ensurePinned();
         HIP_CHECK(hipEventSynchronize(ev[0]));
         HIP_CHECK(hipEventSynchronize(ev[1]));
@@ -228,6 +228,8 @@ struct qgd_case_s {
     ImplView impl{};            // implicitDiffusion branch: its face / cell work arrays
     double* implWork = nullptr;
     int implIters[4] = {0, 0, 0, 0};
+    double implResid[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // initial, final normalised residual of the four solves of the last step
+    int64_t implUnconverged = 0;                      // steps since set_fields in which a solve stopped above implicitTol
     double* coef[4] = {nullptr, nullptr, nullptr, nullptr};  // device copies of non-uniform alphaQGD / ScQGD (cells, patch faces)
     double time = 0;
     int64_t steps = 0;
@@ -303,6 +305,20 @@ static Launcher launcherOf(qgd_case_s* c) {
 __attribute__((constructor)) static void qgdInitOpenMP() { setenv("KMP_BLOCKTIME", "0", 0); }
 
 static bool hasWedgeAndPrism(const HostMesh& m);
+
+// Tuning knobs of the measurement scripts (QGD_*): a value outside the supported set is an error, not a silent change of
+// code path.  allowed == nullptr: any integer in [lo, hi].
+static int envChoice(const char* name, int dflt, const int* allowed, int nAllowed, int lo = 0, int hi = 0) {
+    const char* e = std::getenv(name);
+    if (!e || !*e) return dflt;
+    char* end = nullptr;
+    const long v = std::strtol(e, &end, 10);
+    bool ok = end && *end == '\0';
+    if (ok && allowed) { ok = false; for (int i = 0; i < nAllowed; ++i) ok = ok || allowed[i] == v; }
+    else if (ok) ok = v >= lo && v <= hi;
+    if (!ok) throw std::invalid_argument(std::string(name) + "=" + e + " is not a supported value");
+    return (int)v;
+}
 
 // ---------------------------------------------------------------------------
 extern "C" {
@@ -401,6 +417,7 @@ int qgd_mesh_set_geometry(qgd_mesh_t mh, const double* Sf, const double* Cf, con
         const double* S = &m.Sf[3 * (size_t)f];
         m.magSf[f] = std::sqrt(S[0] * S[0] + S[1] * S[1] + S[2] * S[2]);
     }
+    m.userGeometry = true;
     m.computeDerived();
     return QGD_OK;
     QGD_CATCH
@@ -537,12 +554,18 @@ int qgd_device_create(qgd_mesh_t mh, int deviceId, qgd_device_t* out) {
         v.ie1 = s.ie1; v.ie2 = s.ie2; v.ie3 = s.ie3;
         v.nGeomD = m.nGeometricD;
         for (int k = 0; k < 3; ++k) v.emptyDir[k] = m.geometricD[k] < 0 ? 1 : 0;
-        { const char* e = std::getenv("QGD_XCD_RUN"); v.xcdRun = e ? std::atoi(e) : 16; }
-        { const char* e = std::getenv("QGD_FBLOCK"); v.fblock = e ? std::atoi(e) : 128; }
+        static const int kBlocks[] = {64, 128, 256}, kWaves[] = {2, 3, 4};
+        v.xcdRun = envChoice("QGD_XCD_RUN", 16, nullptr, 0, 0, 1 << 20);   // 0: one contiguous eighth of the tiles per XCD
+        v.fblock = envChoice("QGD_FBLOCK", 128, kBlocks, 3);
         v.hasOther = 0;
         for (int64_t f = 0; f < s.nIF; ++f) if (s.fkind[f] == FK_OTHER) { v.hasOther = 1; break; }
-        { const char* e = std::getenv("QGD_CBLOCK"); v.cblock = e ? std::atoi(e) : 256; }
-        { const char* e = std::getenv("QGD_PBLOCK"); v.pblock = e ? std::atoi(e) : 256; }
+        // Sf of a quadrilateral = (p3-p1) x (p4-p2) / 2 exactly (the triangle fan about any centre sums to it), and the
+        // kernel holds those differences already: 24 B per face less to stream.  Not when the caller supplied its own Sf.
+        static const int kOnOff[] = {0, 1};
+        v.tileWaves = envChoice("QGD_FT_WAVES", 3, kWaves, 3);
+        v.sGeo = (envChoice("QGD_SGEO", 0, kOnOff, 2) != 0 && !m.userGeometry && v.fblock == 128 && v.tileWaves == 3) ? 1 : 0;
+        v.cblock = envChoice("QGD_CBLOCK", 256, kBlocks, 3);
+        v.pblock = envChoice("QGD_PBLOCK", 256, kBlocks, 3);
         // upload + free each table in turn so the host peak stays at one table
         auto up = [&](auto& vec) { auto* p = a.upload(vec); std::decay_t<decltype(vec)>().swap(vec); return p; };
         {
@@ -556,7 +579,6 @@ int qgd_device_create(qgd_mesh_t mh, int deviceId, qgd_device_t* out) {
             const int64_t nTiles = t.fb ? (s.nIF + t.fb - 1) / t.fb : 0;
             if (t.fb != 0 && lds <= 65536 && 4 * (int64_t)t.spill.size() <= nTiles) {
                 v.tileLds = (int32_t)lds;
-                { const char* w = std::getenv("QGD_FT_WAVES"); v.tileWaves = w ? std::atoi(w) : 3; }
                 v.nTileSpill = (int32_t)t.spill.size(); v.tileSpill = up(t.spill);
                 v.tileOff = up(t.off); v.tileCells = up(t.cells); v.tileVerts = up(t.verts);
                 v.locC = up(t.locC); v.locV = reinterpret_cast<const uint2*>(up(t.locV));
@@ -1143,7 +1165,7 @@ int qgd_case_set_fields(qgd_case_t c, const double* U, const double* T, const do
     cleanup();
     c->phiwRegistered = true;  // createFaceFluxes.H registers "phiwStar" before the loop starts
     c->fieldsSet = true;
-    c->time = 0; c->steps = 0;
+    c->time = 0; c->steps = 0; c->implUnconverged = 0;
     return QGD_OK;
     QGD_CATCH
 }
@@ -1187,7 +1209,12 @@ static void stepAdvance(qgd_case_s* c, int part) {
     if (c->opt.implicitDiffusion) {
         // [QGDUEqn.H L54-75, QGDEEqn.H L53-64]: two linear solves inside the step (host-synchronised convergence checks)
         launchImplicitAdvance(c->stream(), m, c->view, c->impl, c->gas, c->bcDev, c->opt.implicitTol, c->opt.implicitMaxIter, c->implWork,
-                              c->implIters);
+                              c->implIters, c->implResid);
+        // a solve that ran out of iterations or broke down (d.Ad <= 0) leaves its last iterate, as OpenFOAM's PCG does; the
+        // caller can tell through qgd_case_implicit_info
+        bool bad = false;
+        for (int k = 0; k < 4; ++k) bad = bad || !(c->implResid[2 * k + 1] < c->opt.implicitTol || c->implResid[2 * k + 1] == 0.0);
+        if (bad) c->implUnconverged++;
         launchBoundaryUpdate(L, m, c->view, c->gas, c->bcDev, false, c->phiwRegistered, 0, nullptr, 0);
         return;
     }
@@ -1222,6 +1249,9 @@ int qgd_case_step_phase(qgd_case_t c, int phase) {
     if (!c) return fail(QGD_ERR_INVALID, "null case");
     if (!c->fieldsSet) return fail(QGD_ERR_INVALID, "qgd_case_step_phase: call qgd_case_set_fields first");
     HIP_CHECK(hipSetDevice(c->dev->deviceId));
+    if (c->opt.implicitDiffusion && (phase == 10 || phase == 11))
+        return fail(QGD_ERR_NOT_IMPLEMENTED, "qgd_case_step_phase: the implicitDiffusion branch advances in one piece (its linear solves span "
+                                            "all cells); use phases 0 and 1");
     if (phase == 0) stepAssemble(c);
     else if (phase == 1) stepAdvance(c, 0);
     else if (phase == 10) stepAdvance(c, 1);
@@ -1627,8 +1657,11 @@ int qgd_comm_create(int deviceId, int rank, int nRanks, const void* id128, qgd_c
 }
 int qgd_comm_free(qgd_comm_t c) {
     if (!c) return QGD_OK;
-    if (c->comm && rcclRef().commDestroy) (void)rcclRef().commDestroy(c->comm);
+    ncclResult_t r = ncclSuccess;
+    if (c->comm && rcclRef().commDestroy) r = rcclRef().commDestroy(c->comm);
     delete c;
+    if (r != ncclSuccess)
+        return fail(QGD_ERR_HIP, std::string("qgd_comm_free: ncclCommDestroy: ") + (rcclRef().errorString ? rcclRef().errorString(r) : "RCCL error"));
     return QGD_OK;
 }
 
@@ -1646,10 +1679,20 @@ static void ensureHaloBuffers(qgd_case_s* c) {
 // pack -> grouped send/recv -> unpack on `stream`
 static void haloExchangeOn(qgd_case_s* c, qgd_comm_s* comm, const int32_t* peers, int nSlots, hipStream_t stream) {
     qgd_device_s* d = c->dev;
+    const int n = std::min<int>(nSlots, (int)d->halo.size());
+    // RCCL matches the messages of one peer in issue order, and both sides issue in their own slot order: two slots towards
+    // the same rank (two ranks on a periodic cut, two disjoint interfaces with one neighbour) would land in each other's
+    // ghost lists.  Refused; a rank exchanging with itself (the one-GPU test of this path) is the one ordered exception.
+    for (int a = 0; a < n; ++a)
+        for (int b = a + 1; b < n; ++b)
+            if (peers[a] >= 0 && peers[a] == peers[b] && peers[a] != comm->rank)
+                throw std::invalid_argument("halo exchange: rank " + std::to_string(peers[a]) + " is the peer of two halo slots; "
+                                            "one slot per neighbouring rank (qgd_mesh_shard builds them that way)");
+    for (int s = 0; s < n; ++s)
+        if (peers[s] >= comm->nRanks) throw std::invalid_argument("halo exchange: peer rank out of range");
     ensureHaloBuffers(c);
     Launcher L = launcherOf(c);
     L.pre = nullptr; L.post = nullptr; L.stream = stream;
-    const int n = std::min<int>(nSlots, (int)d->halo.size());
     (void)hipGetLastError();
     for (int s = 0; s < n; ++s) {
         const qgd_device_s::HaloSlot& h = d->halo[s];
@@ -1658,12 +1701,17 @@ static void haloExchangeOn(qgd_case_s* c, qgd_comm_s* comm, const int32_t* peers
     }
     HIP_CHECK(hipGetLastError());
     RCCL_CHECK(rcclRef().groupStart());
-    for (int s = 0; s < n; ++s) {
-        const qgd_device_s::HaloSlot& h = d->halo[s];
-        if (peers[s] < 0) continue;
-        const size_t ns = 10 * (size_t)h.nSend + 12 * (size_t)h.nSendBF, nr = 10 * (size_t)h.nGhost + 12 * (size_t)h.nGhostBF;
-        if (ns) RCCL_CHECK(rcclRef().send(c->sendBuf[s], ns, ncclFloat64, peers[s], comm->comm, stream));
-        if (nr) RCCL_CHECK(rcclRef().recv(c->recvBuf[s], nr, ncclFloat64, peers[s], comm->comm, stream));
+    try {
+        for (int s = 0; s < n; ++s) {
+            const qgd_device_s::HaloSlot& h = d->halo[s];
+            if (peers[s] < 0) continue;
+            const size_t ns = 10 * (size_t)h.nSend + 12 * (size_t)h.nSendBF, nr = 10 * (size_t)h.nGhost + 12 * (size_t)h.nGhostBF;
+            if (ns) RCCL_CHECK(rcclRef().send(c->sendBuf[s], ns, ncclFloat64, peers[s], comm->comm, stream));
+            if (nr) RCCL_CHECK(rcclRef().recv(c->recvBuf[s], nr, ncclFloat64, peers[s], comm->comm, stream));
+        }
+    } catch (...) {
+        (void)rcclRef().groupEnd();   // never leave the group open behind a failed call: the next collective would join it
+        throw;
     }
     RCCL_CHECK(rcclRef().groupEnd());
     for (int s = 0; s < n; ++s) {
@@ -1827,6 +1875,25 @@ int qgd_case_info(qgd_case_t c, double info[6]) {
     info[5] = (double)c->steps;
     return QGD_OK;
     QGD_CATCH
+}
+
+int qgd_case_implicit_info(qgd_case_t c, double info[14]) {
+    if (!c || !info) return fail(QGD_ERR_INVALID, "null argument");
+    for (int k = 0; k < 4; ++k) {
+        info[k] = c->implIters[k];
+        info[4 + k] = c->implResid[2 * k];
+        info[8 + k] = c->implResid[2 * k + 1];
+    }
+    info[12] = (double)c->implUnconverged;
+    info[13] = c->opt.implicitDiffusion ? 1.0 : 0.0;
+    return QGD_OK;
+}
+
+int qgd_struct_sizes(int64_t sizes[4]) {
+    if (!sizes) return fail(QGD_ERR_INVALID, "null argument");
+    sizes[0] = (int64_t)sizeof(qgd_case_options); sizes[1] = (int64_t)sizeof(qgd_qhd_options);
+    sizes[2] = (int64_t)sizeof(qgd_poisson_control); sizes[3] = QGD_ABI_VERSION;
+    return QGD_OK;
 }
 
 // ---- measurement -------------------------------------------------------------------

@@ -51,6 +51,7 @@ struct MeshView {
     const int32_t* tileSpill; int32_t nTileSpill;   // tiles left to the gather kernel
     int32_t tileLds;         // dynamic LDS bytes of the largest tile
     int32_t tileWaves;       // waves per SIMD the staged kernel is compiled for (2, 3 or 4)
+    int32_t sGeo;            // 1: the 3-D GaussVolPoint kernels rebuild Sf of quadrilateral faces from the vertices (no Sf stream)
     const double* V; const double* hQGD; const uint8_t* ghost;
     const int32_t* bPatch; const double* hQGDb;
 };
@@ -161,7 +162,7 @@ struct ImplView {
     double *xE, *diagE, *rhsE;           // nC
 };
 void launchImplicitAdvance(hipStream_t s, const MeshView& m, const CaseView& c, const ImplView& iv, const GasModel& g, const PatchBCDev* bc,
-                           double tol, int maxIter, double* work, int iters[4]);
+                           double tol, int maxIter, double* work, int iters[4], double resid[8]);
 
 // ---- QHDFoam case resident on the device (qgd_qhd.hip) ---------------------------------------------------------------
 struct QhdView {

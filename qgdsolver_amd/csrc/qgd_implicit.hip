@@ -318,9 +318,9 @@ inline int gridOf(int64_t n) { return (int)((n + QGD_BLOCK - 1) / QGD_BLOCK); }
 }  // namespace
 
 // One implicit-diffusion advance after the flux assembly.  work: 6*nC + 3*ceil(nC/256) + 8 doubles.  iters[0..2] = U
-// components, iters[3] = e.
+// components, iters[3] = e; resid[2k], resid[2k+1] = initial and final normalised residual of solve k.
 void launchImplicitAdvance(hipStream_t s, const MeshView& m, const CaseView& c, const ImplView& iv, const GasModel& g, const PatchBCDev* bc,
-                           double tol, int maxIter, double* work, int iters[4]) {
+                           double tol, int maxIter, double* work, int iters[4], double resid[8]) {
     const int gc = gridOf(m.nC), gf = gridOf(m.nF), gb = gridOf(m.nBF);
     const size_t nC = (size_t)m.nC;
     double res[2];
@@ -329,9 +329,11 @@ void launchImplicitAdvance(hipStream_t s, const MeshView& m, const CaseView& c, 
     implCellUKernel<<<gc, QGD_BLOCK, 0, s>>>(m, c, iv, bc);
     for (int k = 0; k < 3; ++k) {
         iters[k] = 0;
+        resid[2 * k] = resid[2 * k + 1] = 0.0;
         const bool valid = !(m.nGeomD < 3 && m.emptyDir[k]);   // validComponents: empty directions are not solved (L0)
         if (!valid) continue;
         iters[k] = diagLaplacianPcg(s, m, iv.aU, iv.diagU + k * nC, iv.rhsU + k * nC, iv.xU + k * nC, work, tol, maxIter, res);
+        resid[2 * k] = res[0]; resid[2 * k + 1] = res[1];
     }
     implStoreUKernel<<<gc, QGD_BLOCK, 0, s>>>(m, c, iv);
     if (m.nBF) implBcUKernel<<<gb, QGD_BLOCK, 0, s>>>(m, c, bc);
@@ -339,6 +341,7 @@ void launchImplicitAdvance(hipStream_t s, const MeshView& m, const CaseView& c, 
     implSigmaKernel<<<gf, QGD_BLOCK, 0, s>>>(m, c, iv, bc);
     implCellEKernel<<<gc, QGD_BLOCK, 0, s>>>(m, c, iv, g, bc);
     iters[3] = diagLaplacianPcg(s, m, iv.aE, iv.diagE, iv.rhsE, iv.xE, work, tol, maxIter, res);
+    resid[6] = res[0]; resid[7] = res[1];
     implFinishKernel<<<gc, QGD_BLOCK, 0, s>>>(m, c, iv, g);
 }
 

@@ -486,7 +486,7 @@ __device__ __forceinline__ void gvp3FaceBody(const MeshView& m, const CaseView& 
     }
 }
 
-template <bool DBG, int FB>
+template <bool DBG, int FB, bool SGEO = false>
 __global__ __launch_bounds__(FB) __attribute__((amdgpu_waves_per_eu(QGD_F_WAVES_MIN, QGD_F_WAVES_MAX)))
 void faceFluxGvp3Kernel(const MeshView m, const CaseView c, const GasModel gm, const int adjustDt, const int32_t* __restrict__ tileList) {
     // tileList: the tiles the staged kernel below leaves to this one (nullptr: every tile)
@@ -501,7 +501,8 @@ void faceFluxGvp3Kernel(const MeshView m, const CaseView c, const GasModel gm, c
         // (1) streamed face data
         const double w = ldStream(m.w + f);
         const double hf = ldStream(m.hf + f);
-        const double S[3] = {ldStream(m.Sx + f), ldStream(m.Sy + f), ldStream(m.Sz + f)};
+        double S[3] = {0.0, 0.0, 0.0};
+        if (!SGEO || kind != 0) { S[0] = ldStream(m.Sx + f); S[1] = ldStream(m.Sy + f); S[2] = ldStream(m.Sz + f); }
         double msO = 1.0, dnO = 0.0;
         if (m.hasOther) { msO = m.magSf[f]; dnO = m.dn[f]; }
         // (2) gathered records (vertex 3 is clamped for triangles; unused there)
@@ -516,6 +517,7 @@ void faceFluxGvp3Kernel(const MeshView m, const CaseView c, const GasModel gm, c
 
         double coef[12], rVc;
         gvp3Coefs(kind, cO, cN, x0, x1, x2, x3, coef, rVc);
+        if (SGEO && kind == 0) { S[0] = 0.5 * coef[6]; S[1] = 0.5 * coef[7]; S[2] = 0.5 * coef[8]; }   // Sf = (p3-p1) x (p4-p2) / 2
         gvp3FaceBody<DBG>(m, c, gm, f, fp, kind, w, hf, S, Ao, An, Bo, Bn, q0, q1, q2, q3, coef, rVc, msO, dnO, adjustDt, cof, tauMin);
     }
     if (adjustDt) blockMaxMin<FB>(cof, tauMin, c.blkFace + 2 * (size_t)tile, false);
@@ -537,7 +539,7 @@ typedef double v2d __attribute__((ext_vector_type(2)));   // one 16-B piece
 #ifndef QGD_FT_WAVES_MAX
 #define QGD_FT_WAVES_MAX 3
 #endif
-template <int FB, int WAVES>
+template <int FB, int WAVES, bool SGEO = false>
 __global__ __launch_bounds__(FB) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
 void faceFluxGvp3TileKernel(const MeshView m, const CaseView c, const GasModel gm, const int adjustDt) {
     extern __shared__ v2d tileLds[];
@@ -563,7 +565,8 @@ void faceFluxGvp3TileKernel(const MeshView m, const CaseView c, const GasModel g
     const int kind = m.fkind[fl];
     const double w = ldStream(m.w + fl);
     const double hf = ldStream(m.hf + fl);
-    const double S[3] = {ldStream(m.Sx + fl), ldStream(m.Sy + fl), ldStream(m.Sz + fl)};
+    double S[3] = {0.0, 0.0, 0.0};
+    if (!SGEO || kind != 0) { S[0] = ldStream(m.Sx + fl); S[1] = ldStream(m.Sy + fl); S[2] = ldStream(m.Sz + fl); }
     double msO = 1.0, dnO = 0.0;
     if (m.hasOther) { msO = m.magSf[fl]; dnO = m.dn[fl]; }
     int idC[KC], idB[KB2], idV[KV];
@@ -614,6 +617,7 @@ void faceFluxGvp3TileKernel(const MeshView m, const CaseView c, const GasModel g
             const double4 cO = l3(sC, lo), cN = l3(sC, ln);
             const double4 x0 = l3(sX, v0), x1 = l3(sX, v1), x2 = l3(sX, v2), x3 = l3(sX, v3);
             gvp3Coefs(kind, cO, cN, x0, x1, x2, x3, coef, rVc);
+            if (SGEO && kind == 0) { S[0] = 0.5 * coef[6]; S[1] = 0.5 * coef[7]; S[2] = 0.5 * coef[8]; }   // Sf = (p3-p1) x (p4-p2) / 2
         }
         __builtin_amdgcn_sched_barrier(0);
         const RecA Ao = *reinterpret_cast<const RecA*>(sA + 3 * lo), An = *reinterpret_cast<const RecA*>(sA + 3 * ln);
@@ -1395,13 +1399,16 @@ static void launchFaceFluxT(const Launcher& L, int stencil, const MeshView& m, c
                 else if (m.fblock == 256) faceFluxGvp3TileKernel<256, 3><<<grid, QGD_BLOCK, m.tileLds, L.stream>>>(m, c, g, adj);
                 else if (m.tileWaves == 2) faceFluxGvp3TileKernel<128, 2><<<(m.nIF + 127) / 128, 128, m.tileLds, L.stream>>>(m, c, g, adj);
                 else if (m.tileWaves == 4) faceFluxGvp3TileKernel<128, 4><<<(m.nIF + 127) / 128, 128, m.tileLds, L.stream>>>(m, c, g, adj);
+                else if (m.sGeo) faceFluxGvp3TileKernel<128, 3, true><<<(m.nIF + 127) / 128, 128, m.tileLds, L.stream>>>(m, c, g, adj);
                 else faceFluxGvp3TileKernel<128, 3><<<(m.nIF + 127) / 128, 128, m.tileLds, L.stream>>>(m, c, g, adj);
                 if (m.nTileSpill > 0) {
-                    if (m.fblock == 64) faceFluxGvp3Kernel<false, 64><<<m.nTileSpill, 64, 0, L.stream>>>(m, c, g, adj, m.tileSpill);
+                    if (m.sGeo && m.fblock == 128 && m.tileWaves == 3) faceFluxGvp3Kernel<false, 128, true><<<m.nTileSpill, 128, 0, L.stream>>>(m, c, g, adj, m.tileSpill);
+                    else if (m.fblock == 64) faceFluxGvp3Kernel<false, 64><<<m.nTileSpill, 64, 0, L.stream>>>(m, c, g, adj, m.tileSpill);
                     else if (m.fblock == 256) faceFluxGvp3Kernel<false, 256><<<m.nTileSpill, 256, 0, L.stream>>>(m, c, g, adj, m.tileSpill);
                     else faceFluxGvp3Kernel<false, 128><<<m.nTileSpill, 128, 0, L.stream>>>(m, c, g, adj, m.tileSpill);
                 }
             } else if (m.fblock == 64) faceFluxGvp3Kernel<DBG, 64><<<(m.nIF + 63) / 64, 64, 0, L.stream>>>(m, c, g, adj, nullptr);
+            else if (m.fblock == 128 && m.sGeo && m.tileWaves == 3) faceFluxGvp3Kernel<DBG, 128, true><<<(m.nIF + 127) / 128, 128, 0, L.stream>>>(m, c, g, adj, nullptr);
             else if (m.fblock == 128) faceFluxGvp3Kernel<DBG, 128><<<(m.nIF + 127) / 128, 128, 0, L.stream>>>(m, c, g, adj, nullptr);
             else faceFluxGvp3Kernel<DBG, 256><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, adj, nullptr);
             break;

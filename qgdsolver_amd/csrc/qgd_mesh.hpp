@@ -43,6 +43,7 @@ struct HostMesh {
     std::vector<double> nonOrthDeltaCoeffs;  // nFaces  1/max(n.d, 0.05|d|)
     int32_t geometricD[3] = {1, 1, 1}; // -1 for the direction of empty patches
     int32_t nGeometricD = 3;
+    bool userGeometry = false;         // Sf, Cf, C, V came from the caller (qgd_mesh_set_geometry), not from the points
 
     // ---- cell-range sharding --------------------------------------------------
     // one slot per neighbouring shard: the local ghost cells refreshed from it and the local owned cells it needs,

@@ -654,12 +654,22 @@ PressureSolver* pressureSolverCreate(hipStream_t stream, const MeshView& m, cons
         S->m = m; S->stream = stream; S->refCell = refCell; S->precond = precond; S->bKind = bKind;
         { const char* e = std::getenv("QGD_MG_F32"); S->f32 = !e || std::atoi(e) != 0; }   // default: single-precision cycle
         // tuning knobs of the cycle (experiments; the defaults are what the tests and DESIGN.md's numbers use)
-        if (const char* e = std::getenv("QGD_MG_NU")) S->nu = std::max(1, std::atoi(e));
-        if (const char* e = std::getenv("QGD_MG_OC")) S->oc = std::atof(e);
-        if (const char* e = std::getenv("QGD_MG_OMEGA")) S->omega = std::atof(e);
-        if (const char* e = std::getenv("QGD_MG_COARSE_SWEEPS")) S->coarseSweeps = std::max(1, std::atoi(e));
-        int passes = 2;   // pairwise matching passes per level: aggregates of ~4 cells (3 passes = ~8 cells need twice the iterations)
-        if (const char* e = std::getenv("QGD_MG_PASSES")) passes = std::min(4, std::max(1, std::atoi(e)));
+        // out-of-range values are refused (an omega of 0 would stall the smoother silently)
+        auto knob = [](const char* name, double dflt, double lo, double hi) {
+            const char* e = std::getenv(name);
+            if (!e || !*e) return dflt;
+            char* end = nullptr;
+            const double v = std::strtod(e, &end);
+            if (!end || *end != '\0' || !(v >= lo && v <= hi))
+                throw std::invalid_argument(std::string(name) + "=" + e + " is outside [" + std::to_string(lo) + ", " + std::to_string(hi) + "]");
+            return v;
+        };
+        S->nu = (int)knob("QGD_MG_NU", S->nu, 1, 8);
+        S->oc = knob("QGD_MG_OC", S->oc, 0.5, 3.0);
+        S->omega = knob("QGD_MG_OMEGA", S->omega, 0.1, 1.0);
+        S->coarseSweeps = (int)knob("QGD_MG_COARSE_SWEEPS", S->coarseSweeps, 1, 1000);
+        // pairwise matching passes per level: 2 = aggregates of ~4 cells (3 passes = ~8 cells need twice the iterations)
+        const int passes = (int)knob("QGD_MG_PASSES", 2, 1, 4);
         const int nC = m.nC, nF = m.nF, nb = blocksOf(nC);
         S->a = S->alloc<double>(nF); S->gs = S->alloc<double>(std::max(m.nBF, 1));
         S->diag = S->alloc<double>(nC); S->rhs = S->alloc<double>(nC); S->r = S->alloc<double>(nC); S->z = S->alloc<double>(nC);

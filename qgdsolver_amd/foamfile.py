@@ -461,7 +461,8 @@ def read_case_setup(case_dir, time="0"):
     Entries read: constant/polyMesh; constant/thermophysicalProperties (mixture.specie.molWeight,
     thermodynamics.Cv|Cp, transport.mu/Pr; QGD{implicitDiffusion, QGDCoeffs, <model>Dict{ScQGD,PrQGD}} as in
     QGDThermo.C L48-82, QGDCoeffs.C L57-160, constScPrModel1.C L48-90); system/fvSchemes fvsc.default (fvsc.C L47-58);
-    system/controlDict deltaT/adjustTimeStep/maxCo/maxDeltaT (setDeltaT-QGDQHD.H); <time>/{U,T,p}.
+    system/controlDict deltaT/adjustTimeStep/maxCo/maxDeltaT (setDeltaT-QGDQHD.H); system/fvSolution solvers.{U,e}
+    tolerance/maxIter (implicitDiffusion only); <time>/{U,T,p}.
     """
     mesh = read_polymesh(os.path.join(case_dir, "constant", "polyMesh"))
     opt = {}
@@ -512,6 +513,22 @@ def read_case_setup(case_dir, time="0"):
     opt["maxCo"] = float(cd.get("maxCo", 1.0))
     opt["maxDeltaT"] = float(cd.get("maxDeltaT", 1e300))
     opt["cTau"] = float(cd.get("cTau", 0.75))
+
+    # the linear solves of the implicitDiffusion branch take fvSolution's controls of U and e [QGDUEqn.H L66, QGDEEqn.H
+    # L61: solve(...) looks up solvers.<field>]; the tighter of the two tolerances and the larger maxIter serve both
+    # (qgd_case_options has one pair).  OpenFOAM's defaults when an entry is absent: tolerance 1e-6, maxIter 1000.
+    fsol_path = os.path.join(case_dir, "system", "fvSolution")
+    if opt["implicitDiffusion"] and _exists(fsol_path):
+        solvers = read_dict(fsol_path).get("solvers", {})
+        tols, iters = [], []
+        for key, entry in solvers.items() if isinstance(solvers, dict) else ():
+            names = str(key).strip('"()').replace("|", " ").split()
+            if isinstance(entry, dict) and any(n in ("U", "e", "Ux", "Uy", "Uz") or n.startswith(("U.", "e.")) for n in names):
+                tols.append(float(entry.get("tolerance", 1e-6)))
+                iters.append(int(float(entry.get("maxIter", 1000))))
+        if tols:
+            opt["implicitTol"] = min(tols)
+            opt["implicitMaxIter"] = max(iters)
 
     U, bU = read_field(os.path.join(tdir, "U"), mesh)
     T, bT = read_field(os.path.join(tdir, "T"), mesh)

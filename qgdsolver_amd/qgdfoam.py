@@ -159,6 +159,14 @@ class QGDFoamCase:
         L.check(L.lib.qgd_case_info(self._h, a), "qgd_case_info")
         return dict(time=a[0], deltaT=a[1], CoNum=a[2], minRho=a[3], minE=a[4], steps=int(a[5]))
 
+    def implicit_info(self):
+        """the four linear solves of the implicitDiffusion branch in the last step (qgd_case_implicit_info)"""
+        a = (C.c_double * 14)()
+        L.check(L.lib.qgd_case_implicit_info(self._h, a), "qgd_case_implicit_info")
+        names = ("Ux", "Uy", "Uz", "e")
+        return dict(implicit=bool(a[13]), unconverged_steps=int(a[12]),
+                    solves={n: dict(iterations=int(a[k]), initial=a[4 + k], final=a[8 + k]) for k, n in enumerate(names)})
+
     # ---- halo ------------------------------------------------------------------
     def halo_count(self, slot):
         """doubles in the message sent to the neighbour behind halo slot ``slot``"""

@@ -173,3 +173,33 @@ def test_implicit_diffusion_refused_on_sharded_meshes():
         q.QGDFoamCase(dev, q.default_options(implicitDiffusion=1))
     assert ei.value.code == q._lib.ERR_NOT_IMPLEMENTED
     dev.close()
+
+
+@pytest.mark.parametrize("variant", ["hex", "jitter", "jitter+triangles"])
+@pytest.mark.parametrize("adjust", [0, 1])
+def test_bench_kernel_directly_against_the_oracle(variant, adjust):
+    """The kernel bench.py times (faceFluxGvp3TileKernel<128>: the records of a 128-face tile staged in LDS) against the oracle
+    with nothing in between: 20^3 cells, so that the tiles are full (facesPerTile == 128) and all but a few of them stay
+    inside the staged kernel -- asserted, not assumed --, 26 explicit steps with a fixed deltaT and with Courant control."""
+    mesh = q.PolyMesh.box(20, 20, 20)
+    if variant != "hex":
+        mesh.jitter(0.15, seed=2024)
+    if variant == "jitter+triangles":
+        mesh.split_quads(7)
+    dev = q.Device(mesh)
+    ft = dev.face_tiles()
+    assert ft["facesPerTile"] == 128 and ft["tiles"] == (mesh.nInternalFaces + 127) // 128, ft
+    assert 4 * ft["gatherTiles"] < ft["tiles"], ft
+    h = 1.0 / 20
+    opt = q.default_options(stencil="GaussVolPoint", deltaT=0.1 * h / 1.3, mu=1e-3, adjustTimeStep=adjust, maxCo=0.25)
+    gc = q.QGDFoamCase(dev, opt)
+    oc = OracleCase(oracle_mesh_of(mesh), opt)
+    U, T, p = cases.box_initial_fields(mesh.array("C").reshape(-1, 3))
+    gc.set_fields(U, T, p)
+    oc.set_fields(U, T, p)
+    gc.step(26)
+    oc.step(26)
+    compare_fields(gc, oc, ["rho", "U", "p", "e", "rhoE"], STATE_TOL, (variant, adjust, "26 steps"))
+    ig, io = gc.info(), oc.info()
+    assert abs(ig["deltaT"] - io["deltaT"]) <= 1e-11 * io["deltaT"] and abs(ig["time"] - io["time"]) <= 1e-11 * io["time"]
+    gc.close(); dev.close()

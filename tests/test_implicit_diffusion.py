@@ -117,3 +117,59 @@ def test_device_implicit_branch_matches_oracle(kind, stencil, bc_fn):
     ex = run_oracle(mesh, setup, fields, 12, **dict(opt, implicitDiffusion=0))
     assert np.abs(ex["U"] - ref["U"]).max() > 1e-6 * np.abs(ref["U"]).max()
     gc.close(); dev.close()
+
+
+@pytest.mark.gpu
+def test_step_phases_of_the_implicit_branch():
+    """phases 0 + 1 are qgd_case_step; the split advance (10 / 11) does not exist for the implicit branch -- it used to run
+    the whole advance twice -- and is refused"""
+    mesh = make_mesh("box654_jitter")
+    fields = cases.box_initial_fields(mesh.array("C").reshape(-1, 3))
+    opt = q.default_options(stencil="GaussVolPoint", deltaT=5e-4, mu=2e-2, implicitDiffusion=1, implicitTol=1e-13, implicitMaxIter=2000)
+    dev = q.Device(mesh)
+    a, b = q.QGDFoamCase(dev, opt), q.QGDFoamCase(dev, opt)
+    for c in (a, b):
+        mixed_bcs(c)
+        c.set_fields(*fields)
+    a.step(5)
+    for _ in range(5):
+        b.step_phase(0)
+        b.step_phase(1)
+    b.sync()
+    for f in ("rho", "U", "p", "e"):
+        assert np.array_equal(a.field(f), b.field(f)), f
+    assert a.info()["steps"] == b.info()["steps"] == 5
+    for phase in (10, 11):
+        with pytest.raises(q.QgdError) as ei:
+            b.step_phase(phase)
+        assert ei.value.code == L.ERR_NOT_IMPLEMENTED
+    a.close(); b.close(); dev.close()
+
+
+@pytest.mark.gpu
+def test_implicit_solves_report_their_convergence():
+    mesh = make_mesh("box654_jitter")
+    fields = cases.box_initial_fields(mesh.array("C").reshape(-1, 3))
+    dev = q.Device(mesh)
+    good = q.QGDFoamCase(dev, q.default_options(stencil="GaussVolPoint", deltaT=5e-4, mu=2e-2, implicitDiffusion=1, implicitTol=1e-12,
+                                                implicitMaxIter=500))
+    good.set_fields(*fields)
+    good.step(3)
+    ii = good.implicit_info()
+    assert ii["implicit"] and ii["unconverged_steps"] == 0
+    for name, s in ii["solves"].items():
+        assert 0 < s["iterations"] < 500 and s["final"] < 1e-12 <= s["initial"], (name, s)
+    # an iteration limit that cannot be met is counted, step by step, and the step still completes
+    starved = q.QGDFoamCase(dev, q.default_options(stencil="GaussVolPoint", deltaT=5e-4, mu=2e-2, implicitDiffusion=1, implicitTol=1e-14,
+                                                   implicitMaxIter=1))
+    starved.set_fields(*fields)
+    starved.step(3)
+    ii = starved.implicit_info()
+    assert ii["unconverged_steps"] == 3 and all(s["iterations"] == 1 for s in ii["solves"].values())
+    assert np.isfinite(starved.field("rho")).all()
+    # the explicit branch has nothing to report
+    ex = q.QGDFoamCase(dev, q.default_options(stencil="GaussVolPoint", deltaT=5e-4, mu=2e-2))
+    ex.set_fields(*fields)
+    ex.step(1)
+    assert not ex.implicit_info()["implicit"] and ex.implicit_info()["unconverged_steps"] == 0
+    good.close(); starved.close(); ex.close(); dev.close()

@@ -58,3 +58,21 @@ def test_self_exchange_moves_the_boundary_layers_through_rccl(overlapped):
     assert np.isfinite(rho).all() and np.array_equal(rho[0], rho[1]) and np.array_equal(rho[5], rho[4])
     assert case.info()["minRho"] > 0
     case.close(); dev.close(); comm.close()
+
+
+def test_two_slots_towards_one_other_rank_are_refused():
+    """RCCL matches the messages of a peer in issue order: two halo slots with the same (other) peer rank would land in each
+    other's ghost lists, so the exchange refuses them; so does a peer outside the communicator"""
+    comm = NativeComm(0)
+    mesh = q.PolyMesh.box(9, 8, 12, k_range=(3, 9))
+    dev = q.Device(mesh)
+    case = q.QGDFoamCase(dev, q.default_options(stencil="GaussVolPoint", deltaT=1e-3))
+    U, T, p = cases.box_initial_fields(mesh.array("C").reshape(-1, 3))
+    case.set_fields(U, T, p)
+    for peers in ([1, 1], [0, 5]):
+        with pytest.raises(q.QgdError) as ei:
+            comm.exchange(case, peers)
+        assert ei.value.code == q._lib.ERR_INVALID
+    comm.exchange(case, [0, 0])     # the communicator is still usable: no group was left open
+    case.sync()
+    case.close(); dev.close(); comm.close()
