@@ -317,7 +317,7 @@ int qgd_qhd_pressure(qgd_device_t d, const double* phiu, const double* phiwo, co
  * built once: the matrix does not change, QHDFoam never re-corrects its thermo inside the loop), QHDUEqn.H L36-84,
  * QHDTEqn.H L65-91, the reference level of p (L123-130).  Thermo: rhoConst + constTransport (uniform rho0, mu, Pr; the QHD
  * closures leave muQGD = alphauQGD = 0 [T0byGr_8C_source.html L62-72]), laminar; L0 discretisation assumed: Gauss linear
- * gradients, Gauss linear uncorrected laplacians, Euler ddt.  Unsharded meshes only. */
+ * gradients, Gauss linear uncorrected laplacians, Euler ddt.  Sharded meshes: see "the QHD case on a cell-range shard" below. */
 typedef struct qgd_qhd_options {
     int32_t stencil;          /* QGD_FVSC_*                                                                    */
     int32_t implicitDiffusion;/* must be 0                                                                     */
@@ -345,6 +345,35 @@ int qgd_qhd_case_get_field(qgd_qhd_case_t c, const char* name, double* out, int6
 /* info[0]=time, [1]=deltaT, [2..4]= iterations / initial / final normalised residual of the last pressure solve,
  * [5]=steps, [6]=multigrid levels, [7]=milliseconds of the last pressure solve */
 int qgd_qhd_case_info(qgd_qhd_case_t c, double info[8]);
+
+/* ---- the QHD case on a cell-range shard (qgd_mesh_box slabs, qgd_mesh_shard) ------------------------------------------------
+ * What the reference does through processor patches inside fvm::laplacian / PCG / fvc::grad under MPI
+ * [QHDpEqn_8H_source.html L35-47, QHDUEqn_8H_source.html L36-84] becomes, per step, with ONE rank per shard:
+ *   phase 0   flux assembly (updateFields.H, updateFluxes.H), p's boundary conditions, the rows of the pressure equation of the
+ *             owned cells, first residual                       -> all-reduce (SUM) control[0..3)
+ *   phase 1   normFactor                                        -> all-reduce control[3]
+ *   phase 2   first preconditioned residual, search direction   -> all-reduce control[4]; exchange message kind 2
+ *   repeat until qgd_qhd_case_solve_status says done (every rank sees the same flag: it is computed from reduced sums):
+ *     phase 3 A d, d.Ad                                         -> all-reduce control[5]
+ *     phase 4 x, r, z = M r, |r|, r.z                            -> all-reduce control[6..8)
+ *     phase 5 residual, iteration count, done?, new direction   -> exchange message kind 2
+ *   phase 6   p's boundary conditions after the solve           -> exchange message kind 1
+ *   phase 7   phi, QHDUEqn.H, QHDTEqn.H, U/T boundary conditions -> all-reduce control[8] (only when p needs a reference level)
+ *   phase 8   reference level of p, fvc::grad(U) of the new state -> exchange message kind 0
+ * and once after qgd_qhd_case_set_fields: exchange message kind 0 (the ghost cells' fvc::grad(U)).
+ * The preconditioner is the aggregation multigrid of each rank's own block (additive Schwarz: couplings to ghost cells stay in
+ * the diagonal), so the iteration count grows mildly with the number of shards; everything else is the unsharded arithmetic.
+ * control: 16 device doubles (qgd_qhd_case_control_ptr); message kinds: 0 = {U,T} + fvc::grad(U) per cell (13) and {U,T} per
+ * patch face (4), 1 = p per cell (1) and its patch value + gradient (2), 2 = the search direction per cell (1).
+ * pRefCell is a cell label of the UNSHARDED mesh.  All entries are stream-ordered on the device's stream. */
+int qgd_qhd_case_step_phase(qgd_qhd_case_t c, int phase);
+int qgd_qhd_case_control_ptr(qgd_qhd_case_t c, void** devicePtr);
+/* waits for the stream; status = {done (0 no, 1 converged or out of iterations, 2 breakdown), iterations, initial, final residual} */
+int qgd_qhd_case_solve_status(qgd_qhd_case_t c, double status[4]);
+int qgd_qhd_case_sync(qgd_qhd_case_t c);
+int qgd_qhd_case_halo_count(qgd_qhd_case_t c, int slot, int kind, int64_t* sendCount, int64_t* recvCount);
+int qgd_qhd_case_halo_pack(qgd_qhd_case_t c, int slot, int kind, double* sendBufDevice);
+int qgd_qhd_case_halo_unpack(qgd_qhd_case_t c, int slot, int kind, const double* recvBufDevice);
 
 /* ---- QGDFoam case ----------------------------------------------------------- */
 
@@ -484,6 +513,11 @@ int qgd_case_allreduce_max(qgd_case_t c, qgd_comm_t comm);
  * boundary layer is updated first and the exchange runs on the library's halo stream while the compute stream updates the
  * remaining cells; the next assembly waits for the unpack through an event.  Stream-ordered (qgd_case_stream_sync waits). */
 int qgd_case_step_sharded(qgd_case_t c, qgd_comm_t comm, const int32_t* peers, int nSlots, int overlapped);
+/* The QHD case over the same transport: one message of kind 0 / 1 / 2 per neighbouring rank (after qgd_qhd_case_set_fields:
+ * kind 0 once), and nSteps whole steps -- phases, ncclAllReduce of the control block, exchanges -- with no host wait except the
+ * run-ahead check of the pressure solve (the host reads the "done" flag of iteration i-2 before it queues iteration i). */
+int qgd_qhd_case_halo_exchange(qgd_qhd_case_t c, qgd_comm_t comm, const int32_t* peers, int nSlots, int kind);
+int qgd_qhd_case_step_sharded(qgd_qhd_case_t c, qgd_comm_t comm, const int32_t* peers, int nSlots, int32_t nSteps);
 
 /* ---- measurement ------------------------------------------------------------ */
 /* Kernel ids for qgd_case_kernel_time. */

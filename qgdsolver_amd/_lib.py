@@ -98,6 +98,15 @@ SIGNATURES = {
     "qgd_qhd_case_step": (C.c_int, [handle, C.c_int32]),
     "qgd_qhd_case_get_field": (C.c_int, [handle, C.c_char_p, c_double_p, C.c_int64]),
     "qgd_qhd_case_info": (C.c_int, [handle, c_double_p]),
+    "qgd_qhd_case_step_phase": (C.c_int, [handle, C.c_int]),
+    "qgd_qhd_case_control_ptr": (C.c_int, [handle, C.POINTER(C.c_void_p)]),
+    "qgd_qhd_case_solve_status": (C.c_int, [handle, c_double_p]),
+    "qgd_qhd_case_sync": (C.c_int, [handle]),
+    "qgd_qhd_case_halo_count": (C.c_int, [handle, C.c_int, C.c_int, c_int64_p, c_int64_p]),
+    "qgd_qhd_case_halo_pack": (C.c_int, [handle, C.c_int, C.c_int, C.c_void_p]),
+    "qgd_qhd_case_halo_unpack": (C.c_int, [handle, C.c_int, C.c_int, C.c_void_p]),
+    "qgd_qhd_case_halo_exchange": (C.c_int, [handle, handle, c_int32_p, C.c_int, C.c_int]),
+    "qgd_qhd_case_step_sharded": (C.c_int, [handle, handle, c_int32_p, C.c_int, C.c_int32]),
     "qgd_case_options_default": (C.c_int, [C.POINTER(CaseOptions)]),
     "qgd_case_create": (C.c_int, [handle, C.POINTER(CaseOptions), handle_p]),
     "qgd_case_free": (C.c_int, [handle]),

@@ -200,6 +200,18 @@ struct qgd_device_s {
     };
     std::vector<HaloSlot> halo;
     bool sharded() const { for (const HaloSlot& h : halo) if (h.nGhost || h.nSend) return true; return false; }
+    int32_t ownedBegin = 0, ownedEnd = 0;      // local labels of the owned cells (contiguous by construction of the shard builders)
+    std::vector<int32_t> cellGlobal;           // extracted shards: label in the unsharded mesh per local cell (ascending)
+    int64_t cellGlobalOffset = 0;              // box slabs: global label = local label + offset
+    // local label of a cell of the unsharded mesh, -1 when this shard does not OWN it
+    int32_t ownedLocalOf(int64_t globalCell) const {
+        int64_t local = -1;
+        if (!cellGlobal.empty()) {
+            auto it = std::lower_bound(cellGlobal.begin(), cellGlobal.end(), (int32_t)globalCell);
+            if (it != cellGlobal.end() && *it == globalCell) local = it - cellGlobal.begin();
+        } else local = globalCell - cellGlobalOffset;
+        return (local >= ownedBegin && local < ownedEnd) ? (int32_t)local : -1;
+    }
     int32_t* sendAll = nullptr;     // send cells of every slot (each cell once)
     int32_t* sendBFAll = nullptr;   // their real-patch boundary faces
     int32_t nSendAll = 0, nSendBFAll = 0;
@@ -547,6 +559,14 @@ int qgd_device_create(qgd_mesh_t mh, int deviceId, qgd_device_t* out) {
         d->wedgePrism = hasWedgeAndPrism(m);
         d->patches = m.patches;
         d->hf = s.hf;
+        const bool range = m.ownedEnd > m.ownedBegin;
+        d->ownedBegin = range ? m.ownedBegin : 0;
+        d->ownedEnd = range ? m.ownedEnd : m.nCells;
+        d->cellGlobal = m.cellGlobal;
+        d->cellGlobalOffset = m.cellGlobalOffset;
+        for (int32_t c = 0; c < m.nCells && !m.cellIsGhost.empty(); ++c)
+            if ((m.cellIsGhost[c] != 0) == (c >= d->ownedBegin && c < d->ownedEnd))
+                throw std::invalid_argument("qgd_device_create: the owned cells of a shard must be one contiguous label range");
         HIP_CHECK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
         DeviceArena& a = d->arena;
         MeshView& v = d->view;
@@ -563,7 +583,7 @@ int qgd_device_create(qgd_mesh_t mh, int deviceId, qgd_device_t* out) {
         // kernel holds those differences already: 24 B per face less to stream.  Not when the caller supplied its own Sf.
         static const int kOnOff[] = {0, 1};
         v.tileWaves = envChoice("QGD_FT_WAVES", 3, kWaves, 3);
-        v.sGeo = (envChoice("QGD_SGEO", 0, kOnOff, 2) != 0 && !m.userGeometry && v.fblock == 128 && v.tileWaves == 3) ? 1 : 0;
+        v.sGeo = (envChoice("QGD_SGEO", 1, kOnOff, 2) != 0 && !m.userGeometry && v.fblock == 128 && v.tileWaves == 3) ? 1 : 0;
         v.cblock = envChoice("QGD_CBLOCK", 256, kBlocks, 3);
         v.pblock = envChoice("QGD_PBLOCK", 256, kBlocks, 3);
         // upload + free each table in turn so the host peak stays at one table
@@ -1372,6 +1392,9 @@ struct qgd_qhd_case_s {
     uint8_t* bKind = nullptr;
     PressureSolver* solver = nullptr;
     bool needRef = false;
+    int localRefCell = -1;                 // local label of pRefCell when this shard owns it
+    std::vector<int32_t> bcPRequested;     // p kinds as the caller set them (a box slab's cut plane hides the patch's own kind)
+    std::vector<double*> sendBuf, recvBuf; // native transport: message buffers per halo slot (sized for the largest kind)
     double time = 0, lastIter = 0, lastRes0 = 0, lastRes = 0, lastSolveMs = 0;
     int64_t steps = 0;
 };
@@ -1389,7 +1412,6 @@ int qgd_qhd_case_create(qgd_device_t d, const qgd_qhd_options* opt, qgd_qhd_case
     QGD_TRY
     if (!d || !opt || !out) return fail(QGD_ERR_INVALID, "qgd_qhd_case_create: null argument");
     if (opt->implicitDiffusion) return fail(QGD_ERR_NOT_IMPLEMENTED, "implicitDiffusion true: only the explicit branch is on this path");
-    if (d->sharded()) return fail(QGD_ERR_NOT_IMPLEMENTED, "qgd_qhd_case_create: the QHD case (pressure equation, fvc::grad(U)) is not distributed");
     if (!(opt->rho0 > 0) || !(opt->Pr > 0) || !(opt->deltaT > 0) || opt->tauModel < 0 || opt->tauModel > 3)
         return fail(QGD_ERR_INVALID, "qgd_qhd_case_create: rho0, Pr, deltaT must be positive, tauModel in 0..3");
     int st = 0;
@@ -1401,7 +1423,7 @@ int qgd_qhd_case_create(qgd_device_t d, const qgd_qhd_options* opt, qgd_qhd_case
         c->dev = d; c->opt = *opt; c->stencil = st;
         c->usesPoints = (st == ST_GVP3 || st == ST_GVP2);
         const MeshView& v = d->view;
-        if (opt->pRefCell >= v.nC) { delete c; return fail(QGD_ERR_INVALID, "qgd_qhd_case_create: pRefCell out of range"); }
+        if (!d->sharded() && opt->pRefCell >= v.nC) { delete c; return fail(QGD_ERR_INVALID, "qgd_qhd_case_create: pRefCell out of range"); }
         DeviceArena& a = c->arena;
         QhdView& q = c->view;
         const size_t nC = (size_t)v.nC, nB = (size_t)std::max(v.nBF, 1), nF = (size_t)v.nF, nP = (size_t)std::max(v.nP, 1);
@@ -1415,6 +1437,7 @@ int qgd_qhd_case_create(qgd_device_t d, const qgd_qhd_options* opt, qgd_qhd_case
         for (int k = 0; k < 3; ++k) q.g[k] = opt->g[k];
         q.dt = opt->deltaT; q.tauModel = opt->tauModel; q.Tau = opt->Tau; q.aQGD = opt->aQGD; q.UQHD = opt->UQHD; q.T0 = opt->T0; q.Gr = opt->Gr;
         c->bc.resize(d->patches.size());
+        c->bcPRequested.assign(d->patches.size(), QGD_BC_ZEROGRADIENT);
         for (size_t i = 0; i < d->patches.size(); ++i) {
             PatchBCDev& b = c->bc[i];
             std::memset(&b, 0, sizeof(b));
@@ -1447,6 +1470,7 @@ int qgd_qhd_case_set_bc(qgd_qhd_case_t c, int32_t patch, int32_t bcU, const doub
     auto okP = [](int k) { return k == QGD_BC_ZEROGRADIENT || k == QGD_BC_FIXEDVALUE || k == QGD_BC_QGDFLUX || k == QGD_BC_QHDFLUX || k == QGD_BC_NONE; };
     if (!okU(bcU) || !okT(bcT) || !okP(bcP)) return fail(QGD_ERR_INVALID, "qgd_qhd_case_set_bc: unsupported boundary-condition kind");
     PatchBCDev& b = c->bc[patch];
+    c->bcPRequested[patch] = bcP;
     if (b.ptype == QGD_PATCH_EMPTY || b.ptype == QGD_PATCH_HALO) { bcU = bcT = bcP = QGD_BC_NONE; }
     b.bcU = bcU; b.bcT = bcT; b.bcP = bcP; b.vT = valueT; b.vP = valueP;
     if (valueU) for (int k = 0; k < 3; ++k) b.vU[k] = valueU[k];
@@ -1469,11 +1493,15 @@ int qgd_qhd_case_set_fields(qgd_qhd_case_t c, const double* U, const double* T, 
         int k = c->bc[ip].bcP;
         if (pt.type != QGD_PATCH_GENERIC) k = QGD_BC_NONE;
         const uint8_t kk = k == QGD_BC_FIXEDVALUE ? 1 : ((k == QGD_BC_QGDFLUX || k == QGD_BC_QHDFLUX) ? 2 : 0);
-        if (kk == 1 && pt.size > 0) anyFixed = true;
+        // "does p need a reference level" is a property of the WHOLE mesh: a fixedValue patch counts when it has faces anywhere
+        // (a shard may hold none of them; on an inner box slab the patch is the cut plane and only the caller's request is known)
+        const bool genericGlobally = pt.type == QGD_PATCH_GENERIC || (pt.type == QGD_PATCH_HALO && pt.globalSize >= 0 && d->cellGlobal.empty());
+        if (c->bcPRequested[ip] == QGD_BC_FIXEDVALUE && genericGlobally && pt.nonEmptyGlobally()) anyFixed = true;
         for (int32_t f = pt.start; f < pt.start + pt.size; ++f) kind[(size_t)(f - m.nIF)] = kk;
     }
     HIP_CHECK(hipMemcpy(c->bKind, kind.data(), kind.size(), hipMemcpyHostToDevice));
     c->needRef = !anyFixed && c->opt.pRefCell >= 0;
+    c->localRefCell = c->needRef ? (d->sharded() ? d->ownedLocalOf(c->opt.pRefCell) : c->opt.pRefCell) : -1;
     Workspace& ws = d->ws;
     double* dU = ws.get<double>(WS_CELL, 3 * (size_t)m.nC);
     double* dT = ws.get<double>(WS_A, (size_t)m.nC);
@@ -1487,37 +1515,150 @@ int qgd_qhd_case_set_fields(qgd_qhd_case_t c, const double* U, const double* T, 
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(d->stream));
     if (c->solver) { pressureSolverFree(c->solver); c->solver = nullptr; }
-    c->solver = pressureSolverCreate(d->stream, m, c->tbr, c->bKind, c->needRef ? c->opt.pRefCell : -1, c->opt.precond);
+    c->solver = pressureSolverCreate(d->stream, m, c->tbr, c->bKind, c->localRefCell, c->opt.precond, d->ownedBegin, d->ownedEnd);
     c->fieldsSet = true;
     c->time = 0; c->steps = 0;
     return QGD_OK;
     QGD_CATCH
+}
+// One step as stream-ordered phases (the exchanges of a sharded run go between them, see include/qgd_amd.h):
+//   0 flux assembly + rhs + first residual | 1 normFactor | 2 first preconditioned residual | 3, 4, 5 one PCG iteration |
+//   6 p's boundary conditions after the solve | 7 phi, the U and T equations | 8 reference level, fvc::grad(U) of the new state
+static void qhdPhase(qgd_qhd_case_s* c, int phase) {
+    qgd_device_s* d = c->dev;
+    const MeshView& m = d->view;
+    (void)hipGetLastError();
+    switch (phase) {
+        case 0:
+            launchQhdAssemble(d->stream, c->stencil, c->usesPoints, m, c->view, c->bcDev);
+            pressureSolveBegin(c->solver, c->view.phiu, c->view.phiwo, c->view.pb, c->view.pgb, c->opt.pTol, c->opt.pRelTol, c->opt.pMaxIter, c->view.p);
+            break;
+        case 1: case 2: case 3: case 4: case 5: pressureSolvePhase(c->solver, phase); break;
+        case 6: launchQhdPostSolve(d->stream, m, c->view, c->bcDev); break;
+        case 7:
+            pressureSolveFlux(c->solver, c->view.phi);
+            launchQhdAdvance(d->stream, c->stencil, c->usesPoints, m, c->view, c->bcDev, c->needRef, c->localRefCell, c->opt.pRefValue,
+                             pressureSolverCtl(c->solver) + 8);
+            break;
+        case 8:
+            launchQhdFinish(d->stream, m, c->view, c->needRef, pressureSolverCtl(c->solver) + 8);
+            c->time += c->opt.deltaT;
+            c->steps++;
+            break;
+        default: throw std::invalid_argument("qgd_qhd_case_step_phase: phase must be 0..8");
+    }
+    HIP_CHECK(hipGetLastError());
+}
+static void qhdReadStatus(qgd_qhd_case_s* c) {
+    double st[4];
+    pressureSolveStatus(c->solver, st);
+    c->lastIter = st[1]; c->lastRes0 = st[2]; c->lastRes = st[3];
+}
+// a whole step with the transport behind `hooks` (nullptr: one rank); haloState(kind) exchanges message kind 0 or 1
+static void qhdStepWith(qgd_qhd_case_s* c, const SolveHooks* hooks, const std::function<void(int)>& haloState) {
+    qhdPhase(c, 0);
+    HIP_CHECK(hipStreamSynchronize(c->dev->stream));   // one wait per step, so that lastSolveMs is the solve alone
+    const double t0 = nowMs();
+    double res[2];
+    c->lastIter = pressureSolveRun(c->solver, hooks, res);
+    c->lastRes0 = res[0]; c->lastRes = res[1];
+    c->lastSolveMs = nowMs() - t0;
+    qhdPhase(c, 6);
+    if (haloState) haloState(1);
+    qhdPhase(c, 7);
+    if (c->needRef && hooks && hooks->allreduce) hooks->allreduce(pressureSolverCtl(c->solver) + 8, 1);
+    qhdPhase(c, 8);
+    if (haloState) haloState(0);
 }
 int qgd_qhd_case_step(qgd_qhd_case_t c, int32_t nSteps) {
     QGD_TRY
     if (!c) return fail(QGD_ERR_INVALID, "null case");
     if (!c->fieldsSet) return fail(QGD_ERR_INVALID, "qgd_qhd_case_step: call qgd_qhd_case_set_fields first");
     qgd_device_s* d = c->dev;
+    if (d->sharded())
+        return fail(QGD_ERR_INVALID, "qgd_qhd_case_step: sharded mesh, drive it with qgd_qhd_case_step_phase + the exchanges, or qgd_qhd_case_step_sharded");
     HIP_CHECK(hipSetDevice(d->deviceId));
-    const MeshView& m = d->view;
-    for (int i = 0; i < nSteps; ++i) {
-        (void)hipGetLastError();
-        launchQhdAssemble(d->stream, c->stencil, c->usesPoints, m, c->view, c->bcDev);
-        HIP_CHECK(hipGetLastError());
-        double res[2] = {0, 0};
-        const double t0 = nowMs();
-        const int it = pressureSolve(c->solver, c->view.phiu, c->view.phiwo, c->view.pb, c->view.pgb, c->opt.pTol, c->opt.pRelTol, c->opt.pMaxIter,
-                                     c->view.p, c->view.phi, res);
-        HIP_CHECK(hipStreamSynchronize(d->stream));
-        c->lastSolveMs = nowMs() - t0;
-        c->lastIter = it; c->lastRes0 = res[0]; c->lastRes = res[1];
-        launchQhdAdvance(d->stream, c->stencil, c->usesPoints, m, c->view, c->bcDev, c->needRef ? c->opt.pRefCell : -1, c->opt.pRefValue, c->scratch);
-        HIP_CHECK(hipGetLastError());
-        c->time += c->opt.deltaT;
-        c->steps++;
-    }
+    for (int i = 0; i < nSteps; ++i) qhdStepWith(c, nullptr, nullptr);
     HIP_CHECK(hipStreamSynchronize(d->stream));
     return QGD_OK;
+    QGD_CATCH
+}
+int qgd_qhd_case_step_phase(qgd_qhd_case_t c, int phase) {
+    QGD_TRY
+    if (!c) return fail(QGD_ERR_INVALID, "null case");
+    if (!c->fieldsSet) return fail(QGD_ERR_INVALID, "qgd_qhd_case_step_phase: call qgd_qhd_case_set_fields first");
+    if (phase < 0 || phase > 8) return fail(QGD_ERR_INVALID, "qgd_qhd_case_step_phase: phase must be 0..8");
+    HIP_CHECK(hipSetDevice(c->dev->deviceId));
+    qhdPhase(c, phase);
+    return QGD_OK;   // stream-ordered: qgd_qhd_case_solve_status / qgd_qhd_case_sync wait
+    QGD_CATCH
+}
+int qgd_qhd_case_control_ptr(qgd_qhd_case_t c, void** devicePtr) {
+    if (!c || !devicePtr) return fail(QGD_ERR_INVALID, "null argument");
+    if (!c->solver) return fail(QGD_ERR_INVALID, "qgd_qhd_case_control_ptr: call qgd_qhd_case_set_fields first");
+    *devicePtr = pressureSolverCtl(c->solver);
+    return QGD_OK;
+}
+int qgd_qhd_case_solve_status(qgd_qhd_case_t c, double status[4]) {
+    QGD_TRY
+    if (!c || !status) return fail(QGD_ERR_INVALID, "null argument");
+    if (!c->solver) return fail(QGD_ERR_INVALID, "qgd_qhd_case_solve_status: call qgd_qhd_case_set_fields first");
+    HIP_CHECK(hipSetDevice(c->dev->deviceId));
+    pressureSolveStatus(c->solver, status);
+    c->lastIter = status[1]; c->lastRes0 = status[2]; c->lastRes = status[3];
+    return QGD_OK;
+    QGD_CATCH
+}
+int qgd_qhd_case_sync(qgd_qhd_case_t c) {
+    QGD_TRY
+    if (!c) return fail(QGD_ERR_INVALID, "null case");
+    HIP_CHECK(hipSetDevice(c->dev->deviceId));
+    HIP_CHECK(hipStreamSynchronize(c->dev->stream));
+    return QGD_OK;
+    QGD_CATCH
+}
+// halo messages: doubles per listed cell / per listed patch face of message kind 0 (state), 1 (p), 2 (search direction)
+static void qhdHaloWidths(int kind, int& perCell, int& perFace) {
+    perCell = kind == 0 ? 13 : 1;
+    perFace = kind == 0 ? 4 : (kind == 1 ? 2 : 0);
+}
+int qgd_qhd_case_halo_count(qgd_qhd_case_t c, int slot, int kind, int64_t* sendCount, int64_t* recvCount) {
+    if (!c || slot < 0 || kind < 0 || kind > 2 || !sendCount || !recvCount) return fail(QGD_ERR_INVALID, "bad argument");
+    *sendCount = *recvCount = 0;
+    if (slot >= (int)c->dev->halo.size()) return QGD_OK;
+    int pc, pf;
+    qhdHaloWidths(kind, pc, pf);
+    const qgd_device_s::HaloSlot& h = c->dev->halo[slot];
+    *sendCount = (int64_t)pc * h.nSend + (int64_t)pf * h.nSendBF;
+    *recvCount = (int64_t)pc * h.nGhost + (int64_t)pf * h.nGhostBF;
+    return QGD_OK;
+}
+static int qhdHaloMove(qgd_qhd_case_t c, int slot, int kind, double* buf, bool pack, hipStream_t stream) {
+    qgd_device_s* d = c->dev;
+    if (slot >= (int)d->halo.size()) return QGD_OK;
+    const qgd_device_s::HaloSlot& h = d->halo[slot];
+    const int32_t nCells = pack ? h.nSend : h.nGhost, nFaces = pack ? h.nSendBF : h.nGhostBF;
+    if (nCells + nFaces == 0) return QGD_OK;
+    if (!buf) return fail(QGD_ERR_INVALID, "null buffer");
+    if (kind == 2 && !c->solver) return fail(QGD_ERR_INVALID, "no solve in flight");
+    (void)hipGetLastError();
+    launchQhdHalo(stream, c->view, c->solver ? pressureSolverDirection(c->solver) : nullptr, kind, pack ? h.send : h.ghost, nCells,
+                  pack ? h.sendBF : h.ghostBF, nFaces, buf, pack);
+    HIP_CHECK(hipGetLastError());
+    return QGD_OK;
+}
+int qgd_qhd_case_halo_pack(qgd_qhd_case_t c, int slot, int kind, double* sendBufDevice) {
+    QGD_TRY
+    if (!c || slot < 0 || kind < 0 || kind > 2) return fail(QGD_ERR_INVALID, "bad argument");
+    HIP_CHECK(hipSetDevice(c->dev->deviceId));
+    return qhdHaloMove(c, slot, kind, sendBufDevice, true, c->dev->stream);
+    QGD_CATCH
+}
+int qgd_qhd_case_halo_unpack(qgd_qhd_case_t c, int slot, int kind, const double* recvBufDevice) {
+    QGD_TRY
+    if (!c || slot < 0 || kind < 0 || kind > 2) return fail(QGD_ERR_INVALID, "bad argument");
+    HIP_CHECK(hipSetDevice(c->dev->deviceId));
+    return qhdHaloMove(c, slot, kind, const_cast<double*>(recvBufDevice), false, c->dev->stream);
     QGD_CATCH
 }
 int qgd_qhd_case_get_field(qgd_qhd_case_t c, const char* name, double* out, int64_t outDoubles) {
@@ -1773,6 +1914,79 @@ int qgd_case_step_sharded(qgd_case_t c, qgd_comm_t comm, const int32_t* peers, i
     }
     HIP_CHECK(hipGetLastError());
     return QGD_OK;  // stream-ordered: qgd_case_stream_sync waits
+    QGD_CATCH
+}
+
+// ---- the QHD case over the library's own transport ----------------------------------------------------------------------
+// pack -> grouped send/recv -> unpack of message kind 0 (state), 1 (p) or 2 (search direction of the pressure solve) on the
+// device's stream; buffers owned by the case, sized once for the widest kind
+static void qhdHaloExchangeOn(qgd_qhd_case_s* c, qgd_comm_s* comm, const int32_t* peers, int nSlots, int kind) {
+    qgd_device_s* d = c->dev;
+    const int n = std::min<int>(nSlots, (int)d->halo.size());
+    for (int a = 0; a < n; ++a)
+        for (int b = a + 1; b < n; ++b)
+            if (peers[a] >= 0 && peers[a] == peers[b] && peers[a] != comm->rank)
+                throw std::invalid_argument("halo exchange: one slot per neighbouring rank");
+    for (int s2 = 0; s2 < n; ++s2)
+        if (peers[s2] >= comm->nRanks) throw std::invalid_argument("halo exchange: peer rank out of range");
+    if (c->sendBuf.size() != d->halo.size()) {
+        c->sendBuf.assign(d->halo.size(), nullptr);
+        c->recvBuf.assign(d->halo.size(), nullptr);
+        for (size_t s2 = 0; s2 < d->halo.size(); ++s2) {
+            const qgd_device_s::HaloSlot& h = d->halo[s2];
+            c->sendBuf[s2] = c->arena.alloc<double>(13 * (size_t)h.nSend + 4 * (size_t)h.nSendBF);
+            c->recvBuf[s2] = c->arena.alloc<double>(13 * (size_t)h.nGhost + 4 * (size_t)h.nGhostBF);
+        }
+    }
+    int pc, pf;
+    qhdHaloWidths(kind, pc, pf);
+    hipStream_t stream = d->stream;
+    for (int s2 = 0; s2 < n; ++s2)
+        if (peers[s2] >= 0 && qhdHaloMove(c, s2, kind, c->sendBuf[s2], true, stream) != QGD_OK) throw std::invalid_argument(g_lastError);
+    RCCL_CHECK(rcclRef().groupStart());
+    try {
+        for (int s2 = 0; s2 < n; ++s2) {
+            const qgd_device_s::HaloSlot& h = d->halo[s2];
+            if (peers[s2] < 0) continue;
+            const size_t ns = (size_t)pc * h.nSend + (size_t)pf * h.nSendBF, nr = (size_t)pc * h.nGhost + (size_t)pf * h.nGhostBF;
+            if (ns) RCCL_CHECK(rcclRef().send(c->sendBuf[s2], ns, ncclFloat64, peers[s2], comm->comm, stream));
+            if (nr) RCCL_CHECK(rcclRef().recv(c->recvBuf[s2], nr, ncclFloat64, peers[s2], comm->comm, stream));
+        }
+    } catch (...) { (void)rcclRef().groupEnd(); throw; }
+    RCCL_CHECK(rcclRef().groupEnd());
+    for (int s2 = 0; s2 < n; ++s2)
+        if (peers[s2] >= 0 && qhdHaloMove(c, s2, kind, c->recvBuf[s2], false, stream) != QGD_OK) throw std::invalid_argument(g_lastError);
+}
+int qgd_qhd_case_halo_exchange(qgd_qhd_case_t c, qgd_comm_t comm, const int32_t* peers, int nSlots, int kind) {
+    QGD_TRY
+    if (!c || kind < 0 || kind > 2) return fail(QGD_ERR_INVALID, "bad argument");
+    if (c->dev->halo.empty() || nSlots <= 0) return QGD_OK;
+    if (!comm || !peers) return fail(QGD_ERR_INVALID, "qgd_qhd_case_halo_exchange: null argument");
+    HIP_CHECK(hipSetDevice(c->dev->deviceId));
+    qhdHaloExchangeOn(c, comm, peers, nSlots, kind);
+    return QGD_OK;
+    QGD_CATCH
+}
+// one QHDFoam step of a sharded case [QHDFoam_8C L83-139]: the dot products of the pressure solve are ncclAllReduce of the
+// control block, its search direction and the states travel as grouped send/recv pairs; the only host waits are the
+// run-ahead checks of the solve (pressureSolveRun)
+int qgd_qhd_case_step_sharded(qgd_qhd_case_t c, qgd_comm_t comm, const int32_t* peers, int nSlots, int32_t nSteps) {
+    QGD_TRY
+    if (!c) return fail(QGD_ERR_INVALID, "null case");
+    if (!c->fieldsSet) return fail(QGD_ERR_INVALID, "qgd_qhd_case_step_sharded: call qgd_qhd_case_set_fields first");
+    qgd_device_s* d = c->dev;
+    const bool sharded = !d->halo.empty() && nSlots > 0;
+    if (sharded && (!comm || !peers)) return fail(QGD_ERR_INVALID, "qgd_qhd_case_step_sharded: null argument");
+    HIP_CHECK(hipSetDevice(d->deviceId));
+    SolveHooks hooks;
+    if (comm && comm->nRanks > 1)
+        hooks.allreduce = [&](double* ptr, int n) { RCCL_CHECK(rcclRef().allReduce(ptr, ptr, (size_t)n, ncclFloat64, ncclSum, comm->comm, d->stream)); };
+    if (sharded) hooks.haloDirection = [&]() { qhdHaloExchangeOn(c, comm, peers, nSlots, 2); };
+    std::function<void(int)> haloState;
+    if (sharded) haloState = [&](int kind) { qhdHaloExchangeOn(c, comm, peers, nSlots, kind); };
+    for (int i = 0; i < nSteps; ++i) qhdStepWith(c, &hooks, haloState);
+    HIP_CHECK(hipStreamSynchronize(d->stream));
+    return QGD_OK;
     QGD_CATCH
 }
 

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <functional>
 
 namespace qgd {
 
@@ -180,18 +181,40 @@ struct QhdView {
 void launchQhdInit(hipStream_t s, const MeshView& m, const QhdView& q, const PatchBCDev* bc, const double* U, const double* T, const double* p,
                    double* tauF, double* taubyrho);
 void launchQhdAssemble(hipStream_t s, int stencil, bool usesPoints, const MeshView& m, const QhdView& q, const PatchBCDev* bc);
-void launchQhdAdvance(hipStream_t s, int stencil, bool usesPoints, const MeshView& m, const QhdView& q, const PatchBCDev* bc, int refCell,
-                      double refValue, double* scratch);
+void launchQhdPostSolve(hipStream_t s, const MeshView& m, const QhdView& q, const PatchBCDev* bc);
+void launchQhdAdvance(hipStream_t s, int stencil, bool usesPoints, const MeshView& m, const QhdView& q, const PatchBCDev* bc, bool needRef,
+                      int localRefCell, double refValue, double* shift);
+void launchQhdFinish(hipStream_t s, const MeshView& m, const QhdView& q, bool needRef, const double* shift);
+// halo messages of a sharded QHD case: kind 0 = state {U,T} + grad(U) (13 per cell, 4 per patch face), 1 = p (1 per cell, 2 per
+// patch face), 2 = the search direction of the pressure solve (1 per cell)
+void launchQhdHalo(hipStream_t s, const QhdView& q, double* direction, int kind, const int32_t* cells, int nCells, const int32_t* bfaces, int nFaces,
+                   double* buf, bool pack);
 void launchQhdExtract(hipStream_t s, int64_t n, const double* rec4, int field, double* out);
 
 // persistent pressure solver: PCG preconditioned by aggregation multigrid (precond 1) or Jacobi (0); qgd_poisson.hip
 struct PressureSolver;
-PressureSolver* pressureSolverCreate(hipStream_t stream, const MeshView& m, const double* taubyrho, const uint8_t* bKind, int refCell, int precond);
+// ownedBegin/ownedEnd: the rows of the system, i.e. the owned cells of a shard (0, -1: every cell)
+PressureSolver* pressureSolverCreate(hipStream_t stream, const MeshView& m, const double* taubyrho, const uint8_t* bKind, int refCell, int precond,
+                                     int ownedBegin = 0, int ownedEnd = -1);
 void pressureSolverFree(PressureSolver* S);
 int64_t pressureSolverBytes(const PressureSolver* S);
 int pressureSolverLevels(const PressureSolver* S, int* sizes, int cap);
 int pressureSolve(PressureSolver* S, const double* phiu, const double* phiwo, const double* pb, const double* gb, double tolerance,
                   double relTol, int maxIter, double* p, double* phi, double residuals[2]);
+// the same solve as stream-ordered phases (qgd_poisson.hip): a sharded caller reduces the control block and exchanges the
+// ghost entries of the search direction between them
+struct SolveHooks {
+    std::function<void(double* devicePtr, int n)> allreduce;   // SUM over the ranks, in place, stream-ordered
+    std::function<void()> haloDirection;                       // ghost entries of pressureSolverDirection()
+};
+void pressureSolveBegin(PressureSolver* S, const double* phiu, const double* phiwo, const double* pb, const double* gb, double tolerance,
+                        double relTol, int maxIter, double* p);
+void pressureSolvePhase(PressureSolver* S, int phase);
+int pressureSolveRun(PressureSolver* S, const SolveHooks* hooks, double residuals[2]);
+void pressureSolveFlux(PressureSolver* S, double* phi);
+void pressureSolveStatus(PressureSolver* S, double out[4]);
+double* pressureSolverCtl(PressureSolver* S);         // control block: slots [0,3) [3] [4] [5] [6,8) [8] are the sums a sharded run reduces
+double* pressureSolverDirection(PressureSolver* S);   // nC doubles by local cell label
 
 int diagLaplacianPcg(hipStream_t stream, const MeshView& m, const double* a, const double* diag, const double* rhs, double* x,
                      double* work, double tolerance, int maxIter, double residuals[2]);

@@ -374,11 +374,17 @@ HostMesh makeBox(int32_t nx, int32_t ny, int32_t nzGlobal, int32_t kLo, int32_t 
             for (int64_t i = 0; i < nx; ++i) for (int64_t j = 0; j < ny; ++j) emit(i, j, k);
         }
         pt.size = (int32_t)(f - pt.start);
+        // a slab knows the patch sizes of the whole box (zMin / zMax are cut planes on the inner slabs, real patches of the box)
+        if (kLo > 0 || kHi < nzGlobal) pt.globalSize = side < 2 ? ny * nzGlobal : (side < 4 ? nx * nzGlobal : nx * ny);
         m.patches.push_back(pt);
     }
     // slab halo lists
     const bool cutLo = kLo > 0, cutHi = kHi < nzGlobal;
+    m.ownedBegin = 0; m.ownedEnd = (int32_t)nC;
     if (cutLo || cutHi) {
+        m.cellGlobalOffset = (int64_t)nx * ny * kLo;
+        m.ownedBegin = cutLo ? (int32_t)((int64_t)nx * ny) : 0;
+        m.ownedEnd = (int32_t)(nC - (cutHi ? (int64_t)nx * ny : 0));
         m.cellIsGhost.assign((size_t)nC, 0);
         m.haloGhost.assign(2, {});
         m.haloSend.assign(2, {});

@@ -21,6 +21,8 @@ struct Patch {
     int32_t type = 0;   // QGD_PATCH_*
     int32_t start = 0;  // global label of first face
     int32_t size = 0;
+    int32_t globalSize = -1;  // faces of this patch in the unsharded mesh (-1: this mesh is the whole mesh)
+    bool nonEmptyGlobally() const { return (globalSize >= 0 ? globalSize : size) > 0; }
 };
 
 struct HostMesh {
@@ -53,7 +55,8 @@ struct HostMesh {
     std::vector<uint8_t> cellIsGhost;  // nCells (empty when unsharded)
     // labels in the unsharded mesh (filled by extractShard, empty otherwise); faceGlobal is -1-label for flipped faces
     std::vector<int32_t> cellGlobal, faceGlobal, pointGlobal;
-    int32_t ownedBegin = 0, ownedEnd = 0;  // local label range of the owned cells of an extracted shard
+    int32_t ownedBegin = 0, ownedEnd = 0;  // local label range of the owned cells of a shard (extractShard, makeBox slabs)
+    int64_t cellGlobalOffset = 0;          // box slabs: global label = local label + offset (cellGlobal stays empty)
 
     int32_t nBoundaryFaces() const { return nFaces - nInternalFaces; }
     int32_t faceSize(int32_t f) const { return faceOffsets[f + 1] - faceOffsets[f]; }

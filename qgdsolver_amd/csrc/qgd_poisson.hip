@@ -35,6 +35,14 @@ struct PoissonView {
 
 #define PB 256
 
+// Control block of a solve (device doubles, PressureSolver::ctl): the sums that have to be global in a sharded run sit in
+// the front so that a caller all-reduces them in place between the phases; the rest is the loop's own state.  Once
+// C_DONE is set every kernel of the loop returns at once: the host may run ahead of the device without reading anything back.
+enum CtlSlot : int { C_ABSR = 0, C_SUMX = 1, C_N = 2, C_NORM = 3, C_RZ = 4, C_DQ = 5, C_ABSR2 = 6, C_RZNEW = 7, C_SHIFT = 8,
+                     C_RES = 9, C_RES0 = 10, C_DONE = 11, C_ITER = 12, C_ALPHA = 13, C_BETA = 14, C_NORMF = 15, C_COUNT = 16 };
+__device__ __forceinline__ bool solveDone(const double* __restrict__ ctl) { return ctl != nullptr && ctl[C_DONE] != 0.0; }
+
+
 __device__ __forceinline__ double blockSum(double v) {
     __shared__ double s[PB / 64];
 #pragma unroll
@@ -62,9 +70,9 @@ __global__ __launch_bounds__(PB) void coeffKernel(const MeshView m, const double
 // diagonal and source of one cell: its faces in ascending label order
 __global__ __launch_bounds__(PB) void assembleKernel(const MeshView m, const PoissonView v, const double* __restrict__ phiu,
                                                       const double* __restrict__ phiwo, const int refCell, double refValue,
-                                                      const double* __restrict__ refFrom) {
-    const int c = blockIdx.x * PB + threadIdx.x;
-    if (c >= m.nC) return;
+                                                      const double* __restrict__ refFrom, const int rowBegin = 0, const int rowEnd = -1) {
+    const int c = rowBegin + blockIdx.x * PB + threadIdx.x;
+    if (c >= (rowEnd < 0 ? m.nC : rowEnd)) return;
     const int n = m.cfCount[c];
     const size_t base = (size_t)m.cfSlice[c >> 6] * 64 + (c & 63);
     double diag = 0, rhs = 0;
@@ -92,10 +100,13 @@ __global__ __launch_bounds__(PB) void assembleKernel(const MeshView m, const Poi
 
 // y = A x, optionally the block partial sums of x.y (for p.Ap)
 __global__ __launch_bounds__(PB) void applyKernel(const MeshView m, const double* __restrict__ a, const double* __restrict__ diag,
-                                                   const double* __restrict__ x, double* __restrict__ y, double* __restrict__ part) {
-    const int c = blockIdx.x * PB + threadIdx.x;
+                                                   const double* __restrict__ x, double* __restrict__ y, double* __restrict__ part,
+                                                   const int rowBegin = 0, const int rowEnd = -1, const double* __restrict__ ctl = nullptr) {
+    // rows [rowBegin, rowEnd) (the owned cells of a shard; columns may be ghost cells); ctl: the solve's control block
+    if (solveDone(ctl)) return;
+    const int c = rowBegin + blockIdx.x * PB + threadIdx.x;
     double xy = 0;
-    if (c < m.nC) {
+    if (c < (rowEnd < 0 ? m.nC : rowEnd)) {
         const int n = m.cfCount[c];
         const size_t base = (size_t)m.cfSlice[c >> 6] * 64 + (c & 63);
         const double xc = x[c];
@@ -361,9 +372,10 @@ using MgLevelDev = MgLevelT<double>;   // the cycle in double; MgLevelT<float>: 
 // xout = xin + omega (b - A xin)/diag   (xin == nullptr: from zero, xout = omega b/diag);  rout (optional) = b - A xin
 template <typename T>
 __global__ __launch_bounds__(PB) void mgSmoothKernel(const MgLevelT<T> L, const T omega, const T* __restrict__ b,
-                                                     const T* __restrict__ xin, T* __restrict__ xout, T* __restrict__ rout) {
+                                                     const T* __restrict__ xin, T* __restrict__ xout, T* __restrict__ rout,
+                                                     const double* __restrict__ ctl = nullptr) {
     const int i = blockIdx.x * PB + threadIdx.x;
-    if (i >= L.n) return;
+    if (i >= L.n || solveDone(ctl)) return;
     const T d = L.diag[i];
     if (!xin) { xout[i] = omega * b[i] / d; return; }
     const T xi = xin[i];
@@ -378,15 +390,16 @@ __global__ __launch_bounds__(PB) void mgSmoothKernel(const MgLevelT<T> L, const 
 }
 // vectors between the double-precision CG and a single-precision cycle
 template <typename A, typename B>
-__global__ __launch_bounds__(PB) void mgConvertKernel(const int n, const A* __restrict__ in, B* __restrict__ out) {
+__global__ __launch_bounds__(PB) void mgConvertKernel(const int n, const A* __restrict__ in, B* __restrict__ out, const double* __restrict__ ctl = nullptr) {
     const int i = blockIdx.x * PB + threadIdx.x;
-    if (i < n) out[i] = (B)in[i];
+    if (i < n && !solveDone(ctl)) out[i] = (B)in[i];
 }
 // y = A x through the ELL rows of level 0 (the same matrix as applyKernel walks face by face: 150 instead of 266 us at 8 M rows),
 // block partial sums of x.y
 __global__ __launch_bounds__(PB) void mgApplyKernel(const MgLevelDev L, const double* __restrict__ x, double* __restrict__ y,
-                                                    double* __restrict__ part) {
+                                                    double* __restrict__ part, const double* __restrict__ ctl = nullptr) {
     const int i = blockIdx.x * PB + threadIdx.x;
+    if (solveDone(ctl)) return;
     double xy = 0;
     if (i < L.n) {
         const double xi = x[i];
@@ -403,25 +416,26 @@ __global__ __launch_bounds__(PB) void mgApplyKernel(const MgLevelDev L, const do
 }
 template <typename T>
 __global__ __launch_bounds__(PB) void mgRestrictKernel(const int nCoarse, const int* __restrict__ aggStart, const int* __restrict__ aggItems,
-                                                       const T* __restrict__ r, T* __restrict__ rc) {
+                                                       const T* __restrict__ r, T* __restrict__ rc, const double* __restrict__ ctl = nullptr) {
     const int I = blockIdx.x * PB + threadIdx.x;
-    if (I >= nCoarse) return;
+    if (I >= nCoarse || solveDone(ctl)) return;
     T s = 0;
     for (int k = aggStart[I]; k < aggStart[I + 1]; ++k) s += r[aggItems[k]];
     rc[I] = s;
 }
 template <typename T>
 __global__ __launch_bounds__(PB) void mgProlongKernel(const int n, const int* __restrict__ agg, const T oc, const T* __restrict__ ec,
-                                                      T* __restrict__ x) {
+                                                      T* __restrict__ x, const double* __restrict__ ctl = nullptr) {
     const int i = blockIdx.x * PB + threadIdx.x;
-    if (i < n) x[i] += oc * ec[agg[i]];
+    if (i < n && !solveDone(ctl)) x[i] += oc * ec[agg[i]];
 }
 // coarsest level: `sweeps` Jacobi sweeps by one workgroup (n <= MG_COARSE_MAX), the iterate in LDS
 #define MG_COARSE_MAX 1024
 template <typename T>
 __global__ __launch_bounds__(1024) void mgCoarseKernel(const MgLevelT<T> L, const T omega, const int sweeps, const T* __restrict__ b,
-                                                        T* __restrict__ x) {
+                                                        T* __restrict__ x, const double* __restrict__ ctl = nullptr) {
     __shared__ T xa[MG_COARSE_MAX], xb[MG_COARSE_MAX];
+    if (solveDone(ctl)) return;
     const int i = threadIdx.x;
     const bool on = i < L.n;
     const T d = on ? L.diag[i] : (T)1, bi = on ? b[i] : (T)0;
@@ -456,15 +470,21 @@ __global__ __launch_bounds__(1024) void mgCoarseKernel(const MgLevelT<T> L, cons
     }
     if (on) x[i] = cur[i];
 }
-// PCG pieces with a general preconditioner: after z = M r
-__global__ __launch_bounds__(PB) void dotKernel(const int n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ part) {
+// PCG pieces with a general preconditioner.  Vectors are indexed by local cell label; the rows of a solve are the owned cells
+// [ob, ob + n) (a shard's ghost cells lie outside that range and only ever appear as columns of the matrix product).
+__global__ __launch_bounds__(PB) void dotKernel(const int n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ part,
+                                                 const double* __restrict__ ctl) {
+    if (solveDone(ctl)) return;
     const int c = blockIdx.x * PB + threadIdx.x;
     const double t = blockSum(c < n ? a[c] * b[c] : 0.0);
     if (threadIdx.x == 0) part[blockIdx.x] = t;
 }
-// x += alpha d, r -= alpha q; partial sums [|r|]
-__global__ __launch_bounds__(PB) void axpyKernel(const int n, const double alpha, double* __restrict__ x, double* __restrict__ r,
-                                                  const double* __restrict__ d, const double* __restrict__ q, double* __restrict__ part) {
+// x += alpha d, r -= alpha q with alpha from the control block; partial sums [|r|]
+__global__ __launch_bounds__(PB) void axpyKernel(const int n, double* __restrict__ x, double* __restrict__ r,
+                                                  const double* __restrict__ d, const double* __restrict__ q, double* __restrict__ part,
+                                                  const double* __restrict__ ctl) {
+    if (solveDone(ctl)) return;
+    const double alpha = ctl[C_ALPHA];
     const int c = blockIdx.x * PB + threadIdx.x;
     double ar = 0;
     if (c < n) { x[c] += alpha * d[c]; const double rc = r[c] - alpha * q[c]; r[c] = rc; ar = fabs(rc); }
@@ -480,6 +500,63 @@ __global__ __launch_bounds__(PB) void residual0Kernel(const int n, const double*
     const double t0 = blockSum(ar), t1 = blockSum(xs);
     if (threadIdx.x == 0) { part[blockIdx.x] = t0; part[nBlocks + blockIdx.x] = t1; }
 }
+// normFactor pieces with xbar = (global sum of x) / (global number of rows) taken from the control block
+__global__ __launch_bounds__(PB) void normFactorCtlKernel(const int n, const double* __restrict__ ctl, const double* __restrict__ Ax,
+                                                           const double* __restrict__ A1, const double* __restrict__ b, double* __restrict__ part) {
+    const int c = blockIdx.x * PB + threadIdx.x;
+    const double xbar = ctl[C_SUMX] / ctl[C_N];
+    double v = 0;
+    if (c < n) { const double ref = xbar * A1[c]; v = fabs(Ax[c] - ref) + fabs(b[c] - ref); }
+    const double t = blockSum(v);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+// d = z + beta d (beta from the control block; first = 1: d = z)
+__global__ __launch_bounds__(PB) void directionCtlKernel(const int n, const int first, const double* __restrict__ z, double* __restrict__ d,
+                                                          const double* __restrict__ ctl) {
+    if (solveDone(ctl)) return;
+    const int c = blockIdx.x * PB + threadIdx.x;
+    if (c < n) d[c] = first ? z[c] : z[c] + ctl[C_BETA] * d[c];
+}
+// folds `count` rows of partials into ctl[first ...] (one workgroup, ascending order, four chains per thread)
+__global__ __launch_bounds__(PB) void foldCtlKernel(const double* __restrict__ part, const int nBlocks, const int count, double* __restrict__ ctl,
+                                                     const int first, const int always) {
+    if (!always && solveDone(ctl)) return;
+    for (int k = 0; k < count; ++k) {
+        const double* __restrict__ p = part + (size_t)k * nBlocks;
+        double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+        int i = threadIdx.x;
+        for (; i + 3 * PB < nBlocks; i += 4 * PB) { v0 += p[i]; v1 += p[i + PB]; v2 += p[i + 2 * PB]; v3 += p[i + 3 * PB]; }
+        for (; i < nBlocks; i += PB) v0 += p[i];
+        const double t = blockSum((v0 + v1) + (v2 + v3));
+        if (threadIdx.x == 0) ctl[first + k] = t;
+    }
+}
+// the loop's own bookkeeping, one thread each (what the host did between synchronisations before):
+// stage 0: start of a solve (local row count);  1: after the global normFactor: first residual, done?;
+// 2: after the global d.Ad: alpha or breakdown;  3: after the global |r|, r.z: residual, iteration count, done?, beta
+__global__ void ctlKernel(double* __restrict__ ctl, const int stage, const double nRows, const double tol, const double relTol, const int maxIter) {
+    if (stage == 0) {
+        ctl[C_N] = nRows; ctl[C_DONE] = 0.0; ctl[C_ITER] = 0.0; ctl[C_ALPHA] = 0.0; ctl[C_BETA] = 0.0; ctl[C_SHIFT] = 0.0;
+        ctl[C_RZ] = 0.0; ctl[C_DQ] = 0.0; ctl[C_ABSR2] = 0.0; ctl[C_RZNEW] = 0.0;
+    } else if (stage == 1) {
+        const double nf = ctl[C_NORM] + 1e-20;
+        const double res = ctl[C_ABSR] / nf;
+        ctl[C_NORMF] = nf; ctl[C_RES] = res; ctl[C_RES0] = res;
+        if (res < tol || maxIter <= 0) ctl[C_DONE] = 1.0;
+    } else if (ctl[C_DONE] == 0.0) {
+        if (stage == 2) {
+            const double dq = ctl[C_DQ], rz = ctl[C_RZ];
+            if (!(dq > 0) || !(rz > 0)) ctl[C_DONE] = 2.0;   // converged to round-off (or a singular system without reference)
+            else ctl[C_ALPHA] = rz / dq;
+        } else {
+            const double res = ctl[C_ABSR2] / ctl[C_NORMF];
+            const double it = ctl[C_ITER] + 1.0;
+            ctl[C_RES] = res; ctl[C_ITER] = it;
+            if (res < tol || (relTol > 0 && res < relTol * ctl[C_RES0]) || it >= (double)maxIter) ctl[C_DONE] = 1.0;
+            else { ctl[C_BETA] = ctl[C_RZNEW] / ctl[C_RZ]; ctl[C_RZ] = ctl[C_RZNEW]; }
+        }
+    }
+}
 
 }  // namespace
 
@@ -487,17 +564,26 @@ struct PressureSolver {
     MeshView m{};
     hipStream_t stream = nullptr;
     int refCell = -1, precond = 1;
+    int ob = 0, oe = 0;             // rows of the system: the owned cells [ob, oe) of the (possibly sharded) mesh
     double omega = 0.8, oc = 1.8;   // measured (8 M cells / 16 M irregular): 0.67 -> 0.8 with 4:1 coarsening 46 -> 24 / 52 -> 25 iterations
     int nu = 2, coarseSweeps = 40;
     std::vector<void*> owned;
     std::vector<MgLevelDev> L;
     std::vector<MgLevelT<float>> Lf;   // single-precision copy of the hierarchy (QGD_MG_F32; level 0 of L stays for the CG's own A x)
     bool f32 = false;
-    // finest-level vectors
+    // finest-level vectors, indexed by local cell label (ghost entries of d are filled by the caller's halo exchange)
     double *a = nullptr, *gs = nullptr, *diag = nullptr, *rhs = nullptr, *r = nullptr, *z = nullptr, *d = nullptr, *q = nullptr, *A1 = nullptr,
-           *ones = nullptr, *part = nullptr, *scal = nullptr;
+           *ones = nullptr, *part = nullptr;
+    double* ctl = nullptr;          // control block (CtlSlot)
+    double* hostCtl = nullptr;      // pinned mirror: 4 slots of C_COUNT doubles for the run-ahead check + 1 for the final read
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     const uint8_t* bKind = nullptr;
     int64_t bytes = 0;
+    // arguments of the solve in flight (set by phase 0)
+    const double *phiu = nullptr, *phiwo = nullptr, *pb = nullptr, *gb = nullptr;
+    double* p = nullptr;
+    double tol = 0, relTol = 0;
+    int maxIter = 0;
     // the V-cycle is a fixed sequence of ~75 small launches on fixed buffers (r -> z); with QGD_MG_GRAPH=1 it is captured once into
     // a hipGraph and replayed per CG iteration.  Measured: 5.11 -> 5.03 ms per step at 64^3, nothing at 128^3 / 200^3 (the
     // asynchronous launches were already hidden), and rocprofv3 crashes on the captured graph -- hence opt-in.
@@ -518,9 +604,11 @@ struct PressureSolver {
     ~PressureSolver() {
         if (cycleGraph) (void)hipGraphExecDestroy(cycleGraph);
         for (void* p : owned) (void)hipFree(p);
+        if (hostCtl) (void)hipHostFree(hostCtl);
+        for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
     }
 
-    // z = M r on level l (b -> x), in the precision of the level arrays
+    // z = M r on level l (b -> x), in the precision of the level arrays; every launch returns at once when the solve is done
     template <typename T>
     void vcycleT(std::vector<MgLevelT<T>>& Lv, size_t l, const T* b, T* x) {
         MgLevelT<T>& lv = Lv[l];
@@ -529,34 +617,60 @@ struct PressureSolver {
         const T* none = nullptr;
         T* noOut = nullptr;
         if (l + 1 == Lv.size()) {
-            if (lv.n <= MG_COARSE_MAX) mgCoarseKernel<T><<<1, 1024, 0, stream>>>(lv, om, coarseSweeps, b, x);
+            if (lv.n <= MG_COARSE_MAX) mgCoarseKernel<T><<<1, 1024, 0, stream>>>(lv, om, coarseSweeps, b, x, ctl);
             else {
                 T* cur = x; T* nxt = lv.x2;
-                mgSmoothKernel<T><<<nb, PB, 0, stream>>>(lv, om, b, none, cur, noOut);
-                for (int s = 1; s < coarseSweeps; ++s) { mgSmoothKernel<T><<<nb, PB, 0, stream>>>(lv, om, b, cur, nxt, noOut); std::swap(cur, nxt); }
+                mgSmoothKernel<T><<<nb, PB, 0, stream>>>(lv, om, b, none, cur, noOut, ctl);
+                for (int s = 1; s < coarseSweeps; ++s) { mgSmoothKernel<T><<<nb, PB, 0, stream>>>(lv, om, b, cur, nxt, noOut, ctl); std::swap(cur, nxt); }
                 if (cur != x) PCHECK(hipMemcpyAsync(x, cur, sizeof(T) * lv.n, hipMemcpyDeviceToDevice, stream));
             }
             return;
         }
         MgLevelT<T>& nx = Lv[l + 1];
         T* cur = x; T* nxt = lv.x2;
-        mgSmoothKernel<T><<<nb, PB, 0, stream>>>(lv, om, b, none, cur, noOut);
-        for (int s = 1; s < nu; ++s) { mgSmoothKernel<T><<<nb, PB, 0, stream>>>(lv, om, b, cur, nxt, noOut); std::swap(cur, nxt); }
-        mgSmoothKernel<T><<<nb, PB, 0, stream>>>(lv, om, b, cur, noOut, lv.r);           // r = b - A x
-        mgRestrictKernel<T><<<blocksOf(nx.n), PB, 0, stream>>>(nx.n, lv.aggStart, lv.aggItems, lv.r, nx.b);
+        mgSmoothKernel<T><<<nb, PB, 0, stream>>>(lv, om, b, none, cur, noOut, ctl);
+        for (int s = 1; s < nu; ++s) { mgSmoothKernel<T><<<nb, PB, 0, stream>>>(lv, om, b, cur, nxt, noOut, ctl); std::swap(cur, nxt); }
+        mgSmoothKernel<T><<<nb, PB, 0, stream>>>(lv, om, b, cur, noOut, lv.r, ctl);           // r = b - A x
+        mgRestrictKernel<T><<<blocksOf(nx.n), PB, 0, stream>>>(nx.n, lv.aggStart, lv.aggItems, lv.r, nx.b, ctl);
         vcycleT<T>(Lv, l + 1, nx.b, nx.x);
-        mgProlongKernel<T><<<nb, PB, 0, stream>>>(lv.n, lv.agg, over, nx.x, cur);
-        for (int s = 0; s < nu; ++s) { mgSmoothKernel<T><<<nb, PB, 0, stream>>>(lv, om, b, cur, nxt, noOut); std::swap(cur, nxt); }
+        mgProlongKernel<T><<<nb, PB, 0, stream>>>(lv.n, lv.agg, over, nx.x, cur, ctl);
+        for (int s = 0; s < nu; ++s) { mgSmoothKernel<T><<<nb, PB, 0, stream>>>(lv, om, b, cur, nxt, noOut, ctl); std::swap(cur, nxt); }
         if (cur != x) PCHECK(hipMemcpyAsync(x, cur, sizeof(T) * lv.n, hipMemcpyDeviceToDevice, stream));
     }
     void vcycle(size_t l, const double* b, double* x) {
         if (!Lf.empty() && l == 0) {
             // the cycle as a single-precision operator between double-precision CG vectors: half the bytes of every sweep
             const int nb = blocksOf(L[0].n);
-            mgConvertKernel<double, float><<<nb, PB, 0, stream>>>(L[0].n, b, Lf[0].b);
+            mgConvertKernel<double, float><<<nb, PB, 0, stream>>>(L[0].n, b, Lf[0].b, ctl);
             vcycleT<float>(Lf, 0, Lf[0].b, Lf[0].x);
-            mgConvertKernel<float, double><<<nb, PB, 0, stream>>>(L[0].n, Lf[0].x, x);
+            mgConvertKernel<float, double><<<nb, PB, 0, stream>>>(L[0].n, Lf[0].x, x, ctl);
         } else vcycleT<double>(L, l, b, x);
+    }
+    // z = M r over the owned rows (the multigrid hierarchy is built on the owned block: for a shard it is the additive-Schwarz
+    // block of this rank, couplings to ghost cells stay in the diagonal only)
+    void precondition() {
+        const int n = oe - ob, nb = blocksOf(n);
+        if (precond == 1 && !L.empty()) {
+            if (!cycleGraphTried) {
+                cycleGraphTried = true;
+                hipGraph_t g = nullptr;
+                if (std::getenv("QGD_MG_GRAPH") && hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                    bool ok = true;
+                    try { vcycle(0, r + ob, z + ob); } catch (...) { ok = false; }
+                    if (hipStreamEndCapture(stream, &g) != hipSuccess || !ok || !g) { g = nullptr; (void)hipGetLastError(); }
+                    if (g) {
+                        if (hipGraphInstantiate(&cycleGraph, g, nullptr, nullptr, 0) != hipSuccess) { cycleGraph = nullptr; (void)hipGetLastError(); }
+                        (void)hipGraphDestroy(g);
+                    }
+                }
+            }
+            if (cycleGraph) PCHECK(hipGraphLaunch(cycleGraph, stream));
+            else vcycle(0, r + ob, z + ob);
+        } else {
+            MgLevelDev jl; jl.n = n; jl.diag = diag + ob;
+            const double* none = nullptr; double* noOut = nullptr;
+            mgSmoothKernel<double><<<nb, PB, 0, stream>>>(jl, 1.0, r + ob, none, z + ob, noOut, ctl);   // z = r/diag
+        }
     }
 };
 
@@ -648,10 +762,12 @@ static void mgUploadLevel(PressureSolver* S, int n, const std::vector<int>& I, c
 }
 
 PressureSolver* pressureSolverCreate(hipStream_t stream, const MeshView& m, const double* taubyrho, const uint8_t* bKind, int refCell,
-                                     int precond) {
+                                     int precond, int ownedBegin, int ownedEnd) {
     PressureSolver* S = new PressureSolver();
     try {
         S->m = m; S->stream = stream; S->refCell = refCell; S->precond = precond; S->bKind = bKind;
+        S->ob = ownedBegin; S->oe = ownedEnd < 0 ? m.nC : ownedEnd;
+        if (S->ob < 0 || S->oe > m.nC || S->ob >= S->oe) throw std::invalid_argument("pressureSolverCreate: bad owned range");
         { const char* e = std::getenv("QGD_MG_F32"); S->f32 = !e || std::atoi(e) != 0; }   // default: single-precision cycle
         // tuning knobs of the cycle (experiments; the defaults are what the tests and DESIGN.md's numbers use)
         // out-of-range values are refused (an omega of 0 would stall the smoother silently)
@@ -670,31 +786,42 @@ PressureSolver* pressureSolverCreate(hipStream_t stream, const MeshView& m, cons
         S->coarseSweeps = (int)knob("QGD_MG_COARSE_SWEEPS", S->coarseSweeps, 1, 1000);
         // pairwise matching passes per level: 2 = aggregates of ~4 cells (3 passes = ~8 cells need twice the iterations)
         const int passes = (int)knob("QGD_MG_PASSES", 2, 1, 4);
-        const int nC = m.nC, nF = m.nF, nb = blocksOf(nC);
+        const int nC = m.nC, nF = m.nF, ob = S->ob, oe = S->oe, nRows = oe - ob, nb = blocksOf(nRows);
         S->a = S->alloc<double>(nF); S->gs = S->alloc<double>(std::max(m.nBF, 1));
         S->diag = S->alloc<double>(nC); S->rhs = S->alloc<double>(nC); S->r = S->alloc<double>(nC); S->z = S->alloc<double>(nC);
         S->d = S->alloc<double>(nC); S->q = S->alloc<double>(nC); S->A1 = S->alloc<double>(nC); S->ones = S->alloc<double>(nC);
-        S->part = S->alloc<double>(3 * (size_t)nb); S->scal = S->alloc<double>(8);
+        S->part = S->alloc<double>(3 * (size_t)std::max(nb, 1)); S->ctl = S->alloc<double>(C_COUNT);
+        PCHECK(hipHostMalloc((void**)&S->hostCtl, sizeof(double) * C_COUNT * 5, hipHostMallocDefault));
+        for (hipEvent_t& e : S->ev) PCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         coeffKernel<<<blocksOf(nF), PB, 0, stream>>>(m, taubyrho, S->a, S->gs);
         // static part of the matrix: diagonal (with the doubled reference row) from a zero-flux assembly
         PoissonView v{S->a, S->gs, bKind, S->rhs /*unused*/, S->rhs, S->diag, S->rhs};
         double* zeros = S->alloc<double>(nF);
         double* zb = S->alloc<double>(std::max(m.nBF, 1));
         v.pb = zb; v.gb = zb;
-        assembleKernel<<<nb, PB, 0, stream>>>(m, v, zeros, zeros, refCell, 0.0, nullptr);
-        fillKernel<<<nb, PB, 0, stream>>>(nC, 1.0, S->ones);
-        applyKernel<<<nb, PB, 0, stream>>>(m, S->a, S->diag, S->ones, S->A1, nullptr);
+        fillKernel<<<blocksOf(nC), PB, 0, stream>>>(nC, 1.0, S->diag);   // rows outside the owned range: identity (never used)
+        assembleKernel<<<nb, PB, 0, stream>>>(m, v, zeros, zeros, refCell, 0.0, nullptr, ob, oe);
+        fillKernel<<<blocksOf(nC), PB, 0, stream>>>(nC, 1.0, S->ones);
+        applyKernel<<<nb, PB, 0, stream>>>(m, S->a, S->diag, S->ones, S->A1, nullptr, ob, oe);
         PCHECK(hipStreamSynchronize(stream));
         if (precond == 1) {
-            std::vector<int> I((size_t)m.nIF), J((size_t)m.nIF);
-            std::vector<double> w((size_t)m.nIF), diag((size_t)nC);
+            // the hierarchy of the owned block: couplings between two owned cells (a shard's couplings to ghost cells stay in
+            // the diagonal: the block of an additive-Schwarz preconditioner)
+            std::vector<int> own((size_t)m.nIF), nei((size_t)m.nIF);
+            std::vector<double> wAll((size_t)m.nIF), dAll((size_t)nC);
             if (m.nIF) {
-                PCHECK(hipMemcpy(I.data(), m.own, sizeof(int) * (size_t)m.nIF, hipMemcpyDeviceToHost));
-                PCHECK(hipMemcpy(J.data(), m.nei, sizeof(int) * (size_t)m.nIF, hipMemcpyDeviceToHost));
-                PCHECK(hipMemcpy(w.data(), S->a, sizeof(double) * (size_t)m.nIF, hipMemcpyDeviceToHost));
+                PCHECK(hipMemcpy(own.data(), m.own, sizeof(int) * (size_t)m.nIF, hipMemcpyDeviceToHost));
+                PCHECK(hipMemcpy(nei.data(), m.nei, sizeof(int) * (size_t)m.nIF, hipMemcpyDeviceToHost));
+                PCHECK(hipMemcpy(wAll.data(), S->a, sizeof(double) * (size_t)m.nIF, hipMemcpyDeviceToHost));
             }
-            PCHECK(hipMemcpy(diag.data(), S->diag, sizeof(double) * (size_t)nC, hipMemcpyDeviceToHost));
-            int n = nC;
+            PCHECK(hipMemcpy(dAll.data(), S->diag, sizeof(double) * (size_t)nC, hipMemcpyDeviceToHost));
+            std::vector<int> I, J;
+            std::vector<double> w, diag(dAll.begin() + ob, dAll.begin() + oe);
+            I.reserve((size_t)m.nIF); J.reserve((size_t)m.nIF); w.reserve((size_t)m.nIF);
+            for (int f = 0; f < m.nIF; ++f)
+                if (own[f] >= ob && own[f] < oe && nei[f] >= ob && nei[f] < oe) { I.push_back(own[f] - ob); J.push_back(nei[f] - ob); w.push_back(wAll[f]); }
+            std::vector<int>().swap(own); std::vector<int>().swap(nei); std::vector<double>().swap(wAll); std::vector<double>().swap(dAll);
+            int n = nRows;
             mgUploadLevel(S, n, I, J, w, diag);
             while (n > 600 && S->L.size() < 12) {
                 std::vector<int> total((size_t)n);
@@ -733,92 +860,134 @@ int pressureSolverLevels(const PressureSolver* S, int* sizes, int cap) {
     for (size_t l = 0; l < S->L.size() && (int)l < cap; ++l) sizes[l] = S->L[l].n;
     return (int)S->L.size();
 }
+double* pressureSolverCtl(PressureSolver* S) { return S->ctl; }
+double* pressureSolverDirection(PressureSolver* S) { return S->d; }
 
-// One solve of QHDpEqn.H L36-47 with the persistent solver: rhs from the fluxes and the patch data, reference value read
-// from p itself (setReference(pRefCell, getRefCellValue(p, pRefCell))), PCG with the multigrid (or Jacobi) preconditioner,
-// phi = phiu - phiwo + pEqn.flux().  All pointers on the device.
-int pressureSolve(PressureSolver* S, const double* phiu, const double* phiwo, const double* pb, const double* gb, double tolerance,
-                  double relTol, int maxIter, double* p, double* phi, double residuals[2]) {
+// ---------------------------------------------------------------------------------------------------------------------
+// One solve of QHDpEqn.H L36-47 with the persistent solver, as stream-ordered phases with NO host synchronisation inside:
+// every scalar of the loop (alpha, beta, the residual, the iteration count, "done") lives in the control block on the device.
+// Between the phases a sharded caller all-reduces (SUM) the named slots of the control block in place and exchanges the
+// ghost entries of the search direction; a single rank just runs them back to back.
+//   phase 0  rhs from the fluxes and the patch data (reference value read from p itself: setReference(pRefCell,
+//            getRefCellValue(p, pRefCell))), q = A p, r = b - q              -> local {sum|r|, sum x, rows} in ctl[0..3)
+//   phase 1  normFactor pieces with the global xbar (L0: lduMatrix::solver::normFactor)   -> ctl[3]
+//   phase 2  first residual, done?; z = M r, d = z, r.z                     -> ctl[4];   then halo of d
+//   phase 3  q = A d, d.q                                                    -> ctl[5]
+//   phase 4  alpha (or breakdown), x += alpha d, r -= alpha q, z = M r, {sum|r|, r.z}   -> ctl[6..8)
+//   phase 5  residual, iteration count, done?, beta, d = z + beta d;       then halo of d
+// The preconditioner is applied before the convergence test of an iteration (one cycle more than the host-driven loop ran,
+// at the last iteration only) so that |r| and r.z travel in ONE reduction.
+// ---------------------------------------------------------------------------------------------------------------------
+void pressureSolveBegin(PressureSolver* S, const double* phiu, const double* phiwo, const double* pb, const double* gb, double tolerance,
+                        double relTol, int maxIter, double* p) {
+    S->phiu = phiu; S->phiwo = phiwo; S->pb = pb; S->gb = gb; S->tol = tolerance; S->relTol = relTol; S->maxIter = maxIter; S->p = p;
     const MeshView& m = S->m;
     hipStream_t stream = S->stream;
-    const int nC = m.nC, nF = m.nF, nb = blocksOf(nC);
+    const int ob = S->ob, oe = S->oe, n = oe - ob, nb = blocksOf(n);
     PoissonView v{S->a, S->gs, S->bKind, pb, gb, S->diag, S->rhs};
-    double h[4];
-    assembleKernel<<<nb, PB, 0, stream>>>(m, v, phiu, phiwo, S->refCell, 0.0, p);
-    applyKernel<<<nb, PB, 0, stream>>>(m, S->a, S->diag, p, S->q, nullptr);
-    residual0Kernel<<<nb, PB, 0, stream>>>(nC, S->rhs, S->q, p, S->r, S->part, nb);
-    foldKernel<<<1, PB, 0, stream>>>(S->part, nb, 2, S->scal);
-    PCHECK(hipMemcpyAsync(h, S->scal, 2 * sizeof(double), hipMemcpyDeviceToHost, stream));
-    PCHECK(hipStreamSynchronize(stream));
-    const double sumAbsR = h[0], xbar = h[1] / nC;
-    normFactorKernel<<<nb, PB, 0, stream>>>(nC, xbar, S->q, S->A1, S->rhs, S->part);
-    foldKernel<<<1, PB, 0, stream>>>(S->part, nb, 1, S->scal);
-    PCHECK(hipMemcpyAsync(h, S->scal, sizeof(double), hipMemcpyDeviceToHost, stream));
-    PCHECK(hipStreamSynchronize(stream));
-    const double normFactor = h[0] + 1e-20;
-    double res = sumAbsR / normFactor;
-    residuals[0] = res;
-    auto precondition = [&]() {   // z = M r
-        if (S->precond == 1 && !S->L.empty()) {
-            if (!S->cycleGraphTried) {
-                S->cycleGraphTried = true;
-                hipGraph_t g = nullptr;
-                if (std::getenv("QGD_MG_GRAPH") && hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-                    bool ok = true;
-                    try { S->vcycle(0, S->r, S->z); } catch (...) { ok = false; }
-                    if (hipStreamEndCapture(stream, &g) != hipSuccess || !ok || !g) { g = nullptr; (void)hipGetLastError(); }
-                    if (g) {
-                        if (hipGraphInstantiate(&S->cycleGraph, g, nullptr, nullptr, 0) != hipSuccess) { S->cycleGraph = nullptr; (void)hipGetLastError(); }
-                        (void)hipGraphDestroy(g);
-                    }
-                }
-            }
-            if (S->cycleGraph) PCHECK(hipGraphLaunch(S->cycleGraph, stream));
-            else S->vcycle(0, S->r, S->z);
-        } else {
-            MgLevelDev jl; jl.n = nC; jl.diag = S->diag;
-            const double* none = nullptr; double* noOut = nullptr;
-            mgSmoothKernel<double><<<nb, PB, 0, stream>>>(jl, 1.0, S->r, none, S->z, noOut);   // z = r/diag
-        }
-    };
-    auto dot = [&](const double* x, const double* y) {
-        dotKernel<<<nb, PB, 0, stream>>>(nC, x, y, S->part);
-        foldKernel<<<1, PB, 0, stream>>>(S->part, nb, 1, S->scal);
-        PCHECK(hipMemcpyAsync(h, S->scal, sizeof(double), hipMemcpyDeviceToHost, stream));
-        PCHECK(hipStreamSynchronize(stream));
-        return h[0];
-    };
-    int it = 0;
-    double rz = 0;
-    if (!(res < tolerance || (relTol > 0 && res < relTol * residuals[0])) && maxIter > 0) {
-        precondition();
-        PCHECK(hipMemcpyAsync(S->d, S->z, sizeof(double) * nC, hipMemcpyDeviceToDevice, stream));
-        rz = dot(S->r, S->z);
-    }
-    while (it < maxIter && !(res < tolerance || (relTol > 0 && res < relTol * residuals[0]))) {
-        if (S->precond == 1 && !S->L.empty()) mgApplyKernel<<<nb, PB, 0, stream>>>(S->L[0], S->d, S->q, S->part);
-        else applyKernel<<<nb, PB, 0, stream>>>(m, S->a, S->diag, S->d, S->q, S->part);
-        foldKernel<<<1, PB, 0, stream>>>(S->part, nb, 1, S->scal);
-        PCHECK(hipMemcpyAsync(h, S->scal, sizeof(double), hipMemcpyDeviceToHost, stream));
-        PCHECK(hipStreamSynchronize(stream));
-        const double dq = h[0];
-        if (!(dq > 0) || !(rz > 0)) break;
-        const double alpha = rz / dq;
-        axpyKernel<<<nb, PB, 0, stream>>>(nC, alpha, p, S->r, S->d, S->q, S->part);
-        foldKernel<<<1, PB, 0, stream>>>(S->part, nb, 1, S->scal);
-        PCHECK(hipMemcpyAsync(h, S->scal, sizeof(double), hipMemcpyDeviceToHost, stream));
-        PCHECK(hipStreamSynchronize(stream));
-        res = h[0] / normFactor;
-        ++it;
-        if (res < tolerance || (relTol > 0 && res < relTol * residuals[0])) break;
-        precondition();
-        const double rzNew = dot(S->r, S->z);
-        directionKernel<<<nb, PB, 0, stream>>>(nC, rzNew / rz, S->z, S->d);
-        rz = rzNew;
-    }
-    residuals[1] = res;
-    fluxKernel<<<blocksOf(nF), PB, 0, stream>>>(m, v, phiu, phiwo, p, phi);
+    ctlKernel<<<1, 1, 0, stream>>>(S->ctl, 0, (double)n, tolerance, relTol, maxIter);
+    assembleKernel<<<nb, PB, 0, stream>>>(m, v, phiu, phiwo, S->refCell, 0.0, p, ob, oe);
+    applyKernel<<<nb, PB, 0, stream>>>(m, S->a, S->diag, p, S->q, nullptr, ob, oe);
+    residual0Kernel<<<nb, PB, 0, stream>>>(n, S->rhs + ob, S->q + ob, p + ob, S->r + ob, S->part, nb);
+    foldCtlKernel<<<1, PB, 0, stream>>>(S->part, nb, 2, S->ctl, C_ABSR, 1);
     PCHECK(hipGetLastError());
+}
+void pressureSolvePhase(PressureSolver* S, int phase) {
+    const MeshView& m = S->m;
+    hipStream_t stream = S->stream;
+    const int ob = S->ob, oe = S->oe, n = oe - ob, nb = blocksOf(n);
+    double* ctl = S->ctl;
+    switch (phase) {
+        case 1:
+            normFactorCtlKernel<<<nb, PB, 0, stream>>>(n, ctl, S->q + ob, S->A1 + ob, S->rhs + ob, S->part);
+            foldCtlKernel<<<1, PB, 0, stream>>>(S->part, nb, 1, ctl, C_NORM, 1);
+            break;
+        case 2:
+            ctlKernel<<<1, 1, 0, stream>>>(ctl, 1, 0.0, S->tol, S->relTol, S->maxIter);
+            S->precondition();
+            directionCtlKernel<<<nb, PB, 0, stream>>>(n, 1, S->z + ob, S->d + ob, ctl);
+            dotKernel<<<nb, PB, 0, stream>>>(n, S->r + ob, S->z + ob, S->part, ctl);
+            foldCtlKernel<<<1, PB, 0, stream>>>(S->part, nb, 1, ctl, C_RZ, 0);
+            break;
+        case 3:
+            // unsharded: the ELL rows of multigrid level 0 are the whole matrix (150 instead of 266 us at 8 M rows); a shard walks
+            // its faces, whose neighbour columns include the ghost cells
+            if (S->precond == 1 && !S->L.empty() && ob == 0 && oe == m.nC) mgApplyKernel<<<nb, PB, 0, stream>>>(S->L[0], S->d, S->q, S->part, ctl);
+            else applyKernel<<<nb, PB, 0, stream>>>(m, S->a, S->diag, S->d, S->q, S->part, ob, oe, ctl);
+            foldCtlKernel<<<1, PB, 0, stream>>>(S->part, nb, 1, ctl, C_DQ, 0);
+            break;
+        case 4:
+            ctlKernel<<<1, 1, 0, stream>>>(ctl, 2, 0.0, S->tol, S->relTol, S->maxIter);
+            axpyKernel<<<nb, PB, 0, stream>>>(n, S->p + ob, S->r + ob, S->d + ob, S->q + ob, S->part, ctl);
+            S->precondition();
+            dotKernel<<<nb, PB, 0, stream>>>(n, S->r + ob, S->z + ob, S->part + nb, ctl);
+            foldCtlKernel<<<1, PB, 0, stream>>>(S->part, nb, 2, ctl, C_ABSR2, 0);
+            break;
+        case 5:
+            ctlKernel<<<1, 1, 0, stream>>>(ctl, 3, 0.0, S->tol, S->relTol, S->maxIter);
+            directionCtlKernel<<<nb, PB, 0, stream>>>(n, 0, S->z + ob, S->d + ob, ctl);
+            break;
+        default: throw std::invalid_argument("pressureSolvePhase: phase must be 1..5");
+    }
+    PCHECK(hipGetLastError());
+}
+// phi = phiu - phiwo + pEqn.flux() (after the ghost cells of p have been refreshed)
+void pressureSolveFlux(PressureSolver* S, double* phi) {
+    PoissonView v{S->a, S->gs, S->bKind, S->pb, S->gb, S->diag, S->rhs};
+    fluxKernel<<<blocksOf(S->m.nF), PB, 0, S->stream>>>(S->m, v, S->phiu, S->phiwo, S->p, phi);
+    PCHECK(hipGetLastError());
+}
+// {done (1 converged or out of iterations, 2 breakdown), iterations, initial, final normalised residual}; waits for the stream
+void pressureSolveStatus(PressureSolver* S, double out[4]) {
+    double* h = S->hostCtl + 4 * C_COUNT;
+    PCHECK(hipMemcpyAsync(h, S->ctl, sizeof(double) * C_COUNT, hipMemcpyDeviceToHost, S->stream));
+    PCHECK(hipStreamSynchronize(S->stream));
+    out[0] = h[C_DONE]; out[1] = h[C_ITER]; out[2] = h[C_RES0]; out[3] = h[C_RES];
+}
+// The loop of a solve after pressureSolveBegin, for callers that own the transport through two hooks (nullptr on one rank):
+// allreduce(ptr, n) sums n doubles at ptr over the ranks in place (stream-ordered), haloDirection() refreshes the ghost
+// entries of the search direction.  The host runs at most two iterations ahead of the device: it reads the "done" flag of
+// iteration i-2 before it queues iteration i, so the device never idles and at most two iterations of early-returning
+// launches are wasted.
+int pressureSolveRun(PressureSolver* S, const SolveHooks* hooks, double residuals[2]) {
+    hipStream_t stream = S->stream;
+    double* ctl = S->ctl;
+    auto reduce = [&](int first, int count) { if (hooks && hooks->allreduce) hooks->allreduce(ctl + first, count); };
+    auto halo = [&]() { if (hooks && hooks->haloDirection) hooks->haloDirection(); };
+    reduce(C_ABSR, 3);
+    pressureSolvePhase(S, 1);
+    reduce(C_NORM, 1);
+    pressureSolvePhase(S, 2);
+    reduce(C_RZ, 1);
+    halo();
+    const int ahead = 2;
+    for (int it = 0; it < S->maxIter; ++it) {
+        if (it >= ahead) {
+            const int slot = (it - ahead) & 3;
+            PCHECK(hipEventSynchronize(S->ev[slot]));
+            if (S->hostCtl[slot * C_COUNT + C_DONE] != 0.0) break;
+        }
+        pressureSolvePhase(S, 3);
+        reduce(C_DQ, 1);
+        pressureSolvePhase(S, 4);
+        reduce(C_ABSR2, 2);
+        pressureSolvePhase(S, 5);
+        halo();
+        const int slot = it & 3;
+        PCHECK(hipMemcpyAsync(S->hostCtl + slot * C_COUNT, ctl, sizeof(double) * C_COUNT, hipMemcpyDeviceToHost, stream));
+        PCHECK(hipEventRecord(S->ev[slot], stream));
+    }
+    double st[4];
+    pressureSolveStatus(S, st);
+    residuals[0] = st[2]; residuals[1] = st[3];
+    return (int)st[1];
+}
+// single rank, everything: rhs, solve, flux
+int pressureSolve(PressureSolver* S, const double* phiu, const double* phiwo, const double* pb, const double* gb, double tolerance,
+                  double relTol, int maxIter, double* p, double* phi, double residuals[2]) {
+    pressureSolveBegin(S, phiu, phiwo, pb, gb, tolerance, relTol, maxIter, p);
+    const int it = pressureSolveRun(S, nullptr, residuals);
+    pressureSolveFlux(S, phi);
     return it;
 }
 

@@ -104,6 +104,7 @@ __global__ __launch_bounds__(QGD_BLOCK) void qhdPressureBcKernel(const MeshView 
 __global__ __launch_bounds__(QGD_BLOCK) void qhdCellGradKernel(const MeshView m, const QhdView q) {
     const int c = blockIdx.x * QGD_BLOCK + threadIdx.x;
     if (c >= m.nC) return;
+    if (m.ghost && m.ghost[c] == 1) return;   // a ghost cell lacks faces here: its gradient arrives with the halo message
     const int n = m.cfCount[c];
     const size_t base = (size_t)m.cfSlice[c >> 6] * 64 + (c & 63);
     double G[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -268,7 +269,37 @@ __global__ __launch_bounds__(QGD_BLOCK) void qhdBcKernel(const MeshView m, const
 
 // p += pRefValue - p[pRefCell] when the field needs a reference level [QHDFoam.C L123-130]
 __global__ void qhdRefReadKernel(const QhdView q, const int refCell, const double refValue, double* __restrict__ shift) {
-    shift[0] = refValue - q.p[refCell];
+    shift[0] = refCell >= 0 ? refValue - q.p[refCell] : 0.0;   // refCell < 0: another shard owns it (the shifts are summed over the ranks)
+}
+// halo messages of a sharded QHD case.  kind 0: the state after a step, {Ux,Uy,Uz,T} + fvc::grad(U) (13 per cell), {U,T}
+// patch values (4 per patch face); kind 1: p (1 per cell), its patch value and gradient (2 per patch face); kind 2: the
+// search direction of the pressure solve (1 per cell)
+__global__ __launch_bounds__(QGD_BLOCK) void qhdHaloKernel(const QhdView q, double* __restrict__ dirn, const int kind, const int32_t* __restrict__ cells,
+                                                          const int nCells, const int32_t* __restrict__ bfaces, const int nFaces,
+                                                          double* __restrict__ buf, const int pack) {
+    const int i = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    if (i < nCells) {
+        const size_t c = (size_t)cells[i];
+        if (kind == 0) {
+            double* b = buf + (size_t)i * 13;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { if (pack) b[k] = q.c4[c * 4 + k]; else q.c4[c * 4 + k] = b[k]; }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) { if (pack) b[4 + k] = q.gUc[c * 9 + k]; else q.gUc[c * 9 + k] = b[4 + k]; }
+        } else if (kind == 1) { if (pack) buf[i] = q.p[c]; else q.p[c] = buf[i]; }
+        else { if (pack) buf[i] = dirn[c]; else dirn[c] = buf[i]; }
+    } else if (i < nCells + nFaces && kind != 2) {
+        const int j = i - nCells;
+        const size_t f = (size_t)bfaces[j];
+        if (kind == 0) {
+            double* b = buf + (size_t)nCells * 13 + (size_t)j * 4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { if (pack) b[k] = q.b4[f * 4 + k]; else q.b4[f * 4 + k] = b[k]; }
+        } else {
+            double* b = buf + (size_t)nCells + (size_t)j * 2;
+            if (pack) { b[0] = q.pb[f]; b[1] = q.pgb[f]; } else { q.pb[f] = b[0]; q.pgb[f] = b[1]; }
+        }
+    }
 }
 __global__ __launch_bounds__(QGD_BLOCK) void qhdRefShiftKernel(const int nC, const int nBF, const QhdView q, const double* __restrict__ shift) {
     const int i = blockIdx.x * QGD_BLOCK + threadIdx.x;
@@ -331,6 +362,7 @@ void launchQhdInit(hipStream_t s, const MeshView& m, const QhdView& q, const Pat
         qhdBcKernel<<<gridOf(m.nBF), QGD_BLOCK, 0, s>>>(m, q, bc);
         qhdPressureBcKernel<<<gridOf(m.nBF), QGD_BLOCK, 0, s>>>(m, q, bc);
     }
+    qhdCellGradKernel<<<gridOf(m.nC), QGD_BLOCK, 0, s>>>(m, q);
 }
 // everything of the step before the pressure equation
 void launchQhdAssemble(hipStream_t s, int stencil, bool usesPoints, const MeshView& m, const QhdView& q, const PatchBCDev* bc) {
@@ -346,15 +378,18 @@ void launchQhdAssemble(hipStream_t s, int stencil, bool usesPoints, const MeshVi
     }
     if (m.nBF) qhdPressureBcKernel<<<gridOf(m.nBF), QGD_BLOCK, 0, s>>>(m, q, bc);   // p.correctBoundaryConditions() [QHDpEqn.H L35]
 }
-// everything after it
-void launchQhdAdvance(hipStream_t s, int stencil, bool usesPoints, const MeshView& m, const QhdView& q, const PatchBCDev* bc, int refCell,
-                      double refValue, double* scratch) {
-    if (m.nBF) qhdPressureBcKernel<<<gridOf(m.nBF), QGD_BLOCK, 0, s>>>(m, q, bc);   // solve() ends in correctBoundaryConditions()
+// after the solve: solve() ends in correctBoundaryConditions() (a shard then sends p and these patch values to its neighbours)
+void launchQhdPostSolve(hipStream_t s, const MeshView& m, const QhdView& q, const PatchBCDev* bc) {
+    if (m.nBF) qhdPressureBcKernel<<<gridOf(m.nBF), QGD_BLOCK, 0, s>>>(m, q, bc);
+}
+// the U and T equations (phi must be there: pressureSolveFlux).  shift (device, 1 double) receives this rank's share of the
+// reference-level shift of p [QHDFoam.C L123-130]: pRefValue - p[refCell] on the rank that owns refCell (localRefCell >= 0), else 0
+void launchQhdAdvance(hipStream_t s, int stencil, bool usesPoints, const MeshView& m, const QhdView& q, const PatchBCDev* bc, bool needRef,
+                      int localRefCell, double refValue, double* shift) {
     if (usesPoints) {
         pointInterpFastKernel<1><<<gridOf(m.nP), QGD_BLOCK, 0, s>>>(m, q.p, q.ptp);
         if (m.nBP) boundaryPointKernel<1><<<gridOf(m.nBP), QGD_BLOCK, 0, s>>>(m, q.pb, 1, q.ptp, 1, 0);
     }
-    qhdCellGradKernel<<<gridOf(m.nC), QGD_BLOCK, 0, s>>>(m, q);
     switch (stencil) {
         case ST_REDUCED: face2<ST_REDUCED>(s, m, q, bc); break;
         case ST_LSQ: face2<ST_LSQ>(s, m, q, bc); break;
@@ -363,10 +398,18 @@ void launchQhdAdvance(hipStream_t s, int stencil, bool usesPoints, const MeshVie
     }
     qhdCellUpdateKernel<<<gridOf(m.nC), QGD_BLOCK, 0, s>>>(m, q);
     if (m.nBF) qhdBcKernel<<<gridOf(m.nBF), QGD_BLOCK, 0, s>>>(m, q, bc);
-    if (refCell >= 0) {
-        qhdRefReadKernel<<<1, 1, 0, s>>>(q, refCell, refValue, scratch);
-        qhdRefShiftKernel<<<gridOf((int64_t)m.nC + m.nBF), QGD_BLOCK, 0, s>>>(m.nC, m.nBF, q, scratch);
-    }
+    if (needRef) qhdRefReadKernel<<<1, 1, 0, s>>>(q, localRefCell, refValue, shift);
+}
+// end of the step: the (global) shift of p, then fvc::grad(U) of the new velocity for the next step's QHDUEqn.H L76 (computed here
+// so that a shard can send it along with the new state: a ghost cell's gradient cannot be formed locally)
+void launchQhdFinish(hipStream_t s, const MeshView& m, const QhdView& q, bool needRef, const double* shift) {
+    if (needRef) qhdRefShiftKernel<<<gridOf((int64_t)m.nC + m.nBF), QGD_BLOCK, 0, s>>>(m.nC, m.nBF, q, shift);
+    qhdCellGradKernel<<<gridOf(m.nC), QGD_BLOCK, 0, s>>>(m, q);
+}
+void launchQhdHalo(hipStream_t s, const QhdView& q, double* direction, int kind, const int32_t* cells, int nCells, const int32_t* bfaces, int nFaces,
+                   double* buf, bool pack) {
+    const int n = nCells + (kind == 2 ? 0 : nFaces);
+    if (n > 0) qhdHaloKernel<<<gridOf(n), QGD_BLOCK, 0, s>>>(q, direction, kind, cells, nCells, bfaces, kind == 2 ? 0 : nFaces, buf, pack ? 1 : 0);
 }
 void launchQhdExtract(hipStream_t s, int64_t n, const double* rec4, int field, double* out) {
     if (n) qhdExtractKernel<<<gridOf(n), QGD_BLOCK, 0, s>>>(n, rec4, field, out);
