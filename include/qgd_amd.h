@@ -349,8 +349,8 @@ int qgd_qhd_case_info(qgd_qhd_case_t c, double info[8]);
 /* ---- the QHD case on a cell-range shard (qgd_mesh_box slabs, qgd_mesh_shard) ------------------------------------------------
  * What the reference does through processor patches inside fvm::laplacian / PCG / fvc::grad under MPI
  * [QHDpEqn_8H_source.html L35-47, QHDUEqn_8H_source.html L36-84] becomes, per step, with ONE rank per shard:
- *   phase 0   flux assembly (updateFields.H, updateFluxes.H), p's boundary conditions, the rows of the pressure equation of the
- *             owned cells, first residual                       -> all-reduce (SUM) control[0..3)
+ *   phase 0   flux assembly (updateFields.H, updateFluxes.H), p's boundary conditions, fvc::grad(U) of the owned cells, the rows
+ *             of the pressure equation of the owned cells, first residual   -> all-reduce (SUM) control[0..3)
  *   phase 1   normFactor                                        -> all-reduce control[3]
  *   phase 2   first preconditioned residual, search direction   -> all-reduce control[4]; exchange message kind 2
  *   repeat until qgd_qhd_case_solve_status says done (every rank sees the same flag: it is computed from reduced sums):
@@ -359,15 +359,18 @@ int qgd_qhd_case_info(qgd_qhd_case_t c, double info[8]);
  *     phase 5 residual, iteration count, done?, new direction   -> exchange message kind 2
  *   phase 6   p's boundary conditions after the solve           -> exchange message kind 1
  *   phase 7   phi, QHDUEqn.H, QHDTEqn.H, U/T boundary conditions -> all-reduce control[8] (only when p needs a reference level)
- *   phase 8   reference level of p, fvc::grad(U) of the new state -> exchange message kind 0
- * and once after qgd_qhd_case_set_fields: exchange message kind 0 (the ghost cells' fvc::grad(U)).
+ *   phase 8   reference level of p                              -> exchange message kind 0
  * The preconditioner is the aggregation multigrid of each rank's own block (additive Schwarz: couplings to ghost cells stay in
  * the diagonal), so the iteration count grows mildly with the number of shards; everything else is the unsharded arithmetic.
- * control: 16 device doubles (qgd_qhd_case_control_ptr); message kinds: 0 = {U,T} + fvc::grad(U) per cell (13) and {U,T} per
- * patch face (4), 1 = p per cell (1) and its patch value + gradient (2), 2 = the search direction per cell (1).
+ * control: 16 device doubles (qgd_qhd_case_control_ptr); message kinds: 0 = the new state, {U,T} per cell (4) and per patch face
+ * (4); 1 = p + fvc::grad(U) per cell (1 + 9: a ghost cell's gradient cannot be formed locally, it lacks faces) and p's patch value
+ * + gradient per patch face (2); 2 = the search direction per cell (1).
  * pRefCell is a cell label of the UNSHARDED mesh.  All entries are stream-ordered on the device's stream. */
 int qgd_qhd_case_step_phase(qgd_qhd_case_t c, int phase);
 int qgd_qhd_case_control_ptr(qgd_qhd_case_t c, void** devicePtr);
+/* host copy of the control block out (set == 0) or in (set != 0), after everything queued so far: for transports that reduce on
+ * the host (MPI_Allreduce of 16 doubles, torch.distributed over gloo) */
+int qgd_qhd_case_control(qgd_qhd_case_t c, double control[16], int set);
 /* waits for the stream; status = {done (0 no, 1 converged or out of iterations, 2 breakdown), iterations, initial, final residual} */
 int qgd_qhd_case_solve_status(qgd_qhd_case_t c, double status[4]);
 int qgd_qhd_case_sync(qgd_qhd_case_t c);

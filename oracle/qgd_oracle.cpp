@@ -72,6 +72,7 @@ struct Mesh {
     // halo
     std::vector<ivec> haloGhost, haloSend;      // one entry per halo slot (neighbouring shard)
     std::vector<ivec> haloGhostBF, haloSendBF;  // boundary-face indices (global label - nIF)
+    dvec haloFaceH;                             // hQGDf of the halo-patch faces as the unsharded mesh has it, in patch order
     bool sharded() const { for (const ivec& g : haloGhost) if (!g.empty()) return true; return false; }
 
     int nBF() const { return nF - nIF; }
@@ -1801,6 +1802,12 @@ struct QhdCase {
         for (size_t ip = 0; ip < m.patches.size(); ++ip)
             if (!m.coupled((int)ip)) forPatchFaces((int)ip, [&](int gf, int, int) { hQGDf[gf] *= 2.0; });
         for (int f = 0; f < m.nF; ++f) if (!liveFace[f]) hQGDf[f] = 0.0;
+        {   // cut-plane faces are internal faces of the unsharded mesh: a ghost cell's hQGD needs their value THERE
+            size_t k = 0;
+            for (size_t ip = 0; ip < m.patches.size(); ++ip)
+                if (m.patches[ip].type == PATCH_HALO)
+                    for (int gf = m.patches[ip].start; gf < m.patches[ip].start + m.patches[ip].size && k < m.haloFaceH.size(); ++gf) hQGDf[gf] = m.haloFaceH[k++];
+        }
         for (int ci = 0; ci < m.nC; ++ci) {
             double hint = 0, surf = 0;
             for (int fid : m.cells[ci]) {
@@ -1849,6 +1856,7 @@ struct QhdCase {
         initTau();
         correctU(); correctT(); correctP();
         time = 0; steps = 0;
+        gUValid = false;
         return 0;
     }
     // L0 fvc::grad(U), Gauss linear, with gaussGrad::correctBoundaryConditions on the patch values
@@ -1975,6 +1983,238 @@ struct QhdCase {
         }
         ++steps;
     }
+
+    // ---- the same step as phases, for cell-range shards (one rank per shard) --------------------------------------------
+    // What OpenFOAM does through processor patches inside fvm::laplacian / PCG / fvc::grad under MPI [QHDpEqn.H L35-47,
+    // QHDUEqn.H L36-84]: between the phases the caller SUMS the named ctl slots over the ranks and exchanges the halo messages
+    // (kind 0: {U,T} per cell and patch face; kind 1: p + fvc::grad(U) per cell, p's patch value and gradient; kind 2: the
+    // search direction).  Same protocol, slots and message layouts as qgd_qhd_case_step_phase of include/qgd_amd.h.
+    // The preconditioner is Jacobi (local and exact under sharding), as in orc_qhd_pressure.
+    SurfField UgU_, BdFrcf_, Uf_, Tf_, phiTauTReg_, taubyrhof_;
+    VolField BdFrc_, gU_;
+    bool gUValid = false;
+    dvec pa_, pdiag_, prhs_, pr_, pz_, pd_, pq_, pA1_;
+    double ctl[16] = {0};
+    double normF_ = 0;
+    bool refSet = false, needRef_ = false;
+    int refLocal_ = -1;
+    std::vector<char> pkind_, liveB_;
+    bool isOwned(int c) const { return ghostFlag.empty() || !ghostFlag[c]; }
+    std::vector<char> ghostFlag;
+    void ensureShardInfo() {
+        if (ghostFlag.empty() && m.sharded()) {
+            ghostFlag.assign(m.nC, 0);
+            for (const ivec& gl : m.haloGhost) for (int g : gl) ghostFlag[g] = 1;
+        }
+        if (!refSet) {   // unsharded default: the rule of step()
+            bool anyFixed = false;
+            for (size_t ip = 0; ip < bc.size(); ++ip) anyFixed = anyFixed || (bc[ip].bcP == BC_FIXEDVALUE && m.patches[ip].size > 0 && m.patches[ip].type == PATCH_GENERIC);
+            needRef_ = !anyFixed && opt.pRefCell >= 0;
+            refLocal_ = needRef_ ? opt.pRefCell : -1;
+            refSet = true;
+        }
+    }
+    void applyA(const double* x, dvec& y) const {
+        for (int c = 0; c < m.nC; ++c) y[c] = pdiag_[c] * x[c];
+        for (int f = 0; f < m.nIF; ++f) { y[m.own[f]] -= pa_[f] * x[m.nei[f]]; y[m.nei[f]] -= pa_[f] * x[m.own[f]]; }
+    }
+    bool converged(double res) const { return res < opt.pTol || (opt.pRelTol > 0 && res < opt.pRelTol * ctl[10]); }
+    void phase(int ph) {
+        const int nC = m.nC, nF = m.nF, nB = m.nBF(), nIF = m.nIF;
+        const double dt = opt.deltaT;
+        const double rhof = opt.rho0, muf = opt.mu, alphaf = opt.mu / opt.Pr;
+        const double Hif = alphaf / rhof, nuf = muf / rhof;
+        ensureShardInfo();
+        if (ph == 0) {
+            gU_ = gaussGradV(U); gUValid = true;   // fvc::grad(U) of QHDUEqn.H L76 (ghost rows arrive with the pressure message)
+            // updateFields.H L36-73, updateFluxes.H L33-38 (as in step())
+            SurfField gradUf = stencil->gradV(U), gradTf = stencil->gradS(T);
+            Uf_ = linearInterpolate(m, U); Tf_ = linearInterpolate(m, T);
+            BdFrc_ = VolField(m, 3);
+            for (int c = 0; c < nC; ++c) for (int k = 0; k < 3; ++k) BdFrc_.in[3 * (size_t)c + k] = (opt.beta * T.in[c]) * opt.g[k];
+            for (int b = 0; b < nB; ++b) for (int k = 0; k < 3; ++k) BdFrc_.bf[3 * (size_t)b + k] = (opt.beta * T.bf[b]) * opt.g[k];
+            BdFrcf_ = linearInterpolate(m, BdFrc_);
+            UgU_ = SurfField(m, 3); taubyrhof_ = SurfField(m, 1); phiTauTReg_ = SurfField(m, 1);
+            for (int f = 0; f < nF; ++f) {
+                if (!liveFace[f]) continue;
+                const double* S = &m.Sf[3 * (size_t)f];
+                phiu.v[f] = dot3(S, &Uf_.v[3 * (size_t)f]);
+                VdotT(&Uf_.v[3 * (size_t)f], &gradUf.v[9 * (size_t)f], &UgU_.v[3 * (size_t)f]);
+                double wo[3];
+                for (int k = 0; k < 3; ++k) wo[k] = tauQGDf.v[f] * (UgU_.v[3 * (size_t)f + k] - BdFrcf_.v[3 * (size_t)f + k]);
+                phiwo.v[f] = dot3(S, wo);
+                taubyrhof_.v[f] = tauQGDf.v[f] / rhof;
+                phiTauTReg_.v[f] = tauQGDf.v[f] * phiu.v[f] * dot3(&Uf_.v[3 * (size_t)f], &gradTf.v[3 * (size_t)f]);
+            }
+            time += dt;
+            correctP();
+            // the pressure equation's rows [QHDpEqn.H L36-44], assembled like orc_qhd_pressure
+            pa_.assign(nF, 0.0); pdiag_.assign(nC, 0.0); prhs_.assign(nC, 0.0);
+            pkind_.assign(std::max(nB, 1), 0); liveB_.assign(std::max(nB, 1), 1);
+            for (size_t ip = 0; ip < m.patches.size(); ++ip) {
+                int k = bc[ip].bcP;
+                if (m.patches[ip].type != PATCH_GENERIC) k = BC_NONE;
+                const int kk = k == BC_FIXEDVALUE ? 1 : ((k == BC_QGDFLUX || k == BC_QHDFLUX) ? 2 : 0);
+                for (int f = m.patches[ip].start; f < m.patches[ip].start + m.patches[ip].size; ++f) {
+                    pkind_[f - nIF] = (char)kk;
+                    if (!m.patchHasFields((int)ip)) liveB_[f - nIF] = 0;
+                }
+            }
+            for (int f = 0; f < nF; ++f) pa_[f] = taubyrhof_.v[f] * m.magSf[f] * (f < nIF ? m.nonOrthDelta[f] : m.delta[f]);
+            for (int f = 0; f < nF; ++f) {
+                if (f >= nIF && !liveB_[f - nIF]) continue;
+                const double flux = phiu.v[f] - phiwo.v[f];
+                prhs_[m.own[f]] -= flux;
+                if (f < nIF) { prhs_[m.nei[f]] += flux; pdiag_[m.own[f]] += pa_[f]; pdiag_[m.nei[f]] += pa_[f]; }
+                else {
+                    const int b = f - nIF;
+                    if (pkind_[b] == 1) { pdiag_[m.own[f]] += pa_[f]; prhs_[m.own[f]] += pa_[f] * p.bf[b]; }
+                    else if (pkind_[b] == 2) prhs_[m.own[f]] += taubyrhof_.v[f] * m.magSf[f] * p.grad[b];
+                }
+            }
+            if (refLocal_ >= 0) { prhs_[refLocal_] += pdiag_[refLocal_] * p.in[refLocal_]; pdiag_[refLocal_] += pdiag_[refLocal_]; }
+            pr_.assign(nC, 0.0); pz_.assign(nC, 0.0); pd_.assign(nC, 0.0); pq_.assign(nC, 0.0); pA1_.assign(nC, 0.0);
+            applyA(p.in.data(), pq_);
+            for (double& x : ctl) x = 0.0;
+            for (int c = 0; c < nC; ++c) {
+                pr_[c] = prhs_[c] - pq_[c];
+                if (isOwned(c)) { ctl[0] += std::fabs(pr_[c]); ctl[1] += p.in[c]; ctl[2] += 1.0; }
+            }
+        } else if (ph == 1) {
+            dvec ones((size_t)nC, 1.0);
+            applyA(ones.data(), pA1_);
+            const double xbar = ctl[1] / ctl[2];
+            ctl[3] = 0.0;
+            for (int c = 0; c < nC; ++c) if (isOwned(c)) ctl[3] += std::fabs(pq_[c] - xbar * pA1_[c]) + std::fabs(prhs_[c] - xbar * pA1_[c]);
+        } else if (ph == 2) {
+            normF_ = ctl[3] + 1e-20;
+            ctl[9] = ctl[0] / normF_; ctl[10] = ctl[9];
+            ctl[11] = (ctl[9] < opt.pTol || opt.pMaxIter <= 0) ? 1.0 : 0.0;
+            ctl[12] = 0.0; ctl[4] = 0.0;
+            if (ctl[11] == 0.0)
+                for (int c = 0; c < nC; ++c) if (isOwned(c)) { pz_[c] = pr_[c] / pdiag_[c]; pd_[c] = pz_[c]; ctl[4] += pr_[c] * pz_[c]; }
+        } else if (ph == 3) {
+            if (ctl[11] != 0.0) return;
+            applyA(pd_.data(), pq_);
+            ctl[5] = 0.0;
+            for (int c = 0; c < nC; ++c) if (isOwned(c)) ctl[5] += pd_[c] * pq_[c];
+        } else if (ph == 4) {
+            if (ctl[11] != 0.0) return;
+            if (!(ctl[5] > 0) || !(ctl[4] > 0)) { ctl[11] = 2.0; return; }
+            const double alpha = ctl[4] / ctl[5];
+            ctl[13] = alpha; ctl[6] = 0.0; ctl[7] = 0.0;
+            for (int c = 0; c < nC; ++c) if (isOwned(c)) {
+                p.in[c] += alpha * pd_[c]; pr_[c] -= alpha * pq_[c]; pz_[c] = pr_[c] / pdiag_[c];
+                ctl[7] += pr_[c] * pz_[c]; ctl[6] += std::fabs(pr_[c]);
+            }
+        } else if (ph == 5) {
+            if (ctl[11] != 0.0) return;
+            ctl[9] = ctl[6] / normF_;
+            ctl[12] += 1.0;
+            if (converged(ctl[9]) || ctl[12] >= (double)opt.pMaxIter) { ctl[11] = 1.0; return; }
+            const double beta = ctl[7] / ctl[4];
+            ctl[14] = beta; ctl[4] = ctl[7];
+            for (int c = 0; c < nC; ++c) if (isOwned(c)) pd_[c] = pz_[c] + beta * pd_[c];
+        } else if (ph == 6) {
+            lastPIter = ctl[12]; lastPRes0 = ctl[10]; lastPRes = ctl[9];
+            correctP();   // fvMatrix::solve ends in correctBoundaryConditions()
+        } else if (ph == 7) {
+            for (int f = 0; f < nF; ++f) {   // phi = phiu - phiwo + pEqn.flux()
+                double corr = 0;
+                if (f < nIF) corr = -pa_[f] * (p.in[m.nei[f]] - p.in[m.own[f]]);
+                else {
+                    const int b = f - nIF;
+                    if (pkind_[b] == 1) corr = -pa_[f] * (p.bf[b] - p.in[m.own[f]]);
+                    else if (pkind_[b] == 2) corr = -taubyrhof_.v[f] * m.magSf[f] * p.grad[b];
+                }
+                phi.v[f] = (f < nIF || liveB_[f - nIF]) ? (phiu.v[f] - phiwo.v[f]) + corr : 0.0;
+            }
+            // QHDUEqn.H L36-84, QHDTEqn.H L65-91 (as in step(), with fvc::grad(U) kept from the end of the previous step)
+            SurfField gradPf = stencil->gradS(p);
+            SurfField pf = linearInterpolate(m, p);
+            const VolField& gU = gU_;
+            VolField gUT(m, 9);
+            for (int c = 0; c < nC; ++c) for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) gUT.in[9 * (size_t)c + 3 * i + j] = gU.in[9 * (size_t)c + 3 * j + i];
+            for (int b = 0; b < nB; ++b) for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) gUT.bf[9 * (size_t)b + 3 * i + j] = gU.bf[9 * (size_t)b + 3 * j + i];
+            SurfField gUTf = linearInterpolate(m, gUT);
+            SurfField snU = fvcSnGrad(m, U), snT = fvcSnGrad(m, T);
+            dvec FU(3 * (size_t)nF, 0.0), FT((size_t)nF, 0.0), Gp(3 * (size_t)nF, 0.0);
+            for (int f = 0; f < nF; ++f) {
+                if (!liveFace[f]) continue;
+                const double* S = &m.Sf[3 * (size_t)f];
+                double Wf[3], UW[9], uw[3], ext[3];
+                for (int k = 0; k < 3; ++k)
+                    Wf[k] = tauQGDf.v[f] * ((UgU_.v[3 * (size_t)f + k] + gradPf.v[3 * (size_t)f + k] / rhof) - BdFrcf_.v[3 * (size_t)f + k]);
+                outer(&Uf_.v[3 * (size_t)f], Wf, UW);
+                VdotT(S, UW, uw);
+                VdotT(S, &gUTf.v[9 * (size_t)f], ext);
+                for (int k = 0; k < 3; ++k) {
+                    const double phiUf = phi.v[f] * Uf_.v[3 * (size_t)f + k] - uw[k];
+                    const double lap = nuf * snU.v[3 * (size_t)f + k] * m.magSf[f];
+                    FU[3 * (size_t)f + k] = (phiUf - lap) - nuf * ext[k];
+                    Gp[3 * (size_t)f + k] = S[k] * pf.v[f];
+                }
+                FT[f] = (phi.v[f] * Tf_.v[f] - Hif * snT.v[f] * m.magSf[f]) - phiTauTReg_.v[f];
+            }
+            dvec sumU(3 * (size_t)nC, 0.0), sumT((size_t)nC, 0.0), sumG(3 * (size_t)nC, 0.0);
+            for (int f = 0; f < nF; ++f) {
+                if (!liveFace[f]) continue;
+                const int o = m.own[f];
+                for (int k = 0; k < 3; ++k) { sumU[3 * (size_t)o + k] += FU[3 * (size_t)f + k]; sumG[3 * (size_t)o + k] += Gp[3 * (size_t)f + k]; }
+                sumT[o] += FT[f];
+                if (f < m.nIF) {
+                    const int n = m.nei[f];
+                    for (int k = 0; k < 3; ++k) { sumU[3 * (size_t)n + k] -= FU[3 * (size_t)f + k]; sumG[3 * (size_t)n + k] -= Gp[3 * (size_t)f + k]; }
+                    sumT[n] -= FT[f];
+                }
+            }
+            for (int c = 0; c < nC; ++c) {
+                if (!isOwned(c)) continue;   // ghost cells are refreshed by the halo message
+                const double rV = 1.0 / m.V[c];
+                for (int k = 0; k < 3; ++k)
+                    U.in[3 * (size_t)c + k] += dt * ((-(sumU[3 * (size_t)c + k] * rV) - (sumG[3 * (size_t)c + k] * rV) / opt.rho0) + BdFrc_.in[3 * (size_t)c + k]);
+                T.in[c] += dt * (-(sumT[c] * rV));
+            }
+            correctU(); correctT();
+            ctl[8] = (needRef_ && refLocal_ >= 0) ? opt.pRefValue - p.in[refLocal_] : 0.0;   // QHDFoam.C L123-130, this rank's share
+        } else if (ph == 8) {
+            if (needRef_) {
+                for (double& x : p.in) x += ctl[8];
+                for (int b = 0; b < nB; ++b) p.bf[b] += ctl[8];
+            }
+            ++steps;
+        }
+    }
+    int haloWidth(int kind, bool face) const { return face ? (kind == 0 ? 4 : (kind == 1 ? 2 : 0)) : (kind == 0 ? 4 : (kind == 1 ? 10 : 1)); }
+    int64_t haloCount(int side, int kind, bool recv) const {
+        if (side < 0 || (size_t)side >= m.haloGhost.size()) return 0;
+        const ivec& cells = recv ? m.haloGhost[side] : m.haloSend[side];
+        const ivec& faces = recv ? m.haloGhostBF[side] : m.haloSendBF[side];
+        return (int64_t)haloWidth(kind, false) * (int64_t)cells.size() + (int64_t)haloWidth(kind, true) * (int64_t)faces.size();
+    }
+    void haloMove(int side, int kind, double* buf, bool pack) {
+        if (side < 0 || (size_t)side >= m.haloGhost.size()) return;
+        const ivec& cells = pack ? m.haloSend[side] : m.haloGhost[side];
+        const ivec& faces = pack ? m.haloSendBF[side] : m.haloGhostBF[side];
+        if (kind == 1 && !gUValid) { gU_ = gaussGradV(U); gUValid = true; }
+        if (kind == 2 && pd_.size() != (size_t)m.nC) pd_.assign(m.nC, 0.0);
+        auto mv = [&](double& field, double& slot) { if (pack) slot = field; else field = slot; };
+        size_t k = 0;
+        for (int c : cells) {
+            if (kind == 0) {
+                for (int q = 0; q < 3; ++q) mv(U.in[3 * (size_t)c + q], buf[k++]);
+                mv(T.in[c], buf[k++]);
+            } else if (kind == 1) {
+                mv(p.in[c], buf[k++]);
+                for (int q = 0; q < 9; ++q) mv(gU_.in[9 * (size_t)c + q], buf[k++]);
+            } else mv(pd_[c], buf[k++]);
+        }
+        if (kind == 2) return;
+        for (int b : faces) {
+            if (kind == 0) { for (int q = 0; q < 3; ++q) mv(U.bf[3 * (size_t)b + q], buf[k++]); mv(T.bf[b], buf[k++]); }
+            else { mv(p.bf[b], buf[k++]); mv(p.grad[b], buf[k++]); }
+        }
+    }
 };
 
 extern "C" {
@@ -2037,6 +2277,11 @@ int orc_mesh_set_halo(void* mp, int side, int32_t nGhost, const int32_t* ghost, 
     m.haloGhost[side].assign(ghost, ghost + nGhost);
     m.haloSend[side].assign(send, send + nSend);
     m.haloFaces();
+    return 0;
+}
+
+int orc_mesh_set_halo_face_h(void* mp, int32_t n, const double* h) {
+    ((MeshHandle*)mp)->m.haloFaceH.assign(h, h + n);
     return 0;
 }
 
@@ -2346,6 +2591,26 @@ int orc_qhd_case_set_bc(void* cp, int32_t patch, int32_t bcU, const double* vU, 
 }
 int orc_qhd_case_set_fields(void* cp, const double* U, const double* T, const double* p) { return ((QhdCase*)cp)->setFields(U, T, p); }
 int orc_qhd_case_step(void* cp, int32_t n) { for (int i = 0; i < n; ++i) ((QhdCase*)cp)->step(); return 0; }
+int orc_qhd_case_step_phase(void* cp, int phase) { if (phase < 0 || phase > 8) return -1; ((QhdCase*)cp)->phase(phase); return 0; }
+int orc_qhd_case_control(void* cp, double* buf16, int set) {
+    QhdCase* c = (QhdCase*)cp;
+    for (int k = 0; k < 16; ++k) { if (set) c->ctl[k] = buf16[k]; else buf16[k] = c->ctl[k]; }
+    return 0;
+}
+/* whether p needs a reference level is a property of the whole mesh, and pRefCell may belong to another shard: the caller
+ * tells a shard (needRef, local label of the reference cell or -1) */
+int orc_qhd_case_set_reference(void* cp, int needRef, int localRefCell) {
+    QhdCase* c = (QhdCase*)cp;
+    c->needRef_ = needRef != 0; c->refLocal_ = needRef ? localRefCell : -1; c->refSet = true;
+    return 0;
+}
+int orc_qhd_case_halo_count(void* cp, int side, int kind, int64_t* send, int64_t* recv) {
+    QhdCase* c = (QhdCase*)cp;
+    *send = c->haloCount(side, kind, false); *recv = c->haloCount(side, kind, true);
+    return 0;
+}
+int orc_qhd_case_halo_pack(void* cp, int side, int kind, double* buf) { ((QhdCase*)cp)->haloMove(side, kind, buf, true); return 0; }
+int orc_qhd_case_halo_unpack(void* cp, int side, int kind, const double* buf) { ((QhdCase*)cp)->haloMove(side, kind, const_cast<double*>(buf), false); return 0; }
 int orc_qhd_case_get_field(void* cp, const char* name, double* out, int64_t n) {
     QhdCase* c = (QhdCase*)cp;
     const std::string s(name);

@@ -47,6 +47,9 @@ int orc_mesh_info(void* m, int64_t info[4]);
 int orc_mesh_set_halo(void* m, int side, int32_t nGhost, const int32_t* ghost,
                       int32_t nSend, const int32_t* send);
 
+/* hQGDf of the halo-patch faces as the unsharded mesh has it (patch order), so that a ghost cell's hQGD comes out right */
+int orc_mesh_set_halo_face_h(void* m, int32_t n, const double* h);
+
 /* fvsc operators: scheme word as in fvSchemes ("reduced","leastSquares",
  * "leastSquaresOpt","GaussVolPoint"); op = "grad_s","grad_v","div_v","div_t".
  * Returns 0, or -4 when the scheme is refused (leastSquares in 3-D),
@@ -84,6 +87,13 @@ void orc_qhd_case_free(void* c);
 int orc_qhd_case_set_bc(void* c, int32_t patch, int32_t bcU, const double* valueU, int32_t bcT, double valueT, int32_t bcP, double valueP);
 int orc_qhd_case_set_fields(void* c, const double* U, const double* T, const double* p);
 int orc_qhd_case_step(void* c, int32_t nSteps);
+/* the same step as phases for cell-range shards; protocol, control slots and message kinds as qgd_qhd_case_step_phase */
+int orc_qhd_case_step_phase(void* c, int phase);
+int orc_qhd_case_control(void* c, double* buf16, int set);
+int orc_qhd_case_set_reference(void* c, int needRef, int localRefCell);
+int orc_qhd_case_halo_count(void* c, int side, int kind, int64_t* send, int64_t* recv);
+int orc_qhd_case_halo_pack(void* c, int side, int kind, double* buf);
+int orc_qhd_case_halo_unpack(void* c, int side, int kind, const double* buf);
 int orc_qhd_case_get_field(void* c, const char* name, double* out, int64_t n);
 int orc_qhd_case_info(void* c, double info[6]);
 

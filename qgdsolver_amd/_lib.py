@@ -101,6 +101,7 @@ SIGNATURES = {
     "qgd_qhd_case_step_phase": (C.c_int, [handle, C.c_int]),
     "qgd_qhd_case_control_ptr": (C.c_int, [handle, C.POINTER(C.c_void_p)]),
     "qgd_qhd_case_solve_status": (C.c_int, [handle, c_double_p]),
+    "qgd_qhd_case_control": (C.c_int, [handle, c_double_p, C.c_int]),
     "qgd_qhd_case_sync": (C.c_int, [handle]),
     "qgd_qhd_case_halo_count": (C.c_int, [handle, C.c_int, C.c_int, c_int64_p, c_int64_p]),
     "qgd_qhd_case_halo_pack": (C.c_int, [handle, C.c_int, C.c_int, C.c_void_p]),

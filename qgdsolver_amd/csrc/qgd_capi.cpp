@@ -473,6 +473,7 @@ int qgd_mesh_get(qgd_mesh_t mh, const char* name, void* out, int64_t outBytes) {
     else if (s == "cellGlobal") I(m.cellGlobal);
     else if (s == "faceGlobal") I(m.faceGlobal);
     else if (s == "pointGlobal") I(m.pointGlobal);
+    else if (s == "haloFaceH") D(m.haloFaceH);
     else if (s == "Sf") D(m.Sf);
     else if (s == "magSf") D(m.magSf);
     else if (s == "Cf") D(m.Cf);
@@ -1523,7 +1524,7 @@ int qgd_qhd_case_set_fields(qgd_qhd_case_t c, const double* U, const double* T, 
 }
 // One step as stream-ordered phases (the exchanges of a sharded run go between them, see include/qgd_amd.h):
 //   0 flux assembly + rhs + first residual | 1 normFactor | 2 first preconditioned residual | 3, 4, 5 one PCG iteration |
-//   6 p's boundary conditions after the solve | 7 phi, the U and T equations | 8 reference level, fvc::grad(U) of the new state
+//   6 p's boundary conditions after the solve | 7 phi, the U and T equations | 8 reference level of p
 static void qhdPhase(qgd_qhd_case_s* c, int phase) {
     qgd_device_s* d = c->dev;
     const MeshView& m = d->view;
@@ -1599,6 +1600,18 @@ int qgd_qhd_case_control_ptr(qgd_qhd_case_t c, void** devicePtr) {
     *devicePtr = pressureSolverCtl(c->solver);
     return QGD_OK;
 }
+int qgd_qhd_case_control(qgd_qhd_case_t c, double control[16], int set) {
+    QGD_TRY
+    if (!c || !control) return fail(QGD_ERR_INVALID, "null argument");
+    if (!c->solver) return fail(QGD_ERR_INVALID, "qgd_qhd_case_control: call qgd_qhd_case_set_fields first");
+    HIP_CHECK(hipSetDevice(c->dev->deviceId));
+    hipStream_t st = c->dev->stream;
+    if (set) HIP_CHECK(hipMemcpyAsync(pressureSolverCtl(c->solver), control, 16 * sizeof(double), hipMemcpyHostToDevice, st));
+    else HIP_CHECK(hipMemcpyAsync(control, pressureSolverCtl(c->solver), 16 * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    return QGD_OK;
+    QGD_CATCH
+}
 int qgd_qhd_case_solve_status(qgd_qhd_case_t c, double status[4]) {
     QGD_TRY
     if (!c || !status) return fail(QGD_ERR_INVALID, "null argument");
@@ -1619,7 +1632,7 @@ int qgd_qhd_case_sync(qgd_qhd_case_t c) {
 }
 // halo messages: doubles per listed cell / per listed patch face of message kind 0 (state), 1 (p), 2 (search direction)
 static void qhdHaloWidths(int kind, int& perCell, int& perFace) {
-    perCell = kind == 0 ? 13 : 1;
+    perCell = kind == 0 ? 4 : (kind == 1 ? 10 : 1);
     perFace = kind == 0 ? 4 : (kind == 1 ? 2 : 0);
 }
 int qgd_qhd_case_halo_count(qgd_qhd_case_t c, int slot, int kind, int64_t* sendCount, int64_t* recvCount) {
@@ -1934,8 +1947,8 @@ static void qhdHaloExchangeOn(qgd_qhd_case_s* c, qgd_comm_s* comm, const int32_t
         c->recvBuf.assign(d->halo.size(), nullptr);
         for (size_t s2 = 0; s2 < d->halo.size(); ++s2) {
             const qgd_device_s::HaloSlot& h = d->halo[s2];
-            c->sendBuf[s2] = c->arena.alloc<double>(13 * (size_t)h.nSend + 4 * (size_t)h.nSendBF);
-            c->recvBuf[s2] = c->arena.alloc<double>(13 * (size_t)h.nGhost + 4 * (size_t)h.nGhostBF);
+            c->sendBuf[s2] = c->arena.alloc<double>(10 * (size_t)h.nSend + 4 * (size_t)h.nSendBF);
+            c->recvBuf[s2] = c->arena.alloc<double>(10 * (size_t)h.nGhost + 4 * (size_t)h.nGhostBF);
         }
     }
     int pc, pf;

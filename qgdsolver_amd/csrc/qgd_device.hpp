@@ -185,7 +185,7 @@ void launchQhdPostSolve(hipStream_t s, const MeshView& m, const QhdView& q, cons
 void launchQhdAdvance(hipStream_t s, int stencil, bool usesPoints, const MeshView& m, const QhdView& q, const PatchBCDev* bc, bool needRef,
                       int localRefCell, double refValue, double* shift);
 void launchQhdFinish(hipStream_t s, const MeshView& m, const QhdView& q, bool needRef, const double* shift);
-// halo messages of a sharded QHD case: kind 0 = state {U,T} + grad(U) (13 per cell, 4 per patch face), 1 = p (1 per cell, 2 per
+// halo messages of a sharded QHD case: kind 0 = state {U,T} (4 per cell, 4 per patch face), 1 = p + fvc::grad(U) (10 per cell, 2 per
 // patch face), 2 = the search direction of the pressure solve (1 per cell)
 void launchQhdHalo(hipStream_t s, const QhdView& q, double* direction, int kind, const int32_t* cells, int nCells, const int32_t* bfaces, int nFaces,
                    double* buf, bool pack);

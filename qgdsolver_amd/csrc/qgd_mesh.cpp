@@ -406,6 +406,14 @@ HostMesh makeBox(int32_t nx, int32_t ny, int32_t nzGlobal, int32_t kLo, int32_t 
         }
     }
     m.computeGeometry();
+    // the faces of a cut plane are internal faces of the box; its z spacing is uniform, so their hQGDf there is 2 |C_O - C_f|
+    for (const Patch& pt : m.patches)
+        if (pt.type == QGD_PATCH_HALO)
+            for (int32_t fc = pt.start; fc < pt.start + pt.size; ++fc) {
+                double d2 = 0;
+                for (int k = 0; k < 3; ++k) { const double x = m.C[3 * (size_t)m.owner[fc] + k] - m.Cf[3 * (size_t)fc + k]; d2 += x * x; }
+                m.haloFaceH.push_back(2.0 * std::sqrt(d2));
+            }
     return m;
 }
 

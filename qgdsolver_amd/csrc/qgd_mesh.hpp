@@ -57,6 +57,9 @@ struct HostMesh {
     std::vector<int32_t> cellGlobal, faceGlobal, pointGlobal;
     int32_t ownedBegin = 0, ownedEnd = 0;  // local label range of the owned cells of a shard (extractShard, makeBox slabs)
     int64_t cellGlobalOffset = 0;          // box slabs: global label = local label + offset (cellGlobal stays empty)
+    // hQGDf of the faces of the halo patch(es) AS THE UNSHARDED MESH HAS IT (they are internal faces there), in patch order:
+    // with it a ghost cell's hQGD -- an area-weighted mean over all its faces [QGDCoeffs.C L323-362] -- comes out right
+    std::vector<double> haloFaceH;
 
     int32_t nBoundaryFaces() const { return nFaces - nInternalFaces; }
     int32_t faceSize(int32_t f) const { return faceOffsets[f + 1] - faceOffsets[f]; }

@@ -7,6 +7,7 @@
 // vertex-connected ghost layer, which is exactly the neighbourhood volPointInterpolation and the leastSquares stencil
 // reach [FindNb.C:55-80] -- with the halo lists per neighbouring rank.  Host-side set-up code, nothing on the GPU.
 #include <algorithm>
+#include <cmath>
 #include <numeric>
 #include <queue>
 #include <stdexcept>
@@ -245,6 +246,14 @@ HostMesh extractShard(const HostMesh& g, int32_t nRanks, const int32_t* cellStar
             if ((a < 0) == (b < 0)) continue;
             addFace(f, a < 0);  // the local cell becomes the owner; reversed when it was the neighbour
             m.owner.push_back(a < 0 ? b : a);
+            {   // hQGDf of this (internal) face in the unsharded mesh: 2 min(|C_O - C_f|, |C_N - C_f|) [QGDCoeffs.C L305-307]
+                double da = 0, db = 0;
+                for (int k = 0; k < 3; ++k) {
+                    const double x = g.C[3 * (size_t)g.owner[f] + k] - g.Cf[3 * (size_t)f + k], y = g.C[3 * (size_t)g.neighbour[f] + k] - g.Cf[3 * (size_t)f + k];
+                    da += x * x; db += y * y;
+                }
+                m.haloFaceH.push_back(2.0 * std::sqrt(std::min(da, db)));
+            }
         }
         p.size = (int32_t)m.owner.size() - p.start;
         m.patches.push_back(p);

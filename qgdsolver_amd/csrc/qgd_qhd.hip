@@ -271,9 +271,10 @@ __global__ __launch_bounds__(QGD_BLOCK) void qhdBcKernel(const MeshView m, const
 __global__ void qhdRefReadKernel(const QhdView q, const int refCell, const double refValue, double* __restrict__ shift) {
     shift[0] = refCell >= 0 ? refValue - q.p[refCell] : 0.0;   // refCell < 0: another shard owns it (the shifts are summed over the ranks)
 }
-// halo messages of a sharded QHD case.  kind 0: the state after a step, {Ux,Uy,Uz,T} + fvc::grad(U) (13 per cell), {U,T}
-// patch values (4 per patch face); kind 1: p (1 per cell), its patch value and gradient (2 per patch face); kind 2: the
-// search direction of the pressure solve (1 per cell)
+// halo messages of a sharded QHD case.  kind 0: the state after a step, {Ux,Uy,Uz,T} per cell and per patch face (4 + 4);
+// kind 1: after the pressure solve, p + fvc::grad(U) per cell (1 + 9: the gradient was formed at the start of the step, when the
+// ghost cells held the new velocity), p's patch value and gradient per patch face (2); kind 2: the search direction of the
+// pressure solve (1 per cell)
 __global__ __launch_bounds__(QGD_BLOCK) void qhdHaloKernel(const QhdView q, double* __restrict__ dirn, const int kind, const int32_t* __restrict__ cells,
                                                           const int nCells, const int32_t* __restrict__ bfaces, const int nFaces,
                                                           double* __restrict__ buf, const int pack) {
@@ -281,30 +282,27 @@ __global__ __launch_bounds__(QGD_BLOCK) void qhdHaloKernel(const QhdView q, doub
     if (i < nCells) {
         const size_t c = (size_t)cells[i];
         if (kind == 0) {
-            double* b = buf + (size_t)i * 13;
+            double* b = buf + (size_t)i * 4;
 #pragma unroll
             for (int k = 0; k < 4; ++k) { if (pack) b[k] = q.c4[c * 4 + k]; else q.c4[c * 4 + k] = b[k]; }
+        } else if (kind == 1) {
+            double* b = buf + (size_t)i * 10;
+            if (pack) b[0] = q.p[c]; else q.p[c] = b[0];
 #pragma unroll
-            for (int k = 0; k < 9; ++k) { if (pack) b[4 + k] = q.gUc[c * 9 + k]; else q.gUc[c * 9 + k] = b[4 + k]; }
-        } else if (kind == 1) { if (pack) buf[i] = q.p[c]; else q.p[c] = buf[i]; }
-        else { if (pack) buf[i] = dirn[c]; else dirn[c] = buf[i]; }
+            for (int k = 0; k < 9; ++k) { if (pack) b[1 + k] = q.gUc[c * 9 + k]; else q.gUc[c * 9 + k] = b[1 + k]; }
+        } else { if (pack) buf[i] = dirn[c]; else dirn[c] = buf[i]; }
     } else if (i < nCells + nFaces && kind != 2) {
         const int j = i - nCells;
         const size_t f = (size_t)bfaces[j];
         if (kind == 0) {
-            double* b = buf + (size_t)nCells * 13 + (size_t)j * 4;
+            double* b = buf + (size_t)nCells * 4 + (size_t)j * 4;
 #pragma unroll
             for (int k = 0; k < 4; ++k) { if (pack) b[k] = q.b4[f * 4 + k]; else q.b4[f * 4 + k] = b[k]; }
         } else {
-            double* b = buf + (size_t)nCells + (size_t)j * 2;
+            double* b = buf + (size_t)nCells * 10 + (size_t)j * 2;
             if (pack) { b[0] = q.pb[f]; b[1] = q.pgb[f]; } else { q.pb[f] = b[0]; q.pgb[f] = b[1]; }
         }
     }
-}
-__global__ __launch_bounds__(QGD_BLOCK) void qhdRefShiftKernel(const int nC, const int nBF, const QhdView q, const double* __restrict__ shift) {
-    const int i = blockIdx.x * QGD_BLOCK + threadIdx.x;
-    if (i < nC) q.p[i] += shift[0];
-    else if (i < nC + nBF) q.pb[i - nC] += shift[0];
 }
 
 // createFields: cell records from U, T (host order) and p
@@ -362,7 +360,6 @@ void launchQhdInit(hipStream_t s, const MeshView& m, const QhdView& q, const Pat
         qhdBcKernel<<<gridOf(m.nBF), QGD_BLOCK, 0, s>>>(m, q, bc);
         qhdPressureBcKernel<<<gridOf(m.nBF), QGD_BLOCK, 0, s>>>(m, q, bc);
     }
-    qhdCellGradKernel<<<gridOf(m.nC), QGD_BLOCK, 0, s>>>(m, q);
 }
 // everything of the step before the pressure equation
 void launchQhdAssemble(hipStream_t s, int stencil, bool usesPoints, const MeshView& m, const QhdView& q, const PatchBCDev* bc) {
@@ -377,6 +374,9 @@ void launchQhdAssemble(hipStream_t s, int stencil, bool usesPoints, const MeshVi
         default: face1<ST_GVP2>(s, m, q, bc); break;
     }
     if (m.nBF) qhdPressureBcKernel<<<gridOf(m.nBF), QGD_BLOCK, 0, s>>>(m, q, bc);   // p.correctBoundaryConditions() [QHDpEqn.H L35]
+    // fvc::grad(U) of QHDUEqn.H L76, formed here: U does not change before the U equation, and a shard's ghost cells hold the new
+    // velocity now (their own gradient travels with the pressure message, after the solve)
+    qhdCellGradKernel<<<gridOf(m.nC), QGD_BLOCK, 0, s>>>(m, q);
 }
 // after the solve: solve() ends in correctBoundaryConditions() (a shard then sends p and these patch values to its neighbours)
 void launchQhdPostSolve(hipStream_t s, const MeshView& m, const QhdView& q, const PatchBCDev* bc) {
@@ -400,11 +400,9 @@ void launchQhdAdvance(hipStream_t s, int stencil, bool usesPoints, const MeshVie
     if (m.nBF) qhdBcKernel<<<gridOf(m.nBF), QGD_BLOCK, 0, s>>>(m, q, bc);
     if (needRef) qhdRefReadKernel<<<1, 1, 0, s>>>(q, localRefCell, refValue, shift);
 }
-// end of the step: the (global) shift of p, then fvc::grad(U) of the new velocity for the next step's QHDUEqn.H L76 (computed here
-// so that a shard can send it along with the new state: a ghost cell's gradient cannot be formed locally)
+// end of the step: the (global) shift of p [QHDFoam.C L123-130]
 void launchQhdFinish(hipStream_t s, const MeshView& m, const QhdView& q, bool needRef, const double* shift) {
     if (needRef) qhdRefShiftKernel<<<gridOf((int64_t)m.nC + m.nBF), QGD_BLOCK, 0, s>>>(m.nC, m.nBF, q, shift);
-    qhdCellGradKernel<<<gridOf(m.nC), QGD_BLOCK, 0, s>>>(m, q);
 }
 void launchQhdHalo(hipStream_t s, const QhdView& q, double* direction, int kind, const int32_t* cells, int nCells, const int32_t* bfaces, int nFaces,
                    double* buf, bool pack) {

@@ -113,6 +113,14 @@ StaticData buildStaticData(const HostMesh& m) {
         s.Cc = m.C;
     }
 
+    // hQGDf of cut-plane faces as the unsharded mesh has it (HostMesh::haloFaceH), by boundary-face index; -1: not given
+    std::vector<double> haloH((size_t)nBF, -1.0);
+    {
+        size_t k = 0;
+        for (const Patch& pt : m.patches)
+            if (pt.type == QGD_PATCH_HALO)
+                for (int32_t fc = pt.start; fc < pt.start + pt.size && k < m.haloFaceH.size(); ++fc) haloH[(size_t)(fc - nIF)] = m.haloFaceH[k++];
+    }
 #pragma omp parallel for schedule(static)
     for (int64_t f = 0; f < nF; ++f) {
         const int32_t* fp = &m.facePoints[m.faceOffsets[f]];
@@ -139,6 +147,7 @@ StaticData buildStaticData(const HostMesh& m) {
             const double hb = (m.deltaCoeffs[f] != 0.0) ? 1.0 / std::fabs(m.deltaCoeffs[f]) : 0.0;
             const bool coupled = patchType[b] == QGD_PATCH_CYCLIC || patchType[b] == QGD_PATCH_HALO;
             s.hf[f] = skip ? 0.0 : (coupled ? hb : hb * 2.0);  // no field entries on empty patches
+            if (patchType[b] == QGD_PATCH_HALO && haloH[b] >= 0.0) s.hf[f] = haloH[b];   // the value of the unsharded mesh
             s.dn[f] = m.deltaCoeffs[f];
             if (want3D) {
                 double d[3];

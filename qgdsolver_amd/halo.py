@@ -186,3 +186,144 @@ class NativeComm:
         if getattr(self, "_h", None):
             self._L.lib.qgd_comm_free(self._h)
             self._h = None
+
+
+# ---- QHDFoam on cell-range shards ----------------------------------------------------------------------------------------
+# control-block slots that are global sums (include/qgd_amd.h "the QHD case on a cell-range shard")
+QHD_REDUCE_AFTER_PHASE = {0: (0, 3), 1: (3, 1), 2: (4, 1), 3: (5, 1), 4: (6, 2), 7: (8, 1)}
+QHD_STATE, QHD_PRESSURE, QHD_DIRECTION = 0, 1, 2   # halo message kinds
+
+
+class QhdStepper:
+    """The choreography of one QHDFoam step on cell-range shards: the phases of ``qgd_qhd_case_step_phase`` with, between
+    them, the SUM reductions of the control block and the halo messages.  ``world`` supplies the three verbs:
+
+    ``phase(k)`` runs phase k on every shard this process holds, ``allreduce(first, count)`` sums control[first:first+count]
+    over ALL shards, ``exchange(kind)`` moves message kind (0 state, 1 pressure, 2 search direction) between neighbouring
+    shards, ``done()`` tells whether the pressure solve has finished (the same answer on every shard: it is computed from
+    reduced sums).  ``LocalWorld``: several shards in one process; ``DistWorld``: one shard per rank over torch.distributed.
+    """
+
+    def __init__(self, world):
+        self.world = world
+        self.started = False
+
+    def start(self):
+        """after set_fields: the ghost cells' fvc::grad(U) (and state) from their owners"""
+        self.world.exchange(QHD_STATE)
+        self.started = True
+
+    def step(self, n=1):
+        w = self.world
+        if not self.started:
+            self.start()
+        for _ in range(n):
+            for k in (0, 1, 2):
+                w.phase(k)
+                w.allreduce(*QHD_REDUCE_AFTER_PHASE[k])
+            w.exchange(QHD_DIRECTION)
+            while not w.done():
+                for k in (3, 4):
+                    w.phase(k)
+                    w.allreduce(*QHD_REDUCE_AFTER_PHASE[k])
+                w.phase(5)
+                w.exchange(QHD_DIRECTION)
+            w.phase(6)
+            w.exchange(QHD_PRESSURE)
+            w.phase(7)
+            w.allreduce(*QHD_REDUCE_AFTER_PHASE[7])
+            w.phase(8)
+            w.exchange(QHD_STATE)
+
+
+class LocalWorld:
+    """All shards in this process (``cases[r]`` is the case of rank r, ``peers[r][slot]`` the rank behind each of its halo
+    slots, < 0 for none): messages go pack -> buffer -> unpack, reductions through host copies of the control blocks."""
+
+    def __init__(self, cases, peers):
+        self.cases, self.peers = list(cases), [list(p) for p in peers]
+        self.buf = {}
+        for r, case in enumerate(self.cases):
+            for slot, peer in enumerate(self.peers[r]):
+                if peer < 0:
+                    continue
+                n = max(case.halo_count(slot, kind)[0] for kind in (0, 1, 2))
+                self.buf[(r, slot)] = case.halo_buffer(n)
+
+    def phase(self, k):
+        for c in self.cases:
+            c.step_phase(k)
+
+    def allreduce(self, first, count):
+        ctl = [c.control() for c in self.cases]
+        total = sum(a[first:first + count] for a in ctl)
+        for c, a in zip(self.cases, ctl):
+            a[first:first + count] = total
+            c.set_control(a)
+
+    def exchange(self, kind):
+        for (r, slot), buf in self.buf.items():
+            self.cases[r].halo_pack(slot, kind, buf)
+        for c in self.cases:
+            c.sync()
+        for (r, slot), buf in self.buf.items():
+            peer = self.peers[r][slot]
+            back = self.peers[peer].index(r)           # the peer's slot towards r
+            assert self.cases[r].halo_count(slot, kind)[0] == self.cases[peer].halo_count(back, kind)[1]
+            self.cases[peer].halo_unpack(back, kind, buf)
+        for c in self.cases:
+            c.sync()
+
+    def done(self):
+        flags = [c.solve_status()["done"] for c in self.cases]
+        assert all(f == flags[0] for f in flags), flags
+        return flags[0] != 0
+
+
+class DistWorld:
+    """One shard per rank over ``torch.distributed`` (backend "nccl" == RCCL, or "gloo" with host-staged buffers):
+    ``peers[slot]`` = rank behind each halo slot.  ``to_transport(buf, n)`` / ``from_transport(t, buf)`` turn the case's
+    halo buffer (a device pointer, or a numpy array for the CPU oracle) into a torch tensor the backend can send and back."""
+
+    def __init__(self, case, dist, torch, peers, to_transport, from_transport):
+        self.case, self.dist, self.torch, self.peers = case, dist, torch, list(peers)
+        self.to_transport, self.from_transport = to_transport, from_transport
+        self.slots = [s for s, p in enumerate(self.peers) if p >= 0]
+        self.sbuf = {s: case.halo_buffer(max(case.halo_count(s, k)[0] for k in (0, 1, 2))) for s in self.slots}
+        self.rbuf = {s: case.halo_buffer(max(case.halo_count(s, k)[1] for k in (0, 1, 2))) for s in self.slots}
+
+    def phase(self, k):
+        self.case.step_phase(k)
+
+    def allreduce(self, first, count):
+        a = self.case.control()
+        t = self.torch.from_numpy(a[first:first + count].copy())
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        a[first:first + count] = t.numpy()
+        self.case.set_control(a)
+
+    def exchange(self, kind):
+        if not self.slots:
+            return
+        ops, recv = [], {}
+        for s in self.slots:
+            ns, nr = self.case.halo_count(s, kind)
+            self.case.halo_pack(s, kind, self.sbuf[s])
+        self.case.sync()
+        for s in self.slots:
+            ns, nr = self.case.halo_count(s, kind)
+            if ns:
+                ops.append(self.dist.P2POp(self.dist.isend, self.to_transport(self.sbuf[s], ns), self.peers[s]))
+            if nr:
+                recv[s] = self.to_transport(self.rbuf[s], nr)
+                ops.append(self.dist.P2POp(self.dist.irecv, recv[s], self.peers[s]))
+        if ops:
+            for w in self.dist.batch_isend_irecv(ops):
+                w.wait()
+        for s, t in recv.items():
+            self.from_transport(t, self.rbuf[s])
+            self.case.halo_unpack(s, kind, self.rbuf[s])
+        self.case.sync()
+
+    def done(self):
+        return self.case.solve_status()["done"] != 0

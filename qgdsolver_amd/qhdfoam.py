@@ -201,6 +201,50 @@ class QHDFoamCase:
             L.check(L.lib.qgd_qhd_case_get_field(self._h, name.encode(), out.ctypes.data_as(L.c_double_p), out.size), f"qgd_qhd_case_get_field({name})")
         return out
 
+    # ---- the step as phases (cell-range shards; the protocol is in include/qgd_amd.h and halo.QhdStepper) ---------------
+    def step_phase(self, phase):
+        L.check(L.lib.qgd_qhd_case_step_phase(self._h, int(phase)), "qgd_qhd_case_step_phase")
+
+    def control_ptr(self):
+        """device pointer of the 16-double control block of the pressure solve (slots [0,3) [3] [4] [5] [6,8) [8] are reduced)"""
+        p = C.c_void_p()
+        L.check(L.lib.qgd_qhd_case_control_ptr(self._h, C.byref(p)), "qgd_qhd_case_control_ptr")
+        return p.value
+
+    def control(self):
+        """host copy of the control block (waits for the stream)"""
+        a = np.zeros(16)
+        L.check(L.lib.qgd_qhd_case_control(self._h, a.ctypes.data_as(L.c_double_p), 0), "qgd_qhd_case_control")
+        return a
+
+    def set_control(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        assert a.size == 16
+        L.check(L.lib.qgd_qhd_case_control(self._h, a.ctypes.data_as(L.c_double_p), 1), "qgd_qhd_case_control")
+
+    def solve_status(self):
+        a = (C.c_double * 4)()
+        L.check(L.lib.qgd_qhd_case_solve_status(self._h, a), "qgd_qhd_case_solve_status")
+        return dict(done=int(a[0]), iterations=int(a[1]), initialResidual=a[2], finalResidual=a[3])
+
+    def sync(self):
+        L.check(L.lib.qgd_qhd_case_sync(self._h), "qgd_qhd_case_sync")
+
+    def halo_count(self, slot, kind):
+        s, r = C.c_int64(), C.c_int64()
+        L.check(L.lib.qgd_qhd_case_halo_count(self._h, int(slot), int(kind), C.byref(s), C.byref(r)), "qgd_qhd_case_halo_count")
+        return s.value, r.value
+
+    def halo_buffer(self, n):
+        """device buffer of n doubles (released with the device)"""
+        return self.dev.alloc(8 * max(int(n), 1))
+
+    def halo_pack(self, slot, kind, dev_ptr):
+        L.check(L.lib.qgd_qhd_case_halo_pack(self._h, int(slot), int(kind), C.c_void_p(dev_ptr)), "qgd_qhd_case_halo_pack")
+
+    def halo_unpack(self, slot, kind, dev_ptr):
+        L.check(L.lib.qgd_qhd_case_halo_unpack(self._h, int(slot), int(kind), C.c_void_p(dev_ptr)), "qgd_qhd_case_halo_unpack")
+
     def info(self):
         a = (C.c_double * 8)()
         L.check(L.lib.qgd_qhd_case_info(self._h, a), "qgd_qhd_case_info")

@@ -38,6 +38,7 @@ lib.orc_mesh_get.argtypes = [C.c_void_p, C.c_char_p, dp, C.c_int64]
 lib.orc_mesh_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
 lib.orc_mesh_set_geometry.argtypes = [C.c_void_p, dp, dp, dp, dp]
 lib.orc_mesh_set_halo.argtypes = [C.c_void_p, C.c_int, C.c_int32, ip, C.c_int32, ip]
+lib.orc_mesh_set_halo_face_h.argtypes = [C.c_void_p, C.c_int32, dp]
 lib.orc_fvsc.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, dp, dp, dp]
 lib.orc_case_create.restype = C.c_void_p
 lib.orc_case_create.argtypes = [C.c_void_p, C.POINTER(Options)]
@@ -77,6 +78,12 @@ lib.orc_qhd_case_set_fields.argtypes = [C.c_void_p, dp, dp, dp]
 lib.orc_qhd_case_step.argtypes = [C.c_void_p, C.c_int32]
 lib.orc_qhd_case_get_field.argtypes = [C.c_void_p, C.c_char_p, dp, C.c_int64]
 lib.orc_qhd_case_info.argtypes = [C.c_void_p, dp]
+lib.orc_qhd_case_step_phase.argtypes = [C.c_void_p, C.c_int]
+lib.orc_qhd_case_control.argtypes = [C.c_void_p, dp, C.c_int]
+lib.orc_qhd_case_set_reference.argtypes = [C.c_void_p, C.c_int, C.c_int]
+lib.orc_qhd_case_halo_count.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+lib.orc_qhd_case_halo_pack.argtypes = [C.c_void_p, C.c_int, C.c_int, dp]
+lib.orc_qhd_case_halo_unpack.argtypes = [C.c_void_p, C.c_int, C.c_int, dp]
 
 _NCOMP = {"U": 3, "rhoU": 3, "phiJmU": 3, "phiP": 3, "phiPi": 3, "gradUf": 9, "gradef": 3, "gradRhof": 3, "gradPf": 3,
           "Uf": 3, "Pif": 9, "qf": 3, "jm": 3, "tauMC": 9, "phiTauMC": 3}
@@ -132,6 +139,11 @@ class OracleMesh:
         g = np.ascontiguousarray(ghost, dtype=np.int32)
         s = np.ascontiguousarray(send, dtype=np.int32)
         assert lib.orc_mesh_set_halo(self._h, side, g.size, _i(g), s.size, _i(s)) == 0
+
+    def set_halo_face_h(self, h):
+        h = np.ascontiguousarray(h, dtype=np.float64)
+        if h.size:
+            lib.orc_mesh_set_halo_face_h(self._h, h.size, _d(h))
 
     def fvsc(self, scheme, op, cell, bnd):
         """op in grad_s, grad_v, div_v, div_t; returns (status, out)."""
@@ -320,6 +332,43 @@ class OracleQhdCase:
             rc = lib.orc_qhd_case_get_field(self._h, name.encode(), _d(out), out.size)
             assert rc == 0, (name, rc)
         return out
+
+    # ---- the step as phases (cell-range shards); same protocol as qgdsolver_amd.qhdfoam.QHDFoamCase -------------------
+    def step_phase(self, phase):
+        assert lib.orc_qhd_case_step_phase(self._h, int(phase)) == 0
+
+    def control(self):
+        a = np.zeros(16)
+        lib.orc_qhd_case_control(self._h, _d(a), 0)
+        return a
+
+    def set_control(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        lib.orc_qhd_case_control(self._h, _d(a), 1)
+
+    def solve_status(self):
+        a = self.control()
+        return dict(done=int(a[11]), iterations=int(a[12]), initialResidual=a[10], finalResidual=a[9])
+
+    def set_reference(self, need_ref, local_ref_cell):
+        lib.orc_qhd_case_set_reference(self._h, 1 if need_ref else 0, int(local_ref_cell))
+
+    def halo_count(self, slot, kind):
+        s, r = C.c_int64(), C.c_int64()
+        lib.orc_qhd_case_halo_count(self._h, int(slot), int(kind), C.byref(s), C.byref(r))
+        return s.value, r.value
+
+    def halo_buffer(self, n):
+        return np.zeros(max(int(n), 1))
+
+    def halo_pack(self, slot, kind, buf):
+        lib.orc_qhd_case_halo_pack(self._h, int(slot), int(kind), _d(buf))
+
+    def halo_unpack(self, slot, kind, buf):
+        lib.orc_qhd_case_halo_unpack(self._h, int(slot), int(kind), _d(buf))
+
+    def sync(self):
+        pass
 
     def info(self):
         a = (C.c_double * 6)()
