@@ -209,7 +209,8 @@ class QhdStepper:
         self.started = False
 
     def start(self):
-        """after set_fields: the ghost cells' fvc::grad(U) (and state) from their owners"""
+        """after set_fields: the ghost cells' state from their owners (set_fields gave them values already; this makes the
+        start independent of what the caller put there)"""
         self.world.exchange(QHD_STATE)
         self.started = True
 
@@ -283,7 +284,7 @@ class LocalWorld:
 class DistWorld:
     """One shard per rank over ``torch.distributed`` (backend "nccl" == RCCL, or "gloo" with host-staged buffers):
     ``peers[slot]`` = rank behind each halo slot.  ``to_transport(buf, n)`` / ``from_transport(t, buf)`` turn the case's
-    halo buffer (a device pointer, or a numpy array for the CPU oracle) into a torch tensor the backend can send and back."""
+    halo buffer (a device pointer, or a host array when the cases live on the CPU) into a torch tensor the backend can send and back."""
 
     def __init__(self, case, dist, torch, peers, to_transport, from_transport):
         self.case, self.dist, self.torch, self.peers = case, dist, torch, list(peers)
