@@ -227,6 +227,20 @@ int qgd_fvsc_div_v(qgd_device_t d, int stencilId, const double* cell,
 int qgd_fvsc_div_t(qgd_device_t d, int stencilId, const double* cell,
                    const double* bnd, double* out);
 
+/* The same four operators, qgdInterpolate, the QHD flux block and the species block on DEVICE pointers (buffers of
+ * qgd_device_alloc or any allocation of this HIP device): same layouts, nothing staged, nothing crosses PCIe, stream-ordered on
+ * the device handle's own stream -- qgd_device_sync waits.  For hosts whose fields already live in HBM (level 1 of
+ * INTEGRATION.md without the 80 ms of PCIe per step the host-pointer entries cost at 8 M cells).  The struct members of
+ * qgd_qhd_inputs / qgd_qhd_outputs are device pointers here.  qgd_device_copy: a plain synchronous copy for callers that hold
+ * no HIP runtime of their own (toDevice != 0: host -> device). */
+int qgd_fvsc_grad_s_dev(qgd_device_t d, int stencilId, const double* cellDev, const double* bndDev, double* outDev);
+int qgd_fvsc_grad_v_dev(qgd_device_t d, int stencilId, const double* cellDev, const double* bndDev, double* outDev);
+int qgd_fvsc_div_v_dev(qgd_device_t d, int stencilId, const double* cellDev, const double* bndDev, double* outDev);
+int qgd_fvsc_div_t_dev(qgd_device_t d, int stencilId, const double* cellDev, const double* bndDev, double* outDev);
+int qgd_interpolate_dev(qgd_device_t d, int32_t ncomp, const double* cellDev, const double* bndDev, double* outDev);
+int qgd_device_sync(qgd_device_t d);
+int qgd_device_copy(qgd_device_t d, void* dst, const void* src, int64_t bytes, int toDevice);
+
 /* Where the time of the last qgd_fvsc_* call on this device went: ms[0] = host -> device copies, ms[1] = kernels (HIP events),
  * ms[2] = device -> host copy.  Pageable caller memory moves through two pinned staging chunks in a double-buffered
  * pipeline; buffers of the persistent per-device workspace are reused from call to call (no allocation per call). */
@@ -279,6 +293,7 @@ typedef struct qgd_qhd_outputs {             /* every pointer may be NULL */
     double* phiTauTReg;  /* 1 */
 } qgd_qhd_outputs;
 int qgd_qhd_fluxes(qgd_device_t d, int stencilId, const qgd_qhd_inputs* in, qgd_qhd_outputs* out);
+int qgd_qhd_fluxes_dev(qgd_device_t d, int stencilId, const qgd_qhd_inputs* in, qgd_qhd_outputs* out);   /* device pointers */
 
 /* Species flux block -- reactingLagrangianQGDFoam_2updateFluxes_8H_source.html L117-132, one species:
  *     gradYf = fvsc::grad(Y);  phiJmY = qgdFlux(phiJm, Y, Yf);  dydtflux = -phi*tauQGDf*(Uf & gradYf);
@@ -289,6 +304,9 @@ int qgd_qhd_fluxes(qgd_device_t d, int stencilId, const qgd_qhd_inputs* in, qgd_
 int qgd_species_flux(qgd_device_t d, int stencilId, const double* Y, const double* Yb, const double* U, const double* Ub,
                      const double* phiJm, const double* phi, const double* tauQGDf, double* phiJmY, double* diffusiveFlux,
                      double* gradYf);
+int qgd_species_flux_dev(qgd_device_t d, int stencilId, const double* Y, const double* Yb, const double* U, const double* Ub,
+                         const double* phiJm, const double* phi, const double* tauQGDf, double* phiJmY, double* diffusiveFlux,
+                         double* gradYf);   /* device pointers */
 
 /* QHDFoam's pressure equation -- QHDpEqn_8H_source.html L35-47:
  *     fvScalarMatrix pEqn(fvc::div(phiu) - fvc::div(phiwo) - fvm::laplacian(taubyrhof, p));

@@ -9,7 +9,7 @@ CPU fallback.
 from . import _lib  # noqa: F401  (raises ImportError when the HIP library is missing)
 from ._lib import CaseOptions, QgdError  # noqa: F401
 from .mesh import PolyMesh  # noqa: F401
-from .fvsc import Device, fvscStencil, volField  # noqa: F401
+from .fvsc import Device, deviceVolField, fvscStencil, volField  # noqa: F401
 from . import fvsc  # noqa: F401
 from .qgdfoam import QGDFoamCase, QGDThermo, default_options  # noqa: F401
 from . import qhdfoam  # noqa: F401

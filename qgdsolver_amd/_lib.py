@@ -84,6 +84,15 @@ SIGNATURES = {
     "qgd_fvsc_grad_v": (C.c_int, [handle, C.c_int, c_double_p, c_double_p, c_double_p]),
     "qgd_fvsc_div_v": (C.c_int, [handle, C.c_int, c_double_p, c_double_p, c_double_p]),
     "qgd_fvsc_div_t": (C.c_int, [handle, C.c_int, c_double_p, c_double_p, c_double_p]),
+    "qgd_fvsc_grad_s_dev": (C.c_int, [handle, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "qgd_fvsc_grad_v_dev": (C.c_int, [handle, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "qgd_fvsc_div_v_dev": (C.c_int, [handle, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "qgd_fvsc_div_t_dev": (C.c_int, [handle, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "qgd_interpolate_dev": (C.c_int, [handle, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "qgd_device_sync": (C.c_int, [handle]),
+    "qgd_device_copy": (C.c_int, [handle, C.c_void_p, C.c_void_p, C.c_int64, C.c_int]),
+    "qgd_qhd_fluxes_dev": (C.c_int, [handle, C.c_int, C.c_void_p, C.c_void_p]),
+    "qgd_species_flux_dev": (C.c_int, [handle, C.c_int] + [C.c_void_p] * 10),
     "qgd_device_op_times": (C.c_int, [handle, c_double_p]),
     "qgd_device_face_tiles": (C.c_int, [handle, C.POINTER(C.c_int64)]),
     "qgd_interpolate": (C.c_int, [handle, C.c_int32, c_double_p, c_double_p, c_double_p]),

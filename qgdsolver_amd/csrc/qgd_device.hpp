@@ -139,6 +139,8 @@ void launchExtractField(hipStream_t s, const RecA* A, const RecB* B, const doubl
 void launchFvscOp(hipStream_t s, int stencil, int op, int NC, const MeshView& m, const double* cell, const double* bnd,
                   double* pt, double* out);
 
+void launchPack5(hipStream_t s, int64_t n, const double* U, const double* T, const double* p, double* out);
+void launchSoaToAos(hipStream_t s, int64_t n, int nc, const double* src, double* dst);
 void launchInterpolate(hipStream_t s, int NC, const MeshView& m, const double* cell, const double* bnd, double* out);
 
 // ---- QHDFoam face fluxes --------------------------------------------------------

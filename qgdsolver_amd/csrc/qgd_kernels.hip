@@ -1472,6 +1472,27 @@ void launchHaloPack(const Launcher& L, const CaseView& c, const int32_t* cells, 
     haloKernel<<<gridFor(n), QGD_BLOCK, 0, L.stream>>>(c, cells, nCells, bfaces, nFaces, buf, pack ? 1 : 0);
 }
 
+// helpers of the device-pointer operator entries: {U,T,p} -> 5-component records; SoA result slots -> one AoS face field
+__global__ __launch_bounds__(QGD_BLOCK) void pack5Kernel(const int64_t n, const double* __restrict__ U, const double* __restrict__ T,
+                                                        const double* __restrict__ p, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * QGD_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    out[5 * i] = U[3 * i]; out[5 * i + 1] = U[3 * i + 1]; out[5 * i + 2] = U[3 * i + 2];
+    out[5 * i + 3] = T[i];
+    out[5 * i + 4] = p ? p[i] : 0.0;
+}
+__global__ __launch_bounds__(QGD_BLOCK) void soaToAosKernel(const int64_t n, const int nc, const double* __restrict__ src, double* __restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * QGD_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    for (int k = 0; k < nc; ++k) dst[i * nc + k] = src[(size_t)k * n + i];
+}
+void launchPack5(hipStream_t s, int64_t n, const double* U, const double* T, const double* p, double* out) {
+    if (n > 0) pack5Kernel<<<gridFor(n), QGD_BLOCK, 0, s>>>(n, U, T, p, out);
+}
+void launchSoaToAos(hipStream_t s, int64_t n, int nc, const double* src, double* dst) {
+    if (n > 0) soaToAosKernel<<<gridFor(n), QGD_BLOCK, 0, s>>>(n, nc, src, dst);
+}
+
 void launchExtractField(hipStream_t s, const RecA* A, const RecB* B, const double* K, const double* hq, const double* aQ, int64_t n,
                         const GasModel& g, int field, double* out) {
     if (n == 0) return;

@@ -305,6 +305,12 @@ __global__ __launch_bounds__(QGD_BLOCK) void qhdHaloKernel(const QhdView q, doub
     }
 }
 
+__global__ __launch_bounds__(QGD_BLOCK) void qhdRefShiftKernel(const int nC, const int nBF, const QhdView q, const double* __restrict__ shift) {
+    const int i = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    if (i < nC) q.p[i] += shift[0];
+    else if (i < nC + nBF) q.pb[i - nC] += shift[0];
+}
+
 // createFields: cell records from U, T (host order) and p
 __global__ __launch_bounds__(QGD_BLOCK) void qhdInitKernel(const int nC, const QhdView q, const double* __restrict__ U, const double* __restrict__ T,
                                                           const double* __restrict__ p) {

@@ -39,6 +39,24 @@ class Device:
     def release(self, ptr):
         L.check(L.lib.qgd_device_release(self._h, C.c_void_p(ptr)), "qgd_device_release")
 
+    def sync(self):
+        """wait for everything queued on the device handle's stream (the *_dev operator entries are stream-ordered)"""
+        L.check(L.lib.qgd_device_sync(self._h), "qgd_device_sync")
+
+    def to_device(self, array):
+        """copy a host array into a fresh device buffer; returns the device pointer"""
+        a = np.ascontiguousarray(array, dtype=np.float64)
+        ptr = self.alloc(max(a.nbytes, 8))
+        if a.nbytes:
+            L.check(L.lib.qgd_device_copy(self._h, C.c_void_p(ptr), a.ctypes.data_as(C.c_void_p), a.nbytes, 1), "qgd_device_copy")
+        return ptr
+
+    def to_host(self, ptr, shape):
+        out = np.zeros(shape, dtype=np.float64)
+        if out.nbytes:
+            L.check(L.lib.qgd_device_copy(self._h, out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), out.nbytes, 0), "qgd_device_copy")
+        return out
+
     def face_tiles(self):
         """how the internal faces go through the 3-D GaussVolPoint flux kernel (qgd_device_face_tiles)"""
         a = (C.c_int64 * 4)()
@@ -65,6 +83,15 @@ class volField:
         self.internal = np.ascontiguousarray(internal, dtype=np.float64)
         self.boundary = np.ascontiguousarray(boundary, dtype=np.float64)
         self.ncomp = 1 if self.internal.ndim == 1 else self.internal.shape[1]
+
+
+class deviceVolField:
+    """A vol<Type>Field whose internal and patch values already live in device memory (pointers of ``Device.alloc`` /
+    ``Device.to_device``): the operators take it through the ``*_dev`` entries -- nothing is staged, nothing crosses PCIe --
+    and return the DEVICE pointer of the face field they wrote into ``out`` (nFaces x ncompOut doubles, caller-owned)."""
+
+    def __init__(self, name, internal_ptr, boundary_ptr, ncomp):
+        self.name, self.internal, self.boundary, self.ncomp = name, int(internal_ptr), int(boundary_ptr), int(ncomp)
 
 
 class fvscStencil:
@@ -96,10 +123,16 @@ class fvscStencil:
             dev._registry[word] = cls.New(word, dev)
         return dev._registry[word]
 
-    def _op(self, fn, vf, ncomp_in, ncomp_out):
+    def _op(self, fn, vf, ncomp_in, ncomp_out, out=None):
         m = self.dev.mesh
         if vf.ncomp != ncomp_in:
             raise ValueError(f"{fn}: field has {vf.ncomp} components, expected {ncomp_in}")
+        if isinstance(vf, deviceVolField):
+            if out is None:
+                raise ValueError(f"{fn}_dev: a device-resident field needs the device pointer of its result (out=)")
+            L.check(getattr(L.lib, fn + "_dev")(self.dev._h, self.stencil_id, C.c_void_p(vf.internal), C.c_void_p(vf.boundary),
+                                                C.c_void_p(out)), fn + "_dev")
+            return out
         out = np.zeros((m.nFaces, ncomp_out) if ncomp_out > 1 else (m.nFaces,), dtype=np.float64)
         bnd = vf.boundary if vf.boundary.size else np.zeros(1)
         L.check(getattr(L.lib, fn)(self.dev._h, self.stencil_id, vf.internal.ctypes.data_as(L.c_double_p),
@@ -107,18 +140,18 @@ class fvscStencil:
         return out
 
     # the four virtuals (fvscStencil.H L105-130)
-    def Grad(self, vf):
+    def Grad(self, vf, out=None):
         if vf.ncomp == 1:
-            return self._op("qgd_fvsc_grad_s", vf, 1, 3)
+            return self._op("qgd_fvsc_grad_s", vf, 1, 3, out)
         if vf.ncomp == 3:
-            return self._op("qgd_fvsc_grad_v", vf, 3, 9)
+            return self._op("qgd_fvsc_grad_v", vf, 3, 9, out)
         raise L.QgdError(L.ERR_NOT_IMPLEMENTED, "Grad of a field that is neither scalar nor vector")
 
-    def Div(self, vf):
+    def Div(self, vf, out=None):
         if vf.ncomp == 3:
-            return self._op("qgd_fvsc_div_v", vf, 3, 1)
+            return self._op("qgd_fvsc_div_v", vf, 3, 1, out)
         if vf.ncomp == 9:
-            return self._op("qgd_fvsc_div_t", vf, 9, 3)
+            return self._op("qgd_fvsc_div_t", vf, 9, 3, out)
         raise L.QgdError(L.ERR_NOT_IMPLEMENTED, "Div of a field that is neither vector nor tensor")
 
 
@@ -132,18 +165,21 @@ def fvscOpName(dev, term_name):
     return d[term_name] if term_name in d else d["default"]
 
 
-def grad(dev, vf):
-    return fvscStencil.lookupOrNew(fvscOpName(dev, f"grad({vf.name})"), dev).Grad(vf)
+def grad(dev, vf, out=None):
+    return fvscStencil.lookupOrNew(fvscOpName(dev, f"grad({vf.name})"), dev).Grad(vf, out)
 
 
-def div(dev, vf):
-    return fvscStencil.lookupOrNew(fvscOpName(dev, f"div({vf.name})"), dev).Div(vf)
+def div(dev, vf, out=None):
+    return fvscStencil.lookupOrNew(fvscOpName(dev, f"div({vf.name})"), dev).Div(vf, out)
 
 
-def qgdInterpolate(dev, vf):
+def qgdInterpolate(dev, vf, out=None):
     """QGDInterpolate.H L38-67 with no interpolationSchemes entry: linearInterpolate."""
     m = dev.mesh
     nc = vf.ncomp
+    if isinstance(vf, deviceVolField):
+        L.check(L.lib.qgd_interpolate_dev(dev._h, nc, C.c_void_p(vf.internal), C.c_void_p(vf.boundary), C.c_void_p(out)), "qgd_interpolate_dev")
+        return out
     out = np.zeros((m.nFaces, nc) if nc > 1 else (m.nFaces,))
     bnd = vf.boundary if vf.boundary.size else np.zeros(1)
     L.check(L.lib.qgd_interpolate(dev._h, nc, vf.internal.ctypes.data_as(L.c_double_p), bnd.ctypes.data_as(L.c_double_p),

@@ -22,6 +22,8 @@ class _Out(C.Structure):
                                             "phiTauTReg")]
 
 
+QhdInputs, QhdOutputs = _In, _Out   # qgd_qhd_inputs / qgd_qhd_outputs (host pointers for qgd_qhd_fluxes, device pointers for _dev)
+
 L.lib.qgd_qhd_fluxes.restype = C.c_int
 L.lib.qgd_qhd_fluxes.argtypes = [L.handle, C.c_int, C.POINTER(_In), C.POINTER(_Out)]
 
