@@ -49,6 +49,11 @@ def parse():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--edge", dest="n", type=int, default=int(os.environ.get("QGD_BENCH_N", "400")), help="box edge in cells (n^3 cells in total)")
+    ap.add_argument("--workload", default="qgd", choices=["qgd", "qhd"],
+                    help="qgd: the headline (QGDFoam explicit step, BASELINE.json configs 3/4); qhd: the QHDFoam step of config 5 "
+                         "(semi-implicit: flux assembly + pressure equation), one GPU, its own metric line")
+    ap.add_argument("--irregular", action="store_true", help="qhd: the config-5 stand-in mesh (jittered vertices, every 7th quad split into "
+                                                             "triangles, labels shuffled in chunks then Morton-ordered) instead of a uniform box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropin", action="store_true", help="skip the second line (fvsc drop-in path with host fields)")
     ap.add_argument("--dropin-n", type=int, default=200, help="box edge of the fvsc drop-in measurement")
@@ -304,8 +309,118 @@ def self_launch(n_ranks):
     sys.exit(min(worst, 255))
 
 
+# ---- QHDFoam (config 5) -----------------------------------------------------------------------------------------------
+# ALGORITHMIC bytes per cell-step of the QHDFoam step on a hexahedral mesh with GaussVolPoint (3 internal faces and 1 vertex per
+# cell; face geometry counted as SURVEY.md 8(d) counts it for the QGD kernel: 80 B of Gauss coefficients per face), by pass:
+#   vertex values of {U,T}: gather list 8 x (4 + 8) + 4, 32 read, 32 written                                   = 164
+#   face pass 1 [updateFields.H L36-73, updateFluxes.H L33-38]: per face 8 + 24 + 8 + 16 + 80 + tau 8 in, phiu, phiwo,
+#       phiTauTReg, Uf & gradUf (3), BdFrcf (3) out = 72; cell and vertex records 32 + 32                      = 3 x 216 + 64 = 712
+#   fvc::grad(U): 6 face labels 24, 3 x Sf 24, V 8, U 24, 72 written                                            = 200
+#   vertex values of p: 100 + 8 + 8                                                                             = 116
+#   face pass 2 [QHDUEqn.H L36-84, QHDTEqn.H L65-91]: per face 136 + tau, phi, phiTauTReg 24 + ugu, bdf 48 in, 32 out;
+#       per cell {U,T} 32 + p 8 + grad(U) 72, per vertex p 8                                                    = 3 x 240 + 120 = 840
+#   cell update: 24 + 3 x 32 + V 8 + 32 read + 32 written                                                       = 192
+# and per iteration of the pressure solve [QHDpEqn.H L35-47] (multigrid-preconditioned CG; single-precision cycle):
+#   level 0 of the V-cycle: 4 full sweeps x (6 x (4 + 4) + 16) = 256, the first sweep from zero 12, restriction / prolongation 16;
+#   coarser levels add a third (4:1 coarsening)                                                                 = 284 x 4/3 = 379
+#   CG: A d 6 x 12 + 24 = 96, x and r updates 40, two dot products 32, new direction 24, precision conversions 24 = 216
+QHD_EXPLICIT_BYTES_PER_CELL = 164 + 712 + 200 + 116 + 840 + 192
+QHD_BYTES_PER_CELL_PER_ITERATION = 379 + 216
+
+
+def qhd_line(args):
+    """python bench.py --workload qhd [--edge N] [--irregular]: Mcell-steps/s of the resident QHDFoam step (qgd_qhd_case_step)."""
+    import qgdsolver_amd as q
+    from qgdsolver_amd import qhdfoam
+
+    if q.device_count() < 1:
+        raise RuntimeError("bench.py needs a HIP device: qgdsolver_amd has no CPU fallback")
+    n = args.n
+    t_setup = time.perf_counter()
+    if args.irregular:
+        from test_config5_gpu import c5_mesh
+        mesh = c5_mesh(n, 64 ** 3)
+    else:
+        mesh = q.PolyMesh.box(n, n, n)
+    h = 1.0 / n
+    dev = q.Device(mesh)
+    opt = qhdfoam.qhd_options(stencil="GaussVolPoint", tauModel="HbyUQHD", aQGD=0.5, UQHD=0.1, rho0=1.0, mu=1e-3, Pr=0.71, beta=3.4e-3,
+                              g=(0.0, -9.81, 0.0), deltaT=0.02 * h / 0.1, pTol=1e-8, pMaxIter=300, pRefCell=0)
+    case = qhdfoam.QHDFoamCase(dev, opt)
+    WALL = dict(U=("fixedValue", (0.0, 0.0, 0.0)), T=("zeroGradient", None), p=("qhdFluxCoupled", None))
+    for ip in range(mesh.nPatches):   # buoyant cavity: hot xMin, cold xMax, adiabatic walls, impermeable (qhdFlux fed by the flux)
+        case.set_bc(ip, U=WALL["U"], T=("fixedValue", 310.0) if ip == 0 else (("fixedValue", 290.0) if ip == 1 else WALL["T"]), p=WALL["p"])
+    C = mesh.array("C").reshape(-1, 3)
+    rng = np.random.default_rng(5)
+    U = np.zeros((mesh.nCells, 3))
+    U[:, 0] = 0.1 * np.sin(np.pi * C[:, 0]) * np.cos(np.pi * C[:, 1])
+    U[:, 1] = -0.1 * np.cos(np.pi * C[:, 0]) * np.sin(np.pi * C[:, 1])
+    T = 300.0 + 10.0 * (0.5 - C[:, 0]) + 0.1 * rng.standard_normal(mesh.nCells)
+    case.set_fields(U, T, np.zeros(mesh.nCells))
+    del U, T, C
+    nc = mesh.nCells
+    t_setup = time.perf_counter() - t_setup
+    case.step(max(args.warmup, 1))
+    t0 = time.perf_counter()
+    case.step(args.steps)          # returns after the device has finished
+    elapsed = time.perf_counter() - t0
+    info = case.info()
+    # second pass: where the time goes (host clock around stream-ordered phases, each followed by a wait)
+    phase_ms = {"assemble": 0.0, "solve": 0.0, "advance": 0.0}
+    iters = []
+    reps = min(args.steps, 5)
+    for _ in range(reps):
+        case.sync(); t = time.perf_counter()
+        case.step_phase(0); case.sync()
+        phase_ms["assemble"] += time.perf_counter() - t; t = time.perf_counter()
+        for k in (1, 2):
+            case.step_phase(k)
+        while not case.solve_status()["done"]:
+            for k in (3, 4, 5):
+                case.step_phase(k)
+        iters.append(case.solve_status()["iterations"])
+        phase_ms["solve"] += time.perf_counter() - t; t = time.perf_counter()
+        for k in (6, 7, 8):
+            case.step_phase(k)
+        case.sync()
+        phase_ms["advance"] += time.perf_counter() - t
+    phase_ms = {k: 1e3 * v / reps for k, v in phase_ms.items()}
+    sw = case.sweep_time(30)
+    sweep_bytes = sw["rows"] * (sw["width"] * (4 + sw["value_bytes"]) + 4 * sw["value_bytes"])
+    achieved = sweep_bytes / (sw["ms"] * 1e-3) / 1e9 if sw["ms"] else None
+    it = info["pIterations"]
+    step_bytes = nc * (QHD_EXPLICIT_BYTES_PER_CELL + QHD_BYTES_PER_CELL_PER_ITERATION * it)
+    out = {
+        "metric": "Mcell-steps/s (QHDFoam step)", "value": nc * args.steps / elapsed / 1e6, "unit": "Mcell-steps/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": (f"QHDFoam buoyant cavity, {nc / 1e6:.1f}M cells, "
+                                + ("config-5 stand-in mesh (jittered hexahedra, every 7th quad split into triangles, Morton order)" if args.irregular
+                                   else "uniform hex box (blockMesh numbering)")
+                                + ", GaussVolPoint, HbyUQHD, pressure equation to 1e-8 with multigrid-preconditioned CG"),
+                   "cells": nc, "pressure_iterations_per_step": it, "multigrid_levels": info["mgLevels"]},
+        "roofline": {"bound": "hbm", "kernel": "mgSmoothKernel<float>, multigrid level 0 (one damped-Jacobi sweep of the pressure preconditioner)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS if achieved else None,
+                     "traffic": None, "algorithmic_bytes_per_launch": sweep_bytes, "avg_launch_ms": sw["ms"]},
+        "step_bytes_model": {"explicit_bytes_per_cell": QHD_EXPLICIT_BYTES_PER_CELL, "bytes_per_cell_per_pressure_iteration": QHD_BYTES_PER_CELL_PER_ITERATION,
+                             "bytes_per_step": step_bytes},
+        "step_roofline_frac": step_bytes * args.steps / elapsed / (HBM_PEAK_GBS * 1e9),
+        "phase_ms": phase_ms, "pressure_iterations_second_pass": iters, "pressure_final_residual": info["pFinalResidual"],
+        "setup_s": t_setup,
+    }
+    case.close(); dev.close()
+    print(json.dumps(out), flush=True)
+
+
 def main():
     args = parse()
+    if args.workload == "qhd":
+        if args.gpus != 1:
+            sys.exit("bench.py --workload qhd measures one GPU (the sharded QHD step is driven by qgd_qhd_case_step_sharded, see DESIGN.md)")
+        if "QGD_BENCH_N" not in os.environ and "--edge" not in " ".join(sys.argv):
+            args.n = 252 if args.irregular else 200
+        qhd_line(args)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.cpu_only:
         self_launch(args.gpus)   # never returns
     world = int(os.environ.get("WORLD_SIZE", "1"))

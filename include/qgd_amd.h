@@ -392,6 +392,9 @@ int qgd_qhd_case_control(qgd_qhd_case_t c, double control[16], int set);
 /* waits for the stream; status = {done (0 no, 1 converged or out of iterations, 2 breakdown), iterations, initial, final residual} */
 int qgd_qhd_case_solve_status(qgd_qhd_case_t c, double status[4]);
 int qgd_qhd_case_sync(qgd_qhd_case_t c);
+/* measurement: `reps` smoothing sweeps of multigrid level 0 (the kernel the pressure solve spends most of its time in) between two
+ * HIP events; info = {average ms per sweep, rows, ELL width, bytes per matrix value and vector entry (4: single-precision cycle)} */
+int qgd_qhd_case_sweep_time(qgd_qhd_case_t c, int reps, double info[4]);
 int qgd_qhd_case_halo_count(qgd_qhd_case_t c, int slot, int kind, int64_t* sendCount, int64_t* recvCount);
 int qgd_qhd_case_halo_pack(qgd_qhd_case_t c, int slot, int kind, double* sendBufDevice);
 int qgd_qhd_case_halo_unpack(qgd_qhd_case_t c, int slot, int kind, const double* recvBufDevice);

@@ -1715,6 +1715,17 @@ int qgd_qhd_case_control_ptr(qgd_qhd_case_t c, void** devicePtr) {
     *devicePtr = pressureSolverCtl(c->solver);
     return QGD_OK;
 }
+int qgd_qhd_case_sweep_time(qgd_qhd_case_t c, int reps, double info[4]) {
+    QGD_TRY
+    if (!c || !info || reps <= 0) return fail(QGD_ERR_INVALID, "bad argument");
+    if (!c->solver) return fail(QGD_ERR_INVALID, "qgd_qhd_case_sweep_time: call qgd_qhd_case_set_fields first");
+    HIP_CHECK(hipSetDevice(c->dev->deviceId));
+    int rows = 0, width = 0;
+    info[0] = pressureSolverSweepMs(c->solver, reps, &rows, &width);
+    info[1] = rows; info[2] = width; info[3] = pressureSolverSinglePrecisionCycle(c->solver) ? 4.0 : 8.0;
+    return QGD_OK;
+    QGD_CATCH
+}
 int qgd_qhd_case_control(qgd_qhd_case_t c, double control[16], int set) {
     QGD_TRY
     if (!c || !control) return fail(QGD_ERR_INVALID, "null argument");

@@ -982,6 +982,41 @@ int pressureSolveRun(PressureSolver* S, const SolveHooks* hooks, double residual
     residuals[0] = st[2]; residuals[1] = st[3];
     return (int)st[1];
 }
+// measurement: `reps` full damped-Jacobi sweeps of multigrid level 0 (the kernel a solve spends most of its time in) between two
+// HIP events on the solver's stream; returns the average milliseconds per sweep (0 without a hierarchy).  rows / width: the ELL
+// shape of that level, for the byte model.
+double pressureSolverSweepMs(PressureSolver* S, int reps, int* rows, int* width) {
+    if (rows) *rows = 0;
+    if (width) *width = 0;
+    if (S->L.empty() || reps <= 0) return 0.0;
+    hipEvent_t a, b;
+    PCHECK(hipEventCreate(&a)); PCHECK(hipEventCreate(&b));
+    float ms = 0;
+    const int nb = blocksOf(S->L[0].n);
+    if (rows) *rows = S->L[0].n;
+    if (width) *width = S->L[0].width;
+    if (!S->Lf.empty()) {
+        MgLevelT<float>& lv = S->Lf[0];
+        float* noOut = nullptr;
+        mgSmoothKernel<float><<<nb, PB, 0, S->stream>>>(lv, (float)S->omega, lv.b, lv.x, lv.x2, noOut, nullptr);
+        PCHECK(hipEventRecord(a, S->stream));
+        for (int i = 0; i < reps; ++i) mgSmoothKernel<float><<<nb, PB, 0, S->stream>>>(lv, (float)S->omega, lv.b, (i & 1) ? lv.x2 : lv.x, (i & 1) ? lv.x : lv.x2, noOut, nullptr);
+        PCHECK(hipEventRecord(b, S->stream));
+    } else {
+        MgLevelDev& lv = S->L[0];
+        double* noOut = nullptr;
+        mgSmoothKernel<double><<<nb, PB, 0, S->stream>>>(lv, S->omega, lv.b, lv.x, lv.x2, noOut, nullptr);
+        PCHECK(hipEventRecord(a, S->stream));
+        for (int i = 0; i < reps; ++i) mgSmoothKernel<double><<<nb, PB, 0, S->stream>>>(lv, S->omega, lv.b, (i & 1) ? lv.x2 : lv.x, (i & 1) ? lv.x : lv.x2, noOut, nullptr);
+        PCHECK(hipEventRecord(b, S->stream));
+    }
+    PCHECK(hipEventSynchronize(b));
+    PCHECK(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    return (double)ms / reps;
+}
+bool pressureSolverSinglePrecisionCycle(const PressureSolver* S) { return !S->Lf.empty(); }
+
 // single rank, everything: rhs, solve, flux
 int pressureSolve(PressureSolver* S, const double* phiu, const double* phiwo, const double* pb, const double* gb, double tolerance,
                   double relTol, int maxIter, double* p, double* phi, double residuals[2]) {

@@ -232,6 +232,12 @@ class QHDFoamCase:
     def sync(self):
         L.check(L.lib.qgd_qhd_case_sync(self._h), "qgd_qhd_case_sync")
 
+    def sweep_time(self, reps=20):
+        """average ms of one level-0 smoothing sweep of the pressure multigrid (HIP events), its rows, ELL width, bytes per value"""
+        a = (C.c_double * 4)()
+        L.check(L.lib.qgd_qhd_case_sweep_time(self._h, int(reps), a), "qgd_qhd_case_sweep_time")
+        return dict(ms=a[0], rows=int(a[1]), width=int(a[2]), value_bytes=int(a[3]))
+
     def halo_count(self, slot, kind):
         s, r = C.c_int64(), C.c_int64()
         L.check(L.lib.qgd_qhd_case_halo_count(self._h, int(slot), int(kind), C.byref(s), C.byref(r)), "qgd_qhd_case_halo_count")
