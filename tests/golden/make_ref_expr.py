@@ -69,7 +69,7 @@ def lines(name, a, b):
 # ----------------------------------------------------------------------------------------------------------------------
 # C++ statement syntax -> Python statement syntax (expressions are left alone)
 # ----------------------------------------------------------------------------------------------------------------------
-TYPES = r"(?:const\s+)?(?:scalar|label|vector|tensor|symmTensor|bool|face|fvPatch|surfaceScalarField|surfaceVectorField)\b\s*&?"
+TYPES = r"(?:const\s+)?(?:scalar|label|vector|tensor|symmTensor|bool|face|fvPatch|cell|surfaceScalarField|surfaceVectorField|volScalarField)\b\s*&?"
 
 
 def strip_comments(src):
@@ -124,6 +124,12 @@ def statement(st):
     m = re.match(r"^(\w+)\.ref\(\)\s*=(?!=)\s*(.*)$", st)                              # U.ref() = expr: values into the existing field
     if m:
         return [f"{m.group(1)}.assign({expr(m.group(2))})"]
+    m = re.match(r"^surface(?:Scalar|Vector|Tensor)Field\s+(\w+)\s*\((.*)\)$", st)        # surfaceScalarField Cof("Cof", expr) | dfdn(expr)
+    if m:
+        args = split_top(m.group(2))
+        if len(args) == 2 and re.match(r'^\s*"\w+"\s*$', args[0]):
+            return [f"{m.group(1)} = {expr(args[1])}"]
+        return [f"{m.group(1)} = {expr(m.group(2))}"]
     m = re.match(r"^tmp<\s*\w+\s*>\s+(\w+)\s*\((.*)\)$", st)                          # tmp<surfaceVectorField> t(expr)
     if m:
         return [f"{m.group(1)} = {expr(m.group(2))}"]
@@ -1137,6 +1143,337 @@ def species(nfaces=30, seed=16):
     return {k: np.array(v) for k, v in rec.items()}
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# round 3: the listing sections that were still outside the mechanical pin
+# ----------------------------------------------------------------------------------------------------------------------
+class Stream:
+    """Info << ... << endl"""
+    def __lshift__(self, o): return self
+
+
+def gvp2d_vec(nfaces=30, seed=21):
+    """The 2-D GaussVolPoint operators on VECTOR fields, one internal quad between two cells of a one-cell-thick mesh: the gradient
+    through the per-component calls and the re-pack of GaussVolPointBase.C L90-100 (gradf component 3*i+j = d_i U_j), the
+    divergence through GaussVolPointBase2D.C L386-396 (vector) and L447-450, L464-484 (tensor)."""
+    f2 = "GaussVolPointBase2D_8C_source.html"
+    coef_src = transpile(lines(f2, 154, 168))
+    apply_src = transpile(lines(f2, 317, 328))
+    repack_src = transpile(lines("GaussVolPointBase_8C_source.html", 90, 100))
+    divv_src = transpile(lines(f2, 386, 396))
+    idx_src = transpile(lines(f2, 447, 450))
+    divt_src = transpile(lines(f2, 464, 484))
+    rng = np.random.default_rng(seed)
+    rec = {k: [] for k in ("ie3", "pts", "Sf", "Cf", "C", "U", "Tn", "grad_v", "div_v", "div_t")}
+    for n in range(nfaces):
+        ie3 = n % 3
+        ie1, ie2 = (1, 2) if ie3 == 0 else ((0, 2) if ie3 == 1 else (0, 1))
+        e1, e2 = Vec(*np.eye(3)[ie1]), Vec(*np.eye(3)[ie2])
+
+        def place(a, b, h):
+            v = np.zeros(3); v[ie1], v[ie2], v[ie3] = a, b, h
+            return Vec(*v)
+        C4 = place(*(0.2 * rng.standard_normal(2)), 0.05)
+        C2 = place(1.0 + 0.2 * rng.standard_normal(), 0.2 * rng.standard_normal(), 0.05)
+        a0, b0 = 0.5 + 0.2 * rng.standard_normal(), -0.5 + 0.2 * rng.standard_normal()
+        a1, b1 = 0.5 + 0.2 * rng.standard_normal(), 0.5 + 0.2 * rng.standard_normal()
+        order = [(a0, b0, 0.0), (a0, b0, 0.1), (a1, b1, 0.1), (a1, b1, 0.0)]
+        shift = n % 4
+        order = order[shift:] + order[:shift]
+        pts = [place(*o) for o in order]
+        upper = [k for k, o in enumerate(order) if o[2] >= 0.05]
+        ip1, ip3 = upper[0], upper[1]
+        mesh = Obj(C=call([C4, C2]), points=call(pts))
+        one = lambda: [None]  # noqa: E731
+        env = dict(mesh=mesh, iFace=0, ic2=1, ic4=0, ip1=ip1, ip3=ip3, e1_=e1, e2_=e2, mag=mag, v42=one(), v13=one(), mv42_=one(),
+                   mv13_=one(), cosa1=one(), cosa2=one(), sina1=one(), sina2=one(), den=one(), c1_=one(), c2_=one(), c3_=one(), c4_=one())
+        exec(coef_src, env)
+        U = [rng.standard_normal(3), rng.standard_normal(3)]            # owner (ic4), neighbour (ic2)
+        comp_grads = []
+        for k in range(3):
+            fvals = [float(U[0][k]), float(U[1][k])]
+            pvals = [inv_dist(x, [C4, C2], fvals) for x in pts]
+            g = [[0.0, 0.0, 0.0]]
+            e = dict(env)
+            e.update(f=fvals, pF=pvals, gradf=g, ic2_=[1], ic4_=[0], ip1_=[ip1], ip3_=[ip3], ie1_=ie1, ie2_=ie2, ie3_=ie3, dfdn=0.0, dfdt=0.0)
+            exec(apply_src, e)
+            comp_grads.append(g)
+
+        class VFld(list):      # a surfaceVectorField's internal part: .primitiveField().component(c)
+            def primitiveField(self): return self
+            def component(self, c): return [v[c] for v in self]
+
+        class TFld(list):      # a surfaceTensorField's internal part: .primitiveFieldRef().replace(k, values)
+            def primitiveFieldRef(self): return self
+            def replace(self, k, vals):
+                for row, v in zip(self, vals):
+                    row[k] = v
+        gradf = TFld([[None] * 9])
+        exec(repack_src, dict(gradf=gradf, gradU=VFld(comp_grads[0]), gradV=VFld(comp_grads[1]), gradW=VFld(comp_grads[2])))
+        # divergence of the vector field
+        fU = [list(map(float, U[0])), list(map(float, U[1]))]
+        pU = [list(inv_dist(x, [C4, C2], [Vec(*U[0]), Vec(*U[1])]).c) for x in pts]
+        dv = [None]
+        e = dict(env)
+        e.update(f=fU, pF=pU, divf=dv, ic2_=[1], ic4_=[0], ip1_=[ip1], ip3_=[ip3], ie1_=ie1, ie2_=ie2, ie3_=ie3, df1dn=0.0, df2dn=0.0, df1dt=0.0, df2dt=0.0)
+        exec(divv_src, e)
+        # divergence of a tensor field
+        Tn = [rng.standard_normal(9), rng.standard_normal(9)]
+        fT = [list(map(float, Tn[0])), list(map(float, Tn[1]))]
+        w = [1.0 / float(np.sqrt(((x.c - c.c) ** 2).sum())) for x in pts for c in (C4, C2)]
+        pT = []
+        for k, x in enumerate(pts):
+            w0, w1 = w[2 * k], w[2 * k + 1]
+            pT.append(list((w0 / (w0 + w1)) * Tn[0] + (w1 / (w0 + w1)) * Tn[1]))
+        dt_ = [[0.0, 0.0, 0.0]]
+        e = dict(env)
+        e.update(f=fT, pF=pT, divf=dt_, ic2_=[1], ic4_=[0], ip1_=[ip1], ip3_=[ip3], ie1_=ie1, ie2_=ie2, ie3_=ie3)
+        for nm in ("df11dn", "df11dt", "df21dn", "df21dt", "df22dn", "df22dt", "df12dn", "df12dt"):
+            e[nm] = 0.0
+        exec(idx_src, e)
+        exec(divt_src, e)
+        S, cf = face_area_centre(pts)
+        rec["ie3"].append(ie3); rec["pts"].append(np.array([p.c for p in pts])); rec["Sf"].append(S); rec["Cf"].append(cf)
+        rec["C"].append(np.array([C4.c, C2.c])); rec["U"].append(np.array(U)); rec["Tn"].append(np.array(Tn))
+        rec["grad_v"].append(gradf[0]); rec["div_v"].append(dv[0]); rec["div_t"].append(dt_[0])
+    return {k: np.array(v, dtype=float) for k, v in rec.items()}
+
+
+def gvp_other(nfaces=16, seed=22):
+    """Internal faces with MORE THAN FOUR vertices: the 3-D GaussVolPoint gradient falls back to dfdn = nf * snGrad
+    [GaussVolPointBase3D.C L945-948 / L976-979, L759-768 / L856-865]; nf = Sf / |Sf| [fvscStencil.C L126-129]; fvc::snGrad is the
+    uncorrected one, nonOrthDeltaCoeffs (phi_N - phi_O) (L0)."""
+    f3 = "GaussVolPointBase3D_8C_source.html"
+    nf_l = listing("fvscStencil_8C_source.html")
+    nf_src = transpile(["nf_ = " + nf_l[128].strip() + ";"])
+    dfdn_s = transpile(lines(f3, 945, 948))
+    dfdn_v = transpile(lines(f3, 976, 979))
+    other_s = transpile(lines(f3, 760, 768))
+    other_v = transpile(lines(f3, 857, 865))
+    rng = np.random.default_rng(seed)
+    rec = {k: [] for k in ("nv", "pts", "Sf", "Cf", "C", "cell_s", "cell_v", "grad_s", "grad_v")}
+    for n in range(nfaces):
+        nv = 5 + n % 2
+        ang = np.sort(rng.uniform(0, 2 * np.pi, nv))
+        pts = [Vec(0.05 * rng.standard_normal(), 0.5 + 0.5 * np.cos(a), 0.5 + 0.5 * np.sin(a)) for a in ang]
+        own = Vec(*(np.array([-0.5, 0.5, 0.5]) + 0.15 * rng.standard_normal(3)))
+        nei = Vec(*(np.array([0.5, 0.5, 0.5]) + 0.15 * rng.standard_normal(3)))
+        S, cf = face_area_centre(pts)
+        if S[0] < 0:
+            pts = pts[::-1]
+            S, cf = face_area_centre(pts)
+        Sv = Vec(*S)
+        d = nei - own
+        nhat = Sv / mag(Sv)
+        delta = 1.0 / max(nhat & d, 0.05 * mag(d))                       # nonOrthDeltaCoeffs (L0)
+        env = dict(mesh_=Obj(Sf=call(Fld([Sv])), magSf=call(Fld([mag(Sv)]))))
+
+        class DivFld(Fld):
+            def __truediv__(self, o): return Fld([a / b for a, b in zip(self, o)])
+        env["mesh_"] = Obj(Sf=call(DivFld([Sv])), magSf=call(Fld([mag(Sv)])))
+        exec(nf_src, env)
+        nf = env["nf_"]
+        fs = [float(rng.standard_normal()), float(rng.standard_normal())]
+        fv = [rnd_vec(rng), rnd_vec(rng)]
+
+        class Fld2(Fld):      # nf * snGrad: vector x scalar, vector x vector (outer product), face by face
+            def __mul__(self, o): return Fld([a * b for a, b in zip(self, o)])
+        e = dict(nf=Fld2(nf), fvc=Obj(snGrad=lambda fld: Fld([delta * (fld[1] - fld[0])])), sf=fs, vf=fv)
+        exec(dfdn_s, e)
+        gs = [None]
+        exec(other_s, dict(of_=[0], gradf=Obj(primitiveFieldRef=call(gs)), dfdn=Obj(primitiveField=call(e["dfdn"]))))
+        exec(dfdn_v, e)
+        gv = [None]
+        exec(other_v, dict(of_=[0], gradf=Obj(primitiveFieldRef=call(gv)), dfdn=Obj(primitiveField=call(e["dfdn"]))))
+        rec["nv"].append(nv); rec["pts"].append(np.array([p.c for p in pts] + [[0, 0, 0]] * (6 - nv))); rec["Sf"].append(S); rec["Cf"].append(cf)
+        rec["C"].append(np.array([own.c, nei.c])); rec["cell_s"].append(fs); rec["cell_v"].append(np.array([v.c for v in fv]))
+        rec["grad_s"].append(gs[0].c); rec["grad_v"].append(gv[0].m.reshape(9))
+    return {k: np.array(v, dtype=float) for k, v in rec.items()}
+
+
+def qgdlength():
+    """QGDCoeffs::updateQGDLength [QGDCoeffs.C L298-376] executed as listed over WHOLE small meshes (hQGDf of internal and patch
+    faces, the area-weighted hQGD of every cell, hQGD on the patches), starting from hQGDf = 1 / |deltaCoeffs| [L195-199].  Mesh
+    geometry (C, Cf, |Sf|, deltaCoeffs) and addressing (cells() = owned faces in ascending order, then neighbour faces) are the
+    L0 inputs; three meshes: jittered hexahedra, the same with split quads (prism-like cells), a one-cell-thick plane whose empty
+    patches must be skipped."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    import qgdsolver_amd as q
+    G, E = 0, 1
+    src = transpile(lines("QGDCoeffs_8C_source.html", 300, 375))
+    init_l = listing("QGDCoeffs_8C_source.html")[198].strip()
+    init_src = transpile(["hinit = " + init_l.replace("mesh.surfaceInterpolation::deltaCoeffs()", "deltaCoeffs") + ";"])
+    meshes = [q.PolyMesh.box(3, 2, 2).jitter(0.15, seed=31), q.PolyMesh.box(3, 2, 2).jitter(0.1, seed=32).split_quads(3),
+              q.PolyMesh.box(4, 3, 1, hi=(1.0, 0.75, 0.1), patch_types=[G, G, G, G, E, E]).jitter(0.12, seed=33)]
+    out = {"nMeshes": np.array(len(meshes))}
+    for mi, m in enumerate(meshes):
+        prim = m.primitives()
+        nIF, nF, nC = m.nInternalFaces, m.nFaces, m.nCells
+        Cc, Cf = m.array("C").reshape(-1, 3), m.array("Cf").reshape(-1, 3)
+        magSf, dc = m.array("magSf"), m.array("deltaCoeffs")
+        own, nei = prim["owner"], prim["neighbour"]
+        ps, pz, pt = prim["patchStart"], prim["patchSize"], prim["patchType"]
+        cells = [[] for _ in range(nC)]
+        for f in range(nF):
+            cells[own[f]].append(f)
+        for f in range(nIF):
+            cells[nei[f]].append(f)
+
+        class PF(Fld):
+            def __imul__(self, o): return PF([a * o for a in self])
+            def __mul__(self, o): return PF([a * o for a in self])
+
+        class AbsFld(list):
+            pass
+        e0 = dict(mag=lambda fl: [abs(x) for x in fl], deltaCoeffs=list(dc))
+
+        class Recip(float):
+            def __truediv__(self, lst): return [float(self) / x for x in lst]
+        # `1.0 / mag(...)`: a scalar divided by a field
+        init_py = init_src.replace("1.0 /", "Recip(1.0) /")
+        e0["Recip"] = Recip
+        exec(init_py, e0)
+        hinit = e0["hinit"]
+        fv_size = [0 if t == E else int(z) for t, z in zip(pt, pz)]          # emptyFvPatch::size() == 0 (L0)
+        hb = [PF([hinit[int(st) + k] for k in range(n)]) for st, n in zip(ps, fv_size)]
+        hint = list(hinit[:nIF])
+
+        class FaceField:
+            def primitiveField(self): return hint
+            def primitiveFieldRef(self): return hint
+            def boundaryFieldRef(self): return hb
+            def boundaryField(self): return hb
+            def __getitem__(self, f): return hint[f]
+
+        class MagSf:
+            def __getitem__(self, f): return float(magSf[f])
+            def boundaryField(self): return [[float(magSf[int(st) + k]) for k in range(n)] for st, n in zip(ps, fv_size)]
+
+        class BMesh:
+            def whichPatch(self, f):
+                for k, (st, n) in enumerate(zip(ps, pz)):
+                    if st <= f < st + n:
+                        return k
+                return -1
+            def __getitem__(self, k): return Obj(whichFace=lambda f, st=int(ps[k]): f - st)
+        kinds = {G: "fvPatch", E: "emptyFvPatch"}
+        patches = [Obj(kind=kinds[int(t)], coupled=lambda: False) for t in pt]
+        hc, hcb = [0.0] * nC, [None] * len(pt)
+
+        class CellField:
+            def __len__(self): return nC
+            def primitiveFieldRef(self): return hc
+            def boundaryFieldRef(self): return hcb
+        mesh = Obj(C=call([Vec(*c) for c in Cc]), Cf=call([Vec(*c) for c in Cf]), owner=call(list(own)), neighbour=call(list(nei)),
+                   boundary=call(patches), cells=call(cells), isInternalFace=lambda f: f < nIF, magSf=call(MagSf()), boundaryMesh=call(BMesh()))
+        env = dict(mesh=mesh, hQGDf_=FaceField(), hQGD_=CellField(), mag=mag, min=min, isA=lambda kind, o: o.kind == kind)
+        exec(src, env)
+        hf = np.zeros(nF)
+        hf[:nIF] = hint
+        hbnd = np.zeros(nF - nIF)
+        for k, (st, n) in enumerate(zip(ps, fv_size)):
+            for j in range(n):
+                hf[int(st) + j] = hb[k][j]
+                hbnd[int(st) - nIF + j] = hcb[k][j] if hcb[k] is not None else 0.0
+        for key, val in prim.items():
+            out[f"m{mi}_{key}"] = np.asarray(val)
+        out[f"m{mi}_hQGDf"], out[f"m{mi}_hQGD"], out[f"m{mi}_hQGDb"] = hf, np.array(hc), hbnd
+    return out
+
+
+def courant(case):
+    """QGDCourantNo.H L36-53 and setDeltaT-QGDQHD.H L41-61 on the one-face cases of case2cell (Uf, cf, hQGDf, tauQGDf, Sf as that
+    fixture's listing-text evaluation left them), and the speed of sound of hePsiQGDThermo.C L123-124 from psi = 1/(R T), gamma =
+    Cp/Cv of the cells.  Inputs beyond case2cell's: maxCo, maxDeltaT, cTau."""
+    co_src = transpile(lines("QGDCourantNo_8H_source.html", 36, 53))
+    dt_src = transpile(lines("setDeltaT-QGDQHD_8H_source.html", 41, 61))
+    th = listing("hePsiQGDThermo_8C_source.html")
+    c_src = transpile([th[123].replace("this->", "").replace("==", "="), th[124].replace("this->", "")])
+    rng = np.random.default_rng(23)
+    n = len(case["nv"])
+    rec = {k: [] for k in ("maxCo", "maxDeltaT", "cTau", "CoNum", "deltaT1", "c_cells")}
+    for i in range(n):
+        S = Vec(*case["Sf"][i])
+        Uf, cf, hf, tauf, dt = Vec(*case["Uf"][i]), float(case["cf"][i]), float(case["hQGDf"][i]), float(case["tauQGDf"][i]), float(case["deltaT"][i])
+        maxCo, maxDeltaT, cTau = float(rng.uniform(0.05, 0.6)), float(10.0 ** rng.uniform(-4, 0)), float(rng.uniform(0.3, 0.9))
+        ctrl = {"adjustTimeStep": True, "cTau": cTau}
+        holder = {"dt": dt}
+
+        class M(float):       # max(Cof) / min(tauQGDf) of a one-face field
+            def value(self): return float(self)
+
+        def fmax(*a): return M(a[0]) if len(a) == 1 else max(a)
+        def fmin(*a): return M(a[0]) if len(a) == 1 else min(a)
+
+        class VecDiv(Vec):    # mesh.Sf() / mesh.magSf()
+            pass
+        runTime = Obj(controlDict=call(Obj(lookupOrDefault=lambda key, dflt: ctrl.get(key, dflt))), deltaT=call(dt), deltaTValue=lambda: holder["dt"],
+                      setDeltaT=lambda v: holder.__setitem__("dt", float(v)))
+        env = dict(runTime=runTime, Uf=Uf, cf=cf, hQGDf=hf, mesh=Obj(Sf=call(S), magSf=call(mag(S))), max=fmax, mag=mag, Info=Stream(), endl=None,
+                   CoNum=0.0, bool=bool, false=False, true=True)
+        src = co_src.replace("lookupOrDefault<bool>", "lookupOrDefault")
+        exec(src, env)
+        env2 = dict(adjustTimeStep=True, maxCo=maxCo, CoNum=env["CoNum"], SMALL=1e-15, min=fmin, runTime=runTime, maxDeltaT=maxDeltaT,
+                    thermo=Obj(tauQGDf=call(call(tauf))), Info=Stream(), endl=None)
+        exec(dt_src.replace("lookupOrDefault<scalar>", "lookupOrDefault"), env2)
+        R, Cv = float(case["R"][i]), float(case["Cv"][i])
+        cc = []
+        for T in case["T"][i]:
+            e3 = dict(Cp=call(Cv + R), Cv=call(Cv), psi=call(1.0 / (R * float(T))), sqrt=lambda x: float(np.sqrt(x)))
+            exec(c_src, e3)
+            cc.append(e3["c_"])
+        for k, v in (("maxCo", maxCo), ("maxDeltaT", maxDeltaT), ("cTau", cTau), ("CoNum", float(env["CoNum"])), ("deltaT1", holder["dt"]),
+                     ("c_cells", cc)):
+            rec[k].append(v)
+    out = {k: np.array(v, dtype=float) for k, v in rec.items()}
+    for k in ("nv", "pts", "Sf", "Cf", "C", "V", "U", "T", "p", "R", "Cv", "mu", "Pr", "ScQGD", "PrQGD", "alphaQGD", "deltaT"):
+        out[k] = case[k]
+    return out
+
+
+def qhdclosure(nfaces=24, seed=24):
+    """tauQGD of the four QHD closures as listed [constTau.C L71-74, HbyUQHD.C L80-83, T0byGr.C L84-87, H2bynuQHD.C L78-82] on the two
+    cells of a one-face mesh (hQGDf from QGDCoeffs.C L305-307; a cell with one face has hQGD = hQGDf), tauQGDf = linearInterpolate."""
+    h_src = transpile(lines("QGDCoeffs_8C_source.html", 305, 307))
+    def body(fname, a, b): return transpile([ln.replace("this->", "") for ln in lines(fname, a, b)])
+    texts = [body("constTau_8C_source.html", 73, 74), body("HbyUQHD_8C_source.html", 82, 83), body("T0byGr_8C_source.html", 86, 87),
+             body("H2bynuQHD_8C_source.html", 80, 82)]
+    rng = np.random.default_rng(seed)
+    names = ("nv", "pts", "Sf", "Cf", "C", "model", "Tau", "aQGD", "UQHD", "T0", "Gr", "mu", "rho0", "tauQGDf", "tauQGD")
+    rec = {k: [] for k in names}
+
+    class PS(Pair):
+        def _b(self, o): return o if isinstance(o, Pair) else Pair(o, o)
+        def __mul__(self, o): o = self._b(o); return PS(self.o * o.o, self.n * o.n)
+        def __rmul__(self, o): return PS(o * self.o, o * self.n)
+        def __truediv__(self, o): o = self._b(o); return PS(self.o / o.o, self.n / o.n)
+    for n in range(nfaces):
+        nv = 4 if n % 3 != 2 else 3
+        model = n % 4
+        pts, own, nei = skew_face(rng, nv)
+        S, cf = face_area_centre(pts)
+        Sv, Cf = Vec(*S), Vec(*cf)
+        hq = [0.0]
+        ev = dict(mag=mag, min=min, mesh=Obj(C=call([own, nei]), Cf=call([Cf]), owner=call([0]), neighbour=call([1])), iFace=0,
+                  hQGDf_=Obj(primitiveFieldRef=call(hq)), hown=0.0, hnei=0.0)
+        exec(h_src, ev)
+        hf = hq[0]
+        sfo, sfn = abs(Sv & (Cf - own)), abs(Sv & (nei - Cf))
+        w = sfn / (sfo + sfn)
+        lin = lambda qq: w * (qq.o - qq.n) + qq.n  # noqa: E731
+        Tau, aQ, UQ, T0, Gr = float(10 ** rng.uniform(-4, -2)), float(rng.uniform(0.2, 0.8)), float(rng.uniform(0.1, 2.0)), float(rng.uniform(0.5, 2)), float(10 ** rng.uniform(2, 5))
+        mu, rho0 = float(10 ** rng.uniform(-4, -2)), float(rng.uniform(0.8, 1.3))
+        env = dict(tau_=Tau, aQGD_=aQ, hQGD_=PS(hf, hf), UQHD_=UQ, T0_=T0, Gr_=Gr, linearInterpolate=lin, sqr=lambda x: x * x,
+                   dimensionedScalar=lambda nm, dims, v: PS(v, v), dimTime=1.0, dimLength=1.0,     # a uniform value assigned to a field
+                   qgdThermo=Obj(mu=call(PS(mu, mu)), rho=call(PS(rho0, rho0))))
+        exec(texts[model], env)
+        tq, tf = env["tauQGD_"], env["tauQGDf_"]
+        vals = dict(nv=nv, pts=np.array([q_.c for q_ in pts] + ([[0, 0, 0]] if nv == 3 else [])), Sf=S, Cf=cf, C=np.array([own.c, nei.c]), model=model,
+                    Tau=Tau, aQGD=aQ, UQHD=UQ, T0=T0, Gr=Gr, mu=mu, rho0=rho0, tauQGDf=float(tf), tauQGD=[float(tq.o), float(tq.n)])
+        for k in names:
+            rec[k].append(np.array(vals[k], dtype=float))
+    return {k: np.array(v) for k, v in rec.items()}
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit("make_ref_expr.py needs the reference listings under /root/reference (build container only)")
@@ -1145,6 +1482,12 @@ def main():
         path = os.path.join(HERE, f"ref_expr_{name}.npz")
         np.savez_compressed(path, **data)
         print(name, {k: v.shape for k, v in data.items()})
+        if name == "case2cell":
+            case = data
+    for name, data in (("gvp2d_vec", gvp2d_vec()), ("gvp_other", gvp_other()), ("qgdlength", qgdlength()), ("courant", courant(case)),
+                       ("qhdclosure", qhdclosure())):
+        np.savez_compressed(os.path.join(HERE, f"ref_expr_{name}.npz"), **data)
+        print(name, {k: getattr(v, "shape", None) for k, v in data.items()})
 
 
 if __name__ == "__main__":
