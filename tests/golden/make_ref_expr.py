@@ -1474,6 +1474,114 @@ def qhdclosure(nfaces=24, seed=24):
     return {k: np.array(v) for k, v in rec.items()}
 
 
+def casebnd(nfaces=30, seed=25):
+    """The QGDFoam flux assembly on ONE BOUNDARY FACE (3-D, GaussVolPoint): updateFields.H L45-80 with the patch values, the three
+    fvsc::grad of U, e, rho through the boundary-face text of GaussVolPointBase3D.C, updateFluxes.H L41-139, and -- at the place
+    where the listing calls fvsc::grad(p) -- what GaussVolPoint does there first [GaussVolPointStencil.C L73]: p's boundary
+    conditions again, i.e. qgdFluxFvPatchScalarField::updateCoeffs [qgdFluxFvPatchScalarField.C L184-192] with the phiwStar just
+    formed, then fixedGradient's evaluate (patch value = cell value + gradient / deltaCoeffs, L0), then the vertex values of p.
+    constScPrModel1.C L103-104 and its patch loop L121-128 give tauQGDf, muQGD, alphauQGD of the patch face; hQGDf of a patch face is
+    2 / deltaCoeffs [QGDCoeffs.C L195-199, L310-317].  Patch: U fixedValue, T zeroGradient, p qgdFlux (gradient 0 at start-up)."""
+    text = Gvp3dText()
+    fields_src = transpile(lines("QGDFoam_2updateFields_8H_source.html", 45, 80))
+    flux_src = transpile(lines("QGDFoam_2updateFluxes_8H_source.html", 41, 139))
+    cs = listing("constScPrModel1_8C_source.html")
+    tauf_src = transpile([cs[103].replace("this->", "")])
+    taub_src = transpile([cs[104].replace("this->", "")])
+    mub_src = transpile([cs[i] for i in range(121, 129)])
+    bc_l = listing("qgdFluxFvPatchScalarField_8C_source.html")
+    bc_src = transpile([bc_l[i].replace("this->gradient()", "gradient_") for i in range(184, 193)])
+    rng = np.random.default_rng(seed)
+    names = ("nv", "pts", "Sf", "Cf", "C", "U", "T", "p", "Ub", "R", "Cv", "mu", "Pr", "ScQGD", "PrQGD", "alphaQGD", "gradient", "pMid",
+             "tauQGDf", "gradUf", "gradef", "gradRhof", "gradPf", "phiwStar", "phiJm", "phi", "phiJmU", "phiP", "phiPi", "phiJmH", "phiQ", "phiPiU")
+    rec = {k: [] for k in names}
+
+    class BF(Fld):
+        def __truediv__(self, o): return BF([a / b for a, b in zip(self, o)]) if isinstance(o, list) else BF([a / o for a in self])
+        def __mul__(self, o): return BF([a * b for a, b in zip(self, o)]) if isinstance(o, list) else BF([a * o for a in self])
+        def __neg__(self): return BF([-a for a in self])
+    for n in range(nfaces):
+        nv = 4 if n % 3 != 2 else 3
+        pts, own, _ = skew_face(rng, nv)
+        S, cf = face_area_centre(pts)
+        Sv, Cf = Vec(*S), Vec(*cf)
+        magS = mag(Sv)
+        nhat = S / np.sqrt((S * S).sum())
+        dc = 1.0 / abs(float(nhat @ (cf - own.c)))           # fvPatch::deltaCoeffs, patch-normal delta (L0)
+        R = 1 / 1.4
+        Cv = R / 0.4
+        Cp = Cv + R
+        gam = Cp / Cv
+        mu0, Pr = float(rng.uniform(0, 2e-3)), float(rng.uniform(0.6, 1.2))
+        Sc, PrQ, aQ = float(rng.uniform(0.5, 1.5)), float(rng.uniform(0.5, 1.5)), float(rng.uniform(0.3, 0.7))
+        Uo, Ub = rnd_vec(rng, 0.7), rnd_vec(rng, 0.7)
+        To, po = float(rng.uniform(0.8, 1.3)), float(rng.uniform(0.7, 1.4))
+        # createFields.H on the patch (L0 boundary conditions): T zeroGradient, p qgdFlux with gradient 0, U fixedValue
+        Tb, pb = To, po
+        eo, eb = Cv * To, Cv * Tb
+        psio, psib = 1.0 / (R * To), 1.0 / (R * Tb)
+        rhoo, rhob = psio * po, psib * pb
+        cb = float(np.sqrt(gam / psib))
+        alphah0 = (Cp * mu0 * (1.0 / Pr)) / Cp
+        hfb = (1.0 / abs(dc)) * 2.0                                                 # QGDCoeffs.C L195-199 (1/|deltaCoeffs|), L315 (*= 2)
+        hb = hfb * 1.0                                                              # L373
+        B = lambda v: Pair(v, v)  # noqa: E731   a patch value where the listing interpolates: qgdInterpolate returns it
+        lin = lambda qq: qq.n  # noqa: E731
+        ev = dict(aQGD_=B(aQ), cSound=B(cb), hQGDf_=hfb, linearInterpolate=lin)
+        exec(tauf_src, ev)
+        tauf = ev["tauQGDf_"]
+        ev = dict(aQGD_=aQ, hQGD_=hb, cSound=cb)
+        exec(taub_src, ev)
+        taub = ev["tauQGD_"]
+        m_, a_ = [[0.0]], [[0.0]]
+        ev = dict(p=Obj(boundaryField=call([[pb]])), ScQGD_=Obj(boundaryField=call([[Sc]])), PrQGD_=Obj(boundaryField=call([[PrQ]])),
+                  tauQGD_=Obj(boundaryField=call([[taub]])), patchi=0, facei=0, muQGD_=Obj(boundaryFieldRef=call(m_)),
+                  alphauQGD_=Obj(boundaryFieldRef=call(a_)))
+        exec(mub_src, ev)
+        muQb, alQb = m_[0][0], a_[0][0]
+        muEff = B(0.0 + (mu0 + muQb))
+        alphaEff = B(gam * ((alphah0 + alQb) + 0.0))
+        rhoUb = rhob * Ub
+        rhoEb = rhob * eb + rhob * 0.5 * (Ub & Ub)
+        env = dict(qgdInterpolate=lin, rho=B(rhob), U=B(Ub), rhoU=B(rhoUb), p=B(pb), gamma=B(gam), rhoE=B(rhoEb),
+                   thermo=Obj(c=call(B(cb)), Cp=call(B(Cp))), turbulence=Obj(alphaEff=call(alphaEff), muEff=call(muEff)))
+        exec(fields_src, env)
+        # the three gradients that do not involve p's boundary condition: boundary-face text, vertex values = patch value (L0)
+        gU, _ = text.boundary(pts, own, Cf, Uo, Ub, dc * (Ub - Uo), [Ub] * nv, "grad_v")
+        gE, _ = text.boundary(pts, own, Cf, eo, eb, 0.0, [eb] * nv, "grad_s")                         # gradientEnergy with zero gradient
+        gR, _ = text.boundary(pts, own, Cf, rhoo, rhob, dc * (rhob - rhoo), [rhob] * nv, "grad_s")   # calculated patch: generic snGrad
+        mid = {}
+
+        def grad_of(fld):
+            if fld != "p":
+                return {"U": Tensor(gU), "e": Vec(*gE), "rho": Vec(*gR)}[fld]
+            # correctBoundaryConditions() of p inside fvsc::grad(p): qgdFlux::updateCoeffs with the registered phiwStar, tauQGDf
+            # (the listing's `phiw` is the surfaceScalarField registered under the name "phiwStar" [createFaceFluxes.H])
+            e2 = dict(phiws=Obj(boundaryField=call([BF([env2["phiw"]])])), tauQGDf=Obj(boundaryField=call([BF([tauf])])),
+                      patch=call(Obj(index=call(0), magSf=call(BF([magS])))))
+            exec(bc_src, e2)
+            mid["gradient"] = e2["gradient_"][0]
+            mid["pMid"] = po + mid["gradient"] / dc                                                   # fixedGradient::evaluate (L0)
+            gP, _ = text.boundary(pts, own, Cf, po, mid["pMid"], mid["gradient"], [mid["pMid"]] * nv, "grad_s")
+            return Vec(*gP)
+        env2 = {k: env[k] for k in ("rhof", "Uf", "rhoUf", "UrhoUf", "pf", "gammaf", "Hf", "alphauf", "muf")}
+        env2.update(tr=tr, tauQGDf=tauf, mesh=Obj(Sf=call(Sv)), fvsc=Obj(grad=grad_of), U="U", e="e", rho="rho", p="p",
+                    I=Sph(1.0), implicitDiffusion=False, Foam=Obj(T=lambda t: t.T()), qgdFlux=lambda flux, psi, psif: flux * psif, H="H")
+        exec(flux_src, env2)
+        g = env2
+
+        def val(x):
+            return x.c if isinstance(x, Vec) else (x.m.reshape(9) if isinstance(x, Tensor) else x)
+        out = dict(nv=nv, pts=np.array([q_.c for q_ in pts] + ([[0, 0, 0]] if nv == 3 else [])), Sf=S, Cf=cf, C=own.c, U=Uo.c, T=To, p=po, Ub=Ub.c,
+                   R=R, Cv=Cv, mu=mu0, Pr=Pr, ScQGD=Sc, PrQGD=PrQ, alphaQGD=aQ, gradient=mid["gradient"], pMid=mid["pMid"], tauQGDf=tauf,
+                   phiwStar=g["phiw"])
+        for k in ("gradUf", "gradef", "gradRhof", "gradPf", "phiJm", "phi", "phiJmU", "phiP", "phiPi", "phiJmH", "phiQ", "phiPiU"):
+            out[k] = val(g[k])
+        for k in names:
+            rec[k].append(np.array(out[k], dtype=float))
+    return {k: np.array(v) for k, v in rec.items()}
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit("make_ref_expr.py needs the reference listings under /root/reference (build container only)")
@@ -1485,7 +1593,7 @@ def main():
         if name == "case2cell":
             case = data
     for name, data in (("gvp2d_vec", gvp2d_vec()), ("gvp_other", gvp_other()), ("qgdlength", qgdlength()), ("courant", courant(case)),
-                       ("qhdclosure", qhdclosure())):
+                       ("qhdclosure", qhdclosure()), ("casebnd", casebnd())):
         np.savez_compressed(os.path.join(HERE, f"ref_expr_{name}.npz"), **data)
         print(name, {k: getattr(v, "shape", None) for k, v in data.items()})
 

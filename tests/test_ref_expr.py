@@ -356,3 +356,36 @@ def test_qhd_tau_closures():
         oc.set_fields(np.zeros((2, 3)), np.full(2, 300.0), np.zeros(2))
         assert rel(oc.field("tauQGDf")[0], g["tauQGDf"][i]) <= TOL, (i, int(g["model"][i]), oc.field("tauQGDf")[0], g["tauQGDf"][i])
         oc.close(); om.close()
+
+
+BND_FACE_FIELDS = ("tauQGDf", "gradUf", "gradef", "gradRhof", "phiwStar", "gradPf", "phiJm", "phi", "phiJmU", "phiP", "phiPi", "phiJmH", "phiQ", "phiPiU")
+
+
+def boundary_case(g, i, make_mesh, make_case):
+    """the one-boundary-face configuration of ref_expr_casebnd: patch 0 with U fixedValue, T zeroGradient, p qgdFlux"""
+    nv = int(g["nv"][i])
+    mesh = make_mesh(*rc.boundary_face_mesh(g["pts"][i], nv, g["Sf"][i], g["Cf"][i], g["C"][i]))
+    case = make_case(mesh, case_options_of(g, i))
+    case.set_bc(0, U=("fixedValue", tuple(g["Ub"][i])), T=("zeroGradient", None), p=("qgdFlux", None))
+    far = np.array([[0.0, 0.0, 0.0]])
+    case.set_fields(np.vstack([g["U"][i][None, :], far + g["U"][i]]), np.array([g["T"][i], g["T"][i]]), np.array([g["p"][i], g["p"][i]]))
+    return mesh, case
+
+
+def case_options_of(g, i):
+    return q.default_options(stencil="GaussVolPoint", R=float(g["R"][i]), Cv=float(g["Cv"][i]), mu=float(g["mu"][i]), Pr=float(g["Pr"][i]),
+                             ScQGD=float(g["ScQGD"][i]), PrQGD=float(g["PrQGD"][i]), alphaQGD=float(g["alphaQGD"][i]), deltaT=1e-3)
+
+
+def test_flux_assembly_of_one_boundary_face_with_the_qgdflux_condition():
+    """updateFields.H / updateFluxes.H on a patch face, the boundary-face text of GaussVolPointBase3D.C for the four gradients,
+    qgdFluxFvPatchScalarField::updateCoeffs [L184-192] evaluated inside fvsc::grad(p) with the fresh phiwStar (reference quirk B6),
+    constScPrModel1's patch loop: all from the listing text (tests/golden/ref_expr_casebnd.npz)"""
+    g = rc.load("casebnd")
+    for i in range(len(g["nv"])):
+        om, oc = boundary_case(g, i, oracle_mesh, OracleCase)
+        oc.updateFluxes()
+        for f in BND_FACE_FIELDS:
+            assert rel(oc.field(f)[1], g[f][i]) <= 5e-13, (i, f, oc.field(f)[1], g[f][i])
+        assert rel(oc.field("p.boundary")[0], g["pMid"][i]) <= TOL, (i, oc.field("p.boundary")[0], g["pMid"][i])
+        oc.close(); om.close()

@@ -259,3 +259,19 @@ def test_qhd_tau_closures_on_the_device():
         case.set_fields(np.zeros((2, 3)), np.full(2, 300.0), np.zeros(2))
         assert rel(case.field("tauQGDf")[0], g["tauQGDf"][i]) <= TOL, (i, int(g["model"][i]))
         case.close(); dev.close()
+
+
+def test_flux_assembly_of_one_boundary_face_on_the_device():
+    """the boundary-face kernels (boundaryFaceFluxKernel incl. the mid-step evaluation of the qgdFlux condition, quirk B6) against
+    tests/golden/ref_expr_casebnd.npz: the listing text of updateFields.H, updateFluxes.H, GaussVolPointBase3D.C's boundary faces,
+    qgdFluxFvPatchScalarField.C L184-192 and constScPrModel1.C's patch loop"""
+    from test_ref_expr import BND_FACE_FIELDS, boundary_case
+    g = rc.load("casebnd")
+    for i in range(len(g["nv"])):
+        mesh, case = boundary_case(g, i, device_mesh, lambda m, opt: q.QGDFoamCase(q.Device(m), opt))
+        case.updateFluxes()
+        for f in BND_FACE_FIELDS:
+            assert rel(case.field(f)[1], g[f][i]) <= 2e-12, (i, f, case.field(f)[1], g[f][i])
+        assert rel(case.field("p.boundary")[0], g["pMid"][i]) <= TOL, i
+        dev = case.dev
+        case.close(); dev.close()
