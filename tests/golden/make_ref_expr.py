@@ -1582,6 +1582,145 @@ def casebnd(nfaces=30, seed=25):
     return {k: np.array(v) for k, v in rec.items()}
 
 
+def qhdeqn(nfaces=30, seed=26):
+    """One whole QHDFoam step on one internal face between two cells (3-D, GaussVolPoint, explicit branch): updateFields.H L36-73,
+    updateFluxes.H L33-38, QHDpEqn.H L35-47, QHDUEqn.H L36-43 + L68-84, QHDTEqn.H L65-66 + L83-91 and the reference level of
+    QHDFoam.C L123-130 -- every line from the listing text, the fvsc gradients through the GaussVolPoint text.  fvm / fvc are
+    emulated on the two-cell mesh with OpenFOAM's conventions (L0): fvc::div = surfaceIntegrate, fvc::grad Gauss linear,
+    fvc::laplacian = div(Gamma |Sf| snGrad) with the uncorrected snGrad, fvm::laplacian the same as a matrix, volume-weighted
+    sources, setReference doubling the diagonal, flux() = -a (p_N - p_O); Euler ddt."""
+    text = Gvp3dText()
+    fields_src = transpile(lines("QHDFoam_2updateFields_8H_source.html", 36, 73))
+    flux_src = "\n".join(l for l in transpile(lines("QHDFoam_2updateFluxes_8H_source.html", 33, 38)).split("\n") if "setOriented" not in l)
+    peqn_src = transpile(lines("QHDpEqn_8H_source.html", 35, 47))
+    ueqn_a = "\n".join(l for l in transpile(lines("QHDUEqn_8H_source.html", 36, 43)).split("\n") if "setOriented" not in l)
+    ueqn_b = transpile(lines("QHDUEqn_8H_source.html", 46, 85))
+    teqn_a = transpile(lines("QHDTEqn_8H_source.html", 65, 66))
+    teqn_b = transpile(lines("QHDTEqn_8H_source.html", 69, 92))
+    ref_src = transpile(lines("QHDFoam_8C_source.html", 123, 131))
+    rng = np.random.default_rng(seed)
+    names = ("nv", "pts", "Sf", "Cf", "C", "U", "T", "p", "rho0", "mu", "Pr", "beta", "g", "Tau", "deltaT", "pRefCell", "pRefValue", "delta",
+             "p1", "phi1", "U1", "T1", "phiu", "phiwo")
+    rec = {k: [] for k in names}
+
+    class QF(list):
+        """a vol field on the two cells: elementwise arithmetic, the old-time level, and the verbs the listing uses"""
+        def __init__(self, vals, old=None):
+            super().__init__(vals)
+            self.old = list(old if old is not None else vals)
+        def _z(self, o, f): return QF([f(a, b) for a, b in zip(self, o)]) if isinstance(o, list) else QF([f(a, o) for a in self])
+        def __add__(self, o): return o.__radd__(self) if isinstance(o, Eq) else self._z(o, lambda a, b: a + b)
+        def __sub__(self, o): return o.__rsub__(self) if isinstance(o, Eq) else self._z(o, lambda a, b: a - b)
+        def __mul__(self, o): return self._z(o, lambda a, b: a * b)
+        def __rmul__(self, o): return QF([o * a for a in self])
+        def __truediv__(self, o): return self._z(o, lambda a, b: a * (1.0 / b))
+        def __neg__(self): return QF([a * -1.0 for a in self])
+        def __iadd__(self, o): self[:] = [a + o for a in self]; return self
+        def correctBoundaryConditions(self): pass
+        def oldTime(self): return self
+        def needReference(self): return True
+        def dimensions(self): return None
+        def assign(self, vals): self[:] = list(vals)
+
+    class Eq:
+        """M psi = b on the two cells; M = diag(d) - a (offdiagonal), b per cell.  Built from the terms as the listing writes them:
+        every explicit vol-field term F enters b as -(V F) when added on the left, +(V F) when on the right of =="""
+        def __init__(self, psi, d, a, b): self.psi, self.d, self.a, self.b = psi, list(d), a, list(b)
+        def copy(self): return Eq(self.psi, self.d, self.a, self.b)
+        def __add__(self, F): r = self.copy(); r.b = [b - V[i] * f for i, (b, f) in enumerate(zip(r.b, F))]; return r
+        def __sub__(self, F): r = self.copy(); r.b = [b + V[i] * f for i, (b, f) in enumerate(zip(r.b, F))]; return r
+        def __radd__(self, F): return self.__add__(F)
+        def __rsub__(self, F):      # F - M  ==  -(M) + F: the matrix changes sign, F goes to the left-hand side
+            r = Eq(self.psi, [-x for x in self.d], -self.a, [b * -1.0 for b in self.b])
+            return r.__add__(F)
+        def __neg__(self): return Eq(self.psi, [-x for x in self.d], -self.a, [b * -1.0 for b in self.b])
+        def __eq__(self, F): r = self.copy(); r.b = [b + V[i] * f for i, (b, f) in enumerate(zip(r.b, F))]; return r
+        def setReference(self, cell, value):
+            self.b[cell] = self.b[cell] + self.d[cell] * value
+            self.d[cell] = self.d[cell] + self.d[cell]
+        def solve(self):
+            d0, d1, a = self.d[0], self.d[1], self.a
+            det = d0 * d1 - a * a
+            b0, b1 = self.b
+            self.psi.assign([(b0 * d1 + b1 * a) * (1.0 / det), (b1 * d0 + b0 * a) * (1.0 / det)])
+        def flux(self):          # lduMatrix face flux: upper psi_N - lower psi_O with upper = lower = -a of M
+            return -self.a * self.psi[1] + self.a * self.psi[0]
+    for n in range(nfaces):
+        nv = 4 if n % 3 != 2 else 3
+        pts, own, nei = skew_face(rng, nv)
+        S, cf = face_area_centre(pts)
+        Sv, Cf = Vec(*S), Vec(*cf)
+        magS = mag(Sv)
+        V = [1.0, 1.0]
+        dvec = nei - own
+        nhat = Sv / magS
+        delta = 1.0 / max(nhat & dvec, 0.05 * mag(dvec))          # nonOrthDeltaCoeffs (L0)
+        U0 = [rnd_vec(rng, 0.3), rnd_vec(rng, 0.3)]
+        T0 = [float(rng.uniform(290.0, 310.0)) for _ in range(2)]
+        p0 = [float(rng.uniform(-0.1, 0.1)) for _ in range(2)]
+        rho0, mu, Pr = float(rng.uniform(0.9, 1.2)), float(10 ** rng.uniform(-3, -1.5)), float(rng.uniform(0.6, 1.0))
+        beta, gv = float(rng.uniform(1e-3, 5e-3)), rnd_vec(rng, 9.81)
+        Tau, dt = float(10 ** rng.uniform(-3.5, -2)), float(10 ** rng.uniform(-3.5, -2.5))
+        ref_cell, ref_val = int(n % 2), float(rng.uniform(-0.5, 0.5))
+        sfo, sfn = abs(Sv & (Cf - own)), abs(Sv & (nei - Cf))
+        w = sfn / (sfo + sfn)
+
+        def lin(qf):
+            a, b = (qf.o, qf.n) if isinstance(qf, Pair) else (qf[0], qf[1])
+            return w * (a - b) + b
+        cen = [own, nei]
+        gU, _ = text.grad(pts, own, nei, U0, [inv_dist(x, cen, U0) for x in pts], True)
+        gT, _ = text.grad(pts, own, nei, T0, [inv_dist(x, cen, T0) for x in pts], False)
+        grads = dict(U=Tensor(gU), T=Vec(*gT), W=Tensor(np.zeros(9)))
+
+        class TF(QF):       # T*g: a scalar field times a uniform vector
+            def __rmul__(self, sc): return TF([sc * a for a in self])
+            def __mul__(self, v): return QF([a * v for a in self]) if isinstance(v, Vec) else QF.__mul__(self, v)
+        U, T, pfld = QF(U0), TF(T0), QF(p0)
+        W = QF([Vec(0, 0, 0), Vec(0, 0, 0)])
+        one = QF([1.0, 1.0])
+        env = dict(qgdInterpolate=lin, fvsc=Obj(grad=lambda fld: grads["U" if fld is U else ("T" if fld is T else "W")]),
+                   U=U, T=T, W=W, rho=QF([rho0, rho0]), beta=beta, g=gv,
+                   turbulence=Obj(muEff=call(mu * one)), thermo=Obj(alpha=call((mu / Pr) * one), Cp=call(one)))
+        exec(fields_src, env)
+        env2 = dict(mesh=Obj(Sf=call(Sv)), Uf=env["Uf"], gradUf=env["gradUf"], BdFrcf=env["BdFrcf"], tauQGDf=Tau, rhof=env["rhof"])
+        exec(flux_src, env2)
+        # the equations: fvm / fvc on the two-cell mesh (L0 semantics, see the docstring)
+        def surf_int(flux): return QF([flux * (1.0 / V[0]), flux * (-1.0 / V[1])])
+
+        def fvc_grad(fld):
+            ff = lin(fld)
+            return surf_int(Sv * ff)
+
+        def fvc_lap(gam, fld): return surf_int((gam * magS * delta) * (fld[1] - fld[0]))
+        fvm = Obj(ddt=lambda fld: Eq(fld, [V[0] / dt, V[1] / dt], 0.0, [V[0] * o * (1.0 / dt) for o in fld.old][:1] + [V[1] * fld.old[1] * (1.0 / dt)]),
+                  laplacian=lambda gam, fld: Eq(fld, [-(gam * magS * delta)] * 2, -(gam * magS * delta), [0.0, 0.0]))
+        fvc = Obj(div=surf_int, grad=fvc_grad, laplacian=fvc_lap)
+        pe = dict(p=pfld, fvc=fvc, fvm=fvm, phiu=env2["phiu"], phiwo=env2["phiwo"], taubyrhof=env2["taubyrhof"], pRefCell=ref_cell,
+                  getRefCellValue=lambda fld, c: fld[c])
+        exec(peqn_src, pe)
+        phi = pe["phi"]
+        gP, _ = text.grad(pts, own, nei, list(pfld), [inv_dist(x, cen, list(pfld)) for x in pts], False)
+        ue = dict(env2, fvsc=Obj(grad=lambda fld: Vec(*gP)), p=pfld, phi=phi, U=U, qgdFlux=lambda flux, psi, psif: flux * psif, implicitDiffusion=False,
+                  fvm=fvm, fvc=fvc, solve=lambda M: M.solve(), muf=env["muf"], rho=QF([rho0, rho0]), BdFrc=env["BdFrc"],
+                  USu=QF([Vec(0, 0, 0), Vec(0, 0, 0)]), qgdInterpolate=lin, Foam=Obj(T=lambda fld: QF([t.T() for t in fld])))
+        exec(ueqn_a, ue)
+        Uold = list(U)
+        exec(ueqn_b, ue)
+        te = dict(ue, T=T, Tf=env["Tf"], gradTf=env["gradTf"], Hif=env["Hif"], TSu=QF([0.0, 0.0]), max=lambda f: Obj(value=call(max(f))),
+                  min=lambda f: Obj(value=call(min(f))), Info=Stream(), endl=None, U=QF(Uold))
+        exec(teqn_a, te)
+        exec(teqn_b, te)
+        exec(ref_src, dict(p=pfld, dimensionedScalar=lambda nm, dims, v: v, pRefValue=ref_val, pRefCell=ref_cell, getRefCellValue=lambda fld, c: fld[c]))
+        out = dict(nv=nv, pts=np.array([q_.c for q_ in pts] + ([[0, 0, 0]] if nv == 3 else [])), Sf=S, Cf=cf, C=np.array([own.c, nei.c]),
+                   U=np.array([u.c for u in U0]), T=T0, p=p0, rho0=rho0, mu=mu, Pr=Pr, beta=beta, g=gv.c, Tau=Tau, deltaT=dt, pRefCell=ref_cell,
+                   pRefValue=ref_val, delta=delta, p1=list(pfld), phi1=phi, U1=np.array([u.c for u in U]), T1=list(T), phiu=env2["phiu"],
+                   phiwo=env2["phiwo"])
+        for k in names:
+            rec[k].append(np.array(out[k], dtype=float))
+    return {k: np.array(v) for k, v in rec.items()}
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit("make_ref_expr.py needs the reference listings under /root/reference (build container only)")
@@ -1593,7 +1732,7 @@ def main():
         if name == "case2cell":
             case = data
     for name, data in (("gvp2d_vec", gvp2d_vec()), ("gvp_other", gvp_other()), ("qgdlength", qgdlength()), ("courant", courant(case)),
-                       ("qhdclosure", qhdclosure()), ("casebnd", casebnd())):
+                       ("qhdclosure", qhdclosure()), ("casebnd", casebnd()), ("qhdeqn", qhdeqn())):
         np.savez_compressed(os.path.join(HERE, f"ref_expr_{name}.npz"), **data)
         print(name, {k: getattr(v, "shape", None) for k, v in data.items()})
 

@@ -389,3 +389,33 @@ def test_flux_assembly_of_one_boundary_face_with_the_qgdflux_condition():
             assert rel(oc.field(f)[1], g[f][i]) <= 5e-13, (i, f, oc.field(f)[1], g[f][i])
         assert rel(oc.field("p.boundary")[0], g["pMid"][i]) <= TOL, (i, oc.field("p.boundary")[0], g["pMid"][i])
         oc.close(); om.close()
+
+
+def qhd_eqn_options(g, i):
+    from qgdsolver_amd import qhdfoam
+    return qhdfoam.qhd_options(stencil="GaussVolPoint", tauModel="constTau", Tau=float(g["Tau"][i]), rho0=float(g["rho0"][i]), mu=float(g["mu"][i]),
+                               Pr=float(g["Pr"][i]), beta=float(g["beta"][i]), g=tuple(g["g"][i]), deltaT=float(g["deltaT"][i]), pTol=1e-14,
+                               pMaxIter=200, pRefCell=int(g["pRefCell"][i]), pRefValue=float(g["pRefValue"][i]), precond=0)
+
+
+def test_one_whole_qhdfoam_step_from_the_listing_text():
+    """QHDpEqn.H L35-47 (the pressure equation, setReference, flux()), QHDUEqn.H L36-84 and QHDTEqn.H L65-91 (explicit branch), the
+    reference level of QHDFoam.C L123-130, on top of updateFields.H / updateFluxes.H: one step of the QHD case on a two-cell mesh"""
+    from oracle import OracleQhdCase
+    g = rc.load("qhdeqn")
+    assert set(g["pRefCell"]) == {0, 1}
+    for i in range(len(g["nv"])):
+        nv = int(g["nv"][i])
+        om = oracle_mesh(*rc.two_cell_mesh(g["pts"][i], nv, g["Sf"][i], g["Cf"][i], g["C"][i]))
+        assert rel(om.array("nonOrthDeltaCoeffs")[0], g["delta"][i]) <= 1e-14
+        oc = OracleQhdCase(om, qhd_eqn_options(g, i))
+        oc.set_fields(g["U"][i], g["T"][i], g["p"][i])
+        oc.step(1)
+        for f, want in (("phiu", "phiu"), ("phiwo", "phiwo")):
+            assert rel(oc.field(f)[0], g[want][i]) <= 1e-11, (i, f, oc.field(f)[0], g[want][i])
+        # two cells closed by one face: the only divergence-free face flux is zero, so phi = phiu - phiwo + pEqn.flux() pins the SIGN of
+        # the pressure correction (p_N - p_O = (phiu - phiwo)/a), not a value
+        assert abs(oc.field("phi")[0] - g["phi1"][i]) <= 1e-11 * max(abs(g["phiu"][i]), abs(g["phiwo"][i])), (i, oc.field("phi")[0], g["phi1"][i])
+        for f, want in (("p", "p1"), ("U", "U1"), ("T", "T1")):
+            assert rel(oc.field(f), g[want][i]) <= 1e-11, (i, f, oc.field(f), g[want][i])
+        oc.close(); om.close()

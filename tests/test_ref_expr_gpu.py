@@ -275,3 +275,24 @@ def test_flux_assembly_of_one_boundary_face_on_the_device():
         assert rel(case.field("p.boundary")[0], g["pMid"][i]) <= TOL, i
         dev = case.dev
         case.close(); dev.close()
+
+
+def test_one_whole_qhdfoam_step_on_the_device():
+    """the resident QHD case (qgd_qhd_case_step: flux assembly, pressure equation, U and T equations, reference level) against
+    tests/golden/ref_expr_qhdeqn.npz: QHDpEqn.H, QHDUEqn.H, QHDTEqn.H and QHDFoam.C L123-130 executed from the listing text"""
+    from qgdsolver_amd import qhdfoam
+    from test_ref_expr import qhd_eqn_options
+    g = rc.load("qhdeqn")
+    for i in range(len(g["nv"])):
+        nv = int(g["nv"][i])
+        mesh = device_mesh(*rc.two_cell_mesh(g["pts"][i], nv, g["Sf"][i], g["Cf"][i], g["C"][i]))
+        dev = q.Device(mesh)
+        case = qhdfoam.QHDFoamCase(dev, qhd_eqn_options(g, i))
+        case.set_fields(g["U"][i], g["T"][i], g["p"][i])
+        case.step(1)
+        for f, want in (("phiu", "phiu"), ("phiwo", "phiwo")):
+            assert rel(case.field(f)[0], g[want][i]) <= 1e-11, (i, f)
+        assert abs(case.field("phi")[0] - g["phi1"][i]) <= 1e-11 * max(abs(g["phiu"][i]), abs(g["phiwo"][i])), i
+        for f, want in (("p", "p1"), ("U", "U1"), ("T", "T1")):
+            assert rel(case.field(f), g[want][i]) <= 1e-10, (i, f, case.field(f), g[want][i])
+        case.close(); dev.close()
