@@ -899,6 +899,33 @@ def fv_emulation(dt, V):
     return fvm, fvc
 
 
+class Mat2:
+    """L(psi) = b on the two-cell mesh with L(psi)_i = d_i psi_i - a psi_nb: what fvm::ddt(rho, psi) (a = 0) and fvm::laplacian(gamma,
+    psi) (d = a = -gamma |Sf| delta, unit volumes) assemble; explicit fields move to the right-hand side (L0 fvMatrix algebra)"""
+    def __init__(self, psi, d, a, b): self.psi, self.d, self.a, self.b = psi, list(d), a, list(b)
+    def __sub__(self, o):
+        if isinstance(o, Mat2):
+            return Mat2(self.psi, [x - y for x, y in zip(self.d, o.d)], self.a - o.a, [x - y for x, y in zip(self.b, o.b)])
+        return Mat2(self.psi, self.d, self.a, [b + x for b, x in zip(self.b, o)])       # L - F = 0  ->  L = b + F
+    def __add__(self, o): return Mat2(self.psi, self.d, self.a, [b - x for b, x in zip(self.b, o)])
+    def __eq__(self, s): return Mat2(self.psi, self.d, self.a, [b + x for b, x in zip(self.b, s)])
+    def solve(self):
+        d0, d1, a = self.d[0], self.d[1], self.a
+        det = d0 * d1 - a * a
+        b0, b1 = self.b
+        self.psi.assign([(b0 * d1 + b1 * a) * (1.0 / det), (b1 * d0 + b0 * a) * (1.0 / det)])
+
+
+def fv_emulation_implicit(dt, magS, delta):
+    """the same verbs for the implicitDiffusion branch [QGDUEqn.H L56-68, QGDEEqn.H L55-61]: fvm::ddt(rho, psi), fvc::ddt(rho, psi),
+    fvm::laplacian(gamma, psi) with the uncorrected surface-normal gradient, fvc::div (unit volumes)"""
+    fvm = Obj(ddt=lambda rho, psi: Mat2(psi, [r / dt for r in rho], 0.0, [ro * o / dt for ro, o in zip(rho.old, psi.old)]),
+              laplacian=lambda gam, psi: Mat2(psi, [-(gam * magS * delta)] * 2, -(gam * magS * delta), [psi[0] * 0.0, psi[1] * 0.0]))
+    fvc = Obj(ddt=lambda rho, psi: CF([(r * x - ro * o) / dt for r, x, ro, o in zip(rho, psi, rho.old, psi.old)]),
+              div=lambda phi: CF([phi / 1.0, -phi / 1.0]))
+    return fvm, fvc
+
+
 def field_assignments(src, names):
     """`e = expr;` on a field assigns values into the existing object (its old-time level stays): rewrite those statements"""
     return re.sub(r"^(\s*)(%s)\s*=(?!=)\s*(.*)$" % "|".join(names), r"\1\2.assign(\3)", src, flags=re.M)
@@ -927,6 +954,7 @@ def case2cell(nfaces=40, seed=14):
              "gradUf", "gradef", "gradRhof", "gradPf", "phiwStar", "phiJm", "phi", "phiJmU", "phiP", "phiPi", "phiJmH", "phiQ", "phiPiU",
              "muQGD", "alphauQGD", "tauQGD", "hQGD")
     rec = {k: [] for k in names}
+    rec2 = case2cell.implicit_step = {}
     for n in range(nfaces):
         nv = 4 if n % 3 != 2 else 3
         pts, own, nei = skew_face(rng, nv)
@@ -1023,6 +1051,37 @@ def case2cell(nfaces=40, seed=14):
                   **{k: g[k] for k in ("phiJm", "phiJmU", "phiP", "phiPi", "phiJmH", "phiQ", "phiPiU")})
         for code in eq_src:
             exec(code, eq)
+
+        # the same step with implicitDiffusion true [QGDUEqn.H L36-75, QGDEEqn.H L37-64]: explicit part with the fluxes of the implicit
+        # branch (gi), then the two implicit solves (2 x 2 systems here), phiSigmaDotU from fvc::grad of the NEW velocity
+        dvec = nei - own
+        delta = 1.0 / max((S / mag(S)) & dvec, 0.05 * mag(dvec))                       # nonOrthDeltaCoeffs (L0)
+        fvm_e, fvc_e = fv_emulation(dt, [1.0, 1.0])
+        fvm_i, fvc_i = fv_emulation_implicit(dt, mag(S), delta)
+
+        class Both:      # fvm::ddt / fvc::ddt with one argument belong to the explicit part, with two to the implicit part
+            def __init__(self, a, b): self.a, self.b = a, b
+            def ddt(self, *x): return (self.a if len(x) == 1 else self.b).ddt(*x)
+            def __getattr__(self, k): return getattr(self.b, k)
+        sig = Holder()
+        Ui = CF(U)
+
+        def grad_lin(fld):   # linearInterpolate(fvc::grad(U)): Gauss linear gradient of the two one-face cells, then the face value
+            uf = lin(Pair(fld[0], fld[1]))
+            gc = Pair(Tensor(np.outer(S.c, uf.c)), Tensor(-np.outer(S.c, uf.c)))
+            return lin(gc)
+        eqi = dict(fvm=Both(fvm_e, fvm_i), fvc=Both(fvc_e, Obj(ddt=fvc_i.ddt, div=fvc_i.div, grad=lambda fld: fld)), solve=lambda M: M.solve(),
+                   implicitDiffusion=True, magSqr=magSqr, rho=CF(rho), U=Ui, e=CF(e), rhoU=CF([rhoU.o, rhoU.n]), rhoE=CF([rhoE.o, rhoE.n]),
+                   rhoSu=zero_s, rhoUSu=zero_v, rhoESu=zero_s, phiSigmaDotU=0.0, muf=gi["muf"], alphauf=gi["alphauf"], Uf=gi["Uf"],
+                   phiTauMC=gi["phiTauMC"], tauMCPtr=tauMC, sigmaDotUPtr=sig, linearInterpolate=grad_lin, mesh=Obj(Sf=call(S)),
+                   **{k: gi[k] for k in ("phiJm", "phiJmU", "phiP", "phiPi", "phiJmH", "phiQ", "phiPiU")})
+        eq_impl = [eq_src[0], field_assignments(eq_src[1], ("rhoU",)), eq_src[2]]
+        for code in eq_impl:
+            exec(code, eqi)
+        extra = dict(rho1=list(eqi["rho"]), U1=np.array([u.c for u in eqi["U"]]), e1=list(eqi["e"]), rhoE1=list(eqi["rhoE"]),
+                     phiSigmaDotU=eqi["phiSigmaDotU"], delta=delta)
+        for k, v_ in extra.items():
+            rec2.setdefault(k, []).append(np.array(v_, dtype=float))
 
         def val(x):
             return x.c if isinstance(x, Vec) else (x.m.reshape(9) if isinstance(x, Tensor) else x)
@@ -1731,6 +1790,11 @@ def main():
         print(name, {k: v.shape for k, v in data.items()})
         if name == "case2cell":
             case = data
+            impl = {k: np.array(v) for k, v in case2cell.implicit_step.items()}
+            for k in ("nv", "pts", "Sf", "Cf", "C", "U", "T", "p", "R", "Cv", "mu", "Pr", "ScQGD", "PrQGD", "alphaQGD", "deltaT"):
+                impl[k] = data[k]
+            np.savez_compressed(os.path.join(HERE, "ref_expr_implicit2cell.npz"), **impl)
+            print("implicit2cell", {k: v.shape for k, v in impl.items()})
     for name, data in (("gvp2d_vec", gvp2d_vec()), ("gvp_other", gvp_other()), ("qgdlength", qgdlength()), ("courant", courant(case)),
                        ("qhdclosure", qhdclosure()), ("casebnd", casebnd()), ("qhdeqn", qhdeqn())):
         np.savez_compressed(os.path.join(HERE, f"ref_expr_{name}.npz"), **data)

@@ -419,3 +419,23 @@ def test_one_whole_qhdfoam_step_from_the_listing_text():
         for f, want in (("p", "p1"), ("U", "U1"), ("T", "T1")):
             assert rel(oc.field(f), g[want][i]) <= 1e-11, (i, f, oc.field(f), g[want][i])
         oc.close(); om.close()
+
+
+def test_one_step_of_the_implicit_diffusion_branch_from_the_listing_text():
+    """QGDUEqn.H L36-75 and QGDEEqn.H L37-64 with implicitDiffusion true, executed from the listing text on the two-cell mesh of
+    case2cell: the explicit part with the fluxes of the implicit branch, the implicit U and e solves (fvm::ddt(rho, .) - fvc::ddt(rho, .)
+    - fvm::laplacian), rhoU = rho U, phiSigmaDotU = Sf & ((muf lin(grad U) + tauMC) & Uf) from the new velocity, rhoE = rho (e + |U|^2/2)"""
+    g = rc.load("implicit2cell")
+    for i in range(len(g["nv"])):
+        nv = int(g["nv"][i])
+        om = oracle_mesh(*rc.two_cell_mesh(g["pts"][i], nv, g["Sf"][i], g["Cf"][i], g["C"][i]))
+        assert rel(om.array("nonOrthDeltaCoeffs")[0], g["delta"][i]) <= 1e-14
+        opt = case_options(g, i)
+        opt.implicitDiffusion, opt.implicitTol, opt.implicitMaxIter = 1, 1e-15, 100
+        oc = OracleCase(om, opt)
+        oc.set_fields(g["U"][i], g["T"][i], g["p"][i])
+        oc.step(1)
+        for f in ("rho", "U", "e", "rhoE"):
+            assert rel(oc.field(f), g[f + "1"][i]) <= 1e-11, (i, nv, f, oc.field(f), g[f + "1"][i])
+        assert rel(oc.field("phiSigmaDotU")[0], g["phiSigmaDotU"][i]) <= 1e-10, (i, oc.field("phiSigmaDotU")[0], g["phiSigmaDotU"][i])
+        oc.close(); om.close()

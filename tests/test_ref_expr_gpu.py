@@ -296,3 +296,22 @@ def test_one_whole_qhdfoam_step_on_the_device():
         for f, want in (("p", "p1"), ("U", "U1"), ("T", "T1")):
             assert rel(case.field(f), g[want][i]) <= 1e-10, (i, f, case.field(f), g[want][i])
         case.close(); dev.close()
+
+
+def test_one_step_of_the_implicit_diffusion_branch_on_the_device():
+    """the device's implicitDiffusion step (qgd_implicit.hip: face terms, the four PCG solves, phiSigmaDotU) against
+    tests/golden/ref_expr_implicit2cell.npz: QGDUEqn.H L36-75 and QGDEEqn.H L37-64 executed from the listing text"""
+    g = rc.load("implicit2cell")
+    for i in range(len(g["nv"])):
+        nv = int(g["nv"][i])
+        mesh = device_mesh(*rc.two_cell_mesh(g["pts"][i], nv, g["Sf"][i], g["Cf"][i], g["C"][i]))
+        dev = q.Device(mesh)
+        opt = case_options(g, i)
+        opt.implicitDiffusion, opt.implicitTol, opt.implicitMaxIter = 1, 1e-15, 100
+        case = q.QGDFoamCase(dev, opt)
+        case.set_fields(g["U"][i], g["T"][i], g["p"][i])
+        case.step(1)
+        for f in ("rho", "U", "e", "rhoE"):
+            assert rel(case.field(f), g[f + "1"][i]) <= 1e-10, (i, nv, f, case.field(f), g[f + "1"][i])
+        assert rel(case.field("phiSigmaDotU")[0], g["phiSigmaDotU"][i]) <= 1e-9, (i, case.field("phiSigmaDotU")[0], g["phiSigmaDotU"][i])
+        case.close(); dev.close()
