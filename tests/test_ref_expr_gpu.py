@@ -271,6 +271,9 @@ def test_flux_assembly_of_one_boundary_face_on_the_device():
         mesh, case = boundary_case(g, i, device_mesh, lambda m, opt: q.QGDFoamCase(q.Device(m), opt))
         case.updateFluxes()
         for f in BND_FACE_FIELDS:
+            if f == "gradef":   # T zeroGradient: e_b = e_O, the gradient is rounding noise around zero on both sides
+                assert np.abs(case.field(f)[1] - g[f][i]).max() <= 1e-12, (i, f)
+                continue
             assert rel(case.field(f)[1], g[f][i]) <= 2e-12, (i, f, case.field(f)[1], g[f][i])
         assert rel(case.field("p.boundary")[0], g["pMid"][i]) <= TOL, i
         dev = case.dev
