@@ -185,6 +185,12 @@ int qgd_mesh_shard(qgd_mesh_t global, int32_t nRanks, const int32_t* cellStart, 
 /* number of halo slots (neighbouring shards) of a mesh; 0 when unsharded, 2 for a qgd_mesh_box slab */
 int qgd_mesh_halo_slots(qgd_mesh_t m, int32_t* nSlots);
 
+/* The faceSet "degenerateStencilFaces" of the leastSquares stencil [leastSquaresStencil_8C_source.html L58-133]: faces the user
+ * wants treated like the ones whose weight matrix is degenerate, i.e. the face gradient falls back to nf * snGrad
+ * [extendedFaceStencilScalarGrad_8C_source.html L76-83].  Internal face labels count (the listing keeps boundary ones only on
+ * processor patches); the list follows the faces through qgd_mesh_renumber / qgd_mesh_shard.  Call before qgd_device_create.
+ * qgd_mesh_get name: "degenerateFaces". */
+int qgd_mesh_set_degenerate_faces(qgd_mesh_t m, int32_t n, const int32_t* faces);
 int qgd_mesh_set_geometry(qgd_mesh_t m, const double* Sf, const double* Cf,
                           const double* C, const double* V);
 int qgd_mesh_free(qgd_mesh_t m);

@@ -73,6 +73,7 @@ struct Mesh {
     std::vector<ivec> haloGhost, haloSend;      // one entry per halo slot (neighbouring shard)
     std::vector<ivec> haloGhostBF, haloSendBF;  // boundary-face indices (global label - nIF)
     dvec haloFaceH;                             // hQGDf of the halo-patch faces as the unsharded mesh has it, in patch order
+    ivec userDegenerateFaces;                   // faceSet degenerateStencilFaces [leastSquaresStencil.C L63-128]
     bool sharded() const { for (const ivec& g : haloGhost) if (!g.empty()) return true; return false; }
 
     int nBF() const { return nF - nIF; }
@@ -507,7 +508,8 @@ struct LeastSquares : Stencil {
             // det(symmTensor) (L0 formula)
             const double detG = G[0] * G[3] * G[5] + G[1] * G[4] * G[2] + G[2] * G[1] * G[4]
                               - G[0] * G[4] * G[4] - G[1] * G[1] * G[5] - G[2] * G[3] * G[2];
-            if (detG < 1) {
+            // [CalcW.C L136-145]; the user's faceSet joins the same list [leastSquaresStencil.C L84-117]
+            if (detG < 1 || std::find(m.userDegenerateFaces.begin(), m.userDegenerateFaces.end(), facei) != m.userDegenerateFaces.end()) {
                 internalDegFaces.push_back(facei);
             } else {
                 // inv(symmTensor) = cofactors/det (L0)
@@ -2280,6 +2282,13 @@ int orc_mesh_set_halo(void* mp, int side, int32_t nGhost, const int32_t* ghost, 
     return 0;
 }
 
+int orc_mesh_set_degenerate_faces(void* mp, int32_t n, const int32_t* faces) {
+    MeshHandle* h = (MeshHandle*)mp;
+    h->m.userDegenerateFaces.assign(faces, faces + n);
+    for (auto& kv : h->cache.byName) delete kv.second;   // stencils built so far are dropped
+    h->cache.byName.clear();
+    return 0;
+}
 int orc_mesh_set_halo_face_h(void* mp, int32_t n, const double* h) {
     ((MeshHandle*)mp)->m.haloFaceH.assign(h, h + n);
     return 0;

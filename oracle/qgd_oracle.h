@@ -47,6 +47,8 @@ int orc_mesh_info(void* m, int64_t info[4]);
 int orc_mesh_set_halo(void* m, int side, int32_t nGhost, const int32_t* ghost,
                       int32_t nSend, const int32_t* send);
 
+/* the faceSet degenerateStencilFaces of the leastSquares stencil (internal face labels) */
+int orc_mesh_set_degenerate_faces(void* m, int32_t n, const int32_t* faces);
 /* hQGDf of the halo-patch faces as the unsharded mesh has it (patch order), so that a ghost cell's hQGD comes out right */
 int orc_mesh_set_halo_face_h(void* m, int32_t n, const double* h);
 

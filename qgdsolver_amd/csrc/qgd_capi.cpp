@@ -434,6 +434,18 @@ int qgd_mesh_set_geometry(qgd_mesh_t mh, const double* Sf, const double* Cf, con
     return QGD_OK;
     QGD_CATCH
 }
+int qgd_mesh_set_degenerate_faces(qgd_mesh_t mh, int32_t n, const int32_t* faces) {
+    QGD_TRY
+    if (!mh || n < 0 || (n > 0 && !faces)) return fail(QGD_ERR_INVALID, "qgd_mesh_set_degenerate_faces: bad argument");
+    HostMesh& m = mh->m;
+    for (int32_t i = 0; i < n; ++i)
+        if (faces[i] < 0 || faces[i] >= m.nFaces) return fail(QGD_ERR_INVALID, "qgd_mesh_set_degenerate_faces: face label out of range");
+    m.degenerateFaces.assign(faces, faces + n);
+    std::sort(m.degenerateFaces.begin(), m.degenerateFaces.end());
+    m.degenerateFaces.erase(std::unique(m.degenerateFaces.begin(), m.degenerateFaces.end()), m.degenerateFaces.end());
+    return QGD_OK;
+    QGD_CATCH
+}
 int qgd_mesh_free(qgd_mesh_t m) {
     delete m;
     return QGD_OK;
@@ -474,6 +486,7 @@ int qgd_mesh_get(qgd_mesh_t mh, const char* name, void* out, int64_t outBytes) {
     else if (s == "faceGlobal") I(m.faceGlobal);
     else if (s == "pointGlobal") I(m.pointGlobal);
     else if (s == "haloFaceH") D(m.haloFaceH);
+    else if (s == "degenerateFaces") I(m.degenerateFaces);
     else if (s == "Sf") D(m.Sf);
     else if (s == "magSf") D(m.magSf);
     else if (s == "Cf") D(m.Cf);

@@ -60,6 +60,9 @@ struct HostMesh {
     // hQGDf of the faces of the halo patch(es) AS THE UNSHARDED MESH HAS IT (they are internal faces there), in patch order:
     // with it a ghost cell's hQGD -- an area-weighted mean over all its faces [QGDCoeffs.C L323-362] -- comes out right
     std::vector<double> haloFaceH;
+    // the user's faceSet "degenerateStencilFaces" [leastSquaresStencil.C L63-128]: internal faces the leastSquares stencil
+    // treats as degenerate (nf * snGrad) whatever their weights say
+    std::vector<int32_t> degenerateFaces;
 
     int32_t nBoundaryFaces() const { return nFaces - nInternalFaces; }
     int32_t faceSize(int32_t f) const { return faceOffsets[f + 1] - faceOffsets[f]; }

@@ -59,6 +59,13 @@ void renumberCells(HostMesh& m, const int32_t* newOfOld, int32_t* faceNewOfOld) 
         own[f] = newOfOld[m.owner[f]];
         if (faceNewOfOld) faceNewOfOld[f] = f;
     }
+    if (!m.degenerateFaces.empty()) {   // the user's degenerate faces follow their faces
+        std::vector<int32_t> newOf((size_t)nF);
+        for (int32_t k = 0; k < nIF; ++k) newOf[keys[k].old] = k;
+        for (int32_t f = nIF; f < nF; ++f) newOf[f] = f;
+        for (int32_t& f : m.degenerateFaces) f = newOf[f];
+        std::sort(m.degenerateFaces.begin(), m.degenerateFaces.end());
+    }
     m.faceOffsets.swap(fo);
     m.facePoints.swap(fp);
     m.owner.swap(own);
@@ -259,6 +266,14 @@ HostMesh extractShard(const HostMesh& g, int32_t nRanks, const int32_t* cellStar
         m.patches.push_back(p);
     }
     m.nFaces = (int32_t)m.owner.size();
+    if (!g.degenerateFaces.empty()) {
+        std::vector<uint8_t> isDeg((size_t)g.nFaces, 0);
+        for (int32_t f : g.degenerateFaces) isDeg[f] = 1;
+        for (int32_t lf = 0; lf < m.nFaces; ++lf) {
+            const int32_t gf = m.faceGlobal[lf] >= 0 ? m.faceGlobal[lf] : -1 - m.faceGlobal[lf];
+            if (isDeg[gf]) m.degenerateFaces.push_back(lf);
+        }
+    }
     // points in ascending global label
     for (int32_t v : m.facePoints) pointLocal[v] = 0;
     for (int32_t p = 0; p < g.nPoints; ++p)

@@ -222,6 +222,8 @@ StaticData buildStaticData(const HostMesh& m) {
         std::vector<int32_t> lsqOff((size_t)nIF + 1, 0), lsqCellCsr;
         std::vector<double> gwCsr[3];
         s.lsqDeg.assign((size_t)nIF, 0);
+        std::vector<uint8_t> userDeg((size_t)nIF, 0);
+        for (int32_t f : m.degenerateFaces) if (f >= 0 && f < nIF) userDeg[f] = 1;
         std::vector<int32_t> nb;
         for (int64_t f = 0; f < nIF; ++f) {
             nb.clear();
@@ -249,8 +251,10 @@ StaticData buildStaticData(const HostMesh& m) {
             for (int k = 0; k < 6; ++k) G[k] = G[k] + G0[k];
             const double det = G[0] * G[3] * G[5] + G[1] * G[4] * G[2] + G[2] * G[1] * G[4] - G[0] * G[4] * G[4] -
                                G[1] * G[1] * G[5] - G[2] * G[3] * G[2];
-            if (det < 1) {
-                s.lsqDeg[f] = 1;  // G stays un-inverted; the face falls back to nf*snGrad [ScalarGrad.C L76-83]
+            if (det < 1 || userDeg[f]) {
+                // G stays un-inverted; the face falls back to nf*snGrad [ScalarGrad.C L76-83]: the weights' own degeneracy test
+                // [CalcW.C L136-145] or the user's faceSet degenerateStencilFaces [leastSquaresStencil.C L63-128]
+                s.lsqDeg[f] = 1;
             } else {
                 const double I[6] = {(G[3] * G[5] - G[4] * G[4]) / det, (G[2] * G[4] - G[1] * G[5]) / det,
                                      (G[1] * G[4] - G[2] * G[3]) / det, (G[0] * G[5] - G[2] * G[2]) / det,

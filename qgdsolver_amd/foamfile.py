@@ -301,6 +301,13 @@ def read_polymesh(poly_dir):
         ptype.append(PATCH_TYPES[t])
     mesh = PolyMesh.from_arrays(points, fo, fp, owner, neighbour, n_cells, start, size, ptype)
     mesh.patch_names = names
+    # the faceSet the leastSquares stencil reads if present [leastSquaresStencil.C L63-70]
+    dsf = os.path.join(poly_dir, "sets", "degenerateStencilFaces")
+    if _exists(dsf):
+        _, nset, labels = _read_list_file(dsf)
+        if labels.size != nset:
+            raise FoamFileError("sets/degenerateStencilFaces: size mismatch")
+        mesh.set_degenerate_faces(labels.astype(np.int32))
     return mesh
 
 

@@ -5,7 +5,7 @@ import numpy as np
 
 from . import _lib as L
 
-_INT_ARRAYS = {"faceOffsets", "facePoints", "owner", "neighbour", "patchStart", "patchSize", "patchType",
+_INT_ARRAYS = {"degenerateFaces", "faceOffsets", "facePoints", "owner", "neighbour", "patchStart", "patchSize", "patchType",
                "haloPeer", "cellGlobal", "faceGlobal", "pointGlobal"}
 
 
@@ -90,6 +90,14 @@ class PolyMesh:
         assert a[0].size == 3 * self.nFaces and a[1].size == 3 * self.nFaces and a[2].size == 3 * self.nCells and a[3].size == self.nCells
         L.check(L.lib.qgd_mesh_set_geometry(self._h, *[_dp(x) for x in a]), "qgd_mesh_set_geometry")
         self.__init__(self._h)
+        return self
+
+    def set_degenerate_faces(self, faces):
+        """the faceSet degenerateStencilFaces of the leastSquares stencil (leastSquaresStencil.C L58-133): internal faces whose
+        gradient falls back to nf * snGrad; before the Device is created"""
+        f = np.ascontiguousarray(faces, dtype=np.int32)
+        L.check(L.lib.qgd_mesh_set_degenerate_faces(self._h, int(f.size), f.ctypes.data_as(L.c_int32_p) if f.size else None),
+                "qgd_mesh_set_degenerate_faces")
         return self
 
     def jitter(self, amplitude, seed=2024):

@@ -39,6 +39,7 @@ lib.orc_mesh_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
 lib.orc_mesh_set_geometry.argtypes = [C.c_void_p, dp, dp, dp, dp]
 lib.orc_mesh_set_halo.argtypes = [C.c_void_p, C.c_int, C.c_int32, ip, C.c_int32, ip]
 lib.orc_mesh_set_halo_face_h.argtypes = [C.c_void_p, C.c_int32, dp]
+lib.orc_mesh_set_degenerate_faces.argtypes = [C.c_void_p, C.c_int32, ip]
 lib.orc_fvsc.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, dp, dp, dp]
 lib.orc_case_create.restype = C.c_void_p
 lib.orc_case_create.argtypes = [C.c_void_p, C.POINTER(Options)]
@@ -139,6 +140,10 @@ class OracleMesh:
         g = np.ascontiguousarray(ghost, dtype=np.int32)
         s = np.ascontiguousarray(send, dtype=np.int32)
         assert lib.orc_mesh_set_halo(self._h, side, g.size, _i(g), s.size, _i(s)) == 0
+
+    def set_degenerate_faces(self, faces):
+        f = np.ascontiguousarray(faces, dtype=np.int32)
+        lib.orc_mesh_set_degenerate_faces(self._h, f.size, _i(f if f.size else np.zeros(1, dtype=np.int32)))
 
     def set_halo_face_h(self, h):
         h = np.ascontiguousarray(h, dtype=np.float64)
