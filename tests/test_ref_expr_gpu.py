@@ -271,7 +271,7 @@ def test_flux_assembly_of_one_boundary_face_on_the_device():
         mesh, case = boundary_case(g, i, device_mesh, lambda m, opt: q.QGDFoamCase(q.Device(m), opt))
         case.updateFluxes()
         for f in BND_FACE_FIELDS:
-            if f == "gradef":   # T zeroGradient: e_b = e_O, the gradient is rounding noise around zero on both sides
+            if f in ("gradef", "gradRhof"):   # T zeroGradient, p_b = p_O at start-up: e_b = e_O, rho_b = rho_O, the gradients are rounding noise around zero
                 assert np.abs(case.field(f)[1] - g[f][i]).max() <= 1e-12, (i, f)
                 continue
             assert rel(case.field(f)[1], g[f][i]) <= 2e-12, (i, f, case.field(f)[1], g[f][i])
