@@ -412,7 +412,7 @@ typedef struct qgd_case_options {
     int32_t implicitDiffusion;/* 0: the explicit branch [QGDFoam_2updateFluxes_8H_source.html L95-106];
                                  1: the reference's default [QGDThermo_8C_source.html L70-82]: viscous stress and heat
                                  conduction implicit, tauMC / phiSigmaDotU [updateFluxes.H L107-111, QGDUEqn_8H L54-75,
-                                 QGDEEqn_8H L53-64]; unsharded meshes only                                          */
+                                 QGDEEqn_8H L53-64]; on shards see "the implicitDiffusion branch on a cell-range shard"   */
     int32_t adjustTimeStep;   /* 1: Courant/deltaT control
                                  [QGDCourantNo_8H_source.html L36-53,
                                   setDeltaT-QGDQHD_8H_source.html L41-61]         */
@@ -485,6 +485,33 @@ int qgd_case_info(qgd_case_t c, double info[6]);
  * since qgd_case_set_fields in which a solve stopped above implicitTol (iteration limit or breakdown: the step keeps the last
  * iterate, as OpenFOAM does, and counts here); [13] = 1 when the case runs the implicit branch. */
 int qgd_case_implicit_info(qgd_case_t c, double info[14]);
+
+/* ---- the implicitDiffusion branch on a cell-range shard -------------------------------------------------------------------------
+ * implicitDiffusion true is the reference's default [QGDThermo_8C_source.html L70-82].  Its two implicit equations
+ * [QGDUEqn_8H_source.html L54-75, QGDEEqn_8H_source.html L53-64] are solved here by a Jacobi-preconditioned CG whose scalars
+ * live in a control block on the device (the three velocity components as three right-hand sides of ONE matrix walk); under MPI
+ * the reference reaches across ranks through processor patches inside fvm::laplacian, the linear solver and fvc::grad.  With one
+ * rank per shard the advance (after phase 0, the flux assembly) is, through qgd_case_step_phase:
+ *   phase 20  deltaT, fvc::grad(U) of the old state          -> exchange message kind 1
+ *   phase 21  tauMC / phiTauMC, rho, rhoU, the U systems, first solver phase  -> SUM-reduce control[0..12)
+ *   phase 22  normFactor                                      -> reduce control[12..16)
+ *   phase 23  first residual, search direction, r.z           -> reduce control[16..20); exchange kind 3
+ *   repeat until qgd_case_implicit_solve_status says done:
+ *     phase 24 A d, d.Ad -> reduce control[20..24) | phase 25 x, r, |r|, r.z -> reduce control[24..32) | phase 26 new direction -> exchange kind 3
+ *   phase 27  U into the records, its boundary conditions     -> exchange kind 2
+ *   phase 28  fvc::grad(U) of the new velocity                -> exchange kind 1
+ *   phase 29  phiSigmaDotU, the energy equation, the e system, first solver phase -> reduce control[0..12); then 22, 23, (24, 25, 26)*
+ *   phase 35  rhoE, thermo, p, boundary refresh               -> the state message (qgd_case_halo_pack / unpack), phase 2
+ * control: 68 device doubles, slot-major, control[slot * 4 + component].  Message kinds: 1 = fvc::grad(U), 9 per cell; 2 = U, 3 per
+ * cell; 3 = the search direction, one per right-hand side of the solve in flight per cell (counts report room for three).
+ * An unsharded case runs the same phases back to back inside qgd_case_step; qgd_case_step_sharded drives them over RCCL. */
+int qgd_case_implicit_halo_count(qgd_case_t c, int slot, int kind, int64_t* sendCount, int64_t* recvCount);
+int qgd_case_implicit_halo_pack(qgd_case_t c, int slot, int kind, double* sendBufDevice);
+int qgd_case_implicit_halo_unpack(qgd_case_t c, int slot, int kind, const double* recvBufDevice);
+int qgd_case_implicit_control(qgd_case_t c, double control[68], int set);
+int qgd_case_implicit_control_ptr(qgd_case_t c, void** devicePtr);
+/* waits for the stream; status[0] != 0: every right-hand side of the solve in flight is done; status[1] = their number */
+int qgd_case_implicit_solve_status(qgd_case_t c, double status[2]);
 
 /* ---- halo exchange of ghost-cell primitives (multi-GPU) ------------------- */
 /* A shard has one halo slot per neighbouring shard: a qgd_mesh_box slab (kLo>0 or kHi<nzGlobal) has slot 0 = lower k

@@ -131,6 +131,12 @@ SIGNATURES = {
     "qgd_case_info": (C.c_int, [handle, c_double_p]),
     "qgd_case_implicit_info": (C.c_int, [handle, c_double_p]),
     "qgd_struct_sizes": (C.c_int, [c_int64_p]),
+    "qgd_case_implicit_halo_count": (C.c_int, [handle, C.c_int, C.c_int, c_int64_p, c_int64_p]),
+    "qgd_case_implicit_halo_pack": (C.c_int, [handle, C.c_int, C.c_int, C.c_void_p]),
+    "qgd_case_implicit_halo_unpack": (C.c_int, [handle, C.c_int, C.c_int, C.c_void_p]),
+    "qgd_case_implicit_control": (C.c_int, [handle, c_double_p, C.c_int]),
+    "qgd_case_implicit_control_ptr": (C.c_int, [handle, C.POINTER(C.c_void_p)]),
+    "qgd_case_implicit_solve_status": (C.c_int, [handle, c_double_p]),
     "qgd_device_alloc": (C.c_int, [handle, C.c_int64, C.POINTER(C.c_void_p)]),
     "qgd_device_release": (C.c_int, [handle, C.c_void_p]),
     "qgd_species_flux": (C.c_int, [handle, C.c_int] + [c_double_p] * 10),

@@ -238,10 +238,8 @@ struct qgd_case_s {
     CaseView view{};
     double* dbgBuf = nullptr;
     ImplView impl{};            // implicitDiffusion branch: its face / cell work arrays
-    double* implWork = nullptr;
-    int implIters[4] = {0, 0, 0, 0};
-    double implResid[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // initial, final normalised residual of the four solves of the last step
-    int64_t implUnconverged = 0;                      // steps since set_fields in which a solve stopped above implicitTol
+    ImplicitSolver* implSolver = nullptr;   // the two linear solves of the branch (device-scalar multi-right-hand-side PCG)
+    std::vector<double*> implSendBuf, implRecvBuf;   // native transport of the branch's own halo messages
     double* coef[4] = {nullptr, nullptr, nullptr, nullptr};  // device copies of non-uniform alphaQGD / ScQGD (cells, patch faces)
     double time = 0;
     int64_t steps = 0;
@@ -317,6 +315,7 @@ static Launcher launcherOf(qgd_case_s* c) {
 __attribute__((constructor)) static void qgdInitOpenMP() { setenv("KMP_BLOCKTIME", "0", 0); }
 
 static bool hasWedgeAndPrism(const HostMesh& m);
+static int implHaloMove(qgd_case_s* c, int slot, int kind, double* buf, bool pack, hipStream_t stream);
 
 // Tuning knobs of the measurement scripts (QGD_*): a value outside the supported set is an error, not a silent change of
 // code path.  allowed == nullptr: any integer in [lo, hi].
@@ -1144,8 +1143,6 @@ int qgd_case_options_default(qgd_case_options* o) {
 int qgd_case_create(qgd_device_t d, const qgd_case_options* opt, qgd_case_t* out) {
     QGD_TRY
     if (!d || !opt || !out) return fail(QGD_ERR_INVALID, "qgd_case_create: null argument");
-    if (opt->implicitDiffusion && d->sharded())
-        return fail(QGD_ERR_NOT_IMPLEMENTED, "implicitDiffusion true on a sharded mesh: the implicit solves and fvc::grad(U) are not distributed");
     if (opt->implicitDiffusion && (!(opt->implicitTol >= 0) || opt->implicitMaxIter < 0))
         return fail(QGD_ERR_INVALID, "qgd_case_create: bad implicitTol / implicitMaxIter");
     if (!(opt->R > 0) || !(opt->Cv > 0) || !(opt->Pr > 0) || !(opt->PrQGD > 0) || !(opt->deltaT > 0))
@@ -1193,7 +1190,7 @@ int qgd_case_create(qgd_device_t d, const qgd_case_options* opt, qgd_case_t* out
             iv.rhoNew = a.alloc<double>(nC);
             iv.xU = a.alloc<double>(3 * nC); iv.diagU = a.alloc<double>(3 * nC); iv.rhsU = a.alloc<double>(3 * nC);
             iv.xE = a.alloc<double>(nC); iv.diagE = a.alloc<double>(nC); iv.rhsE = a.alloc<double>(nC);
-            c->implWork = a.alloc<double>(6 * nC + 3 * ((nC + 255) / 256) + 8);
+            c->implSolver = implicitSolverCreate(d->stream, v, d->ownedBegin, d->ownedEnd);
         }
         c->bc.resize(d->patches.size());
         for (size_t i = 0; i < d->patches.size(); ++i) {
@@ -1216,6 +1213,7 @@ int qgd_case_free(qgd_case_t c) {
     (void)hipSetDevice(c->dev->deviceId);
     harvestTiming(c);
     for (hipEvent_t e : c->freeEvents) (void)hipEventDestroy(e);
+    if (c->implSolver) { (void)hipStreamSynchronize(c->stream()); implicitSolverFree(c->implSolver); }
     if (c->ownHaloStream) { (void)hipStreamSynchronize(c->ownHaloStream); (void)hipStreamDestroy(c->ownHaloStream); }
     if (c->evLayerDone) (void)hipEventDestroy(c->evLayerDone);
     if (c->evUnpacked) (void)hipEventDestroy(c->evUnpacked);
@@ -1314,7 +1312,8 @@ int qgd_case_set_fields(qgd_case_t c, const double* U, const double* T, const do
     cleanup();
     c->phiwRegistered = true;  // createFaceFluxes.H registers "phiwStar" before the loop starts
     c->fieldsSet = true;
-    c->time = 0; c->steps = 0; c->implUnconverged = 0;
+    c->time = 0; c->steps = 0;
+    if (c->implSolver) { implicitSolverSetStream(c->implSolver, c->stream()); implicitStatsReset(c->implSolver); HIP_CHECK(hipStreamSynchronize(c->stream())); }
     return QGD_OK;
     QGD_CATCH
 }
@@ -1343,6 +1342,70 @@ static void stepAssemble(qgd_case_s* c) {
     assembleFluxes(c, adjust);
     if (adjust) launchFaceReduce(launcherOf(c), c->view);
 }
+// ---- the implicitDiffusion branch [QGDUEqn.H L54-75, QGDEEqn.H L53-64] as stream-ordered phases ---------------------------------
+//   20  fvc::grad(U) of the old state                                       -> message kind 1
+//   21  tauMC / phiTauMC, rho, rhoU, the three U systems, first solver phase -> reduce control slots 0..2
+//   22, 23  solver phases 1, 2                                              -> reduce slot 3 | slot 4 + message kind 3
+//   24, 25, 26  one PCG iteration (solver phases 3, 4, 5)                    -> reduce slot 5 | slots 6..7 | message kind 3
+//   27  U into the records, its boundary conditions                         -> message kind 2
+//   28  fvc::grad(U) of the new velocity                                    -> message kind 1
+//   29  phiSigmaDotU, the energy equation's explicit part, the e system, first solver phase -> reduce slots 0..2
+//       then 22, 23, (24, 25, 26)* again for e
+//   35  rhoE, thermo, p, boundary refresh                                   -> the state message (qgd_case_halo_*)
+// (deltaT, time and step count are advanced by phase 20.)  No host synchronisation anywhere inside.
+static void implicitPhase(qgd_case_s* c, int phase) {
+    const qgd_device_s* d = c->dev;
+    const MeshView& m = d->view;
+    ImplicitSolver* S = c->implSolver;
+    hipStream_t st = c->stream();
+    implicitSolverSetStream(S, st);
+    const double tol = c->opt.implicitTol;
+    const int maxIter = c->opt.implicitMaxIter;
+    (void)hipGetLastError();
+    switch (phase) {
+        case 20: {
+            const bool adjust = c->opt.adjustTimeStep != 0;
+            if (adjust) launchDeltaT(launcherOf(c), c->view, c->opt.maxCo, c->opt.maxDeltaT, c->opt.cTau);
+            c->steps++;
+            if (!adjust) c->time += c->opt.deltaT;
+            implicitStepMark(S, true);
+            launchImplicitPart(st, m, c->view, c->impl, c->gas, c->bcDev, S, tol, maxIter, 0);
+            break;
+        }
+        case 21: launchImplicitPart(st, m, c->view, c->impl, c->gas, c->bcDev, S, tol, maxIter, 1); break;
+        case 22: case 23: case 24: case 25: case 26: implicitSolvePhase(S, phase - 21); break;
+        case 27:
+            implicitSolveEnd(S, 0);
+            launchImplicitPart(st, m, c->view, c->impl, c->gas, c->bcDev, S, tol, maxIter, 2);
+            break;
+        case 28: launchImplicitPart(st, m, c->view, c->impl, c->gas, c->bcDev, S, tol, maxIter, 3); break;
+        case 29: launchImplicitPart(st, m, c->view, c->impl, c->gas, c->bcDev, S, tol, maxIter, 4); break;
+        case 35:
+            implicitSolveEnd(S, 1);
+            launchImplicitPart(st, m, c->view, c->impl, c->gas, c->bcDev, S, tol, maxIter, 5);
+            implicitStepMark(S, false);
+            launchBoundaryUpdate(launcherOf(c), m, c->view, c->gas, c->bcDev, false, c->phiwRegistered, 0, nullptr, 0);
+            break;
+        default: throw std::invalid_argument("implicit branch: phase must be 20..29 or 35");
+    }
+    HIP_CHECK(hipGetLastError());
+}
+// the whole advance with the transport behind the hooks (nullptr: one rank); haloImpl(kind) exchanges message kind 1 / 2
+static void implicitAdvanceWith(qgd_case_s* c, const SolveHooks* hooks, const std::function<void(int)>& haloImpl) {
+    ImplicitSolver* S = c->implSolver;
+    implicitPhase(c, 20);
+    if (haloImpl) haloImpl(1);
+    implicitPhase(c, 21);
+    implicitSolveRun(S, hooks);
+    implicitPhase(c, 27);
+    if (haloImpl) haloImpl(2);
+    implicitPhase(c, 28);
+    if (haloImpl) haloImpl(1);
+    implicitPhase(c, 29);
+    implicitSolveRun(S, hooks);
+    implicitPhase(c, 35);
+}
+
 // part 0 = everything; part 1 = deltaT + the shard's boundary layer (cells a neighbour needs, and their patch faces);
 // part 2 = the remaining owned cells/faces.  Ghost cells and their patch faces are only ever written by halo_unpack.
 static void stepAdvance(qgd_case_s* c, int part) {
@@ -1350,22 +1413,14 @@ static void stepAdvance(qgd_case_s* c, int part) {
     const qgd_device_s* d = c->dev;
     const MeshView& m = d->view;
     const bool adjust = c->opt.adjustTimeStep != 0;
+    if (c->opt.implicitDiffusion) {
+        implicitAdvanceWith(c, nullptr, nullptr);   // deltaT and the step count are advanced inside (phase 20)
+        return;
+    }
     if (part != 2) {
         if (adjust) launchDeltaT(L, c->view, c->opt.maxCo, c->opt.maxDeltaT, c->opt.cTau);
         c->steps++;
         if (!adjust) c->time += c->opt.deltaT;
-    }
-    if (c->opt.implicitDiffusion) {
-        // [QGDUEqn.H L54-75, QGDEEqn.H L53-64]: two linear solves inside the step (host-synchronised convergence checks)
-        launchImplicitAdvance(c->stream(), m, c->view, c->impl, c->gas, c->bcDev, c->opt.implicitTol, c->opt.implicitMaxIter, c->implWork,
-                              c->implIters, c->implResid);
-        // a solve that ran out of iterations or broke down (d.Ad <= 0) leaves its last iterate, as OpenFOAM's PCG does; the
-        // caller can tell through qgd_case_implicit_info
-        bool bad = false;
-        for (int k = 0; k < 4; ++k) bad = bad || !(c->implResid[2 * k + 1] < c->opt.implicitTol || c->implResid[2 * k + 1] == 0.0);
-        if (bad) c->implUnconverged++;
-        launchBoundaryUpdate(L, m, c->view, c->gas, c->bcDev, false, c->phiwRegistered, 0, nullptr, 0);
-        return;
     }
     if (part == 0) {
         launchCellUpdate(L, m, c->view, c->gas, 0, nullptr, 0);
@@ -1399,8 +1454,17 @@ int qgd_case_step_phase(qgd_case_t c, int phase) {
     if (!c->fieldsSet) return fail(QGD_ERR_INVALID, "qgd_case_step_phase: call qgd_case_set_fields first");
     HIP_CHECK(hipSetDevice(c->dev->deviceId));
     if (c->opt.implicitDiffusion && (phase == 10 || phase == 11))
-        return fail(QGD_ERR_NOT_IMPLEMENTED, "qgd_case_step_phase: the implicitDiffusion branch advances in one piece (its linear solves span "
-                                            "all cells); use phases 0 and 1");
+        return fail(QGD_ERR_NOT_IMPLEMENTED, "qgd_case_step_phase: the implicitDiffusion branch has no boundary-layer-first order (its linear "
+                                            "solves span all cells); use phases 0 and 1, or 0 and 20..35 on a shard");
+    if (phase >= 20 && phase <= 35) {
+        if (!c->opt.implicitDiffusion) return fail(QGD_ERR_INVALID, "qgd_case_step_phase: phases 20..35 belong to the implicitDiffusion branch");
+        if ((phase > 29 && phase < 35)) return fail(QGD_ERR_INVALID, "qgd_case_step_phase: phase must be 0, 1, 2, 10, 11, 20..29 or 35");
+        implicitPhase(c, phase);
+        return QGD_OK;
+    }
+    if (c->opt.implicitDiffusion && phase == 1 && c->dev->sharded())
+        return fail(QGD_ERR_INVALID, "qgd_case_step_phase: on a shard the implicitDiffusion branch advances through phases 20..35 with the "
+                                     "exchanges between them");
     if (phase == 0) stepAssemble(c);
     else if (phase == 1) stepAdvance(c, 0);
     else if (phase == 10) stepAdvance(c, 1);
@@ -2033,6 +2097,35 @@ int qgd_case_allreduce_max(qgd_case_t c, qgd_comm_t comm) {
     return QGD_OK;
     QGD_CATCH
 }
+// the implicit branch's own messages (kind 1 grad U, 2 U, 3 search direction) over the library's transport, on the case's stream
+static void implHaloExchangeOn(qgd_case_s* c, qgd_comm_s* comm, const int32_t* peers, int nSlots, int kind) {
+    qgd_device_s* d = c->dev;
+    const int n = std::min<int>(nSlots, (int)d->halo.size());
+    if (c->implSendBuf.size() != d->halo.size()) {
+        c->implSendBuf.assign(d->halo.size(), nullptr);
+        c->implRecvBuf.assign(d->halo.size(), nullptr);
+        for (size_t s2 = 0; s2 < d->halo.size(); ++s2) {
+            c->implSendBuf[s2] = c->arena.alloc<double>(9 * (size_t)d->halo[s2].nSend);
+            c->implRecvBuf[s2] = c->arena.alloc<double>(9 * (size_t)d->halo[s2].nGhost);
+        }
+    }
+    hipStream_t stream = c->stream();
+    const size_t w = (size_t)implicitHaloWidth(c->implSolver, kind);
+    for (int s2 = 0; s2 < n; ++s2)
+        if (peers[s2] >= 0 && implHaloMove(c, s2, kind, c->implSendBuf[s2], true, stream) != QGD_OK) throw std::invalid_argument(g_lastError);
+    RCCL_CHECK(rcclRef().groupStart());
+    try {
+        for (int s2 = 0; s2 < n; ++s2) {
+            const qgd_device_s::HaloSlot& h = d->halo[s2];
+            if (peers[s2] < 0) continue;
+            if (h.nSend) RCCL_CHECK(rcclRef().send(c->implSendBuf[s2], w * h.nSend, ncclFloat64, peers[s2], comm->comm, stream));
+            if (h.nGhost) RCCL_CHECK(rcclRef().recv(c->implRecvBuf[s2], w * h.nGhost, ncclFloat64, peers[s2], comm->comm, stream));
+        }
+    } catch (...) { (void)rcclRef().groupEnd(); throw; }
+    RCCL_CHECK(rcclRef().groupEnd());
+    for (int s2 = 0; s2 < n; ++s2)
+        if (peers[s2] >= 0 && implHaloMove(c, s2, kind, c->implRecvBuf[s2], false, stream) != QGD_OK) throw std::invalid_argument(g_lastError);
+}
 int qgd_case_step_sharded(qgd_case_t c, qgd_comm_t comm, const int32_t* peers, int nSlots, int overlapped) {
     QGD_TRY
     if (!c) return fail(QGD_ERR_INVALID, "null case");
@@ -2045,6 +2138,21 @@ int qgd_case_step_sharded(qgd_case_t c, qgd_comm_t comm, const int32_t* peers, i
     if (adjust && comm && comm->nRanks > 1)
         RCCL_CHECK(rcclRef().allReduce(c->view.red, c->view.red, 2, ncclFloat64, ncclMax, comm->comm, c->stream()));
     if (!sharded) { stepAdvance(c, 0); HIP_CHECK(hipGetLastError()); return QGD_OK; }
+    if (c->opt.implicitDiffusion) {
+        // the reference's default branch on shards: the dot products of its four solves are ncclAllReduce of the control block, the
+        // gradients, the new velocity and the search directions travel as grouped send/recv pairs, then the state message as usual
+        for (int a = 0; a < std::min<int>(nSlots, (int)c->dev->halo.size()); ++a)
+            if (peers[a] >= comm->nRanks) return fail(QGD_ERR_INVALID, "qgd_case_step_sharded: peer rank out of range");
+        SolveHooks hooks;
+        hipStream_t st = c->stream();
+        if (comm->nRanks > 1)
+            hooks.allreduce = [&](double* ptr, int n) { RCCL_CHECK(rcclRef().allReduce(ptr, ptr, (size_t)n, ncclFloat64, ncclSum, comm->comm, st)); };
+        hooks.haloDirection = [&]() { implHaloExchangeOn(c, comm, peers, nSlots, 3); };
+        implicitAdvanceWith(c, &hooks, [&](int kind) { implHaloExchangeOn(c, comm, peers, nSlots, kind); });
+        haloExchangeOn(c, comm, peers, nSlots, st);
+        HIP_CHECK(hipGetLastError());
+        return QGD_OK;
+    }
     if (!overlapped) {
         stepAdvance(c, 0);
         haloExchangeOn(c, comm, peers, nSlots, c->stream());
@@ -2244,15 +2352,85 @@ int qgd_case_info(qgd_case_t c, double info[6]) {
 }
 
 int qgd_case_implicit_info(qgd_case_t c, double info[14]) {
+    QGD_TRY
     if (!c || !info) return fail(QGD_ERR_INVALID, "null argument");
-    for (int k = 0; k < 4; ++k) {
-        info[k] = c->implIters[k];
-        info[4 + k] = c->implResid[2 * k];
-        info[8 + k] = c->implResid[2 * k + 1];
-    }
-    info[12] = (double)c->implUnconverged;
+    for (int k = 0; k < 14; ++k) info[k] = 0.0;
     info[13] = c->opt.implicitDiffusion ? 1.0 : 0.0;
+    if (!c->implSolver) return QGD_OK;
+    HIP_CHECK(hipSetDevice(c->dev->deviceId));
+    implicitSolverSetStream(c->implSolver, c->stream());
+    int it[4]; double r0[4], r1[4], bad = 0;
+    implicitSolverInfo(c->implSolver, it, r0, r1, &bad);
+    for (int k = 0; k < 4; ++k) { info[k] = it[k]; info[4 + k] = r0[k]; info[8 + k] = r1[k]; }
+    info[12] = bad;
     return QGD_OK;
+    QGD_CATCH
+}
+// the branch's own halo messages and control block on a shard (kinds 1 grad U, 2 U, 3 search direction; the state message is
+// qgd_case_halo_*): counts in doubles
+int qgd_case_implicit_halo_count(qgd_case_t c, int slot, int kind, int64_t* sendCount, int64_t* recvCount) {
+    if (!c || slot < 0 || kind < 1 || kind > 3 || !sendCount || !recvCount) return fail(QGD_ERR_INVALID, "bad argument");
+    *sendCount = *recvCount = 0;
+    if (!c->implSolver) return fail(QGD_ERR_INVALID, "qgd_case_implicit_halo_count: not an implicitDiffusion case");
+    if (slot >= (int)c->dev->halo.size()) return QGD_OK;
+    const int w = kind == 3 ? 3 : implicitHaloWidth(c->implSolver, kind);   // kind 3: capacity for the widest solve
+    *sendCount = (int64_t)w * c->dev->halo[slot].nSend;
+    *recvCount = (int64_t)w * c->dev->halo[slot].nGhost;
+    return QGD_OK;
+}
+static int implHaloMove(qgd_case_s* c, int slot, int kind, double* buf, bool pack, hipStream_t stream) {
+    qgd_device_s* d = c->dev;
+    if (slot >= (int)d->halo.size()) return QGD_OK;
+    const qgd_device_s::HaloSlot& h = d->halo[slot];
+    const int32_t n = pack ? h.nSend : h.nGhost;
+    if (n == 0) return QGD_OK;
+    if (!buf) return fail(QGD_ERR_INVALID, "null buffer");
+    launchImplicitHalo(stream, d->view, c->view, c->impl, c->implSolver, kind, pack ? h.send : h.ghost, n, buf, pack);
+    return QGD_OK;
+}
+int qgd_case_implicit_halo_pack(qgd_case_t c, int slot, int kind, double* sendBufDevice) {
+    QGD_TRY
+    if (!c || slot < 0 || kind < 1 || kind > 3 || !c->implSolver) return fail(QGD_ERR_INVALID, "bad argument");
+    HIP_CHECK(hipSetDevice(c->dev->deviceId));
+    return implHaloMove(c, slot, kind, sendBufDevice, true, c->stream());
+    QGD_CATCH
+}
+int qgd_case_implicit_halo_unpack(qgd_case_t c, int slot, int kind, const double* recvBufDevice) {
+    QGD_TRY
+    if (!c || slot < 0 || kind < 1 || kind > 3 || !c->implSolver) return fail(QGD_ERR_INVALID, "bad argument");
+    HIP_CHECK(hipSetDevice(c->dev->deviceId));
+    return implHaloMove(c, slot, kind, const_cast<double*>(recvBufDevice), false, c->stream());
+    QGD_CATCH
+}
+// control block of the solve in flight: 68 doubles, slot-major (control[slot * 4 + component]); a sharded run SUM-reduces
+// control[0..12), [12..16), [16..20), [20..24), [24..32) after solver phases 0, 1, 2, 3, 4.  status: {all components done,
+// right-hand sides of the solve in flight}
+int qgd_case_implicit_control(qgd_case_t c, double control[68], int set) {
+    QGD_TRY
+    if (!c || !control || !c->implSolver) return fail(QGD_ERR_INVALID, "bad argument");
+    HIP_CHECK(hipSetDevice(c->dev->deviceId));
+    hipStream_t st = c->stream();
+    if (set) HIP_CHECK(hipMemcpyAsync(implicitSolverCtl(c->implSolver), control, 68 * sizeof(double), hipMemcpyHostToDevice, st));
+    else HIP_CHECK(hipMemcpyAsync(control, implicitSolverCtl(c->implSolver), 68 * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    return QGD_OK;
+    QGD_CATCH
+}
+int qgd_case_implicit_control_ptr(qgd_case_t c, void** devicePtr) {
+    if (!c || !devicePtr || !c->implSolver) return fail(QGD_ERR_INVALID, "bad argument");
+    *devicePtr = implicitSolverCtl(c->implSolver);
+    return QGD_OK;
+}
+int qgd_case_implicit_solve_status(qgd_case_t c, double status[2]) {
+    QGD_TRY
+    if (!c || !status || !c->implSolver) return fail(QGD_ERR_INVALID, "bad argument");
+    HIP_CHECK(hipSetDevice(c->dev->deviceId));
+    implicitSolverSetStream(c->implSolver, c->stream());
+    int it[3]; double r0[3], r1[3];
+    implicitSolveStatus(c->implSolver, &status[0], it, r0, r1);
+    status[1] = implicitSolverRhs(c->implSolver);
+    return QGD_OK;
+    QGD_CATCH
 }
 
 int qgd_struct_sizes(int64_t sizes[4]) {

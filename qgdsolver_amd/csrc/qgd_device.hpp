@@ -164,8 +164,31 @@ struct ImplView {
     double *xU, *diagU, *rhsU;           // 3*nC SoA: the component systems of UEqn
     double *xE, *diagE, *rhsE;           // nC
 };
-void launchImplicitAdvance(hipStream_t s, const MeshView& m, const CaseView& c, const ImplView& iv, const GasModel& g, const PatchBCDev* bc,
-                           double tol, int maxIter, double* work, int iters[4], double resid[8]);
+// the branch as parts 0..5 (gradient | faces + U systems | store U | gradient of the new U | sigma + e system | finish) around its two
+// multi-right-hand-side Jacobi-PCG solves, all stream-ordered with the scalars of the solves in a device control block
+struct ImplicitSolver;
+struct SolveHooks;
+ImplicitSolver* implicitSolverCreate(hipStream_t stream, const MeshView& m, int ownedBegin = 0, int ownedEnd = -1);
+void implicitSolverFree(ImplicitSolver* S);
+int64_t implicitSolverBytes(const ImplicitSolver* S);
+double* implicitSolverCtl(ImplicitSolver* S);          // 68 doubles, slot-major: ctl[slot * 4 + component]; reduced slots 0..2, 3, 4, 5, 6..7
+double* implicitSolverDirection(ImplicitSolver* S);    // 3 * nC doubles, component-major
+int implicitSolverRhs(const ImplicitSolver* S);        // right-hand sides of the solve in flight (3: U, 1: e)
+void implicitSolveBegin(ImplicitSolver* S, int nRhs, int validMask, const double* a, const double* diag, const double* rhs, double* x, double tol,
+                        int maxIter);
+void implicitSolvePhase(ImplicitSolver* S, int phase);
+void implicitSolveRun(ImplicitSolver* S, const SolveHooks* hooks);
+void implicitSolveStatus(ImplicitSolver* S, double* allDone, int iters[3], double res0[3], double res[3]);
+void implicitSolveEnd(ImplicitSolver* S, int which);             // which = 0: the U solve, 1: the e solve
+void implicitStepMark(ImplicitSolver* S, bool begin);
+void implicitStatsReset(ImplicitSolver* S);
+void implicitSolverInfo(ImplicitSolver* S, int iters[4], double res0[4], double res[4], double* unconvergedSteps);
+int implicitHaloWidth(const ImplicitSolver* S, int kind);   // doubles per cell of message kind 1 (grad U), 2 (U), 3 (search direction)
+void launchImplicitHalo(hipStream_t s, const MeshView& m, const CaseView& c, const ImplView& iv, ImplicitSolver* S, int kind, const int32_t* cells,
+                        int nCells, double* buf, bool pack);
+void implicitSolverSetStream(ImplicitSolver* S, hipStream_t s);
+void launchImplicitPart(hipStream_t s, const MeshView& m, const CaseView& c, const ImplView& iv, const GasModel& g, const PatchBCDev* bc,
+                        ImplicitSolver* S, double tol, int maxIter, int part);
 
 // ---- QHDFoam case resident on the device (qgd_qhd.hip) ---------------------------------------------------------------
 struct QhdView {

@@ -10,6 +10,11 @@
 // gaussGrad::correctBoundaryConditions), fvm::laplacian (Gauss, uncorrected snGrad; patch coefficients of fixedValue,
 // zeroGradient and basicSymmetry patches), segregated component solves.  Not a benchmark path: generic one-thread-per-item
 // kernels, the two linear solves by the reproducible Jacobi-PCG of qgd_poisson.hip.
+#include <algorithm>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
 #include "../../include/qgd_amd.h"
 #include "qgd_device.hpp"
 #include "qgd_stencil_dev.hpp"
@@ -60,6 +65,7 @@ __device__ __forceinline__ void muDev2T(const double* g, const double mu, double
 __global__ __launch_bounds__(QGD_BLOCK) void implCellGradKernel(const MeshView m, const CaseView c, const ImplView iv) {
     const int ci = blockIdx.x * QGD_BLOCK + threadIdx.x;
     if (ci >= m.nC) return;
+    if (m.ghost && m.ghost[ci] == 1) return;   // a ghost cell lacks faces here: its gradient arrives by message
     const int n = m.cfCount[ci];
     const size_t base = (size_t)m.cfSlice[ci >> 6] * 64 + (ci & 63);
     double G[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -143,6 +149,7 @@ __global__ __launch_bounds__(QGD_BLOCK) void implFaceKernel(const MeshView m, co
 __global__ __launch_bounds__(QGD_BLOCK) void implCellUKernel(const MeshView m, const CaseView c, const ImplView iv, const PatchBCDev* __restrict__ bcs) {
     const int ci = blockIdx.x * QGD_BLOCK + threadIdx.x;
     if (ci >= m.nC) return;
+    if (m.ghost && m.ghost[ci] == 1) return;   // ghost rows belong to another shard
     const int n = m.cfCount[ci];
     const size_t base = (size_t)m.cfSlice[ci >> 6] * 64 + (ci & 63);
     const size_t nF = (size_t)m.nF, nC = (size_t)m.nC;
@@ -194,6 +201,7 @@ __global__ __launch_bounds__(QGD_BLOCK) void implCellUKernel(const MeshView m, c
 __global__ __launch_bounds__(QGD_BLOCK) void implStoreUKernel(const MeshView m, const CaseView c, const ImplView iv) {
     const int ci = blockIdx.x * QGD_BLOCK + threadIdx.x;
     if (ci >= m.nC) return;
+    if (m.ghost && m.ghost[ci] == 1) return;
     const size_t nC = (size_t)m.nC;
     RecA a = c.A[ci];
     a.rho = iv.rhoNew[ci];
@@ -258,6 +266,7 @@ __global__ __launch_bounds__(QGD_BLOCK) void implCellEKernel(const MeshView m, c
                                                             const PatchBCDev* __restrict__ bcs) {
     const int ci = blockIdx.x * QGD_BLOCK + threadIdx.x;
     if (ci >= m.nC) return;
+    if (m.ghost && m.ghost[ci] == 1) return;
     const int n = m.cfCount[ci];
     const size_t base = (size_t)m.cfSlice[ci >> 6] * 64 + (ci & 63);
     const size_t nF = (size_t)m.nF;
@@ -290,7 +299,7 @@ __global__ __launch_bounds__(QGD_BLOCK) void implCellEKernel(const MeshView m, c
 __global__ __launch_bounds__(QGD_BLOCK) void implFinishKernel(const MeshView m, const CaseView c, const ImplView iv, const GasModel gm) {
     const int ci = blockIdx.x * QGD_BLOCK + threadIdx.x;
     double rmin = 1e300, emin = 1e300;
-    if (ci < m.nC) {
+    if (ci < m.nC && !(m.ghost && m.ghost[ci] == 1)) {
         RecA A = c.A[ci];
         const double pOld = A.p;
         A.e = iv.xE[ci];
@@ -315,34 +324,444 @@ __global__ __launch_bounds__(QGD_BLOCK) void implFinishKernel(const MeshView m, 
 
 inline int gridOf(int64_t n) { return (int)((n + QGD_BLOCK - 1) / QGD_BLOCK); }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The linear solves of the branch: Jacobi-preconditioned conjugate gradients on  y_c = diag_c x_c - sum_{internal faces of c} a_f x_nb
+// (fvm::ddt(rho, .) - fvm::laplacian(gamma_f, .) of QGDUEqn.H L56-68 / QGDEEqn.H L55-61) for up to three right-hand sides AT ONCE
+// -- the velocity components share the face coefficients, so one walk over the matrix serves all three --, with OpenFOAM's
+// normalised residual per component, reproducible two-level sums, and every scalar of the loop in a control block ON THE
+// DEVICE (slot-major: ctl[slot * 4 + component], slots as in qgd_poisson.hip), so that no host synchronisation sits inside a
+// solve and a sharded caller reduces / exchanges between the phases exactly like for the QHD pressure equation:
+//   phase 0  q = A x, r = b - q, A1 = A 1           -> {sum|r|, sum x, rows} per component  (slots 0..2)
+//   phase 1  normFactor pieces with the global xbar  -> slot 3
+//   phase 2  first residual, done?; d = r/diag; r.z  -> slot 4; then the ghost entries of d
+//   phase 3  q = A d, d.q                            -> slot 5
+//   phase 4  alpha (or breakdown), x += alpha d, r -= alpha q, {sum|r|, r.z}  -> slots 6, 7
+//   phase 5  residual, iteration count, done?, beta, d = r/diag + beta d; then the ghost entries of d
+// Rows are the owned cells [ob, oe) of a shard; ghost cells appear only as columns.
+// ---------------------------------------------------------------------------------------------------------------------
+enum ICtl : int { I_ABSR = 0, I_SUMX = 1, I_N = 2, I_NORM = 3, I_RZ = 4, I_DQ = 5, I_ABSR2 = 6, I_RZNEW = 7, I_RES = 9, I_RES0 = 10, I_DONE = 11,
+                  I_ITER = 12, I_ALPHA = 13, I_BETA = 14, I_NORMF = 15, I_SLOTS = 16, I_ALLDONE = 64, I_COUNT = 68 };
+#define ICTL(slot, k) ((slot) * 4 + (k))
+
+__device__ __forceinline__ double iBlockSum(double v) {
+    __shared__ double s[QGD_BLOCK / 64];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < QGD_BLOCK / 64; ++i) t += s[i];
+    }
+    __syncthreads();
+    return t;
+}
+
+struct ISolveView {
+    int NR, ob, n, nC;                 // right-hand sides, first row, rows, vector stride
+    const double* a;                   // nF
+    const double* diag; const double* rhs; double* x;    // NR * nC each, component-major
+    double *r, *d, *q;                 // NR * nC each
+    double* part;                      // partial sums: (row * NR + k) * nBlocks + block
+    double* ctl;
+    int nBlocks;
+};
+
+// MODE 0: q = A x, r = b - q, d <- A 1 (kept until phase 1), partial {|r|, x};  MODE 1: q = A d, partial {d.q}
+template <int NR, int MODE>
+__global__ __launch_bounds__(QGD_BLOCK) void iApplyKernel(const MeshView m, const ISolveView v) {
+    if (v.ctl[I_ALLDONE] != 0.0 && MODE == 1) return;
+    const int i = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    double s0[NR], s1[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) s0[k] = s1[k] = 0.0;
+    if (i < v.n) {
+        const int c = v.ob + i;
+        const int cnt = m.cfCount[c];
+        const size_t base = (size_t)m.cfSlice[c >> 6] * 64 + (c & 63);
+        const double* __restrict__ src = MODE == 0 ? v.x : v.d;
+        double acc[NR], rowsum = 0.0;
+#pragma unroll
+        for (int k = 0; k < NR; ++k) acc[k] = 0.0;
+        for (int e = 0; e < cnt; ++e) {
+            const int nb = m.cfNbr[base + (size_t)e * 64];
+            if (nb < 0) continue;
+            const int it = m.cfItem[base + (size_t)e * 64];
+            const double af = v.a[it >= 0 ? it : ~it];
+            rowsum += af;
+#pragma unroll
+            for (int k = 0; k < NR; ++k) acc[k] += af * src[(size_t)k * v.nC + nb];
+        }
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const size_t j = (size_t)k * v.nC + c;
+            if (MODE == 1 && v.ctl[ICTL(I_DONE, k)] != 0.0) continue;
+            const double dg = v.diag[j], xv = src[j];
+            const double y = dg * xv - acc[k];
+            v.q[j] = y;
+            if (MODE == 0) {
+                const double rc = v.rhs[j] - y;
+                v.r[j] = rc;
+                v.d[j] = dg - rowsum;          // (A 1)_c
+                s0[k] = fabs(rc); s1[k] = xv;
+            } else s0[k] = xv * y;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const double t0 = iBlockSum(s0[k]);
+        if (threadIdx.x == 0) v.part[(size_t)(0 * NR + k) * v.nBlocks + blockIdx.x] = t0;
+        if (MODE == 0) {
+            const double t1 = iBlockSum(s1[k]);
+            if (threadIdx.x == 0) v.part[(size_t)(1 * NR + k) * v.nBlocks + blockIdx.x] = t1;
+        }
+    }
+}
+// phase 1: sum(|A x - xbar A 1| + |b - xbar A 1|)
+template <int NR>
+__global__ __launch_bounds__(QGD_BLOCK) void iNormKernel(const ISolveView v) {
+    const int i = blockIdx.x * QGD_BLOCK + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        double t = 0.0;
+        if (i < v.n) {
+            const size_t j = (size_t)k * v.nC + v.ob + i;
+            const double ref = (v.ctl[ICTL(I_SUMX, k)] / v.ctl[ICTL(I_N, k)]) * v.d[j];
+            t = fabs(v.q[j] - ref) + fabs(v.rhs[j] - ref);
+        }
+        t = iBlockSum(t);
+        if (threadIdx.x == 0) v.part[(size_t)k * v.nBlocks + blockIdx.x] = t;
+    }
+}
+// phase 2 (FIRST = 1): d = r/diag, partial r.z;  phase 5 (FIRST = 0): d = r/diag + beta d
+template <int NR, int FIRST>
+__global__ __launch_bounds__(QGD_BLOCK) void iDirectionKernel(const ISolveView v) {
+    if (v.ctl[I_ALLDONE] != 0.0) return;
+    const int i = blockIdx.x * QGD_BLOCK + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        double t = 0.0;
+        const bool on = v.ctl[ICTL(I_DONE, k)] == 0.0;
+        if (i < v.n && on) {
+            const size_t j = (size_t)k * v.nC + v.ob + i;
+            const double rc = v.r[j], z = rc / v.diag[j];
+            v.d[j] = FIRST ? z : z + v.ctl[ICTL(I_BETA, k)] * v.d[j];
+            t = rc * z;
+        }
+        if (FIRST) {
+            t = iBlockSum(t);
+            if (threadIdx.x == 0) v.part[(size_t)k * v.nBlocks + blockIdx.x] = t;
+        }
+    }
+}
+// phase 4: x += alpha d, r -= alpha q; partial {|r|, r.z}
+template <int NR>
+__global__ __launch_bounds__(QGD_BLOCK) void iUpdateKernel(const ISolveView v) {
+    if (v.ctl[I_ALLDONE] != 0.0) return;
+    const int i = blockIdx.x * QGD_BLOCK + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        double t0 = 0.0, t1 = 0.0;
+        const bool on = v.ctl[ICTL(I_DONE, k)] == 0.0;
+        if (i < v.n && on) {
+            const size_t j = (size_t)k * v.nC + v.ob + i;
+            const double alpha = v.ctl[ICTL(I_ALPHA, k)];
+            v.x[j] += alpha * v.d[j];
+            const double rc = v.r[j] - alpha * v.q[j];
+            v.r[j] = rc;
+            t0 = fabs(rc); t1 = rc * (rc / v.diag[j]);
+        }
+        t0 = iBlockSum(t0); t1 = iBlockSum(t1);
+        if (threadIdx.x == 0) { v.part[(size_t)(0 * NR + k) * v.nBlocks + blockIdx.x] = t0; v.part[(size_t)(1 * NR + k) * v.nBlocks + blockIdx.x] = t1; }
+    }
+}
+// folds `rows` x NR rows of partials into ctl[(firstSlot + row) * 4 + k]; components that are done keep their values
+__global__ __launch_bounds__(QGD_BLOCK) void iFoldKernel(const ISolveView v, const int NR, const int rows, const int firstSlot, const int always) {
+    if (!always && v.ctl[I_ALLDONE] != 0.0) return;
+    for (int row = 0; row < rows; ++row)
+        for (int k = 0; k < NR; ++k) {
+            if (!always && v.ctl[ICTL(I_DONE, k)] != 0.0) continue;   // uniform over the workgroup
+            const double* __restrict__ p = v.part + (size_t)(row * NR + k) * v.nBlocks;
+            double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+            int i = threadIdx.x;
+            for (; i + 3 * QGD_BLOCK < v.nBlocks; i += 4 * QGD_BLOCK) { v0 += p[i]; v1 += p[i + QGD_BLOCK]; v2 += p[i + 2 * QGD_BLOCK]; v3 += p[i + 3 * QGD_BLOCK]; }
+            for (; i < v.nBlocks; i += QGD_BLOCK) v0 += p[i];
+            const double t = iBlockSum((v0 + v1) + (v2 + v3));
+            if (threadIdx.x == 0) v.ctl[ICTL(firstSlot + row, k)] = t;
+        }
+}
+// bookkeeping, one thread per component.  stage 0: start (valid mask: components along empty directions are "done" from the start);
+// 1: first residual; 2: alpha or breakdown; 3: residual, iteration count, done?, beta.  The last thread-independent step: all done?
+__global__ void iCtlKernel(double* __restrict__ ctl, const int NR, const int stage, const double nRows, const int validMask, const double tol,
+                           const int maxIter) {
+    const int k = threadIdx.x;
+    if (k < NR) {
+        if (stage == 0) {
+            for (int s = 0; s < I_SLOTS; ++s) ctl[ICTL(s, k)] = 0.0;
+            ctl[ICTL(I_N, k)] = nRows;
+            ctl[ICTL(I_DONE, k)] = (validMask >> k) & 1 ? 0.0 : 3.0;   // 3: not solved
+        } else if (ctl[ICTL(I_DONE, k)] == 0.0) {
+            if (stage == 1) {
+                const double nf = ctl[ICTL(I_NORM, k)] + 1e-20, res = ctl[ICTL(I_ABSR, k)] / nf;
+                ctl[ICTL(I_NORMF, k)] = nf; ctl[ICTL(I_RES, k)] = res; ctl[ICTL(I_RES0, k)] = res;
+                if (res < tol || maxIter <= 0) ctl[ICTL(I_DONE, k)] = 1.0;
+            } else if (stage == 2) {
+                const double dq = ctl[ICTL(I_DQ, k)], rz = ctl[ICTL(I_RZ, k)];
+                if (!(dq > 0) || !(rz > 0)) ctl[ICTL(I_DONE, k)] = 2.0;
+                else ctl[ICTL(I_ALPHA, k)] = rz / dq;
+            } else {
+                const double res = ctl[ICTL(I_ABSR2, k)] / ctl[ICTL(I_NORMF, k)], it = ctl[ICTL(I_ITER, k)] + 1.0;
+                ctl[ICTL(I_RES, k)] = res; ctl[ICTL(I_ITER, k)] = it;
+                if (res < tol || it >= (double)maxIter) ctl[ICTL(I_DONE, k)] = 1.0;
+                else { ctl[ICTL(I_BETA, k)] = ctl[ICTL(I_RZNEW, k)] / ctl[ICTL(I_RZ, k)]; ctl[ICTL(I_RZ, k)] = ctl[ICTL(I_RZNEW, k)]; }
+            }
+        }
+    }
+    __syncthreads();
+    if (k == 0) {
+        bool all = true;
+        for (int j = 0; j < NR; ++j) all = all && ctl[ICTL(I_DONE, j)] != 0.0;
+        ctl[I_ALLDONE] = all ? 1.0 : 0.0;
+    }
+}
+
+// halo messages of the branch on a shard.  kind 1: fvc::grad(U) (9 per cell); kind 2: the velocity after its solve (3 per cell);
+// kind 3: the search direction of the solve in flight (its right-hand sides per cell, component-major on the device)
+__global__ __launch_bounds__(QGD_BLOCK) void implHaloKernel(const CaseView c, const ImplView iv, double* __restrict__ dirn, const int nC, const int kind,
+                                                           const int NR, const int32_t* __restrict__ cells, const int nCells,
+                                                           double* __restrict__ buf, const int pack) {
+    const int i = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    if (i >= nCells) return;
+    const size_t ci = (size_t)cells[i];
+    if (kind == 1) {
+        double* b = buf + (size_t)i * 9;
+        for (int k = 0; k < 9; ++k) { if (pack) b[k] = iv.gUc[ci * 9 + k]; else iv.gUc[ci * 9 + k] = b[k]; }
+    } else if (kind == 2) {
+        double* b = buf + (size_t)i * 3;
+        if (pack) { const RecA a = c.A[ci]; b[0] = a.ux; b[1] = a.uy; b[2] = a.uz; }
+        else { RecA a = c.A[ci]; a.ux = b[0]; a.uy = b[1]; a.uz = b[2]; c.A[ci] = a; }
+    } else {
+        double* b = buf + (size_t)i * NR;
+        for (int k = 0; k < NR; ++k) { if (pack) b[k] = dirn[(size_t)k * nC + ci]; else dirn[(size_t)k * nC + ci] = b[k]; }
+    }
+}
+
+// statistics of a step without a host round trip: stats[0] = steps in which a solve stopped above its tolerance (iteration limit or
+// breakdown), stats[1] = the flag of the step in flight.  mode 0: start of a step; 1: after a solve; 2: end of a step
+__global__ void iStatKernel(const double* __restrict__ ctl, double* __restrict__ stats, const int NR, const int mode, const double tol) {
+    if (mode == 0) stats[1] = 0.0;
+    else if (mode == 1) {
+        for (int k = 0; k < NR; ++k) {
+            const double dn = ctl[ICTL(I_DONE, k)];
+            if (dn == 2.0 || (dn == 1.0 && !(ctl[ICTL(I_RES, k)] < tol))) stats[1] = 1.0;
+        }
+    } else stats[0] += stats[1];
+}
+
 }  // namespace
 
-// One implicit-diffusion advance after the flux assembly.  work: 6*nC + 3*ceil(nC/256) + 8 doubles.  iters[0..2] = U
-// components, iters[3] = e; resid[2k], resid[2k+1] = initial and final normalised residual of solve k.
-void launchImplicitAdvance(hipStream_t s, const MeshView& m, const CaseView& c, const ImplView& iv, const GasModel& g, const PatchBCDev* bc,
-                           double tol, int maxIter, double* work, int iters[4], double resid[8]) {
-    const int gc = gridOf(m.nC), gf = gridOf(m.nF), gb = gridOf(m.nBF);
-    const size_t nC = (size_t)m.nC;
-    double res[2];
-    implCellGradKernel<<<gc, QGD_BLOCK, 0, s>>>(m, c, iv);
-    implFaceKernel<<<gf, QGD_BLOCK, 0, s>>>(m, c, iv, g, bc);
-    implCellUKernel<<<gc, QGD_BLOCK, 0, s>>>(m, c, iv, bc);
-    for (int k = 0; k < 3; ++k) {
-        iters[k] = 0;
-        resid[2 * k] = resid[2 * k + 1] = 0.0;
-        const bool valid = !(m.nGeomD < 3 && m.emptyDir[k]);   // validComponents: empty directions are not solved (L0)
-        if (!valid) continue;
-        iters[k] = diagLaplacianPcg(s, m, iv.aU, iv.diagU + k * nC, iv.rhsU + k * nC, iv.xU + k * nC, work, tol, maxIter, res);
-        resid[2 * k] = res[0]; resid[2 * k + 1] = res[1];
+// ---- host side of the solves ---------------------------------------------------------------------------------------------
+struct ImplicitSolver {
+    MeshView m{};
+    hipStream_t stream = nullptr;
+    int ob = 0, oe = 0;
+    double *r = nullptr, *d = nullptr, *q = nullptr, *part = nullptr, *ctl = nullptr, *hostCtl = nullptr;
+    double* stats = nullptr;    // device: [0] unconverged steps, [1] flag of the step in flight, [2 .. 2 + 2*I_COUNT) control blocks of the last U and e solves
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    ISolveView v{};
+    int NR = 1, validMask = 1, maxIter = 0;
+    double tol = 0;
+};
+#define ICHECK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) throw std::runtime_error(std::string("HIP: ") + hipGetErrorString(e_)); \
+    } while (0)
+
+ImplicitSolver* implicitSolverCreate(hipStream_t stream, const MeshView& m, int ownedBegin, int ownedEnd) {
+    ImplicitSolver* S = new ImplicitSolver();
+    S->m = m; S->stream = stream; S->ob = ownedBegin; S->oe = ownedEnd < 0 ? m.nC : ownedEnd;
+    const size_t nC = (size_t)m.nC, nb = (size_t)gridOf(S->oe - S->ob);
+    try {
+        ICHECK(hipMalloc((void**)&S->r, sizeof(double) * 3 * nC)); ICHECK(hipMalloc((void**)&S->d, sizeof(double) * 3 * nC));
+        ICHECK(hipMalloc((void**)&S->q, sizeof(double) * 3 * nC)); ICHECK(hipMalloc((void**)&S->part, sizeof(double) * 6 * std::max<size_t>(nb, 1)));
+        ICHECK(hipMalloc((void**)&S->ctl, sizeof(double) * I_COUNT));
+        ICHECK(hipMalloc((void**)&S->stats, sizeof(double) * (2 + 2 * I_COUNT)));
+        ICHECK(hipMemset(S->stats, 0, sizeof(double) * (2 + 2 * I_COUNT)));
+        ICHECK(hipMemset(S->d, 0, sizeof(double) * 3 * nC));     // ghost entries of the direction are read before the first exchange fills them
+        ICHECK(hipMemset(S->ctl, 0, sizeof(double) * I_COUNT));
+        ICHECK(hipHostMalloc((void**)&S->hostCtl, sizeof(double) * I_COUNT * 5, hipHostMallocDefault));
+        for (hipEvent_t& e : S->ev) ICHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    } catch (...) { implicitSolverFree(S); throw; }
+    return S;
+}
+void implicitSolverFree(ImplicitSolver* S) {
+    if (!S) return;
+    (void)hipFree(S->r); (void)hipFree(S->d); (void)hipFree(S->q); (void)hipFree(S->part); (void)hipFree(S->ctl); (void)hipFree(S->stats);
+    if (S->hostCtl) (void)hipHostFree(S->hostCtl);
+    for (hipEvent_t e : S->ev) if (e) (void)hipEventDestroy(e);
+    delete S;
+}
+int64_t implicitSolverBytes(const ImplicitSolver* S) { return S ? (int64_t)sizeof(double) * (9 * (int64_t)S->m.nC + 6 * gridOf(S->oe - S->ob) + I_COUNT) : 0; }
+double* implicitSolverCtl(ImplicitSolver* S) { return S->ctl; }
+double* implicitSolverDirection(ImplicitSolver* S) { return S->d; }
+int implicitSolverRhs(const ImplicitSolver* S) { return S->NR; }
+
+template <int NR>
+static void iPhaseT(ImplicitSolver* S, int phase) {
+    const ISolveView& v = S->v;
+    hipStream_t s = S->stream;
+    const int nb = v.nBlocks;
+    switch (phase) {
+        case 0:
+            iCtlKernel<<<1, 4, 0, s>>>(v.ctl, NR, 0, (double)v.n, S->validMask, S->tol, S->maxIter);
+            iApplyKernel<NR, 0><<<nb, QGD_BLOCK, 0, s>>>(S->m, v);
+            iFoldKernel<<<1, QGD_BLOCK, 0, s>>>(v, NR, 2, I_ABSR, 1);
+            break;
+        case 1:
+            iNormKernel<NR><<<nb, QGD_BLOCK, 0, s>>>(v);
+            iFoldKernel<<<1, QGD_BLOCK, 0, s>>>(v, NR, 1, I_NORM, 1);
+            break;
+        case 2:
+            iCtlKernel<<<1, 4, 0, s>>>(v.ctl, NR, 1, 0.0, 0, S->tol, S->maxIter);
+            iDirectionKernel<NR, 1><<<nb, QGD_BLOCK, 0, s>>>(v);
+            iFoldKernel<<<1, QGD_BLOCK, 0, s>>>(v, NR, 1, I_RZ, 0);
+            break;
+        case 3:
+            iApplyKernel<NR, 1><<<nb, QGD_BLOCK, 0, s>>>(S->m, v);
+            iFoldKernel<<<1, QGD_BLOCK, 0, s>>>(v, NR, 1, I_DQ, 0);
+            break;
+        case 4:
+            iCtlKernel<<<1, 4, 0, s>>>(v.ctl, NR, 2, 0.0, 0, S->tol, S->maxIter);
+            iUpdateKernel<NR><<<nb, QGD_BLOCK, 0, s>>>(v);
+            iFoldKernel<<<1, QGD_BLOCK, 0, s>>>(v, NR, 2, I_ABSR2, 0);
+            break;
+        case 5:
+            iCtlKernel<<<1, 4, 0, s>>>(v.ctl, NR, 3, 0.0, 0, S->tol, S->maxIter);
+            iDirectionKernel<NR, 0><<<nb, QGD_BLOCK, 0, s>>>(v);
+            break;
+        default: throw std::invalid_argument("implicitSolvePhase: phase must be 0..5");
     }
-    implStoreUKernel<<<gc, QGD_BLOCK, 0, s>>>(m, c, iv);
-    if (m.nBF) implBcUKernel<<<gb, QGD_BLOCK, 0, s>>>(m, c, bc);
-    implCellGradKernel<<<gc, QGD_BLOCK, 0, s>>>(m, c, iv);
-    implSigmaKernel<<<gf, QGD_BLOCK, 0, s>>>(m, c, iv, bc);
-    implCellEKernel<<<gc, QGD_BLOCK, 0, s>>>(m, c, iv, g, bc);
-    iters[3] = diagLaplacianPcg(s, m, iv.aE, iv.diagE, iv.rhsE, iv.xE, work, tol, maxIter, res);
-    resid[6] = res[0]; resid[7] = res[1];
-    implFinishKernel<<<gc, QGD_BLOCK, 0, s>>>(m, c, iv, g);
+    ICHECK(hipGetLastError());
+}
+// a, diag, rhs, x: the system (diag, rhs, x component-major with stride nC, nRhs in {1, 3}); validMask: bit k = component k is solved
+void implicitSolveBegin(ImplicitSolver* S, int nRhs, int validMask, const double* a, const double* diag, const double* rhs, double* x, double tol,
+                        int maxIter) {
+    ISolveView& v = S->v;
+    v.NR = nRhs; v.ob = S->ob; v.n = S->oe - S->ob; v.nC = S->m.nC; v.a = a; v.diag = diag; v.rhs = rhs; v.x = x;
+    v.r = S->r; v.d = S->d; v.q = S->q; v.part = S->part; v.ctl = S->ctl; v.nBlocks = gridOf(v.n);
+    S->NR = nRhs; S->validMask = validMask; S->tol = tol; S->maxIter = maxIter;
+    implicitSolvePhase(S, 0);
+}
+void implicitSolvePhase(ImplicitSolver* S, int phase) {
+    if (S->NR == 3) iPhaseT<3>(S, phase); else iPhaseT<1>(S, phase);
+}
+// {all done, iterations[k], initial[k], final[k]} for k < 3; waits for the stream
+void implicitSolveStatus(ImplicitSolver* S, double* allDone, int iters[3], double res0[3], double res[3]) {
+    double* h = S->hostCtl + 4 * I_COUNT;
+    ICHECK(hipMemcpyAsync(h, S->ctl, sizeof(double) * I_COUNT, hipMemcpyDeviceToHost, S->stream));
+    ICHECK(hipStreamSynchronize(S->stream));
+    *allDone = h[I_ALLDONE];
+    for (int k = 0; k < 3; ++k) {
+        const bool on = k < S->NR && h[ICTL(I_DONE, k)] != 3.0;
+        iters[k] = on ? (int)h[ICTL(I_ITER, k)] : 0; res0[k] = on ? h[ICTL(I_RES0, k)] : 0.0; res[k] = on ? h[ICTL(I_RES, k)] : 0.0;
+    }
+}
+// the loop after implicitSolveBegin (see pressureSolveRun): at most two iterations queued ahead of the last "done" flag read back
+void implicitSolveRun(ImplicitSolver* S, const SolveHooks* hooks) {
+    double* ctl = S->ctl;
+    auto reduce = [&](int firstSlot, int slots) { if (hooks && hooks->allreduce) hooks->allreduce(ctl + 4 * firstSlot, 4 * slots); };
+    auto halo = [&]() { if (hooks && hooks->haloDirection) hooks->haloDirection(); };
+    reduce(I_ABSR, 3);
+    implicitSolvePhase(S, 1);
+    reduce(I_NORM, 1);
+    implicitSolvePhase(S, 2);
+    reduce(I_RZ, 1);
+    halo();
+    const int ahead = 2;
+    for (int it = 0; it < S->maxIter; ++it) {
+        if (it >= ahead) {
+            const int slot = (it - ahead) & 3;
+            ICHECK(hipEventSynchronize(S->ev[slot]));
+            if (S->hostCtl[slot * I_COUNT + I_ALLDONE] != 0.0) break;
+        }
+        implicitSolvePhase(S, 3);
+        reduce(I_DQ, 1);
+        implicitSolvePhase(S, 4);
+        reduce(I_ABSR2, 2);
+        implicitSolvePhase(S, 5);
+        halo();
+        const int slot = it & 3;
+        ICHECK(hipMemcpyAsync(S->hostCtl + slot * I_COUNT, ctl, sizeof(double) * I_COUNT, hipMemcpyDeviceToHost, S->stream));
+        ICHECK(hipEventRecord(S->ev[slot], S->stream));
+    }
+}
+
+// after a solve has finished: its control block is kept for qgd_case_implicit_info (which = 0: U, 1: e), the step's flag updated
+void implicitSolveEnd(ImplicitSolver* S, int which) {
+    iStatKernel<<<1, 1, 0, S->stream>>>(S->ctl, S->stats, S->NR, 1, S->tol);
+    ICHECK(hipMemcpyAsync(S->stats + 2 + (size_t)which * I_COUNT, S->ctl, sizeof(double) * I_COUNT, hipMemcpyDeviceToDevice, S->stream));
+}
+void implicitStepMark(ImplicitSolver* S, bool begin) { iStatKernel<<<1, 1, 0, S->stream>>>(S->ctl, S->stats, 0, begin ? 0 : 2, 0.0); }
+void implicitStatsReset(ImplicitSolver* S) { ICHECK(hipMemsetAsync(S->stats, 0, sizeof(double) * (2 + 2 * I_COUNT), S->stream)); }
+// waits for the stream: iterations / initial / final residual of Ux, Uy, Uz, e in the last step, steps with an unconverged solve
+void implicitSolverInfo(ImplicitSolver* S, int iters[4], double res0[4], double res[4], double* unconvergedSteps) {
+    std::vector<double> h(2 + 2 * I_COUNT);
+    ICHECK(hipMemcpyAsync(h.data(), S->stats, sizeof(double) * h.size(), hipMemcpyDeviceToHost, S->stream));
+    ICHECK(hipStreamSynchronize(S->stream));
+    *unconvergedSteps = h[0];
+    const double* u = h.data() + 2;
+    const double* e = u + I_COUNT;
+    for (int k = 0; k < 3; ++k) {
+        const bool on = u[ICTL(I_DONE, k)] != 3.0;
+        iters[k] = on ? (int)u[ICTL(I_ITER, k)] : 0; res0[k] = on ? u[ICTL(I_RES0, k)] : 0.0; res[k] = on ? u[ICTL(I_RES, k)] : 0.0;
+    }
+    iters[3] = (int)e[ICTL(I_ITER, 0)]; res0[3] = e[ICTL(I_RES0, 0)]; res[3] = e[ICTL(I_RES, 0)];
+}
+
+int implicitHaloWidth(const ImplicitSolver* S, int kind) { return kind == 1 ? 9 : (kind == 2 ? 3 : S->NR); }
+void launchImplicitHalo(hipStream_t s, const MeshView& m, const CaseView& c, const ImplView& iv, ImplicitSolver* S, int kind, const int32_t* cells,
+                        int nCells, double* buf, bool pack) {
+    if (nCells > 0) implHaloKernel<<<gridOf(nCells), QGD_BLOCK, 0, s>>>(c, iv, S->d, m.nC, kind, S->NR, cells, nCells, buf, pack ? 1 : 0);
+    ICHECK(hipGetLastError());
+}
+void implicitSolverSetStream(ImplicitSolver* S, hipStream_t s) { S->stream = s; }
+
+// ---- the advance as phases (stream-ordered; a sharded caller exchanges between them, see include/qgd_amd.h) ---------------
+//   A  fvc::grad(U) of the state before the step                                   -> ghost gradients
+//   B  tauMC / phiTauMC and the laplacian coefficients per face, rho, rhoU, U = rhoU/rho, the U systems; first phase of their solve
+//   C  U of the records, U's boundary conditions                                   -> ghost velocities
+//   D  fvc::grad(U) of the new velocity                                            -> ghost gradients
+//   E  phiSigmaDotU, the energy equation's explicit part, the e system; first phase of its solve
+//   F  rhoE = rho (e + |U|^2/2), thermo, p
+void launchImplicitPart(hipStream_t s, const MeshView& m, const CaseView& c, const ImplView& iv, const GasModel& g, const PatchBCDev* bc,
+                        ImplicitSolver* S, double tol, int maxIter, int part) {
+    const int gc = gridOf(m.nC), gf = gridOf(m.nF), gb = gridOf(m.nBF);
+    switch (part) {
+        case 0: implCellGradKernel<<<gc, QGD_BLOCK, 0, s>>>(m, c, iv); break;
+        case 1: {
+            implFaceKernel<<<gf, QGD_BLOCK, 0, s>>>(m, c, iv, g, bc);
+            implCellUKernel<<<gc, QGD_BLOCK, 0, s>>>(m, c, iv, bc);
+            int mask = 0;
+            for (int k = 0; k < 3; ++k) if (!(m.nGeomD < 3 && m.emptyDir[k])) mask |= 1 << k;   // validComponents (L0)
+            implicitSolveBegin(S, 3, mask, iv.aU, iv.diagU, iv.rhsU, iv.xU, tol, maxIter);
+            break;
+        }
+        case 2:
+            implStoreUKernel<<<gc, QGD_BLOCK, 0, s>>>(m, c, iv);
+            if (m.nBF) implBcUKernel<<<gb, QGD_BLOCK, 0, s>>>(m, c, bc);
+            break;
+        case 3: implCellGradKernel<<<gc, QGD_BLOCK, 0, s>>>(m, c, iv); break;
+        case 4:
+            implSigmaKernel<<<gf, QGD_BLOCK, 0, s>>>(m, c, iv, bc);
+            implCellEKernel<<<gc, QGD_BLOCK, 0, s>>>(m, c, iv, g, bc);
+            implicitSolveBegin(S, 1, 1, iv.aE, iv.diagE, iv.rhsE, iv.xE, tol, maxIter);
+            break;
+        case 5: implFinishKernel<<<gc, QGD_BLOCK, 0, s>>>(m, c, iv, g); break;
+        default: throw std::invalid_argument("launchImplicitPart: part must be 0..5");
+    }
+    ICHECK(hipGetLastError());
 }
 
 }  // namespace qgd

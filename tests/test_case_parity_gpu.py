@@ -164,17 +164,6 @@ def test_thermo_accessors():
     gc.close(); dev.close()
 
 
-def test_implicit_diffusion_refused_on_sharded_meshes():
-    """the implicit solves and fvc::grad(U) are not distributed: a sharded mesh refuses implicitDiffusion loudly"""
-    g = make_mesh("box654")
-    shard = g.shard(2, 0)
-    dev = q.Device(shard)
-    with pytest.raises(q.QgdError) as ei:
-        q.QGDFoamCase(dev, q.default_options(implicitDiffusion=1))
-    assert ei.value.code == q._lib.ERR_NOT_IMPLEMENTED
-    dev.close()
-
-
 @pytest.mark.parametrize("variant", ["hex", "jitter", "jitter+triangles"])
 @pytest.mark.parametrize("adjust", [0, 1])
 def test_bench_kernel_directly_against_the_oracle(variant, adjust):
