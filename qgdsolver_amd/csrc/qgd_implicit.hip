@@ -61,32 +61,42 @@ __device__ __forceinline__ void muDev2T(const double* g, const double mu, double
         }
 }
 
-// fvc::grad(U), Gauss linear: cell gather in ascending face order
+// fvc::grad(U), Gauss linear: cell gather in ascending face order.  The cell's own velocity once, per face the neighbour cell's
+// (cfNbr) or the patch value, the weight and Sf: a third of the bytes of walking owner and neighbour records face by face
+// (1.44 -> 0.5 ms at 8 M cells), same operations in the same order.
 __global__ __launch_bounds__(QGD_BLOCK) void implCellGradKernel(const MeshView m, const CaseView c, const ImplView iv) {
     const int ci = blockIdx.x * QGD_BLOCK + threadIdx.x;
     if (ci >= m.nC) return;
     if (m.ghost && m.ghost[ci] == 1) return;   // a ghost cell lacks faces here: its gradient arrives by message
     const int n = m.cfCount[ci];
     const size_t base = (size_t)m.cfSlice[ci >> 6] * 64 + (ci & 63);
+    const double* __restrict__ Ad = reinterpret_cast<const double*>(c.A);
+    const double* __restrict__ bAd = reinterpret_cast<const double*>(c.bA);
+    const double Uc[3] = {Ad[(size_t)ci * 6 + 1], Ad[(size_t)ci * 6 + 2], Ad[(size_t)ci * 6 + 3]};
     double G[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int i = 0; i < n; ++i) {
         const int it = m.cfItem[base + (size_t)i * 64];
+        const int nb = m.cfNbr[base + (size_t)i * 64];
         const int f = it >= 0 ? it : ~it;
         if (m.fkind[f] == 3) continue;
         double Uf[3];
-        if (f < m.nIF) {
-            const RecA a = c.A[m.own[f]], b = c.A[m.nei[f]];
+        if (nb >= 0) {
             const double w = m.w[f];
-            Uf[0] = lerpf(w, a.ux, b.ux); Uf[1] = lerpf(w, a.uy, b.uy); Uf[2] = lerpf(w, a.uz, b.uz);
+            const double Un[3] = {Ad[(size_t)nb * 6 + 1], Ad[(size_t)nb * 6 + 2], Ad[(size_t)nb * 6 + 3]};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) Uf[k] = it >= 0 ? lerpf(w, Uc[k], Un[k]) : lerpf(w, Un[k], Uc[k]);   // lerp(w, owner, neighbour)
         } else {
-            const RecA b = c.bA[f - m.nIF];
-            Uf[0] = b.ux; Uf[1] = b.uy; Uf[2] = b.uz;
+            const size_t b = (size_t)(f - m.nIF);
+            Uf[0] = bAd[b * 6 + 1]; Uf[1] = bAd[b * 6 + 2]; Uf[2] = bAd[b * 6 + 3];
         }
         const double S[3] = {m.Sx[f], m.Sy[f], m.Sz[f]};
+#pragma unroll
         for (int a = 0; a < 3; ++a)
+#pragma unroll
             for (int j = 0; j < 3; ++j) G[3 * a + j] = it >= 0 ? G[3 * a + j] + S[a] * Uf[j] : G[3 * a + j] - S[a] * Uf[j];
     }
     const double V = m.V[ci];
+#pragma unroll
     for (int k = 0; k < 9; ++k) iv.gUc[(size_t)ci * 9 + k] = G[k] / V;
 }
 
@@ -476,20 +486,19 @@ __global__ __launch_bounds__(QGD_BLOCK) void iUpdateKernel(const ISolveView v) {
         if (threadIdx.x == 0) { v.part[(size_t)(0 * NR + k) * v.nBlocks + blockIdx.x] = t0; v.part[(size_t)(1 * NR + k) * v.nBlocks + blockIdx.x] = t1; }
     }
 }
-// folds `rows` x NR rows of partials into ctl[(firstSlot + row) * 4 + k]; components that are done keep their values
+// folds rows x NR rows of partials into ctl[(firstSlot + row) * 4 + k], one workgroup per row; components that are done keep
+// their values
 __global__ __launch_bounds__(QGD_BLOCK) void iFoldKernel(const ISolveView v, const int NR, const int rows, const int firstSlot, const int always) {
     if (!always && v.ctl[I_ALLDONE] != 0.0) return;
-    for (int row = 0; row < rows; ++row)
-        for (int k = 0; k < NR; ++k) {
-            if (!always && v.ctl[ICTL(I_DONE, k)] != 0.0) continue;   // uniform over the workgroup
-            const double* __restrict__ p = v.part + (size_t)(row * NR + k) * v.nBlocks;
-            double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
-            int i = threadIdx.x;
-            for (; i + 3 * QGD_BLOCK < v.nBlocks; i += 4 * QGD_BLOCK) { v0 += p[i]; v1 += p[i + QGD_BLOCK]; v2 += p[i + 2 * QGD_BLOCK]; v3 += p[i + 3 * QGD_BLOCK]; }
-            for (; i < v.nBlocks; i += QGD_BLOCK) v0 += p[i];
-            const double t = iBlockSum((v0 + v1) + (v2 + v3));
-            if (threadIdx.x == 0) v.ctl[ICTL(firstSlot + row, k)] = t;
-        }
+    const int row = blockIdx.x / NR, k = blockIdx.x % NR;
+    if (!always && v.ctl[ICTL(I_DONE, k)] != 0.0) return;   // uniform over the workgroup
+    const double* __restrict__ p = v.part + (size_t)(row * NR + k) * v.nBlocks;
+    double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+    int i = threadIdx.x;
+    for (; i + 3 * QGD_BLOCK < v.nBlocks; i += 4 * QGD_BLOCK) { v0 += p[i]; v1 += p[i + QGD_BLOCK]; v2 += p[i + 2 * QGD_BLOCK]; v3 += p[i + 3 * QGD_BLOCK]; }
+    for (; i < v.nBlocks; i += QGD_BLOCK) v0 += p[i];
+    const double t = iBlockSum((v0 + v1) + (v2 + v3));
+    if (threadIdx.x == 0) v.ctl[ICTL(firstSlot + row, k)] = t;
 }
 // bookkeeping, one thread per component.  stage 0: start (valid mask: components along empty directions are "done" from the start);
 // 1: first residual; 2: alpha or breakdown; 3: residual, iteration count, done?, beta.  The last thread-independent step: all done?
@@ -617,25 +626,25 @@ static void iPhaseT(ImplicitSolver* S, int phase) {
         case 0:
             iCtlKernel<<<1, 4, 0, s>>>(v.ctl, NR, 0, (double)v.n, S->validMask, S->tol, S->maxIter);
             iApplyKernel<NR, 0><<<nb, QGD_BLOCK, 0, s>>>(S->m, v);
-            iFoldKernel<<<1, QGD_BLOCK, 0, s>>>(v, NR, 2, I_ABSR, 1);
+            iFoldKernel<<<2 * NR, QGD_BLOCK, 0, s>>>(v, NR, 2, I_ABSR, 1);
             break;
         case 1:
             iNormKernel<NR><<<nb, QGD_BLOCK, 0, s>>>(v);
-            iFoldKernel<<<1, QGD_BLOCK, 0, s>>>(v, NR, 1, I_NORM, 1);
+            iFoldKernel<<<1 * NR, QGD_BLOCK, 0, s>>>(v, NR, 1, I_NORM, 1);
             break;
         case 2:
             iCtlKernel<<<1, 4, 0, s>>>(v.ctl, NR, 1, 0.0, 0, S->tol, S->maxIter);
             iDirectionKernel<NR, 1><<<nb, QGD_BLOCK, 0, s>>>(v);
-            iFoldKernel<<<1, QGD_BLOCK, 0, s>>>(v, NR, 1, I_RZ, 0);
+            iFoldKernel<<<1 * NR, QGD_BLOCK, 0, s>>>(v, NR, 1, I_RZ, 0);
             break;
         case 3:
             iApplyKernel<NR, 1><<<nb, QGD_BLOCK, 0, s>>>(S->m, v);
-            iFoldKernel<<<1, QGD_BLOCK, 0, s>>>(v, NR, 1, I_DQ, 0);
+            iFoldKernel<<<1 * NR, QGD_BLOCK, 0, s>>>(v, NR, 1, I_DQ, 0);
             break;
         case 4:
             iCtlKernel<<<1, 4, 0, s>>>(v.ctl, NR, 2, 0.0, 0, S->tol, S->maxIter);
             iUpdateKernel<NR><<<nb, QGD_BLOCK, 0, s>>>(v);
-            iFoldKernel<<<1, QGD_BLOCK, 0, s>>>(v, NR, 2, I_ABSR2, 0);
+            iFoldKernel<<<2 * NR, QGD_BLOCK, 0, s>>>(v, NR, 2, I_ABSR2, 0);
             break;
         case 5:
             iCtlKernel<<<1, 4, 0, s>>>(v.ctl, NR, 3, 0.0, 0, S->tol, S->maxIter);

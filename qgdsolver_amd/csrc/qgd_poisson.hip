@@ -517,19 +517,18 @@ __global__ __launch_bounds__(PB) void directionCtlKernel(const int n, const int 
     const int c = blockIdx.x * PB + threadIdx.x;
     if (c < n) d[c] = first ? z[c] : z[c] + ctl[C_BETA] * d[c];
 }
-// folds `count` rows of partials into ctl[first ...] (one workgroup, ascending order, four chains per thread)
+// folds `count` rows of partials into ctl[first ...] (one workgroup per row, ascending order, four chains per thread)
 __global__ __launch_bounds__(PB) void foldCtlKernel(const double* __restrict__ part, const int nBlocks, const int count, double* __restrict__ ctl,
                                                      const int first, const int always) {
     if (!always && solveDone(ctl)) return;
-    for (int k = 0; k < count; ++k) {
-        const double* __restrict__ p = part + (size_t)k * nBlocks;
-        double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
-        int i = threadIdx.x;
-        for (; i + 3 * PB < nBlocks; i += 4 * PB) { v0 += p[i]; v1 += p[i + PB]; v2 += p[i + 2 * PB]; v3 += p[i + 3 * PB]; }
-        for (; i < nBlocks; i += PB) v0 += p[i];
-        const double t = blockSum((v0 + v1) + (v2 + v3));
-        if (threadIdx.x == 0) ctl[first + k] = t;
-    }
+    const int k = blockIdx.x;
+    const double* __restrict__ p = part + (size_t)k * nBlocks;
+    double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+    int i = threadIdx.x;
+    for (; i + 3 * PB < nBlocks; i += 4 * PB) { v0 += p[i]; v1 += p[i + PB]; v2 += p[i + 2 * PB]; v3 += p[i + 3 * PB]; }
+    for (; i < nBlocks; i += PB) v0 += p[i];
+    const double t = blockSum((v0 + v1) + (v2 + v3));
+    if (threadIdx.x == 0) ctl[first + k] = t;
 }
 // the loop's own bookkeeping, one thread each (what the host did between synchronisations before):
 // stage 0: start of a solve (local row count);  1: after the global normFactor: first residual, done?;
@@ -889,7 +888,7 @@ void pressureSolveBegin(PressureSolver* S, const double* phiu, const double* phi
     assembleKernel<<<nb, PB, 0, stream>>>(m, v, phiu, phiwo, S->refCell, 0.0, p, ob, oe);
     applyKernel<<<nb, PB, 0, stream>>>(m, S->a, S->diag, p, S->q, nullptr, ob, oe);
     residual0Kernel<<<nb, PB, 0, stream>>>(n, S->rhs + ob, S->q + ob, p + ob, S->r + ob, S->part, nb);
-    foldCtlKernel<<<1, PB, 0, stream>>>(S->part, nb, 2, S->ctl, C_ABSR, 1);
+    foldCtlKernel<<<2, PB, 0, stream>>>(S->part, nb, 2, S->ctl, C_ABSR, 1);
     PCHECK(hipGetLastError());
 }
 void pressureSolvePhase(PressureSolver* S, int phase) {
@@ -921,7 +920,7 @@ void pressureSolvePhase(PressureSolver* S, int phase) {
             axpyKernel<<<nb, PB, 0, stream>>>(n, S->p + ob, S->r + ob, S->d + ob, S->q + ob, S->part, ctl);
             S->precondition();
             dotKernel<<<nb, PB, 0, stream>>>(n, S->r + ob, S->z + ob, S->part + nb, ctl);
-            foldCtlKernel<<<1, PB, 0, stream>>>(S->part, nb, 2, ctl, C_ABSR2, 0);
+            foldCtlKernel<<<2, PB, 0, stream>>>(S->part, nb, 2, ctl, C_ABSR2, 0);
             break;
         case 5:
             ctlKernel<<<1, 1, 0, stream>>>(ctl, 3, 0.0, S->tol, S->relTol, S->maxIter);
