@@ -493,17 +493,19 @@ int qgd_case_implicit_info(qgd_case_t c, double info[14]);
  * the reference reaches across ranks through processor patches inside fvm::laplacian, the linear solver and fvc::grad.  With one
  * rank per shard the advance (after phase 0, the flux assembly) is, through qgd_case_step_phase:
  *   phase 20  deltaT, fvc::grad(U) of the old state          -> exchange message kind 1
- *   phase 21  tauMC / phiTauMC, rho, rhoU, the U systems, first solver phase  -> SUM-reduce control[0..12)
- *   phase 22  normFactor                                      -> reduce control[12..16)
- *   phase 23  first residual, search direction, r.z           -> reduce control[16..20); exchange kind 3
+ *   phase 21  tauMC / phiTauMC, rho, rhoU, the three U systems and their start values -> exchange kind 4
+ *   phase 22  first solver phase (A x, r)                     -> SUM-reduce control[0..12)
+ *   phase 23  normFactor                                      -> reduce control[12..16)
+ *   phase 24  first residual, search direction, r.z           -> reduce control[16..20); exchange kind 3
  *   repeat until qgd_case_implicit_solve_status says done:
- *     phase 24 A d, d.Ad -> reduce control[20..24) | phase 25 x, r, |r|, r.z -> reduce control[24..32) | phase 26 new direction -> exchange kind 3
- *   phase 27  U into the records, its boundary conditions     -> exchange kind 2
- *   phase 28  fvc::grad(U) of the new velocity                -> exchange kind 1
- *   phase 29  phiSigmaDotU, the energy equation, the e system, first solver phase -> reduce control[0..12); then 22, 23, (24, 25, 26)*
+ *     phase 25 A d, d.Ad -> reduce control[20..24) | phase 26 x, r, |r|, r.z -> reduce control[24..32) | phase 27 new direction -> exchange kind 3
+ *   phase 28  U into the records, its boundary conditions     -> exchange kind 2
+ *   phase 29  fvc::grad(U) of the new velocity                -> exchange kind 1
+ *   phase 30  phiSigmaDotU, the energy equation, the e system and its start value -> exchange kind 4; then 22, 23, 24, (25, 26, 27)*
  *   phase 35  rhoE, thermo, p, boundary refresh               -> the state message (qgd_case_halo_pack / unpack), phase 2
  * control: 68 device doubles, slot-major, control[slot * 4 + component].  Message kinds: 1 = fvc::grad(U), 9 per cell; 2 = U, 3 per
- * cell; 3 = the search direction, one per right-hand side of the solve in flight per cell (counts report room for three).
+ * cell; 3 = the search direction, 4 = the start value of the solve in flight, one per right-hand side per cell (counts report room
+ * for three).
  * An unsharded case runs the same phases back to back inside qgd_case_step; qgd_case_step_sharded drives them over RCCL. */
 int qgd_case_implicit_halo_count(qgd_case_t c, int slot, int kind, int64_t* sendCount, int64_t* recvCount);
 int qgd_case_implicit_halo_pack(qgd_case_t c, int slot, int kind, double* sendBufDevice);

@@ -1689,6 +1689,281 @@ struct Case {
         if (m.sharded()) computeTauQGDf();
     }
 
+    // ---- the implicitDiffusion advance as phases (cell-range shards) ------------------------------------------------------------
+    // Same protocol, control-block layout (68 doubles, slot-major ictl[slot * 4 + component]) and message kinds (1 fvc::grad(U),
+    // 2 U, 3 search direction, 4 start values) as qgd_case_step_phase 20..35 of include/qgd_amd.h: the three velocity components advance in
+    // lockstep as three right-hand sides, every sum runs over the OWNED cells and is reduced by the caller, ghost cells appear as
+    // columns only.  The arithmetic is stepPhase1's (which stays the unsharded path).
+    VolField gUold_, gUnew_;
+    dvec rhoOld_, rhoUOld_, UOld_, rhoEOld_, eOld_, Ucur_, snU_;
+    struct ISys { int NR = 0; dvec a, diag[3], rhs[3], x[3], r[3], d[3], q[3], A1[3]; bool valid[3] = {false, false, false}; } isys;
+    double ictl[68] = {0};
+    std::vector<char> ghostCell;
+    bool ownedCell(int c) { if (ghostCell.empty() && m.sharded()) { ghostCell.assign(m.nC, 0); for (const ivec& gl : m.haloGhost) for (int g : gl) ghostCell[g] = 1; }
+                            return ghostCell.empty() || !ghostCell[c]; }
+    static int IC(int slot, int k) { return slot * 4 + k; }
+    void patchValuesOfGrad(VolField& g, const VolField& f) {   // gaussGrad::correctBoundaryConditions on the patch values (L0)
+        dvec sn = allPatchSnGrad(m, f);
+        for (size_t ip = 0; ip < m.patches.size(); ++ip) {
+            if (!m.patchHasFields((int)ip)) continue;
+            for (int gf = m.patches[ip].start; gf < m.patches[ip].start + m.patches[ip].size; ++gf) {
+                const int b = gf - m.nIF;
+                double* gb = &g.bf[9 * (size_t)b];
+                for (int k = 0; k < 9; ++k) gb[k] = g.in[9 * (size_t)m.own[gf] + k];
+                if (m.coupled((int)ip)) continue;
+                double n[3], ng[3];
+                for (int k = 0; k < 3; ++k) n[k] = m.Sf[3 * (size_t)gf + k] / m.magSf[gf];
+                VdotT(n, gb, ng);
+                for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) gb[3 * i + j] += n[i] * (sn[3 * (size_t)b + j] - ng[j]);
+            }
+        }
+    }
+    template <class IC_, class BS_>
+    void buildSystem(int k, const SurfField& gammaf, double rDeltaT, const dvec& rhsCell, IC_ icoef, BS_ bsrc) {
+        isys.a.assign((size_t)m.nF, 0.0);
+        for (int f = 0; f < m.nIF; ++f) isys.a[f] = gammaf.v[f] * m.magSf[f] * m.nonOrthDelta[f];
+        dvec& diag = isys.diag[k];
+        diag.assign((size_t)m.nC, 0.0);
+        isys.rhs[k] = rhsCell;
+        for (int ci = 0; ci < m.nC; ++ci) diag[ci] = rDeltaT * rho.in[ci] * m.V[ci];
+        for (int f = 0; f < m.nIF; ++f) { diag[m.own[f]] += isys.a[f]; diag[m.nei[f]] += isys.a[f]; }
+        for (size_t ip = 0; ip < bc.size(); ++ip) forPatchFaces((int)ip, [&](int gf, int b, int o) {
+            if (m.coupled((int)ip)) return;
+            const double gs = gammaf.v[gf] * m.magSf[gf];
+            diag[o] += gs * icoef((int)ip, gf, b, o);
+            isys.rhs[k][o] += gs * bsrc((int)ip, gf, b, o);
+        });
+    }
+    void applySys(int k, const dvec& v, dvec& y) const {
+        for (int c = 0; c < m.nC; ++c) y[c] = isys.diag[k][c] * v[c];
+        for (int f = 0; f < m.nIF; ++f) { y[m.own[f]] -= isys.a[f] * v[m.nei[f]]; y[m.nei[f]] -= isys.a[f] * v[m.own[f]]; }
+    }
+    void solverPhase(int ph) {
+        const int nC = m.nC, NR = isys.NR;
+        const double tol = opt.implicitTol;
+        const int maxIter = opt.implicitMaxIter;
+        for (int k = 0; k < NR; ++k) {
+            double* done = &ictl[IC(11, k)];
+            if (ph == 0) {
+                for (int s = 0; s < 16; ++s) ictl[IC(s, k)] = 0.0;
+                *done = isys.valid[k] ? 0.0 : 3.0;
+                if (!isys.valid[k]) continue;
+                for (dvec* v : {&isys.r[k], &isys.d[k], &isys.q[k], &isys.A1[k]}) v->assign((size_t)nC, 0.0);
+                dvec ones((size_t)nC, 1.0);
+                applySys(k, ones, isys.A1[k]);
+                applySys(k, isys.x[k], isys.q[k]);
+                for (int c = 0; c < nC; ++c) {
+                    isys.r[k][c] = isys.rhs[k][c] - isys.q[k][c];
+                    if (ownedCell(c)) { ictl[IC(0, k)] += std::fabs(isys.r[k][c]); ictl[IC(1, k)] += isys.x[k][c]; ictl[IC(2, k)] += 1.0; }
+                }
+                continue;
+            }
+            if (*done != 0.0) continue;
+            if (ph == 1) {
+                const double xbar = ictl[IC(1, k)] / ictl[IC(2, k)];
+                double t = 0;
+                for (int c = 0; c < nC; ++c) if (ownedCell(c)) t += std::fabs(isys.q[k][c] - xbar * isys.A1[k][c]) + std::fabs(isys.rhs[k][c] - xbar * isys.A1[k][c]);
+                ictl[IC(3, k)] = t;
+            } else if (ph == 2) {
+                const double nf = ictl[IC(3, k)] + 1e-20, res = ictl[IC(0, k)] / nf;
+                ictl[IC(15, k)] = nf; ictl[IC(9, k)] = res; ictl[IC(10, k)] = res;
+                if (res < tol || maxIter <= 0) { *done = 1.0; continue; }
+                double rz = 0;
+                for (int c = 0; c < nC; ++c) if (ownedCell(c)) { const double z = isys.r[k][c] / isys.diag[k][c]; isys.d[k][c] = z; rz += isys.r[k][c] * z; }
+                ictl[IC(4, k)] = rz;
+            } else if (ph == 3) {
+                applySys(k, isys.d[k], isys.q[k]);
+                double dq = 0;
+                for (int c = 0; c < nC; ++c) if (ownedCell(c)) dq += isys.d[k][c] * isys.q[k][c];
+                ictl[IC(5, k)] = dq;
+            } else if (ph == 4) {
+                const double dq = ictl[IC(5, k)], rz = ictl[IC(4, k)];
+                if (!(dq > 0) || !(rz > 0)) { *done = 2.0; continue; }
+                const double alpha = rz / dq;
+                ictl[IC(13, k)] = alpha;
+                double sa = 0, rzn = 0;
+                for (int c = 0; c < nC; ++c) if (ownedCell(c)) {
+                    isys.x[k][c] += alpha * isys.d[k][c];
+                    isys.r[k][c] -= alpha * isys.q[k][c];
+                    sa += std::fabs(isys.r[k][c]); rzn += isys.r[k][c] * (isys.r[k][c] / isys.diag[k][c]);
+                }
+                ictl[IC(6, k)] = sa; ictl[IC(7, k)] = rzn;
+            } else if (ph == 5) {
+                const double res = ictl[IC(6, k)] / ictl[IC(15, k)];
+                ictl[IC(9, k)] = res; ictl[IC(12, k)] += 1.0;
+                if (res < tol || ictl[IC(12, k)] >= (double)maxIter) { *done = 1.0; continue; }
+                const double beta = ictl[IC(7, k)] / ictl[IC(4, k)];
+                ictl[IC(14, k)] = beta; ictl[IC(4, k)] = ictl[IC(7, k)];
+                for (int c = 0; c < nC; ++c) if (ownedCell(c)) isys.d[k][c] = isys.r[k][c] / isys.diag[k][c] + beta * isys.d[k][c];
+            }
+        }
+        bool all = true;
+        for (int k = 0; k < NR; ++k) all = all && ictl[IC(11, k)] != 0.0;
+        ictl[64] = all ? 1.0 : 0.0;
+    }
+    void implicitPhase(int ph) {
+        const int nC = m.nC, nF = m.nF;
+        if (ph == 20) {
+            setDeltaT();
+            time += deltaT; stepCount++;
+            rhoOld_ = rho.in; rhoUOld_ = rhoU.in; UOld_ = U.in; rhoEOld_ = rhoE.in; eOld_ = e.in;
+            gUold_ = gaussGradVector(m, liveFace, U);
+            return;
+        }
+        const double rDeltaT = 1.0 / deltaT;
+        if (ph == 21) {
+            // tauMC / phiTauMC from the (now complete) gradient [updateFluxes.H:107-111]
+            patchValuesOfGrad(gUold_, U);
+            VolField prod(m, 9);
+            auto dev2T = [](const double* g, double muEff, double* out) {
+                const double tr = g[0] + g[4] + g[8];
+                for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+                    double a = g[3 * j + i];
+                    if (i == j) a = a - (2.0 / 3.0) * tr;
+                    out[3 * i + j] = muEff * a;
+                }
+            };
+            for (int ci = 0; ci < nC; ++ci) dev2T(&gUold_.in[9 * (size_t)ci], 0.0 + mu.in[ci], &prod.in[9 * (size_t)ci]);
+            for (int b = 0; b < m.nBF(); ++b) dev2T(&gUold_.bf[9 * (size_t)b], 0.0 + mu.bf[b], &prod.bf[9 * (size_t)b]);
+            tauMC = linearInterpolate(m, prod);
+            phiTauMC = SurfField(m, 3);
+            for (int f = 0; f < nF; ++f) if (liveFace[f]) VdotT(&m.Sf[3 * (size_t)f], &tauMC.v[9 * (size_t)f], &phiTauMC.v[3 * (size_t)f]);
+            // QGDRhoEqn.H, the explicit part of QGDUEqn.H [:36-51]
+            {
+                dvec d = fvcDiv(phiJm);
+                for (int ci = 0; ci < nC; ++ci) {
+                    const double diag = rDeltaT * m.V[ci];
+                    double src = rDeltaT * rhoOld_[ci] * m.V[ci];
+                    src -= m.V[ci] * d[ci];
+                    rho.in[ci] = src / diag;
+                }
+            }
+            dvec d1 = fvcDiv(phiJmU), d2 = fvcDiv(phiP), d3 = fvcDiv(phiPi);
+            for (int ci = 0; ci < nC; ++ci)
+                for (int k = 0; k < 3; ++k) {
+                    const double diag = rDeltaT * m.V[ci];
+                    double src = rDeltaT * rhoUOld_[3 * (size_t)ci + k] * m.V[ci];
+                    src -= m.V[ci] * d1[3 * (size_t)ci + k];
+                    src -= m.V[ci] * d2[3 * (size_t)ci + k];
+                    src += m.V[ci] * d3[3 * (size_t)ci + k];
+                    rhoU.in[3 * (size_t)ci + k] = src / diag;
+                }
+            for (int ci = 0; ci < nC; ++ci) for (int k = 0; k < 3; ++k) U.in[3 * (size_t)ci + k] = rhoU.in[3 * (size_t)ci + k] / rho.in[ci];
+            correctBC_U();
+            // the three systems of UEqn [:56-68]
+            dvec dT = fvcDiv(phiTauMC);
+            snU_ = allPatchSnGrad(m, U);
+            Ucur_ = U.in;
+            isys.NR = 3;
+            for (int k = 0; k < 3; ++k) {
+                isys.valid[k] = !(m.geomD[k] < 0);
+                dvec rhs((size_t)nC);
+                isys.x[k].assign((size_t)nC, 0.0);
+                for (int ci = 0; ci < nC; ++ci) {
+                    double src = rDeltaT * rhoOld_[ci] * UOld_[3 * (size_t)ci + k] * m.V[ci];
+                    src += m.V[ci] * (rDeltaT * (rho.in[ci] * Ucur_[3 * (size_t)ci + k] - rhoOld_[ci] * UOld_[3 * (size_t)ci + k]));
+                    src += m.V[ci] * dT[3 * (size_t)ci + k];
+                    rhs[ci] = src;
+                    isys.x[k][ci] = Ucur_[3 * (size_t)ci + k];
+                }
+                auto ic = [&](int ip, int gf, int, int) {
+                    if (bc[ip].bcU == BC_FIXEDVALUE) return m.delta[gf];
+                    if (bc[ip].bcU == BC_SLIP) return m.delta[gf] * std::fabs(m.Sf[3 * (size_t)gf + k] / m.magSf[gf]);
+                    return 0.0;
+                };
+                auto bs = [&](int ip, int gf, int b, int o) {
+                    if (bc[ip].bcU == BC_FIXEDVALUE) return m.delta[gf] * U.bf[3 * (size_t)b + k];
+                    if (bc[ip].bcU == BC_SLIP)
+                        return snU_[3 * (size_t)b + k] + m.delta[gf] * std::fabs(m.Sf[3 * (size_t)gf + k] / m.magSf[gf]) * Ucur_[3 * (size_t)o + k];
+                    return 0.0;
+                };
+                buildSystem(k, muf, rDeltaT, rhs, ic, bs);
+            }
+        } else if (ph >= 22 && ph <= 27) solverPhase(ph - 22);
+        else if (ph == 28) {
+            for (int k = 0; k < 3; ++k) {
+                lastIterU[k] = (int)ictl[IC(12, k)];
+                if (isys.valid[k]) for (int ci = 0; ci < nC; ++ci) if (ownedCell(ci)) U.in[3 * (size_t)ci + k] = isys.x[k][ci];
+            }
+            correctBC_U();
+        } else if (ph == 29) {
+            for (int ci = 0; ci < nC; ++ci) for (int k = 0; k < 3; ++k) rhoU.in[3 * (size_t)ci + k] = rho.in[ci] * U.in[3 * (size_t)ci + k];   // [:70]
+            gUnew_ = gaussGradVector(m, liveFace, U);
+        } else if (ph == 30) {
+            patchValuesOfGrad(gUnew_, U);
+            SurfField gUf = linearInterpolate(m, gUnew_);
+            phiSigmaDotU = SurfField(m, 1);
+            for (int f = 0; f < nF; ++f) {
+                if (!liveFace[f]) continue;
+                double A[9], sd[3];
+                for (int q = 0; q < 9; ++q) A[q] = muf.v[f] * gUf.v[9 * (size_t)f + q] + tauMC.v[9 * (size_t)f + q];
+                TdotV(A, &Uf.v[3 * (size_t)f], sd);
+                phiSigmaDotU.v[f] = dot3(&m.Sf[3 * (size_t)f], sd);
+            }
+            for (int b = 0; b < m.nBF(); ++b) for (int k = 0; k < 3; ++k) rhoU.bf[3 * (size_t)b + k] = rho.bf[b] * U.bf[3 * (size_t)b + k];
+            // QGDEEqn.H [:37-50]
+            dvec d1 = fvcDiv(phiJmH), d2 = fvcDiv(phiQ), d3 = fvcDiv(phiPiU), d4 = fvcDiv(phiSigmaDotU);
+            for (int ci = 0; ci < nC; ++ci) {
+                const double diag = rDeltaT * m.V[ci];
+                double src = rDeltaT * rhoEOld_[ci] * m.V[ci];
+                src -= m.V[ci] * d1[ci];
+                src -= m.V[ci] * d2[ci];
+                src += m.V[ci] * d3[ci];
+                src += m.V[ci] * d4[ci];
+                rhoE.in[ci] = src / diag;
+            }
+            for (int ci = 0; ci < nC; ++ci) {
+                const double* u = &U.in[3 * (size_t)ci];
+                e.in[ci] = rhoE.in[ci] / rho.in[ci] - 0.5 * (u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+            }
+            correctBC_e();
+            // the e system [:55-61]
+            dvec rhs((size_t)nC);
+            isys.NR = 1; isys.valid[0] = true;
+            isys.x[0] = e.in;
+            for (int ci = 0; ci < nC; ++ci) {
+                double src = rDeltaT * rhoOld_[ci] * eOld_[ci] * m.V[ci];
+                src += m.V[ci] * (rDeltaT * (rho.in[ci] * e.in[ci] - rhoOld_[ci] * eOld_[ci]));
+                rhs[ci] = src;
+            }
+            auto ic = [&](int ip, int gf, int, int) { return bc[ip].bcT == BC_FIXEDVALUE ? m.delta[gf] : 0.0; };
+            auto bs = [&](int ip, int gf, int b, int) { return bc[ip].bcT == BC_FIXEDVALUE ? m.delta[gf] * e.bf[b] : 0.0; };
+            buildSystem(0, alphauf, rDeltaT, rhs, ic, bs);
+        } else if (ph == 35) {
+            lastIterE = (int)ictl[IC(12, 0)];
+            for (int ci = 0; ci < nC; ++ci) if (ownedCell(ci)) e.in[ci] = isys.x[0][ci];
+            correctBC_e();
+            for (int ci = 0; ci < nC; ++ci) {
+                const double* u = &U.in[3 * (size_t)ci];
+                rhoE.in[ci] = rho.in[ci] * (e.in[ci] + 0.5 * (u[0] * u[0] + u[1] * u[1] + u[2] * u[2]));   // [:63]
+            }
+            correctBC_e();
+            for (int b = 0; b < m.nBF(); ++b) {
+                const double* u = &U.bf[3 * (size_t)b];
+                rhoE.bf[b] = rho.bf[b] * (e.bf[b] + 0.5 * (u[0] * u[0] + u[1] * u[1] + u[2] * u[2]));
+            }
+            thermoCalculate();
+            for (int ci = 0; ci < nC; ++ci) p.in[ci] = rho.in[ci] / psi.in[ci];
+            correctBC_p();
+            for (int b = 0; b < m.nBF(); ++b) rho.bf[b] = psi.bf[b] * p.bf[b];
+        }
+    }
+    int implHaloWidth(int kind) const { return kind == 1 ? 9 : (kind == 2 ? 3 : isys.NR); }
+    void implHaloMove(int side, int kind, double* buf, bool pack) {
+        if (side < 0 || (size_t)side >= m.haloGhost.size()) return;
+        const ivec& cells = pack ? m.haloSend[side] : m.haloGhost[side];
+        size_t q = 0;
+        auto io = [&](double& x) { if (pack) buf[q++] = x; else x = buf[q++]; };
+        VolField& g = gUnew_.in.size() && kind == 1 && phaseNew_ ? gUnew_ : gUold_;
+        for (int ci : cells) {
+            if (kind == 1) for (int k = 0; k < 9; ++k) io(g.in[9 * (size_t)ci + k]);
+            else if (kind == 2) for (int k = 0; k < 3; ++k) io(U.in[3 * (size_t)ci + k]);
+            else if (kind == 3) for (int k = 0; k < isys.NR; ++k) { if (isys.d[k].size() != (size_t)m.nC) isys.d[k].assign((size_t)m.nC, 0.0); io(isys.d[k][ci]); }
+            else for (int k = 0; k < isys.NR; ++k) io(isys.x[k][ci]);
+        }
+    }
+    bool phaseNew_ = false;   // which gradient message kind 1 carries: the old state's (after phase 20) or the new velocity's (after 28)
+
     static const int kCellMsg = 15, kFaceMsg = 16;
     void haloCount(int side, int64_t* n, bool recv) const {
         *n = 0;
@@ -2414,9 +2689,30 @@ int orc_case_step(void* cp, int32_t n) {
 }
 int orc_case_step_phase(void* cp, int phase) {
     Case* c = (Case*)cp;
+    if (phase >= 20) {
+        if (phase == 20) c->phaseNew_ = false;
+        c->implicitPhase(phase);
+        if (phase == 29) c->phaseNew_ = true;
+        return 0;
+    }
     if (phase == 0) c->stepPhase0(); else if (phase == 1) c->stepPhase1(); else c->stepPhase2();
     return 0;
 }
+int orc_case_implicit_control(void* cp, double* buf68, int set) {
+    Case* c = (Case*)cp;
+    for (int k = 0; k < 68; ++k) { if (set) c->ictl[k] = buf68[k]; else buf68[k] = c->ictl[k]; }
+    return 0;
+}
+int orc_case_implicit_halo_count(void* cp, int side, int kind, int64_t* send, int64_t* recv) {
+    Case* c = (Case*)cp;
+    *send = *recv = 0;
+    if (side < 0 || (size_t)side >= c->m.haloGhost.size()) return 0;
+    const int w = kind >= 3 ? 3 : c->implHaloWidth(kind);
+    *send = (int64_t)w * (int64_t)c->m.haloSend[side].size(); *recv = (int64_t)w * (int64_t)c->m.haloGhost[side].size();
+    return 0;
+}
+int orc_case_implicit_halo_pack(void* cp, int side, int kind, double* buf) { ((Case*)cp)->implHaloMove(side, kind, buf, true); return 0; }
+int orc_case_implicit_halo_unpack(void* cp, int side, int kind, const double* buf) { ((Case*)cp)->implHaloMove(side, kind, const_cast<double*>(buf), false); return 0; }
 // [0] = max Cof, [1] = -min tauQGDf of this shard: MAX-reduce over the ranks between phase 0 and phase 1
 int orc_case_reduction(void* cp, double* buf, int set) {
     Case* c = (Case*)cp;

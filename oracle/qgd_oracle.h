@@ -114,7 +114,11 @@ int orc_case_halo_count(void* c, int side, int64_t* count);
 int orc_case_halo_recv_count(void* c, int side, int64_t* count);
 int orc_case_halo_pack(void* c, int side, double* sendBuf);
 int orc_case_halo_unpack(void* c, int side, const double* recvBuf);
-int orc_case_step_phase(void* c, int phase);
+int orc_case_step_phase(void* c, int phase);   /* 0, 1, 2; implicitDiffusion on shards: 20..30, 35 as qgd_case_step_phase */
+int orc_case_implicit_control(void* c, double* buf68, int set);
+int orc_case_implicit_halo_count(void* c, int side, int kind, int64_t* send, int64_t* recv);
+int orc_case_implicit_halo_pack(void* c, int side, int kind, double* buf);
+int orc_case_implicit_halo_unpack(void* c, int side, int kind, const double* buf);
 /* STREAM triad on the calling core (host-bandwidth yardstick for bench.py's cpu_baseline) */
 void orc_stream_triad(double* a, const double* b, const double* c, double s, int64_t n, int32_t reps);
 int orc_case_reduction(void* c, double* buf2, int set);

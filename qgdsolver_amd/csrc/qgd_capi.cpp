@@ -239,6 +239,7 @@ struct qgd_case_s {
     double* dbgBuf = nullptr;
     ImplView impl{};            // implicitDiffusion branch: its face / cell work arrays
     ImplicitSolver* implSolver = nullptr;   // the two linear solves of the branch (device-scalar multi-right-hand-side PCG)
+    int implSolveIndex = 0;                 // 0: the U solve is the one in flight, 1: the e solve
     std::vector<double*> implSendBuf, implRecvBuf;   // native transport of the branch's own halo messages
     double* coef[4] = {nullptr, nullptr, nullptr, nullptr};  // device copies of non-uniform alphaQGD / ScQGD (cells, patch faces)
     double time = 0;
@@ -1343,16 +1344,16 @@ static void stepAssemble(qgd_case_s* c) {
     if (adjust) launchFaceReduce(launcherOf(c), c->view);
 }
 // ---- the implicitDiffusion branch [QGDUEqn.H L54-75, QGDEEqn.H L53-64] as stream-ordered phases ---------------------------------
-//   20  fvc::grad(U) of the old state                                       -> message kind 1
-//   21  tauMC / phiTauMC, rho, rhoU, the three U systems, first solver phase -> reduce control slots 0..2
-//   22, 23  solver phases 1, 2                                              -> reduce slot 3 | slot 4 + message kind 3
-//   24, 25, 26  one PCG iteration (solver phases 3, 4, 5)                    -> reduce slot 5 | slots 6..7 | message kind 3
-//   27  U into the records, its boundary conditions                         -> message kind 2
-//   28  fvc::grad(U) of the new velocity                                    -> message kind 1
-//   29  phiSigmaDotU, the energy equation's explicit part, the e system, first solver phase -> reduce slots 0..2
-//       then 22, 23, (24, 25, 26)* again for e
-//   35  rhoE, thermo, p, boundary refresh                                   -> the state message (qgd_case_halo_*)
-// (deltaT, time and step count are advanced by phase 20.)  No host synchronisation anywhere inside.
+//   20  deltaT, fvc::grad(U) of the old state                                -> message kind 1
+//   21  tauMC / phiTauMC, rho, rhoU, the three U systems and their start values -> message kind 4
+//   22  solver phase 0 (A x, r)                                              -> reduce control slots 0..2
+//   23, 24  solver phases 1, 2                                               -> reduce slot 3 | slot 4 + message kind 3
+//   25, 26, 27  one PCG iteration (solver phases 3, 4, 5)                     -> reduce slot 5 | slots 6..7 | message kind 3
+//   28  U into the records, its boundary conditions                          -> message kind 2
+//   29  fvc::grad(U) of the new velocity                                     -> message kind 1
+//   30  phiSigmaDotU, the energy equation's explicit part, the e system       -> message kind 4; then 22, 23, 24, (25, 26, 27)* for e
+//   35  rhoE, thermo, p, boundary refresh                                    -> the state message (qgd_case_halo_*)
+// No host synchronisation anywhere inside.
 static void implicitPhase(qgd_case_s* c, int phase) {
     const qgd_device_s* d = c->dev;
     const MeshView& m = d->view;
@@ -1372,21 +1373,21 @@ static void implicitPhase(qgd_case_s* c, int phase) {
             launchImplicitPart(st, m, c->view, c->impl, c->gas, c->bcDev, S, tol, maxIter, 0);
             break;
         }
-        case 21: launchImplicitPart(st, m, c->view, c->impl, c->gas, c->bcDev, S, tol, maxIter, 1); break;
-        case 22: case 23: case 24: case 25: case 26: implicitSolvePhase(S, phase - 21); break;
-        case 27:
+        case 21: c->implSolveIndex = 0; launchImplicitPart(st, m, c->view, c->impl, c->gas, c->bcDev, S, tol, maxIter, 1); break;
+        case 22: case 23: case 24: case 25: case 26: case 27: implicitSolvePhase(S, phase - 22); break;
+        case 28:
             implicitSolveEnd(S, 0);
             launchImplicitPart(st, m, c->view, c->impl, c->gas, c->bcDev, S, tol, maxIter, 2);
             break;
-        case 28: launchImplicitPart(st, m, c->view, c->impl, c->gas, c->bcDev, S, tol, maxIter, 3); break;
-        case 29: launchImplicitPart(st, m, c->view, c->impl, c->gas, c->bcDev, S, tol, maxIter, 4); break;
+        case 29: launchImplicitPart(st, m, c->view, c->impl, c->gas, c->bcDev, S, tol, maxIter, 3); break;
+        case 30: c->implSolveIndex = 1; launchImplicitPart(st, m, c->view, c->impl, c->gas, c->bcDev, S, tol, maxIter, 4); break;
         case 35:
             implicitSolveEnd(S, 1);
             launchImplicitPart(st, m, c->view, c->impl, c->gas, c->bcDev, S, tol, maxIter, 5);
             implicitStepMark(S, false);
             launchBoundaryUpdate(launcherOf(c), m, c->view, c->gas, c->bcDev, false, c->phiwRegistered, 0, nullptr, 0);
             break;
-        default: throw std::invalid_argument("implicit branch: phase must be 20..29 or 35");
+        default: throw std::invalid_argument("implicit branch: phase must be 20..30 or 35");
     }
     HIP_CHECK(hipGetLastError());
 }
@@ -1396,12 +1397,12 @@ static void implicitAdvanceWith(qgd_case_s* c, const SolveHooks* hooks, const st
     implicitPhase(c, 20);
     if (haloImpl) haloImpl(1);
     implicitPhase(c, 21);
-    implicitSolveRun(S, hooks);
-    implicitPhase(c, 27);
-    if (haloImpl) haloImpl(2);
+    implicitSolveRun(S, hooks);     // message kind 4, phase 0, ... through the hooks
     implicitPhase(c, 28);
-    if (haloImpl) haloImpl(1);
+    if (haloImpl) haloImpl(2);
     implicitPhase(c, 29);
+    if (haloImpl) haloImpl(1);
+    implicitPhase(c, 30);
     implicitSolveRun(S, hooks);
     implicitPhase(c, 35);
 }
@@ -1455,10 +1456,10 @@ int qgd_case_step_phase(qgd_case_t c, int phase) {
     HIP_CHECK(hipSetDevice(c->dev->deviceId));
     if (c->opt.implicitDiffusion && (phase == 10 || phase == 11))
         return fail(QGD_ERR_NOT_IMPLEMENTED, "qgd_case_step_phase: the implicitDiffusion branch has no boundary-layer-first order (its linear "
-                                            "solves span all cells); use phases 0 and 1, or 0 and 20..35 on a shard");
+                                            "solves span all cells); use phases 0 and 1, or 0 and 20..30, 35 on a shard");
     if (phase >= 20 && phase <= 35) {
         if (!c->opt.implicitDiffusion) return fail(QGD_ERR_INVALID, "qgd_case_step_phase: phases 20..35 belong to the implicitDiffusion branch");
-        if ((phase > 29 && phase < 35)) return fail(QGD_ERR_INVALID, "qgd_case_step_phase: phase must be 0, 1, 2, 10, 11, 20..29 or 35");
+        if ((phase > 30 && phase < 35)) return fail(QGD_ERR_INVALID, "qgd_case_step_phase: phase must be 0, 1, 2, 10, 11, 20..30 or 35");
         implicitPhase(c, phase);
         return QGD_OK;
     }
@@ -2148,6 +2149,7 @@ int qgd_case_step_sharded(qgd_case_t c, qgd_comm_t comm, const int32_t* peers, i
         if (comm->nRanks > 1)
             hooks.allreduce = [&](double* ptr, int n) { RCCL_CHECK(rcclRef().allReduce(ptr, ptr, (size_t)n, ncclFloat64, ncclSum, comm->comm, st)); };
         hooks.haloDirection = [&]() { implHaloExchangeOn(c, comm, peers, nSlots, 3); };
+        hooks.haloGuess = [&]() { implHaloExchangeOn(c, comm, peers, nSlots, 4); };
         implicitAdvanceWith(c, &hooks, [&](int kind) { implHaloExchangeOn(c, comm, peers, nSlots, kind); });
         haloExchangeOn(c, comm, peers, nSlots, st);
         HIP_CHECK(hipGetLastError());
@@ -2369,11 +2371,11 @@ int qgd_case_implicit_info(qgd_case_t c, double info[14]) {
 // the branch's own halo messages and control block on a shard (kinds 1 grad U, 2 U, 3 search direction; the state message is
 // qgd_case_halo_*): counts in doubles
 int qgd_case_implicit_halo_count(qgd_case_t c, int slot, int kind, int64_t* sendCount, int64_t* recvCount) {
-    if (!c || slot < 0 || kind < 1 || kind > 3 || !sendCount || !recvCount) return fail(QGD_ERR_INVALID, "bad argument");
+    if (!c || slot < 0 || kind < 1 || kind > 4 || !sendCount || !recvCount) return fail(QGD_ERR_INVALID, "bad argument");
     *sendCount = *recvCount = 0;
     if (!c->implSolver) return fail(QGD_ERR_INVALID, "qgd_case_implicit_halo_count: not an implicitDiffusion case");
     if (slot >= (int)c->dev->halo.size()) return QGD_OK;
-    const int w = kind == 3 ? 3 : implicitHaloWidth(c->implSolver, kind);   // kind 3: capacity for the widest solve
+    const int w = kind >= 3 ? 3 : implicitHaloWidth(c->implSolver, kind);   // kinds 3, 4: room for the widest solve
     *sendCount = (int64_t)w * c->dev->halo[slot].nSend;
     *recvCount = (int64_t)w * c->dev->halo[slot].nGhost;
     return QGD_OK;
@@ -2390,14 +2392,14 @@ static int implHaloMove(qgd_case_s* c, int slot, int kind, double* buf, bool pac
 }
 int qgd_case_implicit_halo_pack(qgd_case_t c, int slot, int kind, double* sendBufDevice) {
     QGD_TRY
-    if (!c || slot < 0 || kind < 1 || kind > 3 || !c->implSolver) return fail(QGD_ERR_INVALID, "bad argument");
+    if (!c || slot < 0 || kind < 1 || kind > 4 || !c->implSolver) return fail(QGD_ERR_INVALID, "bad argument");
     HIP_CHECK(hipSetDevice(c->dev->deviceId));
     return implHaloMove(c, slot, kind, sendBufDevice, true, c->stream());
     QGD_CATCH
 }
 int qgd_case_implicit_halo_unpack(qgd_case_t c, int slot, int kind, const double* recvBufDevice) {
     QGD_TRY
-    if (!c || slot < 0 || kind < 1 || kind > 3 || !c->implSolver) return fail(QGD_ERR_INVALID, "bad argument");
+    if (!c || slot < 0 || kind < 1 || kind > 4 || !c->implSolver) return fail(QGD_ERR_INVALID, "bad argument");
     HIP_CHECK(hipSetDevice(c->dev->deviceId));
     return implHaloMove(c, slot, kind, const_cast<double*>(recvBufDevice), false, c->stream());
     QGD_CATCH

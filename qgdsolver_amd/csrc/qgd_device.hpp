@@ -174,7 +174,7 @@ int64_t implicitSolverBytes(const ImplicitSolver* S);
 double* implicitSolverCtl(ImplicitSolver* S);          // 68 doubles, slot-major: ctl[slot * 4 + component]; reduced slots 0..2, 3, 4, 5, 6..7
 double* implicitSolverDirection(ImplicitSolver* S);    // 3 * nC doubles, component-major
 int implicitSolverRhs(const ImplicitSolver* S);        // right-hand sides of the solve in flight (3: U, 1: e)
-void implicitSolveBegin(ImplicitSolver* S, int nRhs, int validMask, const double* a, const double* diag, const double* rhs, double* x, double tol,
+void implicitSolveSetup(ImplicitSolver* S, int nRhs, int validMask, const double* a, const double* diag, const double* rhs, double* x, double tol,
                         int maxIter);
 void implicitSolvePhase(ImplicitSolver* S, int phase);
 void implicitSolveRun(ImplicitSolver* S, const SolveHooks* hooks);
@@ -183,7 +183,7 @@ void implicitSolveEnd(ImplicitSolver* S, int which);             // which = 0: t
 void implicitStepMark(ImplicitSolver* S, bool begin);
 void implicitStatsReset(ImplicitSolver* S);
 void implicitSolverInfo(ImplicitSolver* S, int iters[4], double res0[4], double res[4], double* unconvergedSteps);
-int implicitHaloWidth(const ImplicitSolver* S, int kind);   // doubles per cell of message kind 1 (grad U), 2 (U), 3 (search direction)
+int implicitHaloWidth(const ImplicitSolver* S, int kind);   // doubles per cell of message kind 1 (grad U), 2 (U), 3 (search direction), 4 (initial guess)
 void launchImplicitHalo(hipStream_t s, const MeshView& m, const CaseView& c, const ImplView& iv, ImplicitSolver* S, int kind, const int32_t* cells,
                         int nCells, double* buf, bool pack);
 void implicitSolverSetStream(ImplicitSolver* S, hipStream_t s);
@@ -231,6 +231,7 @@ int pressureSolve(PressureSolver* S, const double* phiu, const double* phiwo, co
 struct SolveHooks {
     std::function<void(double* devicePtr, int n)> allreduce;   // SUM over the ranks, in place, stream-ordered
     std::function<void()> haloDirection;                       // ghost entries of pressureSolverDirection()
+    std::function<void()> haloGuess;                           // implicit branch: ghost entries of the initial guess, before the first product
 };
 void pressureSolveBegin(PressureSolver* S, const double* phiu, const double* phiwo, const double* pb, const double* gb, double tolerance,
                         double relTol, int maxIter, double* p);

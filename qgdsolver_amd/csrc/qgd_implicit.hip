@@ -536,7 +536,8 @@ __global__ void iCtlKernel(double* __restrict__ ctl, const int NR, const int sta
 }
 
 // halo messages of the branch on a shard.  kind 1: fvc::grad(U) (9 per cell); kind 2: the velocity after its solve (3 per cell);
-// kind 3: the search direction of the solve in flight (its right-hand sides per cell, component-major on the device)
+// kind 3: the search direction of the solve in flight (its right-hand sides per cell, component-major on the device); kind 4: its
+// initial guess (same shape): the first matrix product needs the neighbours' start values in the ghost columns
 __global__ __launch_bounds__(QGD_BLOCK) void implHaloKernel(const CaseView c, const ImplView iv, double* __restrict__ dirn, const int nC, const int kind,
                                                            const int NR, const int32_t* __restrict__ cells, const int nCells,
                                                            double* __restrict__ buf, const int pack) {
@@ -655,13 +656,12 @@ static void iPhaseT(ImplicitSolver* S, int phase) {
     ICHECK(hipGetLastError());
 }
 // a, diag, rhs, x: the system (diag, rhs, x component-major with stride nC, nRhs in {1, 3}); validMask: bit k = component k is solved
-void implicitSolveBegin(ImplicitSolver* S, int nRhs, int validMask, const double* a, const double* diag, const double* rhs, double* x, double tol,
+void implicitSolveSetup(ImplicitSolver* S, int nRhs, int validMask, const double* a, const double* diag, const double* rhs, double* x, double tol,
                         int maxIter) {
     ISolveView& v = S->v;
     v.NR = nRhs; v.ob = S->ob; v.n = S->oe - S->ob; v.nC = S->m.nC; v.a = a; v.diag = diag; v.rhs = rhs; v.x = x;
     v.r = S->r; v.d = S->d; v.q = S->q; v.part = S->part; v.ctl = S->ctl; v.nBlocks = gridOf(v.n);
     S->NR = nRhs; S->validMask = validMask; S->tol = tol; S->maxIter = maxIter;
-    implicitSolvePhase(S, 0);
 }
 void implicitSolvePhase(ImplicitSolver* S, int phase) {
     if (S->NR == 3) iPhaseT<3>(S, phase); else iPhaseT<1>(S, phase);
@@ -677,11 +677,13 @@ void implicitSolveStatus(ImplicitSolver* S, double* allDone, int iters[3], doubl
         iters[k] = on ? (int)h[ICTL(I_ITER, k)] : 0; res0[k] = on ? h[ICTL(I_RES0, k)] : 0.0; res[k] = on ? h[ICTL(I_RES, k)] : 0.0;
     }
 }
-// the loop after implicitSolveBegin (see pressureSolveRun): at most two iterations queued ahead of the last "done" flag read back
+// the whole solve after implicitSolveSetup (see pressureSolveRun): at most two iterations queued ahead of the last "done" flag read back
 void implicitSolveRun(ImplicitSolver* S, const SolveHooks* hooks) {
     double* ctl = S->ctl;
     auto reduce = [&](int firstSlot, int slots) { if (hooks && hooks->allreduce) hooks->allreduce(ctl + 4 * firstSlot, 4 * slots); };
     auto halo = [&]() { if (hooks && hooks->haloDirection) hooks->haloDirection(); };
+    if (hooks && hooks->haloGuess) hooks->haloGuess();     // the neighbours' initial guesses into the ghost columns
+    implicitSolvePhase(S, 0);
     reduce(I_ABSR, 3);
     implicitSolvePhase(S, 1);
     reduce(I_NORM, 1);
@@ -729,20 +731,20 @@ void implicitSolverInfo(ImplicitSolver* S, int iters[4], double res0[4], double 
     iters[3] = (int)e[ICTL(I_ITER, 0)]; res0[3] = e[ICTL(I_RES0, 0)]; res[3] = e[ICTL(I_RES, 0)];
 }
 
-int implicitHaloWidth(const ImplicitSolver* S, int kind) { return kind == 1 ? 9 : (kind == 2 ? 3 : S->NR); }
+int implicitHaloWidth(const ImplicitSolver* S, int kind) { return kind == 1 ? 9 : (kind == 2 ? 3 : S->NR); }   // kinds 3, 4: one per right-hand side
 void launchImplicitHalo(hipStream_t s, const MeshView& m, const CaseView& c, const ImplView& iv, ImplicitSolver* S, int kind, const int32_t* cells,
                         int nCells, double* buf, bool pack) {
-    if (nCells > 0) implHaloKernel<<<gridOf(nCells), QGD_BLOCK, 0, s>>>(c, iv, S->d, m.nC, kind, S->NR, cells, nCells, buf, pack ? 1 : 0);
+    if (nCells > 0) implHaloKernel<<<gridOf(nCells), QGD_BLOCK, 0, s>>>(c, iv, kind == 4 ? S->v.x : S->d, m.nC, kind, S->NR, cells, nCells, buf, pack ? 1 : 0);
     ICHECK(hipGetLastError());
 }
 void implicitSolverSetStream(ImplicitSolver* S, hipStream_t s) { S->stream = s; }
 
 // ---- the advance as phases (stream-ordered; a sharded caller exchanges between them, see include/qgd_amd.h) ---------------
 //   A  fvc::grad(U) of the state before the step                                   -> ghost gradients
-//   B  tauMC / phiTauMC and the laplacian coefficients per face, rho, rhoU, U = rhoU/rho, the U systems; first phase of their solve
+//   B  tauMC / phiTauMC and the laplacian coefficients per face, rho, rhoU, U = rhoU/rho, the U systems (their solve follows)
 //   C  U of the records, U's boundary conditions                                   -> ghost velocities
 //   D  fvc::grad(U) of the new velocity                                            -> ghost gradients
-//   E  phiSigmaDotU, the energy equation's explicit part, the e system; first phase of its solve
+//   E  phiSigmaDotU, the energy equation's explicit part, the e system (its solve follows)
 //   F  rhoE = rho (e + |U|^2/2), thermo, p
 void launchImplicitPart(hipStream_t s, const MeshView& m, const CaseView& c, const ImplView& iv, const GasModel& g, const PatchBCDev* bc,
                         ImplicitSolver* S, double tol, int maxIter, int part) {
@@ -754,7 +756,7 @@ void launchImplicitPart(hipStream_t s, const MeshView& m, const CaseView& c, con
             implCellUKernel<<<gc, QGD_BLOCK, 0, s>>>(m, c, iv, bc);
             int mask = 0;
             for (int k = 0; k < 3; ++k) if (!(m.nGeomD < 3 && m.emptyDir[k])) mask |= 1 << k;   // validComponents (L0)
-            implicitSolveBegin(S, 3, mask, iv.aU, iv.diagU, iv.rhsU, iv.xU, tol, maxIter);
+            implicitSolveSetup(S, 3, mask, iv.aU, iv.diagU, iv.rhsU, iv.xU, tol, maxIter);
             break;
         }
         case 2:
@@ -765,7 +767,7 @@ void launchImplicitPart(hipStream_t s, const MeshView& m, const CaseView& c, con
         case 4:
             implSigmaKernel<<<gf, QGD_BLOCK, 0, s>>>(m, c, iv, bc);
             implCellEKernel<<<gc, QGD_BLOCK, 0, s>>>(m, c, iv, g, bc);
-            implicitSolveBegin(S, 1, 1, iv.aE, iv.diagE, iv.rhsE, iv.xE, tol, maxIter);
+            implicitSolveSetup(S, 1, 1, iv.aE, iv.diagE, iv.rhsE, iv.xE, tol, maxIter);
             break;
         case 5: implFinishKernel<<<gc, QGD_BLOCK, 0, s>>>(m, c, iv, g); break;
         default: throw std::invalid_argument("launchImplicitPart: part must be 0..5");

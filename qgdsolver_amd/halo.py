@@ -241,14 +241,14 @@ class LocalWorld:
     """All shards in this process (``cases[r]`` is the case of rank r, ``peers[r][slot]`` the rank behind each of its halo
     slots, < 0 for none): messages go pack -> buffer -> unpack, reductions through host copies of the control blocks."""
 
-    def __init__(self, cases, peers):
+    def __init__(self, cases, peers, kinds=(0, 1, 2)):
         self.cases, self.peers = list(cases), [list(p) for p in peers]
         self.buf = {}
         for r, case in enumerate(self.cases):
             for slot, peer in enumerate(self.peers[r]):
                 if peer < 0:
                     continue
-                n = max(case.halo_count(slot, kind)[0] for kind in (0, 1, 2))
+                n = max(case.halo_count(slot, kind)[0] for kind in kinds)
                 self.buf[(r, slot)] = case.halo_buffer(n)
 
     def phase(self, k):
@@ -286,12 +286,12 @@ class DistWorld:
     ``peers[slot]`` = rank behind each halo slot.  ``to_transport(buf, n)`` / ``from_transport(t, buf)`` turn the case's
     halo buffer (a device pointer, or a host array when the cases live on the CPU) into a torch tensor the backend can send and back."""
 
-    def __init__(self, case, dist, torch, peers, to_transport, from_transport):
+    def __init__(self, case, dist, torch, peers, to_transport, from_transport, kinds=(0, 1, 2)):
         self.case, self.dist, self.torch, self.peers = case, dist, torch, list(peers)
         self.to_transport, self.from_transport = to_transport, from_transport
         self.slots = [s for s, p in enumerate(self.peers) if p >= 0]
-        self.sbuf = {s: case.halo_buffer(max(case.halo_count(s, k)[0] for k in (0, 1, 2))) for s in self.slots}
-        self.rbuf = {s: case.halo_buffer(max(case.halo_count(s, k)[1] for k in (0, 1, 2))) for s in self.slots}
+        self.sbuf = {s: case.halo_buffer(max(case.halo_count(s, k)[0] for k in kinds)) for s in self.slots}
+        self.rbuf = {s: case.halo_buffer(max(case.halo_count(s, k)[1] for k in kinds)) for s in self.slots}
 
     def phase(self, k):
         self.case.step_phase(k)
@@ -328,3 +328,99 @@ class DistWorld:
 
     def done(self):
         return self.case.solve_status()["done"] != 0
+
+
+# ---- QGDFoam with implicitDiffusion true (the reference's default) on cell-range shards ---------------------------------------
+# control-block ranges (slot-major, 4 components per slot) that are global sums, by SOLVER phase 0..4
+IMPL_REDUCE_AFTER_SOLVER_PHASE = {0: (0, 12), 1: (12, 4), 2: (16, 4), 3: (20, 4), 4: (24, 8)}
+IMPL_STATE, IMPL_GRADU, IMPL_U, IMPL_DIRECTION, IMPL_GUESS = 0, 1, 2, 3, 4   # message kinds (0: the case's own state message)
+
+
+class ImplicitShard:
+    """A QGDFoam case (device or CPU) with implicitDiffusion true, seen through the names LocalWorld / DistWorld use: message
+    kind 0 is the case's state message (qgd_case_halo_*), kinds 1..4 the branch's own (qgd_case_implicit_halo_*); the control
+    block is the one of the linear solve in flight."""
+
+    def __init__(self, case):
+        self.case = case
+
+    def step_phase(self, k):
+        self.case.step_phase(k)
+
+    def control(self):
+        return self.case.implicit_control()
+
+    def set_control(self, a):
+        self.case.set_implicit_control(a)
+
+    def solve_status(self):
+        return dict(done=1 if self.case.implicit_solve_done() else 0)
+
+    def sync(self):
+        self.case.sync()
+
+    def halo_buffer(self, n):
+        return self.case.halo_buffer(n)
+
+    def halo_count(self, slot, kind):
+        if kind == IMPL_STATE:
+            return self.case.halo_count(slot), self.case.halo_recv_count(slot)
+        return self.case.implicit_halo_count(slot, kind)
+
+    def halo_pack(self, slot, kind, buf):
+        if kind == IMPL_STATE:
+            self.case.halo_pack(slot, buf)
+        else:
+            self.case.implicit_halo_pack(slot, kind, buf)
+
+    def halo_unpack(self, slot, kind, buf):
+        if kind == IMPL_STATE:
+            self.case.halo_unpack(slot, buf)
+        else:
+            self.case.implicit_halo_unpack(slot, kind, buf)
+
+
+class ImplicitStepper:
+    """One QGDFoam step with implicitDiffusion true on cell-range shards: phase 0 (flux assembly), then the advance as phases
+    20..35 with the reductions and messages include/qgd_amd.h lists.  ``world``: LocalWorld / DistWorld built over
+    ``ImplicitShard`` wrappers (their message kinds must cover 0..4: pass ``kinds=range(5)``)."""
+
+    def __init__(self, world):
+        self.world = world
+        self.started = False
+
+    def _solve(self):
+        w = self.world
+        w.exchange(IMPL_GUESS)
+        for sp in (0, 1, 2):
+            w.phase(22 + sp)
+            w.allreduce(*IMPL_REDUCE_AFTER_SOLVER_PHASE[sp])
+        w.exchange(IMPL_DIRECTION)
+        while not w.done():
+            for sp in (3, 4):
+                w.phase(22 + sp)
+                w.allreduce(*IMPL_REDUCE_AFTER_SOLVER_PHASE[sp])
+            w.phase(27)
+            w.exchange(IMPL_DIRECTION)
+
+    def step(self, n=1):
+        w = self.world
+        if not self.started:
+            w.exchange(IMPL_STATE)     # ghost cells start from their owners' records
+            w.phase(2)
+            self.started = True
+        for _ in range(n):
+            w.phase(0)
+            w.phase(20)
+            w.exchange(IMPL_GRADU)
+            w.phase(21)
+            self._solve()
+            w.phase(28)
+            w.exchange(IMPL_U)
+            w.phase(29)
+            w.exchange(IMPL_GRADU)
+            w.phase(30)
+            self._solve()
+            w.phase(35)
+            w.exchange(IMPL_STATE)
+            w.phase(2)

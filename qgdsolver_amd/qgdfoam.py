@@ -167,6 +167,43 @@ class QGDFoamCase:
         return dict(implicit=bool(a[13]), unconverged_steps=int(a[12]),
                     solves={n: dict(iterations=int(a[k]), initial=a[4 + k], final=a[8 + k]) for k, n in enumerate(names)})
 
+    # ---- the implicitDiffusion branch on shards (phases 20..35 of qgd_case_step_phase; halo.ImplicitStepper drives them) ----
+    def implicit_control(self):
+        """host copy of the 68-double control block of the solve in flight (slot-major: [slot * 4 + component])"""
+        a = np.zeros(68)
+        L.check(L.lib.qgd_case_implicit_control(self._h, a.ctypes.data_as(L.c_double_p), 0), "qgd_case_implicit_control")
+        return a
+
+    def set_implicit_control(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        assert a.size == 68
+        L.check(L.lib.qgd_case_implicit_control(self._h, a.ctypes.data_as(L.c_double_p), 1), "qgd_case_implicit_control")
+
+    def implicit_control_ptr(self):
+        p = C.c_void_p()
+        L.check(L.lib.qgd_case_implicit_control_ptr(self._h, C.byref(p)), "qgd_case_implicit_control_ptr")
+        return p.value
+
+    def implicit_solve_done(self):
+        a = (C.c_double * 2)()
+        L.check(L.lib.qgd_case_implicit_solve_status(self._h, a), "qgd_case_implicit_solve_status")
+        return a[0] != 0.0
+
+    def implicit_halo_count(self, slot, kind):
+        s, r = C.c_int64(), C.c_int64()
+        L.check(L.lib.qgd_case_implicit_halo_count(self._h, int(slot), int(kind), C.byref(s), C.byref(r)), "qgd_case_implicit_halo_count")
+        return s.value, r.value
+
+    def implicit_halo_pack(self, slot, kind, dev_ptr):
+        L.check(L.lib.qgd_case_implicit_halo_pack(self._h, int(slot), int(kind), C.c_void_p(dev_ptr)), "qgd_case_implicit_halo_pack")
+
+    def implicit_halo_unpack(self, slot, kind, dev_ptr):
+        L.check(L.lib.qgd_case_implicit_halo_unpack(self._h, int(slot), int(kind), C.c_void_p(dev_ptr)), "qgd_case_implicit_halo_unpack")
+
+    def halo_buffer(self, n):
+        """device buffer of n doubles (released with the device)"""
+        return self.dev.alloc(8 * max(int(n), 1))
+
     # ---- halo ------------------------------------------------------------------
     def halo_count(self, slot):
         """doubles in the message sent to the neighbour behind halo slot ``slot``"""

@@ -61,6 +61,10 @@ lib.orc_case_halo_pack.argtypes = [C.c_void_p, C.c_int, dp]
 lib.orc_case_halo_unpack.argtypes = [C.c_void_p, C.c_int, dp]
 lib.orc_case_step_phase.argtypes = [C.c_void_p, C.c_int]
 lib.orc_case_reduction.argtypes = [C.c_void_p, dp, C.c_int]
+lib.orc_case_implicit_control.argtypes = [C.c_void_p, dp, C.c_int]
+lib.orc_case_implicit_halo_count.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+lib.orc_case_implicit_halo_pack.argtypes = [C.c_void_p, C.c_int, C.c_int, dp]
+lib.orc_case_implicit_halo_unpack.argtypes = [C.c_void_p, C.c_int, C.c_int, dp]
 
 class QhdOptions(C.Structure):
     """orc_qhd_options == qgd_qhd_options"""
@@ -276,6 +280,36 @@ class OracleCase:
 
     def halo_unpack(self, side, buf):
         lib.orc_case_halo_unpack(self._h, side, _d(buf))
+
+    # ---- the implicitDiffusion branch on shards: same names as qgdsolver_amd.qgdfoam.QGDFoamCase ------------------------
+    def implicit_control(self):
+        a = np.zeros(68)
+        lib.orc_case_implicit_control(self._h, _d(a), 0)
+        return a
+
+    def set_implicit_control(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        lib.orc_case_implicit_control(self._h, _d(a), 1)
+
+    def implicit_solve_done(self):
+        return self.implicit_control()[64] != 0.0
+
+    def implicit_halo_count(self, slot, kind):
+        s, r = C.c_int64(), C.c_int64()
+        lib.orc_case_implicit_halo_count(self._h, int(slot), int(kind), C.byref(s), C.byref(r))
+        return s.value, r.value
+
+    def implicit_halo_pack(self, slot, kind, buf):
+        lib.orc_case_implicit_halo_pack(self._h, int(slot), int(kind), _d(buf))
+
+    def implicit_halo_unpack(self, slot, kind, buf):
+        lib.orc_case_implicit_halo_unpack(self._h, int(slot), int(kind), _d(buf))
+
+    def halo_buffer(self, n):
+        return np.zeros(max(int(n), 1))
+
+    def sync(self):
+        pass
 
     def close(self):
         if self._h:
