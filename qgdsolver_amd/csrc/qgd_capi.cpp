@@ -1798,7 +1798,8 @@ int qgd_qhd_case_sweep_time(qgd_qhd_case_t c, int reps, double info[4]) {
     if (!c || !info || reps <= 0) return fail(QGD_ERR_INVALID, "bad argument");
     if (!c->solver) return fail(QGD_ERR_INVALID, "qgd_qhd_case_sweep_time: call qgd_qhd_case_set_fields first");
     HIP_CHECK(hipSetDevice(c->dev->deviceId));
-    int rows = 0, width = 0;
+    int rows = 0;
+    double width = 0;
     info[0] = pressureSolverSweepMs(c->solver, reps, &rows, &width);
     info[1] = rows; info[2] = width; info[3] = pressureSolverSinglePrecisionCycle(c->solver) ? 4.0 : 8.0;
     return QGD_OK;

@@ -239,7 +239,7 @@ void pressureSolvePhase(PressureSolver* S, int phase);
 int pressureSolveRun(PressureSolver* S, const SolveHooks* hooks, double residuals[2]);
 void pressureSolveFlux(PressureSolver* S, double* phi);
 void pressureSolveStatus(PressureSolver* S, double out[4]);
-double pressureSolverSweepMs(PressureSolver* S, int reps, int* rows, int* width);   // measurement: one level-0 smoothing sweep
+double pressureSolverSweepMs(PressureSolver* S, int reps, int* rows, double* width);   // measurement: one level-0 smoothing sweep
 bool pressureSolverSinglePrecisionCycle(const PressureSolver* S);
 double* pressureSolverCtl(PressureSolver* S);         // control block: slots [0,3) [3] [4] [5] [6,8) [8] are the sums a sharded run reduces
 double* pressureSolverDirection(PressureSolver* S);   // nC doubles by local cell label

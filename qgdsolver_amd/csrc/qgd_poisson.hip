@@ -12,10 +12,12 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <stdexcept>
 #include <string>
 #include <vector>
+#include <omp.h>
 
 #include "qgd_device.hpp"
 
@@ -342,29 +344,45 @@ int diagLaplacianPcg(hipStream_t stream, const MeshView& m, const double* a, con
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Aggregation multigrid as the preconditioner of the same conjugate-gradient loop.
+// Algebraic multigrid as the preconditioner of the same conjugate-gradient loop.
 //
 // The Jacobi-PCG above needs 772 / 1174 iterations at 2 M / 8 M cells; QHDFoam solves this equation every step
 // [QHDpEqn.H L36-47], and in QHDFoam its matrix never changes (taubyrhof is fixed after start-up), so a hierarchy built once
-// pays for itself at the first step.  Built on the host from the face coefficients: pairwise matching along the strongest
-// connection, two passes per level (aggregates of about four cells; three passes -- the eight-cell aggregates of OpenFOAM's
-// faceAreaPair agglomeration -- need twice the iterations here), Galerkin coarse operators with piecewise-constant prolongation (coarse face coefficient = sum of the fine
-// ones between two aggregates).  One V-cycle = nu damped-Jacobi sweeps before and after the coarse-grid correction, which is
-// over-weighted (x += oc * P e_c, oc = 1.8: plain aggregation under-estimates smooth corrections); with equal pre- and
-// post-smoothing the cycle is a symmetric positive definite operator, as CG needs.  Every sum is a gather in a fixed order:
-// a solve is reproducible bit for bit, like the Jacobi variant.
+// pays for itself at the first step.  Built on the host from the face coefficients, two kinds:
+//   smoothed aggregation (default, see smoothedLevel below): root-and-neighbours aggregates of the strength graph, the prolongator
+//     smoothed by one Jacobi step, Galerkin coarse operators, the last level (<= 1024 rows) solved exactly with its dense inverse;
+//     8 M cells: levels of 8 M / 1 M / 55 k / 1.7 k / 50 rows, 8 CG iterations to QHDFoam's 1e-8;
+//   plain aggregation (QGD_MG_SA=0, what round 2 shipped): pairwise matching along the strongest connection, two passes per level
+//     (aggregates of ~4 cells), piecewise-constant prolongation with an over-weighted correction (x += 1.8 P e_c); 24 iterations.
+// One V-cycle = nu damped-Jacobi sweeps before and after the coarse-grid correction; with equal pre- and post-smoothing the cycle is a
+// symmetric positive definite operator, as CG needs.  Every sum is a gather in a fixed order: a solve is reproducible bit for bit,
+// like the Jacobi variant.
 // ---------------------------------------------------------------------------------------------------------------------
 namespace {
 
 template <typename T>
 struct MgLevelT {
-    int n = 0, width = 0;
+    int n = 0, width = 0;       // rows; the widest row
+    long long entries = 0;      // stored (padded) entries of the sliced ELL
     T* diag = nullptr;          // n
-    int* col = nullptr;         // width*n, column-major ELL, -1 = padding
-    T* val = nullptr;           // width*n: a_ij > 0 (A_ij = -a_ij)
+    // sliced ELL: 64 rows per slice, slice s holds sliceStart[s+1] - sliceStart[s] entry rows of 64 lanes; entry k of row i sits at
+    // (sliceStart[i >> 6] + k) * 64 + (i & 63).  The rows of an aggregated level differ a lot in length (4-cell aggregates of
+    // hexahedra: 6 to ~20 neighbours): padding every row to the widest made level 1 cost two thirds of level 0 with a quarter of the rows.
+    const int* sliceStart = nullptr;   // n/64 + 2
+    // or (rowStart != nullptr) plain CSR walked by one wavefront per row: the small levels of a smoothed-aggregation hierarchy have
+    // 50-100 entries per row and too few rows to fill the chip with one lane per row (55 k rows x 88: 52 us per sweep, 11 us this way)
+    const int* rowStart = nullptr;     // n + 1
+    int* col = nullptr;         // -1 = padding (sliced ELL only)
+    T* val = nullptr;           // a_ij (A_ij = -a_ij)
+    const T* inverse = nullptr; // coarsest level: dense n x n inverse (row-major), or nullptr = Jacobi sweeps
     int* agg = nullptr;         // n: aggregate of each node in the next level
     int* aggStart = nullptr;    // nNext+1
     int* aggItems = nullptr;    // n
+    // smoothed aggregation (pS != nullptr): the prolongator P (n rows, sliced ELL like the matrix: 4-10 entries per row) and its
+    // transpose (nNext rows of 50-500 entries: CSR, one wavefront per row, ptS = row starts; above 300 k rows sliced ELL, ptSliced = 1)
+    const int *pS = nullptr, *pCol = nullptr, *ptS = nullptr, *ptCol = nullptr;
+    int ptSliced = 0;
+    const T *pVal = nullptr, *ptVal = nullptr;
     T *x = nullptr, *x2 = nullptr, *b = nullptr, *r = nullptr;
 };
 using MgLevelDev = MgLevelT<double>;   // the cycle in double; MgLevelT<float>: the same cycle as a single-precision preconditioner
@@ -372,21 +390,28 @@ using MgLevelDev = MgLevelT<double>;   // the cycle in double; MgLevelT<float>: 
 // xout = xin + omega (b - A xin)/diag   (xin == nullptr: from zero, xout = omega b/diag);  rout (optional) = b - A xin
 template <typename T>
 __global__ __launch_bounds__(PB) void mgSmoothKernel(const MgLevelT<T> L, const T omega, const T* __restrict__ b,
-                                                     const T* __restrict__ xin, T* __restrict__ xout, T* __restrict__ rout,
-                                                     const double* __restrict__ ctl = nullptr) {
+                                                     const T* __restrict__ xin, T* xout, T* __restrict__ rout,
+                                                     const double* __restrict__ ctl = nullptr, const T cx = 1, const T cm = 0) {
     const int i = blockIdx.x * PB + threadIdx.x;
     if (i >= L.n || solveDone(ctl)) return;
     const T d = L.diag[i];
     if (!xin) { xout[i] = omega * b[i] / d; return; }
     const T xi = xin[i];
     T s = d * xi;
-    for (int k = 0; k < L.width; ++k) {
-        const int c = L.col[(size_t)k * L.n + i];
-        if (c >= 0) s -= L.val[(size_t)k * L.n + i] * xin[c];
+    const int s0 = L.sliceStart[i >> 6], w = L.sliceStart[(i >> 6) + 1] - s0;
+    const size_t e0 = (size_t)s0 * 64 + (i & 63);
+    for (int k = 0; k < w; ++k) {
+        const int c = L.col[e0 + (size_t)k * 64];
+        if (c >= 0) s -= L.val[e0 + (size_t)k * 64] * xin[c];
     }
     const T r = b[i] - s;
     if (rout) rout[i] = r;
-    if (xout) xout[i] = xi + omega * r / d;
+    if (xout) {
+        // cx = 1, cm = 0: a damped-Jacobi sweep;  otherwise one step of the Chebyshev recurrence, whose previous iterate sits in xout[i]
+        T v = cx * xi + omega * r / d;
+        if (cm != (T)0) v -= cm * xout[i];
+        xout[i] = v;
+    }
 }
 // vectors between the double-precision CG and a single-precision cycle
 template <typename A, typename B>
@@ -404,9 +429,11 @@ __global__ __launch_bounds__(PB) void mgApplyKernel(const MgLevelDev L, const do
     if (i < L.n) {
         const double xi = x[i];
         double s = L.diag[i] * xi;
-        for (int k = 0; k < L.width; ++k) {
-            const int c = L.col[(size_t)k * L.n + i];
-            if (c >= 0) s -= L.val[(size_t)k * L.n + i] * x[c];
+        const int s0 = L.sliceStart[i >> 6], w = L.sliceStart[(i >> 6) + 1] - s0;
+        const size_t e0 = (size_t)s0 * 64 + (i & 63);
+        for (int k = 0; k < w; ++k) {
+            const int c = L.col[e0 + (size_t)k * 64];
+            if (c >= 0) s -= L.val[e0 + (size_t)k * 64] * x[c];
         }
         y[i] = s;
         xy = xi * s;
@@ -429,6 +456,88 @@ __global__ __launch_bounds__(PB) void mgProlongKernel(const int n, const int* __
     const int i = blockIdx.x * PB + threadIdx.x;
     if (i < n && !solveDone(ctl)) x[i] += oc * ec[agg[i]];
 }
+// sum over the 64 lanes of a wavefront, the same tree for every row (valid in lane 0)
+template <typename T>
+__device__ __forceinline__ T waveSum(T v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+// the sweep of mgSmoothKernel for a CSR level, one wavefront per row (PB / 64 rows per workgroup)
+template <typename T>
+__global__ __launch_bounds__(PB) void mgSmoothRowKernel(const MgLevelT<T> L, const T omega, const T* __restrict__ b, const T* __restrict__ xin,
+                                                        T* xout, T* __restrict__ rout, const double* __restrict__ ctl = nullptr, const T cx = 1,
+                                                        const T cm = 0) {
+    const int i = blockIdx.x * (PB / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= L.n || solveDone(ctl)) return;
+    if (!xin) { if (lane == 0) xout[i] = omega * b[i] / L.diag[i]; return; }
+    T s = 0;
+    for (int k = L.rowStart[i] + lane; k < L.rowStart[i + 1]; k += 64) s += L.val[k] * xin[L.col[k]];
+    s = waveSum(s);
+    if (lane != 0) return;
+    const T d = L.diag[i], xi = xin[i];
+    const T r = b[i] - (d * xi - s);
+    if (rout) rout[i] = r;
+    if (xout) {
+        T v = cx * xi + omega * r / d;
+        if (cm != (T)0) v -= cm * xout[i];
+        xout[i] = v;
+    }
+}
+// the same two transfers with a smoothed prolongator: rc = P^T r (one wavefront per coarse row), x += oc P ec
+template <typename T>
+__global__ __launch_bounds__(PB) void mgRestrictRowKernel(const int nCoarse, const int* __restrict__ rowStart, const int* __restrict__ col,
+                                                          const T* __restrict__ val, const T* __restrict__ r, T* __restrict__ rc,
+                                                          const double* __restrict__ ctl = nullptr) {
+    const int I = blockIdx.x * (PB / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (I >= nCoarse || solveDone(ctl)) return;
+    T s = 0;
+    for (int k = rowStart[I] + lane; k < rowStart[I + 1]; k += 64) s += val[k] * r[col[k]];
+    s = waveSum(s);
+    if (lane == 0) rc[I] = s;
+}
+// rc = P^T r with P^T as sliced ELL, one coarse row per lane: level 0 -> 1 has 1 M rows of ~50 entries (105 us; 240 us by wavefronts)
+template <typename T>
+__global__ __launch_bounds__(PB) void mgRestrictEllKernel(const int nCoarse, const int* __restrict__ sliceStart, const int* __restrict__ col,
+                                                          const T* __restrict__ val, const T* __restrict__ r, T* __restrict__ rc,
+                                                          const double* __restrict__ ctl = nullptr) {
+    const int I = blockIdx.x * PB + threadIdx.x;
+    if (I >= nCoarse || solveDone(ctl)) return;
+    const int s0 = sliceStart[I >> 6], w = sliceStart[(I >> 6) + 1] - s0;
+    const size_t e0 = (size_t)s0 * 64 + (I & 63);
+    T s = 0;
+    for (int k = 0; k < w; ++k) {
+        const int c = col[e0 + (size_t)k * 64];
+        if (c >= 0) s += val[e0 + (size_t)k * 64] * r[c];
+    }
+    rc[I] = s;
+}
+// coarsest level: x = A^-1 b with the dense inverse, one wavefront per row
+template <typename T>
+__global__ __launch_bounds__(PB) void mgDenseKernel(const int n, const T* __restrict__ inverse, const T* __restrict__ b, T* __restrict__ x,
+                                                    const double* __restrict__ ctl = nullptr) {
+    const int i = blockIdx.x * (PB / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= n || solveDone(ctl)) return;
+    T s = 0;
+    for (int k = lane; k < n; k += 64) s += inverse[(size_t)i * n + k] * b[k];
+    s = waveSum(s);
+    if (lane == 0) x[i] = s;
+}
+template <typename T>
+__global__ __launch_bounds__(PB) void mgProlongEllKernel(const int n, const int* __restrict__ sliceStart, const int* __restrict__ col,
+                                                         const T* __restrict__ val, const T oc, const T* __restrict__ ec, T* __restrict__ x,
+                                                         const double* __restrict__ ctl = nullptr) {
+    const int i = blockIdx.x * PB + threadIdx.x;
+    if (i >= n || solveDone(ctl)) return;
+    const int s0 = sliceStart[i >> 6], w = sliceStart[(i >> 6) + 1] - s0;
+    const size_t e0 = (size_t)s0 * 64 + (i & 63);
+    T s = 0;
+    for (int k = 0; k < w; ++k) {
+        const int c = col[e0 + (size_t)k * 64];
+        if (c >= 0) s += val[e0 + (size_t)k * 64] * ec[c];
+    }
+    x[i] += oc * s;
+}
 // coarsest level: `sweeps` Jacobi sweeps by one workgroup (n <= MG_COARSE_MAX), the iterate in LDS
 #define MG_COARSE_MAX 1024
 template <typename T>
@@ -445,11 +554,13 @@ __global__ __launch_bounds__(1024) void mgCoarseKernel(const MgLevelT<T> L, cons
     constexpr int MG_COARSE_ROW = 32;
     int cc[MG_COARSE_ROW];
     T vv[MG_COARSE_ROW];
+    const int s0 = on ? L.sliceStart[i >> 6] : 0, wRow = on ? L.sliceStart[(i >> 6) + 1] - s0 : 0;
+    const size_t e0 = (size_t)s0 * 64 + (i & 63);
 #pragma unroll
     for (int k = 0; k < MG_COARSE_ROW; ++k) {
-        const bool has = on && k < L.width;
-        cc[k] = has ? L.col[(size_t)k * L.n + i] : -1;
-        vv[k] = (has && cc[k] >= 0) ? L.val[(size_t)k * L.n + i] : (T)0;
+        const bool has = on && k < wRow;
+        cc[k] = has ? L.col[e0 + (size_t)k * 64] : -1;
+        vv[k] = (has && cc[k] >= 0) ? L.val[e0 + (size_t)k * 64] : (T)0;
         if (cc[k] < 0) cc[k] = i;   // value 0: reads its own entry
     }
     if (on) cur[i] = omega * bi / d;
@@ -459,9 +570,9 @@ __global__ __launch_bounds__(1024) void mgCoarseKernel(const MgLevelT<T> L, cons
             T t = d * cur[i];
 #pragma unroll
             for (int k = 0; k < MG_COARSE_ROW; ++k) t -= vv[k] * cur[cc[k]];
-            for (int k = MG_COARSE_ROW; k < L.width; ++k) {
-                const int c = L.col[(size_t)k * L.n + i];
-                if (c >= 0) t -= L.val[(size_t)k * L.n + i] * cur[c];
+            for (int k = MG_COARSE_ROW; k < wRow; ++k) {
+                const int c = L.col[e0 + (size_t)k * 64];
+                if (c >= 0) t -= L.val[e0 + (size_t)k * 64] * cur[c];
             }
             nxt[i] = cur[i] + omega * (bi - t) / d;
         }
@@ -566,6 +677,24 @@ struct PressureSolver {
     int ob = 0, oe = 0;             // rows of the system: the owned cells [ob, oe) of the (possibly sharded) mesh
     double omega = 0.8, oc = 1.8;   // measured (8 M cells / 16 M irregular): 0.67 -> 0.8 with 4:1 coarsening 46 -> 24 / 52 -> 25 iterations
     int nu = 2, coarseSweeps = 40;
+    // the smoother's steps: x <- (1 + cm) x + cr D^-1 r - cm x_previous.  Damped Jacobi: cr = omega, cm = 0.  With QGD_MG_CHEB=ratio > 1
+    // the nu steps are the Chebyshev polynomial of D^-1 A for the eigenvalue interval [lmax / ratio, lmax] (lmax = 2: Gershgorin, the
+    // rows of every level are weakly diagonally dominant) -- a fixed polynomial, the same before and after the coarse correction, so
+    // the cycle stays a symmetric preconditioner
+    double cr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    void smootherSetup(const double ratio, const double lmax) {
+        for (int k = 0; k < 8; ++k) { cr[k] = omega; cm[k] = 0; }
+        if (!(ratio > 1)) return;
+        const double hi = lmax, lo = lmax / ratio, theta = 0.5 * (hi + lo), delta = 0.5 * (hi - lo), sigma = theta / delta;
+        double rho = 1.0 / sigma;
+        cr[0] = 1.0 / theta;
+        for (int k = 1; k < 8; ++k) {
+            const double rhoNew = 1.0 / (2.0 * sigma - rho);
+            cm[k] = rhoNew * rho; cr[k] = 2.0 * rhoNew / delta;
+            rho = rhoNew;
+        }
+    }
+    std::vector<double> smootherScale;   // per level (smoothed aggregation: coarse operators are no M-matrices, lambda_max is estimated)
     std::vector<void*> owned;
     std::vector<MgLevelDev> L;
     std::vector<MgLevelT<float>> Lf;   // single-precision copy of the hierarchy (QGD_MG_F32; level 0 of L stays for the CG's own A x)
@@ -612,28 +741,46 @@ struct PressureSolver {
     void vcycleT(std::vector<MgLevelT<T>>& Lv, size_t l, const T* b, T* x) {
         MgLevelT<T>& lv = Lv[l];
         const int nb = blocksOf(lv.n);
-        const T om = (T)omega, over = (T)oc;
+        const double sc = l < smootherScale.size() ? smootherScale[l] : 1.0;    // 2 / lambda_max(D^-1 A) of this level (1: the Gershgorin bound)
+        const T om = (T)(omega * sc), over = (T)oc;
         const T* none = nullptr;
         T* noOut = nullptr;
+        const int nbRow = (lv.n + PB / 64 - 1) / (PB / 64);
+        // one sweep of the level in its own layout
+        auto sweep = [&](T w, const T* rhs, const T* xin, T* xout, T* rout, T cx, T cmPrev) {
+            if (lv.rowStart) mgSmoothRowKernel<T><<<nbRow, PB, 0, stream>>>(lv, w, rhs, xin, xout, rout, ctl, cx, cmPrev);
+            else mgSmoothKernel<T><<<nb, PB, 0, stream>>>(lv, w, rhs, xin, xout, rout, ctl, cx, cmPrev);
+        };
         if (l + 1 == Lv.size()) {
-            if (lv.n <= MG_COARSE_MAX) mgCoarseKernel<T><<<1, 1024, 0, stream>>>(lv, om, coarseSweeps, b, x, ctl);
+            if (lv.inverse) mgDenseKernel<T><<<nbRow, PB, 0, stream>>>(lv.n, lv.inverse, b, x, ctl);
+            else if (lv.n <= MG_COARSE_MAX && !lv.rowStart) mgCoarseKernel<T><<<1, 1024, 0, stream>>>(lv, om, coarseSweeps, b, x, ctl);
             else {
                 T* cur = x; T* nxt = lv.x2;
-                mgSmoothKernel<T><<<nb, PB, 0, stream>>>(lv, om, b, none, cur, noOut, ctl);
-                for (int s = 1; s < coarseSweeps; ++s) { mgSmoothKernel<T><<<nb, PB, 0, stream>>>(lv, om, b, cur, nxt, noOut, ctl); std::swap(cur, nxt); }
+                sweep(om, b, none, cur, noOut, (T)1, (T)0);
+                for (int s = 1; s < coarseSweeps; ++s) { sweep(om, b, cur, nxt, noOut, (T)1, (T)0); std::swap(cur, nxt); }
                 if (cur != x) PCHECK(hipMemcpyAsync(x, cur, sizeof(T) * lv.n, hipMemcpyDeviceToDevice, stream));
             }
             return;
         }
         MgLevelT<T>& nx = Lv[l + 1];
         T* cur = x; T* nxt = lv.x2;
-        mgSmoothKernel<T><<<nb, PB, 0, stream>>>(lv, om, b, none, cur, noOut, ctl);
-        for (int s = 1; s < nu; ++s) { mgSmoothKernel<T><<<nb, PB, 0, stream>>>(lv, om, b, cur, nxt, noOut, ctl); std::swap(cur, nxt); }
-        mgSmoothKernel<T><<<nb, PB, 0, stream>>>(lv, om, b, cur, noOut, lv.r, ctl);           // r = b - A x
-        mgRestrictKernel<T><<<blocksOf(nx.n), PB, 0, stream>>>(nx.n, lv.aggStart, lv.aggItems, lv.r, nx.b, ctl);
+        // pre-smoothing from a zero iterate: step 0 is cr[0] b/d, step 1 has no previous iterate to subtract
+        sweep((T)(cr[0] * sc), b, none, cur, noOut, (T)1, (T)0);
+        for (int s = 1; s < nu; ++s) {
+            sweep((T)(cr[s] * sc), b, cur, nxt, noOut, (T)(1.0 + cm[s]), (T)(s >= 2 ? cm[s] : 0.0));
+            std::swap(cur, nxt);
+        }
+        sweep(om, b, cur, noOut, lv.r, (T)1, (T)0);           // r = b - A x
+        if (lv.pS && lv.ptSliced) mgRestrictEllKernel<T><<<blocksOf(nx.n), PB, 0, stream>>>(nx.n, lv.ptS, lv.ptCol, lv.ptVal, lv.r, nx.b, ctl);
+        else if (lv.pS) mgRestrictRowKernel<T><<<(nx.n + PB / 64 - 1) / (PB / 64), PB, 0, stream>>>(nx.n, lv.ptS, lv.ptCol, lv.ptVal, lv.r, nx.b, ctl);
+        else mgRestrictKernel<T><<<blocksOf(nx.n), PB, 0, stream>>>(nx.n, lv.aggStart, lv.aggItems, lv.r, nx.b, ctl);
         vcycleT<T>(Lv, l + 1, nx.b, nx.x);
-        mgProlongKernel<T><<<nb, PB, 0, stream>>>(lv.n, lv.agg, over, nx.x, cur, ctl);
-        for (int s = 0; s < nu; ++s) { mgSmoothKernel<T><<<nb, PB, 0, stream>>>(lv, om, b, cur, nxt, noOut, ctl); std::swap(cur, nxt); }
+        if (lv.pS) mgProlongEllKernel<T><<<nb, PB, 0, stream>>>(lv.n, lv.pS, lv.pCol, lv.pVal, over, nx.x, cur, ctl);
+        else mgProlongKernel<T><<<nb, PB, 0, stream>>>(lv.n, lv.agg, over, nx.x, cur, ctl);
+        for (int s = 0; s < nu; ++s) {
+            sweep((T)(cr[s] * sc), b, cur, nxt, noOut, (T)(1.0 + cm[s]), (T)cm[s]);
+            std::swap(cur, nxt);
+        }
         if (cur != x) PCHECK(hipMemcpyAsync(x, cur, sizeof(T) * lv.n, hipMemcpyDeviceToDevice, stream));
     }
     void vcycle(size_t l, const double* b, double* x) {
@@ -692,13 +839,13 @@ int pairwisePass(int n, const std::vector<int>& I, const std::vector<int>& J, co
     int na = 0;
     for (int i = 0; i < n; ++i) {
         if (agg[i] >= 0) continue;
-        int best = -1; double bw = -1.0;
+        int best = -1; double bw = 0.0;   // only along a positive coupling (smoothed-aggregation levels have a few of the other sign)
         for (int64_t k = off[i]; k < off[i + 1]; ++k) if (agg[nb[k]] < 0 && nb[k] != i && nw[k] > bw) { bw = nw[k]; best = nb[k]; }
         if (best >= 0) { agg[i] = agg[best] = na++; }
     }
     for (int i = 0; i < n; ++i) {
         if (agg[i] >= 0) continue;
-        int best = -1; double bw = -1.0;
+        int best = -1; double bw = -1e300;
         for (int64_t k = off[i]; k < off[i + 1]; ++k) if (agg[nb[k]] >= 0 && nw[k] > bw) { bw = nw[k]; best = nb[k]; }
         agg[i] = best >= 0 ? agg[best] : na++;
     }
@@ -725,39 +872,339 @@ void coarsenGraph(int na, const std::vector<int>& agg, std::vector<int>& I, std:
     }
     diag.swap(dc);
 }
+// ---------------------------------------------------------------------------------------------------------------------
+// Smoothed aggregation (QGD_MG_SA, the default).  With the piecewise-constant prolongator T of the aggregates the V-cycle contracts by
+// ~0.6 per CG iteration (24 iterations for QHDFoam's 1e-8 at 8 M cells) whatever the smoother -- Chebyshev steps instead of Jacobi
+// sweeps changed 24 to 23 -- because the coarse spaces cannot represent smooth corrections.  One Jacobi step on the prolongator,
+//      P = (I - omegaP D^-1 A) T,     A_coarse = P^T A P,     omegaP = 4 / (3 lambda_max(D^-1 A)),
+// fixes that at the price of wider coarse rows, so the aggregates are larger (three pairwise passes, ~8 cells).  Everything is built once
+// on the host: P row by row, the triple product coarse row by coarse row (Gustavson with a marker array per thread; the order of
+// every sum is fixed by the row orders, not by the thread count).
+// ---------------------------------------------------------------------------------------------------------------------
+struct HostCsr {
+    std::vector<int64_t> off;
+    std::vector<int> col;
+    std::vector<double> val;
+};
+static void adjacencyOf(int n, const std::vector<int>& I, const std::vector<int>& J, const std::vector<double>& w, std::vector<int64_t>& off,
+                        std::vector<int>& nb, std::vector<double>& nw) {
+    const size_t E = I.size();
+    off.assign((size_t)n + 1, 0);
+    for (size_t e = 0; e < E; ++e) { off[I[e] + 1]++; off[J[e] + 1]++; }
+    for (int i = 0; i < n; ++i) off[i + 1] += off[i];
+    nb.resize((size_t)off[n]); nw.resize((size_t)off[n]);
+    std::vector<int64_t> fill(off.begin(), off.end() - 1);
+    for (size_t e = 0; e < E; ++e) {
+        nb[fill[I[e]]] = J[e]; nw[fill[I[e]]++] = w[e];
+        nb[fill[J[e]]] = I[e]; nw[fill[J[e]]++] = w[e];
+    }
+}
+// largest eigenvalue of D^-1 A (A_ii = diag, A_ij = -w_ij) by power iteration from a fixed start vector, with a 10 % margin
+static double lambdaMaxOf(int n, const std::vector<int64_t>& off, const std::vector<int>& nb, const std::vector<double>& nw,
+                          const std::vector<double>& diag) {
+    std::vector<double> x((size_t)n), y((size_t)n);
+    uint32_t seed = 12345u;
+    for (int i = 0; i < n; ++i) { seed = seed * 1664525u + 1013904223u; x[i] = ((seed >> 8) & 0xffff) / 65536.0 - 0.5; }
+    double lambda = 0;
+    for (int it = 0; it < 30; ++it) {
+        double xx = 0, yy = 0;
+#pragma omp parallel for schedule(static) reduction(+ : xx, yy) if (n > 20000)
+        for (int i = 0; i < n; ++i) {
+            double sum = diag[i] * x[i];
+            for (int64_t k = off[i]; k < off[i + 1]; ++k) sum -= nw[k] * x[nb[k]];
+            y[i] = sum / diag[i];
+            xx += x[i] * x[i]; yy += y[i] * y[i];
+        }
+        lambda = std::max(lambda, std::sqrt(yy / std::max(xx, 1e-300)));
+        const double inv = 1.0 / std::sqrt(std::max(yy, 1e-300));
+        for (int i = 0; i < n; ++i) x[i] = y[i] * inv;
+    }
+    return 1.1 * lambda;
+}
+// strong couplings of the level: a_ij > theta sqrt(a_ii a_jj) (negative off-diagonal entries only)
+static void strengthOf(int n, const std::vector<int64_t>& off, const std::vector<int>& nb, const std::vector<double>& nw,
+                       const std::vector<double>& diag, double theta, std::vector<uint8_t>& strong) {
+    strong.assign(nb.size(), 0);
+#pragma omp parallel for schedule(static) if (n > 20000)
+    for (int i = 0; i < n; ++i)
+        for (int64_t k = off[i]; k < off[i + 1]; ++k) strong[k] = nw[k] > theta * std::sqrt(diag[i] * diag[nb[k]]) ? 1 : 0;
+}
+// Aggregates of the strength graph (Vanek, Mandel, Brezina 1996): 1. a node whose strong neighbours are all free becomes the root of
+// {node} + neighbours;  2. the remaining nodes join the adjacent aggregate of pass 1 they are coupled to most strongly;  3. what is
+// left (no aggregated strong neighbour) forms aggregates with its free neighbours, isolated nodes stay alone.  Ascending node order.
+static int rootAggregates(int n, const std::vector<int64_t>& off, const std::vector<int>& nb, const std::vector<double>& nw,
+                          const std::vector<uint8_t>& strong, std::vector<int>& agg) {
+    agg.assign((size_t)n, -1);
+    int na = 0;
+    for (int i = 0; i < n; ++i) {
+        if (agg[i] >= 0) continue;
+        bool free = true, any = false;
+        for (int64_t k = off[i]; k < off[i + 1] && free; ++k)
+            if (strong[k]) { any = true; if (agg[nb[k]] >= 0) free = false; }
+        if (!free || !any) continue;
+        agg[i] = na;
+        for (int64_t k = off[i]; k < off[i + 1]; ++k) if (strong[k]) agg[nb[k]] = na;
+        ++na;
+    }
+    std::vector<int> first(agg);
+    for (int i = 0; i < n; ++i) {
+        if (first[i] >= 0) continue;
+        int best = -1; double bw = -1e300;
+        for (int64_t k = off[i]; k < off[i + 1]; ++k) if (strong[k] && first[nb[k]] >= 0 && nw[k] > bw) { bw = nw[k]; best = nb[k]; }
+        if (best >= 0) agg[i] = first[best];
+    }
+    for (int i = 0; i < n; ++i) {
+        if (agg[i] >= 0) continue;
+        agg[i] = na;
+        for (int64_t k = off[i]; k < off[i + 1]; ++k) if (strong[k] && agg[nb[k]] < 0) agg[nb[k]] = na;
+        ++na;
+    }
+    return na;
+}
+// P = (I - omegaP DF^-1 AF) T with the filtered matrix AF (weak couplings lumped into the diagonal), A_coarse = P^T A P with the full A
+static void smoothedLevel(int n, const std::vector<int64_t>& off, const std::vector<int>& nb, const std::vector<double>& nw,
+                          const std::vector<uint8_t>& strong, const std::vector<double>& diag, const std::vector<int>& agg, int nc, double omegaP,
+                          HostCsr& P, HostCsr& PT,
+                          std::vector<int>& cI, std::vector<int>& cJ, std::vector<double>& cw, std::vector<double>& cdiag) {
+    // ---- P, row by row (entries in ascending column order) ----
+    auto rowOfP = [&](int i, std::vector<int>& cols, std::vector<double>& vals) {
+        cols.clear(); vals.clear();
+        double dF = diag[i];
+        for (int64_t k = off[i]; k < off[i + 1]; ++k) if (!strong[k]) dF -= nw[k];
+        if (!(dF > 0.1 * diag[i])) dF = diag[i];
+        cols.push_back(agg[i]); vals.push_back(1.0 - omegaP);
+        const double s = omegaP / dF;
+        for (int64_t k = off[i]; k < off[i + 1]; ++k) {
+            if (!strong[k]) continue;
+            const int a = agg[nb[k]];
+            size_t q = 0;
+            while (q < cols.size() && cols[q] != a) ++q;
+            if (q == cols.size()) { cols.push_back(a); vals.push_back(0.0); }
+            vals[q] += s * nw[k];
+        }
+        for (size_t a = 1; a < cols.size(); ++a)
+            for (size_t b = a; b > 0 && cols[b - 1] > cols[b]; --b) { std::swap(cols[b - 1], cols[b]); std::swap(vals[b - 1], vals[b]); }
+    };
+    P.off.assign((size_t)n + 1, 0);
+#pragma omp parallel
+    {
+        std::vector<int> cols; std::vector<double> vals;
+#pragma omp for schedule(static)
+        for (int i = 0; i < n; ++i) { rowOfP(i, cols, vals); P.off[i + 1] = (int64_t)cols.size(); }
+    }
+    for (int i = 0; i < n; ++i) P.off[i + 1] += P.off[i];
+    P.col.resize((size_t)P.off[n]); P.val.resize((size_t)P.off[n]);
+#pragma omp parallel
+    {
+        std::vector<int> cols; std::vector<double> vals;
+#pragma omp for schedule(static)
+        for (int i = 0; i < n; ++i) {
+            rowOfP(i, cols, vals);
+            for (size_t q = 0; q < cols.size(); ++q) { P.col[P.off[i] + q] = cols[q]; P.val[P.off[i] + q] = vals[q]; }
+        }
+    }
+    // ---- P^T (rows in ascending fine index) ----
+    PT.off.assign((size_t)nc + 1, 0);
+    for (int c : P.col) PT.off[c + 1]++;
+    for (int c = 0; c < nc; ++c) PT.off[c + 1] += PT.off[c];
+    PT.col.resize(P.col.size()); PT.val.resize(P.col.size());
+    {
+        std::vector<int64_t> fill(PT.off.begin(), PT.off.end() - 1);
+        for (int i = 0; i < n; ++i)
+            for (int64_t q = P.off[i]; q < P.off[i + 1]; ++q) { const int64_t at = fill[P.col[q]]++; PT.col[at] = i; PT.val[at] = P.val[q]; }
+    }
+    // ---- A_coarse = P^T A P: row I gathers p_iI * A_ik * p_kJ over the fine rows i of P^T's row I ----
+    cdiag.assign((size_t)nc, 0.0);
+    int nThreads = 1;
+#pragma omp parallel
+    {
+#pragma omp single
+        nThreads = omp_get_num_threads();
+    }
+    std::vector<std::vector<int>> tI((size_t)nThreads), tJ((size_t)nThreads);
+    std::vector<std::vector<double>> tw((size_t)nThreads);
+#pragma omp parallel num_threads(nThreads)
+    {
+        const int t = omp_get_thread_num();
+        const int lo = (int)((int64_t)nc * t / nThreads), hi = (int)((int64_t)nc * (t + 1) / nThreads);
+        std::vector<int> where((size_t)nc, -1), touched;
+        std::vector<double> acc;
+        for (int Ic = lo; Ic < hi; ++Ic) {
+            touched.clear(); acc.clear();
+            auto add = [&](int k, double f) {
+                for (int64_t q = P.off[k]; q < P.off[k + 1]; ++q) {
+                    const int Jc = P.col[q];
+                    int at = where[Jc];
+                    if (at < 0) { at = where[Jc] = (int)touched.size(); touched.push_back(Jc); acc.push_back(0.0); }
+                    acc[at] += f * P.val[q];
+                }
+            };
+            for (int64_t e = PT.off[Ic]; e < PT.off[Ic + 1]; ++e) {
+                const int i = PT.col[e];
+                const double pi = PT.val[e];
+                add(i, pi * diag[i]);
+                for (int64_t k = off[i]; k < off[i + 1]; ++k) add(nb[k], -pi * nw[k]);
+            }
+            const double dI = where[Ic] >= 0 ? acc[where[Ic]] : 0.0;
+            cdiag[Ic] = dI;
+            std::vector<int> order(touched);
+            std::sort(order.begin(), order.end());
+            for (int Jc : order) {
+                const double v = acc[where[Jc]];
+                if (Jc > Ic && std::fabs(v) > 1e-13 * std::fabs(dI)) { tI[t].push_back(Ic); tJ[t].push_back(Jc); tw[t].push_back(-v); }
+            }
+            for (int Jc : touched) where[Jc] = -1;
+        }
+    }
+    cI.clear(); cJ.clear(); cw.clear();
+    for (int t = 0; t < nThreads; ++t) {
+        cI.insert(cI.end(), tI[t].begin(), tI[t].end());
+        cJ.insert(cJ.end(), tJ[t].begin(), tJ[t].end());
+        cw.insert(cw.end(), tw[t].begin(), tw[t].end());
+    }
+}
 }  // namespace
 
+// dense inverse of a small symmetric positive definite level (Cholesky in double); false when a pivot collapses (a singular block)
+static bool denseInverse(int n, const std::vector<int>& I, const std::vector<int>& J, const std::vector<double>& w, const std::vector<double>& diag,
+                         std::vector<double>& inv) {
+    std::vector<double> A((size_t)n * n, 0.0);
+    double dmax = 0;
+    for (int i = 0; i < n; ++i) { A[(size_t)i * n + i] = diag[i]; dmax = std::max(dmax, diag[i]); }
+    for (size_t e = 0; e < I.size(); ++e) { A[(size_t)I[e] * n + J[e]] -= w[e]; A[(size_t)J[e] * n + I[e]] -= w[e]; }
+    // A = L L^T, L in the lower triangle
+    for (int j = 0; j < n; ++j) {
+        double d = A[(size_t)j * n + j];
+        for (int k = 0; k < j; ++k) d -= A[(size_t)j * n + k] * A[(size_t)j * n + k];
+        if (!(d > 1e-12 * dmax)) return false;
+        const double ljj = std::sqrt(d);
+        A[(size_t)j * n + j] = ljj;
+#pragma omp parallel for schedule(static) if (n - j > 256)
+        for (int i = j + 1; i < n; ++i) {
+            double v = A[(size_t)i * n + j];
+            for (int k = 0; k < j; ++k) v -= A[(size_t)i * n + k] * A[(size_t)j * n + k];
+            A[(size_t)i * n + j] = v / ljj;
+        }
+    }
+    inv.assign((size_t)n * n, 0.0);
+#pragma omp parallel for schedule(dynamic, 8)
+    for (int c = 0; c < n; ++c) {
+        std::vector<double> y((size_t)n, 0.0);
+        for (int i = c; i < n; ++i) {            // L y = e_c
+            double v = i == c ? 1.0 : 0.0;
+            for (int k = c; k < i; ++k) v -= A[(size_t)i * n + k] * y[k];
+            y[i] = v / A[(size_t)i * n + i];
+        }
+        for (int i = n - 1; i >= 0; --i) {       // L^T x = y
+            double v = y[i];
+            for (int k = i + 1; k < n; ++k) v -= A[(size_t)k * n + i] * y[k];
+            y[i] = v / A[(size_t)i * n + i];
+        }
+        for (int i = 0; i < n; ++i) inv[(size_t)i * n + c] = y[i];
+    }
+    return true;
+}
+#define MG_DENSE_MAX 1024   // a level of at most this many rows is the last one and is solved exactly
 static void mgUploadLevel(PressureSolver* S, int n, const std::vector<int>& I, const std::vector<int>& J, const std::vector<double>& w,
-                          const std::vector<double>& diag) {
+                          const std::vector<double>& diag, bool last) {
     std::vector<int> deg((size_t)n, 0);
     for (size_t e = 0; e < I.size(); ++e) { deg[I[e]]++; deg[J[e]]++; }
     int width = 0;
     for (int d : deg) width = std::max(width, d);
-    std::vector<int> col((size_t)width * n, -1), fill((size_t)n, 0);
-    std::vector<double> val((size_t)width * n, 0.0);
-    for (size_t e = 0; e < I.size(); ++e) {
-        const int i = I[e], j = J[e];
-        col[(size_t)fill[i] * n + i] = j; val[(size_t)fill[i]++ * n + i] = w[e];
-        col[(size_t)fill[j] * n + j] = i; val[(size_t)fill[j]++ * n + j] = w[e];
+    // layout: one lane per row (sliced ELL) for the large levels, one wavefront per row (CSR) for small levels with long rows
+    const bool rows = !S->L.empty() && n <= 300000 && 2.0 * (double)I.size() >= 24.0 * n;
+    std::vector<int> start, col;
+    std::vector<double> val;
+    long long stored = 0;
+    if (rows) {
+        start.assign((size_t)n + 1, 0);
+        for (int i = 0; i < n; ++i) start[i + 1] = start[i] + deg[i];
+        stored = start[n];
+        col.assign(std::max<size_t>((size_t)stored, 1), 0); val.assign(std::max<size_t>((size_t)stored, 1), 0.0);
+        std::vector<int> fill(start.begin(), start.end() - 1);
+        for (size_t e = 0; e < I.size(); ++e) {
+            const int i = I[e], j = J[e];
+            col[fill[i]] = j; val[fill[i]++] = w[e];
+            col[fill[j]] = i; val[fill[j]++] = w[e];
+        }
+    } else {
+        const int nSlices = (n + 63) / 64;
+        start.assign((size_t)nSlices + 2, 0);
+        for (int sl = 0; sl < nSlices; ++sl) {
+            int wmax = 0;
+            for (int i = sl * 64; i < std::min(n, sl * 64 + 64); ++i) wmax = std::max(wmax, deg[i]);
+            start[sl + 1] = start[sl] + wmax;
+        }
+        start[nSlices + 1] = start[nSlices];
+        stored = (long long)start[nSlices] * 64;
+        col.assign(std::max<size_t>((size_t)stored, 1), -1); val.assign(std::max<size_t>((size_t)stored, 1), 0.0);
+        std::vector<int> fill((size_t)n, 0);
+        auto slot = [&](int i, int k) { return ((size_t)start[i >> 6] + k) * 64 + (i & 63); };
+        for (size_t e = 0; e < I.size(); ++e) {
+            const int i = I[e], j = J[e];
+            col[slot(i, fill[i])] = j; val[slot(i, fill[i]++)] = w[e];
+            col[slot(j, fill[j])] = i; val[slot(j, fill[j]++)] = w[e];
+        }
     }
+    std::vector<double> inv;
+    const bool dense = last && !S->L.empty() && n <= MG_DENSE_MAX && denseInverse(n, I, J, w, diag, inv);
     MgLevelDev lv;
-    lv.n = n; lv.width = width;
+    lv.n = n; lv.width = width; lv.entries = stored;
     lv.diag = S->alloc<double>(n, diag.data());
+    const int* startDev = S->alloc<int>(start.size(), start.data());
+    if (rows) lv.rowStart = startDev; else lv.sliceStart = startDev;
     lv.col = S->alloc<int>(col.size(), col.data());
     lv.val = S->alloc<double>(val.size(), val.data());
     if (S->f32) {
         // the double-precision level keeps only what the CG's own matrix product needs (level 0) or nothing
         std::vector<float> vf(val.begin(), val.end()), df(diag.begin(), diag.end());
         MgLevelT<float> lf;
-        lf.n = n; lf.width = width; lf.col = lv.col;
+        lf.n = n; lf.width = width; lf.entries = lv.entries; lf.col = lv.col; lf.sliceStart = lv.sliceStart; lf.rowStart = lv.rowStart;
         lf.diag = S->alloc<float>(n, df.data());
         lf.val = S->alloc<float>(vf.size(), vf.data());
         lf.x = S->alloc<float>(n); lf.x2 = S->alloc<float>(n); lf.b = S->alloc<float>(n); lf.r = S->alloc<float>(n);
+        if (dense) { std::vector<float> invf(inv.begin(), inv.end()); lf.inverse = S->alloc<float>(invf.size(), invf.data()); }
         S->Lf.push_back(lf);
     } else {
         lv.x = S->alloc<double>(n); lv.x2 = S->alloc<double>(n); lv.b = S->alloc<double>(n); lv.r = S->alloc<double>(n);
+        if (dense) lv.inverse = S->alloc<double>(inv.size(), inv.data());
     }
     S->L.push_back(lv);
+}
+
+// a host CSR as sliced ELL on the device (values in T)
+template <typename T>
+static void mgUploadEll(PressureSolver* S, int nRows, const HostCsr& M, const int** sliceStartOut, const int** colOut, const T** valOut) {
+    const int nSlices = (nRows + 63) / 64;
+    std::vector<int> sliceStart((size_t)nSlices + 2, 0);
+    for (int sl = 0; sl < nSlices; ++sl) {
+        int64_t w = 0;
+        for (int i = sl * 64; i < std::min(nRows, sl * 64 + 64); ++i) w = std::max(w, M.off[i + 1] - M.off[i]);
+        sliceStart[sl + 1] = sliceStart[sl] + (int)w;
+    }
+    sliceStart[nSlices + 1] = sliceStart[nSlices];
+    const size_t nEntries = std::max<size_t>((size_t)sliceStart[nSlices] * 64, 1);
+    std::vector<int> col(nEntries, -1);
+    std::vector<T> val(nEntries, (T)0);
+    for (int i = 0; i < nRows; ++i)
+        for (int64_t q = M.off[i]; q < M.off[i + 1]; ++q) {
+            const size_t at = ((size_t)sliceStart[i >> 6] + (size_t)(q - M.off[i])) * 64 + (i & 63);
+            col[at] = M.col[q]; val[at] = (T)M.val[q];
+        }
+    *sliceStartOut = S->alloc<int>(sliceStart.size(), sliceStart.data());
+    *colOut = S->alloc<int>(col.size(), col.data());
+    *valOut = S->alloc<T>(val.size(), val.data());
+}
+
+template <typename T>
+static void mgUploadCsr(PressureSolver* S, int nRows, const HostCsr& M, const int** rowStartOut, const int** colOut, const T** valOut) {
+    if (M.off[nRows] > 0x7fffffffLL) throw std::runtime_error("multigrid transfer operator has more than 2^31 entries");
+    std::vector<int> start((size_t)nRows + 1);
+    for (int i = 0; i <= nRows; ++i) start[i] = (int)M.off[i];
+    std::vector<T> val(M.val.begin(), M.val.end());
+    *rowStartOut = S->alloc<int>(start.size(), start.data());
+    *colOut = S->alloc<int>(M.col.size(), M.col.data());
+    *valOut = S->alloc<T>(val.size(), val.data());
 }
 
 PressureSolver* pressureSolverCreate(hipStream_t stream, const MeshView& m, const double* taubyrho, const uint8_t* bKind, int refCell,
@@ -783,8 +1230,13 @@ PressureSolver* pressureSolverCreate(hipStream_t stream, const MeshView& m, cons
         S->oc = knob("QGD_MG_OC", S->oc, 0.5, 3.0);
         S->omega = knob("QGD_MG_OMEGA", S->omega, 0.1, 1.0);
         S->coarseSweeps = (int)knob("QGD_MG_COARSE_SWEEPS", S->coarseSweeps, 1, 1000);
+        S->smootherSetup(knob("QGD_MG_CHEB", 0, 0, 1000), knob("QGD_MG_CHEB_LMAX", 2.0, 0.5, 4.0));
         // pairwise matching passes per level: 2 = aggregates of ~4 cells (3 passes = ~8 cells need twice the iterations)
-        const int passes = (int)knob("QGD_MG_PASSES", 2, 1, 4);
+        // smoothed aggregation with ~8-cell aggregates and no over-weighting, or (QGD_MG_SA=0) the plain aggregation of round 2
+        const bool sa = knob("QGD_MG_SA", 1, 0, 1) != 0;
+        const int passes = (int)knob("QGD_MG_PASSES", 2, 1, 4);                // plain aggregation: pairwise matching passes per level
+        const double saTheta = knob("QGD_MG_SA_THETA", 0.08, 0.0, 0.9);       // strength threshold on level 0, halved per level
+        if (sa) S->oc = knob("QGD_MG_OC", 1.0, 0.5, 3.0);
         const int nC = m.nC, nF = m.nF, ob = S->ob, oe = S->oe, nRows = oe - ob, nb = blocksOf(nRows);
         S->a = S->alloc<double>(nF); S->gs = S->alloc<double>(std::max(m.nBF, 1));
         S->diag = S->alloc<double>(nC); S->rhs = S->alloc<double>(nC); S->r = S->alloc<double>(nC); S->z = S->alloc<double>(nC);
@@ -821,11 +1273,46 @@ PressureSolver* pressureSolverCreate(hipStream_t stream, const MeshView& m, cons
                 if (own[f] >= ob && own[f] < oe && nei[f] >= ob && nei[f] < oe) { I.push_back(own[f] - ob); J.push_back(nei[f] - ob); w.push_back(wAll[f]); }
             std::vector<int>().swap(own); std::vector<int>().swap(nei); std::vector<double>().swap(wAll); std::vector<double>().swap(dAll);
             int n = nRows;
-            mgUploadLevel(S, n, I, J, w, diag);
-            while (n > 600 && S->L.size() < 12) {
+            mgUploadLevel(S, n, I, J, w, diag, false);
+            S->smootherScale.assign(1, 1.0);
+            while (n > (sa ? MG_DENSE_MAX : 600) && S->L.size() < 12) {
                 std::vector<int> total((size_t)n);
                 for (int i = 0; i < n; ++i) total[i] = i;
                 int cur = n;
+                if (sa) {
+                    std::vector<int64_t> off;
+                    std::vector<int> nbr;
+                    std::vector<double> nw;
+                    std::vector<uint8_t> strong;
+                    adjacencyOf(n, I, J, w, off, nbr, nw);
+                    strengthOf(n, off, nbr, nw, diag, saTheta * std::pow(0.5, (double)(S->L.size() - 1)), strong);
+                    cur = rootAggregates(n, off, nbr, nw, strong, total);
+                    if (cur >= n || cur < 1) break;
+                    // lambda_max(D^-1 A): 2 on level 0 (Gershgorin; the rows are weakly diagonally dominant), estimated below it
+                    const double lmax = 2.0 / S->smootherScale.back();
+                    HostCsr P, PT;
+                    std::vector<int> cI, cJ;
+                    std::vector<double> cw, cdiag;
+                    smoothedLevel(n, off, nbr, nw, strong, diag, total, cur, (4.0 / 3.0) / lmax, P, PT, cI, cJ, cw, cdiag);
+                    MgLevelDev& fine = S->L.back();
+                    if (S->f32) {
+                        MgLevelT<float>& ff = S->Lf.back();
+                        mgUploadEll<float>(S, n, P, &ff.pS, &ff.pCol, &ff.pVal);
+                        if (cur > 300000) { mgUploadEll<float>(S, cur, PT, &ff.ptS, &ff.ptCol, &ff.ptVal); ff.ptSliced = 1; }
+                        else mgUploadCsr<float>(S, cur, PT, &ff.ptS, &ff.ptCol, &ff.ptVal);
+                        fine.pS = ff.pS;   // marks the level; the double arrays of the levels below 0 are not used with the f32 cycle
+                    } else {
+                        mgUploadEll<double>(S, n, P, &fine.pS, &fine.pCol, &fine.pVal);
+                        if (cur > 300000) { mgUploadEll<double>(S, cur, PT, &fine.ptS, &fine.ptCol, &fine.ptVal); fine.ptSliced = 1; }
+                        else mgUploadCsr<double>(S, cur, PT, &fine.ptS, &fine.ptCol, &fine.ptVal);
+                    }
+                    I.swap(cI); J.swap(cJ); w.swap(cw); diag.swap(cdiag);
+                    n = cur;
+                    adjacencyOf(n, I, J, w, off, nbr, nw);
+                    S->smootherScale.push_back(2.0 / lambdaMaxOf(n, off, nbr, nw, diag));
+                    mgUploadLevel(S, n, I, J, w, diag, n <= MG_DENSE_MAX);
+                    continue;
+                }
                 for (int pass = 0; pass < passes && cur > 64; ++pass) {
                     std::vector<int> agg;
                     const int na = pairwisePass(cur, I, J, w, agg);
@@ -846,9 +1333,14 @@ PressureSolver* pressureSolverCreate(hipStream_t stream, const MeshView& m, cons
                 fine.aggItems = S->alloc<int>(n, items.data());
                 if (S->f32) { MgLevelT<float>& ff = S->Lf.back(); ff.agg = fine.agg; ff.aggStart = fine.aggStart; ff.aggItems = fine.aggItems; }
                 n = cur;
-                mgUploadLevel(S, n, I, J, w, diag);
+                mgUploadLevel(S, n, I, J, w, diag, n <= 600);
             }
         }
+        if (std::getenv("QGD_MG_VERBOSE"))
+            for (size_t l = 0; l < S->L.size(); ++l)
+                std::fprintf(stderr, "[qgd mg] level %zu: %d rows, widest %d, %lld stored entries (%.1f per row), smoother scale %.3f%s\n", l, S->L[l].n,
+                             S->L[l].width, S->L[l].entries, (double)S->L[l].entries / std::max(S->L[l].n, 1),
+                             l < S->smootherScale.size() ? S->smootherScale[l] : 1.0, S->L[l].pS ? ", smoothed prolongator" : "");
     } catch (...) { delete S; throw; }
     return S;
 }
@@ -984,16 +1476,16 @@ int pressureSolveRun(PressureSolver* S, const SolveHooks* hooks, double residual
 // measurement: `reps` full damped-Jacobi sweeps of multigrid level 0 (the kernel a solve spends most of its time in) between two
 // HIP events on the solver's stream; returns the average milliseconds per sweep (0 without a hierarchy).  rows / width: the ELL
 // shape of that level, for the byte model.
-double pressureSolverSweepMs(PressureSolver* S, int reps, int* rows, int* width) {
+double pressureSolverSweepMs(PressureSolver* S, int reps, int* rows, double* width) {
     if (rows) *rows = 0;
-    if (width) *width = 0;
+    if (width) *width = 0.0;
     if (S->L.empty() || reps <= 0) return 0.0;
     hipEvent_t a, b;
     PCHECK(hipEventCreate(&a)); PCHECK(hipEventCreate(&b));
     float ms = 0;
     const int nb = blocksOf(S->L[0].n);
     if (rows) *rows = S->L[0].n;
-    if (width) *width = S->L[0].width;
+    if (width) *width = (double)S->L[0].entries / std::max(1, S->L[0].n);   // stored entries per row
     if (!S->Lf.empty()) {
         MgLevelT<float>& lv = S->Lf[0];
         float* noOut = nullptr;

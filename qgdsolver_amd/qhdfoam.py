@@ -236,7 +236,7 @@ class QHDFoamCase:
         """average ms of one level-0 smoothing sweep of the pressure multigrid (HIP events), its rows, ELL width, bytes per value"""
         a = (C.c_double * 4)()
         L.check(L.lib.qgd_qhd_case_sweep_time(self._h, int(reps), a), "qgd_qhd_case_sweep_time")
-        return dict(ms=a[0], rows=int(a[1]), width=int(a[2]), value_bytes=int(a[3]))
+        return dict(ms=a[0], rows=int(a[1]), width=float(a[2]), value_bytes=int(a[3]))
 
     def halo_count(self, slot, kind):
         s, r = C.c_int64(), C.c_int64()

@@ -153,7 +153,9 @@ def test_multigrid_and_jacobi_preconditioners_agree():
         c.close()
     assert np.abs(res[0][0] - res[1][0]).max() <= 1e-9 * np.abs(res[0][0]).max()
     assert np.abs(res[0][1] - res[1][1]).max() <= 1e-9 * np.abs(res[0][1]).max()
-    assert res[1][2]["mgLevels"] >= 3 and res[1][2]["pIterations"] < res[0][2]["pIterations"] / 3
+    # 5760 cells: the smoothed-aggregation hierarchy is 5760 -> ~700 rows (solved exactly); QGD_MG_SA=0 builds >= 3 plain levels
+    assert res[1][2]["mgLevels"] >= 2, res[1][2]
+    assert res[1][2]["pIterations"] < res[0][2]["pIterations"] / 3, (res[0][2], res[1][2])
     dev.close()
 
 
