@@ -31,10 +31,11 @@ FACE_BYTES_PER_CELL = 48
 FACE_BYTES_PER_POINT = 48
 # What the kernel that is actually launched (faceFluxGvp3TileKernel) has to move at least once, in its own layout: it does not
 # stream the 80 B of Gauss coefficients but rebuilds them from gathered geometry, and it addresses its records through per-tile
-# lists of distinct labels.  Per internal face: six 16-bit list positions 12, flux position 4, kind 1, weight 8, hQGDf 8, Sf 24
-# = 57 B in, ~10 B of label lists (130 cells + 176 vertices per 128 faces on a box), 40 B out; per cell RecA 48 + RecB 32 +
+# lists of distinct labels.  Per internal face: six 16-bit list positions 12, flux position 4, kind 1, weight 8, hQGDf 8
+# = 33 B in (+ Sf 24 for triangles / polygons, or for every face with QGD_SGEO=0: quadrilaterals rebuild Sf from their staged
+# vertices), ~10 B of label lists (130 cells + 176 vertices per 128 faces on a box), 40 B out; per cell RecA 48 + RecB 32 +
 # centre 24 = 104 B; per vertex RecA 48 + coordinates 24 = 72 B.  Reported beside the SURVEY figure, never instead of it.
-OWN_BYTES_PER_FACE = 107
+OWN_BYTES_PER_FACE = 107 if os.environ.get("QGD_SGEO") == "0" else 83   # the bench box has quadrilateral faces only
 OWN_BYTES_PER_CELL = 104
 OWN_BYTES_PER_POINT = 72
 # whole explicit step, per cell-step on a hex box: vertex interp 196 + face kernel 648 + cell update 240

@@ -31,7 +31,22 @@ Snippets evaluated (listing lines of /root/reference/docs/html/<file>_source.htm
   species    reactingLagrangianQGDFoam/updateFields.H L38 (Yf), updateFluxes.H L122-127 (one species of the forAll): what
              qgd_species_flux returns
   case2cell  QGDFoam/updateFields.H L45-80, QGDFoam/updateFluxes.H L41-139 (explicit branch), constScPrModel1.C L103-114,
-             QGDCoeffs.C L305-307, with the four fvsc::grad evaluated by the gvp3d text
+             QGDCoeffs.C L305-307, with the four fvsc::grad evaluated by the gvp3d text; QGDRhoEqn.H L40-47, QGDUEqn.H L36-89,
+             QGDEEqn.H L37-76 on the two-cell mesh (explicit branch)
+  implicit2cell  the same cases with implicitDiffusion true: updateFluxes.H L95-111 / L131-135 (Pif, qf without the Navier-Stokes /
+             Fourier parts, tauMC, phiTauMC), QGDUEqn.H L36-75 and QGDEEqn.H L37-64 incl. the implicit U and e solves and phiSigmaDotU
+  gvp2d_vec  GaussVolPointBase.C L90-100 (re-pack of the per-component 2-D gradients: gradf component 3i+j = d_i U_j),
+             GaussVolPointBase2D.C L386-396 (vector divergence), L447-450 + L464-484 (tensor divergence)
+  gvp_other  GaussVolPointBase3D.C L945-948 / L976-979 (dfdn = nf * snGrad), L759-768 / L856-865 (faces with more than four vertices),
+             fvscStencil.C L126-129 (nf)
+  qgdlength  QGDCoeffs.C L195-199, L298-376 (updateQGDLength over whole small meshes: hQGDf, the area-weighted hQGD, patches)
+  courant    QGDCourantNo.H L36-53, setDeltaT-QGDQHD.H L41-61, hePsiQGDThermo.C L123-124 (speed of sound)
+  qhdclosure constTau.C L71-74, HbyUQHD.C L80-83, T0byGr.C L84-87, H2bynuQHD.C L78-82 (tauQGD of the four QHD closures)
+  casebnd    the QGDFoam flux assembly on ONE BOUNDARY face: updateFields.H L45-80 with patch values, the boundary-face text of the 3-D
+             stencil, updateFluxes.H L41-139, GaussVolPointStencil.C L73 -> qgdFluxFvPatchScalarField.C L184-192 (updateCoeffs with the
+             fresh phiwStar), constScPrModel1.C L103-104, L121-128 (patch loop)
+  qhdeqn     one whole QHDFoam step on the two-cell mesh: updateFields.H L36-73, updateFluxes.H L33-38, QHDpEqn.H L35-47, QHDUEqn.H
+             L36-43 + L46-85, QHDTEqn.H L65-66 + L69-92, QHDFoam.C L123-131 (reference level)
 
 Every configuration is ONE internal face between cells whose centres are prescribed (qgd_mesh_set_geometry /
 orc_mesh_set_geometry), so the public operators (fvsc grad, the QGDFoam case) can be run on it as they are; vertex values
