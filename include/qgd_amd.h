@@ -543,8 +543,20 @@ int qgd_case_set_stream(qgd_case_t c, void* hipStream);
  *   phase 11 = update of all remaining owned cells and patch faces;
  * halo_pack may start as soon as phase 10 is done (on the halo stream of qgd_case_set_halo_stream, ordered after the
  * compute stream by the caller), phase 11 runs meanwhile, and the next phase 0 waits for halo_unpack.
- * Ghost cells and their patch faces are written by halo_unpack only.  phase 2 is a no-op hook. */
+ * Ghost cells and their patch faces are written by halo_unpack only.  phase 2 is a no-op hook.
+ * Phase 0 itself splits when qgd_case_mid_exchange_needed says so (a shard whose GaussVolPoint stencil meets a wall with the qgdFlux
+ * pressure condition): GaussVolPoint re-evaluates p's boundary conditions inside fvsc::grad(p) [GaussVolPointStencil_8C_source.html
+ * L73 -> qgdFluxFvPatchScalarField_8C_source.html L184-192], a ghost cell's patch face forms that mid-step patch pressure from an
+ * incomplete stencil, and the vertex values of p on the wall carry it into the stencil of owned faces (1e-7 in a few cells).  So
+ *   phase 5 = the assembly up to and including that re-evaluation  -> exchange the mid message (qgd_case_mid_halo_*: 2 doubles per
+ *             patch face of the boundary-layer cells)
+ *   phase 6 = the rest of the assembly (+ the Courant reduction of phase 0).
+ * What the reference gets from the processor-patch evaluation inside correctBoundaryConditions(). */
 int qgd_case_step_phase(qgd_case_t c, int phase);
+int qgd_case_mid_exchange_needed(qgd_case_t c, int32_t* needed);
+int qgd_case_mid_halo_count(qgd_case_t c, int slot, int64_t* sendCount, int64_t* recvCount);   /* in doubles */
+int qgd_case_mid_halo_pack(qgd_case_t c, int slot, double* sendBufDevice);
+int qgd_case_mid_halo_unpack(qgd_case_t c, int slot, const double* recvBufDevice);
 int qgd_case_reduction_ptr(qgd_case_t c, void** devicePtr);
 /* Stream (hipStream_t as void*) the halo pack/unpack kernels run on; default: the case's compute stream. */
 int qgd_case_set_halo_stream(qgd_case_t c, void* hipStream);

@@ -1352,7 +1352,8 @@ struct Case {
     }
 
     // updateFluxes.H [QGDFoam/updateFluxes.H:41-139], explicit branch
-    void updateFluxes() {
+    void updateFluxes() { updateFluxesA(); updateFluxesB(); }
+    void updateFluxesA() {
         const int nF = m.nF;
         gradUf = fvscGrad(U, false);
         divUf = SurfField(m, 1);
@@ -1371,7 +1372,15 @@ struct Case {
             for (int k = 0; k < 3; ++k) rhoW.v[3 * (size_t)f + k] = tauQGDf.v[f] * ((t1[k] + (ruf[k] * divUf.v[f])) + t3[k]);
             phiw.v[f] = dot3(&m.Sf[3 * (size_t)f], &rhoW.v[3 * (size_t)f]);
         }
-        gradPf = fvscGrad(p, true);
+        // fvsc::grad(p): under GaussVolPoint p's boundary conditions first (B6) -- the qgdFlux patches read the phiwStar just formed
+        if (stencilWord == "GaussVolPoint") correctBC_p();
+    }
+    // ... and the rest of updateFluxes.H from the gradient of p on.  On a shard the patch faces of GHOST cells hold a mid-step patch
+    // pressure formed from an incomplete stencil (their far vertices lack cells): their owner's values arrive between the two halves
+    // (midHaloMove), because the vertex values of p on the wall mix them into the stencil of owned faces.
+    void updateFluxesB() {
+        const int nF = m.nF;
+        gradPf = p.nc == 1 ? stencil->gradS(p) : stencil->gradV(p);
         jm = SurfField(m, 3); phiJm = SurfField(m, 1); phi = SurfField(m, 1);
         for (int f = 0; f < nF; ++f) {
             if (!liveFace[f]) continue;
@@ -1527,6 +1536,29 @@ struct Case {
         updateFields();
         updateFluxes();
         courantLocal();
+    }
+    // phase 0 in two halves for shards that need the mid-assembly message (midNeeded)
+    void stepPhase5() { updateFields(); updateFluxesA(); }
+    void stepPhase6() { updateFluxesB(); courantLocal(); }
+    bool midNeeded() const {
+        if (m.haloGhost.empty() || stencilWord != "GaussVolPoint") return false;
+        for (const PatchBC& B : bc) if (B.bcP == BC_QGDFLUX) return true;
+        return false;
+    }
+    // the mid-step patch pressure and its gradient on the patch faces of the boundary-layer cells (2 doubles per face)
+    void midHaloCount(int side, int64_t* send, int64_t* recv) const {
+        *send = *recv = 0;
+        if (side < 0 || (size_t)side >= m.haloGhost.size()) return;
+        *send = 2 * (int64_t)m.haloSendBF[side].size(); *recv = 2 * (int64_t)m.haloGhostBF[side].size();
+    }
+    void midHaloMove(int side, double* buf, bool pack) {
+        if (side < 0 || (size_t)side >= m.haloGhost.size()) return;
+        const ivec& facesL = pack ? m.haloSendBF[side] : m.haloGhostBF[side];
+        size_t q = 0;
+        for (int b : facesL) {
+            if (pack) { buf[q++] = p.bf[b]; buf[q++] = p.grad[b]; }
+            else { p.bf[b] = buf[q++]; p.grad[b] = buf[q++]; }
+        }
     }
     void stepPhase1() {
         setDeltaT();
@@ -2695,9 +2727,14 @@ int orc_case_step_phase(void* cp, int phase) {
         if (phase == 29) c->phaseNew_ = true;
         return 0;
     }
-    if (phase == 0) c->stepPhase0(); else if (phase == 1) c->stepPhase1(); else c->stepPhase2();
+    if (phase == 0) c->stepPhase0(); else if (phase == 1) c->stepPhase1(); else if (phase == 5) c->stepPhase5(); else if (phase == 6) c->stepPhase6();
+    else c->stepPhase2();
     return 0;
 }
+int orc_case_mid_exchange_needed(void* cp) { return ((Case*)cp)->midNeeded() ? 1 : 0; }
+int orc_case_mid_halo_count(void* cp, int side, int64_t* send, int64_t* recv) { ((Case*)cp)->midHaloCount(side, send, recv); return 0; }
+int orc_case_mid_halo_pack(void* cp, int side, double* buf) { ((Case*)cp)->midHaloMove(side, buf, true); return 0; }
+int orc_case_mid_halo_unpack(void* cp, int side, const double* buf) { ((Case*)cp)->midHaloMove(side, const_cast<double*>(buf), false); return 0; }
 int orc_case_implicit_control(void* cp, double* buf68, int set) {
     Case* c = (Case*)cp;
     for (int k = 0; k < 68; ++k) { if (set) c->ictl[k] = buf68[k]; else buf68[k] = c->ictl[k]; }

@@ -114,7 +114,12 @@ int orc_case_halo_count(void* c, int side, int64_t* count);
 int orc_case_halo_recv_count(void* c, int side, int64_t* count);
 int orc_case_halo_pack(void* c, int side, double* sendBuf);
 int orc_case_halo_unpack(void* c, int side, const double* recvBuf);
-int orc_case_step_phase(void* c, int phase);   /* 0, 1, 2; implicitDiffusion on shards: 20..30, 35 as qgd_case_step_phase */
+int orc_case_step_phase(void* c, int phase);   /* 0, 1, 2; 5 + 6 = the two halves of 0; implicitDiffusion on shards: 20..30, 35 as qgd_case_step_phase */
+/* the message between phases 5 and 6 (qgd_case_mid_*): mid-step patch pressure + gradient of the boundary-layer cells' patch faces */
+int orc_case_mid_exchange_needed(void* c);
+int orc_case_mid_halo_count(void* c, int side, int64_t* send, int64_t* recv);
+int orc_case_mid_halo_pack(void* c, int side, double* buf);
+int orc_case_mid_halo_unpack(void* c, int side, const double* buf);
 int orc_case_implicit_control(void* c, double* buf68, int set);
 int orc_case_implicit_halo_count(void* c, int side, int kind, int64_t* send, int64_t* recv);
 int orc_case_implicit_halo_pack(void* c, int side, int kind, double* buf);

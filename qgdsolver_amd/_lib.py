@@ -145,6 +145,10 @@ SIGNATURES = {
                                    c_double_p, c_double_p, c_double_p]),
     "qgd_case_halo_count": (C.c_int, [handle, C.c_int, c_int64_p]),
     "qgd_case_halo_recv_count": (C.c_int, [handle, C.c_int, c_int64_p]),
+    "qgd_case_mid_exchange_needed": (C.c_int, [handle, C.POINTER(C.c_int32)]),
+    "qgd_case_mid_halo_count": (C.c_int, [handle, C.c_int, c_int64_p, c_int64_p]),
+    "qgd_case_mid_halo_pack": (C.c_int, [handle, C.c_int, C.c_void_p]),
+    "qgd_case_mid_halo_unpack": (C.c_int, [handle, C.c_int, C.c_void_p]),
     "qgd_case_halo_pack": (C.c_int, [handle, C.c_int, C.c_void_p]),
     "qgd_case_halo_unpack": (C.c_int, [handle, C.c_int, C.c_void_p]),
     "qgd_case_stream_sync": (C.c_int, [handle]),

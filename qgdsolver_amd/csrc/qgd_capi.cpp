@@ -241,6 +241,7 @@ struct qgd_case_s {
     ImplicitSolver* implSolver = nullptr;   // the two linear solves of the branch (device-scalar multi-right-hand-side PCG)
     int implSolveIndex = 0;                 // 0: the U solve is the one in flight, 1: the e solve
     std::vector<double*> implSendBuf, implRecvBuf;   // native transport of the branch's own halo messages
+    std::vector<double*> midSendBuf, midRecvBuf;     // the mid-assembly message (midExchangeOn)
     double* coef[4] = {nullptr, nullptr, nullptr, nullptr};  // device copies of non-uniform alphaQGD / ScQGD (cells, patch faces)
     double time = 0;
     int64_t steps = 0;
@@ -1262,25 +1263,29 @@ int qgd_case_set_qgd_coeffs(qgd_case_t c, const double* alphaQGD, const double* 
     QGD_CATCH
 }
 
-// one flux-assembly pass (updateFields.H + updateFluxes.H) on the current state
-static void assembleFluxes(qgd_case_s* c, bool adjust) {
+// one flux-assembly pass (updateFields.H + updateFluxes.H) on the current state; part 0 = all of it, 1 = up to p's mid-step boundary
+// conditions, 2 = the rest.  A shard whose GaussVolPoint stencil meets a qgdFlux wall exchanges the mid-step patch pressure of the
+// boundary layer's patch faces between 1 and 2 (midExchangeNeeded): a ghost cell's patch face forms it from an incomplete stencil, and the
+// vertex values of p on the wall carry it into the stencil of owned faces.
+static void assembleFluxes(qgd_case_s* c, bool adjust, int part = 0) {
     (void)hipGetLastError();  // drop any stale sticky error: the callers check after their launches
     const Launcher L = launcherOf(c);
     const MeshView& m = c->dev->view;
     const CaseView& v = c->view;
-    if (c->usesPoints) {
+    const bool mid = c->usesPoints && c->hasQgdFlux;
+    if (part != 2 && c->usesPoints) {
         launchPointInterp(L, m, v);
         launchBoundaryPoints(L, m, v, false);
-        if (c->hasQgdFlux) {
-            // fvsc::grad(p) under GaussVolPoint re-runs p's BCs after phiwStar was refreshed
-            // [QGDFoam/updateFluxes.H L63-65, GaussVolPointStencil_8C L73]
-            launchBoundaryFaceFlux(L, c->stencil, m, v, c->gas, c->bcDev, 1, false);  // + the mid-step pressure itself
-            launchBoundaryPoints(L, m, v, true);
-        }
+        // fvsc::grad(p) under GaussVolPoint re-runs p's BCs after phiwStar was refreshed
+        // [QGDFoam/updateFluxes.H L63-65, GaussVolPointStencil_8C L73]
+        if (mid) launchBoundaryFaceFlux(L, c->stencil, m, v, c->gas, c->bcDev, 1, false);  // + the mid-step pressure itself
     }
+    if (part == 1) return;
+    if (mid) launchBoundaryPoints(L, m, v, true);
     launchFaceFlux(L, c->stencil, m, v, c->gas, adjust);
-    launchBoundaryFaceFlux(L, c->stencil, m, v, c->gas, c->bcDev, (c->usesPoints && c->hasQgdFlux) ? 2 : 0, adjust);
+    launchBoundaryFaceFlux(L, c->stencil, m, v, c->gas, c->bcDev, mid ? 2 : 0, adjust);
 }
+static bool midExchangeNeeded(const qgd_case_s* c) { return c->dev->sharded() && c->usesPoints && c->hasQgdFlux; }
 
 int qgd_case_set_fields(qgd_case_t c, const double* U, const double* T, const double* p) {
     QGD_TRY
@@ -1338,10 +1343,10 @@ int qgd_case_update_fluxes(qgd_case_t c) {
 
 // phase 0: flux assembly (+ the shard's max Cof / min tauQGDf into red[0], -red[1]);
 // phase 1: deltaT, cell update, boundary refresh
-static void stepAssemble(qgd_case_s* c) {
+static void stepAssemble(qgd_case_s* c, int part = 0) {
     const bool adjust = c->opt.adjustTimeStep != 0;
-    assembleFluxes(c, adjust);
-    if (adjust) launchFaceReduce(launcherOf(c), c->view);
+    assembleFluxes(c, adjust, part);
+    if (adjust && part != 1) launchFaceReduce(launcherOf(c), c->view);
 }
 // ---- the implicitDiffusion branch [QGDUEqn.H L54-75, QGDEEqn.H L53-64] as stream-ordered phases ---------------------------------
 //   20  deltaT, fvc::grad(U) of the old state                                -> message kind 1
@@ -1467,10 +1472,12 @@ int qgd_case_step_phase(qgd_case_t c, int phase) {
         return fail(QGD_ERR_INVALID, "qgd_case_step_phase: on a shard the implicitDiffusion branch advances through phases 20..35 with the "
                                      "exchanges between them");
     if (phase == 0) stepAssemble(c);
+    else if (phase == 5) stepAssemble(c, 1);
+    else if (phase == 6) stepAssemble(c, 2);
     else if (phase == 1) stepAdvance(c, 0);
     else if (phase == 10) stepAdvance(c, 1);
     else if (phase == 11) stepAdvance(c, 2);
-    else if (phase != 2) return fail(QGD_ERR_INVALID, "qgd_case_step_phase: phase must be 0, 1, 2, 10 or 11");
+    else if (phase != 2) return fail(QGD_ERR_INVALID, "qgd_case_step_phase: phase must be 0, 1, 2, 5, 6, 10 or 11");
     HIP_CHECK(hipGetLastError());
     return QGD_OK;  // asynchronous: qgd_case_stream_sync waits
     QGD_CATCH
@@ -1569,6 +1576,47 @@ int qgd_case_halo_unpack(qgd_case_t c, int slot, const double* recvBufDevice) {
     launchHaloPack(L, c->view, h.ghost, h.nGhost, h.ghostBF, h.nGhostBF, const_cast<double*>(recvBufDevice), false);
     HIP_CHECK(hipGetLastError());
     return QGD_OK;
+    QGD_CATCH
+}
+
+// the message between step phases 5 and 6 (see assembleFluxes): 2 doubles per patch face of the slot's boundary-layer cells
+int qgd_case_mid_exchange_needed(qgd_case_t c, int32_t* needed) {
+    if (!c || !needed) return fail(QGD_ERR_INVALID, "bad argument");
+    *needed = midExchangeNeeded(c) ? 1 : 0;
+    return QGD_OK;
+}
+int qgd_case_mid_halo_count(qgd_case_t c, int slot, int64_t* sendCount, int64_t* recvCount) {
+    if (!c || slot < 0 || !sendCount || !recvCount) return fail(QGD_ERR_INVALID, "bad argument");
+    *sendCount = *recvCount = 0;
+    if (slot >= (int)c->dev->halo.size()) return QGD_OK;
+    *sendCount = 2 * (int64_t)c->dev->halo[slot].nSendBF;
+    *recvCount = 2 * (int64_t)c->dev->halo[slot].nGhostBF;
+    return QGD_OK;
+}
+static int midHaloMove(qgd_case_s* c, int slot, double* buf, bool pack, hipStream_t stream) {
+    qgd_device_s* d = c->dev;
+    if (slot >= (int)d->halo.size()) return QGD_OK;
+    const qgd_device_s::HaloSlot& h = d->halo[slot];
+    const int32_t n = pack ? h.nSendBF : h.nGhostBF;
+    if (n == 0) return QGD_OK;
+    if (!buf) return fail(QGD_ERR_INVALID, "null buffer");
+    (void)hipGetLastError();
+    launchMidHalo(stream, c->view, pack ? h.sendBF : h.ghostBF, n, buf, pack);
+    HIP_CHECK(hipGetLastError());
+    return QGD_OK;
+}
+int qgd_case_mid_halo_pack(qgd_case_t c, int slot, double* sendBufDevice) {
+    QGD_TRY
+    if (!c || slot < 0) return fail(QGD_ERR_INVALID, "bad argument");
+    HIP_CHECK(hipSetDevice(c->dev->deviceId));
+    return midHaloMove(c, slot, sendBufDevice, true, c->stream());
+    QGD_CATCH
+}
+int qgd_case_mid_halo_unpack(qgd_case_t c, int slot, const double* recvBufDevice) {
+    QGD_TRY
+    if (!c || slot < 0) return fail(QGD_ERR_INVALID, "bad argument");
+    HIP_CHECK(hipSetDevice(c->dev->deviceId));
+    return midHaloMove(c, slot, const_cast<double*>(recvBufDevice), false, c->stream());
     QGD_CATCH
 }
 
@@ -2128,6 +2176,34 @@ static void implHaloExchangeOn(qgd_case_s* c, qgd_comm_s* comm, const int32_t* p
     for (int s2 = 0; s2 < n; ++s2)
         if (peers[s2] >= 0 && implHaloMove(c, s2, kind, c->implRecvBuf[s2], false, stream) != QGD_OK) throw std::invalid_argument(g_lastError);
 }
+// the mid-assembly message over the library's transport, on the case's stream
+static void midExchangeOn(qgd_case_s* c, qgd_comm_s* comm, const int32_t* peers, int nSlots) {
+    qgd_device_s* d = c->dev;
+    const int n = std::min<int>(nSlots, (int)d->halo.size());
+    if (c->midSendBuf.size() != d->halo.size()) {
+        c->midSendBuf.assign(d->halo.size(), nullptr);
+        c->midRecvBuf.assign(d->halo.size(), nullptr);
+        for (size_t s2 = 0; s2 < d->halo.size(); ++s2) {
+            c->midSendBuf[s2] = c->arena.alloc<double>(2 * (size_t)d->halo[s2].nSendBF);
+            c->midRecvBuf[s2] = c->arena.alloc<double>(2 * (size_t)d->halo[s2].nGhostBF);
+        }
+    }
+    hipStream_t stream = c->stream();
+    for (int s2 = 0; s2 < n; ++s2)
+        if (peers[s2] >= 0 && midHaloMove(c, s2, c->midSendBuf[s2], true, stream) != QGD_OK) throw std::invalid_argument(g_lastError);
+    RCCL_CHECK(rcclRef().groupStart());
+    try {
+        for (int s2 = 0; s2 < n; ++s2) {
+            const qgd_device_s::HaloSlot& h = d->halo[s2];
+            if (peers[s2] < 0) continue;
+            if (h.nSendBF) RCCL_CHECK(rcclRef().send(c->midSendBuf[s2], 2 * (size_t)h.nSendBF, ncclFloat64, peers[s2], comm->comm, stream));
+            if (h.nGhostBF) RCCL_CHECK(rcclRef().recv(c->midRecvBuf[s2], 2 * (size_t)h.nGhostBF, ncclFloat64, peers[s2], comm->comm, stream));
+        }
+    } catch (...) { (void)rcclRef().groupEnd(); throw; }
+    RCCL_CHECK(rcclRef().groupEnd());
+    for (int s2 = 0; s2 < n; ++s2)
+        if (peers[s2] >= 0 && midHaloMove(c, s2, c->midRecvBuf[s2], false, stream) != QGD_OK) throw std::invalid_argument(g_lastError);
+}
 int qgd_case_step_sharded(qgd_case_t c, qgd_comm_t comm, const int32_t* peers, int nSlots, int overlapped) {
     QGD_TRY
     if (!c) return fail(QGD_ERR_INVALID, "null case");
@@ -2136,7 +2212,13 @@ int qgd_case_step_sharded(qgd_case_t c, qgd_comm_t comm, const int32_t* peers, i
     if (sharded && (!comm || !peers)) return fail(QGD_ERR_INVALID, "qgd_case_step_sharded: null argument");
     HIP_CHECK(hipSetDevice(c->dev->deviceId));
     const bool adjust = c->opt.adjustTimeStep != 0;
-    stepAssemble(c);
+    if (sharded && midExchangeNeeded(c)) {
+        for (int a = 0; a < std::min<int>(nSlots, (int)c->dev->halo.size()); ++a)
+            if (peers[a] >= comm->nRanks) return fail(QGD_ERR_INVALID, "qgd_case_step_sharded: peer rank out of range");
+        stepAssemble(c, 1);
+        midExchangeOn(c, comm, peers, nSlots);
+        stepAssemble(c, 2);
+    } else stepAssemble(c);
     if (adjust && comm && comm->nRanks > 1)
         RCCL_CHECK(rcclRef().allReduce(c->view.red, c->view.red, 2, ncclFloat64, ncclMax, comm->comm, c->stream()));
     if (!sharded) { stepAdvance(c, 0); HIP_CHECK(hipGetLastError()); return QGD_OK; }

@@ -127,6 +127,7 @@ int bfaceBlocks(const MeshView& m);
 int cellBlocks(const MeshView& m);
 void launchHaloPack(const Launcher& L, const CaseView& c, const int32_t* cells, int32_t nCells, const int32_t* bfaces,
                     int32_t nFaces, double* buf, bool pack);
+void launchMidHalo(hipStream_t s, const CaseView& c, const int32_t* bfaces, int32_t n, double* buf, bool pack);
 
 // ---- accessor: one named cell / patch field out of the records (K == nullptr on patches) ----------------------------
 enum ExtractField : int { XF_RHO = 0, XF_U, XF_P, XF_E, XF_T, XF_RHOU, XF_RHOE, XF_C, XF_PSI, XF_MU, XF_ALPHAU, XF_TAUQGD, XF_MUQGD,

@@ -1465,6 +1465,18 @@ void launchCellMinReduce(const Launcher& L, const CaseView& c) { cellMinReduceKe
 int faceBlocks(const MeshView& m) { return (m.nIF + 63) / 64; }
 int bfaceBlocks(const MeshView& m) { return gridFor(m.nBF); }
 int cellBlocks(const MeshView& m) { return (m.nC + 63) / 64; }  // slots laid out for the smallest cell tile
+// the message in the middle of the flux assembly: mid-step patch pressure and qgdFlux gradient of patch faces (2 doubles each)
+__global__ __launch_bounds__(QGD_BLOCK) void midHaloKernel(const CaseView c, const int32_t* __restrict__ bfaces, const int n,
+                                                          double* __restrict__ buf, const int pack) {
+    const int i = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int b = bfaces[i];
+    if (pack) { buf[2 * (size_t)i] = c.bPmid[b]; buf[2 * (size_t)i + 1] = c.bG[b]; }
+    else { c.bPmid[b] = buf[2 * (size_t)i]; c.bG[b] = buf[2 * (size_t)i + 1]; }
+}
+void launchMidHalo(hipStream_t s, const CaseView& c, const int32_t* bfaces, int32_t n, double* buf, bool pack) {
+    if (n > 0) midHaloKernel<<<gridFor(n), QGD_BLOCK, 0, s>>>(c, bfaces, n, buf, pack ? 1 : 0);
+}
 void launchHaloPack(const Launcher& L, const CaseView& c, const int32_t* cells, int32_t nCells, const int32_t* bfaces,
                     int32_t nFaces, double* buf, bool pack) {
     const int n = nCells + nFaces;

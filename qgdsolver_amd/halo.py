@@ -31,28 +31,54 @@ class SlabHalo:
             peers = {0: rank - 1, 1: rank + 1}
         self.peer = dict(peers)
         self.sides = [s for s, peer in sorted(self.peer.items()) if 0 <= peer < world]
+        self._alloc = alloc
         self.send = {s: alloc(case.halo_count(s)) for s in self.sides}
         self.recv = {s: alloc(case.halo_recv_count(s)) for s in self.sides}
 
-    def exchange(self):
+    def _buffers(self, mid):
+        """(send, recv, pack, unpack) of the state message or of the mid-assembly message (2 doubles per patch face of the boundary layer)"""
+        if not mid:
+            return self.send, self.recv, self.case.halo_pack, self.case.halo_unpack
+        if getattr(self, "_mid", None) is None:
+            counts = {s: self.case.mid_halo_count(s) for s in self.sides}
+            self._mid = ({s: self._alloc(max(counts[s][0], 1))[:counts[s][0]] for s in self.sides},
+                         {s: self._alloc(max(counts[s][1], 1))[:counts[s][1]] for s in self.sides})
+        return self._mid[0], self._mid[1], self.case.mid_halo_pack, self.case.mid_halo_unpack
+
+    def exchange(self, mid=False):
         if not self.sides:
             return
+        send, recv, pack, unpack = self._buffers(mid)
         for s in self.sides:
-            self.case.halo_pack(s, self.arg(self.send[s]))
+            if len(send[s]):
+                pack(s, self.arg(send[s]))
         ops = []
         for s in self.sides:
-            ops.append(self.dist.P2POp(self.dist.isend, self.send[s], self.peer[s]))
-            ops.append(self.dist.P2POp(self.dist.irecv, self.recv[s], self.peer[s]))
-        for w in self.dist.batch_isend_irecv(ops):
-            w.wait()
+            if len(send[s]):
+                ops.append(self.dist.P2POp(self.dist.isend, send[s], self.peer[s]))
+            if len(recv[s]):
+                ops.append(self.dist.P2POp(self.dist.irecv, recv[s], self.peer[s]))
+        if ops:
+            for w in self.dist.batch_isend_irecv(ops):
+                w.wait()
         for s in self.sides:
-            self.case.halo_unpack(s, self.arg(self.recv[s]))
+            if len(recv[s]):
+                unpack(s, self.arg(recv[s]))
 
+    def assemble(self):
+        """step phase 0 -- in two halves with the mid-assembly message between them when the case asks for it (a GaussVolPoint
+        shard that meets a qgdFlux wall: include/qgd_amd.h)"""
+        if self.case.needs_mid_exchange():
+            self.case.step_phase(5)
+            self.exchange(mid=True)
+            self.case.step_phase(6)
+        else:
+            self.case.step_phase(0)
 
     def step(self, allreduce_max=None):
         """One sharded step: assemble, (adjustTimeStep: MAX all-reduce of the 2-double reduction buffer through
         ``allreduce_max(case)``), advance, halo exchange, post-exchange refresh."""
-        self.case.step_phase(0)
+        self.assemble()
         if allreduce_max is not None:
             allreduce_max(self.case)
         self.case.step_phase(1)
@@ -69,7 +95,7 @@ class SlabHalo:
             # pack/unpack must be enqueued on the stream the RCCL transfer is ordered against
             self.case.set_halo_stream(halo_stream.cuda_stream)
             self._halo_stream = halo_stream
-        self.case.step_phase(0)
+        self.assemble()
         self.case.step_phase(10)
         halo_stream.wait_stream(compute_stream)
         with torch.cuda.stream(halo_stream):
@@ -114,26 +140,33 @@ class HostStaged:
 
     torch = None
 
-    def exchange(self):
+    def exchange(self, mid=False):
         if not self.sides:
             return
         torch = self.torch
-        dev_s = {s: torch.empty(self.send[s].numel(), dtype=torch.float64, device="cuda") for s in self.sides}
-        dev_r = {s: torch.empty(self.recv[s].numel(), dtype=torch.float64, device="cuda") for s in self.sides}
+        send, recv, pack, unpack = self._buffers(mid)
+        dev_s = {s: torch.empty(max(send[s].numel(), 1), dtype=torch.float64, device="cuda") for s in self.sides}
+        dev_r = {s: torch.empty(max(recv[s].numel(), 1), dtype=torch.float64, device="cuda") for s in self.sides}
         for s in self.sides:
-            self.case.halo_pack(s, dev_s[s].data_ptr())
+            if send[s].numel():
+                pack(s, dev_s[s].data_ptr())
         torch.cuda.synchronize()
         for s in self.sides:
-            self.send[s].copy_(dev_s[s])
+            if send[s].numel():
+                send[s].copy_(dev_s[s][:send[s].numel()])
         ops = []
         for s in self.sides:
-            ops.append(self.dist.P2POp(self.dist.isend, self.send[s], self.peer[s]))
-            ops.append(self.dist.P2POp(self.dist.irecv, self.recv[s], self.peer[s]))
-        for w in self.dist.batch_isend_irecv(ops):
-            w.wait()
+            if send[s].numel():
+                ops.append(self.dist.P2POp(self.dist.isend, send[s], self.peer[s]))
+            if recv[s].numel():
+                ops.append(self.dist.P2POp(self.dist.irecv, recv[s], self.peer[s]))
+        if ops:
+            for w in self.dist.batch_isend_irecv(ops):
+                w.wait()
         for s in self.sides:
-            dev_r[s].copy_(self.recv[s])
-            self.case.halo_unpack(s, dev_r[s].data_ptr())
+            if recv[s].numel():
+                dev_r[s][:recv[s].numel()].copy_(recv[s])
+                unpack(s, dev_r[s].data_ptr())
         torch.cuda.synchronize()
 
 
@@ -243,6 +276,8 @@ class LocalWorld:
 
     def __init__(self, cases, peers, kinds=(0, 1, 2)):
         self.cases, self.peers = list(cases), [list(p) for p in peers]
+        if self.needs_mid():
+            kinds = tuple(kinds) + (IMPL_MID,)
         self.buf = {}
         for r, case in enumerate(self.cases):
             for slot, peer in enumerate(self.peers[r]):
@@ -250,6 +285,9 @@ class LocalWorld:
                     continue
                 n = max(case.halo_count(slot, kind)[0] for kind in kinds)
                 self.buf[(r, slot)] = case.halo_buffer(n)
+
+    def needs_mid(self):
+        return any(getattr(c, "needs_mid_exchange", lambda: False)() for c in self.cases)
 
     def phase(self, k):
         for c in self.cases:
@@ -290,8 +328,13 @@ class DistWorld:
         self.case, self.dist, self.torch, self.peers = case, dist, torch, list(peers)
         self.to_transport, self.from_transport = to_transport, from_transport
         self.slots = [s for s, p in enumerate(self.peers) if p >= 0]
+        if self.needs_mid():
+            kinds = tuple(kinds) + (IMPL_MID,)
         self.sbuf = {s: case.halo_buffer(max(case.halo_count(s, k)[0] for k in kinds)) for s in self.slots}
         self.rbuf = {s: case.halo_buffer(max(case.halo_count(s, k)[1] for k in kinds)) for s in self.slots}
+
+    def needs_mid(self):
+        return getattr(self.case, "needs_mid_exchange", lambda: False)()
 
     def phase(self, k):
         self.case.step_phase(k)
@@ -334,6 +377,7 @@ class DistWorld:
 # control-block ranges (slot-major, 4 components per slot) that are global sums, by SOLVER phase 0..4
 IMPL_REDUCE_AFTER_SOLVER_PHASE = {0: (0, 12), 1: (12, 4), 2: (16, 4), 3: (20, 4), 4: (24, 8)}
 IMPL_STATE, IMPL_GRADU, IMPL_U, IMPL_DIRECTION, IMPL_GUESS = 0, 1, 2, 3, 4   # message kinds (0: the case's own state message)
+IMPL_MID = 5   # the message in the middle of the flux assembly (qgd_case_mid_halo_*)
 
 
 class ImplicitShard:
@@ -362,20 +406,29 @@ class ImplicitShard:
     def halo_buffer(self, n):
         return self.case.halo_buffer(n)
 
+    def needs_mid_exchange(self):
+        return self.case.needs_mid_exchange()
+
     def halo_count(self, slot, kind):
         if kind == IMPL_STATE:
             return self.case.halo_count(slot), self.case.halo_recv_count(slot)
+        if kind == IMPL_MID:
+            return self.case.mid_halo_count(slot)
         return self.case.implicit_halo_count(slot, kind)
 
     def halo_pack(self, slot, kind, buf):
         if kind == IMPL_STATE:
             self.case.halo_pack(slot, buf)
+        elif kind == IMPL_MID:
+            self.case.mid_halo_pack(slot, buf)
         else:
             self.case.implicit_halo_pack(slot, kind, buf)
 
     def halo_unpack(self, slot, kind, buf):
         if kind == IMPL_STATE:
             self.case.halo_unpack(slot, buf)
+        elif kind == IMPL_MID:
+            self.case.mid_halo_unpack(slot, buf)
         else:
             self.case.implicit_halo_unpack(slot, kind, buf)
 
@@ -410,7 +463,12 @@ class ImplicitStepper:
             w.phase(2)
             self.started = True
         for _ in range(n):
-            w.phase(0)
+            if w.needs_mid():          # GaussVolPoint shards meeting a qgdFlux wall: the assembly in two halves
+                w.phase(5)
+                w.exchange(IMPL_MID)
+                w.phase(6)
+            else:
+                w.phase(0)
             w.phase(20)
             w.exchange(IMPL_GRADU)
             w.phase(21)

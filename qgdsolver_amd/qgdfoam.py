@@ -189,6 +189,23 @@ class QGDFoamCase:
         L.check(L.lib.qgd_case_implicit_solve_status(self._h, a), "qgd_case_implicit_solve_status")
         return a[0] != 0.0
 
+    # ---- the message in the middle of the flux assembly (step phases 5 | 6 instead of 0; include/qgd_amd.h) ----
+    def needs_mid_exchange(self):
+        n = C.c_int32()
+        L.check(L.lib.qgd_case_mid_exchange_needed(self._h, C.byref(n)), "qgd_case_mid_exchange_needed")
+        return bool(n.value)
+
+    def mid_halo_count(self, slot):
+        s, r = C.c_int64(), C.c_int64()
+        L.check(L.lib.qgd_case_mid_halo_count(self._h, int(slot), C.byref(s), C.byref(r)), "qgd_case_mid_halo_count")
+        return s.value, r.value
+
+    def mid_halo_pack(self, slot, dev_ptr):
+        L.check(L.lib.qgd_case_mid_halo_pack(self._h, int(slot), C.c_void_p(dev_ptr)), "qgd_case_mid_halo_pack")
+
+    def mid_halo_unpack(self, slot, dev_ptr):
+        L.check(L.lib.qgd_case_mid_halo_unpack(self._h, int(slot), C.c_void_p(dev_ptr)), "qgd_case_mid_halo_unpack")
+
     def implicit_halo_count(self, slot, kind):
         s, r = C.c_int64(), C.c_int64()
         L.check(L.lib.qgd_case_implicit_halo_count(self._h, int(slot), int(kind), C.byref(s), C.byref(r)), "qgd_case_implicit_halo_count")

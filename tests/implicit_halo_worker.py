@@ -17,13 +17,13 @@ def main():
 
     from qgdsolver_amd.halo import DistWorld, ImplicitShard, ImplicitStepper
     import cases
-    from test_implicit_sharded import cut_mesh, oracle_shard_case, range_bcs
+    from test_implicit_sharded import cut_mesh, oracle_shard_case, mixed_bcs
 
     dist.init_process_group(backend="gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     g, shards = cut_mesh("ranges", world)
     sh = shards[rank]
-    case = oracle_shard_case(sh, range_bcs, cases.box_initial_fields(g.array("C").reshape(-1, 3)))
+    case = oracle_shard_case(sh, mixed_bcs, cases.box_initial_fields(g.array("C").reshape(-1, 3)))
     to_t = lambda buf, n: torch.from_numpy(buf[:n])           # noqa: E731
     from_t = lambda t, buf: None                              # noqa: E731
     ImplicitStepper(DistWorld(ImplicitShard(case), dist, torch, sh["peers"], to_t, from_t, kinds=range(5))).step(steps)

@@ -65,6 +65,10 @@ lib.orc_case_implicit_control.argtypes = [C.c_void_p, dp, C.c_int]
 lib.orc_case_implicit_halo_count.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
 lib.orc_case_implicit_halo_pack.argtypes = [C.c_void_p, C.c_int, C.c_int, dp]
 lib.orc_case_implicit_halo_unpack.argtypes = [C.c_void_p, C.c_int, C.c_int, dp]
+lib.orc_case_mid_exchange_needed.argtypes = [C.c_void_p]
+lib.orc_case_mid_halo_count.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+lib.orc_case_mid_halo_pack.argtypes = [C.c_void_p, C.c_int, dp]
+lib.orc_case_mid_halo_unpack.argtypes = [C.c_void_p, C.c_int, dp]
 
 class QhdOptions(C.Structure):
     """orc_qhd_options == qgd_qhd_options"""
@@ -280,6 +284,21 @@ class OracleCase:
 
     def halo_unpack(self, side, buf):
         lib.orc_case_halo_unpack(self._h, side, _d(buf))
+
+    # ---- the message in the middle of the flux assembly (phases 5 | 6 instead of 0), names as in qgdsolver_amd.qgdfoam.QGDFoamCase
+    def needs_mid_exchange(self):
+        return bool(lib.orc_case_mid_exchange_needed(self._h))
+
+    def mid_halo_count(self, slot):
+        s, r = C.c_int64(), C.c_int64()
+        lib.orc_case_mid_halo_count(self._h, int(slot), C.byref(s), C.byref(r))
+        return s.value, r.value
+
+    def mid_halo_pack(self, slot, buf):
+        lib.orc_case_mid_halo_pack(self._h, int(slot), _d(buf))
+
+    def mid_halo_unpack(self, slot, buf):
+        lib.orc_case_mid_halo_unpack(self._h, int(slot), _d(buf))
 
     # ---- the implicitDiffusion branch on shards: same names as qgdsolver_amd.qgdfoam.QGDFoamCase ------------------------
     def implicit_control(self):

@@ -65,19 +65,9 @@ def test_oracle_phases_are_the_oracle_step(kind):
 CUTS = [("slabs", 2), ("slabs", 3), ("ranges", 3)]
 
 
-def range_bcs(case):
-    """mixed_bcs without the qgdFlux pressure condition: on a cell-range cut that meets a qgdFlux wall, GaussVolPoint's re-evaluation
-    of p's boundary conditions inside fvsc::grad(p) (reference quirk B6) reaches, through the wall's boundary points, patch faces of
-    ghost cells whose own stencil is incomplete -- a 1e-8 effect in a few corner cells that the explicit branch shares (DESIGN.md,
-    multi-GPU, known limitation); the slab cuts above keep qgdFlux walls"""
-    case.set_bc(0, U=("fixedValue", (0.1, 0.0, 0.0)), T=("fixedValue", 1.05), p=("zeroGradient", None))
-    case.set_bc(1, U=("zeroGradient", None), T=("zeroGradient", None), p=("fixedValue", 1.0))
-    case.set_bc(2, U=("slip", None), T=("zeroGradient", None), p=("zeroGradient", None))
-    case.set_bc(3, U=("slip", None), T=("zeroGradient", None), p=("zeroGradient", None))
-
-
 def bcs_of(cut):
-    return range_bcs if cut == "ranges" else mixed_bcs
+    """qgdFlux walls on every cut: the range cut of the RCM-ordered mesh needs the mid-assembly message (include/qgd_amd.h, phases 5 | 6)"""
+    return mixed_bcs
 
 
 def cut_mesh(cut, world):
@@ -111,7 +101,7 @@ def test_sharded_oracle_over_gloo(tmp_path, world):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     g, _ = cut_mesh("ranges", world)
-    ref = run_unsharded_oracle(g, range_bcs, cases.box_initial_fields(g.array("C").reshape(-1, 3)), steps)
+    ref = run_unsharded_oracle(g, mixed_bcs, cases.box_initial_fields(g.array("C").reshape(-1, 3)), steps)
     covered = 0
     for rank in range(world):
         d = np.load(os.path.join(tmp_path, f"rank{rank}.npz"))

@@ -6,7 +6,7 @@ import pytest
 
 import qgdsolver_amd as q
 import cases
-from test_partition import mixed_bcs, random_perm, run_oracle
+from test_partition import mixed_bcs, random_perm, rcm_poly_mesh, run_oracle
 from util import make_mesh
 
 pytestmark = pytest.mark.gpu
@@ -54,10 +54,33 @@ def run_sharded_device(g, world, stencil, bc_fn, U, T, p, steps, overlapped=Fals
             c.step_phase(2)
             c.sync()
 
+    mid = {}
+    if cs[0].needs_mid_exchange():
+        for r, (s, c, d) in enumerate(zip(shards, cs, devs)):
+            for k, peer in enumerate(s.array("haloPeer")):
+                mid[(r, int(peer))] = d.alloc(8 * max(1, c.mid_halo_count(k)[0]))
+
+    def exchange_mid():
+        for r, (s, c) in enumerate(zip(shards, cs)):
+            for k, peer in enumerate(s.array("haloPeer")):
+                c.mid_halo_pack(k, mid[(r, int(peer))])
+            c.sync()
+        for r, (s, c) in enumerate(zip(shards, cs)):
+            for k, peer in enumerate(s.array("haloPeer")):
+                c.mid_halo_unpack(k, mid[(int(peer), r)])
+            c.sync()
+
     exchange()
     for _ in range(steps):
-        for c in cs:
-            c.step_phase(0)
+        if mid:
+            for c in cs:
+                c.step_phase(5)
+            exchange_mid()
+            for c in cs:
+                c.step_phase(6)
+        else:
+            for c in cs:
+                c.step_phase(0)
         if overlapped:  # boundary layer first, exchange, then the rest: same result as the plain order
             for c in cs:
                 c.step_phase(10)
@@ -83,12 +106,14 @@ def run_sharded_device(g, world, stencil, bc_fn, U, T, p, steps, overlapped=Fals
 @pytest.mark.parametrize("kind,stencil,world,bc_fn,opt,overlapped", [
     ("box654_poly", "GaussVolPoint", 3, mixed_bcs, dict(deltaT=1e-3, mu=1e-3), False),
     ("box654_poly", "GaussVolPoint", 3, mixed_bcs, dict(deltaT=1e-3, mu=1e-3), True),
+    ("box654_poly_rcm", "GaussVolPoint", 3, mixed_bcs, dict(deltaT=1e-3, mu=1e-3), False),
+    ("box654_poly_rcm", "GaussVolPoint", 3, mixed_bcs, dict(deltaT=1e-3, mu=1e-3), True),
     ("box654_jitter", "reduced", 2, mixed_bcs, dict(deltaT=1e-3), False),
     ("step2d", "leastSquares", 4, cases.forward_step_bcs, dict(deltaT=5e-4), True),
     ("step2d", "GaussVolPoint", 3, cases.forward_step_bcs, dict(deltaT=5e-4), False),
 ])
 def test_sharded_device_matches_unsharded_and_oracle(kind, stencil, world, bc_fn, opt, overlapped):
-    g = make_mesh(kind)
+    g = rcm_poly_mesh() if kind == "box654_poly_rcm" else make_mesh(kind)
     if kind == "box654_poly":
         g.renumber(random_perm(g.nCells, 21))
     C = g.array("C").reshape(-1, 3)
