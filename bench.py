@@ -85,27 +85,33 @@ def _cpu_rank_worker(n, steps, sync_dir, idx):
     U, T, p = cases.box_initial_fields(mesh.array("C").reshape(-1, 3))
     oc.set_fields(U, T, p)
     oc.step(1)
-    open(os.path.join(sync_dir, f"ready{idx}"), "w").close()
-    go = os.path.join(sync_dir, "go")
-    t_wait = time.time()
-    while not os.path.exists(go):
-        if time.time() - t_wait > 300:
-            sys.exit(3)
-        time.sleep(0.005)
+
+    def barrier(tag):
+        """all ranks enter a timed region together: ready file, then wait for the parent's go file"""
+        open(os.path.join(sync_dir, f"ready{tag}_{idx}"), "w").close()
+        go = os.path.join(sync_dir, f"go{tag}")
+        t_wait = time.time()
+        while not os.path.exists(go):
+            if time.time() - t_wait > 600:
+                sys.exit(3)
+            time.sleep(0.005)
+
+    barrier("a")
     t0 = time.perf_counter()
     oc.step(steps)
     print(f"CPU_RANK_SECONDS {time.perf_counter() - t0:.6f}", flush=True)
+    # the same steps with the flux assembly fused (one vertex pass + one face pass, seven face fields stored: oracle/qgd_oracle.cpp
+    # updateFluxesFused, same arithmetic -- tests/test_oracle_fused.py): what a CPU code organised for speed does with these formulas
+    barrier("f")
+    t0 = time.perf_counter()
+    ok = oc.step_fused(steps)
+    print(f"CPU_RANK_FUSED_SECONDS {(time.perf_counter() - t0) if ok else -1.0:.6f}", flush=True)
     # host-bandwidth yardstick on the same cores, all ranks at once: STREAM triad over 3 x 256 MB per rank
     import oracle as orc
     m = 32 * 1024 * 1024
     a, b, c = np.zeros(m), np.ones(m), np.full(m, 2.0)
     orc.lib.orc_stream_triad(orc._d(a), orc._d(b), orc._d(c), 3.0, m, 1)
-    open(os.path.join(sync_dir, f"ready2_{idx}"), "w").close()
-    t_wait = time.time()
-    while not os.path.exists(os.path.join(sync_dir, "go2")):
-        if time.time() - t_wait > 300:
-            sys.exit(3)
-        time.sleep(0.005)
+    barrier("t")
     reps = 10
     t0 = time.perf_counter()
     orc.lib.orc_stream_triad(orc._d(a), orc._d(b), orc._d(c), 3.0, m, reps)
@@ -154,24 +160,22 @@ def cpu_baseline(n, steps, ranks):
     with tempfile.TemporaryDirectory() as sync_dir:
         procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-rank-worker", str(n), str(steps), sync_dir, str(i)],
                                   stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env) for i in range(ranks)]
-        t_wait = time.time()
-        while sum(os.path.exists(os.path.join(sync_dir, f"ready{i}")) for i in range(ranks)) < ranks:
-            if any(pr.poll() not in (None, 0) for pr in procs) or time.time() - t_wait > 280:
-                for pr in procs:
-                    pr.kill()
-                return {"value": None, "unit": "Mcell-steps/s", "cores": ranks, "kind": "port", "sample": "CPU baseline ranks failed to start"}
-            time.sleep(0.05)
-        open(os.path.join(sync_dir, "go"), "w").close()
-        t_wait = time.time()
-        while sum(os.path.exists(os.path.join(sync_dir, f"ready2_{i}")) for i in range(ranks)) < ranks:
-            if any(pr.poll() not in (None, 0) for pr in procs) or time.time() - t_wait > 900:
-                break
-            time.sleep(0.05)
-        open(os.path.join(sync_dir, "go2"), "w").close()
-        times, triad = [], []
+        for tag, limit in (("a", 280), ("f", 900), ("t", 900)):
+            t_wait = time.time()
+            while sum(os.path.exists(os.path.join(sync_dir, f"ready{tag}_{i}")) for i in range(ranks)) < ranks:
+                if any(pr.poll() not in (None, 0) for pr in procs) or time.time() - t_wait > limit:
+                    if tag == "a":
+                        for pr in procs:
+                            pr.kill()
+                        return {"value": None, "unit": "Mcell-steps/s", "cores": ranks, "kind": "port", "sample": "CPU baseline ranks failed to start"}
+                    break
+                time.sleep(0.05)
+            open(os.path.join(sync_dir, f"go{tag}"), "w").close()
+        times, fused, triad = [], [], []
         for pr in procs:
             out, _ = pr.communicate(timeout=900)
             times += [float(line.split()[1]) for line in out.splitlines() if line.startswith("CPU_RANK_SECONDS")]
+            fused += [float(line.split()[1]) for line in out.splitlines() if line.startswith("CPU_RANK_FUSED_SECONDS")]
             triad += [float(line.split()[1]) for line in out.splitlines() if line.startswith("CPU_RANK_TRIAD_GBS")]
     if len(times) != ranks:
         return {"value": None, "unit": "Mcell-steps/s", "cores": ranks, "kind": "port", "sample": "CPU baseline ranks failed"}
@@ -180,6 +184,11 @@ def cpu_baseline(n, steps, ranks):
             "sample": f"{ranks} single-threaded oracle ranks x {n}^3-cell box x {steps} steps (field-at-a-time restatement "
                       f"of the reference listings, no halo exchange; slowest rank {dt:.1f} s)",
             "single_rank_value": n ** 3 * steps / min(times) / 1e6,
+            # the same ranks, the same steps, the flux assembly fused (measured, not modelled)
+            "fused": ({"value": ranks * n ** 3 * steps / max(fused) / 1e6, "unit": "Mcell-steps/s",
+                       "sample": f"the same {ranks} ranks x {steps} steps with one vertex pass + one face pass per step instead of ~50 "
+                                 f"field-at-a-time passes (slowest rank {max(fused):.1f} s)"}
+                      if len(fused) == ranks and min(fused) > 0 else None),
             # what ANY CPU code (a perfectly fused one included) could reach on these cores: the step's algorithmic
             # bytes per cell-step against the STREAM-triad bandwidth the same ranks sustain together
             "host_triad_GBs": sum(triad) if len(triad) == ranks else None,

@@ -1452,6 +1452,206 @@ struct Case {
         }
     }
 
+    // -----------------------------------------------------------------------------------------------------------------------------
+    // The same flux assembly FUSED (bench.py cpu_baseline "fused"): one pass over the vertices for the six interpolated fields, one
+    // pass over the faces that forms the four fvsc gradients, the 13 interpolations and the whole flux algebra in registers and stores
+    // only the seven face fields the equations read -- what a CPU code written for speed would do with the reference's formulas,
+    // where updateFields() / updateFluxes() above materialise ~50 face fields one at a time like the reference does.  Same operations
+    // in the same order per face, so the results are those of the unfused path (tests/test_oracle_fused.py).  Scope: 3-D
+    // GaussVolPoint, quadrilateral faces only, explicit branch, fixed deltaT, no qgdFlux patch (their mid-assembly boundary condition
+    // would split the face pass); anything else returns false and the caller keeps the unfused path.
+    // -----------------------------------------------------------------------------------------------------------------------------
+    dvec fusedPv;
+    bool fusedSupported() const {
+        const GaussVolPoint* gv = dynamic_cast<const GaussVolPoint*>(stencil);
+        if (!gv || m.nGeomD != 3 || opt.implicitDiffusion || opt.adjustTimeStep || !m.haloGhost.empty()) return false;
+        if (!gv->tf.empty() || !gv->of.empty()) return false;
+        for (size_t ip = 0; ip < m.patches.size(); ++ip) {
+            if (!m.patchHasFields((int)ip)) continue;
+            if (!gv->btf[ip].empty() || !gv->bof[ip].empty() || bc[ip].bcP == BC_QGDFLUX) return false;
+        }
+        return true;
+    }
+    // flat copies of what the fused passes walk (the stencil keeps one small vector per face and per vertex, as the reference does)
+    struct FusedTables {
+        dvec coef;                 // 19 per face: a[direction][slot] (3 x 6: four vertices, "neighbour", owner), volume
+        std::vector<int64_t> pcOff; ivec pcCell; dvec pcW;        // interior vertices: cells and weights (CSR)
+        ivec bpPoint; std::vector<int64_t> bpOff; ivec bpFace; dvec bpW;   // patch vertices: patch faces (flatBoundaryField index, -1 = zero) and weights
+    } ft;
+    void buildFusedTables(const GaussVolPoint* gv) {
+        ft.coef.assign((size_t)m.nF * 19, 0.0);
+        auto put = [&](int f, const std::vector<dvec>* a, size_t ai, double vol) {
+            double* c = &ft.coef[(size_t)f * 19];
+            for (int d = 0; d < 3; ++d) for (int k = 0; k < 6; ++k) c[6 * d + k] = a[d][ai][k];
+            c[18] = vol;
+        };
+        for (size_t i = 0; i < gv->qf.size(); ++i) put(gv->qf[i], gv->aq, i, gv->vq[i]);
+        for (size_t ip = 0; ip < m.patches.size(); ++ip) {
+            if (!m.patchHasFields((int)ip)) continue;
+            const std::vector<dvec> a3[3] = {gv->baq[0][ip], gv->baq[1][ip], gv->baq[2][ip]};
+            for (size_t k = 0; k < gv->bqf[ip].size(); ++k) put(m.patches[ip].start + gv->bqf[ip][k], a3, k, gv->bvq[ip][k]);
+        }
+        ft.pcOff.assign((size_t)m.nP + 1, 0);
+        for (int pt = 0; pt < m.nP; ++pt) ft.pcOff[pt + 1] = ft.pcOff[pt] + (m.isPatchPoint[pt] ? 0 : (int64_t)m.pointCells[pt].size());
+        ft.pcCell.resize((size_t)ft.pcOff[m.nP]); ft.pcW.resize((size_t)ft.pcOff[m.nP]);
+        for (int pt = 0; pt < m.nP; ++pt) {
+            if (m.isPatchPoint[pt]) continue;
+            for (size_t i = 0; i < m.pointCells[pt].size(); ++i) { ft.pcCell[ft.pcOff[pt] + i] = m.pointCells[pt][i]; ft.pcW[ft.pcOff[pt] + i] = m.pointWeights[pt][i]; }
+        }
+        ft.bpPoint.clear(); ft.bpOff.assign(1, 0); ft.bpFace.clear(); ft.bpW.clear();
+        for (size_t i = 0; i < m.bndMeshPoints.size(); ++i) {
+            const int pt = m.bndMeshPoints[i];
+            if (!m.isPatchPoint[pt]) continue;
+            ft.bpPoint.push_back(pt);
+            for (size_t j = 0; j < m.bndPointFaces[i].size(); ++j) {
+                const int b = m.bndPointFaces[i][j];
+                if (!m.isPatchFace[b]) continue;
+                const int pid = patchOf(m.nIF + b);
+                const bool flat = pid >= 0 && m.patches[pid].type != PATCH_EMPTY && !m.coupled(pid);   // flatBoundaryField: zero elsewhere
+                ft.bpFace.push_back(flat ? b : -1);
+                ft.bpW.push_back(m.bndPointWeights[i][j]);
+            }
+            ft.bpOff.push_back((int64_t)ft.bpFace.size());
+        }
+    }
+    bool updateFluxesFused() {
+        if (!fusedSupported()) return false;
+        const GaussVolPoint* gv = dynamic_cast<const GaussVolPoint*>(stencil);
+        if (ft.coef.size() != (size_t)m.nF * 19) buildFusedTables(gv);
+        const int nF = m.nF, nP = m.nP;
+        // H of updateFields.H L63
+        for (int ci = 0; ci < m.nC; ++ci) H.in[ci] = (rhoE.in[ci] + p.in[ci]) / rho.in[ci];
+        forAllPatchFaces([&](int, int b, int) { H.bf[b] = (rhoE.bf[b] + p.bf[b]) / rho.bf[b]; });
+        // ---- vertex values of rho, U, p, e in one pass (volPointInterpolate of each, same sums) ----
+        if (fusedPv.size() != (size_t)nP * 6) fusedPv.assign((size_t)nP * 6, 0.0);
+        dvec& pv = fusedPv;
+        for (int pt = 0; pt < nP; ++pt) {
+            double* o = &pv[(size_t)pt * 6];
+            for (int k = 0; k < 6; ++k) o[k] = 0.0;
+            for (int64_t i = ft.pcOff[pt]; i < ft.pcOff[pt + 1]; ++i) {
+                const double w = ft.pcW[i];
+                const size_t ci = (size_t)ft.pcCell[i];
+                o[0] += w * rho.in[ci];
+                o[1] += w * U.in[3 * ci]; o[2] += w * U.in[3 * ci + 1]; o[3] += w * U.in[3 * ci + 2];
+                o[4] += w * p.in[ci];
+                o[5] += w * e.in[ci];
+            }
+        }
+        for (size_t i = 0; i < ft.bpPoint.size(); ++i) {
+            double* o = &pv[(size_t)ft.bpPoint[i] * 6];
+            for (int64_t j = ft.bpOff[i]; j < ft.bpOff[i + 1]; ++j) {
+                const double w = ft.bpW[j];
+                const int b = ft.bpFace[j];
+                if (b < 0) { for (int k = 0; k < 6; ++k) o[k] += w * 0.0; continue; }
+                o[0] += w * rho.bf[b];
+                o[1] += w * U.bf[3 * (size_t)b]; o[2] += w * U.bf[3 * (size_t)b + 1]; o[3] += w * U.bf[3 * (size_t)b + 2];
+                o[4] += w * p.bf[b];
+                o[5] += w * e.bf[b];
+            }
+        }
+        // psin = patch value + snGrad * |vO - vN| / 2 of the four fields (boundary-sized)
+        const dvec psinR = gv->psiN(rho), psinU = gv->psiN(U), psinP = gv->psiN(p), psinE = gv->psiN(e);
+        for (SurfField* sf : {&phiJm, &phiJmH, &phiQ, &phiPiU, &phi}) if ((int)sf->v.size() != nF) *sf = SurfField(m, 1);
+        for (SurfField* sf : {&phiJmU, &phiP, &phiPi}) if ((int)sf->v.size() != 3 * nF) *sf = SurfField(m, 3);
+        const double gm = Cp() / opt.Cv;
+        // one face: six gradients from the stencil's own coefficient tables, then everything else in registers
+        auto face = [&](int f, bool boundary, int b) {
+            const double* cf19 = &ft.coef[(size_t)f * 19];
+            const double vol = cf19[18];
+            const int o = m.own[f], n = boundary ? -1 : m.nei[f];
+            const int* q = m.fp(f);
+            // values at "neighbour" (psin on a patch), owner, the four vertices
+            double vn[6], vo[6];
+            vo[0] = rho.in[o]; vo[1] = U.in[3 * (size_t)o]; vo[2] = U.in[3 * (size_t)o + 1]; vo[3] = U.in[3 * (size_t)o + 2]; vo[4] = p.in[o]; vo[5] = e.in[o];
+            if (boundary) {
+                vn[0] = psinR[b]; vn[1] = psinU[3 * (size_t)b]; vn[2] = psinU[3 * (size_t)b + 1]; vn[3] = psinU[3 * (size_t)b + 2]; vn[4] = psinP[b]; vn[5] = psinE[b];
+            } else {
+                vn[0] = rho.in[n]; vn[1] = U.in[3 * (size_t)n]; vn[2] = U.in[3 * (size_t)n + 1]; vn[3] = U.in[3 * (size_t)n + 2]; vn[4] = p.in[n]; vn[5] = e.in[n];
+            }
+            double g[6][3];   // g[field][direction]
+            for (int d = 0; d < 3; ++d) {
+                const double* c = cf19 + 6 * d;
+                for (int k = 0; k < 6; ++k) {
+                    double s2 = vn[k] * c[4];
+                    s2 += vo[k] * c[5];
+                    for (int v = 0; v < 4; ++v) s2 += pv[(size_t)q[v] * 6 + k] * c[v];
+                    g[k][d] = 0.0 + (s2 / vol);
+                }
+            }
+            double gU[9], gRho[3], gP[3], gE[3];
+            for (int d = 0; d < 3; ++d) { gRho[d] = g[0][d]; gP[d] = g[4][d]; gE[d] = g[5][d]; for (int c2 = 0; c2 < 3; ++c2) gU[3 * d + c2] = g[1 + c2][d]; }
+            const double divU = gU[0] + gU[4] + gU[8];
+            // the interpolations of updateFields.H
+            auto lerp = [&](double ao, double an) { return m.w[f] * (ao - an) + an; };
+            double rhof_, uf[3], ruf[3], UrU[9], pf_, cf_, gammaf_, Hf_, alphauf_, muf_;
+            if (boundary) {
+                rhof_ = rho.bf[b]; pf_ = p.bf[b]; cf_ = c.bf[b]; gammaf_ = gamma.bf[b]; Hf_ = H.bf[b];
+                alphauf_ = gamma.bf[b] * (alpha.bf[b] + 0.0); muf_ = 0.0 + mu.bf[b];
+                for (int k = 0; k < 3; ++k) { uf[k] = U.bf[3 * (size_t)b + k]; ruf[k] = rhoU.bf[3 * (size_t)b + k]; }
+                outer(&U.bf[3 * (size_t)b], &rhoU.bf[3 * (size_t)b], UrU);
+            } else {
+                rhof_ = lerp(rho.in[o], rho.in[n]); pf_ = lerp(p.in[o], p.in[n]); cf_ = lerp(c.in[o], c.in[n]);
+                gammaf_ = lerp(gamma.in[o], gamma.in[n]); Hf_ = lerp(H.in[o], H.in[n]);
+                alphauf_ = lerp(gamma.in[o] * (alpha.in[o] + 0.0), gamma.in[n] * (alpha.in[n] + 0.0));
+                muf_ = lerp(0.0 + mu.in[o], 0.0 + mu.in[n]);
+                double Ao[9], An[9];
+                outer(&U.in[3 * (size_t)o], &rhoU.in[3 * (size_t)o], Ao);
+                outer(&U.in[3 * (size_t)n], &rhoU.in[3 * (size_t)n], An);
+                for (int k = 0; k < 3; ++k) { uf[k] = lerp(U.in[3 * (size_t)o + k], U.in[3 * (size_t)n + k]); ruf[k] = lerp(rhoU.in[3 * (size_t)o + k], rhoU.in[3 * (size_t)n + k]); }
+                for (int k = 0; k < 9; ++k) UrU[k] = lerp(Ao[k], An[k]);
+            }
+            (void)cf_; (void)gm;
+            const double tau = tauQGDf.v[f];
+            const double* S = &m.Sf[3 * (size_t)f];
+            // updateFluxes.H L41-139, explicit branch, as updateFluxesA/B have it
+            double A[9], t1[3], t3[3], rw[3], jm_[3];
+            outer(uf, gRho, A);
+            TdotV(A, uf, t1);
+            VdotT(ruf, gU, t3);
+            for (int k = 0; k < 3; ++k) rw[k] = tau * ((t1[k] + (ruf[k] * divU)) + t3[k]);
+            for (int k = 0; k < 3; ++k) { rw[k] += tau * gP[k]; jm_[k] = ruf[k] - rw[k]; }
+            const double pJm = dot3(S, jm_);
+            phiJm.v[f] = pJm;
+            phi.v[f] = dot3(S, ruf);
+            for (int k = 0; k < 3; ++k) { phiJmU.v[3 * (size_t)f + k] = pJm * uf[k]; phiP.v[3 * (size_t)f + k] = S[k] * pf_; }
+            double B[9], Pi[9];
+            TdotT(UrU, gU, A);
+            outer(uf, gP, B);
+            const double sph = tau * (1.0 * (dot3(uf, gP) + (gammaf_ * pf_ * divU)));
+            for (int k = 0; k < 9; ++k) Pi[k] = tau * (A[k] + B[k]);
+            Pi[0] += sph; Pi[4] += sph; Pi[8] += sph;
+            const double s23 = (2.0 / 3.0) * 1.0 * divU;
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+                double t = gU[3 * i + j] + gU[3 * j + i];
+                if (i == j) t = t - s23;
+                Pi[3 * i + j] += muf_ * t;
+            }
+            VdotT(S, Pi, &phiPi.v[3 * (size_t)f]);
+            phiJmH.v[f] = pJm * Hf_;
+            double g2[3], qv[3], qf_[3];
+            const double pr2 = pf_ / rhof_ / rhof_;
+            for (int k = 0; k < 3; ++k) g2[k] = gE[k] - pr2 * gRho[k];
+            TdotV(UrU, g2, qv);
+            for (int k = 0; k < 3; ++k) { qf_[k] = (-tau) * qv[k]; qf_[k] -= alphauf_ * gE[k]; }
+            phiQ.v[f] = dot3(S, qf_);
+            double piU[3];
+            TdotV(Pi, uf, piU);
+            phiPiU.v[f] = dot3(S, piU);
+        };
+        for (int f = 0; f < m.nIF; ++f) face(f, false, -1);
+        for (size_t ip = 0; ip < m.patches.size(); ++ip) {
+            if (!m.patchHasFields((int)ip)) continue;
+            for (int gf = m.patches[ip].start; gf < m.patches[ip].start + m.patches[ip].size; ++gf) face(gf, true, gf - m.nIF);
+        }
+        return true;
+    }
+    // n steps with the fused assembly (the equations, thermo and boundary conditions stay stepPhase1); false: not supported here
+    bool stepFused(int n) {
+        if (!fusedSupported()) return false;
+        for (int i = 0; i < n; ++i) { updateFluxesFused(); stepPhase1(); }
+        return true;
+    }
+
     // the matrix of fvm::ddt(rho, x) - fvm::laplacian(gamma_f, x) for one scalar (component): face coefficients a_f =
     // gamma_f |S_f| delta_f (uncorrected, L0), diagonal rDeltaT rho V + sum a_f + the patch internal coefficients
     // icoef(face) (gamma |S| x -gradientInternalCoeffs), source bsrc(face) (gamma |S| x gradientBoundaryCoeffs)
@@ -2731,6 +2931,8 @@ int orc_case_step_phase(void* cp, int phase) {
     else c->stepPhase2();
     return 0;
 }
+/* nSteps with the fused flux assembly (bench.py cpu_baseline "fused"); 1 = this case is outside the fused path's scope */
+int orc_case_step_fused(void* cp, int32_t nSteps) { return ((Case*)cp)->stepFused(nSteps) ? 0 : 1; }
 int orc_case_mid_exchange_needed(void* cp) { return ((Case*)cp)->midNeeded() ? 1 : 0; }
 int orc_case_mid_halo_count(void* cp, int side, int64_t* send, int64_t* recv) { ((Case*)cp)->midHaloCount(side, send, recv); return 0; }
 int orc_case_mid_halo_pack(void* cp, int side, double* buf) { ((Case*)cp)->midHaloMove(side, buf, true); return 0; }

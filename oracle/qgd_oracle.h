@@ -116,6 +116,10 @@ int orc_case_halo_pack(void* c, int side, double* sendBuf);
 int orc_case_halo_unpack(void* c, int side, const double* recvBuf);
 int orc_case_step_phase(void* c, int phase);   /* 0, 1, 2; 5 + 6 = the two halves of 0; implicitDiffusion on shards: 20..30, 35 as qgd_case_step_phase */
 /* the message between phases 5 and 6 (qgd_case_mid_*): mid-step patch pressure + gradient of the boundary-layer cells' patch faces */
+/* nSteps of the explicit branch with the flux assembly fused into one vertex pass + one face pass (same arithmetic as orc_case_step,
+ * seven face fields stored instead of ~50): the "fused CPU" baseline of bench.py.  Returns 1 when the case is outside its scope
+ * (3-D GaussVolPoint, quadrilateral faces, explicit, fixed deltaT, no qgdFlux patch, unsharded). */
+int orc_case_step_fused(void* c, int32_t nSteps);
 int orc_case_mid_exchange_needed(void* c);
 int orc_case_mid_halo_count(void* c, int side, int64_t* send, int64_t* recv);
 int orc_case_mid_halo_pack(void* c, int side, double* buf);

@@ -65,6 +65,7 @@ lib.orc_case_implicit_control.argtypes = [C.c_void_p, dp, C.c_int]
 lib.orc_case_implicit_halo_count.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
 lib.orc_case_implicit_halo_pack.argtypes = [C.c_void_p, C.c_int, C.c_int, dp]
 lib.orc_case_implicit_halo_unpack.argtypes = [C.c_void_p, C.c_int, C.c_int, dp]
+lib.orc_case_step_fused.argtypes = [C.c_void_p, C.c_int32]
 lib.orc_case_mid_exchange_needed.argtypes = [C.c_void_p]
 lib.orc_case_mid_halo_count.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
 lib.orc_case_mid_halo_pack.argtypes = [C.c_void_p, C.c_int, dp]
@@ -239,6 +240,10 @@ class OracleCase:
 
     def step_phase(self, phase):
         assert lib.orc_case_step_phase(self._h, phase) == 0
+
+    def step_fused(self, n=1):
+        """n steps with the fused flux assembly (bench.py's "fused CPU" baseline); False when the case is outside its scope"""
+        return lib.orc_case_step_fused(self._h, int(n)) == 0
 
     def field(self, name):
         base = name[:-len(".boundary")] if name.endswith(".boundary") else name
