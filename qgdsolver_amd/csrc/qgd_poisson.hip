@@ -653,6 +653,14 @@ __global__ void ctlKernel(double* __restrict__ ctl, const int stage, const doubl
         const double res = ctl[C_ABSR] / nf;
         ctl[C_NORMF] = nf; ctl[C_RES] = res; ctl[C_RES0] = res;
         if (res < tol || maxIter <= 0) ctl[C_DONE] = 1.0;
+    } else if (stage == 4) {
+        // unsharded solves only: the convergence test BEFORE the preconditioner is applied to the new residual (the sums are local, so
+        // the early test costs one fold; a sharded solve keeps |r| and r.z in one all-reduce and pays one cycle at the last iteration)
+        if (ctl[C_DONE] == 0.0) {
+            const double res = ctl[C_ABSR2] / ctl[C_NORMF];
+            const double it = ctl[C_ITER] + 1.0;
+            if (res < tol || (relTol > 0 && res < relTol * ctl[C_RES0]) || it >= (double)maxIter) { ctl[C_RES] = res; ctl[C_ITER] = it; ctl[C_DONE] = 1.0; }
+        }
     } else if (ctl[C_DONE] == 0.0) {
         if (stage == 2) {
             const double dq = ctl[C_DQ], rz = ctl[C_RZ];
@@ -712,6 +720,7 @@ struct PressureSolver {
     double* p = nullptr;
     double tol = 0, relTol = 0;
     int maxIter = 0;
+    bool earlyTest = false;   // pressureSolveRun without an all-reduce hook: test convergence before the last cycle instead of after it
     // the V-cycle is a fixed sequence of ~75 small launches on fixed buffers (r -> z); with QGD_MG_GRAPH=1 it is captured once into
     // a hipGraph and replayed per CG iteration.  Measured: 5.11 -> 5.03 ms per step at 64^3, nothing at 128^3 / 200^3 (the
     // asynchronous launches were already hidden), and rocprofv3 crashes on the captured graph -- hence opt-in.
@@ -1371,6 +1380,7 @@ double* pressureSolverDirection(PressureSolver* S) { return S->d; }
 // ---------------------------------------------------------------------------------------------------------------------
 void pressureSolveBegin(PressureSolver* S, const double* phiu, const double* phiwo, const double* pb, const double* gb, double tolerance,
                         double relTol, int maxIter, double* p) {
+    S->earlyTest = false;
     S->phiu = phiu; S->phiwo = phiwo; S->pb = pb; S->gb = gb; S->tol = tolerance; S->relTol = relTol; S->maxIter = maxIter; S->p = p;
     const MeshView& m = S->m;
     hipStream_t stream = S->stream;
@@ -1410,6 +1420,10 @@ void pressureSolvePhase(PressureSolver* S, int phase) {
         case 4:
             ctlKernel<<<1, 1, 0, stream>>>(ctl, 2, 0.0, S->tol, S->relTol, S->maxIter);
             axpyKernel<<<nb, PB, 0, stream>>>(n, S->p + ob, S->r + ob, S->d + ob, S->q + ob, S->part, ctl);
+            if (S->earlyTest) {
+                foldCtlKernel<<<1, PB, 0, stream>>>(S->part, nb, 1, ctl, C_ABSR2, 0);
+                ctlKernel<<<1, 1, 0, stream>>>(ctl, 4, 0.0, S->tol, S->relTol, S->maxIter);
+            }
             S->precondition();
             dotKernel<<<nb, PB, 0, stream>>>(n, S->r + ob, S->z + ob, S->part + nb, ctl);
             foldCtlKernel<<<2, PB, 0, stream>>>(S->part, nb, 2, ctl, C_ABSR2, 0);
@@ -1445,6 +1459,7 @@ int pressureSolveRun(PressureSolver* S, const SolveHooks* hooks, double residual
     double* ctl = S->ctl;
     auto reduce = [&](int first, int count) { if (hooks && hooks->allreduce) hooks->allreduce(ctl + first, count); };
     auto halo = [&]() { if (hooks && hooks->haloDirection) hooks->haloDirection(); };
+    S->earlyTest = !(hooks && hooks->allreduce);
     reduce(C_ABSR, 3);
     pressureSolvePhase(S, 1);
     reduce(C_NORM, 1);
