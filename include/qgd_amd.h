@@ -388,9 +388,23 @@ int qgd_qhd_case_info(qgd_qhd_case_t c, double info[8]);
  * the diagonal), so the iteration count grows mildly with the number of shards; everything else is the unsharded arithmetic.
  * control: 16 device doubles (qgd_qhd_case_control_ptr); message kinds: 0 = the new state, {U,T} per cell (4) and per patch face
  * (4); 1 = p + fvc::grad(U) per cell (1 + 9: a ghost cell's gradient cannot be formed locally, it lacks faces) and p's patch value
- * + gradient per patch face (2); 2 = the search direction per cell (1).
+ * + gradient per patch face (2); 2 = the search direction per cell (1); 3 = the multigrid iterate per cell (1), see qgd_qhd_case_pending.
  * pRefCell is a cell label of the UNSHARDED mesh.  All entries are stream-ordered on the device's stream. */
 int qgd_qhd_case_step_phase(qgd_qhd_case_t c, int phase);
+/* The multigrid hierarchy of a sharded pressure solve SPANS THE RANKS (QGD_MG_DIST=0: every rank preconditions with the hierarchy of
+ * its own rows, which is block Jacobi: 7 -> 65 / 97 / 140 iterations on 2 / 4 / 8 shards of a 128^3 box).  Level 0 stays distributed --
+ * each rank smooths its own rows, the ghost entries of the iterate refreshed before every sweep (message kind 3: one double per cell)
+ * -- and every level below it is replicated: the ranks all-reduce their shares of the level-1 right-hand side and run the coarse part
+ * of the cycle redundantly.  The comm points fall INSIDE phases 0 (set-up, first step only: the global matrix is gathered by two
+ * all-reduces), 2 and 4 (the cycle), so after EVERY qgd_qhd_case_step_phase call the caller asks
+ *     qgd_qhd_case_pending(c, &action, &ptr, &count)
+ * and, while action != 0, performs it and calls qgd_qhd_case_step_phase(c, 9):
+ *     action 1  exchange message kind 3 (halo_pack / halo_unpack with kind 3)
+ *     action 2  SUM all-reduce of the `count` device doubles at ptr, in place
+ *     action 3  MAX all-reduce of the same
+ * then goes on with the reductions and messages the table above lists for that phase.  Every rank sees the same sequence.
+ * qgd_qhd_case_step_sharded does all of this itself. */
+int qgd_qhd_case_pending(qgd_qhd_case_t c, int32_t* action, void** devicePtr, int64_t* count);
 int qgd_qhd_case_control_ptr(qgd_qhd_case_t c, void** devicePtr);
 /* host copy of the control block out (set == 0) or in (set != 0), after everything queued so far: for transports that reduce on
  * the host (MPI_Allreduce of 16 doubles, torch.distributed over gloo) */

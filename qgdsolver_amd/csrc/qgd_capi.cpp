@@ -1757,7 +1757,8 @@ int qgd_qhd_case_set_fields(qgd_qhd_case_t c, const double* U, const double* T, 
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(d->stream));
     if (c->solver) { pressureSolverFree(c->solver); c->solver = nullptr; }
-    c->solver = pressureSolverCreate(d->stream, m, c->tbr, c->bKind, c->localRefCell, c->opt.precond, d->ownedBegin, d->ownedEnd);
+    c->solver = pressureSolverCreate(d->stream, m, c->tbr, c->bKind, c->localRefCell, c->opt.precond, d->ownedBegin, d->ownedEnd,
+                                     d->cellGlobal.empty() ? nullptr : d->cellGlobal.data(), d->cellGlobalOffset, d->sharded());
     c->fieldsSet = true;
     c->time = 0; c->steps = 0;
     return QGD_OK;
@@ -1787,7 +1788,8 @@ static void qhdPhase(qgd_qhd_case_s* c, int phase) {
             c->time += c->opt.deltaT;
             c->steps++;
             break;
-        default: throw std::invalid_argument("qgd_qhd_case_step_phase: phase must be 0..8");
+        case 9: pressureSolveContinue(c->solver); break;   // after the collective qgd_qhd_case_pending asked for
+        default: throw std::invalid_argument("qgd_qhd_case_step_phase: phase must be 0..9");
     }
     HIP_CHECK(hipGetLastError());
 }
@@ -1829,7 +1831,7 @@ int qgd_qhd_case_step_phase(qgd_qhd_case_t c, int phase) {
     QGD_TRY
     if (!c) return fail(QGD_ERR_INVALID, "null case");
     if (!c->fieldsSet) return fail(QGD_ERR_INVALID, "qgd_qhd_case_step_phase: call qgd_qhd_case_set_fields first");
-    if (phase < 0 || phase > 8) return fail(QGD_ERR_INVALID, "qgd_qhd_case_step_phase: phase must be 0..8");
+    if (phase < 0 || phase > 9) return fail(QGD_ERR_INVALID, "qgd_qhd_case_step_phase: phase must be 0..9");
     HIP_CHECK(hipSetDevice(c->dev->deviceId));
     qhdPhase(c, phase);
     return QGD_OK;   // stream-ordered: qgd_qhd_case_solve_status / qgd_qhd_case_sync wait
@@ -1883,13 +1885,24 @@ int qgd_qhd_case_sync(qgd_qhd_case_t c) {
     return QGD_OK;
     QGD_CATCH
 }
-// halo messages: doubles per listed cell / per listed patch face of message kind 0 (state), 1 (p), 2 (search direction)
+// halo messages: doubles per listed cell / per listed patch face of message kind 0 (state), 1 (p), 2 (search direction), 3 (the iterate of
+// the multigrid level that spans the ranks)
 static void qhdHaloWidths(int kind, int& perCell, int& perFace) {
     perCell = kind == 0 ? 4 : (kind == 1 ? 10 : 1);
     perFace = kind == 0 ? 4 : (kind == 1 ? 2 : 0);
 }
+// what the phase in flight waits for before qgd_qhd_case_step_phase(c, 9): see include/qgd_amd.h
+int qgd_qhd_case_pending(qgd_qhd_case_t c, int32_t* action, void** devicePtr, int64_t* count) {
+    if (!c || !action) return fail(QGD_ERR_INVALID, "bad argument");
+    double* buf = nullptr;
+    int64_t n = 0;
+    *action = c->solver ? pressureSolvePending(c->solver, &buf, &n) : 0;
+    if (devicePtr) *devicePtr = buf;
+    if (count) *count = n;
+    return QGD_OK;
+}
 int qgd_qhd_case_halo_count(qgd_qhd_case_t c, int slot, int kind, int64_t* sendCount, int64_t* recvCount) {
-    if (!c || slot < 0 || kind < 0 || kind > 2 || !sendCount || !recvCount) return fail(QGD_ERR_INVALID, "bad argument");
+    if (!c || slot < 0 || kind < 0 || kind > 3 || !sendCount || !recvCount) return fail(QGD_ERR_INVALID, "bad argument");
     *sendCount = *recvCount = 0;
     if (slot >= (int)c->dev->halo.size()) return QGD_OK;
     int pc, pf;
@@ -1906,8 +1919,15 @@ static int qhdHaloMove(qgd_qhd_case_t c, int slot, int kind, double* buf, bool p
     const int32_t nCells = pack ? h.nSend : h.nGhost, nFaces = pack ? h.nSendBF : h.nGhostBF;
     if (nCells + nFaces == 0) return QGD_OK;
     if (!buf) return fail(QGD_ERR_INVALID, "null buffer");
-    if (kind == 2 && !c->solver) return fail(QGD_ERR_INVALID, "no solve in flight");
+    if (kind >= 2 && !c->solver) return fail(QGD_ERR_INVALID, "no solve in flight");
     (void)hipGetLastError();
+    if (kind == 3) {
+        float* vec = pressureSolverMgHaloVec(c->solver);
+        if (!vec) return fail(QGD_ERR_INVALID, "message kind 3: no multigrid iterate is waiting for its ghost entries (qgd_qhd_case_pending)");
+        launchQhdHaloFloat(stream, vec, pack ? h.send : h.ghost, nCells, buf, pack);
+        HIP_CHECK(hipGetLastError());
+        return QGD_OK;
+    }
     launchQhdHalo(stream, c->view, c->solver ? pressureSolverDirection(c->solver) : nullptr, kind, pack ? h.send : h.ghost, nCells,
                   pack ? h.sendBF : h.ghostBF, nFaces, buf, pack);
     HIP_CHECK(hipGetLastError());
@@ -1915,14 +1935,14 @@ static int qhdHaloMove(qgd_qhd_case_t c, int slot, int kind, double* buf, bool p
 }
 int qgd_qhd_case_halo_pack(qgd_qhd_case_t c, int slot, int kind, double* sendBufDevice) {
     QGD_TRY
-    if (!c || slot < 0 || kind < 0 || kind > 2) return fail(QGD_ERR_INVALID, "bad argument");
+    if (!c || slot < 0 || kind < 0 || kind > 3) return fail(QGD_ERR_INVALID, "bad argument");
     HIP_CHECK(hipSetDevice(c->dev->deviceId));
     return qhdHaloMove(c, slot, kind, sendBufDevice, true, c->dev->stream);
     QGD_CATCH
 }
 int qgd_qhd_case_halo_unpack(qgd_qhd_case_t c, int slot, int kind, const double* recvBufDevice) {
     QGD_TRY
-    if (!c || slot < 0 || kind < 0 || kind > 2) return fail(QGD_ERR_INVALID, "bad argument");
+    if (!c || slot < 0 || kind < 0 || kind > 3) return fail(QGD_ERR_INVALID, "bad argument");
     HIP_CHECK(hipSetDevice(c->dev->deviceId));
     return qhdHaloMove(c, slot, kind, const_cast<double*>(recvBufDevice), false, c->dev->stream);
     QGD_CATCH
@@ -2304,7 +2324,7 @@ static void qhdHaloExchangeOn(qgd_qhd_case_s* c, qgd_comm_s* comm, const int32_t
 }
 int qgd_qhd_case_halo_exchange(qgd_qhd_case_t c, qgd_comm_t comm, const int32_t* peers, int nSlots, int kind) {
     QGD_TRY
-    if (!c || kind < 0 || kind > 2) return fail(QGD_ERR_INVALID, "bad argument");
+    if (!c || kind < 0 || kind > 3) return fail(QGD_ERR_INVALID, "bad argument");
     if (c->dev->halo.empty() || nSlots <= 0) return QGD_OK;
     if (!comm || !peers) return fail(QGD_ERR_INVALID, "qgd_qhd_case_halo_exchange: null argument");
     HIP_CHECK(hipSetDevice(c->dev->deviceId));
@@ -2327,6 +2347,11 @@ int qgd_qhd_case_step_sharded(qgd_qhd_case_t c, qgd_comm_t comm, const int32_t* 
     if (comm && comm->nRanks > 1)
         hooks.allreduce = [&](double* ptr, int n) { RCCL_CHECK(rcclRef().allReduce(ptr, ptr, (size_t)n, ncclFloat64, ncclSum, comm->comm, d->stream)); };
     if (sharded) hooks.haloDirection = [&]() { qhdHaloExchangeOn(c, comm, peers, nSlots, 2); };
+    if (sharded) hooks.haloMg = [&]() { qhdHaloExchangeOn(c, comm, peers, nSlots, 3); };
+    if (comm && comm->nRanks > 1)
+        hooks.allreduceBuf = [&](double* ptr, int64_t n, int op) {
+            RCCL_CHECK(rcclRef().allReduce(ptr, ptr, (size_t)n, ncclFloat64, op == 3 ? ncclMax : ncclSum, comm->comm, d->stream));
+        };
     std::function<void(int)> haloState;
     if (sharded) haloState = [&](int kind) { qhdHaloExchangeOn(c, comm, peers, nSlots, kind); };
     for (int i = 0; i < nSteps; ++i) qhdStepWith(c, &hooks, haloState);

@@ -215,13 +215,15 @@ void launchQhdFinish(hipStream_t s, const MeshView& m, const QhdView& q, bool ne
 // patch face), 2 = the search direction of the pressure solve (1 per cell)
 void launchQhdHalo(hipStream_t s, const QhdView& q, double* direction, int kind, const int32_t* cells, int nCells, const int32_t* bfaces, int nFaces,
                    double* buf, bool pack);
+void launchQhdHaloFloat(hipStream_t s, float* vec, const int32_t* cells, int nCells, double* buf, bool pack);
 void launchQhdExtract(hipStream_t s, int64_t n, const double* rec4, int field, double* out);
 
 // persistent pressure solver: PCG preconditioned by aggregation multigrid (precond 1) or Jacobi (0); qgd_poisson.hip
 struct PressureSolver;
 // ownedBegin/ownedEnd: the rows of the system, i.e. the owned cells of a shard (0, -1: every cell)
 PressureSolver* pressureSolverCreate(hipStream_t stream, const MeshView& m, const double* taubyrho, const uint8_t* bKind, int refCell, int precond,
-                                     int ownedBegin = 0, int ownedEnd = -1);
+                                     int ownedBegin = 0, int ownedEnd = -1, const int32_t* cellGlobal = nullptr, int64_t cellGlobalOffset = 0,
+                                     bool sharded = false);   // sharded: cellGlobal (or local + offset) = labels of the unsharded mesh
 void pressureSolverFree(PressureSolver* S);
 int64_t pressureSolverBytes(const PressureSolver* S);
 int pressureSolverLevels(const PressureSolver* S, int* sizes, int cap);
@@ -231,12 +233,21 @@ int pressureSolve(PressureSolver* S, const double* phiu, const double* phiwo, co
 // ghost entries of the search direction between them
 struct SolveHooks {
     std::function<void(double* devicePtr, int n)> allreduce;   // SUM over the ranks, in place, stream-ordered
+    // the distributed multigrid hierarchy of a sharded pressure solve (pressureSolvePending): op 2 = SUM, 3 = MAX over the ranks of a
+    // device buffer, in place; haloMg: ghost entries of the multigrid iterate (message kind 3 of the QHD case)
+    std::function<void(double* devicePtr, int64_t n, int op)> allreduceBuf;
+    std::function<void()> haloMg;
     std::function<void()> haloDirection;                       // ghost entries of pressureSolverDirection()
     std::function<void()> haloGuess;                           // implicit branch: ghost entries of the initial guess, before the first product
 };
 void pressureSolveBegin(PressureSolver* S, const double* phiu, const double* phiwo, const double* pb, const double* gb, double tolerance,
                         double relTol, int maxIter, double* p);
 void pressureSolvePhase(PressureSolver* S, int phase);
+// what the caller owes the phase in flight before pressureSolveContinue: 0 nothing (the phase is complete), 1 halo of the multigrid
+// iterate (pressureSolverMgHaloVec: one float per local cell), 2 / 3 SUM / MAX all-reduce of *buf[0, *n)
+int pressureSolvePending(PressureSolver* S, double** buf, int64_t* n);
+void pressureSolveContinue(PressureSolver* S);
+float* pressureSolverMgHaloVec(PressureSolver* S);
 int pressureSolveRun(PressureSolver* S, const SolveHooks* hooks, double residuals[2]);
 void pressureSolveFlux(PressureSolver* S, double* phi);
 void pressureSolveStatus(PressureSolver* S, double out[4]);

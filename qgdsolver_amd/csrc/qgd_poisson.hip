@@ -512,6 +512,45 @@ __global__ __launch_bounds__(PB) void mgRestrictEllKernel(const int nCoarse, con
     }
     rc[I] = s;
 }
+// ---- the distributed level 0 of a sharded solve (DistMg below): rows = the owned cells [ob, ob + L.n), every vector indexed by the
+// LOCAL cell label (so that the ghost columns of a row read the ghost entries a halo exchange has just refreshed) ----
+template <typename T>
+__global__ __launch_bounds__(PB) void mgSmoothOwnedKernel(const MgLevelT<T> L, const int ob, const T omega, const T* __restrict__ b,
+                                                          const T* __restrict__ xin, T* xout, T* __restrict__ rout,
+                                                          const double* __restrict__ ctl, const T cx, const T cm) {
+    const int r = blockIdx.x * PB + threadIdx.x;
+    if (r >= L.n || solveDone(ctl)) return;
+    const int i = r + ob;
+    const T d = L.diag[i];
+    if (!xin) { xout[i] = omega * b[i] / d; return; }
+    const T xi = xin[i];
+    T s = d * xi;
+    const int s0 = L.sliceStart[r >> 6], w = L.sliceStart[(r >> 6) + 1] - s0;
+    const size_t e0 = (size_t)s0 * 64 + (r & 63);
+    for (int k = 0; k < w; ++k) {
+        const int c = L.col[e0 + (size_t)k * 64];
+        if (c >= 0) s -= L.val[e0 + (size_t)k * 64] * xin[c];
+    }
+    const T res = b[i] - s;
+    if (rout) rout[i] = res;
+    if (xout) {
+        T v = cx * xi + omega * res / d;
+        if (cm != (T)0) v -= cm * xout[i];
+        xout[i] = v;
+    }
+}
+// this rank's share of P^T r for the coarse nodes its cells touch (one wavefront per touched node), as doubles for the all-reduce
+template <typename T>
+__global__ __launch_bounds__(PB) void mgRestrictPartialKernel(const int nRows, const int* __restrict__ rowNode, const int* __restrict__ rowStart,
+                                                              const int* __restrict__ col, const T* __restrict__ val, const T* __restrict__ r,
+                                                              double* __restrict__ out, const double* __restrict__ ctl) {
+    const int k = blockIdx.x * (PB / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (k >= nRows || solveDone(ctl)) return;
+    T s = 0;
+    for (int e = rowStart[k] + lane; e < rowStart[k + 1]; e += 64) s += val[e] * r[col[e]];
+    s = waveSum(s);
+    if (lane == 0) out[rowNode[k]] = (double)s;
+}
 // coarsest level: x = A^-1 b with the dense inverse, one wavefront per row
 template <typename T>
 __global__ __launch_bounds__(PB) void mgDenseKernel(const int n, const T* __restrict__ inverse, const T* __restrict__ b, T* __restrict__ x,
@@ -721,6 +760,43 @@ struct PressureSolver {
     double tol = 0, relTol = 0;
     int maxIter = 0;
     bool earlyTest = false;   // pressureSolveRun without an all-reduce hook: test convergence before the last cycle instead of after it
+    // knobs of the hierarchy builder (read once at creation; the distributed hierarchy is built later, at the first solve)
+    bool sa = true;
+    int passes = 2;
+    double saTheta = 0.08;
+    // ---- a hierarchy that SPANS THE RANKS of a sharded solve (QGD_MG_DIST, default on; 0: the rank-local block hierarchy) ----------------
+    // A rank-local hierarchy is block Jacobi: 7 -> 65 / 97 / 140 iterations on 2 / 4 / 8 shards of a 128^3 box.  Here level 0 stays
+    // distributed (each rank smooths its own rows, the ghost entries of the iterate refreshed before every sweep), every level below it
+    // is REPLICATED: all ranks hold the same global coarse hierarchy, all-reduce their shares of the level-1 right-hand side and run
+    // the coarse part of the cycle redundantly (1/8 of the rows and less: cheaper than exchanging per level).  Set-up: the global
+    // matrix is gathered by two all-reduces of a zero-padded buffer (sizes: MAX; diagonal and, per global cell, the couplings to its
+    // higher-numbered neighbours: SUM), then every rank builds the same hierarchy.  The comm points are handed to the caller one at a
+    // time: `pending` says what to do with `buf` / `haloVec` before pressureSolveContinue.
+    struct Dist {
+        bool wanted = false, built = false;
+        int pending = 0;            // 0 nothing, 1 halo of haloVec (one value per cell), 2 SUM all-reduce of buf[0, bufN), 3 MAX all-reduce
+        int setupStage = 0, pc = -1, resumePhase = -1, sweep = 0;
+        double* buf = nullptr;
+        int64_t bufN = 0, bufCap = 0;
+        float* haloVec = nullptr;
+        std::vector<int> own, nei;             // the local mesh's internal faces (host copies for the gather and level 0)
+        std::vector<double> a, diag;
+        std::vector<int32_t> cellGlobal;       // extracted shards; empty: global = local + cellGlobalOffset
+        int64_t cellGlobalOffset = 0, nCg = 0;
+        int K = 0, n1 = 0;
+        int nPt = 0;                           // coarse nodes this rank's cells touch, their rows of P^T (CSR over owned cells, local labels)
+        int *ptNode = nullptr, *ptStart = nullptr, *ptCol = nullptr;
+        float* ptVal = nullptr;
+        float *cur = nullptr, *nxt = nullptr;
+        const double* rhs = nullptr;           // r -> z of the application in flight
+        double* out = nullptr;
+        int64_t globalOf(int i) const { return cellGlobal.empty() ? (int64_t)i + cellGlobalOffset : (int64_t)cellGlobal[i]; }
+    } dist;
+    void distEnsureBuf(int64_t n) {
+        if (n <= dist.bufCap) return;
+        dist.buf = alloc<double>((size_t)n);      // the old one stays in `owned` until the solver goes (set-up only grows it twice)
+        dist.bufCap = n;
+    }
     // the V-cycle is a fixed sequence of ~75 small launches on fixed buffers (r -> z); with QGD_MG_GRAPH=1 it is captured once into
     // a hipGraph and replayed per CG iteration.  Measured: 5.11 -> 5.03 ms per step at 64^3, nothing at 128^3 / 200^3 (the
     // asynchronous launches were already hidden), and rocprofv3 crashes on the captured graph -- hence opt-in.
@@ -1216,8 +1292,82 @@ static void mgUploadCsr(PressureSolver* S, int nRows, const HostCsr& M, const in
     *valOut = S->alloc<T>(val.size(), val.data());
 }
 
+// The levels below level 0 of graph (n, I, J, w, diag): S->L.back() is level 0 already (uploaded by the caller: the whole matrix,
+// the owned block of a shard, or the distributed level 0 of DistMg).  firstTransfer (optional) receives the prolongator of level 0 and
+// the size of level 1 INSTEAD of the default upload of P and P^T (the distributed level 0 keeps only its own rows of them).
+static void mgBuildHierarchy(PressureSolver* S, int n, std::vector<int>& I, std::vector<int>& J, std::vector<double>& w, std::vector<double>& diag,
+                     const std::function<void(const HostCsr& P, int nCoarse)>& firstTransfer) {
+    const bool sa = S->sa;
+    const int passes = S->passes;
+    const double saTheta = S->saTheta;
+    S->smootherScale.assign(1, 1.0);
+    while (n > (sa ? MG_DENSE_MAX : 600) && S->L.size() < 12) {
+        std::vector<int> total((size_t)n);
+        for (int i = 0; i < n; ++i) total[i] = i;
+        int cur = n;
+        if (sa) {
+            std::vector<int64_t> off;
+            std::vector<int> nbr;
+            std::vector<double> nw;
+            std::vector<uint8_t> strong;
+            adjacencyOf(n, I, J, w, off, nbr, nw);
+            strengthOf(n, off, nbr, nw, diag, saTheta * std::pow(0.5, (double)(S->L.size() - 1)), strong);
+            cur = rootAggregates(n, off, nbr, nw, strong, total);
+            if (cur >= n || cur < 1) break;
+            // lambda_max(D^-1 A): 2 on level 0 (Gershgorin; the rows are weakly diagonally dominant), estimated below it
+            const double lmax = 2.0 / S->smootherScale.back();
+            HostCsr P, PT;
+            std::vector<int> cI, cJ;
+            std::vector<double> cw, cdiag;
+            smoothedLevel(n, off, nbr, nw, strong, diag, total, cur, (4.0 / 3.0) / lmax, P, PT, cI, cJ, cw, cdiag);
+            MgLevelDev& fine = S->L.back();
+            if (firstTransfer && S->L.size() == 1) {
+                firstTransfer(P, cur);
+                fine.pS = S->Lf.back().pS;
+            } else if (S->f32) {
+                MgLevelT<float>& ff = S->Lf.back();
+                mgUploadEll<float>(S, n, P, &ff.pS, &ff.pCol, &ff.pVal);
+                if (cur > 300000) { mgUploadEll<float>(S, cur, PT, &ff.ptS, &ff.ptCol, &ff.ptVal); ff.ptSliced = 1; }
+                else mgUploadCsr<float>(S, cur, PT, &ff.ptS, &ff.ptCol, &ff.ptVal);
+                fine.pS = ff.pS;   // marks the level; the double arrays of the levels below 0 are not used with the f32 cycle
+            } else {
+                mgUploadEll<double>(S, n, P, &fine.pS, &fine.pCol, &fine.pVal);
+                if (cur > 300000) { mgUploadEll<double>(S, cur, PT, &fine.ptS, &fine.ptCol, &fine.ptVal); fine.ptSliced = 1; }
+                else mgUploadCsr<double>(S, cur, PT, &fine.ptS, &fine.ptCol, &fine.ptVal);
+            }
+            I.swap(cI); J.swap(cJ); w.swap(cw); diag.swap(cdiag);
+            n = cur;
+            adjacencyOf(n, I, J, w, off, nbr, nw);
+            S->smootherScale.push_back(2.0 / lambdaMaxOf(n, off, nbr, nw, diag));
+            mgUploadLevel(S, n, I, J, w, diag, n <= MG_DENSE_MAX);
+            continue;
+        }
+        for (int pass = 0; pass < passes && cur > 64; ++pass) {
+            std::vector<int> agg;
+            const int na = pairwisePass(cur, I, J, w, agg);
+            coarsenGraph(na, agg, I, J, w, diag);
+            for (int i = 0; i < n; ++i) total[i] = agg[total[i]];
+            cur = na;
+        }
+        if (cur >= n) break;
+        // aggregate lists of the level just finished (CSR by coarse node, members in ascending order)
+        std::vector<int> start((size_t)cur + 1, 0), items((size_t)n);
+        for (int i = 0; i < n; ++i) start[total[i] + 1]++;
+        for (int k = 0; k < cur; ++k) start[k + 1] += start[k];
+        std::vector<int> fill(start.begin(), start.end() - 1);
+        for (int i = 0; i < n; ++i) items[fill[total[i]]++] = i;
+        MgLevelDev& fine = S->L.back();
+        fine.agg = S->alloc<int>(n, total.data());
+        fine.aggStart = S->alloc<int>((size_t)cur + 1, start.data());
+        fine.aggItems = S->alloc<int>(n, items.data());
+        if (S->f32) { MgLevelT<float>& ff = S->Lf.back(); ff.agg = fine.agg; ff.aggStart = fine.aggStart; ff.aggItems = fine.aggItems; }
+        n = cur;
+        mgUploadLevel(S, n, I, J, w, diag, n <= 600);
+    }
+}
+
 PressureSolver* pressureSolverCreate(hipStream_t stream, const MeshView& m, const double* taubyrho, const uint8_t* bKind, int refCell,
-                                     int precond, int ownedBegin, int ownedEnd) {
+                                     int precond, int ownedBegin, int ownedEnd, const int32_t* cellGlobal, int64_t cellGlobalOffset, bool sharded) {
     PressureSolver* S = new PressureSolver();
     try {
         S->m = m; S->stream = stream; S->refCell = refCell; S->precond = precond; S->bKind = bKind;
@@ -1242,10 +1392,12 @@ PressureSolver* pressureSolverCreate(hipStream_t stream, const MeshView& m, cons
         S->smootherSetup(knob("QGD_MG_CHEB", 0, 0, 1000), knob("QGD_MG_CHEB_LMAX", 2.0, 0.5, 4.0));
         // pairwise matching passes per level: 2 = aggregates of ~4 cells (3 passes = ~8 cells need twice the iterations)
         // smoothed aggregation with ~8-cell aggregates and no over-weighting, or (QGD_MG_SA=0) the plain aggregation of round 2
-        const bool sa = knob("QGD_MG_SA", 1, 0, 1) != 0;
-        const int passes = (int)knob("QGD_MG_PASSES", 2, 1, 4);                // plain aggregation: pairwise matching passes per level
-        const double saTheta = knob("QGD_MG_SA_THETA", 0.08, 0.0, 0.9);       // strength threshold on level 0, halved per level
+        const bool sa = S->sa = knob("QGD_MG_SA", 1, 0, 1) != 0;
+        S->passes = (int)knob("QGD_MG_PASSES", 2, 1, 4);                   // plain aggregation: pairwise matching passes per level
+        S->saTheta = knob("QGD_MG_SA_THETA", 0.08, 0.0, 0.9);             // strength threshold on level 0, halved per level
         if (sa) S->oc = knob("QGD_MG_OC", 1.0, 0.5, 3.0);
+        // a shard with smoothed aggregation and the single-precision cycle builds the hierarchy that spans the ranks, at its first solve
+        const bool distWanted = sharded && precond == 1 && sa && S->f32 && knob("QGD_MG_DIST", 1, 0, 1) != 0;
         const int nC = m.nC, nF = m.nF, ob = S->ob, oe = S->oe, nRows = oe - ob, nb = blocksOf(nRows);
         S->a = S->alloc<double>(nF); S->gs = S->alloc<double>(std::max(m.nBF, 1));
         S->diag = S->alloc<double>(nC); S->rhs = S->alloc<double>(nC); S->r = S->alloc<double>(nC); S->z = S->alloc<double>(nC);
@@ -1275,6 +1427,13 @@ PressureSolver* pressureSolverCreate(hipStream_t stream, const MeshView& m, cons
                 PCHECK(hipMemcpy(wAll.data(), S->a, sizeof(double) * (size_t)m.nIF, hipMemcpyDeviceToHost));
             }
             PCHECK(hipMemcpy(dAll.data(), S->diag, sizeof(double) * (size_t)nC, hipMemcpyDeviceToHost));
+            if (distWanted) {
+                S->dist.wanted = true;
+                S->dist.own.swap(own); S->dist.nei.swap(nei); S->dist.a.swap(wAll); S->dist.diag.swap(dAll);
+                if (cellGlobal) S->dist.cellGlobal.assign(cellGlobal, cellGlobal + nC);
+                S->dist.cellGlobalOffset = cellGlobalOffset;
+                return S;
+            }
             std::vector<int> I, J;
             std::vector<double> w, diag(dAll.begin() + ob, dAll.begin() + oe);
             I.reserve((size_t)m.nIF); J.reserve((size_t)m.nIF); w.reserve((size_t)m.nIF);
@@ -1283,67 +1442,7 @@ PressureSolver* pressureSolverCreate(hipStream_t stream, const MeshView& m, cons
             std::vector<int>().swap(own); std::vector<int>().swap(nei); std::vector<double>().swap(wAll); std::vector<double>().swap(dAll);
             int n = nRows;
             mgUploadLevel(S, n, I, J, w, diag, false);
-            S->smootherScale.assign(1, 1.0);
-            while (n > (sa ? MG_DENSE_MAX : 600) && S->L.size() < 12) {
-                std::vector<int> total((size_t)n);
-                for (int i = 0; i < n; ++i) total[i] = i;
-                int cur = n;
-                if (sa) {
-                    std::vector<int64_t> off;
-                    std::vector<int> nbr;
-                    std::vector<double> nw;
-                    std::vector<uint8_t> strong;
-                    adjacencyOf(n, I, J, w, off, nbr, nw);
-                    strengthOf(n, off, nbr, nw, diag, saTheta * std::pow(0.5, (double)(S->L.size() - 1)), strong);
-                    cur = rootAggregates(n, off, nbr, nw, strong, total);
-                    if (cur >= n || cur < 1) break;
-                    // lambda_max(D^-1 A): 2 on level 0 (Gershgorin; the rows are weakly diagonally dominant), estimated below it
-                    const double lmax = 2.0 / S->smootherScale.back();
-                    HostCsr P, PT;
-                    std::vector<int> cI, cJ;
-                    std::vector<double> cw, cdiag;
-                    smoothedLevel(n, off, nbr, nw, strong, diag, total, cur, (4.0 / 3.0) / lmax, P, PT, cI, cJ, cw, cdiag);
-                    MgLevelDev& fine = S->L.back();
-                    if (S->f32) {
-                        MgLevelT<float>& ff = S->Lf.back();
-                        mgUploadEll<float>(S, n, P, &ff.pS, &ff.pCol, &ff.pVal);
-                        if (cur > 300000) { mgUploadEll<float>(S, cur, PT, &ff.ptS, &ff.ptCol, &ff.ptVal); ff.ptSliced = 1; }
-                        else mgUploadCsr<float>(S, cur, PT, &ff.ptS, &ff.ptCol, &ff.ptVal);
-                        fine.pS = ff.pS;   // marks the level; the double arrays of the levels below 0 are not used with the f32 cycle
-                    } else {
-                        mgUploadEll<double>(S, n, P, &fine.pS, &fine.pCol, &fine.pVal);
-                        if (cur > 300000) { mgUploadEll<double>(S, cur, PT, &fine.ptS, &fine.ptCol, &fine.ptVal); fine.ptSliced = 1; }
-                        else mgUploadCsr<double>(S, cur, PT, &fine.ptS, &fine.ptCol, &fine.ptVal);
-                    }
-                    I.swap(cI); J.swap(cJ); w.swap(cw); diag.swap(cdiag);
-                    n = cur;
-                    adjacencyOf(n, I, J, w, off, nbr, nw);
-                    S->smootherScale.push_back(2.0 / lambdaMaxOf(n, off, nbr, nw, diag));
-                    mgUploadLevel(S, n, I, J, w, diag, n <= MG_DENSE_MAX);
-                    continue;
-                }
-                for (int pass = 0; pass < passes && cur > 64; ++pass) {
-                    std::vector<int> agg;
-                    const int na = pairwisePass(cur, I, J, w, agg);
-                    coarsenGraph(na, agg, I, J, w, diag);
-                    for (int i = 0; i < n; ++i) total[i] = agg[total[i]];
-                    cur = na;
-                }
-                if (cur >= n) break;
-                // aggregate lists of the level just finished (CSR by coarse node, members in ascending order)
-                std::vector<int> start((size_t)cur + 1, 0), items((size_t)n);
-                for (int i = 0; i < n; ++i) start[total[i] + 1]++;
-                for (int k = 0; k < cur; ++k) start[k + 1] += start[k];
-                std::vector<int> fill(start.begin(), start.end() - 1);
-                for (int i = 0; i < n; ++i) items[fill[total[i]]++] = i;
-                MgLevelDev& fine = S->L.back();
-                fine.agg = S->alloc<int>(n, total.data());
-                fine.aggStart = S->alloc<int>((size_t)cur + 1, start.data());
-                fine.aggItems = S->alloc<int>(n, items.data());
-                if (S->f32) { MgLevelT<float>& ff = S->Lf.back(); ff.agg = fine.agg; ff.aggStart = fine.aggStart; ff.aggItems = fine.aggItems; }
-                n = cur;
-                mgUploadLevel(S, n, I, J, w, diag, n <= 600);
-            }
+            mgBuildHierarchy(S, n, I, J, w, diag, nullptr);
         }
         if (std::getenv("QGD_MG_VERBOSE"))
             for (size_t l = 0; l < S->L.size(); ++l)
@@ -1378,19 +1477,297 @@ double* pressureSolverDirection(PressureSolver* S) { return S->d; }
 // The preconditioner is applied before the convergence test of an iteration (one cycle more than the host-driven loop ran,
 // at the last iteration only) so that |r| and r.z travel in ONE reduction.
 // ---------------------------------------------------------------------------------------------------------------------
+// ---- DistMg: set-up ------------------------------------------------------------------------------------------------------------
+static void distBlockFallback(PressureSolver* S) {
+    // too small for two levels (or a single rank): the rank-local hierarchy after all
+    PressureSolver::Dist& D = S->dist;
+    const int ob = S->ob, oe = S->oe;
+    std::vector<int> I, J;
+    std::vector<double> w, diag(D.diag.begin() + ob, D.diag.begin() + oe);
+    for (size_t f = 0; f < D.own.size(); ++f)
+        if (D.own[f] >= ob && D.own[f] < oe && D.nei[f] >= ob && D.nei[f] < oe) { I.push_back(D.own[f] - ob); J.push_back(D.nei[f] - ob); w.push_back(D.a[f]); }
+    mgUploadLevel(S, oe - ob, I, J, w, diag, false);
+    mgBuildHierarchy(S, oe - ob, I, J, w, diag, nullptr);
+    D.wanted = false;
+}
+// one stage of the set-up; returns true when the hierarchy stands (or was abandoned), false when a collective is pending
+static bool distSetupStep(PressureSolver* S) {
+    PressureSolver::Dist& D = S->dist;
+    const int ob = S->ob, oe = S->oe, nOwned = oe - ob;
+    hipStream_t stream = S->stream;
+    if (D.setupStage == 0) {
+        // sizes: the number of cells of the unsharded mesh, the most couplings any cell has to higher-numbered neighbours
+        std::vector<int> cnt((size_t)S->m.nC, 0);
+        int64_t gmax = 0;
+        int K = 0;
+        for (int i = ob; i < oe; ++i) gmax = std::max(gmax, D.globalOf(i) + 1);
+        for (size_t f = 0; f < D.own.size(); ++f) {
+            const int lo = D.globalOf(D.own[f]) < D.globalOf(D.nei[f]) ? D.own[f] : D.nei[f];
+            if (lo >= ob && lo < oe) K = std::max(K, ++cnt[lo]);
+        }
+        S->distEnsureBuf(2);
+        const double v[2] = {(double)gmax, (double)K};
+        PCHECK(hipMemcpyAsync(D.buf, v, sizeof(v), hipMemcpyHostToDevice, stream));
+        PCHECK(hipStreamSynchronize(stream));
+        D.bufN = 2; D.pending = 3; D.setupStage = 1;
+        return false;
+    }
+    if (D.setupStage == 1) {
+        double v[2];
+        PCHECK(hipMemcpyAsync(v, D.buf, sizeof(v), hipMemcpyDeviceToHost, stream));
+        PCHECK(hipStreamSynchronize(stream));
+        D.nCg = (int64_t)v[0]; D.K = (int)v[1];
+        if (D.nCg <= MG_DENSE_MAX || D.nCg >= 0x7fffffffLL || D.nCg == nOwned) { distBlockFallback(S); D.built = true; return true; }
+        // this rank's share of the global matrix: the diagonal of its cells and, per cell, its couplings to higher-numbered neighbours
+        const int64_t n = D.nCg, K = D.K;
+        std::vector<double> h((size_t)(n * (1 + 2 * K)), 0.0);
+        std::vector<int> cnt((size_t)S->m.nC, 0);
+        for (int i = ob; i < oe; ++i) h[(size_t)D.globalOf(i)] = D.diag[i];
+        for (size_t f = 0; f < D.own.size(); ++f) {
+            const int64_t go = D.globalOf(D.own[f]), gn = D.globalOf(D.nei[f]);
+            const int lo = go < gn ? D.own[f] : D.nei[f];
+            if (lo < ob || lo >= oe) continue;
+            const int64_t glo = std::min(go, gn), ghi = std::max(go, gn);
+            const int k = cnt[lo]++;
+            h[(size_t)(n + glo * K + k)] = (double)(ghi + 1);
+            h[(size_t)(n + n * K + glo * K + k)] = D.a[f];
+        }
+        S->distEnsureBuf((int64_t)h.size());
+        PCHECK(hipMemcpyAsync(D.buf, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, stream));
+        PCHECK(hipStreamSynchronize(stream));
+        D.bufN = (int64_t)h.size(); D.pending = 2; D.setupStage = 2;
+        return false;
+    }
+    // stage 2: every rank holds the whole matrix now and builds the same hierarchy from it
+    const int64_t n = D.nCg, K = D.K;
+    std::vector<int> I, J;
+    std::vector<double> w, diag((size_t)n);
+    {
+        std::vector<double> h((size_t)D.bufN);
+        PCHECK(hipMemcpyAsync(h.data(), D.buf, sizeof(double) * h.size(), hipMemcpyDeviceToHost, stream));
+        PCHECK(hipStreamSynchronize(stream));
+        for (int64_t g = 0; g < n; ++g) {
+            diag[(size_t)g] = h[(size_t)g];
+            for (int k = 0; k < K; ++k) {
+                const double nb1 = h[(size_t)(n + g * K + k)];
+                if (nb1 > 0) { I.push_back((int)g); J.push_back((int)(nb1 - 1.0)); w.push_back(h[(size_t)(n + n * K + g * K + k)]); }
+            }
+        }
+    }
+    // a cell nobody contributed (a caller without the all-reduce: one rank driving a shard on its own) -> the rank-local hierarchy
+    bool complete = true;
+    for (int64_t g = 0; g < n && complete; ++g) complete = diag[(size_t)g] > 0.0;
+    if (!complete) { distBlockFallback(S); D.built = true; return true; }
+    // level 0, distributed: the owned rows with their ghost columns, every vector by local cell label
+    const int nC = S->m.nC;
+    {
+        std::vector<int> deg((size_t)nOwned, 0);
+        for (size_t f = 0; f < D.own.size(); ++f) {
+            if (D.own[f] >= ob && D.own[f] < oe) deg[D.own[f] - ob]++;
+            if (D.nei[f] >= ob && D.nei[f] < oe) deg[D.nei[f] - ob]++;
+        }
+        const int nSlices = (nOwned + 63) / 64;
+        std::vector<int> start((size_t)nSlices + 2, 0);
+        int width = 0;
+        for (int sl = 0; sl < nSlices; ++sl) {
+            int wmax = 0;
+            for (int r = sl * 64; r < std::min(nOwned, sl * 64 + 64); ++r) wmax = std::max(wmax, deg[r]);
+            start[sl + 1] = start[sl] + wmax;
+            width = std::max(width, wmax);
+        }
+        start[nSlices + 1] = start[nSlices];
+        const size_t stored = std::max<size_t>((size_t)start[nSlices] * 64, 1);
+        std::vector<int> col(stored, -1), fill((size_t)nOwned, 0);
+        std::vector<float> val(stored, 0.0f);
+        auto put = [&](int rowCell, int colCell, double a) {
+            const int r = rowCell - ob;
+            const size_t at = ((size_t)start[r >> 6] + fill[r]++) * 64 + (r & 63);
+            col[at] = colCell; val[at] = (float)a;
+        };
+        for (size_t f = 0; f < D.own.size(); ++f) {
+            if (D.own[f] >= ob && D.own[f] < oe) put(D.own[f], D.nei[f], D.a[f]);
+            if (D.nei[f] >= ob && D.nei[f] < oe) put(D.nei[f], D.own[f], D.a[f]);
+        }
+        std::vector<float> df(D.diag.begin(), D.diag.end());
+        MgLevelDev lv;        // the double-precision twin only marks the level (sizes for the log, pS as the flag)
+        lv.n = nOwned; lv.width = width; lv.entries = (long long)stored;
+        MgLevelT<float> lf;
+        lf.n = nOwned; lf.width = width; lf.entries = (long long)stored;
+        lf.sliceStart = S->alloc<int>(start.size(), start.data());
+        lf.col = S->alloc<int>(col.size(), col.data());
+        lf.val = S->alloc<float>(val.size(), val.data());
+        lf.diag = S->alloc<float>(nC, df.data());
+        lf.x = S->alloc<float>(nC); lf.x2 = S->alloc<float>(nC); lf.b = S->alloc<float>(nC); lf.r = S->alloc<float>(nC);
+        lv.sliceStart = lf.sliceStart;
+        S->L.push_back(lv); S->Lf.push_back(lf);
+    }
+    auto firstTransfer = [&](const HostCsr& P, int nCoarse) {
+        D.n1 = nCoarse;
+        // the owned cells' rows of P (columns: nodes of the replicated level 1) ...
+        HostCsr Pl;
+        Pl.off.assign((size_t)nOwned + 1, 0);
+        for (int r = 0; r < nOwned; ++r) { const int64_t g = D.globalOf(r + ob); Pl.off[r + 1] = Pl.off[r] + (P.off[g + 1] - P.off[g]); }
+        Pl.col.resize((size_t)Pl.off[nOwned]); Pl.val.resize((size_t)Pl.off[nOwned]);
+        std::vector<std::pair<int64_t, int64_t>> trip;   // (node, position in Pl) -> rows of P^T over this rank's cells
+        trip.reserve(Pl.col.size());
+        for (int r = 0; r < nOwned; ++r) {
+            const int64_t g = D.globalOf(r + ob);
+            for (int64_t q = P.off[g], at = Pl.off[r]; q < P.off[g + 1]; ++q, ++at) { Pl.col[at] = P.col[q]; Pl.val[at] = P.val[q]; trip.push_back({(int64_t)P.col[q], at}); }
+        }
+        MgLevelT<float>& ff = S->Lf.back();
+        mgUploadEll<float>(S, nOwned, Pl, &ff.pS, &ff.pCol, &ff.pVal);
+        // ... and, for every coarse node they touch, its row of P^T over them (ascending cell)
+        std::sort(trip.begin(), trip.end());
+        std::vector<int> node, start(1, 0), colr;
+        std::vector<float> valr;
+        std::vector<int> rowOfPos(Pl.col.size());
+        for (int r = 0; r < nOwned; ++r) for (int64_t at = Pl.off[r]; at < Pl.off[r + 1]; ++at) rowOfPos[(size_t)at] = r;
+        for (size_t t = 0; t < trip.size(); ++t) {
+            if (t == 0 || trip[t].first != trip[t - 1].first) { if (t) start.push_back((int)colr.size()); node.push_back((int)trip[t].first); }
+            colr.push_back(rowOfPos[(size_t)trip[t].second] + ob);      // local cell label: r is indexed like every level-0 vector
+            valr.push_back((float)Pl.val[(size_t)trip[t].second]);
+        }
+        start.push_back((int)colr.size());
+        D.nPt = (int)node.size();
+        D.ptNode = S->alloc<int>(node.size(), node.data());
+        D.ptStart = S->alloc<int>(start.size(), start.data());
+        D.ptCol = S->alloc<int>(colr.size(), colr.data());
+        D.ptVal = S->alloc<float>(valr.size(), valr.data());
+    };
+    mgBuildHierarchy(S, (int)n, I, J, w, diag, firstTransfer);
+    if (S->L.size() < 2) throw std::runtime_error("distributed multigrid: the global hierarchy has a single level");
+    S->distEnsureBuf(D.n1);
+    std::vector<int>().swap(D.own); std::vector<int>().swap(D.nei); std::vector<double>().swap(D.a); std::vector<double>().swap(D.diag);
+    if (std::getenv("QGD_MG_VERBOSE"))
+        for (size_t l = 0; l < S->L.size(); ++l)
+            std::fprintf(stderr, "[qgd mg, spanning the ranks] level %zu: %d rows%s, %.1f stored entries per row\n", l, S->L[l].n,
+                         l == 0 ? " of this rank" : " (replicated)", (double)S->L[l].entries / std::max(S->L[l].n, 1));
+    D.built = true;
+    return true;
+}
+// ---- DistMg: one application z = M r, from comm point to comm point; returns true when z stands ----
+static bool distApplyStep(PressureSolver* S) {
+    PressureSolver::Dist& D = S->dist;
+    hipStream_t stream = S->stream;
+    const int ob = S->ob, nOwned = S->oe - S->ob, nb = blocksOf(nOwned), nu = S->nu;
+    MgLevelT<float>& L0 = S->Lf[0];
+    MgLevelT<float>& L1 = S->Lf[1];
+    const double* ctl = S->ctl;
+    const float* none = nullptr;
+    float* noOut = nullptr;
+    auto sweep = [&](double w, const float* xin, float* xout, float* rout, double cx, double cmPrev) {
+        mgSmoothOwnedKernel<float><<<nb, PB, 0, stream>>>(L0, ob, (float)w, L0.b, xin, xout, rout, ctl, (float)cx, (float)cmPrev);
+    };
+    auto halo = [&](float* v) { D.haloVec = v; D.pending = 1; };
+    // pc: 0 start | 1 .. nu-1 pre-sweeps | 100 residual + restriction | 101 coarse levels + prolongation | 200 + s post-sweeps
+    for (;;) {
+        if (D.pc == 0) {
+            mgConvertKernel<double, float><<<nb, PB, 0, stream>>>(nOwned, D.rhs + ob, L0.b + ob, ctl);
+            D.cur = L0.x; D.nxt = L0.x2;
+            sweep(S->cr[0], none, D.cur, noOut, 1.0, 0.0);
+            D.pc = nu > 1 ? 1 : 100;
+            halo(D.cur);
+            return false;
+        }
+        if (D.pc >= 1 && D.pc < 100) {
+            const int s2 = D.pc;
+            sweep(S->cr[s2], D.cur, D.nxt, noOut, 1.0 + S->cm[s2], s2 >= 2 ? S->cm[s2] : 0.0);
+            std::swap(D.cur, D.nxt);
+            D.pc = s2 + 1 < nu ? s2 + 1 : 100;
+            halo(D.cur);
+            return false;
+        }
+        if (D.pc == 100) {
+            sweep(S->omega, D.cur, noOut, L0.r, 1.0, 0.0);     // r = b - A x over the owned rows
+            PCHECK(hipMemsetAsync(D.buf, 0, sizeof(double) * (size_t)D.n1, stream));
+            if (D.nPt > 0)
+                mgRestrictPartialKernel<float><<<(D.nPt + PB / 64 - 1) / (PB / 64), PB, 0, stream>>>(D.nPt, D.ptNode, D.ptStart, D.ptCol, D.ptVal, L0.r,
+                                                                                                   D.buf, ctl);
+            D.bufN = D.n1; D.pending = 2; D.pc = 101;
+            return false;
+        }
+        if (D.pc == 101) {
+            mgConvertKernel<double, float><<<blocksOf(D.n1), PB, 0, stream>>>(D.n1, D.buf, L1.b, ctl);
+            S->vcycleT<float>(S->Lf, 1, L1.b, L1.x);
+            mgProlongEllKernel<float><<<nb, PB, 0, stream>>>(nOwned, L0.pS, L0.pCol, L0.pVal, (float)S->oc, L1.x, D.cur + ob, ctl);
+            D.pc = 200;
+            halo(D.cur);
+            return false;
+        }
+        const int s2 = D.pc - 200;
+        sweep(S->cr[s2], D.cur, D.nxt, noOut, 1.0 + S->cm[s2], S->cm[s2]);
+        std::swap(D.cur, D.nxt);
+        if (s2 + 1 < nu) { D.pc = 200 + s2 + 1; halo(D.cur); return false; }
+        mgConvertKernel<float, double><<<nb, PB, 0, stream>>>(nOwned, D.cur + ob, D.out + ob, ctl);
+        D.pc = -1;
+        PCHECK(hipGetLastError());
+        return true;
+    }
+}
+static void pressurePhaseTail(PressureSolver* S, int phase);
+// runs the preconditioner of phase `phase`; with the hierarchy that spans the ranks it stops at every comm point (pending != 0)
+static void pressurePrecondition(PressureSolver* S, int phase) {
+    PressureSolver::Dist& D = S->dist;
+    if (!(D.wanted && D.built && S->L.size() >= 2 && S->Lf.size() >= 2 && S->Lf[0].pS && D.n1 > 0)) { S->precondition(); pressurePhaseTail(S, phase); return; }
+    D.rhs = S->r; D.out = S->z; D.pc = 0; D.resumePhase = phase;
+    if (distApplyStep(S)) { D.resumePhase = -1; pressurePhaseTail(S, phase); }
+}
+int pressureSolvePending(PressureSolver* S, double** buf, int64_t* n) {
+    if (buf) *buf = S->dist.buf;
+    if (n) *n = S->dist.bufN;
+    return S->dist.pending;
+}
+float* pressureSolverMgHaloVec(PressureSolver* S) { return S->dist.haloVec; }
+static void pressureBeginBody(PressureSolver* S);
+void pressureSolveContinue(PressureSolver* S) {
+    PressureSolver::Dist& D = S->dist;
+    if (D.pending == 0) return;
+    D.pending = 0;
+    if (D.resumePhase == 0) {            // set-up inside pressureSolveBegin
+        if (!distSetupStep(S)) return;
+        D.resumePhase = -1;
+        pressureBeginBody(S);
+        return;
+    }
+    if (distApplyStep(S)) { const int ph = D.resumePhase; D.resumePhase = -1; pressurePhaseTail(S, ph); }
+}
 void pressureSolveBegin(PressureSolver* S, const double* phiu, const double* phiwo, const double* pb, const double* gb, double tolerance,
                         double relTol, int maxIter, double* p) {
     S->earlyTest = false;
     S->phiu = phiu; S->phiwo = phiwo; S->pb = pb; S->gb = gb; S->tol = tolerance; S->relTol = relTol; S->maxIter = maxIter; S->p = p;
+    if (S->dist.wanted && !S->dist.built) {
+        // the first solve of a shard builds the hierarchy that spans the ranks: two collectives (pressureSolvePending), then the rest
+        S->dist.resumePhase = 0;
+        if (!distSetupStep(S)) return;
+        S->dist.resumePhase = -1;
+    }
+    pressureBeginBody(S);
+}
+static void pressureBeginBody(PressureSolver* S) {
     const MeshView& m = S->m;
     hipStream_t stream = S->stream;
     const int ob = S->ob, oe = S->oe, n = oe - ob, nb = blocksOf(n);
-    PoissonView v{S->a, S->gs, S->bKind, pb, gb, S->diag, S->rhs};
-    ctlKernel<<<1, 1, 0, stream>>>(S->ctl, 0, (double)n, tolerance, relTol, maxIter);
-    assembleKernel<<<nb, PB, 0, stream>>>(m, v, phiu, phiwo, S->refCell, 0.0, p, ob, oe);
-    applyKernel<<<nb, PB, 0, stream>>>(m, S->a, S->diag, p, S->q, nullptr, ob, oe);
-    residual0Kernel<<<nb, PB, 0, stream>>>(n, S->rhs + ob, S->q + ob, p + ob, S->r + ob, S->part, nb);
+    PoissonView v{S->a, S->gs, S->bKind, S->pb, S->gb, S->diag, S->rhs};
+    ctlKernel<<<1, 1, 0, stream>>>(S->ctl, 0, (double)n, S->tol, S->relTol, S->maxIter);
+    assembleKernel<<<nb, PB, 0, stream>>>(m, v, S->phiu, S->phiwo, S->refCell, 0.0, S->p, ob, oe);
+    applyKernel<<<nb, PB, 0, stream>>>(m, S->a, S->diag, S->p, S->q, nullptr, ob, oe);
+    residual0Kernel<<<nb, PB, 0, stream>>>(n, S->rhs + ob, S->q + ob, S->p + ob, S->r + ob, S->part, nb);
     foldCtlKernel<<<2, PB, 0, stream>>>(S->part, nb, 2, S->ctl, C_ABSR, 1);
+    PCHECK(hipGetLastError());
+}
+// what follows the preconditioner in phases 2 and 4
+static void pressurePhaseTail(PressureSolver* S, int phase) {
+    hipStream_t stream = S->stream;
+    const int ob = S->ob, n = S->oe - ob, nb = blocksOf(n);
+    double* ctl = S->ctl;
+    if (phase == 2) {
+        directionCtlKernel<<<nb, PB, 0, stream>>>(n, 1, S->z + ob, S->d + ob, ctl);
+        dotKernel<<<nb, PB, 0, stream>>>(n, S->r + ob, S->z + ob, S->part, ctl);
+        foldCtlKernel<<<1, PB, 0, stream>>>(S->part, nb, 1, ctl, C_RZ, 0);
+    } else {
+        dotKernel<<<nb, PB, 0, stream>>>(n, S->r + ob, S->z + ob, S->part + nb, ctl);
+        foldCtlKernel<<<2, PB, 0, stream>>>(S->part, nb, 2, ctl, C_ABSR2, 0);
+    }
     PCHECK(hipGetLastError());
 }
 void pressureSolvePhase(PressureSolver* S, int phase) {
@@ -1398,6 +1775,7 @@ void pressureSolvePhase(PressureSolver* S, int phase) {
     hipStream_t stream = S->stream;
     const int ob = S->ob, oe = S->oe, n = oe - ob, nb = blocksOf(n);
     double* ctl = S->ctl;
+    if (S->dist.pending) throw std::logic_error("pressureSolvePhase: a collective of the phase in flight is pending (pressureSolvePending)");
     switch (phase) {
         case 1:
             normFactorCtlKernel<<<nb, PB, 0, stream>>>(n, ctl, S->q + ob, S->A1 + ob, S->rhs + ob, S->part);
@@ -1405,10 +1783,7 @@ void pressureSolvePhase(PressureSolver* S, int phase) {
             break;
         case 2:
             ctlKernel<<<1, 1, 0, stream>>>(ctl, 1, 0.0, S->tol, S->relTol, S->maxIter);
-            S->precondition();
-            directionCtlKernel<<<nb, PB, 0, stream>>>(n, 1, S->z + ob, S->d + ob, ctl);
-            dotKernel<<<nb, PB, 0, stream>>>(n, S->r + ob, S->z + ob, S->part, ctl);
-            foldCtlKernel<<<1, PB, 0, stream>>>(S->part, nb, 1, ctl, C_RZ, 0);
+            pressurePrecondition(S, 2);       // + the tail of the phase, now or after the pending collectives
             break;
         case 3:
             // unsharded: the ELL rows of multigrid level 0 are the whole matrix (150 instead of 266 us at 8 M rows); a shard walks
@@ -1424,9 +1799,7 @@ void pressureSolvePhase(PressureSolver* S, int phase) {
                 foldCtlKernel<<<1, PB, 0, stream>>>(S->part, nb, 1, ctl, C_ABSR2, 0);
                 ctlKernel<<<1, 1, 0, stream>>>(ctl, 4, 0.0, S->tol, S->relTol, S->maxIter);
             }
-            S->precondition();
-            dotKernel<<<nb, PB, 0, stream>>>(n, S->r + ob, S->z + ob, S->part + nb, ctl);
-            foldCtlKernel<<<2, PB, 0, stream>>>(S->part, nb, 2, ctl, C_ABSR2, 0);
+            pressurePrecondition(S, 4);
             break;
         case 5:
             ctlKernel<<<1, 1, 0, stream>>>(ctl, 3, 0.0, S->tol, S->relTol, S->maxIter);
@@ -1460,10 +1833,21 @@ int pressureSolveRun(PressureSolver* S, const SolveHooks* hooks, double residual
     auto reduce = [&](int first, int count) { if (hooks && hooks->allreduce) hooks->allreduce(ctl + first, count); };
     auto halo = [&]() { if (hooks && hooks->haloDirection) hooks->haloDirection(); };
     S->earlyTest = !(hooks && hooks->allreduce);
+    // the comm points of the hierarchy that spans the ranks (set-up inside pressureSolveBegin, the cycle inside phases 2 and 4)
+    auto drain = [&]() {
+        double* buf; int64_t nbuf;
+        for (int what; (what = pressureSolvePending(S, &buf, &nbuf)) != 0;) {
+            if (what == 1) { if (hooks && hooks->haloMg) hooks->haloMg(); }
+            else if (hooks && hooks->allreduceBuf) hooks->allreduceBuf(buf, nbuf, what);
+            pressureSolveContinue(S);
+        }
+    };
+    drain();
     reduce(C_ABSR, 3);
     pressureSolvePhase(S, 1);
     reduce(C_NORM, 1);
     pressureSolvePhase(S, 2);
+    drain();
     reduce(C_RZ, 1);
     halo();
     const int ahead = 2;
@@ -1476,6 +1860,7 @@ int pressureSolveRun(PressureSolver* S, const SolveHooks* hooks, double residual
         pressureSolvePhase(S, 3);
         reduce(C_DQ, 1);
         pressureSolvePhase(S, 4);
+        drain();
         reduce(C_ABSR2, 2);
         pressureSolvePhase(S, 5);
         halo();
@@ -1494,7 +1879,7 @@ int pressureSolveRun(PressureSolver* S, const SolveHooks* hooks, double residual
 double pressureSolverSweepMs(PressureSolver* S, int reps, int* rows, double* width) {
     if (rows) *rows = 0;
     if (width) *width = 0.0;
-    if (S->L.empty() || reps <= 0) return 0.0;
+    if (S->L.empty() || reps <= 0 || S->dist.wanted) return 0.0;
     hipEvent_t a, b;
     PCHECK(hipEventCreate(&a)); PCHECK(hipEventCreate(&b));
     float ms = 0;

@@ -415,6 +415,16 @@ void launchQhdAdvance(hipStream_t s, int stencil, bool usesPoints, const MeshVie
 void launchQhdFinish(hipStream_t s, const MeshView& m, const QhdView& q, bool needRef, const double* shift) {
     if (needRef) qhdRefShiftKernel<<<gridOf((int64_t)m.nC + m.nBF), QGD_BLOCK, 0, s>>>(m.nC, m.nBF, q, shift);
 }
+// message kind 3: one value per listed cell of a single-precision vector (the iterate of the multigrid level that spans the ranks)
+__global__ __launch_bounds__(QGD_BLOCK) void qhdHaloFloatKernel(float* __restrict__ vec, const int32_t* __restrict__ cells, const int nCells,
+                                                               double* __restrict__ buf, const int pack) {
+    const int i = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    if (i >= nCells) return;
+    if (pack) buf[i] = (double)vec[cells[i]]; else vec[cells[i]] = (float)buf[i];
+}
+void launchQhdHaloFloat(hipStream_t s, float* vec, const int32_t* cells, int nCells, double* buf, bool pack) {
+    if (nCells > 0) qhdHaloFloatKernel<<<gridOf(nCells), QGD_BLOCK, 0, s>>>(vec, cells, nCells, buf, pack ? 1 : 0);
+}
 void launchQhdHalo(hipStream_t s, const QhdView& q, double* direction, int kind, const int32_t* cells, int nCells, const int32_t* bfaces, int nFaces,
                    double* buf, bool pack) {
     const int n = nCells + (kind == 2 ? 0 : nFaces);

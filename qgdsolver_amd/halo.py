@@ -7,6 +7,10 @@ at most two neighbours, so each pair talks over its own xGMI link).  ``torch.dis
 transport (backend "nccl" == RCCL on ROCm, "gloo" on CPU); pack/unpack are the library's own kernels.
 """
 
+import ctypes as C
+
+from . import _lib as L
+
 
 def slab_range(n, rank, world):
     """owned planes [lo, hi) and the mesh window [k_lo, k_hi) including ghost planes"""
@@ -224,7 +228,7 @@ class NativeComm:
 # ---- QHDFoam on cell-range shards ----------------------------------------------------------------------------------------
 # control-block slots that are global sums (include/qgd_amd.h "the QHD case on a cell-range shard")
 QHD_REDUCE_AFTER_PHASE = {0: (0, 3), 1: (3, 1), 2: (4, 1), 3: (5, 1), 4: (6, 2), 7: (8, 1)}
-QHD_STATE, QHD_PRESSURE, QHD_DIRECTION = 0, 1, 2   # halo message kinds
+QHD_STATE, QHD_PRESSURE, QHD_DIRECTION, QHD_MG_ITERATE = 0, 1, 2, 3   # halo message kinds
 
 
 class QhdStepper:
@@ -292,6 +296,28 @@ class LocalWorld:
     def phase(self, k):
         for c in self.cases:
             c.step_phase(k)
+        self._drain()
+
+    def _drain(self):
+        """the comm points inside a phase (the multigrid hierarchy that spans the ranks: qgd_qhd_case_pending)"""
+        if not hasattr(self.cases[0], "pending"):
+            return
+        import numpy as np
+        while True:
+            pend = [c.pending() for c in self.cases]
+            assert len({p[0] for p in pend}) == 1 and len({p[2] for p in pend}) == 1, pend
+            action, _, count = pend[0]
+            if action == 0:
+                return
+            if action == 1:
+                self.exchange(QHD_MG_ITERATE)
+            else:
+                host = [c.dev.to_host(p[1], (count,)) for c, p in zip(self.cases, pend)]
+                total = np.sum(host, axis=0) if action == 2 else np.max(host, axis=0)
+                for c, p in zip(self.cases, pend):
+                    L.check(L.lib.qgd_device_copy(c.dev._h, C.c_void_p(p[1]), total.ctypes.data_as(C.c_void_p), total.nbytes, 1), "qgd_device_copy")
+            for c in self.cases:
+                c.step_phase(9)
 
     def allreduce(self, first, count):
         ctl = [c.control() for c in self.cases]
@@ -338,6 +364,20 @@ class DistWorld:
 
     def phase(self, k):
         self.case.step_phase(k)
+        if not hasattr(self.case, "pending"):
+            return
+        while True:                       # the comm points inside a phase (qgd_qhd_case_pending)
+            action, ptr, count = self.case.pending()
+            if action == 0:
+                return
+            if action == 1:
+                self.exchange(QHD_MG_ITERATE)
+            else:
+                t = self.to_transport(ptr, count)
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM if action == 2 else self.dist.ReduceOp.MAX)
+                self.from_transport(t, ptr)
+                self.case.sync()
+            self.case.step_phase(9)
 
     def allreduce(self, first, count):
         a = self.case.control()

@@ -207,6 +207,13 @@ class QHDFoamCase:
     def step_phase(self, phase):
         L.check(L.lib.qgd_qhd_case_step_phase(self._h, int(phase)), "qgd_qhd_case_step_phase")
 
+    def pending(self):
+        """(action, device pointer, count) the phase in flight waits for before step_phase(9): 0 nothing, 1 halo message kind 3,
+        2 / 3 SUM / MAX all-reduce of `count` doubles at the pointer (the multigrid hierarchy that spans the ranks, include/qgd_amd.h)"""
+        a, p, n = C.c_int32(), C.c_void_p(), C.c_int64()
+        L.check(L.lib.qgd_qhd_case_pending(self._h, C.byref(a), C.byref(p), C.byref(n)), "qgd_qhd_case_pending")
+        return a.value, p.value, n.value
+
     def control_ptr(self):
         """device pointer of the 16-double control block of the pressure solve (slots [0,3) [3] [4] [5] [6,8) [8] are reduced)"""
         p = C.c_void_p()

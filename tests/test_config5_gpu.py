@@ -189,7 +189,8 @@ def test_c5_qhd_case_cut_8_ways_resident_on_one_gpu():
     vertex-connected ghost layer and one halo slot per neighbouring range), eight resident QHDFoam cases stepped in lockstep by the
     QhdStepper a real run uses (messages device-to-device through the pack / unpack kernels, the PCG's sums through the control
     blocks), two steps, against the unsharded 16 M-cell case.  The pressure equation is solved to 1e-11, so p agrees to ~1e-7 and
-    U, T to 1e-9; the block (additive Schwarz) preconditioner may cost iterations, not accuracy."""
+    U, T to 1e-9.  The pressure solver's multigrid hierarchy spans the eight shards (two all-reduces gather the global matrix at the first
+    step; level 0 distributed, coarse levels replicated), so the iteration count is the unsharded one."""
     import os
     from qgdsolver_amd.halo import LocalWorld, QhdStepper
     from qhd_shards import gather, range_shards
@@ -226,9 +227,9 @@ def test_c5_qhd_case_cut_8_ways_resident_on_one_gpu():
     QhdStepper(LocalWorld(cases, [sh["peers"] for sh in shards])).step(steps)
     infos = [c.info() for c in cases]
     assert all(i["steps"] == steps and i["pFinalResidual"] < 1e-11 for i in infos), infos
-    # every rank's multigrid hierarchy covers its own rows only (additive Schwarz without a coarse space that spans the ranks): measured
-    # 186 iterations against 16 unsharded at 1e-11 (DESIGN.md section 6 states the penalty); the bound guards against worse
-    assert len({i["pIterations"] for i in infos}) == 1 and infos[0]["pIterations"] <= 15 * winfo["pIterations"] + 20, (infos[0], winfo)
+    # the multigrid hierarchy spans the ranks (distributed level 0, replicated coarse levels): the sharded solve needs the iterations
+    # of the unsharded one (16 = 16 at 1e-11; with rank-local hierarchies, QGD_MG_DIST=0, it was 186)
+    assert len({i["pIterations"] for i in infos}) == 1 and infos[0]["pIterations"] <= winfo["pIterations"] + 2, (infos[0], winfo)
     print("c5 8-way: pressure iterations", infos[0]["pIterations"], "sharded,", winfo["pIterations"], "unsharded")
     for f, ncomp, tol in (("U", 3, 1e-8), ("T", 1, 1e-9), ("p", 1, 1e-6)):
         got = gather(shards, cases, f, nc, ncomp)

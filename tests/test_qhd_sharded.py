@@ -172,6 +172,54 @@ def test_device_shards_match_unsharded_device_and_oracle(cut, world, bc_fn, ref_
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cut,world", [("slabs", 3), ("ranges", 4)])
+def test_multigrid_hierarchy_spans_the_ranks(cut, world, monkeypatch):
+    """Meshes large enough for a real hierarchy (> 1024 cells: below that the ranks keep their own): the first step gathers the global
+    matrix (two all-reduces through qgd_qhd_case_pending), level 0 stays distributed, the coarse levels are replicated -- the sharded
+    solve then needs the unsharded solve's iterations, where rank-local hierarchies (QGD_MG_DIST=0) need several times as many; the
+    fields agree with the unsharded device case and the oracle either way."""
+    if cut == "slabs":
+        g = q.PolyMesh.box(16, 14, 18)
+        make = lambda: box_slabs(16, 14, 18, world)
+    else:
+        g = q.PolyMesh.box(14, 12, 16).jitter(0.2, seed=3)
+        g.split_quads(5)
+        g.renumber(np.random.default_rng(8).permutation(g.nCells).astype(np.int32))
+        g.renumber(g.morton_order())
+        make = lambda: range_shards(g, world)
+    opt = options("GaussVolPoint", deltaT=1e-3, pRefCell=g.nCells // 2, pRefValue=0.1, pTol=1e-11)
+    fields = perturbed(g)
+    steps = 3
+    ref = run_unsharded_oracle(g, options("GaussVolPoint", deltaT=1e-3, precond=0, pRefCell=g.nCells // 2, pRefValue=0.1, pTol=1e-13), cavity_bcs, fields, steps)
+    gdev = q.Device(g)
+    whole = qhdfoam.QHDFoamCase(gdev, opt)
+    cavity_bcs(whole, g)
+    whole.set_fields(*fields)
+    whole.step(steps)
+    assert whole.info()["mgLevels"] >= 2
+    iters = {}
+    for dist in ("1", "0"):
+        monkeypatch.setenv("QGD_MG_DIST", dist)
+        shards = make()
+        pairs = [make_device_shard_case(sh, opt, cavity_bcs, fields) for sh in shards]
+        cases = [c for _, c in pairs]
+        QhdStepper(LocalWorld(cases, [sh["peers"] for sh in shards])).step(steps)
+        for f, nc in FIELDS:
+            got = gather(shards, cases, f, g.nCells, nc)
+            for tag, want in (("unsharded device", whole.field(f)), ("oracle", ref.field(f))):
+                err = np.abs(got - want).max() / max(np.abs(want).max(), 1e-300)
+                assert err <= 1e-7, (cut, dist, f, tag, err)
+        its = {c.info()["pIterations"] for c in cases}
+        assert len(its) == 1
+        iters[dist] = its.pop()
+        for d, c in pairs:
+            c.close(); d.close()
+    assert iters["1"] <= whole.info()["pIterations"] + 2, (iters, whole.info())
+    assert iters["0"] > iters["1"], iters
+    whole.close(); gdev.close()
+
+
+@pytest.mark.gpu
 def test_native_step_on_one_rank_is_the_plain_step():
     """qgd_qhd_case_step_sharded over a one-rank communicator on an unsharded mesh: the library's own loop (ncclAllReduce and
     exchanges degenerate to nothing) gives the plain step bit for bit"""
