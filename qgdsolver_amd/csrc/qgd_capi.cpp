@@ -82,7 +82,7 @@ struct DeviceArena {
     T* alloc(size_t n, bool zero = true) {
         if (n == 0) return nullptr;
         void* d = raw(n * sizeof(T));
-        if (zero) HIP_CHECK(hipMemset(d, 0, n * sizeof(T)));
+        if (zero) { HIP_CHECK(hipMemset(d, 0, n * sizeof(T))); HIP_CHECK(hipStreamSynchronize(nullptr)); }   // see PressureSolver::alloc
         return (T*)d;
     }
     void release() {
@@ -838,8 +838,10 @@ int qgd_device_copy(qgd_device_t d, void* dst, const void* src, int64_t bytes, i
     QGD_TRY
     if (!d || !dst || !src || bytes < 0) return fail(QGD_ERR_INVALID, "qgd_device_copy: bad argument");
     HIP_CHECK(hipSetDevice(d->deviceId));
+    // on the device's own stream and complete at return: that stream is non-blocking, and a hipMemcpy from pageable memory on the null
+    // stream may return while its staged copy is still on the way -- a kernel queued on d->stream right after could read the old bytes
+    if (bytes) HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)bytes, toDevice ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, d->stream));
     HIP_CHECK(hipStreamSynchronize(d->stream));
-    if (bytes) HIP_CHECK(hipMemcpy(dst, src, (size_t)bytes, toDevice ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost));
     return QGD_OK;
     QGD_CATCH
 }
@@ -1101,7 +1103,7 @@ int qgd_qhd_pressure(qgd_device_t d, const double* phiu, const double* phiwo, co
         auto upD = [&](const double* src, size_t n) {
             double* dst = tmp.alloc<double>(std::max<size_t>(n, 1), false);
             if (src && n) HIP_CHECK(hipMemcpy(dst, src, sizeof(double) * n, hipMemcpyHostToDevice));
-            else HIP_CHECK(hipMemset(dst, 0, sizeof(double) * std::max<size_t>(n, 1)));
+            else { HIP_CHECK(hipMemset(dst, 0, sizeof(double) * std::max<size_t>(n, 1))); HIP_CHECK(hipStreamSynchronize(nullptr)); }
             return dst;
         };
         double* dGamma = upD(taubyrhof, nF);
@@ -1517,6 +1519,7 @@ int qgd_device_alloc(qgd_device_t d, int64_t bytes, void** devicePtr) {
     HIP_CHECK(hipSetDevice(d->deviceId));
     HIP_CHECK(hipMalloc(devicePtr, (size_t)bytes));
     HIP_CHECK(hipMemset(*devicePtr, 0, (size_t)bytes));
+    HIP_CHECK(hipStreamSynchronize(nullptr));   // the zero-fill is done before the caller's first copy on the device's (non-blocking) stream
     return QGD_OK;
     QGD_CATCH
 }

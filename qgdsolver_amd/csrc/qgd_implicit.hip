@@ -601,6 +601,7 @@ ImplicitSolver* implicitSolverCreate(hipStream_t stream, const MeshView& m, int 
         ICHECK(hipMemset(S->stats, 0, sizeof(double) * (2 + 2 * I_COUNT)));
         ICHECK(hipMemset(S->d, 0, sizeof(double) * 3 * nC));     // ghost entries of the direction are read before the first exchange fills them
         ICHECK(hipMemset(S->ctl, 0, sizeof(double) * I_COUNT));
+        ICHECK(hipStreamSynchronize(nullptr));   // null-stream zero-fills are done before anything runs on the solver's non-blocking stream
         ICHECK(hipHostMalloc((void**)&S->hostCtl, sizeof(double) * I_COUNT * 5, hipHostMallocDefault));
         for (hipEvent_t& e : S->ev) ICHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     } catch (...) { implicitSolverFree(S); throw; }

@@ -811,7 +811,12 @@ struct PressureSolver {
         owned.push_back(p);
         bytes += (int64_t)nb;
         if (host && n) PCHECK(hipMemcpy(p, host, n * sizeof(T), hipMemcpyHostToDevice));
-        else PCHECK(hipMemset(p, 0, nb));
+        else {
+            // hipMemset runs on the NULL stream and returns before it is done; the solver's stream is non-blocking, so a copy or kernel
+            // queued there right after could be overtaken by the zero-fill (seen: the gather buffers of DistMg zeroed AFTER they were filled)
+            PCHECK(hipMemset(p, 0, nb));
+            PCHECK(hipStreamSynchronize(nullptr));
+        }
         return (T*)p;
     }
     ~PressureSolver() {
@@ -1517,7 +1522,10 @@ static bool distSetupStep(PressureSolver* S) {
         PCHECK(hipMemcpyAsync(v, D.buf, sizeof(v), hipMemcpyDeviceToHost, stream));
         PCHECK(hipStreamSynchronize(stream));
         D.nCg = (int64_t)v[0]; D.K = (int)v[1];
-        if (D.nCg <= MG_DENSE_MAX || D.nCg >= 0x7fffffffLL || D.nCg == nOwned) { distBlockFallback(S); D.built = true; return true; }
+        if (D.nCg <= MG_DENSE_MAX || D.nCg >= 0x7fffffffLL || D.nCg == nOwned) {
+            if (std::getenv("QGD_MG_VERBOSE")) std::fprintf(stderr, "[qgd mg] rank-local hierarchy: %lld cells in all, %d here\n", (long long)D.nCg, nOwned);
+            distBlockFallback(S); D.built = true; return true;
+        }
         // this rank's share of the global matrix: the diagonal of its cells and, per cell, its couplings to higher-numbered neighbours
         const int64_t n = D.nCg, K = D.K;
         std::vector<double> h((size_t)(n * (1 + 2 * K)), 0.0);
@@ -1529,6 +1537,7 @@ static bool distSetupStep(PressureSolver* S) {
             if (lo < ob || lo >= oe) continue;
             const int64_t glo = std::min(go, gn), ghi = std::max(go, gn);
             const int k = cnt[lo]++;
+            if (k >= K || glo >= n || ghi >= n) throw std::runtime_error("distributed multigrid: the ranks disagree about the size of the global matrix");
             h[(size_t)(n + glo * K + k)] = (double)(ghi + 1);
             h[(size_t)(n + n * K + glo * K + k)] = D.a[f];
         }
@@ -1557,7 +1566,10 @@ static bool distSetupStep(PressureSolver* S) {
     // a cell nobody contributed (a caller without the all-reduce: one rank driving a shard on its own) -> the rank-local hierarchy
     bool complete = true;
     for (int64_t g = 0; g < n && complete; ++g) complete = diag[(size_t)g] > 0.0;
-    if (!complete) { distBlockFallback(S); D.built = true; return true; }
+    if (!complete) {
+        if (std::getenv("QGD_MG_VERBOSE")) std::fprintf(stderr, "[qgd mg] rank-local hierarchy: the gathered matrix has rows nobody contributed\n");
+        distBlockFallback(S); D.built = true; return true;
+    }
     // level 0, distributed: the owned rows with their ghost columns, every vector by local cell label
     const int nC = S->m.nC;
     {

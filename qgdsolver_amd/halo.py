@@ -312,6 +312,8 @@ class LocalWorld:
             if action == 1:
                 self.exchange(QHD_MG_ITERATE)
             else:
+                for c in self.cases:
+                    c.sync()                      # the buffers are written by kernels on the cases' streams
                 host = [c.dev.to_host(p[1], (count,)) for c, p in zip(self.cases, pend)]
                 total = np.sum(host, axis=0) if action == 2 else np.max(host, axis=0)
                 for c, p in zip(self.cases, pend):
@@ -373,6 +375,7 @@ class DistWorld:
             if action == 1:
                 self.exchange(QHD_MG_ITERATE)
             else:
+                self.case.sync()                  # the buffer is written by kernels on the case's stream
                 t = self.to_transport(ptr, count)
                 self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM if action == 2 else self.dist.ReduceOp.MAX)
                 self.from_transport(t, ptr)

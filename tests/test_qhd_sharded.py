@@ -182,10 +182,8 @@ def test_multigrid_hierarchy_spans_the_ranks(cut, world, monkeypatch):
         g = q.PolyMesh.box(16, 14, 18)
         make = lambda: box_slabs(16, 14, 18, world)
     else:
-        g = q.PolyMesh.box(14, 12, 16).jitter(0.2, seed=3)
-        g.split_quads(5)
-        g.renumber(np.random.default_rng(8).permutation(g.nCells).astype(np.int32))
-        g.renumber(g.morton_order())
+        from qhd_halo_worker_gpu import spanning_test_mesh
+        g = spanning_test_mesh()
         make = lambda: range_shards(g, world)
     opt = options("GaussVolPoint", deltaT=1e-3, pRefCell=g.nCells // 2, pRefValue=0.1, pTol=1e-11)
     fields = perturbed(g)
@@ -216,6 +214,39 @@ def test_multigrid_hierarchy_spans_the_ranks(cut, world, monkeypatch):
             c.close(); d.close()
     assert iters["1"] <= whole.info()["pIterations"] + 2, (iters, whole.info())
     assert iters["0"] > iters["1"], iters
+    whole.close(); gdev.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_device_shards_over_gloo(tmp_path, world):
+    """the sharded device case as separate processes (all on the one GPU of the box, gloo with host-staged buffers): halo messages,
+    the all-reduced PCG scalars and the comm points of the multigrid hierarchy that spans the ranks through DistWorld"""
+    from qhd_halo_worker_gpu import spanning_test_mesh
+    steps = 3
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(29570 + world), os.path.join(ROOT, "tests", "qhd_halo_worker_gpu.py"), str(tmp_path), str(steps)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    g = spanning_test_mesh()
+    opt = options("GaussVolPoint", deltaT=1e-3, pRefCell=g.nCells // 2, pRefValue=0.1, pTol=1e-11)
+    fields = perturbed(g)
+    gdev = q.Device(g)
+    whole = qhdfoam.QHDFoamCase(gdev, opt)
+    cavity_bcs(whole, g)
+    whole.set_fields(*fields)
+    whole.step(steps)
+    covered = 0
+    for rank in range(world):
+        d = np.load(os.path.join(tmp_path, f"rank{rank}.npz"))
+        covered += d["cells"].size
+        for f, _ in FIELDS:
+            want = whole.field(f)[d["cells"]]
+            assert np.abs(d[f] - want).max() <= 1e-7 * max(np.abs(whole.field(f)).max(), 1e-300), (rank, f)
+        assert 0 < int(d["iterations"]) <= whole.info()["pIterations"] + 2, (int(d["iterations"]), whole.info())
+        assert int(d["levels"]) == whole.info()["mgLevels"]      # the same global hierarchy on every rank
+    assert covered == g.nCells
     whole.close(); gdev.close()
 
 
