@@ -423,13 +423,133 @@ def qhd_line(args):
     print(json.dumps(out), flush=True)
 
 
+def qhd_line_sharded(args):
+    """python bench.py --workload qhd --gpus N [--irregular]: the QHDFoam step on N cell-range shards, one rank per GPU -- config 5 as
+    configured.  Transport: the library's own RCCL path (qgd_qhd_case_step_sharded: halo messages, all-reduced PCG scalars, the comm
+    points of the multigrid hierarchy that spans the ranks); with --backend gloo every rank sits on GPU 0 and DistWorld stages the
+    messages through host tensors (the debugging mode a 1-GPU box can run)."""
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+
+    import qgdsolver_amd as q
+    from qgdsolver_amd import _lib as L, qhdfoam
+    from qgdsolver_amd.halo import DistWorld, NativeComm, QhdStepper, slab_range
+
+    world, rank, local_rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
+    staged = args.backend == "gloo"
+    if staged:
+        local_rank = 0
+    if q.device_count() < 1:
+        raise RuntimeError("bench.py needs a HIP device: qgdsolver_amd has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend="gloo") if staged else dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    n = args.n
+    t_setup = time.perf_counter()
+    if args.irregular:
+        from test_config5_gpu import c5_mesh
+        g = c5_mesh(n, 64 ** 3)
+        mesh = g.shard(world, rank)
+        n_global = g.nCells
+        cg = mesh.array("cellGlobal")
+        lo, hi = (n_global * rank) // world, (n_global * (rank + 1)) // world
+        owned = int(((cg >= lo) & (cg < hi)).sum())
+        peers = [int(p) for p in mesh.array("haloPeer")]
+        g.close()
+    else:
+        lo, hi, k_lo, k_hi = slab_range(n, rank, world)
+        mesh = q.PolyMesh.box(n, n, n, k_range=(k_lo, k_hi))
+        n_global = n ** 3
+        cg = np.arange(n * n * k_lo, n * n * k_hi)
+        owned = n * n * (hi - lo)
+        peers = [rank - 1 if rank > 0 else -1, rank + 1 if rank < world - 1 else -1]
+    h = 1.0 / n
+    dev = q.Device(mesh, device_id=local_rank)
+    opt = qhdfoam.qhd_options(stencil="GaussVolPoint", tauModel="HbyUQHD", aQGD=0.5, UQHD=0.1, rho0=1.0, mu=1e-3, Pr=0.71, beta=3.4e-3,
+                              g=(0.0, -9.81, 0.0), deltaT=0.02 * h / 0.1, pTol=1e-8, pMaxIter=300, pRefCell=0)
+    case = qhdfoam.QHDFoamCase(dev, opt)
+    WALL = dict(U=("fixedValue", (0.0, 0.0, 0.0)), T=("zeroGradient", None), p=("qhdFluxCoupled", None))
+    for ip in range(mesh.nPatches):
+        case.set_bc(ip, U=WALL["U"], T=("fixedValue", 310.0) if ip == 0 else (("fixedValue", 290.0) if ip == 1 else WALL["T"]), p=WALL["p"])
+    Cc = mesh.array("C").reshape(-1, 3)
+    noise = np.random.default_rng(5).standard_normal(n_global)[cg]      # a function of the GLOBAL cell label: shards agree with the whole
+    U = np.zeros((mesh.nCells, 3))
+    U[:, 0] = 0.1 * np.sin(np.pi * Cc[:, 0]) * np.cos(np.pi * Cc[:, 1])
+    U[:, 1] = -0.1 * np.cos(np.pi * Cc[:, 0]) * np.sin(np.pi * Cc[:, 1])
+    case.set_fields(U, 300.0 + 10.0 * (0.5 - Cc[:, 0]) + 0.1 * noise, np.zeros(mesh.nCells))
+    del U, Cc, noise
+    t_setup = time.perf_counter() - t_setup
+    if staged:
+        def to_t(ptr, cnt):
+            return torch.from_numpy(dev.to_host(ptr, (int(cnt),)))
+
+        def from_t(t, ptr):
+            a = np.ascontiguousarray(t.numpy())
+            if a.nbytes:
+                L.check(L.lib.qgd_device_copy(dev._h, C.c_void_p(ptr), a.ctypes.data_as(C.c_void_p), a.nbytes, 1), "qgd_device_copy")
+
+        stepper = QhdStepper(DistWorld(case, dist, torch, peers, to_t, from_t))
+        run = stepper.step
+        transport = "gloo, host-staged (debugging mode: every rank on GPU 0)"
+    else:
+        def bcast(raw):
+            box = [raw]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+
+        comm = NativeComm(local_rank, rank, world, bcast=bcast)
+        comm.qhd_exchange(case, peers, 0)          # ghost cells start from their owners
+        run = lambda k: comm.qhd_step(case, peers, k)   # noqa: E731
+        transport = "RCCL inside the library (qgd_qhd_case_step_sharded)"
+    t_first = time.perf_counter()
+    run(max(args.warmup, 1))                       # the first step also builds the multigrid hierarchy that spans the ranks
+    case.sync()
+    t_first = time.perf_counter() - t_first
+    dist.barrier()
+    t0 = time.perf_counter()
+    run(args.steps)
+    case.sync()
+    dist.barrier()
+    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=None if staged else "cuda")
+    dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+    info = case.info()
+    check = torch.tensor([float(np.abs(case.field("p")[: min(owned, mesh.nCells)]).sum())], dtype=torch.float64, device=None if staged else "cuda")
+    dist.all_reduce(check, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "Mcell-steps/s (QHDFoam step)", "value": n_global * args.steps / elapsed / 1e6, "unit": "Mcell-steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": (f"QHDFoam buoyant cavity, {n_global / 1e6:.1f}M cells on {world} cell-range shards, "
+                                    + ("config-5 stand-in mesh (jittered hexahedra, every 7th quad split into triangles, Morton order)" if args.irregular
+                                       else "uniform hex box cut into k-slabs")
+                                    + ", GaussVolPoint, HbyUQHD, pressure equation to 1e-8, multigrid hierarchy spanning the ranks"),
+                       "cells": n_global, "cells_per_gpu": n_global // world, "transport": transport,
+                       "pressure_iterations_per_step": info["pIterations"], "multigrid_levels": info["mgLevels"]},
+            "roofline": {"bound": "hbm", "kernel": "distributed level 0 of the multigrid cycle: no separate sweep timing on shards", "achieved": None,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None},
+            "pressure_final_residual": info["pFinalResidual"], "first_steps_s": t_first, "setup_s": t_setup,
+            "sum_abs_p_owned_prefix": float(check.item())}), flush=True)
+    case.close(); dev.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     args = parse()
     if args.workload == "qhd":
-        if args.gpus != 1:
-            sys.exit("bench.py --workload qhd measures one GPU (the sharded QHD step is driven by qgd_qhd_case_step_sharded, see DESIGN.md)")
         if "QGD_BENCH_N" not in os.environ and "--edge" not in " ".join(sys.argv):
             args.n = 252 if args.irregular else 200
+        if args.gpus > 1:
+            if "WORLD_SIZE" not in os.environ:
+                self_launch(args.gpus)   # never returns
+            if int(os.environ["WORLD_SIZE"]) != args.gpus:
+                print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}: the launcher and the flag disagree", file=sys.stderr)
+                sys.exit(2)
+            qhd_line_sharded(args)
+            return
         qhd_line(args)
         return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.cpu_only:

@@ -219,6 +219,17 @@ class NativeComm:
     def allreduce_max(self, case):
         self._L.check(self._L.lib.qgd_case_allreduce_max(case._h, self._h), "qgd_case_allreduce_max")
 
+    def qhd_exchange(self, case, peers, kind=0):
+        """message kind 0 (state), 1 (p) ... of a sharded QHDFoam case over RCCL (qgd_qhd_case_halo_exchange)"""
+        a, p, n = self._peers(peers)
+        self._L.check(self._L.lib.qgd_qhd_case_halo_exchange(case._h, self._h, p, n, int(kind)), "qgd_qhd_case_halo_exchange")
+
+    def qhd_step(self, case, peers, n_steps=1):
+        """whole QHDFoam steps of a sharded case with the transport inside the library (qgd_qhd_case_step_sharded): halo messages,
+        the all-reduced scalars of the pressure solve and the comm points of its multigrid hierarchy, all on the device's stream"""
+        a, p, n = self._peers(peers)
+        self._L.check(self._L.lib.qgd_qhd_case_step_sharded(case._h, self._h, p, n, int(n_steps)), "qgd_qhd_case_step_sharded")
+
     def close(self):
         if getattr(self, "_h", None):
             self._L.lib.qgd_comm_free(self._h)

@@ -54,3 +54,20 @@ def test_two_ranks_self_launched_match_one_rank():
     for x, y in zip(a["checksum_rho"], b["checksum_rho"]):
         assert abs(x - y) <= 1e-12 * abs(x), (a["checksum_rho"], b["checksum_rho"])
     assert b["roofline"]["frac"] is not None and b["value"] > 0
+
+
+@pytest.mark.gpu
+def test_qhd_workload_on_two_self_launched_ranks():
+    """python bench.py --workload qhd --gpus 2: config 5's path (sharded QHDFoam case, pressure solve with the multigrid hierarchy that
+    spans the ranks) as two processes on the one GPU of the box, gloo with host-staged messages; same pressure iterations as one rank"""
+    common = ["--workload", "qhd", "--edge", "32", "--steps", "2", "--warmup", "1"]
+    one, _ = run_bench(["--gpus", "1"] + common, 900)
+    assert one.returncode == 0, one.stderr[-800:]
+    two, _ = run_bench(["--gpus", "2", "--backend", "gloo"] + common, 900)
+    assert two.returncode == 0, two.stderr[-1500:]
+    a = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+    b = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
+    assert a["n_gpus"] == 1 and b["n_gpus"] == 2 and b["config"]["cells"] == 32 ** 3 and b["config"]["cells_per_gpu"] == 32 ** 3 // 2
+    assert b["config"]["transport"].startswith("gloo") and b["value"] > 0
+    assert 0 < b["config"]["pressure_iterations_per_step"] <= a["config"]["pressure_iterations_per_step"] + 2, (a["config"], b["config"])
+    assert b["config"]["multigrid_levels"] == a["config"]["multigrid_levels"] and b["pressure_final_residual"] < 1e-8
