@@ -126,16 +126,40 @@ def run(case_dir, n_steps=None, device_id=0, write=True, log=print, renumber="no
         else:
             halo = RangeHalo(case, rank, world, dist, alloc=lambda c: torch.empty(c, dtype=torch.float64, device="cuda"),
                              arg=lambda t: t.data_ptr())
-        halo.exchange()
         from .halo import allreduce_max_of
         allreduce_max = allreduce_max_of(torch, dist, case, staged)
+        stepper = None
+        if case.options.implicitDiffusion:
+            # the reference's default branch on shards: phases 20..35 with their messages and all-reduced solver scalars
+            # (include/qgd_amd.h "the implicitDiffusion branch on a cell-range shard")
+            import ctypes as C
+            from . import _lib as L
+            from .halo import DistWorld, ImplicitShard, ImplicitStepper, device_tensor
+            peers = [int(p) for p in mesh.array("haloPeer")]
+            if staged:
+                def to_t(ptr, cnt):
+                    return torch.from_numpy(dev.to_host(ptr, (int(cnt),)))
+
+                def from_t(t, ptr):
+                    a = np.ascontiguousarray(t.numpy())
+                    if a.nbytes:
+                        L.check(L.lib.qgd_device_copy(dev._h, C.c_void_p(ptr), a.ctypes.data_as(C.c_void_p), a.nbytes, 1), "qgd_device_copy")
+            else:
+                to_t = lambda ptr, cnt: device_tensor(torch, ptr, cnt)     # noqa: E731  (views of the library's buffers)
+                from_t = lambda t, ptr: None                               # noqa: E731
+            stepper = ImplicitStepper(DistWorld(ImplicitShard(case), dist, torch, peers, to_t, from_t, kinds=range(5), device_reduce=not staged))
+        else:
+            halo.exchange()
 
     def advance(n):
         if world == 1:
             case.step(n)
             return
-        for _ in range(n):
-            halo.step(allreduce_max if adjust else None)
+        if stepper is not None:
+            stepper.step(n, (lambda: allreduce_max(case)) if adjust else None)
+        else:
+            for _ in range(n):
+                halo.step(allreduce_max if adjust else None)
         case.sync()
 
     def gather(name):

@@ -363,8 +363,11 @@ class DistWorld:
     ``peers[slot]`` = rank behind each halo slot.  ``to_transport(buf, n)`` / ``from_transport(t, buf)`` turn the case's
     halo buffer (a device pointer, or a host array when the cases live on the CPU) into a torch tensor the backend can send and back."""
 
-    def __init__(self, case, dist, torch, peers, to_transport, from_transport, kinds=(0, 1, 2)):
+    def __init__(self, case, dist, torch, peers, to_transport, from_transport, kinds=(0, 1, 2), device_reduce=False):
+        # device_reduce: the backend takes device tensors (nccl == RCCL) -- reductions run in place on views of the library's own
+        # device memory (the case's kernels must run on torch's current stream: case.set_stream)
         self.case, self.dist, self.torch, self.peers = case, dist, torch, list(peers)
+        self.device_reduce = device_reduce
         self.to_transport, self.from_transport = to_transport, from_transport
         self.slots = [s for s, p in enumerate(self.peers) if p >= 0]
         if self.needs_mid():
@@ -385,6 +388,9 @@ class DistWorld:
                 return
             if action == 1:
                 self.exchange(QHD_MG_ITERATE)
+            elif self.device_reduce:
+                t = device_tensor(self.torch, ptr, count)
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM if action == 2 else self.dist.ReduceOp.MAX)
             else:
                 self.case.sync()                  # the buffer is written by kernels on the case's stream
                 t = self.to_transport(ptr, count)
@@ -394,6 +400,10 @@ class DistWorld:
             self.case.step_phase(9)
 
     def allreduce(self, first, count):
+        if self.device_reduce:
+            t = device_tensor(self.torch, self.case.control_ptr() + 8 * first, count)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+            return
         a = self.case.control()
         t = self.torch.from_numpy(a[first:first + count].copy())
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
@@ -450,6 +460,9 @@ class ImplicitShard:
 
     def set_control(self, a):
         self.case.set_implicit_control(a)
+
+    def control_ptr(self):
+        return self.case.implicit_control_ptr()
 
     def solve_status(self):
         return dict(done=1 if self.case.implicit_solve_done() else 0)
@@ -510,7 +523,9 @@ class ImplicitStepper:
             w.phase(27)
             w.exchange(IMPL_DIRECTION)
 
-    def step(self, n=1):
+    def step(self, n=1, allreduce_max=None):
+        """``allreduce_max()`` (adjustTimeStep): the MAX all-reduce of every shard's {max Co, -min tauQGDf} buffer, between the
+        assembly and phase 20 (which forms deltaT from it)"""
         w = self.world
         if not self.started:
             w.exchange(IMPL_STATE)     # ghost cells start from their owners' records
@@ -523,6 +538,8 @@ class ImplicitStepper:
                 w.phase(6)
             else:
                 w.phase(0)
+            if allreduce_max is not None:
+                allreduce_max()
             w.phase(20)
             w.exchange(IMPL_GRADU)
             w.phase(21)
