@@ -66,38 +66,9 @@ __device__ __forceinline__ void muDev2T(const double* g, const double mu, double
 // (1.44 -> 0.5 ms at 8 M cells), same operations in the same order.
 __global__ __launch_bounds__(QGD_BLOCK) void implCellGradKernel(const MeshView m, const CaseView c, const ImplView iv) {
     const int ci = blockIdx.x * QGD_BLOCK + threadIdx.x;
-    if (ci >= m.nC) return;
-    if (m.ghost && m.ghost[ci] == 1) return;   // a ghost cell lacks faces here: its gradient arrives by message
-    const int n = m.cfCount[ci];
-    const size_t base = (size_t)m.cfSlice[ci >> 6] * 64 + (ci & 63);
-    const double* __restrict__ Ad = reinterpret_cast<const double*>(c.A);
-    const double* __restrict__ bAd = reinterpret_cast<const double*>(c.bA);
-    const double Uc[3] = {Ad[(size_t)ci * 6 + 1], Ad[(size_t)ci * 6 + 2], Ad[(size_t)ci * 6 + 3]};
-    double G[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int i = 0; i < n; ++i) {
-        const int it = m.cfItem[base + (size_t)i * 64];
-        const int nb = m.cfNbr[base + (size_t)i * 64];
-        const int f = it >= 0 ? it : ~it;
-        if (m.fkind[f] == 3) continue;
-        double Uf[3];
-        if (nb >= 0) {
-            const double w = m.w[f];
-            const double Un[3] = {Ad[(size_t)nb * 6 + 1], Ad[(size_t)nb * 6 + 2], Ad[(size_t)nb * 6 + 3]};
-#pragma unroll
-            for (int k = 0; k < 3; ++k) Uf[k] = it >= 0 ? lerpf(w, Uc[k], Un[k]) : lerpf(w, Un[k], Uc[k]);   // lerp(w, owner, neighbour)
-        } else {
-            const size_t b = (size_t)(f - m.nIF);
-            Uf[0] = bAd[b * 6 + 1]; Uf[1] = bAd[b * 6 + 2]; Uf[2] = bAd[b * 6 + 3];
-        }
-        const double S[3] = {m.Sx[f], m.Sy[f], m.Sz[f]};
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) G[3 * a + j] = it >= 0 ? G[3 * a + j] + S[a] * Uf[j] : G[3 * a + j] - S[a] * Uf[j];
-    }
-    const double V = m.V[ci];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) iv.gUc[(size_t)ci * 9 + k] = G[k] / V;
+    const bool live = ci < m.nC && !(m.ghost && m.ghost[ci] == 1);   // a ghost cell lacks faces here: its gradient arrives by message
+    if (__ballot(live) == 0) return;
+    if (live) cellGradGauss<6, 1, 6, 1>(m, ci, reinterpret_cast<const double*>(c.A), reinterpret_cast<const double*>(c.bA), iv.gUc);
 }
 
 // per face: muf, alphauf, Uf, tauMC -> phiTauMC, Sf.(tauMC & Uf), the laplacian coefficients [updateFluxes.H L107-111]

@@ -104,38 +104,9 @@ __global__ __launch_bounds__(QGD_BLOCK) void qhdPressureBcKernel(const MeshView 
 // (cfNbr) or the patch value, the weight and Sf (same operations, same order as walking owner and neighbour face by face)
 __global__ __launch_bounds__(QGD_BLOCK) void qhdCellGradKernel(const MeshView m, const QhdView q) {
     const int c = blockIdx.x * QGD_BLOCK + threadIdx.x;
-    if (c >= m.nC) return;
-    if (m.ghost && m.ghost[c] == 1) return;   // a ghost cell lacks faces here: its gradient arrives with the halo message
-    const int n = m.cfCount[c];
-    const size_t base = (size_t)m.cfSlice[c >> 6] * 64 + (c & 63);
-    const double Uc[3] = {q.c4[(size_t)c * 4], q.c4[(size_t)c * 4 + 1], q.c4[(size_t)c * 4 + 2]};
-    double G[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int i = 0; i < n; ++i) {
-        const int it = m.cfItem[base + (size_t)i * 64];
-        const int nb = m.cfNbr[base + (size_t)i * 64];
-        const int f = it >= 0 ? it : ~it;
-        if (m.fkind[f] == 3) continue;
-        double Uf[3];
-        if (nb >= 0) {
-            const double w = m.w[f];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const double un = q.c4[(size_t)nb * 4 + k];
-                Uf[k] = it >= 0 ? lerpf(w, Uc[k], un) : lerpf(w, un, Uc[k]);   // lerp(w, owner, neighbour)
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) Uf[k] = q.b4[(size_t)(f - m.nIF) * 4 + k];
-        }
-        const double S[3] = {m.Sx[f], m.Sy[f], m.Sz[f]};
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) G[3 * a + j] = it >= 0 ? G[3 * a + j] + S[a] * Uf[j] : G[3 * a + j] - S[a] * Uf[j];
-    }
-    const double V = m.V[c];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) q.gUc[(size_t)c * 9 + k] = G[k] / V;
+    const bool live = c < m.nC && !(m.ghost && m.ghost[c] == 1);   // a ghost cell lacks faces here: its gradient arrives with the halo message
+    if (__ballot(live) == 0) return;
+    if (live) cellGradGauss<4, 0, 4, 0>(m, c, q.c4, q.b4, q.gUc);
 }
 
 // face pass 2 [QHDUEqn.H L36-84, QHDTEqn.H L65-91]: the net face terms of the U and T equations

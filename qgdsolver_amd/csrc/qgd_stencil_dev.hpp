@@ -368,4 +368,74 @@ __device__ __forceinline__ double alphaEffOf(const GasModel& gm, double muQGD) {
     return gm.gamma * ((gm.alphah0 + muQGD / gm.PrQGD) + 0.0);
 }
 
+// fvc::grad(U), Gauss linear (L0), of one cell: gather in ascending face order -- the cell's own velocity once, per face the neighbour
+// cell's (cfNbr) or the patch value, the weight and Sf; same operations in the same order as walking owner and neighbour face by
+// face.  U of cell c at Ucell[c * CS + CO ...], of patch face b at Ubnd[b * BS + BO ...].  A wavefront of hexahedra takes the six-face
+// pass with every load in flight before the first use (the loop is one dependent chain per face: 1.08 ms at 8 M cells; this: see
+// DESIGN.md); wavefronts with other cells take the loop as a whole.
+template <int CS, int CO, int BS, int BO>
+__device__ __forceinline__ void cellGradGauss(const MeshView& m, const int ci, const double* __restrict__ Ucell, const double* __restrict__ Ubnd,
+                                              double* __restrict__ gOut) {
+    const int n = m.cfCount[ci];
+    const size_t base = (size_t)m.cfSlice[ci >> 6] * 64 + (ci & 63);
+    const double Uc[3] = {Ucell[(size_t)ci * CS + CO], Ucell[(size_t)ci * CS + CO + 1], Ucell[(size_t)ci * CS + CO + 2]};
+    double G[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto add = [&](const int it, const int kind, const double (&Uf)[3], const double (&S)[3]) {
+        if (kind == 3) return;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) G[3 * a + j] = it >= 0 ? G[3 * a + j] + S[a] * Uf[j] : G[3 * a + j] - S[a] * Uf[j];
+    };
+    if (__ballot(n != 6) == 0) {
+        int it[6], nb[6], kind[6];
+        double w[6], S[6][3], Un[6][3];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) { it[q] = m.cfItem[base + (size_t)q * 64]; nb[q] = m.cfNbr[base + (size_t)q * 64]; }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const int f = it[q] >= 0 ? it[q] : ~it[q];
+            kind[q] = m.fkind[f];
+            w[q] = m.w[f];
+            S[q][0] = m.Sx[f]; S[q][1] = m.Sy[f]; S[q][2] = m.Sz[f];
+            const double* __restrict__ src = nb[q] >= 0 ? Ucell + (size_t)nb[q] * CS + CO : Ubnd + (size_t)(f - m.nIF) * BS + BO;
+            Un[q][0] = src[0]; Un[q][1] = src[1]; Un[q][2] = src[2];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            double Uf[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                Uf[k] = nb[q] < 0 ? Un[q][k] : (it[q] >= 0 ? lerpf(w[q], Uc[k], Un[q][k]) : lerpf(w[q], Un[q][k], Uc[k]));   // lerp(w, owner, neighbour)
+            add(it[q], kind[q], Uf, S[q]);
+        }
+    } else {
+        for (int i = 0; i < n; ++i) {
+            const int it = m.cfItem[base + (size_t)i * 64];
+            const int nb = m.cfNbr[base + (size_t)i * 64];
+            const int f = it >= 0 ? it : ~it;
+            const int kind = m.fkind[f];
+            if (kind == 3) continue;
+            double Uf[3];
+            if (nb >= 0) {
+                const double w = m.w[f];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const double un = Ucell[(size_t)nb * CS + CO + k];
+                    Uf[k] = it >= 0 ? lerpf(w, Uc[k], un) : lerpf(w, un, Uc[k]);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) Uf[k] = Ubnd[(size_t)(f - m.nIF) * BS + BO + k];
+            }
+            const double S[3] = {m.Sx[f], m.Sy[f], m.Sz[f]};
+            add(it, kind, Uf, S);
+        }
+    }
+    const double V = m.V[ci];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) gOut[(size_t)ci * 9 + k] = G[k] / V;
+}
+
 }  // namespace qgd
