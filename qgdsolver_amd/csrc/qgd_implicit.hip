@@ -135,13 +135,40 @@ __global__ __launch_bounds__(QGD_BLOCK) void implCellUKernel(const MeshView m, c
     const size_t base = (size_t)m.cfSlice[ci >> 6] * 64 + (ci & 63);
     const size_t nF = (size_t)m.nF, nC = (size_t)m.nC;
     double sum[4] = {0, 0, 0, 0}, dTau[3] = {0, 0, 0}, diagBase = 0;
-    for (int i = 0; i < n; ++i) {
-        const int it = m.cfItem[base + (size_t)i * 64];
-        const int f = it >= 0 ? it : ~it;
-        const size_t pos = f < m.nIF ? (size_t)m.fpos[f] : (size_t)f;
-        for (int k = 0; k < 4; ++k) { const double x = c.flux[(size_t)k * nF + pos]; sum[k] = it >= 0 ? sum[k] + x : sum[k] - x; }
-        for (int k = 0; k < 3; ++k) { const double x = iv.phiTau[(size_t)k * nF + f]; dTau[k] = it >= 0 ? dTau[k] + x : dTau[k] - x; }
-        if (f < m.nIF) diagBase += iv.aU[f];
+    if (__ballot(n != 6) == 0) {
+        // a wavefront of hexahedra: labels and flux positions of the six faces, then their 48 values in flight before the ordered sums
+        int it[6], ps[6];
+        double fx[6][4], tx[6][3], ax[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { it[i] = m.cfItem[base + (size_t)i * 64]; ps[i] = m.cfPos[base + (size_t)i * 64]; }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const size_t f = (size_t)(it[i] >= 0 ? it[i] : ~it[i]), pos = (size_t)(ps[i] >= 0 ? ps[i] : ~ps[i]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) fx[i][k] = c.flux[(size_t)k * nF + pos];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) tx[i][k] = iv.phiTau[(size_t)k * nF + f];
+            ax[i] = iv.aU[f];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int f = it[i] >= 0 ? it[i] : ~it[i];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sum[k] = it[i] >= 0 ? sum[k] + fx[i][k] : sum[k] - fx[i][k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dTau[k] = it[i] >= 0 ? dTau[k] + tx[i][k] : dTau[k] - tx[i][k];
+            if (f < m.nIF) diagBase += ax[i];
+        }
+    } else {
+        for (int i = 0; i < n; ++i) {
+            const int it = m.cfItem[base + (size_t)i * 64];
+            const int f = it >= 0 ? it : ~it;
+            const size_t pos = f < m.nIF ? (size_t)m.fpos[f] : (size_t)f;
+            for (int k = 0; k < 4; ++k) { const double x = c.flux[(size_t)k * nF + pos]; sum[k] = it >= 0 ? sum[k] + x : sum[k] - x; }
+            for (int k = 0; k < 3; ++k) { const double x = iv.phiTau[(size_t)k * nF + f]; dTau[k] = it >= 0 ? dTau[k] + x : dTau[k] - x; }
+            if (f < m.nIF) diagBase += iv.aU[f];
+        }
     }
     const RecA A = c.A[ci];
     const double V = m.V[ci], dt = c.dt[0], dtV = dt / V, rDeltaT = 1.0 / dt;
@@ -252,19 +279,38 @@ __global__ __launch_bounds__(QGD_BLOCK) void implCellEKernel(const MeshView m, c
     const size_t base = (size_t)m.cfSlice[ci >> 6] * 64 + (ci & 63);
     const size_t nF = (size_t)m.nF;
     double sum = 0, diag = 0, rhs = 0;
-    for (int i = 0; i < n; ++i) {
-        const int it = m.cfItem[base + (size_t)i * 64];
-        const int f = it >= 0 ? it : ~it;
-        const size_t pos = f < m.nIF ? (size_t)m.fpos[f] : (size_t)f;
-        const double x = c.flux[4 * nF + pos] - iv.phiSig[f];   // phiJmH + phiQ - phiPiU - phiSigmaDotU
+    // one face of the cell: its net energy flux, the laplacian coefficient, the patch coefficients of a fixedEnergy face
+    auto face = [&](const int it, const int f, const double fl, const double sg, const double a) {
+        const double x = fl - sg;   // phiJmH + phiQ - phiPiU - phiSigmaDotU
         sum = it >= 0 ? sum + x : sum - x;
-        if (f < m.nIF) diag += iv.aE[f];
+        if (f < m.nIF) diag += a;
         else if (m.fkind[f] != 3) {
             const PatchBCDev bc = bcs[m.bPatch[f - m.nIF]];
             if (bc.ptype != QGD_PATCH_HALO && bc.ptype != QGD_PATCH_CYCLIC && bc.bcT == QGD_BC_FIXEDVALUE) {
-                diag += iv.aE[f];                       // fixedEnergy = fixedValue
-                rhs += iv.aE[f] * (gm.Cv * bc.vT);
+                diag += a;                       // fixedEnergy = fixedValue
+                rhs += a * (gm.Cv * bc.vT);
             }
+        }
+    };
+    if (__ballot(n != 6) == 0) {
+        int it[6], ps[6];
+        double fl[6], sg[6], a[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { it[i] = m.cfItem[base + (size_t)i * 64]; ps[i] = m.cfPos[base + (size_t)i * 64]; }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const size_t f = (size_t)(it[i] >= 0 ? it[i] : ~it[i]), pos = (size_t)(ps[i] >= 0 ? ps[i] : ~ps[i]);
+            fl[i] = c.flux[4 * nF + pos]; sg[i] = iv.phiSig[f]; a[i] = iv.aE[f];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) face(it[i], it[i] >= 0 ? it[i] : ~it[i], fl[i], sg[i], a[i]);
+    } else {
+        for (int i = 0; i < n; ++i) {
+            const int it = m.cfItem[base + (size_t)i * 64];
+            const int f = it >= 0 ? it : ~it;
+            const size_t pos = f < m.nIF ? (size_t)m.fpos[f] : (size_t)f;
+            face(it, f, c.flux[4 * nF + pos], iv.phiSig[f], iv.aE[f]);
         }
     }
     const RecA A = c.A[ci];   // rho, U of the new time level

@@ -205,11 +205,30 @@ __global__ __launch_bounds__(QGD_BLOCK) void qhdCellUpdateKernel(const MeshView 
     const size_t base = (size_t)m.cfSlice[c >> 6] * 64 + (c & 63);
     const size_t nF = (size_t)m.nF;
     double s[4] = {0, 0, 0, 0};
-    for (int i = 0; i < n; ++i) {
-        const int it = m.cfItem[base + (size_t)i * 64];
-        const size_t f = (size_t)(it >= 0 ? it : ~it);
+    if (__ballot(n != 6) == 0) {
+        // a wavefront of hexahedra: the 24 face terms in flight before the ordered sums (ascending face label, as below)
+        int it[6];
+        double x[6][4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { const double x = q.F[(size_t)k * nF + f]; s[k] = it >= 0 ? s[k] + x : s[k] - x; }
+        for (int i = 0; i < 6; ++i) it[i] = m.cfItem[base + (size_t)i * 64];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const size_t f = (size_t)(it[i] >= 0 ? it[i] : ~it[i]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) x[i][k] = q.F[(size_t)k * nF + f];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s[k] = it[i] >= 0 ? s[k] + x[i][k] : s[k] - x[i][k];
+    } else {
+        for (int i = 0; i < n; ++i) {
+            const int it = m.cfItem[base + (size_t)i * 64];
+            const size_t f = (size_t)(it >= 0 ? it : ~it);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const double x = q.F[(size_t)k * nF + f]; s[k] = it >= 0 ? s[k] + x : s[k] - x; }
+        }
     }
     const double rV = 1.0 / m.V[c];
     double* rec = q.c4 + (size_t)c * 4;
