@@ -246,6 +246,11 @@ int qgd_fvsc_div_t_dev(qgd_device_t d, int stencilId, const double* cellDev, con
 int qgd_interpolate_dev(qgd_device_t d, int32_t ncomp, const double* cellDev, const double* bndDev, double* outDev);
 int qgd_device_sync(qgd_device_t d);
 int qgd_device_copy(qgd_device_t d, void* dst, const void* src, int64_t bytes, int toDevice);
+/* The leastSquares stencil of internal face `face` as the device holds it: the cells in the order they are summed, which is the order
+ * the reference builds [extendedFaceStencilFindNeighbours_8C_source.html L48-84: the face's points in order, each point's cells in
+ * pointCells() order, first occurrence kept].  *count = their number (the first `cap` are written).  Diagnostic entry (a few small
+ * copies per call): tests/test_ref_expr_gpu.py compares it with the order executed from the listing text.  QGD_ERR_SCHEME on 3-D meshes. */
+int qgd_device_lsq_stencil(qgd_device_t d, int32_t face, int32_t* cells, int32_t cap, int32_t* count);
 
 /* Where the time of the last qgd_fvsc_* call on this device went: ms[0] = host -> device copies, ms[1] = kernels (HIP events),
  * ms[2] = device -> host copy.  Pageable caller memory moves through two pinned staging chunks in a double-buffered

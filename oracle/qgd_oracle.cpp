@@ -2796,6 +2796,18 @@ int orc_mesh_set_degenerate_faces(void* mp, int32_t n, const int32_t* faces) {
     h->cache.byName.clear();
     return 0;
 }
+/* the leastSquares stencil of internal face `face` in the order the reference builds it [extendedFaceStencilFindNeighbours.C:48-84];
+ * returns the number of cells (the first `cap` are written), < 0 when the mesh has no leastSquares stencil (3-D) */
+int orc_mesh_lsq_stencil(void* mp, int32_t face, int32_t* cells, int32_t cap) {
+    MeshHandle* h = (MeshHandle*)mp;
+    Stencil* st = nullptr;
+    if (h->cache.lookup(h->m, "leastSquares", &st) != 0) return -1;
+    const LeastSquares* ls = dynamic_cast<const LeastSquares*>(st);
+    if (!ls || face < 0 || face >= h->m.nIF) return -1;
+    const ivec& nb = ls->neighbourCells[face];
+    for (int i = 0; i < (int)nb.size() && i < cap; ++i) cells[i] = nb[i];
+    return (int)nb.size();
+}
 int orc_mesh_set_halo_face_h(void* mp, int32_t n, const double* h) {
     ((MeshHandle*)mp)->m.haloFaceH.assign(h, h + n);
     return 0;

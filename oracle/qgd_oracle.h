@@ -120,6 +120,8 @@ int orc_case_step_phase(void* c, int phase);   /* 0, 1, 2; 5 + 6 = the two halve
  * seven face fields stored instead of ~50): the "fused CPU" baseline of bench.py.  Returns 1 when the case is outside its scope
  * (3-D GaussVolPoint, quadrilateral faces, explicit, fixed deltaT, no qgdFlux patch, unsharded). */
 int orc_case_step_fused(void* c, int32_t nSteps);
+/* cells of the leastSquares stencil of an internal face, in the reference's order; returns their number (< 0: no such stencil) */
+int orc_mesh_lsq_stencil(void* mesh, int32_t face, int32_t* cells, int32_t cap);
 int orc_case_mid_exchange_needed(void* c);
 int orc_case_mid_halo_count(void* c, int side, int64_t* send, int64_t* recv);
 int orc_case_mid_halo_pack(void* c, int side, double* buf);

@@ -834,6 +834,26 @@ int qgd_device_sync(qgd_device_t d) {
     return QGD_OK;
     QGD_CATCH
 }
+// the leastSquares stencil of an internal face as the device holds it (sliced ELL read back): cells in the order they are summed
+int qgd_device_lsq_stencil(qgd_device_t d, int32_t face, int32_t* cells, int32_t cap, int32_t* count) {
+    QGD_TRY
+    if (!d || !count || (cap > 0 && !cells)) return fail(QGD_ERR_INVALID, "qgd_device_lsq_stencil: bad argument");
+    const MeshView& m = d->view;
+    if (!m.lsqCnt || !m.lsqSlice || !m.lsqCell) return fail(QGD_ERR_SCHEME, "qgd_device_lsq_stencil: the mesh has no leastSquares stencil (3-D)");
+    if (face < 0 || face >= m.nIF) return fail(QGD_ERR_INVALID, "qgd_device_lsq_stencil: not an internal face");
+    HIP_CHECK(hipSetDevice(d->deviceId));
+    HIP_CHECK(hipStreamSynchronize(d->stream));
+    uint8_t cnt8 = 0;
+    int32_t slice = 0;
+    HIP_CHECK(hipMemcpy(&cnt8, m.lsqCnt + face, sizeof(uint8_t), hipMemcpyDeviceToHost));
+    const int32_t cnt = cnt8;
+    HIP_CHECK(hipMemcpy(&slice, m.lsqSlice + (face >> 6), sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (int k = 0; k < cnt && k < cap; ++k)
+        HIP_CHECK(hipMemcpy(cells + k, m.lsqCell + ((size_t)slice + k) * 64 + (face & 63), sizeof(int32_t), hipMemcpyDeviceToHost));
+    *count = cnt;
+    return QGD_OK;
+    QGD_CATCH
+}
 int qgd_device_copy(qgd_device_t d, void* dst, const void* src, int64_t bytes, int toDevice) {
     QGD_TRY
     if (!d || !dst || !src || bytes < 0) return fail(QGD_ERR_INVALID, "qgd_device_copy: bad argument");

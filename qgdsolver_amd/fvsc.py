@@ -57,6 +57,13 @@ class Device:
             L.check(L.lib.qgd_device_copy(self._h, out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), out.nbytes, 0), "qgd_device_copy")
         return out
 
+    def lsq_stencil(self, face, cap=64):
+        """cells of the leastSquares stencil of an internal face in the order the device sums them (qgd_device_lsq_stencil)"""
+        out = (C.c_int32 * cap)()
+        n = C.c_int32()
+        L.check(L.lib.qgd_device_lsq_stencil(self._h, int(face), out, cap, C.byref(n)), "qgd_device_lsq_stencil")
+        return [int(out[i]) for i in range(min(n.value, cap))]
+
     def face_tiles(self):
         """how the internal faces go through the 3-D GaussVolPoint flux kernel (qgd_device_face_tiles)"""
         a = (C.c_int64 * 4)()

@@ -45,6 +45,9 @@ Snippets evaluated (listing lines of /root/reference/docs/html/<file>_source.htm
   casebnd    the QGDFoam flux assembly on ONE BOUNDARY face: updateFields.H L45-80 with patch values, the boundary-face text of the 3-D
              stencil, updateFluxes.H L41-139, GaussVolPointStencil.C L73 -> qgdFluxFvPatchScalarField.C L184-192 (updateCoeffs with the
              fresh phiwStar), constScPrModel1.C L103-104, L121-128 (patch loop)
+  thermo2cell  hePsiQGDThermo.C L48-64 + L123-124 and QGDFoam.C L152-154 (thermo.correct(), p = rho / psi after the explicit step)
+  qhdflux    qhdFluxFvPatchScalarField.C L193-203 (updateCoeffs with the registered flux) on the walls of a small cavity
+  lsqorder   extendedFaceStencilFindNeighbours.C L48-84 (the stencil search: which cells, in which order) on whole small 2-D meshes
   qhdeqn     one whole QHDFoam step on the two-cell mesh: updateFields.H L36-73, updateFluxes.H L33-38, QHDpEqn.H L35-47, QHDUEqn.H
              L36-43 + L46-85, QHDTEqn.H L65-66 + L69-92, QHDFoam.C L123-131 (reference level)
 
@@ -157,6 +160,9 @@ def statement(st):
         if len(args) == 2:
             return [f"{m.group(1)} = Fld([None]*({expr(args[0])}))"]
         return [f"{m.group(1)} = {expr(m.group(2))}"]
+    m = re.match(r"^labelList\s+(\w+)\s*(?:=\s*(.*))?$", st)                         # labelList a; | labelList a = expr;  (a copy)
+    if m:
+        return [f"{m.group(1)} = LabelList({expr(m.group(2)) if m.group(2) else ''})"]
     m = re.match(rf"^{TYPES}\s*(.*)$", st)
     if m and re.match(r"^\w+\s*(=|,|$)", m.group(1)):
         out = []
@@ -388,6 +394,8 @@ class Fld(list):
     def __sub__(self, o): return self._zip(o, lambda a, b: a - b)
     def __mul__(self, o): return self._zip(o, lambda a, b: a * b)
     def __rmul__(self, o): return Fld([o * a for a in self])
+    def __truediv__(self, o): return self._zip(o, lambda a, b: a / b)
+    def __neg__(self): return Fld([-a for a in self])
 
 
 class FieldWithPatches(list):
@@ -1504,6 +1512,36 @@ def courant(case):
     return out
 
 
+def thermo2cell(case):
+    """thermo.correct() and the pressure update after the explicit step, executed as listed on the two cells of every case2cell case:
+    hePsiQGDThermo.C L48-64 (T from e, psi, mu, alpha per cell), L123-124 (gamma, c) and QGDFoam.C L152-154 (p = rho / psi), with the
+    new rho and e of that fixture.  `mixture_` is the L0 part: perfectGas (psi = 1 / (R T)), eConst with Tref = 0, Hf = 0 (THE: T = e /
+    Cv -- the value OpenFOAM's Newton iteration converges to), constTransport (mu, alphah = mu / Pr)."""
+    th = listing("hePsiQGDThermo_8C_source.html")
+    cell_txt = [th[i] for i in range(48, 65) if i not in (50, 51)]          # without the declaration of the reference mixture_
+    cell_src = transpile(cell_txt)
+    c_src = transpile([th[123].replace("this->", "").replace("==", "="), th[124].replace("this->", "")])
+    qf = listing("QGDFoam_8C_source.html")
+    p_expr = " ".join(qf[i].strip() for i in (152, 153, 154)).rstrip(";")
+    assert p_expr.replace(" ", "") == "p.ref()=rho()/psi()", p_expr
+    rec = {k: [] for k in ("T1", "psi1", "c1", "p1", "mu1", "alpha1")}
+    for i in range(len(case["nv"])):
+        R, Cv, mu0, Pr = float(case["R"][i]), float(case["Cv"][i]), float(case["mu"][i]), float(case["Pr"][i])
+        mix = Obj(THE=lambda he, p, T0: he / Cv, psi=lambda p, T: 1.0 / (R * T), mu=lambda p, T: mu0, alphah=lambda p, T: mu0 / Pr)
+        env = dict(TCells=[float(t) for t in case["T"][i]], hCells=[float(e) for e in case["e1"][i]], pCells=[float(x) for x in case["p"][i]],
+                   psiCells=[0.0, 0.0], muCells=[0.0, 0.0], alphaCells=[0.0, 0.0], mixture_=mix)
+        exec(cell_src, env)
+        cc, pp = [], []
+        for k in range(2):
+            e3 = dict(Cp=call(Cv + R), Cv=call(Cv), psi=call(env["psiCells"][k]), sqrt=lambda x: float(np.sqrt(x)))
+            exec(c_src, e3)
+            cc.append(e3["c_"])
+            pp.append(eval(p_expr.split("=", 1)[1].replace("rho()", "rho_").replace("psi()", "psi_"), dict(rho_=float(case["rho1"][i][k]), psi_=env["psiCells"][k])))
+        for k, v in (("T1", env["TCells"]), ("psi1", env["psiCells"]), ("c1", cc), ("p1", pp), ("mu1", env["muCells"]), ("alpha1", env["alphaCells"])):
+            rec[k].append(v)
+    return {k: np.array(v, dtype=float) for k, v in rec.items()}
+
+
 def qhdclosure(nfaces=24, seed=24):
     """tauQGD of the four QHD closures as listed [constTau.C L71-74, HbyUQHD.C L80-83, T0byGr.C L84-87, H2bynuQHD.C L78-82] on the two
     cells of a one-face mesh (hQGDf from QGDCoeffs.C L305-307; a cell with one face has hQGD = hQGDf), tauQGDf = linearInterpolate."""
@@ -1795,6 +1833,87 @@ def qhdeqn(nfaces=30, seed=26):
     return {k: np.array(v) for k, v in rec.items()}
 
 
+class LabelList(list):
+    """OpenFOAM's labelList as the stencil search uses it: append(label) and append(list) (List::append(const UList&))"""
+    def append(self, x):
+        if isinstance(x, list):
+            self.extend(x)
+        else:
+            list.append(self, x)
+
+
+def lsqorder():
+    """The stencil search of the leastSquares scheme executed as listed [extendedFaceStencilFindNeighbours.C L48-84] on whole small 2-D
+    meshes: for every internal face the cells around its points, the face's points in order, each point's cells in pointCells() order
+    (L0: ascending cell label, primitiveMesh::calcPointCells), the first occurrence kept.  The order is the summation order of the weights
+    [CalcW.C L64-153] and of the gradient [ScalarGrad.C L66-72]."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    sys.path.insert(0, os.path.dirname(HERE))
+    from util import make_mesh
+    src = transpile(lines("extendedFaceStencilFindNeighbours_8C_source.html", 48, 84))
+    out = {}
+    for kind in ("plane2d_jitter", "step2d", "plane2d"):
+        mesh = make_mesh(kind)
+        fo, fp = mesh.array("faceOffsets"), mesh.array("facePoints")
+        own, nei, nif = mesh.array("owner"), mesh.array("neighbour"), mesh.nInternalFaces
+        faces = [LabelList(int(p) for p in fp[fo[f]:fo[f + 1]]) for f in range(mesh.nFaces)]
+        cell_faces = [[] for _ in range(mesh.nCells)]
+        for f in range(mesh.nFaces):
+            cell_faces[own[f]].append(f)
+            if f < nif:
+                cell_faces[nei[f]].append(f)
+        point_cells = [LabelList() for _ in range(mesh.nPoints)]
+        for c in range(mesh.nCells):                       # L0 calcPointCells: cells ascending, a cell once per point
+            for f in cell_faces[c]:
+                for p in faces[f]:
+                    if c not in point_cells[p]:
+                        point_cells[p].append(c)
+
+        class CMesh:
+            def isInternalFace(self, f): return f < nif
+            def pointCells(self): return point_cells
+        env = dict(faces=faces, cMesh_=CMesh(), neighbourCellsForFace=[LabelList() for _ in range(nif)], LabelList=LabelList, true=True, false=False)
+        exec(src, env)
+        lists = env["neighbourCellsForFace"]
+        out[kind + "_off"] = np.cumsum([0] + [len(x) for x in lists]).astype(np.int64)
+        out[kind + "_cells"] = np.array([c for x in lists for c in x], dtype=np.int64)
+    return out
+
+
+def qhdflux():
+    """qhdFluxFvPatchScalarField::updateCoeffs L193-203 executed as listed on the wall faces of a small buoyant cavity: the fixed gradient
+    of p from the registered flux, gradient = -(phiwStar_b / tauQGDf_b * rhof_b / |Sf|), then fixedGradient's evaluate (L0: patch value =
+    cell value + gradient / deltaCoeffs).  The state is the CPU restatement's after three steps (mulesQHDFoam-style walls fed by the
+    registered flux, QGD_BC_QHDFLUX); what is pinned is that its patch pressure IS this formula of its own flux, and the device's."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    sys.path.insert(0, os.path.dirname(HERE))
+    from oracle import OracleQhdCase
+    from test_qhd_case import cavity_bcs, initial, options
+    from util import make_mesh, oracle_mesh_of
+    bc_l = listing("qhdFluxFvPatchScalarField_8C_source.html")
+    txt = [bc_l[i] for i in range(193, 204)]
+    txt = [t.replace("phiws.boundaryField()[patch().index()]", "phiws_b").replace("tauQGDf.boundaryField()[patch().index()]", "tauQGDf_b")
+            .replace("rhof.boundaryField()[patch().index()]", "rhof_b").replace("patch().magSf()", "magSf_b").replace("this->gradient()", "gradient_")
+           for t in txt]
+    src = transpile(txt)
+    mesh = make_mesh("box654_jitter")
+    oc = OracleQhdCase(oracle_mesh_of(mesh), options(deltaT=1e-3))
+    cavity_bcs(oc, mesh)
+    U, T, p = initial(mesh)
+    U = U + 1e-2 * np.random.default_rng(3).standard_normal(U.shape)
+    oc.set_fields(U, T, p)
+    oc.step(3)
+    nif = mesh.nInternalFaces
+    own = mesh.array("owner")[nif:]
+    env = dict(phiws_b=Fld(list(oc.field("phiwo")[nif:])), tauQGDf_b=Fld(list(oc.field("tauQGDf")[nif:])),
+               rhof_b=Fld([1.0] * mesh.nBoundaryFaces), magSf_b=Fld(list(mesh.array("magSf")[nif:])), Fld=Fld)
+    exec(src, env)
+    grad = np.array(list(env["gradient_"]), dtype=float)
+    delta = mesh.array("deltaCoeffs")[nif:]
+    pc = oc.field("p")[own]
+    return dict(steps=np.array(3), gradient=grad, pb=pc + grad / delta, phiwo_b=oc.field("phiwo")[nif:], tau_b=oc.field("tauQGDf")[nif:])
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit("make_ref_expr.py needs the reference listings under /root/reference (build container only)")
@@ -1811,7 +1930,8 @@ def main():
             np.savez_compressed(os.path.join(HERE, "ref_expr_implicit2cell.npz"), **impl)
             print("implicit2cell", {k: v.shape for k, v in impl.items()})
     for name, data in (("gvp2d_vec", gvp2d_vec()), ("gvp_other", gvp_other()), ("qgdlength", qgdlength()), ("courant", courant(case)),
-                       ("qhdclosure", qhdclosure()), ("casebnd", casebnd()), ("qhdeqn", qhdeqn())):
+                       ("thermo2cell", thermo2cell(case)),
+                       ("qhdclosure", qhdclosure()), ("casebnd", casebnd()), ("qhdeqn", qhdeqn()), ("lsqorder", lsqorder()), ("qhdflux", qhdflux())):
         np.savez_compressed(os.path.join(HERE, f"ref_expr_{name}.npz"), **data)
         print(name, {k: getattr(v, "shape", None) for k, v in data.items()})
 

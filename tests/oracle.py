@@ -66,6 +66,7 @@ lib.orc_case_implicit_halo_count.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POI
 lib.orc_case_implicit_halo_pack.argtypes = [C.c_void_p, C.c_int, C.c_int, dp]
 lib.orc_case_implicit_halo_unpack.argtypes = [C.c_void_p, C.c_int, C.c_int, dp]
 lib.orc_case_step_fused.argtypes = [C.c_void_p, C.c_int32]
+lib.orc_mesh_lsq_stencil.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.c_int32]
 lib.orc_case_mid_exchange_needed.argtypes = [C.c_void_p]
 lib.orc_case_mid_halo_count.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
 lib.orc_case_mid_halo_pack.argtypes = [C.c_void_p, C.c_int, dp]
@@ -134,6 +135,13 @@ class OracleMesh:
         out = np.zeros(n)
         assert lib.orc_mesh_get(self._h, name.encode(), _d(out), n) == 0
         return out
+
+    def lsq_stencil(self, face, cap=64):
+        """cells of the leastSquares stencil of an internal face, in the reference's order"""
+        out = (C.c_int32 * cap)()
+        n = lib.orc_mesh_lsq_stencil(self._h, int(face), out, cap)
+        assert n >= 0
+        return [int(out[i]) for i in range(min(n, cap))]
 
     def set_geometry(self, Sf, Cf, Cc, V):
         a = [np.ascontiguousarray(x, dtype=np.float64) for x in (Sf, Cf, Cc, V)]

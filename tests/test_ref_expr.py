@@ -167,6 +167,7 @@ FACE_FIELDS = ("rhof", "Uf", "pf", "cf", "Hf", "alphauf", "muf", "tauQGDf", "hQG
 
 
 STEP_FIELDS = ["rho", "U", "e", "rhoU", "rhoE"]
+THERMO_FIELDS = ["T", "p", "c", "psi"]
 
 
 def case_options(g, i):
@@ -193,6 +194,10 @@ def test_flux_assembly_of_one_face():
         oc.step(1)
         for f in STEP_FIELDS:
             assert rel(oc.field(f), g[f + "1"][i]) <= TOL, (i, nv, f, oc.field(f), g[f + "1"][i])
+        # ... then thermo.correct() and p = rho / psi: hePsiQGDThermo.C L48-64, L123-124 and QGDFoam.C L152-154 from the text
+        th = rc.load("thermo2cell")
+        for f in THERMO_FIELDS:
+            assert rel(oc.field(f), th[f + "1"][i]) <= TOL, (i, nv, f, oc.field(f), th[f + "1"][i])
         oc.close(); om.close()
 
 
@@ -439,3 +444,43 @@ def test_one_step_of_the_implicit_diffusion_branch_from_the_listing_text():
             assert rel(oc.field(f), g[f + "1"][i]) <= 1e-11, (i, nv, f, oc.field(f), g[f + "1"][i])
         assert rel(oc.field("phiSigmaDotU")[0], g["phiSigmaDotU"][i]) <= 1e-10, (i, oc.field("phiSigmaDotU")[0], g["phiSigmaDotU"][i])
         oc.close(); om.close()
+
+
+def test_leastsquares_stencil_order_from_the_listing_text():
+    """extendedFaceStencilFindNeighbours.C L48-84 executed as listed on three 2-D meshes: which cells every internal face gathers and
+    in which order (the order of the weights' and the gradient's sums)"""
+    from util import make_mesh, oracle_mesh_of
+    g = rc.load("lsqorder")
+    for kind in ("plane2d_jitter", "step2d", "plane2d"):
+        mesh = make_mesh(kind)
+        om = oracle_mesh_of(mesh)
+        off, cells = g[kind + "_off"], g[kind + "_cells"]
+        assert len(off) == mesh.nInternalFaces + 1
+        for f in range(mesh.nInternalFaces):
+            assert om.lsq_stencil(f) == [int(c) for c in cells[off[f]:off[f + 1]]], (kind, f)
+
+
+def qhdflux_case(case_cls, mesh_handle, mesh):
+    """the small buoyant cavity of ref_expr_qhdflux (walls with the qhdFlux pressure condition fed by the registered flux)"""
+    from test_qhd_case import cavity_bcs, initial, options
+    c = case_cls(mesh_handle, options(deltaT=1e-3))
+    cavity_bcs(c, mesh)
+    U, T, p = initial(mesh)
+    U = U + 1e-2 * np.random.default_rng(3).standard_normal(U.shape)
+    c.set_fields(U, T, p)
+    return c
+
+
+def test_qhdflux_wall_gradient_from_the_listing_text():
+    """qhdFluxFvPatchScalarField.C L193-203 (updateCoeffs with the registered flux) + fixedGradient's evaluate: the patch pressure of
+    the walls after three steps is that formula of the step's own phiwo"""
+    from oracle import OracleQhdCase
+    from util import make_mesh, oracle_mesh_of
+    g = rc.load("qhdflux")
+    mesh = make_mesh("box654_jitter")
+    oc = qhdflux_case(OracleQhdCase, oracle_mesh_of(mesh), mesh)
+    oc.step(int(g["steps"]))
+    nif = mesh.nInternalFaces
+    assert np.abs(g["gradient"]).max() > 1e-6           # the walls do carry a gradient
+    assert rel(oc.field("phiwo")[nif:], g["phiwo_b"]) <= 1e-13
+    assert rel(oc.field("p.boundary"), g["pb"]) <= 1e-12

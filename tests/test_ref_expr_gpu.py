@@ -140,6 +140,9 @@ def test_flux_assembly_of_one_face_on_the_device():
         case.step(1)
         for f in STEP_FIELDS:
             assert rel(case.field(f), g[f + "1"][i]) <= TOL, (i, nv, f, case.field(f), g[f + "1"][i])
+        th = rc.load("thermo2cell")     # thermo.correct(), p = rho / psi: hePsiQGDThermo.C L48-64, L123-124, QGDFoam.C L152-154 from the text
+        for f in ("T", "p", "c"):
+            assert rel(case.field(f), th[f + "1"][i]) <= TOL, (i, nv, f, case.field(f), th[f + "1"][i])
         case.close(); dev.close()
 
 
@@ -321,3 +324,34 @@ def test_one_step_of_the_implicit_diffusion_branch_on_the_device():
             assert rel(case.field(f), g[f + "1"][i]) <= 1e-10, (i, nv, f, case.field(f), g[f + "1"][i])
         assert rel(case.field("phiSigmaDotU")[0], g["phiSigmaDotU"][i]) <= 1e-9, (i, case.field("phiSigmaDotU")[0], g["phiSigmaDotU"][i])
         case.close(); dev.close()
+
+
+def test_leastsquares_stencil_order_on_the_device():
+    """the sliced-ELL stencil lists the device sums over hold the cells of every internal face in the order
+    extendedFaceStencilFindNeighbours.C L48-84 produces (ref_expr_lsqorder: that text executed)"""
+    from util import make_mesh
+    g = rc.load("lsqorder")
+    for kind in ("plane2d_jitter", "step2d"):
+        mesh = make_mesh(kind)
+        dev = q.Device(mesh)
+        off, cells = g[kind + "_off"], g[kind + "_cells"]
+        faces = range(mesh.nInternalFaces) if mesh.nInternalFaces < 150 else range(0, mesh.nInternalFaces, 7)
+        for f in faces:
+            assert dev.lsq_stencil(f) == [int(c) for c in cells[off[f]:off[f + 1]]], (kind, f)
+        dev.close()
+
+
+def test_qhdflux_wall_gradient_on_the_device():
+    """the device's QHD case: patch pressure of the qhdFlux walls against qhdFluxFvPatchScalarField.C L193-203 executed from the text"""
+    from qgdsolver_amd import qhdfoam
+    from test_ref_expr import qhdflux_case
+    from util import make_mesh
+    g = rc.load("qhdflux")
+    mesh = make_mesh("box654_jitter")
+    dev = q.Device(mesh)
+    gc = qhdflux_case(qhdfoam.QHDFoamCase, dev, mesh)
+    gc.step(int(g["steps"]))
+    nif = mesh.nInternalFaces
+    assert rel(gc.field("phiwo")[nif:], g["phiwo_b"]) <= 1e-8
+    assert rel(gc.field("p.boundary"), g["pb"]) <= 1e-8
+    gc.close(); dev.close()
