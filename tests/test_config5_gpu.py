@@ -28,8 +28,19 @@ pytestmark = pytest.mark.gpu
 BETA, G = 3.4e-3, (0.0, -9.81, 0.0)
 
 
+_C5_CACHE = {}
+
+
 def c5_mesh(n, chunk, poly=False):
-    """the C5 stand-in recipe at edge n"""
+    """the C5 stand-in recipe at edge n (the 16 M-cell mesh takes 30 s to build: the tests of this module share it)"""
+    key = (n, chunk, poly)
+    if key not in _C5_CACHE:
+        _C5_CACHE.clear()
+        _C5_CACHE[key] = _c5_mesh(n, chunk, poly)
+    return _C5_CACHE[key]
+
+
+def _c5_mesh(n, chunk, poly=False):
     mesh = q.PolyMesh.box(n, n, n)
     mesh.jitter(0.2, seed=2024)
     mesh.split_quads(7)
