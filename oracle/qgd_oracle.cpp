@@ -3040,6 +3040,47 @@ int orc_species_flux(void* mp, const char* scheme, const double* Yc, const doubl
     return 0;
 }
 
+// QGDYEqn.H L44-45, L67-86 for ONE species, explicit branch, the sources (combustion->R, parcels.SYi) handed in as an explicit field:
+//   solve(fvm::ddt(rho,Yi) + fvc::div(phiJmYi) - fvc::laplacian(muf/Sc_i, Yi) == Su);
+//   diffusiveFlux_i += (muf/Sc_i) * fvc::snGrad(Yi.oldTime()) * mesh.magSf();   Yi.max(0.0);
+// L0: Euler ddt, fvc::div = surfaceIntegrate, Gauss laplacian with the uncorrected snGrad (nonOrthDeltaCoeffs inside, patch snGrad =
+// deltaCoeffs (patch value - cell value) on the patches).  The inert species (L65/L83, L90-91) is the caller's two axpys.
+int orc_species_step(void* mp, const double* Yc, const double* Yb, const double* rhoOld, const double* rho, const double* phiJmY,
+                     const double* muf, double Sc, double deltaT, const double* Su, double* diffusiveFlux, double* Ynew) {
+    MeshHandle* h = (MeshHandle*)mp;
+    const Mesh& m = h->m;
+    const int nC = m.nC, nF = m.nF;
+    std::vector<char> live(nF, 1);
+    for (size_t ip = 0; ip < m.patches.size(); ++ip)
+        if (!m.patchHasFields((int)ip) || m.patches[ip].type == PATCH_HALO)
+            for (int f = m.patches[ip].start; f < m.patches[ip].start + m.patches[ip].size; ++f) live[f] = 0;
+    dvec lapFlux((size_t)nF, 0.0);   // (muf/Sc) snGrad(Yi) |Sf|
+    for (int f = 0; f < nF; ++f) {
+        if (!live[f]) continue;
+        const double sn = f < m.nIF ? m.nonOrthDelta[f] * (Yc[m.nei[f]] - Yc[m.own[f]]) : m.delta[f] * (Yb[f - m.nIF] - Yc[m.own[f]]);
+        lapFlux[f] = (muf[f] / Sc) * sn * m.magSf[f];
+    }
+    auto div = [&](auto flux) {
+        dvec d((size_t)nC, 0.0);
+        for (int f = 0; f < m.nIF; ++f) { const double x = flux(f); d[m.own[f]] += x; d[m.nei[f]] -= x; }
+        for (int f = m.nIF; f < nF; ++f) if (live[f]) d[m.own[f]] += flux(f);
+        for (int ci = 0; ci < nC; ++ci) d[ci] /= m.V[ci];
+        return d;
+    };
+    const dvec d1 = div([&](int f) { return live[f] ? phiJmY[f] : 0.0; }), d2 = div([&](int f) { return lapFlux[f]; });
+    const double rDeltaT = 1.0 / deltaT;
+    for (int ci = 0; ci < nC; ++ci) {
+        const double diag = rDeltaT * rho[ci] * m.V[ci];
+        double src = rDeltaT * rhoOld[ci] * Yc[ci] * m.V[ci];
+        src -= m.V[ci] * d1[ci];
+        src += m.V[ci] * d2[ci];
+        if (Su) src += m.V[ci] * Su[ci];
+        Ynew[ci] = std::max(src / diag, 0.0);
+    }
+    for (int f = 0; f < nF; ++f) if (live[f]) diffusiveFlux[f] += lapFlux[f];
+    return 0;
+}
+
 // QHDpEqn.H L35-47: fvc::div(phiu) - fvc::div(phiwo) - fvm::laplacian(taubyrhof, p) == 0 with setReference and
 // phi = phiu - phiwo + pEqn.flux().  L0 assumptions: Gauss laplacian, uncorrected snGrad (nonOrthDeltaCoeffs inside,
 // deltaCoeffs on patches); fixedValue / fixedGradient / zeroGradient patch coefficients; the linear solver is a plain

@@ -74,6 +74,10 @@ int orc_species_flux(void* mesh, const char* scheme, const double* Y, const doub
                      const double* phiJm, const double* phi, const double* tauQGDf, double* phiJmY, double* diffusiveFlux,
                      double* gradYf);
 
+/* one species of QGDYEqn.H L44-45, L67-86 (explicit branch, explicit source Su or NULL); same argument meaning as qgd_species_step */
+int orc_species_step(void* mesh, const double* Y, const double* Yb, const double* rhoOld, const double* rho, const double* phiJmY,
+                     const double* muf, double Sc, double deltaT, const double* Su, double* diffusiveFlux, double* Ynew);
+
 /* QHDFoam pressure equation; same argument meaning as qgd_qhd_pressure (QHDpEqn.H L35-47) */
 int orc_qhd_pressure(void* mesh, const double* phiu, const double* phiwo, const double* taubyrhof, const int32_t* patchKind,
                      const double* pb, const double* gradb, double tolerance, double relTol, int32_t maxIter, int32_t pRefCell,

@@ -930,6 +930,51 @@ int qgd_species_flux_dev(qgd_device_t d, int stencilId, const double* Y, const d
     QGD_CATCH
 }
 
+int qgd_species_step_dev(qgd_device_t d, const double* Y, const double* Yb, const double* rhoOld, const double* rho, const double* phiJmY,
+                         const double* muf, double Sc, double deltaT, const double* Su, double* diffusiveFlux, double* Ynew) {
+    QGD_TRY
+    if (!d || !Y || !rhoOld || !rho || !phiJmY || !muf || !diffusiveFlux || !Ynew) return fail(QGD_ERR_INVALID, "qgd_species_step_dev: null argument");
+    if (!(Sc > 0) || !(deltaT > 0)) return fail(QGD_ERR_INVALID, "qgd_species_step_dev: Sc and deltaT must be positive");
+    const MeshView& v = d->view;
+    if (v.nBF > 0 && !Yb) return fail(QGD_ERR_INVALID, "qgd_species_step_dev: patch values of Y are required");
+    HIP_CHECK(hipSetDevice(d->deviceId));
+    double* net = d->ws.get<double>(WS_OUT, (size_t)v.nF);
+    (void)hipGetLastError();
+    launchSpeciesStep(d->stream, v, Y, Yb, rhoOld, rho, phiJmY, muf, Sc, deltaT, Su, diffusiveFlux, net, Ynew);
+    HIP_CHECK(hipGetLastError());
+    return QGD_OK;
+    QGD_CATCH
+}
+int qgd_species_step(qgd_device_t d, const double* Y, const double* Yb, const double* rhoOld, const double* rho, const double* phiJmY,
+                     const double* muf, double Sc, double deltaT, const double* Su, double* diffusiveFlux, double* Ynew) {
+    QGD_TRY
+    if (!d || !Y || !rhoOld || !rho || !phiJmY || !muf || !diffusiveFlux || !Ynew) return fail(QGD_ERR_INVALID, "qgd_species_step: null argument");
+    if (!(Sc > 0) || !(deltaT > 0)) return fail(QGD_ERR_INVALID, "qgd_species_step: Sc and deltaT must be positive");
+    const MeshView& v = d->view;
+    if (v.nBF > 0 && !Yb) return fail(QGD_ERR_INVALID, "qgd_species_step: patch values of Y are required");
+    HIP_CHECK(hipSetDevice(d->deviceId));
+    const size_t nC = (size_t)v.nC, nB = (size_t)v.nBF, nF = (size_t)v.nF;
+    Workspace& ws = d->ws;
+    hipStream_t st_ = d->stream;
+    int nextSlot = WS_CELL;
+    auto upD = [&](const double* src, size_t n) {
+        double* dst = ws.get<double>((size_t)nextSlot++, n);
+        if (src && n) ws.h2d(dst, src, sizeof(double) * n, st_);
+        return dst;
+    };
+    double *dY = upD(Y, nC), *dYb = upD(Yb, nB), *dRo = upD(rhoOld, nC), *dR = upD(rho, nC), *dJ = upD(phiJmY, nF), *dMu = upD(muf, nF);
+    double* dSu = Su ? upD(Su, nC) : nullptr;
+    double *dDf = upD(diffusiveFlux, nF), *dNet = upD(nullptr, nF), *dNew = upD(nullptr, nC);
+    (void)hipGetLastError();
+    launchSpeciesStep(st_, v, dY, dYb, dRo, dR, dJ, dMu, Sc, deltaT, dSu, dDf, dNet, dNew);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(st_));
+    ws.d2h(diffusiveFlux, dDf, sizeof(double) * nF, st_);
+    ws.d2h(Ynew, dNew, sizeof(double) * nC, st_);
+    return QGD_OK;
+    QGD_CATCH
+}
+
 int qgd_interpolate(qgd_device_t d, int32_t ncomp, const double* cell, const double* bnd, double* out) {
     QGD_TRY
     if (!d || !cell || !out || ncomp < 1 || ncomp > 9 || (!bnd && d->view.nBF > 0)) return fail(QGD_ERR_INVALID, "qgd_interpolate: bad argument");

@@ -155,6 +155,9 @@ void launchQhdFluxes(hipStream_t s, int stencil, const MeshView& m, const double
 // ---- species flux block: out = 5 SoA slots of nF doubles {phiJmY, diffusiveFlux, gradYf(3)} -------------------
 void launchSpeciesFlux(hipStream_t s, int stencil, const MeshView& m, const double* Y, const double* Yb, double* ptY,
                        const double* U, const double* Ub, const double* phiJm, const double* phi, const double* tau, double* out);
+void launchSpeciesStep(hipStream_t s, const MeshView& m, const double* Yc, const double* Yb, const double* rhoOld, const double* rho,
+                       const double* phiJmY, const double* muf, double Sc, double dt, const double* Su, double* diffusiveFlux, double* net,
+                       double* Ynew);
 
 // ---- implicitDiffusion branch of QGDFoam (qgd_implicit.hip) -----------------------------------------------------------
 struct ImplView {

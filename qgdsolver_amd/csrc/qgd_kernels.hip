@@ -1628,6 +1628,46 @@ __global__ __launch_bounds__(QGD_BLOCK) void speciesFaceKernel(const MeshView m,
     for (int k = 0; k < 3; ++k) out[(size_t)(2 + k) * nF + f] = g[k];
 }
 
+// QGDYEqn.H L67-86, one species, explicit branch.  Face pass: the explicit laplacian flux (muf/Sc) snGrad(Yi) |Sf| (uncorrected snGrad, L0),
+// added to diffusiveFlux as L82 does, and the net flux phiJmYi - that of the cell pass.  Empty faces carry nothing.
+__global__ __launch_bounds__(QGD_BLOCK) void speciesLapKernel(const MeshView m, const double* __restrict__ Yc, const double* __restrict__ Yb,
+                                                             const double* __restrict__ phiJmY, const double* __restrict__ muf, const double Sc,
+                                                             double* __restrict__ diffusiveFlux, double* __restrict__ net) {
+    const int f = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    if (f >= m.nF) return;
+    if (m.fkind[f] == 3) { net[f] = 0.0; return; }   // (a shard's cut faces touch ghost cells only, whose values the caller refreshes)
+    const double yo = Yc[m.own[f]];
+    const double sn = f < m.nIF ? m.dn[f] * (Yc[m.nei[f]] - yo) : m.dn[f] * (Yb[f - m.nIF] - yo);
+    const double lap = (muf[f] / Sc) * sn * m.magSf[f];
+    diffusiveFlux[f] += lap;
+    net[f] = phiJmY[f] - lap;
+}
+// cell pass: fvm::ddt(rho,Yi) + fvc::div(net) == Su (Euler), the divergence gathered in ascending face label; Yi.max(0)
+__global__ __launch_bounds__(QGD_BLOCK) void speciesCellKernel(const MeshView m, const double* __restrict__ net, const double* __restrict__ Yc,
+                                                              const double* __restrict__ rhoOld, const double* __restrict__ rho, const double dt,
+                                                              const double* __restrict__ Su, double* __restrict__ Ynew) {
+    const int c = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    if (c >= m.nC) return;
+    const int n = m.cfCount[c];
+    const size_t base = (size_t)m.cfSlice[c >> 6] * 64 + (c & 63);
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const int it = m.cfItem[base + (size_t)i * 64];
+        const double x = net[it >= 0 ? it : ~it];
+        s = it >= 0 ? s + x : s - x;
+    }
+    const double V = m.V[c], rDeltaT = 1.0 / dt;
+    double src = rDeltaT * rhoOld[c] * Yc[c] * V - s;
+    if (Su) src += V * Su[c];
+    Ynew[c] = fmax(src / (rDeltaT * rho[c] * V), 0.0);
+}
+void launchSpeciesStep(hipStream_t s, const MeshView& m, const double* Yc, const double* Yb, const double* rhoOld, const double* rho,
+                       const double* phiJmY, const double* muf, double Sc, double dt, const double* Su, double* diffusiveFlux, double* net,
+                       double* Ynew) {
+    if (m.nF) speciesLapKernel<<<gridFor(m.nF), QGD_BLOCK, 0, s>>>(m, Yc, Yb, phiJmY, muf, Sc, diffusiveFlux, net);
+    if (m.nC) speciesCellKernel<<<gridFor(m.nC), QGD_BLOCK, 0, s>>>(m, net, Yc, rhoOld, rho, dt, Su, Ynew);
+}
+
 template <int ST>
 static void launchSpeciesT(hipStream_t s, const MeshView& m, const double* Y, const double* Yb, double* ptY, const double* U,
                            const double* Ub, const double* phiJm, const double* phi, const double* tau, double* out) {

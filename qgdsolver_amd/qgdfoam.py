@@ -286,3 +286,42 @@ def speciesFlux(dev, scheme, Y, U, phiJm, phi, tauQGDf, call=None):
     else:
         call(scheme, Yc, Yb, Uc, Ub, jm, ph, tau, out["phiJmY"], out["diffusiveFlux"], out["gradYf"])
     return out
+
+
+def speciesStep(dev, Y, rhoOld, rho, phiJmY, muf, Sc, deltaT, diffusiveFlux, Su=None, call=None):
+    """One species of QGDYEqn.H L67-86 (explicit branch; the sources as one explicit field Su or None): returns the new cell values of
+    Yi (already clipped at 0) and adds (muf/Sc) snGrad(Yi.old) |Sf| to diffusiveFlux in place.  Y: (internal, boundary) pair."""
+    m = dev.mesh
+    a = lambda x, n: np.ascontiguousarray(x, dtype=np.float64).reshape(-1) if n else np.zeros(1)  # noqa: E731
+    Yc, Yb = a(Y[0], m.nCells), a(Y[1], m.nBoundaryFaces)
+    ro, rn, jm, mf = a(rhoOld, 1), a(rho, 1), a(phiJmY, 1), a(muf, 1)
+    su = None if Su is None else a(Su, 1)
+    assert Yc.size == m.nCells and ro.size == m.nCells and rn.size == m.nCells and jm.size == m.nFaces and mf.size == m.nFaces
+    assert isinstance(diffusiveFlux, np.ndarray) and diffusiveFlux.dtype == np.float64 and diffusiveFlux.size == m.nFaces and diffusiveFlux.flags.c_contiguous
+    Ynew = np.zeros(m.nCells)
+    dp = lambda x: x.ctypes.data_as(L.c_double_p)  # noqa: E731
+    if call is None:
+        L.check(L.lib.qgd_species_step(dev._h, dp(Yc), dp(Yb), dp(ro), dp(rn), dp(jm), dp(mf), float(Sc), float(deltaT),
+                                       dp(su) if su is not None else None, dp(diffusiveFlux), dp(Ynew)), "qgd_species_step")
+    else:
+        call(Yc, Yb, ro, rn, jm, mf, float(Sc), float(deltaT), su, diffusiveFlux, Ynew)
+    return Ynew
+
+
+def QGDYEqn(dev, Y, rhoOld, rho, phiJmY, muf, ScNumbers, deltaT, diffusiveFlux, inertIndex, active=None, Su=None, call=None):
+    """QGDYEqn.H L38-92, explicit branch, over all species: Y[i] = (internal, boundary) pairs (old time level), phiJmY[i], diffusiveFlux[i]
+    per species (numpy arrays over the faces, updated in place), Su[i] explicit sources or None.  Returns the list of new cell fields:
+    the active species from speciesStep, the inert one as 1 - sum of the others, clipped at 0 [L86-91]."""
+    n = len(Y)
+    new = [None] * n
+    Yt = np.zeros(dev.mesh.nCells)                                # volScalarField Yt(0.0*Y[0])
+    for i in range(n):
+        if i != inertIndex and (active is None or active[i]):
+            new[i] = speciesStep(dev, Y[i], rhoOld, rho, phiJmY[i], muf, ScNumbers[i], deltaT, diffusiveFlux[i], None if Su is None else Su[i], call)
+            diffusiveFlux[inertIndex] -= diffusiveFlux[i]           # L83 (as listed: the running total of species i, not this step's increment)
+            Yt += new[i]
+    for i in range(n):
+        if new[i] is None and i != inertIndex:
+            new[i] = np.array(Y[i][0], dtype=float)                # inactive species keep their values
+    new[inertIndex] = np.maximum(1.0 - Yt, 0.0)                    # L90-91
+    return new

@@ -45,6 +45,7 @@ Snippets evaluated (listing lines of /root/reference/docs/html/<file>_source.htm
   casebnd    the QGDFoam flux assembly on ONE BOUNDARY face: updateFields.H L45-80 with patch values, the boundary-face text of the 3-D
              stencil, updateFluxes.H L41-139, GaussVolPointStencil.C L73 -> qgdFluxFvPatchScalarField.C L184-192 (updateCoeffs with the
              fresh phiwStar), constScPrModel1.C L103-104, L121-128 (patch loop)
+  specieseqn QGDYEqn.H L40-45, L69-92 (the species loop, explicit branch, three species with an inert one) on the two-cell mesh
   thermo2cell  hePsiQGDThermo.C L48-64 + L123-124 and QGDFoam.C L152-154 (thermo.correct(), p = rho / psi after the explicit step)
   qhdflux    qhdFluxFvPatchScalarField.C L193-203 (updateCoeffs with the registered flux) on the walls of a small cavity
   lsqorder   extendedFaceStencilFindNeighbours.C L48-84 (the stencil search: which cells, in which order) on whole small 2-D meshes
@@ -886,7 +887,13 @@ class CF(list):
     def __mul__(self, o): return self._z(o, lambda a, b: a * b)
     def __rmul__(self, o): return CF([o * a for a in self])
     def __truediv__(self, o): return self._z(o, lambda a, b: a / b)
+    def __rsub__(self, o): return CF([o - a for a in self])
+    def __iadd__(self, o):                       # Yt += Yi: elementwise (a plain list would be extended)
+        self[:] = list(self + o)
+        return self
     def __call__(self): return self
+    def oldTime(self): return CF(self.old)
+    def max(self, v): self[:] = [max(a, v) for a in self]
     def assign(self, o): self[:] = list(o)
     def correctBoundaryConditions(self): pass
     def boundaryFieldRef(self): return Nil()
@@ -1833,6 +1840,60 @@ def qhdeqn(nfaces=30, seed=26):
     return {k: np.array(v) for k, v in rec.items()}
 
 
+def specieseqn(nfaces=24, seed=27):
+    """QGDYEqn.H L40-45, L69-92 (the explicit branch of the species loop) executed as listed on the two-cell mesh for three species, the
+    last one inert: solve(fvm::ddt(rho,Yi) + fvc::div(phiJmYi) - fvc::laplacian(muf/ScNumbers[i],Yi) == combustion->R(Yi) + parcels.SYi(i,Yi)),
+    diffusiveFlux[i] += (muf/ScNumbers[i]) fvc::snGrad(Yi.oldTime()) magSf, diffusiveFlux[inert] -= diffusiveFlux[i], Yi.max(0), Yt,
+    Y[inert] = 1 - Yt.  fvm / fvc are the two-cell emulations (L0: Euler ddt, surfaceIntegrate, Gauss laplacian with the uncorrected
+    snGrad); combustion->R and parcels.SYi return explicit source fields (their sum is what qgd_species_step takes as Su)."""
+    ye = listing("QGDYEqn_8H_source.html")
+    txt = [ye[i] for i in list(range(40, 46)) + list(range(69, 84)) + list(range(86, 93))]
+    src = transpile(txt)
+    rng = np.random.default_rng(seed)
+    names = ("nv", "pts", "Sf", "Cf", "C", "delta", "rhoOld", "rho", "Y", "phiJmY", "muf", "Sc", "Su", "deltaT", "inertIndex", "diffusiveFlux0",
+             "Ynew", "diffusiveFlux1")
+    rec = {k: [] for k in names}
+    for n in range(nfaces):
+        nv = 4 if n % 3 != 2 else 3
+        pts, own, nei = skew_face(rng, nv)
+        S, cf = face_area_centre(pts)
+        S, Cf = Vec(*S), Vec(*cf)
+        dvec = nei - own
+        delta = 1.0 / max((S / mag(S)) & dvec, 0.05 * mag(dvec))                       # nonOrthDeltaCoeffs (L0)
+        dt = float(10.0 ** rng.uniform(-3, -2))
+        V = [1.0, 1.0]
+        rho_old = [float(rng.uniform(0.8, 1.2)) for _ in range(2)]
+        rho_new = [float(r * rng.uniform(0.97, 1.03)) for r in rho_old]
+        ns, inert = 3, 2
+        Y0 = [[float(rng.uniform(0.0, 0.5)) for _ in range(2)] for _ in range(ns)]
+        if n % 4 == 1:
+            Y0[0][0] = 1e-4                                                             # a value the step drives below zero: Yi.max(0.0)
+        jm = [float(0.3 * rng.standard_normal()) for _ in range(ns)]
+        if n % 4 == 1:
+            jm[0] = 5.0 * abs(jm[0]) + 1.0
+        muf = float(rng.uniform(1e-3, 1e-1))
+        Sc = [float(rng.uniform(0.5, 1.5)) for _ in range(ns)]
+        Su = [[float(0.2 * rng.standard_normal()) for _ in range(2)] for _ in range(ns)]
+        df0 = [float(0.1 * rng.standard_normal()) for _ in range(ns)]
+        fvm, fvc = fv_emulation(dt, V)
+        fvc.laplacian = lambda gam, psi: CF([gam * mag(S) * delta * (psi[1] - psi[0]) / V[0], -(gam * mag(S) * delta * (psi[1] - psi[0])) / V[1]])
+        fvc.snGrad = lambda psi: delta * (psi[1] - psi[0])
+        Y = [CF(list(y)) for y in Y0]
+        rho = CF(rho_new, old=rho_old)
+        half = [[0.5 * x for x in su] for su in Su]                                      # R and SYi: two halves of the explicit source
+        env = dict(Y=Y, phiJmY=list(jm), inertIndex=inert, composition=Obj(active=lambda i: True), fvm=fvm, fvc=fvc, rho=rho, muf=muf,
+                   ScNumbers=Sc, combustion=Obj(R=lambda Yi: CF(half[[id(y) for y in Y].index(id(Yi))])),
+                   parcels=Obj(SYi=lambda i, Yi: CF(half[i])), diffusiveFlux=list(df0), mesh=Obj(magSf=call(mag(S))), Yt=CF([0.0, 0.0]),
+                   solve=lambda M: M.solve(), scalar=float)
+        exec(src, env)
+        out = dict(nv=nv, pts=np.array([q.c for q in pts] + ([[0, 0, 0]] if nv == 3 else [])), Sf=S.c, Cf=Cf.c, C=np.array([own.c, nei.c]), delta=delta,
+                   rhoOld=rho_old, rho=rho_new, Y=Y0, phiJmY=jm, muf=muf, Sc=Sc, Su=Su, deltaT=dt, inertIndex=inert, diffusiveFlux0=df0,
+                   Ynew=[list(y) for y in env["Y"]], diffusiveFlux1=env["diffusiveFlux"])
+        for k in names:
+            rec[k].append(np.array(out[k], dtype=float))
+    return {k: np.array(v) for k, v in rec.items()}
+
+
 class LabelList(list):
     """OpenFOAM's labelList as the stencil search uses it: append(label) and append(list) (List::append(const UList&))"""
     def append(self, x):
@@ -1931,7 +1992,7 @@ def main():
             print("implicit2cell", {k: v.shape for k, v in impl.items()})
     for name, data in (("gvp2d_vec", gvp2d_vec()), ("gvp_other", gvp_other()), ("qgdlength", qgdlength()), ("courant", courant(case)),
                        ("thermo2cell", thermo2cell(case)),
-                       ("qhdclosure", qhdclosure()), ("casebnd", casebnd()), ("qhdeqn", qhdeqn()), ("lsqorder", lsqorder()), ("qhdflux", qhdflux())):
+                       ("qhdclosure", qhdclosure()), ("casebnd", casebnd()), ("qhdeqn", qhdeqn()), ("lsqorder", lsqorder()), ("qhdflux", qhdflux()), ("specieseqn", specieseqn())):
         np.savez_compressed(os.path.join(HERE, f"ref_expr_{name}.npz"), **data)
         print(name, {k: getattr(v, "shape", None) for k, v in data.items()})
 

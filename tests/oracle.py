@@ -364,6 +364,13 @@ def species_flux(omesh, scheme, Yc, Yb, Uc, Ub, jm, ph, tau, phiJmY, diffusiveFl
                                 _d(diffusiveFlux), _d(gradYf))
 
 
+def species_step(omesh, Yc, Yb, rho_old, rho, phiJmY, muf, Sc, deltaT, Su, diffusiveFlux, Ynew):
+    """drop-in for the `call` hook of qgdsolver_amd.qgdfoam.speciesStep"""
+    lib.orc_species_step.argtypes = [C.c_void_p, dp, dp, dp, dp, dp, dp, C.c_double, C.c_double, dp, dp, dp]
+    return lib.orc_species_step(omesh._h, _d(Yc), _d(Yb), _d(rho_old), _d(rho), _d(phiJmY), _d(muf), float(Sc), float(deltaT),
+                                _d(Su) if Su is not None else None, _d(diffusiveFlux), _d(Ynew))
+
+
 class OracleQhdCase:
     """QHDFoam case of the oracle (explicit branch of QHDFoam.C L83-139); mirrors qgdsolver_amd.qhdfoam.QHDFoamCase"""
     KINDS = {"zeroGradient": 0, "fixedValue": 1, "slip": 2, "fixedGradient": 3, "qhdFlux": 3, "none": 4, "qhdFluxCoupled": 5}

@@ -484,3 +484,37 @@ def test_qhdflux_wall_gradient_from_the_listing_text():
     assert np.abs(g["gradient"]).max() > 1e-6           # the walls do carry a gradient
     assert rel(oc.field("phiwo")[nif:], g["phiwo_b"]) <= 1e-13
     assert rel(oc.field("p.boundary"), g["pb"]) <= 1e-12
+
+
+def species_equation_inputs(g, i):
+    """arguments of qgdfoam.QGDYEqn for case i of ref_expr_specieseqn (the two-cell mesh has no boundary faces)"""
+    ns = g["Y"].shape[1]
+    Y = [(g["Y"][i][k].copy(), np.zeros(0)) for k in range(ns)]
+    jm = [np.array([g["phiJmY"][i][k]]) for k in range(ns)]
+    df = [np.array([g["diffusiveFlux0"][i][k]]) for k in range(ns)]
+    Su = [g["Su"][i][k].copy() for k in range(ns)]
+    return Y, jm, df, Su, np.array([float(g["muf"][i])])
+
+
+def test_species_equation_from_the_listing_text():
+    """QGDYEqn.H L40-45, L69-92 executed as listed (three species, the last inert, explicit sources, one case with a value the step
+    drives below zero) against qgdfoam.QGDYEqn over the oracle's orc_species_step"""
+    from qgdsolver_amd import qgdfoam
+    from test_qhd_pressure import HostDev
+    g = rc.load("specieseqn")
+    assert (g["Ynew"] == 0.0).any()
+    for i in range(len(g["nv"])):
+        prim, geom = rc.two_cell_mesh(g["pts"][i], int(g["nv"][i]), g["Sf"][i], g["Cf"][i], g["C"][i])
+        om = oracle_mesh(prim, geom)
+        assert rel(om.array("nonOrthDeltaCoeffs")[0], g["delta"][i]) <= 1e-14
+        mesh = type("M", (), dict(nCells=2, nFaces=1, nBoundaryFaces=0))()
+        Y, jm, df, Su, muf = species_equation_inputs(g, i)
+
+        def call(*a):
+            assert oracle.species_step(om, *a) == 0
+        new = qgdfoam.QGDYEqn(HostDev(mesh), Y, g["rhoOld"][i], g["rho"][i], jm, muf, list(g["Sc"][i]), float(g["deltaT"][i]), df,
+                              int(g["inertIndex"][i]), Su=Su, call=call)
+        for k in range(len(new)):
+            assert np.abs(new[k] - g["Ynew"][i][k]).max() <= 1e-12, (i, k, new[k], g["Ynew"][i][k])
+            assert abs(df[k][0] - g["diffusiveFlux1"][i][k]) <= 1e-12 * max(1.0, abs(g["diffusiveFlux1"][i][k])), (i, k)
+        om.close()

@@ -355,3 +355,19 @@ def test_qhdflux_wall_gradient_on_the_device():
     assert rel(gc.field("phiwo")[nif:], g["phiwo_b"]) <= 1e-8
     assert rel(gc.field("p.boundary"), g["pb"]) <= 1e-8
     gc.close(); dev.close()
+
+
+def test_species_equation_on_the_device():
+    """qgd_species_step (through qgdfoam.QGDYEqn) against QGDYEqn.H L40-45, L69-92 executed from the listing text"""
+    from qgdsolver_amd import qgdfoam
+    from test_ref_expr import species_equation_inputs
+    g = rc.load("specieseqn")
+    for i in range(len(g["nv"])):
+        mesh = device_mesh(*rc.two_cell_mesh(g["pts"][i], int(g["nv"][i]), g["Sf"][i], g["Cf"][i], g["C"][i]))
+        dev = q.Device(mesh)
+        Y, jm, df, Su, muf = species_equation_inputs(g, i)
+        new = qgdfoam.QGDYEqn(dev, Y, g["rhoOld"][i], g["rho"][i], jm, muf, list(g["Sc"][i]), float(g["deltaT"][i]), df, int(g["inertIndex"][i]), Su=Su)
+        for k in range(len(new)):
+            assert np.abs(new[k] - g["Ynew"][i][k]).max() <= 1e-12, (i, k, new[k], g["Ynew"][i][k])
+            assert abs(df[k][0] - g["diffusiveFlux1"][i][k]) <= 1e-12 * max(1.0, abs(g["diffusiveFlux1"][i][k])), (i, k)
+        dev.close()

@@ -83,3 +83,64 @@ def test_device_matches_oracle(kind, scheme):
         with pytest.raises(q.QgdError):
             qgdfoam.speciesFlux(dev, "leastSquares", Y, U, phiJm, phi, tau)
     dev.close()
+
+
+# ---- the species equation itself (QGDYEqn.H L67-86, explicit branch): qgd_species_step -------------------------------------------
+def step_inputs(mesh, seed):
+    rng = np.random.default_rng(seed)
+    Y = (0.2 + 0.6 * rng.random(mesh.nCells), 0.2 + 0.6 * rng.random(mesh.nBoundaryFaces))
+    rho_old = 1.0 + 0.1 * rng.random(mesh.nCells)
+    rho = rho_old * (1.0 + 0.01 * rng.standard_normal(mesh.nCells))
+    phiJmY = 1e-3 * rng.standard_normal(mesh.nFaces)
+    muf = 1e-3 * (1.0 + rng.random(mesh.nFaces))
+    Su = 0.05 * rng.standard_normal(mesh.nCells)
+    return Y, rho_old, rho, phiJmY, muf, Su
+
+
+def test_oracle_species_step_conserves_the_species_mass():
+    """sum V rho Y changes by -dt (boundary fluxes of phiJmY - laplacian flux) + dt sum V Su: the internal faces cancel in pairs"""
+    mesh = make_mesh("box654_poly")
+    om = oracle_mesh_of(mesh)
+    Y, rho_old, rho, phiJmY, muf, Su = step_inputs(mesh, 4)
+    dt, Sc = 1e-3, 0.8
+    df = np.zeros(mesh.nFaces)
+
+    def call(*a):
+        assert orc.species_step(om, *a) == 0
+    new = qgdfoam.speciesStep(HostDev(mesh), Y, rho_old, rho, phiJmY, muf, Sc, dt, df, Su=Su, call=call)
+    assert new.min() > 0          # nothing clipped with these inputs
+    V, nif = mesh.array("V"), mesh.nInternalFaces
+    types = mesh.array("patchType")
+    live = np.ones(mesh.nBoundaryFaces, dtype=bool)
+    for ip in range(mesh.nPatches):
+        if types[ip] == q._lib.PATCH_EMPTY:
+            s0 = mesh.array("patchStart")[ip] - nif
+            live[s0:s0 + mesh.array("patchSize")[ip]] = False
+    lhs = (V * rho * new).sum() - (V * rho_old * Y[0]).sum()
+    rhs = -dt * ((phiJmY[nif:] - df[nif:])[live]).sum() + dt * (V * Su).sum()
+    assert abs(lhs - rhs) <= 1e-13 * (V * rho_old * Y[0]).sum()
+    # the laplacian flux added to diffusiveFlux is (muf/Sc) snGrad(Y) |Sf| with the uncorrected snGrad
+    own, nei = mesh.array("owner"), mesh.array("neighbour")
+    want = muf[:nif] / Sc * mesh.array("nonOrthDeltaCoeffs")[:nif] * (Y[0][nei] - Y[0][own[:nif]]) * mesh.array("magSf")[:nif]
+    assert np.abs(df[:nif] - want).max() <= 1e-15 * np.abs(want).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["box654_poly", "box654_jitter", "plane2d_jitter", "step2d"])
+def test_device_species_step_matches_oracle(kind):
+    mesh = make_mesh(kind)
+    om = oracle_mesh_of(mesh)
+    dev = q.Device(mesh)
+    Y, rho_old, rho, phiJmY, muf, Su = step_inputs(mesh, 6)
+    Y[0][:3] = 1e-7            # cells the step drives below zero: Yi.max(0.0)
+    phiJmY[:mesh.nInternalFaces] += 0.0
+    dt, Sc = 2e-3, 1.3
+    for su in (Su, None):
+        dfo, dfd = 0.01 * np.ones(mesh.nFaces), 0.01 * np.ones(mesh.nFaces)
+
+        def call(*a):
+            assert orc.species_step(om, *a) == 0
+        want = qgdfoam.speciesStep(HostDev(mesh), Y, rho_old, rho, phiJmY, muf, Sc, dt, dfo, Su=su, call=call)
+        got = qgdfoam.speciesStep(dev, Y, rho_old, rho, phiJmY, muf, Sc, dt, dfd, Su=su)
+        assert rel_err(got, want) <= 1e-12 and rel_err(dfd, dfo) <= 1e-13, (kind, rel_err(got, want))
+    dev.close()
