@@ -411,14 +411,30 @@ __global__ __launch_bounds__(QGD_BLOCK) void iApplyKernel(const MeshView m, cons
         double acc[NR], rowsum = 0.0;
 #pragma unroll
         for (int k = 0; k < NR; ++k) acc[k] = 0.0;
-        for (int e = 0; e < cnt; ++e) {
-            const int nb = m.cfNbr[base + (size_t)e * 64];
-            if (nb < 0) continue;
-            const int it = m.cfItem[base + (size_t)e * 64];
-            const double af = v.a[it >= 0 ? it : ~it];
-            rowsum += af;
+        // eight entries at a time, every level of the chain (lists -> face coefficient and neighbour values) requested before the
+        // first use; entries past the row end and boundary faces (nb < 0) add 0 * 0 in their place, which changes no bit
+        constexpr int U = 8;
+        for (int e0 = 0; e0 < cnt; e0 += U) {
+            int nb[U], it[U];
+            double af[U], xs[NR][U];
 #pragma unroll
-            for (int k = 0; k < NR; ++k) acc[k] += af * src[(size_t)k * v.nC + nb];
+            for (int u = 0; u < U; ++u) {
+                const bool in = e0 + u < cnt;
+                nb[u] = in ? m.cfNbr[base + (size_t)(e0 + u) * 64] : -1;
+                it[u] = in ? m.cfItem[base + (size_t)(e0 + u) * 64] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                af[u] = nb[u] >= 0 ? v.a[it[u] >= 0 ? it[u] : ~it[u]] : 0.0;
+#pragma unroll
+                for (int k = 0; k < NR; ++k) xs[k][u] = nb[u] >= 0 ? src[(size_t)k * v.nC + nb[u]] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                rowsum += af[u];
+#pragma unroll
+                for (int k = 0; k < NR; ++k) acc[k] += af[u] * xs[k][u];
+            }
         }
 #pragma unroll
         for (int k = 0; k < NR; ++k) {
