@@ -350,8 +350,8 @@ int diagLaplacianPcg(hipStream_t stream, const MeshView& m, const double* a, con
 // [QHDpEqn.H L36-47], and in QHDFoam its matrix never changes (taubyrhof is fixed after start-up), so a hierarchy built once
 // pays for itself at the first step.  Built on the host from the face coefficients, two kinds:
 //   smoothed aggregation (default, see smoothedLevel below): root-and-neighbours aggregates of the strength graph, the prolongator
-//     smoothed by one Jacobi step, Galerkin coarse operators, the last level (<= 1024 rows) solved exactly with its dense inverse;
-//     8 M cells: levels of 8 M / 1 M / 55 k / 1.7 k / 50 rows, 8 CG iterations to QHDFoam's 1e-8;
+//     smoothed by one Jacobi step, Galerkin coarse operators, the last level (<= 2048 rows, QGD_MG_DENSE_MAX) solved exactly with its dense inverse;
+//     8 M cells: levels of 8 M / 1 M / 55 k / 1.7 k rows, 6 CG iterations to QHDFoam's 1e-8;
 //   plain aggregation (QGD_MG_SA=0, what round 2 shipped): pairwise matching along the strongest connection, two passes per level
 //     (aggregates of ~4 cells), piecewise-constant prolongation with an over-weighted correction (x += 1.8 P e_c); 24 iterations.
 // One V-cycle = nu damped-Jacobi sweeps before and after the coarse-grid correction; with equal pre- and post-smoothing the cycle is a
@@ -775,6 +775,7 @@ struct PressureSolver {
     bool sa = true;
     int passes = 2;
     double saTheta = 0.08;
+    int denseMax = 2048;                   // QGD_MG_DENSE_MAX
     // ---- a hierarchy that SPANS THE RANKS of a sharded solve (QGD_MG_DIST, default on; 0: the rank-local block hierarchy) ----------------
     // A rank-local hierarchy is block Jacobi: 7 -> 65 / 97 / 140 iterations on 2 / 4 / 8 shards of a 128^3 box.  Here level 0 stays
     // distributed (each rank smooths its own rows, the ghost entries of the iterate refreshed before every sweep), every level below it
@@ -1205,7 +1206,7 @@ static bool denseInverse(int n, const std::vector<int>& I, const std::vector<int
     }
     return true;
 }
-#define MG_DENSE_MAX 1024   // a level of at most this many rows is the last one and is solved exactly
+#define MG_DENSE_MAX 2048   // a level of at most this many rows is the last one and is solved exactly (default of QGD_MG_DENSE_MAX)
 static void mgUploadLevel(PressureSolver* S, int n, const std::vector<int>& I, const std::vector<int>& J, const std::vector<double>& w,
                           const std::vector<double>& diag, bool last) {
     std::vector<int> deg((size_t)n, 0);
@@ -1248,7 +1249,7 @@ static void mgUploadLevel(PressureSolver* S, int n, const std::vector<int>& I, c
         }
     }
     std::vector<double> inv;
-    const bool dense = last && !S->L.empty() && n <= MG_DENSE_MAX && denseInverse(n, I, J, w, diag, inv);
+    const bool dense = last && !S->L.empty() && n <= S->denseMax && denseInverse(n, I, J, w, diag, inv);
     MgLevelDev lv;
     lv.n = n; lv.width = width; lv.entries = stored;
     lv.diag = S->alloc<double>(n, diag.data());
@@ -1317,7 +1318,7 @@ static void mgBuildHierarchy(PressureSolver* S, int n, std::vector<int>& I, std:
     const int passes = S->passes;
     const double saTheta = S->saTheta;
     S->smootherScale.assign(1, 1.0);
-    while (n > (sa ? MG_DENSE_MAX : 600) && S->L.size() < 12) {
+    while (n > (sa ? S->denseMax : 600) && S->L.size() < 12) {
         std::vector<int> total((size_t)n);
         for (int i = 0; i < n; ++i) total[i] = i;
         int cur = n;
@@ -1355,7 +1356,7 @@ static void mgBuildHierarchy(PressureSolver* S, int n, std::vector<int>& I, std:
             n = cur;
             adjacencyOf(n, I, J, w, off, nbr, nw);
             S->smootherScale.push_back(2.0 / lambdaMaxOf(n, off, nbr, nw, diag));
-            mgUploadLevel(S, n, I, J, w, diag, n <= MG_DENSE_MAX);
+            mgUploadLevel(S, n, I, J, w, diag, n <= S->denseMax);
             continue;
         }
         for (int pass = 0; pass < passes && cur > 64; ++pass) {
@@ -1411,6 +1412,7 @@ PressureSolver* pressureSolverCreate(hipStream_t stream, const MeshView& m, cons
         const bool sa = S->sa = knob("QGD_MG_SA", 1, 0, 1) != 0;
         S->passes = (int)knob("QGD_MG_PASSES", 2, 1, 4);                   // plain aggregation: pairwise matching passes per level
         S->saTheta = knob("QGD_MG_SA_THETA", 0.08, 0.0, 0.9);             // strength threshold on level 0, halved per level
+        S->denseMax = (int)knob("QGD_MG_DENSE_MAX", MG_DENSE_MAX, 64, 8192);  // the last level (solved exactly) has at most this many rows
         if (sa) S->oc = knob("QGD_MG_OC", 1.0, 0.5, 3.0);
         // a shard with smoothed aggregation and the single-precision cycle builds the hierarchy that spans the ranks, at its first solve
         const bool distWanted = sharded && precond == 1 && sa && S->f32 && knob("QGD_MG_DIST", 1, 0, 1) != 0;
@@ -1533,7 +1535,7 @@ static bool distSetupStep(PressureSolver* S) {
         PCHECK(hipMemcpyAsync(v, D.buf, sizeof(v), hipMemcpyDeviceToHost, stream));
         PCHECK(hipStreamSynchronize(stream));
         D.nCg = (int64_t)v[0]; D.K = (int)v[1];
-        if (D.nCg <= MG_DENSE_MAX || D.nCg >= 0x7fffffffLL || D.nCg == nOwned) {
+        if (D.nCg <= S->denseMax || D.nCg >= 0x7fffffffLL || D.nCg == nOwned) {
             if (std::getenv("QGD_MG_VERBOSE")) std::fprintf(stderr, "[qgd mg] rank-local hierarchy: %lld cells in all, %d here\n", (long long)D.nCg, nOwned);
             distBlockFallback(S); D.built = true; return true;
         }
