@@ -78,17 +78,33 @@ __global__ __launch_bounds__(PB) void assembleKernel(const MeshView m, const Poi
     const int n = m.cfCount[c];
     const size_t base = (size_t)m.cfSlice[c >> 6] * 64 + (c & 63);
     double diag = 0, rhs = 0;
-    for (int i = 0; i < n; ++i) {
-        const int it = m.cfItem[base + (size_t)i * 64];
-        const int f = it >= 0 ? it : ~it;
-        if (m.fkind[f] == 3) continue;  // empty patches
-        const double flux = phiu[f] - phiwo[f];
-        rhs = it >= 0 ? rhs - flux : rhs + flux;  // -(fvc::div(phiu) - fvc::div(phiwo)) V
-        if (f < m.nIF) diag += v.a[f];
-        else {
-            const int b = f - m.nIF;
-            if (v.bKind[b] == 1) { diag += v.a[f]; rhs += v.a[f] * v.pb[b]; }
-            else if (v.bKind[b] == 2) rhs += v.gs[b] * v.gb[b];
+    // eight faces per pass: labels, then kind / fluxes / coefficient of every face in flight before the ordered sums
+    for (int i0 = 0; i0 < n; i0 += 8) {
+        int itv[8], kind[8];
+        double fu[8], fw[8], av[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) itv[u] = i0 + u < n ? m.cfItem[base + (size_t)(i0 + u) * 64] : 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool on = i0 + u < n;
+            const int f = itv[u] >= 0 ? itv[u] : ~itv[u];
+            kind[u] = on ? m.fkind[f] : 3;
+            fu[u] = on ? phiu[f] : 0.0;
+            fw[u] = on ? phiwo[f] : 0.0;
+            av[u] = on ? v.a[f] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (kind[u] == 3) continue;  // empty patches (and the entries past the row end)
+            const int it = itv[u], f = it >= 0 ? it : ~it;
+            const double flux = fu[u] - fw[u];
+            rhs = it >= 0 ? rhs - flux : rhs + flux;  // -(fvc::div(phiu) - fvc::div(phiwo)) V
+            if (f < m.nIF) diag += av[u];
+            else {
+                const int b = f - m.nIF;
+                if (v.bKind[b] == 1) { diag += av[u]; rhs += av[u] * v.pb[b]; }
+                else if (v.bKind[b] == 2) rhs += v.gs[b] * v.gb[b];
+            }
         }
     }
     if (c == refCell) {  // fvMatrix::setReference (L0): source += diag*value, diag += diag
@@ -678,17 +694,23 @@ __global__ __launch_bounds__(PB) void directionCtlKernel(const int n, const int 
     const int c = blockIdx.x * PB + threadIdx.x;
     if (c < n) d[c] = first ? z[c] : z[c] + ctl[C_BETA] * d[c];
 }
-// folds `count` rows of partials into ctl[first ...] (one workgroup per row, ascending order, four chains per thread)
+// folds `count` rows of partials into ctl[first ...] (one workgroup per row, ascending order, eight chains per thread)
 __global__ __launch_bounds__(PB) void foldCtlKernel(const double* __restrict__ part, const int nBlocks, const int count, double* __restrict__ ctl,
                                                      const int first, const int always) {
     if (!always && solveDone(ctl)) return;
     const int k = blockIdx.x;
     const double* __restrict__ p = part + (size_t)k * nBlocks;
-    double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+    double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int i = threadIdx.x;
-    for (; i + 3 * PB < nBlocks; i += 4 * PB) { v0 += p[i]; v1 += p[i + PB]; v2 += p[i + 2 * PB]; v3 += p[i + 3 * PB]; }
-    for (; i < nBlocks; i += PB) v0 += p[i];
-    const double t = blockSum((v0 + v1) + (v2 + v3));
+    for (; i + 7 * PB < nBlocks; i += 8 * PB) {
+        double x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = p[i + j * PB];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += x[j];
+    }
+    for (; i < nBlocks; i += PB) v[0] += p[i];
+    const double t = blockSum(((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])));
     if (threadIdx.x == 0) ctl[first + k] = t;
 }
 // the loop's own bookkeeping, one thread each (what the host did between synchronisations before):
