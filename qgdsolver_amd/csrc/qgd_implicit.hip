@@ -526,11 +526,18 @@ __global__ __launch_bounds__(QGD_BLOCK) void iFoldKernel(const ISolveView v, con
     const int row = blockIdx.x / NR, k = blockIdx.x % NR;
     if (!always && v.ctl[ICTL(I_DONE, k)] != 0.0) return;   // uniform over the workgroup
     const double* __restrict__ p = v.part + (size_t)(row * NR + k) * v.nBlocks;
-    double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+    // eight independent chains per thread, their loads requested together (31 250 partials at 8 M cells: 15 round trips instead of 30)
+    double w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int i = threadIdx.x;
-    for (; i + 3 * QGD_BLOCK < v.nBlocks; i += 4 * QGD_BLOCK) { v0 += p[i]; v1 += p[i + QGD_BLOCK]; v2 += p[i + 2 * QGD_BLOCK]; v3 += p[i + 3 * QGD_BLOCK]; }
-    for (; i < v.nBlocks; i += QGD_BLOCK) v0 += p[i];
-    const double t = iBlockSum((v0 + v1) + (v2 + v3));
+    for (; i + 7 * QGD_BLOCK < v.nBlocks; i += 8 * QGD_BLOCK) {
+        double x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = p[i + j * QGD_BLOCK];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[j] += x[j];
+    }
+    for (; i < v.nBlocks; i += QGD_BLOCK) w[0] += p[i];
+    const double t = iBlockSum(((w[0] + w[1]) + (w[2] + w[3])) + ((w[4] + w[5]) + (w[6] + w[7])));
     if (threadIdx.x == 0) v.ctl[ICTL(firstSlot + row, k)] = t;
 }
 // bookkeeping, one thread per component.  stage 0: start (valid mask: components along empty directions are "done" from the start);
