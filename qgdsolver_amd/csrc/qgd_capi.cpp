@@ -2460,11 +2460,14 @@ int qgd_case_get_field(qgd_case_t c, const char* name, double* out, int64_t outD
         const int nc = s == "phiTauMC" ? 3 : 1;
         if ((int64_t)m.nF * nc > outDoubles) return fail(QGD_ERR_INVALID, "output too small");
         HIP_CHECK(hipStreamSynchronize(c->stream()));
+        // stored at the faces' slot-major positions (qgd_implicit.hip implFaceKernel): internal face f at fpos[f], patch faces at their label
         std::vector<double> tmp((size_t)m.nF);
+        std::vector<int32_t> fpos((size_t)m.nIF);
+        if (m.nIF) HIP_CHECK(hipMemcpy(fpos.data(), m.fpos, sizeof(int32_t) * (size_t)m.nIF, hipMemcpyDeviceToHost));
         for (int k = 0; k < nc; ++k) {
             const double* src = nc == 3 ? c->impl.phiTau + (size_t)k * m.nF : c->impl.phiSig;
             HIP_CHECK(hipMemcpy(tmp.data(), src, sizeof(double) * (size_t)m.nF, hipMemcpyDeviceToHost));
-            for (int64_t f = 0; f < m.nF; ++f) out[f * nc + k] = tmp[f];
+            for (int64_t f = 0; f < m.nF; ++f) out[f * nc + k] = tmp[f < m.nIF ? (size_t)fpos[f] : (size_t)f];
         }
         return QGD_OK;
     }

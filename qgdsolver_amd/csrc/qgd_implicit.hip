@@ -77,9 +77,13 @@ __global__ __launch_bounds__(QGD_BLOCK) void implFaceKernel(const MeshView m, co
     const int f = blockIdx.x * QGD_BLOCK + threadIdx.x;
     if (f >= m.nF) return;
     const size_t nF = (size_t)m.nF;
+    // what the cell kernels and the matrix products gather (phiTauMC, the laplacian coefficients, phiSigmaDotU) sits at the face's
+    // slot-major POSITION like the net fluxes (MeshView::fpos, cfPos): consecutive cells find it at consecutive addresses, by label
+    // they would touch every third double of the lines they fetch
+    const size_t pos = f < m.nIF ? (size_t)m.fpos[f] : (size_t)f;
     if (m.fkind[f] == 3) {
-        for (int k = 0; k < 3; ++k) { iv.phiTau[(size_t)k * nF + f] = 0.0; iv.UfS[(size_t)k * nF + f] = 0.0; }
-        iv.sTau[f] = iv.mufS[f] = iv.aU[f] = iv.aE[f] = 0.0;
+        for (int k = 0; k < 3; ++k) { iv.phiTau[(size_t)k * nF + pos] = 0.0; iv.UfS[(size_t)k * nF + f] = 0.0; }
+        iv.sTau[f] = iv.mufS[f] = iv.aU[pos] = iv.aE[pos] = 0.0;
         return;
     }
     const int o = m.own[f];
@@ -116,14 +120,14 @@ __global__ __launch_bounds__(QGD_BLOCK) void implFaceKernel(const MeshView m, co
     double tU[3];
     for (int i = 0; i < 3; ++i) tU[i] = tau[3 * i] * Uf[0] + tau[3 * i + 1] * Uf[1] + tau[3 * i + 2] * Uf[2];   // tauMC & Uf
     for (int j = 0; j < 3; ++j) {
-        iv.phiTau[(size_t)j * nF + f] = S[0] * tau[j] + S[1] * tau[3 + j] + S[2] * tau[6 + j];                  // Sf & tauMC
+        iv.phiTau[(size_t)j * nF + pos] = S[0] * tau[j] + S[1] * tau[3 + j] + S[2] * tau[6 + j];                  // Sf & tauMC
         iv.UfS[(size_t)j * nF + f] = Uf[j];
     }
     iv.sTau[f] = S[0] * tU[0] + S[1] * tU[1] + S[2] * tU[2];
     iv.mufS[f] = muf;
     const double gsd = m.magSf[f] * m.dn[f];   // |Sf| * (nonOrthDeltaCoeffs inside, deltaCoeffs on patches)
-    iv.aU[f] = muf * gsd;
-    iv.aE[f] = alf * gsd;
+    iv.aU[pos] = muf * gsd;
+    iv.aE[pos] = alf * gsd;
 }
 
 // QGDRhoEqn.H, the first solve of QGDUEqn.H (rhoU), U = rhoU/rho, and the matrix + source of UEqn per component
@@ -143,12 +147,12 @@ __global__ __launch_bounds__(QGD_BLOCK) void implCellUKernel(const MeshView m, c
         for (int i = 0; i < 6; ++i) { it[i] = m.cfItem[base + (size_t)i * 64]; ps[i] = m.cfPos[base + (size_t)i * 64]; }
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            const size_t f = (size_t)(it[i] >= 0 ? it[i] : ~it[i]), pos = (size_t)(ps[i] >= 0 ? ps[i] : ~ps[i]);
+            const size_t pos = (size_t)(ps[i] >= 0 ? ps[i] : ~ps[i]);
 #pragma unroll
             for (int k = 0; k < 4; ++k) fx[i][k] = c.flux[(size_t)k * nF + pos];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) tx[i][k] = iv.phiTau[(size_t)k * nF + f];
-            ax[i] = iv.aU[f];
+            for (int k = 0; k < 3; ++k) tx[i][k] = iv.phiTau[(size_t)k * nF + pos];
+            ax[i] = iv.aU[pos];
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -166,8 +170,8 @@ __global__ __launch_bounds__(QGD_BLOCK) void implCellUKernel(const MeshView m, c
             const int f = it >= 0 ? it : ~it;
             const size_t pos = f < m.nIF ? (size_t)m.fpos[f] : (size_t)f;
             for (int k = 0; k < 4; ++k) { const double x = c.flux[(size_t)k * nF + pos]; sum[k] = it >= 0 ? sum[k] + x : sum[k] - x; }
-            for (int k = 0; k < 3; ++k) { const double x = iv.phiTau[(size_t)k * nF + f]; dTau[k] = it >= 0 ? dTau[k] + x : dTau[k] - x; }
-            if (f < m.nIF) diagBase += iv.aU[f];
+            for (int k = 0; k < 3; ++k) { const double x = iv.phiTau[(size_t)k * nF + pos]; dTau[k] = it >= 0 ? dTau[k] + x : dTau[k] - x; }
+            if (f < m.nIF) diagBase += iv.aU[pos];
         }
     }
     const RecA A = c.A[ci];
@@ -245,8 +249,8 @@ __global__ __launch_bounds__(QGD_BLOCK) void implBcUKernel(const MeshView m, con
 __global__ __launch_bounds__(QGD_BLOCK) void implSigmaKernel(const MeshView m, const CaseView c, const ImplView iv, const PatchBCDev* __restrict__ bcs) {
     const int f = blockIdx.x * QGD_BLOCK + threadIdx.x;
     if (f >= m.nF) return;
-    if (m.fkind[f] == 3) { iv.phiSig[f] = 0.0; return; }
-    const size_t nF = (size_t)m.nF;
+    const size_t nF = (size_t)m.nF, pos = f < m.nIF ? (size_t)m.fpos[f] : (size_t)f;   // phiSigmaDotU at the face's position (see implFaceKernel)
+    if (m.fkind[f] == 3) { iv.phiSig[pos] = 0.0; return; }
     const int o = m.own[f];
     double g[9];
     if (f < m.nIF) {
@@ -266,7 +270,7 @@ __global__ __launch_bounds__(QGD_BLOCK) void implSigmaKernel(const MeshView m, c
     const double S[3] = {m.Sx[f], m.Sy[f], m.Sz[f]};
     double gu[3];
     for (int i = 0; i < 3; ++i) gu[i] = g[3 * i] * Uf[0] + g[3 * i + 1] * Uf[1] + g[3 * i + 2] * Uf[2];
-    iv.phiSig[f] = iv.mufS[f] * (S[0] * gu[0] + S[1] * gu[1] + S[2] * gu[2]) + iv.sTau[f];
+    iv.phiSig[pos] = iv.mufS[f] * (S[0] * gu[0] + S[1] * gu[1] + S[2] * gu[2]) + iv.sTau[f];
 }
 
 // EEqn [QGDEEqn.H L37-50] and the matrix + source of the e equation [L55-61]
@@ -299,8 +303,8 @@ __global__ __launch_bounds__(QGD_BLOCK) void implCellEKernel(const MeshView m, c
         for (int i = 0; i < 6; ++i) { it[i] = m.cfItem[base + (size_t)i * 64]; ps[i] = m.cfPos[base + (size_t)i * 64]; }
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            const size_t f = (size_t)(it[i] >= 0 ? it[i] : ~it[i]), pos = (size_t)(ps[i] >= 0 ? ps[i] : ~ps[i]);
-            fl[i] = c.flux[4 * nF + pos]; sg[i] = iv.phiSig[f]; a[i] = iv.aE[f];
+            const size_t pos = (size_t)(ps[i] >= 0 ? ps[i] : ~ps[i]);
+            fl[i] = c.flux[4 * nF + pos]; sg[i] = iv.phiSig[pos]; a[i] = iv.aE[pos];
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -310,7 +314,7 @@ __global__ __launch_bounds__(QGD_BLOCK) void implCellEKernel(const MeshView m, c
             const int it = m.cfItem[base + (size_t)i * 64];
             const int f = it >= 0 ? it : ~it;
             const size_t pos = f < m.nIF ? (size_t)m.fpos[f] : (size_t)f;
-            face(it, f, c.flux[4 * nF + pos], iv.phiSig[f], iv.aE[f]);
+            face(it, f, c.flux[4 * nF + pos], iv.phiSig[pos], iv.aE[pos]);
         }
     }
     const RecA A = c.A[ci];   // rho, U of the new time level
@@ -387,7 +391,7 @@ __device__ __forceinline__ double iBlockSum(double v) {
 
 struct ISolveView {
     int NR, ob, n, nC;                 // right-hand sides, first row, rows, vector stride
-    const double* a;                   // nF
+    const double* a;                   // nF, at the faces' slot-major positions (MeshView::fpos / cfPos)
     const double* diag; const double* rhs; double* x;    // NR * nC each, component-major
     double *r, *d, *q;                 // NR * nC each
     double* part;                      // partial sums: (row * NR + k) * nBlocks + block
@@ -421,7 +425,7 @@ __global__ __launch_bounds__(QGD_BLOCK) void iApplyKernel(const MeshView m, cons
             for (int u = 0; u < U; ++u) {
                 const bool in = e0 + u < cnt;
                 nb[u] = in ? m.cfNbr[base + (size_t)(e0 + u) * 64] : -1;
-                it[u] = in ? m.cfItem[base + (size_t)(e0 + u) * 64] : 0;
+                it[u] = in ? m.cfPos[base + (size_t)(e0 + u) * 64] : 0;      // v.a is stored by position
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
