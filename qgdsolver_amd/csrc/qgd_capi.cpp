@@ -181,6 +181,7 @@ struct Workspace {
     }
 };
 
+static int envChoice(const char* name, int dflt, const int* allowed, int nAllowed, int lo, int hi);
 struct qgd_device_s {
     int deviceId = 0;
     Workspace ws;
@@ -216,6 +217,16 @@ struct qgd_device_s {
     int32_t* sendBFAll = nullptr;   // their real-patch boundary faces
     int32_t nSendAll = 0, nSendBFAll = 0;
     hipStream_t stream = nullptr;
+    // MeshView::geoPos, built the first time a case that takes fvc::grad(U) per cell is created on this device (QGD_GEOPOS=0: never)
+    void ensureFaceGeoPos() {
+        static const int kOnOff[] = {0, 1};
+        if (view.geoPos || view.nF == 0 || !envChoice("QGD_GEOPOS", 1, kOnOff, 2, 0, 0)) return;
+        double4* g = arena.alloc<double4>((size_t)view.nF, false);
+        launchFaceGeoPos(stream, view, g);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(stream));
+        view.geoPos = g;
+    }
 };
 
 struct TimedLaunch {
@@ -1252,6 +1263,7 @@ int qgd_case_create(qgd_device_t d, const qgd_case_options* opt, qgd_case_t* out
         if (opt->implicitDiffusion) {
             ImplView& iv = c->impl;
             const size_t nC = (size_t)v.nC, nF = (size_t)v.nF;
+            d->ensureFaceGeoPos();
             iv.gUc = a.alloc<double>(9 * nC);
             iv.phiTau = a.alloc<double>(3 * nF); iv.UfS = a.alloc<double>(3 * nF);
             iv.sTau = a.alloc<double>(nF); iv.mufS = a.alloc<double>(nF); iv.aU = a.alloc<double>(nF); iv.aE = a.alloc<double>(nF);
@@ -1732,6 +1744,7 @@ int qgd_qhd_case_create(qgd_device_t d, const qgd_qhd_options* opt, qgd_qhd_case
     try {
         c->dev = d; c->opt = *opt; c->stencil = st;
         c->usesPoints = (st == ST_GVP3 || st == ST_GVP2);
+        d->ensureFaceGeoPos();
         const MeshView& v = d->view;
         if (!d->sharded() && opt->pRefCell >= v.nC) { delete c; return fail(QGD_ERR_INVALID, "qgd_qhd_case_create: pRefCell out of range"); }
         DeviceArena& a = c->arena;

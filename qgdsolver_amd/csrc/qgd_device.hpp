@@ -46,6 +46,9 @@ struct MeshView {
     const int32_t* fpos;     // nIF: storage position of an internal face's net fluxes (slot-major, qgd_setup.hpp)
     const int32_t* cfPos;    // cfItem with positions instead of labels: gather list of the cell kernel
     const int32_t* cfNbr;    // cfItem's neighbour cells (-1: boundary face): gather list of the matrix products
+    // {w, Sx, Sy, Sz} of every face at its slot-major POSITION (fpos; patch faces at their label), w = -1 on faces of empty patches:
+    // what fvc::grad(U) per cell gathers (cellGradGauss).  nullptr until a QHD or implicitDiffusion case asks for it (32 B per face).
+    const double4* geoPos;
     // face tiles of the LDS-staged 3-D GaussVolPoint kernel (qgd_setup.hpp FaceTiles); tileOff == nullptr: gather kernel
     const int32_t* tileOff; const int32_t* tileCells; const int32_t* tileVerts;
     const uint32_t* locC; const uint2* locV;
@@ -128,6 +131,7 @@ int cellBlocks(const MeshView& m);
 void launchHaloPack(const Launcher& L, const CaseView& c, const int32_t* cells, int32_t nCells, const int32_t* bfaces,
                     int32_t nFaces, double* buf, bool pack);
 void launchMidHalo(hipStream_t s, const CaseView& c, const int32_t* bfaces, int32_t n, double* buf, bool pack);
+void launchFaceGeoPos(hipStream_t s, const MeshView& m, double4* out);   // fills MeshView::geoPos
 
 // ---- accessor: one named cell / patch field out of the records (K == nullptr on patches) ----------------------------
 enum ExtractField : int { XF_RHO = 0, XF_U, XF_P, XF_E, XF_T, XF_RHOU, XF_RHOE, XF_C, XF_PSI, XF_MU, XF_ALPHAU, XF_TAUQGD, XF_MUQGD,

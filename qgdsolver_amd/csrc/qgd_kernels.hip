@@ -1661,6 +1661,16 @@ __global__ __launch_bounds__(QGD_BLOCK) void speciesCellKernel(const MeshView m,
     if (Su) src += V * Su[c];
     Ynew[c] = fmax(src / (rDeltaT * rho[c] * V), 0.0);
 }
+// MeshView::geoPos: the face geometry fvc::grad(U) per cell needs, at the faces' slot-major positions
+__global__ __launch_bounds__(QGD_BLOCK) void faceGeoPosKernel(const MeshView m, double4* __restrict__ out) {
+    const int f = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    if (f >= m.nF) return;
+    const size_t pos = f < m.nIF ? (size_t)m.fpos[f] : (size_t)f;
+    out[pos] = make_double4(m.fkind[f] == 3 ? -1.0 : m.w[f], m.Sx[f], m.Sy[f], m.Sz[f]);
+}
+void launchFaceGeoPos(hipStream_t s, const MeshView& m, double4* out) {
+    if (m.nF) faceGeoPosKernel<<<gridFor(m.nF), QGD_BLOCK, 0, s>>>(m, out);
+}
 void launchSpeciesStep(hipStream_t s, const MeshView& m, const double* Yc, const double* Yb, const double* rhoOld, const double* rho,
                        const double* phiJmY, const double* muf, double Sc, double dt, const double* Su, double* diffusiveFlux, double* net,
                        double* Ynew) {

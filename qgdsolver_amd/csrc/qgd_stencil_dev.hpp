@@ -387,7 +387,32 @@ __device__ __forceinline__ void cellGradGauss(const MeshView& m, const int ci, c
 #pragma unroll
             for (int j = 0; j < 3; ++j) G[3 * a + j] = it >= 0 ? G[3 * a + j] + S[a] * Uf[j] : G[3 * a + j] - S[a] * Uf[j];
     };
-    if (__ballot(n != 6) == 0) {
+    if (m.geoPos && __ballot(n != 6) == 0) {
+        // the faces' {w, Sf} at their slot-major positions: one contiguous 2-KB run per slot and wavefront (by label, on a hexahedral
+        // box, every third double of twelve lines per array: 0.30 of this kernel's 0.69 ms at 8 M cells)
+        int ps[6], nb[6];
+        double4 ge[6];
+        double Un[6][3];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) { ps[q] = m.cfPos[base + (size_t)q * 64]; nb[q] = m.cfNbr[base + (size_t)q * 64]; }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const int pos = ps[q] >= 0 ? ps[q] : ~ps[q];
+            ge[q] = m.geoPos[pos];
+            const double* __restrict__ src = nb[q] >= 0 ? Ucell + (size_t)nb[q] * CS + CO : Ubnd + (size_t)(pos - m.nIF) * BS + BO;
+            Un[q][0] = src[0]; Un[q][1] = src[1]; Un[q][2] = src[2];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const double w = ge[q].x, S[3] = {ge[q].y, ge[q].z, ge[q].w};
+            double Uf[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                Uf[k] = nb[q] < 0 ? Un[q][k] : (ps[q] >= 0 ? lerpf(w, Uc[k], Un[q][k]) : lerpf(w, Un[q][k], Uc[k]));   // lerp(w, owner, neighbour)
+            add(ps[q], w < 0.0 ? 3 : 0, Uf, S);
+        }
+    } else if (__ballot(n != 6) == 0) {
         int it[6], nb[6], kind[6];
         double w[6], S[6][3], Un[6][3];
 #pragma unroll
