@@ -263,9 +263,6 @@ bool pressureSolverSinglePrecisionCycle(const PressureSolver* S);
 double* pressureSolverCtl(PressureSolver* S);         // control block: slots [0,3) [3] [4] [5] [6,8) [8] are the sums a sharded run reduces
 double* pressureSolverDirection(PressureSolver* S);   // nC doubles by local cell label
 
-int diagLaplacianPcg(hipStream_t stream, const MeshView& m, const double* a, const double* diag, const double* rhs, double* x,
-                     double* work, double tolerance, int maxIter, double residuals[2]);
-
 // ---- QHDFoam pressure equation (qgd_poisson.hip) -------------------------------------
 // all pointers are device memory; work holds 8*nC + nF + max(nBF,1) + 3*ceil(nC/256) + 8 doubles
 int solveQhdPressure(hipStream_t stream, const MeshView& m, const double* gamma, const double* phiu, const double* phiwo,

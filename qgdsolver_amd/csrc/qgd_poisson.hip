@@ -304,61 +304,6 @@ int solveQhdPressure(hipStream_t stream, const MeshView& m, const double* gamma,
 }
 
 
-// Jacobi-preconditioned conjugate gradients on  y_c = diag_c x_c - sum_{internal faces of c} a_f x_nb  (a symmetric positive
-// definite "diagonal + Gauss laplacian" system: the implicit-diffusion solves of QGDUEqn.H L56-68 / QGDEEqn.H L55-61), with
-// the reproducible two-level sums and OpenFOAM's normalised residual.  work: 6*nC + 3*blocks + 8 doubles.  Returns iterations.
-int diagLaplacianPcg(hipStream_t stream, const MeshView& m, const double* a, const double* diag, const double* rhs, double* x,
-                     double* work, double tolerance, int maxIter, double residuals[2]) {
-    const int nC = m.nC, nb = blocksOf(nC);
-    double* r = work;
-    double* z = r + nC;
-    double* d = z + nC;
-    double* q = d + nC;
-    double* A1 = q + nC;
-    double* ones = A1 + nC;
-    double* part = ones + nC;
-    double* scal = part + 3 * (size_t)nb;
-    double h[4];
-    fillKernel<<<nb, PB, 0, stream>>>(nC, 1.0, ones);
-    applyKernel<<<nb, PB, 0, stream>>>(m, a, diag, ones, A1, nullptr);
-    applyKernel<<<nb, PB, 0, stream>>>(m, a, diag, x, q, nullptr);
-    updateKernel<<<nb, PB, 0, stream>>>(nC, 0, 0.0, diag, rhs, x, r, z, d, q, part, nb);
-    foldKernel<<<1, PB, 0, stream>>>(part, nb, 3, scal);
-    PCHECK(hipMemcpyAsync(h, scal, 3 * sizeof(double), hipMemcpyDeviceToHost, stream));
-    PCHECK(hipStreamSynchronize(stream));
-    double rz = h[0];
-    const double sumAbsR = h[1], xbar = h[2] / nC;
-    normFactorKernel<<<nb, PB, 0, stream>>>(nC, xbar, q, A1, rhs, part);
-    foldKernel<<<1, PB, 0, stream>>>(part, nb, 1, scal);
-    PCHECK(hipMemcpyAsync(h, scal, sizeof(double), hipMemcpyDeviceToHost, stream));
-    PCHECK(hipStreamSynchronize(stream));
-    const double normFactor = h[0] + 1e-20;
-    double res = sumAbsR / normFactor;
-    residuals[0] = res;
-    int it = 0;
-    while (it < maxIter && !(res < tolerance)) {
-        applyKernel<<<nb, PB, 0, stream>>>(m, a, diag, d, q, part);
-        foldKernel<<<1, PB, 0, stream>>>(part, nb, 1, scal);
-        PCHECK(hipMemcpyAsync(h, scal, sizeof(double), hipMemcpyDeviceToHost, stream));
-        PCHECK(hipStreamSynchronize(stream));
-        const double dq = h[0];
-        if (!(dq > 0) || !(rz > 0)) break;
-        const double alpha = rz / dq;
-        updateKernel<<<nb, PB, 0, stream>>>(nC, 1, alpha, diag, rhs, x, r, z, d, q, part, nb);
-        foldKernel<<<1, PB, 0, stream>>>(part, nb, 3, scal);
-        PCHECK(hipMemcpyAsync(h, scal, 3 * sizeof(double), hipMemcpyDeviceToHost, stream));
-        PCHECK(hipStreamSynchronize(stream));
-        const double rzNew = h[0];
-        res = h[1] / normFactor;
-        directionKernel<<<nb, PB, 0, stream>>>(nC, rzNew / rz, z, d);
-        rz = rzNew;
-        ++it;
-    }
-    residuals[1] = res;
-    PCHECK(hipGetLastError());
-    return it;
-}
-
 // ---------------------------------------------------------------------------------------------------------------------
 // Algebraic multigrid as the preconditioner of the same conjugate-gradient loop.
 //
