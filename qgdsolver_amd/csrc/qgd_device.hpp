@@ -206,7 +206,7 @@ struct QhdView {
     double *phiu, *phiwo, *phi, *phitr;        // nF
     double *ugu, *bdf;                         // 3*nF SoA: Uf & gradUf, BdFrcf
     double* gUc;                               // 9*nC fvc::grad(U)
-    double* F;                                 // 4*nF SoA: net face terms of the U (3) and T equations
+    double* F;                                 // 4*nF SoA at the faces' slot-major positions (MeshView::fpos): net face terms of the U (3) and T equations
     double rho0, nu, Hi, beta, g[3], dt;
     int32_t tauModel;                          // 0 constTau, 1 HbyUQHD, 2 T0byGr, 3 H2bynuQHD
     double Tau, aQGD, UQHD, T0, Gr;

@@ -114,8 +114,10 @@ template <int ST>
 __global__ __launch_bounds__(QGD_BLOCK) void qhdFace2Kernel(const MeshView m, const QhdView q, const PatchBCDev* __restrict__ bcs) {
     const int f = blockIdx.x * QGD_BLOCK + threadIdx.x;
     if (f >= m.nF) return;
-    const size_t nF = (size_t)m.nF;
-    if (m.fkind[f] == 3) { for (int k = 0; k < 4; ++k) q.F[(size_t)k * nF + f] = 0.0; return; }
+    // the net face terms go to the face's slot-major position (MeshView::fpos), where the cell update finds those of consecutive cells
+    // at consecutive addresses (by label: every third double of the lines it fetches)
+    const size_t nF = (size_t)m.nF, pos = f < m.nIF ? (size_t)m.fpos[f] : (size_t)f;
+    if (m.fkind[f] == 3) { for (int k = 0; k < 4; ++k) q.F[(size_t)k * nF + pos] = 0.0; return; }
     const bool internal = f < m.nIF;
     const int o = m.own[f];
     const double S[3] = {m.Sx[f], m.Sy[f], m.Sz[f]};
@@ -191,9 +193,9 @@ __global__ __launch_bounds__(QGD_BLOCK) void qhdFace2Kernel(const MeshView m, co
         const double lap = q.nu * snU[j] * magS;                                                     // fvc::laplacian(muf/rhof, U), L74
         const double ext = S[0] * gUT[0 * 3 + j] + S[1] * gUT[1 * 3 + j] + S[2] * gUT[2 * 3 + j];    // Sf & lin(T(grad U)), L76
         // the Gauss term of -fvc::grad(p)/rho (uniform rho) rides in the same face flux: S_j p_f / rho
-        q.F[(size_t)j * nF + f] = ((phiUf - lap) - q.nu * ext) + (S[j] * pf) / q.rho0;
+        q.F[(size_t)j * nF + pos] = ((phiUf - lap) - q.nu * ext) + (S[j] * pf) / q.rho0;
     }
-    q.F[3 * nF + f] = (phi * Tf - q.Hi * snT * magS) - q.phitr[f];                                   // QHDTEqn.H L65-66, L85-88
+    q.F[3 * nF + pos] = (phi * Tf - q.Hi * snT * magS) - q.phitr[f];                                   // QHDTEqn.H L65-66, L85-88
 }
 
 // explicit Euler of the U and T equations [QHDUEqn.H L68-84, QHDTEqn.H L83-91]
@@ -206,16 +208,16 @@ __global__ __launch_bounds__(QGD_BLOCK) void qhdCellUpdateKernel(const MeshView 
     const size_t nF = (size_t)m.nF;
     double s[4] = {0, 0, 0, 0};
     if (__ballot(n != 6) == 0) {
-        // a wavefront of hexahedra: the 24 face terms in flight before the ordered sums (ascending face label, as below)
+        // a wavefront of hexahedra: the 24 face terms in flight before the ordered sums (ascending face label, as below; cfPos keeps cfItem's order)
         int it[6];
         double x[6][4];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) it[i] = m.cfItem[base + (size_t)i * 64];
+        for (int i = 0; i < 6; ++i) it[i] = m.cfPos[base + (size_t)i * 64];
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            const size_t f = (size_t)(it[i] >= 0 ? it[i] : ~it[i]);
+            const size_t pos = (size_t)(it[i] >= 0 ? it[i] : ~it[i]);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) x[i][k] = q.F[(size_t)k * nF + f];
+            for (int k = 0; k < 4; ++k) x[i][k] = q.F[(size_t)k * nF + pos];
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -224,10 +226,10 @@ __global__ __launch_bounds__(QGD_BLOCK) void qhdCellUpdateKernel(const MeshView 
             for (int k = 0; k < 4; ++k) s[k] = it[i] >= 0 ? s[k] + x[i][k] : s[k] - x[i][k];
     } else {
         for (int i = 0; i < n; ++i) {
-            const int it = m.cfItem[base + (size_t)i * 64];
-            const size_t f = (size_t)(it >= 0 ? it : ~it);
+            const int it = m.cfPos[base + (size_t)i * 64];
+            const size_t pos = (size_t)(it >= 0 ? it : ~it);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { const double x = q.F[(size_t)k * nF + f]; s[k] = it >= 0 ? s[k] + x : s[k] - x; }
+            for (int k = 0; k < 4; ++k) { const double x = q.F[(size_t)k * nF + pos]; s[k] = it >= 0 ? s[k] + x : s[k] - x; }
         }
     }
     const double rV = 1.0 / m.V[c];
