@@ -206,3 +206,15 @@ class QgdError(RuntimeError):
 def check(code, where):
     if code != QGD_OK:
         raise QgdError(code, where)
+
+
+class NativeHandle:
+    """an opaque library handle and the entry that frees it; free() is idempotent, so a case and its device may both call it"""
+
+    def __init__(self, value, free_fn):
+        self.value, self._free = value, free_fn
+
+    def free(self):
+        if self.value:
+            self._free(self.value)
+            self.value = None

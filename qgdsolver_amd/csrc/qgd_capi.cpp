@@ -42,9 +42,11 @@ struct HipError : std::runtime_error {
 #define HIP_CHECK(expr)                                                                                     \
     do {                                                                                                    \
         hipError_t _e = (expr);                                                                             \
-        if (_e != hipSuccess)                                                                               \
+        if (_e != hipSuccess) {                                                                             \
+            (void)hipGetLastError(); /* reported here, once: a later hipGetLastError() must not see it */   \
             throw HipError(std::string(#expr) + ": " + hipGetErrorString(_e) + " at " + __FILE__ + ":" +   \
                            std::to_string(__LINE__));                                                       \
+        }                                                                                                   \
     } while (0)
 #define QGD_TRY try {
 #define QGD_CATCH                                                                 \
@@ -222,6 +224,7 @@ struct qgd_device_s {
         static const int kOnOff[] = {0, 1};
         if (view.geoPos || view.nF == 0 || !envChoice("QGD_GEOPOS", 1, kOnOff, 2, 0, 0)) return;
         double4* g = arena.alloc<double4>((size_t)view.nF, false);
+        (void)hipGetLastError();   // a stale error of an earlier, refused call must not be taken for this launch's
         launchFaceGeoPos(stream, view, g);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipStreamSynchronize(stream));

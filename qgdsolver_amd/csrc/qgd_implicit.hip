@@ -630,7 +630,7 @@ struct ImplicitSolver {
 #define ICHECK(expr)                                                                                   \
     do {                                                                                               \
         hipError_t e_ = (expr);                                                                        \
-        if (e_ != hipSuccess) throw std::runtime_error(std::string("HIP: ") + hipGetErrorString(e_)); \
+        if (e_ != hipSuccess) { (void)hipGetLastError(); throw std::runtime_error(std::string("HIP: ") + hipGetErrorString(e_)); } \
     } while (0)
 
 ImplicitSolver* implicitSolverCreate(hipStream_t stream, const MeshView& m, int ownedBegin, int ownedEnd) {

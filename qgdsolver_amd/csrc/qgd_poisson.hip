@@ -230,7 +230,7 @@ inline int blocksOf(int64_t n) { return (int)((n + PB - 1) / PB); }
 #define PCHECK(expr)                                                                                   \
     do {                                                                                               \
         hipError_t e_ = (expr);                                                                        \
-        if (e_ != hipSuccess) throw std::runtime_error(std::string("HIP: ") + hipGetErrorString(e_)); \
+        if (e_ != hipSuccess) { (void)hipGetLastError(); throw std::runtime_error(std::string("HIP: ") + hipGetErrorString(e_)); } \
     } while (0)
 
 }  // namespace

@@ -27,6 +27,7 @@ class Device:
         h = C.c_void_p()
         L.check(L.lib.qgd_device_create(mesh._h, device_id, C.byref(h)), "qgd_device_create")
         self._h = h
+        self._case_handles = []   # native handles of the cases created on this device: close() frees them first (see adopt)
         self.fvSchemes = fv_schemes if fv_schemes is not None else {"fvsc": {"default": "GaussVolPoint"}}
         self._registry = {}  # objectRegistry of stencils by name
 
@@ -70,8 +71,19 @@ class Device:
         L.check(L.lib.qgd_device_face_tiles(self._h, a), "qgd_device_face_tiles")
         return dict(facesPerTile=a[0], tiles=a[1], gatherTiles=a[2], ldsBytes=a[3])
 
+    def adopt(self, handle):
+        """A case keeps a pointer to its device inside the library, so it has to be freed BEFORE the device.  A reference from the
+        case to the device orders that under reference counting, but not when both die in one pass of the cycle collector, which
+        runs finalisers in any order and clears weak references first (seen: qgd_case_free reading the freed device, `invalid
+        device ordinal`).  The device therefore holds the cases' native handles (NativeHandle: freed once, by whoever comes first)
+        and frees those still open before it frees itself."""
+        self._case_handles = [h for h in self._case_handles if h.value] + [handle]
+
     def close(self):
         if getattr(self, "_h", None):
+            for h in getattr(self, "_case_handles", ()):
+                h.free()
+            self._case_handles = []
             L.lib.qgd_device_free(self._h)
             self._h = None
 

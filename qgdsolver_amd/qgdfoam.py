@@ -76,7 +76,8 @@ class QGDFoamCase:
         self.options = options if options is not None else default_options()
         h = C.c_void_p()
         L.check(L.lib.qgd_case_create(dev._h, C.byref(self.options), C.byref(h)), "qgd_case_create")
-        self._h = h
+        self._handle = L.NativeHandle(h, L.lib.qgd_case_free)
+        dev.adopt(self._handle)
         self.thermo = QGDThermo(self)
 
     def set_bc(self, patch, U=("zeroGradient", None), T=("zeroGradient", None), p=("zeroGradient", None)):
@@ -257,10 +258,13 @@ class QGDFoamCase:
         L.check(L.lib.qgd_case_device_bytes(self._h, C.byref(n)), "qgd_case_device_bytes")
         return n.value
 
+    @property
+    def _h(self):
+        return self._handle.value
+
     def close(self):
-        if getattr(self, "_h", None):
-            L.lib.qgd_case_free(self._h)
-            self._h = None
+        if getattr(self, "_handle", None):
+            self._handle.free()
 
     def __del__(self):
         try:

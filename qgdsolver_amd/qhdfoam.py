@@ -178,7 +178,8 @@ class QHDFoamCase:
         self.options = options if options is not None else qhd_options()
         h = C.c_void_p()
         L.check(L.lib.qgd_qhd_case_create(dev._h, C.byref(self.options), C.byref(h)), "qgd_qhd_case_create")
-        self._h = h
+        self._handle = L.NativeHandle(h, L.lib.qgd_qhd_case_free)
+        dev.adopt(self._handle)
 
     def set_bc(self, patch, U=("zeroGradient", None), T=("zeroGradient", None), p=("zeroGradient", None)):
         vu = np.asarray(U[1] if U[1] is not None else (0.0, 0.0, 0.0), dtype=np.float64)
@@ -266,10 +267,13 @@ class QHDFoamCase:
         return dict(time=a[0], deltaT=a[1], pIterations=int(a[2]), pInitialResidual=a[3], pFinalResidual=a[4], steps=int(a[5]),
                     mgLevels=int(a[6]), pSolveMs=a[7])
 
+    @property
+    def _h(self):
+        return self._handle.value
+
     def close(self):
-        if getattr(self, "_h", None):
-            L.lib.qgd_qhd_case_free(self._h)
-            self._h = None
+        if getattr(self, "_handle", None):
+            self._handle.free()
 
     def __del__(self):
         try:

@@ -48,3 +48,58 @@ def test_tiny_meshes(dims, ptypes, stencil):
         assert rel_err(gc.field(f), oc.field(f)) <= 1e-11, (dims, stencil, f)
     assert np.all(np.isfinite(gc.field("rho")))
     gc.close(); dev.close()
+
+
+def test_a_refused_hip_call_does_not_poison_the_next_one():
+    """An entry that fails inside HIP reports that error once; the launches of later calls must not find it in hipGetLastError()
+    (seen: `invalid device ordinal` of a refused qgd_device_create surfacing in the next qgd_case_create)."""
+    mesh = q.PolyMesh.box(4, 3, 2)
+    with pytest.raises(q.QgdError):
+        q.Device(mesh, device_id=4096)
+    dev = q.Device(mesh)
+    n = mesh.nCells
+    for impl in (1, 0):
+        case = q.QGDFoamCase(dev, q.default_options(deltaT=1e-3, mu=1e-3, implicitDiffusion=impl))
+        case.set_fields(np.zeros((n, 3)), np.ones(n), np.ones(n))
+        case.step(2)
+        assert np.isfinite(case.field("rho")).all()
+        case.close()
+    from qgdsolver_amd import qhdfoam
+    qc = qhdfoam.QHDFoamCase(dev, qhdfoam.qhd_options(stencil="GaussVolPoint", tauModel="HbyUQHD", aQGD=0.5, UQHD=1.0, rho0=1.0, mu=1e-2, Pr=0.71,
+                                                     beta=3e-3, g=(0.0, -9.81, 0.0), deltaT=1e-3, pTol=1e-10, pMaxIter=200, pRefCell=0, pRefValue=0.0))
+    qc.close(); dev.close()
+
+
+def test_cases_and_their_device_may_die_in_any_order():
+    """A case points at its device inside the library.  Under reference counting the case goes first; the cycle collector
+    finalises in any order (seen: qgd_case_free reading a freed device and leaving `invalid device ordinal` behind for the next
+    launch check).  The device frees the cases still open on it before itself; both close() are idempotent."""
+    import ctypes
+    import gc
+    from qgdsolver_amd import qhdfoam
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipGetLastError()
+    mesh = q.PolyMesh.box(4, 3, 2)
+    opt = q.default_options(deltaT=1e-3, mu=1e-3, implicitDiffusion=1)
+    qopt = qhdfoam.qhd_options(stencil="GaussVolPoint", tauModel="HbyUQHD", aQGD=0.5, UQHD=1.0, rho0=1.0, mu=1e-2, Pr=0.71, beta=3e-3,
+                               g=(0.0, -9.81, 0.0), deltaT=1e-3, pTol=1e-10, pMaxIter=200, pRefCell=0, pRefValue=0.0)
+    dev = q.Device(mesh)
+    case, qcase = q.QGDFoamCase(dev, opt), qhdfoam.QHDFoamCase(dev, qopt)
+    dev.close()                                    # the device first
+    assert case._h is None and qcase._h is None    # ... has freed its cases
+    case.close(); qcase.close()
+    assert hip.hipGetLastError() == 0
+    for _ in range(3):                             # one garbage cycle holding both: the collector picks the order
+        dev = q.Device(mesh)
+        cyc = [dev, q.QGDFoamCase(dev, opt), qhdfoam.QHDFoamCase(dev, qopt)]
+        cyc.append(cyc)
+        del dev, cyc
+        gc.collect()
+        assert hip.hipGetLastError() == 0
+    dev = q.Device(mesh)
+    case = q.QGDFoamCase(dev, opt)
+    n = mesh.nCells
+    case.set_fields(np.zeros((n, 3)), np.ones(n), np.ones(n))
+    case.step(2)
+    assert np.isfinite(case.field("rho")).all()
+    case.close(); dev.close()
