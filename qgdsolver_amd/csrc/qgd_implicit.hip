@@ -165,13 +165,33 @@ __global__ __launch_bounds__(QGD_BLOCK) void implCellUKernel(const MeshView m, c
             if (f < m.nIF) diagBase += ax[i];
         }
     } else {
-        for (int i = 0; i < n; ++i) {
-            const int it = m.cfItem[base + (size_t)i * 64];
-            const int f = it >= 0 ? it : ~it;
-            const size_t pos = f < m.nIF ? (size_t)m.fpos[f] : (size_t)f;
-            for (int k = 0; k < 4; ++k) { const double x = c.flux[(size_t)k * nF + pos]; sum[k] = it >= 0 ? sum[k] + x : sum[k] - x; }
-            for (int k = 0; k < 3; ++k) { const double x = iv.phiTau[(size_t)k * nF + pos]; dTau[k] = it >= 0 ? dTau[k] + x : dTau[k] - x; }
-            if (f < m.nIF) diagBase += iv.aU[pos];
+        // any cell shapes: eight faces per pass (positions, then their 64 values in flight, then the ordered sums); a position below
+        // nIF is an internal face's, patch faces keep their label (MeshView::fpos)
+        for (int i0 = 0; i0 < n; i0 += 8) {
+            int ps[8];
+            double fx[8][4], tx[8][3], ax[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) ps[u] = i0 + u < n ? m.cfPos[base + (size_t)(i0 + u) * 64] : 0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool on = i0 + u < n;
+                const size_t pos = (size_t)(ps[u] >= 0 ? ps[u] : ~ps[u]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) fx[u][k] = on ? c.flux[(size_t)k * nF + pos] : 0.0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) tx[u][k] = on ? iv.phiTau[(size_t)k * nF + pos] : 0.0;
+                ax[u] = on ? iv.aU[pos] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (i0 + u >= n) continue;
+                const int pos = ps[u] >= 0 ? ps[u] : ~ps[u];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sum[k] = ps[u] >= 0 ? sum[k] + fx[u][k] : sum[k] - fx[u][k];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) dTau[k] = ps[u] >= 0 ? dTau[k] + tx[u][k] : dTau[k] - tx[u][k];
+                if (pos < m.nIF) diagBase += ax[u];
+            }
         }
     }
     const RecA A = c.A[ci];
@@ -310,11 +330,23 @@ __global__ __launch_bounds__(QGD_BLOCK) void implCellEKernel(const MeshView m, c
 #pragma unroll
         for (int i = 0; i < 6; ++i) face(it[i], it[i] >= 0 ? it[i] : ~it[i], fl[i], sg[i], a[i]);
     } else {
-        for (int i = 0; i < n; ++i) {
-            const int it = m.cfItem[base + (size_t)i * 64];
-            const int f = it >= 0 ? it : ~it;
-            const size_t pos = f < m.nIF ? (size_t)m.fpos[f] : (size_t)f;
-            face(it, f, c.flux[4 * nF + pos], iv.phiSig[pos], iv.aE[pos]);
+        for (int i0 = 0; i0 < n; i0 += 8) {   // any cell shapes: eight faces per pass, as in implCellUKernel
+            int ps[8];
+            double fl[8], sg[8], a[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) ps[u] = i0 + u < n ? m.cfPos[base + (size_t)(i0 + u) * 64] : 0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool on = i0 + u < n;
+                const size_t pos = (size_t)(ps[u] >= 0 ? ps[u] : ~ps[u]);
+                fl[u] = on ? c.flux[4 * nF + pos] : 0.0; sg[u] = on ? iv.phiSig[pos] : 0.0; a[u] = on ? iv.aE[pos] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (i0 + u >= n) continue;
+                const int pos = ps[u] >= 0 ? ps[u] : ~ps[u];   // = the label for a patch face, < nIF for an internal one: all face() asks
+                face(ps[u], pos, fl[u], sg[u], a[u]);
+            }
         }
     }
     const RecA A = c.A[ci];   // rho, U of the new time level

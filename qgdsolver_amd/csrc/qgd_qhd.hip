@@ -225,11 +225,25 @@ __global__ __launch_bounds__(QGD_BLOCK) void qhdCellUpdateKernel(const MeshView 
 #pragma unroll
             for (int k = 0; k < 4; ++k) s[k] = it[i] >= 0 ? s[k] + x[i][k] : s[k] - x[i][k];
     } else {
-        for (int i = 0; i < n; ++i) {
-            const int it = m.cfPos[base + (size_t)i * 64];
-            const size_t pos = (size_t)(it >= 0 ? it : ~it);
+        // any cell shapes: eight faces per pass, positions first, then the 32 terms in flight before the ordered sums
+        for (int i0 = 0; i0 < n; i0 += 8) {
+            int it[8];
+            double x[8][4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { const double x = q.F[(size_t)k * nF + pos]; s[k] = it >= 0 ? s[k] + x : s[k] - x; }
+            for (int u = 0; u < 8; ++u) it[u] = i0 + u < n ? m.cfPos[base + (size_t)(i0 + u) * 64] : 0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool on = i0 + u < n;
+                const size_t pos = (size_t)(it[u] >= 0 ? it[u] : ~it[u]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) x[u][k] = on ? q.F[(size_t)k * nF + pos] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (i0 + u >= n) continue;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s[k] = it[u] >= 0 ? s[k] + x[u][k] : s[k] - x[u][k];
+            }
         }
     }
     const double rV = 1.0 / m.V[c];
