@@ -50,9 +50,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--edge", dest="n", type=int, default=int(os.environ.get("QGD_BENCH_N", "400")), help="box edge in cells (n^3 cells in total)")
-    ap.add_argument("--workload", default="qgd", choices=["qgd", "qhd"],
+    ap.add_argument("--workload", default="qgd", choices=["qgd", "qhd", "implicit"],
                     help="qgd: the headline (QGDFoam explicit step, BASELINE.json configs 3/4); qhd: the QHDFoam step of config 5 "
-                         "(semi-implicit: flux assembly + pressure equation), one GPU, its own metric line")
+                         "(semi-implicit: flux assembly + pressure equation), its own metric line; implicit: the QGDFoam step with "
+                         "implicitDiffusion true (the reference's default branch), one GPU, its own metric line")
     ap.add_argument("--irregular", action="store_true", help="qhd: the config-5 stand-in mesh (jittered vertices, every 7th quad split into "
                                                              "triangles, labels shuffled in chunks then Morton-ordered) instead of a uniform box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -423,6 +424,63 @@ def qhd_line(args):
     print(json.dumps(out), flush=True)
 
 
+# the implicitDiffusion branch: bytes one Jacobi-PCG iteration of the three-component U system moves per cell in the build's layout
+# (hexahedra: 6 list entries x 8 B + 3 face coefficients x 8 B (each face serves two cells) + diag, direction, product 3 x 8 B each
+# = 144 B for the matrix product; x, r, d, q, diag read and x, r written = 168 B for the update; r, diag, d read and d written =
+# 96 B for the direction), and a third of the vector part for the one-component e system
+IMPL_APPLY_BYTES_PER_CELL = 144
+IMPL_ITER_BYTES_PER_CELL_U = 144 + 168 + 96
+IMPL_ITER_BYTES_PER_CELL_E = 48 + 24 + 24 + 56 + 32
+
+
+def implicit_line(args):
+    """python bench.py --workload implicit [--edge N]: Mcell-steps/s of the QGDFoam step with implicitDiffusion true, the reference's
+    default branch [QGDThermo.C L70-82]: the explicit flux assembly without the viscous parts + the U and e systems by Jacobi-PCG."""
+    import qgdsolver_amd as q
+    import cases
+
+    if q.device_count() < 1:
+        raise RuntimeError("bench.py needs a HIP device: qgdsolver_amd has no CPU fallback")
+    n = args.n
+    t_setup = time.perf_counter()
+    mesh = q.PolyMesh.box(n, n, n)
+    dev = q.Device(mesh)
+    opt = q.default_options(stencil="GaussVolPoint", deltaT=0.1 / n / 1.3, implicitDiffusion=1, mu=1e-3)
+    case = q.QGDFoamCase(dev, opt)
+    U, T, p = cases.box_initial_fields(mesh.array("C").reshape(-1, 3))
+    case.set_fields(U, T, p)
+    del U, T, p
+    nc = mesh.nCells
+    t_setup = time.perf_counter() - t_setup
+    case.step(max(args.warmup, 1))
+    t0 = time.perf_counter()
+    case.step(args.steps)          # returns after the device has finished
+    elapsed = time.perf_counter() - t0
+    info, solves = case.info(), case.implicit_info()
+    ap = case.implicit_apply_time(30)
+    apply_bytes = IMPL_APPLY_BYTES_PER_CELL * ap["rows"]
+    achieved = apply_bytes / (ap["ms"] * 1e-3) / 1e9 if ap["ms"] else None
+    it_u = max(solves["solves"][k]["iterations"] for k in ("Ux", "Uy", "Uz"))
+    it_e = solves["solves"]["e"]["iterations"]
+    out = {
+        "metric": "Mcell-steps/s (QGDFoam step, implicitDiffusion true)", "value": nc * args.steps / elapsed / 1e6, "unit": "Mcell-steps/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": (f"QGDFoam {n}^3 = {nc / 1e6:.1f}M-cell uniform hex box (blockMesh numbering), GaussVolPoint, constScPrModel1, "
+                                "implicitDiffusion true (the reference's default), mu = 1e-3, zeroGradient patches, fixed deltaT, "
+                                "U and e systems by Jacobi-PCG to 1e-10"),
+                   "cells": nc, "iterations_U": it_u, "iterations_e": it_e, "unconverged_steps": solves["unconverged_steps"]},
+        "roofline": {"bound": "hbm", "kernel": "iApplyKernel<3,1> (matrix product of the three-component U system, one walk of the matrix for the three right-hand sides)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS if achieved else None,
+                     "traffic": None, "algorithmic_bytes_per_launch": apply_bytes, "avg_launch_ms": ap["ms"]},
+        "solver_bytes_model": {"per_cell_per_iteration_U": IMPL_ITER_BYTES_PER_CELL_U, "per_cell_per_iteration_e": IMPL_ITER_BYTES_PER_CELL_E,
+                               "bytes_per_step_in_the_solves": nc * (IMPL_ITER_BYTES_PER_CELL_U * it_u + IMPL_ITER_BYTES_PER_CELL_E * it_e)},
+        "min_rho": info["minRho"], "setup_s": t_setup,
+    }
+    case.close(); dev.close()
+    print(json.dumps(out), flush=True)
+
+
 def qhd_line_sharded(args):
     """python bench.py --workload qhd --gpus N [--irregular]: the QHDFoam step on N cell-range shards, one rank per GPU -- config 5 as
     configured.  Transport: the library's own RCCL path (qgd_qhd_case_step_sharded: halo messages, all-reduced PCG scalars, the comm
@@ -539,6 +597,14 @@ def qhd_line_sharded(args):
 
 def main():
     args = parse()
+    if args.workload == "implicit":
+        if "QGD_BENCH_N" not in os.environ and "--edge" not in " ".join(sys.argv):
+            args.n = 200
+        if args.gpus > 1:
+            print("bench.py: --workload implicit is a one-GPU line (the branch shards: tests/test_implicit_sharded.py)", file=sys.stderr)
+            sys.exit(2)
+        implicit_line(args)
+        return
     if args.workload == "qhd":
         if "QGD_BENCH_N" not in os.environ and "--edge" not in " ".join(sys.argv):
             args.n = 252 if args.irregular else 200

@@ -522,6 +522,10 @@ int qgd_case_info(qgd_case_t c, double info[6]);
  * since qgd_case_set_fields in which a solve stopped above implicitTol (iteration limit or breakdown: the step keeps the last
  * iterate, as OpenFOAM does, and counts here); [13] = 1 when the case runs the implicit branch. */
 int qgd_case_implicit_info(qgd_case_t c, double info[14]);
+/* measurement: `reps` matrix products of the three-component U system (QGDUEqn_8H_source.html L54-68: the `fvm::laplacian(muf,U)`
+ * matrix applied to a search direction; the kernel the branch spends most of its time in) between two HIP events, on the vectors
+ * the last step left; info = {average ms per product, rows} */
+int qgd_case_implicit_apply_time(qgd_case_t c, int reps, double info[2]);
 
 /* ---- the implicitDiffusion branch on a cell-range shard -------------------------------------------------------------------------
  * implicitDiffusion true is the reference's default [QGDThermo_8C_source.html L70-82].  Its two implicit equations

@@ -118,6 +118,7 @@ SIGNATURES = {
     "qgd_qhd_case_control": (C.c_int, [handle, c_double_p, C.c_int]),
     "qgd_qhd_case_sync": (C.c_int, [handle]),
     "qgd_qhd_case_sweep_time": (C.c_int, [handle, C.c_int, c_double_p]),
+    "qgd_case_implicit_apply_time": (C.c_int, [handle, C.c_int, c_double_p]),
     "qgd_qhd_case_halo_count": (C.c_int, [handle, C.c_int, C.c_int, c_int64_p, c_int64_p]),
     "qgd_qhd_case_halo_pack": (C.c_int, [handle, C.c_int, C.c_int, C.c_void_p]),
     "qgd_qhd_case_halo_unpack": (C.c_int, [handle, C.c_int, C.c_int, C.c_void_p]),

@@ -2563,6 +2563,20 @@ int qgd_case_implicit_info(qgd_case_t c, double info[14]) {
     return QGD_OK;
     QGD_CATCH
 }
+int qgd_case_implicit_apply_time(qgd_case_t c, int reps, double info[2]) {
+    QGD_TRY
+    if (!c || !info || reps <= 0) return fail(QGD_ERR_INVALID, "bad argument");
+    if (!c->implSolver || !c->fieldsSet) return fail(QGD_ERR_INVALID, "qgd_case_implicit_apply_time: an implicitDiffusion case after qgd_case_set_fields");
+    HIP_CHECK(hipSetDevice(c->dev->deviceId));
+    implicitSolverSetStream(c->implSolver, c->stream());
+    HIP_CHECK(hipStreamSynchronize(c->stream()));
+    (void)hipGetLastError();
+    int rows = 0;
+    info[0] = implicitApplyMs(c->implSolver, c->impl, reps, &rows);
+    info[1] = rows;
+    return QGD_OK;
+    QGD_CATCH
+}
 // the branch's own halo messages and control block on a shard (kinds 1 grad U, 2 U, 3 search direction; the state message is
 // qgd_case_halo_*): counts in doubles
 int qgd_case_implicit_halo_count(qgd_case_t c, int slot, int kind, int64_t* sendCount, int64_t* recvCount) {

@@ -188,6 +188,7 @@ void implicitSolvePhase(ImplicitSolver* S, int phase);
 void implicitSolveRun(ImplicitSolver* S, const SolveHooks* hooks);
 void implicitSolveStatus(ImplicitSolver* S, double* allDone, int iters[3], double res0[3], double res[3]);
 void implicitSolveEnd(ImplicitSolver* S, int which);             // which = 0: the U solve, 1: the e solve
+double implicitApplyMs(ImplicitSolver* S, const ImplView& iv, int reps, int* rows);   // measurement: average ms of the U system's matrix product
 void implicitStepMark(ImplicitSolver* S, bool begin);
 void implicitStatsReset(ImplicitSolver* S);
 void implicitSolverInfo(ImplicitSolver* S, int iters[4], double res0[4], double res[4], double* unconvergedSteps);

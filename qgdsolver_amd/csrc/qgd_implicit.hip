@@ -815,6 +815,27 @@ void launchImplicitHalo(hipStream_t s, const MeshView& m, const CaseView& c, con
     ICHECK(hipGetLastError());
 }
 void implicitSolverSetStream(ImplicitSolver* S, hipStream_t s) { S->stream = s; }
+// measurement: `reps` matrix products q = A d of the three-component U system (iApplyKernel<3, 1>, the kernel the branch spends most
+// of its time in) on the vectors the last step left, between two HIP events; returns the average ms.  The control block is cleared
+// first (a finished solve makes every launch return at once); it is only kept for implicitSolverInfo, which reads its own copy.
+double implicitApplyMs(ImplicitSolver* S, const ImplView& iv, int reps, int* rows) {
+    implicitSolveSetup(S, 3, 7, iv.aU, iv.diagU, iv.rhsU, iv.xU, S->tol, S->maxIter);
+    const ISolveView& v = S->v;
+    *rows = v.n;
+    hipEvent_t a, b;
+    ICHECK(hipEventCreate(&a)); ICHECK(hipEventCreate(&b));
+    ICHECK(hipMemsetAsync(S->ctl, 0, sizeof(double) * I_COUNT, S->stream));
+    iApplyKernel<3, 1><<<v.nBlocks, QGD_BLOCK, 0, S->stream>>>(S->m, v);
+    ICHECK(hipEventRecord(a, S->stream));
+    for (int i = 0; i < reps; ++i) iApplyKernel<3, 1><<<v.nBlocks, QGD_BLOCK, 0, S->stream>>>(S->m, v);
+    ICHECK(hipEventRecord(b, S->stream));
+    ICHECK(hipGetLastError());
+    ICHECK(hipEventSynchronize(b));
+    float ms = 0;
+    ICHECK(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    return (double)ms / reps;
+}
 
 // ---- the advance as phases (stream-ordered; a sharded caller exchanges between them, see include/qgd_amd.h) ---------------
 //   A  fvc::grad(U) of the state before the step                                   -> ghost gradients

@@ -168,6 +168,12 @@ class QGDFoamCase:
         return dict(implicit=bool(a[13]), unconverged_steps=int(a[12]),
                     solves={n: dict(iterations=int(a[k]), initial=a[4 + k], final=a[8 + k]) for k, n in enumerate(names)})
 
+    def implicit_apply_time(self, reps=20):
+        """measurement: average ms of the U system's matrix product (iApplyKernel<3,1>) over `reps` launches, and its rows"""
+        a = (C.c_double * 2)()
+        L.check(L.lib.qgd_case_implicit_apply_time(self._h, int(reps), a), "qgd_case_implicit_apply_time")
+        return dict(ms=a[0], rows=int(a[1]))
+
     # ---- the implicitDiffusion branch on shards (phases 20..35 of qgd_case_step_phase; halo.ImplicitStepper drives them) ----
     def implicit_control(self):
         """host copy of the 68-double control block of the solve in flight (slot-major: [slot * 4 + component])"""
