@@ -12,6 +12,7 @@ pytestmark = pytest.mark.gpu
 G, E = L.PATCH_GENERIC, L.PATCH_EMPTY
 
 
+@pytest.mark.parametrize("implicit", [0, 1])
 @pytest.mark.parametrize("dims,ptypes,stencil", [
     ((1, 1, 1), None, "GaussVolPoint"),
     ((1, 1, 1), None, "reduced"),
@@ -20,7 +21,7 @@ G, E = L.PATCH_GENERIC, L.PATCH_EMPTY
     ((2, 2, 1), [G, G, G, G, E, E], "leastSquares"),
     ((2, 2, 1), [G, G, G, G, E, E], "GaussVolPoint"),
 ])
-def test_tiny_meshes(dims, ptypes, stencil):
+def test_tiny_meshes(dims, ptypes, stencil, implicit):
     mesh = q.PolyMesh.box(*dims, patch_types=ptypes)
     assert mesh.nInternalFaces == (dims[0] - 1) * dims[1] * dims[2] + dims[0] * (dims[1] - 1) * dims[2] + dims[0] * dims[1] * (dims[2] - 1)
     n = mesh.nCells
@@ -32,7 +33,7 @@ def test_tiny_meshes(dims, ptypes, stencil):
                 U[:, d] = 0.0
     T = 1.0 + 0.05 * rng.standard_normal(n)
     p = 1.0 + 0.05 * rng.standard_normal(n)
-    opt = q.default_options(stencil=stencil, deltaT=1e-3, mu=1e-3)
+    opt = q.default_options(stencil=stencil, deltaT=1e-3, mu=1e-3, implicitDiffusion=implicit, implicitTol=1e-14, implicitMaxIter=200)
     dev = q.Device(mesh)
     gc = q.QGDFoamCase(dev, opt)
     oc = OracleCase(oracle_mesh_of(mesh), opt)
@@ -45,8 +46,39 @@ def test_tiny_meshes(dims, ptypes, stencil):
         assert rel_err(gc.field(f), oc.field(f)) <= 1e-11, (dims, stencil, f)
     gc.step(10); oc.step(10)
     for f in ("rho", "U", "p", "e"):
-        assert rel_err(gc.field(f), oc.field(f)) <= 1e-11, (dims, stencil, f)
+        assert rel_err(gc.field(f), oc.field(f)) <= 1e-11, (dims, stencil, implicit, f)
     assert np.all(np.isfinite(gc.field("rho")))
+    gc.close(); dev.close()
+
+
+@pytest.mark.parametrize("dims,ptypes", [((1, 1, 1), None), ((2, 1, 1), None), ((3, 2, 1), [G, G, G, G, E, E]), ((2, 2, 2), None)])
+def test_tiny_meshes_qhd(dims, ptypes):
+    """QHDFoam's step where the pressure equation has one to eight rows (multigrid has nothing to coarsen: Jacobi-PCG or one level)"""
+    from qgdsolver_amd import qhdfoam
+    from oracle import OracleQhdCase
+    mesh = q.PolyMesh.box(*dims, patch_types=ptypes)
+    n = mesh.nCells
+    rng = np.random.default_rng(2)
+    U = 1e-2 * rng.standard_normal((n, 3))
+    if ptypes:
+        U[:, 2] = 0.0
+    T = 300.0 + rng.standard_normal(n)
+    opt = qhdfoam.qhd_options(stencil="GaussVolPoint", tauModel="HbyUQHD", aQGD=0.5, UQHD=1.0, rho0=1.0, mu=1e-2, Pr=0.71, beta=3e-3,
+                              g=(0.0, -9.81, 0.0), deltaT=1e-3, pTol=1e-13, pMaxIter=500, pRefCell=0, pRefValue=0.0, precond=1)
+    dev = q.Device(mesh)
+    gc, oc = qhdfoam.QHDFoamCase(dev, opt), OracleQhdCase(oracle_mesh_of(mesh), opt)
+    types = mesh.array("patchType")
+    for c in (gc, oc):
+        for ip in range(mesh.nPatches):
+            if types[ip] == E:
+                c.set_bc(ip, U=("none", None), T=("none", None), p=("none", None))
+            else:
+                c.set_bc(ip, U=("fixedValue", (0.0, 0.0, 0.0)), T=("fixedValue", 301.0) if ip == 0 else ("zeroGradient", None), p=("qhdFluxCoupled", None))
+        c.set_fields(U, T, np.zeros(n))
+    gc.step(8); oc.step(8)
+    for f in ("U", "T", "p", "phi"):
+        ref = oc.field(f)
+        assert np.abs(gc.field(f) - ref).max() <= 1e-9 * max(np.abs(ref).max(), 1e-30), (dims, f)
     gc.close(); dev.close()
 
 
