@@ -325,18 +325,18 @@ def self_launch(n_ranks):
 # cell; face geometry counted as SURVEY.md 8(d) counts it for the QGD kernel: 80 B of Gauss coefficients per face), by pass:
 #   vertex values of {U,T}: gather list 8 x (4 + 8) + 4, 32 read, 32 written                                   = 164
 #   face pass 1 [updateFields.H L36-73, updateFluxes.H L33-38]: per face 8 + 24 + 8 + 16 + 80 + tau 8 in, phiu, phiwo,
-#       phiTauTReg, Uf & gradUf (3), BdFrcf (3) out = 72; cell and vertex records 32 + 32                      = 3 x 216 + 64 = 712
+#       phiTauTReg, Uf & gradUf (3) out = 48 (BdFrcf is formed again in pass 2); cell and vertex records 32 + 32 = 3 x 192 + 64 = 640
 #   fvc::grad(U): 6 face labels 24, 3 x Sf 24, V 8, U 24, 72 written                                            = 200
 #   vertex values of p: 100 + 8 + 8                                                                             = 116
-#   face pass 2 [QHDUEqn.H L36-84, QHDTEqn.H L65-91]: per face 136 + tau, phi, phiTauTReg 24 + ugu, bdf 48 in, 32 out;
-#       per cell {U,T} 32 + p 8 + grad(U) 72, per vertex p 8                                                    = 3 x 240 + 120 = 840
+#   face pass 2 [QHDUEqn.H L36-84, QHDTEqn.H L65-91]: per face 136 + tau, phi, phiTauTReg 24 + ugu 24 in, 32 out;
+#       per cell {U,T} 32 + p 8 + grad(U) 72, per vertex p 8                                                    = 3 x 216 + 120 = 768
 #   cell update: 24 + 3 x 32 + V 8 + 32 read + 32 written                                                       = 192
 # and per iteration of the pressure solve [QHDpEqn.H L35-47] (multigrid-preconditioned CG; single-precision cycle):
 #   level 0 of the V-cycle: 4 full sweeps x (6 x (4 + 4) + 16) = 256, the first sweep from zero 12, the smoothed prolongator and its
 #   transpose (4.3 entries per fine row each, x 8, + 8 and 4 for the vectors) 82;  level 1 (1/8 of the rows, 34.5 entries per row):
 #   4 x (34.5 x 8 + 16) / 8 = 146;  the levels below ~10                                                       = 506
 #   CG: A d 6 x 12 + 24 = 96, x and r updates 40, two dot products 32, new direction 24, precision conversions 24 = 216
-QHD_EXPLICIT_BYTES_PER_CELL = 164 + 712 + 200 + 116 + 840 + 192
+QHD_EXPLICIT_BYTES_PER_CELL = 164 + 640 + 200 + 116 + 768 + 192
 QHD_BYTES_PER_CELL_PER_ITERATION = 506 + 216
 
 

@@ -1757,7 +1757,7 @@ int qgd_qhd_case_create(qgd_device_t d, const qgd_qhd_options* opt, qgd_qhd_case
         q.p = a.alloc<double>(nC); q.pb = a.alloc<double>(nB); q.pgb = a.alloc<double>(nB); q.ptp = a.alloc<double>(nP);
         c->tauF = a.alloc<double>(nF); c->tbr = a.alloc<double>(nF); q.tauF = c->tauF;
         q.phiu = a.alloc<double>(nF); q.phiwo = a.alloc<double>(nF); q.phi = a.alloc<double>(nF); q.phitr = a.alloc<double>(nF);
-        q.ugu = a.alloc<double>(3 * nF); q.bdf = a.alloc<double>(3 * nF); q.gUc = a.alloc<double>(9 * nC); q.F = a.alloc<double>(4 * nF);
+        q.ugu = a.alloc<double>(3 * nF); q.gUc = a.alloc<double>(9 * nC); q.F = a.alloc<double>(4 * nF);
         c->scratch = a.alloc<double>(8);
         q.rho0 = opt->rho0; q.nu = opt->mu / opt->rho0; q.Hi = (opt->mu / opt->Pr) / opt->rho0; q.beta = opt->beta;
         for (int k = 0; k < 3; ++k) q.g[k] = opt->g[k];

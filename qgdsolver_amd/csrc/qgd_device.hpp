@@ -205,7 +205,7 @@ struct QhdView {
     double* p;   double* pb;  double* pgb;  double* ptp;   // p: cells, patch values, patch gradients, vertices
     const double* tauF;                        // nF tauQGDf
     double *phiu, *phiwo, *phi, *phitr;        // nF
-    double *ugu, *bdf;                         // 3*nF SoA: Uf & gradUf, BdFrcf
+    double* ugu;                               // 3*nF SoA: Uf & gradUf (BdFrcf is formed again in face pass 2)
     double* gUc;                               // 9*nC fvc::grad(U)
     double* F;                                 // 4*nF SoA at the faces' slot-major positions (MeshView::fpos): net face terms of the U (3) and T equations
     double rho0, nu, Hi, beta, g[3], dt;

@@ -74,8 +74,7 @@ __global__ __launch_bounds__(QGD_BLOCK) void qhdFace1Kernel(const MeshView m, co
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const double UgU = Uf[0] * g[0 * 4 + j] + Uf[1] * g[1 * 4 + j] + Uf[2] * g[2 * 4 + j];   // Uf & gradUf
-        q.ugu[(size_t)j * nF + f] = UgU;
-        q.bdf[(size_t)j * nF + f] = Bf[j];
+        q.ugu[(size_t)j * nF + f] = UgU;   // (BdFrcf is not stored: face pass 2 holds T of both cells and forms it again from the same expression)
         wo[j] = tau * (UgU - Bf[j]);
     }
     q.phiu[f] = phiu;
@@ -183,7 +182,8 @@ __global__ __launch_bounds__(QGD_BLOCK) void qhdFace2Kernel(const MeshView m, co
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         Uf[k] = internal ? lerpf(w, Uo[k], Un[k]) : Un[k];
-        Wf[k] = tau * ((q.ugu[(size_t)k * nF + f] + gP[k] / q.rho0) - q.bdf[(size_t)k * nF + f]);   // L37
+        const double Bf = internal ? lerpf(w, (q.beta * To) * q.g[k], (q.beta * Tn) * q.g[k]) : (q.beta * Tn) * q.g[k];   // BdFrcf [updateFields.H L66-67], as in face pass 1
+        Wf[k] = tau * ((q.ugu[(size_t)k * nF + f] + gP[k] / q.rho0) - Bf);   // L37
     }
     const double Tf = internal ? lerpf(w, To, Tn) : Tn;
 #pragma unroll
