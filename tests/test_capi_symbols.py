@@ -84,3 +84,14 @@ def test_header_is_plain_c_and_links(tmp_path):
     assert r.returncode == 0, r.stderr
     r = subprocess.run([str(exe)], capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout.split()[-2:] == ["12", "2"], (r.returncode, r.stdout, r.stderr)
+
+
+def test_native_handle_is_freed_once_by_whoever_comes_first():
+    """fvsc.Device holds the handles of the cases created on it and frees those still open before itself (a case freed after its
+    device would read freed memory); the case's own close() then finds nothing left to do."""
+    from qgdsolver_amd._lib import NativeHandle
+    freed = []
+    h = NativeHandle(1234, freed.append)
+    assert h.value == 1234
+    h.free(); h.free()
+    assert freed == [1234] and h.value is None
