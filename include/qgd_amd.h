@@ -211,8 +211,8 @@ int qgd_mesh_get(qgd_mesh_t m, const char* name, void* out, int64_t outBytes);
 int qgd_device_create(qgd_mesh_t m, int deviceId, qgd_device_t* out);
 /* Ownership (fvscStencil_8C_source.html L57, L104-117: the reference's stencils live in the mesh's registry and die with it):
  * every case (qgd_case_t, qgd_qhd_case_t) keeps a pointer to the device it was created on and uses its stream until it is
- * freed, so free the cases BEFORE their device; a case freed after its device reads freed memory.  The Python mirror enforces
- * the order (fvsc.Device.close frees the cases still open on it first). */
+ * freed, so free the cases BEFORE their device: qgd_device_free returns QGD_ERR_INVALID (and frees nothing) while cases created on
+ * the device are still open.  The Python mirror enforces the order (fvsc.Device.close frees the cases still open on it first). */
 int qgd_device_free(qgd_device_t d);
 
 /* Run-time selection by word, like fvscStencil::New: "reduced",

@@ -219,6 +219,7 @@ struct qgd_device_s {
     int32_t* sendBFAll = nullptr;   // their real-patch boundary faces
     int32_t nSendAll = 0, nSendBFAll = 0;
     hipStream_t stream = nullptr;
+    int liveCases = 0;   // qgd_case_t / qgd_qhd_case_t created on this device and not freed yet (qgd_device_free refuses while > 0)
     // MeshView::geoPos, built the first time a case that takes fvc::grad(U) per cell is created on this device (QGD_GEOPOS=0: never)
     void ensureFaceGeoPos() {
         static const int kOnOff[] = {0, 1};
@@ -687,6 +688,9 @@ int qgd_device_create(qgd_mesh_t mh, int deviceId, qgd_device_t* out) {
 }
 int qgd_device_free(qgd_device_t d) {
     if (!d) return QGD_OK;
+    // a case keeps a pointer to its device and runs on its stream: freed after the device it would read freed memory
+    if (d->liveCases > 0)
+        return fail(QGD_ERR_INVALID, "qgd_device_free: " + std::to_string(d->liveCases) + " case(s) created on this device are still open; free them first");
     (void)hipSetDevice(d->deviceId);
     d->ws.release();
     for (hipEvent_t e : d->opEv) if (e) (void)hipEventDestroy(e);
@@ -1288,6 +1292,7 @@ int qgd_case_create(qgd_device_t d, const qgd_case_options* opt, qgd_case_t* out
         const double dt0[8] = {opt->deltaT, 0, 0, 0, 0, 0, 0, 0};
         HIP_CHECK(hipMemcpy(cv.dt, dt0, sizeof(dt0), hipMemcpyHostToDevice));
     } catch (...) { c->arena.release(); delete c; throw; }
+    d->liveCases++;
     *out = c;
     return QGD_OK;
     QGD_CATCH
@@ -1302,6 +1307,7 @@ int qgd_case_free(qgd_case_t c) {
     if (c->evLayerDone) (void)hipEventDestroy(c->evLayerDone);
     if (c->evUnpacked) (void)hipEventDestroy(c->evUnpacked);
     c->arena.release();
+    c->dev->liveCases--;
     delete c;
     return QGD_OK;
 }
@@ -1774,6 +1780,7 @@ int qgd_qhd_case_create(qgd_device_t d, const qgd_qhd_options* opt, qgd_qhd_case
         c->bcDev = a.alloc<PatchBCDev>(std::max<size_t>(1, c->bc.size()));
         c->bKind = a.alloc<uint8_t>(nB);
     } catch (...) { c->arena.release(); delete c; throw; }
+    d->liveCases++;
     *out = c;
     return QGD_OK;
     QGD_CATCH
@@ -1783,6 +1790,7 @@ int qgd_qhd_case_free(qgd_qhd_case_t c) {
     (void)hipSetDevice(c->dev->deviceId);
     if (c->solver) pressureSolverFree(c->solver);
     c->arena.release();
+    c->dev->liveCases--;
     delete c;
     return QGD_OK;
 }

@@ -135,3 +135,20 @@ def test_cases_and_their_device_may_die_in_any_order():
     case.step(2)
     assert np.isfinite(case.field("rho")).all()
     case.close(); dev.close()
+
+
+def test_device_free_is_refused_while_its_cases_are_open():
+    """the C-ABI's own guard (a C host has no Python mirror ordering its frees): qgd_device_free returns QGD_ERR_INVALID and frees
+    nothing while a case created on the device is open"""
+    mesh = q.PolyMesh.box(3, 2, 2)
+    dev = q.Device(mesh)
+    case = q.QGDFoamCase(dev, q.default_options(deltaT=1e-3))
+    rc = L.lib.qgd_device_free(dev._h)
+    assert rc != L.QGD_OK and b"still open" in L.lib.qgd_last_error()
+    n = mesh.nCells
+    case.set_fields(np.zeros((n, 3)), np.ones(n), np.ones(n))
+    case.step(1)                      # device and case are untouched
+    assert np.isfinite(case.field("rho")).all()
+    case.close()
+    assert L.lib.qgd_device_free(dev._h) == L.QGD_OK
+    dev._h = None
