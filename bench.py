@@ -413,7 +413,8 @@ def qhd_line(args):
                    "cells": nc, "pressure_iterations_per_step": it, "multigrid_levels": info["mgLevels"]},
         "roofline": {"bound": "hbm", "kernel": "mgSmoothKernel<float>, multigrid level 0 (one damped-Jacobi sweep of the pressure preconditioner)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS if achieved else None,
-                     "traffic": None, "algorithmic_bytes_per_launch": sweep_bytes, "avg_launch_ms": sw["ms"]},
+                     "traffic": secondary_traffic("qhd_n200") if (n == 200 and not args.irregular) else None, "traffic_is_static": True,
+                     "traffic_source": SECONDARY_TRAFFIC_SOURCE, "algorithmic_bytes_per_launch": sweep_bytes, "avg_launch_ms": sw["ms"]},
         "step_bytes_model": {"explicit_bytes_per_cell": QHD_EXPLICIT_BYTES_PER_CELL, "bytes_per_cell_per_pressure_iteration": QHD_BYTES_PER_CELL_PER_ITERATION,
                              "bytes_per_step": step_bytes},
         "step_roofline_frac": step_bytes * args.steps / elapsed / (HBM_PEAK_GBS * 1e9),
@@ -431,6 +432,22 @@ def qhd_line(args):
 IMPL_APPLY_BYTES_PER_CELL = 144
 IMPL_ITER_BYTES_PER_CELL_U = 144 + 168 + 96
 IMPL_ITER_BYTES_PER_CELL_E = 48 + 24 + 24 + 56 + 32
+
+
+def secondary_traffic(key):
+    """HBM-side bytes per launch of the kernel in a secondary line's `roofline` object: a constant from profiles/r03_pmc_secondary.json
+    (TCC EA request counters of the builder's profiling run of this workload at 200^3, scripts/collect_secondary_pmc.sh), not counters
+    of THIS run; None when the file or the key is missing (other sizes, the irregular mesh)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r03_pmc_secondary.json")) as f:
+            return json.load(f)[key]["bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+SECONDARY_TRAFFIC_SOURCE = ("rocprofv3 --pmc TCC_EA0_RDREQ_{32B,64B,128B}_sum / TCC_EA0_WRREQ{,_64B}_sum in separate passes over "
+                            "scripts/secondary_kernel_probe.py (scripts/collect_secondary_pmc.sh), bytes = sum(size*requests), average of "
+                            "the 30 launches of the measurement entry; L2-miss traffic, Infinity-Cache hits included; profiles/r03_pmc_secondary.json")
 
 
 def implicit_line(args):
@@ -472,7 +489,8 @@ def implicit_line(args):
                    "cells": nc, "iterations_U": it_u, "iterations_e": it_e, "unconverged_steps": solves["unconverged_steps"]},
         "roofline": {"bound": "hbm", "kernel": "iApplyKernel<3,1> (matrix product of the three-component U system, one walk of the matrix for the three right-hand sides)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS if achieved else None,
-                     "traffic": None, "algorithmic_bytes_per_launch": apply_bytes, "avg_launch_ms": ap["ms"]},
+                     "traffic": secondary_traffic("implicit_n200") if n == 200 else None, "traffic_is_static": True,
+                     "traffic_source": SECONDARY_TRAFFIC_SOURCE, "algorithmic_bytes_per_launch": apply_bytes, "avg_launch_ms": ap["ms"]},
         "solver_bytes_model": {"per_cell_per_iteration_U": IMPL_ITER_BYTES_PER_CELL_U, "per_cell_per_iteration_e": IMPL_ITER_BYTES_PER_CELL_E,
                                "bytes_per_step_in_the_solves": nc * (IMPL_ITER_BYTES_PER_CELL_U * it_u + IMPL_ITER_BYTES_PER_CELL_E * it_e)},
         "min_rho": info["minRho"], "setup_s": t_setup,

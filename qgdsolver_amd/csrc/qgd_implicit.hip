@@ -429,13 +429,21 @@ struct ISolveView {
     double* part;                      // partial sums: (row * NR + k) * nBlocks + block
     double* ctl;
     int nBlocks;
+    int xrun;                          // row blocks per XCD run of the matrix product (see rowBlock in qgd_poisson.hip), 0: plain order
 };
 
 // MODE 0: q = A x, r = b - q, d <- A 1 (kept until phase 1), partial {|r|, x};  MODE 1: q = A d, partial {d.q}
 template <int NR, int MODE>
 __global__ __launch_bounds__(QGD_BLOCK) void iApplyKernel(const MeshView m, const ISolveView v) {
     if (v.ctl[I_ALLDONE] != 0.0 && MODE == 1) return;
-    const int i = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    // workgroup b runs on XCD b % 8 (private L2 each): runs of v.xrun consecutive row blocks per XCD keep a row and its neighbours one
+    // mesh row away in one L2 (round-robin: the product read 217 B per cell where 120 are compulsory); partials stay in block order
+    int blk = blockIdx.x;
+    if (v.xrun > 0) {
+        const int span = v.xrun << 3, full = ((int)gridDim.x / span) * span;
+        if (blk < full) { const int xcd = blk & 7, q = blk >> 3; blk = ((q / v.xrun) * 8 + xcd) * v.xrun + (q % v.xrun); }
+    }
+    const int i = blk * QGD_BLOCK + threadIdx.x;
     double s0[NR], s1[NR];
 #pragma unroll
     for (int k = 0; k < NR; ++k) s0[k] = s1[k] = 0.0;
@@ -490,10 +498,10 @@ __global__ __launch_bounds__(QGD_BLOCK) void iApplyKernel(const MeshView m, cons
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
         const double t0 = iBlockSum(s0[k]);
-        if (threadIdx.x == 0) v.part[(size_t)(0 * NR + k) * v.nBlocks + blockIdx.x] = t0;
+        if (threadIdx.x == 0) v.part[(size_t)(0 * NR + k) * v.nBlocks + blk] = t0;
         if (MODE == 0) {
             const double t1 = iBlockSum(s1[k]);
-            if (threadIdx.x == 0) v.part[(size_t)(1 * NR + k) * v.nBlocks + blockIdx.x] = t1;
+            if (threadIdx.x == 0) v.part[(size_t)(1 * NR + k) * v.nBlocks + blk] = t1;
         }
     }
 }
@@ -658,6 +666,7 @@ struct ImplicitSolver {
     ISolveView v{};
     int NR = 1, validMask = 1, maxIter = 0;
     double tol = 0;
+    int rowRun = 64;            // QGD_ROW_XCD_RUN (0 ... 4096): row blocks per XCD run of the matrix product, 0: plain order (measured: 0.286 -> 0.274 ms per product at 8 M cells)
 };
 #define ICHECK(expr)                                                                                   \
     do {                                                                                               \
@@ -668,6 +677,12 @@ struct ImplicitSolver {
 ImplicitSolver* implicitSolverCreate(hipStream_t stream, const MeshView& m, int ownedBegin, int ownedEnd) {
     ImplicitSolver* S = new ImplicitSolver();
     S->m = m; S->stream = stream; S->ob = ownedBegin; S->oe = ownedEnd < 0 ? m.nC : ownedEnd;
+    if (const char* e = std::getenv("QGD_ROW_XCD_RUN")) {
+        char* end = nullptr;
+        const long v = std::strtol(e, &end, 10);
+        if (!end || *end != '\0' || v < 0 || v > 4096) { delete S; throw std::invalid_argument(std::string("QGD_ROW_XCD_RUN=") + e + " is outside [0, 4096]"); }
+        S->rowRun = (int)v;
+    }
     const size_t nC = (size_t)m.nC, nb = (size_t)gridOf(S->oe - S->ob);
     try {
         ICHECK(hipMalloc((void**)&S->r, sizeof(double) * 3 * nC)); ICHECK(hipMalloc((void**)&S->d, sizeof(double) * 3 * nC));
@@ -738,6 +753,7 @@ void implicitSolveSetup(ImplicitSolver* S, int nRhs, int validMask, const double
     ISolveView& v = S->v;
     v.NR = nRhs; v.ob = S->ob; v.n = S->oe - S->ob; v.nC = S->m.nC; v.a = a; v.diag = diag; v.rhs = rhs; v.x = x;
     v.r = S->r; v.d = S->d; v.q = S->q; v.part = S->part; v.ctl = S->ctl; v.nBlocks = gridOf(v.n);
+    v.xrun = S->rowRun;
     S->NR = nRhs; S->validMask = validMask; S->tol = tol; S->maxIter = maxIter;
 }
 void implicitSolvePhase(ImplicitSolver* S, int phase) {

@@ -324,6 +324,7 @@ namespace {
 template <typename T>
 struct MgLevelT {
     int n = 0, width = 0;       // rows; the widest row
+    int xrun = 0;               // row blocks per XCD run (rowBlock), 0: plain order
     long long entries = 0;      // stored (padded) entries of the sliced ELL
     T* diag = nullptr;          // n
     // sliced ELL: 64 rows per slice, slice s holds sliceStart[s+1] - sliceStart[s] entry rows of 64 lanes; entry k of row i sits at
@@ -348,6 +349,20 @@ struct MgLevelT {
 };
 using MgLevelDev = MgLevelT<double>;   // the cycle in double; MgLevelT<float>: the same cycle as a single-precision preconditioner
 
+// Workgroup b runs on XCD b % 8, each XCD with a private 4 MiB L2.  Dealt round-robin, the 256-row blocks of a sweep put a row and its
+// neighbours one mesh row away on different XCDs, and every gathered line is fetched by about five of them (measured: the implicit
+// matrix product read 217 B per cell where 120 are compulsory, a level-0 sweep 73 B per row where 60 are).  Runs of `run` consecutive
+// blocks per XCD keep those neighbours in one L2 (the same map as xcdTile of the explicit kernels); run <= 0: identity.  Measured
+// (profiles/r03_ab_row_xcd_run.txt): the double-precision matrix product of the implicit branch gains 3-4 % with runs of 16-64, the
+// single-precision sweeps here lose 1 % -- the extra fetches are Infinity-Cache hits -- so this solver's default is the plain order.
+__device__ __forceinline__ int rowBlock(const int run) {
+    const int b = blockIdx.x;
+    if (run <= 0) return b;
+    const int span = run << 3, full = ((int)gridDim.x / span) * span;
+    if (b >= full) return b;
+    const int xcd = b & 7, i = b >> 3;
+    return ((i / run) * 8 + xcd) * run + (i % run);
+}
 // s (+/-)= sum_k val[k] x[col[k]] over the w entries of one sliced-ELL row, in entry order.  The labels and coefficients of eight
 // entries are requested before the first gather goes out: the plain loop (label, wait, gather, wait, per entry) left the level-0
 // sweep latency-bound at 3.7 TB/s.  Padding (col < 0) adds 0 * 0, which changes no bit of s; w is uniform over the wavefront.
@@ -379,7 +394,7 @@ template <typename T>
 __global__ __launch_bounds__(PB) void mgSmoothKernel(const MgLevelT<T> L, const T omega, const T* __restrict__ b,
                                                      const T* __restrict__ xin, T* xout, T* __restrict__ rout,
                                                      const double* __restrict__ ctl = nullptr, const T cx = 1, const T cm = 0) {
-    const int i = blockIdx.x * PB + threadIdx.x;
+    const int i = rowBlock(L.xrun) * PB + threadIdx.x;
     if (i >= L.n || solveDone(ctl)) return;
     const T d = L.diag[i];
     if (!xin) { xout[i] = omega * b[i] / d; return; }
@@ -407,7 +422,8 @@ __global__ __launch_bounds__(PB) void mgConvertKernel(const int n, const A* __re
 // block partial sums of x.y
 __global__ __launch_bounds__(PB) void mgApplyKernel(const MgLevelDev L, const double* __restrict__ x, double* __restrict__ y,
                                                     double* __restrict__ part, const double* __restrict__ ctl = nullptr) {
-    const int i = blockIdx.x * PB + threadIdx.x;
+    const int blk = rowBlock(L.xrun);   // the partial sums stay in block order: the fold adds them as before
+    const int i = blk * PB + threadIdx.x;
     if (solveDone(ctl)) return;
     double xy = 0;
     if (i < L.n) {
@@ -420,7 +436,7 @@ __global__ __launch_bounds__(PB) void mgApplyKernel(const MgLevelDev L, const do
         xy = xi * s;
     }
     const double t = blockSum(xy);
-    if (threadIdx.x == 0) part[blockIdx.x] = t;
+    if (threadIdx.x == 0) part[blk] = t;
 }
 template <typename T>
 __global__ __launch_bounds__(PB) void mgRestrictKernel(const int nCoarse, const int* __restrict__ aggStart, const int* __restrict__ aggItems,
@@ -743,6 +759,7 @@ struct PressureSolver {
     int passes = 2;
     double saTheta = 0.08;
     int denseMax = 2048;                   // QGD_MG_DENSE_MAX
+    int rowRun = 0;                        // QGD_ROW_XCD_RUN: row blocks per XCD run of the sliced-ELL sweeps (rowBlock), 0: plain order (measured: runs of 16 make the f32 sweeps 1 % slower)
     // ---- a hierarchy that SPANS THE RANKS of a sharded solve (QGD_MG_DIST, default on; 0: the rank-local block hierarchy) ----------------
     // A rank-local hierarchy is block Jacobi: 7 -> 65 / 97 / 140 iterations on 2 / 4 / 8 shards of a 128^3 box.  Here level 0 stays
     // distributed (each rank smooths its own rows, the ghost entries of the iterate refreshed before every sweep), every level below it
@@ -1218,7 +1235,7 @@ static void mgUploadLevel(PressureSolver* S, int n, const std::vector<int>& I, c
     std::vector<double> inv;
     const bool dense = last && !S->L.empty() && n <= S->denseMax && denseInverse(n, I, J, w, diag, inv);
     MgLevelDev lv;
-    lv.n = n; lv.width = width; lv.entries = stored;
+    lv.n = n; lv.width = width; lv.entries = stored; lv.xrun = S->rowRun;
     lv.diag = S->alloc<double>(n, diag.data());
     const int* startDev = S->alloc<int>(start.size(), start.data());
     if (rows) lv.rowStart = startDev; else lv.sliceStart = startDev;
@@ -1228,7 +1245,7 @@ static void mgUploadLevel(PressureSolver* S, int n, const std::vector<int>& I, c
         // the double-precision level keeps only what the CG's own matrix product needs (level 0) or nothing
         std::vector<float> vf(val.begin(), val.end()), df(diag.begin(), diag.end());
         MgLevelT<float> lf;
-        lf.n = n; lf.width = width; lf.entries = lv.entries; lf.col = lv.col; lf.sliceStart = lv.sliceStart; lf.rowStart = lv.rowStart;
+        lf.n = n; lf.width = width; lf.entries = lv.entries; lf.xrun = lv.xrun; lf.col = lv.col; lf.sliceStart = lv.sliceStart; lf.rowStart = lv.rowStart;
         lf.diag = S->alloc<float>(n, df.data());
         lf.val = S->alloc<float>(vf.size(), vf.data());
         lf.x = S->alloc<float>(n); lf.x2 = S->alloc<float>(n); lf.b = S->alloc<float>(n); lf.r = S->alloc<float>(n);
@@ -1379,6 +1396,7 @@ PressureSolver* pressureSolverCreate(hipStream_t stream, const MeshView& m, cons
         const bool sa = S->sa = knob("QGD_MG_SA", 1, 0, 1) != 0;
         S->passes = (int)knob("QGD_MG_PASSES", 2, 1, 4);                   // plain aggregation: pairwise matching passes per level
         S->saTheta = knob("QGD_MG_SA_THETA", 0.08, 0.0, 0.9);             // strength threshold on level 0, halved per level
+        S->rowRun = (int)knob("QGD_ROW_XCD_RUN", 0, 0, 4096);
         S->denseMax = (int)knob("QGD_MG_DENSE_MAX", MG_DENSE_MAX, 64, 8192);  // the last level (solved exactly) has at most this many rows
         if (sa) S->oc = knob("QGD_MG_OC", 1.0, 0.5, 3.0);
         // a shard with smoothed aggregation and the single-precision cycle builds the hierarchy that spans the ranks, at its first solve
