@@ -65,7 +65,7 @@ __device__ __forceinline__ void muDev2T(const double* g, const double mu, double
 // (cfNbr) or the patch value, the weight and Sf: a third of the bytes of walking owner and neighbour records face by face
 // (1.44 -> 0.5 ms at 8 M cells), same operations in the same order.
 __global__ __launch_bounds__(QGD_BLOCK) void implCellGradKernel(const MeshView m, const CaseView c, const ImplView iv) {
-    const int ci = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    const int ci = xcdTile((int)gridDim.x, m.xcdRun) * QGD_BLOCK + threadIdx.x;   // runs of consecutive blocks per XCD: neighbours meet in one L2
     const bool live = ci < m.nC && !(m.ghost && m.ghost[ci] == 1);   // a ghost cell lacks faces here: its gradient arrives by message
     if (__ballot(live) == 0) return;
     if (live) cellGradGauss<6, 1, 6, 1>(m, ci, reinterpret_cast<const double*>(c.A), reinterpret_cast<const double*>(c.bA), iv.gUc);
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(QGD_BLOCK) void implCellGradKernel(const MeshView m
 // per face: muf, alphauf, Uf, tauMC -> phiTauMC, Sf.(tauMC & Uf), the laplacian coefficients [updateFluxes.H L107-111]
 __global__ __launch_bounds__(QGD_BLOCK) void implFaceKernel(const MeshView m, const CaseView c, const ImplView iv, const GasModel gm,
                                                            const PatchBCDev* __restrict__ bcs) {
-    const int f = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    const int f = xcdTile((int)gridDim.x, m.xcdRun) * QGD_BLOCK + threadIdx.x;   // runs of consecutive blocks per XCD: neighbours meet in one L2
     if (f >= m.nF) return;
     const size_t nF = (size_t)m.nF;
     // what the cell kernels and the matrix products gather (phiTauMC, the laplacian coefficients, phiSigmaDotU) sits at the face's
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(QGD_BLOCK) void implFaceKernel(const MeshView m, co
 
 // QGDRhoEqn.H, the first solve of QGDUEqn.H (rhoU), U = rhoU/rho, and the matrix + source of UEqn per component
 __global__ __launch_bounds__(QGD_BLOCK) void implCellUKernel(const MeshView m, const CaseView c, const ImplView iv, const PatchBCDev* __restrict__ bcs) {
-    const int ci = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    const int ci = xcdTile((int)gridDim.x, m.xcdRun) * QGD_BLOCK + threadIdx.x;   // runs of consecutive blocks per XCD: neighbours meet in one L2
     if (ci >= m.nC) return;
     if (m.ghost && m.ghost[ci] == 1) return;   // ghost rows belong to another shard
     const int n = m.cfCount[ci];
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(QGD_BLOCK) void implBcUKernel(const MeshView m, con
 
 // phiSigmaDotU = Sf & ((muf*lin(fvc::grad(U)) + tauMC) & Uf) with the new U's gradient [QGDUEqn.H L72-74]
 __global__ __launch_bounds__(QGD_BLOCK) void implSigmaKernel(const MeshView m, const CaseView c, const ImplView iv, const PatchBCDev* __restrict__ bcs) {
-    const int f = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    const int f = xcdTile((int)gridDim.x, m.xcdRun) * QGD_BLOCK + threadIdx.x;   // runs of consecutive blocks per XCD: neighbours meet in one L2
     if (f >= m.nF) return;
     const size_t nF = (size_t)m.nF, pos = f < m.nIF ? (size_t)m.fpos[f] : (size_t)f;   // phiSigmaDotU at the face's position (see implFaceKernel)
     if (m.fkind[f] == 3) { iv.phiSig[pos] = 0.0; return; }
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(QGD_BLOCK) void implSigmaKernel(const MeshView m, c
 // EEqn [QGDEEqn.H L37-50] and the matrix + source of the e equation [L55-61]
 __global__ __launch_bounds__(QGD_BLOCK) void implCellEKernel(const MeshView m, const CaseView c, const ImplView iv, const GasModel gm,
                                                             const PatchBCDev* __restrict__ bcs) {
-    const int ci = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    const int ci = xcdTile((int)gridDim.x, m.xcdRun) * QGD_BLOCK + threadIdx.x;   // runs of consecutive blocks per XCD: neighbours meet in one L2
     if (ci >= m.nC) return;
     if (m.ghost && m.ghost[ci] == 1) return;
     const int n = m.cfCount[ci];

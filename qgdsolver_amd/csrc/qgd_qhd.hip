@@ -41,7 +41,7 @@ __device__ __forceinline__ void qhdBoundaryVals4(const MeshView& m, const PatchB
 // face pass 1 [updateFields.H L36-73, updateFluxes.H L33-38, QHDTEqn.H L66]
 template <int ST>
 __global__ __launch_bounds__(QGD_BLOCK) void qhdFace1Kernel(const MeshView m, const QhdView q, const PatchBCDev* __restrict__ bcs) {
-    const int f = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    const int f = xcdTile((int)gridDim.x, m.xcdRun) * QGD_BLOCK + threadIdx.x;   // runs of consecutive blocks per XCD: neighbours meet in one L2
     if (f >= m.nF) return;
     if (m.fkind[f] == 3) return;
     const bool internal = f < m.nIF;
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(QGD_BLOCK) void qhdPressureBcKernel(const MeshView 
 // fvc::grad(U), Gauss linear (L0): cell gather in ascending face order -- the cell's own velocity once, per face the neighbour cell's
 // (cfNbr) or the patch value, the weight and Sf (same operations, same order as walking owner and neighbour face by face)
 __global__ __launch_bounds__(QGD_BLOCK) void qhdCellGradKernel(const MeshView m, const QhdView q) {
-    const int c = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    const int c = xcdTile((int)gridDim.x, m.xcdRun) * QGD_BLOCK + threadIdx.x;   // runs of consecutive blocks per XCD: neighbours meet in one L2
     const bool live = c < m.nC && !(m.ghost && m.ghost[c] == 1);   // a ghost cell lacks faces here: its gradient arrives with the halo message
     if (__ballot(live) == 0) return;
     if (live) cellGradGauss<4, 0, 4, 0>(m, c, q.c4, q.b4, q.gUc);
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(QGD_BLOCK) void qhdCellGradKernel(const MeshView m,
 // face pass 2 [QHDUEqn.H L36-84, QHDTEqn.H L65-91]: the net face terms of the U and T equations
 template <int ST>
 __global__ __launch_bounds__(QGD_BLOCK) void qhdFace2Kernel(const MeshView m, const QhdView q, const PatchBCDev* __restrict__ bcs) {
-    const int f = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    const int f = xcdTile((int)gridDim.x, m.xcdRun) * QGD_BLOCK + threadIdx.x;   // runs of consecutive blocks per XCD: neighbours meet in one L2
     if (f >= m.nF) return;
     // the net face terms go to the face's slot-major position (MeshView::fpos), where the cell update finds those of consecutive cells
     // at consecutive addresses (by label: every third double of the lines it fetches)
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(QGD_BLOCK) void qhdFace2Kernel(const MeshView m, co
 
 // explicit Euler of the U and T equations [QHDUEqn.H L68-84, QHDTEqn.H L83-91]
 __global__ __launch_bounds__(QGD_BLOCK) void qhdCellUpdateKernel(const MeshView m, const QhdView q) {
-    const int c = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    const int c = xcdTile((int)gridDim.x, m.xcdRun) * QGD_BLOCK + threadIdx.x;   // runs of consecutive blocks per XCD: neighbours meet in one L2
     if (c >= m.nC) return;
     if (m.ghost && m.ghost[c] == 1) return;
     const int n = m.cfCount[c];
