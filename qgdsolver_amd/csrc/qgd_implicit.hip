@@ -429,20 +429,14 @@ struct ISolveView {
     double* part;                      // partial sums: (row * NR + k) * nBlocks + block
     double* ctl;
     int nBlocks;
-    int xrun;                          // row blocks per XCD run of the matrix product (see rowBlock in qgd_poisson.hip), 0: plain order
+    int xrun;                          // row blocks per XCD run of the matrix product (xcdRunBlock in qgd_device.hpp), 0: plain order
 };
 
 // MODE 0: q = A x, r = b - q, d <- A 1 (kept until phase 1), partial {|r|, x};  MODE 1: q = A d, partial {d.q}
 template <int NR, int MODE>
 __global__ __launch_bounds__(QGD_BLOCK) void iApplyKernel(const MeshView m, const ISolveView v) {
     if (v.ctl[I_ALLDONE] != 0.0 && MODE == 1) return;
-    // workgroup b runs on XCD b % 8 (private L2 each): runs of v.xrun consecutive row blocks per XCD keep a row and its neighbours one
-    // mesh row away in one L2 (round-robin: the product read 217 B per cell where 120 are compulsory); partials stay in block order
-    int blk = blockIdx.x;
-    if (v.xrun > 0) {
-        const int span = v.xrun << 3, full = ((int)gridDim.x / span) * span;
-        if (blk < full) { const int xcd = blk & 7, q = blk >> 3; blk = ((q / v.xrun) * 8 + xcd) * v.xrun + (q % v.xrun); }
-    }
+    const int blk = xcdRunBlock(v.xrun);   // runs of row blocks per XCD (qgd_device.hpp); the partial sums stay in block order
     const int i = blk * QGD_BLOCK + threadIdx.x;
     double s0[NR], s1[NR];
 #pragma unroll

@@ -324,7 +324,7 @@ namespace {
 template <typename T>
 struct MgLevelT {
     int n = 0, width = 0;       // rows; the widest row
-    int xrun = 0;               // row blocks per XCD run (rowBlock), 0: plain order
+    int xrun = 0;               // row blocks per XCD run (xcdRunBlock), 0: plain order
     long long entries = 0;      // stored (padded) entries of the sliced ELL
     T* diag = nullptr;          // n
     // sliced ELL: 64 rows per slice, slice s holds sliceStart[s+1] - sliceStart[s] entry rows of 64 lanes; entry k of row i sits at
@@ -349,20 +349,9 @@ struct MgLevelT {
 };
 using MgLevelDev = MgLevelT<double>;   // the cycle in double; MgLevelT<float>: the same cycle as a single-precision preconditioner
 
-// Workgroup b runs on XCD b % 8, each XCD with a private 4 MiB L2.  Dealt round-robin, the 256-row blocks of a sweep put a row and its
-// neighbours one mesh row away on different XCDs, and every gathered line is fetched by about five of them (measured: the implicit
-// matrix product read 217 B per cell where 120 are compulsory, a level-0 sweep 73 B per row where 60 are).  Runs of `run` consecutive
-// blocks per XCD keep those neighbours in one L2 (the same map as xcdTile of the explicit kernels); run <= 0: identity.  Measured
-// (profiles/r03_ab_row_xcd_run.txt): the double-precision matrix product of the implicit branch gains 3-4 % with runs of 16-64, the
-// single-precision sweeps here lose 1 % -- the extra fetches are Infinity-Cache hits -- so this solver's default is the plain order.
-__device__ __forceinline__ int rowBlock(const int run) {
-    const int b = blockIdx.x;
-    if (run <= 0) return b;
-    const int span = run << 3, full = ((int)gridDim.x / span) * span;
-    if (b >= full) return b;
-    const int xcd = b & 7, i = b >> 3;
-    return ((i / run) * 8 + xcd) * run + (i % run);
-}
+// (the order of the row blocks over the XCDs: xcdRunBlock in qgd_device.hpp.  Measured, profiles/r03_ab_row_xcd_run.txt: the double-precision
+// matrix product of the implicit branch gains 3-4 % with runs of 16-64, the single-precision sweeps here lose 1 % -- their extra fetches
+// are Infinity-Cache hits -- so this solver's default is the plain order, QGD_ROW_XCD_RUN = 0)
 // s (+/-)= sum_k val[k] x[col[k]] over the w entries of one sliced-ELL row, in entry order.  The labels and coefficients of eight
 // entries are requested before the first gather goes out: the plain loop (label, wait, gather, wait, per entry) left the level-0
 // sweep latency-bound at 3.7 TB/s.  Padding (col < 0) adds 0 * 0, which changes no bit of s; w is uniform over the wavefront.
@@ -394,7 +383,7 @@ template <typename T>
 __global__ __launch_bounds__(PB) void mgSmoothKernel(const MgLevelT<T> L, const T omega, const T* __restrict__ b,
                                                      const T* __restrict__ xin, T* xout, T* __restrict__ rout,
                                                      const double* __restrict__ ctl = nullptr, const T cx = 1, const T cm = 0) {
-    const int i = rowBlock(L.xrun) * PB + threadIdx.x;
+    const int i = xcdRunBlock(L.xrun) * PB + threadIdx.x;
     if (i >= L.n || solveDone(ctl)) return;
     const T d = L.diag[i];
     if (!xin) { xout[i] = omega * b[i] / d; return; }
@@ -422,7 +411,7 @@ __global__ __launch_bounds__(PB) void mgConvertKernel(const int n, const A* __re
 // block partial sums of x.y
 __global__ __launch_bounds__(PB) void mgApplyKernel(const MgLevelDev L, const double* __restrict__ x, double* __restrict__ y,
                                                     double* __restrict__ part, const double* __restrict__ ctl = nullptr) {
-    const int blk = rowBlock(L.xrun);   // the partial sums stay in block order: the fold adds them as before
+    const int blk = xcdRunBlock(L.xrun);   // the partial sums stay in block order: the fold adds them as before
     const int i = blk * PB + threadIdx.x;
     if (solveDone(ctl)) return;
     double xy = 0;
@@ -759,7 +748,7 @@ struct PressureSolver {
     int passes = 2;
     double saTheta = 0.08;
     int denseMax = 2048;                   // QGD_MG_DENSE_MAX
-    int rowRun = 0;                        // QGD_ROW_XCD_RUN: row blocks per XCD run of the sliced-ELL sweeps (rowBlock), 0: plain order (measured: runs of 16 make the f32 sweeps 1 % slower)
+    int rowRun = 0;                        // QGD_ROW_XCD_RUN: row blocks per XCD run of the sliced-ELL sweeps (xcdRunBlock), 0: plain order (measured: runs of 16 make the f32 sweeps 1 % slower)
     // ---- a hierarchy that SPANS THE RANKS of a sharded solve (QGD_MG_DIST, default on; 0: the rank-local block hierarchy) ----------------
     // A rank-local hierarchy is block Jacobi: 7 -> 65 / 97 / 140 iterations on 2 / 4 / 8 shards of a 128^3 box.  Here level 0 stays
     // distributed (each rank smooths its own rows, the ghost entries of the iterate refreshed before every sweep), every level below it
