@@ -40,6 +40,11 @@ def test_launcher_and_flag_must_agree():
     assert pr.returncode == 2 and "disagree" in pr.stderr
 
 
+def test_the_implicit_line_is_a_one_gpu_line():
+    pr, _ = run_bench(["--workload", "implicit", "--gpus", "2", "--steps", "1"], 120)
+    assert pr.returncode == 2 and "one-GPU line" in pr.stderr
+
+
 @pytest.mark.gpu
 def test_two_ranks_self_launched_match_one_rank():
     common = ["--backend", "gloo", "--edge", "48", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-dropin", "--check"]
