@@ -76,3 +76,16 @@ def test_qhd_workload_on_two_self_launched_ranks():
     assert b["config"]["transport"].startswith("gloo") and b["value"] > 0
     assert 0 < b["config"]["pressure_iterations_per_step"] <= a["config"]["pressure_iterations_per_step"] + 2, (a["config"], b["config"])
     assert b["config"]["multigrid_levels"] == a["config"]["multigrid_levels"] and b["pressure_final_residual"] < 1e-8
+
+
+@pytest.mark.gpu
+def test_implicit_workload_line():
+    """the reference's default branch as a bench line: metric, iterations of both systems, the timed matrix product"""
+    pr, _ = run_bench(["--workload", "implicit", "--edge", "24", "--steps", "3", "--warmup", "1"], 600)
+    assert pr.returncode == 0, pr.stderr[-800:]
+    d = json.loads([ln for ln in pr.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["metric"].startswith("Mcell-steps/s") and d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0
+    assert d["config"]["cells"] == 24 ** 3 and d["config"]["iterations_U"] > 0 and d["config"]["iterations_e"] > 0
+    assert d["config"]["unconverged_steps"] == 0 and d["min_rho"] > 0
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["avg_launch_ms"] > 0 and r["algorithmic_bytes_per_launch"] == 144 * 24 ** 3 and r["traffic"] is None
