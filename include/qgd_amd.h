@@ -397,25 +397,34 @@ int qgd_qhd_case_info(qgd_qhd_case_t c, double info[8]);
  * What the reference does through processor patches inside fvm::laplacian / PCG / fvc::grad under MPI
  * [QHDpEqn_8H_source.html L35-47, QHDUEqn_8H_source.html L36-84] becomes, per step, with ONE rank per shard:
  *   phase 0   flux assembly (updateFields.H, updateFluxes.H), p's boundary conditions, fvc::grad(U) of the owned cells, the rows
- *             of the pressure equation of the owned cells, first residual   -> all-reduce (SUM) control[0..3)
+ *             of the pressure equation of the owned cells, first residual   -> DRAIN PENDING; all-reduce (SUM) control[0..3)
  *   phase 1   normFactor                                        -> all-reduce control[3]
- *   phase 2   first preconditioned residual, search direction   -> all-reduce control[4]; exchange message kind 2
+ *   phase 2   first preconditioned residual, search direction   -> DRAIN PENDING; all-reduce control[4]; exchange message kind 2
  *   repeat until qgd_qhd_case_solve_status says done (every rank sees the same flag: it is computed from reduced sums):
  *     phase 3 A d, d.Ad                                         -> all-reduce control[5]
- *     phase 4 x, r, z = M r, |r|, r.z                            -> all-reduce control[6..8)
+ *     phase 4 x, r, z = M r, |r|, r.z                            -> DRAIN PENDING; all-reduce control[6..8)
  *     phase 5 residual, iteration count, done?, new direction   -> exchange message kind 2
  *   phase 6   p's boundary conditions after the solve           -> exchange message kind 1
  *   phase 7   phi, QHDUEqn.H, QHDTEqn.H, U/T boundary conditions -> all-reduce control[8] (only when p needs a reference level)
  *   phase 8   reference level of p                              -> exchange message kind 0
- * The preconditioner is the aggregation multigrid of each rank's own block (additive Schwarz: couplings to ghost cells stay in
- * the diagonal), so the iteration count grows mildly with the number of shards; everything else is the unsharded arithmetic.
+ * DRAIN PENDING = the comm points of the preconditioner, which fall INSIDE phases 0, 2 and 4: after the phase call, and again after
+ * every qgd_qhd_case_step_phase(c, 9), ask qgd_qhd_case_pending and perform what it names until it answers 0 (protocol below).  A
+ * caller that implements only the table and never drains gets an error status from the next phase ("a collective of the phase in
+ * flight is pending"), not a wrong answer.
+ * Preconditioner: by DEFAULT the smoothed-aggregation hierarchy SPANS THE RANKS (level 0 distributed, coarse levels replicated;
+ * same iteration count as the unsharded solve).  It replicates the global matrix on every rank at set-up, so it is built only up
+ * to QGD_MG_DIST_MAX_CELLS cells of the unsharded mesh (default 20 000 000; memory per rank ~ nCells (1 + 2K) doubles on host and
+ * device, K = couplings per cell to higher-numbered neighbours, plus a host coarsening of nCells rows).  Above that, with
+ * QGD_MG_DIST=0, with the plain-aggregation or double-precision cycle, or for a caller that never performs the set-up all-reduces,
+ * every rank preconditions with the hierarchy of its own rows (block Jacobi across the shards: couplings to ghost cells stay in the
+ * diagonal; 7 -> 65 / 97 / 140 iterations on 2 / 4 / 8 shards of a 128^3 box) and a line on stderr says so.  Everything else is the
+ * unsharded arithmetic.
  * control: 16 device doubles (qgd_qhd_case_control_ptr); message kinds: 0 = the new state, {U,T} per cell (4) and per patch face
  * (4); 1 = p + fvc::grad(U) per cell (1 + 9: a ghost cell's gradient cannot be formed locally, it lacks faces) and p's patch value
  * + gradient per patch face (2); 2 = the search direction per cell (1); 3 = the multigrid iterate per cell (1), see qgd_qhd_case_pending.
  * pRefCell is a cell label of the UNSHARDED mesh.  All entries are stream-ordered on the device's stream. */
 int qgd_qhd_case_step_phase(qgd_qhd_case_t c, int phase);
-/* The multigrid hierarchy of a sharded pressure solve SPANS THE RANKS (QGD_MG_DIST=0: every rank preconditions with the hierarchy of
- * its own rows, which is block Jacobi: 7 -> 65 / 97 / 140 iterations on 2 / 4 / 8 shards of a 128^3 box).  Level 0 stays distributed --
+/* The hierarchy that spans the ranks (default up to QGD_MG_DIST_MAX_CELLS, see above).  Level 0 stays distributed --
  * each rank smooths its own rows, the ghost entries of the iterate refreshed before every sweep (message kind 3: one double per cell)
  * -- and every level below it is replicated: the ranks all-reduce their shares of the level-1 right-hand side and run the coarse part
  * of the cycle redundantly.  The comm points fall INSIDE phases 0 (set-up, first step only: the global matrix is gathered by two

@@ -416,6 +416,7 @@ int qgd_mesh_jitter(qgd_mesh_t m, double amplitude, uint64_t seed) {
     QGD_TRY
     if (!m) return fail(QGD_ERR_INVALID, "null mesh");
     jitterPoints(m->m, amplitude, seed);
+    m->m.haloFaceH.clear();   // the cut faces' hQGDf of the unsharded mesh no longer describes these points: back to the local rule
     return QGD_OK;
     QGD_CATCH
 }
@@ -423,6 +424,7 @@ int qgd_mesh_split_quads(qgd_mesh_t m, int32_t stride) {
     QGD_TRY
     if (!m) return fail(QGD_ERR_INVALID, "null mesh");
     splitQuads(m->m, stride);
+    m->m.haloFaceH.clear();   // face lists changed: the per-halo-face values would be misaligned
     return QGD_OK;
     QGD_CATCH
 }
@@ -430,6 +432,7 @@ int qgd_mesh_split_edges(qgd_mesh_t m, int32_t stride) {
     QGD_TRY
     if (!m) return fail(QGD_ERR_INVALID, "null mesh");
     splitEdges(m->m, stride);
+    m->m.haloFaceH.clear();
     return QGD_OK;
     QGD_CATCH
 }
@@ -446,6 +449,7 @@ int qgd_mesh_set_geometry(qgd_mesh_t mh, const double* Sf, const double* Cf, con
         m.magSf[f] = std::sqrt(S[0] * S[0] + S[1] * S[1] + S[2] * S[2]);
     }
     m.userGeometry = true;
+    m.haloFaceH.clear();      // computed from the library's own centres; the caller's geometry rules now
     m.computeDerived();
     return QGD_OK;
     QGD_CATCH
@@ -2195,13 +2199,12 @@ static void ensureHaloBuffers(qgd_case_s* c) {
         c->recvBuf[s] = c->arena.alloc<double>(10 * (size_t)h.nGhost + 12 * (size_t)h.nGhostBF);
     }
 }
-// pack -> grouped send/recv -> unpack on `stream`
-static void haloExchangeOn(qgd_case_s* c, qgd_comm_s* comm, const int32_t* peers, int nSlots, hipStream_t stream) {
-    qgd_device_s* d = c->dev;
-    const int n = std::min<int>(nSlots, (int)d->halo.size());
-    // RCCL matches the messages of one peer in issue order, and both sides issue in their own slot order: two slots towards
-    // the same rank (two ranks on a periodic cut, two disjoint interfaces with one neighbour) would land in each other's
-    // ghost lists.  Refused; a rank exchanging with itself (the one-GPU test of this path) is the one ordered exception.
+// RCCL matches the messages of one peer in issue order, and both sides issue in their own slot order: two slots towards
+// the same rank (two ranks on a periodic cut, two disjoint interfaces with one neighbour) would land in each other's
+// ghost lists.  Refused; a rank exchanging with itself (the one-GPU test of this path) is the one ordered exception.
+// Called by every exchange AND at the top of the sharded step entries, before the first message of a step is issued
+// (the mid-assembly message and the messages inside the implicit solves come before the state message).
+static void checkHaloPeers(const qgd_comm_s* comm, const int32_t* peers, int n) {
     for (int a = 0; a < n; ++a)
         for (int b = a + 1; b < n; ++b)
             if (peers[a] >= 0 && peers[a] == peers[b] && peers[a] != comm->rank)
@@ -2209,6 +2212,12 @@ static void haloExchangeOn(qgd_case_s* c, qgd_comm_s* comm, const int32_t* peers
                                             "one slot per neighbouring rank (qgd_mesh_shard builds them that way)");
     for (int s = 0; s < n; ++s)
         if (peers[s] >= comm->nRanks) throw std::invalid_argument("halo exchange: peer rank out of range");
+}
+// pack -> grouped send/recv -> unpack on `stream`
+static void haloExchangeOn(qgd_case_s* c, qgd_comm_s* comm, const int32_t* peers, int nSlots, hipStream_t stream) {
+    qgd_device_s* d = c->dev;
+    const int n = std::min<int>(nSlots, (int)d->halo.size());
+    checkHaloPeers(comm, peers, n);
     ensureHaloBuffers(c);
     Launcher L = launcherOf(c);
     L.pre = nullptr; L.post = nullptr; L.stream = stream;
@@ -2263,6 +2272,7 @@ int qgd_case_allreduce_max(qgd_case_t c, qgd_comm_t comm) {
 static void implHaloExchangeOn(qgd_case_s* c, qgd_comm_s* comm, const int32_t* peers, int nSlots, int kind) {
     qgd_device_s* d = c->dev;
     const int n = std::min<int>(nSlots, (int)d->halo.size());
+    checkHaloPeers(comm, peers, n);
     if (c->implSendBuf.size() != d->halo.size()) {
         c->implSendBuf.assign(d->halo.size(), nullptr);
         c->implRecvBuf.assign(d->halo.size(), nullptr);
@@ -2292,6 +2302,7 @@ static void implHaloExchangeOn(qgd_case_s* c, qgd_comm_s* comm, const int32_t* p
 static void midExchangeOn(qgd_case_s* c, qgd_comm_s* comm, const int32_t* peers, int nSlots) {
     qgd_device_s* d = c->dev;
     const int n = std::min<int>(nSlots, (int)d->halo.size());
+    checkHaloPeers(comm, peers, n);
     if (c->midSendBuf.size() != d->halo.size()) {
         c->midSendBuf.assign(d->halo.size(), nullptr);
         c->midRecvBuf.assign(d->halo.size(), nullptr);
@@ -2324,9 +2335,8 @@ int qgd_case_step_sharded(qgd_case_t c, qgd_comm_t comm, const int32_t* peers, i
     if (sharded && (!comm || !peers)) return fail(QGD_ERR_INVALID, "qgd_case_step_sharded: null argument");
     HIP_CHECK(hipSetDevice(c->dev->deviceId));
     const bool adjust = c->opt.adjustTimeStep != 0;
+    if (sharded) checkHaloPeers(comm, peers, std::min<int>(nSlots, (int)c->dev->halo.size()));   // before the first message of the step
     if (sharded && midExchangeNeeded(c)) {
-        for (int a = 0; a < std::min<int>(nSlots, (int)c->dev->halo.size()); ++a)
-            if (peers[a] >= comm->nRanks) return fail(QGD_ERR_INVALID, "qgd_case_step_sharded: peer rank out of range");
         stepAssemble(c, 1);
         midExchangeOn(c, comm, peers, nSlots);
         stepAssemble(c, 2);
@@ -2337,8 +2347,6 @@ int qgd_case_step_sharded(qgd_case_t c, qgd_comm_t comm, const int32_t* peers, i
     if (c->opt.implicitDiffusion) {
         // the reference's default branch on shards: the dot products of its four solves are ncclAllReduce of the control block, the
         // gradients, the new velocity and the search directions travel as grouped send/recv pairs, then the state message as usual
-        for (int a = 0; a < std::min<int>(nSlots, (int)c->dev->halo.size()); ++a)
-            if (peers[a] >= comm->nRanks) return fail(QGD_ERR_INVALID, "qgd_case_step_sharded: peer rank out of range");
         SolveHooks hooks;
         hipStream_t st = c->stream();
         if (comm->nRanks > 1)
@@ -2380,12 +2388,7 @@ int qgd_case_step_sharded(qgd_case_t c, qgd_comm_t comm, const int32_t* peers, i
 static void qhdHaloExchangeOn(qgd_qhd_case_s* c, qgd_comm_s* comm, const int32_t* peers, int nSlots, int kind) {
     qgd_device_s* d = c->dev;
     const int n = std::min<int>(nSlots, (int)d->halo.size());
-    for (int a = 0; a < n; ++a)
-        for (int b = a + 1; b < n; ++b)
-            if (peers[a] >= 0 && peers[a] == peers[b] && peers[a] != comm->rank)
-                throw std::invalid_argument("halo exchange: one slot per neighbouring rank");
-    for (int s2 = 0; s2 < n; ++s2)
-        if (peers[s2] >= comm->nRanks) throw std::invalid_argument("halo exchange: peer rank out of range");
+    checkHaloPeers(comm, peers, n);
     if (c->sendBuf.size() != d->halo.size()) {
         c->sendBuf.assign(d->halo.size(), nullptr);
         c->recvBuf.assign(d->halo.size(), nullptr);
@@ -2435,6 +2438,7 @@ int qgd_qhd_case_step_sharded(qgd_qhd_case_t c, qgd_comm_t comm, const int32_t* 
     const bool sharded = !d->halo.empty() && nSlots > 0;
     if (sharded && (!comm || !peers)) return fail(QGD_ERR_INVALID, "qgd_qhd_case_step_sharded: null argument");
     HIP_CHECK(hipSetDevice(d->deviceId));
+    if (sharded) checkHaloPeers(comm, peers, std::min<int>(nSlots, (int)d->halo.size()));
     SolveHooks hooks;
     if (comm && comm->nRanks > 1)
         hooks.allreduce = [&](double* ptr, int n) { RCCL_CHECK(rcclRef().allReduce(ptr, ptr, (size_t)n, ncclFloat64, ncclSum, comm->comm, d->stream)); };

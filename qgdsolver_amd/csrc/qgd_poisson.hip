@@ -748,6 +748,7 @@ struct PressureSolver {
     int passes = 2;
     double saTheta = 0.08;
     int denseMax = 2048;                   // QGD_MG_DENSE_MAX
+    int64_t distMaxCells = 20000000;       // QGD_MG_DIST_MAX_CELLS: above it a sharded solve keeps the rank-local hierarchy (distSetupStep)
     int rowRun = 0;                        // QGD_ROW_XCD_RUN: row blocks per XCD run of the sliced-ELL sweeps (xcdRunBlock), 0: plain order (measured: runs of 16 make the f32 sweeps 1 % slower)
     // ---- a hierarchy that SPANS THE RANKS of a sharded solve (QGD_MG_DIST, default on; 0: the rank-local block hierarchy) ----------------
     // A rank-local hierarchy is block Jacobi: 7 -> 65 / 97 / 140 iterations on 2 / 4 / 8 shards of a 128^3 box.  Here level 0 stays
@@ -1388,6 +1389,7 @@ PressureSolver* pressureSolverCreate(hipStream_t stream, const MeshView& m, cons
         S->rowRun = (int)knob("QGD_ROW_XCD_RUN", 0, 0, 4096);
         S->denseMax = (int)knob("QGD_MG_DENSE_MAX", MG_DENSE_MAX, 64, 8192);  // the last level (solved exactly) has at most this many rows
         if (sa) S->oc = knob("QGD_MG_OC", 1.0, 0.5, 3.0);
+        S->distMaxCells = (int64_t)knob("QGD_MG_DIST_MAX_CELLS", (double)S->distMaxCells, 0, 2.0e9);
         // a shard with smoothed aggregation and the single-precision cycle builds the hierarchy that spans the ranks, at its first solve
         const bool distWanted = sharded && precond == 1 && sa && S->f32 && knob("QGD_MG_DIST", 1, 0, 1) != 0;
         const int nC = m.nC, nF = m.nF, ob = S->ob, oe = S->oe, nRows = oe - ob, nb = blocksOf(nRows);
@@ -1509,8 +1511,16 @@ static bool distSetupStep(PressureSolver* S) {
         PCHECK(hipMemcpyAsync(v, D.buf, sizeof(v), hipMemcpyDeviceToHost, stream));
         PCHECK(hipStreamSynchronize(stream));
         D.nCg = (int64_t)v[0]; D.K = (int)v[1];
-        if (D.nCg <= S->denseMax || D.nCg >= 0x7fffffffLL || D.nCg == nOwned) {
-            if (std::getenv("QGD_MG_VERBOSE")) std::fprintf(stderr, "[qgd mg] rank-local hierarchy: %lld cells in all, %d here\n", (long long)D.nCg, nOwned);
+        // The hierarchy that spans the ranks REPLICATES the global matrix: every rank gathers nCg (1 + 2K) doubles (host and device),
+        // rebuilds the global rows and coarsens them on its own host -- set-up time and memory grow with the GLOBAL cell count, on every
+        // rank of the node at once (64 M cells, K = 3: 3.6 GB per buffer per rank, a 64 M-row host coarsening times eight).  Above
+        // distMaxCells (default 20 M: config 5's 16 M cells fit, 1.2 GB per buffer) the rank-local hierarchy is kept and said so.
+        const bool tooLarge = D.nCg > S->distMaxCells;
+        if (D.nCg <= S->denseMax || D.nCg >= 0x7fffffffLL || D.nCg == nOwned || tooLarge) {
+            if (tooLarge)
+                std::fprintf(stderr, "[qgd mg] %lld cells in all exceed QGD_MG_DIST_MAX_CELLS = %lld: the multigrid hierarchy stays rank-local "
+                                     "(block Jacobi across the shards; expect more pressure iterations)\n", (long long)D.nCg, (long long)S->distMaxCells);
+            else if (std::getenv("QGD_MG_VERBOSE")) std::fprintf(stderr, "[qgd mg] rank-local hierarchy: %lld cells in all, %d here\n", (long long)D.nCg, nOwned);
             distBlockFallback(S); D.built = true; return true;
         }
         // this rank's share of the global matrix: the diagonal of its cells and, per cell, its couplings to higher-numbered neighbours

@@ -115,7 +115,9 @@ StaticData buildStaticData(const HostMesh& m) {
 
     // hQGDf of cut-plane faces as the unsharded mesh has it (HostMesh::haloFaceH), by boundary-face index; -1: not given
     std::vector<double> haloH((size_t)nBF, -1.0);
-    {
+    size_t nHaloFaces = 0;
+    for (const Patch& pt : m.patches) if (pt.type == QGD_PATCH_HALO) nHaloFaces += (size_t)pt.size;
+    if (m.haloFaceH.size() == nHaloFaces) {   // a list of another length belongs to other face lists: ignored (local rule)
         size_t k = 0;
         for (const Patch& pt : m.patches)
             if (pt.type == QGD_PATCH_HALO)

@@ -35,7 +35,7 @@ static void qgdCheck(int status, const char* where)
 
 Foam::fvsc::hipStencil::hipStencil(const IOobject& io, const word& targetWord)
 :
-    fvscStencil(io), hmesh_(nullptr), hdev_(nullptr), stencilId_(-1)
+    fvscStencil(io), hmesh_(nullptr), hdev_(nullptr), stencilId_(-1), correctBCs_(targetWord == "GaussVolPoint")
 {
     uploadMesh(targetWord);
 }
@@ -49,6 +49,24 @@ Foam::fvsc::hipStencil::~hipStencil()
 void Foam::fvsc::hipStencil::uploadMesh(const word& targetWord)
 {
     const fvMesh& mesh = mesh_;
+    // The reference's stencils serve processor patches (patchNeighbourField: GaussVolPointBase3D_8C L588, L688, L785, L882;
+    // extendedFaceStencilScalarGrad_8C L116-268).  This adapter does not yet: QGD_PATCH_HALO means "ghost cells behind the
+    // patch", and a decomposed OpenFOAM mesh has none.  Refuse instead of answering wrongly under mpirun.
+    if (Pstream::parRun())
+    {
+        FatalErrorIn("hipStencil::uploadMesh")
+            << "hip* fvsc stencils do not serve decomposed cases yet (Pstream::parRun()): run undecomposed, or shard "
+            << "inside the library (qgd_mesh_shard / qgd_case_step_sharded, INTEGRATION.md)" << nl << exit(FatalError);
+    }
+    forAll(mesh.boundary(), patchi)
+    {
+        if (isA<processorFvPatch>(mesh.boundary()[patchi]) && mesh.boundary()[patchi].size() > 0)
+        {
+            FatalErrorIn("hipStencil::uploadMesh")
+                << "patch " << mesh.boundary()[patchi].name() << " is a processor patch with faces; hip* fvsc stencils "
+                << "do not serve processor patches yet" << nl << exit(FatalError);
+        }
+    }
     const faceList& faces = mesh.faces();
     labelList offsets(faces.size() + 1, 0);
     forAll(faces, f) { offsets[f + 1] = offsets[f] + faces[f].size(); }
@@ -67,7 +85,6 @@ void Foam::fvsc::hipStencil::uploadMesh(const word& targetWord)
           : isA<symmetryPlaneFvPatch>(fvp) ? QGD_PATCH_SYMMETRYPLANE
           : isA<symmetryFvPatch>(fvp)      ? QGD_PATCH_SYMMETRY
           : isA<wedgeFvPatch>(fvp)         ? QGD_PATCH_WEDGE
-          : isA<processorFvPatch>(fvp)     ? QGD_PATCH_HALO
           : isA<coupledFvPatch>(fvp)       ? QGD_PATCH_CYCLIC
           :                                  QGD_PATCH_GENERIC;
     }
@@ -153,8 +170,9 @@ Foam::fvsc::hipStencil::wrap(const word& name, const dimensionSet& dims, const L
 
 Foam::tmp<Foam::surfaceVectorField> Foam::fvsc::hipStencil::Grad(const volScalarField& vF)
 {
-    // GaussVolPoint re-evaluates the BCs of its input first [GaussVolPointStencil_8C L73]; keep that side effect
-    const_cast<volScalarField&>(vF).correctBoundaryConditions();
+    // GaussVolPoint re-evaluates the BCs of its input first [GaussVolPointStencil_8C L73]; keep that side effect for
+    // that word only (reduced and leastSquares never do: reducedFaceNormalStencil_8C L69-108)
+    refreshPatches(vF);
     List<scalar> bnd, out(mesh_.nFaces()*3);
     flattenBoundary(vF, bnd);
     qgdCheck(qgd_fvsc_grad_s(hdev_, stencilId_, vF.primitiveField().cdata(), bnd.cdata(), out.data()), "hipStencil::Grad");
@@ -163,7 +181,7 @@ Foam::tmp<Foam::surfaceVectorField> Foam::fvsc::hipStencil::Grad(const volScalar
 
 Foam::tmp<Foam::surfaceTensorField> Foam::fvsc::hipStencil::Grad(const volVectorField& iVF)
 {
-    const_cast<volVectorField&>(iVF).correctBoundaryConditions();
+    refreshPatches(iVF);
     List<scalar> bnd, out(mesh_.nFaces()*9);
     flattenBoundary(iVF, bnd);
     qgdCheck
@@ -176,7 +194,7 @@ Foam::tmp<Foam::surfaceTensorField> Foam::fvsc::hipStencil::Grad(const volVector
 
 Foam::tmp<Foam::surfaceScalarField> Foam::fvsc::hipStencil::Div(const volVectorField& iVF)
 {
-    const_cast<volVectorField&>(iVF).correctBoundaryConditions();
+    refreshPatches(iVF);
     List<scalar> bnd, out(mesh_.nFaces());
     flattenBoundary(iVF, bnd);
     qgdCheck
@@ -189,7 +207,7 @@ Foam::tmp<Foam::surfaceScalarField> Foam::fvsc::hipStencil::Div(const volVectorF
 
 Foam::tmp<Foam::surfaceVectorField> Foam::fvsc::hipStencil::Div(const volTensorField& iTF)
 {
-    const_cast<volTensorField&>(iTF).correctBoundaryConditions();
+    refreshPatches(iTF);
     List<scalar> bnd, out(mesh_.nFaces()*3);
     flattenBoundary(iTF, bnd);
     qgdCheck

@@ -84,7 +84,11 @@ class Device:
             for h in getattr(self, "_case_handles", ()):
                 h.free()
             self._case_handles = []
-            L.lib.qgd_device_free(self._h)
+            # qgd_device_free refuses (and frees nothing) while a case created on the device is still open -- one made through the
+            # raw C entry and never adopted here, say.  Keep the handle then, so the free can be retried, and say so.
+            rc = L.lib.qgd_device_free(self._h)
+            if rc != 0:
+                raise RuntimeError("qgd_device_free: " + L.lib.qgd_last_error().decode())
             self._h = None
 
     def __del__(self):

@@ -196,8 +196,12 @@ def test_multigrid_hierarchy_spans_the_ranks(cut, world, monkeypatch):
     whole.step(steps)
     assert whole.info()["mgLevels"] >= 2
     iters = {}
-    for dist in ("1", "0"):
-        monkeypatch.setenv("QGD_MG_DIST", dist)
+    # "cap": the hierarchy that spans the ranks replicates the global matrix on every rank, so above QGD_MG_DIST_MAX_CELLS (default
+    # 20 M cells) a solve keeps the rank-local hierarchy and says so on stderr -- same answer, the iterations of QGD_MG_DIST=0
+    for dist in ("1", "0", "cap"):
+        monkeypatch.setenv("QGD_MG_DIST", "0" if dist == "0" else "1")
+        if dist == "cap":
+            monkeypatch.setenv("QGD_MG_DIST_MAX_CELLS", "1000")
         shards = make()
         pairs = [make_device_shard_case(sh, opt, cavity_bcs, fields) for sh in shards]
         cases = [c for _, c in pairs]
@@ -214,6 +218,7 @@ def test_multigrid_hierarchy_spans_the_ranks(cut, world, monkeypatch):
             c.close(); d.close()
     assert iters["1"] <= whole.info()["pIterations"] + 2, (iters, whole.info())
     assert iters["0"] > iters["1"], iters
+    assert iters["cap"] == iters["0"], iters
     whole.close(); gdev.close()
 
 

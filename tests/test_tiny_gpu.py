@@ -152,3 +152,20 @@ def test_device_free_is_refused_while_its_cases_are_open():
     case.close()
     assert L.lib.qgd_device_free(dev._h) == L.QGD_OK
     dev._h = None
+
+
+def test_device_close_keeps_its_handle_when_the_free_is_refused():
+    """Device.close() with a case it does not know about (created through the raw C entry, never adopted): the library refuses the free,
+    close() raises with the library's message and keeps the handle, so the free can be retried once the case is gone."""
+    import ctypes as C
+    mesh = q.PolyMesh.box(3, 2, 2)
+    dev = q.Device(mesh)
+    opt = q.default_options(deltaT=1e-3)
+    raw = C.c_void_p()
+    assert L.lib.qgd_case_create(dev._h, C.byref(opt), C.byref(raw)) == L.QGD_OK
+    with pytest.raises(RuntimeError, match="still open"):
+        dev.close()
+    assert dev._h                     # not leaked: still there to be freed
+    assert L.lib.qgd_case_free(raw) == L.QGD_OK
+    dev.close()
+    assert dev._h is None
