@@ -8,7 +8,15 @@ uniform hex cells in blockMesh numbering, all six patches zeroGradient, fvsc Gau
 step (one cell plane + its patch faces per neighbour).
 
 A step = one pass of the QGDFoam loop body (flux assembly + cell update + BC refresh), inputs resident in HBM.
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0.  Beside the contract's keys the line carries
+  N = 1: `secondary` {qhd_n200, implicit_n200} -- the QHDFoam step and the implicitDiffusion step, 20 timed steps each, as child
+         processes after the headline (--no-secondary skips them), `dropin_fvsc`, `cpu_baseline`;
+  N > 1: `native_transport` {ms_per_step, value, checksum_rho, rccl_ranks} -- the same run repeated by a second, fresh set of ranks
+         over the library's own RCCL path (qgd_case_step_sharded, the C-ABI a C++/MPI host calls; --no-native-line skips it);
+  always: `config.rccl_ranks` (ranks the halo communicator reports), `config.env` (every QGD_* variable that was set).
+Without a launcher around it `--gpus N` starts its own ranks; that relay parent never touches the GPU and enforces
+QGD_BENCH_DEADLINE_S (default 900 s: children killed, status 124).  Ranks started by torch.distributed.run carry the same
+deadline as a watchdog timer.
 """
 import argparse
 import json
@@ -22,6 +30,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import numpy as np  # noqa: E402
 
+T_START = time.perf_counter()
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 # ALGORITHMIC bytes of the fused face kernel as SURVEY.md 8(d) defines them (the figure `roofline.achieved` is quoted on):
 # per internal face 144 B streamed in (owner+neighbour 8, Sf 24, weight 8, hQGDf 8, 9 Gauss coefficients + 1/V 80, 4 vertex
@@ -63,6 +72,10 @@ def parse():
                     help="gloo = debugging aid: all ranks share GPU 0 and halo messages are staged through host memory")
     ap.add_argument("--halo", default=os.environ.get("QGD_BENCH_HALO", "torch"), choices=["torch", "native"],
                     help="halo transport: torch.distributed P2P (default) or the library's own RCCL path (qgd_case_step_sharded)")
+    ap.add_argument("--no-native-line", action="store_true",
+                    help="N > 1: skip the second set of ranks that repeats the run over the library's own RCCL transport (native_transport)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="N = 1: skip the two secondary lines (QHDFoam step and implicitDiffusion step at 200^3) appended under `secondary`")
     ap.add_argument("--check", action="store_true", help="print a checksum of the owned cells (to compare runs at different N)")
     ap.add_argument("--cpu-n", type=int, default=64, help="edge of each CPU-baseline rank's sample box")
     ap.add_argument("--cpu-steps", type=int, default=24)
@@ -268,43 +281,86 @@ def host_cpu_quota():
     return max(1, cpus)
 
 
-def self_launch(n_ranks):
-    """`python bench.py --gpus N` without a launcher around it: start N rank processes (one per GPU) as plain children
-    BEFORE this process imports torch or touches HIP, relay rank 0's JSON line and exit with the worst child status.
-    Nothing is re-exec'ed: the parent stays a relay that never initialises the GPU.  Host set-up of the library is OpenMP:
-    every rank gets cpu_quota // N threads so that N ranks do not oversubscribe the cgroup."""
+def qgd_env():
+    """every QGD_* variable set in this process's environment: they select code paths inside the library and the bench, so the line
+    records them (a stray variable on the GPU box would otherwise change what is measured without a trace)"""
+    return {k: v for k, v in sorted(os.environ.items()) if k.startswith("QGD_")}
+
+
+def bench_deadline_s():
+    try:
+        return float(os.environ.get("QGD_BENCH_DEADLINE_S", "900"))
+    except ValueError:
+        return 900.0
+
+
+def arm_watchdog(seconds, what):
+    """A rank started by somebody else's launcher (torch.distributed.run) has no relay parent of ours to end a hung collective: a
+    daemon timer ends THIS process instead (collectives and synchronize release the GIL).  Exit status 124 like timeout(1)."""
+    import threading
+
+    def fire():
+        print(f"bench.py: {what} exceeded QGD_BENCH_DEADLINE_S = {seconds:.0f} s; giving up", file=sys.stderr, flush=True)
+        os._exit(124)
+
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    return t
+
+
+def launch_ranks(n_ranks, argv, deadline_s, cmd=None):
+    """Start n_ranks rank processes (one per GPU) as plain children, wait for them under a deadline, return
+    {"line": rank 0's JSON line or None, "rc": worst status, "timed_out": bool, "stderr": rank 0's last stderr lines}.
+    A rank that dies takes the job with it (its peers would wait in the rendezvous or the first exchange for ever); when the
+    deadline passes every child is killed.  The caller never touches the GPU through this function.  Host set-up of the library
+    is OpenMP: every rank gets cpu_quota // N threads so that N ranks do not oversubscribe the cgroup.  Variables a surrounding
+    torch.distributed.run set for ITS ranks are not handed down (TORCHELASTIC_USE_AGENT_STORE would make rank 0 look for the agent's
+    store instead of opening its own)."""
     import socket
     import subprocess
+    import tempfile
 
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
     threads = max(1, host_cpu_quota() // n_ranks)
+    base = {k: v for k, v in os.environ.items()
+            if not (k.startswith("TORCHELASTIC_") or k in ("GROUP_RANK", "ROLE_RANK", "ROLE_NAME", "ROLE_WORLD_SIZE", "GROUP_WORLD_SIZE",
+                                                            "LOCAL_WORLD_SIZE", "TORCH_NCCL_ASYNC_ERROR_HANDLING", "OMP_NUM_THREADS_SET_BY_TORCHRUN"))}
     procs = []
+    err0 = tempfile.TemporaryFile(mode="w+")
     for r in range(n_ranks):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        env.setdefault("OMP_NUM_THREADS", str(threads))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
-    worst = 0
-    line = None
+        if "OMP_NUM_THREADS" not in os.environ or "TORCHELASTIC_RUN_ID" in os.environ:   # torchrun pins 1 thread per rank: not ours
+            env["OMP_NUM_THREADS"] = str(threads)
+        procs.append(subprocess.Popen((cmd or [sys.executable, os.path.abspath(__file__)]) + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                                      stderr=err0 if r == 0 else None, text=(r == 0)))
+    worst, line, timed_out = 0, None, False
+    t_end = time.time() + deadline_s
     try:
-        # rank 0's stdout is the result line; the others only have a status.  A rank that dies takes the job with it
-        # (its peers would wait in the rendezvous or the first exchange for ever).
+        import threading
+        box = {}
+        reader = threading.Thread(target=lambda: box.setdefault("out", procs[0].stdout.read()), daemon=True)
+        reader.start()   # rank 0's stdout is drained while we wait, so a long line cannot block it
         while any(pr.poll() is None for pr in procs):
-            dead = [pr for pr in procs if pr.poll() not in (None, 0)]
-            if dead:
-                for pr in procs:
-                    if pr.poll() is None:
-                        pr.kill()
+            if [pr for pr in procs if pr.poll() not in (None, 0)]:
+                break
+            if time.time() > t_end:
+                timed_out = True
                 break
             time.sleep(0.2)
-        out, _ = procs[0].communicate()
+        if timed_out or [pr for pr in procs if pr.poll() not in (None, 0)]:
+            for pr in procs:
+                if pr.poll() is None:
+                    pr.kill()
         for pr in procs:
             rc = pr.wait()
             worst = max(worst, abs(rc)) if rc else worst
-        for ln in (out or "").splitlines():
+        reader.join(10)
+        for ln in (box.get("out") or "").splitlines():
             if ln.startswith("{"):
                 line = ln
             elif ln.strip():
@@ -313,11 +369,79 @@ def self_launch(n_ranks):
         for pr in procs:
             if pr.poll() is None:
                 pr.kill()
-    if line:
-        print(line, flush=True)
+    err0.seek(0)
+    tail = err0.read().splitlines()[-12:]
+    err0.close()
+    if timed_out:
+        worst = 124
+    return {"line": line, "rc": worst, "timed_out": timed_out, "stderr": tail}
+
+
+def self_launch(n_ranks):
+    """`python bench.py --gpus N` without a launcher around it: start N rank processes BEFORE this process imports torch or touches
+    HIP, relay rank 0's JSON line and exit with the worst child status.  Nothing is re-exec'ed: the parent stays a relay that never
+    initialises the GPU, and it holds the deadline (QGD_BENCH_DEADLINE_S, default 900 s): a hung collective ends with the children
+    killed and status 124 instead of burning the caller's whole timeout."""
+    deadline = bench_deadline_s()
+    res = launch_ranks(n_ranks, sys.argv[1:], deadline)
+    for ln in res["stderr"]:
+        print(ln, file=sys.stderr)
+    if res["timed_out"]:
+        print(f"bench.py: the ranks did not finish within QGD_BENCH_DEADLINE_S = {deadline:.0f} s; killed", file=sys.stderr)
+    worst = res["rc"]
+    if res["line"] and not res["timed_out"]:
+        print(res["line"], flush=True)
     elif worst == 0:
         worst = 1
     sys.exit(min(worst, 255))
+
+
+def child_line(argv, timeout_s):
+    """one bench.py child process (a one-GPU line of another workload, started after this process has released its device
+    memory): its parsed JSON line, or {"error": ...}.  A child, never an exec: this process has initialised the GPU."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")
+           and not k.startswith("TORCHELASTIC_")}
+    try:
+        pr = subprocess.run([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, capture_output=True, text=True, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return {"error": f"no result within {timeout_s:.0f} s"}
+    lines = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
+    if pr.returncode != 0 or not lines:
+        return {"error": f"status {pr.returncode}", "stderr": pr.stderr.splitlines()[-6:]}
+    return json.loads(lines[-1])
+
+
+def secondary_lines(args):
+    """The two workloads the headline never touches (qgd_poisson.hip + qgd_qhd.hip, qgd_implicit.hip), 20 timed steps each after
+    warm-up at 200^3, as child processes once the headline's device memory is released.  Same keys as the stand-alone lines
+    (`--workload qhd`, `--workload implicit`), cut to what a reader compares."""
+    keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "config", "roofline", "phase_ms", "step_roofline_frac", "setup_s", "error", "stderr")
+    out = {}
+    n = os.environ.get("QGD_BENCH_SECONDARY_N", "200")   # tests shrink it; any value but 200 is visible in the key and in config.env
+    for key, argv in ((f"qhd_n{n}", ["--workload", "qhd", "--edge", n, "--steps", "20", "--warmup", "10"]),
+                      (f"implicit_n{n}", ["--workload", "implicit", "--edge", n, "--steps", "20", "--warmup", "5"])):
+        t0 = time.perf_counter()
+        d = child_line(argv, 420)
+        out[key] = {k: d[k] for k in keep if k in d}
+        out[key]["wall_s"] = time.perf_counter() - t0
+    return out
+
+
+def native_transport_line(args, world, t_budget_s):
+    """N > 1: the same run again on a FRESH set of ranks whose halo transport is the library's own RCCL path
+    (qgd_case_step_sharded -- what a C++/MPI host of the C-ABI uses; torch.distributed only carries the unique id and the timing
+    barrier there, over gloo).  Returns what the first line is compared on, or {"error": ...}: the second set must never cost the
+    first line."""
+    argv = ["--gpus", str(world), "--steps", str(args.steps), "--warmup", str(args.warmup), "--edge", str(args.n), "--backend", args.backend,
+            "--halo", "native", "--no-native-line", "--no-secondary", "--no-cpu-baseline", "--no-dropin", "--check"]
+    res = launch_ranks(world, argv, t_budget_s)
+    if not res["line"] or res["rc"]:
+        return {"error": ("no result within %.0f s" % t_budget_s) if res["timed_out"] else f"status {res['rc']}", "stderr": res["stderr"][-6:]}
+    d = json.loads(res["line"])
+    return {"ms_per_step": d["ms_per_step"], "value": d["value"], "checksum_rho": d.get("checksum_rho"), "transport": d["config"].get("transport"),
+            "rccl_ranks": d["config"].get("rccl_ranks"), "overlap_selfcheck_rel": d.get("overlap_selfcheck_rel"),
+            "partition": d["config"].get("partition")}
 
 
 # ---- QHDFoam (config 5) -----------------------------------------------------------------------------------------------
@@ -410,7 +534,7 @@ def qhd_line(args):
                                 + ("config-5 stand-in mesh (jittered hexahedra, every 7th quad split into triangles, Morton order)" if args.irregular
                                    else "uniform hex box (blockMesh numbering)")
                                 + ", GaussVolPoint, HbyUQHD, pressure equation to 1e-8 with multigrid-preconditioned CG"),
-                   "cells": nc, "pressure_iterations_per_step": it, "multigrid_levels": info["mgLevels"]},
+                   "cells": nc, "pressure_iterations_per_step": it, "multigrid_levels": info["mgLevels"], "env": qgd_env()},
         "roofline": {"bound": "hbm", "kernel": "mgSmoothKernel<float>, multigrid level 0 (one damped-Jacobi sweep of the pressure preconditioner)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS if achieved else None,
                      "traffic": secondary_traffic("qhd_n200") if (n == 200 and not args.irregular) else None, "traffic_is_static": True,
@@ -486,7 +610,7 @@ def implicit_line(args):
         "config": {"workload": (f"QGDFoam {n}^3 = {nc / 1e6:.1f}M-cell uniform hex box (blockMesh numbering), GaussVolPoint, constScPrModel1, "
                                 "implicitDiffusion true (the reference's default), mu = 1e-3, zeroGradient patches, fixed deltaT, "
                                 "U and e systems by Jacobi-PCG to 1e-10"),
-                   "cells": nc, "iterations_U": it_u, "iterations_e": it_e, "unconverged_steps": solves["unconverged_steps"]},
+                   "cells": nc, "iterations_U": it_u, "iterations_e": it_e, "unconverged_steps": solves["unconverged_steps"], "env": qgd_env()},
         "roofline": {"bound": "hbm", "kernel": "iApplyKernel<3,1> (matrix product of the three-component U system, one walk of the matrix for the three right-hand sides)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS if achieved else None,
                      "traffic": secondary_traffic("implicit_n200") if n == 200 else None, "traffic_is_static": True,
@@ -520,7 +644,9 @@ def qhd_line_sharded(args):
         raise RuntimeError("bench.py needs a HIP device: qgdsolver_amd has no CPU fallback")
     torch.cuda.set_device(local_rank)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group(backend="gloo") if staged else dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    # torch.distributed is the control plane only (unique id, timing barrier, checksum) and runs over gloo on the host: the data path
+    # is the library's own RCCL communicator, and no second RCCL instance is initialised in the process
+    dist.init_process_group(backend="gloo")
     n = args.n
     t_setup = time.perf_counter()
     if args.irregular:
@@ -587,11 +713,11 @@ def qhd_line_sharded(args):
     run(args.steps)
     case.sync()
     dist.barrier()
-    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=None if staged else "cuda")
+    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
     info = case.info()
-    check = torch.tensor([float(np.abs(case.field("p")[: min(owned, mesh.nCells)]).sum())], dtype=torch.float64, device=None if staged else "cuda")
+    check = torch.tensor([float(np.abs(case.field("p")[: min(owned, mesh.nCells)]).sum())], dtype=torch.float64)
     dist.all_reduce(check, op=dist.ReduceOp.SUM)
     if rank == 0:
         print(json.dumps({
@@ -603,7 +729,8 @@ def qhd_line_sharded(args):
                                        else "uniform hex box cut into k-slabs")
                                     + ", GaussVolPoint, HbyUQHD, pressure equation to 1e-8, multigrid hierarchy spanning the ranks"),
                        "cells": n_global, "cells_per_gpu": n_global // world, "transport": transport,
-                       "pressure_iterations_per_step": info["pIterations"], "multigrid_levels": info["mgLevels"]},
+                       "pressure_iterations_per_step": info["pIterations"], "multigrid_levels": info["mgLevels"],
+                       "rccl_ranks": None if staged else comm.info()["ranks"], "env": qgd_env()},
             "roofline": {"bound": "hbm", "kernel": "distributed level 0 of the multigrid cycle: no separate sweep timing on shards", "achieved": None,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None},
             "pressure_final_residual": info["pFinalResidual"], "first_steps_s": t_first, "setup_s": t_setup,
@@ -638,6 +765,11 @@ def main():
         return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.cpu_only:
         self_launch(args.gpus)   # never returns
+    if "TORCHELASTIC_RUN_ID" in os.environ and os.environ.get("OMP_NUM_THREADS") == "1":
+        # torch.distributed.run pins one OpenMP thread per rank; the library's host set-up (mesh tables) is OpenMP and not timed
+        os.environ["OMP_NUM_THREADS"] = str(max(1, host_cpu_quota() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))))
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1:
+        arm_watchdog(bench_deadline_s(), f"rank {os.environ.get('RANK', '?')}")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -663,10 +795,13 @@ def main():
     staged = args.backend == "gloo"
     if staged:
         local_rank = 0  # every rank on GPU 0; exercises the multi-rank logic on a 1-GPU box
+    # --halo native: the DATA path is the library's own RCCL communicator; torch.distributed only carries the unique id, the timing
+    # barrier and the checksum, over gloo on the host, so that no second RCCL instance is initialised in the process
+    ctrl_host = staged or (args.halo == "native" and world > 1)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if staged:
+        if ctrl_host:
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
@@ -713,7 +848,11 @@ def main():
 
     ov = os.environ.get("QGD_BENCH_OVERLAP", "1")
     overlap = (world > 1) and ov != "0" and (not staged or ov == "force")
-    native = (args.halo == "native") and world > 1 and not staged
+    if staged and args.halo == "native":
+        raise RuntimeError("--halo native needs one GPU per rank: RCCL refuses two ranks of one communicator on the same device "
+                           "(\"Duplicate GPU detected\"), so the gloo debugging mode (every rank on GPU 0) cannot stand in for it")
+    native = (args.halo == "native") and world > 1
+    rccl_ranks = None if (world == 1 or staged) else dist.get_world_size()   # torch's communicator (staged: gloo, no RCCL at all)
     if native:
         # the library's own transport: communicator bootstrapped like an MPI host would (id from rank 0, broadcast by the launcher)
         from qgdsolver_amd.halo import NativeComm
@@ -724,6 +863,7 @@ def main():
             return box[0]
 
         comm = NativeComm(local_rank, rank, world, bcast=bcast)
+        rccl_ranks = comm.info()["ranks"]           # ncclCommCount of the library's communicator: what RCCL itself saw
         peers = [rank - 1 if rank > 0 else -1, rank + 1 if rank < world - 1 else -1]
         exchange = lambda: comm.exchange(case, peers)  # noqa: E731
 
@@ -750,7 +890,7 @@ def main():
     def owned_checksum():
         plane = n * n
         r = case.field("rho")[plane * (lo - k_lo): plane * (hi - k_lo)]
-        t = torch.tensor([float(r.sum()), float((r * r).sum())], dtype=torch.float64, device="cpu" if staged else "cuda")
+        t = torch.tensor([float(r.sum()), float((r * r).sum())], dtype=torch.float64, device="cpu" if ctrl_host else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return [float(x) for x in t]
 
@@ -804,7 +944,7 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if staged else "cuda")
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if ctrl_host else "cuda")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -813,7 +953,7 @@ def main():
         plane = n * n
         rho_owned = case.field("rho")[plane * (lo - k_lo): plane * (hi - k_lo)]
         cs = torch.tensor([float(rho_owned.sum()), float((rho_owned ** 2).sum())], dtype=torch.float64,
-                          device="cpu" if staged else "cuda")
+                          device="cpu" if ctrl_host else "cuda")
         if world > 1:
             dist.all_reduce(cs, op=dist.ReduceOp.SUM)
         checksum = [float(x) for x in cs]
@@ -862,10 +1002,14 @@ def main():
                 "partition": (f"{world} k-slab(s), 1 ghost plane per cut, one send/recv pair per neighbour per step"
                               + (", exchange overlapped with the cell update" if overlap else "")) if world > 1 else "single shard",
                 "transport": (("gloo, host-staged (debugging mode: every rank on GPU 0)" if staged else
-                               ("RCCL inside the library (qgd_case_step_sharded)" if native else "RCCL through torch.distributed P2P"))
+                               ("RCCL inside the library (qgd_case_step_sharded; torch.distributed over gloo only for the unique id, the timing "
+                                "barrier and the checksum)" if native else "RCCL through torch.distributed P2P"))
                               if world > 1 else None),
                 "host_threads_per_rank": int(os.environ.get("OMP_NUM_THREADS", "0")) or None,
                 "stencil": "GaussVolPoint",
+                "rccl_ranks": rccl_ranks,   # ranks the communicator carrying the halo messages reports (None: one rank, or gloo staging)
+                "halo_message_bytes": {"per_ghost_cell": 80, "per_ghost_patch_face": 96} if world > 1 else None,
+                "env": qgd_env(),
             },
             "roofline": {
                 "bound": "hbm",
@@ -918,7 +1062,26 @@ def main():
                 pass
     case.close()
     dev.close()
+    if native:
+        comm.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()   # the other ranks leave now; rank 0 may still start the second set of ranks below
     if rank == 0:
+        if world > 1 and not native and not staged and not args.no_native_line:
+            left = bench_deadline_s() - (time.perf_counter() - T_START)
+            try:
+                out["native_transport"] = (native_transport_line(args, world, min(420.0, left - 30.0)) if left > 90.0
+                                           else {"error": "no time left before QGD_BENCH_DEADLINE_S"})
+            except Exception as e:   # the second set of ranks must never cost the first line
+                out["native_transport"] = {"error": repr(e)}
+        elif world > 1 and staged and not args.no_native_line:
+            out["native_transport"] = {"skipped": "gloo debugging mode: every rank sits on GPU 0 and RCCL refuses two ranks of one communicator on one device"}
+        if world == 1 and not args.no_secondary and args.workload == "qgd":
+            try:
+                out["secondary"] = secondary_lines(args)
+            except Exception as e:
+                out["secondary"] = {"error": repr(e)}
         if world == 1 and not args.no_dropin:
             try:
                 out["dropin_fvsc"] = dropin_fvsc_line(q, args.dropin_n, 3)
@@ -928,8 +1091,6 @@ def main():
             ranks = args.cpu_ranks or cpu_rank_budget(args.cpu_n)
             out["cpu_baseline"] = cpu_baseline(args.cpu_n, args.cpu_steps, ranks)
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -624,6 +624,9 @@ typedef struct qgd_comm_s* qgd_comm_t;
 int qgd_comm_unique_id(void* id128);
 int qgd_comm_create(int deviceId, int rank, int nRanks, const void* id128, qgd_comm_t* out);
 int qgd_comm_free(qgd_comm_t comm);
+/* info = {this rank (ncclCommUserRank), ranks RCCL itself counts in the communicator (ncclCommCount), HIP device (ncclCommCuDevice)}:
+ * what the transport SAW, for logs and bench lines -- not what the caller asked for */
+int qgd_comm_info(qgd_comm_t comm, int32_t info[3]);
 /* pack -> send/recv with peers[slot] (rank behind each halo slot; < 0: skip the slot) -> unpack, stream-ordered on the
  * case's stream, buffers owned by the library.  No-op for an unsharded case. */
 int qgd_case_halo_exchange(qgd_case_t c, qgd_comm_t comm, const int32_t* peers, int nSlots);

@@ -164,6 +164,7 @@ SIGNATURES = {
     "qgd_comm_unique_id": (C.c_int, [C.c_void_p]),
     "qgd_comm_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, handle_p]),
     "qgd_comm_free": (C.c_int, [handle]),
+    "qgd_comm_info": (C.c_int, [handle, c_int32_p]),
     "qgd_case_halo_exchange": (C.c_int, [handle, handle, c_int32_p, C.c_int]),
     "qgd_case_allreduce_max": (C.c_int, [handle, handle]),
     "qgd_case_step_sharded": (C.c_int, [handle, handle, c_int32_p, C.c_int, C.c_int]),

@@ -1247,7 +1247,7 @@ int qgd_case_create(qgd_device_t d, const qgd_case_options* opt, qgd_case_t* out
         c->dev = d; c->opt = *opt; c->stencil = st;
         c->usesPoints = (st == ST_GVP3 || st == ST_GVP2);
         GasModel& g = c->gas;
-        g.R = opt->R; g.Cv = opt->Cv; g.mu0 = opt->mu; g.Pr = opt->Pr; g.ScQGD = opt->ScQGD; g.PrQGD = opt->PrQGD;
+        g.R = opt->R; g.Cv = opt->Cv; g.mu0 = opt->mu; g.Pr = opt->Pr; g.ScQGD = opt->ScQGD; g.PrQGD = opt->PrQGD; g.rPrQGD = 1.0 / opt->PrQGD;
         g.alphaQGD = opt->alphaQGD;
         g.consistentEnergy = opt->consistentEnergy ? 1 : 0;
         g.implicitDiffusion = opt->implicitDiffusion ? 1 : 0;
@@ -2106,6 +2106,9 @@ struct Rccl {
     decltype(&ncclGroupStart) groupStart = nullptr;
     decltype(&ncclGroupEnd) groupEnd = nullptr;
     decltype(&ncclGetErrorString) errorString = nullptr;
+    decltype(&ncclCommCount) commCount = nullptr;
+    decltype(&ncclCommUserRank) commUserRank = nullptr;
+    decltype(&ncclCommCuDevice) commCuDevice = nullptr;
     std::string why;
 };
 Rccl& rcclRef() {
@@ -2137,6 +2140,9 @@ Rccl& rcclRef() {
     r.groupStart = (decltype(r.groupStart))sym("ncclGroupStart");
     r.groupEnd = (decltype(r.groupEnd))sym("ncclGroupEnd");
     r.errorString = (decltype(r.errorString))sym("ncclGetErrorString");
+    r.commCount = (decltype(r.commCount))sym("ncclCommCount");
+    r.commUserRank = (decltype(r.commUserRank))sym("ncclCommUserRank");
+    r.commCuDevice = (decltype(r.commCuDevice))sym("ncclCommCuDevice");
     return r;
 }
 }  // namespace
@@ -2186,6 +2192,18 @@ int qgd_comm_free(qgd_comm_t c) {
     if (r != ncclSuccess)
         return fail(QGD_ERR_HIP, std::string("qgd_comm_free: ncclCommDestroy: ") + (rcclRef().errorString ? rcclRef().errorString(r) : "RCCL error"));
     return QGD_OK;
+}
+
+int qgd_comm_info(qgd_comm_t c, int32_t info[3]) {
+    QGD_TRY
+    if (!c || !info) return fail(QGD_ERR_INVALID, "qgd_comm_info: null argument");
+    int rank = -1, count = -1, device = -1;
+    RCCL_CHECK(rcclRef().commUserRank(c->comm, &rank));
+    RCCL_CHECK(rcclRef().commCount(c->comm, &count));
+    RCCL_CHECK(rcclRef().commCuDevice(c->comm, &device));
+    info[0] = rank; info[1] = count; info[2] = device;
+    return QGD_OK;
+    QGD_CATCH
 }
 
 static void ensureHaloBuffers(qgd_case_s* c) {

@@ -70,6 +70,7 @@ struct GasModel {
     double alphah0;   // (Cp*mu*rPr)/Cp
     int32_t consistentEnergy;  // qgd_case_options::consistentEnergy
     int32_t implicitDiffusion; // qgd_case_options::implicitDiffusion
+    double rPrQGD;             // 1/PrQGD
 };
 
 // Mutable case state on the device

@@ -94,7 +94,12 @@ __device__ __forceinline__ void qgdFluxes(const FaceState& s, const double* __re
     }
     // energy [L119-139]
     const double phiJmH = phiJm * s.Hf;
+#if QGD_F_DIET
+    const double rrho = rcpNewton(s.rhof);
+    const double pr2 = s.pf * rrho * rrho;
+#else
     const double pr2 = s.pf / s.rhof / s.rhof;
+#endif
     double g2[3], qf[3], piU[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) g2[k] = gE[k] - pr2 * gR[k];
@@ -368,7 +373,11 @@ __device__ __forceinline__ void gvp3Coefs(const int kind, const double4& cO, con
             coef[6 + d] = d24[u] * d31[w2] - d24[w2] * d31[u];
         }
         coef[9] = coef[10] = coef[11] = 0.0;
+#if QGD_F_DIET
+        rV = -rcpNewton(d31[0] * coef[0] + d31[1] * coef[1] + d31[2] * coef[2]);
+#else
         rV = -1.0 / (d31[0] * coef[0] + d31[1] * coef[1] + d31[2] * coef[2]);
+#endif
     } else if (kind == 1) {
         gvpTriCoef(cO, cN, x0, x1, x2, coef, rV);
     } else {
@@ -533,6 +542,9 @@ void faceFluxGvp3Kernel(const MeshView m, const CaseView c, const GasModel gm, c
 // operation order, bit-identical fluxes.
 // ---------------------------------------------------------------------------
 typedef double v2d __attribute__((ext_vector_type(2)));   // one 16-B piece
+#ifndef QGD_F_BUF
+#define QGD_F_BUF 0
+#endif
 #ifndef QGD_FT_WAVES_MIN
 #define QGD_FT_WAVES_MIN 2
 #endif
@@ -591,12 +603,37 @@ void faceFluxGvp3TileKernel(const MeshView m, const CaseView c, const GasModel g
     const v2d* __restrict__ gP = reinterpret_cast<const v2d*>(c.P);
     v2d dA[KC], dB[KB2], dP[KV];
     double dC[KC], dX[KV];
+#if QGD_F_BUF
+    // QGD_F_BUF (compile-time experiment): the piece gathers as raw buffer loads -- a 32-bit byte offset per
+    // load instead of a 64-bit address (one v_lshlrev_b32 in place of v_ashrrev + v_lshl_add_u64); needs every array below 4 GiB
+    (void)gA; (void)gB; (void)gP;
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+    typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)c.A, 0, (int)0xffffffffu, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)c.B, 0, (int)0xffffffffu, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)c.P, 0, (int)0xffffffffu, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc((void*)m.Cc, 0, (int)0xffffffffu, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)m.X, 0, (int)0xffffffffu, 0x00020000);
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+        dA[k] = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(rA, (int)((unsigned)idC[k] << 4), 0, 0));
+        dC[k] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rC, (int)((unsigned)idC[k] << 3), 0, 0));
+    }
+#pragma unroll
+    for (int k = 0; k < KB2; ++k) dB[k] = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(rB, (int)((unsigned)idB[k] << 4), 0, 0));
+#pragma unroll
+    for (int k = 0; k < KV; ++k) {
+        dP[k] = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(rP, (int)((unsigned)idV[k] << 4), 0, 0));
+        dX[k] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rX, (int)((unsigned)idV[k] << 3), 0, 0));
+    }
+#else
 #pragma unroll
     for (int k = 0; k < KC; ++k) { dA[k] = gA[idC[k]]; dC[k] = m.Cc[idC[k]]; }
 #pragma unroll
     for (int k = 0; k < KB2; ++k) dB[k] = gB[idB[k]];
 #pragma unroll
     for (int k = 0; k < KV; ++k) { dP[k] = gP[idV[k]]; dX[k] = m.X[idV[k]]; }
+#endif
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int k = 0; k < KC; ++k) { const int q = tid + k * FB; if (q < 3 * nUc) { sA[q] = dA[k]; sC[q] = dC[k]; } }

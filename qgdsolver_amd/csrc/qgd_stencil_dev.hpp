@@ -12,6 +12,18 @@ namespace qgd {
 
 __device__ __forceinline__ double lerpf(double w, double a, double b) { return w * (a - b) + b; }
 
+// QGD_F_DIET (compile-time experiment): reciprocal by v_rcp_f64 + two Newton steps (~1 ulp) instead of
+// the IEEE division sequence (div_scale x2, rcp, 6 fma, div_fmas, div_fixup) in the face kernels' five divisions
+#ifndef QGD_F_DIET
+#define QGD_F_DIET 0
+#endif
+__device__ __forceinline__ double rcpNewton(const double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return r;
+}
+
 // geometry records are packed triples (24 B): the face kernels pay for every byte their gathers pull in, padding included
 __device__ __forceinline__ double4 ld3(const double* __restrict__ base, const int i) {
     const double* p = base + 3 * (size_t)i;
@@ -365,7 +377,11 @@ __device__ __forceinline__ void blockMaxMin(double a, double b, double* __restri
 // [QGDThermo_8C L91-98, constScPrModel1_8C L106-115].
 __device__ __forceinline__ double muEffOf(const GasModel& gm, double muQGD) { return 0.0 + (gm.mu0 + muQGD); }
 __device__ __forceinline__ double alphaEffOf(const GasModel& gm, double muQGD) {
+#if QGD_F_DIET
+    return gm.gamma * ((gm.alphah0 + muQGD * gm.rPrQGD) + 0.0);
+#else
     return gm.gamma * ((gm.alphah0 + muQGD / gm.PrQGD) + 0.0);
+#endif
 }
 
 // fvc::grad(U), Gauss linear (L0), of one cell: gather in ascending face order -- the cell's own velocity once, per face the neighbour

@@ -203,6 +203,12 @@ class NativeComm:
         L.check(L.lib.qgd_comm_create(int(device_id), int(rank), int(world), buf, C.byref(h)), "qgd_comm_create")
         self._h, self.rank, self.world = h, rank, world
 
+    def info(self):
+        """{rank, ranks, device} as RCCL itself reports them for the communicator (qgd_comm_info)"""
+        v = (self._C.c_int32 * 3)()
+        self._L.check(self._L.lib.qgd_comm_info(self._h, v), "qgd_comm_info")
+        return {"rank": int(v[0]), "ranks": int(v[1]), "device": int(v[2])}
+
     def _peers(self, peers):
         import numpy as np
         a = np.ascontiguousarray(peers, dtype=np.int32)

@@ -45,9 +45,78 @@ def test_the_implicit_line_is_a_one_gpu_line():
     assert pr.returncode == 2 and "one-GPU line" in pr.stderr
 
 
+def test_deadline_kills_hung_ranks():
+    """a hung collective must not burn the caller's timeout: when QGD_BENCH_DEADLINE_S passes the relay kills every rank and reports
+    status 124; a rank that dies takes the others with it at once"""
+    import bench
+    hang = [sys.executable, "-c", "import time; time.sleep(120)"]
+    t0 = time.time()
+    res = bench.launch_ranks(2, [], 2.0, cmd=hang)
+    assert res["timed_out"] and res["rc"] == 124 and res["line"] is None and time.time() - t0 < 30
+    # rank 1 dies after a second, rank 0 would sleep for two minutes
+    die = [sys.executable, "-c", "import os, sys, time; time.sleep(1 if os.environ['RANK'] == '1' else 120); sys.exit(7)"]
+    t0 = time.time()
+    res = bench.launch_ranks(2, [], 60.0, cmd=die)
+    assert not res["timed_out"] and res["rc"] != 0 and time.time() - t0 < 30
+    # the ordinary case: rank 0's JSON line is relayed, other stdout is not a line, the launcher's own variables reach the ranks and a
+    # surrounding torchrun's do not
+    ok = [sys.executable, "-c", "import os, json; r = os.environ['RANK']; print('noise'); "
+                                "print(json.dumps({'rank': r, 'world': os.environ['WORLD_SIZE'], 'agent': os.environ.get('TORCHELASTIC_USE_AGENT_STORE')}))"]
+    os.environ["TORCHELASTIC_USE_AGENT_STORE"] = "True"
+    try:
+        res = bench.launch_ranks(3, [], 60.0, cmd=ok)
+    finally:
+        del os.environ["TORCHELASTIC_USE_AGENT_STORE"]
+    assert res["rc"] == 0 and json.loads(res["line"]) == {"rank": "0", "world": "3", "agent": None}
+
+
+def test_self_launch_enforces_the_deadline_from_the_environment():
+    """python bench.py --gpus 2 with QGD_BENCH_DEADLINE_S: the relay parent itself (no GPU needed: the ranks are replaced by sleepers
+    through the same launch_ranks the relay uses)"""
+    code = ("import sys, bench; bench.launch_ranks.__defaults__ = ([sys.executable, '-c', 'import time; time.sleep(120)'],); "
+            "sys.argv = ['bench.py', '--gpus', '2']; bench.self_launch(2)")
+    env = dict(os.environ, QGD_BENCH_DEADLINE_S="2", PYTHONPATH=ROOT)
+    t0 = time.time()
+    pr = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert pr.returncode == 124 and "QGD_BENCH_DEADLINE_S" in pr.stderr and time.time() - t0 < 60, (pr.returncode, pr.stderr[-300:])
+    assert not [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_native_transport_is_attached_from_a_second_set_of_ranks(monkeypatch):
+    """the merge logic of the second line (the real thing needs N > 1 GPUs: RCCL refuses two ranks on one device): what the fresh
+    ranks print is cut to the keys the first line is compared on, a failure becomes {"error": ...} and never an exception"""
+    import bench
+    seen = {}
+
+    def fake(n, argv, deadline, cmd=None):
+        seen["argv"], seen["n"] = list(argv), n
+        return {"line": json.dumps({"ms_per_step": 2.5, "value": 25600.0, "checksum_rho": [1.0, 2.0],
+                                     "config": {"transport": "RCCL inside the library (qgd_case_step_sharded; ...)", "rccl_ranks": 8, "partition": "8 k-slab(s)"}}),
+                "rc": 0, "timed_out": False, "stderr": []}
+
+    monkeypatch.setattr(bench, "launch_ranks", fake)
+    args = type("A", (), {"steps": 100, "warmup": 20, "n": 400, "backend": "nccl"})()
+    nt = bench.native_transport_line(args, 8, 300.0)
+    assert nt["ms_per_step"] == 2.5 and nt["checksum_rho"] == [1.0, 2.0] and nt["rccl_ranks"] == 8 and nt["transport"].startswith("RCCL inside the library")
+    a = seen["argv"]
+    assert seen["n"] == 8 and a[a.index("--halo") + 1] == "native" and "--no-native-line" in a and "--check" in a
+    assert a[a.index("--steps") + 1] == "100" and a[a.index("--warmup") + 1] == "20" and a[a.index("--edge") + 1] == "400"
+    monkeypatch.setattr(bench, "launch_ranks", lambda *a, **k: {"line": None, "rc": 124, "timed_out": True, "stderr": ["stuck"]})
+    nt = bench.native_transport_line(args, 8, 5.0)
+    assert "error" in nt and "5 s" in nt["error"] and nt["stderr"] == ["stuck"]
+
+
+def test_env_switches_are_echoed(monkeypatch):
+    import bench
+    monkeypatch.setenv("QGD_XCD_RUN", "16")
+    monkeypatch.setenv("NOT_OURS", "1")
+    e = bench.qgd_env()
+    assert e["QGD_XCD_RUN"] == "16" and "NOT_OURS" not in e
+
+
 @pytest.mark.gpu
 def test_two_ranks_self_launched_match_one_rank():
-    common = ["--backend", "gloo", "--edge", "48", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-dropin", "--check"]
+    common = ["--backend", "gloo", "--edge", "48", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-dropin", "--no-secondary", "--check"]
     one, _ = run_bench(["--gpus", "1"] + common, 900)
     assert one.returncode == 0, one.stderr[-800:]
     two, _ = run_bench(["--gpus", "2"] + common, 900)
@@ -59,13 +128,43 @@ def test_two_ranks_self_launched_match_one_rank():
     for x, y in zip(a["checksum_rho"], b["checksum_rho"]):
         assert abs(x - y) <= 1e-12 * abs(x), (a["checksum_rho"], b["checksum_rho"])
     assert b["roofline"]["frac"] is not None and b["value"] > 0
+    # new keys: gloo staging has no RCCL communicator, the C-ABI transport cannot stand on one GPU, and says so
+    assert b["config"]["rccl_ranks"] is None and "skipped" in b["native_transport"] and "one device" in b["native_transport"]["skipped"]
+    assert b["config"]["halo_message_bytes"] == {"per_ghost_cell": 80, "per_ghost_patch_face": 96} and isinstance(b["config"]["env"], dict)
+
+
+@pytest.mark.gpu
+def test_native_halo_refuses_the_one_gpu_stand_in():
+    pr, _ = run_bench(["--gpus", "2", "--backend", "gloo", "--halo", "native", "--edge", "16", "--steps", "1", "--warmup", "0",
+                       "--no-cpu-baseline", "--no-dropin", "--no-secondary"], 600)
+    assert pr.returncode != 0 and not [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
+
+
+@pytest.mark.gpu
+def test_default_line_carries_the_secondary_workloads_and_the_env():
+    """python bench.py --gpus 1 (the driver's command) appends `secondary` {qhd, implicit} from child processes, 20 timed steps each,
+    and echoes every QGD_* variable; shrunk here through QGD_BENCH_SECONDARY_N, which the echo then shows"""
+    env = dict(os.environ, QGD_BENCH_SECONDARY_N="24")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    pr = subprocess.run([sys.executable, BENCH, "--edge", "32", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-dropin"], env=env,
+                        capture_output=True, text=True, timeout=1200)
+    assert pr.returncode == 0, pr.stderr[-800:]
+    d = json.loads([ln for ln in pr.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["config"]["env"]["QGD_BENCH_SECONDARY_N"] == "24" and d["config"]["rccl_ranks"] is None and "native_transport" not in d
+    sec = d["secondary"]
+    assert set(sec) == {"qhd_n24", "implicit_n24"}
+    for key, it_key in (("qhd_n24", "pressure_iterations_per_step"), ("implicit_n24", "iterations_U")):
+        x = sec[key]
+        assert "error" not in x, x
+        assert x["steps"] == 20 and x["ms_per_step"] > 0 and x["value"] > 0 and x["config"][it_key] > 0 and x["roofline"]["avg_launch_ms"] > 0
 
 
 @pytest.mark.gpu
 def test_qhd_workload_on_two_self_launched_ranks():
     """python bench.py --workload qhd --gpus 2: config 5's path (sharded QHDFoam case, pressure solve with the multigrid hierarchy that
     spans the ranks) as two processes on the one GPU of the box, gloo with host-staged messages; same pressure iterations as one rank"""
-    common = ["--workload", "qhd", "--edge", "32", "--steps", "2", "--warmup", "1"]
+    common = ["--workload", "qhd", "--edge", "32", "--steps", "2", "--warmup", "1"]   # (secondary lines belong to the qgd workload only)
     one, _ = run_bench(["--gpus", "1"] + common, 900)
     assert one.returncode == 0, one.stderr[-800:]
     two, _ = run_bench(["--gpus", "2", "--backend", "gloo"] + common, 900)
