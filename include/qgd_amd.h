@@ -105,7 +105,7 @@ typedef struct qgd_case_s* qgd_case_t;     /* a QGDFoam case on one device      
 
 /* ---- library ---------------------------------------------------------------- */
 /* Bumped whenever an options struct grows or an entry changes its meaning (3: round 3). */
-#define QGD_ABI_VERSION 3
+#define QGD_ABI_VERSION 4
 const char* qgd_version(void);
 /* sizes[0..2] = sizeof(qgd_case_options), sizeof(qgd_qhd_options), sizeof(qgd_poisson_control) as THIS library was built,
  * sizes[3] = its QGD_ABI_VERSION: a host compiled against another header compares before it passes a struct (the structs
@@ -359,7 +359,7 @@ int qgd_qhd_pressure(qgd_device_t d, const double* phiu, const double* phiwo, co
                      double* p, double* phi, double info[3]);
 
 /* ---- QHDFoam case resident on the device --------------------------------------------------------------------------- */
-/* The loop body of QHDFoam [QHDFoam_8C_source.html L83-139], explicit branch (implicitDiffusion false): updateFields.H,
+/* The loop body of QHDFoam [QHDFoam_8C_source.html L83-139], both branches of implicitDiffusion: updateFields.H,
  * updateFluxes.H, the pressure equation QHDpEqn.H L35-47 (conjugate gradients preconditioned by an aggregation multigrid
  * built once: the matrix does not change, QHDFoam never re-corrects its thermo inside the loop), QHDUEqn.H L36-84,
  * QHDTEqn.H L65-91, the reference level of p (L123-130).  Thermo: rhoConst + constTransport (uniform rho0, mu, Pr; the QHD
@@ -367,7 +367,9 @@ int qgd_qhd_pressure(qgd_device_t d, const double* phiu, const double* phiwo, co
  * gradients, Gauss linear uncorrected laplacians, Euler ddt.  Sharded meshes: see "the QHD case on a cell-range shard" below. */
 typedef struct qgd_qhd_options {
     int32_t stencil;          /* QGD_FVSC_*                                                                    */
-    int32_t implicitDiffusion;/* must be 0                                                                     */
+    int32_t implicitDiffusion;/* 0: fvc::laplacian in both equations; 1 (the reference's default, QGDThermo_8C_source.html L70-82):
+                                 fvm::laplacian(muf/rhof, U) and fvm::laplacian(Hif, T) [QHDUEqn_8H_source.html L46-65,
+                                 QHDTEqn_8H_source.html L69-80]: the four systems as ONE matrix walk (see implicitTol)     */
     int32_t tauModel;         /* QGDCoeffs closure: 0 constTau (Tau), 1 HbyUQHD (aQGD, UQHD), 2 T0byGr (T0, Gr),
                                  3 H2bynuQHD (aQGD; nu = mu/rho0)                                                */
     int32_t pRefCell;         /* fvSolution pRefCell; < 0: no reference level                                  */
@@ -376,6 +378,9 @@ typedef struct qgd_qhd_options {
     double rho0, mu, Pr, beta, g[3], deltaT;
     double Tau, aQGD, UQHD, T0, Gr;
     double pTol, pRelTol, pRefValue;
+    double implicitTol;       /* implicitDiffusion: tolerance (OpenFOAM's normalised residual) of the U and T solves (1e-10) */
+    int32_t implicitMaxIter;  /* ... and their iteration limit (1000)                                          */
+    int32_t pad_;
 } qgd_qhd_options;
 typedef struct qgd_qhd_case_s* qgd_qhd_case_t;
 int qgd_qhd_options_default(qgd_qhd_options* opt);
@@ -392,6 +397,12 @@ int qgd_qhd_case_get_field(qgd_qhd_case_t c, const char* name, double* out, int6
 /* info[0]=time, [1]=deltaT, [2..4]= iterations / initial / final normalised residual of the last pressure solve,
  * [5]=steps, [6]=multigrid levels, [7]=milliseconds of the last pressure solve */
 int qgd_qhd_case_info(qgd_qhd_case_t c, double info[8]);
+/* implicitDiffusion: the solve of the last step -- info[0..3] = iterations of Ux, Uy, Uz, T, [4..7] = initial, [8..11] = final
+ * normalised residuals (what OpenFOAM prints as "Solving for Ux, Initial residual = ..."), [12] = steps since
+ * qgd_qhd_case_set_fields in which a component stopped above implicitTol, [13] = 0 explicit branch | 1 conjugate gradients
+ * (QGD_IMPL_SOLVER=pcg) | 2 Chebyshev iteration (default).  The four systems share |Sf| delta_f up to {nu, nu, nu, Hi} and are
+ * solved as four right-hand sides of one matrix walk. */
+int qgd_qhd_case_implicit_info(qgd_qhd_case_t c, double info[14]);
 
 /* ---- the QHD case on a cell-range shard (qgd_mesh_box slabs, qgd_mesh_shard) ------------------------------------------------
  * What the reference does through processor patches inside fvm::laplacian / PCG / fvc::grad under MPI
@@ -406,6 +417,12 @@ int qgd_qhd_case_info(qgd_qhd_case_t c, double info[8]);
  *     phase 5 residual, iteration count, done?, new direction   -> exchange message kind 2
  *   phase 6   p's boundary conditions after the solve           -> exchange message kind 1
  *   phase 7   phi, QHDUEqn.H, QHDTEqn.H, U/T boundary conditions -> all-reduce control[8] (only when p needs a reference level)
+ *             implicitDiffusion: phi, the face terms without the laplacians, the right-hand sides of the four systems; then the
+ *             solve with ITS OWN 68-double control block (qgd_qhd_case_implicit_control*), phases and reductions exactly those of
+ *             "the implicitDiffusion branch on a cell-range shard" below, numbered 10..15 here instead of 22..27, message kind 4 in
+ *             place of its kind 3 (no start-value message: the ghost columns start from the state message), until
+ *             qgd_qhd_case_implicit_solve_status says done; then
+ *   phase 16  (implicitDiffusion) the solution into the records, U/T boundary conditions -> all-reduce control[8] as after phase 7
  *   phase 8   reference level of p                              -> exchange message kind 0
  * DRAIN PENDING = the comm points of the preconditioner, which fall INSIDE phases 0, 2 and 4: after the phase call, and again after
  * every qgd_qhd_case_step_phase(c, 9), ask qgd_qhd_case_pending and perform what it names until it answers 0 (protocol below).  A
@@ -421,7 +438,8 @@ int qgd_qhd_case_info(qgd_qhd_case_t c, double info[8]);
  * unsharded arithmetic.
  * control: 16 device doubles (qgd_qhd_case_control_ptr); message kinds: 0 = the new state, {U,T} per cell (4) and per patch face
  * (4); 1 = p + fvc::grad(U) per cell (1 + 9: a ghost cell's gradient cannot be formed locally, it lacks faces) and p's patch value
- * + gradient per patch face (2); 2 = the search direction per cell (1); 3 = the multigrid iterate per cell (1), see qgd_qhd_case_pending.
+ * + gradient per patch face (2); 2 = the search direction per cell (1); 3 = the multigrid iterate per cell (1), see qgd_qhd_case_pending;
+ * 4 = what the implicitDiffusion solve's next matrix product reads in the ghost columns, {Ux, Uy, Uz, T} per cell (4).
  * pRefCell is a cell label of the UNSHARDED mesh.  All entries are stream-ordered on the device's stream. */
 int qgd_qhd_case_step_phase(qgd_qhd_case_t c, int phase);
 /* The hierarchy that spans the ranks (default up to QGD_MG_DIST_MAX_CELLS, see above).  Level 0 stays distributed --
@@ -437,6 +455,11 @@ int qgd_qhd_case_step_phase(qgd_qhd_case_t c, int phase);
  * then goes on with the reductions and messages the table above lists for that phase.  Every rank sees the same sequence.
  * qgd_qhd_case_step_sharded does all of this itself. */
 int qgd_qhd_case_pending(qgd_qhd_case_t c, int32_t* action, void** devicePtr, int64_t* count);
+/* the control block of the implicitDiffusion solve (68 doubles, control[slot * 4 + component], as qgd_case_implicit_control) and
+ * its state: status[0] != 0: every component is done; status[1] = right-hand sides (4) */
+int qgd_qhd_case_implicit_control(qgd_qhd_case_t c, double control[68], int set);
+int qgd_qhd_case_implicit_control_ptr(qgd_qhd_case_t c, void** devicePtr);
+int qgd_qhd_case_implicit_solve_status(qgd_qhd_case_t c, double status[2]);
 int qgd_qhd_case_control_ptr(qgd_qhd_case_t c, void** devicePtr);
 /* host copy of the control block out (set == 0) or in (set != 0), after everything queued so far: for transports that reduce on
  * the host (MPI_Allreduce of 16 doubles, torch.distributed over gloo) */
@@ -538,24 +561,29 @@ int qgd_case_implicit_apply_time(qgd_case_t c, int reps, double info[2]);
 
 /* ---- the implicitDiffusion branch on a cell-range shard -------------------------------------------------------------------------
  * implicitDiffusion true is the reference's default [QGDThermo_8C_source.html L70-82].  Its two implicit equations
- * [QGDUEqn_8H_source.html L54-75, QGDEEqn_8H_source.html L53-64] are solved here by a Jacobi-preconditioned CG whose scalars
- * live in a control block on the device (the three velocity components as three right-hand sides of ONE matrix walk); under MPI
- * the reference reaches across ranks through processor patches inside fvm::laplacian, the linear solver and fvc::grad.  With one
- * rank per shard the advance (after phase 0, the flux assembly) is, through qgd_case_step_phase:
+ * [QGDUEqn_8H_source.html L54-75, QGDEEqn_8H_source.html L53-64] are solved here with the scalars of the solve in a control block
+ * on the device (the three velocity components as three right-hand sides of ONE matrix walk).  The solver is a Chebyshev iteration
+ * on the Jacobi-preconditioned system by default (these matrices are strictly diagonally dominant, Gershgorin bounds the spectrum;
+ * no dot products), or Jacobi-preconditioned conjugate gradients with QGD_IMPL_SOLVER=pcg; the phases, reductions and messages below
+ * serve both (a slot the algorithm in use does not write is zero, a phase it does not need does nothing).  Under MPI the reference
+ * reaches across ranks through processor patches inside fvm::laplacian, the linear solver and fvc::grad.  With one rank per shard
+ * the advance (after phase 0, the flux assembly) is, through qgd_case_step_phase:
  *   phase 20  deltaT, fvc::grad(U) of the old state          -> exchange message kind 1
  *   phase 21  tauMC / phiTauMC, rho, rhoU, the three U systems and their start values -> exchange kind 4
- *   phase 22  first solver phase (A x, r)                     -> SUM-reduce control[0..12)
- *   phase 23  normFactor                                      -> reduce control[12..16)
- *   phase 24  first residual, search direction, r.z           -> reduce control[16..20); exchange kind 3
+ *   phase 22  first solver phase (A x, r, row radii)          -> SUM-reduce control[0..12), MAX-reduce control[32..36)
+ *   phase 23  normFactor                                      -> SUM-reduce control[12..16)
+ *   phase 24  first residual; Chebyshev: x_1 | CG: search direction, r.z -> SUM-reduce control[16..20); exchange kind 3
  *   repeat until qgd_case_implicit_solve_status says done:
- *     phase 25 A d, d.Ad -> reduce control[20..24) | phase 26 x, r, |r|, r.z -> reduce control[24..32) | phase 27 new direction -> exchange kind 3
+ *     phase 25 Chebyshev: one step, sum |b - A x| | CG: A d, d.Ad    -> SUM-reduce control[20..24)
+ *     phase 26 Chebyshev: residual, done?, next constants | CG: x, r, |r|, r.z -> SUM-reduce control[24..32)
+ *     phase 27 Chebyshev: nothing | CG: new direction           -> exchange kind 3
  *   phase 28  U into the records, its boundary conditions     -> exchange kind 2
  *   phase 29  fvc::grad(U) of the new velocity                -> exchange kind 1
  *   phase 30  phiSigmaDotU, the energy equation, the e system and its start value -> exchange kind 4; then 22, 23, 24, (25, 26, 27)*
  *   phase 35  rhoE, thermo, p, boundary refresh               -> the state message (qgd_case_halo_pack / unpack), phase 2
  * control: 68 device doubles, slot-major, control[slot * 4 + component].  Message kinds: 1 = fvc::grad(U), 9 per cell; 2 = U, 3 per
- * cell; 3 = the search direction, 4 = the start value of the solve in flight, one per right-hand side per cell (counts report room
- * for three).
+ * cell; 3 = what the next matrix product reads in the ghost columns (Chebyshev: the iterate, CG: the search direction), 4 = the start
+ * value of the solve in flight, one per right-hand side per cell (counts report room for three).
  * An unsharded case runs the same phases back to back inside qgd_case_step; qgd_case_step_sharded drives them over RCCL. */
 int qgd_case_implicit_halo_count(qgd_case_t c, int slot, int kind, int64_t* sendCount, int64_t* recvCount);
 int qgd_case_implicit_halo_pack(qgd_case_t c, int slot, int kind, double* sendBufDevice);

@@ -2231,7 +2231,8 @@ extern "C" int orc_qhd_pressure(void* mp, const double* phiu, const double* phiw
                                 double pRefValue, double* p, double* phi, double info[3]);
 
 // ---------------------------------------------------------------------------
-// QHDFoam case: the loop body of QHDFoam.C L83-139, explicit branch (implicitDiffusion false), with rhoConst +
+// QHDFoam case: the loop body of QHDFoam.C L83-139, both branches of implicitDiffusion [QHDUEqn.H L46-85, QHDTEqn.H L69-92]
+// (step(); the phase form for shards restates the explicit branch only), with rhoConst +
 // constTransport thermo (rho, mu, alpha = mu/Pr uniform; the QHD closures keep muQGD = alphauQGD = 0 [T0byGr.C L62-72])
 // and laminar transport.  thermo.correct() is not called inside the loop [QHDFoam.C L83-139], so rho, mu, alpha and
 // tauQGDf are those of start-up.
@@ -2252,6 +2253,7 @@ struct QhdCase {
     double time = 0;
     int64_t steps = 0;
     double lastPIter = 0, lastPRes0 = 0, lastPRes = 0;
+    int lastIterU[3] = {0, 0, 0}, lastIterT = 0;   // implicitDiffusion: iterations of the U and T solves of the last step
 
     QhdCase(MeshHandle* h, const orc_qhd_options& o) : mh(h), m(h->m), opt(o), bc(h->m.patches.size()) {
         for (size_t ip = 0; ip < bc.size(); ++ip)
@@ -2445,6 +2447,7 @@ struct QhdCase {
         for (int b = 0; b < nB; ++b) for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) gUT.bf[9 * (size_t)b + 3 * i + j] = gU.bf[9 * (size_t)b + 3 * j + i];
         SurfField gUTf = linearInterpolate(m, gUT);
         SurfField snU = fvcSnGrad(m, U), snT = fvcSnGrad(m, T);
+        const bool implicit = opt.implicitDiffusion != 0;
         dvec FU(3 * (size_t)nF, 0.0), FT((size_t)nF, 0.0), Gp(3 * (size_t)nF, 0.0);
         for (int f = 0; f < nF; ++f) {
             if (!liveFace[f]) continue;
@@ -2454,14 +2457,15 @@ struct QhdCase {
                 Wf[k] = tauQGDf.v[f] * ((UgU.v[3 * (size_t)f + k] + gradPf.v[3 * (size_t)f + k] / rhof) - BdFrcf.v[3 * (size_t)f + k]);   // L37
             outer(&Uf.v[3 * (size_t)f], Wf, UW);
             VdotT(S, UW, uw);                                                                          // L39
-            VdotT(S, &gUTf.v[9 * (size_t)f], ext);                                                     // Sf & lin(T(grad U)), L76
+            VdotT(S, &gUTf.v[9 * (size_t)f], ext);                                                     // Sf & lin(T(grad U)), L56 / L76
             for (int k = 0; k < 3; ++k) {
                 const double phiUf = phi.v[f] * Uf.v[3 * (size_t)f + k] - uw[k];                       // L41-43
                 const double lap = nuf * snU.v[3 * (size_t)f + k] * m.magSf[f];                        // fvc::laplacian(muf/rhof, U), L74
-                FU[3 * (size_t)f + k] = (phiUf - lap) - nuf * ext[k];
+                FU[3 * (size_t)f + k] = implicit ? phiUf - nuf * ext[k] : (phiUf - lap) - nuf * ext[k];   // L54: the laplacian is in the matrix
                 Gp[3 * (size_t)f + k] = S[k] * pf.v[f];                                                // fvc::grad(p), Gauss linear
             }
-            FT[f] = (phi.v[f] * Tf.v[f] - Hif * snT.v[f] * m.magSf[f]) - phiTauTReg.v[f];              // QHDTEqn.H L65-66, L85-88
+            FT[f] = implicit ? phi.v[f] * Tf.v[f] - phiTauTReg.v[f]                                    // QHDTEqn.H L73-76
+                             : (phi.v[f] * Tf.v[f] - Hif * snT.v[f] * m.magSf[f]) - phiTauTReg.v[f];   // QHDTEqn.H L65-66, L85-88
         }
         dvec sumU(3 * (size_t)nC, 0.0), sumT((size_t)nC, 0.0), sumG(3 * (size_t)nC, 0.0);
         for (int f = 0; f < nF; ++f) {   // surfaceIntegrate order
@@ -2475,11 +2479,73 @@ struct QhdCase {
                 sumT[n] -= FT[f];
             }
         }
-        for (int c = 0; c < nC; ++c) {
-            const double rV = 1.0 / m.V[c];
-            for (int k = 0; k < 3; ++k)
-                U.in[3 * (size_t)c + k] += dt * ((-(sumU[3 * (size_t)c + k] * rV) - (sumG[3 * (size_t)c + k] * rV) / opt.rho0) + BdFrc.in[3 * (size_t)c + k]);
-            T.in[c] += dt * (-(sumT[c] * rV));
+        if (!implicit) {
+            for (int c = 0; c < nC; ++c) {
+                const double rV = 1.0 / m.V[c];
+                for (int k = 0; k < 3; ++k)
+                    U.in[3 * (size_t)c + k] += dt * ((-(sumU[3 * (size_t)c + k] * rV) - (sumG[3 * (size_t)c + k] * rV) / opt.rho0) + BdFrc.in[3 * (size_t)c + k]);
+                T.in[c] += dt * (-(sumT[c] * rV));
+            }
+        } else {
+            // fvm::ddt(U) - fvm::laplacian(muf/rhof, U) per component [QHDUEqn.H L48-64] and fvm::ddt(T) - fvm::laplacian(Hif, T)
+            // [QHDTEqn.H L71-79]: face coefficients gamma |Sf| delta_f (Gauss linear uncorrected, L0), diagonal V/deltaT + sum a_f +
+            // the patch internal coefficients; patch coefficients of -fvm::laplacian (L0): fixedValue delta / delta*value;
+            // basicSymmetry (slip) delta*|n_k| / snGrad_k + delta*|n_k|*patchInternalField_k (transformFvPatchField);
+            // zeroGradient none.  Components along empty directions are not solved (fvMatrix<vector>::solveSegregated, L0).
+            const double rDeltaT = 1.0 / dt;
+            dvec gS((size_t)nF, 0.0);
+            for (int f = 0; f < nF; ++f) gS[f] = m.magSf[f] * (f < m.nIF ? m.nonOrthDelta[f] : m.delta[f]);
+            const dvec snUb = allPatchSnGrad(m, U);
+            const dvec Ucur = U.in;
+            auto solveOne = [&](const double gamma, const dvec& rhsCell, auto icoef, auto bsrc, double* x) {
+                dvec a((size_t)nF, 0.0), diag((size_t)nC), rhs = rhsCell;
+                for (int f = 0; f < m.nIF; ++f) a[f] = gamma * gS[f];
+                for (int c = 0; c < nC; ++c) diag[c] = rDeltaT * m.V[c];
+                for (int f = 0; f < m.nIF; ++f) { diag[m.own[f]] += a[f]; diag[m.nei[f]] += a[f]; }
+                for (size_t ip = 0; ip < bc.size(); ++ip) forPatchFaces((int)ip, [&](int gf, int b, int o) {
+                    if (m.coupled((int)ip)) return;
+                    const double gs = gamma * m.magSf[gf];
+                    diag[o] += gs * icoef((int)ip, gf, b, o);
+                    rhs[o] += gs * bsrc((int)ip, gf, b, o);
+                });
+                return solveDiagLaplacian(m, a, diag, rhs, x, opt.implicitTol, opt.implicitMaxIter);
+            };
+            for (int k = 0; k < 3; ++k) {
+                if (m.geomD[k] < 0) continue;
+                dvec rhs((size_t)nC), x((size_t)nC);
+                for (int c = 0; c < nC; ++c) {
+                    const double rV = 1.0 / m.V[c];
+                    // rDeltaT U.old V  +  V (-div(phiUf - nu Sf & lin(T(grad U))) - grad(p)/rho + BdFrc)
+                    rhs[c] = rDeltaT * Ucur[3 * (size_t)c + k] * m.V[c]
+                             + m.V[c] * ((-(sumU[3 * (size_t)c + k] * rV) - (sumG[3 * (size_t)c + k] * rV) / opt.rho0) + BdFrc.in[3 * (size_t)c + k]);
+                    x[c] = Ucur[3 * (size_t)c + k];
+                }
+                auto ic = [&](int ip, int gf, int, int) {
+                    if (bc[ip].bcU == BC_FIXEDVALUE) return m.delta[gf];
+                    if (bc[ip].bcU == BC_SLIP) return m.delta[gf] * std::fabs(m.Sf[3 * (size_t)gf + k] / m.magSf[gf]);
+                    return 0.0;
+                };
+                auto bs = [&](int ip, int gf, int b, int o) {
+                    if (bc[ip].bcU == BC_FIXEDVALUE) return m.delta[gf] * U.bf[3 * (size_t)b + k];
+                    if (bc[ip].bcU == BC_SLIP)
+                        return snUb[3 * (size_t)b + k] + m.delta[gf] * std::fabs(m.Sf[3 * (size_t)gf + k] / m.magSf[gf]) * Ucur[3 * (size_t)o + k];
+                    return 0.0;
+                };
+                lastIterU[k] = solveOne(nuf, rhs, ic, bs, x.data());
+                for (int c = 0; c < nC; ++c) U.in[3 * (size_t)c + k] = x[c];
+            }
+            {
+                dvec rhs((size_t)nC), x((size_t)nC);
+                for (int c = 0; c < nC; ++c) {
+                    const double rV = 1.0 / m.V[c];
+                    rhs[c] = rDeltaT * T.in[c] * m.V[c] + m.V[c] * (-(sumT[c] * rV));
+                    x[c] = T.in[c];
+                }
+                auto ic = [&](int ip, int gf, int, int) { return bc[ip].bcT == BC_FIXEDVALUE ? m.delta[gf] : 0.0; };
+                auto bs = [&](int ip, int gf, int b, int) { return bc[ip].bcT == BC_FIXEDVALUE ? m.delta[gf] * T.bf[b] : 0.0; };
+                lastIterT = solveOne(Hif, rhs, ic, bs, x.data());
+                for (int c = 0; c < nC; ++c) T.in[c] = x[c];
+            }
         }
         correctU(); correctT();
         // QHDFoam.C L123-130
@@ -3188,7 +3254,11 @@ int orc_qhd_case_set_bc(void* cp, int32_t patch, int32_t bcU, const double* vU, 
 }
 int orc_qhd_case_set_fields(void* cp, const double* U, const double* T, const double* p) { return ((QhdCase*)cp)->setFields(U, T, p); }
 int orc_qhd_case_step(void* cp, int32_t n) { for (int i = 0; i < n; ++i) ((QhdCase*)cp)->step(); return 0; }
-int orc_qhd_case_step_phase(void* cp, int phase) { if (phase < 0 || phase > 8) return -1; ((QhdCase*)cp)->phase(phase); return 0; }
+int orc_qhd_case_step_phase(void* cp, int phase) {
+    if (phase < 0 || phase > 8 || ((QhdCase*)cp)->opt.implicitDiffusion) return -1;   // the phase form restates the explicit branch only
+    ((QhdCase*)cp)->phase(phase);
+    return 0;
+}
 int orc_qhd_case_control(void* cp, double* buf16, int set) {
     QhdCase* c = (QhdCase*)cp;
     for (int k = 0; k < 16; ++k) { if (set) c->ctl[k] = buf16[k]; else buf16[k] = c->ctl[k]; }

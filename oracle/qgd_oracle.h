@@ -87,6 +87,7 @@ int orc_qhd_pressure(void* mesh, const double* phiu, const double* phiwo, const 
 typedef struct orc_qhd_options {
     int32_t stencil, implicitDiffusion, tauModel, pRefCell, pMaxIter, precond;
     double rho0, mu, Pr, beta, g[3], deltaT, Tau, aQGD, UQHD, T0, Gr, pTol, pRelTol, pRefValue;
+    double implicitTol; int32_t implicitMaxIter, pad_;
 } orc_qhd_options;
 void* orc_qhd_case_create(void* mesh, const orc_qhd_options* opt);
 void orc_qhd_case_free(void* c);

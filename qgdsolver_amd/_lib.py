@@ -53,7 +53,8 @@ class QhdOptions(C.Structure):
                 ("pMaxIter", C.c_int32), ("precond", C.c_int32),
                 ("rho0", C.c_double), ("mu", C.c_double), ("Pr", C.c_double), ("beta", C.c_double), ("g", C.c_double * 3),
                 ("deltaT", C.c_double), ("Tau", C.c_double), ("aQGD", C.c_double), ("UQHD", C.c_double), ("T0", C.c_double),
-                ("Gr", C.c_double), ("pTol", C.c_double), ("pRelTol", C.c_double), ("pRefValue", C.c_double)]
+                ("Gr", C.c_double), ("pTol", C.c_double), ("pRelTol", C.c_double), ("pRefValue", C.c_double),
+                ("implicitTol", C.c_double), ("implicitMaxIter", C.c_int32), ("pad_", C.c_int32)]
 
 
 # every symbol include/qgd_amd.h declares: name -> (restype, argtypes)
@@ -108,6 +109,10 @@ SIGNATURES = {
     "qgd_qhd_case_step": (C.c_int, [handle, C.c_int32]),
     "qgd_qhd_case_get_field": (C.c_int, [handle, C.c_char_p, c_double_p, C.c_int64]),
     "qgd_qhd_case_info": (C.c_int, [handle, c_double_p]),
+    "qgd_qhd_case_implicit_info": (C.c_int, [handle, c_double_p]),
+    "qgd_qhd_case_implicit_control": (C.c_int, [handle, c_double_p, C.c_int]),
+    "qgd_qhd_case_implicit_control_ptr": (C.c_int, [handle, handle_p]),
+    "qgd_qhd_case_implicit_solve_status": (C.c_int, [handle, c_double_p]),
     "qgd_qhd_case_step_phase": (C.c_int, [handle, C.c_int]),
     "qgd_species_step": (C.c_int, [handle] + [c_double_p] * 6 + [C.c_double, C.c_double, c_double_p, c_double_p, c_double_p]),
     "qgd_species_step_dev": (C.c_int, [handle] + [C.c_void_p] * 6 + [C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -1726,6 +1726,8 @@ struct qgd_qhd_case_s {
     double *tauF = nullptr, *tbr = nullptr, *scratch = nullptr;
     uint8_t* bKind = nullptr;
     PressureSolver* solver = nullptr;
+    ImplicitSolver* implSolver = nullptr;  // implicitDiffusion: the four systems {Ux, Uy, Uz, T} as one multi-right-hand-side solve
+    int implMask = 15;                     // components that are solved (validComponents: not those along empty directions)
     bool needRef = false;
     int localRefCell = -1;                 // local label of pRefCell when this shard owns it
     std::vector<int32_t> bcPRequested;     // p kinds as the caller set them (a box slab's cut plane hides the patch's own kind)
@@ -1741,12 +1743,14 @@ int qgd_qhd_options_default(qgd_qhd_options* o) {
     o->tauModel = 2; o->pRefCell = 0; o->pMaxIter = 1000; o->precond = 1;
     o->rho0 = 1.0; o->mu = 1e-3; o->Pr = 0.71; o->beta = 3e-3; o->g[1] = -9.81; o->deltaT = 1e-3;
     o->Tau = 1e-3; o->aQGD = 0.5; o->UQHD = 1.0; o->T0 = 1.0; o->Gr = 1e3; o->pTol = 1e-8; o->pRelTol = 0.0; o->pRefValue = 0.0;
+    o->implicitTol = 1e-10; o->implicitMaxIter = 1000;
     return QGD_OK;
 }
 int qgd_qhd_case_create(qgd_device_t d, const qgd_qhd_options* opt, qgd_qhd_case_t* out) {
     QGD_TRY
     if (!d || !opt || !out) return fail(QGD_ERR_INVALID, "qgd_qhd_case_create: null argument");
-    if (opt->implicitDiffusion) return fail(QGD_ERR_NOT_IMPLEMENTED, "implicitDiffusion true: only the explicit branch is on this path");
+    if (opt->implicitDiffusion && (!(opt->implicitTol > 0) || opt->implicitMaxIter < 1))
+        return fail(QGD_ERR_INVALID, "qgd_qhd_case_create: implicitDiffusion needs implicitTol > 0 and implicitMaxIter >= 1");
     if (!(opt->rho0 > 0) || !(opt->Pr > 0) || !(opt->deltaT > 0) || opt->tauModel < 0 || opt->tauModel > 3)
         return fail(QGD_ERR_INVALID, "qgd_qhd_case_create: rho0, Pr, deltaT must be positive, tauModel in 0..3");
     int st = 0;
@@ -1769,6 +1773,13 @@ int qgd_qhd_case_create(qgd_device_t d, const qgd_qhd_options* opt, qgd_qhd_case
         q.phiu = a.alloc<double>(nF); q.phiwo = a.alloc<double>(nF); q.phi = a.alloc<double>(nF); q.phitr = a.alloc<double>(nF);
         q.ugu = a.alloc<double>(3 * nF); q.gUc = a.alloc<double>(9 * nC); q.F = a.alloc<double>(4 * nF);
         c->scratch = a.alloc<double>(8);
+        q.implicit = opt->implicitDiffusion ? 1 : 0;
+        if (q.implicit) {
+            q.aG = a.alloc<double>(nF); q.diag4 = a.alloc<double>(4 * nC); q.rhs4 = a.alloc<double>(4 * nC); q.x4 = a.alloc<double>(4 * nC);
+            c->implSolver = implicitSolverCreate(d->stream, v, d->ownedBegin, d->ownedEnd);
+            c->implMask = 8;
+            for (int k = 0; k < 3; ++k) if (!(v.nGeomD < 3 && v.emptyDir[k])) c->implMask |= 1 << k;   // validComponents (L0)
+        }
         q.rho0 = opt->rho0; q.nu = opt->mu / opt->rho0; q.Hi = (opt->mu / opt->Pr) / opt->rho0; q.beta = opt->beta;
         for (int k = 0; k < 3; ++k) q.g[k] = opt->g[k];
         q.dt = opt->deltaT; q.tauModel = opt->tauModel; q.Tau = opt->Tau; q.aQGD = opt->aQGD; q.UQHD = opt->UQHD; q.T0 = opt->T0; q.Gr = opt->Gr;
@@ -1783,7 +1794,7 @@ int qgd_qhd_case_create(qgd_device_t d, const qgd_qhd_options* opt, qgd_qhd_case
         }
         c->bcDev = a.alloc<PatchBCDev>(std::max<size_t>(1, c->bc.size()));
         c->bKind = a.alloc<uint8_t>(nB);
-    } catch (...) { c->arena.release(); delete c; throw; }
+    } catch (...) { if (c->implSolver) implicitSolverFree(c->implSolver); c->arena.release(); delete c; throw; }
     d->liveCases++;
     *out = c;
     return QGD_OK;
@@ -1793,6 +1804,7 @@ int qgd_qhd_case_free(qgd_qhd_case_t c) {
     if (!c) return QGD_OK;
     (void)hipSetDevice(c->dev->deviceId);
     if (c->solver) pressureSolverFree(c->solver);
+    if (c->implSolver) { (void)hipStreamSynchronize(c->dev->stream); implicitSolverFree(c->implSolver); }
     c->arena.release();
     c->dev->liveCases--;
     delete c;
@@ -1850,6 +1862,10 @@ int qgd_qhd_case_set_fields(qgd_qhd_case_t c, const double* U, const double* T, 
     (void)hipGetLastError();
     HIP_CHECK(hipMemsetAsync(c->view.phiwo, 0, sizeof(double) * (size_t)m.nF, d->stream));
     launchQhdInit(d->stream, m, c->view, c->bcDev, dU, dT, dp, c->tauF, c->tbr);
+    if (c->view.implicit) {   // the matrix of the U and T equations: constant in time (thermo is not corrected in the loop, deltaT is fixed)
+        launchQhdImplicitMatrix(d->stream, m, c->view, c->bcDev);
+        implicitStatsReset(c->implSolver);
+    }
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(d->stream));
     if (c->solver) { pressureSolverFree(c->solver); c->solver = nullptr; }
@@ -1876,8 +1892,30 @@ static void qhdPhase(qgd_qhd_case_s* c, int phase) {
         case 6: launchQhdPostSolve(d->stream, m, c->view, c->bcDev); break;
         case 7:
             pressureSolveFlux(c->solver, c->view.phi);
-            launchQhdAdvance(d->stream, c->stencil, c->usesPoints, m, c->view, c->bcDev, c->needRef, c->localRefCell, c->opt.pRefValue,
-                             pressureSolverCtl(c->solver) + 8);
+            if (!c->view.implicit)
+                launchQhdAdvance(d->stream, c->stencil, c->usesPoints, m, c->view, c->bcDev, c->needRef, c->localRefCell, c->opt.pRefValue,
+                                 pressureSolverCtl(c->solver) + 8);
+            else {
+                // implicitDiffusion: face pass 2 without the laplacians, the right-hand sides; the solve (phases 10..15) and phase 16 follow
+                static const double one = 1.0;
+                (void)one;
+                implicitStepMark(c->implSolver, true);
+                launchQhdImplicitAdvance(d->stream, c->stencil, c->usesPoints, m, c->view, c->bcDev, 0, c->implMask, false, -1, 0.0, nullptr);
+                const double gamma[4] = {c->view.nu, c->view.nu, c->view.nu, c->view.Hi};
+                implicitSolveSetup(c->implSolver, 4, c->implMask, c->view.aG, c->view.diag4, c->view.rhs4, c->view.x4, c->opt.implicitTol,
+                                   c->opt.implicitMaxIter, gamma);
+            }
+            break;
+        case 10: case 11: case 12: case 13: case 14: case 15:
+            if (!c->view.implicit) throw std::invalid_argument("qgd_qhd_case_step_phase: phases 10..16 belong to the implicitDiffusion branch");
+            implicitSolvePhase(c->implSolver, phase - 10);
+            break;
+        case 16:
+            if (!c->view.implicit) throw std::invalid_argument("qgd_qhd_case_step_phase: phases 10..16 belong to the implicitDiffusion branch");
+            implicitSolveEnd(c->implSolver, 0);
+            implicitStepMark(c->implSolver, false);
+            launchQhdImplicitAdvance(d->stream, c->stencil, c->usesPoints, m, c->view, c->bcDev, 1, c->implMask, c->needRef, c->localRefCell,
+                                     c->opt.pRefValue, pressureSolverCtl(c->solver) + 8);
             break;
         case 8:
             launchQhdFinish(d->stream, m, c->view, c->needRef, pressureSolverCtl(c->solver) + 8);
@@ -1885,7 +1923,7 @@ static void qhdPhase(qgd_qhd_case_s* c, int phase) {
             c->steps++;
             break;
         case 9: pressureSolveContinue(c->solver); break;   // after the collective qgd_qhd_case_pending asked for
-        default: throw std::invalid_argument("qgd_qhd_case_step_phase: phase must be 0..9");
+        default: throw std::invalid_argument("qgd_qhd_case_step_phase: phase must be 0..9 (10..16: implicitDiffusion)");
     }
     HIP_CHECK(hipGetLastError());
 }
@@ -1906,6 +1944,15 @@ static void qhdStepWith(qgd_qhd_case_s* c, const SolveHooks* hooks, const std::f
     qhdPhase(c, 6);
     if (haloState) haloState(1);
     qhdPhase(c, 7);
+    if (c->view.implicit) {
+        // the four systems of QHDUEqn.H L48-64 / QHDTEqn.H L71-79 as one solve; on shards its reductions and the ghost entries of
+        // the iterate go through the hooks (message kind 4)
+        SolveHooks ih;
+        if (hooks) { ih.allreduce = hooks->allreduce; ih.allreduceBuf = hooks->allreduceBuf; }
+        if (haloState) ih.haloDirection = [&]() { haloState(4); };
+        implicitSolveRun(c->implSolver, &ih);
+        qhdPhase(c, 16);
+    }
     if (c->needRef && hooks && hooks->allreduce) hooks->allreduce(pressureSolverCtl(c->solver) + 8, 1);
     qhdPhase(c, 8);
     if (haloState) haloState(0);
@@ -1927,7 +1974,7 @@ int qgd_qhd_case_step_phase(qgd_qhd_case_t c, int phase) {
     QGD_TRY
     if (!c) return fail(QGD_ERR_INVALID, "null case");
     if (!c->fieldsSet) return fail(QGD_ERR_INVALID, "qgd_qhd_case_step_phase: call qgd_qhd_case_set_fields first");
-    if (phase < 0 || phase > 9) return fail(QGD_ERR_INVALID, "qgd_qhd_case_step_phase: phase must be 0..9");
+    if (phase < 0 || phase > 16) return fail(QGD_ERR_INVALID, "qgd_qhd_case_step_phase: phase must be 0..9 (10..16: implicitDiffusion)");
     HIP_CHECK(hipSetDevice(c->dev->deviceId));
     qhdPhase(c, phase);
     return QGD_OK;   // stream-ordered: qgd_qhd_case_solve_status / qgd_qhd_case_sync wait
@@ -1963,6 +2010,51 @@ int qgd_qhd_case_control(qgd_qhd_case_t c, double control[16], int set) {
     return QGD_OK;
     QGD_CATCH
 }
+// the control block (68 doubles) and the state of the implicitDiffusion solve in flight
+int qgd_qhd_case_implicit_control(qgd_qhd_case_t c, double control[68], int set) {
+    QGD_TRY
+    if (!c || !control || !c->implSolver) return fail(QGD_ERR_INVALID, "qgd_qhd_case_implicit_control: an implicitDiffusion case is needed");
+    HIP_CHECK(hipSetDevice(c->dev->deviceId));
+    hipStream_t st = c->dev->stream;
+    if (set) HIP_CHECK(hipMemcpyAsync(implicitSolverCtl(c->implSolver), control, 68 * sizeof(double), hipMemcpyHostToDevice, st));
+    else HIP_CHECK(hipMemcpyAsync(control, implicitSolverCtl(c->implSolver), 68 * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    return QGD_OK;
+    QGD_CATCH
+}
+int qgd_qhd_case_implicit_control_ptr(qgd_qhd_case_t c, void** devicePtr) {
+    if (!c || !devicePtr || !c->implSolver) return fail(QGD_ERR_INVALID, "qgd_qhd_case_implicit_control_ptr: an implicitDiffusion case is needed");
+    *devicePtr = implicitSolverCtl(c->implSolver);
+    return QGD_OK;
+}
+int qgd_qhd_case_implicit_info(qgd_qhd_case_t c, double info[14]) {
+    QGD_TRY
+    if (!c || !info) return fail(QGD_ERR_INVALID, "bad argument");
+    for (int i = 0; i < 14; ++i) info[i] = 0.0;
+    if (!c->implSolver) return QGD_OK;
+    HIP_CHECK(hipSetDevice(c->dev->deviceId));
+    double allDone = 0, st[4];
+    int it[4];
+    double r0[4], r1[4];
+    implicitSolveStatus4(c->implSolver, &allDone, it, r0, r1);
+    (void)st;
+    for (int k = 0; k < 4; ++k) { info[k] = it[k]; info[4 + k] = r0[k]; info[8 + k] = r1[k]; }
+    info[12] = implicitSolverUnconverged(c->implSolver);
+    info[13] = implicitSolverChebyshev(c->implSolver) ? 2.0 : 1.0;
+    return QGD_OK;
+    QGD_CATCH
+}
+int qgd_qhd_case_implicit_solve_status(qgd_qhd_case_t c, double status[2]) {
+    QGD_TRY
+    if (!c || !status || !c->implSolver) return fail(QGD_ERR_INVALID, "qgd_qhd_case_implicit_solve_status: an implicitDiffusion case is needed");
+    HIP_CHECK(hipSetDevice(c->dev->deviceId));
+    int it[4];
+    double r0[4], r1[4];
+    implicitSolveStatus4(c->implSolver, &status[0], it, r0, r1);
+    status[1] = implicitSolverRhs(c->implSolver);
+    return QGD_OK;
+    QGD_CATCH
+}
 int qgd_qhd_case_solve_status(qgd_qhd_case_t c, double status[4]) {
     QGD_TRY
     if (!c || !status) return fail(QGD_ERR_INVALID, "null argument");
@@ -1984,7 +2076,7 @@ int qgd_qhd_case_sync(qgd_qhd_case_t c) {
 // halo messages: doubles per listed cell / per listed patch face of message kind 0 (state), 1 (p), 2 (search direction), 3 (the iterate of
 // the multigrid level that spans the ranks)
 static void qhdHaloWidths(int kind, int& perCell, int& perFace) {
-    perCell = kind == 0 ? 4 : (kind == 1 ? 10 : 1);
+    perCell = kind == 0 ? 4 : (kind == 1 ? 10 : (kind == 4 ? 4 : 1));   // kind 4: the iterate of the implicit solve, {Ux, Uy, Uz, T}
     perFace = kind == 0 ? 4 : (kind == 1 ? 2 : 0);
 }
 // what the phase in flight waits for before qgd_qhd_case_step_phase(c, 9): see include/qgd_amd.h
@@ -1998,7 +2090,7 @@ int qgd_qhd_case_pending(qgd_qhd_case_t c, int32_t* action, void** devicePtr, in
     return QGD_OK;
 }
 int qgd_qhd_case_halo_count(qgd_qhd_case_t c, int slot, int kind, int64_t* sendCount, int64_t* recvCount) {
-    if (!c || slot < 0 || kind < 0 || kind > 3 || !sendCount || !recvCount) return fail(QGD_ERR_INVALID, "bad argument");
+    if (!c || slot < 0 || kind < 0 || kind > 4 || !sendCount || !recvCount) return fail(QGD_ERR_INVALID, "bad argument");
     *sendCount = *recvCount = 0;
     if (slot >= (int)c->dev->halo.size()) return QGD_OK;
     int pc, pf;
@@ -2017,6 +2109,12 @@ static int qhdHaloMove(qgd_qhd_case_t c, int slot, int kind, double* buf, bool p
     if (!buf) return fail(QGD_ERR_INVALID, "null buffer");
     if (kind >= 2 && !c->solver) return fail(QGD_ERR_INVALID, "no solve in flight");
     (void)hipGetLastError();
+    if (kind == 4) {
+        if (!c->implSolver) return fail(QGD_ERR_INVALID, "message kind 4 belongs to the implicitDiffusion branch");
+        launchSolverHalo(stream, c->implSolver, pack ? h.send : h.ghost, nCells, buf, pack);
+        HIP_CHECK(hipGetLastError());
+        return QGD_OK;
+    }
     if (kind == 3) {
         float* vec = pressureSolverMgHaloVec(c->solver);
         if (!vec) return fail(QGD_ERR_INVALID, "message kind 3: no multigrid iterate is waiting for its ghost entries (qgd_qhd_case_pending)");
@@ -2031,14 +2129,14 @@ static int qhdHaloMove(qgd_qhd_case_t c, int slot, int kind, double* buf, bool p
 }
 int qgd_qhd_case_halo_pack(qgd_qhd_case_t c, int slot, int kind, double* sendBufDevice) {
     QGD_TRY
-    if (!c || slot < 0 || kind < 0 || kind > 3) return fail(QGD_ERR_INVALID, "bad argument");
+    if (!c || slot < 0 || kind < 0 || kind > 4) return fail(QGD_ERR_INVALID, "bad argument");
     HIP_CHECK(hipSetDevice(c->dev->deviceId));
     return qhdHaloMove(c, slot, kind, sendBufDevice, true, c->dev->stream);
     QGD_CATCH
 }
 int qgd_qhd_case_halo_unpack(qgd_qhd_case_t c, int slot, int kind, const double* recvBufDevice) {
     QGD_TRY
-    if (!c || slot < 0 || kind < 0 || kind > 3) return fail(QGD_ERR_INVALID, "bad argument");
+    if (!c || slot < 0 || kind < 0 || kind > 4) return fail(QGD_ERR_INVALID, "bad argument");
     HIP_CHECK(hipSetDevice(c->dev->deviceId));
     return qhdHaloMove(c, slot, kind, const_cast<double*>(recvBufDevice), false, c->dev->stream);
     QGD_CATCH
@@ -2367,8 +2465,13 @@ int qgd_case_step_sharded(qgd_case_t c, qgd_comm_t comm, const int32_t* peers, i
         // gradients, the new velocity and the search directions travel as grouped send/recv pairs, then the state message as usual
         SolveHooks hooks;
         hipStream_t st = c->stream();
-        if (comm->nRanks > 1)
+        if (comm->nRanks > 1) {
             hooks.allreduce = [&](double* ptr, int n) { RCCL_CHECK(rcclRef().allReduce(ptr, ptr, (size_t)n, ncclFloat64, ncclSum, comm->comm, st)); };
+            // the Chebyshev solves' spectral bound: MAX over the ranks (op 3; 2 = SUM)
+            hooks.allreduceBuf = [&](double* ptr, int64_t n, int op) {
+                RCCL_CHECK(rcclRef().allReduce(ptr, ptr, (size_t)n, ncclFloat64, op == 3 ? ncclMax : ncclSum, comm->comm, st));
+            };
+        }
         hooks.haloDirection = [&]() { implHaloExchangeOn(c, comm, peers, nSlots, 3); };
         hooks.haloGuess = [&]() { implHaloExchangeOn(c, comm, peers, nSlots, 4); };
         implicitAdvanceWith(c, &hooks, [&](int kind) { implHaloExchangeOn(c, comm, peers, nSlots, kind); });
@@ -2437,7 +2540,7 @@ static void qhdHaloExchangeOn(qgd_qhd_case_s* c, qgd_comm_s* comm, const int32_t
 }
 int qgd_qhd_case_halo_exchange(qgd_qhd_case_t c, qgd_comm_t comm, const int32_t* peers, int nSlots, int kind) {
     QGD_TRY
-    if (!c || kind < 0 || kind > 3) return fail(QGD_ERR_INVALID, "bad argument");
+    if (!c || kind < 0 || kind > 4) return fail(QGD_ERR_INVALID, "bad argument");
     if (c->dev->halo.empty() || nSlots <= 0) return QGD_OK;
     if (!comm || !peers) return fail(QGD_ERR_INVALID, "qgd_qhd_case_halo_exchange: null argument");
     HIP_CHECK(hipSetDevice(c->dev->deviceId));

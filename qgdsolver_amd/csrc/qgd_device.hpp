@@ -200,10 +200,17 @@ double* implicitSolverCtl(ImplicitSolver* S);          // 68 doubles, slot-major
 double* implicitSolverDirection(ImplicitSolver* S);    // 3 * nC doubles, component-major
 int implicitSolverRhs(const ImplicitSolver* S);        // right-hand sides of the solve in flight (3: U, 1: e)
 void implicitSolveSetup(ImplicitSolver* S, int nRhs, int validMask, const double* a, const double* diag, const double* rhs, double* x, double tol,
-                        int maxIter);
+                        int maxIter, const double* gamma = nullptr);   // gamma[k] scales the face coefficients of component k (nullptr: 1)
+bool implicitSolverChebyshev(const ImplicitSolver* S);   // the algorithm of the solves: Chebyshev (default) or conjugate gradients (QGD_IMPL_SOLVER=pcg)
+double* implicitSolverIterate(ImplicitSolver* S);        // the buffer that holds the iterate after the steps queued so far (halo kind 3, Chebyshev)
 void implicitSolvePhase(ImplicitSolver* S, int phase);
 void implicitSolveRun(ImplicitSolver* S, const SolveHooks* hooks);
 void implicitSolveStatus(ImplicitSolver* S, double* allDone, int iters[3], double res0[3], double res[3]);
+void implicitSolveStatus4(ImplicitSolver* S, double* allDone, int iters[4], double res0[4], double res[4]);   // the same for up to four right-hand sides
+double implicitSolverUnconverged(ImplicitSolver* S);   // steps since implicitStatsReset in which a solve stopped above its tolerance (waits)
+// ghost entries of what the next matrix product reads (Chebyshev: the iterate; conjugate gradients: the search direction): its
+// right-hand sides per listed cell, cell-major in the message
+void launchSolverHalo(hipStream_t s, ImplicitSolver* S, const int32_t* cells, int nCells, double* buf, bool pack);
 void implicitSolveEnd(ImplicitSolver* S, int which);             // which = 0: the U solve, 1: the e solve
 double implicitApplyMs(ImplicitSolver* S, const ImplView& iv, int reps, int* rows);   // measurement: average ms of the U system's matrix product
 void implicitStepMark(ImplicitSolver* S, bool begin);
@@ -226,6 +233,11 @@ struct QhdView {
     double* gUc;                               // 9*nC fvc::grad(U)
     double* F;                                 // 4*nF SoA at the faces' slot-major positions (MeshView::fpos): net face terms of the U (3) and T equations
     double rho0, nu, Hi, beta, g[3], dt;
+    // implicitDiffusion [QHDUEqn_8H L46-65, QHDTEqn_8H L69-80]: the four systems {Ux, Uy, Uz, T} share the face coefficients
+    // aG = |Sf| delta_f (at the faces' slot-major positions) up to gamma = {nu, nu, nu, Hi}; the matrix does not change in time
+    // (thermo is not corrected inside the loop, deltaT is fixed): diag4 is built once, rhs4 / x4 every step (component-major, 4 * nC)
+    int32_t implicit;
+    double *aG, *diag4, *rhs4, *x4;
     int32_t tauModel;                          // 0 constTau, 1 HbyUQHD, 2 T0byGr, 3 H2bynuQHD
     double Tau, aQGD, UQHD, T0, Gr;
 };
@@ -236,6 +248,12 @@ void launchQhdPostSolve(hipStream_t s, const MeshView& m, const QhdView& q, cons
 void launchQhdAdvance(hipStream_t s, int stencil, bool usesPoints, const MeshView& m, const QhdView& q, const PatchBCDev* bc, bool needRef,
                       int localRefCell, double refValue, double* shift);
 void launchQhdFinish(hipStream_t s, const MeshView& m, const QhdView& q, bool needRef, const double* shift);
+// implicitDiffusion: the constant matrix (set-up), then per step part 0 = face pass 2 + right-hand sides and start values (the
+// solve of the four systems follows: implicitSolveSetup with gamma = {nu, nu, nu, Hi}), part 1 = the solution into the records,
+// U / T boundary conditions, this rank's share of the reference-level shift of p
+void launchQhdImplicitMatrix(hipStream_t s, const MeshView& m, const QhdView& q, const PatchBCDev* bc);
+void launchQhdImplicitAdvance(hipStream_t s, int stencil, bool usesPoints, const MeshView& m, const QhdView& q, const PatchBCDev* bc, int part,
+                              int validMask, bool needRef, int localRefCell, double refValue, double* shift);
 // halo messages of a sharded QHD case: kind 0 = state {U,T} (4 per cell, 4 per patch face), 1 = p + fvc::grad(U) (10 per cell, 2 per
 // patch face), 2 = the search direction of the pressure solve (1 per cell)
 void launchQhdHalo(hipStream_t s, const QhdView& q, double* direction, int kind, const int32_t* cells, int nCells, const int32_t* bfaces, int nFaces,

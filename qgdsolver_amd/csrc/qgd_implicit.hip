@@ -388,22 +388,39 @@ __global__ __launch_bounds__(QGD_BLOCK) void implFinishKernel(const MeshView m, 
 inline int gridOf(int64_t n) { return (int)((n + QGD_BLOCK - 1) / QGD_BLOCK); }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// The linear solves of the branch: Jacobi-preconditioned conjugate gradients on  y_c = diag_c x_c - sum_{internal faces of c} a_f x_nb
-// (fvm::ddt(rho, .) - fvm::laplacian(gamma_f, .) of QGDUEqn.H L56-68 / QGDEEqn.H L55-61) for up to three right-hand sides AT ONCE
-// -- the velocity components share the face coefficients, so one walk over the matrix serves all three --, with OpenFOAM's
-// normalised residual per component, reproducible two-level sums, and every scalar of the loop in a control block ON THE
-// DEVICE (slot-major: ctl[slot * 4 + component], slots as in qgd_poisson.hip), so that no host synchronisation sits inside a
-// solve and a sharded caller reduces / exchanges between the phases exactly like for the QHD pressure equation:
-//   phase 0  q = A x, r = b - q, A1 = A 1           -> {sum|r|, sum x, rows} per component  (slots 0..2)
-//   phase 1  normFactor pieces with the global xbar  -> slot 3
-//   phase 2  first residual, done?; d = r/diag; r.z  -> slot 4; then the ghost entries of d
-//   phase 3  q = A d, d.q                            -> slot 5
-//   phase 4  alpha (or breakdown), x += alpha d, r -= alpha q, {sum|r|, r.z}  -> slots 6, 7
-//   phase 5  residual, iteration count, done?, beta, d = r/diag + beta d; then the ghost entries of d
-// Rows are the owned cells [ob, oe) of a shard; ghost cells appear only as columns.
+// The linear solves of the branch:  y_c = diag_c x_c - gamma_k sum_{internal faces of c} a_f x_nb
+// (fvm::ddt(rho, .) - fvm::laplacian(gamma_f, .) of QGDUEqn.H L56-68 / QGDEEqn.H L55-61; QHDUEqn.H L48-64 / QHDTEqn.H L71-79 with
+// a_f = |Sf| delta_f and gamma_k = nu, nu, nu, Hi) for up to FOUR right-hand sides AT ONCE -- the components share the face
+// coefficients, so one walk over the matrix serves all of them --, with OpenFOAM's normalised residual per component,
+// reproducible two-level sums, and every scalar of the loop in a control block ON THE DEVICE (slot-major:
+// ctl[slot * 4 + component]), so that no host synchronisation sits inside a solve and a sharded caller reduces / exchanges
+// between the phases exactly like for the QHD pressure equation.  Rows are the owned cells [ob, oe) of a shard; ghost cells
+// appear only as columns.
+//
+// Default algorithm (round 4): CHEBYSHEV iteration on the Jacobi-preconditioned system.  These matrices are strictly
+// diagonally dominant -- the ddt term carries the diagonal, the laplacian adds rho_c = gamma sum_f a_f / diag_c (0.09 at the
+// bench's 200^3 case) -- so Gershgorin bounds the spectrum of D^-1 A by [1 - delta, 1 + delta], delta = max_c rho_c, and the
+// Chebyshev polynomial for that interval converges at the conjugate-gradient bound WITHOUT dot products:
+//     z_i = D^-1 (b - A x_i);  d_i = c1_i d_(i-1) + c2_i z_i;  x_(i+1) = x_i + d_i          [Saad, Iterative Methods, Alg. 12.1]
+//     sigma = 1/delta, rho_0 = delta, c1_0 = 0, c2_0 = 1;  rho_i = 1/(2 sigma - rho_(i-1)), c1_i = rho_i rho_(i-1), c2_i = 2 rho_i/delta
+// ONE kernel per iteration does the product, the update of d and x and the partial sums of |b - A x_i| (the residual OpenFOAM
+// prints, here of the iterate the step started from), a second one folds them and, unsharded, runs the control logic in the same
+// launch: 2 launches and 216 B per cell instead of 7 launches and 408 B of the conjugate-gradient loop (three components,
+// hexahedra).  x ping-pongs between the caller's vector and one of the solver's (neighbours read the old iterate while rows write
+// the new one); the iterate after i steps sits in buffer i & 1, and implicitSolveEnd copies odd ones home.
+//   phase 0  q = A x, r = b - q, A1 = A 1, rho_c      -> {sum|r|, sum x, rows} per component (slots 0..2: SUM), delta (slot 8: MAX)
+//   phase 1  normFactor pieces with the global xbar    -> slot 3
+//   phase 2  first residual, done?, the constants; x_1 = x_0 + D^-1 r_0             -> then the ghost entries of the iterate
+//   phase 3  one step: the kernel above + the fold      -> slot 5 (sum |b - A x_i|); then the ghost entries of the new iterate
+//   phase 4  residual of x_i, iteration count, done?, c1, c2 (unsharded: done inside phase 3's fold launch)
+//   phase 5  nothing (kept so that drivers written for the conjugate-gradient phases run both)
+// QGD_IMPL_SOLVER=pcg keeps round 3's Jacobi-preconditioned conjugate gradients (same phases: 2 d = r/diag, r.z -> slot 4 + ghost
+// entries of d | 3 q = A d, d.q -> slot 5 | 4 alpha, x, r, {sum|r|, r.z} -> slots 6, 7 | 5 residual, done?, beta, d -> ghost entries).
 // ---------------------------------------------------------------------------------------------------------------------
-enum ICtl : int { I_ABSR = 0, I_SUMX = 1, I_N = 2, I_NORM = 3, I_RZ = 4, I_DQ = 5, I_ABSR2 = 6, I_RZNEW = 7, I_RES = 9, I_RES0 = 10, I_DONE = 11,
-                  I_ITER = 12, I_ALPHA = 13, I_BETA = 14, I_NORMF = 15, I_SLOTS = 16, I_ALLDONE = 64, I_COUNT = 68 };
+enum ICtl : int { I_ABSR = 0, I_SUMX = 1, I_N = 2, I_NORM = 3, I_RZ = 4, I_DQ = 5, I_ABSR2 = 6, I_RZNEW = 7, I_DELTA = 8, I_RES = 9, I_RES0 = 10,
+                  I_DONE = 11, I_ITER = 12, I_ALPHA = 13, I_BETA = 14, I_NORMF = 15, I_SLOTS = 16, I_ALLDONE = 64, I_COUNT = 68,
+                  // Chebyshev: slot 5 holds sum |b - A x_i|, slots 13 / 14 the coefficients c1 / c2
+                  I_CABSR = 5, I_C1 = 13, I_C2 = 14 };
 #define ICTL(slot, k) ((slot) * 4 + (k))
 
 __device__ __forceinline__ double iBlockSum(double v) {
@@ -421,8 +438,25 @@ __device__ __forceinline__ double iBlockSum(double v) {
     return t;
 }
 
+__device__ __forceinline__ double iBlockMax(double v) {
+    __shared__ double s[QGD_BLOCK / 64];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < QGD_BLOCK / 64; ++i) t = fmax(t, s[i]);
+    }
+    __syncthreads();
+    return t;
+}
+
 struct ISolveView {
     int NR, ob, n, nC;                 // right-hand sides, first row, rows, vector stride
+    double gam[4];                     // gamma_k: the face coefficients of component k are gam[k] * a
+    double* xb;                        // Chebyshev: the second buffer of the iterate (NR * nC)
     const double* a;                   // nF, at the faces' slot-major positions (MeshView::fpos / cfPos)
     const double* diag; const double* rhs; double* x;    // NR * nC each, component-major
     double *r, *d, *q;                 // NR * nC each
@@ -438,9 +472,9 @@ __global__ __launch_bounds__(QGD_BLOCK) void iApplyKernel(const MeshView m, cons
     if (v.ctl[I_ALLDONE] != 0.0 && MODE == 1) return;
     const int blk = xcdRunBlock(v.xrun);   // runs of row blocks per XCD (qgd_device.hpp); the partial sums stay in block order
     const int i = blk * QGD_BLOCK + threadIdx.x;
-    double s0[NR], s1[NR];
+    double s0[NR], s1[NR], s2[NR];
 #pragma unroll
-    for (int k = 0; k < NR; ++k) s0[k] = s1[k] = 0.0;
+    for (int k = 0; k < NR; ++k) s0[k] = s1[k] = s2[k] = 0.0;
     if (i < v.n) {
         const int c = v.ob + i;
         const int cnt = m.cfCount[c];
@@ -479,13 +513,14 @@ __global__ __launch_bounds__(QGD_BLOCK) void iApplyKernel(const MeshView m, cons
             const size_t j = (size_t)k * v.nC + c;
             if (MODE == 1 && v.ctl[ICTL(I_DONE, k)] != 0.0) continue;
             const double dg = v.diag[j], xv = src[j];
-            const double y = dg * xv - acc[k];
+            const double y = dg * xv - v.gam[k] * acc[k];
             v.q[j] = y;
             if (MODE == 0) {
                 const double rc = v.rhs[j] - y;
                 v.r[j] = rc;
-                v.d[j] = dg - rowsum;          // (A 1)_c
+                v.d[j] = dg - v.gam[k] * rowsum;          // (A 1)_c
                 s0[k] = fabs(rc); s1[k] = xv;
+                s2[k] = (v.gam[k] * rowsum) / dg;          // Gershgorin radius of row c of D^-1 A
             } else s0[k] = xv * y;
         }
     }
@@ -496,7 +531,90 @@ __global__ __launch_bounds__(QGD_BLOCK) void iApplyKernel(const MeshView m, cons
         if (MODE == 0) {
             const double t1 = iBlockSum(s1[k]);
             if (threadIdx.x == 0) v.part[(size_t)(1 * NR + k) * v.nBlocks + blk] = t1;
+            const double t2 = iBlockMax(s2[k]);
+            if (threadIdx.x == 0) v.part[(size_t)(2 * NR + k) * v.nBlocks + blk] = t2;
         }
+    }
+}
+
+// One Chebyshev step (see the head of this section).  FIRST: x_1 = x_0 + D^-1 r_0 from the residual phase 0 left (no product);
+// otherwise the product on the current iterate (buffer step & 1), the new d and the next iterate into the other buffer, and the
+// partial sums of |b - A x_i|.  Components that are done are not touched; all others have made the same number of steps.
+template <int NR, int FIRST>
+__global__ __launch_bounds__(QGD_BLOCK) void iChebKernel(const MeshView m, const ISolveView v) {
+    const int blk = FIRST ? (int)blockIdx.x : xcdRunBlock(v.xrun);
+    const int i = blk * QGD_BLOCK + threadIdx.x;
+    int step = -1;                                        // steps made so far by the components still running (all the same number)
+#pragma unroll
+    for (int k = 0; k < NR; ++k) if (v.ctl[ICTL(I_DONE, k)] == 0.0) step = (int)v.ctl[ICTL(I_ITER, k)];
+    if (step < 0) return;
+    const double* __restrict__ src = (step & 1) ? v.xb : v.x;
+    double* __restrict__ dst = (step & 1) ? v.x : v.xb;
+    double s0[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) s0[k] = 0.0;
+    if (i < v.n) {
+        const int c = v.ob + i;
+        double acc[NR];
+#pragma unroll
+        for (int k = 0; k < NR; ++k) acc[k] = 0.0;
+        if (!FIRST) {
+            const int cnt = m.cfCount[c];
+            const size_t base = (size_t)m.cfSlice[c >> 6] * 64 + (c & 63);
+            constexpr int U = 8;   // eight entries at a time, every level of the chain requested before the first use (as iApplyKernel)
+            for (int e0 = 0; e0 < cnt; e0 += U) {
+                int nb[U], it[U];
+                double af[U], xs[NR][U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const bool in = e0 + u < cnt;
+                    nb[u] = in ? m.cfNbr[base + (size_t)(e0 + u) * 64] : -1;
+                    it[u] = in ? m.cfPos[base + (size_t)(e0 + u) * 64] : 0;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    af[u] = nb[u] >= 0 ? v.a[it[u] >= 0 ? it[u] : ~it[u]] : 0.0;
+#pragma unroll
+                    for (int k = 0; k < NR; ++k) xs[k][u] = nb[u] >= 0 ? src[(size_t)k * v.nC + nb[u]] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int k = 0; k < NR; ++k) acc[k] += af[u] * xs[k][u];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            if (v.ctl[ICTL(I_DONE, k)] != 0.0) continue;
+            const size_t j = (size_t)k * v.nC + c;
+            const double dg = v.diag[j], xv = src[j];
+            double rc, dn;
+            if (FIRST) { rc = v.r[j]; dn = rc / dg; }
+            else {
+                rc = v.rhs[j] - (dg * xv - v.gam[k] * acc[k]);
+                dn = v.ctl[ICTL(I_C1, k)] * v.d[j] + v.ctl[ICTL(I_C2, k)] * (rc / dg);
+            }
+            v.d[j] = dn;
+            dst[j] = xv + dn;
+            s0[k] = fabs(rc);
+        }
+    }
+    if (!FIRST) {
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const double t0 = iBlockSum(s0[k]);
+            if (threadIdx.x == 0) v.part[(size_t)k * v.nBlocks + blk] = t0;
+        }
+    }
+}
+// after the last step: iterates that ended in the solver's buffer (odd step counts) go home to the caller's vector
+__global__ __launch_bounds__(QGD_BLOCK) void iChebHomeKernel(const ISolveView v) {
+    const int i = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    if (i >= v.n) return;
+    for (int k = 0; k < v.NR; ++k) {
+        if (v.ctl[ICTL(I_DONE, k)] == 3.0 || (((int)v.ctl[ICTL(I_ITER, k)]) & 1) == 0) continue;
+        const size_t j = (size_t)k * v.nC + v.ob + i;
+        v.x[j] = v.xb[j];
     }
 }
 // phase 1: sum(|A x - xbar A 1| + |b - xbar A 1|)
@@ -558,30 +676,62 @@ __global__ __launch_bounds__(QGD_BLOCK) void iUpdateKernel(const ISolveView v) {
     }
 }
 // folds rows x NR rows of partials into ctl[(firstSlot + row) * 4 + k], one workgroup per row; components that are done keep
-// their values
-__global__ __launch_bounds__(QGD_BLOCK) void iFoldKernel(const ISolveView v, const int NR, const int rows, const int firstSlot, const int always) {
-    if (!always && v.ctl[I_ALLDONE] != 0.0) return;
-    const int row = blockIdx.x / NR, k = blockIdx.x % NR;
-    if (!always && v.ctl[ICTL(I_DONE, k)] != 0.0) return;   // uniform over the workgroup
-    const double* __restrict__ p = v.part + (size_t)(row * NR + k) * v.nBlocks;
+// their values.  maxRow >= 0: that row is folded with max into ctl[(maxSlot) * 4 + k] (the Gershgorin radius of phase 0).
+__device__ __forceinline__ double iFoldRow(const double* __restrict__ p, const int n, const bool useMax) {
     // eight independent chains per thread, their loads requested together (31 250 partials at 8 M cells: 15 round trips instead of 30)
     double w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int i = threadIdx.x;
-    for (; i + 7 * QGD_BLOCK < v.nBlocks; i += 8 * QGD_BLOCK) {
+    for (; i + 7 * QGD_BLOCK < n; i += 8 * QGD_BLOCK) {
         double x[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) x[j] = p[i + j * QGD_BLOCK];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) w[j] += x[j];
+        for (int j = 0; j < 8; ++j) w[j] = useMax ? fmax(w[j], x[j]) : w[j] + x[j];
     }
-    for (; i < v.nBlocks; i += QGD_BLOCK) w[0] += p[i];
-    const double t = iBlockSum(((w[0] + w[1]) + (w[2] + w[3])) + ((w[4] + w[5]) + (w[6] + w[7])));
-    if (threadIdx.x == 0) v.ctl[ICTL(firstSlot + row, k)] = t;
+    for (; i < n; i += QGD_BLOCK) w[0] = useMax ? fmax(w[0], p[i]) : w[0] + p[i];
+    if (useMax) return iBlockMax(fmax(fmax(fmax(w[0], w[1]), fmax(w[2], w[3])), fmax(fmax(w[4], w[5]), fmax(w[6], w[7]))));
+    return iBlockSum(((w[0] + w[1]) + (w[2] + w[3])) + ((w[4] + w[5]) + (w[6] + w[7])));
+}
+__global__ __launch_bounds__(QGD_BLOCK) void iFoldKernel(const ISolveView v, const int NR, const int rows, const int firstSlot, const int always,
+                                                        const int maxRow, const int maxSlot) {
+    if (!always && v.ctl[I_ALLDONE] != 0.0) return;
+    const int row = blockIdx.x / NR, k = blockIdx.x % NR;
+    if (!always && v.ctl[ICTL(I_DONE, k)] != 0.0) return;   // uniform over the workgroup
+    const double t = iFoldRow(v.part + (size_t)(row * NR + k) * v.nBlocks, v.nBlocks, row == maxRow);
+    if (threadIdx.x == 0) v.ctl[ICTL(row == maxRow ? maxSlot : firstSlot + row, k)] = t;
+}
+// the Chebyshev constants of the step after `rhoPrev` (see the head of this section)
+__device__ __forceinline__ void chebNext(double* __restrict__ ctl, const int k, const double rhoPrev) {
+    const double delta = ctl[ICTL(I_DELTA, k)];
+    const double rho = 1.0 / (2.0 / delta - rhoPrev);
+    ctl[ICTL(I_C1, k)] = rho * rhoPrev;
+    ctl[ICTL(I_C2, k)] = 2.0 * rho / delta;
+}
+// what follows a Chebyshev step for component k, whose sum |b - A x_i| is in slot I_CABSR: the residual of the iterate the step
+// started from, the step count, done?, the next constants
+__device__ __forceinline__ void chebAfterStep(double* __restrict__ ctl, const int k, const double tol, const int maxIter) {
+    const double res = ctl[ICTL(I_CABSR, k)] / ctl[ICTL(I_NORMF, k)], it = ctl[ICTL(I_ITER, k)] + 1.0;
+    ctl[ICTL(I_RES, k)] = res; ctl[ICTL(I_ITER, k)] = it;
+    if (res < tol || it >= (double)maxIter) ctl[ICTL(I_DONE, k)] = 1.0;
+    else chebNext(ctl, k, ctl[ICTL(I_C2, k)] * ctl[ICTL(I_DELTA, k)] * 0.5);   // rho_i = c2_i delta / 2
+}
+// one rank: the fold of a Chebyshev step and its control logic in ONE launch, one workgroup per component (the components do not
+// depend on each other; nothing reads I_ALLDONE on this path)
+__global__ __launch_bounds__(QGD_BLOCK) void iFoldChebKernel(const ISolveView v, const double tol, const int maxIter) {
+    const int k = blockIdx.x;
+    if (v.ctl[ICTL(I_DONE, k)] != 0.0) return;   // uniform over the workgroup
+    const double t = iFoldRow(v.part + (size_t)k * v.nBlocks, v.nBlocks, false);
+    if (threadIdx.x == 0) {
+        v.ctl[ICTL(I_CABSR, k)] = t;
+        chebAfterStep(v.ctl, k, tol, maxIter);
+    }
 }
 // bookkeeping, one thread per component.  stage 0: start (valid mask: components along empty directions are "done" from the start);
-// 1: first residual; 2: alpha or breakdown; 3: residual, iteration count, done?, beta.  The last thread-independent step: all done?
+// 1: first residual; 2: alpha or breakdown; 3: residual, iteration count, done?, beta (conjugate gradients);  Chebyshev: 1 also sets
+// the constants of step 1, 4: after the first step (x_1 stands), 5: after any later step.  Last, thread-independent: all done?
+// ctl[I_ALLDONE + 1] = Chebyshev steps made so far by the components still running (which buffer holds the iterate).
 __global__ void iCtlKernel(double* __restrict__ ctl, const int NR, const int stage, const double nRows, const int validMask, const double tol,
-                           const int maxIter) {
+                           const int maxIter, const int cheb) {
     const int k = threadIdx.x;
     if (k < NR) {
         if (stage == 0) {
@@ -593,16 +743,26 @@ __global__ void iCtlKernel(double* __restrict__ ctl, const int NR, const int sta
                 const double nf = ctl[ICTL(I_NORM, k)] + 1e-20, res = ctl[ICTL(I_ABSR, k)] / nf;
                 ctl[ICTL(I_NORMF, k)] = nf; ctl[ICTL(I_RES, k)] = res; ctl[ICTL(I_RES0, k)] = res;
                 if (res < tol || maxIter <= 0) ctl[ICTL(I_DONE, k)] = 1.0;
+                else if (cheb) {
+                    // Gershgorin: the spectrum of D^-1 A lies in [1 - delta, 1 + delta]; strictly below 1 by diagonal dominance.  The
+                    // clamps keep the recurrence finite for a purely diagonal matrix (delta = 0: x_1 is exact) and for a singular one
+                    const double delta = fmin(fmax(ctl[ICTL(I_DELTA, k)], 1e-30), 1.0 - 1e-9);
+                    ctl[ICTL(I_DELTA, k)] = delta;
+                    chebNext(ctl, k, delta);   // rho_0 = delta
+                }
             } else if (stage == 2) {
                 const double dq = ctl[ICTL(I_DQ, k)], rz = ctl[ICTL(I_RZ, k)];
                 if (!(dq > 0) || !(rz > 0)) ctl[ICTL(I_DONE, k)] = 2.0;
                 else ctl[ICTL(I_ALPHA, k)] = rz / dq;
-            } else {
+            } else if (stage == 3) {
                 const double res = ctl[ICTL(I_ABSR2, k)] / ctl[ICTL(I_NORMF, k)], it = ctl[ICTL(I_ITER, k)] + 1.0;
                 ctl[ICTL(I_RES, k)] = res; ctl[ICTL(I_ITER, k)] = it;
                 if (res < tol || it >= (double)maxIter) ctl[ICTL(I_DONE, k)] = 1.0;
                 else { ctl[ICTL(I_BETA, k)] = ctl[ICTL(I_RZNEW, k)] / ctl[ICTL(I_RZ, k)]; ctl[ICTL(I_RZ, k)] = ctl[ICTL(I_RZNEW, k)]; }
-            }
+            } else if (stage == 4) {
+                ctl[ICTL(I_ITER, k)] = 1.0;                       // x_1 stands (its residual is known after the next step)
+                if (maxIter <= 1) ctl[ICTL(I_DONE, k)] = 1.0;
+            } else if (stage == 5) chebAfterStep(ctl, k, tol, maxIter);
         }
     }
     __syncthreads();
@@ -610,6 +770,7 @@ __global__ void iCtlKernel(double* __restrict__ ctl, const int NR, const int sta
         bool all = true;
         for (int j = 0; j < NR; ++j) all = all && ctl[ICTL(I_DONE, j)] != 0.0;
         ctl[I_ALLDONE] = all ? 1.0 : 0.0;
+        if (stage == 0) ctl[I_ALLDONE + 1] = 0.0;
     }
 }
 
@@ -654,7 +815,9 @@ struct ImplicitSolver {
     MeshView m{};
     hipStream_t stream = nullptr;
     int ob = 0, oe = 0;
-    double *r = nullptr, *d = nullptr, *q = nullptr, *part = nullptr, *ctl = nullptr, *hostCtl = nullptr;
+    double *r = nullptr, *d = nullptr, *q = nullptr, *xb = nullptr, *part = nullptr, *ctl = nullptr, *hostCtl = nullptr;
+    bool cheb = true;           // QGD_IMPL_SOLVER: "cheb" (default) | "pcg"
+    int hostSteps = 0;          // Chebyshev steps queued so far in the solve in flight (which buffer a halo message moves)
     double* stats = nullptr;    // device: [0] unconverged steps, [1] flag of the step in flight, [2 .. 2 + 2*I_COUNT) control blocks of the last U and e solves
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     ISolveView v{};
@@ -677,14 +840,21 @@ ImplicitSolver* implicitSolverCreate(hipStream_t stream, const MeshView& m, int 
         if (!end || *end != '\0' || v < 0 || v > 4096) { delete S; throw std::invalid_argument(std::string("QGD_ROW_XCD_RUN=") + e + " is outside [0, 4096]"); }
         S->rowRun = (int)v;
     }
+    if (const char* e = std::getenv("QGD_IMPL_SOLVER")) {
+        const std::string w(e);
+        if (w != "cheb" && w != "pcg") { delete S; throw std::invalid_argument("QGD_IMPL_SOLVER=" + w + " is not a supported value (cheb, pcg)"); }
+        S->cheb = w == "cheb";
+    }
     const size_t nC = (size_t)m.nC, nb = (size_t)gridOf(S->oe - S->ob);
     try {
-        ICHECK(hipMalloc((void**)&S->r, sizeof(double) * 3 * nC)); ICHECK(hipMalloc((void**)&S->d, sizeof(double) * 3 * nC));
-        ICHECK(hipMalloc((void**)&S->q, sizeof(double) * 3 * nC)); ICHECK(hipMalloc((void**)&S->part, sizeof(double) * 6 * std::max<size_t>(nb, 1)));
+        ICHECK(hipMalloc((void**)&S->r, sizeof(double) * 4 * nC)); ICHECK(hipMalloc((void**)&S->d, sizeof(double) * 4 * nC));
+        ICHECK(hipMalloc((void**)&S->q, sizeof(double) * 4 * nC)); ICHECK(hipMalloc((void**)&S->part, sizeof(double) * 12 * std::max<size_t>(nb, 1)));
+        ICHECK(hipMalloc((void**)&S->xb, sizeof(double) * 4 * nC));
+        ICHECK(hipMemset(S->xb, 0, sizeof(double) * 4 * nC));
         ICHECK(hipMalloc((void**)&S->ctl, sizeof(double) * I_COUNT));
         ICHECK(hipMalloc((void**)&S->stats, sizeof(double) * (2 + 2 * I_COUNT)));
         ICHECK(hipMemset(S->stats, 0, sizeof(double) * (2 + 2 * I_COUNT)));
-        ICHECK(hipMemset(S->d, 0, sizeof(double) * 3 * nC));     // ghost entries of the direction are read before the first exchange fills them
+        ICHECK(hipMemset(S->d, 0, sizeof(double) * 4 * nC));     // ghost entries of the direction are read before the first exchange fills them
         ICHECK(hipMemset(S->ctl, 0, sizeof(double) * I_COUNT));
         ICHECK(hipStreamSynchronize(nullptr));   // null-stream zero-fills are done before anything runs on the solver's non-blocking stream
         ICHECK(hipHostMalloc((void**)&S->hostCtl, sizeof(double) * I_COUNT * 5, hipHostMallocDefault));
@@ -694,102 +864,167 @@ ImplicitSolver* implicitSolverCreate(hipStream_t stream, const MeshView& m, int 
 }
 void implicitSolverFree(ImplicitSolver* S) {
     if (!S) return;
-    (void)hipFree(S->r); (void)hipFree(S->d); (void)hipFree(S->q); (void)hipFree(S->part); (void)hipFree(S->ctl); (void)hipFree(S->stats);
+    (void)hipFree(S->r); (void)hipFree(S->d); (void)hipFree(S->q); (void)hipFree(S->xb); (void)hipFree(S->part); (void)hipFree(S->ctl); (void)hipFree(S->stats);
     if (S->hostCtl) (void)hipHostFree(S->hostCtl);
     for (hipEvent_t e : S->ev) if (e) (void)hipEventDestroy(e);
     delete S;
 }
-int64_t implicitSolverBytes(const ImplicitSolver* S) { return S ? (int64_t)sizeof(double) * (9 * (int64_t)S->m.nC + 6 * gridOf(S->oe - S->ob) + I_COUNT) : 0; }
+int64_t implicitSolverBytes(const ImplicitSolver* S) { return S ? (int64_t)sizeof(double) * (16 * (int64_t)S->m.nC + 12 * gridOf(S->oe - S->ob) + I_COUNT) : 0; }
 double* implicitSolverCtl(ImplicitSolver* S) { return S->ctl; }
 double* implicitSolverDirection(ImplicitSolver* S) { return S->d; }
 int implicitSolverRhs(const ImplicitSolver* S) { return S->NR; }
+bool implicitSolverChebyshev(const ImplicitSolver* S) { return S->cheb; }
+double* implicitSolverIterate(ImplicitSolver* S) { return (S->hostSteps & 1) ? S->xb : S->v.x; }
 
 template <int NR>
-static void iPhaseT(ImplicitSolver* S, int phase) {
+static void iPhaseT(ImplicitSolver* S, int phase, bool fused = false) {
     const ISolveView& v = S->v;
     hipStream_t s = S->stream;
-    const int nb = v.nBlocks;
+    const int nb = v.nBlocks, cheb = S->cheb ? 1 : 0;
     switch (phase) {
         case 0:
-            iCtlKernel<<<1, 4, 0, s>>>(v.ctl, NR, 0, (double)v.n, S->validMask, S->tol, S->maxIter);
+            S->hostSteps = 0;
+            iCtlKernel<<<1, 4, 0, s>>>(v.ctl, NR, 0, (double)v.n, S->validMask, S->tol, S->maxIter, cheb);
             iApplyKernel<NR, 0><<<nb, QGD_BLOCK, 0, s>>>(S->m, v);
-            iFoldKernel<<<2 * NR, QGD_BLOCK, 0, s>>>(v, NR, 2, I_ABSR, 1);
+            iFoldKernel<<<3 * NR, QGD_BLOCK, 0, s>>>(v, NR, 3, I_ABSR, 1, 2, I_DELTA);   // rows: sum|r|, sum x | max rho_c -> slot 8
             break;
         case 1:
             iNormKernel<NR><<<nb, QGD_BLOCK, 0, s>>>(v);
-            iFoldKernel<<<1 * NR, QGD_BLOCK, 0, s>>>(v, NR, 1, I_NORM, 1);
+            iFoldKernel<<<1 * NR, QGD_BLOCK, 0, s>>>(v, NR, 1, I_NORM, 1, -1, 0);
             break;
         case 2:
-            iCtlKernel<<<1, 4, 0, s>>>(v.ctl, NR, 1, 0.0, 0, S->tol, S->maxIter);
-            iDirectionKernel<NR, 1><<<nb, QGD_BLOCK, 0, s>>>(v);
-            iFoldKernel<<<1 * NR, QGD_BLOCK, 0, s>>>(v, NR, 1, I_RZ, 0);
+            iCtlKernel<<<1, 4, 0, s>>>(v.ctl, NR, 1, 0.0, 0, S->tol, S->maxIter, cheb);
+            if (S->cheb) {
+                iChebKernel<NR, 1><<<nb, QGD_BLOCK, 0, s>>>(S->m, v);
+                iCtlKernel<<<1, 4, 0, s>>>(v.ctl, NR, 4, 0.0, 0, S->tol, S->maxIter, cheb);
+                S->hostSteps = 1;
+            } else {
+                iDirectionKernel<NR, 1><<<nb, QGD_BLOCK, 0, s>>>(v);
+                iFoldKernel<<<1 * NR, QGD_BLOCK, 0, s>>>(v, NR, 1, I_RZ, 0, -1, 0);
+            }
             break;
         case 3:
-            iApplyKernel<NR, 1><<<nb, QGD_BLOCK, 0, s>>>(S->m, v);
-            iFoldKernel<<<1 * NR, QGD_BLOCK, 0, s>>>(v, NR, 1, I_DQ, 0);
+            if (S->cheb) {
+                iChebKernel<NR, 0><<<nb, QGD_BLOCK, 0, s>>>(S->m, v);
+                if (fused) iFoldChebKernel<<<NR, QGD_BLOCK, 0, s>>>(v, S->tol, S->maxIter);
+                else iFoldKernel<<<1 * NR, QGD_BLOCK, 0, s>>>(v, NR, 1, I_CABSR, 0, -1, 0);
+                S->hostSteps++;
+            } else {
+                iApplyKernel<NR, 1><<<nb, QGD_BLOCK, 0, s>>>(S->m, v);
+                iFoldKernel<<<1 * NR, QGD_BLOCK, 0, s>>>(v, NR, 1, I_DQ, 0, -1, 0);
+            }
             break;
         case 4:
-            iCtlKernel<<<1, 4, 0, s>>>(v.ctl, NR, 2, 0.0, 0, S->tol, S->maxIter);
-            iUpdateKernel<NR><<<nb, QGD_BLOCK, 0, s>>>(v);
-            iFoldKernel<<<2 * NR, QGD_BLOCK, 0, s>>>(v, NR, 2, I_ABSR2, 0);
+            if (S->cheb) { if (!fused) iCtlKernel<<<1, 4, 0, s>>>(v.ctl, NR, 5, 0.0, 0, S->tol, S->maxIter, cheb); }
+            else {
+                iCtlKernel<<<1, 4, 0, s>>>(v.ctl, NR, 2, 0.0, 0, S->tol, S->maxIter, cheb);
+                iUpdateKernel<NR><<<nb, QGD_BLOCK, 0, s>>>(v);
+                iFoldKernel<<<2 * NR, QGD_BLOCK, 0, s>>>(v, NR, 2, I_ABSR2, 0, -1, 0);
+            }
             break;
         case 5:
-            iCtlKernel<<<1, 4, 0, s>>>(v.ctl, NR, 3, 0.0, 0, S->tol, S->maxIter);
-            iDirectionKernel<NR, 0><<<nb, QGD_BLOCK, 0, s>>>(v);
+            if (!S->cheb) {
+                iCtlKernel<<<1, 4, 0, s>>>(v.ctl, NR, 3, 0.0, 0, S->tol, S->maxIter, cheb);
+                iDirectionKernel<NR, 0><<<nb, QGD_BLOCK, 0, s>>>(v);
+            }
             break;
         default: throw std::invalid_argument("implicitSolvePhase: phase must be 0..5");
     }
     ICHECK(hipGetLastError());
 }
-// a, diag, rhs, x: the system (diag, rhs, x component-major with stride nC, nRhs in {1, 3}); validMask: bit k = component k is solved
+static void iPhase(ImplicitSolver* S, int phase, bool fused) {
+    if (S->NR == 4) iPhaseT<4>(S, phase, fused); else if (S->NR == 3) iPhaseT<3>(S, phase, fused); else iPhaseT<1>(S, phase, fused);
+}
+// a, diag, rhs, x: the system (diag, rhs, x component-major with stride nC, nRhs in {1, 3, 4}); validMask: bit k = component k is solved;
+// gamma (nullptr: ones): the face coefficients of component k are gamma[k] * a
 void implicitSolveSetup(ImplicitSolver* S, int nRhs, int validMask, const double* a, const double* diag, const double* rhs, double* x, double tol,
-                        int maxIter) {
+                        int maxIter, const double* gamma) {
+    if (nRhs != 1 && nRhs != 3 && nRhs != 4) throw std::invalid_argument("implicitSolveSetup: 1, 3 or 4 right-hand sides");
     ISolveView& v = S->v;
     v.NR = nRhs; v.ob = S->ob; v.n = S->oe - S->ob; v.nC = S->m.nC; v.a = a; v.diag = diag; v.rhs = rhs; v.x = x;
-    v.r = S->r; v.d = S->d; v.q = S->q; v.part = S->part; v.ctl = S->ctl; v.nBlocks = gridOf(v.n);
+    for (int k = 0; k < 4; ++k) v.gam[k] = gamma && k < nRhs ? gamma[k] : 1.0;
+    v.r = S->r; v.d = S->d; v.q = S->q; v.xb = S->xb; v.part = S->part; v.ctl = S->ctl; v.nBlocks = gridOf(v.n);
     v.xrun = S->rowRun;
     S->NR = nRhs; S->validMask = validMask; S->tol = tol; S->maxIter = maxIter;
 }
-void implicitSolvePhase(ImplicitSolver* S, int phase) {
-    if (S->NR == 3) iPhaseT<3>(S, phase); else iPhaseT<1>(S, phase);
+void implicitSolvePhase(ImplicitSolver* S, int phase) { iPhase(S, phase, false); }
+static bool iAllDone(const ImplicitSolver* S, const double* h) {
+    for (int k = 0; k < S->NR; ++k) if (h[ICTL(I_DONE, k)] == 0.0) return false;
+    return true;
 }
 // {all done, iterations[k], initial[k], final[k]} for k < 3; waits for the stream
 void implicitSolveStatus(ImplicitSolver* S, double* allDone, int iters[3], double res0[3], double res[3]) {
     double* h = S->hostCtl + 4 * I_COUNT;
     ICHECK(hipMemcpyAsync(h, S->ctl, sizeof(double) * I_COUNT, hipMemcpyDeviceToHost, S->stream));
     ICHECK(hipStreamSynchronize(S->stream));
-    *allDone = h[I_ALLDONE];
+    *allDone = iAllDone(S, h) ? 1.0 : 0.0;
     for (int k = 0; k < 3; ++k) {
         const bool on = k < S->NR && h[ICTL(I_DONE, k)] != 3.0;
         iters[k] = on ? (int)h[ICTL(I_ITER, k)] : 0; res0[k] = on ? h[ICTL(I_RES0, k)] : 0.0; res[k] = on ? h[ICTL(I_RES, k)] : 0.0;
     }
 }
-// the whole solve after implicitSolveSetup (see pressureSolveRun): at most two iterations queued ahead of the last "done" flag read back
+void implicitSolveStatus4(ImplicitSolver* S, double* allDone, int iters[4], double res0[4], double res[4]) {
+    double* h = S->hostCtl + 4 * I_COUNT;
+    ICHECK(hipMemcpyAsync(h, S->ctl, sizeof(double) * I_COUNT, hipMemcpyDeviceToHost, S->stream));
+    ICHECK(hipStreamSynchronize(S->stream));
+    *allDone = iAllDone(S, h) ? 1.0 : 0.0;
+    for (int k = 0; k < 4; ++k) {
+        const bool on = k < S->NR && h[ICTL(I_DONE, k)] != 3.0;
+        iters[k] = on ? (int)h[ICTL(I_ITER, k)] : 0; res0[k] = on ? h[ICTL(I_RES0, k)] : 0.0; res[k] = on ? h[ICTL(I_RES, k)] : 0.0;
+    }
+}
+double implicitSolverUnconverged(ImplicitSolver* S) {
+    double h = 0;
+    ICHECK(hipMemcpyAsync(&h, S->stats, sizeof(double), hipMemcpyDeviceToHost, S->stream));
+    ICHECK(hipStreamSynchronize(S->stream));
+    return h;
+}
+__global__ __launch_bounds__(QGD_BLOCK) void iVecHaloKernel(double* __restrict__ vec, const int nC, const int NR, const int32_t* __restrict__ cells,
+                                                          const int nCells, double* __restrict__ buf, const int pack) {
+    const int i = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    if (i >= nCells) return;
+    const size_t ci = (size_t)cells[i];
+    double* b = buf + (size_t)i * NR;
+    for (int k = 0; k < NR; ++k) { if (pack) b[k] = vec[(size_t)k * nC + ci]; else vec[(size_t)k * nC + ci] = b[k]; }
+}
+void launchSolverHalo(hipStream_t s, ImplicitSolver* S, const int32_t* cells, int nCells, double* buf, bool pack) {
+    if (nCells > 0) iVecHaloKernel<<<gridOf(nCells), QGD_BLOCK, 0, s>>>(S->cheb ? implicitSolverIterate(S) : S->d, S->m.nC, S->NR, cells, nCells, buf, pack ? 1 : 0);
+    ICHECK(hipGetLastError());
+}
+// the whole solve after implicitSolveSetup (see pressureSolveRun): at most two iterations queued ahead of the last "done" flags read back
 void implicitSolveRun(ImplicitSolver* S, const SolveHooks* hooks) {
     double* ctl = S->ctl;
-    auto reduce = [&](int firstSlot, int slots) { if (hooks && hooks->allreduce) hooks->allreduce(ctl + 4 * firstSlot, 4 * slots); };
+    const bool sharded = hooks && hooks->allreduce;
+    auto reduce = [&](int firstSlot, int slots) { if (sharded) hooks->allreduce(ctl + 4 * firstSlot, 4 * slots); };
     auto halo = [&]() { if (hooks && hooks->haloDirection) hooks->haloDirection(); };
     if (hooks && hooks->haloGuess) hooks->haloGuess();     // the neighbours' initial guesses into the ghost columns
-    implicitSolvePhase(S, 0);
+    iPhase(S, 0, false);
     reduce(I_ABSR, 3);
-    implicitSolvePhase(S, 1);
+    if (sharded && S->cheb) {
+        if (!hooks->allreduceBuf) throw std::logic_error("implicitSolveRun: the Chebyshev solver needs a MAX all-reduce (SolveHooks::allreduceBuf)");
+        hooks->allreduceBuf(ctl + 4 * I_DELTA, 4, 3);      // the spectral bound is the maximum over the ranks
+    }
+    iPhase(S, 1, false);
     reduce(I_NORM, 1);
-    implicitSolvePhase(S, 2);
-    reduce(I_RZ, 1);
+    iPhase(S, 2, false);
+    if (!S->cheb) reduce(I_RZ, 1);
     halo();
     const int ahead = 2;
     for (int it = 0; it < S->maxIter; ++it) {
         if (it >= ahead) {
             const int slot = (it - ahead) & 3;
             ICHECK(hipEventSynchronize(S->ev[slot]));
-            if (S->hostCtl[slot * I_COUNT + I_ALLDONE] != 0.0) break;
+            if (iAllDone(S, S->hostCtl + slot * I_COUNT)) break;
         }
-        implicitSolvePhase(S, 3);
-        reduce(I_DQ, 1);
-        implicitSolvePhase(S, 4);
-        reduce(I_ABSR2, 2);
-        implicitSolvePhase(S, 5);
-        halo();
+        iPhase(S, 3, !sharded);
+        reduce(I_DQ, 1);                                   // conjugate gradients: d.q; Chebyshev: sum |b - A x_i| (the same slot)
+        if (S->cheb) halo();                               // the new iterate's ghost entries do not wait for the control logic
+        iPhase(S, 4, !sharded);
+        if (!S->cheb) {
+            reduce(I_ABSR2, 2);
+            iPhase(S, 5, false);
+            halo();
+        }
         const int slot = it & 3;
         ICHECK(hipMemcpyAsync(S->hostCtl + slot * I_COUNT, ctl, sizeof(double) * I_COUNT, hipMemcpyDeviceToHost, S->stream));
         ICHECK(hipEventRecord(S->ev[slot], S->stream));
@@ -798,6 +1033,7 @@ void implicitSolveRun(ImplicitSolver* S, const SolveHooks* hooks) {
 
 // after a solve has finished: its control block is kept for qgd_case_implicit_info (which = 0: U, 1: e), the step's flag updated
 void implicitSolveEnd(ImplicitSolver* S, int which) {
+    if (S->cheb) iChebHomeKernel<<<S->v.nBlocks, QGD_BLOCK, 0, S->stream>>>(S->v);   // iterates that ended in the solver's buffer
     iStatKernel<<<1, 1, 0, S->stream>>>(S->ctl, S->stats, S->NR, 1, S->tol);
     ICHECK(hipMemcpyAsync(S->stats + 2 + (size_t)which * I_COUNT, S->ctl, sizeof(double) * I_COUNT, hipMemcpyDeviceToDevice, S->stream));
 }
@@ -821,23 +1057,29 @@ void implicitSolverInfo(ImplicitSolver* S, int iters[4], double res0[4], double 
 int implicitHaloWidth(const ImplicitSolver* S, int kind) { return kind == 1 ? 9 : (kind == 2 ? 3 : S->NR); }   // kinds 3, 4: one per right-hand side
 void launchImplicitHalo(hipStream_t s, const MeshView& m, const CaseView& c, const ImplView& iv, ImplicitSolver* S, int kind, const int32_t* cells,
                         int nCells, double* buf, bool pack) {
-    if (nCells > 0) implHaloKernel<<<gridOf(nCells), QGD_BLOCK, 0, s>>>(c, iv, kind == 4 ? S->v.x : S->d, m.nC, kind, S->NR, cells, nCells, buf, pack ? 1 : 0);
+    if (nCells > 0) implHaloKernel<<<gridOf(nCells), QGD_BLOCK, 0, s>>>(c, iv, kind == 4 ? S->v.x : (S->cheb ? implicitSolverIterate(S) : S->d), m.nC, kind, S->NR, cells, nCells, buf, pack ? 1 : 0);
     ICHECK(hipGetLastError());
 }
 void implicitSolverSetStream(ImplicitSolver* S, hipStream_t s) { S->stream = s; }
-// measurement: `reps` matrix products q = A d of the three-component U system (iApplyKernel<3, 1>, the kernel the branch spends most
-// of its time in) on the vectors the last step left, between two HIP events; returns the average ms.  The control block is cleared
-// first (a finished solve makes every launch return at once); it is only kept for implicitSolverInfo, which reads its own copy.
+// measurement: `reps` launches of the kernel the branch spends most of its time in -- one Chebyshev step of the three-component U
+// system (iChebKernel<3, 0>: product, d, next iterate, partial residual sums) or, with QGD_IMPL_SOLVER=pcg, its matrix product
+// q = A d (iApplyKernel<3, 1>) -- on the vectors the last step left, between two HIP events; returns the average ms.  The control
+// block is cleared first (a finished solve makes every launch return at once); it is only kept for implicitSolverInfo, which
+// reads its own copy.  The iterate of the U system is overwritten: call between steps only (the next step rebuilds it).
 double implicitApplyMs(ImplicitSolver* S, const ImplView& iv, int reps, int* rows) {
     implicitSolveSetup(S, 3, 7, iv.aU, iv.diagU, iv.rhsU, iv.xU, S->tol, S->maxIter);
     const ISolveView& v = S->v;
     *rows = v.n;
     hipEvent_t a, b;
     ICHECK(hipEventCreate(&a)); ICHECK(hipEventCreate(&b));
-    ICHECK(hipMemsetAsync(S->ctl, 0, sizeof(double) * I_COUNT, S->stream));
-    iApplyKernel<3, 1><<<v.nBlocks, QGD_BLOCK, 0, S->stream>>>(S->m, v);
+    ICHECK(hipMemsetAsync(S->ctl, 0, sizeof(double) * I_COUNT, S->stream));   // every component "running", step 0, c1 = c2 = 0
+    auto launch = [&]() {
+        if (S->cheb) iChebKernel<3, 0><<<v.nBlocks, QGD_BLOCK, 0, S->stream>>>(S->m, v);
+        else iApplyKernel<3, 1><<<v.nBlocks, QGD_BLOCK, 0, S->stream>>>(S->m, v);
+    };
+    launch();
     ICHECK(hipEventRecord(a, S->stream));
-    for (int i = 0; i < reps; ++i) iApplyKernel<3, 1><<<v.nBlocks, QGD_BLOCK, 0, S->stream>>>(S->m, v);
+    for (int i = 0; i < reps; ++i) launch();
     ICHECK(hipEventRecord(b, S->stream));
     ICHECK(hipGetLastError());
     ICHECK(hipEventSynchronize(b));

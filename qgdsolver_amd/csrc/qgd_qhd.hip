@@ -1,4 +1,5 @@
-// qgd_qhd.hip -- QHDFoam's loop body resident on the device (explicit branch, QHDFoam_8C_source.html L83-139):
+// qgd_qhd.hip -- QHDFoam's loop body resident on the device (QHDFoam_8C_source.html L83-139; both branches of implicitDiffusion:
+// fvc::laplacian in the face terms, or fvm::laplacian as ONE four-component system solved by qgd_implicit.hip's solver):
 //
 //   updateFields.H L36-73      gradUf, gradTf, Uf, Tf, BdFrcf                          face pass 1
 //   updateFluxes.H L33-38      phiu, phiwo, taubyrhof                                  face pass 1
@@ -191,11 +192,13 @@ __global__ __launch_bounds__(QGD_BLOCK) void qhdFace2Kernel(const MeshView m, co
         const double uw = S[0] * (Uf[0] * Wf[j]) + S[1] * (Uf[1] * Wf[j]) + S[2] * (Uf[2] * Wf[j]);   // Sf & (Uf*Wf), L39
         const double phiUf = phi * Uf[j] - uw;                                                       // L41-43
         const double lap = q.nu * snU[j] * magS;                                                     // fvc::laplacian(muf/rhof, U), L74
-        const double ext = S[0] * gUT[0 * 3 + j] + S[1] * gUT[1 * 3 + j] + S[2] * gUT[2 * 3 + j];    // Sf & lin(T(grad U)), L76
-        // the Gauss term of -fvc::grad(p)/rho (uniform rho) rides in the same face flux: S_j p_f / rho
-        q.F[(size_t)j * nF + pos] = ((phiUf - lap) - q.nu * ext) + (S[j] * pf) / q.rho0;
+        const double ext = S[0] * gUT[0 * 3 + j] + S[1] * gUT[1 * 3 + j] + S[2] * gUT[2 * 3 + j];    // Sf & lin(T(grad U)), L56 / L76
+        // the Gauss term of -fvc::grad(p)/rho (uniform rho) rides in the same face flux: S_j p_f / rho;
+        // implicitDiffusion: the laplacian sits in the matrix (fvm::laplacian, L54)
+        q.F[(size_t)j * nF + pos] = (q.implicit ? phiUf - q.nu * ext : (phiUf - lap) - q.nu * ext) + (S[j] * pf) / q.rho0;
     }
-    q.F[3 * nF + pos] = (phi * Tf - q.Hi * snT * magS) - q.phitr[f];                                   // QHDTEqn.H L65-66, L85-88
+    q.F[3 * nF + pos] = q.implicit ? phi * Tf - q.phitr[f]                                             // QHDTEqn.H L73-76
+                                   : (phi * Tf - q.Hi * snT * magS) - q.phitr[f];                      // QHDTEqn.H L65-66, L85-88
 }
 
 // explicit Euler of the U and T equations [QHDUEqn.H L68-84, QHDTEqn.H L83-91]
@@ -252,6 +255,126 @@ __global__ __launch_bounds__(QGD_BLOCK) void qhdCellUpdateKernel(const MeshView 
 #pragma unroll
     for (int k = 0; k < 3; ++k) rec[k] += q.dt * (-(s[k] * rV) + (q.beta * T) * q.g[k]);   // BdFrc = beta*T*g of updateFields.H L66
     rec[3] = T + q.dt * (-(s[3] * rV));
+}
+
+// ---- implicitDiffusion [QHDUEqn.H L46-65, QHDTEqn.H L69-80] ------------------------------------------------------------------------
+// patch coefficients of -fvm::laplacian(gamma, x) on owner-side boundary face f (L0): fixedValue: internal delta, source delta*value;
+// basicSymmetry (slip, U only): internal delta*|n_k|, source snGrad_k + delta*|n_k|*patchInternalField_k (transformFvPatchField);
+// zeroGradient: none.  ic[k] / bs[k] for k = Ux, Uy, Uz, T, in units of delta_f (the caller multiplies by gamma_k |Sf|); cur = the
+// owner's current {U, T} (nullptr: coefficients only)
+__device__ __forceinline__ void qhdPatchCoeffs(const MeshView& m, const PatchBCDev& bc, const int f, const double* cur, double ic[4], double bs[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ic[k] = bs[k] = 0.0;
+    if (bc.ptype == QGD_PATCH_HALO || bc.ptype == QGD_PATCH_CYCLIC) return;
+    const double dc = m.dn[f];
+    if (bc.bcU == QGD_BC_FIXEDVALUE) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { ic[k] = dc; bs[k] = dc * bc.vU[k]; }
+    } else if (bc.bcU == QGD_BC_SLIP) {
+        const double ms = m.magSf[f];
+        const double n[3] = {m.Sx[f] / ms, m.Sy[f] / ms, m.Sz[f] / ms};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) ic[k] = dc * fabs(n[k]);
+        if (cur) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const double tv = ((i == 0 ? 1.0 : 0.0) - 2.0 * (n[i] * n[0])) * cur[0] + ((i == 1 ? 1.0 : 0.0) - 2.0 * (n[i] * n[1])) * cur[1] +
+                                  ((i == 2 ? 1.0 : 0.0) - 2.0 * (n[i] * n[2])) * cur[2];
+                bs[i] = (tv - cur[i]) * (dc / 2.0) + ic[i] * cur[i];   // basicSymmetry::snGrad + gIC * patchInternalField
+            }
+        }
+    }
+    if (bc.bcT == QGD_BC_FIXEDVALUE) { ic[3] = dc; bs[3] = dc * bc.vT; }
+}
+// the shared face coefficient |Sf| delta_f at the face's slot-major position (what the matrix products gather)
+__global__ __launch_bounds__(QGD_BLOCK) void qhdImplicitFaceCoefKernel(const MeshView m, const QhdView q) {
+    const int f = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    if (f >= m.nF) return;
+    const size_t pos = f < m.nIF ? (size_t)m.fpos[f] : (size_t)f;
+    q.aG[pos] = m.fkind[f] == 3 ? 0.0 : m.magSf[f] * m.dn[f];   // nonOrthDeltaCoeffs inside, deltaCoeffs on patches
+}
+// the diagonals: V/deltaT + gamma_k (sum of the internal faces' coefficients + the patch internal coefficients)
+__global__ __launch_bounds__(QGD_BLOCK) void qhdImplicitDiagKernel(const MeshView m, const QhdView q, const PatchBCDev* __restrict__ bcs) {
+    const int c = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    if (c >= m.nC) return;
+    const size_t nC = (size_t)m.nC;
+    if (m.ghost && m.ghost[c] == 1) { for (int k = 0; k < 4; ++k) q.diag4[(size_t)k * nC + c] = 1.0; return; }   // never a row
+    const int n = m.cfCount[c];
+    const size_t base = (size_t)m.cfSlice[c >> 6] * 64 + (c & 63);
+    double inner = 0.0, pc[4] = {0, 0, 0, 0};
+    for (int i = 0; i < n; ++i) {
+        const int it = m.cfItem[base + (size_t)i * 64], ps = m.cfPos[base + (size_t)i * 64];
+        const int f = it >= 0 ? it : ~it;
+        const double g = q.aG[ps >= 0 ? ps : ~ps];
+        if (f < m.nIF) { inner += g; continue; }
+        if (m.fkind[f] == 3) continue;
+        double ic[4], bs[4];
+        qhdPatchCoeffs(m, bcs[m.bPatch[f - m.nIF]], f, nullptr, ic, bs);
+        const double ms = m.magSf[f];
+        for (int k = 0; k < 4; ++k) pc[k] += ms * ic[k];
+    }
+    const double rDV = (1.0 / q.dt) * m.V[c];
+    for (int k = 0; k < 4; ++k) {
+        const double gam = k < 3 ? q.nu : q.Hi;
+        q.diag4[(size_t)k * nC + c] = (rDV + gam * inner) + gam * pc[k];
+    }
+}
+// right-hand sides and start values of the four systems: fvm::ddt's source + V (-div(face terms) + BdFrc) + the patch sources
+__global__ __launch_bounds__(QGD_BLOCK) void qhdImplicitRhsKernel(const MeshView m, const QhdView q, const PatchBCDev* __restrict__ bcs) {
+    const int c = xcdTile((int)gridDim.x, m.xcdRun) * QGD_BLOCK + threadIdx.x;
+    if (c >= m.nC) return;
+    const size_t nC = (size_t)m.nC, nF = (size_t)m.nF;
+    double cur[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { cur[k] = q.c4[(size_t)c * 4 + k]; q.x4[(size_t)k * nC + c] = cur[k]; }   // ghost columns start from the state message
+    if (m.ghost && m.ghost[c] == 1) return;
+    const int n = m.cfCount[c];
+    const size_t base = (size_t)m.cfSlice[c >> 6] * 64 + (c & 63);
+    double s[4] = {0, 0, 0, 0}, src[4] = {0, 0, 0, 0};
+    for (int i0 = 0; i0 < n; i0 += 8) {   // eight faces per pass: positions, then the 32 terms in flight before the ordered sums (ascending face label)
+        int it[8], ps[8];
+        double x[8][4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool on = i0 + u < n;
+            it[u] = on ? m.cfItem[base + (size_t)(i0 + u) * 64] : 0;
+            ps[u] = on ? m.cfPos[base + (size_t)(i0 + u) * 64] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool on = i0 + u < n;
+            const size_t pos = (size_t)(ps[u] >= 0 ? ps[u] : ~ps[u]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) x[u][k] = on ? q.F[(size_t)k * nF + pos] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (i0 + u >= n) continue;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s[k] = ps[u] >= 0 ? s[k] + x[u][k] : s[k] - x[u][k];
+            const int f = it[u] >= 0 ? it[u] : ~it[u];
+            if (f >= m.nIF && m.fkind[f] != 3) {
+                double ic[4], bs[4];
+                qhdPatchCoeffs(m, bcs[m.bPatch[f - m.nIF]], f, cur, ic, bs);
+                const double ms = m.magSf[f];
+                for (int k = 0; k < 4; ++k) src[k] += ((k < 3 ? q.nu : q.Hi) * ms) * bs[k];
+            }
+        }
+    }
+    const double V = m.V[c], rV = 1.0 / V, rD = 1.0 / q.dt;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        q.rhs4[(size_t)k * nC + c] = (rD * cur[k] * V + V * (-(s[k] * rV) + (q.beta * cur[3]) * q.g[k])) + src[k];   // BdFrc = beta*T*g [updateFields.H L66]
+    q.rhs4[3 * nC + c] = (rD * cur[3] * V + V * (-(s[3] * rV))) + src[3];
+}
+// the solution into the records (components that were not solved keep their values)
+__global__ __launch_bounds__(QGD_BLOCK) void qhdImplicitStoreKernel(const MeshView m, const QhdView q, const int validMask) {
+    const int c = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    if (c >= m.nC) return;
+    if (m.ghost && m.ghost[c] == 1) return;
+    const size_t nC = (size_t)m.nC;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if ((validMask >> k) & 1) q.c4[(size_t)c * 4 + k] = q.x4[(size_t)k * nC + c];
 }
 
 // correctBoundaryConditions of U and T after their solves
@@ -416,6 +539,30 @@ void launchQhdAdvance(hipStream_t s, int stencil, bool usesPoints, const MeshVie
     qhdCellUpdateKernel<<<gridOf(m.nC), QGD_BLOCK, 0, s>>>(m, q);
     if (m.nBF) qhdBcKernel<<<gridOf(m.nBF), QGD_BLOCK, 0, s>>>(m, q, bc);
     if (needRef) qhdRefReadKernel<<<1, 1, 0, s>>>(q, localRefCell, refValue, shift);
+}
+void launchQhdImplicitMatrix(hipStream_t s, const MeshView& m, const QhdView& q, const PatchBCDev* bc) {
+    qhdImplicitFaceCoefKernel<<<gridOf(m.nF), QGD_BLOCK, 0, s>>>(m, q);
+    qhdImplicitDiagKernel<<<gridOf(m.nC), QGD_BLOCK, 0, s>>>(m, q, bc);
+}
+void launchQhdImplicitAdvance(hipStream_t s, int stencil, bool usesPoints, const MeshView& m, const QhdView& q, const PatchBCDev* bc, int part,
+                              int validMask, bool needRef, int localRefCell, double refValue, double* shift) {
+    if (part == 0) {
+        if (usesPoints) {
+            pointInterpFastKernel<1><<<gridOf(m.nP), QGD_BLOCK, 0, s>>>(m, q.p, q.ptp);
+            if (m.nBP) boundaryPointKernel<1><<<gridOf(m.nBP), QGD_BLOCK, 0, s>>>(m, q.pb, 1, q.ptp, 1, 0);
+        }
+        switch (stencil) {
+            case ST_REDUCED: face2<ST_REDUCED>(s, m, q, bc); break;
+            case ST_LSQ: face2<ST_LSQ>(s, m, q, bc); break;
+            case ST_GVP3: face2<ST_GVP3>(s, m, q, bc); break;
+            default: face2<ST_GVP2>(s, m, q, bc); break;
+        }
+        qhdImplicitRhsKernel<<<gridOf(m.nC), QGD_BLOCK, 0, s>>>(m, q, bc);
+    } else {
+        qhdImplicitStoreKernel<<<gridOf(m.nC), QGD_BLOCK, 0, s>>>(m, q, validMask);
+        if (m.nBF) qhdBcKernel<<<gridOf(m.nBF), QGD_BLOCK, 0, s>>>(m, q, bc);
+        if (needRef) qhdRefReadKernel<<<1, 1, 0, s>>>(q, localRefCell, refValue, shift);
+    }
 }
 // end of the step: the (global) shift of p [QHDFoam.C L123-130]
 void launchQhdFinish(hipStream_t s, const MeshView& m, const QhdView& q, bool needRef, const double* shift) {

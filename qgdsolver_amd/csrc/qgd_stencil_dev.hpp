@@ -12,10 +12,14 @@ namespace qgd {
 
 __device__ __forceinline__ double lerpf(double w, double a, double b) { return w * (a - b) + b; }
 
-// QGD_F_DIET (compile-time experiment): reciprocal by v_rcp_f64 + two Newton steps (~1 ulp) instead of
-// the IEEE division sequence (div_scale x2, rcp, 6 fma, div_fmas, div_fixup) in the face kernels' five divisions
+// The five fp64 divisions of a face -- 1/(6V) of the Gauss coefficients, p/rho/rho of the heat flux, muQGD/PrQGD of the two cells' alphaEff --
+// as v_rcp_f64 + two Newton steps (<= 1-2 ulp) or a product with the precomputed 1/PrQGD instead of the IEEE division sequence
+// (v_div_scale x2, v_rcp, 6 fma, v_div_fmas, v_div_fixup): -43 of 726 fp64 instructions of the staged face kernel, F 7.31 -> 7.12 ms at
+// 64 M cells on one box (profiles/r04_ab_face_instruction_diet.txt).  A deliberate deviation of a few ulp from the listing's
+// divisions, the same in every face kernel (staged, gather, 2-D, boundary), so they stay bit-identical to each
+// other.  -DQGD_F_DIET=0 builds the divisions back.
 #ifndef QGD_F_DIET
-#define QGD_F_DIET 0
+#define QGD_F_DIET 1
 #endif
 __device__ __forceinline__ double rcpNewton(const double x) {
     double r = __builtin_amdgcn_rcp(x);

@@ -245,7 +245,7 @@ class NativeComm:
 # ---- QHDFoam on cell-range shards ----------------------------------------------------------------------------------------
 # control-block slots that are global sums (include/qgd_amd.h "the QHD case on a cell-range shard")
 QHD_REDUCE_AFTER_PHASE = {0: (0, 3), 1: (3, 1), 2: (4, 1), 3: (5, 1), 4: (6, 2), 7: (8, 1)}
-QHD_STATE, QHD_PRESSURE, QHD_DIRECTION, QHD_MG_ITERATE = 0, 1, 2, 3   # halo message kinds
+QHD_STATE, QHD_PRESSURE, QHD_DIRECTION, QHD_MG_ITERATE, QHD_IMPLICIT_ITERATE = 0, 1, 2, 3, 4   # halo message kinds
 
 
 class QhdStepper:
@@ -286,6 +286,22 @@ class QhdStepper:
             w.phase(6)
             w.exchange(QHD_PRESSURE)
             w.phase(7)
+            if w.implicit():
+                # implicitDiffusion: the four systems {Ux, Uy, Uz, T} as one solve with its own control block; phases 10..15 are the
+                # solver phases of the QGDFoam branch (22..27 there), message kind 4 carries what the next product reads in the ghosts
+                for sp in (0, 1, 2):
+                    w.phase(10 + sp)
+                    w.allreduce(*IMPL_REDUCE_AFTER_SOLVER_PHASE[sp], block="implicit")
+                    if sp == 0:
+                        w.allreduce(*IMPL_MAX_AFTER_SOLVER_PHASE_0, op="max", block="implicit")
+                w.exchange(QHD_IMPLICIT_ITERATE)
+                while not w.done(block="implicit"):
+                    for sp in (3, 4):
+                        w.phase(10 + sp)
+                        w.allreduce(*IMPL_REDUCE_AFTER_SOLVER_PHASE[sp], block="implicit")
+                    w.phase(15)
+                    w.exchange(QHD_IMPLICIT_ITERATE)
+                w.phase(16)
             w.allreduce(*QHD_REDUCE_AFTER_PHASE[7])
             w.phase(8)
             w.exchange(QHD_STATE)
@@ -338,12 +354,18 @@ class LocalWorld:
             for c in self.cases:
                 c.step_phase(9)
 
-    def allreduce(self, first, count):
-        ctl = [c.control() for c in self.cases]
-        total = sum(a[first:first + count] for a in ctl)
+    def implicit(self):
+        return bool(getattr(self.cases[0], "implicit", False))
+
+    def allreduce(self, first, count, op="sum", block=None):
+        """block="implicit": the control block of a QHD case's implicitDiffusion solve instead of the pressure solve's"""
+        import numpy as np
+        get = (lambda c: c.implicit_control()) if block == "implicit" else (lambda c: c.control())
+        ctl = [get(c) for c in self.cases]
+        total = sum(a[first:first + count] for a in ctl) if op == "sum" else np.max([a[first:first + count] for a in ctl], axis=0)
         for c, a in zip(self.cases, ctl):
             a[first:first + count] = total
-            c.set_control(a)
+            c.set_implicit_control(a) if block == "implicit" else c.set_control(a)
 
     def exchange(self, kind):
         for (r, slot), buf in self.buf.items():
@@ -358,8 +380,8 @@ class LocalWorld:
         for c in self.cases:
             c.sync()
 
-    def done(self):
-        flags = [c.solve_status()["done"] for c in self.cases]
+    def done(self, block=None):
+        flags = [(1 if c.implicit_solve_done() else 0) if block == "implicit" else c.solve_status()["done"] for c in self.cases]
         assert all(f == flags[0] for f in flags), flags
         return flags[0] != 0
 
@@ -405,16 +427,21 @@ class DistWorld:
                 self.case.sync()
             self.case.step_phase(9)
 
-    def allreduce(self, first, count):
+    def implicit(self):
+        return bool(getattr(self.case, "implicit", False))
+
+    def allreduce(self, first, count, op="sum", block=None):
+        rop = self.dist.ReduceOp.SUM if op == "sum" else self.dist.ReduceOp.MAX
+        imp = block == "implicit"
         if self.device_reduce:
-            t = device_tensor(self.torch, self.case.control_ptr() + 8 * first, count)
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+            t = device_tensor(self.torch, (self.case.implicit_control_ptr() if imp else self.case.control_ptr()) + 8 * first, count)
+            self.dist.all_reduce(t, op=rop)
             return
-        a = self.case.control()
+        a = self.case.implicit_control() if imp else self.case.control()
         t = self.torch.from_numpy(a[first:first + count].copy())
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        self.dist.all_reduce(t, op=rop)
         a[first:first + count] = t.numpy()
-        self.case.set_control(a)
+        self.case.set_implicit_control(a) if imp else self.case.set_control(a)
 
     def exchange(self, kind):
         if not self.slots:
@@ -439,13 +466,16 @@ class DistWorld:
             self.case.halo_unpack(s, kind, self.rbuf[s])
         self.case.sync()
 
-    def done(self):
+    def done(self, block=None):
+        if block == "implicit":
+            return self.case.implicit_solve_done()
         return self.case.solve_status()["done"] != 0
 
 
 # ---- QGDFoam with implicitDiffusion true (the reference's default) on cell-range shards ---------------------------------------
 # control-block ranges (slot-major, 4 components per slot) that are global sums, by SOLVER phase 0..4
 IMPL_REDUCE_AFTER_SOLVER_PHASE = {0: (0, 12), 1: (12, 4), 2: (16, 4), 3: (20, 4), 4: (24, 8)}
+IMPL_MAX_AFTER_SOLVER_PHASE_0 = (32, 4)   # control slot 8: max over the ranks (Gershgorin radius of the Chebyshev solves)
 IMPL_STATE, IMPL_GRADU, IMPL_U, IMPL_DIRECTION, IMPL_GUESS = 0, 1, 2, 3, 4   # message kinds (0: the case's own state message)
 IMPL_MID = 5   # the message in the middle of the flux assembly (qgd_case_mid_halo_*)
 
@@ -521,6 +551,8 @@ class ImplicitStepper:
         for sp in (0, 1, 2):
             w.phase(22 + sp)
             w.allreduce(*IMPL_REDUCE_AFTER_SOLVER_PHASE[sp])
+            if sp == 0:
+                w.allreduce(*IMPL_MAX_AFTER_SOLVER_PHASE_0, op="max")   # the Chebyshev solves' spectral bound (zeros under PCG)
         w.exchange(IMPL_DIRECTION)
         while not w.done():
             for sp in (3, 4):

@@ -171,7 +171,7 @@ def qhd_options(**kw):
 
 
 class QHDFoamCase:
-    """createFields.H + the while-loop body of QHDFoam.C L83-139 (explicit branch) over the C-ABI (qgd_qhd_case_*)"""
+    """createFields.H + the while-loop body of QHDFoam.C L83-139 (both branches of implicitDiffusion) over the C-ABI (qgd_qhd_case_*)"""
 
     def __init__(self, dev, options=None):
         self.dev, self.mesh = dev, dev.mesh
@@ -231,6 +231,40 @@ class QHDFoamCase:
         a = np.ascontiguousarray(a, dtype=np.float64)
         assert a.size == 16
         L.check(L.lib.qgd_qhd_case_control(self._h, a.ctypes.data_as(L.c_double_p), 1), "qgd_qhd_case_control")
+
+    # ---- implicitDiffusion: the solve of the four systems {Ux, Uy, Uz, T} (its own 68-double control block) ----
+    @property
+    def implicit(self):
+        return bool(self.options.implicitDiffusion)
+
+    def implicit_control(self):
+        a = np.zeros(68)
+        L.check(L.lib.qgd_qhd_case_implicit_control(self._h, a.ctypes.data_as(L.c_double_p), 0), "qgd_qhd_case_implicit_control")
+        return a
+
+    def set_implicit_control(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        assert a.size == 68
+        L.check(L.lib.qgd_qhd_case_implicit_control(self._h, a.ctypes.data_as(L.c_double_p), 1), "qgd_qhd_case_implicit_control")
+
+    def implicit_control_ptr(self):
+        p = C.c_void_p()
+        L.check(L.lib.qgd_qhd_case_implicit_control_ptr(self._h, C.byref(p)), "qgd_qhd_case_implicit_control_ptr")
+        return p.value
+
+    def implicit_solve_done(self):
+        a = (C.c_double * 2)()
+        L.check(L.lib.qgd_qhd_case_implicit_solve_status(self._h, a), "qgd_qhd_case_implicit_solve_status")
+        return a[0] != 0.0
+
+    def implicit_info(self):
+        """iterations / initial / final residual of Ux, Uy, Uz, T in the last step (what OpenFOAM prints per solve), the steps in which
+        a solve stopped above implicitTol, and the algorithm (QGD_IMPL_SOLVER)"""
+        a = (C.c_double * 14)()
+        L.check(L.lib.qgd_qhd_case_implicit_info(self._h, a), "qgd_qhd_case_implicit_info")
+        names = ("Ux", "Uy", "Uz", "T")
+        return dict(implicit=a[13] != 0.0, solver={0: None, 1: "pcg", 2: "chebyshev"}[int(a[13])], unconverged_steps=int(a[12]),
+                    solves={n: dict(iterations=int(a[k]), initial=a[4 + k], final=a[8 + k]) for k, n in enumerate(names)})
 
     def solve_status(self):
         a = (C.c_double * 4)()

@@ -78,7 +78,8 @@ class QhdOptions(C.Structure):
                 ("pMaxIter", C.c_int32), ("precond", C.c_int32),
                 ("rho0", C.c_double), ("mu", C.c_double), ("Pr", C.c_double), ("beta", C.c_double), ("g", C.c_double * 3),
                 ("deltaT", C.c_double), ("Tau", C.c_double), ("aQGD", C.c_double), ("UQHD", C.c_double), ("T0", C.c_double),
-                ("Gr", C.c_double), ("pTol", C.c_double), ("pRelTol", C.c_double), ("pRefValue", C.c_double)]
+                ("Gr", C.c_double), ("pTol", C.c_double), ("pRelTol", C.c_double), ("pRefValue", C.c_double),
+                ("implicitTol", C.c_double), ("implicitMaxIter", C.c_int32), ("pad_", C.c_int32)]
 
 
 lib.orc_qhd_case_create.restype = C.c_void_p

@@ -173,3 +173,34 @@ def test_implicit_solves_report_their_convergence():
     ex.step(1)
     assert not ex.implicit_info()["implicit"] and ex.implicit_info()["unconverged_steps"] == 0
     good.close(); starved.close(); ex.close(); dev.close()
+
+
+@pytest.mark.gpu
+def test_conjugate_gradient_solver_is_still_selectable(monkeypatch):
+    """round 4's default for the U and e systems is the Chebyshev iteration (no dot products: one kernel + one fold per iteration);
+    QGD_IMPL_SOLVER=pcg keeps round 3's Jacobi-preconditioned conjugate gradients.  Same answer to the solver tolerance, and an
+    unknown word is refused"""
+    mesh = make_mesh("box654_jitter")
+    fields = cases.box_initial_fields(mesh.array("C").reshape(-1, 3))
+    opt = dict(stencil="GaussVolPoint", deltaT=5e-4, mu=2e-2, implicitDiffusion=1, implicitTol=1e-14, implicitMaxIter=2000)
+    ref = run_oracle(mesh, mixed_bcs, fields, 8, **opt)
+    dev = q.Device(mesh)
+    its = {}
+    for solver in ("cheb", "pcg"):
+        monkeypatch.setenv("QGD_IMPL_SOLVER", solver)
+        gc = q.QGDFoamCase(dev, q.default_options(**opt))
+        mixed_bcs(gc)
+        gc.set_fields(*fields)
+        gc.step(8)
+        for f in ref:
+            err = np.abs(gc.field(f) - ref[f]).max() / np.abs(ref[f]).max()
+            assert err <= 1e-10, (solver, f, err)
+        ii = gc.implicit_info()
+        assert ii["unconverged_steps"] == 0
+        its[solver] = max(s["iterations"] for s in ii["solves"].values())
+        gc.close()
+    assert 0 < its["cheb"] <= 2 * its["pcg"] + 4, its       # the Chebyshev bound is the conjugate-gradient bound
+    monkeypatch.setenv("QGD_IMPL_SOLVER", "sor")
+    with pytest.raises(q.QgdError):
+        q.QGDFoamCase(dev, q.default_options(**opt))
+    dev.close()
