@@ -554,6 +554,10 @@ def qhd_line(args):
 # = 144 B for the matrix product; x, r, d, q, diag read and x, r written = 168 B for the update; r, diag, d read and d written =
 # 96 B for the direction), and a third of the vector part for the one-component e system
 IMPL_APPLY_BYTES_PER_CELL = 144
+# one Chebyshev step of the three-component system (round 4's default solver: product, d, next iterate, partial residual sums in ONE
+# kernel): 6 list entries x 8 B + 3 face coefficients x 8 B + per component diag, rhs, x, d read and d, x written = 3 x 48 B
+IMPL_CHEB_BYTES_PER_CELL = 48 + 24 + 3 * 48
+IMPL_CHEB_BYTES_PER_CELL_E = 48 + 24 + 48
 IMPL_ITER_BYTES_PER_CELL_U = 144 + 168 + 96
 IMPL_ITER_BYTES_PER_CELL_E = 48 + 24 + 24 + 56 + 32
 
@@ -599,7 +603,8 @@ def implicit_line(args):
     elapsed = time.perf_counter() - t0
     info, solves = case.info(), case.implicit_info()
     ap = case.implicit_apply_time(30)
-    apply_bytes = IMPL_APPLY_BYTES_PER_CELL * ap["rows"]
+    cheb = solves.get("solver") == "chebyshev"
+    apply_bytes = (IMPL_CHEB_BYTES_PER_CELL if cheb else IMPL_APPLY_BYTES_PER_CELL) * ap["rows"]
     achieved = apply_bytes / (ap["ms"] * 1e-3) / 1e9 if ap["ms"] else None
     it_u = max(solves["solves"][k]["iterations"] for k in ("Ux", "Uy", "Uz"))
     it_e = solves["solves"]["e"]["iterations"]
@@ -609,14 +614,19 @@ def implicit_line(args):
         "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": (f"QGDFoam {n}^3 = {nc / 1e6:.1f}M-cell uniform hex box (blockMesh numbering), GaussVolPoint, constScPrModel1, "
                                 "implicitDiffusion true (the reference's default), mu = 1e-3, zeroGradient patches, fixed deltaT, "
-                                "U and e systems by Jacobi-PCG to 1e-10"),
+                                + ("U and e systems by Chebyshev iteration on the Jacobi-preconditioned systems to 1e-10" if cheb
+                                   else "U and e systems by Jacobi-PCG to 1e-10 (QGD_IMPL_SOLVER=pcg)")),
                    "cells": nc, "iterations_U": it_u, "iterations_e": it_e, "unconverged_steps": solves["unconverged_steps"], "env": qgd_env()},
-        "roofline": {"bound": "hbm", "kernel": "iApplyKernel<3,1> (matrix product of the three-component U system, one walk of the matrix for the three right-hand sides)",
+        "roofline": {"bound": "hbm", "kernel": ("iChebKernel<3,0> (one Chebyshev step of the three-component U system: matrix product, d, next iterate and the "
+                                                "partial residual sums in one walk of the matrix for the three right-hand sides)" if cheb else
+                                                "iApplyKernel<3,1> (matrix product of the three-component U system, one walk of the matrix for the three right-hand sides)"),
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS if achieved else None,
-                     "traffic": secondary_traffic("implicit_n200") if n == 200 else None, "traffic_is_static": True,
+                     "traffic": secondary_traffic("implicit_n200") if (n == 200 and not cheb) else None, "traffic_is_static": True,
                      "traffic_source": SECONDARY_TRAFFIC_SOURCE, "algorithmic_bytes_per_launch": apply_bytes, "avg_launch_ms": ap["ms"]},
-        "solver_bytes_model": {"per_cell_per_iteration_U": IMPL_ITER_BYTES_PER_CELL_U, "per_cell_per_iteration_e": IMPL_ITER_BYTES_PER_CELL_E,
-                               "bytes_per_step_in_the_solves": nc * (IMPL_ITER_BYTES_PER_CELL_U * it_u + IMPL_ITER_BYTES_PER_CELL_E * it_e)},
+        "solver_bytes_model": {"per_cell_per_iteration_U": IMPL_CHEB_BYTES_PER_CELL if cheb else IMPL_ITER_BYTES_PER_CELL_U,
+                               "per_cell_per_iteration_e": IMPL_CHEB_BYTES_PER_CELL_E if cheb else IMPL_ITER_BYTES_PER_CELL_E,
+                               "bytes_per_step_in_the_solves": nc * ((IMPL_CHEB_BYTES_PER_CELL if cheb else IMPL_ITER_BYTES_PER_CELL_U) * it_u
+                                                                     + (IMPL_CHEB_BYTES_PER_CELL_E if cheb else IMPL_ITER_BYTES_PER_CELL_E) * it_e)},
         "min_rho": info["minRho"], "setup_s": t_setup,
     }
     case.close(); dev.close()

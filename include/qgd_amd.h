@@ -330,12 +330,27 @@ int qgd_species_flux_dev(qgd_device_t d, int stencilId, const double* Y, const d
  * QGDRhoEqn), phiJmY [nFaces] (qgd_species_flux), muf [nFaces] (qgd_case_get_field "muf"), Sc = ScNumbers[i], deltaT.
  * In/out: diffusiveFlux [nFaces].  Out: Ynew [nCells].  Euler ddt, fvc::div = surfaceIntegrate in ascending face label, Gauss laplacian
  * with the uncorrected snGrad (L0).  The inert species (L65 / L83, L90-91: Y_inert = 1 - sum, diffusiveFlux_inert -= diffusiveFlux_i)
- * is two axpys over these arrays and stays with the caller (qgdsolver_amd.qgdfoam.QGDYEqn does it).  The implicitDiffusion branch of
- * the species equation (L47-66) is not provided. */
+ * is two axpys over these arrays and stays with the caller (qgdsolver_amd.qgdfoam.QGDYEqn does it). */
 int qgd_species_step(qgd_device_t d, const double* Y, const double* Yb, const double* rhoOld, const double* rho, const double* phiJmY,
                      const double* muf, double Sc, double deltaT, const double* Su, double* diffusiveFlux, double* Ynew);
 int qgd_species_step_dev(qgd_device_t d, const double* Y, const double* Yb, const double* rhoOld, const double* rho, const double* phiJmY,
                          const double* muf, double Sc, double deltaT, const double* Su, double* diffusiveFlux, double* Ynew);   /* device pointers */   /* device pointers */
+
+/* The same equation, implicitDiffusion branch -- QGDYEqn_8H_source.html L47-66:
+ *     fvScalarMatrix YEqn(fvm::ddt(rho,Yi) + fvc::div(phiJmYi) - fvm::laplacian(muf/ScNumbers[i],Yi) == combustion->R(Yi) + parcels.SYi(i, Yi));
+ *     YEqn.solve();   diffusiveFlux[i] += YEqn.flux();   Yi.max(0.0);
+ * Arguments as above plus fixedValueFace [nBoundaryFaces] (1: the face belongs to a fixedValue patch of Yi, value Yb: diagonal and source
+ * coefficients |Sf| delta (muf/Sc); 0: zeroGradient, no contribution; NULL: all zeroGradient), and the controls fvSolution gives the
+ * solver of Yi: tolerance on OpenFOAM's normalised residual, maxIter.  YEqn.flux() is the matrix's own face flux (L0 fvMatrix::flux) of
+ * the NEW Yi: -a_f (Y_N - Y_O) inside, -a_b (Y_b - Y_P) on fixedValue faces -- the sign "- fvm::laplacian" gives it, opposite to the
+ * explicit branch's +(muf/Sc) snGrad |Sf| of L82; replicated as listed.  info (host) = {iterations, initial, final residual}.  Solved by
+ * the library's device-resident solver (Chebyshev iteration, or conjugate gradients with QGD_IMPL_SOLVER=pcg); one device, no shards. */
+int qgd_species_step_implicit(qgd_device_t d, const double* Y, const double* Yb, const uint8_t* fixedValueFace, const double* rhoOld,
+                              const double* rho, const double* phiJmY, const double* muf, double Sc, double deltaT, const double* Su,
+                              double tolerance, int32_t maxIter, double* diffusiveFlux, double* Ynew, double info[3]);
+int qgd_species_step_implicit_dev(qgd_device_t d, const double* Y, const double* Yb, const uint8_t* fixedValueFace, const double* rhoOld,
+                                  const double* rho, const double* phiJmY, const double* muf, double Sc, double deltaT, const double* Su,
+                                  double tolerance, int32_t maxIter, double* diffusiveFlux, double* Ynew, double info[3]);   /* device pointers */
 
 /* QHDFoam's pressure equation -- QHDpEqn_8H_source.html L35-47:
  *     fvScalarMatrix pEqn(fvc::div(phiu) - fvc::div(phiwo) - fvm::laplacian(taubyrhof, p));
@@ -552,7 +567,8 @@ int qgd_case_info(qgd_case_t c, double info[6]);
  * residual = ..., Final residual = ..., No Iterations ...") [QGDUEqn_8H_source.html L54-68, QGDEEqn_8H_source.html L53-61]:
  * info[0..3] = iterations of Ux, Uy, Uz, e; [4..7] = initial, [8..11] = final normalised residuals; [12] = number of steps
  * since qgd_case_set_fields in which a solve stopped above implicitTol (iteration limit or breakdown: the step keeps the last
- * iterate, as OpenFOAM does, and counts here); [13] = 1 when the case runs the implicit branch. */
+ * iterate, as OpenFOAM does, and counts here); [13] = 0 explicit branch | 1 implicit, conjugate gradients (QGD_IMPL_SOLVER=pcg) |
+ * 2 implicit, Chebyshev iteration (the default). */
 int qgd_case_implicit_info(qgd_case_t c, double info[14]);
 /* measurement: `reps` matrix products of the three-component U system (QGDUEqn_8H_source.html L54-68: the `fvm::laplacian(muf,U)`
  * matrix applied to a search direction; the kernel the branch spends most of its time in) between two HIP events, on the vectors

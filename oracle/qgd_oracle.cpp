@@ -3147,6 +3147,62 @@ int orc_species_step(void* mp, const double* Yc, const double* Yb, const double*
     return 0;
 }
 
+// QGDYEqn.H L47-66, one species, implicitDiffusion branch: fvm::ddt(rho,Yi) + fvc::div(phiJmYi) - fvm::laplacian(muf/Sc, Yi) == Su;
+// diffusiveFlux += YEqn.flux() (L0 fvMatrix::flux: upper psi_N - lower psi_O with upper = lower = -a for "- fvm::laplacian", patch
+// faces internalCoeffs psi_P - boundaryCoeffs); Yi.max(0).  fixedFace[b] != 0: the face belongs to a fixedValue patch of Yi.
+int orc_species_step_implicit(void* mp, const double* Yc, const double* Yb, const uint8_t* fixedFace, const double* rhoOld, const double* rho,
+                              const double* phiJmY, const double* muf, double Sc, double deltaT, const double* Su, double tol, int32_t maxIter,
+                              double* diffusiveFlux, double* Ynew, double info[3]) {
+    MeshHandle* h = (MeshHandle*)mp;
+    const Mesh& m = h->m;
+    const int nC = m.nC, nF = m.nF;
+    std::vector<char> live(nF, 1);
+    for (size_t ip = 0; ip < m.patches.size(); ++ip)
+        if (!m.patchHasFields((int)ip) || m.patches[ip].type == PATCH_HALO)
+            for (int f = m.patches[ip].start; f < m.patches[ip].start + m.patches[ip].size; ++f) live[f] = 0;
+    dvec a((size_t)nF, 0.0), diag((size_t)nC), rhs((size_t)nC), d1((size_t)nC, 0.0);
+    for (int f = 0; f < nF; ++f) if (live[f]) a[f] = (muf[f] / Sc) * m.magSf[f] * (f < m.nIF ? m.nonOrthDelta[f] : m.delta[f]);
+    for (int f = 0; f < m.nIF; ++f) { d1[m.own[f]] += phiJmY[f]; d1[m.nei[f]] -= phiJmY[f]; }
+    for (int f = m.nIF; f < nF; ++f) if (live[f]) d1[m.own[f]] += phiJmY[f];
+    const double rDeltaT = 1.0 / deltaT;
+    for (int ci = 0; ci < nC; ++ci) {
+        diag[ci] = rDeltaT * rho[ci] * m.V[ci];
+        double src = rDeltaT * rhoOld[ci] * Yc[ci] * m.V[ci];
+        src -= m.V[ci] * (d1[ci] / m.V[ci]);
+        if (Su) src += m.V[ci] * Su[ci];
+        rhs[ci] = src;
+    }
+    for (int f = 0; f < m.nIF; ++f) { diag[m.own[f]] += a[f]; diag[m.nei[f]] += a[f]; }
+    for (int f = m.nIF; f < nF; ++f)
+        if (live[f] && fixedFace && fixedFace[f - m.nIF]) { diag[m.own[f]] += a[f]; rhs[m.own[f]] += a[f] * Yb[f - m.nIF]; }
+    dvec ai(a.begin(), a.end());
+    for (int f = m.nIF; f < nF; ++f) ai[f] = 0.0;
+    dvec x(Yc, Yc + nC);
+    // initial / final normalised residuals as OpenFOAM prints them
+    auto resid = [&](const dvec& v) {
+        dvec q((size_t)nC), A1((size_t)nC);
+        for (int c = 0; c < nC; ++c) { q[c] = diag[c] * v[c]; A1[c] = diag[c]; }
+        for (int f = 0; f < m.nIF; ++f) { q[m.own[f]] -= a[f] * v[m.nei[f]]; q[m.nei[f]] -= a[f] * v[m.own[f]]; A1[m.own[f]] -= a[f]; A1[m.nei[f]] -= a[f]; }
+        double xbar = 0; for (int c = 0; c < nC; ++c) xbar += v[c];
+        xbar /= nC;
+        double nf = 1e-20, sr = 0;
+        for (int c = 0; c < nC; ++c) { nf += std::fabs(q[c] - xbar * A1[c]) + std::fabs(rhs[c] - xbar * A1[c]); sr += std::fabs(rhs[c] - q[c]); }
+        return sr / nf;
+    };
+    info[1] = resid(x);
+    info[0] = solveDiagLaplacian(m, ai, diag, rhs, x.data(), tol, maxIter);
+    info[2] = resid(x);
+    for (int f = 0; f < nF; ++f) {
+        if (!live[f]) continue;
+        double fl = 0.0;
+        if (f < m.nIF) fl = -(a[f] * (x[m.nei[f]] - x[m.own[f]]));
+        else if (fixedFace && fixedFace[f - m.nIF]) fl = -(a[f] * (Yb[f - m.nIF] - x[m.own[f]]));
+        diffusiveFlux[f] += fl;
+    }
+    for (int ci = 0; ci < nC; ++ci) Ynew[ci] = std::max(x[ci], 0.0);
+    return 0;
+}
+
 // QHDpEqn.H L35-47: fvc::div(phiu) - fvc::div(phiwo) - fvm::laplacian(taubyrhof, p) == 0 with setReference and
 // phi = phiu - phiwo + pEqn.flux().  L0 assumptions: Gauss laplacian, uncorrected snGrad (nonOrthDeltaCoeffs inside,
 // deltaCoeffs on patches); fixedValue / fixedGradient / zeroGradient patch coefficients; the linear solver is a plain

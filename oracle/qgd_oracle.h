@@ -77,6 +77,11 @@ int orc_species_flux(void* mesh, const char* scheme, const double* Y, const doub
 /* one species of QGDYEqn.H L44-45, L67-86 (explicit branch, explicit source Su or NULL); same argument meaning as qgd_species_step */
 int orc_species_step(void* mesh, const double* Y, const double* Yb, const double* rhoOld, const double* rho, const double* phiJmY,
                      const double* muf, double Sc, double deltaT, const double* Su, double* diffusiveFlux, double* Ynew);
+/* QGDYEqn.H L47-66: the implicitDiffusion branch of the same equation (fvm::laplacian, diffusiveFlux += YEqn.flux()); info = {iterations,
+ * initial, final residual} */
+int orc_species_step_implicit(void* mesh, const double* Y, const double* Yb, const uint8_t* fixedValueFace, const double* rhoOld, const double* rho,
+                              const double* phiJmY, const double* muf, double Sc, double deltaT, const double* Su, double tolerance, int32_t maxIter,
+                              double* diffusiveFlux, double* Ynew, double info[3]);
 
 /* QHDFoam pressure equation; same argument meaning as qgd_qhd_pressure (QHDpEqn.H L35-47) */
 int orc_qhd_pressure(void* mesh, const double* phiu, const double* phiwo, const double* taubyrhof, const int32_t* patchKind,

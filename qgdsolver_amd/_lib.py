@@ -116,6 +116,10 @@ SIGNATURES = {
     "qgd_qhd_case_step_phase": (C.c_int, [handle, C.c_int]),
     "qgd_species_step": (C.c_int, [handle] + [c_double_p] * 6 + [C.c_double, C.c_double, c_double_p, c_double_p, c_double_p]),
     "qgd_species_step_dev": (C.c_int, [handle] + [C.c_void_p] * 6 + [C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "qgd_species_step_implicit": (C.c_int, [handle, c_double_p, c_double_p, C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_double,
+                                            C.c_double, c_double_p, C.c_double, C.c_int32, c_double_p, c_double_p, c_double_p]),
+    "qgd_species_step_implicit_dev": (C.c_int, [handle, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double,
+                                                C.c_double, C.c_void_p, C.c_double, C.c_int32, C.c_void_p, C.c_void_p, c_double_p]),
     "qgd_device_lsq_stencil": (C.c_int, [handle, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32)]),
     "qgd_qhd_case_pending": (C.c_int, [handle, C.POINTER(C.c_int32), C.POINTER(C.c_void_p), c_int64_p]),
     "qgd_qhd_case_control_ptr": (C.c_int, [handle, C.POINTER(C.c_void_p)]),

@@ -220,6 +220,7 @@ struct qgd_device_s {
     int32_t nSendAll = 0, nSendBFAll = 0;
     hipStream_t stream = nullptr;
     int liveCases = 0;   // qgd_case_t / qgd_qhd_case_t created on this device and not freed yet (qgd_device_free refuses while > 0)
+    ImplicitSolver* opSolver = nullptr;   // the linear solver of the stateless implicit operators (qgd_species_step_implicit), made on first use
     // MeshView::geoPos, built the first time a case that takes fvc::grad(U) per cell is created on this device (QGD_GEOPOS=0: never)
     void ensureFaceGeoPos() {
         static const int kOnOff[] = {0, 1};
@@ -696,6 +697,7 @@ int qgd_device_free(qgd_device_t d) {
     if (d->liveCases > 0)
         return fail(QGD_ERR_INVALID, "qgd_device_free: " + std::to_string(d->liveCases) + " case(s) created on this device are still open; free them first");
     (void)hipSetDevice(d->deviceId);
+    if (d->opSolver) { (void)hipStreamSynchronize(d->stream); implicitSolverFree(d->opSolver); d->opSolver = nullptr; }
     d->ws.release();
     for (hipEvent_t e : d->opEv) if (e) (void)hipEventDestroy(e);
     d->arena.release();
@@ -990,6 +992,62 @@ int qgd_species_step(qgd_device_t d, const double* Y, const double* Yb, const do
     (void)hipGetLastError();
     launchSpeciesStep(st_, v, dY, dYb, dRo, dR, dJ, dMu, Sc, deltaT, dSu, dDf, dNet, dNew);
     HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(st_));
+    ws.d2h(diffusiveFlux, dDf, sizeof(double) * nF, st_);
+    ws.d2h(Ynew, dNew, sizeof(double) * nC, st_);
+    return QGD_OK;
+    QGD_CATCH
+}
+
+// the implicitDiffusion branch of the species equation [QGDYEqn_8H L47-66] on device pointers; info (host) = {iterations, initial, final residual}
+int qgd_species_step_implicit_dev(qgd_device_t d, const double* Y, const double* Yb, const uint8_t* fixedValueFace, const double* rhoOld,
+                                  const double* rho, const double* phiJmY, const double* muf, double Sc, double deltaT, const double* Su, double tolerance,
+                                  int32_t maxIter, double* diffusiveFlux, double* Ynew, double info[3]) {
+    QGD_TRY
+    if (!d || !Y || !rhoOld || !rho || !phiJmY || !muf || !diffusiveFlux || !Ynew || !info)
+        return fail(QGD_ERR_INVALID, "qgd_species_step_implicit_dev: null argument");
+    if (!(Sc > 0) || !(deltaT > 0) || !(tolerance > 0) || maxIter < 1)
+        return fail(QGD_ERR_INVALID, "qgd_species_step_implicit_dev: Sc, deltaT, tolerance must be positive, maxIter >= 1");
+    const MeshView& v = d->view;
+    if (v.nBF > 0 && !Yb) return fail(QGD_ERR_INVALID, "qgd_species_step_implicit_dev: patch values of Y are required");
+    if (d->sharded()) return fail(QGD_ERR_NOT_IMPLEMENTED, "qgd_species_step_implicit: the stateless operator solves on one device (no reductions across shards)");
+    HIP_CHECK(hipSetDevice(d->deviceId));
+    if (!d->opSolver) d->opSolver = implicitSolverCreate(d->stream, v, d->ownedBegin, d->ownedEnd);
+    double* work = d->ws.get<double>(WS_H, 3 * (size_t)v.nC + (size_t)v.nF);   // the last slot: the host-pointer entry fills the first ten
+    (void)hipGetLastError();
+    launchSpeciesStepImplicit(d->opSolver, v, Y, Yb, fixedValueFace, rhoOld, rho, phiJmY, muf, Sc, deltaT, Su, tolerance, maxIter, work, diffusiveFlux, Ynew, info);
+    HIP_CHECK(hipGetLastError());
+    return QGD_OK;
+    QGD_CATCH
+}
+int qgd_species_step_implicit(qgd_device_t d, const double* Y, const double* Yb, const uint8_t* fixedValueFace, const double* rhoOld, const double* rho,
+                              const double* phiJmY, const double* muf, double Sc, double deltaT, const double* Su, double tolerance, int32_t maxIter,
+                              double* diffusiveFlux, double* Ynew, double info[3]) {
+    QGD_TRY
+    if (!d || !Y || !rhoOld || !rho || !phiJmY || !muf || !diffusiveFlux || !Ynew || !info)
+        return fail(QGD_ERR_INVALID, "qgd_species_step_implicit: null argument");
+    const MeshView& v = d->view;
+    if (v.nBF > 0 && !Yb) return fail(QGD_ERR_INVALID, "qgd_species_step_implicit: patch values of Y are required");
+    HIP_CHECK(hipSetDevice(d->deviceId));
+    const size_t nC = (size_t)v.nC, nB = (size_t)v.nBF, nF = (size_t)v.nF;
+    Workspace& ws = d->ws;
+    hipStream_t st_ = d->stream;
+    int nextSlot = WS_CELL;
+    auto upD = [&](const double* src, size_t n) {
+        double* dst = ws.get<double>((size_t)nextSlot++, n);
+        if (src && n) ws.h2d(dst, src, sizeof(double) * n, st_);
+        return dst;
+    };
+    double *dY = upD(Y, nC), *dYb = upD(Yb, nB), *dRo = upD(rhoOld, nC), *dR = upD(rho, nC), *dJ = upD(phiJmY, nF), *dMu = upD(muf, nF);
+    double* dSu = Su ? upD(Su, nC) : nullptr;
+    double *dDf = upD(diffusiveFlux, nF), *dNew = upD(nullptr, nC);
+    uint8_t* dFix = nullptr;
+    if (fixedValueFace && nB) {
+        dFix = reinterpret_cast<uint8_t*>(ws.get<double>((size_t)nextSlot++, (nB + 7) / 8));
+        ws.h2d(dFix, fixedValueFace, nB, st_);
+    }
+    const int rc = qgd_species_step_implicit_dev(d, dY, dYb, dFix, dRo, dR, dJ, dMu, Sc, deltaT, dSu, tolerance, maxIter, dDf, dNew, info);
+    if (rc) return rc;
     HIP_CHECK(hipStreamSynchronize(st_));
     ws.d2h(diffusiveFlux, dDf, sizeof(double) * nF, st_);
     ws.d2h(Ynew, dNew, sizeof(double) * nC, st_);
@@ -2687,6 +2745,7 @@ int qgd_case_implicit_info(qgd_case_t c, double info[14]) {
     for (int k = 0; k < 14; ++k) info[k] = 0.0;
     info[13] = c->opt.implicitDiffusion ? 1.0 : 0.0;
     if (!c->implSolver) return QGD_OK;
+    info[13] = implicitSolverChebyshev(c->implSolver) ? 2.0 : 1.0;   // 1: conjugate gradients (QGD_IMPL_SOLVER=pcg), 2: Chebyshev iteration
     HIP_CHECK(hipSetDevice(c->dev->deviceId));
     implicitSolverSetStream(c->implSolver, c->stream());
     int it[4]; double r0[4], r1[4], bad = 0;

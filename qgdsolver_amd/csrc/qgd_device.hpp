@@ -164,6 +164,12 @@ void launchSpeciesStep(hipStream_t s, const MeshView& m, const double* Yc, const
                        const double* phiJmY, const double* muf, double Sc, double dt, const double* Su, double* diffusiveFlux, double* net,
                        double* Ynew);
 
+// the species equation with fvm::laplacian [QGDYEqn_8H L47-66], one species; work = 3 * nC + nF doubles (qgd_implicit.hip)
+struct ImplicitSolver;
+void launchSpeciesStepImplicit(ImplicitSolver* S, const MeshView& m, const double* Yc, const double* Yb, const uint8_t* fixedFace, const double* rhoOld,
+                               const double* rho, const double* phiJmY, const double* muf, double Sc, double dt, const double* Su, double tol, int maxIter,
+                               double* work, double* diffusiveFlux, double* Ynew, double info[3]);
+
 // ---- implicitDiffusion branch of QGDFoam (qgd_implicit.hip) -----------------------------------------------------------
 #if defined(__HIPCC__)
 // Workgroup b runs on XCD b % 8, each XCD with a private 4 MiB L2.  Dealt round-robin, the 256-row blocks of a row-wise kernel put a row

@@ -711,8 +711,16 @@ __device__ __forceinline__ void chebNext(double* __restrict__ ctl, const int k, 
 // started from, the step count, done?, the next constants
 __device__ __forceinline__ void chebAfterStep(double* __restrict__ ctl, const int k, const double tol, const int maxIter) {
     const double res = ctl[ICTL(I_CABSR, k)] / ctl[ICTL(I_NORMF, k)], it = ctl[ICTL(I_ITER, k)] + 1.0;
-    ctl[ICTL(I_RES, k)] = res; ctl[ICTL(I_ITER, k)] = it;
-    if (res < tol || it >= (double)maxIter) ctl[ICTL(I_DONE, k)] = 1.0;
+    const double prev = ctl[ICTL(I_RES, k)], prev2 = ctl[ICTL(I_RZ, k)];   // residuals of the two iterates before (slot 4 is free here: only the
+    ctl[ICTL(I_RES, k)] = res; ctl[ICTL(I_ITER, k)] = it;                  // conjugate-gradient loop uses it, and it is reduced after phase 2 only)
+    ctl[ICTL(I_RZ, k)] = prev;
+    // the residual here is the TRUE one, b - A x_i, not a recurrence: it stalls at the rounding floor of the product (the conjugate-
+    // gradient loop's recurrence residual keeps falling below it and never notices).  A tolerance under that floor would burn maxIter
+    // steps for nothing: stop when two steps gained less than ONE step of the Chebyshev bound should (and count the solve as stopped
+    // above its tolerance, which it is).  Only looked at below 1e-8, far inside the asymptotic regime.
+    const double sigma = 1.0 / ctl[ICTL(I_DELTA, k)], rate = sigma - sqrt(fmax(sigma * sigma - 1.0, 0.0));
+    const bool stalled = it >= 3.0 && res < 1e-8 && prev2 > 0.0 && res >= fmax(rate, 0.25) * prev2;
+    if (res < tol || it >= (double)maxIter || stalled) ctl[ICTL(I_DONE, k)] = 1.0;
     else chebNext(ctl, k, ctl[ICTL(I_C2, k)] * ctl[ICTL(I_DELTA, k)] * 0.5);   // rho_i = c2_i delta / 2
 }
 // one rank: the fold of a Chebyshev step and its control logic in ONE launch, one workgroup per component (the components do not
@@ -1087,6 +1095,87 @@ double implicitApplyMs(ImplicitSolver* S, const ImplView& iv, int reps, int* row
     ICHECK(hipEventElapsedTime(&ms, a, b));
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
     return (double)ms / reps;
+}
+
+// ---- the species equation, implicitDiffusion branch [QGDYEqn.H L47-66], one species, as an operator on plain device fields ----------
+//     fvScalarMatrix YEqn(fvm::ddt(rho,Yi) + fvc::div(phiJmYi) - fvm::laplacian(muf/ScNumbers[i],Yi) == R(Yi) + SYi);  YEqn.solve();
+//     diffusiveFlux[i] += YEqn.flux();   Yi.max(0.0);
+// Face coefficients a_f = (muf/Sc) |Sf| delta_f (Gauss, uncorrected snGrad, L0) at the faces' slot-major positions; patch faces flagged
+// fixedValue add a_b to the diagonal and a_b Yb to the source, the others (zeroGradient) nothing.  YEqn.flux() is the matrix's own face
+// flux (L0 fvMatrix::flux): -a_f (Y_N - Y_O) inside, -a_b (Y_b - Y_P) on fixedValue faces, of the NEW Y -- the sign the listing gets
+// from "- fvm::laplacian", opposite to the explicit branch's "+ (muf/Sc) snGrad |Sf|" of L82; replicated as listed.
+namespace {
+__global__ __launch_bounds__(QGD_BLOCK) void speciesImplFaceKernel(const MeshView m, const double* __restrict__ muf, const double Sc, double* __restrict__ a) {
+    const int f = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    if (f >= m.nF) return;
+    const size_t pos = f < m.nIF ? (size_t)m.fpos[f] : (size_t)f;
+    a[pos] = m.fkind[f] == 3 ? 0.0 : (muf[f] / Sc) * m.magSf[f] * m.dn[f];
+}
+__global__ __launch_bounds__(QGD_BLOCK) void speciesImplCellKernel(const MeshView m, const double* __restrict__ a, const double* __restrict__ Yc,
+                                                                  const double* __restrict__ Yb, const uint8_t* __restrict__ fixedFace,
+                                                                  const double* __restrict__ rhoOld, const double* __restrict__ rho,
+                                                                  const double* __restrict__ phiJmY, const double dt, const double* __restrict__ Su,
+                                                                  double* __restrict__ diag, double* __restrict__ rhs, double* __restrict__ x) {
+    const int c = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    if (c >= m.nC) return;
+    x[c] = Yc[c];
+    if (m.ghost && m.ghost[c] == 1) { diag[c] = 1.0; rhs[c] = 0.0; return; }
+    const int n = m.cfCount[c];
+    const size_t base = (size_t)m.cfSlice[c >> 6] * 64 + (c & 63);
+    double s = 0.0, dsum = 0.0, src = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const int it = m.cfItem[base + (size_t)i * 64], ps = m.cfPos[base + (size_t)i * 64];
+        const int f = it >= 0 ? it : ~it;
+        if (m.fkind[f] == 3) continue;
+        const double j = phiJmY[f];
+        s = it >= 0 ? s + j : s - j;                       // fvc::div(phiJmYi): surfaceIntegrate, ascending face label
+        const double af = a[ps >= 0 ? ps : ~ps];
+        if (f < m.nIF) dsum += af;
+        else if (fixedFace && fixedFace[f - m.nIF]) { dsum += af; src += af * Yb[f - m.nIF]; }
+    }
+    const double V = m.V[c], rD = 1.0 / dt;
+    diag[c] = rD * rho[c] * V + dsum;
+    double r = rD * rhoOld[c] * Yc[c] * V - s;
+    if (Su) r += V * Su[c];
+    rhs[c] = r + src;
+}
+__global__ __launch_bounds__(QGD_BLOCK) void speciesImplFluxKernel(const MeshView m, const double* __restrict__ a, const double* __restrict__ x,
+                                                                  const double* __restrict__ Yb, const uint8_t* __restrict__ fixedFace,
+                                                                  double* __restrict__ diffusiveFlux) {
+    const int f = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    if (f >= m.nF) return;
+    if (m.fkind[f] == 3) return;
+    const size_t pos = f < m.nIF ? (size_t)m.fpos[f] : (size_t)f;
+    double fl = 0.0;
+    if (f < m.nIF) fl = -(a[pos] * (x[m.nei[f]] - x[m.own[f]]));
+    else if (fixedFace && fixedFace[f - m.nIF]) fl = -(a[pos] * (Yb[f - m.nIF] - x[m.own[f]]));
+    diffusiveFlux[f] += fl;                                                                       // L64
+}
+__global__ __launch_bounds__(QGD_BLOCK) void speciesImplMaxKernel(const int n, const double* __restrict__ x, double* __restrict__ Ynew) {
+    const int c = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    if (c < n) Ynew[c] = fmax(x[c], 0.0);                                                          // L86
+}
+}  // namespace
+// work: 3 * nC + nF doubles of device scratch (diag, rhs, x | a).  Returns after queueing; info (host) is filled after a wait.
+void launchSpeciesStepImplicit(ImplicitSolver* S, const MeshView& m, const double* Yc, const double* Yb, const uint8_t* fixedFace, const double* rhoOld,
+                               const double* rho, const double* phiJmY, const double* muf, double Sc, double dt, const double* Su, double tol, int maxIter,
+                               double* work, double* diffusiveFlux, double* Ynew, double info[3]) {
+    hipStream_t s = S->stream;
+    const size_t nC = (size_t)m.nC;
+    double *diag = work, *rhs = work + nC, *x = work + 2 * nC, *a = work + 3 * nC;
+    if (m.nF) speciesImplFaceKernel<<<gridOf(m.nF), QGD_BLOCK, 0, s>>>(m, muf, Sc, a);
+    speciesImplCellKernel<<<gridOf(m.nC), QGD_BLOCK, 0, s>>>(m, a, Yc, Yb, fixedFace, rhoOld, rho, phiJmY, dt, Su, diag, rhs, x);
+    implicitSolveSetup(S, 1, 1, a, diag, rhs, x, tol, maxIter);
+    implicitSolveRun(S, nullptr);
+    implicitSolveEnd(S, 1);
+    if (m.nF) speciesImplFluxKernel<<<gridOf(m.nF), QGD_BLOCK, 0, s>>>(m, a, x, Yb, fixedFace, diffusiveFlux);
+    speciesImplMaxKernel<<<gridOf(m.nC), QGD_BLOCK, 0, s>>>(m.nC, x, Ynew);
+    ICHECK(hipGetLastError());
+    double done = 0;
+    int it[4];
+    double r0[4], r1[4];
+    implicitSolveStatus4(S, &done, it, r0, r1);
+    info[0] = it[0]; info[1] = r0[0]; info[2] = r1[0];
 }
 
 // ---- the advance as phases (stream-ordered; a sharded caller exchanges between them, see include/qgd_amd.h) ---------------

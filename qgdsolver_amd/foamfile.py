@@ -406,12 +406,15 @@ def read_field(path, mesh):
         rec = dict(e)
         rec["type"] = str(e["type"])
         rec["value"] = _field_values(e["value"], int(sizes[i]), ncomp, f"{path}: {name}.value") if "value" in e else None
+        if "gradient" in e:   # fixedGradient / qhdFlux patches
+            rec["gradient"] = _field_values(e["gradient"], int(sizes[i]), ncomp, f"{path}: {name}.gradient")
         patches[name] = rec
     return internal, patches
 
 
 def write_field(path, mesh, name, internal, patches, dimensions="[0 0 0 0 0 0 0]"):
-    """(nCells[, 3]) array + {patch: (type word, value or None)} -> vol<Type>Field file (values at full precision)"""
+    """(nCells[, 3]) array + {patch: (type word, value or None[, {extra entry: scalar}])} -> vol<Type>Field file (values at full
+    precision; the optional third member writes further uniform entries of the patch, e.g. the gradient of a fixedGradient patch)"""
     a = np.asarray(internal, dtype=np.float64)
     vec = a.ndim == 2 and a.shape[1] == 3
     cls, typ = ("volVectorField", "vector") if vec else ("volScalarField", "scalar")
@@ -431,8 +434,10 @@ def write_field(path, mesh, name, internal, patches, dimensions="[0 0 0 0 0 0 0]
         f.write(_header(cls, name, os.path.basename(os.path.dirname(path))))
         f.write(f"dimensions      {dimensions};\n\ninternalField   {values(a)};\n\nboundaryField\n{{\n")
         for pn in names:
-            t, v = patches[pn]
+            t, v = patches[pn][0], patches[pn][1]
             f.write(f"    {pn}\n    {{\n        type            {t};\n")
+            for key, x in (patches[pn][2].items() if len(patches[pn]) > 2 else ()):
+                f.write(f"        {key:<15} uniform {_fmt(float(x))};\n")
             if v is not None:
                 f.write(f"        value           {values(v)};\n")
             f.write("    }\n")
@@ -548,6 +553,174 @@ def read_case_setup(case_dir, time="0"):
     fields = {"U": U, "T": T[:, 0], "p": p[:, 0]}
     fields.update(coeff_fields)
     return mesh, opt, fields, bcs
+
+
+def _truthy(v):
+    return str(v) in ("true", "on", "yes", "1")
+
+
+def _bc_p_qhd(rec, what):
+    """p of a QHDFoam case: zeroGradient | fixedValue (uniform) | fixedGradient (uniform gradient) | qhdFlux.  Inside QHDFoam a
+    qhdFlux patch keeps the gradient of its file -- its registry lookup of "phiwStar" finds nothing, the solver registers its flux
+    as "phiwo" [qhdFluxFvPatchScalarField.C L166-168] -- so it is read as the fixedGradient patch it behaves like (gradient
+    entry, default 0)."""
+    t = rec["type"]
+    if t in _CONSTRAINT_BCS:
+        return ("none", None)
+    if t == "zeroGradient":
+        return ("zeroGradient", None)
+    if t == "fixedValue":
+        v = rec["value"]
+        if v is None or np.any(v != v[0]):
+            raise FoamFileError(f"{what}: fixedValue needs a uniform value")
+        return ("fixedValue", float(v[0, 0]))
+    if t in ("fixedGradient", "qhdFlux"):
+        g = rec.get("gradient")
+        if g is None:
+            return ("fixedGradient", 0.0)
+        g = np.asarray(g, dtype=np.float64).reshape(-1)
+        if np.any(g != g[0]):
+            raise FoamFileError(f"{what}: only uniform gradients are supported")
+        return ("fixedGradient", float(g[0]))
+    raise FoamFileError(f"{what}: boundary condition '{t}' is not supported")
+
+
+def read_qhd_case_setup(case_dir, time="0"):
+    """Read an OpenFOAM QHDFoam case directory [QHDFoam.C L63-72, QHDFoam/createFields.H L32-167].
+
+    Returns (mesh, options dict for ``qhdfoam.qhd_options``, {'U','T','p'} internal arrays, per-patch BC triples).
+    Entries read: constant/polyMesh; constant/thermophysicalProperties -- thermoType (equationOfState rhoConst, transport const),
+    mixture.equationOfState.rho, mixture.transport.{mu, Pr, beta} [createFields.H L110-115], QGD{implicitDiffusion (default true,
+    QGDThermo.C L70-82), QGDCoeffs constTau | HbyUQHD | T0byGr | H2bynuQHD with the keys of <model>Dict or of QGD itself
+    [QGDCoeffs.C L81-116; constTau.C L71, HbyUQHD.C L61, T0byGr.C L74-75], pRefCell, pRefValue [createFields.H L162-165]};
+    constant/gravitationalProperties g [createFields.H L96-108]; <time>/alphaQGD when present and uniform [QGDCoeffs.C L119-160,
+    default 0.5]; system/fvSchemes fvsc.default; system/controlDict deltaT; system/fvSolution solvers.p {tolerance, relTol,
+    maxIter} and, with implicitDiffusion, solvers.(U|T) {tolerance, maxIter}; <time>/{U,T,p}."""
+    mesh = read_polymesh(os.path.join(case_dir, "constant", "polyMesh"))
+    opt = {}
+    tp = read_dict(os.path.join(case_dir, "constant", "thermophysicalProperties"))
+    tt = tp.get("thermoType", {})
+    for key, want in (("equationOfState", "rhoConst"), ("transport", "const")):
+        if isinstance(tt, dict) and key in tt and str(tt[key]) != want:
+            raise FoamFileError(f"thermoType.{key} '{tt[key]}' is not supported by the QHDFoam path (only {want})")
+    mix = tp["mixture"]
+    opt["rho0"] = float(mix["equationOfState"]["rho"])
+    tr = mix["transport"]
+    opt["mu"], opt["Pr"], opt["beta"] = float(tr["mu"]), float(tr["Pr"]), float(tr["beta"])
+    qgd = tp["QGD"]
+    opt["implicitDiffusion"] = 1 if _truthy(qgd.get("implicitDiffusion", "true")) else 0
+    model = str(qgd["QGDCoeffs"])
+    if model not in ("constTau", "HbyUQHD", "T0byGr", "H2bynuQHD"):
+        raise FoamFileError(f"QGDCoeffs '{model}' is not a closure of the QHDFoam path (constTau, HbyUQHD, T0byGr, H2bynuQHD)")
+    opt["tauModel"] = model
+    md = qgd.get(model + "Dict", qgd)
+    for key, needed in (("Tau", model == "constTau"), ("UQHD", model == "HbyUQHD"), ("T0", model == "T0byGr"), ("Gr", model == "T0byGr")):
+        if needed:
+            if key not in md:
+                raise FoamFileError(f"QGD.{model}: entry '{key}' is missing")
+            opt[key] = float(md[key])
+    opt["pRefCell"] = int(float(qgd.get("pRefCell", 0)))      # setRefCell(p, thermo.subDict("QGD"), ...) [createFields.H L165]
+    opt["pRefValue"] = float(qgd.get("pRefValue", 0.0))
+    gp = read_dict(os.path.join(case_dir, "constant", "gravitationalProperties"))
+    g = gp["g"]
+    g = [x for x in (g if isinstance(g, (list, tuple, np.ndarray)) else [g])]
+    # `g g [0 1 -2 0 0 0 0] (0 -9.81 0);`, `g [0 1 -2 0 0 0 0] (0 -9.81 0);` or `g (0 -9.81 0);`: the vector is the last list of 3
+    vec = None
+    for item in reversed(g):
+        if isinstance(item, (list, tuple, np.ndarray)) and len(item) == 3:
+            vec = [float(x) for x in item]
+            break
+    if vec is None and len(g) == 3 and all(isinstance(x, (int, float)) for x in g):
+        vec = [float(x) for x in g]
+    if vec is None:
+        raise FoamFileError(f"{case_dir}/constant/gravitationalProperties: cannot read the vector g")
+    opt["g"] = tuple(vec)
+    tdir = os.path.join(case_dir, str(time))
+    opt["aQGD"] = 0.5
+    apath = os.path.join(tdir, "alphaQGD")
+    if _exists(apath):
+        vals, _ = read_field(apath, mesh)
+        if not np.all(vals == vals[0]):
+            raise FoamFileError(f"{apath}: a non-uniform alphaQGD is not supported by the QHDFoam path")
+        opt["aQGD"] = float(vals[0, 0])
+    fs = read_dict(os.path.join(case_dir, "system", "fvSchemes"))
+    opt["stencil"] = str(fs.get("fvsc", {}).get("default", "reduced"))
+    cd = read_dict(os.path.join(case_dir, "system", "controlDict"))
+    opt["deltaT"] = float(cd["deltaT"])
+    if _truthy(cd.get("adjustTimeStep", "no")):
+        raise FoamFileError("adjustTimeStep yes: the QHDFoam path runs with the fixed deltaT of controlDict (its matrices are built once)")
+    fsol_path = os.path.join(case_dir, "system", "fvSolution")
+    if _exists(fsol_path):
+        solvers = read_dict(fsol_path).get("solvers", {})
+        tols, iters = [], []
+        for key, entry in solvers.items() if isinstance(solvers, dict) else ():
+            names = str(key).strip('"()').replace("|", " ").split()
+            if not isinstance(entry, dict):
+                continue
+            if "p" in names:
+                opt["pTol"] = float(entry.get("tolerance", 1e-6))
+                opt["pRelTol"] = float(entry.get("relTol", 0.0))
+                opt["pMaxIter"] = int(float(entry.get("maxIter", 1000)))
+            if any(n in ("U", "T", "Ux", "Uy", "Uz") for n in names):
+                tols.append(float(entry.get("tolerance", 1e-6)))
+                iters.append(int(float(entry.get("maxIter", 1000))))
+        if tols and opt["implicitDiffusion"]:
+            opt["implicitTol"] = min(tols)
+            opt["implicitMaxIter"] = max(iters)
+    U, bU = read_field(os.path.join(tdir, "U"), mesh)
+    T, bT = read_field(os.path.join(tdir, "T"), mesh)
+    p, bP = read_field(os.path.join(tdir, "p"), mesh)
+    ptw = [PATCH_WORDS.get(int(t), "patch") for t in mesh.array("patchType")]
+    bcs = []
+    for i, name in enumerate(mesh.patch_names):
+        bu, bt = _bc(bU[name], True, ptw[i], f"U.{name}"), _bc(bT[name], False, ptw[i], f"T.{name}")
+        if bu[0] == "qgdFlux" or bt[0] in ("qgdFlux", "slip"):
+            raise FoamFileError(f"patch {name}: boundary condition not supported for U / T of a QHDFoam case")
+        bcs.append({"U": bu, "T": bt, "p": _bc_p_qhd(bP[name], f"p.{name}")})
+    return mesh, opt, {"U": U, "T": T[:, 0], "p": p[:, 0]}, bcs
+
+
+def load_qhd_case(case_dir, time="0", device_id=0):
+    """Case directory -> (Device, QHDFoamCase) ready to ``step()``: the createFields.H sequence of QHDFoam over the C-ABI."""
+    from .fvsc import Device
+    from .qhdfoam import QHDFoamCase, qhd_options
+
+    mesh, opt, fields, bcs = read_qhd_case_setup(case_dir, time)
+    dev = Device(mesh, device_id, fv_schemes={"fvsc": {"default": opt["stencil"]}})
+    case = QHDFoamCase(dev, qhd_options(**opt))
+    for i, bc in enumerate(bcs):
+        case.set_bc(i, U=bc["U"], T=bc["T"], p=bc["p"])
+    case.set_fields(fields["U"], fields["T"], fields["p"])
+    return dev, case
+
+
+def write_qhd_time(case, case_dir, time_name, bcs=None):
+    """U, T, p of a QHDFoamCase into <case_dir>/<time_name>/ (the AUTO_WRITE fields of QHDFoam that this path carries); patch
+    entries carry the patch values as ``value`` (fixedGradient patches also their ``gradient``)."""
+    mesh = case.mesh
+    names = getattr(mesh, "patch_names", None) or [f"patch{i}" for i in range(mesh.nPatches)]
+    ps, pz, pt = mesh.array("patchStart"), mesh.array("patchSize"), mesh.array("patchType")
+    nIF = mesh.nInternalFaces
+    dims = {"U": "[0 1 -1 0 0 0 0]", "T": "[0 0 0 1 0 0 0]", "p": "[0 2 -2 0 0 0 0]"}
+    for fname in ("U", "T", "p"):
+        internal = case.field(fname)
+        bvals = case.field(fname + ".boundary")
+        patches = {}
+        for i, pn in enumerate(names):
+            word = PATCH_WORDS.get(int(pt[i]), "patch")
+            if word in _CONSTRAINT_BCS:
+                patches[pn] = (word, None)
+                continue
+            kind, extra = "calculated", None
+            if bcs is not None and fname in bcs[i]:
+                kind = bcs[i][fname][0]
+                if kind == "none":
+                    kind = "calculated"
+                if kind == "fixedGradient":
+                    extra = {"gradient": float(bcs[i][fname][1] or 0.0)}
+            b0 = int(ps[i]) - nIF
+            patches[pn] = (kind, bvals[b0:b0 + int(pz[i])]) if extra is None else (kind, bvals[b0:b0 + int(pz[i])], extra)
+        write_field(os.path.join(case_dir, str(time_name), fname), mesh, fname, internal, patches, dims[fname])
 
 
 def _patch_values(mesh, internal, patches, what):

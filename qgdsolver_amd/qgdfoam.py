@@ -165,11 +165,12 @@ class QGDFoamCase:
         a = (C.c_double * 14)()
         L.check(L.lib.qgd_case_implicit_info(self._h, a), "qgd_case_implicit_info")
         names = ("Ux", "Uy", "Uz", "e")
-        return dict(implicit=bool(a[13]), unconverged_steps=int(a[12]),
+        return dict(implicit=bool(a[13]), solver={0: None, 1: "pcg", 2: "chebyshev"}[int(a[13])], unconverged_steps=int(a[12]),
                     solves={n: dict(iterations=int(a[k]), initial=a[4 + k], final=a[8 + k]) for k, n in enumerate(names)})
 
     def implicit_apply_time(self, reps=20):
-        """measurement: average ms of the U system's matrix product (iApplyKernel<3,1>) over `reps` launches, and its rows"""
+        """measurement: average ms over `reps` launches of the kernel the branch spends most of its time in -- one Chebyshev step of the
+        U system (iChebKernel<3,0>) or, with QGD_IMPL_SOLVER=pcg, its matrix product (iApplyKernel<3,1>) -- and its rows"""
         a = (C.c_double * 2)()
         L.check(L.lib.qgd_case_implicit_apply_time(self._h, int(reps), a), "qgd_case_implicit_apply_time")
         return dict(ms=a[0], rows=int(a[1]))
@@ -318,8 +319,35 @@ def speciesStep(dev, Y, rhoOld, rho, phiJmY, muf, Sc, deltaT, diffusiveFlux, Su=
     return Ynew
 
 
-def QGDYEqn(dev, Y, rhoOld, rho, phiJmY, muf, ScNumbers, deltaT, diffusiveFlux, inertIndex, active=None, Su=None, call=None):
-    """QGDYEqn.H L38-92, explicit branch, over all species: Y[i] = (internal, boundary) pairs (old time level), phiJmY[i], diffusiveFlux[i]
+def speciesStepImplicit(dev, Y, rhoOld, rho, phiJmY, muf, Sc, deltaT, diffusiveFlux, Su=None, fixedValueFaces=None, tolerance=1e-10, maxIter=1000,
+                        call=None):
+    """One species of QGDYEqn.H L47-66 (the implicitDiffusion branch: fvm::laplacian(muf/Sc, Yi), diffusiveFlux += YEqn.flux()): returns
+    (new cell values of Yi clipped at 0, {iterations, initial, final}).  fixedValueFaces: boolean mask over the boundary faces of the
+    fixedValue patches of Yi (their values are Y[1]); all other patch faces are zeroGradient."""
+    m = dev.mesh
+    a = lambda x, n: np.ascontiguousarray(x, dtype=np.float64).reshape(-1) if n else np.zeros(1)  # noqa: E731
+    Yc, Yb = a(Y[0], m.nCells), a(Y[1], m.nBoundaryFaces)
+    ro, rn, jm, mf = a(rhoOld, 1), a(rho, 1), a(phiJmY, 1), a(muf, 1)
+    su = None if Su is None else a(Su, 1)
+    fx = None if fixedValueFaces is None else np.ascontiguousarray(fixedValueFaces, dtype=np.uint8).reshape(-1)
+    assert Yc.size == m.nCells and ro.size == m.nCells and rn.size == m.nCells and jm.size == m.nFaces and mf.size == m.nFaces
+    assert fx is None or fx.size == m.nBoundaryFaces
+    assert isinstance(diffusiveFlux, np.ndarray) and diffusiveFlux.dtype == np.float64 and diffusiveFlux.size == m.nFaces and diffusiveFlux.flags.c_contiguous
+    Ynew, info = np.zeros(m.nCells), np.zeros(3)
+    dp = lambda x: x.ctypes.data_as(L.c_double_p)  # noqa: E731
+    if call is None:
+        L.check(L.lib.qgd_species_step_implicit(dev._h, dp(Yc), dp(Yb), fx.ctypes.data_as(C.c_void_p) if fx is not None and fx.size else None, dp(ro),
+                                                dp(rn), dp(jm), dp(mf), float(Sc), float(deltaT), dp(su) if su is not None else None,
+                                                float(tolerance), int(maxIter), dp(diffusiveFlux), dp(Ynew), dp(info)), "qgd_species_step_implicit")
+    else:
+        call(Yc, Yb, fx, ro, rn, jm, mf, float(Sc), float(deltaT), su, float(tolerance), int(maxIter), diffusiveFlux, Ynew, info)
+    return Ynew, dict(iterations=int(info[0]), initial=float(info[1]), final=float(info[2]))
+
+
+def QGDYEqn(dev, Y, rhoOld, rho, phiJmY, muf, ScNumbers, deltaT, diffusiveFlux, inertIndex, active=None, Su=None, call=None, implicitDiffusion=False,
+            fixedValueFaces=None, tolerance=1e-10, maxIter=1000):
+    """QGDYEqn.H L38-92 over all species (implicitDiffusion: L47-66 through speciesStepImplicit, fixedValueFaces[i] = mask of species i's
+    fixedValue patch faces; else the explicit branch L67-86): Y[i] = (internal, boundary) pairs (old time level), phiJmY[i], diffusiveFlux[i]
     per species (numpy arrays over the faces, updated in place), Su[i] explicit sources or None.  Returns the list of new cell fields:
     the active species from speciesStep, the inert one as 1 - sum of the others, clipped at 0 [L86-91]."""
     n = len(Y)
@@ -327,8 +355,12 @@ def QGDYEqn(dev, Y, rhoOld, rho, phiJmY, muf, ScNumbers, deltaT, diffusiveFlux, 
     Yt = np.zeros(dev.mesh.nCells)                                # volScalarField Yt(0.0*Y[0])
     for i in range(n):
         if i != inertIndex and (active is None or active[i]):
-            new[i] = speciesStep(dev, Y[i], rhoOld, rho, phiJmY[i], muf, ScNumbers[i], deltaT, diffusiveFlux[i], None if Su is None else Su[i], call)
-            diffusiveFlux[inertIndex] -= diffusiveFlux[i]           # L83 (as listed: the running total of species i, not this step's increment)
+            if implicitDiffusion:
+                new[i], _ = speciesStepImplicit(dev, Y[i], rhoOld, rho, phiJmY[i], muf, ScNumbers[i], deltaT, diffusiveFlux[i], None if Su is None else Su[i],
+                                                None if fixedValueFaces is None else fixedValueFaces[i], tolerance, maxIter, call)
+            else:
+                new[i] = speciesStep(dev, Y[i], rhoOld, rho, phiJmY[i], muf, ScNumbers[i], deltaT, diffusiveFlux[i], None if Su is None else Su[i], call)
+            diffusiveFlux[inertIndex] -= diffusiveFlux[i]           # L65 / L83 (as listed: the running total of species i, not this step's increment)
             Yt += new[i]
     for i in range(n):
         if new[i] is None and i != inertIndex:

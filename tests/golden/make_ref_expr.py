@@ -49,6 +49,8 @@ Snippets evaluated (listing lines of /root/reference/docs/html/<file>_source.htm
   thermo2cell  hePsiQGDThermo.C L48-64 + L123-124 and QGDFoam.C L152-154 (thermo.correct(), p = rho / psi after the explicit step)
   qhdflux    qhdFluxFvPatchScalarField.C L193-203 (updateCoeffs with the registered flux) on the walls of a small cavity
   lsqorder   extendedFaceStencilFindNeighbours.C L48-84 (the stencil search: which cells, in which order) on whole small 2-D meshes
+  specieseqn_implicit  QGDYEqn.H L47-66: the species loop through fvm::laplacian and YEqn.flux()
+  qhdeqn_implicit  the same step through the listing's implicitDiffusion branch (QHDUEqn.H L46-65, QHDTEqn.H L69-80: fvm::laplacian)
   qhdeqn     one whole QHDFoam step on the two-cell mesh: updateFields.H L36-73, updateFluxes.H L33-38, QHDpEqn.H L35-47, QHDUEqn.H
              L36-43 + L46-85, QHDTEqn.H L65-66 + L69-92, QHDFoam.C L123-131 (reference level)
 
@@ -944,6 +946,8 @@ class Mat2:
         det = d0 * d1 - a * a
         b0, b1 = self.b
         self.psi.assign([(b0 * d1 + b1 * a) * (1.0 / det), (b1 * d0 + b0 * a) * (1.0 / det)])
+    def flux(self):              # fvMatrix::flux on the internal face (L0): upper psi_N - lower psi_O, upper = lower = -a of L
+        return -self.a * self.psi[1] + self.a * self.psi[0]
 
 
 def fv_emulation_implicit(dt, magS, delta):
@@ -1701,8 +1705,9 @@ def casebnd(nfaces=30, seed=25):
     return {k: np.array(v) for k, v in rec.items()}
 
 
-def qhdeqn(nfaces=30, seed=26):
-    """One whole QHDFoam step on one internal face between two cells (3-D, GaussVolPoint, explicit branch): updateFields.H L36-73,
+def qhdeqn(nfaces=30, seed=26, implicit=False):
+    """One whole QHDFoam step on one internal face between two cells (3-D, GaussVolPoint; implicit: the implicitDiffusion branch
+    of QHDUEqn.H L46-65 / QHDTEqn.H L69-80, i.e. fvm::laplacian, selected by the listing's own `if (implicitDiffusion)`): updateFields.H L36-73,
     updateFluxes.H L33-38, QHDpEqn.H L35-47, QHDUEqn.H L36-43 + L68-84, QHDTEqn.H L65-66 + L83-91 and the reference level of
     QHDFoam.C L123-130 -- every line from the listing text, the fvsc gradients through the GaussVolPoint text.  fvm / fvc are
     emulated on the two-cell mesh with OpenFOAM's conventions (L0): fvc::div = surfaceIntegrate, fvc::grad Gauss linear,
@@ -1747,7 +1752,10 @@ def qhdeqn(nfaces=30, seed=26):
         def __init__(self, psi, d, a, b): self.psi, self.d, self.a, self.b = psi, list(d), a, list(b)
         def copy(self): return Eq(self.psi, self.d, self.a, self.b)
         def __add__(self, F): r = self.copy(); r.b = [b - V[i] * f for i, (b, f) in enumerate(zip(r.b, F))]; return r
-        def __sub__(self, F): r = self.copy(); r.b = [b + V[i] * f for i, (b, f) in enumerate(zip(r.b, F))]; return r
+        def __sub__(self, F):
+            if isinstance(F, Eq):       # M - L: matrices subtract coefficient by coefficient (fvm::ddt(U) + ... - fvm::laplacian(gamma, U))
+                return Eq(self.psi, [x - y for x, y in zip(self.d, F.d)], self.a - F.a, [x - y for x, y in zip(self.b, F.b)])
+            r = self.copy(); r.b = [b + V[i] * f for i, (b, f) in enumerate(zip(r.b, F))]; return r
         def __radd__(self, F): return self.__add__(F)
         def __rsub__(self, F):      # F - M  ==  -(M) + F: the matrix changes sign, F goes to the left-hand side
             r = Eq(self.psi, [-x for x in self.d], -self.a, [b * -1.0 for b in self.b])
@@ -1813,14 +1821,14 @@ def qhdeqn(nfaces=30, seed=26):
 
         def fvc_lap(gam, fld): return surf_int((gam * magS * delta) * (fld[1] - fld[0]))
         fvm = Obj(ddt=lambda fld: Eq(fld, [V[0] / dt, V[1] / dt], 0.0, [V[0] * o * (1.0 / dt) for o in fld.old][:1] + [V[1] * fld.old[1] * (1.0 / dt)]),
-                  laplacian=lambda gam, fld: Eq(fld, [-(gam * magS * delta)] * 2, -(gam * magS * delta), [0.0, 0.0]))
+                  laplacian=lambda gam, fld: Eq(fld, [-(gam * magS * delta)] * 2, -(gam * magS * delta), [fld[0] * 0.0, fld[1] * 0.0]))
         fvc = Obj(div=surf_int, grad=fvc_grad, laplacian=fvc_lap)
         pe = dict(p=pfld, fvc=fvc, fvm=fvm, phiu=env2["phiu"], phiwo=env2["phiwo"], taubyrhof=env2["taubyrhof"], pRefCell=ref_cell,
                   getRefCellValue=lambda fld, c: fld[c])
         exec(peqn_src, pe)
         phi = pe["phi"]
         gP, _ = text.grad(pts, own, nei, list(pfld), [inv_dist(x, cen, list(pfld)) for x in pts], False)
-        ue = dict(env2, fvsc=Obj(grad=lambda fld: Vec(*gP)), p=pfld, phi=phi, U=U, qgdFlux=lambda flux, psi, psif: flux * psif, implicitDiffusion=False,
+        ue = dict(env2, fvsc=Obj(grad=lambda fld: Vec(*gP)), p=pfld, phi=phi, U=U, qgdFlux=lambda flux, psi, psif: flux * psif, implicitDiffusion=bool(implicit),
                   fvm=fvm, fvc=fvc, solve=lambda M: M.solve(), muf=env["muf"], rho=QF([rho0, rho0]), BdFrc=env["BdFrc"],
                   USu=QF([Vec(0, 0, 0), Vec(0, 0, 0)]), qgdInterpolate=lin, Foam=Obj(T=lambda fld: QF([t.T() for t in fld])))
         exec(ueqn_a, ue)
@@ -1840,14 +1848,16 @@ def qhdeqn(nfaces=30, seed=26):
     return {k: np.array(v) for k, v in rec.items()}
 
 
-def specieseqn(nfaces=24, seed=27):
-    """QGDYEqn.H L40-45, L69-92 (the explicit branch of the species loop) executed as listed on the two-cell mesh for three species, the
+def specieseqn(nfaces=24, seed=27, implicit=False):
+    """implicit: QGDYEqn.H L40-66, L86-92 (the implicitDiffusion branch: fvScalarMatrix YEqn(fvm::ddt(rho,Yi) + fvc::div(phiJmYi) -
+    fvm::laplacian(muf/ScNumbers[i],Yi) == ...), YEqn.solve(), diffusiveFlux[i] += YEqn.flux()) with fv_emulation_implicit; otherwise
+    QGDYEqn.H L40-45, L69-92 (the explicit branch of the species loop) executed as listed on the two-cell mesh for three species, the
     last one inert: solve(fvm::ddt(rho,Yi) + fvc::div(phiJmYi) - fvc::laplacian(muf/ScNumbers[i],Yi) == combustion->R(Yi) + parcels.SYi(i,Yi)),
     diffusiveFlux[i] += (muf/ScNumbers[i]) fvc::snGrad(Yi.oldTime()) magSf, diffusiveFlux[inert] -= diffusiveFlux[i], Yi.max(0), Yt,
     Y[inert] = 1 - Yt.  fvm / fvc are the two-cell emulations (L0: Euler ddt, surfaceIntegrate, Gauss laplacian with the uncorrected
     snGrad); combustion->R and parcels.SYi return explicit source fields (their sum is what qgd_species_step takes as Su)."""
     ye = listing("QGDYEqn_8H_source.html")
-    txt = [ye[i] for i in list(range(40, 46)) + list(range(69, 84)) + list(range(86, 93))]
+    txt = [ye[i] for i in list(range(40, 46)) + (list(range(47, 67)) if implicit else list(range(69, 84))) + list(range(86, 93))]
     src = transpile(txt)
     rng = np.random.default_rng(seed)
     names = ("nv", "pts", "Sf", "Cf", "C", "delta", "rhoOld", "rho", "Y", "phiJmY", "muf", "Sc", "Su", "deltaT", "inertIndex", "diffusiveFlux0",
@@ -1875,7 +1885,7 @@ def specieseqn(nfaces=24, seed=27):
         Sc = [float(rng.uniform(0.5, 1.5)) for _ in range(ns)]
         Su = [[float(0.2 * rng.standard_normal()) for _ in range(2)] for _ in range(ns)]
         df0 = [float(0.1 * rng.standard_normal()) for _ in range(ns)]
-        fvm, fvc = fv_emulation(dt, V)
+        fvm, fvc = fv_emulation_implicit(dt, mag(S), delta) if implicit else fv_emulation(dt, V)
         fvc.laplacian = lambda gam, psi: CF([gam * mag(S) * delta * (psi[1] - psi[0]) / V[0], -(gam * mag(S) * delta * (psi[1] - psi[0])) / V[1]])
         fvc.snGrad = lambda psi: delta * (psi[1] - psi[0])
         Y = [CF(list(y)) for y in Y0]
@@ -1884,7 +1894,7 @@ def specieseqn(nfaces=24, seed=27):
         env = dict(Y=Y, phiJmY=list(jm), inertIndex=inert, composition=Obj(active=lambda i: True), fvm=fvm, fvc=fvc, rho=rho, muf=muf,
                    ScNumbers=Sc, combustion=Obj(R=lambda Yi: CF(half[[id(y) for y in Y].index(id(Yi))])),
                    parcels=Obj(SYi=lambda i, Yi: CF(half[i])), diffusiveFlux=list(df0), mesh=Obj(magSf=call(mag(S))), Yt=CF([0.0, 0.0]),
-                   solve=lambda M: M.solve(), scalar=float)
+                   solve=lambda M: M.solve(), scalar=float, implicitDiffusion=bool(implicit))
         exec(src, env)
         out = dict(nv=nv, pts=np.array([q.c for q in pts] + ([[0, 0, 0]] if nv == 3 else [])), Sf=S.c, Cf=Cf.c, C=np.array([own.c, nei.c]), delta=delta,
                    rhoOld=rho_old, rho=rho_new, Y=Y0, phiJmY=jm, muf=muf, Sc=Sc, Su=Su, deltaT=dt, inertIndex=inert, diffusiveFlux0=df0,
@@ -1992,7 +2002,8 @@ def main():
             print("implicit2cell", {k: v.shape for k, v in impl.items()})
     for name, data in (("gvp2d_vec", gvp2d_vec()), ("gvp_other", gvp_other()), ("qgdlength", qgdlength()), ("courant", courant(case)),
                        ("thermo2cell", thermo2cell(case)),
-                       ("qhdclosure", qhdclosure()), ("casebnd", casebnd()), ("qhdeqn", qhdeqn()), ("lsqorder", lsqorder()), ("qhdflux", qhdflux()), ("specieseqn", specieseqn())):
+                       ("qhdclosure", qhdclosure()), ("casebnd", casebnd()), ("qhdeqn", qhdeqn()), ("qhdeqn_implicit", qhdeqn(seed=29, implicit=True)), ("lsqorder", lsqorder()), ("qhdflux", qhdflux()), ("specieseqn", specieseqn()),
+                       ("specieseqn_implicit", specieseqn(seed=31, implicit=True))):
         np.savez_compressed(os.path.join(HERE, f"ref_expr_{name}.npz"), **data)
         print(name, {k: getattr(v, "shape", None) for k, v in data.items()})
 

@@ -372,6 +372,14 @@ def species_step(omesh, Yc, Yb, rho_old, rho, phiJmY, muf, Sc, deltaT, Su, diffu
                                 _d(Su) if Su is not None else None, _d(diffusiveFlux), _d(Ynew))
 
 
+def species_step_implicit(omesh, Yc, Yb, fixed, rho_old, rho, phiJmY, muf, Sc, deltaT, Su, tol, max_iter, diffusiveFlux, Ynew, info):
+    """drop-in for the `call` hook of qgdsolver_amd.qgdfoam.speciesStepImplicit"""
+    lib.orc_species_step_implicit.argtypes = [C.c_void_p, dp, dp, C.c_void_p, dp, dp, dp, dp, C.c_double, C.c_double, dp, C.c_double, C.c_int32, dp, dp, dp]
+    return lib.orc_species_step_implicit(omesh._h, _d(Yc), _d(Yb), fixed.ctypes.data_as(C.c_void_p) if fixed is not None and fixed.size else None,
+                                         _d(rho_old), _d(rho), _d(phiJmY), _d(muf), float(Sc), float(deltaT), _d(Su) if Su is not None else None,
+                                         float(tol), int(max_iter), _d(diffusiveFlux), _d(Ynew), _d(info))
+
+
 class OracleQhdCase:
     """QHDFoam case of the oracle (explicit branch of QHDFoam.C L83-139); mirrors qgdsolver_amd.qhdfoam.QHDFoamCase"""
     KINDS = {"zeroGradient": 0, "fixedValue": 1, "slip": 2, "fixedGradient": 3, "qhdFlux": 3, "none": 4, "qhdFluxCoupled": 5}

@@ -187,4 +187,4 @@ def test_implicit_workload_line():
     assert d["config"]["cells"] == 24 ** 3 and d["config"]["iterations_U"] > 0 and d["config"]["iterations_e"] > 0
     assert d["config"]["unconverged_steps"] == 0 and d["min_rho"] > 0
     r = d["roofline"]
-    assert r["bound"] == "hbm" and r["avg_launch_ms"] > 0 and r["algorithmic_bytes_per_launch"] == 144 * 24 ** 3 and r["traffic"] is None
+    assert r["bound"] == "hbm" and r["avg_launch_ms"] > 0 and r["algorithmic_bytes_per_launch"] == 216 * 24 ** 3 and r["traffic"] is None and "iChebKernel" in r["kernel"]

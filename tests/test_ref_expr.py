@@ -426,6 +426,31 @@ def test_one_whole_qhdfoam_step_from_the_listing_text():
         oc.close(); om.close()
 
 
+def test_one_whole_qhdfoam_step_implicit_branch_from_the_listing_text():
+    """the same step through the listing's own `if (implicitDiffusion)` [QHDUEqn.H L46-65, QHDTEqn.H L69-80]: fvm::laplacian(muf/rhof, U)
+    and fvm::laplacian(Hif, T) as matrices on the two-cell mesh (tests/golden/ref_expr_qhdeqn_implicit.npz)"""
+    from oracle import OracleQhdCase
+    g = rc.load("qhdeqn_implicit")
+    for i in range(len(g["nv"])):
+        nv = int(g["nv"][i])
+        om = oracle_mesh(*rc.two_cell_mesh(g["pts"][i], nv, g["Sf"][i], g["Cf"][i], g["C"][i]))
+        opt = qhd_eqn_options(g, i)
+        opt.implicitDiffusion, opt.implicitTol, opt.implicitMaxIter = 1, 1e-15, 100
+        oc = OracleQhdCase(om, opt)
+        oc.set_fields(g["U"][i], g["T"][i], g["p"][i])
+        oc.step(1)
+        assert abs(oc.field("phi")[0] - g["phi1"][i]) <= 1e-11 * max(abs(g["phiu"][i]), abs(g["phiwo"][i])), i
+        for f, want in (("p", "p1"), ("U", "U1"), ("T", "T1")):
+            assert rel(oc.field(f), g[want][i]) <= 1e-11, (i, f, oc.field(f), g[want][i])
+        # and the branch matters on these inputs: the explicit oracle lands elsewhere
+        opt.implicitDiffusion = 0
+        ex = OracleQhdCase(om, opt)
+        ex.set_fields(g["U"][i], g["T"][i], g["p"][i])
+        ex.step(1)
+        assert rel(ex.field("U"), g["U1"][i]) > 1e-9, i
+        oc.close(); ex.close(); om.close()
+
+
 def test_one_step_of_the_implicit_diffusion_branch_from_the_listing_text():
     """QGDUEqn.H L36-75 and QGDEEqn.H L37-64 with implicitDiffusion true, executed from the listing text on the two-cell mesh of
     case2cell: the explicit part with the fluxes of the implicit branch, the implicit U and e solves (fvm::ddt(rho, .) - fvc::ddt(rho, .)

@@ -307,6 +307,27 @@ def test_one_whole_qhdfoam_step_on_the_device():
         case.close(); dev.close()
 
 
+def test_one_whole_qhdfoam_step_implicit_branch_on_the_device():
+    """the resident QHD case with implicitDiffusion true (the four systems {Ux, Uy, Uz, T} as one multi-right-hand-side solve) against
+    tests/golden/ref_expr_qhdeqn_implicit.npz: QHDUEqn.H L46-65 and QHDTEqn.H L69-80 executed from the listing text"""
+    from qgdsolver_amd import qhdfoam
+    from test_ref_expr import qhd_eqn_options
+    g = rc.load("qhdeqn_implicit")
+    for i in range(len(g["nv"])):
+        nv = int(g["nv"][i])
+        mesh = device_mesh(*rc.two_cell_mesh(g["pts"][i], nv, g["Sf"][i], g["Cf"][i], g["C"][i]))
+        dev = q.Device(mesh)
+        opt = qhd_eqn_options(g, i)
+        opt.implicitDiffusion, opt.implicitTol, opt.implicitMaxIter = 1, 1e-15, 200
+        case = qhdfoam.QHDFoamCase(dev, opt)
+        case.set_fields(g["U"][i], g["T"][i], g["p"][i])
+        case.step(1)
+        assert abs(case.field("phi")[0] - g["phi1"][i]) <= 1e-11 * max(abs(g["phiu"][i]), abs(g["phiwo"][i])), i
+        for f, want in (("p", "p1"), ("U", "U1"), ("T", "T1")):
+            assert rel(case.field(f), g[want][i]) <= 1e-10, (i, f, case.field(f), g[want][i])
+        case.close(); dev.close()
+
+
 def test_one_step_of_the_implicit_diffusion_branch_on_the_device():
     """the device's implicitDiffusion step (qgd_implicit.hip: face terms, the four PCG solves, phiSigmaDotU) against
     tests/golden/ref_expr_implicit2cell.npz: QGDUEqn.H L36-75 and QGDEEqn.H L37-64 executed from the listing text"""
@@ -370,4 +391,22 @@ def test_species_equation_on_the_device():
         for k in range(len(new)):
             assert np.abs(new[k] - g["Ynew"][i][k]).max() <= 1e-12, (i, k, new[k], g["Ynew"][i][k])
             assert abs(df[k][0] - g["diffusiveFlux1"][i][k]) <= 1e-12 * max(1.0, abs(g["diffusiveFlux1"][i][k])), (i, k)
+        dev.close()
+
+
+def test_species_equation_implicit_branch_on_the_device():
+    """qgd_species_step_implicit (through qgdfoam.QGDYEqn(implicitDiffusion=True)) against QGDYEqn.H L40-66, L86-92 executed from the
+    listing text (tests/golden/ref_expr_specieseqn_implicit.npz): the solve, diffusiveFlux[i] += YEqn.flux(), the inert species"""
+    from qgdsolver_amd import qgdfoam
+    from test_ref_expr import species_equation_inputs
+    g = rc.load("specieseqn_implicit")
+    for i in range(len(g["nv"])):
+        mesh = device_mesh(*rc.two_cell_mesh(g["pts"][i], int(g["nv"][i]), g["Sf"][i], g["Cf"][i], g["C"][i]))
+        dev = q.Device(mesh)
+        Y, jm, df, Su, muf = species_equation_inputs(g, i)
+        new = qgdfoam.QGDYEqn(dev, Y, g["rhoOld"][i], g["rho"][i], jm, muf, list(g["Sc"][i]), float(g["deltaT"][i]), df, int(g["inertIndex"][i]), Su=Su,
+                              implicitDiffusion=True, tolerance=1e-15, maxIter=100)
+        for k in range(len(new)):
+            assert np.abs(new[k] - g["Ynew"][i][k]).max() <= 1e-11, (i, k, new[k], g["Ynew"][i][k])
+            assert abs(df[k][0] - g["diffusiveFlux1"][i][k]) <= 1e-11 * max(1.0, abs(g["diffusiveFlux1"][i][k])), (i, k)
         dev.close()

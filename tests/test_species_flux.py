@@ -144,3 +144,111 @@ def test_device_species_step_matches_oracle(kind):
         got = qgdfoam.speciesStep(dev, Y, rho_old, rho, phiJmY, muf, Sc, dt, dfd, Su=su)
         assert rel_err(got, want) <= 1e-12 and rel_err(dfd, dfo) <= 1e-13, (kind, rel_err(got, want))
     dev.close()
+
+
+# ---- the implicitDiffusion branch of the species equation [QGDYEqn.H L47-66] (VERDICT r03 "missing" #4) ---------------------------------
+def fixed_faces(mesh, patches=(0,)):
+    nif = mesh.nInternalFaces
+    fx = np.zeros(mesh.nBoundaryFaces, dtype=np.uint8)
+    for ip in patches:
+        s0 = mesh.array("patchStart")[ip] - nif
+        fx[s0:s0 + mesh.array("patchSize")[ip]] = 1
+    return fx
+
+
+def test_oracle_implicit_species_step():
+    """mass: sum V rho Y changes by -dt (boundary phiJmY + boundary YEqn.flux()) + dt sum V Su; diffusiveFlux gets YEqn.flux() = -a (Y_N - Y_O)
+    of the NEW Y (the sign "- fvm::laplacian" gives it); as deltaT -> 0 the two branches meet; without diffusion they are one"""
+    mesh = make_mesh("box654_poly")
+    om = oracle_mesh_of(mesh)
+    Y, rho_old, rho, phiJmY, muf, Su = step_inputs(mesh, 4)
+    dt, Sc = 1e-3, 0.8
+    fx = fixed_faces(mesh)
+    df = np.zeros(mesh.nFaces)
+
+    def call(*a):
+        assert orc.species_step_implicit(om, *a) == 0
+    new, info = qgdfoam.speciesStepImplicit(HostDev(mesh), Y, rho_old, rho, phiJmY, muf, Sc, dt, df, Su=Su, fixedValueFaces=fx, tolerance=1e-15,
+                                            maxIter=500, call=call)
+    assert new.min() > 0 and 0 < info["iterations"] < 100 and info["final"] < 1e-14 < info["initial"]
+    V, nif = mesh.array("V"), mesh.nInternalFaces
+    own, nei = mesh.array("owner"), mesh.array("neighbour")
+    a = muf / Sc * mesh.array("magSf") * np.where(np.arange(mesh.nFaces) < nif, mesh.array("nonOrthDeltaCoeffs"), mesh.array("deltaCoeffs"))
+    want = -a[:nif] * (new[nei] - new[own[:nif]])
+    assert np.abs(df[:nif] - want).max() <= 1e-13 * np.abs(want).max()
+    wb = np.where(fx == 1, -a[nif:] * (Y[1] - new[own[nif:]]), 0.0)
+    assert np.abs(df[nif:] - wb).max() <= 1e-13 * max(np.abs(wb).max(), 1e-300)
+    types = mesh.array("patchType")
+    live = np.ones(mesh.nBoundaryFaces, dtype=bool)
+    for ip in range(mesh.nPatches):
+        if types[ip] == q._lib.PATCH_EMPTY:
+            s0 = mesh.array("patchStart")[ip] - nif
+            live[s0:s0 + mesh.array("patchSize")[ip]] = False
+    lhs = (V * rho * new).sum() - (V * rho_old * Y[0]).sum()
+    rhs = -dt * ((phiJmY[nif:] + df[nif:])[live]).sum() + dt * (V * Su).sum()
+    assert abs(lhs - rhs) <= 1e-12 * (V * rho_old * Y[0]).sum()
+    # no diffusion: the explicit branch
+    z = np.zeros(mesh.nFaces)
+    new0, _ = qgdfoam.speciesStepImplicit(HostDev(mesh), Y, rho_old, rho, phiJmY, 0.0 * muf, Sc, dt, z.copy(), Su=Su, fixedValueFaces=fx, tolerance=1e-15, call=call)
+    ex0 = qgdfoam.speciesStep(HostDev(mesh), Y, rho_old, rho, phiJmY, 0.0 * muf, Sc, dt, z.copy(), Su=Su, call=lambda *b: orc.species_step(om, *b))
+    assert rel_err(new0, ex0) <= 1e-14
+    # first order in deltaT between the branches (all patches fixedValue here: the explicit step treats every patch value as one)
+    allfx = np.ones(mesh.nBoundaryFaces, dtype=np.uint8)
+    diffs = []
+    for k in (1, 2):
+        h = 2e-4 / k
+        im, _ = qgdfoam.speciesStepImplicit(HostDev(mesh), Y, rho_old, rho_old, 0 * phiJmY, muf, Sc, h, z.copy(), fixedValueFaces=allfx, tolerance=1e-15, call=call)
+        ex = qgdfoam.speciesStep(HostDev(mesh), Y, rho_old, rho_old, 0 * phiJmY, muf, Sc, h, z.copy(), call=lambda *b: orc.species_step(om, *b))
+        diffs.append(np.abs(im - ex).max())
+    assert 0 < diffs[1] < 0.3 * diffs[0], diffs          # the difference of one step is O(deltaT^2)
+
+
+def test_species_implicit_step_from_the_listing_text():
+    """tests/golden/ref_expr_specieseqn_implicit.npz: QGDYEqn.H L40-66, L86-92 executed as listed on the two-cell mesh (three species, the
+    last one inert): YEqn.solve(), diffusiveFlux[i] += YEqn.flux(), the inert species' bookkeeping"""
+    import ref_expr_cases as rc
+    from test_ref_expr import oracle_mesh
+    g = rc.load("specieseqn_implicit")
+    for i in range(len(g["nv"])):
+        nv = int(g["nv"][i])
+        om = oracle_mesh(*rc.two_cell_mesh(g["pts"][i], nv, g["Sf"][i], g["Cf"][i], g["C"][i]))
+        mesh = type("M", (), {"nCells": 2, "nFaces": om.nFaces, "nBoundaryFaces": om.nBoundaryFaces})()
+        dev = type("D", (), {"mesh": mesh})()
+        nf = om.nFaces
+        ns, inert = g["Y"][i].shape[0], int(g["inertIndex"][i])
+        Y = [(g["Y"][i][k].copy(), np.zeros(om.nBoundaryFaces)) for k in range(ns)]
+        jm = [np.concatenate([[g["phiJmY"][i][k]], np.zeros(nf - 1)]) for k in range(ns)]
+        muf = np.full(nf, float(g["muf"][i]))
+        df = [np.concatenate([[g["diffusiveFlux0"][i][k]], np.zeros(nf - 1)]) for k in range(ns)]
+        new = qgdfoam.QGDYEqn(dev, Y, g["rhoOld"][i], g["rho"][i], jm, muf, list(g["Sc"][i]), float(g["deltaT"][i]), df, inert, Su=list(g["Su"][i]),
+                              implicitDiffusion=True, tolerance=1e-15, maxIter=50, call=lambda *a: orc.species_step_implicit(om, *a))
+        for k in range(ns):
+            assert rel_err(new[k], g["Ynew"][i][k]) <= 1e-11, (i, k, new[k], g["Ynew"][i][k])
+            assert abs(df[k][0] - g["diffusiveFlux1"][i][k]) <= 1e-11 * max(np.abs(g["diffusiveFlux1"][i]).max(), 1e-300), (i, k)
+        om.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["box654_poly", "box654_jitter", "plane2d_jitter", "step2d"])
+def test_device_implicit_species_step_matches_oracle(kind):
+    mesh = make_mesh(kind)
+    om = oracle_mesh_of(mesh)
+    dev = q.Device(mesh)
+    Y, rho_old, rho, phiJmY, muf, Su = step_inputs(mesh, 6)
+    Y[0][:3] = 1e-7
+    dt, Sc = 2e-3, 1.3
+    fx = fixed_faces(mesh, (0, 1))
+    if mesh.nGeometricD == 2:
+        types = mesh.array("patchType")
+        for ip in range(mesh.nPatches):
+            if types[ip] == q._lib.PATCH_EMPTY:
+                s0 = mesh.array("patchStart")[ip] - mesh.nInternalFaces
+                fx[s0:s0 + mesh.array("patchSize")[ip]] = 0
+    for su, fixed in ((Su, fx), (None, None)):
+        dfo, dfd = 0.01 * np.ones(mesh.nFaces), 0.01 * np.ones(mesh.nFaces)
+        want, io = qgdfoam.speciesStepImplicit(HostDev(mesh), Y, rho_old, rho, phiJmY, muf, Sc, dt, dfo, Su=su, fixedValueFaces=fixed, tolerance=1e-14,
+                                               maxIter=500, call=lambda *a: orc.species_step_implicit(om, *a))
+        got, ig = qgdfoam.speciesStepImplicit(dev, Y, rho_old, rho, phiJmY, muf, Sc, dt, dfd, Su=su, fixedValueFaces=fixed, tolerance=1e-14, maxIter=500)
+        assert rel_err(got, want) <= 1e-11 and rel_err(dfd, dfo) <= 1e-10, (kind, rel_err(got, want), rel_err(dfd, dfo))
+        assert 0 < ig["iterations"] < 500 and ig["final"] < 1e-13 and abs(ig["initial"] - io["initial"]) <= 1e-9 * io["initial"], (ig, io)
+    dev.close()
