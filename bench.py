@@ -1018,7 +1018,7 @@ def main():
                 "host_threads_per_rank": int(os.environ.get("OMP_NUM_THREADS", "0")) or None,
                 "stencil": "GaussVolPoint",
                 "rccl_ranks": rccl_ranks,   # ranks the communicator carrying the halo messages reports (None: one rank, or gloo staging)
-                "halo_message_bytes": {"per_ghost_cell": 80, "per_ghost_patch_face": 96} if world > 1 else None,
+                "halo_message_bytes": {"per_ghost_cell": 64, "per_ghost_patch_face": 96} if world > 1 else None,
                 "env": qgd_env(),
             },
             "roofline": {

@@ -614,6 +614,10 @@ int qgd_case_implicit_solve_status(qgd_case_t c, double status[2]);
  * and slot 1 = upper k; a qgd_mesh_shard mesh has one per rank in "haloPeer".  count / recv_count = number of doubles
  * in the message sent to / received from that neighbour.  pack gathers the owned boundary-layer cells' records into
  * the DEVICE buffer sendBuf; unpack scatters recvBuf into the ghost cells.
+ * The state message carries 8 doubles per cell -- {rho, Ux, Uy, Uz, p, e} as SURVEY 8(e) plans, plus H and muQGD, the two derived
+ * quantities a receiver cannot rebuild from them (rhoE is an independent field under the listing's energy re-solve; muQGD is formed with
+ * the previous step's pressure and the owner's hQGD); c and alphaQGD/c are recomputed on arrival -- and 12 per patch face of those cells
+ * (both records, the qgdFlux gradient, the lagged patch density).  Always ask qgd_case_halo_count: the layout may change.
  * Both are asynchronous on the case's stream; qgd_case_stream_sync waits. */
 /* Plain device buffers for callers that own the transport (GPU-aware MPI, RCCL, ...). */
 int qgd_device_alloc(qgd_device_t d, int64_t bytes, void** devicePtr);

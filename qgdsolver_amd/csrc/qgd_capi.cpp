@@ -1685,14 +1685,14 @@ int qgd_case_halo_count(qgd_case_t c, int slot, int64_t* count) {
     if (!c || !count || slot < 0) return fail(QGD_ERR_INVALID, "bad argument");
     *count = 0;
     if (slot >= (int)c->dev->halo.size()) return QGD_OK;  // an unsharded mesh has no slots: nothing to exchange
-    *count = 10 * (int64_t)c->dev->halo[slot].nSend + 12 * (int64_t)c->dev->halo[slot].nSendBF;
+    *count = QGD_HALO_CELL_DOUBLES_HOST * (int64_t)c->dev->halo[slot].nSend + 12 * (int64_t)c->dev->halo[slot].nSendBF;
     return QGD_OK;
 }
 int qgd_case_halo_recv_count(qgd_case_t c, int slot, int64_t* count) {
     if (!c || !count || slot < 0) return fail(QGD_ERR_INVALID, "bad argument");
     *count = 0;
     if (slot >= (int)c->dev->halo.size()) return QGD_OK;
-    *count = 10 * (int64_t)c->dev->halo[slot].nGhost + 12 * (int64_t)c->dev->halo[slot].nGhostBF;
+    *count = QGD_HALO_CELL_DOUBLES_HOST * (int64_t)c->dev->halo[slot].nGhost + 12 * (int64_t)c->dev->halo[slot].nGhostBF;
     return QGD_OK;
 }
 int qgd_case_halo_pack(qgd_case_t c, int slot, double* sendBufDevice) {
@@ -1707,7 +1707,7 @@ int qgd_case_halo_pack(qgd_case_t c, int slot, double* sendBufDevice) {
     L.pre = nullptr; L.post = nullptr;
     if (c->useHaloStream) L.stream = c->haloStream;
     (void)hipGetLastError();
-    launchHaloPack(L, c->view, h.send, h.nSend, h.sendBF, h.nSendBF, sendBufDevice, true);
+    launchHaloPack(L, c->view, c->gas, h.send, h.nSend, h.sendBF, h.nSendBF, sendBufDevice, true);
     HIP_CHECK(hipGetLastError());
     return QGD_OK;
     QGD_CATCH
@@ -1724,7 +1724,7 @@ int qgd_case_halo_unpack(qgd_case_t c, int slot, const double* recvBufDevice) {
     L.pre = nullptr; L.post = nullptr;
     if (c->useHaloStream) L.stream = c->haloStream;
     (void)hipGetLastError();
-    launchHaloPack(L, c->view, h.ghost, h.nGhost, h.ghostBF, h.nGhostBF, const_cast<double*>(recvBufDevice), false);
+    launchHaloPack(L, c->view, c->gas, h.ghost, h.nGhost, h.ghostBF, h.nGhostBF, const_cast<double*>(recvBufDevice), false);
     HIP_CHECK(hipGetLastError());
     return QGD_OK;
     QGD_CATCH
@@ -2369,8 +2369,8 @@ static void ensureHaloBuffers(qgd_case_s* c) {
     c->recvBuf.assign(d->halo.size(), nullptr);
     for (size_t s = 0; s < d->halo.size(); ++s) {
         const qgd_device_s::HaloSlot& h = d->halo[s];
-        c->sendBuf[s] = c->arena.alloc<double>(10 * (size_t)h.nSend + 12 * (size_t)h.nSendBF);
-        c->recvBuf[s] = c->arena.alloc<double>(10 * (size_t)h.nGhost + 12 * (size_t)h.nGhostBF);
+        c->sendBuf[s] = c->arena.alloc<double>(QGD_HALO_CELL_DOUBLES_HOST * (size_t)h.nSend + 12 * (size_t)h.nSendBF);
+        c->recvBuf[s] = c->arena.alloc<double>(QGD_HALO_CELL_DOUBLES_HOST * (size_t)h.nGhost + 12 * (size_t)h.nGhostBF);
     }
 }
 // RCCL matches the messages of one peer in issue order, and both sides issue in their own slot order: two slots towards
@@ -2399,7 +2399,7 @@ static void haloExchangeOn(qgd_case_s* c, qgd_comm_s* comm, const int32_t* peers
     for (int s = 0; s < n; ++s) {
         const qgd_device_s::HaloSlot& h = d->halo[s];
         if (peers[s] < 0 || !h.nSend) continue;
-        launchHaloPack(L, c->view, h.send, h.nSend, h.sendBF, h.nSendBF, c->sendBuf[s], true);
+        launchHaloPack(L, c->view, c->gas, h.send, h.nSend, h.sendBF, h.nSendBF, c->sendBuf[s], true);
     }
     HIP_CHECK(hipGetLastError());
     RCCL_CHECK(rcclRef().groupStart());
@@ -2407,7 +2407,7 @@ static void haloExchangeOn(qgd_case_s* c, qgd_comm_s* comm, const int32_t* peers
         for (int s = 0; s < n; ++s) {
             const qgd_device_s::HaloSlot& h = d->halo[s];
             if (peers[s] < 0) continue;
-            const size_t ns = 10 * (size_t)h.nSend + 12 * (size_t)h.nSendBF, nr = 10 * (size_t)h.nGhost + 12 * (size_t)h.nGhostBF;
+            const size_t ns = QGD_HALO_CELL_DOUBLES_HOST * (size_t)h.nSend + 12 * (size_t)h.nSendBF, nr = QGD_HALO_CELL_DOUBLES_HOST * (size_t)h.nGhost + 12 * (size_t)h.nGhostBF;
             if (ns) RCCL_CHECK(rcclRef().send(c->sendBuf[s], ns, ncclFloat64, peers[s], comm->comm, stream));
             if (nr) RCCL_CHECK(rcclRef().recv(c->recvBuf[s], nr, ncclFloat64, peers[s], comm->comm, stream));
         }
@@ -2419,7 +2419,7 @@ static void haloExchangeOn(qgd_case_s* c, qgd_comm_s* comm, const int32_t* peers
     for (int s = 0; s < n; ++s) {
         const qgd_device_s::HaloSlot& h = d->halo[s];
         if (peers[s] < 0 || !h.nGhost) continue;
-        launchHaloPack(L, c->view, h.ghost, h.nGhost, h.ghostBF, h.nGhostBF, c->recvBuf[s], false);
+        launchHaloPack(L, c->view, c->gas, h.ghost, h.nGhost, h.ghostBF, h.nGhostBF, c->recvBuf[s], false);
     }
     HIP_CHECK(hipGetLastError());
 }

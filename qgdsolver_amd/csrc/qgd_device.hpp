@@ -129,7 +129,8 @@ void launchCellMinReduce(const Launcher& L, const CaseView& c);
 int faceBlocks(const MeshView& m);
 int bfaceBlocks(const MeshView& m);
 int cellBlocks(const MeshView& m);
-void launchHaloPack(const Launcher& L, const CaseView& c, const int32_t* cells, int32_t nCells, const int32_t* bfaces,
+#define QGD_HALO_CELL_DOUBLES_HOST 8   // doubles per cell of the state message (qgd_kernels.hip haloKernel), 12 per patch face
+void launchHaloPack(const Launcher& L, const CaseView& c, const GasModel& g, const int32_t* cells, int32_t nCells, const int32_t* bfaces,
                     int32_t nFaces, double* buf, bool pack);
 void launchMidHalo(hipStream_t s, const CaseView& c, const int32_t* bfaces, int32_t n, double* buf, bool pack);
 void launchFaceGeoPos(hipStream_t s, const MeshView& m, double4* out);   // fills MeshView::geoPos

@@ -1112,28 +1112,38 @@ __global__ __launch_bounds__(QGD_BLOCK) void cellMinReduceKernel(const CaseView 
     if (threadIdx.x == 0) c.red[2] = -c.red[2];
 }
 
-// halo message = 10 doubles per listed cell (RecA, RecB), then 12 per listed boundary face (RecA, RecB, p gradient,
-// lagged patch density).  A ghost cell's conserved record is rebuilt from what arrives (it only feeds the ghost's
-// own, discarded, update).
-__global__ __launch_bounds__(QGD_BLOCK) void haloKernel(const CaseView c, const int32_t* __restrict__ cells, const int nCells,
+// halo message = 8 doubles per listed cell -- the six primitives of SURVEY 8(e) {rho, U, p, e} plus the two derived quantities a
+// receiver cannot rebuild from them: H (rhoE is an independent field under the listing's explicit energy re-solve, QGDEEqn_8H L67-72)
+// and muQGD (formed with the PREVIOUS step's pressure, QGDFoam_8C L149-154, and the owner's hQGD, a mean over ALL faces of the cell, which
+// a ghost cell does not have here); c and alphaQGD/c are recomputed from e by the formulas of the cell update -- then 12 per listed
+// boundary face (RecA, RecB, p gradient, lagged patch density: patch records follow their boundary conditions, not these formulas).
+// A ghost cell's conserved record is rebuilt from what arrives (it only feeds the ghost's own, discarded, update).
+#define QGD_HALO_CELL_DOUBLES 8
+__global__ __launch_bounds__(QGD_BLOCK) void haloKernel(const CaseView c, const GasModel gm, const int32_t* __restrict__ cells, const int nCells,
                                                        const int32_t* __restrict__ bfaces, const int nFaces,
                                                        double* __restrict__ buf, const int pack) {
     const int i = blockIdx.x * QGD_BLOCK + threadIdx.x;
     if (i < nCells) {
         const int ci = cells[i];
-        double* q = buf + 10 * (size_t)i;
+        double* q = buf + QGD_HALO_CELL_DOUBLES * (size_t)i;
         if (pack) {
             const RecA a = c.A[ci]; const RecB b = c.B[ci];
-            q[0] = a.rho; q[1] = a.ux; q[2] = a.uy; q[3] = a.uz; q[4] = a.p; q[5] = a.e; q[6] = b.H; q[7] = b.c; q[8] = b.muQGD; q[9] = b.aOc;
+            q[0] = a.rho; q[1] = a.ux; q[2] = a.uy; q[3] = a.uz; q[4] = a.p; q[5] = a.e; q[6] = b.H; q[7] = b.muQGD;
         } else {
             RecA a; RecB b;
-            a.rho = q[0]; a.ux = q[1]; a.uy = q[2]; a.uz = q[3]; a.p = q[4]; a.e = q[5]; b.H = q[6]; b.c = q[7]; b.muQGD = q[8]; b.aOc = q[9];
+            a.rho = q[0]; a.ux = q[1]; a.uy = q[2]; a.uz = q[3]; a.p = q[4]; a.e = q[5]; b.H = q[6]; b.muQGD = q[7];
+            // thermo.correct() of the cell update [hePsiQGDThermo_8C L48-64], the same operations in the same order: the same bits
+            const double T = a.e / gm.Cv;
+            const double psi = 1.0 / (gm.R * T);
+            const double cs = sqrt(gm.gamma / psi);
+            b.c = cs;
+            b.aOc = (c.aQ ? c.aQ[ci] : gm.alphaQGD) / cs;
             c.A[ci] = a; c.B[ci] = b; c.rE[ci] = b.H * a.rho - a.p;
         }
     } else if (i < nCells + nFaces) {
         const int j = i - nCells;
         const int bi = bfaces[j];
-        double* q = buf + 10 * (size_t)nCells + 12 * (size_t)j;
+        double* q = buf + QGD_HALO_CELL_DOUBLES * (size_t)nCells + 12 * (size_t)j;
         if (pack) {
             const RecA a = c.bA[bi]; const RecB b = c.bB[bi];
             q[0] = a.rho; q[1] = a.ux; q[2] = a.uy; q[3] = a.uz; q[4] = a.p; q[5] = a.e; q[6] = b.H; q[7] = b.c; q[8] = b.muQGD; q[9] = b.aOc;
@@ -1514,11 +1524,11 @@ __global__ __launch_bounds__(QGD_BLOCK) void midHaloKernel(const CaseView c, con
 void launchMidHalo(hipStream_t s, const CaseView& c, const int32_t* bfaces, int32_t n, double* buf, bool pack) {
     if (n > 0) midHaloKernel<<<gridFor(n), QGD_BLOCK, 0, s>>>(c, bfaces, n, buf, pack ? 1 : 0);
 }
-void launchHaloPack(const Launcher& L, const CaseView& c, const int32_t* cells, int32_t nCells, const int32_t* bfaces,
+void launchHaloPack(const Launcher& L, const CaseView& c, const GasModel& g, const int32_t* cells, int32_t nCells, const int32_t* bfaces,
                     int32_t nFaces, double* buf, bool pack) {
     const int n = nCells + nFaces;
     if (n == 0) return;
-    haloKernel<<<gridFor(n), QGD_BLOCK, 0, L.stream>>>(c, cells, nCells, bfaces, nFaces, buf, pack ? 1 : 0);
+    haloKernel<<<gridFor(n), QGD_BLOCK, 0, L.stream>>>(c, g, cells, nCells, bfaces, nFaces, buf, pack ? 1 : 0);
 }
 
 // helpers of the device-pointer operator entries: {U,T,p} -> 5-component records; SoA result slots -> one AoS face field

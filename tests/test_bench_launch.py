@@ -130,7 +130,7 @@ def test_two_ranks_self_launched_match_one_rank():
     assert b["roofline"]["frac"] is not None and b["value"] > 0
     # new keys: gloo staging has no RCCL communicator, the C-ABI transport cannot stand on one GPU, and says so
     assert b["config"]["rccl_ranks"] is None and "skipped" in b["native_transport"] and "one device" in b["native_transport"]["skipped"]
-    assert b["config"]["halo_message_bytes"] == {"per_ghost_cell": 80, "per_ghost_patch_face": 96} and isinstance(b["config"]["env"], dict)
+    assert b["config"]["halo_message_bytes"] == {"per_ghost_cell": 64, "per_ghost_patch_face": 96} and isinstance(b["config"]["env"], dict)
 
 
 @pytest.mark.gpu

@@ -43,7 +43,7 @@ def test_self_exchange_moves_the_boundary_layers_through_rccl(overlapped):
     case = q.QGDFoamCase(dev, q.default_options(stencil="GaussVolPoint", deltaT=1e-3, mu=1e-3))
     U, T, p = cases.box_initial_fields(mesh.array("C").reshape(-1, 3))
     case.set_fields(U, T, p)
-    assert case.halo_count(0) == case.halo_recv_count(0) == case.halo_count(1) == case.halo_recv_count(1) > 10 * plane
+    assert case.halo_count(0) == case.halo_recv_count(0) == case.halo_count(1) == case.halo_recv_count(1) > 8 * plane
     comm.exchange(case, [0, 0])
     case.sync()
     rho, Uf = case.field("rho").reshape(6, plane), case.field("U").reshape(6, plane, 3)
