@@ -567,15 +567,16 @@ def secondary_traffic(key):
     (TCC EA request counters of the builder's profiling run of this workload at 200^3, scripts/collect_secondary_pmc.sh), not counters
     of THIS run; None when the file or the key is missing (other sizes, the irregular mesh)."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r03_pmc_secondary.json")) as f:
+        with open(os.path.join(ROOT, "profiles", SECONDARY_TRAFFIC_FILE)) as f:
             return json.load(f)[key]["bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         return None
 
 
+SECONDARY_TRAFFIC_FILE = "r04_pmc_secondary.json"
 SECONDARY_TRAFFIC_SOURCE = ("rocprofv3 --pmc TCC_EA0_RDREQ_{32B,64B,128B}_sum / TCC_EA0_WRREQ{,_64B}_sum in separate passes over "
                             "scripts/secondary_kernel_probe.py (scripts/collect_secondary_pmc.sh), bytes = sum(size*requests), average of "
-                            "the 30 launches of the measurement entry; L2-miss traffic, Infinity-Cache hits included; profiles/r03_pmc_secondary.json")
+                            "the 30 launches of the measurement entry; L2-miss traffic, Infinity-Cache hits included; profiles/" + SECONDARY_TRAFFIC_FILE)
 
 
 def implicit_line(args):
@@ -621,7 +622,7 @@ def implicit_line(args):
                                                 "partial residual sums in one walk of the matrix for the three right-hand sides)" if cheb else
                                                 "iApplyKernel<3,1> (matrix product of the three-component U system, one walk of the matrix for the three right-hand sides)"),
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS if achieved else None,
-                     "traffic": secondary_traffic("implicit_n200") if (n == 200 and not cheb) else None, "traffic_is_static": True,
+                     "traffic": secondary_traffic("implicit_n200") if (n == 200 and cheb) else None, "traffic_is_static": True,
                      "traffic_source": SECONDARY_TRAFFIC_SOURCE, "algorithmic_bytes_per_launch": apply_bytes, "avg_launch_ms": ap["ms"]},
         "solver_bytes_model": {"per_cell_per_iteration_U": IMPL_CHEB_BYTES_PER_CELL if cheb else IMPL_ITER_BYTES_PER_CELL_U,
                                "per_cell_per_iteration_e": IMPL_CHEB_BYTES_PER_CELL_E if cheb else IMPL_ITER_BYTES_PER_CELL_E,

@@ -2,7 +2,7 @@
 the LAST 30 dispatches of that name (the launches of the measurement entry) and the HBM-side bytes derived from them."""
 import csv, glob, json, os, sys
 out_dir, tag = sys.argv[1], sys.argv[2]
-WANT = {"qhd": "mgSmoothKernel<float>", "implicit": "iApplyKernel<3, 1>"}
+WANT = {"qhd": "mgSmoothKernel<float>", "implicit": "iChebKernel<3, 0>" if os.environ.get("QGD_IMPL_SOLVER", "cheb") == "cheb" else "iApplyKernel<3, 1>"}
 res = {}
 for which, pattern in WANT.items():
     c = {}

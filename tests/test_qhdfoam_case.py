@@ -70,7 +70,7 @@ def write_cavity_case(case_dir, stencil="GaussVolPoint", n=(8, 7, 6), implicit_l
             solvers
             {
                 p { solver PCG; preconditioner DIC; tolerance 1e-12; relTol 0; maxIter 2000; }
-                "(U|T)" { solver PBiCGStab; preconditioner DILU; tolerance 1e-14; relTol 0; maxIter 1500; }
+                "(U|T)" { solver PBiCGStab; preconditioner DILU; tolerance 1e-12; relTol 0; maxIter 1500; }
             }
             '''))
     with open(os.path.join(case_dir, "system", "controlDict"), "w") as f:
@@ -86,7 +86,7 @@ def hand_built_oracle(mesh, implicit, stencil="GaussVolPoint"):
     from util import oracle_mesh_of
     opt = qhdfoam.qhd_options(stencil=stencil, tauModel="HbyUQHD", aQGD=0.5, UQHD=0.8, rho0=1.2, mu=1.8e-2, Pr=0.71, beta=3.4e-3,
                               g=(0.0, -9.81, 0.0), deltaT=1e-3, pTol=1e-12, pRelTol=0.0, pMaxIter=2000, pRefCell=17, pRefValue=0.25,
-                              implicitDiffusion=implicit, implicitTol=1e-14, implicitMaxIter=1500, precond=0)
+                              implicitDiffusion=implicit, implicitTol=1e-14, implicitMaxIter=1500, precond=0)   # (the oracle's CG: tighter than the case's 1e-12)
     oc = OracleQhdCase(oracle_mesh_of(mesh), opt)
     for ip, name in enumerate(mesh.patch_names):
         T = ("fixedValue", 310.0) if name == "hot" else (("fixedValue", 290.0) if name == "cold" else ("zeroGradient", None))
@@ -104,7 +104,7 @@ def test_read_qhd_case_setup(tmp_path):
     assert opt["implicitDiffusion"] == 1                       # absent from QGD{}: the reference's default [QGDThermo.C L70-82]
     assert (opt["rho0"], opt["mu"], opt["Pr"], opt["beta"]) == (1.2, 1.8e-2, 0.71, 3.4e-3) and opt["g"] == (0.0, -9.81, 0.0)
     assert opt["tauModel"] == "HbyUQHD" and opt["UQHD"] == 0.8 and opt["aQGD"] == 0.5 and opt["pRefCell"] == 17 and opt["pRefValue"] == 0.25
-    assert (opt["pTol"], opt["pRelTol"], opt["pMaxIter"]) == (1e-12, 0.0, 2000) and (opt["implicitTol"], opt["implicitMaxIter"]) == (1e-14, 1500)
+    assert (opt["pTol"], opt["pRelTol"], opt["pMaxIter"]) == (1e-12, 0.0, 2000) and (opt["implicitTol"], opt["implicitMaxIter"]) == (1e-12, 1500)
     by = dict(zip(m2.patch_names, bcs))
     assert by["hot"]["T"] == ("fixedValue", 310.0) and by["cold"]["T"] == ("fixedValue", 290.0) and by["floor"]["T"] == ("zeroGradient", None)
     assert by["hot"]["U"][0] == "fixedValue" and by["ceiling"]["p"] == ("fixedGradient", 0.02)
