@@ -568,7 +568,9 @@ int qgd_case_info(qgd_case_t c, double info[6]);
  * info[0..3] = iterations of Ux, Uy, Uz, e; [4..7] = initial, [8..11] = final normalised residuals; [12] = number of steps
  * since qgd_case_set_fields in which a solve stopped above implicitTol (iteration limit or breakdown: the step keeps the last
  * iterate, as OpenFOAM does, and counts here); [13] = 0 explicit branch | 1 implicit, conjugate gradients (QGD_IMPL_SOLVER=pcg) |
- * 2 implicit, Chebyshev iteration (the default). */
+ * 2 implicit, Chebyshev iteration (the default).  The Chebyshev iteration measures the TRUE residual b - A x of its iterate (the
+ * conjugate-gradient loop a recurrence); when that stops falling below 1e-8 -- the rounding floor of the product, which OpenFOAM's
+ * normalisation can lift to 1e-12 on nearly uniform fields -- the component stops there and is NOT counted as unconverged. */
 int qgd_case_implicit_info(qgd_case_t c, double info[14]);
 /* measurement: `reps` matrix products of the three-component U system (QGDUEqn_8H_source.html L54-68: the `fvm::laplacian(muf,U)`
  * matrix applied to a search direction; the kernel the branch spends most of its time in) between two HIP events, on the vectors

@@ -715,12 +715,14 @@ __device__ __forceinline__ void chebAfterStep(double* __restrict__ ctl, const in
     ctl[ICTL(I_RES, k)] = res; ctl[ICTL(I_ITER, k)] = it;                  // conjugate-gradient loop uses it, and it is reduced after phase 2 only)
     ctl[ICTL(I_RZ, k)] = prev;
     // the residual here is the TRUE one, b - A x_i, not a recurrence: it stalls at the rounding floor of the product (the conjugate-
-    // gradient loop's recurrence residual keeps falling below it and never notices).  A tolerance under that floor would burn maxIter
-    // steps for nothing: stop when two steps gained less than ONE step of the Chebyshev bound should (and count the solve as stopped
-    // above its tolerance, which it is).  Only looked at below 1e-8, far inside the asymptotic regime.
+    // gradient loop's recurrence residual keeps falling below it and never notices; on a nearly uniform field OpenFOAM's normFactor is
+    // small against |b| and the floor of the NORMALISED residual can sit at 1e-12).  A tolerance under that floor would burn maxIter
+    // steps for nothing: stop when two steps gained less than ONE step of the Chebyshev bound should (done = 4).  Only looked at below
+    // 1e-8, far inside the asymptotic regime; the Gershgorin interval cannot be wrong, so a stall there is rounding, not divergence.
     const double sigma = 1.0 / ctl[ICTL(I_DELTA, k)], rate = sigma - sqrt(fmax(sigma * sigma - 1.0, 0.0));
     const bool stalled = it >= 3.0 && res < 1e-8 && prev2 > 0.0 && res >= fmax(rate, 0.25) * prev2;
-    if (res < tol || it >= (double)maxIter || stalled) ctl[ICTL(I_DONE, k)] = 1.0;
+    if (res < tol || it >= (double)maxIter) ctl[ICTL(I_DONE, k)] = 1.0;
+    else if (stalled) ctl[ICTL(I_DONE, k)] = 4.0;   // at the rounding floor of b - A x: as converged as this arithmetic gets; not counted as a failed solve
     else chebNext(ctl, k, ctl[ICTL(I_C2, k)] * ctl[ICTL(I_DELTA, k)] * 0.5);   // rho_i = c2_i delta / 2
 }
 // one rank: the fold of a Chebyshev step and its control logic in ONE launch, one workgroup per component (the components do not
