@@ -9,7 +9,8 @@ step (one cell plane + its patch faces per neighbour).
 
 A step = one pass of the QGDFoam loop body (flux assembly + cell update + BC refresh), inputs resident in HBM.
 Prints ONE JSON line on rank 0.  Beside the contract's keys the line carries
-  N = 1: `secondary` {qhd_n200, implicit_n200} -- the QHDFoam step and the implicitDiffusion step, 20 timed steps each, as child
+  N = 1: `secondary` {qhd_n200, qhd_implicit_n200, implicit_n200} -- the QHDFoam step (both branches of implicitDiffusion) and QGDFoam's
+         implicitDiffusion step, 20 timed steps each, as child
          processes after the headline (--no-secondary skips them), `dropin_fvsc`, `cpu_baseline`;
   N > 1: `native_transport` {ms_per_step, value, checksum_rho, rccl_ranks} -- the same run repeated by a second, fresh set of ranks
          over the library's own RCCL path (qgd_case_step_sharded, the C-ABI a C++/MPI host calls; --no-native-line skips it);
@@ -65,6 +66,9 @@ def parse():
                          "implicitDiffusion true (the reference's default branch), one GPU, its own metric line")
     ap.add_argument("--irregular", action="store_true", help="qhd: the config-5 stand-in mesh (jittered vertices, every 7th quad split into "
                                                              "triangles, labels shuffled in chunks then Morton-ordered) instead of a uniform box")
+    ap.add_argument("--implicit-diffusion", action="store_true",
+                    help="qhd: implicitDiffusion true, the reference's default [QGDThermo.C L70-82]: fvm::laplacian in the U and T equations, the four "
+                         "systems as one multi-right-hand-side solve (one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropin", action="store_true", help="skip the second line (fvsc drop-in path with host fields)")
     ap.add_argument("--dropin-n", type=int, default=200, help="box edge of the fvsc drop-in measurement")
@@ -420,6 +424,7 @@ def secondary_lines(args):
     out = {}
     n = os.environ.get("QGD_BENCH_SECONDARY_N", "200")   # tests shrink it; any value but 200 is visible in the key and in config.env
     for key, argv in ((f"qhd_n{n}", ["--workload", "qhd", "--edge", n, "--steps", "20", "--warmup", "10"]),
+                      (f"qhd_implicit_n{n}", ["--workload", "qhd", "--implicit-diffusion", "--edge", n, "--steps", "20", "--warmup", "10"]),
                       (f"implicit_n{n}", ["--workload", "implicit", "--edge", n, "--steps", "20", "--warmup", "5"])):
         t0 = time.perf_counter()
         d = child_line(argv, 420)
@@ -481,7 +486,8 @@ def qhd_line(args):
     h = 1.0 / n
     dev = q.Device(mesh)
     opt = qhdfoam.qhd_options(stencil="GaussVolPoint", tauModel="HbyUQHD", aQGD=0.5, UQHD=0.1, rho0=1.0, mu=1e-3, Pr=0.71, beta=3.4e-3,
-                              g=(0.0, -9.81, 0.0), deltaT=0.02 * h / 0.1, pTol=1e-8, pMaxIter=300, pRefCell=0)
+                              g=(0.0, -9.81, 0.0), deltaT=0.02 * h / 0.1, pTol=1e-8, pMaxIter=300, pRefCell=0,
+                              implicitDiffusion=1 if args.implicit_diffusion else 0, implicitTol=1e-10, implicitMaxIter=1000)
     case = qhdfoam.QHDFoamCase(dev, opt)
     WALL = dict(U=("fixedValue", (0.0, 0.0, 0.0)), T=("zeroGradient", None), p=("qhdFluxCoupled", None))
     for ip in range(mesh.nPatches):   # buoyant cavity: hot xMin, cold xMax, adiabatic walls, impermeable (qhdFlux fed by the flux)
@@ -504,7 +510,7 @@ def qhd_line(args):
     # second pass: where the time goes (host clock around stream-ordered phases, each followed by a wait)
     phase_ms = {"assemble": 0.0, "solve": 0.0, "advance": 0.0}
     iters = []
-    reps = min(args.steps, 5)
+    reps = 0 if args.implicit_diffusion else min(args.steps, 5)   # (the implicit branch's advance is phases 7, 10..16: timed as a whole step only)
     for _ in range(reps):
         case.sync(); t = time.perf_counter()
         case.step_phase(0); case.sync()
@@ -520,12 +526,15 @@ def qhd_line(args):
             case.step_phase(k)
         case.sync()
         phase_ms["advance"] += time.perf_counter() - t
-    phase_ms = {k: 1e3 * v / reps for k, v in phase_ms.items()}
+    phase_ms = {k: 1e3 * v / reps for k, v in phase_ms.items()} if reps else None
+    impl = case.implicit_info() if args.implicit_diffusion else None
     sw = case.sweep_time(30)
     sweep_bytes = sw["rows"] * (sw["width"] * (4 + sw["value_bytes"]) + 4 * sw["value_bytes"])
     achieved = sweep_bytes / (sw["ms"] * 1e-3) / 1e9 if sw["ms"] else None
     it = info["pIterations"]
     step_bytes = nc * (QHD_EXPLICIT_BYTES_PER_CELL + QHD_BYTES_PER_CELL_PER_ITERATION * it)
+    if impl:   # the four-component Chebyshev step: lists 48 + face coefficients 24 + per component diag, rhs, x, d read and d, x written 48
+        step_bytes += nc * (48 + 24 + 4 * 48) * max(v["iterations"] for v in impl["solves"].values())
     out = {
         "metric": "Mcell-steps/s (QHDFoam step)", "value": nc * args.steps / elapsed / 1e6, "unit": "Mcell-steps/s", "n_gpus": 1,
         "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
@@ -533,8 +542,12 @@ def qhd_line(args):
         "config": {"workload": (f"QHDFoam buoyant cavity, {nc / 1e6:.1f}M cells, "
                                 + ("config-5 stand-in mesh (jittered hexahedra, every 7th quad split into triangles, Morton order)" if args.irregular
                                    else "uniform hex box (blockMesh numbering)")
-                                + ", GaussVolPoint, HbyUQHD, pressure equation to 1e-8 with multigrid-preconditioned CG"),
-                   "cells": nc, "pressure_iterations_per_step": it, "multigrid_levels": info["mgLevels"], "env": qgd_env()},
+                                + ", GaussVolPoint, HbyUQHD, pressure equation to 1e-8 with multigrid-preconditioned CG"
+                                + (", implicitDiffusion true (the reference's default): U and T systems as four right-hand sides of one "
+                                   f"{impl['solver']} solve to 1e-10" if impl else ", implicitDiffusion false")),
+                   "cells": nc, "pressure_iterations_per_step": it, "multigrid_levels": info["mgLevels"],
+                   "implicit_iterations": {k: v["iterations"] for k, v in impl["solves"].items()} if impl else None,
+                   "implicit_unconverged_steps": impl["unconverged_steps"] if impl else None, "env": qgd_env()},
         "roofline": {"bound": "hbm", "kernel": "mgSmoothKernel<float>, multigrid level 0 (one damped-Jacobi sweep of the pressure preconditioner)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS if achieved else None,
                      "traffic": secondary_traffic("qhd_n200") if (n == 200 and not args.irregular) else None, "traffic_is_static": True,
@@ -764,6 +777,9 @@ def main():
     if args.workload == "qhd":
         if "QGD_BENCH_N" not in os.environ and "--edge" not in " ".join(sys.argv):
             args.n = 252 if args.irregular else 200
+        if args.gpus > 1 and args.implicit_diffusion:
+            print("bench.py: --workload qhd --implicit-diffusion is a one-GPU line (the branch shards: tests/test_qhd_implicit.py)", file=sys.stderr)
+            sys.exit(2)
         if args.gpus > 1:
             if "WORLD_SIZE" not in os.environ:
                 self_launch(args.gpus)   # never returns

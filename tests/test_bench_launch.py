@@ -153,8 +153,9 @@ def test_default_line_carries_the_secondary_workloads_and_the_env():
     d = json.loads([ln for ln in pr.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["config"]["env"]["QGD_BENCH_SECONDARY_N"] == "24" and d["config"]["rccl_ranks"] is None and "native_transport" not in d
     sec = d["secondary"]
-    assert set(sec) == {"qhd_n24", "implicit_n24"}
-    for key, it_key in (("qhd_n24", "pressure_iterations_per_step"), ("implicit_n24", "iterations_U")):
+    assert set(sec) == {"qhd_n24", "qhd_implicit_n24", "implicit_n24"}
+    assert sec["qhd_implicit_n24"]["config"]["implicit_iterations"]["T"] > 0 and sec["qhd_n24"]["config"]["implicit_iterations"] is None
+    for key, it_key in (("qhd_n24", "pressure_iterations_per_step"), ("qhd_implicit_n24", "pressure_iterations_per_step"), ("implicit_n24", "iterations_U")):
         x = sec[key]
         assert "error" not in x, x
         assert x["steps"] == 20 and x["ms_per_step"] > 0 and x["value"] > 0 and x["config"][it_key] > 0 and x["roofline"]["avg_launch_ms"] > 0
