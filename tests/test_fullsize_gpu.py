@@ -89,7 +89,7 @@ def _c2_oracle_worker(args):
     return {f: oc.field(f) for f in ("rho", "U", "p")}
 
 
-def test_config2_forward_step_100k_cells_1000_steps():
+def test_config2_forward_step_100k_cells_1000_steps_at_deltaT_5e_5():
     """BASELINE config 2: forwardStep planform, 100 800 hex cells one cell thick, Mach 3 inflow, slip walls
     with qgdFlux pressure, 1000 steps; leastSquares and GaussVolPoint; rho, U, p within 1e-10 of the oracle.
     Delta t = 5e-5 (t_end = 0.05): with the 5e-4 of the SURVEY's sketch the explicit scheme loses positivity within 100
