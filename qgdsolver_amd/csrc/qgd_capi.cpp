@@ -1955,8 +1955,6 @@ static void qhdPhase(qgd_qhd_case_s* c, int phase) {
                                  pressureSolverCtl(c->solver) + 8);
             else {
                 // implicitDiffusion: face pass 2 without the laplacians, the right-hand sides; the solve (phases 10..15) and phase 16 follow
-                static const double one = 1.0;
-                (void)one;
                 implicitStepMark(c->implSolver, true);
                 launchQhdImplicitAdvance(d->stream, c->stencil, c->usesPoints, m, c->view, c->bcDev, 0, c->implMask, false, -1, 0.0, nullptr);
                 const double gamma[4] = {c->view.nu, c->view.nu, c->view.nu, c->view.Hi};
@@ -2091,11 +2089,10 @@ int qgd_qhd_case_implicit_info(qgd_qhd_case_t c, double info[14]) {
     for (int i = 0; i < 14; ++i) info[i] = 0.0;
     if (!c->implSolver) return QGD_OK;
     HIP_CHECK(hipSetDevice(c->dev->deviceId));
-    double allDone = 0, st[4];
+    double allDone = 0;
     int it[4];
     double r0[4], r1[4];
     implicitSolveStatus4(c->implSolver, &allDone, it, r0, r1);
-    (void)st;
     for (int k = 0; k < 4; ++k) { info[k] = it[k]; info[4 + k] = r0[k]; info[8 + k] = r1[k]; }
     info[12] = implicitSolverUnconverged(c->implSolver);
     info[13] = implicitSolverChebyshev(c->implSolver) ? 2.0 : 1.0;

@@ -1075,7 +1075,7 @@ void implicitSolverSetStream(ImplicitSolver* S, hipStream_t s) { S->stream = s; 
 // system (iChebKernel<3, 0>: product, d, next iterate, partial residual sums) or, with QGD_IMPL_SOLVER=pcg, its matrix product
 // q = A d (iApplyKernel<3, 1>) -- on the vectors the last step left, between two HIP events; returns the average ms.  The control
 // block is cleared first (a finished solve makes every launch return at once); it is only kept for implicitSolverInfo, which
-// reads its own copy.  The iterate of the U system is overwritten: call between steps only (the next step rebuilds it).
+// reads its own copy.  Scratch vectors of the solver are overwritten (the search direction, the second iterate buffer): call between steps.
 double implicitApplyMs(ImplicitSolver* S, const ImplView& iv, int reps, int* rows) {
     implicitSolveSetup(S, 3, 7, iv.aU, iv.diagU, iv.rhsU, iv.xU, S->tol, S->maxIter);
     const ISolveView& v = S->v;
