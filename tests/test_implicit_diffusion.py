@@ -204,3 +204,25 @@ def test_conjugate_gradient_solver_is_still_selectable(monkeypatch):
     with pytest.raises(q.QgdError):
         q.QGDFoamCase(dev, q.default_options(**opt))
     dev.close()
+
+
+@pytest.mark.gpu
+def test_chebyshev_solver_on_a_weakly_dominant_system():
+    """a viscosity large enough that the laplacian carries most of the diagonal (Gershgorin radius of D^-1 A around 0.9 instead of the 0.1
+    of the other cases): the Chebyshev interval is wide, the iteration count goes up, the answer stays the oracle's"""
+    mesh = make_mesh("box654_jitter")
+    fields = cases.box_initial_fields(mesh.array("C").reshape(-1, 3))
+    opt = dict(stencil="GaussVolPoint", deltaT=2e-3, mu=30.0, implicitDiffusion=1, implicitTol=1e-13, implicitMaxIter=3000)   # nu deltaT / h^2 ~ 1
+    ref = run_oracle(mesh, mixed_bcs, fields, 6, **opt)
+    dev = q.Device(mesh)
+    gc = q.QGDFoamCase(dev, q.default_options(**opt))
+    mixed_bcs(gc)
+    gc.set_fields(*fields)
+    gc.step(6)
+    for f in ref:
+        err = np.abs(gc.field(f) - ref[f]).max() / np.abs(ref[f]).max()
+        assert err <= 1e-10, (f, err)
+    ii = gc.implicit_info()
+    its = max(s["iterations"] for s in ii["solves"].values())
+    assert ii["unconverged_steps"] == 0 and 20 < its < 400, ii
+    gc.close(); dev.close()
