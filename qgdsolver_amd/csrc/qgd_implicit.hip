@@ -420,7 +420,7 @@ inline int gridOf(int64_t n) { return (int)((n + QGD_BLOCK - 1) / QGD_BLOCK); }
 enum ICtl : int { I_ABSR = 0, I_SUMX = 1, I_N = 2, I_NORM = 3, I_RZ = 4, I_DQ = 5, I_ABSR2 = 6, I_RZNEW = 7, I_DELTA = 8, I_RES = 9, I_RES0 = 10,
                   I_DONE = 11, I_ITER = 12, I_ALPHA = 13, I_BETA = 14, I_NORMF = 15, I_SLOTS = 16, I_ALLDONE = 64, I_COUNT = 68,
                   // Chebyshev: slot 5 holds sum |b - A x_i|, slots 13 / 14 the coefficients c1 / c2
-                  I_CABSR = 5, I_C1 = 13, I_C2 = 14 };
+                  I_CABSR = 5, I_C1 = 13, I_C2 = 14, I_BEST = 0, I_STALL = 1 };   // (slots 0, 1: reused from phase 2 on, see chebAfterStep)
 #define ICTL(slot, k) ((slot) * 4 + (k))
 
 __device__ __forceinline__ double iBlockSum(double v) {
@@ -711,16 +711,21 @@ __device__ __forceinline__ void chebNext(double* __restrict__ ctl, const int k, 
 // started from, the step count, done?, the next constants
 __device__ __forceinline__ void chebAfterStep(double* __restrict__ ctl, const int k, const double tol, const int maxIter) {
     const double res = ctl[ICTL(I_CABSR, k)] / ctl[ICTL(I_NORMF, k)], it = ctl[ICTL(I_ITER, k)] + 1.0;
-    const double prev = ctl[ICTL(I_RES, k)], prev2 = ctl[ICTL(I_RZ, k)];   // residuals of the two iterates before (slot 4 is free here: only the
-    ctl[ICTL(I_RES, k)] = res; ctl[ICTL(I_ITER, k)] = it;                  // conjugate-gradient loop uses it, and it is reduced after phase 2 only)
-    ctl[ICTL(I_RZ, k)] = prev;
+    ctl[ICTL(I_RES, k)] = res; ctl[ICTL(I_ITER, k)] = it;
     // the residual here is the TRUE one, b - A x_i, not a recurrence: it stalls at the rounding floor of the product (the conjugate-
     // gradient loop's recurrence residual keeps falling below it and never notices; on a nearly uniform field OpenFOAM's normFactor is
     // small against |b| and the floor of the NORMALISED residual can sit at 1e-12).  A tolerance under that floor would burn maxIter
-    // steps for nothing: stop when two steps gained less than ONE step of the Chebyshev bound should (done = 4).  Only looked at below
-    // 1e-8, far inside the asymptotic regime; the Gershgorin interval cannot be wrong, so a stall there is rounding, not divergence.
+    // steps for nothing.  The 1-norm of a Chebyshev residual is not monotone, so one slow pair of steps proves nothing: the best
+    // residual so far (slot 0) has to go unimproved by a factor 2 for several times as many steps as the Chebyshev bound needs to
+    // halve it (slot 1 counts them) -- then the component stops (done = 4).  Only looked at below 1e-8; the Gershgorin interval cannot
+    // be wrong, so a stall there is rounding, not divergence.  (Slots 0 and 1 are free from phase 2 on: the first residual and the
+    // mean of x were consumed by phases 1 and 2, and no later reduction touches them.)
     const double sigma = 1.0 / ctl[ICTL(I_DELTA, k)], rate = sigma - sqrt(fmax(sigma * sigma - 1.0, 0.0));
-    const bool stalled = it >= 3.0 && res < 1e-8 && prev2 > 0.0 && res >= fmax(rate, 0.25) * prev2;
+    const double halving = rate < 1.0 ? log(0.5) / log(fmax(rate, 1e-300)) : 1e9;   // steps the bound needs to halve the residual
+    double best = ctl[ICTL(I_BEST, k)], count = ctl[ICTL(I_STALL, k)];
+    if (res < 0.5 * best) { best = res; count = 0.0; } else count += 1.0;
+    ctl[ICTL(I_BEST, k)] = best; ctl[ICTL(I_STALL, k)] = count;
+    const bool stalled = res < 1e-8 && count >= 8.0 + 4.0 * halving;
     if (res < tol || it >= (double)maxIter) ctl[ICTL(I_DONE, k)] = 1.0;
     else if (stalled) ctl[ICTL(I_DONE, k)] = 4.0;   // at the rounding floor of b - A x: as converged as this arithmetic gets; not counted as a failed solve
     else chebNext(ctl, k, ctl[ICTL(I_C2, k)] * ctl[ICTL(I_DELTA, k)] * 0.5);   // rho_i = c2_i delta / 2
@@ -754,6 +759,7 @@ __global__ void iCtlKernel(double* __restrict__ ctl, const int NR, const int sta
                 ctl[ICTL(I_NORMF, k)] = nf; ctl[ICTL(I_RES, k)] = res; ctl[ICTL(I_RES0, k)] = res;
                 if (res < tol || maxIter <= 0) ctl[ICTL(I_DONE, k)] = 1.0;
                 else if (cheb) {
+                    ctl[ICTL(I_BEST, k)] = res; ctl[ICTL(I_STALL, k)] = 0.0;   // stall detection of chebAfterStep
                     // Gershgorin: the spectrum of D^-1 A lies in [1 - delta, 1 + delta]; strictly below 1 by diagonal dominance.  The
                     // clamps keep the recurrence finite for a purely diagonal matrix (delta = 0: x_1 is exact) and for a singular one
                     const double delta = fmin(fmax(ctl[ICTL(I_DELTA, k)], 1e-30), 1.0 - 1e-9);

@@ -707,6 +707,7 @@ struct PressureSolver {
     int ob = 0, oe = 0;             // rows of the system: the owned cells [ob, oe) of the (possibly sharded) mesh
     double omega = 0.8, oc = 1.8;   // measured (8 M cells / 16 M irregular): 0.67 -> 0.8 with 4:1 coarsening 46 -> 24 / 52 -> 25 iterations
     int nu = 2, coarseSweeps = 40;
+    int nu0 = 0;                           // QGD_MG_NU0: sweeps before / after on level 0 only (0: as nu) -- the level whose passes cost
     // the smoother's steps: x <- (1 + cm) x + cr D^-1 r - cm x_previous.  Damped Jacobi: cr = omega, cm = 0.  With QGD_MG_CHEB=ratio > 1
     // the nu steps are the Chebyshev polynomial of D^-1 A for the eigenvalue interval [lmax / ratio, lmax] (lmax = 2: Gershgorin, the
     // rows of every level are weakly diagonally dominant) -- a fixed polynomial, the same before and after the coarse correction, so
@@ -840,6 +841,7 @@ struct PressureSolver {
         }
         MgLevelT<T>& nx = Lv[l + 1];
         T* cur = x; T* nxt = lv.x2;
+        const int nu = l == 0 ? nu0 : this->nu;   // level 0 may take fewer sweeps than the cheap coarse levels (QGD_MG_NU0)
         // pre-smoothing from a zero iterate: step 0 is cr[0] b/d, step 1 has no previous iterate to subtract
         sweep((T)(cr[0] * sc), b, none, cur, noOut, (T)1, (T)0);
         for (int s = 1; s < nu; ++s) {
@@ -1377,6 +1379,8 @@ PressureSolver* pressureSolverCreate(hipStream_t stream, const MeshView& m, cons
             return v;
         };
         S->nu = (int)knob("QGD_MG_NU", S->nu, 1, 8);
+        S->nu0 = (int)knob("QGD_MG_NU0", 0, 0, 8);
+        if (S->nu0 == 0) S->nu0 = S->nu;
         S->oc = knob("QGD_MG_OC", S->oc, 0.5, 3.0);
         S->omega = knob("QGD_MG_OMEGA", S->omega, 0.1, 1.0);
         S->coarseSweeps = (int)knob("QGD_MG_COARSE_SWEEPS", S->coarseSweeps, 1, 1000);
@@ -1658,7 +1662,7 @@ static bool distSetupStep(PressureSolver* S) {
 static bool distApplyStep(PressureSolver* S) {
     PressureSolver::Dist& D = S->dist;
     hipStream_t stream = S->stream;
-    const int ob = S->ob, nOwned = S->oe - S->ob, nb = blocksOf(nOwned), nu = S->nu;
+    const int ob = S->ob, nOwned = S->oe - S->ob, nb = blocksOf(nOwned), nu = S->nu0;   // level 0 of the spanning hierarchy
     MgLevelT<float>& L0 = S->Lf[0];
     MgLevelT<float>& L1 = S->Lf[1];
     const double* ctl = S->ctl;
