@@ -401,6 +401,35 @@ __global__ __launch_bounds__(PB) void mgSmoothKernel(const MgLevelT<T> L, const 
         xout[i] = v;
     }
 }
+// The LAST post-smoothing sweep of level 0 in a single-precision cycle, fused with what used to follow it: the iterate goes out in double
+// (z of the CG) and the block's share of r.z is summed on the way -- the copy into the level's x, the conversion pass and the dot-product
+// pass (read 4 + write 8, read 8 + 8 bytes per row) are gone; r costs 8 bytes per row here.  Same sweep arithmetic as mgSmoothKernel,
+// same block partials as dotKernel (block blk of PB rows -> part[blk]): not a bit of the solve changes.
+__global__ __launch_bounds__(PB) void mgSmoothLastKernel(const MgLevelT<float> L, const float omega, const float* __restrict__ b,
+                                                         const float* __restrict__ xin, const float* __restrict__ xprev, double* __restrict__ z,
+                                                         const double* __restrict__ r, double* __restrict__ part,
+                                                         const double* __restrict__ ctl, const float cx, const float cm) {
+    const int blk = xcdRunBlock(L.xrun);
+    const int i = blk * PB + threadIdx.x;
+    if (solveDone(ctl)) return;
+    double rz = 0;
+    if (i < L.n) {
+        const float d = L.diag[i];
+        const float xi = xin[i];
+        float s = d * xi;
+        const int s0 = L.sliceStart[i >> 6], w = L.sliceStart[(i >> 6) + 1] - s0;
+        const size_t e0 = (size_t)s0 * 64 + (i & 63);
+        s = ellRowAcc<-1>(s, L.col, L.val, xin, e0, w);
+        const float res = b[i] - s;
+        float v = cx * xi + omega * res / d;
+        if (cm != 0.0f) v -= cm * xprev[i];
+        const double zi = (double)v;
+        z[i] = zi;
+        rz = r[i] * zi;
+    }
+    const double t = blockSum(rz);
+    if (threadIdx.x == 0) part[blk] = t;
+}
 // vectors between the double-precision CG and a single-precision cycle
 template <typename A, typename B>
 __global__ __launch_bounds__(PB) void mgConvertKernel(const int n, const A* __restrict__ in, B* __restrict__ out, const double* __restrict__ ctl = nullptr) {
@@ -607,14 +636,20 @@ __global__ __launch_bounds__(PB) void dotKernel(const int n, const double* __res
     if (threadIdx.x == 0) part[blockIdx.x] = t;
 }
 // x += alpha d, r -= alpha q with alpha from the control block; partial sums [|r|]
+// b0 != nullptr: the head of the single-precision cycle rides along -- its right-hand side b0 = (float) r and its first pre-smoothing step
+// from the zero iterate x0 = om0 b0 / diag0 (what mgConvertKernel + the first mgSmoothKernel launch of the cycle did in two more passes)
 __global__ __launch_bounds__(PB) void axpyKernel(const int n, double* __restrict__ x, double* __restrict__ r,
                                                   const double* __restrict__ d, const double* __restrict__ q, double* __restrict__ part,
-                                                  const double* __restrict__ ctl) {
+                                                  const double* __restrict__ ctl, float* __restrict__ b0 = nullptr, float* __restrict__ x0 = nullptr,
+                                                  const float* __restrict__ diag0 = nullptr, const float om0 = 0) {
     if (solveDone(ctl)) return;
     const double alpha = ctl[C_ALPHA];
     const int c = blockIdx.x * PB + threadIdx.x;
     double ar = 0;
-    if (c < n) { x[c] += alpha * d[c]; const double rc = r[c] - alpha * q[c]; r[c] = rc; ar = fabs(rc); }
+    if (c < n) {
+        x[c] += alpha * d[c]; const double rc = r[c] - alpha * q[c]; r[c] = rc; ar = fabs(rc);
+        if (b0) { const float bf = (float)rc; b0[c] = bf; x0[c] = om0 * bf / diag0[c]; }
+    }
     const double t = blockSum(ar);
     if (threadIdx.x == 0) part[blockIdx.x] = t;
 }
@@ -814,6 +849,12 @@ struct PressureSolver {
     }
 
     // z = M r on level l (b -> x), in the precision of the level arrays; every launch returns at once when the solve is done
+    // Fused hand-over between the CG and the single-precision cycle (unsharded solves; QGD_MG_FUSE=0: the separate passes).  headDone:
+    // b and the first pre-smoothing step of level 0 were written by axpyKernel; tailZ/tailR/tailPart: the last post-smoothing sweep of
+    // level 0 writes z in double and the block partials of r.z (mgSmoothLastKernel)
+    bool fuse = false, headDone = false;
+    double* tailZ = nullptr; const double* tailR = nullptr; double* tailPart = nullptr;
+    bool fusedCycle() const { return fuse && precond == 1 && Lf.size() >= 2 && !Lf[0].rowStart && nu0 >= 1 && !dist.wanted; }
     template <typename T>
     void vcycleT(std::vector<MgLevelT<T>>& Lv, size_t l, const T* b, T* x) {
         MgLevelT<T>& lv = Lv[l];
@@ -843,7 +884,7 @@ struct PressureSolver {
         T* cur = x; T* nxt = lv.x2;
         const int nu = l == 0 ? nu0 : this->nu;   // level 0 may take fewer sweeps than the cheap coarse levels (QGD_MG_NU0)
         // pre-smoothing from a zero iterate: step 0 is cr[0] b/d, step 1 has no previous iterate to subtract
-        sweep((T)(cr[0] * sc), b, none, cur, noOut, (T)1, (T)0);
+        if (!(l == 0 && headDone)) sweep((T)(cr[0] * sc), b, none, cur, noOut, (T)1, (T)0);
         for (int s = 1; s < nu; ++s) {
             sweep((T)(cr[s] * sc), b, cur, nxt, noOut, (T)(1.0 + cm[s]), (T)(s >= 2 ? cm[s] : 0.0));
             std::swap(cur, nxt);
@@ -856,6 +897,12 @@ struct PressureSolver {
         if (lv.pS) mgProlongEllKernel<T><<<nb, PB, 0, stream>>>(lv.n, lv.pS, lv.pCol, lv.pVal, over, nx.x, cur, ctl);
         else mgProlongKernel<T><<<nb, PB, 0, stream>>>(lv.n, lv.agg, over, nx.x, cur, ctl);
         for (int s = 0; s < nu; ++s) {
+            if constexpr (std::is_same<T, float>::value) {
+                if (l == 0 && tailZ && s == nu - 1 && !lv.rowStart) {
+                    mgSmoothLastKernel<<<nb, PB, 0, stream>>>(lv, (float)(cr[s] * sc), b, cur, nxt, tailZ, tailR, tailPart, ctl, (float)(1.0 + cm[s]), (float)cm[s]);
+                    return;
+                }
+            }
             sweep((T)(cr[s] * sc), b, cur, nxt, noOut, (T)(1.0 + cm[s]), (T)cm[s]);
             std::swap(cur, nxt);
         }
@@ -865,15 +912,21 @@ struct PressureSolver {
         if (!Lf.empty() && l == 0) {
             // the cycle as a single-precision operator between double-precision CG vectors: half the bytes of every sweep
             const int nb = blocksOf(L[0].n);
-            mgConvertKernel<double, float><<<nb, PB, 0, stream>>>(L[0].n, b, Lf[0].b, ctl);
+            if (!headDone) mgConvertKernel<double, float><<<nb, PB, 0, stream>>>(L[0].n, b, Lf[0].b, ctl);
             vcycleT<float>(Lf, 0, Lf[0].b, Lf[0].x);
-            mgConvertKernel<float, double><<<nb, PB, 0, stream>>>(L[0].n, Lf[0].x, x, ctl);
+            if (!tailZ) mgConvertKernel<float, double><<<nb, PB, 0, stream>>>(L[0].n, Lf[0].x, x, ctl);
         } else vcycleT<double>(L, l, b, x);
     }
     // z = M r over the owned rows (the multigrid hierarchy is built on the owned block: for a shard it is the additive-Schwarz
     // block of this rank, couplings to ghost cells stay in the diagonal only)
-    void precondition() {
+    // head: the caller's axpyKernel wrote the head of the cycle; rzPart != nullptr: the cycle's last sweep leaves the block partials of
+    // r.z there (both only with `fuse`; returns whether the partials were written)
+    bool precondition(bool head = false, double* rzPart = nullptr) {
         const int n = oe - ob, nb = blocksOf(n);
+        const bool fused = fusedCycle();
+        headDone = fused && head;
+        tailZ = fused && rzPart ? z + ob : nullptr; tailR = r + ob; tailPart = rzPart;
+        struct Reset { PressureSolver* s; ~Reset() { s->headDone = false; s->tailZ = nullptr; } } reset{this};
         if (precond == 1 && !L.empty()) {
             if (!cycleGraphTried) {
                 cycleGraphTried = true;
@@ -895,6 +948,7 @@ struct PressureSolver {
             const double* none = nullptr; double* noOut = nullptr;
             mgSmoothKernel<double><<<nb, PB, 0, stream>>>(jl, 1.0, r + ob, none, z + ob, noOut, ctl);   // z = r/diag
         }
+        return tailZ != nullptr;
     }
 };
 
@@ -1380,6 +1434,7 @@ PressureSolver* pressureSolverCreate(hipStream_t stream, const MeshView& m, cons
         };
         S->nu = (int)knob("QGD_MG_NU", S->nu, 1, 8);
         S->nu0 = (int)knob("QGD_MG_NU0", 0, 0, 8);
+        S->fuse = knob("QGD_MG_FUSE", 1, 0, 1) != 0 && !std::getenv("QGD_MG_GRAPH");
         if (S->nu0 == 0) S->nu0 = S->nu;
         S->oc = knob("QGD_MG_OC", S->oc, 0.5, 3.0);
         S->omega = knob("QGD_MG_OMEGA", S->omega, 0.1, 1.0);
@@ -1717,11 +1772,16 @@ static bool distApplyStep(PressureSolver* S) {
         return true;
     }
 }
-static void pressurePhaseTail(PressureSolver* S, int phase);
+static void pressurePhaseTail(PressureSolver* S, int phase, bool rzDone = false);
 // runs the preconditioner of phase `phase`; with the hierarchy that spans the ranks it stops at every comm point (pending != 0)
 static void pressurePrecondition(PressureSolver* S, int phase) {
     PressureSolver::Dist& D = S->dist;
-    if (!(D.wanted && D.built && S->L.size() >= 2 && S->Lf.size() >= 2 && S->Lf[0].pS && D.n1 > 0)) { S->precondition(); pressurePhaseTail(S, phase); return; }
+    if (!(D.wanted && D.built && S->L.size() >= 2 && S->Lf.size() >= 2 && S->Lf[0].pS && D.n1 > 0)) {
+        // (unsharded: phase 4's axpyKernel wrote the head of this cycle, the cycle's last sweep leaves the partials of r.z)
+        const bool rzDone = S->precondition(phase == 4, phase == 2 ? S->part : S->part + blocksOf(S->oe - S->ob));
+        pressurePhaseTail(S, phase, rzDone);
+        return;
+    }
     D.rhs = S->r; D.out = S->z; D.pc = 0; D.resumePhase = phase;
     if (distApplyStep(S)) { D.resumePhase = -1; pressurePhaseTail(S, phase); }
 }
@@ -1769,16 +1829,17 @@ static void pressureBeginBody(PressureSolver* S) {
     PCHECK(hipGetLastError());
 }
 // what follows the preconditioner in phases 2 and 4
-static void pressurePhaseTail(PressureSolver* S, int phase) {
+static void pressurePhaseTail(PressureSolver* S, int phase, bool rzDone) {
+    // rzDone: the block partials of r.z are in place already (mgSmoothLastKernel)
     hipStream_t stream = S->stream;
     const int ob = S->ob, n = S->oe - ob, nb = blocksOf(n);
     double* ctl = S->ctl;
     if (phase == 2) {
         directionCtlKernel<<<nb, PB, 0, stream>>>(n, 1, S->z + ob, S->d + ob, ctl);
-        dotKernel<<<nb, PB, 0, stream>>>(n, S->r + ob, S->z + ob, S->part, ctl);
+        if (!rzDone) dotKernel<<<nb, PB, 0, stream>>>(n, S->r + ob, S->z + ob, S->part, ctl);
         foldCtlKernel<<<1, PB, 0, stream>>>(S->part, nb, 1, ctl, C_RZ, 0);
     } else {
-        dotKernel<<<nb, PB, 0, stream>>>(n, S->r + ob, S->z + ob, S->part + nb, ctl);
+        if (!rzDone) dotKernel<<<nb, PB, 0, stream>>>(n, S->r + ob, S->z + ob, S->part + nb, ctl);
         foldCtlKernel<<<2, PB, 0, stream>>>(S->part, nb, 2, ctl, C_ABSR2, 0);
     }
     PCHECK(hipGetLastError());
@@ -1807,7 +1868,11 @@ void pressureSolvePhase(PressureSolver* S, int phase) {
             break;
         case 4:
             ctlKernel<<<1, 1, 0, stream>>>(ctl, 2, 0.0, S->tol, S->relTol, S->maxIter);
-            axpyKernel<<<nb, PB, 0, stream>>>(n, S->p + ob, S->r + ob, S->d + ob, S->q + ob, S->part, ctl);
+            if (S->fusedCycle()) {
+                const double sc0 = S->smootherScale.empty() ? 1.0 : S->smootherScale[0];
+                axpyKernel<<<nb, PB, 0, stream>>>(n, S->p + ob, S->r + ob, S->d + ob, S->q + ob, S->part, ctl, S->Lf[0].b, S->Lf[0].x, S->Lf[0].diag,
+                                                  (float)(S->cr[0] * sc0));
+            } else axpyKernel<<<nb, PB, 0, stream>>>(n, S->p + ob, S->r + ob, S->d + ob, S->q + ob, S->part, ctl);
             if (S->earlyTest) {
                 foldCtlKernel<<<1, PB, 0, stream>>>(S->part, nb, 1, ctl, C_ABSR2, 0);
                 ctlKernel<<<1, 1, 0, stream>>>(ctl, 4, 0.0, S->tol, S->relTol, S->maxIter);

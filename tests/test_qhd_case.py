@@ -160,6 +160,35 @@ def test_multigrid_and_jacobi_preconditioners_agree():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nu0", [0, 1])
+def test_fused_cycle_hand_over_changes_no_bit_of_a_solve(nu0, monkeypatch):
+    """QGD_MG_FUSE (default 1): the head of the single-precision cycle rides in the CG's axpy kernel, its last post-smoothing sweep
+    writes z in double and the block partials of r.z.  Same arithmetic, same partial sums: pressure, velocity and the iteration
+    count after 6 steps are those of the separate passes, bit for bit (48^3 cells: three levels; also with one sweep on level 0)."""
+    mesh = q.PolyMesh.box(48, 48, 48).jitter(0.1, seed=2)
+    dev = q.Device(mesh)
+    res = {}
+    if nu0:
+        monkeypatch.setenv("QGD_MG_NU0", str(nu0))
+    for fuse in (0, 1):
+        monkeypatch.setenv("QGD_MG_FUSE", str(fuse))
+        c = qhdfoam.QHDFoamCase(dev, options(deltaT=1e-3, pTol=1e-10))
+        cavity_bcs(c, mesh)
+        c.set_fields(*initial(mesh))
+        its = []
+        for _ in range(6):
+            c.step(1)
+            its.append(c.info()["pIterations"])
+        res[fuse] = (c.field("p"), c.field("U"), c.field("T"), its, c.info())
+        c.close()
+    assert res[1][4]["mgLevels"] >= 3, res[1][4]
+    assert res[0][3] == res[1][3] and min(res[0][3]) >= 2, (res[0][3], res[1][3])
+    for k in range(3):
+        assert np.isfinite(res[0][k]).all() and np.array_equal(res[0][k], res[1][k]), k
+    dev.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n", [128, 200])
 def test_pressure_equation_at_scale_under_100_iterations(n):
     """2 M and 8 M cells (one 8-GPU shard of config 5's size): QHDpEqn.H L36-47 to 1e-8 in < 100 iterations"""
