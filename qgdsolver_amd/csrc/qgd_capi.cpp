@@ -634,6 +634,8 @@ int qgd_device_create(qgd_mesh_t mh, int deviceId, qgd_device_t* out) {
             const int64_t nTiles = t.fb ? (s.nIF + t.fb - 1) / t.fb : 0;
             if (t.fb != 0 && lds <= 65536 && 4 * (int64_t)t.spill.size() <= nTiles) {
                 v.tileLds = (int32_t)lds;
+                v.tileMaxC = t.maxCells; v.tileMaxV = t.maxVerts;
+                v.qhdTiles = envChoice("QGD_QHD_TILES", 1, kOnOff, 2);
                 v.nTileSpill = (int32_t)t.spill.size(); v.tileSpill = up(t.spill);
                 v.tileOff = up(t.off); v.tileCells = up(t.cells); v.tileVerts = up(t.verts);
                 v.locC = up(t.locC); v.locV = reinterpret_cast<const uint2*>(up(t.locV));

@@ -54,6 +54,8 @@ struct MeshView {
     const uint32_t* locC; const uint2* locV;
     const int32_t* tileSpill; int32_t nTileSpill;   // tiles left to the gather kernel
     int32_t tileLds;         // dynamic LDS bytes of the largest tile
+    int32_t tileMaxC, tileMaxV;   // distinct cells / vertices of the largest staged tile
+    int32_t qhdTiles;        // QGD_QHD_TILES (default 1): QHD's two face passes use the tiles too (qgd_qhd.hip qhdFace{1,2}TileKernel)
     int32_t tileWaves;       // waves per SIMD the staged kernel is compiled for (2, 3 or 4)
     int32_t sGeo;            // 1: the 3-D GaussVolPoint kernels rebuild Sf of quadrilateral faces from the vertices (no Sf stream)
     const double* V; const double* hQGD; const uint8_t* ghost;

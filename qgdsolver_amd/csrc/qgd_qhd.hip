@@ -40,10 +40,13 @@ __device__ __forceinline__ void qhdBoundaryVals4(const MeshView& m, const PatchB
 }
 
 // face pass 1 [updateFields.H L36-73, updateFluxes.H L33-38, QHDTEqn.H L66]
+// (tileList != nullptr: 128 threads per workgroup, the 128-face tiles the staged kernel leaves to this one; else the faces from fBegin on)
 template <int ST>
-__global__ __launch_bounds__(QGD_BLOCK) void qhdFace1Kernel(const MeshView m, const QhdView q, const PatchBCDev* __restrict__ bcs) {
-    const int f = xcdTile((int)gridDim.x, m.xcdRun) * QGD_BLOCK + threadIdx.x;   // runs of consecutive blocks per XCD: neighbours meet in one L2
-    if (f >= m.nF) return;
+__global__ __launch_bounds__(QGD_BLOCK) void qhdFace1Kernel(const MeshView m, const QhdView q, const PatchBCDev* __restrict__ bcs,
+                                                            const int32_t* __restrict__ tileList, const int fBegin) {
+    const int f = tileList ? tileList[blockIdx.x] * 128 + (int)threadIdx.x
+                           : fBegin + xcdTile((int)gridDim.x, m.xcdRun) * QGD_BLOCK + (int)threadIdx.x;   // runs of consecutive blocks per XCD: neighbours meet in one L2
+    if (f >= (tileList ? m.nIF : m.nF)) return;
     if (m.fkind[f] == 3) return;
     const bool internal = f < m.nIF;
     const int o = m.own[f];
@@ -111,9 +114,11 @@ __global__ __launch_bounds__(QGD_BLOCK) void qhdCellGradKernel(const MeshView m,
 
 // face pass 2 [QHDUEqn.H L36-84, QHDTEqn.H L65-91]: the net face terms of the U and T equations
 template <int ST>
-__global__ __launch_bounds__(QGD_BLOCK) void qhdFace2Kernel(const MeshView m, const QhdView q, const PatchBCDev* __restrict__ bcs) {
-    const int f = xcdTile((int)gridDim.x, m.xcdRun) * QGD_BLOCK + threadIdx.x;   // runs of consecutive blocks per XCD: neighbours meet in one L2
-    if (f >= m.nF) return;
+__global__ __launch_bounds__(QGD_BLOCK) void qhdFace2Kernel(const MeshView m, const QhdView q, const PatchBCDev* __restrict__ bcs,
+                                                            const int32_t* __restrict__ tileList, const int fBegin) {
+    const int f = tileList ? tileList[blockIdx.x] * 128 + (int)threadIdx.x
+                           : fBegin + xcdTile((int)gridDim.x, m.xcdRun) * QGD_BLOCK + (int)threadIdx.x;   // runs of consecutive blocks per XCD: neighbours meet in one L2
+    if (f >= (tileList ? m.nIF : m.nF)) return;
     // the net face terms go to the face's slot-major position (MeshView::fpos), where the cell update finds those of consecutive cells
     // at consecutive addresses (by label: every third double of the lines it fetches)
     const size_t nF = (size_t)m.nF, pos = f < m.nIF ? (size_t)m.fpos[f] : (size_t)f;
@@ -199,6 +204,188 @@ __global__ __launch_bounds__(QGD_BLOCK) void qhdFace2Kernel(const MeshView m, co
     }
     q.F[3 * nF + pos] = q.implicit ? phi * Tf - q.phitr[f]                                             // QHDTEqn.H L73-76
                                    : (phi * Tf - q.Hi * snT * magS) - q.phitr[f];                      // QHDTEqn.H L65-66, L85-88
+}
+
+// ---------------------------------------------------------------------------
+// The two face passes through LDS on 3-D GaussVolPoint meshes, like the QGD face kernel (qgd_kernels.hip faceFluxGvp3TileKernel,
+// qgd_setup.hpp FaceTiles): a workgroup owns a tile of 128 consecutive internal faces, brings every DISTINCT cell / vertex record of
+// the tile in once as consecutive 16-B or 8-B pieces (lane q takes piece q: whole cache lines per wave instruction instead of one
+// scattered record per lane) and every face picks its records out of LDS.  Pass 2 gains most: fvc::grad(U) alone is 2 x 72 B per
+// face as nine scattered doubles in the generic walk.  Same expressions as the generic kernels (which keep the boundary faces and
+// the tiles beyond the caps).
+// ---------------------------------------------------------------------------
+typedef double v2d __attribute__((ext_vector_type(2)));
+// K rounds of pieces of type PT (PPR pieces per record): lane q of round k takes piece tid + k * FB of the tile's list
+template <typename PT, int K, int PPR, int FB>
+struct TileStager {
+    PT d[K];
+    __device__ __forceinline__ void load(const PT* __restrict__ g, const int32_t* __restrict__ list, const int nU, const int tid) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int q = tid + k * FB, r = q / PPR;
+            d[k] = g[(size_t)list[min(r, nU - 1)] * PPR + (q - r * PPR)];
+        }
+    }
+    __device__ __forceinline__ void store(PT* __restrict__ s, const int nU, const int tid) const {
+#pragma unroll
+        for (int k = 0; k < K; ++k) { const int q = tid + k * FB; if (q < nU * PPR) s[q] = d[k]; }
+    }
+};
+constexpr int kQhdFB = 128;
+static_assert(2 * (kQhdFB + kQhdFB / 16) <= 3 * kQhdFB && 3 * (kQhdFB + kQhdFB / 16) <= 4 * kQhdFB && 9 * (kQhdFB + kQhdFB / 16) <= 10 * kQhdFB &&
+              2 * (((kQhdFB * 23) / 16 + 7) / 8 * 8) <= 3 * kQhdFB && 3 * (((kQhdFB * 23) / 16 + 7) / 8 * 8) <= 5 * kQhdFB, "faceTileCap*");
+
+// face pass 1 on the staged tiles: the internal-face branch of qhdFace1Kernel
+__global__ __launch_bounds__(kQhdFB) void qhdFace1TileKernel(const MeshView m, const QhdView q) {
+    constexpr int FB = kQhdFB;
+    extern __shared__ v2d qhdLds[];
+    const int tile = xcdTile((int)gridDim.x, m.xcdRun * (QGD_BLOCK / FB));
+    const int tid = (int)threadIdx.x;
+    const int f = tile * FB + tid;
+    const bool active = f < m.nIF;
+    const int cOff = m.tileOff[2 * tile], vOff = m.tileOff[2 * tile + 1];
+    const int nUc = m.tileOff[2 * tile + 2] - cOff, nUv = m.tileOff[2 * tile + 3] - vOff;
+    if (nUc == 0) return;   // beyond the caps: in m.tileSpill, done by the generic kernel
+    v2d* const s4 = qhdLds;                                    // 2 nUc pieces: cell {U,T}
+    v2d* const sP = s4 + 2 * nUc;                              // 2 nUv: vertex {U,T}
+    double* const sC = reinterpret_cast<double*>(sP + 2 * nUv);   // 3 nUc: cell centres
+    double* const sX = sC + 3 * nUc;                           // 3 nUv: vertex coordinates
+    const int fl = active ? f : m.nIF - 1;
+    const unsigned lc = ldStream(m.locC + fl);
+    const uint2 lv = m.locV[fl];
+    const int kind = m.fkind[fl];
+    const double w = ldStream(m.w + fl), tau = ldStream(q.tauF + fl);
+    const double S[3] = {ldStream(m.Sx + fl), ldStream(m.Sy + fl), ldStream(m.Sz + fl)};
+    TileStager<v2d, 3, 2, FB> g4, gP;
+    TileStager<double, 4, 3, FB> gC;
+    TileStager<double, 5, 3, FB> gX;
+    g4.load(reinterpret_cast<const v2d*>(q.c4), m.tileCells + cOff, nUc, tid);
+    gC.load(m.Cc, m.tileCells + cOff, nUc, tid);
+    gP.load(reinterpret_cast<const v2d*>(q.pt4), m.tileVerts + vOff, nUv, tid);
+    gX.load(m.X, m.tileVerts + vOff, nUv, tid);
+    __builtin_amdgcn_sched_barrier(0);
+    g4.store(s4, nUc, tid); gC.store(sC, nUc, tid); gP.store(sP, nUv, tid); gX.store(sX, nUv, tid);
+    __syncthreads();
+    if (!active) return;
+    const int lo = (int)(lc & 0xffffu), ln = (int)(lc >> 16);
+    const int v0 = (int)(lv.x & 0xffffu), v1 = (int)(lv.x >> 16), v2 = (int)(lv.y & 0xffffu), v3 = (int)(lv.y >> 16);
+    auto l3 = [](const double* p, int i) { return make_double4(p[3 * i], p[3 * i + 1], p[3 * i + 2], 0.0); };
+    auto l4 = [](const v2d* p, int i, double* o) { const v2d a = p[2 * i], b = p[2 * i + 1]; o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y; };
+    FaceVals<4> v;
+    l4(s4, lo, v.o); l4(s4, ln, v.n);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v.sn[k] = 0.0;
+    double g[12];
+    if (kind == 2) faceGradient<ST_GVP3, 4, 0>(m, f, v, q.c4, q.pt4, g);   // more than four vertices: nf (x) snGrad, out of global memory
+    else {
+        double q0[4], q1[4], q2[4], q3[4];
+        l4(sP, v0, q0); l4(sP, v1, q1); l4(sP, v2, q2); l4(sP, v3, q3);
+        gvp3GradCore<4, 0>(kind, true, l3(sC, lo), l3(sC, ln), l3(sX, v0), l3(sX, v1), l3(sX, v2), l3(sX, v3), v.o, v.n, q0, q1, q2, q3, g);
+    }
+    const double gv[3] = {q.g[0], q.g[1], q.g[2]};
+    double Uf[3], Bf[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        Uf[k] = lerpf(w, v.o[k], v.n[k]);
+        Bf[k] = lerpf(w, (q.beta * v.o[3]) * gv[k], (q.beta * v.n[3]) * gv[k]);   // L66-67
+    }
+    const size_t nF = (size_t)m.nF;
+    const double phiu = S[0] * Uf[0] + S[1] * Uf[1] + S[2] * Uf[2];
+    double wo[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const double UgU = Uf[0] * g[0 * 4 + j] + Uf[1] * g[1 * 4 + j] + Uf[2] * g[2 * 4 + j];   // Uf & gradUf
+        q.ugu[(size_t)j * nF + f] = UgU;
+        wo[j] = tau * (UgU - Bf[j]);
+    }
+    q.phiu[f] = phiu;
+    q.phiwo[f] = S[0] * wo[0] + S[1] * wo[1] + S[2] * wo[2];
+    q.phitr[f] = tau * phiu * (Uf[0] * g[0 * 4 + 3] + Uf[1] * g[1 * 4 + 3] + Uf[2] * g[2 * 4 + 3]);
+}
+
+// face pass 2 on the staged tiles: the internal-face branch of qhdFace2Kernel
+__global__ __launch_bounds__(kQhdFB) void qhdFace2TileKernel(const MeshView m, const QhdView q) {
+    constexpr int FB = kQhdFB;
+    extern __shared__ v2d qhdLds[];
+    const int tile = xcdTile((int)gridDim.x, m.xcdRun * (QGD_BLOCK / FB));
+    const int tid = (int)threadIdx.x;
+    const int f = tile * FB + tid;
+    const bool active = f < m.nIF;
+    const int cOff = m.tileOff[2 * tile], vOff = m.tileOff[2 * tile + 1];
+    const int nUc = m.tileOff[2 * tile + 2] - cOff, nUv = m.tileOff[2 * tile + 3] - vOff;
+    if (nUc == 0) return;
+    v2d* const s4 = qhdLds;                                       // 2 nUc pieces: cell {U,T}
+    double* const sG = reinterpret_cast<double*>(s4 + 2 * nUc);   // 9 nUc: fvc::grad(U)
+    double* const sC = sG + 9 * nUc;                              // 3 nUc: cell centres
+    double* const sp = sC + 3 * nUc;                              // nUc: p
+    double* const sX = sp + nUc;                                  // 3 nUv: vertex coordinates
+    double* const sq = sX + 3 * nUv;                              // nUv: vertex p
+    const int fl = active ? f : m.nIF - 1;
+    const unsigned lc = ldStream(m.locC + fl);
+    const uint2 lv = m.locV[fl];
+    const int kind = m.fkind[fl];
+    const size_t nF = (size_t)m.nF;
+    const size_t pos = (size_t)ldStream(m.fpos + fl);
+    const double w = ldStream(m.w + fl), dn = ldStream(m.dn + fl), magS = ldStream(m.magSf + fl);
+    const double S[3] = {ldStream(m.Sx + fl), ldStream(m.Sy + fl), ldStream(m.Sz + fl)};
+    const double tau = ldStream(q.tauF + fl), phi = q.phi[fl], phitr = q.phitr[fl];
+    const double ugu[3] = {q.ugu[fl], q.ugu[nF + fl], q.ugu[2 * nF + fl]};
+    TileStager<v2d, 3, 2, FB> g4;
+    TileStager<double, 10, 9, FB> gG;
+    TileStager<double, 4, 3, FB> gC;
+    TileStager<double, 2, 1, FB> gp, gq;
+    TileStager<double, 5, 3, FB> gX;
+    g4.load(reinterpret_cast<const v2d*>(q.c4), m.tileCells + cOff, nUc, tid);
+    gG.load(q.gUc, m.tileCells + cOff, nUc, tid);
+    gC.load(m.Cc, m.tileCells + cOff, nUc, tid);
+    gp.load(q.p, m.tileCells + cOff, nUc, tid);
+    gX.load(m.X, m.tileVerts + vOff, nUv, tid);
+    gq.load(q.ptp, m.tileVerts + vOff, nUv, tid);
+    __builtin_amdgcn_sched_barrier(0);
+    g4.store(s4, nUc, tid); gG.store(sG, nUc, tid); gC.store(sC, nUc, tid); gp.store(sp, nUc, tid); gX.store(sX, nUv, tid); gq.store(sq, nUv, tid);
+    __syncthreads();
+    if (!active) return;
+    const int lo = (int)(lc & 0xffffu), ln = (int)(lc >> 16);
+    const int v0 = (int)(lv.x & 0xffffu), v1 = (int)(lv.x >> 16), v2 = (int)(lv.y & 0xffffu), v3 = (int)(lv.y >> 16);
+    auto l3 = [](const double* p, int i) { return make_double4(p[3 * i], p[3 * i + 1], p[3 * i + 2], 0.0); };
+    auto l4 = [](const v2d* p, int i, double* o) { const v2d a = p[2 * i], b = p[2 * i + 1]; o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y; };
+    if (kind == 3) { for (int k = 0; k < 4; ++k) q.F[(size_t)k * nF + pos] = 0.0; return; }
+    double o4[4], n4[4];
+    l4(s4, lo, o4); l4(s4, ln, n4);
+    const double Uo[3] = {o4[0], o4[1], o4[2]}, Un[3] = {n4[0], n4[1], n4[2]}, To = o4[3], Tn = n4[3];
+    FaceVals<1> vp;
+    vp.o[0] = sp[lo]; vp.n[0] = sp[ln]; vp.sn[0] = 0.0;
+    double snU[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) snU[k] = dn * (Un[k] - Uo[k]);   // fvc::snGrad, uncorrected (L0)
+    const double snT = dn * (Tn - To);
+    const double pf = lerpf(w, vp.o[0], vp.n[0]);
+    double gUT[9];   // T(grad U) at the face: gUT[3i+j] = lin(gradU)[3j+i]
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) gUT[3 * i + j] = lerpf(w, sG[9 * lo + 3 * j + i], sG[9 * ln + 3 * j + i]);
+    double gP[3];
+    if (kind == 2) faceGradient<ST_GVP3, 1, -1>(m, f, vp, q.p, q.ptp, gP);
+    else gvp3GradCore<1, -1>(kind, true, l3(sC, lo), l3(sC, ln), l3(sX, v0), l3(sX, v1), l3(sX, v2), l3(sX, v3), vp.o, vp.n, sq + v0, sq + v1, sq + v2,
+                             sq + v3, gP);                                                       // QHDUEqn.H L36
+    double Uf[3], Wf[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        Uf[k] = lerpf(w, Uo[k], Un[k]);
+        const double Bf = lerpf(w, (q.beta * To) * q.g[k], (q.beta * Tn) * q.g[k]);   // BdFrcf [updateFields.H L66-67], as in face pass 1
+        Wf[k] = tau * ((ugu[k] + gP[k] / q.rho0) - Bf);   // L37
+    }
+    const double Tf = lerpf(w, To, Tn);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const double uw = S[0] * (Uf[0] * Wf[j]) + S[1] * (Uf[1] * Wf[j]) + S[2] * (Uf[2] * Wf[j]);   // Sf & (Uf*Wf), L39
+        const double phiUf = phi * Uf[j] - uw;                                                       // L41-43
+        const double lap = q.nu * snU[j] * magS;                                                     // fvc::laplacian(muf/rhof, U), L74
+        const double ext = S[0] * gUT[0 * 3 + j] + S[1] * gUT[1 * 3 + j] + S[2] * gUT[2 * 3 + j];    // Sf & lin(T(grad U)), L56 / L76
+        q.F[(size_t)j * nF + pos] = (q.implicit ? phiUf - q.nu * ext : (phiUf - lap) - q.nu * ext) + (S[j] * pf) / q.rho0;
+    }
+    q.F[3 * nF + pos] = q.implicit ? phi * Tf - phitr : (phi * Tf - q.Hi * snT * magS) - phitr;   // QHDTEqn.H L65-66, L73-76, L85-88
 }
 
 // explicit Euler of the U and T equations [QHDUEqn.H L68-84, QHDTEqn.H L83-91]
@@ -485,10 +672,27 @@ __global__ __launch_bounds__(QGD_BLOCK) void qhdExtractKernel(const int64_t n, c
 
 inline int gridOf(int64_t n) { return (int)((n + QGD_BLOCK - 1) / QGD_BLOCK); }
 
+// 3-D GaussVolPoint with face tiles of 128 (MeshView::qhdTiles): the staged kernels take the internal faces, the generic ones the
+// tiles beyond the caps and the boundary faces
+inline bool staged(int st, const MeshView& m) { return st == ST_GVP3 && m.qhdTiles != 0 && m.tileOff != nullptr && m.fblock == kQhdFB; }
 template <int ST>
-void face1(hipStream_t s, const MeshView& m, const QhdView& q, const PatchBCDev* bc) { qhdFace1Kernel<ST><<<gridOf(m.nF), QGD_BLOCK, 0, s>>>(m, q, bc); }
+void face1(hipStream_t s, const MeshView& m, const QhdView& q, const PatchBCDev* bc) {
+    if (staged(ST, m)) {
+        const size_t lds = ((size_t)m.tileMaxC * 56 + (size_t)m.tileMaxV * 56 + 255) / 256 * 256;
+        qhdFace1TileKernel<<<(m.nIF + kQhdFB - 1) / kQhdFB, kQhdFB, lds, s>>>(m, q);
+        if (m.nTileSpill > 0) qhdFace1Kernel<ST><<<m.nTileSpill, 128, 0, s>>>(m, q, bc, m.tileSpill, 0);
+        if (m.nBF > 0) qhdFace1Kernel<ST><<<gridOf(m.nBF), QGD_BLOCK, 0, s>>>(m, q, bc, nullptr, m.nIF);
+    } else qhdFace1Kernel<ST><<<gridOf(m.nF), QGD_BLOCK, 0, s>>>(m, q, bc, nullptr, 0);
+}
 template <int ST>
-void face2(hipStream_t s, const MeshView& m, const QhdView& q, const PatchBCDev* bc) { qhdFace2Kernel<ST><<<gridOf(m.nF), QGD_BLOCK, 0, s>>>(m, q, bc); }
+void face2(hipStream_t s, const MeshView& m, const QhdView& q, const PatchBCDev* bc) {
+    if (staged(ST, m)) {
+        const size_t lds = ((size_t)m.tileMaxC * 136 + (size_t)m.tileMaxV * 32 + 255) / 256 * 256;
+        qhdFace2TileKernel<<<(m.nIF + kQhdFB - 1) / kQhdFB, kQhdFB, lds, s>>>(m, q);
+        if (m.nTileSpill > 0) qhdFace2Kernel<ST><<<m.nTileSpill, 128, 0, s>>>(m, q, bc, m.tileSpill, 0);
+        if (m.nBF > 0) qhdFace2Kernel<ST><<<gridOf(m.nBF), QGD_BLOCK, 0, s>>>(m, q, bc, nullptr, m.nIF);
+    } else qhdFace2Kernel<ST><<<gridOf(m.nF), QGD_BLOCK, 0, s>>>(m, q, bc, nullptr, 0);
+}
 
 }  // namespace
 

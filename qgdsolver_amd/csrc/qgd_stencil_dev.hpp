@@ -113,6 +113,61 @@ __device__ __forceinline__ void gvpTriCoef(const double4 O, const double4 N, con
     }
 }
 
+// The quadrilateral / triangle forms of the GaussVolPoint face gradient from values already in registers (the generic walk below
+// and the LDS-staged QHD kernels share it): o / psiN the owner and neighbour (boundary: mirror-point) values, q0..q3 the vertex
+// values, geometry as in gvpQuadCoef / gvpTriCoef.  kind 0: quadrilateral, otherwise triangle (x3 / q3 unused).
+template <int NC, int UOFF>
+__device__ __forceinline__ void gvp3GradCore(const int kind, const bool internal, const double4 cO, const double4 cN, const double4 x0,
+                                             const double4 x1, const double4 x2, const double4 x3, const double* __restrict__ o,
+                                             const double* __restrict__ psiN, const double* __restrict__ q0, const double* __restrict__ q1,
+                                             const double* __restrict__ q2, const double* __restrict__ q3, double* __restrict__ g) {
+    double rV;
+    if (kind == 0) {  // quad: a2=-a0, a3=-a1, a4(nei)=-a5(own) [3D.C L361-363]
+        double a[9];
+        gvpQuadCoef(cO, cN, x0, x1, x2, x3, a, rV);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const double a0 = a[3 * d], a1 = a[3 * d + 1], a5 = a[3 * d + 2];
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                double s = psiN[k] * (-a5);
+                s += o[k] * a5;
+                s += q0[k] * a0;
+                s += q1[k] * a1;
+                s += q2[k] * (-a0);
+                s += q3[k] * (-a1);
+                g[d * NC + k] = s * rV;
+            }
+        }
+    } else {  // triangle: slots a0,a1,a2 vertices, a3 neighbour, owner = -a3 [3D.C L193-229]
+        double t[12];
+        gvpTriCoef(cO, cN, x0, x1, x2, t, rV);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const double a0 = t[4 * d], a1 = t[4 * d + 1], a2 = t[4 * d + 2], a3 = t[4 * d + 3];
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                double s = psiN[k] * a3;
+                s += o[k] * (-a3);
+                s += q0[k] * a0;
+                s += q1[k] * a1;
+                s += q2[k] * a2;
+                g[d * NC + k] = s * rV;
+            }
+        }
+        if (UOFF >= 0 && internal) {
+            // interior triangles, vector field: every row i holds d_j U_j [3D.C L844-854]
+            double dg[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) dg[j] = g[j * NC + UOFF + j];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) g[i * NC + UOFF + j] = dg[j];
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // fvsc face gradient of an NC-component field: g[i*NC + k] = d_i phi_k.
 // cellF / ptF are AoS with stride NC (cell and vertex values).
@@ -162,61 +217,15 @@ __device__ __forceinline__ void faceGradient(const MeshView& m, const int f, con
         }
         const double4 cO = ld3(m.Cc, m.own[f]);
         const double4 cN = internal ? ld3(m.Cc, m.nei[f]) : m.bN[b];
-        double rV;
-        if (kind == 0) {  // quad: a2=-a0, a3=-a1, a4(nei)=-a5(own) [3D.C L361-363]
-            double a[9];
-            gvpQuadCoef(cO, cN, ld3(m.X, vt.x), ld3(m.X, vt.y), ld3(m.X, vt.z), ld3(m.X, vt.w), a, rV);
-            const double* p0 = ptF + (size_t)vt.x * NC;
-            const double* p1 = ptF + (size_t)vt.y * NC;
-            const double* p2 = ptF + (size_t)vt.z * NC;
-            const double* p3 = ptF + (size_t)vt.w * NC;
-            double q0[NC], q1[NC], q2[NC], q3[NC];
+        const int v3 = kind == 0 ? vt.w : vt.z;   // (a triangle has no fourth vertex: its slot is not read)
+        const double* p0 = ptF + (size_t)vt.x * NC;
+        const double* p1 = ptF + (size_t)vt.y * NC;
+        const double* p2 = ptF + (size_t)vt.z * NC;
+        const double* p3 = ptF + (size_t)v3 * NC;
+        double q0[NC], q1[NC], q2[NC], q3[NC];
 #pragma unroll
-            for (int k = 0; k < NC; ++k) { q0[k] = p0[k]; q1[k] = p1[k]; q2[k] = p2[k]; q3[k] = p3[k]; }
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                const double a0 = a[3 * d], a1 = a[3 * d + 1], a5 = a[3 * d + 2];
-#pragma unroll
-                for (int k = 0; k < NC; ++k) {
-                    double s = psiN[k] * (-a5);
-                    s += v.o[k] * a5;
-                    s += q0[k] * a0;
-                    s += q1[k] * a1;
-                    s += q2[k] * (-a0);
-                    s += q3[k] * (-a1);
-                    g[d * NC + k] = s * rV;
-                }
-            }
-        } else {  // triangle: slots a0,a1,a2 vertices, a3 neighbour, owner = -a3 [3D.C L193-229]
-            double t[12];
-            gvpTriCoef(cO, cN, ld3(m.X, vt.x), ld3(m.X, vt.y), ld3(m.X, vt.z), t, rV);
-            const double* p0 = ptF + (size_t)vt.x * NC;
-            const double* p1 = ptF + (size_t)vt.y * NC;
-            const double* p2 = ptF + (size_t)vt.z * NC;
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                const double a0 = t[4 * d], a1 = t[4 * d + 1], a2 = t[4 * d + 2], a3 = t[4 * d + 3];
-#pragma unroll
-                for (int k = 0; k < NC; ++k) {
-                    double s = psiN[k] * a3;
-                    s += v.o[k] * (-a3);
-                    s += p0[k] * a0;
-                    s += p1[k] * a1;
-                    s += p2[k] * a2;
-                    g[d * NC + k] = s * rV;
-                }
-            }
-            if (UOFF >= 0 && internal) {
-                // interior triangles, vector field: every row i holds d_j U_j [3D.C L844-854]
-                double dg[3];
-#pragma unroll
-                for (int j = 0; j < 3; ++j) dg[j] = g[j * NC + UOFF + j];
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) g[i * NC + UOFF + j] = dg[j];
-            }
-        }
+        for (int k = 0; k < NC; ++k) { q0[k] = p0[k]; q1[k] = p1[k]; q2[k] = p2[k]; q3[k] = p3[k]; }
+        gvp3GradCore<NC, UOFF>(kind, internal, cO, cN, ld3(m.X, vt.x), ld3(m.X, vt.y), ld3(m.X, vt.z), ld3(m.X, v3), v.o, psiN, q0, q1, q2, q3, g);
         return;
     }
     if constexpr (ST == ST_GVP2) {
