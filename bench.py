@@ -461,12 +461,14 @@ def native_transport_line(args, world, t_budget_s):
 #       per cell {U,T} 32 + p 8 + grad(U) 72, per vertex p 8                                                    = 3 x 216 + 120 = 768
 #   cell update: 24 + 3 x 32 + V 8 + 32 read + 32 written                                                       = 192
 # and per iteration of the pressure solve [QHDpEqn.H L35-47] (multigrid-preconditioned CG; single-precision cycle):
-#   level 0 of the V-cycle: 4 full sweeps x (6 x (4 + 4) + 16) = 256, the first sweep from zero 12, the smoothed prolongator and its
-#   transpose (4.3 entries per fine row each, x 8, + 8 and 4 for the vectors) 82;  level 1 (1/8 of the rows, 34.5 entries per row):
-#   4 x (34.5 x 8 + 16) / 8 = 146;  the levels below ~10                                                       = 506
-#   CG: A d 6 x 12 + 24 = 96, x and r updates 40, two dot products 32, new direction 24, precision conversions 24 = 216
+#   level 0 of the V-cycle: 4 full sweeps x (6 x (4 + 4) + 16) = 256 (the last one reads r and writes z in double: + 12), the first
+#   sweep from zero 12 (written by the CG's axpy kernel since round 4), the smoothed prolongator and its transpose (4.3 entries per
+#   fine row each, x 8, + 8 and 4 for the vectors) 82;  level 1 (1/8 of the rows, 34.5 entries per row):
+#   4 x (34.5 x 8 + 16) / 8 = 146;  the levels below ~10                                                       = 518
+#   CG: A d 6 x 12 + 24 = 96, x and r updates 40 (|r| summed on the way; r.z is summed by the cycle's last sweep), new direction 24 = 160
+#   (round 3, separate passes: + two dot products 32 and the precision conversions 24 - 12 = 722 in all)
 QHD_EXPLICIT_BYTES_PER_CELL = 164 + 640 + 200 + 116 + 768 + 192
-QHD_BYTES_PER_CELL_PER_ITERATION = 506 + 216
+QHD_BYTES_PER_CELL_PER_ITERATION = 518 + 160
 
 
 def qhd_line(args):
