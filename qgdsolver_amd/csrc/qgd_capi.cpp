@@ -628,7 +628,7 @@ int qgd_device_create(qgd_mesh_t mh, int deviceId, qgd_device_t* out) {
             const char* e = std::getenv("QGD_FTILE");
             FaceTiles t;
             if (!e || std::atoi(e) != 0) t = buildFaceTiles(s, v.fblock);
-            const int64_t lds = ((int64_t)t.maxCells * (QGD_F_DMA ? 112 : 104) + (int64_t)t.maxVerts * (QGD_F_DMA ? 80 : 72) + 255) / 256 * 256;
+            const int64_t lds = ((int64_t)t.maxCells * 104 + (int64_t)t.maxVerts * 72 + 255) / 256 * 256;
             // a numbering under which a quarter of the tiles do not fit (reverse Cuthill-McKee levels, scrambled labels) is
             // better off with the gather kernel alone: 2.68 instead of 2.97 ms on the 16 M-cell irregular mesh in RCM order
             const int64_t nTiles = t.fb ? (s.nIF + t.fb - 1) / t.fb : 0;

@@ -8,9 +8,6 @@
 namespace qgd {
 
 // ---- gathered records (AoS, 16-B aligned so they move as dwordx4) ----------
-#ifndef QGD_F_DMA
-#define QGD_F_DMA 0   // compile-time experiment: the staged face kernel fills its LDS tile by global_load_lds (qgd_kernels.hip)
-#endif
 struct alignas(16) RecA { double rho, ux, uy, uz, p, e; };   // 48 B: fields whose face gradients are needed
 struct alignas(16) RecB { double H, c, muQGD, aOc; };        // 32 B: derived per-cell quantities the face kernel interpolates
 

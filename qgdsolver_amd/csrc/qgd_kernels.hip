@@ -567,15 +567,8 @@ void faceFluxGvp3TileKernel(const MeshView m, const CaseView c, const GasModel g
     v2d* const sA = tileLds;               // 3 nUc pieces: cell RecA
     v2d* const sB = sA + 3 * nUc;          // 2 nUc: cell RecB
     v2d* const sP = sB + 2 * nUc;          // 3 nUv: vertex RecA
-#if QGD_F_DMA
-    // QGD_F_DMA (compile-time experiment): the pieces go from global memory straight into LDS (global_load_lds), no staging registers,
-    // no ds_write.  The 24-B geometry records travel as two 12-B pieces, each of which lands in a 16-B slot (lds_dma_probe.hip)
-    v2d* const sC = sP + 3 * nUv;          // 2 nUc slots: cell centres
-    v2d* const sX = sC + 2 * nUc;          // 2 nUv slots: vertex coordinates
-#else
     double* const sC = reinterpret_cast<double*>(sP + 3 * nUv);   // 3 nUc: cell centres
     double* const sX = sC + 3 * nUc;           // 3 nUv: vertex coordinates
-#endif
     // (0) labels of this thread's pieces; the face's own streamed data
     const int fl = active ? f : m.nIF - 1;
     const unsigned lc = ldStream(m.locC + fl);
@@ -588,52 +581,6 @@ void faceFluxGvp3TileKernel(const MeshView m, const CaseView c, const GasModel g
     if (!SGEO || kind != 0) { S[0] = ldStream(m.Sx + fl); S[1] = ldStream(m.Sy + fl); S[2] = ldStream(m.Sz + fl); }
     double msO = 1.0, dnO = 0.0;
     if (m.hasOther) { msO = m.magSf[fl]; dnO = m.dn[fl]; }
-#if QGD_F_DMA
-    {
-        typedef __attribute__((address_space(3))) void* ldsPtr;
-        typedef const __attribute__((address_space(1))) void* gblPtr;
-        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-        const char* const gA8 = reinterpret_cast<const char*>(c.A);
-        const char* const gB8 = reinterpret_cast<const char*>(c.B);
-        const char* const gP8 = reinterpret_cast<const char*>(c.P);
-        const char* const gC8 = reinterpret_cast<const char*>(m.Cc);
-        const char* const gX8 = reinterpret_cast<const char*>(m.X);
-        int cc[KC], cb[KB2], vv[KV], vx[KB2];
-#pragma unroll
-        for (int k = 0; k < KC; ++k) cc[k] = m.tileCells[cOff + min(((tid + k * FB) * 43691) >> 17, nUc - 1)];
-#pragma unroll
-        for (int k = 0; k < KB2; ++k) cb[k] = m.tileCells[cOff + min((tid + k * FB) >> 1, nUc - 1)];
-#pragma unroll
-        for (int k = 0; k < KV; ++k) vv[k] = m.tileVerts[vOff + min(((tid + k * FB) * 43691) >> 17, nUv - 1)];
-#pragma unroll
-        for (int k = 0; k < KB2; ++k) vx[k] = m.tileVerts[vOff + min((tid + k * FB) >> 1, nUv - 1)];
-#pragma unroll
-        for (int k = 0; k < KC; ++k) {
-            const int q = tid + k * FB, r = (q * 43691) >> 17;
-            if (q < 3 * nUc) __builtin_amdgcn_global_load_lds((gblPtr)(gA8 + (size_t)(cc[k] * 3 + (q - 3 * r)) * 16), (ldsPtr)(sA + k * FB + wv * 64), 16, 0, 0);
-        }
-#pragma unroll
-        for (int k = 0; k < KB2; ++k) {
-            const int q = tid + k * FB, id = cb[k] * 2 + (q & 1);
-            if (q < 2 * nUc) {
-                __builtin_amdgcn_global_load_lds((gblPtr)(gB8 + (size_t)id * 16), (ldsPtr)(sB + k * FB + wv * 64), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((gblPtr)(gC8 + (size_t)id * 12), (ldsPtr)(sC + k * FB + wv * 64), 12, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < KV; ++k) {
-            const int q = tid + k * FB, r = (q * 43691) >> 17;
-            if (q < 3 * nUv) __builtin_amdgcn_global_load_lds((gblPtr)(gP8 + (size_t)(vv[k] * 3 + (q - 3 * r)) * 16), (ldsPtr)(sP + k * FB + wv * 64), 16, 0, 0);
-        }
-#pragma unroll
-        for (int k = 0; k < KB2; ++k) {
-            const int q = tid + k * FB;
-            if (q < 2 * nUv) __builtin_amdgcn_global_load_lds((gblPtr)(gX8 + (size_t)(vx[k] * 2 + (q & 1)) * 12), (ldsPtr)(sX + k * FB + wv * 64), 12, 0, 0);
-        }
-        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's pieces have landed; the barrier makes that true of the other wave's
-        __syncthreads();
-    }
-#else
     int idC[KC], idB[KB2], idV[KV];
 #pragma unroll
     for (int k = 0; k < KC; ++k) {
@@ -695,21 +642,13 @@ void faceFluxGvp3TileKernel(const MeshView m, const CaseView c, const GasModel g
 #pragma unroll
     for (int k = 0; k < KV; ++k) { const int q = tid + k * FB; if (q < 3 * nUv) { sP[q] = dP[k]; sX[q] = dX[k]; } }
     __syncthreads();
-#endif
     // (2) every face picks its records out of LDS
     double cof = -1e300, tauMin = 1e300;
     if (active) {
         const int lo = (int)(lc & 0xffffu), ln = (int)(lc >> 16);
         const int v0 = (int)(lv.x & 0xffffu), v1 = (int)(lv.x >> 16), v2 = (int)(lv.y & 0xffffu), v3 = (int)(lv.y >> 16);
         // geometry first: once the Gauss coefficients are there its 36 registers are free for the field values
-#if QGD_F_DMA
-        auto l3 = [](const v2d* p, int i) {   // {x.lo x.hi y.lo -} {y.hi z.lo z.hi -}
-            const uint4 a = *reinterpret_cast<const uint4*>(p + 2 * i), b = *reinterpret_cast<const uint4*>(p + 2 * i + 1);
-            return make_double4(__hiloint2double((int)a.y, (int)a.x), __hiloint2double((int)b.x, (int)a.z), __hiloint2double((int)b.z, (int)b.y), 0.0);
-        };
-#else
         auto l3 = [](const double* p, int i) { return make_double4(p[3 * i], p[3 * i + 1], p[3 * i + 2], 0.0); };
-#endif
         double coef[12], rVc;
         {
             const double4 cO = l3(sC, lo), cN = l3(sC, ln);
