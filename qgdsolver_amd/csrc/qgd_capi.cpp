@@ -636,6 +636,26 @@ int qgd_device_create(qgd_mesh_t mh, int deviceId, qgd_device_t* out) {
                 v.tileLds = (int32_t)lds;
                 v.tileMaxC = t.maxCells; v.tileMaxV = t.maxVerts;
                 v.qhdTiles = envChoice("QGD_QHD_TILES", 1, kOnOff, 2);
+                if (v.sGeo && envChoice("QGD_FTILE_FIXED", 1, kOnOff, 2) != 0 &&
+                    (int64_t)nTiles * std::max(t.maxCells, t.maxVerts) < (int64_t)INT32_MAX) {
+                    // the lists once more at a fixed stride (built and uploaded one after the other: the host peak stays at one table)
+                    std::vector<uint8_t> flag((size_t)nTiles, 0);
+                    for (int32_t tile : t.spill) flag[tile] = 1;
+                    auto padded = [&](const std::vector<int32_t>& list, int which, int32_t stride) {
+                        std::vector<int32_t> out((size_t)nTiles * stride, 0);
+#pragma omp parallel for schedule(static)
+                        for (int64_t tile = 0; tile < nTiles; ++tile) {
+                            const int32_t b = t.off[2 * tile + which], e = t.off[2 * (tile + 1) + which];
+                            if (e == b) continue;
+                            int32_t* o = out.data() + (size_t)tile * stride;
+                            for (int32_t i = 0; i < stride; ++i) o[i] = list[b + std::min(i, e - b - 1)];
+                        }
+                        return out;
+                    };
+                    { auto pc = padded(t.cells, 0, t.maxCells); v.tileCellsFix = up(pc); }
+                    { auto pv = padded(t.verts, 1, t.maxVerts); v.tileVertsFix = up(pv); }
+                    v.tileFlag = up(flag);
+                }
                 v.nTileSpill = (int32_t)t.spill.size(); v.tileSpill = up(t.spill);
                 v.tileOff = up(t.off); v.tileCells = up(t.cells); v.tileVerts = up(t.verts);
                 v.locC = up(t.locC); v.locV = reinterpret_cast<const uint2*>(up(t.locV));

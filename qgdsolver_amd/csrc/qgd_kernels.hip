@@ -545,25 +545,45 @@ typedef double v2d __attribute__((ext_vector_type(2)));   // one 16-B piece
 #ifndef QGD_F_BUF
 #define QGD_F_BUF 0
 #endif
+#ifndef QGD_F_PRIO
+#define QGD_F_PRIO 1
+#endif
 #ifndef QGD_FT_WAVES_MIN
 #define QGD_FT_WAVES_MIN 2
 #endif
 #ifndef QGD_FT_WAVES_MAX
 #define QGD_FT_WAVES_MAX 3
 #endif
-template <int FB, int WAVES, bool SGEO = false>
+// FIXED: the tile lists at a fixed stride (MeshView::tileCellsFix / tileVertsFix: every tile's list padded to the longest one by
+// repeating its last label, tileFlag = 1 for the tiles left to the gather kernel).  A tile's life is a chain of dependent memory
+// round trips -- list offsets -> labels -> pieces -> LDS -> algebra -- and with 6 workgroups per CU in flight the kernel's rate is
+// tiles in flight / length of that chain, not bytes (29 % fewer L2 misses under a pencil order: -1.6 % time,
+// profiles/r04_ab_pencil_xcd_matched.txt).  With computed offsets the chain is one round trip shorter.
+template <int FB, int WAVES, bool SGEO = false, bool FIXED = false>
 __global__ __launch_bounds__(FB) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
 void faceFluxGvp3TileKernel(const MeshView m, const CaseView c, const GasModel gm, const int adjustDt) {
     extern __shared__ v2d tileLds[];
+#if QGD_F_PRIO
+    __builtin_amdgcn_s_setprio(3);   // the address arithmetic in front of the loads ahead of the other waves' flux algebra
+#endif
     constexpr int KC = 4, KB2 = 3, KV = 5;   // piece loads per thread: ceil(3 capC / FB), ceil(2 capC / FB), ceil(3 capV / FB) (faceTileCap*)
     static_assert(3 * (FB + FB / 16) <= KC * FB && 2 * (FB + FB / 16) <= KB2 * FB && 3 * (((FB * 23) / 16 + 7) / 8 * 8) <= KV * FB, "caps");
     const int tile = xcdTile((int)gridDim.x, m.xcdRun * (QGD_BLOCK / FB));
     const int tid = (int)threadIdx.x;
     const int f = tile * FB + tid;
     const bool active = f < m.nIF;
-    const int cOff = m.tileOff[2 * tile], vOff = m.tileOff[2 * tile + 1];
-    const int nUc = m.tileOff[2 * tile + 2] - cOff, nUv = m.tileOff[2 * tile + 3] - vOff;
-    if (nUc == 0) return;   // more distinct records than the piece loads below cover: in m.tileSpill, done by the gather kernel
+    int cOff, vOff, nUc, nUv, spill = 0;
+    const int32_t* __restrict__ tCells = m.tileCells;
+    const int32_t* __restrict__ tVerts = m.tileVerts;
+    if (FIXED) {
+        nUc = m.tileMaxC; nUv = m.tileMaxV; cOff = tile * nUc; vOff = tile * nUv;
+        tCells = m.tileCellsFix; tVerts = m.tileVertsFix;
+        spill = m.tileFlag[tile];          // (arrives with the labels: no round trip of its own)
+    } else {
+        cOff = m.tileOff[2 * tile]; vOff = m.tileOff[2 * tile + 1];
+        nUc = m.tileOff[2 * tile + 2] - cOff; nUv = m.tileOff[2 * tile + 3] - vOff;
+        if (nUc == 0) return;   // more distinct records than the piece loads below cover: in m.tileSpill, done by the gather kernel
+    }
     v2d* const sA = tileLds;               // 3 nUc pieces: cell RecA
     v2d* const sB = sA + 3 * nUc;          // 2 nUc: cell RecB
     v2d* const sP = sB + 2 * nUc;          // 3 nUv: vertex RecA
@@ -578,24 +598,24 @@ void faceFluxGvp3TileKernel(const MeshView m, const CaseView c, const GasModel g
     const double w = ldStream(m.w + fl);
     const double hf = ldStream(m.hf + fl);
     double S[3] = {0.0, 0.0, 0.0};
-    if (!SGEO || kind != 0) { S[0] = ldStream(m.Sx + fl); S[1] = ldStream(m.Sy + fl); S[2] = ldStream(m.Sz + fl); }
-    double msO = 1.0, dnO = 0.0;
-    if (m.hasOther) { msO = m.magSf[fl]; dnO = m.dn[fl]; }
+    if (!SGEO) { S[0] = ldStream(m.Sx + fl); S[1] = ldStream(m.Sy + fl); S[2] = ldStream(m.Sz + fl); }
+    // (what depends on the face's kind is loaded BELOW, after the piece loads have gone out: a branch on a loaded value here makes
+    // the label loads wait for a whole memory round trip)
     int idC[KC], idB[KB2], idV[KV];
 #pragma unroll
     for (int k = 0; k < KC; ++k) {
         const int q = tid + k * FB, r = (q * 43691) >> 17;   // q / 3 for q < 98304
-        idC[k] = m.tileCells[cOff + min(r, nUc - 1)] * 3 + (q - 3 * r);
+        idC[k] = tCells[cOff + min(r, nUc - 1)] * 3 + (q - 3 * r);
     }
 #pragma unroll
     for (int k = 0; k < KB2; ++k) {
         const int q = tid + k * FB, r = q >> 1;
-        idB[k] = m.tileCells[cOff + min(r, nUc - 1)] * 2 + (q & 1);
+        idB[k] = tCells[cOff + min(r, nUc - 1)] * 2 + (q & 1);
     }
 #pragma unroll
     for (int k = 0; k < KV; ++k) {
         const int q = tid + k * FB, r = (q * 43691) >> 17;
-        idV[k] = m.tileVerts[vOff + min(r, nUv - 1)] * 3 + (q - 3 * r);
+        idV[k] = tVerts[vOff + min(r, nUv - 1)] * 3 + (q - 3 * r);
     }
     // (1) the distinct records of the tile, piece by piece (pieces past the end repeat the last record and are dropped)
     const v2d* __restrict__ gA = reinterpret_cast<const v2d*>(c.A);
@@ -634,7 +654,14 @@ void faceFluxGvp3TileKernel(const MeshView m, const CaseView c, const GasModel g
 #pragma unroll
     for (int k = 0; k < KV; ++k) { dP[k] = gP[idV[k]]; dX[k] = m.X[idV[k]]; }
 #endif
+#if QGD_F_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    double msO = 1.0, dnO = 0.0;
+    if (SGEO && kind != 0) { S[0] = ldStream(m.Sx + fl); S[1] = ldStream(m.Sy + fl); S[2] = ldStream(m.Sz + fl); }
+    if (m.hasOther) { msO = m.magSf[fl]; dnO = m.dn[fl]; }
     __builtin_amdgcn_sched_barrier(0);
+    if (FIXED && spill) return;   // in m.tileSpill, done by the gather kernel (the piece loads above went to record 0: harmless)
 #pragma unroll
     for (int k = 0; k < KC; ++k) { const int q = tid + k * FB; if (q < 3 * nUc) { sA[q] = dA[k]; sC[q] = dC[k]; } }
 #pragma unroll
@@ -1446,6 +1473,7 @@ static void launchFaceFluxT(const Launcher& L, int stencil, const MeshView& m, c
                 else if (m.fblock == 256) faceFluxGvp3TileKernel<256, 3><<<grid, QGD_BLOCK, m.tileLds, L.stream>>>(m, c, g, adj);
                 else if (m.tileWaves == 2) faceFluxGvp3TileKernel<128, 2><<<(m.nIF + 127) / 128, 128, m.tileLds, L.stream>>>(m, c, g, adj);
                 else if (m.tileWaves == 4) faceFluxGvp3TileKernel<128, 4><<<(m.nIF + 127) / 128, 128, m.tileLds, L.stream>>>(m, c, g, adj);
+                else if (m.sGeo && m.tileFlag) faceFluxGvp3TileKernel<128, 3, true, true><<<(m.nIF + 127) / 128, 128, m.tileLds, L.stream>>>(m, c, g, adj);
                 else if (m.sGeo) faceFluxGvp3TileKernel<128, 3, true><<<(m.nIF + 127) / 128, 128, m.tileLds, L.stream>>>(m, c, g, adj);
                 else faceFluxGvp3TileKernel<128, 3><<<(m.nIF + 127) / 128, 128, m.tileLds, L.stream>>>(m, c, g, adj);
                 if (m.nTileSpill > 0) {
