@@ -387,6 +387,14 @@ __device__ __forceinline__ void gvp3Coefs(const int kind, const double4& cO, con
     }
 }
 
+// QGD_F_PRIO: wave priority inside the staged face kernel.  Its rate is tiles in flight / length of a tile's chain of dependent round
+// trips (profiles/r04_ab_face_latency_chain.txt), and the instructions between those round trips -- address arithmetic, LDS stores, the
+// barrier -- compete for issue with the flux algebra of the other waves of the SIMD: 0 never raised, 1 raised until the piece loads are
+// out, 2 until the tile is in LDS (default: F 6.75 / 6.63 / 6.50 ms for 0 / 1 / 2; kept up until the records are in registers -- with the
+// Gauss coefficients' arithmetic inside the window -- 7.0-7.3 ms).
+#ifndef QGD_F_PRIO
+#define QGD_F_PRIO 2
+#endif
 // everything after the loads of one internal face: gradient coefficients from the geometry, the 6-component gradient, the 13
 // interpolations, the flux algebra, the five net fluxes (slot-major position fp), the face's share of the Courant number
 template <bool DBG>
@@ -545,9 +553,6 @@ typedef double v2d __attribute__((ext_vector_type(2)));   // one 16-B piece
 #ifndef QGD_F_BUF
 #define QGD_F_BUF 0
 #endif
-#ifndef QGD_F_PRIO
-#define QGD_F_PRIO 1
-#endif
 #ifndef QGD_FT_WAVES_MIN
 #define QGD_FT_WAVES_MIN 2
 #endif
@@ -654,7 +659,7 @@ void faceFluxGvp3TileKernel(const MeshView m, const CaseView c, const GasModel g
 #pragma unroll
     for (int k = 0; k < KV; ++k) { dP[k] = gP[idV[k]]; dX[k] = m.X[idV[k]]; }
 #endif
-#if QGD_F_PRIO
+#if QGD_F_PRIO == 1
     __builtin_amdgcn_s_setprio(0);
 #endif
     double msO = 1.0, dnO = 0.0;
@@ -669,6 +674,9 @@ void faceFluxGvp3TileKernel(const MeshView m, const CaseView c, const GasModel g
 #pragma unroll
     for (int k = 0; k < KV; ++k) { const int q = tid + k * FB; if (q < 3 * nUv) { sP[q] = dP[k]; sX[q] = dX[k]; } }
     __syncthreads();
+#if QGD_F_PRIO == 2
+    __builtin_amdgcn_s_setprio(0);
+#endif
     // (2) every face picks its records out of LDS
     double cof = -1e300, tauMin = 1e300;
     if (active) {
