@@ -84,6 +84,21 @@ def test_staged_kernel_is_bit_identical_to_gather_kernel(fb):
                 assert np.array_equal(a[k], b[k]), (tag, fb, opt, k, np.abs(a[k] - b[k]).max())
 
 
+def test_offset_table_and_fixed_stride_lists_agree():
+    """The staged kernel reads its tile lists from the fixed-stride copy by default (offsets computed: one dependent round trip less per
+    tile); QGD_FTILE_FIXED=0 keeps the offset table.  Both against the gather kernel, bit for bit, on every mesh of this module."""
+    for tag, mesh in meshes():
+        h = 1.0 / 20
+        for opt in (dict(deltaT=0.05 * h), dict(deltaT=0.05 * h, adjustTimeStep=1, maxCo=0.2)):
+            a = run(mesh, 5, {"QGD_FTILE": "0"}, **opt)
+            a.pop("tiles")
+            for fixed in ("0", "1"):
+                b = run(mesh, 5, {"QGD_FTILE": "1", "QGD_FTILE_FIXED": fixed}, **opt)
+                b.pop("tiles")
+                for k in a:
+                    assert np.array_equal(a[k], b[k]), (tag, fixed, opt, k, np.abs(a[k] - b[k]).max())
+
+
 def test_staged_kernel_on_a_shard():
     mesh = q.PolyMesh.box(24, 12, 12)
     shard = mesh.shard(2, 1)
