@@ -80,21 +80,26 @@ __global__ __launch_bounds__(QGD_BLOCK) void implFaceKernel(const MeshView m, co
     // what the cell kernels and the matrix products gather (phiTauMC, the laplacian coefficients, phiSigmaDotU) sits at the face's
     // slot-major POSITION like the net fluxes (MeshView::fpos, cfPos): consecutive cells find it at consecutive addresses, by label
     // they would touch every third double of the lines they fetch
+    // (labels, kind and weight go out together and the owner's records right behind them: a branch on the loaded kind in front of
+    // them would cost every face one more memory round trip)
     const size_t pos = f < m.nIF ? (size_t)m.fpos[f] : (size_t)f;
-    if (m.fkind[f] == 3) {
+    const int kind = m.fkind[f];
+    const int o = m.own[f];
+    const int nLab = f < m.nIF ? m.nei[f] : o;
+    const double wLin = f < m.nIF ? m.w[f] : 1.0;
+    const RecA Ao = c.A[o];
+    const RecB Bo = c.B[o];
+    if (kind == 3) {
         for (int k = 0; k < 3; ++k) { iv.phiTau[(size_t)k * nF + pos] = 0.0; iv.UfS[(size_t)k * nF + f] = 0.0; }
         iv.sTau[f] = iv.mufS[f] = iv.aU[pos] = iv.aE[pos] = 0.0;
         return;
     }
-    const int o = m.own[f];
-    const RecA Ao = c.A[o];
-    const RecB Bo = c.B[o];
     double muf, alf, Uf[3], tau[9];
     if (f < m.nIF) {
-        const int n = m.nei[f];
+        const int n = nLab;
         const RecA An = c.A[n];
         const RecB Bn = c.B[n];
-        const double w = m.w[f];
+        const double w = wLin;
         muf = lerpf(w, muEffOf(gm, Bo.muQGD), muEffOf(gm, Bn.muQGD));
         alf = lerpf(w, alphaEffOf(gm, Bo.muQGD), alphaEffOf(gm, Bn.muQGD));
         Uf[0] = lerpf(w, Ao.ux, An.ux); Uf[1] = lerpf(w, Ao.uy, An.uy); Uf[2] = lerpf(w, Ao.uz, An.uz);
