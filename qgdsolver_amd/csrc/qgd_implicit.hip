@@ -275,12 +275,15 @@ __global__ __launch_bounds__(QGD_BLOCK) void implSigmaKernel(const MeshView m, c
     const int f = xcdTile((int)gridDim.x, m.xcdRun) * QGD_BLOCK + threadIdx.x;   // runs of consecutive blocks per XCD: neighbours meet in one L2
     if (f >= m.nF) return;
     const size_t nF = (size_t)m.nF, pos = f < m.nIF ? (size_t)m.fpos[f] : (size_t)f;   // phiSigmaDotU at the face's position (see implFaceKernel)
-    if (m.fkind[f] == 3) { iv.phiSig[pos] = 0.0; return; }
+    const int kind = m.fkind[f];          // (loaded together with the labels: no branch on it in front of them, see implFaceKernel)
     const int o = m.own[f];
+    const int nLab = f < m.nIF ? m.nei[f] : o;
+    const double wLin = f < m.nIF ? m.w[f] : 1.0;
+    if (kind == 3) { iv.phiSig[pos] = 0.0; return; }
     double g[9];
     if (f < m.nIF) {
-        const int n = m.nei[f];
-        const double w = m.w[f];
+        const int n = nLab;
+        const double w = wLin;
         for (int k = 0; k < 9; ++k) g[k] = lerpf(w, iv.gUc[(size_t)o * 9 + k], iv.gUc[(size_t)n * 9 + k]);
     } else {
         const int b = f - m.nIF;
