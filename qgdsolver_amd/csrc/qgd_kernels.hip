@@ -553,9 +553,6 @@ typedef double v2d __attribute__((ext_vector_type(2)));   // one 16-B piece
 #ifndef QGD_F_BUF
 #define QGD_F_BUF 0
 #endif
-#ifndef QGD_F_LABELS_FIRST
-#define QGD_F_LABELS_FIRST 0   // 1: the tile's label loads go out before the face's own stream (the pieces wait for the labels only)
-#endif
 #ifndef QGD_FT_WAVES_MIN
 #define QGD_FT_WAVES_MIN 2
 #endif
@@ -597,7 +594,6 @@ void faceFluxGvp3TileKernel(const MeshView m, const CaseView c, const GasModel g
     v2d* const sP = sB + 2 * nUc;          // 3 nUv: vertex RecA
     double* const sC = reinterpret_cast<double*>(sP + 3 * nUv);   // 3 nUc: cell centres
     double* const sX = sC + 3 * nUc;           // 3 nUv: vertex coordinates
-#if !QGD_F_LABELS_FIRST
     // (0) labels of this thread's pieces; the face's own streamed data
     const int fl = active ? f : m.nIF - 1;
     const unsigned lc = ldStream(m.locC + fl);
@@ -608,7 +604,6 @@ void faceFluxGvp3TileKernel(const MeshView m, const CaseView c, const GasModel g
     const double hf = ldStream(m.hf + fl);
     double S[3] = {0.0, 0.0, 0.0};
     if (!SGEO) { S[0] = ldStream(m.Sx + fl); S[1] = ldStream(m.Sy + fl); S[2] = ldStream(m.Sz + fl); }
-#endif
     // (what depends on the face's kind is loaded BELOW, after the piece loads have gone out: a branch on a loaded value here makes
     // the label loads wait for a whole memory round trip)
     int idC[KC], idB[KB2], idV[KV];
@@ -627,18 +622,6 @@ void faceFluxGvp3TileKernel(const MeshView m, const CaseView c, const GasModel g
         const int q = tid + k * FB, r = (q * 43691) >> 17;
         idV[k] = tVerts[vOff + min(r, nUv - 1)] * 3 + (q - 3 * r);
     }
-#if QGD_F_LABELS_FIRST == 1
-    // (0) labels of this thread's pieces; the face's own streamed data
-    const int fl = active ? f : m.nIF - 1;
-    const unsigned lc = ldStream(m.locC + fl);
-    const uint2 lv = m.locV[fl];
-    const int fp = ldStream(m.fpos + fl);
-    const int kind = m.fkind[fl];
-    const double w = ldStream(m.w + fl);
-    const double hf = ldStream(m.hf + fl);
-    double S[3] = {0.0, 0.0, 0.0};
-    if (!SGEO) { S[0] = ldStream(m.Sx + fl); S[1] = ldStream(m.Sy + fl); S[2] = ldStream(m.Sz + fl); }
-#endif
     // (1) the distinct records of the tile, piece by piece (pieces past the end repeat the last record and are dropped)
     const v2d* __restrict__ gA = reinterpret_cast<const v2d*>(c.A);
     const v2d* __restrict__ gB = reinterpret_cast<const v2d*>(c.B);
@@ -675,18 +658,6 @@ void faceFluxGvp3TileKernel(const MeshView m, const CaseView c, const GasModel g
     for (int k = 0; k < KB2; ++k) dB[k] = gB[idB[k]];
 #pragma unroll
     for (int k = 0; k < KV; ++k) { dP[k] = gP[idV[k]]; dX[k] = m.X[idV[k]]; }
-#endif
-#if QGD_F_LABELS_FIRST == 2
-    // (0) labels of this thread's pieces; the face's own streamed data
-    const int fl = active ? f : m.nIF - 1;
-    const unsigned lc = ldStream(m.locC + fl);
-    const uint2 lv = m.locV[fl];
-    const int fp = ldStream(m.fpos + fl);
-    const int kind = m.fkind[fl];
-    const double w = ldStream(m.w + fl);
-    const double hf = ldStream(m.hf + fl);
-    double S[3] = {0.0, 0.0, 0.0};
-    if (!SGEO) { S[0] = ldStream(m.Sx + fl); S[1] = ldStream(m.Sy + fl); S[2] = ldStream(m.Sz + fl); }
 #endif
 #if QGD_F_PRIO == 1
     __builtin_amdgcn_s_setprio(0);
