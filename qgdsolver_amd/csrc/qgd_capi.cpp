@@ -256,6 +256,8 @@ struct qgd_case_s {
     ImplView impl{};            // implicitDiffusion branch: its face / cell work arrays
     ImplicitSolver* implSolver = nullptr;   // the two linear solves of the branch (device-scalar multi-right-hand-side PCG)
     int implSolveIndex = 0;                 // 0: the U solve is the one in flight, 1: the e solve
+    bool reuseGradU = true;                 // QGD_IMPL_REUSE_GRADU (default 1)
+    bool gradUValid = false;                // implicit branch, unsharded: fvc::grad(U) of phase 29 is still that of the records (phase 20 of the next step skips it)
     std::vector<double*> implSendBuf, implRecvBuf;   // native transport of the branch's own halo messages
     std::vector<double*> midSendBuf, midRecvBuf;     // the mid-assembly message (midExchangeOn)
     double* coef[4] = {nullptr, nullptr, nullptr, nullptr};  // device copies of non-uniform alphaQGD / ScQGD (cells, patch faces)
@@ -1363,6 +1365,7 @@ int qgd_case_create(qgd_device_t d, const qgd_case_options* opt, qgd_case_t* out
             iv.xU = a.alloc<double>(3 * nC); iv.diagU = a.alloc<double>(3 * nC); iv.rhsU = a.alloc<double>(3 * nC);
             iv.xE = a.alloc<double>(nC); iv.diagE = a.alloc<double>(nC); iv.rhsE = a.alloc<double>(nC);
             c->implSolver = implicitSolverCreate(d->stream, v, d->ownedBegin, d->ownedEnd);
+            { static const int kOnOff[] = {0, 1}; c->reuseGradU = envChoice("QGD_IMPL_REUSE_GRADU", 1, kOnOff, 2) != 0; }
         }
         c->bc.resize(d->patches.size());
         for (size_t i = 0; i < d->patches.size(); ++i) {
@@ -1409,6 +1412,7 @@ int qgd_case_set_bc(qgd_case_t c, int32_t patch, int32_t bcU, const double* valu
     b.bcU = bcU; b.bcT = bcT; b.bcP = bcP; b.vT = valueT; b.vP = valueP;
     if (valueU) for (int k = 0; k < 3; ++k) b.vU[k] = valueU[k];
     c->fieldsSet = false;
+    c->gradUValid = false;
     return QGD_OK;
     QGD_CATCH
 }
@@ -1431,6 +1435,7 @@ int qgd_case_set_qgd_coeffs(qgd_case_t c, const double* alphaQGD, const double* 
     c->view.sc = put(ScQGD, (size_t)m.nC, c->coef[2]);
     c->view.scb = put(ScQGD ? ScQGDb : nullptr, (size_t)m.nBF, c->coef[3]);
     c->fieldsSet = false;
+    c->gradUValid = false;
     return QGD_OK;
     QGD_CATCH
 }
@@ -1490,6 +1495,7 @@ int qgd_case_set_fields(qgd_case_t c, const double* U, const double* T, const do
     cleanup();
     c->phiwRegistered = true;  // createFaceFluxes.H registers "phiwStar" before the loop starts
     c->fieldsSet = true;
+    c->gradUValid = false;
     c->time = 0; c->steps = 0;
     if (c->implSolver) { implicitSolverSetStream(c->implSolver, c->stream()); implicitStatsReset(c->implSolver); HIP_CHECK(hipStreamSynchronize(c->stream())); }
     return QGD_OK;
@@ -1547,7 +1553,10 @@ static void implicitPhase(qgd_case_s* c, int phase) {
             c->steps++;
             if (!adjust) c->time += c->opt.deltaT;
             implicitStepMark(S, true);
-            launchImplicitPart(st, m, c->view, c->impl, c->gas, c->bcDev, S, tol, maxIter, 0);
+            // fvc::grad(U) of the state before the step IS the gradient phase 29 of the step before formed from the new velocity and its
+            // patch values: nothing has touched either since (unsharded; any field, BC or coefficient upload resets the flag)
+            if (!(c->reuseGradU && c->gradUValid && !d->sharded())) launchImplicitPart(st, m, c->view, c->impl, c->gas, c->bcDev, S, tol, maxIter, 0);
+            c->gradUValid = false;
             break;
         }
         case 21: c->implSolveIndex = 0; launchImplicitPart(st, m, c->view, c->impl, c->gas, c->bcDev, S, tol, maxIter, 1); break;
@@ -1556,7 +1565,7 @@ static void implicitPhase(qgd_case_s* c, int phase) {
             implicitSolveEnd(S, 0);
             launchImplicitPart(st, m, c->view, c->impl, c->gas, c->bcDev, S, tol, maxIter, 2);
             break;
-        case 29: launchImplicitPart(st, m, c->view, c->impl, c->gas, c->bcDev, S, tol, maxIter, 3); break;
+        case 29: launchImplicitPart(st, m, c->view, c->impl, c->gas, c->bcDev, S, tol, maxIter, 3); c->gradUValid = true; break;
         case 30: c->implSolveIndex = 1; launchImplicitPart(st, m, c->view, c->impl, c->gas, c->bcDev, S, tol, maxIter, 4); break;
         case 35:
             implicitSolveEnd(S, 1);

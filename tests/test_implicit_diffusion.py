@@ -120,6 +120,48 @@ def test_device_implicit_branch_matches_oracle(kind, stencil, bc_fn):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind,stencil,bc_fn", GPU_CASES)
+def test_gradient_of_the_new_velocity_is_reused_by_the_next_step(kind, stencil, bc_fn, monkeypatch):
+    """fvc::grad(U) is formed twice per step in the listing (QGDUEqn.H: of the state before the step for tauMC, of the new velocity for
+    sigmaDotU).  Unsharded, the first of step n+1 IS the second of step n -- same cell values, same patch values -- and is skipped
+    (QGD_IMPL_REUSE_GRADU, default 1).  Bit for bit the same states as with both gradients formed, on every mesh / patch kind of this module,
+    also across a re-upload of the fields in mid-run (which invalidates the stored gradient)."""
+    mesh = make_mesh(kind)
+    C = mesh.array("C").reshape(-1, 3)
+    if kind == "step2d":
+        U = np.zeros((mesh.nCells, 3)); U[:, 0] = 3.0
+        fields = (U, 1.0 + 0.05 * np.sin(2.0 * C[:, 0]) * np.cos(3.0 * C[:, 1]), 1.0 + 0.05 * np.cos(1.5 * C[:, 0] + C[:, 1]))
+    else:
+        fields = cases.box_initial_fields(C)
+        if mesh.nGeometricD == 2:
+            fields[0][:, 2] = 0.0
+    opt = dict(stencil=stencil, deltaT=5e-4, mu=2e-2, implicitDiffusion=1, implicitTol=1e-12, implicitMaxIter=2000)
+
+    def empty_patches(case):
+        for ip, t in enumerate(mesh.array("patchType")):
+            if t == E:
+                case.set_bc(ip, U=("none", None), T=("none", None), p=("none", None))
+
+    setup = bc_fn if bc_fn else empty_patches
+    dev = q.Device(mesh)
+    res = {}
+    for reuse in ("0", "1"):
+        monkeypatch.setenv("QGD_IMPL_REUSE_GRADU", reuse)
+        gc = q.QGDFoamCase(dev, q.default_options(**opt))
+        setup(gc)
+        gc.set_fields(*fields)
+        gc.step(5)
+        U5, T5, p5 = gc.field("U").copy(), gc.field("T").copy(), gc.field("p").copy()
+        gc.set_fields(U5 * 1.01, T5, p5)       # a fresh state: the stored gradient must not survive it
+        gc.step(4)
+        res[reuse] = {f: gc.field(f).copy() for f in ("rho", "U", "p", "e")}
+        gc.close()
+    for f in res["0"]:
+        assert np.isfinite(res["0"][f]).all() and np.array_equal(res["0"][f], res["1"][f]), (kind, stencil, f, np.abs(res["0"][f] - res["1"][f]).max())
+    dev.close()
+
+
+@pytest.mark.gpu
 def test_step_phases_of_the_implicit_branch():
     """phases 0 + 1 are qgd_case_step; the split advance (10 / 11) does not exist for the implicit branch -- it used to run
     the whole advance twice -- and is refused"""
