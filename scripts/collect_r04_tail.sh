@@ -14,3 +14,6 @@ OUT=/tmp/prof_r04_tail
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_implicit" -- python3 "$REPO/bench.py" --workload implicit --steps 20 --warmup 5 > "$KEEP/r04_implicit_n200_bench_under_rocprof.log" 2>&1
 cp $(find "$OUT/stats_implicit" -name "*kernel_stats.csv" | head -1) "$KEEP/r04_implicit_n200_kernel_stats.csv"
 ls -la "$KEEP"
+cd "$REPO"
+python3 bench.py > "$KEEP/r04_bench_default.json" 2> "$KEEP/bench_default.err"
+ls -la "$KEEP"
