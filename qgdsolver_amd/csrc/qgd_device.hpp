@@ -55,7 +55,7 @@ struct MeshView {
     const int32_t* tileSpill; int32_t nTileSpill;   // tiles left to the gather kernel
     int32_t tileLds;         // dynamic LDS bytes of the largest tile
     int32_t tileMaxC, tileMaxV;   // distinct cells / vertices of the largest staged tile
-    // QGD_FTILE_FIXED (default 1; 128-face tiles, 3 waves per SIMD, Sf from the vertices): the same lists at a fixed stride of tileMaxC /
+    // QGD_FTILE_FIXED (default 1; 128-face tiles, 3 waves per SIMD): the same lists at a fixed stride of tileMaxC /
     // tileMaxV labels per tile (padded with the tile's last label; all zero for the tiles of tileSpill, which carry tileFlag = 1)
     const int32_t* tileCellsFix; const int32_t* tileVertsFix; const uint8_t* tileFlag;
     int32_t qhdTiles;        // QGD_QHD_TILES (default 1): QHD's two face passes use the tiles too (qgd_qhd.hip qhdFace{1,2}TileKernel)

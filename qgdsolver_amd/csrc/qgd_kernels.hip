@@ -1482,6 +1482,7 @@ static void launchFaceFluxT(const Launcher& L, int stencil, const MeshView& m, c
                 else if (m.tileWaves == 2) faceFluxGvp3TileKernel<128, 2><<<(m.nIF + 127) / 128, 128, m.tileLds, L.stream>>>(m, c, g, adj);
                 else if (m.tileWaves == 4) faceFluxGvp3TileKernel<128, 4><<<(m.nIF + 127) / 128, 128, m.tileLds, L.stream>>>(m, c, g, adj);
                 else if (m.sGeo && m.tileFlag) faceFluxGvp3TileKernel<128, 3, true, true><<<(m.nIF + 127) / 128, 128, m.tileLds, L.stream>>>(m, c, g, adj);
+                else if (m.tileFlag) faceFluxGvp3TileKernel<128, 3, false, true><<<(m.nIF + 127) / 128, 128, m.tileLds, L.stream>>>(m, c, g, adj);
                 else if (m.sGeo) faceFluxGvp3TileKernel<128, 3, true><<<(m.nIF + 127) / 128, 128, m.tileLds, L.stream>>>(m, c, g, adj);
                 else faceFluxGvp3TileKernel<128, 3><<<(m.nIF + 127) / 128, 128, m.tileLds, L.stream>>>(m, c, g, adj);
                 if (m.nTileSpill > 0) {

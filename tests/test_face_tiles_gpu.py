@@ -90,13 +90,14 @@ def test_offset_table_and_fixed_stride_lists_agree():
     for tag, mesh in meshes():
         h = 1.0 / 20
         for opt in (dict(deltaT=0.05 * h), dict(deltaT=0.05 * h, adjustTimeStep=1, maxCo=0.2)):
-            a = run(mesh, 5, {"QGD_FTILE": "0"}, **opt)
-            a.pop("tiles")
-            for fixed in ("0", "1"):
-                b = run(mesh, 5, {"QGD_FTILE": "1", "QGD_FTILE_FIXED": fixed}, **opt)
-                b.pop("tiles")
-                for k in a:
-                    assert np.array_equal(a[k], b[k]), (tag, fixed, opt, k, np.abs(a[k] - b[k]).max())
+            for sgeo in ("1", "0"):     # Sf of quadrilaterals rebuilt from the staged vertices / streamed (as with the caller's own geometry)
+                a = run(mesh, 5, {"QGD_FTILE": "0", "QGD_SGEO": sgeo}, **opt)
+                a.pop("tiles")
+                for fixed in ("0", "1"):
+                    b = run(mesh, 5, {"QGD_FTILE": "1", "QGD_FTILE_FIXED": fixed, "QGD_SGEO": sgeo}, **opt)
+                    b.pop("tiles")
+                    for k in a:
+                        assert np.array_equal(a[k], b[k]), (tag, sgeo, fixed, opt, k, np.abs(a[k] - b[k]).max())
 
 
 def test_staged_kernel_on_a_shard():
