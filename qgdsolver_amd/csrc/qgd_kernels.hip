@@ -395,6 +395,9 @@ __device__ __forceinline__ void gvp3Coefs(const int kind, const double4& cO, con
 #ifndef QGD_F_PRIO
 #define QGD_F_PRIO 2
 #endif
+#ifndef QGD_P_PRIO
+#define QGD_P_PRIO 1   // the same in the vertex kernel, until its gathers are out: P 2.53 -> 2.48 ms (nothing in the cell kernel: not kept there)
+#endif
 // everything after the loads of one internal face: gradient coefficients from the geometry, the 6-component gradient, the 13
 // interpolations, the flux algebra, the five net fluxes (slot-major position fp), the face's share of the Courant number
 template <bool DBG>
@@ -838,6 +841,9 @@ __global__ __launch_bounds__(QGD_BLOCK) void pointInterpKernel(const MeshView m,
 template <int PB>
 __global__ __launch_bounds__(PB) __attribute__((amdgpu_waves_per_eu(QGD_P_WAVES_MIN, QGD_P_WAVES_MAX)))
 void pointInterpRecKernel(const MeshView m, const RecA* __restrict__ A, RecA* __restrict__ P) {
+#if QGD_P_PRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
     const int p = xcdTile((int)gridDim.x, m.xcdRun * (QGD_BLOCK / PB)) * PB + threadIdx.x;
     if (p >= m.nP) return;
     const int n = m.pcCount[p];
@@ -855,6 +861,9 @@ void pointInterpRecKernel(const MeshView m, const RecA* __restrict__ A, RecA* __
         for (int q = 0; q < 8; ++q) { id[q] = m.pcCell[base + (size_t)q * 64]; w[q] = m.pcW[base + (size_t)q * 64]; }
 #pragma unroll
         for (int q = 0; q < 8; ++q) r[q] = A[id[q]];
+#if QGD_P_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
