@@ -638,6 +638,7 @@ int qgd_device_create(qgd_mesh_t mh, int deviceId, qgd_device_t* out) {
                 v.tileLds = (int32_t)lds;
                 v.tileMaxC = t.maxCells; v.tileMaxV = t.maxVerts;
                 v.qhdTiles = envChoice("QGD_QHD_TILES", 1, kOnOff, 2);
+                v.implTiles = envChoice("QGD_IMPL_TILES", 1, kOnOff, 2);
                 if (v.fblock == 128 && v.tileWaves == 3 && envChoice("QGD_FTILE_FIXED", 1, kOnOff, 2) != 0 &&
                     (int64_t)nTiles * std::max(t.maxCells, t.maxVerts) < (int64_t)INT32_MAX) {
                     // the lists once more at a fixed stride (built and uploaded one after the other: the host peak stays at one table)

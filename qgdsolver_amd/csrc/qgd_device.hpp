@@ -59,6 +59,7 @@ struct MeshView {
     // tileMaxV labels per tile (padded with the tile's last label; all zero for the tiles of tileSpill, which carry tileFlag = 1)
     const int32_t* tileCellsFix; const int32_t* tileVertsFix; const uint8_t* tileFlag;
     int32_t qhdTiles;        // QGD_QHD_TILES (default 1): QHD's two face passes use the tiles too (qgd_qhd.hip qhdFace{1,2}TileKernel)
+    int32_t implTiles;       // QGD_IMPL_TILES (default 1): so does the face kernel of QGDFoam's implicit branch (qgd_implicit.hip implFaceTileKernel)
     int32_t tileWaves;       // waves per SIMD the staged kernel is compiled for (2, 3 or 4)
     int32_t sGeo;            // 1: the 3-D GaussVolPoint kernels rebuild Sf of quadrilateral faces from the vertices (no Sf stream)
     const double* V; const double* hQGD; const uint8_t* ghost;

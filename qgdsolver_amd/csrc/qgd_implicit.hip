@@ -72,10 +72,12 @@ __global__ __launch_bounds__(QGD_BLOCK) void implCellGradKernel(const MeshView m
 }
 
 // per face: muf, alphauf, Uf, tauMC -> phiTauMC, Sf.(tauMC & Uf), the laplacian coefficients [updateFluxes.H L107-111]
+// (tileList != nullptr: 128 threads per workgroup, the 128-face tiles the staged kernel below leaves to this one; else the faces from fBegin on)
 __global__ __launch_bounds__(QGD_BLOCK) void implFaceKernel(const MeshView m, const CaseView c, const ImplView iv, const GasModel gm,
-                                                           const PatchBCDev* __restrict__ bcs) {
-    const int f = xcdTile((int)gridDim.x, m.xcdRun) * QGD_BLOCK + threadIdx.x;   // runs of consecutive blocks per XCD: neighbours meet in one L2
-    if (f >= m.nF) return;
+                                                           const PatchBCDev* __restrict__ bcs, const int32_t* __restrict__ tileList, const int fBegin) {
+    const int f = tileList ? tileList[blockIdx.x] * 128 + (int)threadIdx.x
+                           : fBegin + xcdTile((int)gridDim.x, m.xcdRun) * QGD_BLOCK + (int)threadIdx.x;   // runs of consecutive blocks per XCD: neighbours meet in one L2
+    if (f >= (tileList ? m.nIF : m.nF)) return;
     const size_t nF = (size_t)m.nF;
     // what the cell kernels and the matrix products gather (phiTauMC, the laplacian coefficients, phiSigmaDotU) sits at the face's
     // slot-major POSITION like the net fluxes (MeshView::fpos, cfPos): consecutive cells find it at consecutive addresses, by label
@@ -131,6 +133,67 @@ __global__ __launch_bounds__(QGD_BLOCK) void implFaceKernel(const MeshView m, co
     iv.sTau[f] = S[0] * tU[0] + S[1] * tU[1] + S[2] * tU[2];
     iv.mufS[f] = muf;
     const double gsd = m.magSf[f] * m.dn[f];   // |Sf| * (nonOrthDeltaCoeffs inside, deltaCoeffs on patches)
+    iv.aU[pos] = muf * gsd;
+    iv.aE[pos] = alf * gsd;
+}
+
+// The same for the internal faces of a face tile (qgd_setup.hpp FaceTiles, 3-D meshes), its distinct cell records -- the velocity, muQGD and
+// the nine gradients that the generic walk gathers as eleven scattered pieces per cell and face -- staged through LDS once: the internal-face
+// branch of implFaceKernel, expression by expression.
+__global__ __launch_bounds__(128) void implFaceTileKernel(const MeshView m, const CaseView c, const ImplView iv, const GasModel gm) {
+    constexpr int FB = 128;
+    static_assert(2 * (FB + FB / 16) <= 3 * FB && (FB + FB / 16) <= 2 * FB && 9 * (FB + FB / 16) <= 10 * FB, "faceTileCapCells");
+    extern __shared__ v2dTile implLds[];
+    const int tile = xcdTile((int)gridDim.x, m.xcdRun * (QGD_BLOCK / FB));
+    const int tid = (int)threadIdx.x;
+    const int f = tile * FB + tid;
+    const bool active = f < m.nIF;
+    const int cOff = m.tileOff[2 * tile];
+    const int nUc = m.tileOff[2 * tile + 2] - cOff;
+    if (nUc == 0) return;   // beyond the caps: in m.tileSpill, done by the generic kernel
+    v2dTile* const sA = implLds;                                  // 2 nUc pieces: {rho, ux} {uy, uz} of the cell record
+    v2dTile* const sB = sA + 2 * nUc;                             // nUc: {muQGD, alphaQGD / c}
+    double* const sG = reinterpret_cast<double*>(sB + nUc);       // 9 nUc: fvc::grad(U)
+    const int fl = active ? f : m.nIF - 1;
+    const unsigned lc = ldStream(m.locC + fl);
+    const size_t nF = (size_t)m.nF, pos = (size_t)ldStream(m.fpos + fl);
+    const int kind = m.fkind[fl];
+    const double w = ldStream(m.w + fl);
+    const double S[3] = {ldStream(m.Sx + fl), ldStream(m.Sy + fl), ldStream(m.Sz + fl)};
+    const double gsd = ldStream(m.magSf + fl) * ldStream(m.dn + fl);   // |Sf| * nonOrthDeltaCoeffs
+    TileStager<v2dTile, 3, 2, FB, 3, 0> gA;
+    TileStager<v2dTile, 2, 1, FB, 2, 1> gB;
+    TileStager<double, 10, 9, FB> gG;
+    gA.load(reinterpret_cast<const v2dTile*>(c.A), m.tileCells + cOff, nUc, tid);
+    gB.load(reinterpret_cast<const v2dTile*>(c.B), m.tileCells + cOff, nUc, tid);
+    gG.load(iv.gUc, m.tileCells + cOff, nUc, tid);
+    __builtin_amdgcn_sched_barrier(0);
+    gA.store(sA, nUc, tid); gB.store(sB, nUc, tid); gG.store(sG, nUc, tid);
+    __syncthreads();
+    if (!active) return;
+    if (kind == 3) {
+        for (int k = 0; k < 3; ++k) { iv.phiTau[(size_t)k * nF + pos] = 0.0; iv.UfS[(size_t)k * nF + f] = 0.0; }
+        iv.sTau[f] = iv.mufS[f] = iv.aU[pos] = iv.aE[pos] = 0.0;
+        return;
+    }
+    const int lo = (int)(lc & 0xffffu), ln = (int)(lc >> 16);
+    const v2dTile a0 = sA[2 * lo], a1 = sA[2 * lo + 1], n0 = sA[2 * ln], n1 = sA[2 * ln + 1];
+    const double muQo = sB[lo].x, muQn = sB[ln].x;
+    const double muf = lerpf(w, muEffOf(gm, muQo), muEffOf(gm, muQn));
+    const double alf = lerpf(w, alphaEffOf(gm, muQo), alphaEffOf(gm, muQn));
+    const double Uf[3] = {lerpf(w, a0.y, n0.y), lerpf(w, a1.x, n1.x), lerpf(w, a1.y, n1.y)};
+    double to[9], tn[9], tau[9];
+    muDev2T(sG + 9 * lo, muEffOf(gm, muQo), to);
+    muDev2T(sG + 9 * ln, muEffOf(gm, muQn), tn);
+    for (int k = 0; k < 9; ++k) tau[k] = lerpf(w, to[k], tn[k]);
+    double tU[3];
+    for (int i = 0; i < 3; ++i) tU[i] = tau[3 * i] * Uf[0] + tau[3 * i + 1] * Uf[1] + tau[3 * i + 2] * Uf[2];   // tauMC & Uf
+    for (int j = 0; j < 3; ++j) {
+        iv.phiTau[(size_t)j * nF + pos] = S[0] * tau[j] + S[1] * tau[3 + j] + S[2] * tau[6 + j];                  // Sf & tauMC
+        iv.UfS[(size_t)j * nF + f] = Uf[j];
+    }
+    iv.sTau[f] = S[0] * tU[0] + S[1] * tU[1] + S[2] * tU[2];
+    iv.mufS[f] = muf;
     iv.aU[pos] = muf * gsd;
     iv.aE[pos] = alf * gsd;
 }
@@ -1207,7 +1270,13 @@ void launchImplicitPart(hipStream_t s, const MeshView& m, const CaseView& c, con
     switch (part) {
         case 0: implCellGradKernel<<<gc, QGD_BLOCK, 0, s>>>(m, c, iv); break;
         case 1: {
-            implFaceKernel<<<gf, QGD_BLOCK, 0, s>>>(m, c, iv, g, bc);
+            if (m.tileOff != nullptr && m.fblock == 128 && m.implTiles) {
+                // internal faces of the staged tiles out of LDS, the tiles beyond the caps and the boundary faces through the generic walk
+                const size_t lds = ((size_t)m.tileMaxC * 120 + 255) / 256 * 256;
+                implFaceTileKernel<<<(m.nIF + 127) / 128, 128, lds, s>>>(m, c, iv, g);
+                if (m.nTileSpill > 0) implFaceKernel<<<m.nTileSpill, 128, 0, s>>>(m, c, iv, g, bc, m.tileSpill, 0);
+                if (m.nBF > 0) implFaceKernel<<<gb, QGD_BLOCK, 0, s>>>(m, c, iv, g, bc, nullptr, m.nIF);
+            } else implFaceKernel<<<gf, QGD_BLOCK, 0, s>>>(m, c, iv, g, bc, nullptr, 0);
             implCellUKernel<<<gc, QGD_BLOCK, 0, s>>>(m, c, iv, bc);
             int mask = 0;
             for (int k = 0; k < 3; ++k) if (!(m.nGeomD < 3 && m.emptyDir[k])) mask |= 1 << k;   // validComponents (L0)

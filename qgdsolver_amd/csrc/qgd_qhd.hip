@@ -215,22 +215,6 @@ __global__ __launch_bounds__(QGD_BLOCK) void qhdFace2Kernel(const MeshView m, co
 // the tiles beyond the caps).
 // ---------------------------------------------------------------------------
 typedef double v2d __attribute__((ext_vector_type(2)));
-// K rounds of pieces of type PT (PPR pieces per record): lane q of round k takes piece tid + k * FB of the tile's list
-template <typename PT, int K, int PPR, int FB>
-struct TileStager {
-    PT d[K];
-    __device__ __forceinline__ void load(const PT* __restrict__ g, const int32_t* __restrict__ list, const int nU, const int tid) {
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const int q = tid + k * FB, r = q / PPR;
-            d[k] = g[(size_t)list[min(r, nU - 1)] * PPR + (q - r * PPR)];
-        }
-    }
-    __device__ __forceinline__ void store(PT* __restrict__ s, const int nU, const int tid) const {
-#pragma unroll
-        for (int k = 0; k < K; ++k) { const int q = tid + k * FB; if (q < nU * PPR) s[q] = d[k]; }
-    }
-};
 constexpr int kQhdFB = 128;
 static_assert(2 * (kQhdFB + kQhdFB / 16) <= 3 * kQhdFB && 3 * (kQhdFB + kQhdFB / 16) <= 4 * kQhdFB && 9 * (kQhdFB + kQhdFB / 16) <= 10 * kQhdFB &&
               2 * (((kQhdFB * 23) / 16 + 7) / 8 * 8) <= 3 * kQhdFB && 3 * (((kQhdFB * 23) / 16 + 7) / 8 * 8) <= 5 * kQhdFB, "faceTileCap*");

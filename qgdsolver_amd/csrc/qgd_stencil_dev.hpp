@@ -168,6 +168,26 @@ __device__ __forceinline__ void gvp3GradCore(const int kind, const bool internal
     }
 }
 
+// ---- staging the distinct records of a face tile through LDS (qgd_setup.hpp FaceTiles; QHD face passes, implicit face kernel) ----------
+typedef double v2dTile __attribute__((ext_vector_type(2)));
+// K rounds of pieces of type PT: lane q of round k takes piece tid + k * FB of the tile's list -- PPR consecutive pieces per record, taken
+// from a record of STRIDE pieces starting at piece OFFSET (the whole record by default)
+template <typename PT, int K, int PPR, int FB, int STRIDE = PPR, int OFFSET = 0>
+struct TileStager {
+    PT d[K];
+    __device__ __forceinline__ void load(const PT* __restrict__ g, const int32_t* __restrict__ list, const int nU, const int tid) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int q = tid + k * FB, r = q / PPR;
+            d[k] = g[(size_t)list[min(r, nU - 1)] * STRIDE + OFFSET + (q - r * PPR)];
+        }
+    }
+    __device__ __forceinline__ void store(PT* __restrict__ s, const int nU, const int tid) const {
+#pragma unroll
+        for (int k = 0; k < K; ++k) { const int q = tid + k * FB; if (q < nU * PPR) s[q] = d[k]; }
+    }
+};
+
 // ---------------------------------------------------------------------------
 // fvsc face gradient of an NC-component field: g[i*NC + k] = d_i phi_k.
 // cellF / ptF are AoS with stride NC (cell and vertex values).

@@ -162,6 +162,37 @@ def test_gradient_of_the_new_velocity_is_reused_by_the_next_step(kind, stencil, 
 
 
 @pytest.mark.gpu
+def test_staged_face_kernel_of_the_implicit_branch_is_the_generic_walk_bit_for_bit(monkeypatch):
+    """implFaceTileKernel (the internal faces of a 128-face tile: velocity, muQGD and fvc::grad(U) of its distinct cells out of LDS;
+    QGD_IMPL_TILES default 1) against the generic implFaceKernel (QGD_IMPL_TILES=0): the same states after 6 steps, bit for bit, on hexahedra
+    with a ragged last tile and row ends beyond the caps, on a jittered mesh with triangles and polygon faces and mixed patch kinds, and on a
+    scrambled numbering (most tiles left to the generic kernel)."""
+    from test_config5_gpu import c5_mesh
+    scr = q.PolyMesh.box(12, 10, 8)
+    scr.renumber(np.random.default_rng(5).permutation(scr.nCells).astype(np.int32))
+    for tag, mesh, bc_fn in (("hex 37x11x5", q.PolyMesh.box(37, 11, 5), None), ("box654_tri", make_mesh("box654_tri"), mixed_bcs),
+                             ("triangles + polygons, Morton order", c5_mesh(16, 8 ** 3, poly=True), None), ("scrambled labels", scr, None)):
+        fields = cases.box_initial_fields(mesh.array("C").reshape(-1, 3))
+        opt = dict(stencil="GaussVolPoint", deltaT=5e-4, mu=2e-2, implicitDiffusion=1, implicitTol=1e-12, implicitMaxIter=2000)
+        res = {}
+        for tiles in ("0", "1"):
+            monkeypatch.setenv("QGD_IMPL_TILES", tiles)
+            dev = q.Device(mesh)
+            ft = dev.face_tiles()
+            gc = q.QGDFoamCase(dev, q.default_options(**opt))
+            if bc_fn:
+                bc_fn(gc)
+            gc.set_fields(*fields)
+            gc.step(6)
+            res[tiles] = {f: gc.field(f).copy() for f in ("rho", "U", "p", "e")}
+            gc.close(); dev.close()
+        if not tag.startswith("scrambled"):
+            assert ft["facesPerTile"] == 128 and ft["gatherTiles"] < ft["tiles"], (tag, ft)
+        for f in res["0"]:
+            assert np.isfinite(res["0"][f]).all() and np.array_equal(res["0"][f], res["1"][f]), (tag, f, np.abs(res["0"][f] - res["1"][f]).max())
+
+
+@pytest.mark.gpu
 def test_step_phases_of_the_implicit_branch():
     """phases 0 + 1 are qgd_case_step; the split advance (10 / 11) does not exist for the implicit branch -- it used to run
     the whole advance twice -- and is refused"""
