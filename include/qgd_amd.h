@@ -105,7 +105,7 @@ typedef struct qgd_case_s* qgd_case_t;     /* a QGDFoam case on one device      
 
 /* ---- library ---------------------------------------------------------------- */
 /* Bumped whenever an options struct grows or an entry changes its meaning (3: round 3). */
-#define QGD_ABI_VERSION 4
+#define QGD_ABI_VERSION 5
 const char* qgd_version(void);
 /* sizes[0..2] = sizeof(qgd_case_options), sizeof(qgd_qhd_options), sizeof(qgd_poisson_control) as THIS library was built,
  * sizes[3] = its QGD_ABI_VERSION: a host compiled against another header compares before it passes a struct (the structs
@@ -274,6 +274,10 @@ int qgd_interpolate(qgd_device_t d, int32_t ncomp, const double* cell, const dou
 /* qgdFlux [QGDInterpolate_8H_source.html L76-118] without a divSchemes entry: out = flux*psif (flux nFaces, psif and out
  * nFaces*ncomp).  Pure host arithmetic (one multiply per value): kept so call sites read like the reference. */
 int qgd_flux(qgd_device_t d, int32_t ncomp, const double* flux, const double* psif, double* out);
+/* qgdFlux WITH a divSchemes entry `Gauss upwind` for the flux's name [QGDInterpolate_8H_source.html L86-104 -> fvc::flux]:
+ * out = flux * (pos0(flux)*(psi_O - psi_N) + psi_N) on internal faces, flux * patch value on patch faces (`Gauss linear` is qgd_flux
+ * on the linear psif: the same numbers).  flux nFaces, cell nCells*ncomp, bnd nBoundaryFaces*ncomp, out nFaces*ncomp, HOST pointers. */
+int qgd_flux_upwind(qgd_device_t d, int32_t ncomp, const double* flux, const double* cell, const double* bnd, double* out);
 /* Static QGD length scales of the mesh [QGDCoeffs_8C_source.html L298-376]: name = "hQGD" (nCells), "hQGDf" (nFaces),
  * "hQGD.boundary" (nBoundaryFaces).  The QHD tau closures (constTau, HbyUQHD, T0byGr, H2bynuQHD) are one line each on
  * top of these and qgd_interpolate; see qgdsolver_amd/qhdfoam.py. */
@@ -380,6 +384,13 @@ int qgd_qhd_pressure(qgd_device_t d, const double* phiu, const double* phiwo, co
  * QHDTEqn.H L65-91, the reference level of p (L123-130).  Thermo: rhoConst + constTransport (uniform rho0, mu, Pr; the QHD
  * closures leave muQGD = alphauQGD = 0 [T0byGr_8C_source.html L62-72]), laminar; L0 discretisation assumed: Gauss linear
  * gradients, Gauss linear uncorrected laplacians, Euler ddt.  Sharded meshes: see "the QHD case on a cell-range shard" below. */
+/* qgdFlux [QGDInterpolate_8H_source.html L76-105]: the flux's own divSchemes entry decides */
+enum qgd_flux_scheme {
+    QGD_FLUX_LINEAR = 0,   /* no entry (flux*psif) or `Gauss linear` (fvc::flux with linear weights: the same numbers) */
+    QGD_FLUX_UPWIND = 1    /* `Gauss upwind`: psi_f = pos0(flux)*(psi_O - psi_N) + psi_N (L0: upwind::weights = pos0(faceFlux),
+                              surfaceInterpolationScheme::interpolate), patch faces keep the patch value               */
+};
+
 typedef struct qgd_qhd_options {
     int32_t stencil;          /* QGD_FVSC_*                                                                    */
     int32_t implicitDiffusion;/* 0: fvc::laplacian in both equations; 1 (the reference's default, QGDThermo_8C_source.html L70-82):
@@ -395,6 +406,8 @@ typedef struct qgd_qhd_options {
     double pTol, pRelTol, pRefValue;
     double implicitTol;       /* implicitDiffusion: tolerance (OpenFOAM's normalised residual) of the U and T solves (1e-10) */
     int32_t implicitMaxIter;  /* ... and their iteration limit (1000)                                          */
+    int32_t fluxSchemeU;      /* QGD_FLUX_* of qgdFlux(phi,U,Uf) [QHDUEqn_8H_source.html L41], entry `div(phi,U)`          */
+    int32_t fluxSchemeT;      /* ... of qgdFlux(phi,T,Tf) [QHDTEqn_8H_source.html L65], entry `div(phi,T)`                 */
     int32_t pad_;
 } qgd_qhd_options;
 typedef struct qgd_qhd_case_s* qgd_qhd_case_t;
@@ -518,6 +531,11 @@ typedef struct qgd_case_options {
     double implicitTol;       /* implicitDiffusion: tolerance (OpenFOAM's normalised residual) of the U and e solves,
                                  fvSolution's `tolerance` of those fields                                         */
     int32_t implicitMaxIter;  /* ... and their iteration limit                                                    */
+    int32_t fluxSchemeU;      /* QGD_FLUX_*: what qgdFlux(phiJm,U,Uf) [QGDFoam_2updateFluxes_8H_source.html L78] does: LINEAR = flux*psif,
+                                 the default branch and `divSchemes{div(phiJm,U) Gauss linear;}` (same numbers); UPWIND =
+                                 `div(phiJm,U) Gauss upwind;` -> fvc::flux [QGDInterpolate_8H_source.html L86-104]: the upwind cell's
+                                 U on internal faces, the patch value on patch faces                                  */
+    int32_t fluxSchemeH;      /* the same for qgdFlux(phiJm,H,Hf) [updateFluxes.H L119], entry `div(phiJm,H)`          */
     int32_t pad_;
 } qgd_case_options;
 

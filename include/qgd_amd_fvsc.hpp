@@ -120,29 +120,44 @@ inline surfaceField div(fvMesh& mesh, const volField& vf) {
 }  // namespace fvsc
 
 // qgdInterpolate [QGDInterpolate.H L38-67]: linearInterpolate(psi) unless interpolationSchemes names a scheme for
-// "interpolate(<psi>)" or a default other than `none`; those branches hand the field to fvc::interpolate, i.e. to OpenFOAM's
-// own scheme library, which is not behind this boundary: here they are fatal, like a missing run-time table entry.
+// "interpolate(<psi>)" or a default other than `none`; those branches hand the field to fvc::interpolate.  With the word
+// `linear` (what nearly every fvSchemes file carries as its default) fvc::interpolate IS linearInterpolate -- the same weights,
+// the same numbers -- and takes the library path; any other scheme lives in OpenFOAM's scheme library, which is not behind
+// this boundary: fatal, like a missing run-time table entry.
 inline surfaceField qgdInterpolate(fvMesh& mesh, const volField& psi) {
     const auto& is = mesh.interpolationSchemes;
-    const bool own = is.count("interpolate(" + psi.name + ")") > 0;
+    const auto own = is.find("interpolate(" + psi.name + ")");
     const auto def = is.find("default");
-    if (own || (def != is.end() && def->second != "none"))
-        throw FatalError(QGD_ERR_NOT_IMPLEMENTED, "qgdInterpolate(" + psi.name + "): fvc::interpolate with a user scheme stays in OpenFOAM");
+    if (own != is.end()) {
+        if (own->second != "linear")
+            throw FatalError(QGD_ERR_NOT_IMPLEMENTED, "qgdInterpolate(" + psi.name + "): interpolationSchemes{interpolate(" + psi.name + ") " + own->second +
+                                                          ";} -- fvc::interpolate with a scheme other than linear stays in OpenFOAM");
+    } else if (def != is.end() && def->second != "none" && def->second != "linear") {
+        throw FatalError(QGD_ERR_NOT_IMPLEMENTED, "qgdInterpolate(" + psi.name + "): interpolationSchemes{default " + def->second +
+                                                      ";} -- fvc::interpolate with a scheme other than linear stays in OpenFOAM");
+    }
     surfaceField r;
     r.ncomp = psi.ncomp;
     r.values.resize((size_t)mesh.nFaces * psi.ncomp);
     check(qgd_interpolate(mesh.device, psi.ncomp, psi.internal.data(), psi.boundary.data(), r.values.data()), "qgdInterpolate");
     return r;
 }
-// qgdFlux [QGDInterpolate.H L76-118]: flux*psif unless divSchemes holds an entry for the flux name (then fvc::flux, OpenFOAM's)
+// qgdFlux [QGDInterpolate.H L76-118]: flux*psif unless divSchemes holds an entry for the flux name; then fvc::flux(flux, psi, name):
+// `Gauss linear` = flux * linear(psi), the same numbers; `Gauss upwind` = flux * the upwind cell's psi (qgd_flux_upwind); limited
+// schemes stay in OpenFOAM (fatal).  divSchemes.default is not consulted (`found(fluxName)`, L86).
 inline surfaceField qgdFlux(fvMesh& mesh, const surfaceField& flux, const volField& psi, const surfaceField& psif,
                             const std::string& fluxName) {
-    if (mesh.divSchemes.count(fluxName))
-        throw FatalError(QGD_ERR_NOT_IMPLEMENTED, "qgdFlux(" + fluxName + "): fvc::flux with a user scheme stays in OpenFOAM");
-    (void)psi;
     surfaceField r;
     r.ncomp = psif.ncomp;
     r.values.resize(psif.values.size());
+    const auto it = mesh.divSchemes.find(fluxName);
+    if (it != mesh.divSchemes.end() && it->second == "Gauss upwind") {
+        check(qgd_flux_upwind(mesh.device, psi.ncomp, flux.values.data(), psi.internal.data(), psi.boundary.data(), r.values.data()), "qgdFlux");
+        return r;
+    }
+    if (it != mesh.divSchemes.end() && it->second != "Gauss linear")
+        throw FatalError(QGD_ERR_NOT_IMPLEMENTED, "qgdFlux(" + fluxName + "): divSchemes{" + fluxName + " " + it->second +
+                                                      ";} -- fvc::flux with a scheme other than Gauss linear / Gauss upwind stays in OpenFOAM");
     check(qgd_flux(mesh.device, psif.ncomp, flux.values.data(), psif.values.data(), r.values.data()), "qgdFlux");
     return r;
 }

@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -45,7 +46,12 @@ inline void cross3(const double* a, const double* b, double* c) {
     c[2] = a[0] * b[1] - a[1] * b[0];
 }
 
-struct PatchInfo { int type, start, size; };
+struct PatchInfo {
+    int type, start, size;
+    // symmetryPlane: the one normal of the patch = average of its faces' unit normals (L0 assumption:
+    // symmetryPlanePolyPatch::calcGeometry, n_ = gAverage(faceNormals())); symmetryPlaneFvPatchField reflects about it on every face
+    double nHat[3] = {0, 0, 0};
+};
 
 // ---------------------------------------------------------------------------
 // Mesh + L0 geometry
@@ -69,6 +75,11 @@ struct Mesh {
     std::vector<ivec> bndPointFaces;  // per boundary point: boundary-face indices (ascending)
     std::vector<dvec> pointWeights;   // per point (non patch points)
     std::vector<dvec> bndPointWeights;// per boundary point
+    // point constraints of vector / tensor point fields (L0 assumption: pointConstraints::constrain at the end of
+    // volPointInterpolation::interpolateBoundaryField): per mesh point the ordered list of operations
+    struct PointOp { int kind; double T[9]; };   // 0: x = (x + transform(T, x))/2 (symmetry evaluate), 1: x = transform(T, x)
+    std::map<int, std::vector<PointOp>> pointOps;
+    void pointConstraintOps();
     // halo
     std::vector<ivec> haloGhost, haloSend;      // one entry per halo slot (neighbouring shard)
     std::vector<ivec> haloGhostBF, haloSendBF;  // boundary-face indices (global label - nIF)
@@ -81,6 +92,12 @@ struct Mesh {
     const int* fp(int f) const { return &fPts[fOff[f]]; }
     bool patchHasFields(int p) const { return patches[p].type != PATCH_EMPTY; }  // emptyFvPatch::size()==0
     bool coupled(int p) const { return patches[p].type == PATCH_CYCLIC || patches[p].type == PATCH_HALO; }
+    // the normal a reflecting patch field uses on face gf of patch p: patch().nf() (basicSymmetry: slip, symmetry) or the
+    // patch's own normal (symmetryPlane)
+    void symmNormal(int p, int gf, double n[3]) const {
+        if (patches[p].type == PATCH_SYMMETRYPLANE) { for (int k = 0; k < 3; ++k) n[k] = patches[p].nHat[k]; return; }
+        for (int k = 0; k < 3; ++k) n[k] = Sf[3 * (size_t)gf + k] / magSf[gf];
+    }
 
     void geometry();
     void derivedGeometry();
@@ -158,6 +175,12 @@ void Mesh::derivedGeometry() {
     // L0: surfaceInterpolation weights / deltaCoeffs / nonOrthDeltaCoeffs,
     // fvPatch::delta() patch-normal on non-coupled patches
     w.assign(nF, 1.0); delta.assign(nF, 0.0); nonOrthDelta.assign(nF, 0.0);
+    for (PatchInfo& pt : patches) {
+        if (pt.type != PATCH_SYMMETRYPLANE || pt.size <= 0) continue;
+        double sum[3] = {0, 0, 0};
+        for (int f = pt.start; f < pt.start + pt.size; ++f) for (int k = 0; k < 3; ++k) sum[k] += Sf[3 * (size_t)f + k] / magSf[f];
+        for (int k = 0; k < 3; ++k) pt.nHat[k] = sum[k] / (double)pt.size;
+    }
     for (int f = 0; f < nF; ++f) {
         const double* S = &Sf[3 * (size_t)f];
         const double* cf = &Cf[3 * (size_t)f];
@@ -270,6 +293,80 @@ void Mesh::pointInterpolationWeights() {
         }
         for (size_t j = 0; j < pw.size(); ++j) pw[j] /= sum;
     }
+    pointConstraintOps();
+}
+
+// L0 (OpenFOAM v2312, restated from knowledge -- none of it is in the reference tree):
+//  * pointPatchField::New gives the point field of a constraint patch the patch's own type; pointConstraints::constrain first calls
+//    correctBoundaryConditions(): symmetryPlanePointPatchField / symmetryPointPatchField::evaluate set, patch by patch in patch order,
+//    x = (x + transform(I - 2 nn, x))/2 at every point of the patch (n = symmetryPlanePolyPatch::n() | pointNormals()[point]),
+//    wedgePointPatchField x = transform(I - nn, x) with n = pointNormals()[0];
+//  * then constrainCorners(): the points on the rim of a patch (end points of patch edges with a single patch face) collect the
+//    constraint directions of the patches they rim (pointConstraint::applyConstraint) and get x = transform(constraintTransformation(), x):
+//    I - nn for one direction, the squared edge direction for two, 0 for three;
+//  * transform() is the identity on scalars.
+void Mesh::pointConstraintOps() {
+    pointOps.clear();
+    struct Corner { int first = 0; double second[3] = {0, 0, 0}; };
+    std::map<int, Corner> corners;
+    for (const PatchInfo& pt : patches) {
+        const bool plane = pt.type == PATCH_SYMMETRYPLANE, symm = pt.type == PATCH_SYMMETRY, wedge = pt.type == PATCH_WEDGE;
+        if (!(plane || symm || wedge) || pt.size <= 0) continue;
+        // PrimitivePatch addressing of this patch: meshPoints in order of appearance, pointFaces ascending, edge -> number of faces
+        ivec meshPoints;
+        std::map<int, int> localOf;
+        std::vector<ivec> pointFaces;
+        std::map<std::pair<int, int>, int> nEdgeFaces;
+        for (int f = pt.start; f < pt.start + pt.size; ++f) {
+            const int n = fsize(f);
+            const int* q = fp(f);
+            for (int i = 0; i < n; ++i) {
+                if (!localOf.count(q[i])) { localOf[q[i]] = (int)meshPoints.size(); meshPoints.push_back(q[i]); pointFaces.push_back(ivec()); }
+                pointFaces[localOf[q[i]]].push_back(f);
+                const int a = q[i], b = q[(i + 1) % n];
+                nEdgeFaces[std::make_pair(std::min(a, b), std::max(a, b))] += 1;
+            }
+        }
+        // PrimitivePatch::calcPointNormals
+        dvec pointNormals(3 * meshPoints.size(), 0.0);
+        for (size_t lp = 0; lp < meshPoints.size(); ++lp) {
+            double* cur = &pointNormals[3 * lp];
+            for (int f : pointFaces[lp]) for (int k = 0; k < 3; ++k) cur[k] += Sf[3 * (size_t)f + k] / magSf[f];
+            const double mg = mag3(cur) + VSMALL;
+            for (int k = 0; k < 3; ++k) cur[k] /= mg;
+        }
+        std::set<int> rim;
+        for (const auto& e : nEdgeFaces) if (e.second == 1) { rim.insert(e.first.first); rim.insert(e.first.second); }
+        for (size_t lp = 0; lp < meshPoints.size(); ++lp) {
+            const double* n = plane ? pt.nHat : (wedge ? &pointNormals[0] : &pointNormals[3 * lp]);
+            PointOp op;
+            op.kind = wedge ? 1 : 0;
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) op.T[3 * i + j] = (i == j ? 1.0 : 0.0) - (wedge ? 1.0 : 2.0) * (n[i] * n[j]);
+            pointOps[meshPoints[lp]].push_back(op);
+            if (rim.count(meshPoints[lp])) {   // pointConstraint::applyConstraint(n)
+                Corner& c = corners[meshPoints[lp]];
+                if (c.first == 0) { c.first = 1; for (int k = 0; k < 3; ++k) c.second[k] = n[k]; }
+                else if (c.first == 1) {
+                    double planeNormal[3];
+                    cross3(n, c.second, planeNormal);
+                    const double mg = mag3(planeNormal);
+                    if (mg > 1e-3) { c.first = 2; for (int k = 0; k < 3; ++k) c.second[k] = planeNormal[k] / mg; }
+                } else if (c.first == 2) {
+                    if (std::fabs(dot3(n, c.second)) > 1e-3) { c.first = 3; c.second[0] = c.second[1] = c.second[2] = 0.0; }
+                }
+            }
+        }
+    }
+    for (const auto& pc : corners) {   // pointConstraint::constraintTransformation
+        const Corner& c = pc.second;
+        PointOp op;
+        op.kind = 1;
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+            const double ss = c.second[i] * c.second[j];
+            op.T[3 * i + j] = c.first == 1 ? (i == j ? 1.0 : 0.0) - ss : (c.first == 2 ? ss : 0.0);
+        }
+        pointOps[pc.first].push_back(op);
+    }
 }
 
 void Mesh::haloFaces() {
@@ -316,7 +413,11 @@ struct SurfField {
 void patchSnGrad(const Mesh& m, const VolField& f, int patch, dvec& sn /*nBF*nc*/) {
     const PatchInfo& p = m.patches[patch];
     if (!m.patchHasFields(patch)) return;
-    const int kind = f.snKind.empty() ? SN_GENERIC : f.snKind[patch];
+    int kind = f.snKind.empty() ? SN_GENERIC : f.snKind[patch];
+    // a SCALAR field on a symmetryPlane / symmetry / wedge patch carries the patch's own field type whatever it was created with
+    // (L0: fvPatchField::New lets the constraint type win; basicSymmetry / wedge are specialised for scalars): snGrad = 0.  This is
+    // what vF.component(d) of the 2-D GaussVolPoint vector gradient [GaussVolPointBase.C L79-87] and thermo.rho() see there.
+    if (f.nc == 1 && (p.type == PATCH_SYMMETRYPLANE || p.type == PATCH_SYMMETRY || p.type == PATCH_WEDGE)) kind = SN_ZERO;
     for (int gf = p.start; gf < p.start + p.size; ++gf) {
         const int b = gf - m.nIF, o = m.own[gf];
         if (kind == SN_ZERO) {
@@ -325,7 +426,7 @@ void patchSnGrad(const Mesh& m, const VolField& f, int patch, dvec& sn /*nBF*nc*
             for (int k = 0; k < f.nc; ++k) sn[(size_t)b * f.nc + k] = f.grad[(size_t)b * f.nc + k];
         } else if (kind == SN_SYMM && f.nc == 3) {
             double n[3];
-            for (int k = 0; k < 3; ++k) n[k] = m.Sf[3 * (size_t)gf + k] / m.magSf[gf];
+            m.symmNormal(patch, gf, n);
             // symmTensor T = I - 2.0*sqr(nHat); transform(T, v) = T & v
             double T[9];
             for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) T[3 * i + j] = (i == j ? 1.0 : 0.0) - 2.0 * (n[i] * n[j]);
@@ -356,6 +457,25 @@ SurfField linearInterpolate(const Mesh& m, const VolField& f) {
             const double a = f.in[(size_t)m.own[fc] * f.nc + k], b = f.in[(size_t)m.nei[fc] * f.nc + k];
             s.v[(size_t)fc * f.nc + k] = m.w[fc] * (a - b) + b;
         }
+    for (size_t p = 0; p < m.patches.size(); ++p) {
+        if (!m.patchHasFields((int)p)) continue;
+        for (int fc = m.patches[p].start; fc < m.patches[p].start + m.patches[p].size; ++fc)
+            for (int k = 0; k < f.nc; ++k) s.v[(size_t)fc * f.nc + k] = f.bf[(size_t)(fc - m.nIF) * f.nc + k];
+    }
+    return s;
+}
+
+// qgdFlux's fvc::flux(flux, psi, name) branch [QGDInterpolate.H L86-104] with the entry `Gauss upwind` (L0, restated from knowledge):
+// gaussConvectionScheme::flux = faceFlux * tinterpScheme().interpolate(vf); upwind is a limitedSurfaceInterpolationScheme whose
+// weights() are pos0(faceFlux); surfaceInterpolationScheme::interpolate(vf, lambdas) forms lambda*(vf[P] - vf[N]) + vf[N] on internal
+// faces and takes the patch value on (non-coupled) patch faces.  Returns the interpolated field psi_f (the caller multiplies by the flux).
+SurfField upwindInterpolate(const Mesh& m, const SurfField& faceFlux, const VolField& f) {
+    SurfField s(m, f.nc);
+    for (int fc = 0; fc < m.nIF; ++fc) {
+        const double lambda = faceFlux.v[fc] >= 0.0 ? 1.0 : 0.0;   // pos0
+        for (int k = 0; k < f.nc; ++k)
+            s.v[(size_t)fc * f.nc + k] = lambda * (f.in[(size_t)m.own[fc] * f.nc + k] - f.in[(size_t)m.nei[fc] * f.nc + k]) + f.in[(size_t)m.nei[fc] * f.nc + k];
+    }
     for (size_t p = 0; p < m.patches.size(); ++p) {
         if (!m.patchHasFields((int)p)) continue;
         for (int fc = m.patches[p].start; fc < m.patches[p].start + m.patches[p].size; ++fc)
@@ -411,6 +531,25 @@ dvec volPointInterpolate(const Mesh& m, const VolField& f) {
         for (size_t j = 0; j < pfc.size(); ++j) {
             if (!m.isPatchFace[pfc[j]]) continue;
             for (int k = 0; k < nc; ++k) pf[(size_t)pt * nc + k] += pw[j] * bv[(size_t)pfc[j] * nc + k];
+        }
+    }
+    // pointConstraints::constrain (see Mesh::pointConstraintOps): vectors and tensors only
+    if (nc == 3 || nc == 9) {
+        for (const auto& po : m.pointOps) {
+            if (!m.isPatchPoint[po.first]) continue;
+            double* x = &pf[(size_t)po.first * nc];
+            for (const Mesh::PointOp& op : po.second) {
+                double tx[9];
+                if (nc == 3) { for (int i = 0; i < 3; ++i) tx[i] = op.T[3 * i] * x[0] + op.T[3 * i + 1] * x[1] + op.T[3 * i + 2] * x[2]; }
+                else {   // transform(T, A) = T & A & T^T (L0 transform.H)
+                    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+                        double acc = 0.0;
+                        for (int l = 0; l < 3; ++l) acc += (op.T[3 * i] * x[l] + op.T[3 * i + 1] * x[3 + l] + op.T[3 * i + 2] * x[6 + l]) * op.T[3 * j + l];
+                        tx[3 * i + j] = acc;
+                    }
+                }
+                for (int k = 0; k < nc; ++k) x[k] = op.kind == 0 ? (x[k] + tx[k]) / 2.0 : tx[k];
+            }
         }
     }
     return pf;
@@ -1075,7 +1214,14 @@ int solveDiagLaplacian(const Mesh& m, const dvec& a, const dvec& diag, const dve
 // ---------------------------------------------------------------------------
 // QGDFoam case
 // ---------------------------------------------------------------------------
-struct PatchBC { int bcU = BC_ZEROGRADIENT, bcT = BC_ZEROGRADIENT, bcP = BC_ZEROGRADIENT; double vU[3] = {0, 0, 0}, vT = 0, vP = 0; };
+inline double symmAbsN(const Mesh& m, int ip, int gf, int k) { double n[3]; m.symmNormal(ip, gf, n); return std::fabs(n[k]); }
+// OpenFOAM gives a field on a constraint patch the patch's own field type whatever the field file says (L0: fvPatchField::New):
+// empty / cut planes carry nothing, symmetryPlane / symmetry reflect vectors (basicSymmetry) and leave scalars zero-gradient
+inline void constraintKinds(int ptype, int32_t& bcU, int32_t& bcT, int32_t& bcP) {
+    if (ptype == PATCH_EMPTY || ptype == PATCH_HALO) { bcU = bcT = bcP = BC_NONE; }
+    else if (ptype == PATCH_SYMMETRYPLANE || ptype == PATCH_SYMMETRY) { bcU = BC_SLIP; bcT = bcP = BC_ZEROGRADIENT; }
+}
+struct PatchBC { int32_t bcU = BC_ZEROGRADIENT, bcT = BC_ZEROGRADIENT, bcP = BC_ZEROGRADIENT; double vU[3] = {0, 0, 0}, vT = 0, vP = 0; };
 
 struct Case {
     MeshHandle* mh;
@@ -1105,10 +1251,7 @@ struct Case {
         for (size_t ip = 0; ip < h->m.patches.size(); ++ip)
             if (!h->m.patchHasFields((int)ip))
                 for (int f = h->m.patches[ip].start; f < h->m.patches[ip].start + h->m.patches[ip].size; ++f) liveFace[f] = 0;
-        for (size_t ip = 0; ip < bc.size(); ++ip) {
-            const int t = m.patches[ip].type;
-            if (t == PATCH_EMPTY || t == PATCH_HALO) bc[ip].bcU = bc[ip].bcT = bc[ip].bcP = BC_NONE;
-        }
+        for (size_t ip = 0; ip < bc.size(); ++ip) constraintKinds(m.patches[ip].type, bc[ip].bcU, bc[ip].bcT, bc[ip].bcP);
     }
 
     // ---- thermo closures (L0: perfectGas + eConst(Tref=0,Esref=0) + constTransport)
@@ -1142,7 +1285,7 @@ struct Case {
             if (B.bcU == BC_FIXEDVALUE) { for (int k = 0; k < 3; ++k) U.bf[3 * (size_t)b + k] = B.vU[k]; }
             else if (B.bcU == BC_SLIP) {  // L0 basicSymmetry::evaluate: (pif + transform(I - 2 nn, pif))/2
                 double n[3], T[9];
-                for (int k = 0; k < 3; ++k) n[k] = m.Sf[3 * (size_t)gf + k] / m.magSf[gf];
+                m.symmNormal((int)ip, gf, n);
                 for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) T[3 * i + j] = (i == j ? 1.0 : 0.0) - 2.0 * (n[i] * n[j]);
                 double tv[3];
                 TdotV(T, &U.in[3 * (size_t)o], tv);
@@ -1393,6 +1536,10 @@ struct Case {
         }
         phiJmU = SurfField(m, 3); phiP = SurfField(m, 3); Pif = SurfField(m, 9); phiPi = SurfField(m, 3);
         phiJmH = SurfField(m, 1); qf = SurfField(m, 3); phiQ = SurfField(m, 1); phiPiU = SurfField(m, 1);
+        // qgdFlux(phiJm,U,Uf) / qgdFlux(phiJm,H,Hf): flux*psif, or fvc::flux when divSchemes has the flux's entry [QGDInterpolate.H L86-104]
+        SurfField UfUp, HfUp;
+        if (opt.fluxSchemeU) UfUp = upwindInterpolate(m, phiJm, U);
+        if (opt.fluxSchemeH) HfUp = upwindInterpolate(m, phiJm, H);
         for (int f = 0; f < nF; ++f) {
             if (!liveFace[f]) continue;
             const double* uf = &Uf.v[3 * (size_t)f];
@@ -1400,7 +1547,7 @@ struct Case {
             const double* gP = &gradPf.v[3 * (size_t)f];
             const double tau = tauQGDf.v[f];
             for (int k = 0; k < 3; ++k) {
-                phiJmU.v[3 * (size_t)f + k] = phiJm.v[f] * uf[k];                 // qgdFlux -> flux*psif [QGDInterpolate.H:104]
+                phiJmU.v[3 * (size_t)f + k] = phiJm.v[f] * (opt.fluxSchemeU ? UfUp.v[3 * (size_t)f + k] : uf[k]);   // qgdFlux -> flux*psif [QGDInterpolate.H:104]
                 phiP.v[3 * (size_t)f + k] = m.Sf[3 * (size_t)f + k] * pf.v[f];
             }
             double A[9], B[9];
@@ -1418,7 +1565,7 @@ struct Case {
                 Pi[3 * i + j] += muf.v[f] * t;
             }
             VdotT(&m.Sf[3 * (size_t)f], Pi, &phiPi.v[3 * (size_t)f]);
-            phiJmH.v[f] = phiJm.v[f] * Hf.v[f];
+            phiJmH.v[f] = phiJm.v[f] * (opt.fluxSchemeH ? HfUp.v[f] : Hf.v[f]);
             double g2[3], q[3];
             const double pr2 = pf.v[f] / rhof.v[f] / rhof.v[f];
             for (int k = 0; k < 3; ++k) g2[k] = gradef.v[3 * (size_t)f + k] - pr2 * gradRhof.v[3 * (size_t)f + k];
@@ -1464,7 +1611,7 @@ struct Case {
     dvec fusedPv;
     bool fusedSupported() const {
         const GaussVolPoint* gv = dynamic_cast<const GaussVolPoint*>(stencil);
-        if (!gv || m.nGeomD != 3 || opt.implicitDiffusion || opt.adjustTimeStep || !m.haloGhost.empty()) return false;
+        if (!gv || m.nGeomD != 3 || opt.implicitDiffusion || opt.adjustTimeStep || !m.haloGhost.empty() || !m.pointOps.empty() || opt.fluxSchemeU || opt.fluxSchemeH) return false;
         if (!gv->tf.empty() || !gv->of.empty()) return false;
         for (size_t ip = 0; ip < m.patches.size(); ++ip) {
             if (!m.patchHasFields((int)ip)) continue;
@@ -1811,13 +1958,13 @@ struct Case {
                     }
                     auto ic = [&](int ip, int gf, int, int) {
                         if (bc[ip].bcU == BC_FIXEDVALUE) return m.delta[gf];
-                        if (bc[ip].bcU == BC_SLIP) return m.delta[gf] * std::fabs(m.Sf[3 * (size_t)gf + k] / m.magSf[gf]);
+                        if (bc[ip].bcU == BC_SLIP) return m.delta[gf] * symmAbsN(m, (int)ip, gf, k);
                         return 0.0;
                     };
                     auto bs = [&](int ip, int gf, int b, int o) {
                         if (bc[ip].bcU == BC_FIXEDVALUE) return m.delta[gf] * U.bf[3 * (size_t)b + k];
                         if (bc[ip].bcU == BC_SLIP)
-                            return sn[3 * (size_t)b + k] + m.delta[gf] * std::fabs(m.Sf[3 * (size_t)gf + k] / m.magSf[gf]) * Ucur[3 * (size_t)o + k];
+                            return sn[3 * (size_t)b + k] + m.delta[gf] * symmAbsN(m, (int)ip, gf, k) * Ucur[3 * (size_t)o + k];
                         return 0.0;
                     };
                     lastIterU[k] = implicitDiffusionSolve(muf, rDeltaT, rhs, ic, bs, x.data());
@@ -2100,13 +2247,13 @@ struct Case {
                 }
                 auto ic = [&](int ip, int gf, int, int) {
                     if (bc[ip].bcU == BC_FIXEDVALUE) return m.delta[gf];
-                    if (bc[ip].bcU == BC_SLIP) return m.delta[gf] * std::fabs(m.Sf[3 * (size_t)gf + k] / m.magSf[gf]);
+                    if (bc[ip].bcU == BC_SLIP) return m.delta[gf] * symmAbsN(m, (int)ip, gf, k);
                     return 0.0;
                 };
                 auto bs = [&](int ip, int gf, int b, int o) {
                     if (bc[ip].bcU == BC_FIXEDVALUE) return m.delta[gf] * U.bf[3 * (size_t)b + k];
                     if (bc[ip].bcU == BC_SLIP)
-                        return snU_[3 * (size_t)b + k] + m.delta[gf] * std::fabs(m.Sf[3 * (size_t)gf + k] / m.magSf[gf]) * Ucur_[3 * (size_t)o + k];
+                        return snU_[3 * (size_t)b + k] + m.delta[gf] * symmAbsN(m, (int)ip, gf, k) * Ucur_[3 * (size_t)o + k];
                     return 0.0;
                 };
                 buildSystem(k, muf, rDeltaT, rhs, ic, bs);
@@ -2256,8 +2403,7 @@ struct QhdCase {
     int lastIterU[3] = {0, 0, 0}, lastIterT = 0;   // implicitDiffusion: iterations of the U and T solves of the last step
 
     QhdCase(MeshHandle* h, const orc_qhd_options& o) : mh(h), m(h->m), opt(o), bc(h->m.patches.size()) {
-        for (size_t ip = 0; ip < bc.size(); ++ip)
-            if (m.patches[ip].type == PATCH_EMPTY || m.patches[ip].type == PATCH_HALO) bc[ip].bcU = bc[ip].bcT = bc[ip].bcP = BC_NONE;
+        for (size_t ip = 0; ip < bc.size(); ++ip) constraintKinds(m.patches[ip].type, bc[ip].bcU, bc[ip].bcT, bc[ip].bcP);
         liveFace.assign(m.nF, 1);
         for (size_t ip = 0; ip < m.patches.size(); ++ip)
             if (!m.patchHasFields((int)ip))
@@ -2274,7 +2420,7 @@ struct QhdCase {
             if (B.bcU == BC_FIXEDVALUE) { for (int k = 0; k < 3; ++k) U.bf[3 * (size_t)b + k] = B.vU[k]; }
             else if (B.bcU == BC_SLIP) {
                 double n[3], Tm[9], tv[3];
-                for (int k = 0; k < 3; ++k) n[k] = m.Sf[3 * (size_t)gf + k] / m.magSf[gf];
+                m.symmNormal((int)ip, gf, n);
                 for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Tm[3 * i + j] = (i == j ? 1.0 : 0.0) - 2.0 * (n[i] * n[j]);
                 TdotV(Tm, &U.in[3 * (size_t)o], tv);
                 for (int k = 0; k < 3; ++k) U.bf[3 * (size_t)b + k] = (U.in[3 * (size_t)o + k] + tv[k]) / 2.0;
@@ -2448,6 +2594,8 @@ struct QhdCase {
         SurfField gUTf = linearInterpolate(m, gUT);
         SurfField snU = fvcSnGrad(m, U), snT = fvcSnGrad(m, T);
         const bool implicit = opt.implicitDiffusion != 0;
+        // qgdFlux(phi,U,Uf) [QHDUEqn.H L41], qgdFlux(phi,T,Tf) [QHDTEqn.H L65]: fvc::flux when divSchemes has the flux's entry
+        const SurfField UfFlux = opt.fluxSchemeU ? upwindInterpolate(m, phi, U) : Uf, TfFlux = opt.fluxSchemeT ? upwindInterpolate(m, phi, T) : Tf;
         dvec FU(3 * (size_t)nF, 0.0), FT((size_t)nF, 0.0), Gp(3 * (size_t)nF, 0.0);
         for (int f = 0; f < nF; ++f) {
             if (!liveFace[f]) continue;
@@ -2459,13 +2607,13 @@ struct QhdCase {
             VdotT(S, UW, uw);                                                                          // L39
             VdotT(S, &gUTf.v[9 * (size_t)f], ext);                                                     // Sf & lin(T(grad U)), L56 / L76
             for (int k = 0; k < 3; ++k) {
-                const double phiUf = phi.v[f] * Uf.v[3 * (size_t)f + k] - uw[k];                       // L41-43
+                const double phiUf = phi.v[f] * UfFlux.v[3 * (size_t)f + k] - uw[k];                   // L41-43
                 const double lap = nuf * snU.v[3 * (size_t)f + k] * m.magSf[f];                        // fvc::laplacian(muf/rhof, U), L74
                 FU[3 * (size_t)f + k] = implicit ? phiUf - nuf * ext[k] : (phiUf - lap) - nuf * ext[k];   // L54: the laplacian is in the matrix
                 Gp[3 * (size_t)f + k] = S[k] * pf.v[f];                                                // fvc::grad(p), Gauss linear
             }
-            FT[f] = implicit ? phi.v[f] * Tf.v[f] - phiTauTReg.v[f]                                    // QHDTEqn.H L73-76
-                             : (phi.v[f] * Tf.v[f] - Hif * snT.v[f] * m.magSf[f]) - phiTauTReg.v[f];   // QHDTEqn.H L65-66, L85-88
+            FT[f] = implicit ? phi.v[f] * TfFlux.v[f] - phiTauTReg.v[f]                                // QHDTEqn.H L73-76
+                             : (phi.v[f] * TfFlux.v[f] - Hif * snT.v[f] * m.magSf[f]) - phiTauTReg.v[f];   // QHDTEqn.H L65-66, L85-88
         }
         dvec sumU(3 * (size_t)nC, 0.0), sumT((size_t)nC, 0.0), sumG(3 * (size_t)nC, 0.0);
         for (int f = 0; f < nF; ++f) {   // surfaceIntegrate order
@@ -2522,13 +2670,13 @@ struct QhdCase {
                 }
                 auto ic = [&](int ip, int gf, int, int) {
                     if (bc[ip].bcU == BC_FIXEDVALUE) return m.delta[gf];
-                    if (bc[ip].bcU == BC_SLIP) return m.delta[gf] * std::fabs(m.Sf[3 * (size_t)gf + k] / m.magSf[gf]);
+                    if (bc[ip].bcU == BC_SLIP) return m.delta[gf] * symmAbsN(m, (int)ip, gf, k);
                     return 0.0;
                 };
                 auto bs = [&](int ip, int gf, int b, int o) {
                     if (bc[ip].bcU == BC_FIXEDVALUE) return m.delta[gf] * U.bf[3 * (size_t)b + k];
                     if (bc[ip].bcU == BC_SLIP)
-                        return snUb[3 * (size_t)b + k] + m.delta[gf] * std::fabs(m.Sf[3 * (size_t)gf + k] / m.magSf[gf]) * Ucur[3 * (size_t)o + k];
+                        return snUb[3 * (size_t)b + k] + m.delta[gf] * symmAbsN(m, (int)ip, gf, k) * Ucur[3 * (size_t)o + k];
                     return 0.0;
                 };
                 lastIterU[k] = solveOne(nuf, rhs, ic, bs, x.data());
@@ -2713,6 +2861,7 @@ struct QhdCase {
             for (int b = 0; b < nB; ++b) for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) gUT.bf[9 * (size_t)b + 3 * i + j] = gU.bf[9 * (size_t)b + 3 * j + i];
             SurfField gUTf = linearInterpolate(m, gUT);
             SurfField snU = fvcSnGrad(m, U), snT = fvcSnGrad(m, T);
+            const SurfField UfFlux = opt.fluxSchemeU ? upwindInterpolate(m, phi, U) : Uf_, TfFlux = opt.fluxSchemeT ? upwindInterpolate(m, phi, T) : Tf_;
             dvec FU(3 * (size_t)nF, 0.0), FT((size_t)nF, 0.0), Gp(3 * (size_t)nF, 0.0);
             for (int f = 0; f < nF; ++f) {
                 if (!liveFace[f]) continue;
@@ -2724,12 +2873,12 @@ struct QhdCase {
                 VdotT(S, UW, uw);
                 VdotT(S, &gUTf.v[9 * (size_t)f], ext);
                 for (int k = 0; k < 3; ++k) {
-                    const double phiUf = phi.v[f] * Uf_.v[3 * (size_t)f + k] - uw[k];
+                    const double phiUf = phi.v[f] * UfFlux.v[3 * (size_t)f + k] - uw[k];
                     const double lap = nuf * snU.v[3 * (size_t)f + k] * m.magSf[f];
                     FU[3 * (size_t)f + k] = (phiUf - lap) - nuf * ext[k];
                     Gp[3 * (size_t)f + k] = S[k] * pf.v[f];
                 }
-                FT[f] = (phi.v[f] * Tf_.v[f] - Hif * snT.v[f] * m.magSf[f]) - phiTauTReg_.v[f];
+                FT[f] = (phi.v[f] * TfFlux.v[f] - Hif * snT.v[f] * m.magSf[f]) - phiTauTReg_.v[f];
             }
             dvec sumU(3 * (size_t)nC, 0.0), sumT((size_t)nC, 0.0), sumG(3 * (size_t)nC, 0.0);
             for (int f = 0; f < nF; ++f) {
@@ -2963,7 +3112,13 @@ int orc_qhd_fluxes(void* mp, const char* scheme, const orc_qhd_inputs* in, orc_q
     return 0;
 }
 
+// cyclic / wedge patches with faces: the cases restate no coupled / wedge patch field (NULL, like qgd_case_create's refusal)
+static bool caseServesMesh(const Mesh& m) {
+    for (const PatchInfo& p : m.patches) if ((p.type == PATCH_CYCLIC || p.type == PATCH_WEDGE) && p.size > 0) return false;
+    return true;
+}
 void* orc_case_create(void* mesh, const orc_case_options* opt) {
+    if (!caseServesMesh(((MeshHandle*)mesh)->m)) return nullptr;
     Case* c = new Case((MeshHandle*)mesh, *opt);
     c->stencilWord = opt->stencil == FVSC_REDUCED ? "reduced" : (opt->stencil == FVSC_LEASTSQUARES ? "leastSquares" : "GaussVolPoint");
     const Mesh& m = c->m;
@@ -2978,6 +3133,7 @@ int orc_case_set_bc(void* cp, int32_t patch, int32_t bcU, const double* valueU, 
     Case* c = (Case*)cp;
     if (patch < 0 || patch >= (int)c->bc.size()) return -1;
     PatchBC& b = c->bc[patch];
+    constraintKinds(c->m.patches[patch].type, bcU, bcT, bcP);
     b.bcU = bcU; b.bcT = bcT; b.bcP = bcP; b.vT = valueT; b.vP = valueP;
     if (valueU) for (int k = 0; k < 3; ++k) b.vU[k] = valueU[k];
     return 0;
@@ -3294,6 +3450,7 @@ int orc_qhd_pressure(void* mp, const double* phiu, const double* phiwo, const do
 // STREAM triad a = b + s*c (24 bytes per element by the STREAM convention): bench.py times it on the same host cores as
 // the oracle ranks to bound what ANY fused CPU implementation of the step could reach there (bytes per cell-step / bandwidth)
 void* orc_qhd_case_create(void* mesh, const orc_qhd_options* opt) {
+    if (!caseServesMesh(((MeshHandle*)mesh)->m)) return nullptr;
     QhdCase* c = new QhdCase((MeshHandle*)mesh, *opt);
     c->word = opt->stencil == FVSC_REDUCED ? "reduced" : (opt->stencil == FVSC_LEASTSQUARES ? "leastSquares" : "GaussVolPoint");
     return c;
@@ -3303,7 +3460,7 @@ int orc_qhd_case_set_bc(void* cp, int32_t patch, int32_t bcU, const double* vU, 
     QhdCase* c = (QhdCase*)cp;
     if (patch < 0 || patch >= (int32_t)c->bc.size()) return -1;
     PatchBC& b = c->bc[patch];
-    if (c->m.patches[patch].type == PATCH_EMPTY || c->m.patches[patch].type == PATCH_HALO) { bcU = bcT = bcP = BC_NONE; }
+    constraintKinds(c->m.patches[patch].type, bcU, bcT, bcP);
     b.bcU = bcU; b.bcT = bcT; b.bcP = bcP; b.vT = vT; b.vP = vP;
     if (vU) for (int k = 0; k < 3; ++k) b.vU[k] = vU[k];
     return 0;

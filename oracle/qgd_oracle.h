@@ -27,7 +27,9 @@ typedef struct orc_case_options {
     int32_t stencil, implicitDiffusion, adjustTimeStep, consistentEnergy;
     double R, Cv, mu, Pr, ScQGD, PrQGD, alphaQGD, deltaT, maxCo, maxDeltaT, cTau;
     double implicitTol;        /* fvSolution tolerance of the two implicit-diffusion solves */
-    int32_t implicitMaxIter, pad_;
+    int32_t implicitMaxIter;
+    int32_t fluxSchemeU, fluxSchemeH;   /* 0 flux*psif (= Gauss linear), 1 Gauss upwind: divSchemes entry of qgdFlux's flux [QGDInterpolate.H L86-104] */
+    int32_t pad_;
 } orc_case_options;
 
 void* orc_mesh_create(int32_t nPoints, const double* points, int32_t nFaces,
@@ -92,7 +94,8 @@ int orc_qhd_pressure(void* mesh, const double* phiu, const double* phiwo, const 
 typedef struct orc_qhd_options {
     int32_t stencil, implicitDiffusion, tauModel, pRefCell, pMaxIter, precond;
     double rho0, mu, Pr, beta, g[3], deltaT, Tau, aQGD, UQHD, T0, Gr, pTol, pRelTol, pRefValue;
-    double implicitTol; int32_t implicitMaxIter, pad_;
+    double implicitTol; int32_t implicitMaxIter;
+    int32_t fluxSchemeU, fluxSchemeT, pad_;
 } orc_qhd_options;
 void* orc_qhd_case_create(void* mesh, const orc_qhd_options* opt);
 void orc_qhd_case_free(void* c);

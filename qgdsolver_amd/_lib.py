@@ -43,7 +43,8 @@ class CaseOptions(C.Structure):
         ("stencil", C.c_int32), ("implicitDiffusion", C.c_int32), ("adjustTimeStep", C.c_int32), ("consistentEnergy", C.c_int32),
         ("R", C.c_double), ("Cv", C.c_double), ("mu", C.c_double), ("Pr", C.c_double), ("ScQGD", C.c_double),
         ("PrQGD", C.c_double), ("alphaQGD", C.c_double), ("deltaT", C.c_double), ("maxCo", C.c_double),
-        ("maxDeltaT", C.c_double), ("cTau", C.c_double), ("implicitTol", C.c_double), ("implicitMaxIter", C.c_int32), ("pad_", C.c_int32),
+        ("maxDeltaT", C.c_double), ("cTau", C.c_double), ("implicitTol", C.c_double), ("implicitMaxIter", C.c_int32),
+        ("fluxSchemeU", C.c_int32), ("fluxSchemeH", C.c_int32), ("pad_", C.c_int32),
     ]
 
 
@@ -54,7 +55,8 @@ class QhdOptions(C.Structure):
                 ("rho0", C.c_double), ("mu", C.c_double), ("Pr", C.c_double), ("beta", C.c_double), ("g", C.c_double * 3),
                 ("deltaT", C.c_double), ("Tau", C.c_double), ("aQGD", C.c_double), ("UQHD", C.c_double), ("T0", C.c_double),
                 ("Gr", C.c_double), ("pTol", C.c_double), ("pRelTol", C.c_double), ("pRefValue", C.c_double),
-                ("implicitTol", C.c_double), ("implicitMaxIter", C.c_int32), ("pad_", C.c_int32)]
+                ("implicitTol", C.c_double), ("implicitMaxIter", C.c_int32),
+                ("fluxSchemeU", C.c_int32), ("fluxSchemeT", C.c_int32), ("pad_", C.c_int32)]
 
 
 # every symbol include/qgd_amd.h declares: name -> (restype, argtypes)
@@ -99,6 +101,7 @@ SIGNATURES = {
     "qgd_device_face_tiles": (C.c_int, [handle, C.POINTER(C.c_int64)]),
     "qgd_interpolate": (C.c_int, [handle, C.c_int32, c_double_p, c_double_p, c_double_p]),
     "qgd_flux": (C.c_int, [handle, C.c_int32, c_double_p, c_double_p, c_double_p]),
+    "qgd_flux_upwind": (C.c_int, [handle, C.c_int32, c_double_p, c_double_p, c_double_p, c_double_p]),
     "qgd_device_get": (C.c_int, [handle, C.c_char_p, c_double_p, C.c_int64]),
     "qgd_qhd_fluxes": (C.c_int, [handle, C.c_int, C.c_void_p, C.c_void_p]),
     "qgd_qhd_options_default": (C.c_int, [C.POINTER(QhdOptions)]),
@@ -202,6 +205,7 @@ ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_SCHEME, ERR_UNKNOWN_NAME, ERR_NOT_IMPLE
 PATCH_GENERIC, PATCH_EMPTY, PATCH_SYMMETRYPLANE, PATCH_SYMMETRY, PATCH_WEDGE, PATCH_CYCLIC, PATCH_HALO = range(7)
 BC_ZEROGRADIENT, BC_FIXEDVALUE, BC_SLIP, BC_QGDFLUX, BC_NONE, BC_QHDFLUX = range(6)
 FVSC_REDUCED, FVSC_LEASTSQUARES, FVSC_GAUSSVOLPOINT = range(3)
+FLUX_LINEAR, FLUX_UPWIND = range(2)
 K_POINT, K_FACE, K_BFACE, K_CELL, K_BC, K_BPOINT = range(6)
 
 

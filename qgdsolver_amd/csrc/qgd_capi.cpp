@@ -184,6 +184,46 @@ struct Workspace {
 };
 
 static int envChoice(const char* name, int dflt, const int* allowed, int nAllowed, int lo, int hi);
+
+// ---- constraint patches in the resident cases -----------------------------------------------------------------------------------------
+// OpenFOAM gives a field on a constraint patch the patch's own field type whatever the field file says (L0: fvPatchField<Type>::New,
+// "patchFieldType overridden by the patch's constraint type"): empty patches and the cut planes of a shard carry nothing;
+// symmetryPlane / symmetry reflect vectors (symmetryPlaneFvPatchField / basicSymmetryFvPatchField: evaluate = (pif +
+// transform(I - 2 nn, pif))/2) and leave scalars zero-gradient.  The stencils know the same list
+// [extendedFaceStencilScalarGrad.C L90-101, GaussVolPointBase3D.C L783-794].
+static void constraintKinds(int ptype, int32_t& bcU, int32_t& bcT, int32_t& bcP) {
+    if (ptype == QGD_PATCH_EMPTY || ptype == QGD_PATCH_HALO) { bcU = bcT = bcP = QGD_BC_NONE; }
+    else if (ptype == QGD_PATCH_SYMMETRYPLANE || ptype == QGD_PATCH_SYMMETRY) { bcU = QGD_BC_SLIP; bcT = bcP = QGD_BC_ZEROGRADIENT; }
+}
+static void initPatchBC(PatchBCDev& b, const Patch& p) {
+    std::memset(&b, 0, sizeof(b));
+    b.ptype = p.type;
+    b.bcU = b.bcT = b.bcP = QGD_BC_ZEROGRADIENT;
+    constraintKinds(p.type, b.bcU, b.bcT, b.bcP);
+    if (p.type == QGD_PATCH_SYMMETRYPLANE && (p.size > 0 || p.nHatInherited)) {
+        b.planeN = 1;
+        for (int k = 0; k < 3; ++k) b.nHat[k] = p.nHat[k];
+    }
+}
+static void residentCasePatchCheck(const HostMesh& m, std::string& why, int& code) {
+    why.clear(); code = 0;
+    for (const Patch& p : m.patches) {
+        if ((p.type == QGD_PATCH_CYCLIC || p.type == QGD_PATCH_WEDGE) && p.nonEmptyGlobally()) {
+            why = std::string("patch '") + p.name + "' is a " + (p.type == QGD_PATCH_CYCLIC ? "cyclic" : "wedge") +
+                  " patch: the resident cases do not serve coupled / wedge patch fields (use the fvsc operators, which do)";
+            code = QGD_ERR_NOT_IMPLEMENTED;
+            return;
+        }
+        if (p.type == QGD_PATCH_SYMMETRYPLANE) {
+            for (int32_t f = p.start; f < p.start + p.size; ++f) {   // L0: symmetryPlanePolyPatch::calcGeometry, magSqr(n_ - nf) > SMALL is fatal
+                double d2 = 0;
+                for (int k = 0; k < 3; ++k) { const double x = p.nHat[k] - m.Sf[3 * (size_t)f + k] / m.magSf[f]; d2 += x * x; }
+                if (d2 > 1e-15) { why = std::string("Symmetry plane '") + p.name + "' is not planar (use the symmetry patch type)"; code = QGD_ERR_INVALID; return; }
+            }
+        }
+    }
+}
+
 struct qgd_device_s {
     int deviceId = 0;
     Workspace ws;
@@ -195,6 +235,9 @@ struct qgd_device_s {
     bool hasTri = false;
     bool wedgePrism = false;  // wedge patches + prism cells: GaussVolPoint is refused [fvsc_8C L65-82]
     std::vector<Patch> patches;
+    // why a resident case (qgd_case_create / qgd_qhd_case_create) cannot run on this mesh, empty when it can: cyclic / wedge patches
+    // with faces (their coupled / rotated patch fields are not served), a symmetryPlane that is not planar (fatal in OpenFOAM too)
+    std::string caseRefusal; int caseRefusalCode = 0;
     std::vector<double> hf;  // host copy of hQGDf for the accessor
     // halo lists (device) and sizes, one entry per halo slot (neighbouring shard)
     struct HaloSlot {
@@ -595,6 +638,7 @@ int qgd_device_create(qgd_mesh_t mh, int deviceId, qgd_device_t* out) {
         d->hasTri = s.hasTri;
         d->wedgePrism = hasWedgeAndPrism(m);
         d->patches = m.patches;
+        residentCasePatchCheck(m, d->caseRefusal, d->caseRefusalCode);
         d->hf = s.hf;
         const bool range = m.ownedEnd > m.ownedBegin;
         d->ownedBegin = range ? m.ownedBegin : 0;
@@ -675,9 +719,11 @@ int qgd_device_create(qgd_mesh_t mh, int deviceId, qgd_device_t* out) {
         v.lsqSlice = up(s.lsqSlice); v.lsqCnt = up(s.lsqCnt); v.lsqCell = up(s.lsqCell);
         v.lsqGx = up(s.lsqGx); v.lsqGy = up(s.lsqGy); v.lsqGz = up(s.lsqGz); v.lsqDeg = up(s.lsqDeg);
         v.lsqBndZero = up(s.lsqBndZero);
+        if (!s.bSymm.empty()) v.bSymm = up(s.bSymm);
         v.pcSlice = up(s.pcSlice); v.pcCount = up(s.pcCount); v.pcCell = up(s.pcCell); v.pcW = up(s.pcW);
         v.nBP = (int32_t)s.bpPoint.size();
         v.bpPoint = up(s.bpPoint); v.bpOff = up(s.bpOff); v.bpFace = up(s.bpFace); v.bpW = up(s.bpW);
+        if (!s.cpOff.empty() && s.cpOff.back() > 0) { v.cpOff = up(s.cpOff); v.cpKind = up(s.cpKind); v.cpT = up(s.cpT); }
         v.cfSlice = up(s.cfSlice); v.cfCount = up(s.cfCount); v.cfItem = up(s.cfItem); v.cfNbr = up(s.cfNbr);
         v.fpos = up(s.fpos); v.cfPos = up(s.cfPos);
         v.V = up(s.V); v.hQGD = up(s.hQGD); v.ghost = up(s.ghost);
@@ -1106,6 +1152,27 @@ int qgd_flux(qgd_device_t d, int32_t ncomp, const double* flux, const double* ps
         for (int k = 0; k < ncomp; ++k) out[f * ncomp + k] = flux[f] * psif[f * ncomp + k];  // flux*psif [QGDInterpolate_8H L104]
     return QGD_OK;
 }
+int qgd_flux_upwind(qgd_device_t d, int32_t ncomp, const double* flux, const double* cell, const double* bnd, double* out) {
+    QGD_TRY
+    if (!d || !flux || !cell || !out || ncomp < 1 || ncomp > 9 || (!bnd && d->view.nBF > 0)) return fail(QGD_ERR_INVALID, "qgd_flux_upwind: bad argument");
+    HIP_CHECK(hipSetDevice(d->deviceId));
+    const MeshView& v = d->view;
+    Workspace& ws = d->ws;
+    double* dc = ws.get<double>(WS_CELL, (size_t)v.nC * ncomp);
+    double* db = ws.get<double>(WS_BND, (size_t)v.nBF * ncomp);
+    double* df = ws.get<double>(WS_A, (size_t)v.nF);
+    double* dout = ws.get<double>(WS_OUT, (size_t)v.nF * ncomp);
+    ws.h2d(dc, cell, sizeof(double) * (size_t)v.nC * ncomp, d->stream);
+    if (v.nBF) ws.h2d(db, bnd, sizeof(double) * (size_t)v.nBF * ncomp, d->stream);
+    ws.h2d(df, flux, sizeof(double) * (size_t)v.nF, d->stream);
+    (void)hipGetLastError();
+    launchFluxUpwind(d->stream, ncomp, v, df, dc, db, dout);
+    HIP_CHECK(hipGetLastError());
+    ws.d2h(out, dout, sizeof(double) * (size_t)v.nF * ncomp, d->stream);
+    HIP_CHECK(hipStreamSynchronize(d->stream));
+    return QGD_OK;
+    QGD_CATCH
+}
 int qgd_device_get(qgd_device_t d, const char* name, double* out, int64_t outDoubles) {
     QGD_TRY
     if (!d || !name || !out) return fail(QGD_ERR_INVALID, "qgd_device_get: null argument");
@@ -1321,6 +1388,9 @@ int qgd_case_create(qgd_device_t d, const qgd_case_options* opt, qgd_case_t* out
         return fail(QGD_ERR_INVALID, "qgd_case_create: bad implicitTol / implicitMaxIter");
     if (!(opt->R > 0) || !(opt->Cv > 0) || !(opt->Pr > 0) || !(opt->PrQGD > 0) || !(opt->deltaT > 0))
         return fail(QGD_ERR_INVALID, "qgd_case_create: R, Cv, Pr, PrQGD, deltaT must be positive");
+    if ((opt->fluxSchemeU != QGD_FLUX_LINEAR && opt->fluxSchemeU != QGD_FLUX_UPWIND) || (opt->fluxSchemeH != QGD_FLUX_LINEAR && opt->fluxSchemeH != QGD_FLUX_UPWIND))
+        return fail(QGD_ERR_INVALID, "qgd_case_create: fluxSchemeU / fluxSchemeH must be QGD_FLUX_LINEAR or QGD_FLUX_UPWIND");
+    if (!d->caseRefusal.empty()) return fail(d->caseRefusalCode, "qgd_case_create: " + d->caseRefusal);
     int st = 0;
     int rc = deviceStencil(d, opt->stencil, &st);
     if (rc) return rc;
@@ -1334,6 +1404,8 @@ int qgd_case_create(qgd_device_t d, const qgd_case_options* opt, qgd_case_t* out
         g.alphaQGD = opt->alphaQGD;
         g.consistentEnergy = opt->consistentEnergy ? 1 : 0;
         g.implicitDiffusion = opt->implicitDiffusion ? 1 : 0;
+        g.upwindU = opt->fluxSchemeU == QGD_FLUX_UPWIND ? 1 : 0;
+        g.upwindH = opt->fluxSchemeH == QGD_FLUX_UPWIND ? 1 : 0;
         const double Cp = opt->Cv + opt->R;
         g.gamma = Cp / opt->Cv;
         const double rPr = 1.0 / opt->Pr;
@@ -1369,13 +1441,7 @@ int qgd_case_create(qgd_device_t d, const qgd_case_options* opt, qgd_case_t* out
             { static const int kOnOff[] = {0, 1}; c->reuseGradU = envChoice("QGD_IMPL_REUSE_GRADU", 1, kOnOff, 2) != 0; }
         }
         c->bc.resize(d->patches.size());
-        for (size_t i = 0; i < d->patches.size(); ++i) {
-            PatchBCDev& b = c->bc[i];
-            std::memset(&b, 0, sizeof(b));
-            b.ptype = d->patches[i].type;
-            const bool none = b.ptype == QGD_PATCH_EMPTY || b.ptype == QGD_PATCH_HALO;
-            b.bcU = b.bcT = b.bcP = none ? QGD_BC_NONE : QGD_BC_ZEROGRADIENT;
-        }
+        for (size_t i = 0; i < d->patches.size(); ++i) initPatchBC(c->bc[i], d->patches[i]);
         c->bcDev = a.alloc<PatchBCDev>(std::max<size_t>(1, c->bc.size()));
         const double dt0[8] = {opt->deltaT, 0, 0, 0, 0, 0, 0, 0};
         HIP_CHECK(hipMemcpy(cv.dt, dt0, sizeof(dt0), hipMemcpyHostToDevice));
@@ -1409,7 +1475,7 @@ int qgd_case_set_bc(qgd_case_t c, int32_t patch, int32_t bcU, const double* valu
     auto okP = [](int k) { return k == QGD_BC_ZEROGRADIENT || k == QGD_BC_FIXEDVALUE || k == QGD_BC_QGDFLUX || k == QGD_BC_NONE; };
     if (!okU(bcU) || !okT(bcT) || !okP(bcP)) return fail(QGD_ERR_INVALID, "qgd_case_set_bc: unsupported boundary-condition kind");
     PatchBCDev& b = c->bc[patch];
-    if (b.ptype == QGD_PATCH_EMPTY || b.ptype == QGD_PATCH_HALO) { bcU = bcT = bcP = QGD_BC_NONE; }
+    constraintKinds(b.ptype, bcU, bcT, bcP);   // a constraint patch keeps its own field type whatever the caller asks for
     b.bcU = bcU; b.bcT = bcT; b.bcP = bcP; b.vT = valueT; b.vP = valueP;
     if (valueU) for (int k = 0; k < 3; ++k) b.vU[k] = valueU[k];
     c->fieldsSet = false;
@@ -1843,6 +1909,9 @@ int qgd_qhd_case_create(qgd_device_t d, const qgd_qhd_options* opt, qgd_qhd_case
         return fail(QGD_ERR_INVALID, "qgd_qhd_case_create: implicitDiffusion needs implicitTol > 0 and implicitMaxIter >= 1");
     if (!(opt->rho0 > 0) || !(opt->Pr > 0) || !(opt->deltaT > 0) || opt->tauModel < 0 || opt->tauModel > 3)
         return fail(QGD_ERR_INVALID, "qgd_qhd_case_create: rho0, Pr, deltaT must be positive, tauModel in 0..3");
+    if ((opt->fluxSchemeU != QGD_FLUX_LINEAR && opt->fluxSchemeU != QGD_FLUX_UPWIND) || (opt->fluxSchemeT != QGD_FLUX_LINEAR && opt->fluxSchemeT != QGD_FLUX_UPWIND))
+        return fail(QGD_ERR_INVALID, "qgd_qhd_case_create: fluxSchemeU / fluxSchemeT must be QGD_FLUX_LINEAR or QGD_FLUX_UPWIND");
+    if (!d->caseRefusal.empty()) return fail(d->caseRefusalCode, "qgd_qhd_case_create: " + d->caseRefusal);
     int st = 0;
     int rc = deviceStencil(d, opt->stencil, &st);
     if (rc) return rc;
@@ -1864,6 +1933,8 @@ int qgd_qhd_case_create(qgd_device_t d, const qgd_qhd_options* opt, qgd_qhd_case
         q.ugu = a.alloc<double>(3 * nF); q.gUc = a.alloc<double>(9 * nC); q.F = a.alloc<double>(4 * nF);
         c->scratch = a.alloc<double>(8);
         q.implicit = opt->implicitDiffusion ? 1 : 0;
+        q.upwindU = opt->fluxSchemeU == QGD_FLUX_UPWIND ? 1 : 0;
+        q.upwindT = opt->fluxSchemeT == QGD_FLUX_UPWIND ? 1 : 0;
         if (q.implicit) {
             q.aG = a.alloc<double>(nF); q.diag4 = a.alloc<double>(4 * nC); q.rhs4 = a.alloc<double>(4 * nC); q.x4 = a.alloc<double>(4 * nC);
             c->implSolver = implicitSolverCreate(d->stream, v, d->ownedBegin, d->ownedEnd);
@@ -1875,13 +1946,7 @@ int qgd_qhd_case_create(qgd_device_t d, const qgd_qhd_options* opt, qgd_qhd_case
         q.dt = opt->deltaT; q.tauModel = opt->tauModel; q.Tau = opt->Tau; q.aQGD = opt->aQGD; q.UQHD = opt->UQHD; q.T0 = opt->T0; q.Gr = opt->Gr;
         c->bc.resize(d->patches.size());
         c->bcPRequested.assign(d->patches.size(), QGD_BC_ZEROGRADIENT);
-        for (size_t i = 0; i < d->patches.size(); ++i) {
-            PatchBCDev& b = c->bc[i];
-            std::memset(&b, 0, sizeof(b));
-            b.ptype = d->patches[i].type;
-            const bool none = b.ptype == QGD_PATCH_EMPTY || b.ptype == QGD_PATCH_HALO;
-            b.bcU = b.bcT = b.bcP = none ? QGD_BC_NONE : QGD_BC_ZEROGRADIENT;
-        }
+        for (size_t i = 0; i < d->patches.size(); ++i) initPatchBC(c->bc[i], d->patches[i]);
         c->bcDev = a.alloc<PatchBCDev>(std::max<size_t>(1, c->bc.size()));
         c->bKind = a.alloc<uint8_t>(nB);
     } catch (...) { if (c->implSolver) implicitSolverFree(c->implSolver); c->arena.release(); delete c; throw; }
@@ -1911,7 +1976,7 @@ int qgd_qhd_case_set_bc(qgd_qhd_case_t c, int32_t patch, int32_t bcU, const doub
     if (!okU(bcU) || !okT(bcT) || !okP(bcP)) return fail(QGD_ERR_INVALID, "qgd_qhd_case_set_bc: unsupported boundary-condition kind");
     PatchBCDev& b = c->bc[patch];
     c->bcPRequested[patch] = bcP;
-    if (b.ptype == QGD_PATCH_EMPTY || b.ptype == QGD_PATCH_HALO) { bcU = bcT = bcP = QGD_BC_NONE; }
+    constraintKinds(b.ptype, bcU, bcT, bcP);   // a constraint patch keeps its own field type whatever the caller asks for
     b.bcU = bcU; b.bcT = bcT; b.bcP = bcP; b.vT = valueT; b.vP = valueP;
     if (valueU) for (int k = 0; k < 3; ++k) b.vU[k] = valueU[k];
     c->fieldsSet = false;

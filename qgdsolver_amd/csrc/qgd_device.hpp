@@ -42,6 +42,10 @@ struct MeshView {
     const double* lsqGx; const double* lsqGy; const double* lsqGz; const uint8_t* lsqDeg; const uint8_t* lsqBndZero;
     const int32_t* pcSlice; const uint8_t* pcCount; const int32_t* pcCell; const double* pcW;  // sliced ELL (64-point slices)
     int32_t nBP; const int32_t* bpPoint; const int32_t* bpOff; const int32_t* bpFace; const double* bpW;
+    // point constraints of vector / tensor vertex fields on symmetryPlane / symmetry / wedge patches (qgd_setup.hpp StaticData::cpOff);
+    // cpOff == nullptr: the mesh has none
+    const int32_t* cpOff; const uint8_t* cpKind; const double* cpT;
+    const uint8_t* bSymm;    // nBF: 1 on faces of symmetryPlane / symmetry / wedge patches (nullptr: the mesh has none)
     const int32_t* cfSlice; const uint8_t* cfCount; const int32_t* cfItem;                     // sliced ELL (64-cell slices)
     const int32_t* fpos;     // nIF: storage position of an internal face's net fluxes (slot-major, qgd_setup.hpp)
     const int32_t* cfPos;    // cfItem with positions instead of labels: gather list of the cell kernel
@@ -67,7 +71,12 @@ struct MeshView {
 };
 
 // Per-patch boundary-condition table (device copy, <= 64 patches)
-struct PatchBCDev { int32_t bcU, bcT, bcP, ptype; double vU[3]; double vT, vP; };
+struct PatchBCDev {
+    int32_t bcU, bcT, bcP, ptype; double vU[3]; double vT, vP;
+    // symmetryPlane patches: the one normal of the patch (qgd_mesh.hpp Patch::nHat), used on every face where basicSymmetry (slip,
+    // symmetry) uses the face's own normal (L0: symmetryPlaneFvPatchField::evaluate / snGrad / snGradTransformDiag)
+    double nHat[3]; int32_t planeN, pad_;
+};
 #define QGD_MAX_PATCHES 64
 
 struct GasModel {
@@ -77,6 +86,7 @@ struct GasModel {
     int32_t consistentEnergy;  // qgd_case_options::consistentEnergy
     int32_t implicitDiffusion; // qgd_case_options::implicitDiffusion
     double rPrQGD;             // 1/PrQGD
+    int32_t upwindU, upwindH;  // qgd_case_options::fluxSchemeU / fluxSchemeH == QGD_FLUX_UPWIND
 };
 
 // Mutable case state on the device
@@ -155,6 +165,7 @@ void launchFvscOp(hipStream_t s, int stencil, int op, int NC, const MeshView& m,
 void launchPack5(hipStream_t s, int64_t n, const double* U, const double* T, const double* p, double* out);
 void launchSoaToAos(hipStream_t s, int64_t n, int nc, const double* src, double* dst);
 void launchInterpolate(hipStream_t s, int NC, const MeshView& m, const double* cell, const double* bnd, double* out);
+void launchFluxUpwind(hipStream_t s, int NC, const MeshView& m, const double* flux, const double* cell, const double* bnd, double* out);
 
 // ---- QHDFoam face fluxes --------------------------------------------------------
 // rec5 = {Ux,Uy,Uz,T,p} per cell / patch face / vertex; out = 26 SoA slots of nF doubles (see QhdSlot)
@@ -246,6 +257,7 @@ struct QhdView {
     double* gUc;                               // 9*nC fvc::grad(U)
     double* F;                                 // 4*nF SoA at the faces' slot-major positions (MeshView::fpos): net face terms of the U (3) and T equations
     double rho0, nu, Hi, beta, g[3], dt;
+    int32_t upwindU, upwindT;                  // qgd_qhd_options::fluxSchemeU / fluxSchemeT == QGD_FLUX_UPWIND
     // implicitDiffusion [QHDUEqn_8H L46-65, QHDTEqn_8H L69-80]: the four systems {Ux, Uy, Uz, T} share the face coefficients
     // aG = |Sf| delta_f (at the faces' slot-major positions) up to gamma = {nu, nu, nu, Hi}; the matrix does not change in time
     // (thermo is not corrected inside the loop, deltaT is fixed): diag4 is built once, rhs4 / x4 every step (component-major, 4 * nC)

@@ -29,8 +29,8 @@ __device__ __forceinline__ void patchSnGradU(const MeshView& m, const PatchBCDev
     const double dc = m.dn[f];
     if (bc.bcU == QGD_BC_FIXEDVALUE) { for (int k = 0; k < 3; ++k) sn[k] = dc * (ub[k] - uo[k]); }
     else if (bc.bcU == QGD_BC_SLIP) {
-        const double ms = m.magSf[f];
-        const double n[3] = {m.Sx[f] / ms, m.Sy[f] / ms, m.Sz[f] / ms};
+        double n[3];
+        symmNormal(m, bc, f, n);
         for (int i = 0; i < 3; ++i) {
             const double tv = ((i == 0 ? 1.0 : 0.0) - 2.0 * (n[i] * n[0])) * uo[0] + ((i == 1 ? 1.0 : 0.0) - 2.0 * (n[i] * n[1])) * uo[1] +
                               ((i == 2 ? 1.0 : 0.0) - 2.0 * (n[i] * n[2])) * uo[2];
@@ -287,7 +287,8 @@ __global__ __launch_bounds__(QGD_BLOCK) void implCellUKernel(const MeshView m, c
             for (int k = 0; k < 3; ++k) { diag[k] += a; rhs[k] += a * bc.vU[k]; }
         } else if (bc.bcU == QGD_BC_SLIP) {
             const double ms = m.magSf[f], dc = m.dn[f], gs = iv.mufS[f] * ms;
-            const double nv[3] = {m.Sx[f] / ms, m.Sy[f] / ms, m.Sz[f] / ms};
+            double nv[3];
+            symmNormal(m, bc, f, nv);
             double sn[3];
             patchSnGradU(m, bc, f, Ucur, Ucur, sn);
             for (int k = 0; k < 3; ++k) { diag[k] += a * fabs(nv[k]); rhs[k] += gs * (sn[k] + dc * fabs(nv[k]) * Ucur[k]); }
@@ -319,8 +320,8 @@ __global__ __launch_bounds__(QGD_BLOCK) void implBcUKernel(const MeshView m, con
     RecA Ab = c.bA[b];
     if (bc.bcU == QGD_BC_FIXEDVALUE) { Ab.ux = bc.vU[0]; Ab.uy = bc.vU[1]; Ab.uz = bc.vU[2]; }
     else if (bc.bcU == QGD_BC_SLIP) {
-        const double ms = m.magSf[f];
-        const double n[3] = {m.Sx[f] / ms, m.Sy[f] / ms, m.Sz[f] / ms};
+        double n[3];
+        symmNormal(m, bc, f, n);
         const double u[3] = {Ao.ux, Ao.uy, Ao.uz};
         double r[3];
         for (int i = 0; i < 3; ++i) {

@@ -39,9 +39,15 @@ __device__ __forceinline__ int faceBlocksDev(const MeshView& m) { return (m.nIF 
 struct FaceState {
     double rhof, Uf[3], rhoUf[3], UrhoUf[9], pf, cf, Hf, gammaf, alphauf, muf, tauf;
     int implicitDiffusion;   // 1: the Navier-Stokes part of Pi and the Fourier part of q are left to the implicit solves
+    // the UPW instantiations only (a `div(phiJm,U|H) Gauss upwind` entry): the two cells' U and H, which of the two fluxes takes them
+    double Uo[3], Un[3], Ho, Hn;
+    int upwindU, upwindH;
 };
 
-template <bool DBG>
+// UPW: qgdFlux with a divSchemes entry `Gauss upwind` [QGDInterpolate.H L86-104 -> fvc::flux]: psi_f = lambda (psi_O - psi_N) + psi_N with
+// lambda = pos0(phiJm) (L0: upwind::weights, surfaceInterpolationScheme::interpolate); internal faces only -- a patch face keeps its patch
+// value, which is what s.Uf / s.Hf hold there, so the boundary kernel instantiates UPW = false
+template <bool DBG, bool UPW = false>
 __device__ __forceinline__ void qgdFluxes(const FaceState& s, const double* __restrict__ g, const double S[3],
                                           double out[5], double& phiwStar, double* __restrict__ dbg, size_t dbgStride) {
     double gR[3], gP[3], gE[3], gU[9];
@@ -89,11 +95,11 @@ __device__ __forceinline__ void qgdFluxes(const FaceState& s, const double* __re
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         phiPi[j] = S[0] * Pi[j] + S[1] * Pi[3 + j] + S[2] * Pi[6 + j];
-        phiJmU[j] = phiJm * s.Uf[j];
+        phiJmU[j] = phiJm * ((UPW && s.upwindU) ? lerpf(phiJm >= 0.0 ? 1.0 : 0.0, s.Uo[j], s.Un[j]) : s.Uf[j]);
         phiP[j] = S[j] * s.pf;
     }
     // energy [L119-139]
-    const double phiJmH = phiJm * s.Hf;
+    const double phiJmH = phiJm * ((UPW && s.upwindH) ? lerpf(phiJm >= 0.0 ? 1.0 : 0.0, s.Ho, s.Hn) : s.Hf);
 #if QGD_F_DIET
     const double rrho = rcpNewton(s.rhof);
     const double pr2 = s.pf * rrho * rrho;
@@ -136,7 +142,7 @@ __device__ __forceinline__ void loadVals(const RecA& a, double* o) {
 // What follows the gradient on an internal face: the 13 interpolations of updateFields.H, the flux algebra, the five
 // net fluxes, the face's share of the Courant number.  Shared by the loads-first kernels of the 2-D stencils below.
 // ---------------------------------------------------------------------------
-template <bool DBG>
+template <bool DBG, bool UPW = false>
 __device__ __forceinline__ void finishInternalFace(const MeshView& m, const CaseView& c, const GasModel& gm, const int f, const int o,
                                                    const int n, const RecA& Ao, const RecA& An, const RecB& Bo, const RecB& Bn,
                                                    const double w, const double hf, const double S[3], const double* __restrict__ g,
@@ -165,8 +171,13 @@ __device__ __forceinline__ void finishInternalFace(const MeshView& m, const Case
     s.muf = lerpf(w, muEffOf(gm, Bo.muQGD), muEffOf(gm, Bn.muQGD));
     s.tauf = lerpf(w, Bo.aOc, Bn.aOc) * hf;  // tauQGDf = lin(aQGD/c)*hQGDf [constScPrModel1_8C L103]
     s.implicitDiffusion = gm.implicitDiffusion;
+    if (UPW) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { s.Uo[k] = Uo[k]; s.Un[k] = Un[k]; }
+        s.Ho = Bo.H; s.Hn = Bn.H; s.upwindU = gm.upwindU; s.upwindH = gm.upwindH;
+    }
     double out[5], phiw;
-    qgdFluxes<DBG>(s, g, S, out, phiw, DBG ? c.dbg + f : nullptr, nF);
+    qgdFluxes<DBG, UPW>(s, g, S, out, phiw, DBG ? c.dbg + f : nullptr, nF);
 #pragma unroll
     for (int k = 0; k < 5; ++k) c.flux[(size_t)k * nF + fp] = out[k];
     if (adjustDt) {
@@ -187,7 +198,7 @@ __device__ __forceinline__ void finishInternalFace(const MeshView& m, const Case
 // gathered record; then the ordered accumulation out of registers.  Longer stencils finish in a loop.
 // ---------------------------------------------------------------------------
 #define QGD_LSQ_SLOTS 6
-template <bool DBG>
+template <bool DBG, bool UPW = false>
 __global__ __launch_bounds__(QGD_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 3)))
 void faceFluxLsqKernel(const MeshView m, const CaseView c, const GasModel gm, const int adjustDt) {
     const int tile = xcdTile((int)gridDim.x, m.xcdRun);
@@ -262,7 +273,7 @@ void faceFluxLsqKernel(const MeshView m, const CaseView c, const GasModel gm, co
                 }
             }
         }
-        finishInternalFace<DBG>(m, c, gm, f, o, n, Ao, An, Bo, Bn, w, hf, S, g, fp, adjustDt, cof, tauMin);
+        finishInternalFace<DBG, UPW>(m, c, gm, f, o, n, Ao, An, Bo, Bn, w, hf, S, g, fp, adjustDt, cof, tauMin);
     }
     if (adjustDt) blockMaxMin(cof, tauMin, c.blkFace + 2 * (size_t)tile, false);
 }
@@ -270,7 +281,7 @@ void faceFluxLsqKernel(const MeshView m, const CaseView c, const GasModel gm, co
 // ---------------------------------------------------------------------------
 // reduced stencil internal faces: nf (x) snGrad [reducedFaceNormalStencil_8C L69-108], loads-first.
 // ---------------------------------------------------------------------------
-template <bool DBG>
+template <bool DBG, bool UPW = false>
 __global__ __launch_bounds__(QGD_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 4)))
 void faceFluxReducedKernel(const MeshView m, const CaseView c, const GasModel gm, const int adjustDt) {
     const int tile = xcdTile((int)gridDim.x, m.xcdRun);
@@ -296,7 +307,7 @@ void faceFluxReducedKernel(const MeshView m, const CaseView c, const GasModel gm
             g[1 * 6 + k] = ny * sn;
             g[2 * 6 + k] = nz * sn;
         }
-        finishInternalFace<DBG>(m, c, gm, f, o, n, Ao, An, Bo, Bn, w, hf, S, g, fp, adjustDt, cof, tauMin);
+        finishInternalFace<DBG, UPW>(m, c, gm, f, o, n, Ao, An, Bo, Bn, w, hf, S, g, fp, adjustDt, cof, tauMin);
     }
     if (adjustDt) blockMaxMin(cof, tauMin, c.blkFace + 2 * (size_t)tile, false);
 }
@@ -305,7 +316,7 @@ void faceFluxReducedKernel(const MeshView m, const CaseView c, const GasModel gm
 // GaussVolPoint 2-D internal faces: the arithmetic of faceGradient<ST_GVP2> [GaussVolPointBase2D_8C L301-367], loads-first: labels and the
 // two face vertices; the streamed face data incl. the six coefficients; the two cell and two vertex records.
 // ---------------------------------------------------------------------------
-template <bool DBG>
+template <bool DBG, bool UPW = false>
 __global__ __launch_bounds__(QGD_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 4)))
 void faceFluxGvp2Kernel(const MeshView m, const CaseView c, const GasModel gm, const int adjustDt) {
     const int tile = xcdTile((int)gridDim.x, m.xcdRun);
@@ -336,7 +347,7 @@ void faceFluxGvp2Kernel(const MeshView m, const CaseView c, const GasModel gm, c
 #pragma unroll
             for (int d = 0; d < 3; ++d) g[d * 6 + k] = (d == ie1) ? g1 : ((d == ie2) ? g2 : 0.0);  // no dynamic register index
         }
-        finishInternalFace<DBG>(m, c, gm, f, o, n, Ao, An, Bo, Bn, w, hf, S, g, fp, adjustDt, cof, tauMin);
+        finishInternalFace<DBG, UPW>(m, c, gm, f, o, n, Ao, An, Bo, Bn, w, hf, S, g, fp, adjustDt, cof, tauMin);
     }
     if (adjustDt) blockMaxMin(cof, tauMin, c.blkFace + 2 * (size_t)tile, false);
 }
@@ -400,7 +411,7 @@ __device__ __forceinline__ void gvp3Coefs(const int kind, const double4& cO, con
 #endif
 // everything after the loads of one internal face: gradient coefficients from the geometry, the 6-component gradient, the 13
 // interpolations, the flux algebra, the five net fluxes (slot-major position fp), the face's share of the Courant number
-template <bool DBG>
+template <bool DBG, bool UPW = false>
 __device__ __forceinline__ void gvp3FaceBody(const MeshView& m, const CaseView& c, const GasModel& gm, const int f, const int fp, const int kind,
                                              const double w, const double hf, const double (&S)[3], const RecA& Ao, const RecA& An,
                                              const RecB& Bo, const RecB& Bn, const RecA& q0, const RecA& q1, const RecA& q2, const RecA& q3,
@@ -490,8 +501,13 @@ __device__ __forceinline__ void gvp3FaceBody(const MeshView& m, const CaseView& 
     s.muf = lerpf(w, muEffOf(gm, Bo.muQGD), muEffOf(gm, Bn.muQGD));
     s.tauf = lerpf(w, Bo.aOc, Bn.aOc) * hf;
     s.implicitDiffusion = gm.implicitDiffusion;
+    if (UPW) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { s.Uo[k] = Uo[k]; s.Un[k] = Un[k]; }
+        s.Ho = Bo.H; s.Hn = Bn.H; s.upwindU = gm.upwindU; s.upwindH = gm.upwindH;
+    }
     double out[5], phiw;
-    qgdFluxes<DBG>(s, g, S, out, phiw, DBG ? c.dbg + f : nullptr, nF);
+    qgdFluxes<DBG, UPW>(s, g, S, out, phiw, DBG ? c.dbg + f : nullptr, nF);
 #pragma unroll
     for (int k = 0; k < 5; ++k) c.flux[(size_t)k * nF + fp] = out[k];
     if (adjustDt) {
@@ -506,7 +522,7 @@ __device__ __forceinline__ void gvp3FaceBody(const MeshView& m, const CaseView& 
     }
 }
 
-template <bool DBG, int FB, bool SGEO = false>
+template <bool DBG, int FB, bool SGEO = false, bool UPW = false>
 __global__ __launch_bounds__(FB) __attribute__((amdgpu_waves_per_eu(QGD_F_WAVES_MIN, QGD_F_WAVES_MAX)))
 void faceFluxGvp3Kernel(const MeshView m, const CaseView c, const GasModel gm, const int adjustDt, const int32_t* __restrict__ tileList) {
     // tileList: the tiles the staged kernel below leaves to this one (nullptr: every tile)
@@ -538,7 +554,7 @@ void faceFluxGvp3Kernel(const MeshView m, const CaseView c, const GasModel gm, c
         double coef[12], rVc;
         gvp3Coefs(kind, cO, cN, x0, x1, x2, x3, coef, rVc);
         if (SGEO && kind == 0) { S[0] = 0.5 * coef[6]; S[1] = 0.5 * coef[7]; S[2] = 0.5 * coef[8]; }   // Sf = (p3-p1) x (p4-p2) / 2
-        gvp3FaceBody<DBG>(m, c, gm, f, fp, kind, w, hf, S, Ao, An, Bo, Bn, q0, q1, q2, q3, coef, rVc, msO, dnO, adjustDt, cof, tauMin);
+        gvp3FaceBody<DBG, UPW>(m, c, gm, f, fp, kind, w, hf, S, Ao, An, Bo, Bn, q0, q1, q2, q3, coef, rVc, msO, dnO, adjustDt, cof, tauMin);
     }
     if (adjustDt) blockMaxMin<FB>(cof, tauMin, c.blkFace + 2 * (size_t)tile, false);
 }
@@ -567,7 +583,7 @@ typedef double v2d __attribute__((ext_vector_type(2)));   // one 16-B piece
 // round trips -- list offsets -> labels -> pieces -> LDS -> algebra -- and with 6 workgroups per CU in flight the kernel's rate is
 // tiles in flight / length of that chain, not bytes (29 % fewer L2 misses under a pencil order: -1.6 % time,
 // profiles/r04_ab_pencil_xcd_matched.txt).  With computed offsets the chain is one round trip shorter.
-template <int FB, int WAVES, bool SGEO = false, bool FIXED = false>
+template <int FB, int WAVES, bool SGEO = false, bool FIXED = false, bool UPW = false>
 __global__ __launch_bounds__(FB) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
 void faceFluxGvp3TileKernel(const MeshView m, const CaseView c, const GasModel gm, const int adjustDt) {
     extern __shared__ v2d tileLds[];
@@ -699,14 +715,16 @@ void faceFluxGvp3TileKernel(const MeshView m, const CaseView c, const GasModel g
         const RecB Bo = *reinterpret_cast<const RecB*>(sB + 2 * lo), Bn = *reinterpret_cast<const RecB*>(sB + 2 * ln);
         const RecA q0 = *reinterpret_cast<const RecA*>(sP + 3 * v0), q1 = *reinterpret_cast<const RecA*>(sP + 3 * v1),
                    q2 = *reinterpret_cast<const RecA*>(sP + 3 * v2), q3 = *reinterpret_cast<const RecA*>(sP + 3 * v3);
-        gvp3FaceBody<false>(m, c, gm, f, fp, kind, w, hf, S, Ao, An, Bo, Bn, q0, q1, q2, q3, coef, rVc, msO, dnO, adjustDt, cof, tauMin);
+        gvp3FaceBody<false, UPW>(m, c, gm, f, fp, kind, w, hf, S, Ao, An, Bo, Bn, q0, q1, q2, q3, coef, rVc, msO, dnO, adjustDt, cof, tauMin);
     }
     if (adjustDt) blockMaxMin<FB>(cof, tauMin, c.blkFace + 2 * (size_t)tile, false);
 }
 
 // patch snGrad of the six case fields on boundary face (global label f)
+// perComponent: the 2-D GaussVolPoint gradient of U goes component by component [GaussVolPointBase.C L79-87], each a scalar field whose
+// patch field on a symmetryPlane / symmetry patch is the scalar symmetry one (L0: fvPatchField::New lets the constraint type win), snGrad = 0
 __device__ __forceinline__ void boundaryVals(const MeshView& m, const CaseView& c, const PatchBCDev& bc, const int f,
-                                             const RecA& Ao, const RecA& Ab, FaceVals<6>& v) {
+                                             const RecA& Ao, const RecA& Ab, FaceVals<6>& v, const bool perComponent) {
     const int b = f - m.nIF;
     loadVals(Ao, v.o);
     loadVals(Ab, v.n);
@@ -716,8 +734,8 @@ __device__ __forceinline__ void boundaryVals(const MeshView& m, const CaseView& 
     for (int k = 0; k < 6; ++k) v.sn[k] = dc * (v.n[k] - v.o[k]);  // fvPatchField::snGrad (L0)
     if (bc.bcU == QGD_BC_SLIP) {
         // basicSymmetry::snGrad (L0): (transform(I - 2 nn, pif) - pif)*(deltaCoeffs/2)
-        const double ms = m.magSf[f];
-        const double n[3] = {m.Sx[f] / ms, m.Sy[f] / ms, m.Sz[f] / ms};
+        double n[3];
+        symmNormal(m, bc, f, n);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const double tv = ((i == 0 ? 1.0 : 0.0) - 2.0 * (n[i] * n[0])) * v.o[1] + ((i == 1 ? 1.0 : 0.0) - 2.0 * (n[i] * n[1])) * v.o[2] +
@@ -730,6 +748,10 @@ __device__ __forceinline__ void boundaryVals(const MeshView& m, const CaseView& 
     if (bc.bcP == QGD_BC_QGDFLUX) v.sn[4] = c.bG[b];             // fixedGradient::snGrad = gradient()
     else if (bc.bcP != QGD_BC_FIXEDVALUE) v.sn[4] = 0.0;          // zeroGradient
     if (bc.bcT != QGD_BC_FIXEDVALUE) v.sn[5] = 0.0;               // gradientEnergy with zero gradient
+    if (bc.ptype == QGD_PATCH_SYMMETRYPLANE || bc.ptype == QGD_PATCH_SYMMETRY) {
+        v.sn[0] = 0.0;   // rho's calculated patch is the scalar symmetry patch there: snGrad = 0 whatever psi_b p_b rounds to
+        if (perComponent) v.sn[1] = v.sn[2] = v.sn[3] = 0.0;
+    }
 }
 
 template <int ST, bool DBG>
@@ -749,7 +771,7 @@ __global__ __launch_bounds__(QGD_BLOCK) void boundaryFaceFluxKernel(const MeshVi
             const RecA Ao = c.A[o], Ab = c.bA[b];
             const RecB Bb = c.bB[b];
             FaceVals<6> v;
-            boundaryVals(m, c, bc, f, Ao, Ab, v);
+            boundaryVals(m, c, bc, f, Ao, Ab, v, ST == ST_GVP2);
             double g[18];
             faceGradient<ST, 6, 1>(m, f, v, reinterpret_cast<const double*>(c.A), reinterpret_cast<const double*>(c.P), g);
             FaceState s;
@@ -1058,8 +1080,8 @@ __global__ __launch_bounds__(QGD_BLOCK) void boundaryUpdateKernel(const MeshView
     // U
     if (bc.bcU == QGD_BC_FIXEDVALUE) { Ab.ux = bc.vU[0]; Ab.uy = bc.vU[1]; Ab.uz = bc.vU[2]; }
     else if (bc.bcU == QGD_BC_SLIP) {
-        const double ms = m.magSf[f];
-        const double n[3] = {m.Sx[f] / ms, m.Sy[f] / ms, m.Sz[f] / ms};
+        double n[3];
+        symmNormal(m, bc, f, n);
         const double u[3] = {Ao.ux, Ao.uy, Ao.uz};
         double r[3];
 #pragma unroll
@@ -1222,6 +1244,12 @@ __global__ __launch_bounds__(QGD_BLOCK) void fvscOpKernel(const MeshView m, cons
         const double dc = m.dn[f];
 #pragma unroll
         for (int k = 0; k < NC; ++k) { v.n[k] = bndF[(size_t)b * NC + k]; v.sn[k] = dc * (v.n[k] - v.o[k]); }
+        // symmetryPlane / symmetry / wedge patches: a SCALAR patch field there has snGrad = 0 by type (L0: basicSymmetry / wedge
+        // specialisations), and the 2-D GaussVolPoint gradient of a vector sees three scalar fields [GaussVolPointBase.C L79-87]
+        if ((NC == 1 || (NC == 3 && OP == 0 && ST == ST_GVP2)) && m.bSymm && m.bSymm[b]) {
+#pragma unroll
+            for (int k = 0; k < NC; ++k) v.sn[k] = 0.0;
+        }
     }
     double g[3 * NC];
     // the vector-gradient operator (NC==3, OP==0) carries the interior-triangle pattern
@@ -1472,19 +1500,29 @@ void launchBoundaryPoints(const Launcher& L, const MeshView& m, const CaseView& 
     if (m.nBP == 0) return;
     if (pOnly)
         QGD_TIMED(L, QGD_K_BPOINT, (boundaryPointKernel<1><<<gridFor(m.nBP), QGD_BLOCK, 0, L.stream>>>(
-            m, c.bPmid, 1, reinterpret_cast<double*>(c.P), 6, 4)));
+            m, c.bPmid, 1, reinterpret_cast<double*>(c.P), 6, 4, -1)));
     else
         QGD_TIMED(L, QGD_K_BPOINT, (boundaryPointKernel<6><<<gridFor(m.nBP), QGD_BLOCK, 0, L.stream>>>(
-            m, reinterpret_cast<const double*>(c.bA), 6, reinterpret_cast<double*>(c.P), 6, 0)));
+            m, reinterpret_cast<const double*>(c.bA), 6, reinterpret_cast<double*>(c.P), 6, 0, m.nGeomD == 3 ? 1 : -1)));   // U of the records: a pointVectorField in 3-D only
 }
-template <bool DBG>
+template <bool DBG, bool UPW>
 static void launchFaceFluxT(const Launcher& L, int stencil, const MeshView& m, const CaseView& c, const GasModel& g, bool adj) {
     const int grid = gridFor(m.nIF);
     if (grid == 0) return;
     switch (stencil) {
-        case ST_REDUCED: faceFluxReducedKernel<DBG><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, adj); break;
-        case ST_LSQ: faceFluxLsqKernel<DBG><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, adj); break;
+        case ST_REDUCED: faceFluxReducedKernel<DBG, UPW><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, adj); break;
+        case ST_LSQ: faceFluxLsqKernel<DBG, UPW><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, adj); break;
         case ST_GVP3:
+            if constexpr (UPW) {
+                // `Gauss upwind` fluxes: the default tile configuration has its upwind instantiation, every other one takes the gather kernel
+                if (!DBG && m.tileOff != nullptr && m.fblock == 128 && m.tileWaves == 3 && m.sGeo && m.tileFlag) {
+                    faceFluxGvp3TileKernel<128, 3, true, true, true><<<(m.nIF + 127) / 128, 128, m.tileLds, L.stream>>>(m, c, g, adj);
+                    if (m.nTileSpill > 0) faceFluxGvp3Kernel<false, 128, true, true><<<m.nTileSpill, 128, 0, L.stream>>>(m, c, g, adj, m.tileSpill);
+                } else if (m.fblock == 64) faceFluxGvp3Kernel<DBG, 64, false, true><<<(m.nIF + 63) / 64, 64, 0, L.stream>>>(m, c, g, adj, nullptr);
+                else if (m.fblock == 128) faceFluxGvp3Kernel<DBG, 128, false, true><<<(m.nIF + 127) / 128, 128, 0, L.stream>>>(m, c, g, adj, nullptr);
+                else faceFluxGvp3Kernel<DBG, 256, false, true><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, adj, nullptr);
+                break;
+            }
             if (!DBG && m.tileOff != nullptr) {
                 if (m.fblock == 64) faceFluxGvp3TileKernel<64, 3><<<(m.nIF + 63) / 64, 64, m.tileLds, L.stream>>>(m, c, g, adj);
                 else if (m.fblock == 256) faceFluxGvp3TileKernel<256, 3><<<grid, QGD_BLOCK, m.tileLds, L.stream>>>(m, c, g, adj);
@@ -1505,12 +1543,13 @@ static void launchFaceFluxT(const Launcher& L, int stencil, const MeshView& m, c
             else if (m.fblock == 128) faceFluxGvp3Kernel<DBG, 128><<<(m.nIF + 127) / 128, 128, 0, L.stream>>>(m, c, g, adj, nullptr);
             else faceFluxGvp3Kernel<DBG, 256><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, adj, nullptr);
             break;
-        default: faceFluxGvp2Kernel<DBG><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, adj); break;
+        default: faceFluxGvp2Kernel<DBG, UPW><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, adj); break;
     }
 }
 void launchFaceFlux(const Launcher& L, int stencil, const MeshView& m, const CaseView& c, const GasModel& g, bool adjustDt) {
-    QGD_TIMED(L, QGD_K_FACE, (c.dbg ? launchFaceFluxT<true>(L, stencil, m, c, g, adjustDt)
-                                    : launchFaceFluxT<false>(L, stencil, m, c, g, adjustDt)));
+    const bool upw = g.upwindU || g.upwindH;
+    QGD_TIMED(L, QGD_K_FACE, (c.dbg ? (upw ? launchFaceFluxT<true, true>(L, stencil, m, c, g, adjustDt) : launchFaceFluxT<true, false>(L, stencil, m, c, g, adjustDt))
+                                    : (upw ? launchFaceFluxT<false, true>(L, stencil, m, c, g, adjustDt) : launchFaceFluxT<false, false>(L, stencil, m, c, g, adjustDt))));
 }
 template <bool DBG>
 static void launchBFaceFluxT(const Launcher& L, int stencil, const MeshView& m, const CaseView& c, const GasModel& g,
@@ -1608,7 +1647,11 @@ template <int ST, int NC>
 static void launchFvscOpT(hipStream_t s, int op, const MeshView& m, const double* cell, const double* bnd, double* pt, double* out) {
     if (ST == ST_GVP3 || ST == ST_GVP2) {
         pointInterpFastKernel<NC><<<gridFor(m.nP), QGD_BLOCK, 0, s>>>(m, cell, pt);
-        if (m.nBP) boundaryPointKernel<NC><<<gridFor(m.nBP), QGD_BLOCK, 0, s>>>(m, bnd, NC, pt, NC, 0);
+        // what the reference interpolates as a pointVectorField / pointTensorField: the 3-D operators [GaussVolPointBase3D.C L938, L969,
+        // L1000, L1026] and the 2-D divergences [GaussVolPointBase2D.C L376-382, L454-460]; the 2-D gradient of a vector goes
+        // component by component [GaussVolPointBase.C L79-87]
+        const int vecMode = NC == 9 ? -2 : ((NC == 3 && (op != 0 || ST == ST_GVP3)) ? 0 : -1);
+        if (m.nBP) boundaryPointKernel<NC><<<gridFor(m.nBP), QGD_BLOCK, 0, s>>>(m, bnd, NC, pt, NC, 0, vecMode);
     }
     if (ST == ST_GVP3 && op == 0 && NC <= 3) {
         // the drop-in path of updateFluxes.H: internal faces through the loads-first kernel, patch faces through the generic one
@@ -1652,6 +1695,26 @@ __global__ __launch_bounds__(QGD_BLOCK) void interpolateKernel(const MeshView m,
 void launchInterpolate(hipStream_t s, int NC, const MeshView& m, const double* cell, const double* bnd, double* out) {
     interpolateKernel<<<gridFor(m.nF), QGD_BLOCK, 0, s>>>(m, NC, cell, bnd, out);
 }
+// qgdFlux with a `Gauss upwind` entry [QGDInterpolate_8H L86-104 -> fvc::flux]: flux * (pos0(flux) (psi_O - psi_N) + psi_N), the patch
+// value on patch faces (L0: upwind::weights, surfaceInterpolationScheme::interpolate)
+__global__ __launch_bounds__(QGD_BLOCK) void fluxUpwindKernel(const MeshView m, const int NC, const double* __restrict__ flux,
+                                                             const double* __restrict__ cell, const double* __restrict__ bnd,
+                                                             double* __restrict__ out) {
+    const int f = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    if (f >= m.nF) return;
+    const double phi = flux[f];
+    if (f < m.nIF) {
+        const int o = m.own[f], n = m.nei[f];
+        const double lambda = phi >= 0.0 ? 1.0 : 0.0;
+        for (int k = 0; k < NC; ++k) out[(size_t)f * NC + k] = phi * lerpf(lambda, cell[(size_t)o * NC + k], cell[(size_t)n * NC + k]);
+    } else {
+        const bool live = m.fkind[f] != 3;
+        for (int k = 0; k < NC; ++k) out[(size_t)f * NC + k] = live ? phi * bnd[(size_t)(f - m.nIF) * NC + k] : 0.0;
+    }
+}
+void launchFluxUpwind(hipStream_t s, int NC, const MeshView& m, const double* flux, const double* cell, const double* bnd, double* out) {
+    fluxUpwindKernel<<<gridFor(m.nF), QGD_BLOCK, 0, s>>>(m, NC, flux, cell, bnd, out);
+}
 
 template <int ST>
 static void launchQhdT(hipStream_t s, const MeshView& m, const double* cell5, const double* bnd5, double* pt5, const double* rho,
@@ -1659,7 +1722,7 @@ static void launchQhdT(hipStream_t s, const MeshView& m, const double* cell5, co
                        double* out) {
     if (ST == ST_GVP3 || ST == ST_GVP2) {
         pointInterpKernel<5><<<gridFor(m.nP), QGD_BLOCK, 0, s>>>(m, cell5, 5, pt5);
-        if (m.nBP) boundaryPointKernel<5><<<gridFor(m.nBP), QGD_BLOCK, 0, s>>>(m, bnd5, 5, pt5, 5, 0);
+        if (m.nBP) boundaryPointKernel<5><<<gridFor(m.nBP), QGD_BLOCK, 0, s>>>(m, bnd5, 5, pt5, 5, 0, ST == ST_GVP3 ? 0 : -1);
     }
     qhdFaceKernel<ST><<<gridFor(m.nF), QGD_BLOCK, 0, s>>>(m, cell5, bnd5, pt5, rho, rhob, tau, phi, beta, gx, gy, gz, out);
 }
@@ -1776,7 +1839,7 @@ static void launchSpeciesT(hipStream_t s, const MeshView& m, const double* Y, co
                            const double* Ub, const double* phiJm, const double* phi, const double* tau, double* out) {
     if (ST == ST_GVP3 || ST == ST_GVP2) {
         pointInterpKernel<1><<<gridFor(m.nP), QGD_BLOCK, 0, s>>>(m, Y, 1, ptY);
-        if (m.nBP) boundaryPointKernel<1><<<gridFor(m.nBP), QGD_BLOCK, 0, s>>>(m, Yb, 1, ptY, 1, 0);
+        if (m.nBP) boundaryPointKernel<1><<<gridFor(m.nBP), QGD_BLOCK, 0, s>>>(m, Yb, 1, ptY, 1, 0, -1);
     }
     speciesFaceKernel<ST><<<gridFor(m.nF), QGD_BLOCK, 0, s>>>(m, Y, Yb, ptY, U, Ub, phiJm, phi, tau, out);
 }

@@ -155,6 +155,14 @@ void HostMesh::computeDerived() {
             }
         }
     }
+    // the patch normal of symmetry planes (see Patch::nHat)
+    for (Patch& pt : patches) {
+        if (pt.type != QGD_PATCH_SYMMETRYPLANE || pt.nHatInherited || pt.size <= 0) continue;
+        double sum[3] = {0, 0, 0};
+        for (int32_t f = pt.start; f < pt.start + pt.size; ++f)
+            for (int k = 0; k < 3; ++k) sum[k] += Sf[3 * (size_t)f + k] / magSf[f];
+        for (int k = 0; k < 3; ++k) pt.nHat[k] = sum[k] / (double)pt.size;
+    }
     // geometric directions from empty patches
     double dirVec[3] = {0, 0, 0};
     bool hasEmpty = false;

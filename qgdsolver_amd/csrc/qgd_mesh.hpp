@@ -22,6 +22,12 @@ struct Patch {
     int32_t start = 0;  // global label of first face
     int32_t size = 0;
     int32_t globalSize = -1;  // faces of this patch in the unsharded mesh (-1: this mesh is the whole mesh)
+    // symmetryPlane patches: the ONE normal of the patch, the average of its faces' unit normals (L0 assumption:
+    // symmetryPlanePolyPatch::calcGeometry, n_ = gAverage(faceNormals())), which symmetryPlaneFvPatchField uses on every face
+    // instead of the face's own normal.  A shard inherits the normal of the whole patch (extractShard) so that cut and uncut
+    // meshes agree bit for bit.
+    double nHat[3] = {0.0, 0.0, 0.0};
+    bool nHatInherited = false;
     bool nonEmptyGlobally() const { return (globalSize >= 0 ? globalSize : size) > 0; }
 };
 

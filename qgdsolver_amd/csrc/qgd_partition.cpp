@@ -233,6 +233,7 @@ HostMesh extractShard(const HostMesh& g, int32_t nRanks, const int32_t* cellStar
     for (const Patch& gp : g.patches) {
         Patch p = gp;
         p.globalSize = gp.globalSize >= 0 ? gp.globalSize : gp.size;
+        p.nHatInherited = gp.type == QGD_PATCH_SYMMETRYPLANE && (gp.nHatInherited || gp.size > 0);   // the whole patch's normal, not the shard's
         p.start = (int32_t)m.owner.size();
         for (int32_t f = gp.start; f < gp.start + gp.size; ++f) {
             const int32_t a = localOf[g.owner[f]];

@@ -21,14 +21,16 @@ namespace {
 
 // patch snGrad of {U,T} (4 components) on boundary face f: fvPatchField::snGrad = deltaCoeffs*(value - internal) (L0);
 // basicSymmetry::snGrad for slip
+// perComponent (the 2-D GaussVolPoint gradient of U [GaussVolPointBase.C L79-87]: one scalar field per component, whose patch field on a
+// symmetryPlane / symmetry patch is the scalar symmetry one, snGrad = 0 -- L0: fvPatchField::New lets the constraint patch type win)
 __device__ __forceinline__ void qhdBoundaryVals4(const MeshView& m, const PatchBCDev& bc, const int f, const double* o4, const double* b4,
-                                                 FaceVals<4>& v) {
+                                                 FaceVals<4>& v, const bool perComponent = false) {
     const double dc = m.dn[f];
 #pragma unroll
     for (int k = 0; k < 4; ++k) { v.o[k] = o4[k]; v.n[k] = b4[k]; v.sn[k] = dc * (b4[k] - o4[k]); }
     if (bc.bcU == QGD_BC_SLIP) {
-        const double ms = m.magSf[f];
-        const double n[3] = {m.Sx[f] / ms, m.Sy[f] / ms, m.Sz[f] / ms};
+        double n[3];
+        symmNormal(m, bc, f, n);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const double tv = ((i == 0 ? 1.0 : 0.0) - 2.0 * (n[i] * n[0])) * o4[0] + ((i == 1 ? 1.0 : 0.0) - 2.0 * (n[i] * n[1])) * o4[1] +
@@ -37,6 +39,7 @@ __device__ __forceinline__ void qhdBoundaryVals4(const MeshView& m, const PatchB
         }
     } else if (bc.bcU != QGD_BC_FIXEDVALUE) v.sn[0] = v.sn[1] = v.sn[2] = 0.0;
     if (bc.bcT != QGD_BC_FIXEDVALUE) v.sn[3] = 0.0;
+    if (perComponent && (bc.ptype == QGD_PATCH_SYMMETRYPLANE || bc.ptype == QGD_PATCH_SYMMETRY)) v.sn[0] = v.sn[1] = v.sn[2] = 0.0;
 }
 
 // face pass 1 [updateFields.H L36-73, updateFluxes.H L33-38, QHDTEqn.H L66]
@@ -59,7 +62,7 @@ __global__ __launch_bounds__(QGD_BLOCK) void qhdFace1Kernel(const MeshView m, co
         w = m.w[f];
     } else {
         const int b = f - m.nIF;
-        qhdBoundaryVals4(m, bcs[m.bPatch[b]], f, q.c4 + (size_t)o * 4, q.b4 + (size_t)b * 4, v);
+        qhdBoundaryVals4(m, bcs[m.bPatch[b]], f, q.c4 + (size_t)o * 4, q.b4 + (size_t)b * 4, v, ST == ST_GVP2);
     }
     double g[12];
     faceGradient<ST, 4, 0>(m, f, v, q.c4, q.pt4, g);   // g[i*4 + k] = d_i {Ux,Uy,Uz,T}_k
@@ -195,15 +198,18 @@ __global__ __launch_bounds__(QGD_BLOCK) void qhdFace2Kernel(const MeshView m, co
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const double uw = S[0] * (Uf[0] * Wf[j]) + S[1] * (Uf[1] * Wf[j]) + S[2] * (Uf[2] * Wf[j]);   // Sf & (Uf*Wf), L39
-        const double phiUf = phi * Uf[j] - uw;                                                       // L41-43
+        // qgdFlux(phi,U,Uf) [L41]: phi*Uf, or with `div(phi,U) Gauss upwind` fvc::flux = phi * (pos0(phi) (U_O - U_N) + U_N) inside,
+        // the patch value on patch faces [QGDInterpolate.H L86-104]
+        const double phiUf = phi * ((q.upwindU && internal) ? lerpf(phi >= 0.0 ? 1.0 : 0.0, Uo[j], Un[j]) : Uf[j]) - uw;   // L41-43
         const double lap = q.nu * snU[j] * magS;                                                     // fvc::laplacian(muf/rhof, U), L74
         const double ext = S[0] * gUT[0 * 3 + j] + S[1] * gUT[1 * 3 + j] + S[2] * gUT[2 * 3 + j];    // Sf & lin(T(grad U)), L56 / L76
         // the Gauss term of -fvc::grad(p)/rho (uniform rho) rides in the same face flux: S_j p_f / rho;
         // implicitDiffusion: the laplacian sits in the matrix (fvm::laplacian, L54)
         q.F[(size_t)j * nF + pos] = (q.implicit ? phiUf - q.nu * ext : (phiUf - lap) - q.nu * ext) + (S[j] * pf) / q.rho0;
     }
-    q.F[3 * nF + pos] = q.implicit ? phi * Tf - q.phitr[f]                                             // QHDTEqn.H L73-76
-                                   : (phi * Tf - q.Hi * snT * magS) - q.phitr[f];                      // QHDTEqn.H L65-66, L85-88
+    const double phiTf = phi * ((q.upwindT && internal) ? lerpf(phi >= 0.0 ? 1.0 : 0.0, To, Tn) : Tf);   // qgdFlux(phi,T,Tf) [QHDTEqn.H L65]
+    q.F[3 * nF + pos] = q.implicit ? phiTf - q.phitr[f]                                                // QHDTEqn.H L73-76
+                                   : (phiTf - q.Hi * snT * magS) - q.phitr[f];                         // QHDTEqn.H L65-66, L85-88
 }
 
 // ---------------------------------------------------------------------------
@@ -364,12 +370,13 @@ __global__ __launch_bounds__(kQhdFB) void qhdFace2TileKernel(const MeshView m, c
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const double uw = S[0] * (Uf[0] * Wf[j]) + S[1] * (Uf[1] * Wf[j]) + S[2] * (Uf[2] * Wf[j]);   // Sf & (Uf*Wf), L39
-        const double phiUf = phi * Uf[j] - uw;                                                       // L41-43
+        const double phiUf = phi * (q.upwindU ? lerpf(phi >= 0.0 ? 1.0 : 0.0, Uo[j], Un[j]) : Uf[j]) - uw;   // L41-43 (upwind: see qhdFace2Kernel)
         const double lap = q.nu * snU[j] * magS;                                                     // fvc::laplacian(muf/rhof, U), L74
         const double ext = S[0] * gUT[0 * 3 + j] + S[1] * gUT[1 * 3 + j] + S[2] * gUT[2 * 3 + j];    // Sf & lin(T(grad U)), L56 / L76
         q.F[(size_t)j * nF + pos] = (q.implicit ? phiUf - q.nu * ext : (phiUf - lap) - q.nu * ext) + (S[j] * pf) / q.rho0;
     }
-    q.F[3 * nF + pos] = q.implicit ? phi * Tf - phitr : (phi * Tf - q.Hi * snT * magS) - phitr;   // QHDTEqn.H L65-66, L73-76, L85-88
+    const double phiTf = phi * (q.upwindT ? lerpf(phi >= 0.0 ? 1.0 : 0.0, To, Tn) : Tf);
+    q.F[3 * nF + pos] = q.implicit ? phiTf - phitr : (phiTf - q.Hi * snT * magS) - phitr;   // QHDTEqn.H L65-66, L73-76, L85-88
 }
 
 // explicit Euler of the U and T equations [QHDUEqn.H L68-84, QHDTEqn.H L83-91]
@@ -442,8 +449,8 @@ __device__ __forceinline__ void qhdPatchCoeffs(const MeshView& m, const PatchBCD
 #pragma unroll
         for (int k = 0; k < 3; ++k) { ic[k] = dc; bs[k] = dc * bc.vU[k]; }
     } else if (bc.bcU == QGD_BC_SLIP) {
-        const double ms = m.magSf[f];
-        const double n[3] = {m.Sx[f] / ms, m.Sy[f] / ms, m.Sz[f] / ms};
+        double n[3];
+        symmNormal(m, bc, f, n);
 #pragma unroll
         for (int k = 0; k < 3; ++k) ic[k] = dc * fabs(n[k]);
         if (cur) {
@@ -560,8 +567,8 @@ __global__ __launch_bounds__(QGD_BLOCK) void qhdBcKernel(const MeshView m, const
     double* b4 = q.b4 + (size_t)b * 4;
     if (bc.bcU == QGD_BC_FIXEDVALUE) { b4[0] = bc.vU[0]; b4[1] = bc.vU[1]; b4[2] = bc.vU[2]; }
     else if (bc.bcU == QGD_BC_SLIP) {
-        const double ms = m.magSf[f];
-        const double n[3] = {m.Sx[f] / ms, m.Sy[f] / ms, m.Sz[f] / ms};
+        double n[3];
+        symmNormal(m, bc, f, n);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const double tv = ((i == 0 ? 1.0 : 0.0) - 2.0 * (n[i] * n[0])) * o4[0] + ((i == 1 ? 1.0 : 0.0) - 2.0 * (n[i] * n[1])) * o4[1] +
@@ -693,7 +700,7 @@ void launchQhdInit(hipStream_t s, const MeshView& m, const QhdView& q, const Pat
 void launchQhdAssemble(hipStream_t s, int stencil, bool usesPoints, const MeshView& m, const QhdView& q, const PatchBCDev* bc) {
     if (usesPoints) {
         pointInterpFastKernel<4><<<gridOf(m.nP), QGD_BLOCK, 0, s>>>(m, q.c4, q.pt4);
-        if (m.nBP) boundaryPointKernel<4><<<gridOf(m.nBP), QGD_BLOCK, 0, s>>>(m, q.b4, 4, q.pt4, 4, 0);
+        if (m.nBP) boundaryPointKernel<4><<<gridOf(m.nBP), QGD_BLOCK, 0, s>>>(m, q.b4, 4, q.pt4, 4, 0, m.nGeomD == 3 ? 0 : -1);
     }
     switch (stencil) {
         case ST_REDUCED: face1<ST_REDUCED>(s, m, q, bc); break;
@@ -716,7 +723,7 @@ void launchQhdAdvance(hipStream_t s, int stencil, bool usesPoints, const MeshVie
                       int localRefCell, double refValue, double* shift) {
     if (usesPoints) {
         pointInterpFastKernel<1><<<gridOf(m.nP), QGD_BLOCK, 0, s>>>(m, q.p, q.ptp);
-        if (m.nBP) boundaryPointKernel<1><<<gridOf(m.nBP), QGD_BLOCK, 0, s>>>(m, q.pb, 1, q.ptp, 1, 0);
+        if (m.nBP) boundaryPointKernel<1><<<gridOf(m.nBP), QGD_BLOCK, 0, s>>>(m, q.pb, 1, q.ptp, 1, 0, -1);
     }
     switch (stencil) {
         case ST_REDUCED: face2<ST_REDUCED>(s, m, q, bc); break;
@@ -737,7 +744,7 @@ void launchQhdImplicitAdvance(hipStream_t s, int stencil, bool usesPoints, const
     if (part == 0) {
         if (usesPoints) {
             pointInterpFastKernel<1><<<gridOf(m.nP), QGD_BLOCK, 0, s>>>(m, q.p, q.ptp);
-            if (m.nBP) boundaryPointKernel<1><<<gridOf(m.nBP), QGD_BLOCK, 0, s>>>(m, q.pb, 1, q.ptp, 1, 0);
+            if (m.nBP) boundaryPointKernel<1><<<gridOf(m.nBP), QGD_BLOCK, 0, s>>>(m, q.pb, 1, q.ptp, 1, 0, -1);
         }
         switch (stencil) {
             case ST_REDUCED: face2<ST_REDUCED>(s, m, q, bc); break;

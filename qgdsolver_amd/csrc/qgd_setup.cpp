@@ -14,6 +14,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <stdexcept>
+#include <unordered_map>
 
 #include "../../include/qgd_amd.h"
 
@@ -62,11 +63,120 @@ static void toSlicedEll(const std::vector<int32_t>& off, int64_t nRows, const st
 int64_t StaticData::bytes() const {
     auto sz = [](auto& v) { return (int64_t)(v.size() * sizeof(v[0])); };
     int64_t b = sz(own) + sz(nei) + sz(verts) + sz(fkind) + sz(magSf) + sz(w) + sz(hf) + sz(dn) + sz(X) + sz(Cc) + sz(bN) +
-                sz(bmvON) + sz(ip13) + sz(c2d) + sz(lsqSlice) + sz(lsqCnt) + sz(lsqCell) + sz(lsqGx) + sz(lsqGy) + sz(lsqGz) + sz(lsqDeg) + sz(lsqBndZero) +
-                sz(pcSlice) + sz(pcCount) + sz(pcCell) + sz(pcW) + sz(bpPoint) + sz(bpOff) + sz(bpFace) + sz(bpW) + sz(cfSlice) + sz(cfCount) + sz(cfItem) + sz(cfNbr) + sz(fpos) + sz(cfPos) +
+                sz(bmvON) + sz(ip13) + sz(c2d) + sz(lsqSlice) + sz(lsqCnt) + sz(lsqCell) + sz(lsqGx) + sz(lsqGy) + sz(lsqGz) + sz(lsqDeg) + sz(lsqBndZero) + sz(bSymm) +
+                sz(pcSlice) + sz(pcCount) + sz(pcCell) + sz(pcW) + sz(bpPoint) + sz(bpOff) + sz(bpFace) + sz(bpW) + sz(cpOff) + sz(cpKind) + sz(cpT) + sz(cfSlice) + sz(cfCount) + sz(cfItem) + sz(cfNbr) + sz(fpos) + sz(cfPos) +
                 sz(V) + sz(hQGD) + sz(ghost) + sz(bPatch) + sz(hQGDb);
     for (int k = 0; k < 3; ++k) b += sz(Sf[k]);
     return b;
+}
+
+// ---- point constraints (StaticData::cpOff / cpKind / cpT) ------------------------------------------------------------------------------
+// L0 assumptions restated from OpenFOAM v2312: symmetryPlanePointPatchField / symmetryPointPatchField / wedgePointPatchField::evaluate,
+// PrimitivePatch::calcPointNormals (sum of the unit normals of the point's patch faces, divided by its magnitude + VSMALL),
+// pointConstraints::makePatchPatchAddressing (every patch applies its constraint at the points of its rim = the end points of
+// patch edges with one patch face), pointConstraint::applyConstraint / constraintTransformation.
+namespace {
+struct PointConstraint {
+    int first = 0;
+    double second[3] = {0, 0, 0};
+    void apply(const double cd[3]) {
+        if (first == 0) { first = 1; for (int k = 0; k < 3; ++k) second[k] = cd[k]; }
+        else if (first == 1) {
+            const double pn[3] = {cd[1] * second[2] - cd[2] * second[1], cd[2] * second[0] - cd[0] * second[2], cd[0] * second[1] - cd[1] * second[0]};
+            const double mg = std::sqrt(pn[0] * pn[0] + pn[1] * pn[1] + pn[2] * pn[2]);
+            if (mg > 1e-3) { first = 2; for (int k = 0; k < 3; ++k) second[k] = pn[k] / mg; }
+        } else if (first == 2) {
+            if (std::fabs(cd[0] * second[0] + cd[1] * second[1] + cd[2] * second[2]) > 1e-3) { first = 3; second[0] = second[1] = second[2] = 0.0; }
+        }
+    }
+    void transformation(double T[9]) const {
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                const double ss = second[i] * second[j];
+                T[3 * i + j] = first == 1 ? (i == j ? 1.0 : 0.0) - ss : (first == 2 ? ss : 0.0);
+            }
+    }
+};
+}  // namespace
+
+static void buildPointConstraints(const HostMesh& m, const std::vector<int32_t>& bpSlot, StaticData& s) {
+    bool any = false;
+    for (const Patch& pt : m.patches)
+        if (pt.size > 0 && (pt.type == QGD_PATCH_SYMMETRYPLANE || pt.type == QGD_PATCH_SYMMETRY || pt.type == QGD_PATCH_WEDGE)) any = true;
+    if (!any) return;
+    const size_t nBP = s.bpPoint.size();
+    std::vector<std::vector<uint8_t>> kinds(nBP);
+    std::vector<std::vector<double>> tens(nBP);
+    std::vector<PointConstraint> corner(nBP);
+    auto pushOp = [&](int32_t slot, uint8_t kind, const double T[9]) {
+        kinds[(size_t)slot].push_back(kind);
+        tens[(size_t)slot].insert(tens[(size_t)slot].end(), T, T + 9);
+    };
+    for (const Patch& pt : m.patches) {
+        if (pt.size <= 0 || !(pt.type == QGD_PATCH_SYMMETRYPLANE || pt.type == QGD_PATCH_SYMMETRY || pt.type == QGD_PATCH_WEDGE)) continue;
+        // meshPoints of the patch in order of appearance, their point normals, the rim of the patch
+        std::vector<int32_t> meshPoints;
+        std::unordered_map<int32_t, int32_t> local;
+        std::vector<double> pn;   // 3 per patch point: sum of the unit normals of its patch faces (ascending face label)
+        std::unordered_map<uint64_t, int32_t> edgeFaces;
+        for (int32_t f = pt.start; f < pt.start + pt.size; ++f) {
+            const double nf[3] = {m.Sf[3 * (size_t)f] / m.magSf[f], m.Sf[3 * (size_t)f + 1] / m.magSf[f], m.Sf[3 * (size_t)f + 2] / m.magSf[f]};
+            const int32_t b = m.faceOffsets[f], e = m.faceOffsets[f + 1];
+            for (int32_t q = b; q < e; ++q) {
+                const int32_t p = m.facePoints[q];
+                auto it = local.find(p);
+                int32_t lp;
+                if (it == local.end()) { lp = (int32_t)meshPoints.size(); local.emplace(p, lp); meshPoints.push_back(p); pn.insert(pn.end(), {0.0, 0.0, 0.0}); }
+                else lp = it->second;
+                for (int k = 0; k < 3; ++k) pn[3 * (size_t)lp + k] += nf[k];
+                const int32_t p2 = m.facePoints[q + 1 < e ? q + 1 : b];
+                const uint64_t key = ((uint64_t)(uint32_t)std::min(p, p2) << 32) | (uint32_t)std::max(p, p2);
+                edgeFaces[key]++;
+            }
+        }
+        for (size_t lp = 0; lp < meshPoints.size(); ++lp) {
+            double* v = &pn[3 * lp];
+            const double mg = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]) + 1e-300;
+            for (int k = 0; k < 3; ++k) v[k] /= mg;
+        }
+        auto normalAt = [&](int32_t lp, double n[3]) {
+            if (pt.type == QGD_PATCH_SYMMETRYPLANE) { for (int k = 0; k < 3; ++k) n[k] = pt.nHat[k]; }
+            else if (pt.type == QGD_PATCH_WEDGE) { for (int k = 0; k < 3; ++k) n[k] = pn[k]; }   // wedgePointPatchField: pointNormals()[0]
+            else { for (int k = 0; k < 3; ++k) n[k] = pn[3 * (size_t)lp + k]; }
+        };
+        for (size_t lp = 0; lp < meshPoints.size(); ++lp) {
+            const int32_t slot = bpSlot[(size_t)meshPoints[lp]];
+            if (slot < 0) continue;
+            double n[3], T[9];
+            normalAt((int32_t)lp, n);
+            const double two = pt.type == QGD_PATCH_WEDGE ? 1.0 : 2.0;
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) T[3 * i + j] = (i == j ? 1.0 : 0.0) - two * (n[i] * n[j]);
+            pushOp(slot, pt.type == QGD_PATCH_WEDGE ? 1 : 0, T);
+        }
+        std::vector<uint8_t> onRim(meshPoints.size(), 0);
+        for (const auto& ef : edgeFaces)
+            if (ef.second == 1) { onRim[(size_t)local[(int32_t)(ef.first >> 32)]] = 1; onRim[(size_t)local[(int32_t)(ef.first & 0xffffffffu)]] = 1; }
+        for (size_t lp = 0; lp < meshPoints.size(); ++lp) {
+            if (!onRim[lp]) continue;
+            const int32_t slot = bpSlot[(size_t)meshPoints[lp]];
+            if (slot < 0) continue;
+            double n[3];
+            // the constraint direction of the patch at this point: symmetryPlanePointPatch / wedgePointPatch::applyConstraint use the
+            // patch normal (wedgePolyPatch::n() = the average face normal; for a planar wedge = the first point normal), symmetry its point normal
+            normalAt((int32_t)lp, n);
+            corner[(size_t)slot].apply(n);
+        }
+    }
+    s.cpOff.assign(nBP + 1, 0);
+    for (size_t i = 0; i < nBP; ++i) {
+        if (corner[i].first != 0) { double T[9]; corner[i].transformation(T); pushOp((int32_t)i, 1, T); }
+        s.cpOff[i + 1] = s.cpOff[i] + (int32_t)kinds[i].size();
+    }
+    s.cpKind.reserve((size_t)s.cpOff[nBP]); s.cpT.reserve(9 * (size_t)s.cpOff[nBP]);
+    for (size_t i = 0; i < nBP; ++i) {
+        s.cpKind.insert(s.cpKind.end(), kinds[i].begin(), kinds[i].end());
+        s.cpT.insert(s.cpT.end(), tens[i].begin(), tens[i].end());
+    }
 }
 
 StaticData buildStaticData(const HostMesh& m) {
@@ -220,6 +330,15 @@ StaticData buildStaticData(const HostMesh& m) {
         s.lsqBndZero[b] = (t == QGD_PATCH_EMPTY || t == QGD_PATCH_WEDGE || t == QGD_PATCH_CYCLIC || t == QGD_PATCH_HALO ||
                            t == QGD_PATCH_SYMMETRY || t == QGD_PATCH_SYMMETRYPLANE) ? 1 : 0;
     }
+    {
+        bool anySymm = false;
+        for (int64_t b = 0; b < nBF; ++b) anySymm = anySymm || patchType[b] == QGD_PATCH_SYMMETRYPLANE || patchType[b] == QGD_PATCH_SYMMETRY || patchType[b] == QGD_PATCH_WEDGE;
+        if (anySymm) {
+            s.bSymm.assign((size_t)nBF, 0);
+            for (int64_t b = 0; b < nBF; ++b)
+                s.bSymm[b] = (patchType[b] == QGD_PATCH_SYMMETRYPLANE || patchType[b] == QGD_PATCH_SYMMETRY || patchType[b] == QGD_PATCH_WEDGE) ? 1 : 0;
+        }
+    }
     if (m.nGeometricD < 3) {
         std::vector<int32_t> lsqOff((size_t)nIF + 1, 0), lsqCellCsr;
         std::vector<double> gwCsr[3];
@@ -353,6 +472,7 @@ StaticData buildStaticData(const HostMesh& m) {
             for (int32_t k = s.bpOff[i]; k < s.bpOff[i + 1]; ++k) sum += s.bpW[k];
             for (int32_t k = s.bpOff[i]; k < s.bpOff[i + 1]; ++k) s.bpW[k] /= sum;
         }
+        buildPointConstraints(m, slot, s);
     }
 
     // ---- cells ---------------------------------------------------------------------

@@ -51,6 +51,7 @@ struct StaticData {
     std::vector<double> lsqGx, lsqGy, lsqGz;
     std::vector<uint8_t> lsqDeg;  // nIF
     std::vector<uint8_t> lsqBndZero;  // nBF: 1 on constraint patches (gradient left zero)
+    std::vector<uint8_t> bSymm;       // nBF: 1 on symmetryPlane / symmetry / wedge patches (empty: none) -- scalar patch fields there have snGrad = 0 by type
 
     // ---- points -------------------------------------------------------------
     // point -> cells in sliced-ELL form: a slice is 64 consecutive points (one wavefront); entry i of the 64
@@ -65,6 +66,16 @@ struct StaticData {
     std::vector<int32_t> bpOff;   // bpPoint.size()+1
     std::vector<int32_t> bpFace;  // boundary-face index (global label - nIF)
     std::vector<double> bpW;
+    // Point constraints of VECTOR / TENSOR vertex fields (L0 assumption: volPointInterpolation::interpolateBoundaryField ends with
+    // pointConstraints::constrain): per patch point (row i of bpPoint) the operations cpOff[i] .. cpOff[i+1], applied in order to the
+    // weighted mean of the patch-face values.  kind 0: x = (x + transform(T, x))/2 with T = I - 2 nn -- the evaluate() of a
+    // symmetryPlane (n = the patch normal) or symmetry (n = the point normal) point patch, in patch order; kind 1: x = transform(T, x)
+    // -- a wedge point patch (T = I - nn) and, last, the patch-patch ("corner") constraint of points on the rim of one or more
+    // constraint patches (T = I - nn | the edge direction squared | 0 for one | two | three independent normals).  Scalars are
+    // untouched (transform is the identity on them).  Empty when the mesh has no symmetryPlane / symmetry / wedge patch.
+    std::vector<int32_t> cpOff;   // bpPoint.size()+1 (empty: no constraints)
+    std::vector<uint8_t> cpKind;
+    std::vector<double> cpT;      // 9 per operation, row-major
 
     // ---- cells --------------------------------------------------------------
     // cell -> faces flux gather list, sliced-ELL like pc*; rows in ascending face label (== the summation order of

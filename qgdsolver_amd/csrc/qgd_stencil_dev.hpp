@@ -28,6 +28,14 @@ __device__ __forceinline__ double rcpNewton(const double x) {
     return r;
 }
 
+// the normal a slip / symmetry / symmetryPlane patch reflects about on boundary face f: the face's own unit normal
+// (basicSymmetryFvPatchField: patch().nf()), or the patch's one normal on a symmetryPlane (PatchBCDev::nHat)
+__device__ __forceinline__ void symmNormal(const MeshView& m, const PatchBCDev& bc, const int f, double n[3]) {
+    if (bc.planeN) { n[0] = bc.nHat[0]; n[1] = bc.nHat[1]; n[2] = bc.nHat[2]; return; }
+    const double ms = m.magSf[f];
+    n[0] = m.Sx[f] / ms; n[1] = m.Sy[f] / ms; n[2] = m.Sz[f] / ms;
+}
+
 // geometry records are packed triples (24 B): the face kernels pay for every byte their gathers pull in, padding included
 __device__ __forceinline__ double4 ld3(const double* __restrict__ base, const int i) {
     const double* p = base + 3 * (size_t)i;
@@ -322,13 +330,34 @@ __device__ __forceinline__ int xcdTile(int nTiles, int run = 0) {
     return ((i / run) * 8 + xcd) * run + (i % run);
 }
 
+// transform(T, v) = T & v and transform(T, A) = T & A & T^T (L0: transform.H), T row-major
+__device__ __forceinline__ void transformVec(const double* __restrict__ T, const double v[3], double out[3]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) out[i] = T[3 * i] * v[0] + T[3 * i + 1] * v[1] + T[3 * i + 2] * v[2];
+}
+__device__ __forceinline__ void transformTen(const double* __restrict__ T, const double A[9], double out[9]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            double acc = 0.0;
+#pragma unroll
+            for (int l = 0; l < 3; ++l) acc += (T[3 * i] * A[l] + T[3 * i + 1] * A[3 + l] + T[3 * i + 2] * A[6 + l]) * T[3 * j + l];
+            out[3 * i + j] = acc;
+        }
+}
+
 // patch points: weighted mean of the surrounding boundary-face values.  Source
 // and destination strides/offset are free so the qgdFlux pass can refresh the
 // pressure component alone from the mid-step patch pressures.
+// vecMode: what of the NC components is a vector / tensor and therefore subject to the mesh's point constraints
+// (MeshView::cpOff; L0: pointConstraints::constrain at the end of volPointInterpolation::interpolateBoundaryField):
+// -1 nothing (scalars, or a field the reference interpolates component by component: the 2-D gradient of a vector
+// [GaussVolPointBase.C L79-87]), 0..NC-3 the offset of a vector, -2 the whole record is a tensor (NC = 9).
 template <int NC>
 __global__ __launch_bounds__(QGD_BLOCK) void boundaryPointKernel(const MeshView m, const double* __restrict__ bndF,
                                                                 const int bndStride, double* __restrict__ ptF,
-                                                                const int ptStride, const int ptOffset) {
+                                                                const int ptStride, const int ptOffset, const int vecMode) {
     const int i = blockIdx.x * QGD_BLOCK + threadIdx.x;
     if (i >= m.nBP) return;
     const int p = m.bpPoint[i];
@@ -340,6 +369,29 @@ __global__ __launch_bounds__(QGD_BLOCK) void boundaryPointKernel(const MeshView 
         const double* bv = bndF + (size_t)m.bpFace[e] * bndStride;
 #pragma unroll
         for (int k = 0; k < NC; ++k) acc[k] += w * bv[k];
+    }
+    if constexpr (NC >= 3) {
+        if (vecMode != -1 && m.cpOff) {
+            for (int e = m.cpOff[i]; e < m.cpOff[i + 1]; ++e) {
+                const double* T = m.cpT + 9 * (size_t)e;
+                const bool mean = m.cpKind[e] == 0;
+                if constexpr (NC == 9) {
+                    if (vecMode == -2) {
+                        double tA[9];
+                        transformTen(T, acc, tA);
+#pragma unroll
+                        for (int k = 0; k < 9; ++k) acc[k] = mean ? (acc[k] + tA[k]) / 2.0 : tA[k];
+                        continue;
+                    }
+                }
+                if (vecMode >= 0 && vecMode + 3 <= NC) {
+                    double v[3], tv[3];
+                    for (int k = 0; k < 3; ++k) v[k] = acc[vecMode + k];
+                    transformVec(T, v, tv);
+                    for (int k = 0; k < 3; ++k) acc[vecMode + k] = mean ? (v[k] + tv[k]) / 2.0 : tv[k];
+                }
+            }
+        }
     }
     double* o = ptF + (size_t)p * ptStride + ptOffset;
 #pragma unroll

@@ -38,7 +38,7 @@ class FoamFileError(ValueError):
 # tokenizer / dictionary parser
 # ---------------------------------------------------------------------------------------------------------------------
 _COMMENT = re.compile(r"//[^\n]*|/\*.*?\*/", re.S)
-_TOKEN = re.compile(r'"(?:[^"\\]|\\.)*"|[{}()\[\];]|[^\s{}()\[\];"]+')
+_TOKEN = re.compile(r'\s*("(?:[^"\\]|\\.)*"|[{}()\[\];]|[^\s{}()\[\];"]+)')
 _LIST_HEAD = re.compile(r"(?:List<\s*(\w+)\s*>\s*)?(?<![\w.+-])(\d+)\s*\(")
 
 
@@ -56,9 +56,46 @@ def _number(tok):
             return tok
 
 
+_WORD_START = re.compile(r"[A-Za-z_]")
+_WORD_END = set(" \t\r\n;{}[]\"")
+
+
+def _tokenize(text):
+    """OpenFOAM's token stream as far as dictionaries need it.  A word that starts with a letter runs on through BALANCED parentheses
+    (ISstream::read(word&), L0): `grad(U)`, `div(phiJm,U)`, `interpolate((U*rhoU))` are single keywords; a '(' at the start of a
+    token, or after a number (`4(a b c d)`), is punctuation."""
+    toks = []
+    pos, n = 0, len(text)
+    while pos < n:
+        m = _TOKEN.match(text, pos)
+        if m is None:
+            pos += 1
+            continue
+        tok = m.group(1)
+        start, end = m.start(1), m.end()
+        if _WORD_START.match(tok) and end < n and text[end] == "(":
+            depth, k = 0, end
+            while k < n:
+                ch = text[k]
+                if ch == "(":
+                    depth += 1
+                elif ch == ")":
+                    if depth == 0:
+                        break
+                    depth -= 1
+                elif ch in _WORD_END:
+                    break
+                k += 1
+            if depth == 0:   # balanced: the parentheses belong to the word
+                tok, end = text[start:k], k
+        toks.append(tok)
+        pos = end
+    return toks
+
+
 class _Parser:
     def __init__(self, text, lists):
-        self.toks = _TOKEN.findall(text)
+        self.toks = _tokenize(text)
         self.i = 0
         self.lists = lists
 
@@ -448,10 +485,23 @@ def write_field(path, mesh, name, internal, patches, dimensions="[0 0 0 0 0 0 0]
 # case set-up (what QGDFoam's createFields.H reads)
 # ---------------------------------------------------------------------------------------------------------------------
 def _bc(rec, vector, patch_type_word, what):
-    """boundaryField entry -> the (kind, value) pair QGDFoamCase.set_bc takes"""
+    """boundaryField entry -> the (kind, value) pair QGDFoamCase.set_bc takes.
+
+    Constraint patches (L0: fvPatchField<Type>::New(p, iF, dict)): the entry's type must be the patch's own constraint type --
+    OpenFOAM stops with "inconsistent patch and patchField types" otherwise -- and the field then IS that constraint field:
+    symmetryPlane / symmetry reflect U (basicSymmetry, the library's ``slip`` arithmetic) and leave scalars zero-gradient; empty
+    carries nothing.  cyclic / wedge fields are not served by the resident cases (read_case_setup refuses such meshes)."""
     t = rec["type"]
+    if patch_type_word in _CONSTRAINT_BCS:
+        if t != patch_type_word:
+            raise FoamFileError(f"{what}: inconsistent patch and patchField types: the patch is '{patch_type_word}', the field says '{t}'")
+        if patch_type_word == "empty":
+            return ("none", None)
+        if patch_type_word in ("symmetryPlane", "symmetry"):
+            return ("slip", None) if vector else ("zeroGradient", None)
+        raise FoamFileError(f"{what}: '{patch_type_word}' patch fields are not supported by the resident cases")
     if t in _CONSTRAINT_BCS:
-        return ("none", None)
+        raise FoamFileError(f"{what}: boundary condition '{t}' needs a patch of that type (the patch is '{patch_type_word}')")
     if t in ("zeroGradient", "slip", "qgdFlux"):
         if t == "slip" and not vector:
             return ("zeroGradient", None)  # slip on a scalar is zeroGradient (basicSymmetry, L0)
@@ -466,6 +516,137 @@ def _bc(rec, vector, patch_type_word, what):
     raise FoamFileError(f"{what}: boundary condition '{t}' is not supported")
 
 
+def _refuse_unserved_patches(mesh, case_dir):
+    """cyclic / wedge patches with faces: their coupled / rotated patch fields are not served by the resident cases (the fvsc operators
+    of a Device do serve such meshes)"""
+    pt, pz = mesh.array("patchType"), mesh.array("patchSize")
+    for i, name in enumerate(mesh.patch_names):
+        word = PATCH_WORDS.get(int(pt[i]), "patch")
+        if word in ("cyclic", "wedge") and int(pz[i]) > 0:
+            raise FoamFileError(f"{case_dir}: patch '{name}' is a {word} patch; the resident QGDFoam / QHDFoam cases do not serve "
+                                f"{word} patch fields")
+
+
+def _scheme_words(v):
+    """a scheme entry as the list of its words: `linear;` -> ['linear'], `Gauss linear corrected;` -> ['Gauss','linear','corrected']"""
+    return [str(x) for x in v] if isinstance(v, list) else [str(v)]
+
+
+def _find_entry(d, key):
+    """dictionary::found / lookup of OpenFOAM (L0): the literal key first, then the quoted (regular-expression) keys, last one first"""
+    if not isinstance(d, dict):
+        return None
+    if key in d:
+        return d[key]
+    for k in reversed(list(d.keys())):
+        if k == key or not any(ch in k for ch in ".*+?[]|^$\\"):
+            continue
+        try:
+            if re.fullmatch(k, key):
+                return d[k]
+        except re.error:
+            pass
+    return None
+
+
+def read_face_schemes(fs, flux_terms, grad_terms, what="system/fvSchemes"):
+    """The fvSchemes sub-dictionaries the face-flux path consults, checked against what the library computes.
+
+    * ``fvsc`` [fvsc.C L47-58]: the word of every term in ``grad_terms`` (its own entry, else ``default``).  The fused case has ONE
+      stencil: a term whose word differs from the others is refused, naming the entry.
+    * ``interpolationSchemes`` [QGDInterpolate.H L42-66]: a field with an ``interpolate(<name>)`` entry, or any field under a
+      ``default`` other than ``none``, goes to ``fvc::interpolate``: with ``linear`` that is linearInterpolate = the numbers the
+      library produces; anything else is refused, naming the entry.  The sub-dictionary must exist (``subDict`` is fatal otherwise).
+    * ``divSchemes`` [QGDInterpolate.H L86-104]: a flux with an entry of its own name (``div(phiJm,U)`` ...) goes to ``fvc::flux``;
+      ``Gauss linear`` is flux * linear(psi) = the default branch, ``Gauss upwind`` the in-register upwind branch of the face kernels
+      (options ``fluxScheme*``); limited schemes are refused.  ``default`` is NOT consulted by qgdFlux (``found(fluxName)``).
+
+    Returns (stencil word, {flux term: 'linear' | 'upwind'})."""
+    fvsc = fs.get("fvsc")
+    if not isinstance(fvsc, dict):
+        raise FoamFileError(f"{what}: sub-dictionary 'fvsc' is missing [fvsc.C L51]")
+    words = {}
+    for term in grad_terms:
+        v = _find_entry(fvsc, term)
+        if v is None:
+            v = _find_entry(fvsc, "default")
+            if v is None:
+                raise FoamFileError(f"{what}: fvsc has neither '{term}' nor 'default' [fvsc.C L57]")
+        words[term] = _scheme_words(v)[0]
+    distinct = sorted(set(words.values()))
+    if len(distinct) > 1:
+        raise FoamFileError(f"{what}: fvsc gives different stencils to different terms ({words}); the resident case runs ONE stencil "
+                            f"for all its face gradients -- use the fvsc operators of a Device for mixed stencils")
+    stencil = distinct[0]
+    interp = fs.get("interpolationSchemes")
+    if not isinstance(interp, dict):
+        raise FoamFileError(f"{what}: sub-dictionary 'interpolationSchemes' is missing (qgdInterpolate looks it up, QGDInterpolate.H L44)")
+    for key, v in interp.items():
+        w = _scheme_words(v)
+        if key == "default":
+            if w not in (["none"], ["linear"]):
+                raise FoamFileError(f"{what}: interpolationSchemes.default '{' '.join(w)}' is not supported: the face-flux path interpolates "
+                                    f"linearly (accepted: none, linear)")
+        elif w != ["linear"]:
+            raise FoamFileError(f"{what}: interpolationSchemes.{key} '{' '.join(w)}' is not supported: the face-flux path interpolates "
+                                f"linearly (accepted: linear)")
+    div = fs.get("divSchemes")
+    if not isinstance(div, dict):
+        raise FoamFileError(f"{what}: sub-dictionary 'divSchemes' is missing (qgdFlux looks it up, QGDInterpolate.H L86)")
+    flux = {}
+    for term in flux_terms:
+        v = _find_entry(div, term)
+        if v is None:
+            flux[term] = "linear"      # flux*psif [QGDInterpolate.H L104]
+            continue
+        w = _scheme_words(v)
+        if w == ["Gauss", "linear"]:
+            flux[term] = "linear"
+        elif w == ["Gauss", "upwind"]:
+            flux[term] = "upwind"
+        else:
+            raise FoamFileError(f"{what}: divSchemes.{term} '{' '.join(w)}' is not supported (accepted: Gauss linear, Gauss upwind)")
+    return stencil, flux
+
+
+def _check_fv_schemes(fs, mesh, need_laplacian, need_grad, what="system/fvSchemes"):
+    """ddtSchemes / laplacianSchemes / gradSchemes as far as the path's fvm:: / fvc:: operators read them (L0): Euler; the uncorrected
+    Gauss linear laplacian (a corrected one is the same operator on an orthogonal mesh and is accepted there); Gauss linear gradients"""
+    ddt = fs.get("ddtSchemes", {})
+    w = _scheme_words(ddt.get("default", "Euler")) if isinstance(ddt, dict) else ["Euler"]
+    if w != ["Euler"]:
+        raise FoamFileError(f"{what}: ddtSchemes.default '{' '.join(w)}' is not supported (the path is the explicit Euler step of the reference)")
+    if need_laplacian:
+        lap = fs.get("laplacianSchemes", {})
+        for key, v in (lap.items() if isinstance(lap, dict) else ()):
+            w = _scheme_words(v)
+            ok = w[:2] == ["Gauss", "linear"] and len(w) == 3 and w[2] in ("uncorrected", "orthogonal", "corrected")
+            if ok and w[2] == "corrected" and not _orthogonal(mesh):
+                raise FoamFileError(f"{what}: laplacianSchemes.{key} 'Gauss linear corrected' on a non-orthogonal mesh: the explicit "
+                                    f"non-orthogonal correction is not part of the path (accepted: Gauss linear uncorrected)")
+            if not ok:
+                raise FoamFileError(f"{what}: laplacianSchemes.{key} '{' '.join(w)}' is not supported (accepted: Gauss linear uncorrected)")
+    if need_grad:
+        gs = fs.get("gradSchemes", {})
+        for key, v in (gs.items() if isinstance(gs, dict) else ()):
+            w = _scheme_words(v)
+            if w != ["Gauss", "linear"]:
+                raise FoamFileError(f"{what}: gradSchemes.{key} '{' '.join(w)}' is not supported (accepted: Gauss linear)")
+
+
+def _orthogonal(mesh, tol=1e-12):
+    """every internal face normal parallel to the line of its two cell centres (nonOrthCorrectionVectors = 0 to rounding)"""
+    nif = mesh.nInternalFaces
+    if nif == 0:
+        return True
+    Sf = mesh.array("Sf").reshape(-1, 3)[:nif]
+    C = mesh.array("C").reshape(-1, 3)
+    d = C[mesh.array("neighbour")] - C[mesh.array("owner")[:nif]]
+    n = Sf / np.linalg.norm(Sf, axis=1)[:, None]
+    corr = n - d / (n * d).sum(axis=1)[:, None]
+    return bool(np.abs(corr).max() <= tol)
+
+
 def read_case_setup(case_dir, time="0"):
     """Read an OpenFOAM QGDFoam case directory.
 
@@ -477,6 +658,7 @@ def read_case_setup(case_dir, time="0"):
     tolerance/maxIter (implicitDiffusion only); <time>/{U,T,p}.
     """
     mesh = read_polymesh(os.path.join(case_dir, "constant", "polyMesh"))
+    _refuse_unserved_patches(mesh, case_dir)
     opt = {}
     tp = read_dict(os.path.join(case_dir, "constant", "thermophysicalProperties"))
     tt = tp.get("thermoType", {})
@@ -516,8 +698,13 @@ def read_case_setup(case_dir, time="0"):
                 opt[fname] = float(vals[0, 0])
             else:
                 coeff_fields[fname] = (vals[:, 0].copy(), patch_vals)
-    fs = read_dict(os.path.join(case_dir, "system", "fvSchemes"))
-    opt["stencil"] = str(fs.get("fvsc", {}).get("default", "reduced"))
+    fs_path = os.path.join(case_dir, "system", "fvSchemes")
+    fs = read_dict(fs_path)
+    # the four fvsc::grad calls [QGDFoam/updateFluxes.H L41-65] and the two qgdFlux calls [L78, L119]
+    opt["stencil"], flux = read_face_schemes(fs, ("div(phiJm,U)", "div(phiJm,H)"), ("grad(U)", "grad(e)", "grad(rho)", "grad(p)"), fs_path)
+    opt["fluxSchemeU"] = 1 if flux["div(phiJm,U)"] == "upwind" else 0
+    opt["fluxSchemeH"] = 1 if flux["div(phiJm,H)"] == "upwind" else 0
+    _check_fv_schemes(fs, mesh, need_laplacian=bool(opt["implicitDiffusion"]), need_grad=bool(opt["implicitDiffusion"]), what=fs_path)
     cd = read_dict(os.path.join(case_dir, "system", "controlDict"))
     opt["deltaT"] = float(cd["deltaT"])
     opt["adjustTimeStep"] = 1 if str(cd.get("adjustTimeStep", "no")) in ("yes", "on", "true", "1") else 0
@@ -597,6 +784,7 @@ def read_qhd_case_setup(case_dir, time="0"):
     default 0.5]; system/fvSchemes fvsc.default; system/controlDict deltaT; system/fvSolution solvers.p {tolerance, relTol,
     maxIter} and, with implicitDiffusion, solvers.(U|T) {tolerance, maxIter}; <time>/{U,T,p}."""
     mesh = read_polymesh(os.path.join(case_dir, "constant", "polyMesh"))
+    _refuse_unserved_patches(mesh, case_dir)
     opt = {}
     tp = read_dict(os.path.join(case_dir, "constant", "thermophysicalProperties"))
     tt = tp.get("thermoType", {})
@@ -643,8 +831,13 @@ def read_qhd_case_setup(case_dir, time="0"):
         if not np.all(vals == vals[0]):
             raise FoamFileError(f"{apath}: a non-uniform alphaQGD is not supported by the QHDFoam path")
         opt["aQGD"] = float(vals[0, 0])
-    fs = read_dict(os.path.join(case_dir, "system", "fvSchemes"))
-    opt["stencil"] = str(fs.get("fvsc", {}).get("default", "reduced"))
+    fs_path = os.path.join(case_dir, "system", "fvSchemes")
+    fs = read_dict(fs_path)
+    # fvsc::grad of U, W, T [QHDFoam/updateFields.H L36-40] and p [QHDUEqn.H L36]; qgdFlux(phi,U,Uf) [QHDUEqn.H L41], qgdFlux(phi,T,Tf) [QHDTEqn.H L65]
+    opt["stencil"], flux = read_face_schemes(fs, ("div(phi,U)", "div(phi,T)"), ("grad(U)", "grad(W)", "grad(T)", "grad(p)"), fs_path)
+    opt["fluxSchemeU"] = 1 if flux["div(phi,U)"] == "upwind" else 0
+    opt["fluxSchemeT"] = 1 if flux["div(phi,T)"] == "upwind" else 0
+    _check_fv_schemes(fs, mesh, need_laplacian=True, need_grad=True, what=fs_path)
     cd = read_dict(os.path.join(case_dir, "system", "controlDict"))
     opt["deltaT"] = float(cd["deltaT"])
     if _truthy(cd.get("adjustTimeStep", "no")):

@@ -196,8 +196,21 @@ def div(dev, vf, out=None):
     return fvscStencil.lookupOrNew(fvscOpName(dev, f"div({vf.name})"), dev).Div(vf, out)
 
 
+def _scheme_text(v):
+    return " ".join(str(x) for x in v) if isinstance(v, (list, tuple)) else str(v)
+
+
 def qgdInterpolate(dev, vf, out=None):
-    """QGDInterpolate.H L38-67 with no interpolationSchemes entry: linearInterpolate."""
+    """QGDInterpolate.H L38-67.  Without an entry (or with ``default none``) linearInterpolate; an ``interpolate(<name>)`` entry or
+    any other default hands the field to fvc::interpolate -- with ``linear`` that is the same weights and the same numbers and
+    takes the library path; any other scheme lives in OpenFOAM's scheme library and is refused."""
+    schemes = dev.fvSchemes.get("interpolationSchemes", {})
+    own = schemes.get(f"interpolate({vf.name})")
+    word = _scheme_text(own) if own is not None else _scheme_text(schemes.get("default", "none"))
+    if word not in ("linear",) + (() if own is not None else ("none",)):
+        entry = f"interpolate({vf.name})" if own is not None else "default"
+        raise L.QgdError(L.ERR_NOT_IMPLEMENTED, f"qgdInterpolate({vf.name}): interpolationSchemes{{{entry} {word};}} -- fvc::interpolate with a "
+                                                f"scheme other than linear stays in OpenFOAM")
     m = dev.mesh
     nc = vf.ncomp
     if isinstance(vf, deviceVolField):
@@ -210,12 +223,26 @@ def qgdInterpolate(dev, vf, out=None):
     return out
 
 
-def qgdFlux(dev, flux, psif):
-    """QGDInterpolate.H L76-118 with no divSchemes entry: flux*psif."""
+def qgdFlux(dev, flux, psif, psi=None, flux_name=None):
+    """QGDInterpolate.H L76-118: flux*psif unless ``divSchemes`` holds an entry for the flux's name (``div(<flux>,<psi>)``, L116); then
+    fvc::flux(flux, psi, name): ``Gauss linear`` = the same numbers, ``Gauss upwind`` = flux times the upwind cell's psi
+    (``qgd_flux_upwind``); limited schemes stay in OpenFOAM (refused).  ``default`` is not consulted (``found(fluxName)``, L86)."""
     flux = np.ascontiguousarray(flux, dtype=np.float64)
     psif = np.ascontiguousarray(psif, dtype=np.float64)
     nc = 1 if psif.ndim == 1 else psif.shape[1]
     out = np.zeros_like(psif)
+    entry = dev.fvSchemes.get("divSchemes", {}).get(flux_name) if flux_name is not None else None
+    word = _scheme_text(entry) if entry is not None else None
+    if word == "Gauss upwind":
+        if psi is None:
+            raise ValueError("qgdFlux: the upwind branch needs the volField psi")
+        bnd = psi.boundary if psi.boundary.size else np.zeros(1)
+        L.check(L.lib.qgd_flux_upwind(dev._h, nc, flux.ctypes.data_as(L.c_double_p), psi.internal.ctypes.data_as(L.c_double_p),
+                                      bnd.ctypes.data_as(L.c_double_p), out.ctypes.data_as(L.c_double_p)), "qgd_flux_upwind")
+        return out
+    if word not in (None, "Gauss linear"):
+        raise L.QgdError(L.ERR_NOT_IMPLEMENTED, f"qgdFlux({flux_name}): divSchemes{{{flux_name} {word};}} -- fvc::flux with a scheme other "
+                                                f"than Gauss linear / Gauss upwind stays in OpenFOAM")
     L.check(L.lib.qgd_flux(dev._h, nc, flux.ctypes.data_as(L.c_double_p), psif.ctypes.data_as(L.c_double_p),
                            out.ctypes.data_as(L.c_double_p)), "qgd_flux")
     return out

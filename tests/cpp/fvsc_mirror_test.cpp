@@ -62,10 +62,34 @@ int main() {
     for (int64_t f = 0; f < sz[1]; ++f) if (phiP.values[f] != 2.0 * pf.values[f]) return 9;
     mesh.interpolationSchemes["default"] = "none";          // `none` still means linearInterpolate [L56-63]
     if (qgdInterpolate(mesh, p).values[0] != pf.values[0]) return 10;
-    mesh.interpolationSchemes["interpolate(p)"] = "vanLeer";  // a user scheme is OpenFOAM's business: fatal here
+    // `default linear` (what nearly every fvSchemes file carries) and `interpolate(p) linear` go to fvc::interpolate in the reference
+    // [L42-65] = the same weights, the same numbers: served by the library, bit for bit
+    mesh.interpolationSchemes["default"] = "linear";
+    { surfaceField r = qgdInterpolate(mesh, p); for (int64_t f = 0; f < sz[1]; ++f) if (r.values[f] != pf.values[f]) return 15; }
+    mesh.interpolationSchemes["interpolate(p)"] = "linear";
+    { surfaceField r = qgdInterpolate(mesh, p); for (int64_t f = 0; f < sz[1]; ++f) if (r.values[f] != pf.values[f]) return 16; }
+    mesh.interpolationSchemes["interpolate(p)"] = "vanLeer";  // any other scheme is OpenFOAM's business: fatal here
     try { qgdInterpolate(mesh, p); return 11; } catch (const FatalError& e) { if (e.status != QGD_ERR_NOT_IMPLEMENTED) return 12; }
+    mesh.interpolationSchemes.erase("interpolate(p)");
+    mesh.interpolationSchemes["default"] = "cubic";
+    try { qgdInterpolate(mesh, p); return 17; } catch (const FatalError& e) { if (e.status != QGD_ERR_NOT_IMPLEMENTED) return 18; }
+    mesh.interpolationSchemes["default"] = "linear";
+    // qgdFlux with a divSchemes entry of the flux's own name [L86-104]: Gauss linear = flux * linear(psi), Gauss upwind = flux * the upwind cell
     mesh.divSchemes["div(phiJm,p)"] = "Gauss linear";
-    try { qgdFlux(mesh, phi, "phiJm", p, pf); return 13; } catch (const FatalError& e) { if (e.status != QGD_ERR_NOT_IMPLEMENTED) return 14; }
+    { surfaceField r = qgdFlux(mesh, phi, "phiJm", p, pf); for (int64_t f = 0; f < sz[1]; ++f) if (r.values[f] != 2.0 * pf.values[f]) return 13; }
+    mesh.divSchemes["div(phiJm,p)"] = "Gauss upwind";
+    for (int64_t f = 0; f < sz[1]; ++f) phi.values[f] = (f % 3 == 0) ? -1.5 : 2.0;   // both flux directions
+    {
+        surfaceField r = qgdFlux(mesh, phi, "phiJm", p, pf);
+        for (int64_t f = 0; f < sz[2]; ++f) {
+            const double lambda = phi.values[f] >= 0.0 ? 1.0 : 0.0;
+            const double up = lambda * (p.internal[own[f]] - p.internal[nei[f]]) + p.internal[nei[f]];
+            if (r.values[f] != phi.values[f] * up) return 14;
+        }
+        for (int64_t f = sz[2]; f < sz[1]; ++f) if (r.values[f] != phi.values[f] * p.boundary[f - sz[2]]) return 19;
+    }
+    mesh.divSchemes["div(phiJm,p)"] = "Gauss limitedLinear 1";
+    try { qgdFlux(mesh, phi, "phiJm", p, pf); return 20; } catch (const FatalError& e) { if (e.status != QGD_ERR_NOT_IMPLEMENTED) return 21; }
     mesh.registry.clear();
     qgd_device_free(mesh.device);
     qgd_mesh_free(m);

@@ -27,7 +27,8 @@ class Options(C.Structure):
         ("stencil", C.c_int32), ("implicitDiffusion", C.c_int32), ("adjustTimeStep", C.c_int32), ("consistentEnergy", C.c_int32),
         ("R", C.c_double), ("Cv", C.c_double), ("mu", C.c_double), ("Pr", C.c_double), ("ScQGD", C.c_double),
         ("PrQGD", C.c_double), ("alphaQGD", C.c_double), ("deltaT", C.c_double), ("maxCo", C.c_double),
-        ("maxDeltaT", C.c_double), ("cTau", C.c_double), ("implicitTol", C.c_double), ("implicitMaxIter", C.c_int32), ("pad_", C.c_int32),
+        ("maxDeltaT", C.c_double), ("cTau", C.c_double), ("implicitTol", C.c_double), ("implicitMaxIter", C.c_int32),
+        ("fluxSchemeU", C.c_int32), ("fluxSchemeH", C.c_int32), ("pad_", C.c_int32),
     ]
 
 
@@ -79,7 +80,8 @@ class QhdOptions(C.Structure):
                 ("rho0", C.c_double), ("mu", C.c_double), ("Pr", C.c_double), ("beta", C.c_double), ("g", C.c_double * 3),
                 ("deltaT", C.c_double), ("Tau", C.c_double), ("aQGD", C.c_double), ("UQHD", C.c_double), ("T0", C.c_double),
                 ("Gr", C.c_double), ("pTol", C.c_double), ("pRelTol", C.c_double), ("pRefValue", C.c_double),
-                ("implicitTol", C.c_double), ("implicitMaxIter", C.c_int32), ("pad_", C.c_int32)]
+                ("implicitTol", C.c_double), ("implicitMaxIter", C.c_int32),
+                ("fluxSchemeU", C.c_int32), ("fluxSchemeT", C.c_int32), ("pad_", C.c_int32)]
 
 
 lib.orc_qhd_case_create.restype = C.c_void_p
@@ -210,6 +212,8 @@ class OracleCase:
             setattr(o, f, getattr(options, f))
         self.options = o
         self._h = lib.orc_case_create(omesh._h, C.byref(o))
+        if not self._h:
+            raise ValueError("oracle: the case does not serve this mesh (cyclic / wedge patches with faces)")
 
     def set_bc(self, patch, U=("zeroGradient", None), T=("zeroGradient", None), p=("zeroGradient", None)):
         kinds = {"zeroGradient": 0, "fixedValue": 1, "slip": 2, "qgdFlux": 3, "none": 4}
@@ -396,6 +400,8 @@ class OracleQhdCase:
                 setattr(o, f, v)
         self.options = o
         self._h = lib.orc_qhd_case_create(omesh._h, C.byref(o))
+        if not self._h:
+            raise ValueError("oracle: the QHD case does not serve this mesh (cyclic / wedge patches with faces)")
 
     def set_bc(self, patch, U=("zeroGradient", None), T=("zeroGradient", None), p=("zeroGradient", None)):
         vu = np.asarray(U[1] if U[1] is not None else (0.0, 0.0, 0.0), dtype=np.float64)

@@ -72,18 +72,27 @@ def test_dictionary_grammar():
         ff.parse_foam_text("a 1 }")
 
 
-def write_step_case(case_dir, stencil="leastSquares", nx=30, ny=10):
-    """a small forwardStep-style case directory written the way a QGDFoam user would"""
+def write_step_case(case_dir, stencil="leastSquares", nx=30, ny=10, schemes=None, symmetry_walls=False, field_types=None):
+    """a small forwardStep-style case directory written the way a QGDFoam user would.  schemes: {sub-dictionary of fvSchemes: body}
+    over the usual ones; symmetry_walls: bottom and top are symmetryPlane patches as in OpenFOAM's forwardStep tutorial;
+    field_types: {(field, patch): entry body} over the usual boundary conditions"""
     mesh = q.PolyMesh.forward_step(nx, ny, nx // 5, ny // 5)
+    if symmetry_walls:
+        ptypes = mesh.array("patchType").copy()
+        ptypes[2] = ptypes[3] = L.PATCH_SYMMETRYPLANE
+        mesh = q.PolyMesh.from_arrays(mesh.array("points"), mesh.array("faceOffsets"), mesh.array("facePoints"), mesh.array("owner"),
+                                      mesh.array("neighbour"), mesh.nCells, mesh.array("patchStart"), mesh.array("patchSize"), ptypes)
     mesh.patch_names = ["inlet", "outlet", "bottom", "top", "obstacle", "frontAndBack"][:mesh.nPatches]
     ff.write_polymesh(mesh, os.path.join(case_dir, "constant", "polyMesh"))
     names = mesh.patch_names
     pt = mesh.array("patchType")
 
-    def bf(entries):
+    def bf(entries, field):
         out = []
         for i, n in enumerate(names):
-            body = "type empty;" if pt[i] == L.PATCH_EMPTY else entries.get(n, entries["default"])
+            body = "type empty;" if pt[i] == L.PATCH_EMPTY else ("type symmetryPlane;" if pt[i] == L.PATCH_SYMMETRYPLANE
+                                                                 else entries.get(n, entries["default"]))
+            body = (field_types or {}).get((field, n), body)
             out.append(f"    {n} {{ {body} }}")
         return "boundaryField\n{\n" + "\n".join(out) + "\n}\n"
 
@@ -92,13 +101,13 @@ def write_step_case(case_dir, stencil="leastSquares", nx=30, ny=10):
     os.makedirs(os.path.join(case_dir, "system"))
     with open(os.path.join(case_dir, "0", "U"), "w") as f:
         f.write(hdr.format(cls="volVectorField", obj="U") + "dimensions [0 1 -1 0 0 0 0];\ninternalField uniform (3 0 0);\n" +
-                bf({"inlet": "type fixedValue; value uniform (3 0 0);", "outlet": "type zeroGradient;", "default": "type slip;"}))
+                bf({"inlet": "type fixedValue; value uniform (3 0 0);", "outlet": "type zeroGradient;", "default": "type slip;"}, "U"))
     with open(os.path.join(case_dir, "0", "T"), "w") as f:
         f.write(hdr.format(cls="volScalarField", obj="T") + "dimensions [0 0 0 1 0 0 0];\ninternalField uniform 1;\n" +
-                bf({"inlet": "type fixedValue; value uniform 1;", "default": "type zeroGradient;"}))
+                bf({"inlet": "type fixedValue; value uniform 1;", "default": "type zeroGradient;"}, "T"))
     with open(os.path.join(case_dir, "0", "p"), "w") as f:
         f.write(hdr.format(cls="volScalarField", obj="p") + "dimensions [1 -1 -2 0 0 0 0];\ninternalField uniform 1;\n" +
-                bf({"inlet": "type fixedValue; value uniform 1;", "outlet": "type zeroGradient;", "default": "type qgdFlux;"}))
+                bf({"inlet": "type fixedValue; value uniform 1;", "outlet": "type zeroGradient;", "default": "type qgdFlux;"}, "p"))
     with open(os.path.join(case_dir, "constant", "thermophysicalProperties"), "w") as f:
         f.write(hdr.format(cls="dictionary", obj="thermophysicalProperties") + textwrap.dedent(f'''
             thermoType {{ type hePsiQGDThermo; mixture pureMixture; transport const; thermo eConst;
@@ -117,8 +126,12 @@ def write_step_case(case_dir, stencil="leastSquares", nx=30, ny=10):
             }}
             '''))
     with open(os.path.join(case_dir, "system", "fvSchemes"), "w") as f:
+        sections = {"ddtSchemes": "default Euler;", "gradSchemes": "default Gauss linear;", "divSchemes": "default none;",
+                    "laplacianSchemes": "default Gauss linear corrected;", "interpolationSchemes": "default linear;",
+                    "snGradSchemes": "default corrected;", "fvsc": f"default {stencil};"}
+        sections.update(schemes or {})
         f.write(hdr.format(cls="dictionary", obj="fvSchemes") +
-                f"ddtSchemes {{ default Euler; }}\nfvsc {{ default {stencil}; }}\ninterpolationSchemes {{ default linear; }}\n")
+                "".join(f"{k} {{ {v} }}\n" for k, v in sections.items() if v is not None))
     with open(os.path.join(case_dir, "system", "controlDict"), "w") as f:
         f.write(hdr.format(cls="dictionary", obj="controlDict") +
                 "application QGDFoam;\nstartTime 0;\nendTime 1;\ndeltaT 5e-4;\nadjustTimeStep no;\nmaxCo 0.2;\n")
@@ -240,3 +253,97 @@ def test_list_head_is_not_found_inside_numbers_or_words():
     words = " ".join(f"p{i}" for i in range(70))
     d = ff.parse_foam_text(f"FoamFile {{ format ascii; }}\nnames 70({words});")
     assert d["names"][0] == "p0" and len(d["names"]) == 70
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# fvSchemes sub-dictionaries the face-flux path consults [QGDInterpolate.H L42-104, fvsc.C L51-58] and constraint patches
+# ---------------------------------------------------------------------------------------------------------------------
+def test_symmetry_plane_walls_read_as_the_constraint_they_are(tmp_path):
+    """OpenFOAM's forwardStep tutorial: bottom and top are symmetryPlane patches; the field entries must carry that type and the
+    fields ARE the constraint (U reflected, scalars zero-gradient), whatever the solver-level boundary conditions elsewhere"""
+    write_step_case(str(tmp_path), symmetry_walls=True)
+    m2, opt, fields, bcs = ff.read_case_setup(str(tmp_path))
+    by = dict(zip(m2.patch_names, bcs))
+    for wall in ("bottom", "top"):
+        assert by[wall] == {"U": ("slip", None), "T": ("zeroGradient", None), "p": ("zeroGradient", None)}
+    assert by["obstacle"]["U"][0] == "slip" and by["obstacle"]["p"][0] == "qgdFlux"
+    # a field entry of another type on a constraint patch is OpenFOAM's "inconsistent patch and patchField types"
+    write_step_case(str(tmp_path / "bad"), symmetry_walls=True, field_types={("U", "top"): "type zeroGradient;"})
+    with pytest.raises(ff.FoamFileError, match="inconsistent patch and patchField types.*symmetryPlane"):
+        ff.read_case_setup(str(tmp_path / "bad"))
+    # ... and a constraint type on an ordinary patch needs a patch of that type
+    write_step_case(str(tmp_path / "bad2"), field_types={("p", "top"): "type symmetryPlane;"})
+    with pytest.raises(ff.FoamFileError, match="needs a patch of that type"):
+        ff.read_case_setup(str(tmp_path / "bad2"))
+
+
+@pytest.mark.parametrize("word", ["cyclic", "wedge"])
+def test_cyclic_and_wedge_cases_are_refused(tmp_path, word):
+    write_step_case(str(tmp_path))
+    bpath = os.path.join(str(tmp_path), "constant", "polyMesh", "boundary")
+    text = open(bpath).read()
+    open(bpath, "w").write(text.replace("type            patch;", f"type            {word};", 1))
+    with pytest.raises(ff.FoamFileError, match=f"{word} patch"):
+        ff.read_case_setup(str(tmp_path))
+
+
+def test_schemes_that_change_nothing_are_accepted(tmp_path):
+    """`linear` goes through fvc::interpolate with the same weights; `Gauss linear` through fvc::flux with the same numbers; a per-term
+    fvsc entry that repeats the default is the default"""
+    write_step_case(str(tmp_path), schemes={
+        "interpolationSchemes": "default linear; interpolate(rho) linear; interpolate(U) linear;",
+        "divSchemes": "default none; div(phiJm,U) Gauss linear; div(phi,K) Gauss limitedLinear 1;",   # the last is not one of qgdFlux's names
+        "fvsc": "default leastSquares; grad(p) leastSquares;"})
+    opt = ff.read_case_setup(str(tmp_path))[1]
+    assert opt["stencil"] == "leastSquares" and opt["fluxSchemeU"] == 0 and opt["fluxSchemeH"] == 0
+    write_step_case(str(tmp_path / "none"), schemes={"interpolationSchemes": "default none;"})
+    assert ff.read_case_setup(str(tmp_path / "none"))[1]["stencil"] == "leastSquares"
+
+
+def test_gauss_upwind_fluxes_become_options(tmp_path):
+    write_step_case(str(tmp_path), schemes={"divSchemes": "default none; div(phiJm,U) Gauss upwind;"})
+    opt = ff.read_case_setup(str(tmp_path))[1]
+    assert (opt["fluxSchemeU"], opt["fluxSchemeH"]) == (1, 0)
+    o = q.default_options(**opt)
+    assert (o.fluxSchemeU, o.fluxSchemeH) == (L.FLUX_UPWIND, L.FLUX_LINEAR)
+    # a quoted (regular-expression) key matches like dictionary::found does
+    write_step_case(str(tmp_path / "re"), schemes={"divSchemes": 'default none; "div\\(phiJm,.*\\)" Gauss upwind;'})
+    opt = ff.read_case_setup(str(tmp_path / "re"))[1]
+    assert (opt["fluxSchemeU"], opt["fluxSchemeH"]) == (1, 1)
+
+
+@pytest.mark.parametrize("schemes,needle", [
+    ({"interpolationSchemes": "default cubic;"}, "interpolationSchemes.default 'cubic'"),
+    ({"interpolationSchemes": "default linear; interpolate(rhoU) vanLeer;"}, r"interpolationSchemes.interpolate\(rhoU\) 'vanLeer'"),
+    ({"divSchemes": "default none; div(phiJm,H) Gauss limitedLinear 1;"}, r"divSchemes.div\(phiJm,H\) 'Gauss limitedLinear 1'"),
+    ({"fvsc": "default leastSquares; grad(p) reduced;"}, "different stencils"),
+    ({"fvsc": "grad(U) reduced;"}, "neither 'grad\\(e\\)' nor 'default'"),
+    ({"interpolationSchemes": None}, "'interpolationSchemes' is missing"),
+    ({"divSchemes": None}, "'divSchemes' is missing"),
+    ({"ddtSchemes": "default backward;"}, "ddtSchemes.default 'backward'"),
+])
+def test_schemes_the_path_does_not_compute_are_refused_by_name(tmp_path, schemes, needle):
+    write_step_case(str(tmp_path), schemes=schemes)
+    with pytest.raises(ff.FoamFileError, match=needle):
+        ff.read_case_setup(str(tmp_path))
+
+
+def test_laplacian_and_grad_schemes_of_the_implicit_branch(tmp_path):
+    """implicitDiffusion reads laplacianSchemes (fvm::laplacian) and gradSchemes (fvc::grad(U)): Gauss linear [un]corrected, the
+    corrected form only where it is the same operator (an orthogonal mesh)"""
+    def with_implicit(case_dir, **kw):
+        write_step_case(case_dir, **kw)
+        tp = os.path.join(case_dir, "constant", "thermophysicalProperties")
+        text = open(tp).read().replace("implicitDiffusion false;", "implicitDiffusion true;")
+        open(tp, "w").write(text)
+    with_implicit(str(tmp_path / "a"))
+    assert ff.read_case_setup(str(tmp_path / "a"))[1]["implicitDiffusion"] == 1     # Gauss linear corrected on the orthogonal step mesh
+    with_implicit(str(tmp_path / "b"), schemes={"laplacianSchemes": "default Gauss linear limited 0.5;"})
+    with pytest.raises(ff.FoamFileError, match="laplacianSchemes.default 'Gauss linear limited 0.5'"):
+        ff.read_case_setup(str(tmp_path / "b"))
+    with_implicit(str(tmp_path / "c"), schemes={"gradSchemes": "default leastSquares;"})
+    with pytest.raises(ff.FoamFileError, match="gradSchemes.default 'leastSquares'"):
+        ff.read_case_setup(str(tmp_path / "c"))
+    # the explicit branch reads neither
+    write_step_case(str(tmp_path / "d"), schemes={"gradSchemes": "default leastSquares;"})
+    assert ff.read_case_setup(str(tmp_path / "d"))[1]["implicitDiffusion"] == 0

@@ -64,7 +64,9 @@ def write_cavity_case(case_dir, stencil="GaussVolPoint", n=(8, 7, 6), implicit_l
     with open(os.path.join(case_dir, "constant", "gravitationalProperties"), "w") as f:
         f.write(HDR.format(cls="uniformDimensionedVectorField", obj="gravitationalProperties") + "g g [0 1 -2 0 0 0 0] (0 -9.81 0);\n")
     with open(os.path.join(case_dir, "system", "fvSchemes"), "w") as f:
-        f.write(HDR.format(cls="dictionary", obj="fvSchemes") + f"ddtSchemes {{ default Euler; }}\nfvsc {{ default {stencil}; }}\n")
+        f.write(HDR.format(cls="dictionary", obj="fvSchemes") + f"ddtSchemes {{ default Euler; }}\ngradSchemes {{ default Gauss linear; }}\n"
+                f"divSchemes {{ default none; }}\nlaplacianSchemes {{ default Gauss linear uncorrected; }}\n"
+                f"interpolationSchemes {{ default linear; }}\nsnGradSchemes {{ default corrected; }}\nfvsc {{ default {stencil}; }}\n")
     with open(os.path.join(case_dir, "system", "fvSolution"), "w") as f:
         f.write(HDR.format(cls="dictionary", obj="fvSolution") + textwrap.dedent('''
             solvers
