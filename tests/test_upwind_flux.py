@@ -122,7 +122,9 @@ def test_device_upwind_fluxes_match_the_oracle_on_the_case_matrix(idx):
     # the branch is live: it differs from the linear product on some internal face
     nif = mesh.nInternalFaces
     Uf = fvsc.qgdInterpolate(dev, fvsc.volField("U", gc.field("U"), gc.field("U.boundary")))
-    assert not np.array_equal(gc.field("phiJmU")[:nif], (gc.field("phiJm")[:, None] * Uf)[:nif])
+    Hf = fvsc.qgdInterpolate(dev, fvsc.volField("H", gc.field("H"), gc.field("H.boundary")))
+    assert (not np.array_equal(gc.field("phiJmU")[:nif], (gc.field("phiJm")[:, None] * Uf)[:nif])      # (a uniform U upwinds to itself: step2d)
+            or not np.array_equal(gc.field("phiJmH")[:nif], (gc.field("phiJm") * Hf)[:nif]))
     for chunk in (1, 9):
         gc.step(chunk); oc.step(chunk)
         t.compare_fields(gc, oc, ["rho", "U", "p", "e", "rhoU", "rhoE"], t.STATE_TOL, (mesh_kind, scheme, f"upwind step+{chunk}"))
