@@ -9,9 +9,10 @@ step (one cell plane + its patch faces per neighbour).
 
 A step = one pass of the QGDFoam loop body (flux assembly + cell update + BC refresh), inputs resident in HBM.
 Prints ONE JSON line on rank 0.  Beside the contract's keys the line carries
-  N = 1: `secondary` {qhd_n200, qhd_implicit_n200, implicit_n200} -- the QHDFoam step (both branches of implicitDiffusion) and QGDFoam's
-         implicitDiffusion step, 20 timed steps each, as child
-         processes after the headline (--no-secondary skips them), `dropin_fvsc`, `cpu_baseline`;
+  N = 1: `secondary` {qhd_n200, qhd_implicit_n200, implicit_n200, qhd_c5} -- the QHDFoam step (both branches of implicitDiffusion), QGDFoam's
+         implicitDiffusion step at 200^3 and the QHDFoam step on BASELINE config 5's 16 M-cell irregular mesh, 20 timed steps each, as
+         child processes after the headline (--no-secondary skips them; skipped by themselves under a profiler), `dropin_fvsc`,
+         `cpu_baseline`;
   N > 1: `native_transport` {ms_per_step, value, checksum_rho, rccl_ranks} -- the same run repeated by a second, fresh set of ranks
          over the library's own RCCL path (qgd_case_step_sharded, the C-ABI a C++/MPI host calls; --no-native-line skips it);
   always: `config.rccl_ranks` (ranks the halo communicator reports), `config.env` (every QGD_* variable that was set).
@@ -305,6 +306,8 @@ def arm_watchdog(seconds, what):
 
     def fire():
         print(f"bench.py: {what} exceeded QGD_BENCH_DEADLINE_S = {seconds:.0f} s; giving up", file=sys.stderr, flush=True)
+        for pr in list(LIVE_CHILDREN):   # the second generation (secondary lines, native-transport ranks) goes with us
+            kill_group(pr)
         os._exit(124)
 
     t = threading.Timer(seconds, fire)
@@ -341,7 +344,8 @@ def launch_ranks(n_ranks, argv, deadline_s, cmd=None):
             env["OMP_NUM_THREADS"] = str(threads)
         procs.append(subprocess.Popen((cmd or [sys.executable, os.path.abspath(__file__)]) + list(argv), env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
-                                      stderr=err0 if r == 0 else None, text=(r == 0)))
+                                      stderr=err0 if r == 0 else None, text=(r == 0), start_new_session=True))
+        LIVE_CHILDREN.append(procs[-1])
     worst, line, timed_out = 0, None, False
     t_end = time.time() + deadline_s
     try:
@@ -358,8 +362,7 @@ def launch_ranks(n_ranks, argv, deadline_s, cmd=None):
             time.sleep(0.2)
         if timed_out or [pr for pr in procs if pr.poll() not in (None, 0)]:
             for pr in procs:
-                if pr.poll() is None:
-                    pr.kill()
+                kill_group(pr)     # the rank AND whatever it started (rank 0's secondary lines / second set of ranks)
         for pr in procs:
             rc = pr.wait()
             worst = max(worst, abs(rc)) if rc else worst
@@ -372,7 +375,9 @@ def launch_ranks(n_ranks, argv, deadline_s, cmd=None):
     finally:
         for pr in procs:
             if pr.poll() is None:
-                pr.kill()
+                kill_group(pr)
+            if pr in LIVE_CHILDREN:
+                LIVE_CHILDREN.remove(pr)
     err0.seek(0)
     tail = err0.read().splitlines()[-12:]
     err0.close()
@@ -400,20 +405,53 @@ def self_launch(n_ranks):
     sys.exit(min(worst, 255))
 
 
+def kill_group(proc):
+    """end a child started with start_new_session=True TOGETHER with everything it started (its ranks, its CPU-baseline workers):
+    killing only the direct child would orphan a second generation that keeps the GPUs and an RCCL rendezvous busy"""
+    import signal
+    try:
+        os.killpg(proc.pid, signal.SIGKILL)
+    except (ProcessLookupError, PermissionError, OSError):
+        pass
+    try:
+        proc.kill()
+    except OSError:
+        pass
+
+
+LIVE_CHILDREN = []   # process groups this process started and has not reaped (arm_watchdog and the deadline paths kill them)
+
+
 def child_line(argv, timeout_s):
     """one bench.py child process (a one-GPU line of another workload, started after this process has released its device
-    memory): its parsed JSON line, or {"error": ...}.  A child, never an exec: this process has initialised the GPU."""
+    memory): its parsed JSON line, or {"error": ...}.  A child in a session of its own, never an exec: this process has
+    initialised the GPU; on timeout the whole group goes."""
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")
            and not k.startswith("TORCHELASTIC_")}
+    pr = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          text=True, start_new_session=True)
+    LIVE_CHILDREN.append(pr)
     try:
-        pr = subprocess.run([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, capture_output=True, text=True, timeout=timeout_s)
+        stdout, stderr = pr.communicate(timeout=timeout_s)
     except subprocess.TimeoutExpired:
+        kill_group(pr)
+        pr.communicate()
         return {"error": f"no result within {timeout_s:.0f} s"}
-    lines = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
+    finally:
+        if pr in LIVE_CHILDREN:
+            LIVE_CHILDREN.remove(pr)
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
     if pr.returncode != 0 or not lines:
-        return {"error": f"status {pr.returncode}", "stderr": pr.stderr.splitlines()[-6:]}
+        return {"error": f"status {pr.returncode}", "stderr": stderr.splitlines()[-6:]}
     return json.loads(lines[-1])
+
+
+def under_profiler():
+    """rocprofv3 (and friends) preload a tool library into every process of the tree: a child workload would run under counter collection
+    too, multiply the run time and write its own traces.  The secondary lines and the second set of ranks are skipped then."""
+    pre = os.environ.get("LD_PRELOAD", "") + os.environ.get("HSA_TOOLS_LIB", "") + os.environ.get("ROCP_TOOL_LIB", "")
+    return ("rocprof" in pre) or any(k.startswith(("ROCPROF_", "ROCPROFILER_")) for k in os.environ)
 
 
 def secondary_lines(args):
@@ -423,9 +461,21 @@ def secondary_lines(args):
     keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "config", "roofline", "phase_ms", "step_roofline_frac", "setup_s", "error", "stderr")
     out = {}
     n = os.environ.get("QGD_BENCH_SECONDARY_N", "200")   # tests shrink it; any value but 200 is visible in the key and in config.env
-    for key, argv in ((f"qhd_n{n}", ["--workload", "qhd", "--edge", n, "--steps", "20", "--warmup", "10"]),
-                      (f"qhd_implicit_n{n}", ["--workload", "qhd", "--implicit-diffusion", "--edge", n, "--steps", "20", "--warmup", "10"]),
-                      (f"implicit_n{n}", ["--workload", "implicit", "--edge", n, "--steps", "20", "--warmup", "5"])):
+    lines = [(f"qhd_n{n}", ["--workload", "qhd", "--edge", n, "--steps", "20", "--warmup", "10"]),
+             (f"qhd_implicit_n{n}", ["--workload", "qhd", "--implicit-diffusion", "--edge", n, "--steps", "20", "--warmup", "10"]),
+             (f"implicit_n{n}", ["--workload", "implicit", "--edge", n, "--steps", "20", "--warmup", "5"])]
+    # BASELINE config 5 (16 M irregular cells, QHDFoam) on one GPU: ~45 s of host mesh set-up + 30 steps.  QGD_BENCH_C5=0 leaves it out,
+    # QGD_BENCH_C5_N shrinks it (tests), QGD_BENCH_C5_IMPLICIT=1 adds the implicitDiffusion branch on the same mesh.
+    if os.environ.get("QGD_BENCH_C5", "1") != "0":
+        c5n = os.environ.get("QGD_BENCH_C5_N", "252")
+        key = "qhd_c5" if c5n == "252" else f"qhd_c5_n{c5n}"
+        lines.append((key, ["--workload", "qhd", "--irregular", "--edge", c5n, "--steps", "20", "--warmup", "10"]))
+        if os.environ.get("QGD_BENCH_C5_IMPLICIT", "0") == "1":
+            lines.append((key + "_implicit", ["--workload", "qhd", "--irregular", "--implicit-diffusion", "--edge", c5n, "--steps", "20", "--warmup", "10"]))
+    for key, argv in lines:
+        if bench_deadline_s() - (time.perf_counter() - T_START) < 150.0:
+            out[key] = {"error": "not started: less than 150 s left before QGD_BENCH_DEADLINE_S"}
+            continue
         t0 = time.perf_counter()
         d = child_line(argv, 420)
         out[key] = {k: d[k] for k in keep if k in d}
@@ -552,7 +602,9 @@ def qhd_line(args):
                    "implicit_unconverged_steps": impl["unconverged_steps"] if impl else None, "env": qgd_env()},
         "roofline": {"bound": "hbm", "kernel": "mgSmoothKernel<float>, multigrid level 0 (one damped-Jacobi sweep of the pressure preconditioner)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS if achieved else None,
-                     "traffic": secondary_traffic("qhd_n200") if (n == 200 and not args.irregular) else None, "traffic_is_static": True,
+                     "traffic": (secondary_traffic("qhd_n200") if (n == 200 and not args.irregular and not args.implicit_diffusion)
+                                 else (secondary_traffic("qhd_c5") if (n == 252 and args.irregular and not args.implicit_diffusion) else None)),
+                     "traffic_is_static": True,
                      "traffic_source": SECONDARY_TRAFFIC_SOURCE, "algorithmic_bytes_per_launch": sweep_bytes, "avg_launch_ms": sw["ms"]},
         "step_bytes_model": {"explicit_bytes_per_cell": QHD_EXPLICIT_BYTES_PER_CELL, "bytes_per_cell_per_pressure_iteration": QHD_BYTES_PER_CELL_PER_ITERATION,
                              "bytes_per_step": step_bytes},
@@ -1097,7 +1149,9 @@ def main():
         dist.barrier()
         dist.destroy_process_group()   # the other ranks leave now; rank 0 may still start the second set of ranks below
     if rank == 0:
-        if world > 1 and not native and not staged and not args.no_native_line:
+        if world > 1 and not native and not staged and not args.no_native_line and under_profiler():
+            out["native_transport"] = {"skipped": "a profiler's tool library is preloaded into this process tree"}
+        elif world > 1 and not native and not staged and not args.no_native_line:
             left = bench_deadline_s() - (time.perf_counter() - T_START)
             try:
                 out["native_transport"] = (native_transport_line(args, world, min(420.0, left - 30.0)) if left > 90.0
@@ -1106,11 +1160,16 @@ def main():
                 out["native_transport"] = {"error": repr(e)}
         elif world > 1 and staged and not args.no_native_line:
             out["native_transport"] = {"skipped": "gloo debugging mode: every rank sits on GPU 0 and RCCL refuses two ranks of one communicator on one device"}
+        # the headline is known from here on: say so on stderr before any child workload starts (stdout carries ONE line, at the end)
+        print(f"bench.py: headline {out['value']:.1f} {out['unit']}, {out['ms_per_step']:.3f} ms per step; secondary lines next", file=sys.stderr, flush=True)
         if world == 1 and not args.no_secondary and args.workload == "qgd":
-            try:
-                out["secondary"] = secondary_lines(args)
-            except Exception as e:
-                out["secondary"] = {"error": repr(e)}
+            if under_profiler():
+                out["secondary"] = {"skipped": "a profiler's tool library is preloaded into this process tree: child workloads would run under it too"}
+            else:
+                try:
+                    out["secondary"] = secondary_lines(args)
+                except Exception as e:
+                    out["secondary"] = {"error": repr(e)}
         if world == 1 and not args.no_dropin:
             try:
                 out["dropin_fvsc"] = dropin_fvsc_line(q, args.dropin_n, 3)

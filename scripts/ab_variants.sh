@@ -7,7 +7,7 @@ OUT=gpurun_out/ab_$N.txt
 for V in "$@"; do
   echo "== $V" >> $OUT
   if [ "$V" = "-" ]; then V="QGD_DUMMY=1"; fi
-  env $V python bench.py --edge $N --steps 30 --warmup 5 --no-cpu-baseline --no-dropin 2>/dev/null | python -c "
+  env $V python bench.py --edge $N --steps 30 --warmup 5 --no-cpu-baseline --no-dropin --no-secondary 2>/dev/null | python -c "
 import json,sys
 for l in sys.stdin:
     if l.startswith('{'):

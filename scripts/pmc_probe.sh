@@ -10,7 +10,7 @@ rm -rf "$OUT"; mkdir -p "$OUT"
 i=0
 while read -r GROUP; do
   i=$((i+1))
-  timeout 240 rocprofv3 --kernel-trace --pmc $GROUP --output-format csv -d "$OUT/g$i" -- python3 "$REPO/bench.py" --edge $N --steps 4 --warmup 2 --no-cpu-baseline --no-dropin > "$OUT/g$i.log" 2>&1
+  timeout 240 rocprofv3 --kernel-trace --pmc $GROUP --output-format csv -d "$OUT/g$i" -- python3 "$REPO/bench.py" --edge $N --steps 4 --warmup 2 --no-cpu-baseline --no-dropin --no-secondary > "$OUT/g$i.log" 2>&1
   echo "group $i ($GROUP): rc=$?"
 done < "${2:-$REPO/scripts/pmc_groups_l1.txt}"
 python3 - "$OUT" <<'PY'

@@ -2,7 +2,7 @@
 the LAST 30 dispatches of that name (the launches of the measurement entry) and the HBM-side bytes derived from them."""
 import csv, glob, json, os, sys
 out_dir, tag = sys.argv[1], sys.argv[2]
-WANT = {"qhd": "mgSmoothKernel<float>", "implicit": "iChebKernel<3, 0>" if os.environ.get("QGD_IMPL_SOLVER", "cheb") == "cheb" else "iApplyKernel<3, 1>"}
+WANT = {"qhd": "mgSmoothKernel<float>", "qhd_c5": "mgSmoothKernel<float>", "implicit": "iChebKernel<3, 0>" if os.environ.get("QGD_IMPL_SOLVER", "cheb") == "cheb" else "iApplyKernel<3, 1>"}
 res = {}
 for which, pattern in WANT.items():
     c = {}
@@ -27,7 +27,7 @@ for which, pattern in WANT.items():
     if "hbm_read_bytes" in c and "hbm_write_bytes" in c:
         c["bytes_per_launch"] = c["hbm_read_bytes"] + c["hbm_write_bytes"]
     c["kernel"] = pattern
-    res[which + "_n200"] = c
+    res[which if which == "qhd_c5" else which + "_n200"] = c
 path = os.path.join(out_dir, f"{tag}_pmc_secondary.json")
 json.dump(res, open(path, "w"), indent=1, sort_keys=True)
 print(json.dumps(res, indent=1, sort_keys=True))

@@ -144,7 +144,7 @@ def test_native_halo_refuses_the_one_gpu_stand_in():
 def test_default_line_carries_the_secondary_workloads_and_the_env():
     """python bench.py --gpus 1 (the driver's command) appends `secondary` {qhd, implicit} from child processes, 20 timed steps each,
     and echoes every QGD_* variable; shrunk here through QGD_BENCH_SECONDARY_N, which the echo then shows"""
-    env = dict(os.environ, QGD_BENCH_SECONDARY_N="24")
+    env = dict(os.environ, QGD_BENCH_SECONDARY_N="24", QGD_BENCH_C5_N="20")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     pr = subprocess.run([sys.executable, BENCH, "--edge", "32", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-dropin"], env=env,
@@ -153,7 +153,9 @@ def test_default_line_carries_the_secondary_workloads_and_the_env():
     d = json.loads([ln for ln in pr.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["config"]["env"]["QGD_BENCH_SECONDARY_N"] == "24" and d["config"]["rccl_ranks"] is None and "native_transport" not in d
     sec = d["secondary"]
-    assert set(sec) == {"qhd_n24", "qhd_implicit_n24", "implicit_n24"}
+    assert set(sec) == {"qhd_n24", "qhd_implicit_n24", "implicit_n24", "qhd_c5_n20"}    # BASELINE config 5's mesh recipe, shrunk
+    assert "config-5 stand-in mesh" in sec["qhd_c5_n20"]["config"]["workload"] and sec["qhd_c5_n20"]["steps"] == 20 and sec["qhd_c5_n20"]["value"] > 0
+    assert "headline" in pr.stderr                         # the headline is announced before the child workloads start
     assert sec["qhd_implicit_n24"]["config"]["implicit_iterations"]["T"] > 0 and sec["qhd_n24"]["config"]["implicit_iterations"] is None
     for key, it_key in (("qhd_n24", "pressure_iterations_per_step"), ("qhd_implicit_n24", "pressure_iterations_per_step"), ("implicit_n24", "iterations_U")):
         x = sec[key]
