@@ -599,7 +599,8 @@ def qhd_line(args):
                                    f"{impl['solver']} solve to 1e-10" if impl else ", implicitDiffusion false")),
                    "cells": nc, "pressure_iterations_per_step": it, "multigrid_levels": info["mgLevels"],
                    "implicit_iterations": {k: v["iterations"] for k, v in impl["solves"].items()} if impl else None,
-                   "implicit_unconverged_steps": impl["unconverged_steps"] if impl else None, "env": qgd_env()},
+                   "implicit_unconverged_steps": impl["unconverged_steps"] if impl else None,
+                   "implicit_stalled_steps": impl["stalled_steps"] if impl else None, "env": qgd_env()},
         "roofline": {"bound": "hbm", "kernel": "mgSmoothKernel<float>, multigrid level 0 (one damped-Jacobi sweep of the pressure preconditioner)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS if achieved else None,
                      "traffic": (secondary_traffic("qhd_n200") if (n == 200 and not args.irregular and not args.implicit_diffusion)
@@ -684,7 +685,8 @@ def implicit_line(args):
                                 "implicitDiffusion true (the reference's default), mu = 1e-3, zeroGradient patches, fixed deltaT, "
                                 + ("U and e systems by Chebyshev iteration on the Jacobi-preconditioned systems to 1e-10" if cheb
                                    else "U and e systems by Jacobi-PCG to 1e-10 (QGD_IMPL_SOLVER=pcg)")),
-                   "cells": nc, "iterations_U": it_u, "iterations_e": it_e, "unconverged_steps": solves["unconverged_steps"], "env": qgd_env()},
+                   "cells": nc, "iterations_U": it_u, "iterations_e": it_e, "unconverged_steps": solves["unconverged_steps"], "stalled_steps": solves["stalled_steps"],
+                   "env": qgd_env()},
         "roofline": {"bound": "hbm", "kernel": ("iChebKernel<3,0> (one Chebyshev step of the three-component U system: matrix product, d, next iterate and the "
                                                 "partial residual sums in one walk of the matrix for the three right-hand sides)" if cheb else
                                                 "iApplyKernel<3,1> (matrix product of the three-component U system, one walk of the matrix for the three right-hand sides)"),

@@ -428,9 +428,10 @@ int qgd_qhd_case_info(qgd_qhd_case_t c, double info[8]);
 /* implicitDiffusion: the solve of the last step -- info[0..3] = iterations of Ux, Uy, Uz, T, [4..7] = initial, [8..11] = final
  * normalised residuals (what OpenFOAM prints as "Solving for Ux, Initial residual = ..."), [12] = steps since
  * qgd_qhd_case_set_fields in which a component stopped above implicitTol, [13] = 0 explicit branch | 1 conjugate gradients
- * (QGD_IMPL_SOLVER=pcg) | 2 Chebyshev iteration (default).  The four systems share |Sf| delta_f up to {nu, nu, nu, Hi} and are
- * solved as four right-hand sides of one matrix walk. */
-int qgd_qhd_case_implicit_info(qgd_qhd_case_t c, double info[14]);
+ * (QGD_IMPL_SOLVER=pcg) | 2 Chebyshev iteration (default), [14] = steps in which a component ended at the rounding floor of its
+ * true residual ABOVE implicitTol (see qgd_case_implicit_info), [15] reserved.  The four systems share |Sf| delta_f up to
+ * {nu, nu, nu, Hi} and are solved as four right-hand sides of one matrix walk. */
+int qgd_qhd_case_implicit_info(qgd_qhd_case_t c, double info[16]);
 
 /* ---- the QHD case on a cell-range shard (qgd_mesh_box slabs, qgd_mesh_shard) ------------------------------------------------
  * What the reference does through processor patches inside fvm::laplacian / PCG / fvc::grad under MPI
@@ -588,8 +589,10 @@ int qgd_case_info(qgd_case_t c, double info[6]);
  * iterate, as OpenFOAM does, and counts here); [13] = 0 explicit branch | 1 implicit, conjugate gradients (QGD_IMPL_SOLVER=pcg) |
  * 2 implicit, Chebyshev iteration (the default).  The Chebyshev iteration measures the TRUE residual b - A x of its iterate (the
  * conjugate-gradient loop a recurrence); when that stops falling below 1e-8 -- the rounding floor of the product, which OpenFOAM's
- * normalisation can lift to 1e-12 on nearly uniform fields -- the component stops there and is NOT counted as unconverged. */
-int qgd_case_implicit_info(qgd_case_t c, double info[14]);
+ * normalisation can lift to 1e-12 on nearly uniform fields -- the component stops there and is NOT counted as unconverged in [12];
+ * [14] = number of steps in which a solve ended that way ABOVE implicitTol (OpenFOAM would have iterated on to maxIter and printed the
+ * residual: "solved to implicitTol" holds only while [12] and [14] are both 0); [15] reserved. */
+int qgd_case_implicit_info(qgd_case_t c, double info[16]);
 /* measurement: `reps` matrix products of the three-component U system (QGDUEqn_8H_source.html L54-68: the `fvm::laplacian(muf,U)`
  * matrix applied to a search direction; the kernel the branch spends most of its time in) between two HIP events, on the vectors
  * the last step left; info = {average ms per product, rows} */

@@ -227,6 +227,9 @@ def run(case_dir, n_steps=None, device_id=0, write=True, log=print, renumber="no
             if ii["unconverged_steps"]:
                 log(f"  WARNING: {ii['unconverged_steps']} step(s) so far in which an implicit solve stopped above its tolerance "
                     f"(implicitTol {case.options.implicitTol:g}, maxIter {case.options.implicitMaxIter})")
+            if ii["stalled_steps"]:
+                log(f"  NOTE: {ii['stalled_steps']} step(s) so far in which a Chebyshev solve ended at the rounding floor of its residual, above "
+                    f"implicitTol {case.options.implicitTol:g} (OpenFOAM would have iterated on to maxIter)")
         if not np.isfinite(info["minRho"]) or info["minRho"] <= 0:
             raise FloatingPointError(f"density lost positivity at time {t:g}")
         if write:

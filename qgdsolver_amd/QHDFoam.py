@@ -64,6 +64,9 @@ def run(case_dir, n_steps=None, device_id=0, write=True, log=print):
             if ii["unconverged_steps"]:
                 log(f"  WARNING: {ii['unconverged_steps']} step(s) so far in which an implicit solve stopped above its tolerance "
                     f"(implicitTol {case.options.implicitTol:g}, maxIter {case.options.implicitMaxIter})")
+            if ii["stalled_steps"]:
+                log(f"  NOTE: {ii['stalled_steps']} step(s) so far in which a Chebyshev solve ended at the rounding floor of its residual, above "
+                    f"implicitTol {case.options.implicitTol:g} (OpenFOAM would have iterated on to maxIter)")
         log(f"  max/min of T: {T.max():.9g}/{T.min():.9g}  ClockTime {_time.perf_counter() - wall0:.2f} s")   # QHDTEqn.H L94
         if not np.isfinite(T).all():
             raise FloatingPointError(f"T is not finite at time {t:g}")

@@ -1082,6 +1082,9 @@ int qgd_species_step_implicit_dev(qgd_device_t d, const double* Y, const double*
     const MeshView& v = d->view;
     if (v.nBF > 0 && !Yb) return fail(QGD_ERR_INVALID, "qgd_species_step_implicit_dev: patch values of Y are required");
     if (d->sharded()) return fail(QGD_ERR_NOT_IMPLEMENTED, "qgd_species_step_implicit: the stateless operator solves on one device (no reductions across shards)");
+    for (const Patch& pt : d->patches)   // fvm::laplacian couples the two sides of a cyclic patch inside the matrix; this one has no such rows
+        if (pt.type == QGD_PATCH_CYCLIC && pt.nonEmptyGlobally())
+            return fail(QGD_ERR_NOT_IMPLEMENTED, "qgd_species_step_implicit: patch '" + pt.name + "' is cyclic: the implicit laplacian across coupled patches is not served");
     HIP_CHECK(hipSetDevice(d->deviceId));
     if (!d->opSolver) d->opSolver = implicitSolverCreate(d->stream, v, d->ownedBegin, d->ownedEnd);
     double* work = d->ws.get<double>(WS_H, 3 * (size_t)v.nC + (size_t)v.nF);   // the last slot: the host-pointer entry fills the first ten
@@ -2180,10 +2183,10 @@ int qgd_qhd_case_implicit_control_ptr(qgd_qhd_case_t c, void** devicePtr) {
     *devicePtr = implicitSolverCtl(c->implSolver);
     return QGD_OK;
 }
-int qgd_qhd_case_implicit_info(qgd_qhd_case_t c, double info[14]) {
+int qgd_qhd_case_implicit_info(qgd_qhd_case_t c, double info[16]) {
     QGD_TRY
     if (!c || !info) return fail(QGD_ERR_INVALID, "bad argument");
-    for (int i = 0; i < 14; ++i) info[i] = 0.0;
+    for (int i = 0; i < 16; ++i) info[i] = 0.0;
     if (!c->implSolver) return QGD_OK;
     HIP_CHECK(hipSetDevice(c->dev->deviceId));
     double allDone = 0;
@@ -2191,7 +2194,7 @@ int qgd_qhd_case_implicit_info(qgd_qhd_case_t c, double info[14]) {
     double r0[4], r1[4];
     implicitSolveStatus4(c->implSolver, &allDone, it, r0, r1);
     for (int k = 0; k < 4; ++k) { info[k] = it[k]; info[4 + k] = r0[k]; info[8 + k] = r1[k]; }
-    info[12] = implicitSolverUnconverged(c->implSolver);
+    info[12] = implicitSolverUnconverged(c->implSolver, &info[14]);
     info[13] = implicitSolverChebyshev(c->implSolver) ? 2.0 : 1.0;
     return QGD_OK;
     QGD_CATCH
@@ -2833,19 +2836,19 @@ int qgd_case_info(qgd_case_t c, double info[6]) {
     QGD_CATCH
 }
 
-int qgd_case_implicit_info(qgd_case_t c, double info[14]) {
+int qgd_case_implicit_info(qgd_case_t c, double info[16]) {
     QGD_TRY
     if (!c || !info) return fail(QGD_ERR_INVALID, "null argument");
-    for (int k = 0; k < 14; ++k) info[k] = 0.0;
+    for (int k = 0; k < 16; ++k) info[k] = 0.0;
     info[13] = c->opt.implicitDiffusion ? 1.0 : 0.0;
     if (!c->implSolver) return QGD_OK;
     info[13] = implicitSolverChebyshev(c->implSolver) ? 2.0 : 1.0;   // 1: conjugate gradients (QGD_IMPL_SOLVER=pcg), 2: Chebyshev iteration
     HIP_CHECK(hipSetDevice(c->dev->deviceId));
     implicitSolverSetStream(c->implSolver, c->stream());
-    int it[4]; double r0[4], r1[4], bad = 0;
-    implicitSolverInfo(c->implSolver, it, r0, r1, &bad);
+    int it[4]; double r0[4], r1[4], bad = 0, stalled = 0;
+    implicitSolverInfo(c->implSolver, it, r0, r1, &bad, &stalled);
     for (int k = 0; k < 4; ++k) { info[k] = it[k]; info[4 + k] = r0[k]; info[8 + k] = r1[k]; }
-    info[12] = bad;
+    info[12] = bad; info[14] = stalled;
     return QGD_OK;
     QGD_CATCH
 }

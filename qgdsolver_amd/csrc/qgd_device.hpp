@@ -231,7 +231,7 @@ void implicitSolvePhase(ImplicitSolver* S, int phase);
 void implicitSolveRun(ImplicitSolver* S, const SolveHooks* hooks);
 void implicitSolveStatus(ImplicitSolver* S, double* allDone, int iters[3], double res0[3], double res[3]);
 void implicitSolveStatus4(ImplicitSolver* S, double* allDone, int iters[4], double res0[4], double res[4]);   // the same for up to four right-hand sides
-double implicitSolverUnconverged(ImplicitSolver* S);   // steps since implicitStatsReset in which a solve stopped above its tolerance (waits)
+double implicitSolverUnconverged(ImplicitSolver* S, double* stalledSteps);   // steps since implicitStatsReset in which a solve stopped above its tolerance (waits)
 // ghost entries of what the next matrix product reads (Chebyshev: the iterate; conjugate gradients: the search direction): its
 // right-hand sides per listed cell, cell-major in the message
 void launchSolverHalo(hipStream_t s, ImplicitSolver* S, const int32_t* cells, int nCells, double* buf, bool pack);
@@ -239,7 +239,7 @@ void implicitSolveEnd(ImplicitSolver* S, int which);             // which = 0: t
 double implicitApplyMs(ImplicitSolver* S, const ImplView& iv, int reps, int* rows);   // measurement: average ms of the U system's matrix product
 void implicitStepMark(ImplicitSolver* S, bool begin);
 void implicitStatsReset(ImplicitSolver* S);
-void implicitSolverInfo(ImplicitSolver* S, int iters[4], double res0[4], double res[4], double* unconvergedSteps);
+void implicitSolverInfo(ImplicitSolver* S, int iters[4], double res0[4], double res[4], double* unconvergedSteps, double* stalledSteps);
 int implicitHaloWidth(const ImplicitSolver* S, int kind);   // doubles per cell of message kind 1 (grad U), 2 (U), 3 (search direction), 4 (initial guess)
 void launchImplicitHalo(hipStream_t s, const MeshView& m, const CaseView& c, const ImplView& iv, ImplicitSolver* S, int kind, const int32_t* cells,
                         int nCells, double* buf, bool pack);

@@ -885,15 +885,20 @@ __global__ __launch_bounds__(QGD_BLOCK) void implHaloKernel(const CaseView c, co
 }
 
 // statistics of a step without a host round trip: stats[0] = steps in which a solve stopped above its tolerance (iteration limit or
-// breakdown), stats[1] = the flag of the step in flight.  mode 0: start of a step; 1: after a solve; 2: end of a step
+// breakdown), stats[1] = the flag of the step in flight; stats[2] / stats[3] the same for solves that the Chebyshev iteration ended at
+// the rounding floor of its true residual (done = 4) while that floor lay ABOVE the tolerance: not a failure of the iteration, but not
+// "solved to implicitTol" either -- OpenFOAM would have gone on to maxIter and printed the residual; callers report the count.
+// mode 0: start of a step; 1: after a solve; 2: end of a step
+#define ISTAT_COUNT 4
 __global__ void iStatKernel(const double* __restrict__ ctl, double* __restrict__ stats, const int NR, const int mode, const double tol) {
-    if (mode == 0) stats[1] = 0.0;
+    if (mode == 0) stats[1] = stats[3] = 0.0;
     else if (mode == 1) {
         for (int k = 0; k < NR; ++k) {
             const double dn = ctl[ICTL(I_DONE, k)];
             if (dn == 2.0 || (dn == 1.0 && !(ctl[ICTL(I_RES, k)] < tol))) stats[1] = 1.0;
+            if (dn == 4.0 && !(ctl[ICTL(I_RES, k)] < tol)) stats[3] = 1.0;
         }
-    } else stats[0] += stats[1];
+    } else { stats[0] += stats[1]; stats[2] += stats[3]; }
 }
 
 }  // namespace
@@ -906,7 +911,7 @@ struct ImplicitSolver {
     double *r = nullptr, *d = nullptr, *q = nullptr, *xb = nullptr, *part = nullptr, *ctl = nullptr, *hostCtl = nullptr;
     bool cheb = true;           // QGD_IMPL_SOLVER: "cheb" (default) | "pcg"
     int hostSteps = 0;          // Chebyshev steps queued so far in the solve in flight (which buffer a halo message moves)
-    double* stats = nullptr;    // device: [0] unconverged steps, [1] flag of the step in flight, [2 .. 2 + 2*I_COUNT) control blocks of the last U and e solves
+    double* stats = nullptr;    // device: [0] unconverged steps, [1] flag of the step in flight, [2], [3] the same for stalled solves (iStatKernel), then the control blocks of the last U and e solves
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     ISolveView v{};
     int NR = 1, validMask = 1, maxIter = 0;
@@ -940,8 +945,8 @@ ImplicitSolver* implicitSolverCreate(hipStream_t stream, const MeshView& m, int 
         ICHECK(hipMalloc((void**)&S->xb, sizeof(double) * 4 * nC));
         ICHECK(hipMemset(S->xb, 0, sizeof(double) * 4 * nC));
         ICHECK(hipMalloc((void**)&S->ctl, sizeof(double) * I_COUNT));
-        ICHECK(hipMalloc((void**)&S->stats, sizeof(double) * (2 + 2 * I_COUNT)));
-        ICHECK(hipMemset(S->stats, 0, sizeof(double) * (2 + 2 * I_COUNT)));
+        ICHECK(hipMalloc((void**)&S->stats, sizeof(double) * (ISTAT_COUNT + 2 * I_COUNT)));
+        ICHECK(hipMemset(S->stats, 0, sizeof(double) * (ISTAT_COUNT + 2 * I_COUNT)));
         ICHECK(hipMemset(S->d, 0, sizeof(double) * 4 * nC));     // ghost entries of the direction are read before the first exchange fills them
         ICHECK(hipMemset(S->ctl, 0, sizeof(double) * I_COUNT));
         ICHECK(hipStreamSynchronize(nullptr));   // null-stream zero-fills are done before anything runs on the solver's non-blocking stream
@@ -1061,11 +1066,12 @@ void implicitSolveStatus4(ImplicitSolver* S, double* allDone, int iters[4], doub
         iters[k] = on ? (int)h[ICTL(I_ITER, k)] : 0; res0[k] = on ? h[ICTL(I_RES0, k)] : 0.0; res[k] = on ? h[ICTL(I_RES, k)] : 0.0;
     }
 }
-double implicitSolverUnconverged(ImplicitSolver* S) {
-    double h = 0;
-    ICHECK(hipMemcpyAsync(&h, S->stats, sizeof(double), hipMemcpyDeviceToHost, S->stream));
+double implicitSolverUnconverged(ImplicitSolver* S, double* stalledSteps) {
+    double h[ISTAT_COUNT] = {0, 0, 0, 0};
+    ICHECK(hipMemcpyAsync(h, S->stats, sizeof(h), hipMemcpyDeviceToHost, S->stream));
     ICHECK(hipStreamSynchronize(S->stream));
-    return h;
+    if (stalledSteps) *stalledSteps = h[2];
+    return h[0];
 }
 __global__ __launch_bounds__(QGD_BLOCK) void iVecHaloKernel(double* __restrict__ vec, const int nC, const int NR, const int32_t* __restrict__ cells,
                                                           const int nCells, double* __restrict__ buf, const int pack) {
@@ -1123,17 +1129,18 @@ void implicitSolveRun(ImplicitSolver* S, const SolveHooks* hooks) {
 void implicitSolveEnd(ImplicitSolver* S, int which) {
     if (S->cheb) iChebHomeKernel<<<S->v.nBlocks, QGD_BLOCK, 0, S->stream>>>(S->v);   // iterates that ended in the solver's buffer
     iStatKernel<<<1, 1, 0, S->stream>>>(S->ctl, S->stats, S->NR, 1, S->tol);
-    ICHECK(hipMemcpyAsync(S->stats + 2 + (size_t)which * I_COUNT, S->ctl, sizeof(double) * I_COUNT, hipMemcpyDeviceToDevice, S->stream));
+    ICHECK(hipMemcpyAsync(S->stats + ISTAT_COUNT + (size_t)which * I_COUNT, S->ctl, sizeof(double) * I_COUNT, hipMemcpyDeviceToDevice, S->stream));
 }
 void implicitStepMark(ImplicitSolver* S, bool begin) { iStatKernel<<<1, 1, 0, S->stream>>>(S->ctl, S->stats, 0, begin ? 0 : 2, 0.0); }
-void implicitStatsReset(ImplicitSolver* S) { ICHECK(hipMemsetAsync(S->stats, 0, sizeof(double) * (2 + 2 * I_COUNT), S->stream)); }
+void implicitStatsReset(ImplicitSolver* S) { ICHECK(hipMemsetAsync(S->stats, 0, sizeof(double) * (ISTAT_COUNT + 2 * I_COUNT), S->stream)); }
 // waits for the stream: iterations / initial / final residual of Ux, Uy, Uz, e in the last step, steps with an unconverged solve
-void implicitSolverInfo(ImplicitSolver* S, int iters[4], double res0[4], double res[4], double* unconvergedSteps) {
-    std::vector<double> h(2 + 2 * I_COUNT);
+void implicitSolverInfo(ImplicitSolver* S, int iters[4], double res0[4], double res[4], double* unconvergedSteps, double* stalledSteps) {
+    std::vector<double> h(ISTAT_COUNT + 2 * I_COUNT);
     ICHECK(hipMemcpyAsync(h.data(), S->stats, sizeof(double) * h.size(), hipMemcpyDeviceToHost, S->stream));
     ICHECK(hipStreamSynchronize(S->stream));
     *unconvergedSteps = h[0];
-    const double* u = h.data() + 2;
+    if (stalledSteps) *stalledSteps = h[2];
+    const double* u = h.data() + ISTAT_COUNT;
     const double* e = u + I_COUNT;
     for (int k = 0; k < 3; ++k) {
         const bool on = u[ICTL(I_DONE, k)] != 3.0;

@@ -384,11 +384,7 @@ __device__ __forceinline__ void gvp3Coefs(const int kind, const double4& cO, con
             coef[6 + d] = d24[u] * d31[w2] - d24[w2] * d31[u];
         }
         coef[9] = coef[10] = coef[11] = 0.0;
-#if QGD_F_DIET
-        rV = -rcpNewton(d31[0] * coef[0] + d31[1] * coef[1] + d31[2] * coef[2]);
-#else
-        rV = -1.0 / (d31[0] * coef[0] + d31[1] * coef[1] + d31[2] * coef[2]);
-#endif
+        rV = -QGD_RCP(d31[0] * coef[0] + d31[1] * coef[1] + d31[2] * coef[2]);
     } else if (kind == 1) {
         gvpTriCoef(cO, cN, x0, x1, x2, coef, rV);
     } else {
@@ -1314,7 +1310,7 @@ __global__ __launch_bounds__(QGD_BLOCK) void fvscGradGvp3Kernel(const MeshView m
                 A1[d] = NO[u] * d31[w2] - NO[w2] * d31[u];
                 A5[d] = d24[u] * d31[w2] - d24[w2] * d31[u];
             }
-            const double rV6 = -1.0 / (d31[0] * A0[0] + d31[1] * A0[1] + d31[2] * A0[2]);
+            const double rV6 = -QGD_RCP(d31[0] * A0[0] + d31[1] * A0[1] + d31[2] * A0[2]);
 #pragma unroll
             for (int k = 0; k < NC; ++k) {
                 const double D5 = (v.o[k] - v.n[k]) * rV6, D0 = (p0[k] - p2[k]) * rV6, D1 = (p1[k] - p3[k]) * rV6;
@@ -1469,10 +1465,18 @@ __global__ __launch_bounds__(QGD_BLOCK) void extractFieldKernel(const RecA* __re
         case XF_C: out[i] = b.c; break;
         case XF_PSI: out[i] = 1.0 / (g.R * (a.e / g.Cv)); break;
         case XF_MU: out[i] = g.mu0 + b.muQGD; break;
+#if QGD_F_DIET
+        case XF_ALPHAU: out[i] = g.alphah0 + b.muQGD * g.rPrQGD; break;     // as alphaEffOf forms it in the face kernels
+#else
         case XF_ALPHAU: out[i] = g.alphah0 + b.muQGD / g.PrQGD; break;
+#endif
         case XF_TAUQGD: out[i] = (aQ ? aQ[i] : g.alphaQGD) * hq[i] / b.c; break;
         case XF_MUQGD: out[i] = b.muQGD; break;
+#if QGD_F_DIET
+        case XF_ALPHAUQGD: out[i] = b.muQGD * g.rPrQGD; break;
+#else
         case XF_ALPHAUQGD: out[i] = b.muQGD / g.PrQGD; break;
+#endif
         case XF_HQGD: out[i] = hq[i]; break;
         case XF_H: out[i] = b.H; break;
         default: out[i] = g.gamma; break;

@@ -16,8 +16,10 @@ __device__ __forceinline__ double lerpf(double w, double a, double b) { return w
 // as v_rcp_f64 + two Newton steps (<= 1-2 ulp) or a product with the precomputed 1/PrQGD instead of the IEEE division sequence
 // (v_div_scale x2, v_rcp, 6 fma, v_div_fmas, v_div_fixup): -43 of 726 fp64 instructions of the staged face kernel, F 7.31 -> 7.12 ms at
 // 64 M cells on one box (profiles/r04_ab_face_instruction_diet.txt).  A deliberate deviation of a few ulp from the listing's
-// divisions, the same in every face kernel (staged, gather, 2-D, boundary), so they stay bit-identical to each
-// other.  -DQGD_F_DIET=0 builds the divisions back.
+// divisions.  ONE flavour everywhere a face kernel divides (QGD_RCP): the case's kernels (staged, gather, 2-D, boundary)
+// -- which therefore stay bit-identical to each other -- and the stateless fvsc operators and field accessors.  (Operators and case
+// still differ in the last bits on quadrilaterals for another reason: the operators form the listing's coefficients a_k/6 and 1/V, the
+// case the difference form with 1/(6V); parity tests hold both to the oracle, <= 1e-11.)  -DQGD_F_DIET=0 builds the divisions back.
 #ifndef QGD_F_DIET
 #define QGD_F_DIET 1
 #endif
@@ -27,6 +29,11 @@ __device__ __forceinline__ double rcpNewton(const double x) {
     r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
     return r;
 }
+#if QGD_F_DIET
+#define QGD_RCP(x) rcpNewton(x)
+#else
+#define QGD_RCP(x) (1.0 / (x))
+#endif
 
 // the normal a slip / symmetry / symmetryPlane patch reflects about on boundary face f: the face's own unit normal
 // (basicSymmetryFvPatchField: patch().nf()), or the patch's one normal on a symmetryPlane (PatchBCDev::nHat)
@@ -90,7 +97,7 @@ __device__ __forceinline__ void gvpQuadCoef(const double4 O, const double4 N, co
     const double cr[3] = {d42[1] * on[2] - d42[2] * on[1], d42[2] * on[0] - d42[0] * on[2], d42[0] * on[1] - d42[1] * on[0]};
     double vol = d31[0] * cr[0] + d31[1] * cr[1] + d31[2] * cr[2];
     vol *= sixth;
-    rV = 1.0 / vol;
+    rV = QGD_RCP(vol);
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         const int u = (d + 1) % 3, v = (d + 2) % 3;
@@ -110,7 +117,7 @@ __device__ __forceinline__ void gvpTriCoef(const double4 O, const double4 N, con
     const double cr[3] = {e21[1] * e31[2] - e21[2] * e31[1], e21[2] * e31[0] - e21[0] * e31[2], e21[0] * e31[1] - e21[1] * e31[0]};
     double vol = cr[0] * on[0] + cr[1] * on[1] + cr[2] * on[2];
     vol *= sixth;
-    rV = 1.0 / vol;
+    rV = QGD_RCP(vol);
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         const int u = (d + 1) % 3, v = (d + 2) % 3;

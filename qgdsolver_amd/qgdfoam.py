@@ -162,10 +162,10 @@ class QGDFoamCase:
 
     def implicit_info(self):
         """the four linear solves of the implicitDiffusion branch in the last step (qgd_case_implicit_info)"""
-        a = (C.c_double * 14)()
+        a = (C.c_double * 16)()
         L.check(L.lib.qgd_case_implicit_info(self._h, a), "qgd_case_implicit_info")
         names = ("Ux", "Uy", "Uz", "e")
-        return dict(implicit=bool(a[13]), solver={0: None, 1: "pcg", 2: "chebyshev"}[int(a[13])], unconverged_steps=int(a[12]),
+        return dict(implicit=bool(a[13]), solver={0: None, 1: "pcg", 2: "chebyshev"}[int(a[13])], unconverged_steps=int(a[12]), stalled_steps=int(a[14]),
                     solves={n: dict(iterations=int(a[k]), initial=a[4 + k], final=a[8 + k]) for k, n in enumerate(names)})
 
     def implicit_apply_time(self, reps=20):

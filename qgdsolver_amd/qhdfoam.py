@@ -260,10 +260,10 @@ class QHDFoamCase:
     def implicit_info(self):
         """iterations / initial / final residual of Ux, Uy, Uz, T in the last step (what OpenFOAM prints per solve), the steps in which
         a solve stopped above implicitTol, and the algorithm (QGD_IMPL_SOLVER)"""
-        a = (C.c_double * 14)()
+        a = (C.c_double * 16)()
         L.check(L.lib.qgd_qhd_case_implicit_info(self._h, a), "qgd_qhd_case_implicit_info")
         names = ("Ux", "Uy", "Uz", "T")
-        return dict(implicit=a[13] != 0.0, solver={0: None, 1: "pcg", 2: "chebyshev"}[int(a[13])], unconverged_steps=int(a[12]),
+        return dict(implicit=a[13] != 0.0, solver={0: None, 1: "pcg", 2: "chebyshev"}[int(a[13])], unconverged_steps=int(a[12]), stalled_steps=int(a[14]),
                     solves={n: dict(iterations=int(a[k]), initial=a[4 + k], final=a[8 + k]) for k, n in enumerate(names)})
 
     def solve_status(self):

@@ -298,4 +298,10 @@ def test_chebyshev_solver_on_a_weakly_dominant_system():
     ii = gc.implicit_info()
     its = max(s["iterations"] for s in ii["solves"].values())
     assert ii["unconverged_steps"] == 0 and 20 < its < 400, ii
+    # implicitTol = 1e-13 lies below the rounding floor of the true residual here: the solves end at the floor (done = 4).  That is no
+    # failure of the iteration, but it is not "solved to implicitTol" either, and the count says so (OpenFOAM would have run on to maxIter)
+    worst = max(s["final"] for s in ii["solves"].values())
+    if worst >= 1e-13:
+        assert ii["stalled_steps"] > 0, ii
+    assert 0 <= ii["stalled_steps"] <= 6, ii
     gc.close(); dev.close()
