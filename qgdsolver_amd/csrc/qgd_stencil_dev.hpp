@@ -19,7 +19,7 @@ __device__ __forceinline__ double lerpf(double w, double a, double b) { return w
 // divisions.  ONE flavour everywhere a face kernel divides (QGD_RCP): the case's kernels (staged, gather, 2-D, boundary)
 // -- which therefore stay bit-identical to each other -- and the stateless fvsc operators and field accessors.  (Operators and case
 // still differ in the last bits on quadrilaterals for another reason: the operators form the listing's coefficients a_k/6 and 1/V, the
-// case the difference form with 1/(6V); parity tests hold both to the oracle, <= 1e-11.)  -DQGD_F_DIET=0 builds the divisions back.
+// case the difference form with 1/(6V); the parity tests hold both to the CPU restatement, <= 1e-11.)  -DQGD_F_DIET=0 builds the divisions back.
 #ifndef QGD_F_DIET
 #define QGD_F_DIET 1
 #endif
