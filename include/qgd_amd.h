@@ -538,6 +538,13 @@ typedef struct qgd_case_options {
                                  U on internal faces, the patch value on patch faces                                  */
     int32_t fluxSchemeH;      /* the same for qgdFlux(phiJm,H,Hf) [updateFluxes.H L119], entry `div(phiJm,H)`          */
     int32_t pad_;
+    int32_t termStencil[4];   /* per-term entries of fvSchemes.fvsc [fvsc_8C_source.html L51-58] for the four face gradients of the step,
+                                 in the order grad(U), grad(e), grad(rho), grad(p) [QGDFoam_2updateFluxes_8H_source.html L41-65]:
+                                 0 = no entry of its own (the `default` word = `stencil`), else 1 + QGD_FVSC_*.  At most two distinct
+                                 stencils per case (QGD_ERR_NOT_IMPLEMENTED beyond); a mixed case walks its faces through the generic
+                                 gather kernels (each gradient formed by its own stencil, the flux algebra unchanged), a uniform one
+                                 through the fused kernels as before.  GaussVolPoint's re-evaluation of its input's boundary
+                                 conditions [GaussVolPointStencil_8C_source.html L73] follows grad(p)'s word.                   */
 } qgd_case_options;
 
 int qgd_case_options_default(qgd_case_options* opt);

@@ -1230,6 +1230,11 @@ struct Case {
     std::vector<PatchBC> bc;
     Stencil* stencil = nullptr;
     std::string stencilWord;
+    // per-term entries of fvSchemes.fvsc [fvsc.C L51-58]: grad(U), grad(e), grad(rho), grad(p); empty word = the default
+    enum { TERM_U = 0, TERM_E = 1, TERM_RHO = 2, TERM_P = 3 };
+    std::string termWord[4];
+    Stencil* termStencil[4] = {nullptr, nullptr, nullptr, nullptr};
+    const std::string& wordOf(int term) const { return termWord[term].empty() ? stencilWord : termWord[term]; }
     // thermo + state (cells + boundary)
     VolField p, T, e, U, rho, rhoU, rhoE, psi, mu, alpha, gamma, c, H;
     // QGDCoeffs
@@ -1410,6 +1415,10 @@ struct Case {
     int setFields(const double* U0, const double* T0, const double* p0) {
         int rc = mh->cache.lookup(m, stencilWord, &stencil);
         if (rc) return rc;
+        for (int t = 0; t < 4; ++t) {
+            rc = mh->cache.lookup(m, wordOf(t), &termStencil[t]);
+            if (rc) return rc;
+        }
         p = VolField(m, 1); T = VolField(m, 1); e = VolField(m, 1); U = VolField(m, 3); rho = VolField(m, 1);
         rhoU = VolField(m, 3); rhoE = VolField(m, 1); psi = VolField(m, 1); mu = VolField(m, 1); alpha = VolField(m, 1);
         gamma = VolField(m, 1); c = VolField(m, 1); H = VolField(m, 1);
@@ -1451,7 +1460,7 @@ struct Case {
         // createFaceFluxes.H registers "phiwStar" = Sf & (tauQGDf*gradPf); with
         // GaussVolPoint that first grad(p) runs the qgdFlux BC before the name exists
         phiwRegistered = false;
-        gradPf = fvscGrad(p, true);
+        gradPf = fvscGrad(p, TERM_P);
         phiw = SurfField(m, 1);
         for (int f = 0; f < m.nF; ++f) {
             double rw[3];
@@ -1465,9 +1474,9 @@ struct Case {
 
     // fvsc::grad: GaussVolPoint re-evaluates the BCs of its input first
     // [GaussVolPointStencil.C:73,91]; of the case's fields only p's qgdFlux BC changes by that (B6)
-    SurfField fvscGrad(VolField& f, bool isP) {
-        if (isP && stencilWord == "GaussVolPoint") correctBC_p();
-        return f.nc == 1 ? stencil->gradS(f) : stencil->gradV(f);
+    SurfField fvscGrad(VolField& f, int term) {
+        if (term == TERM_P && wordOf(TERM_P) == "GaussVolPoint") correctBC_p();
+        return f.nc == 1 ? termStencil[term]->gradS(f) : termStencil[term]->gradV(f);
     }
 
     // updateFields.H [QGDFoam/updateFields.H:45-80]
@@ -1498,11 +1507,11 @@ struct Case {
     void updateFluxes() { updateFluxesA(); updateFluxesB(); }
     void updateFluxesA() {
         const int nF = m.nF;
-        gradUf = fvscGrad(U, false);
+        gradUf = fvscGrad(U, TERM_U);
         divUf = SurfField(m, 1);
         for (int f = 0; f < nF; ++f) divUf.v[f] = gradUf.v[9 * (size_t)f] + gradUf.v[9 * (size_t)f + 4] + gradUf.v[9 * (size_t)f + 8];
-        gradef = fvscGrad(e, false);
-        gradRhof = fvscGrad(rho, false);
+        gradef = fvscGrad(e, TERM_E);
+        gradRhof = fvscGrad(rho, TERM_RHO);
         rhoW = SurfField(m, 3); phiw = SurfField(m, 1);
         for (int f = 0; f < nF; ++f) {
             if (!liveFace[f]) continue;
@@ -1516,14 +1525,14 @@ struct Case {
             phiw.v[f] = dot3(&m.Sf[3 * (size_t)f], &rhoW.v[3 * (size_t)f]);
         }
         // fvsc::grad(p): under GaussVolPoint p's boundary conditions first (B6) -- the qgdFlux patches read the phiwStar just formed
-        if (stencilWord == "GaussVolPoint") correctBC_p();
+        if (wordOf(TERM_P) == "GaussVolPoint") correctBC_p();
     }
     // ... and the rest of updateFluxes.H from the gradient of p on.  On a shard the patch faces of GHOST cells hold a mid-step patch
     // pressure formed from an incomplete stencil (their far vertices lack cells): their owner's values arrive between the two halves
     // (midHaloMove), because the vertex values of p on the wall mix them into the stencil of owned faces.
     void updateFluxesB() {
         const int nF = m.nF;
-        gradPf = p.nc == 1 ? stencil->gradS(p) : stencil->gradV(p);
+        gradPf = termStencil[TERM_P]->gradS(p);
         jm = SurfField(m, 3); phiJm = SurfField(m, 1); phi = SurfField(m, 1);
         for (int f = 0; f < nF; ++f) {
             if (!liveFace[f]) continue;
@@ -1612,6 +1621,7 @@ struct Case {
     bool fusedSupported() const {
         const GaussVolPoint* gv = dynamic_cast<const GaussVolPoint*>(stencil);
         if (!gv || m.nGeomD != 3 || opt.implicitDiffusion || opt.adjustTimeStep || !m.haloGhost.empty() || !m.pointOps.empty() || opt.fluxSchemeU || opt.fluxSchemeH) return false;
+        for (int t = 0; t < 4; ++t) if (!termWord[t].empty() && termWord[t] != stencilWord) return false;   // mixed stencils: the field-at-a-time form only
         if (!gv->tf.empty() || !gv->of.empty()) return false;
         for (size_t ip = 0; ip < m.patches.size(); ++ip) {
             if (!m.patchHasFields((int)ip)) continue;
@@ -1888,7 +1898,7 @@ struct Case {
     void stepPhase5() { updateFields(); updateFluxesA(); }
     void stepPhase6() { updateFluxesB(); courantLocal(); }
     bool midNeeded() const {
-        if (m.haloGhost.empty() || stencilWord != "GaussVolPoint") return false;
+        if (m.haloGhost.empty() || wordOf(TERM_P) != "GaussVolPoint") return false;
         for (const PatchBC& B : bc) if (B.bcP == BC_QGDFLUX) return true;
         return false;
     }
@@ -3120,7 +3130,9 @@ static bool caseServesMesh(const Mesh& m) {
 void* orc_case_create(void* mesh, const orc_case_options* opt) {
     if (!caseServesMesh(((MeshHandle*)mesh)->m)) return nullptr;
     Case* c = new Case((MeshHandle*)mesh, *opt);
-    c->stencilWord = opt->stencil == FVSC_REDUCED ? "reduced" : (opt->stencil == FVSC_LEASTSQUARES ? "leastSquares" : "GaussVolPoint");
+    auto wordOfId = [](int id) { return std::string(id == FVSC_REDUCED ? "reduced" : (id == FVSC_LEASTSQUARES ? "leastSquares" : "GaussVolPoint")); };
+    c->stencilWord = wordOfId(opt->stencil);
+    for (int t = 0; t < 4; ++t) if (opt->termStencil[t] != 0) c->termWord[t] = wordOfId(opt->termStencil[t] - 1);
     const Mesh& m = c->m;
     if (m.sharded()) {
         c->ghostFlag.assign(m.nC, 0);

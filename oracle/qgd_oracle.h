@@ -30,6 +30,7 @@ typedef struct orc_case_options {
     int32_t implicitMaxIter;
     int32_t fluxSchemeU, fluxSchemeH;   /* 0 flux*psif (= Gauss linear), 1 Gauss upwind: divSchemes entry of qgdFlux's flux [QGDInterpolate.H L86-104] */
     int32_t pad_;
+    int32_t termStencil[4];             /* fvsc entries of grad(U), grad(e), grad(rho), grad(p): 0 = default, else 1 + FVSC_* [fvsc.C L51-58] */
 } orc_case_options;
 
 void* orc_mesh_create(int32_t nPoints, const double* points, int32_t nFaces,

@@ -44,7 +44,7 @@ class CaseOptions(C.Structure):
         ("R", C.c_double), ("Cv", C.c_double), ("mu", C.c_double), ("Pr", C.c_double), ("ScQGD", C.c_double),
         ("PrQGD", C.c_double), ("alphaQGD", C.c_double), ("deltaT", C.c_double), ("maxCo", C.c_double),
         ("maxDeltaT", C.c_double), ("cTau", C.c_double), ("implicitTol", C.c_double), ("implicitMaxIter", C.c_int32),
-        ("fluxSchemeU", C.c_int32), ("fluxSchemeH", C.c_int32), ("pad_", C.c_int32),
+        ("fluxSchemeU", C.c_int32), ("fluxSchemeH", C.c_int32), ("pad_", C.c_int32), ("termStencil", C.c_int32 * 4),
     ]
 
 

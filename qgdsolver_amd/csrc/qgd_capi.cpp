@@ -287,6 +287,10 @@ struct qgd_case_s {
     qgd_case_options opt{};
     GasModel gas{};
     int stencil = ST_GVP3;      // device stencil kind
+    // per-term fvsc entries (qgd_case_options::termStencil): mixB >= 0: the case walks its faces with the two stencils stencil < mixB, the
+    // gradient components in mixMask by mixB (bit k: rho, Ux, Uy, Uz, p, e)
+    int mixB = -1, mixMask = 0;
+    bool pRefresh = true;       // grad(p)'s word is GaussVolPoint: p's boundary conditions are re-evaluated inside it [GaussVolPointStencil_8C L73] (quirk B6)
     bool usesPoints = true;
     bool hasQgdFlux = false;
     bool phiwRegistered = false;
@@ -1402,6 +1406,27 @@ int qgd_case_create(qgd_device_t d, const qgd_case_options* opt, qgd_case_t* out
     try {
         c->dev = d; c->opt = *opt; c->stencil = st;
         c->usesPoints = (st == ST_GVP3 || st == ST_GVP2);
+        c->pRefresh = c->usesPoints;
+        {   // per-term entries [fvsc_8C L51-58]: grad(U), grad(e), grad(rho), grad(p) -> components (Ux,Uy,Uz), e, rho, p of the face gradient
+            static const int kBits[4] = {0x0e, 0x20, 0x01, 0x10};
+            int term[4], lo = st, hi = st;
+            for (int t = 0; t < 4; ++t) {
+                term[t] = st;
+                if (opt->termStencil[t] != 0) {
+                    const int r2 = deviceStencil(d, opt->termStencil[t] - 1, &term[t]);   // the checks of fvscOpName apply per term
+                    if (r2) { delete c; return r2; }
+                }
+                lo = std::min(lo, term[t]); hi = std::max(hi, term[t]);
+            }
+            for (int t = 0; t < 4; ++t)
+                if (term[t] != lo && term[t] != hi) { delete c; return fail(QGD_ERR_NOT_IMPLEMENTED, "qgd_case_create: more than two distinct fvsc stencils in one case"); }
+            if (lo != hi) {
+                c->stencil = lo; c->mixB = hi; c->mixMask = 0;
+                for (int t = 0; t < 4; ++t) if (term[t] == hi) c->mixMask |= kBits[t];
+                c->usesPoints = (hi == ST_GVP3 || hi == ST_GVP2 || lo == ST_GVP3 || lo == ST_GVP2);
+            } else c->stencil = lo;
+            c->pRefresh = (term[3] == ST_GVP3 || term[3] == ST_GVP2);
+        }
         GasModel& g = c->gas;
         g.R = opt->R; g.Cv = opt->Cv; g.mu0 = opt->mu; g.Pr = opt->Pr; g.ScQGD = opt->ScQGD; g.PrQGD = opt->PrQGD; g.rPrQGD = 1.0 / opt->PrQGD;
         g.alphaQGD = opt->alphaQGD;
@@ -1519,20 +1544,25 @@ static void assembleFluxes(qgd_case_s* c, bool adjust, int part = 0) {
     const Launcher L = launcherOf(c);
     const MeshView& m = c->dev->view;
     const CaseView& v = c->view;
-    const bool mid = c->usesPoints && c->hasQgdFlux;
+    const bool mid = c->pRefresh && c->hasQgdFlux;
+    auto bface = [&](int phiwOnly, bool adj) {
+        if (c->mixB >= 0) launchBoundaryFaceFluxMixed(L, c->stencil, c->mixB, c->mixMask, m, v, c->gas, c->bcDev, phiwOnly, adj);
+        else launchBoundaryFaceFlux(L, c->stencil, m, v, c->gas, c->bcDev, phiwOnly, adj);
+    };
     if (part != 2 && c->usesPoints) {
         launchPointInterp(L, m, v);
         launchBoundaryPoints(L, m, v, false);
         // fvsc::grad(p) under GaussVolPoint re-runs p's BCs after phiwStar was refreshed
         // [QGDFoam/updateFluxes.H L63-65, GaussVolPointStencil_8C L73]
-        if (mid) launchBoundaryFaceFlux(L, c->stencil, m, v, c->gas, c->bcDev, 1, false);  // + the mid-step pressure itself
+        if (mid) bface(1, false);  // + the mid-step pressure itself
     }
     if (part == 1) return;
     if (mid) launchBoundaryPoints(L, m, v, true);
-    launchFaceFlux(L, c->stencil, m, v, c->gas, adjust);
-    launchBoundaryFaceFlux(L, c->stencil, m, v, c->gas, c->bcDev, mid ? 2 : 0, adjust);
+    if (c->mixB >= 0) launchFaceFluxMixed(L, c->stencil, c->mixB, c->mixMask, m, v, c->gas, adjust);
+    else launchFaceFlux(L, c->stencil, m, v, c->gas, adjust);
+    bface(mid ? 2 : 0, adjust);
 }
-static bool midExchangeNeeded(const qgd_case_s* c) { return c->dev->sharded() && c->usesPoints && c->hasQgdFlux; }
+static bool midExchangeNeeded(const qgd_case_s* c) { return c->dev->sharded() && c->pRefresh && c->hasQgdFlux; }
 
 int qgd_case_set_fields(qgd_case_t c, const double* U, const double* T, const double* p) {
     QGD_TRY

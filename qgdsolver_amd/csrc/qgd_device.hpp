@@ -132,6 +132,10 @@ void launchBoundaryPoints(const Launcher& L, const MeshView& m, const CaseView& 
 void launchFaceFlux(const Launcher& L, int stencil, const MeshView& m, const CaseView& c, const GasModel& g, bool adjustDt);
 void launchBoundaryFaceFlux(const Launcher& L, int stencil, const MeshView& m, const CaseView& c, const GasModel& g,
                             const PatchBCDev* bc, int phiwOnly, bool adjustDt);
+// per-term fvsc entries: stencils a < b, component k of the six-component gradient by b where bit k of maskB is set (rho, Ux, Uy, Uz, p, e)
+void launchFaceFluxMixed(const Launcher& L, int a, int b, int maskB, const MeshView& m, const CaseView& c, const GasModel& g, bool adjustDt);
+void launchBoundaryFaceFluxMixed(const Launcher& L, int a, int b, int maskB, const MeshView& m, const CaseView& c, const GasModel& g,
+                                 const PatchBCDev* bc, int phiwOnly, bool adjustDt);
 void launchCellUpdate(const Launcher& L, const MeshView& m, const CaseView& c, const GasModel& g, int mode,
                       const int32_t* list, int nList);
 void launchBoundaryUpdate(const Launcher& L, const MeshView& m, const CaseView& c, const GasModel& g, const PatchBCDev* bc,

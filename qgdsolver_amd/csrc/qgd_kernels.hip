@@ -24,6 +24,8 @@
 //                    constScPrModel1_8C L97-131, QGDThermo_8C L84-111
 #include "qgd_device.hpp"
 
+#include <stdexcept>
+
 #include "../../include/qgd_amd.h"
 #include "qgd_stencil_dev.hpp"
 
@@ -347,6 +349,40 @@ void faceFluxGvp2Kernel(const MeshView m, const CaseView c, const GasModel gm, c
 #pragma unroll
             for (int d = 0; d < 3; ++d) g[d * 6 + k] = (d == ie1) ? g1 : ((d == ie2) ? g2 : 0.0);  // no dynamic register index
         }
+        finishInternalFace<DBG, UPW>(m, c, gm, f, o, n, Ao, An, Bo, Bn, w, hf, S, g, fp, adjustDt, cof, tauMin);
+    }
+    if (adjustDt) blockMaxMin(cof, tauMin, c.blkFace + 2 * (size_t)tile, false);
+}
+
+// ---------------------------------------------------------------------------
+// Per-term fvsc entries [fvsc_8C L51-58]: `fvsc{default GaussVolPoint; grad(p) reduced;}` gives the four gradients of updateFluxes.H
+// L41-65 different stencils.  Internal faces of such a case: the six-component gradient by STA and by STB through the generic
+// faceGradient (the arithmetic the fused kernels restate), component k taken from STB's where bit k of maskB is set
+// (k = rho, Ux, Uy, Uz, p, e), then the common tail.  Twice the gradient work of a uniform case; the flux algebra is the same.
+// ---------------------------------------------------------------------------
+template <int STA, int STB, bool DBG, bool UPW>
+__global__ __launch_bounds__(QGD_BLOCK) void faceFluxMixedKernel(const MeshView m, const CaseView c, const GasModel gm, const int adjustDt,
+                                                                const int maskB) {
+    const int tile = xcdTile((int)gridDim.x, m.xcdRun);
+    const int f = tile * QGD_BLOCK + (int)threadIdx.x;
+    double cof = -1e300, tauMin = 1e300;
+    if (f < m.nIF) {
+        const int o = m.own[f], n = m.nei[f], fp = m.fpos[f];
+        const double w = m.w[f], hf = m.hf[f];
+        const double S[3] = {m.Sx[f], m.Sy[f], m.Sz[f]};
+        const RecA Ao = c.A[o], An = c.A[n];
+        const RecB Bo = c.B[o], Bn = c.B[n];
+        FaceVals<6> v;
+        loadVals(Ao, v.o); loadVals(An, v.n);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) v.sn[k] = 0.0;
+        double gA[18], gB[18], g[18];
+        faceGradient<STA, 6, 1>(m, f, v, reinterpret_cast<const double*>(c.A), reinterpret_cast<const double*>(c.P), gA);
+        faceGradient<STB, 6, 1>(m, f, v, reinterpret_cast<const double*>(c.A), reinterpret_cast<const double*>(c.P), gB);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) g[i * 6 + k] = ((maskB >> k) & 1) ? gB[i * 6 + k] : gA[i * 6 + k];
         finishInternalFace<DBG, UPW>(m, c, gm, f, o, n, Ao, An, Bo, Bn, w, hf, S, g, fp, adjustDt, cof, tauMin);
     }
     if (adjustDt) blockMaxMin(cof, tauMin, c.blkFace + 2 * (size_t)tile, false);
@@ -750,10 +786,11 @@ __device__ __forceinline__ void boundaryVals(const MeshView& m, const CaseView& 
     }
 }
 
-template <int ST, bool DBG>
+template <int ST, bool DBG, int STB = ST>
 __global__ __launch_bounds__(QGD_BLOCK) void boundaryFaceFluxKernel(const MeshView m, const CaseView c, const GasModel gm,
                                                                    const PatchBCDev* __restrict__ bcs, const int phiwOnly,
-                                                                   const int adjustDt) {
+                                                                   const int adjustDt, const int maskB = 0) {
+    // STB != ST: per-term fvsc entries (faceFluxMixedKernel): component k of the gradient by STB where bit k of maskB is set
     // phiwOnly: 0 = fluxes; 1 = phiwStar + the mid-step pressure of qgdFlux patches only; 2 = fluxes, then the patch
     // pressure becomes the mid-step one
     const int b = blockIdx.x * QGD_BLOCK + threadIdx.x;
@@ -767,9 +804,17 @@ __global__ __launch_bounds__(QGD_BLOCK) void boundaryFaceFluxKernel(const MeshVi
             const RecA Ao = c.A[o], Ab = c.bA[b];
             const RecB Bb = c.bB[b];
             FaceVals<6> v;
-            boundaryVals(m, c, bc, f, Ao, Ab, v, ST == ST_GVP2);
+            boundaryVals(m, c, bc, f, Ao, Ab, v, (STB != ST && (maskB & 2) ? STB : ST) == ST_GVP2);   // (the stencil of grad(U))
             double g[18];
             faceGradient<ST, 6, 1>(m, f, v, reinterpret_cast<const double*>(c.A), reinterpret_cast<const double*>(c.P), g);
+            if (STB != ST) {
+                double gB[18];
+                faceGradient<STB, 6, 1>(m, f, v, reinterpret_cast<const double*>(c.A), reinterpret_cast<const double*>(c.P), gB);
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) if ((maskB >> k) & 1) g[i * 6 + k] = gB[i * 6 + k];
+            }
             FaceState s;
             s.rhof = Ab.rho;
             const double Ub[3] = {Ab.ux, Ab.uy, Ab.uz};
@@ -1549,6 +1594,38 @@ static void launchFaceFluxT(const Launcher& L, int stencil, const MeshView& m, c
             break;
         default: faceFluxGvp2Kernel<DBG, UPW><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, adj); break;
     }
+}
+// the two-stencil walk of a case with per-term fvsc entries; (a, b) normalised to a < b by the caller
+template <bool DBG, bool UPW>
+static void launchFaceFluxMixedT(const Launcher& L, int a, int b, int maskB, const MeshView& m, const CaseView& c, const GasModel& g, bool adj) {
+    const int grid = gridFor(m.nIF);
+    if (grid == 0) return;
+    if (a == ST_REDUCED && b == ST_LSQ) faceFluxMixedKernel<ST_REDUCED, ST_LSQ, DBG, UPW><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, adj, maskB);
+    else if (a == ST_REDUCED && b == ST_GVP3) faceFluxMixedKernel<ST_REDUCED, ST_GVP3, DBG, UPW><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, adj, maskB);
+    else if (a == ST_REDUCED && b == ST_GVP2) faceFluxMixedKernel<ST_REDUCED, ST_GVP2, DBG, UPW><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, adj, maskB);
+    else if (a == ST_LSQ && b == ST_GVP2) faceFluxMixedKernel<ST_LSQ, ST_GVP2, DBG, UPW><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, adj, maskB);
+    else throw std::invalid_argument("launchFaceFluxMixed: no such pair of stencils on one mesh");
+}
+void launchFaceFluxMixed(const Launcher& L, int a, int b, int maskB, const MeshView& m, const CaseView& c, const GasModel& g, bool adjustDt) {
+    const bool upw = g.upwindU || g.upwindH;
+    QGD_TIMED(L, QGD_K_FACE, (c.dbg ? (upw ? launchFaceFluxMixedT<true, true>(L, a, b, maskB, m, c, g, adjustDt) : launchFaceFluxMixedT<true, false>(L, a, b, maskB, m, c, g, adjustDt))
+                                    : (upw ? launchFaceFluxMixedT<false, true>(L, a, b, maskB, m, c, g, adjustDt) : launchFaceFluxMixedT<false, false>(L, a, b, maskB, m, c, g, adjustDt))));
+}
+template <bool DBG>
+static void launchBFaceFluxMixedT(const Launcher& L, int a, int b, int maskB, const MeshView& m, const CaseView& c, const GasModel& g,
+                                  const PatchBCDev* bc, int phiwOnly, bool adj) {
+    const int grid = gridFor(m.nBF);
+    if (grid == 0) return;
+    if (a == ST_REDUCED && b == ST_LSQ) boundaryFaceFluxKernel<ST_REDUCED, DBG, ST_LSQ><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, bc, phiwOnly, adj, maskB);
+    else if (a == ST_REDUCED && b == ST_GVP3) boundaryFaceFluxKernel<ST_REDUCED, DBG, ST_GVP3><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, bc, phiwOnly, adj, maskB);
+    else if (a == ST_REDUCED && b == ST_GVP2) boundaryFaceFluxKernel<ST_REDUCED, DBG, ST_GVP2><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, bc, phiwOnly, adj, maskB);
+    else if (a == ST_LSQ && b == ST_GVP2) boundaryFaceFluxKernel<ST_LSQ, DBG, ST_GVP2><<<grid, QGD_BLOCK, 0, L.stream>>>(m, c, g, bc, phiwOnly, adj, maskB);
+    else throw std::invalid_argument("launchBoundaryFaceFluxMixed: no such pair of stencils on one mesh");
+}
+void launchBoundaryFaceFluxMixed(const Launcher& L, int a, int b, int maskB, const MeshView& m, const CaseView& c, const GasModel& g,
+                                 const PatchBCDev* bc, int phiwOnly, bool adjustDt) {
+    QGD_TIMED(L, QGD_K_BFACE, (c.dbg && phiwOnly != 1 ? launchBFaceFluxMixedT<true>(L, a, b, maskB, m, c, g, bc, phiwOnly, adjustDt)
+                                                   : launchBFaceFluxMixedT<false>(L, a, b, maskB, m, c, g, bc, phiwOnly, adjustDt)));
 }
 void launchFaceFlux(const Launcher& L, int stencil, const MeshView& m, const CaseView& c, const GasModel& g, bool adjustDt) {
     const bool upw = g.upwindU || g.upwindH;

@@ -552,8 +552,8 @@ def _find_entry(d, key):
 def read_face_schemes(fs, flux_terms, grad_terms, what="system/fvSchemes"):
     """The fvSchemes sub-dictionaries the face-flux path consults, checked against what the library computes.
 
-    * ``fvsc`` [fvsc.C L47-58]: the word of every term in ``grad_terms`` (its own entry, else ``default``).  The fused case has ONE
-      stencil: a term whose word differs from the others is refused, naming the entry.
+    * ``fvsc`` [fvsc.C L47-58]: the word of every term in ``grad_terms`` (its own entry, else ``default``), returned per term.  The
+      QGDFoam case serves up to two distinct stencils (``qgd_case_options::termStencil``); what a caller cannot serve it refuses itself.
     * ``interpolationSchemes`` [QGDInterpolate.H L42-66]: a field with an ``interpolate(<name>)`` entry, or any field under a
       ``default`` other than ``none``, goes to ``fvc::interpolate``: with ``linear`` that is linearInterpolate = the numbers the
       library produces; anything else is refused, naming the entry.  The sub-dictionary must exist (``subDict`` is fatal otherwise).
@@ -561,7 +561,7 @@ def read_face_schemes(fs, flux_terms, grad_terms, what="system/fvSchemes"):
       ``Gauss linear`` is flux * linear(psi) = the default branch, ``Gauss upwind`` the in-register upwind branch of the face kernels
       (options ``fluxScheme*``); limited schemes are refused.  ``default`` is NOT consulted by qgdFlux (``found(fluxName)``).
 
-    Returns (stencil word, {flux term: 'linear' | 'upwind'})."""
+    Returns ({gradient term: stencil word}, {flux term: 'linear' | 'upwind'})."""
     fvsc = fs.get("fvsc")
     if not isinstance(fvsc, dict):
         raise FoamFileError(f"{what}: sub-dictionary 'fvsc' is missing [fvsc.C L51]")
@@ -573,11 +573,6 @@ def read_face_schemes(fs, flux_terms, grad_terms, what="system/fvSchemes"):
             if v is None:
                 raise FoamFileError(f"{what}: fvsc has neither '{term}' nor 'default' [fvsc.C L57]")
         words[term] = _scheme_words(v)[0]
-    distinct = sorted(set(words.values()))
-    if len(distinct) > 1:
-        raise FoamFileError(f"{what}: fvsc gives different stencils to different terms ({words}); the resident case runs ONE stencil "
-                            f"for all its face gradients -- use the fvsc operators of a Device for mixed stencils")
-    stencil = distinct[0]
     interp = fs.get("interpolationSchemes")
     if not isinstance(interp, dict):
         raise FoamFileError(f"{what}: sub-dictionary 'interpolationSchemes' is missing (qgdInterpolate looks it up, QGDInterpolate.H L44)")
@@ -606,7 +601,7 @@ def read_face_schemes(fs, flux_terms, grad_terms, what="system/fvSchemes"):
             flux[term] = "upwind"
         else:
             raise FoamFileError(f"{what}: divSchemes.{term} '{' '.join(w)}' is not supported (accepted: Gauss linear, Gauss upwind)")
-    return stencil, flux
+    return words, flux
 
 
 def _check_fv_schemes(fs, mesh, need_laplacian, need_grad, what="system/fvSchemes"):
@@ -701,7 +696,16 @@ def read_case_setup(case_dir, time="0"):
     fs_path = os.path.join(case_dir, "system", "fvSchemes")
     fs = read_dict(fs_path)
     # the four fvsc::grad calls [QGDFoam/updateFluxes.H L41-65] and the two qgdFlux calls [L78, L119]
-    opt["stencil"], flux = read_face_schemes(fs, ("div(phiJm,U)", "div(phiJm,H)"), ("grad(U)", "grad(e)", "grad(rho)", "grad(p)"), fs_path)
+    words, flux = read_face_schemes(fs, ("div(phiJm,U)", "div(phiJm,H)"), ("grad(U)", "grad(e)", "grad(rho)", "grad(p)"), fs_path)
+    # the case's `stencil` = the default word when there is one, else grad(U)'s; terms with another word travel as termStencils
+    dflt = _find_entry(fs["fvsc"], "default")
+    opt["stencil"] = _scheme_words(dflt)[0] if dflt is not None else words["grad(U)"]
+    per_term = {t: w for t, w in words.items() if w != opt["stencil"]}
+    if len(set(words.values())) > 2:
+        raise FoamFileError(f"{fs_path}: fvsc gives the four face gradients more than two distinct stencils ({words}); the resident case "
+                            f"serves at most two")
+    if per_term:
+        opt["termStencils"] = per_term
     opt["fluxSchemeU"] = 1 if flux["div(phiJm,U)"] == "upwind" else 0
     opt["fluxSchemeH"] = 1 if flux["div(phiJm,H)"] == "upwind" else 0
     _check_fv_schemes(fs, mesh, need_laplacian=bool(opt["implicitDiffusion"]), need_grad=bool(opt["implicitDiffusion"]), what=fs_path)
@@ -834,7 +838,12 @@ def read_qhd_case_setup(case_dir, time="0"):
     fs_path = os.path.join(case_dir, "system", "fvSchemes")
     fs = read_dict(fs_path)
     # fvsc::grad of U, W, T [QHDFoam/updateFields.H L36-40] and p [QHDUEqn.H L36]; qgdFlux(phi,U,Uf) [QHDUEqn.H L41], qgdFlux(phi,T,Tf) [QHDTEqn.H L65]
-    opt["stencil"], flux = read_face_schemes(fs, ("div(phi,U)", "div(phi,T)"), ("grad(U)", "grad(W)", "grad(T)", "grad(p)"), fs_path)
+    words, flux = read_face_schemes(fs, ("div(phi,U)", "div(phi,T)"), ("grad(U)", "grad(W)", "grad(T)", "grad(p)"), fs_path)
+    used = {t: w for t, w in words.items() if t != "grad(W)"}     # gradWf [QHDFoam/updateFields.H L38] is formed by the reference and never consumed
+    if len(set(used.values())) > 1:
+        raise FoamFileError(f"{fs_path}: fvsc gives different stencils to different terms ({used}); the resident QHDFoam case runs ONE stencil "
+                            f"for its face gradients -- use the fvsc operators of a Device for mixed stencils")
+    opt["stencil"] = used["grad(U)"]
     opt["fluxSchemeU"] = 1 if flux["div(phi,U)"] == "upwind" else 0
     opt["fluxSchemeT"] = 1 if flux["div(phi,T)"] == "upwind" else 0
     _check_fv_schemes(fs, mesh, need_laplacian=True, need_grad=True, what=fs_path)

@@ -19,12 +19,21 @@ STENCIL_IDS = {"reduced": L.FVSC_REDUCED, "leastSquares": L.FVSC_LEASTSQUARES, "
                "GaussVolPoint": L.FVSC_GAUSSVOLPOINT}
 
 
+TERM_ORDER = ("grad(U)", "grad(e)", "grad(rho)", "grad(p)")   # qgd_case_options::termStencil [QGDFoam/updateFluxes.H L41-65]
+
+
 def default_options(**kw):
+    """qgd_case_options with the library defaults.  ``stencil`` may be a word; ``termStencils`` a dict {"grad(p)": "reduced", ...} of
+    per-term fvsc entries [fvsc.C L51-58] (terms not named take ``stencil``)"""
     o = L.CaseOptions()
     L.check(L.lib.qgd_case_options_default(C.byref(o)), "qgd_case_options_default")
     for k, v in kw.items():
         if k == "stencil" and isinstance(v, str):
             v = STENCIL_IDS[v]
+        if k == "termStencils":
+            for term, word in (v or {}).items():
+                o.termStencil[TERM_ORDER.index(term)] = 1 + (STENCIL_IDS[word] if isinstance(word, str) else int(word))
+            continue
         setattr(o, k, v)
     return o
 

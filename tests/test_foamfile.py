@@ -300,6 +300,19 @@ def test_schemes_that_change_nothing_are_accepted(tmp_path):
     assert ff.read_case_setup(str(tmp_path / "none"))[1]["stencil"] == "leastSquares"
 
 
+def test_per_term_fvsc_entries_become_options(tmp_path):
+    """fvsc{default leastSquares; grad(p) reduced;} [fvsc.C L51-58]: the term's own word travels as qgd_case_options::termStencil"""
+    write_step_case(str(tmp_path), schemes={"fvsc": "default leastSquares; grad(p) reduced; grad(U) leastSquares;"})
+    opt = ff.read_case_setup(str(tmp_path))[1]
+    assert opt["stencil"] == "leastSquares" and opt["termStencils"] == {"grad(p)": "reduced"}
+    o = q.default_options(**opt)
+    assert list(o.termStencil) == [0, 0, 0, 1 + L.FVSC_REDUCED] and o.stencil == L.FVSC_LEASTSQUARES
+    # no default: every term carries its own word
+    write_step_case(str(tmp_path / "nodefault"), schemes={"fvsc": "grad(U) GaussVolPoint; grad(e) GaussVolPoint; grad(rho) GaussVolPoint; grad(p) reduced;"})
+    opt = ff.read_case_setup(str(tmp_path / "nodefault"))[1]
+    assert opt["stencil"] == "GaussVolPoint" and opt["termStencils"] == {"grad(p)": "reduced"}
+
+
 def test_gauss_upwind_fluxes_become_options(tmp_path):
     write_step_case(str(tmp_path), schemes={"divSchemes": "default none; div(phiJm,U) Gauss upwind;"})
     opt = ff.read_case_setup(str(tmp_path))[1]
@@ -316,7 +329,7 @@ def test_gauss_upwind_fluxes_become_options(tmp_path):
     ({"interpolationSchemes": "default cubic;"}, "interpolationSchemes.default 'cubic'"),
     ({"interpolationSchemes": "default linear; interpolate(rhoU) vanLeer;"}, r"interpolationSchemes.interpolate\(rhoU\) 'vanLeer'"),
     ({"divSchemes": "default none; div(phiJm,H) Gauss limitedLinear 1;"}, r"divSchemes.div\(phiJm,H\) 'Gauss limitedLinear 1'"),
-    ({"fvsc": "default leastSquares; grad(p) reduced;"}, "different stencils"),
+    ({"fvsc": "default leastSquares; grad(p) reduced; grad(e) GaussVolPoint;"}, "more than two distinct stencils"),
     ({"fvsc": "grad(U) reduced;"}, "neither 'grad\\(e\\)' nor 'default'"),
     ({"interpolationSchemes": None}, "'interpolationSchemes' is missing"),
     ({"divSchemes": None}, "'divSchemes' is missing"),
