@@ -167,6 +167,32 @@ def cpu_rank_budget(n):
     return max(1, min(128, cores))
 
 
+def host_description():
+    """what the box's host is, beside what this process may use of it: CPU model, sockets, physical cores, hardware threads (lscpu's
+    facts from /proc/cpuinfo) and the cgroup quota -- SURVEY 8(d) asks for one rank per PHYSICAL core; a container quota below that is
+    a property of the measurement, stated with it"""
+    model, phys, threads = None, set(), 0
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model is None:
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                pid = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":", 1)[1].strip()
+            elif line.startswith("processor"):
+                threads += 1
+            elif not line.strip() and pid is not None:
+                phys.add((pid, cid)); pid = cid = None
+        if pid is not None:
+            phys.add((pid, cid))
+    except OSError:
+        pass
+    return {"cpu_model": model, "sockets": len({p for p, _ in phys}) or None, "physical_cores": len(phys) or None,
+            "hardware_threads": threads or (os.cpu_count() or None), "cpu_quota": host_cpu_quota()}
+
+
 def cpu_baseline(n, steps, ranks):
     """The CPU oracle (a restatement of the reference listings: the reference itself cannot be built here) timed on
     the host cores the way the reference would run: R single-threaded ranks, one per core, each with its own slab of
@@ -199,9 +225,14 @@ def cpu_baseline(n, steps, ranks):
     if len(times) != ranks:
         return {"value": None, "unit": "Mcell-steps/s", "cores": ranks, "kind": "port", "sample": "CPU baseline ranks failed"}
     dt = max(times)
+    host = host_description()
     return {"value": ranks * n ** 3 * steps / dt / 1e6, "unit": "Mcell-steps/s", "cores": ranks, "kind": "port",
             "sample": f"{ranks} single-threaded oracle ranks x {n}^3-cell box x {steps} steps (field-at-a-time restatement "
-                      f"of the reference listings, no halo exchange; slowest rank {dt:.1f} s)",
+                      f"of the reference listings, no halo exchange; slowest rank {dt:.1f} s); host: {host['cpu_model']}, "
+                      f"{host['sockets']} socket(s), {host['physical_cores']} physical cores, {host['hardware_threads']} hardware threads, "
+                      f"of which this process may use {host['cpu_quota']} (cgroup quota / affinity): the ranks are what the quota and "
+                      f"the memory allow, NOT one per physical core",
+            "host": host,
             "single_rank_value": n ** 3 * steps / min(times) / 1e6,
             # the same ranks, the same steps, the flux assembly fused (measured, not modelled)
             "fused": ({"value": ranks * n ** 3 * steps / max(fused) / 1e6, "unit": "Mcell-steps/s",
