@@ -532,6 +532,7 @@ struct ISolveView {
     const double* a;                   // nF, at the faces' slot-major positions (MeshView::fpos / cfPos)
     const double* diag; const double* rhs; double* x;    // NR * nC each, component-major
     double *r, *d, *q;                 // NR * nC each
+    float* df;                         // Chebyshev: d_{i-1} of the recurrence d_i = c1 d_{i-1} + c2 z, kept in single precision (see iChebKernel)
     double* part;                      // partial sums: (row * NR + k) * nBlocks + block
     double* ctl;
     int nBlocks;
@@ -612,6 +613,9 @@ __global__ __launch_bounds__(QGD_BLOCK) void iApplyKernel(const MeshView m, cons
 // One Chebyshev step (see the head of this section).  FIRST: x_1 = x_0 + D^-1 r_0 from the residual phase 0 left (no product);
 // otherwise the product on the current iterate (buffer step & 1), the new d and the next iterate into the other buffer, and the
 // partial sums of |b - A x_i|.  Components that are done are not touched; all others have made the same number of steps.
+#ifndef QGD_CHEB_DF
+#define QGD_CHEB_DF 1   // 0: the recurrence's d in double (A/B: profiles/r05_ab_implicit_direction_f32.txt)
+#endif
 template <int NR, int FIRST>
 __global__ __launch_bounds__(QGD_BLOCK) void iChebKernel(const MeshView m, const ISolveView v) {
     const int blk = FIRST ? (int)blockIdx.x : xcdRunBlock(v.xrun);
@@ -664,9 +668,20 @@ __global__ __launch_bounds__(QGD_BLOCK) void iChebKernel(const MeshView m, const
             if (FIRST) { rc = v.r[j]; dn = rc / dg; }
             else {
                 rc = v.rhs[j] - (dg * xv - v.gam[k] * acc[k]);
+#if QGD_CHEB_DF
+                dn = v.ctl[ICTL(I_C1, k)] * (double)v.df[j] + v.ctl[ICTL(I_C2, k)] * (rc / dg);
+#else
                 dn = v.ctl[ICTL(I_C1, k)] * v.d[j] + v.ctl[ICTL(I_C2, k)] * (rc / dg);
+#endif
             }
+            // the update x_{i+1} = x_i + d_i is made with d_i in double; what the NEXT step's recurrence reads back is d_i rounded to single
+            // precision (4 + 4 instead of 8 + 8 B per component and step).  z is the true residual of the iterate every step, so the rounding
+            // (6e-8 of a term that c1 < 1 damps) perturbs the polynomial, not the fixed point: same solution to the same tolerance
+#if QGD_CHEB_DF
+            v.df[j] = (float)dn;
+#else
             v.d[j] = dn;
+#endif
             dst[j] = xv + dn;
             s0[k] = fabs(rc);
         }
@@ -909,6 +924,7 @@ struct ImplicitSolver {
     hipStream_t stream = nullptr;
     int ob = 0, oe = 0;
     double *r = nullptr, *d = nullptr, *q = nullptr, *xb = nullptr, *part = nullptr, *ctl = nullptr, *hostCtl = nullptr;
+    float* df = nullptr;
     bool cheb = true;           // QGD_IMPL_SOLVER: "cheb" (default) | "pcg"
     int hostSteps = 0;          // Chebyshev steps queued so far in the solve in flight (which buffer a halo message moves)
     double* stats = nullptr;    // device: [0] unconverged steps, [1] flag of the step in flight, [2], [3] the same for stalled solves (iStatKernel), then the control blocks of the last U and e solves
@@ -940,7 +956,7 @@ ImplicitSolver* implicitSolverCreate(hipStream_t stream, const MeshView& m, int 
     }
     const size_t nC = (size_t)m.nC, nb = (size_t)gridOf(S->oe - S->ob);
     try {
-        ICHECK(hipMalloc((void**)&S->r, sizeof(double) * 4 * nC)); ICHECK(hipMalloc((void**)&S->d, sizeof(double) * 4 * nC));
+        ICHECK(hipMalloc((void**)&S->r, sizeof(double) * 4 * nC)); ICHECK(hipMalloc((void**)&S->d, sizeof(double) * 4 * nC)); ICHECK(hipMalloc((void**)&S->df, sizeof(float) * 4 * nC)); ICHECK(hipMemset(S->df, 0, sizeof(float) * 4 * nC));
         ICHECK(hipMalloc((void**)&S->q, sizeof(double) * 4 * nC)); ICHECK(hipMalloc((void**)&S->part, sizeof(double) * 12 * std::max<size_t>(nb, 1)));
         ICHECK(hipMalloc((void**)&S->xb, sizeof(double) * 4 * nC));
         ICHECK(hipMemset(S->xb, 0, sizeof(double) * 4 * nC));
@@ -957,7 +973,7 @@ ImplicitSolver* implicitSolverCreate(hipStream_t stream, const MeshView& m, int 
 }
 void implicitSolverFree(ImplicitSolver* S) {
     if (!S) return;
-    (void)hipFree(S->r); (void)hipFree(S->d); (void)hipFree(S->q); (void)hipFree(S->xb); (void)hipFree(S->part); (void)hipFree(S->ctl); (void)hipFree(S->stats);
+    (void)hipFree(S->r); (void)hipFree(S->d); (void)hipFree(S->df); (void)hipFree(S->q); (void)hipFree(S->xb); (void)hipFree(S->part); (void)hipFree(S->ctl); (void)hipFree(S->stats);
     if (S->hostCtl) (void)hipHostFree(S->hostCtl);
     for (hipEvent_t e : S->ev) if (e) (void)hipEventDestroy(e);
     delete S;
@@ -1036,7 +1052,7 @@ void implicitSolveSetup(ImplicitSolver* S, int nRhs, int validMask, const double
     ISolveView& v = S->v;
     v.NR = nRhs; v.ob = S->ob; v.n = S->oe - S->ob; v.nC = S->m.nC; v.a = a; v.diag = diag; v.rhs = rhs; v.x = x;
     for (int k = 0; k < 4; ++k) v.gam[k] = gamma && k < nRhs ? gamma[k] : 1.0;
-    v.r = S->r; v.d = S->d; v.q = S->q; v.xb = S->xb; v.part = S->part; v.ctl = S->ctl; v.nBlocks = gridOf(v.n);
+    v.r = S->r; v.d = S->d; v.df = S->df; v.q = S->q; v.xb = S->xb; v.part = S->part; v.ctl = S->ctl; v.nBlocks = gridOf(v.n);
     v.xrun = S->rowRun;
     S->NR = nRhs; S->validMask = validMask; S->tol = tol; S->maxIter = maxIter;
 }
