@@ -1908,6 +1908,7 @@ struct qgd_qhd_case_s {
     qgd_qhd_options opt{};
     int stencil = ST_GVP3;
     bool usesPoints = true, fieldsSet = false;
+    double *pPrev = nullptr, *pPrev2 = nullptr; int pPrevHave = 0;   // QGD_QHD_PEXTRAP: p of the step before (start value of the pressure solve, qgd_qhd.hip)
     std::vector<PatchBCDev> bc;
     PatchBCDev* bcDev = nullptr;
     DeviceArena arena;
@@ -1982,6 +1983,12 @@ int qgd_qhd_case_create(qgd_device_t d, const qgd_qhd_options* opt, qgd_qhd_case
         for (size_t i = 0; i < d->patches.size(); ++i) initPatchBC(c->bc[i], d->patches[i]);
         c->bcDev = a.alloc<PatchBCDev>(std::max<size_t>(1, c->bc.size()));
         c->bKind = a.alloc<uint8_t>(nB);
+        {
+            static const int kModes[] = {0, 1, 2};
+            const int mode = envChoice("QGD_QHD_PEXTRAP", 2, kModes, 3);   // 0: OpenFOAM's start value p^n; 1: linear; 2: quadratic extrapolation in time (default)
+            if (mode >= 1) c->pPrev = a.alloc<double>(nC);
+            if (mode >= 2) c->pPrev2 = a.alloc<double>(nC);
+        }
     } catch (...) { if (c->implSolver) implicitSolverFree(c->implSolver); c->arena.release(); delete c; throw; }
     d->liveCases++;
     *out = c;
@@ -2060,6 +2067,7 @@ int qgd_qhd_case_set_fields(qgd_qhd_case_t c, const double* U, const double* T, 
     c->solver = pressureSolverCreate(d->stream, m, c->tbr, c->bKind, c->localRefCell, c->opt.precond, d->ownedBegin, d->ownedEnd,
                                      d->cellGlobal.empty() ? nullptr : d->cellGlobal.data(), d->cellGlobalOffset, d->sharded());
     c->fieldsSet = true;
+    c->pPrevHave = 0;
     c->time = 0; c->steps = 0;
     return QGD_OK;
     QGD_CATCH
@@ -2074,6 +2082,7 @@ static void qhdPhase(qgd_qhd_case_s* c, int phase) {
     switch (phase) {
         case 0:
             launchQhdAssemble(d->stream, c->stencil, c->usesPoints, m, c->view, c->bcDev);
+            if (c->pPrev) { launchQhdExtrapolateP(d->stream, m.nC, c->view.p, c->pPrev, c->pPrev2, c->pPrevHave); c->pPrevHave = std::min(c->pPrevHave + 1, 2); }
             pressureSolveBegin(c->solver, c->view.phiu, c->view.phiwo, c->view.pb, c->view.pgb, c->opt.pTol, c->opt.pRelTol, c->opt.pMaxIter, c->view.p);
             break;
         case 1: case 2: case 3: case 4: case 5: pressureSolvePhase(c->solver, phase); break;

@@ -273,6 +273,7 @@ struct QhdView {
 void launchQhdInit(hipStream_t s, const MeshView& m, const QhdView& q, const PatchBCDev* bc, const double* U, const double* T, const double* p,
                    double* tauF, double* taubyrho);
 void launchQhdAssemble(hipStream_t s, int stencil, bool usesPoints, const MeshView& m, const QhdView& q, const PatchBCDev* bc);
+void launchQhdExtrapolateP(hipStream_t s, int nC, double* p, double* pPrev, double* pPrev2, int have);
 void launchQhdPostSolve(hipStream_t s, const MeshView& m, const QhdView& q, const PatchBCDev* bc);
 void launchQhdAdvance(hipStream_t s, int stencil, bool usesPoints, const MeshView& m, const QhdView& q, const PatchBCDev* bc, bool needRef,
                       int localRefCell, double refValue, double* shift);

@@ -713,6 +713,26 @@ void launchQhdAssemble(hipStream_t s, int stencil, bool usesPoints, const MeshVi
     // velocity now (their own gradient travels with the pressure message, after the solve)
     qhdCellGradKernel<<<gridOf(m.nC), QGD_BLOCK, 0, s>>>(m, q);
 }
+// The start value of the pressure solve [QHDpEqn.H L45]: OpenFOAM starts from the field as it stands, p^n (QGD_QHD_PEXTRAP=0).  The default
+// (QGD_QHD_PEXTRAP=2) starts from the extrapolation in time 3 p^n - 3 p^(n-1) + p^(n-2) (=1: the linear 2 p^n - p^(n-1)): the same system,
+// the same tolerance, a smaller first residual on a flow that evolves smoothly -- 6 -> 4 / 3 conjugate-gradient iterations per step on the
+// 8 M-cell cavity, 9 -> 5 on the 16 M-cell irregular mesh (profiles/r05_ab_qhd_pressure_start_value.txt).  A solver-internal choice: the
+// answer is the same to the solve's tolerance, the "Initial residual" of the log is not; a start value that happens to be worse than p^n
+// costs iterations, never convergence.  pPrev <- p^n either way; have: how many earlier fields there are (0, 1, 2).
+// (pPrev2 != nullptr and have >= 2: the quadratic 3 p^n - 3 p^(n-1) + p^(n-2))
+__global__ __launch_bounds__(QGD_BLOCK) void qhdExtrapolatePKernel(const int n, double* __restrict__ p, double* __restrict__ pPrev, double* __restrict__ pPrev2,
+                                                                  const int have) {
+    const int i = blockIdx.x * QGD_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const double pn = p[i], p1 = pPrev[i];
+    if (pPrev2 && have >= 2) p[i] = 3.0 * pn - 3.0 * p1 + pPrev2[i];
+    else if (have) p[i] = 2.0 * pn - p1;
+    if (pPrev2) pPrev2[i] = p1;
+    pPrev[i] = pn;
+}
+void launchQhdExtrapolateP(hipStream_t s, int nC, double* p, double* pPrev, double* pPrev2, int have) {
+    if (nC > 0) qhdExtrapolatePKernel<<<gridOf(nC), QGD_BLOCK, 0, s>>>(nC, p, pPrev, pPrev2, have);
+}
 // after the solve: solve() ends in correctBoundaryConditions() (a shard then sends p and these patch values to its neighbours)
 void launchQhdPostSolve(hipStream_t s, const MeshView& m, const QhdView& q, const PatchBCDev* bc) {
     if (m.nBF) qhdPressureBcKernel<<<gridOf(m.nBF), QGD_BLOCK, 0, s>>>(m, q, bc);
