@@ -290,6 +290,7 @@ struct qgd_case_s {
     // per-term fvsc entries (qgd_case_options::termStencil): mixB >= 0: the case walks its faces with the two stencils stencil < mixB, the
     // gradient components in mixMask by mixB (bit k: rho, Ux, Uy, Uz, p, e)
     int mixB = -1, mixMask = 0;
+    int implXOrder = 0;         // QGD_IMPL_XEXTRAP: order of the start-value extrapolation of the implicit branch's solves (ImplView::have counts up to it)
     bool pRefresh = true;       // grad(p)'s word is GaussVolPoint: p's boundary conditions are re-evaluated inside it [GaussVolPointStencil_8C L73] (quirk B6)
     bool usesPoints = true;
     bool hasQgdFlux = false;
@@ -1467,6 +1468,14 @@ int qgd_case_create(qgd_device_t d, const qgd_case_options* opt, qgd_case_t* out
             iv.xE = a.alloc<double>(nC); iv.diagE = a.alloc<double>(nC); iv.rhsE = a.alloc<double>(nC);
             c->implSolver = implicitSolverCreate(d->stream, v, d->ownedBegin, d->ownedEnd);
             { static const int kOnOff[] = {0, 1}; c->reuseGradU = envChoice("QGD_IMPL_REUSE_GRADU", 1, kOnOff, 2) != 0; }
+            {   // start values of the two solves (qgd_implicit.hip "start values"): 0 = OpenFOAM's (the predictor), 1..3 = + the extrapolated correction
+                static const int kOrders[] = {0, 1, 2, 3};
+                c->implXOrder = envChoice("QGD_IMPL_XEXTRAP", 3, kOrders, 4);
+                if (c->implXOrder > 0) {
+                    iv.pred = a.alloc<double>(4 * nC); iv.dh0 = a.alloc<double>(4 * nC); iv.dh1 = a.alloc<double>(4 * nC); iv.dh2 = a.alloc<double>(4 * nC);
+                }
+                iv.have = 0;
+            }
         }
         c->bc.resize(d->patches.size());
         for (size_t i = 0; i < d->patches.size(); ++i) initPatchBC(c->bc[i], d->patches[i]);
@@ -1596,6 +1605,7 @@ int qgd_case_set_fields(qgd_case_t c, const double* U, const double* T, const do
     c->phiwRegistered = true;  // createFaceFluxes.H registers "phiwStar" before the loop starts
     c->fieldsSet = true;
     c->gradUValid = false;
+    c->impl.have = 0;          // the start values of the implicit solves begin without a history
     c->time = 0; c->steps = 0;
     if (c->implSolver) { implicitSolverSetStream(c->implSolver, c->stream()); implicitStatsReset(c->implSolver); HIP_CHECK(hipStreamSynchronize(c->stream())); }
     return QGD_OK;
@@ -1670,6 +1680,11 @@ static void implicitPhase(qgd_case_s* c, int phase) {
         case 35:
             implicitSolveEnd(S, 1);
             launchImplicitPart(st, m, c->view, c->impl, c->gas, c->bcDev, S, tol, maxIter, 5);
+            if (c->impl.pred) {   // this step's corrections sit in the oldest slot: it becomes the newest
+                ImplView& iv = c->impl;
+                double* t = iv.dh2; iv.dh2 = iv.dh1; iv.dh1 = iv.dh0; iv.dh0 = t;
+                iv.have = std::min(iv.have + 1, c->implXOrder);
+            }
             implicitStepMark(S, false);
             launchBoundaryUpdate(launcherOf(c), m, c->view, c->gas, c->bcDev, false, c->phiwRegistered, 0, nullptr, 0);
             break;

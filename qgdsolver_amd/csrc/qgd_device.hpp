@@ -216,6 +216,11 @@ struct ImplView {
     double* rhoNew;                      // nC
     double *xU, *diagU, *rhsU;           // 3*nC SoA: the component systems of UEqn
     double *xE, *diagE, *rhsE;           // nC
+    // start values of the two solves (QGD_IMPL_XEXTRAP, qgd_implicit.hip "start values"): the predictor each solve would start from as the
+    // listing has it (U = rhoU/rho, e = rhoE/rho - |U|^2/2), and the corrections solution - predictor of the last `have` steps, newest first
+    // (dh2 doubles as this step's write target); 4*nC each, component-major {Ux, Uy, Uz, e}; pred == nullptr: off
+    double *pred, *dh0, *dh1, *dh2;
+    int have;
 };
 // the branch as parts 0..5 (gradient | faces + U systems | store U | gradient of the new U | sigma + e system | finish) around its two
 // multi-right-hand-side Jacobi-PCG solves, all stream-ordered with the scalars of the solves in a device control block

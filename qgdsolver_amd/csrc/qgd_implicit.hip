@@ -61,6 +61,27 @@ __device__ __forceinline__ void muDev2T(const double* g, const double mu, double
         }
 }
 
+// ---- start values of the two solves -------------------------------------------------------------------------------------------------------
+// OpenFOAM starts a solve from the field as it stands: the predictor U = rhoU/rho [QGDUEqn.H L48-50], e = rhoE/rho - |U|^2/2 [QGDEEqn.H L49]
+// (QGD_IMPL_XEXTRAP=0).  What the solve adds to the predictor -- the implicit part of the viscous / conductive update -- changes slowly from
+// step to step, so the default starts from predictor + the correction of the steps before extrapolated in time (=1: the last one, =2:
+// 2 d1 - d2, =3, default: 3 d1 - 3 d2 + d3): the same system, the same right-hand side, the same tolerance, a first residual smaller by
+// orders of magnitude and correspondingly fewer Chebyshev steps (profiles/r05_ab_implicit_start_values.txt).  A solver-internal choice like
+// the pressure solve's (qgd_qhd.hip qhdExtrapolatePKernel): the answer is the same to the solve's tolerance, the "Initial residual" of the
+// log is not.  Ghost columns of a shard receive their neighbours' start values with message kind 4 as before.
+__device__ __forceinline__ double startValue(const ImplView& iv, const size_t j, const double pred) {
+    if (iv.pred == nullptr) return pred;
+    iv.pred[j] = pred;
+    if (iv.have >= 3) return pred + ((3.0 * iv.dh0[j] - 3.0 * iv.dh1[j]) + iv.dh2[j]);
+    if (iv.have == 2) return pred + (2.0 * iv.dh0[j] - iv.dh1[j]);
+    if (iv.have == 1) return pred + iv.dh0[j];
+    return pred;
+}
+// after a solve: this step's correction into the oldest slot (the host rotates the three pointers at the end of the step)
+__device__ __forceinline__ void keepCorrection(const ImplView& iv, const size_t j, const double solved) {
+    if (iv.pred != nullptr) iv.dh2[j] = solved - iv.pred[j];
+}
+
 // fvc::grad(U), Gauss linear: cell gather in ascending face order.  The cell's own velocity once, per face the neighbour cell's
 // (cfNbr) or the patch value, the weight and Sf: a third of the bytes of walking owner and neighbour records face by face
 // (1.44 -> 0.5 ms at 8 M cells), same operations in the same order.
@@ -295,7 +316,10 @@ __global__ __launch_bounds__(QGD_BLOCK) void implCellUKernel(const MeshView m, c
         }
     }
     iv.rhoNew[ci] = rho;
-    for (int k = 0; k < 3; ++k) { iv.xU[(size_t)k * nC + ci] = Ucur[k]; iv.diagU[(size_t)k * nC + ci] = diag[k]; iv.rhsU[(size_t)k * nC + ci] = rhs[k]; }
+    for (int k = 0; k < 3; ++k) {
+        iv.xU[(size_t)k * nC + ci] = startValue(iv, (size_t)k * nC + ci, Ucur[k]);
+        iv.diagU[(size_t)k * nC + ci] = diag[k]; iv.rhsU[(size_t)k * nC + ci] = rhs[k];
+    }
 }
 
 // after the U solve: rho and U of the records (p and e stay those of the old time level), patch values of U
@@ -308,6 +332,7 @@ __global__ __launch_bounds__(QGD_BLOCK) void implStoreUKernel(const MeshView m, 
     a.rho = iv.rhoNew[ci];
     a.ux = iv.xU[ci]; a.uy = iv.xU[nC + ci]; a.uz = iv.xU[2 * nC + ci];
     c.A[ci] = a;
+    keepCorrection(iv, ci, a.ux); keepCorrection(iv, nC + ci, a.uy); keepCorrection(iv, 2 * nC + ci, a.uz);
 }
 __global__ __launch_bounds__(QGD_BLOCK) void implBcUKernel(const MeshView m, const CaseView c, const PatchBCDev* __restrict__ bcs) {
     const int b = blockIdx.x * QGD_BLOCK + threadIdx.x;
@@ -425,7 +450,7 @@ __global__ __launch_bounds__(QGD_BLOCK) void implCellEKernel(const MeshView m, c
     const double V = m.V[ci], dt = c.dt[0], rDeltaT = 1.0 / dt;
     const double rE = c.rE[ci] - (dt / V) * sum;
     const double ecur = rE / A.rho - 0.5 * (A.ux * A.ux + A.uy * A.uy + A.uz * A.uz);   // [L49]
-    iv.xE[ci] = ecur;
+    iv.xE[ci] = startValue(iv, 3 * (size_t)m.nC + ci, ecur);
     iv.diagE[ci] = rDeltaT * A.rho * V + diag;
     iv.rhsE[ci] = rDeltaT * A.rho * ecur * V + rhs;   // fvm::ddt(rho,e) - fvc::ddt(rho,e) [L57]
 }
@@ -438,6 +463,7 @@ __global__ __launch_bounds__(QGD_BLOCK) void implFinishKernel(const MeshView m, 
         RecA A = c.A[ci];
         const double pOld = A.p;
         A.e = iv.xE[ci];
+        keepCorrection(iv, 3 * (size_t)m.nC + ci, A.e);
         const double rE = A.rho * (A.e + 0.5 * (A.ux * A.ux + A.uy * A.uy + A.uz * A.uz));
         const double T = A.e / gm.Cv;
         const double psi = 1.0 / (gm.R * T);
