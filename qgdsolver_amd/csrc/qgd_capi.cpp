@@ -1923,7 +1923,8 @@ struct qgd_qhd_case_s {
     qgd_qhd_options opt{};
     int stencil = ST_GVP3;
     bool usesPoints = true, fieldsSet = false;
-    double *pPrev = nullptr, *pPrev2 = nullptr; int pPrevHave = 0;   // QGD_QHD_PEXTRAP: p of the step before (start value of the pressure solve, qgd_qhd.hip)
+    double *pPrev = nullptr, *pPrev2 = nullptr; int pPrevHave = 0;
+    int implXOrder = 0;         // QGD_IMPL_XEXTRAP (QhdView::xHave counts up to it)   // QGD_QHD_PEXTRAP: p of the step before (start value of the pressure solve, qgd_qhd.hip)
     std::vector<PatchBCDev> bc;
     PatchBCDev* bcDev = nullptr;
     DeviceArena arena;
@@ -1989,6 +1990,12 @@ int qgd_qhd_case_create(qgd_device_t d, const qgd_qhd_options* opt, qgd_qhd_case
             c->implSolver = implicitSolverCreate(d->stream, v, d->ownedBegin, d->ownedEnd);
             c->implMask = 8;
             for (int k = 0; k < 3; ++k) if (!(v.nGeomD < 3 && v.emptyDir[k])) c->implMask |= 1 << k;   // validComponents (L0)
+            {   // start values of the four systems: 0 = the current fields (OpenFOAM's), 1..3 = + the extrapolated time increment
+                static const int kOrders[] = {0, 1, 2, 3};
+                c->implXOrder = envChoice("QGD_IMPL_XEXTRAP", 3, kOrders, 4);
+                if (c->implXOrder > 0) { q.xd0 = a.alloc<double>(4 * nC); q.xd1 = a.alloc<double>(4 * nC); q.xd2 = a.alloc<double>(4 * nC); }
+                q.xHave = 0;
+            }
         }
         q.rho0 = opt->rho0; q.nu = opt->mu / opt->rho0; q.Hi = (opt->mu / opt->Pr) / opt->rho0; q.beta = opt->beta;
         for (int k = 0; k < 3; ++k) q.g[k] = opt->g[k];
@@ -2083,6 +2090,7 @@ int qgd_qhd_case_set_fields(qgd_qhd_case_t c, const double* U, const double* T, 
                                      d->cellGlobal.empty() ? nullptr : d->cellGlobal.data(), d->cellGlobalOffset, d->sharded());
     c->fieldsSet = true;
     c->pPrevHave = 0;
+    c->view.xHave = 0;
     c->time = 0; c->steps = 0;
     return QGD_OK;
     QGD_CATCH
@@ -2111,6 +2119,11 @@ static void qhdPhase(qgd_qhd_case_s* c, int phase) {
                 // implicitDiffusion: face pass 2 without the laplacians, the right-hand sides; the solve (phases 10..15) and phase 16 follow
                 implicitStepMark(c->implSolver, true);
                 launchQhdImplicitAdvance(d->stream, c->stencil, c->usesPoints, m, c->view, c->bcDev, 0, c->implMask, false, -1, 0.0, nullptr);
+                if (c->view.xd0) {   // the right-hand-side kernel put the current fields into the oldest slot: it becomes the newest
+                    QhdView& q = c->view;
+                    double* t = q.xd2; q.xd2 = q.xd1; q.xd1 = q.xd0; q.xd0 = t;
+                    q.xHave = std::min(q.xHave + 1, c->implXOrder);
+                }
                 const double gamma[4] = {c->view.nu, c->view.nu, c->view.nu, c->view.Hi};
                 implicitSolveSetup(c->implSolver, 4, c->implMask, c->view.aG, c->view.diag4, c->view.rhs4, c->view.x4, c->opt.implicitTol,
                                    c->opt.implicitMaxIter, gamma);

@@ -272,6 +272,10 @@ struct QhdView {
     // (thermo is not corrected inside the loop, deltaT is fixed): diag4 is built once, rhs4 / x4 every step (component-major, 4 * nC)
     int32_t implicit;
     double *aG, *diag4, *rhs4, *x4;
+    // start values of the four systems (QGD_IMPL_XEXTRAP): the fields {U, T} of the last `xHave` steps before the current one, newest first
+    // (xd2 doubles as the slot the current fields go into); 4 * nC each, component-major; xd0 == nullptr: off (start from the current
+    // fields, as OpenFOAM does)
+    double *xd0, *xd1, *xd2; int xHave;
     int32_t tauModel;                          // 0 constTau, 1 HbyUQHD, 2 T0byGr, 3 H2bynuQHD
     double Tau, aQGD, UQHD, T0, Gr;
 };

@@ -505,6 +505,26 @@ __global__ __launch_bounds__(QGD_BLOCK) void qhdImplicitRhsKernel(const MeshView
     double cur[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) { cur[k] = q.c4[(size_t)c * 4 + k]; q.x4[(size_t)k * nC + c] = cur[k]; }   // ghost columns start from the state message
+    // start values: the current fields (OpenFOAM's) + their time increments of the steps before extrapolated (QGD_IMPL_XEXTRAP, see the "start
+    // values" note in qgd_implicit.hip).  The history is kept here, for EVERY cell: a ghost cell's record is its owner's, bit for bit (state
+    // message), so both ranks form the same start value and the first product needs no extra message.  xd0/1/2 = the fields one, two, three
+    // steps back (xd2 doubles as the slot the current fields go into; the host rotates the pointers after the launch)
+    if (q.xd0 != nullptr) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const size_t j = (size_t)k * nC + c;
+            if (q.xHave > 0) {
+                const double d0 = cur[k] - q.xd0[j];
+                double e = d0;
+                if (q.xHave >= 2) {
+                    const double d1 = q.xd0[j] - q.xd1[j];
+                    e = q.xHave >= 3 ? (3.0 * d0 - 3.0 * d1) + (q.xd1[j] - q.xd2[j]) : 2.0 * d0 - d1;
+                }
+                q.x4[j] = cur[k] + e;
+            }
+            q.xd2[j] = cur[k];
+        }
+    }
     if (m.ghost && m.ghost[c] == 1) return;
     const int n = m.cfCount[c];
     const size_t base = (size_t)m.cfSlice[c >> 6] * 64 + (c & 63);
