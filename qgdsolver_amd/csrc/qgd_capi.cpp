@@ -1469,12 +1469,13 @@ int qgd_case_create(qgd_device_t d, const qgd_case_options* opt, qgd_case_t* out
             c->implSolver = implicitSolverCreate(d->stream, v, d->ownedBegin, d->ownedEnd);
             { static const int kOnOff[] = {0, 1}; c->reuseGradU = envChoice("QGD_IMPL_REUSE_GRADU", 1, kOnOff, 2) != 0; }
             {   // start values of the two solves (qgd_implicit.hip "start values"): 0 = OpenFOAM's (the predictor), 1..3 = + the extrapolated correction
-                static const int kOrders[] = {0, 1, 2, 3};
-                c->implXOrder = envChoice("QGD_IMPL_XEXTRAP", 3, kOrders, 4);
+                static const int kOrders[] = {0, 1, 2, 3, 4};
+                c->implXOrder = envChoice("QGD_IMPL_XEXTRAP", 3, kOrders, 5);
                 if (c->implXOrder > 0) {
-                    iv.pred = a.alloc<double>(4 * nC); iv.dh0 = a.alloc<double>(4 * nC); iv.dh1 = a.alloc<double>(4 * nC); iv.dh2 = a.alloc<double>(4 * nC);
+                    iv.pred = a.alloc<double>(4 * nC);
+                    for (int j = 0; j < c->implXOrder; ++j) iv.dh[j] = a.alloc<double>(4 * nC);
                 }
-                iv.have = 0;
+                iv.have = 0; iv.order = c->implXOrder;
             }
         }
         c->bc.resize(d->patches.size());
@@ -1682,8 +1683,10 @@ static void implicitPhase(qgd_case_s* c, int phase) {
             launchImplicitPart(st, m, c->view, c->impl, c->gas, c->bcDev, S, tol, maxIter, 5);
             if (c->impl.pred) {   // this step's corrections sit in the oldest slot: it becomes the newest
                 ImplView& iv = c->impl;
-                double* t = iv.dh2; iv.dh2 = iv.dh1; iv.dh1 = iv.dh0; iv.dh0 = t;
-                iv.have = std::min(iv.have + 1, c->implXOrder);
+                double* t = iv.dh[iv.order - 1];
+                for (int j = iv.order - 1; j >= 1; --j) iv.dh[j] = iv.dh[j - 1];
+                iv.dh[0] = t;
+                iv.have = std::min(iv.have + 1, iv.order);
             }
             implicitStepMark(S, false);
             launchBoundaryUpdate(launcherOf(c), m, c->view, c->gas, c->bcDev, false, c->phiwRegistered, 0, nullptr, 0);
@@ -1923,7 +1926,7 @@ struct qgd_qhd_case_s {
     qgd_qhd_options opt{};
     int stencil = ST_GVP3;
     bool usesPoints = true, fieldsSet = false;
-    double *pPrev = nullptr, *pPrev2 = nullptr; int pPrevHave = 0;
+    double* pHist[4] = {nullptr, nullptr, nullptr, nullptr}; int pOrder = 0, pPrevHave = 0;   // QGD_QHD_PEXTRAP: p of the steps before (start value of the pressure solve, qgd_qhd.hip)
     int implXOrder = 0;         // QGD_IMPL_XEXTRAP (QhdView::xHave counts up to it)   // QGD_QHD_PEXTRAP: p of the step before (start value of the pressure solve, qgd_qhd.hip)
     std::vector<PatchBCDev> bc;
     PatchBCDev* bcDev = nullptr;
@@ -1991,10 +1994,10 @@ int qgd_qhd_case_create(qgd_device_t d, const qgd_qhd_options* opt, qgd_qhd_case
             c->implMask = 8;
             for (int k = 0; k < 3; ++k) if (!(v.nGeomD < 3 && v.emptyDir[k])) c->implMask |= 1 << k;   // validComponents (L0)
             {   // start values of the four systems: 0 = the current fields (OpenFOAM's), 1..3 = + the extrapolated time increment
-                static const int kOrders[] = {0, 1, 2, 3};
-                c->implXOrder = envChoice("QGD_IMPL_XEXTRAP", 3, kOrders, 4);
-                if (c->implXOrder > 0) { q.xd0 = a.alloc<double>(4 * nC); q.xd1 = a.alloc<double>(4 * nC); q.xd2 = a.alloc<double>(4 * nC); }
-                q.xHave = 0;
+                static const int kOrders[] = {0, 1, 2, 3, 4};
+                c->implXOrder = envChoice("QGD_IMPL_XEXTRAP", 3, kOrders, 5);
+                for (int j = 0; j < c->implXOrder; ++j) q.xd[j] = a.alloc<double>(4 * nC);
+                q.xHave = 0; q.xOrder = c->implXOrder;
             }
         }
         q.rho0 = opt->rho0; q.nu = opt->mu / opt->rho0; q.Hi = (opt->mu / opt->Pr) / opt->rho0; q.beta = opt->beta;
@@ -2006,10 +2009,9 @@ int qgd_qhd_case_create(qgd_device_t d, const qgd_qhd_options* opt, qgd_qhd_case
         c->bcDev = a.alloc<PatchBCDev>(std::max<size_t>(1, c->bc.size()));
         c->bKind = a.alloc<uint8_t>(nB);
         {
-            static const int kModes[] = {0, 1, 2};
-            const int mode = envChoice("QGD_QHD_PEXTRAP", 2, kModes, 3);   // 0: OpenFOAM's start value p^n; 1: linear; 2: quadratic extrapolation in time (default)
-            if (mode >= 1) c->pPrev = a.alloc<double>(nC);
-            if (mode >= 2) c->pPrev2 = a.alloc<double>(nC);
+            static const int kModes[] = {0, 1, 2, 3, 4};
+            c->pOrder = envChoice("QGD_QHD_PEXTRAP", 4, kModes, 5);   // 0: OpenFOAM's start value p^n; k: extrapolation of order k in time (qgd_qhd.hip)
+            for (int j = 0; j < c->pOrder; ++j) c->pHist[j] = a.alloc<double>(nC);
         }
     } catch (...) { if (c->implSolver) implicitSolverFree(c->implSolver); c->arena.release(); delete c; throw; }
     d->liveCases++;
@@ -2105,7 +2107,7 @@ static void qhdPhase(qgd_qhd_case_s* c, int phase) {
     switch (phase) {
         case 0:
             launchQhdAssemble(d->stream, c->stencil, c->usesPoints, m, c->view, c->bcDev);
-            if (c->pPrev) { launchQhdExtrapolateP(d->stream, m.nC, c->view.p, c->pPrev, c->pPrev2, c->pPrevHave); c->pPrevHave = std::min(c->pPrevHave + 1, 2); }
+            if (c->pOrder > 0) { launchQhdExtrapolateP(d->stream, m.nC, c->view.p, c->pHist, c->pPrevHave, c->pOrder); c->pPrevHave = std::min(c->pPrevHave + 1, c->pOrder); }
             pressureSolveBegin(c->solver, c->view.phiu, c->view.phiwo, c->view.pb, c->view.pgb, c->opt.pTol, c->opt.pRelTol, c->opt.pMaxIter, c->view.p);
             break;
         case 1: case 2: case 3: case 4: case 5: pressureSolvePhase(c->solver, phase); break;
@@ -2119,10 +2121,12 @@ static void qhdPhase(qgd_qhd_case_s* c, int phase) {
                 // implicitDiffusion: face pass 2 without the laplacians, the right-hand sides; the solve (phases 10..15) and phase 16 follow
                 implicitStepMark(c->implSolver, true);
                 launchQhdImplicitAdvance(d->stream, c->stencil, c->usesPoints, m, c->view, c->bcDev, 0, c->implMask, false, -1, 0.0, nullptr);
-                if (c->view.xd0) {   // the right-hand-side kernel put the current fields into the oldest slot: it becomes the newest
+                if (c->view.xOrder > 0) {   // the right-hand-side kernel put the current fields into the oldest slot: it becomes the newest
                     QhdView& q = c->view;
-                    double* t = q.xd2; q.xd2 = q.xd1; q.xd1 = q.xd0; q.xd0 = t;
-                    q.xHave = std::min(q.xHave + 1, c->implXOrder);
+                    double* t = q.xd[q.xOrder - 1];
+                    for (int j = q.xOrder - 1; j >= 1; --j) q.xd[j] = q.xd[j - 1];
+                    q.xd[0] = t;
+                    q.xHave = std::min(q.xHave + 1, q.xOrder);
                 }
                 const double gamma[4] = {c->view.nu, c->view.nu, c->view.nu, c->view.Hi};
                 implicitSolveSetup(c->implSolver, 4, c->implMask, c->view.aG, c->view.diag4, c->view.rhs4, c->view.x4, c->opt.implicitTol,

@@ -218,9 +218,9 @@ struct ImplView {
     double *xE, *diagE, *rhsE;           // nC
     // start values of the two solves (QGD_IMPL_XEXTRAP, qgd_implicit.hip "start values"): the predictor each solve would start from as the
     // listing has it (U = rhoU/rho, e = rhoE/rho - |U|^2/2), and the corrections solution - predictor of the last `have` steps, newest first
-    // (dh2 doubles as this step's write target); 4*nC each, component-major {Ux, Uy, Uz, e}; pred == nullptr: off
-    double *pred, *dh0, *dh1, *dh2;
-    int have;
+    // (the oldest doubles as this step's write target: dh[order - 1]); 4*nC each, component-major {Ux, Uy, Uz, e}; pred == nullptr: off
+    double *pred, *dh[4];
+    int have, order;
 };
 // the branch as parts 0..5 (gradient | faces + U systems | store U | gradient of the new U | sigma + e system | finish) around its two
 // multi-right-hand-side Jacobi-PCG solves, all stream-ordered with the scalars of the solves in a device control block
@@ -273,16 +273,16 @@ struct QhdView {
     int32_t implicit;
     double *aG, *diag4, *rhs4, *x4;
     // start values of the four systems (QGD_IMPL_XEXTRAP): the fields {U, T} of the last `xHave` steps before the current one, newest first
-    // (xd2 doubles as the slot the current fields go into); 4 * nC each, component-major; xd0 == nullptr: off (start from the current
-    // fields, as OpenFOAM does)
-    double *xd0, *xd1, *xd2; int xHave;
+    // (the oldest, xd[xOrder - 1], doubles as the slot the current fields go into); 4 * nC each, component-major; xOrder == 0: off (start from
+    // the current fields, as OpenFOAM does)
+    double* xd[4]; int xHave, xOrder;
     int32_t tauModel;                          // 0 constTau, 1 HbyUQHD, 2 T0byGr, 3 H2bynuQHD
     double Tau, aQGD, UQHD, T0, Gr;
 };
 void launchQhdInit(hipStream_t s, const MeshView& m, const QhdView& q, const PatchBCDev* bc, const double* U, const double* T, const double* p,
                    double* tauF, double* taubyrho);
 void launchQhdAssemble(hipStream_t s, int stencil, bool usesPoints, const MeshView& m, const QhdView& q, const PatchBCDev* bc);
-void launchQhdExtrapolateP(hipStream_t s, int nC, double* p, double* pPrev, double* pPrev2, int have);
+void launchQhdExtrapolateP(hipStream_t s, int nC, double* p, double* const hist[4], int have, int order);
 void launchQhdPostSolve(hipStream_t s, const MeshView& m, const QhdView& q, const PatchBCDev* bc);
 void launchQhdAdvance(hipStream_t s, int stencil, bool usesPoints, const MeshView& m, const QhdView& q, const PatchBCDev* bc, bool needRef,
                       int localRefCell, double refValue, double* shift);

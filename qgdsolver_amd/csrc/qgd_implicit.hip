@@ -65,21 +65,28 @@ __device__ __forceinline__ void muDev2T(const double* g, const double mu, double
 // OpenFOAM starts a solve from the field as it stands: the predictor U = rhoU/rho [QGDUEqn.H L48-50], e = rhoE/rho - |U|^2/2 [QGDEEqn.H L49]
 // (QGD_IMPL_XEXTRAP=0).  What the solve adds to the predictor -- the implicit part of the viscous / conductive update -- changes slowly from
 // step to step, so the default starts from predictor + the correction of the steps before extrapolated in time (=1: the last one, =2:
-// 2 d1 - d2, =3, default: 3 d1 - 3 d2 + d3): the same system, the same right-hand side, the same tolerance, a first residual smaller by
+// 2 d1 - d2, =3, default: 3 d1 - 3 d2 + d3, =4: 4 d1 - 6 d2 + 4 d3 - d4 -- no further gain): the same system, the same right-hand side, the same tolerance, a first residual smaller by
 // orders of magnitude and correspondingly fewer Chebyshev steps (profiles/r05_ab_implicit_start_values.txt).  A solver-internal choice like
 // the pressure solve's (qgd_qhd.hip qhdExtrapolatePKernel): the answer is the same to the solve's tolerance, the "Initial residual" of the
 // log is not.  Ghost columns of a shard receive their neighbours' start values with message kind 4 as before.
+// The extrapolated correction is LIMITED to twice the last one per value (see qhdExtrapolatePKernel): where the history is not smooth the start
+// value falls back towards the predictor.
 __device__ __forceinline__ double startValue(const ImplView& iv, const size_t j, const double pred) {
     if (iv.pred == nullptr) return pred;
     iv.pred[j] = pred;
-    if (iv.have >= 3) return pred + ((3.0 * iv.dh0[j] - 3.0 * iv.dh1[j]) + iv.dh2[j]);
-    if (iv.have == 2) return pred + (2.0 * iv.dh0[j] - iv.dh1[j]);
-    if (iv.have == 1) return pred + iv.dh0[j];
-    return pred;
+    const int k = iv.have < iv.order ? iv.have : iv.order;
+    if (k == 0) return pred;
+    const double d1 = iv.dh[0][j];
+    double e = d1;
+    if (k == 2) e = 2.0 * d1 - iv.dh[1][j];
+    else if (k == 3) e = (3.0 * d1 - 3.0 * iv.dh[1][j]) + iv.dh[2][j];
+    else if (k >= 4) e = ((4.0 * d1 - 6.0 * iv.dh[1][j]) + 4.0 * iv.dh[2][j]) - iv.dh[3][j];
+    const double lim = 2.0 * fabs(d1);
+    return pred + fmin(fmax(e, -lim), lim);
 }
-// after a solve: this step's correction into the oldest slot (the host rotates the three pointers at the end of the step)
+// after a solve: this step's correction into the oldest slot (the host rotates the pointers at the end of the step)
 __device__ __forceinline__ void keepCorrection(const ImplView& iv, const size_t j, const double solved) {
-    if (iv.pred != nullptr) iv.dh2[j] = solved - iv.pred[j];
+    if (iv.pred != nullptr) iv.dh[iv.order - 1][j] = solved - iv.pred[j];
 }
 
 // fvc::grad(U), Gauss linear: cell gather in ascending face order.  The cell's own velocity once, per face the neighbour cell's

@@ -507,22 +507,26 @@ __global__ __launch_bounds__(QGD_BLOCK) void qhdImplicitRhsKernel(const MeshView
     for (int k = 0; k < 4; ++k) { cur[k] = q.c4[(size_t)c * 4 + k]; q.x4[(size_t)k * nC + c] = cur[k]; }   // ghost columns start from the state message
     // start values: the current fields (OpenFOAM's) + their time increments of the steps before extrapolated (QGD_IMPL_XEXTRAP, see the "start
     // values" note in qgd_implicit.hip).  The history is kept here, for EVERY cell: a ghost cell's record is its owner's, bit for bit (state
-    // message), so both ranks form the same start value and the first product needs no extra message.  xd0/1/2 = the fields one, two, three
-    // steps back (xd2 doubles as the slot the current fields go into; the host rotates the pointers after the launch)
-    if (q.xd0 != nullptr) {
+    // message), so both ranks form the same start value and the first product needs no extra message.  xd[0..] = the fields one, two, ...
+    // steps back (the oldest doubles as the slot the current fields go into; the host rotates the pointers after the launch)
+    if (q.xOrder > 0) {
+        const int kk = q.xHave < q.xOrder ? q.xHave : q.xOrder;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const size_t j = (size_t)k * nC + c;
-            if (q.xHave > 0) {
-                const double d0 = cur[k] - q.xd0[j];
+            double v[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[t] = t < q.xOrder ? q.xd[t][j] : 0.0;
+            if (kk >= 1) {
+                const double d0 = cur[k] - v[0];
                 double e = d0;
-                if (q.xHave >= 2) {
-                    const double d1 = q.xd0[j] - q.xd1[j];
-                    e = q.xHave >= 3 ? (3.0 * d0 - 3.0 * d1) + (q.xd1[j] - q.xd2[j]) : 2.0 * d0 - d1;
-                }
-                q.x4[j] = cur[k] + e;
+                if (kk == 2) e = (2.0 * cur[k] - 3.0 * v[0]) + v[1];
+                else if (kk == 3) e = ((3.0 * cur[k] - 6.0 * v[0]) + 4.0 * v[1]) - v[2];
+                else if (kk >= 4) e = (((4.0 * cur[k] - 10.0 * v[0]) + 10.0 * v[1]) - 5.0 * v[2]) + v[3];
+                const double lim = 2.0 * fabs(d0);     // limited like the pressure's (qhdExtrapolatePKernel)
+                q.x4[j] = cur[k] + fmin(fmax(e, -lim), lim);
             }
-            q.xd2[j] = cur[k];
+            q.xd[q.xOrder - 1][j] = cur[k];            // the current fields into the oldest slot (the host rotates the pointers)
         }
     }
     if (m.ghost && m.ghost[c] == 1) return;
@@ -734,24 +738,44 @@ void launchQhdAssemble(hipStream_t s, int stencil, bool usesPoints, const MeshVi
     qhdCellGradKernel<<<gridOf(m.nC), QGD_BLOCK, 0, s>>>(m, q);
 }
 // The start value of the pressure solve [QHDpEqn.H L45]: OpenFOAM starts from the field as it stands, p^n (QGD_QHD_PEXTRAP=0).  The default
-// (QGD_QHD_PEXTRAP=2) starts from the extrapolation in time 3 p^n - 3 p^(n-1) + p^(n-2) (=1: the linear 2 p^n - p^(n-1)): the same system,
-// the same tolerance, a smaller first residual on a flow that evolves smoothly -- 6 -> 4 / 3 conjugate-gradient iterations per step on the
-// 8 M-cell cavity, 9 -> 5 on the 16 M-cell irregular mesh (profiles/r05_ab_qhd_pressure_start_value.txt).  A solver-internal choice: the
-// answer is the same to the solve's tolerance, the "Initial residual" of the log is not; a start value that happens to be worse than p^n
-// costs iterations, never convergence.  pPrev <- p^n either way; have: how many earlier fields there are (0, 1, 2).
-// (pPrev2 != nullptr and have >= 2: the quadratic 3 p^n - 3 p^(n-1) + p^(n-2))
-__global__ __launch_bounds__(QGD_BLOCK) void qhdExtrapolatePKernel(const int n, double* __restrict__ p, double* __restrict__ pPrev, double* __restrict__ pPrev2,
-                                                                  const int have) {
+// starts from the polynomial extrapolation in time through the last k + 1 fields, sum_j (-1)^j C(k+1, j+1) p^(n-j) (k = QGD_QHD_PEXTRAP:
+// 1 linear 2 p^n - p^(n-1), 2 quadratic, 3 cubic, 4 quartic): the same system, the same tolerance, a smaller first residual on a flow that
+// evolves smoothly -- 6 -> 5 / 3-4 / 2 conjugate-gradient iterations per step on the 8 M-cell cavity for k = 1 / 2 / 3, 9 -> 7 / 5 / 3 on the
+// 16 M-cell irregular mesh (profiles/r05_ab_qhd_pressure_start_value*.txt).  A solver-internal choice: the answer is the same to the
+// solve's tolerance, the "Initial residual" of the log is not.  The extrapolated increment is LIMITED to twice the last one per cell
+// (|p_start - p^n| <= 2 |p^n - p^(n-1)|): where the history is not smooth (a turning point, a change of a boundary value) the start
+// value falls back towards p^n, so it is never further from the new solution than three of the last increments -- at worst an iteration
+// more than OpenFOAM's start, never a different answer.  h[0..3]: the fields one to four steps back, rotated here (have = how many are valid).
+struct TimeHistory { double* h[4]; int have; int order; };
+__global__ __launch_bounds__(QGD_BLOCK) void qhdExtrapolatePKernel(const int n, double* __restrict__ p, const TimeHistory H) {
     const int i = blockIdx.x * QGD_BLOCK + threadIdx.x;
     if (i >= n) return;
-    const double pn = p[i], p1 = pPrev[i];
-    if (pPrev2 && have >= 2) p[i] = 3.0 * pn - 3.0 * p1 + pPrev2[i];
-    else if (have) p[i] = 2.0 * pn - p1;
-    if (pPrev2) pPrev2[i] = p1;
-    pPrev[i] = pn;
+    const double pn = p[i];
+    double v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = (j < H.order && H.h[j]) ? H.h[j][i] : 0.0;
+    const int k = H.have < H.order ? H.have : H.order;
+    if (k >= 1) {
+        const double d0 = pn - v[0];
+        double e = d0;                                                                             // 2 p^n - p^(n-1)
+        if (k == 2) e = (2.0 * pn - 3.0 * v[0]) + v[1];                                            // 3, -3, 1
+        else if (k == 3) e = ((3.0 * pn - 6.0 * v[0]) + 4.0 * v[1]) - v[2];                        // 4, -6, 4, -1
+        else if (k >= 4) e = (((4.0 * pn - 10.0 * v[0]) + 10.0 * v[1]) - 5.0 * v[2]) + v[3];       // 5, -10, 10, -5, 1
+        const double lim = 2.0 * fabs(d0);
+        e = fmin(fmax(e, -lim), lim);
+        p[i] = pn + e;
+    }
+    // the ring: h[j] <- h[j-1], h[0] <- p^n (each lane moves its own entries; no other lane reads them)
+#pragma unroll
+    for (int j = 3; j >= 1; --j) if (j < H.order && H.h[j]) H.h[j][i] = v[j - 1];
+    if (H.order >= 1 && H.h[0]) H.h[0][i] = pn;
 }
-void launchQhdExtrapolateP(hipStream_t s, int nC, double* p, double* pPrev, double* pPrev2, int have) {
-    if (nC > 0) qhdExtrapolatePKernel<<<gridOf(nC), QGD_BLOCK, 0, s>>>(nC, p, pPrev, pPrev2, have);
+void launchQhdExtrapolateP(hipStream_t s, int nC, double* p, double* const hist[4], int have, int order) {
+    if (nC <= 0 || order <= 0) return;
+    TimeHistory H;
+    for (int j = 0; j < 4; ++j) H.h[j] = hist[j];
+    H.have = have; H.order = order;
+    qhdExtrapolatePKernel<<<gridOf(nC), QGD_BLOCK, 0, s>>>(nC, p, H);
 }
 // after the solve: solve() ends in correctBoundaryConditions() (a shard then sends p and these patch values to its neighbours)
 void launchQhdPostSolve(hipStream_t s, const MeshView& m, const QhdView& q, const PatchBCDev* bc) {

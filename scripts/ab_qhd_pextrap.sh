@@ -1,4 +1,4 @@
-for V in QGD_QHD_PEXTRAP=0 QGD_QHD_PEXTRAP=1 QGD_QHD_PEXTRAP=2 QGD_QHD_PEXTRAP=1 QGD_QHD_PEXTRAP=2; do
+for V in ${VARIANTS:-QGD_QHD_PEXTRAP=0 QGD_QHD_PEXTRAP=1 QGD_QHD_PEXTRAP=2 QGD_QHD_PEXTRAP=1 QGD_QHD_PEXTRAP=2}; do
   for W in "" "--irregular" "--implicit-diffusion"; do
   echo "== $V $W"
   env $V python bench.py --workload qhd $W --steps 20 --warmup 10 2>/dev/null | python -c "

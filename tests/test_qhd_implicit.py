@@ -109,7 +109,9 @@ def test_oracle_phases_refuse_the_implicit_branch():
 @pytest.mark.parametrize("kind,stencil", GPU_CASES)
 def test_device_implicit_branch_matches_oracle(kind, stencil):
     mesh = make_mesh(kind)
-    opt = options(stencil, deltaT=1e-3, mu=2e-2, **TIGHT)
+    # (pTol 1e-13: the device's pressure solve starts from a time-extrapolated field and stops as soon as the tolerance is met, the oracle
+    # starts from p^n and overshoots it by an iteration; at 1e-12 the two answers differ by 1.6e-9 in phi on one of the cases)
+    opt = options(stencil, deltaT=1e-3, mu=2e-2, pTol=1e-13, **TIGHT)
     U, T, p = initial(mesh)
     U = U + 1e-2 * np.random.default_rng(3).standard_normal(U.shape)
     if mesh.nGeometricD == 2:
