@@ -78,7 +78,9 @@ def test_tiny_meshes_qhd(dims, ptypes):
     gc.step(8); oc.step(8)
     for f in ("U", "T", "p", "phi"):
         ref = oc.field(f)
-        assert np.abs(gc.field(f) - ref).max() <= 1e-9 * max(np.abs(ref).max(), 1e-30), (dims, f)
+        # (+ 1e-15: on a closed one-row mesh phi IS rounding noise, 1e-17 of a flux scale of 1e-3, and that noise depends on where the
+        # pressure solve starts)
+        assert np.abs(gc.field(f) - ref).max() <= 1e-9 * max(np.abs(ref).max(), 1e-30) + 1e-15, (dims, f)
     gc.close(); dev.close()
 
 
