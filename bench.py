@@ -672,7 +672,7 @@ def secondary_traffic(key):
         return None
 
 
-SECONDARY_TRAFFIC_FILE = "r04_pmc_secondary.json"
+SECONDARY_TRAFFIC_FILE = "r05_pmc_secondary.json"
 SECONDARY_TRAFFIC_SOURCE = ("rocprofv3 --pmc TCC_EA0_RDREQ_{32B,64B,128B}_sum / TCC_EA0_WRREQ{,_64B}_sum in separate passes over "
                             "scripts/secondary_kernel_probe.py (scripts/collect_secondary_pmc.sh), bytes = sum(size*requests), average of "
                             "the 30 launches of the measurement entry; L2-miss traffic, Infinity-Cache hits included; profiles/" + SECONDARY_TRAFFIC_FILE)

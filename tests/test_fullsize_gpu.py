@@ -72,16 +72,28 @@ def test_mass_conservation_and_symmetry(n):
     case.close(); dev.close()
 
 
+def _c2_mesh(q2, symmetry_walls):
+    """the forwardStep planform; symmetry_walls: bottom and top are symmetryPlane patches, as in OpenFOAM's own forwardStep tutorial"""
+    mesh = q2.PolyMesh.forward_step(600, 200, 120, 40)
+    if symmetry_walls:
+        from qgdsolver_amd import _lib as L2
+        ptypes = mesh.array("patchType").copy()
+        ptypes[2] = ptypes[3] = L2.PATCH_SYMMETRYPLANE
+        mesh = q2.PolyMesh.from_arrays(mesh.array("points"), mesh.array("faceOffsets"), mesh.array("facePoints"), mesh.array("owner"),
+                                       mesh.array("neighbour"), mesh.nCells, mesh.array("patchStart"), mesh.array("patchSize"), ptypes)
+    return mesh
+
+
 def _c2_oracle_worker(args):
-    """the CPU side of config 2 (a child process per stencil so the two oracle runs overlap)"""
-    stencil, steps = args
+    """the CPU side of config 2 (a child process per variant so the oracle runs overlap)"""
+    stencil, steps, symmetry_walls = args
     import qgdsolver_amd as q2
     import cases as cs
     from oracle import OracleCase, OracleMesh
 
-    mesh = q2.PolyMesh.forward_step(600, 200, 120, 40)
+    mesh = _c2_mesh(q2, symmetry_walls)
     oc = OracleCase(OracleMesh(mesh.primitives()), q2.default_options(stencil=stencil, deltaT=5e-5))
-    cs.forward_step_bcs(oc)
+    cs.forward_step_bcs(oc)     # (on symmetryPlane patches the patch type wins over what this asks for)
     n = mesh.nCells
     U = np.zeros((n, 3)); U[:, 0] = 3.0
     oc.set_fields(U, np.ones(n), np.ones(n))
@@ -99,24 +111,31 @@ def test_config2_forward_step_100k_cells_1000_steps_at_deltaT_5e_5():
     import multiprocessing as mp
 
     steps = 1000
+    # the two stencils on slip walls (SURVEY's C2) and, since round 5, the tutorial's own patch types: symmetryPlane bottom and top
+    variants = [("leastSquares", False), ("GaussVolPoint", False), ("leastSquares", True), ("GaussVolPoint", True)]
     ctx = mp.get_context("spawn")
-    with ctx.Pool(2) as pool:
-        pending = pool.map_async(_c2_oracle_worker, [("leastSquares", steps), ("GaussVolPoint", steps)])
-        mesh = q.PolyMesh.forward_step(600, 200, 120, 40)
-        assert mesh.nCells == 100800
-        n = mesh.nCells
-        U = np.zeros((n, 3)); U[:, 0] = 3.0
+    with ctx.Pool(4) as pool:
+        pending = pool.map_async(_c2_oracle_worker, [(st, steps, sym) for st, sym in variants])
         got = {}
-        for stencil in ("leastSquares", "GaussVolPoint"):
+        for stencil, sym in variants:
+            mesh = _c2_mesh(q, sym)
+            assert mesh.nCells == 100800
+            n = mesh.nCells
+            U = np.zeros((n, 3)); U[:, 0] = 3.0
             dev = q.Device(mesh)
             gc = q.QGDFoamCase(dev, q.default_options(stencil=stencil, deltaT=5e-5))
             cases.forward_step_bcs(gc)
             gc.set_fields(U, np.ones(n), np.ones(n))
             gc.step(steps)
-            got[stencil] = {f: gc.field(f) for f in ("rho", "U", "p")}
+            got[(stencil, sym)] = {f: gc.field(f) for f in ("rho", "U", "p")}
             assert gc.info()["minRho"] > 0
+            if sym:   # nothing crosses the symmetry planes: the patch velocity has no normal component (y is the planes' normal)
+                ps, pz, nif = mesh.array("patchStart"), mesh.array("patchSize"), mesh.nInternalFaces
+                Ub = gc.field("U.boundary").reshape(-1, 3)
+                for ip in (2, 3):
+                    assert np.abs(Ub[ps[ip] - nif: ps[ip] - nif + pz[ip], 1]).max() == 0.0
             gc.close(); dev.close()
-        ref = dict(zip(("leastSquares", "GaussVolPoint"), pending.get(timeout=1500)))
+        ref = dict(zip(variants, pending.get(timeout=2400)))
     for stencil in got:
         # the shock has formed ahead of the step by now: the fields are far from uniform
         assert got[stencil]["p"].max() > 3.0 and got[stencil]["rho"].max() > 2.0, (got[stencil]["p"].max(), got[stencil]["rho"].max())
