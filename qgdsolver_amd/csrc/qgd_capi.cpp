@@ -669,7 +669,6 @@ int qgd_device_create(qgd_mesh_t mh, int deviceId, qgd_device_t* out) {
         // kernel holds those differences already: 24 B per face less to stream.  Not when the caller supplied its own Sf.
         static const int kOnOff[] = {0, 1};
         v.tileWaves = envChoice("QGD_FT_WAVES", 3, kWaves, 3);
-        v.pShare = envChoice("QGD_P_SHARE", 0, kOnOff, 2);
         v.sGeo = (envChoice("QGD_SGEO", 1, kOnOff, 2) != 0 && !m.userGeometry && v.fblock == 128 && v.tileWaves == 3) ? 1 : 0;
         v.cblock = envChoice("QGD_CBLOCK", 256, kBlocks, 3);
         v.pblock = envChoice("QGD_PBLOCK", 256, kBlocks, 3);

@@ -65,7 +65,6 @@ struct MeshView {
     int32_t qhdTiles;        // QGD_QHD_TILES (default 1): QHD's two face passes use the tiles too (qgd_qhd.hip qhdFace{1,2}TileKernel)
     int32_t implTiles;       // QGD_IMPL_TILES (default 1): so does the face kernel of QGDFoam's implicit branch (qgd_implicit.hip implFaceTileKernel)
     int32_t tileWaves;       // waves per SIMD the staged kernel is compiled for (2, 3 or 4)
-    int32_t pShare;          // QGD_P_SHARE: the vertex kernel takes a cell record its neighbouring lane gathered instead of gathering it again (qgd_kernels.hip)
     int32_t sGeo;            // 1: the 3-D GaussVolPoint kernels rebuild Sf of quadrilateral faces from the vertices (no Sf stream)
     const double* V; const double* hQGD; const uint8_t* ghost;
     const int32_t* bPatch; const double* hQGDb;

@@ -922,31 +922,8 @@ void pointInterpRecKernel(const MeshView m, const RecA* __restrict__ A, RecA* __
         RecA r[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) { id[q] = m.pcCell[base + (size_t)q * 64]; w[q] = m.pcW[base + (size_t)q * 64]; }
-        if (m.pShare) {
-            // Structured rows (ascending labels c, c+1, c+nx, c+nx+1, ...): entry 2q+1 of this point is entry 2q of the NEXT point, which
-            // the next lane gathers anyway.  Each lane gathers its four even entries; the odd ones come from lane + 1 across the wavefront,
-            // except where the labels say otherwise (the last lane, row ends, any unstructured row), which gather their own.  Same records,
-            // same order of the sum: bit-identical; 12 instead of 24 sixteen-byte gathers per point.
-            bool own = (threadIdx.x & 63) == 63;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) own = own || __shfl_down(id[2 * q], 1) != id[2 * q + 1];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) r[2 * q] = A[id[2 * q]];
-            if (own) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) r[2 * q + 1] = A[id[2 * q + 1]];
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                RecA t;
-                t.rho = __shfl_down(r[2 * q].rho, 1); t.ux = __shfl_down(r[2 * q].ux, 1); t.uy = __shfl_down(r[2 * q].uy, 1);
-                t.uz = __shfl_down(r[2 * q].uz, 1); t.p = __shfl_down(r[2 * q].p, 1); t.e = __shfl_down(r[2 * q].e, 1);
-                if (!own) r[2 * q + 1] = t;
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) r[q] = A[id[q]];
-        }
+        for (int q = 0; q < 8; ++q) r[q] = A[id[q]];
 #if QGD_P_PRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
