@@ -985,6 +985,9 @@ def main():
         if native:
             comm.step(case, peers, overlapped=False)
             return
+        if world == 1:
+            case.step_phase(3)   # one whole step, stream-ordered: the fused face + cell kernel when the case uses it (config.fused)
+            return
         case.step_phase(0)   # flux assembly
         case.step_phase(1)   # cell update + boundary refresh (fixed deltaT: no global reduction needed)
         exchange()           # pack/unpack on the compute stream: strictly after the update, before the next assembly

@@ -589,6 +589,13 @@ int qgd_case_get_field(qgd_case_t c, const char* name, double* out,
 
 /* info[0]=time, [1]=deltaT, [2]=CoNum, [3]=min(rho), [4]=min(e), [5]=step count */
 int qgd_case_info(qgd_case_t c, double info[6]);
+/* Whether qgd_case_step advances this case with the fused face + cell kernel (QGD_FUSED, default on): a uniform 3-D GaussVolPoint case on an
+ * unsharded mesh, explicit branch, fixed deltaT, linear qgdFlux schemes.  The net fluxes of internal faces then never reach device memory --
+ * a workgroup computes every internal face of its block of <= 128 cells into LDS and advances those cells from there, in the summation order
+ * of fvc::surfaceIntegrate; same arithmetic, bit-identical states.  info[0] = 1 when in use, [1] = blocks, [2] = internal faces computed per
+ * step (faces on a block's surface are computed by the block on either side), [3] = LDS bytes per workgroup.  qgd_case_step_phase,
+ * qgd_case_update_fluxes and every other branch keep the separate face and cell kernels. */
+int qgd_case_fused_info(qgd_case_t c, int64_t info[4]);
 /* The linear solves of the implicitDiffusion branch in the last step (what OpenFOAM prints as "Solving for Ux, Initial
  * residual = ..., Final residual = ..., No Iterations ...") [QGDUEqn_8H_source.html L54-68, QGDEEqn_8H_source.html L53-61]:
  * info[0..3] = iterations of Ux, Uy, Uz, e; [4..7] = initial, [8..11] = final normalised residuals; [12] = number of steps
@@ -672,6 +679,8 @@ int qgd_case_set_stream(qgd_case_t c, void* hipStream);
  * halo_pack may start as soon as phase 10 is done (on the halo stream of qgd_case_set_halo_stream, ordered after the
  * compute stream by the caller), phase 11 runs meanwhile, and the next phase 0 waits for halo_unpack.
  * Ghost cells and their patch faces are written by halo_unpack only.  phase 2 is a no-op hook.
+ * phase 3 = one whole step of an UNSHARDED case, stream-ordered like the others (qgd_case_step without its host synchronisation; the
+ *   fused face + cell kernel when qgd_case_fused_info says the case uses it).
  * Phase 0 itself splits when qgd_case_mid_exchange_needed says so (a shard whose GaussVolPoint stencil meets a wall with the qgdFlux
  * pressure condition): GaussVolPoint re-evaluates p's boundary conditions inside fvsc::grad(p) [GaussVolPointStencil_8C_source.html
  * L73 -> qgdFluxFvPatchScalarField_8C_source.html L184-192], a ghost cell's patch face forms that mid-step patch pressure from an

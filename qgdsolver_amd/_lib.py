@@ -99,6 +99,7 @@ SIGNATURES = {
     "qgd_species_flux_dev": (C.c_int, [handle, C.c_int] + [C.c_void_p] * 10),
     "qgd_device_op_times": (C.c_int, [handle, c_double_p]),
     "qgd_device_face_tiles": (C.c_int, [handle, C.POINTER(C.c_int64)]),
+    "qgd_case_fused_info": (C.c_int, [handle, C.POINTER(C.c_int64)]),
     "qgd_interpolate": (C.c_int, [handle, C.c_int32, c_double_p, c_double_p, c_double_p]),
     "qgd_flux": (C.c_int, [handle, C.c_int32, c_double_p, c_double_p, c_double_p]),
     "qgd_flux_upwind": (C.c_int, [handle, C.c_int32, c_double_p, c_double_p, c_double_p, c_double_p]),

@@ -234,6 +234,7 @@ struct qgd_device_s {
     int32_t nGeomD = 3;
     bool hasTri = false;
     bool wedgePrism = false;  // wedge patches + prism cells: GaussVolPoint is refused [fvsc_8C L65-82]
+    int64_t fusedRedundantFaces = 0;   // faces the fused kernel's blocks compute beyond the mesh's internal faces (MeshView::fuBlocks > 0)
     std::vector<Patch> patches;
     // why a resident case (qgd_case_create / qgd_qhd_case_create) cannot run on this mesh, empty when it can: cyclic / wedge patches
     // with faces (their coupled / rotated patch fields are not served), a symmetryPlane that is not planar (fatal in OpenFOAM too)
@@ -293,6 +294,7 @@ struct qgd_case_s {
     int implXOrder = 0;         // QGD_IMPL_XEXTRAP: order of the start-value extrapolation of the implicit branch's solves (ImplView::have counts up to it)
     bool pRefresh = true;       // grad(p)'s word is GaussVolPoint: p's boundary conditions are re-evaluated inside it [GaussVolPointStencil_8C L73] (quirk B6)
     bool usesPoints = true;
+    bool fused = false;         // qgd_case_step advances with fusedFaceCellKernel (QGD_FUSED)
     bool hasQgdFlux = false;
     bool phiwRegistered = false;
     bool fieldsSet = false;
@@ -711,6 +713,23 @@ int qgd_device_create(qgd_mesh_t mh, int deviceId, qgd_device_t* out) {
                 v.nTileSpill = (int32_t)t.spill.size(); v.tileSpill = up(t.spill);
                 v.tileOff = up(t.off); v.tileCells = up(t.cells); v.tileVerts = up(t.verts);
                 v.locC = up(t.locC); v.locV = reinterpret_cast<const uint2*>(up(t.locV));
+            }
+        }
+        {
+            // cell blocks of the fused face + cell kernel (QGD_FUSED, qgd_setup.hpp FusedBlocks): 3-D unsharded meshes whose tiles were built
+            static const int kOnOff2[] = {0, 1};
+            if (envChoice("QGD_FUSED", 1, kOnOff2, 2) != 0) {
+                FusedBlocks fb = buildFusedBlocks(s);
+                // LDS: cell records (80 B) + cell centres and vertex records + coordinates (24 + 72 B), the last three later overwritten by the fluxes
+                const int64_t ldsRec = (int64_t)fb.capC * 80 + std::max((int64_t)fb.capC * 24 + (int64_t)fb.capV * 72, (int64_t)fb.capF * 40);
+                const int64_t lds = (ldsRec + 6 * 128 * 8 + 255) / 256 * 256;   // + the per-cell park (rhoE, V, hQGD, six face entries)
+                if (fb.nBlocks > 0 && fb.capC <= kFusedCapC && fb.capV <= kFusedCapV && fb.capF <= kFusedCapF &&
+                    lds <= 80 * 1024) {
+                    v.fuBlocks = fb.nBlocks; v.fuCapC = fb.capC; v.fuCapV = fb.capV; v.fuCapF = fb.capF; v.fuCapE = fb.capE; v.fuLds = (int32_t)lds; v.fuLdsCell = (int32_t)(ldsRec / 8);
+                    d->fusedRedundantFaces = fb.redundantFaces;
+                    v.fuHdr = reinterpret_cast<const int4*>(up(fb.hdr)); v.fuCells = up(fb.cells); v.fuVerts = up(fb.verts);
+                    v.fuFace = reinterpret_cast<const int4*>(up(fb.face)); v.fuNEntry = up(fb.nEntry); v.fuEntry = up(fb.entry);
+                }
             }
         }
         v.own = up(s.own); v.nei = up(s.nei);
@@ -1444,11 +1463,15 @@ int qgd_case_create(qgd_device_t d, const qgd_case_options* opt, qgd_case_t* out
         CaseView& cv = c->view;
         cv.A = a.alloc<RecA>(v.nC); cv.B = a.alloc<RecB>(v.nC); cv.rE = a.alloc<double>(v.nC);
         cv.P = a.alloc<RecA>(v.nP);
+        // the fused face + cell step (fusedFaceCellKernel): uniform 3-D GaussVolPoint, explicit, fixed deltaT, linear fluxes
+        c->fused = v.fuBlocks > 0 && c->stencil == ST_GVP3 && c->mixB < 0 && !opt->implicitDiffusion && !opt->adjustTimeStep && !g.upwindU &&
+                   !g.upwindH;
+        if (c->fused) { cv.A2 = a.alloc<RecA>(v.nC); cv.B2 = a.alloc<RecB>(v.nC); }
         cv.bA = a.alloc<RecA>(v.nBF); cv.bB = a.alloc<RecB>(v.nBF);
         cv.bG = a.alloc<double>(v.nBF); cv.bPhiw = a.alloc<double>(v.nBF); cv.bPmid = a.alloc<double>(v.nBF);
         cv.bRhoLag = a.alloc<double>(v.nBF);
         cv.nBlkFace = faceBlocks(v) + bfaceBlocks(v);
-        cv.nBlkCell = cellBlocks(v) + (d->nSendAll + 63) / 64;
+        cv.nBlkCell = std::max(cellBlocks(v), v.fuBlocks) + (d->nSendAll + 63) / 64;   // (the fused kernel monitors min(rho), min(e) per block)
         cv.blkFace = a.alloc<double>(2 * (size_t)std::max(1, cv.nBlkFace));
         cv.blkCell = a.alloc<double>(2 * (size_t)std::max(1, cv.nBlkCell));
         cv.flux = a.alloc<double>(5 * (size_t)v.nF);
@@ -1549,7 +1572,8 @@ int qgd_case_set_qgd_coeffs(qgd_case_t c, const double* alphaQGD, const double* 
 // conditions, 2 = the rest.  A shard whose GaussVolPoint stencil meets a qgdFlux wall exchanges the mid-step patch pressure of the
 // boundary layer's patch faces between 1 and 2 (midExchangeNeeded): a ghost cell's patch face forms it from an incomplete stencil, and the
 // vertex values of p on the wall carry it into the stencil of owned faces.
-static void assembleFluxes(qgd_case_s* c, bool adjust, int part = 0) {
+static void assembleFluxes(qgd_case_s* c, bool adjust, int part = 0, bool internalFaces = true) {
+    // internalFaces = false: the fused step computes them itself (stepFused)
     (void)hipGetLastError();  // drop any stale sticky error: the callers check after their launches
     const Launcher L = launcherOf(c);
     const MeshView& m = c->dev->view;
@@ -1568,7 +1592,8 @@ static void assembleFluxes(qgd_case_s* c, bool adjust, int part = 0) {
     }
     if (part == 1) return;
     if (mid) launchBoundaryPoints(L, m, v, true);
-    if (c->mixB >= 0) launchFaceFluxMixed(L, c->stencil, c->mixB, c->mixMask, m, v, c->gas, adjust);
+    if (!internalFaces) {}
+    else if (c->mixB >= 0) launchFaceFluxMixed(L, c->stencil, c->mixB, c->mixMask, m, v, c->gas, adjust);
     else launchFaceFlux(L, c->stencil, m, v, c->gas, adjust);
     bface(mid ? 2 : 0, adjust);
 }
@@ -1739,6 +1764,20 @@ static void stepAdvance(qgd_case_s* c, int part) {
     }
 }
 
+// One explicit step with the internal faces and the cell update in one kernel: vertex values, patch faces (their fluxes go to c.flux,
+// where the fused kernel's cells find them), then every block computes its faces and advances its cells into A2 / B2, which become A / B.
+static void stepFused(qgd_case_s* c) {
+    const Launcher L = launcherOf(c);
+    const MeshView& m = c->dev->view;
+    assembleFluxes(c, false, 0, false);
+    c->steps++;
+    c->time += c->opt.deltaT;
+    launchFusedFaceCell(L, m, c->view, c->gas);
+    std::swap(c->view.A, c->view.A2);
+    std::swap(c->view.B, c->view.B2);
+    launchBoundaryUpdate(L, m, c->view, c->gas, c->bcDev, false, c->phiwRegistered, 0, nullptr, 0);
+}
+
 int qgd_case_step(qgd_case_t c, int32_t nSteps) {
     QGD_TRY
     if (!c) return fail(QGD_ERR_INVALID, "null case");
@@ -1746,7 +1785,10 @@ int qgd_case_step(qgd_case_t c, int32_t nSteps) {
     if (c->dev->sharded())
         return fail(QGD_ERR_INVALID, "qgd_case_step: sharded mesh, drive it with qgd_case_step_phase + halo exchange");
     HIP_CHECK(hipSetDevice(c->dev->deviceId));
-    for (int i = 0; i < nSteps; ++i) { stepAssemble(c); stepAdvance(c, 0); }
+    for (int i = 0; i < nSteps; ++i) {
+        if (c->fused) stepFused(c);
+        else { stepAssemble(c); stepAdvance(c, 0); }
+    }
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(c->stream()));
     return QGD_OK;
@@ -1776,7 +1818,11 @@ int qgd_case_step_phase(qgd_case_t c, int phase) {
     else if (phase == 1) stepAdvance(c, 0);
     else if (phase == 10) stepAdvance(c, 1);
     else if (phase == 11) stepAdvance(c, 2);
-    else if (phase != 2) return fail(QGD_ERR_INVALID, "qgd_case_step_phase: phase must be 0, 1, 2, 5, 6, 10 or 11");
+    else if (phase == 3) {
+        if (c->dev->sharded()) return fail(QGD_ERR_INVALID, "qgd_case_step_phase: phase 3 (one whole step, no exchange) is for unsharded meshes");
+        if (c->fused) stepFused(c);
+        else { stepAssemble(c); stepAdvance(c, 0); }
+    } else if (phase != 2) return fail(QGD_ERR_INVALID, "qgd_case_step_phase: phase must be 0, 1, 2, 3, 5, 6, 10 or 11");
     HIP_CHECK(hipGetLastError());
     return QGD_OK;  // asynchronous: qgd_case_stream_sync waits
     QGD_CATCH
@@ -2905,6 +2951,16 @@ int qgd_case_info(qgd_case_t c, double info[6]) {
     info[5] = (double)c->steps;
     return QGD_OK;
     QGD_CATCH
+}
+
+int qgd_case_fused_info(qgd_case_t c, int64_t info[4]) {
+    if (!c || !info) return fail(QGD_ERR_INVALID, "null argument");
+    const MeshView& v = c->dev->view;
+    info[0] = c->fused ? 1 : 0;
+    info[1] = c->fused ? v.fuBlocks : 0;
+    info[2] = c->fused ? (int64_t)v.nIF + c->dev->fusedRedundantFaces : 0;
+    info[3] = c->fused ? v.fuLds : 0;
+    return QGD_OK;
 }
 
 int qgd_case_implicit_info(qgd_case_t c, double info[16]) {

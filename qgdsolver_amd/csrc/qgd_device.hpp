@@ -68,6 +68,9 @@ struct MeshView {
     int32_t sGeo;            // 1: the 3-D GaussVolPoint kernels rebuild Sf of quadrilateral faces from the vertices (no Sf stream)
     const double* V; const double* hQGD; const uint8_t* ghost;
     const int32_t* bPatch; const double* hQGDb;
+    // cell blocks of the fused face + cell kernel (qgd_setup.hpp FusedBlocks); fuBlocks == 0: not built
+    int32_t fuBlocks, fuCapC, fuCapV, fuCapF, fuCapE, fuLds, fuLdsCell;   // fuLdsCell: where the per-cell park of the kernel starts, in doubles
+    const int4* fuHdr; const int32_t* fuCells; const int32_t* fuVerts; const int4* fuFace; const uint8_t* fuNEntry; const int32_t* fuEntry;
 };
 
 // Per-patch boundary-condition table (device copy, <= 64 patches)
@@ -92,6 +95,7 @@ struct GasModel {
 // Mutable case state on the device
 struct CaseView {
     RecA* A; RecB* B;               // nC
+    RecA* A2; RecB* B2;             // nC, fused step only: the records the step writes (it reads its neighbours' old ones); swapped with A, B after the step
     double* rE;                     // nC total energy rho*E (rhoU is rho*U of the record: the explicit re-solve keeps them equal)
     RecA* P;                        // nP vertex records
     RecA* bA; RecB* bB;             // nBF boundary records
@@ -136,6 +140,7 @@ void launchBoundaryFaceFlux(const Launcher& L, int stencil, const MeshView& m, c
 void launchFaceFluxMixed(const Launcher& L, int a, int b, int maskB, const MeshView& m, const CaseView& c, const GasModel& g, bool adjustDt);
 void launchBoundaryFaceFluxMixed(const Launcher& L, int a, int b, int maskB, const MeshView& m, const CaseView& c, const GasModel& g,
                                  const PatchBCDev* bc, int phiwOnly, bool adjustDt);
+void launchFusedFaceCell(const Launcher& L, const MeshView& m, const CaseView& c, const GasModel& g);
 void launchCellUpdate(const Launcher& L, const MeshView& m, const CaseView& c, const GasModel& g, int mode,
                       const int32_t* list, int nList);
 void launchBoundaryUpdate(const Launcher& L, const MeshView& m, const CaseView& c, const GasModel& g, const PatchBCDev* bc,

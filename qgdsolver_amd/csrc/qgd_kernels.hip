@@ -448,7 +448,8 @@ __device__ __forceinline__ void gvp3FaceBody(const MeshView& m, const CaseView& 
                                              const double w, const double hf, const double (&S)[3], const RecA& Ao, const RecA& An,
                                              const RecB& Bo, const RecB& Bn, const RecA& q0, const RecA& q1, const RecA& q2, const RecA& q3,
                                              const double (&coef)[12], const double rVc, const double msO, const double dnO,
-                                             const int adjustDt, double& cof, double& tauMin) {
+                                             const int adjustDt, double& cof, double& tauMin, double* const fluxOut, const size_t fluxStride) {
+    // fluxOut / fluxStride: where the five net fluxes go -- c.flux + fp at a stride of nF faces, or a slot of the fused kernel's LDS
     // msO, dnO: |Sf| and deltaCoeffs of the face, read only on meshes that have faces with more than four vertices
     const size_t nF = (size_t)m.nF;
     FaceVals<6> v;
@@ -541,7 +542,7 @@ __device__ __forceinline__ void gvp3FaceBody(const MeshView& m, const CaseView& 
     double out[5], phiw;
     qgdFluxes<DBG, UPW>(s, g, S, out, phiw, DBG ? c.dbg + f : nullptr, nF);
 #pragma unroll
-    for (int k = 0; k < 5; ++k) c.flux[(size_t)k * nF + fp] = out[k];
+    for (int k = 0; k < 5; ++k) fluxOut[(size_t)k * fluxStride] = out[k];
     if (adjustDt) {
         bool counted = true;
         if (m.ghost != nullptr) counted = !(m.ghost[m.own[f]] == 1 && m.ghost[m.nei[f]] == 1);
@@ -586,7 +587,8 @@ void faceFluxGvp3Kernel(const MeshView m, const CaseView c, const GasModel gm, c
         double coef[12], rVc;
         gvp3Coefs(kind, cO, cN, x0, x1, x2, x3, coef, rVc);
         if (SGEO && kind == 0) { S[0] = 0.5 * coef[6]; S[1] = 0.5 * coef[7]; S[2] = 0.5 * coef[8]; }   // Sf = (p3-p1) x (p4-p2) / 2
-        gvp3FaceBody<DBG, UPW>(m, c, gm, f, fp, kind, w, hf, S, Ao, An, Bo, Bn, q0, q1, q2, q3, coef, rVc, msO, dnO, adjustDt, cof, tauMin);
+        gvp3FaceBody<DBG, UPW>(m, c, gm, f, fp, kind, w, hf, S, Ao, An, Bo, Bn, q0, q1, q2, q3, coef, rVc, msO, dnO, adjustDt, cof, tauMin,
+                               c.flux + fp, (size_t)m.nF);
     }
     if (adjustDt) blockMaxMin<FB>(cof, tauMin, c.blkFace + 2 * (size_t)tile, false);
 }
@@ -601,6 +603,7 @@ void faceFluxGvp3Kernel(const MeshView m, const CaseView c, const GasModel gm, c
 // operation order, bit-identical fluxes.
 // ---------------------------------------------------------------------------
 typedef double v2d __attribute__((ext_vector_type(2)));   // one 16-B piece
+constexpr int kFusedCapCDev = 320, kFusedCapVDev = 256, kFusedCapFDev = 512;   // = kFusedCap{C,V,F} of qgd_setup.hpp
 #ifndef QGD_F_BUF
 #define QGD_F_BUF 0
 #endif
@@ -747,7 +750,8 @@ void faceFluxGvp3TileKernel(const MeshView m, const CaseView c, const GasModel g
         const RecB Bo = *reinterpret_cast<const RecB*>(sB + 2 * lo), Bn = *reinterpret_cast<const RecB*>(sB + 2 * ln);
         const RecA q0 = *reinterpret_cast<const RecA*>(sP + 3 * v0), q1 = *reinterpret_cast<const RecA*>(sP + 3 * v1),
                    q2 = *reinterpret_cast<const RecA*>(sP + 3 * v2), q3 = *reinterpret_cast<const RecA*>(sP + 3 * v3);
-        gvp3FaceBody<false, UPW>(m, c, gm, f, fp, kind, w, hf, S, Ao, An, Bo, Bn, q0, q1, q2, q3, coef, rVc, msO, dnO, adjustDt, cof, tauMin);
+        gvp3FaceBody<false, UPW>(m, c, gm, f, fp, kind, w, hf, S, Ao, An, Bo, Bn, q0, q1, q2, q3, coef, rVc, msO, dnO, adjustDt, cof, tauMin,
+                                 c.flux + fp, (size_t)m.nF);
     }
     if (adjustDt) blockMaxMin<FB>(cof, tauMin, c.blkFace + 2 * (size_t)tile, false);
 }
@@ -958,6 +962,39 @@ void pointInterpRecKernel(const MeshView m, const RecA* __restrict__ A, RecA* __
     P[p] = acc;
 }
 
+// QGDRhoEqn / QGDUEqn / QGDEEqn + thermo + QGD coefficients of one cell from the sum of its net face fluxes (shared by the cell kernel and
+// the fused face + cell kernel)
+__device__ __forceinline__ void advanceCell(const CaseView& c, const GasModel& gm, const int ci, const RecA& A, const double rEold,
+                                            const double Vc, const double hq, const double (&sum)[5], RecA& An, RecB& Bn, double& rEnew) {
+    const double dtV = c.dt[0] / Vc;
+    // QGDRhoEqn / QGDUEqn / QGDEEqn: explicit Euler on rho, rhoU, rhoE
+    const double rho = A.rho - dtV * sum[0];
+    // rhoU is not stored: it equals rho*U up to rounding by the re-solve identity below, so its increment is taken
+    // directly (rhoU_new - rhoU_old = -dtV*sum); rhoE is an independent field (the explicit energy re-solve as listed does
+    // not keep rhoE = rho*(e + |U|^2/2)), 8 B per cell
+    rEnew = rEold - dtV * sum[4];
+    // solve(fvm::ddt(rho,U) - fvc::ddt(rhoU)) [QGDUEqn_8H L79-86]
+    An.rho = rho;
+    An.ux = (A.rho * A.ux + (-(dtV * sum[1]))) / rho;
+    An.uy = (A.rho * A.uy + (-(dtV * sum[2]))) / rho;
+    An.uz = (A.rho * A.uz + (-(dtV * sum[3]))) / rho;
+    // solve(fvm::ddt(rho,e) - fvc::ddt(rhoE)) [QGDEEqn_8H L67-72], as written in the listing
+    An.e = gm.consistentEnergy ? rEnew / rho - 0.5 * (An.ux * An.ux + An.uy * An.uy + An.uz * An.uz)   // e of [QGDEEqn_8H L49] kept
+                               : (A.rho * A.e + (rEnew - rEold)) / rho;
+    // thermo.correct(): eConst + perfectGas [hePsiQGDThermo_8C L48-64, L123-124]
+    const double T = An.e / gm.Cv;
+    const double psi = 1.0 / (gm.R * T);
+    const double cs = sqrt(gm.gamma / psi);
+    // constScPrModel1 [L103-115]: the pressure seen here is still the old one [QGDFoam_8C L149-154]
+    const double aq = c.aQ ? c.aQ[ci] : gm.alphaQGD, scq = c.sc ? c.sc[ci] : gm.ScQGD;
+    const double tauQGD = aq * hq / cs;
+    Bn.muQGD = A.p * scq * tauQGD;
+    Bn.c = cs;
+    Bn.aOc = aq / cs;
+    An.p = rho / psi;                  // [QGDFoam_8C L152-154]
+    Bn.H = (rEnew + An.p) / rho;       // H = (rhoE + p)/rho [QGDFoam/updateFields.H L71]
+}
+
 // ---------------------------------------------------------------------------
 // cell update: gather of the net face fluxes in ascending face order (the
 // summation order of fvc::surfaceIntegrate), explicit Euler, thermo, QGD coeffs
@@ -1032,35 +1069,11 @@ void cellUpdateKernel(const MeshView m, const CaseView c, const GasModel gm, con
                 }
             }
         }
-        const double dtV = c.dt[0] / Vc;
-        // QGDRhoEqn / QGDUEqn / QGDEEqn: explicit Euler on rho, rhoU, rhoE
-        const double rho = A.rho - dtV * sum[0];
-        // rhoU is not stored: it equals rho*U up to rounding by the re-solve identity below, so its increment is taken
-        // directly (rhoU_new - rhoU_old = -dtV*sum); rhoE is an independent field (the explicit energy re-solve as listed does
-        // not keep rhoE = rho*(e + |U|^2/2)), 8 B per cell
-        const double rEnew = rEold - dtV * sum[4];
-        // solve(fvm::ddt(rho,U) - fvc::ddt(rhoU)) [QGDUEqn_8H L79-86]
         RecA An;
-        An.rho = rho;
-        An.ux = (A.rho * A.ux + (-(dtV * sum[1]))) / rho;
-        An.uy = (A.rho * A.uy + (-(dtV * sum[2]))) / rho;
-        An.uz = (A.rho * A.uz + (-(dtV * sum[3]))) / rho;
-        // solve(fvm::ddt(rho,e) - fvc::ddt(rhoE)) [QGDEEqn_8H L67-72], as written in the listing
-        An.e = gm.consistentEnergy ? rEnew / rho - 0.5 * (An.ux * An.ux + An.uy * An.uy + An.uz * An.uz)   // e of [QGDEEqn_8H L49] kept
-                                   : (A.rho * A.e + (rEnew - rEold)) / rho;
-        // thermo.correct(): eConst + perfectGas [hePsiQGDThermo_8C L48-64, L123-124]
-        const double T = An.e / gm.Cv;
-        const double psi = 1.0 / (gm.R * T);
-        const double cs = sqrt(gm.gamma / psi);
-        // constScPrModel1 [L103-115]: the pressure seen here is still the old one [QGDFoam_8C L149-154]
-        const double aq = c.aQ ? c.aQ[ci] : gm.alphaQGD, scq = c.sc ? c.sc[ci] : gm.ScQGD;
-        const double tauQGD = aq * hq / cs;
         RecB Bn;
-        Bn.muQGD = A.p * scq * tauQGD;
-        Bn.c = cs;
-        Bn.aOc = aq / cs;
-        An.p = rho / psi;                  // [QGDFoam_8C L152-154]
-        Bn.H = (rEnew + An.p) / rho;       // H = (rhoE + p)/rho [QGDFoam/updateFields.H L71]
+        double rEnew;
+        advanceCell(c, gm, ci, A, rEold, Vc, hq, sum, An, Bn, rEnew);
+        const double rho = An.rho;
         c.A[ci] = An;
         c.B[ci] = Bn;
         c.rE[ci] = rEnew;
@@ -1070,6 +1083,188 @@ void cellUpdateKernel(const MeshView m, const CaseView c, const GasModel gm, con
     }
     // positivity monitor [QGDFoam_8C L142]: one plain store pair per workgroup, no atomics
     blockMaxMin<CB>(-rmin, emin, c.blkCell + 2 * (size_t)(slotBase + tile), true);
+}
+
+// ---------------------------------------------------------------------------
+// QGD_FUSED: face fluxes and cell update of a BLOCK of cells in one workgroup (qgd_setup.hpp FusedBlocks).  The three kernels of the
+// explicit step run at what the memory system delivers (profiles/r05_ab_face_four_waves.txt), and a third of the step's bytes are the net
+// fluxes' round trip through HBM: 40 B per face written by F, read back twice by C.  Here a workgroup stages the records of its <= 128 cells,
+// of the cells across the block's surface and of their vertices in LDS (fewer distinct records per face than a run of consecutive faces has:
+// the block is compact in all three directions), computes EVERY internal face of its cells -- the surface faces are computed by the block
+// on either side, 21 % more face work on 8x4x4 bricks -- leaves the five fluxes in LDS, and advances its own cells out of LDS in the
+// summation order of fvc::surfaceIntegrate (ascending face label; boundary faces from c.flux, where the boundary kernel put them).  It
+// reads the OLD records of its neighbours while other blocks write new ones: the step writes A2 / B2, the host swaps them with A / B.
+// Same arithmetic per face and per cell as faceFluxGvp3Kernel + cellUpdateKernel, same order: bit-identical states.  Fixed deltaT, no
+// shards, no debug fields, linear fluxes (everything else keeps the two kernels).
+// ---------------------------------------------------------------------------
+#ifndef QGD_FU_WAVES
+#define QGD_FU_WAVES 3
+#endif
+template <bool SGEO>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QGD_FU_WAVES, QGD_FU_WAVES)))
+void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm) {
+    extern __shared__ v2d tileLds[];
+#if QGD_F_PRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
+    constexpr int NT = 256, KC = 4, KB2 = 3, KV = 3, KF = 2, KE = 6;   // piece loads per thread for <= 320 cells / 256 vertices, faces per thread, face entries of a cell held in registers
+    static_assert(3 * kFusedCapCDev <= KC * NT && 2 * kFusedCapCDev <= KB2 * NT && 3 * kFusedCapVDev <= KV * NT && kFusedCapFDev <= KF * NT, "caps");
+    const int blk = xcdTile((int)gridDim.x, m.xcdRun);
+    const int tid = (int)threadIdx.x;
+    const int capC = m.fuCapC, capV = m.fuCapV, capF = m.fuCapF;
+    const int32_t* __restrict__ tCells = m.fuCells + (size_t)blk * capC;
+    const int32_t* __restrict__ tVerts = m.fuVerts + (size_t)blk * capV;
+    const int4* __restrict__ tFace = m.fuFace + (size_t)blk * capF;
+    const int32_t* __restrict__ ent = m.fuEntry + (size_t)blk * m.fuCapE * 128 + (tid & 127);
+    // LDS: the cells' records stay to the end (an own cell's old record is read by its update); the vertex records and all coordinates
+    // are dead once every face has its fluxes in registers, and the fluxes take their place
+    v2d* const sA = tileLds;               // 3 capC pieces: cell RecA
+    v2d* const sB = sA + 3 * capC;         // 2 capC: cell RecB
+    v2d* const sP = sB + 2 * capC;         // 3 capV: vertex RecA
+    double* const sX = reinterpret_cast<double*>(sP + 3 * capV);   // 3 capV: vertex coordinates
+    double* const sC = sX + 3 * capV;      // 3 capC: cell centres
+    double* const sF = reinterpret_cast<double*>(sP);   // 5 capF: net fluxes, plane by plane (after the second barrier)
+    double* const sS = reinterpret_cast<double*>(tileLds) + m.fuLdsCell;   // 6 x 128: an own cell's rhoE, V, hQGD and first six face entries, parked until its update
+    // (0) everything whose address does not depend on a loaded value: the counts, the lists (padded to their strides with their last entry,
+    // so no count is needed to read them), this thread's two faces, its cell's face entries
+    const int4 hdr = m.fuHdr[blk];
+    int4 fc[KF];
+#pragma unroll
+    for (int j = 0; j < KF; ++j) fc[j] = tFace[min(tid + j * NT, capF - 1)];
+    int idC[KC], idB[KB2], idV[KV];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+        const int q = tid + k * NT, r = (q * 43691) >> 17;
+        idC[k] = tCells[min(r, capC - 1)] * 3 + (q - 3 * r);
+    }
+#pragma unroll
+    for (int k = 0; k < KB2; ++k) {
+        const int q = tid + k * NT, r = q >> 1;
+        idB[k] = tCells[min(r, capC - 1)] * 2 + (q & 1);
+    }
+#pragma unroll
+    for (int k = 0; k < KV; ++k) {
+        const int q = tid + k * NT, r = (q * 43691) >> 17;
+        idV[k] = tVerts[min(r, capV - 1)] * 3 + (q - 3 * r);
+    }
+    const int ci = tCells[tid & 127];
+    const int nEraw = (int)m.fuNEntry[(size_t)blk * 128 + (tid & 127)];
+    int e6[KE];
+#pragma unroll
+    for (int i = 0; i < KE; ++i) e6[i] = ent[(size_t)min(i, m.fuCapE - 1) * 128];
+    // (1) one round trip later: the records, piece by piece; the faces' streams; the cell's own scalars
+    const v2d* __restrict__ gA = reinterpret_cast<const v2d*>(c.A);
+    const v2d* __restrict__ gB = reinterpret_cast<const v2d*>(c.B);
+    const v2d* __restrict__ gP = reinterpret_cast<const v2d*>(c.P);
+    v2d dA[KC], dB[KB2], dP[KV];
+    double dC[KC], dX[KV];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) { dA[k] = gA[idC[k]]; dC[k] = m.Cc[idC[k]]; }
+#pragma unroll
+    for (int k = 0; k < KB2; ++k) dB[k] = gB[idB[k]];
+#pragma unroll
+    for (int k = 0; k < KV; ++k) { dP[k] = gP[idV[k]]; dX[k] = m.X[idV[k]]; }
+    double fw[KF], fh[KF];
+    int fk[KF];
+#pragma unroll
+    for (int j = 0; j < KF; ++j) { fw[j] = ldStream(m.w + fc[j].x); fh[j] = ldStream(m.hf + fc[j].x); fk[j] = m.fkind[fc[j].x]; }
+    {
+        const double rEold = c.rE[ci], Vc = m.V[ci], hq = m.hQGD[ci];
+        __builtin_amdgcn_sched_barrier(0);
+        if (tid < 128) {
+            sS[tid] = rEold; sS[128 + tid] = Vc; sS[256 + tid] = hq;
+            int* const sE = reinterpret_cast<int*>(sS + 384);
+#pragma unroll
+            for (int i = 0; i < KE; ++i) sE[i * 128 + tid] = e6[i];
+        }
+    }
+    const int nOwn = hdr.x, nUc = hdr.y, nUv = hdr.z, nFc = hdr.w;
+#pragma unroll
+    for (int k = 0; k < KC; ++k) { const int q = tid + k * NT; if (q < 3 * nUc) { sA[q] = dA[k]; sC[q] = dC[k]; } }
+#pragma unroll
+    for (int k = 0; k < KB2; ++k) { const int q = tid + k * NT; if (q < 2 * nUc) sB[q] = dB[k]; }
+#pragma unroll
+    for (int k = 0; k < KV; ++k) { const int q = tid + k * NT; if (q < 3 * nUv) { sP[q] = dP[k]; sX[q] = dX[k]; } }
+    __syncthreads();
+#if QGD_F_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    // (2) the faces: fluxes into registers
+    auto l3 = [](const double* p, int i) { return make_double4(p[3 * i], p[3 * i + 1], p[3 * i + 2], 0.0); };
+    double out[KF][5];
+#pragma unroll
+    for (int j = 0; j < KF; ++j) {
+        const int lf = tid + j * NT;
+        if (lf < nFc) {
+            const int f = fc[j].x, kind = fk[j];
+            const unsigned lc = (unsigned)fc[j].y, lva = (unsigned)fc[j].z, lvb = (unsigned)fc[j].w;
+            const int lo = (int)(lc & 0xffffu), ln = (int)(lc >> 16);
+            const int v0 = (int)(lva & 0xffffu), v1 = (int)(lva >> 16), v2 = (int)(lvb & 0xffffu), v3 = (int)(lvb >> 16);
+            double S[3] = {0.0, 0.0, 0.0};
+            double msO = 1.0, dnO = 0.0;
+            if (!SGEO || kind != 0) { S[0] = ldStream(m.Sx + f); S[1] = ldStream(m.Sy + f); S[2] = ldStream(m.Sz + f); }
+            if (m.hasOther) { msO = m.magSf[f]; dnO = m.dn[f]; }
+            double coef[12], rVc;
+            {
+                const double4 cO = l3(sC, lo), cN = l3(sC, ln);
+                const double4 x0 = l3(sX, v0), x1 = l3(sX, v1), x2 = l3(sX, v2), x3 = l3(sX, v3);
+                gvp3Coefs(kind, cO, cN, x0, x1, x2, x3, coef, rVc);
+                if (SGEO && kind == 0) { S[0] = 0.5 * coef[6]; S[1] = 0.5 * coef[7]; S[2] = 0.5 * coef[8]; }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const RecA Ao = *reinterpret_cast<const RecA*>(sA + 3 * lo), An = *reinterpret_cast<const RecA*>(sA + 3 * ln);
+            const RecB Bo = *reinterpret_cast<const RecB*>(sB + 2 * lo), Bn = *reinterpret_cast<const RecB*>(sB + 2 * ln);
+            const RecA q0 = *reinterpret_cast<const RecA*>(sP + 3 * v0), q1 = *reinterpret_cast<const RecA*>(sP + 3 * v1),
+                       q2 = *reinterpret_cast<const RecA*>(sP + 3 * v2), q3 = *reinterpret_cast<const RecA*>(sP + 3 * v3);
+            double cof, tauMin;
+            gvp3FaceBody<false, false>(m, c, gm, f, 0, kind, fw[j], fh[j], S, Ao, An, Bo, Bn, q0, q1, q2, q3, coef, rVc, msO, dnO, 0, cof, tauMin,
+                                       &out[j][0], (size_t)1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();   // every face has read its vertex records and coordinates
+#pragma unroll
+    for (int j = 0; j < KF; ++j) {
+        const int lf = tid + j * NT;
+        if (lf < nFc) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) sF[k * capF + lf] = out[j][k];
+        }
+    }
+    __syncthreads();
+    // (3) the block's own cells out of LDS
+    double rmin = 1e300, emin = 1e300;
+    if (tid < nOwn) {
+        const size_t nF = (size_t)m.nF;
+        double sum[5] = {0, 0, 0, 0, 0};
+        const int nE = nEraw;
+        const int* const sE = reinterpret_cast<const int*>(sS + 384);
+        const double rEold = sS[tid], Vc = sS[128 + tid], hq = sS[256 + tid];
+        for (int i = 0; i < nE; ++i) {
+            const int e = (i < KE) ? sE[i * 128 + tid] : ent[(size_t)i * 128];
+            double fl[5];
+            if (e >= 0) {
+#pragma unroll
+                for (int k = 0; k < 5; ++k) fl[k] = sF[k * capF + (e >> 1)];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 5; ++k) fl[k] = c.flux[k * nF + (size_t)(~e)];
+            }
+#pragma unroll
+            for (int k = 0; k < 5; ++k) sum[k] = (e < 0 || !(e & 1)) ? sum[k] + fl[k] : sum[k] - fl[k];
+        }
+        const RecA A = *reinterpret_cast<const RecA*>(sA + 3 * tid);
+        RecA An;
+        RecB Bn;
+        double rEnew;
+        advanceCell(c, gm, ci, A, rEold, Vc, hq, sum, An, Bn, rEnew);
+        c.A2[ci] = An;
+        c.B2[ci] = Bn;
+        c.rE[ci] = rEnew;
+        rmin = (An.rho == An.rho) ? An.rho : -1e300;
+        emin = (An.e == An.e) ? An.e : -1e300;
+    }
+    blockMaxMin<NT>(-rmin, emin, c.blkCell + 2 * (size_t)blk, true);
 }
 
 // createFields.H for the cells [QGDFoam_2createFields_8H L3-109]
@@ -1648,6 +1843,11 @@ void launchBoundaryFaceFlux(const Launcher& L, int stencil, const MeshView& m, c
                             const PatchBCDev* bc, int phiwOnly, bool adjustDt) {
     QGD_TIMED(L, QGD_K_BFACE, (c.dbg && phiwOnly != 1 ? launchBFaceFluxT<true>(L, stencil, m, c, g, bc, phiwOnly, adjustDt)
                                                    : launchBFaceFluxT<false>(L, stencil, m, c, g, bc, phiwOnly, adjustDt)));
+}
+void launchFusedFaceCell(const Launcher& L, const MeshView& m, const CaseView& c, const GasModel& g) {
+    if (m.fuBlocks == 0) return;
+    if (m.sGeo) QGD_TIMED(L, QGD_K_FACE, (fusedFaceCellKernel<true><<<m.fuBlocks, 256, m.fuLds, L.stream>>>(m, c, g)));
+    else QGD_TIMED(L, QGD_K_FACE, (fusedFaceCellKernel<false><<<m.fuBlocks, 256, m.fuLds, L.stream>>>(m, c, g)));
 }
 void launchCellUpdate(const Launcher& L, const MeshView& m, const CaseView& c, const GasModel& g, int mode,
                       const int32_t* list, int nList) {

@@ -655,4 +655,179 @@ FaceTiles buildFaceTiles(const StaticData& s, int32_t fb) {
     return t;
 }
 
+// ---- cell blocks of the fused face + cell kernel (qgd_setup.hpp FusedBlocks) ---------------------------------------------------------
+namespace {
+inline uint64_t spread21(uint64_t x) {   // 21 bits -> every third bit
+    x &= 0x1fffffull;
+    x = (x | x << 32) & 0x1f00000000ffffull;
+    x = (x | x << 16) & 0x1f0000ff0000ffull;
+    x = (x | x << 8) & 0x100f00f00f00f00full;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+struct OneBlock {
+    std::vector<int32_t> cells, verts, face, entry;   // entry: row-major here (own cell x capE), transposed at the end
+    std::vector<uint8_t> nEntry;
+    int32_t nOwn = 0, maxE = 0;
+};
+}  // namespace
+
+FusedBlocks buildFusedBlocks(const StaticData& s) {
+    FusedBlocks B;
+    const int64_t nC = s.nC, nIF = s.nIF;
+    if (nC == 0 || nIF == 0 || s.nGeomD != 3 || !s.ghost.empty()) return B;
+    if (3 * (int64_t)s.nC > INT32_MAX || 3 * (int64_t)s.nP > INT32_MAX) return B;
+    // Morton order of the cell centres on a lattice of the mean cell spacing
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int64_t c = 0; c < nC; ++c)
+        for (int d = 0; d < 3; ++d) { lo[d] = std::min(lo[d], s.Cc[3 * c + d]); hi[d] = std::max(hi[d], s.Cc[3 * c + d]); }
+    double vol = 0.0;
+    for (int64_t c = 0; c < nC; ++c) vol += s.V[c];
+    const double h = std::cbrt(vol / (double)nC);
+    std::vector<std::pair<uint64_t, int32_t>> key((size_t)nC);
+#pragma omp parallel for schedule(static)
+    for (int64_t c = 0; c < nC; ++c) {
+        uint64_t q[3];
+        for (int d = 0; d < 3; ++d) q[d] = (uint64_t)std::min(2097151.0, std::max(0.0, std::floor((s.Cc[3 * c + d] - lo[d]) / h + 0.25)));
+        key[c] = {spread21(q[0]) | spread21(q[1]) << 1 | spread21(q[2]) << 2, (int32_t)c};
+    }
+    // (sorted in runs, then merged: keeps the host peak at one copy and uses the cores)
+    {
+        const int nRuns = 16;
+        std::vector<int64_t> cut(nRuns + 1);
+        for (int r = 0; r <= nRuns; ++r) cut[r] = nC * r / nRuns;
+#pragma omp parallel for schedule(dynamic, 1)
+        for (int r = 0; r < nRuns; ++r) std::sort(key.begin() + cut[r], key.begin() + cut[r + 1]);
+        for (int width = 1; width < nRuns; width *= 2) {
+#pragma omp parallel for schedule(dynamic, 1)
+            for (int r = 0; r < nRuns; r += 2 * width)
+                if (r + width < nRuns)
+                    std::inplace_merge(key.begin() + cut[r], key.begin() + cut[r + width], key.begin() + cut[std::min(nRuns, r + 2 * width)]);
+        }
+    }
+    auto entriesOf = [&](int32_t c, int32_t* out) {   // ascending face label, ~f when the cell is the neighbour
+        const int n = s.cfCount[c];
+        const size_t base = (size_t)s.cfSlice[c >> 6] * 64 + (c & 63);
+        for (int i = 0; i < n; ++i) out[i] = s.cfItem[base + (size_t)i * 64];
+        return n;
+    };
+    // one range of the sorted cells -> one block, or false when it does not fit the caps
+    auto tryBlock = [&](int64_t b0, int64_t b1, OneBlock& o) {
+        o = OneBlock();
+        o.nOwn = (int32_t)(b1 - b0);
+        std::vector<int32_t> faces;
+        int32_t ent[256];
+        for (int64_t i = b0; i < b1; ++i) {
+            const int32_t c = key[i].second;
+            if (s.cfCount[c] > 255) return false;
+            const int n = entriesOf(c, ent);
+            o.maxE = std::max(o.maxE, n);
+            for (int k = 0; k < n; ++k) { const int32_t f = ent[k] >= 0 ? ent[k] : ~ent[k]; if (f < nIF) faces.push_back(f); }
+        }
+        std::sort(faces.begin(), faces.end());
+        faces.erase(std::unique(faces.begin(), faces.end()), faces.end());
+        if ((int32_t)faces.size() > kFusedCapF) return false;
+        // staged cells: own cells in block order, then the others in ascending label
+        std::unordered_map<int32_t, int32_t> posC, posV;
+        posC.reserve(512); posV.reserve(512);
+        for (int64_t i = b0; i < b1; ++i) { posC[key[i].second] = (int32_t)o.cells.size(); o.cells.push_back(key[i].second); }
+        std::vector<int32_t> others, vs;
+        for (int32_t f : faces) {
+            if (!posC.count(s.own[f])) others.push_back(s.own[f]);
+            if (!posC.count(s.nei[f])) others.push_back(s.nei[f]);
+            for (int q = 0; q < 4; ++q) if (s.verts[4 * (size_t)f + q] >= 0) vs.push_back(s.verts[4 * (size_t)f + q]);
+        }
+        std::sort(others.begin(), others.end()); others.erase(std::unique(others.begin(), others.end()), others.end());
+        std::sort(vs.begin(), vs.end()); vs.erase(std::unique(vs.begin(), vs.end()), vs.end());
+        if ((int64_t)o.cells.size() + (int64_t)others.size() > kFusedCapC || (int32_t)vs.size() > kFusedCapV) return false;
+        for (int32_t c : others) { posC[c] = (int32_t)o.cells.size(); o.cells.push_back(c); }
+        for (int32_t v : vs) { posV[v] = (int32_t)o.verts.size(); o.verts.push_back(v); }
+        std::unordered_map<int32_t, int32_t> posF;
+        posF.reserve(1024);
+        o.face.resize(4 * faces.size());
+        for (size_t lf = 0; lf < faces.size(); ++lf) {
+            const int32_t f = faces[lf];
+            posF[f] = (int32_t)lf;
+            uint32_t pv[4] = {0, 0, 0, 0};
+            for (int q = 0; q < 4; ++q) { const int32_t v = s.verts[4 * (size_t)f + q]; pv[q] = v >= 0 ? (uint32_t)posV[v] : 0u; }
+            o.face[4 * lf] = f;
+            o.face[4 * lf + 1] = (int32_t)((uint32_t)posC[s.own[f]] | (uint32_t)posC[s.nei[f]] << 16);
+            o.face[4 * lf + 2] = (int32_t)(pv[0] | pv[1] << 16);
+            o.face[4 * lf + 3] = (int32_t)(pv[2] | pv[3] << 16);
+        }
+        o.nEntry.assign((size_t)o.nOwn, 0);
+        o.entry.assign((size_t)o.nOwn * (size_t)std::max(o.maxE, 1), 0);
+        for (int32_t j = 0; j < o.nOwn; ++j) {
+            const int n = entriesOf(o.cells[j], ent);
+            o.nEntry[j] = (uint8_t)n;
+            for (int k = 0; k < n; ++k) {
+                const int32_t f = ent[k] >= 0 ? ent[k] : ~ent[k];
+                o.entry[(size_t)j * o.maxE + k] = f < nIF ? (posF[f] << 1 | (ent[k] < 0 ? 1 : 0)) : ~f;
+            }
+        }
+        return true;
+    };
+    const int64_t nRanges = (nC + kFusedCells - 1) / kFusedCells;
+    std::vector<std::vector<OneBlock>> made((size_t)nRanges);
+    bool failed = false;
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t r = 0; r < nRanges; ++r) {
+        std::vector<std::pair<int64_t, int64_t>> work{{r * kFusedCells, std::min(nC, (r + 1) * (int64_t)kFusedCells)}};
+        while (!work.empty()) {
+            const auto [b0, b1] = work.back();
+            work.pop_back();
+            OneBlock o;
+            if (tryBlock(b0, b1, o)) { made[r].push_back(std::move(o)); continue; }
+            if (b1 - b0 == 1) { failed = true; break; }   // one cell with more faces / vertices than a block holds
+            const int64_t mid = (b0 + b1) / 2;
+            work.push_back({mid, b1});
+            work.push_back({b0, mid});
+        }
+    }
+    if (failed) return B;
+    int64_t nBlocks = 0, facesDone = 0;
+    for (auto& v : made)
+        for (auto& o : v) {
+            ++nBlocks;
+            B.maxC = std::max<int32_t>(B.maxC, (int32_t)o.cells.size());
+            B.maxV = std::max<int32_t>(B.maxV, (int32_t)o.verts.size());
+            B.maxF = std::max<int32_t>(B.maxF, (int32_t)o.face.size() / 4);
+            B.capE = std::max(B.capE, o.maxE);
+            facesDone += (int64_t)o.face.size() / 4;
+        }
+    B.capC = (B.maxC + 7) / 8 * 8; B.capV = (B.maxV + 7) / 8 * 8; B.capF = (B.maxF + 7) / 8 * 8;
+    B.capE = std::max(B.capE, 1);
+    if (nBlocks * (int64_t)std::max({B.capC, B.capV, 4 * B.capF, B.capE * kFusedCells}) > (int64_t)INT32_MAX) return B;
+    B.nBlocks = (int32_t)nBlocks;
+    B.redundantFaces = facesDone - nIF;
+    B.hdr.assign(4 * (size_t)nBlocks, 0);
+    B.cells.assign((size_t)nBlocks * B.capC, 0);
+    B.verts.assign((size_t)nBlocks * B.capV, 0);
+    B.face.assign((size_t)nBlocks * B.capF * 4, 0);
+    B.nEntry.assign((size_t)nBlocks * kFusedCells, 0);
+    B.entry.assign((size_t)nBlocks * B.capE * kFusedCells, 0);
+    std::vector<int64_t> first((size_t)nRanges + 1, 0);
+    for (int64_t r = 0; r < nRanges; ++r) first[r + 1] = first[r] + (int64_t)made[r].size();
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t r = 0; r < nRanges; ++r) {
+        for (size_t k = 0; k < made[r].size(); ++k) {
+            const OneBlock& o = made[r][k];
+            const size_t b = (size_t)(first[r] + (int64_t)k);
+            const int32_t nAll = (int32_t)o.cells.size(), nV = (int32_t)o.verts.size(), nF = (int32_t)o.face.size() / 4;
+            B.hdr[4 * b] = o.nOwn; B.hdr[4 * b + 1] = nAll; B.hdr[4 * b + 2] = nV; B.hdr[4 * b + 3] = nF;
+            for (int32_t i = 0; i < B.capC; ++i) B.cells[b * B.capC + i] = o.cells[std::min(i, nAll - 1)];
+            for (int32_t i = 0; i < B.capV; ++i) B.verts[b * B.capV + i] = nV ? o.verts[std::min(i, nV - 1)] : 0;
+            for (int32_t i = 0; i < B.capF; ++i)
+                for (int q = 0; q < 4; ++q) B.face[(b * B.capF + i) * 4 + q] = nF ? o.face[4 * (size_t)std::min(i, nF - 1) + q] : 0;
+            for (int32_t j = 0; j < o.nOwn; ++j) {
+                B.nEntry[b * kFusedCells + j] = o.nEntry[j];
+                for (int32_t e = 0; e < o.nEntry[j]; ++e) B.entry[(b * B.capE + e) * kFusedCells + j] = o.entry[(size_t)j * o.maxE + e];
+            }
+        }
+        std::vector<OneBlock>().swap(made[r]);
+    }
+    return B;
+}
+
 }  // namespace qgd

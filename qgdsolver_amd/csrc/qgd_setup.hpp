@@ -133,4 +133,25 @@ inline int32_t faceTileCapCells(int32_t fb) { return fb + fb / 16; }
 inline int32_t faceTileCapVerts(int32_t fb) { return ((fb * 23) / 16 + 7) / 8 * 8; }
 FaceTiles buildFaceTiles(const StaticData& s, int32_t fb);
 
+// ---- cell blocks of the fused face + cell kernel (QGD_FUSED; qgd_kernels.hip fusedFaceCellKernel) ---------------------------------
+// A block is up to 128 cells that sit together in space (consecutive cells of a Morton order of the cell centres: an 8x4x4 brick on
+// a uniform box) and EVERY internal face of those cells -- the faces on the block's surface are computed by the block on either side.
+// One workgroup stages the distinct cell records (the block's own cells first, then the cells across its surface) and vertex records
+// of those faces in LDS, computes the five net fluxes of each face into LDS, and advances its own cells out of LDS: the fluxes of
+// internal faces never reach HBM.  Fixed strides (capC, capV, capF, capE), lists padded with their last entry.
+struct FusedBlocks {
+    int32_t nBlocks = 0;
+    int32_t capC = 0, capV = 0, capF = 0, capE = 0;   // strides: staged cells, staged vertices, faces, face entries per own cell
+    int32_t maxC = 0, maxV = 0, maxF = 0;             // what the largest block uses (sizes the LDS)
+    std::vector<int32_t> hdr;      // 4 per block: own cells, staged cells, staged vertices, faces
+    std::vector<int32_t> cells;    // capC per block
+    std::vector<int32_t> verts;    // capV per block
+    std::vector<int32_t> face;     // 4 per face, capF faces per block: label, lo | ln << 16, v0 | v1 << 16, v2 | v3 << 16 (positions in the staged lists)
+    std::vector<uint8_t> nEntry;   // 128 per block: face entries of each own cell
+    std::vector<int32_t> entry;    // capE x 128 per block, entry-major: (local face << 1) | (1: the cell is the neighbour, minus), or ~label of a boundary face
+    int64_t redundantFaces = 0;    // faces computed minus internal faces of the mesh
+};
+constexpr int32_t kFusedCells = 128, kFusedCapC = 320, kFusedCapV = 256, kFusedCapF = 512;
+FusedBlocks buildFusedBlocks(const StaticData& s);
+
 }  // namespace qgd

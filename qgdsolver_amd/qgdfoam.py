@@ -169,6 +169,12 @@ class QGDFoamCase:
         L.check(L.lib.qgd_case_info(self._h, a), "qgd_case_info")
         return dict(time=a[0], deltaT=a[1], CoNum=a[2], minRho=a[3], minE=a[4], steps=int(a[5]))
 
+    def fused_info(self):
+        """whether step() advances with the fused face + cell kernel, its blocks, faces computed per step, LDS bytes (qgd_case_fused_info)"""
+        a = (C.c_int64 * 4)()
+        L.check(L.lib.qgd_case_fused_info(self._h, a), "qgd_case_fused_info")
+        return dict(fused=bool(a[0]), blocks=int(a[1]), facesComputed=int(a[2]), ldsBytes=int(a[3]))
+
     def implicit_info(self):
         """the four linear solves of the implicitDiffusion branch in the last step (qgd_case_implicit_info)"""
         a = (C.c_double * 16)()

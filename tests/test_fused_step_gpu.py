@@ -1,0 +1,131 @@
+"""The fused face + cell step (fusedFaceCellKernel, QGD_FUSED): a workgroup computes every internal face of a block of <= 128 cells into LDS
+and advances those cells from there; the net fluxes of internal faces never reach device memory.  Same arithmetic per face and per cell, same
+summation order as faceFluxGvp3(Tile)Kernel + cellUpdateKernel: the states must agree BIT FOR BIT with QGD_FUSED=0 -- on hexahedra, on
+jittered meshes with triangles and polygon faces, scrambled numberings, with patches of every kind the step knows (their fluxes come from the
+boundary kernel through device memory), the qgdFlux walls of the forward step's 3-D cousin, and over a long run.  Cases the fused kernel
+does not serve (Courant-number control, implicit diffusion, upwind fluxes, per-term stencils, shards) must say so and run the two kernels."""
+import os
+
+import numpy as np
+import pytest
+
+import qgdsolver_amd as q
+
+import cases
+from test_config5_gpu import c5_mesh
+
+pytestmark = pytest.mark.gpu
+
+
+def run(mesh, steps, fused, bc_fn=None, chunks=(None,), **opt):
+    old = os.environ.get("QGD_FUSED")
+    os.environ["QGD_FUSED"] = "1" if fused else "0"
+    try:
+        dev = q.Device(mesh)
+    finally:
+        if old is None:
+            del os.environ["QGD_FUSED"]
+        else:
+            os.environ["QGD_FUSED"] = old
+    case = q.QGDFoamCase(dev, q.default_options(stencil="GaussVolPoint", **opt))
+    if bc_fn:
+        bc_fn(case)
+    U, T, p = cases.box_initial_fields(mesh.array("C").reshape(-1, 3))
+    case.set_fields(U, T, p)
+    info = case.fused_info()
+    for n in chunks:
+        case.step(steps if n is None else n)
+    out = {n: case.field(n).copy() for n in ("rho", "U", "p", "e", "rhoE", "p.boundary", "U.boundary")}
+    i = case.info()
+    out["mins"] = np.array([i["minRho"], i["minE"], i["steps"], i["time"]])
+    case.close(); dev.close()
+    return out, info
+
+
+def meshes():
+    yield "hex 20^3", q.PolyMesh.box(20, 20, 20)
+    yield "hex 37x11x5", q.PolyMesh.box(37, 11, 5)
+    yield "hex 150x6x6", q.PolyMesh.box(150, 6, 6)
+    yield "hex 8x4x4 (one block)", q.PolyMesh.box(8, 4, 4)
+    yield "hex 3x2x2 (less than a wavefront of cells)", q.PolyMesh.box(3, 2, 2)
+    yield "jitter + triangles + polygons, Morton order", c5_mesh(16, 8 ** 3, poly=True)
+    tri = q.PolyMesh.box(9, 7, 5)
+    tri.jitter(0.15, seed=3); tri.split_quads(3)
+    yield "every third quad split, natural order", tri
+    scr = q.PolyMesh.box(12, 10, 8)
+    scr.renumber(np.random.default_rng(5).permutation(scr.nCells).astype(np.int32))
+    yield "scrambled labels", scr
+
+
+def equal(a, b, tag):
+    for k in a:
+        assert np.isfinite(a[k]).all(), (tag, k)
+        assert np.array_equal(a[k], b[k]), (tag, k, np.abs(a[k] - b[k]).max())
+
+
+def test_fused_step_is_bit_identical_to_the_two_kernels():
+    for tag, mesh in meshes():
+        h = 1.0 / 20
+        for opt in (dict(deltaT=0.05 * h), dict(deltaT=0.05 * h, mu=2e-3, consistentEnergy=1)):
+            a, ia = run(mesh, 7, False, **opt)
+            b, ib = run(mesh, 7, True, **opt)
+            assert not ia["fused"] and ib["fused"], (tag, ia, ib)
+            assert ib["blocks"] >= (mesh.nCells + 127) // 128 and ib["ldsBytes"] <= 80 * 1024, ib
+            assert ib["facesComputed"] >= mesh.nInternalFaces, ib
+            equal(a, b, (tag, opt))
+
+
+def test_fused_step_with_patches_of_every_kind_and_in_chunks():
+    import test_case_parity_gpu as t
+    mesh = q.PolyMesh.box(14, 9, 6)
+    mesh.jitter(0.1, seed=11)
+    for bc_fn in (t.mixed_box_bcs, None):
+        a, _ = run(mesh, 0, False, bc_fn=bc_fn, chunks=(1, 2, 5), deltaT=5e-4, mu=1e-3)
+        b, ib = run(mesh, 0, True, bc_fn=bc_fn, chunks=(1, 2, 5), deltaT=5e-4, mu=1e-3)
+        assert ib["fused"]
+        equal(a, b, bc_fn)
+
+
+def test_fused_step_stays_bit_identical_over_a_long_run():
+    mesh = q.PolyMesh.box(48, 48, 48)
+    opt = dict(deltaT=0.1 / 48 / 1.3)
+    a, _ = run(mesh, 300, False, **opt)
+    b, ib = run(mesh, 300, True, **opt)
+    assert ib["fused"] and ib["blocks"] == 48 ** 3 // 128      # 8x4x4 bricks
+    assert ib["facesComputed"] == 864 * (3 * 128 + 80) - 2 * 3 * 48 * 48    # 464 per brick, less what the domain's six sides lack
+    equal(a, b, "48^3 x 300")
+
+
+def test_cases_the_fused_kernel_does_not_serve_keep_the_two_kernels():
+    mesh = q.PolyMesh.box(10, 8, 6)
+    os.environ["QGD_FUSED"] = "1"
+    try:
+        dev = q.Device(mesh)
+    finally:
+        del os.environ["QGD_FUSED"]
+    for opt in (dict(adjustTimeStep=1, maxCo=0.2), dict(implicitDiffusion=1, mu=1e-3), dict(fluxSchemeU=1), dict(fluxSchemeH=1),
+                dict(termStencils={"grad(p)": "reduced"})):
+        case = q.QGDFoamCase(dev, q.default_options(stencil="GaussVolPoint", deltaT=1e-3, **opt))
+        assert not case.fused_info()["fused"], opt
+        case.close()
+    case = q.QGDFoamCase(dev, q.default_options(stencil="reduced", deltaT=1e-3))
+    assert not case.fused_info()["fused"]
+    case.close()
+    case = q.QGDFoamCase(dev, q.default_options(stencil="GaussVolPoint", deltaT=1e-3))
+    assert case.fused_info()["fused"]
+    # step_phase on such a case runs the two kernels in place; mixing the two ways of stepping is legal
+    U, T, p = cases.box_initial_fields(mesh.array("C").reshape(-1, 3))
+    case.set_fields(U, T, p)
+    case.step(2); case.step_phase(0); case.step_phase(1); case.step(1)
+    ref = q.QGDFoamCase(dev, q.default_options(stencil="GaussVolPoint", deltaT=1e-3, adjustTimeStep=0))
+    ref.set_fields(U, T, p)
+    for _ in range(4):
+        ref.step_phase(0); ref.step_phase(1)
+    for n in ("rho", "U", "p", "e"):
+        assert np.array_equal(case.field(n), ref.field(n)), n
+    case.close(); ref.close(); dev.close()
+    shard = q.PolyMesh.box(12, 6, 6).shard(2, 0)
+    dev = q.Device(shard)
+    case = q.QGDFoamCase(dev, q.default_options(stencil="GaussVolPoint", deltaT=1e-3))
+    assert not case.fused_info()["fused"]
+    case.close(); dev.close()
