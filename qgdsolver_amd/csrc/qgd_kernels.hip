@@ -406,21 +406,26 @@ __global__ __launch_bounds__(QGD_BLOCK) void faceFluxMixedKernel(const MeshView 
 //   V d_d phi = a5_d (phi_O - phi_N) + a0_d (phi_1 - phi_3) + a1_d (phi_2 - phi_4),
 //   6 a0 = (N-O) x (p2-p4),  6 a1 = (N-O) x (p3-p1),  6 a5 = (p1-p3) x (p2-p4),  6 V = -(p3-p1).(6 a0)
 // (the 1/6 cancel): coef = {a0[3], a1[3], a5[3]}, rV = 1/(6V).  Triangle [L193-229]: coef = t[12] of gvpTriCoef.
+// the quadrilateral's coefficients from its three difference vectors N-O, p2-p4, p3-p1 (one definition: the fused kernel forms the
+// differences one after the other out of LDS)
+__device__ __forceinline__ void gvp3QuadCoefs(const double (&NO)[3], const double (&d24)[3], const double (&d31)[3], double (&coef)[12], double& rV) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int u = (d + 1) % 3, w2 = (d + 2) % 3;
+        coef[d] = NO[u] * d24[w2] - NO[w2] * d24[u];
+        coef[3 + d] = NO[u] * d31[w2] - NO[w2] * d31[u];
+        coef[6 + d] = d24[u] * d31[w2] - d24[w2] * d31[u];
+    }
+    coef[9] = coef[10] = coef[11] = 0.0;
+    rV = -QGD_RCP(d31[0] * coef[0] + d31[1] * coef[1] + d31[2] * coef[2]);
+}
 __device__ __forceinline__ void gvp3Coefs(const int kind, const double4& cO, const double4& cN, const double4& x0, const double4& x1,
                                           const double4& x2, const double4& x3, double (&coef)[12], double& rV) {
     if (kind == 0) {
         const double NO[3] = {cN.x - cO.x, cN.y - cO.y, cN.z - cO.z};
         const double d24[3] = {x1.x - x3.x, x1.y - x3.y, x1.z - x3.z};
         const double d31[3] = {x2.x - x0.x, x2.y - x0.y, x2.z - x0.z};
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const int u = (d + 1) % 3, w2 = (d + 2) % 3;
-            coef[d] = NO[u] * d24[w2] - NO[w2] * d24[u];
-            coef[3 + d] = NO[u] * d31[w2] - NO[w2] * d31[u];
-            coef[6 + d] = d24[u] * d31[w2] - d24[w2] * d31[u];
-        }
-        coef[9] = coef[10] = coef[11] = 0.0;
-        rV = -QGD_RCP(d31[0] * coef[0] + d31[1] * coef[1] + d31[2] * coef[2]);
+        gvp3QuadCoefs(NO, d24, d31, coef, rV);
     } else if (kind == 1) {
         gvpTriCoef(cO, cN, x0, x1, x2, coef, rV);
     } else {
@@ -443,74 +448,23 @@ __device__ __forceinline__ void gvp3Coefs(const int kind, const double4& cO, con
 #endif
 // everything after the loads of one internal face: gradient coefficients from the geometry, the 6-component gradient, the 13
 // interpolations, the flux algebra, the five net fluxes (slot-major position fp), the face's share of the Courant number
+// component k of the quadrilateral's gradient [GaussVolPointBase3D_8C L346-389, L488-513 in difference form, gvp3Coefs]: one definition for the
+// kernels that hold the six records in registers and the one that reads them out of LDS component by component
+__device__ __forceinline__ void gvp3QuadGradK(const double (&coef)[12], const double rV6, const double vo, const double vn, const double p0,
+                                              const double p1, const double p2, const double p3, double (&g)[18], const int k) {
+    const double D5 = (vo - vn) * rV6, D0 = (p0 - p2) * rV6, D1 = (p1 - p3) * rV6;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) g[d * 6 + k] = coef[6 + d] * D5 + coef[d] * D0 + coef[3 + d] * D1;
+}
+
+// what follows the gradient on an internal face of the 3-D GaussVolPoint kernels: the 13 interpolations, the flux algebra, the five net
+// fluxes (fluxOut / fluxStride: c.flux + fp at a stride of nF faces, or registers / LDS of the fused kernel), the face's share of the Courant number
 template <bool DBG, bool UPW = false>
-__device__ __forceinline__ void gvp3FaceBody(const MeshView& m, const CaseView& c, const GasModel& gm, const int f, const int fp, const int kind,
-                                             const double w, const double hf, const double (&S)[3], const RecA& Ao, const RecA& An,
-                                             const RecB& Bo, const RecB& Bn, const RecA& q0, const RecA& q1, const RecA& q2, const RecA& q3,
-                                             const double (&coef)[12], const double rVc, const double msO, const double dnO,
-                                             const int adjustDt, double& cof, double& tauMin, double* const fluxOut, const size_t fluxStride) {
-    // fluxOut / fluxStride: where the five net fluxes go -- c.flux + fp at a stride of nF faces, or a slot of the fused kernel's LDS
-    // msO, dnO: |Sf| and deltaCoeffs of the face, read only on meshes that have faces with more than four vertices
+__device__ __forceinline__ void gvp3FaceTail(const MeshView& m, const CaseView& c, const GasModel& gm, const int f, const double w, const double hf,
+                                             const double (&S)[3], const RecA& Ao, const RecA& An, const RecB& Bo, const RecB& Bn,
+                                             const double (&g)[18], const int adjustDt, double& cof, double& tauMin, double* const fluxOut,
+                                             const size_t fluxStride) {
     const size_t nF = (size_t)m.nF;
-    FaceVals<6> v;
-    loadVals(Ao, v.o);
-    loadVals(An, v.n);
-    double g[18];
-    if (kind == 0) {
-        // Quad: coef = {a0, a1, a5}, rVc = 1/(6V) (gvp3Coefs)
-        const double* A0 = coef;
-        const double* A1 = coef + 3;
-        const double* A5 = coef + 6;
-        const double rV6 = rVc;
-        double p0[6], p1[6], p2[6], p3[6];
-        loadVals(q0, p0); loadVals(q1, p1); loadVals(q2, p2); loadVals(q3, p3);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const double D5 = (v.o[k] - v.n[k]) * rV6, D0 = (p0[k] - p2[k]) * rV6, D1 = (p1[k] - p3[k]) * rV6;
-#pragma unroll
-            for (int d = 0; d < 3; ++d) g[d * 6 + k] = A5[d] * D5 + A0[d] * D0 + A1[d] * D1;
-        }
-    } else if (kind == 1) {
-        // Triangle [GaussVolPointBase3D_8C L193-229, L844-854], out of the records already in registers: the same
-        // operations in the same order as faceGradient<ST_GVP3> (no second round of loads in mixed wavefronts)
-        const double* t = coef;
-        const double rV = rVc;
-        double p0[6], p1[6], p2[6];
-        loadVals(q0, p0); loadVals(q1, p1); loadVals(q2, p2);
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const double a0 = t[4 * d], a1 = t[4 * d + 1], a2 = t[4 * d + 2], a3 = t[4 * d + 3];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                double sg = v.n[k] * a3;
-                sg += v.o[k] * (-a3);
-                sg += p0[k] * a0;
-                sg += p1[k] * a1;
-                sg += p2[k] * a2;
-                g[d * 6 + k] = sg * rV;
-            }
-        }
-        double dg[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) dg[j] = g[j * 6 + 1 + j];
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) g[i * 6 + 1 + j] = dg[j];
-    } else if (kind == 2) {
-        // more than four vertices: nf (x) snGrad [GaussVolPointBase3D_8C L759-768], as faceGradient<ST_GVP3> has it
-        const double nx = S[0] / msO, ny = S[1] / msO, nz = S[2] / msO;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const double sn = dnO * (v.n[k] - v.o[k]);
-            g[0 * 6 + k] = nx * sn;
-            g[1 * 6 + k] = ny * sn;
-            g[2 * 6 + k] = nz * sn;
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 18; ++i) g[i] = 0.0;
-    }
     FaceState s;
     s.rhof = lerpf(w, Ao.rho, An.rho);
     const double Uo[3] = {Ao.ux, Ao.uy, Ao.uz}, Un[3] = {An.ux, An.uy, An.uz};
@@ -553,6 +507,69 @@ __device__ __forceinline__ void gvp3FaceBody(const MeshView& m, const CaseView& 
             tauMin = s.tauf;
         }
     }
+}
+
+
+template <bool DBG, bool UPW = false>
+__device__ __forceinline__ void gvp3FaceBody(const MeshView& m, const CaseView& c, const GasModel& gm, const int f, const int fp, const int kind,
+                                             const double w, const double hf, const double (&S)[3], const RecA& Ao, const RecA& An,
+                                             const RecB& Bo, const RecB& Bn, const RecA& q0, const RecA& q1, const RecA& q2, const RecA& q3,
+                                             const double (&coef)[12], const double rVc, const double msO, const double dnO,
+                                             const int adjustDt, double& cof, double& tauMin, double* const fluxOut, const size_t fluxStride) {
+    // fluxOut / fluxStride: where the five net fluxes go -- c.flux + fp at a stride of nF faces, or a slot of the fused kernel's LDS
+    // msO, dnO: |Sf| and deltaCoeffs of the face, read only on meshes that have faces with more than four vertices
+    FaceVals<6> v;
+    loadVals(Ao, v.o);
+    loadVals(An, v.n);
+    double g[18];
+    if (kind == 0) {
+        // Quad: coef = {a0, a1, a5}, rVc = 1/(6V) (gvp3Coefs)
+        double p0[6], p1[6], p2[6], p3[6];
+        loadVals(q0, p0); loadVals(q1, p1); loadVals(q2, p2); loadVals(q3, p3);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) gvp3QuadGradK(coef, rVc, v.o[k], v.n[k], p0[k], p1[k], p2[k], p3[k], g, k);
+    } else if (kind == 1) {
+        // Triangle [GaussVolPointBase3D_8C L193-229, L844-854], out of the records already in registers: the same
+        // operations in the same order as faceGradient<ST_GVP3> (no second round of loads in mixed wavefronts)
+        const double* t = coef;
+        const double rV = rVc;
+        double p0[6], p1[6], p2[6];
+        loadVals(q0, p0); loadVals(q1, p1); loadVals(q2, p2);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const double a0 = t[4 * d], a1 = t[4 * d + 1], a2 = t[4 * d + 2], a3 = t[4 * d + 3];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                double sg = v.n[k] * a3;
+                sg += v.o[k] * (-a3);
+                sg += p0[k] * a0;
+                sg += p1[k] * a1;
+                sg += p2[k] * a2;
+                g[d * 6 + k] = sg * rV;
+            }
+        }
+        double dg[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) dg[j] = g[j * 6 + 1 + j];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) g[i * 6 + 1 + j] = dg[j];
+    } else if (kind == 2) {
+        // more than four vertices: nf (x) snGrad [GaussVolPointBase3D_8C L759-768], as faceGradient<ST_GVP3> has it
+        const double nx = S[0] / msO, ny = S[1] / msO, nz = S[2] / msO;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const double sn = dnO * (v.n[k] - v.o[k]);
+            g[0 * 6 + k] = nx * sn;
+            g[1 * 6 + k] = ny * sn;
+            g[2 * 6 + k] = nz * sn;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 18; ++i) g[i] = 0.0;
+    }
+    gvp3FaceTail<DBG, UPW>(m, c, gm, f, w, hf, S, Ao, An, Bo, Bn, g, adjustDt, cof, tauMin, fluxOut, fluxStride);
 }
 
 template <bool DBG, int FB, bool SGEO = false, bool UPW = false>
@@ -1204,21 +1221,80 @@ void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm) 
             double msO = 1.0, dnO = 0.0;
             if (!SGEO || kind != 0) { S[0] = ldStream(m.Sx + f); S[1] = ldStream(m.Sy + f); S[2] = ldStream(m.Sz + f); }
             if (m.hasOther) { msO = m.magSf[f]; dnO = m.dn[f]; }
+            // Gauss coefficients; the quadrilateral's three differences one after the other (six coordinates live, not eighteen)
             double coef[12], rVc;
-            {
+            // (the branch below asks a copy of `kind` the compiler cannot see through: with the same condition here and in front of the
+            // gradient it threads the two, compiles the flux algebra once per kind, and the two copies contract their multiply-adds
+            // differently -- 1e-16 away from the two-kernel step)
+            int kindC = kind;
+            asm volatile("" : "+v"(kindC));
+            if (kindC == 0) {
+                double NO[3], d24[3], d31[3];
+                { const double4 cO = l3(sC, lo), cN = l3(sC, ln); NO[0] = cN.x - cO.x; NO[1] = cN.y - cO.y; NO[2] = cN.z - cO.z; }
+                __builtin_amdgcn_sched_barrier(0);
+                { const double4 x1 = l3(sX, v1), x3 = l3(sX, v3); d24[0] = x1.x - x3.x; d24[1] = x1.y - x3.y; d24[2] = x1.z - x3.z; }
+                __builtin_amdgcn_sched_barrier(0);
+                { const double4 x2 = l3(sX, v2), x0 = l3(sX, v0); d31[0] = x2.x - x0.x; d31[1] = x2.y - x0.y; d31[2] = x2.z - x0.z; }
+                gvp3QuadCoefs(NO, d24, d31, coef, rVc);
+                if (SGEO) { S[0] = 0.5 * coef[6]; S[1] = 0.5 * coef[7]; S[2] = 0.5 * coef[8]; }
+            } else {
                 const double4 cO = l3(sC, lo), cN = l3(sC, ln);
                 const double4 x0 = l3(sX, v0), x1 = l3(sX, v1), x2 = l3(sX, v2), x3 = l3(sX, v3);
                 gvp3Coefs(kind, cO, cN, x0, x1, x2, x3, coef, rVc);
-                if (SGEO && kind == 0) { S[0] = 0.5 * coef[6]; S[1] = 0.5 * coef[7]; S[2] = 0.5 * coef[8]; }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // the six-component gradient, one component of the six records at a time out of LDS (gvp3FaceBody holds the records in registers)
+            const double* const vO = reinterpret_cast<const double*>(sA + 3 * lo);
+            const double* const vN = reinterpret_cast<const double*>(sA + 3 * ln);
+            const double* const r0 = reinterpret_cast<const double*>(sP + 3 * v0);
+            const double* const r1 = reinterpret_cast<const double*>(sP + 3 * v1);
+            const double* const r2 = reinterpret_cast<const double*>(sP + 3 * v2);
+            const double* const r3 = reinterpret_cast<const double*>(sP + 3 * v3);
+            double cof, tauMin;
+            double g[18];
+            if (kind == 0) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) gvp3QuadGradK(coef, rVc, vO[k], vN[k], r0[k], r1[k], r2[k], r3[k], g, k);
+            } else if (kind == 1) {
+                const double* t = coef;
+                const double rV = rVc;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const double a0 = t[4 * d], a1 = t[4 * d + 1], a2 = t[4 * d + 2], a3 = t[4 * d + 3];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        double sg = vN[k] * a3;
+                        sg += vO[k] * (-a3);
+                        sg += r0[k] * a0;
+                        sg += r1[k] * a1;
+                        sg += r2[k] * a2;
+                        g[d * 6 + k] = sg * rV;
+                    }
+                }
+                double dg[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) dg[q] = g[q * 6 + 1 + q];
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) g[i * 6 + 1 + q] = dg[q];
+            } else if (kind == 2) {
+                const double nx = S[0] / msO, ny = S[1] / msO, nz = S[2] / msO;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    const double sn = dnO * (vN[k] - vO[k]);
+                    g[0 * 6 + k] = nx * sn;
+                    g[1 * 6 + k] = ny * sn;
+                    g[2 * 6 + k] = nz * sn;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 18; ++i) g[i] = 0.0;
             }
             __builtin_amdgcn_sched_barrier(0);
             const RecA Ao = *reinterpret_cast<const RecA*>(sA + 3 * lo), An = *reinterpret_cast<const RecA*>(sA + 3 * ln);
             const RecB Bo = *reinterpret_cast<const RecB*>(sB + 2 * lo), Bn = *reinterpret_cast<const RecB*>(sB + 2 * ln);
-            const RecA q0 = *reinterpret_cast<const RecA*>(sP + 3 * v0), q1 = *reinterpret_cast<const RecA*>(sP + 3 * v1),
-                       q2 = *reinterpret_cast<const RecA*>(sP + 3 * v2), q3 = *reinterpret_cast<const RecA*>(sP + 3 * v3);
-            double cof, tauMin;
-            gvp3FaceBody<false, false>(m, c, gm, f, 0, kind, fw[j], fh[j], S, Ao, An, Bo, Bn, q0, q1, q2, q3, coef, rVc, msO, dnO, 0, cof, tauMin,
-                                       &out[j][0], (size_t)1);
+            gvp3FaceTail<false, false>(m, c, gm, f, fw[j], fh[j], S, Ao, An, Bo, Bn, g, 0, cof, tauMin, &out[j][0], (size_t)1);
         }
         __builtin_amdgcn_sched_barrier(0);
     }

@@ -20,7 +20,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/g*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0]
-        if any(s in k for s in ("faceFluxGvp3", "cellUpdateKernel", "pointInterpRec")):
+        if any(s in k for s in ("faceFluxGvp3", "cellUpdateKernel", "pointInterpRec", "fusedFaceCell")):
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in acc.items():
     print(k)
