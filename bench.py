@@ -1090,10 +1090,21 @@ def main():
     face_bytes = FACE_BYTES_PER_FACE * n_if + FACE_BYTES_PER_CELL * n_c + FACE_BYTES_PER_POINT * n_p
     face_ms = kt["face"]["ms_avg"]
     ft = dev.face_tiles()
-    face_kernel_name = (f"faceFluxGvp3TileKernel<{ft['facesPerTile']}> (+ faceFluxGvp3Kernel on {ft['gatherTiles']} of {ft['tiles']} tiles; "
-                        "avg_launch_ms covers both launches)") if ft["facesPerTile"] else "faceFluxGvp3Kernel"
+    fused = case.fused_info()
+    if fused["fused"] and world == 1:
+        # ONE launch does the work of SURVEY 8(d)'s face row AND its cell-update row: the algorithmic bytes of both (the net fluxes the two
+        # rows hand over through HBM -- 40 B per face out, 240 B per cell in -- are part of that figure although this kernel never moves them)
+        face_bytes += CELL_BYTES_PER_CELL * n_c
+        face_kernel_name = (f"fusedFaceCellKernel ({fused['blocks']} blocks of <= 128 cells; {fused['facesComputed']} faces computed for "
+                            f"{n_if} internal faces; the cell update is part of the launch)")
+        # its own compulsory bytes: per computed face 16 B of block list + weight 8 + hQGDf 8 + kind 1; per cell RecA 48 + RecB 32 + centre 24
+        # read, rhoE 8 + V 8 + hQGD 8 read, 88 + 8 written, ~33 B of block lists; per vertex RecA 48 + coordinates 24 + 4 of list
+        own_bytes = 33 * fused["facesComputed"] + 265 * n_c + 76 * n_p
+    else:
+        face_kernel_name = (f"faceFluxGvp3TileKernel<{ft['facesPerTile']}> (+ faceFluxGvp3Kernel on {ft['gatherTiles']} of {ft['tiles']} tiles; "
+                            "avg_launch_ms covers both launches)") if ft["facesPerTile"] else "faceFluxGvp3Kernel"
+        own_bytes = OWN_BYTES_PER_FACE * n_if + OWN_BYTES_PER_CELL * n_c + OWN_BYTES_PER_POINT * n_p
     achieved = face_bytes / (face_ms * 1e-3) / 1e9 if face_ms else None
-    own_bytes = OWN_BYTES_PER_FACE * n_if + OWN_BYTES_PER_CELL * n_c + OWN_BYTES_PER_POINT * n_p
 
     if rank == 0:
         total_cells = n ** 3
@@ -1126,6 +1137,7 @@ def main():
                 "stencil": "GaussVolPoint",
                 "rccl_ranks": rccl_ranks,   # ranks the communicator carrying the halo messages reports (None: one rank, or gloo staging)
                 "halo_message_bytes": {"per_ghost_cell": 64, "per_ghost_patch_face": 96} if world > 1 else None,
+                "fused_face_cell": fused if (fused["fused"] and world == 1) else False,
                 "env": qgd_env(),
             },
             "roofline": {
@@ -1164,7 +1176,7 @@ def main():
             try:
                 tr = json.load(open(traffic_file))
                 key = f"n{n}_gpus{world}"
-                if key in tr:
+                if key in tr and ("fusedFaceCell" in tr[key].get("kernel", "")) == bool(fused["fused"] and world == 1):   # counters of the kernel that ran
                     out["roofline"]["traffic"] = tr[key]["bytes_per_launch"]
                     out["roofline"]["traffic_source"] = tr[key].get("source")
                     # a constant read from profiles/pmc_traffic.json (counters of the builder's profiling run of this

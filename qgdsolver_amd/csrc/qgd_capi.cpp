@@ -234,7 +234,7 @@ struct qgd_device_s {
     int32_t nGeomD = 3;
     bool hasTri = false;
     bool wedgePrism = false;  // wedge patches + prism cells: GaussVolPoint is refused [fvsc_8C L65-82]
-    int64_t fusedRedundantFaces = 0;   // faces the fused kernel's blocks compute beyond the mesh's internal faces (MeshView::fuBlocks > 0)
+    int64_t fusedFacesComputed = 0;   // internal faces the fused kernel's blocks compute per step, surface faces once per side (MeshView::fuBlocks > 0)
     std::vector<Patch> patches;
     // why a resident case (qgd_case_create / qgd_qhd_case_create) cannot run on this mesh, empty when it can: cyclic / wedge patches
     // with faces (their coupled / rotated patch fields are not served), a symmetryPlane that is not planar (fatal in OpenFOAM too)
@@ -725,8 +725,8 @@ int qgd_device_create(qgd_mesh_t mh, int deviceId, qgd_device_t* out) {
                 const int64_t lds = (ldsRec + 6 * 128 * 8 + 255) / 256 * 256;   // + the per-cell park (rhoE, V, hQGD, six face entries)
                 if (fb.nBlocks > 0 && fb.capC <= kFusedCapC && fb.capV <= kFusedCapV && fb.capF <= kFusedCapF &&
                     lds <= 80 * 1024) {
-                    v.fuBlocks = fb.nBlocks; v.fuCapC = fb.capC; v.fuCapV = fb.capV; v.fuCapF = fb.capF; v.fuCapE = fb.capE; v.fuLds = (int32_t)lds; v.fuLdsCell = (int32_t)(ldsRec / 8);
-                    d->fusedRedundantFaces = fb.redundantFaces;
+                    v.fuBlocks = fb.nBlocks; v.fuLayerBlocks = fb.nLayerBlocks; v.fuCapC = fb.capC; v.fuCapV = fb.capV; v.fuCapF = fb.capF; v.fuCapE = fb.capE; v.fuLds = (int32_t)lds; v.fuLdsCell = (int32_t)(ldsRec / 8);
+                    d->fusedFacesComputed = fb.facesComputed;
                     v.fuHdr = reinterpret_cast<const int4*>(up(fb.hdr)); v.fuCells = up(fb.cells); v.fuVerts = up(fb.verts);
                     v.fuFace = reinterpret_cast<const int4*>(up(fb.face)); v.fuNEntry = up(fb.nEntry); v.fuEntry = up(fb.entry);
                 }
@@ -1622,6 +1622,10 @@ int qgd_case_set_fields(qgd_case_t c, const double* U, const double* T, const do
         launchCellInit(L, m, c->view, c->gas, dU, dT, dp);
         launchBoundaryUpdate(L, m, c->view, c->gas, c->bcDev, true, false, 0, nullptr, 0);
         launchResetReductions(L, c->view);
+        if (c->fused) {   // a shard's ghost records are written by the halo exchange only: both buffers start with the initial ones
+            HIP_CHECK(hipMemcpyAsync(c->view.A2, c->view.A, sizeof(RecA) * (size_t)m.nC, hipMemcpyDeviceToDevice, c->stream()));
+            HIP_CHECK(hipMemcpyAsync(c->view.B2, c->view.B, sizeof(RecB) * (size_t)m.nC, hipMemcpyDeviceToDevice, c->stream()));
+        }
         const double dt0[3] = {c->opt.deltaT, 0.0, 0.0};
         HIP_CHECK(hipMemcpyAsync(c->view.dt, dt0, sizeof(dt0), hipMemcpyHostToDevice, c->stream()));
         HIP_CHECK(hipGetLastError());
@@ -1659,7 +1663,7 @@ int qgd_case_update_fluxes(qgd_case_t c) {
 // phase 1: deltaT, cell update, boundary refresh
 static void stepAssemble(qgd_case_s* c, int part = 0) {
     const bool adjust = c->opt.adjustTimeStep != 0;
-    assembleFluxes(c, adjust, part);
+    assembleFluxes(c, adjust, part, !c->fused);   // a fused case computes its internal faces inside the advance (stepAdvance)
     if (adjust && part != 1) launchFaceReduce(launcherOf(c), c->view);
 }
 // ---- the implicitDiffusion branch [QGDUEqn.H L54-75, QGDEEqn.H L53-64] as stream-ordered phases ---------------------------------
@@ -1752,6 +1756,29 @@ static void stepAdvance(qgd_case_s* c, int part) {
         c->steps++;
         if (!adjust) c->time += c->opt.deltaT;
     }
+    if (c->fused) {
+        // The fused face + cell kernel writes the new records to A2 / B2 (its blocks read their neighbours' OLD records), which then become
+        // A / B.  On a shard the boundary-layer blocks go first (part 1) and the swap follows them at once, so that the halo pack and the
+        // patch faces of those cells see the new records; the remaining blocks (part 2) then read the old records where the swap left
+        // them -- A2 / B2 -- and write where the new ones belong.
+        if (part == 0) {
+            launchFusedFaceCell(L, m, c->view, c->gas, 0, m.fuBlocks);
+            std::swap(c->view.A, c->view.A2);
+            std::swap(c->view.B, c->view.B2);
+        } else if (part == 1) {
+            launchFusedFaceCell(L, m, c->view, c->gas, 0, m.fuLayerBlocks);
+            std::swap(c->view.A, c->view.A2);
+            std::swap(c->view.B, c->view.B2);
+        } else {
+            CaseView back = c->view;
+            std::swap(back.A, back.A2);
+            std::swap(back.B, back.B2);
+            launchFusedFaceCell(L, m, back, c->gas, m.fuLayerBlocks, m.fuBlocks - m.fuLayerBlocks);
+        }
+        launchBoundaryUpdate(L, m, c->view, c->gas, c->bcDev, false, c->phiwRegistered, part,
+                             part == 1 ? d->sendBFAll : nullptr, part == 1 ? d->nSendBFAll : 0);
+        return;
+    }
     if (part == 0) {
         launchCellUpdate(L, m, c->view, c->gas, 0, nullptr, 0);
         launchBoundaryUpdate(L, m, c->view, c->gas, c->bcDev, false, c->phiwRegistered, 0, nullptr, 0);
@@ -1764,20 +1791,6 @@ static void stepAdvance(qgd_case_s* c, int part) {
     }
 }
 
-// One explicit step with the internal faces and the cell update in one kernel: vertex values, patch faces (their fluxes go to c.flux,
-// where the fused kernel's cells find them), then every block computes its faces and advances its cells into A2 / B2, which become A / B.
-static void stepFused(qgd_case_s* c) {
-    const Launcher L = launcherOf(c);
-    const MeshView& m = c->dev->view;
-    assembleFluxes(c, false, 0, false);
-    c->steps++;
-    c->time += c->opt.deltaT;
-    launchFusedFaceCell(L, m, c->view, c->gas);
-    std::swap(c->view.A, c->view.A2);
-    std::swap(c->view.B, c->view.B2);
-    launchBoundaryUpdate(L, m, c->view, c->gas, c->bcDev, false, c->phiwRegistered, 0, nullptr, 0);
-}
-
 int qgd_case_step(qgd_case_t c, int32_t nSteps) {
     QGD_TRY
     if (!c) return fail(QGD_ERR_INVALID, "null case");
@@ -1785,10 +1798,7 @@ int qgd_case_step(qgd_case_t c, int32_t nSteps) {
     if (c->dev->sharded())
         return fail(QGD_ERR_INVALID, "qgd_case_step: sharded mesh, drive it with qgd_case_step_phase + halo exchange");
     HIP_CHECK(hipSetDevice(c->dev->deviceId));
-    for (int i = 0; i < nSteps; ++i) {
-        if (c->fused) stepFused(c);
-        else { stepAssemble(c); stepAdvance(c, 0); }
-    }
+    for (int i = 0; i < nSteps; ++i) { stepAssemble(c); stepAdvance(c, 0); }
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(c->stream()));
     return QGD_OK;
@@ -1820,8 +1830,8 @@ int qgd_case_step_phase(qgd_case_t c, int phase) {
     else if (phase == 11) stepAdvance(c, 2);
     else if (phase == 3) {
         if (c->dev->sharded()) return fail(QGD_ERR_INVALID, "qgd_case_step_phase: phase 3 (one whole step, no exchange) is for unsharded meshes");
-        if (c->fused) stepFused(c);
-        else { stepAssemble(c); stepAdvance(c, 0); }
+        stepAssemble(c);
+        stepAdvance(c, 0);
     } else if (phase != 2) return fail(QGD_ERR_INVALID, "qgd_case_step_phase: phase must be 0, 1, 2, 3, 5, 6, 10 or 11");
     HIP_CHECK(hipGetLastError());
     return QGD_OK;  // asynchronous: qgd_case_stream_sync waits
@@ -2958,7 +2968,7 @@ int qgd_case_fused_info(qgd_case_t c, int64_t info[4]) {
     const MeshView& v = c->dev->view;
     info[0] = c->fused ? 1 : 0;
     info[1] = c->fused ? v.fuBlocks : 0;
-    info[2] = c->fused ? (int64_t)v.nIF + c->dev->fusedRedundantFaces : 0;
+    info[2] = c->fused ? c->dev->fusedFacesComputed : 0;
     info[3] = c->fused ? v.fuLds : 0;
     return QGD_OK;
 }

@@ -69,7 +69,7 @@ struct MeshView {
     const double* V; const double* hQGD; const uint8_t* ghost;
     const int32_t* bPatch; const double* hQGDb;
     // cell blocks of the fused face + cell kernel (qgd_setup.hpp FusedBlocks); fuBlocks == 0: not built
-    int32_t fuBlocks, fuCapC, fuCapV, fuCapF, fuCapE, fuLds, fuLdsCell;   // fuLdsCell: where the per-cell park of the kernel starts, in doubles
+    int32_t fuBlocks, fuLayerBlocks, fuCapC, fuCapV, fuCapF, fuCapE, fuLds, fuLdsCell;   // fuLayerBlocks: a shard's boundary-layer blocks come first;   // fuLdsCell: where the per-cell park of the kernel starts, in doubles
     const int4* fuHdr; const int32_t* fuCells; const int32_t* fuVerts; const int4* fuFace; const uint8_t* fuNEntry; const int32_t* fuEntry;
 };
 
@@ -140,7 +140,7 @@ void launchBoundaryFaceFlux(const Launcher& L, int stencil, const MeshView& m, c
 void launchFaceFluxMixed(const Launcher& L, int a, int b, int maskB, const MeshView& m, const CaseView& c, const GasModel& g, bool adjustDt);
 void launchBoundaryFaceFluxMixed(const Launcher& L, int a, int b, int maskB, const MeshView& m, const CaseView& c, const GasModel& g,
                                  const PatchBCDev* bc, int phiwOnly, bool adjustDt);
-void launchFusedFaceCell(const Launcher& L, const MeshView& m, const CaseView& c, const GasModel& g);
+void launchFusedFaceCell(const Launcher& L, const MeshView& m, const CaseView& c, const GasModel& g, int firstBlock, int nBlocks);
 void launchCellUpdate(const Launcher& L, const MeshView& m, const CaseView& c, const GasModel& g, int mode,
                       const int32_t* list, int nList);
 void launchBoundaryUpdate(const Launcher& L, const MeshView& m, const CaseView& c, const GasModel& g, const PatchBCDev* bc,

@@ -1119,14 +1119,14 @@ void cellUpdateKernel(const MeshView m, const CaseView c, const GasModel gm, con
 #endif
 template <bool SGEO>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QGD_FU_WAVES, QGD_FU_WAVES)))
-void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm) {
+void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm, const int firstBlock) {
     extern __shared__ v2d tileLds[];
 #if QGD_F_PRIO
     __builtin_amdgcn_s_setprio(3);
 #endif
     constexpr int NT = 256, KC = 4, KB2 = 3, KV = 3, KF = 2, KE = 6;   // piece loads per thread for <= 320 cells / 256 vertices, faces per thread, face entries of a cell held in registers
     static_assert(3 * kFusedCapCDev <= KC * NT && 2 * kFusedCapCDev <= KB2 * NT && 3 * kFusedCapVDev <= KV * NT && kFusedCapFDev <= KF * NT, "caps");
-    const int blk = xcdTile((int)gridDim.x, m.xcdRun);
+    const int blk = firstBlock + xcdTile((int)gridDim.x, m.xcdRun);
     const int tid = (int)threadIdx.x;
     const int capC = m.fuCapC, capV = m.fuCapV, capF = m.fuCapF;
     const int32_t* __restrict__ tCells = m.fuCells + (size_t)blk * capC;
@@ -1920,10 +1920,10 @@ void launchBoundaryFaceFlux(const Launcher& L, int stencil, const MeshView& m, c
     QGD_TIMED(L, QGD_K_BFACE, (c.dbg && phiwOnly != 1 ? launchBFaceFluxT<true>(L, stencil, m, c, g, bc, phiwOnly, adjustDt)
                                                    : launchBFaceFluxT<false>(L, stencil, m, c, g, bc, phiwOnly, adjustDt)));
 }
-void launchFusedFaceCell(const Launcher& L, const MeshView& m, const CaseView& c, const GasModel& g) {
-    if (m.fuBlocks == 0) return;
-    if (m.sGeo) QGD_TIMED(L, QGD_K_FACE, (fusedFaceCellKernel<true><<<m.fuBlocks, 256, m.fuLds, L.stream>>>(m, c, g)));
-    else QGD_TIMED(L, QGD_K_FACE, (fusedFaceCellKernel<false><<<m.fuBlocks, 256, m.fuLds, L.stream>>>(m, c, g)));
+void launchFusedFaceCell(const Launcher& L, const MeshView& m, const CaseView& c, const GasModel& g, int firstBlock, int nBlocks) {
+    if (nBlocks <= 0) return;
+    if (m.sGeo) QGD_TIMED(L, QGD_K_FACE, (fusedFaceCellKernel<true><<<nBlocks, 256, m.fuLds, L.stream>>>(m, c, g, firstBlock)));
+    else QGD_TIMED(L, QGD_K_FACE, (fusedFaceCellKernel<false><<<nBlocks, 256, m.fuLds, L.stream>>>(m, c, g, firstBlock)));
 }
 void launchCellUpdate(const Launcher& L, const MeshView& m, const CaseView& c, const GasModel& g, int mode,
                       const int32_t* list, int nList) {

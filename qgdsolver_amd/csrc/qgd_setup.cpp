@@ -676,7 +676,7 @@ struct OneBlock {
 FusedBlocks buildFusedBlocks(const StaticData& s) {
     FusedBlocks B;
     const int64_t nC = s.nC, nIF = s.nIF;
-    if (nC == 0 || nIF == 0 || s.nGeomD != 3 || !s.ghost.empty()) return B;
+    if (nC == 0 || nIF == 0 || s.nGeomD != 3) return B;
     if (3 * (int64_t)s.nC > INT32_MAX || 3 * (int64_t)s.nP > INT32_MAX) return B;
     // Morton order of the cell centres on a lattice of the mean cell spacing
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
@@ -685,18 +685,34 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
     double vol = 0.0;
     for (int64_t c = 0; c < nC; ++c) vol += s.V[c];
     const double h = std::cbrt(vol / (double)nC);
-    std::vector<std::pair<uint64_t, int32_t>> key((size_t)nC);
-#pragma omp parallel for schedule(static)
+    // a shard: its ghost cells belong to no block (the halo exchange writes them), and the cells a neighbour waits for (role 2) form their
+    // own blocks, in front of the others, so that the step can advance them first and overlap the exchange with the rest
+    std::vector<int32_t> ownedCells;
+    ownedCells.reserve((size_t)nC);
+    int64_t nLayer = 0;
     for (int64_t c = 0; c < nC; ++c) {
-        uint64_t q[3];
-        for (int d = 0; d < 3; ++d) q[d] = (uint64_t)std::min(2097151.0, std::max(0.0, std::floor((s.Cc[3 * c + d] - lo[d]) / h + 0.25)));
-        key[c] = {spread21(q[0]) | spread21(q[1]) << 1 | spread21(q[2]) << 2, (int32_t)c};
+        const int role = s.ghost.empty() ? 0 : s.ghost[c];
+        if (role == 1) continue;
+        ownedCells.push_back((int32_t)c);
+        if (role == 2) ++nLayer;
     }
+    const int64_t nOwned = (int64_t)ownedCells.size();
+    if (nOwned == 0) return B;
+    std::vector<std::pair<uint64_t, int32_t>> key((size_t)nOwned);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < nOwned; ++i) {
+        const int32_t c = ownedCells[i];
+        uint64_t q[3];
+        for (int d = 0; d < 3; ++d) q[d] = (uint64_t)std::min(2097151.0, std::max(0.0, std::floor((s.Cc[3 * (size_t)c + d] - lo[d]) / h + 0.25)));
+        const uint64_t rest = (!s.ghost.empty() && s.ghost[c] == 2) ? 0ull : 1ull << 63;
+        key[i] = {rest | spread21(q[0]) | spread21(q[1]) << 1 | spread21(q[2]) << 2, c};
+    }
+    std::vector<int32_t>().swap(ownedCells);
     // (sorted in runs, then merged: keeps the host peak at one copy and uses the cores)
     {
         const int nRuns = 16;
         std::vector<int64_t> cut(nRuns + 1);
-        for (int r = 0; r <= nRuns; ++r) cut[r] = nC * r / nRuns;
+        for (int r = 0; r <= nRuns; ++r) cut[r] = nOwned * r / nRuns;
 #pragma omp parallel for schedule(dynamic, 1)
         for (int r = 0; r < nRuns; ++r) std::sort(key.begin() + cut[r], key.begin() + cut[r + 1]);
         for (int width = 1; width < nRuns; width *= 2) {
@@ -768,12 +784,19 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
         }
         return true;
     };
-    const int64_t nRanges = (nC + kFusedCells - 1) / kFusedCells;
+    // ranges of the sorted cells: the boundary layer first, then the rest; no range straddles the two
+    const int64_t nLayerRanges = (nLayer + kFusedCells - 1) / kFusedCells;
+    const int64_t nRanges = nLayerRanges + (nOwned - nLayer + kFusedCells - 1) / kFusedCells;
+    auto rangeOf = [&](int64_t r) {
+        if (r < nLayerRanges) return std::pair<int64_t, int64_t>{r * kFusedCells, std::min(nLayer, (r + 1) * (int64_t)kFusedCells)};
+        const int64_t q = r - nLayerRanges;
+        return std::pair<int64_t, int64_t>{nLayer + q * kFusedCells, std::min(nOwned, nLayer + (q + 1) * (int64_t)kFusedCells)};
+    };
     std::vector<std::vector<OneBlock>> made((size_t)nRanges);
     bool failed = false;
 #pragma omp parallel for schedule(dynamic, 64)
     for (int64_t r = 0; r < nRanges; ++r) {
-        std::vector<std::pair<int64_t, int64_t>> work{{r * kFusedCells, std::min(nC, (r + 1) * (int64_t)kFusedCells)}};
+        std::vector<std::pair<int64_t, int64_t>> work{rangeOf(r)};
         while (!work.empty()) {
             const auto [b0, b1] = work.back();
             work.pop_back();
@@ -800,7 +823,8 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
     B.capE = std::max(B.capE, 1);
     if (nBlocks * (int64_t)std::max({B.capC, B.capV, 4 * B.capF, B.capE * kFusedCells}) > (int64_t)INT32_MAX) return B;
     B.nBlocks = (int32_t)nBlocks;
-    B.redundantFaces = facesDone - nIF;
+    for (int64_t r = 0; r < nLayerRanges; ++r) B.nLayerBlocks += (int32_t)made[r].size();
+    B.facesComputed = facesDone;
     B.hdr.assign(4 * (size_t)nBlocks, 0);
     B.cells.assign((size_t)nBlocks * B.capC, 0);
     B.verts.assign((size_t)nBlocks * B.capV, 0);

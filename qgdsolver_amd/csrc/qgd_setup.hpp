@@ -141,6 +141,7 @@ FaceTiles buildFaceTiles(const StaticData& s, int32_t fb);
 // internal faces never reach HBM.  Fixed strides (capC, capV, capF, capE), lists padded with their last entry.
 struct FusedBlocks {
     int32_t nBlocks = 0;
+    int32_t nLayerBlocks = 0;                         // a shard: the first nLayerBlocks blocks hold the cells a neighbour waits for
     int32_t capC = 0, capV = 0, capF = 0, capE = 0;   // strides: staged cells, staged vertices, faces, face entries per own cell
     int32_t maxC = 0, maxV = 0, maxF = 0;             // what the largest block uses (sizes the LDS)
     std::vector<int32_t> hdr;      // 4 per block: own cells, staged cells, staged vertices, faces
@@ -149,7 +150,7 @@ struct FusedBlocks {
     std::vector<int32_t> face;     // 4 per face, capF faces per block: label, lo | ln << 16, v0 | v1 << 16, v2 | v3 << 16 (positions in the staged lists)
     std::vector<uint8_t> nEntry;   // 128 per block: face entries of each own cell
     std::vector<int32_t> entry;    // capE x 128 per block, entry-major: (local face << 1) | (1: the cell is the neighbour, minus), or ~label of a boundary face
-    int64_t redundantFaces = 0;    // faces computed minus internal faces of the mesh
+    int64_t facesComputed = 0;     // over all blocks (a face between two blocks is computed by both)
 };
 constexpr int32_t kFusedCells = 128, kFusedCapC = 320, kFusedCapV = 256, kFusedCapF = 512;
 FusedBlocks buildFusedBlocks(const StaticData& s);

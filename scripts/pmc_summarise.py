@@ -48,7 +48,8 @@ for n in (400, 200):
     if per_kernel:
         json.dump(per_kernel, open(os.path.join(prof, f"{tag}_n{n}_pmc_tcc.json"), "w"), indent=1, sort_keys=True)
         # the face pass is the LDS-staged kernel plus the gather kernel on the tiles the former leaves out: one launch of each per step
-        face = [(name, c) for name, c in per_kernel.items() if "faceFluxGvp3" in name and "hbm_read_bytes" in c and "hbm_write_bytes" in c]
+        # (with QGD_FUSED, the default: ONE kernel, fusedFaceCellKernel, which is the cell update as well)
+        face = [(name, c) for name, c in per_kernel.items() if ("faceFluxGvp3" in name or "fusedFaceCell" in name) and "hbm_read_bytes" in c and "hbm_write_bytes" in c]
         if face:
             rd = sum(c["hbm_read_bytes"] for _, c in face)
             wr = sum(c["hbm_write_bytes"] for _, c in face)

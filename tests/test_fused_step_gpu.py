@@ -124,8 +124,38 @@ def test_cases_the_fused_kernel_does_not_serve_keep_the_two_kernels():
     for n in ("rho", "U", "p", "e"):
         assert np.array_equal(case.field(n), ref.field(n)), n
     case.close(); ref.close(); dev.close()
-    shard = q.PolyMesh.box(12, 6, 6).shard(2, 0)
-    dev = q.Device(shard)
-    case = q.QGDFoamCase(dev, q.default_options(stencil="GaussVolPoint", deltaT=1e-3))
-    assert not case.fused_info()["fused"]
+
+
+def shard_run(shard, fused, order, steps=4):
+    old = os.environ.get("QGD_FUSED")
+    os.environ["QGD_FUSED"] = "1" if fused else "0"
+    try:
+        dev = q.Device(shard)
+    finally:
+        if old is None:
+            del os.environ["QGD_FUSED"]
+        else:
+            os.environ["QGD_FUSED"] = old
+    case = q.QGDFoamCase(dev, q.default_options(stencil="GaussVolPoint", deltaT=1e-3, mu=1e-3))
+    U, T, p = cases.box_initial_fields(shard.array("C").reshape(-1, 3))
+    case.set_fields(U, T, p)
+    assert case.fused_info()["fused"] == fused
+    for _ in range(steps):          # no exchange: the ghost cells keep their values, in both runs
+        for ph in order:
+            case.step_phase(ph)
+    case.sync()
+    out = {n: case.field(n).copy() for n in ("rho", "U", "p", "e", "rhoE", "p.boundary", "U.boundary")}
     case.close(); dev.close()
+    return out
+
+
+@pytest.mark.parametrize("nShards,which", [(2, 0), (2, 1), (3, 1)])
+def test_fused_step_on_a_shard(nShards, which):
+    """ghost cells belong to no block, the cells a neighbour waits for form the first blocks: phases 0, 1 and the boundary-layer-first order
+    0, 10, 11 (the swap of the record buffers falls between 10 and 11) against the two kernels, bit for bit"""
+    for mesh in (q.PolyMesh.box(24, 12, 12), c5_mesh(16, 8 ** 3, poly=True)):
+        shard = mesh.shard(nShards, which)
+        ref = shard_run(shard, False, (0, 1))
+        for order in ((0, 1), (0, 10, 11)):
+            got = shard_run(shard, True, order)
+            equal(ref, got, (nShards, which, order))
