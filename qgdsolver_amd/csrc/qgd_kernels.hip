@@ -1164,7 +1164,7 @@ void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm, 
         const int q = tid + k * NT, r = (q * 43691) >> 17;
         idV[k] = tVerts[min(r, capV - 1)] * 3 + (q - 3 * r);
     }
-    const int ci = tCells[tid & 127];
+    const int ci = tCells[min(tid & 127, capC - 1)];   // (threads beyond the block's cells repeat its last label: loads stay inside the lists)
     const int nEraw = (int)m.fuNEntry[(size_t)blk * 128 + (tid & 127)];
     int e6[KE];
 #pragma unroll
