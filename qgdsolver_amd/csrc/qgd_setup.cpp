@@ -666,8 +666,26 @@ inline uint64_t spread21(uint64_t x) {   // 21 bits -> every third bit
     x = (x | x << 2) & 0x1249249249249249ull;
     return x;
 }
+// label -> position among the few hundred labels of one block: open addressing on a stamped table (no allocation, no clearing per block)
+struct SmallMap {
+    static constexpr uint32_t N = 4096;
+    int32_t key[N], val[N];
+    uint32_t stamp[N];
+    uint32_t gen = 0;
+    SmallMap() { for (uint32_t i = 0; i < N; ++i) stamp[i] = 0; }
+    void clear() { ++gen; }
+    uint32_t slot(int32_t k) const {
+        uint32_t h = ((uint32_t)k * 2654435761u) >> 20;
+        while (stamp[h] == gen && key[h] != k) h = (h + 1) & (N - 1);
+        return h;
+    }
+    bool has(int32_t k) const { return stamp[slot(k)] == gen; }
+    void put(int32_t k, int32_t v) { const uint32_t h = slot(k); stamp[h] = gen; key[h] = k; val[h] = v; }
+    int32_t at(int32_t k) const { return val[slot(k)]; }
+};
 struct OneBlock {
     std::vector<int32_t> cells, verts, face, entry;   // entry: row-major here (own cell x capE), transposed at the end
+    std::vector<int32_t> faces, others, vs;           // scratch of tryBlock (kept between blocks: no allocation per block)
     std::vector<uint8_t> nEntry;
     int32_t nOwn = 0, maxE = 0;
 };
@@ -729,10 +747,11 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
         return n;
     };
     // one range of the sorted cells -> one block, or false when it does not fit the caps
-    auto tryBlock = [&](int64_t b0, int64_t b1, OneBlock& o) {
-        o = OneBlock();
+    auto tryBlock = [&](int64_t b0, int64_t b1, OneBlock& o, SmallMap& posC, SmallMap& posV, SmallMap& posF) {
+        o.cells.clear(); o.verts.clear(); o.face.clear(); o.entry.clear(); o.nEntry.clear(); o.maxE = 0;
         o.nOwn = (int32_t)(b1 - b0);
-        std::vector<int32_t> faces;
+        std::vector<int32_t>& faces = o.faces;
+        faces.clear();
         int32_t ent[256];
         for (int64_t i = b0; i < b1; ++i) {
             const int32_t c = key[i].second;
@@ -745,30 +764,28 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
         faces.erase(std::unique(faces.begin(), faces.end()), faces.end());
         if ((int32_t)faces.size() > kFusedCapF) return false;
         // staged cells: own cells in block order, then the others in ascending label
-        std::unordered_map<int32_t, int32_t> posC, posV;
-        posC.reserve(512); posV.reserve(512);
-        for (int64_t i = b0; i < b1; ++i) { posC[key[i].second] = (int32_t)o.cells.size(); o.cells.push_back(key[i].second); }
-        std::vector<int32_t> others, vs;
+        posC.clear(); posV.clear(); posF.clear();
+        for (int64_t i = b0; i < b1; ++i) { posC.put(key[i].second, (int32_t)o.cells.size()); o.cells.push_back(key[i].second); }
+        std::vector<int32_t>&others = o.others, &vs = o.vs;
+        others.clear(); vs.clear();
         for (int32_t f : faces) {
-            if (!posC.count(s.own[f])) others.push_back(s.own[f]);
-            if (!posC.count(s.nei[f])) others.push_back(s.nei[f]);
+            if (!posC.has(s.own[f])) others.push_back(s.own[f]);
+            if (!posC.has(s.nei[f])) others.push_back(s.nei[f]);
             for (int q = 0; q < 4; ++q) if (s.verts[4 * (size_t)f + q] >= 0) vs.push_back(s.verts[4 * (size_t)f + q]);
         }
         std::sort(others.begin(), others.end()); others.erase(std::unique(others.begin(), others.end()), others.end());
         std::sort(vs.begin(), vs.end()); vs.erase(std::unique(vs.begin(), vs.end()), vs.end());
         if ((int64_t)o.cells.size() + (int64_t)others.size() > kFusedCapC || (int32_t)vs.size() > kFusedCapV) return false;
-        for (int32_t c : others) { posC[c] = (int32_t)o.cells.size(); o.cells.push_back(c); }
-        for (int32_t v : vs) { posV[v] = (int32_t)o.verts.size(); o.verts.push_back(v); }
-        std::unordered_map<int32_t, int32_t> posF;
-        posF.reserve(1024);
+        for (int32_t c : others) { posC.put(c, (int32_t)o.cells.size()); o.cells.push_back(c); }
+        for (int32_t v : vs) { posV.put(v, (int32_t)o.verts.size()); o.verts.push_back(v); }
         o.face.resize(4 * faces.size());
         for (size_t lf = 0; lf < faces.size(); ++lf) {
             const int32_t f = faces[lf];
-            posF[f] = (int32_t)lf;
+            posF.put(f, (int32_t)lf);
             uint32_t pv[4] = {0, 0, 0, 0};
-            for (int q = 0; q < 4; ++q) { const int32_t v = s.verts[4 * (size_t)f + q]; pv[q] = v >= 0 ? (uint32_t)posV[v] : 0u; }
+            for (int q = 0; q < 4; ++q) { const int32_t v = s.verts[4 * (size_t)f + q]; pv[q] = v >= 0 ? (uint32_t)posV.at(v) : 0u; }
             o.face[4 * lf] = f;
-            o.face[4 * lf + 1] = (int32_t)((uint32_t)posC[s.own[f]] | (uint32_t)posC[s.nei[f]] << 16);
+            o.face[4 * lf + 1] = (int32_t)((uint32_t)posC.at(s.own[f]) | (uint32_t)posC.at(s.nei[f]) << 16);
             o.face[4 * lf + 2] = (int32_t)(pv[0] | pv[1] << 16);
             o.face[4 * lf + 3] = (int32_t)(pv[2] | pv[3] << 16);
         }
@@ -779,7 +796,7 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
             o.nEntry[j] = (uint8_t)n;
             for (int k = 0; k < n; ++k) {
                 const int32_t f = ent[k] >= 0 ? ent[k] : ~ent[k];
-                o.entry[(size_t)j * o.maxE + k] = f < nIF ? (posF[f] << 1 | (ent[k] < 0 ? 1 : 0)) : ~f;
+                o.entry[(size_t)j * o.maxE + k] = f < nIF ? (posF.at(f) << 1 | (ent[k] < 0 ? 1 : 0)) : ~f;
             }
         }
         return true;
@@ -792,64 +809,81 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
         const int64_t q = r - nLayerRanges;
         return std::pair<int64_t, int64_t>{nLayer + q * kFusedCells, std::min(nOwned, nLayer + (q + 1) * (int64_t)kFusedCells)};
     };
-    std::vector<std::vector<OneBlock>> made((size_t)nRanges);
+    // Pass 1: where each range is cut (nearly always: not at all) and what the largest block needs.  Pass 2 builds every block again,
+    // straight into the padded tables: twice the arithmetic instead of half a million small vectors kept between the passes.
+    std::vector<int32_t> nOf((size_t)nRanges, 1);
+    std::vector<std::vector<std::pair<int64_t, int64_t>>> cuts((size_t)nRanges);   // only for the ranges that were cut
     bool failed = false;
-#pragma omp parallel for schedule(dynamic, 64)
-    for (int64_t r = 0; r < nRanges; ++r) {
-        std::vector<std::pair<int64_t, int64_t>> work{rangeOf(r)};
-        while (!work.empty()) {
-            const auto [b0, b1] = work.back();
-            work.pop_back();
-            OneBlock o;
-            if (tryBlock(b0, b1, o)) { made[r].push_back(std::move(o)); continue; }
-            if (b1 - b0 == 1) { failed = true; break; }   // one cell with more faces / vertices than a block holds
-            const int64_t mid = (b0 + b1) / 2;
-            work.push_back({mid, b1});
-            work.push_back({b0, mid});
+    int64_t facesDone = 0;
+    int32_t maxC = 0, maxV = 0, maxF = 0, maxE = 1;
+#pragma omp parallel reduction(+ : facesDone) reduction(max : maxC, maxV, maxF, maxE)
+    {
+        std::vector<SmallMap> maps(3);
+        OneBlock o;
+#pragma omp for schedule(dynamic, 64)
+        for (int64_t r = 0; r < nRanges; ++r) {
+            std::vector<std::pair<int64_t, int64_t>> work{rangeOf(r)}, done;
+            while (!work.empty()) {
+                const auto [b0, b1] = work.back();
+                work.pop_back();
+                if (tryBlock(b0, b1, o, maps[0], maps[1], maps[2])) {
+                    done.push_back({b0, b1});
+                    maxC = std::max<int32_t>(maxC, (int32_t)o.cells.size());
+                    maxV = std::max<int32_t>(maxV, (int32_t)o.verts.size());
+                    maxF = std::max<int32_t>(maxF, (int32_t)o.face.size() / 4);
+                    maxE = std::max(maxE, o.maxE);
+                    facesDone += (int64_t)o.face.size() / 4;
+                    continue;
+                }
+                if (b1 - b0 == 1) { failed = true; break; }   // one cell with more faces / vertices than a block holds
+                const int64_t mid = (b0 + b1) / 2;
+                work.push_back({mid, b1});
+                work.push_back({b0, mid});
+            }
+            nOf[r] = (int32_t)done.size();
+            if (done.size() != 1) cuts[r] = std::move(done);
         }
     }
     if (failed) return B;
-    int64_t nBlocks = 0, facesDone = 0;
-    for (auto& v : made)
-        for (auto& o : v) {
-            ++nBlocks;
-            B.maxC = std::max<int32_t>(B.maxC, (int32_t)o.cells.size());
-            B.maxV = std::max<int32_t>(B.maxV, (int32_t)o.verts.size());
-            B.maxF = std::max<int32_t>(B.maxF, (int32_t)o.face.size() / 4);
-            B.capE = std::max(B.capE, o.maxE);
-            facesDone += (int64_t)o.face.size() / 4;
-        }
+    std::vector<int64_t> first((size_t)nRanges + 1, 0);
+    for (int64_t r = 0; r < nRanges; ++r) first[r + 1] = first[r] + nOf[r];
+    const int64_t nBlocks = first[nRanges];
+    B.maxC = maxC; B.maxV = maxV; B.maxF = maxF;
     B.capC = (B.maxC + 7) / 8 * 8; B.capV = (B.maxV + 7) / 8 * 8; B.capF = (B.maxF + 7) / 8 * 8;
-    B.capE = std::max(B.capE, 1);
+    B.capE = maxE;
     if (nBlocks * (int64_t)std::max({B.capC, B.capV, 4 * B.capF, B.capE * kFusedCells}) > (int64_t)INT32_MAX) return B;
     B.nBlocks = (int32_t)nBlocks;
-    for (int64_t r = 0; r < nLayerRanges; ++r) B.nLayerBlocks += (int32_t)made[r].size();
+    B.nLayerBlocks = (int32_t)first[nLayerRanges];
     B.facesComputed = facesDone;
-    B.hdr.assign(4 * (size_t)nBlocks, 0);
-    B.cells.assign((size_t)nBlocks * B.capC, 0);
-    B.verts.assign((size_t)nBlocks * B.capV, 0);
-    B.face.assign((size_t)nBlocks * B.capF * 4, 0);
-    B.nEntry.assign((size_t)nBlocks * kFusedCells, 0);
-    B.entry.assign((size_t)nBlocks * B.capE * kFusedCells, 0);
-    std::vector<int64_t> first((size_t)nRanges + 1, 0);
-    for (int64_t r = 0; r < nRanges; ++r) first[r + 1] = first[r] + (int64_t)made[r].size();
-#pragma omp parallel for schedule(dynamic, 64)
-    for (int64_t r = 0; r < nRanges; ++r) {
-        for (size_t k = 0; k < made[r].size(); ++k) {
-            const OneBlock& o = made[r][k];
-            const size_t b = (size_t)(first[r] + (int64_t)k);
-            const int32_t nAll = (int32_t)o.cells.size(), nV = (int32_t)o.verts.size(), nF = (int32_t)o.face.size() / 4;
-            B.hdr[4 * b] = o.nOwn; B.hdr[4 * b + 1] = nAll; B.hdr[4 * b + 2] = nV; B.hdr[4 * b + 3] = nF;
-            for (int32_t i = 0; i < B.capC; ++i) B.cells[b * B.capC + i] = o.cells[std::min(i, nAll - 1)];
-            for (int32_t i = 0; i < B.capV; ++i) B.verts[b * B.capV + i] = nV ? o.verts[std::min(i, nV - 1)] : 0;
-            for (int32_t i = 0; i < B.capF; ++i)
-                for (int q = 0; q < 4; ++q) B.face[(b * B.capF + i) * 4 + q] = nF ? o.face[4 * (size_t)std::min(i, nF - 1) + q] : 0;
-            for (int32_t j = 0; j < o.nOwn; ++j) {
-                B.nEntry[b * kFusedCells + j] = o.nEntry[j];
-                for (int32_t e = 0; e < o.nEntry[j]; ++e) B.entry[(b * B.capE + e) * kFusedCells + j] = o.entry[(size_t)j * o.maxE + e];
+    B.hdr.resize(4 * (size_t)nBlocks);
+    B.cells.resize((size_t)nBlocks * B.capC);
+    B.verts.resize((size_t)nBlocks * B.capV);
+    B.face.resize((size_t)nBlocks * B.capF * 4);
+    B.nEntry.resize((size_t)nBlocks * kFusedCells);
+    B.entry.resize((size_t)nBlocks * B.capE * kFusedCells);
+#pragma omp parallel
+    {
+        std::vector<SmallMap> maps(3);
+        OneBlock o;
+#pragma omp for schedule(dynamic, 64)
+        for (int64_t r = 0; r < nRanges; ++r) {
+            for (int32_t k = 0; k < nOf[r]; ++k) {
+                const auto [b0, b1] = nOf[r] == 1 ? rangeOf(r) : cuts[r][k];
+                tryBlock(b0, b1, o, maps[0], maps[1], maps[2]);
+                const size_t b = (size_t)(first[r] + k);
+                const int32_t nAll = (int32_t)o.cells.size(), nV = (int32_t)o.verts.size(), nF = (int32_t)o.face.size() / 4;
+                B.hdr[4 * b] = o.nOwn; B.hdr[4 * b + 1] = nAll; B.hdr[4 * b + 2] = nV; B.hdr[4 * b + 3] = nF;
+                for (int32_t i = 0; i < B.capC; ++i) B.cells[b * B.capC + i] = o.cells[std::min(i, nAll - 1)];
+                for (int32_t i = 0; i < B.capV; ++i) B.verts[b * B.capV + i] = nV ? o.verts[std::min(i, nV - 1)] : 0;
+                for (int32_t i = 0; i < B.capF; ++i)
+                    for (int q = 0; q < 4; ++q) B.face[(b * B.capF + i) * 4 + q] = nF ? o.face[4 * (size_t)std::min(i, nF - 1) + q] : 0;
+                for (int32_t j = 0; j < kFusedCells; ++j) {
+                    const int32_t nE = j < o.nOwn ? o.nEntry[j] : 0;
+                    B.nEntry[b * kFusedCells + j] = (uint8_t)nE;
+                    for (int32_t e = 0; e < B.capE; ++e) B.entry[(b * B.capE + e) * kFusedCells + j] = e < nE ? o.entry[(size_t)j * o.maxE + e] : 0;
+                }
             }
         }
-        std::vector<OneBlock>().swap(made[r]);
     }
     return B;
 }
