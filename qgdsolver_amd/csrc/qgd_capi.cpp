@@ -73,8 +73,8 @@ struct DeviceArena {
         bytes += (int64_t)nbytes;
         return d;
     }
-    template <class T>
-    T* upload(const std::vector<T>& v) {
+    template <class T, class Al>
+    T* upload(const std::vector<T, Al>& v) {
         if (v.empty()) return nullptr;
         void* d = raw(v.size() * sizeof(T));
         HIP_CHECK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
@@ -720,13 +720,19 @@ int qgd_device_create(qgd_mesh_t mh, int deviceId, qgd_device_t* out) {
             static const int kOnOff2[] = {0, 1};
             if (envChoice("QGD_FUSED", 1, kOnOff2, 2) != 0) {
                 FusedBlocks fb = buildFusedBlocks(s);
-                // LDS: cell records (80 B) + cell centres and vertex records + coordinates (24 + 72 B), the last three later overwritten by the fluxes
-                const int64_t ldsRec = (int64_t)fb.capC * 80 + std::max((int64_t)fb.capC * 24 + (int64_t)fb.capV * 72, (int64_t)fb.capF * 40);
-                const int64_t lds = (ldsRec + 6 * 128 * 8 + 255) / 256 * 256;   // + the per-cell park (rhoE, V, hQGD, six face entries)
-                if (fb.nBlocks > 0 && fb.capC <= kFusedCapC && fb.capV <= kFusedCapV && fb.capF <= kFusedCapF &&
-                    lds <= 80 * 1024) {
-                    v.fuBlocks = fb.nBlocks; v.fuLayerBlocks = fb.nLayerBlocks; v.fuCapC = fb.capC; v.fuCapV = fb.capV; v.fuCapF = fb.capF; v.fuCapE = fb.capE; v.fuLds = (int32_t)lds; v.fuLdsCell = (int32_t)(ldsRec / 8);
+                // LDS, by the largest block: RecA of every staged cell, RecB of the own + across-a-face cells, then vertex records + all
+                // coordinates, later overwritten by the fluxes; then the parked face entries of the own cells
+                const int64_t ldsRec = (int64_t)fb.maxTot * 48 + (int64_t)fb.maxAll * 32 +
+                                       std::max((int64_t)fb.maxV * 72 + (int64_t)fb.maxAll * 24, (int64_t)fb.maxF * 40);
+                const int64_t ldsPark = (ldsRec + 15) / 16 * 16;
+                const int64_t lds = (ldsPark + 6 * 128 * 4 + 255) / 256 * 256;
+                if (fb.nBlocks > 0 && fb.maxAll <= kFusedCapC && fb.maxTot <= kFusedCapTot && fb.capV <= kFusedCapV && fb.capF <= kFusedCapF &&
+                    fb.capPE <= 255 && lds <= 80 * 1024) {
+                    v.fuBlocks = fb.nBlocks; v.fuLayerBlocks = fb.nLayerBlocks; v.fuCapC = fb.capC; v.fuCapV = fb.capV; v.fuCapF = fb.capF;
+                    v.fuCapE = fb.capE; v.fuLds = (int32_t)lds; v.fuLdsCell = (int32_t)(ldsPark / 8);
+                    v.fuCapPE = fb.capPE; v.fuMaxTot = fb.maxTot; v.fuMaxAll = fb.maxAll; v.fuMaxV = fb.maxV; v.fuMaxF = fb.maxF;
                     d->fusedFacesComputed = fb.facesComputed;
+                    v.fuHdr2 = reinterpret_cast<const int4*>(up(fb.hdr2)); v.fuVCount = up(fb.vCount); v.fuVPos = up(fb.vPos); v.fuVW = up(fb.vW);
                     v.fuHdr = reinterpret_cast<const int4*>(up(fb.hdr)); v.fuCells = up(fb.cells); v.fuVerts = up(fb.verts);
                     v.fuFace = reinterpret_cast<const int4*>(up(fb.face)); v.fuNEntry = up(fb.nEntry); v.fuEntry = up(fb.entry);
                 }
@@ -1584,7 +1590,7 @@ static void assembleFluxes(qgd_case_s* c, bool adjust, int part = 0, bool intern
         else launchBoundaryFaceFlux(L, c->stencil, m, v, c->gas, c->bcDev, phiwOnly, adj);
     };
     if (part != 2 && c->usesPoints) {
-        launchPointInterp(L, m, v);
+        if (internalFaces) launchPointInterp(L, m, v);   // (the fused kernel forms the vertex values of its blocks itself; patch points below)
         launchBoundaryPoints(L, m, v, false);
         // fvsc::grad(p) under GaussVolPoint re-runs p's BCs after phiwStar was refreshed
         // [QGDFoam/updateFluxes.H L63-65, GaussVolPointStencil_8C L73]

@@ -620,7 +620,7 @@ void faceFluxGvp3Kernel(const MeshView m, const CaseView c, const GasModel gm, c
 // operation order, bit-identical fluxes.
 // ---------------------------------------------------------------------------
 typedef double v2d __attribute__((ext_vector_type(2)));   // one 16-B piece
-constexpr int kFusedCapCDev = 320, kFusedCapVDev = 256, kFusedCapFDev = 512;   // = kFusedCap{C,V,F} of qgd_setup.hpp
+constexpr int kFusedCapCDev = 320, kFusedCapVDev = 256, kFusedCapFDev = 512, kFusedCapTotDev = 384;   // = kFusedCap{C,V,F,Tot} of qgd_setup.hpp
 #ifndef QGD_F_BUF
 #define QGD_F_BUF 0
 #endif
@@ -1124,27 +1124,33 @@ void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm, 
 #if QGD_F_PRIO
     __builtin_amdgcn_s_setprio(3);
 #endif
-    constexpr int NT = 256, KC = 4, KB2 = 3, KV = 3, KF = 2, KE = 6;   // piece loads per thread for <= 320 cells / 256 vertices, faces per thread, face entries of a cell held in registers
-    static_assert(3 * kFusedCapCDev <= KC * NT && 2 * kFusedCapCDev <= KB2 * NT && 3 * kFusedCapVDev <= KV * NT && kFusedCapFDev <= KF * NT, "caps");
+    constexpr int NT = 256, KC = 5, KCC = 4, KB2 = 3, KV = 3, KF = 2, KE = 6, KP = 8;
+    // piece loads per thread: RecA of <= 384 staged cells, centres and RecB of the <= 320 own + across-a-face cells, coordinates of <= 256
+    // vertices; faces per thread; face entries of a cell / cells of a vertex held in registers
+    static_assert(3 * kFusedCapTotDev <= KC * NT && 3 * kFusedCapCDev <= KCC * NT && 2 * kFusedCapCDev <= KB2 * NT && 3 * kFusedCapVDev <= KV * NT &&
+                  kFusedCapFDev <= KF * NT && kFusedCapVDev <= NT, "caps");
     const int blk = firstBlock + xcdTile((int)gridDim.x, m.xcdRun);
     const int tid = (int)threadIdx.x;
-    const int capC = m.fuCapC, capV = m.fuCapV, capF = m.fuCapF;
+    const int capC = m.fuCapC, capV = m.fuCapV, capF = m.fuCapF, capPE = m.fuCapPE;
     const int32_t* __restrict__ tCells = m.fuCells + (size_t)blk * capC;
     const int32_t* __restrict__ tVerts = m.fuVerts + (size_t)blk * capV;
     const int4* __restrict__ tFace = m.fuFace + (size_t)blk * capF;
     const int32_t* __restrict__ ent = m.fuEntry + (size_t)blk * m.fuCapE * 128 + (tid & 127);
-    // LDS: the cells' records stay to the end (an own cell's old record is read by its update); the vertex records and all coordinates
-    // are dead once every face has its fluxes in registers, and the fluxes take their place
-    v2d* const sA = tileLds;               // 3 capC pieces: cell RecA
-    v2d* const sB = sA + 3 * capC;         // 2 capC: cell RecB
-    v2d* const sP = sB + 2 * capC;         // 3 capV: vertex RecA
-    double* const sX = reinterpret_cast<double*>(sP + 3 * capV);   // 3 capV: vertex coordinates
-    double* const sC = sX + 3 * capV;      // 3 capC: cell centres
-    double* const sF = reinterpret_cast<double*>(sP);   // 5 capF: net fluxes, plane by plane (after the second barrier)
-    double* const sS = reinterpret_cast<double*>(tileLds) + m.fuLdsCell;   // 6 x 128: an own cell's rhoE, V, hQGD and first six face entries, parked until its update
+    // LDS (sized by the largest block of the mesh): RecA of every staged cell and RecB of the own + across-a-face cells stay to the end (an own
+    // cell's old record is read by its update); the vertex records -- formed HERE, from the staged cells -- and all coordinates are dead once
+    // every face has its fluxes in registers, and the fluxes take their place
+    v2d* const sA = tileLds;                     // 3 maxTot pieces
+    v2d* const sB = sA + 3 * m.fuMaxTot;         // 2 maxAll
+    v2d* const sP = sB + 2 * m.fuMaxAll;         // 3 maxV: vertex RecA
+    double* const sX = reinterpret_cast<double*>(sP + 3 * m.fuMaxV);   // 3 maxV: vertex coordinates
+    double* const sC = sX + 3 * m.fuMaxV;        // 3 maxAll: cell centres
+    double* const sF = reinterpret_cast<double*>(sP);   // 5 maxF: net fluxes, plane by plane (after the third barrier)
+    int* const sE = reinterpret_cast<int*>(reinterpret_cast<double*>(tileLds) + m.fuLdsCell);   // 6 x 128: an own cell's first six face entries, parked until its update
+    const int strideF = m.fuMaxF;
     // (0) everything whose address does not depend on a loaded value: the counts, the lists (padded to their strides with their last entry,
-    // so no count is needed to read them), this thread's two faces, its cell's face entries
+    // so no count is needed to read them), this thread's two faces, its cell's face entries, its vertex's cells and weights
     const int4 hdr = m.fuHdr[blk];
+    const int nTot = m.fuHdr2[blk].x;
     int4 fc[KF];
 #pragma unroll
     for (int j = 0; j < KF; ++j) fc[j] = tFace[min(tid + j * NT, capF - 1)];
@@ -1169,39 +1175,91 @@ void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm, 
     int e6[KE];
 #pragma unroll
     for (int i = 0; i < KE; ++i) e6[i] = ent[(size_t)min(i, m.fuCapE - 1) * 128];
-    // (1) one round trip later: the records, piece by piece; the faces' streams; the cell's own scalars
+    // this thread's vertex (thread v forms vertex v of the block's list)
+    const int vt = min(tid, capV - 1);
+    const int myVert = tVerts[vt];
+    const int nPc = (int)m.fuVCount[(size_t)blk * capV + vt];
+    const uint16_t* __restrict__ vPos = m.fuVPos + (size_t)blk * capPE * capV + vt;
+    const double* __restrict__ vW = m.fuVW + (size_t)blk * capPE * capV + vt;
+    int pcPos[KP];
+    double pcW[KP];
+#pragma unroll
+    for (int i = 0; i < KP; ++i) { pcPos[i] = (int)vPos[(size_t)min(i, capPE - 1) * capV]; pcW[i] = vW[(size_t)min(i, capPE - 1) * capV]; }
+    // (1) one round trip later: the records, piece by piece; the faces' streams; the cell's own scalars; a patch point's record
     const v2d* __restrict__ gA = reinterpret_cast<const v2d*>(c.A);
     const v2d* __restrict__ gB = reinterpret_cast<const v2d*>(c.B);
     const v2d* __restrict__ gP = reinterpret_cast<const v2d*>(c.P);
-    v2d dA[KC], dB[KB2], dP[KV];
-    double dC[KC], dX[KV];
+    v2d dA[KC], dB[KB2];
+    double dC[KCC], dX[KV];
 #pragma unroll
-    for (int k = 0; k < KC; ++k) { dA[k] = gA[idC[k]]; dC[k] = m.Cc[idC[k]]; }
+    for (int k = 0; k < KC; ++k) dA[k] = gA[idC[k]];
+#pragma unroll
+    for (int k = 0; k < KCC; ++k) dC[k] = m.Cc[idC[k]];
 #pragma unroll
     for (int k = 0; k < KB2; ++k) dB[k] = gB[idB[k]];
 #pragma unroll
-    for (int k = 0; k < KV; ++k) { dP[k] = gP[idV[k]]; dX[k] = m.X[idV[k]]; }
+    for (int k = 0; k < KV; ++k) dX[k] = m.X[idV[k]];
     double fw[KF], fh[KF];
     int fk[KF];
 #pragma unroll
     for (int j = 0; j < KF; ++j) { fw[j] = ldStream(m.w + fc[j].x); fh[j] = ldStream(m.hf + fc[j].x); fk[j] = m.fkind[fc[j].x]; }
-    {
-        const double rEold = c.rE[ci], Vc = m.V[ci], hq = m.hQGD[ci];
-        __builtin_amdgcn_sched_barrier(0);
-        if (tid < 128) {
-            sS[tid] = rEold; sS[128 + tid] = Vc; sS[256 + tid] = hq;
-            int* const sE = reinterpret_cast<int*>(sS + 384);
+    const double rEold = c.rE[ci], Vc = m.V[ci], hq = m.hQGD[ci];
+    v2d dPt[3];
+    dPt[0] = dPt[1] = dPt[2] = v2d{0.0, 0.0};
+    if (nPc == 0) {   // a patch point: the patch-point kernel has put its value into the vertex records
 #pragma unroll
-            for (int i = 0; i < KE; ++i) sE[i * 128 + tid] = e6[i];
-        }
+        for (int k = 0; k < 3; ++k) dPt[k] = gP[(size_t)myVert * 3 + k];
     }
+    __builtin_amdgcn_sched_barrier(0);
     const int nOwn = hdr.x, nUc = hdr.y, nUv = hdr.z, nFc = hdr.w;
+    if (tid < 128) {
 #pragma unroll
-    for (int k = 0; k < KC; ++k) { const int q = tid + k * NT; if (q < 3 * nUc) { sA[q] = dA[k]; sC[q] = dC[k]; } }
+        for (int i = 0; i < KE; ++i) sE[i * 128 + tid] = e6[i];
+    }
+#pragma unroll
+    for (int k = 0; k < KC; ++k) { const int q = tid + k * NT; if (q < 3 * nTot) sA[q] = dA[k]; }
+#pragma unroll
+    for (int k = 0; k < KCC; ++k) { const int q = tid + k * NT; if (q < 3 * nUc) sC[q] = dC[k]; }
 #pragma unroll
     for (int k = 0; k < KB2; ++k) { const int q = tid + k * NT; if (q < 2 * nUc) sB[q] = dB[k]; }
 #pragma unroll
-    for (int k = 0; k < KV; ++k) { const int q = tid + k * NT; if (q < 3 * nUv) { sP[q] = dP[k]; sX[q] = dX[k]; } }
+    for (int k = 0; k < KV; ++k) { const int q = tid + k * NT; if (q < 3 * nUv) sX[q] = dX[k]; }
+    __syncthreads();
+    // (1b) the vertex values [volPointInterpolation: inverse-distance weights over pointCells, in their order -- pointInterpRecKernel's
+    // arithmetic, out of the staged cell records]
+    if (tid < nUv) {
+        if (__ballot(nPc != KP) == 0) {
+            // a wavefront of interior vertices of hexahedra: eight cells each, no predicates
+            RecA acc = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int i = 0; i < KP; ++i) {
+                const RecA r = *reinterpret_cast<const RecA*>(sA + 3 * pcPos[i]);
+                acc.rho += pcW[i] * r.rho; acc.ux += pcW[i] * r.ux; acc.uy += pcW[i] * r.uy;
+                acc.uz += pcW[i] * r.uz; acc.p += pcW[i] * r.p; acc.e += pcW[i] * r.e;
+            }
+            *reinterpret_cast<RecA*>(sP + 3 * tid) = acc;
+        } else if (nPc > 0) {
+            RecA acc = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            for (int i = 0; i < nPc; ++i) {
+                int pos = 0;
+                double w = 0.0;
+                if (i < KP) {
+#pragma unroll
+                    for (int q = 0; q < KP; ++q) { pos = (i == q) ? pcPos[q] : pos; w = (i == q) ? pcW[q] : w; }
+                } else {
+                    pos = (int)vPos[(size_t)i * capV];
+                    w = vW[(size_t)i * capV];
+                }
+                const RecA r = *reinterpret_cast<const RecA*>(sA + 3 * pos);
+                acc.rho += w * r.rho; acc.ux += w * r.ux; acc.uy += w * r.uy;
+                acc.uz += w * r.uz; acc.p += w * r.p; acc.e += w * r.e;
+            }
+            *reinterpret_cast<RecA*>(sP + 3 * tid) = acc;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) sP[3 * tid + k] = dPt[k];
+        }
+    }
     __syncthreads();
 #if QGD_F_PRIO
     __builtin_amdgcn_s_setprio(0);
@@ -1304,7 +1362,7 @@ void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm, 
         const int lf = tid + j * NT;
         if (lf < nFc) {
 #pragma unroll
-            for (int k = 0; k < 5; ++k) sF[k * capF + lf] = out[j][k];
+            for (int k = 0; k < 5; ++k) sF[k * strideF + lf] = out[j][k];
         }
     }
     __syncthreads();
@@ -1314,14 +1372,12 @@ void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm, 
         const size_t nF = (size_t)m.nF;
         double sum[5] = {0, 0, 0, 0, 0};
         const int nE = nEraw;
-        const int* const sE = reinterpret_cast<const int*>(sS + 384);
-        const double rEold = sS[tid], Vc = sS[128 + tid], hq = sS[256 + tid];
         for (int i = 0; i < nE; ++i) {
             const int e = (i < KE) ? sE[i * 128 + tid] : ent[(size_t)i * 128];
             double fl[5];
             if (e >= 0) {
 #pragma unroll
-                for (int k = 0; k < 5; ++k) fl[k] = sF[k * capF + (e >> 1)];
+                for (int k = 0; k < 5; ++k) fl[k] = sF[k * strideF + (e >> 1)];
             } else {
 #pragma unroll
                 for (int k = 0; k < 5; ++k) fl[k] = c.flux[k * nF + (size_t)(~e)];

@@ -686,6 +686,10 @@ struct SmallMap {
 struct OneBlock {
     std::vector<int32_t> cells, verts, face, entry;   // entry: row-major here (own cell x capE), transposed at the end
     std::vector<int32_t> faces, others, vs;           // scratch of tryBlock (kept between blocks: no allocation per block)
+    std::vector<uint8_t> vCount;                      // per staged vertex
+    std::vector<uint16_t> vPos;                       // row-major here (vertex x maxPE)
+    std::vector<double> vW;
+    int32_t nAll = 0, maxPE = 0;                      // own + across-a-face cells (cells.size() counts the extras too)
     std::vector<uint8_t> nEntry;
     int32_t nOwn = 0, maxE = 0;
 };
@@ -778,6 +782,29 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
         if ((int64_t)o.cells.size() + (int64_t)others.size() > kFusedCapC || (int32_t)vs.size() > kFusedCapV) return false;
         for (int32_t c : others) { posC.put(c, (int32_t)o.cells.size()); o.cells.push_back(c); }
         for (int32_t v : vs) { posV.put(v, (int32_t)o.verts.size()); o.verts.push_back(v); }
+        o.nAll = (int32_t)o.cells.size();
+        // the cells around every vertex (pointCells order = the summation order of volPointInterpolation); those not staged yet follow
+        o.maxPE = 0;
+        for (int32_t v : vs) o.maxPE = std::max<int32_t>(o.maxPE, s.pcCount[v]);
+        o.vCount.assign(vs.size(), 0);
+        o.vPos.assign(vs.size() * (size_t)std::max(o.maxPE, 1), 0);
+        o.vW.assign(vs.size() * (size_t)std::max(o.maxPE, 1), 0.0);
+        for (size_t lv = 0; lv < vs.size(); ++lv) {
+            const int32_t v = vs[lv];
+            const int n = s.pcCount[v];
+            o.vCount[lv] = (uint8_t)n;
+            const size_t base = (size_t)s.pcSlice[v >> 6] * 64 + (v & 63);
+            for (int i = 0; i < n; ++i) {
+                const int32_t c = s.pcCell[base + (size_t)i * 64];
+                if (!posC.has(c)) {
+                    if ((int32_t)o.cells.size() >= kFusedCapTot) return false;
+                    posC.put(c, (int32_t)o.cells.size());
+                    o.cells.push_back(c);
+                }
+                o.vPos[lv * o.maxPE + i] = (uint16_t)posC.at(c);
+                o.vW[lv * o.maxPE + i] = s.pcW[base + (size_t)i * 64];
+            }
+        }
         o.face.resize(4 * faces.size());
         for (size_t lf = 0; lf < faces.size(); ++lf) {
             const int32_t f = faces[lf];
@@ -815,8 +842,8 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
     std::vector<std::vector<std::pair<int64_t, int64_t>>> cuts((size_t)nRanges);   // only for the ranges that were cut
     bool failed = false;
     int64_t facesDone = 0;
-    int32_t maxC = 0, maxV = 0, maxF = 0, maxE = 1;
-#pragma omp parallel reduction(+ : facesDone) reduction(max : maxC, maxV, maxF, maxE)
+    int32_t maxC = 0, maxV = 0, maxF = 0, maxE = 1, maxAll = 0, maxPE = 1;
+#pragma omp parallel reduction(+ : facesDone) reduction(max : maxC, maxV, maxF, maxE, maxAll, maxPE)
     {
         std::vector<SmallMap> maps(3);
         OneBlock o;
@@ -832,6 +859,8 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
                     maxV = std::max<int32_t>(maxV, (int32_t)o.verts.size());
                     maxF = std::max<int32_t>(maxF, (int32_t)o.face.size() / 4);
                     maxE = std::max(maxE, o.maxE);
+                    maxAll = std::max(maxAll, o.nAll);
+                    maxPE = std::max(maxPE, o.maxPE);
                     facesDone += (int64_t)o.face.size() / 4;
                     continue;
                 }
@@ -851,11 +880,16 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
     B.maxC = maxC; B.maxV = maxV; B.maxF = maxF;
     B.capC = (B.maxC + 7) / 8 * 8; B.capV = (B.maxV + 7) / 8 * 8; B.capF = (B.maxF + 7) / 8 * 8;
     B.capE = maxE;
-    if (nBlocks * (int64_t)std::max({B.capC, B.capV, 4 * B.capF, B.capE * kFusedCells}) > (int64_t)INT32_MAX) return B;
+    B.capPE = maxPE; B.maxTot = maxC; B.maxAll = maxAll;
+    if (nBlocks * (int64_t)std::max({B.capC, B.capV * B.capPE, 4 * B.capF, B.capE * kFusedCells}) > (int64_t)INT32_MAX) return B;
     B.nBlocks = (int32_t)nBlocks;
     B.nLayerBlocks = (int32_t)first[nLayerRanges];
     B.facesComputed = facesDone;
     B.hdr.resize(4 * (size_t)nBlocks);
+    B.hdr2.resize(4 * (size_t)nBlocks);
+    B.vCount.resize((size_t)nBlocks * B.capV);
+    B.vPos.resize((size_t)nBlocks * B.capPE * B.capV);
+    B.vW.resize((size_t)nBlocks * B.capPE * B.capV);
     B.cells.resize((size_t)nBlocks * B.capC);
     B.verts.resize((size_t)nBlocks * B.capV);
     B.face.resize((size_t)nBlocks * B.capF * 4);
@@ -871,9 +905,18 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
                 const auto [b0, b1] = nOf[r] == 1 ? rangeOf(r) : cuts[r][k];
                 tryBlock(b0, b1, o, maps[0], maps[1], maps[2]);
                 const size_t b = (size_t)(first[r] + k);
-                const int32_t nAll = (int32_t)o.cells.size(), nV = (int32_t)o.verts.size(), nF = (int32_t)o.face.size() / 4;
-                B.hdr[4 * b] = o.nOwn; B.hdr[4 * b + 1] = nAll; B.hdr[4 * b + 2] = nV; B.hdr[4 * b + 3] = nF;
-                for (int32_t i = 0; i < B.capC; ++i) B.cells[b * B.capC + i] = o.cells[std::min(i, nAll - 1)];
+                const int32_t nTot = (int32_t)o.cells.size(), nV = (int32_t)o.verts.size(), nF = (int32_t)o.face.size() / 4;
+                B.hdr[4 * b] = o.nOwn; B.hdr[4 * b + 1] = o.nAll; B.hdr[4 * b + 2] = nV; B.hdr[4 * b + 3] = nF;
+                B.hdr2[4 * b] = nTot; B.hdr2[4 * b + 1] = B.hdr2[4 * b + 2] = B.hdr2[4 * b + 3] = 0;
+                for (int32_t i = 0; i < B.capC; ++i) B.cells[b * B.capC + i] = o.cells[std::min(i, nTot - 1)];
+                for (int32_t i = 0; i < B.capV; ++i) {
+                    const int32_t n = i < nV ? o.vCount[i] : 0;
+                    B.vCount[b * B.capV + i] = (uint8_t)n;
+                    for (int32_t e = 0; e < B.capPE; ++e) {
+                        B.vPos[(b * B.capPE + e) * B.capV + i] = e < n ? o.vPos[(size_t)i * o.maxPE + e] : (uint16_t)0;
+                        B.vW[(b * B.capPE + e) * B.capV + i] = e < n ? o.vW[(size_t)i * o.maxPE + e] : 0.0;
+                    }
+                }
                 for (int32_t i = 0; i < B.capV; ++i) B.verts[b * B.capV + i] = nV ? o.verts[std::min(i, nV - 1)] : 0;
                 for (int32_t i = 0; i < B.capF; ++i)
                     for (int q = 0; q < 4; ++q) B.face[(b * B.capF + i) * 4 + q] = nF ? o.face[4 * (size_t)std::min(i, nF - 1) + q] : 0;

@@ -9,6 +9,9 @@
 //    contiguous 16-B aligned chunk)
 #pragma once
 #include <cstdint>
+#include <memory>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "qgd_mesh.hpp"
@@ -133,6 +136,17 @@ inline int32_t faceTileCapCells(int32_t fb) { return fb + fb / 16; }
 inline int32_t faceTileCapVerts(int32_t fb) { return ((fb * 23) / 16 + 7) / 8 * 8; }
 FaceTiles buildFaceTiles(const StaticData& s, int32_t fb);
 
+// vector whose resize() leaves new elements uninitialised: multi-GB tables that a parallel loop fills completely are first touched by the
+// threads that fill them (a value-initialising resize touches every page from one thread first: 4 s per GB in this kind of container)
+template <class T>
+struct DefaultInitAllocator : std::allocator<T> {
+    template <class U> struct rebind { using other = DefaultInitAllocator<U>; };
+    using std::allocator<T>::allocator;
+    template <class U> void construct(U* p) noexcept(std::is_nothrow_default_constructible<U>::value) { ::new (static_cast<void*>(p)) U; }
+    template <class U, class... Args> void construct(U* p, Args&&... args) { ::new (static_cast<void*>(p)) U(std::forward<Args>(args)...); }
+};
+template <class T> using RawVec = std::vector<T, DefaultInitAllocator<T>>;
+
 // ---- cell blocks of the fused face + cell kernel (QGD_FUSED; qgd_kernels.hip fusedFaceCellKernel) ---------------------------------
 // A block is up to 128 cells that sit together in space (consecutive cells of a Morton order of the cell centres: an 8x4x4 brick on
 // a uniform box) and EVERY internal face of those cells -- the faces on the block's surface are computed by the block on either side.
@@ -144,15 +158,24 @@ struct FusedBlocks {
     int32_t nLayerBlocks = 0;                         // a shard: the first nLayerBlocks blocks hold the cells a neighbour waits for
     int32_t capC = 0, capV = 0, capF = 0, capE = 0;   // strides: staged cells, staged vertices, faces, face entries per own cell
     int32_t maxC = 0, maxV = 0, maxF = 0;             // what the largest block uses (sizes the LDS)
-    std::vector<int32_t> hdr;      // 4 per block: own cells, staged cells, staged vertices, faces
-    std::vector<int32_t> cells;    // capC per block
-    std::vector<int32_t> verts;    // capV per block
-    std::vector<int32_t> face;     // 4 per face, capF faces per block: label, lo | ln << 16, v0 | v1 << 16, v2 | v3 << 16 (positions in the staged lists)
-    std::vector<uint8_t> nEntry;   // 128 per block: face entries of each own cell
-    std::vector<int32_t> entry;    // capE x 128 per block, entry-major: (local face << 1) | (1: the cell is the neighbour, minus), or ~label of a boundary face
+    RawVec<int32_t> hdr;      // 4 per block: own cells, staged cells, staged vertices, faces
+    RawVec<int32_t> cells;    // capC per block
+    RawVec<int32_t> verts;    // capV per block
+    RawVec<int32_t> face;     // 4 per face, capF faces per block: label, lo | ln << 16, v0 | v1 << 16, v2 | v3 << 16 (positions in the staged lists)
+    // the vertex values formed inside the block (volPointInterpolation's inverse-distance weights, pointCells order): the cells around the
+    // block's vertices that are neither its own nor across one of its faces ("extra": edge and corner neighbours) are staged too, behind
+    // the others in `cells`; hdr2[0] = all staged cells.  Per vertex: its cells' positions in `cells` and the weights, entry-major
+    // (capPE x capV per block); count 0 = a patch point, whose value the patch-point kernel has put into the vertex records.
+    int32_t capPE = 0, maxTot = 0, maxAll = 0;        // cells per vertex; staged cells incl. extras / without them, of the largest block
+    RawVec<int32_t> hdr2;     // 4 per block: all staged cells, 0, 0, 0
+    RawVec<uint8_t> vCount;   // capV per block
+    RawVec<uint16_t> vPos;    // capPE x capV per block
+    RawVec<double> vW;        // capPE x capV per block
+    RawVec<uint8_t> nEntry;   // 128 per block: face entries of each own cell
+    RawVec<int32_t> entry;    // capE x 128 per block, entry-major: (local face << 1) | (1: the cell is the neighbour, minus), or ~label of a boundary face
     int64_t facesComputed = 0;     // over all blocks (a face between two blocks is computed by both)
 };
-constexpr int32_t kFusedCells = 128, kFusedCapC = 320, kFusedCapV = 256, kFusedCapF = 512;
+constexpr int32_t kFusedCells = 128, kFusedCapC = 320, kFusedCapV = 256, kFusedCapF = 512, kFusedCapTot = 384;   // kFusedCapC: own + across-a-face cells
 FusedBlocks buildFusedBlocks(const StaticData& s);
 
 }  // namespace qgd
