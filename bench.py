@@ -1091,15 +1091,22 @@ def main():
     face_ms = kt["face"]["ms_avg"]
     ft = dev.face_tiles()
     fused = case.fused_info()
-    if fused["fused"] and world == 1:
-        # ONE launch does the work of SURVEY 8(d)'s face row AND its cell-update row: the algorithmic bytes of both (the net fluxes the two
-        # rows hand over through HBM -- 40 B per face out, 240 B per cell in -- are part of that figure although this kernel never moves them)
-        face_bytes += CELL_BYTES_PER_CELL * n_c
+    if fused["fused"] and kt["face"]["launches"]:
+        # per STEP: on a shard the fused kernel runs as two launches (the boundary-layer blocks, then the rest)
+        face_ms = kt["face"]["ms_total"] / min(args.steps, 20)
+    if fused["fused"]:
+        # ONE launch does the work of all three rows of SURVEY 8(d) -- vertex interpolation, face kernel, cell update: the algorithmic bytes of
+        # the whole step (what the rows hand each other through HBM -- 48 B per vertex, 40 B per face out, 240 B per cell in -- is part of
+        # that figure although this kernel never moves it)
+        face_bytes += (CELL_BYTES_PER_CELL + POINT_BYTES_PER_CELL) * n_c
         face_kernel_name = (f"fusedFaceCellKernel ({fused['blocks']} blocks of <= 128 cells; {fused['facesComputed']} faces computed for "
-                            f"{n_if} internal faces; the cell update is part of the launch)")
-        # its own compulsory bytes: per computed face 16 B of block list + weight 8 + hQGDf 8 + kind 1; per cell RecA 48 + RecB 32 + centre 24
-        # read, rhoE 8 + V 8 + hQGD 8 read, 88 + 8 written, ~33 B of block lists; per vertex RecA 48 + coordinates 24 + 4 of list
-        own_bytes = 33 * fused["facesComputed"] + 265 * n_c + 76 * n_p
+                            f"{n_if} internal faces, {fused['verticesFormed']} vertex values formed for {n_p} vertices; vertex values, faces and "
+                            "cell update are ONE launch)")
+        # its own compulsory bytes, from what its blocks stage: per computed face 16 B of block list + weight 8 + hQGDf 8 + kind 1; per staged
+        # cell RecA 48 + label 4, for own cells and cells across a face also RecB 32 + centre 24; per own cell rhoE 8 + V 8 + hQGD 8 read,
+        # 88 + 8 written, 25 B of face entries; per vertex formed 8 positions 16 + 8 weights 64 + count 1 + label 4 + coordinates 24
+        own_bytes = (33 * fused["facesComputed"] + 52 * fused["cellsStaged"] + 56 * fused["cellsStagedFull"] + 145 * n_c +
+                     109 * fused["verticesFormed"])
     else:
         face_kernel_name = (f"faceFluxGvp3TileKernel<{ft['facesPerTile']}> (+ faceFluxGvp3Kernel on {ft['gatherTiles']} of {ft['tiles']} tiles; "
                             "avg_launch_ms covers both launches)") if ft["facesPerTile"] else "faceFluxGvp3Kernel"
@@ -1137,7 +1144,7 @@ def main():
                 "stencil": "GaussVolPoint",
                 "rccl_ranks": rccl_ranks,   # ranks the communicator carrying the halo messages reports (None: one rank, or gloo staging)
                 "halo_message_bytes": {"per_ghost_cell": 64, "per_ghost_patch_face": 96} if world > 1 else None,
-                "fused_face_cell": fused if (fused["fused"] and world == 1) else False,
+                "fused_step": fused if fused["fused"] else False,
                 "env": qgd_env(),
             },
             "roofline": {
@@ -1176,7 +1183,7 @@ def main():
             try:
                 tr = json.load(open(traffic_file))
                 key = f"n{n}_gpus{world}"
-                if key in tr and ("fusedFaceCell" in tr[key].get("kernel", "")) == bool(fused["fused"] and world == 1):   # counters of the kernel that ran
+                if key in tr and ("fusedFaceCell" in tr[key].get("kernel", "")) == bool(fused["fused"]):   # counters of the kernel that ran
                     out["roofline"]["traffic"] = tr[key]["bytes_per_launch"]
                     out["roofline"]["traffic_source"] = tr[key].get("source")
                     # a constant read from profiles/pmc_traffic.json (counters of the builder's profiling run of this

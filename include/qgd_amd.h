@@ -589,13 +589,16 @@ int qgd_case_get_field(qgd_case_t c, const char* name, double* out,
 
 /* info[0]=time, [1]=deltaT, [2]=CoNum, [3]=min(rho), [4]=min(e), [5]=step count */
 int qgd_case_info(qgd_case_t c, double info[6]);
-/* Whether qgd_case_step advances this case with the fused face + cell kernel (QGD_FUSED, default on): a uniform 3-D GaussVolPoint case on an
- * unsharded mesh, explicit branch, fixed deltaT, linear qgdFlux schemes.  The net fluxes of internal faces then never reach device memory --
- * a workgroup computes every internal face of its block of <= 128 cells into LDS and advances those cells from there, in the summation order
- * of fvc::surfaceIntegrate; same arithmetic, bit-identical states.  info[0] = 1 when in use, [1] = blocks, [2] = internal faces computed per
- * step (faces on a block's surface are computed by the block on either side), [3] = LDS bytes per workgroup.  qgd_case_step_phase,
- * qgd_case_update_fluxes and every other branch keep the separate face and cell kernels. */
-int qgd_case_fused_info(qgd_case_t c, int64_t info[4]);
+/* Whether this case advances with the fused kernel of the explicit step (QGD_FUSED, default on): a uniform 3-D GaussVolPoint case, explicit
+ * branch, fixed deltaT, linear qgdFlux schemes; shards included.  One workgroup per block of <= 128 cells then stages the records of those
+ * cells and of the cells around them in LDS, forms the vertex values of the block from them (volPointInterpolation's weights, pointCells
+ * order), computes every internal face of its cells into LDS and advances the cells from there, in the summation order of
+ * fvc::surfaceIntegrate: neither the vertex values nor the net fluxes of internal faces reach device memory, and the vertex kernel, the face
+ * kernel and the cell kernel are one launch.  Same arithmetic, bit-identical states.  info[0] = 1 when in use, [1] = blocks, [2] = internal
+ * faces computed per step (faces on a block's surface are computed by the block on either side), [3] = LDS bytes per workgroup, [4] = cell
+ * records staged per step over all blocks, [5] = of which with their second record and centre (own cells + cells across a face), [6] =
+ * vertex values formed per step over all blocks, [7] = 0.  qgd_case_update_fluxes and every other branch keep the separate kernels. */
+int qgd_case_fused_info(qgd_case_t c, int64_t info[8]);
 /* The linear solves of the implicitDiffusion branch in the last step (what OpenFOAM prints as "Solving for Ux, Initial
  * residual = ..., Final residual = ..., No Iterations ...") [QGDUEqn_8H_source.html L54-68, QGDEEqn_8H_source.html L53-61]:
  * info[0..3] = iterations of Ux, Uy, Uz, e; [4..7] = initial, [8..11] = final normalised residuals; [12] = number of steps

@@ -235,6 +235,7 @@ struct qgd_device_s {
     bool hasTri = false;
     bool wedgePrism = false;  // wedge patches + prism cells: GaussVolPoint is refused [fvsc_8C L65-82]
     int64_t fusedFacesComputed = 0;   // internal faces the fused kernel's blocks compute per step, surface faces once per side (MeshView::fuBlocks > 0)
+    int64_t fusedCellsStaged = 0, fusedCellsStagedFull = 0, fusedVertsStaged = 0;   // cell records / of which with RecB and centre / vertices its blocks stage per step
     std::vector<Patch> patches;
     // why a resident case (qgd_case_create / qgd_qhd_case_create) cannot run on this mesh, empty when it can: cyclic / wedge patches
     // with faces (their coupled / rotated patch fields are not served), a symmetryPlane that is not planar (fatal in OpenFOAM too)
@@ -731,7 +732,8 @@ int qgd_device_create(qgd_mesh_t mh, int deviceId, qgd_device_t* out) {
                     v.fuBlocks = fb.nBlocks; v.fuLayerBlocks = fb.nLayerBlocks; v.fuCapC = fb.capC; v.fuCapV = fb.capV; v.fuCapF = fb.capF;
                     v.fuCapE = fb.capE; v.fuLds = (int32_t)lds; v.fuLdsCell = (int32_t)(ldsPark / 8);
                     v.fuCapPE = fb.capPE; v.fuMaxTot = fb.maxTot; v.fuMaxAll = fb.maxAll; v.fuMaxV = fb.maxV; v.fuMaxF = fb.maxF;
-                    d->fusedFacesComputed = fb.facesComputed;
+                    d->fusedFacesComputed = fb.facesComputed; d->fusedCellsStaged = fb.cellsStaged; d->fusedCellsStagedFull = fb.cellsStagedFull;
+                    d->fusedVertsStaged = fb.vertsStaged;
                     v.fuHdr2 = reinterpret_cast<const int4*>(up(fb.hdr2)); v.fuVCount = up(fb.vCount); v.fuVPos = up(fb.vPos); v.fuVW = up(fb.vW);
                     v.fuHdr = reinterpret_cast<const int4*>(up(fb.hdr)); v.fuCells = up(fb.cells); v.fuVerts = up(fb.verts);
                     v.fuFace = reinterpret_cast<const int4*>(up(fb.face)); v.fuNEntry = up(fb.nEntry); v.fuEntry = up(fb.entry);
@@ -2969,13 +2971,17 @@ int qgd_case_info(qgd_case_t c, double info[6]) {
     QGD_CATCH
 }
 
-int qgd_case_fused_info(qgd_case_t c, int64_t info[4]) {
+int qgd_case_fused_info(qgd_case_t c, int64_t info[8]) {
     if (!c || !info) return fail(QGD_ERR_INVALID, "null argument");
     const MeshView& v = c->dev->view;
     info[0] = c->fused ? 1 : 0;
     info[1] = c->fused ? v.fuBlocks : 0;
     info[2] = c->fused ? c->dev->fusedFacesComputed : 0;
     info[3] = c->fused ? v.fuLds : 0;
+    info[4] = c->fused ? c->dev->fusedCellsStaged : 0;
+    info[5] = c->fused ? c->dev->fusedCellsStagedFull : 0;
+    info[6] = c->fused ? c->dev->fusedVertsStaged : 0;
+    info[7] = 0;
     return QGD_OK;
 }
 

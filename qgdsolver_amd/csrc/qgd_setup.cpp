@@ -841,9 +841,9 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
     std::vector<int32_t> nOf((size_t)nRanges, 1);
     std::vector<std::vector<std::pair<int64_t, int64_t>>> cuts((size_t)nRanges);   // only for the ranges that were cut
     bool failed = false;
-    int64_t facesDone = 0;
+    int64_t facesDone = 0, cellsTot = 0, cellsAll = 0, vertsTot = 0;
     int32_t maxC = 0, maxV = 0, maxF = 0, maxE = 1, maxAll = 0, maxPE = 1;
-#pragma omp parallel reduction(+ : facesDone) reduction(max : maxC, maxV, maxF, maxE, maxAll, maxPE)
+#pragma omp parallel reduction(+ : facesDone, cellsTot, cellsAll, vertsTot) reduction(max : maxC, maxV, maxF, maxE, maxAll, maxPE)
     {
         std::vector<SmallMap> maps(3);
         OneBlock o;
@@ -862,6 +862,7 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
                     maxAll = std::max(maxAll, o.nAll);
                     maxPE = std::max(maxPE, o.maxPE);
                     facesDone += (int64_t)o.face.size() / 4;
+                    cellsTot += (int64_t)o.cells.size(); cellsAll += o.nAll; vertsTot += (int64_t)o.verts.size();
                     continue;
                 }
                 if (b1 - b0 == 1) { failed = true; break; }   // one cell with more faces / vertices than a block holds
@@ -884,7 +885,7 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
     if (nBlocks * (int64_t)std::max({B.capC, B.capV * B.capPE, 4 * B.capF, B.capE * kFusedCells}) > (int64_t)INT32_MAX) return B;
     B.nBlocks = (int32_t)nBlocks;
     B.nLayerBlocks = (int32_t)first[nLayerRanges];
-    B.facesComputed = facesDone;
+    B.facesComputed = facesDone; B.cellsStaged = cellsTot; B.cellsStagedFull = cellsAll; B.vertsStaged = vertsTot;
     B.hdr.resize(4 * (size_t)nBlocks);
     B.hdr2.resize(4 * (size_t)nBlocks);
     B.vCount.resize((size_t)nBlocks * B.capV);

@@ -174,6 +174,7 @@ struct FusedBlocks {
     RawVec<uint8_t> nEntry;   // 128 per block: face entries of each own cell
     RawVec<int32_t> entry;    // capE x 128 per block, entry-major: (local face << 1) | (1: the cell is the neighbour, minus), or ~label of a boundary face
     int64_t facesComputed = 0;     // over all blocks (a face between two blocks is computed by both)
+    int64_t cellsStaged = 0, cellsStagedFull = 0, vertsStaged = 0;   // over all blocks: cell records staged (RecA), of which with RecB + centre; vertices formed
 };
 constexpr int32_t kFusedCells = 128, kFusedCapC = 320, kFusedCapV = 256, kFusedCapF = 512, kFusedCapTot = 384;   // kFusedCapC: own + across-a-face cells
 FusedBlocks buildFusedBlocks(const StaticData& s);

@@ -170,10 +170,12 @@ class QGDFoamCase:
         return dict(time=a[0], deltaT=a[1], CoNum=a[2], minRho=a[3], minE=a[4], steps=int(a[5]))
 
     def fused_info(self):
-        """whether step() advances with the fused face + cell kernel, its blocks, faces computed per step, LDS bytes (qgd_case_fused_info)"""
-        a = (C.c_int64 * 4)()
+        """whether the case advances with the fused kernel of the explicit step (vertex values, faces and cell update of a block of cells in
+        one launch), its blocks, faces computed / cell records staged / vertex values formed per step, LDS bytes (qgd_case_fused_info)"""
+        a = (C.c_int64 * 8)()
         L.check(L.lib.qgd_case_fused_info(self._h, a), "qgd_case_fused_info")
-        return dict(fused=bool(a[0]), blocks=int(a[1]), facesComputed=int(a[2]), ldsBytes=int(a[3]))
+        return dict(fused=bool(a[0]), blocks=int(a[1]), facesComputed=int(a[2]), ldsBytes=int(a[3]), cellsStaged=int(a[4]),
+                    cellsStagedFull=int(a[5]), verticesFormed=int(a[6]))
 
     def implicit_info(self):
         """the four linear solves of the implicitDiffusion branch in the last step (qgd_case_implicit_info)"""
