@@ -769,7 +769,11 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
         if ((int32_t)faces.size() > kFusedCapF) return false;
         // staged cells: own cells in block order, then the others in ascending label
         posC.clear(); posV.clear(); posF.clear();
-        for (int64_t i = b0; i < b1; ++i) { posC.put(key[i].second, (int32_t)o.cells.size()); o.cells.push_back(key[i].second); }
+        // (own cells in ascending label inside the block: in LDS a record is 12 banks wide, and neighbours 16, 32 or 64 positions apart -- what
+        // the Morton order makes of the y and z neighbours of a brick -- sit in the same banks)
+        for (int64_t i = b0; i < b1; ++i) o.cells.push_back(key[i].second);
+        std::sort(o.cells.begin(), o.cells.end());
+        for (size_t i = 0; i < o.cells.size(); ++i) posC.put(o.cells[i], (int32_t)i);
         std::vector<int32_t>&others = o.others, &vs = o.vs;
         others.clear(); vs.clear();
         for (int32_t f : faces) {

@@ -1,6 +1,7 @@
-"""The fused face + cell step (fusedFaceCellKernel, QGD_FUSED): a workgroup computes every internal face of a block of <= 128 cells into LDS
-and advances those cells from there; the net fluxes of internal faces never reach device memory.  Same arithmetic per face and per cell, same
-summation order as faceFluxGvp3(Tile)Kernel + cellUpdateKernel: the states must agree BIT FOR BIT with QGD_FUSED=0 -- on hexahedra, on
+"""The fused step of the explicit branch (fusedFaceCellKernel, QGD_FUSED): a workgroup stages a block of <= 128 cells and the cells around it in
+LDS, forms the block's vertex values, computes every internal face of its cells into LDS and advances those cells from there; neither vertex
+values nor net fluxes of internal faces reach device memory.  Same arithmetic per vertex, face and cell, same summation orders as
+pointInterpRecKernel + faceFluxGvp3(Tile)Kernel + cellUpdateKernel: the states must agree BIT FOR BIT with QGD_FUSED=0 -- on hexahedra, on
 jittered meshes with triangles and polygon faces, scrambled numberings, with patches of every kind the step knows (their fluxes come from the
 boundary kernel through device memory), the qgdFlux walls of the forward step's 3-D cousin, and over a long run.  Cases the fused kernel
 does not serve (Courant-number control, implicit diffusion, upwind fluxes, per-term stencils, shards) must say so and run the two kernels."""
@@ -17,16 +18,18 @@ from test_config5_gpu import c5_mesh
 pytestmark = pytest.mark.gpu
 
 
-def run(mesh, steps, fused, bc_fn=None, chunks=(None,), **opt):
-    old = os.environ.get("QGD_FUSED")
-    os.environ["QGD_FUSED"] = "1" if fused else "0"
+def run(mesh, steps, fused, bc_fn=None, chunks=(None,), env=None, **opt):
+    env = dict(env or {}, QGD_FUSED="1" if fused else "0")
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
     try:
         dev = q.Device(mesh)
     finally:
-        if old is None:
-            del os.environ["QGD_FUSED"]
-        else:
-            os.environ["QGD_FUSED"] = old
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
     case = q.QGDFoamCase(dev, q.default_options(stencil="GaussVolPoint", **opt))
     if bc_fn:
         bc_fn(case)
@@ -73,6 +76,18 @@ def test_fused_step_is_bit_identical_to_the_two_kernels():
             assert ib["blocks"] >= (mesh.nCells + 127) // 128 and ib["ldsBytes"] <= 80 * 1024, ib
             assert ib["facesComputed"] >= mesh.nInternalFaces, ib
             equal(a, b, (tag, opt))
+
+
+def test_fused_step_with_streamed_face_areas():
+    """QGD_SGEO=0 (what a mesh with caller-supplied Sf gets): the kernel reads Sf instead of rebuilding it from the staged vertices"""
+    for tag, mesh in list(meshes())[:1] + list(meshes())[5:7]:
+        a, _ = run(mesh, 5, False, env={"QGD_SGEO": "0"}, deltaT=2e-3, mu=1e-3)
+        b, ib = run(mesh, 5, True, env={"QGD_SGEO": "0"}, deltaT=2e-3, mu=1e-3)
+        assert ib["fused"]
+        equal(a, b, tag)
+        c, _ = run(mesh, 5, True, deltaT=2e-3, mu=1e-3)      # and Sf from the vertices gives the same states as before
+        d, _ = run(mesh, 5, False, deltaT=2e-3, mu=1e-3)
+        equal(c, d, tag)
 
 
 def test_fused_step_with_patches_of_every_kind_and_in_chunks():
