@@ -704,9 +704,23 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
     for (int64_t c = 0; c < nC; ++c)
         for (int d = 0; d < 3; ++d) { lo[d] = std::min(lo[d], s.Cc[3 * c + d]); hi[d] = std::max(hi[d], s.Cc[3 * c + d]); }
+    // lattice spacing per axis: the mean distance of the two cell centres across the faces that look along that axis (dx, dy, dz on a box,
+    // whatever its cells' aspect ratio); the mean cell size where an axis has no such faces
     double vol = 0.0;
     for (int64_t c = 0; c < nC; ++c) vol += s.V[c];
-    const double h = std::cbrt(vol / (double)nC);
+    double h[3] = {std::cbrt(vol / (double)nC), 0.0, 0.0};
+    h[1] = h[2] = h[0];
+    {
+        double sum[3] = {0, 0, 0};
+        int64_t cnt[3] = {0, 0, 0};
+        for (int64_t f = 0; f < nIF; ++f) {
+            const double a[3] = {std::fabs(s.Sf[0][f]), std::fabs(s.Sf[1][f]), std::fabs(s.Sf[2][f])};
+            const int d = a[0] >= a[1] ? (a[0] >= a[2] ? 0 : 2) : (a[1] >= a[2] ? 1 : 2);
+            sum[d] += std::fabs(s.Cc[3 * (size_t)s.nei[f] + d] - s.Cc[3 * (size_t)s.own[f] + d]);
+            ++cnt[d];
+        }
+        for (int d = 0; d < 3; ++d) if (cnt[d] > 0 && sum[d] > 0.0) h[d] = sum[d] / (double)cnt[d];
+    }
     // a shard: its ghost cells belong to no block (the halo exchange writes them), and the cells a neighbour waits for (role 2) form their
     // own blocks, in front of the others, so that the step can advance them first and overlap the exchange with the rest
     std::vector<int32_t> ownedCells;
@@ -725,7 +739,7 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
     for (int64_t i = 0; i < nOwned; ++i) {
         const int32_t c = ownedCells[i];
         uint64_t q[3];
-        for (int d = 0; d < 3; ++d) q[d] = (uint64_t)std::min(2097151.0, std::max(0.0, std::floor((s.Cc[3 * (size_t)c + d] - lo[d]) / h + 0.25)));
+        for (int d = 0; d < 3; ++d) q[d] = (uint64_t)std::min(2097151.0, std::max(0.0, std::floor((s.Cc[3 * (size_t)c + d] - lo[d]) / h[d] + 0.25)));
         const uint64_t rest = (!s.ghost.empty() && s.ghost[c] == 2) ? 0ull : 1ull << 63;
         key[i] = {rest | spread21(q[0]) | spread21(q[1]) << 1 | spread21(q[2]) << 2, c};
     }

@@ -1,0 +1,142 @@
+// The host side of the fused step: qgd_setup.cpp buildFusedBlocks (CPU only; compiled by tests/test_fused_blocks_host.py with plain g++ from the
+// library's own host sources).  Checks the tables the kernel trusts blindly:
+//   * every owned cell is an own cell of exactly one block, ghost cells of none; a shard's boundary-layer cells fill the first blocks;
+//   * a block's face list holds every internal face of its own cells, once, with owner / neighbour / vertex positions that point at those very
+//     labels; every list is padded to its stride with its last entry;
+//   * the face entries of an own cell are the cell's faces in ascending label with the right side bit, patch faces as ~label;
+//   * a vertex's cell positions are its pointCells in order, with the weights of the vertex kernel's table; patch points have count 0;
+//   * the maxima the LDS layout is sized by are the maxima.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <set>
+#include <vector>
+
+#include "qgd_mesh.hpp"
+#include "qgd_setup.hpp"
+
+using namespace qgd;
+
+static int fails = 0;
+#define CHECK(cond, ...)                                   \
+    do {                                                   \
+        if (!(cond)) {                                     \
+            if (fails < 20) { std::printf("FAILED %s:%d  %s  ", __FILE__, __LINE__, #cond); std::printf(__VA_ARGS__); std::printf("\n"); } \
+            ++fails;                                       \
+        }                                                  \
+    } while (0)
+
+static void checkMesh(const char* tag, HostMesh& m) {
+    if (m.magSf.empty()) m.computeGeometry();
+    m.computeDerived();
+    const StaticData s = buildStaticData(m);
+    const FusedBlocks B = buildFusedBlocks(s);
+    std::printf("%s: %d cells, %d blocks (%d boundary-layer), strides %d %d %d %d %d, faces computed %lld of %d\n", tag, s.nC, B.nBlocks, B.nLayerBlocks, B.capC,
+                B.capV, B.capF, B.capE, B.capPE, (long long)B.facesComputed, s.nIF);
+    CHECK(B.nBlocks > 0, "%s: no blocks", tag);
+    if (B.nBlocks == 0) return;
+    std::vector<int> ownerBlock((size_t)s.nC, -1);
+    int32_t maxTot = 0, maxAll = 0, maxV = 0, maxF = 0;
+    int64_t faces = 0;
+    for (int32_t b = 0; b < B.nBlocks; ++b) {
+        const int32_t nOwn = B.hdr[4 * b], nAll = B.hdr[4 * b + 1], nV = B.hdr[4 * b + 2], nF = B.hdr[4 * b + 3], nTot = B.hdr2[4 * b];
+        CHECK(nOwn >= 1 && nOwn <= kFusedCells && nOwn <= nAll && nAll <= nTot && nTot <= B.capC && nAll <= kFusedCapC && nTot <= kFusedCapTot, "block %d counts", b);
+        CHECK(nV <= B.capV && nV <= kFusedCapV && nF <= B.capF && nF <= kFusedCapF, "block %d counts", b);
+        maxTot = std::max(maxTot, nTot); maxAll = std::max(maxAll, nAll); maxV = std::max(maxV, nV); maxF = std::max(maxF, nF);
+        faces += nF;
+        const int32_t* cells = &B.cells[(size_t)b * B.capC];
+        const int32_t* verts = &B.verts[(size_t)b * B.capV];
+        for (int32_t i = nTot; i < B.capC; ++i) CHECK(cells[i] == cells[nTot - 1], "block %d cell padding", b);
+        for (int32_t i = std::max(nV, 1); i < B.capV; ++i) CHECK(verts[i] == verts[std::max(nV, 1) - 1], "block %d vertex padding", b);
+        std::set<int32_t> distinct(cells, cells + nTot);
+        CHECK((int32_t)distinct.size() == nTot, "block %d lists a cell twice", b);
+        for (int32_t j = 0; j < nOwn; ++j) {
+            const int32_t c = cells[j];
+            const int role = s.ghost.empty() ? 0 : s.ghost[c];
+            CHECK(role != 1, "ghost cell %d owned by block %d", c, b);
+            CHECK(ownerBlock[c] == -1, "cell %d owned twice", c);
+            ownerBlock[c] = b;
+            CHECK((role == 2) == (b < B.nLayerBlocks), "cell %d (role %d) in block %d of %d boundary-layer blocks", c, role, b, B.nLayerBlocks);
+        }
+        // faces
+        std::set<int32_t> want;
+        for (int32_t j = 0; j < nOwn; ++j) {
+            const int32_t c = cells[j];
+            const size_t base = (size_t)s.cfSlice[c >> 6] * 64 + (c & 63);
+            for (int i = 0; i < s.cfCount[c]; ++i) {
+                const int32_t it = s.cfItem[base + (size_t)i * 64], f = it >= 0 ? it : ~it;
+                if (f < s.nIF) want.insert(f);
+            }
+        }
+        CHECK((int32_t)want.size() == nF, "block %d: %d faces listed, %d wanted", b, nF, (int)want.size());
+        const int32_t* face = &B.face[(size_t)b * B.capF * 4];
+        for (int32_t lf = 0; lf < nF; ++lf) {
+            const int32_t f = face[4 * lf];
+            const uint32_t lc = (uint32_t)face[4 * lf + 1], va = (uint32_t)face[4 * lf + 2], vb = (uint32_t)face[4 * lf + 3];
+            CHECK(want.count(f) == 1, "block %d lists face %d", b, f);
+            CHECK((int32_t)(lc & 0xffff) < nAll && (int32_t)(lc >> 16) < nAll, "block %d face %d cell positions", b, f);
+            CHECK(cells[lc & 0xffff] == s.own[f] && cells[lc >> 16] == s.nei[f], "block %d face %d owner / neighbour", b, f);
+            const uint32_t pv[4] = {va & 0xffff, va >> 16, vb & 0xffff, vb >> 16};
+            for (int q = 0; q < 4; ++q) {
+                const int32_t v = s.verts[4 * (size_t)f + q];
+                if (v >= 0) CHECK((int32_t)pv[q] < nV && verts[pv[q]] == v, "block %d face %d vertex %d", b, f, q);
+            }
+            if (lf > 0) CHECK(face[4 * (lf - 1)] < f, "block %d faces not ascending", b);
+        }
+        for (int32_t lf = nF; lf < B.capF; ++lf)
+            for (int q = 0; q < 4; ++q) CHECK(nF == 0 || face[4 * lf + q] == face[4 * (nF - 1) + q], "block %d face padding", b);
+        // face entries of the own cells
+        for (int32_t j = 0; j < kFusedCells; ++j) {
+            const int nE = B.nEntry[(size_t)b * kFusedCells + j];
+            if (j >= nOwn) { CHECK(nE == 0, "block %d entry count beyond the own cells", b); continue; }
+            const int32_t c = cells[j];
+            CHECK(nE == s.cfCount[c] && nE <= B.capE, "block %d cell %d entry count", b, c);
+            const size_t base = (size_t)s.cfSlice[c >> 6] * 64 + (c & 63);
+            for (int e = 0; e < nE; ++e) {
+                const int32_t it = s.cfItem[base + (size_t)e * 64], f = it >= 0 ? it : ~it;
+                const int32_t got = B.entry[((size_t)b * B.capE + e) * kFusedCells + j];
+                if (f >= s.nIF) CHECK(got == ~f && it >= 0, "block %d cell %d patch-face entry", b, c);
+                else CHECK(got >= 0 && (got >> 1) < nF && face[4 * (got >> 1)] == f && (got & 1) == (it < 0 ? 1 : 0), "block %d cell %d entry %d", b, c, e);
+            }
+        }
+        // vertex tables
+        for (int32_t lv = 0; lv < B.capV; ++lv) {
+            const int n = B.vCount[(size_t)b * B.capV + lv];
+            if (lv >= nV) { CHECK(n == 0, "block %d vertex count beyond the list", b); continue; }
+            const int32_t v = verts[lv];
+            CHECK(n == s.pcCount[v] && n <= B.capPE, "block %d vertex %d count", b, v);
+            const size_t base = (size_t)s.pcSlice[v >> 6] * 64 + (v & 63);
+            for (int e = 0; e < n; ++e) {
+                const int32_t pos = B.vPos[((size_t)b * B.capPE + e) * B.capV + lv];
+                CHECK(pos < nTot && cells[pos] == s.pcCell[base + (size_t)e * 64], "block %d vertex %d cell %d", b, v, e);
+                CHECK(B.vW[((size_t)b * B.capPE + e) * B.capV + lv] == s.pcW[base + (size_t)e * 64], "block %d vertex %d weight %d", b, v, e);
+            }
+        }
+    }
+    for (int32_t c = 0; c < s.nC; ++c) {
+        const int role = s.ghost.empty() ? 0 : s.ghost[c];
+        CHECK((ownerBlock[c] >= 0) == (role != 1), "cell %d (role %d) block %d", c, role, ownerBlock[c]);
+    }
+    CHECK(maxTot == B.maxTot && maxAll == B.maxAll && maxV == B.maxV && maxF == B.maxF, "%s: maxima %d %d %d %d vs %d %d %d %d", tag, maxTot, maxAll, maxV,
+          maxF, B.maxTot, B.maxAll, B.maxV, B.maxF);
+    CHECK(faces == B.facesComputed && faces >= 0, "%s: faces computed", tag);
+}
+
+int main() {
+    const double lo[3] = {0, 0, 0}, hi[3] = {1, 1, 1};
+    const int32_t pt[6] = {0, 0, 0, 0, 0, 0};
+    { HostMesh m = makeBox(16, 8, 8, 0, 8, lo, hi, pt); checkMesh("box 16x8x8 (bricks)", m); }
+    { HostMesh m = makeBox(13, 7, 5, 0, 5, lo, hi, pt); checkMesh("box 13x7x5 (ragged)", m); }
+    { HostMesh m = makeBox(3, 2, 2, 0, 2, lo, hi, pt); checkMesh("box 3x2x2", m); }
+    {
+        HostMesh m = makeBox(11, 9, 7, 0, 7, lo, hi, pt);
+        jitterPoints(m, 0.15, 7);
+        splitQuads(m, 3);
+        splitEdges(m, 5);
+        checkMesh("jittered, every third quad split, every fifth edge split (triangles, polygons)", m);
+    }
+    { HostMesh m = makeBox(12, 6, 12, 3, 9, lo, hi, pt); checkMesh("slab 3..9 of a 12x6x12 box (two cuts)", m); }
+    if (fails) { std::printf("%d checks failed\n", fails); return 1; }
+    std::printf("ok\n");
+    return 0;
+}
