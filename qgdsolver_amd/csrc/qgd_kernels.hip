@@ -11,6 +11,8 @@
 //   C   cellUpdateKernel       deterministic gather of face fluxes + explicit
 //                              Euler update + thermo + QGD coefficients
 //   B   boundaryUpdateKernel   boundary-condition refresh
+//   PFC fusedFaceCellKernel    P + F + C of a block of <= 128 cells in one workgroup (QGD_FUSED, the default of fixed-deltaT explicit
+//                              3-D GaussVolPoint cases): vertex values, internal faces and cell update out of LDS
 //
 // Reference restated (listing lines under /root/reference/docs/html/):
 //   interpolations   QGDFoam_2updateFields_8H_source.html L45-80
@@ -1103,16 +1105,25 @@ void cellUpdateKernel(const MeshView m, const CaseView c, const GasModel gm, con
 }
 
 // ---------------------------------------------------------------------------
-// QGD_FUSED: face fluxes and cell update of a BLOCK of cells in one workgroup (qgd_setup.hpp FusedBlocks).  The three kernels of the
-// explicit step run at what the memory system delivers (profiles/r05_ab_face_four_waves.txt), and a third of the step's bytes are the net
-// fluxes' round trip through HBM: 40 B per face written by F, read back twice by C.  Here a workgroup stages the records of its <= 128 cells,
-// of the cells across the block's surface and of their vertices in LDS (fewer distinct records per face than a run of consecutive faces has:
-// the block is compact in all three directions), computes EVERY internal face of its cells -- the surface faces are computed by the block
-// on either side, 21 % more face work on 8x4x4 bricks -- leaves the five fluxes in LDS, and advances its own cells out of LDS in the
-// summation order of fvc::surfaceIntegrate (ascending face label; boundary faces from c.flux, where the boundary kernel put them).  It
-// reads the OLD records of its neighbours while other blocks write new ones: the step writes A2 / B2, the host swaps them with A / B.
-// Same arithmetic per face and per cell as faceFluxGvp3Kernel + cellUpdateKernel, same order: bit-identical states.  Fixed deltaT, no
-// shards, no debug fields, linear fluxes (everything else keeps the two kernels).
+// QGD_FUSED: the explicit step of a BLOCK of cells in one workgroup (qgd_setup.hpp FusedBlocks) -- vertex values, internal faces, cell update.
+// The three kernels of the explicit step (P, F, C above) run at what the memory system delivers (profiles/r05_ab_face_four_waves.txt), and
+// most of the step's bytes are what they hand each other through HBM: 48 B per vertex written by P and read back by F, 40 B per face written
+// by F and read back twice by C.  Here a workgroup (256 threads) takes <= 128 cells that are compact in space -- an 8x4x4 brick on a box --
+// and
+//   (0) reads its lists (no address depends on a loaded value: they are padded to fixed strides) and, one round trip later, stages in LDS
+//       RecA of its own cells, of the cells across its surface and of the edge / corner cells around its vertices (360 on a box), RecB and
+//       the centres of the first two groups (288), the coordinates of its vertices (225);
+//   (1) thread v forms vertex v: volPointInterpolation's weighted sum over pointCells, in their order (pointInterpRecKernel's arithmetic,
+//       out of the staged records); a patch point takes the patch-point kernel's value from the vertex records;
+//   (2) every thread computes two of the block's internal faces (464 on a box: the 80 surface faces are computed by the block on the other
+//       side as well, +21 % face arithmetic) -- Gauss coefficients with the quadrilateral's three differences formed one after the other,
+//       the gradient component by component out of LDS (144-152 VGPRs: three blocks per CU), then gvp3FaceTail -- and keeps the fluxes;
+//   (3) once every face is done with the vertex records and coordinates, the fluxes take their place in LDS, and threads 0..127 advance one
+//       own cell each: the ordered sum of its faces' fluxes in ascending face label = fvc::surfaceIntegrate's order (patch faces from c.flux,
+//       where the patch-face kernel put them), advanceCell, 88 B of new records.
+// The block reads the OLD records of its neighbours while other blocks write new ones: the step writes A2 / B2, the host swaps them with A / B.
+// Same arithmetic per vertex, face and cell as P + F + C, same orders: bit-identical states (tests/test_fused_step_gpu.py).  Fixed deltaT,
+// no debug fields, linear fluxes (everything else keeps the three kernels); shards run it too (the boundary-layer blocks first, stepAdvance).
 // ---------------------------------------------------------------------------
 #ifndef QGD_FU_WAVES
 #define QGD_FU_WAVES 3
