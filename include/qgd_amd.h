@@ -590,7 +590,7 @@ int qgd_case_get_field(qgd_case_t c, const char* name, double* out,
 /* info[0]=time, [1]=deltaT, [2]=CoNum, [3]=min(rho), [4]=min(e), [5]=step count */
 int qgd_case_info(qgd_case_t c, double info[6]);
 /* Whether this case advances with the fused kernel of the explicit step (QGD_FUSED, default on): a uniform 3-D GaussVolPoint case, explicit
- * branch, fixed deltaT, linear qgdFlux schemes; shards included.  One workgroup per block of <= 128 cells then stages the records of those
+ * branch, fixed deltaT (linear or `Gauss upwind` qgdFlux schemes); shards included.  One workgroup per block of <= 128 cells then stages the records of those
  * cells and of the cells around them in LDS, forms the vertex values of the block from them (volPointInterpolation's weights, pointCells
  * order), computes every internal face of its cells into LDS and advances the cells from there, in the summation order of
  * fvc::surfaceIntegrate: neither the vertex values nor the net fluxes of internal faces reach device memory, and the vertex kernel, the face

@@ -1471,9 +1471,8 @@ int qgd_case_create(qgd_device_t d, const qgd_case_options* opt, qgd_case_t* out
         CaseView& cv = c->view;
         cv.A = a.alloc<RecA>(v.nC); cv.B = a.alloc<RecB>(v.nC); cv.rE = a.alloc<double>(v.nC);
         cv.P = a.alloc<RecA>(v.nP);
-        // the fused face + cell step (fusedFaceCellKernel): uniform 3-D GaussVolPoint, explicit, fixed deltaT, linear fluxes
-        c->fused = v.fuBlocks > 0 && c->stencil == ST_GVP3 && c->mixB < 0 && !opt->implicitDiffusion && !opt->adjustTimeStep && !g.upwindU &&
-                   !g.upwindH;
+        // the fused step (fusedFaceCellKernel): uniform 3-D GaussVolPoint, explicit, fixed deltaT; `Gauss upwind` fluxes are an instantiation
+        c->fused = v.fuBlocks > 0 && c->stencil == ST_GVP3 && c->mixB < 0 && !opt->implicitDiffusion && !opt->adjustTimeStep;
         if (c->fused) { cv.A2 = a.alloc<RecA>(v.nC); cv.B2 = a.alloc<RecB>(v.nC); }
         cv.bA = a.alloc<RecA>(v.nBF); cv.bB = a.alloc<RecB>(v.nBF);
         cv.bG = a.alloc<double>(v.nBF); cv.bPhiw = a.alloc<double>(v.nBF); cv.bPmid = a.alloc<double>(v.nBF);

@@ -1123,12 +1123,13 @@ void cellUpdateKernel(const MeshView m, const CaseView c, const GasModel gm, con
 //       where the patch-face kernel put them), advanceCell, 88 B of new records.
 // The block reads the OLD records of its neighbours while other blocks write new ones: the step writes A2 / B2, the host swaps them with A / B.
 // Same arithmetic per vertex, face and cell as P + F + C, same orders: bit-identical states (tests/test_fused_step_gpu.py).  Fixed deltaT,
-// no debug fields, linear fluxes (everything else keeps the three kernels); shards run it too (the boundary-layer blocks first, stepAdvance).
+// no debug fields (everything else keeps the three kernels); UPW = `Gauss upwind` fluxes; shards run it too (the boundary-layer blocks first,
+// stepAdvance).
 // ---------------------------------------------------------------------------
 #ifndef QGD_FU_WAVES
 #define QGD_FU_WAVES 3
 #endif
-template <bool SGEO>
+template <bool SGEO, bool UPW = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QGD_FU_WAVES, QGD_FU_WAVES)))
 void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm, const int firstBlock) {
     extern __shared__ v2d tileLds[];
@@ -1363,7 +1364,7 @@ void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm, 
             __builtin_amdgcn_sched_barrier(0);
             const RecA Ao = *reinterpret_cast<const RecA*>(sA + 3 * lo), An = *reinterpret_cast<const RecA*>(sA + 3 * ln);
             const RecB Bo = *reinterpret_cast<const RecB*>(sB + 2 * lo), Bn = *reinterpret_cast<const RecB*>(sB + 2 * ln);
-            gvp3FaceTail<false, false>(m, c, gm, f, fw[j], fh[j], S, Ao, An, Bo, Bn, g, 0, cof, tauMin, &out[j][0], (size_t)1);
+            gvp3FaceTail<false, UPW>(m, c, gm, f, fw[j], fh[j], S, Ao, An, Bo, Bn, g, 0, cof, tauMin, &out[j][0], (size_t)1);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -1989,7 +1990,10 @@ void launchBoundaryFaceFlux(const Launcher& L, int stencil, const MeshView& m, c
 }
 void launchFusedFaceCell(const Launcher& L, const MeshView& m, const CaseView& c, const GasModel& g, int firstBlock, int nBlocks) {
     if (nBlocks <= 0) return;
-    if (m.sGeo) QGD_TIMED(L, QGD_K_FACE, (fusedFaceCellKernel<true><<<nBlocks, 256, m.fuLds, L.stream>>>(m, c, g, firstBlock)));
+    const bool upw = g.upwindU || g.upwindH;   // a `Gauss upwind` entry for div(phiJm,U) or div(phiJm,H)
+    if (m.sGeo && upw) QGD_TIMED(L, QGD_K_FACE, (fusedFaceCellKernel<true, true><<<nBlocks, 256, m.fuLds, L.stream>>>(m, c, g, firstBlock)));
+    else if (upw) QGD_TIMED(L, QGD_K_FACE, (fusedFaceCellKernel<false, true><<<nBlocks, 256, m.fuLds, L.stream>>>(m, c, g, firstBlock)));
+    else if (m.sGeo) QGD_TIMED(L, QGD_K_FACE, (fusedFaceCellKernel<true><<<nBlocks, 256, m.fuLds, L.stream>>>(m, c, g, firstBlock)));
     else QGD_TIMED(L, QGD_K_FACE, (fusedFaceCellKernel<false><<<nBlocks, 256, m.fuLds, L.stream>>>(m, c, g, firstBlock)));
 }
 void launchCellUpdate(const Launcher& L, const MeshView& m, const CaseView& c, const GasModel& g, int mode,

@@ -4,7 +4,7 @@ values nor net fluxes of internal faces reach device memory.  Same arithmetic pe
 pointInterpRecKernel + faceFluxGvp3(Tile)Kernel + cellUpdateKernel: the states must agree BIT FOR BIT with QGD_FUSED=0 -- on hexahedra, on
 jittered meshes with triangles and polygon faces, scrambled numberings, with patches of every kind the step knows (their fluxes come from the
 boundary kernel through device memory), the qgdFlux walls of the forward step's 3-D cousin, and over a long run.  Cases the fused kernel
-does not serve (Courant-number control, implicit diffusion, upwind fluxes, per-term stencils, shards) must say so and run the two kernels."""
+does not serve (Courant-number control, implicit diffusion, per-term stencils) must say so and run the three kernels."""
 import os
 
 import numpy as np
@@ -90,6 +90,18 @@ def test_fused_step_with_streamed_face_areas():
         equal(c, d, tag)
 
 
+def test_fused_step_with_upwind_fluxes():
+    """`div(phiJm,U|H) Gauss upwind`: the UPW instantiation of the fused kernel against the UPW face kernel + cell kernel"""
+    for tag, mesh in list(meshes())[:1] + list(meshes())[5:6]:
+        for opt in (dict(fluxSchemeU=1), dict(fluxSchemeH=1), dict(fluxSchemeU=1, fluxSchemeH=1)):
+            a, ia = run(mesh, 6, False, deltaT=2e-3, mu=1e-3, **opt)
+            b, ib = run(mesh, 6, True, deltaT=2e-3, mu=1e-3, **opt)
+            assert ib["fused"] and not ia["fused"]
+            equal(a, b, (tag, opt))
+        lin, _ = run(mesh, 6, True, deltaT=2e-3, mu=1e-3)
+        assert not np.array_equal(lin["U"], b["U"])        # (the scheme does something)
+
+
 def test_fused_step_with_patches_of_every_kind_and_in_chunks():
     import test_case_parity_gpu as t
     mesh = q.PolyMesh.box(14, 9, 6)
@@ -118,8 +130,7 @@ def test_cases_the_fused_kernel_does_not_serve_keep_the_two_kernels():
         dev = q.Device(mesh)
     finally:
         del os.environ["QGD_FUSED"]
-    for opt in (dict(adjustTimeStep=1, maxCo=0.2), dict(implicitDiffusion=1, mu=1e-3), dict(fluxSchemeU=1), dict(fluxSchemeH=1),
-                dict(termStencils={"grad(p)": "reduced"})):
+    for opt in (dict(adjustTimeStep=1, maxCo=0.2), dict(implicitDiffusion=1, mu=1e-3), dict(termStencils={"grad(p)": "reduced"})):
         case = q.QGDFoamCase(dev, q.default_options(stencil="GaussVolPoint", deltaT=1e-3, **opt))
         assert not case.fused_info()["fused"], opt
         case.close()
