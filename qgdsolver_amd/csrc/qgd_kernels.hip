@@ -1129,11 +1129,15 @@ void cellUpdateKernel(const MeshView m, const CaseView c, const GasModel gm, con
 #ifndef QGD_FU_WAVES
 #define QGD_FU_WAVES 3
 #endif
+// wave priority raised from the kernel's start: 0 never, 1 until the loads are out, 2 until the block is staged, 3 until its vertex values are formed
+#ifndef QGD_FU_PRIO
+#define QGD_FU_PRIO 3
+#endif
 template <bool SGEO, bool UPW = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QGD_FU_WAVES, QGD_FU_WAVES)))
 void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm, const int firstBlock) {
     extern __shared__ v2d tileLds[];
-#if QGD_F_PRIO
+#if QGD_FU_PRIO
     __builtin_amdgcn_s_setprio(3);
 #endif
     constexpr int NT = 256, KC = 5, KCC = 4, KB2 = 3, KV = 3, KF = 2, KE = 6, KP = 8;
@@ -1223,6 +1227,9 @@ void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm, 
         for (int k = 0; k < 3; ++k) dPt[k] = gP[(size_t)myVert * 3 + k];
     }
     __builtin_amdgcn_sched_barrier(0);
+#if QGD_FU_PRIO == 1
+    __builtin_amdgcn_s_setprio(0);
+#endif
     const int nOwn = hdr.x, nUc = hdr.y, nUv = hdr.z, nFc = hdr.w;
     if (tid < 128) {
 #pragma unroll
@@ -1237,6 +1244,9 @@ void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm, 
 #pragma unroll
     for (int k = 0; k < KV; ++k) { const int q = tid + k * NT; if (q < 3 * nUv) sX[q] = dX[k]; }
     __syncthreads();
+#if QGD_FU_PRIO == 2
+    __builtin_amdgcn_s_setprio(0);
+#endif
     // (1b) the vertex values [volPointInterpolation: inverse-distance weights over pointCells, in their order -- pointInterpRecKernel's
     // arithmetic, out of the staged cell records]
     if (tid < nUv) {
@@ -1273,7 +1283,7 @@ void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm, 
         }
     }
     __syncthreads();
-#if QGD_F_PRIO
+#if QGD_FU_PRIO == 3
     __builtin_amdgcn_s_setprio(0);
 #endif
     // (2) the faces: fluxes into registers
