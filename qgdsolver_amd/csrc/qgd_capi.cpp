@@ -718,8 +718,9 @@ int qgd_device_create(qgd_mesh_t mh, int deviceId, qgd_device_t* out) {
         }
         {
             // cell blocks of the fused face + cell kernel (QGD_FUSED, qgd_setup.hpp FusedBlocks): 3-D unsharded meshes whose tiles were built
-            static const int kOnOff2[] = {0, 1};
-            if (envChoice("QGD_FUSED", 1, kOnOff2, 2) != 0) {
+            static const int kFusedModes[] = {0, 1, 2};
+            const int fusedMode = envChoice("QGD_FUSED", 1, kFusedModes, 3);   // 2: whatever the blocks look like (tests, probes)
+            if (fusedMode != 0) {
                 FusedBlocks fb = buildFusedBlocks(s);
                 // LDS, by the largest block: RecA of every staged cell, RecB of the own + across-a-face cells, then vertex records + all
                 // coordinates, later overwritten by the fluxes; then the parked face entries of the own cells
@@ -727,8 +728,12 @@ int qgd_device_create(qgd_mesh_t mh, int deviceId, qgd_device_t* out) {
                                        std::max((int64_t)fb.maxV * 72 + (int64_t)fb.maxAll * 24, (int64_t)fb.maxF * 40);
                 const int64_t ldsPark = (ldsRec + 15) / 16 * 16;
                 const int64_t lds = (ldsPark + 6 * 128 * 4 + 255) / 256 * 256;
-                if (fb.nBlocks > 0 && fb.maxAll <= kFusedCapC && fb.maxTot <= kFusedCapTot && fb.capV <= kFusedCapV && fb.capF <= kFusedCapF &&
-                    fb.capPE <= 255 && lds <= 80 * 1024) {
+                // (a mesh whose blocks come out small -- under 88 cells on average: every block costs a workgroup two face passes whatever it
+                // holds -- is better off with the three kernels: 5.0 against 4.4 ms per step on the 16 M-cell mesh of config 5 with 67-cell blocks)
+                int64_t owned = 0;
+                for (int64_t ci = 0; ci < s.nC; ++ci) owned += (s.ghost.empty() || s.ghost[ci] != 1) ? 1 : 0;
+                if (fb.nBlocks > 0 && (fusedMode == 2 || (int64_t)fb.nBlocks * 88 <= owned + 87) && fb.maxAll <= kFusedCapC && fb.maxTot <= kFusedCapTot &&
+                    fb.capV <= kFusedCapV && fb.capF <= kFusedCapF && fb.capPE <= 255 && lds <= 80 * 1024) {
                     v.fuBlocks = fb.nBlocks; v.fuLayerBlocks = fb.nLayerBlocks; v.fuCapC = fb.capC; v.fuCapV = fb.capV; v.fuCapF = fb.capF;
                     v.fuCapE = fb.capE; v.fuLds = (int32_t)lds; v.fuLdsCell = (int32_t)(ldsPark / 8);
                     v.fuCapPE = fb.capPE; v.fuMaxTot = fb.maxTot; v.fuMaxAll = fb.maxAll; v.fuMaxV = fb.maxV; v.fuMaxF = fb.maxF;

@@ -846,51 +846,64 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
         }
         return true;
     };
-    // ranges of the sorted cells: the boundary layer first, then the rest; no range straddles the two
-    const int64_t nLayerRanges = (nLayer + kFusedCells - 1) / kFusedCells;
-    const int64_t nRanges = nLayerRanges + (nOwned - nLayer + kFusedCells - 1) / kFusedCells;
+    // ranges of the sorted cells: the boundary layer first, then the rest; no range straddles the two.  A range that does not fit the caps
+    // is halved -- and a mesh whose 128-cell ranges mostly do not fit (cells with more than six faces: triangles, polyhedra) would end up with
+    // 64-cell blocks whose second face pass runs nearly empty; so the range length comes down in steps until few ranges need the cut.
+    int64_t rangeLen = kFusedCells, nLayerRanges = 0, nRanges = 0;
     auto rangeOf = [&](int64_t r) {
-        if (r < nLayerRanges) return std::pair<int64_t, int64_t>{r * kFusedCells, std::min(nLayer, (r + 1) * (int64_t)kFusedCells)};
+        if (r < nLayerRanges) return std::pair<int64_t, int64_t>{r * rangeLen, std::min(nLayer, (r + 1) * rangeLen)};
         const int64_t q = r - nLayerRanges;
-        return std::pair<int64_t, int64_t>{nLayer + q * kFusedCells, std::min(nOwned, nLayer + (q + 1) * (int64_t)kFusedCells)};
+        return std::pair<int64_t, int64_t>{nLayer + q * rangeLen, std::min(nOwned, nLayer + (q + 1) * rangeLen)};
     };
     // Pass 1: where each range is cut (nearly always: not at all) and what the largest block needs.  Pass 2 builds every block again,
     // straight into the padded tables: twice the arithmetic instead of half a million small vectors kept between the passes.
-    std::vector<int32_t> nOf((size_t)nRanges, 1);
-    std::vector<std::vector<std::pair<int64_t, int64_t>>> cuts((size_t)nRanges);   // only for the ranges that were cut
+    std::vector<int32_t> nOf;
+    std::vector<std::vector<std::pair<int64_t, int64_t>>> cuts;   // only for the ranges that were cut
     bool failed = false;
     int64_t facesDone = 0, cellsTot = 0, cellsAll = 0, vertsTot = 0;
     int32_t maxC = 0, maxV = 0, maxF = 0, maxE = 1, maxAll = 0, maxPE = 1;
-#pragma omp parallel reduction(+ : facesDone, cellsTot, cellsAll, vertsTot) reduction(max : maxC, maxV, maxF, maxE, maxAll, maxPE)
-    {
-        std::vector<SmallMap> maps(3);
-        OneBlock o;
+    for (const int64_t len : {(int64_t)kFusedCells, (int64_t)112, (int64_t)96, (int64_t)80, (int64_t)64}) {
+        rangeLen = len;
+        nLayerRanges = (nLayer + rangeLen - 1) / rangeLen;
+        nRanges = nLayerRanges + (nOwned - nLayer + rangeLen - 1) / rangeLen;
+        nOf.assign((size_t)nRanges, 1);
+        cuts.assign((size_t)nRanges, {});
+        failed = false;
+        facesDone = cellsTot = cellsAll = vertsTot = 0;
+        maxC = maxV = maxF = maxAll = 0; maxE = maxPE = 1;
+        int64_t nCut = 0;
+#pragma omp parallel reduction(+ : facesDone, cellsTot, cellsAll, vertsTot, nCut) reduction(max : maxC, maxV, maxF, maxE, maxAll, maxPE)
+        {
+            std::vector<SmallMap> maps(3);
+            OneBlock o;
 #pragma omp for schedule(dynamic, 64)
-        for (int64_t r = 0; r < nRanges; ++r) {
-            std::vector<std::pair<int64_t, int64_t>> work{rangeOf(r)}, done;
-            while (!work.empty()) {
-                const auto [b0, b1] = work.back();
-                work.pop_back();
-                if (tryBlock(b0, b1, o, maps[0], maps[1], maps[2])) {
-                    done.push_back({b0, b1});
-                    maxC = std::max<int32_t>(maxC, (int32_t)o.cells.size());
-                    maxV = std::max<int32_t>(maxV, (int32_t)o.verts.size());
-                    maxF = std::max<int32_t>(maxF, (int32_t)o.face.size() / 4);
-                    maxE = std::max(maxE, o.maxE);
-                    maxAll = std::max(maxAll, o.nAll);
-                    maxPE = std::max(maxPE, o.maxPE);
-                    facesDone += (int64_t)o.face.size() / 4;
-                    cellsTot += (int64_t)o.cells.size(); cellsAll += o.nAll; vertsTot += (int64_t)o.verts.size();
-                    continue;
+            for (int64_t r = 0; r < nRanges; ++r) {
+                std::vector<std::pair<int64_t, int64_t>> work{rangeOf(r)}, done;
+                while (!work.empty()) {
+                    const auto [b0, b1] = work.back();
+                    work.pop_back();
+                    if (tryBlock(b0, b1, o, maps[0], maps[1], maps[2])) {
+                        done.push_back({b0, b1});
+                        maxC = std::max<int32_t>(maxC, (int32_t)o.cells.size());
+                        maxV = std::max<int32_t>(maxV, (int32_t)o.verts.size());
+                        maxF = std::max<int32_t>(maxF, (int32_t)o.face.size() / 4);
+                        maxE = std::max(maxE, o.maxE);
+                        maxAll = std::max(maxAll, o.nAll);
+                        maxPE = std::max(maxPE, o.maxPE);
+                        facesDone += (int64_t)o.face.size() / 4;
+                        cellsTot += (int64_t)o.cells.size(); cellsAll += o.nAll; vertsTot += (int64_t)o.verts.size();
+                        continue;
+                    }
+                    if (b1 - b0 == 1) { failed = true; break; }   // one cell with more faces / vertices than a block holds
+                    const int64_t mid = (b0 + b1) / 2;
+                    work.push_back({mid, b1});
+                    work.push_back({b0, mid});
                 }
-                if (b1 - b0 == 1) { failed = true; break; }   // one cell with more faces / vertices than a block holds
-                const int64_t mid = (b0 + b1) / 2;
-                work.push_back({mid, b1});
-                work.push_back({b0, mid});
+                nOf[r] = (int32_t)done.size();
+                if (done.size() != 1) { cuts[r] = std::move(done); ++nCut; }
             }
-            nOf[r] = (int32_t)done.size();
-            if (done.size() != 1) cuts[r] = std::move(done);
         }
+        if (failed || 20 * nCut <= nRanges) break;   // at most one range in twenty cut: good enough
     }
     if (failed) return B;
     std::vector<int64_t> first((size_t)nRanges + 1, 0);

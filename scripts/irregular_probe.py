@@ -36,7 +36,7 @@ def run(mesh, tag, steps):
         parts.append(f"{nm} {ms / max(cnt, 1):.3f}")
     bw = int(np.abs(mesh.array("neighbour").astype(np.int64) - mesh.array("owner")[:mesh.nInternalFaces]).max())
     print(f"{tag:10s} {mesh.nCells / 1e6:6.2f} Mcells  bandwidth {bw:9d}  {1e3 * wall:7.3f} ms/step  {mesh.nCells / wall / 1e6:7.1f} Mcell-steps/s  "
-          f"[{'  '.join(parts)}]  setup {setup:.1f} s  min_rho {case.info()['minRho']:.4f}  tiles {dev.face_tiles()}", flush=True)
+          f"[{'  '.join(parts)}]  setup {setup:.1f} s  min_rho {case.info()['minRho']:.4f}  tiles {dev.face_tiles()}  fused {case.fused_info()}", flush=True)
     case.close()
     dev.close()
 

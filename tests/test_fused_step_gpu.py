@@ -19,7 +19,8 @@ pytestmark = pytest.mark.gpu
 
 
 def run(mesh, steps, fused, bc_fn=None, chunks=(None,), env=None, **opt):
-    env = dict(env or {}, QGD_FUSED="1" if fused else "0")
+    env = dict(env or {}, QGD_FUSED="2" if fused else "0")     # 2: fused whatever the blocks look like (1, the default, leaves meshes
+    # whose blocks come out small to the three kernels)
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
@@ -125,7 +126,7 @@ def test_fused_step_stays_bit_identical_over_a_long_run():
 
 def test_cases_the_fused_kernel_does_not_serve_keep_the_two_kernels():
     mesh = q.PolyMesh.box(10, 8, 6)
-    os.environ["QGD_FUSED"] = "1"
+    os.environ["QGD_FUSED"] = "2"
     try:
         dev = q.Device(mesh)
     finally:
@@ -154,7 +155,7 @@ def test_cases_the_fused_kernel_does_not_serve_keep_the_two_kernels():
 
 def shard_run(shard, fused, order, steps=4):
     old = os.environ.get("QGD_FUSED")
-    os.environ["QGD_FUSED"] = "1" if fused else "0"
+    os.environ["QGD_FUSED"] = "2" if fused else "0"
     try:
         dev = q.Device(shard)
     finally:
@@ -173,6 +174,20 @@ def shard_run(shard, fused, order, steps=4):
     out = {n: case.field(n).copy() for n in ("rho", "U", "p", "e", "rhoE", "p.boundary", "U.boundary")}
     case.close(); dev.close()
     return out
+
+
+def test_default_leaves_meshes_with_small_blocks_to_the_three_kernels():
+    """QGD_FUSED unset (= 1): a box of bricks is fused; a mesh with every quadrilateral split (twelve faces per cell: a block holds 64 cells
+    before its 512 faces are full) is not -- every block costs a workgroup two face passes whatever it holds"""
+    assert "QGD_FUSED" not in os.environ
+    tri = q.PolyMesh.box(20, 20, 20)
+    tri.jitter(0.15, seed=3); tri.split_quads(1)
+    for mesh, want in ((q.PolyMesh.box(32, 16, 16), True), (tri, False)):
+        dev = q.Device(mesh)
+        case = q.QGDFoamCase(dev, q.default_options(stencil="GaussVolPoint", deltaT=1e-3))
+        info = case.fused_info()
+        assert info["fused"] == want, (mesh.nCells, info)
+        case.close(); dev.close()
 
 
 @pytest.mark.parametrize("nShards,which", [(2, 0), (2, 1), (3, 1)])
