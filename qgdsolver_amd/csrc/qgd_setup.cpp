@@ -848,12 +848,57 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
     };
     // ranges of the sorted cells: the boundary layer first, then the rest; no range straddles the two.  A range that does not fit the caps
     // is halved -- and a mesh whose 128-cell ranges mostly do not fit (cells with more than six faces: triangles, polyhedra) would end up with
-    // 64-cell blocks whose second face pass runs nearly empty; so the range length comes down in steps until few ranges need the cut.
-    int64_t rangeLen = kFusedCells, nLayerRanges = 0, nRanges = 0;
+    // 64-cell blocks whose second face pass runs nearly empty; so the ranges get shorter in steps until few of them need the cut.
+    // First choice: the lattice BRICKS themselves -- the cells whose Morton keys share everything above their lowest seven bits (8x4x4 lattice
+    // cells) --, whatever the mesh's extents and wherever a shard's ghost planes sit; bricks of one 16x8x8 parent that are short of cells (the
+    // rim of the mesh, a shard's one-plane boundary layer) are joined up to 128 cells, a brick with more is cut evenly.  Runs of a fixed
+    // count instead (second choice, lengths 112 ... 64) drift across the bricks as soon as one brick is short.
+    std::vector<int64_t> rangeStart;   // nRanges + 1 positions in the sorted cells
+    int64_t nLayerRanges = 0, nRanges = 0;
+    auto brickRanges = [&]() {
+        rangeStart.clear();
+        auto part = [&](int64_t p0, int64_t p1) {   // [p0, p1) of the sorted cells, all of one role
+            int64_t curStart = -1, curEnd = -1;
+            uint64_t curParent = 0;
+            auto flush = [&]() { if (curStart >= 0) rangeStart.push_back(curStart); curStart = -1; };
+            int64_t i = p0;
+            while (i < p1) {
+                const uint64_t brick = key[i].first >> 7;
+                int64_t j = i + 1;
+                while (j < p1 && (key[j].first >> 7) == brick) ++j;
+                const int64_t sz = j - i;
+                if (sz > kFusedCells) {
+                    flush();
+                    const int64_t k = (sz + kFusedCells - 1) / kFusedCells;
+                    for (int64_t q = 0; q < k; ++q) rangeStart.push_back(i + sz * q / k);
+                } else if (curStart >= 0 && curEnd == i && (curEnd - curStart) + sz <= kFusedCells && (brick >> 3) == curParent) {
+                    curEnd = j;
+                } else {
+                    flush();
+                    curStart = i; curEnd = j; curParent = brick >> 3;
+                }
+                i = j;
+            }
+            flush();
+        };
+        part(0, nLayer);
+        nLayerRanges = (int64_t)rangeStart.size();
+        part(nLayer, nOwned);
+        nRanges = (int64_t)rangeStart.size();
+        rangeStart.push_back(nOwned);
+        if (nLayerRanges < nRanges) { /* the first range of the second part starts at nLayer by construction */ }
+    };
+    auto runRanges = [&](int64_t len) {
+        rangeStart.clear();
+        for (int64_t p = 0; p < nLayer; p += len) rangeStart.push_back(p);
+        nLayerRanges = (int64_t)rangeStart.size();
+        for (int64_t p = nLayer; p < nOwned; p += len) rangeStart.push_back(p);
+        nRanges = (int64_t)rangeStart.size();
+        rangeStart.push_back(nOwned);
+    };
     auto rangeOf = [&](int64_t r) {
-        if (r < nLayerRanges) return std::pair<int64_t, int64_t>{r * rangeLen, std::min(nLayer, (r + 1) * rangeLen)};
-        const int64_t q = r - nLayerRanges;
-        return std::pair<int64_t, int64_t>{nLayer + q * rangeLen, std::min(nOwned, nLayer + (q + 1) * rangeLen)};
+        const int64_t e = (r + 1 == nLayerRanges) ? nLayer : rangeStart[r + 1];
+        return std::pair<int64_t, int64_t>{rangeStart[r], e};
     };
     // Pass 1: where each range is cut (nearly always: not at all) and what the largest block needs.  Pass 2 builds every block again,
     // straight into the padded tables: twice the arithmetic instead of half a million small vectors kept between the passes.
@@ -862,10 +907,12 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
     bool failed = false;
     int64_t facesDone = 0, cellsTot = 0, cellsAll = 0, vertsTot = 0;
     int32_t maxC = 0, maxV = 0, maxF = 0, maxE = 1, maxAll = 0, maxPE = 1;
-    for (const int64_t len : {(int64_t)kFusedCells, (int64_t)112, (int64_t)96, (int64_t)80, (int64_t)64}) {
-        rangeLen = len;
-        nLayerRanges = (nLayer + rangeLen - 1) / rangeLen;
-        nRanges = nLayerRanges + (nOwned - nLayer + rangeLen - 1) / rangeLen;
+    // keep the first way of cutting ranges whose blocks average 104 cells or more, else the one with the largest average
+    struct Kept { std::vector<int64_t> rangeStart; std::vector<int32_t> nOf; std::vector<std::vector<std::pair<int64_t, int64_t>>> cuts;
+                  int64_t nLayerRanges = 0, nRanges = 0, facesDone = 0, cellsTot = 0, cellsAll = 0, vertsTot = 0, blocks = 0;
+                  int32_t maxC = 0, maxV = 0, maxF = 0, maxE = 1, maxAll = 0, maxPE = 1; } best;
+    for (const int64_t len : {(int64_t)0, (int64_t)112, (int64_t)96, (int64_t)80, (int64_t)64}) {
+        if (len == 0) brickRanges(); else runRanges(len);
         nOf.assign((size_t)nRanges, 1);
         cuts.assign((size_t)nRanges, {});
         failed = false;
@@ -903,7 +950,21 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
                 if (done.size() != 1) { cuts[r] = std::move(done); ++nCut; }
             }
         }
-        if (failed || 20 * nCut <= nRanges) break;   // at most one range in twenty cut: good enough
+        (void)nCut;
+        if (failed) break;
+        int64_t blocks = 0;
+        for (int64_t r = 0; r < nRanges; ++r) blocks += nOf[r];
+        if (best.blocks == 0 || blocks < best.blocks) {
+            best.rangeStart = rangeStart; best.nOf = nOf; best.cuts = cuts; best.nLayerRanges = nLayerRanges; best.nRanges = nRanges;
+            best.facesDone = facesDone; best.cellsTot = cellsTot; best.cellsAll = cellsAll; best.vertsTot = vertsTot; best.blocks = blocks;
+            best.maxC = maxC; best.maxV = maxV; best.maxF = maxF; best.maxE = maxE; best.maxAll = maxAll; best.maxPE = maxPE;
+        }
+        if (blocks * 104 <= nOwned) break;
+    }
+    if (!failed) {
+        rangeStart.swap(best.rangeStart); nOf.swap(best.nOf); cuts.swap(best.cuts); nLayerRanges = best.nLayerRanges; nRanges = best.nRanges;
+        facesDone = best.facesDone; cellsTot = best.cellsTot; cellsAll = best.cellsAll; vertsTot = best.vertsTot;
+        maxC = best.maxC; maxV = best.maxV; maxF = best.maxF; maxE = best.maxE; maxAll = best.maxAll; maxPE = best.maxPE;
     }
     if (failed) return B;
     std::vector<int64_t> first((size_t)nRanges + 1, 0);
