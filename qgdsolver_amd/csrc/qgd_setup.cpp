@@ -773,7 +773,7 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
         int32_t ent[256];
         for (int64_t i = b0; i < b1; ++i) {
             const int32_t c = key[i].second;
-            if (s.cfCount[c] > 255) return false;
+            if (s.cfCount[c] == 255) return false;   // (a saturated count: more faces than the table holds)
             const int n = entriesOf(c, ent);
             o.maxE = std::max(o.maxE, n);
             for (int k = 0; k < n; ++k) { const int32_t f = ent[k] >= 0 ? ent[k] : ~ent[k]; if (f < nIF) faces.push_back(f); }
@@ -886,7 +886,6 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
         part(nLayer, nOwned);
         nRanges = (int64_t)rangeStart.size();
         rangeStart.push_back(nOwned);
-        if (nLayerRanges < nRanges) { /* the first range of the second part starts at nLayer by construction */ }
     };
     auto runRanges = [&](int64_t len) {
         rangeStart.clear();
@@ -918,8 +917,7 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
         failed = false;
         facesDone = cellsTot = cellsAll = vertsTot = 0;
         maxC = maxV = maxF = maxAll = 0; maxE = maxPE = 1;
-        int64_t nCut = 0;
-#pragma omp parallel reduction(+ : facesDone, cellsTot, cellsAll, vertsTot, nCut) reduction(max : maxC, maxV, maxF, maxE, maxAll, maxPE)
+#pragma omp parallel reduction(+ : facesDone, cellsTot, cellsAll, vertsTot) reduction(max : maxC, maxV, maxF, maxE, maxAll, maxPE)
         {
             std::vector<SmallMap> maps(3);
             OneBlock o;
@@ -947,10 +945,9 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
                     work.push_back({b0, mid});
                 }
                 nOf[r] = (int32_t)done.size();
-                if (done.size() != 1) { cuts[r] = std::move(done); ++nCut; }
+                if (done.size() != 1) cuts[r] = std::move(done);
             }
         }
-        (void)nCut;
         if (failed) break;
         int64_t blocks = 0;
         for (int64_t r = 0; r < nRanges; ++r) blocks += nOf[r];
