@@ -722,10 +722,9 @@ int qgd_device_create(qgd_mesh_t mh, int deviceId, qgd_device_t* out) {
             const int fusedMode = envChoice("QGD_FUSED", 1, kFusedModes, 3);   // 2: whatever the blocks look like (tests, probes)
             if (fusedMode != 0) {
                 FusedBlocks fb = buildFusedBlocks(s);
-                // LDS, by the largest block: RecA of every staged cell, RecB of the own + across-a-face cells, then vertex records + all
-                // coordinates, later overwritten by the fluxes; then the parked face entries of the own cells
-                const int64_t ldsRec = (int64_t)fb.maxTot * 48 + (int64_t)fb.maxAll * 32 +
-                                       std::max((int64_t)fb.maxV * 72 + (int64_t)fb.maxAll * 24, (int64_t)fb.maxF * 40);
+                // LDS per workgroup: RecA of every staged cell, RecB of the own + across-a-face cells, then vertex records + all coordinates,
+                // later overwritten by the fluxes (FusedBlocks::maxLds); then the parked face entries of the own cells
+                const int64_t ldsRec = fb.maxLds;   // the block that needs most; every block lays its records out by its own counts
                 const int64_t ldsPark = (ldsRec + 15) / 16 * 16;
                 const int64_t lds = (ldsPark + 6 * 128 * 4 + 255) / 256 * 256;
                 // (a mesh whose blocks come out small -- under 88 cells on average: every block costs a workgroup two face passes whatever it

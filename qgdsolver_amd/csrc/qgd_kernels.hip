@@ -1152,17 +1152,6 @@ void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm, 
     const int32_t* __restrict__ tVerts = m.fuVerts + (size_t)blk * capV;
     const int4* __restrict__ tFace = m.fuFace + (size_t)blk * capF;
     const int32_t* __restrict__ ent = m.fuEntry + (size_t)blk * m.fuCapE * 128 + (tid & 127);
-    // LDS (sized by the largest block of the mesh): RecA of every staged cell and RecB of the own + across-a-face cells stay to the end (an own
-    // cell's old record is read by its update); the vertex records -- formed HERE, from the staged cells -- and all coordinates are dead once
-    // every face has its fluxes in registers, and the fluxes take their place
-    v2d* const sA = tileLds;                     // 3 maxTot pieces
-    v2d* const sB = sA + 3 * m.fuMaxTot;         // 2 maxAll
-    v2d* const sP = sB + 2 * m.fuMaxAll;         // 3 maxV: vertex RecA
-    double* const sX = reinterpret_cast<double*>(sP + 3 * m.fuMaxV);   // 3 maxV: vertex coordinates
-    double* const sC = sX + 3 * m.fuMaxV;        // 3 maxAll: cell centres
-    double* const sF = reinterpret_cast<double*>(sP);   // 5 maxF: net fluxes, plane by plane (after the third barrier)
-    int* const sE = reinterpret_cast<int*>(reinterpret_cast<double*>(tileLds) + m.fuLdsCell);   // 6 x 128: an own cell's first six face entries, parked until its update
-    const int strideF = m.fuMaxF;
     // (0) everything whose address does not depend on a loaded value: the counts, the lists (padded to their strides with their last entry,
     // so no count is needed to read them), this thread's two faces, its cell's face entries, its vertex's cells and weights
     const int4 hdr = m.fuHdr[blk];
@@ -1231,6 +1220,18 @@ void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm, 
     __builtin_amdgcn_s_setprio(0);
 #endif
     const int nOwn = hdr.x, nUc = hdr.y, nUv = hdr.z, nFc = hdr.w;
+    // LDS, laid out by THIS block's counts (the launch reserves what the block that needs most takes): RecA of every staged cell and RecB of
+    // the own + across-a-face cells stay to the end (an own cell's old record is read by its update); the vertex records -- formed HERE, from
+    // the staged cells -- and all coordinates are dead once every face has its fluxes in registers, and the fluxes take their place.  The
+    // parked face entries of the own cells sit at a fixed place behind all that.
+    v2d* const sA = tileLds;                     // 3 nTot pieces
+    v2d* const sB = sA + 3 * nTot;               // 2 nAll
+    v2d* const sP = sB + 2 * hdr.y;              // 3 nV: vertex RecA
+    double* const sX = reinterpret_cast<double*>(sP + 3 * hdr.z);   // 3 nV: vertex coordinates
+    double* const sC = sX + 3 * hdr.z;           // 3 nAll: cell centres
+    double* const sF = reinterpret_cast<double*>(sP);   // 5 nF: net fluxes, plane by plane (after the third barrier)
+    int* const sE = reinterpret_cast<int*>(reinterpret_cast<double*>(tileLds) + m.fuLdsCell);   // 6 x 128: an own cell's first six face entries, parked until its update
+    const int strideF = hdr.w;
     if (tid < 128) {
 #pragma unroll
         for (int i = 0; i < KE; ++i) sE[i * 128 + tid] = e6[i];

@@ -689,7 +689,7 @@ struct OneBlock {
     std::vector<uint8_t> vCount;                      // per staged vertex
     std::vector<uint16_t> vPos;                       // row-major here (vertex x maxPE)
     std::vector<double> vW;
-    int32_t nAll = 0, maxPE = 0;                      // own + across-a-face cells (cells.size() counts the extras too)
+    int32_t nAll = 0, maxPE = 0, lds = 0;             // own + across-a-face cells (cells.size() counts the extras too); LDS bytes of its records
     std::vector<uint8_t> nEntry;
     int32_t nOwn = 0, maxE = 0;
 };
@@ -823,6 +823,11 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
                 o.vW[lv * o.maxPE + i] = s.pcW[base + (size_t)i * 64];
             }
         }
+        // what the block needs of the kernel's LDS (fusedFaceCellKernel: RecA of every staged cell, RecB of the own + across-a-face ones, then
+        // vertex records + coordinates + centres, which the fluxes overwrite): a block over the budget that lets three blocks share a CU is
+        // cut like one over the caps, unless it is small already
+        o.lds = 48 * (int32_t)o.cells.size() + 32 * o.nAll + std::max(72 * (int32_t)vs.size() + 24 * o.nAll, 40 * (int32_t)faces.size());
+        if (o.lds > kFusedLdsTarget && o.nOwn > 32) return false;
         o.face.resize(4 * faces.size());
         for (size_t lf = 0; lf < faces.size(); ++lf) {
             const int32_t f = faces[lf];
@@ -905,19 +910,19 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
     std::vector<std::vector<std::pair<int64_t, int64_t>>> cuts;   // only for the ranges that were cut
     bool failed = false;
     int64_t facesDone = 0, cellsTot = 0, cellsAll = 0, vertsTot = 0;
-    int32_t maxC = 0, maxV = 0, maxF = 0, maxE = 1, maxAll = 0, maxPE = 1;
+    int32_t maxC = 0, maxV = 0, maxF = 0, maxE = 1, maxAll = 0, maxPE = 1, maxLds = 0;
     // keep the first way of cutting ranges whose blocks average 104 cells or more, else the one with the largest average
     struct Kept { std::vector<int64_t> rangeStart; std::vector<int32_t> nOf; std::vector<std::vector<std::pair<int64_t, int64_t>>> cuts;
                   int64_t nLayerRanges = 0, nRanges = 0, facesDone = 0, cellsTot = 0, cellsAll = 0, vertsTot = 0, blocks = 0;
-                  int32_t maxC = 0, maxV = 0, maxF = 0, maxE = 1, maxAll = 0, maxPE = 1; } best;
+                  int32_t maxC = 0, maxV = 0, maxF = 0, maxE = 1, maxAll = 0, maxPE = 1, maxLds = 0; } best;
     for (const int64_t len : {(int64_t)0, (int64_t)112, (int64_t)96, (int64_t)80, (int64_t)64}) {
         if (len == 0) brickRanges(); else runRanges(len);
         nOf.assign((size_t)nRanges, 1);
         cuts.assign((size_t)nRanges, {});
         failed = false;
         facesDone = cellsTot = cellsAll = vertsTot = 0;
-        maxC = maxV = maxF = maxAll = 0; maxE = maxPE = 1;
-#pragma omp parallel reduction(+ : facesDone, cellsTot, cellsAll, vertsTot) reduction(max : maxC, maxV, maxF, maxE, maxAll, maxPE)
+        maxC = maxV = maxF = maxAll = maxLds = 0; maxE = maxPE = 1;
+#pragma omp parallel reduction(+ : facesDone, cellsTot, cellsAll, vertsTot) reduction(max : maxC, maxV, maxF, maxE, maxAll, maxPE, maxLds)
         {
             std::vector<SmallMap> maps(3);
             OneBlock o;
@@ -935,6 +940,7 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
                         maxE = std::max(maxE, o.maxE);
                         maxAll = std::max(maxAll, o.nAll);
                         maxPE = std::max(maxPE, o.maxPE);
+                        maxLds = std::max(maxLds, o.lds);
                         facesDone += (int64_t)o.face.size() / 4;
                         cellsTot += (int64_t)o.cells.size(); cellsAll += o.nAll; vertsTot += (int64_t)o.verts.size();
                         continue;
@@ -954,14 +960,14 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
         if (best.blocks == 0 || blocks < best.blocks) {
             best.rangeStart = rangeStart; best.nOf = nOf; best.cuts = cuts; best.nLayerRanges = nLayerRanges; best.nRanges = nRanges;
             best.facesDone = facesDone; best.cellsTot = cellsTot; best.cellsAll = cellsAll; best.vertsTot = vertsTot; best.blocks = blocks;
-            best.maxC = maxC; best.maxV = maxV; best.maxF = maxF; best.maxE = maxE; best.maxAll = maxAll; best.maxPE = maxPE;
+            best.maxC = maxC; best.maxV = maxV; best.maxF = maxF; best.maxE = maxE; best.maxAll = maxAll; best.maxPE = maxPE; best.maxLds = maxLds;
         }
         if (blocks * 104 <= nOwned) break;
     }
     if (!failed) {
         rangeStart.swap(best.rangeStart); nOf.swap(best.nOf); cuts.swap(best.cuts); nLayerRanges = best.nLayerRanges; nRanges = best.nRanges;
         facesDone = best.facesDone; cellsTot = best.cellsTot; cellsAll = best.cellsAll; vertsTot = best.vertsTot;
-        maxC = best.maxC; maxV = best.maxV; maxF = best.maxF; maxE = best.maxE; maxAll = best.maxAll; maxPE = best.maxPE;
+        maxC = best.maxC; maxV = best.maxV; maxF = best.maxF; maxE = best.maxE; maxAll = best.maxAll; maxPE = best.maxPE; maxLds = best.maxLds;
     }
     if (failed) return B;
     std::vector<int64_t> first((size_t)nRanges + 1, 0);
@@ -970,7 +976,7 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
     B.maxC = maxC; B.maxV = maxV; B.maxF = maxF;
     B.capC = (B.maxC + 7) / 8 * 8; B.capV = (B.maxV + 7) / 8 * 8; B.capF = (B.maxF + 7) / 8 * 8;
     B.capE = maxE;
-    B.capPE = maxPE; B.maxTot = maxC; B.maxAll = maxAll;
+    B.capPE = maxPE; B.maxTot = maxC; B.maxAll = maxAll; B.maxLds = maxLds;
     if (nBlocks * (int64_t)std::max({B.capC, B.capV * B.capPE, 4 * B.capF, B.capE * kFusedCells}) > (int64_t)INT32_MAX) return B;
     B.nBlocks = (int32_t)nBlocks;
     B.nLayerBlocks = (int32_t)first[nLayerRanges];

@@ -167,6 +167,7 @@ struct FusedBlocks {
     // the others in `cells`; hdr2[0] = all staged cells.  Per vertex: its cells' positions in `cells` and the weights, entry-major
     // (capPE x capV per block); count 0 = a patch point, whose value the patch-point kernel has put into the vertex records.
     int32_t capPE = 0, maxTot = 0, maxAll = 0;        // cells per vertex; staged cells incl. extras / without them, of the largest block
+    int32_t maxLds = 0;                               // LDS bytes of the records of the block that needs most (the kernel lays each block out by its own counts)
     RawVec<int32_t> hdr2;     // 4 per block: all staged cells, 0, 0, 0
     RawVec<uint8_t> vCount;   // capV per block
     RawVec<uint16_t> vPos;    // capPE x capV per block
@@ -176,6 +177,8 @@ struct FusedBlocks {
     int64_t facesComputed = 0;     // over all blocks (a face between two blocks is computed by both)
     int64_t cellsStaged = 0, cellsStagedFull = 0, vertsStaged = 0;   // over all blocks: cell records staged (RecA), of which with RecB + centre; vertices formed
 };
+// LDS a block's records may take so that three blocks (+ 3 KB of parked face entries each) share a CU's 160 KB: what an 8x4x4 brick needs
+constexpr int32_t kFusedLdsTarget = 48 * 360 + 32 * 288 + 72 * 225 + 24 * 288;
 constexpr int32_t kFusedCells = 128, kFusedCapC = 320, kFusedCapV = 256, kFusedCapF = 512, kFusedCapTot = 384;   // kFusedCapC: own + across-a-face cells
 FusedBlocks buildFusedBlocks(const StaticData& s);
 

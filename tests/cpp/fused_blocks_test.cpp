@@ -5,7 +5,7 @@
 //     labels; every list is padded to its stride with its last entry;
 //   * the face entries of an own cell are the cell's faces in ascending label with the right side bit, patch faces as ~label;
 //   * a vertex's cell positions are its pointCells in order, with the weights of the vertex kernel's table; patch points have count 0;
-//   * the maxima the LDS layout is sized by are the maxima.
+//   * the maxima are the maxima, and no block of more than 32 cells needs more LDS than lets three blocks share a CU.
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -36,7 +36,7 @@ static void checkMesh(const char* tag, HostMesh& m) {
     CHECK(B.nBlocks > 0, "%s: no blocks", tag);
     if (B.nBlocks == 0) return;
     std::vector<int> ownerBlock((size_t)s.nC, -1);
-    int32_t maxTot = 0, maxAll = 0, maxV = 0, maxF = 0;
+    int32_t maxTot = 0, maxAll = 0, maxV = 0, maxF = 0, maxLds = 0;
     int64_t faces = 0;
     for (int32_t b = 0; b < B.nBlocks; ++b) {
         const int32_t nOwn = B.hdr[4 * b], nAll = B.hdr[4 * b + 1], nV = B.hdr[4 * b + 2], nF = B.hdr[4 * b + 3], nTot = B.hdr2[4 * b];
@@ -44,6 +44,9 @@ static void checkMesh(const char* tag, HostMesh& m) {
         CHECK(nV <= B.capV && nV <= kFusedCapV && nF <= B.capF && nF <= kFusedCapF, "block %d counts", b);
         maxTot = std::max(maxTot, nTot); maxAll = std::max(maxAll, nAll); maxV = std::max(maxV, nV); maxF = std::max(maxF, nF);
         faces += nF;
+        const int32_t lds = 48 * nTot + 32 * nAll + std::max(72 * nV + 24 * nAll, 40 * nF);   // the kernel's layout of this block's records
+        maxLds = std::max(maxLds, lds);
+        CHECK(lds <= kFusedLdsTarget || nOwn <= 32, "block %d needs %d B of LDS with %d own cells", b, lds, nOwn);
         const int32_t* cells = &B.cells[(size_t)b * B.capC];
         const int32_t* verts = &B.verts[(size_t)b * B.capV];
         for (int32_t i = nTot; i < B.capC; ++i) CHECK(cells[i] == cells[nTot - 1], "block %d cell padding", b);
@@ -119,6 +122,7 @@ static void checkMesh(const char* tag, HostMesh& m) {
     }
     CHECK(maxTot == B.maxTot && maxAll == B.maxAll && maxV == B.maxV && maxF == B.maxF, "%s: maxima %d %d %d %d vs %d %d %d %d", tag, maxTot, maxAll, maxV,
           maxF, B.maxTot, B.maxAll, B.maxV, B.maxF);
+    CHECK(maxLds == B.maxLds, "%s: LDS %d vs %d", tag, maxLds, B.maxLds);
     CHECK(faces == B.facesComputed && faces >= 0, "%s: faces computed", tag);
 }
 
