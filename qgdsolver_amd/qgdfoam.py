@@ -128,9 +128,13 @@ class QGDFoamCase:
         L.check(L.lib.qgd_case_update_fluxes(self._h), "qgd_case_update_fluxes")
 
     def step(self, n=1):
+        """n whole steps of an unsharded case; returns when the device has finished (qgd_case_step)"""
         L.check(L.lib.qgd_case_step(self._h, int(n)), "qgd_case_step")
 
     def step_phase(self, phase):
+        """one stream-ordered phase of a step, no host synchronisation (qgd_case_step_phase): 0 assembly, 1 advance (10 + 11: the boundary
+        layer of a shard first), 5 + 6 the assembly split around the mid-step exchange, 3 = one whole step of an unsharded case, 20..35 the
+        implicitDiffusion branch; the exchanges between the phases are the caller's (halo.py)"""
         L.check(L.lib.qgd_case_step_phase(self._h, int(phase)), "qgd_case_step_phase")
 
     def reduction_ptr(self):
