@@ -255,8 +255,7 @@ def dropin_fvsc_line(q, n, reps):
     from qgdsolver_amd import _lib as L
 
     mesh = q.PolyMesh.box(n, n, n)
-    os.environ.setdefault("QGD_FUSED", "0")   # this workload never runs the fused explicit step: no need to build its block tables (seconds of set-up, GBs)
-    dev = q.Device(mesh, fv_schemes={"fvsc": {"default": "GaussVolPoint"}})
+    dev = q.Device(mesh, fv_schemes={"fvsc": {"default": "GaussVolPoint"}}, fused_tables=False)   # stateless operators only
     rng = np.random.default_rng(1)
     nc, nb, nif, npnt = mesh.nCells, mesh.nBoundaryFaces, mesh.nInternalFaces, mesh.nPoints
     fields = [q.volField("U", rng.standard_normal((nc, 3)), rng.standard_normal((nb, 3)))] + \
@@ -568,8 +567,7 @@ def qhd_line(args):
     else:
         mesh = q.PolyMesh.box(n, n, n)
     h = 1.0 / n
-    os.environ.setdefault("QGD_FUSED", "0")   # this workload never runs the fused explicit step: no need to build its block tables (seconds of set-up, GBs)
-    dev = q.Device(mesh)
+    dev = q.Device(mesh, fused_tables=False)   # (the block tables of QGDFoam's fused explicit step: not this workload's)
     opt = qhdfoam.qhd_options(stencil="GaussVolPoint", tauModel="HbyUQHD", aQGD=0.5, UQHD=0.1, rho0=1.0, mu=1e-3, Pr=0.71, beta=3.4e-3,
                               g=(0.0, -9.81, 0.0), deltaT=0.02 * h / 0.1, pTol=1e-8, pMaxIter=300, pRefCell=0,
                               implicitDiffusion=1 if args.implicit_diffusion else 0, implicitTol=1e-10, implicitMaxIter=1000)
@@ -691,8 +689,7 @@ def implicit_line(args):
     n = args.n
     t_setup = time.perf_counter()
     mesh = q.PolyMesh.box(n, n, n)
-    os.environ.setdefault("QGD_FUSED", "0")   # this workload never runs the fused explicit step: no need to build its block tables (seconds of set-up, GBs)
-    dev = q.Device(mesh)
+    dev = q.Device(mesh, fused_tables=False)   # (the block tables of the fused explicit step: not this branch's)
     opt = q.default_options(stencil="GaussVolPoint", deltaT=0.1 / n / 1.3, implicitDiffusion=1, mu=1e-3)
     case = q.QGDFoamCase(dev, opt)
     U, T, p = cases.box_initial_fields(mesh.array("C").reshape(-1, 3))
@@ -781,8 +778,7 @@ def qhd_line_sharded(args):
         owned = n * n * (hi - lo)
         peers = [rank - 1 if rank > 0 else -1, rank + 1 if rank < world - 1 else -1]
     h = 1.0 / n
-    os.environ.setdefault("QGD_FUSED", "0")   # this workload never runs the fused explicit step: no need to build its block tables (seconds of set-up, GBs)
-    dev = q.Device(mesh, device_id=local_rank)
+    dev = q.Device(mesh, device_id=local_rank, fused_tables=False)
     opt = qhdfoam.qhd_options(stencil="GaussVolPoint", tauModel="HbyUQHD", aQGD=0.5, UQHD=0.1, rho0=1.0, mu=1e-3, Pr=0.71, beta=3.4e-3,
                               g=(0.0, -9.81, 0.0), deltaT=0.02 * h / 0.1, pTol=1e-8, pMaxIter=300, pRefCell=0)
     case = qhdfoam.QHDFoamCase(dev, opt)

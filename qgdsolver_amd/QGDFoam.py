@@ -93,9 +93,9 @@ def run(case_dir, n_steps=None, device_id=0, write=True, log=print, renumber="no
         owned = (mesh.array("cellGlobal") >= lo) & (mesh.array("cellGlobal") < hi)
     else:
         mesh, cells, owned = gmesh, old_of_new, np.ones(n_global, dtype=bool)
-    if opt.get("adjustTimeStep") or opt.get("implicitDiffusion") or opt.get("termStencils"):
-        os.environ.setdefault("QGD_FUSED", "0")   # only a fixed-deltaT explicit case with one stencil runs the fused step: no block tables otherwise
-    dev = Device(mesh, device_id, fv_schemes={"fvsc": {"default": opt["stencil"]}})
+    # only a fixed-deltaT explicit case with one stencil runs the fused step: no block tables otherwise
+    eligible = not (opt.get("adjustTimeStep") or opt.get("implicitDiffusion") or opt.get("termStencils"))
+    dev = Device(mesh, device_id, fv_schemes={"fvsc": {"default": opt["stencil"]}}, fused_tables=eligible)
     case = QGDFoamCase(dev, default_options(**opt))
     for i, bc in enumerate(bcs):
         case.set_bc(i, U=bc["U"], T=bc["T"], p=bc["p"])

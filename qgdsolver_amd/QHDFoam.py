@@ -25,8 +25,7 @@ def run(case_dir, n_steps=None, device_id=0, write=True, log=print):
     from .qhdfoam import QHDFoamCase, qhd_options
 
     mesh, opt, fields, bcs = ff.read_qhd_case_setup(case_dir, t0_name)
-    os.environ.setdefault("QGD_FUSED", "0")   # the block tables of QGDFoam's fused explicit step: QHDFoam never runs it (seconds of set-up, GBs)
-    dev = Device(mesh, device_id, fv_schemes={"fvsc": {"default": opt["stencil"]}})
+    dev = Device(mesh, device_id, fv_schemes={"fvsc": {"default": opt["stencil"]}}, fused_tables=False)   # QHDFoam never runs QGDFoam's fused explicit step
     case = QHDFoamCase(dev, qhd_options(**opt))
     for i, bc in enumerate(bcs):
         case.set_bc(i, U=bc["U"], T=bc["T"], p=bc["p"])
