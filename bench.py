@@ -28,7 +28,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import numpy as np  # noqa: E402
 
@@ -49,6 +48,10 @@ FACE_BYTES_PER_POINT = 48
 OWN_BYTES_PER_FACE = 107 if os.environ.get("QGD_SGEO") == "0" else 83   # the bench box has quadrilateral faces only
 OWN_BYTES_PER_CELL = 104
 OWN_BYTES_PER_POINT = 72
+# the fused one-launch step (fusedFaceCellKernel): SURVEY 8(d)'s three rows minus the bytes they hand each other through HBM (see main())
+FUSED_BYTES_PER_FACE = 144
+FUSED_BYTES_PER_CELL = 48 + 120
+FUSED_BYTES_PER_POINT = 100
 # whole explicit step, per cell-step on a hex box: vertex interp 196 + face kernel 648 + cell update 240
 STEP_BYTES_PER_CELL = 1084
 POINT_BYTES_PER_CELL = 196
@@ -93,15 +96,16 @@ def _cpu_rank_worker(n, steps, sync_dir, idx):
     """One single-threaded "rank" of the CPU baseline (child process started by cpu_baseline): the oracle on its own
     n^3 box.  Ranks start their timed region together through a ready/go file handshake."""
     import qgdsolver_amd as q
-    import cases
-    from oracle import OracleCase, OracleMesh
+    from qgdsolver_amd.synthetic import box_initial_fields
+    sys.path.insert(0, os.path.join(ROOT, "tests"))   # tests/oracle.py, the ctypes wrapper of oracle/: the cpu_baseline leg is the one part of
+    from oracle import OracleCase, OracleMesh           # this file that may touch the checker
 
     mesh = q.PolyMesh.box(n, n, n)
     om = OracleMesh(mesh.primitives())
     h = 1.0 / n
     opt = q.default_options(stencil="GaussVolPoint", deltaT=0.1 * h / 1.3)
     oc = OracleCase(om, opt)
-    U, T, p = cases.box_initial_fields(mesh.array("C").reshape(-1, 3))
+    U, T, p = box_initial_fields(mesh.array("C").reshape(-1, 3))
     oc.set_fields(U, T, p)
     oc.step(1)
 
@@ -562,7 +566,7 @@ def qhd_line(args):
     n = args.n
     t_setup = time.perf_counter()
     if args.irregular:
-        from test_config5_gpu import c5_mesh
+        from qgdsolver_amd.synthetic import c5_mesh
         mesh = c5_mesh(n, 64 ** 3)
     else:
         mesh = q.PolyMesh.box(n, n, n)
@@ -682,7 +686,7 @@ def implicit_line(args):
     """python bench.py --workload implicit [--edge N]: Mcell-steps/s of the QGDFoam step with implicitDiffusion true, the reference's
     default branch [QGDThermo.C L70-82]: the explicit flux assembly without the viscous parts + the U and e systems by Jacobi-PCG."""
     import qgdsolver_amd as q
-    import cases
+    from qgdsolver_amd.synthetic import box_initial_fields
 
     if q.device_count() < 1:
         raise RuntimeError("bench.py needs a HIP device: qgdsolver_amd has no CPU fallback")
@@ -692,7 +696,7 @@ def implicit_line(args):
     dev = q.Device(mesh, fused_tables=False)   # (the block tables of the fused explicit step: not this branch's)
     opt = q.default_options(stencil="GaussVolPoint", deltaT=0.1 / n / 1.3, implicitDiffusion=1, mu=1e-3)
     case = q.QGDFoamCase(dev, opt)
-    U, T, p = cases.box_initial_fields(mesh.array("C").reshape(-1, 3))
+    U, T, p = box_initial_fields(mesh.array("C").reshape(-1, 3))
     case.set_fields(U, T, p)
     del U, T, p
     nc = mesh.nCells
@@ -761,7 +765,7 @@ def qhd_line_sharded(args):
     n = args.n
     t_setup = time.perf_counter()
     if args.irregular:
-        from test_config5_gpu import c5_mesh
+        from qgdsolver_amd.synthetic import c5_mesh
         g = c5_mesh(n, 64 ** 3)
         mesh = g.shard(world, rank)
         n_global = g.nCells
@@ -902,7 +906,7 @@ def main():
     import qgdsolver_amd as q
     from qgdsolver_amd import _lib as L
     from qgdsolver_amd.halo import SlabHalo, slab_range
-    import cases
+    from qgdsolver_amd.synthetic import box_initial_fields
 
     if not torch.cuda.is_available() or q.device_count() < 1:
         raise RuntimeError("bench.py needs a HIP device: qgdsolver_amd has no CPU fallback")
@@ -930,7 +934,7 @@ def main():
     opt = q.default_options(stencil="GaussVolPoint", deltaT=0.1 * h / 1.3)  # fixed deltaT = 0.1 h / (c+|U|)_max
     case = q.QGDFoamCase(dev, opt)
     C = mesh.array("C").reshape(-1, 3)
-    U, T, p = cases.box_initial_fields(C)
+    U, T, p = box_initial_fields(C)
     # the noise must be a function of the GLOBAL cell label so that shards agree with the unsharded run
     rng = np.random.Generator(np.random.MT19937(12345))
     noise = rng.uniform(-1e-3, 1e-3, size=n * n * n)
@@ -1091,14 +1095,34 @@ def main():
     face_ms = kt["face"]["ms_avg"]
     ft = dev.face_tiles()
     fused = case.fused_info()
+    if fused["fused"]:
+        fused["mean_cells_per_block"] = owned_cells / fused["blocks"]
+    # what a cut costs the blocks, and the set-up of N ranks sharing one host's cores: every rank's figures in rank 0's line
+    per_rank = None
+    if world > 1:
+        mine = torch.tensor([float(fused["blocks"]), float(fused.get("layerBlocks", 0)), float(owned_cells), t_setup,
+                             float(fused.get("facesComputed", 0)), float(fused.get("cellsStaged", 0))], dtype=torch.float64,
+                            device="cpu" if ctrl_host else "cuda")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [{"blocks": int(e[0]), "layer_blocks": int(e[1]), "owned_cells": int(e[2]),
+                     "mean_cells_per_block": (float(e[2]) / float(e[0])) if float(e[0]) else None, "setup_s": float(e[3]),
+                     "faces_computed_per_cell": float(e[4]) / float(e[2]), "cell_records_staged_per_cell": float(e[5]) / float(e[2])}
+                    for e in (x.cpu() for x in every)]
     if fused["fused"] and kt["face"]["launches"]:
         # per STEP: on a shard the fused kernel runs as two launches (the boundary-layer blocks, then the rest)
         face_ms = kt["face"]["ms_total"] / min(args.steps, 20)
+    unfused_bytes = None
     if fused["fused"]:
-        # ONE launch does the work of all three rows of SURVEY 8(d) -- vertex interpolation, face kernel, cell update: the algorithmic bytes of
-        # the whole step (what the rows hand each other through HBM -- 48 B per vertex, 40 B per face out, 240 B per cell in -- is part of
-        # that figure although this kernel never moves it)
-        face_bytes += (CELL_BYTES_PER_CELL + POINT_BYTES_PER_CELL) * n_c
+        # ONE launch does the work of all three rows of SURVEY 8(d) -- vertex interpolation (P), face kernel (F), cell update (C).  Its
+        # ALGORITHMIC bytes are those rows' bytes WITHOUT what the rows hand each other through HBM, because that is exactly what the fusion
+        # removes and never moves: F: 144 B per face in (its 40 B of net fluxes stay in LDS) + every cell record once 48 B; P: 8 weights 64 +
+        # 8 labels 32 + offset 4 = 100 B per vertex (the cell records are the ones F counts; the 48 B vertex record is neither written nor read
+        # back); C: face ids + signs 24 + V 8 + 5 old conserved 40 + 6 primitives written 48 = 120 B per cell (the 120 B of fluxes come out of LDS).
+        # 3 x 144 + 48 + 100 + 120 = 700 B per cell-step on a hex box; the three-kernel figure (1084 B, rounds 1-5's `achieved`) stays beside
+        # it as `equivalent_unfused_*`: how fast the STEP is against the reference's own data flow at 8 TB/s -- not a statement about HBM.
+        unfused_bytes = face_bytes + (CELL_BYTES_PER_CELL + POINT_BYTES_PER_CELL) * n_c
+        face_bytes = FUSED_BYTES_PER_FACE * n_if + FUSED_BYTES_PER_CELL * n_c + FUSED_BYTES_PER_POINT * n_p
         face_kernel_name = (f"fusedFaceCellKernel ({fused['blocks']} blocks of <= 128 cells; {fused['facesComputed']} faces computed for "
                             f"{n_if} internal faces, {fused['verticesFormed']} vertex values formed for {n_p} vertices; vertex values, faces and "
                             "cell update are ONE launch)")
@@ -1159,6 +1183,11 @@ def main():
                 "avg_launch_ms": face_ms,
                 "own_layout_bytes_per_launch": own_bytes,
                 "own_layout_frac": (own_bytes / (face_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if face_ms else None,
+                # fused step only: SURVEY 8(d)'s three-kernel bytes (1084 B per cell-step, incl. the hand-over bytes the fused launch never moves)
+                # over the same launch time -- the figure rounds 1-5 reported as `achieved` / `frac`
+                "equivalent_unfused_bytes_per_launch": unfused_bytes,
+                "equivalent_unfused_frac": (unfused_bytes / (face_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (unfused_bytes and face_ms) else None,
+                "moved_frac": None,   # traffic / avg_launch_ms / peak: filled in below when counters of this workload exist
             },
             "other_kernels": {
                 "pointInterpRecKernel": {"algorithmic_bytes_per_launch": POINT_BYTES_PER_CELL * n_c, "avg_launch_ms": kt["point"]["ms_avg"],
@@ -1171,7 +1200,8 @@ def main():
             "step_roofline_frac": STEP_BYTES_PER_CELL * owned_cells * args.steps / elapsed / (HBM_PEAK_GBS * 1e9),
             "kernels_ms_avg": {k: v["ms_avg"] for k, v in kt.items()},
             "device_bytes": case.device_bytes(),
-            "setup_s": t_setup,
+            "setup_s": t_setup if per_rank is None else max(r["setup_s"] for r in per_rank),   # N > 1: the slowest rank's (they share the host's cores)
+            "per_rank": per_rank,
             "min_rho": info["minRho"],
         }
         if checksum is not None:
@@ -1189,6 +1219,8 @@ def main():
                     # a constant read from profiles/pmc_traffic.json (counters of the builder's profiling run of this
                     # workload), not counters of THIS run
                     out["roofline"]["traffic_is_static"] = True
+                    if face_ms:   # bytes the memory system really moved per launch (L2 <-> fabric) over the launch time, against the peak
+                        out["roofline"]["moved_frac"] = tr[key]["bytes_per_launch"] / (face_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
                     # measured HBM-side bytes / algorithmic bytes, per kernel (1.0 = nothing fetched twice)
                     out["roofline"]["kernel_traffic_ratio"] = {
                         "face": tr[key]["bytes_per_launch"] / face_bytes,

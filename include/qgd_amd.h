@@ -209,6 +209,16 @@ int qgd_mesh_get(qgd_mesh_t m, const char* name, void* out, int64_t outBytes);
 /* Upload the mesh to HIP device `deviceId` and build the static stencil data.
  * Fails with QGD_ERR_NO_DEVICE when no GPU is present. */
 int qgd_device_create(qgd_mesh_t m, int deviceId, qgd_device_t* out);
+/* The same with the caller's choice about the block tables of QGDFoam's fused explicit step (qgd_case_fused_info; 3-D meshes only: ~30 KB per
+ * block of 128 cells on the device and seconds of host set-up at tens of millions of cells), instead of the QGD_FUSED environment variable:
+ *   QGD_DEVICE_NO_FUSED_TABLES   do not build them: a device whose cases never run the fused step (QHDFoam, implicitDiffusion, adjustTimeStep
+ *                                with QGD_FUSED_ADJUST=0, reduced / leastSquares stencils) -- every case then steps with the separate kernels;
+ *   QGD_DEVICE_FUSED_ANY_BLOCKS  build them and use them whatever the blocks look like (the default leaves a mesh whose blocks average under
+ *                                88 cells to the separate kernels, which are faster there).
+ * flags = 0 is qgd_device_create. */
+#define QGD_DEVICE_NO_FUSED_TABLES 1
+#define QGD_DEVICE_FUSED_ANY_BLOCKS 2
+int qgd_device_create_with(qgd_mesh_t m, int deviceId, int32_t flags, qgd_device_t* out);
 /* Ownership (fvscStencil_8C_source.html L57, L104-117: the reference's stencils live in the mesh's registry and die with it):
  * every case (qgd_case_t, qgd_qhd_case_t) keeps a pointer to the device it was created on and uses its stream until it is
  * freed, so free the cases BEFORE their device: qgd_device_free returns QGD_ERR_INVALID (and frees nothing) while cases created on
@@ -597,7 +607,9 @@ int qgd_case_info(qgd_case_t c, double info[6]);
  * kernel and the cell kernel are one launch.  Same arithmetic, bit-identical states.  info[0] = 1 when in use, [1] = blocks, [2] = internal
  * faces computed per step (faces on a block's surface are computed by the block on either side), [3] = LDS bytes per workgroup, [4] = cell
  * records staged per step over all blocks, [5] = of which with their second record and centre (own cells + cells across a face), [6] =
- * vertex values formed per step over all blocks, [7] = 0.  qgd_case_update_fluxes and every other branch keep the separate kernels. */
+ * vertex values formed per step over all blocks, [7] = on a shard, the leading blocks that hold the cells a neighbouring rank waits for (phase 10
+ * launches them, phase 11 the others; whole bricks, so they hold other owned cells too).  Owned cells / info[1] = mean cells per block: 128
+ * on a box its bricks divide, 123 on a 50-plane slab between two cuts.  qgd_case_update_fluxes and every other branch keep the separate kernels. */
 int qgd_case_fused_info(qgd_case_t c, int64_t info[8]);
 /* The linear solves of the implicitDiffusion branch in the last step (what OpenFOAM prints as "Solving for Ux, Initial
  * residual = ..., Final residual = ..., No Iterations ...") [QGDUEqn_8H_source.html L54-68, QGDEEqn_8H_source.html L53-61]:

@@ -82,6 +82,7 @@ SIGNATURES = {
     "qgd_mesh_sizes": (C.c_int, [handle, c_int64_p]),
     "qgd_mesh_get": (C.c_int, [handle, C.c_char_p, C.c_void_p, C.c_int64]),
     "qgd_device_create": (C.c_int, [handle, C.c_int, handle_p]),
+    "qgd_device_create_with": (C.c_int, [handle, C.c_int, C.c_int32, handle_p]),
     "qgd_device_free": (C.c_int, [handle]),
     "qgd_stencil_lookup": (C.c_int, [handle, C.c_char_p, C.POINTER(C.c_int)]),
     "qgd_fvsc_grad_s": (C.c_int, [handle, C.c_int, c_double_p, c_double_p, c_double_p]),
@@ -204,6 +205,7 @@ ABI_VERSION = int(_sizes[3])
 QGD_OK = 0
 ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_SCHEME, ERR_UNKNOWN_NAME, ERR_NOT_IMPLEMENTED = -1, -2, -3, -4, -5, -6
 PATCH_GENERIC, PATCH_EMPTY, PATCH_SYMMETRYPLANE, PATCH_SYMMETRY, PATCH_WEDGE, PATCH_CYCLIC, PATCH_HALO = range(7)
+DEVICE_NO_FUSED_TABLES, DEVICE_FUSED_ANY_BLOCKS = 1, 2   # flags of qgd_device_create_with
 BC_ZEROGRADIENT, BC_FIXEDVALUE, BC_SLIP, BC_QGDFLUX, BC_NONE, BC_QHDFLUX = range(6)
 FVSC_REDUCED, FVSC_LEASTSQUARES, FVSC_GAUSSVOLPOINT = range(3)
 FLUX_LINEAR, FLUX_UPWIND = range(2)

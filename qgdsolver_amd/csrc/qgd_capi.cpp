@@ -628,7 +628,16 @@ int qgd_mesh_halo_slots(qgd_mesh_t mh, int32_t* nSlots) {
 }
 
 // ---- device ----------------------------------------------------------------------
-int qgd_device_create(qgd_mesh_t mh, int deviceId, qgd_device_t* out) {
+static int deviceCreate(qgd_mesh_t mh, int deviceId, int fusedChoice, qgd_device_t* out);
+int qgd_device_create(qgd_mesh_t mh, int deviceId, qgd_device_t* out) { return deviceCreate(mh, deviceId, -1, out); }
+int qgd_device_create_with(qgd_mesh_t mh, int deviceId, int32_t flags, qgd_device_t* out) {
+    if (flags & ~(QGD_DEVICE_NO_FUSED_TABLES | QGD_DEVICE_FUSED_ANY_BLOCKS)) return fail(QGD_ERR_INVALID, "qgd_device_create_with: unknown flag");
+    if ((flags & QGD_DEVICE_NO_FUSED_TABLES) && (flags & QGD_DEVICE_FUSED_ANY_BLOCKS))
+        return fail(QGD_ERR_INVALID, "qgd_device_create_with: QGD_DEVICE_NO_FUSED_TABLES and QGD_DEVICE_FUSED_ANY_BLOCKS exclude each other");
+    return deviceCreate(mh, deviceId, (flags & QGD_DEVICE_NO_FUSED_TABLES) ? 0 : ((flags & QGD_DEVICE_FUSED_ANY_BLOCKS) ? 2 : -1), out);
+}
+// fusedChoice: -1 = QGD_FUSED of the environment (default 1), 0 = no block tables, 2 = blocks of any size
+static int deviceCreate(qgd_mesh_t mh, int deviceId, int fusedChoice, qgd_device_t* out) {
     QGD_TRY
     if (!mh || !out) return fail(QGD_ERR_INVALID, "qgd_device_create: null argument");
     int n = 0;
@@ -719,7 +728,8 @@ int qgd_device_create(qgd_mesh_t mh, int deviceId, qgd_device_t* out) {
         {
             // cell blocks of the fused face + cell kernel (QGD_FUSED, qgd_setup.hpp FusedBlocks): 3-D unsharded meshes whose tiles were built
             static const int kFusedModes[] = {0, 1, 2};
-            const int fusedMode = envChoice("QGD_FUSED", 1, kFusedModes, 3);   // 2: whatever the blocks look like (tests, probes)
+            // 2: whatever the blocks look like (tests, probes); the caller's explicit choice (qgd_device_create_with) wins over the environment
+            const int fusedMode = fusedChoice >= 0 ? fusedChoice : envChoice("QGD_FUSED", 1, kFusedModes, 3);
             if (fusedMode != 0) {
                 FusedBlocks fb = buildFusedBlocks(s);
                 // LDS per workgroup: RecA of every staged cell, RecB of the own + across-a-face cells, then vertex records + all coordinates,
@@ -2984,7 +2994,7 @@ int qgd_case_fused_info(qgd_case_t c, int64_t info[8]) {
     info[4] = c->fused ? c->dev->fusedCellsStaged : 0;
     info[5] = c->fused ? c->dev->fusedCellsStagedFull : 0;
     info[6] = c->fused ? c->dev->fusedVertsStaged : 0;
-    info[7] = 0;
+    info[7] = c->fused ? v.fuLayerBlocks : 0;
     return QGD_OK;
 }
 

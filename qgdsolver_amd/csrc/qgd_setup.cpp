@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <stdexcept>
 #include <unordered_map>
@@ -700,10 +701,6 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
     const int64_t nC = s.nC, nIF = s.nIF;
     if (nC == 0 || nIF == 0 || s.nGeomD != 3) return B;
     if (3 * (int64_t)s.nC > INT32_MAX || 3 * (int64_t)s.nP > INT32_MAX) return B;
-    // Morton order of the cell centres on a lattice of the mean cell spacing
-    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-    for (int64_t c = 0; c < nC; ++c)
-        for (int d = 0; d < 3; ++d) { lo[d] = std::min(lo[d], s.Cc[3 * c + d]); hi[d] = std::max(hi[d], s.Cc[3 * c + d]); }
     // lattice spacing per axis: the mean distance of the two cell centres across the faces that look along that axis (dx, dy, dz on a box,
     // whatever its cells' aspect ratio); the mean cell size where an axis has no such faces
     double vol = 0.0;
@@ -721,27 +718,86 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
         }
         for (int d = 0; d < 3; ++d) if (cnt[d] > 0 && sum[d] > 0.0) h[d] = sum[d] / (double)cnt[d];
     }
-    // a shard: its ghost cells belong to no block (the halo exchange writes them), and the cells a neighbour waits for (role 2) form their
-    // own blocks, in front of the others, so that the step can advance them first and overlap the exchange with the rest
+    // a shard: its ghost cells belong to no block (the halo exchange writes them).  The lattice is anchored at the OWNED cells -- a ghost
+    // plane in front of them must not shift every brick off the shard's own planes (round 5 took the minimum over all cells: a slab between
+    // two cuts started at lattice index 1 and averaged 106 cells per block instead of 128).
     std::vector<int32_t> ownedCells;
     ownedCells.reserve((size_t)nC);
-    int64_t nLayer = 0;
     for (int64_t c = 0; c < nC; ++c) {
         const int role = s.ghost.empty() ? 0 : s.ghost[c];
         if (role == 1) continue;
         ownedCells.push_back((int32_t)c);
-        if (role == 2) ++nLayer;
     }
     const int64_t nOwned = (int64_t)ownedCells.size();
     if (nOwned == 0) return B;
+    double lo[3] = {1e300, 1e300, 1e300};
+    for (int64_t i = 0; i < nOwned; ++i)
+        for (int d = 0; d < 3; ++d) lo[d] = std::min(lo[d], s.Cc[3 * (size_t)ownedCells[i] + d]);
+    auto latticeOf = [&](int32_t c, int d) {
+        return (int64_t)std::min(2097151.0, std::max(0.0, std::floor((s.Cc[3 * (size_t)c + d] - lo[d]) / h[d] + 0.25)));
+    };
+    // Bricks of AT MOST 8 x 4 x 4 lattice cells whose extents divide the owned lattice evenly: an axis of n lattice cells is cut into
+    // ceil(n / b) segments of floor / ceil(n / segments) cells (400 -> 50 x 8; a 50-plane slab -> 13 segments of 3 or 4 planes: 123 cells per
+    // brick instead of twelve full layers and a flat two-plane rest).  Key = Morton code of the brick coordinates above the position inside
+    // the brick, so that bricks which are neighbours in space are neighbours in the launch order, as before.
+    int64_t nLat[3] = {1, 1, 1};
+    for (int64_t i = 0; i < nOwned; ++i)
+        for (int d = 0; d < 3; ++d) nLat[d] = std::max(nLat[d], latticeOf(ownedCells[i], d) + 1);
+    // The brick is 8 x 4 x 4 unless another shape fills its blocks markedly better on this lattice (a 50^3 box: 7 x 13 x 13 bricks of 106 cells,
+    // or 10^3 cubes of 5^3 = 125): among the shapes of at most 128 cells whose full brick fits the LDS budget of three blocks per CU, the one
+    // with the most cells per brick wins if it beats 8 x 4 x 4 by more than 5 %.  QGD_FUSED_BRICK=bx,by,bz forces one (probes).
+    int64_t kBrick[3] = {8, 4, 4};
+    {
+        auto fits = [](int64_t bx, int64_t by, int64_t bz) {
+            const int64_t own = bx * by * bz, surf = bx * by + by * bz + bx * bz;
+            const int64_t nAll = own + 2 * surf, tot = nAll + 4 * (bx + by + bz) + 8, nV = (bx + 1) * (by + 1) * (bz + 1), nF = 3 * own + surf;
+            return own <= kFusedCells && nAll <= kFusedCapC && tot <= kFusedCapTot && nV <= kFusedCapV && nF <= kFusedCapF &&
+                   48 * tot + 32 * nAll + std::max(72 * nV + 24 * nAll, 40 * nF) <= (int64_t)kFusedLdsTarget;
+        };
+        auto meanCells = [&](int64_t bx, int64_t by, int64_t bz) {
+            const int64_t b[3] = {bx, by, bz};
+            double m = 1.0;
+            for (int d = 0; d < 3; ++d) m *= (double)nLat[d] / (double)((nLat[d] + b[d] - 1) / b[d]);
+            return m;
+        };
+        int forced[3] = {0, 0, 0};
+        const char* e = std::getenv("QGD_FUSED_BRICK");
+        if (e && std::sscanf(e, "%d,%d,%d", &forced[0], &forced[1], &forced[2]) == 3 && forced[0] >= 1 && forced[0] <= 16 && forced[1] >= 1 &&
+            forced[1] <= 16 && forced[2] >= 1 && forced[2] <= 16 && fits(forced[0], forced[1], forced[2])) {
+            for (int d = 0; d < 3; ++d) kBrick[d] = forced[d];
+        } else {
+            double best = meanCells(8, 4, 4) * 1.05;
+            for (int64_t bx = 3; bx <= 8; ++bx)
+                for (int64_t by = 3; by <= 8; ++by)
+                    for (int64_t bz = 3; bz <= 8; ++bz) {
+                        if (!fits(bx, by, bz)) continue;
+                        const double m = meanCells(bx, by, bz);
+                        if (m > best) { best = m; kBrick[0] = bx; kBrick[1] = by; kBrick[2] = bz; }
+                    }
+        }
+    }
+    int lbits[3];   // bits of the position inside a brick, per axis
+    for (int d = 0; d < 3; ++d) { lbits[d] = 0; while ((1ll << lbits[d]) < kBrick[d]) ++lbits[d]; }
+    const int lshift = lbits[0] + lbits[1] + lbits[2];
+    std::vector<int32_t> segOf[3], segLo[3];
+    for (int d = 0; d < 3; ++d) {
+        const int64_t n = nLat[d], ns = (n + kBrick[d] - 1) / kBrick[d];
+        segOf[d].resize((size_t)n); segLo[d].resize((size_t)ns + 1);
+        for (int64_t i = 0; i <= ns; ++i) segLo[d][(size_t)i] = (int32_t)(i * n / ns);
+        for (int64_t i = 0; i < ns; ++i)
+            for (int32_t q = segLo[d][(size_t)i]; q < segLo[d][(size_t)i + 1]; ++q) segOf[d][(size_t)q] = (int32_t)i;
+    }
     std::vector<std::pair<uint64_t, int32_t>> key((size_t)nOwned);
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < nOwned; ++i) {
         const int32_t c = ownedCells[i];
-        uint64_t q[3];
-        for (int d = 0; d < 3; ++d) q[d] = (uint64_t)std::min(2097151.0, std::max(0.0, std::floor((s.Cc[3 * (size_t)c + d] - lo[d]) / h[d] + 0.25)));
-        const uint64_t rest = (!s.ghost.empty() && s.ghost[c] == 2) ? 0ull : 1ull << 63;
-        key[i] = {rest | spread21(q[0]) | spread21(q[1]) << 1 | spread21(q[2]) << 2, c};
+        uint64_t b[3], l[3];
+        for (int d = 0; d < 3; ++d) {
+            const int64_t q = latticeOf(c, d);
+            b[d] = (uint64_t)segOf[d][(size_t)q];
+            l[d] = (uint64_t)(q - segLo[d][b[d]]);
+        }
+        key[i] = {(spread21(b[0]) | spread21(b[1]) << 1 | spread21(b[2]) << 2) << lshift | l[0] | l[1] << lbits[0] | l[2] << (lbits[0] + lbits[1]), c};
     }
     std::vector<int32_t>().swap(ownedCells);
     // (sorted in runs, then merged: keeps the host peak at one copy and uses the cores)
@@ -851,15 +907,15 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
         }
         return true;
     };
-    // ranges of the sorted cells: the boundary layer first, then the rest; no range straddles the two.  A range that does not fit the caps
+    // ranges of the sorted cells.  A range that does not fit the caps
     // is halved -- and a mesh whose 128-cell ranges mostly do not fit (cells with more than six faces: triangles, polyhedra) would end up with
     // 64-cell blocks whose second face pass runs nearly empty; so the ranges get shorter in steps until few of them need the cut.
-    // First choice: the lattice BRICKS themselves -- the cells whose Morton keys share everything above their lowest seven bits (8x4x4 lattice
+    // First choice: the lattice BRICKS themselves -- the cells whose Morton keys share everything above the position inside the brick (8x4x4 lattice
     // cells) --, whatever the mesh's extents and wherever a shard's ghost planes sit; bricks of one 16x8x8 parent that are short of cells (the
     // rim of the mesh, a shard's one-plane boundary layer) are joined up to 128 cells, a brick with more is cut evenly.  Runs of a fixed
     // count instead (second choice, lengths 112 ... 64) drift across the bricks as soon as one brick is short.
     std::vector<int64_t> rangeStart;   // nRanges + 1 positions in the sorted cells
-    int64_t nLayerRanges = 0, nRanges = 0;
+    int64_t nRanges = 0;
     auto brickRanges = [&]() {
         rangeStart.clear();
         auto part = [&](int64_t p0, int64_t p1) {   // [p0, p1) of the sorted cells, all of one role
@@ -868,9 +924,9 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
             auto flush = [&]() { if (curStart >= 0) rangeStart.push_back(curStart); curStart = -1; };
             int64_t i = p0;
             while (i < p1) {
-                const uint64_t brick = key[i].first >> 7;
+                const uint64_t brick = key[i].first >> lshift;
                 int64_t j = i + 1;
-                while (j < p1 && (key[j].first >> 7) == brick) ++j;
+                while (j < p1 && (key[j].first >> lshift) == brick) ++j;
                 const int64_t sz = j - i;
                 if (sz > kFusedCells) {
                     flush();
@@ -886,23 +942,18 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
             }
             flush();
         };
-        part(0, nLayer);
-        nLayerRanges = (int64_t)rangeStart.size();
-        part(nLayer, nOwned);
+        part(0, nOwned);
         nRanges = (int64_t)rangeStart.size();
         rangeStart.push_back(nOwned);
     };
     auto runRanges = [&](int64_t len) {
         rangeStart.clear();
-        for (int64_t p = 0; p < nLayer; p += len) rangeStart.push_back(p);
-        nLayerRanges = (int64_t)rangeStart.size();
-        for (int64_t p = nLayer; p < nOwned; p += len) rangeStart.push_back(p);
+        for (int64_t p = 0; p < nOwned; p += len) rangeStart.push_back(p);
         nRanges = (int64_t)rangeStart.size();
         rangeStart.push_back(nOwned);
     };
     auto rangeOf = [&](int64_t r) {
-        const int64_t e = (r + 1 == nLayerRanges) ? nLayer : rangeStart[r + 1];
-        return std::pair<int64_t, int64_t>{rangeStart[r], e};
+        return std::pair<int64_t, int64_t>{rangeStart[r], rangeStart[r + 1]};
     };
     // Pass 1: where each range is cut (nearly always: not at all) and what the largest block needs.  Pass 2 builds every block again,
     // straight into the padded tables: twice the arithmetic instead of half a million small vectors kept between the passes.
@@ -913,7 +964,7 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
     int32_t maxC = 0, maxV = 0, maxF = 0, maxE = 1, maxAll = 0, maxPE = 1, maxLds = 0;
     // keep the first way of cutting ranges whose blocks average 104 cells or more, else the one with the largest average
     struct Kept { std::vector<int64_t> rangeStart; std::vector<int32_t> nOf; std::vector<std::vector<std::pair<int64_t, int64_t>>> cuts;
-                  int64_t nLayerRanges = 0, nRanges = 0, facesDone = 0, cellsTot = 0, cellsAll = 0, vertsTot = 0, blocks = 0;
+                  int64_t nRanges = 0, facesDone = 0, cellsTot = 0, cellsAll = 0, vertsTot = 0, blocks = 0;
                   int32_t maxC = 0, maxV = 0, maxF = 0, maxE = 1, maxAll = 0, maxPE = 1, maxLds = 0; } best;
     for (const int64_t len : {(int64_t)0, (int64_t)112, (int64_t)96, (int64_t)80, (int64_t)64}) {
         if (len == 0) brickRanges(); else runRanges(len);
@@ -928,6 +979,10 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
             OneBlock o;
 #pragma omp for schedule(dynamic, 64)
             for (int64_t r = 0; r < nRanges; ++r) {
+                bool stop;
+#pragma omp atomic read
+                stop = failed;
+                if (stop) continue;
                 std::vector<std::pair<int64_t, int64_t>> work{rangeOf(r)}, done;
                 while (!work.empty()) {
                     const auto [b0, b1] = work.back();
@@ -945,7 +1000,11 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
                         cellsTot += (int64_t)o.cells.size(); cellsAll += o.nAll; vertsTot += (int64_t)o.verts.size();
                         continue;
                     }
-                    if (b1 - b0 == 1) { failed = true; break; }   // one cell with more faces / vertices than a block holds
+                    if (b1 - b0 == 1) {   // one cell with more faces / vertices than a block holds
+#pragma omp atomic write
+                        failed = true;
+                        break;
+                    }
                     const int64_t mid = (b0 + b1) / 2;
                     work.push_back({mid, b1});
                     work.push_back({b0, mid});
@@ -958,28 +1017,49 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
         int64_t blocks = 0;
         for (int64_t r = 0; r < nRanges; ++r) blocks += nOf[r];
         if (best.blocks == 0 || blocks < best.blocks) {
-            best.rangeStart = rangeStart; best.nOf = nOf; best.cuts = cuts; best.nLayerRanges = nLayerRanges; best.nRanges = nRanges;
+            best.rangeStart = rangeStart; best.nOf = nOf; best.cuts = cuts; best.nRanges = nRanges;
             best.facesDone = facesDone; best.cellsTot = cellsTot; best.cellsAll = cellsAll; best.vertsTot = vertsTot; best.blocks = blocks;
             best.maxC = maxC; best.maxV = maxV; best.maxF = maxF; best.maxE = maxE; best.maxAll = maxAll; best.maxPE = maxPE; best.maxLds = maxLds;
         }
         if (blocks * 104 <= nOwned) break;
     }
     if (!failed) {
-        rangeStart.swap(best.rangeStart); nOf.swap(best.nOf); cuts.swap(best.cuts); nLayerRanges = best.nLayerRanges; nRanges = best.nRanges;
+        rangeStart.swap(best.rangeStart); nOf.swap(best.nOf); cuts.swap(best.cuts); nRanges = best.nRanges;
         facesDone = best.facesDone; cellsTot = best.cellsTot; cellsAll = best.cellsAll; vertsTot = best.vertsTot;
         maxC = best.maxC; maxV = best.maxV; maxF = best.maxF; maxE = best.maxE; maxAll = best.maxAll; maxPE = best.maxPE; maxLds = best.maxLds;
     }
     if (failed) return B;
-    std::vector<int64_t> first((size_t)nRanges + 1, 0);
-    for (int64_t r = 0; r < nRanges; ++r) first[r + 1] = first[r] + nOf[r];
-    const int64_t nBlocks = first[nRanges];
+    // a shard: the blocks that hold a cell a neighbour waits for (role 2) come first, so that the step can advance them before the others and
+    // overlap the exchange with the rest (qgd_capi.cpp stepAdvance).  They are whole bricks like every other block -- round 5 gave the
+    // one-plane boundary layer blocks of its own, flat 8 x 8 x 1 ones of 64 cells that staged three records per cell.
+    std::vector<std::pair<int64_t, int64_t>> blk;   // every block's range of the sorted cells, in range order
+    for (int64_t r = 0; r < nRanges; ++r) {
+        if (nOf[r] == 1) blk.push_back(rangeOf(r));
+        else blk.insert(blk.end(), cuts[r].begin(), cuts[r].end());
+    }
+    const int64_t nBlocks = (int64_t)blk.size();
+    std::vector<uint8_t> layerBlock((size_t)nBlocks, 0);
+    if (!s.ghost.empty()) {
+#pragma omp parallel for schedule(static)
+        for (int64_t b = 0; b < nBlocks; ++b)
+            for (int64_t i = blk[b].first; i < blk[b].second; ++i) if (s.ghost[key[i].second] == 2) { layerBlock[b] = 1; break; }
+    }
+    std::vector<int64_t> first((size_t)nBlocks, 0);   // where block b of the range order goes
+    int64_t nLayerBlocks = 0;
+    {
+        int64_t pos = 0;
+        for (int pass = 1; pass >= 0; --pass) {
+            for (int64_t b = 0; b < nBlocks; ++b) if (layerBlock[b] == pass) first[b] = pos++;
+            if (pass == 1) nLayerBlocks = pos;
+        }
+    }
     B.maxC = maxC; B.maxV = maxV; B.maxF = maxF;
     B.capC = (B.maxC + 7) / 8 * 8; B.capV = (B.maxV + 7) / 8 * 8; B.capF = (B.maxF + 7) / 8 * 8;
     B.capE = maxE;
     B.capPE = maxPE; B.maxTot = maxC; B.maxAll = maxAll; B.maxLds = maxLds;
     if (nBlocks * (int64_t)std::max({B.capC, B.capV * B.capPE, 4 * B.capF, B.capE * kFusedCells}) > (int64_t)INT32_MAX) return B;
     B.nBlocks = (int32_t)nBlocks;
-    B.nLayerBlocks = (int32_t)first[nLayerRanges];
+    B.nLayerBlocks = (int32_t)nLayerBlocks;
     B.facesComputed = facesDone; B.cellsStaged = cellsTot; B.cellsStagedFull = cellsAll; B.vertsStaged = vertsTot;
     B.hdr.resize(4 * (size_t)nBlocks);
     B.hdr2.resize(4 * (size_t)nBlocks);
@@ -996,11 +1076,11 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
         std::vector<SmallMap> maps(3);
         OneBlock o;
 #pragma omp for schedule(dynamic, 64)
-        for (int64_t r = 0; r < nRanges; ++r) {
-            for (int32_t k = 0; k < nOf[r]; ++k) {
-                const auto [b0, b1] = nOf[r] == 1 ? rangeOf(r) : cuts[r][k];
+        for (int64_t ib = 0; ib < nBlocks; ++ib) {
+            {
+                const auto [b0, b1] = blk[ib];
                 tryBlock(b0, b1, o, maps[0], maps[1], maps[2]);
-                const size_t b = (size_t)(first[r] + k);
+                const size_t b = (size_t)first[ib];
                 const int32_t nTot = (int32_t)o.cells.size(), nV = (int32_t)o.verts.size(), nF = (int32_t)o.face.size() / 4;
                 B.hdr[4 * b] = o.nOwn; B.hdr[4 * b + 1] = o.nAll; B.hdr[4 * b + 2] = nV; B.hdr[4 * b + 3] = nF;
                 B.hdr2[4 * b] = nTot; B.hdr2[4 * b + 1] = B.hdr2[4 * b + 2] = B.hdr2[4 * b + 3] = 0;

@@ -23,20 +23,14 @@ class Device:
 
     def __init__(self, mesh, device_id=0, fv_schemes=None, fused_tables=True):
         """fused_tables=False: do not build the block tables of QGDFoam's fused explicit step (seconds of set-up and GBs of device memory a
-        QHDFoam case, an implicitDiffusion or adjustTimeStep case never uses); the library reads the choice from QGD_FUSED while the device
-        is created, so the variable is set for that call only -- unless the caller has set it, which wins"""
+        QHDFoam case or an implicitDiffusion case never uses); "any": build and use them whatever the blocks look like (tests, probes: the
+        default leaves meshes whose blocks come out small to the separate kernels); True: the library's default, which the QGD_FUSED
+        environment variable can still override (qgd_device_create_with)"""
         self.mesh = mesh
         self.device_id = device_id
         h = C.c_void_p()
-        import os
-        mine = not fused_tables and "QGD_FUSED" not in os.environ
-        if mine:
-            os.environ["QGD_FUSED"] = "0"
-        try:
-            L.check(L.lib.qgd_device_create(mesh._h, device_id, C.byref(h)), "qgd_device_create")
-        finally:
-            if mine:
-                del os.environ["QGD_FUSED"]
+        flags = {True: 0, False: L.DEVICE_NO_FUSED_TABLES, "any": L.DEVICE_FUSED_ANY_BLOCKS}[fused_tables]
+        L.check(L.lib.qgd_device_create_with(mesh._h, device_id, flags, C.byref(h)), "qgd_device_create_with")
         self._h = h
         self._case_handles = []   # native handles of the cases created on this device: close() frees them first (see adopt)
         self.fvSchemes = fv_schemes if fv_schemes is not None else {"fvsc": {"default": "GaussVolPoint"}}

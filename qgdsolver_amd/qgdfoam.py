@@ -179,7 +179,7 @@ class QGDFoamCase:
         a = (C.c_int64 * 8)()
         L.check(L.lib.qgd_case_fused_info(self._h, a), "qgd_case_fused_info")
         return dict(fused=bool(a[0]), blocks=int(a[1]), facesComputed=int(a[2]), ldsBytes=int(a[3]), cellsStaged=int(a[4]),
-                    cellsStagedFull=int(a[5]), verticesFormed=int(a[6]))
+                    cellsStagedFull=int(a[5]), verticesFormed=int(a[6]), layerBlocks=int(a[7]))
 
     def implicit_info(self):
         """the four linear solves of the implicitDiffusion branch in the last step (qgd_case_implicit_info)"""

@@ -1,6 +1,7 @@
 // The host side of the fused step: qgd_setup.cpp buildFusedBlocks (CPU only; compiled by tests/test_fused_blocks_host.py with plain g++ from the
 // library's own host sources).  Checks the tables the kernel trusts blindly:
-//   * every owned cell is an own cell of exactly one block, ghost cells of none; a shard's boundary-layer cells fill the first blocks;
+//   * every owned cell is an own cell of exactly one block, ghost cells of none; every cell a neighbouring shard waits for sits in one of
+//     the first nLayerBlocks blocks (whole bricks: they hold other cells too), and every one of those blocks holds such a cell;
 //   * a block's face list holds every internal face of its own cells, once, with owner / neighbour / vertex positions that point at those very
 //     labels; every list is padded to its stride with its last entry;
 //   * the face entries of an own cell are the cell's faces in ascending label with the right side bit, patch faces as ~label;
@@ -26,7 +27,7 @@ static int fails = 0;
         }                                                  \
     } while (0)
 
-static void checkMesh(const char* tag, HostMesh& m) {
+static void checkMesh(const char* tag, HostMesh& m, double minMeanCells = 0.0) {
     if (m.magSf.empty()) m.computeGeometry();
     m.computeDerived();
     const StaticData s = buildStaticData(m);
@@ -35,6 +36,14 @@ static void checkMesh(const char* tag, HostMesh& m) {
                 B.capV, B.capF, B.capE, B.capPE, (long long)B.facesComputed, s.nIF);
     CHECK(B.nBlocks > 0, "%s: no blocks", tag);
     if (B.nBlocks == 0) return;
+    {
+        int64_t owned = 0;
+        for (int32_t c = 0; c < s.nC; ++c) owned += (s.ghost.empty() || s.ghost[c] != 1) ? 1 : 0;
+        const double mean = (double)owned / B.nBlocks;
+        std::printf("    %.1f cells per block, %.2f cell records staged per cell, %.2f faces computed per cell\n", mean, (double)B.cellsStaged / owned,
+                    (double)B.facesComputed / owned);
+        CHECK(mean >= minMeanCells, "%s: %.1f cells per block on average, %.1f wanted", tag, mean, minMeanCells);
+    }
     std::vector<int> ownerBlock((size_t)s.nC, -1);
     int32_t maxTot = 0, maxAll = 0, maxV = 0, maxF = 0, maxLds = 0;
     int64_t faces = 0;
@@ -53,14 +62,17 @@ static void checkMesh(const char* tag, HostMesh& m) {
         for (int32_t i = std::max(nV, 1); i < B.capV; ++i) CHECK(verts[i] == verts[std::max(nV, 1) - 1], "block %d vertex padding", b);
         std::set<int32_t> distinct(cells, cells + nTot);
         CHECK((int32_t)distinct.size() == nTot, "block %d lists a cell twice", b);
+        bool hasLayerCell = false;
         for (int32_t j = 0; j < nOwn; ++j) {
             const int32_t c = cells[j];
             const int role = s.ghost.empty() ? 0 : s.ghost[c];
             CHECK(role != 1, "ghost cell %d owned by block %d", c, b);
             CHECK(ownerBlock[c] == -1, "cell %d owned twice", c);
             ownerBlock[c] = b;
-            CHECK((role == 2) == (b < B.nLayerBlocks), "cell %d (role %d) in block %d of %d boundary-layer blocks", c, role, b, B.nLayerBlocks);
+            CHECK(role != 2 || b < B.nLayerBlocks, "cell %d (role %d) in block %d of %d boundary-layer blocks", c, role, b, B.nLayerBlocks);
+            if (role == 2) hasLayerCell = true;
         }
+        CHECK(hasLayerCell || b >= B.nLayerBlocks || nOwn < 1, "block %d of the %d boundary-layer blocks holds no cell a neighbour waits for", b, B.nLayerBlocks);
         // faces
         std::set<int32_t> want;
         for (int32_t j = 0; j < nOwn; ++j) {
@@ -140,6 +152,10 @@ int main() {
         checkMesh("jittered, every third quad split, every fifth edge split (triangles, polygons)", m);
     }
     { HostMesh m = makeBox(12, 6, 12, 3, 9, lo, hi, pt); checkMesh("slab 3..9 of a 12x6x12 box (two cuts)", m); }
+    // what a cut must not cost: a 50-plane slab between two cuts keeps brick-shaped blocks -- 13 brick layers of 3 or 4
+    // planes, 123 cells per block -- and the blocks of the planes a neighbour waits for are whole bricks, not flat one-plane ones
+    { HostMesh m = makeBox(80, 80, 150, 49, 101, lo, hi, pt); checkMesh("planes 50..100 of an 80x80x150 box (50 owned planes between two ghost planes)", m, 120.0); }
+    { HostMesh m = makeBox(50, 50, 50, 0, 50, lo, hi, pt); checkMesh("box 50x50x50 (extents 8x4x4 bricks do not divide: 5x5x5 ones)", m, 120.0); }
     if (fails) { std::printf("%d checks failed\n", fails); return 1; }
     std::printf("ok\n");
     return 0;

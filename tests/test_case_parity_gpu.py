@@ -10,7 +10,7 @@ import qgdsolver_amd as q
 
 import cases
 from oracle import OracleCase
-from util import make_mesh, oracle_mesh_of, rel_err
+from util import assert_path, device_pair_arms, expects_fused, make_mesh, oracle_mesh_of, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -21,12 +21,16 @@ FACE_FIELDS = ["phiJm", "phiJmU", "phiP", "phiPi", "phiJmH", "phiQ", "phiPiU", "
 CELL_FIELDS = ["rho", "U", "p", "e", "T", "rhoU", "rhoE", "c", "psi", "mu", "alphau", "tauQGD", "muQGD", "alphauQGD", "hQGD", "H"]
 
 
-def build_pair(mesh_kind, scheme, bc_fn=None, init_fn=None, **opt):
+def build_pair(mesh_kind, scheme, bc_fn=None, init_fn=None, arm=None, **opt):
+    """arm: "fused" = the one-launch step (fusedFaceCellKernel: the kernel bench.py times), "kernels" = the separate vertex / face / cell
+    kernels; None = whichever the library's default picks.  The arm asked for is asserted to be the path that runs."""
     mesh = make_mesh(mesh_kind)
     om = oracle_mesh_of(mesh)
     options = q.default_options(stencil=scheme, **opt)
-    dev = q.Device(mesh)
+    dev = q.Device(mesh, fused_tables={None: True, "fused": "any", "kernels": False}[arm])
     gc = q.QGDFoamCase(dev, options)
+    if arm is not None:
+        assert_path(gc, arm, (mesh_kind, scheme))
     oc = OracleCase(om, options)
     if bc_fn:
         bc_fn(gc)
@@ -97,10 +101,26 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("mesh_kind,scheme,bc_fn,init_fn,opt", CASES)
-def test_update_fluxes_and_steps(mesh_kind, scheme, bc_fn, init_fn, opt):
-    mesh, dev, gc, oc = build_pair(mesh_kind, scheme, bc_fn, init_fn, **opt)
-    tag = (mesh_kind, scheme)
+def _arms_of(mesh_kind, scheme, opt):
+    mesh = make_mesh(mesh_kind)
+    arms = [a for a, _ in device_pair_arms(mesh, q.default_options(stencil=scheme, **opt))]
+    mesh.close()
+    return arms
+
+
+# every fixed-deltaT 3-D GaussVolPoint case runs TWICE against the oracle: through the fused one-launch step -- the kernel the benchmark times --
+# and through the separate kernels (what every other branch and qgd_case_update_fluxes run); which one ran is asserted (build_pair)
+CASE_ARMS = [c + (arm,) for c in CASES for arm in _arms_of(c[0], c[1], c[4])]
+
+
+def test_the_case_matrix_covers_the_fused_step():
+    assert sum(1 for c in CASE_ARMS if c[5] == "fused") == 8 and sum(1 for c in CASE_ARMS if c[5] == "kernels") == len(CASES)
+
+
+@pytest.mark.parametrize("mesh_kind,scheme,bc_fn,init_fn,opt,arm", CASE_ARMS)
+def test_update_fluxes_and_steps(mesh_kind, scheme, bc_fn, init_fn, opt, arm):
+    mesh, dev, gc, oc = build_pair(mesh_kind, scheme, bc_fn, init_fn, arm=arm, **opt)
+    tag = (mesh_kind, scheme, arm)
     # state straight after createFields.H
     compare_fields(gc, oc, CELL_FIELDS, 1e-13, tag + ("init",))
     compare_fields(gc, oc, [n + ".boundary" for n in ("rho", "U", "p", "e", "c", "H", "muQGD")], 1e-13, tag + ("init.bnd",))
@@ -165,30 +185,43 @@ def test_thermo_accessors():
 
 
 @pytest.mark.parametrize("variant", ["hex", "jitter", "jitter+triangles"])
-@pytest.mark.parametrize("adjust", [0, 1])
-def test_bench_kernel_directly_against_the_oracle(variant, adjust):
-    """The kernel bench.py times (faceFluxGvp3TileKernel<128>: the records of a 128-face tile staged in LDS) against the oracle
-    with nothing in between: 20^3 cells, so that the tiles are full (facesPerTile == 128) and all but a few of them stay
-    inside the staged kernel -- asserted, not assumed --, 26 explicit steps with a fixed deltaT and with Courant control."""
+@pytest.mark.parametrize("arm", ["fused", "kernels", "kernels+adjustTimeStep"])
+def test_bench_kernel_directly_against_the_oracle(variant, arm):
+    """The kernel bench.py times -- fusedFaceCellKernel: a block of <= 128 cells stages its cells and the cells around them in LDS, forms its
+    vertex values, computes every internal face of its cells and advances them, ONE launch per step -- against the oracle with nothing in
+    between, on a mesh large enough for real blocks (20^3 cells: 64 bricks of 5^3) -- asserted, not assumed: the case says it is
+    fused, it has many blocks and none tiny on average, blocks border on blocks (faces on a block's surface are computed by the block
+    on either side: facesComputed > nInternalFaces), and no block is the one-block degenerate case of the small parity meshes.  The
+    "kernels" arms keep the three kernels it replaced (faceFluxGvp3TileKernel<128> on full face tiles: asserted too) oracle-checked, with a
+    fixed deltaT and under Courant-number control.  26 explicit steps."""
     mesh = q.PolyMesh.box(20, 20, 20)
     if variant != "hex":
         mesh.jitter(0.15, seed=2024)
     if variant == "jitter+triangles":
         mesh.split_quads(7)
-    dev = q.Device(mesh)
-    ft = dev.face_tiles()
-    assert ft["facesPerTile"] == 128 and ft["tiles"] == (mesh.nInternalFaces + 127) // 128, ft
-    assert 4 * ft["gatherTiles"] < ft["tiles"], ft
+    adjust = 1 if arm.endswith("adjustTimeStep") else 0
+    dev = q.Device(mesh, fused_tables="any" if arm == "fused" else False)
     h = 1.0 / 20
     opt = q.default_options(stencil="GaussVolPoint", deltaT=0.1 * h / 1.3, mu=1e-3, adjustTimeStep=adjust, maxCo=0.25)
     gc = q.QGDFoamCase(dev, opt)
+    assert_path(gc, arm.split("+")[0], (variant, arm))
+    if arm == "fused":
+        fi = gc.fused_info()
+        assert fi["blocks"] >= (mesh.nCells + 127) // 128 and fi["blocks"] <= mesh.nCells // 40, fi      # many blocks, none tiny on average
+        assert fi["facesComputed"] > mesh.nInternalFaces, fi                                            # rim faces computed on both sides
+        assert fi["cellsStaged"] > 2 * mesh.nCells and fi["verticesFormed"] > mesh.nPoints, fi          # the blocks stage their surroundings
+        assert 0 < fi["ldsBytes"] <= 64 * 1024, fi
+    else:
+        ft = dev.face_tiles()
+        assert ft["facesPerTile"] == 128 and ft["tiles"] == (mesh.nInternalFaces + 127) // 128, ft
+        assert 4 * ft["gatherTiles"] < ft["tiles"], ft
     oc = OracleCase(oracle_mesh_of(mesh), opt)
     U, T, p = cases.box_initial_fields(mesh.array("C").reshape(-1, 3))
     gc.set_fields(U, T, p)
     oc.set_fields(U, T, p)
     gc.step(26)
     oc.step(26)
-    compare_fields(gc, oc, ["rho", "U", "p", "e", "rhoE"], STATE_TOL, (variant, adjust, "26 steps"))
+    compare_fields(gc, oc, ["rho", "U", "p", "e", "rhoE"], STATE_TOL, (variant, arm, "26 steps"))
     ig, io = gc.info(), oc.info()
     assert abs(ig["deltaT"] - io["deltaT"]) <= 1e-11 * io["deltaT"] and abs(ig["time"] - io["time"]) <= 1e-11 * io["time"]
     gc.close(); dev.close()

@@ -40,20 +40,7 @@ def c5_mesh(n, chunk, poly=False):
     return _C5_CACHE[key]
 
 
-def _c5_mesh(n, chunk, poly=False):
-    mesh = q.PolyMesh.box(n, n, n)
-    mesh.jitter(0.2, seed=2024)
-    mesh.split_quads(7)
-    if poly:
-        mesh.split_edges(11)
-    rng = np.random.default_rng(7)
-    perm = np.arange(mesh.nCells, dtype=np.int32)
-    for a in range(0, mesh.nCells, chunk):
-        b = min(a + chunk, mesh.nCells)
-        perm[a:b] = a + rng.permutation(b - a)
-    mesh.renumber(perm)
-    mesh.renumber(mesh.morton_order())
-    return mesh
+from qgdsolver_amd.synthetic import c5_mesh as _c5_mesh  # noqa: E402  (the recipe lives in the package: bench.py builds the same mesh)
 
 
 def cavity_fields(mesh, seed=5):

@@ -19,12 +19,12 @@ pytestmark = pytest.mark.gpu
 
 
 def run(mesh, steps, fused, bc_fn=None, chunks=(None,), env=None, **opt):
-    env = dict(env or {}, QGD_FUSED="2" if fused else "0")     # 2: fused whatever the blocks look like (1, the default, leaves meshes
-    # whose blocks come out small to the three kernels)
+    env = dict(env or {})
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
-        dev = q.Device(mesh)
+        # "any": fused whatever the blocks look like (the default leaves meshes whose blocks come out small to the three kernels)
+        dev = q.Device(mesh, fused_tables="any" if fused else False)
     finally:
         for k, v in old.items():
             if v is None:
@@ -126,11 +126,7 @@ def test_fused_step_stays_bit_identical_over_a_long_run():
 
 def test_cases_the_fused_kernel_does_not_serve_keep_the_two_kernels():
     mesh = q.PolyMesh.box(10, 8, 6)
-    os.environ["QGD_FUSED"] = "2"
-    try:
-        dev = q.Device(mesh)
-    finally:
-        del os.environ["QGD_FUSED"]
+    dev = q.Device(mesh, fused_tables="any")
     for opt in (dict(adjustTimeStep=1, maxCo=0.2), dict(implicitDiffusion=1, mu=1e-3), dict(termStencils={"grad(p)": "reduced"})):
         case = q.QGDFoamCase(dev, q.default_options(stencil="GaussVolPoint", deltaT=1e-3, **opt))
         assert not case.fused_info()["fused"], opt
@@ -154,15 +150,7 @@ def test_cases_the_fused_kernel_does_not_serve_keep_the_two_kernels():
 
 
 def shard_run(shard, fused, order, steps=4):
-    old = os.environ.get("QGD_FUSED")
-    os.environ["QGD_FUSED"] = "2" if fused else "0"
-    try:
-        dev = q.Device(shard)
-    finally:
-        if old is None:
-            del os.environ["QGD_FUSED"]
-        else:
-            os.environ["QGD_FUSED"] = old
+    dev = q.Device(shard, fused_tables="any" if fused else False)
     case = q.QGDFoamCase(dev, q.default_options(stencil="GaussVolPoint", deltaT=1e-3, mu=1e-3))
     U, T, p = cases.box_initial_fields(shard.array("C").reshape(-1, 3))
     case.set_fields(U, T, p)

@@ -12,9 +12,11 @@ from util import make_mesh
 pytestmark = pytest.mark.gpu
 
 
-def run_device(mesh, stencil, bc_fn, U, T, p, steps, **opt):
-    dev = q.Device(mesh)
+def run_device(mesh, stencil, bc_fn, U, T, p, steps, fused_tables=True, **opt):
+    dev = q.Device(mesh, fused_tables=fused_tables)
     gc = q.QGDFoamCase(dev, q.default_options(stencil=stencil, **opt))
+    if fused_tables in ("any", False):
+        assert gc.fused_info()["fused"] == (fused_tables == "any"), gc.fused_info()
     if bc_fn:
         bc_fn(gc)
     gc.set_fields(U, T, p)
@@ -24,12 +26,19 @@ def run_device(mesh, stencil, bc_fn, U, T, p, steps, **opt):
     return out
 
 
-def run_sharded_device(g, world, stencil, bc_fn, U, T, p, steps, overlapped=False, **opt):
+def run_sharded_device(g, world, stencil, bc_fn, U, T, p, steps, overlapped=False, fused_tables=True, **opt):
+    """fused_tables="any": every shard steps with the fused one-launch kernel (phase 1 = all blocks; phases 10 / 11 = the blocks that hold a
+    cell a neighbour waits for, then the others, with the record buffers swapped in between) -- asserted per shard; False: the separate
+    kernels; True: the library's choice (shards this small take the separate kernels)"""
     shards = [g.shard(world, r) for r in range(world)]
     devs, cs = [], []
     for s in shards:
-        d = q.Device(s)
+        d = q.Device(s, fused_tables=fused_tables)
         c = q.QGDFoamCase(d, q.default_options(stencil=stencil, **opt))
+        if fused_tables in ("any", False):
+            fi = c.fused_info()
+            assert fi["fused"] == (fused_tables == "any"), fi
+            assert fused_tables is False or 1 <= fi["layerBlocks"] <= fi["blocks"], fi
         if bc_fn:
             bc_fn(c)
         cg = s.array("cellGlobal")
@@ -103,17 +112,24 @@ def run_sharded_device(g, world, stencil, bc_fn, U, T, p, steps, overlapped=Fals
     return out
 
 
-@pytest.mark.parametrize("kind,stencil,world,bc_fn,opt,overlapped", [
-    ("box654_poly", "GaussVolPoint", 3, mixed_bcs, dict(deltaT=1e-3, mu=1e-3), False),
-    ("box654_poly", "GaussVolPoint", 3, mixed_bcs, dict(deltaT=1e-3, mu=1e-3), True),
-    ("box654_poly_rcm", "GaussVolPoint", 3, mixed_bcs, dict(deltaT=1e-3, mu=1e-3), False),
-    ("box654_poly_rcm", "GaussVolPoint", 3, mixed_bcs, dict(deltaT=1e-3, mu=1e-3), True),
-    ("box654_jitter", "reduced", 2, mixed_bcs, dict(deltaT=1e-3), False),
-    ("step2d", "leastSquares", 4, cases.forward_step_bcs, dict(deltaT=5e-4), True),
-    ("step2d", "GaussVolPoint", 3, cases.forward_step_bcs, dict(deltaT=5e-4), False),
+@pytest.mark.parametrize("kind,stencil,world,bc_fn,opt,overlapped,fused", [
+    ("box654_poly", "GaussVolPoint", 3, mixed_bcs, dict(deltaT=1e-3, mu=1e-3), False, False),
+    ("box654_poly", "GaussVolPoint", 3, mixed_bcs, dict(deltaT=1e-3, mu=1e-3), True, False),
+    ("box654_poly_rcm", "GaussVolPoint", 3, mixed_bcs, dict(deltaT=1e-3, mu=1e-3), False, False),
+    ("box654_poly_rcm", "GaussVolPoint", 3, mixed_bcs, dict(deltaT=1e-3, mu=1e-3), True, False),
+    # the fused one-launch step on shards against the ORACLE (not only against the separate kernels, tests/test_fused_step_gpu.py): plain
+    # order (phases 0, 1) and boundary-layer-first order (0, 10, 11), 2 and 3 shards, meshes with triangles / polygons / qgdFlux walls
+    ("box654_poly", "GaussVolPoint", 3, mixed_bcs, dict(deltaT=1e-3, mu=1e-3), False, "any"),
+    ("box654_poly", "GaussVolPoint", 3, mixed_bcs, dict(deltaT=1e-3, mu=1e-3), True, "any"),
+    ("box654_poly_rcm", "GaussVolPoint", 2, mixed_bcs, dict(deltaT=1e-3, mu=1e-3), True, "any"),
+    ("box12108", "GaussVolPoint", 2, None, dict(deltaT=2e-3, mu=1e-3), True, "any"),
+    ("box12108", "GaussVolPoint", 3, mixed_bcs, dict(deltaT=1e-3, mu=1e-3), False, "any"),
+    ("box654_jitter", "reduced", 2, mixed_bcs, dict(deltaT=1e-3), False, True),
+    ("step2d", "leastSquares", 4, cases.forward_step_bcs, dict(deltaT=5e-4), True, True),
+    ("step2d", "GaussVolPoint", 3, cases.forward_step_bcs, dict(deltaT=5e-4), False, True),
 ])
-def test_sharded_device_matches_unsharded_and_oracle(kind, stencil, world, bc_fn, opt, overlapped):
-    g = rcm_poly_mesh() if kind == "box654_poly_rcm" else make_mesh(kind)
+def test_sharded_device_matches_unsharded_and_oracle(kind, stencil, world, bc_fn, opt, overlapped, fused):
+    g = rcm_poly_mesh() if kind == "box654_poly_rcm" else (q.PolyMesh.box(12, 10, 8).jitter(0.1, seed=5) if kind == "box12108" else make_mesh(kind))
     if kind == "box654_poly":
         g.renumber(random_perm(g.nCells, 21))
     C = g.array("C").reshape(-1, 3)
@@ -125,8 +141,8 @@ def test_sharded_device_matches_unsharded_and_oracle(kind, stencil, world, bc_fn
         U, T, p = cases.box_initial_fields(C)
     steps = 10
     ref = run_oracle(g, stencil, bc_fn, U, T, p, steps, **opt)
-    one = run_device(g, stencil, bc_fn, U, T, p, steps, **opt)
-    got = run_sharded_device(g, world, stencil, bc_fn, U, T, p, steps, overlapped=overlapped, **opt)
+    one = run_device(g, stencil, bc_fn, U, T, p, steps, fused_tables=fused, **opt)
+    got = run_sharded_device(g, world, stencil, bc_fn, U, T, p, steps, overlapped=overlapped, fused_tables=fused, **opt)
     for f in ref:
         scale = np.abs(ref[f]).max()
         assert np.abs(got[f] - one[f]).max() <= 1e-12 * scale, (kind, stencil, f, "sharded vs unsharded device")

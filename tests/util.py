@@ -43,3 +43,27 @@ def make_mesh(kind):
 
 def oracle_mesh_of(mesh):
     return OracleMesh(mesh.primitives())
+
+
+def expects_fused(mesh, options):
+    """whether a case with these options is one the fused one-launch step (fusedFaceCellKernel, the kernel bench.py times) serves: a 3-D mesh,
+    one GaussVolPoint stencil, explicit branch, fixed deltaT (qgd_capi.cpp qgd_case_create)"""
+    return (mesh.nGeometricD == 3 and options.stencil == L.FVSC_GAUSSVOLPOINT and not options.implicitDiffusion and
+            not options.adjustTimeStep and not any(options.termStencil))
+
+
+def device_pair_arms(mesh, options):
+    """the two ways a device can step such a case, for tests that pin BOTH to the oracle on purpose: ("fused", Device with the block tables
+    whatever the blocks look like) and ("kernels", Device without them); a case the fused step does not serve has the second arm only"""
+    arms = [("kernels", False)]
+    if expects_fused(mesh, options):
+        arms.insert(0, ("fused", "any"))
+    return arms
+
+
+def assert_path(case, arm, tag=None):
+    """the arm under test is the path that runs -- asserted, not left to a default or to the block-size heuristic"""
+    info = case.fused_info()
+    assert info["fused"] == (arm == "fused"), (tag, arm, info)
+    if arm == "fused":
+        assert info["blocks"] >= 1 and info["facesComputed"] >= case.dev.mesh.nInternalFaces, (tag, info)
