@@ -195,6 +195,14 @@ def run(case_dir, n_steps=None, device_id=0, write=True, log=print, renumber="no
     branch = "implicitDiffusion true" if opt.get("implicitDiffusion") else "explicit branch"
     log(f"QGDFoam (qgdsolver_amd, {branch}): {n_global} cells on {world} rank(s), fvsc {opt['stencil']}, "
         f"deltaT {dt:g}, start {t0_name}, cell order {renumber}")
+    if opt.get("implicitDiffusion"):
+        x = os.environ.get("QGD_IMPL_XEXTRAP", "3")
+        if x != "0":
+            log(f"  NOTE: the U and e solves start from the predictor + the correction of the last steps extrapolated in time (QGD_IMPL_XEXTRAP={x}; "
+                + ("Lagrange weights from the deltaT ratios under adjustTimeStep; " if adjust else "")
+                + "limited per value), not from the predictor alone as OpenFOAM does: same systems, same tolerance, same answer to that "
+                "tolerance -- but the 'initial' residuals and iteration counts below are NOT comparable with a reference QGDFoam log.  "
+                "QGD_IMPL_XEXTRAP=0 restores OpenFOAM's start values.")
     done = 0
     wall0 = _time.perf_counter()
     written = []

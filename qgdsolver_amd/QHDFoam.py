@@ -45,6 +45,13 @@ def run(case_dir, n_steps=None, device_id=0, write=True, log=print):
     branch = "implicitDiffusion true" if opt["implicitDiffusion"] else "implicitDiffusion false"
     log(f"QHDFoam (qgdsolver_amd, {branch}): {mesh.nCells} cells, fvsc {opt['stencil']}, QGDCoeffs {opt['tauModel']}, deltaT {dt:g}, "
         f"start {t0_name}")
+    px, xx = os.environ.get("QGD_QHD_PEXTRAP", "4"), os.environ.get("QGD_IMPL_XEXTRAP", "3")
+    if px != "0" or (opt.get("implicitDiffusion") and xx != "0"):
+        log(f"  NOTE: the pressure solve starts from p extrapolated in time over the last steps (QGD_QHD_PEXTRAP={px}, limited per value)"
+            + (f", the U / T solves from the extrapolated fields (QGD_IMPL_XEXTRAP={xx})" if opt.get("implicitDiffusion") else "")
+            + ", not from the old field as OpenFOAM does [QHDpEqn.H L45]: same systems, same tolerances, same answer to those tolerances -- but "
+            "'Initial residual' and 'No Iterations' below are NOT comparable with a reference QHDFoam log.  QGD_QHD_PEXTRAP=0 "
+            "QGD_IMPL_XEXTRAP=0 restore OpenFOAM's start values.")
     done = 0
     wall0 = _time.perf_counter()
     written = []

@@ -741,8 +741,14 @@ static int deviceCreate(qgd_mesh_t mh, int deviceId, int fusedChoice, qgd_device
                 // holds -- is better off with the three kernels: 5.0 against 4.4 ms per step on the 16 M-cell mesh of config 5 with 67-cell blocks)
                 int64_t owned = 0;
                 for (int64_t ci = 0; ci < s.nC; ++ci) owned += (s.ghost.empty() || s.ghost[ci] != 1) ? 1 : 0;
+                // what one workgroup may ask for without raising the kernel's dynamic-LDS attribute: the device's own figure (64 KB on gfx950;
+                // blocks of <= 32 cells are exempt from the builder's three-per-CU budget, so one fat polyhedral block could exceed it -- such
+                // a mesh keeps the three kernels instead of failing in its first step)
+                hipDeviceProp_t prop;
+                HIP_CHECK(hipGetDeviceProperties(&prop, deviceId));
+                const int64_t ldsLimit = std::min<int64_t>((int64_t)prop.sharedMemPerBlock, 64 * 1024);
                 if (fb.nBlocks > 0 && (fusedMode == 2 || (int64_t)fb.nBlocks * 88 <= owned + 87) && fb.maxAll <= kFusedCapC && fb.maxTot <= kFusedCapTot &&
-                    fb.capV <= kFusedCapV && fb.capF <= kFusedCapF && fb.capPE <= 255 && lds <= 80 * 1024) {
+                    fb.capV <= kFusedCapV && fb.capF <= kFusedCapF && fb.capPE <= 255 && lds <= ldsLimit) {
                     v.fuBlocks = fb.nBlocks; v.fuLayerBlocks = fb.nLayerBlocks; v.fuCapC = fb.capC; v.fuCapV = fb.capV; v.fuCapF = fb.capF;
                     v.fuCapE = fb.capE; v.fuLds = (int32_t)lds; v.fuLdsCell = (int32_t)(ldsPark / 8);
                     v.fuCapPE = fb.capPE; v.fuMaxTot = fb.maxTot; v.fuMaxAll = fb.maxAll; v.fuMaxV = fb.maxV; v.fuMaxF = fb.maxF;
@@ -1520,6 +1526,8 @@ int qgd_case_create(qgd_device_t d, const qgd_case_options* opt, qgd_case_t* out
                     for (int j = 0; j < c->implXOrder; ++j) iv.dh[j] = a.alloc<double>(4 * nC);
                 }
                 iv.have = 0; iv.order = c->implXOrder;
+                iv.w = nullptr; iv.dtHist = nullptr;
+                if (c->implXOrder > 0 && opt->adjustTimeStep) { iv.w = a.alloc<double>(4); iv.dtHist = a.alloc<double>(8); }   // (zero-filled)
             }
         }
         c->bc.resize(d->patches.size());
@@ -1711,6 +1719,7 @@ static void implicitPhase(qgd_case_s* c, int phase) {
         case 20: {
             const bool adjust = c->opt.adjustTimeStep != 0;
             if (adjust) launchDeltaT(launcherOf(c), c->view, c->opt.maxCo, c->opt.maxDeltaT, c->opt.cTau);
+            if (adjust) launchImplicitStartWeights(st, c->view, c->impl);   // the start values' Lagrange weights from the deltaT ratios
             c->steps++;
             if (!adjust) c->time += c->opt.deltaT;
             implicitStepMark(S, true);

@@ -228,11 +228,16 @@ struct ImplView {
     // (the oldest doubles as this step's write target: dh[order - 1]); 4*nC each, component-major {Ux, Uy, Uz, e}; pred == nullptr: off
     double *pred, *dh[4];
     int have, order;
+    // adjustTimeStep: the steps of the history differ in length, so the extrapolation takes Lagrange weights from the deltaT ratios instead of
+    // the binomial ones (w[0..3], written on the device by implStartWeightsKernel from the ring dtHist[0..4] = deltaT of this step and of the
+    // four before); nullptr with a fixed deltaT
+    double *w, *dtHist;
 };
 // the branch as parts 0..5 (gradient | faces + U systems | store U | gradient of the new U | sigma + e system | finish) around its two
 // multi-right-hand-side Jacobi-PCG solves, all stream-ordered with the scalars of the solves in a device control block
 struct ImplicitSolver;
 struct SolveHooks;
+void launchImplicitStartWeights(hipStream_t s, const CaseView& c, const ImplView& iv);   // after deltaTKernel, before the step's first start value
 ImplicitSolver* implicitSolverCreate(hipStream_t stream, const MeshView& m, int ownedBegin = 0, int ownedEnd = -1);
 void implicitSolverFree(ImplicitSolver* S);
 int64_t implicitSolverBytes(const ImplicitSolver* S);

@@ -78,11 +78,42 @@ __device__ __forceinline__ double startValue(const ImplView& iv, const size_t j,
     if (k == 0) return pred;
     const double d1 = iv.dh[0][j];
     double e = d1;
-    if (k == 2) e = 2.0 * d1 - iv.dh[1][j];
+    if (iv.w != nullptr) {   // adjustTimeStep: steps of different length (implStartWeightsKernel)
+        e = iv.w[0] * d1;
+        if (k >= 2) e += iv.w[1] * iv.dh[1][j];
+        if (k >= 3) e += iv.w[2] * iv.dh[2][j];
+        if (k >= 4) e += iv.w[3] * iv.dh[3][j];
+    } else if (k == 2) e = 2.0 * d1 - iv.dh[1][j];
     else if (k == 3) e = (3.0 * d1 - 3.0 * iv.dh[1][j]) + iv.dh[2][j];
     else if (k >= 4) e = ((4.0 * d1 - 6.0 * iv.dh[1][j]) + 4.0 * iv.dh[2][j]) - iv.dh[3][j];
     const double lim = 2.0 * fabs(d1);
     return pred + fmin(fmax(e, -lim), lim);
+}
+// Under Courant-number control [setDeltaT-QGDQHD.H L41-61] the steps of the history differ in length and what a solve adds to its predictor
+// scales with the step: the smooth quantity is correction / deltaT at the END of its step.  With T_n = 0 the end of the step about to be
+// taken, the corrections of the k steps before sit at tau_j = -(deltaT_n + ... + deltaT_{n-j+1}), j = 1..k, and the start value is
+// deltaT_n * sum_j L_j(0) d_j / deltaT_{n-j} with the Lagrange polynomials of those nodes -- the binomial weights 3, -3, 1 when all steps are equal.
+// One thread, once per step, behind deltaTKernel: rotates the ring of step lengths and writes w[0..3] for min(have, order) nodes.
+__global__ void implStartWeightsKernel(const CaseView c, const ImplView iv) {
+    double* h = iv.dtHist;
+    for (int j = 4; j >= 1; --j) h[j] = h[j - 1];
+    h[0] = c.dt[0];
+    const int k = iv.have < iv.order ? iv.have : iv.order;
+    double tau[4] = {0, 0, 0, 0}, t = 0.0;
+    for (int j = 0; j < k; ++j) { t -= h[j]; tau[j] = t; }
+    for (int j = 0; j < 4; ++j) {
+        double L = 0.0;
+        if (j < k && h[j + 1] > 0.0) {
+            L = 1.0;
+            for (int q = 0; q < k; ++q) if (q != j) L *= (0.0 - tau[q]) / (tau[j] - tau[q]);
+            L *= h[0] / h[j + 1];
+        }
+        iv.w[j] = L;
+    }
+}
+void launchImplicitStartWeights(hipStream_t s, const CaseView& c, const ImplView& iv) {
+    if (iv.w == nullptr || iv.pred == nullptr) return;
+    implStartWeightsKernel<<<1, 1, 0, s>>>(c, iv);
 }
 // after a solve: this step's correction into the oldest slot (the host rotates the pointers at the end of the step)
 __device__ __forceinline__ void keepCorrection(const ImplView& iv, const size_t j, const double solved) {

@@ -74,7 +74,7 @@ def test_fused_step_is_bit_identical_to_the_two_kernels():
             a, ia = run(mesh, 7, False, **opt)
             b, ib = run(mesh, 7, True, **opt)
             assert not ia["fused"] and ib["fused"], (tag, ia, ib)
-            assert ib["blocks"] >= (mesh.nCells + 127) // 128 and ib["ldsBytes"] <= 80 * 1024, ib
+            assert ib["blocks"] >= (mesh.nCells + 127) // 128 and ib["ldsBytes"] <= 64 * 1024, ib
             assert ib["facesComputed"] >= mesh.nInternalFaces, ib
             equal(a, b, (tag, opt))
 
