@@ -1097,6 +1097,9 @@ def main():
     fused = case.fused_info()
     if fused["fused"]:
         fused["mean_cells_per_block"] = owned_cells / fused["blocks"]
+        fb = dev.fused_blocks()
+        fused.update(templates=fb["templates"], brick=list(fb["brick"]), block_list_bytes=fb["blockListBytes"], template_bytes=fb["templateBytes"],
+                     block_builder_s=fb["buildSeconds"])
     # what a cut costs the blocks, and the set-up of N ranks sharing one host's cores: every rank's figures in rank 0's line
     per_rank = None
     if world > 1:
@@ -1129,8 +1132,10 @@ def main():
         # its own compulsory bytes, from what its blocks stage: per computed face 16 B of block list + weight 8 + hQGDf 8 + kind 1; per staged
         # cell RecA 48 + label 4, for own cells and cells across a face also RecB 32 + centre 24; per own cell rhoE 8 + V 8 + hQGD 8 read,
         # 88 + 8 written, 25 B of face entries; per vertex formed 8 positions 16 + 8 weights 64 + count 1 + label 4 + coordinates 24
-        own_bytes = (33 * fused["facesComputed"] + 52 * fused["cellsStaged"] + 56 * fused["cellsStagedFull"] + 145 * n_c +
-                     109 * fused["verticesFormed"])
+        # round 6: the per-face positions (12 B), the own cells' face entries (25 B per cell) and the vertices' cell positions (16 B) come out of the
+        # block's TEMPLATE, which blocks that are alike share (L2-resident on a structured mesh): counted once per template, not per block
+        own_bytes = (21 * fused["facesComputed"] + 52 * fused["cellsStaged"] + 56 * fused["cellsStagedFull"] + 120 * n_c +
+                     93 * fused["verticesFormed"] + fb["templateBytes"] * fb["templates"])
     else:
         face_kernel_name = (f"faceFluxGvp3TileKernel<{ft['facesPerTile']}> (+ faceFluxGvp3Kernel on {ft['gatherTiles']} of {ft['tiles']} tiles; "
                             "avg_launch_ms covers both launches)") if ft["facesPerTile"] else "faceFluxGvp3Kernel"

@@ -277,6 +277,13 @@ int qgd_device_op_times(qgd_device_t d, double ms[3]);
  * info[3] = LDS bytes per workgroup.  Both kernels do the arithmetic of GaussVolPointBase3D_8C_source.html L346-389,
  * L488-513 + QGDFoam_2updateFluxes_8H_source.html L41-139 in the same order: results are bit-identical. */
 int qgd_device_face_tiles(qgd_device_t d, int64_t info[4]);
+/* The block tables of the fused explicit step on this device (all 0 when they were not built or not accepted; qgd_case_fused_info says whether
+ * a case uses them): info[0] = blocks, [1] = of which the leading boundary-layer blocks of a shard, [2] = distinct templates of the blocks'
+ * local topology (per-face list positions, per-cell face entries, per-vertex cell positions: blocks that are alike share one, so on a
+ * structured mesh those tables stay in L2 instead of being streamed per block per step), [3] = LDS bytes per workgroup, [4] = bytes of a
+ * block's own lists (labels, weights, counts), [5] = bytes of one template, [6] = host milliseconds the builder took, [7] = the lattice brick
+ * the blocks were cut from, bx | by << 8 | bz << 16 (0: count-based runs of the Morton order). */
+int qgd_device_fused_blocks(qgd_device_t d, int64_t info[8]);
 
 /* qgdInterpolate / linearInterpolate [QGDInterpolate_8H_source.html L38-67]: face = w*(phi_O - phi_N) + phi_N, patch faces
  * take the patch value.  cell nCells*ncomp, bnd nBoundaryFaces*ncomp, out nFaces*ncomp (HOST pointers), ncomp in 1..9. */

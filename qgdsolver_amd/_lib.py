@@ -83,6 +83,7 @@ SIGNATURES = {
     "qgd_mesh_get": (C.c_int, [handle, C.c_char_p, C.c_void_p, C.c_int64]),
     "qgd_device_create": (C.c_int, [handle, C.c_int, handle_p]),
     "qgd_device_create_with": (C.c_int, [handle, C.c_int, C.c_int32, handle_p]),
+    "qgd_device_fused_blocks": (C.c_int, [handle, C.POINTER(C.c_int64)]),
     "qgd_device_free": (C.c_int, [handle]),
     "qgd_stencil_lookup": (C.c_int, [handle, C.c_char_p, C.POINTER(C.c_int)]),
     "qgd_fvsc_grad_s": (C.c_int, [handle, C.c_int, c_double_p, c_double_p, c_double_p]),

@@ -234,6 +234,7 @@ struct qgd_device_s {
     int32_t nGeomD = 3;
     bool hasTri = false;
     bool wedgePrism = false;  // wedge patches + prism cells: GaussVolPoint is refused [fvsc_8C L65-82]
+    int64_t fusedInfo[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // qgd_device_fused_blocks
     int64_t fusedFacesComputed = 0;   // internal faces the fused kernel's blocks compute per step, surface faces once per side (MeshView::fuBlocks > 0)
     int64_t fusedCellsStaged = 0, fusedCellsStagedFull = 0, fusedVertsStaged = 0;   // cell records / of which with RecB and centre / vertices its blocks stage per step
     std::vector<Patch> patches;
@@ -756,7 +757,14 @@ static int deviceCreate(qgd_mesh_t mh, int deviceId, int fusedChoice, qgd_device
                     d->fusedVertsStaged = fb.vertsStaged;
                     v.fuHdr2 = reinterpret_cast<const int4*>(up(fb.hdr2)); v.fuVCount = up(fb.vCount); v.fuVPos = up(fb.vPos); v.fuVW = up(fb.vW);
                     v.fuHdr = reinterpret_cast<const int4*>(up(fb.hdr)); v.fuCells = up(fb.cells); v.fuVerts = up(fb.verts);
-                    v.fuFace = reinterpret_cast<const int4*>(up(fb.face)); v.fuNEntry = up(fb.nEntry); v.fuEntry = up(fb.entry);
+                    v.fuFaceLabel = up(fb.faceLabel); v.fuFacePos = up(fb.facePos); v.fuNEntry = up(fb.nEntry); v.fuEntry = up(fb.entry);
+                    v.fuTemplates = fb.nTemplates;
+                    d->fusedInfo[0] = fb.nBlocks; d->fusedInfo[1] = fb.nLayerBlocks; d->fusedInfo[2] = fb.nTemplates; d->fusedInfo[3] = lds;
+                    // bytes a block streams per step out of its own lists / of its template's
+                    d->fusedInfo[4] = 32 + 4 * (int64_t)fb.capC + 4 * (int64_t)fb.capV + 4 * (int64_t)fb.capF + fb.capV + 128 + 8 * (int64_t)fb.capPE * fb.capV;
+                    d->fusedInfo[5] = 12 * (int64_t)fb.capF + 4 * (int64_t)fb.capE * 128 + 2 * (int64_t)fb.capPE * fb.capV;
+                    d->fusedInfo[6] = (int64_t)(fb.buildSeconds * 1e3);
+                    d->fusedInfo[7] = fb.brick[0] | fb.brick[1] << 8 | fb.brick[2] << 16;
                 }
             }
         }
@@ -933,6 +941,11 @@ int qgd_device_face_tiles(qgd_device_t d, int64_t info[4]) {
     info[1] = on ? (v.nIF + v.fblock - 1) / v.fblock : 0;
     info[2] = on ? v.nTileSpill : 0;
     info[3] = on ? v.tileLds : 0;
+    return QGD_OK;
+}
+int qgd_device_fused_blocks(qgd_device_t d, int64_t info[8]) {
+    if (!d || !info) return fail(QGD_ERR_INVALID, "null argument");
+    for (int k = 0; k < 8; ++k) info[k] = d->fusedInfo[k];
     return QGD_OK;
 }
 int qgd_fvsc_grad_s(qgd_device_t d, int id, const double* cell, const double* bnd, double* out) { return fvscOp(d, id, 0, 1, cell, bnd, out); }

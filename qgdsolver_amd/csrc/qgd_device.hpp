@@ -70,7 +70,9 @@ struct MeshView {
     const int32_t* bPatch; const double* hQGDb;
     // cell blocks of the fused face + cell kernel (qgd_setup.hpp FusedBlocks); fuBlocks == 0: not built
     int32_t fuBlocks, fuLayerBlocks, fuCapC, fuCapV, fuCapF, fuCapE, fuLds, fuLdsCell;   // fuLayerBlocks: a shard's boundary-layer blocks come first;   // fuLdsCell: where the per-cell park of the kernel starts, in doubles
-    const int4* fuHdr; const int32_t* fuCells; const int32_t* fuVerts; const int4* fuFace; const uint8_t* fuNEntry; const int32_t* fuEntry;
+    const int4* fuHdr; const int32_t* fuCells; const int32_t* fuVerts; const int32_t* fuFaceLabel; const uint8_t* fuNEntry;
+    // a block's local topology sits in its template (fuHdr2[blk].y): 3 position words per face, the own cells' face entries, the vertices' cell positions
+    const uint32_t* fuFacePos; const int32_t* fuEntry; int32_t fuTemplates;
     int32_t fuCapPE, fuMaxTot, fuMaxAll, fuMaxV, fuMaxF;   // cells per vertex (stride); staged cells incl. / without the extra ones, vertices, faces: maxima over the blocks (information; a block lays its LDS out by its own counts)
     const int4* fuHdr2; const uint8_t* fuVCount; const uint16_t* fuVPos; const double* fuVW;   // the vertex values are formed inside the block
 };

@@ -111,10 +111,7 @@ __global__ void implStartWeightsKernel(const CaseView c, const ImplView iv) {
         iv.w[j] = L;
     }
 }
-void launchImplicitStartWeights(hipStream_t s, const CaseView& c, const ImplView& iv) {
-    if (iv.w == nullptr || iv.pred == nullptr) return;
-    implStartWeightsKernel<<<1, 1, 0, s>>>(c, iv);
-}
+
 // after a solve: this step's correction into the oldest slot (the host rotates the pointers at the end of the step)
 __device__ __forceinline__ void keepCorrection(const ImplView& iv, const size_t j, const double solved) {
     if (iv.pred != nullptr) iv.dh[iv.order - 1][j] = solved - iv.pred[j];
@@ -981,6 +978,11 @@ __global__ void iStatKernel(const double* __restrict__ ctl, double* __restrict__
 }
 
 }  // namespace
+
+void launchImplicitStartWeights(hipStream_t s, const CaseView& c, const ImplView& iv) {
+    if (iv.w == nullptr || iv.pred == nullptr) return;
+    implStartWeightsKernel<<<1, 1, 0, s>>>(c, iv);
+}
 
 // ---- host side of the solves ---------------------------------------------------------------------------------------------
 struct ImplicitSolver {

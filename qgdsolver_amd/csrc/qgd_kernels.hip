@@ -1150,15 +1150,15 @@ void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm, 
     const int capC = m.fuCapC, capV = m.fuCapV, capF = m.fuCapF, capPE = m.fuCapPE;
     const int32_t* __restrict__ tCells = m.fuCells + (size_t)blk * capC;
     const int32_t* __restrict__ tVerts = m.fuVerts + (size_t)blk * capV;
-    const int4* __restrict__ tFace = m.fuFace + (size_t)blk * capF;
-    const int32_t* __restrict__ ent = m.fuEntry + (size_t)blk * m.fuCapE * 128 + (tid & 127);
-    // (0) everything whose address does not depend on a loaded value: the counts, the lists (padded to their strides with their last entry,
-    // so no count is needed to read them), this thread's two faces, its cell's face entries, its vertex's cells and weights
+    const int32_t* __restrict__ tFaceLabel = m.fuFaceLabel + (size_t)blk * capF;
+    // (0) everything whose address does not depend on a loaded value: the counts and the template id, the lists (padded to their strides with
+    // their last entry, so no count is needed to read them), the labels of this thread's two faces, its vertex's weights
     const int4 hdr = m.fuHdr[blk];
-    const int nTot = m.fuHdr2[blk].x;
-    int4 fc[KF];
+    const int4 hdr2 = m.fuHdr2[blk];
+    const int nTot = hdr2.x;
+    int fl[KF];
 #pragma unroll
-    for (int j = 0; j < KF; ++j) fc[j] = tFace[min(tid + j * NT, capF - 1)];
+    for (int j = 0; j < KF; ++j) fl[j] = tFaceLabel[min(tid + j * NT, capF - 1)];
     int idC[KC], idB[KB2], idV[KV];
 #pragma unroll
     for (int k = 0; k < KC; ++k) {
@@ -1177,20 +1177,32 @@ void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm, 
     }
     const int ci = tCells[min(tid & 127, capC - 1)];   // (threads beyond the block's cells repeat its last label: loads stay inside the lists)
     const int nEraw = (int)m.fuNEntry[(size_t)blk * 128 + (tid & 127)];
-    int e6[KE];
-#pragma unroll
-    for (int i = 0; i < KE; ++i) e6[i] = ent[(size_t)min(i, m.fuCapE - 1) * 128];
     // this thread's vertex (thread v forms vertex v of the block's list)
     const int vt = min(tid, capV - 1);
     const int myVert = tVerts[vt];
     const int nPc = (int)m.fuVCount[(size_t)blk * capV + vt];
-    const uint16_t* __restrict__ vPos = m.fuVPos + (size_t)blk * capPE * capV + vt;
     const double* __restrict__ vW = m.fuVW + (size_t)blk * capPE * capV + vt;
-    int pcPos[KP];
     double pcW[KP];
 #pragma unroll
-    for (int i = 0; i < KP; ++i) { pcPos[i] = (int)vPos[(size_t)min(i, capPE - 1) * capV]; pcW[i] = vW[(size_t)min(i, capPE - 1) * capV]; }
-    // (1) one round trip later: the records, piece by piece; the faces' streams; the cell's own scalars; a patch point's record
+    for (int i = 0; i < KP; ++i) pcW[i] = vW[(size_t)min(i, capPE - 1) * capV];
+    // (1) one round trip later: the records, piece by piece; the faces' streams; the cell's own scalars; a patch point's record -- and the
+    // block's local topology out of its TEMPLATE (hdr2.y; qgd_setup.hpp FusedBlocks: the interior bricks of a structured region share a few
+    // hundred templates, which stay in L2): the positions of this thread's two faces' cells and vertices in the staged lists, its cell's face
+    // entries, its vertex's cell positions.  None of it is needed before the records are staged, so the template costs no round trip.
+    const size_t tpl = (size_t)hdr2.y;
+    struct Pos3 { uint32_t c, va, vb; };
+    const Pos3* __restrict__ tFacePos = reinterpret_cast<const Pos3*>(m.fuFacePos) + tpl * capF;
+    const int32_t* __restrict__ ent = m.fuEntry + tpl * m.fuCapE * 128 + (tid & 127);
+    const uint16_t* __restrict__ vPos = m.fuVPos + tpl * capPE * capV + vt;
+    Pos3 fp[KF];
+#pragma unroll
+    for (int j = 0; j < KF; ++j) fp[j] = tFacePos[min(tid + j * NT, capF - 1)];
+    int e6[KE];
+#pragma unroll
+    for (int i = 0; i < KE; ++i) e6[i] = ent[(size_t)min(i, m.fuCapE - 1) * 128];
+    int pcPos[KP];
+#pragma unroll
+    for (int i = 0; i < KP; ++i) pcPos[i] = (int)vPos[(size_t)min(i, capPE - 1) * capV];
     const v2d* __restrict__ gA = reinterpret_cast<const v2d*>(c.A);
     const v2d* __restrict__ gB = reinterpret_cast<const v2d*>(c.B);
     const v2d* __restrict__ gP = reinterpret_cast<const v2d*>(c.P);
@@ -1207,7 +1219,7 @@ void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm, 
     double fw[KF], fh[KF];
     int fk[KF];
 #pragma unroll
-    for (int j = 0; j < KF; ++j) { fw[j] = ldStream(m.w + fc[j].x); fh[j] = ldStream(m.hf + fc[j].x); fk[j] = m.fkind[fc[j].x]; }
+    for (int j = 0; j < KF; ++j) { fw[j] = ldStream(m.w + fl[j]); fh[j] = ldStream(m.hf + fl[j]); fk[j] = m.fkind[fl[j]]; }
     const double rEold = c.rE[ci], Vc = m.V[ci], hq = m.hQGD[ci];
     v2d dPt[3];
     dPt[0] = dPt[1] = dPt[2] = v2d{0.0, 0.0};
@@ -1294,8 +1306,8 @@ void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm, 
     for (int j = 0; j < KF; ++j) {
         const int lf = tid + j * NT;
         if (lf < nFc) {
-            const int f = fc[j].x, kind = fk[j];
-            const unsigned lc = (unsigned)fc[j].y, lva = (unsigned)fc[j].z, lvb = (unsigned)fc[j].w;
+            const int f = fl[j], kind = fk[j];
+            const unsigned lc = fp[j].c, lva = fp[j].va, lvb = fp[j].vb;
             const int lo = (int)(lc & 0xffffu), ln = (int)(lc >> 16);
             const int v0 = (int)(lva & 0xffffu), v1 = (int)(lva >> 16), v2 = (int)(lvb & 0xffffu), v3 = (int)(lvb >> 16);
             double S[3] = {0.0, 0.0, 0.0};

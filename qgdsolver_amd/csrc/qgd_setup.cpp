@@ -10,6 +10,8 @@
 #include "qgd_setup.hpp"
 
 #include <algorithm>
+#include <array>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -693,11 +695,26 @@ struct OneBlock {
     int32_t nAll = 0, maxPE = 0, lds = 0;             // own + across-a-face cells (cells.size() counts the extras too); LDS bytes of its records
     std::vector<uint8_t> nEntry;
     int32_t nOwn = 0, maxE = 0;
+    // 128-bit fingerprint of the block's local topology (counts, per-face positions, face entries, per-vertex cell positions): what two
+    // blocks must share to share a template
+    std::array<uint64_t, 2> topoHash() const {
+        uint64_t h1 = 0x9e3779b97f4a7c15ull, h2 = 0xc2b2ae3d27d4eb4full;
+        auto mix = [&](uint64_t x) {
+            h1 = (h1 ^ x) * 0x100000001b3ull; h1 ^= h1 >> 29;
+            h2 = (h2 + x) * 0xff51afd7ed558ccdull; h2 ^= h2 >> 32;
+        };
+        mix((uint64_t)nOwn); mix((uint64_t)nAll); mix((uint64_t)cells.size()); mix((uint64_t)verts.size()); mix((uint64_t)face.size()); mix((uint64_t)maxE); mix((uint64_t)maxPE);
+        for (size_t lf = 0; lf < face.size() / 4; ++lf) { mix((uint32_t)face[4 * lf + 1]); mix((uint32_t)face[4 * lf + 2]); mix((uint32_t)face[4 * lf + 3]); }
+        for (size_t j = 0; j < (size_t)nOwn; ++j) { mix(nEntry[j]); for (int k = 0; k < nEntry[j]; ++k) mix((uint32_t)entry[j * (size_t)maxE + k]); }
+        for (size_t lv = 0; lv < verts.size(); ++lv) { mix(vCount[lv]); for (int k = 0; k < vCount[lv]; ++k) mix(vPos[lv * (size_t)maxPE + k]); }
+        return {h1, h2};
+    }
 };
 }  // namespace
 
 FusedBlocks buildFusedBlocks(const StaticData& s) {
     FusedBlocks B;
+    const auto tStart = std::chrono::steady_clock::now();
     const int64_t nC = s.nC, nIF = s.nIF;
     if (nC == 0 || nIF == 0 || s.nGeomD != 3) return B;
     if (3 * (int64_t)s.nC > INT32_MAX || 3 * (int64_t)s.nP > INT32_MAX) return B;
@@ -959,17 +976,23 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
     // straight into the padded tables: twice the arithmetic instead of half a million small vectors kept between the passes.
     std::vector<int32_t> nOf;
     std::vector<std::vector<std::pair<int64_t, int64_t>>> cuts;   // only for the ranges that were cut
+    using Hash = std::array<uint64_t, 2>;
+    std::vector<Hash> hashOne;                  // the topology fingerprint of a range that is one block
+    std::vector<std::vector<Hash>> hashCuts;    // ... of the blocks of a range that was cut
     bool failed = false;
     int64_t facesDone = 0, cellsTot = 0, cellsAll = 0, vertsTot = 0;
     int32_t maxC = 0, maxV = 0, maxF = 0, maxE = 1, maxAll = 0, maxPE = 1, maxLds = 0;
     // keep the first way of cutting ranges whose blocks average 104 cells or more, else the one with the largest average
     struct Kept { std::vector<int64_t> rangeStart; std::vector<int32_t> nOf; std::vector<std::vector<std::pair<int64_t, int64_t>>> cuts;
+                  std::vector<Hash> hashOne; std::vector<std::vector<Hash>> hashCuts; bool bricks = false;
                   int64_t nRanges = 0, facesDone = 0, cellsTot = 0, cellsAll = 0, vertsTot = 0, blocks = 0;
                   int32_t maxC = 0, maxV = 0, maxF = 0, maxE = 1, maxAll = 0, maxPE = 1, maxLds = 0; } best;
     for (const int64_t len : {(int64_t)0, (int64_t)112, (int64_t)96, (int64_t)80, (int64_t)64}) {
         if (len == 0) brickRanges(); else runRanges(len);
         nOf.assign((size_t)nRanges, 1);
         cuts.assign((size_t)nRanges, {});
+        hashOne.assign((size_t)nRanges, Hash{0, 0});
+        hashCuts.assign((size_t)nRanges, {});
         failed = false;
         facesDone = cellsTot = cellsAll = vertsTot = 0;
         maxC = maxV = maxF = maxAll = maxLds = 0; maxE = maxPE = 1;
@@ -984,11 +1007,13 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
                 stop = failed;
                 if (stop) continue;
                 std::vector<std::pair<int64_t, int64_t>> work{rangeOf(r)}, done;
+                std::vector<Hash> doneHash;
                 while (!work.empty()) {
                     const auto [b0, b1] = work.back();
                     work.pop_back();
                     if (tryBlock(b0, b1, o, maps[0], maps[1], maps[2])) {
                         done.push_back({b0, b1});
+                        doneHash.push_back(o.topoHash());
                         maxC = std::max<int32_t>(maxC, (int32_t)o.cells.size());
                         maxV = std::max<int32_t>(maxV, (int32_t)o.verts.size());
                         maxF = std::max<int32_t>(maxF, (int32_t)o.face.size() / 4);
@@ -1010,14 +1035,17 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
                     work.push_back({b0, mid});
                 }
                 nOf[r] = (int32_t)done.size();
-                if (done.size() != 1) cuts[r] = std::move(done);
+                if (done.size() != 1) { cuts[r] = std::move(done); hashCuts[r] = std::move(doneHash); }
+                else hashOne[r] = doneHash[0];
             }
         }
         if (failed) break;
         int64_t blocks = 0;
         for (int64_t r = 0; r < nRanges; ++r) blocks += nOf[r];
         if (best.blocks == 0 || blocks < best.blocks) {
+            best.bricks = (len == 0);
             best.rangeStart = rangeStart; best.nOf = nOf; best.cuts = cuts; best.nRanges = nRanges;
+            best.hashOne = hashOne; best.hashCuts = hashCuts;
             best.facesDone = facesDone; best.cellsTot = cellsTot; best.cellsAll = cellsAll; best.vertsTot = vertsTot; best.blocks = blocks;
             best.maxC = maxC; best.maxV = maxV; best.maxF = maxF; best.maxE = maxE; best.maxAll = maxAll; best.maxPE = maxPE; best.maxLds = maxLds;
         }
@@ -1025,6 +1053,7 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
     }
     if (!failed) {
         rangeStart.swap(best.rangeStart); nOf.swap(best.nOf); cuts.swap(best.cuts); nRanges = best.nRanges;
+        hashOne.swap(best.hashOne); hashCuts.swap(best.hashCuts);
         facesDone = best.facesDone; cellsTot = best.cellsTot; cellsAll = best.cellsAll; vertsTot = best.vertsTot;
         maxC = best.maxC; maxV = best.maxV; maxF = best.maxF; maxE = best.maxE; maxAll = best.maxAll; maxPE = best.maxPE; maxLds = best.maxLds;
     }
@@ -1033,9 +1062,10 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
     // overlap the exchange with the rest (qgd_capi.cpp stepAdvance).  They are whole bricks like every other block -- round 5 gave the
     // one-plane boundary layer blocks of its own, flat 8 x 8 x 1 ones of 64 cells that staged three records per cell.
     std::vector<std::pair<int64_t, int64_t>> blk;   // every block's range of the sorted cells, in range order
+    std::vector<Hash> blkHash;
     for (int64_t r = 0; r < nRanges; ++r) {
-        if (nOf[r] == 1) blk.push_back(rangeOf(r));
-        else blk.insert(blk.end(), cuts[r].begin(), cuts[r].end());
+        if (nOf[r] == 1) { blk.push_back(rangeOf(r)); blkHash.push_back(hashOne[r]); }
+        else { blk.insert(blk.end(), cuts[r].begin(), cuts[r].end()); blkHash.insert(blkHash.end(), hashCuts[r].begin(), hashCuts[r].end()); }
     }
     const int64_t nBlocks = (int64_t)blk.size();
     std::vector<uint8_t> layerBlock((size_t)nBlocks, 0);
@@ -1057,53 +1087,85 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
     B.capC = (B.maxC + 7) / 8 * 8; B.capV = (B.maxV + 7) / 8 * 8; B.capF = (B.maxF + 7) / 8 * 8;
     B.capE = maxE;
     B.capPE = maxPE; B.maxTot = maxC; B.maxAll = maxAll; B.maxLds = maxLds;
-    if (nBlocks * (int64_t)std::max({B.capC, B.capV * B.capPE, 4 * B.capF, B.capE * kFusedCells}) > (int64_t)INT32_MAX) return B;
+    // templates: the distinct topology fingerprints in ascending order (deterministic); a block's template = its fingerprint's rank; the
+    // template's tables are written by the first block (in launch order) that has it.  QGD_FUSED_TEMPLATES=0: one template per block.
+    std::vector<int32_t> tplOf((size_t)nBlocks, 0);      // by launch position
+    std::vector<int64_t> tplWriter;                       // range-order index of the block that writes template t
+    int64_t nTemplates = nBlocks;
+    bool templated = false;
+    {
+        std::vector<Hash> uniq(blkHash);
+        std::sort(uniq.begin(), uniq.end());
+        uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+        const char* e = std::getenv("QGD_FUSED_TEMPLATES");
+        templated = !(e && std::atoi(e) == 0) && (int64_t)uniq.size() < nBlocks;   // any two blocks alike
+        if (templated) {
+            nTemplates = (int64_t)uniq.size();
+            tplWriter.assign((size_t)nTemplates, -1);
+            std::vector<int64_t> writerPos((size_t)nTemplates, INT64_MAX);
+            for (int64_t ib = 0; ib < nBlocks; ++ib) {
+                const int64_t t = std::lower_bound(uniq.begin(), uniq.end(), blkHash[ib]) - uniq.begin();
+                tplOf[(size_t)first[ib]] = (int32_t)t;
+                if (first[ib] < writerPos[t]) { writerPos[t] = first[ib]; tplWriter[t] = ib; }
+            }
+        } else {
+            for (int64_t b = 0; b < nBlocks; ++b) tplOf[b] = (int32_t)b;
+        }
+    }
+    if (std::max(nBlocks * (int64_t)std::max({B.capC, B.capV * B.capPE, B.capF}), nTemplates * (int64_t)std::max({B.capV * B.capPE, 3 * B.capF, B.capE * kFusedCells})) >
+        (int64_t)INT32_MAX) return B;
     B.nBlocks = (int32_t)nBlocks;
     B.nLayerBlocks = (int32_t)nLayerBlocks;
+    B.nTemplates = (int32_t)nTemplates; B.templated = templated ? 1 : 0;
+    for (int d = 0; d < 3; ++d) B.brick[d] = best.bricks ? (int32_t)kBrick[d] : 0;
     B.facesComputed = facesDone; B.cellsStaged = cellsTot; B.cellsStagedFull = cellsAll; B.vertsStaged = vertsTot;
     B.hdr.resize(4 * (size_t)nBlocks);
     B.hdr2.resize(4 * (size_t)nBlocks);
     B.vCount.resize((size_t)nBlocks * B.capV);
-    B.vPos.resize((size_t)nBlocks * B.capPE * B.capV);
     B.vW.resize((size_t)nBlocks * B.capPE * B.capV);
     B.cells.resize((size_t)nBlocks * B.capC);
     B.verts.resize((size_t)nBlocks * B.capV);
-    B.face.resize((size_t)nBlocks * B.capF * 4);
+    B.faceLabel.resize((size_t)nBlocks * B.capF);
     B.nEntry.resize((size_t)nBlocks * kFusedCells);
-    B.entry.resize((size_t)nBlocks * B.capE * kFusedCells);
+    B.vPos.resize((size_t)nTemplates * B.capPE * B.capV);
+    B.facePos.resize((size_t)nTemplates * B.capF * 3);
+    B.entry.resize((size_t)nTemplates * B.capE * kFusedCells);
 #pragma omp parallel
     {
         std::vector<SmallMap> maps(3);
         OneBlock o;
 #pragma omp for schedule(dynamic, 64)
         for (int64_t ib = 0; ib < nBlocks; ++ib) {
-            {
-                const auto [b0, b1] = blk[ib];
-                tryBlock(b0, b1, o, maps[0], maps[1], maps[2]);
-                const size_t b = (size_t)first[ib];
-                const int32_t nTot = (int32_t)o.cells.size(), nV = (int32_t)o.verts.size(), nF = (int32_t)o.face.size() / 4;
-                B.hdr[4 * b] = o.nOwn; B.hdr[4 * b + 1] = o.nAll; B.hdr[4 * b + 2] = nV; B.hdr[4 * b + 3] = nF;
-                B.hdr2[4 * b] = nTot; B.hdr2[4 * b + 1] = B.hdr2[4 * b + 2] = B.hdr2[4 * b + 3] = 0;
-                for (int32_t i = 0; i < B.capC; ++i) B.cells[b * B.capC + i] = o.cells[std::min(i, nTot - 1)];
-                for (int32_t i = 0; i < B.capV; ++i) {
-                    const int32_t n = i < nV ? o.vCount[i] : 0;
-                    B.vCount[b * B.capV + i] = (uint8_t)n;
-                    for (int32_t e = 0; e < B.capPE; ++e) {
-                        B.vPos[(b * B.capPE + e) * B.capV + i] = e < n ? o.vPos[(size_t)i * o.maxPE + e] : (uint16_t)0;
-                        B.vW[(b * B.capPE + e) * B.capV + i] = e < n ? o.vW[(size_t)i * o.maxPE + e] : 0.0;
-                    }
-                }
-                for (int32_t i = 0; i < B.capV; ++i) B.verts[b * B.capV + i] = nV ? o.verts[std::min(i, nV - 1)] : 0;
-                for (int32_t i = 0; i < B.capF; ++i)
-                    for (int q = 0; q < 4; ++q) B.face[(b * B.capF + i) * 4 + q] = nF ? o.face[4 * (size_t)std::min(i, nF - 1) + q] : 0;
-                for (int32_t j = 0; j < kFusedCells; ++j) {
-                    const int32_t nE = j < o.nOwn ? o.nEntry[j] : 0;
-                    B.nEntry[b * kFusedCells + j] = (uint8_t)nE;
-                    for (int32_t e = 0; e < B.capE; ++e) B.entry[(b * B.capE + e) * kFusedCells + j] = e < nE ? o.entry[(size_t)j * o.maxE + e] : 0;
-                }
+            const auto [b0, b1] = blk[ib];
+            tryBlock(b0, b1, o, maps[0], maps[1], maps[2]);
+            const size_t b = (size_t)first[ib];
+            const int32_t nTot = (int32_t)o.cells.size(), nV = (int32_t)o.verts.size(), nF = (int32_t)o.face.size() / 4;
+            const size_t t = (size_t)tplOf[b];
+            B.hdr[4 * b] = o.nOwn; B.hdr[4 * b + 1] = o.nAll; B.hdr[4 * b + 2] = nV; B.hdr[4 * b + 3] = nF;
+            B.hdr2[4 * b] = nTot; B.hdr2[4 * b + 1] = (int32_t)t; B.hdr2[4 * b + 2] = B.hdr2[4 * b + 3] = 0;
+            for (int32_t i = 0; i < B.capC; ++i) B.cells[b * B.capC + i] = o.cells[std::min(i, nTot - 1)];
+            for (int32_t i = 0; i < B.capV; ++i) {
+                const int32_t n = i < nV ? o.vCount[i] : 0;
+                B.vCount[b * B.capV + i] = (uint8_t)n;
+                for (int32_t e = 0; e < B.capPE; ++e) B.vW[(b * B.capPE + e) * B.capV + i] = e < n ? o.vW[(size_t)i * o.maxPE + e] : 0.0;
+            }
+            for (int32_t i = 0; i < B.capV; ++i) B.verts[b * B.capV + i] = nV ? o.verts[std::min(i, nV - 1)] : 0;
+            for (int32_t i = 0; i < B.capF; ++i) B.faceLabel[b * B.capF + i] = nF ? o.face[4 * (size_t)std::min(i, nF - 1)] : 0;
+            for (int32_t j = 0; j < kFusedCells; ++j) B.nEntry[b * kFusedCells + j] = (uint8_t)(j < o.nOwn ? o.nEntry[j] : 0);
+            if (templated && tplWriter[t] != ib) continue;   // the template's tables are another block's to write
+            for (int32_t i = 0; i < B.capV; ++i) {
+                const int32_t n = i < nV ? o.vCount[i] : 0;
+                for (int32_t e = 0; e < B.capPE; ++e) B.vPos[(t * B.capPE + e) * B.capV + i] = e < n ? o.vPos[(size_t)i * o.maxPE + e] : (uint16_t)0;
+            }
+            for (int32_t i = 0; i < B.capF; ++i)
+                for (int q = 0; q < 3; ++q) B.facePos[(t * B.capF + i) * 3 + q] = nF ? (uint32_t)o.face[4 * (size_t)std::min(i, nF - 1) + 1 + q] : 0u;
+            for (int32_t j = 0; j < kFusedCells; ++j) {
+                const int32_t nE = j < o.nOwn ? o.nEntry[j] : 0;
+                for (int32_t e = 0; e < B.capE; ++e) B.entry[(t * B.capE + e) * kFusedCells + j] = e < nE ? o.entry[(size_t)j * o.maxE + e] : 0;
             }
         }
     }
+    B.buildSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - tStart).count();
     return B;
 }
 

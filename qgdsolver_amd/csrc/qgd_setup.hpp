@@ -161,19 +161,28 @@ struct FusedBlocks {
     RawVec<int32_t> hdr;      // 4 per block: own cells, staged cells, staged vertices, faces
     RawVec<int32_t> cells;    // capC per block
     RawVec<int32_t> verts;    // capV per block
-    RawVec<int32_t> face;     // 4 per face, capF faces per block: label, lo | ln << 16, v0 | v1 << 16, v2 | v3 << 16 (positions in the staged lists)
+    RawVec<int32_t> faceLabel;   // capF per block: the global face label
+    // The block's LOCAL TOPOLOGY -- per face the positions of its two cells and four vertices in the staged lists, per own cell its face
+    // entries, per vertex the positions of its cells -- is stored per TEMPLATE, and hdr2[1] names a block's template: the interior bricks of
+    // a structured region are all alike (a 400^3 box: 500 000 blocks, a few hundred templates), so 12.4 of the 31.3 KB a block streamed per step
+    // in round 5 stay in L2 instead.  Blocks with a patch face (its entry is the face's own label) and the blocks of a jittered, renumbered mesh
+    // (no two bricks list their cells alike) have templates of their own: the same bytes as before, read through the template id.
+    int32_t nTemplates = 0, templated = 0;
+    RawVec<uint32_t> facePos;    // 3 per face, capF faces per template: lo | ln << 16, v0 | v1 << 16, v2 | v3 << 16 (positions in the staged lists)
     // the vertex values formed inside the block (volPointInterpolation's inverse-distance weights, pointCells order): the cells around the
     // block's vertices that are neither its own nor across one of its faces ("extra": edge and corner neighbours) are staged too, behind
     // the others in `cells`; hdr2[0] = all staged cells.  Per vertex: its cells' positions in `cells` and the weights, entry-major
     // (capPE x capV per block); count 0 = a patch point, whose value the patch-point kernel has put into the vertex records.
     int32_t capPE = 0, maxTot = 0, maxAll = 0;        // cells per vertex; staged cells incl. extras / without them, of the largest block
     int32_t maxLds = 0;                               // LDS bytes of the records of the block that needs most (the kernel lays each block out by its own counts)
-    RawVec<int32_t> hdr2;     // 4 per block: all staged cells, 0, 0, 0
+    RawVec<int32_t> hdr2;     // 4 per block: all staged cells, template, 0, 0
     RawVec<uint8_t> vCount;   // capV per block
-    RawVec<uint16_t> vPos;    // capPE x capV per block
+    RawVec<uint16_t> vPos;    // capPE x capV per template
     RawVec<double> vW;        // capPE x capV per block
     RawVec<uint8_t> nEntry;   // 128 per block: face entries of each own cell
-    RawVec<int32_t> entry;    // capE x 128 per block, entry-major: (local face << 1) | (1: the cell is the neighbour, minus), or ~label of a boundary face
+    RawVec<int32_t> entry;    // capE x 128 per template, entry-major: (local face << 1) | (1: the cell is the neighbour, minus), or ~label of a boundary face
+    int32_t brick[3] = {0, 0, 0};  // the lattice brick the blocks were cut from (8 x 4 x 4 unless another shape fills the blocks better; 0: count-based runs)
+    double buildSeconds = 0.0;     // host time of buildFusedBlocks
     int64_t facesComputed = 0;     // over all blocks (a face between two blocks is computed by both)
     int64_t cellsStaged = 0, cellsStagedFull = 0, vertsStaged = 0;   // over all blocks: cell records staged (RecA), of which with RecB + centre; vertices formed
 };

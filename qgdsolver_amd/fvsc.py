@@ -70,6 +70,14 @@ class Device:
         L.check(L.lib.qgd_device_lsq_stencil(self._h, int(face), out, cap, C.byref(n)), "qgd_device_lsq_stencil")
         return [int(out[i]) for i in range(min(n.value, cap))]
 
+    def fused_blocks(self):
+        """the block tables of the fused explicit step on this device (qgd_device_fused_blocks)"""
+        a = (C.c_int64 * 8)()
+        L.check(L.lib.qgd_device_fused_blocks(self._h, a), "qgd_device_fused_blocks")
+        b = int(a[7])
+        return dict(blocks=int(a[0]), layerBlocks=int(a[1]), templates=int(a[2]), ldsBytes=int(a[3]), blockListBytes=int(a[4]),
+                    templateBytes=int(a[5]), buildSeconds=a[6] / 1e3, brick=(b & 255, (b >> 8) & 255, (b >> 16) & 255))
+
     def face_tiles(self):
         """how the internal faces go through the 3-D GaussVolPoint flux kernel (qgd_device_face_tiles)"""
         a = (C.c_int64 * 4)()

@@ -27,7 +27,7 @@ static int fails = 0;
         }                                                  \
     } while (0)
 
-static void checkMesh(const char* tag, HostMesh& m, double minMeanCells = 0.0) {
+static void checkMesh(const char* tag, HostMesh& m, double minMeanCells = 0.0, int maxTemplates = -1) {
     if (m.magSf.empty()) m.computeGeometry();
     m.computeDerived();
     const StaticData s = buildStaticData(m);
@@ -45,6 +45,9 @@ static void checkMesh(const char* tag, HostMesh& m, double minMeanCells = 0.0) {
         CHECK(mean >= minMeanCells, "%s: %.1f cells per block on average, %.1f wanted", tag, mean, minMeanCells);
     }
     std::vector<int> ownerBlock((size_t)s.nC, -1);
+    std::vector<int> tplUsed((size_t)std::max(B.nTemplates, 1), 0);
+    std::printf("    %d templates for %d blocks (%s)\n", B.nTemplates, B.nBlocks, B.templated ? "shared" : "one per block");
+    CHECK(maxTemplates < 0 || B.nTemplates <= maxTemplates, "%s: %d templates, at most %d wanted", tag, B.nTemplates, maxTemplates);
     int32_t maxTot = 0, maxAll = 0, maxV = 0, maxF = 0, maxLds = 0;
     int64_t faces = 0;
     for (int32_t b = 0; b < B.nBlocks; ++b) {
@@ -84,10 +87,15 @@ static void checkMesh(const char* tag, HostMesh& m, double minMeanCells = 0.0) {
             }
         }
         CHECK((int32_t)want.size() == nF, "block %d: %d faces listed, %d wanted", b, nF, (int)want.size());
-        const int32_t* face = &B.face[(size_t)b * B.capF * 4];
+        // the block's local topology sits in its template (hdr2[1]); blocks that share one must expand to their own labels all the same
+        const int32_t tpl = B.hdr2[4 * b + 1];
+        CHECK(tpl >= 0 && tpl < B.nTemplates && (B.templated || tpl == b) && (B.templated == (B.nTemplates < B.nBlocks)), "block %d template %d of %d", b, tpl, B.nTemplates);
+        tplUsed[tpl]++;
+        const int32_t* face = &B.faceLabel[(size_t)b * B.capF];
+        const uint32_t* fpos = &B.facePos[(size_t)tpl * B.capF * 3];
         for (int32_t lf = 0; lf < nF; ++lf) {
-            const int32_t f = face[4 * lf];
-            const uint32_t lc = (uint32_t)face[4 * lf + 1], va = (uint32_t)face[4 * lf + 2], vb = (uint32_t)face[4 * lf + 3];
+            const int32_t f = face[lf];
+            const uint32_t lc = fpos[3 * lf], va = fpos[3 * lf + 1], vb = fpos[3 * lf + 2];
             CHECK(want.count(f) == 1, "block %d lists face %d", b, f);
             CHECK((int32_t)(lc & 0xffff) < nAll && (int32_t)(lc >> 16) < nAll, "block %d face %d cell positions", b, f);
             CHECK(cells[lc & 0xffff] == s.own[f] && cells[lc >> 16] == s.nei[f], "block %d face %d owner / neighbour", b, f);
@@ -96,10 +104,12 @@ static void checkMesh(const char* tag, HostMesh& m, double minMeanCells = 0.0) {
                 const int32_t v = s.verts[4 * (size_t)f + q];
                 if (v >= 0) CHECK((int32_t)pv[q] < nV && verts[pv[q]] == v, "block %d face %d vertex %d", b, f, q);
             }
-            if (lf > 0) CHECK(face[4 * (lf - 1)] < f, "block %d faces not ascending", b);
+            if (lf > 0) CHECK(face[lf - 1] < f, "block %d faces not ascending", b);
         }
-        for (int32_t lf = nF; lf < B.capF; ++lf)
-            for (int q = 0; q < 4; ++q) CHECK(nF == 0 || face[4 * lf + q] == face[4 * (nF - 1) + q], "block %d face padding", b);
+        for (int32_t lf = nF; lf < B.capF; ++lf) {
+            CHECK(nF == 0 || face[lf] == face[nF - 1], "block %d face padding", b);
+            for (int q = 0; q < 3; ++q) CHECK(nF == 0 || fpos[3 * lf + q] == fpos[3 * (nF - 1) + q], "block %d face padding", b);
+        }
         // face entries of the own cells
         for (int32_t j = 0; j < kFusedCells; ++j) {
             const int nE = B.nEntry[(size_t)b * kFusedCells + j];
@@ -109,9 +119,9 @@ static void checkMesh(const char* tag, HostMesh& m, double minMeanCells = 0.0) {
             const size_t base = (size_t)s.cfSlice[c >> 6] * 64 + (c & 63);
             for (int e = 0; e < nE; ++e) {
                 const int32_t it = s.cfItem[base + (size_t)e * 64], f = it >= 0 ? it : ~it;
-                const int32_t got = B.entry[((size_t)b * B.capE + e) * kFusedCells + j];
+                const int32_t got = B.entry[((size_t)tpl * B.capE + e) * kFusedCells + j];
                 if (f >= s.nIF) CHECK(got == ~f && it >= 0, "block %d cell %d patch-face entry", b, c);
-                else CHECK(got >= 0 && (got >> 1) < nF && face[4 * (got >> 1)] == f && (got & 1) == (it < 0 ? 1 : 0), "block %d cell %d entry %d", b, c, e);
+                else CHECK(got >= 0 && (got >> 1) < nF && face[got >> 1] == f && (got & 1) == (it < 0 ? 1 : 0), "block %d cell %d entry %d", b, c, e);
             }
         }
         // vertex tables
@@ -122,7 +132,7 @@ static void checkMesh(const char* tag, HostMesh& m, double minMeanCells = 0.0) {
             CHECK(n == s.pcCount[v] && n <= B.capPE, "block %d vertex %d count", b, v);
             const size_t base = (size_t)s.pcSlice[v >> 6] * 64 + (v & 63);
             for (int e = 0; e < n; ++e) {
-                const int32_t pos = B.vPos[((size_t)b * B.capPE + e) * B.capV + lv];
+                const int32_t pos = B.vPos[((size_t)tpl * B.capPE + e) * B.capV + lv];
                 CHECK(pos < nTot && cells[pos] == s.pcCell[base + (size_t)e * 64], "block %d vertex %d cell %d", b, v, e);
                 CHECK(B.vW[((size_t)b * B.capPE + e) * B.capV + lv] == s.pcW[base + (size_t)e * 64], "block %d vertex %d weight %d", b, v, e);
             }
@@ -132,6 +142,7 @@ static void checkMesh(const char* tag, HostMesh& m, double minMeanCells = 0.0) {
         const int role = s.ghost.empty() ? 0 : s.ghost[c];
         CHECK((ownerBlock[c] >= 0) == (role != 1), "cell %d (role %d) block %d", c, role, ownerBlock[c]);
     }
+    for (int32_t t = 0; t < B.nTemplates; ++t) CHECK(tplUsed[t] >= 1, "%s: template %d is nobody's", tag, t);
     CHECK(maxTot == B.maxTot && maxAll == B.maxAll && maxV == B.maxV && maxF == B.maxF, "%s: maxima %d %d %d %d vs %d %d %d %d", tag, maxTot, maxAll, maxV,
           maxF, B.maxTot, B.maxAll, B.maxV, B.maxF);
     CHECK(maxLds == B.maxLds, "%s: LDS %d vs %d", tag, maxLds, B.maxLds);
@@ -154,8 +165,13 @@ int main() {
     { HostMesh m = makeBox(12, 6, 12, 3, 9, lo, hi, pt); checkMesh("slab 3..9 of a 12x6x12 box (two cuts)", m); }
     // what a cut must not cost: a 50-plane slab between two cuts keeps brick-shaped blocks -- 13 brick layers of 3 or 4
     // planes, 123 cells per block -- and the blocks of the planes a neighbour waits for are whole bricks, not flat one-plane ones
-    { HostMesh m = makeBox(80, 80, 150, 49, 101, lo, hi, pt); checkMesh("planes 50..100 of an 80x80x150 box (50 owned planes between two ghost planes)", m, 120.0); }
-    { HostMesh m = makeBox(50, 50, 50, 0, 50, lo, hi, pt); checkMesh("box 50x50x50 (extents 8x4x4 bricks do not divide: 5x5x5 ones)", m, 120.0); }
+    { HostMesh m = makeBox(80, 80, 150, 49, 101, lo, hi, pt); checkMesh("planes 50..100 of an 80x80x150 box (50 owned planes between two ghost planes)", m, 120.0, 2600 - 8 * 18 * 11 + 40); }   // the 8 x 18 x 11 bricks without a patch face or a ghost plane share a handful of templates
+    { HostMesh m = makeBox(50, 50, 50, 0, 50, lo, hi, pt); checkMesh("box 50x50x50 (extents 8x4x4 bricks do not divide: 5x5x5 ones)", m, 120.0, 1000 - 8 * 8 * 8 + 1); }   // 512 interior cubes, ONE template
+    {   // a jittered, Morton-renumbered mesh: no two blocks list their cells alike -> one template per block, the kernel's untemplated path
+        HostMesh m = makeBox(24, 16, 16, 0, 16, lo, hi, pt);
+        jitterPoints(m, 0.15, 7);
+        splitQuads(m, 7);
+        checkMesh("jittered 24x16x16, every seventh quad split", m, 0.0, -1); }
     if (fails) { std::printf("%d checks failed\n", fails); return 1; }
     std::printf("ok\n");
     return 0;
