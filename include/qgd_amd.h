@@ -182,6 +182,17 @@ int qgd_mesh_morton_order(qgd_mesh_t m, int32_t* newOfOld);
  * and one halo slot per neighbouring rank.  qgd_mesh_get names of a shard: "cellGlobal","faceGlobal" (-1-label when
  * reversed),"pointGlobal","haloPeer","haloGhost<slot>","haloSend<slot>". */
 int qgd_mesh_shard(qgd_mesh_t global, int32_t nRanks, const int32_t* cellStart, int32_t rank, qgd_mesh_t* out);
+/* Translational cyclic patch pairs served by ghost cells.  The reference's stencils reach across a coupled patch through
+ * patchNeighbourField and the true neighbour centre [GaussVolPointBase3D_8C_source.html L398-415, L588, L688, L783-794;
+ * extendedFaceStencilScalarGrad_8C_source.html L90-101]; here the two halves of each pair are glued: `out` is the mesh followed by one
+ * vertex-connected layer of translated copies of its own cells behind every half (diagonal copies at the edges / corners where several pairs
+ * meet), the pairs' faces turned into internal faces between a real cell and a copy, the cyclic patches left empty (same indices), a
+ * trailing QGD_PATCH_HALO patch, and halo slots whose messages stay on the rank: qgd_mesh_get "haloSelf" names, per slot, the slot whose
+ * packed message it unpacks.  pairs = 2 * nPairs patch indices {A, B} with face i of A = face i of B shifted by one vector (checked:
+ * rotational pairs are refused with QGD_ERR_NOT_IMPLEMENTED); nPairs = 0 pairs consecutive cyclic patches.  Real cells, points and patch
+ * faces keep their labels ("cellGlobal" = the original of every cell).  A case on such a mesh steps with plain qgd_case_step (explicit branch):
+ * the library refreshes the copies from their originals after every step, on the case's stream. */
+int qgd_mesh_unroll_cyclic(qgd_mesh_t mesh, int32_t nPairs, const int32_t* pairs, qgd_mesh_t* out);
 /* number of halo slots (neighbouring shards) of a mesh; 0 when unsharded, 2 for a qgd_mesh_box slab */
 int qgd_mesh_halo_slots(qgd_mesh_t m, int32_t* nSlots);
 

@@ -93,8 +93,17 @@ def run(case_dir, n_steps=None, device_id=0, write=True, log=print, renumber="no
         owned = (mesh.array("cellGlobal") >= lo) & (mesh.array("cellGlobal") < hi)
     else:
         mesh, cells, owned = gmesh, old_of_new, np.ones(n_global, dtype=bool)
+    if getattr(gmesh, "cyclic_pairs", None):
+        # translational cyclic pairs: the halves are glued, translated copies of the cells behind either half are refreshed by the library
+        # after every step (PolyMesh.unroll_cyclic, DESIGN 6 "cyclic patches"); real cells keep their labels, the copies follow them
+        if world > 1 or opt.get("implicitDiffusion") or renumber != "none":
+            raise ff.FoamFileError(f"{case_dir}: a case with cyclic patches runs on one rank, explicit branch (QGD {{ implicitDiffusion false; }}), "
+                                   "in the case's own cell order")
+        mesh = gmesh.unroll_cyclic(gmesh.cyclic_pairs)
+        cells = mesh.array("cellGlobal")
+        owned = np.arange(mesh.nCells) < n_global
     # only a fixed-deltaT explicit case with one stencil runs the fused step: no block tables otherwise
-    eligible = not (opt.get("adjustTimeStep") or opt.get("implicitDiffusion") or opt.get("termStencils"))
+    eligible = not (opt.get("adjustTimeStep") or opt.get("implicitDiffusion") or opt.get("termStencils")) and opt["stencil"] == "GaussVolPoint"
     dev = Device(mesh, device_id, fv_schemes={"fvsc": {"default": opt["stencil"]}}, fused_tables=eligible)
     case = QGDFoamCase(dev, default_options(**opt))
     for i, bc in enumerate(bcs):
@@ -168,8 +177,8 @@ def run(case_dir, n_steps=None, device_id=0, write=True, log=print, renumber="no
         """owned cells of every rank -> the field in the case's own cell order (rank 0; None elsewhere)"""
         local = case.field(name)
         if world == 1:
-            out = np.empty_like(local)
-            out[cells] = local
+            out = np.empty((n_global,) + local.shape[1:])
+            out[cells[owned]] = local[owned]     # (a mesh with cyclic patches carries copies of its cells behind the real ones)
             return out
         parts = [None] * world if rank == 0 else None
         dist.gather_object((cells[owned], local[owned]), parts, dst=0)

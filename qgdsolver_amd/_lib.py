@@ -75,6 +75,7 @@ SIGNATURES = {
     "qgd_mesh_rcm_order": (C.c_int, [handle, c_int32_p]),
     "qgd_mesh_morton_order": (C.c_int, [handle, c_int32_p]),
     "qgd_mesh_shard": (C.c_int, [handle, C.c_int32, c_int32_p, C.c_int32, handle_p]),
+    "qgd_mesh_unroll_cyclic": (C.c_int, [handle, C.c_int32, c_int32_p, handle_p]),
     "qgd_mesh_halo_slots": (C.c_int, [handle, c_int32_p]),
     "qgd_mesh_set_geometry": (C.c_int, [handle, c_double_p, c_double_p, c_double_p, c_double_p]),
     "qgd_mesh_set_degenerate_faces": (C.c_int, [handle, C.c_int32, c_int32_p]),

@@ -248,6 +248,9 @@ struct qgd_device_s {
         int32_t nGhost = 0, nSend = 0, nGhostBF = 0, nSendBF = 0;
     };
     std::vector<HaloSlot> halo;
+    // cyclic patch pairs served by ghost cells (qgd_mesh_unroll_cyclic): slot k unpacks what slot haloSelf[k] of the SAME case packs
+    std::vector<int32_t> haloSelf;
+    bool periodic() const { if (haloSelf.empty()) return false; for (int32_t x : haloSelf) if (x < 0) return false; return true; }
     bool sharded() const { for (const HaloSlot& h : halo) if (h.nGhost || h.nSend) return true; return false; }
     int32_t ownedBegin = 0, ownedEnd = 0;      // local labels of the owned cells (contiguous by construction of the shard builders)
     std::vector<int32_t> cellGlobal;           // extracted shards: label in the unsharded mesh per local cell (ascending)
@@ -297,6 +300,8 @@ struct qgd_case_s {
     bool pRefresh = true;       // grad(p)'s word is GaussVolPoint: p's boundary conditions are re-evaluated inside it [GaussVolPointStencil_8C L73] (quirk B6)
     bool usesPoints = true;
     bool fused = false;         // qgd_case_step advances with fusedFaceCellKernel (QGD_FUSED)
+    std::vector<double*> selfBuf;   // cyclic pairs served by ghost cells: one message buffer per halo slot (selfHaloExchange)
+    bool ghostsCurrent = false;     // ... and whether the copies hold their originals' records (reset by set_fields / set_bc)
     bool hasQgdFlux = false;
     bool phiwRegistered = false;
     bool fieldsSet = false;
@@ -557,6 +562,7 @@ int qgd_mesh_get(qgd_mesh_t mh, const char* name, void* out, int64_t outBytes) {
         const auto& lists = ghost ? m.haloGhost : m.haloSend;
         if (slot >= 0 && slot < (int)lists.size()) I(lists[slot]); else I(tmp);
     } else if (s == "haloPeer") I(m.haloPeer);
+    else if (s == "haloSelf") I(m.haloSelf);
     else if (s == "cellGlobal") I(m.cellGlobal);
     else if (s == "faceGlobal") I(m.faceGlobal);
     else if (s == "pointGlobal") I(m.pointGlobal);
@@ -618,6 +624,28 @@ int qgd_mesh_shard(qgd_mesh_t global, int32_t nRanks, const int32_t* cellStart, 
         const std::string err = h->m.check();
         if (!err.empty()) { delete h; return fail(QGD_ERR_INVALID, "qgd_mesh_shard: " + err); }
     } catch (...) { delete h; throw; }
+    *out = h;
+    return QGD_OK;
+    QGD_CATCH
+}
+int qgd_mesh_unroll_cyclic(qgd_mesh_t mesh, int32_t nPairs, const int32_t* pairs, qgd_mesh_t* out) {
+    QGD_TRY
+    if (!mesh || !out || (nPairs > 0 && !pairs)) return fail(QGD_ERR_INVALID, "qgd_mesh_unroll_cyclic: null argument");
+    std::vector<std::pair<int32_t, int32_t>> pr;
+    if (nPairs > 0) for (int32_t k = 0; k < nPairs; ++k) pr.push_back({pairs[2 * k], pairs[2 * k + 1]});
+    else {   // consecutive cyclic patches with faces are the two halves of a pair (how blockMesh / createPatch write them)
+        std::vector<int32_t> cyc;
+        for (size_t i = 0; i < mesh->m.patches.size(); ++i) if (mesh->m.patches[i].type == QGD_PATCH_CYCLIC && mesh->m.patches[i].size > 0) cyc.push_back((int32_t)i);
+        if (cyc.empty() || cyc.size() % 2) return fail(QGD_ERR_INVALID, "qgd_mesh_unroll_cyclic: the mesh has no cyclic patches, or an odd number of them");
+        for (size_t i = 0; i < cyc.size(); i += 2) pr.push_back({cyc[i], cyc[i + 1]});
+    }
+    qgd_mesh_s* h = new qgd_mesh_s();
+    try {
+        h->m = unrollCyclic(mesh->m, pr);
+        const std::string err = h->m.check();
+        if (!err.empty()) { delete h; return fail(QGD_ERR_INVALID, "qgd_mesh_unroll_cyclic: " + err); }
+    } catch (const std::invalid_argument& e) { delete h; return fail(QGD_ERR_NOT_IMPLEMENTED, e.what()); }
+    catch (...) { delete h; throw; }
     *out = h;
     return QGD_OK;
     QGD_CATCH
@@ -800,6 +828,8 @@ static int deviceCreate(qgd_mesh_t mh, int deviceId, int fusedChoice, qgd_device
             d->nSendAll = (int32_t)sc.size(); d->nSendBFAll = (int32_t)sf.size();
             d->sendAll = a.upload(sc); d->sendBFAll = a.upload(sf);
         }
+        d->haloSelf = m.haloSelf;
+        if (!d->haloSelf.empty() && d->haloSelf.size() != s.haloGhost.size()) throw std::invalid_argument("qgd_device_create: haloSelf does not match the halo slots");
         d->halo.resize(s.haloGhost.size());
         for (size_t slot = 0; slot < d->halo.size(); ++slot) {
             qgd_device_s::HaloSlot& h = d->halo[slot];
@@ -1675,6 +1705,7 @@ int qgd_case_set_fields(qgd_case_t c, const double* U, const double* T, const do
     } catch (...) { cleanup(); throw; }
     cleanup();
     c->phiwRegistered = true;  // createFaceFluxes.H registers "phiwStar" before the loop starts
+    c->ghostsCurrent = false;  // (cyclic pairs served by ghost cells: the copies take their originals' records before the first step)
     c->fieldsSet = true;
     c->gradUValid = false;
     c->impl.have = 0;          // the start values of the implicit solves begin without a history
@@ -1834,13 +1865,63 @@ static void stepAdvance(qgd_case_s* c, int part) {
     }
 }
 
+// cyclic pairs served by ghost cells: every slot packs into the case's own buffers, every slot unpacks what its partner slot packed
+// (mid = the 2-double message in the middle of the assembly, see assembleFluxes)
+static void selfHaloExchange(qgd_case_s* c, bool mid) {
+    qgd_device_s* d = c->dev;
+    const size_t nSlots = d->halo.size();
+    if (c->selfBuf.size() != nSlots) {
+        c->selfBuf.assign(nSlots, nullptr);
+        for (size_t k = 0; k < nSlots; ++k) {
+            const qgd_device_s::HaloSlot& h = d->halo[k];
+            const size_t n = std::max<size_t>(1, QGD_HALO_CELL_DOUBLES_HOST * (size_t)h.nSend + 12 * (size_t)h.nSendBF);
+            c->selfBuf[k] = c->arena.alloc<double>(n);
+        }
+    }
+    Launcher L = launcherOf(c);
+    L.pre = nullptr; L.post = nullptr;
+    (void)hipGetLastError();
+    for (size_t k = 0; k < nSlots; ++k) {
+        const qgd_device_s::HaloSlot& h = d->halo[k];
+        if (mid) { if (h.nSendBF) launchMidHalo(L.stream, c->view, h.sendBF, h.nSendBF, c->selfBuf[k], true); }
+        else if (h.nSend) launchHaloPack(L, c->view, c->gas, h.send, h.nSend, h.sendBF, h.nSendBF, c->selfBuf[k], true);
+    }
+    for (size_t k = 0; k < nSlots; ++k) {
+        const qgd_device_s::HaloSlot& h = d->halo[k];
+        const qgd_device_s::HaloSlot& from = d->halo[(size_t)d->haloSelf[k]];
+        if (from.nSend != h.nGhost || from.nSendBF != h.nGhostBF) throw std::runtime_error("cyclic self-exchange: a slot's ghosts do not match its partner's message");
+        double* buf = c->selfBuf[(size_t)d->haloSelf[k]];
+        if (mid) { if (h.nGhostBF) launchMidHalo(L.stream, c->view, h.ghostBF, h.nGhostBF, buf, false); }
+        else if (h.nGhost) launchHaloPack(L, c->view, c->gas, h.ghost, h.nGhost, h.ghostBF, h.nGhostBF, buf, false);
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
 int qgd_case_step(qgd_case_t c, int32_t nSteps) {
     QGD_TRY
     if (!c) return fail(QGD_ERR_INVALID, "null case");
     if (!c->fieldsSet) return fail(QGD_ERR_INVALID, "qgd_case_step: call qgd_case_set_fields first");
-    if (c->dev->sharded())
+    if (c->dev->sharded() && !c->dev->periodic())
         return fail(QGD_ERR_INVALID, "qgd_case_step: sharded mesh, drive it with qgd_case_step_phase + halo exchange");
     HIP_CHECK(hipSetDevice(c->dev->deviceId));
+    if (c->dev->periodic()) {
+        // cyclic pairs served by ghost cells: the copies are refreshed from their originals after every step (and in the middle of the
+        // assembly where a shard would exchange there), all on the case's stream -- what a rank does with its neighbours, with itself
+        if (c->opt.implicitDiffusion)
+            return fail(QGD_ERR_NOT_IMPLEMENTED, "qgd_case_step: the implicitDiffusion branch on a mesh with cyclic patches (qgd_mesh_unroll_cyclic) is not served: "
+                                                 "its solves would need the coupled rows; use the explicit branch");
+        if (!c->ghostsCurrent) { selfHaloExchange(c, false); c->ghostsCurrent = true; }
+        for (int i = 0; i < nSteps; ++i) {
+            if (midExchangeNeeded(c)) { stepAssemble(c, 1); selfHaloExchange(c, true); stepAssemble(c, 2); }
+            else stepAssemble(c);
+            if (c->opt.adjustTimeStep) {}   // (one rank: the shard's own maximum IS the global one)
+            stepAdvance(c, 0);
+            selfHaloExchange(c, false);
+        }
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(c->stream()));
+        return QGD_OK;
+    }
     for (int i = 0; i < nSteps; ++i) { stepAssemble(c); stepAdvance(c, 0); }
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(c->stream()));

@@ -12,6 +12,7 @@
 #pragma once
 #include <cstdint>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace qgd {
@@ -58,6 +59,9 @@ struct HostMesh {
     // both in ascending label order (box slabs: slot 0 = lower, slot 1 = upper neighbour, either may be empty)
     std::vector<std::vector<int32_t>> haloGhost, haloSend;
     std::vector<int32_t> haloPeer;     // rank behind each slot (-1 when the builder does not know it)
+    // cyclic patch pairs served by ghost cells (unrollCyclic): slot k's ghosts are copies of THIS mesh's own cells, and the message they
+    // expect is the one slot haloSelf[k] packs (empty, or -1 per slot, on an ordinary shard)
+    std::vector<int32_t> haloSelf;
     std::vector<uint8_t> cellIsGhost;  // nCells (empty when unsharded)
     // labels in the unsharded mesh (filled by extractShard, empty otherwise); faceGlobal is -1-label for flipped faces
     std::vector<int32_t> cellGlobal, faceGlobal, pointGlobal;
@@ -119,5 +123,9 @@ std::vector<int32_t> mortonOrder(const HostMesh& m);
 // one vertex-connected layer of ghost cells, every face of those cells (faces whose other cell is absent form a trailing
 // QGD_PATCH_HALO patch), halo lists per neighbouring rank.
 HostMesh extractShard(const HostMesh& g, int32_t nRanks, const int32_t* cellStart, int32_t rank);
+// Translational cyclic patch pairs (patch indices {A, B}: face i of A is face i of B shifted) served by ghost cells: the real mesh followed by
+// one vertex-connected layer of translated copies behind every half, the pairs' faces glued into internal faces, halo slots that refresh the
+// copies from their originals on the same rank (haloSelf).  Rotational pairs are refused.
+HostMesh unrollCyclic(const HostMesh& g, const std::vector<std::pair<int32_t, int32_t>>& pairs);
 
 }  // namespace qgd

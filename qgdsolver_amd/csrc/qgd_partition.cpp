@@ -7,6 +7,11 @@
 // vertex-connected ghost layer, which is exactly the neighbourhood volPointInterpolation and the leastSquares stencil
 // reach [FindNb.C:55-80] -- with the halo lists per neighbouring rank.  Host-side set-up code, nothing on the GPU.
 #include <algorithm>
+#include <utility>
+#include <unordered_map>
+#include <string>
+#include <map>
+#include <array>
 #include <cmath>
 #include <numeric>
 #include <queue>
@@ -304,6 +309,312 @@ HostMesh extractShard(const HostMesh& g, int32_t nRanks, const int32_t* cellStar
         m.haloPeer.push_back(r);
         m.haloGhost.push_back(ghostOf[r]);
         m.haloSend.push_back(s);
+    }
+    m.computeGeometry();
+    return m;
+}
+
+
+// ---- translational cyclic patch pairs served by ghost cells ---------------------------------------------------------------------------
+// The reference treats a coupled patch through patchNeighbourField / the true neighbour centre [GaussVolPointBase3D.C L398-415, L783-794
+// (processor patches); extendedFaceStencilScalarGrad.C L90-101].  Here the two halves of a cyclic pair are GLUED: behind every half sit
+// translated copies ("ghost cells") of the cells that touch the other half -- one vertex-connected layer, what volPointInterpolation and the
+// stencils reach -- so that a cyclic face becomes an internal face between a real cell and a ghost, computed by the internal-face kernels like
+// a cut face of a shard; the ghosts' records are refreshed from their originals once per step by the halo pack / unpack of the SAME rank
+// (haloSelf: the slot whose packed message a slot unpacks).  Points are merged geometrically (a copy's point that falls on a real point IS
+// that point), faces with the same points are one face.  Corners and edges between several pairs get the diagonal copies too (shift
+// vectors {-1, 0, 1}^K).  The real cells, points and patch faces keep their labels and relative order; cyclic patches end up empty; faces
+// of ghosts whose other cell is not part of the layer form a trailing QGD_PATCH_HALO patch.
+HostMesh unrollCyclic(const HostMesh& g, const std::vector<std::pair<int32_t, int32_t>>& pairs) {
+    const int K = (int)pairs.size();
+    if (K < 1 || K > 3) throw std::invalid_argument("unrollCyclic: one to three cyclic pairs");
+    if (!g.haloGhost.empty()) throw std::invalid_argument("unrollCyclic: the mesh is a shard already");
+    if (g.userGeometry) throw std::invalid_argument("unrollCyclic: meshes with caller-supplied geometry are not served (the copies' geometry is rebuilt from points)");
+    const int32_t nC = g.nCells, nP = g.nPoints;
+    double bbLo[3] = {1e300, 1e300, 1e300}, bbHi[3] = {-1e300, -1e300, -1e300};
+    for (int32_t p = 0; p < nP; ++p)
+        for (int d = 0; d < 3; ++d) { bbLo[d] = std::min(bbLo[d], g.points[3 * (size_t)p + d]); bbHi[d] = std::max(bbHi[d], g.points[3 * (size_t)p + d]); }
+    const double diag = std::sqrt((bbHi[0] - bbLo[0]) * (bbHi[0] - bbLo[0]) + (bbHi[1] - bbLo[1]) * (bbHi[1] - bbLo[1]) + (bbHi[2] - bbLo[2]) * (bbHi[2] - bbLo[2]));
+    const double tol = 1e-8 * diag;
+    // the translation of each pair: face i of A lies at face i of B minus t (OpenFOAM orders the two halves alike)
+    std::vector<std::array<double, 3>> t((size_t)K);
+    std::vector<uint8_t> maskA((size_t)nP, 0), maskB((size_t)nP, 0), patchIsCyclicHalf(g.patches.size(), 0);
+    for (int k = 0; k < K; ++k) {
+        const int32_t a = pairs[k].first, b = pairs[k].second;
+        if (a < 0 || b < 0 || a >= (int32_t)g.patches.size() || b >= (int32_t)g.patches.size() || a == b)
+            throw std::invalid_argument("unrollCyclic: patch index out of range");
+        const Patch &A = g.patches[a], &B = g.patches[b];
+        if (A.type != QGD_PATCH_CYCLIC || B.type != QGD_PATCH_CYCLIC) throw std::invalid_argument("unrollCyclic: patches '" + A.name + "' / '" + B.name + "' are not both cyclic");
+        if (A.size != B.size || A.size == 0) throw std::invalid_argument("unrollCyclic: the halves '" + A.name + "' / '" + B.name + "' differ in size or are empty");
+        if (patchIsCyclicHalf[a] || patchIsCyclicHalf[b]) throw std::invalid_argument("unrollCyclic: a patch appears in two pairs");
+        patchIsCyclicHalf[a] = patchIsCyclicHalf[b] = 1;
+        double sum[3] = {0, 0, 0};
+        for (int32_t i = 0; i < A.size; ++i)
+            for (int d = 0; d < 3; ++d) sum[d] += g.Cf[3 * (size_t)(B.start + i) + d] - g.Cf[3 * (size_t)(A.start + i) + d];
+        for (int d = 0; d < 3; ++d) t[k][d] = sum[d] / A.size;
+        const double tl = std::sqrt(t[k][0] * t[k][0] + t[k][1] * t[k][1] + t[k][2] * t[k][2]);
+        for (int32_t i = 0; i < A.size; ++i) {
+            double dev = 0, dS = 0;
+            for (int d = 0; d < 3; ++d) {
+                const double x = g.Cf[3 * (size_t)(B.start + i) + d] - g.Cf[3 * (size_t)(A.start + i) + d] - t[k][d];
+                dev += x * x;
+                const double y = g.Sf[3 * (size_t)(B.start + i) + d] + g.Sf[3 * (size_t)(A.start + i) + d];   // the halves face each other
+                dS += y * y;
+            }
+            if (std::sqrt(dev) > 1e-6 * tl || std::sqrt(dS) > 1e-6 * g.magSf[A.start + i])
+                throw std::invalid_argument("unrollCyclic: the halves '" + A.name + "' / '" + B.name +
+                                            "' are not translates of each other face by face (rotational cyclics are not served)");
+        }
+        for (int32_t f = A.start; f < A.start + A.size; ++f) for (int32_t q = g.faceOffsets[f]; q < g.faceOffsets[f + 1]; ++q) maskA[g.facePoints[q]] |= (uint8_t)(1 << k);
+        for (int32_t f = B.start; f < B.start + B.size; ++f) for (int32_t q = g.faceOffsets[f]; q < g.faceOffsets[f + 1]; ++q) maskB[g.facePoints[q]] |= (uint8_t)(1 << k);
+    }
+    for (size_t pi = 0; pi < g.patches.size(); ++pi)
+        if (g.patches[pi].type == QGD_PATCH_CYCLIC && g.patches[pi].size > 0 && !patchIsCyclicHalf[pi])
+            throw std::invalid_argument("unrollCyclic: cyclic patch '" + g.patches[pi].name + "' has no partner in the pair list");
+    // cell -> faces, cell -> points
+    const Csr cf = buildCellFaces(g);
+    auto cellPoints = [&](int32_t c, std::vector<int32_t>& out) {
+        out.clear();
+        for (int32_t q = cf.offsets[c]; q < cf.offsets[c + 1]; ++q) {
+            const int32_t f = cf.items[q];
+            for (int32_t r = g.faceOffsets[f]; r < g.faceOffsets[f + 1]; ++r) out.push_back(g.facePoints[r]);
+        }
+        std::sort(out.begin(), out.end());
+        out.erase(std::unique(out.begin(), out.end()), out.end());
+    };
+    // tiles: shift vectors s in {-1, 0, 1}^K \ {0}; the copy of cell c shifted by sum s_k t_k touches the real mesh iff one of its points lies on
+    // A_k for every s_k = +1 (the copy's A_k side lands on the real B_k) and on B_k for every s_k = -1
+    int nTiles = 1;
+    for (int k = 0; k < K; ++k) nTiles *= 3;
+    auto shiftOf = [&](int tile, int k) { int v = tile; for (int q = 0; q < k; ++q) v /= 3; return v % 3 - 1; };
+    const int centre = (nTiles - 1) / 2;
+    auto opposite = [&](int tile) { return nTiles - 1 - tile; };
+    std::vector<std::vector<int32_t>> tileCells((size_t)nTiles);
+    {
+        std::vector<int32_t> pts;
+        for (int32_t c = 0; c < nC; ++c) {
+            cellPoints(c, pts);
+            for (int tile = 0; tile < nTiles; ++tile) {
+                if (tile == centre) continue;
+                uint8_t needA = 0, needB = 0;
+                for (int k = 0; k < K; ++k) { const int sk = shiftOf(tile, k); if (sk > 0) needA |= (uint8_t)(1 << k); if (sk < 0) needB |= (uint8_t)(1 << k); }
+                bool in = false;
+                for (int32_t p : pts) if ((maskA[p] & needA) == needA && (maskB[p] & needB) == needB) { in = true; break; }
+                if (in) tileCells[tile].push_back(c);
+            }
+        }
+    }
+    // local cell labels: the real cells, then the copies tile by tile in ascending source label
+    std::vector<std::vector<int32_t>> localOf((size_t)nTiles, std::vector<int32_t>());
+    HostMesh m;
+    m.nCells = nC;
+    m.cellGlobal.resize((size_t)nC);
+    for (int32_t c = 0; c < nC; ++c) m.cellGlobal[c] = c;
+    for (int tile = 0; tile < nTiles; ++tile) {
+        if (tile == centre) continue;
+        localOf[tile].assign((size_t)nC, -1);
+        for (int32_t c : tileCells[tile]) { localOf[tile][c] = m.nCells++; m.cellGlobal.push_back(c); }
+    }
+    auto localCell = [&](int tile, int32_t c) { return tile == centre ? c : localOf[tile][c]; };
+    // points: the real ones keep their labels; a copy's point within tol of a point already there is that point
+    m.points = g.points;
+    m.nPoints = nP;
+    m.pointGlobal.resize((size_t)nP);
+    for (int32_t p = 0; p < nP; ++p) m.pointGlobal[p] = p;
+    const double cellSz = 4.0 * tol;
+    auto keyOf = [&](const double* x, int dx, int dy, int dz) {
+        const int64_t i = (int64_t)std::floor((x[0] - bbLo[0]) / cellSz) + dx, j = (int64_t)std::floor((x[1] - bbLo[1]) / cellSz) + dy, l = (int64_t)std::floor((x[2] - bbLo[2]) / cellSz) + dz;
+        return (uint64_t)(i * 73856093ll) ^ (uint64_t)(j * 19349663ll) ^ (uint64_t)(l * 83492791ll);
+    };
+    std::unordered_map<uint64_t, std::vector<int32_t>> grid;
+    grid.reserve((size_t)nP * 2);
+    for (int32_t p = 0; p < nP; ++p) grid[keyOf(&m.points[3 * (size_t)p], 0, 0, 0)].push_back(p);
+    auto findOrAdd = [&](const double* x, int32_t source) {
+        for (int dx = -1; dx <= 1; ++dx) for (int dy = -1; dy <= 1; ++dy) for (int dz = -1; dz <= 1; ++dz) {
+            auto it = grid.find(keyOf(x, dx, dy, dz));
+            if (it == grid.end()) continue;
+            for (int32_t q : it->second) {
+                const double* y = &m.points[3 * (size_t)q];
+                if (std::fabs(x[0] - y[0]) <= tol && std::fabs(x[1] - y[1]) <= tol && std::fabs(x[2] - y[2]) <= tol) return q;
+            }
+        }
+        const int32_t q = m.nPoints++;
+        for (int d = 0; d < 3; ++d) m.points.push_back(x[d]);
+        m.pointGlobal.push_back(source);
+        grid[keyOf(x, 0, 0, 0)].push_back(q);
+        return q;
+    };
+    std::vector<std::vector<int32_t>> pointOf((size_t)nTiles);
+    auto tileShift = [&](int tile, double sh[3]) {
+        sh[0] = sh[1] = sh[2] = 0.0;
+        for (int k = 0; k < K; ++k) for (int d = 0; d < 3; ++d) sh[d] += shiftOf(tile, k) * t[k][d];
+    };
+    {
+        std::vector<int32_t> pts;
+        for (int tile = 0; tile < nTiles; ++tile) {
+            if (tile == centre || tileCells[tile].empty()) continue;
+            pointOf[tile].assign((size_t)nP, -1);
+            double sh[3];
+            tileShift(tile, sh);
+            for (int32_t c : tileCells[tile]) {
+                cellPoints(c, pts);
+                for (int32_t p : pts) {
+                    if (pointOf[tile][p] >= 0) continue;
+                    const double x[3] = {g.points[3 * (size_t)p] + sh[0], g.points[3 * (size_t)p + 1] + sh[1], g.points[3 * (size_t)p + 2] + sh[2]};
+                    pointOf[tile][p] = findOrAdd(x, p);
+                }
+            }
+        }
+    }
+    auto localPoint = [&](int tile, int32_t p) { return tile == centre ? p : pointOf[tile][p]; };
+    // face instances: (tile, face of g) with the local cell(s) it has there; instances with the same points are one face
+    struct Inst { int tile; int32_t f; int32_t own, nei; };   // nei = -1: the other cell is not here (or f is a boundary face of g)
+    std::vector<Inst> inst;
+    std::vector<int> tileOrder{centre};   // the real mesh first: its faces keep their relative order in every patch
+    for (int tile = 0; tile < nTiles; ++tile) if (tile != centre) tileOrder.push_back(tile);
+    for (const int tile : tileOrder) {
+        if (tile != centre && tileCells[tile].empty()) continue;
+        for (int32_t f = 0; f < g.nFaces; ++f) {
+            const int32_t a = localCell(tile, g.owner[f]);
+            const int32_t b = f < g.nInternalFaces ? localCell(tile, g.neighbour[f]) : -1;
+            if (a < 0 && b < 0) continue;
+            inst.push_back({tile, f, a, b});
+        }
+    }
+    auto facePts = [&](const Inst& in, std::vector<int32_t>& out) {
+        out.clear();
+        for (int32_t q = g.faceOffsets[in.f]; q < g.faceOffsets[in.f + 1]; ++q) out.push_back(localPoint(in.tile, g.facePoints[q]));
+    };
+    struct Glued { int32_t own = -1, nei = -1; size_t instOwn = 0; bool flipOwn = false; int patch = -1; size_t first = 0; };
+    std::vector<Glued> faces;
+    {
+        std::map<std::vector<int32_t>, size_t> byPoints;
+        std::vector<int32_t> pts, key;
+        for (size_t i = 0; i < inst.size(); ++i) {
+            const Inst& in = inst[i];
+            facePts(in, pts);
+            key = pts;
+            std::sort(key.begin(), key.end());
+            auto it = byPoints.find(key);
+            // the cells this instance brings, and whether the face's point order (normal owner -> neighbour in g) points out of the FIRST of them
+            if (in.own >= 0 && in.nei >= 0) {
+                if (it != byPoints.end()) throw std::runtime_error("unrollCyclic: an internal face coincides with another face");
+                Glued G; G.own = in.own; G.nei = in.nei; G.instOwn = i; G.flipOwn = false; G.first = i;
+                byPoints[key] = faces.size(); faces.push_back(G);
+                continue;
+            }
+            const int32_t cell = in.own >= 0 ? in.own : in.nei;
+            const bool outward = in.own >= 0;   // g's orientation points out of its owner
+            if (it == byPoints.end()) {
+                Glued G; G.own = cell; G.instOwn = i; G.flipOwn = !outward; G.first = i;
+                G.patch = in.f >= g.nInternalFaces ? g.patchOfFace(in.f) : -1;
+                byPoints[key] = faces.size(); faces.push_back(G);
+            } else {
+                Glued& G = faces[it->second];
+                if (G.nei >= 0) throw std::runtime_error("unrollCyclic: three cells meet in one face");
+                G.nei = cell;
+                if (G.nei < G.own) { std::swap(G.own, G.nei); G.instOwn = i; G.flipOwn = !outward; }
+                G.patch = -2;   // glued: internal now
+            }
+        }
+    }
+    // order: internal faces by (owner, neighbour); then g's patches (real faces first, in their order, then the copies' in tile / label order:
+    // `faces` was filled in exactly that order); cyclic patches empty; the halo patch last
+    std::vector<size_t> internal, halo;
+    std::vector<std::vector<size_t>> onPatch(g.patches.size());
+    for (size_t i = 0; i < faces.size(); ++i) {
+        const Glued& G = faces[i];
+        if (G.nei >= 0) internal.push_back(i);
+        else if (G.patch >= 0 && !patchIsCyclicHalf[G.patch]) onPatch[G.patch].push_back(i);
+        else halo.push_back(i);
+    }
+    std::sort(internal.begin(), internal.end(), [&](size_t a, size_t b) {
+        return faces[a].own != faces[b].own ? faces[a].own < faces[b].own : (faces[a].nei != faces[b].nei ? faces[a].nei < faces[b].nei : a < b);
+    });
+    std::vector<int32_t> pts;
+    m.faceOffsets.push_back(0);
+    auto emit = [&](size_t i) {
+        const Glued& G = faces[i];
+        facePts(inst[G.instOwn], pts);
+        if (!G.flipOwn) for (int32_t v : pts) m.facePoints.push_back(v);
+        else { m.facePoints.push_back(pts[0]); for (size_t q = pts.size() - 1; q > 0; --q) m.facePoints.push_back(pts[q]); }
+        m.faceOffsets.push_back((int32_t)m.facePoints.size());
+        m.owner.push_back(G.own);
+        const Inst& in = inst[G.first];
+        m.faceGlobal.push_back(in.tile == centre ? in.f : -1 - in.f);   // a real face's label in g; -1-label: a face only the copies have
+    };
+    for (size_t i : internal) { emit(i); m.neighbour.push_back(faces[i].nei); }
+    m.nInternalFaces = (int32_t)m.owner.size();
+    for (size_t pi = 0; pi < g.patches.size(); ++pi) {
+        Patch p = g.patches[pi];
+        p.start = (int32_t)m.owner.size();
+        for (size_t i : onPatch[pi]) emit(i);
+        p.size = (int32_t)m.owner.size() - p.start;
+        p.nHatInherited = g.patches[pi].type == QGD_PATCH_SYMMETRYPLANE && g.patches[pi].size > 0;
+        m.patches.push_back(p);
+    }
+    {
+        Patch p;
+        p.name = "halo";
+        p.type = QGD_PATCH_HALO;
+        p.start = (int32_t)m.owner.size();
+        for (size_t i : halo) {
+            emit(i);
+            // hQGDf of the face as the periodic mesh has it: 2 min(|C_O - C_f|, |C_N - C_f|) [QGDCoeffs.C L305-307] with the absent cell's centre
+            const Inst& in = inst[faces[i].first];
+            double sh[3];
+            tileShift(in.tile, sh);
+            int32_t other = -1;
+            double osh[3] = {sh[0], sh[1], sh[2]};
+            if (in.f < g.nInternalFaces) other = in.own >= 0 ? g.neighbour[in.f] : g.owner[in.f];
+            else {
+                const int pa = g.patchOfFace(in.f);
+                for (int k = 0; k < K; ++k) {
+                    const Patch &A = g.patches[pairs[k].first], &B = g.patches[pairs[k].second];
+                    if (pa == pairs[k].first) { other = g.owner[B.start + (in.f - A.start)]; for (int d = 0; d < 3; ++d) osh[d] -= t[k][d]; }
+                    if (pa == pairs[k].second) { other = g.owner[A.start + (in.f - B.start)]; for (int d = 0; d < 3; ++d) osh[d] += t[k][d]; }
+                }
+            }
+            const int32_t mine = in.own >= 0 ? g.owner[in.f] : g.neighbour[in.f];
+            double da = 0, db = 0;
+            for (int d = 0; d < 3; ++d) {
+                const double cfx = g.Cf[3 * (size_t)in.f + d] + sh[d];
+                const double x = g.C[3 * (size_t)mine + d] + sh[d] - cfx;
+                da += x * x;
+                if (other >= 0) { const double y = g.C[3 * (size_t)other + d] + osh[d] - cfx; db += y * y; } else db = 1e300;
+            }
+            m.haloFaceH.push_back(2.0 * std::sqrt(std::min(da, db)));
+        }
+        p.size = (int32_t)m.owner.size() - p.start;
+        m.patches.push_back(p);
+    }
+    m.nFaces = (int32_t)m.owner.size();
+    // halo slots: one per tile that has copies; a slot's ghosts are that tile's copies, what it sends are the real cells whose copies sit
+    // in the OPPOSITE tile (the real mesh seen from the copy is the copy seen from the real mesh, mirrored): both ascending by source label,
+    // so the message a slot packs is exactly what the opposite slot's ghosts expect -- haloSelf
+    m.ownedBegin = 0; m.ownedEnd = nC;
+    m.cellIsGhost.assign((size_t)m.nCells, 0);
+    for (int32_t c = nC; c < m.nCells; ++c) m.cellIsGhost[c] = 1;
+    std::vector<int> slotOfTile((size_t)nTiles, -1);
+    for (int tile = 0; tile < nTiles; ++tile)
+        if (tile != centre && !tileCells[tile].empty()) { slotOfTile[tile] = (int)m.haloGhost.size(); m.haloGhost.emplace_back(); m.haloSend.emplace_back(); m.haloPeer.push_back(-1); }
+    m.haloSelf.assign(m.haloGhost.size(), -1);
+    for (int tile = 0; tile < nTiles; ++tile) {
+        const int slot = slotOfTile[tile];
+        if (slot < 0) continue;
+        if (slotOfTile[opposite(tile)] < 0 || tileCells[opposite(tile)].size() != tileCells[tile].size())
+            throw std::runtime_error("unrollCyclic: the two sides of a pair see different layers (the halves do not match point by point)");
+        for (int32_t c : tileCells[tile]) m.haloGhost[slot].push_back(localOf[tile][c]);
+        m.haloSend[slot] = tileCells[opposite(tile)];
+        m.haloSelf[slot] = slotOfTile[opposite(tile)];
+    }
+    if (!g.degenerateFaces.empty()) {
+        std::vector<uint8_t> isDeg((size_t)g.nFaces, 0);
+        for (int32_t f : g.degenerateFaces) isDeg[f] = 1;
+        for (int32_t lf = 0; lf < m.nFaces; ++lf) {
+            const int32_t gf = m.faceGlobal[lf] >= 0 ? m.faceGlobal[lf] : -1 - m.faceGlobal[lf];
+            if (isDeg[gf] && lf < m.nInternalFaces) m.degenerateFaces.push_back(lf);
+        }
     }
     m.computeGeometry();
     return m;

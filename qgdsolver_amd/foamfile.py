@@ -327,7 +327,7 @@ def read_polymesh(poly_dir):
     pd = _Parser(body, []).parse_dict_body(top=True)
     if len(pd) != int(m.group(1)):
         raise FoamFileError("boundary: patch count mismatch")
-    names, start, size, ptype = [], [], [], []
+    names, start, size, ptype, partner = [], [], [], [], {}
     for name, e in pd.items():
         t = str(e.get("type", "patch"))
         if t not in PATCH_TYPES:
@@ -336,8 +336,22 @@ def read_polymesh(poly_dir):
         start.append(int(e["startFace"]))
         size.append(int(e["nFaces"]))
         ptype.append(PATCH_TYPES[t])
+        if t == "cyclic" and "neighbourPatch" in e:
+            partner[name] = str(e["neighbourPatch"])
+            if str(e.get("transform", "unknown")) == "rotational":
+                raise FoamFileError(f"boundary: cyclic patch '{name}' is rotational: only translational cyclic pairs are served")
     mesh = PolyMesh.from_arrays(points, fo, fp, owner, neighbour, n_cells, start, size, ptype)
     mesh.patch_names = names
+    # cyclic pairs (patch index of a half, of its neighbourPatch), each pair once, in patch order: what PolyMesh.unroll_cyclic takes
+    mesh.cyclic_pairs = []
+    for i, name in enumerate(names):
+        if name in partner:
+            other = partner[name]
+            if other not in names or partner.get(other) != name:
+                raise FoamFileError(f"boundary: cyclic patch '{name}' names neighbourPatch '{other}', which does not name it back")
+            j = names.index(other)
+            if i < j:
+                mesh.cyclic_pairs.append((i, j))
     # the faceSet the leastSquares stencil reads if present [leastSquaresStencil.C L63-70]
     dsf = os.path.join(poly_dir, "sets", "degenerateStencilFaces")
     if _exists(dsf):
@@ -393,7 +407,11 @@ def write_polymesh(mesh, poly_dir, patch_names=None):
         for i in range(mesh.nPatches):
             if int(pt[i]) not in PATCH_WORDS:
                 raise FoamFileError("halo (cell-range shard) patches have no polyMesh spelling")
-            f.write(f"    {names[i]}\n    {{\n        type            {PATCH_WORDS[int(pt[i])]};\n"
+            nbr = ""
+            for pa, pb in getattr(mesh, "cyclic_pairs", []):
+                if i in (pa, pb):
+                    nbr = f"        neighbourPatch  {names[pb if i == pa else pa]};\n"
+            f.write(f"    {names[i]}\n    {{\n        type            {PATCH_WORDS[int(pt[i])]};\n{nbr}"
                     f"        nFaces          {int(pz[i])};\n        startFace       {int(ps[i])};\n    }}\n")
         f.write(")\n")
 
@@ -499,6 +517,8 @@ def _bc(rec, vector, patch_type_word, what):
             return ("none", None)
         if patch_type_word in ("symmetryPlane", "symmetry"):
             return ("slip", None) if vector else ("zeroGradient", None)
+        if patch_type_word == "cyclic":
+            return ("none", None)   # the pair's faces become internal faces (PolyMesh.unroll_cyclic): no patch field is left to evaluate
         raise FoamFileError(f"{what}: '{patch_type_word}' patch fields are not supported by the resident cases")
     if t in _CONSTRAINT_BCS:
         raise FoamFileError(f"{what}: boundary condition '{t}' needs a patch of that type (the patch is '{patch_type_word}')")
@@ -516,12 +536,18 @@ def _bc(rec, vector, patch_type_word, what):
     raise FoamFileError(f"{what}: boundary condition '{t}' is not supported")
 
 
-def _refuse_unserved_patches(mesh, case_dir):
-    """cyclic / wedge patches with faces: their coupled / rotated patch fields are not served by the resident cases (the fvsc operators
-    of a Device do serve such meshes)"""
+def _refuse_unserved_patches(mesh, case_dir, cyclic_ok=False):
+    """wedge patches with faces: their rotated patch fields are not served by the resident cases (the fvsc operators of a Device do serve
+    such meshes).  cyclic patches: QGDFoam's explicit branch serves translational pairs named by `neighbourPatch` (cyclic_ok; the
+    application unrolls them into ghost cells, PolyMesh.unroll_cyclic); QHDFoam does not."""
     pt, pz = mesh.array("patchType"), mesh.array("patchSize")
+    paired = {i for pr in getattr(mesh, "cyclic_pairs", []) for i in pr}
     for i, name in enumerate(mesh.patch_names):
         word = PATCH_WORDS.get(int(pt[i]), "patch")
+        if word == "cyclic" and int(pz[i]) > 0 and cyclic_ok:
+            if i not in paired:
+                raise FoamFileError(f"{case_dir}: cyclic patch '{name}' has no neighbourPatch entry in constant/polyMesh/boundary")
+            continue
         if word in ("cyclic", "wedge") and int(pz[i]) > 0:
             raise FoamFileError(f"{case_dir}: patch '{name}' is a {word} patch; the resident QGDFoam / QHDFoam cases do not serve "
                                 f"{word} patch fields")
@@ -653,7 +679,7 @@ def read_case_setup(case_dir, time="0"):
     tolerance/maxIter (implicitDiffusion only); <time>/{U,T,p}.
     """
     mesh = read_polymesh(os.path.join(case_dir, "constant", "polyMesh"))
-    _refuse_unserved_patches(mesh, case_dir)
+    _refuse_unserved_patches(mesh, case_dir, cyclic_ok=True)
     opt = {}
     tp = read_dict(os.path.join(case_dir, "constant", "thermophysicalProperties"))
     tt = tp.get("thermoType", {})
@@ -900,6 +926,8 @@ def write_qhd_time(case, case_dir, time_name, bcs=None):
     """U, T, p of a QHDFoamCase into <case_dir>/<time_name>/ (the AUTO_WRITE fields of QHDFoam that this path carries); patch
     entries carry the patch values as ``value`` (fixedGradient patches also their ``gradient``)."""
     mesh = case.mesh
+    if hasattr(mesh, "file_mesh"):
+        raise FoamFileError("write_time: a case with cyclic patches carries copies of its cells; python -m qgdsolver_amd.QGDFoam writes its time directories")
     names = getattr(mesh, "patch_names", None) or [f"patch{i}" for i in range(mesh.nPatches)]
     ps, pz, pt = mesh.array("patchStart"), mesh.array("patchSize"), mesh.array("patchType")
     nIF = mesh.nInternalFaces
@@ -955,6 +983,16 @@ def load_case(case_dir, time="0", device_id=0):
     from .qgdfoam import QGDFoamCase, default_options
 
     mesh, opt, fields, bcs = read_case_setup(case_dir, time)
+    if getattr(mesh, "cyclic_pairs", None):
+        # translational cyclic pairs: glued, with translated copies of the cells behind either half (PolyMesh.unroll_cyclic); the real cells
+        # keep their labels, case.field(...)[:case.mesh.file_mesh.nCells] are theirs
+        if opt.get("implicitDiffusion") or "alphaQGD" in fields or "ScQGD" in fields:
+            raise FoamFileError(f"{case_dir}: a case with cyclic patches runs the explicit branch (QGD {{ implicitDiffusion false; }}) with uniform alphaQGD / ScQGD")
+        file_mesh = mesh
+        mesh = file_mesh.unroll_cyclic(file_mesh.cyclic_pairs)
+        mesh.file_mesh = file_mesh
+        cg = mesh.array("cellGlobal")
+        fields = {k: v[cg] for k, v in fields.items()}
     dev = Device(mesh, device_id, fv_schemes={"fvsc": {"default": opt["stencil"]}})
     case = QGDFoamCase(dev, default_options(**opt))
     for i, bc in enumerate(bcs):
@@ -969,6 +1007,8 @@ def write_time(case, case_dir, time_name, bcs=None):
     """Write U, T, p, rho of a QGDFoamCase into <case_dir>/<time_name>/ (what runTime.write() leaves for QGDFoam's
     AUTO_WRITE fields); patch entries carry the patch values as ``value``."""
     mesh = case.mesh
+    if hasattr(mesh, "file_mesh"):
+        raise FoamFileError("write_time: a case with cyclic patches carries copies of its cells; python -m qgdsolver_amd.QGDFoam writes its time directories")
     names = getattr(mesh, "patch_names", None) or [f"patch{i}" for i in range(mesh.nPatches)]
     ps, pz, pt = mesh.array("patchStart"), mesh.array("patchSize"), mesh.array("patchType")
     nIF = mesh.nInternalFaces

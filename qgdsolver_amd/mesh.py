@@ -6,7 +6,7 @@ import numpy as np
 from . import _lib as L
 
 _INT_ARRAYS = {"degenerateFaces", "faceOffsets", "facePoints", "owner", "neighbour", "patchStart", "patchSize", "patchType",
-               "haloPeer", "cellGlobal", "faceGlobal", "pointGlobal"}
+               "haloPeer", "haloSelf", "cellGlobal", "faceGlobal", "pointGlobal"}
 
 
 def _dp(a):
@@ -148,6 +148,19 @@ class PolyMesh:
         names = getattr(self, "patch_names", None)
         if names:
             out.patch_names = list(names) + (["halo"] if n_ranks > 1 else [])
+        return out
+
+    def unroll_cyclic(self, pairs=None):
+        """translational cyclic patch pairs served by ghost cells (qgd_mesh_unroll_cyclic): this mesh + one layer of translated copies of its
+        own cells behind every half, the pairs' faces glued into internal faces; pairs = [(patchA, patchB), ...], None pairs consecutive
+        cyclic patches.  A QGDFoamCase on the result steps with plain step(): the library refreshes the copies itself."""
+        flat = np.ascontiguousarray([x for pr in (pairs or []) for x in pr], dtype=np.int32)
+        h = C.c_void_p()
+        L.check(L.lib.qgd_mesh_unroll_cyclic(self._h, flat.size // 2, _ip(flat) if flat.size else None, C.byref(h)), "qgd_mesh_unroll_cyclic")
+        out = PolyMesh(h)
+        names = getattr(self, "patch_names", None)
+        if names:
+            out.patch_names = list(names) + ["halo"]
         return out
 
     def close(self):

@@ -114,7 +114,7 @@ CASE_ARMS = [c + (arm,) for c in CASES for arm in _arms_of(c[0], c[1], c[4])]
 
 
 def test_the_case_matrix_covers_the_fused_step():
-    assert sum(1 for c in CASE_ARMS if c[5] == "fused") == 8 and sum(1 for c in CASE_ARMS if c[5] == "kernels") == len(CASES)
+    assert sum(1 for c in CASE_ARMS if c[5] == "fused") == 7 and sum(1 for c in CASE_ARMS if c[5] == "kernels") == len(CASES)
 
 
 @pytest.mark.parametrize("mesh_kind,scheme,bc_fn,init_fn,opt,arm", CASE_ARMS)
