@@ -314,7 +314,8 @@ def test_application_runs_a_periodic_case_directory(tmp_path):
     case_dir = str(tmp_path)
     mesh, (U, T, p) = write_periodic_case(case_dir)
     cd = os.path.join(case_dir, "system", "controlDict")
-    open(cd, "w").write(open(cd).read().replace("endTime 1;", "endTime 0.01;") + "writeControl timeStep;\nwriteInterval 10;\n")
+    text = open(cd).read()
+    open(cd, "w").write(text.replace("endTime 1;", "endTime 0.01;") + "writeControl timeStep;\nwriteInterval 10;\n")
     dev, case, written = QGDFoam.run(case_dir, n_steps=20, log=lambda *a, **k: None)
     assert written == ["0.005", "0.01"]
     opt = q.default_options(stencil="GaussVolPoint", deltaT=5e-4, R=1 / 1.4, Cv=1 / 1.4 / 0.4, mu=0.0, Pr=1.0, ScQGD=1.0, PrQGD=1.0, alphaQGD=0.5)
