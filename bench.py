@@ -693,7 +693,7 @@ def implicit_line(args):
     n = args.n
     t_setup = time.perf_counter()
     mesh = q.PolyMesh.box(n, n, n)
-    dev = q.Device(mesh, fused_tables=False)   # (the block tables of the fused explicit step: not this branch's)
+    dev = q.Device(mesh)   # (with the cell blocks: the branch assembles its U systems on them, QGD_IMPL_FUSED)
     opt = q.default_options(stencil="GaussVolPoint", deltaT=0.1 / n / 1.3, implicitDiffusion=1, mu=1e-3)
     case = q.QGDFoamCase(dev, opt)
     U, T, p = box_initial_fields(mesh.array("C").reshape(-1, 3))
@@ -706,6 +706,7 @@ def implicit_line(args):
     case.step(args.steps)          # returns after the device has finished
     elapsed = time.perf_counter() - t0
     info, solves = case.info(), case.implicit_info()
+    fused_impl = case.fused_info().get("fusedImplicit", False)
     ap = case.implicit_apply_time(30)
     cheb = solves.get("solver") == "chebyshev"
     apply_bytes = (IMPL_CHEB_BYTES_PER_CELL if cheb else IMPL_APPLY_BYTES_PER_CELL) * ap["rows"]
@@ -721,6 +722,8 @@ def implicit_line(args):
                                 + ("U and e systems by Chebyshev iteration on the Jacobi-preconditioned systems to 1e-10" if cheb
                                    else "U and e systems by Jacobi-PCG to 1e-10 (QGD_IMPL_SOLVER=pcg)")),
                    "cells": nc, "iterations_U": it_u, "iterations_e": it_e, "unconverged_steps": solves["unconverged_steps"], "stalled_steps": solves["stalled_steps"],
+                   # True: vertex values, QGD fluxes, tauMC and the rows of the three U systems are ONE launch on the fused step's cell blocks
+                   "fused_assembly_of_the_U_systems": bool(fused_impl),
                    "env": qgd_env()},
         "roofline": {"bound": "hbm", "kernel": ("iChebKernel<3,0> (one Chebyshev step of the three-component U system: matrix product, d, next iterate and the "
                                                 "partial residual sums in one walk of the matrix for the three right-hand sides)" if cheb else

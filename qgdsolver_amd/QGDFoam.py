@@ -102,8 +102,10 @@ def run(case_dir, n_steps=None, device_id=0, write=True, log=print, renumber="no
         mesh = gmesh.unroll_cyclic(gmesh.cyclic_pairs)
         cells = mesh.array("cellGlobal")
         owned = np.arange(mesh.nCells) < n_global
-    # only a fixed-deltaT explicit case with one stencil runs the fused step: no block tables otherwise
-    eligible = not (opt.get("adjustTimeStep") or opt.get("implicitDiffusion") or opt.get("termStencils")) and opt["stencil"] == "GaussVolPoint"
+    # only a fixed-deltaT case with one GaussVolPoint stencil uses the cell blocks: no block tables otherwise
+    # (the blocks serve the explicit branch's one-launch step, shards included, and the implicitDiffusion branch's assembly of the U systems on one rank)
+    eligible = (not (opt.get("adjustTimeStep") or opt.get("termStencils")) and opt["stencil"] == "GaussVolPoint"
+                and not (opt.get("implicitDiffusion") and world > 1))
     dev = Device(mesh, device_id, fv_schemes={"fvsc": {"default": opt["stencil"]}}, fused_tables=eligible)
     case = QGDFoamCase(dev, default_options(**opt))
     for i, bc in enumerate(bcs):

@@ -300,6 +300,7 @@ struct qgd_case_s {
     bool pRefresh = true;       // grad(p)'s word is GaussVolPoint: p's boundary conditions are re-evaluated inside it [GaussVolPointStencil_8C L73] (quirk B6)
     bool usesPoints = true;
     bool fused = false;         // qgd_case_step advances with fusedFaceCellKernel (QGD_FUSED)
+    bool fusedImpl = false;     // implicitDiffusion: vertex values, QGD fluxes, tauMC and the U systems' rows are one launch on the same blocks (QGD_IMPL_FUSED)
     std::vector<double*> selfBuf;   // cyclic pairs served by ghost cells: one message buffer per halo slot (selfHaloExchange)
     bool ghostsCurrent = false;     // ... and whether the copies hold their originals' records (reset by set_fields / set_bc)
     bool hasQgdFlux = false;
@@ -787,6 +788,12 @@ static int deviceCreate(qgd_mesh_t mh, int deviceId, int fusedChoice, qgd_device
                     v.fuHdr = reinterpret_cast<const int4*>(up(fb.hdr)); v.fuCells = up(fb.cells); v.fuVerts = up(fb.verts);
                     v.fuFaceLabel = up(fb.faceLabel); v.fuFacePos = up(fb.facePos); v.fuNEntry = up(fb.nEntry); v.fuEntry = up(fb.entry);
                     v.fuTemplates = fb.nTemplates;
+                    {   // the implicitDiffusion branch's layout of the same blocks (qgd_kernels.hip fusedFaceCellKernel<..., IMPL>)
+                        const int64_t parkI = ((int64_t)fb.maxLdsImpl + 15) / 16 * 16, ldsI = (parkI + 6 * 128 * 4 + 255) / 256 * 256;
+                        const int64_t most = std::max<int64_t>((int64_t)prop.sharedMemPerBlock, (int64_t)prop.maxSharedMemoryPerMultiProcessor);
+                        v.fuLdsImpl = ldsI <= std::min<int64_t>(most, 160 * 1024) / 2 ? (int32_t)ldsI : 0;   // (two blocks per CU, or not at all)
+                        v.fuLdsCellImpl = (int32_t)(parkI / 8);
+                    }
                     d->fusedInfo[0] = fb.nBlocks; d->fusedInfo[1] = fb.nLayerBlocks; d->fusedInfo[2] = fb.nTemplates; d->fusedInfo[3] = lds;
                     // bytes a block streams per step out of its own lists / of its template's
                     d->fusedInfo[4] = 32 + 4 * (int64_t)fb.capC + 4 * (int64_t)fb.capV + 4 * (int64_t)fb.capF + fb.capV + 128 + 8 * (int64_t)fb.capPE * fb.capV;
@@ -1537,6 +1544,11 @@ int qgd_case_create(qgd_device_t d, const qgd_case_options* opt, qgd_case_t* out
         // the fused step (fusedFaceCellKernel): uniform 3-D GaussVolPoint, explicit, fixed deltaT; `Gauss upwind` fluxes are an instantiation
         c->fused = v.fuBlocks > 0 && c->stencil == ST_GVP3 && c->mixB < 0 && !opt->implicitDiffusion && !opt->adjustTimeStep;
         if (c->fused) { cv.A2 = a.alloc<RecA>(v.nC); cv.B2 = a.alloc<RecB>(v.nC); }
+        {   // the reference's default branch on the same blocks (unsharded, fixed deltaT, one 3-D GaussVolPoint stencil)
+            static const int kOnOff[] = {0, 1};
+            c->fusedImpl = v.fuBlocks > 0 && v.fuLdsImpl > 0 && c->stencil == ST_GVP3 && c->mixB < 0 && opt->implicitDiffusion && !opt->adjustTimeStep &&
+                           !d->sharded() && envChoice("QGD_IMPL_FUSED", 1, kOnOff, 2) != 0 && fusedImplUPrepare(v, c->gas);
+        }
         cv.bA = a.alloc<RecA>(v.nBF); cv.bB = a.alloc<RecB>(v.nBF);
         cv.bG = a.alloc<double>(v.nBF); cv.bPhiw = a.alloc<double>(v.nBF); cv.bPmid = a.alloc<double>(v.nBF);
         cv.bRhoLag = a.alloc<double>(v.nBF);
@@ -1736,7 +1748,7 @@ int qgd_case_update_fluxes(qgd_case_t c) {
 // phase 1: deltaT, cell update, boundary refresh
 static void stepAssemble(qgd_case_s* c, int part = 0) {
     const bool adjust = c->opt.adjustTimeStep != 0;
-    assembleFluxes(c, adjust, part, !c->fused);   // a fused case computes its internal faces inside the advance (stepAdvance)
+    assembleFluxes(c, adjust, part, !(c->fused || c->fusedImpl));   // a fused case computes its internal faces inside the advance (stepAdvance / phase 21)
     if (adjust && part != 1) launchFaceReduce(launcherOf(c), c->view);
 }
 // ---- the implicitDiffusion branch [QGDUEqn.H L54-75, QGDEEqn.H L53-64] as stream-ordered phases ---------------------------------
@@ -1773,7 +1785,7 @@ static void implicitPhase(qgd_case_s* c, int phase) {
             c->gradUValid = false;
             break;
         }
-        case 21: c->implSolveIndex = 0; launchImplicitPart(st, m, c->view, c->impl, c->gas, c->bcDev, S, tol, maxIter, 1); break;
+        case 21: c->implSolveIndex = 0; launchImplicitPart(st, m, c->view, c->impl, c->gas, c->bcDev, S, tol, maxIter, 1, c->fusedImpl); break;
         case 22: case 23: case 24: case 25: case 26: case 27: implicitSolvePhase(S, phase - 22); break;
         case 28:
             implicitSolveEnd(S, 0);
@@ -3090,10 +3102,10 @@ int qgd_case_info(qgd_case_t c, double info[6]) {
 int qgd_case_fused_info(qgd_case_t c, int64_t info[8]) {
     if (!c || !info) return fail(QGD_ERR_INVALID, "null argument");
     const MeshView& v = c->dev->view;
-    info[0] = c->fused ? 1 : 0;
-    info[1] = c->fused ? v.fuBlocks : 0;
+    info[0] = c->fused ? 1 : (c->fusedImpl ? 2 : 0);   // 2: the implicitDiffusion branch's block-fused assembly of the U systems
+    info[1] = (c->fused || c->fusedImpl) ? v.fuBlocks : 0;
     info[2] = c->fused ? c->dev->fusedFacesComputed : 0;
-    info[3] = c->fused ? v.fuLds : 0;
+    info[3] = c->fused ? v.fuLds : (c->fusedImpl ? v.fuLdsImpl : 0);
     info[4] = c->fused ? c->dev->fusedCellsStaged : 0;
     info[5] = c->fused ? c->dev->fusedCellsStagedFull : 0;
     info[6] = c->fused ? c->dev->fusedVertsStaged : 0;

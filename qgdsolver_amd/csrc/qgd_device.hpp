@@ -73,6 +73,7 @@ struct MeshView {
     const int4* fuHdr; const int32_t* fuCells; const int32_t* fuVerts; const int32_t* fuFaceLabel; const uint8_t* fuNEntry;
     // a block's local topology sits in its template (fuHdr2[blk].y): 3 position words per face, the own cells' face entries, the vertices' cell positions
     const uint32_t* fuFacePos; const int32_t* fuEntry; int32_t fuTemplates;
+    int32_t fuLdsImpl, fuLdsCellImpl;   // the same two figures as fuLds / fuLdsCell for the implicitDiffusion branch's layout (+ 72 B of fvc::grad(U) per own / across-a-face cell, eight flux planes)
     int32_t fuCapPE, fuMaxTot, fuMaxAll, fuMaxV, fuMaxF;   // cells per vertex (stride); staged cells incl. / without the extra ones, vertices, faces: maxima over the blocks (information; a block lays its LDS out by its own counts)
     const int4* fuHdr2; const uint8_t* fuVCount; const uint16_t* fuVPos; const double* fuVW;   // the vertex values are formed inside the block
 };
@@ -145,6 +146,9 @@ void launchFaceFluxMixed(const Launcher& L, int a, int b, int maskB, const MeshV
 void launchBoundaryFaceFluxMixed(const Launcher& L, int a, int b, int maskB, const MeshView& m, const CaseView& c, const GasModel& g,
                                  const PatchBCDev* bc, int phiwOnly, bool adjustDt);
 void launchFusedFaceCell(const Launcher& L, const MeshView& m, const CaseView& c, const GasModel& g, int firstBlock, int nBlocks);
+struct ImplView;
+bool fusedImplUPrepare(const MeshView& m, const GasModel& g);   // raises the dynamic-LDS limit of the IMPL instantiation; false: not available
+void launchFusedImplU(const Launcher& L, const MeshView& m, const CaseView& c, const GasModel& g, const ImplView& iv, const PatchBCDev* bc);
 void launchCellUpdate(const Launcher& L, const MeshView& m, const CaseView& c, const GasModel& g, int mode,
                       const int32_t* list, int nList);
 void launchBoundaryUpdate(const Launcher& L, const MeshView& m, const CaseView& c, const GasModel& g, const PatchBCDev* bc,
@@ -268,7 +272,7 @@ void launchImplicitHalo(hipStream_t s, const MeshView& m, const CaseView& c, con
                         int nCells, double* buf, bool pack);
 void implicitSolverSetStream(ImplicitSolver* S, hipStream_t s);
 void launchImplicitPart(hipStream_t s, const MeshView& m, const CaseView& c, const ImplView& iv, const GasModel& g, const PatchBCDev* bc,
-                        ImplicitSolver* S, double tol, int maxIter, int part);
+                        ImplicitSolver* S, double tol, int maxIter, int part, bool fusedU = false);
 
 // ---- QHDFoam case resident on the device (qgd_qhd.hip) ---------------------------------------------------------------
 struct QhdView {

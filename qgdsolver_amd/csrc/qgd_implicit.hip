@@ -18,77 +18,12 @@
 #include "../../include/qgd_amd.h"
 #include "qgd_device.hpp"
 #include "qgd_stencil_dev.hpp"
+#include "qgd_implicit_dev.hpp"
 
 namespace qgd {
 
 namespace {
 
-// patch snGrad of U on boundary face f from the owner's and the patch's velocity
-__device__ __forceinline__ void patchSnGradU(const MeshView& m, const PatchBCDev& bc, const int f, const double uo[3], const double ub[3],
-                                             double sn[3]) {
-    const double dc = m.dn[f];
-    if (bc.bcU == QGD_BC_FIXEDVALUE) { for (int k = 0; k < 3; ++k) sn[k] = dc * (ub[k] - uo[k]); }
-    else if (bc.bcU == QGD_BC_SLIP) {
-        double n[3];
-        symmNormal(m, bc, f, n);
-        for (int i = 0; i < 3; ++i) {
-            const double tv = ((i == 0 ? 1.0 : 0.0) - 2.0 * (n[i] * n[0])) * uo[0] + ((i == 1 ? 1.0 : 0.0) - 2.0 * (n[i] * n[1])) * uo[1] +
-                              ((i == 2 ? 1.0 : 0.0) - 2.0 * (n[i] * n[2])) * uo[2];
-            sn[i] = (tv - uo[i]) * (dc / 2.0);
-        }
-    } else { sn[0] = sn[1] = sn[2] = 0.0; }
-}
-// patch value of fvc::grad(U): the owner's gradient with its normal part replaced by the patch snGrad (L0)
-__device__ __forceinline__ void patchGradU(const MeshView& m, const PatchBCDev& bc, const int f, const double* gOwner, const double sn[3],
-                                           double gb[9]) {
-    for (int k = 0; k < 9; ++k) gb[k] = gOwner[k];
-    if (bc.ptype == QGD_PATCH_HALO || bc.ptype == QGD_PATCH_CYCLIC) return;
-    const double ms = m.magSf[f];
-    const double n[3] = {m.Sx[f] / ms, m.Sy[f] / ms, m.Sz[f] / ms};
-    double ng[3];
-    for (int j = 0; j < 3; ++j) ng[j] = n[0] * gb[j] + n[1] * gb[3 + j] + n[2] * gb[6 + j];
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) gb[3 * i + j] += n[i] * (sn[j] - ng[j]);
-}
-// mu * dev2(T(g)):  dev2(A) = A - (2/3) tr(A) I
-__device__ __forceinline__ void muDev2T(const double* g, const double mu, double out[9]) {
-    const double tr = g[0] + g[4] + g[8];
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) {
-            double a = g[3 * j + i];
-            if (i == j) a = a - (2.0 / 3.0) * tr;
-            out[3 * i + j] = mu * a;
-        }
-}
-
-// ---- start values of the two solves -------------------------------------------------------------------------------------------------------
-// OpenFOAM starts a solve from the field as it stands: the predictor U = rhoU/rho [QGDUEqn.H L48-50], e = rhoE/rho - |U|^2/2 [QGDEEqn.H L49]
-// (QGD_IMPL_XEXTRAP=0).  What the solve adds to the predictor -- the implicit part of the viscous / conductive update -- changes slowly from
-// step to step, so the default starts from predictor + the correction of the steps before extrapolated in time (=1: the last one, =2:
-// 2 d1 - d2, =3, default: 3 d1 - 3 d2 + d3, =4: 4 d1 - 6 d2 + 4 d3 - d4 -- no further gain): the same system, the same right-hand side, the same tolerance, a first residual smaller by
-// orders of magnitude and correspondingly fewer Chebyshev steps (profiles/r05_ab_implicit_start_values.txt).  A solver-internal choice like
-// the pressure solve's (qgd_qhd.hip qhdExtrapolatePKernel): the answer is the same to the solve's tolerance, the "Initial residual" of the
-// log is not.  Ghost columns of a shard receive their neighbours' start values with message kind 4 as before.
-// The extrapolated correction is LIMITED to twice the last one per value (see qhdExtrapolatePKernel): where the history is not smooth the start
-// value falls back towards the predictor.
-__device__ __forceinline__ double startValue(const ImplView& iv, const size_t j, const double pred) {
-    if (iv.pred == nullptr) return pred;
-    iv.pred[j] = pred;
-    const int k = iv.have < iv.order ? iv.have : iv.order;
-    if (k == 0) return pred;
-    const double d1 = iv.dh[0][j];
-    double e = d1;
-    if (iv.w != nullptr) {   // adjustTimeStep: steps of different length (implStartWeightsKernel)
-        e = iv.w[0] * d1;
-        if (k >= 2) e += iv.w[1] * iv.dh[1][j];
-        if (k >= 3) e += iv.w[2] * iv.dh[2][j];
-        if (k >= 4) e += iv.w[3] * iv.dh[3][j];
-    } else if (k == 2) e = 2.0 * d1 - iv.dh[1][j];
-    else if (k == 3) e = (3.0 * d1 - 3.0 * iv.dh[1][j]) + iv.dh[2][j];
-    else if (k >= 4) e = ((4.0 * d1 - 6.0 * iv.dh[1][j]) + 4.0 * iv.dh[2][j]) - iv.dh[3][j];
-    const double lim = 2.0 * fabs(d1);
-    return pred + fmin(fmax(e, -lim), lim);
-}
 // Under Courant-number control [setDeltaT-QGDQHD.H L41-61] the steps of the history differ in length and what a solve adds to its predictor
 // scales with the step: the smooth quantity is correction / deltaT at the END of its step.  With T_n = 0 the end of the step about to be
 // taken, the corrections of the k steps before sit at tau_j = -(deltaT_n + ... + deltaT_{n-j+1}), j = 1..k, and the start value is
@@ -112,10 +47,6 @@ __global__ void implStartWeightsKernel(const CaseView c, const ImplView iv) {
     }
 }
 
-// after a solve: this step's correction into the oldest slot (the host rotates the pointers at the end of the step)
-__device__ __forceinline__ void keepCorrection(const ImplView& iv, const size_t j, const double solved) {
-    if (iv.pred != nullptr) iv.dh[iv.order - 1][j] = solved - iv.pred[j];
-}
 
 // fvc::grad(U), Gauss linear: cell gather in ascending face order.  The cell's own velocity once, per face the neighbour cell's
 // (cfNbr) or the patch value, the weight and Sf: a third of the bytes of walking owner and neighbour records face by face
@@ -235,23 +166,17 @@ __global__ __launch_bounds__(128) void implFaceTileKernel(const MeshView m, cons
     const int lo = (int)(lc & 0xffffu), ln = (int)(lc >> 16);
     const v2dTile a0 = sA[2 * lo], a1 = sA[2 * lo + 1], n0 = sA[2 * ln], n1 = sA[2 * ln + 1];
     const double muQo = sB[lo].x, muQn = sB[ln].x;
-    const double muf = lerpf(w, muEffOf(gm, muQo), muEffOf(gm, muQn));
-    const double alf = lerpf(w, alphaEffOf(gm, muQo), alphaEffOf(gm, muQn));
-    const double Uf[3] = {lerpf(w, a0.y, n0.y), lerpf(w, a1.x, n1.x), lerpf(w, a1.y, n1.y)};
-    double to[9], tn[9], tau[9];
-    muDev2T(sG + 9 * lo, muEffOf(gm, muQo), to);
-    muDev2T(sG + 9 * ln, muEffOf(gm, muQn), tn);
-    for (int k = 0; k < 9; ++k) tau[k] = lerpf(w, to[k], tn[k]);
-    double tU[3];
-    for (int i = 0; i < 3; ++i) tU[i] = tau[3 * i] * Uf[0] + tau[3 * i + 1] * Uf[1] + tau[3 * i + 2] * Uf[2];   // tauMC & Uf
+    const double uo[3] = {a0.y, a1.x, a1.y}, un[3] = {n0.y, n1.x, n1.y};
+    ImplFaceOut r;
+    implInternalFace(gm, w, muQo, muQn, uo, un, sG + 9 * lo, sG + 9 * ln, S, gsd, r);   // (shared with the block-fused assembly, qgd_implicit_dev.hpp)
     for (int j = 0; j < 3; ++j) {
-        iv.phiTau[(size_t)j * nF + pos] = S[0] * tau[j] + S[1] * tau[3 + j] + S[2] * tau[6 + j];                  // Sf & tauMC
-        iv.UfS[(size_t)j * nF + f] = Uf[j];
+        iv.phiTau[(size_t)j * nF + pos] = r.phiTau[j];
+        iv.UfS[(size_t)j * nF + f] = r.Uf[j];
     }
-    iv.sTau[f] = S[0] * tU[0] + S[1] * tU[1] + S[2] * tU[2];
-    iv.mufS[f] = muf;
-    iv.aU[pos] = muf * gsd;
-    iv.aE[pos] = alf * gsd;
+    iv.sTau[f] = r.sTau;
+    iv.mufS[f] = r.muf;
+    iv.aU[pos] = r.aU;
+    iv.aE[pos] = r.aE;
 }
 
 // QGDRhoEqn.H, the first solve of QGDUEqn.H (rhoU), U = rhoU/rho, and the matrix + source of UEqn per component
@@ -261,7 +186,7 @@ __global__ __launch_bounds__(QGD_BLOCK) void implCellUKernel(const MeshView m, c
     if (m.ghost && m.ghost[ci] == 1) return;   // ghost rows belong to another shard
     const int n = m.cfCount[ci];
     const size_t base = (size_t)m.cfSlice[ci >> 6] * 64 + (ci & 63);
-    const size_t nF = (size_t)m.nF, nC = (size_t)m.nC;
+    const size_t nF = (size_t)m.nF;
     double sum[4] = {0, 0, 0, 0}, dTau[3] = {0, 0, 0}, diagBase = 0;
     if (__ballot(n != 6) == 0) {
         // a wavefront of hexahedra: labels and flux positions of the six faces, then their 48 values in flight before the ordered sums
@@ -319,42 +244,7 @@ __global__ __launch_bounds__(QGD_BLOCK) void implCellUKernel(const MeshView m, c
         }
     }
     const RecA A = c.A[ci];
-    const double V = m.V[ci], dt = c.dt[0], dtV = dt / V, rDeltaT = 1.0 / dt;
-    const double rho = A.rho - dtV * sum[0];
-    const double uo[3] = {A.ux, A.uy, A.uz};
-    double Ucur[3];
-    for (int k = 0; k < 3; ++k) Ucur[k] = (A.rho * uo[k] - dtV * sum[1 + k]) / rho;   // rhoU/rho [QGDUEqn.H L36-50]
-    double diag[3], rhs[3];
-    for (int k = 0; k < 3; ++k) {
-        diag[k] = rDeltaT * rho * V + diagBase;
-        rhs[k] = rDeltaT * rho * Ucur[k] * V + dTau[k];   // fvm::ddt(rho,U) - fvc::ddt(rho,U) - fvc::div(phiTauMC) [L58-60]
-    }
-    // patch coefficients of -fvm::laplacian(muf, U) (L0): fixedValue: delta / delta*value; basicSymmetry: delta*|n_k| /
-    // snGrad_k + delta*|n_k|*patchInternalField_k (transformFvPatchField); zeroGradient: none
-    for (int i = 0; i < n; ++i) {
-        const int it = m.cfItem[base + (size_t)i * 64];
-        if (it < m.nIF) continue;   // owner-side boundary faces only (it >= nIF implies it >= 0)
-        const int f = it, b = f - m.nIF;
-        if (m.fkind[f] == 3) continue;
-        const PatchBCDev bc = bcs[m.bPatch[b]];
-        if (bc.ptype == QGD_PATCH_HALO || bc.ptype == QGD_PATCH_CYCLIC) continue;
-        const double a = iv.aU[f];
-        if (bc.bcU == QGD_BC_FIXEDVALUE) {
-            for (int k = 0; k < 3; ++k) { diag[k] += a; rhs[k] += a * bc.vU[k]; }
-        } else if (bc.bcU == QGD_BC_SLIP) {
-            const double ms = m.magSf[f], dc = m.dn[f], gs = iv.mufS[f] * ms;
-            double nv[3];
-            symmNormal(m, bc, f, nv);
-            double sn[3];
-            patchSnGradU(m, bc, f, Ucur, Ucur, sn);
-            for (int k = 0; k < 3; ++k) { diag[k] += a * fabs(nv[k]); rhs[k] += gs * (sn[k] + dc * fabs(nv[k]) * Ucur[k]); }
-        }
-    }
-    iv.rhoNew[ci] = rho;
-    for (int k = 0; k < 3; ++k) {
-        iv.xU[(size_t)k * nC + ci] = startValue(iv, (size_t)k * nC + ci, Ucur[k]);
-        iv.diagU[(size_t)k * nC + ci] = diag[k]; iv.rhsU[(size_t)k * nC + ci] = rhs[k];
-    }
+    implCellU(m, c, iv, bcs, ci, A, m.V[ci], sum, dTau, diagBase, n, [&](int i) { return m.cfItem[base + (size_t)i * 64]; });   // (qgd_implicit_dev.hpp)
 }
 
 // after the U solve: rho and U of the records (p and e stay those of the old time level), patch values of U
@@ -1355,11 +1245,18 @@ void launchSpeciesStepImplicit(ImplicitSolver* S, const MeshView& m, const doubl
 //   E  phiSigmaDotU, the energy equation's explicit part, the e system (its solve follows)
 //   F  rhoE = rho (e + |U|^2/2), thermo, p
 void launchImplicitPart(hipStream_t s, const MeshView& m, const CaseView& c, const ImplView& iv, const GasModel& g, const PatchBCDev* bc,
-                        ImplicitSolver* S, double tol, int maxIter, int part) {
+                        ImplicitSolver* S, double tol, int maxIter, int part, bool fusedU) {
     const int gc = gridOf(m.nC), gf = gridOf(m.nF), gb = gridOf(m.nBF);
     switch (part) {
         case 0: implCellGradKernel<<<gc, QGD_BLOCK, 0, s>>>(m, c, iv); break;
         case 1: {
+            if (fusedU) {
+                // the block-fused assembly (qgd_kernels.hip fusedFaceCellKernel<..., IMPL>): the patch faces first -- the blocks read their
+                // phiTauMC and laplacian coefficients --, then vertex values, QGD fluxes, tauMC and the rows of the U systems in ONE launch
+                if (m.nBF > 0) implFaceKernel<<<gb, QGD_BLOCK, 0, s>>>(m, c, iv, g, bc, nullptr, m.nIF);
+                const Launcher L{s, nullptr, nullptr, nullptr};
+                launchFusedImplU(L, m, c, g, iv, bc);
+            } else {
             if (m.tileOff != nullptr && m.fblock == 128 && m.implTiles) {
                 // internal faces of the staged tiles out of LDS, the tiles beyond the caps and the boundary faces through the generic walk
                 const size_t lds = ((size_t)m.tileMaxC * 120 + 255) / 256 * 256;
@@ -1368,6 +1265,7 @@ void launchImplicitPart(hipStream_t s, const MeshView& m, const CaseView& c, con
                 if (m.nBF > 0) implFaceKernel<<<gb, QGD_BLOCK, 0, s>>>(m, c, iv, g, bc, nullptr, m.nIF);
             } else implFaceKernel<<<gf, QGD_BLOCK, 0, s>>>(m, c, iv, g, bc, nullptr, 0);
             implCellUKernel<<<gc, QGD_BLOCK, 0, s>>>(m, c, iv, bc);
+            }
             int mask = 0;
             for (int k = 0; k < 3; ++k) if (!(m.nGeomD < 3 && m.emptyDir[k])) mask |= 1 << k;   // validComponents (L0)
             implicitSolveSetup(S, 3, mask, iv.aU, iv.diagU, iv.rhsU, iv.xU, tol, maxIter);

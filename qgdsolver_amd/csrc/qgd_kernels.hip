@@ -30,6 +30,7 @@
 
 #include "../../include/qgd_amd.h"
 #include "qgd_stencil_dev.hpp"
+#include "qgd_implicit_dev.hpp"
 
 namespace qgd {
 
@@ -1133,14 +1134,23 @@ void cellUpdateKernel(const MeshView m, const CaseView c, const GasModel gm, con
 #ifndef QGD_FU_PRIO
 #define QGD_FU_PRIO 3
 #endif
-template <bool SGEO, bool UPW = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QGD_FU_WAVES, QGD_FU_WAVES)))
-void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm, const int firstBlock) {
+// IMPL = the implicitDiffusion branch [QGDUEqn.H L36-68, updateFluxes.H L95-111]: the same block forms its vertex values and the QGD fluxes of
+// its faces (without the Navier-Stokes / Fourier parts), then -- with fvc::grad(U) of its own and across-a-face cells staged beside the records --
+// tauMC, phiTauMC and the laplacian coefficients of every face (implInternalFace: implFaceTileKernel's expressions), and instead of advancing
+// its cells it assembles their rows of the three U systems out of LDS (implCellU: implCellUKernel's): rho, the predictor U = rhoU/rho, diagonal,
+// right-hand side, start value.  What the solves and the energy equation read later goes to device memory once, from the block that owns the
+// face's owner: the laplacian coefficients, Uf, Sf.(tauMC & Uf), muf, the net energy flux, phiTauMC.  The vertex kernel, the QGD face kernel,
+// implFaceTileKernel and implCellUKernel are this one launch; two blocks per CU (72 B of gradient per staged cell more LDS).  Unsharded cases.
+template <bool SGEO, bool UPW = false, bool IMPL = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IMPL ? 2 : QGD_FU_WAVES, IMPL ? 2 : QGD_FU_WAVES)))
+void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm, const int firstBlock, const ImplView iv,
+                         const PatchBCDev* __restrict__ bcs) {
     extern __shared__ v2d tileLds[];
 #if QGD_FU_PRIO
     __builtin_amdgcn_s_setprio(3);
 #endif
-    constexpr int NT = 256, KC = 5, KCC = 4, KB2 = 3, KV = 3, KF = 2, KE = 6, KP = 8;
+    constexpr int NT = 256, KC = 5, KCC = 4, KB2 = 3, KV = 3, KF = 2, KE = 6, KP = 8, KG = 12;
+    static_assert(9 * kFusedCapCDev <= KG * NT, "caps");
     // piece loads per thread: RecA of <= 384 staged cells, centres and RecB of the <= 320 own + across-a-face cells, coordinates of <= 256
     // vertices; faces per thread; face entries of a cell / cells of a vertex held in registers
     static_assert(3 * kFusedCapTotDev <= KC * NT && 3 * kFusedCapCDev <= KCC * NT && 2 * kFusedCapCDev <= KB2 * NT && 3 * kFusedCapVDev <= KV * NT &&
@@ -1174,6 +1184,14 @@ void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm, 
     for (int k = 0; k < KV; ++k) {
         const int q = tid + k * NT, r = (q * 43691) >> 17;
         idV[k] = tVerts[min(r, capV - 1)] * 3 + (q - 3 * r);
+    }
+    int idG[IMPL ? KG : 1];
+    if constexpr (IMPL) {
+#pragma unroll
+        for (int k = 0; k < KG; ++k) {
+            const int q = tid + k * NT, r = q / 9;
+            idG[k] = tCells[min(r, capC - 1)] * 9 + (q - 9 * r);
+        }
     }
     const int ci = tCells[min(tid & 127, capC - 1)];   // (threads beyond the block's cells repeat its last label: loads stay inside the lists)
     const int nEraw = (int)m.fuNEntry[(size_t)blk * 128 + (tid & 127)];
@@ -1220,6 +1238,20 @@ void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm, 
     int fk[KF];
 #pragma unroll
     for (int j = 0; j < KF; ++j) { fw[j] = ldStream(m.w + fl[j]); fh[j] = ldStream(m.hf + fl[j]); fk[j] = m.fkind[fl[j]]; }
+    // IMPL: fvc::grad(U) of the own + across-a-face cells, piece by piece; per face its flux position, |Sf| * nonOrthDeltaCoeffs and the STREAMED
+    // Sf (implFaceTileKernel multiplies with that one, the QGD fluxes with the Sf rebuilt from the vertices: both as in the separate kernels)
+    double dG[IMPL ? KG : 1], fgsd[IMPL ? KF : 1], fS[IMPL ? KF : 1][3];
+    int fps[IMPL ? KF : 1];
+    if constexpr (IMPL) {
+#pragma unroll
+        for (int k = 0; k < KG; ++k) dG[k] = iv.gUc[idG[k]];
+#pragma unroll
+        for (int j = 0; j < KF; ++j) {
+            fps[j] = ldStream(m.fpos + fl[j]);
+            fgsd[j] = ldStream(m.magSf + fl[j]) * ldStream(m.dn + fl[j]);
+            fS[j][0] = ldStream(m.Sx + fl[j]); fS[j][1] = ldStream(m.Sy + fl[j]); fS[j][2] = ldStream(m.Sz + fl[j]);
+        }
+    }
     const double rEold = c.rE[ci], Vc = m.V[ci], hq = m.hQGD[ci];
     v2d dPt[3];
     dPt[0] = dPt[1] = dPt[2] = v2d{0.0, 0.0};
@@ -1241,8 +1273,9 @@ void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm, 
     v2d* const sP = sB + 2 * hdr.y;              // 3 nV: vertex RecA
     double* const sX = reinterpret_cast<double*>(sP + 3 * hdr.z);   // 3 nV: vertex coordinates
     double* const sC = sX + 3 * hdr.z;           // 3 nAll: cell centres
-    double* const sF = reinterpret_cast<double*>(sP);   // 5 nF: net fluxes, plane by plane (after the third barrier)
-    int* const sE = reinterpret_cast<int*>(reinterpret_cast<double*>(tileLds) + m.fuLdsCell);   // 6 x 128: an own cell's first six face entries, parked until its update
+    double* const sG = sC + 3 * hdr.y;           // IMPL: 9 nAll: fvc::grad(U) of the own + across-a-face cells
+    double* const sF = reinterpret_cast<double*>(sP);   // 5 nF (IMPL: 8 nF): net fluxes, plane by plane (after the third barrier)
+    int* const sE = reinterpret_cast<int*>(reinterpret_cast<double*>(tileLds) + (IMPL ? m.fuLdsCellImpl : m.fuLdsCell));   // 6 x 128: an own cell's first six face entries, parked until its update
     const int strideF = hdr.w;
     if (tid < 128) {
 #pragma unroll
@@ -1256,6 +1289,10 @@ void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm, 
     for (int k = 0; k < KB2; ++k) { const int q = tid + k * NT; if (q < 2 * nUc) sB[q] = dB[k]; }
 #pragma unroll
     for (int k = 0; k < KV; ++k) { const int q = tid + k * NT; if (q < 3 * nUv) sX[q] = dX[k]; }
+    if constexpr (IMPL) {
+#pragma unroll
+        for (int k = 0; k < KG; ++k) { const int q = tid + k * NT; if (q < 9 * nUc) sG[q] = dG[k]; }
+    }
     __syncthreads();
 #if QGD_FU_PRIO == 2
     __builtin_amdgcn_s_setprio(0);
@@ -1302,6 +1339,7 @@ void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm, 
     // (2) the faces: fluxes into registers
     auto l3 = [](const double* p, int i) { return make_double4(p[3 * i], p[3 * i + 1], p[3 * i + 2], 0.0); };
     double out[KF][5];
+    double oxi[IMPL ? KF : 1][4];   // IMPL: phiTauMC (3) and the laplacian coefficient of the U systems
 #pragma unroll
     for (int j = 0; j < KF; ++j) {
         const int lf = tid + j * NT;
@@ -1388,6 +1426,22 @@ void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm, 
             const RecA Ao = *reinterpret_cast<const RecA*>(sA + 3 * lo), An = *reinterpret_cast<const RecA*>(sA + 3 * ln);
             const RecB Bo = *reinterpret_cast<const RecB*>(sB + 2 * lo), Bn = *reinterpret_cast<const RecB*>(sB + 2 * ln);
             gvp3FaceTail<false, UPW>(m, c, gm, f, fw[j], fh[j], S, Ao, An, Bo, Bn, g, 0, cof, tauMin, &out[j][0], (size_t)1);
+            if constexpr (IMPL) {
+                const double uo[3] = {Ao.ux, Ao.uy, Ao.uz}, un[3] = {An.ux, An.uy, An.uz};
+                ImplFaceOut r;
+                implInternalFace(gm, fw[j], Bo.muQGD, Bn.muQGD, uo, un, sG + 9 * lo, sG + 9 * ln, fS[j], fgsd[j], r);
+                oxi[j][0] = r.phiTau[0]; oxi[j][1] = r.phiTau[1]; oxi[j][2] = r.phiTau[2]; oxi[j][3] = r.aU;
+                if (lo < nOwn) {   // the block that owns the face's owner writes what the solves and the energy equation read later
+                    const size_t nF = (size_t)m.nF, pos = (size_t)fps[j];
+                    c.flux[4 * nF + pos] = out[j][4];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { iv.phiTau[(size_t)k * nF + pos] = r.phiTau[k]; iv.UfS[(size_t)k * nF + f] = r.Uf[k]; }
+                    iv.sTau[f] = r.sTau;
+                    iv.mufS[f] = r.muf;
+                    iv.aU[pos] = r.aU;
+                    iv.aE[pos] = r.aE;
+                }
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -1397,10 +1451,49 @@ void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm, 
         const int lf = tid + j * NT;
         if (lf < nFc) {
 #pragma unroll
-            for (int k = 0; k < 5; ++k) sF[k * strideF + lf] = out[j][k];
+            for (int k = 0; k < (IMPL ? 4 : 5); ++k) sF[k * strideF + lf] = out[j][k];
+            if constexpr (IMPL) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sF[(4 + k) * strideF + lf] = oxi[j][k];
+            }
         }
     }
     __syncthreads();
+    if constexpr (IMPL) {
+        // (3') the rows of the U systems of the block's own cells out of LDS: implCellUKernel's ordered sums and arithmetic
+        if (tid < nOwn) {
+            const size_t nF = (size_t)m.nF;
+            double sum[4] = {0, 0, 0, 0}, dTau[3] = {0, 0, 0}, diagBase = 0;
+            const int nE = nEraw;
+            for (int i = 0; i < nE; ++i) {
+                const int e = (i < KE) ? sE[i * 128 + tid] : ent[(size_t)i * 128];
+                double fx[4], tx[3];
+                if (e >= 0) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) fx[k] = sF[k * strideF + (e >> 1)];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) tx[k] = sF[(4 + k) * strideF + (e >> 1)];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) fx[k] = c.flux[k * nF + (size_t)(~e)];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) tx[k] = iv.phiTau[k * nF + (size_t)(~e)];
+                }
+                const bool plus = e < 0 || !(e & 1);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sum[k] = plus ? sum[k] + fx[k] : sum[k] - fx[k];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) dTau[k] = plus ? dTau[k] + tx[k] : dTau[k] - tx[k];
+                if (e >= 0) diagBase += sF[7 * strideF + (e >> 1)];
+            }
+            const RecA A = *reinterpret_cast<const RecA*>(sA + 3 * tid);
+            implCellU(m, c, iv, bcs, ci, A, Vc, sum, dTau, diagBase, nE, [&](int i) {
+                const int e = (i < KE) ? sE[i * 128 + tid] : ent[(size_t)i * 128];
+                return e < 0 ? ~e : -1;   // a patch face's label; internal faces carry no patch coefficient
+            });
+        }
+        return;
+    }
     // (3) the block's own cells out of LDS
     double rmin = 1e300, emin = 1e300;
     if (tid < nOwn) {
@@ -2014,10 +2107,33 @@ void launchBoundaryFaceFlux(const Launcher& L, int stencil, const MeshView& m, c
 void launchFusedFaceCell(const Launcher& L, const MeshView& m, const CaseView& c, const GasModel& g, int firstBlock, int nBlocks) {
     if (nBlocks <= 0) return;
     const bool upw = g.upwindU || g.upwindH;   // a `Gauss upwind` entry for div(phiJm,U) or div(phiJm,H)
-    if (m.sGeo && upw) QGD_TIMED(L, QGD_K_FACE, (fusedFaceCellKernel<true, true><<<nBlocks, 256, m.fuLds, L.stream>>>(m, c, g, firstBlock)));
-    else if (upw) QGD_TIMED(L, QGD_K_FACE, (fusedFaceCellKernel<false, true><<<nBlocks, 256, m.fuLds, L.stream>>>(m, c, g, firstBlock)));
-    else if (m.sGeo) QGD_TIMED(L, QGD_K_FACE, (fusedFaceCellKernel<true><<<nBlocks, 256, m.fuLds, L.stream>>>(m, c, g, firstBlock)));
-    else QGD_TIMED(L, QGD_K_FACE, (fusedFaceCellKernel<false><<<nBlocks, 256, m.fuLds, L.stream>>>(m, c, g, firstBlock)));
+    const ImplView none{};
+    if (m.sGeo && upw) QGD_TIMED(L, QGD_K_FACE, (fusedFaceCellKernel<true, true><<<nBlocks, 256, m.fuLds, L.stream>>>(m, c, g, firstBlock, none, nullptr)));
+    else if (upw) QGD_TIMED(L, QGD_K_FACE, (fusedFaceCellKernel<false, true><<<nBlocks, 256, m.fuLds, L.stream>>>(m, c, g, firstBlock, none, nullptr)));
+    else if (m.sGeo) QGD_TIMED(L, QGD_K_FACE, (fusedFaceCellKernel<true><<<nBlocks, 256, m.fuLds, L.stream>>>(m, c, g, firstBlock, none, nullptr)));
+    else QGD_TIMED(L, QGD_K_FACE, (fusedFaceCellKernel<false><<<nBlocks, 256, m.fuLds, L.stream>>>(m, c, g, firstBlock, none, nullptr)));
+}
+// the implicitDiffusion branch's block-fused assembly of the U systems (fusedFaceCellKernel<..., IMPL = true>): more dynamic LDS than the
+// 64 KB a launch gets by default, so the kernels' limit is raised first; false when the device refuses (the caller keeps the separate kernels)
+template <bool SGEO, bool UPW>
+static bool fusedImplLimit(int lds) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&fusedFaceCellKernel<SGEO, UPW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+}
+bool fusedImplUPrepare(const MeshView& m, const GasModel& g) {
+    if (m.fuBlocks <= 0 || m.fuLdsImpl <= 0) return false;
+    const bool upw = g.upwindU || g.upwindH;
+    const bool ok = m.sGeo ? (upw ? fusedImplLimit<true, true>(m.fuLdsImpl) : fusedImplLimit<true, false>(m.fuLdsImpl))
+                           : (upw ? fusedImplLimit<false, true>(m.fuLdsImpl) : fusedImplLimit<false, false>(m.fuLdsImpl));
+    if (!ok) (void)hipGetLastError();
+    return ok;
+}
+void launchFusedImplU(const Launcher& L, const MeshView& m, const CaseView& c, const GasModel& g, const ImplView& iv, const PatchBCDev* bc) {
+    const bool upw = g.upwindU || g.upwindH;
+    const int n = m.fuBlocks;
+    if (m.sGeo && upw) QGD_TIMED(L, QGD_K_FACE, (fusedFaceCellKernel<true, true, true><<<n, 256, m.fuLdsImpl, L.stream>>>(m, c, g, 0, iv, bc)));
+    else if (upw) QGD_TIMED(L, QGD_K_FACE, (fusedFaceCellKernel<false, true, true><<<n, 256, m.fuLdsImpl, L.stream>>>(m, c, g, 0, iv, bc)));
+    else if (m.sGeo) QGD_TIMED(L, QGD_K_FACE, (fusedFaceCellKernel<true, false, true><<<n, 256, m.fuLdsImpl, L.stream>>>(m, c, g, 0, iv, bc)));
+    else QGD_TIMED(L, QGD_K_FACE, (fusedFaceCellKernel<false, false, true><<<n, 256, m.fuLdsImpl, L.stream>>>(m, c, g, 0, iv, bc)));
 }
 void launchCellUpdate(const Launcher& L, const MeshView& m, const CaseView& c, const GasModel& g, int mode,
                       const int32_t* list, int nList) {

@@ -692,7 +692,7 @@ struct OneBlock {
     std::vector<uint8_t> vCount;                      // per staged vertex
     std::vector<uint16_t> vPos;                       // row-major here (vertex x maxPE)
     std::vector<double> vW;
-    int32_t nAll = 0, maxPE = 0, lds = 0;             // own + across-a-face cells (cells.size() counts the extras too); LDS bytes of its records
+    int32_t nAll = 0, maxPE = 0, lds = 0, ldsImpl = 0;   // own + across-a-face cells (cells.size() counts the extras too); LDS bytes of its records (explicit / implicit layout)
     std::vector<uint8_t> nEntry;
     int32_t nOwn = 0, maxE = 0;
     // 128-bit fingerprint of the block's local topology (counts, per-face positions, face entries, per-vertex cell positions): what two
@@ -900,6 +900,7 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
         // vertex records + coordinates + centres, which the fluxes overwrite): a block over the budget that lets three blocks share a CU is
         // cut like one over the caps, unless it is small already
         o.lds = 48 * (int32_t)o.cells.size() + 32 * o.nAll + std::max(72 * (int32_t)vs.size() + 24 * o.nAll, 40 * (int32_t)faces.size());
+        o.ldsImpl = 48 * (int32_t)o.cells.size() + 32 * o.nAll + std::max(72 * (int32_t)vs.size() + 96 * o.nAll, 64 * (int32_t)faces.size());
         if (o.lds > kFusedLdsTarget && o.nOwn > 32) return false;
         o.face.resize(4 * faces.size());
         for (size_t lf = 0; lf < faces.size(); ++lf) {
@@ -981,12 +982,12 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
     std::vector<std::vector<Hash>> hashCuts;    // ... of the blocks of a range that was cut
     bool failed = false;
     int64_t facesDone = 0, cellsTot = 0, cellsAll = 0, vertsTot = 0;
-    int32_t maxC = 0, maxV = 0, maxF = 0, maxE = 1, maxAll = 0, maxPE = 1, maxLds = 0;
+    int32_t maxC = 0, maxV = 0, maxF = 0, maxE = 1, maxAll = 0, maxPE = 1, maxLds = 0, maxLdsImpl = 0;
     // keep the first way of cutting ranges whose blocks average 104 cells or more, else the one with the largest average
     struct Kept { std::vector<int64_t> rangeStart; std::vector<int32_t> nOf; std::vector<std::vector<std::pair<int64_t, int64_t>>> cuts;
                   std::vector<Hash> hashOne; std::vector<std::vector<Hash>> hashCuts; bool bricks = false;
                   int64_t nRanges = 0, facesDone = 0, cellsTot = 0, cellsAll = 0, vertsTot = 0, blocks = 0;
-                  int32_t maxC = 0, maxV = 0, maxF = 0, maxE = 1, maxAll = 0, maxPE = 1, maxLds = 0; } best;
+                  int32_t maxC = 0, maxV = 0, maxF = 0, maxE = 1, maxAll = 0, maxPE = 1, maxLds = 0, maxLdsImpl = 0; } best;
     for (const int64_t len : {(int64_t)0, (int64_t)112, (int64_t)96, (int64_t)80, (int64_t)64}) {
         if (len == 0) brickRanges(); else runRanges(len);
         nOf.assign((size_t)nRanges, 1);
@@ -995,8 +996,8 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
         hashCuts.assign((size_t)nRanges, {});
         failed = false;
         facesDone = cellsTot = cellsAll = vertsTot = 0;
-        maxC = maxV = maxF = maxAll = maxLds = 0; maxE = maxPE = 1;
-#pragma omp parallel reduction(+ : facesDone, cellsTot, cellsAll, vertsTot) reduction(max : maxC, maxV, maxF, maxE, maxAll, maxPE, maxLds)
+        maxC = maxV = maxF = maxAll = maxLds = maxLdsImpl = 0; maxE = maxPE = 1;
+#pragma omp parallel reduction(+ : facesDone, cellsTot, cellsAll, vertsTot) reduction(max : maxC, maxV, maxF, maxE, maxAll, maxPE, maxLds, maxLdsImpl)
         {
             std::vector<SmallMap> maps(3);
             OneBlock o;
@@ -1021,6 +1022,7 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
                         maxAll = std::max(maxAll, o.nAll);
                         maxPE = std::max(maxPE, o.maxPE);
                         maxLds = std::max(maxLds, o.lds);
+                        maxLdsImpl = std::max(maxLdsImpl, o.ldsImpl);
                         facesDone += (int64_t)o.face.size() / 4;
                         cellsTot += (int64_t)o.cells.size(); cellsAll += o.nAll; vertsTot += (int64_t)o.verts.size();
                         continue;
@@ -1047,7 +1049,7 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
             best.rangeStart = rangeStart; best.nOf = nOf; best.cuts = cuts; best.nRanges = nRanges;
             best.hashOne = hashOne; best.hashCuts = hashCuts;
             best.facesDone = facesDone; best.cellsTot = cellsTot; best.cellsAll = cellsAll; best.vertsTot = vertsTot; best.blocks = blocks;
-            best.maxC = maxC; best.maxV = maxV; best.maxF = maxF; best.maxE = maxE; best.maxAll = maxAll; best.maxPE = maxPE; best.maxLds = maxLds;
+            best.maxC = maxC; best.maxV = maxV; best.maxF = maxF; best.maxE = maxE; best.maxAll = maxAll; best.maxPE = maxPE; best.maxLds = maxLds; best.maxLdsImpl = maxLdsImpl;
         }
         if (blocks * 104 <= nOwned) break;
     }
@@ -1055,7 +1057,7 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
         rangeStart.swap(best.rangeStart); nOf.swap(best.nOf); cuts.swap(best.cuts); nRanges = best.nRanges;
         hashOne.swap(best.hashOne); hashCuts.swap(best.hashCuts);
         facesDone = best.facesDone; cellsTot = best.cellsTot; cellsAll = best.cellsAll; vertsTot = best.vertsTot;
-        maxC = best.maxC; maxV = best.maxV; maxF = best.maxF; maxE = best.maxE; maxAll = best.maxAll; maxPE = best.maxPE; maxLds = best.maxLds;
+        maxC = best.maxC; maxV = best.maxV; maxF = best.maxF; maxE = best.maxE; maxAll = best.maxAll; maxPE = best.maxPE; maxLds = best.maxLds; maxLdsImpl = best.maxLdsImpl;
     }
     if (failed) return B;
     // a shard: the blocks that hold a cell a neighbour waits for (role 2) come first, so that the step can advance them before the others and
@@ -1086,7 +1088,7 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
     B.maxC = maxC; B.maxV = maxV; B.maxF = maxF;
     B.capC = (B.maxC + 7) / 8 * 8; B.capV = (B.maxV + 7) / 8 * 8; B.capF = (B.maxF + 7) / 8 * 8;
     B.capE = maxE;
-    B.capPE = maxPE; B.maxTot = maxC; B.maxAll = maxAll; B.maxLds = maxLds;
+    B.capPE = maxPE; B.maxTot = maxC; B.maxAll = maxAll; B.maxLds = maxLds; B.maxLdsImpl = maxLdsImpl;
     // templates: the distinct topology fingerprints in ascending order (deterministic); a block's template = its fingerprint's rank; the
     // template's tables are written by the first block (in launch order) that has it.  QGD_FUSED_TEMPLATES=0: one template per block.
     std::vector<int32_t> tplOf((size_t)nBlocks, 0);      // by launch position

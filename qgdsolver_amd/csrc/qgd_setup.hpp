@@ -175,6 +175,7 @@ struct FusedBlocks {
     // (capPE x capV per block); count 0 = a patch point, whose value the patch-point kernel has put into the vertex records.
     int32_t capPE = 0, maxTot = 0, maxAll = 0;        // cells per vertex; staged cells incl. extras / without them, of the largest block
     int32_t maxLds = 0;                               // LDS bytes of the records of the block that needs most (the kernel lays each block out by its own counts)
+    int32_t maxLdsImpl = 0;                           // ... in the layout of the implicitDiffusion branch's assembly (fvc::grad(U) staged too, eight flux planes)
     RawVec<int32_t> hdr2;     // 4 per block: all staged cells, template, 0, 0
     RawVec<uint8_t> vCount;   // capV per block
     RawVec<uint16_t> vPos;    // capPE x capV per template

@@ -129,7 +129,10 @@ def test_cases_the_fused_kernel_does_not_serve_keep_the_two_kernels():
     dev = q.Device(mesh, fused_tables="any")
     for opt in (dict(adjustTimeStep=1, maxCo=0.2), dict(implicitDiffusion=1, mu=1e-3), dict(termStencils={"grad(p)": "reduced"})):
         case = q.QGDFoamCase(dev, q.default_options(stencil="GaussVolPoint", deltaT=1e-3, **opt))
-        assert not case.fused_info()["fused"], opt
+        fi = case.fused_info()
+        assert not fi["fused"], opt
+        # (the implicitDiffusion branch has its own block-fused assembly on the same blocks: tests/test_implicit_diffusion.py)
+        assert fi["fusedImplicit"] == bool(opt.get("implicitDiffusion")), (opt, fi)
         case.close()
     case = q.QGDFoamCase(dev, q.default_options(stencil="reduced", deltaT=1e-3))
     assert not case.fused_info()["fused"]

@@ -83,9 +83,15 @@ GPU_CASES = [("box654_jitter", "GaussVolPoint", mixed_bcs), ("box654_tri", "Gaus
              ("plane2d_jitter", "leastSquares", None)]
 
 
+def _implicit_arms(kind, stencil):
+    """3-D GaussVolPoint cases run twice: through the block-fused assembly of the U systems (fusedFaceCellKernel<..., IMPL>: vertex values, QGD
+    fluxes, tauMC and the rows of the three systems in one launch) and through the separate kernels; everything else the second way only"""
+    return ["fused", "kernels"] if (stencil == "GaussVolPoint" and kind.startswith("box")) else ["kernels"]
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind,stencil,bc_fn", GPU_CASES)
-def test_device_implicit_branch_matches_oracle(kind, stencil, bc_fn):
+@pytest.mark.parametrize("kind,stencil,bc_fn,arm", [c + (a,) for c in GPU_CASES for a in _implicit_arms(c[0], c[1])])
+def test_device_implicit_branch_matches_oracle(kind, stencil, bc_fn, arm):
     mesh = make_mesh(kind)
     C = mesh.array("C").reshape(-1, 3)
     if kind == "step2d":
@@ -104,8 +110,10 @@ def test_device_implicit_branch_matches_oracle(kind, stencil, bc_fn):
 
     setup = bc_fn if bc_fn else empty_patches
     ref = run_oracle(mesh, setup, fields, 12, **opt)
-    dev = q.Device(mesh)
+    dev = q.Device(mesh, fused_tables="any" if arm == "fused" else False)
     gc = q.QGDFoamCase(dev, q.default_options(**opt))
+    fi = gc.fused_info()
+    assert fi["fusedImplicit"] == (arm == "fused") and not fi["fused"], (arm, fi)    # the arm under test is the path that runs
     setup(gc)
     gc.set_fields(*fields)
     gc.step(12)
@@ -304,4 +312,51 @@ def test_chebyshev_solver_on_a_weakly_dominant_system():
     if worst >= 1e-13:
         assert ii["stalled_steps"] > 0, ii
     assert 0 <= ii["stalled_steps"] <= 6, ii
+    gc.close(); dev.close()
+
+
+@pytest.mark.gpu
+def test_block_fused_assembly_of_the_u_systems_is_the_separate_kernels_bit_for_bit():
+    """fusedFaceCellKernel<..., IMPL> against pointInterpRecKernel + faceFluxGvp3TileKernel + implFaceTileKernel + implCellUKernel: the same
+    inlined expressions (qgd_implicit_dev.hpp), the same summation orders -- states, phiTauMC and phiSigmaDotU agree BIT FOR BIT after several
+    steps, on hexahedra (several blocks), a jittered mesh with triangles and polygons in Morton order, walls of every kind, upwind fluxes;
+    cases the fused assembly does not serve (shards, Courant-number control, other stencils) say so and run the separate kernels"""
+    from test_config5_gpu import c5_mesh
+    from test_case_parity_gpu import mixed_box_bcs
+
+    def run(mesh, fused, bc_fn, steps, **opt):
+        dev = q.Device(mesh, fused_tables="any" if fused else False)
+        gc = q.QGDFoamCase(dev, q.default_options(stencil="GaussVolPoint", implicitDiffusion=1, **opt))
+        assert gc.fused_info()["fusedImplicit"] == fused
+        if bc_fn:
+            bc_fn(gc)
+        gc.set_fields(*cases.box_initial_fields(mesh.array("C").reshape(-1, 3)))
+        gc.step(steps)
+        out = {n: gc.field(n).copy() for n in ("rho", "U", "p", "e", "rhoE", "phiTauMC", "phiSigmaDotU", "U.boundary", "p.boundary")}
+        info = gc.implicit_info()
+        gc.close(); dev.close()
+        return out, info
+
+    jit = q.PolyMesh.box(14, 9, 6).jitter(0.1, seed=11)
+    for tag, mesh, bc_fn, opt in (("hex 20^3", q.PolyMesh.box(20, 20, 20), None, dict(deltaT=2e-3, mu=1e-2)),
+                                  ("hex 37x11x5 + walls", q.PolyMesh.box(37, 11, 5), mixed_box_bcs, dict(deltaT=1e-3, mu=2e-2)),
+                                  ("jitter + walls", jit, mixed_box_bcs, dict(deltaT=5e-4, mu=2e-2)),
+                                  ("triangles + polygons, Morton order", c5_mesh(16, 8 ** 3, poly=True), None, dict(deltaT=1e-3, mu=1e-2)),
+                                  ("upwind fluxes", q.PolyMesh.box(12, 10, 8), mixed_box_bcs, dict(deltaT=1e-3, mu=1e-2, fluxSchemeU=1, fluxSchemeH=1))):
+        a, ia = run(mesh, False, bc_fn, 6, **opt)
+        b, ib = run(mesh, True, bc_fn, 6, **opt)
+        for k in a:
+            assert np.isfinite(b[k]).all() and np.array_equal(a[k], b[k]), (tag, k, np.abs(a[k] - b[k]).max())
+        assert ia["solves"] == ib["solves"], (tag, ia, ib)
+    # not served: a shard, Courant-number control, another stencil
+    dev = q.Device(q.PolyMesh.box(12, 10, 8), fused_tables="any")
+    for opt in (dict(adjustTimeStep=1, maxCo=0.2), dict(stencil="reduced")):
+        gc = q.QGDFoamCase(dev, q.default_options(**dict(dict(stencil="GaussVolPoint", deltaT=1e-3, mu=1e-2, implicitDiffusion=1), **opt)))
+        assert not gc.fused_info()["fusedImplicit"], opt
+        gc.close()
+    dev.close()
+    sh = q.PolyMesh.box(24, 12, 12).shard(2, 0)
+    dev = q.Device(sh, fused_tables="any")
+    gc = q.QGDFoamCase(dev, q.default_options(stencil="GaussVolPoint", deltaT=1e-3, mu=1e-2, implicitDiffusion=1))
+    assert not gc.fused_info()["fusedImplicit"]
     gc.close(); dev.close()
