@@ -91,10 +91,13 @@ __device__ __forceinline__ void implInternalFace(const GasModel& gm, const doubl
     muDev2T(gO, muEffOf(gm, muQo), to);
     muDev2T(gN, muEffOf(gm, muQn), tn);
     for (int k = 0; k < 9; ++k) tau[k] = lerpf(w, to[k], tn[k]);
+    // (the three-term products with their multiply-adds spelled out: left to the compiler's contraction, `a*b + c*d + e*f` may fuse one product
+    // in one kernel and another in the other, and the two callers of this function would differ in the last bit)
+    auto dot3 = [](double a0, double b0, double a1, double b1, double a2, double b2) { return fma(a2, b2, fma(a1, b1, a0 * b0)); };
     double tU[3];
-    for (int i = 0; i < 3; ++i) tU[i] = tau[3 * i] * o.Uf[0] + tau[3 * i + 1] * o.Uf[1] + tau[3 * i + 2] * o.Uf[2];   // tauMC & Uf
-    for (int j = 0; j < 3; ++j) o.phiTau[j] = S[0] * tau[j] + S[1] * tau[3 + j] + S[2] * tau[6 + j];                  // Sf & tauMC
-    o.sTau = S[0] * tU[0] + S[1] * tU[1] + S[2] * tU[2];
+    for (int i = 0; i < 3; ++i) tU[i] = dot3(tau[3 * i], o.Uf[0], tau[3 * i + 1], o.Uf[1], tau[3 * i + 2], o.Uf[2]);   // tauMC & Uf
+    for (int j = 0; j < 3; ++j) o.phiTau[j] = dot3(S[0], tau[j], S[1], tau[3 + j], S[2], tau[6 + j]);                  // Sf & tauMC
+    o.sTau = dot3(S[0], tU[0], S[1], tU[1], S[2], tU[2]);
     o.muf = muf;
     o.aU = muf * gsd;
     o.aE = alf * gsd;
@@ -112,7 +115,7 @@ __device__ __forceinline__ void implCellU(const MeshView& m, const CaseView& c, 
     const double rho = A.rho - dtV * sum[0];
     const double uo[3] = {A.ux, A.uy, A.uz};
     double Ucur[3];
-    for (int k = 0; k < 3; ++k) Ucur[k] = (A.rho * uo[k] - dtV * sum[1 + k]) / rho;   // rhoU/rho [QGDUEqn.H L36-50]
+    for (int k = 0; k < 3; ++k) Ucur[k] = fma(-dtV, sum[1 + k], A.rho * uo[k]) / rho;   // rhoU/rho [QGDUEqn.H L36-50] (one spelling of the multiply-add, see implInternalFace)
     double diag[3], rhs[3];
     for (int k = 0; k < 3; ++k) {
         diag[k] = rDeltaT * rho * V + diagBase;
