@@ -790,8 +790,7 @@ static int deviceCreate(qgd_mesh_t mh, int deviceId, int fusedChoice, qgd_device
                     v.fuTemplates = fb.nTemplates;
                     {   // the implicitDiffusion branch's layout of the same blocks (qgd_kernels.hip fusedFaceCellKernel<..., IMPL>)
                         const int64_t parkI = ((int64_t)fb.maxLdsImpl + 15) / 16 * 16, ldsI = (parkI + 6 * 128 * 4 + 255) / 256 * 256;
-                        const int64_t most = std::max<int64_t>((int64_t)prop.sharedMemPerBlock, (int64_t)prop.maxSharedMemoryPerMultiProcessor);
-                        v.fuLdsImpl = ldsI <= std::min<int64_t>(most, 160 * 1024) / 2 ? (int32_t)ldsI : 0;   // (two blocks per CU, or not at all)
+                        v.fuLdsImpl = ldsI <= ldsLimit ? (int32_t)ldsI : 0;   // (on a box: the explicit step's figure, three blocks per CU)
                         v.fuLdsCellImpl = (int32_t)(parkI / 8);
                     }
                     d->fusedInfo[0] = fb.nBlocks; d->fusedInfo[1] = fb.nLayerBlocks; d->fusedInfo[2] = fb.nTemplates; d->fusedInfo[3] = lds;

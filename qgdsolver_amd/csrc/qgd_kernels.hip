@@ -1135,14 +1135,15 @@ void cellUpdateKernel(const MeshView m, const CaseView c, const GasModel gm, con
 #define QGD_FU_PRIO 3
 #endif
 // IMPL = the implicitDiffusion branch [QGDUEqn.H L36-68, updateFluxes.H L95-111]: the same block forms its vertex values and the QGD fluxes of
-// its faces (without the Navier-Stokes / Fourier parts), then -- with fvc::grad(U) of its own and across-a-face cells staged beside the records --
-// tauMC, phiTauMC and the laplacian coefficients of every face (implInternalFace: implFaceTileKernel's expressions), and instead of advancing
-// its cells it assembles their rows of the three U systems out of LDS (implCellU: implCellUKernel's): rho, the predictor U = rhoU/rho, diagonal,
-// right-hand side, start value.  What the solves and the energy equation read later goes to device memory once, from the block that owns the
-// face's owner: the laplacian coefficients, Uf, Sf.(tauMC & Uf), muf, the net energy flux, phiTauMC.  The vertex kernel, the QGD face kernel,
-// implFaceTileKernel and implCellUKernel are this one launch; two blocks per CU (72 B of gradient per staged cell more LDS).  Unsharded cases.
+// its faces (without the Navier-Stokes / Fourier parts), then -- with fvc::grad(U) of its own and across-a-face cells staged where the vertex
+// records were -- tauMC, phiTauMC and the laplacian coefficients of every face (implInternalFace: implFaceTileKernel's expressions), and instead
+// of advancing its cells it assembles their rows of the three U systems out of LDS (implCellU: implCellUKernel's): rho, the predictor
+// U = rhoU/rho, diagonal, right-hand side, start value.  What the solves and the energy equation read later goes to device memory once, from the
+// block that owns the face's owner: the laplacian coefficients, Uf, Sf.(tauMC & Uf), muf, the net energy flux, phiTauMC.  The vertex kernel, the
+// QGD face kernel, implFaceTileKernel and implCellUKernel are this one launch, in the explicit step's LDS (three blocks per CU).  Unsharded cases.
 template <bool SGEO, bool UPW = false, bool IMPL = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IMPL ? 2 : QGD_FU_WAVES, IMPL ? 2 : QGD_FU_WAVES)))
+// (IMPL with `Gauss upwind` fluxes needs a few registers more than three waves per SIMD leave: that instantiation is compiled for two -- no scratch)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((IMPL && UPW) ? 2 : QGD_FU_WAVES, (IMPL && UPW) ? 2 : QGD_FU_WAVES)))
 void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm, const int firstBlock, const ImplView iv,
                          const PatchBCDev* __restrict__ bcs) {
     extern __shared__ v2d tileLds[];
@@ -1184,14 +1185,6 @@ void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm, 
     for (int k = 0; k < KV; ++k) {
         const int q = tid + k * NT, r = (q * 43691) >> 17;
         idV[k] = tVerts[min(r, capV - 1)] * 3 + (q - 3 * r);
-    }
-    int idG[IMPL ? KG : 1];
-    if constexpr (IMPL) {
-#pragma unroll
-        for (int k = 0; k < KG; ++k) {
-            const int q = tid + k * NT, r = q / 9;
-            idG[k] = tCells[min(r, capC - 1)] * 9 + (q - 9 * r);
-        }
     }
     const int ci = tCells[min(tid & 127, capC - 1)];   // (threads beyond the block's cells repeat its last label: loads stay inside the lists)
     const int nEraw = (int)m.fuNEntry[(size_t)blk * 128 + (tid & 127)];
@@ -1238,20 +1231,6 @@ void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm, 
     int fk[KF];
 #pragma unroll
     for (int j = 0; j < KF; ++j) { fw[j] = ldStream(m.w + fl[j]); fh[j] = ldStream(m.hf + fl[j]); fk[j] = m.fkind[fl[j]]; }
-    // IMPL: fvc::grad(U) of the own + across-a-face cells, piece by piece; per face its flux position, |Sf| * nonOrthDeltaCoeffs and the STREAMED
-    // Sf (implFaceTileKernel multiplies with that one, the QGD fluxes with the Sf rebuilt from the vertices: both as in the separate kernels)
-    double dG[IMPL ? KG : 1], fgsd[IMPL ? KF : 1], fS[IMPL ? KF : 1][3];
-    int fps[IMPL ? KF : 1];
-    if constexpr (IMPL) {
-#pragma unroll
-        for (int k = 0; k < KG; ++k) dG[k] = iv.gUc[idG[k]];
-#pragma unroll
-        for (int j = 0; j < KF; ++j) {
-            fps[j] = ldStream(m.fpos + fl[j]);
-            fgsd[j] = ldStream(m.magSf + fl[j]) * ldStream(m.dn + fl[j]);
-            fS[j][0] = ldStream(m.Sx + fl[j]); fS[j][1] = ldStream(m.Sy + fl[j]); fS[j][2] = ldStream(m.Sz + fl[j]);
-        }
-    }
     const double rEold = c.rE[ci], Vc = m.V[ci], hq = m.hQGD[ci];
     v2d dPt[3];
     dPt[0] = dPt[1] = dPt[2] = v2d{0.0, 0.0};
@@ -1273,9 +1252,9 @@ void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm, 
     v2d* const sP = sB + 2 * hdr.y;              // 3 nV: vertex RecA
     double* const sX = reinterpret_cast<double*>(sP + 3 * hdr.z);   // 3 nV: vertex coordinates
     double* const sC = sX + 3 * hdr.z;           // 3 nAll: cell centres
-    double* const sG = sC + 3 * hdr.y;           // IMPL: 9 nAll: fvc::grad(U) of the own + across-a-face cells
-    double* const sF = reinterpret_cast<double*>(sP);   // 5 nF (IMPL: 8 nF): net fluxes, plane by plane (after the third barrier)
-    int* const sE = reinterpret_cast<int*>(reinterpret_cast<double*>(tileLds) + (IMPL ? m.fuLdsCellImpl : m.fuLdsCell));   // 6 x 128: an own cell's first six face entries, parked until its update
+    double* const sF = reinterpret_cast<double*>(sP);   // 5 nF: net fluxes, plane by plane (after the third barrier)
+    double* const sG = reinterpret_cast<double*>(sP);   // IMPL: 9 nAll: fvc::grad(U) of the own + across-a-face cells, between the two rounds of flux planes
+    int* const sE = reinterpret_cast<int*>(reinterpret_cast<double*>(tileLds) + (IMPL ? m.fuLdsCellImpl : m.fuLdsCell));   // (IMPL: the same figure unless a block's gradients need more than its vertex region)   // 6 x 128: an own cell's first six face entries, parked until its update
     const int strideF = hdr.w;
     if (tid < 128) {
 #pragma unroll
@@ -1289,10 +1268,6 @@ void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm, 
     for (int k = 0; k < KB2; ++k) { const int q = tid + k * NT; if (q < 2 * nUc) sB[q] = dB[k]; }
 #pragma unroll
     for (int k = 0; k < KV; ++k) { const int q = tid + k * NT; if (q < 3 * nUv) sX[q] = dX[k]; }
-    if constexpr (IMPL) {
-#pragma unroll
-        for (int k = 0; k < KG; ++k) { const int q = tid + k * NT; if (q < 9 * nUc) sG[q] = dG[k]; }
-    }
     __syncthreads();
 #if QGD_FU_PRIO == 2
     __builtin_amdgcn_s_setprio(0);
@@ -1339,7 +1314,6 @@ void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm, 
     // (2) the faces: fluxes into registers
     auto l3 = [](const double* p, int i) { return make_double4(p[3 * i], p[3 * i + 1], p[3 * i + 2], 0.0); };
     double out[KF][5];
-    double oxi[IMPL ? KF : 1][4];   // IMPL: phiTauMC (3) and the laplacian coefficient of the U systems
 #pragma unroll
     for (int j = 0; j < KF; ++j) {
         const int lf = tid + j * NT;
@@ -1426,13 +1400,76 @@ void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm, 
             const RecA Ao = *reinterpret_cast<const RecA*>(sA + 3 * lo), An = *reinterpret_cast<const RecA*>(sA + 3 * ln);
             const RecB Bo = *reinterpret_cast<const RecB*>(sB + 2 * lo), Bn = *reinterpret_cast<const RecB*>(sB + 2 * ln);
             gvp3FaceTail<false, UPW>(m, c, gm, f, fw[j], fh[j], S, Ao, An, Bo, Bn, g, 0, cof, tauMin, &out[j][0], (size_t)1);
-            if constexpr (IMPL) {
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();   // every face has read its vertex records and coordinates
+    if constexpr (IMPL) {
+        // The implicitDiffusion branch keeps the explicit step's LDS (three blocks per CU) by using the dead vertex region three times:
+        // (a) the four mass / momentum flux planes -> the own cells' ordered sums; (b) fvc::grad(U) of the own + across-a-face cells ->
+        // tauMC, phiTauMC, the laplacian coefficients of every face; (c) the phiTauMC / coefficient planes -> the cells' second sums and
+        // their rows of the U systems.  The gradients and the faces' streamed data are requested before (a) and arrive behind it.
+        const size_t nF = (size_t)m.nF;
+        double dG[KG], fgsd[KF], fS[KF][3];
+        int fps[KF];
+#pragma unroll
+        for (int k = 0; k < KG; ++k) {
+            const int q = tid + k * NT, r = q / 9;
+            dG[k] = iv.gUc[(size_t)tCells[min(r, capC - 1)] * 9 + (q - 9 * r)];
+        }
+#pragma unroll
+        for (int j = 0; j < KF; ++j) {
+            fps[j] = ldStream(m.fpos + fl[j]);
+            fgsd[j] = ldStream(m.magSf + fl[j]) * ldStream(m.dn + fl[j]);   // |Sf| * nonOrthDeltaCoeffs
+            // the STREAMED Sf: implFaceTileKernel multiplies with that one, the QGD fluxes above with the Sf rebuilt from the vertices
+            fS[j][0] = ldStream(m.Sx + fl[j]); fS[j][1] = ldStream(m.Sy + fl[j]); fS[j][2] = ldStream(m.Sz + fl[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < KF; ++j) {
+            const int lf = tid + j * NT;
+            if (lf < nFc) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sF[k * strideF + lf] = out[j][k];
+            }
+        }
+        __syncthreads();
+        double sum[4] = {0, 0, 0, 0}, dTau[3] = {0, 0, 0}, diagBase = 0;
+        const int nE = nEraw;
+        if (tid < nOwn) {
+            for (int i = 0; i < nE; ++i) {
+                const int e = (i < KE) ? sE[i * 128 + tid] : ent[(size_t)i * 128];
+                double fx[4];
+                if (e >= 0) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) fx[k] = sF[k * strideF + (e >> 1)];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) fx[k] = c.flux[k * nF + (size_t)(~e)];
+                }
+                const bool plus = e < 0 || !(e & 1);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sum[k] = plus ? sum[k] + fx[k] : sum[k] - fx[k];
+            }
+        }
+        __syncthreads();   // the flux planes are summed: the gradients take their place
+#pragma unroll
+        for (int k = 0; k < KG; ++k) { const int q = tid + k * NT; if (q < 9 * nUc) sG[q] = dG[k]; }
+        __syncthreads();
+        double oxi[KF][4];   // phiTauMC (3) and the laplacian coefficient of the U systems
+#pragma unroll
+        for (int j = 0; j < KF; ++j) {
+            const int lf = tid + j * NT;
+            if (lf < nFc) {
+                const int f = fl[j];
+                const int lo = (int)(fp[j].c & 0xffffu), ln = (int)(fp[j].c >> 16);
+                const RecA Ao = *reinterpret_cast<const RecA*>(sA + 3 * lo), An = *reinterpret_cast<const RecA*>(sA + 3 * ln);
+                const double muQo = reinterpret_cast<const RecB*>(sB + 2 * lo)->muQGD, muQn = reinterpret_cast<const RecB*>(sB + 2 * ln)->muQGD;
                 const double uo[3] = {Ao.ux, Ao.uy, Ao.uz}, un[3] = {An.ux, An.uy, An.uz};
                 ImplFaceOut r;
-                implInternalFace(gm, fw[j], Bo.muQGD, Bn.muQGD, uo, un, sG + 9 * lo, sG + 9 * ln, fS[j], fgsd[j], r);
+                implInternalFace(gm, fw[j], muQo, muQn, uo, un, sG + 9 * lo, sG + 9 * ln, fS[j], fgsd[j], r);
                 oxi[j][0] = r.phiTau[0]; oxi[j][1] = r.phiTau[1]; oxi[j][2] = r.phiTau[2]; oxi[j][3] = r.aU;
                 if (lo < nOwn) {   // the block that owns the face's owner writes what the solves and the energy equation read later
-                    const size_t nF = (size_t)m.nF, pos = (size_t)fps[j];
+                    const size_t pos = (size_t)fps[j];
                     c.flux[4 * nF + pos] = out[j][4];
 #pragma unroll
                     for (int k = 0; k < 3; ++k) { iv.phiTau[(size_t)k * nF + pos] = r.phiTau[k]; iv.UfS[(size_t)k * nF + f] = r.Uf[k]; }
@@ -1443,48 +1480,32 @@ void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm, 
                 }
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    __syncthreads();   // every face has read its vertex records and coordinates
+        __syncthreads();   // every face has read its two gradients: the second round of planes takes their place
 #pragma unroll
-    for (int j = 0; j < KF; ++j) {
-        const int lf = tid + j * NT;
-        if (lf < nFc) {
+        for (int j = 0; j < KF; ++j) {
+            const int lf = tid + j * NT;
+            if (lf < nFc) {
 #pragma unroll
-            for (int k = 0; k < (IMPL ? 4 : 5); ++k) sF[k * strideF + lf] = out[j][k];
-            if constexpr (IMPL) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) sF[(4 + k) * strideF + lf] = oxi[j][k];
+                for (int k = 0; k < 4; ++k) sF[k * strideF + lf] = oxi[j][k];
             }
         }
-    }
-    __syncthreads();
-    if constexpr (IMPL) {
-        // (3') the rows of the U systems of the block's own cells out of LDS: implCellUKernel's ordered sums and arithmetic
+        __syncthreads();
+        // (3') the rows of the U systems of the block's own cells: implCellUKernel's ordered sums and arithmetic
         if (tid < nOwn) {
-            const size_t nF = (size_t)m.nF;
-            double sum[4] = {0, 0, 0, 0}, dTau[3] = {0, 0, 0}, diagBase = 0;
-            const int nE = nEraw;
             for (int i = 0; i < nE; ++i) {
                 const int e = (i < KE) ? sE[i * 128 + tid] : ent[(size_t)i * 128];
-                double fx[4], tx[3];
+                double tx[3];
                 if (e >= 0) {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) fx[k] = sF[k * strideF + (e >> 1)];
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) tx[k] = sF[(4 + k) * strideF + (e >> 1)];
+                    for (int k = 0; k < 3; ++k) tx[k] = sF[k * strideF + (e >> 1)];
                 } else {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) fx[k] = c.flux[k * nF + (size_t)(~e)];
 #pragma unroll
                     for (int k = 0; k < 3; ++k) tx[k] = iv.phiTau[k * nF + (size_t)(~e)];
                 }
                 const bool plus = e < 0 || !(e & 1);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) sum[k] = plus ? sum[k] + fx[k] : sum[k] - fx[k];
-#pragma unroll
                 for (int k = 0; k < 3; ++k) dTau[k] = plus ? dTau[k] + tx[k] : dTau[k] - tx[k];
-                if (e >= 0) diagBase += sF[7 * strideF + (e >> 1)];
+                if (e >= 0) diagBase += sF[3 * strideF + (e >> 1)];
             }
             const RecA A = *reinterpret_cast<const RecA*>(sA + 3 * tid);
             implCellU(m, c, iv, bcs, ci, A, Vc, sum, dTau, diagBase, nE, [&](int i) {
@@ -1494,6 +1515,15 @@ void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm, 
         }
         return;
     }
+#pragma unroll
+    for (int j = 0; j < KF; ++j) {
+        const int lf = tid + j * NT;
+        if (lf < nFc) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) sF[k * strideF + lf] = out[j][k];
+        }
+    }
+    __syncthreads();
     // (3) the block's own cells out of LDS
     double rmin = 1e300, emin = 1e300;
     if (tid < nOwn) {

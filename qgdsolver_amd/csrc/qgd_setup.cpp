@@ -900,7 +900,9 @@ FusedBlocks buildFusedBlocks(const StaticData& s) {
         // vertex records + coordinates + centres, which the fluxes overwrite): a block over the budget that lets three blocks share a CU is
         // cut like one over the caps, unless it is small already
         o.lds = 48 * (int32_t)o.cells.size() + 32 * o.nAll + std::max(72 * (int32_t)vs.size() + 24 * o.nAll, 40 * (int32_t)faces.size());
-        o.ldsImpl = 48 * (int32_t)o.cells.size() + 32 * o.nAll + std::max(72 * (int32_t)vs.size() + 96 * o.nAll, 64 * (int32_t)faces.size());
+        // (the implicitDiffusion branch's assembly reuses the vertex region for four flux planes, then the gradients of the own + across-a-face
+        // cells, then four planes again: qgd_kernels.hip fusedFaceCellKernel<..., IMPL>)
+        o.ldsImpl = 48 * (int32_t)o.cells.size() + 32 * o.nAll + std::max({72 * (int32_t)vs.size() + 24 * o.nAll, 32 * (int32_t)faces.size(), 72 * o.nAll});
         if (o.lds > kFusedLdsTarget && o.nOwn > 32) return false;
         o.face.resize(4 * faces.size());
         for (size_t lf = 0; lf < faces.size(); ++lf) {
