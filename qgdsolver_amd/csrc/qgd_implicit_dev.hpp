@@ -10,6 +10,7 @@ namespace qgd {
 // patch snGrad of U on boundary face f from the owner's and the patch's velocity
 __device__ __forceinline__ void patchSnGradU(const MeshView& m, const PatchBCDev& bc, const int f, const double uo[3], const double ub[3],
                                              double sn[3]) {
+#pragma clang fp contract(off)   // (no fusing left to the compiler: inlined into different kernels it would fuse different products, see implInternalFace)
     const double dc = m.dn[f];
     if (bc.bcU == QGD_BC_FIXEDVALUE) { for (int k = 0; k < 3; ++k) sn[k] = dc * (ub[k] - uo[k]); }
     else if (bc.bcU == QGD_BC_SLIP) {
@@ -36,6 +37,7 @@ __device__ __forceinline__ void patchGradU(const MeshView& m, const PatchBCDev& 
 }
 // mu * dev2(T(g)):  dev2(A) = A - (2/3) tr(A) I
 __device__ __forceinline__ void muDev2T(const double* g, const double mu, double out[9]) {
+#pragma clang fp contract(off)   // (no fusing left to the compiler: inlined into different kernels it would fuse different products, see implInternalFace)
     const double tr = g[0] + g[4] + g[8];
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) {
@@ -84,6 +86,7 @@ struct ImplFaceOut { double phiTau[3], Uf[3], sTau, muf, aU, aE; };
 __device__ __forceinline__ void implInternalFace(const GasModel& gm, const double w, const double muQo, const double muQn, const double uo[3],
                                                  const double un[3], const double* gO, const double* gN, const double S[3], const double gsd,
                                                  ImplFaceOut& o) {
+#pragma clang fp contract(off)   // (no fusing left to the compiler: inlined into different kernels it would fuse different products, see implInternalFace)
     const double muf = lerpf(w, muEffOf(gm, muQo), muEffOf(gm, muQn));
     const double alf = lerpf(w, alphaEffOf(gm, muQo), alphaEffOf(gm, muQn));
     o.Uf[0] = lerpf(w, uo[0], un[0]); o.Uf[1] = lerpf(w, uo[1], un[1]); o.Uf[2] = lerpf(w, uo[2], un[2]);
@@ -110,6 +113,7 @@ template <class PatchFaceFn>
 __device__ __forceinline__ void implCellU(const MeshView& m, const CaseView& c, const ImplView& iv, const PatchBCDev* __restrict__ bcs, const int ci,
                                           const RecA& A, const double V, const double sum[4], const double dTau[3], const double diagBase,
                                           const int nPatchFaces, PatchFaceFn patchFace) {
+#pragma clang fp contract(off)   // (no fusing left to the compiler: inlined into different kernels it would fuse different products, see implInternalFace)
     const size_t nC = (size_t)m.nC;
     const double dt = c.dt[0], dtV = dt / V, rDeltaT = 1.0 / dt;
     const double rho = A.rho - dtV * sum[0];
