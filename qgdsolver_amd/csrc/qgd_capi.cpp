@@ -300,6 +300,7 @@ struct qgd_case_s {
     bool pRefresh = true;       // grad(p)'s word is GaussVolPoint: p's boundary conditions are re-evaluated inside it [GaussVolPointStencil_8C L73] (quirk B6)
     bool usesPoints = true;
     bool fused = false;         // qgd_case_step advances with fusedFaceCellKernel (QGD_FUSED)
+    bool fusedAdj = false;      // adjustTimeStep: the blocks run up to their flux sums + Courant partials, cellFinishKernel advances once deltaT is known (QGD_FUSED_ADJUST)
     bool fusedImpl = false;     // implicitDiffusion: vertex values, QGD fluxes, tauMC and the U systems' rows are one launch on the same blocks (QGD_IMPL_FUSED)
     std::vector<double*> selfBuf;   // cyclic pairs served by ghost cells: one message buffer per halo slot (selfHaloExchange)
     bool ghostsCurrent = false;     // ... and whether the copies hold their originals' records (reset by set_fields / set_bc)
@@ -1543,6 +1544,12 @@ int qgd_case_create(qgd_device_t d, const qgd_case_options* opt, qgd_case_t* out
         // the fused step (fusedFaceCellKernel): uniform 3-D GaussVolPoint, explicit, fixed deltaT; `Gauss upwind` fluxes are an instantiation
         c->fused = v.fuBlocks > 0 && c->stencil == ST_GVP3 && c->mixB < 0 && !opt->implicitDiffusion && !opt->adjustTimeStep;
         if (c->fused) { cv.A2 = a.alloc<RecA>(v.nC); cv.B2 = a.alloc<RecB>(v.nC); }
+        {   // the same blocks under Courant-number control: two launches (blocks up to their sums, then the cells) instead of three kernels
+            static const int kOnOff[] = {0, 1};
+            c->fusedAdj = v.fuBlocks > 0 && c->stencil == ST_GVP3 && c->mixB < 0 && !opt->implicitDiffusion && opt->adjustTimeStep &&
+                          envChoice("QGD_FUSED_ADJUST", 1, kOnOff, 2) != 0;
+            if (c->fusedAdj) cv.cellSum = a.alloc<double>(5 * (size_t)v.nC);
+        }
         {   // the reference's default branch on the same blocks (unsharded, fixed deltaT, one 3-D GaussVolPoint stencil)
             static const int kOnOff[] = {0, 1};
             c->fusedImpl = v.fuBlocks > 0 && v.fuLdsImpl > 0 && c->stencil == ST_GVP3 && c->mixB < 0 && opt->implicitDiffusion && !opt->adjustTimeStep &&
@@ -1679,6 +1686,9 @@ static void assembleFluxes(qgd_case_s* c, bool adjust, int part = 0, bool intern
     else if (c->mixB >= 0) launchFaceFluxMixed(L, c->stencil, c->mixB, c->mixMask, m, v, c->gas, adjust);
     else launchFaceFlux(L, c->stencil, m, v, c->gas, adjust);
     bface(mid ? 2 : 0, adjust);
+    // Courant-number control on the cell blocks: every block up to its cells' flux sums and its faces' Courant partials (the patch faces'
+    // fluxes are in place now); the cells advance in stepAdvance, once deltaT is known
+    if (c->fusedAdj && !internalFaces && !c->view.dbg) launchFusedAdjust(L, m, v, c->gas);
 }
 static bool midExchangeNeeded(const qgd_case_s* c) { return c->dev->sharded() && c->pRefresh && c->hasQgdFlux; }
 
@@ -1747,7 +1757,7 @@ int qgd_case_update_fluxes(qgd_case_t c) {
 // phase 1: deltaT, cell update, boundary refresh
 static void stepAssemble(qgd_case_s* c, int part = 0) {
     const bool adjust = c->opt.adjustTimeStep != 0;
-    assembleFluxes(c, adjust, part, !(c->fused || c->fusedImpl));   // a fused case computes its internal faces inside the advance (stepAdvance / phase 21)
+    assembleFluxes(c, adjust, part, !(c->fused || c->fusedImpl || c->fusedAdj));   // a fused case computes its internal faces inside the advance (stepAdvance / phase 21)
     if (adjust && part != 1) launchFaceReduce(launcherOf(c), c->view);
 }
 // ---- the implicitDiffusion branch [QGDUEqn.H L54-75, QGDEEqn.H L53-64] as stream-ordered phases ---------------------------------
@@ -1840,6 +1850,12 @@ static void stepAdvance(qgd_case_s* c, int part) {
         if (adjust) launchDeltaT(L, c->view, c->opt.maxCo, c->opt.maxDeltaT, c->opt.cTau);
         c->steps++;
         if (!adjust) c->time += c->opt.deltaT;
+    }
+    if (c->fusedAdj) {
+        launchCellFinish(L, m, c->view, c->gas, part, part == 1 ? d->sendAll : nullptr, part == 1 ? d->nSendAll : 0);
+        launchBoundaryUpdate(L, m, c->view, c->gas, c->bcDev, false, c->phiwRegistered, part,
+                             part == 1 ? d->sendBFAll : nullptr, part == 1 ? d->nSendBFAll : 0);
+        return;
     }
     if (c->fused) {
         // The fused face + cell kernel writes the new records to A2 / B2 (its blocks read their neighbours' OLD records), which then become
@@ -3101,10 +3117,10 @@ int qgd_case_info(qgd_case_t c, double info[6]) {
 int qgd_case_fused_info(qgd_case_t c, int64_t info[8]) {
     if (!c || !info) return fail(QGD_ERR_INVALID, "null argument");
     const MeshView& v = c->dev->view;
-    info[0] = c->fused ? 1 : (c->fusedImpl ? 2 : 0);   // 2: the implicitDiffusion branch's block-fused assembly of the U systems
-    info[1] = (c->fused || c->fusedImpl) ? v.fuBlocks : 0;
+    info[0] = c->fused ? 1 : (c->fusedImpl ? 2 : (c->fusedAdj ? 3 : 0));   // 2: the implicitDiffusion branch's block-fused assembly of the U systems; 3: Courant-number control (blocks up to their sums + a cell kernel)
+    info[1] = (c->fused || c->fusedImpl || c->fusedAdj) ? v.fuBlocks : 0;
     info[2] = c->fused ? c->dev->fusedFacesComputed : 0;
-    info[3] = c->fused ? v.fuLds : (c->fusedImpl ? v.fuLdsImpl : 0);
+    info[3] = (c->fused || c->fusedAdj) ? v.fuLds : (c->fusedImpl ? v.fuLdsImpl : 0);
     info[4] = c->fused ? c->dev->fusedCellsStaged : 0;
     info[5] = c->fused ? c->dev->fusedCellsStagedFull : 0;
     info[6] = c->fused ? c->dev->fusedVertsStaged : 0;

@@ -109,6 +109,7 @@ struct CaseView {
     double* bPmid;                  // nBF patch pressure after GaussVolPoint's mid-step BC evaluation
     double* bRhoLag;                // nBF patch density of the previous step: rhoU_b, rhoE_b are built with it
                                     //     [QGDUEqn_8H L88-89, QGDEEqn_8H L75-76 run before QGDFoam_8C L156]
+    double* cellSum;                // 5*nC, fused step under Courant-number control only: the ordered net flux sums of every owned cell (the blocks stop there until deltaT is known)
     double* flux;                   // 5*nF net face fluxes, SoA: flux[k*nF + fpos[f]] (boundary faces: their label)
     double* red;                    // [0]=max Co, [1]=min tauQGDf, [2]=min rho, [3]=min e
     double* blkFace;                // 2 per face-kernel workgroup (internal then boundary): max Cof, min tauQGDf
@@ -146,6 +147,8 @@ void launchFaceFluxMixed(const Launcher& L, int a, int b, int maskB, const MeshV
 void launchBoundaryFaceFluxMixed(const Launcher& L, int a, int b, int maskB, const MeshView& m, const CaseView& c, const GasModel& g,
                                  const PatchBCDev* bc, int phiwOnly, bool adjustDt);
 void launchFusedFaceCell(const Launcher& L, const MeshView& m, const CaseView& c, const GasModel& g, int firstBlock, int nBlocks);
+void launchFusedAdjust(const Launcher& L, const MeshView& m, const CaseView& c, const GasModel& g);   // Courant-number control: every block up to its flux sums
+void launchCellFinish(const Launcher& L, const MeshView& m, const CaseView& c, const GasModel& g, int mode, const int32_t* list, int nList);
 struct ImplView;
 bool fusedImplUPrepare(const MeshView& m, const GasModel& g);   // raises the dynamic-LDS limit of the IMPL instantiation; false: not available
 void launchFusedImplU(const Launcher& L, const MeshView& m, const CaseView& c, const GasModel& g, const ImplView& iv, const PatchBCDev* bc);

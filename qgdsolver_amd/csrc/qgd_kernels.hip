@@ -1141,7 +1141,11 @@ void cellUpdateKernel(const MeshView m, const CaseView c, const GasModel gm, con
 // U = rhoU/rho, diagonal, right-hand side, start value.  What the solves and the energy equation read later goes to device memory once, from the
 // block that owns the face's owner: the laplacian coefficients, Uf, Sf.(tauMC & Uf), muf, the net energy flux, phiTauMC.  The vertex kernel, the
 // QGD face kernel, implFaceTileKernel and implCellUKernel are this one launch, in the explicit step's LDS (three blocks per CU).  Unsharded cases.
-template <bool SGEO, bool UPW = false, bool IMPL = false>
+// ADJ = Courant-number control [QGDCourantNo.H L36-53, setDeltaT-QGDQHD.H L41-61]: the new deltaT needs every face's Courant number and
+// tauQGDf before the first cell may advance, so the block stops after its ordered sums: it leaves max Cof / min tauQGDf of its faces in its
+// slot of blkFace (the three kernels' partial slots; faceReduceKernel folds them, deltaTKernel follows) and the five net flux sums of each own
+// cell in cellSum; cellFinishKernel advances the cells from there.  Vertex values and face fluxes still never reach device memory.
+template <bool SGEO, bool UPW = false, bool IMPL = false, bool ADJ = false>
 // (IMPL with `Gauss upwind` fluxes needs a few registers more than three waves per SIMD leave: that instantiation is compiled for two -- no scratch)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((IMPL && UPW) ? 2 : QGD_FU_WAVES, (IMPL && UPW) ? 2 : QGD_FU_WAVES)))
 void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm, const int firstBlock, const ImplView iv,
@@ -1314,6 +1318,7 @@ void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm, 
     // (2) the faces: fluxes into registers
     auto l3 = [](const double* p, int i) { return make_double4(p[3 * i], p[3 * i + 1], p[3 * i + 2], 0.0); };
     double out[KF][5];
+    double cofMax = -1e300, tauMinAll = 1e300;   // ADJ: this thread's faces
 #pragma unroll
     for (int j = 0; j < KF; ++j) {
         const int lf = tid + j * NT;
@@ -1355,7 +1360,7 @@ void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm, 
             const double* const r1 = reinterpret_cast<const double*>(sP + 3 * v1);
             const double* const r2 = reinterpret_cast<const double*>(sP + 3 * v2);
             const double* const r3 = reinterpret_cast<const double*>(sP + 3 * v3);
-            double cof, tauMin;
+            double cof = -1e300, tauMin = 1e300;
             double g[18];
             if (kind == 0) {
 #pragma unroll
@@ -1399,7 +1404,8 @@ void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm, 
             __builtin_amdgcn_sched_barrier(0);
             const RecA Ao = *reinterpret_cast<const RecA*>(sA + 3 * lo), An = *reinterpret_cast<const RecA*>(sA + 3 * ln);
             const RecB Bo = *reinterpret_cast<const RecB*>(sB + 2 * lo), Bn = *reinterpret_cast<const RecB*>(sB + 2 * ln);
-            gvp3FaceTail<false, UPW>(m, c, gm, f, fw[j], fh[j], S, Ao, An, Bo, Bn, g, 0, cof, tauMin, &out[j][0], (size_t)1);
+            gvp3FaceTail<false, UPW>(m, c, gm, f, fw[j], fh[j], S, Ao, An, Bo, Bn, g, ADJ ? 1 : 0, cof, tauMin, &out[j][0], (size_t)1);
+            if constexpr (ADJ) { cofMax = fmax(cofMax, cof); tauMinAll = fmin(tauMinAll, tauMin); }
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -1543,18 +1549,56 @@ void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm, 
 #pragma unroll
             for (int k = 0; k < 5; ++k) sum[k] = (e < 0 || !(e & 1)) ? sum[k] + fl[k] : sum[k] - fl[k];
         }
-        const RecA A = *reinterpret_cast<const RecA*>(sA + 3 * tid);
+        if constexpr (ADJ) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) c.cellSum[(size_t)k * m.nC + ci] = sum[k];
+        } else {
+            const RecA A = *reinterpret_cast<const RecA*>(sA + 3 * tid);
+            RecA An;
+            RecB Bn;
+            double rEnew;
+            advanceCell(c, gm, ci, A, rEold, Vc, hq, sum, An, Bn, rEnew);
+            c.A2[ci] = An;
+            c.B2[ci] = Bn;
+            c.rE[ci] = rEnew;
+            rmin = (An.rho == An.rho) ? An.rho : -1e300;
+            emin = (An.e == An.e) ? An.e : -1e300;
+        }
+    }
+    if constexpr (ADJ) blockMaxMin<NT>(cofMax, tauMinAll, c.blkFace + 2 * (size_t)blk, false);
+    else blockMaxMin<NT>(-rmin, emin, c.blkCell + 2 * (size_t)blk, true);
+}
+
+// Courant-number control with the fused step: the cells advance from the flux sums the blocks left in cellSum, once deltaT is known
+// (advanceCell: the cell kernel's arithmetic; mode / list as in cellUpdateKernel)
+template <int CB>
+__global__ __launch_bounds__(CB) void cellFinishKernel(const MeshView m, const CaseView c, const GasModel gm, const int mode,
+                                                      const int32_t* __restrict__ list, const int nList, const int slotBase) {
+    const int tile = (mode == 1) ? (int)blockIdx.x : xcdTile((int)gridDim.x, m.xcdRun * (QGD_BLOCK / CB));
+    const int idx = tile * CB + threadIdx.x;
+    int ci = -1;
+    if (mode == 1) { if (idx < nList) ci = list[idx]; }
+    else if (idx < m.nC) {
+        const int role = m.ghost ? m.ghost[idx] : 0;
+        if (role != 1 && !(mode == 2 && role == 2)) ci = idx;
+    }
+    double rmin = 1e300, emin = 1e300;
+    if (ci >= 0) {
+        double sum[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) sum[k] = c.cellSum[(size_t)k * m.nC + ci];
+        const RecA A = c.A[ci];
         RecA An;
         RecB Bn;
         double rEnew;
-        advanceCell(c, gm, ci, A, rEold, Vc, hq, sum, An, Bn, rEnew);
-        c.A2[ci] = An;
-        c.B2[ci] = Bn;
+        advanceCell(c, gm, ci, A, c.rE[ci], m.V[ci], m.hQGD[ci], sum, An, Bn, rEnew);
+        c.A[ci] = An;
+        c.B[ci] = Bn;
         c.rE[ci] = rEnew;
         rmin = (An.rho == An.rho) ? An.rho : -1e300;
         emin = (An.e == An.e) ? An.e : -1e300;
     }
-    blockMaxMin<NT>(-rmin, emin, c.blkCell + 2 * (size_t)blk, true);
+    blockMaxMin<CB>(-rmin, emin, c.blkCell + 2 * (size_t)(slotBase + tile), true);
 }
 
 // createFields.H for the cells [QGDFoam_2createFields_8H L3-109]
@@ -2142,6 +2186,24 @@ void launchFusedFaceCell(const Launcher& L, const MeshView& m, const CaseView& c
     else if (upw) QGD_TIMED(L, QGD_K_FACE, (fusedFaceCellKernel<false, true><<<nBlocks, 256, m.fuLds, L.stream>>>(m, c, g, firstBlock, none, nullptr)));
     else if (m.sGeo) QGD_TIMED(L, QGD_K_FACE, (fusedFaceCellKernel<true><<<nBlocks, 256, m.fuLds, L.stream>>>(m, c, g, firstBlock, none, nullptr)));
     else QGD_TIMED(L, QGD_K_FACE, (fusedFaceCellKernel<false><<<nBlocks, 256, m.fuLds, L.stream>>>(m, c, g, firstBlock, none, nullptr)));
+}
+// Courant-number control: all blocks up to their flux sums (+ the Courant partials), then -- after deltaTKernel -- the cells
+void launchFusedAdjust(const Launcher& L, const MeshView& m, const CaseView& c, const GasModel& g) {
+    if (m.fuBlocks <= 0) return;
+    const bool upw = g.upwindU || g.upwindH;
+    const ImplView none{};
+    const int n = m.fuBlocks;
+    if (m.sGeo && upw) QGD_TIMED(L, QGD_K_FACE, (fusedFaceCellKernel<true, true, false, true><<<n, 256, m.fuLds, L.stream>>>(m, c, g, 0, none, nullptr)));
+    else if (upw) QGD_TIMED(L, QGD_K_FACE, (fusedFaceCellKernel<false, true, false, true><<<n, 256, m.fuLds, L.stream>>>(m, c, g, 0, none, nullptr)));
+    else if (m.sGeo) QGD_TIMED(L, QGD_K_FACE, (fusedFaceCellKernel<true, false, false, true><<<n, 256, m.fuLds, L.stream>>>(m, c, g, 0, none, nullptr)));
+    else QGD_TIMED(L, QGD_K_FACE, (fusedFaceCellKernel<false, false, false, true><<<n, 256, m.fuLds, L.stream>>>(m, c, g, 0, none, nullptr)));
+}
+void launchCellFinish(const Launcher& L, const MeshView& m, const CaseView& c, const GasModel& g, int mode, const int32_t* list, int nList) {
+    const int n = (mode == 1) ? nList : m.nC;
+    if (n == 0) return;
+    // (mode 1 uses the monitor slots behind the fused kernel's / the cell kernel's, like launchCellUpdate)
+    const int slotBase = (mode == 1) ? std::max((m.nC + m.cblock - 1) / m.cblock, m.fuBlocks) : 0;
+    QGD_TIMED(L, QGD_K_CELL, (cellFinishKernel<256><<<(n + 255) / 256, 256, 0, L.stream>>>(m, c, g, mode, list, nList, slotBase)));
 }
 // the implicitDiffusion branch's block-fused assembly of the U systems (fusedFaceCellKernel<..., IMPL = true>): more dynamic LDS than the
 // 64 KB a launch gets by default, so the kernels' limit is raised first; false when the device refuses (the caller keeps the separate kernels)

@@ -178,7 +178,7 @@ class QGDFoamCase:
         one launch), its blocks, faces computed / cell records staged / vertex values formed per step, LDS bytes (qgd_case_fused_info)"""
         a = (C.c_int64 * 8)()
         L.check(L.lib.qgd_case_fused_info(self._h, a), "qgd_case_fused_info")
-        return dict(fused=int(a[0]) == 1, fusedImplicit=int(a[0]) == 2, blocks=int(a[1]), facesComputed=int(a[2]), ldsBytes=int(a[3]), cellsStaged=int(a[4]),
+        return dict(fused=int(a[0]) == 1, fusedImplicit=int(a[0]) == 2, fusedAdjust=int(a[0]) == 3, blocks=int(a[1]), facesComputed=int(a[2]), ldsBytes=int(a[3]), cellsStaged=int(a[4]),
                     cellsStagedFull=int(a[5]), verticesFormed=int(a[6]), layerBlocks=int(a[7]))
 
     def implicit_info(self):

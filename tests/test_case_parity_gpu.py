@@ -27,7 +27,7 @@ def build_pair(mesh_kind, scheme, bc_fn=None, init_fn=None, arm=None, **opt):
     mesh = make_mesh(mesh_kind)
     om = oracle_mesh_of(mesh)
     options = q.default_options(stencil=scheme, **opt)
-    dev = q.Device(mesh, fused_tables={None: True, "fused": "any", "kernels": False}[arm])
+    dev = q.Device(mesh, fused_tables={None: True, "fused": "any", "fusedAdjust": "any", "kernels": False}[arm])
     gc = q.QGDFoamCase(dev, options)
     if arm is not None:
         assert_path(gc, arm, (mesh_kind, scheme))
@@ -150,13 +150,16 @@ def test_update_fluxes_and_steps(mesh_kind, scheme, bc_fn, init_fn, opt, arm):
     gc.close(); dev.close()
 
 
-@pytest.mark.parametrize("mesh_kind,scheme,bc_fn,init_fn", [
-    ("box654", "GaussVolPoint", None, None),
-    ("step2d", "leastSquares", cases.forward_step_bcs, step_init),
+@pytest.mark.parametrize("mesh_kind,scheme,bc_fn,init_fn,arm", [
+    ("box654", "GaussVolPoint", None, None, "kernels"),
+    ("box654", "GaussVolPoint", None, None, "fusedAdjust"),
+    ("box654_poly", "GaussVolPoint", mixed_box_bcs, None, "fusedAdjust"),
+    ("step2d", "leastSquares", cases.forward_step_bcs, step_init, "kernels"),
 ])
-def test_adjust_time_step(mesh_kind, scheme, bc_fn, init_fn):
-    """QGDCourantNo.H + setDeltaT-QGDQHD.H: Courant number and deltaT follow the oracle."""
-    mesh, dev, gc, oc = build_pair(mesh_kind, scheme, bc_fn, init_fn, deltaT=1e-4, adjustTimeStep=1, maxCo=0.3,
+def test_adjust_time_step(mesh_kind, scheme, bc_fn, init_fn, arm):
+    """QGDCourantNo.H + setDeltaT-QGDQHD.H: Courant number and deltaT follow the oracle -- with the three kernels, and with the cell blocks
+    (every block up to its flux sums and Courant partials, then deltaT, then the cell kernel)."""
+    mesh, dev, gc, oc = build_pair(mesh_kind, scheme, bc_fn, init_fn, arm=arm, deltaT=1e-4, adjustTimeStep=1, maxCo=0.3,
                                    maxDeltaT=1.0, cTau=0.75)
     for _ in range(10):
         gc.step(1)
@@ -185,7 +188,7 @@ def test_thermo_accessors():
 
 
 @pytest.mark.parametrize("variant", ["hex", "jitter", "jitter+triangles"])
-@pytest.mark.parametrize("arm", ["fused", "kernels", "kernels+adjustTimeStep"])
+@pytest.mark.parametrize("arm", ["fused", "kernels", "kernels+adjustTimeStep", "fusedAdjust+adjustTimeStep"])
 def test_bench_kernel_directly_against_the_oracle(variant, arm):
     """The kernel bench.py times -- fusedFaceCellKernel: a block of <= 128 cells stages its cells and the cells around them in LDS, forms its
     vertex values, computes every internal face of its cells and advances them, ONE launch per step -- against the oracle with nothing in
@@ -200,7 +203,7 @@ def test_bench_kernel_directly_against_the_oracle(variant, arm):
     if variant == "jitter+triangles":
         mesh.split_quads(7)
     adjust = 1 if arm.endswith("adjustTimeStep") else 0
-    dev = q.Device(mesh, fused_tables="any" if arm == "fused" else False)
+    dev = q.Device(mesh, fused_tables="any" if arm.startswith("fused") else False)
     h = 1.0 / 20
     opt = q.default_options(stencil="GaussVolPoint", deltaT=0.1 * h / 1.3, mu=1e-3, adjustTimeStep=adjust, maxCo=0.25)
     gc = q.QGDFoamCase(dev, opt)
@@ -211,7 +214,7 @@ def test_bench_kernel_directly_against_the_oracle(variant, arm):
         assert fi["facesComputed"] > mesh.nInternalFaces, fi                                            # rim faces computed on both sides
         assert fi["cellsStaged"] > 2 * mesh.nCells and fi["verticesFormed"] > mesh.nPoints, fi          # the blocks stage their surroundings
         assert 0 < fi["ldsBytes"] <= 64 * 1024, fi
-    else:
+    elif arm.startswith("kernels"):
         ft = dev.face_tiles()
         assert ft["facesPerTile"] == 128 and ft["tiles"] == (mesh.nInternalFaces + 127) // 128, ft
         assert 4 * ft["gatherTiles"] < ft["tiles"], ft

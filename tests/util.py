@@ -52,6 +52,12 @@ def expects_fused(mesh, options):
             not options.adjustTimeStep and not any(options.termStencil))
 
 
+def expects_fused_adjust(mesh, options):
+    """... and under Courant-number control the same blocks run up to their flux sums, a cell kernel advances once deltaT is known"""
+    return (mesh.nGeometricD == 3 and options.stencil == L.FVSC_GAUSSVOLPOINT and not options.implicitDiffusion and
+            bool(options.adjustTimeStep) and not any(options.termStencil))
+
+
 def device_pair_arms(mesh, options):
     """the two ways a device can step such a case, for tests that pin BOTH to the oracle on purpose: ("fused", Device with the block tables
     whatever the blocks look like) and ("kernels", Device without them); a case the fused step does not serve has the second arm only"""
@@ -64,6 +70,9 @@ def device_pair_arms(mesh, options):
 def assert_path(case, arm, tag=None):
     """the arm under test is the path that runs -- asserted, not left to a default or to the block-size heuristic"""
     info = case.fused_info()
-    assert info["fused"] == (arm == "fused"), (tag, arm, info)
+    if arm == "fusedAdjust":
+        assert info["fusedAdjust"] and not info["fused"] and info["blocks"] >= 1, (tag, arm, info)
+        return
+    assert info["fused"] == (arm == "fused") and not info["fusedAdjust"], (tag, arm, info)
     if arm == "fused":
         assert info["blocks"] >= 1 and info["facesComputed"] >= case.dev.mesh.nInternalFaces, (tag, info)
