@@ -1561,6 +1561,7 @@ int qgd_case_create(qgd_device_t d, const qgd_case_options* opt, qgd_case_t* out
         cv.nBlkFace = faceBlocks(v) + bfaceBlocks(v);
         cv.nBlkCell = std::max(cellBlocks(v), v.fuBlocks) + (d->nSendAll + 63) / 64;   // (the fused kernel monitors min(rho), min(e) per block)
         cv.blkFace = a.alloc<double>(2 * (size_t)std::max(1, cv.nBlkFace));
+        cv.blkFace2 = a.alloc<double>(2 * (size_t)QGD_FACE_REDUCE_PARTIALS);
         cv.blkCell = a.alloc<double>(2 * (size_t)std::max(1, cv.nBlkCell));
         cv.flux = a.alloc<double>(5 * (size_t)v.nF);
         cv.red = a.alloc<double>(8);

@@ -98,6 +98,7 @@ struct GasModel {
 };
 
 // Mutable case state on the device
+#define QGD_FACE_REDUCE_PARTIALS 1024
 struct CaseView {
     RecA* A; RecB* B;               // nC
     RecA* A2; RecB* B2;             // nC, fused step only: the records the step writes (it reads its neighbours' old ones); swapped with A, B after the step
@@ -113,6 +114,7 @@ struct CaseView {
     double* flux;                   // 5*nF net face fluxes, SoA: flux[k*nF + fpos[f]] (boundary faces: their label)
     double* red;                    // [0]=max Co, [1]=min tauQGDf, [2]=min rho, [3]=min e
     double* blkFace;                // 2 per face-kernel workgroup (internal then boundary): max Cof, min tauQGDf
+    double* blkFace2;               // 2 x QGD_FACE_REDUCE_PARTIALS: the first level of their fold (launchFaceReduce)
     double* blkCell;                // 2 per cell-kernel workgroup: min rho, min e since the last query
     int32_t nBlkFace, nBlkCell;
     double* dt;                     // [0]=deltaT (device resident so adjustTimeStep needs no host round trip)

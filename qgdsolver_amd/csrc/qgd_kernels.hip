@@ -1702,11 +1702,21 @@ __global__ __launch_bounds__(QGD_BLOCK) void boundaryUpdateKernel(const MeshView
 
 // adjustTimeStep: one workgroup folds the per-workgroup partials of the face kernels into red[0] = max Cof and
 // red[1] = -min tauQGDf (one MAX all-reduce serves both in a sharded run) [QGDCourantNo_8H L50, setDeltaT-QGDQHD_8H L46]
-__global__ __launch_bounds__(QGD_BLOCK) void faceReduceKernel(const CaseView c) {
+// (two levels since round 6: ONE workgroup walking the three million partial slots of a 64 M-cell mesh took 6 ms per step -- a third of the
+// adjusted step; max and min do not care about the order, so the result is the same bit for bit)
+__global__ __launch_bounds__(QGD_BLOCK) void faceReduceStage1Kernel(const CaseView c) {
     double co = -1e300, tmin = 1e300;
-    for (int i = threadIdx.x; i < c.nBlkFace; i += QGD_BLOCK) {
+    for (int i = blockIdx.x * QGD_BLOCK + threadIdx.x; i < c.nBlkFace; i += gridDim.x * QGD_BLOCK) {
         co = fmax(co, c.blkFace[2 * (size_t)i]);
         tmin = fmin(tmin, c.blkFace[2 * (size_t)i + 1]);
+    }
+    blockMaxMin(co, tmin, c.blkFace2 + 2 * (size_t)blockIdx.x, false);
+}
+__global__ __launch_bounds__(QGD_BLOCK) void faceReduceKernel(const CaseView c, const int nPartials) {
+    double co = -1e300, tmin = 1e300;
+    for (int i = threadIdx.x; i < nPartials; i += QGD_BLOCK) {
+        co = fmax(co, c.blkFace2[2 * (size_t)i]);
+        tmin = fmin(tmin, c.blkFace2[2 * (size_t)i + 1]);
     }
     blockMaxMin(co, tmin, c.red, false);
     __syncthreads();
@@ -2250,7 +2260,11 @@ void launchCellInit(const Launcher& L, const MeshView& m, const CaseView& c, con
 void launchDeltaT(const Launcher& L, const CaseView& c, double maxCo, double maxDeltaT, double cTau) {
     deltaTKernel<<<1, 1, 0, L.stream>>>(c, maxCo, maxDeltaT, cTau);
 }
-void launchFaceReduce(const Launcher& L, const CaseView& c) { faceReduceKernel<<<1, QGD_BLOCK, 0, L.stream>>>(c); }
+void launchFaceReduce(const Launcher& L, const CaseView& c) {
+    const int g = std::max(1, std::min(QGD_FACE_REDUCE_PARTIALS, (c.nBlkFace + QGD_BLOCK - 1) / QGD_BLOCK));
+    faceReduceStage1Kernel<<<g, QGD_BLOCK, 0, L.stream>>>(c);
+    faceReduceKernel<<<1, QGD_BLOCK, 0, L.stream>>>(c, g);
+}
 void launchResetReductions(const Launcher& L, const CaseView& c) { resetReductionsKernel<<<64, QGD_BLOCK, 0, L.stream>>>(c); }
 void launchCellMinReduce(const Launcher& L, const CaseView& c) { cellMinReduceKernel<<<1, QGD_BLOCK, 0, L.stream>>>(c); }
 int faceBlocks(const MeshView& m) { return (m.nIF + 63) / 64; }
