@@ -14,6 +14,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <map>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -806,6 +808,21 @@ struct PressureSolver {
         std::vector<int32_t> cellGlobal;       // extracted shards; empty: global = local + cellGlobalOffset
         int64_t cellGlobalOffset = 0, nCg = 0;
         int K = 0, n1 = 0;
+        // QGD_MG_DIST=2: level 0 is coarsened PER RANK (aggregates, prolongator and the rank's rows of the level-1 matrix from its own cells;
+        // cells next to a cut keep their tentative prolongator row, so that no coarse row needs another rank's fine rows), only the level-1
+        // matrix is gathered and replicated -- distSetupStep stages 10..15
+        int mode = 1;
+        struct Local0 {
+            std::vector<int64_t> off; std::vector<int> nb; std::vector<double> nw; std::vector<uint8_t> strong, cutAdj;
+            std::vector<double> diag;
+            std::vector<int> cutI, cutJ; std::vector<double> cutW;      // cut faces: owned row (0-based), ghost cell (local label), coefficient
+            std::vector<int> agg, gid, ghostGid;                        // aggregate of each owned cell; its dense global number; the same of the ghost cells
+            int na = 0;
+            std::vector<float> tmp;
+            std::vector<int> e1I, e1J; std::vector<double> e1W, d1;     // this rank's share of the level-1 matrix (global numbers, lower number first)
+            std::vector<int64_t> pOff; std::vector<int> pCol; std::vector<double> pVal;   // the owned cells' rows of P (columns: global level-1 numbers)
+        };
+        std::shared_ptr<Local0> l0;
         int nPt = 0;                           // coarse nodes this rank's cells touch, their rows of P^T (CSR over owned cells, local labels)
         int *ptNode = nullptr, *ptStart = nullptr, *ptCol = nullptr;
         float* ptVal = nullptr;
@@ -1097,10 +1114,13 @@ static int rootAggregates(int n, const std::vector<int64_t>& off, const std::vec
 static void smoothedLevel(int n, const std::vector<int64_t>& off, const std::vector<int>& nb, const std::vector<double>& nw,
                           const std::vector<uint8_t>& strong, const std::vector<double>& diag, const std::vector<int>& agg, int nc, double omegaP,
                           HostCsr& P, HostCsr& PT,
-                          std::vector<int>& cI, std::vector<int>& cJ, std::vector<double>& cw, std::vector<double>& cdiag) {
+                          std::vector<int>& cI, std::vector<int>& cJ, std::vector<double>& cw, std::vector<double>& cdiag,
+                          const std::vector<uint8_t>* noSmooth = nullptr) {
+    // noSmooth[i] != 0: row i keeps its tentative entry (1 at its aggregate) -- the cells next to a cut of a per-rank coarsening (distSetupStep)
     // ---- P, row by row (entries in ascending column order) ----
     auto rowOfP = [&](int i, std::vector<int>& cols, std::vector<double>& vals) {
         cols.clear(); vals.clear();
+        if (noSmooth && (*noSmooth)[i]) { cols.push_back(agg[i]); vals.push_back(1.0); return; }
         double dF = diag[i];
         for (int64_t k = off[i]; k < off[i + 1]; ++k) if (!strong[k]) dF -= nw[k];
         if (!(dF > 0.1 * diag[i])) dF = diag[i];
@@ -1343,11 +1363,13 @@ static void mgUploadCsr(PressureSolver* S, int nRows, const HostCsr& M, const in
 // the owned block of a shard, or the distributed level 0 of DistMg).  firstTransfer (optional) receives the prolongator of level 0 and
 // the size of level 1 INSTEAD of the default upload of P and P^T (the distributed level 0 keeps only its own rows of them).
 static void mgBuildHierarchy(PressureSolver* S, int n, std::vector<int>& I, std::vector<int>& J, std::vector<double>& w, std::vector<double>& diag,
-                     const std::function<void(const HostCsr& P, int nCoarse)>& firstTransfer) {
+                     const std::function<void(const HostCsr& P, int nCoarse)>& firstTransfer, bool resume = false) {
+    // resume: the levels so far (and their smoother scales) stand -- the per-rank coarsening of level 0 (distSetupStep) continues with the
+    // replicated levels from level 1 on
     const bool sa = S->sa;
     const int passes = S->passes;
     const double saTheta = S->saTheta;
-    S->smootherScale.assign(1, 1.0);
+    if (!resume) S->smootherScale.assign(1, 1.0);
     while (n > (sa ? S->denseMax : 600) && S->L.size() < 12) {
         std::vector<int> total((size_t)n);
         for (int i = 0; i < n; ++i) total[i] = i;
@@ -1450,7 +1472,9 @@ PressureSolver* pressureSolverCreate(hipStream_t stream, const MeshView& m, cons
         if (sa) S->oc = knob("QGD_MG_OC", 1.0, 0.5, 3.0);
         S->distMaxCells = (int64_t)knob("QGD_MG_DIST_MAX_CELLS", (double)S->distMaxCells, 0, 2.0e9);
         // a shard with smoothed aggregation and the single-precision cycle builds the hierarchy that spans the ranks, at its first solve
-        const bool distWanted = sharded && precond == 1 && sa && S->f32 && knob("QGD_MG_DIST", 1, 0, 1) != 0;
+        const int distMode = (int)knob("QGD_MG_DIST", 1, 0, 2);   // 1: the global level-0 matrix replicated on every rank; 2: level 0 coarsened per rank
+        const bool distWanted = sharded && precond == 1 && sa && S->f32 && distMode != 0;
+        S->dist.mode = distMode;
         const int nC = m.nC, nF = m.nF, ob = S->ob, oe = S->oe, nRows = oe - ob, nb = blocksOf(nRows);
         S->a = S->alloc<double>(nF); S->gs = S->alloc<double>(std::max(m.nBF, 1));
         S->diag = S->alloc<double>(nC); S->rhs = S->alloc<double>(nC); S->r = S->alloc<double>(nC); S->z = S->alloc<double>(nC);
@@ -1543,90 +1567,10 @@ static void distBlockFallback(PressureSolver* S) {
     mgBuildHierarchy(S, oe - ob, I, J, w, diag, nullptr);
     D.wanted = false;
 }
-// one stage of the set-up; returns true when the hierarchy stands (or was abandoned), false when a collective is pending
-static bool distSetupStep(PressureSolver* S) {
+// level 0 of a hierarchy that spans the ranks: the owned rows with their ghost columns as a sliced ELL, every vector by local cell label
+static void distUploadLevel0(PressureSolver* S) {
     PressureSolver::Dist& D = S->dist;
     const int ob = S->ob, oe = S->oe, nOwned = oe - ob;
-    hipStream_t stream = S->stream;
-    if (D.setupStage == 0) {
-        // sizes: the number of cells of the unsharded mesh, the most couplings any cell has to higher-numbered neighbours
-        std::vector<int> cnt((size_t)S->m.nC, 0);
-        int64_t gmax = 0;
-        int K = 0;
-        for (int i = ob; i < oe; ++i) gmax = std::max(gmax, D.globalOf(i) + 1);
-        for (size_t f = 0; f < D.own.size(); ++f) {
-            const int lo = D.globalOf(D.own[f]) < D.globalOf(D.nei[f]) ? D.own[f] : D.nei[f];
-            if (lo >= ob && lo < oe) K = std::max(K, ++cnt[lo]);
-        }
-        S->distEnsureBuf(2);
-        const double v[2] = {(double)gmax, (double)K};
-        PCHECK(hipMemcpyAsync(D.buf, v, sizeof(v), hipMemcpyHostToDevice, stream));
-        PCHECK(hipStreamSynchronize(stream));
-        D.bufN = 2; D.pending = 3; D.setupStage = 1;
-        return false;
-    }
-    if (D.setupStage == 1) {
-        double v[2];
-        PCHECK(hipMemcpyAsync(v, D.buf, sizeof(v), hipMemcpyDeviceToHost, stream));
-        PCHECK(hipStreamSynchronize(stream));
-        D.nCg = (int64_t)v[0]; D.K = (int)v[1];
-        // The hierarchy that spans the ranks REPLICATES the global matrix: every rank gathers nCg (1 + 2K) doubles (host and device),
-        // rebuilds the global rows and coarsens them on its own host -- set-up time and memory grow with the GLOBAL cell count, on every
-        // rank of the node at once (64 M cells, K = 3: 3.6 GB per buffer per rank, a 64 M-row host coarsening times eight).  Above
-        // distMaxCells (default 20 M: config 5's 16 M cells fit, 1.2 GB per buffer) the rank-local hierarchy is kept and said so.
-        const bool tooLarge = D.nCg > S->distMaxCells;
-        if (D.nCg <= S->denseMax || D.nCg >= 0x7fffffffLL || D.nCg == nOwned || tooLarge) {
-            if (tooLarge)
-                std::fprintf(stderr, "[qgd mg] %lld cells in all exceed QGD_MG_DIST_MAX_CELLS = %lld: the multigrid hierarchy stays rank-local "
-                                     "(block Jacobi across the shards; expect more pressure iterations)\n", (long long)D.nCg, (long long)S->distMaxCells);
-            else if (std::getenv("QGD_MG_VERBOSE")) std::fprintf(stderr, "[qgd mg] rank-local hierarchy: %lld cells in all, %d here\n", (long long)D.nCg, nOwned);
-            distBlockFallback(S); D.built = true; return true;
-        }
-        // this rank's share of the global matrix: the diagonal of its cells and, per cell, its couplings to higher-numbered neighbours
-        const int64_t n = D.nCg, K = D.K;
-        std::vector<double> h((size_t)(n * (1 + 2 * K)), 0.0);
-        std::vector<int> cnt((size_t)S->m.nC, 0);
-        for (int i = ob; i < oe; ++i) h[(size_t)D.globalOf(i)] = D.diag[i];
-        for (size_t f = 0; f < D.own.size(); ++f) {
-            const int64_t go = D.globalOf(D.own[f]), gn = D.globalOf(D.nei[f]);
-            const int lo = go < gn ? D.own[f] : D.nei[f];
-            if (lo < ob || lo >= oe) continue;
-            const int64_t glo = std::min(go, gn), ghi = std::max(go, gn);
-            const int k = cnt[lo]++;
-            if (k >= K || glo >= n || ghi >= n) throw std::runtime_error("distributed multigrid: the ranks disagree about the size of the global matrix");
-            h[(size_t)(n + glo * K + k)] = (double)(ghi + 1);
-            h[(size_t)(n + n * K + glo * K + k)] = D.a[f];
-        }
-        S->distEnsureBuf((int64_t)h.size());
-        PCHECK(hipMemcpyAsync(D.buf, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, stream));
-        PCHECK(hipStreamSynchronize(stream));
-        D.bufN = (int64_t)h.size(); D.pending = 2; D.setupStage = 2;
-        return false;
-    }
-    // stage 2: every rank holds the whole matrix now and builds the same hierarchy from it
-    const int64_t n = D.nCg, K = D.K;
-    std::vector<int> I, J;
-    std::vector<double> w, diag((size_t)n);
-    {
-        std::vector<double> h((size_t)D.bufN);
-        PCHECK(hipMemcpyAsync(h.data(), D.buf, sizeof(double) * h.size(), hipMemcpyDeviceToHost, stream));
-        PCHECK(hipStreamSynchronize(stream));
-        for (int64_t g = 0; g < n; ++g) {
-            diag[(size_t)g] = h[(size_t)g];
-            for (int k = 0; k < K; ++k) {
-                const double nb1 = h[(size_t)(n + g * K + k)];
-                if (nb1 > 0) { I.push_back((int)g); J.push_back((int)(nb1 - 1.0)); w.push_back(h[(size_t)(n + n * K + g * K + k)]); }
-            }
-        }
-    }
-    // a cell nobody contributed (a caller without the all-reduce: one rank driving a shard on its own) -> the rank-local hierarchy
-    bool complete = true;
-    for (int64_t g = 0; g < n && complete; ++g) complete = diag[(size_t)g] > 0.0;
-    if (!complete) {
-        if (std::getenv("QGD_MG_VERBOSE")) std::fprintf(stderr, "[qgd mg] rank-local hierarchy: the gathered matrix has rows nobody contributed\n");
-        distBlockFallback(S); D.built = true; return true;
-    }
-    // level 0, distributed: the owned rows with their ghost columns, every vector by local cell label
     const int nC = S->m.nC;
     {
         std::vector<int> deg((size_t)nOwned, 0);
@@ -1669,38 +1613,134 @@ static bool distSetupStep(PressureSolver* S) {
         lv.sliceStart = lf.sliceStart;
         S->L.push_back(lv); S->Lf.push_back(lf);
     }
+}
+// the transfer between the distributed level 0 and the replicated level 1 from the owned cells' rows of P (columns: level-1 numbers):
+// P as a sliced ELL over the owned cells and, for every coarse node they touch, its row of P^T over them (ascending cell)
+static void distUploadTransfer(PressureSolver* S, const HostCsr& Pl, int nCoarse) {
+    PressureSolver::Dist& D = S->dist;
+    const int ob = S->ob, nOwned = S->oe - S->ob;
+    D.n1 = nCoarse;
+    std::vector<std::pair<int64_t, int64_t>> trip;   // (node, position in Pl) -> rows of P^T over this rank's cells
+    trip.reserve(Pl.col.size());
+    std::vector<int> rowOfPos(Pl.col.size());
+    for (int r = 0; r < nOwned; ++r)
+        for (int64_t at = Pl.off[r]; at < Pl.off[r + 1]; ++at) { trip.push_back({(int64_t)Pl.col[at], at}); rowOfPos[(size_t)at] = r; }
+    MgLevelT<float>& ff = S->Lf.back();
+    mgUploadEll<float>(S, nOwned, Pl, &ff.pS, &ff.pCol, &ff.pVal);
+    std::sort(trip.begin(), trip.end());
+    std::vector<int> node, start(1, 0), colr;
+    std::vector<float> valr;
+    for (size_t t = 0; t < trip.size(); ++t) {
+        if (t == 0 || trip[t].first != trip[t - 1].first) { if (t) start.push_back((int)colr.size()); node.push_back((int)trip[t].first); }
+        colr.push_back(rowOfPos[(size_t)trip[t].second] + ob);      // local cell label: r is indexed like every level-0 vector
+        valr.push_back((float)Pl.val[(size_t)trip[t].second]);
+    }
+    start.push_back((int)colr.size());
+    D.nPt = (int)node.size();
+    D.ptNode = S->alloc<int>(node.size(), node.data());
+    D.ptStart = S->alloc<int>(start.size(), start.data());
+    D.ptCol = S->alloc<int>(colr.size(), colr.data());
+    D.ptVal = S->alloc<float>(valr.size(), valr.data());
+}
+static bool distSetupLocal0(PressureSolver* S);
+// one stage of the set-up; returns true when the hierarchy stands (or was abandoned), false when a collective is pending
+static bool distSetupStep(PressureSolver* S) {
+    PressureSolver::Dist& D = S->dist;
+    const int ob = S->ob, oe = S->oe, nOwned = oe - ob;
+    hipStream_t stream = S->stream;
+    if (D.setupStage == 0) {
+        // sizes: the number of cells of the unsharded mesh, the most couplings any cell has to higher-numbered neighbours
+        std::vector<int> cnt((size_t)S->m.nC, 0);
+        int64_t gmax = 0;
+        int K = 0;
+        for (int i = ob; i < oe; ++i) gmax = std::max(gmax, D.globalOf(i) + 1);
+        for (size_t f = 0; f < D.own.size(); ++f) {
+            const int lo = D.globalOf(D.own[f]) < D.globalOf(D.nei[f]) ? D.own[f] : D.nei[f];
+            if (lo >= ob && lo < oe) K = std::max(K, ++cnt[lo]);
+        }
+        S->distEnsureBuf(2);
+        const double v[2] = {(double)gmax, (double)K};
+        PCHECK(hipMemcpyAsync(D.buf, v, sizeof(v), hipMemcpyHostToDevice, stream));
+        PCHECK(hipStreamSynchronize(stream));
+        D.bufN = 2; D.pending = 3; D.setupStage = 1;
+        return false;
+    }
+    if (D.setupStage == 1) {
+        double v[2];
+        PCHECK(hipMemcpyAsync(v, D.buf, sizeof(v), hipMemcpyDeviceToHost, stream));
+        PCHECK(hipStreamSynchronize(stream));
+        D.nCg = (int64_t)v[0]; D.K = (int)v[1];
+        // The hierarchy that spans the ranks REPLICATES the global matrix: every rank gathers nCg (1 + 2K) doubles (host and device),
+        // rebuilds the global rows and coarsens them on its own host -- set-up time and memory grow with the GLOBAL cell count, on every
+        // rank of the node at once (64 M cells, K = 3: 3.6 GB per buffer per rank, a 64 M-row host coarsening times eight).  Above
+        // distMaxCells (default 20 M: config 5's 16 M cells fit, 1.2 GB per buffer) the rank-local hierarchy is kept and said so.
+        // (QGD_MG_DIST=2 gathers one flag per global cell and the level-1 matrix only: its limit is eight times the replicated set-up's)
+        const bool tooLarge = D.nCg > (D.mode == 2 ? 8 * S->distMaxCells : S->distMaxCells);
+        if (D.nCg <= S->denseMax || D.nCg >= 0x7fffffffLL || D.nCg == nOwned || tooLarge) {
+            if (tooLarge)
+                std::fprintf(stderr, "[qgd mg] %lld cells in all exceed QGD_MG_DIST_MAX_CELLS = %lld: the multigrid hierarchy stays rank-local "
+                                     "(block Jacobi across the shards; expect more pressure iterations)\n", (long long)D.nCg, (long long)S->distMaxCells);
+            else if (std::getenv("QGD_MG_VERBOSE")) std::fprintf(stderr, "[qgd mg] rank-local hierarchy: %lld cells in all, %d here\n", (long long)D.nCg, nOwned);
+            distBlockFallback(S); D.built = true; return true;
+        }
+        if (D.mode == 2) return distSetupLocal0(S);
+        // this rank's share of the global matrix: the diagonal of its cells and, per cell, its couplings to higher-numbered neighbours
+        const int64_t n = D.nCg, K = D.K;
+        std::vector<double> h((size_t)(n * (1 + 2 * K)), 0.0);
+        std::vector<int> cnt((size_t)S->m.nC, 0);
+        for (int i = ob; i < oe; ++i) h[(size_t)D.globalOf(i)] = D.diag[i];
+        for (size_t f = 0; f < D.own.size(); ++f) {
+            const int64_t go = D.globalOf(D.own[f]), gn = D.globalOf(D.nei[f]);
+            const int lo = go < gn ? D.own[f] : D.nei[f];
+            if (lo < ob || lo >= oe) continue;
+            const int64_t glo = std::min(go, gn), ghi = std::max(go, gn);
+            const int k = cnt[lo]++;
+            if (k >= K || glo >= n || ghi >= n) throw std::runtime_error("distributed multigrid: the ranks disagree about the size of the global matrix");
+            h[(size_t)(n + glo * K + k)] = (double)(ghi + 1);
+            h[(size_t)(n + n * K + glo * K + k)] = D.a[f];
+        }
+        S->distEnsureBuf((int64_t)h.size());
+        PCHECK(hipMemcpyAsync(D.buf, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, stream));
+        PCHECK(hipStreamSynchronize(stream));
+        D.bufN = (int64_t)h.size(); D.pending = 2; D.setupStage = 2;
+        return false;
+    }
+    if (D.setupStage >= 10) return distSetupLocal0(S);
+    // stage 2: every rank holds the whole matrix now and builds the same hierarchy from it
+    const int64_t n = D.nCg, K = D.K;
+    std::vector<int> I, J;
+    std::vector<double> w, diag((size_t)n);
+    {
+        std::vector<double> h((size_t)D.bufN);
+        PCHECK(hipMemcpyAsync(h.data(), D.buf, sizeof(double) * h.size(), hipMemcpyDeviceToHost, stream));
+        PCHECK(hipStreamSynchronize(stream));
+        for (int64_t g = 0; g < n; ++g) {
+            diag[(size_t)g] = h[(size_t)g];
+            for (int k = 0; k < K; ++k) {
+                const double nb1 = h[(size_t)(n + g * K + k)];
+                if (nb1 > 0) { I.push_back((int)g); J.push_back((int)(nb1 - 1.0)); w.push_back(h[(size_t)(n + n * K + g * K + k)]); }
+            }
+        }
+    }
+    // a cell nobody contributed (a caller without the all-reduce: one rank driving a shard on its own) -> the rank-local hierarchy
+    bool complete = true;
+    for (int64_t g = 0; g < n && complete; ++g) complete = diag[(size_t)g] > 0.0;
+    if (!complete) {
+        if (std::getenv("QGD_MG_VERBOSE")) std::fprintf(stderr, "[qgd mg] rank-local hierarchy: the gathered matrix has rows nobody contributed\n");
+        distBlockFallback(S); D.built = true; return true;
+    }
+    distUploadLevel0(S);
     auto firstTransfer = [&](const HostCsr& P, int nCoarse) {
-        D.n1 = nCoarse;
-        // the owned cells' rows of P (columns: nodes of the replicated level 1) ...
+        // the owned cells' rows of the global P (columns: nodes of the replicated level 1)
         HostCsr Pl;
         Pl.off.assign((size_t)nOwned + 1, 0);
         for (int r = 0; r < nOwned; ++r) { const int64_t g = D.globalOf(r + ob); Pl.off[r + 1] = Pl.off[r] + (P.off[g + 1] - P.off[g]); }
         Pl.col.resize((size_t)Pl.off[nOwned]); Pl.val.resize((size_t)Pl.off[nOwned]);
-        std::vector<std::pair<int64_t, int64_t>> trip;   // (node, position in Pl) -> rows of P^T over this rank's cells
-        trip.reserve(Pl.col.size());
         for (int r = 0; r < nOwned; ++r) {
             const int64_t g = D.globalOf(r + ob);
-            for (int64_t q = P.off[g], at = Pl.off[r]; q < P.off[g + 1]; ++q, ++at) { Pl.col[at] = P.col[q]; Pl.val[at] = P.val[q]; trip.push_back({(int64_t)P.col[q], at}); }
+            for (int64_t q = P.off[g], at = Pl.off[r]; q < P.off[g + 1]; ++q, ++at) { Pl.col[at] = P.col[q]; Pl.val[at] = P.val[q]; }
         }
-        MgLevelT<float>& ff = S->Lf.back();
-        mgUploadEll<float>(S, nOwned, Pl, &ff.pS, &ff.pCol, &ff.pVal);
-        // ... and, for every coarse node they touch, its row of P^T over them (ascending cell)
-        std::sort(trip.begin(), trip.end());
-        std::vector<int> node, start(1, 0), colr;
-        std::vector<float> valr;
-        std::vector<int> rowOfPos(Pl.col.size());
-        for (int r = 0; r < nOwned; ++r) for (int64_t at = Pl.off[r]; at < Pl.off[r + 1]; ++at) rowOfPos[(size_t)at] = r;
-        for (size_t t = 0; t < trip.size(); ++t) {
-            if (t == 0 || trip[t].first != trip[t - 1].first) { if (t) start.push_back((int)colr.size()); node.push_back((int)trip[t].first); }
-            colr.push_back(rowOfPos[(size_t)trip[t].second] + ob);      // local cell label: r is indexed like every level-0 vector
-            valr.push_back((float)Pl.val[(size_t)trip[t].second]);
-        }
-        start.push_back((int)colr.size());
-        D.nPt = (int)node.size();
-        D.ptNode = S->alloc<int>(node.size(), node.data());
-        D.ptStart = S->alloc<int>(start.size(), start.data());
-        D.ptCol = S->alloc<int>(colr.size(), colr.data());
-        D.ptVal = S->alloc<float>(valr.size(), valr.data());
+        distUploadTransfer(S, Pl, nCoarse);
     };
     mgBuildHierarchy(S, (int)n, I, J, w, diag, firstTransfer);
     if (S->L.size() < 2) throw std::runtime_error("distributed multigrid: the global hierarchy has a single level");
@@ -1709,6 +1749,191 @@ static bool distSetupStep(PressureSolver* S) {
     if (std::getenv("QGD_MG_VERBOSE"))
         for (size_t l = 0; l < S->L.size(); ++l)
             std::fprintf(stderr, "[qgd mg, spanning the ranks] level %zu: %d rows%s, %.1f stored entries per row\n", l, S->L[l].n,
+                         l == 0 ? " of this rank" : " (replicated)", (double)S->L[l].entries / std::max(S->L[l].n, 1));
+    D.built = true;
+    return true;
+}
+// ---- QGD_MG_DIST=2: level 0 coarsened PER RANK ----------------------------------------------------------------------------------------
+// The replicated set-up above gathers the GLOBAL level-0 matrix on every rank and coarsens it there: memory and host time grow with the
+// global cell count on every rank at once.  Here each rank aggregates its OWN cells (couplings across a cut count as weak), smooths the
+// prolongator of its own rows -- cells with a coupling across a cut keep their tentative row, so a coarse node's row of P^T A P needs the
+// fine rows of its owner only, and the two ranks of a cut face compute the coupling of their two coarse nodes from the same number --, and
+// contributes its coarse rows to the level-1 matrix, which is gathered (1/8 of the rows) and replicated with everything below it as before.
+// What the ranks exchange: the aggregates' global numbers (a flag per global cell at each aggregate's lowest-numbered member: SUM, then a
+// prefix sum), the numbers of the ghost cells' aggregates (two halo messages: the high and the low twelve bits as floats), the widest coarse
+// row (MAX), the level-1 matrix (SUM of a zero-padded buffer, as for level 0 above).  Stages 10..15 of the set-up.
+static bool distSetupLocal0(PressureSolver* S) {
+    PressureSolver::Dist& D = S->dist;
+    const int ob = S->ob, oe = S->oe, nOwned = oe - ob, nC = S->m.nC;
+    hipStream_t stream = S->stream;
+    if (!D.l0) D.l0 = std::make_shared<PressureSolver::Dist::Local0>();
+    PressureSolver::Dist::Local0& Z = *D.l0;
+    auto download = [&](std::vector<double>& h, int64_t n) {
+        h.resize((size_t)n);
+        PCHECK(hipMemcpyAsync(h.data(), D.buf, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, stream));
+        PCHECK(hipStreamSynchronize(stream));
+    };
+    auto upload = [&](const std::vector<double>& h) {
+        S->distEnsureBuf((int64_t)h.size());
+        PCHECK(hipMemcpyAsync(D.buf, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, stream));
+        PCHECK(hipStreamSynchronize(stream));
+        D.bufN = (int64_t)h.size();
+    };
+    auto sendPerCell = [&](int shift) {   // twelve bits of every owned cell's aggregate number, as a float, to the neighbours' ghost copies
+        Z.tmp.assign((size_t)nC, 0.0f);
+        for (int i = 0; i < nOwned; ++i) Z.tmp[(size_t)(ob + i)] = (float)((Z.gid[Z.agg[i]] >> shift) & 4095);
+        MgLevelT<float>& L0 = S->Lf[0];
+        PCHECK(hipMemcpyAsync(L0.x, Z.tmp.data(), sizeof(float) * (size_t)nC, hipMemcpyHostToDevice, stream));
+        PCHECK(hipStreamSynchronize(stream));
+        D.haloVec = L0.x; D.pending = 1;
+    };
+    auto receivePerCell = [&](int shift) {
+        MgLevelT<float>& L0 = S->Lf[0];
+        Z.tmp.resize((size_t)nC);
+        PCHECK(hipMemcpyAsync(Z.tmp.data(), L0.x, sizeof(float) * (size_t)nC, hipMemcpyDeviceToHost, stream));
+        PCHECK(hipStreamSynchronize(stream));
+        for (int c = 0; c < nC; ++c) if (c < ob || c >= oe) Z.ghostGid[c] |= ((int)Z.tmp[(size_t)c]) << shift;
+    };
+    if (D.setupStage == 1) {
+        // the owned block's graph, the couplings across the cuts, the aggregates
+        std::vector<int> I, J;
+        std::vector<double> w;
+        for (size_t f = 0; f < D.own.size(); ++f) {
+            const bool o = D.own[f] >= ob && D.own[f] < oe, n = D.nei[f] >= ob && D.nei[f] < oe;
+            if (o && n) { I.push_back(D.own[f] - ob); J.push_back(D.nei[f] - ob); w.push_back(D.a[f]); }
+            else if (o != n) { Z.cutI.push_back((o ? D.own[f] : D.nei[f]) - ob); Z.cutJ.push_back(o ? D.nei[f] : D.own[f]); Z.cutW.push_back(D.a[f]); }
+        }
+        Z.diag.assign(D.diag.begin() + ob, D.diag.begin() + oe);
+        adjacencyOf(nOwned, I, J, w, Z.off, Z.nb, Z.nw);
+        strengthOf(nOwned, Z.off, Z.nb, Z.nw, Z.diag, S->saTheta, Z.strong);
+        Z.cutAdj.assign((size_t)nOwned, 0);
+        for (int i : Z.cutI) Z.cutAdj[(size_t)i] = 1;
+        Z.na = rootAggregates(nOwned, Z.off, Z.nb, Z.nw, Z.strong, Z.agg);
+        if (Z.na < 1 || Z.na >= nOwned) { distBlockFallback(S); D.built = true; return true; }
+        // a flag at the lowest global cell number of every aggregate; summed over the ranks, its prefix sums number the aggregates globally
+        std::vector<int64_t> repOf((size_t)Z.na, INT64_MAX);
+        for (int i = 0; i < nOwned; ++i) repOf[(size_t)Z.agg[i]] = std::min(repOf[(size_t)Z.agg[i]], D.globalOf(ob + i));
+        std::vector<double> h((size_t)D.nCg, 0.0);
+        for (int a = 0; a < Z.na; ++a) h[(size_t)repOf[(size_t)a]] = 1.0;
+        Z.gid.resize((size_t)Z.na);
+        for (int a = 0; a < Z.na; ++a) Z.gid[(size_t)a] = (int)repOf[(size_t)a];   // (the representative for now; its prefix count in stage 10)
+        upload(h);
+        D.pending = 2; D.setupStage = 10;
+        return false;
+    }
+    if (D.setupStage == 10) {
+        std::vector<double> h;
+        download(h, D.nCg);
+        std::vector<int> order((size_t)Z.na);
+        for (int a = 0; a < Z.na; ++a) order[(size_t)a] = a;
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return Z.gid[(size_t)a] < Z.gid[(size_t)b]; });
+        int64_t count = 0, g = 0;
+        for (int a : order) {
+            const int64_t rep = Z.gid[(size_t)a];
+            for (; g < rep; ++g) count += h[(size_t)g] != 0.0 ? 1 : 0;
+            Z.gid[(size_t)a] = (int)count;
+        }
+        for (; g < D.nCg; ++g) count += h[(size_t)g] != 0.0 ? 1 : 0;
+        if (count >= (1 << 24) || count < 2) { distBlockFallback(S); D.built = true; return true; }   // (numbers travel as two twelve-bit floats)
+        D.n1 = (int)count;
+        distUploadLevel0(S);     // the distributed level 0 (its vectors carry the two halo messages below)
+        Z.ghostGid.assign((size_t)nC, 0);
+        sendPerCell(12);
+        D.setupStage = 11;
+        return false;
+    }
+    if (D.setupStage == 11) { receivePerCell(12); sendPerCell(0); D.setupStage = 12; return false; }
+    if (D.setupStage == 12) {
+        receivePerCell(0);
+        // the prolongator of the owned rows (tentative next to a cut) and this rank's rows of P^T A P, in local aggregate numbers ...
+        HostCsr P, PT;
+        std::vector<int> cI, cJ;
+        std::vector<double> cw, cdiag;
+        smoothedLevel(nOwned, Z.off, Z.nb, Z.nw, Z.strong, Z.diag, Z.agg, Z.na, (4.0 / 3.0) / 2.0, P, PT, cI, cJ, cw, cdiag, &Z.cutAdj);
+        // ... then in global numbers, with the couplings across the cuts: a cut face between the aggregates I (here) and J (there) adds its
+        // coefficient to their coupling; the owner of the lower number contributes the pair (the other side computes the same number)
+        std::map<std::pair<int, int>, double> pairs;
+        for (size_t e = 0; e < cI.size(); ++e) {
+            const int a = Z.gid[(size_t)cI[e]], b = Z.gid[(size_t)cJ[e]];
+            pairs[{std::min(a, b), std::max(a, b)}] += cw[e];
+        }
+        for (size_t e = 0; e < Z.cutI.size(); ++e) {
+            const int a = Z.gid[(size_t)Z.agg[(size_t)Z.cutI[e]]], b = Z.ghostGid[(size_t)Z.cutJ[e]];
+            if (a == b || b < 0 || b >= D.n1) throw std::runtime_error("distributed multigrid: a ghost cell's aggregate number is out of range");
+            if (a < b) pairs[{a, b}] += Z.cutW[e];
+        }
+        Z.e1I.clear(); Z.e1J.clear(); Z.e1W.clear();
+        std::vector<int> cnt((size_t)D.n1, 0);
+        int K1 = 0;
+        for (const auto& kv : pairs) {
+            Z.e1I.push_back(kv.first.first); Z.e1J.push_back(kv.first.second); Z.e1W.push_back(kv.second);
+            K1 = std::max(K1, ++cnt[(size_t)kv.first.first]);
+        }
+        Z.d1.assign((size_t)Z.na, 0.0);
+        for (int a = 0; a < Z.na; ++a) Z.d1[(size_t)a] = cdiag[(size_t)a];
+        Z.pOff = P.off; Z.pCol.resize(P.col.size()); Z.pVal = P.val;
+        for (size_t q = 0; q < P.col.size(); ++q) Z.pCol[q] = Z.gid[(size_t)P.col[q]];
+        std::vector<int64_t>().swap(Z.off); std::vector<int>().swap(Z.nb); std::vector<double>().swap(Z.nw); std::vector<uint8_t>().swap(Z.strong);
+        upload(std::vector<double>{(double)K1});
+        D.pending = 3; D.setupStage = 13;
+        return false;
+    }
+    if (D.setupStage == 13) {
+        std::vector<double> v;
+        download(v, 1);
+        D.K = (int)v[0];
+        const int64_t n = D.n1, K = D.K;
+        std::vector<double> h((size_t)(n * (1 + 2 * K)), 0.0);
+        for (int a = 0; a < Z.na; ++a) h[(size_t)Z.gid[(size_t)a]] = Z.d1[(size_t)a];
+        std::vector<int> cnt((size_t)n, 0);
+        for (size_t e = 0; e < Z.e1I.size(); ++e) {
+            const int64_t lo = Z.e1I[e];
+            const int k = cnt[(size_t)lo]++;
+            if (k >= K) throw std::runtime_error("distributed multigrid: the ranks disagree about the width of the level-1 matrix");
+            h[(size_t)(n + lo * K + k)] = (double)(Z.e1J[e] + 1);
+            h[(size_t)(n + n * K + lo * K + k)] = Z.e1W[e];
+        }
+        upload(h);
+        D.pending = 2; D.setupStage = 14;
+        return false;
+    }
+    // stage 14: every rank holds the level-1 matrix; the levels from 1 on are built from it, identically everywhere
+    const int64_t n = D.n1, K = D.K;
+    std::vector<int> I, J;
+    std::vector<double> w, diag((size_t)n);
+    {
+        std::vector<double> h;
+        download(h, D.bufN);
+        for (int64_t g = 0; g < n; ++g) {
+            diag[(size_t)g] = h[(size_t)g];
+            for (int k = 0; k < K; ++k) {
+                const double nb1 = h[(size_t)(n + g * K + k)];
+                if (nb1 > 0) { I.push_back((int)g); J.push_back((int)(nb1 - 1.0)); w.push_back(h[(size_t)(n + n * K + g * K + k)]); }
+            }
+        }
+    }
+    for (int64_t g = 0; g < n; ++g)
+        if (!(diag[(size_t)g] > 0.0)) throw std::runtime_error("distributed multigrid: a level-1 row nobody contributed (did every rank reduce?)");
+    {
+        HostCsr Pl;
+        Pl.off = Z.pOff; Pl.col = Z.pCol; Pl.val = Z.pVal;
+        distUploadTransfer(S, Pl, (int)n);
+        S->L.back().pS = S->Lf.back().pS;
+    }
+    std::vector<int64_t> off;
+    std::vector<int> nbr;
+    std::vector<double> nw;
+    adjacencyOf((int)n, I, J, w, off, nbr, nw);
+    S->smootherScale.assign(1, 1.0);
+    S->smootherScale.push_back(2.0 / lambdaMaxOf((int)n, off, nbr, nw, diag));
+    mgUploadLevel(S, (int)n, I, J, w, diag, n <= S->denseMax);
+    mgBuildHierarchy(S, (int)n, I, J, w, diag, nullptr, true);
+    S->distEnsureBuf(D.n1);
+    std::vector<int>().swap(D.own); std::vector<int>().swap(D.nei); std::vector<double>().swap(D.a); std::vector<double>().swap(D.diag);
+    D.l0.reset();
+    if (std::getenv("QGD_MG_VERBOSE"))
+        for (size_t l = 0; l < S->L.size(); ++l)
+            std::fprintf(stderr, "[qgd mg, spanning the ranks, level 0 coarsened per rank] level %zu: %d rows%s, %.1f stored entries per row\n", l, S->L[l].n,
                          l == 0 ? " of this rank" : " (replicated)", (double)S->L[l].entries / std::max(S->L[l].n, 1));
     D.built = true;
     return true;

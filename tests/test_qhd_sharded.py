@@ -198,8 +198,10 @@ def test_multigrid_hierarchy_spans_the_ranks(cut, world, monkeypatch):
     iters = {}
     # "cap": the hierarchy that spans the ranks replicates the global matrix on every rank, so above QGD_MG_DIST_MAX_CELLS (default
     # 20 M cells) a solve keeps the rank-local hierarchy and says so on stderr -- same answer, the iterations of QGD_MG_DIST=0
-    for dist in ("1", "0", "cap"):
-        monkeypatch.setenv("QGD_MG_DIST", "0" if dist == "0" else "1")
+    # "2": level 0 coarsened PER RANK (aggregates and prolongator from the rank's own cells, cells next to a cut unsmoothed), only the
+    # level-1 matrix gathered and replicated: nothing of the global level-0 matrix on any rank -- within a few iterations of "1"
+    for dist in ("1", "2", "0", "cap"):
+        monkeypatch.setenv("QGD_MG_DIST", {"0": "0", "2": "2"}.get(dist, "1"))
         if dist == "cap":
             monkeypatch.setenv("QGD_MG_DIST_MAX_CELLS", "1000")
         shards = make()
@@ -217,6 +219,7 @@ def test_multigrid_hierarchy_spans_the_ranks(cut, world, monkeypatch):
         for d, c in pairs:
             c.close(); d.close()
     assert iters["1"] <= whole.info()["pIterations"] + 2, (iters, whole.info())
+    assert iters["2"] <= iters["1"] + 3 and iters["2"] < iters["0"], iters
     assert iters["0"] > iters["1"], iters
     assert iters["cap"] == iters["0"], iters
     whole.close(); gdev.close()
