@@ -645,6 +645,9 @@ def qhd_line(args):
         "step_bytes_model": {"explicit_bytes_per_cell": QHD_EXPLICIT_BYTES_PER_CELL, "bytes_per_cell_per_pressure_iteration": QHD_BYTES_PER_CELL_PER_ITERATION,
                              "bytes_per_step": step_bytes},
         "step_roofline_frac": step_bytes * args.steps / elapsed / (HBM_PEAK_GBS * 1e9),
+        # which kernel the step spends most of its GPU time in: from the committed profile of this workload; when it is
+        # the multigrid sweep, `roofline` above is that kernel's level-0 instance measured live
+        "largest_kernel": (largest_kernel(f"r06_qhd_n{n}_kernel_stats.csv") if (not args.irregular and not args.implicit_diffusion) else None),
         "phase_ms": phase_ms, "pressure_iterations_second_pass": iters, "pressure_final_residual": info["pFinalResidual"],
         "setup_s": t_setup,
     }
@@ -663,6 +666,22 @@ IMPL_CHEB_BYTES_PER_CELL = 48 + 24 + 3 * 48
 IMPL_CHEB_BYTES_PER_CELL_E = 48 + 24 + 48
 IMPL_ITER_BYTES_PER_CELL_U = 144 + 168 + 96
 IMPL_ITER_BYTES_PER_CELL_E = 48 + 24 + 24 + 56 + 32
+
+
+def largest_kernel(stats_csv):
+    """the kernel with the largest share of the GPU time of a workload, from the committed rocprofv3 --kernel-trace --stats summary of the
+    builder's profiling run of that workload (static, like `traffic`): {"kernel", "share", "avg_us", "calls", "source"} or None"""
+    path = os.path.join(ROOT, "profiles", stats_csv)
+    try:
+        import csv
+        rows = list(csv.DictReader(open(path)))
+        tot = sum(float(r["TotalDurationNs"]) for r in rows)
+        r = max(rows, key=lambda x: float(x["TotalDurationNs"]))
+        name = r["Name"].replace("qgd::(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+        return {"kernel": name, "share": float(r["TotalDurationNs"]) / tot, "avg_us": float(r["AverageNs"]) / 1e3, "calls": int(r["Calls"]),
+                "source": "profiles/" + stats_csv, "is_static": True}
+    except Exception:
+        return None
 
 
 def secondary_traffic(key):
@@ -735,6 +754,7 @@ def implicit_line(args):
                                "per_cell_per_iteration_e": IMPL_CHEB_BYTES_PER_CELL_E if cheb else IMPL_ITER_BYTES_PER_CELL_E,
                                "bytes_per_step_in_the_solves": nc * ((IMPL_CHEB_BYTES_PER_CELL if cheb else IMPL_ITER_BYTES_PER_CELL_U) * it_u
                                                                      + (IMPL_CHEB_BYTES_PER_CELL_E if cheb else IMPL_ITER_BYTES_PER_CELL_E) * it_e)},
+        "largest_kernel": largest_kernel(f"r06_implicit_n{n}_kernel_stats.csv"),
         "min_rho": info["minRho"], "setup_s": t_setup,
     }
     case.close(); dev.close()
