@@ -1674,7 +1674,13 @@ static bool distSetupStep(PressureSolver* S) {
         // rebuilds the global rows and coarsens them on its own host -- set-up time and memory grow with the GLOBAL cell count, on every
         // rank of the node at once (64 M cells, K = 3: 3.6 GB per buffer per rank, a 64 M-row host coarsening times eight).  Above
         // distMaxCells (default 20 M: config 5's 16 M cells fit, 1.2 GB per buffer) the rank-local hierarchy is kept and said so.
-        // (QGD_MG_DIST=2 gathers one flag per global cell and the level-1 matrix only: its limit is eight times the replicated set-up's)
+        // (QGD_MG_DIST=2 gathers one flag per global cell and the level-1 matrix only: its limit is eight times the replicated set-up's, and a
+        // mesh too large for the replicated set-up takes it by itself instead of falling back to rank-local hierarchies)
+        if (D.mode == 1 && D.nCg > S->distMaxCells && D.nCg <= 8 * S->distMaxCells) {
+            D.mode = 2;
+            std::fprintf(stderr, "[qgd mg] %lld cells in all exceed QGD_MG_DIST_MAX_CELLS = %lld: level 0 of the multigrid hierarchy is coarsened per rank "
+                                 "(QGD_MG_DIST=2), only the level-1 matrix is gathered\n", (long long)D.nCg, (long long)S->distMaxCells);
+        }
         const bool tooLarge = D.nCg > (D.mode == 2 ? 8 * S->distMaxCells : S->distMaxCells);
         if (D.nCg <= S->denseMax || D.nCg >= 0x7fffffffLL || D.nCg == nOwned || tooLarge) {
             if (tooLarge)

@@ -200,10 +200,12 @@ def test_multigrid_hierarchy_spans_the_ranks(cut, world, monkeypatch):
     # 20 M cells) a solve keeps the rank-local hierarchy and says so on stderr -- same answer, the iterations of QGD_MG_DIST=0
     # "2": level 0 coarsened PER RANK (aggregates and prolongator from the rank's own cells, cells next to a cut unsmoothed), only the
     # level-1 matrix gathered and replicated: nothing of the global level-0 matrix on any rank -- within a few iterations of "1"
-    for dist in ("1", "2", "0", "cap"):
+    # "cap2": a mesh above QGD_MG_DIST_MAX_CELLS but within eight times it takes the per-rank coarsening by itself; "cap": above that, rank-local
+    for dist in ("1", "2", "0", "cap2", "cap"):
         monkeypatch.setenv("QGD_MG_DIST", {"0": "0", "2": "2"}.get(dist, "1"))
-        if dist == "cap":
-            monkeypatch.setenv("QGD_MG_DIST_MAX_CELLS", "1000")
+        monkeypatch.delenv("QGD_MG_DIST_MAX_CELLS", raising=False)
+        if dist in ("cap", "cap2"):
+            monkeypatch.setenv("QGD_MG_DIST_MAX_CELLS", "100" if dist == "cap" else "1000")
         shards = make()
         pairs = [make_device_shard_case(sh, opt, cavity_bcs, fields) for sh in shards]
         cases = [c for _, c in pairs]
@@ -221,7 +223,7 @@ def test_multigrid_hierarchy_spans_the_ranks(cut, world, monkeypatch):
     assert iters["1"] <= whole.info()["pIterations"] + 2, (iters, whole.info())
     assert iters["2"] <= iters["1"] + 3 and iters["2"] < iters["0"], iters
     assert iters["0"] > iters["1"], iters
-    assert iters["cap"] == iters["0"], iters
+    assert iters["cap"] == iters["0"] and iters["cap2"] == iters["2"], iters
     whole.close(); gdev.close()
 
 
