@@ -64,10 +64,11 @@ def parse():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--edge", dest="n", type=int, default=int(os.environ.get("QGD_BENCH_N", "400")), help="box edge in cells (n^3 cells in total)")
-    ap.add_argument("--workload", default="qgd", choices=["qgd", "qhd", "implicit"],
+    ap.add_argument("--workload", default="qgd", choices=["qgd", "qhd", "implicit", "adjust"],
                     help="qgd: the headline (QGDFoam explicit step, BASELINE.json configs 3/4); qhd: the QHDFoam step of config 5 "
                          "(semi-implicit: flux assembly + pressure equation), its own metric line; implicit: the QGDFoam step with "
-                         "implicitDiffusion true (the reference's default branch), one GPU, its own metric line")
+                         "implicitDiffusion true (the reference's default branch), one GPU, its own metric line; adjust: the QGDFoam explicit step "
+                         "under Courant-number control (adjustTimeStep, QGDFoam.C L118-120), one GPU, its own metric line")
     ap.add_argument("--irregular", action="store_true", help="qhd: the config-5 stand-in mesh (jittered vertices, every 7th quad split into "
                                                              "triangles, labels shuffled in chunks then Morton-ordered) instead of a uniform box")
     ap.add_argument("--implicit-diffusion", action="store_true",
@@ -498,7 +499,8 @@ def secondary_lines(args):
     n = os.environ.get("QGD_BENCH_SECONDARY_N", "200")   # tests shrink it; any value but 200 is visible in the key and in config.env
     lines = [(f"qhd_n{n}", ["--workload", "qhd", "--edge", n, "--steps", "20", "--warmup", "10"]),
              (f"qhd_implicit_n{n}", ["--workload", "qhd", "--implicit-diffusion", "--edge", n, "--steps", "20", "--warmup", "10"]),
-             (f"implicit_n{n}", ["--workload", "implicit", "--edge", n, "--steps", "20", "--warmup", "5"])]
+             (f"implicit_n{n}", ["--workload", "implicit", "--edge", n, "--steps", "20", "--warmup", "5"]),
+             (f"adjust_n{n}", ["--workload", "adjust", "--edge", n, "--steps", "50", "--warmup", "10"])]
     # BASELINE config 5 (16 M irregular cells, QHDFoam) on one GPU: ~45 s of host mesh set-up + 30 steps.  QGD_BENCH_C5=0 leaves it out,
     # QGD_BENCH_C5_N shrinks it (tests), QGD_BENCH_C5_IMPLICIT=1 adds the implicitDiffusion branch on the same mesh.
     if os.environ.get("QGD_BENCH_C5", "1") != "0":
@@ -761,6 +763,49 @@ def implicit_line(args):
     print(json.dumps(out), flush=True)
 
 
+def adjust_line(args):
+    """python bench.py --workload adjust [--edge N]: Mcell-steps/s of the QGDFoam explicit step under Courant-number control (adjustTimeStep:
+    QGDCourantNo.H L36-53 + setDeltaT-QGDQHD.H L41-61 every step [QGDFoam.C L118-120]): every face's Courant number and tauQGDf before the first
+    cell may advance -- the cell blocks up to their flux sums and Courant partials, the two-level reduction, deltaT on the device, the cell kernel."""
+    import qgdsolver_amd as q
+    from qgdsolver_amd.synthetic import box_initial_fields
+
+    if q.device_count() < 1:
+        raise RuntimeError("bench.py needs a HIP device: qgdsolver_amd has no CPU fallback")
+    n = args.n
+    t_setup = time.perf_counter()
+    mesh = q.PolyMesh.box(n, n, n)
+    dev = q.Device(mesh)
+    opt = q.default_options(stencil="GaussVolPoint", deltaT=0.05 / n / 1.3, adjustTimeStep=1, maxCo=0.1, maxDeltaT=1.0)
+    case = q.QGDFoamCase(dev, opt)
+    U, T, p = box_initial_fields(mesh.array("C").reshape(-1, 3))
+    case.set_fields(U, T, p)
+    del U, T, p
+    nc = mesh.nCells
+    t_setup = time.perf_counter() - t_setup
+    fi = case.fused_info()
+    case.step(max(args.warmup, 1))
+    t0 = time.perf_counter()
+    case.step(args.steps)          # returns after the device has finished
+    elapsed = time.perf_counter() - t0
+    info = case.info()
+    out = {
+        "metric": "Mcell-steps/s (QGDFoam explicit step, adjustTimeStep)", "value": nc * args.steps / elapsed / 1e6, "unit": "Mcell-steps/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": (f"QGDFoam {n}^3 = {nc / 1e6:.1f}M-cell uniform hex box (blockMesh numbering), GaussVolPoint, constScPrModel1, explicit "
+                                "diffusion, zeroGradient patches, adjustTimeStep with maxCo 0.1 (deltaT recomputed on the device every step)"),
+                   "cells": nc, "deltaT": info["deltaT"], "CoNum": info["CoNum"],
+                   "path": ("cell blocks in two launches (fusedFaceCellKernel<..., ADJ> up to the flux sums and Courant partials, cellFinishKernel)"
+                            if fi.get("fusedAdjust") else "three kernels (vertex values, faces with the Courant partials, cells)"),
+                   "blocks": fi["blocks"], "env": qgd_env()},
+        "step_roofline_frac": STEP_BYTES_PER_CELL * nc * args.steps / elapsed / (HBM_PEAK_GBS * 1e9),
+        "min_rho": info["minRho"], "setup_s": t_setup,
+    }
+    case.close(); dev.close()
+    print(json.dumps(out), flush=True)
+
+
 def qhd_line_sharded(args):
     """python bench.py --workload qhd --gpus N [--irregular]: the QHDFoam step on N cell-range shards, one rank per GPU -- config 5 as
     configured.  Transport: the library's own RCCL path (qgd_qhd_case_step_sharded: halo messages, all-reduced PCG scalars, the comm
@@ -887,6 +932,14 @@ def main():
             print("bench.py: --workload implicit is a one-GPU line (the branch shards: tests/test_implicit_sharded.py)", file=sys.stderr)
             sys.exit(2)
         implicit_line(args)
+        return
+    if args.workload == "adjust":
+        if "QGD_BENCH_N" not in os.environ and "--edge" not in " ".join(sys.argv):
+            args.n = 200
+        if args.gpus > 1:
+            print("bench.py: --workload adjust is a one-GPU line (the all-reduce of the Courant number on shards: tests/test_halo_gloo.py)", file=sys.stderr)
+            sys.exit(2)
+        adjust_line(args)
         return
     if args.workload == "qhd":
         if "QGD_BENCH_N" not in os.environ and "--edge" not in " ".join(sys.argv):
