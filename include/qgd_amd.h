@@ -105,7 +105,7 @@ typedef struct qgd_case_s* qgd_case_t;     /* a QGDFoam case on one device      
 
 /* ---- library ---------------------------------------------------------------- */
 /* Bumped whenever an options struct grows or an entry changes its meaning (3: round 3). */
-#define QGD_ABI_VERSION 5
+#define QGD_ABI_VERSION 6
 const char* qgd_version(void);
 /* sizes[0..2] = sizeof(qgd_case_options), sizeof(qgd_qhd_options), sizeof(qgd_poisson_control) as THIS library was built,
  * sizes[3] = its QGD_ABI_VERSION: a host compiled against another header compares before it passes a struct (the structs
@@ -622,7 +622,11 @@ int qgd_case_info(qgd_case_t c, double info[6]);
  * cells and of the cells around them in LDS, forms the vertex values of the block from them (volPointInterpolation's weights, pointCells
  * order), computes every internal face of its cells into LDS and advances the cells from there, in the summation order of
  * fvc::surfaceIntegrate: neither the vertex values nor the net fluxes of internal faces reach device memory, and the vertex kernel, the face
- * kernel and the cell kernel are one launch.  Same arithmetic, bit-identical states.  info[0] = 1 when in use, [1] = blocks, [2] = internal
+ * kernel and the cell kernel are one launch.  Same arithmetic, bit-identical states.  info[0] = 1 when in use (2: the same blocks assemble
+ * the three U systems of an unsharded fixed-deltaT implicitDiffusion case in one launch -- vertex values, QGD fluxes, tauMC, phiTauMC, the rows
+ * [QGDUEqn_8H_source.html L36-68, QGDFoam_2updateFluxes_8H_source.html L95-111], QGD_IMPL_FUSED; 3: Courant-number control, adjustTimeStep
+ * [QGDCourantNo_8H_source.html L36-53, setDeltaT-QGDQHD_8H_source.html L41-61] -- the blocks run up to their cells' flux sums and their faces'
+ * Courant partials, deltaT follows on the device, a cell kernel advances: two launches, QGD_FUSED_ADJUST; 0: the separate kernels), [1] = blocks, [2] = internal
  * faces computed per step (faces on a block's surface are computed by the block on either side), [3] = LDS bytes per workgroup, [4] = cell
  * records staged per step over all blocks, [5] = of which with their second record and centre (own cells + cells across a face), [6] =
  * vertex values formed per step over all blocks, [7] = on a shard, the leading blocks that hold the cells a neighbouring rank waits for (phase 10
