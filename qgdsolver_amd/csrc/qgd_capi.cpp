@@ -2166,6 +2166,9 @@ int qgd_qhd_options_default(qgd_qhd_options* o) {
 int qgd_qhd_case_create(qgd_device_t d, const qgd_qhd_options* opt, qgd_qhd_case_t* out) {
     QGD_TRY
     if (!d || !opt || !out) return fail(QGD_ERR_INVALID, "qgd_qhd_case_create: null argument");
+    if (d->periodic())
+        return fail(QGD_ERR_NOT_IMPLEMENTED, "qgd_qhd_case_create: a mesh whose cyclic patches were unrolled into ghost cells (qgd_mesh_unroll_cyclic) is served by "
+                                             "QGDFoam's explicit branch only: the pressure equation would need the coupled rows");
     if (opt->implicitDiffusion && (!(opt->implicitTol > 0) || opt->implicitMaxIter < 1))
         return fail(QGD_ERR_INVALID, "qgd_qhd_case_create: implicitDiffusion needs implicitTol > 0 and implicitMaxIter >= 1");
     if (!(opt->rho0 > 0) || !(opt->Pr > 0) || !(opt->deltaT > 0) || opt->tauModel < 0 || opt->tauModel > 3)

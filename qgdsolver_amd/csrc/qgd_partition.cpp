@@ -472,13 +472,24 @@ HostMesh unrollCyclic(const HostMesh& g, const std::vector<std::pair<int32_t, in
     std::vector<Inst> inst;
     std::vector<int> tileOrder{centre};   // the real mesh first: its faces keep their relative order in every patch
     for (int tile = 0; tile < nTiles; ++tile) if (tile != centre) tileOrder.push_back(tile);
-    for (const int tile : tileOrder) {
-        if (tile != centre && tileCells[tile].empty()) continue;
-        for (int32_t f = 0; f < g.nFaces; ++f) {
-            const int32_t a = localCell(tile, g.owner[f]);
-            const int32_t b = f < g.nInternalFaces ? localCell(tile, g.neighbour[f]) : -1;
-            if (a < 0 && b < 0) continue;
-            inst.push_back({tile, f, a, b});
+    {
+        std::vector<int32_t> stamp((size_t)g.nFaces, -1), tileFaces;
+        for (const int tile : tileOrder) {
+            if (tile != centre && tileCells[tile].empty()) continue;
+            // the faces of the tile's cells in ascending label (a copy tile holds a surface layer only: walk its cells, not every face of g)
+            tileFaces.clear();
+            if (tile == centre) { tileFaces.resize((size_t)g.nFaces); for (int32_t f = 0; f < g.nFaces; ++f) tileFaces[(size_t)f] = f; }
+            else {
+                for (int32_t c : tileCells[tile])
+                    for (int32_t q = cf.offsets[c]; q < cf.offsets[c + 1]; ++q) { const int32_t f = cf.items[q]; if (stamp[(size_t)f] != tile) { stamp[(size_t)f] = tile; tileFaces.push_back(f); } }
+                std::sort(tileFaces.begin(), tileFaces.end());
+            }
+            for (int32_t f : tileFaces) {
+                const int32_t a = localCell(tile, g.owner[f]);
+                const int32_t b = f < g.nInternalFaces ? localCell(tile, g.neighbour[f]) : -1;
+                if (a < 0 && b < 0) continue;
+                inst.push_back({tile, f, a, b});
+            }
         }
     }
     auto facePts = [&](const Inst& in, std::vector<int32_t>& out) {
@@ -492,17 +503,17 @@ HostMesh unrollCyclic(const HostMesh& g, const std::vector<std::pair<int32_t, in
         std::vector<int32_t> pts, key;
         for (size_t i = 0; i < inst.size(); ++i) {
             const Inst& in = inst[i];
+            // a face with both its cells in one tile is what it was (only faces with ONE cell here can meet a partner: the map holds those alone)
+            if (in.own >= 0 && in.nei >= 0) {
+                Glued G; G.own = in.own; G.nei = in.nei; G.instOwn = i; G.flipOwn = false; G.first = i;
+                faces.push_back(G);
+                continue;
+            }
             facePts(in, pts);
             key = pts;
             std::sort(key.begin(), key.end());
             auto it = byPoints.find(key);
-            // the cells this instance brings, and whether the face's point order (normal owner -> neighbour in g) points out of the FIRST of them
-            if (in.own >= 0 && in.nei >= 0) {
-                if (it != byPoints.end()) throw std::runtime_error("unrollCyclic: an internal face coincides with another face");
-                Glued G; G.own = in.own; G.nei = in.nei; G.instOwn = i; G.flipOwn = false; G.first = i;
-                byPoints[key] = faces.size(); faces.push_back(G);
-                continue;
-            }
+            // the cell this instance brings, and whether the face's point order (normal owner -> neighbour in g) points out of it
             const int32_t cell = in.own >= 0 ? in.own : in.nei;
             const bool outward = in.own >= 0;   // g's orientation points out of its owner
             if (it == byPoints.end()) {

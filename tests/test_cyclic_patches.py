@@ -252,6 +252,9 @@ def test_device_steps_a_periodic_case_like_the_oracle(periodic, bc_fn, stencil, 
         ic = q.QGDFoamCase(dev, q.default_options(stencil=stencil, deltaT=1e-3, mu=1e-3, implicitDiffusion=1))
         ic.set_fields(U[cg], T[cg], p[cg])
         ic.step(1)
+    from qgdsolver_amd import qhdfoam
+    with pytest.raises(q.QgdError, match="unrolled"):
+        qhdfoam.QHDFoamCase(dev, qhdfoam.qhd_options(stencil=stencil, deltaT=1e-3))
     gc.close(); dev.close()
 
 
