@@ -497,18 +497,20 @@ def secondary_lines(args):
     keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "config", "roofline", "phase_ms", "step_roofline_frac", "setup_s", "error", "stderr")
     out = {}
     n = os.environ.get("QGD_BENCH_SECONDARY_N", "200")   # tests shrink it; any value but 200 is visible in the key and in config.env
-    lines = [(f"qhd_n{n}", ["--workload", "qhd", "--edge", n, "--steps", "20", "--warmup", "10"]),
-             (f"qhd_implicit_n{n}", ["--workload", "qhd", "--implicit-diffusion", "--edge", n, "--steps", "20", "--warmup", "10"]),
-             (f"implicit_n{n}", ["--workload", "implicit", "--edge", n, "--steps", "20", "--warmup", "5"]),
+    # (20 warm-up steps like the headline -- SURVEY 8(d): "steady state: >= 20 warm-up steps discarded"; rounds 4-5 timed steps 6-25 / 11-30, in
+    # which the iterative solves' start values were still building their history)
+    lines = [(f"qhd_n{n}", ["--workload", "qhd", "--edge", n, "--steps", "20", "--warmup", "20"]),
+             (f"qhd_implicit_n{n}", ["--workload", "qhd", "--implicit-diffusion", "--edge", n, "--steps", "20", "--warmup", "20"]),
+             (f"implicit_n{n}", ["--workload", "implicit", "--edge", n, "--steps", "20", "--warmup", "20"]),
              (f"adjust_n{n}", ["--workload", "adjust", "--edge", n, "--steps", "50", "--warmup", "10"])]
     # BASELINE config 5 (16 M irregular cells, QHDFoam) on one GPU: ~45 s of host mesh set-up + 30 steps.  QGD_BENCH_C5=0 leaves it out,
     # QGD_BENCH_C5_N shrinks it (tests), QGD_BENCH_C5_IMPLICIT=1 adds the implicitDiffusion branch on the same mesh.
     if os.environ.get("QGD_BENCH_C5", "1") != "0":
         c5n = os.environ.get("QGD_BENCH_C5_N", "252")
         key = "qhd_c5" if c5n == "252" else f"qhd_c5_n{c5n}"
-        lines.append((key, ["--workload", "qhd", "--irregular", "--edge", c5n, "--steps", "20", "--warmup", "10"]))
+        lines.append((key, ["--workload", "qhd", "--irregular", "--edge", c5n, "--steps", "20", "--warmup", "20"]))
         if os.environ.get("QGD_BENCH_C5_IMPLICIT", "0") == "1":
-            lines.append((key + "_implicit", ["--workload", "qhd", "--irregular", "--implicit-diffusion", "--edge", c5n, "--steps", "20", "--warmup", "10"]))
+            lines.append((key + "_implicit", ["--workload", "qhd", "--irregular", "--implicit-diffusion", "--edge", c5n, "--steps", "20", "--warmup", "20"]))
     for key, argv in lines:
         if bench_deadline_s() - (time.perf_counter() - T_START) < 150.0:
             out[key] = {"error": "not started: less than 150 s left before QGD_BENCH_DEADLINE_S"}
