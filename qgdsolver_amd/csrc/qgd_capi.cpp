@@ -705,6 +705,7 @@ static int deviceCreate(qgd_mesh_t mh, int deviceId, int fusedChoice, qgd_device
         for (int k = 0; k < 3; ++k) v.emptyDir[k] = m.geometricD[k] < 0 ? 1 : 0;
         static const int kBlocks[] = {64, 128, 256}, kWaves[] = {2, 3, 4};
         v.xcdRun = envChoice("QGD_XCD_RUN", 16, nullptr, 0, 0, 1 << 20);   // 0: one contiguous eighth of the tiles per XCD
+        v.fuXcdRun = envChoice("QGD_FU_XCD_RUN", 64, nullptr, 0, 0, 1 << 20);   // (measured at 64 M cells: 4: 9.63, 16: 9.51-9.53, 64: 9.44, 256: 9.35-9.38 on one box; 16: 9.39, 64: 9.29-9.36, 1024: 9.38 on another)
         v.fblock = envChoice("QGD_FBLOCK", 128, kBlocks, 3);
         v.hasOther = 0;
         for (int64_t f = 0; f < s.nIF; ++f) if (s.fkind[f] == FK_OTHER) { v.hasOther = 1; break; }

@@ -73,6 +73,7 @@ struct MeshView {
     const int4* fuHdr; const int32_t* fuCells; const int32_t* fuVerts; const int32_t* fuFaceLabel; const uint8_t* fuNEntry;
     // a block's local topology sits in its template (fuHdr2[blk].y): 3 position words per face, the own cells' face entries, the vertices' cell positions
     const uint32_t* fuFacePos; const int32_t* fuEntry; int32_t fuTemplates;
+    int32_t fuXcdRun;        // QGD_FU_XCD_RUN (default 64): consecutive blocks dealt to one XCD before the next XCD's run (the face tiles' xcdRun is 16)
     int32_t fuLdsImpl, fuLdsCellImpl;   // the same two figures as fuLds / fuLdsCell for the implicitDiffusion branch's layout (+ 72 B of fvc::grad(U) per own / across-a-face cell, eight flux planes)
     int32_t fuCapPE, fuMaxTot, fuMaxAll, fuMaxV, fuMaxF;   // cells per vertex (stride); staged cells incl. / without the extra ones, vertices, faces: maxima over the blocks (information; a block lays its LDS out by its own counts)
     const int4* fuHdr2; const uint8_t* fuVCount; const uint16_t* fuVPos; const double* fuVW;   // the vertex values are formed inside the block

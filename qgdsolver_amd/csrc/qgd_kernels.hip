@@ -1160,7 +1160,7 @@ void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm, 
     // vertices; faces per thread; face entries of a cell / cells of a vertex held in registers
     static_assert(3 * kFusedCapTotDev <= KC * NT && 3 * kFusedCapCDev <= KCC * NT && 2 * kFusedCapCDev <= KB2 * NT && 3 * kFusedCapVDev <= KV * NT &&
                   kFusedCapFDev <= KF * NT && kFusedCapVDev <= NT, "caps");
-    const int blk = firstBlock + xcdTile((int)gridDim.x, m.xcdRun);
+    const int blk = firstBlock + xcdTile((int)gridDim.x, m.fuXcdRun);
     const int tid = (int)threadIdx.x;
     const int capC = m.fuCapC, capV = m.fuCapV, capF = m.fuCapF, capPE = m.fuCapPE;
     const int32_t* __restrict__ tCells = m.fuCells + (size_t)blk * capC;
