@@ -1151,6 +1151,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((IMPL && UP
 void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm, const int firstBlock, const ImplView iv,
                          const PatchBCDev* __restrict__ bcs) {
     extern __shared__ v2d tileLds[];
+#if QGD_FU_CLOCK   // timing probe (scripts/fused_phase_clock.py): where a block's lifetime goes, in shader-clock ticks, left in its cells' new records
+    const uint64_t tk0 = __builtin_readcyclecounter();
+    uint64_t tk1 = 0, tk2 = 0, tk3 = 0, tk4 = 0, tk5 = 0;
+#endif
 #if QGD_FU_PRIO
     __builtin_amdgcn_s_setprio(3);
 #endif
@@ -1204,6 +1208,10 @@ void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm, 
     // block's local topology out of its TEMPLATE (hdr2.y; qgd_setup.hpp FusedBlocks: the interior bricks of a structured region share a few
     // hundred templates, which stay in L2): the positions of this thread's two faces' cells and vertices in the staged lists, its cell's face
     // entries, its vertex's cell positions.  None of it is needed before the records are staged, so the template costs no round trip.
+#if QGD_FU_CLOCK
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (probe only: the two rounds one after the other, to time them apart)
+    tk1 = __builtin_readcyclecounter();
+#endif
     const size_t tpl = (size_t)hdr2.y;
     struct Pos3 { uint32_t c, va, vb; };
     const Pos3* __restrict__ tFacePos = reinterpret_cast<const Pos3*>(m.fuFacePos) + tpl * capF;
@@ -1272,6 +1280,9 @@ void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm, 
     for (int k = 0; k < KB2; ++k) { const int q = tid + k * NT; if (q < 2 * nUc) sB[q] = dB[k]; }
 #pragma unroll
     for (int k = 0; k < KV; ++k) { const int q = tid + k * NT; if (q < 3 * nUv) sX[q] = dX[k]; }
+#if QGD_FU_CLOCK
+    tk2 = __builtin_readcyclecounter();
+#endif
     __syncthreads();
 #if QGD_FU_PRIO == 2
     __builtin_amdgcn_s_setprio(0);
@@ -1311,6 +1322,9 @@ void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm, 
             for (int k = 0; k < 3; ++k) sP[3 * tid + k] = dPt[k];
         }
     }
+#if QGD_FU_CLOCK
+    tk3 = __builtin_readcyclecounter();
+#endif
     __syncthreads();
 #if QGD_FU_PRIO == 3
     __builtin_amdgcn_s_setprio(0);
@@ -1409,6 +1423,9 @@ void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm, 
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+#if QGD_FU_CLOCK
+    tk4 = __builtin_readcyclecounter();
+#endif
     __syncthreads();   // every face has read its vertex records and coordinates
     if constexpr (IMPL) {
         // The implicitDiffusion branch keeps the explicit step's LDS (three blocks per CU) by using the dead vertex region three times:
@@ -1530,24 +1547,48 @@ void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm, 
         }
     }
     __syncthreads();
+#if QGD_FU_CLOCK
+    tk5 = __builtin_readcyclecounter();
+#endif
     // (3) the block's own cells out of LDS
     double rmin = 1e300, emin = 1e300;
     if (tid < nOwn) {
         const size_t nF = (size_t)m.nF;
         double sum[5] = {0, 0, 0, 0, 0};
         const int nE = nEraw;
-        for (int i = 0; i < nE; ++i) {
-            const int e = (i < KE) ? sE[i * 128 + tid] : ent[(size_t)i * 128];
-            double fl[5];
-            if (e >= 0) {
+        int eq[KE];
 #pragma unroll
-                for (int k = 0; k < 5; ++k) fl[k] = sF[k * strideF + (e >> 1)];
-            } else {
+        for (int i = 0; i < KE; ++i) eq[i] = sE[i * 128 + tid];
+        bool inner = nE == KE;
 #pragma unroll
-                for (int k = 0; k < 5; ++k) fl[k] = c.flux[k * nF + (size_t)(~e)];
+        for (int i = 0; i < KE; ++i) inner = inner && eq[i] >= 0;
+        if (__ballot(!inner) == 0) {
+            // a wavefront of hexahedra away from the patches (cellUpdateKernel's first branch): the thirty flux terms in flight out of LDS before
+            // the ordered sums -- the loop below waits for every face's terms before it asks for the next face's
+            double x[KE][5];
+#pragma unroll
+            for (int i = 0; i < KE; ++i)
+#pragma unroll
+                for (int k = 0; k < 5; ++k) x[i][k] = sF[k * strideF + (eq[i] >> 1)];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < KE; ++i)
+#pragma unroll
+                for (int k = 0; k < 5; ++k) sum[k] = (eq[i] & 1) ? sum[k] - x[i][k] : sum[k] + x[i][k];
+        } else {
+            for (int i = 0; i < nE; ++i) {
+                const int e = (i < KE) ? sE[i * 128 + tid] : ent[(size_t)i * 128];
+                double fl[5];
+                if (e >= 0) {
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) fl[k] = sF[k * strideF + (e >> 1)];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) fl[k] = c.flux[k * nF + (size_t)(~e)];
+                }
+#pragma unroll
+                for (int k = 0; k < 5; ++k) sum[k] = (e < 0 || !(e & 1)) ? sum[k] + fl[k] : sum[k] - fl[k];
             }
-#pragma unroll
-            for (int k = 0; k < 5; ++k) sum[k] = (e < 0 || !(e & 1)) ? sum[k] + fl[k] : sum[k] - fl[k];
         }
         if constexpr (ADJ) {
 #pragma unroll
@@ -1558,6 +1599,15 @@ void fusedFaceCellKernel(const MeshView m, const CaseView c, const GasModel gm, 
             RecB Bn;
             double rEnew;
             advanceCell(c, gm, ci, A, rEold, Vc, hq, sum, An, Bn, rEnew);
+#if QGD_FU_CLOCK
+            {
+                asm volatile("" ::"v"(An.rho), "v"(An.e), "v"(Bn.muQGD), "v"(rEnew));
+                const uint64_t tk6 = __builtin_readcyclecounter();
+                // lists (round 0) | records (round 1) + staging | barrier + vertex values | barrier + faces | barriers + flux planes | sums + advanceCell
+                An.rho = (double)(tk1 - tk0); An.ux = (double)(tk2 - tk1); An.uy = (double)(tk3 - tk2); An.uz = (double)(tk4 - tk3);
+                An.p = (double)(tk5 - tk4); An.e = (double)(tk6 - tk5);
+            }
+#endif
             c.A2[ci] = An;
             c.B2[ci] = Bn;
             c.rE[ci] = rEnew;
