@@ -575,7 +575,10 @@ def qhd_line(args):
     else:
         mesh = q.PolyMesh.box(n, n, n)
     h = 1.0 / n
-    dev = q.Device(mesh, fused_tables=False)   # (the block tables of QGDFoam's fused explicit step: not this workload's)
+    # QGD_QHD_FUSED=1: the cell blocks of QGDFoam's one-launch step carry the explicit branch's U and T equations (qgd_qhd.hip; off by default --
+    # no gain measured); otherwise their tables are not this workload's
+    blocks = (not args.implicit_diffusion) and os.environ.get("QGD_QHD_FUSED", "0") == "1"
+    dev = q.Device(mesh, fused_tables=True if blocks else False)
     opt = qhdfoam.qhd_options(stencil="GaussVolPoint", tauModel="HbyUQHD", aQGD=0.5, UQHD=0.1, rho0=1.0, mu=1e-3, Pr=0.71, beta=3.4e-3,
                               g=(0.0, -9.81, 0.0), deltaT=0.02 * h / 0.1, pTol=1e-8, pMaxIter=300, pRefCell=0,
                               implicitDiffusion=1 if args.implicit_diffusion else 0, implicitTol=1e-10, implicitMaxIter=1000)
@@ -639,7 +642,7 @@ def qhd_line(args):
                    "cells": nc, "pressure_iterations_per_step": it, "multigrid_levels": info["mgLevels"],
                    "implicit_iterations": {k: v["iterations"] for k, v in impl["solves"].items()} if impl else None,
                    "implicit_unconverged_steps": impl["unconverged_steps"] if impl else None,
-                   "implicit_stalled_steps": impl["stalled_steps"] if impl else None, "env": qgd_env()},
+                   "implicit_stalled_steps": impl["stalled_steps"] if impl else None, "fused_step": case.fused_info(), "env": qgd_env()},
         "roofline": {"bound": "hbm", "kernel": "mgSmoothKernel<float>, multigrid level 0 (one damped-Jacobi sweep of the pressure preconditioner)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS if achieved else None,
                      "traffic": (secondary_traffic("qhd_n200") if (n == 200 and not args.irregular and not args.implicit_diffusion)

@@ -105,7 +105,7 @@ typedef struct qgd_case_s* qgd_case_t;     /* a QGDFoam case on one device      
 
 /* ---- library ---------------------------------------------------------------- */
 /* Bumped whenever an options struct grows or an entry changes its meaning (3: round 3). */
-#define QGD_ABI_VERSION 6
+#define QGD_ABI_VERSION 7
 const char* qgd_version(void);
 /* sizes[0..2] = sizeof(qgd_case_options), sizeof(qgd_qhd_options), sizeof(qgd_poisson_control) as THIS library was built,
  * sizes[3] = its QGD_ABI_VERSION: a host compiled against another header compares before it passes a struct (the structs
@@ -453,6 +453,13 @@ int qgd_qhd_case_get_field(qgd_qhd_case_t c, const char* name, double* out, int6
 /* info[0]=time, [1]=deltaT, [2..4]= iterations / initial / final normalised residual of the last pressure solve,
  * [5]=steps, [6]=multigrid levels, [7]=milliseconds of the last pressure solve */
 int qgd_qhd_case_info(qgd_qhd_case_t c, double info[8]);
+/* QGD_QHD_FUSED=1 (off by default: at 8 M cells the one launch takes what the three kernels take, profiles/r06_ab_qhd_fused_advance.txt):
+ * the U and T equations of the explicit branch [QHDUEqn_8H L36-84, QHDTEqn_8H L65-91] -- vertex values of p, face pass 2, explicit Euler
+ * update -- run as ONE launch on the cell blocks of QGDFoam's one-launch step (qgd_qhd.hip qhdFusedAdvanceKernel).  info[0] = bit 0: they do
+ * (bit 1 is reserved for the part in front of the pressure equation, not built); info[1] = blocks; info[2] = LDS bytes per workgroup;
+ * info[3] = 0.  Needs a device with block tables (qgd_device_create, or _with QGD_DEVICE_FUSED_ANY_BLOCKS), 3-D GaussVolPoint, an unsharded
+ * mesh, implicitDiffusion false; everything else keeps the separate kernels. */
+int qgd_qhd_case_fused_info(qgd_qhd_case_t c, int64_t info[4]);
 /* implicitDiffusion: the solve of the last step -- info[0..3] = iterations of Ux, Uy, Uz, T, [4..7] = initial, [8..11] = final
  * normalised residuals (what OpenFOAM prints as "Solving for Ux, Initial residual = ..."), [12] = steps since
  * qgd_qhd_case_set_fields in which a component stopped above implicitTol, [13] = 0 explicit branch | 1 conjugate gradients

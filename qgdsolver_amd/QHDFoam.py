@@ -25,7 +25,11 @@ def run(case_dir, n_steps=None, device_id=0, write=True, log=print):
     from .qhdfoam import QHDFoamCase, qhd_options
 
     mesh, opt, fields, bcs = ff.read_qhd_case_setup(case_dir, t0_name)
-    dev = Device(mesh, device_id, fv_schemes={"fvsc": {"default": opt["stencil"]}}, fused_tables=False)   # QHDFoam never runs QGDFoam's fused explicit step
+    # QGD_QHD_FUSED=1: the cell blocks of QGDFoam's one-launch step carry QHDFoam's explicit U and T equations on 3-D GaussVolPoint cases (off
+    # by default: no gain measured); otherwise QHDFoam has no use for their tables
+    blocks = (os.environ.get("QGD_QHD_FUSED", "0") == "1" and opt["stencil"] == "GaussVolPoint" and not opt.get("implicitDiffusion")
+              and mesh.nGeometricD == 3)
+    dev = Device(mesh, device_id, fv_schemes={"fvsc": {"default": opt["stencil"]}}, fused_tables=True if blocks else False)
     case = QHDFoamCase(dev, qhd_options(**opt))
     for i, bc in enumerate(bcs):
         case.set_bc(i, U=bc["U"], T=bc["T"], p=bc["p"])

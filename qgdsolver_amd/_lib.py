@@ -116,6 +116,7 @@ SIGNATURES = {
     "qgd_qhd_case_step": (C.c_int, [handle, C.c_int32]),
     "qgd_qhd_case_get_field": (C.c_int, [handle, C.c_char_p, c_double_p, C.c_int64]),
     "qgd_qhd_case_info": (C.c_int, [handle, c_double_p]),
+    "qgd_qhd_case_fused_info": (C.c_int, [handle, C.POINTER(C.c_int64)]),
     "qgd_qhd_case_implicit_info": (C.c_int, [handle, c_double_p]),
     "qgd_qhd_case_implicit_control": (C.c_int, [handle, c_double_p, C.c_int]),
     "qgd_qhd_case_implicit_control_ptr": (C.c_int, [handle, handle_p]),

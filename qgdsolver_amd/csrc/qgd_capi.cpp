@@ -2141,6 +2141,7 @@ struct qgd_qhd_case_s {
     PatchBCDev* bcDev = nullptr;
     DeviceArena arena;
     QhdView view{};
+    double* c4b = nullptr;      // QGD_QHD_FUSED: the second {U,T} array of the block-fused U / T equations (qgd_qhd.hip qhdFusedAdvanceKernel); swapped with view.c4 every step
     double *tauF = nullptr, *tbr = nullptr, *scratch = nullptr;
     uint8_t* bKind = nullptr;
     PressureSolver* solver = nullptr;
@@ -2200,6 +2201,9 @@ int qgd_qhd_case_create(qgd_device_t d, const qgd_qhd_options* opt, qgd_qhd_case
         q.implicit = opt->implicitDiffusion ? 1 : 0;
         q.upwindU = opt->fluxSchemeU == QGD_FLUX_UPWIND ? 1 : 0;
         q.upwindT = opt->fluxSchemeT == QGD_FLUX_UPWIND ? 1 : 0;
+        static const int kFusedOnOff[] = {0, 1};
+        // (off by default: measured at 8 M cells the one launch takes what the three kernels take -- profiles/r06_ab_qhd_fused_advance.txt)
+        if (envChoice("QGD_QHD_FUSED", 0, kFusedOnOff, 2) != 0 && qhdFusedAdvanceEligible(st, v, q, nullptr, nullptr)) c->c4b = a.alloc<double>(4 * nC);
         if (q.implicit) {
             q.aG = a.alloc<double>(nF); q.diag4 = a.alloc<double>(4 * nC); q.rhs4 = a.alloc<double>(4 * nC); q.x4 = a.alloc<double>(4 * nC);
             c->implSolver = implicitSolverCreate(d->stream, v, d->ownedBegin, d->ownedEnd);
@@ -2327,9 +2331,11 @@ static void qhdPhase(qgd_qhd_case_s* c, int phase) {
         case 7:
             pressureSolveFlux(c->solver, c->view.phi);
             if (!c->view.implicit)
-                launchQhdAdvance(d->stream, c->stencil, c->usesPoints, m, c->view, c->bcDev, c->needRef, c->localRefCell, c->opt.pRefValue,
-                                 pressureSolverCtl(c->solver) + 8);
-            else {
+            {
+                if (launchQhdAdvance(d->stream, c->stencil, c->usesPoints, m, c->view, c->bcDev, c->needRef, c->localRefCell, c->opt.pRefValue,
+                                     pressureSolverCtl(c->solver) + 8, c->c4b))
+                    std::swap(c->view.c4, c->c4b);   // the blocks wrote the new {U,T} into the second array
+            } else {
                 // implicitDiffusion: face pass 2 without the laplacians, the right-hand sides; the solve (phases 10..15) and phase 16 follow
                 implicitStepMark(c->implSolver, true);
                 launchQhdImplicitAdvance(d->stream, c->stencil, c->usesPoints, m, c->view, c->bcDev, 0, c->implMask, false, -1, 0.0, nullptr);
@@ -2622,6 +2628,14 @@ int qgd_qhd_case_info(qgd_qhd_case_t c, double info[8]) {
     info[0] = c->time; info[1] = c->opt.deltaT; info[2] = c->lastIter; info[3] = c->lastRes0; info[4] = c->lastRes; info[5] = (double)c->steps;
     info[6] = c->solver ? (double)pressureSolverLevels(c->solver, sizes, 16) : 0.0;
     info[7] = c->lastSolveMs;
+    return QGD_OK;
+}
+
+int qgd_qhd_case_fused_info(qgd_qhd_case_t c, int64_t info[4]) {
+    if (!c || !info) return fail(QGD_ERR_INVALID, "null argument");
+    info[0] = info[1] = info[2] = info[3] = 0;
+    int lds = 0;
+    if (c->c4b && qhdFusedAdvanceEligible(c->stencil, c->dev->view, c->view, &lds, nullptr)) { info[0] |= 1; info[1] = c->dev->view.fuBlocks; info[2] = lds; }
     return QGD_OK;
 }
 

@@ -308,8 +308,9 @@ void launchQhdInit(hipStream_t s, const MeshView& m, const QhdView& q, const Pat
 void launchQhdAssemble(hipStream_t s, int stencil, bool usesPoints, const MeshView& m, const QhdView& q, const PatchBCDev* bc);
 void launchQhdExtrapolateP(hipStream_t s, int nC, double* p, double* const hist[4], int have, int order);
 void launchQhdPostSolve(hipStream_t s, const MeshView& m, const QhdView& q, const PatchBCDev* bc);
-void launchQhdAdvance(hipStream_t s, int stencil, bool usesPoints, const MeshView& m, const QhdView& q, const PatchBCDev* bc, bool needRef,
-                      int localRefCell, double refValue, double* shift);
+bool launchQhdAdvance(hipStream_t s, int stencil, bool usesPoints, const MeshView& m, const QhdView& q, const PatchBCDev* bc, bool needRef,
+                      int localRefCell, double refValue, double* shift, double* c4new = nullptr);   // true: the new {U,T} are in c4new
+bool qhdFusedAdvanceEligible(int stencil, const MeshView& m, const QhdView& q, int* ldsBytes, int* ldsCell);
 void launchQhdFinish(hipStream_t s, const MeshView& m, const QhdView& q, bool needRef, const double* shift);
 // implicitDiffusion: the constant matrix (set-up), then per step part 0 = face pass 2 + right-hand sides and start values (the
 // solve of the four systems follows: implicitSolveSetup with gamma = {nu, nu, nu, Hi}), part 1 = the solution into the records,

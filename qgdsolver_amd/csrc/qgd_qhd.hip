@@ -435,6 +435,283 @@ __global__ __launch_bounds__(QGD_BLOCK) void qhdCellUpdateKernel(const MeshView 
     rec[3] = T + q.dt * (-(s[3] * rV));
 }
 
+// ---------------------------------------------------------------------------
+// QGD_QHD_FUSED: the U and T equations of a BLOCK of cells in one workgroup, on the cell blocks of QGDFoam's one-launch step (qgd_setup.hpp
+// FusedBlocks; qgd_kernels.hip fusedFaceCellKernel) -- the vertex values of p, face pass 2 and the explicit Euler update [QHDUEqn.H L36-84,
+// QHDTEqn.H L65-91] without the 8 B per vertex and the 2 x 32 B per face the three kernels hand each other through device memory.  A workgroup
+// (256 threads) stages {U,T}, fvc::grad(U) and the centres of its own + across-a-face cells, p of those and of the edge / corner cells around
+// its vertices, the vertex coordinates; thread v forms p at vertex v (pointInterpFastKernel's sum, out of LDS; a patch point takes
+// boundaryPointKernel's value); every thread computes the net terms of two of the block's internal faces (qhdFace2TileKernel's expressions);
+// the terms take the gradients' place in LDS and threads 0..127 advance one own cell each (qhdCellUpdateKernel's ordered sums; patch faces
+// from q.F, where qhdFace2Kernel put them).  The block reads the OLD {U,T} of its neighbours while other blocks write new ones: the update
+// goes to a second record array, the host swaps the two.  Unsharded cases, implicitDiffusion false.
+// ---------------------------------------------------------------------------
+constexpr int kQhdFuCapC = 320, kQhdFuCapV = 256, kQhdFuCapF = 512, kQhdFuCapTot = 384;   // = kFusedCap{C,V,F,Tot} of qgd_setup.hpp
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void qhdFusedAdvanceKernel(const MeshView m, const QhdView q, double* __restrict__ c4new, const int ldsCell) {
+    extern __shared__ v2d qhdLds[];
+    constexpr int NT = 256, KB2 = 3, KCC = 4, KG = 12, KPC = 2, KV = 3, KF = 2, KE = 6, KP = 8;
+    static_assert(2 * kQhdFuCapC <= KB2 * NT && 3 * kQhdFuCapC <= KCC * NT && 9 * kQhdFuCapC <= KG * NT && kQhdFuCapTot <= KPC * NT &&
+                  3 * kQhdFuCapV <= KV * NT && kQhdFuCapF <= KF * NT && kQhdFuCapV <= NT, "caps");
+    const int blk = xcdTile((int)gridDim.x, m.fuXcdRun);
+    const int tid = (int)threadIdx.x;
+    const int capC = m.fuCapC, capV = m.fuCapV, capF = m.fuCapF, capPE = m.fuCapPE;
+    const int32_t* __restrict__ tCells = m.fuCells + (size_t)blk * capC;
+    const int32_t* __restrict__ tVerts = m.fuVerts + (size_t)blk * capV;
+    const int32_t* __restrict__ tFaceLabel = m.fuFaceLabel + (size_t)blk * capF;
+    // (0) the lists: nothing here depends on a loaded value
+    const int4 hdr = m.fuHdr[blk];
+    const int4 hdr2 = m.fuHdr2[blk];
+    int fl[KF];
+#pragma unroll
+    for (int j = 0; j < KF; ++j) fl[j] = tFaceLabel[min(tid + j * NT, capF - 1)];
+    // the cell list goes through LDS: every thread reads two labels, the 21 piece indices below come out of LDS instead of 21 more loads
+    // (the CU's address unit is what a block's rounds of loads queue in: profiles/r06_fused_phase_clock.txt)
+    int* const sList = reinterpret_cast<int*>(reinterpret_cast<double*>(qhdLds) + ldsCell) + KE * 128;
+    int idP[KPC];
+#pragma unroll
+    for (int k = 0; k < KPC; ++k) idP[k] = tCells[min(tid + k * NT, capC - 1)];
+#pragma unroll
+    for (int k = 0; k < KPC; ++k) { if (tid + k * NT < capC) sList[tid + k * NT] = idP[k]; }
+    __syncthreads();
+    int idB[KB2], idC[KCC], idG[KG], idV[KV];
+#pragma unroll
+    for (int k = 0; k < KB2; ++k) { const int qq = tid + k * NT, r = qq >> 1; idB[k] = sList[min(r, capC - 1)] * 2 + (qq & 1); }
+#pragma unroll
+    for (int k = 0; k < KCC; ++k) { const int qq = tid + k * NT, r = (qq * 43691) >> 17; idC[k] = sList[min(r, capC - 1)] * 3 + (qq - 3 * r); }
+#pragma unroll
+    for (int k = 0; k < KG; ++k) { const int qq = tid + k * NT, r = qq / 9; idG[k] = sList[min(r, capC - 1)] * 9 + (qq - 9 * r); }
+#pragma unroll
+    for (int k = 0; k < KV; ++k) { const int qq = tid + k * NT, r = (qq * 43691) >> 17; idV[k] = tVerts[min(r, capV - 1)] * 3 + (qq - 3 * r); }
+    const int ci = sList[min(tid & 127, capC - 1)];
+    const int nEraw = (int)m.fuNEntry[(size_t)blk * 128 + (tid & 127)];
+    const int vt = min(tid, capV - 1);
+    const int myVert = tVerts[vt];
+    const int nPc = (int)m.fuVCount[(size_t)blk * capV + vt];
+    const double* __restrict__ vW = m.fuVW + (size_t)blk * capPE * capV + vt;
+    double pcW[KP];
+#pragma unroll
+    for (int i = 0; i < KP; ++i) pcW[i] = vW[(size_t)min(i, capPE - 1) * capV];
+    // (1) one round trip later: the records piece by piece, the faces' streams, the block's local topology out of its template
+    const size_t tpl = (size_t)hdr2.y;
+    struct Pos3 { uint32_t c, va, vb; };
+    const Pos3* __restrict__ tFacePos = reinterpret_cast<const Pos3*>(m.fuFacePos) + tpl * capF;
+    const int32_t* __restrict__ ent = m.fuEntry + tpl * m.fuCapE * 128 + (tid & 127);
+    const uint16_t* __restrict__ vPos = m.fuVPos + tpl * capPE * capV + vt;
+    Pos3 fp[KF];
+#pragma unroll
+    for (int j = 0; j < KF; ++j) fp[j] = tFacePos[min(tid + j * NT, capF - 1)];
+    int e6[KE];
+#pragma unroll
+    for (int i = 0; i < KE; ++i) e6[i] = ent[(size_t)min(i, m.fuCapE - 1) * 128];
+    int pcPos[KP];
+#pragma unroll
+    for (int i = 0; i < KP; ++i) pcPos[i] = (int)vPos[(size_t)min(i, capPE - 1) * capV];
+    v2d d4[KB2];
+    double dC[KCC], dG[KG], dP[KPC], dX[KV];
+    const v2d* __restrict__ g4 = reinterpret_cast<const v2d*>(q.c4);
+#pragma unroll
+    for (int k = 0; k < KB2; ++k) d4[k] = g4[idB[k]];
+#pragma unroll
+    for (int k = 0; k < KCC; ++k) dC[k] = m.Cc[idC[k]];
+#pragma unroll
+    for (int k = 0; k < KG; ++k) dG[k] = q.gUc[idG[k]];
+#pragma unroll
+    for (int k = 0; k < KPC; ++k) dP[k] = q.p[idP[k]];
+#pragma unroll
+    for (int k = 0; k < KV; ++k) dX[k] = m.X[idV[k]];
+    const size_t nF = (size_t)m.nF;
+    const double Vc = m.V[ci];
+    double dPt = 0.0;
+    if (nPc == 0) dPt = q.ptp[myVert];   // a patch point: boundaryPointKernel has put its value there
+    __builtin_amdgcn_sched_barrier(0);
+    const int nOwn = hdr.x, nUc = hdr.y, nUv = hdr.z, nFc = hdr.w, nTot = hdr2.x;
+    // LDS by THIS block's counts: {U,T}, fvc::grad(U) (the four planes of net terms take their place once every face is done), centres, p, vertex
+    // coordinates, vertex p; the own cells' parked face entries at a fixed place behind
+    const int nG = max(9 * nUc, 4 * nFc);
+    v2d* const s4 = qhdLds;                                        // 2 nUc pieces
+    double* const sG = reinterpret_cast<double*>(s4 + 2 * nUc);    // 9 nUc
+    double* const sC = sG + nG;                                    // 3 nUc
+    double* const sp = sC + 3 * nUc;                               // nTot
+    double* const sX = sp + nTot;                                  // 3 nUv
+    double* const sq = sX + 3 * nUv;                               // nUv
+    double* const sF = sG;
+    int* const sE = reinterpret_cast<int*>(reinterpret_cast<double*>(qhdLds) + ldsCell);
+    const int strideF = nFc;
+    if (tid < 128) {
+#pragma unroll
+        for (int i = 0; i < KE; ++i) sE[i * 128 + tid] = e6[i];
+    }
+#pragma unroll
+    for (int k = 0; k < KB2; ++k) { const int qq = tid + k * NT; if (qq < 2 * nUc) s4[qq] = d4[k]; }
+#pragma unroll
+    for (int k = 0; k < KCC; ++k) { const int qq = tid + k * NT; if (qq < 3 * nUc) sC[qq] = dC[k]; }
+#pragma unroll
+    for (int k = 0; k < KG; ++k) { const int qq = tid + k * NT; if (qq < 9 * nUc) sG[qq] = dG[k]; }
+#pragma unroll
+    for (int k = 0; k < KPC; ++k) { const int qq = tid + k * NT; if (qq < nTot) sp[qq] = dP[k]; }
+#pragma unroll
+    for (int k = 0; k < KV; ++k) { const int qq = tid + k * NT; if (qq < 3 * nUv) sX[qq] = dX[k]; }
+    __builtin_amdgcn_sched_barrier(0);
+    // the first face's streams are asked for now that the staging registers are free, and arrive behind the vertex values; the second face's
+    // in the middle of the first face (two faces' streams next to one face's algebra do not fit three waves per SIMD)
+    struct FaceStreams { double w, dn, magS, S[3], tau, phi, phitr, ugu[3]; int kind; };
+    auto loadStreams = [&](FaceStreams& t, const int f) {
+        t.w = ldStream(m.w + f); t.dn = ldStream(m.dn + f); t.magS = ldStream(m.magSf + f);
+        t.S[0] = ldStream(m.Sx + f); t.S[1] = ldStream(m.Sy + f); t.S[2] = ldStream(m.Sz + f);
+        t.tau = ldStream(q.tauF + f); t.phi = q.phi[f]; t.phitr = q.phitr[f];
+        t.ugu[0] = q.ugu[f]; t.ugu[1] = q.ugu[nF + f]; t.ugu[2] = q.ugu[2 * nF + f];
+        t.kind = m.fkind[f];
+    };
+    FaceStreams st[KF];
+    loadStreams(st[0], fl[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    // (1b) p at the vertices [volPointInterpolation: pointInterpFastKernel's sum in pointCells order, out of the staged cells]
+    if (tid < nUv) {
+        double acc = 0.0;
+        if (__ballot(nPc != KP) == 0) {
+#pragma unroll
+            for (int i = 0; i < KP; ++i) acc += pcW[i] * sp[pcPos[i]];
+        } else if (nPc > 0) {
+            for (int i = 0; i < nPc; ++i) {
+                int pos = 0;
+                double w = 0.0;
+                if (i < KP) {
+#pragma unroll
+                    for (int u = 0; u < KP; ++u) { pos = (i == u) ? pcPos[u] : pos; w = (i == u) ? pcW[u] : w; }
+                } else {
+                    pos = (int)vPos[(size_t)i * capV];
+                    w = vW[(size_t)i * capV];
+                }
+                acc += w * sp[pos];
+            }
+        } else acc = dPt;
+        sq[tid] = acc;
+    }
+    __syncthreads();
+    // (2) the faces: qhdFace2TileKernel's expressions, the net terms into registers
+    auto l3 = [](const double* p, int i) { return make_double4(p[3 * i], p[3 * i + 1], p[3 * i + 2], 0.0); };
+    auto l4 = [](const v2d* p, int i, double* o) { const v2d a = p[2 * i], b = p[2 * i + 1]; o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y; };
+    double out[KF][4];
+#pragma unroll
+    for (int j = 0; j < KF; ++j) {
+        const int lf = tid + j * NT;
+        if (lf < nFc) {
+            const int f = fl[j], kind = st[j].kind;
+            const int lo = (int)(fp[j].c & 0xffffu), ln = (int)(fp[j].c >> 16);
+            const int v0 = (int)(fp[j].va & 0xffffu), v1 = (int)(fp[j].va >> 16), v2 = (int)(fp[j].vb & 0xffffu), v3 = (int)(fp[j].vb >> 16);
+            if (kind == 3) {
+                out[j][0] = out[j][1] = out[j][2] = out[j][3] = 0.0;
+                if (j + 1 < KF) loadStreams(st[j + 1], fl[j + 1]);
+            } else {
+                const double w = st[j].w, dn = st[j].dn, magS = st[j].magS, tau = st[j].tau, phi = st[j].phi, phitr = st[j].phitr;
+                const double S[3] = {st[j].S[0], st[j].S[1], st[j].S[2]};
+                double o4[4], n4[4];
+                l4(s4, lo, o4); l4(s4, ln, n4);
+                const double Uo[3] = {o4[0], o4[1], o4[2]}, Un[3] = {n4[0], n4[1], n4[2]}, To = o4[3], Tn = n4[3];
+                FaceVals<1> vp;
+                vp.o[0] = sp[lo]; vp.n[0] = sp[ln]; vp.sn[0] = 0.0;
+                double snU[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) snU[k] = dn * (Un[k] - Uo[k]);   // fvc::snGrad, uncorrected (L0)
+                const double snT = dn * (Tn - To);
+                const double pf = lerpf(w, vp.o[0], vp.n[0]);
+                double gUT[9];   // T(grad U) at the face: gUT[3i+j] = lin(gradU)[3j+i]
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 3; ++jj) gUT[3 * i + jj] = lerpf(w, sG[9 * lo + 3 * jj + i], sG[9 * ln + 3 * jj + i]);
+                double gP[3];
+                if (kind == 2) faceGradient<ST_GVP3, 1, -1>(m, f, vp, q.p, q.ptp, gP);
+                else gvp3GradCore<1, -1>(kind, true, l3(sC, lo), l3(sC, ln), l3(sX, v0), l3(sX, v1), l3(sX, v2), l3(sX, v3), vp.o, vp.n, sq + v0, sq + v1,
+                                         sq + v2, sq + v3, gP);                                      // QHDUEqn.H L36
+                if (j + 1 < KF) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    loadStreams(st[j + 1], fl[j + 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                double Uf[3], Wf[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    Uf[k] = lerpf(w, Uo[k], Un[k]);
+                    const double Bf = lerpf(w, (q.beta * To) * q.g[k], (q.beta * Tn) * q.g[k]);   // BdFrcf [updateFields.H L66-67], as in face pass 1
+                    Wf[k] = tau * ((st[j].ugu[k] + gP[k] / q.rho0) - Bf);   // L37
+                }
+                const double Tf = lerpf(w, To, Tn);
+#pragma unroll
+                for (int jj = 0; jj < 3; ++jj) {
+                    const double uw = S[0] * (Uf[0] * Wf[jj]) + S[1] * (Uf[1] * Wf[jj]) + S[2] * (Uf[2] * Wf[jj]);   // Sf & (Uf*Wf), L39
+                    const double phiUf = phi * (q.upwindU ? lerpf(phi >= 0.0 ? 1.0 : 0.0, Uo[jj], Un[jj]) : Uf[jj]) - uw;   // L41-43
+                    const double lap = q.nu * snU[jj] * magS;                                                      // fvc::laplacian(muf/rhof, U), L74
+                    const double ext = S[0] * gUT[0 * 3 + jj] + S[1] * gUT[1 * 3 + jj] + S[2] * gUT[2 * 3 + jj];   // Sf & lin(T(grad U)), L56 / L76
+                    out[j][jj] = ((phiUf - lap) - q.nu * ext) + (S[jj] * pf) / q.rho0;
+                }
+                const double phiTf = phi * (q.upwindT ? lerpf(phi >= 0.0 ? 1.0 : 0.0, To, Tn) : Tf);
+                out[j][3] = (phiTf - q.Hi * snT * magS) - phitr;   // QHDTEqn.H L65-66, L85-88
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();   // every face has read its gradients: the planes of net terms take their place
+#pragma unroll
+    for (int j = 0; j < KF; ++j) {
+        const int lf = tid + j * NT;
+        if (lf < nFc) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sF[k * strideF + lf] = out[j][k];
+        }
+    }
+    __syncthreads();
+    // (3) the block's own cells [QHDUEqn.H L68-84, QHDTEqn.H L83-91]: qhdCellUpdateKernel's ordered sums (ascending face label) and update
+    if (tid < nOwn) {
+        double s[4] = {0, 0, 0, 0};
+        const int nE = nEraw;
+        int eq[KE];
+#pragma unroll
+        for (int i = 0; i < KE; ++i) eq[i] = sE[i * 128 + tid];
+        bool inner = nE == KE;
+#pragma unroll
+        for (int i = 0; i < KE; ++i) inner = inner && eq[i] >= 0;
+        if (__ballot(!inner) == 0) {
+            double x[KE][4];
+#pragma unroll
+            for (int i = 0; i < KE; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) x[i][k] = sF[k * strideF + (eq[i] >> 1)];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < KE; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s[k] = (eq[i] & 1) ? s[k] - x[i][k] : s[k] + x[i][k];
+        } else {
+            for (int i = 0; i < nE; ++i) {
+                const int e = (i < KE) ? sE[i * 128 + tid] : ent[(size_t)i * 128];
+                double x[4];
+                if (e >= 0) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) x[k] = sF[k * strideF + (e >> 1)];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) x[k] = q.F[(size_t)k * nF + (size_t)(~e)];   // a patch face: the owner's side, plus
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s[k] = (e < 0 || !(e & 1)) ? s[k] + x[k] : s[k] - x[k];
+            }
+        }
+        const double rV = 1.0 / Vc;
+        double rec[4];
+        l4(s4, tid, rec);
+        const double T = rec[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) rec[k] += q.dt * (-(s[k] * rV) + (q.beta * T) * q.g[k]);   // BdFrc = beta*T*g of updateFields.H L66
+        rec[3] = T + q.dt * (-(s[3] * rV));
+        v2d* const dst = reinterpret_cast<v2d*>(c4new) + 2 * (size_t)ci;
+        dst[0] = v2d{rec[0], rec[1]};
+        dst[1] = v2d{rec[2], rec[3]};
+    }
+}
+
 // ---- implicitDiffusion [QHDUEqn.H L46-65, QHDTEqn.H L69-80] ------------------------------------------------------------------------
 // patch coefficients of -fvm::laplacian(gamma, x) on owner-side boundary face f (L0): fixedValue: internal delta, source delta*value;
 // basicSymmetry (slip, U only): internal delta*|n_k|, source snGrad_k + delta*|n_k|*patchInternalField_k (transformFvPatchField);
@@ -783,8 +1060,31 @@ void launchQhdPostSolve(hipStream_t s, const MeshView& m, const QhdView& q, cons
 }
 // the U and T equations (phi must be there: pressureSolveFlux).  shift (device, 1 double) receives this rank's share of the
 // reference-level shift of p [QHDFoam.C L123-130]: pRefValue - p[refCell] on the rank that owns refCell (localRefCell >= 0), else 0
-void launchQhdAdvance(hipStream_t s, int stencil, bool usesPoints, const MeshView& m, const QhdView& q, const PatchBCDev* bc, bool needRef,
-                      int localRefCell, double refValue, double* shift) {
+// c4new != nullptr (qhdFusedAdvanceEligible): vertex values of p, internal faces and the cell update are ONE launch on the cell blocks; the new
+// {U,T} land in c4new and the caller swaps it with q.c4
+bool qhdFusedAdvanceEligible(int stencil, const MeshView& m, const QhdView& q, int* ldsBytes, int* ldsCell) {
+    if (stencil != ST_GVP3 || m.fuBlocks <= 0 || m.fuHdr == nullptr || m.fuHdr2 == nullptr || m.ghost != nullptr || q.implicit || m.nGeomD != 3) return false;
+    if (m.fuMaxAll > kQhdFuCapC || m.fuMaxTot > kQhdFuCapTot || m.fuMaxV > kQhdFuCapV || m.fuMaxF > kQhdFuCapF) return false;
+    const int cell = 7 * m.fuMaxAll + std::max(9 * m.fuMaxAll, 4 * m.fuMaxF) + m.fuMaxTot + 4 * m.fuMaxV;
+    const int lds = 8 * cell + 6 * 128 * 4 + 4 * m.fuCapC;   // records, the own cells' parked face entries, the cell list
+    if (lds > 65536) return false;
+    if (ldsBytes) *ldsBytes = lds;
+    if (ldsCell) *ldsCell = cell;
+    return true;
+}
+bool launchQhdAdvance(hipStream_t s, int stencil, bool usesPoints, const MeshView& m, const QhdView& q, const PatchBCDev* bc, bool needRef,
+                      int localRefCell, double refValue, double* shift, double* c4new) {
+    int lds = 0, ldsCell = 0;
+    if (c4new && qhdFusedAdvanceEligible(stencil, m, q, &lds, &ldsCell)) {
+        if (m.nBP) boundaryPointKernel<1><<<gridOf(m.nBP), QGD_BLOCK, 0, s>>>(m, q.pb, 1, q.ptp, 1, 0, -1);
+        if (m.nBF > 0) qhdFace2Kernel<ST_GVP3><<<gridOf(m.nBF), QGD_BLOCK, 0, s>>>(m, q, bc, nullptr, m.nIF);
+        qhdFusedAdvanceKernel<<<m.fuBlocks, 256, lds, s>>>(m, q, c4new, ldsCell);
+        QhdView q2 = q;
+        q2.c4 = c4new;
+        if (m.nBF) qhdBcKernel<<<gridOf(m.nBF), QGD_BLOCK, 0, s>>>(m, q2, bc);
+        if (needRef) qhdRefReadKernel<<<1, 1, 0, s>>>(q2, localRefCell, refValue, shift);
+        return true;
+    }
     if (usesPoints) {
         pointInterpFastKernel<1><<<gridOf(m.nP), QGD_BLOCK, 0, s>>>(m, q.p, q.ptp);
         if (m.nBP) boundaryPointKernel<1><<<gridOf(m.nBP), QGD_BLOCK, 0, s>>>(m, q.pb, 1, q.ptp, 1, 0, -1);
@@ -798,6 +1098,7 @@ void launchQhdAdvance(hipStream_t s, int stencil, bool usesPoints, const MeshVie
     qhdCellUpdateKernel<<<gridOf(m.nC), QGD_BLOCK, 0, s>>>(m, q);
     if (m.nBF) qhdBcKernel<<<gridOf(m.nBF), QGD_BLOCK, 0, s>>>(m, q, bc);
     if (needRef) qhdRefReadKernel<<<1, 1, 0, s>>>(q, localRefCell, refValue, shift);
+    return false;
 }
 void launchQhdImplicitMatrix(hipStream_t s, const MeshView& m, const QhdView& q, const PatchBCDev* bc) {
     qhdImplicitFaceCoefKernel<<<gridOf(m.nF), QGD_BLOCK, 0, s>>>(m, q);

@@ -301,6 +301,12 @@ class QHDFoamCase:
         return dict(time=a[0], deltaT=a[1], pIterations=int(a[2]), pInitialResidual=a[3], pFinalResidual=a[4], steps=int(a[5]),
                     mgLevels=int(a[6]), pSolveMs=a[7])
 
+    def fused_info(self):
+        """which parts of the step run on the cell blocks of QGDFoam's one-launch step (qgd_qhd_case_fused_info)"""
+        a = (C.c_int64 * 4)()
+        L.check(L.lib.qgd_qhd_case_fused_info(self._h, a), "qgd_qhd_case_fused_info")
+        return dict(fusedAdvance=bool(a[0] & 1), fusedAssemble=bool(a[0] & 2), blocks=int(a[1]), ldsAdvance=int(a[2]), ldsAssemble=int(a[3]))
+
     @property
     def _h(self):
         return self._handle.value
