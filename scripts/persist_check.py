@@ -1,5 +1,5 @@
 """QGD_FU_PERSIST (the plain explicit step as a persistent launch: each workgroup takes block after block, the next block's lists fetched during
-this block's cell update) against one workgroup per block: the same states bit for bit after a few steps on an n^3 box and on a box whose edges
+this block's cell update; a PROBE, not in the product: apply scripts/probes/fused_persistent_probe_r06.patch first) against one workgroup per block: the same states bit for bit after a few steps on an n^3 box and on a box whose edges
 the bricks do not divide.    python scripts/persist_check.py [n=128] [steps=5]"""
 import os
 import sys
