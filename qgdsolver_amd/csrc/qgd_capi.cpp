@@ -660,6 +660,7 @@ int qgd_mesh_halo_slots(qgd_mesh_t mh, int32_t* nSlots) {
 
 // ---- device ----------------------------------------------------------------------
 static int deviceCreate(qgd_mesh_t mh, int deviceId, int fusedChoice, qgd_device_t* out);
+static double nowMs();
 int qgd_device_create(qgd_mesh_t mh, int deviceId, qgd_device_t* out) { return deviceCreate(mh, deviceId, -1, out); }
 int qgd_device_create_with(qgd_mesh_t mh, int deviceId, int32_t flags, qgd_device_t* out) {
     if (flags & ~(QGD_DEVICE_NO_FUSED_TABLES | QGD_DEVICE_FUSED_ANY_BLOCKS)) return fail(QGD_ERR_INVALID, "qgd_device_create_with: unknown flag");
@@ -678,7 +679,17 @@ static int deviceCreate(qgd_mesh_t mh, int deviceId, int fusedChoice, qgd_device
     HIP_CHECK(hipSetDevice(deviceId));
     const HostMesh& m = mh->m;
     if (m.patches.size() > QGD_MAX_PATCHES) return fail(QGD_ERR_INVALID, "too many patches");
+    // QGD_SETUP_TIMING=1: where the device's set-up time goes, stage by stage, on stderr
+    const bool stageTiming = std::getenv("QGD_SETUP_TIMING") && std::atoi(std::getenv("QGD_SETUP_TIMING")) != 0;
+    double stageT0 = nowMs();
+    auto stage = [&](const char* what) {
+        if (!stageTiming) return;
+        const double t = nowMs();
+        std::fprintf(stderr, "qgd_device_create: %-44s %8.2f s\n", what, (t - stageT0) * 1e-3);
+        stageT0 = t;
+    };
     StaticData s = buildStaticData(m);
+    stage("static tables on the host (buildStaticData)");
     qgd_device_s* d = new qgd_device_s();
     try {
         d->deviceId = deviceId;
@@ -763,7 +774,9 @@ static int deviceCreate(qgd_mesh_t mh, int deviceId, int fusedChoice, qgd_device
             // 2: whatever the blocks look like (tests, probes); the caller's explicit choice (qgd_device_create_with) wins over the environment
             const int fusedMode = fusedChoice >= 0 ? fusedChoice : envChoice("QGD_FUSED", 1, kFusedModes, 3);
             if (fusedMode != 0) {
+                stage("face tiles (build + upload)");
                 FusedBlocks fb = buildFusedBlocks(s);
+                stage("cell blocks of the fused step (build)");
                 // LDS per workgroup: RecA of every staged cell, RecB of the own + across-a-face cells, then vertex records + all coordinates,
                 // later overwritten by the fluxes (FusedBlocks::maxLds); then the parked face entries of the own cells
                 const int64_t ldsRec = fb.maxLds;   // the block that needs most; every block lays its records out by its own counts
@@ -804,6 +817,7 @@ static int deviceCreate(qgd_mesh_t mh, int deviceId, int fusedChoice, qgd_device
                 }
             }
         }
+        stage("block tables (upload) / up to the static tables");
         v.own = up(s.own); v.nei = up(s.nei);
         v.verts = reinterpret_cast<const int4*>(up(s.verts));
         v.fkind = up(s.fkind);
@@ -856,6 +870,7 @@ static int deviceCreate(qgd_mesh_t mh, int deviceId, int fusedChoice, qgd_device
         delete d;
         throw;
     }
+    stage("static tables (upload), halo lists");
     *out = d;
     return QGD_OK;
     QGD_CATCH
