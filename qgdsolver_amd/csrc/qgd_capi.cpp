@@ -698,7 +698,7 @@ static int deviceCreate(qgd_mesh_t mh, int deviceId, int fusedChoice, qgd_device
         d->wedgePrism = hasWedgeAndPrism(m);
         d->patches = m.patches;
         residentCasePatchCheck(m, d->caseRefusal, d->caseRefusalCode);
-        d->hf = s.hf;
+        d->hf.assign(s.hf.begin(), s.hf.end());
         const bool range = m.ownedEnd > m.ownedBegin;
         d->ownedBegin = range ? m.ownedBegin : 0;
         d->ownedEnd = range ? m.ownedEnd : m.nCells;

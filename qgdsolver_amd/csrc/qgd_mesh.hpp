@@ -95,6 +95,7 @@ struct Csr {
 
 // point -> cells, each row in ascending cell label (OpenFOAM pointCells order)
 Csr buildPointCells(const HostMesh& m);
+Csr buildPointCells(const HostMesh& m, const Csr& cellFaces);   // ... with buildCellFaces(m) at hand
 // cell -> faces, ascending face label; used both for h_QGD and for the
 // deterministic flux gather (== summation order of fvc::surfaceIntegrate)
 Csr buildCellFaces(const HostMesh& m);

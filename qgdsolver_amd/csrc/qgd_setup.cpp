@@ -34,31 +34,42 @@ inline void cross(const double* a, const double* b, double* c) {
 }  // namespace
 
 // CSR (off, items[, weights]) -> sliced ELL with 64-row slices
+template <class VI, class VW>
 static void toSlicedEll(const std::vector<int32_t>& off, int64_t nRows, const std::vector<int32_t>& items,
                         const std::vector<double>* weights, std::vector<int32_t>& slice, std::vector<uint8_t>& count,
-                        std::vector<int32_t>& ellItems, std::vector<double>* ellW, int32_t padItem) {
+                        VI& ellItems, VW* ellW, int32_t padItem) {
     const int64_t nSlices = (nRows + 63) / 64;
     slice.assign((size_t)nSlices + 1, 0);
-    count.assign((size_t)nRows, 0);
+    count.resize((size_t)nRows);
+    std::vector<int32_t> width((size_t)nSlices, 0);
+    bool tooLong = false;
+#pragma omp parallel for schedule(static) reduction(|| : tooLong)
     for (int64_t s = 0; s < nSlices; ++s) {
-        int32_t width = 0;
+        int32_t w = 0;
         for (int64_t r = 64 * s; r < std::min<int64_t>(nRows, 64 * s + 64); ++r) {
             const int32_t n = off[r + 1] - off[r];
-            if (n > 255) throw std::invalid_argument("gather row longer than 255 entries");
-            count[r] = (uint8_t)n;
-            width = std::max(width, n);
+            tooLong = tooLong || n > 255;
+            count[r] = (uint8_t)std::min(n, 255);
+            w = std::max(w, n);
         }
-        slice[s + 1] = slice[s] + width;
+        width[s] = w;
     }
-    ellItems.assign((size_t)slice[nSlices] * 64, padItem);
-    if (ellW) ellW->assign((size_t)slice[nSlices] * 64, 0.0);
+    if (tooLong) throw std::invalid_argument("gather row longer than 255 entries");
+    for (int64_t s = 0; s < nSlices; ++s) slice[s + 1] = slice[s] + width[s];
+    // (the padded tables are GBs at 64 M cells: every slice -- entries and padding -- is written, and so first touched, by the thread that owns it)
+    ellItems.resize((size_t)slice[nSlices] * 64);
+    if (ellW) ellW->resize((size_t)slice[nSlices] * 64);
 #pragma omp parallel for schedule(static)
-    for (int64_t r = 0; r < nRows; ++r) {
-        const int64_t s = r >> 6, lane = r & 63;
-        for (int32_t i = 0; i < off[r + 1] - off[r]; ++i) {
-            const size_t dst = ((size_t)slice[s] + i) * 64 + lane;
-            ellItems[dst] = items[off[r] + i];
-            if (ellW) (*ellW)[dst] = (*weights)[off[r] + i];
+    for (int64_t s = 0; s < nSlices; ++s) {
+        const int64_t r0 = 64 * s, r1 = std::min<int64_t>(nRows, r0 + 64);
+        for (int32_t i = 0; i < width[s]; ++i) {
+            const size_t row = ((size_t)slice[s] + i) * 64;
+            for (int64_t lane = 0; lane < 64; ++lane) {
+                const int64_t r = r0 + lane;
+                const bool on = r < r1 && i < off[r + 1] - off[r];
+                ellItems[row + lane] = on ? items[off[r] + i] : padItem;
+                if (ellW) (*ellW)[row + lane] = on ? (*weights)[off[r] + i] : 0.0;
+            }
         }
     }
 }
@@ -184,6 +195,15 @@ static void buildPointConstraints(const HostMesh& m, const std::vector<int32_t>&
 
 StaticData buildStaticData(const HostMesh& m) {
     StaticData s;
+    // QGD_SETUP_TIMING=1: this function's sections on stderr (qgd_device_create prints its own stages)
+    const bool stageTiming = std::getenv("QGD_SETUP_TIMING") && std::atoi(std::getenv("QGD_SETUP_TIMING")) != 0;
+    auto stageClock = std::chrono::steady_clock::now();
+    auto stage = [&](const char* what) {
+        if (!stageTiming) return;
+        const auto t = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "  buildStaticData: %-40s %8.2f s\n", what, std::chrono::duration<double>(t - stageClock).count());
+        stageClock = t;
+    };
     s.nP = m.nPoints; s.nF = m.nFaces; s.nIF = m.nInternalFaces; s.nC = m.nCells; s.nBF = m.nBoundaryFaces();
     s.nGeomD = m.nGeometricD;
     const int64_t nF = s.nF, nIF = s.nIF, nC = s.nC, nBF = s.nBF;
@@ -203,27 +223,25 @@ StaticData buildStaticData(const HostMesh& m) {
     auto hasFields = [&](int64_t b) { return patchType[b] != QGD_PATCH_EMPTY; };
 
     // ---- faces: topology + streamed geometry --------------------------------
-    s.own = m.owner;
-    s.nei = m.neighbour;
-    s.verts.assign(4 * (size_t)nF, -1);
-    s.fkind.assign((size_t)nF, FK_QUAD);
+    parallelCopy(s.own, m.owner);
+    parallelCopy(s.nei, m.neighbour);
+    s.verts.resize(4 * (size_t)nF);   // (every entry of these is written by the parallel loop below)
+    s.fkind.resize((size_t)nF);
     for (int k = 0; k < 3; ++k) s.Sf[k].resize((size_t)nF);
-    s.magSf = m.magSf;
-    s.w = m.weights;
-    s.hf.assign((size_t)nF, 0.0);
-    s.dn.assign((size_t)nF, 0.0);
+    parallelCopy(s.magSf, m.magSf);
+    parallelCopy(s.w, m.weights);
+    s.hf.resize((size_t)nF);
+    s.dn.resize((size_t)nF);
     bool hasTri = false;
-    for (int64_t f = 0; f < nF; ++f) {
-        const int n = m.faceSize((int32_t)f);
-        if (n == 3) hasTri = true;
-    }
+#pragma omp parallel for schedule(static) reduction(|| : hasTri)
+    for (int64_t f = 0; f < nF; ++f) hasTri = hasTri || m.faceSize((int32_t)f) == 3;
     s.hasTri = hasTri;
     const bool want3D = (m.nGeometricD == 3);
     if (want3D) {
         s.bmvON.assign((size_t)nBF, 0.0);
         s.bN.assign(4 * (size_t)nBF, 0.0);
-        s.X = m.points;
-        s.Cc = m.C;
+        parallelCopy(s.X, m.points);
+        parallelCopy(s.Cc, m.C);
     }
 
     // hQGDf of cut-plane faces as the unsharded mesh has it (HostMesh::haloFaceH), by boundary-face index; -1: not given
@@ -273,9 +291,10 @@ StaticData buildStaticData(const HostMesh& m) {
         uint8_t kind = (n == 4) ? FK_QUAD : (n == 3 ? FK_TRI : FK_OTHER);
         if (skip) kind = FK_SKIP;
         s.fkind[f] = kind;
-        for (int q = 0; q < std::min(n, 4); ++q) s.verts[4 * f + q] = fp[q];
+        for (int q = 0; q < 4; ++q) s.verts[4 * f + q] = q < n ? fp[q] : -1;
     }
 
+    stage("faces: topology + streamed geometry");
     // ---- GaussVolPoint 2-D -----------------------------------------------------
     if (m.nGeometricD == 2) {
         int ie3 = 2;
@@ -323,9 +342,12 @@ StaticData buildStaticData(const HostMesh& m) {
         }
     }
 
+    stage("GaussVolPoint 2-D");
     // ---- adjacency ---------------------------------------------------------------
-    Csr pc = buildPointCells(m);
+    Csr cf = buildCellFaces(m);   // (once: the point-cell lists and the cells' gather lists below both walk it)
+    Csr pc = buildPointCells(m, cf);
 
+    stage("adjacency");
     // ---- leastSquares (allowed on 1-D/2-D meshes only [fvsc.C L60-63]) -------
     s.lsqBndZero.assign((size_t)nBF, 0);
     for (int64_t b = 0; b < nBF; ++b) {
@@ -400,6 +422,7 @@ StaticData buildStaticData(const HostMesh& m) {
         toSlicedEll(lsqOff, nIF, lsqCellCsr, &gwCsr[2], s.lsqSlice, s.lsqCnt, dupCells, &s.lsqGz, 0);
     }
 
+    stage("leastSquares");
     // ---- vertex interpolation ------------------------------------------------------
     std::vector<uint8_t> isPatchPoint((size_t)m.nPoints, 0);
     for (int64_t b = 0; b < nBF; ++b) {
@@ -478,23 +501,25 @@ StaticData buildStaticData(const HostMesh& m) {
         buildPointConstraints(m, slot, s);
     }
 
+    stage("vertex interpolation");
     // ---- cells ---------------------------------------------------------------------
     s.V = m.V;
     {
         // flux gather list: ascending face label == summation order of
         // fvc::surfaceIntegrate for that cell (upper-triangular face order)
-        Csr cf = buildCellFaces(m);
         std::vector<int32_t> cfOff((size_t)nC + 1, 0), cfItemCsr;
         auto keep = [&](int32_t f) {
             if (f < nIF) return true;
             const int t = patchType[f - nIF];
             return t != QGD_PATCH_EMPTY && t != QGD_PATCH_HALO;
         };
+#pragma omp parallel for schedule(static)
         for (int64_t c = 0; c < nC; ++c) {
             int32_t n = 0;
             for (int32_t k = cf.offsets[c]; k < cf.offsets[c + 1]; ++k) if (keep(cf.items[k])) ++n;
-            cfOff[c + 1] = cfOff[c] + n;
+            cfOff[c + 1] = n;
         }
+        for (int64_t c = 0; c < nC; ++c) cfOff[c + 1] += cfOff[c];
         cfItemCsr.resize((size_t)cfOff[nC]);
 #pragma omp parallel for schedule(static)
         for (int64_t c = 0; c < nC; ++c) {
@@ -505,7 +530,7 @@ StaticData buildStaticData(const HostMesh& m) {
                 cfItemCsr[o++] = (m.owner[f] == c) ? f : ~f;
             }
         }
-        toSlicedEll(cfOff, nC, cfItemCsr, nullptr, s.cfSlice, s.cfCount, s.cfItem, nullptr, 0);
+        toSlicedEll(cfOff, nC, cfItemCsr, nullptr, s.cfSlice, s.cfCount, s.cfItem, (RawVec<double>*)nullptr, 0);
         {
             // the cell on the other side of each entry (-1: a boundary face): the matrix products of the implicit solves and of the
             // pressure equation gather x[cfNbr] and a[face] side by side instead of following face -> owner/neighbour -> x
@@ -517,31 +542,47 @@ StaticData buildStaticData(const HostMesh& m) {
             }
             std::vector<int32_t> slice2;
             std::vector<uint8_t> count2;
-            toSlicedEll(cfOff, nC, nbrCsr, nullptr, slice2, count2, s.cfNbr, nullptr, -1);
+            toSlicedEll(cfOff, nC, nbrCsr, nullptr, slice2, count2, s.cfNbr, (RawVec<double>*)nullptr, -1);
         }
         // slot-major storage positions of the internal-face fluxes (see qgd_setup.hpp)
         {
+            // rank of an internal face among the faces its owner owns (they are consecutive: upper-triangular order), then a stable partition
+            // of the faces by rank -- a counting sort, in parallel: contiguous chunks, per-chunk counts per rank, positions from their prefix sums
             s.fpos.assign((size_t)nIF, 0);
-            std::vector<int32_t> rank((size_t)nIF, 0), owned((size_t)nC, 0);
-            std::vector<int64_t> bucket;
+            std::vector<int32_t> rank((size_t)nIF);
+            int32_t maxRank = 0;
+#pragma omp parallel for schedule(static) reduction(max : maxRank)
             for (int64_t f = 0; f < nIF; ++f) {
-                const int32_t r = owned[m.owner[f]]++;
+                int32_t r = 0;
+                while (f - 1 - r >= 0 && m.owner[f - 1 - r] == m.owner[f]) ++r;
                 rank[f] = r;
-                if ((size_t)r >= bucket.size()) bucket.resize((size_t)r + 1, 0);
-                bucket[r]++;
+                maxRank = std::max(maxRank, r);
             }
-            std::vector<int64_t> start(bucket.size() + 1, 0);
-            for (size_t r = 0; r < bucket.size(); ++r) start[r + 1] = start[r] + bucket[r];
             const bool labelOrder = std::getenv("QGD_FLUX_LABEL_ORDER") != nullptr;  // experiment switch
-            for (int64_t f = 0; f < nIF; ++f) s.fpos[f] = labelOrder ? (int32_t)f : (int32_t)(start[rank[f]]++);
-            for (int32_t& it : cfItemCsr) {
-                const int32_t f = it >= 0 ? it : ~it;
+            const int64_t nChunks = std::max<int64_t>(1, std::min<int64_t>(1024, nIF / 4096));
+            const size_t nR = (size_t)maxRank + 1;
+            std::vector<int64_t> cnt((size_t)nChunks * nR, 0);
+            auto chunkLo = [&](int64_t ch) { return nIF * ch / nChunks; };
+#pragma omp parallel for schedule(static)
+            for (int64_t ch = 0; ch < nChunks; ++ch)
+                for (int64_t f = chunkLo(ch); f < chunkLo(ch + 1); ++f) cnt[(size_t)ch * nR + rank[f]]++;
+            {   // exclusive prefix in (rank, chunk) order: where chunk ch's first face of rank r goes
+                int64_t run = 0;
+                for (size_t r = 0; r < nR; ++r)
+                    for (int64_t ch = 0; ch < nChunks; ++ch) { const int64_t n = cnt[(size_t)ch * nR + r]; cnt[(size_t)ch * nR + r] = run; run += n; }
+            }
+#pragma omp parallel for schedule(static)
+            for (int64_t ch = 0; ch < nChunks; ++ch)
+                for (int64_t f = chunkLo(ch); f < chunkLo(ch + 1); ++f) s.fpos[f] = labelOrder ? (int32_t)f : (int32_t)(cnt[(size_t)ch * nR + rank[f]]++);
+#pragma omp parallel for schedule(static)
+            for (int64_t k = 0; k < (int64_t)cfItemCsr.size(); ++k) {
+                const int32_t it = cfItemCsr[k], f = it >= 0 ? it : ~it;
                 const int32_t pos = f < nIF ? s.fpos[f] : f;
-                it = it >= 0 ? pos : ~pos;
+                cfItemCsr[k] = it >= 0 ? pos : ~pos;
             }
             std::vector<int32_t> slice2;
             std::vector<uint8_t> count2;
-            toSlicedEll(cfOff, nC, cfItemCsr, nullptr, slice2, count2, s.cfPos, nullptr, 0);
+            toSlicedEll(cfOff, nC, cfItemCsr, nullptr, slice2, count2, s.cfPos, (RawVec<double>*)nullptr, 0);
         }
         // hQGD: area-weighted mean of hQGDf over the cell's faces, OpenFOAM
         // cells() order, skipping empty/wedge patches [QGDCoeffs.C L323-362]
@@ -572,6 +613,7 @@ StaticData buildStaticData(const HostMesh& m) {
         for (size_t slot = 0; slot < nSlots; ++slot)
             for (int32_t c : m.haloSend[slot]) s.ghost[c] = 2;
 
+    stage("cells (gather lists, positions, hQGD)");
     // ---- halo lists (cells + their real-patch boundary faces, ascending) -----
     s.haloGhost = m.haloGhost;
     s.haloSend = m.haloSend;
@@ -588,6 +630,7 @@ StaticData buildStaticData(const HostMesh& m) {
             if (isS[o]) s.haloSendBF[slot].push_back((int32_t)b);
         }
     }
+    stage("halo lists");
     return s;
 }
 

@@ -18,6 +18,25 @@
 
 namespace qgd {
 
+// vector whose resize() leaves new elements uninitialised: multi-GB tables that a parallel loop fills completely are first touched by the
+// threads that fill them (a value-initialising resize touches every page from one thread first: 4 s per GB in this kind of container)
+template <class T>
+struct DefaultInitAllocator : std::allocator<T> {
+    template <class U> struct rebind { using other = DefaultInitAllocator<U>; };
+    using std::allocator<T>::allocator;
+    template <class U> void construct(U* p) noexcept(std::is_nothrow_default_constructible<U>::value) { ::new (static_cast<void*>(p)) U; }
+    template <class U, class... Args> void construct(U* p, Args&&... args) { ::new (static_cast<void*>(p)) U(std::forward<Args>(args)...); }
+};
+template <class T> using RawVec = std::vector<T, DefaultInitAllocator<T>>;
+// dst = src with every page of dst first touched by the thread that copies it
+template <class T, class A>
+inline void parallelCopy(RawVec<T>& dst, const std::vector<T, A>& src) {
+    dst.resize(src.size());
+    const int64_t n = (int64_t)src.size();
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) dst[i] = src[i];
+}
+
 enum FaceKind : uint8_t { FK_QUAD = 0, FK_TRI = 1, FK_OTHER = 2, FK_SKIP = 3 };
 
 struct StaticData {
@@ -26,20 +45,20 @@ struct StaticData {
     bool hasTri = false;
 
     // ---- faces --------------------------------------------------------------
-    std::vector<int32_t> own;     // nF
-    std::vector<int32_t> nei;     // nIF
-    std::vector<int32_t> verts;   // 4*nF (tri: [3] = -1)
-    std::vector<uint8_t> fkind;   // nF
-    std::vector<double> Sf[3];    // nF each
-    std::vector<double> magSf;    // nF
-    std::vector<double> w;        // nF linear weights
-    std::vector<double> hf;       // nF hQGDf
-    std::vector<double> dn;       // nF: nonOrthDeltaCoeffs (internal), deltaCoeffs (boundary)
+    RawVec<int32_t> own;     // nF   (RawVec: the per-face / per-cell tables are filled by parallel loops, qgd_setup.cpp)
+    RawVec<int32_t> nei;     // nIF
+    RawVec<int32_t> verts;   // 4*nF (tri: [3] = -1)
+    RawVec<uint8_t> fkind;   // nF
+    RawVec<double> Sf[3];    // nF each
+    RawVec<double> magSf;    // nF
+    RawVec<double> w;        // nF linear weights
+    RawVec<double> hf;       // nF hQGDf
+    RawVec<double> dn;       // nF: nonOrthDeltaCoeffs (internal), deltaCoeffs (boundary)
     // GaussVolPoint 3-D: the 10 (quad) / 13 (triangle) Gauss coefficients of a face are NOT stored: the face kernel
     // rebuilds them from the vertex coordinates and the two cell centres, which are gathered (and cached) instead
     // of streaming 80 B per face.  Boundary faces use the mirror point C_O + 2 (C_f - C_O) as "neighbour centre".
-    std::vector<double> X;        // 3*nP: vertex coordinates (packed 24-B records)
-    std::vector<double> Cc;       // 3*nC: cell centres (packed 24-B records)
+    RawVec<double> X;        // 3*nP: vertex coordinates (packed 24-B records)
+    RawVec<double> Cc;       // 3*nC: cell centres (packed 24-B records)
     std::vector<double> bN;       // 4*nBF: mirror points of the boundary faces
     std::vector<double> bmvON;    // nBF
     // GaussVolPoint 2-D
@@ -63,8 +82,8 @@ struct StaticData {
     // have count 0.
     std::vector<int32_t> pcSlice; // nSlices+1, in rows of 64 entries
     std::vector<uint8_t> pcCount; // nP
-    std::vector<int32_t> pcCell;  // padded entries: -1
-    std::vector<double> pcW;
+    RawVec<int32_t> pcCell;  // padded entries: -1
+    RawVec<double> pcW;
     std::vector<int32_t> bpPoint; // patch points
     std::vector<int32_t> bpOff;   // bpPoint.size()+1
     std::vector<int32_t> bpFace;  // boundary-face index (global label - nIF)
@@ -85,8 +104,8 @@ struct StaticData {
     // fvc::surfaceIntegrate); item = f (cell is owner, +) or ~f (cell is neighbour, -); empty/halo faces left out
     std::vector<int32_t> cfSlice; // nSlices+1
     std::vector<uint8_t> cfCount; // nC
-    std::vector<int32_t> cfItem;
-    std::vector<int32_t> cfNbr;   // like cfItem: the cell across the face, -1 for boundary faces
+    RawVec<int32_t> cfItem;
+    RawVec<int32_t> cfNbr;   // like cfItem: the cell across the face, -1 for boundary faces
     // Storage order of the net face fluxes (CaseView::flux).  Internal face f keeps its five fluxes at position
     // fpos[f] of each SoA plane: faces are bucketed by their rank among the faces their owner owns (bucket 0 = every
     // cell's first owned face, in cell order, then bucket 1, ...), so that consecutive cells find their own faces AND
@@ -94,7 +113,7 @@ struct StaticData {
     // Boundary faces stay at their label.  cfPos = cfItem with the label replaced by the position (same row order, ~pos
     // when the cell is the neighbour): the cell kernel's gather list.
     std::vector<int32_t> fpos;    // nIF
-    std::vector<int32_t> cfPos;   // like cfItem
+    RawVec<int32_t> cfPos;   // like cfItem
     std::vector<double> V;        // nC
     std::vector<double> hQGD;     // nC
     std::vector<uint8_t> ghost;   // nC cell role (empty when unsharded): 0 owned, 1 ghost, 2 owned + sent to a neighbour
@@ -136,16 +155,6 @@ inline int32_t faceTileCapCells(int32_t fb) { return fb + fb / 16; }
 inline int32_t faceTileCapVerts(int32_t fb) { return ((fb * 23) / 16 + 7) / 8 * 8; }
 FaceTiles buildFaceTiles(const StaticData& s, int32_t fb);
 
-// vector whose resize() leaves new elements uninitialised: multi-GB tables that a parallel loop fills completely are first touched by the
-// threads that fill them (a value-initialising resize touches every page from one thread first: 4 s per GB in this kind of container)
-template <class T>
-struct DefaultInitAllocator : std::allocator<T> {
-    template <class U> struct rebind { using other = DefaultInitAllocator<U>; };
-    using std::allocator<T>::allocator;
-    template <class U> void construct(U* p) noexcept(std::is_nothrow_default_constructible<U>::value) { ::new (static_cast<void*>(p)) U; }
-    template <class U, class... Args> void construct(U* p, Args&&... args) { ::new (static_cast<void*>(p)) U(std::forward<Args>(args)...); }
-};
-template <class T> using RawVec = std::vector<T, DefaultInitAllocator<T>>;
 
 // ---- cell blocks of the fused face + cell kernel (QGD_FUSED; qgd_kernels.hip fusedFaceCellKernel) ---------------------------------
 // A block is up to 128 cells that sit together in space (consecutive cells of a Morton order of the cell centres: an 8x4x4 brick on
