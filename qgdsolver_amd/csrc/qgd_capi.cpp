@@ -548,7 +548,7 @@ int qgd_mesh_get(qgd_mesh_t mh, const char* name, void* out, int64_t outBytes) {
     const void* src = nullptr;
     size_t bytes = 0;
     std::vector<int32_t> tmp;
-    auto D = [&](const std::vector<double>& v) { src = v.data(); bytes = v.size() * sizeof(double); };
+    auto D = [&](const auto& v) { src = v.data(); bytes = v.size() * sizeof(double); };
     auto I = [&](const std::vector<int32_t>& v) { src = v.data(); bytes = v.size() * sizeof(int32_t); };
     if (s == "points") D(m.points);
     else if (s == "faceOffsets") I(m.faceOffsets);

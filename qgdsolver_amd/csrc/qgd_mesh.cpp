@@ -25,11 +25,11 @@ int32_t HostMesh::patchOfFace(int32_t f) const {
 // about the average of face centres).
 // ---------------------------------------------------------------------------
 void HostMesh::computeGeometry() {
-    Sf.assign(3 * (size_t)nFaces, 0.0);
-    Cf.assign(3 * (size_t)nFaces, 0.0);
-    magSf.assign((size_t)nFaces, 0.0);
-    C.assign(3 * (size_t)nCells, 0.0);
-    V.assign((size_t)nCells, 0.0);
+    Sf.resize(3 * (size_t)nFaces);   // (every entry of these is written by the parallel loops below)
+    Cf.resize(3 * (size_t)nFaces);
+    magSf.resize((size_t)nFaces);
+    C.resize(3 * (size_t)nCells);
+    V.resize((size_t)nCells);
     const double* p = points.data();
 
 #pragma omp parallel for schedule(static)
@@ -77,45 +77,32 @@ void HostMesh::computeGeometry() {
         magSf[f] = std::sqrt(S[0] * S[0] + S[1] * S[1] + S[2] * S[2]);
     }
 
-    // cell centres / volumes (sequential: accumulation order = face order)
-    std::vector<double> cEst(3 * (size_t)nCells, 0.0);
-    std::vector<int32_t> nCellFaces((size_t)nCells, 0);
-    for (int32_t f = 0; f < nFaces; ++f) {
-        const int32_t o = owner[f];
-        for (int k = 0; k < 3; ++k) cEst[3 * (size_t)o + k] += Cf[3 * (size_t)f + k];
-        nCellFaces[o]++;
-    }
-    for (int32_t f = 0; f < nInternalFaces; ++f) {
-        const int32_t n = neighbour[f];
-        for (int k = 0; k < 3; ++k) cEst[3 * (size_t)n + k] += Cf[3 * (size_t)f + k];
-        nCellFaces[n]++;
-    }
-    for (int32_t c = 0; c < nCells; ++c)
-        for (int k = 0; k < 3; ++k) cEst[3 * (size_t)c + k] /= nCellFaces[c];
-    for (int32_t f = 0; f < nFaces; ++f) {
-        const int32_t o = owner[f];
-        const double* S = &Sf[3 * (size_t)f];
-        const double* c = &Cf[3 * (size_t)f];
-        const double* e = &cEst[3 * (size_t)o];
-        const double pyr3 = S[0] * (c[0] - e[0]) + S[1] * (c[1] - e[1]) + S[2] * (c[2] - e[2]);
-        for (int k = 0; k < 3; ++k) C[3 * (size_t)o + k] += pyr3 * (0.75 * c[k] + 0.25 * e[k]);
-        V[o] += pyr3;
-    }
-    for (int32_t f = 0; f < nInternalFaces; ++f) {
-        const int32_t n = neighbour[f];
-        const double* S = &Sf[3 * (size_t)f];
-        const double* c = &Cf[3 * (size_t)f];
-        const double* e = &cEst[3 * (size_t)n];
-        const double pyr3 = S[0] * (e[0] - c[0]) + S[1] * (e[1] - c[1]) + S[2] * (e[2] - c[2]);
-        for (int k = 0; k < 3; ++k) C[3 * (size_t)n + k] += pyr3 * (0.75 * c[k] + 0.25 * e[k]);
-        V[n] += pyr3;
-    }
-    for (int32_t c = 0; c < nCells; ++c) {
-        if (std::fabs(V[c]) > 1e-300)
-            for (int k = 0; k < 3; ++k) C[3 * (size_t)c + k] /= V[c];
-        else
-            for (int k = 0; k < 3; ++k) C[3 * (size_t)c + k] = cEst[3 * (size_t)c + k];
-        V[c] *= (1.0 / 3.0);
+    // cell centres / volumes: per cell, its faces in the order the two sequential face walks of primitiveMesh::makeCellCentresAndVols add them
+    // (the faces it owns in ascending label, then the faces it is the neighbour of, ascending) -- the same sums bit for bit, one cell per thread
+    {
+        const Csr cfo = buildCellFacesFoamOrder(*this);
+#pragma omp parallel for schedule(static)
+        for (int32_t c = 0; c < nCells; ++c) {
+            double e[3] = {0, 0, 0}, cc[3] = {0, 0, 0}, vol = 0;
+            const int32_t k0 = cfo.offsets[c], k1 = cfo.offsets[c + 1];
+            for (int32_t k = k0; k < k1; ++k)
+                for (int d = 0; d < 3; ++d) e[d] += Cf[3 * (size_t)cfo.items[k] + d];
+            for (int d = 0; d < 3; ++d) e[d] /= (k1 - k0);
+            for (int32_t k = k0; k < k1; ++k) {
+                const int32_t f = cfo.items[k];
+                const double* S = &Sf[3 * (size_t)f];
+                const double* fc = &Cf[3 * (size_t)f];
+                const double pyr3 = owner[f] == c ? S[0] * (fc[0] - e[0]) + S[1] * (fc[1] - e[1]) + S[2] * (fc[2] - e[2])
+                                                  : S[0] * (e[0] - fc[0]) + S[1] * (e[1] - fc[1]) + S[2] * (e[2] - fc[2]);
+                for (int d = 0; d < 3; ++d) cc[d] += pyr3 * (0.75 * fc[d] + 0.25 * e[d]);
+                vol += pyr3;
+            }
+            if (std::fabs(vol) > 1e-300)
+                for (int d = 0; d < 3; ++d) C[3 * (size_t)c + d] = cc[d] / vol;
+            else
+                for (int d = 0; d < 3; ++d) C[3 * (size_t)c + d] = e[d];
+            V[c] = vol * (1.0 / 3.0);
+        }
     }
     computeDerived();
 }
@@ -124,11 +111,12 @@ void HostMesh::computeGeometry() {
 // makeNonOrthDeltaCoeffs and fvPatch::delta() (patch-normal on non-coupled
 // patches), polyMesh::calcDirections for geometricD.
 void HostMesh::computeDerived() {
-    weights.assign((size_t)nFaces, 1.0);
-    deltaCoeffs.assign((size_t)nFaces, 0.0);
-    nonOrthDeltaCoeffs.assign((size_t)nFaces, 0.0);
+    weights.resize((size_t)nFaces);
+    deltaCoeffs.resize((size_t)nFaces);
+    nonOrthDeltaCoeffs.resize((size_t)nFaces);
 #pragma omp parallel for schedule(static)
     for (int32_t f = 0; f < nFaces; ++f) {
+        weights[f] = 1.0; deltaCoeffs[f] = 0.0; nonOrthDeltaCoeffs[f] = 0.0;
         const double* S = &Sf[3 * (size_t)f];
         const double* cf = &Cf[3 * (size_t)f];
         const double* co = &C[3 * (size_t)owner[f]];

@@ -17,6 +17,26 @@
 
 namespace qgd {
 
+// vector whose resize() leaves new elements uninitialised: multi-GB tables that a parallel loop fills completely are first touched by the
+// threads that fill them (a value-initialising resize touches every page from one thread first: 4 s per GB in this kind of container)
+template <class T>
+struct DefaultInitAllocator : std::allocator<T> {
+    template <class U> struct rebind { using other = DefaultInitAllocator<U>; };
+    using std::allocator<T>::allocator;
+    template <class U> void construct(U* p) noexcept(std::is_nothrow_default_constructible<U>::value) { ::new (static_cast<void*>(p)) U; }
+    template <class U, class... Args> void construct(U* p, Args&&... args) { ::new (static_cast<void*>(p)) U(std::forward<Args>(args)...); }
+};
+template <class T> using RawVec = std::vector<T, DefaultInitAllocator<T>>;
+// dst = src with every page of dst first touched by the thread that copies it
+template <class T, class A>
+inline void parallelCopy(RawVec<T>& dst, const std::vector<T, A>& src) {
+    dst.resize(src.size());
+    const int64_t n = (int64_t)src.size();
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) dst[i] = src[i];
+}
+
+
 struct Patch {
     std::string name;
     int32_t type = 0;   // QGD_PATCH_*
@@ -43,13 +63,13 @@ struct HostMesh {
     std::vector<Patch> patches;
 
     // ---- geometry -----------------------------------------------------------
-    std::vector<double> Sf, Cf;        // 3*nFaces
-    std::vector<double> magSf;         // nFaces
-    std::vector<double> C;             // 3*nCells
-    std::vector<double> V;             // nCells
-    std::vector<double> weights;       // nFaces  (boundary = 1)
-    std::vector<double> deltaCoeffs;   // nFaces  1/|d|   (patch-normal delta on boundary)
-    std::vector<double> nonOrthDeltaCoeffs;  // nFaces  1/max(n.d, 0.05|d|)
+    RawVec<double> Sf, Cf;        // 3*nFaces   (RawVec: the geometry is written in full by parallel loops, computeGeometry)
+    RawVec<double> magSf;         // nFaces
+    RawVec<double> C;             // 3*nCells
+    RawVec<double> V;             // nCells
+    RawVec<double> weights;       // nFaces  (boundary = 1)
+    RawVec<double> deltaCoeffs;   // nFaces  1/|d|   (patch-normal delta on boundary)
+    RawVec<double> nonOrthDeltaCoeffs;  // nFaces  1/max(n.d, 0.05|d|)
     int32_t geometricD[3] = {1, 1, 1}; // -1 for the direction of empty patches
     int32_t nGeometricD = 3;
     bool userGeometry = false;         // Sf, Cf, C, V came from the caller (qgd_mesh_set_geometry), not from the points

@@ -503,7 +503,7 @@ StaticData buildStaticData(const HostMesh& m) {
 
     stage("vertex interpolation");
     // ---- cells ---------------------------------------------------------------------
-    s.V = m.V;
+    s.V.assign(m.V.begin(), m.V.end());
     {
         // flux gather list: ascending face label == summation order of
         // fvc::surfaceIntegrate for that cell (upper-triangular face order)

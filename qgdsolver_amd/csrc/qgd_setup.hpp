@@ -18,25 +18,6 @@
 
 namespace qgd {
 
-// vector whose resize() leaves new elements uninitialised: multi-GB tables that a parallel loop fills completely are first touched by the
-// threads that fill them (a value-initialising resize touches every page from one thread first: 4 s per GB in this kind of container)
-template <class T>
-struct DefaultInitAllocator : std::allocator<T> {
-    template <class U> struct rebind { using other = DefaultInitAllocator<U>; };
-    using std::allocator<T>::allocator;
-    template <class U> void construct(U* p) noexcept(std::is_nothrow_default_constructible<U>::value) { ::new (static_cast<void*>(p)) U; }
-    template <class U, class... Args> void construct(U* p, Args&&... args) { ::new (static_cast<void*>(p)) U(std::forward<Args>(args)...); }
-};
-template <class T> using RawVec = std::vector<T, DefaultInitAllocator<T>>;
-// dst = src with every page of dst first touched by the thread that copies it
-template <class T, class A>
-inline void parallelCopy(RawVec<T>& dst, const std::vector<T, A>& src) {
-    dst.resize(src.size());
-    const int64_t n = (int64_t)src.size();
-#pragma omp parallel for schedule(static)
-    for (int64_t i = 0; i < n; ++i) dst[i] = src[i];
-}
-
 enum FaceKind : uint8_t { FK_QUAD = 0, FK_TRI = 1, FK_OTHER = 2, FK_SKIP = 3 };
 
 struct StaticData {
