@@ -1,6 +1,6 @@
-"""QGD_FU_PERSIST (the plain explicit step as a persistent launch: each workgroup takes block after block, the next block's lists fetched during
-this block's cell update; a PROBE, not in the product: apply scripts/probes/fused_persistent_probe_r06.patch first) against one workgroup per block: the same states bit for bit after a few steps on an n^3 box and on a box whose edges
-the bricks do not divide.    python scripts/persist_check.py [n=128] [steps=5]"""
+"""A launch-shape switch of the plain explicit step (default QGD_FU_PAIR = a workgroup takes two consecutive blocks, the second one's lists fetched
+during the first one's cell update; QGD_FU_PERSIST with scripts/probes/fused_persistent_probe_r06.patch applied) against one workgroup per block: the same states bit for bit after a few steps on an n^3 box and on a box whose edges
+the bricks do not divide.    python scripts/fused_launch_shape_check.py [n=128] [steps=5] [VARIABLE=QGD_FU_PAIR] [value=1]"""
 import os
 import sys
 
@@ -12,8 +12,12 @@ import qgdsolver_amd as q  # noqa: E402
 from qgdsolver_amd.synthetic import box_initial_fields  # noqa: E402
 
 
+VAR = sys.argv[3] if len(sys.argv) > 3 else "QGD_FU_PAIR"
+ON = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+
+
 def run(dims, persist, steps):
-    os.environ["QGD_FU_PERSIST"] = str(persist)
+    os.environ[VAR] = str(persist)
     mesh = q.PolyMesh.box(*dims)
     dev = q.Device(mesh)
     case = q.QGDFoamCase(dev, q.default_options(stencil="GaussVolPoint", deltaT=0.1 / max(dims) / 1.3))
@@ -35,7 +39,7 @@ def main():
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
     for dims in ((n, n, n), (n + 3, n - 5, n + 1)):
         a, fa, ia = run(dims, 0, steps)
-        b, fb, ib = run(dims, 3, steps)
+        b, fb, ib = run(dims, ON, steps)
         same = all(np.array_equal(a[k], b[k]) for k in a)
         worst = max(float(np.abs(a[k] - b[k]).max()) for k in a)
         print(dims, "blocks", fa["blocks"], "fused", fa["fused"], fb["fused"], "bit-identical", same, "max diff", worst, "minRho", ia["minRho"], ib["minRho"], flush=True)
